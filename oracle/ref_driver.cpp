@@ -1,0 +1,307 @@
+// ref_driver.cpp — drives the GENUINE reference (compiled from /root/reference where it lies; see
+// oracle/Makefile) over this repo's deterministic corpus, and prints one JSON line per command.
+//
+// TEST INFRASTRUCTURE ONLY.  This file is new code written against the reference's public API
+// (Codecs::Google::IndexSession/Encoder, IndexSource, exec_query, Similarity::…BM25Scorer); it contains
+// no reference source.  It exists to (1) pin oracle/trinity_oracle.c against the real implementation and
+// (2) produce the fixtures under tests/golden/ (see tests/golden/make_golden.py).  It cannot run on the
+// GPU box (no /root/reference there) — only its prebuilt binary in oracle/_ref/ travels.
+//
+// Commands (stdin, one per line):
+//   index                          -> {len, fnv, terms_fnv, postings, totalTerms}
+//   dumpindex <path>               -> writes raw index bytes + term table (u32 triples) to <path>{.index,.terms}
+//   decode <term>                  -> {n, docs_fnv, freqs_fnv, first[], last[]}  via PostingsListIterator::next()
+//   advance <term> <seed> <steps>  -> {trace_fnv, n} seeded advance()/next() mix, hash of (doc,freq) after each op
+//   positions <term> <everyNth>    -> {fnv} materialize_hits positions of every Nth document
+//   query <flags> <k> <text…>      -> {n, fnv, first[], last[], score_sum, top[[doc,score]…]}  exec_query()
+//   queryfull <flags> <text…>      -> as query plus full docs[] (+scores[])
+#include "exec.h"
+#include "google_codec.h"
+#include "trinity_oracle.h" // corpus generator + hashing only (this repo's code)
+#include <cinttypes>
+#include <cstdio>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using namespace Trinity;
+
+namespace {
+        struct Collector final : public MatchedIndexDocumentsFilter {
+                std::vector<docid_t> ids;
+                std::vector<double> scores;
+                void consider(const docid_t id) override { ids.push_back(id); }
+                void consider(const docid_t id, const double score) override {
+                        ids.push_back(id);
+                        scores.push_back(score);
+                }
+        };
+
+        // A custom IndexSource over an in-memory Google-codec index (index_source.h:19-24 invites exactly this)
+        struct MemIndexSource final : public IndexSource {
+                std::vector<term_index_ctx> terms;
+                Codecs::Google::AccessProxy *access{nullptr};
+                field_statistics fs;
+
+                term_index_ctx resolve_term_ctx(const str8_t term) override {
+                        if (term.size() < 2 || term.data()[0] != 't')
+                                return {};
+                        uint64_t r = 0;
+                        for (uint32_t i = 1; i < term.size(); ++i) {
+                                const char c = term.data()[i];
+                                if (c < '0' || c > '9')
+                                        return {};
+                                r = r * 10 + uint32_t(c - '0');
+                        }
+                        if (r >= terms.size())
+                                return {};
+                        return terms[r];
+                }
+                Codecs::Decoder *new_postings_decoder(const str8_t, const term_index_ctx ctx) override { return access->new_decoder(ctx); }
+                field_statistics default_field_stats() override { return fs; }
+                bool index_empty() const override { return false; }
+        };
+
+        uint64_t fnv_bytes(const uint8_t *p, size_t n, uint64_t h = 1469598103934665603ull) {
+                for (size_t i = 0; i < n; ++i)
+                        h = (h ^ p[i]) * 1099511628211ull;
+                return h;
+        }
+        uint64_t fnv_u32(uint32_t v, uint64_t h) { return fnv_bytes(reinterpret_cast<const uint8_t *>(&v), 4, h); }
+
+        void print_u32s(const char *name, const uint32_t *v, size_t n) {
+                printf("\"%s\":[", name);
+                for (size_t i = 0; i < n; ++i)
+                        printf("%s%u", i ? "," : "", v[i]);
+                printf("]");
+        }
+} // namespace
+
+int main(int argc, char **argv) {
+        if (argc < 5) {
+                fprintf(stderr, "usage: %s D V slots seed < commands\n", argv[0]);
+                return 2;
+        }
+        const uint32_t D = strtoul(argv[1], nullptr, 10), V = strtoul(argv[2], nullptr, 10), slots = strtoul(argv[3], nullptr, 10);
+        const uint64_t seed = strtoull(argv[4], nullptr, 10);
+        to_corpus *corpus = to_corpus_generate(D, V, slots, seed);
+
+        // ---- index with the reference's own encoder (google_codec.cpp:9-176), terms in rank order
+        Codecs::Google::IndexSession sess("/tmp");
+        sess.begin();
+        std::unique_ptr<Codecs::Encoder> enc(sess.new_encoder());
+        MemIndexSource *src = new MemIndexSource();
+        src->terms.resize(V);
+        uint64_t postings = 0;
+        uint32_t totalTerms = 0;
+        for (uint32_t t = 0; t < V; ++t) {
+                const uint64_t b = corpus->term_off[t], e = corpus->term_off[t + 1];
+                if (b == e) {
+                        src->terms[t] = term_index_ctx{0, range32_t{0, 0}};
+                        continue;
+                }
+                term_index_ctx tctx;
+                enc->begin_term();
+                for (uint64_t i = b; i < e;) {
+                        const uint32_t d = corpus->tok_doc[i];
+                        enc->begin_document(d);
+                        for (; i < e && corpus->tok_doc[i] == d; ++i)
+                                enc->new_hit(corpus->tok_pos[i], {});
+                        enc->end_document();
+                }
+                enc->end_term(&tctx);
+                src->terms[t] = tctx;
+                postings += tctx.documents;
+                ++totalTerms;
+        }
+        sess.end();
+        // keep the bytes alive + 16 bytes of slack
+        std::vector<uint8_t> index(sess.indexOut.size() + 16, 0);
+        memcpy(index.data(), sess.indexOut.data(), sess.indexOut.size());
+        const size_t indexLen = sess.indexOut.size();
+        Codecs::Google::AccessProxy access("/tmp", index.data());
+        src->access = &access;
+        src->fs.sumTermHits = corpus->ntokens;
+        src->fs.totalTerms = totalTerms;
+        src->fs.sumTermsDocs = postings;
+        src->fs.docsCnt = D;
+
+        IndexSourcesCollection collection;
+        collection.insert(src);
+        // NB: collection.commit() only gathers masked documents (index_source.cpp:3-30); there are none.
+        Similarity::IndexSourcesCollectionBM25Scorer bm25;
+        auto noMasked = masked_documents_registry::make(nullptr, 0);
+
+        std::string line;
+        while (std::getline(std::cin, line)) {
+                std::istringstream is(line);
+                std::string cmd;
+                if (!(is >> cmd) || cmd[0] == '#')
+                        continue;
+                if (cmd == "index") {
+                        uint64_t th = 1469598103934665603ull;
+                        for (uint32_t t = 0; t < V; ++t) {
+                                th = fnv_u32(src->terms[t].documents, th);
+                                th = fnv_u32(src->terms[t].indexChunk.offset, th);
+                                th = fnv_u32(src->terms[t].indexChunk.size(), th);
+                        }
+                        printf("{\"cmd\":\"index\",\"len\":%zu,\"fnv\":\"%" PRIu64 "\",\"terms_fnv\":\"%" PRIu64 "\",\"postings\":%" PRIu64 ",\"totalTerms\":%u}\n", indexLen,
+                               fnv_bytes(index.data(), indexLen), th, postings, totalTerms);
+                } else if (cmd == "dumpindex") {
+                        std::string path;
+                        is >> path;
+                        FILE *f = fopen((path + ".index").c_str(), "wb");
+                        fwrite(index.data(), 1, indexLen, f);
+                        fclose(f);
+                        f = fopen((path + ".terms").c_str(), "wb");
+                        for (uint32_t t = 0; t < V; ++t) {
+                                const uint32_t rec[3] = {src->terms[t].documents, src->terms[t].indexChunk.offset, src->terms[t].indexChunk.size()};
+                                fwrite(rec, 4, 3, f);
+                        }
+                        fclose(f);
+                        printf("{\"cmd\":\"dumpindex\",\"len\":%zu}\n", indexLen);
+                } else if (cmd == "decode") {
+                        uint32_t t;
+                        is >> t;
+                        std::unique_ptr<Codecs::Decoder> dec(access.new_decoder(src->terms[t]));
+                        std::unique_ptr<Codecs::PostingsListIterator> it(dec->new_iterator());
+                        std::vector<uint32_t> docs;
+                        uint64_t fh = 1469598103934665603ull;
+                        for (auto id = it->next(); id != DocIDsEND; id = it->next()) {
+                                docs.push_back(id);
+                                fh = fnv_u32(it->freq, fh);
+                        }
+                        const size_t n = docs.size(), k = n < 8 ? n : 8;
+                        printf("{\"cmd\":\"decode\",\"term\":%u,\"n\":%zu,\"docs_fnv\":\"%" PRIu64 "\",\"freqs_fnv\":\"%" PRIu64 "\",", t, n, to_fnv1a_docs(docs.data(), n), fh);
+                        print_u32s("first", docs.data(), k);
+                        printf(",");
+                        print_u32s("last", docs.data() + (n - k), k);
+                        printf("}\n");
+                } else if (cmd == "advance") {
+                        uint32_t t, steps;
+                        uint64_t s;
+                        is >> t >> s >> steps;
+                        std::unique_ptr<Codecs::Decoder> dec(access.new_decoder(src->terms[t]));
+                        std::unique_ptr<Codecs::PostingsListIterator> it(dec->new_iterator());
+                        uint64_t h = 1469598103934665603ull, st = s;
+                        uint32_t done = 0;
+                        // seeded mix: next(), small forward jumps, block-sized jumps, big jumps, targets <= current
+                        for (; done < steps && it->current() != DocIDsEND; ++done) {
+                                const uint64_t r = to_splitmix64(&st);
+                                const uint32_t cur = it->current();
+                                uint32_t id;
+                                switch (r & 7) {
+                                        case 0:
+                                        case 1:
+                                                id = it->next();
+                                                break;
+                                        case 2:
+                                                id = cur ? it->advance(cur) : it->next(); // target == current
+                                                break;
+                                        case 3:
+                                                id = it->advance(cur + 1 + uint32_t((r >> 8) % 3));
+                                                break;
+                                        case 4:
+                                                id = it->advance(cur + 1 + uint32_t((r >> 8) % 64));
+                                                break;
+                                        case 5:
+                                                id = it->advance(cur + 1 + uint32_t((r >> 8) % 2048));
+                                                break;
+                                        case 6:
+                                                id = it->advance(cur + 1 + uint32_t((r >> 8) % (D / 16 + 1)));
+                                                break;
+                                        default:
+                                                id = cur > 3 ? it->advance(cur - uint32_t((r >> 8) % 3)) : it->next(); // target <= current
+                                                break;
+                                }
+                                h = fnv_u32(id, h);
+                                h = fnv_u32(id == DocIDsEND ? 0 : it->freq, h);
+                        }
+                        printf("{\"cmd\":\"advance\",\"term\":%u,\"seed\":\"%" PRIu64 "\",\"steps\":%u,\"done\":%u,\"trace_fnv\":\"%" PRIu64 "\"}\n", t, s, steps, done, h);
+                } else if (cmd == "positions") {
+                        uint32_t t, nth;
+                        is >> t >> nth;
+                        std::unique_ptr<Codecs::Decoder> dec(access.new_decoder(src->terms[t]));
+                        std::unique_ptr<Codecs::PostingsListIterator> it(dec->new_iterator());
+                        DocWordsSpace dws(8192);
+                        std::vector<term_hit> hits(65536);
+                        uint64_t h = 1469598103934665603ull;
+                        uint32_t i = 0, cnt = 0;
+                        for (auto id = it->next(); id != DocIDsEND; id = it->next(), ++i) {
+                                if (i % nth)
+                                        continue;
+                                const auto f = it->freq;
+                                dws.reset();
+                                it->materialize_hits(&dws, hits.data());
+                                h = fnv_u32(id, h);
+                                for (uint32_t k = 0; k < f; ++k)
+                                        h = fnv_u32(hits[k].pos, h);
+                                ++cnt;
+                        }
+                        printf("{\"cmd\":\"positions\",\"term\":%u,\"nth\":%u,\"docs\":%u,\"fnv\":\"%" PRIu64 "\"}\n", t, nth, cnt, h);
+                } else if (cmd == "query" || cmd == "queryfull") {
+                        uint32_t flags, k = 0;
+                        is >> flags;
+                        if (cmd == "query")
+                                is >> k;
+                        std::string text;
+                        std::getline(is, text);
+                        while (!text.empty() && text[0] == ' ')
+                                text.erase(0, 1);
+                        Collector coll;
+                        query q{str32_t(text.data(), uint32_t(text.size()))};
+                        std::unique_ptr<Similarity::IndexSourceTermsScorer> scorer;
+                        if (flags & unsigned(ExecFlags::AccumulatedScoreScheme)) {
+                                bm25.reset(&collection);
+                                scorer.reset(bm25.new_source_scorer(src));
+                        }
+                        exec_query(q, src, noMasked.get(), &coll, nullptr, flags, scorer.get());
+                        const size_t n = coll.ids.size(), kk = n < 16 ? n : 16;
+                        double ssum = 0;
+                        for (auto s : coll.scores)
+                                ssum += s;
+                        printf("{\"cmd\":\"%s\",\"flags\":%u,\"q\":\"", cmd.c_str(), flags);
+                        for (char c : text) {
+                                if (c == '"')
+                                        printf("\\\"");
+                                else
+                                        putchar(c);
+                        }
+                        printf("\",\"n\":%zu,\"fnv\":\"%" PRIu64 "\",", n, to_fnv1a_docs(coll.ids.data(), n));
+                        print_u32s("first", coll.ids.data(), kk);
+                        printf(",");
+                        print_u32s("last", coll.ids.data() + (n - kk), kk);
+                        printf(",\"score_sum\":%.17g", ssum);
+                        if (k && !coll.scores.empty()) {
+                                to_result r;
+                                r.docs = coll.ids.data();
+                                r.scores = coll.scores.data();
+                                r.n = r.cap = n;
+                                std::vector<uint32_t> td(k);
+                                std::vector<float> ts(k);
+                                const uint32_t m = to_topk(&r, k, td.data(), ts.data()); // this repo's tie rule
+                                printf(",\"top\":[");
+                                for (uint32_t i = 0; i < m; ++i)
+                                        printf("%s[%u,%.9g]", i ? "," : "", td[i], double(ts[i]));
+                                printf("]");
+                        }
+                        if (cmd == "queryfull") {
+                                printf(",");
+                                print_u32s("docs", coll.ids.data(), n);
+                                if (!coll.scores.empty()) {
+                                        printf(",\"scores\":[");
+                                        for (size_t i = 0; i < n; ++i)
+                                                printf("%s%.17g", i ? "," : "", coll.scores[i]);
+                                        printf("]");
+                                }
+                        }
+                        printf("}\n");
+                } else {
+                        printf("{\"cmd\":\"%s\",\"error\":\"unknown\"}\n", cmd.c_str());
+                }
+                fflush(stdout);
+        }
+        to_corpus_free(corpus);
+        return 0;
+}

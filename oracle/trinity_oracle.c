@@ -1,0 +1,1493 @@
+/*
+ * trinity_oracle.c — CPU ORACLE (test infrastructure only; see trinity_oracle.h).
+ *
+ * Plain-C restatement of the reference's document-at-a-time execution path.  Nothing here is
+ * reachable from the product path.  Citations are file:line in the reference tree.
+ */
+#include "trinity_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define GOOGLE_N 32            /* google_codec.h:18 */
+#define GOOGLE_SKIPLIST_STEP 8 /* google_codec.h:19  (256 / N) */
+#define SPAN_SHIFT 13          /* docset_spans.h:74 */
+#define SPAN_SIZE (1u << SPAN_SHIFT)
+#define SPAN_MASK (SPAN_SIZE - 1)
+#define MAX_POSITION (1u << 14) /* trinity_limits.h:15 */
+#define MAX_PHRASE 16           /* trinity_limits.h:12 */
+
+static void *xmalloc(size_t n) {
+        void *p = malloc(n ? n : 1);
+        if (!p) {
+                fprintf(stderr, "trinity_oracle: out of memory (%zu)\n", n);
+                abort();
+        }
+        return p;
+}
+static void *xcalloc(size_t n, size_t s) {
+        void *p = calloc(n ? n : 1, s ? s : 1);
+        if (!p) {
+                fprintf(stderr, "trinity_oracle: out of memory\n");
+                abort();
+        }
+        return p;
+}
+static void *xrealloc(void *q, size_t n) {
+        void *p = realloc(q, n ? n : 1);
+        if (!p) {
+                fprintf(stderr, "trinity_oracle: out of memory\n");
+                abort();
+        }
+        return p;
+}
+
+/* ================================================================== a1: prefix varint */
+/* Switch/switch_compiler_aux.h:23-51 */
+size_t to_varbyte_put32(uint8_t *op, uint32_t x) {
+        if (x < (1u << 7)) {
+                op[0] = (uint8_t)x;
+                return 1;
+        } else if (x < (1u << 14)) { /* bswap16(x | 0x8000): big-endian 14 bit */
+                op[0] = (uint8_t)((x >> 8) | 0x80u);
+                op[1] = (uint8_t)x;
+                return 2;
+        } else if (x < (1u << 21)) { /* high 5 bits, then low 16 bits little-endian */
+                op[0] = (uint8_t)((x >> 16) | 0xc0u);
+                op[1] = (uint8_t)x;
+                op[2] = (uint8_t)(x >> 8);
+                return 3;
+        } else if (x < (1u << 28)) { /* bswap32(x | 0xe0000000): big-endian 28 bit */
+                op[0] = (uint8_t)((x >> 24) | 0xe0u);
+                op[1] = (uint8_t)(x >> 16);
+                op[2] = (uint8_t)(x >> 8);
+                op[3] = (uint8_t)x;
+                return 4;
+        } else { /* (u64)x >> 32 | 0xf0 == 0xf0, then little-endian u32 */
+                op[0] = 0xf0u;
+                op[1] = (uint8_t)x;
+                op[2] = (uint8_t)(x >> 8);
+                op[3] = (uint8_t)(x >> 16);
+                op[4] = (uint8_t)(x >> 24);
+                return 5;
+        }
+}
+
+/* Switch/switch_compiler_aux.h:53-80 */
+size_t to_varbyte_get32(const uint8_t *ip, uint32_t *v) {
+        uint32_t x = ip[0];
+        if (!(x & 0x80u)) {
+                *v = x;
+                return 1;
+        } else if (!(x & 0x40u)) {
+                *v = ((x & 0x3fu) << 8) | ip[1];
+                return 2;
+        } else if (!(x & 0x20u)) {
+                *v = ((x & 0x1fu) << 16) | ip[1] | ((uint32_t)ip[2] << 8);
+                return 3;
+        } else if (!(x & 0x10u)) {
+                *v = ((x & 0x0fu) << 24) | ((uint32_t)ip[1] << 16) | ((uint32_t)ip[2] << 8) | ip[3];
+                return 4;
+        } else { /* ((x & 7) << 32) truncated to 32 bit | ctou32(ip+1) */
+                *v = ip[1] | ((uint32_t)ip[2] << 8) | ((uint32_t)ip[3] << 16) | ((uint32_t)ip[4] << 24);
+                return 5;
+        }
+}
+
+/* ================================================================== corpus generator */
+uint64_t to_splitmix64(uint64_t *s) {
+        uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        return z ^ (z >> 31);
+}
+
+struct to_zipf {
+        uint32_t V;
+        double *cdf;     /* cdf[i] = (sum_{j<=i} 1/(j+1)) / H, sequential double sums */
+        uint32_t *guide; /* guide[k] = first i with cdf[i] >= k/G  (search accelerator only) */
+        uint32_t G;
+};
+
+static uint32_t lower_bound_d(const double *a, uint32_t lo, uint32_t hi, double x) {
+        while (lo < hi) {
+                uint32_t mid = lo + (hi - lo) / 2;
+                if (a[mid] < x)
+                        lo = mid + 1;
+                else
+                        hi = mid;
+        }
+        return lo;
+}
+
+to_zipf *to_zipf_new(uint32_t V) {
+        to_zipf *z = (to_zipf *)xmalloc(sizeof *z);
+        z->V = V;
+        z->cdf = (double *)xmalloc(sizeof(double) * V);
+        double s = 0;
+        for (uint32_t i = 0; i < V; ++i) {
+                s += 1.0 / (double)(i + 1);
+                z->cdf[i] = s;
+        }
+        for (uint32_t i = 0; i < V; ++i)
+                z->cdf[i] /= s;
+        z->G = 1u << 16;
+        z->guide = (uint32_t *)xmalloc(sizeof(uint32_t) * (z->G + 1));
+        for (uint32_t k = 0; k <= z->G; ++k) {
+                uint32_t r = lower_bound_d(z->cdf, 0, V, (double)k / (double)z->G);
+                z->guide[k] = r < V ? r : V - 1;
+        }
+        return z;
+}
+
+void to_zipf_free(to_zipf *z) {
+        if (!z)
+                return;
+        free(z->cdf);
+        free(z->guide);
+        free(z);
+}
+
+uint32_t to_zipf_rank(const to_zipf *z, uint64_t u) {
+        const double x = (double)(u >> 11) * (1.0 / 9007199254740992.0);
+        const uint32_t k = (uint32_t)(x * (double)z->G);
+        uint32_t lo = z->guide[k], hi = z->guide[k + 1] + 1;
+        if (hi > z->V)
+                hi = z->V;
+        /* guide[] only narrows the window; result == lower_bound over the whole table */
+        while (lo > 0 && z->cdf[lo - 1] >= x)
+                --lo;
+        uint32_t r = lower_bound_d(z->cdf, lo, hi, x);
+        if (r >= z->V)
+                r = z->V - 1;
+        return r;
+}
+
+to_corpus *to_corpus_generate(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed) {
+        to_corpus *c = (to_corpus *)xcalloc(1, sizeof *c);
+        c->D = D;
+        c->V = V;
+        c->slots = slots;
+        c->ntokens = (uint64_t)D * slots;
+        to_zipf *z = to_zipf_new(V);
+        uint32_t *ranks = (uint32_t *)xmalloc(sizeof(uint32_t) * c->ntokens);
+        c->term_off = (uint64_t *)xcalloc((size_t)V + 1, sizeof(uint64_t));
+        uint64_t st = seed;
+        for (uint64_t i = 0; i < c->ntokens; ++i) {
+                const uint32_t r = to_zipf_rank(z, to_splitmix64(&st));
+                ranks[i] = r;
+                c->term_off[r + 1]++;
+        }
+        for (uint32_t t = 0; t < V; ++t)
+                c->term_off[t + 1] += c->term_off[t];
+        c->tok_doc = (uint32_t *)xmalloc(sizeof(uint32_t) * c->ntokens);
+        c->tok_pos = (uint16_t *)xmalloc(sizeof(uint16_t) * c->ntokens);
+        uint64_t *cur = (uint64_t *)xmalloc(sizeof(uint64_t) * V);
+        memcpy(cur, c->term_off, sizeof(uint64_t) * V);
+        uint64_t i = 0;
+        for (uint32_t d = 1; d <= D; ++d)
+                for (uint32_t p = 1; p <= slots; ++p, ++i) {
+                        const uint64_t o = cur[ranks[i]]++;
+                        c->tok_doc[o] = d;
+                        c->tok_pos[o] = (uint16_t)p;
+                }
+        free(cur);
+        free(ranks);
+        to_zipf_free(z);
+        return c;
+}
+
+void to_corpus_free(to_corpus *c) {
+        if (!c)
+                return;
+        free(c->term_off);
+        free(c->tok_doc);
+        free(c->tok_pos);
+        free(c);
+}
+
+void to_gen_queries(uint32_t V, uint64_t seed, uint32_t nq, uint32_t nterms, uint32_t *out) {
+        to_zipf *z = to_zipf_new(V);
+        uint64_t st = seed;
+        for (uint32_t q = 0; q < nq; ++q) {
+                uint32_t *t = out + (size_t)q * nterms;
+                for (uint32_t i = 0; i < nterms;) {
+                        const uint32_t r = to_zipf_rank(z, to_splitmix64(&st));
+                        int dup = 0;
+                        for (uint32_t j = 0; j < i; ++j)
+                                dup |= (t[j] == r);
+                        if (!dup)
+                                t[i++] = r;
+                }
+        }
+        to_zipf_free(z);
+}
+
+/* ================================================================== Google codec: writer */
+typedef struct {
+        uint8_t *d;
+        size_t n, cap;
+} buf_t;
+static void buf_room(buf_t *b, size_t extra) {
+        if (b->n + extra > b->cap) {
+                size_t nc = b->cap ? b->cap * 2 : 4096;
+                while (nc < b->n + extra)
+                        nc *= 2;
+                b->d = (uint8_t *)xrealloc(b->d, nc);
+                b->cap = nc;
+        }
+}
+static void buf_varbyte(buf_t *b, uint32_t v) {
+        buf_room(b, 5);
+        b->n += to_varbyte_put32(b->d + b->n, v);
+}
+static void buf_u8(buf_t *b, uint8_t v) {
+        buf_room(b, 1);
+        b->d[b->n++] = v;
+}
+static void buf_u32(buf_t *b, uint32_t v) {
+        buf_room(b, 4);
+        memcpy(b->d + b->n, &v, 4);
+        b->n += 4;
+}
+static void buf_bytes(buf_t *b, const void *p, size_t n) {
+        buf_room(b, n);
+        memcpy(b->d + b->n, p, n);
+        b->n += n;
+}
+
+typedef struct { /* google_codec.h:46-60 Encoder state */
+        buf_t *out;
+        buf_t skipListData, block, hitsData;
+        uint32_t prevBlockLastDocumentID, curDocID, lastCommitedDocID;
+        uint8_t curBlockSize, curPayloadSize;
+        uint32_t lastPos;
+        uint32_t docDeltas[GOOGLE_N];
+        uint32_t blockFreqs[GOOGLE_N];
+        uint32_t skiplistEntryCountdown; /* NOT reset per term: google_codec.h:57 vs google_codec.cpp:9-23 */
+        uint32_t curTermOffset;
+        uint32_t termDocuments;
+} genc_t;
+
+/* google_codec.cpp:9-23 */
+static void genc_begin_term(genc_t *e) {
+        e->curBlockSize = 0;
+        e->lastCommitedDocID = 0;
+        e->prevBlockLastDocumentID = 0;
+        e->hitsData.n = 0;
+        e->termDocuments = 0;
+        e->curTermOffset = (uint32_t)e->out->n;
+        buf_room(e->out, 2); /* u16 skiplist entry count, patched in end_term */
+        e->out->d[e->out->n] = 0;
+        e->out->d[e->out->n + 1] = 0;
+        e->out->n += 2;
+}
+
+/* google_codec.cpp:25-36 */
+static void genc_begin_document(genc_t *e, uint32_t documentID) {
+        if (!documentID || documentID <= e->lastCommitedDocID) {
+                fprintf(stderr, "trinity_oracle: unexpected documentID %u <= %u\n", documentID, e->lastCommitedDocID);
+                abort();
+        }
+        e->curDocID = documentID;
+        e->lastPos = 0;
+        e->curPayloadSize = 0;
+        e->blockFreqs[e->curBlockSize] = 0;
+}
+
+/* google_codec.cpp:38-74, payload-less hits (payloadSize == 0) */
+static void genc_new_hit(genc_t *e, uint32_t pos) {
+        const uint8_t payloadSize = 0;
+        if (!pos && !payloadSize)
+                return;
+        const uint32_t delta = pos - e->lastPos;
+        ++e->blockFreqs[e->curBlockSize];
+        if (payloadSize != e->curPayloadSize) {
+                buf_varbyte(&e->hitsData, (delta << 1) | 1);
+                buf_u8(&e->hitsData, payloadSize);
+                e->curPayloadSize = payloadSize;
+        } else
+                buf_varbyte(&e->hitsData, delta << 1);
+        e->lastPos = pos;
+}
+
+/* google_codec.cpp:118-176 */
+static void genc_commit_block(genc_t *e) {
+        const uint32_t delta = e->curDocID - e->prevBlockLastDocumentID;
+        const uint32_t n = e->curBlockSize - 1u;
+        e->block.n = 0;
+        for (uint32_t i = 0; i != n; ++i)
+                buf_varbyte(&e->block, e->docDeltas[i]);
+        for (uint32_t i = 0; i != e->curBlockSize; ++i)
+                buf_varbyte(&e->block, e->blockFreqs[i]);
+        const uint32_t blockLength = (uint32_t)(e->block.n + e->hitsData.n);
+        if (--e->skiplistEntryCountdown == 0) {
+                if (e->skipListData.n / 8 < UINT16_MAX) {
+                        buf_u32(&e->skipListData, e->prevBlockLastDocumentID);
+                        buf_u32(&e->skipListData, (uint32_t)(e->out->n - e->curTermOffset));
+                }
+                e->skiplistEntryCountdown = GOOGLE_SKIPLIST_STEP;
+        }
+        buf_varbyte(e->out, delta);
+        buf_varbyte(e->out, blockLength);
+        buf_u8(e->out, e->curBlockSize);
+        buf_bytes(e->out, e->block.d, e->block.n);
+        buf_bytes(e->out, e->hitsData.d, e->hitsData.n);
+        e->hitsData.n = 0;
+        e->prevBlockLastDocumentID = e->curDocID;
+        e->curBlockSize = 0;
+}
+
+/* google_codec.cpp:76-88 */
+static void genc_end_document(genc_t *e) {
+        e->docDeltas[e->curBlockSize++] = e->curDocID - e->lastCommitedDocID;
+        if (e->curBlockSize == GOOGLE_N)
+                genc_commit_block(e);
+        e->lastCommitedDocID = e->curDocID;
+        ++e->termDocuments;
+}
+
+/* google_codec.cpp:90-116 */
+static void genc_end_term(genc_t *e, to_term *tctx) {
+        if (e->curBlockSize)
+                genc_commit_block(e);
+        const uint16_t skipListEntries = (uint16_t)(e->skipListData.n / 8);
+        buf_bytes(e->out, e->skipListData.d, e->skipListData.n);
+        memcpy(e->out->d + e->curTermOffset, &skipListEntries, 2);
+        tctx->offset = e->curTermOffset;
+        tctx->size = (uint32_t)(e->out->n - e->curTermOffset);
+        tctx->documents = e->termDocuments;
+        e->skipListData.n = 0;
+}
+
+to_index *to_google_encode(const to_corpus *c) {
+        to_index *ix = (to_index *)xcalloc(1, sizeof *ix);
+        buf_t out = {0, 0, 0};
+        genc_t e;
+        memset(&e, 0, sizeof e);
+        e.out = &out;
+        e.skiplistEntryCountdown = GOOGLE_SKIPLIST_STEP;
+        ix->terms = (to_term *)xcalloc(c->V, sizeof(to_term));
+        ix->nterms = c->V;
+        for (uint32_t t = 0; t < c->V; ++t) {
+                const uint64_t b = c->term_off[t], end = c->term_off[t + 1];
+                if (b == end)
+                        continue; /* term never occurs: no chunk, documents = 0 */
+                genc_begin_term(&e);
+                for (uint64_t i = b; i < end;) {
+                        const uint32_t d = c->tok_doc[i];
+                        genc_begin_document(&e, d);
+                        for (; i < end && c->tok_doc[i] == d; ++i)
+                                genc_new_hit(&e, c->tok_pos[i]);
+                        genc_end_document(&e);
+                }
+                genc_end_term(&e, &ix->terms[t]);
+                ix->totalTerms++;
+                ix->sumTermsDocs += ix->terms[t].documents;
+        }
+        if (out.n > 0xffffffffull) {
+                fprintf(stderr, "trinity_oracle: index exceeds 32-bit offsets (codecs.h:26)\n");
+                abort();
+        }
+        buf_room(&out, 16); /* slack so that wide reads near the end stay in bounds */
+        memset(out.d + out.n, 0, 16);
+        ix->bytes = out.d;
+        ix->len = out.n;
+        ix->sumTermHits = c->ntokens;
+        ix->docsCnt = c->D;
+        ix->owns = 1;
+        free(e.skipListData.d);
+        free(e.block.d);
+        free(e.hitsData.d);
+        return ix;
+}
+
+to_index *to_index_wrap(const uint8_t *bytes, size_t len, const to_term *terms, uint32_t nterms, uint32_t docsCnt,
+                        uint64_t sumTermsDocs, uint64_t sumTermHits) {
+        to_index *ix = (to_index *)xcalloc(1, sizeof *ix);
+        ix->bytes = (uint8_t *)xmalloc(len + 16);
+        memcpy(ix->bytes, bytes, len);
+        memset(ix->bytes + len, 0, 16);
+        ix->len = len;
+        ix->terms = (to_term *)xmalloc(sizeof(to_term) * nterms);
+        memcpy(ix->terms, terms, sizeof(to_term) * nterms);
+        ix->nterms = nterms;
+        ix->docsCnt = docsCnt;
+        ix->sumTermsDocs = sumTermsDocs;
+        ix->sumTermHits = sumTermHits;
+        for (uint32_t i = 0; i < nterms; ++i)
+                ix->totalTerms += terms[i].documents != 0;
+        ix->owns = 1;
+        return ix;
+}
+
+void to_index_free(to_index *ix) {
+        if (!ix)
+                return;
+        if (ix->owns) {
+                free(ix->bytes);
+                free(ix->terms);
+        }
+        free(ix);
+}
+
+/* Appendix A.2 of SURVEY.md / google_codec.cpp:118-176, 936-983 */
+uint32_t to_google_chunk_stats(const to_index *ix, uint32_t term, uint64_t *hdr, uint64_t *docfreq, uint64_t *hits,
+                               uint64_t *skip, uint64_t *postings) {
+        const to_term *t = &ix->terms[term];
+        *hdr = *docfreq = *hits = *skip = *postings = 0;
+        if (!t->size)
+                return 0;
+        const uint8_t *base = ix->bytes + t->offset, *p = base, *end = base + t->size;
+        uint16_t sk;
+        memcpy(&sk, p, 2);
+        p += 2;
+        *hdr += 2;
+        end -= (size_t)sk * 8;
+        *skip = (uint64_t)sk * 8;
+        uint32_t blocks = 0;
+        while (p != end) {
+                uint32_t v, blockLength;
+                const uint8_t *h = p;
+                p += to_varbyte_get32(p, &v);
+                p += to_varbyte_get32(p, &blockLength);
+                const uint8_t n = *p++;
+                *hdr += (uint64_t)(p - h);
+                const uint8_t *q = p;
+                for (uint32_t i = 0; i + 1 < n; ++i)
+                        q += to_varbyte_get32(q, &v);
+                for (uint32_t i = 0; i < n; ++i)
+                        q += to_varbyte_get32(q, &v);
+                *docfreq += (uint64_t)(q - p);
+                *hits += blockLength - (uint64_t)(q - p);
+                *postings += n;
+                p += blockLength;
+                ++blocks;
+        }
+        return blocks;
+}
+
+/* ================================================================== Google codec: reader */
+enum { IT_PLI = 0, IT_CONJ, IT_DISJ, IT_PHRASE };
+
+typedef struct to_iter to_iter;
+struct to_iter { /* docset_iterators_base.h:45-96 Iterator + relevant_documents.h:43-67 IteratorScorer */
+        uint8_t type;
+        uint32_t cur; /* curDocument.id; 0 before the first next() */
+        uint32_t (*next)(to_iter *);
+        uint32_t (*advance)(to_iter *, uint32_t);
+        double (*score)(to_iter *);
+        uint64_t cost;
+};
+
+struct to_pli { /* google_codec.h:104-133 PostingsListIterator + :143-187 Decoder */
+        to_iter it;
+        /* decoder */
+        const uint8_t *base, *chunkEnd;
+        const uint8_t *skiplist; /* entries {u32 prevBlockLastDocID, u32 offset} */
+        uint32_t skiplistSize;
+        uint32_t term, documents;
+        /* iterator */
+        uint8_t blockDocIdx;
+        uint32_t documentsArr[GOOGLE_N];
+        uint32_t blockLastDocID;
+        uint32_t freqs[GOOGLE_N];
+        uint32_t skipListIdx;
+        const uint8_t *p;
+        uint16_t freq; /* codecs.h:217 tokenpos_t */
+        /* scoring (docset_iterators_scorers.cpp:10-36) */
+        double idf;
+};
+
+static uint32_t sk_first(const to_pli *d, uint32_t i) {
+        uint32_t v;
+        memcpy(&v, d->skiplist + (size_t)i * 8, 4);
+        return v;
+}
+static uint32_t sk_second(const to_pli *d, uint32_t i) {
+        uint32_t v;
+        memcpy(&v, d->skiplist + (size_t)i * 8 + 4, 4);
+        return v;
+}
+
+/* google_codec.h:165-172 */
+static void pli_finalize(to_pli *it) {
+        it->blockDocIdx = 0;
+        it->blockLastDocID = TO_DOCIDS_END;
+        it->documentsArr[0] = TO_DOCIDS_END;
+        it->p = it->chunkEnd;
+        it->it.cur = TO_DOCIDS_END;
+}
+
+/* google_codec.cpp:464-495 */
+static uint32_t pli_skiplist_search(const to_pli *it, uint32_t target) {
+        uint32_t idx = UINT32_MAX;
+        const uint32_t skipListIdx = it->skipListIdx;
+        for (int32_t top = (int32_t)it->skiplistSize - 1, btm = (int32_t)skipListIdx; btm <= top;) {
+                const int32_t mid = (btm + top) / 2;
+                const uint32_t v = sk_first(it, (uint32_t)mid);
+                if (target < v)
+                        top = mid - 1;
+                else {
+                        if (v != target)
+                                idx = (uint32_t)mid;
+                        else if ((uint32_t)mid != skipListIdx)
+                                idx = (uint32_t)mid - 1;
+                        btm = mid + 1;
+                }
+        }
+        return idx;
+}
+
+/* google_codec.cpp:497-531 */
+static void pli_skip_block_doc(to_pli *it) {
+        const uint32_t freq = it->freqs[it->blockDocIdx];
+        uint8_t curPayloadSize = 0;
+        uint32_t dummy;
+        const uint8_t *p = it->p;
+        for (uint32_t i = 0; i != freq; ++i) {
+                p += to_varbyte_get32(p, &dummy);
+                if (dummy & 1)
+                        curPayloadSize = *p++;
+                p += curPayloadSize;
+        }
+        it->p = p;
+}
+
+/* google_codec.cpp:596-639 */
+static void pli_unpack_block(to_pli *it, uint32_t thisBlockLastDocID, uint8_t n) {
+        const uint32_t k = n - 1u;
+        uint32_t id = it->blockLastDocID;
+        const uint8_t *p = it->p;
+        for (uint32_t i = 0; i != k; ++i) {
+                uint32_t delta;
+                p += to_varbyte_get32(p, &delta);
+                id += delta;
+                it->documentsArr[i] = id;
+        }
+        for (uint32_t i = 0; i != n; ++i) {
+                uint32_t v;
+                p += to_varbyte_get32(p, &v);
+                it->freqs[i] = v;
+        }
+        it->p = p;
+        it->blockLastDocID = thisBlockLastDocID;
+        it->documentsArr[k] = thisBlockLastDocID;
+        it->blockDocIdx = 0;
+}
+
+/* google_codec.cpp:641-697 */
+static void pli_seek_block(to_pli *it, uint32_t target) {
+        const uint8_t *p = it->p;
+        uint32_t blockLastDocID = it->blockLastDocID;
+        for (;;) {
+                uint32_t v, blockSize;
+                p += to_varbyte_get32(p, &v);
+                const uint32_t thisBlockLastDocID = blockLastDocID + v;
+                p += to_varbyte_get32(p, &blockSize);
+                const uint8_t blockDocsCnt = *p++;
+                if (target > thisBlockLastDocID) {
+                        p += blockSize;
+                        if (p == it->chunkEnd) {
+                                pli_finalize(it);
+                                return;
+                        }
+                        blockLastDocID = thisBlockLastDocID;
+                } else {
+                        it->p = p;
+                        it->blockLastDocID = blockLastDocID;
+                        pli_unpack_block(it, thisBlockLastDocID, blockDocsCnt);
+                        return;
+                }
+        }
+}
+
+/* google_codec.cpp:699-724 */
+static void pli_unpack_next_block(to_pli *it) {
+        uint32_t v, blockSize;
+        const uint8_t *p = it->p;
+        p += to_varbyte_get32(p, &v);
+        const uint32_t thisBlockLastDocID = it->blockLastDocID + v;
+        p += to_varbyte_get32(p, &blockSize);
+        const uint8_t blockDocsCnt = *p++;
+        it->p = p;
+        pli_unpack_block(it, thisBlockLastDocID, blockDocsCnt);
+}
+
+/* google_codec.cpp:726-775 */
+static void pli_skip_remaining_block_documents(to_pli *it) {
+        uint8_t blockDocIdx = it->blockDocIdx;
+        const uint32_t blockLastDocID = it->blockLastDocID;
+        const uint8_t *p = it->p;
+        for (;;) {
+                uint32_t freq = it->freqs[blockDocIdx];
+                uint32_t dummy;
+                uint8_t payloadSize = 0;
+                while (freq) {
+                        --freq;
+                        p += to_varbyte_get32(p, &dummy);
+                        if (dummy & 1)
+                                payloadSize = *p++;
+                        p += payloadSize;
+                }
+                if (it->documentsArr[blockDocIdx] == blockLastDocID)
+                        break;
+                else
+                        ++blockDocIdx;
+        }
+        it->p = p;
+        it->blockDocIdx = blockDocIdx;
+}
+
+/* google_codec.cpp:777-819 */
+static uint32_t pli_next(to_iter *self) {
+        to_pli *it = (to_pli *)self;
+        if (it->documentsArr[it->blockDocIdx] == it->blockLastDocID) {
+                pli_skip_block_doc(it);
+                if (it->p != it->chunkEnd)
+                        pli_unpack_next_block(it);
+                else {
+                        pli_finalize(it);
+                        return it->it.cur;
+                }
+        } else {
+                pli_skip_block_doc(it);
+                ++it->blockDocIdx;
+        }
+        it->it.cur = it->documentsArr[it->blockDocIdx];
+        it->freq = (uint16_t)it->freqs[it->blockDocIdx];
+        return it->it.cur;
+}
+
+/* google_codec.cpp:821-934 */
+static uint32_t pli_advance(to_iter *self, uint32_t target) {
+        to_pli *it = (to_pli *)self;
+        if (target > it->blockLastDocID) {
+                pli_skip_remaining_block_documents(it);
+                if (it->p == it->chunkEnd) {
+                        pli_finalize(it);
+                        return it->it.cur;
+                }
+                if (it->skipListIdx != it->skiplistSize) {
+                        const uint32_t idx = pli_skiplist_search(it, target);
+                        if (idx != UINT32_MAX) {
+                                const uint32_t savedBlockLastDocID = it->blockLastDocID;
+                                it->blockLastDocID = sk_first(it, idx);
+                                it->p = it->base + sk_second(it, idx);
+                                if (target > savedBlockLastDocID)
+                                        it->skipListIdx = idx + 1;
+                        }
+                }
+                pli_seek_block(it, target);
+                /* NB: after finalize() documents[0] == END > target, the scan below settles on END */
+        }
+        uint8_t blockDocIdx = it->blockDocIdx;
+        for (;;) {
+                const uint32_t docID = it->documentsArr[blockDocIdx];
+                if (docID > target)
+                        break;
+                else if (docID == target)
+                        break;
+                else if (docID == it->blockLastDocID)
+                        break;
+                else {
+                        it->blockDocIdx = blockDocIdx;
+                        pli_skip_block_doc(it);
+                        ++blockDocIdx;
+                }
+        }
+        it->it.cur = it->documentsArr[blockDocIdx];
+        it->freq = (uint16_t)it->freqs[blockDocIdx];
+        it->blockDocIdx = blockDocIdx;
+        return it->it.cur;
+}
+
+/* google_codec.cpp:533-594 (positions only; payload bytes are skipped exactly as the reference reads them) */
+uint32_t to_pli_materialize_positions(to_pli *it, uint16_t *out) {
+        const uint32_t freq = it->freqs[it->blockDocIdx];
+        uint16_t pos = 0;
+        uint8_t curPayloadSize = 0;
+        uint32_t step;
+        const uint8_t *p = it->p;
+        for (uint32_t i = 0; i != (uint16_t)freq; ++i) { /* loop index is tokenpos_t in the reference */
+                p += to_varbyte_get32(p, &step);
+                if (step & 1)
+                        curPayloadSize = *p++;
+                pos = (uint16_t)(pos + (step >> 1));
+                p += curPayloadSize;
+                out[i] = pos;
+        }
+        it->p = p;
+        it->freqs[it->blockDocIdx] = 0; /* google_codec.cpp:593 */
+        return (uint16_t)freq;
+}
+
+static double pli_score(to_iter *self);
+
+/* google_codec.cpp:936-990 (Decoder::init) + 442-462 (new_iterator) */
+to_pli *to_pli_new(const to_index *ix, uint32_t term) {
+        to_pli *it = (to_pli *)xcalloc(1, sizeof *it);
+        const to_term *t = &ix->terms[term];
+        const uint8_t *ptr = ix->bytes + t->offset;
+        it->it.type = IT_PLI;
+        it->it.next = pli_next;
+        it->it.advance = pli_advance;
+        it->it.score = pli_score;
+        it->it.cost = t->documents; /* docset_iterators.cpp:57-58 */
+        it->term = term;
+        it->documents = t->documents;
+        it->base = ptr;
+        it->chunkEnd = ptr + t->size;
+        if (t->size) {
+                uint16_t cnt;
+                memcpy(&cnt, ptr, 2);
+                if (cnt) {
+                        it->skiplist = (ptr + t->size) - (size_t)cnt * 8;
+                        it->skiplistSize = cnt;
+                        it->chunkEnd = it->skiplist;
+                }
+                it->blockDocIdx = 0;
+                it->documentsArr[0] = 0;
+                it->blockLastDocID = 0;
+                it->freqs[0] = 0;
+                it->skipListIdx = 0;
+                it->p = ptr + 2;
+        } else
+                pli_finalize(it);
+        it->idf = to_bm25_idf(t->documents, ix->docsCnt);
+        return it;
+}
+
+void to_pli_free(to_pli *it) { free(it); }
+uint32_t to_pli_next(to_pli *it) { return pli_next(&it->it); }
+uint32_t to_pli_advance(to_pli *it, uint32_t t) { return pli_advance(&it->it, t); }
+uint32_t to_pli_current(const to_pli *it) { return it->it.cur; }
+uint32_t to_pli_freq(const to_pli *it) { return it->freq; }
+
+uint32_t to_decode_term(const to_index *ix, uint32_t term, uint32_t *docs, uint32_t *freqs) {
+        to_pli *it = to_pli_new(ix, term);
+        uint32_t n = 0;
+        for (uint32_t id = pli_next(&it->it); id != TO_DOCIDS_END; id = pli_next(&it->it)) {
+                docs[n] = id;
+                if (freqs)
+                        freqs[n] = it->freq;
+                ++n;
+        }
+        to_pli_free(it);
+        return n;
+}
+
+/* ================================================================== similarity (BM25) */
+/* similarity.h:179-181: std::log(1 + (docsCnt - docFreq + 0.5f) / (docFreq + 0.5f)) — the whole
+ * expression is float (u64 -> float, u32 -> float, int 1 -> float, std::log(float) == logf). */
+double to_bm25_idf(uint32_t docFreq, uint64_t docsCnt) {
+        const float num = (float)(docsCnt - (uint64_t)docFreq) + 0.5f;
+        const float den = (float)docFreq + 0.5f;
+        return (double)logf(1 + num / den);
+}
+
+/* similarity.h:228-235: return idf * float(freq) / double(freq + k1), k1 = 1.2f, rounded to float */
+float to_bm25_score(double idf, uint16_t freq) {
+        const float norm = 1.2f;
+        return (float)(idf * (float)freq / (double)((float)freq + norm));
+}
+
+/* docset_iterators_scorers.cpp:28-32 */
+static double pli_score(to_iter *self) {
+        to_pli *it = (to_pli *)self;
+        return to_bm25_score(it->idf, it->freq);
+}
+
+/* ================================================================== Conjuction */
+typedef struct { /* docset_iterators.h:333-362 */
+        to_iter it;
+        to_iter **its;
+        uint16_t size;
+} to_conj;
+
+/* docset_iterators.cpp:308-348 */
+static uint32_t conj_next_impl(to_conj *c, uint32_t id) {
+        const uint16_t localSize = c->size;
+restart:
+        for (uint16_t i = 1; i != localSize; ++i) {
+                to_iter *it = c->its[i];
+                if (it->cur != id) {
+                        const uint32_t next = it->advance(it, id);
+                        if (next > id) {
+                                if (next == TO_DOCIDS_END) {
+                                        c->size = 0;
+                                        return c->it.cur = TO_DOCIDS_END;
+                                }
+                                id = c->its[0]->advance(c->its[0], next);
+                                if (id == TO_DOCIDS_END) {
+                                        c->size = 0;
+                                        return c->it.cur = TO_DOCIDS_END;
+                                }
+                                goto restart;
+                        }
+                }
+        }
+        return c->it.cur = id;
+}
+
+/* docset_iterators.cpp:295-306 */
+static uint32_t conj_next(to_iter *self) {
+        to_conj *c = (to_conj *)self;
+        if (c->size) {
+                const uint32_t id = c->its[0]->next(c->its[0]);
+                if (id == TO_DOCIDS_END) {
+                        c->size = 0;
+                        return c->it.cur = TO_DOCIDS_END;
+                }
+                return conj_next_impl(c, id);
+        }
+        return TO_DOCIDS_END;
+}
+
+/* docset_iterators.cpp:282-293 */
+static uint32_t conj_advance(to_iter *self, uint32_t target) {
+        to_conj *c = (to_conj *)self;
+        if (c->size) {
+                const uint32_t id = c->its[0]->advance(c->its[0], target);
+                if (id == TO_DOCIDS_END) {
+                        c->size = 0;
+                        return c->it.cur = TO_DOCIDS_END;
+                }
+                return conj_next_impl(c, id);
+        }
+        return TO_DOCIDS_END;
+}
+
+/* docset_iterators_scorers.cpp:173-193; `size` is read at scoring time in the reference, but a
+ * drained conjunction is never scored, so the construction-time count is equivalent */
+typedef struct {
+        to_conj c;
+        uint16_t nscore;
+} to_conj_s;
+static double conj_score(to_iter *self) {
+        to_conj_s *c = (to_conj_s *)self;
+        double res = 0;
+        for (uint16_t i = 0; i != c->nscore; ++i)
+                res += c->c.its[i]->score(c->c.its[i]);
+        return res;
+}
+
+/* ================================================================== Disjunction */
+typedef struct { /* docset_iterators.h:221-303; Switch/prioqueue.h min-heap on current() */
+        to_iter it;
+        to_iter **heap; /* 1-based */
+        uint32_t n;
+} to_disj;
+
+static void heap_down(to_iter **h, uint32_t n, uint32_t i) {
+        to_iter *x = h[i];
+        for (;;) {
+                uint32_t c = i * 2;
+                if (c > n)
+                        break;
+                if (c + 1 <= n && h[c + 1]->cur < h[c]->cur)
+                        ++c;
+                if (h[c]->cur < x->cur) {
+                        h[i] = h[c];
+                        i = c;
+                } else
+                        break;
+        }
+        h[i] = x;
+}
+static void heap_up(to_iter **h, uint32_t i) {
+        to_iter *x = h[i];
+        while (i > 1 && x->cur < h[i / 2]->cur) {
+                h[i] = h[i / 2];
+                i /= 2;
+        }
+        h[i] = x;
+}
+static void heap_push(to_iter **h, uint32_t *n, to_iter *x) {
+        h[++*n] = x;
+        heap_up(h, *n);
+}
+static to_iter *heap_pop(to_iter **h, uint32_t *n) {
+        to_iter *top = h[1];
+        h[1] = h[*n];
+        --*n;
+        if (*n)
+                heap_down(h, *n, 1);
+        return top;
+}
+
+/* docset_iterators.cpp:350-372 (DisjunctionAllPLI::next) == 592-614 (Disjunction::next) */
+static uint32_t disj_next(to_iter *self) {
+        to_disj *d = (to_disj *)self;
+        if (!d->n)
+                return TO_DOCIDS_END;
+        to_iter *top = d->heap[1];
+        const uint32_t doc = top->cur;
+        do {
+                if (top->next(top) != TO_DOCIDS_END) {
+                        heap_down(d->heap, d->n, 1); /* pq.update_top() */
+                        top = d->heap[1];
+                } else {
+                        heap_pop(d->heap, &d->n); /* pq.erase(top) */
+                        if (!d->n)
+                                return d->it.cur = TO_DOCIDS_END;
+                        top = d->heap[1];
+                }
+        } while ((d->it.cur = top->cur) == doc);
+        return d->it.cur;
+}
+
+/* docset_iterators.cpp:374-405 */
+static uint32_t disj_advance(to_iter *self, uint32_t target) {
+        to_disj *d = (to_disj *)self;
+        if (!d->n)
+                return TO_DOCIDS_END;
+        to_iter *top = d->heap[1];
+        do {
+                const uint32_t res = top->advance(top, target);
+                if (res != TO_DOCIDS_END) {
+                        heap_down(d->heap, d->n, 1);
+                        top = d->heap[1];
+                } else {
+                        heap_pop(d->heap, &d->n);
+                        if (!d->n)
+                                return d->it.cur = TO_DOCIDS_END;
+                        top = d->heap[1];
+                }
+        } while ((d->it.cur = top->cur) < target);
+        return d->it.cur;
+}
+
+/* docset_iterators_scorers.cpp:107-148: sum over heap entries positioned on the current doc
+ * (for_each_top tree walk, Switch/prioqueue.h) */
+static void disj_score_walk(to_disj *d, uint32_t i, uint32_t doc, double *sum) {
+        if (i > d->n || d->heap[i]->cur != doc)
+                return;
+        *sum += d->heap[i]->score(d->heap[i]);
+        disj_score_walk(d, i * 2, doc, sum);
+        disj_score_walk(d, i * 2 + 1, doc, sum);
+}
+static double disj_score(to_iter *self) {
+        to_disj *d = (to_disj *)self;
+        double sum = 0;
+        if (d->n)
+                disj_score_walk(d, 1, d->heap[1]->cur, &sum);
+        return sum;
+}
+
+/* ================================================================== Phrase */
+typedef struct { /* docwordspace.h:16-92: one term per position, last writer wins; docSeq marks validity */
+        uint16_t termID[65536 + MAX_PHRASE + 1];
+        uint32_t docSeq[65536 + MAX_PHRASE + 1];
+        uint32_t curSeq;
+} to_dws;
+
+typedef struct { /* docset_iterators.h:364-402 */
+        to_iter it;
+        to_pli **its;
+        uint16_t size;
+        uint16_t nterms;
+        uint16_t maxMatchCnt, matchCnt;
+        uint16_t execTermID[MAX_PHRASE]; /* distinct per distinct term (queryexec_ctx::resolve_term) */
+        double weight;                   /* similarity.h:202-226: sum of the terms' idf */
+        to_dws *dws;
+        uint16_t *hits0;
+        uint16_t *scratch;
+} to_phrase;
+
+/* docset_iterators.cpp:66-158 + queryexec_ctx.cpp:317-351 (materialize_term_hits) */
+static int phrase_consider(to_phrase *ph) {
+        to_dws *dws = ph->dws;
+        const uint16_t n = ph->nterms;
+        /* fresh DocWordsSpace for this candidate document (docwordspace.h:40-55 reset()) */
+        if (++dws->curSeq == 0) {
+                memset(dws->docSeq, 0, sizeof dws->docSeq);
+                dws->curSeq = 1;
+        }
+        uint32_t firstTermFreq = 0;
+        ph->matchCnt = 0;
+        for (uint16_t i = 0; i != n; ++i) {
+                /* term hits are materialized once per (document, exec term id): a term repeated inside
+                 * the phrase is NOT re-materialized (queryexec_ctx.cpp:330 th->doc_id != did) */
+                int seen = 0;
+                for (uint16_t j = 0; j < i; ++j)
+                        seen |= (ph->execTermID[j] == ph->execTermID[i]);
+                if (seen)
+                        continue;
+                to_pli *it = ph->its[i];
+                if (i == 0)
+                        firstTermFreq = it->freq; /* th->set_freq(it->freq): u16 */
+                uint16_t *dst = i == 0 ? ph->hits0 : ph->scratch;
+                const uint32_t cnt = to_pli_materialize_positions(it, dst);
+                for (uint32_t k = 0; k < cnt; ++k) {
+                        const uint16_t pos = dst[k];
+                        if (pos) { /* google_codec.cpp:578-584: dws->set(termID, pos) */
+                                dws->termID[pos] = ph->execTermID[i];
+                                dws->docSeq[pos] = dws->curSeq;
+                        }
+                }
+        }
+        for (uint32_t i = 0; i != firstTermFreq; ++i) {
+                const uint16_t pos = ph->hits0[i];
+                if (!pos)
+                        continue;
+                for (uint16_t k = 1;; ++k) {
+                        if (k == n) {
+                                if (++ph->matchCnt == ph->maxMatchCnt)
+                                        return 1;
+                                break;
+                        }
+                        const uint32_t q = (uint32_t)pos + k;
+                        if (!(dws->docSeq[q] == dws->curSeq && dws->termID[q] == ph->execTermID[k]))
+                                break;
+                }
+        }
+        return ph->matchCnt != 0;
+}
+
+/* docset_iterators.cpp:160-183 */
+static uint32_t phrase_next_impl(to_phrase *ph, uint32_t id) {
+restart:
+        for (uint16_t i = 1; i != ph->size; ++i) {
+                to_iter *it = &ph->its[i]->it;
+                if (it->cur != id) {
+                        const uint32_t next = it->advance(it, id);
+                        if (next > id) {
+                                if (next == TO_DOCIDS_END)
+                                        return TO_DOCIDS_END;
+                                id = ph->its[0]->it.advance(&ph->its[0]->it, next);
+                                if (id == TO_DOCIDS_END)
+                                        return TO_DOCIDS_END;
+                                goto restart;
+                        }
+                }
+        }
+        return ph->it.cur = id;
+}
+
+/* docset_iterators.cpp:205-224 */
+static uint32_t phrase_next(to_iter *self) {
+        to_phrase *ph = (to_phrase *)self;
+        if (ph->size) {
+                to_iter *lead = &ph->its[0]->it;
+                uint32_t id = lead->next(lead);
+                if (id == TO_DOCIDS_END) {
+                        ph->size = 0;
+                        return ph->it.cur = TO_DOCIDS_END;
+                }
+                for (id = phrase_next_impl(ph, id);; id = phrase_next_impl(ph, lead->next(lead))) {
+                        if (id == TO_DOCIDS_END) {
+                                ph->size = 0;
+                                return ph->it.cur = TO_DOCIDS_END;
+                        } else if (phrase_consider(ph))
+                                return ph->it.cur = id;
+                }
+        }
+        return TO_DOCIDS_END;
+}
+
+/* docset_iterators.cpp:185-203.  NB: when lead->next() returns END inside the for-increment the
+ * reference hands END to next_impl(), whose members then advance(END) and report END. */
+static uint32_t phrase_advance(to_iter *self, uint32_t target) {
+        to_phrase *ph = (to_phrase *)self;
+        if (ph->size) {
+                to_iter *lead = &ph->its[0]->it;
+                uint32_t id = lead->advance(lead, target);
+                if (id == TO_DOCIDS_END) {
+                        ph->size = 0;
+                        return ph->it.cur = TO_DOCIDS_END;
+                }
+                for (id = phrase_next_impl(ph, id);; id = phrase_next_impl(ph, lead->next(lead))) {
+                        if (id == TO_DOCIDS_END) {
+                                ph->size = 0;
+                                return ph->it.cur = TO_DOCIDS_END;
+                        } else if (phrase_consider(ph))
+                                return id;
+                }
+        }
+        return TO_DOCIDS_END;
+}
+
+/* docset_iterators_scorers.cpp:195-228: scorer->score(id, matchCnt, weight) */
+static double phrase_score(to_iter *self) {
+        to_phrase *ph = (to_phrase *)self;
+        return to_bm25_score(ph->weight, ph->matchCnt);
+}
+
+/* ================================================================== plan -> iterator tree */
+typedef struct {
+        const to_index *ix;
+        uint32_t flags;
+        void **owned;
+        size_t nowned, capowned;
+        /* exec term ids: one per distinct term of the query (queryexec_ctx.cpp:279-296) */
+        uint32_t termOf[64];
+        uint16_t nTermIDs;
+} to_ctx;
+
+static void *ctx_own(to_ctx *c, void *p) {
+        if (c->nowned == c->capowned) {
+                c->capowned = c->capowned ? c->capowned * 2 : 32;
+                c->owned = (void **)xrealloc(c->owned, sizeof(void *) * c->capowned);
+        }
+        c->owned[c->nowned++] = p;
+        return p;
+}
+
+static uint16_t ctx_term_id(to_ctx *c, uint32_t term) {
+        for (uint16_t i = 0; i < c->nTermIDs; ++i)
+                if (c->termOf[i] == term)
+                        return (uint16_t)(i + 1);
+        if (c->nTermIDs == 64)
+                abort();
+        c->termOf[c->nTermIDs++] = term;
+        return c->nTermIDs;
+}
+
+typedef struct pnode {
+        uint32_t op, term;
+        struct pnode **kids;
+        uint32_t nkids;
+        uint64_t cost;
+        int empty; /* can never match (a term with documents == 0 under AND / PHRASE) */
+} pnode;
+
+static pnode *pn_new(to_ctx *c, uint32_t op) {
+        pnode *n = (pnode *)ctx_own(c, xcalloc(1, sizeof *n));
+        n->op = op;
+        return n;
+}
+
+/* Parse the postfix program, flatten nested AND/AND and OR/OR (exec.cpp:339-358, 382-393),
+ * drop never-matching operands of OR, propagate emptiness through AND/PHRASE (what the reference's
+ * compiler does with unknown terms: compilation_ctx.cpp constfalse propagation), and compute costs
+ * (exec.cpp:35-110 reorder_execnode_impl / docset_iterators.cpp:10-64 cost()). */
+static pnode *parse_prog(to_ctx *c, const uint32_t *prog, uint32_t len) {
+        pnode **stack = (pnode **)ctx_own(c, xmalloc(sizeof(pnode *) * (len + 1)));
+        uint32_t sp = 0;
+        for (uint32_t i = 0; i < len; ++i) {
+                const uint32_t op = TO_TOK_OP(prog[i]), arg = TO_TOK_ARG(prog[i]);
+                if (op == TO_OP_TERM) {
+                        pnode *n = pn_new(c, op);
+                        n->term = arg;
+                        /* unknown term == no documents (index_source.h:60-72 term_ctx -> {0,{}}) */
+                        n->cost = arg < c->ix->nterms ? c->ix->terms[arg].documents : 0;
+                        n->empty = n->cost == 0;
+                        stack[sp++] = n;
+                        continue;
+                }
+                if (arg < 1 || arg > sp)
+                        return NULL;
+                pnode *n = pn_new(c, op);
+                pnode **kids = stack + (sp - arg);
+                n->kids = (pnode **)ctx_own(c, xmalloc(sizeof(pnode *) * (len + 1)));
+                if (op == TO_OP_PHRASE) {
+                        if (arg > MAX_PHRASE)
+                                return NULL;
+                        for (uint32_t k = 0; k < arg; ++k) {
+                                if (kids[k]->op != TO_OP_TERM)
+                                        return NULL;
+                                n->kids[n->nkids++] = kids[k];
+                                n->empty |= kids[k]->empty;
+                        }
+                        /* exec.cpp:28-34 phrase_cost */
+                        n->cost = (uint64_t)kids[0]->cost + UINT32_MAX + (uint64_t)UINT16_MAX * arg;
+                } else if (op == TO_OP_AND) {
+                        for (uint32_t k = 0; k < arg; ++k) {
+                                n->empty |= kids[k]->empty;
+                                if (kids[k]->op == TO_OP_AND)
+                                        for (uint32_t j = 0; j < kids[k]->nkids; ++j)
+                                                n->kids[n->nkids++] = kids[k]->kids[j];
+                                else
+                                        n->kids[n->nkids++] = kids[k];
+                        }
+                        /* lowest cost first (exec.cpp:154-170 sort by df; 44-55 lhs/rhs swap); stable */
+                        for (uint32_t a = 1; a < n->nkids; ++a) {
+                                pnode *x = n->kids[a];
+                                uint32_t b = a;
+                                while (b > 0 && n->kids[b - 1]->cost > x->cost) {
+                                        n->kids[b] = n->kids[b - 1];
+                                        --b;
+                                }
+                                n->kids[b] = x;
+                        }
+                        n->cost = n->kids[0]->cost;
+                } else if (op == TO_OP_OR) {
+                        for (uint32_t k = 0; k < arg; ++k) {
+                                if (kids[k]->empty)
+                                        continue;
+                                if (kids[k]->op == TO_OP_OR)
+                                        for (uint32_t j = 0; j < kids[k]->nkids; ++j)
+                                                n->kids[n->nkids++] = kids[k]->kids[j];
+                                else
+                                        n->kids[n->nkids++] = kids[k];
+                        }
+                        n->empty = n->nkids == 0;
+                        for (uint32_t j = 0; j < n->nkids; ++j)
+                                n->cost += n->kids[j]->cost;
+                } else
+                        return NULL;
+                sp -= arg;
+                stack[sp++] = n;
+        }
+        return sp == 1 ? stack[0] : NULL;
+}
+
+/* exec.cpp:253-449 build_iterator (+ docset_iterators_scorers.cpp wrap_iterator) */
+static to_iter *build_iter(to_ctx *c, const pnode *n) {
+        switch (n->op) {
+                case TO_OP_TERM: {
+                        to_pli *p = (to_pli *)ctx_own(c, to_pli_new(c->ix, n->term));
+                        ctx_term_id(c, n->term);
+                        return &p->it;
+                }
+                case TO_OP_PHRASE: {
+                        if (n->nkids == 1)
+                                return build_iter(c, n->kids[0]);
+                        to_phrase *ph = (to_phrase *)ctx_own(c, xcalloc(1, sizeof *ph));
+                        ph->it.type = IT_PHRASE;
+                        ph->it.next = phrase_next;
+                        ph->it.advance = phrase_advance;
+                        ph->it.score = phrase_score;
+                        ph->it.cost = n->cost;
+                        ph->size = ph->nterms = (uint16_t)n->nkids;
+                        ph->its = (to_pli **)ctx_own(c, xmalloc(sizeof(to_pli *) * n->nkids));
+                        /* exec.cpp:296: trackCnt = AccumulatedScoreScheme */
+                        ph->maxMatchCnt = (c->flags & TO_FLAG_ACCUM_SCORE) ? UINT16_MAX : 1;
+                        for (uint32_t i = 0; i < n->nkids; ++i) {
+                                ph->its[i] = (to_pli *)ctx_own(c, to_pli_new(c->ix, n->kids[i]->term));
+                                ph->execTermID[i] = ctx_term_id(c, n->kids[i]->term);
+                                ph->weight += to_bm25_idf(c->ix->terms[n->kids[i]->term].documents, c->ix->docsCnt);
+                        }
+                        ph->dws = (to_dws *)ctx_own(c, xcalloc(1, sizeof(to_dws)));
+                        ph->hits0 = (uint16_t *)ctx_own(c, xmalloc(sizeof(uint16_t) * 65536));
+                        ph->scratch = (uint16_t *)ctx_own(c, xmalloc(sizeof(uint16_t) * 65536));
+                        return &ph->it;
+                }
+                case TO_OP_AND: {
+                        to_conj_s *cj = (to_conj_s *)ctx_own(c, xcalloc(1, sizeof *cj));
+                        cj->c.it.type = IT_CONJ;
+                        cj->c.it.next = conj_next;
+                        cj->c.it.advance = conj_advance;
+                        cj->c.it.score = conj_score;
+                        cj->c.it.cost = n->cost;
+                        cj->c.size = cj->nscore = (uint16_t)n->nkids;
+                        cj->c.its = (to_iter **)ctx_own(c, xmalloc(sizeof(to_iter *) * n->nkids));
+                        for (uint32_t i = 0; i < n->nkids; ++i)
+                                cj->c.its[i] = build_iter(c, n->kids[i]);
+                        return &cj->c.it;
+                }
+                case TO_OP_OR: {
+                        if (n->nkids == 1)
+                                return build_iter(c, n->kids[0]);
+                        to_disj *d = (to_disj *)ctx_own(c, xcalloc(1, sizeof *d));
+                        d->it.type = IT_DISJ;
+                        d->it.next = disj_next;
+                        d->it.advance = disj_advance;
+                        d->it.score = disj_score;
+                        d->it.cost = n->cost;
+                        d->heap = (to_iter **)ctx_own(c, xmalloc(sizeof(to_iter *) * (n->nkids + 2)));
+                        for (uint32_t i = 0; i < n->nkids; ++i)
+                                heap_push(d->heap, &d->n, build_iter(c, n->kids[i])); /* all at cur == 0 */
+                        return &d->it;
+                }
+        }
+        return NULL;
+}
+
+/* ================================================================== spans + handlers */
+static void res_push(to_result *r, uint32_t id, double score, int scored) {
+        if (r->n == r->cap) {
+                r->cap = r->cap ? r->cap * 2 : 1024;
+                r->docs = (uint32_t *)xrealloc(r->docs, sizeof(uint32_t) * r->cap);
+                if (scored)
+                        r->scores = (double *)xrealloc(r->scores, sizeof(double) * r->cap);
+        }
+        r->docs[r->n] = id;
+        if (scored)
+                r->scores[r->n] = score;
+        ++r->n;
+}
+
+/* docset_spans.cpp:269-290 GenericDocsSetSpan::process(mp, 1, DocIDsEND) fast path, with the
+ * exec.cpp:1213-1229 (docs-only) / 1322-1341 (accumulated score) no-filter handlers inlined */
+static void span_generic(to_iter *it, uint32_t flags, to_result *out) {
+        const int scored = (flags & TO_FLAG_ACCUM_SCORE) != 0;
+        for (uint32_t id = it->next(it); id != TO_DOCIDS_END; id = it->next(it))
+                res_push(out, id, scored ? it->score(it) : 0.0, scored);
+}
+
+/* docset_spans.cpp:98-173 (DocsSetSpanForDisjunctions) and 681-790 (…WithThreshold(1, its, true)) */
+static void span_disjunction(to_ctx *c, to_iter **its, uint32_t cnt, uint32_t flags, to_result *out) {
+        const int scored = (flags & TO_FLAG_ACCUM_SCORE) != 0;
+        uint64_t *matching = (uint64_t *)ctx_own(c, xcalloc(SPAN_SIZE / 64, sizeof(uint64_t)));
+        double *trkScore = (double *)ctx_own(c, xcalloc(SPAN_SIZE, sizeof(double)));
+        to_iter **heap = (to_iter **)ctx_own(c, xmalloc(sizeof(to_iter *) * (cnt + 2)));
+        to_iter **collected = (to_iter **)ctx_own(c, xmalloc(sizeof(to_iter *) * (cnt + 1)));
+        uint32_t hn = 0;
+        for (uint32_t i = 0; i < cnt; ++i) { /* docset_spans.h:157-163, 208-214: ctor primes children */
+                its[i]->next(its[i]);
+                heap_push(heap, &hn, its[i]);
+        }
+        const uint32_t max = TO_DOCIDS_END;
+        for (;;) {
+                to_iter *it = heap[1];
+                const uint32_t id = it->cur;
+                if (id >= max)
+                        break;
+                const uint32_t windowBase = id & ~SPAN_MASK;
+                const uint64_t wm = (uint64_t)windowBase + SPAN_SIZE;
+                const uint32_t windowMax = wm < max ? (uint32_t)wm : max;
+                uint32_t collectedCnt = 1;
+                collected[0] = it;
+                for (heap_pop(heap, &hn); hn && (it = heap[1])->cur < windowMax; heap_pop(heap, &hn))
+                        collected[collectedCnt++] = it;
+                if (collectedCnt == 1) { /* docset_spans.cpp:120-129 / 712-719 */
+                        to_iter *one = collected[0];
+                        for (uint32_t d = one->cur; d < windowMax; d = one->next(one))
+                                res_push(out, d, scored ? one->score(one) : 0.0, scored);
+                        heap_push(heap, &hn, one);
+                } else {
+                        uint32_t m = 0;
+                        for (uint32_t i_ = 0; i_ != collectedCnt; ++i_) {
+                                to_iter *ci = collected[i_];
+                                for (uint32_t d = ci->cur; d < windowMax; d = ci->next(ci)) {
+                                        const uint32_t i = d - windowBase, mi = i >> 6;
+                                        if (mi > m)
+                                                m = mi;
+                                        matching[mi] |= (uint64_t)1 << (i & 63);
+                                        if (scored)
+                                                trkScore[i] += ci->score(ci);
+                                }
+                                heap_push(heap, &hn, ci);
+                        }
+                        for (uint32_t idx = 0; idx <= m; ++idx) {
+                                for (uint64_t b = matching[idx]; b;) {
+                                        const uint32_t bidx = (uint32_t)__builtin_ctzll(b);
+                                        const uint32_t translated = (idx << 6) + bidx;
+                                        b ^= (uint64_t)1 << bidx;
+                                        res_push(out, windowBase + translated, trkScore[translated], scored);
+                                        trkScore[translated] = 0;
+                                }
+                        }
+                        memset(matching, 0, (m + 1) * sizeof(uint64_t));
+                }
+        }
+}
+
+int to_exec_query(const to_index *ix, const uint32_t *prog, uint32_t proglen, uint32_t flags, to_result *out) {
+        memset(out, 0, sizeof *out);
+        if ((flags & (TO_FLAG_DOCUMENTS_ONLY | TO_FLAG_ACCUM_SCORE)) == 0 ||
+            (flags & (TO_FLAG_DOCUMENTS_ONLY | TO_FLAG_ACCUM_SCORE)) == (TO_FLAG_DOCUMENTS_ONLY | TO_FLAG_ACCUM_SCORE))
+                return -1; /* exec.h:45-48: mutually exclusive; the default rich mode is out of scope */
+        to_ctx c;
+        memset(&c, 0, sizeof c);
+        c.ix = ix;
+        c.flags = flags;
+        int rc = 0;
+        pnode *root = parse_prog(&c, prog, proglen);
+        if (!root)
+                rc = -2;
+        else if (!root->empty) {
+                to_iter *sit = build_iter(&c, root);
+                /* exec.cpp:452-505 build_span: a root disjunction hands its children to the window span */
+                if (sit->type == IT_DISJ) {
+                        to_disj *d = (to_disj *)sit;
+                        to_iter **kids = (to_iter **)ctx_own(&c, xmalloc(sizeof(to_iter *) * d->n));
+                        const uint32_t cnt = d->n;
+                        for (uint32_t i = 0; i < cnt; ++i)
+                                kids[i] = d->heap[i + 1];
+                        span_disjunction(&c, kids, cnt, flags, out);
+                } else
+                        span_generic(sit, flags, out);
+        }
+        for (size_t i = 0; i < c.nowned; ++i)
+                free(c.owned[i]);
+        free(c.owned);
+        return rc;
+}
+
+void to_result_free(to_result *r) {
+        free(r->docs);
+        free(r->scores);
+        memset(r, 0, sizeof *r);
+}
+
+/* Application-side top-K (matches.h:139-185 leaves ranking to the application).
+ * Order: score descending, docID ascending. */
+uint32_t to_topk(const to_result *r, uint32_t k, uint32_t *docs, float *scores) {
+        if (!k)
+                return 0;
+        uint32_t *hd = (uint32_t *)xmalloc(sizeof(uint32_t) * k);
+        double *hs = (double *)xmalloc(sizeof(double) * k);
+        uint32_t n = 0;
+        /* "worse" = lower score, or equal score and larger docID; keep a min-heap on "better" */
+#define WORSE(s1, d1, s2, d2) ((s1) < (s2) || ((s1) == (s2) && (d1) > (d2)))
+        for (size_t i = 0; i < r->n; ++i) {
+                const double s = r->scores ? r->scores[i] : 0.0;
+                const uint32_t d = r->docs[i];
+                if (n < k) {
+                        uint32_t j = n++;
+                        while (j > 0) {
+                                uint32_t pa = (j - 1) / 2;
+                                if (WORSE(s, d, hs[pa], hd[pa])) {
+                                        hs[j] = hs[pa];
+                                        hd[j] = hd[pa];
+                                        j = pa;
+                                } else
+                                        break;
+                        }
+                        hs[j] = s;
+                        hd[j] = d;
+                } else if (WORSE(hs[0], hd[0], s, d)) {
+                        uint32_t j = 0;
+                        for (;;) {
+                                uint32_t l = 2 * j + 1, rr = l + 1, m = l;
+                                if (l >= n)
+                                        break;
+                                if (rr < n && WORSE(hs[rr], hd[rr], hs[l], hd[l]))
+                                        m = rr;
+                                if (WORSE(hs[m], hd[m], s, d)) {
+                                        hs[j] = hs[m];
+                                        hd[j] = hd[m];
+                                        j = m;
+                                } else
+                                        break;
+                        }
+                        hs[j] = s;
+                        hd[j] = d;
+                }
+        }
+        /* selection sort out of the heap: best first */
+        for (uint32_t i = 0; i < n; ++i) {
+                uint32_t best = i;
+                for (uint32_t j = i + 1; j < n; ++j)
+                        if (WORSE(hs[best], hd[best], hs[j], hd[j]))
+                                best = j;
+                double ts = hs[i];
+                hs[i] = hs[best];
+                hs[best] = ts;
+                uint32_t td = hd[i];
+                hd[i] = hd[best];
+                hd[best] = td;
+                docs[i] = hd[i];
+                scores[i] = (float)hs[i];
+        }
+#undef WORSE
+        free(hd);
+        free(hs);
+        return n;
+}
+
+uint64_t to_fnv1a_docs(const uint32_t *docs, size_t n) {
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; ++i) {
+                uint32_t d = docs[i];
+                for (int b = 0; b < 4; ++b) {
+                        h = (h ^ (d & 0xff)) * 1099511628211ull;
+                        d >>= 8;
+                }
+        }
+        return h;
+}

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the GENUINE reference (oracle/_ref/ref_driver, built from
+/root/reference by oracle/Makefile).  Runs only in the build container (the GPU box has no reference).
+
+The fixtures are DATA: inputs (corpus parameters of this repo's deterministic generator, query texts,
+seeds) and the reference's outputs (counts, FNV-1a hashes, first/last docIDs, score sums, top-K, and full
+(docID, score) lists on the small corpus).  No reference source text is stored.
+
+usage: python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib as O  # noqa: E402
+
+CORPORA = {
+    # name: (D, V, slots, seed)
+    "tiny": (2000, 200, 10, 42),
+    "small": (20000, 2000, 10, 42),
+    "dense": (20000, 500, 12, 7),  # heavy duplication inside documents (freq > 1), long lists
+}
+
+TEMPLATES = [
+    "t{a} t{b}",
+    "t{a} t{b} t{c} t{d} t{e}",
+    "t{a} OR t{b}",
+    "t{a} OR t{b} OR t{c} OR t{d} OR t{e}",
+    "t{a} t{b} (t{c} OR t{d} OR t{e})",
+    "(t{a} OR t{b}) (t{c} OR t{d}) t{e}",
+    '"t{a} t{b}"',
+    '"t{a} t{b} t{c}"',
+    '"t{a} t{b}" t{c}',
+]
+
+
+def commands_for(name, D, V, slots, seed):
+    cmds = ["index"]
+    terms = [0, 1, 2, 3, 7, 19, V // 4, V // 2, V - 1]
+    for t in terms:
+        cmds.append(f"decode {t}")
+    for t in (0, 1, 5, 19):
+        for s in (1, 2, 3):
+            cmds.append(f"advance {t} {s} 4000")
+    for t in (0, 3, V // 4):
+        cmds.append(f"positions {t} 3")
+    qs = O.gen_queries(V, 1337, 12, 5)
+    head = [[0, 1, 2, 3, 4], [1, 0, 2, 5, 9], [3, 7, 11, 0, 2]]
+    for ri, row in enumerate(head + qs.tolist()):
+        full = name == "tiny" and ri < 3  # full (docID, score) lists only for the three head rows
+        a, b, c, d, e = [int(x) for x in row]
+        for tpl in TEMPLATES:
+            text = tpl.format(a=a, b=b, c=c, d=d, e=e)
+            for flags in (1, 2):
+                if full:
+                    cmds.append(f"queryfull {flags} {text}")
+                else:
+                    cmds.append(f"query {flags} {10 if flags == 2 else 0} {text}")
+    # a term with zero documents (if the corpus has one) and an out-of-vocabulary term
+    cmds.append(f"query 1 0 t0 t{V + 5}")
+    cmds.append(f"query 1 0 t0 OR t{V + 5}")
+    return cmds
+
+
+def main():
+    for name, (D, V, slots, seed) in CORPORA.items():
+        cmds = commands_for(name, D, V, slots, seed)
+        res = O.run_ref_driver(D, V, slots, seed, cmds)
+        assert len(res) == len(cmds), (len(res), len(cmds))
+        out = {"corpus": {"D": D, "V": V, "slots": slots, "seed": seed}, "query_seed": 1337, "results": res}
+        path = os.path.join(HERE, f"ref_{name}.json")
+        with open(path, "w") as f:
+            json.dump(out, f, separators=(",", ":"))
+        print(path, len(res), "records", os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,241 @@
+"""CPU tests: the oracle (oracle/trinity_oracle.c) against the fixtures produced by the GENUINE reference
+(tests/golden/ref_*.json, generator tests/golden/make_golden.py) and, when the prebuilt reference driver is
+present (oracle/_ref/ref_driver), against live runs of it."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["tiny", "small", "dense"]
+
+
+def fnv_bytes(a):
+    h = 1469598103934665603
+    for x in a.tolist():
+        h = ((h ^ x) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.fixture(scope="module", params=NAMES)
+def golden(request):
+    with open(os.path.join(GOLDEN, f"ref_{request.param}.json")) as f:
+        g = json.load(f)
+    c = g["corpus"]
+    ix = O.Index.generate(c["D"], c["V"], c["slots"], c["seed"])
+    return g, ix
+
+
+# ---- a1: prefix varint known answers (Switch/switch_compiler_aux.h:23-80) ---------------------------
+VARBYTE_KAT = [
+    (0, [0x00]),
+    (1, [0x01]),
+    (127, [0x7F]),
+    (128, [0x80, 0x80]),
+    (300, [0x81, 0x2C]),
+    (16383, [0xBF, 0xFF]),
+    (16384, [0xC0, 0x00, 0x40]),
+    (0x12345, [0xC1, 0x45, 0x23]),
+    (2097151, [0xDF, 0xFF, 0xFF]),
+    (2097152, [0xE0, 0x20, 0x00, 0x00]),
+    (0x0ABCDEF1, [0xEA, 0xBC, 0xDE, 0xF1]),
+    (268435455, [0xEF, 0xFF, 0xFF, 0xFF]),
+    (268435456, [0xF0, 0x00, 0x00, 0x00, 0x10]),
+    (0xFFFFFFFF, [0xF0, 0xFF, 0xFF, 0xFF, 0xFF]),
+]
+
+
+def test_varbyte_kat():
+    import ctypes as C
+
+    L = O.lib()
+    for v, enc in VARBYTE_KAT:
+        buf = (C.c_uint8 * 8)()
+        n = L.to_varbyte_put32(buf, v)
+        assert list(buf[:n]) == enc, (v, list(buf[:n]))
+        out = C.c_uint32()
+        m = L.to_varbyte_get32(buf, C.byref(out))
+        assert (m, out.value) == (n, v)
+
+
+def test_varbyte_roundtrip_random():
+    import ctypes as C
+
+    L = O.lib()
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.integers(0, 1 << b, 200, dtype=np.uint64) for b in (7, 8, 14, 15, 21, 22, 28, 29, 32)])
+    buf = (C.c_uint8 * 8)()
+    out = C.c_uint32()
+    for v in vals.tolist():
+        n = L.to_varbyte_put32(buf, v)
+        assert L.to_varbyte_get32(buf, C.byref(out)) == n and out.value == v
+
+
+def test_index_bytes_match_reference(golden):
+    g, ix = golden
+    r = g["results"][0]
+    assert r["cmd"] == "index"
+    assert ix.c.len == r["len"]
+    assert str(fnv_bytes(ix.bytes())) == r["fnv"]
+    assert str(O.fnv1a_docs(ix.terms().reshape(-1))) == r["terms_fnv"]
+    assert int(ix.c.sumTermsDocs) == r["postings"] and int(ix.c.totalTerms) == r["totalTerms"]
+
+
+def test_chunk_walker_accounts_for_every_byte(golden):
+    _, ix = golden
+    tot = 0
+    for t in range(ix.c.nterms):
+        s = ix.chunk_stats(t)
+        tot += s["hdr"] + s["docfreq"] + s["hits"] + s["skip"]
+        assert s["postings"] == ix.c.terms[t].documents
+    assert tot == ix.c.len
+
+
+def test_decode_next_matches_reference(golden):
+    g, ix = golden
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] != "decode":
+            continue
+        d, f = ix.decode_term(r["term"])
+        assert len(d) == r["n"]
+        assert str(O.fnv1a_docs(d)) == r["docs_fnv"] and str(O.fnv1a_docs(f)) == r["freqs_fnv"]
+        k = min(8, len(d))
+        assert d[:k].tolist() == r["first"] and d[len(d) - k :].tolist() == r["last"]
+        n += 1
+    assert n >= 5
+
+
+def _advance_trace(ix, D, term, seed, steps):
+    import ctypes as C
+
+    L = O.lib()
+    it = O.PLI(ix, term)
+    st = C.c_uint64(seed)
+    vals = []
+    done = 0
+    while done < steps and it.current() != O.DOCIDS_END:
+        r = L.to_splitmix64(C.byref(st))
+        cur = it.current()
+        op = r & 7
+        j = r >> 8
+        if op in (0, 1):
+            i = it.next()
+        elif op == 2:
+            i = it.advance(cur) if cur else it.next()
+        elif op == 3:
+            i = it.advance(cur + 1 + j % 3)
+        elif op == 4:
+            i = it.advance(cur + 1 + j % 64)
+        elif op == 5:
+            i = it.advance(cur + 1 + j % 2048)
+        elif op == 6:
+            i = it.advance(cur + 1 + j % (D // 16 + 1))
+        else:
+            i = it.advance(cur - j % 3) if cur > 3 else it.next()
+        vals += [i, 0 if i == O.DOCIDS_END else it.freq()]
+        done += 1
+    return done, O.fnv1a_u32_stream(np.array(vals, dtype=np.uint32))
+
+
+def test_advance_traces_match_reference(golden):
+    g, ix = golden
+    D = g["corpus"]["D"]
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] != "advance":
+            continue
+        done, h = _advance_trace(ix, D, r["term"], int(r["seed"]), r["steps"])
+        assert done == r["done"] and str(h) == r["trace_fnv"], r
+        n += 1
+    assert n >= 6
+
+
+def test_positions_match_reference(golden):
+    g, ix = golden
+    for r in g["results"]:
+        if r["cmd"] != "positions":
+            continue
+        it = O.PLI(ix, r["term"])
+        vals = []
+        i = 0
+        cnt = 0
+        while True:
+            d = it.next()
+            if d == O.DOCIDS_END:
+                break
+            if i % r["nth"] == 0:
+                f = it.freq()
+                pos = it.positions()
+                assert len(pos) == f
+                vals += [d] + pos
+                cnt += 1
+            i += 1
+        assert cnt == r["docs"] and str(O.fnv1a_u32_stream(np.array(vals, dtype=np.uint32))) == r["fnv"]
+
+
+def test_queries_match_reference(golden):
+    g, ix = golden
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] not in ("query", "queryfull"):
+            continue
+        docs, scores = ix.exec(O.parse_query(r["q"]), r["flags"])
+        assert len(docs) == r["n"], r["q"]
+        assert str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]  # bit-exact docID set, ascending
+        k = min(16, len(docs))
+        assert docs[:k].tolist() == r["first"] and docs[len(docs) - k :].tolist() == r["last"]
+        if r["flags"] & 2:
+            ref_sum = r["score_sum"]
+            assert abs(scores.sum() - ref_sum) <= 1e-5 * max(1.0, abs(ref_sum))
+            if "top" in r:
+                td, ts = ix.topk(docs, scores, len(r["top"]))
+                assert td.tolist() == [x[0] for x in r["top"]]
+                np.testing.assert_allclose(ts, [x[1] for x in r["top"]], rtol=1e-5)
+            if "scores" in r:
+                assert docs.tolist() == r["docs"]
+                np.testing.assert_allclose(scores, r["scores"], rtol=1e-5, atol=0)
+        elif "docs" in r:
+            assert docs.tolist() == r["docs"]
+        n += 1
+    assert n > 200
+
+
+def test_bm25_formula_known_answers():
+    L = O.lib()
+    # similarity.h:179-181 float-precision idf; :228-235 score
+    import math
+
+    N, df = 20000, 17135
+    f32 = np.float32
+    idf = float(np.log(f32(1) + (f32(N - df) + f32(0.5)) / (f32(df) + f32(0.5)), dtype=np.float32))
+    assert L.to_bm25_idf(df, N) == pytest.approx(idf, rel=1e-7)
+    for fr in (1, 2, 3, 10, 65535):
+        want = f32(idf * float(f32(fr)) / float(f32(fr) + f32(1.2)))
+        assert L.to_bm25_score(idf, fr) == pytest.approx(float(want), rel=1e-6)
+    assert math.isfinite(L.to_bm25_idf(0, 1))
+
+
+@pytest.mark.skipif(not os.path.exists(O.REF_DRIVER), reason="prebuilt reference driver not present")
+def test_live_reference_random_queries():
+    """Live cross-check at a size the fixtures do not hold: 50K docs, seeded random 2..5-term shapes."""
+    D, V, S, seed = 50000, 3000, 10, 99
+    ix = O.Index.generate(D, V, S, seed)
+    qs = O.gen_queries(V, 4242, 40, 5).tolist()
+    tpls = ["t{a} t{b}", "t{a} OR t{b} OR t{c}", "t{a} t{b} (t{c} OR t{d} OR t{e})", '"t{a} t{b}"', "(t{a} OR t{b}) (t{c} OR t{d}) t{e}"]
+    cmds, meta = ["index"], []
+    for i, row in enumerate(qs):
+        a, b, c, d, e = row
+        text = tpls[i % len(tpls)].format(a=a, b=b, c=c, d=d, e=e)
+        for fl in (1, 2):
+            cmds.append(f"query {fl} {10 if fl == 2 else 0} {text}")
+    res = O.run_ref_driver(D, V, S, seed, cmds)
+    assert str(fnv_bytes(ix.bytes())) == res[0]["fnv"]
+    for r in res[1:]:
+        docs, scores = ix.exec(O.parse_query(r["q"]), r["flags"])
+        assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
+        if r["flags"] & 2:
+            assert abs(scores.sum() - r["score_sum"]) <= 1e-5 * max(1.0, abs(r["score_sum"]))
