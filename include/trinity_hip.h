@@ -1,0 +1,154 @@
+/*
+ * trinity_hip.h — C-ABI of libtrinity_hip.so, the MI355X (gfx950) execution engine for Trinity's
+ * query hot path: postings decode -> docset intersection/union -> per-document BM25 -> top-K.
+ *
+ * Plain C: opaque handles, plain pointers and sizes, int status codes.  Nothing throws across this
+ * boundary.  Every entry point names the reference interface (file:line under the reference tree)
+ * whose work it takes over; INTEGRATION.md shows the binding a Trinity maintainer would add.
+ *
+ * Threading: one tri_dev per (host thread, device).  Handles are not internally locked.
+ */
+#ifndef TRINITY_HIP_H
+#define TRINITY_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRI_ABI_VERSION 1
+
+/* status codes */
+#define TRI_OK 0
+#define TRI_ERR_INVALID (-1)     /* bad argument / malformed program   (reference: Switch::invalid_argument) */
+#define TRI_ERR_DEVICE (-2)      /* HIP runtime error                  */
+#define TRI_ERR_UNSUPPORTED (-3) /* query shape not lowered yet        */
+#define TRI_ERR_FORMAT (-4)      /* index bytes fail validation        (reference: Switch::data_error)      */
+#define TRI_ERR_NOMEM (-5)
+
+/* codecs (segment `id` file codec name: indexer.cpp:266-270, segment_index_source.cpp:172-179) */
+#define TRI_CODEC_GOOGLE 1
+#define TRI_CODEC_LUCENE 2
+
+/* exec.h:11-43 ExecFlags (same values) */
+#define TRI_FLAG_DOCUMENTS_ONLY 1u
+#define TRI_FLAG_ACCUMULATED_SCORE 2u
+
+/* similarity.h scorers: Trivial :56-72, TF-IDF :75-163, BM25 :165-255 */
+#define TRI_SIM_BM25 0
+#define TRI_SIM_TFIDF 1
+#define TRI_SIM_TRIVIAL 2
+
+/* postfix query program tokens: (op << 28) | arg.  The host-side planner (the mirror of
+ * queryexec_ctx::build_iterator, exec.cpp:253-449) emits these from its iterator tree. */
+#define TRI_OP_TERM 0u   /* arg = index into the uploaded term table                              */
+#define TRI_OP_AND 1u    /* arg = #children   (DocsSetIterators::Conjuction[AllPLI])              */
+#define TRI_OP_OR 2u     /* arg = #children   (DocsSetIterators::Disjunction[AllPLI] / union span) */
+#define TRI_OP_PHRASE 3u /* arg = #terms, the preceding arg tokens are TERMs (DocsSetIterators::Phrase) */
+#define TRI_TOK(op, arg) (((uint32_t)(op) << 28) | ((uint32_t)(arg)&0x0fffffffu))
+
+typedef struct tri_dev tri_dev;
+typedef struct tri_index tri_index;
+typedef struct tri_batch tri_batch;
+
+/* == Trinity::term_index_ctx {documents, indexChunk{offset,len}} (codecs.h:17-55) */
+typedef struct tri_term {
+        uint32_t documents;
+        uint32_t offset;
+        uint32_t size;
+} tri_term;
+
+/* one query = a slice of the shared postfix program */
+typedef struct tri_query {
+        uint32_t prog_off;
+        uint32_t prog_len;
+} tri_query;
+
+typedef struct tri_index_info {
+        uint64_t index_bytes;    /* raw `index` bytes resident in HBM                                  */
+        uint64_t directory_bytes; /* per-block directory built at upload                                */
+        uint64_t blocks;
+        uint64_t postings;       /* sum of documents over terms (field_statistics::sumTermsDocs)       */
+        uint64_t doc_bytes;      /* header + delta + freq bytes of every chunk            */
+        uint64_t hit_bytes;
+        uint32_t nterms;
+        uint32_t docs_cnt;
+} tri_index_info;
+
+typedef struct tri_batch_info {
+        uint64_t nqueries;
+        uint64_t algorithmic_bytes; /* sum_q [ sum_t docbytes(t) + out(q) ] of the LAST run */
+        uint64_t matches;           /* total matches of the last run                                    */
+        uint64_t out_capacity;      /* docID slots reserved for docsets                                 */
+        float last_run_ms;          /* HIP-event time of the last tri_batch_run (kernels only)          */
+        uint32_t launches;          /* kernel launches per run                                          */
+} tri_batch_info;
+
+const char *tri_last_error(void);
+int tri_abi_version(void);
+
+/* ---- device --------------------------------------------------------------------------------------- */
+int tri_dev_open(int device, tri_dev **out);
+void tri_dev_close(tri_dev *);
+int tri_dev_sync(tri_dev *);
+/* the engine's HIP stream (hipStream_t as void*), for callers that order their own work against it */
+void *tri_dev_stream(tri_dev *);
+
+/* ---- index upload ---------------------------------------------------------------------------------
+ * Replaces SegmentIndexSource's mmap of `index` (segment_index_source.cpp:84-93) + per-query
+ * Codecs::Google::Decoder::init (google_codec.cpp:936-983): copies the segment's raw codec bytes to HBM
+ * once and materialises a dense per-block directory {payload offset, last docID} (the analogue of the
+ * decoder materialising its skiplist) plus a device term table.  `terms[i]` is what
+ * IndexSource::resolve_term_ctx (index_source.h:103) returns for term i.
+ * `hits`/`hits_len` are the Lucene codec's hits.data (lucene_codec.h:206); NULL/0 for GOOGLE. */
+int tri_index_upload(tri_dev *, const uint8_t *index, size_t len, const uint8_t *hits, size_t hits_len, int codec,
+                     const tri_term *terms, size_t nterms, uint32_t docs_cnt, tri_index **out);
+void tri_index_destroy(tri_index *);
+int tri_index_get_info(const tri_index *, tri_index_info *);
+/* algorithmic doc bytes (SURVEY §8d docbytes(t)) of the given terms */
+int tri_index_term_docbytes(const tri_index *, const uint32_t *terms, size_t n, uint64_t *out);
+
+/* ---- postings decode (codec seam) -----------------------------------------------------------------
+ * Replaces Codecs::PostingsListIterator::next() driven to exhaustion (google_codec.cpp:777-819,
+ * unpack_block :596-639): decodes whole postings lists on the GPU.  out_offsets[n+1] receives the prefix
+ * offsets into docs/freqs (host buffers with room for sum(documents)). */
+int tri_decode_terms(tri_index *, const uint32_t *terms, size_t n, uint32_t *docs, uint32_t *freqs, uint64_t *out_offsets);
+
+/* ---- batched query execution (span seam) -----------------------------------------------------------
+ * Replaces, for a whole batch of queries at once: queryexec_ctx::build_iterator + build_span
+ * (exec.cpp:253-505), DocsSetSpan::process(mp, 1, DocIDsEND) (docset_spans.cpp:98-173, 269-290, 681-790)
+ * over Conjuction/Disjunction/Phrase iterators (docset_iterators.cpp:66-405), the IteratorScorer wrappers
+ * (docset_iterators_scorers.cpp) with Similarity BM25 (similarity.h:165-255), and the application's
+ * top-K MatchedIndexDocumentsFilter::consider(id, score) heap (matches.h:155-171).
+ *
+ * prog/queries: postfix programs.  flags: TRI_FLAG_DOCUMENTS_ONLY (results = ascending docID sets) or
+ * TRI_FLAG_ACCUMULATED_SCORE (results = top-K by score desc, docID asc + total match counts).
+ * weights: optional, one double per program token (TERM tokens: the term's ScorerWeight, PHRASE tokens:
+ * the phrase's); NULL => BM25 idf computed from the index's own statistics exactly as
+ * IndexSourcesCollectionBM25Scorer does for a single source (similarity.h:179-181, 202-226). */
+int tri_batch_create(tri_index *, const uint32_t *prog, size_t prog_len, const tri_query *queries, size_t nq,
+                     const double *weights, uint32_t flags, uint32_t topk, int similarity, tri_batch **out);
+void tri_batch_destroy(tri_batch *);
+/* enqueue the batch on the engine stream (asynchronous) */
+int tri_batch_run(tri_batch *);
+/* wait for completion; also refreshes tri_batch_info */
+int tri_batch_sync(tri_batch *);
+int tri_batch_get_info(const tri_batch *, tri_batch_info *);
+
+/* results (call after tri_batch_sync) */
+int tri_batch_match_counts(tri_batch *, uint64_t *counts /* [nq] */);
+/* DocumentsOnly: copy query q's ascending docID set; what MatchedIndexDocumentsFilter::consider(ids, cnt)
+ * (matches.h:161-165) receives */
+int tri_batch_docset(tri_batch *, size_t q, uint32_t *out, size_t cap, size_t *n);
+/* AccumulatedScore: docids/scores are [nq][topk] row-major, counts[nq] = min(matches, topk) */
+int tri_batch_topk(tri_batch *, uint32_t *docids, float *scores, uint32_t *counts);
+/* device-resident result blocks for the multi-GPU gather (per rank: [nq][topk] u32 + f32, [nq] u32) */
+int tri_batch_topk_device(tri_batch *, void **docids, void **scores, void **counts);
+/* FNV-1a(64) of every query's docID set computed from the device results (tests at full size) */
+int tri_batch_docset_hashes(tri_batch *, uint64_t *hashes /* [nq] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,179 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs, against the fixtures produced by the genuine reference, and — at sizes the
+oracle cannot cover quickly — through size-independent properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def T():
+    import trinity_amd
+
+    trinity_amd.build_all()
+    return trinity_amd
+
+
+@pytest.fixture(scope="module")
+def dev(T):
+    d = T.Device(0)
+    yield d
+    d.close()
+
+
+class World:
+    def __init__(self, T, dev, D, V, slots, seed):
+        self.T, self.D, self.V = T, D, V
+        self.seg = T.Segment(D, V, slots, seed)
+        self.ora = O.Index.wrap(self.seg.index, self.seg.terms, self.seg.docs_cnt, self.seg.sum_terms_docs, self.seg.sum_term_hits)
+        self.ix = T.Index.from_segment(dev, self.seg)
+
+    def df(self, t):
+        return int(self.seg.terms[t, 0]) if t < self.V else 0
+
+
+@pytest.fixture(scope="module")
+def small(T, dev):
+    return World(T, dev, 20000, 2000, 10, 42)
+
+
+@pytest.fixture(scope="module")
+def medium(T, dev):
+    return World(T, dev, 300000, 30000, 10, 42)
+
+
+@pytest.fixture(scope="module")
+def dense(T, dev):
+    return World(T, dev, 20000, 500, 12, 7)
+
+
+def run_docs_only(w, programs):
+    b = w.T.Batch(w.ix, programs, w.T.FLAG_DOCUMENTS_ONLY)
+    b.run()
+    b.sync()
+    counts = b.counts()
+    sets = [b.docset(i, int(counts[i])) for i in range(len(programs))]
+    hashes = b.docset_hashes()
+    info = b.info()
+    b.close()
+    return sets, hashes, info
+
+
+def and_prog(T, terms):
+    return np.array([T.tok(T.OP_TERM, t) for t in terms] + [T.tok(T.OP_AND, len(terms))], dtype=np.uint32)
+
+
+# ------------------------------------------------------------------------------------------ decode (K1)
+@pytest.mark.parametrize("world", ["small", "dense", "medium"])
+def test_decode_terms_bit_exact(request, world):
+    w = request.getfixturevalue(world)
+    terms = [0, 1, 2, 3, 5, 17, w.V // 3, w.V // 2, w.V - 1]
+    terms = [t for t in terms if w.df(t)]
+    docs, freqs, offs = w.ix.decode_terms(terms, [w.df(t) for t in terms])
+    for i, t in enumerate(terms):
+        d, f = w.ora.decode_term(t)
+        assert np.array_equal(docs[offs[i] : offs[i + 1]], d), t
+        assert np.array_equal(freqs[offs[i] : offs[i + 1]], f), t
+
+
+def test_directory_accounts_for_every_chunk_byte(small):
+    info = small.ix.info()
+    skip = sum(small.ora.chunk_stats(t)["skip"] for t in range(small.V))
+    assert info["doc_bytes"] + info["hit_bytes"] + skip == info["index_bytes"] == small.seg.index.size
+    assert info["postings"] == small.seg.sum_terms_docs
+    db = small.ix.term_docbytes(np.arange(8))
+    for t in range(8):
+        s = small.ora.chunk_stats(t)
+        assert db[t] == s["hdr"] + s["docfreq"]  # SURVEY §8(d) docbytes(t)
+
+
+# ------------------------------------------------------------------------------------------ AND (K3)
+@pytest.mark.parametrize("world,nq", [("small", 400), ("dense", 300), ("medium", 250)])
+def test_and2_matches_oracle(request, world, nq):
+    w = request.getfixturevalue(world)
+    T = w.T
+    qs = T.gen_queries(w.V, 1337, nq, 2).tolist() + [[0, 1], [1, 0], [0, 2], [0, w.V - 1], [1, w.V // 2], [3, 4]]
+    progs = [and_prog(T, q) for q in qs]
+    sets, hashes, info = run_docs_only(w, progs)
+    tot = 0
+    for q, got, h in zip(qs, sets, hashes):
+        want, _ = w.ora.exec(and_prog(T, q), O.FLAG_DOCUMENTS_ONLY)
+        assert np.array_equal(got, want), (q, len(got), len(want))
+        assert int(h) == O.fnv1a_docs(want)
+        tot += len(want)
+    assert info["matches"] == tot
+
+
+@pytest.mark.parametrize("k", [3, 5])
+def test_and_k_terms_matches_oracle(small, dense, k):
+    for w in (small, dense):
+        T = w.T
+        qs = T.gen_queries(w.V, 99, 150, k).tolist() + [list(range(k)), list(range(k))[::-1]]
+        sets, _, _ = run_docs_only(w, [and_prog(T, q) for q in qs])
+        for q, got in zip(qs, sets):
+            want, _ = w.ora.exec(and_prog(T, q), O.FLAG_DOCUMENTS_ONLY)
+            assert np.array_equal(got, want), q
+
+
+def test_and_edge_cases(small):
+    w, T = small, small.T
+    V = w.V
+    cases = [
+        [0, V + 7],  # unknown term: no documents (index_source.h:60-72) => empty
+        [0, 0],  # the same term twice
+        [5],  # single term == its postings list
+        [V - 1, V - 2],  # two rare terms
+    ]
+    progs = [and_prog(T, c) if len(c) > 1 else np.array([T.tok(T.OP_TERM, c[0])], dtype=np.uint32) for c in cases]
+    sets, _, _ = run_docs_only(w, progs)
+    assert len(sets[0]) == 0
+    assert np.array_equal(sets[1], w.ora.decode_term(0)[0])
+    assert np.array_equal(sets[2], w.ora.decode_term(5)[0])
+    want, _ = w.ora.exec(and_prog(T, cases[3]), O.FLAG_DOCUMENTS_ONLY)
+    assert np.array_equal(sets[3], want)
+
+
+def test_and_against_reference_fixtures(T, dev):
+    """DocumentsOnly conjunction records of tests/golden/ref_*.json (outputs of the genuine reference)."""
+    checked = 0
+    for name in ("tiny", "small", "dense"):
+        g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
+        c = g["corpus"]
+        w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
+        recs = [r for r in g["results"] if r["cmd"] in ("query", "queryfull") and r["flags"] == 1 and not any(ch in r["q"] for ch in '"()O')]
+        progs = [O.parse_query(r["q"]) for r in recs]
+        sets, hashes, _ = run_docs_only(w, progs)
+        for r, got, h in zip(recs, sets, hashes):
+            assert len(got) == r["n"], r["q"]
+            assert str(int(h)) == r["fnv"], r["q"]
+            k = min(16, len(got))
+            assert got[:k].tolist() == r["first"] and got[len(got) - k :].tolist() == r["last"]
+            checked += 1
+        w.ix.close()
+    assert checked >= 60
+
+
+def test_and_properties_at_scale(medium):
+    """Size-independent properties: A∩A = A; A∩B = B∩A (program order is irrelevant); |A∩B| <= min df; results
+    ascending and members of both lists."""
+    w, T = medium, medium.T
+    pairs = [[0, 1], [0, 3], [2, 1], [0, 50], [7, 9000]]
+    progs = [and_prog(T, p) for p in pairs] + [and_prog(T, p[::-1]) for p in pairs] + [and_prog(T, [0, 0])]
+    sets, _, _ = run_docs_only(w, progs)
+    n = len(pairs)
+    for i, p in enumerate(pairs):
+        a, b = sets[i], sets[n + i]
+        assert np.array_equal(a, b)
+        assert len(a) <= min(w.df(p[0]), w.df(p[1]))
+        assert np.all(a[1:] > a[:-1])
+        da = w.ora.decode_term(p[0])[0]
+        db = w.ora.decode_term(p[1])[0]
+        assert np.array_equal(a, np.intersect1d(da, db))
+    assert np.array_equal(sets[-1], w.ora.decode_term(0)[0])

@@ -1,0 +1,52 @@
+"""In-tree build of the native libraries (explicit hipcc / g++; no JIT cache, so the .so files travel with the
+repo snapshot to the GPU box)."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+LIB_HIP = os.path.join(PKG, "libtrinity_hip.so")
+LIB_HOST = os.path.join(PKG, "libtrinity_host.so")
+HIP_SRCS = [os.path.join(PKG, "csrc", "trinity_hip.hip")]
+HOST_SRCS = [os.path.join(PKG, "csrc", "host", "synth.cpp")]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _deps(srcs):
+    out = list(srcs) + [os.path.join(ROOT, "include", "trinity_hip.h")]
+    for s in srcs:
+        d = os.path.dirname(s)
+        out += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hpp", ".h", ".cuh"))]
+    return out
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build_hip(force=False):
+    if force or _newer(LIB_HIP, _deps(HIP_SRCS)):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_HIP] + HIP_SRCS
+        subprocess.run(cmd, check=True)
+    return LIB_HIP
+
+
+def build_host(force=False):
+    if force or _newer(LIB_HOST, _deps(HOST_SRCS)):
+        cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_HOST] + HOST_SRCS
+        subprocess.run(cmd, check=True)
+    return LIB_HOST
+
+
+def build_all(force=False):
+    return build_hip(force), build_host(force)

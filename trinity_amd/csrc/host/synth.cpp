@@ -1,0 +1,156 @@
+// synth.cpp — deterministic synthetic segment + query generator of SURVEY.md §8(d) / BASELINE.md §3, exported
+// with a C ABI for bench.py and the tests.  Host-only C++ (no HIP).  New code; independent of oracle/.
+//
+//   corpus : splitmix64(seed); documents 1..D; `slots` token slots per document at positions 1..slots; every
+//            slot draws a term rank r in [0,V) from Zipf(s=1) by inverse CDF (first i with cdf[i] >= x,
+//            x = (u >> 11) * 2^-53, cdf built by sequential double sums); term r is the r-th term of the table
+//   queries: splitmix64(seed); terms drawn from the same Zipf, distinct within a query
+#include "google_encoder.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <memory>
+
+using namespace trinity_amd;
+
+namespace {
+        inline uint64_t splitmix64(uint64_t &s) {
+                uint64_t z = (s += 0x9e3779b97f4a7c15ull);
+                z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+                z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+                return z ^ (z >> 31);
+        }
+
+        struct Zipf {
+                std::vector<double> cdf;
+                std::vector<uint32_t> guide; // guide[k] = lower_bound(cdf, k / G): narrows the search, never changes it
+                static constexpr uint32_t G = 1u << 16;
+                explicit Zipf(uint32_t V)
+                    : cdf(V), guide(G + 1) {
+                        double s = 0;
+                        for (uint32_t i = 0; i < V; ++i) {
+                                s += 1.0 / double(i + 1);
+                                cdf[i] = s;
+                        }
+                        for (auto &c : cdf)
+                                c /= s;
+                        for (uint32_t k = 0; k <= G; ++k) {
+                                const auto it = std::lower_bound(cdf.begin(), cdf.end(), double(k) / double(G));
+                                guide[k] = std::min<uint32_t>(uint32_t(it - cdf.begin()), V - 1);
+                        }
+                }
+                uint32_t rank(uint64_t u) const {
+                        const double x = double(u >> 11) * (1.0 / 9007199254740992.0);
+                        const uint32_t k = uint32_t(x * double(G));
+                        auto b = cdf.begin() + guide[k];
+                        auto e = cdf.begin() + std::min<size_t>(size_t(guide[k + 1]) + 1, cdf.size());
+                        while (b != cdf.begin() && *(b - 1) >= x)
+                                --b;
+                        const auto it = std::lower_bound(b, e, x);
+                        return std::min<uint32_t>(uint32_t(it - cdf.begin()), uint32_t(cdf.size() - 1));
+                }
+        };
+
+        struct Segment {
+                std::vector<uint8_t> index;
+                std::vector<term_index_ctx> terms;
+                uint64_t sumTermsDocs{0}, sumTermHits{0};
+                uint32_t totalTerms{0}, docsCnt{0};
+        };
+} // namespace
+
+extern "C" {
+// Build the synthetic GOOGLE-codec segment.  Returns an opaque handle (NULL on failure).
+void *tri_synth_segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed) {
+        try {
+                auto seg = std::make_unique<Segment>();
+                const uint64_t ntok = uint64_t(D) * slots;
+                Zipf z(V);
+                std::vector<uint32_t> ranks(ntok);
+                std::vector<uint64_t> off(size_t(V) + 1, 0);
+                uint64_t st = seed;
+                for (uint64_t i = 0; i < ntok; ++i) {
+                        const uint32_t r = z.rank(splitmix64(st));
+                        ranks[i] = r;
+                        ++off[r + 1];
+                }
+                for (uint32_t t = 0; t < V; ++t)
+                        off[t + 1] += off[t];
+                // counting sort of the (term, doc, pos) tokens by term; generation order keeps (doc, pos) ascending
+                std::vector<uint32_t> tdoc(ntok);
+                std::vector<uint16_t> tpos(ntok);
+                {
+                        std::vector<uint64_t> cur(off.begin(), off.end() - 1);
+                        uint64_t i = 0;
+                        for (uint32_t d = 1; d <= D; ++d)
+                                for (uint32_t p = 1; p <= slots; ++p, ++i) {
+                                        const uint64_t o = cur[ranks[i]]++;
+                                        tdoc[o] = d;
+                                        tpos[o] = uint16_t(p);
+                                }
+                }
+                std::vector<uint32_t>().swap(ranks);
+                Codecs::Google::IndexSession sess;
+                sess.indexOut.reserve(size_t(ntok) * 4);
+                Codecs::Google::Encoder enc(&sess);
+                seg->terms.resize(V);
+                for (uint32_t t = 0; t < V; ++t) {
+                        const uint64_t b = off[t], e = off[t + 1];
+                        if (b == e)
+                                continue;
+                        enc.begin_term();
+                        for (uint64_t i = b; i < e;) {
+                                const uint32_t d = tdoc[i];
+                                enc.begin_document(d);
+                                for (; i < e && tdoc[i] == d; ++i)
+                                        enc.new_hit(tpos[i]);
+                                enc.end_document();
+                        }
+                        enc.end_term(&seg->terms[t]);
+                        seg->sumTermsDocs += seg->terms[t].documents;
+                        ++seg->totalTerms;
+                }
+                if (sess.indexOut.size() > 0xffffffffull)
+                        return nullptr; // 32-bit chunk offsets (codecs.h:26)
+                seg->index.swap(sess.indexOut);
+                seg->sumTermHits = ntok;
+                seg->docsCnt = D;
+                return seg.release();
+        } catch (...) {
+                return nullptr;
+        }
+}
+
+void tri_synth_segment_free(void *h) { delete static_cast<Segment *>(h); }
+const uint8_t *tri_synth_segment_index(void *h, uint64_t *len) {
+        auto *s = static_cast<Segment *>(h);
+        *len = s->index.size();
+        return s->index.data();
+}
+// term table as {documents, offset, size} u32 triples == term_index_ctx
+const uint32_t *tri_synth_segment_terms(void *h, uint32_t *nterms) {
+        auto *s = static_cast<Segment *>(h);
+        static_assert(sizeof(term_index_ctx) == 12, "term_index_ctx layout");
+        *nterms = uint32_t(s->terms.size());
+        return reinterpret_cast<const uint32_t *>(s->terms.data());
+}
+void tri_synth_segment_stats(void *h, uint64_t *sumTermsDocs, uint64_t *sumTermHits, uint32_t *totalTerms, uint32_t *docsCnt) {
+        auto *s = static_cast<Segment *>(h);
+        *sumTermsDocs = s->sumTermsDocs;
+        *sumTermHits = s->sumTermHits;
+        *totalTerms = s->totalTerms;
+        *docsCnt = s->docsCnt;
+}
+// nq queries x nterms distinct Zipf-sampled term ranks
+void tri_synth_queries(uint32_t V, uint64_t seed, uint32_t nq, uint32_t nterms, uint32_t *out) {
+        Zipf z(V);
+        uint64_t st = seed;
+        for (uint32_t q = 0; q < nq; ++q) {
+                uint32_t *t = out + size_t(q) * nterms;
+                for (uint32_t i = 0; i < nterms;) {
+                        const uint32_t r = z.rank(splitmix64(st));
+                        if (std::find(t, t + i, r) == t + i)
+                                t[i++] = r;
+                }
+        }
+}
+}

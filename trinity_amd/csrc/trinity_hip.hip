@@ -1,0 +1,1007 @@
+// trinity_hip.hip — libtrinity_hip.so: MI355X (gfx950 / CDNA4) execution engine for Trinity's query hot
+// path.  Hand-written HIP; wave64; no MFMA (integer/byte work bounded by HBM + LDS + VALU issue).
+//
+// Data layout in HBM (built once at tri_index_upload):
+//   index[]        raw reference-format segment bytes (google_codec.cpp:9-176 layout), +64 B slack
+//   blk_last[]     u32 last docID of every block, all terms concatenated      (SoA: searched, 4 B/blk)
+//   blk_off[]      u32 byte offset of every block's payload (first delta byte) (SoA: touched on decode)
+//   terms[]        {documents, first_block, nblocks, last_n} per term
+// The reference discovers block boundaries by hopping headers serially (google_codec.cpp:641-697) and
+// keeps a sparse skiplist; a dense directory is the GPU analogue of Decoder::init (936-983).
+//
+// Kernels
+//   k_decode_terms   one lane per block: prefix-varint stream decode of deltas+freqs (unpack_block 596-639)
+//   k_and            persistent workgroups pull queries; per query the lead (lowest-df) list is decoded in
+//                    tiles of 256 blocks into an LDS candidate array; every other term filters the tile:
+//                    block-driven (dense) or candidate-driven galloping (sparse) over the block directory,
+//                    one lane per needed block, merging the decoded docs against the candidates in LDS
+//                    (Conjuction::next_impl leapfrog, docset_iterators.cpp:308-348, as a set operation)
+#include "../../include/trinity_hip.h"
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, ...) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(g_err, sizeof g_err, fmt, ap);
+        va_end(ap);
+        return code;
+}
+#define HIP_TRY(expr)                                                                                       \
+        do {                                                                                                \
+                hipError_t e_ = (expr);                                                                     \
+                if (e_ != hipSuccess)                                                                       \
+                        return fail(TRI_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+        } while (0)
+
+extern "C" const char *tri_last_error(void) { return g_err; }
+extern "C" int tri_abi_version(void) { return TRI_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------ structs
+struct DevTerm {
+        uint32_t documents;
+        uint32_t first_block;
+        uint32_t nblocks;
+        uint32_t last_n; // docs in the final block (1..32)
+};
+
+struct DevQuery {      // one conjunctive query (v1)
+        uint32_t nterms;    // >= 1, evaluation order = ascending df (exec.cpp:154-170)
+        uint32_t term_base; // into qterms[]
+        uint64_t out_off;   // docID slots
+        uint32_t out_cap;
+        uint32_t qid; // caller's query index
+};
+
+struct tri_dev {
+        int device;
+        hipStream_t stream;
+        hipEvent_t ev0, ev1;
+        int cus;
+};
+
+struct tri_index {
+        tri_dev *dev;
+        uint8_t *d_index = nullptr;
+        uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr;
+        DevTerm *d_terms = nullptr;
+        std::vector<DevTerm> terms;
+        std::vector<tri_term> tctx;
+        std::vector<uint64_t> docbytes, hitbytes;
+        tri_index_info info{};
+};
+
+struct tri_batch {
+        tri_index *ix;
+        uint32_t flags, topk;
+        size_t nq;
+        std::vector<DevQuery> plan; // execution order (cost descending)
+        std::vector<uint32_t> qterms;
+        std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: trivially empty)
+        DevQuery *d_plan = nullptr;
+        uint32_t *d_qterms = nullptr;
+        uint32_t *d_out = nullptr;
+        uint32_t *d_counts = nullptr; // per plan slot
+        uint32_t *d_ticket = nullptr;
+        uint64_t *d_hashes = nullptr;
+        uint64_t out_capacity = 0;
+        uint64_t term_bytes = 0; // sum of docbytes over all query terms
+        std::vector<uint32_t> h_counts;
+        bool synced = false;
+        tri_batch_info info{};
+};
+
+// ------------------------------------------------------------------------------------------ device: varint
+// Prefix varint of Switch/switch_compiler_aux.h:53-80, branch-free.  `w` holds the next >= 5 stream bytes,
+// least-significant byte first.
+__device__ __forceinline__ uint32_t vb_decode(uint64_t w, uint32_t &len) {
+        const uint32_t lo32 = (uint32_t)w;
+        const uint32_t b0 = lo32 & 0xffu;
+        const uint32_t ones = __clz(~(lo32 << 24)); // leading 1-bits of b0 (0..8)
+        const uint32_t n = ones < 4u ? ones : 4u;
+        const uint32_t be = __builtin_bswap32(lo32); // b0 b1 b2 b3
+        const uint32_t v1 = b0;
+        const uint32_t v2 = (be >> 16) & 0x3fffu;
+        const uint32_t v3 = ((b0 & 0x1fu) << 16) | ((lo32 >> 8) & 0xffffu);
+        const uint32_t v4 = be & 0x0fffffffu;
+        const uint32_t v5 = (uint32_t)(w >> 8);
+        len = n + 1;
+        uint32_t v = v1;
+        v = n == 1 ? v2 : v;
+        v = n == 2 ? v3 : v;
+        v = n == 3 ? v4 : v;
+        v = n == 4 ? v5 : v;
+        return v;
+}
+
+// Per-lane byte stream over global memory: a 16-byte register window refilled with aligned 8-byte loads,
+// the next qword always in flight (index[] carries >= 64 bytes of slack past the last chunk).
+struct VbStream {
+        const uint64_t *q;
+        uint64_t lo, hi, nxt;
+        int valid;
+
+        __device__ __forceinline__ void init(const uint8_t *p) {
+                const uintptr_t a = (uintptr_t)p;
+                const uint32_t sk = (uint32_t)(a & 7u);
+                q = (const uint64_t *)(a & ~(uintptr_t)7);
+                const uint64_t w0 = q[0], w1 = q[1];
+                nxt = q[2];
+                q += 3;
+                const uint32_t sh = sk * 8;
+                lo = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+                hi = sh ? (w1 >> sh) : w1;
+                valid = 16 - (int)sk;
+        }
+        __device__ __forceinline__ void refill() {
+                if (valid <= 8) {
+                        const uint64_t w = nxt;
+                        nxt = *q++;
+                        if (valid == 8)
+                                hi = w;
+                        else {
+                                const uint32_t sh = (uint32_t)valid * 8;
+                                lo |= sh ? (w << sh) : w;
+                                hi = sh ? (w >> (64 - sh)) : 0;
+                                if (!sh)
+                                        lo = w;
+                        }
+                        valid += 8;
+                }
+        }
+        __device__ __forceinline__ uint32_t next() {
+                refill();
+                uint32_t len;
+                const uint32_t v = vb_decode(lo, len);
+                const uint32_t s = len * 8;
+                lo = (lo >> s) | (hi << (64 - s));
+                hi >>= s;
+                valid -= (int)len;
+                return v;
+        }
+};
+
+// ------------------------------------------------------------------------------------------ k_decode_terms
+struct DecodeJob {
+        uint32_t term;
+        uint32_t pad;
+        uint64_t out_off;
+};
+
+// grid.x covers blocks of job blockIdx.y in chunks of 256; one lane per block (google_codec.cpp:596-639)
+__global__ __launch_bounds__(256) void k_decode_terms(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                      const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
+                                                      const DecodeJob *__restrict__ jobs, uint32_t *__restrict__ docs,
+                                                      uint32_t *__restrict__ freqs) {
+        const DecodeJob job = jobs[blockIdx.y];
+        const DevTerm t = terms[job.term];
+        for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < t.nblocks; b += gridDim.x * 256) {
+                const uint32_t gb = t.first_block + b;
+                const uint32_t off = blk_off[gb];
+                const uint32_t n = index[off - 1];
+                const uint32_t last = blk_last[gb];
+                uint32_t doc = b ? blk_last[gb - 1] : 0;
+                VbStream s;
+                s.init(index + off);
+                uint32_t *od = docs + job.out_off + (uint64_t)b * 32;
+                for (uint32_t i = 0; i + 1 < n; ++i) {
+                        doc += s.next();
+                        od[i] = doc;
+                }
+                od[n - 1] = last;
+                if (freqs) {
+                        uint32_t *of = freqs + job.out_off + (uint64_t)b * 32;
+                        for (uint32_t i = 0; i < n; ++i)
+                                of[i] = s.next();
+                }
+        }
+}
+
+// ------------------------------------------------------------------------------------------ k_and
+constexpr int AND_WG = 256;
+constexpr int TILE_BLOCKS = 256;
+constexpr int TILE_CANDS = TILE_BLOCKS * 32;
+
+// LDS candidate layout: logical slot j lives at phys(j); rotating each 32-slot row by its row number keeps
+// the one-lane-per-row writes of the lead decode (lane t writes row t, column i) off a single bank.
+__device__ __forceinline__ uint32_t phys(uint32_t j) { return (j & ~31u) | ((j + (j >> 5)) & 31u); }
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if ((int)(threadIdx.x & 63) >= d)
+                        x += y;
+        }
+        total = __shfl(x, 63, 64);
+        return x - v;
+}
+
+struct AndShared {
+        uint32_t cand[TILE_CANDS];
+        uint32_t hit[TILE_BLOCKS]; // bit k of hit[r] <=> logical candidate r*32+k matched
+        uint32_t scan[8];
+        uint32_t bcast[4];
+        uint32_t blkof[AND_WG + 1];
+        uint32_t lcur[8]; // per filter term: directory cursor (block-driven mode), uniform across the workgroup
+};
+
+// Filter the C candidates in sh.cand (logical order ascending) against term `t`: sets sh.hit bits.
+// Caller syncs before and after.
+__device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                const uint32_t *__restrict__ blk_off, const DevTerm t, const uint32_t C, const uint32_t lcur_slot,
+                                const bool block_driven) {
+        const uint32_t tid = threadIdx.x;
+        const uint32_t *bl = blk_last + t.first_block;
+        const uint32_t *bo = blk_off + t.first_block;
+        const uint32_t cmin = sh.cand[phys(0)], cmax = sh.cand[phys(C - 1)];
+
+        if (block_driven) {
+                // advance lcur to the first block whose last docID >= cmin (tiles arrive in ascending docID order)
+                uint32_t lcur = sh.lcur[lcur_slot];
+                for (;;) {
+                        const uint32_t b = lcur + tid;
+                        const bool below = b < t.nblocks && bl[b] < cmin;
+                        const uint64_t m = __ballot(below);
+                        // number of leading lanes (from lane 0) with below == true, per wave
+                        const uint32_t lead = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+                        if ((tid & 63) == 0)
+                                sh.scan[tid >> 6] = lead;
+                        __syncthreads();
+                        uint32_t adv = 0;
+                        for (int w = 0; w < AND_WG / 64; ++w) {
+                                adv += sh.scan[w];
+                                if (sh.scan[w] != 64)
+                                        break;
+                        }
+                        __syncthreads();
+                        lcur += adv;
+                        if (adv != AND_WG || lcur >= t.nblocks)
+                                break;
+                }
+                if (tid == 0)
+                        sh.lcur[lcur_slot] = lcur;
+                for (uint32_t cb = lcur; cb < t.nblocks; cb += AND_WG) {
+                        const uint32_t b = cb + tid;
+                        bool beyond = true;
+                        if (b < t.nblocks) {
+                                const uint32_t prev = b ? bl[b - 1] : 0; // docs of block b lie in (prev, last]
+                                const uint32_t last = bl[b];
+                                beyond = last >= cmax;
+                                if (prev < cmax) {
+                                        // first candidate > prev
+                                        uint32_t lo = 0, hi = C;
+                                        while (lo < hi) {
+                                                const uint32_t mid = (lo + hi) >> 1;
+                                                if (sh.cand[phys(mid)] <= prev)
+                                                        lo = mid + 1;
+                                                else
+                                                        hi = mid;
+                                        }
+                                        uint32_t ptr = lo;
+                                        uint32_t cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
+                                        if (cv <= last) {
+                                                const uint32_t off = bo[b];
+                                                const uint32_t n = index[off - 1];
+                                                VbStream s;
+                                                s.init(index + off);
+                                                uint32_t doc = prev;
+                                                for (uint32_t i = 0; i < n; ++i) {
+                                                        doc = (i + 1 < n) ? doc + s.next() : last;
+                                                        while (cv < doc) {
+                                                                ++ptr;
+                                                                cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
+                                                        }
+                                                        if (cv == doc)
+                                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
+                                                        if (cv > last)
+                                                                break;
+                                                }
+                                        }
+                                }
+                        }
+                        if (__syncthreads_or(beyond))
+                                break;
+                }
+        } else {
+                // candidate-driven galloping: each candidate finds its block in the directory; the first
+                // candidate of each run that maps to the same block decodes it and merges forward
+                if (tid == 0)
+                        sh.blkof[0] = 0xffffffffu;
+                __syncthreads();
+                for (uint32_t base = 0; base < C; base += AND_WG) {
+                        const uint32_t j = base + tid;
+                        uint32_t bj = 0xffffffffu;
+                        uint32_t cv = 0;
+                        if (j < C) {
+                                cv = sh.cand[phys(j)];
+                                uint32_t lo = 0, hi = t.nblocks; // first block with last >= cv
+                                while (lo < hi) {
+                                        const uint32_t mid = (lo + hi) >> 1;
+                                        if (bl[mid] < cv)
+                                                lo = mid + 1;
+                                        else
+                                                hi = mid;
+                                }
+                                bj = lo; // == nblocks: beyond the list
+                        }
+                        sh.blkof[tid + 1] = bj;
+                        __syncthreads();
+                        const uint32_t prevb = sh.blkof[tid];
+                        __syncthreads();
+                        if (tid == AND_WG - 1)
+                                sh.blkof[0] = bj;
+                        if (j < C && bj < t.nblocks && bj != prevb) {
+                                const uint32_t prev = bj ? bl[bj - 1] : 0;
+                                const uint32_t last = bl[bj];
+                                const uint32_t off = bo[bj];
+                                const uint32_t n = index[off - 1];
+                                VbStream s;
+                                s.init(index + off);
+                                uint32_t doc = prev;
+                                uint32_t ptr = j;
+                                for (uint32_t i = 0; i < n; ++i) {
+                                        doc = (i + 1 < n) ? doc + s.next() : last;
+                                        while (cv < doc) {
+                                                ++ptr;
+                                                cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
+                                        }
+                                        if (cv == doc)
+                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
+                                        if (cv > last)
+                                                break;
+                                }
+                        }
+                        __syncthreads();
+                }
+        }
+}
+
+__global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
+                                                const DevQuery *__restrict__ plan, const uint32_t *__restrict__ qterms,
+                                                const uint32_t nq, uint32_t *__restrict__ ticket, uint32_t *__restrict__ out,
+                                                uint32_t *__restrict__ counts) {
+        __shared__ AndShared sh;
+        const uint32_t tid = threadIdx.x;
+        for (;;) {
+                if (tid == 0)
+                        sh.bcast[0] = atomicAdd(ticket, 1u);
+                __syncthreads();
+                const uint32_t slot = sh.bcast[0];
+                __syncthreads();
+                if (slot >= nq)
+                        break;
+                const DevQuery q = plan[slot];
+                const DevTerm lead = terms[qterms[q.term_base]];
+                uint32_t *qout = out + q.out_off;
+                uint32_t produced = 0;
+                if (tid < 8)
+                        sh.lcur[tid] = 0;
+
+                for (uint32_t tb = 0; tb < lead.nblocks; tb += TILE_BLOCKS) {
+                        const uint32_t nb = min((uint32_t)TILE_BLOCKS, lead.nblocks - tb);
+                        uint32_t C = (tb + nb == lead.nblocks) ? (nb - 1) * 32 + lead.last_n : nb * 32;
+                        // ---- decode the lead tile: one lane per block (unpack_block, google_codec.cpp:596-639)
+                        if (tid < nb) {
+                                const uint32_t b = tb + tid, gb = lead.first_block + b;
+                                const uint32_t off = blk_off[gb];
+                                const uint32_t n = index[off - 1];
+                                const uint32_t last = blk_last[gb];
+                                uint32_t doc = b ? blk_last[gb - 1] : 0;
+                                VbStream s;
+                                s.init(index + off);
+                                const uint32_t row = tid * 32;
+                                for (uint32_t i = 0; i + 1 < n; ++i) {
+                                        doc += s.next();
+                                        sh.cand[row | ((i + tid) & 31u)] = doc;
+                                }
+                                sh.cand[row | ((n - 1 + tid) & 31u)] = last;
+                        }
+                        __syncthreads();
+
+                        // ---- every other term filters the surviving candidates
+                        for (uint32_t k = 1; k < q.nterms && C; ++k) {
+                                const DevTerm t = terms[qterms[q.term_base + k]];
+                                sh.hit[tid] = 0;
+                                __syncthreads();
+                                and_filter_tile(sh, index, blk_last, blk_off, t, C, k - 1, t.nblocks <= lead.documents);
+                                __syncthreads();
+                                // compact survivors (stable => still ascending)
+                                const uint32_t bits = sh.hit[tid];
+                                const uint32_t cnt = __popc(bits);
+                                uint32_t wtot;
+                                uint32_t ex = wave_excl_scan(cnt, wtot);
+                                if ((tid & 63) == 63)
+                                        sh.scan[tid >> 6] = wtot;
+                                __syncthreads();
+                                uint32_t wbase = 0, total = 0;
+                                for (int w = 0; w < AND_WG / 64; ++w) {
+                                        if (w < (int)(tid >> 6))
+                                                wbase += sh.scan[w];
+                                        total += sh.scan[w];
+                                }
+                                ex += wbase;
+                                if (k + 1 == q.nterms) {
+                                        // last conjunct: survivors go straight to the result, ascending
+                                        uint32_t m = bits, o = produced + ex;
+                                        while (m) {
+                                                const uint32_t kbit = __builtin_ctz(m);
+                                                m &= m - 1;
+                                                qout[o++] = sh.cand[phys(tid * 32 + kbit)];
+                                        }
+                                } else {
+                                        // in-place compaction: every lane lifts its row into registers first
+                                        uint32_t vals[32];
+#pragma unroll
+                                        for (int kk = 0; kk < 32; ++kk)
+                                                vals[kk] = sh.cand[(tid * 32) | ((kk + tid) & 31u)];
+                                        __syncthreads();
+                                        uint32_t o = ex;
+#pragma unroll
+                                        for (int kk = 0; kk < 32; ++kk)
+                                                if ((bits >> kk) & 1u) {
+                                                        sh.cand[phys(o)] = vals[kk];
+                                                        ++o;
+                                                }
+                                }
+                                C = total;
+                                __syncthreads();
+                        }
+                        if (q.nterms == 1) {
+                                for (uint32_t j = tid; j < C; j += AND_WG)
+                                        qout[produced + j] = sh.cand[phys(j)];
+                        }
+                        produced += C;
+                        __syncthreads();
+                }
+                if (tid == 0)
+                        counts[slot] = produced;
+        }
+}
+
+// FNV-1a(64) of each query's docID set (little-endian bytes), one lane per query — verification helper
+__global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const uint32_t *__restrict__ counts, const uint32_t nq,
+                               const uint32_t *__restrict__ out, uint64_t *__restrict__ hashes) {
+        const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+        if (s >= nq)
+                return;
+        const uint32_t *p = out + plan[s].out_off;
+        const uint32_t n = counts[s];
+        uint64_t h = 1469598103934665603ull;
+        for (uint32_t i = 0; i < n; ++i) {
+                uint32_t d = p[i];
+                for (int b = 0; b < 4; ++b) {
+                        h = (h ^ (d & 0xffu)) * 1099511628211ull;
+                        d >>= 8;
+                }
+        }
+        hashes[s] = h;
+}
+
+// ------------------------------------------------------------------------------------------ host: device
+extern "C" int tri_dev_open(int device, tri_dev **out) {
+        if (!out)
+                return fail(TRI_ERR_INVALID, "tri_dev_open: null out");
+        int n = 0;
+        HIP_TRY(hipGetDeviceCount(&n));
+        if (device < 0 || device >= n)
+                return fail(TRI_ERR_INVALID, "tri_dev_open: device %d out of range (%d devices)", device, n);
+        HIP_TRY(hipSetDevice(device));
+        auto d = std::make_unique<tri_dev>();
+        d->device = device;
+        HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&d->ev0));
+        HIP_TRY(hipEventCreate(&d->ev1));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        d->cus = prop.multiProcessorCount;
+        *out = d.release();
+        return TRI_OK;
+}
+
+extern "C" void tri_dev_close(tri_dev *d) {
+        if (!d)
+                return;
+        hipSetDevice(d->device);
+        hipEventDestroy(d->ev0);
+        hipEventDestroy(d->ev1);
+        hipStreamDestroy(d->stream);
+        delete d;
+}
+
+extern "C" int tri_dev_sync(tri_dev *d) {
+        if (!d)
+                return fail(TRI_ERR_INVALID, "null dev");
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        return TRI_OK;
+}
+
+extern "C" void *tri_dev_stream(tri_dev *d) { return d ? (void *)d->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------ host: upload
+namespace {
+        // host-side prefix varint (Switch/switch_compiler_aux.h:53-80) — used only by the upload-time walk
+        inline size_t h_vb_get(const uint8_t *ip, uint32_t &v) {
+                const uint32_t x = ip[0];
+                if (!(x & 0x80u)) {
+                        v = x;
+                        return 1;
+                } else if (!(x & 0x40u)) {
+                        v = ((x & 0x3fu) << 8) | ip[1];
+                        return 2;
+                } else if (!(x & 0x20u)) {
+                        v = ((x & 0x1fu) << 16) | ip[1] | ((uint32_t)ip[2] << 8);
+                        return 3;
+                } else if (!(x & 0x10u)) {
+                        v = ((x & 0x0fu) << 24) | ((uint32_t)ip[1] << 16) | ((uint32_t)ip[2] << 8) | ip[3];
+                        return 4;
+                }
+                v = ip[1] | ((uint32_t)ip[2] << 8) | ((uint32_t)ip[3] << 16) | ((uint32_t)ip[4] << 24);
+                return 5;
+        }
+        inline size_t h_vb_len(uint8_t b0) { return b0 < 0x80 ? 1 : b0 < 0xc0 ? 2 : b0 < 0xe0 ? 3 : b0 < 0xf0 ? 4 : 5; }
+
+        template <class T>
+        int dev_upload(T **dst, const std::vector<T> &src, size_t extra = 0) {
+                HIP_TRY(hipMalloc((void **)dst, (src.size() + extra) * sizeof(T) + 16));
+                if (!src.empty())
+                        HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+                return TRI_OK;
+        }
+} // namespace
+
+extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, const uint8_t *hits, size_t hits_len, int codec,
+                                const tri_term *terms, size_t nterms, uint32_t docs_cnt, tri_index **out) {
+        (void)hits;
+        (void)hits_len;
+        if (!dev || !out || (!index && len) || (!terms && nterms))
+                return fail(TRI_ERR_INVALID, "tri_index_upload: null argument");
+        if (codec != TRI_CODEC_GOOGLE)
+                return fail(TRI_ERR_UNSUPPORTED, "tri_index_upload: codec %d not supported yet", codec);
+        if (len > 0xffffffffull)
+                return fail(TRI_ERR_FORMAT, "index exceeds 32-bit chunk offsets (codecs.h:26)");
+        HIP_TRY(hipSetDevice(dev->device));
+        auto ix = std::make_unique<tri_index>();
+        ix->dev = dev;
+        ix->terms.resize(nterms);
+        ix->tctx.assign(terms, terms + nterms);
+        ix->docbytes.assign(nterms, 0);
+        ix->hitbytes.assign(nterms, 0);
+        std::vector<uint32_t> blk_last, blk_off;
+        blk_last.reserve(len / 96 + nterms);
+        blk_off.reserve(len / 96 + nterms);
+        uint64_t postings = 0, docb = 0, hitb = 0;
+        // One pass over every chunk: hop block headers (google_codec.cpp:641-697), validate, record the directory
+        // and the algorithmic byte split of SURVEY §8(d).
+        for (size_t ti = 0; ti < nterms; ++ti) {
+                const tri_term &t = terms[ti];
+                DevTerm &dt = ix->terms[ti];
+                dt.documents = t.documents;
+                dt.first_block = (uint32_t)blk_last.size();
+                dt.nblocks = 0;
+                dt.last_n = 0;
+                if (!t.size || !t.documents) {
+                        dt.documents = 0;
+                        continue;
+                }
+                if ((uint64_t)t.offset + t.size > len || t.size < 2)
+                        return fail(TRI_ERR_FORMAT, "term %zu: chunk [%u,+%u) outside index (%zu)", ti, t.offset, t.size, len);
+                const uint8_t *base = index + t.offset, *p = base + 2, *end = base + t.size;
+                uint16_t sk;
+                memcpy(&sk, base, 2);
+                if ((size_t)sk * 8 + 2 > t.size)
+                        return fail(TRI_ERR_FORMAT, "term %zu: skiplist larger than chunk", ti);
+                end -= (size_t)sk * 8;
+                uint64_t db = 2, hb = 0;
+                uint32_t lastDoc = 0, docs = 0;
+                while (p != end) {
+                        if (p + 3 > end)
+                                return fail(TRI_ERR_FORMAT, "term %zu: truncated block header", ti);
+                        const uint8_t *h = p;
+                        uint32_t delta, blockLength;
+                        p += h_vb_get(p, delta);
+                        p += h_vb_get(p, blockLength);
+                        const uint32_t n = *p++;
+                        if (n < 1 || n > 32 || !delta || (uint64_t)(end - p) < blockLength)
+                                return fail(TRI_ERR_FORMAT, "term %zu: bad block header (n=%u, delta=%u, len=%u)", ti, n, delta, blockLength);
+                        lastDoc += delta;
+                        const uint8_t *s = p;
+                        for (uint32_t i = 0; i < 2 * n - 1; ++i)
+                                s += h_vb_len(*s);
+                        if ((uint64_t)(s - p) > blockLength)
+                                return fail(TRI_ERR_FORMAT, "term %zu: deltas+freqs overrun the block", ti);
+                        db += (uint64_t)(s - h);
+                        hb += blockLength - (uint64_t)(s - p);
+                        blk_last.push_back(lastDoc);
+                        blk_off.push_back((uint32_t)(p - index));
+                        dt.nblocks++;
+                        dt.last_n = n;
+                        docs += n;
+                        p += blockLength;
+                }
+                if (docs != t.documents)
+                        return fail(TRI_ERR_FORMAT, "term %zu: %u documents in blocks, %u declared", ti, docs, t.documents);
+                ix->docbytes[ti] = db;
+                ix->hitbytes[ti] = hb;
+                postings += docs;
+                docb += db;
+                hitb += hb;
+        }
+        // device copies
+        HIP_TRY(hipMalloc((void **)&ix->d_index, len + 64));
+        HIP_TRY(hipMemset(ix->d_index, 0, len + 64));
+        if (len)
+                HIP_TRY(hipMemcpy(ix->d_index, index, len, hipMemcpyHostToDevice));
+        int rc;
+        if ((rc = dev_upload(&ix->d_blk_last, blk_last)) || (rc = dev_upload(&ix->d_blk_off, blk_off)) || (rc = dev_upload(&ix->d_terms, ix->terms)))
+                return rc;
+        ix->info.index_bytes = len;
+        ix->info.directory_bytes = blk_last.size() * 8 + nterms * sizeof(DevTerm);
+        ix->info.blocks = blk_last.size();
+        ix->info.postings = postings;
+        ix->info.doc_bytes = docb;
+        ix->info.hit_bytes = hitb;
+        ix->info.nterms = (uint32_t)nterms;
+        ix->info.docs_cnt = docs_cnt;
+        *out = ix.release();
+        return TRI_OK;
+}
+
+extern "C" void tri_index_destroy(tri_index *ix) {
+        if (!ix)
+                return;
+        hipSetDevice(ix->dev->device);
+        hipFree(ix->d_index);
+        hipFree(ix->d_blk_last);
+        hipFree(ix->d_blk_off);
+        hipFree(ix->d_terms);
+        delete ix;
+}
+
+extern "C" int tri_index_get_info(const tri_index *ix, tri_index_info *info) {
+        if (!ix || !info)
+                return fail(TRI_ERR_INVALID, "null argument");
+        *info = ix->info;
+        return TRI_OK;
+}
+
+extern "C" int tri_index_term_docbytes(const tri_index *ix, const uint32_t *terms, size_t n, uint64_t *out) {
+        if (!ix || (!terms && n) || (!out && n))
+                return fail(TRI_ERR_INVALID, "null argument");
+        for (size_t i = 0; i < n; ++i)
+                out[i] = terms[i] < ix->docbytes.size() ? ix->docbytes[terms[i]] : 0;
+        return TRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ host: decode
+extern "C" int tri_decode_terms(tri_index *ix, const uint32_t *terms, size_t n, uint32_t *docs, uint32_t *freqs, uint64_t *out_offsets) {
+        if (!ix || (!terms && n) || !out_offsets)
+                return fail(TRI_ERR_INVALID, "null argument");
+        tri_dev *dev = ix->dev;
+        HIP_TRY(hipSetDevice(dev->device));
+        std::vector<DecodeJob> jobs(n);
+        uint64_t tot = 0, padded = 0;
+        uint32_t maxblocks = 0;
+        for (size_t i = 0; i < n; ++i) {
+                if (terms[i] >= ix->terms.size())
+                        return fail(TRI_ERR_INVALID, "term %u out of range", terms[i]);
+                const DevTerm &t = ix->terms[terms[i]];
+                jobs[i] = {terms[i], 0, padded};
+                out_offsets[i] = tot;
+                tot += t.documents;
+                padded += (uint64_t)t.nblocks * 32;
+                maxblocks = std::max(maxblocks, t.nblocks);
+        }
+        out_offsets[n] = tot;
+        if (!tot || !docs)
+                return TRI_OK;
+        DecodeJob *d_jobs = nullptr;
+        uint32_t *d_docs = nullptr, *d_freqs = nullptr;
+        HIP_TRY(hipMalloc((void **)&d_jobs, n * sizeof(DecodeJob)));
+        HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), n * sizeof(DecodeJob), hipMemcpyHostToDevice, dev->stream));
+        HIP_TRY(hipMalloc((void **)&d_docs, padded * 4));
+        if (freqs)
+                HIP_TRY(hipMalloc((void **)&d_freqs, padded * 4));
+        dim3 grid(std::min<uint32_t>((maxblocks + 255) / 256, 4096), (uint32_t)n);
+        hipLaunchKernelGGL(k_decode_terms, grid, dim3(256), 0, dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_terms, d_jobs, d_docs,
+                           d_freqs);
+        HIP_TRY(hipGetLastError());
+        // blocks are full (32) except the last one of each term: the padded layout is dense per term
+        for (size_t i = 0; i < n; ++i) {
+                const DevTerm &t = ix->terms[terms[i]];
+                if (!t.documents)
+                        continue;
+                HIP_TRY(hipMemcpyAsync(docs + out_offsets[i], d_docs + jobs[i].out_off, (size_t)t.documents * 4, hipMemcpyDeviceToHost, dev->stream));
+                if (freqs)
+                        HIP_TRY(hipMemcpyAsync(freqs + out_offsets[i], d_freqs + jobs[i].out_off, (size_t)t.documents * 4, hipMemcpyDeviceToHost, dev->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(dev->stream));
+        hipFree(d_jobs);
+        hipFree(d_docs);
+        hipFree(d_freqs);
+        return TRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ host: planner
+namespace {
+        struct PNode {
+                uint32_t op, term;
+                std::vector<int> kids;
+                uint64_t cost = 0;
+                bool empty = false;
+        };
+
+        // Parse one postfix program into a tree with the reference's flattening (exec.cpp:339-358, 382-393),
+        // emptiness propagation and cost model (exec.cpp:35-110).  Returns root index or -1.
+        int parse_program(const tri_index *ix, const uint32_t *prog, uint32_t len, std::vector<PNode> &nodes) {
+                std::vector<int> st;
+                for (uint32_t i = 0; i < len; ++i) {
+                        const uint32_t op = prog[i] >> 28, arg = prog[i] & 0x0fffffffu;
+                        PNode n;
+                        n.op = op;
+                        if (op == TRI_OP_TERM) {
+                                n.term = arg;
+                                n.cost = arg < ix->terms.size() ? ix->terms[arg].documents : 0;
+                                n.empty = n.cost == 0; // unknown term == no documents (index_source.h:60-72)
+                        } else {
+                                if (arg < 1 || arg > st.size())
+                                        return -1;
+                                std::vector<int> kids(st.end() - arg, st.end());
+                                st.resize(st.size() - arg);
+                                if (op == TRI_OP_PHRASE) {
+                                        if (arg > 16) // trinity_limits.h:12 MaxPhraseSize
+                                                return -1;
+                                        for (int k : kids) {
+                                                if (nodes[k].op != TRI_OP_TERM)
+                                                        return -1;
+                                                n.empty |= nodes[k].empty;
+                                        }
+                                        n.kids = kids;
+                                        n.cost = nodes[kids[0]].cost + UINT32_MAX + (uint64_t)UINT16_MAX * arg;
+                                } else if (op == TRI_OP_AND) {
+                                        for (int k : kids) {
+                                                n.empty |= nodes[k].empty;
+                                                if (nodes[k].op == TRI_OP_AND)
+                                                        n.kids.insert(n.kids.end(), nodes[k].kids.begin(), nodes[k].kids.end());
+                                                else
+                                                        n.kids.push_back(k);
+                                        }
+                                        std::stable_sort(n.kids.begin(), n.kids.end(), [&](int a, int b) { return nodes[a].cost < nodes[b].cost; });
+                                        n.cost = nodes[n.kids[0]].cost;
+                                } else if (op == TRI_OP_OR) {
+                                        for (int k : kids) {
+                                                if (nodes[k].empty)
+                                                        continue;
+                                                if (nodes[k].op == TRI_OP_OR)
+                                                        n.kids.insert(n.kids.end(), nodes[k].kids.begin(), nodes[k].kids.end());
+                                                else
+                                                        n.kids.push_back(k);
+                                        }
+                                        n.empty = n.kids.empty();
+                                        for (int k : n.kids)
+                                                n.cost += nodes[k].cost;
+                                } else
+                                        return -1;
+                        }
+                        nodes.push_back(std::move(n));
+                        st.push_back((int)nodes.size() - 1);
+                }
+                return st.size() == 1 ? st[0] : -1;
+        }
+} // namespace
+
+extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog_len, const tri_query *queries, size_t nq, const double *weights,
+                                uint32_t flags, uint32_t topk, int similarity, tri_batch **out) {
+        (void)weights;
+        (void)similarity;
+        if (!ix || !out || (!prog && prog_len) || (!queries && nq))
+                return fail(TRI_ERR_INVALID, "tri_batch_create: null argument");
+        const uint32_t mode = flags & (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE);
+        if (mode == 0 || mode == (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE))
+                return fail(TRI_ERR_INVALID, "DocumentsOnly and AccumulatedScoreScheme are mutually exclusive; the default rich mode is not lowered (exec.h:45-48)");
+        if (mode != TRI_FLAG_DOCUMENTS_ONLY)
+                return fail(TRI_ERR_UNSUPPORTED, "AccumulatedScoreScheme not lowered yet");
+        tri_dev *dev = ix->dev;
+        HIP_TRY(hipSetDevice(dev->device));
+        auto b = std::make_unique<tri_batch>();
+        b->ix = ix;
+        b->flags = flags;
+        b->topk = topk;
+        b->nq = nq;
+        b->slot_of_query.assign(nq, UINT32_MAX);
+        struct Tmp {
+                DevQuery q;
+                uint64_t cost;
+        };
+        std::vector<Tmp> tmp;
+        std::vector<PNode> nodes;
+        for (size_t qi = 0; qi < nq; ++qi) {
+                const tri_query &tq = queries[qi];
+                if ((uint64_t)tq.prog_off + tq.prog_len > prog_len || !tq.prog_len)
+                        return fail(TRI_ERR_INVALID, "query %zu: program slice out of range", qi);
+                nodes.clear();
+                const int root = parse_program(ix, prog + tq.prog_off, tq.prog_len, nodes);
+                if (root < 0)
+                        return fail(TRI_ERR_INVALID, "query %zu: malformed postfix program", qi);
+                const PNode &r = nodes[root];
+                if (r.empty)
+                        continue; // matches nothing (compiles to constfalse in the reference)
+                std::vector<uint32_t> ts;
+                if (r.op == TRI_OP_TERM)
+                        ts.push_back(r.term);
+                else if (r.op == TRI_OP_AND) {
+                        for (int k : r.kids) {
+                                if (nodes[k].op != TRI_OP_TERM)
+                                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: only conjunctions of terms are lowered so far", qi);
+                                ts.push_back(nodes[k].term);
+                        }
+                } else
+                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: only conjunctions of terms are lowered so far", qi);
+                // a term repeated inside a conjunction adds nothing to a docs-only result
+                std::vector<uint32_t> uniq;
+                for (uint32_t t : ts)
+                        if (std::find(uniq.begin(), uniq.end(), t) == uniq.end())
+                                uniq.push_back(t);
+                if (uniq.size() > 8)
+                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: more than 8 conjuncts", qi);
+                Tmp t;
+                t.q.nterms = (uint32_t)uniq.size();
+                t.q.term_base = (uint32_t)b->qterms.size();
+                t.q.out_cap = ix->terms[uniq[0]].documents; // |A ∩ …| <= min df
+                t.q.out_off = 0;
+                t.q.qid = (uint32_t)qi;
+                t.cost = 0;
+                for (uint32_t term : uniq) {
+                        b->qterms.push_back(term);
+                        b->term_bytes += ix->docbytes[term];
+                        // cost estimate: the lead is decoded fully; every other list costs min(its blocks, lead docs)
+                        t.cost += term == uniq[0] ? ix->terms[term].documents : 32ull * std::min<uint64_t>(ix->terms[term].nblocks, ix->terms[uniq[0]].documents);
+                }
+                tmp.push_back(t);
+        }
+        std::stable_sort(tmp.begin(), tmp.end(), [](const Tmp &a, const Tmp &c) { return a.cost > c.cost; });
+        uint64_t off = 0;
+        b->plan.reserve(tmp.size());
+        for (auto &t : tmp) {
+                t.q.out_off = off;
+                off += t.q.out_cap;
+                b->slot_of_query[t.q.qid] = (uint32_t)b->plan.size();
+                b->plan.push_back(t.q);
+        }
+        b->out_capacity = off;
+        int rc;
+        if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)))
+                return rc;
+        HIP_TRY(hipMalloc((void **)&b->d_out, (off + 64) * 4));
+        HIP_TRY(hipMalloc((void **)&b->d_counts, (b->plan.size() + 1) * 4));
+        HIP_TRY(hipMalloc((void **)&b->d_ticket, 64));
+        b->info.nqueries = nq;
+        b->info.out_capacity = off;
+        b->info.launches = 1;
+        *out = b.release();
+        return TRI_OK;
+}
+
+extern "C" void tri_batch_destroy(tri_batch *b) {
+        if (!b)
+                return;
+        hipSetDevice(b->ix->dev->device);
+        hipFree(b->d_plan);
+        hipFree(b->d_qterms);
+        hipFree(b->d_out);
+        hipFree(b->d_counts);
+        hipFree(b->d_ticket);
+        hipFree(b->d_hashes);
+        delete b;
+}
+
+extern "C" int tri_batch_run(tri_batch *b) {
+        if (!b)
+                return fail(TRI_ERR_INVALID, "null batch");
+        tri_dev *dev = b->ix->dev;
+        HIP_TRY(hipSetDevice(dev->device));
+        b->synced = false;
+        const uint32_t n = (uint32_t)b->plan.size();
+        HIP_TRY(hipEventRecord(dev->ev0, dev->stream));
+        if (n) {
+                HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 4, dev->stream));
+                const uint32_t grid = std::min<uint32_t>(n, (uint32_t)dev->cus * 4);
+                hipLaunchKernelGGL(k_and, dim3(grid), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms,
+                                   b->d_plan, b->d_qterms, n, b->d_ticket, b->d_out, b->d_counts);
+                HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(dev->ev1, dev->stream));
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_sync(tri_batch *b) {
+        if (!b)
+                return fail(TRI_ERR_INVALID, "null batch");
+        tri_dev *dev = b->ix->dev;
+        HIP_TRY(hipSetDevice(dev->device));
+        HIP_TRY(hipStreamSynchronize(dev->stream));
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, dev->ev0, dev->ev1) == hipSuccess)
+                b->info.last_run_ms = ms;
+        b->h_counts.resize(b->plan.size());
+        if (!b->plan.empty())
+                HIP_TRY(hipMemcpy(b->h_counts.data(), b->d_counts, b->plan.size() * 4, hipMemcpyDeviceToHost));
+        uint64_t m = 0;
+        for (uint32_t c : b->h_counts)
+                m += c;
+        b->info.matches = m;
+        b->info.algorithmic_bytes = b->term_bytes + 4 * m; // docbytes + 4 B per match (docs-only)
+        b->synced = true;
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_get_info(const tri_batch *b, tri_batch_info *info) {
+        if (!b || !info)
+                return fail(TRI_ERR_INVALID, "null argument");
+        *info = b->info;
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_match_counts(tri_batch *b, uint64_t *counts) {
+        if (!b || !counts)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (!b->synced)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync first");
+        for (size_t q = 0; q < b->nq; ++q)
+                counts[q] = b->slot_of_query[q] == UINT32_MAX ? 0 : b->h_counts[b->slot_of_query[q]];
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_docset(tri_batch *b, size_t q, uint32_t *out, size_t cap, size_t *n) {
+        if (!b || !n || q >= b->nq)
+                return fail(TRI_ERR_INVALID, "bad argument");
+        if (!b->synced)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync first");
+        const uint32_t slot = b->slot_of_query[q];
+        *n = slot == UINT32_MAX ? 0 : b->h_counts[slot];
+        if (!*n || !out)
+                return TRI_OK;
+        if (cap < *n)
+                return fail(TRI_ERR_INVALID, "docset needs %zu slots, %zu given", *n, cap);
+        HIP_TRY(hipSetDevice(b->ix->dev->device));
+        HIP_TRY(hipMemcpy(out, b->d_out + b->plan[slot].out_off, *n * 4, hipMemcpyDeviceToHost));
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_docset_hashes(tri_batch *b, uint64_t *hashes) {
+        if (!b || !hashes)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (!b->synced)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync first");
+        tri_dev *dev = b->ix->dev;
+        HIP_TRY(hipSetDevice(dev->device));
+        const uint32_t n = (uint32_t)b->plan.size();
+        std::vector<uint64_t> h(n);
+        if (n) {
+                if (!b->d_hashes)
+                        HIP_TRY(hipMalloc((void **)&b->d_hashes, (size_t)n * 8));
+                hipLaunchKernelGGL(k_hash_docsets, dim3((n + 63) / 64), dim3(64), 0, dev->stream, b->d_plan, b->d_counts, n, b->d_out, b->d_hashes);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(dev->stream));
+                HIP_TRY(hipMemcpy(h.data(), b->d_hashes, (size_t)n * 8, hipMemcpyDeviceToHost));
+        }
+        for (size_t q = 0; q < b->nq; ++q)
+                hashes[q] = b->slot_of_query[q] == UINT32_MAX ? 1469598103934665603ull : h[b->slot_of_query[q]];
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_topk(tri_batch *, uint32_t *, float *, uint32_t *) { return fail(TRI_ERR_UNSUPPORTED, "AccumulatedScoreScheme not lowered yet"); }
+extern "C" int tri_batch_topk_device(tri_batch *, void **, void **, void **) { return fail(TRI_ERR_UNSUPPORTED, "AccumulatedScoreScheme not lowered yet"); }

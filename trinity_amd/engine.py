@@ -1,0 +1,283 @@
+"""ctypes harness over the C-ABI (include/trinity_hip.h) and the host tools (csrc/host/synth.cpp).
+
+No fallbacks: a missing libtrinity_hip.so, a missing GPU or a failing call raises TrinityError."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB_HIP, LIB_HOST
+
+OP_TERM, OP_AND, OP_OR, OP_PHRASE = 0, 1, 2, 3
+FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE = 1, 2
+CODEC_GOOGLE, CODEC_LUCENE = 1, 2
+FNV_EMPTY = 1469598103934665603
+
+
+class TrinityError(RuntimeError):
+    pass
+
+
+def tok(op, arg):
+    return (op << 28) | (arg & 0x0FFFFFFF)
+
+
+class TriTerm(C.Structure):
+    _fields_ = [("documents", C.c_uint32), ("offset", C.c_uint32), ("size", C.c_uint32)]
+
+
+class TriQuery(C.Structure):
+    _fields_ = [("prog_off", C.c_uint32), ("prog_len", C.c_uint32)]
+
+
+class TriIndexInfo(C.Structure):
+    _fields_ = [
+        ("index_bytes", C.c_uint64),
+        ("directory_bytes", C.c_uint64),
+        ("blocks", C.c_uint64),
+        ("postings", C.c_uint64),
+        ("doc_bytes", C.c_uint64),
+        ("hit_bytes", C.c_uint64),
+        ("nterms", C.c_uint32),
+        ("docs_cnt", C.c_uint32),
+    ]
+
+
+class TriBatchInfo(C.Structure):
+    _fields_ = [
+        ("nqueries", C.c_uint64),
+        ("algorithmic_bytes", C.c_uint64),
+        ("matches", C.c_uint64),
+        ("out_capacity", C.c_uint64),
+        ("last_run_ms", C.c_float),
+        ("launches", C.c_uint32),
+    ]
+
+
+# every symbol include/trinity_hip.h declares (tests/test_abi.py checks the library exports all of them)
+ABI_SYMBOLS = [
+    "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream",
+    "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_decode_terms",
+    "tri_batch_create", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
+    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_docset_hashes",
+]  # fmt: skip
+
+_hip = None
+_host = None
+
+
+def hip_lib():
+    """Load libtrinity_hip.so; raises (never falls back) when it is missing."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    if not os.path.exists(LIB_HIP):
+        raise TrinityError(f"{LIB_HIP} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` — there is no CPU fallback")
+    L = C.CDLL(LIB_HIP)
+    vp, u32p, u64p = C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.tri_last_error.restype = C.c_char_p
+    L.tri_abi_version.restype = C.c_int
+    L.tri_dev_open.argtypes = [C.c_int, C.POINTER(vp)]
+    L.tri_dev_close.argtypes = [vp]
+    L.tri_dev_sync.argtypes = [vp]
+    L.tri_dev_stream.restype = vp
+    L.tri_dev_stream.argtypes = [vp]
+    L.tri_index_upload.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_uint32, C.POINTER(vp)]
+    L.tri_index_destroy.argtypes = [vp]
+    L.tri_index_get_info.argtypes = [vp, C.POINTER(TriIndexInfo)]
+    L.tri_index_term_docbytes.argtypes = [vp, vp, C.c_size_t, vp]
+    L.tri_decode_terms.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
+    L.tri_batch_create.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
+    L.tri_batch_destroy.argtypes = [vp]
+    L.tri_batch_run.argtypes = [vp]
+    L.tri_batch_sync.argtypes = [vp]
+    L.tri_batch_get_info.argtypes = [vp, C.POINTER(TriBatchInfo)]
+    L.tri_batch_match_counts.argtypes = [vp, vp]
+    L.tri_batch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.tri_batch_topk.argtypes = [vp, vp, vp, vp]
+    L.tri_batch_topk_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.tri_batch_docset_hashes.argtypes = [vp, vp]
+    _hip = L
+    return L
+
+
+def host_lib():
+    global _host
+    if _host is not None:
+        return _host
+    if not os.path.exists(LIB_HOST):
+        raise TrinityError(f"{LIB_HOST} is missing: run __graft_entry__.build()")
+    L = C.CDLL(LIB_HOST)
+    L.tri_synth_segment_build.restype = C.c_void_p
+    L.tri_synth_segment_build.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.tri_synth_segment_free.argtypes = [C.c_void_p]
+    L.tri_synth_segment_index.restype = C.POINTER(C.c_uint8)
+    L.tri_synth_segment_index.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.tri_synth_segment_terms.restype = C.POINTER(C.c_uint32)
+    L.tri_synth_segment_terms.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.tri_synth_segment_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.tri_synth_queries.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    _host = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise TrinityError(f"rc={rc}: {hip_lib().tri_last_error().decode()}")
+
+
+def gen_queries(V, seed, nq, nterms):
+    out = np.zeros((nq, nterms), dtype=np.uint32)
+    host_lib().tri_synth_queries(V, seed, nq, nterms, out.ctypes.data)
+    return out
+
+
+class Segment:
+    """A synthetic GOOGLE-codec segment built on the host (csrc/host/synth.cpp): raw `index` bytes + term table."""
+
+    def __init__(self, D, V, slots=10, seed=42):
+        L = host_lib()
+        self.D, self.V, self.slots, self.seed = D, V, slots, seed
+        self.h = L.tri_synth_segment_build(D, V, slots, seed)
+        if not self.h:
+            raise TrinityError("segment build failed (index larger than 4 GiB?)")
+        n = C.c_uint64()
+        p = L.tri_synth_segment_index(self.h, C.byref(n))
+        self.index = np.ctypeslib.as_array(p, shape=(n.value,))
+        nt = C.c_uint32()
+        tp = L.tri_synth_segment_terms(self.h, C.byref(nt))
+        self.terms = np.ctypeslib.as_array(tp, shape=(nt.value, 3))
+        a, b, c, d = C.c_uint64(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        L.tri_synth_segment_stats(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        self.sum_terms_docs, self.sum_term_hits, self.total_terms, self.docs_cnt = a.value, b.value, c.value, d.value
+
+    def __del__(self):
+        try:
+            if self.h:
+                host_lib().tri_synth_segment_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Device:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        _check(hip_lib().tri_dev_open(device, C.byref(self.h)))
+
+    def sync(self):
+        _check(hip_lib().tri_dev_sync(self.h))
+
+    def close(self):
+        if self.h:
+            hip_lib().tri_dev_close(self.h)
+            self.h = C.c_void_p()
+
+
+class Index:
+    def __init__(self, dev, index_bytes, terms, docs_cnt, codec=CODEC_GOOGLE):
+        self.dev = dev
+        b = np.ascontiguousarray(index_bytes, dtype=np.uint8)
+        t = np.ascontiguousarray(terms, dtype=np.uint32).reshape(-1, 3)
+        self.nterms = t.shape[0]
+        self.h = C.c_void_p()
+        _check(hip_lib().tri_index_upload(dev.h, b.ctypes.data, b.size, None, 0, codec, t.ctypes.data, t.shape[0], docs_cnt, C.byref(self.h)))
+
+    @classmethod
+    def from_segment(cls, dev, seg):
+        return cls(dev, seg.index, seg.terms, seg.docs_cnt)
+
+    def info(self):
+        i = TriIndexInfo()
+        _check(hip_lib().tri_index_get_info(self.h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in TriIndexInfo._fields_}
+
+    def term_docbytes(self, terms):
+        t = np.ascontiguousarray(terms, dtype=np.uint32)
+        out = np.zeros(t.size, dtype=np.uint64)
+        _check(hip_lib().tri_index_term_docbytes(self.h, t.ctypes.data, t.size, out.ctypes.data))
+        return out
+
+    def decode_terms(self, terms, df, want_freqs=True):
+        """GPU decode of whole postings lists; df = documents per requested term (sizes the host buffers)."""
+        t = np.ascontiguousarray(terms, dtype=np.uint32)
+        tot = int(np.sum(df))
+        docs = np.zeros(tot, dtype=np.uint32)
+        freqs = np.zeros(tot, dtype=np.uint32) if want_freqs else None
+        offs = np.zeros(t.size + 1, dtype=np.uint64)
+        _check(hip_lib().tri_decode_terms(self.h, t.ctypes.data, t.size, docs.ctypes.data, freqs.ctypes.data if want_freqs else None, offs.ctypes.data))
+        assert int(offs[-1]) == tot, (int(offs[-1]), tot)
+        return docs, freqs, offs
+
+    def close(self):
+        if self.h:
+            hip_lib().tri_index_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Batch:
+    """A compiled batch of postfix query programs."""
+
+    def __init__(self, index, programs, flags, topk=0, similarity=0):
+        self.index = index
+        progs = [np.ascontiguousarray(p, dtype=np.uint32) for p in programs]
+        self.nq = len(progs)
+        flat = np.concatenate(progs) if progs else np.zeros(0, np.uint32)
+        q = (TriQuery * max(1, self.nq))()
+        off = 0
+        for i, p in enumerate(progs):
+            q[i].prog_off, q[i].prog_len = off, p.size
+            off += p.size
+        self.flags, self.topk = flags, topk
+        self.h = C.c_void_p()
+        _check(hip_lib().tri_batch_create(index.h, flat.ctypes.data, flat.size, q, self.nq, None, flags, topk, similarity, C.byref(self.h)))
+
+    @classmethod
+    def conjunctions(cls, index, term_rows, flags=FLAG_DOCUMENTS_ONLY, topk=0):
+        rows = np.asarray(term_rows, dtype=np.uint32)
+        k = rows.shape[1]
+        progs = np.empty((rows.shape[0], k + 1), dtype=np.uint32)
+        progs[:, :k] = rows  # TERM tokens: op 0 => the raw term id
+        progs[:, k] = tok(OP_AND, k)
+        return cls(index, list(progs), flags, topk)
+
+    def run(self):
+        _check(hip_lib().tri_batch_run(self.h))
+
+    def sync(self):
+        _check(hip_lib().tri_batch_sync(self.h))
+
+    def info(self):
+        i = TriBatchInfo()
+        _check(hip_lib().tri_batch_get_info(self.h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in TriBatchInfo._fields_}
+
+    def counts(self):
+        out = np.zeros(self.nq, dtype=np.uint64)
+        _check(hip_lib().tri_batch_match_counts(self.h, out.ctypes.data))
+        return out
+
+    def docset(self, q, n=None):
+        if n is None:
+            n = int(self.counts()[q])
+        out = np.zeros(n, dtype=np.uint32)
+        got = C.c_size_t()
+        _check(hip_lib().tri_batch_docset(self.h, q, out.ctypes.data, n, C.byref(got)))
+        return out[: got.value]
+
+    def docset_hashes(self):
+        out = np.zeros(self.nq, dtype=np.uint64)
+        _check(hip_lib().tri_batch_docset_hashes(self.h, out.ctypes.data))
+        return out
+
+    def topk_results(self):
+        d = np.zeros((self.nq, self.topk), dtype=np.uint32)
+        s = np.zeros((self.nq, self.topk), dtype=np.float32)
+        c = np.zeros(self.nq, dtype=np.uint32)
+        _check(hip_lib().tri_batch_topk(self.h, d.ctypes.data, s.ctypes.data, c.ctypes.data))
+        return d, s, c
+
+    def close(self):
+        if self.h:
+            hip_lib().tri_batch_destroy(self.h)
+            self.h = C.c_void_p()
