@@ -24,6 +24,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
+#include <unistd.h>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -101,6 +103,32 @@ struct tri_batch {
         bool synced = false;
         tri_batch_info info{};
 };
+
+// ------------------------------------------------------------------------------------------ debug trace
+// -DTRI_TRACE builds write per-workgroup progress markers into host-pinned memory; tri_batch_sync then polls
+// with a watchdog (env TRINITY_WATCHDOG_S) and dumps the markers instead of hanging.  Not in product builds.
+#ifdef TRI_TRACE
+static uint32_t *g_trace_host = nullptr;
+__device__ volatile uint32_t *g_trace = nullptr;
+#ifndef TRI_TRACE_MASK
+#define TRI_TRACE_MASK 0xffffffffu
+#endif
+#define TRACE(stage, a, b)                                                      \
+        do {                                                                    \
+                if (((TRI_TRACE_MASK >> (stage)) & 1u) && threadIdx.x == 0 && g_trace) {                              \
+                        volatile uint32_t *t_ = g_trace + (blockIdx.x & 63) * 4; \
+                        t_[0] = (stage);                                        \
+                        t_[1] = (a);                                            \
+                        t_[2] = (b);                                            \
+                        t_[3] = t_[3] + 1;                                      \
+                        __threadfence_system();                                 \
+                }                                                               \
+        } while (0)
+#else
+#define TRACE(stage, a, b) \
+        do {               \
+        } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------ device: varint
 // Prefix varint of Switch/switch_compiler_aux.h:53-80, branch-free.  `w` holds the next >= 5 stream bytes,
@@ -213,6 +241,11 @@ constexpr int AND_WG = 256;
 constexpr int TILE_BLOCKS = 256;
 constexpr int TILE_CANDS = TILE_BLOCKS * 32;
 
+// Values that are workgroup-uniform by construction but read back from LDS look divergent to the compiler; a
+// loop whose exit depends on one gets exec-masked structurisation, which is fatal around s_barrier (lanes
+// "leave" the loop at different times).  uni() pins such values into an SGPR so the branch is scalar.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
 // LDS candidate layout: logical slot j lives at phys(j); rotating each 32-slot row by its row number keeps
 // the one-lane-per-row writes of the lead decode (lane t writes row t, column i) off a single bank.
 __device__ __forceinline__ uint32_t phys(uint32_t j) { return (j & ~31u) | ((j + (j >> 5)) & 31u); }
@@ -250,15 +283,14 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
 
         if (block_driven) {
                 // advance lcur to the first block whose last docID >= cmin (tiles arrive in ascending docID order)
-                uint32_t lcur = sh.lcur[lcur_slot];
+                uint32_t lcur = uni(sh.lcur[lcur_slot]);
                 for (;;) {
                         const uint32_t b = lcur + tid;
                         const bool below = b < t.nblocks && bl[b] < cmin;
                         const uint64_t m = __ballot(below);
                         // number of leading lanes (from lane 0) with below == true, per wave
                         const uint32_t lead = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
-                        if ((tid & 63) == 0)
-                                sh.scan[tid >> 6] = lead;
+                        sh.scan[tid >> 6] = lead; // wave-uniform value, every lane stores it: no divergent branch
                         __syncthreads();
                         uint32_t adv = 0;
                         for (int w = 0; w < AND_WG / 64; ++w) {
@@ -266,14 +298,16 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                 if (sh.scan[w] != 64)
                                         break;
                         }
+                        adv = uni(adv);
                         __syncthreads();
                         lcur += adv;
                         if (adv != AND_WG || lcur >= t.nblocks)
                                 break;
                 }
-                if (tid == 0)
-                        sh.lcur[lcur_slot] = lcur;
+                sh.lcur[lcur_slot] = lcur; // uniform value, branch-free store
+                TRACE(10, lcur, t.nblocks);
                 for (uint32_t cb = lcur; cb < t.nblocks; cb += AND_WG) {
+                        TRACE(11, cb, t.nblocks);
                         const uint32_t b = cb + tid;
                         bool beyond = true;
                         if (b < t.nblocks) {
@@ -312,16 +346,21 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                         }
                                 }
                         }
-                        if (__syncthreads_or(beyond))
+                        // workgroup-wide OR of `beyond`, branch-free: one ballot per wave, four LDS words
+                        sh.scan[4 + (tid >> 6)] = __ballot(beyond) != 0ull;
+                        __syncthreads();
+                        const uint32_t any_beyond = uni(sh.scan[4] | sh.scan[5] | sh.scan[6] | sh.scan[7]);
+                        __syncthreads();
+                        if (any_beyond)
                                 break;
                 }
         } else {
                 // candidate-driven galloping: each candidate finds its block in the directory; the first
                 // candidate of each run that maps to the same block decodes it and merges forward
-                if (tid == 0)
-                        sh.blkof[0] = 0xffffffffu;
+                sh.blkof[0] = 0xffffffffu;
                 __syncthreads();
                 for (uint32_t base = 0; base < C; base += AND_WG) {
+                        TRACE(20, base, C);
                         const uint32_t j = base + tid;
                         uint32_t bj = 0xffffffffu;
                         uint32_t cv = 0;
@@ -341,8 +380,13 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                         __syncthreads();
                         const uint32_t prevb = sh.blkof[tid];
                         __syncthreads();
-                        if (tid == AND_WG - 1)
-                                sh.blkof[0] = bj;
+                        {
+                                // carry the last lane's block into the next round (slot 0), branch-free:
+                                // lanes of the last wave all store lane 63's value, other waves rewrite their own slot
+                                const uint32_t lastb = __shfl(bj, 63, 64);
+                                const bool lastwave = (tid >> 6) == (AND_WG / 64 - 1);
+                                sh.blkof[lastwave ? 0 : tid + 1] = lastwave ? lastb : bj;
+                        }
                         if (j < C && bj < t.nblocks && bj != prevb) {
                                 const uint32_t prev = bj ? bl[bj - 1] : 0;
                                 const uint32_t last = bl[bj];
@@ -376,20 +420,26 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                                 uint32_t *__restrict__ counts) {
         __shared__ AndShared sh;
         const uint32_t tid = threadIdx.x;
+        const uint32_t wave = uni(tid >> 6);
         for (;;) {
-                if (tid == 0)
-                        sh.bcast[0] = atomicAdd(ticket, 1u);
+                // next query: wave 0 draws the ticket.  All 64 lanes add 1 (the compiler folds that into ONE
+                // global atomic of +64 with a uniform operand — no lane-divergent branch at the loop head), so the
+                // counter advances in units of 64 per draw.
+                if (wave == 0) {
+                        const uint32_t old = atomicAdd(ticket, 1u);
+                        sh.bcast[0] = uni(old) >> 6;
+                }
                 __syncthreads();
-                const uint32_t slot = sh.bcast[0];
+                const uint32_t slot = uni(sh.bcast[0]);
                 __syncthreads();
                 if (slot >= nq)
                         break;
                 const DevQuery q = plan[slot];
                 const DevTerm lead = terms[qterms[q.term_base]];
+                TRACE(1, slot, q.nterms);
                 uint32_t *qout = out + q.out_off;
                 uint32_t produced = 0;
-                if (tid < 8)
-                        sh.lcur[tid] = 0;
+                sh.lcur[tid & 7] = 0;
 
                 for (uint32_t tb = 0; tb < lead.nblocks; tb += TILE_BLOCKS) {
                         const uint32_t nb = min((uint32_t)TILE_BLOCKS, lead.nblocks - tb);
@@ -411,21 +461,30 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                 sh.cand[row | ((n - 1 + tid) & 31u)] = last;
                         }
                         __syncthreads();
+                        TRACE(2, slot, tb);
 
                         // ---- every other term filters the surviving candidates
                         for (uint32_t k = 1; k < q.nterms && C; ++k) {
                                 const DevTerm t = terms[qterms[q.term_base + k]];
                                 sh.hit[tid] = 0;
                                 __syncthreads();
-                                and_filter_tile(sh, index, blk_last, blk_off, t, C, k - 1, t.nblocks <= lead.documents);
+                #if defined(TRI_FORCE_CAND)
+                                const bool bd = false;
+#elif defined(TRI_FORCE_BLOCK)
+                                const bool bd = true;
+#else
+                                const bool bd = t.nblocks <= lead.documents;
+#endif
+                                TRACE(3, slot, (k << 16) | (bd ? 1 : 0));
+                                and_filter_tile(sh, index, blk_last, blk_off, t, C, k - 1, bd);
+                                TRACE(4, slot, C);
                                 __syncthreads();
                                 // compact survivors (stable => still ascending)
                                 const uint32_t bits = sh.hit[tid];
                                 const uint32_t cnt = __popc(bits);
                                 uint32_t wtot;
                                 uint32_t ex = wave_excl_scan(cnt, wtot);
-                                if ((tid & 63) == 63)
-                                        sh.scan[tid >> 6] = wtot;
+                                sh.scan[tid >> 6] = wtot; // wave-uniform
                                 __syncthreads();
                                 uint32_t wbase = 0, total = 0;
                                 for (int w = 0; w < AND_WG / 64; ++w) {
@@ -457,7 +516,7 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                                         ++o;
                                                 }
                                 }
-                                C = total;
+                                C = uni(total);
                                 __syncthreads();
                         }
                         if (q.nterms == 1) {
@@ -467,9 +526,11 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                         produced += C;
                         __syncthreads();
                 }
-                if (tid == 0)
-                        counts[slot] = produced;
+                if (wave == 0)
+                        counts[slot] = produced; // scalar branch; the wave's lanes store one identical dword
+                TRACE(5, slot, produced);
         }
+        TRACE(6, 0, 0);
 }
 
 // FNV-1a(64) of each query's docID set (little-endian bytes), one lane per query — verification helper
@@ -915,6 +976,15 @@ extern "C" int tri_batch_run(tri_batch *b) {
         HIP_TRY(hipSetDevice(dev->device));
         b->synced = false;
         const uint32_t n = (uint32_t)b->plan.size();
+#ifdef TRI_TRACE
+        if (!g_trace_host) {
+                HIP_TRY(hipHostMalloc((void **)&g_trace_host, 64 * 16, hipHostMallocMapped | hipHostMallocCoherent));
+                uint32_t *dptr = nullptr;
+                HIP_TRY(hipHostGetDevicePointer((void **)&dptr, g_trace_host, 0));
+                HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &dptr, sizeof dptr));
+        }
+        memset(g_trace_host, 0, 64 * 16);
+#endif
         HIP_TRY(hipEventRecord(dev->ev0, dev->stream));
         if (n) {
                 HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 4, dev->stream));
@@ -932,6 +1002,29 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 return fail(TRI_ERR_INVALID, "null batch");
         tri_dev *dev = b->ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
+#if (defined(TRI_TRACE) && !defined(TRI_TRACE_NOPOLL)) || defined(TRI_POLL)
+        {
+                const char *w = getenv("TRINITY_WATCHDOG_S");
+                const double limit = w ? atof(w) : 10.0;
+                double waited = 0;
+                while (hipEventQuery(dev->ev1) == hipErrorNotReady) {
+                        struct timespec ts = {0, 50 * 1000 * 1000};
+                        nanosleep(&ts, nullptr);
+                        waited += 0.05;
+                        if (waited > limit) {
+                                fprintf(stderr, "[tri watchdog] kernel still running after %.1fs; per-workgroup markers {stage,a,b,count}:\n", waited);
+#ifdef TRI_TRACE
+                                for (int i = 0; i < 64; ++i)
+                                        if (g_trace_host[i * 4 + 3])
+                                                fprintf(stderr, "  wg%%64=%d stage=%u a=%u b=%u n=%u\n", i, g_trace_host[i * 4], g_trace_host[i * 4 + 1],
+                                                        g_trace_host[i * 4 + 2], g_trace_host[i * 4 + 3]);
+#endif
+                                fflush(stderr);
+                                _exit(3);
+                        }
+                }
+        }
+#endif
         HIP_TRY(hipStreamSynchronize(dev->stream));
         float ms = 0;
         if (hipEventElapsedTime(&ms, dev->ev0, dev->ev1) == hipSuccess)
