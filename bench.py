@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path's headline benchmark on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): batched 2-term AND queries (Zipf-sampled terms, seed 1337,
+distinct within a query) over the 10M-document / 1M-term synthetic Zipf(1.0) segment (corpus seed 42,
+google_codec), DocumentsOnly mode — every query's full ascending docID set is materialised in HBM.
+One "step" = one pass of the engine over one batch of --queries queries per GPU (index and compiled batch
+already resident in HBM).  Multi-GPU: one process per GPU, the index replicated, every rank runs its own
+batch of the same size (weak scaling; queries are independent, exec.h:57-62), and the per-query match counts
+are all-gathered over RCCL at the end of every step (the only exchange the DocumentsOnly path has).
+
+Rank 0 prints ONE JSON line: metric/value = queries/s over all GPUs; `roofline` = algorithmic bytes (SURVEY §8d:
+sum over queries of docbytes(t) of both terms + 4 B per match) / mean kernel time measured with HIP events on the
+engine's stream; `cpu_baseline` = the CPU oracle (restatement of the reference exec path, one thread) timed on a
+bounded sample of the same batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--docs", type=int, default=10_000_000)
+    ap.add_argument("--vocab", type=int, default=1_000_000)
+    ap.add_argument("--queries", type=int, default=16384, help="queries per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...")
+        args.gpus = world
+
+    import numpy as np
+    import torch
+
+    import trinity_amd as T
+
+    T.build_all()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    # ---- synthetic segment (identical on every rank) and this rank's query batch
+    t0 = time.time()
+    seg = T.Segment(args.docs, args.vocab, 10, 42)
+    build_s = time.time() - t0
+    dev = T.Device(local_rank)
+    ix = T.Index.from_segment(dev, seg)
+    info = ix.info()
+    qall = T.gen_queries(args.vocab, 1337, args.queries * world, 2)
+    qs = qall[rank::world][: args.queries]  # interleaved shard: same cost distribution on every rank
+    batch = T.Batch.conjunctions(ix, qs, T.FLAG_DOCUMENTS_ONLY)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    counts_dev = None
+    gathered = None
+    if dist is not None:
+        counts_dev = torch.zeros(args.queries, dtype=torch.int64, device="cuda")
+        gathered = [torch.zeros_like(counts_dev) for _ in range(world)]
+
+    def step():
+        batch.run()
+        batch.sync()
+        if dist is not None:
+            # result exchange: per-query match counts to every rank (docsets stay sharded in HBM)
+            counts_dev.copy_(torch.from_numpy(batch.counts().astype(np.int64)))
+            dist.all_gather(gathered, counts_dev)
+        return batch.info()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    binfo = None
+    for _ in range(args.steps):
+        binfo = step()
+        kernel_ms += binfo["last_run_ms"]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        m = torch.tensor([float(binfo["matches"]), float(binfo["algorithmic_bytes"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(m, op=dist.ReduceOp.SUM)
+        matches_all, alg_all = float(m[0].item()), float(m[1].item())
+    else:
+        matches_all, alg_all = float(binfo["matches"]), float(binfo["algorithmic_bytes"])
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        ms_per_step = elapsed * 1e3 / steps
+        qps = args.queries * world * steps / elapsed
+        k_ms = kernel_ms / steps  # this rank's dominant kernel (k_and), HIP events on the engine stream
+        alg = float(binfo["algorithmic_bytes"])
+        achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        out = {
+            "metric": "queries/sec",
+            "value": qps,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {
+                "workload": "cfg2: batched 2-term AND, google_codec, DocumentsOnly, Zipf(1.0) 10M docs / 1M terms" if args.docs == 10_000_000 else f"2-term AND, google_codec, DocumentsOnly, {args.docs} docs / {args.vocab} terms",
+                "docs": args.docs,
+                "vocab": args.vocab,
+                "queries_per_gpu_per_step": args.queries,
+                "index_bytes": int(info["index_bytes"]),
+                "postings": int(info["postings"]),
+                "parallelism": f"query-sharded x{world}, index replicated",
+            },
+            "matched_docids_per_sec": matches_all * steps / elapsed,
+            "matches_per_step": matches_all,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "k_and",
+                "kernel_ms": k_ms,
+                "algorithmic_bytes_per_launch": alg,
+            },
+            "segment_build_s": build_s,
+        }
+        if args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(seg, qs, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    batch.close()
+    ix.close()
+    dev.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(seg, qs, budget_s):
+    """The CPU oracle (plain-C restatement of the reference's iterator path: Google::Decoder next/advance ->
+    Conjuction leapfrog -> GenericDocsSetSpan), one thread, on the first queries of the same batch until the time
+    budget is spent.  A reported baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as O
+
+    ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
+    n = 0
+    matches = 0
+    t0 = time.perf_counter()
+    for a, b in qs.tolist():
+        docs, _ = ora.exec(np.array([O.tok(O.OP_TERM, a), O.tok(O.OP_TERM, b), O.tok(O.OP_AND, 2)], dtype=np.uint32), O.FLAG_DOCUMENTS_ONLY)
+        matches += len(docs)
+        n += 1
+        if time.perf_counter() - t0 > budget_s and n >= 32:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt,
+        "unit": "queries/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {n} queries of rank 0's batch ({matches} matches) in {dt:.1f}s, oracle/trinity_oracle.c single thread",
+        "matched_docids_per_sec": matches / dt,
+        "host_cpus": os.cpu_count(),
+    }
+
+
+if __name__ == "__main__":
+    main()
