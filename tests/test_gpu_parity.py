@@ -111,6 +111,37 @@ def test_and2_matches_oracle(request, world, nq):
     assert info["matches"] == tot
 
 
+@pytest.fixture(scope="module")
+def large(T, dev):
+    return World(T, dev, 2_000_000, 200_000, 10, 42)
+
+
+def test_and_dense_windows_match_oracle(large):
+    """Head x head conjunctions on a 2M-document segment run as TASK_DENSE (bitmap windows, many tasks/query)."""
+    w, T = large, large.T
+    qs = [[0, 1], [1, 0], [0, 2], [1, 2], [0, 7], [3, 5], [0, 1, 2], [2, 4, 1, 0], [0, 25], [1, 40]]
+    progs = [and_prog(T, q) for q in qs]
+    sets, hashes, info = run_docs_only(w, progs)
+    for q, got, h in zip(qs, sets, hashes):
+        want, _ = w.ora.exec(and_prog(T, q), O.FLAG_DOCUMENTS_ONLY)
+        assert np.array_equal(got, want), (q, len(got), len(want))
+        assert int(h) == O.fnv1a_docs(want)
+
+
+@pytest.mark.parametrize("world,nq", [("small", 300), ("dense", 200)])
+def test_and_forced_dense_path_matches_oracle(request, monkeypatch, world, nq):
+    """TRINITY_DENSE_MIN=0 forces every eligible query through the bitmap-window path: sparse windows, windows
+    with no blocks, lists ending mid-window, k-way conjunctions."""
+    monkeypatch.setenv("TRINITY_DENSE_MIN", "0")
+    w = request.getfixturevalue(world)
+    T = w.T
+    qs = T.gen_queries(w.V, 7, nq, 2).tolist() + T.gen_queries(w.V, 8, 60, 3).tolist() + [[0, 1], [0, 1, 2, 3], [w.V - 1, 0]]
+    sets, _, _ = run_docs_only(w, [and_prog(T, q) for q in qs])
+    for q, got in zip(qs, sets):
+        want, _ = w.ora.exec(and_prog(T, q), O.FLAG_DOCUMENTS_ONLY)
+        assert np.array_equal(got, want), (q, len(got), len(want))
+
+
 @pytest.mark.parametrize("k", [3, 5])
 def test_and_k_terms_matches_oracle(small, dense, k):
     for w in (small, dense):

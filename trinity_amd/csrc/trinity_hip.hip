@@ -64,7 +64,22 @@ struct DevQuery {      // one conjunctive query (v1)
         uint64_t out_off;   // docID slots
         uint32_t out_cap;
         uint32_t qid; // caller's query index
+        uint32_t first_task, ntasks;
 };
+
+// Unit of scheduling: a run of lead-list tiles of one query.  Heavy queries are cut into many tasks so that no
+// single workgroup carries a multi-millisecond tail; task `i` of a query writes its (ascending) matches at
+// out_off + tile_begin * TILE_CANDS, a region no other task can reach because matches are a subset of the
+// lead tile's documents.  A query's docID set is the in-order concatenation of its tasks' segments.
+struct DevTask {
+        uint32_t slot;       // plan slot of the query
+        uint32_t tile_begin; // TASK_CAND: lead tiles [tile_begin, tile_end); TASK_DENSE: docID windows [begin, end)
+        uint32_t tile_end;
+        uint32_t kind;
+        uint64_t out_off; // absolute docID slot in out[] where this task's segment starts
+};
+constexpr uint32_t TASK_CAND = 0;  // candidate tiles of the lead list, filtered by galloping / block-driven merge
+constexpr uint32_t TASK_DENSE = 1; // bitmap algebra over fixed docID windows (every list dense enough)
 
 struct tri_dev {
         int device;
@@ -79,6 +94,7 @@ struct tri_index {
         uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr;
         DevTerm *d_terms = nullptr;
         std::vector<DevTerm> terms;
+        std::vector<uint32_t> h_blk_last; // host copy of the directory's last-docID column (planner: task output offsets)
         std::vector<tri_term> tctx;
         std::vector<uint64_t> docbytes, hitbytes;
         tri_index_info info{};
@@ -92,14 +108,18 @@ struct tri_batch {
         std::vector<uint32_t> qterms;
         std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: trivially empty)
         DevQuery *d_plan = nullptr;
+        std::vector<DevTask> tasks; // scheduling order (cost descending)
+        DevTask *d_tasks = nullptr;
+        uint32_t *d_sched = nullptr; // task indices, heaviest first
         uint32_t *d_qterms = nullptr;
         uint32_t *d_out = nullptr;
-        uint32_t *d_counts = nullptr; // per plan slot
+        uint32_t *d_counts = nullptr; // per task, indexed first_task + i in query order
         uint32_t *d_ticket = nullptr;
         uint64_t *d_hashes = nullptr;
         uint64_t out_capacity = 0;
         uint64_t term_bytes = 0; // sum of docbytes over all query terms
-        std::vector<uint32_t> h_counts;
+        std::vector<uint32_t> h_counts;       // per task
+        std::vector<uint64_t> h_query_counts; // per plan slot
         bool synced = false;
         tri_batch_info info{};
 };
@@ -153,11 +173,12 @@ __device__ __forceinline__ uint32_t vb_decode(uint64_t w, uint32_t &len) {
         return v;
 }
 
-// Per-lane byte stream over global memory: a 16-byte register window refilled with aligned 8-byte loads,
-// the next qword always in flight (index[] carries >= 64 bytes of slack past the last chunk).
+// Per-lane byte stream over global memory: a 16-byte register window (lo = next 8 bytes, hi = the following
+// ones) refilled from aligned 8-byte loads, with three further qwords always in flight so that the load
+// latency sits behind ~24 bytes of decoding (index[] carries >= 64 bytes of slack past the last chunk).
 struct VbStream {
         const uint64_t *q;
-        uint64_t lo, hi, nxt;
+        uint64_t lo, hi, n1, n2, n3;
         int valid;
 
         __device__ __forceinline__ void init(const uint8_t *p) {
@@ -165,8 +186,10 @@ struct VbStream {
                 const uint32_t sk = (uint32_t)(a & 7u);
                 q = (const uint64_t *)(a & ~(uintptr_t)7);
                 const uint64_t w0 = q[0], w1 = q[1];
-                nxt = q[2];
-                q += 3;
+                n1 = q[2];
+                n2 = q[3];
+                n3 = q[4];
+                q += 5;
                 const uint32_t sh = sk * 8;
                 lo = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
                 hi = sh ? (w1 >> sh) : w1;
@@ -174,16 +197,19 @@ struct VbStream {
         }
         __device__ __forceinline__ void refill() {
                 if (valid <= 8) {
-                        const uint64_t w = nxt;
-                        nxt = *q++;
+                        const uint64_t w = n1;
+                        n1 = n2;
+                        n2 = n3;
+                        n3 = *q++;
+                        const uint32_t sh = (uint32_t)valid * 8; // 0..64
                         if (valid == 8)
                                 hi = w;
-                        else {
-                                const uint32_t sh = (uint32_t)valid * 8;
-                                lo |= sh ? (w << sh) : w;
-                                hi = sh ? (w >> (64 - sh)) : 0;
-                                if (!sh)
-                                        lo = w;
+                        else if (valid == 0) {
+                                lo = w;
+                                hi = 0;
+                        } else {
+                                lo |= w << sh;
+                                hi = w >> (64 - sh);
                         }
                         valid += 8;
                 }
@@ -197,6 +223,15 @@ struct VbStream {
                 hi >>= s;
                 valid -= (int)len;
                 return v;
+        }
+        // after refill(): true when the next 8 bytes are 8 one-byte varints (values < 128)
+        __device__ __forceinline__ bool eight_small() const { return (lo & 0x8080808080808080ull) == 0; }
+        __device__ __forceinline__ uint64_t take8() {
+                const uint64_t w = lo;
+                lo = hi;
+                hi = 0;
+                valid -= 8;
+                return w;
         }
 };
 
@@ -262,14 +297,47 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
         return x - v;
 }
 
+constexpr uint32_t SPAN_BITS = 1u << 17; // docIDs per dense window
+constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
+
 struct AndShared {
-        uint32_t cand[TILE_CANDS];
-        uint32_t hit[TILE_BLOCKS]; // bit k of hit[r] <=> logical candidate r*32+k matched
+        union {
+                struct {
+                        uint32_t cand[TILE_CANDS];
+                        uint32_t hit[TILE_BLOCKS]; // bit k of hit[r] <=> logical candidate r*32+k matched
+                        uint32_t blkof[AND_WG + 1];
+                };
+                uint32_t bits[2][SPAN_WORDS]; // TASK_DENSE: two docID-window bitmaps (candidates / survivors)
+        };
+        uint32_t tbase[AND_WG];
         uint32_t scan[8];
         uint32_t bcast[4];
-        uint32_t blkof[AND_WG + 1];
-        uint32_t lcur[8]; // per filter term: directory cursor (block-driven mode), uniform across the workgroup
+        uint32_t lcur[8]; // per term: directory cursor, uniform across the workgroup
 };
+
+// Workgroup-cooperative lower bound over a sorted global array: first i in [0, n) with a[i] >= key, else n.
+// 256-ary search: every lane probes the end of its segment, one ballot per wave finds the first segment whose
+// last element is >= key; ~log256(n) rounds of one (L2-resident) load each instead of log2(n) dependent loads.
+__device__ uint32_t wg_lower_bound(AndShared &sh, const uint32_t *__restrict__ a, const uint32_t n, const uint32_t key) {
+        const uint32_t tid = threadIdx.x;
+        uint32_t lo = 0, hi = n; // answer in [lo, hi]
+        while (hi > lo) {
+                const uint32_t len = hi - lo;
+                const uint32_t step = (len + AND_WG - 1) / AND_WG;
+                const uint32_t pos = lo + (tid + 1) * step - 1;
+                const bool ge = pos >= hi ? true : a[pos] >= key;
+                const uint64_t m = __ballot(ge);
+                sh.scan[tid >> 6] = m ? (tid & ~63u) + (uint32_t)__builtin_ctzll(m) : 0xffffffffu;
+                __syncthreads();
+                const uint32_t first = uni(min(min(sh.scan[0], sh.scan[1]), min(sh.scan[2], sh.scan[3])));
+                __syncthreads();
+                const uint32_t nlo = lo + first * step;
+                const uint32_t nhi = min(hi, lo + (first + 1) * step - 1);
+                lo = nlo;
+                hi = step == 1 ? nlo : nhi;
+        }
+        return lo;
+}
 
 // Filter the C candidates in sh.cand (logical order ascending) against term `t`: sets sh.hit bits.
 // Caller syncs before and after.
@@ -284,6 +352,8 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
         if (block_driven) {
                 // advance lcur to the first block whose last docID >= cmin (tiles arrive in ascending docID order)
                 uint32_t lcur = uni(sh.lcur[lcur_slot]);
+                if (lcur == 0xffffffffu) // first tile of this task: position by cooperative search, then gallop forward
+                        lcur = wg_lower_bound(sh, bl, t.nblocks, cmin);
                 for (;;) {
                         const uint32_t b = lcur + tid;
                         const bool below = b < t.nblocks && bl[b] < cmin;
@@ -413,11 +483,149 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
         }
 }
 
+// ---- TASK_DENSE: bitmap algebra over docID windows -------------------------------------------------------
+// One lane decodes one block (unpack_block, google_codec.cpp:596-639) and ORs its documents into / tests them
+// against a window bitmap in LDS.  Consecutive documents of a dense list fall into the same 32-bit word, so the
+// lane keeps the current word in registers and touches LDS once per word, not once per posting.
+template <bool FIRST>
+__device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
+                                            const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
+        VbStream s;
+        s.init(index + off);
+        uint32_t doc = prev, curword = 0xffffffffu, cw = 0, acc = 0;
+        auto visit = [&](const uint32_t d) {
+                const uint32_t rel = d - w0; // documents outside the window land on word >= SPAN_WORDS
+                const uint32_t word = rel >> 5;
+                if (word != curword) {
+                        if (acc)
+                                atomicOr(&dst[curword], acc);
+                        acc = 0;
+                        curword = word;
+                        cw = word < SPAN_WORDS ? (FIRST ? 0xffffffffu : src[word]) : 0u;
+                }
+                acc |= cw & (1u << (rel & 31u));
+        };
+        const uint32_t nd = n - 1;
+        uint32_t i = 0;
+        while (i < nd) {
+                s.refill();
+                if (nd - i >= 8 && s.eight_small()) {
+                        uint64_t w = s.take8();
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                                doc += (uint32_t)(w & 0xffu);
+                                w >>= 8;
+                                visit(doc);
+                        }
+                        i += 8;
+                } else {
+                        doc += s.next();
+                        visit(doc);
+                        ++i;
+                }
+        }
+        visit(last);
+        if (acc)
+                atomicOr(&dst[curword], acc);
+}
+
+__device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                           const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms, const uint32_t *__restrict__ qterms,
+                           const DevQuery q, const DevTask task, uint32_t *__restrict__ out, uint32_t *__restrict__ count_out) {
+        const uint32_t tid = threadIdx.x;
+        uint32_t *qout = out + task.out_off;
+        uint32_t produced = 0;
+        sh.lcur[tid & 7] = 0xffffffffu;
+        __syncthreads();
+        bool exhausted = false; // uniform: some list has no documents at or beyond this window
+        for (uint32_t w = task.tile_begin; w < task.tile_end && !exhausted; ++w) {
+                const uint32_t w0 = w * SPAN_BITS;
+                const uint32_t wlast = w0 + (SPAN_BITS - 1);
+                for (uint32_t k = 0; k < q.nterms; ++k) {
+                        const DevTerm t = terms[qterms[q.term_base + k]];
+                        const uint32_t *bl = blk_last + t.first_block;
+                        const uint32_t *bo = blk_off + t.first_block;
+                        uint32_t *dst = sh.bits[k & 1];
+                        const uint32_t *src = sh.bits[(k & 1) ^ 1];
+                        for (uint32_t i = tid; i < SPAN_WORDS; i += AND_WG)
+                                dst[i] = 0;
+                        // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
+                        uint32_t b_lo = uni(sh.lcur[k]);
+                        if (b_lo == 0xffffffffu)
+                                b_lo = wg_lower_bound(sh, bl, t.nblocks, w0);
+                        if (b_lo >= t.nblocks) {
+                                exhausted = true;
+                                break;
+                        }
+                        uint32_t b_hi = b_lo + wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, wlast);
+                        if (b_hi >= t.nblocks)
+                                b_hi = t.nblocks - 1;
+                        __syncthreads(); // dst cleared, previous pass complete
+                        sh.lcur[k] = b_hi;
+                        for (uint32_t cb = b_lo; cb <= b_hi; cb += AND_WG) {
+                                const uint32_t b = cb + tid;
+                                if (b <= b_hi) {
+                                        const uint32_t prev = b ? bl[b - 1] : 0;
+                                        const uint32_t last = bl[b];
+                                        const uint32_t off = bo[b];
+                                        const uint32_t n = index[off - 1];
+                                        if (k == 0)
+                                                dense_block<true>(index, off, n, prev, last, w0, src, dst);
+                                        else
+                                                dense_block<false>(index, off, n, prev, last, w0, src, dst);
+                                }
+                        }
+                        __syncthreads();
+                }
+                if (exhausted)
+                        break;
+                // ---- expand the survivors bitmap into ascending docIDs
+                const uint32_t *fin = sh.bits[(q.nterms - 1) & 1];
+                uint32_t *pre = sh.bits[q.nterms & 1]; // the other bitmap is dead: per-word exclusive prefix
+                {
+                        uint32_t run = 0;
+                        for (uint32_t j = 0; j < SPAN_WORDS / AND_WG; ++j) {
+                                const uint32_t wi = tid * (SPAN_WORDS / AND_WG) + j;
+                                pre[wi] = run;
+                                run += __popc(fin[wi]);
+                        }
+                        uint32_t wtot;
+                        const uint32_t ex = wave_excl_scan(run, wtot);
+                        sh.scan[tid >> 6] = wtot;
+                        __syncthreads();
+                        uint32_t wbase = 0, total = 0;
+                        for (int wv = 0; wv < AND_WG / 64; ++wv) {
+                                if (wv < (int)(tid >> 6))
+                                        wbase += sh.scan[wv];
+                                total += sh.scan[wv];
+                        }
+                        sh.tbase[tid] = ex + wbase;
+                        __syncthreads();
+                        // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
+                        for (uint32_t wi = tid; wi < SPAN_WORDS; wi += AND_WG) {
+                                uint32_t m = fin[wi];
+                                uint32_t o = produced + sh.tbase[wi / (SPAN_WORDS / AND_WG)] + pre[wi];
+                                const uint32_t base = w0 + wi * 32;
+                                while (m) {
+                                        qout[o++] = base + (uint32_t)__builtin_ctz(m);
+                                        m &= m - 1;
+                                }
+                        }
+                        produced += uni(total);
+                        __syncthreads();
+                }
+        }
+        __syncthreads();
+        if (uni(tid >> 6) == 0)
+                *count_out = produced;
+}
+
 __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                 const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
-                                                const DevQuery *__restrict__ plan, const uint32_t *__restrict__ qterms,
-                                                const uint32_t nq, uint32_t *__restrict__ ticket, uint32_t *__restrict__ out,
-                                                uint32_t *__restrict__ counts) {
+                                                const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
+                                                const uint32_t *__restrict__ sched, const uint32_t *__restrict__ qterms,
+                                                const uint32_t ntasks, uint32_t *__restrict__ ticket,
+                                                uint32_t *__restrict__ out, uint32_t *__restrict__ counts) {
         __shared__ AndShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
@@ -430,18 +638,26 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                         sh.bcast[0] = uni(old) >> 6;
                 }
                 __syncthreads();
-                const uint32_t slot = uni(sh.bcast[0]);
+                const uint32_t ticket_no = uni(sh.bcast[0]);
                 __syncthreads();
-                if (slot >= nq)
+                if (ticket_no >= ntasks)
                         break;
+                const uint32_t tix = sched[ticket_no];
+                const DevTask task = tasks[tix];
+                const uint32_t slot = task.slot;
                 const DevQuery q = plan[slot];
+                if (task.kind == TASK_DENSE) {
+                        dense_task(sh, index, blk_last, blk_off, terms, qterms, q, task, out, counts + tix);
+                        continue;
+                }
                 const DevTerm lead = terms[qterms[q.term_base]];
                 TRACE(1, slot, q.nterms);
-                uint32_t *qout = out + q.out_off;
+                uint32_t *qout = out + task.out_off;
                 uint32_t produced = 0;
-                sh.lcur[tid & 7] = 0;
+                sh.lcur[tid & 7] = 0xffffffffu; // "not positioned yet"
+                const uint32_t tb_end = min(lead.nblocks, task.tile_end * TILE_BLOCKS);
 
-                for (uint32_t tb = 0; tb < lead.nblocks; tb += TILE_BLOCKS) {
+                for (uint32_t tb = task.tile_begin * TILE_BLOCKS; tb < tb_end; tb += TILE_BLOCKS) {
                         const uint32_t nb = min((uint32_t)TILE_BLOCKS, lead.nblocks - tb);
                         uint32_t C = (tb + nb == lead.nblocks) ? (nb - 1) * 32 + lead.last_n : nb * 32;
                         // ---- decode the lead tile: one lane per block (unpack_block, google_codec.cpp:596-639)
@@ -527,26 +743,30 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                         __syncthreads();
                 }
                 if (wave == 0)
-                        counts[slot] = produced; // scalar branch; the wave's lanes store one identical dword
+                        counts[tix] = produced; // scalar branch; the wave's lanes store one identical dword
                 TRACE(5, slot, produced);
         }
         TRACE(6, 0, 0);
 }
 
 // FNV-1a(64) of each query's docID set (little-endian bytes), one lane per query — verification helper
-__global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const uint32_t *__restrict__ counts, const uint32_t nq,
-                               const uint32_t *__restrict__ out, uint64_t *__restrict__ hashes) {
+__global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks_by_query,
+                               const uint32_t *__restrict__ counts_by_query, const uint32_t nq, const uint32_t *__restrict__ out,
+                               uint64_t *__restrict__ hashes) {
         const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
         if (s >= nq)
                 return;
-        const uint32_t *p = out + plan[s].out_off;
-        const uint32_t n = counts[s];
+        const DevQuery q = plan[s];
         uint64_t h = 1469598103934665603ull;
-        for (uint32_t i = 0; i < n; ++i) {
-                uint32_t d = p[i];
-                for (int b = 0; b < 4; ++b) {
-                        h = (h ^ (d & 0xffu)) * 1099511628211ull;
-                        d >>= 8;
+        for (uint32_t t = 0; t < q.ntasks; ++t) {
+                const uint32_t *p = out + tasks_by_query[q.first_task + t].out_off;
+                const uint32_t n = counts_by_query[q.first_task + t];
+                for (uint32_t i = 0; i < n; ++i) {
+                        uint32_t d = p[i];
+                        for (int b = 0; b < 4; ++b) {
+                                h = (h ^ (d & 0xffu)) * 1099511628211ull;
+                                d >>= 8;
+                        }
                 }
         }
         hashes[s] = h;
@@ -709,9 +929,10 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         int rc;
         if ((rc = dev_upload(&ix->d_blk_last, blk_last)) || (rc = dev_upload(&ix->d_blk_off, blk_off)) || (rc = dev_upload(&ix->d_terms, ix->terms)))
                 return rc;
+        ix->h_blk_last = std::move(blk_last);
         ix->info.index_bytes = len;
-        ix->info.directory_bytes = blk_last.size() * 8 + nterms * sizeof(DevTerm);
-        ix->info.blocks = blk_last.size();
+        ix->info.directory_bytes = ix->h_blk_last.size() * 8 + nterms * sizeof(DevTerm);
+        ix->info.blocks = ix->h_blk_last.size();
         ix->info.postings = postings;
         ix->info.doc_bytes = docb;
         ix->info.hit_bytes = hitb;
@@ -936,18 +1157,71 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         std::stable_sort(tmp.begin(), tmp.end(), [](const Tmp &a, const Tmp &c) { return a.cost > c.cost; });
         uint64_t off = 0;
         b->plan.reserve(tmp.size());
+        // cut every query into tasks of roughly TASK_COST postings, then schedule heaviest first
+        constexpr uint64_t TASK_COST = 96 * 1024;
+        // tunables (environment overrides exist for tests and perf probes)
+        uint64_t DENSE_MIN_POSTINGS = 512 * 1024;
+        if (const char *e = getenv("TRINITY_DENSE_MIN"))
+                DENSE_MIN_POSTINGS = strtoull(e, nullptr, 10);
+        std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
         for (auto &t : tmp) {
+                const uint32_t slot = (uint32_t)b->plan.size();
+                b->slot_of_query[t.q.qid] = slot;
+                const uint32_t *qt = &b->qterms[t.q.term_base];
+                const DevTerm &lead = ix->terms[qt[0]];
+                // TASK_DENSE when every other list is within a factor 32 of the lead (no block can be skipped anyway)
+                // and there is enough work per docID window to keep 256 lanes busy
+                uint64_t sumdf = 0;
+                bool dense = t.q.nterms >= 2;
+                uint32_t last_doc = 0xffffffffu;
+                for (uint32_t k = 0; k < t.q.nterms; ++k) {
+                        const DevTerm &tk = ix->terms[qt[k]];
+                        sumdf += tk.documents;
+                        dense &= tk.nblocks <= lead.documents;
+                        last_doc = std::min(last_doc, ix->h_blk_last[tk.first_block + tk.nblocks - 1]);
+                }
+                dense &= sumdf >= DENSE_MIN_POSTINGS;
                 t.q.out_off = off;
+                t.q.first_task = (uint32_t)b->tasks.size();
+                if (dense) {
+                        const uint32_t nwin = last_doc / SPAN_BITS + 1; // no match can lie beyond the shortest list's last document
+                        const uint64_t per_win = std::max<uint64_t>(1, sumdf / (ix->info.docs_cnt / SPAN_BITS + 1));
+                        const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, TASK_COST / per_win);
+                        const uint32_t *lb = &ix->h_blk_last[lead.first_block];
+                        uint32_t ord = 0;
+                        for (uint32_t wb = 0; wb < nwin; wb += win_per_task, ++ord) {
+                                const uint32_t we = std::min(nwin, wb + win_per_task);
+                                // matches of windows [wb, we) are lead documents of blocks b1 .. (next task's b1): a private region
+                                const uint32_t b1 = (uint32_t)(std::lower_bound(lb, lb + lead.nblocks, wb * SPAN_BITS) - lb);
+                                order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
+                                b->tasks.push_back({slot, wb, we, TASK_DENSE, off + (uint64_t)b1 * 32 + 32ull * ord});
+                        }
+                        t.q.out_cap = lead.nblocks * 32 + 32 * (ord + 1);
+                } else {
+                        const uint32_t ntiles = (lead.nblocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
+                        const uint64_t per_tile = std::max<uint64_t>(1, t.cost / ntiles);
+                        const uint32_t tiles_per_task = (uint32_t)std::max<uint64_t>(1, TASK_COST / per_tile);
+                        for (uint32_t tb = 0; tb < ntiles; tb += tiles_per_task) {
+                                const uint32_t te = std::min(ntiles, tb + tiles_per_task);
+                                order.emplace_back(per_tile * (te - tb), (uint32_t)b->tasks.size());
+                                b->tasks.push_back({slot, tb, te, TASK_CAND, off + (uint64_t)tb * TILE_CANDS});
+                        }
+                }
                 off += t.q.out_cap;
-                b->slot_of_query[t.q.qid] = (uint32_t)b->plan.size();
+                t.q.ntasks = (uint32_t)b->tasks.size() - t.q.first_task;
                 b->plan.push_back(t.q);
         }
+        std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &c) { return a.first > c.first; });
+        std::vector<uint32_t> sched(order.size());
+        for (size_t i = 0; i < order.size(); ++i)
+                sched[i] = order[i].second;
         b->out_capacity = off;
         int rc;
-        if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)))
+        if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)) || (rc = dev_upload(&b->d_tasks, b->tasks)) ||
+            (rc = dev_upload(&b->d_sched, sched)))
                 return rc;
         HIP_TRY(hipMalloc((void **)&b->d_out, (off + 64) * 4));
-        HIP_TRY(hipMalloc((void **)&b->d_counts, (b->plan.size() + 1) * 4));
+        HIP_TRY(hipMalloc((void **)&b->d_counts, (b->tasks.size() + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_ticket, 64));
         b->info.nqueries = nq;
         b->info.out_capacity = off;
@@ -961,6 +1235,8 @@ extern "C" void tri_batch_destroy(tri_batch *b) {
                 return;
         hipSetDevice(b->ix->dev->device);
         hipFree(b->d_plan);
+        hipFree(b->d_tasks);
+        hipFree(b->d_sched);
         hipFree(b->d_qterms);
         hipFree(b->d_out);
         hipFree(b->d_counts);
@@ -975,7 +1251,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
         tri_dev *dev = b->ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
         b->synced = false;
-        const uint32_t n = (uint32_t)b->plan.size();
+        const uint32_t n = (uint32_t)b->tasks.size();
 #ifdef TRI_TRACE
         if (!g_trace_host) {
                 HIP_TRY(hipHostMalloc((void **)&g_trace_host, 64 * 16, hipHostMallocMapped | hipHostMallocCoherent));
@@ -990,7 +1266,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 4, dev->stream));
                 const uint32_t grid = std::min<uint32_t>(n, (uint32_t)dev->cus * 4);
                 hipLaunchKernelGGL(k_and, dim3(grid), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms,
-                                   b->d_plan, b->d_qterms, n, b->d_ticket, b->d_out, b->d_counts);
+                                   b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, n, b->d_ticket, b->d_out, b->d_counts);
                 HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(dev->ev1, dev->stream));
@@ -1029,12 +1305,17 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, dev->ev0, dev->ev1) == hipSuccess)
                 b->info.last_run_ms = ms;
-        b->h_counts.resize(b->plan.size());
-        if (!b->plan.empty())
-                HIP_TRY(hipMemcpy(b->h_counts.data(), b->d_counts, b->plan.size() * 4, hipMemcpyDeviceToHost));
+        b->h_counts.resize(b->tasks.size());
+        if (!b->tasks.empty())
+                HIP_TRY(hipMemcpy(b->h_counts.data(), b->d_counts, b->tasks.size() * 4, hipMemcpyDeviceToHost));
         uint64_t m = 0;
-        for (uint32_t c : b->h_counts)
-                m += c;
+        b->h_query_counts.assign(b->plan.size(), 0);
+        for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
+                const DevQuery &q = b->plan[sidx];
+                for (uint32_t t = 0; t < q.ntasks; ++t)
+                        b->h_query_counts[sidx] += b->h_counts[q.first_task + t];
+                m += b->h_query_counts[sidx];
+        }
         b->info.matches = m;
         b->info.algorithmic_bytes = b->term_bytes + 4 * m; // docbytes + 4 B per match (docs-only)
         b->synced = true;
@@ -1054,7 +1335,7 @@ extern "C" int tri_batch_match_counts(tri_batch *b, uint64_t *counts) {
         if (!b->synced)
                 return fail(TRI_ERR_INVALID, "tri_batch_sync first");
         for (size_t q = 0; q < b->nq; ++q)
-                counts[q] = b->slot_of_query[q] == UINT32_MAX ? 0 : b->h_counts[b->slot_of_query[q]];
+                counts[q] = b->slot_of_query[q] == UINT32_MAX ? 0 : b->h_query_counts[b->slot_of_query[q]];
         return TRI_OK;
 }
 
@@ -1064,13 +1345,24 @@ extern "C" int tri_batch_docset(tri_batch *b, size_t q, uint32_t *out, size_t ca
         if (!b->synced)
                 return fail(TRI_ERR_INVALID, "tri_batch_sync first");
         const uint32_t slot = b->slot_of_query[q];
-        *n = slot == UINT32_MAX ? 0 : b->h_counts[slot];
+        *n = slot == UINT32_MAX ? 0 : b->h_query_counts[slot];
         if (!*n || !out)
                 return TRI_OK;
         if (cap < *n)
                 return fail(TRI_ERR_INVALID, "docset needs %zu slots, %zu given", *n, cap);
         HIP_TRY(hipSetDevice(b->ix->dev->device));
-        HIP_TRY(hipMemcpy(out, b->d_out + b->plan[slot].out_off, *n * 4, hipMemcpyDeviceToHost));
+        // the docID set is the in-order concatenation of the query's task segments
+        const DevQuery &dq = b->plan[slot];
+        size_t w = 0;
+        for (uint32_t t = 0; t < dq.ntasks; ++t) {
+                const uint32_t c = b->h_counts[dq.first_task + t];
+                if (!c)
+                        continue;
+                const uint32_t *src = b->d_out + b->tasks[dq.first_task + t].out_off;
+                HIP_TRY(hipMemcpyAsync(out + w, src, (size_t)c * 4, hipMemcpyDeviceToHost, b->ix->dev->stream));
+                w += c;
+        }
+        HIP_TRY(hipStreamSynchronize(b->ix->dev->stream));
         return TRI_OK;
 }
 
@@ -1086,7 +1378,8 @@ extern "C" int tri_batch_docset_hashes(tri_batch *b, uint64_t *hashes) {
         if (n) {
                 if (!b->d_hashes)
                         HIP_TRY(hipMalloc((void **)&b->d_hashes, (size_t)n * 8));
-                hipLaunchKernelGGL(k_hash_docsets, dim3((n + 63) / 64), dim3(64), 0, dev->stream, b->d_plan, b->d_counts, n, b->d_out, b->d_hashes);
+                hipLaunchKernelGGL(k_hash_docsets, dim3((n + 63) / 64), dim3(64), 0, dev->stream, b->d_plan, b->d_tasks, b->d_counts, n, b->d_out,
+                                   b->d_hashes);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(dev->stream));
                 HIP_TRY(hipMemcpy(h.data(), b->d_hashes, (size_t)n * 8, hipMemcpyDeviceToHost));
