@@ -152,7 +152,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args, world),
                 "kernel": "k_and",
                 "kernel_ms": k_ms,
                 "algorithmic_bytes_per_launch": alg,
@@ -169,6 +169,20 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, world):
+    """HBM bytes per k_and launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction
+    + WRITE_SIZE; profiles/r01_pmc_cfg2.json, collected with this exact workload) — PMC counters cannot be read
+    from inside the timed run, so the figure is reported only when the configuration matches."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
+            p = json.load(f)["bench_cfg2"]
+        if (p["docs"], p["vocab"], p["queries"]) == (args.docs, args.vocab, args.queries):
+            return p["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
 
 
 def cpu_baseline(seg, qs, budget_s):
