@@ -208,3 +208,51 @@ def test_and_properties_at_scale(medium):
         db = w.ora.decode_term(p[1])[0]
         assert np.array_equal(a, np.intersect1d(da, db))
     assert np.array_equal(sets[-1], w.ora.decode_term(0)[0])
+
+
+# ------------------------------------------------------------------------------------------ BM25 + top-K (K5)
+def run_scored(w, programs, k):
+    b = w.T.Batch(w.ix, programs, w.T.FLAG_ACCUMULATED_SCORE, topk=k)
+    b.run()
+    b.sync()
+    d, s, c = b.topk_results()
+    counts = b.counts()
+    b.close()
+    return d, s, c, counts
+
+
+@pytest.mark.parametrize("world,nq,k", [("small", 200, 10), ("dense", 150, 100), ("medium", 120, 100), ("small", 60, 256)])
+def test_scored_and_topk_matches_oracle(request, world, nq, k):
+    """AccumulatedScoreScheme + BM25 + application top-K: docIDs exact (score desc, docID asc), scores within 1e-5
+    relative (the tolerance BASELINE.json states), total match counts exact."""
+    w = request.getfixturevalue(world)
+    T = w.T
+    qs = T.gen_queries(w.V, 21, nq, 2).tolist() + T.gen_queries(w.V, 22, nq // 4, 3).tolist() + [[0, 1], [1, 0], [0, 1, 2, 3, 4], [0, 0], [5]]
+    progs = [and_prog(T, q) if len(q) > 1 else np.array([T.tok(T.OP_TERM, q[0])], dtype=np.uint32) for q in qs]
+    d, s, c, counts = run_scored(w, progs, k)
+    for i, q in enumerate(qs):
+        docs, scores = w.ora.exec(progs[i], O.FLAG_ACCUM_SCORE)
+        assert int(counts[i]) == len(docs), q
+        td, ts = w.ora.topk(docs, scores, k)
+        assert int(c[i]) == len(td), q
+        assert d[i, : len(td)].tolist() == td.tolist(), q
+        np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+
+
+def test_scored_against_reference_fixtures(T, dev):
+    """flags=2 conjunction records of the reference fixtures: count, top-10 (docID, score)."""
+    checked = 0
+    for name in ("small", "dense"):
+        g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
+        c = g["corpus"]
+        w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
+        recs = [r for r in g["results"] if r["cmd"] == "query" and r["flags"] == 2 and "top" in r and not any(ch in r["q"] for ch in '"()O')]
+        d, s, cnt, counts = run_scored(w, [O.parse_query(r["q"]) for r in recs], 10)
+        for i, r in enumerate(recs):
+            assert int(counts[i]) == r["n"], r["q"]
+            top = r["top"]
+            assert d[i, : len(top)].tolist() == [x[0] for x in top], r["q"]
+            np.testing.assert_allclose(s[i, : len(top)], [x[1] for x in top], rtol=1e-5)
+            checked += 1
+        w.ix.close()
+    assert checked >= 20

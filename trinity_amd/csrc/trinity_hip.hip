@@ -65,6 +65,7 @@ struct DevQuery {      // one conjunctive query (v1)
         uint32_t out_cap;
         uint32_t qid; // caller's query index
         uint32_t first_task, ntasks;
+        uint32_t score_base, nscore; // AccumulatedScoreScheme: sterms[]/sweights[] slice, reference summation order
 };
 
 // Unit of scheduling: a run of lead-list tiles of one query.  Heavy queries are cut into many tasks so that no
@@ -116,6 +117,14 @@ struct tri_batch {
         uint32_t *d_counts = nullptr; // per task, indexed first_task + i in query order
         uint32_t *d_ticket = nullptr;
         uint64_t *d_hashes = nullptr;
+        // AccumulatedScoreScheme
+        std::vector<uint32_t> sterms;
+        std::vector<double> sweights;
+        uint32_t *d_sterms = nullptr;
+        double *d_sweights = nullptr;
+        uint32_t *d_part_docs = nullptr, *d_part_counts = nullptr, *d_top_docs = nullptr, *d_top_counts = nullptr;
+        double *d_part_scores = nullptr;
+        float *d_top_scores = nullptr;
         uint64_t out_capacity = 0;
         uint64_t term_bytes = 0; // sum of docbytes over all query terms
         std::vector<uint32_t> h_counts;       // per task
@@ -749,6 +758,264 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
         TRACE(6, 0, 0);
 }
 
+// ------------------------------------------------------------------------------------------ k_score / k_topk_merge
+// AccumulatedScoreScheme (exec.h:36-41).  k_and has produced every query's ascending match list; k_score walks each
+// task's segment in tiles of 4096 matches, and for every scoring term looks the matches up again through the
+// directory (each match binary-searches its block, the first match of a block decodes it once: deltas to locate the
+// matching positions, then the freqs), adding  float(idf * float(f) / double(f + 1.2f))  to a per-match double in LDS —
+// IndexSourcesCollectionBM25Scorer::Scorer::score (similarity.h:228-235) summed in iterator order by the Conjuction
+// wrapper (docset_iterators_scorers.cpp:173-193).  The tile is then offered to the task's top-K (score descending,
+// docID ascending: the application-side MatchedIndexDocumentsFilter heap, matches.h:155-171).  k_topk_merge folds
+// the tasks' partial lists into one list per query.
+constexpr uint32_t SCORE_TILE = 4096;
+constexpr uint32_t TOPK_MAX = 256;
+constexpr uint32_t TOPK_CAP = TOPK_MAX + AND_WG; // survivors + one wave of newcomers
+
+struct TopK {
+        double s[TOPK_CAP];
+        uint32_t d[TOPK_CAP];
+        uint32_t n;       // entries held (uniform)
+        uint32_t full;    // n has reached k at least once => thr_* valid
+        double thr_s;     // the k-th best entry
+        uint32_t thr_d;
+};
+
+__device__ __forceinline__ bool better(const double s1, const uint32_t d1, const double s2, const uint32_t d2) {
+        return s1 > s2 || (s1 == s2 && d1 < d2);
+}
+
+// Keep the best k of the n entries, sorted best-first (rank by counting: the order is strict, ranks are unique).
+__device__ void topk_prune(TopK &tk, const uint32_t k, uint32_t *scan) {
+        const uint32_t tid = threadIdx.x;
+        const uint32_t n = uni(tk.n);
+        double es[2];
+        uint32_t ed[2], rk[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+                const uint32_t i = tid + r * AND_WG;
+                rk[r] = 0xffffffffu;
+                if (i < n) {
+                        es[r] = tk.s[i];
+                        ed[r] = tk.d[i];
+                        uint32_t c = 0;
+                        for (uint32_t j = 0; j < n; ++j)
+                                c += better(tk.s[j], tk.d[j], es[r], ed[r]) ? 1u : 0u;
+                        rk[r] = c;
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+                if (rk[r] < k) {
+                        tk.s[rk[r]] = es[r];
+                        tk.d[rk[r]] = ed[r];
+                }
+        __syncthreads();
+        const uint32_t m = n < k ? n : k;
+        // uniform stores by every lane (no single-lane branch around the barrier loop that calls us)
+        tk.n = m;
+        if (m == k) {
+                tk.full = 1;
+                tk.thr_s = tk.s[k - 1];
+                tk.thr_d = tk.d[k - 1];
+        }
+        (void)scan;
+        __syncthreads();
+}
+
+// Every lane offers at most one (score, doc); survivors of the threshold are appended, pruning when the buffer fills.
+__device__ void topk_offer(TopK &tk, const uint32_t k, const bool valid, const double sc, const uint32_t doc, uint32_t *scan) {
+        const uint32_t tid = threadIdx.x;
+        const uint32_t n0 = uni(tk.n); // stable: the previous call ended with a barrier
+        const bool take = valid && (!tk.full || better(sc, doc, tk.thr_s, tk.thr_d));
+        const uint64_t m = __ballot(take);
+        const uint32_t lane = tid & 63;
+        const uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+        scan[tid >> 6] = __popcll(m);
+        __syncthreads();
+        uint32_t base = n0, tot = 0;
+        for (uint32_t w = 0; w < AND_WG / 64; ++w) {
+                if (w < (tid >> 6))
+                        base += scan[w];
+                tot += scan[w];
+        }
+        tot = uni(tot);
+        if (take) {
+                tk.s[base + before] = sc;
+                tk.d[base + before] = doc;
+        }
+        __syncthreads();
+        tk.n = n0 + tot; // same value from every lane
+        __syncthreads();
+        if (n0 + tot > TOPK_MAX)
+                topk_prune(tk, k, scan);
+}
+
+struct ScoreShared {
+        uint32_t cand[SCORE_TILE];
+        double score[SCORE_TILE];
+        uint32_t blkof[AND_WG + 1];
+        uint32_t scan[8];
+        uint32_t bcast[4];
+        TopK tk;
+};
+
+__device__ __forceinline__ float bm25_term(const double idf, const uint32_t freq32) {
+        const uint16_t freq = (uint16_t)freq32; // PostingsListIterator::freq is tokenpos_t (codecs.h:217)
+        return (float)(idf * (double)(float)freq / (double)((float)freq + 1.2f));
+}
+
+__global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                  const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
+                                                  const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
+                                                  const uint32_t *__restrict__ sched, const uint32_t *__restrict__ sterms,
+                                                  const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket,
+                                                  const uint32_t *__restrict__ out, const uint32_t *__restrict__ counts, const uint32_t k,
+                                                  uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
+                                                  uint32_t *__restrict__ part_counts) {
+        __shared__ ScoreShared sh;
+        const uint32_t tid = threadIdx.x;
+        const uint32_t wave = uni(tid >> 6);
+        for (;;) {
+                if (wave == 0) {
+                        const uint32_t old = atomicAdd(ticket, 1u);
+                        sh.bcast[0] = uni(old) >> 6;
+                }
+                __syncthreads();
+                const uint32_t ticket_no = uni(sh.bcast[0]);
+                __syncthreads();
+                if (ticket_no >= ntasks)
+                        break;
+                const uint32_t tix = sched[ticket_no];
+                const DevTask task = tasks[tix];
+                const DevQuery q = plan[task.slot];
+                const uint32_t M = counts[tix];
+                const uint32_t *seg = out + task.out_off;
+                sh.tk.n = 0;
+                sh.tk.full = 0;
+                __syncthreads();
+                for (uint32_t tb = 0; tb < M; tb += SCORE_TILE) {
+                        const uint32_t C = min(SCORE_TILE, M - tb);
+                        for (uint32_t j = tid; j < C; j += AND_WG) {
+                                sh.cand[j] = seg[tb + j];
+                                sh.score[j] = 0.0;
+                        }
+                        __syncthreads();
+                        for (uint32_t ti = 0; ti < q.nscore; ++ti) {
+                                const DevTerm t = terms[sterms[q.score_base + ti]];
+                                const double w = sweights[q.score_base + ti];
+                                const uint32_t *bl = blk_last + t.first_block;
+                                const uint32_t *bo = blk_off + t.first_block;
+                                sh.blkof[0] = 0xffffffffu;
+                                __syncthreads();
+                                for (uint32_t base = 0; base < C; base += AND_WG) {
+                                        const uint32_t j = base + tid;
+                                        uint32_t bj = 0xffffffffu, cv = 0;
+                                        if (j < C) {
+                                                cv = sh.cand[j];
+                                                uint32_t lo = 0, hi = t.nblocks;
+                                                while (lo < hi) {
+                                                        const uint32_t mid = (lo + hi) >> 1;
+                                                        if (bl[mid] < cv)
+                                                                lo = mid + 1;
+                                                        else
+                                                                hi = mid;
+                                                }
+                                                bj = lo;
+                                        }
+                                        sh.blkof[tid + 1] = bj;
+                                        __syncthreads();
+                                        const uint32_t prevb = sh.blkof[tid];
+                                        __syncthreads();
+                                        {
+                                                const uint32_t lastb = __shfl(bj, 63, 64);
+                                                const bool lastwave = (tid >> 6) == (AND_WG / 64 - 1);
+                                                sh.blkof[lastwave ? 0 : tid + 1] = lastwave ? lastb : bj;
+                                        }
+                                        if (j < C && bj < t.nblocks && bj != prevb) {
+                                                const uint32_t prev = bj ? bl[bj - 1] : 0;
+                                                const uint32_t last = bl[bj];
+                                                const uint32_t off = bo[bj];
+                                                const uint32_t n = index[off - 1];
+                                                VbStream s;
+                                                s.init(index + off);
+                                                // deltas: mark the block positions that hold a match (matches are consecutive
+                                                // candidates starting at j: every candidate is a document of this list)
+                                                uint32_t doc = prev, ptr = j, mask = 0;
+                                                for (uint32_t i = 0; i < n; ++i) {
+                                                        doc = (i + 1 < n) ? doc + s.next() : last;
+                                                        if (cv == doc) {
+                                                                mask |= 1u << i;
+                                                                ++ptr;
+                                                                cv = ptr < C ? sh.cand[ptr] : 0xffffffffu;
+                                                        }
+                                                }
+                                                // freqs follow the n-1 deltas
+                                                ptr = j;
+                                                for (uint32_t i = 0; i < n; ++i) {
+                                                        const uint32_t f = s.next();
+                                                        if ((mask >> i) & 1u) {
+                                                                sh.score[ptr] += (double)bm25_term(w, f);
+                                                                ++ptr;
+                                                        }
+                                                }
+                                        }
+                                        __syncthreads();
+                                }
+                        }
+                        // offer the tile to the task's top-K
+                        for (uint32_t base = 0; base < C; base += AND_WG) {
+                                const uint32_t j = base + tid;
+                                topk_offer(sh.tk, k, j < C, j < C ? sh.score[j] : 0.0, j < C ? sh.cand[j] : 0u, sh.scan);
+                        }
+                        __syncthreads();
+                }
+                topk_prune(sh.tk, k, sh.scan);
+                const uint32_t n = uni(sh.tk.n);
+                for (uint32_t i = tid; i < n; i += AND_WG) {
+                        part_docs[(uint64_t)tix * k + i] = sh.tk.d[i];
+                        part_scores[(uint64_t)tix * k + i] = sh.tk.s[i];
+                }
+                if (wave == 0)
+                        part_counts[tix] = n;
+                __syncthreads();
+        }
+}
+
+// one workgroup per query: stream the tasks' partial lists through the same top-K structure
+__global__ __launch_bounds__(AND_WG) void k_topk_merge(const DevQuery *__restrict__ plan, const uint32_t nq, const uint32_t k,
+                                                       const uint32_t *__restrict__ part_docs, const double *__restrict__ part_scores,
+                                                       const uint32_t *__restrict__ part_counts, uint32_t *__restrict__ top_docs,
+                                                       float *__restrict__ top_scores, uint32_t *__restrict__ top_counts) {
+        __shared__ TopK tk;
+        __shared__ uint32_t scan[8];
+        const uint32_t tid = threadIdx.x;
+        for (uint32_t slot = blockIdx.x; slot < nq; slot += gridDim.x) {
+                const DevQuery q = plan[slot];
+                tk.n = 0;
+                tk.full = 0;
+                __syncthreads();
+                for (uint32_t t = 0; t < q.ntasks; ++t) {
+                        const uint32_t tix = q.first_task + t;
+                        const uint32_t c = part_counts[tix];
+                        for (uint32_t base = 0; base < c; base += AND_WG) {
+                                const uint32_t i = base + tid;
+                                const bool v = i < c;
+                                topk_offer(tk, k, v, v ? part_scores[(uint64_t)tix * k + i] : 0.0, v ? part_docs[(uint64_t)tix * k + i] : 0u, scan);
+                        }
+                }
+                topk_prune(tk, k, scan);
+                const uint32_t n = uni(tk.n);
+                for (uint32_t i = tid; i < k; i += AND_WG) {
+                        top_docs[(uint64_t)q.qid * k + i] = i < n ? tk.d[i] : 0u;
+                        top_scores[(uint64_t)q.qid * k + i] = i < n ? (float)tk.s[i] : 0.0f;
+                }
+                if (uni(tid >> 6) == 0)
+                        top_counts[q.qid] = n;
+                __syncthreads();
+        }
+}
+
 // FNV-1a(64) of each query's docID set (little-endian bytes), one lane per query — verification helper
 __global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks_by_query,
                                const uint32_t *__restrict__ counts_by_query, const uint32_t nq, const uint32_t *__restrict__ out,
@@ -1087,15 +1354,16 @@ namespace {
 
 extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog_len, const tri_query *queries, size_t nq, const double *weights,
                                 uint32_t flags, uint32_t topk, int similarity, tri_batch **out) {
-        (void)weights;
-        (void)similarity;
         if (!ix || !out || (!prog && prog_len) || (!queries && nq))
                 return fail(TRI_ERR_INVALID, "tri_batch_create: null argument");
         const uint32_t mode = flags & (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE);
         if (mode == 0 || mode == (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE))
                 return fail(TRI_ERR_INVALID, "DocumentsOnly and AccumulatedScoreScheme are mutually exclusive; the default rich mode is not lowered (exec.h:45-48)");
-        if (mode != TRI_FLAG_DOCUMENTS_ONLY)
-                return fail(TRI_ERR_UNSUPPORTED, "AccumulatedScoreScheme not lowered yet");
+        const bool scored = mode == TRI_FLAG_ACCUMULATED_SCORE;
+        if (scored && (topk < 1 || topk > TOPK_MAX))
+                return fail(TRI_ERR_INVALID, "AccumulatedScoreScheme needs 1 <= topk <= %u", TOPK_MAX);
+        if (scored && similarity != TRI_SIM_BM25)
+                return fail(TRI_ERR_UNSUPPORTED, "only TRI_SIM_BM25 is lowered");
         tri_dev *dev = ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
         auto b = std::make_unique<tri_batch>();
@@ -1140,6 +1408,39 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if (uniq.size() > 8)
                         return fail(TRI_ERR_UNSUPPORTED, "query %zu: more than 8 conjuncts", qi);
                 Tmp t;
+                t.q.score_base = (uint32_t)b->sterms.size();
+                t.q.nscore = 0;
+                if (scored) {
+                        // one scorer per PostingsListIterator of the conjunction, summed in iterator order
+                        // (docset_iterators_scorers.cpp:173-193); weight = BM25 idf (similarity.h:179-181, float math)
+                        // unless the caller supplied ScorerWeights per TERM token
+                        std::vector<std::pair<uint32_t, double>> sc;
+                        if (r.op == TRI_OP_TERM)
+                                sc.emplace_back(r.term, 0.0);
+                        else
+                                for (int k : r.kids)
+                                        sc.emplace_back(nodes[k].term, 0.0);
+                        for (auto &e : sc) {
+                                const uint32_t df = ix->terms[e.first].documents;
+                                const float num = (float)((uint64_t)ix->info.docs_cnt - (uint64_t)df) + 0.5f;
+                                const float den = (float)df + 0.5f;
+                                e.second = (double)std::log(1 + num / den);
+                        }
+                        if (weights) {
+                                // caller-provided weights follow the program's TERM tokens; map by first occurrence
+                                for (auto &e : sc)
+                                        for (uint32_t pi = 0; pi < tq.prog_len; ++pi)
+                                                if (prog[tq.prog_off + pi] == TRI_TOK(TRI_OP_TERM, e.first)) {
+                                                        e.second = weights[tq.prog_off + pi];
+                                                        break;
+                                                }
+                        }
+                        for (auto &e : sc) {
+                                b->sterms.push_back(e.first);
+                                b->sweights.push_back(e.second);
+                        }
+                        t.q.nscore = (uint32_t)sc.size();
+                }
                 t.q.nterms = (uint32_t)uniq.size();
                 t.q.term_base = (uint32_t)b->qterms.size();
                 t.q.out_cap = ix->terms[uniq[0]].documents; // |A ∩ …| <= min df
@@ -1222,10 +1523,22 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 return rc;
         HIP_TRY(hipMalloc((void **)&b->d_out, (off + 64) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_counts, (b->tasks.size() + 1) * 4));
-        HIP_TRY(hipMalloc((void **)&b->d_ticket, 64));
+        HIP_TRY(hipMalloc((void **)&b->d_ticket, 256));
+        if (scored) {
+                if ((rc = dev_upload(&b->d_sterms, b->sterms)) || (rc = dev_upload(&b->d_sweights, b->sweights)))
+                        return rc;
+                const size_t nt = b->tasks.size();
+                HIP_TRY(hipMalloc((void **)&b->d_part_docs, (nt * topk + 1) * 4));
+                HIP_TRY(hipMalloc((void **)&b->d_part_scores, (nt * topk + 1) * 8));
+                HIP_TRY(hipMalloc((void **)&b->d_part_counts, (nt + 1) * 4));
+                HIP_TRY(hipMalloc((void **)&b->d_top_docs, (nq * topk + 1) * 4));
+                HIP_TRY(hipMalloc((void **)&b->d_top_scores, (nq * topk + 1) * 4));
+                HIP_TRY(hipMalloc((void **)&b->d_top_counts, (nq + 1) * 4));
+                HIP_TRY(hipMemset(b->d_top_counts, 0, (nq + 1) * 4)); // queries that can never match keep count 0
+        }
         b->info.nqueries = nq;
         b->info.out_capacity = off;
-        b->info.launches = 1;
+        b->info.launches = scored ? 3 : 1;
         *out = b.release();
         return TRI_OK;
 }
@@ -1242,6 +1555,14 @@ extern "C" void tri_batch_destroy(tri_batch *b) {
         hipFree(b->d_counts);
         hipFree(b->d_ticket);
         hipFree(b->d_hashes);
+        hipFree(b->d_sterms);
+        hipFree(b->d_sweights);
+        hipFree(b->d_part_docs);
+        hipFree(b->d_part_scores);
+        hipFree(b->d_part_counts);
+        hipFree(b->d_top_docs);
+        hipFree(b->d_top_scores);
+        hipFree(b->d_top_counts);
         delete b;
 }
 
@@ -1263,11 +1584,21 @@ extern "C" int tri_batch_run(tri_batch *b) {
 #endif
         HIP_TRY(hipEventRecord(dev->ev0, dev->stream));
         if (n) {
-                HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 4, dev->stream));
+                HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 256, dev->stream));
                 const uint32_t grid = std::min<uint32_t>(n, (uint32_t)dev->cus * 4);
                 hipLaunchKernelGGL(k_and, dim3(grid), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms,
                                    b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, n, b->d_ticket, b->d_out, b->d_counts);
                 HIP_TRY(hipGetLastError());
+                if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
+                        hipLaunchKernelGGL(k_score, dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 2)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
+                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, n,
+                                           b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts);
+                        HIP_TRY(hipGetLastError());
+                        const uint32_t nqs = (uint32_t)b->plan.size();
+                        hipLaunchKernelGGL(k_topk_merge, dim3(std::min<uint32_t>(nqs, (uint32_t)dev->cus * 8)), dim3(AND_WG), 0, dev->stream, b->d_plan, nqs,
+                                           b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->d_top_docs, b->d_top_scores, b->d_top_counts);
+                        HIP_TRY(hipGetLastError());
+                }
         }
         HIP_TRY(hipEventRecord(dev->ev1, dev->stream));
         return TRI_OK;
@@ -1317,7 +1648,13 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 m += b->h_query_counts[sidx];
         }
         b->info.matches = m;
-        b->info.algorithmic_bytes = b->term_bytes + 4 * m; // docbytes + 4 B per match (docs-only)
+        if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
+                uint64_t outb = 0; // 8 B x min(matches, K) per query
+                for (uint64_t c : b->h_query_counts)
+                        outb += 8 * std::min<uint64_t>(c, b->topk);
+                b->info.algorithmic_bytes = b->term_bytes + outb;
+        } else
+                b->info.algorithmic_bytes = b->term_bytes + 4 * m; // docbytes + 4 B per match (docs-only)
         b->synced = true;
         return TRI_OK;
 }
@@ -1389,5 +1726,27 @@ extern "C" int tri_batch_docset_hashes(tri_batch *b, uint64_t *hashes) {
         return TRI_OK;
 }
 
-extern "C" int tri_batch_topk(tri_batch *, uint32_t *, float *, uint32_t *) { return fail(TRI_ERR_UNSUPPORTED, "AccumulatedScoreScheme not lowered yet"); }
-extern "C" int tri_batch_topk_device(tri_batch *, void **, void **, void **) { return fail(TRI_ERR_UNSUPPORTED, "AccumulatedScoreScheme not lowered yet"); }
+extern "C" int tri_batch_topk(tri_batch *b, uint32_t *docids, float *scores, uint32_t *counts) {
+        if (!b || !docids || !scores || !counts)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (!(b->flags & TRI_FLAG_ACCUMULATED_SCORE))
+                return fail(TRI_ERR_INVALID, "batch was not created with TRI_FLAG_ACCUMULATED_SCORE");
+        if (!b->synced)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync first");
+        HIP_TRY(hipSetDevice(b->ix->dev->device));
+        HIP_TRY(hipMemcpy(docids, b->d_top_docs, b->nq * b->topk * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(scores, b->d_top_scores, b->nq * b->topk * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(counts, b->d_top_counts, b->nq * 4, hipMemcpyDeviceToHost));
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_topk_device(tri_batch *b, void **docids, void **scores, void **counts) {
+        if (!b || !docids || !scores || !counts)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (!(b->flags & TRI_FLAG_ACCUMULATED_SCORE))
+                return fail(TRI_ERR_INVALID, "batch was not created with TRI_FLAG_ACCUMULATED_SCORE");
+        *docids = b->d_top_docs;
+        *scores = b->d_top_scores;
+        *counts = b->d_top_counts;
+        return TRI_OK;
+}
