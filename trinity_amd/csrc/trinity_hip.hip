@@ -58,8 +58,13 @@ struct DevTerm {
         uint32_t last_n; // docs in the final block (1..32)
 };
 
-struct DevQuery {      // one conjunctive query (v1)
-        uint32_t nterms;    // >= 1, evaluation order = ascending df (exec.cpp:154-170)
+// A query in conjunctive normal form: AND of groups, a group = one term or an OR of terms.  qterms[] lists the terms
+// group by group, cheapest group first (exec.cpp:35-110 cost model); bit 31 marks the first term of a group.
+// Root OR of terms == a single group.  (Conjuction / DisjunctionAllPLI semantics, docset_iterators.cpp:226-405.)
+constexpr uint32_t QT_GROUP = 0x80000000u;
+constexpr uint32_t MAX_QTERMS = 16;
+struct DevQuery {
+        uint32_t nterms;    // total terms over all groups (<= MAX_QTERMS)
         uint32_t term_base; // into qterms[]
         uint64_t out_off;   // docID slots
         uint32_t out_cap;
@@ -321,7 +326,7 @@ struct AndShared {
         uint32_t tbase[AND_WG];
         uint32_t scan[8];
         uint32_t bcast[4];
-        uint32_t lcur[8]; // per term: directory cursor, uniform across the workgroup
+        uint32_t lcur[16]; // per term: directory cursor, uniform across the workgroup
 };
 
 // Workgroup-cooperative lower bound over a sorted global array: first i in [0, n) with a[i] >= key, else n.
@@ -544,53 +549,93 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
         const uint32_t tid = threadIdx.x;
         uint32_t *qout = out + task.out_off;
         uint32_t produced = 0;
-        sh.lcur[tid & 7] = 0xffffffffu;
+        sh.lcur[tid & 15] = 0; // per term: a block index at or before the first block that can matter
         __syncthreads();
-        bool exhausted = false; // uniform: some list has no documents at or beyond this window
-        for (uint32_t w = task.tile_begin; w < task.tile_end && !exhausted; ++w) {
+        // number of terms in the lead group (it creates the candidates; the other groups test them)
+        uint32_t nlead = 1;
+        while (nlead < q.nterms && !(qterms[q.term_base + nlead] & QT_GROUP))
+                ++nlead;
+        bool done = false; // uniform
+        for (uint32_t w = task.tile_begin; w < task.tile_end && !done;) {
+                // ---- skip windows no lead-group list reaches: position the lead cursors at w, look at the first
+                //      document each may hold at or after it
+                uint32_t wnext = 0xffffffffu;
+                for (uint32_t k = 0; k < nlead; ++k) {
+                        const DevTerm t = terms[qterms[q.term_base + k] & ~QT_GROUP];
+                        const uint32_t *bl = blk_last + t.first_block;
+                        uint32_t cur = uni(sh.lcur[k]);
+                        if (cur < t.nblocks && bl[cur] < w * SPAN_BITS)
+                                cur += wg_lower_bound(sh, bl + cur, t.nblocks - cur, w * SPAN_BITS);
+                        __syncthreads();
+                        sh.lcur[k] = cur;
+                        if (cur < t.nblocks) {
+                                const uint32_t first_possible = cur ? bl[cur - 1] + 1 : 1;
+                                wnext = min(wnext, max(w, first_possible / SPAN_BITS));
+                        }
+                }
+                __syncthreads();
+                if (wnext >= task.tile_end)
+                        break; // the lead group holds nothing more in this task's range
+                w = wnext;
                 const uint32_t w0 = w * SPAN_BITS;
                 const uint32_t wlast = w0 + (SPAN_BITS - 1);
+                uint32_t gi = 0;       // group index
+                bool galive = false;   // some term of the current group reaches this window or beyond
                 for (uint32_t k = 0; k < q.nterms; ++k) {
-                        const DevTerm t = terms[qterms[q.term_base + k]];
+                        const uint32_t tt = qterms[q.term_base + k];
+                        const DevTerm t = terms[tt & ~QT_GROUP];
                         const uint32_t *bl = blk_last + t.first_block;
                         const uint32_t *bo = blk_off + t.first_block;
-                        uint32_t *dst = sh.bits[k & 1];
-                        const uint32_t *src = sh.bits[(k & 1) ^ 1];
-                        for (uint32_t i = tid; i < SPAN_WORDS; i += AND_WG)
-                                dst[i] = 0;
+                        if (k && (tt & QT_GROUP)) {
+                                if (!galive) { // an exhausted conjunct: no further match anywhere
+                                        done = true;
+                                        break;
+                                }
+                                ++gi;
+                                galive = false;
+                        }
+                        uint32_t *dst = sh.bits[gi & 1];
+                        const uint32_t *src = sh.bits[(gi & 1) ^ 1];
+                        if (tt & QT_GROUP)
+                                for (uint32_t i = tid; i < SPAN_WORDS; i += AND_WG)
+                                        dst[i] = 0;
                         // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
                         uint32_t b_lo = uni(sh.lcur[k]);
-                        if (b_lo == 0xffffffffu)
-                                b_lo = wg_lower_bound(sh, bl, t.nblocks, w0);
-                        if (b_lo >= t.nblocks) {
-                                exhausted = true;
-                                break;
+                        if (b_lo < t.nblocks && bl[b_lo] < w0)
+                                b_lo += wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, w0);
+                        uint32_t b_hi = b_lo;
+                        if (b_lo < t.nblocks) {
+                                galive = true;
+                                b_hi = b_lo + wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, wlast);
+                                if (b_hi >= t.nblocks)
+                                        b_hi = t.nblocks - 1;
                         }
-                        uint32_t b_hi = b_lo + wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, wlast);
-                        if (b_hi >= t.nblocks)
-                                b_hi = t.nblocks - 1;
-                        __syncthreads(); // dst cleared, previous pass complete
-                        sh.lcur[k] = b_hi;
-                        for (uint32_t cb = b_lo; cb <= b_hi; cb += AND_WG) {
-                                const uint32_t b = cb + tid;
-                                if (b <= b_hi) {
-                                        const uint32_t prev = b ? bl[b - 1] : 0;
-                                        const uint32_t last = bl[b];
-                                        const uint32_t off = bo[b];
-                                        const uint32_t n = index[off - 1];
-                                        if (k == 0)
-                                                dense_block<true>(index, off, n, prev, last, w0, src, dst);
-                                        else
-                                                dense_block<false>(index, off, n, prev, last, w0, src, dst);
+                        __syncthreads(); // dst cleared, earlier passes complete, cursor reads done
+                        sh.lcur[k] = b_lo < t.nblocks ? b_hi : b_lo;
+                        if (b_lo < t.nblocks) {
+                                for (uint32_t cb = b_lo; cb <= b_hi; cb += AND_WG) {
+                                        const uint32_t b = cb + tid;
+                                        if (b <= b_hi) {
+                                                const uint32_t prev = b ? bl[b - 1] : 0;
+                                                const uint32_t last = bl[b];
+                                                const uint32_t off = bo[b];
+                                                const uint32_t n = index[off - 1];
+                                                if (gi == 0)
+                                                        dense_block<true>(index, off, n, prev, last, w0, src, dst);
+                                                else
+                                                        dense_block<false>(index, off, n, prev, last, w0, src, dst);
+                                        }
                                 }
                         }
                         __syncthreads();
                 }
-                if (exhausted)
+                if (done || !galive) {
+                        done = true;
                         break;
+                }
                 // ---- expand the survivors bitmap into ascending docIDs
-                const uint32_t *fin = sh.bits[(q.nterms - 1) & 1];
-                uint32_t *pre = sh.bits[q.nterms & 1]; // the other bitmap is dead: per-word exclusive prefix
+                const uint32_t *fin = sh.bits[gi & 1];
+                uint32_t *pre = sh.bits[(gi & 1) ^ 1]; // the other bitmap is dead: per-word exclusive prefix
                 {
                         uint32_t run = 0;
                         for (uint32_t j = 0; j < SPAN_WORDS / AND_WG; ++j) {
@@ -623,6 +668,7 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
                         produced += uni(total);
                         __syncthreads();
                 }
+                ++w;
         }
         __syncthreads();
         if (uni(tid >> 6) == 0)
@@ -659,11 +705,11 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                         dense_task(sh, index, blk_last, blk_off, terms, qterms, q, task, out, counts + tix);
                         continue;
                 }
-                const DevTerm lead = terms[qterms[q.term_base]];
+                const DevTerm lead = terms[qterms[q.term_base] & ~QT_GROUP];
                 TRACE(1, slot, q.nterms);
                 uint32_t *qout = out + task.out_off;
                 uint32_t produced = 0;
-                sh.lcur[tid & 7] = 0xffffffffu; // "not positioned yet"
+                sh.lcur[tid & 15] = 0xffffffffu; // "not positioned yet"
                 const uint32_t tb_end = min(lead.nblocks, task.tile_end * TILE_BLOCKS);
 
                 for (uint32_t tb = task.tile_begin * TILE_BLOCKS; tb < tb_end; tb += TILE_BLOCKS) {
@@ -688,12 +734,15 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                         __syncthreads();
                         TRACE(2, slot, tb);
 
-                        // ---- every other term filters the surviving candidates
+                        // ---- every other group filters the surviving candidates: a candidate survives a group when any
+                        //      of the group's terms holds it (hit bits are OR-ed across the group's terms)
                         for (uint32_t k = 1; k < q.nterms && C; ++k) {
-                                const DevTerm t = terms[qterms[q.term_base + k]];
-                                sh.hit[tid] = 0;
+                                const uint32_t tt = qterms[q.term_base + k];
+                                const DevTerm t = terms[tt & ~QT_GROUP];
+                                if (tt & QT_GROUP)
+                                        sh.hit[tid] = 0;
                                 __syncthreads();
-                #if defined(TRI_FORCE_CAND)
+#if defined(TRI_FORCE_CAND)
                                 const bool bd = false;
 #elif defined(TRI_FORCE_BLOCK)
                                 const bool bd = true;
@@ -704,6 +753,9 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                 and_filter_tile(sh, index, blk_last, blk_off, t, C, k - 1, bd);
                                 TRACE(4, slot, C);
                                 __syncthreads();
+                                const bool lastterm = k + 1 == q.nterms;
+                                if (!lastterm && !(qterms[q.term_base + k + 1] & QT_GROUP))
+                                        continue; // more terms of this OR group to come
                                 // compact survivors (stable => still ascending)
                                 const uint32_t bits = sh.hit[tid];
                                 const uint32_t cnt = __popc(bits);
@@ -718,8 +770,8 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                         total += sh.scan[w];
                                 }
                                 ex += wbase;
-                                if (k + 1 == q.nterms) {
-                                        // last conjunct: survivors go straight to the result, ascending
+                                if (lastterm) {
+                                        // last group: survivors go straight to the result, ascending
                                         uint32_t m = bits, o = produced + ex;
                                         while (m) {
                                                 const uint32_t kbit = __builtin_ctz(m);
@@ -854,6 +906,7 @@ __device__ void topk_offer(TopK &tk, const uint32_t k, const bool valid, const d
 struct ScoreShared {
         uint32_t cand[SCORE_TILE];
         double score[SCORE_TILE];
+        uint32_t hit[SCORE_TILE / 32]; // per scoring term: which matches this term holds
         uint32_t blkof[AND_WG + 1];
         uint32_t scan[8];
         uint32_t bcast[4];
@@ -907,6 +960,8 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                 const uint32_t *bl = blk_last + t.first_block;
                                 const uint32_t *bo = blk_off + t.first_block;
                                 sh.blkof[0] = 0xffffffffu;
+                                if (tid < SCORE_TILE / 32)
+                                        sh.hit[tid] = 0;
                                 __syncthreads();
                                 for (uint32_t base = 0; base < C; base += AND_WG) {
                                         const uint32_t j = base + tid;
@@ -939,22 +994,29 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                                 const uint32_t n = index[off - 1];
                                                 VbStream s;
                                                 s.init(index + off);
-                                                // deltas: mark the block positions that hold a match (matches are consecutive
-                                                // candidates starting at j: every candidate is a document of this list)
+                                                // deltas: merge the block's documents against the matches from j on; remember
+                                                // the block positions (mask) and the matches (hit bits) that coincide.  Under an
+                                                // OR a match need not be a document of this list.
                                                 uint32_t doc = prev, ptr = j, mask = 0;
                                                 for (uint32_t i = 0; i < n; ++i) {
                                                         doc = (i + 1 < n) ? doc + s.next() : last;
-                                                        if (cv == doc) {
-                                                                mask |= 1u << i;
+                                                        while (cv < doc) {
                                                                 ++ptr;
                                                                 cv = ptr < C ? sh.cand[ptr] : 0xffffffffu;
                                                         }
+                                                        if (cv == doc) {
+                                                                mask |= 1u << i;
+                                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
+                                                        }
                                                 }
-                                                // freqs follow the n-1 deltas
+                                                // freqs follow the n-1 deltas; the i-th marked position belongs to the i-th
+                                                // marked match (both ascending; only this lane marks matches in its block's range)
                                                 ptr = j;
                                                 for (uint32_t i = 0; i < n; ++i) {
                                                         const uint32_t f = s.next();
                                                         if ((mask >> i) & 1u) {
+                                                                while (!((sh.hit[ptr >> 5] >> (ptr & 31)) & 1u))
+                                                                        ++ptr;
                                                                 sh.score[ptr] += (double)bm25_term(w, f);
                                                                 ++ptr;
                                                         }
@@ -1375,6 +1437,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         struct Tmp {
                 DevQuery q;
                 uint64_t cost;
+                uint32_t nlead;
         };
         std::vector<Tmp> tmp;
         std::vector<PNode> nodes;
@@ -1389,24 +1452,57 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const PNode &r = nodes[root];
                 if (r.empty)
                         continue; // matches nothing (compiles to constfalse in the reference)
-                std::vector<uint32_t> ts;
-                if (r.op == TRI_OP_TERM)
-                        ts.push_back(r.term);
-                else if (r.op == TRI_OP_AND) {
-                        for (int k : r.kids) {
-                                if (nodes[k].op != TRI_OP_TERM)
-                                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: only conjunctions of terms are lowered so far", qi);
-                                ts.push_back(nodes[k].term);
-                        }
-                } else
-                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: only conjunctions of terms are lowered so far", qi);
-                // a term repeated inside a conjunction adds nothing to a docs-only result
-                std::vector<uint32_t> uniq;
-                for (uint32_t t : ts)
-                        if (std::find(uniq.begin(), uniq.end(), t) == uniq.end())
-                                uniq.push_back(t);
-                if (uniq.size() > 8)
-                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: more than 8 conjuncts", qi);
+                // ---- conjunctive normal form over terms: AND of (term | OR of terms); a root OR is one group
+                std::vector<std::vector<uint32_t>> groups;
+                std::vector<uint32_t> leaves; // every TERM leaf in evaluation order: one scorer each
+                auto add_group = [&](const PNode &g) -> bool {
+                        std::vector<uint32_t> ts;
+                        if (g.op == TRI_OP_TERM)
+                                ts.push_back(g.term);
+                        else if (g.op == TRI_OP_OR) {
+                                for (int k : g.kids) {
+                                        if (nodes[k].op != TRI_OP_TERM)
+                                                return false;
+                                        ts.push_back(nodes[k].term);
+                                }
+                        } else
+                                return false;
+                        leaves.insert(leaves.end(), ts.begin(), ts.end());
+                        // a term repeated inside a group, or a single-term group seen before, adds nothing to the docID set
+                        std::vector<uint32_t> u;
+                        for (uint32_t x : ts)
+                                if (std::find(u.begin(), u.end(), x) == u.end())
+                                        u.push_back(x);
+                        if (u.size() == 1)
+                                for (const auto &og : groups)
+                                        if (og.size() == 1 && og[0] == u[0])
+                                                return true;
+                        groups.push_back(std::move(u));
+                        return true;
+                };
+                bool ok = true;
+                if (r.op == TRI_OP_AND)
+                        for (int k : r.kids)
+                                ok &= add_group(nodes[k]);
+                else
+                        ok = add_group(r);
+                if (!ok)
+                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: only AND of terms / OR-of-terms groups (and a root OR of terms) are lowered so far", qi);
+                auto gcost = [&](const std::vector<uint32_t> &g) {
+                        uint64_t c = 0;
+                        for (uint32_t x : g)
+                                c += ix->terms[x].documents;
+                        return c;
+                };
+                std::stable_sort(groups.begin(), groups.end(), [&](const auto &x, const auto &y) { return gcost(x) < gcost(y); });
+                std::vector<uint32_t> uniq; // terms group by group, QT_GROUP on the first of each group
+                for (const auto &g : groups)
+                        for (size_t i = 0; i < g.size(); ++i)
+                                uniq.push_back(g[i] | (i == 0 ? QT_GROUP : 0u));
+                if (uniq.size() > MAX_QTERMS)
+                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: more than %u terms", qi, MAX_QTERMS);
+                const uint32_t nlead = (uint32_t)groups[0].size();
+                const uint64_t lead_docs = gcost(groups[0]);
                 Tmp t;
                 t.q.score_base = (uint32_t)b->sterms.size();
                 t.q.nscore = 0;
@@ -1415,11 +1511,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         // (docset_iterators_scorers.cpp:173-193); weight = BM25 idf (similarity.h:179-181, float math)
                         // unless the caller supplied ScorerWeights per TERM token
                         std::vector<std::pair<uint32_t, double>> sc;
-                        if (r.op == TRI_OP_TERM)
-                                sc.emplace_back(r.term, 0.0);
-                        else
-                                for (int k : r.kids)
-                                        sc.emplace_back(nodes[k].term, 0.0);
+                        for (uint32_t x : leaves)
+                                sc.emplace_back(x, 0.0);
                         for (auto &e : sc) {
                                 const uint32_t df = ix->terms[e.first].documents;
                                 const float num = (float)((uint64_t)ix->info.docs_cnt - (uint64_t)df) + 0.5f;
@@ -1443,15 +1536,26 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 }
                 t.q.nterms = (uint32_t)uniq.size();
                 t.q.term_base = (uint32_t)b->qterms.size();
-                t.q.out_cap = ix->terms[uniq[0]].documents; // |A ∩ …| <= min df
+                t.q.out_cap = 0;
                 t.q.out_off = 0;
                 t.q.qid = (uint32_t)qi;
                 t.cost = 0;
-                for (uint32_t term : uniq) {
-                        b->qterms.push_back(term);
-                        b->term_bytes += ix->docbytes[term];
-                        // cost estimate: the lead is decoded fully; every other list costs min(its blocks, lead docs)
-                        t.cost += term == uniq[0] ? ix->terms[term].documents : 32ull * std::min<uint64_t>(ix->terms[term].nblocks, ix->terms[uniq[0]].documents);
+                t.nlead = nlead;
+                {
+                        std::vector<uint32_t> seen;
+                        for (uint32_t tt : uniq) {
+                                const uint32_t term = tt & ~QT_GROUP;
+                                b->qterms.push_back(tt);
+                                if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
+                                        seen.push_back(term);
+                                        b->term_bytes += ix->docbytes[term];
+                                }
+                        }
+                        // cost estimate: the lead group is decoded fully; every other list costs min(its blocks x 32, lead docs x 32)
+                        for (size_t i = 0; i < uniq.size(); ++i) {
+                                const DevTerm &tk = ix->terms[uniq[i] & ~QT_GROUP];
+                                t.cost += i < nlead ? tk.documents : 32ull * std::min<uint64_t>(tk.nblocks, lead_docs);
+                        }
                 }
                 tmp.push_back(t);
         }
@@ -1469,35 +1573,54 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint32_t slot = (uint32_t)b->plan.size();
                 b->slot_of_query[t.q.qid] = slot;
                 const uint32_t *qt = &b->qterms[t.q.term_base];
-                const DevTerm &lead = ix->terms[qt[0]];
-                // TASK_DENSE when every other list is within a factor 32 of the lead (no block can be skipped anyway)
-                // and there is enough work per docID window to keep 256 lanes busy
+                const DevTerm &lead = ix->terms[qt[0] & ~QT_GROUP];
+                const uint32_t nlead = t.nlead;
+                uint64_t lead_docs = 0;
+                for (uint32_t k = 0; k < nlead; ++k)
+                        lead_docs += ix->terms[qt[k] & ~QT_GROUP].documents;
+                // TASK_DENSE (bitmap windows) when the lead group is an OR (it has to be materialised as a set anyway), or
+                // when every other list is within a factor 32 of the lead (no block could be skipped) and there is enough
+                // work per docID window to keep 256 lanes busy
                 uint64_t sumdf = 0;
                 bool dense = t.q.nterms >= 2;
-                uint32_t last_doc = 0xffffffffu;
+                uint32_t last_doc = 0xffffffffu, glast = 0; // no match beyond the group whose lists end first
                 for (uint32_t k = 0; k < t.q.nterms; ++k) {
-                        const DevTerm &tk = ix->terms[qt[k]];
+                        const DevTerm &tk = ix->terms[qt[k] & ~QT_GROUP];
                         sumdf += tk.documents;
-                        dense &= tk.nblocks <= lead.documents;
-                        last_doc = std::min(last_doc, ix->h_blk_last[tk.first_block + tk.nblocks - 1]);
+                        dense &= tk.nblocks <= lead_docs;
+                        if (k && (qt[k] & QT_GROUP)) {
+                                last_doc = std::min(last_doc, glast);
+                                glast = 0;
+                        }
+                        glast = std::max(glast, ix->h_blk_last[tk.first_block + tk.nblocks - 1]);
                 }
+                last_doc = std::min(last_doc, glast);
                 dense &= sumdf >= DENSE_MIN_POSTINGS;
+                dense |= nlead > 1;
                 t.q.out_off = off;
                 t.q.first_task = (uint32_t)b->tasks.size();
                 if (dense) {
-                        const uint32_t nwin = last_doc / SPAN_BITS + 1; // no match can lie beyond the shortest list's last document
+                        const uint32_t nwin = last_doc / SPAN_BITS + 1;
                         const uint64_t per_win = std::max<uint64_t>(1, sumdf / (ix->info.docs_cnt / SPAN_BITS + 1));
                         const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, TASK_COST / per_win);
-                        const uint32_t *lb = &ix->h_blk_last[lead.first_block];
                         uint32_t ord = 0;
+                        uint64_t lead_blocks = 0;
+                        for (uint32_t k = 0; k < nlead; ++k)
+                                lead_blocks += ix->terms[qt[k] & ~QT_GROUP].nblocks;
                         for (uint32_t wb = 0; wb < nwin; wb += win_per_task, ++ord) {
                                 const uint32_t we = std::min(nwin, wb + win_per_task);
-                                // matches of windows [wb, we) are lead documents of blocks b1 .. (next task's b1): a private region
-                                const uint32_t b1 = (uint32_t)(std::lower_bound(lb, lb + lead.nblocks, wb * SPAN_BITS) - lb);
+                                // matches of windows [wb, we) are lead-group documents of blocks b1 .. (next task's b1) of every
+                                // lead list: a private region (+32 slots of slack per lead list and task for the straddling block)
+                                uint64_t b1 = 0;
+                                for (uint32_t k = 0; k < nlead; ++k) {
+                                        const DevTerm &tk = ix->terms[qt[k] & ~QT_GROUP];
+                                        const uint32_t *lb = &ix->h_blk_last[tk.first_block];
+                                        b1 += (uint64_t)(std::lower_bound(lb, lb + tk.nblocks, wb * SPAN_BITS) - lb);
+                                }
                                 order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
-                                b->tasks.push_back({slot, wb, we, TASK_DENSE, off + (uint64_t)b1 * 32 + 32ull * ord});
+                                b->tasks.push_back({slot, wb, we, TASK_DENSE, off + b1 * 32 + 32ull * ord * nlead});
                         }
-                        t.q.out_cap = lead.nblocks * 32 + 32 * (ord + 1);
+                        t.q.out_cap = (uint32_t)std::min<uint64_t>(0xffffffffull, lead_blocks * 32 + 32ull * (ord + 1) * nlead);
                 } else {
                         const uint32_t ntiles = (lead.nblocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
                         const uint64_t per_tile = std::max<uint64_t>(1, t.cost / ntiles);
@@ -1507,6 +1630,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 order.emplace_back(per_tile * (te - tb), (uint32_t)b->tasks.size());
                                 b->tasks.push_back({slot, tb, te, TASK_CAND, off + (uint64_t)tb * TILE_CANDS});
                         }
+                        t.q.out_cap = lead.documents; // |A ∩ …| <= df of the lead
                 }
                 off += t.q.out_cap;
                 t.q.ntasks = (uint32_t)b->tasks.size() - t.q.first_task;
