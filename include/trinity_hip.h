@@ -123,7 +123,8 @@ int tri_decode_terms(tri_index *, const uint32_t *terms, size_t n, uint32_t *doc
  * top-K MatchedIndexDocumentsFilter::consider(id, score) heap (matches.h:155-171).
  *
  * prog/queries: postfix programs.  flags: TRI_FLAG_DOCUMENTS_ONLY (results = ascending docID sets) or
- * TRI_FLAG_ACCUMULATED_SCORE (results = top-K by score desc, docID asc + total match counts).
+ * TRI_FLAG_ACCUMULATED_SCORE (topk >= 1: results = top-K by score desc, docID asc + total match counts;
+ * topk == 0: every match's score is kept, see tri_batch_scores).
  * weights: optional, one double per program token (TERM tokens: the term's ScorerWeight, PHRASE tokens:
  * the phrase's); NULL => BM25 idf computed from the index's own statistics exactly as
  * IndexSourcesCollectionBM25Scorer does for a single source (similarity.h:179-181, 202-226). */
@@ -141,7 +142,10 @@ int tri_batch_match_counts(tri_batch *, uint64_t *counts /* [nq] */);
 /* DocumentsOnly: copy query q's ascending docID set; what MatchedIndexDocumentsFilter::consider(ids, cnt)
  * (matches.h:161-165) receives */
 int tri_batch_docset(tri_batch *, size_t q, uint32_t *out, size_t cap, size_t *n);
-/* AccumulatedScore: docids/scores are [nq][topk] row-major, counts[nq] = min(matches, topk) */
+/* AccumulatedScore with topk == 0: the score of every match of query q, parallel to tri_batch_docset(q) — the
+ * (id, score) stream MatchedIndexDocumentsFilter::consider(id, score) receives (matches.h:169; exec.cpp:1322-1341) */
+int tri_batch_scores(tri_batch *, size_t q, double *out, size_t cap, size_t *n);
+/* AccumulatedScore with topk >= 1: docids/scores are [nq][topk] row-major, counts[nq] = min(matches, topk) */
 int tri_batch_topk(tri_batch *, uint32_t *docids, float *scores, uint32_t *counts);
 /* device-resident result blocks for the multi-GPU gather (per rank: [nq][topk] u32 + f32, [nq] u32) */
 int tri_batch_topk_device(tri_batch *, void **docids, void **scores, void **counts);

@@ -1,0 +1,122 @@
+// host_mirror_test.cpp — exercises the C++ operator surface (trinity_gpu.hpp) the way an application written
+// against Trinity would: build an index source, build iterator trees, exec_query with a
+// MatchedIndexDocumentsFilter in DocumentsOnly and AccumulatedScoreScheme+BM25 modes, drive a
+// PostingsListIterator by hand.  Prints one line per check for the Python test to compare with the oracle.
+//   usage: host_mirror_test <index file> <terms file (u32 triples)> <docsCnt>
+#include "../../trinity_amd/csrc/host/trinity_gpu.hpp"
+#include <cinttypes>
+#include <cstdio>
+#include <fstream>
+
+using namespace trinity_amd;
+
+struct Collect final : public MatchedIndexDocumentsFilter {
+        std::vector<docid_t> ids;
+        std::vector<double> scores;
+        void consider(const docid_t id) override { ids.push_back(id); }
+        void consider(const docid_t id, const double s) override {
+                ids.push_back(id);
+                scores.push_back(s);
+        }
+};
+
+struct EvenOnly final : public IndexDocumentsFilter {
+        bool filter(const docid_t id) override { return id & 1; } // disregard odd documents
+};
+
+static uint64_t fnv(const std::vector<docid_t> &v) {
+        uint64_t h = 1469598103934665603ull;
+        for (auto d : v)
+                for (int b = 0; b < 4; ++b, d >>= 8)
+                        h = (h ^ (d & 0xff)) * 1099511628211ull;
+        return h;
+}
+
+int main(int argc, char **argv) {
+        if (argc < 4)
+                return 2;
+        std::ifstream fi(argv[1], std::ios::binary);
+        std::vector<uint8_t> index((std::istreambuf_iterator<char>(fi)), std::istreambuf_iterator<char>());
+        std::ifstream ft(argv[2], std::ios::binary);
+        std::vector<char> tb((std::istreambuf_iterator<char>(ft)), std::istreambuf_iterator<char>());
+        const size_t nterms = tb.size() / 12;
+        std::vector<term_index_ctx> tctx(nterms);
+        memcpy(tctx.data(), tb.data(), nterms * 12);
+        std::vector<std::string> names(nterms);
+        field_statistics fs;
+        for (size_t i = 0; i < nterms; ++i) {
+                names[i] = "t" + std::to_string(i);
+                fs.sumTermsDocs += tctx[i].documents;
+                fs.totalTerms += tctx[i].documents != 0;
+        }
+        fs.docsCnt = uint32_t(strtoul(argv[3], nullptr, 10));
+        try {
+                IndexSource src(0, index.data(), index.size(), names, tctx, fs);
+                Similarity::IndexSourcesCollectionBM25Scorer bm25;
+                std::unique_ptr<Similarity::IndexSourceTermsScorer> scorer(bm25.new_source_scorer(&src));
+
+                auto show = [&](const char *name, const Collect &c) {
+                        double sum = 0;
+                        for (auto s : c.scores)
+                                sum += s;
+                        printf("%s n=%zu fnv=%" PRIu64 " score_sum=%.17g\n", name, c.ids.size(), fnv(c.ids), sum);
+                };
+                { // t0 t1, DocumentsOnly
+                        Collect c;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, &c, nullptr, unsigned(ExecFlags::DocumentsOnly));
+                        show("and_docs", c);
+                }
+                { // t0 t1, AccumulatedScoreScheme + BM25
+                        Collect c;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("and_scored", c);
+                }
+                { // t0 t1 (t2 OR t3 OR t4), scored
+                        Collect c;
+                        auto q = src.conjunction({src.term("t0"), src.term("t1"), src.disjunction({src.term("t2"), src.term("t3"), src.term("t4")})});
+                        exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("mixed_scored", c);
+                }
+                { // t3 OR t7 with an IndexDocumentsFilter
+                        Collect c;
+                        EvenOnly even;
+                        exec_query(src.disjunction({src.term("t3"), src.term("t7")}), &src, &c, &even, unsigned(ExecFlags::DocumentsOnly));
+                        show("or_even", c);
+                }
+                { // unknown term => no documents
+                        Collect c;
+                        exec_query(src.conjunction({src.term("t0"), src.term("nosuchterm")}), &src, &c, nullptr, unsigned(ExecFlags::DocumentsOnly));
+                        show("unknown", c);
+                }
+                { // codec seam by hand: next()/advance()/freq
+                        auto it = src.term("t5");
+                        uint64_t h = 1469598103934665603ull;
+                        uint32_t n = 0;
+                        for (auto id = it->next(); id != DocIDsEND; id = it->next(), ++n)
+                                h = (h ^ (uint64_t(id) * 31 + it->freq)) * 1099511628211ull;
+                        auto it2 = src.term("t5");
+                        const auto a = it2->advance(1000);
+                        const auto f = it2->freq;
+                        const auto b2 = it2->advance(1000);
+                        printf("pli n=%u h=%" PRIu64 " adv1000=%u freq=%u again=%u\n", n, h, a, unsigned(f), b2);
+                }
+                { // batched
+                        Collect c0, c1;
+                        exec_queries({src.conjunction({src.term("t1"), src.term("t2")}), src.disjunction({src.term("t8"), src.term("t9")})}, &src, {&c0, &c1},
+                                     unsigned(ExecFlags::DocumentsOnly));
+                        show("batch0", c0);
+                        show("batch1", c1);
+                }
+                try { // error behaviour: mutually exclusive flags (exec.h:45-48)
+                        Collect c;
+                        exec_query(src.term("t0"), &src, &c, nullptr, 3);
+                        printf("flags no-throw\n");
+                } catch (const invalid_argument &e) {
+                        printf("flags invalid_argument\n");
+                }
+        } catch (const std::exception &e) {
+                printf("EXCEPTION %s\n", e.what());
+                return 1;
+        }
+        return 0;
+}

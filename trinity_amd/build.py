@@ -48,5 +48,19 @@ def build_host(force=False):
     return LIB_HOST
 
 
+MIRROR_TEST_SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror_test.cpp")
+MIRROR_TEST_BIN = os.path.join(ROOT, "tests", "cpp", "host_mirror_test")
+
+
+def build_mirror_test(force=False):
+    """The C++ operator surface (csrc/host/trinity_gpu.hpp) compiled into its test driver, linked to libtrinity_hip.so."""
+    deps = [MIRROR_TEST_SRC, os.path.join(PKG, "csrc", "host", "trinity_gpu.hpp"), os.path.join(PKG, "csrc", "host", "google_encoder.hpp"), os.path.join(ROOT, "include", "trinity_hip.h")]
+    if force or _newer(MIRROR_TEST_BIN, deps):
+        build_hip()
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-o", MIRROR_TEST_BIN, MIRROR_TEST_SRC, "-L" + PKG, "-ltrinity_hip", "-Wl,-rpath,$ORIGIN/../../trinity_amd"]
+        subprocess.run(cmd, check=True)
+    return MIRROR_TEST_BIN
+
+
 def build_all(force=False):
-    return build_hip(force), build_host(force)
+    return build_hip(force), build_host(force), build_mirror_test(force)

@@ -130,6 +130,7 @@ struct tri_batch {
         uint32_t *d_part_docs = nullptr, *d_part_counts = nullptr, *d_top_docs = nullptr, *d_top_counts = nullptr;
         double *d_part_scores = nullptr;
         float *d_top_scores = nullptr;
+        double *d_all_scores = nullptr; // topk == 0: one double per out[] slot
         uint64_t out_capacity = 0;
         uint64_t term_bytes = 0; // sum of docbytes over all query terms
         std::vector<uint32_t> h_counts;       // per task
@@ -925,7 +926,7 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                                   const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket,
                                                   const uint32_t *__restrict__ out, const uint32_t *__restrict__ counts, const uint32_t k,
                                                   uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
-                                                  uint32_t *__restrict__ part_counts) {
+                                                  uint32_t *__restrict__ part_counts, double *__restrict__ all_scores) {
         __shared__ ScoreShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
@@ -1025,21 +1026,28 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                         __syncthreads();
                                 }
                         }
-                        // offer the tile to the task's top-K
-                        for (uint32_t base = 0; base < C; base += AND_WG) {
-                                const uint32_t j = base + tid;
-                                topk_offer(sh.tk, k, j < C, j < C ? sh.score[j] : 0.0, j < C ? sh.cand[j] : 0u, sh.scan);
+                        if (all_scores) // full score stream: what consider(id, score) receives for every match
+                                for (uint32_t j = tid; j < C; j += AND_WG)
+                                        all_scores[task.out_off + tb + j] = sh.score[j];
+                        if (k) {
+                                // offer the tile to the task's top-K
+                                for (uint32_t base = 0; base < C; base += AND_WG) {
+                                        const uint32_t j = base + tid;
+                                        topk_offer(sh.tk, k, j < C, j < C ? sh.score[j] : 0.0, j < C ? sh.cand[j] : 0u, sh.scan);
+                                }
                         }
                         __syncthreads();
                 }
-                topk_prune(sh.tk, k, sh.scan);
-                const uint32_t n = uni(sh.tk.n);
-                for (uint32_t i = tid; i < n; i += AND_WG) {
-                        part_docs[(uint64_t)tix * k + i] = sh.tk.d[i];
-                        part_scores[(uint64_t)tix * k + i] = sh.tk.s[i];
+                if (k) {
+                        topk_prune(sh.tk, k, sh.scan);
+                        const uint32_t n = uni(sh.tk.n);
+                        for (uint32_t i = tid; i < n; i += AND_WG) {
+                                part_docs[(uint64_t)tix * k + i] = sh.tk.d[i];
+                                part_scores[(uint64_t)tix * k + i] = sh.tk.s[i];
+                        }
+                        if (wave == 0)
+                                part_counts[tix] = n;
                 }
-                if (wave == 0)
-                        part_counts[tix] = n;
                 __syncthreads();
         }
 }
@@ -1422,8 +1430,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         if (mode == 0 || mode == (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE))
                 return fail(TRI_ERR_INVALID, "DocumentsOnly and AccumulatedScoreScheme are mutually exclusive; the default rich mode is not lowered (exec.h:45-48)");
         const bool scored = mode == TRI_FLAG_ACCUMULATED_SCORE;
-        if (scored && (topk < 1 || topk > TOPK_MAX))
-                return fail(TRI_ERR_INVALID, "AccumulatedScoreScheme needs 1 <= topk <= %u", TOPK_MAX);
+        if (scored && topk > TOPK_MAX)
+                return fail(TRI_ERR_INVALID, "AccumulatedScoreScheme: topk <= %u (0 = keep every match's score instead of a top-K)", TOPK_MAX);
         if (scored && similarity != TRI_SIM_BM25)
                 return fail(TRI_ERR_UNSUPPORTED, "only TRI_SIM_BM25 is lowered");
         tri_dev *dev = ix->dev;
@@ -1652,6 +1660,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if ((rc = dev_upload(&b->d_sterms, b->sterms)) || (rc = dev_upload(&b->d_sweights, b->sweights)))
                         return rc;
                 const size_t nt = b->tasks.size();
+                if (!topk)
+                        HIP_TRY(hipMalloc((void **)&b->d_all_scores, (off + 64) * 8));
                 HIP_TRY(hipMalloc((void **)&b->d_part_docs, (nt * topk + 1) * 4));
                 HIP_TRY(hipMalloc((void **)&b->d_part_scores, (nt * topk + 1) * 8));
                 HIP_TRY(hipMalloc((void **)&b->d_part_counts, (nt + 1) * 4));
@@ -1687,6 +1697,7 @@ extern "C" void tri_batch_destroy(tri_batch *b) {
         hipFree(b->d_top_docs);
         hipFree(b->d_top_scores);
         hipFree(b->d_top_counts);
+        hipFree(b->d_all_scores);
         delete b;
 }
 
@@ -1716,10 +1727,12 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                         hipLaunchKernelGGL(k_score, dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 2)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, n,
-                                           b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts);
+                                           b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,
+                                           b->d_all_scores);
                         HIP_TRY(hipGetLastError());
                         const uint32_t nqs = (uint32_t)b->plan.size();
-                        hipLaunchKernelGGL(k_topk_merge, dim3(std::min<uint32_t>(nqs, (uint32_t)dev->cus * 8)), dim3(AND_WG), 0, dev->stream, b->d_plan, nqs,
+                        if (b->topk)
+                                hipLaunchKernelGGL(k_topk_merge, dim3(std::min<uint32_t>(nqs, (uint32_t)dev->cus * 8)), dim3(AND_WG), 0, dev->stream, b->d_plan, nqs,
                                            b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->d_top_docs, b->d_top_scores, b->d_top_counts);
                         HIP_TRY(hipGetLastError());
                 }
@@ -1861,6 +1874,33 @@ extern "C" int tri_batch_topk(tri_batch *b, uint32_t *docids, float *scores, uin
         HIP_TRY(hipMemcpy(docids, b->d_top_docs, b->nq * b->topk * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(scores, b->d_top_scores, b->nq * b->topk * 4, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(counts, b->d_top_counts, b->nq * 4, hipMemcpyDeviceToHost));
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_scores(tri_batch *b, size_t q, double *out, size_t cap, size_t *n) {
+        if (!b || !n || q >= b->nq)
+                return fail(TRI_ERR_INVALID, "bad argument");
+        if (!(b->flags & TRI_FLAG_ACCUMULATED_SCORE) || b->topk)
+                return fail(TRI_ERR_INVALID, "per-match scores are kept only for AccumulatedScoreScheme batches created with topk == 0");
+        if (!b->synced)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync first");
+        const uint32_t slot = b->slot_of_query[q];
+        *n = slot == UINT32_MAX ? 0 : b->h_query_counts[slot];
+        if (!*n || !out)
+                return TRI_OK;
+        if (cap < *n)
+                return fail(TRI_ERR_INVALID, "scores need %zu slots, %zu given", *n, cap);
+        HIP_TRY(hipSetDevice(b->ix->dev->device));
+        const DevQuery &dq = b->plan[slot];
+        size_t w = 0;
+        for (uint32_t t = 0; t < dq.ntasks; ++t) {
+                const uint32_t c = b->h_counts[dq.first_task + t];
+                if (!c)
+                        continue;
+                HIP_TRY(hipMemcpyAsync(out + w, b->d_all_scores + b->tasks[dq.first_task + t].out_off, (size_t)c * 8, hipMemcpyDeviceToHost, b->ix->dev->stream));
+                w += c;
+        }
+        HIP_TRY(hipStreamSynchronize(b->ix->dev->stream));
         return TRI_OK;
 }
 

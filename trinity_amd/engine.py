@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream",
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_decode_terms",
     "tri_batch_create", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
-    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_docset_hashes",
+    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_docset_hashes",
 ]  # fmt: skip
 
 _hip = None
@@ -94,6 +94,7 @@ def hip_lib():
     L.tri_batch_get_info.argtypes = [vp, C.POINTER(TriBatchInfo)]
     L.tri_batch_match_counts.argtypes = [vp, vp]
     L.tri_batch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.tri_batch_scores.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_topk.argtypes = [vp, vp, vp, vp]
     L.tri_batch_topk_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.tri_batch_docset_hashes.argtypes = [vp, vp]
@@ -263,6 +264,14 @@ class Batch:
         out = np.zeros(n, dtype=np.uint32)
         got = C.c_size_t()
         _check(hip_lib().tri_batch_docset(self.h, q, out.ctypes.data, n, C.byref(got)))
+        return out[: got.value]
+
+    def scores(self, q, n=None):
+        if n is None:
+            n = int(self.counts()[q])
+        out = np.zeros(n, dtype=np.float64)
+        got = C.c_size_t()
+        _check(hip_lib().tri_batch_scores(self.h, q, out.ctypes.data, n, C.byref(got)))
         return out[: got.value]
 
     def docset_hashes(self):
