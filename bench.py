@@ -52,6 +52,7 @@ def main():
     import torch
 
     import trinity_amd as T
+    from trinity_amd import dist as TD
 
     T.build_all()
     dist = None
@@ -71,7 +72,7 @@ def main():
     ix = T.Index.from_segment(dev, seg)
     info = ix.info()
     qall = T.gen_queries(args.vocab, 1337, args.queries * world, 2)
-    qs = qall[rank::world][: args.queries]  # interleaved shard: same cost distribution on every rank
+    qs = TD.shard_rows(qall, rank, world, args.queries)  # interleaved shard: same cost distribution on every rank
     batch = T.Batch.conjunctions(ix, qs, T.FLAG_DOCUMENTS_ONLY)
 
     def barrier():
@@ -80,10 +81,8 @@ def main():
         torch.cuda.synchronize()
 
     counts_dev = None
-    gathered = None
     if dist is not None:
         counts_dev = torch.zeros(args.queries, dtype=torch.int64, device="cuda")
-        gathered = [torch.zeros_like(counts_dev) for _ in range(world)]
 
     def step():
         batch.run()
@@ -91,7 +90,7 @@ def main():
         if dist is not None:
             # result exchange: per-query match counts to every rank (docsets stay sharded in HBM)
             counts_dev.copy_(torch.from_numpy(batch.counts().astype(np.int64)))
-            dist.all_gather(gathered, counts_dev)
+            TD.gather_counts(dist, counts_dev)
         return batch.info()
 
     for _ in range(args.warmup):
