@@ -239,13 +239,20 @@ struct VbStream {
                 valid -= (int)len;
                 return v;
         }
-        // after refill(): true when the next 8 bytes are 8 one-byte varints (values < 128)
-        __device__ __forceinline__ bool eight_small() const { return (lo & 0x8080808080808080ull) == 0; }
-        __device__ __forceinline__ uint64_t take8() {
+        // after refill(): true when the next k (1..8) bytes are k one-byte varints (values < 128)
+        __device__ __forceinline__ bool small_run(const uint32_t k) const { return (lo & (0x8080808080808080ull >> (8u * (8u - k)))) == 0; }
+        // consume k (1..8) bytes, returning the window they were in (byte j = j-th value)
+        __device__ __forceinline__ uint64_t take(const uint32_t k) {
                 const uint64_t w = lo;
-                lo = hi;
-                hi = 0;
-                valid -= 8;
+                if (k == 8) {
+                        lo = hi;
+                        hi = 0;
+                } else {
+                        const uint32_t s = k * 8;
+                        lo = (lo >> s) | (hi << (64 - s));
+                        hi >>= s;
+                }
+                valid -= (int)k;
                 return w;
         }
 };
@@ -312,6 +319,9 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
         return x - v;
 }
 
+#ifndef TRI_DENSE_V
+#define TRI_DENSE_V 1
+#endif
 constexpr uint32_t SPAN_BITS = 1u << 17; // docIDs per dense window
 constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
 
@@ -322,7 +332,7 @@ struct AndShared {
                         uint32_t hit[TILE_BLOCKS]; // bit k of hit[r] <=> logical candidate r*32+k matched
                         uint32_t blkof[AND_WG + 1];
                 };
-                uint32_t bits[2][SPAN_WORDS]; // TASK_DENSE: two docID-window bitmaps (candidates / survivors)
+                uint32_t bits[2][SPAN_WORDS + 1]; // TASK_DENSE: two docID-window bitmaps (candidates / survivors), +1 sink word
         };
         uint32_t tbase[AND_WG];
         uint32_t scan[8];
@@ -502,12 +512,23 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
 // One lane decodes one block (unpack_block, google_codec.cpp:596-639) and ORs its documents into / tests them
 // against a window bitmap in LDS.  Consecutive documents of a dense list fall into the same 32-bit word, so the
 // lane keeps the current word in registers and touches LDS once per word, not once per posting.
+// Bitmap word -> LDS slot.  Neighbouring lanes decode neighbouring blocks, i.e. words a small constant stride apart,
+// which lands lanes l and l+16 on one bank; XOR-ing in the next five index bits spreads every 32-word row differently.
+// A bijection inside each 1024-word group; the sink word (index SPAN_WORDS) maps to itself.
+#if TRI_DENSE_V == 1
+__device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w ^ ((w >> 5) & 31u); }
+#else
+__device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w; }
+#endif
+
 template <bool FIRST>
 __device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
                                             const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
         VbStream s;
         s.init(index + off);
-        uint32_t doc = prev, curword = 0xffffffffu, cw = 0, acc = 0;
+        uint32_t doc = prev;
+#if TRI_DENSE_V == 0
+        uint32_t curword = 0xffffffffu, cw = 0, acc = 0;
         auto visit = [&](const uint32_t d) {
                 const uint32_t rel = d - w0; // documents outside the window land on word >= SPAN_WORDS
                 const uint32_t word = rel >> 5;
@@ -520,19 +541,35 @@ __device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, c
                 }
                 acc |= cw & (1u << (rel & 31u));
         };
+#else
+        // branch-free: one LDS OR (plus one LDS read when testing) per posting; documents outside the window go to the
+        // sink word.  No lane-divergent control flow inside the 8-posting fast path, so the reads pipeline.
+        auto visit = [&](const uint32_t d) {
+                const uint32_t rel = d - w0;
+                const uint32_t word = bswz(min(rel >> 5, SPAN_WORDS));
+                const uint32_t bit = 1u << (rel & 31u);
+                if (FIRST)
+                        atomicOr(&dst[word], bit);
+                else
+                        atomicOr(&dst[word], src[word] & bit);
+        };
+#endif
         const uint32_t nd = n - 1;
         uint32_t i = 0;
         while (i < nd) {
                 s.refill();
-                if (nd - i >= 8 && s.eight_small()) {
-                        uint64_t w = s.take8();
+                const uint32_t k = min(8u, nd - i);
+                if (s.small_run(k)) { // k one-byte deltas (the rule for head terms): no per-value length decode
+                        uint64_t w = s.take(k);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                                doc += (uint32_t)(w & 0xffu);
-                                w >>= 8;
-                                visit(doc);
+                        for (uint32_t j = 0; j < 8; ++j) {
+                                if (j < k) {
+                                        doc += (uint32_t)(w & 0xffu);
+                                        w >>= 8;
+                                        visit(doc);
+                                }
                         }
-                        i += 8;
+                        i += k;
                 } else {
                         doc += s.next();
                         visit(doc);
@@ -540,8 +577,10 @@ __device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, c
                 }
         }
         visit(last);
+#if TRI_DENSE_V == 0
         if (acc)
                 atomicOr(&dst[curword], acc);
+#endif
 }
 
 __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
@@ -642,7 +681,7 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
                         for (uint32_t j = 0; j < SPAN_WORDS / AND_WG; ++j) {
                                 const uint32_t wi = tid * (SPAN_WORDS / AND_WG) + j;
                                 pre[wi] = run;
-                                run += __popc(fin[wi]);
+                                run += __popc(fin[bswz(wi)]);
                         }
                         uint32_t wtot;
                         const uint32_t ex = wave_excl_scan(run, wtot);
@@ -658,7 +697,7 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
                         __syncthreads();
                         // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
                         for (uint32_t wi = tid; wi < SPAN_WORDS; wi += AND_WG) {
-                                uint32_t m = fin[wi];
+                                uint32_t m = fin[bswz(wi)];
                                 uint32_t o = produced + sh.tbase[wi / (SPAN_WORDS / AND_WG)] + pre[wi];
                                 const uint32_t base = w0 + wi * 32;
                                 while (m) {
