@@ -55,8 +55,11 @@ struct DevTerm {
         uint32_t documents;
         uint32_t first_block;
         uint32_t nblocks;
-        uint32_t last_n; // docs in the final block (1..32)
+        uint32_t last_n;  // docs in the final block (1..32)
+        uint32_t win_off; // lists of >= WIN_MIN_BLOCKS blocks: row in win[] (first block with last >= w * SPAN_BITS, per window w); else ~0
+        uint32_t pad[3];
 };
+constexpr uint32_t WIN_MIN_BLOCKS = 128;
 
 // A query in conjunctive normal form: AND of groups, a group = one term or an OR of terms.  qterms[] lists the terms
 // group by group, cheapest group first (exec.cpp:35-110 cost model); bit 31 marks the first term of a group.
@@ -97,7 +100,8 @@ struct tri_dev {
 struct tri_index {
         tri_dev *dev;
         uint8_t *d_index = nullptr;
-        uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr;
+        uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr, *d_win = nullptr;
+        uint32_t nwin = 0; // windows per win[] row (+1 sentinel column)
         DevTerm *d_terms = nullptr;
         std::vector<DevTerm> terms;
         std::vector<uint32_t> h_blk_last; // host copy of the directory's last-docID column (planner: task output offsets)
@@ -584,8 +588,9 @@ __device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, c
 }
 
 __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                           const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms, const uint32_t *__restrict__ qterms,
-                           const DevQuery q, const DevTask task, uint32_t *__restrict__ out, uint32_t *__restrict__ count_out) {
+                           const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
+                           const uint32_t *__restrict__ qterms, const DevQuery q, const DevTask task, uint32_t *__restrict__ out,
+                           uint32_t *__restrict__ count_out) {
         const uint32_t tid = threadIdx.x;
         uint32_t *qout = out + task.out_off;
         uint32_t produced = 0;
@@ -603,11 +608,16 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
                 for (uint32_t k = 0; k < nlead; ++k) {
                         const DevTerm t = terms[qterms[q.term_base + k] & ~QT_GROUP];
                         const uint32_t *bl = blk_last + t.first_block;
-                        uint32_t cur = uni(sh.lcur[k]);
-                        if (cur < t.nblocks && bl[cur] < w * SPAN_BITS)
-                                cur += wg_lower_bound(sh, bl + cur, t.nblocks - cur, w * SPAN_BITS);
-                        __syncthreads();
-                        sh.lcur[k] = cur;
+                        uint32_t cur;
+                        if (t.win_off != 0xffffffffu)
+                                cur = win[t.win_off + w]; // indexed list: first block with last >= w * SPAN_BITS
+                        else {
+                                cur = uni(sh.lcur[k]);
+                                if (cur < t.nblocks && bl[cur] < w * SPAN_BITS)
+                                        cur += wg_lower_bound(sh, bl + cur, t.nblocks - cur, w * SPAN_BITS);
+                                __syncthreads();
+                                sh.lcur[k] = cur;
+                        }
                         if (cur < t.nblocks) {
                                 const uint32_t first_possible = cur ? bl[cur - 1] + 1 : 1;
                                 wnext = min(wnext, max(w, first_possible / SPAN_BITS));
@@ -640,18 +650,29 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
                                 for (uint32_t i = tid; i < SPAN_WORDS; i += AND_WG)
                                         dst[i] = 0;
                         // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
-                        uint32_t b_lo = uni(sh.lcur[k]);
-                        if (b_lo < t.nblocks && bl[b_lo] < w0)
-                                b_lo += wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, w0);
-                        uint32_t b_hi = b_lo;
-                        if (b_lo < t.nblocks) {
-                                galive = true;
-                                b_hi = b_lo + wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, wlast);
-                                if (b_hi >= t.nblocks)
-                                        b_hi = t.nblocks - 1;
+                        uint32_t b_lo, b_hi;
+                        if (t.win_off != 0xffffffffu) {
+                                // indexed list: two scalar loads replace both directory searches (win[w + 1] is the first block
+                                // with last >= the next window's first docID; it may still hold documents of this window)
+                                b_lo = win[t.win_off + w];
+                                b_hi = min(win[t.win_off + w + 1], t.nblocks - 1);
+                                if (b_lo < t.nblocks)
+                                        galive = true;
+                                __syncthreads(); // dst cleared, earlier passes complete
+                        } else {
+                                b_lo = uni(sh.lcur[k]);
+                                if (b_lo < t.nblocks && bl[b_lo] < w0)
+                                        b_lo += wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, w0);
+                                b_hi = b_lo;
+                                if (b_lo < t.nblocks) {
+                                        galive = true;
+                                        b_hi = b_lo + wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, wlast);
+                                        if (b_hi >= t.nblocks)
+                                                b_hi = t.nblocks - 1;
+                                }
+                                __syncthreads(); // dst cleared, earlier passes complete, cursor reads done
+                                sh.lcur[k] = b_lo < t.nblocks ? b_hi : b_lo;
                         }
-                        __syncthreads(); // dst cleared, earlier passes complete, cursor reads done
-                        sh.lcur[k] = b_lo < t.nblocks ? b_hi : b_lo;
                         if (b_lo < t.nblocks) {
                                 for (uint32_t cb = b_lo; cb <= b_hi; cb += AND_WG) {
                                         const uint32_t b = cb + tid;
@@ -716,7 +737,8 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
 }
 
 __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                                const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
+                                                const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
+                                                const DevTerm *__restrict__ terms,
                                                 const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
                                                 const uint32_t *__restrict__ sched, const uint32_t *__restrict__ qterms,
                                                 const uint32_t ntasks, uint32_t *__restrict__ ticket,
@@ -742,7 +764,7 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                 const uint32_t slot = task.slot;
                 const DevQuery q = plan[slot];
                 if (task.kind == TASK_DENSE) {
-                        dense_task(sh, index, blk_last, blk_off, terms, qterms, q, task, out, counts + tix);
+                        dense_task(sh, index, blk_last, blk_off, win, terms, qterms, q, task, out, counts + tix);
                         continue;
                 }
                 const DevTerm lead = terms[qterms[q.term_base] & ~QT_GROUP];
@@ -1297,7 +1319,30 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 docb += db;
                 hitb += hb;
         }
+        // per-window block index of the longer lists (TASK_DENSE reads two entries instead of searching the directory)
+        const uint32_t max_doc = blk_last.empty() ? 0 : *std::max_element(blk_last.begin(), blk_last.end());
+        ix->nwin = max_doc / SPAN_BITS + 2;
+        std::vector<uint32_t> win;
+        for (size_t ti = 0; ti < nterms; ++ti) {
+                DevTerm &dt = ix->terms[ti];
+                dt.win_off = 0xffffffffu;
+                dt.pad[0] = dt.pad[1] = dt.pad[2] = 0;
+                if (dt.nblocks < WIN_MIN_BLOCKS)
+                        continue;
+                dt.win_off = (uint32_t)win.size();
+                const uint32_t *bl = &blk_last[dt.first_block];
+                uint32_t b = 0;
+                for (uint32_t w = 0; w < ix->nwin; ++w) {
+                        const uint64_t key = (uint64_t)w * SPAN_BITS;
+                        while (b < dt.nblocks && bl[b] < key)
+                                ++b;
+                        win.push_back(b);
+                }
+        }
         // device copies
+        int rcw;
+        if ((rcw = dev_upload(&ix->d_win, win)))
+                return rcw;
         HIP_TRY(hipMalloc((void **)&ix->d_index, len + 64));
         HIP_TRY(hipMemset(ix->d_index, 0, len + 64));
         if (len)
@@ -1307,7 +1352,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 return rc;
         ix->h_blk_last = std::move(blk_last);
         ix->info.index_bytes = len;
-        ix->info.directory_bytes = ix->h_blk_last.size() * 8 + nterms * sizeof(DevTerm);
+        ix->info.directory_bytes = ix->h_blk_last.size() * 8 + nterms * sizeof(DevTerm) + win.size() * 4;
         ix->info.blocks = ix->h_blk_last.size();
         ix->info.postings = postings;
         ix->info.doc_bytes = docb;
@@ -1325,6 +1370,7 @@ extern "C" void tri_index_destroy(tri_index *ix) {
         hipFree(ix->d_index);
         hipFree(ix->d_blk_last);
         hipFree(ix->d_blk_off);
+        hipFree(ix->d_win);
         hipFree(ix->d_terms);
         delete ix;
 }
@@ -1760,7 +1806,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
         if (n) {
                 HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 256, dev->stream));
                 const uint32_t grid = std::min<uint32_t>(n, (uint32_t)dev->cus * 4);
-                hipLaunchKernelGGL(k_and, dim3(grid), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms,
+                hipLaunchKernelGGL(k_and, dim3(grid), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win,
+                                   b->ix->d_terms,
                                    b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, n, b->d_ticket, b->d_out, b->d_counts);
                 HIP_TRY(hipGetLastError());
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
