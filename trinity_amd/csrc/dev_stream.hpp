@@ -1,0 +1,124 @@
+// dev_stream.hpp — debug trace hooks, prefix-varint decode and the per-lane byte stream
+// Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
+#pragma once
+#include "dev_structs.hpp"
+#include <hip/hip_runtime.h>
+
+// ------------------------------------------------------------------------------------------ debug trace
+// -DTRI_TRACE builds write per-workgroup progress markers into host-pinned memory; tri_batch_sync then polls
+// with a watchdog (env TRINITY_WATCHDOG_S) and dumps the markers instead of hanging.  Not in product builds.
+#ifdef TRI_TRACE
+static uint32_t *g_trace_host = nullptr;
+__device__ volatile uint32_t *g_trace = nullptr;
+#ifndef TRI_TRACE_MASK
+#define TRI_TRACE_MASK 0xffffffffu
+#endif
+#define TRACE(stage, a, b)                                                      \
+        do {                                                                    \
+                if (((TRI_TRACE_MASK >> (stage)) & 1u) && threadIdx.x == 0 && g_trace) {                              \
+                        volatile uint32_t *t_ = g_trace + (blockIdx.x & 63) * 4; \
+                        t_[0] = (stage);                                        \
+                        t_[1] = (a);                                            \
+                        t_[2] = (b);                                            \
+                        t_[3] = t_[3] + 1;                                      \
+                        __threadfence_system();                                 \
+                }                                                               \
+        } while (0)
+#else
+#define TRACE(stage, a, b) \
+        do {               \
+        } while (0)
+#endif
+
+// ------------------------------------------------------------------------------------------ device: varint
+// Prefix varint of Switch/switch_compiler_aux.h:53-80, branch-free.  `w` holds the next >= 5 stream bytes,
+// least-significant byte first.
+__device__ __forceinline__ uint32_t vb_decode(uint64_t w, uint32_t &len) {
+        const uint32_t lo32 = (uint32_t)w;
+        const uint32_t b0 = lo32 & 0xffu;
+        const uint32_t ones = __clz(~(lo32 << 24)); // leading 1-bits of b0 (0..8)
+        const uint32_t n = ones < 4u ? ones : 4u;
+        const uint32_t be = __builtin_bswap32(lo32); // b0 b1 b2 b3
+        const uint32_t v1 = b0;
+        const uint32_t v2 = (be >> 16) & 0x3fffu;
+        const uint32_t v3 = ((b0 & 0x1fu) << 16) | ((lo32 >> 8) & 0xffffu);
+        const uint32_t v4 = be & 0x0fffffffu;
+        const uint32_t v5 = (uint32_t)(w >> 8);
+        len = n + 1;
+        uint32_t v = v1;
+        v = n == 1 ? v2 : v;
+        v = n == 2 ? v3 : v;
+        v = n == 3 ? v4 : v;
+        v = n == 4 ? v5 : v;
+        return v;
+}
+
+// Per-lane byte stream over global memory: a 16-byte register window (lo = next 8 bytes, hi = the following
+// ones) refilled from aligned 8-byte loads, with three further qwords always in flight so that the load
+// latency sits behind ~24 bytes of decoding (index[] carries >= 64 bytes of slack past the last chunk).
+struct VbStream {
+        const uint64_t *q;
+        uint64_t lo, hi, n1, n2, n3;
+        int valid;
+
+        __device__ __forceinline__ void init(const uint8_t *p) {
+                const uintptr_t a = (uintptr_t)p;
+                const uint32_t sk = (uint32_t)(a & 7u);
+                q = (const uint64_t *)(a & ~(uintptr_t)7);
+                const uint64_t w0 = q[0], w1 = q[1];
+                n1 = q[2];
+                n2 = q[3];
+                n3 = q[4];
+                q += 5;
+                const uint32_t sh = sk * 8;
+                lo = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+                hi = sh ? (w1 >> sh) : w1;
+                valid = 16 - (int)sk;
+        }
+        __device__ __forceinline__ void refill() {
+                if (valid <= 8) {
+                        const uint64_t w = n1;
+                        n1 = n2;
+                        n2 = n3;
+                        n3 = *q++;
+                        const uint32_t sh = (uint32_t)valid * 8; // 0..64
+                        if (valid == 8)
+                                hi = w;
+                        else if (valid == 0) {
+                                lo = w;
+                                hi = 0;
+                        } else {
+                                lo |= w << sh;
+                                hi = w >> (64 - sh);
+                        }
+                        valid += 8;
+                }
+        }
+        __device__ __forceinline__ uint32_t next() {
+                refill();
+                uint32_t len;
+                const uint32_t v = vb_decode(lo, len);
+                const uint32_t s = len * 8;
+                lo = (lo >> s) | (hi << (64 - s));
+                hi >>= s;
+                valid -= (int)len;
+                return v;
+        }
+        // after refill(): true when the next k (1..8) bytes are k one-byte varints (values < 128)
+        __device__ __forceinline__ bool small_run(const uint32_t k) const { return (lo & (0x8080808080808080ull >> (8u * (8u - k)))) == 0; }
+        // consume k (1..8) bytes, returning the window they were in (byte j = j-th value)
+        __device__ __forceinline__ uint64_t take(const uint32_t k) {
+                const uint64_t w = lo;
+                if (k == 8) {
+                        lo = hi;
+                        hi = 0;
+                } else {
+                        const uint32_t s = k * 8;
+                        lo = (lo >> s) | (hi << (64 - s));
+                        hi >>= s;
+                }
+                valid -= (int)k;
+                return w;
+        }
+};
+

@@ -1,0 +1,43 @@
+// dev_structs.hpp — device-visible plan structures shared by the host planner and the kernels
+// Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
+#pragma once
+#include <cstdint>
+
+struct DevTerm {
+        uint32_t documents;
+        uint32_t first_block;
+        uint32_t nblocks;
+        uint32_t last_n;  // docs in the final block (1..32)
+        uint32_t win_off; // lists of >= WIN_MIN_BLOCKS blocks: row in win[] (first block with last >= w * SPAN_BITS, per window w); else ~0
+        uint32_t pad[3];
+};
+constexpr uint32_t WIN_MIN_BLOCKS = 128;
+
+// A query in conjunctive normal form: AND of groups, a group = one term or an OR of terms.  qterms[] lists the terms
+// group by group, cheapest group first (exec.cpp:35-110 cost model); bit 31 marks the first term of a group.
+// Root OR of terms == a single group.  (Conjuction / DisjunctionAllPLI semantics, docset_iterators.cpp:226-405.)
+constexpr uint32_t QT_GROUP = 0x80000000u;
+constexpr uint32_t MAX_QTERMS = 16;
+struct DevQuery {
+        uint32_t nterms;    // total terms over all groups (<= MAX_QTERMS)
+        uint32_t term_base; // into qterms[]
+        uint64_t out_off;   // docID slots
+        uint32_t out_cap;
+        uint32_t qid; // caller's query index
+        uint32_t first_task, ntasks;
+        uint32_t score_base, nscore; // AccumulatedScoreScheme: sterms[]/sweights[] slice, reference summation order
+};
+
+// Unit of scheduling: a run of lead-list tiles of one query.  Heavy queries are cut into many tasks so that no
+// single workgroup carries a multi-millisecond tail; task `i` of a query writes its (ascending) matches at
+// out_off + tile_begin * TILE_CANDS, a region no other task can reach because matches are a subset of the
+// lead tile's documents.  A query's docID set is the in-order concatenation of its tasks' segments.
+struct DevTask {
+        uint32_t slot;       // plan slot of the query
+        uint32_t tile_begin; // TASK_CAND: lead tiles [tile_begin, tile_end); TASK_DENSE: docID windows [begin, end)
+        uint32_t tile_end;
+        uint32_t kind;
+        uint64_t out_off; // absolute docID slot in out[] where this task's segment starts
+};
+constexpr uint32_t TASK_CAND = 0;  // candidate tiles of the lead list, filtered by galloping / block-driven merge
+constexpr uint32_t TASK_DENSE = 1; // bitmap algebra over fixed docID windows (every list dense enough)

@@ -1,0 +1,639 @@
+// k_match.hpp — docset matching kernels: candidate tiles (galloping / block-driven) and dense bitmap windows
+// Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
+#pragma once
+#include "dev_stream.hpp"
+
+// ------------------------------------------------------------------------------------------ k_and
+constexpr int AND_WG = 256;   // candidate-tile kernel (k_and) and the scoring kernels
+constexpr int DENSE_WG = 512; // bitmap-window kernel (k_and_dense): 8 waves share one 36 KB window state
+constexpr int TILE_BLOCKS = 256;
+constexpr int TILE_CANDS = TILE_BLOCKS * 32;
+
+// Values that are workgroup-uniform by construction but read back from LDS look divergent to the compiler; a
+// loop whose exit depends on one gets exec-masked structurisation, which is fatal around s_barrier (lanes
+// "leave" the loop at different times).  uni() pins such values into an SGPR so the branch is scalar.
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// LDS candidate layout: logical slot j lives at phys(j); rotating each 32-slot row by its row number keeps
+// the one-lane-per-row writes of the lead decode (lane t writes row t, column i) off a single bank.
+__device__ __forceinline__ uint32_t phys(uint32_t j) { return (j & ~31u) | ((j + (j >> 5)) & 31u); }
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if ((int)(threadIdx.x & 63) >= d)
+                        x += y;
+        }
+        total = __shfl(x, 63, 64);
+        return x - v;
+}
+
+#ifndef TRI_DENSE_V
+#define TRI_DENSE_V 1
+#endif
+constexpr uint32_t SPAN_BITS = 1u << 17; // docIDs per dense window
+constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
+
+struct AndShared {
+        union {
+                struct {
+                        uint32_t cand[TILE_CANDS];
+                        uint32_t hit[TILE_BLOCKS]; // bit k of hit[r] <=> logical candidate r*32+k matched
+                        uint32_t blkof[AND_WG + 1];
+                };
+                uint32_t bits[2][SPAN_WORDS + 1]; // TASK_DENSE: two docID-window bitmaps (candidates / survivors), +1 sink word
+        };
+        uint32_t tbase[DENSE_WG];
+        uint32_t scan[8];
+        uint32_t bcast[4];
+        uint32_t lcur[16]; // per term: directory cursor, uniform across the workgroup
+};
+
+// Workgroup-cooperative lower bound over a sorted global array: first i in [0, n) with a[i] >= key, else n.
+// 256-ary search: every lane probes the end of its segment, one ballot per wave finds the first segment whose
+// last element is >= key; ~log256(n) rounds of one (L2-resident) load each instead of log2(n) dependent loads.
+template <int WG = AND_WG>
+__device__ uint32_t wg_lower_bound(AndShared &sh, const uint32_t *__restrict__ a, const uint32_t n, const uint32_t key) {
+        const uint32_t tid = threadIdx.x;
+        uint32_t lo = 0, hi = n; // answer in [lo, hi]
+        while (hi > lo) {
+                const uint32_t len = hi - lo;
+                const uint32_t step = (len + WG - 1) / WG;
+                const uint32_t pos = lo + (tid + 1) * step - 1;
+                const bool ge = pos >= hi ? true : a[pos] >= key;
+                const uint64_t m = __ballot(ge);
+                sh.scan[tid >> 6] = m ? (tid & ~63u) + (uint32_t)__builtin_ctzll(m) : 0xffffffffu;
+                __syncthreads();
+                uint32_t first = 0xffffffffu;
+#pragma unroll
+                for (int wv = 0; wv < WG / 64; ++wv)
+                        first = min(first, sh.scan[wv]);
+                first = uni(first);
+                __syncthreads();
+                const uint32_t nlo = lo + first * step;
+                const uint32_t nhi = min(hi, lo + (first + 1) * step - 1);
+                lo = nlo;
+                hi = step == 1 ? nlo : nhi;
+        }
+        return lo;
+}
+
+// Filter the C candidates in sh.cand (logical order ascending) against term `t`: sets sh.hit bits.
+// Caller syncs before and after.
+__device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                const uint32_t *__restrict__ blk_off, const DevTerm t, const uint32_t C, const uint32_t lcur_slot,
+                                const bool block_driven) {
+        const uint32_t tid = threadIdx.x;
+        const uint32_t *bl = blk_last + t.first_block;
+        const uint32_t *bo = blk_off + t.first_block;
+        const uint32_t cmin = sh.cand[phys(0)], cmax = sh.cand[phys(C - 1)];
+
+        if (block_driven) {
+                // advance lcur to the first block whose last docID >= cmin (tiles arrive in ascending docID order)
+                uint32_t lcur = uni(sh.lcur[lcur_slot]);
+                if (lcur == 0xffffffffu) // first tile of this task: position by cooperative search, then gallop forward
+                        lcur = wg_lower_bound(sh, bl, t.nblocks, cmin);
+                for (;;) {
+                        const uint32_t b = lcur + tid;
+                        const bool below = b < t.nblocks && bl[b] < cmin;
+                        const uint64_t m = __ballot(below);
+                        // number of leading lanes (from lane 0) with below == true, per wave
+                        const uint32_t lead = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+                        sh.scan[tid >> 6] = lead; // wave-uniform value, every lane stores it: no divergent branch
+                        __syncthreads();
+                        uint32_t adv = 0;
+                        for (int w = 0; w < AND_WG / 64; ++w) {
+                                adv += sh.scan[w];
+                                if (sh.scan[w] != 64)
+                                        break;
+                        }
+                        adv = uni(adv);
+                        __syncthreads();
+                        lcur += adv;
+                        if (adv != AND_WG || lcur >= t.nblocks)
+                                break;
+                }
+                sh.lcur[lcur_slot] = lcur; // uniform value, branch-free store
+                TRACE(10, lcur, t.nblocks);
+                for (uint32_t cb = lcur; cb < t.nblocks; cb += AND_WG) {
+                        TRACE(11, cb, t.nblocks);
+                        const uint32_t b = cb + tid;
+                        bool beyond = true;
+                        if (b < t.nblocks) {
+                                const uint32_t prev = b ? bl[b - 1] : 0; // docs of block b lie in (prev, last]
+                                const uint32_t last = bl[b];
+                                beyond = last >= cmax;
+                                if (prev < cmax) {
+                                        // first candidate > prev
+                                        uint32_t lo = 0, hi = C;
+                                        while (lo < hi) {
+                                                const uint32_t mid = (lo + hi) >> 1;
+                                                if (sh.cand[phys(mid)] <= prev)
+                                                        lo = mid + 1;
+                                                else
+                                                        hi = mid;
+                                        }
+                                        uint32_t ptr = lo;
+                                        uint32_t cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
+                                        if (cv <= last) {
+                                                const uint32_t off = bo[b];
+                                                const uint32_t n = index[off - 1];
+                                                VbStream s;
+                                                s.init(index + off);
+                                                uint32_t doc = prev;
+                                                for (uint32_t i = 0; i < n; ++i) {
+                                                        doc = (i + 1 < n) ? doc + s.next() : last;
+                                                        while (cv < doc) {
+                                                                ++ptr;
+                                                                cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
+                                                        }
+                                                        if (cv == doc)
+                                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
+                                                        if (cv > last)
+                                                                break;
+                                                }
+                                        }
+                                }
+                        }
+                        // workgroup-wide OR of `beyond`, branch-free: one ballot per wave, four LDS words
+                        sh.scan[4 + (tid >> 6)] = __ballot(beyond) != 0ull;
+                        __syncthreads();
+                        const uint32_t any_beyond = uni(sh.scan[4] | sh.scan[5] | sh.scan[6] | sh.scan[7]);
+                        __syncthreads();
+                        if (any_beyond)
+                                break;
+                }
+        } else {
+                // candidate-driven galloping: each candidate finds its block in the directory; the first
+                // candidate of each run that maps to the same block decodes it and merges forward
+                sh.blkof[0] = 0xffffffffu;
+                __syncthreads();
+                for (uint32_t base = 0; base < C; base += AND_WG) {
+                        TRACE(20, base, C);
+                        const uint32_t j = base + tid;
+                        uint32_t bj = 0xffffffffu;
+                        uint32_t cv = 0;
+                        if (j < C) {
+                                cv = sh.cand[phys(j)];
+                                uint32_t lo = 0, hi = t.nblocks; // first block with last >= cv
+                                while (lo < hi) {
+                                        const uint32_t mid = (lo + hi) >> 1;
+                                        if (bl[mid] < cv)
+                                                lo = mid + 1;
+                                        else
+                                                hi = mid;
+                                }
+                                bj = lo; // == nblocks: beyond the list
+                        }
+                        sh.blkof[tid + 1] = bj;
+                        __syncthreads();
+                        const uint32_t prevb = sh.blkof[tid];
+                        __syncthreads();
+                        {
+                                // carry the last lane's block into the next round (slot 0), branch-free:
+                                // lanes of the last wave all store lane 63's value, other waves rewrite their own slot
+                                const uint32_t lastb = __shfl(bj, 63, 64);
+                                const bool lastwave = (tid >> 6) == (AND_WG / 64 - 1);
+                                sh.blkof[lastwave ? 0 : tid + 1] = lastwave ? lastb : bj;
+                        }
+                        if (j < C && bj < t.nblocks && bj != prevb) {
+                                const uint32_t prev = bj ? bl[bj - 1] : 0;
+                                const uint32_t last = bl[bj];
+                                const uint32_t off = bo[bj];
+                                const uint32_t n = index[off - 1];
+                                VbStream s;
+                                s.init(index + off);
+                                uint32_t doc = prev;
+                                uint32_t ptr = j;
+                                for (uint32_t i = 0; i < n; ++i) {
+                                        doc = (i + 1 < n) ? doc + s.next() : last;
+                                        while (cv < doc) {
+                                                ++ptr;
+                                                cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
+                                        }
+                                        if (cv == doc)
+                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
+                                        if (cv > last)
+                                                break;
+                                }
+                        }
+                        __syncthreads();
+                }
+        }
+}
+
+// ---- TASK_DENSE: bitmap algebra over docID windows -------------------------------------------------------
+// One lane decodes one block (unpack_block, google_codec.cpp:596-639) and ORs its documents into / tests them
+// against a window bitmap in LDS.  Consecutive documents of a dense list fall into the same 32-bit word, so the
+// lane keeps the current word in registers and touches LDS once per word, not once per posting.
+// Bitmap word -> LDS slot.  Neighbouring lanes decode neighbouring blocks, i.e. words a small constant stride apart,
+// which lands lanes l and l+16 on one bank; XOR-ing in the next five index bits spreads every 32-word row differently.
+// A bijection inside each 1024-word group; the sink word (index SPAN_WORDS) maps to itself.
+#if TRI_DENSE_V == 1
+__device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w ^ ((w >> 5) & 31u); }
+#else
+__device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w; }
+#endif
+
+// One posting into the window bitmap: set (FIRST) or test-and-set.  Branch-free; documents outside the window go to
+// the sink word.
+template <bool FIRST>
+__device__ __forceinline__ void dense_visit(const uint32_t d, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
+        const uint32_t rel = d - w0;
+        const uint32_t word = bswz(min(rel >> 5, SPAN_WORDS));
+        const uint32_t bit = 1u << (rel & 31u);
+        if (FIRST)
+                atomicOr(&dst[word], bit);
+        else
+                atomicOr(&dst[word], src[word] & bit);
+}
+
+// Generic block walk over the per-lane byte stream (any varint lengths, any n).
+template <bool FIRST>
+__device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
+                                                   const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
+        VbStream s;
+        s.init(index + off);
+        uint32_t doc = prev;
+        const uint32_t nd = n - 1;
+        uint32_t i = 0;
+        while (i < nd) {
+                s.refill();
+                const uint32_t k = min(8u, nd - i);
+                if (s.small_run(k)) { // k one-byte deltas: no per-value length decode
+                        uint64_t w = s.take(k);
+#pragma unroll
+                        for (uint32_t j = 0; j < 8; ++j) {
+                                if (j < k) {
+                                        doc += (uint32_t)(w & 0xffu);
+                                        w >>= 8;
+                                        dense_visit<FIRST>(doc, w0, src, dst);
+                                }
+                        }
+                        i += k;
+                } else {
+                        doc += s.next();
+                        dense_visit<FIRST>(doc, w0, src, dst);
+                        ++i;
+                }
+        }
+        dense_visit<FIRST>(last, w0, src, dst);
+}
+
+// A full block (n == 32) whose 31 deltas are all one byte long — every block of a head term — is decoded from THREE
+// 16-byte-aligned loads (the 31 delta bytes sit in the first 46 bytes after the aligned-down payload address; the freqs
+// and hits that follow are never touched in DocumentsOnly mode), realigned in registers (a dword select stage and a
+// v_alignbyte stage) and walked with a fully unrolled add per posting.  One wave-load touches 64 cache lines whatever
+// its width, so 3 wide loads per block instead of 13 eight-byte ones is what takes the pressure off the L1/TA path.
+template <bool FIRST>
+__device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
+                                            const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
+#if TRI_DENSE_V == 1
+        if (n == 32) {
+                const uintptr_t a = (uintptr_t)(index + off);
+                const uint4 *q = (const uint4 *)(a & ~(uintptr_t)15);
+                const uint4 A = q[0], B = q[1], C = q[2];
+                const uint32_t sk = (uint32_t)(a & 15u);
+                uint32_t r[12] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z, C.w};
+                // dword shift by sk >> 2 (two select stages, static register indices)
+                if (sk & 4u) {
+#pragma unroll
+                        for (int i = 0; i < 11; ++i)
+                                r[i] = r[i + 1];
+                }
+                if (sk & 8u) {
+#pragma unroll
+                        for (int i = 0; i < 10; ++i)
+                                r[i] = r[i + 2];
+                }
+                // byte shift by sk & 3
+                uint32_t v[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                        v[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], sk & 3u);
+                const uint32_t hib = (v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | (v[7] & 0x00ffffffu)) & 0x80808080u;
+                if (hib == 0) {
+                        uint32_t doc = prev;
+#pragma unroll
+                        for (int j = 0; j < 31; ++j) {
+                                doc += (v[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+                                dense_visit<FIRST>(doc, w0, src, dst);
+                        }
+                        dense_visit<FIRST>(last, w0, src, dst);
+                        return;
+                }
+        }
+#endif
+        dense_block_stream<FIRST>(index, off, n, prev, last, w0, src, dst);
+}
+
+template <int WG>
+__device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                           const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
+                           const uint32_t *__restrict__ qterms, const DevQuery q, const DevTask task, uint32_t *__restrict__ out,
+                           uint32_t *__restrict__ count_out) {
+        const uint32_t tid = threadIdx.x;
+        uint32_t *qout = out + task.out_off;
+        uint32_t produced = 0;
+        sh.lcur[tid & 15] = 0; // per term: a block index at or before the first block that can matter
+        __syncthreads();
+        // number of terms in the lead group (it creates the candidates; the other groups test them)
+        uint32_t nlead = 1;
+        while (nlead < q.nterms && !(qterms[q.term_base + nlead] & QT_GROUP))
+                ++nlead;
+        bool done = false; // uniform
+        for (uint32_t w = task.tile_begin; w < task.tile_end && !done;) {
+                // ---- skip windows no lead-group list reaches: position the lead cursors at w, look at the first
+                //      document each may hold at or after it
+                uint32_t wnext = 0xffffffffu;
+                for (uint32_t k = 0; k < nlead; ++k) {
+                        const DevTerm t = terms[qterms[q.term_base + k] & ~QT_GROUP];
+                        const uint32_t *bl = blk_last + t.first_block;
+                        uint32_t cur;
+                        if (t.win_off != 0xffffffffu)
+                                cur = win[t.win_off + w]; // indexed list: first block with last >= w * SPAN_BITS
+                        else {
+                                cur = uni(sh.lcur[k]);
+                                if (cur < t.nblocks && bl[cur] < w * SPAN_BITS)
+                                        cur += wg_lower_bound<WG>(sh, bl + cur, t.nblocks - cur, w * SPAN_BITS);
+                                __syncthreads();
+                                sh.lcur[k] = cur;
+                        }
+                        if (cur < t.nblocks) {
+                                const uint32_t first_possible = cur ? bl[cur - 1] + 1 : 1;
+                                wnext = min(wnext, max(w, first_possible / SPAN_BITS));
+                        }
+                }
+                __syncthreads();
+                if (wnext >= task.tile_end)
+                        break; // the lead group holds nothing more in this task's range
+                w = wnext;
+                const uint32_t w0 = w * SPAN_BITS;
+                const uint32_t wlast = w0 + (SPAN_BITS - 1);
+                uint32_t gi = 0;       // group index
+                bool galive = false;   // some term of the current group reaches this window or beyond
+                for (uint32_t k = 0; k < q.nterms; ++k) {
+                        const uint32_t tt = qterms[q.term_base + k];
+                        const DevTerm t = terms[tt & ~QT_GROUP];
+                        const uint32_t *bl = blk_last + t.first_block;
+                        const uint32_t *bo = blk_off + t.first_block;
+                        if (k && (tt & QT_GROUP)) {
+                                if (!galive) { // an exhausted conjunct: no further match anywhere
+                                        done = true;
+                                        break;
+                                }
+                                ++gi;
+                                galive = false;
+                        }
+                        uint32_t *dst = sh.bits[gi & 1];
+                        const uint32_t *src = sh.bits[(gi & 1) ^ 1];
+                        if (tt & QT_GROUP)
+                                for (uint32_t i = tid; i < SPAN_WORDS; i += WG)
+                                        dst[i] = 0;
+                        // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
+                        uint32_t b_lo, b_hi;
+                        if (t.win_off != 0xffffffffu) {
+                                // indexed list: two scalar loads replace both directory searches (win[w + 1] is the first block
+                                // with last >= the next window's first docID; it may still hold documents of this window)
+                                b_lo = win[t.win_off + w];
+                                b_hi = min(win[t.win_off + w + 1], t.nblocks - 1);
+                                if (b_lo < t.nblocks)
+                                        galive = true;
+                                __syncthreads(); // dst cleared, earlier passes complete
+                        } else {
+                                b_lo = uni(sh.lcur[k]);
+                                if (b_lo < t.nblocks && bl[b_lo] < w0)
+                                        b_lo += wg_lower_bound<WG>(sh, bl + b_lo, t.nblocks - b_lo, w0);
+                                b_hi = b_lo;
+                                if (b_lo < t.nblocks) {
+                                        galive = true;
+                                        b_hi = b_lo + wg_lower_bound<WG>(sh, bl + b_lo, t.nblocks - b_lo, wlast);
+                                        if (b_hi >= t.nblocks)
+                                                b_hi = t.nblocks - 1;
+                                }
+                                __syncthreads(); // dst cleared, earlier passes complete, cursor reads done
+                                sh.lcur[k] = b_lo < t.nblocks ? b_hi : b_lo;
+                        }
+                        if (b_lo < t.nblocks) {
+                                for (uint32_t cb = b_lo; cb <= b_hi; cb += WG) {
+                                        const uint32_t b = cb + tid;
+                                        if (b <= b_hi) {
+                                                const uint32_t prev = b ? bl[b - 1] : 0;
+                                                const uint32_t last = bl[b];
+                                                const uint32_t off = bo[b];
+                                                const uint32_t n = index[off - 1];
+                                                if (gi == 0)
+                                                        dense_block<true>(index, off, n, prev, last, w0, src, dst);
+                                                else
+                                                        dense_block<false>(index, off, n, prev, last, w0, src, dst);
+                                        }
+                                }
+                        }
+                        __syncthreads();
+                }
+                if (done || !galive) {
+                        done = true;
+                        break;
+                }
+                // ---- expand the survivors bitmap into ascending docIDs
+                const uint32_t *fin = sh.bits[gi & 1];
+                uint32_t *pre = sh.bits[(gi & 1) ^ 1]; // the other bitmap is dead: per-word exclusive prefix
+                {
+                        uint32_t run = 0;
+                        for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
+                                const uint32_t wi = tid * (SPAN_WORDS / WG) + j;
+                                pre[wi] = run;
+                                run += __popc(fin[bswz(wi)]);
+                        }
+                        uint32_t wtot;
+                        const uint32_t ex = wave_excl_scan(run, wtot);
+                        sh.scan[tid >> 6] = wtot;
+                        __syncthreads();
+                        uint32_t wbase = 0, total = 0;
+                        for (int wv = 0; wv < WG / 64; ++wv) {
+                                if (wv < (int)(tid >> 6))
+                                        wbase += sh.scan[wv];
+                                total += sh.scan[wv];
+                        }
+                        sh.tbase[tid] = ex + wbase;
+                        __syncthreads();
+                        // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
+                        for (uint32_t wi = tid; wi < SPAN_WORDS; wi += WG) {
+                                uint32_t m = fin[bswz(wi)];
+                                uint32_t o = produced + sh.tbase[wi / (SPAN_WORDS / WG)] + pre[wi];
+                                const uint32_t base = w0 + wi * 32;
+                                while (m) {
+                                        qout[o++] = base + (uint32_t)__builtin_ctz(m);
+                                        m &= m - 1;
+                                }
+                        }
+                        produced += uni(total);
+                        __syncthreads();
+                }
+                ++w;
+        }
+        __syncthreads();
+        if (uni(tid >> 6) == 0)
+                *count_out = produced;
+}
+
+// bitmap-window tasks: persistent 512-thread workgroups draw TASK_DENSE tasks, heaviest first
+__global__ __launch_bounds__(DENSE_WG) void k_and_dense(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                        const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
+                                                        const DevTerm *__restrict__ terms, const DevQuery *__restrict__ plan,
+                                                        const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched,
+                                                        const uint32_t *__restrict__ qterms, const uint32_t ntasks, uint32_t *__restrict__ ticket,
+                                                        uint32_t *__restrict__ out, uint32_t *__restrict__ counts) {
+        __shared__ AndShared sh;
+        const uint32_t wave = uni(threadIdx.x >> 6);
+        for (;;) {
+                if (wave == 0) { // uniform draw: 64 lanes add 1 each (one +64 atomic), see k_and
+                        const uint32_t old = atomicAdd(ticket, 1u);
+                        sh.bcast[0] = uni(old) >> 6;
+                }
+                __syncthreads();
+                const uint32_t ticket_no = uni(sh.bcast[0]);
+                __syncthreads();
+                if (ticket_no >= ntasks)
+                        break;
+                const uint32_t tix = sched[ticket_no];
+                const DevTask task = tasks[tix];
+                dense_task<DENSE_WG>(sh, index, blk_last, blk_off, win, terms, qterms, plan[task.slot], task, out, counts + tix);
+        }
+}
+
+// candidate-tile tasks (TASK_CAND)
+__global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
+                                                const DevTerm *__restrict__ terms,
+                                                const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
+                                                const uint32_t *__restrict__ sched, const uint32_t *__restrict__ qterms,
+                                                const uint32_t ntasks, uint32_t *__restrict__ ticket,
+                                                uint32_t *__restrict__ out, uint32_t *__restrict__ counts) {
+        __shared__ AndShared sh;
+        const uint32_t tid = threadIdx.x;
+        const uint32_t wave = uni(tid >> 6);
+        for (;;) {
+                // next query: wave 0 draws the ticket.  All 64 lanes add 1 (the compiler folds that into ONE
+                // global atomic of +64 with a uniform operand — no lane-divergent branch at the loop head), so the
+                // counter advances in units of 64 per draw.
+                if (wave == 0) {
+                        const uint32_t old = atomicAdd(ticket, 1u);
+                        sh.bcast[0] = uni(old) >> 6;
+                }
+                __syncthreads();
+                const uint32_t ticket_no = uni(sh.bcast[0]);
+                __syncthreads();
+                if (ticket_no >= ntasks)
+                        break;
+                const uint32_t tix = sched[ticket_no];
+                const DevTask task = tasks[tix];
+                const uint32_t slot = task.slot;
+                const DevQuery q = plan[slot];
+                const DevTerm lead = terms[qterms[q.term_base] & ~QT_GROUP];
+                TRACE(1, slot, q.nterms);
+                uint32_t *qout = out + task.out_off;
+                uint32_t produced = 0;
+                sh.lcur[tid & 15] = 0xffffffffu; // "not positioned yet"
+                const uint32_t tb_end = min(lead.nblocks, task.tile_end * TILE_BLOCKS);
+
+                for (uint32_t tb = task.tile_begin * TILE_BLOCKS; tb < tb_end; tb += TILE_BLOCKS) {
+                        const uint32_t nb = min((uint32_t)TILE_BLOCKS, lead.nblocks - tb);
+                        uint32_t C = (tb + nb == lead.nblocks) ? (nb - 1) * 32 + lead.last_n : nb * 32;
+                        // ---- decode the lead tile: one lane per block (unpack_block, google_codec.cpp:596-639)
+                        if (tid < nb) {
+                                const uint32_t b = tb + tid, gb = lead.first_block + b;
+                                const uint32_t off = blk_off[gb];
+                                const uint32_t n = index[off - 1];
+                                const uint32_t last = blk_last[gb];
+                                uint32_t doc = b ? blk_last[gb - 1] : 0;
+                                VbStream s;
+                                s.init(index + off);
+                                const uint32_t row = tid * 32;
+                                for (uint32_t i = 0; i + 1 < n; ++i) {
+                                        doc += s.next();
+                                        sh.cand[row | ((i + tid) & 31u)] = doc;
+                                }
+                                sh.cand[row | ((n - 1 + tid) & 31u)] = last;
+                        }
+                        __syncthreads();
+                        TRACE(2, slot, tb);
+
+                        // ---- every other group filters the surviving candidates: a candidate survives a group when any
+                        //      of the group's terms holds it (hit bits are OR-ed across the group's terms)
+                        for (uint32_t k = 1; k < q.nterms && C; ++k) {
+                                const uint32_t tt = qterms[q.term_base + k];
+                                const DevTerm t = terms[tt & ~QT_GROUP];
+                                if (tt & QT_GROUP)
+                                        sh.hit[tid] = 0;
+                                __syncthreads();
+#if defined(TRI_FORCE_CAND)
+                                const bool bd = false;
+#elif defined(TRI_FORCE_BLOCK)
+                                const bool bd = true;
+#else
+                                const bool bd = t.nblocks <= lead.documents;
+#endif
+                                TRACE(3, slot, (k << 16) | (bd ? 1 : 0));
+                                and_filter_tile(sh, index, blk_last, blk_off, t, C, k - 1, bd);
+                                TRACE(4, slot, C);
+                                __syncthreads();
+                                const bool lastterm = k + 1 == q.nterms;
+                                if (!lastterm && !(qterms[q.term_base + k + 1] & QT_GROUP))
+                                        continue; // more terms of this OR group to come
+                                // compact survivors (stable => still ascending)
+                                const uint32_t bits = sh.hit[tid];
+                                const uint32_t cnt = __popc(bits);
+                                uint32_t wtot;
+                                uint32_t ex = wave_excl_scan(cnt, wtot);
+                                sh.scan[tid >> 6] = wtot; // wave-uniform
+                                __syncthreads();
+                                uint32_t wbase = 0, total = 0;
+                                for (int w = 0; w < AND_WG / 64; ++w) {
+                                        if (w < (int)(tid >> 6))
+                                                wbase += sh.scan[w];
+                                        total += sh.scan[w];
+                                }
+                                ex += wbase;
+                                if (lastterm) {
+                                        // last group: survivors go straight to the result, ascending
+                                        uint32_t m = bits, o = produced + ex;
+                                        while (m) {
+                                                const uint32_t kbit = __builtin_ctz(m);
+                                                m &= m - 1;
+                                                qout[o++] = sh.cand[phys(tid * 32 + kbit)];
+                                        }
+                                } else {
+                                        // in-place compaction: every lane lifts its row into registers first
+                                        uint32_t vals[32];
+#pragma unroll
+                                        for (int kk = 0; kk < 32; ++kk)
+                                                vals[kk] = sh.cand[(tid * 32) | ((kk + tid) & 31u)];
+                                        __syncthreads();
+                                        uint32_t o = ex;
+#pragma unroll
+                                        for (int kk = 0; kk < 32; ++kk)
+                                                if ((bits >> kk) & 1u) {
+                                                        sh.cand[phys(o)] = vals[kk];
+                                                        ++o;
+                                                }
+                                }
+                                C = uni(total);
+                                __syncthreads();
+                        }
+                        if (q.nterms == 1) {
+                                for (uint32_t j = tid; j < C; j += AND_WG)
+                                        qout[produced + j] = sh.cand[phys(j)];
+                        }
+                        produced += C;
+                        __syncthreads();
+                }
+                if (wave == 0)
+                        counts[tix] = produced; // scalar branch; the wave's lanes store one identical dword
+                TRACE(5, slot, produced);
+        }
+        TRACE(6, 0, 0);
+}
+

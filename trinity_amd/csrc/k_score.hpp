@@ -1,0 +1,303 @@
+// k_score.hpp — BM25 scoring over match segments, per-task and per-query top-K, docset hashing
+// Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
+#pragma once
+#include "k_match.hpp"
+
+// ------------------------------------------------------------------------------------------ k_score / k_topk_merge
+// AccumulatedScoreScheme (exec.h:36-41).  k_and has produced every query's ascending match list; k_score walks each
+// task's segment in tiles of 4096 matches, and for every scoring term looks the matches up again through the
+// directory (each match binary-searches its block, the first match of a block decodes it once: deltas to locate the
+// matching positions, then the freqs), adding  float(idf * float(f) / double(f + 1.2f))  to a per-match double in LDS —
+// IndexSourcesCollectionBM25Scorer::Scorer::score (similarity.h:228-235) summed in iterator order by the Conjuction
+// wrapper (docset_iterators_scorers.cpp:173-193).  The tile is then offered to the task's top-K (score descending,
+// docID ascending: the application-side MatchedIndexDocumentsFilter heap, matches.h:155-171).  k_topk_merge folds
+// the tasks' partial lists into one list per query.
+constexpr uint32_t SCORE_TILE = 4096;
+constexpr uint32_t TOPK_MAX = 256;
+constexpr uint32_t TOPK_CAP = TOPK_MAX + AND_WG; // survivors + one wave of newcomers
+
+struct TopK {
+        double s[TOPK_CAP];
+        uint32_t d[TOPK_CAP];
+        uint32_t n;       // entries held (uniform)
+        uint32_t full;    // n has reached k at least once => thr_* valid
+        double thr_s;     // the k-th best entry
+        uint32_t thr_d;
+};
+
+__device__ __forceinline__ bool better(const double s1, const uint32_t d1, const double s2, const uint32_t d2) {
+        return s1 > s2 || (s1 == s2 && d1 < d2);
+}
+
+// Keep the best k of the n entries, sorted best-first (rank by counting: the order is strict, ranks are unique).
+__device__ void topk_prune(TopK &tk, const uint32_t k, uint32_t *scan) {
+        const uint32_t tid = threadIdx.x;
+        const uint32_t n = uni(tk.n);
+        double es[2];
+        uint32_t ed[2], rk[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+                const uint32_t i = tid + r * AND_WG;
+                rk[r] = 0xffffffffu;
+                if (i < n) {
+                        es[r] = tk.s[i];
+                        ed[r] = tk.d[i];
+                        uint32_t c = 0;
+                        for (uint32_t j = 0; j < n; ++j)
+                                c += better(tk.s[j], tk.d[j], es[r], ed[r]) ? 1u : 0u;
+                        rk[r] = c;
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+                if (rk[r] < k) {
+                        tk.s[rk[r]] = es[r];
+                        tk.d[rk[r]] = ed[r];
+                }
+        __syncthreads();
+        const uint32_t m = n < k ? n : k;
+        // uniform stores by every lane (no single-lane branch around the barrier loop that calls us)
+        tk.n = m;
+        if (m == k) {
+                tk.full = 1;
+                tk.thr_s = tk.s[k - 1];
+                tk.thr_d = tk.d[k - 1];
+        }
+        (void)scan;
+        __syncthreads();
+}
+
+// Every lane offers at most one (score, doc); survivors of the threshold are appended, pruning when the buffer fills.
+__device__ void topk_offer(TopK &tk, const uint32_t k, const bool valid, const double sc, const uint32_t doc, uint32_t *scan) {
+        const uint32_t tid = threadIdx.x;
+        const uint32_t n0 = uni(tk.n); // stable: the previous call ended with a barrier
+        const bool take = valid && (!tk.full || better(sc, doc, tk.thr_s, tk.thr_d));
+        const uint64_t m = __ballot(take);
+        const uint32_t lane = tid & 63;
+        const uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
+        scan[tid >> 6] = __popcll(m);
+        __syncthreads();
+        uint32_t base = n0, tot = 0;
+        for (uint32_t w = 0; w < AND_WG / 64; ++w) {
+                if (w < (tid >> 6))
+                        base += scan[w];
+                tot += scan[w];
+        }
+        tot = uni(tot);
+        if (take) {
+                tk.s[base + before] = sc;
+                tk.d[base + before] = doc;
+        }
+        __syncthreads();
+        tk.n = n0 + tot; // same value from every lane
+        __syncthreads();
+        if (n0 + tot > TOPK_MAX)
+                topk_prune(tk, k, scan);
+}
+
+struct ScoreShared {
+        uint32_t cand[SCORE_TILE];
+        double score[SCORE_TILE];
+        uint32_t hit[SCORE_TILE / 32]; // per scoring term: which matches this term holds
+        uint32_t blkof[AND_WG + 1];
+        uint32_t scan[8];
+        uint32_t bcast[4];
+        TopK tk;
+};
+
+__device__ __forceinline__ float bm25_term(const double idf, const uint32_t freq32) {
+        const uint16_t freq = (uint16_t)freq32; // PostingsListIterator::freq is tokenpos_t (codecs.h:217)
+        return (float)(idf * (double)(float)freq / (double)((float)freq + 1.2f));
+}
+
+__global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                  const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
+                                                  const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
+                                                  const uint32_t *__restrict__ sched, const uint32_t *__restrict__ sterms,
+                                                  const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket,
+                                                  const uint32_t *__restrict__ out, const uint32_t *__restrict__ counts, const uint32_t k,
+                                                  uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
+                                                  uint32_t *__restrict__ part_counts, double *__restrict__ all_scores) {
+        __shared__ ScoreShared sh;
+        const uint32_t tid = threadIdx.x;
+        const uint32_t wave = uni(tid >> 6);
+        for (;;) {
+                if (wave == 0) {
+                        const uint32_t old = atomicAdd(ticket, 1u);
+                        sh.bcast[0] = uni(old) >> 6;
+                }
+                __syncthreads();
+                const uint32_t ticket_no = uni(sh.bcast[0]);
+                __syncthreads();
+                if (ticket_no >= ntasks)
+                        break;
+                const uint32_t tix = sched[ticket_no];
+                const DevTask task = tasks[tix];
+                const DevQuery q = plan[task.slot];
+                const uint32_t M = counts[tix];
+                const uint32_t *seg = out + task.out_off;
+                sh.tk.n = 0;
+                sh.tk.full = 0;
+                __syncthreads();
+                for (uint32_t tb = 0; tb < M; tb += SCORE_TILE) {
+                        const uint32_t C = min(SCORE_TILE, M - tb);
+                        for (uint32_t j = tid; j < C; j += AND_WG) {
+                                sh.cand[j] = seg[tb + j];
+                                sh.score[j] = 0.0;
+                        }
+                        __syncthreads();
+                        for (uint32_t ti = 0; ti < q.nscore; ++ti) {
+                                const DevTerm t = terms[sterms[q.score_base + ti]];
+                                const double w = sweights[q.score_base + ti];
+                                const uint32_t *bl = blk_last + t.first_block;
+                                const uint32_t *bo = blk_off + t.first_block;
+                                sh.blkof[0] = 0xffffffffu;
+                                if (tid < SCORE_TILE / 32)
+                                        sh.hit[tid] = 0;
+                                __syncthreads();
+                                for (uint32_t base = 0; base < C; base += AND_WG) {
+                                        const uint32_t j = base + tid;
+                                        uint32_t bj = 0xffffffffu, cv = 0;
+                                        if (j < C) {
+                                                cv = sh.cand[j];
+                                                uint32_t lo = 0, hi = t.nblocks;
+                                                while (lo < hi) {
+                                                        const uint32_t mid = (lo + hi) >> 1;
+                                                        if (bl[mid] < cv)
+                                                                lo = mid + 1;
+                                                        else
+                                                                hi = mid;
+                                                }
+                                                bj = lo;
+                                        }
+                                        sh.blkof[tid + 1] = bj;
+                                        __syncthreads();
+                                        const uint32_t prevb = sh.blkof[tid];
+                                        __syncthreads();
+                                        {
+                                                const uint32_t lastb = __shfl(bj, 63, 64);
+                                                const bool lastwave = (tid >> 6) == (AND_WG / 64 - 1);
+                                                sh.blkof[lastwave ? 0 : tid + 1] = lastwave ? lastb : bj;
+                                        }
+                                        if (j < C && bj < t.nblocks && bj != prevb) {
+                                                const uint32_t prev = bj ? bl[bj - 1] : 0;
+                                                const uint32_t last = bl[bj];
+                                                const uint32_t off = bo[bj];
+                                                const uint32_t n = index[off - 1];
+                                                VbStream s;
+                                                s.init(index + off);
+                                                // deltas: merge the block's documents against the matches from j on; remember
+                                                // the block positions (mask) and the matches (hit bits) that coincide.  Under an
+                                                // OR a match need not be a document of this list.
+                                                uint32_t doc = prev, ptr = j, mask = 0;
+                                                for (uint32_t i = 0; i < n; ++i) {
+                                                        doc = (i + 1 < n) ? doc + s.next() : last;
+                                                        while (cv < doc) {
+                                                                ++ptr;
+                                                                cv = ptr < C ? sh.cand[ptr] : 0xffffffffu;
+                                                        }
+                                                        if (cv == doc) {
+                                                                mask |= 1u << i;
+                                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
+                                                        }
+                                                }
+                                                // freqs follow the n-1 deltas; the i-th marked position belongs to the i-th
+                                                // marked match (both ascending; only this lane marks matches in its block's range)
+                                                ptr = j;
+                                                for (uint32_t i = 0; i < n; ++i) {
+                                                        const uint32_t f = s.next();
+                                                        if ((mask >> i) & 1u) {
+                                                                while (!((sh.hit[ptr >> 5] >> (ptr & 31)) & 1u))
+                                                                        ++ptr;
+                                                                sh.score[ptr] += (double)bm25_term(w, f);
+                                                                ++ptr;
+                                                        }
+                                                }
+                                        }
+                                        __syncthreads();
+                                }
+                        }
+                        if (all_scores) // full score stream: what consider(id, score) receives for every match
+                                for (uint32_t j = tid; j < C; j += AND_WG)
+                                        all_scores[task.out_off + tb + j] = sh.score[j];
+                        if (k) {
+                                // offer the tile to the task's top-K
+                                for (uint32_t base = 0; base < C; base += AND_WG) {
+                                        const uint32_t j = base + tid;
+                                        topk_offer(sh.tk, k, j < C, j < C ? sh.score[j] : 0.0, j < C ? sh.cand[j] : 0u, sh.scan);
+                                }
+                        }
+                        __syncthreads();
+                }
+                if (k) {
+                        topk_prune(sh.tk, k, sh.scan);
+                        const uint32_t n = uni(sh.tk.n);
+                        for (uint32_t i = tid; i < n; i += AND_WG) {
+                                part_docs[(uint64_t)tix * k + i] = sh.tk.d[i];
+                                part_scores[(uint64_t)tix * k + i] = sh.tk.s[i];
+                        }
+                        if (wave == 0)
+                                part_counts[tix] = n;
+                }
+                __syncthreads();
+        }
+}
+
+// one workgroup per query: stream the tasks' partial lists through the same top-K structure
+__global__ __launch_bounds__(AND_WG) void k_topk_merge(const DevQuery *__restrict__ plan, const uint32_t nq, const uint32_t k,
+                                                       const uint32_t *__restrict__ part_docs, const double *__restrict__ part_scores,
+                                                       const uint32_t *__restrict__ part_counts, uint32_t *__restrict__ top_docs,
+                                                       float *__restrict__ top_scores, uint32_t *__restrict__ top_counts) {
+        __shared__ TopK tk;
+        __shared__ uint32_t scan[8];
+        const uint32_t tid = threadIdx.x;
+        for (uint32_t slot = blockIdx.x; slot < nq; slot += gridDim.x) {
+                const DevQuery q = plan[slot];
+                tk.n = 0;
+                tk.full = 0;
+                __syncthreads();
+                for (uint32_t t = 0; t < q.ntasks; ++t) {
+                        const uint32_t tix = q.first_task + t;
+                        const uint32_t c = part_counts[tix];
+                        for (uint32_t base = 0; base < c; base += AND_WG) {
+                                const uint32_t i = base + tid;
+                                const bool v = i < c;
+                                topk_offer(tk, k, v, v ? part_scores[(uint64_t)tix * k + i] : 0.0, v ? part_docs[(uint64_t)tix * k + i] : 0u, scan);
+                        }
+                }
+                topk_prune(tk, k, scan);
+                const uint32_t n = uni(tk.n);
+                for (uint32_t i = tid; i < k; i += AND_WG) {
+                        top_docs[(uint64_t)q.qid * k + i] = i < n ? tk.d[i] : 0u;
+                        top_scores[(uint64_t)q.qid * k + i] = i < n ? (float)tk.s[i] : 0.0f;
+                }
+                if (uni(tid >> 6) == 0)
+                        top_counts[q.qid] = n;
+                __syncthreads();
+        }
+}
+
+// FNV-1a(64) of each query's docID set (little-endian bytes), one lane per query — verification helper
+__global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks_by_query,
+                               const uint32_t *__restrict__ counts_by_query, const uint32_t nq, const uint32_t *__restrict__ out,
+                               uint64_t *__restrict__ hashes) {
+        const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+        if (s >= nq)
+                return;
+        const DevQuery q = plan[s];
+        uint64_t h = 1469598103934665603ull;
+        for (uint32_t t = 0; t < q.ntasks; ++t) {
+                const uint32_t *p = out + tasks_by_query[q.first_task + t].out_off;
+                const uint32_t n = counts_by_query[q.first_task + t];
+                for (uint32_t i = 0; i < n; ++i) {
+                        uint32_t d = p[i];
+                        for (int b = 0; b < 4; ++b) {
+                                h = (h ^ (d & 0xffu)) * 1099511628211ull;
+                                d >>= 8;
+                        }
+                }
+        }
+        hashes[s] = h;
+}
+

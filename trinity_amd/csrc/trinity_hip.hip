@@ -50,45 +50,8 @@ static int fail(int code, const char *fmt, ...) {
 extern "C" const char *tri_last_error(void) { return g_err; }
 extern "C" int tri_abi_version(void) { return TRI_ABI_VERSION; }
 
-// ------------------------------------------------------------------------------------------ structs
-struct DevTerm {
-        uint32_t documents;
-        uint32_t first_block;
-        uint32_t nblocks;
-        uint32_t last_n;  // docs in the final block (1..32)
-        uint32_t win_off; // lists of >= WIN_MIN_BLOCKS blocks: row in win[] (first block with last >= w * SPAN_BITS, per window w); else ~0
-        uint32_t pad[3];
-};
-constexpr uint32_t WIN_MIN_BLOCKS = 128;
-
-// A query in conjunctive normal form: AND of groups, a group = one term or an OR of terms.  qterms[] lists the terms
-// group by group, cheapest group first (exec.cpp:35-110 cost model); bit 31 marks the first term of a group.
-// Root OR of terms == a single group.  (Conjuction / DisjunctionAllPLI semantics, docset_iterators.cpp:226-405.)
-constexpr uint32_t QT_GROUP = 0x80000000u;
-constexpr uint32_t MAX_QTERMS = 16;
-struct DevQuery {
-        uint32_t nterms;    // total terms over all groups (<= MAX_QTERMS)
-        uint32_t term_base; // into qterms[]
-        uint64_t out_off;   // docID slots
-        uint32_t out_cap;
-        uint32_t qid; // caller's query index
-        uint32_t first_task, ntasks;
-        uint32_t score_base, nscore; // AccumulatedScoreScheme: sterms[]/sweights[] slice, reference summation order
-};
-
-// Unit of scheduling: a run of lead-list tiles of one query.  Heavy queries are cut into many tasks so that no
-// single workgroup carries a multi-millisecond tail; task `i` of a query writes its (ascending) matches at
-// out_off + tile_begin * TILE_CANDS, a region no other task can reach because matches are a subset of the
-// lead tile's documents.  A query's docID set is the in-order concatenation of its tasks' segments.
-struct DevTask {
-        uint32_t slot;       // plan slot of the query
-        uint32_t tile_begin; // TASK_CAND: lead tiles [tile_begin, tile_end); TASK_DENSE: docID windows [begin, end)
-        uint32_t tile_end;
-        uint32_t kind;
-        uint64_t out_off; // absolute docID slot in out[] where this task's segment starts
-};
-constexpr uint32_t TASK_CAND = 0;  // candidate tiles of the lead list, filtered by galloping / block-driven merge
-constexpr uint32_t TASK_DENSE = 1; // bitmap algebra over fixed docID windows (every list dense enough)
+// device-visible structures and kernels
+#include "dev_structs.hpp"
 
 struct tri_dev {
         int device;
@@ -120,7 +83,8 @@ struct tri_batch {
         DevQuery *d_plan = nullptr;
         std::vector<DevTask> tasks; // scheduling order (cost descending)
         DevTask *d_tasks = nullptr;
-        uint32_t *d_sched = nullptr; // task indices, heaviest first
+        uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones
+        uint32_t n_dense = 0, n_cand = 0;
         uint32_t *d_qterms = nullptr;
         uint32_t *d_out = nullptr;
         uint32_t *d_counts = nullptr; // per task, indexed first_task + i in query order
@@ -143,1032 +107,10 @@ struct tri_batch {
         tri_batch_info info{};
 };
 
-// ------------------------------------------------------------------------------------------ debug trace
-// -DTRI_TRACE builds write per-workgroup progress markers into host-pinned memory; tri_batch_sync then polls
-// with a watchdog (env TRINITY_WATCHDOG_S) and dumps the markers instead of hanging.  Not in product builds.
-#ifdef TRI_TRACE
-static uint32_t *g_trace_host = nullptr;
-__device__ volatile uint32_t *g_trace = nullptr;
-#ifndef TRI_TRACE_MASK
-#define TRI_TRACE_MASK 0xffffffffu
-#endif
-#define TRACE(stage, a, b)                                                      \
-        do {                                                                    \
-                if (((TRI_TRACE_MASK >> (stage)) & 1u) && threadIdx.x == 0 && g_trace) {                              \
-                        volatile uint32_t *t_ = g_trace + (blockIdx.x & 63) * 4; \
-                        t_[0] = (stage);                                        \
-                        t_[1] = (a);                                            \
-                        t_[2] = (b);                                            \
-                        t_[3] = t_[3] + 1;                                      \
-                        __threadfence_system();                                 \
-                }                                                               \
-        } while (0)
-#else
-#define TRACE(stage, a, b) \
-        do {               \
-        } while (0)
-#endif
-
-// ------------------------------------------------------------------------------------------ device: varint
-// Prefix varint of Switch/switch_compiler_aux.h:53-80, branch-free.  `w` holds the next >= 5 stream bytes,
-// least-significant byte first.
-__device__ __forceinline__ uint32_t vb_decode(uint64_t w, uint32_t &len) {
-        const uint32_t lo32 = (uint32_t)w;
-        const uint32_t b0 = lo32 & 0xffu;
-        const uint32_t ones = __clz(~(lo32 << 24)); // leading 1-bits of b0 (0..8)
-        const uint32_t n = ones < 4u ? ones : 4u;
-        const uint32_t be = __builtin_bswap32(lo32); // b0 b1 b2 b3
-        const uint32_t v1 = b0;
-        const uint32_t v2 = (be >> 16) & 0x3fffu;
-        const uint32_t v3 = ((b0 & 0x1fu) << 16) | ((lo32 >> 8) & 0xffffu);
-        const uint32_t v4 = be & 0x0fffffffu;
-        const uint32_t v5 = (uint32_t)(w >> 8);
-        len = n + 1;
-        uint32_t v = v1;
-        v = n == 1 ? v2 : v;
-        v = n == 2 ? v3 : v;
-        v = n == 3 ? v4 : v;
-        v = n == 4 ? v5 : v;
-        return v;
-}
-
-// Per-lane byte stream over global memory: a 16-byte register window (lo = next 8 bytes, hi = the following
-// ones) refilled from aligned 8-byte loads, with three further qwords always in flight so that the load
-// latency sits behind ~24 bytes of decoding (index[] carries >= 64 bytes of slack past the last chunk).
-struct VbStream {
-        const uint64_t *q;
-        uint64_t lo, hi, n1, n2, n3;
-        int valid;
-
-        __device__ __forceinline__ void init(const uint8_t *p) {
-                const uintptr_t a = (uintptr_t)p;
-                const uint32_t sk = (uint32_t)(a & 7u);
-                q = (const uint64_t *)(a & ~(uintptr_t)7);
-                const uint64_t w0 = q[0], w1 = q[1];
-                n1 = q[2];
-                n2 = q[3];
-                n3 = q[4];
-                q += 5;
-                const uint32_t sh = sk * 8;
-                lo = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
-                hi = sh ? (w1 >> sh) : w1;
-                valid = 16 - (int)sk;
-        }
-        __device__ __forceinline__ void refill() {
-                if (valid <= 8) {
-                        const uint64_t w = n1;
-                        n1 = n2;
-                        n2 = n3;
-                        n3 = *q++;
-                        const uint32_t sh = (uint32_t)valid * 8; // 0..64
-                        if (valid == 8)
-                                hi = w;
-                        else if (valid == 0) {
-                                lo = w;
-                                hi = 0;
-                        } else {
-                                lo |= w << sh;
-                                hi = w >> (64 - sh);
-                        }
-                        valid += 8;
-                }
-        }
-        __device__ __forceinline__ uint32_t next() {
-                refill();
-                uint32_t len;
-                const uint32_t v = vb_decode(lo, len);
-                const uint32_t s = len * 8;
-                lo = (lo >> s) | (hi << (64 - s));
-                hi >>= s;
-                valid -= (int)len;
-                return v;
-        }
-        // after refill(): true when the next k (1..8) bytes are k one-byte varints (values < 128)
-        __device__ __forceinline__ bool small_run(const uint32_t k) const { return (lo & (0x8080808080808080ull >> (8u * (8u - k)))) == 0; }
-        // consume k (1..8) bytes, returning the window they were in (byte j = j-th value)
-        __device__ __forceinline__ uint64_t take(const uint32_t k) {
-                const uint64_t w = lo;
-                if (k == 8) {
-                        lo = hi;
-                        hi = 0;
-                } else {
-                        const uint32_t s = k * 8;
-                        lo = (lo >> s) | (hi << (64 - s));
-                        hi >>= s;
-                }
-                valid -= (int)k;
-                return w;
-        }
-};
-
-// ------------------------------------------------------------------------------------------ k_decode_terms
-struct DecodeJob {
-        uint32_t term;
-        uint32_t pad;
-        uint64_t out_off;
-};
-
-// grid.x covers blocks of job blockIdx.y in chunks of 256; one lane per block (google_codec.cpp:596-639)
-__global__ __launch_bounds__(256) void k_decode_terms(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                                      const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
-                                                      const DecodeJob *__restrict__ jobs, uint32_t *__restrict__ docs,
-                                                      uint32_t *__restrict__ freqs) {
-        const DecodeJob job = jobs[blockIdx.y];
-        const DevTerm t = terms[job.term];
-        for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < t.nblocks; b += gridDim.x * 256) {
-                const uint32_t gb = t.first_block + b;
-                const uint32_t off = blk_off[gb];
-                const uint32_t n = index[off - 1];
-                const uint32_t last = blk_last[gb];
-                uint32_t doc = b ? blk_last[gb - 1] : 0;
-                VbStream s;
-                s.init(index + off);
-                uint32_t *od = docs + job.out_off + (uint64_t)b * 32;
-                for (uint32_t i = 0; i + 1 < n; ++i) {
-                        doc += s.next();
-                        od[i] = doc;
-                }
-                od[n - 1] = last;
-                if (freqs) {
-                        uint32_t *of = freqs + job.out_off + (uint64_t)b * 32;
-                        for (uint32_t i = 0; i < n; ++i)
-                                of[i] = s.next();
-                }
-        }
-}
-
-// ------------------------------------------------------------------------------------------ k_and
-constexpr int AND_WG = 256;
-constexpr int TILE_BLOCKS = 256;
-constexpr int TILE_CANDS = TILE_BLOCKS * 32;
-
-// Values that are workgroup-uniform by construction but read back from LDS look divergent to the compiler; a
-// loop whose exit depends on one gets exec-masked structurisation, which is fatal around s_barrier (lanes
-// "leave" the loop at different times).  uni() pins such values into an SGPR so the branch is scalar.
-__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
-// LDS candidate layout: logical slot j lives at phys(j); rotating each 32-slot row by its row number keeps
-// the one-lane-per-row writes of the lead decode (lane t writes row t, column i) off a single bank.
-__device__ __forceinline__ uint32_t phys(uint32_t j) { return (j & ~31u) | ((j + (j >> 5)) & 31u); }
-
-__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
-        uint32_t x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if ((int)(threadIdx.x & 63) >= d)
-                        x += y;
-        }
-        total = __shfl(x, 63, 64);
-        return x - v;
-}
-
-#ifndef TRI_DENSE_V
-#define TRI_DENSE_V 1
-#endif
-constexpr uint32_t SPAN_BITS = 1u << 17; // docIDs per dense window
-constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
-
-struct AndShared {
-        union {
-                struct {
-                        uint32_t cand[TILE_CANDS];
-                        uint32_t hit[TILE_BLOCKS]; // bit k of hit[r] <=> logical candidate r*32+k matched
-                        uint32_t blkof[AND_WG + 1];
-                };
-                uint32_t bits[2][SPAN_WORDS + 1]; // TASK_DENSE: two docID-window bitmaps (candidates / survivors), +1 sink word
-        };
-        uint32_t tbase[AND_WG];
-        uint32_t scan[8];
-        uint32_t bcast[4];
-        uint32_t lcur[16]; // per term: directory cursor, uniform across the workgroup
-};
-
-// Workgroup-cooperative lower bound over a sorted global array: first i in [0, n) with a[i] >= key, else n.
-// 256-ary search: every lane probes the end of its segment, one ballot per wave finds the first segment whose
-// last element is >= key; ~log256(n) rounds of one (L2-resident) load each instead of log2(n) dependent loads.
-__device__ uint32_t wg_lower_bound(AndShared &sh, const uint32_t *__restrict__ a, const uint32_t n, const uint32_t key) {
-        const uint32_t tid = threadIdx.x;
-        uint32_t lo = 0, hi = n; // answer in [lo, hi]
-        while (hi > lo) {
-                const uint32_t len = hi - lo;
-                const uint32_t step = (len + AND_WG - 1) / AND_WG;
-                const uint32_t pos = lo + (tid + 1) * step - 1;
-                const bool ge = pos >= hi ? true : a[pos] >= key;
-                const uint64_t m = __ballot(ge);
-                sh.scan[tid >> 6] = m ? (tid & ~63u) + (uint32_t)__builtin_ctzll(m) : 0xffffffffu;
-                __syncthreads();
-                const uint32_t first = uni(min(min(sh.scan[0], sh.scan[1]), min(sh.scan[2], sh.scan[3])));
-                __syncthreads();
-                const uint32_t nlo = lo + first * step;
-                const uint32_t nhi = min(hi, lo + (first + 1) * step - 1);
-                lo = nlo;
-                hi = step == 1 ? nlo : nhi;
-        }
-        return lo;
-}
-
-// Filter the C candidates in sh.cand (logical order ascending) against term `t`: sets sh.hit bits.
-// Caller syncs before and after.
-__device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                const uint32_t *__restrict__ blk_off, const DevTerm t, const uint32_t C, const uint32_t lcur_slot,
-                                const bool block_driven) {
-        const uint32_t tid = threadIdx.x;
-        const uint32_t *bl = blk_last + t.first_block;
-        const uint32_t *bo = blk_off + t.first_block;
-        const uint32_t cmin = sh.cand[phys(0)], cmax = sh.cand[phys(C - 1)];
-
-        if (block_driven) {
-                // advance lcur to the first block whose last docID >= cmin (tiles arrive in ascending docID order)
-                uint32_t lcur = uni(sh.lcur[lcur_slot]);
-                if (lcur == 0xffffffffu) // first tile of this task: position by cooperative search, then gallop forward
-                        lcur = wg_lower_bound(sh, bl, t.nblocks, cmin);
-                for (;;) {
-                        const uint32_t b = lcur + tid;
-                        const bool below = b < t.nblocks && bl[b] < cmin;
-                        const uint64_t m = __ballot(below);
-                        // number of leading lanes (from lane 0) with below == true, per wave
-                        const uint32_t lead = m == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
-                        sh.scan[tid >> 6] = lead; // wave-uniform value, every lane stores it: no divergent branch
-                        __syncthreads();
-                        uint32_t adv = 0;
-                        for (int w = 0; w < AND_WG / 64; ++w) {
-                                adv += sh.scan[w];
-                                if (sh.scan[w] != 64)
-                                        break;
-                        }
-                        adv = uni(adv);
-                        __syncthreads();
-                        lcur += adv;
-                        if (adv != AND_WG || lcur >= t.nblocks)
-                                break;
-                }
-                sh.lcur[lcur_slot] = lcur; // uniform value, branch-free store
-                TRACE(10, lcur, t.nblocks);
-                for (uint32_t cb = lcur; cb < t.nblocks; cb += AND_WG) {
-                        TRACE(11, cb, t.nblocks);
-                        const uint32_t b = cb + tid;
-                        bool beyond = true;
-                        if (b < t.nblocks) {
-                                const uint32_t prev = b ? bl[b - 1] : 0; // docs of block b lie in (prev, last]
-                                const uint32_t last = bl[b];
-                                beyond = last >= cmax;
-                                if (prev < cmax) {
-                                        // first candidate > prev
-                                        uint32_t lo = 0, hi = C;
-                                        while (lo < hi) {
-                                                const uint32_t mid = (lo + hi) >> 1;
-                                                if (sh.cand[phys(mid)] <= prev)
-                                                        lo = mid + 1;
-                                                else
-                                                        hi = mid;
-                                        }
-                                        uint32_t ptr = lo;
-                                        uint32_t cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
-                                        if (cv <= last) {
-                                                const uint32_t off = bo[b];
-                                                const uint32_t n = index[off - 1];
-                                                VbStream s;
-                                                s.init(index + off);
-                                                uint32_t doc = prev;
-                                                for (uint32_t i = 0; i < n; ++i) {
-                                                        doc = (i + 1 < n) ? doc + s.next() : last;
-                                                        while (cv < doc) {
-                                                                ++ptr;
-                                                                cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
-                                                        }
-                                                        if (cv == doc)
-                                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
-                                                        if (cv > last)
-                                                                break;
-                                                }
-                                        }
-                                }
-                        }
-                        // workgroup-wide OR of `beyond`, branch-free: one ballot per wave, four LDS words
-                        sh.scan[4 + (tid >> 6)] = __ballot(beyond) != 0ull;
-                        __syncthreads();
-                        const uint32_t any_beyond = uni(sh.scan[4] | sh.scan[5] | sh.scan[6] | sh.scan[7]);
-                        __syncthreads();
-                        if (any_beyond)
-                                break;
-                }
-        } else {
-                // candidate-driven galloping: each candidate finds its block in the directory; the first
-                // candidate of each run that maps to the same block decodes it and merges forward
-                sh.blkof[0] = 0xffffffffu;
-                __syncthreads();
-                for (uint32_t base = 0; base < C; base += AND_WG) {
-                        TRACE(20, base, C);
-                        const uint32_t j = base + tid;
-                        uint32_t bj = 0xffffffffu;
-                        uint32_t cv = 0;
-                        if (j < C) {
-                                cv = sh.cand[phys(j)];
-                                uint32_t lo = 0, hi = t.nblocks; // first block with last >= cv
-                                while (lo < hi) {
-                                        const uint32_t mid = (lo + hi) >> 1;
-                                        if (bl[mid] < cv)
-                                                lo = mid + 1;
-                                        else
-                                                hi = mid;
-                                }
-                                bj = lo; // == nblocks: beyond the list
-                        }
-                        sh.blkof[tid + 1] = bj;
-                        __syncthreads();
-                        const uint32_t prevb = sh.blkof[tid];
-                        __syncthreads();
-                        {
-                                // carry the last lane's block into the next round (slot 0), branch-free:
-                                // lanes of the last wave all store lane 63's value, other waves rewrite their own slot
-                                const uint32_t lastb = __shfl(bj, 63, 64);
-                                const bool lastwave = (tid >> 6) == (AND_WG / 64 - 1);
-                                sh.blkof[lastwave ? 0 : tid + 1] = lastwave ? lastb : bj;
-                        }
-                        if (j < C && bj < t.nblocks && bj != prevb) {
-                                const uint32_t prev = bj ? bl[bj - 1] : 0;
-                                const uint32_t last = bl[bj];
-                                const uint32_t off = bo[bj];
-                                const uint32_t n = index[off - 1];
-                                VbStream s;
-                                s.init(index + off);
-                                uint32_t doc = prev;
-                                uint32_t ptr = j;
-                                for (uint32_t i = 0; i < n; ++i) {
-                                        doc = (i + 1 < n) ? doc + s.next() : last;
-                                        while (cv < doc) {
-                                                ++ptr;
-                                                cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
-                                        }
-                                        if (cv == doc)
-                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
-                                        if (cv > last)
-                                                break;
-                                }
-                        }
-                        __syncthreads();
-                }
-        }
-}
-
-// ---- TASK_DENSE: bitmap algebra over docID windows -------------------------------------------------------
-// One lane decodes one block (unpack_block, google_codec.cpp:596-639) and ORs its documents into / tests them
-// against a window bitmap in LDS.  Consecutive documents of a dense list fall into the same 32-bit word, so the
-// lane keeps the current word in registers and touches LDS once per word, not once per posting.
-// Bitmap word -> LDS slot.  Neighbouring lanes decode neighbouring blocks, i.e. words a small constant stride apart,
-// which lands lanes l and l+16 on one bank; XOR-ing in the next five index bits spreads every 32-word row differently.
-// A bijection inside each 1024-word group; the sink word (index SPAN_WORDS) maps to itself.
-#if TRI_DENSE_V == 1
-__device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w ^ ((w >> 5) & 31u); }
-#else
-__device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w; }
-#endif
-
-template <bool FIRST>
-__device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
-                                            const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
-        VbStream s;
-        s.init(index + off);
-        uint32_t doc = prev;
-#if TRI_DENSE_V == 0
-        uint32_t curword = 0xffffffffu, cw = 0, acc = 0;
-        auto visit = [&](const uint32_t d) {
-                const uint32_t rel = d - w0; // documents outside the window land on word >= SPAN_WORDS
-                const uint32_t word = rel >> 5;
-                if (word != curword) {
-                        if (acc)
-                                atomicOr(&dst[curword], acc);
-                        acc = 0;
-                        curword = word;
-                        cw = word < SPAN_WORDS ? (FIRST ? 0xffffffffu : src[word]) : 0u;
-                }
-                acc |= cw & (1u << (rel & 31u));
-        };
-#else
-        // branch-free: one LDS OR (plus one LDS read when testing) per posting; documents outside the window go to the
-        // sink word.  No lane-divergent control flow inside the 8-posting fast path, so the reads pipeline.
-        auto visit = [&](const uint32_t d) {
-                const uint32_t rel = d - w0;
-                const uint32_t word = bswz(min(rel >> 5, SPAN_WORDS));
-                const uint32_t bit = 1u << (rel & 31u);
-                if (FIRST)
-                        atomicOr(&dst[word], bit);
-                else
-                        atomicOr(&dst[word], src[word] & bit);
-        };
-#endif
-        const uint32_t nd = n - 1;
-        uint32_t i = 0;
-        while (i < nd) {
-                s.refill();
-                const uint32_t k = min(8u, nd - i);
-                if (s.small_run(k)) { // k one-byte deltas (the rule for head terms): no per-value length decode
-                        uint64_t w = s.take(k);
-#pragma unroll
-                        for (uint32_t j = 0; j < 8; ++j) {
-                                if (j < k) {
-                                        doc += (uint32_t)(w & 0xffu);
-                                        w >>= 8;
-                                        visit(doc);
-                                }
-                        }
-                        i += k;
-                } else {
-                        doc += s.next();
-                        visit(doc);
-                        ++i;
-                }
-        }
-        visit(last);
-#if TRI_DENSE_V == 0
-        if (acc)
-                atomicOr(&dst[curword], acc);
-#endif
-}
-
-__device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                           const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
-                           const uint32_t *__restrict__ qterms, const DevQuery q, const DevTask task, uint32_t *__restrict__ out,
-                           uint32_t *__restrict__ count_out) {
-        const uint32_t tid = threadIdx.x;
-        uint32_t *qout = out + task.out_off;
-        uint32_t produced = 0;
-        sh.lcur[tid & 15] = 0; // per term: a block index at or before the first block that can matter
-        __syncthreads();
-        // number of terms in the lead group (it creates the candidates; the other groups test them)
-        uint32_t nlead = 1;
-        while (nlead < q.nterms && !(qterms[q.term_base + nlead] & QT_GROUP))
-                ++nlead;
-        bool done = false; // uniform
-        for (uint32_t w = task.tile_begin; w < task.tile_end && !done;) {
-                // ---- skip windows no lead-group list reaches: position the lead cursors at w, look at the first
-                //      document each may hold at or after it
-                uint32_t wnext = 0xffffffffu;
-                for (uint32_t k = 0; k < nlead; ++k) {
-                        const DevTerm t = terms[qterms[q.term_base + k] & ~QT_GROUP];
-                        const uint32_t *bl = blk_last + t.first_block;
-                        uint32_t cur;
-                        if (t.win_off != 0xffffffffu)
-                                cur = win[t.win_off + w]; // indexed list: first block with last >= w * SPAN_BITS
-                        else {
-                                cur = uni(sh.lcur[k]);
-                                if (cur < t.nblocks && bl[cur] < w * SPAN_BITS)
-                                        cur += wg_lower_bound(sh, bl + cur, t.nblocks - cur, w * SPAN_BITS);
-                                __syncthreads();
-                                sh.lcur[k] = cur;
-                        }
-                        if (cur < t.nblocks) {
-                                const uint32_t first_possible = cur ? bl[cur - 1] + 1 : 1;
-                                wnext = min(wnext, max(w, first_possible / SPAN_BITS));
-                        }
-                }
-                __syncthreads();
-                if (wnext >= task.tile_end)
-                        break; // the lead group holds nothing more in this task's range
-                w = wnext;
-                const uint32_t w0 = w * SPAN_BITS;
-                const uint32_t wlast = w0 + (SPAN_BITS - 1);
-                uint32_t gi = 0;       // group index
-                bool galive = false;   // some term of the current group reaches this window or beyond
-                for (uint32_t k = 0; k < q.nterms; ++k) {
-                        const uint32_t tt = qterms[q.term_base + k];
-                        const DevTerm t = terms[tt & ~QT_GROUP];
-                        const uint32_t *bl = blk_last + t.first_block;
-                        const uint32_t *bo = blk_off + t.first_block;
-                        if (k && (tt & QT_GROUP)) {
-                                if (!galive) { // an exhausted conjunct: no further match anywhere
-                                        done = true;
-                                        break;
-                                }
-                                ++gi;
-                                galive = false;
-                        }
-                        uint32_t *dst = sh.bits[gi & 1];
-                        const uint32_t *src = sh.bits[(gi & 1) ^ 1];
-                        if (tt & QT_GROUP)
-                                for (uint32_t i = tid; i < SPAN_WORDS; i += AND_WG)
-                                        dst[i] = 0;
-                        // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
-                        uint32_t b_lo, b_hi;
-                        if (t.win_off != 0xffffffffu) {
-                                // indexed list: two scalar loads replace both directory searches (win[w + 1] is the first block
-                                // with last >= the next window's first docID; it may still hold documents of this window)
-                                b_lo = win[t.win_off + w];
-                                b_hi = min(win[t.win_off + w + 1], t.nblocks - 1);
-                                if (b_lo < t.nblocks)
-                                        galive = true;
-                                __syncthreads(); // dst cleared, earlier passes complete
-                        } else {
-                                b_lo = uni(sh.lcur[k]);
-                                if (b_lo < t.nblocks && bl[b_lo] < w0)
-                                        b_lo += wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, w0);
-                                b_hi = b_lo;
-                                if (b_lo < t.nblocks) {
-                                        galive = true;
-                                        b_hi = b_lo + wg_lower_bound(sh, bl + b_lo, t.nblocks - b_lo, wlast);
-                                        if (b_hi >= t.nblocks)
-                                                b_hi = t.nblocks - 1;
-                                }
-                                __syncthreads(); // dst cleared, earlier passes complete, cursor reads done
-                                sh.lcur[k] = b_lo < t.nblocks ? b_hi : b_lo;
-                        }
-                        if (b_lo < t.nblocks) {
-                                for (uint32_t cb = b_lo; cb <= b_hi; cb += AND_WG) {
-                                        const uint32_t b = cb + tid;
-                                        if (b <= b_hi) {
-                                                const uint32_t prev = b ? bl[b - 1] : 0;
-                                                const uint32_t last = bl[b];
-                                                const uint32_t off = bo[b];
-                                                const uint32_t n = index[off - 1];
-                                                if (gi == 0)
-                                                        dense_block<true>(index, off, n, prev, last, w0, src, dst);
-                                                else
-                                                        dense_block<false>(index, off, n, prev, last, w0, src, dst);
-                                        }
-                                }
-                        }
-                        __syncthreads();
-                }
-                if (done || !galive) {
-                        done = true;
-                        break;
-                }
-                // ---- expand the survivors bitmap into ascending docIDs
-                const uint32_t *fin = sh.bits[gi & 1];
-                uint32_t *pre = sh.bits[(gi & 1) ^ 1]; // the other bitmap is dead: per-word exclusive prefix
-                {
-                        uint32_t run = 0;
-                        for (uint32_t j = 0; j < SPAN_WORDS / AND_WG; ++j) {
-                                const uint32_t wi = tid * (SPAN_WORDS / AND_WG) + j;
-                                pre[wi] = run;
-                                run += __popc(fin[bswz(wi)]);
-                        }
-                        uint32_t wtot;
-                        const uint32_t ex = wave_excl_scan(run, wtot);
-                        sh.scan[tid >> 6] = wtot;
-                        __syncthreads();
-                        uint32_t wbase = 0, total = 0;
-                        for (int wv = 0; wv < AND_WG / 64; ++wv) {
-                                if (wv < (int)(tid >> 6))
-                                        wbase += sh.scan[wv];
-                                total += sh.scan[wv];
-                        }
-                        sh.tbase[tid] = ex + wbase;
-                        __syncthreads();
-                        // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
-                        for (uint32_t wi = tid; wi < SPAN_WORDS; wi += AND_WG) {
-                                uint32_t m = fin[bswz(wi)];
-                                uint32_t o = produced + sh.tbase[wi / (SPAN_WORDS / AND_WG)] + pre[wi];
-                                const uint32_t base = w0 + wi * 32;
-                                while (m) {
-                                        qout[o++] = base + (uint32_t)__builtin_ctz(m);
-                                        m &= m - 1;
-                                }
-                        }
-                        produced += uni(total);
-                        __syncthreads();
-                }
-                ++w;
-        }
-        __syncthreads();
-        if (uni(tid >> 6) == 0)
-                *count_out = produced;
-}
-
-__global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                                const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
-                                                const DevTerm *__restrict__ terms,
-                                                const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
-                                                const uint32_t *__restrict__ sched, const uint32_t *__restrict__ qterms,
-                                                const uint32_t ntasks, uint32_t *__restrict__ ticket,
-                                                uint32_t *__restrict__ out, uint32_t *__restrict__ counts) {
-        __shared__ AndShared sh;
-        const uint32_t tid = threadIdx.x;
-        const uint32_t wave = uni(tid >> 6);
-        for (;;) {
-                // next query: wave 0 draws the ticket.  All 64 lanes add 1 (the compiler folds that into ONE
-                // global atomic of +64 with a uniform operand — no lane-divergent branch at the loop head), so the
-                // counter advances in units of 64 per draw.
-                if (wave == 0) {
-                        const uint32_t old = atomicAdd(ticket, 1u);
-                        sh.bcast[0] = uni(old) >> 6;
-                }
-                __syncthreads();
-                const uint32_t ticket_no = uni(sh.bcast[0]);
-                __syncthreads();
-                if (ticket_no >= ntasks)
-                        break;
-                const uint32_t tix = sched[ticket_no];
-                const DevTask task = tasks[tix];
-                const uint32_t slot = task.slot;
-                const DevQuery q = plan[slot];
-                if (task.kind == TASK_DENSE) {
-                        dense_task(sh, index, blk_last, blk_off, win, terms, qterms, q, task, out, counts + tix);
-                        continue;
-                }
-                const DevTerm lead = terms[qterms[q.term_base] & ~QT_GROUP];
-                TRACE(1, slot, q.nterms);
-                uint32_t *qout = out + task.out_off;
-                uint32_t produced = 0;
-                sh.lcur[tid & 15] = 0xffffffffu; // "not positioned yet"
-                const uint32_t tb_end = min(lead.nblocks, task.tile_end * TILE_BLOCKS);
-
-                for (uint32_t tb = task.tile_begin * TILE_BLOCKS; tb < tb_end; tb += TILE_BLOCKS) {
-                        const uint32_t nb = min((uint32_t)TILE_BLOCKS, lead.nblocks - tb);
-                        uint32_t C = (tb + nb == lead.nblocks) ? (nb - 1) * 32 + lead.last_n : nb * 32;
-                        // ---- decode the lead tile: one lane per block (unpack_block, google_codec.cpp:596-639)
-                        if (tid < nb) {
-                                const uint32_t b = tb + tid, gb = lead.first_block + b;
-                                const uint32_t off = blk_off[gb];
-                                const uint32_t n = index[off - 1];
-                                const uint32_t last = blk_last[gb];
-                                uint32_t doc = b ? blk_last[gb - 1] : 0;
-                                VbStream s;
-                                s.init(index + off);
-                                const uint32_t row = tid * 32;
-                                for (uint32_t i = 0; i + 1 < n; ++i) {
-                                        doc += s.next();
-                                        sh.cand[row | ((i + tid) & 31u)] = doc;
-                                }
-                                sh.cand[row | ((n - 1 + tid) & 31u)] = last;
-                        }
-                        __syncthreads();
-                        TRACE(2, slot, tb);
-
-                        // ---- every other group filters the surviving candidates: a candidate survives a group when any
-                        //      of the group's terms holds it (hit bits are OR-ed across the group's terms)
-                        for (uint32_t k = 1; k < q.nterms && C; ++k) {
-                                const uint32_t tt = qterms[q.term_base + k];
-                                const DevTerm t = terms[tt & ~QT_GROUP];
-                                if (tt & QT_GROUP)
-                                        sh.hit[tid] = 0;
-                                __syncthreads();
-#if defined(TRI_FORCE_CAND)
-                                const bool bd = false;
-#elif defined(TRI_FORCE_BLOCK)
-                                const bool bd = true;
-#else
-                                const bool bd = t.nblocks <= lead.documents;
-#endif
-                                TRACE(3, slot, (k << 16) | (bd ? 1 : 0));
-                                and_filter_tile(sh, index, blk_last, blk_off, t, C, k - 1, bd);
-                                TRACE(4, slot, C);
-                                __syncthreads();
-                                const bool lastterm = k + 1 == q.nterms;
-                                if (!lastterm && !(qterms[q.term_base + k + 1] & QT_GROUP))
-                                        continue; // more terms of this OR group to come
-                                // compact survivors (stable => still ascending)
-                                const uint32_t bits = sh.hit[tid];
-                                const uint32_t cnt = __popc(bits);
-                                uint32_t wtot;
-                                uint32_t ex = wave_excl_scan(cnt, wtot);
-                                sh.scan[tid >> 6] = wtot; // wave-uniform
-                                __syncthreads();
-                                uint32_t wbase = 0, total = 0;
-                                for (int w = 0; w < AND_WG / 64; ++w) {
-                                        if (w < (int)(tid >> 6))
-                                                wbase += sh.scan[w];
-                                        total += sh.scan[w];
-                                }
-                                ex += wbase;
-                                if (lastterm) {
-                                        // last group: survivors go straight to the result, ascending
-                                        uint32_t m = bits, o = produced + ex;
-                                        while (m) {
-                                                const uint32_t kbit = __builtin_ctz(m);
-                                                m &= m - 1;
-                                                qout[o++] = sh.cand[phys(tid * 32 + kbit)];
-                                        }
-                                } else {
-                                        // in-place compaction: every lane lifts its row into registers first
-                                        uint32_t vals[32];
-#pragma unroll
-                                        for (int kk = 0; kk < 32; ++kk)
-                                                vals[kk] = sh.cand[(tid * 32) | ((kk + tid) & 31u)];
-                                        __syncthreads();
-                                        uint32_t o = ex;
-#pragma unroll
-                                        for (int kk = 0; kk < 32; ++kk)
-                                                if ((bits >> kk) & 1u) {
-                                                        sh.cand[phys(o)] = vals[kk];
-                                                        ++o;
-                                                }
-                                }
-                                C = uni(total);
-                                __syncthreads();
-                        }
-                        if (q.nterms == 1) {
-                                for (uint32_t j = tid; j < C; j += AND_WG)
-                                        qout[produced + j] = sh.cand[phys(j)];
-                        }
-                        produced += C;
-                        __syncthreads();
-                }
-                if (wave == 0)
-                        counts[tix] = produced; // scalar branch; the wave's lanes store one identical dword
-                TRACE(5, slot, produced);
-        }
-        TRACE(6, 0, 0);
-}
-
-// ------------------------------------------------------------------------------------------ k_score / k_topk_merge
-// AccumulatedScoreScheme (exec.h:36-41).  k_and has produced every query's ascending match list; k_score walks each
-// task's segment in tiles of 4096 matches, and for every scoring term looks the matches up again through the
-// directory (each match binary-searches its block, the first match of a block decodes it once: deltas to locate the
-// matching positions, then the freqs), adding  float(idf * float(f) / double(f + 1.2f))  to a per-match double in LDS —
-// IndexSourcesCollectionBM25Scorer::Scorer::score (similarity.h:228-235) summed in iterator order by the Conjuction
-// wrapper (docset_iterators_scorers.cpp:173-193).  The tile is then offered to the task's top-K (score descending,
-// docID ascending: the application-side MatchedIndexDocumentsFilter heap, matches.h:155-171).  k_topk_merge folds
-// the tasks' partial lists into one list per query.
-constexpr uint32_t SCORE_TILE = 4096;
-constexpr uint32_t TOPK_MAX = 256;
-constexpr uint32_t TOPK_CAP = TOPK_MAX + AND_WG; // survivors + one wave of newcomers
-
-struct TopK {
-        double s[TOPK_CAP];
-        uint32_t d[TOPK_CAP];
-        uint32_t n;       // entries held (uniform)
-        uint32_t full;    // n has reached k at least once => thr_* valid
-        double thr_s;     // the k-th best entry
-        uint32_t thr_d;
-};
-
-__device__ __forceinline__ bool better(const double s1, const uint32_t d1, const double s2, const uint32_t d2) {
-        return s1 > s2 || (s1 == s2 && d1 < d2);
-}
-
-// Keep the best k of the n entries, sorted best-first (rank by counting: the order is strict, ranks are unique).
-__device__ void topk_prune(TopK &tk, const uint32_t k, uint32_t *scan) {
-        const uint32_t tid = threadIdx.x;
-        const uint32_t n = uni(tk.n);
-        double es[2];
-        uint32_t ed[2], rk[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-                const uint32_t i = tid + r * AND_WG;
-                rk[r] = 0xffffffffu;
-                if (i < n) {
-                        es[r] = tk.s[i];
-                        ed[r] = tk.d[i];
-                        uint32_t c = 0;
-                        for (uint32_t j = 0; j < n; ++j)
-                                c += better(tk.s[j], tk.d[j], es[r], ed[r]) ? 1u : 0u;
-                        rk[r] = c;
-                }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-                if (rk[r] < k) {
-                        tk.s[rk[r]] = es[r];
-                        tk.d[rk[r]] = ed[r];
-                }
-        __syncthreads();
-        const uint32_t m = n < k ? n : k;
-        // uniform stores by every lane (no single-lane branch around the barrier loop that calls us)
-        tk.n = m;
-        if (m == k) {
-                tk.full = 1;
-                tk.thr_s = tk.s[k - 1];
-                tk.thr_d = tk.d[k - 1];
-        }
-        (void)scan;
-        __syncthreads();
-}
-
-// Every lane offers at most one (score, doc); survivors of the threshold are appended, pruning when the buffer fills.
-__device__ void topk_offer(TopK &tk, const uint32_t k, const bool valid, const double sc, const uint32_t doc, uint32_t *scan) {
-        const uint32_t tid = threadIdx.x;
-        const uint32_t n0 = uni(tk.n); // stable: the previous call ended with a barrier
-        const bool take = valid && (!tk.full || better(sc, doc, tk.thr_s, tk.thr_d));
-        const uint64_t m = __ballot(take);
-        const uint32_t lane = tid & 63;
-        const uint32_t before = __popcll(m & ((1ull << lane) - 1ull));
-        scan[tid >> 6] = __popcll(m);
-        __syncthreads();
-        uint32_t base = n0, tot = 0;
-        for (uint32_t w = 0; w < AND_WG / 64; ++w) {
-                if (w < (tid >> 6))
-                        base += scan[w];
-                tot += scan[w];
-        }
-        tot = uni(tot);
-        if (take) {
-                tk.s[base + before] = sc;
-                tk.d[base + before] = doc;
-        }
-        __syncthreads();
-        tk.n = n0 + tot; // same value from every lane
-        __syncthreads();
-        if (n0 + tot > TOPK_MAX)
-                topk_prune(tk, k, scan);
-}
-
-struct ScoreShared {
-        uint32_t cand[SCORE_TILE];
-        double score[SCORE_TILE];
-        uint32_t hit[SCORE_TILE / 32]; // per scoring term: which matches this term holds
-        uint32_t blkof[AND_WG + 1];
-        uint32_t scan[8];
-        uint32_t bcast[4];
-        TopK tk;
-};
-
-__device__ __forceinline__ float bm25_term(const double idf, const uint32_t freq32) {
-        const uint16_t freq = (uint16_t)freq32; // PostingsListIterator::freq is tokenpos_t (codecs.h:217)
-        return (float)(idf * (double)(float)freq / (double)((float)freq + 1.2f));
-}
-
-__global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                                  const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
-                                                  const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
-                                                  const uint32_t *__restrict__ sched, const uint32_t *__restrict__ sterms,
-                                                  const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket,
-                                                  const uint32_t *__restrict__ out, const uint32_t *__restrict__ counts, const uint32_t k,
-                                                  uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
-                                                  uint32_t *__restrict__ part_counts, double *__restrict__ all_scores) {
-        __shared__ ScoreShared sh;
-        const uint32_t tid = threadIdx.x;
-        const uint32_t wave = uni(tid >> 6);
-        for (;;) {
-                if (wave == 0) {
-                        const uint32_t old = atomicAdd(ticket, 1u);
-                        sh.bcast[0] = uni(old) >> 6;
-                }
-                __syncthreads();
-                const uint32_t ticket_no = uni(sh.bcast[0]);
-                __syncthreads();
-                if (ticket_no >= ntasks)
-                        break;
-                const uint32_t tix = sched[ticket_no];
-                const DevTask task = tasks[tix];
-                const DevQuery q = plan[task.slot];
-                const uint32_t M = counts[tix];
-                const uint32_t *seg = out + task.out_off;
-                sh.tk.n = 0;
-                sh.tk.full = 0;
-                __syncthreads();
-                for (uint32_t tb = 0; tb < M; tb += SCORE_TILE) {
-                        const uint32_t C = min(SCORE_TILE, M - tb);
-                        for (uint32_t j = tid; j < C; j += AND_WG) {
-                                sh.cand[j] = seg[tb + j];
-                                sh.score[j] = 0.0;
-                        }
-                        __syncthreads();
-                        for (uint32_t ti = 0; ti < q.nscore; ++ti) {
-                                const DevTerm t = terms[sterms[q.score_base + ti]];
-                                const double w = sweights[q.score_base + ti];
-                                const uint32_t *bl = blk_last + t.first_block;
-                                const uint32_t *bo = blk_off + t.first_block;
-                                sh.blkof[0] = 0xffffffffu;
-                                if (tid < SCORE_TILE / 32)
-                                        sh.hit[tid] = 0;
-                                __syncthreads();
-                                for (uint32_t base = 0; base < C; base += AND_WG) {
-                                        const uint32_t j = base + tid;
-                                        uint32_t bj = 0xffffffffu, cv = 0;
-                                        if (j < C) {
-                                                cv = sh.cand[j];
-                                                uint32_t lo = 0, hi = t.nblocks;
-                                                while (lo < hi) {
-                                                        const uint32_t mid = (lo + hi) >> 1;
-                                                        if (bl[mid] < cv)
-                                                                lo = mid + 1;
-                                                        else
-                                                                hi = mid;
-                                                }
-                                                bj = lo;
-                                        }
-                                        sh.blkof[tid + 1] = bj;
-                                        __syncthreads();
-                                        const uint32_t prevb = sh.blkof[tid];
-                                        __syncthreads();
-                                        {
-                                                const uint32_t lastb = __shfl(bj, 63, 64);
-                                                const bool lastwave = (tid >> 6) == (AND_WG / 64 - 1);
-                                                sh.blkof[lastwave ? 0 : tid + 1] = lastwave ? lastb : bj;
-                                        }
-                                        if (j < C && bj < t.nblocks && bj != prevb) {
-                                                const uint32_t prev = bj ? bl[bj - 1] : 0;
-                                                const uint32_t last = bl[bj];
-                                                const uint32_t off = bo[bj];
-                                                const uint32_t n = index[off - 1];
-                                                VbStream s;
-                                                s.init(index + off);
-                                                // deltas: merge the block's documents against the matches from j on; remember
-                                                // the block positions (mask) and the matches (hit bits) that coincide.  Under an
-                                                // OR a match need not be a document of this list.
-                                                uint32_t doc = prev, ptr = j, mask = 0;
-                                                for (uint32_t i = 0; i < n; ++i) {
-                                                        doc = (i + 1 < n) ? doc + s.next() : last;
-                                                        while (cv < doc) {
-                                                                ++ptr;
-                                                                cv = ptr < C ? sh.cand[ptr] : 0xffffffffu;
-                                                        }
-                                                        if (cv == doc) {
-                                                                mask |= 1u << i;
-                                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
-                                                        }
-                                                }
-                                                // freqs follow the n-1 deltas; the i-th marked position belongs to the i-th
-                                                // marked match (both ascending; only this lane marks matches in its block's range)
-                                                ptr = j;
-                                                for (uint32_t i = 0; i < n; ++i) {
-                                                        const uint32_t f = s.next();
-                                                        if ((mask >> i) & 1u) {
-                                                                while (!((sh.hit[ptr >> 5] >> (ptr & 31)) & 1u))
-                                                                        ++ptr;
-                                                                sh.score[ptr] += (double)bm25_term(w, f);
-                                                                ++ptr;
-                                                        }
-                                                }
-                                        }
-                                        __syncthreads();
-                                }
-                        }
-                        if (all_scores) // full score stream: what consider(id, score) receives for every match
-                                for (uint32_t j = tid; j < C; j += AND_WG)
-                                        all_scores[task.out_off + tb + j] = sh.score[j];
-                        if (k) {
-                                // offer the tile to the task's top-K
-                                for (uint32_t base = 0; base < C; base += AND_WG) {
-                                        const uint32_t j = base + tid;
-                                        topk_offer(sh.tk, k, j < C, j < C ? sh.score[j] : 0.0, j < C ? sh.cand[j] : 0u, sh.scan);
-                                }
-                        }
-                        __syncthreads();
-                }
-                if (k) {
-                        topk_prune(sh.tk, k, sh.scan);
-                        const uint32_t n = uni(sh.tk.n);
-                        for (uint32_t i = tid; i < n; i += AND_WG) {
-                                part_docs[(uint64_t)tix * k + i] = sh.tk.d[i];
-                                part_scores[(uint64_t)tix * k + i] = sh.tk.s[i];
-                        }
-                        if (wave == 0)
-                                part_counts[tix] = n;
-                }
-                __syncthreads();
-        }
-}
-
-// one workgroup per query: stream the tasks' partial lists through the same top-K structure
-__global__ __launch_bounds__(AND_WG) void k_topk_merge(const DevQuery *__restrict__ plan, const uint32_t nq, const uint32_t k,
-                                                       const uint32_t *__restrict__ part_docs, const double *__restrict__ part_scores,
-                                                       const uint32_t *__restrict__ part_counts, uint32_t *__restrict__ top_docs,
-                                                       float *__restrict__ top_scores, uint32_t *__restrict__ top_counts) {
-        __shared__ TopK tk;
-        __shared__ uint32_t scan[8];
-        const uint32_t tid = threadIdx.x;
-        for (uint32_t slot = blockIdx.x; slot < nq; slot += gridDim.x) {
-                const DevQuery q = plan[slot];
-                tk.n = 0;
-                tk.full = 0;
-                __syncthreads();
-                for (uint32_t t = 0; t < q.ntasks; ++t) {
-                        const uint32_t tix = q.first_task + t;
-                        const uint32_t c = part_counts[tix];
-                        for (uint32_t base = 0; base < c; base += AND_WG) {
-                                const uint32_t i = base + tid;
-                                const bool v = i < c;
-                                topk_offer(tk, k, v, v ? part_scores[(uint64_t)tix * k + i] : 0.0, v ? part_docs[(uint64_t)tix * k + i] : 0u, scan);
-                        }
-                }
-                topk_prune(tk, k, scan);
-                const uint32_t n = uni(tk.n);
-                for (uint32_t i = tid; i < k; i += AND_WG) {
-                        top_docs[(uint64_t)q.qid * k + i] = i < n ? tk.d[i] : 0u;
-                        top_scores[(uint64_t)q.qid * k + i] = i < n ? (float)tk.s[i] : 0.0f;
-                }
-                if (uni(tid >> 6) == 0)
-                        top_counts[q.qid] = n;
-                __syncthreads();
-        }
-}
-
-// FNV-1a(64) of each query's docID set (little-endian bytes), one lane per query — verification helper
-__global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks_by_query,
-                               const uint32_t *__restrict__ counts_by_query, const uint32_t nq, const uint32_t *__restrict__ out,
-                               uint64_t *__restrict__ hashes) {
-        const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-        if (s >= nq)
-                return;
-        const DevQuery q = plan[s];
-        uint64_t h = 1469598103934665603ull;
-        for (uint32_t t = 0; t < q.ntasks; ++t) {
-                const uint32_t *p = out + tasks_by_query[q.first_task + t].out_off;
-                const uint32_t n = counts_by_query[q.first_task + t];
-                for (uint32_t i = 0; i < n; ++i) {
-                        uint32_t d = p[i];
-                        for (int b = 0; b < 4; ++b) {
-                                h = (h ^ (d & 0xffu)) * 1099511628211ull;
-                                d >>= 8;
-                        }
-                }
-        }
-        hashes[s] = h;
-}
+#include "dev_stream.hpp"
+#include "k_decode.hpp"
+#include "k_match.hpp"
+#include "k_score.hpp"
 
 // ------------------------------------------------------------------------------------------ host: device
 extern "C" int tri_dev_open(int device, tri_dev **out) {
@@ -1730,9 +672,16 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 b->plan.push_back(t.q);
         }
         std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &c) { return a.first > c.first; });
-        std::vector<uint32_t> sched(order.size());
-        for (size_t i = 0; i < order.size(); ++i)
-                sched[i] = order[i].second;
+        std::vector<uint32_t> sched;
+        sched.reserve(order.size());
+        for (const auto &o : order)
+                if (b->tasks[o.second].kind == TASK_DENSE)
+                        sched.push_back(o.second);
+        b->n_dense = (uint32_t)sched.size();
+        for (const auto &o : order)
+                if (b->tasks[o.second].kind == TASK_CAND)
+                        sched.push_back(o.second);
+        b->n_cand = (uint32_t)sched.size() - b->n_dense;
         b->out_capacity = off;
         int rc;
         if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)) || (rc = dev_upload(&b->d_tasks, b->tasks)) ||
@@ -1805,10 +754,17 @@ extern "C" int tri_batch_run(tri_batch *b) {
         HIP_TRY(hipEventRecord(dev->ev0, dev->stream));
         if (n) {
                 HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 256, dev->stream));
-                const uint32_t grid = std::min<uint32_t>(n, (uint32_t)dev->cus * 4);
-                hipLaunchKernelGGL(k_and, dim3(grid), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win,
-                                   b->ix->d_terms,
-                                   b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, n, b->d_ticket, b->d_out, b->d_counts);
+                // two persistent kernels back to back on the engine stream: bitmap windows (512 threads), then candidate tiles
+                if (b->n_dense) {
+                        hipLaunchKernelGGL(k_and_dense, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * 4)), dim3(DENSE_WG), 0, dev->stream, b->ix->d_index,
+                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
+                                           b->d_ticket + 16, b->d_out, b->d_counts);
+                        HIP_TRY(hipGetLastError());
+                }
+                if (b->n_cand)
+                        hipLaunchKernelGGL(k_and, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * 4)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
+                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
+                                           b->n_cand, b->d_ticket, b->d_out, b->d_counts);
                 HIP_TRY(hipGetLastError());
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                         hipLaunchKernelGGL(k_score, dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 2)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
