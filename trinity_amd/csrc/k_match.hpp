@@ -80,6 +80,74 @@ __device__ uint32_t wg_lower_bound(AndShared &sh, const uint32_t *__restrict__ a
         return lo;
 }
 
+// The first 32 payload bytes of a block from THREE 16-byte-aligned loads, realigned in registers (a dword select
+// stage, then v_alignbyte).  Returns true when bytes 0..30 — the 31 doc deltas of a full block — are all one-byte varints
+// (every block of a head term), in which case delta j is byte j of v[].  One wave-load touches 64 cache lines whatever
+// its width, so 3 wide loads per block instead of ~13 eight-byte stream loads takes the pressure off the L1/TA path;
+// the freqs and hits behind the deltas are never touched in DocumentsOnly mode.
+__device__ __forceinline__ bool load_block_bytes32(const uint8_t *__restrict__ p, uint32_t (&v)[8]) {
+        const uintptr_t a = (uintptr_t)p;
+        const uint4 *q = (const uint4 *)(a & ~(uintptr_t)15);
+        const uint4 A = q[0], B = q[1], C = q[2];
+        const uint32_t sk = (uint32_t)(a & 15u);
+        uint32_t r[12] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z, C.w};
+        if (sk & 4u) {
+#pragma unroll
+                for (int i = 0; i < 11; ++i)
+                        r[i] = r[i + 1];
+        }
+        if (sk & 8u) {
+#pragma unroll
+                for (int i = 0; i < 10; ++i)
+                        r[i] = r[i + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+                v[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], sk & 3u);
+        return ((v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | (v[7] & 0x00ffffffu)) & 0x80808080u) == 0;
+}
+
+// Merge one block of term t against the candidates from `ptr` on (cv = candidate at ptr): set the hit bit of every
+// candidate that is a document of the block.  Full blocks of one-byte deltas take the register path above.
+__device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t off, const uint32_t prev,
+                                            const uint32_t last, uint32_t ptr, uint32_t cv, const uint32_t C) {
+        const uint32_t n = index[off - 1];
+        uint32_t doc = prev;
+        uint32_t v[8];
+        if (n == 32 && load_block_bytes32(index + off, v)) {
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                        doc = j < 31 ? doc + ((v[j >> 2] >> ((j & 3) * 8)) & 0xffu) : last;
+                        if (cv <= doc) {
+                                if (cv == doc)
+                                        atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
+                                do { // at most a handful of candidates fall into one block
+                                        ++ptr;
+                                        cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
+                                } while (cv < doc);
+                                if (cv == doc) // (only after skipping candidates that were below doc)
+                                        atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
+                                if (cv > last)
+                                        return;
+                        }
+                }
+                return;
+        }
+        VbStream s;
+        s.init(index + off);
+        for (uint32_t i = 0; i < n; ++i) {
+                doc = (i + 1 < n) ? doc + s.next() : last;
+                while (cv < doc) {
+                        ++ptr;
+                        cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
+                }
+                if (cv == doc)
+                        atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
+                if (cv > last)
+                        break;
+        }
+}
+
 // Filter the C candidates in sh.cand (logical order ascending) against term `t`: sets sh.hit bits.
 // Caller syncs before and after.
 __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
@@ -137,24 +205,8 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                         }
                                         uint32_t ptr = lo;
                                         uint32_t cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
-                                        if (cv <= last) {
-                                                const uint32_t off = bo[b];
-                                                const uint32_t n = index[off - 1];
-                                                VbStream s;
-                                                s.init(index + off);
-                                                uint32_t doc = prev;
-                                                for (uint32_t i = 0; i < n; ++i) {
-                                                        doc = (i + 1 < n) ? doc + s.next() : last;
-                                                        while (cv < doc) {
-                                                                ++ptr;
-                                                                cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
-                                                        }
-                                                        if (cv == doc)
-                                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
-                                                        if (cv > last)
-                                                                break;
-                                                }
-                                        }
+                                        if (cv <= last)
+                                                merge_block(sh, index, bo[b], prev, last, ptr, cv, C);
                                 }
                         }
                         // workgroup-wide OR of `beyond`, branch-free: one ballot per wave, four LDS words
@@ -200,24 +252,7 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                         }
                         if (j < C && bj < t.nblocks && bj != prevb) {
                                 const uint32_t prev = bj ? bl[bj - 1] : 0;
-                                const uint32_t last = bl[bj];
-                                const uint32_t off = bo[bj];
-                                const uint32_t n = index[off - 1];
-                                VbStream s;
-                                s.init(index + off);
-                                uint32_t doc = prev;
-                                uint32_t ptr = j;
-                                for (uint32_t i = 0; i < n; ++i) {
-                                        doc = (i + 1 < n) ? doc + s.next() : last;
-                                        while (cv < doc) {
-                                                ++ptr;
-                                                cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
-                                        }
-                                        if (cv == doc)
-                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
-                                        if (cv > last)
-                                                break;
-                                }
+                                merge_block(sh, index, bo[bj], prev, bl[bj], j, cv, C);
                         }
                         __syncthreads();
                 }
@@ -282,39 +317,15 @@ __device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ i
         dense_visit<FIRST>(last, w0, src, dst);
 }
 
-// A full block (n == 32) whose 31 deltas are all one byte long — every block of a head term — is decoded from THREE
-// 16-byte-aligned loads (the 31 delta bytes sit in the first 46 bytes after the aligned-down payload address; the freqs
-// and hits that follow are never touched in DocumentsOnly mode), realigned in registers (a dword select stage and a
-// v_alignbyte stage) and walked with a fully unrolled add per posting.  One wave-load touches 64 cache lines whatever
-// its width, so 3 wide loads per block instead of 13 eight-byte ones is what takes the pressure off the L1/TA path.
+// A full block (n == 32) of one-byte deltas takes the register path (load_block_bytes32) and a fully unrolled add per
+// posting; anything else goes through the generic stream.
 template <bool FIRST>
 __device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
                                             const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
 #if TRI_DENSE_V == 1
         if (n == 32) {
-                const uintptr_t a = (uintptr_t)(index + off);
-                const uint4 *q = (const uint4 *)(a & ~(uintptr_t)15);
-                const uint4 A = q[0], B = q[1], C = q[2];
-                const uint32_t sk = (uint32_t)(a & 15u);
-                uint32_t r[12] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z, C.w};
-                // dword shift by sk >> 2 (two select stages, static register indices)
-                if (sk & 4u) {
-#pragma unroll
-                        for (int i = 0; i < 11; ++i)
-                                r[i] = r[i + 1];
-                }
-                if (sk & 8u) {
-#pragma unroll
-                        for (int i = 0; i < 10; ++i)
-                                r[i] = r[i + 2];
-                }
-                // byte shift by sk & 3
                 uint32_t v[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                        v[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], sk & 3u);
-                const uint32_t hib = (v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | (v[7] & 0x00ffffffu)) & 0x80808080u;
-                if (hib == 0) {
+                if (load_block_bytes32(index + off, v)) {
                         uint32_t doc = prev;
 #pragma unroll
                         for (int j = 0; j < 31; ++j) {
