@@ -9,8 +9,14 @@ struct DevTerm {
         uint32_t nblocks;
         uint32_t last_n;  // docs in the final block (1..32)
         uint32_t win_off; // lists of >= WIN_MIN_BLOCKS blocks: row in win[] (first block with last >= w * SPAN_BITS, per window w); else ~0
-        uint32_t pad[3];
+        uint32_t flags;   // TERM_FULL_BLOCKS: every block but the last holds 32 documents (always true for chunks written by the
+                          // reference encoder, google_codec.cpp:76-88; verified at upload) => n needs no load
+        uint32_t pad[2];
 };
+constexpr uint32_t TERM_FULL_BLOCKS = 1u;
+
+// documents in block b of term t
+#define TRI_BLOCK_N(t, b, index, off) (((t).flags & TERM_FULL_BLOCKS) ? ((b) + 1 == (t).nblocks ? (t).last_n : 32u) : (uint32_t)(index)[(off)-1])
 constexpr uint32_t WIN_MIN_BLOCKS = 128;
 
 // A query in conjunctive normal form: AND of groups, a group = one term or an OR of terms.  qterms[] lists the terms

@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_decode_terms(const uint8_t *__restrict_
         for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b < t.nblocks; b += gridDim.x * 256) {
                 const uint32_t gb = t.first_block + b;
                 const uint32_t off = blk_off[gb];
-                const uint32_t n = index[off - 1];
+                const uint32_t n = TRI_BLOCK_N(t, b, index, off);
                 const uint32_t last = blk_last[gb];
                 uint32_t doc = b ? blk_last[gb - 1] : 0;
                 VbStream s;

@@ -6,7 +6,8 @@
 // ------------------------------------------------------------------------------------------ k_and
 constexpr int AND_WG = 256;   // candidate-tile kernel (k_and) and the scoring kernels
 constexpr int DENSE_WG = 512; // bitmap-window kernel (k_and_dense): 8 waves share one 36 KB window state
-constexpr int TILE_BLOCKS = 256;
+constexpr int TILE_BLOCKS = 256; // one candidate row per lane: must equal AND_WG
+static_assert(TILE_BLOCKS == 256, "the candidate kernel maps one 32-candidate row to each of its 256 lanes");
 constexpr int TILE_CANDS = TILE_BLOCKS * 32;
 
 // Values that are workgroup-uniform by construction but read back from LDS look divergent to the compiler; a
@@ -36,26 +37,30 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
 constexpr uint32_t SPAN_BITS = 1u << 17; // docIDs per dense window
 constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
 
+// LDS state of the candidate-tile kernel
 struct AndShared {
-        union {
-                struct {
-                        uint32_t cand[TILE_CANDS];
-                        uint32_t hit[TILE_BLOCKS]; // bit k of hit[r] <=> logical candidate r*32+k matched
-                        uint32_t blkof[AND_WG + 1];
-                };
-                uint32_t bits[2][SPAN_WORDS + 1]; // TASK_DENSE: two docID-window bitmaps (candidates / survivors), +1 sink word
-        };
-        uint32_t tbase[DENSE_WG];
+        uint32_t cand[TILE_CANDS];
+        uint32_t hit[TILE_BLOCKS]; // bit k of hit[r] <=> logical candidate r*32+k matched
+        uint32_t blkof[AND_WG + 1];
         uint32_t scan[8];
         uint32_t bcast[4];
         uint32_t lcur[16]; // per term: directory cursor, uniform across the workgroup
+};
+
+// LDS state of the bitmap-window kernel
+struct DenseShared {
+        uint32_t bits[2][SPAN_WORDS + 1]; // two docID-window bitmaps (candidates / survivors), +1 sink word each
+        uint32_t tbase[DENSE_WG];
+        uint32_t scan[8];
+        uint32_t bcast[4];
+        uint32_t lcur[16];
 };
 
 // Workgroup-cooperative lower bound over a sorted global array: first i in [0, n) with a[i] >= key, else n.
 // 256-ary search: every lane probes the end of its segment, one ballot per wave finds the first segment whose
 // last element is >= key; ~log256(n) rounds of one (L2-resident) load each instead of log2(n) dependent loads.
 template <int WG = AND_WG>
-__device__ uint32_t wg_lower_bound(AndShared &sh, const uint32_t *__restrict__ a, const uint32_t n, const uint32_t key) {
+__device__ uint32_t wg_lower_bound(uint32_t *scan, const uint32_t *__restrict__ a, const uint32_t n, const uint32_t key) {
         const uint32_t tid = threadIdx.x;
         uint32_t lo = 0, hi = n; // answer in [lo, hi]
         while (hi > lo) {
@@ -64,13 +69,15 @@ __device__ uint32_t wg_lower_bound(AndShared &sh, const uint32_t *__restrict__ a
                 const uint32_t pos = lo + (tid + 1) * step - 1;
                 const bool ge = pos >= hi ? true : a[pos] >= key;
                 const uint64_t m = __ballot(ge);
-                sh.scan[tid >> 6] = m ? (tid & ~63u) + (uint32_t)__builtin_ctzll(m) : 0xffffffffu;
+                scan[tid >> 6] = m ? (tid & ~63u) + (uint32_t)__builtin_ctzll(m) : 0xffffffffu;
                 __syncthreads();
                 uint32_t first = 0xffffffffu;
 #pragma unroll
                 for (int wv = 0; wv < WG / 64; ++wv)
-                        first = min(first, sh.scan[wv]);
+                        first = min(first, scan[wv]);
                 first = uni(first);
+                if (first == 0xffffffffu) // every probe < key (the last probe sat exactly on a[hi - 1]): nothing >= key
+                        return hi;
                 __syncthreads();
                 const uint32_t nlo = lo + first * step;
                 const uint32_t nhi = min(hi, lo + (first + 1) * step - 1);
@@ -109,9 +116,8 @@ __device__ __forceinline__ bool load_block_bytes32(const uint8_t *__restrict__ p
 
 // Merge one block of term t against the candidates from `ptr` on (cv = candidate at ptr): set the hit bit of every
 // candidate that is a document of the block.  Full blocks of one-byte deltas take the register path above.
-__device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t off, const uint32_t prev,
-                                            const uint32_t last, uint32_t ptr, uint32_t cv, const uint32_t C) {
-        const uint32_t n = index[off - 1];
+__device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n,
+                                            const uint32_t prev, const uint32_t last, uint32_t ptr, uint32_t cv, const uint32_t C) {
         uint32_t doc = prev;
         uint32_t v[8];
         if (n == 32 && load_block_bytes32(index + off, v)) {
@@ -148,6 +154,27 @@ __device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__rest
         }
 }
 
+// Wave-cooperative lower bound over a[lo, hi): first i with a[i] >= key (key wave-uniform), hi when none.  64-ary search
+// with one ballot per round — no LDS, no barrier; every active lane gets the same answer.
+__device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict__ a, uint32_t lo, uint32_t hi, const uint32_t key) {
+        const uint32_t lane = threadIdx.x & 63u;
+        while (hi > lo) {
+                const uint32_t len = hi - lo;
+                const uint32_t step = (len + 63u) / 64u;
+                const uint32_t pos = lo + (lane + 1) * step - 1;
+                const bool ge = pos >= hi ? true : a[pos] >= key;
+                const uint64_t m = __ballot(ge);
+                if (m == 0)
+                        return hi;
+                const uint32_t first = (uint32_t)__builtin_ctzll(m);
+                const uint32_t nlo = lo + first * step;
+                const uint32_t nhi = min(hi, lo + (first + 1) * step - 1);
+                lo = nlo;
+                hi = step == 1 ? nlo : nhi;
+        }
+        return lo;
+}
+
 // Filter the C candidates in sh.cand (logical order ascending) against term `t`: sets sh.hit bits.
 // Caller syncs before and after.
 __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
@@ -162,7 +189,7 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                 // advance lcur to the first block whose last docID >= cmin (tiles arrive in ascending docID order)
                 uint32_t lcur = uni(sh.lcur[lcur_slot]);
                 if (lcur == 0xffffffffu) // first tile of this task: position by cooperative search, then gallop forward
-                        lcur = wg_lower_bound(sh, bl, t.nblocks, cmin);
+                        lcur = wg_lower_bound(sh.scan, bl, t.nblocks, cmin);
                 for (;;) {
                         const uint32_t b = lcur + tid;
                         const bool below = b < t.nblocks && bl[b] < cmin;
@@ -206,7 +233,7 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                         uint32_t ptr = lo;
                                         uint32_t cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
                                         if (cv <= last)
-                                                merge_block(sh, index, bo[b], prev, last, ptr, cv, C);
+                                                merge_block(sh, index, bo[b], TRI_BLOCK_N(t, b, index, bo[b]), prev, last, ptr, cv, C);
                                 }
                         }
                         // workgroup-wide OR of `beyond`, branch-free: one ballot per wave, four LDS words
@@ -222,14 +249,26 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                 // candidate of each run that maps to the same block decodes it and merges forward
                 sh.blkof[0] = 0xffffffffu;
                 __syncthreads();
+                uint32_t wcur = 0; // this wave's directory cursor: its candidates only move forward from round to round
                 for (uint32_t base = 0; base < C; base += AND_WG) {
                         TRACE(20, base, C);
                         const uint32_t j = base + tid;
                         uint32_t bj = 0xffffffffu;
                         uint32_t cv = 0;
+                        // hierarchical narrowing: the wave's 64 ascending candidates bracket a directory range with two
+                        // cooperative 64-ary searches; each lane then bisects only inside that (cache-resident) range
+                        const uint32_t wbase = base + (tid & ~63u);
+                        uint32_t rlo = 0, rhi = 0;
+                        if (wbase < C) { // wave-uniform
+                                const uint32_t nval = min(64u, C - wbase);
+                                const uint32_t klo = sh.cand[phys(wbase)], khi = sh.cand[phys(wbase + nval - 1)];
+                                rlo = wave_lower_bound(bl, wcur, t.nblocks, klo);
+                                rhi = wave_lower_bound(bl, rlo, t.nblocks, khi);
+                                wcur = rlo;
+                        }
                         if (j < C) {
                                 cv = sh.cand[phys(j)];
-                                uint32_t lo = 0, hi = t.nblocks; // first block with last >= cv
+                                uint32_t lo = rlo, hi = rhi; // first block with last >= cv lies in [rlo, rhi]
                                 while (lo < hi) {
                                         const uint32_t mid = (lo + hi) >> 1;
                                         if (bl[mid] < cv)
@@ -252,7 +291,7 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                         }
                         if (j < C && bj < t.nblocks && bj != prevb) {
                                 const uint32_t prev = bj ? bl[bj - 1] : 0;
-                                merge_block(sh, index, bo[bj], prev, bl[bj], j, cv, C);
+                                merge_block(sh, index, bo[bj], TRI_BLOCK_N(t, bj, index, bo[bj]), prev, bl[bj], j, cv, C);
                         }
                         __syncthreads();
                 }
@@ -341,7 +380,7 @@ __device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, c
 }
 
 template <int WG>
-__device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+__device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                            const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                            const uint32_t *__restrict__ qterms, const DevQuery q, const DevTask task, uint32_t *__restrict__ out,
                            uint32_t *__restrict__ count_out) {
@@ -368,7 +407,7 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
                         else {
                                 cur = uni(sh.lcur[k]);
                                 if (cur < t.nblocks && bl[cur] < w * SPAN_BITS)
-                                        cur += wg_lower_bound<WG>(sh, bl + cur, t.nblocks - cur, w * SPAN_BITS);
+                                        cur += wg_lower_bound<WG>(sh.scan, bl + cur, t.nblocks - cur, w * SPAN_BITS);
                                 __syncthreads();
                                 sh.lcur[k] = cur;
                         }
@@ -416,11 +455,11 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
                         } else {
                                 b_lo = uni(sh.lcur[k]);
                                 if (b_lo < t.nblocks && bl[b_lo] < w0)
-                                        b_lo += wg_lower_bound<WG>(sh, bl + b_lo, t.nblocks - b_lo, w0);
+                                        b_lo += wg_lower_bound<WG>(sh.scan, bl + b_lo, t.nblocks - b_lo, w0);
                                 b_hi = b_lo;
                                 if (b_lo < t.nblocks) {
                                         galive = true;
-                                        b_hi = b_lo + wg_lower_bound<WG>(sh, bl + b_lo, t.nblocks - b_lo, wlast);
+                                        b_hi = b_lo + wg_lower_bound<WG>(sh.scan, bl + b_lo, t.nblocks - b_lo, wlast);
                                         if (b_hi >= t.nblocks)
                                                 b_hi = t.nblocks - 1;
                                 }
@@ -434,7 +473,7 @@ __device__ void dense_task(AndShared &sh, const uint8_t *__restrict__ index, con
                                                 const uint32_t prev = b ? bl[b - 1] : 0;
                                                 const uint32_t last = bl[b];
                                                 const uint32_t off = bo[b];
-                                                const uint32_t n = index[off - 1];
+                                                const uint32_t n = TRI_BLOCK_N(t, b, index, off);
                                                 if (gi == 0)
                                                         dense_block<true>(index, off, n, prev, last, w0, src, dst);
                                                 else
@@ -497,7 +536,7 @@ __global__ __launch_bounds__(DENSE_WG) void k_and_dense(const uint8_t *__restric
                                                         const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched,
                                                         const uint32_t *__restrict__ qterms, const uint32_t ntasks, uint32_t *__restrict__ ticket,
                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ counts) {
-        __shared__ AndShared sh;
+        __shared__ DenseShared sh;
         const uint32_t wave = uni(threadIdx.x >> 6);
         for (;;) {
                 if (wave == 0) { // uniform draw: 64 lanes add 1 each (one +64 atomic), see k_and
@@ -557,7 +596,7 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                         if (tid < nb) {
                                 const uint32_t b = tb + tid, gb = lead.first_block + b;
                                 const uint32_t off = blk_off[gb];
-                                const uint32_t n = index[off - 1];
+                                const uint32_t n = TRI_BLOCK_N(lead, b, index, off);
                                 const uint32_t last = blk_last[gb];
                                 uint32_t doc = b ? blk_last[gb - 1] : 0;
                                 VbStream s;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                                 const uint32_t prev = bj ? bl[bj - 1] : 0;
                                                 const uint32_t last = bl[bj];
                                                 const uint32_t off = bo[bj];
-                                                const uint32_t n = index[off - 1];
+                                                const uint32_t n = TRI_BLOCK_N(t, bj, index, off);
                                                 VbStream s;
                                                 s.init(index + off);
                                                 // deltas: merge the block's documents against the matches from j on; remember

@@ -214,6 +214,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 dt.first_block = (uint32_t)blk_last.size();
                 dt.nblocks = 0;
                 dt.last_n = 0;
+                dt.flags = 0;
                 if (!t.size || !t.documents) {
                         dt.documents = 0;
                         continue;
@@ -228,6 +229,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 end -= (size_t)sk * 8;
                 uint64_t db = 2, hb = 0;
                 uint32_t lastDoc = 0, docs = 0;
+                bool full_blocks = true;
                 while (p != end) {
                         if (p + 3 > end)
                                 return fail(TRI_ERR_FORMAT, "term %zu: truncated block header", ti);
@@ -248,6 +250,8 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                         hb += blockLength - (uint64_t)(s - p);
                         blk_last.push_back(lastDoc);
                         blk_off.push_back((uint32_t)(p - index));
+                        if (dt.nblocks && dt.last_n != 32)
+                                full_blocks = false; // a short block that is not the last one
                         dt.nblocks++;
                         dt.last_n = n;
                         docs += n;
@@ -255,6 +259,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 }
                 if (docs != t.documents)
                         return fail(TRI_ERR_FORMAT, "term %zu: %u documents in blocks, %u declared", ti, docs, t.documents);
+                dt.flags = full_blocks ? TERM_FULL_BLOCKS : 0;
                 ix->docbytes[ti] = db;
                 ix->hitbytes[ti] = hb;
                 postings += docs;
@@ -268,7 +273,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         for (size_t ti = 0; ti < nterms; ++ti) {
                 DevTerm &dt = ix->terms[ti];
                 dt.win_off = 0xffffffffu;
-                dt.pad[0] = dt.pad[1] = dt.pad[2] = 0;
+                dt.pad[0] = dt.pad[1] = 0;
                 if (dt.nblocks < WIN_MIN_BLOCKS)
                         continue;
                 dt.win_off = (uint32_t)win.size();
