@@ -83,6 +83,11 @@ int main(int argc, char **argv) {
                         exec_query(src.disjunction({src.term("t3"), src.term("t7")}), &src, &c, &even, unsigned(ExecFlags::DocumentsOnly));
                         show("or_even", c);
                 }
+                { // "t0 t1" t2 : Phrase iterator inside a conjunction, scored (phrase weight = sum of its terms' idf)
+                        Collect c;
+                        exec_query(src.conjunction({src.phrase({"t0", "t1"}), src.term("t2")}), &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("phrase_scored", c);
+                }
                 { // unknown term => no documents
                         Collect c;
                         exec_query(src.conjunction({src.term("t0"), src.term("nosuchterm")}), &src, &c, nullptr, unsigned(ExecFlags::DocumentsOnly));

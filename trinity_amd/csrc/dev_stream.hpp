@@ -104,6 +104,20 @@ struct VbStream {
                 valid -= (int)len;
                 return v;
         }
+        // address of the next unread byte (24 bytes sit in n1..n3, `valid` more in the window)
+        __device__ __forceinline__ const uint8_t *tell() const { return (const uint8_t *)q - 24 - valid; }
+        __device__ __forceinline__ uint32_t byte() {
+                refill();
+                const uint32_t b = (uint32_t)lo & 0xffu;
+                lo = (lo >> 8) | (hi << 56);
+                hi >>= 8;
+                valid -= 1;
+                return b;
+        }
+        __device__ __forceinline__ void skip(uint32_t n) {
+                for (; n; --n)
+                        (void)byte();
+        }
         // after refill(): true when the next k (1..8) bytes are k one-byte varints (values < 128)
         __device__ __forceinline__ bool small_run(const uint32_t k) const { return (lo & (0x8080808080808080ull >> (8u * (8u - k)))) == 0; }
         // consume k (1..8) bytes, returning the window they were in (byte j = j-th value)

@@ -32,6 +32,16 @@ struct DevQuery {
         uint32_t qid; // caller's query index
         uint32_t first_task, ntasks;
         uint32_t score_base, nscore; // AccumulatedScoreScheme: sterms[]/sweights[] slice, reference summation order
+        uint32_t phrase_base, nphrases; // positional constraints applied to the match list (DocsSetIterators::Phrase)
+};
+
+// A phrase constraint: its terms (phrase order) live in pterms[term_base .. +nterms); weight = sum of the terms' idf
+// (similarity.h:209-217).
+constexpr uint32_t MAX_PHRASE_TERMS = 16; // trinity_limits.h:12 MaxPhraseSize
+struct DevPhrase {
+        uint32_t term_base;
+        uint32_t nterms;
+        double weight;
 };
 
 // Unit of scheduling: a run of lead-list tiles of one query.  Heavy queries are cut into many tasks so that no

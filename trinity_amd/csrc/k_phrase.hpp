@@ -1,0 +1,208 @@
+// k_phrase.hpp — positional (phrase) constraints over match segments
+// Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
+#pragma once
+#include "k_match.hpp"
+
+// DocsSetIterators::Phrase (docset_iterators.cpp:66-224) is a conjunction on docIDs followed by a positional check
+// through the DocWordsSpace (docwordspace.h:16-92): the hits of every phrase term are materialised for the candidate
+// document in phrase order (candidate_document::materialize_term_hits, queryexec_ctx.cpp:317-351; a term repeated in
+// the phrase only once), each hit doing dws->set(termID, pos) — ONE term per position, last writer wins — and the
+// phrase matches at a start position p0 of term 0 when dws->test(term_k, p0 + k) holds for k = 1..n-1.  matchCnt
+// counts the matching start positions (capped at 1 unless scores are accumulated, exec.cpp:296).
+//
+// Here k_and has already intersected the phrase's terms (they are conjuncts of the query), so every candidate of a
+// task's match segment holds every phrase term.  One lane takes one candidate: for each term it finds the block through
+// the directory, walks the deltas to the document's slot, the freqs to its frequency, then the hits of the preceding
+// slots (Google::Decoder::skip_block_doc, google_codec.cpp:497-531) to the document's own hits; positions are streamed
+// from there (materialize_hits, :533-594) for the membership / ownership tests.  Survivors are compacted in place.
+struct PhraseShared {
+        uint32_t hits_off[MAX_PHRASE_TERMS][AND_WG]; // byte offset into index[] of the candidate's hits, per phrase term
+        uint32_t freq[MAX_PHRASE_TERMS][AND_WG];
+        uint32_t scan[8];
+        uint32_t bcast[4];
+};
+
+// Locate `doc` (known to be a document of term t) and return its hit count and the address of its first hit.
+__device__ __forceinline__ void phrase_locate(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+                                              const DevTerm t, const uint32_t doc, uint32_t &hits_off, uint32_t &freq) {
+        const uint32_t *bl = blk_last + t.first_block;
+        uint32_t lo = 0, hi = t.nblocks;
+        while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (bl[mid] < doc)
+                        lo = mid + 1;
+                else
+                        hi = mid;
+        }
+        const uint32_t b = lo;
+        const uint32_t off = blk_off[t.first_block + b];
+        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
+        VbStream s;
+        s.init(index + off);
+        uint32_t d = b ? bl[b - 1] : 0, idx = n - 1; // the last slot's docID is implied by the header
+        for (uint32_t i = 0; i + 1 < n; ++i) {
+                d += s.next();
+                if (d == doc)
+                        idx = i;
+        }
+        VbStream sf = s; // freqs start here
+        for (uint32_t i = 0; i < n; ++i)
+                (void)s.next(); // s: hits start
+        for (uint32_t i = 0; i < idx; ++i) { // skip the hits of the preceding slots
+                const uint32_t f = sf.next();
+                uint32_t plen = 0; // payload length state restarts with every document
+                for (uint32_t h = 0; h < f; ++h) {
+                        const uint32_t v = s.next();
+                        if (v & 1u)
+                                plen = s.byte();
+                        s.skip(plen);
+                }
+        }
+        freq = sf.next();
+        hits_off = (uint32_t)(s.tell() - index);
+}
+
+// Is position `q` among the `freq` hits starting at index[hits_off]?  (positions ascend within a document)
+__device__ __forceinline__ bool phrase_has_pos(const uint8_t *__restrict__ index, const uint32_t hits_off, const uint32_t freq, const uint32_t q) {
+        VbStream s;
+        s.init(index + hits_off);
+        uint32_t pos = 0, plen = 0;
+        for (uint32_t h = 0; h < (freq & 0xffffu); ++h) { // th->freq is tokenpos_t
+                const uint32_t v = s.next();
+                if (v & 1u)
+                        plen = s.byte();
+                s.skip(plen);
+                pos = (pos + (v >> 1)) & 0xffffu;
+                if (pos == q)
+                        return true;
+                if (pos > q)
+                        return false;
+        }
+        return false;
+}
+
+__global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                   const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
+                                                   const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
+                                                   const uint32_t *__restrict__ ptasks, const uint32_t nptasks, const DevPhrase *__restrict__ phrases,
+                                                   const uint32_t *__restrict__ pterms, uint32_t *__restrict__ ticket, uint32_t *__restrict__ out,
+                                                   uint32_t *__restrict__ counts, double *__restrict__ pscore, const uint32_t max_match_cnt) {
+        __shared__ PhraseShared sh;
+        const uint32_t tid = threadIdx.x;
+        const uint32_t wave = uni(tid >> 6);
+        for (;;) {
+                if (wave == 0) {
+                        const uint32_t old = atomicAdd(ticket, 1u);
+                        sh.bcast[0] = uni(old) >> 6;
+                }
+                __syncthreads();
+                const uint32_t ticket_no = uni(sh.bcast[0]);
+                __syncthreads();
+                if (ticket_no >= nptasks)
+                        break;
+                const uint32_t tix = ptasks[ticket_no];
+                const DevTask task = tasks[tix];
+                const DevQuery q = plan[task.slot];
+                const uint32_t M = counts[tix];
+                uint32_t *seg = out + task.out_off;
+                uint32_t wpos = 0;
+                for (uint32_t tb = 0; tb < M; tb += AND_WG) {
+                        const uint32_t j = tb + tid;
+                        const bool have = j < M;
+                        const uint32_t doc = have ? seg[j] : 0;
+                        bool ok = have;
+                        double ps = 0;
+                        for (uint32_t pi = 0; pi < q.nphrases; ++pi) {
+                                const DevPhrase ph = phrases[q.phrase_base + pi];
+                                uint32_t cnt = 0;
+                                if (ok) {
+                                        // materialise: hit address + freq of every distinct phrase term (first occurrence order)
+                                        for (uint32_t k = 0; k < ph.nterms; ++k) {
+                                                const uint32_t tk = pterms[ph.term_base + k];
+                                                uint32_t first = k;
+                                                for (uint32_t m = 0; m < k; ++m)
+                                                        if (pterms[ph.term_base + m] == tk) {
+                                                                first = m;
+                                                                break;
+                                                        }
+                                                if (first == k) {
+                                                        uint32_t ho, f;
+                                                        phrase_locate(index, blk_last, blk_off, terms[tk], doc, ho, f);
+                                                        sh.hits_off[k][tid] = ho;
+                                                        sh.freq[k][tid] = f;
+                                                } else {
+                                                        sh.hits_off[k][tid] = sh.hits_off[first][tid];
+                                                        sh.freq[k][tid] = sh.freq[first][tid];
+                                                }
+                                        }
+                                        // walk the start positions of term 0 (docset_iterators.cpp:101-143)
+                                        VbStream s0;
+                                        s0.init(index + sh.hits_off[0][tid]);
+                                        uint32_t p0 = 0, plen = 0;
+                                        const uint32_t f0 = sh.freq[0][tid] & 0xffffu;
+                                        for (uint32_t h = 0; h < f0 && cnt < max_match_cnt; ++h) {
+                                                const uint32_t v = s0.next();
+                                                if (v & 1u)
+                                                        plen = s0.byte();
+                                                s0.skip(plen);
+                                                p0 = (p0 + (v >> 1)) & 0xffffu;
+                                                if (!p0)
+                                                        continue;
+                                                bool all = true;
+                                                for (uint32_t k = 1; k < ph.nterms && all; ++k) {
+                                                        const uint32_t qpos = p0 + k;
+                                                        const uint32_t tk = pterms[ph.term_base + k];
+                                                        // dws->test(term_k, qpos): term k has a hit there …
+                                                        all = phrase_has_pos(index, sh.hits_off[k][tid], sh.freq[k][tid], qpos);
+                                                        // … and no term materialised after it overwrote the slot (last writer wins)
+                                                        uint32_t firstk = k;
+                                                        for (uint32_t m = 0; m < k; ++m)
+                                                                if (pterms[ph.term_base + m] == tk) {
+                                                                        firstk = m;
+                                                                        break;
+                                                                }
+                                                        for (uint32_t m = firstk + 1; m < ph.nterms && all; ++m) {
+                                                                const uint32_t tm = pterms[ph.term_base + m];
+                                                                if (tm == tk)
+                                                                        continue;
+                                                                bool seen = false; // only first occurrences materialise
+                                                                for (uint32_t z = 0; z < m; ++z)
+                                                                        seen |= pterms[ph.term_base + z] == tm;
+                                                                if (!seen && phrase_has_pos(index, sh.hits_off[m][tid], sh.freq[m][tid], qpos))
+                                                                        all = false;
+                                                        }
+                                                }
+                                                if (all)
+                                                        ++cnt;
+                                        }
+                                        ok = cnt != 0;
+                                        // docset_iterators_scorers.cpp:220-224: scorer->score(id, matchCnt, weight)
+                                        const uint16_t mc = (uint16_t)cnt;
+                                        ps += (double)(float)(ph.weight * (double)(float)mc / (double)((float)mc + 1.2f));
+                                }
+                        }
+                        // stable in-place compaction of the survivors (the write cursor never passes the read cursor)
+                        const uint64_t m = __ballot(ok);
+                        const uint32_t before = __popcll(m & ((1ull << (tid & 63)) - 1ull));
+                        sh.scan[tid >> 6] = __popcll(m);
+                        __syncthreads();
+                        uint32_t base = 0, tot = 0;
+                        for (uint32_t w = 0; w < AND_WG / 64; ++w) {
+                                if (w < (tid >> 6))
+                                        base += sh.scan[w];
+                                tot += sh.scan[w];
+                        }
+                        tot = uni(tot);
+                        if (ok) {
+                                seg[wpos + base + before] = doc;
+                                if (pscore)
+                                        pscore[task.out_off + wpos + base + before] = ps;
+                        }
+                        wpos += tot;
+                        __syncthreads();
+                }
+                if (wave == 0)
+                        counts[tix] = wpos;
+                __syncthreads();
+        }
+}

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                                   const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket,
                                                   const uint32_t *__restrict__ out, const uint32_t *__restrict__ counts, const uint32_t k,
                                                   uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
-                                                  uint32_t *__restrict__ part_counts, double *__restrict__ all_scores) {
+                                                  uint32_t *__restrict__ part_counts, double *__restrict__ all_scores,
+                                                  const double *__restrict__ pscore) {
         __shared__ ScoreShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
@@ -144,7 +145,8 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                         const uint32_t C = min(SCORE_TILE, M - tb);
                         for (uint32_t j = tid; j < C; j += AND_WG) {
                                 sh.cand[j] = seg[tb + j];
-                                sh.score[j] = 0.0;
+                                // a Phrase iterator scores as one unit; k_phrase left its contribution beside the match
+                                sh.score[j] = (q.nphrases && pscore) ? pscore[task.out_off + tb + j] : 0.0;
                         }
                         __syncthreads();
                         for (uint32_t ti = 0; ti < q.nscore; ++ti) {

@@ -99,6 +99,12 @@ struct tri_batch {
         double *d_part_scores = nullptr;
         float *d_top_scores = nullptr;
         double *d_all_scores = nullptr; // topk == 0: one double per out[] slot
+        // phrases
+        std::vector<DevPhrase> phrases;
+        std::vector<uint32_t> pterms, ptasks;
+        DevPhrase *d_phrases = nullptr;
+        uint32_t *d_pterms = nullptr, *d_ptasks = nullptr;
+        double *d_pscore = nullptr; // per out[] slot: sum of the phrase scores of the match (scored mode)
         uint64_t out_capacity = 0;
         uint64_t term_bytes = 0; // sum of docbytes over all query terms
         std::vector<uint32_t> h_counts;       // per task
@@ -111,6 +117,7 @@ struct tri_batch {
 #include "k_decode.hpp"
 #include "k_match.hpp"
 #include "k_score.hpp"
+#include "k_phrase.hpp"
 
 // ------------------------------------------------------------------------------------------ host: device
 extern "C" int tri_dev_open(int device, tri_dev **out) {
@@ -495,9 +502,43 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 // ---- conjunctive normal form over terms: AND of (term | OR of terms); a root OR is one group
                 std::vector<std::vector<uint32_t>> groups;
                 std::vector<uint32_t> leaves; // every TERM leaf in evaluation order: one scorer each
+                struct PhraseTmp {
+                        std::vector<uint32_t> terms;
+                        double weight;
+                };
+                std::vector<PhraseTmp> qphrases;
                 auto add_group = [&](const PNode &g) -> bool {
                         std::vector<uint32_t> ts;
-                        if (g.op == TRI_OP_TERM)
+                        if (g.op == TRI_OP_PHRASE && g.kids.size() > 1) {
+                                // Phrase = conjunction of its terms + a positional constraint on the matches (k_phrase);
+                                // it scores as ONE iterator with the summed idf (docset_iterators_scorers.cpp:195-228)
+                                PhraseTmp ph;
+                                ph.weight = 0;
+                                for (int k : g.kids) {
+                                        const uint32_t x = nodes[k].term;
+                                        ph.terms.push_back(x);
+                                        const uint32_t df = ix->terms[x].documents;
+                                        ph.weight += (double)std::log(1 + ((float)((uint64_t)ix->info.docs_cnt - (uint64_t)df) + 0.5f) / ((float)df + 0.5f));
+                                        bool dup = false;
+                                        for (const auto &og : groups)
+                                                dup |= og.size() == 1 && og[0] == x;
+                                        if (!dup)
+                                                groups.push_back({x});
+                                }
+                                if (weights) { // the PHRASE token's ScorerWeight, when the caller supplies weights
+                                        for (uint32_t pi = 0; pi < tq.prog_len; ++pi)
+                                                if ((prog[tq.prog_off + pi] >> 28) == TRI_OP_PHRASE && (prog[tq.prog_off + pi] & 0x0fffffffu) == g.kids.size() &&
+                                                    pi >= g.kids.size() && prog[tq.prog_off + pi - g.kids.size()] == TRI_TOK(TRI_OP_TERM, ph.terms[0])) {
+                                                        ph.weight = weights[tq.prog_off + pi];
+                                                        break;
+                                                }
+                                }
+                                qphrases.push_back(std::move(ph));
+                                return true;
+                        }
+                        if (g.op == TRI_OP_PHRASE)
+                                ts.push_back(nodes[g.kids[0]].term); // a one-word phrase is a term (exec.cpp: phrase of size 1)
+                        else if (g.op == TRI_OP_TERM)
                                 ts.push_back(g.term);
                         else if (g.op == TRI_OP_OR) {
                                 for (int k : g.kids) {
@@ -527,7 +568,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 else
                         ok = add_group(r);
                 if (!ok)
-                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: only AND of terms / OR-of-terms groups (and a root OR of terms) are lowered so far", qi);
+                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: only AND of terms / phrases / OR-of-terms groups (and a root OR of terms) are lowered so far", qi);
                 auto gcost = [&](const std::vector<uint32_t> &g) {
                         uint64_t c = 0;
                         for (uint32_t x : g)
@@ -544,6 +585,15 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint32_t nlead = (uint32_t)groups[0].size();
                 const uint64_t lead_docs = gcost(groups[0]);
                 Tmp t;
+                t.q.phrase_base = (uint32_t)b->phrases.size();
+                t.q.nphrases = (uint32_t)qphrases.size();
+                for (const auto &ph : qphrases) {
+                        b->phrases.push_back({(uint32_t)b->pterms.size(), (uint32_t)ph.terms.size(), ph.weight});
+                        for (uint32_t x : ph.terms) {
+                                b->pterms.push_back(x);
+                                b->term_bytes += ix->hitbytes[x]; // phrase queries also stream the hit bytes
+                        }
+                }
                 t.q.score_base = (uint32_t)b->sterms.size();
                 t.q.nscore = 0;
                 if (scored) {
@@ -674,6 +724,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 }
                 off += t.q.out_cap;
                 t.q.ntasks = (uint32_t)b->tasks.size() - t.q.first_task;
+                if (t.q.nphrases)
+                        for (uint32_t ti = t.q.first_task; ti < t.q.first_task + t.q.ntasks; ++ti)
+                                b->ptasks.push_back(ti);
                 b->plan.push_back(t.q);
         }
         std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &c) { return a.first > c.first; });
@@ -695,6 +748,14 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         HIP_TRY(hipMalloc((void **)&b->d_out, (off + 64) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_counts, (b->tasks.size() + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_ticket, 256));
+        if (!b->phrases.empty()) {
+                if ((rc = dev_upload(&b->d_phrases, b->phrases)) || (rc = dev_upload(&b->d_pterms, b->pterms)) || (rc = dev_upload(&b->d_ptasks, b->ptasks)))
+                        return rc;
+                if (scored) {
+                        HIP_TRY(hipMalloc((void **)&b->d_pscore, (off + 64) * 8));
+                        HIP_TRY(hipMemset(b->d_pscore, 0, (off + 64) * 8));
+                }
+        }
         if (scored) {
                 if ((rc = dev_upload(&b->d_sterms, b->sterms)) || (rc = dev_upload(&b->d_sweights, b->sweights)))
                         return rc;
@@ -737,6 +798,10 @@ extern "C" void tri_batch_destroy(tri_batch *b) {
         hipFree(b->d_top_scores);
         hipFree(b->d_top_counts);
         hipFree(b->d_all_scores);
+        hipFree(b->d_phrases);
+        hipFree(b->d_pterms);
+        hipFree(b->d_ptasks);
+        hipFree(b->d_pscore);
         delete b;
 }
 
@@ -771,11 +836,20 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
                                            b->n_cand, b->d_ticket, b->d_out, b->d_counts);
                 HIP_TRY(hipGetLastError());
+                if (!b->ptasks.empty()) {
+                        // positional constraints: filter + compact the match segments of the queries that hold phrases
+                        const uint32_t np = (uint32_t)b->ptasks.size();
+                        hipLaunchKernelGGL(k_phrase, dim3(std::min<uint32_t>(np, (uint32_t)dev->cus * 4)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
+                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_ptasks, np, b->d_phrases, b->d_pterms,
+                                           b->d_ticket + 48, b->d_out, b->d_counts, b->d_pscore,
+                                           (b->flags & TRI_FLAG_ACCUMULATED_SCORE) ? 65535u : 1u); // exec.cpp:296 trackCnt
+                        HIP_TRY(hipGetLastError());
+                }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                         hipLaunchKernelGGL(k_score, dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 2)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, n,
                                            b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,
-                                           b->d_all_scores);
+                                           b->d_all_scores, b->d_pscore);
                         HIP_TRY(hipGetLastError());
                         const uint32_t nqs = (uint32_t)b->plan.size();
                         if (b->topk)
