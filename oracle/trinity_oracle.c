@@ -5,6 +5,7 @@
  * reachable from the product path.  Citations are file:line in the reference tree.
  */
 #include "trinity_oracle.h"
+#include "oracle_internal.h"
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,7 +19,7 @@
 #define MAX_POSITION (1u << 14) /* trinity_limits.h:15 */
 #define MAX_PHRASE 16           /* trinity_limits.h:12 */
 
-static void *xmalloc(size_t n) {
+void *xmalloc(size_t n) {
         void *p = malloc(n ? n : 1);
         if (!p) {
                 fprintf(stderr, "trinity_oracle: out of memory (%zu)\n", n);
@@ -26,7 +27,7 @@ static void *xmalloc(size_t n) {
         }
         return p;
 }
-static void *xcalloc(size_t n, size_t s) {
+void *xcalloc(size_t n, size_t s) {
         void *p = calloc(n ? n : 1, s ? s : 1);
         if (!p) {
                 fprintf(stderr, "trinity_oracle: out of memory\n");
@@ -34,7 +35,7 @@ static void *xcalloc(size_t n, size_t s) {
         }
         return p;
 }
-static void *xrealloc(void *q, size_t n) {
+void *xrealloc(void *q, size_t n) {
         void *p = realloc(q, n ? n : 1);
         if (!p) {
                 fprintf(stderr, "trinity_oracle: out of memory\n");
@@ -225,11 +226,7 @@ void to_gen_queries(uint32_t V, uint64_t seed, uint32_t nq, uint32_t nterms, uin
 }
 
 /* ================================================================== Google codec: writer */
-typedef struct {
-        uint8_t *d;
-        size_t n, cap;
-} buf_t;
-static void buf_room(buf_t *b, size_t extra) {
+void buf_room(buf_t *b, size_t extra) {
         if (b->n + extra > b->cap) {
                 size_t nc = b->cap ? b->cap * 2 : 4096;
                 while (nc < b->n + extra)
@@ -238,20 +235,20 @@ static void buf_room(buf_t *b, size_t extra) {
                 b->cap = nc;
         }
 }
-static void buf_varbyte(buf_t *b, uint32_t v) {
+void buf_varbyte(buf_t *b, uint32_t v) {
         buf_room(b, 5);
         b->n += to_varbyte_put32(b->d + b->n, v);
 }
-static void buf_u8(buf_t *b, uint8_t v) {
+void buf_u8(buf_t *b, uint8_t v) {
         buf_room(b, 1);
         b->d[b->n++] = v;
 }
-static void buf_u32(buf_t *b, uint32_t v) {
+void buf_u32(buf_t *b, uint32_t v) {
         buf_room(b, 4);
         memcpy(b->d + b->n, &v, 4);
         b->n += 4;
 }
-static void buf_bytes(buf_t *b, const void *p, size_t n) {
+void buf_bytes(buf_t *b, const void *p, size_t n) {
         buf_room(b, n);
         memcpy(b->d + b->n, p, n);
         b->n += n;
@@ -428,6 +425,7 @@ void to_index_free(to_index *ix) {
         if (ix->owns) {
                 free(ix->bytes);
                 free(ix->terms);
+                free(ix->hits);
         }
         free(ix);
 }
@@ -469,25 +467,12 @@ uint32_t to_google_chunk_stats(const to_index *ix, uint32_t term, uint64_t *hdr,
 }
 
 /* ================================================================== Google codec: reader */
-enum { IT_PLI = 0, IT_CONJ, IT_DISJ, IT_PHRASE };
-
-typedef struct to_iter to_iter;
-struct to_iter { /* docset_iterators_base.h:45-96 Iterator + relevant_documents.h:43-67 IteratorScorer */
-        uint8_t type;
-        uint32_t cur; /* curDocument.id; 0 before the first next() */
-        uint32_t (*next)(to_iter *);
-        uint32_t (*advance)(to_iter *, uint32_t);
-        double (*score)(to_iter *);
-        uint64_t cost;
-};
-
 struct to_pli { /* google_codec.h:104-133 PostingsListIterator + :143-187 Decoder */
-        to_iter it;
+        TO_PLI_HEAD
         /* decoder */
         const uint8_t *base, *chunkEnd;
         const uint8_t *skiplist; /* entries {u32 prevBlockLastDocID, u32 offset} */
         uint32_t skiplistSize;
-        uint32_t term, documents;
         /* iterator */
         uint8_t blockDocIdx;
         uint32_t documentsArr[GOOGLE_N];
@@ -495,9 +480,6 @@ struct to_pli { /* google_codec.h:104-133 PostingsListIterator + :143-187 Decode
         uint32_t freqs[GOOGLE_N];
         uint32_t skipListIdx;
         const uint8_t *p;
-        uint16_t freq; /* codecs.h:217 tokenpos_t */
-        /* scoring (docset_iterators_scorers.cpp:10-36) */
-        double idf;
 };
 
 static uint32_t sk_first(const to_pli *d, uint32_t i) {
@@ -704,7 +686,9 @@ static uint32_t pli_advance(to_iter *self, uint32_t target) {
 }
 
 /* google_codec.cpp:533-594 (positions only; payload bytes are skipped exactly as the reference reads them) */
-uint32_t to_pli_materialize_positions(to_pli *it, uint16_t *out) {
+uint32_t to_pli_materialize_positions(to_pli *it, uint16_t *out) { return it->materialize(it, out); }
+
+static uint32_t google_materialize_positions(to_pli *it, uint16_t *out) {
         const uint32_t freq = it->freqs[it->blockDocIdx];
         uint16_t pos = 0;
         uint8_t curPayloadSize = 0;
@@ -723,17 +707,19 @@ uint32_t to_pli_materialize_positions(to_pli *it, uint16_t *out) {
         return (uint16_t)freq;
 }
 
-static double pli_score(to_iter *self);
 
 /* google_codec.cpp:936-990 (Decoder::init) + 442-462 (new_iterator) */
 to_pli *to_pli_new(const to_index *ix, uint32_t term) {
+        if (ix->codec == TO_CODEC_LUCENE)
+                return to_lucene_pli_new(ix, term);
         to_pli *it = (to_pli *)xcalloc(1, sizeof *it);
+        it->materialize = google_materialize_positions;
         const to_term *t = &ix->terms[term];
         const uint8_t *ptr = ix->bytes + t->offset;
         it->it.type = IT_PLI;
         it->it.next = pli_next;
         it->it.advance = pli_advance;
-        it->it.score = pli_score;
+        it->it.score = to_pli_score_bm25;
         it->it.cost = t->documents; /* docset_iterators.cpp:57-58 */
         it->term = term;
         it->documents = t->documents;
@@ -759,16 +745,20 @@ to_pli *to_pli_new(const to_index *ix, uint32_t term) {
         return it;
 }
 
-void to_pli_free(to_pli *it) { free(it); }
-uint32_t to_pli_next(to_pli *it) { return pli_next(&it->it); }
-uint32_t to_pli_advance(to_pli *it, uint32_t t) { return pli_advance(&it->it, t); }
+void to_pli_free(to_pli *it) {
+        if (it && it->destroy)
+                it->destroy(it);
+        free(it);
+}
+uint32_t to_pli_next(to_pli *it) { return it->it.next(&it->it); }
+uint32_t to_pli_advance(to_pli *it, uint32_t t) { return it->it.advance(&it->it, t); }
 uint32_t to_pli_current(const to_pli *it) { return it->it.cur; }
 uint32_t to_pli_freq(const to_pli *it) { return it->freq; }
 
 uint32_t to_decode_term(const to_index *ix, uint32_t term, uint32_t *docs, uint32_t *freqs) {
         to_pli *it = to_pli_new(ix, term);
         uint32_t n = 0;
-        for (uint32_t id = pli_next(&it->it); id != TO_DOCIDS_END; id = pli_next(&it->it)) {
+        for (uint32_t id = it->it.next(&it->it); id != TO_DOCIDS_END; id = it->it.next(&it->it)) {
                 docs[n] = id;
                 if (freqs)
                         freqs[n] = it->freq;
@@ -794,7 +784,7 @@ float to_bm25_score(double idf, uint16_t freq) {
 }
 
 /* docset_iterators_scorers.cpp:28-32 */
-static double pli_score(to_iter *self) {
+double to_pli_score_bm25(to_iter *self) {
         to_pli *it = (to_pli *)self;
         return to_bm25_score(it->idf, it->freq);
 }

@@ -85,7 +85,22 @@ typedef struct to_index {
         uint64_t sumTermsDocs;
         uint32_t docsCnt;
         int owns;
+        int codec;     /* TO_CODEC_GOOGLE (default, 0 also means Google) or TO_CODEC_LUCENE */
+        uint8_t *hits; /* Lucene: the segment's hits.data (lucene_codec.h:206) */
+        size_t hits_len;
 } to_index;
+
+#define TO_CODEC_GOOGLE 1
+#define TO_CODEC_LUCENE 2
+
+/* ------------------------------------------------------------------ index (Lucene-shaped codec)
+ * Container exactly as lucene_codec.cpp:163-388 writes it (term header, 128-document blocks as two ints() groups, varbyte
+ * tail, 22-byte skiplist entries, hits.data framing).  The ints() payload is THIS REPO'S PFOR128 (include/pfor128.md):
+ * the reference delegates it to lemire/FastPFor, an absent un-vendored submodule — "parity unpinned" for those bytes. */
+to_index *to_lucene_encode(const to_corpus *);
+/* ints() group of 128 values (lucene_codec.cpp:26-66 / 69-100): returns bytes written / consumed */
+size_t to_ints_encode(const uint32_t *values, uint8_t *out);
+size_t to_ints_decode(const uint8_t *in, uint32_t *values);
 
 /* google_codec.cpp:9-176 writer, terms encoded in rank order, hits = positions, no payloads */
 to_index *to_google_encode(const to_corpus *);

@@ -39,6 +39,9 @@ class ToIndex(C.Structure):
         ("sumTermsDocs", C.c_uint64),
         ("docsCnt", C.c_uint32),
         ("owns", C.c_int),
+        ("codec", C.c_int),
+        ("hits", C.POINTER(C.c_uint8)),
+        ("hits_len", C.c_size_t),
     ]
 
 
@@ -84,6 +87,12 @@ def lib():
     L.to_gen_queries.argtypes = [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, u32p]
     L.to_google_encode.restype = C.POINTER(ToIndex)
     L.to_google_encode.argtypes = [C.POINTER(ToCorpus)]
+    L.to_lucene_encode.restype = C.POINTER(ToIndex)
+    L.to_lucene_encode.argtypes = [C.POINTER(ToCorpus)]
+    L.to_ints_encode.restype = C.c_size_t
+    L.to_ints_encode.argtypes = [C.c_void_p, C.c_void_p]
+    L.to_ints_decode.restype = C.c_size_t
+    L.to_ints_decode.argtypes = [C.c_void_p, C.c_void_p]
     L.to_index_wrap.restype = C.POINTER(ToIndex)
     L.to_index_wrap.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64]
     L.to_index_free.argtypes = [C.POINTER(ToIndex)]
@@ -142,11 +151,14 @@ class Index:
         self.corpus = corpus
 
     @classmethod
-    def generate(cls, D, V, slots=10, seed=42):
+    def generate(cls, D, V, slots=10, seed=42, codec="google"):
         L = lib()
         c = L.to_corpus_generate(D, V, slots, seed)
-        ix = L.to_google_encode(c)
+        ix = L.to_lucene_encode(c) if codec == "lucene" else L.to_google_encode(c)
         return cls(ix, c)
+
+    def hits(self):
+        return np.ctypeslib.as_array(self.c.hits, shape=(self.c.hits_len,)).copy() if self.c.hits_len else np.zeros(0, np.uint8)
 
     @classmethod
     def wrap(cls, index_bytes, terms, docs_cnt, sum_terms_docs=0, sum_term_hits=0):

@@ -83,3 +83,14 @@ def test_no_gpu_means_error_not_fallback(T):
         pytest.skip("GPU present")
     with pytest.raises(T.TrinityError):
         T.Device(0)
+
+
+@pytest.mark.parametrize("cfg", [(2000, 200, 10, 42), (20000, 500, 12, 7), (30000, 5000, 10, 3)])
+def test_lucene_segment_builder_matches_oracle_bytes(T, cfg):
+    """Two independent writers of the Lucene-shaped container + PFOR128 payload (include/pfor128.md) agree byte for byte."""
+    from trinity_amd.engine import CODEC_LUCENE
+
+    D, V, S, seed = cfg
+    seg = T.Segment(D, V, S, seed, codec=CODEC_LUCENE)
+    ix = O.Index.generate(D, V, S, seed, codec="lucene")
+    assert np.array_equal(seg.index, ix.bytes()) and np.array_equal(seg.hits, ix.hits()) and np.array_equal(seg.terms, ix.terms())

@@ -239,3 +239,75 @@ def test_live_reference_random_queries():
         assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
         if r["flags"] & 2:
             assert abs(scores.sum() - r["score_sum"]) <= 1e-5 * max(1.0, abs(r["score_sum"]))
+
+
+# ------------------------------------------------------------------ Lucene-shaped codec (PFOR payload parity unpinned)
+def test_ints_group_roundtrip_and_known_answers():
+    """ints() groups (lucene_codec.cpp:26-100): all-equal rule is the reference's; the packed payload is this repo's
+    PFOR128 (include/pfor128.md)."""
+    L = O.lib()
+    buf = np.zeros(2048, np.uint8)
+    out = np.zeros(128, np.uint32)
+    v = np.full(128, 300, np.uint32)  # all equal: u8 0 + prefix-varint(300) = 00 81 2C
+    assert L.to_ints_encode(v.ctypes.data, buf.ctypes.data) == 3 and buf[:3].tolist() == [0x00, 0x81, 0x2C]
+    v = (np.arange(128) & 3).astype(np.uint32)  # width 2, no exceptions: L = 1 + 4*2 words
+    n = L.to_ints_encode(v.ctypes.data, buf.ctypes.data)
+    assert n == 1 + 4 * 9 and buf[0] == 9 and buf[1:5].tolist() == [2, 0, 0, 0] and buf[5] == 0b11100100
+    rng = np.random.default_rng(5)
+    for trial in range(1500):
+        kind = trial % 5
+        if kind == 0:
+            v = rng.integers(0, 4, 128)
+        elif kind == 1:
+            v = rng.geometric(0.2, 128)
+        elif kind == 2:
+            v = np.where(rng.random(128) < 0.08, rng.integers(0, 1 << 31, 128), rng.integers(0, 16, 128))
+        elif kind == 3:
+            v = rng.integers(0, 1 << 32, 128)
+        else:
+            v = rng.integers(0, 1 << rng.integers(1, 32), 128)
+        v = v.astype(np.uint32)
+        n = L.to_ints_encode(v.ctypes.data, buf.ctypes.data)
+        assert L.to_ints_decode(buf.ctypes.data, out.ctypes.data) == n and np.array_equal(v, out)
+        assert buf[0] == 0 or n == 1 + 4 * int(buf[0])
+
+
+@pytest.fixture(scope="module", params=NAMES)
+def both_codecs(request):
+    with open(os.path.join(GOLDEN, f"ref_{request.param}.json")) as f:
+        g = json.load(f)
+    c = g["corpus"]
+    return g, O.Index.generate(c["D"], c["V"], c["slots"], c["seed"]), O.Index.generate(c["D"], c["V"], c["slots"], c["seed"], codec="lucene")
+
+
+def test_lucene_codec_results_equal_reference_fixtures(both_codecs):
+    """The genuine reference could only be built with its Google codec here; a Lucene-coded segment of the same corpus
+    must give the same docID sets and scores (the reference's codecs are interchangeable behind Codecs::Decoder)."""
+    g, _, lx = both_codecs
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] == "decode":
+            d, f = lx.decode_term(r["term"])
+            assert str(O.fnv1a_docs(d)) == r["docs_fnv"] and str(O.fnv1a_docs(f)) == r["freqs_fnv"]
+        elif r["cmd"] in ("query", "queryfull"):
+            docs, scores = lx.exec(O.parse_query(r["q"]), r["flags"])
+            assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
+            if r["flags"] & 2:
+                assert abs(scores.sum() - r["score_sum"]) <= 1e-5 * max(1.0, abs(r["score_sum"]))
+            n += 1
+        elif r["cmd"] == "positions":
+            it = O.PLI(lx, r["term"])
+            vals, i = [], 0
+            while True:
+                d = it.next()
+                if d == O.DOCIDS_END:
+                    break
+                if i % r["nth"] == 0:
+                    vals += [d] + it.positions()
+                i += 1
+            assert str(O.fnv1a_u32_stream(np.array(vals, dtype=np.uint32))) == r["fnv"]
+        elif r["cmd"] == "advance":
+            D = g["corpus"]["D"]
+            done, h = _advance_trace(lx, D, r["term"], int(r["seed"]), r["steps"])
+            assert done == r["done"] and str(h) == r["trace_fnv"], r  # same (doc, freq) after every next()/advance()
+    assert n > 200

@@ -6,6 +6,7 @@
 //            x = (u >> 11) * 2^-53, cdf built by sequential double sums); term r is the r-th term of the table
 //   queries: splitmix64(seed); terms drawn from the same Zipf, distinct within a query
 #include "google_encoder.hpp"
+#include "lucene_encoder.hpp"
 #include <algorithm>
 #include <cstdlib>
 #include <memory>
@@ -51,7 +52,7 @@ namespace {
         };
 
         struct Segment {
-                std::vector<uint8_t> index;
+                std::vector<uint8_t> index, hits; // hits: the LUCENE codec's hits.data
                 std::vector<term_index_ctx> terms;
                 uint64_t sumTermsDocs{0}, sumTermHits{0};
                 uint32_t totalTerms{0}, docsCnt{0};
@@ -59,8 +60,14 @@ namespace {
 } // namespace
 
 extern "C" {
+static void *segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed, int codec);
 // Build the synthetic GOOGLE-codec segment.  Returns an opaque handle (NULL on failure).
-void *tri_synth_segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed) {
+void *tri_synth_segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed) { return segment_build(D, V, slots, seed, 1); }
+// codec: 1 = GOOGLE, 2 = LUCENE-shaped (PFOR128 payload)
+void *tri_synth_segment_build_codec(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed, int codec) { return segment_build(D, V, slots, seed, codec); }
+const uint8_t *tri_synth_segment_hits(void *h, uint64_t *len);
+
+static void *segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed, int codec) {
         try {
                 auto seg = std::make_unique<Segment>();
                 const uint64_t ntok = uint64_t(D) * slots;
@@ -89,29 +96,40 @@ void *tri_synth_segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t s
                                 }
                 }
                 std::vector<uint32_t>().swap(ranks);
-                Codecs::Google::IndexSession sess;
-                sess.indexOut.reserve(size_t(ntok) * 4);
-                Codecs::Google::Encoder enc(&sess);
                 seg->terms.resize(V);
-                for (uint32_t t = 0; t < V; ++t) {
-                        const uint64_t b = off[t], e = off[t + 1];
-                        if (b == e)
-                                continue;
-                        enc.begin_term();
-                        for (uint64_t i = b; i < e;) {
-                                const uint32_t d = tdoc[i];
-                                enc.begin_document(d);
-                                for (; i < e && tdoc[i] == d; ++i)
-                                        enc.new_hit(tpos[i]);
-                                enc.end_document();
+                auto feed = [&](auto &enc) {
+                        for (uint32_t t = 0; t < V; ++t) {
+                                const uint64_t b = off[t], e = off[t + 1];
+                                if (b == e)
+                                        continue;
+                                enc.begin_term();
+                                for (uint64_t i = b; i < e;) {
+                                        const uint32_t d = tdoc[i];
+                                        enc.begin_document(d);
+                                        for (; i < e && tdoc[i] == d; ++i)
+                                                enc.new_hit(tpos[i]);
+                                        enc.end_document();
+                                }
+                                enc.end_term(&seg->terms[t]);
+                                seg->sumTermsDocs += seg->terms[t].documents;
+                                ++seg->totalTerms;
                         }
-                        enc.end_term(&seg->terms[t]);
-                        seg->sumTermsDocs += seg->terms[t].documents;
-                        ++seg->totalTerms;
+                };
+                if (codec == 2) {
+                        Codecs::Lucene::IndexSession sess;
+                        Codecs::Lucene::Encoder enc(&sess);
+                        feed(enc);
+                        seg->index.swap(sess.indexOut);
+                        seg->hits.swap(sess.positionsOut);
+                } else {
+                        Codecs::Google::IndexSession sess;
+                        sess.indexOut.reserve(size_t(ntok) * 4);
+                        Codecs::Google::Encoder enc(&sess);
+                        feed(enc);
+                        seg->index.swap(sess.indexOut);
                 }
-                if (sess.indexOut.size() > 0xffffffffull)
+                if (seg->index.size() > 0xffffffffull || seg->hits.size() > 0xffffffffull)
                         return nullptr; // 32-bit chunk offsets (codecs.h:26)
-                seg->index.swap(sess.indexOut);
                 seg->sumTermHits = ntok;
                 seg->docsCnt = D;
                 return seg.release();
@@ -121,6 +139,11 @@ void *tri_synth_segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t s
 }
 
 void tri_synth_segment_free(void *h) { delete static_cast<Segment *>(h); }
+const uint8_t *tri_synth_segment_hits(void *h, uint64_t *len) {
+        auto *s = static_cast<Segment *>(h);
+        *len = s->hits.size();
+        return s->hits.data();
+}
 const uint8_t *tri_synth_segment_index(void *h, uint64_t *len) {
         auto *s = static_cast<Segment *>(h);
         *len = s->index.size();

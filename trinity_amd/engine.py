@@ -111,6 +111,10 @@ def host_lib():
     L = C.CDLL(LIB_HOST)
     L.tri_synth_segment_build.restype = C.c_void_p
     L.tri_synth_segment_build.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.tri_synth_segment_build_codec.restype = C.c_void_p
+    L.tri_synth_segment_build_codec.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int]
+    L.tri_synth_segment_hits.restype = C.POINTER(C.c_uint8)
+    L.tri_synth_segment_hits.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.tri_synth_segment_free.argtypes = [C.c_void_p]
     L.tri_synth_segment_index.restype = C.POINTER(C.c_uint8)
     L.tri_synth_segment_index.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -136,15 +140,17 @@ def gen_queries(V, seed, nq, nterms):
 class Segment:
     """A synthetic GOOGLE-codec segment built on the host (csrc/host/synth.cpp): raw `index` bytes + term table."""
 
-    def __init__(self, D, V, slots=10, seed=42):
+    def __init__(self, D, V, slots=10, seed=42, codec=CODEC_GOOGLE):
         L = host_lib()
-        self.D, self.V, self.slots, self.seed = D, V, slots, seed
-        self.h = L.tri_synth_segment_build(D, V, slots, seed)
+        self.D, self.V, self.slots, self.seed, self.codec = D, V, slots, seed, codec
+        self.h = L.tri_synth_segment_build_codec(D, V, slots, seed, codec)
         if not self.h:
             raise TrinityError("segment build failed (index larger than 4 GiB?)")
         n = C.c_uint64()
         p = L.tri_synth_segment_index(self.h, C.byref(n))
         self.index = np.ctypeslib.as_array(p, shape=(n.value,))
+        hp = L.tri_synth_segment_hits(self.h, C.byref(n))
+        self.hits = np.ctypeslib.as_array(hp, shape=(n.value,)) if n.value else np.zeros(0, np.uint8)
         nt = C.c_uint32()
         tp = L.tri_synth_segment_terms(self.h, C.byref(nt))
         self.terms = np.ctypeslib.as_array(tp, shape=(nt.value, 3))
