@@ -29,10 +29,15 @@ def dev(T):
 
 
 class World:
-    def __init__(self, T, dev, D, V, slots, seed):
+    def __init__(self, T, dev, D, V, slots, seed, codec=1):
         self.T, self.D, self.V = T, D, V
-        self.seg = T.Segment(D, V, slots, seed)
-        self.ora = O.Index.wrap(self.seg.index, self.seg.terms, self.seg.docs_cnt, self.seg.sum_terms_docs, self.seg.sum_term_hits)
+        self.seg = T.Segment(D, V, slots, seed, codec=codec)
+        if codec == 1:
+            self.ora = O.Index.wrap(self.seg.index, self.seg.terms, self.seg.docs_cnt, self.seg.sum_terms_docs, self.seg.sum_term_hits)
+        else:
+            # LUCENE-shaped segment on the GPU; the checker is the oracle's own Lucene-coded index of the same corpus
+            # (byte-identical to the product builder's, tests/test_abi.py), whose results equal the Google-coded ones
+            self.ora = O.Index.generate(D, V, slots, seed, codec="lucene")
         self.ix = T.Index.from_segment(dev, self.seg)
 
     def df(self, t):
@@ -352,3 +357,75 @@ def test_phrase_scored_topk_match_oracle(request, world, n, k):
         td, ts = w.ora.topk(docs, scores, k)
         assert d[i, : len(td)].tolist() == td.tolist(), t
         np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+
+
+# ------------------------------------------------------------------------------------------ LUCENE-shaped codec (K2)
+@pytest.fixture(scope="module")
+def small_l(T, dev):
+    return World(T, dev, 20000, 2000, 10, 42, codec=2)
+
+
+@pytest.fixture(scope="module")
+def dense_l(T, dev):
+    return World(T, dev, 20000, 500, 12, 7, codec=2)
+
+
+@pytest.fixture(scope="module")
+def medium_l(T, dev):
+    return World(T, dev, 300000, 30000, 10, 42, codec=2)
+
+
+@pytest.mark.parametrize("world", ["small_l", "dense_l", "medium_l"])
+def test_lucene_decode_terms_bit_exact(request, world):
+    w = request.getfixturevalue(world)
+    terms = [t for t in [0, 1, 2, 3, 5, 17, 40, w.V // 3, w.V // 2, w.V - 1] if w.df(t)]
+    docs, freqs, offs = w.ix.decode_terms(terms, [w.df(t) for t in terms])
+    for i, t in enumerate(terms):
+        d, f = w.ora.decode_term(t)
+        assert np.array_equal(docs[offs[i] : offs[i + 1]], d), t
+        assert np.array_equal(freqs[offs[i] : offs[i + 1]], f), t
+
+
+@pytest.mark.parametrize("world,n", [("small_l", 40), ("dense_l", 30), ("medium_l", 25)])
+def test_lucene_docsets_match_oracle(request, world, n):
+    w = request.getfixturevalue(world)
+    T = w.T
+    texts = template_queries(w, 51, n) + [f"t{a} t{b}" for a, b in T.gen_queries(w.V, 52, 150, 2).tolist()] + ["t0 t1", "t0 t1 t2 t3 t4", "t5"]
+    progs = [O.parse_query(t) for t in texts]
+    sets, hashes, _ = run_docs_only(w, progs)
+    for t, p, got, h in zip(texts, progs, sets, hashes):
+        want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+        assert np.array_equal(got, want), (t, len(got), len(want))
+        assert int(h) == O.fnv1a_docs(want)
+
+
+@pytest.mark.parametrize("world,n,k", [("small_l", 25, 100), ("dense_l", 20, 10)])
+def test_lucene_scored_topk_match_oracle(request, world, n, k):
+    """cfg3's shape: 5-term mixed AND/OR, BM25, top-K over the Lucene-shaped codec."""
+    w = request.getfixturevalue(world)
+    texts = template_queries(w, 53, n) + ["t0 t1", "t0 t1 t2 t3 t4"]
+    progs = [O.parse_query(t) for t in texts]
+    d, s, c, counts = run_scored(w, progs, k)
+    for i, t in enumerate(texts):
+        docs, scores = w.ora.exec(progs[i], O.FLAG_ACCUM_SCORE)
+        assert int(counts[i]) == len(docs), t
+        td, ts = w.ora.topk(docs, scores, k)
+        assert d[i, : len(td)].tolist() == td.tolist(), t
+        np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+
+
+def test_lucene_forced_dense_and_fixtures(T, dev, monkeypatch):
+    """Reference fixture records (non-phrase) against a LUCENE-coded segment, bitmap-window path forced."""
+    monkeypatch.setenv("TRINITY_DENSE_MIN", "0")
+    checked = 0
+    for name in ("small", "dense"):
+        g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
+        c = g["corpus"]
+        w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"], codec=2)
+        recs = [r for r in g["results"] if r["cmd"] in ("query", "queryfull") and r["flags"] == 1 and '"' not in r["q"]]
+        sets, hashes, _ = run_docs_only(w, [O.parse_query(r["q"]) for r in recs])
+        for r, got, h in zip(recs, sets, hashes):
+            assert len(got) == r["n"] and str(int(h)) == r["fnv"], r["q"]
+            checked += 1
+        w.ix.close()
+    assert checked >= 100

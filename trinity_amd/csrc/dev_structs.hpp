@@ -11,7 +11,8 @@ struct DevTerm {
         uint32_t win_off; // lists of >= WIN_MIN_BLOCKS blocks: row in win[] (first block with last >= w * SPAN_BITS, per window w); else ~0
         uint32_t flags;   // TERM_FULL_BLOCKS: every block but the last holds 32 documents (always true for chunks written by the
                           // reference encoder, google_codec.cpp:76-88; verified at upload) => n needs no load
-        uint32_t pad[2];
+        uint32_t npfor;   // LUCENE: directory rows that are quarters of full 128-document PFOR blocks (the rest is the varbyte tail)
+        uint32_t pad;
 };
 constexpr uint32_t TERM_FULL_BLOCKS = 1u;
 

@@ -1,7 +1,7 @@
 // k_decode.hpp — k_decode_terms: whole postings lists, one lane per block (codec seam)
 // Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
 #pragma once
-#include "dev_stream.hpp"
+#include "codec_streams.hpp"
 
 // ------------------------------------------------------------------------------------------ k_decode_terms
 struct DecodeJob {
@@ -11,6 +11,7 @@ struct DecodeJob {
 };
 
 // grid.x covers blocks of job blockIdx.y in chunks of 256; one lane per block (google_codec.cpp:596-639)
+template <int CODEC>
 __global__ __launch_bounds__(256) void k_decode_terms(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                       const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
                                                       const DecodeJob *__restrict__ jobs, uint32_t *__restrict__ docs,
@@ -23,8 +24,8 @@ __global__ __launch_bounds__(256) void k_decode_terms(const uint8_t *__restrict_
                 const uint32_t n = TRI_BLOCK_N(t, b, index, off);
                 const uint32_t last = blk_last[gb];
                 uint32_t doc = b ? blk_last[gb - 1] : 0;
-                VbStream s;
-                s.init(index + off);
+                DeltaStream<CODEC> s;
+                s.init(index, t, b, off);
                 uint32_t *od = docs + job.out_off + (uint64_t)b * 32;
                 for (uint32_t i = 0; i + 1 < n; ++i) {
                         doc += s.next();
@@ -33,8 +34,10 @@ __global__ __launch_bounds__(256) void k_decode_terms(const uint8_t *__restrict_
                 od[n - 1] = last;
                 if (freqs) {
                         uint32_t *of = freqs + job.out_off + (uint64_t)b * 32;
+                        FreqStream<CODEC> fs;
+                        fs.init(index, t, b, off, s);
                         for (uint32_t i = 0; i < n; ++i)
-                                of[i] = s.next();
+                                of[i] = fs.next();
                 }
         }
 }

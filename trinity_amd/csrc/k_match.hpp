@@ -1,7 +1,7 @@
 // k_match.hpp — docset matching kernels: candidate tiles (galloping / block-driven) and dense bitmap windows
 // Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
 #pragma once
-#include "dev_stream.hpp"
+#include "codec_streams.hpp"
 
 // ------------------------------------------------------------------------------------------ k_and
 constexpr int AND_WG = 256;   // candidate-tile kernel (k_and) and the scoring kernels
@@ -116,11 +116,12 @@ __device__ __forceinline__ bool load_block_bytes32(const uint8_t *__restrict__ p
 
 // Merge one block of term t against the candidates from `ptr` on (cv = candidate at ptr): set the hit bit of every
 // candidate that is a document of the block.  Full blocks of one-byte deltas take the register path above.
-__device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n,
-                                            const uint32_t prev, const uint32_t last, uint32_t ptr, uint32_t cv, const uint32_t C) {
+template <int CODEC>
+__device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
+                                            const uint32_t n, const uint32_t prev, const uint32_t last, uint32_t ptr, uint32_t cv, const uint32_t C) {
         uint32_t doc = prev;
         uint32_t v[8];
-        if (n == 32 && load_block_bytes32(index + off, v)) {
+        if (CODEC == CODEC_GOOGLE && n == 32 && load_block_bytes32(index + off, v)) {
 #pragma unroll
                 for (int j = 0; j < 32; ++j) {
                         doc = j < 31 ? doc + ((v[j >> 2] >> ((j & 3) * 8)) & 0xffu) : last;
@@ -139,8 +140,8 @@ __device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__rest
                 }
                 return;
         }
-        VbStream s;
-        s.init(index + off);
+        DeltaStream<CODEC> s;
+        s.init(index, t, b, off);
         for (uint32_t i = 0; i < n; ++i) {
                 doc = (i + 1 < n) ? doc + s.next() : last;
                 while (cv < doc) {
@@ -177,6 +178,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict_
 
 // Filter the C candidates in sh.cand (logical order ascending) against term `t`: sets sh.hit bits.
 // Caller syncs before and after.
+template <int CODEC>
 __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                 const uint32_t *__restrict__ blk_off, const DevTerm t, const uint32_t C, const uint32_t lcur_slot,
                                 const bool block_driven) {
@@ -233,7 +235,7 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                         uint32_t ptr = lo;
                                         uint32_t cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
                                         if (cv <= last)
-                                                merge_block(sh, index, bo[b], TRI_BLOCK_N(t, b, index, bo[b]), prev, last, ptr, cv, C);
+                                                merge_block<CODEC>(sh, index, t, b, bo[b], TRI_BLOCK_N(t, b, index, bo[b]), prev, last, ptr, cv, C);
                                 }
                         }
                         // workgroup-wide OR of `beyond`, branch-free: one ballot per wave, four LDS words
@@ -291,7 +293,7 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                         }
                         if (j < C && bj < t.nblocks && bj != prevb) {
                                 const uint32_t prev = bj ? bl[bj - 1] : 0;
-                                merge_block(sh, index, bo[bj], TRI_BLOCK_N(t, bj, index, bo[bj]), prev, bl[bj], j, cv, C);
+                                merge_block<CODEC>(sh, index, t, bj, bo[bj], TRI_BLOCK_N(t, bj, index, bo[bj]), prev, bl[bj], j, cv, C);
                         }
                         __syncthreads();
                 }
@@ -325,13 +327,24 @@ __device__ __forceinline__ void dense_visit(const uint32_t d, const uint32_t w0,
 }
 
 // Generic block walk over the per-lane byte stream (any varint lengths, any n).
-template <bool FIRST>
-__device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
-                                                   const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
-        VbStream s;
-        s.init(index + off);
+template <bool FIRST, int CODEC>
+__device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
+                                                   const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, const uint32_t *src,
+                                                   uint32_t *dst) {
         uint32_t doc = prev;
         const uint32_t nd = n - 1;
+        if (CODEC != CODEC_GOOGLE) {
+                DeltaStream<CODEC> ls;
+                ls.init(index, t, b, off);
+                for (uint32_t i = 0; i < nd; ++i) {
+                        doc += ls.next();
+                        dense_visit<FIRST>(doc, w0, src, dst);
+                }
+                dense_visit<FIRST>(last, w0, src, dst);
+                return;
+        }
+        VbStream s;
+        s.init(index + off);
         uint32_t i = 0;
         while (i < nd) {
                 s.refill();
@@ -358,11 +371,11 @@ __device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ i
 
 // A full block (n == 32) of one-byte deltas takes the register path (load_block_bytes32) and a fully unrolled add per
 // posting; anything else goes through the generic stream.
-template <bool FIRST>
-__device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
-                                            const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
+template <bool FIRST, int CODEC>
+__device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
+                                            const uint32_t prev, const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
 #if TRI_DENSE_V == 1
-        if (n == 32) {
+        if (CODEC == CODEC_GOOGLE && n == 32) {
                 uint32_t v[8];
                 if (load_block_bytes32(index + off, v)) {
                         uint32_t doc = prev;
@@ -376,10 +389,10 @@ __device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, c
                 }
         }
 #endif
-        dense_block_stream<FIRST>(index, off, n, prev, last, w0, src, dst);
+        dense_block_stream<FIRST, CODEC>(index, t, b, off, n, prev, last, w0, src, dst);
 }
 
-template <int WG>
+template <int WG, int CODEC>
 __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                            const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                            const uint32_t *__restrict__ qterms, const DevQuery q, const DevTask task, uint32_t *__restrict__ out,
@@ -475,9 +488,9 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                                                 const uint32_t off = bo[b];
                                                 const uint32_t n = TRI_BLOCK_N(t, b, index, off);
                                                 if (gi == 0)
-                                                        dense_block<true>(index, off, n, prev, last, w0, src, dst);
+                                                        dense_block<true, CODEC>(index, t, b, off, n, prev, last, w0, src, dst);
                                                 else
-                                                        dense_block<false>(index, off, n, prev, last, w0, src, dst);
+                                                        dense_block<false, CODEC>(index, t, b, off, n, prev, last, w0, src, dst);
                                         }
                                 }
                         }
@@ -530,6 +543,7 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
 }
 
 // bitmap-window tasks: persistent 512-thread workgroups draw TASK_DENSE tasks, heaviest first
+template <int CODEC>
 __global__ __launch_bounds__(DENSE_WG) void k_and_dense(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                         const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
                                                         const DevTerm *__restrict__ terms, const DevQuery *__restrict__ plan,
@@ -550,11 +564,12 @@ __global__ __launch_bounds__(DENSE_WG) void k_and_dense(const uint8_t *__restric
                         break;
                 const uint32_t tix = sched[ticket_no];
                 const DevTask task = tasks[tix];
-                dense_task<DENSE_WG>(sh, index, blk_last, blk_off, win, terms, qterms, plan[task.slot], task, out, counts + tix);
+                dense_task<DENSE_WG, CODEC>(sh, index, blk_last, blk_off, win, terms, qterms, plan[task.slot], task, out, counts + tix);
         }
 }
 
 // candidate-tile tasks (TASK_CAND)
+template <int CODEC>
 __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                 const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
                                                 const DevTerm *__restrict__ terms,
@@ -599,8 +614,8 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                 const uint32_t n = TRI_BLOCK_N(lead, b, index, off);
                                 const uint32_t last = blk_last[gb];
                                 uint32_t doc = b ? blk_last[gb - 1] : 0;
-                                VbStream s;
-                                s.init(index + off);
+                                DeltaStream<CODEC> s;
+                                s.init(index, lead, b, off);
                                 const uint32_t row = tid * 32;
                                 for (uint32_t i = 0; i + 1 < n; ++i) {
                                         doc += s.next();
@@ -627,7 +642,7 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                 const bool bd = t.nblocks <= lead.documents;
 #endif
                                 TRACE(3, slot, (k << 16) | (bd ? 1 : 0));
-                                and_filter_tile(sh, index, blk_last, blk_off, t, C, k - 1, bd);
+                                and_filter_tile<CODEC>(sh, index, blk_last, blk_off, t, C, k - 1, bd);
                                 TRACE(4, slot, C);
                                 __syncthreads();
                                 const bool lastterm = k + 1 == q.nterms;

@@ -111,6 +111,7 @@ __device__ __forceinline__ float bm25_term(const double idf, const uint32_t freq
         return (float)(idf * (double)(float)freq / (double)((float)freq + 1.2f));
 }
 
+template <int CODEC>
 __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                   const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
                                                   const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
@@ -187,8 +188,8 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                                 const uint32_t last = bl[bj];
                                                 const uint32_t off = bo[bj];
                                                 const uint32_t n = TRI_BLOCK_N(t, bj, index, off);
-                                                VbStream s;
-                                                s.init(index + off);
+                                                DeltaStream<CODEC> s;
+                                                s.init(index, t, bj, off);
                                                 // deltas: merge the block's documents against the matches from j on; remember
                                                 // the block positions (mask) and the matches (hit bits) that coincide.  Under an
                                                 // OR a match need not be a document of this list.
@@ -207,8 +208,10 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                                 // freqs follow the n-1 deltas; the i-th marked position belongs to the i-th
                                                 // marked match (both ascending; only this lane marks matches in its block's range)
                                                 ptr = j;
+                                                FreqStream<CODEC> fs;
+                                                fs.init(index, t, bj, off, s);
                                                 for (uint32_t i = 0; i < n; ++i) {
-                                                        const uint32_t f = s.next();
+                                                        const uint32_t f = fs.next();
                                                         if ((mask >> i) & 1u) {
                                                                 while (!((sh.hit[ptr >> 5] >> (ptr & 31)) & 1u))
                                                                         ++ptr;

@@ -62,7 +62,8 @@ struct tri_dev {
 
 struct tri_index {
         tri_dev *dev;
-        uint8_t *d_index = nullptr;
+        int codec = TRI_CODEC_GOOGLE;
+        uint8_t *d_index = nullptr, *d_hits = nullptr;
         uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr, *d_win = nullptr;
         uint32_t nwin = 0; // windows per win[] row (+1 sentinel column)
         DevTerm *d_terms = nullptr;
@@ -118,6 +119,15 @@ struct tri_batch {
 #include "k_match.hpp"
 #include "k_score.hpp"
 #include "k_phrase.hpp"
+
+// launch the instantiation of a codec-templated kernel that matches the uploaded segment
+#define TRI_LAUNCH(K, codec, grid, block, stream, ...)                                              \
+        do {                                                                                        \
+                if ((codec) == TRI_CODEC_LUCENE)                                                    \
+                        hipLaunchKernelGGL(K<CODEC_LUCENE>, grid, block, 0, stream, __VA_ARGS__);   \
+                else                                                                                \
+                        hipLaunchKernelGGL(K<CODEC_GOOGLE>, grid, block, 0, stream, __VA_ARGS__);   \
+        } while (0)
 
 // ------------------------------------------------------------------------------------------ host: device
 extern "C" int tri_dev_open(int device, tri_dev **out) {
@@ -182,6 +192,56 @@ namespace {
         }
         inline size_t h_vb_len(uint8_t b0) { return b0 < 0x80 ? 1 : b0 < 0xc0 ? 2 : b0 < 0xe0 ? 3 : b0 < 0xf0 ? 4 : 5; }
 
+        // ints() group of 128 values (lucene_codec.cpp:69-100 framing; PFOR128 payload, include/pfor128.md).  Returns the
+        // bytes consumed, 0 when malformed.  Upload-time only: it yields the per-32-document directory rows.
+        inline size_t h_ints_decode(const uint8_t *p, const uint8_t *end, uint32_t *v) {
+                if (p >= end)
+                        return 0;
+                const uint32_t L = p[0];
+                if (!L) {
+                        uint32_t x;
+                        const size_t n = h_vb_get(p + 1, x);
+                        for (int i = 0; i < 128; ++i)
+                                v[i] = x;
+                        return 1 + n;
+                }
+                if (p + 1 + 4 * (size_t)L > end + 16)
+                        return 0;
+                std::vector<uint32_t> w(L + 2, 0);
+                memcpy(w.data(), p + 1, (size_t)L * 4);
+                const uint32_t b = w[0] & 0xff, nexc = (w[0] >> 8) & 0xff, eb = (w[0] >> 16) & 0xff;
+                if (b > 32 || eb > 32 || 1 + 4 * b + (nexc + 3) / 4 + (nexc * eb + 31) / 32 != L)
+                        return 0;
+                const uint32_t *packed = w.data() + 1, *epos = packed + 4 * b, *ehigh = epos + (nexc + 3) / 4;
+                for (uint32_t i = 0; i < 128; ++i) {
+                        uint32_t x = 0;
+                        if (b) {
+                                const uint32_t bit = i * b;
+                                uint64_t win = packed[bit >> 5];
+                                if ((bit & 31) + b > 32)
+                                        win |= (uint64_t)packed[(bit >> 5) + 1] << 32;
+                                x = (uint32_t)((win >> (bit & 31)) & (b == 32 ? 0xffffffffull : ((1ull << b) - 1)));
+                        }
+                        v[i] = x;
+                }
+                for (uint32_t e = 0; e < nexc; ++e) {
+                        const uint32_t pos = (epos[e >> 2] >> ((e & 3) * 8)) & 0xff;
+                        const uint32_t bit = e * eb;
+                        uint64_t win = ehigh[bit >> 5];
+                        if ((bit & 31) + eb > 32)
+                                win |= (uint64_t)ehigh[(bit >> 5) + 1] << 32;
+                        if (pos >= 128 || b >= 32)
+                                return 0;
+                        v[pos] |= (uint32_t)((win >> (bit & 31)) & (eb == 32 ? 0xffffffffull : ((1ull << eb) - 1))) << b;
+                }
+                return 1 + (size_t)L * 4;
+        }
+        inline size_t h_ints_skip(const uint8_t *p, const uint8_t *end) {
+                if (p >= end)
+                        return 0;
+                return p[0] ? 1 + 4 * (size_t)p[0] : 1 + h_vb_len(p[1]);
+        }
+
         template <class T>
         int dev_upload(T **dst, const std::vector<T> &src, size_t extra = 0) {
                 HIP_TRY(hipMalloc((void **)dst, (src.size() + extra) * sizeof(T) + 16));
@@ -193,17 +253,16 @@ namespace {
 
 extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, const uint8_t *hits, size_t hits_len, int codec,
                                 const tri_term *terms, size_t nterms, uint32_t docs_cnt, tri_index **out) {
-        (void)hits;
-        (void)hits_len;
-        if (!dev || !out || (!index && len) || (!terms && nterms))
+        if (!dev || !out || (!index && len) || (!terms && nterms) || (!hits && hits_len))
                 return fail(TRI_ERR_INVALID, "tri_index_upload: null argument");
-        if (codec != TRI_CODEC_GOOGLE)
-                return fail(TRI_ERR_UNSUPPORTED, "tri_index_upload: codec %d not supported yet", codec);
+        if (codec != TRI_CODEC_GOOGLE && codec != TRI_CODEC_LUCENE)
+                return fail(TRI_ERR_INVALID, "tri_index_upload: unknown codec %d", codec);
         if (len > 0xffffffffull)
                 return fail(TRI_ERR_FORMAT, "index exceeds 32-bit chunk offsets (codecs.h:26)");
         HIP_TRY(hipSetDevice(dev->device));
         auto ix = std::make_unique<tri_index>();
         ix->dev = dev;
+        ix->codec = codec;
         ix->terms.resize(nterms);
         ix->tctx.assign(terms, terms + nterms);
         ix->docbytes.assign(nterms, 0);
@@ -222,8 +281,80 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 dt.nblocks = 0;
                 dt.last_n = 0;
                 dt.flags = 0;
+                dt.npfor = 0;
+                dt.flags = 0;
                 if (!t.size || !t.documents) {
                         dt.documents = 0;
+                        continue;
+                }
+                if (codec == TRI_CODEC_LUCENE) {
+                        // Lucene-shaped chunk (lucene_codec.cpp:163-388): 14-byte header, full 128-document blocks as two ints()
+                        // groups, varbyte (delta, freq) tail, 22-byte skiplist entries.  One directory row per 32 documents.
+                        if ((uint64_t)t.offset + t.size > len || t.size < 14)
+                                return fail(TRI_ERR_FORMAT, "term %zu: chunk [%u,+%u) outside index (%zu)", ti, t.offset, t.size, len);
+                        const uint8_t *base = index + t.offset, *p = base + 14;
+                        uint32_t posChunk;
+                        uint16_t sk;
+                        memcpy(&posChunk, base + 8, 4);
+                        memcpy(&sk, base + 12, 2);
+                        if (14 + (size_t)sk * 22 > t.size)
+                                return fail(TRI_ERR_FORMAT, "term %zu: skiplist larger than chunk", ti);
+                        const uint8_t *end = base + t.size - (size_t)sk * 22;
+                        uint32_t left = t.documents, doc = 0;
+                        uint32_t vals[128];
+                        while (left >= 128) {
+                                if (p >= end)
+                                        return fail(TRI_ERR_FORMAT, "term %zu: truncated block", ti);
+                                const uint32_t goff = (uint32_t)(p - index);
+                                const size_t used = h_ints_decode(p, end, vals);
+                                if (!used)
+                                        return fail(TRI_ERR_FORMAT, "term %zu: bad ints() group", ti);
+                                p += used;
+                                for (uint32_t q4 = 0; q4 < 4; ++q4) {
+                                        for (uint32_t i = 0; i < 32; ++i) {
+                                                if (!vals[q4 * 32 + i])
+                                                        return fail(TRI_ERR_FORMAT, "term %zu: zero document delta", ti);
+                                                doc += vals[q4 * 32 + i];
+                                        }
+                                        blk_last.push_back(doc);
+                                        blk_off.push_back(goff);
+                                        dt.nblocks++;
+                                }
+                                const size_t usedf = h_ints_skip(p, end);
+                                if (!usedf)
+                                        return fail(TRI_ERR_FORMAT, "term %zu: bad freqs group", ti);
+                                p += usedf;
+                                left -= 128;
+                        }
+                        dt.npfor = dt.nblocks;
+                        dt.last_n = 32;
+                        while (left) {
+                                const uint32_t n = std::min(left, 32u);
+                                blk_off.push_back((uint32_t)(p - index));
+                                for (uint32_t i = 0; i < n; ++i) {
+                                        uint32_t d, f;
+                                        if (p + 10 > end + 16)
+                                                return fail(TRI_ERR_FORMAT, "term %zu: truncated tail", ti);
+                                        p += h_vb_get(p, d);
+                                        p += h_vb_get(p, f);
+                                        if (!d)
+                                                return fail(TRI_ERR_FORMAT, "term %zu: zero document delta", ti);
+                                        doc += d;
+                                }
+                                blk_last.push_back(doc);
+                                dt.nblocks++;
+                                dt.last_n = n;
+                                left -= n;
+                        }
+                        if (p != end)
+                                return fail(TRI_ERR_FORMAT, "term %zu: %zd stray bytes before the skiplist", ti, (ssize_t)(end - p));
+                        dt.flags = TERM_FULL_BLOCKS;
+                        const uint64_t db = (uint64_t)(end - base); // 14-byte header + block bytes, no skiplist, no hits.data
+                        ix->docbytes[ti] = db;
+                        ix->hitbytes[ti] = posChunk;
+                        postings += t.documents;
+                        docb += db;
+                        hitb += posChunk;
                         continue;
                 }
                 if ((uint64_t)t.offset + t.size > len || t.size < 2)
@@ -280,7 +411,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         for (size_t ti = 0; ti < nterms; ++ti) {
                 DevTerm &dt = ix->terms[ti];
                 dt.win_off = 0xffffffffu;
-                dt.pad[0] = dt.pad[1] = 0;
+                dt.pad = 0;
                 if (dt.nblocks < WIN_MIN_BLOCKS)
                         continue;
                 dt.win_off = (uint32_t)win.size();
@@ -304,6 +435,11 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         int rc;
         if ((rc = dev_upload(&ix->d_blk_last, blk_last)) || (rc = dev_upload(&ix->d_blk_off, blk_off)) || (rc = dev_upload(&ix->d_terms, ix->terms)))
                 return rc;
+        if (hits_len) { // LUCENE: hits.data (positions) resident next to the index
+                HIP_TRY(hipMalloc((void **)&ix->d_hits, hits_len + 64));
+                HIP_TRY(hipMemset(ix->d_hits, 0, hits_len + 64));
+                HIP_TRY(hipMemcpy(ix->d_hits, hits, hits_len, hipMemcpyHostToDevice));
+        }
         ix->h_blk_last = std::move(blk_last);
         ix->info.index_bytes = len;
         ix->info.directory_bytes = ix->h_blk_last.size() * 8 + nterms * sizeof(DevTerm) + win.size() * 4;
@@ -322,6 +458,7 @@ extern "C" void tri_index_destroy(tri_index *ix) {
                 return;
         hipSetDevice(ix->dev->device);
         hipFree(ix->d_index);
+        hipFree(ix->d_hits);
         hipFree(ix->d_blk_last);
         hipFree(ix->d_blk_off);
         hipFree(ix->d_win);
@@ -374,7 +511,7 @@ extern "C" int tri_decode_terms(tri_index *ix, const uint32_t *terms, size_t n, 
         if (freqs)
                 HIP_TRY(hipMalloc((void **)&d_freqs, padded * 4));
         dim3 grid(std::min<uint32_t>((maxblocks + 255) / 256, 4096), (uint32_t)n);
-        hipLaunchKernelGGL(k_decode_terms, grid, dim3(256), 0, dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_terms, d_jobs, d_docs,
+        TRI_LAUNCH(k_decode_terms, ix->codec, grid, dim3(256), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_terms, d_jobs, d_docs,
                            d_freqs);
         HIP_TRY(hipGetLastError());
         // blocks are full (32) except the last one of each term: the padded layout is dense per term
@@ -585,6 +722,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint32_t nlead = (uint32_t)groups[0].size();
                 const uint64_t lead_docs = gcost(groups[0]);
                 Tmp t;
+                if (!qphrases.empty() && ix->codec != TRI_CODEC_GOOGLE)
+                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: phrases over a LUCENE segment (hits.data) are not lowered yet", qi);
                 t.q.phrase_base = (uint32_t)b->phrases.size();
                 t.q.nphrases = (uint32_t)qphrases.size();
                 for (const auto &ph : qphrases) {
@@ -826,13 +965,13 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 256, dev->stream));
                 // two persistent kernels back to back on the engine stream: bitmap windows (512 threads), then candidate tiles
                 if (b->n_dense) {
-                        hipLaunchKernelGGL(k_and_dense, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * 4)), dim3(DENSE_WG), 0, dev->stream, b->ix->d_index,
+                        TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * 4)), dim3(DENSE_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
                                            b->d_ticket + 16, b->d_out, b->d_counts);
                         HIP_TRY(hipGetLastError());
                 }
                 if (b->n_cand)
-                        hipLaunchKernelGGL(k_and, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * 4)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
+                        TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * 4)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
                                            b->n_cand, b->d_ticket, b->d_out, b->d_counts);
                 HIP_TRY(hipGetLastError());
@@ -846,7 +985,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
-                        hipLaunchKernelGGL(k_score, dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 2)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
+                        TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 2)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, n,
                                            b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,
                                            b->d_all_scores, b->d_pscore);

@@ -182,17 +182,18 @@ class Device:
 
 
 class Index:
-    def __init__(self, dev, index_bytes, terms, docs_cnt, codec=CODEC_GOOGLE):
+    def __init__(self, dev, index_bytes, terms, docs_cnt, codec=CODEC_GOOGLE, hits=None):
         self.dev = dev
         b = np.ascontiguousarray(index_bytes, dtype=np.uint8)
         t = np.ascontiguousarray(terms, dtype=np.uint32).reshape(-1, 3)
+        h = np.ascontiguousarray(hits, dtype=np.uint8) if hits is not None and len(hits) else None
         self.nterms = t.shape[0]
         self.h = C.c_void_p()
-        _check(hip_lib().tri_index_upload(dev.h, b.ctypes.data, b.size, None, 0, codec, t.ctypes.data, t.shape[0], docs_cnt, C.byref(self.h)))
+        _check(hip_lib().tri_index_upload(dev.h, b.ctypes.data, b.size, h.ctypes.data if h is not None else None, h.size if h is not None else 0, codec, t.ctypes.data, t.shape[0], docs_cnt, C.byref(self.h)))
 
     @classmethod
     def from_segment(cls, dev, seg):
-        return cls(dev, seg.index, seg.terms, seg.docs_cnt)
+        return cls(dev, seg.index, seg.terms, seg.docs_cnt, codec=getattr(seg, "codec", CODEC_GOOGLE), hits=getattr(seg, "hits", None))
 
     def info(self):
         i = TriIndexInfo()
