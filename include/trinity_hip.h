@@ -83,6 +83,11 @@ typedef struct tri_batch_info {
         uint64_t out_capacity;      /* docID slots reserved for docsets                                 */
         float last_run_ms;          /* HIP-event time of the last tri_batch_run (kernels only)          */
         uint32_t launches;          /* kernel launches per run                                          */
+        /* per matching kernel (HIP events on the engine stream around each launch; algorithmic bytes of the queries
+         * each one processes): k_and_dense = bitmap windows, k_and = candidate tiles */
+        float dense_ms, cand_ms;
+        uint64_t dense_algorithmic_bytes, cand_algorithmic_bytes;
+        uint64_t dense_queries, cand_queries;
 } tri_batch_info;
 
 const char *tri_last_error(void);

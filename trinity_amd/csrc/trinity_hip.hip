@@ -56,7 +56,7 @@ extern "C" int tri_abi_version(void) { return TRI_ABI_VERSION; }
 struct tri_dev {
         int device;
         hipStream_t stream;
-        hipEvent_t ev0, ev1;
+        hipEvent_t ev0, ev1, ev_a, ev_b; // ev_a / ev_b: after k_and_dense / after k_and
         int cus;
 };
 
@@ -108,6 +108,7 @@ struct tri_batch {
         double *d_pscore = nullptr; // per out[] slot: sum of the phrase scores of the match (scored mode)
         uint64_t out_capacity = 0;
         uint64_t term_bytes = 0; // sum of docbytes over all query terms
+        uint64_t term_bytes_dense = 0; // … of the queries that run as TASK_DENSE
         std::vector<uint32_t> h_counts;       // per task
         std::vector<uint64_t> h_query_counts; // per plan slot
         bool synced = false;
@@ -143,6 +144,8 @@ extern "C" int tri_dev_open(int device, tri_dev **out) {
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&d->ev0));
         HIP_TRY(hipEventCreate(&d->ev1));
+        HIP_TRY(hipEventCreate(&d->ev_a));
+        HIP_TRY(hipEventCreate(&d->ev_b));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         d->cus = prop.multiProcessorCount;
@@ -156,6 +159,8 @@ extern "C" void tri_dev_close(tri_dev *d) {
         hipSetDevice(d->device);
         hipEventDestroy(d->ev0);
         hipEventDestroy(d->ev1);
+        hipEventDestroy(d->ev_a);
+        hipEventDestroy(d->ev_b);
         hipStreamDestroy(d->stream);
         delete d;
 }
@@ -826,6 +831,18 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 last_doc = std::min(last_doc, glast);
                 dense &= sumdf >= DENSE_MIN_POSTINGS;
                 dense |= nlead > 1;
+                if (dense) {
+                        std::vector<uint32_t> seen;
+                        for (uint32_t k = 0; k < t.q.nterms; ++k) {
+                                const uint32_t term = qt[k] & ~QT_GROUP;
+                                if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
+                                        seen.push_back(term);
+                                        b->term_bytes_dense += ix->docbytes[term];
+                                }
+                        }
+                        ++b->info.dense_queries;
+                } else
+                        ++b->info.cand_queries;
                 t.q.out_off = off;
                 t.q.first_task = (uint32_t)b->tasks.size();
                 if (dense) {
@@ -970,11 +987,13 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                            b->d_ticket + 16, b->d_out, b->d_counts);
                         HIP_TRY(hipGetLastError());
                 }
+                HIP_TRY(hipEventRecord(dev->ev_a, dev->stream));
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * 4)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
                                            b->n_cand, b->d_ticket, b->d_out, b->d_counts);
                 HIP_TRY(hipGetLastError());
+                HIP_TRY(hipEventRecord(dev->ev_b, dev->stream));
                 if (!b->ptasks.empty()) {
                         // positional constraints: filter + compact the match segments of the queries that hold phrases
                         const uint32_t np = (uint32_t)b->ptasks.size();
@@ -1033,17 +1052,29 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, dev->ev0, dev->ev1) == hipSuccess)
                 b->info.last_run_ms = ms;
+        b->info.dense_ms = b->info.cand_ms = 0;
+        if (!b->tasks.empty()) {
+                if (hipEventElapsedTime(&ms, dev->ev0, dev->ev_a) == hipSuccess)
+                        b->info.dense_ms = ms; // includes the 256-byte ticket memset that precedes it
+                if (hipEventElapsedTime(&ms, dev->ev_a, dev->ev_b) == hipSuccess)
+                        b->info.cand_ms = ms;
+        }
         b->h_counts.resize(b->tasks.size());
         if (!b->tasks.empty())
                 HIP_TRY(hipMemcpy(b->h_counts.data(), b->d_counts, b->tasks.size() * 4, hipMemcpyDeviceToHost));
         uint64_t m = 0;
         b->h_query_counts.assign(b->plan.size(), 0);
+        uint64_t m_dense = 0;
         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                 const DevQuery &q = b->plan[sidx];
                 for (uint32_t t = 0; t < q.ntasks; ++t)
                         b->h_query_counts[sidx] += b->h_counts[q.first_task + t];
                 m += b->h_query_counts[sidx];
+                if (q.ntasks && b->tasks[q.first_task].kind == TASK_DENSE)
+                        m_dense += b->h_query_counts[sidx];
         }
+        b->info.dense_algorithmic_bytes = b->term_bytes_dense + 4 * m_dense;
+        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense) + 4 * (m - m_dense);
         b->info.matches = m;
         if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                 uint64_t outb = 0; // 8 B x min(matches, K) per query

@@ -51,6 +51,12 @@ class TriBatchInfo(C.Structure):
         ("out_capacity", C.c_uint64),
         ("last_run_ms", C.c_float),
         ("launches", C.c_uint32),
+        ("dense_ms", C.c_float),
+        ("cand_ms", C.c_float),
+        ("dense_algorithmic_bytes", C.c_uint64),
+        ("cand_algorithmic_bytes", C.c_uint64),
+        ("dense_queries", C.c_uint64),
+        ("cand_queries", C.c_uint64),
     ]
 
 
