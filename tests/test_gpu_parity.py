@@ -414,6 +414,60 @@ def test_lucene_scored_topk_match_oracle(request, world, n, k):
         np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("world,n", [("small_l", 25), ("dense_l", 25), ("medium_l", 10)])
+def test_lucene_phrase_docsets_match_oracle(request, world, n):
+    """a10: positions from hits.data (128-hit blocks independent of the document blocks + varbyte tail)."""
+    w = request.getfixturevalue(world)
+    texts = phrase_queries(w, 61, n)
+    progs = [O.parse_query(t) for t in texts]
+    sets, hashes, _ = run_docs_only(w, progs)
+    nonempty = 0
+    for t, p, got, h in zip(texts, progs, sets, hashes):
+        want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+        assert np.array_equal(got, want), (t, len(got), len(want))
+        assert int(h) == O.fnv1a_docs(want)
+        nonempty += len(want) > 0
+    assert nonempty >= 20
+
+
+@pytest.mark.parametrize("world,n,k", [("small_l", 15, 10), ("dense_l", 15, 100)])
+def test_lucene_phrase_scored_topk_match_oracle(request, world, n, k):
+    w = request.getfixturevalue(world)
+    texts = phrase_queries(w, 62, n)
+    progs = [O.parse_query(t) for t in texts]
+    d, s, c, counts = run_scored(w, progs, k)
+    for i, t in enumerate(texts):
+        docs, scores = w.ora.exec(progs[i], O.FLAG_ACCUM_SCORE)
+        assert int(counts[i]) == len(docs), t
+        td, ts = w.ora.topk(docs, scores, k)
+        assert d[i, : len(td)].tolist() == td.tolist(), t
+        np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+
+
+def test_lucene_phrase_fixtures(T, dev):
+    """The reference's own phrase results (produced through its Google codec) from a LUCENE-coded segment of the same corpus."""
+    checked = 0
+    for name in ("small", "dense"):
+        g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
+        c = g["corpus"]
+        w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"], codec=2)
+        recs = [r for r in g["results"] if r["cmd"] in ("query", "queryfull") and r["flags"] == 1 and '"' in r["q"]]
+        sets, hashes, _ = run_docs_only(w, [O.parse_query(r["q"]) for r in recs])
+        for r, got, h in zip(recs, sets, hashes):
+            assert len(got) == r["n"] and str(int(h)) == r["fnv"], r["q"]
+            checked += 1
+        w.ix.close()
+    assert checked >= 30
+
+
+def test_lucene_phrase_needs_hits(T, dev):
+    seg = T.Segment(2000, 200, 10, 42, codec=2)
+    ix = T.Index(dev, seg.index, seg.terms, seg.docs_cnt, codec=2)  # no hits.data
+    with pytest.raises(T.TrinityError):
+        T.Batch(ix, [O.parse_query('"t0 t1"')], T.FLAG_DOCUMENTS_ONLY)
+    ix.close()
+
+
 def test_lucene_forced_dense_and_fixtures(T, dev, monkeypatch):
     """Reference fixture records (non-phrase) against a LUCENE-coded segment, bitmap-window path forced."""
     monkeypatch.setenv("TRINITY_DENSE_MIN", "0")

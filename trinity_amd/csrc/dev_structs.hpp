@@ -12,7 +12,7 @@ struct DevTerm {
         uint32_t flags;   // TERM_FULL_BLOCKS: every block but the last holds 32 documents (always true for chunks written by the
                           // reference encoder, google_codec.cpp:76-88; verified at upload) => n needs no load
         uint32_t npfor;   // LUCENE: directory rows that are quarters of full 128-document PFOR blocks (the rest is the varbyte tail)
-        uint32_t pad;
+        uint32_t pad;     // LUCENE with hits.data: the term's row in hdir[] ({nfull, off[nfull], tail_off}); otherwise 0
 };
 constexpr uint32_t TERM_FULL_BLOCKS = 1u;
 

@@ -15,6 +15,85 @@
 // the directory, walks the deltas to the document's slot, the freqs to its frequency, then the hits of the preceding
 // slots (Google::Decoder::skip_block_doc, google_codec.cpp:497-531) to the document's own hits; positions are streamed
 // from there (materialize_hits, :533-594) for the membership / ownership tests.  Survivors are compacted in place.
+//
+// LUCENE keeps the positions of a term as ONE stream in hits.data, in blocks of 128 hits that are independent of the document
+// blocks (lucene_codec.cpp:245-307 writer, 401-462 refill_hits): a document's hits are found by COUNT — the hits of all preceding
+// documents of the term.  The upload pass therefore records, per directory row, the hits before the row (blk_hits[]) and, per
+// term, the byte offset of every 128-hit block and of the varbyte tail (hdir[]); a lane adds the freqs of the preceding slots of
+// its row and lands on the absolute hit index, which HitStream<CODEC_LUCENE> turns into (block, quarter, slot).
+struct HitCtx {
+        const uint8_t *base;      // GOOGLE: index[] (hits are inline), LUCENE: hits.data
+        const uint32_t *blk_hits; // LUCENE: hits of the term before each directory row
+        const uint32_t *hdir;     // LUCENE: per term { nfull, off[0..nfull-1], tail_off } into hits.data
+};
+
+template <int CODEC>
+struct HitStream;
+
+template <>
+struct HitStream<CODEC_GOOGLE> { // google_codec.cpp:533-594: varbyte (delta << 1 | newPayloadLen) [u8 len] payload
+        VbStream s;
+        uint32_t plen;
+        static constexpr uint32_t FREQ_MASK = 0xffffu; // th->freq is tokenpos_t
+        __device__ __forceinline__ void init(const HitCtx &c, const uint32_t, const uint32_t loc) {
+                s.init(c.base + loc);
+                plen = 0; // payload length state restarts with every document
+        }
+        __device__ __forceinline__ uint32_t next() {
+                const uint32_t v = s.next();
+                if (v & 1u)
+                        plen = s.byte();
+                s.skip(plen);
+                return v >> 1;
+        }
+};
+
+template <>
+struct HitStream<CODEC_LUCENE> {
+        const uint8_t *hits;
+        const uint32_t *hd;
+        uint32_t nfull, h;
+        LValStream lv;
+        VbStream vb;
+        bool tail;
+        static constexpr uint32_t FREQ_MASK = 0xffffffffu;
+        __device__ __forceinline__ void seek() {
+                const uint32_t hb = h >> 7;
+                if (hb < nfull) {
+                        tail = false;
+                        lv.init_group(hits, hd[1 + hb], (h & 127u) >> 5);
+                        for (uint32_t k = 0; k < (h & 31u); ++k)
+                                (void)lv.next();
+                } else { // lucene_codec.cpp:339-352: varbyte (posDelta << 1 | newLen) [u8 len]; payload bytes follow the whole tail
+                        tail = true;
+                        vb.init(hits + hd[1 + nfull]);
+                        for (uint32_t k = nfull * 128u; k < h; ++k)
+                                if (vb.next() & 1u)
+                                        (void)vb.byte();
+                }
+        }
+        __device__ __forceinline__ void init(const HitCtx &c, const uint32_t hdir_off, const uint32_t loc) {
+                hits = c.base;
+                hd = c.hdir + hdir_off;
+                nfull = hd[0];
+                h = loc;
+                seek();
+        }
+        __device__ __forceinline__ uint32_t next() {
+                if (tail) {
+                        const uint32_t v = vb.next();
+                        if (v & 1u)
+                                (void)vb.byte();
+                        return v >> 1;
+                }
+                const uint32_t v = lv.next();
+                ++h;
+                if (!(h & 31u))
+                        seek();
+                return v;
+        }
+};
+
 struct PhraseShared {
         uint32_t hits_off[MAX_PHRASE_TERMS][AND_WG]; // byte offset into index[] of the candidate's hits, per phrase term
         uint32_t freq[MAX_PHRASE_TERMS][AND_WG];
@@ -22,9 +101,51 @@ struct PhraseShared {
         uint32_t bcast[4];
 };
 
-// Locate `doc` (known to be a document of term t) and return its hit count and the address of its first hit.
+// Locate `doc` (known to be a document of term t) and return its hit count and where its first hit is (GOOGLE: byte offset
+// into index[]; LUCENE: hit ordinal within the term).
+template <int CODEC>
 __device__ __forceinline__ void phrase_locate(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
-                                              const DevTerm t, const uint32_t doc, uint32_t &hits_off, uint32_t &freq) {
+                                              const HitCtx &ctx, const DevTerm t, const uint32_t doc, uint32_t &hits_off, uint32_t &freq);
+
+template <>
+__device__ __forceinline__ void phrase_locate<CODEC_LUCENE>(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                            const uint32_t *__restrict__ blk_off, const HitCtx &ctx, const DevTerm t, const uint32_t doc,
+                                                            uint32_t &hits_off, uint32_t &freq) {
+        const uint32_t *bl = blk_last + t.first_block;
+        uint32_t lo = 0, hi = t.nblocks;
+        while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (bl[mid] < doc)
+                        lo = mid + 1;
+                else
+                        hi = mid;
+        }
+        const uint32_t b = lo;
+        const uint32_t off = blk_off[t.first_block + b];
+        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
+        DeltaStream<CODEC_LUCENE> ds;
+        ds.init(index, t, b, off);
+        uint32_t d = b ? bl[b - 1] : 0, idx = n - 1;
+        for (uint32_t i = 0; i + 1 < n; ++i) {
+                d += ds.next();
+                if (d == doc) {
+                        idx = i;
+                        break;
+                }
+        }
+        FreqStream<CODEC_LUCENE> fs;
+        fs.init(index, t, b, off, ds);
+        uint32_t h = ctx.blk_hits[t.first_block + b];
+        for (uint32_t i = 0; i < idx; ++i)
+                h += fs.next();
+        freq = fs.next();
+        hits_off = h;
+}
+
+template <>
+__device__ __forceinline__ void phrase_locate<CODEC_GOOGLE>(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                            const uint32_t *__restrict__ blk_off, const HitCtx &, const DevTerm t, const uint32_t doc,
+                                                            uint32_t &hits_off, uint32_t &freq) {
         const uint32_t *bl = blk_last + t.first_block;
         uint32_t lo = 0, hi = t.nblocks;
         while (lo < hi) {
@@ -63,16 +184,13 @@ __device__ __forceinline__ void phrase_locate(const uint8_t *__restrict__ index,
 }
 
 // Is position `q` among the `freq` hits starting at index[hits_off]?  (positions ascend within a document)
-__device__ __forceinline__ bool phrase_has_pos(const uint8_t *__restrict__ index, const uint32_t hits_off, const uint32_t freq, const uint32_t q) {
-        VbStream s;
-        s.init(index + hits_off);
-        uint32_t pos = 0, plen = 0;
-        for (uint32_t h = 0; h < (freq & 0xffffu); ++h) { // th->freq is tokenpos_t
-                const uint32_t v = s.next();
-                if (v & 1u)
-                        plen = s.byte();
-                s.skip(plen);
-                pos = (pos + (v >> 1)) & 0xffffu;
+template <int CODEC>
+__device__ __forceinline__ bool phrase_has_pos(const HitCtx &ctx, const uint32_t hdir_off, const uint32_t hits_off, const uint32_t freq, const uint32_t q) {
+        HitStream<CODEC> s;
+        s.init(ctx, hdir_off, hits_off);
+        uint32_t pos = 0;
+        for (uint32_t h = 0; h < (freq & HitStream<CODEC>::FREQ_MASK); ++h) {
+                pos = (pos + s.next()) & 0xffffu;
                 if (pos == q)
                         return true;
                 if (pos > q)
@@ -81,7 +199,9 @@ __device__ __forceinline__ bool phrase_has_pos(const uint8_t *__restrict__ index
         return false;
 }
 
-__global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+template <int CODEC>
+__global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ index, const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits,
+                                                   const uint32_t *__restrict__ hdir, const uint32_t *__restrict__ blk_last,
                                                    const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
                                                    const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
                                                    const uint32_t *__restrict__ ptasks, const uint32_t nptasks, const DevPhrase *__restrict__ phrases,
@@ -90,6 +210,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
         __shared__ PhraseShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
+        const HitCtx ctx{CODEC == CODEC_GOOGLE ? index : hits, blk_hits, hdir};
         for (;;) {
                 if (wave == 0) {
                         const uint32_t old = atomicAdd(ticket, 1u);
@@ -127,7 +248,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                         }
                                                 if (first == k) {
                                                         uint32_t ho, f;
-                                                        phrase_locate(index, blk_last, blk_off, terms[tk], doc, ho, f);
+                                                        phrase_locate<CODEC>(index, blk_last, blk_off, ctx, terms[tk], doc, ho, f);
                                                         sh.hits_off[k][tid] = ho;
                                                         sh.freq[k][tid] = f;
                                                 } else {
@@ -136,16 +257,12 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                 }
                                         }
                                         // walk the start positions of term 0 (docset_iterators.cpp:101-143)
-                                        VbStream s0;
-                                        s0.init(index + sh.hits_off[0][tid]);
-                                        uint32_t p0 = 0, plen = 0;
-                                        const uint32_t f0 = sh.freq[0][tid] & 0xffffu;
+                                        HitStream<CODEC> s0;
+                                        s0.init(ctx, terms[pterms[ph.term_base]].pad, sh.hits_off[0][tid]);
+                                        uint32_t p0 = 0;
+                                        const uint32_t f0 = sh.freq[0][tid] & HitStream<CODEC>::FREQ_MASK;
                                         for (uint32_t h = 0; h < f0 && cnt < max_match_cnt; ++h) {
-                                                const uint32_t v = s0.next();
-                                                if (v & 1u)
-                                                        plen = s0.byte();
-                                                s0.skip(plen);
-                                                p0 = (p0 + (v >> 1)) & 0xffffu;
+                                                p0 = (p0 + s0.next()) & 0xffffu;
                                                 if (!p0)
                                                         continue;
                                                 bool all = true;
@@ -153,7 +270,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                         const uint32_t qpos = p0 + k;
                                                         const uint32_t tk = pterms[ph.term_base + k];
                                                         // dws->test(term_k, qpos): term k has a hit there …
-                                                        all = phrase_has_pos(index, sh.hits_off[k][tid], sh.freq[k][tid], qpos);
+                                                        all = phrase_has_pos<CODEC>(ctx, terms[tk].pad, sh.hits_off[k][tid], sh.freq[k][tid], qpos);
                                                         // … and no term materialised after it overwrote the slot (last writer wins)
                                                         uint32_t firstk = k;
                                                         for (uint32_t m = 0; m < k; ++m)
@@ -168,7 +285,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                                 bool seen = false; // only first occurrences materialise
                                                                 for (uint32_t z = 0; z < m; ++z)
                                                                         seen |= pterms[ph.term_base + z] == tm;
-                                                                if (!seen && phrase_has_pos(index, sh.hits_off[m][tid], sh.freq[m][tid], qpos))
+                                                                if (!seen && phrase_has_pos<CODEC>(ctx, terms[tm].pad, sh.hits_off[m][tid], sh.freq[m][tid], qpos))
                                                                         all = false;
                                                         }
                                                 }

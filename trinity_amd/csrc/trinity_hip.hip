@@ -65,6 +65,7 @@ struct tri_index {
         int codec = TRI_CODEC_GOOGLE;
         uint8_t *d_index = nullptr, *d_hits = nullptr;
         uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr, *d_win = nullptr;
+        uint32_t *d_blk_hits = nullptr, *d_hdir = nullptr; // LUCENE + hits.data: positional access (k_phrase.hpp)
         uint32_t nwin = 0; // windows per win[] row (+1 sentinel column)
         DevTerm *d_terms = nullptr;
         std::vector<DevTerm> terms;
@@ -273,6 +274,8 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         ix->docbytes.assign(nterms, 0);
         ix->hitbytes.assign(nterms, 0);
         std::vector<uint32_t> blk_last, blk_off;
+        std::vector<uint32_t> blk_hits, hdir; // LUCENE + hits.data only
+        const bool want_hits = codec == TRI_CODEC_LUCENE && hits_len;
         blk_last.reserve(len / 96 + nterms);
         blk_off.reserve(len / 96 + nterms);
         uint64_t postings = 0, docb = 0, hitb = 0;
@@ -287,7 +290,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 dt.last_n = 0;
                 dt.flags = 0;
                 dt.npfor = 0;
-                dt.flags = 0;
+                dt.pad = 0;
                 if (!t.size || !t.documents) {
                         dt.documents = 0;
                         continue;
@@ -298,15 +301,18 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                         if ((uint64_t)t.offset + t.size > len || t.size < 14)
                                 return fail(TRI_ERR_FORMAT, "term %zu: chunk [%u,+%u) outside index (%zu)", ti, t.offset, t.size, len);
                         const uint8_t *base = index + t.offset, *p = base + 14;
-                        uint32_t posChunk;
+                        uint32_t posChunk, hitsOff, sumHits;
                         uint16_t sk;
+                        memcpy(&hitsOff, base, 4);
+                        memcpy(&sumHits, base + 4, 4);
                         memcpy(&posChunk, base + 8, 4);
                         memcpy(&sk, base + 12, 2);
                         if (14 + (size_t)sk * 22 > t.size)
                                 return fail(TRI_ERR_FORMAT, "term %zu: skiplist larger than chunk", ti);
                         const uint8_t *end = base + t.size - (size_t)sk * 22;
                         uint32_t left = t.documents, doc = 0;
-                        uint32_t vals[128];
+                        uint32_t vals[128], fvals[128];
+                        uint64_t hits_seen = 0;
                         while (left >= 128) {
                                 if (p >= end)
                                         return fail(TRI_ERR_FORMAT, "term %zu: truncated block", ti);
@@ -315,20 +321,24 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                                 if (!used)
                                         return fail(TRI_ERR_FORMAT, "term %zu: bad ints() group", ti);
                                 p += used;
+                                const size_t usedf = want_hits ? h_ints_decode(p, end, fvals) : h_ints_skip(p, end);
+                                if (!usedf)
+                                        return fail(TRI_ERR_FORMAT, "term %zu: bad freqs group", ti);
+                                p += usedf;
                                 for (uint32_t q4 = 0; q4 < 4; ++q4) {
+                                        if (want_hits)
+                                                blk_hits.push_back((uint32_t)hits_seen);
                                         for (uint32_t i = 0; i < 32; ++i) {
                                                 if (!vals[q4 * 32 + i])
                                                         return fail(TRI_ERR_FORMAT, "term %zu: zero document delta", ti);
                                                 doc += vals[q4 * 32 + i];
+                                                if (want_hits)
+                                                        hits_seen += fvals[q4 * 32 + i];
                                         }
                                         blk_last.push_back(doc);
                                         blk_off.push_back(goff);
                                         dt.nblocks++;
                                 }
-                                const size_t usedf = h_ints_skip(p, end);
-                                if (!usedf)
-                                        return fail(TRI_ERR_FORMAT, "term %zu: bad freqs group", ti);
-                                p += usedf;
                                 left -= 128;
                         }
                         dt.npfor = dt.nblocks;
@@ -336,6 +346,8 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                         while (left) {
                                 const uint32_t n = std::min(left, 32u);
                                 blk_off.push_back((uint32_t)(p - index));
+                                if (want_hits)
+                                        blk_hits.push_back((uint32_t)hits_seen);
                                 for (uint32_t i = 0; i < n; ++i) {
                                         uint32_t d, f;
                                         if (p + 10 > end + 16)
@@ -345,6 +357,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                                         if (!d)
                                                 return fail(TRI_ERR_FORMAT, "term %zu: zero document delta", ti);
                                         doc += d;
+                                        hits_seen += f;
                                 }
                                 blk_last.push_back(doc);
                                 dt.nblocks++;
@@ -354,6 +367,33 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                         if (p != end)
                                 return fail(TRI_ERR_FORMAT, "term %zu: %zd stray bytes before the skiplist", ti, (ssize_t)(end - p));
                         dt.flags = TERM_FULL_BLOCKS;
+                        if (want_hits) {
+                                // hits.data of this term (lucene_codec.cpp:245-307, 339-352): sumHits / 128 full blocks
+                                // { ints(posDeltas) ints(payloadLens) varbyte(payloadBytes) payload }, then the varbyte tail
+                                if (hits_seen != sumHits)
+                                        return fail(TRI_ERR_FORMAT, "term %zu: %llu hits by frequency, %u declared", ti, (unsigned long long)hits_seen, sumHits);
+                                if ((uint64_t)hitsOff + posChunk > hits_len)
+                                        return fail(TRI_ERR_FORMAT, "term %zu: positions chunk [%u,+%u) outside hits.data (%zu)", ti, hitsOff, posChunk, hits_len);
+                                const uint8_t *hp = hits + hitsOff, *hend = hp + posChunk;
+                                const uint32_t nfull = sumHits / 128;
+                                dt.pad = (uint32_t)hdir.size();
+                                hdir.push_back(nfull);
+                                for (uint32_t hb = 0; hb < nfull; ++hb) {
+                                        hdir.push_back((uint32_t)(hp - hits));
+                                        for (int g = 0; g < 2; ++g) {
+                                                const size_t used = h_ints_skip(hp, hend);
+                                                if (!used || hp + used > hend)
+                                                        return fail(TRI_ERR_FORMAT, "term %zu: bad hits block %u", ti, hb);
+                                                hp += used;
+                                        }
+                                        uint32_t payloadBytes;
+                                        hp += h_vb_get(hp, payloadBytes);
+                                        if (hp + payloadBytes > hend)
+                                                return fail(TRI_ERR_FORMAT, "term %zu: hits block %u payload overruns the chunk", ti, hb);
+                                        hp += payloadBytes;
+                                }
+                                hdir.push_back((uint32_t)(hp - hits));
+                        }
                         const uint64_t db = (uint64_t)(end - base); // 14-byte header + block bytes, no skiplist, no hits.data
                         ix->docbytes[ti] = db;
                         ix->hitbytes[ti] = posChunk;
@@ -416,7 +456,6 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         for (size_t ti = 0; ti < nterms; ++ti) {
                 DevTerm &dt = ix->terms[ti];
                 dt.win_off = 0xffffffffu;
-                dt.pad = 0;
                 if (dt.nblocks < WIN_MIN_BLOCKS)
                         continue;
                 dt.win_off = (uint32_t)win.size();
@@ -444,6 +483,8 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 HIP_TRY(hipMalloc((void **)&ix->d_hits, hits_len + 64));
                 HIP_TRY(hipMemset(ix->d_hits, 0, hits_len + 64));
                 HIP_TRY(hipMemcpy(ix->d_hits, hits, hits_len, hipMemcpyHostToDevice));
+                if (want_hits && ((rc = dev_upload(&ix->d_blk_hits, blk_hits)) || (rc = dev_upload(&ix->d_hdir, hdir))))
+                        return rc;
         }
         ix->h_blk_last = std::move(blk_last);
         ix->info.index_bytes = len;
@@ -464,6 +505,8 @@ extern "C" void tri_index_destroy(tri_index *ix) {
         hipSetDevice(ix->dev->device);
         hipFree(ix->d_index);
         hipFree(ix->d_hits);
+        hipFree(ix->d_blk_hits);
+        hipFree(ix->d_hdir);
         hipFree(ix->d_blk_last);
         hipFree(ix->d_blk_off);
         hipFree(ix->d_win);
@@ -727,8 +770,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint32_t nlead = (uint32_t)groups[0].size();
                 const uint64_t lead_docs = gcost(groups[0]);
                 Tmp t;
-                if (!qphrases.empty() && ix->codec != TRI_CODEC_GOOGLE)
-                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: phrases over a LUCENE segment (hits.data) are not lowered yet", qi);
+                if (!qphrases.empty() && ix->codec == TRI_CODEC_LUCENE && !ix->d_hdir)
+                        return fail(TRI_ERR_INVALID, "query %zu: phrase over a LUCENE segment that was uploaded without hits.data", qi);
                 t.q.phrase_base = (uint32_t)b->phrases.size();
                 t.q.nphrases = (uint32_t)qphrases.size();
                 for (const auto &ph : qphrases) {
@@ -997,8 +1040,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 if (!b->ptasks.empty()) {
                         // positional constraints: filter + compact the match segments of the queries that hold phrases
                         const uint32_t np = (uint32_t)b->ptasks.size();
-                        hipLaunchKernelGGL(k_phrase, dim3(std::min<uint32_t>(np, (uint32_t)dev->cus * 4)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
-                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_ptasks, np, b->d_phrases, b->d_pterms,
+                        TRI_LAUNCH(k_phrase, b->ix->codec, dim3(std::min<uint32_t>(np, (uint32_t)dev->cus * 4)), dim3(AND_WG), dev->stream, b->ix->d_index,
+                                           b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_ptasks, np, b->d_phrases, b->d_pterms,
                                            b->d_ticket + 48, b->d_out, b->d_counts, b->d_pscore,
                                            (b->flags & TRI_FLAG_ACCUMULATED_SCORE) ? 65535u : 1u); // exec.cpp:296 trackCnt
                         HIP_TRY(hipGetLastError());
