@@ -313,34 +313,29 @@ __device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w ^ ((w >> 5
 __device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w; }
 #endif
 
-// One posting into the window bitmap: set (FIRST) or test-and-set.  Branch-free; documents outside the window go to
-// the sink word.
-template <bool FIRST>
-__device__ __forceinline__ void dense_visit(const uint32_t d, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
-        const uint32_t rel = d - w0;
+// One posting into a window bitmap, by its window-relative docID (documents below the window wrap to huge values).
+// Branch-free, fire-and-forget (no value comes back from LDS, so nothing in the lane's chain waits on it); documents
+// outside the window go to the sink word.  Every term only SETS bits: a conjunct is folded in by AND-ing whole bitmaps
+// afterwards (dense_task), which costs 8 words per thread instead of a dependent LDS read per posting.
+__device__ __forceinline__ void dense_visit(const uint32_t rel, uint32_t *dst) {
         const uint32_t word = bswz(min(rel >> 5, SPAN_WORDS));
-        const uint32_t bit = 1u << (rel & 31u);
-        if (FIRST)
-                atomicOr(&dst[word], bit);
-        else
-                atomicOr(&dst[word], src[word] & bit);
+        atomicOr(&dst[word], 1u << (rel & 31u));
 }
 
 // Generic block walk over the per-lane byte stream (any varint lengths, any n).
-template <bool FIRST, int CODEC>
+template <int CODEC>
 __device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
-                                                   const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, const uint32_t *src,
-                                                   uint32_t *dst) {
-        uint32_t doc = prev;
+                                                   const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *dst) {
+        uint32_t rel = prev - w0;
         const uint32_t nd = n - 1;
         if (CODEC != CODEC_GOOGLE) {
                 DeltaStream<CODEC> ls;
                 ls.init(index, t, b, off);
                 for (uint32_t i = 0; i < nd; ++i) {
-                        doc += ls.next();
-                        dense_visit<FIRST>(doc, w0, src, dst);
+                        rel += ls.next();
+                        dense_visit(rel, dst);
                 }
-                dense_visit<FIRST>(last, w0, src, dst);
+                dense_visit(last - w0, dst);
                 return;
         }
         VbStream s;
@@ -354,42 +349,42 @@ __device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ i
 #pragma unroll
                         for (uint32_t j = 0; j < 8; ++j) {
                                 if (j < k) {
-                                        doc += (uint32_t)(w & 0xffu);
+                                        rel += (uint32_t)(w & 0xffu);
                                         w >>= 8;
-                                        dense_visit<FIRST>(doc, w0, src, dst);
+                                        dense_visit(rel, dst);
                                 }
                         }
                         i += k;
                 } else {
-                        doc += s.next();
-                        dense_visit<FIRST>(doc, w0, src, dst);
+                        rel += s.next();
+                        dense_visit(rel, dst);
                         ++i;
                 }
         }
-        dense_visit<FIRST>(last, w0, src, dst);
+        dense_visit(last - w0, dst);
 }
 
 // A full block (n == 32) of one-byte deltas takes the register path (load_block_bytes32) and a fully unrolled add per
 // posting; anything else goes through the generic stream.
-template <bool FIRST, int CODEC>
+template <int CODEC>
 __device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
-                                            const uint32_t prev, const uint32_t last, const uint32_t w0, const uint32_t *src, uint32_t *dst) {
+                                            const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *dst) {
 #if TRI_DENSE_V == 1
         if (CODEC == CODEC_GOOGLE && n == 32) {
                 uint32_t v[8];
                 if (load_block_bytes32(index + off, v)) {
-                        uint32_t doc = prev;
+                        uint32_t rel = prev - w0;
 #pragma unroll
                         for (int j = 0; j < 31; ++j) {
-                                doc += (v[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-                                dense_visit<FIRST>(doc, w0, src, dst);
+                                rel += (v[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+                                dense_visit(rel, dst);
                         }
-                        dense_visit<FIRST>(last, w0, src, dst);
+                        dense_visit(last - w0, dst);
                         return;
                 }
         }
 #endif
-        dense_block_stream<FIRST, CODEC>(index, t, b, off, n, prev, last, w0, src, dst);
+        dense_block_stream<CODEC>(index, t, b, off, n, prev, last, w0, dst);
 }
 
 template <int WG, int CODEC>
@@ -442,19 +437,26 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                         const DevTerm t = terms[tt & ~QT_GROUP];
                         const uint32_t *bl = blk_last + t.first_block;
                         const uint32_t *bo = blk_off + t.first_block;
-                        if (k && (tt & QT_GROUP)) {
+                        // bits[0] = A: the lead group's union, then the running conjunction; bits[1] = B: the union of the group
+                        // being read.  A finished group is folded in word-wise (A &= B) when the next one starts; the last
+                        // group's fold is fused into the expansion below.  (The previous term's pass ended with a barrier.)
+                        if (k == 0) {
+                                for (uint32_t i = tid; i < SPAN_WORDS; i += WG)
+                                        sh.bits[0][i] = 0;
+                        } else if (tt & QT_GROUP) {
                                 if (!galive) { // an exhausted conjunct: no further match anywhere
                                         done = true;
                                         break;
                                 }
+                                for (uint32_t i = tid; i < SPAN_WORDS; i += WG) {
+                                        if (gi)
+                                                sh.bits[0][i] &= sh.bits[1][i];
+                                        sh.bits[1][i] = 0;
+                                }
                                 ++gi;
                                 galive = false;
                         }
-                        uint32_t *dst = sh.bits[gi & 1];
-                        const uint32_t *src = sh.bits[(gi & 1) ^ 1];
-                        if (tt & QT_GROUP)
-                                for (uint32_t i = tid; i < SPAN_WORDS; i += WG)
-                                        dst[i] = 0;
+                        uint32_t *dst = sh.bits[gi ? 1 : 0];
                         // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
                         uint32_t b_lo, b_hi;
                         if (t.win_off != 0xffffffffu) {
@@ -487,10 +489,7 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                                                 const uint32_t last = bl[b];
                                                 const uint32_t off = bo[b];
                                                 const uint32_t n = TRI_BLOCK_N(t, b, index, off);
-                                                if (gi == 0)
-                                                        dense_block<true, CODEC>(index, t, b, off, n, prev, last, w0, src, dst);
-                                                else
-                                                        dense_block<false, CODEC>(index, t, b, off, n, prev, last, w0, src, dst);
+                                                dense_block<CODEC>(index, t, b, off, n, prev, last, w0, dst);
                                         }
                                 }
                         }
@@ -501,14 +500,19 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                         break;
                 }
                 // ---- expand the survivors bitmap into ascending docIDs
-                const uint32_t *fin = sh.bits[gi & 1];
-                uint32_t *pre = sh.bits[(gi & 1) ^ 1]; // the other bitmap is dead: per-word exclusive prefix
+                uint32_t *fin = sh.bits[0];
+                uint32_t *pre = sh.bits[1]; // B dies word by word as it is folded in: per-word exclusive prefix takes its place
                 {
                         uint32_t run = 0;
                         for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
-                                const uint32_t wi = tid * (SPAN_WORDS / WG) + j;
+                                const uint32_t wi = bswz(tid * (SPAN_WORDS / WG) + j);
+                                uint32_t m = fin[wi];
+                                if (gi) {
+                                        m &= pre[wi];
+                                        fin[wi] = m;
+                                }
                                 pre[wi] = run;
-                                run += __popc(fin[bswz(wi)]);
+                                run += __popc(m);
                         }
                         uint32_t wtot;
                         const uint32_t ex = wave_excl_scan(run, wtot);
@@ -525,7 +529,7 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                         // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
                         for (uint32_t wi = tid; wi < SPAN_WORDS; wi += WG) {
                                 uint32_t m = fin[bswz(wi)];
-                                uint32_t o = produced + sh.tbase[wi / (SPAN_WORDS / WG)] + pre[wi];
+                                uint32_t o = produced + sh.tbase[wi / (SPAN_WORDS / WG)] + pre[bswz(wi)];
                                 const uint32_t base = w0 + wi * 32;
                                 while (m) {
                                         qout[o++] = base + (uint32_t)__builtin_ctz(m);
