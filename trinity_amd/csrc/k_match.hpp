@@ -50,11 +50,16 @@ struct AndShared {
 // LDS state of the bitmap-window kernel
 struct DenseShared {
         uint32_t bits[2][SPAN_WORDS + 1]; // two docID-window bitmaps (candidates / survivors), +1 sink word each
-        uint32_t tbase[DENSE_WG];
+        uint32_t tbase[DENSE_WG]; // expansion: per-thread output base; decode passes: the deferred (slow) block list
         uint32_t scan[8];
         uint32_t bcast[4];
         uint32_t lcur[16];
+        uint32_t seg_lo[MAX_QTERMS];      // per query term: first block reaching the current window ...
+        uint32_t seg_cnt[MAX_QTERMS + 1]; // ... and how many do (+ sentinel)
+        DevTerm seg_term[MAX_QTERMS];
+        uint32_t nslow;
 };
+constexpr uint32_t DENSE_SLOW_CAP = DENSE_WG;
 
 // Workgroup-cooperative lower bound over a sorted global array: first i in [0, n) with a[i] >= key, else n.
 // 256-ary search: every lane probes the end of its segment, one ballot per wave finds the first segment whose
@@ -364,27 +369,74 @@ __device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ i
         dense_visit(last - w0, dst);
 }
 
-// A full block (n == 32) of one-byte deltas takes the register path (load_block_bytes32) and a fully unrolled add per
-// posting; anything else goes through the generic stream.
-template <int CODEC>
-__device__ __forceinline__ void dense_block(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
-                                            const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *dst) {
-#if TRI_DENSE_V == 1
-        if (CODEC == CODEC_GOOGLE && n == 32) {
-                uint32_t v[8];
-                if (load_block_bytes32(index + off, v)) {
-                        uint32_t rel = prev - w0;
-#pragma unroll
-                        for (int j = 0; j < 31; ++j) {
-                                rel += (v[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-                                dense_visit(rel, dst);
+// One pass over a window: the blocks of terms [kbeg, kend) that reach the window form one virtual work list (term after
+// term), dealt out to the lanes round by round — so a short list does not leave most of the workgroup idle and the terms
+// of a pass share one barrier.  Terms below ksplit set bits in A (bits[0]), the others in B (bits[1]).  A block that
+// cannot take the static register path (a multi-byte delta, a short last block) is not decoded in place — that would make
+// its whole wave run the slow stream path — but appended to an LDS list which the workgroup then works off densely.
+template <int WG, int CODEC>
+__device__ __forceinline__ void dense_pass(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                           const uint32_t *__restrict__ blk_off, const uint32_t kbeg, const uint32_t kend, const uint32_t ksplit,
+                                           const uint32_t w0) {
+        const uint32_t tid = threadIdx.x;
+        uint32_t total = 0;
+        for (uint32_t k = kbeg; k < kend; ++k)
+                total += uni(sh.seg_cnt[k]);
+        for (uint32_t v0 = 0; v0 < total; v0 += WG) {
+                const uint32_t v = v0 + tid;
+                if (v < total) {
+                        uint32_t k = kbeg, r = v;
+                        for (uint32_t c = sh.seg_cnt[k]; r >= c; c = sh.seg_cnt[k]) {
+                                r -= c;
+                                ++k;
                         }
-                        dense_visit(last - w0, dst);
-                        return;
+                        const DevTerm t = sh.seg_term[k];
+                        const uint32_t b = sh.seg_lo[k] + r;
+                        const uint32_t *bl = blk_last + t.first_block;
+                        const uint32_t prev = b ? bl[b - 1] : 0;
+                        const uint32_t last = bl[b];
+                        const uint32_t off = blk_off[t.first_block + b];
+                        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
+                        uint32_t *dst = sh.bits[k < ksplit ? 0 : 1];
+                        bool decoded = false;
+                        if (CODEC == CODEC_GOOGLE && n == 32) {
+                                uint32_t dv[8];
+                                if (load_block_bytes32(index + off, dv)) {
+                                        uint32_t rel = prev - w0;
+#pragma unroll
+                                        for (int j = 0; j < 31; ++j) {
+                                                rel += (dv[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+                                                dense_visit(rel, dst);
+                                        }
+                                        dense_visit(last - w0, dst);
+                                        decoded = true;
+                                }
+                        }
+                        if (!decoded) {
+                                const uint32_t slot = CODEC == CODEC_GOOGLE ? atomicAdd(&sh.nslow, 1u) : DENSE_SLOW_CAP;
+                                if (slot < DENSE_SLOW_CAP)
+                                        sh.tbase[slot] = (k << 16) | r; // r <= SPAN_BITS / 32 + 1 blocks of one term reach a window
+                                else
+                                        dense_block_stream<CODEC>(index, t, b, off, n, prev, last, w0, dst);
+                        }
                 }
         }
-#endif
-        dense_block_stream<CODEC>(index, t, b, off, n, prev, last, w0, dst);
+        if (CODEC == CODEC_GOOGLE) {
+                __syncthreads();
+                const uint32_t ns = min(uni(sh.nslow), DENSE_SLOW_CAP);
+                for (uint32_t i = tid; i < ns; i += WG) {
+                        const uint32_t e = sh.tbase[i];
+                        const uint32_t k = e >> 16;
+                        const DevTerm t = sh.seg_term[k];
+                        const uint32_t b = sh.seg_lo[k] + (e & 0xffffu);
+                        const uint32_t *bl = blk_last + t.first_block;
+                        const uint32_t off = blk_off[t.first_block + b];
+                        dense_block_stream<CODEC>(index, t, b, off, TRI_BLOCK_N(t, b, index, off), b ? bl[b - 1] : 0, bl[b], w0, sh.bits[k < ksplit ? 0 : 1]);
+                }
+                __syncthreads();
+                sh.nslow = 0; // uniform store; the next pass's appends come after at least one more barrier
+        }
+        __syncthreads();
 }
 
 template <int WG, int CODEC>
@@ -396,6 +448,7 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
         uint32_t *qout = out + task.out_off;
         uint32_t produced = 0;
         sh.lcur[tid & 15] = 0; // per term: a block index at or before the first block that can matter
+        sh.nslow = 0;
         __syncthreads();
         // number of terms in the lead group (it creates the candidates; the other groups test them)
         uint32_t nlead = 1;
@@ -430,33 +483,24 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                 w = wnext;
                 const uint32_t w0 = w * SPAN_BITS;
                 const uint32_t wlast = w0 + (SPAN_BITS - 1);
-                uint32_t gi = 0;       // group index
-                bool galive = false;   // some term of the current group reaches this window or beyond
+                // ---- block range of every term in this window; a group none of whose lists reaches the window or beyond
+                //      ends the task (an exhausted conjunct: no further match anywhere)
+                uint32_t ngroups = 0, g1 = q.nterms, g2 = q.nterms; // first term of group 1 / group 2
+                bool galive = false;
                 for (uint32_t k = 0; k < q.nterms; ++k) {
                         const uint32_t tt = qterms[q.term_base + k];
                         const DevTerm t = terms[tt & ~QT_GROUP];
                         const uint32_t *bl = blk_last + t.first_block;
-                        const uint32_t *bo = blk_off + t.first_block;
-                        // bits[0] = A: the lead group's union, then the running conjunction; bits[1] = B: the union of the group
-                        // being read.  A finished group is folded in word-wise (A &= B) when the next one starts; the last
-                        // group's fold is fused into the expansion below.  (The previous term's pass ended with a barrier.)
-                        if (k == 0) {
-                                for (uint32_t i = tid; i < SPAN_WORDS; i += WG)
-                                        sh.bits[0][i] = 0;
-                        } else if (tt & QT_GROUP) {
-                                if (!galive) { // an exhausted conjunct: no further match anywhere
+                        if (tt & QT_GROUP) {
+                                if (k && !galive)
                                         done = true;
-                                        break;
-                                }
-                                for (uint32_t i = tid; i < SPAN_WORDS; i += WG) {
-                                        if (gi)
-                                                sh.bits[0][i] &= sh.bits[1][i];
-                                        sh.bits[1][i] = 0;
-                                }
-                                ++gi;
+                                if (ngroups == 1)
+                                        g1 = k;
+                                else if (ngroups == 2)
+                                        g2 = k;
+                                ++ngroups;
                                 galive = false;
                         }
-                        uint32_t *dst = sh.bits[gi ? 1 : 0];
                         // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
                         uint32_t b_lo, b_hi;
                         if (t.win_off != 0xffffffffu) {
@@ -464,40 +508,51 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                                 // with last >= the next window's first docID; it may still hold documents of this window)
                                 b_lo = win[t.win_off + w];
                                 b_hi = min(win[t.win_off + w + 1], t.nblocks - 1);
-                                if (b_lo < t.nblocks)
-                                        galive = true;
-                                __syncthreads(); // dst cleared, earlier passes complete
                         } else {
                                 b_lo = uni(sh.lcur[k]);
                                 if (b_lo < t.nblocks && bl[b_lo] < w0)
                                         b_lo += wg_lower_bound<WG>(sh.scan, bl + b_lo, t.nblocks - b_lo, w0);
                                 b_hi = b_lo;
                                 if (b_lo < t.nblocks) {
-                                        galive = true;
                                         b_hi = b_lo + wg_lower_bound<WG>(sh.scan, bl + b_lo, t.nblocks - b_lo, wlast);
                                         if (b_hi >= t.nblocks)
                                                 b_hi = t.nblocks - 1;
                                 }
-                                __syncthreads(); // dst cleared, earlier passes complete, cursor reads done
+                                __syncthreads(); // cursor reads done
                                 sh.lcur[k] = b_lo < t.nblocks ? b_hi : b_lo;
                         }
-                        if (b_lo < t.nblocks) {
-                                for (uint32_t cb = b_lo; cb <= b_hi; cb += WG) {
-                                        const uint32_t b = cb + tid;
-                                        if (b <= b_hi) {
-                                                const uint32_t prev = b ? bl[b - 1] : 0;
-                                                const uint32_t last = bl[b];
-                                                const uint32_t off = bo[b];
-                                                const uint32_t n = TRI_BLOCK_N(t, b, index, off);
-                                                dense_block<CODEC>(index, t, b, off, n, prev, last, w0, dst);
-                                        }
-                                }
+                        if (b_lo < t.nblocks)
+                                galive = true;
+                        // uniform stores by every lane (see the control-flow note in k_and)
+                        sh.seg_lo[k] = b_lo;
+                        sh.seg_cnt[k] = b_lo < t.nblocks ? b_hi - b_lo + 1 : 0;
+                        sh.seg_term[k] = t;
+                }
+                sh.seg_cnt[q.nterms] = 0xffffffffu; // sentinel: the lane-to-term walk stops here
+                if (!galive)
+                        done = true;
+                if (done)
+                        break;
+                // bits[0] = A: the lead group's union, then the running conjunction; bits[1] = B: the union of the group being
+                // read.  Every term only sets bits; a finished group is folded in word-wise (A &= B) before B is reused, and
+                // the last group's fold is fused into the expansion below.
+                for (uint32_t i = tid; i < SPAN_WORDS; i += WG) {
+                        sh.bits[0][i] = 0;
+                        sh.bits[1][i] = 0;
+                }
+                __syncthreads();
+                dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, 0, g2, g1, w0); // groups 0 and 1 together
+                for (uint32_t kb = g2; kb < q.nterms;) {
+                        uint32_t ke = kb + 1;
+                        while (ke < q.nterms && !(qterms[q.term_base + ke] & QT_GROUP))
+                                ++ke;
+                        for (uint32_t i = tid; i < SPAN_WORDS; i += WG) {
+                                sh.bits[0][i] &= sh.bits[1][i];
+                                sh.bits[1][i] = 0;
                         }
                         __syncthreads();
-                }
-                if (done || !galive) {
-                        done = true;
-                        break;
+                        dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, kb, ke, kb, w0);
+                        kb = ke;
                 }
                 // ---- expand the survivors bitmap into ascending docIDs
                 uint32_t *fin = sh.bits[0];
@@ -507,7 +562,7 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                         for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
                                 const uint32_t wi = bswz(tid * (SPAN_WORDS / WG) + j);
                                 uint32_t m = fin[wi];
-                                if (gi) {
+                                if (ngroups > 1) {
                                         m &= pre[wi];
                                         fin[wi] = m;
                                 }
