@@ -21,12 +21,31 @@ bd = nbo <= lead
 dense = bd & (d.sum(1) >= 512 * 1024)
 classes = {"dense(bitmap windows)": dense, "cand block-driven": bd & ~dense, "cand galloping": ~bd}
 
+def prof_dump(tag):
+    """TRI_PROF builds (TRINITY_HIP_LIB=...): per-phase cycle totals of wave 0 of every workgroup."""
+    import ctypes as C
+    L = E_lib()
+    if not hasattr(L, "tri_debug_prof"):
+        return
+    buf = (C.c_uint64 * 32)()
+    L.tri_debug_prof(buf)
+    v = list(buf)[:16]
+    tot = sum(v) or 1
+    print(f"  prof[{tag}] " + " ".join(f"p{i}={x / tot * 100:.1f}%" for i, x in enumerate(v) if x), f"(total {tot:.3e} cycles)")
+
+
+def E_lib():
+    import trinity_amd.engine as E
+    return E.hip_lib()
+
+
 def run(q, reps=3):
     b = T.Batch.conjunctions(ix, q)
     best = 1e9
     for _ in range(reps):
         b.run(); b.sync(); best = min(best, b.info()["last_run_ms"])
     inf = b.info(); b.close()
+    prof_dump("%d queries" % len(q))
     return best, inf
 
 only = os.environ.get("CLASS")

@@ -7,6 +7,45 @@
 // ------------------------------------------------------------------------------------------ debug trace
 // -DTRI_TRACE builds write per-workgroup progress markers into host-pinned memory; tri_batch_sync then polls
 // with a watchdog (env TRINITY_WATCHDOG_S) and dumps the markers instead of hanging.  Not in product builds.
+// -DTRI_PROF builds accumulate, per kernel phase, the shader-clock cycles wave 0 of every workgroup spent in it
+// (g_prof[phase], summed over workgroups; read back and reset with tri_debug_prof).  Perf-probe builds only.
+#ifdef TRI_PROF
+__device__ unsigned long long g_prof[32];
+struct ProfClock {
+        long long t;
+        unsigned long long acc[16];
+        __device__ __forceinline__ void start() {
+                for (int i = 0; i < 16; ++i)
+                        acc[i] = 0;
+                t = clock64();
+        }
+        __device__ __forceinline__ void lap(const int phase) {
+                const long long n = clock64();
+                acc[phase] += (unsigned long long)(n - t);
+                t = n;
+        }
+        __device__ __forceinline__ void flush() {
+                if (threadIdx.x == 0)
+                        for (int i = 0; i < 16; ++i)
+                                if (acc[i])
+                                        atomicAdd(&g_prof[i], acc[i]);
+        }
+};
+#define PROF_DECL ProfClock prof_
+#define PROF_START() prof_.start()
+#define PROF_LAP(p) prof_.lap(p)
+#define PROF_FLUSH() prof_.flush()
+#define PROF_ARG , ProfClock &prof_
+#define PROF_PASS , prof_
+#else
+#define PROF_DECL
+#define PROF_START()
+#define PROF_LAP(p)
+#define PROF_FLUSH()
+#define PROF_ARG
+#define PROF_PASS
+#endif
+
 #ifdef TRI_TRACE
 static uint32_t *g_trace_host = nullptr;
 __device__ volatile uint32_t *g_trace = nullptr;

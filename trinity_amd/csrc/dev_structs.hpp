@@ -15,6 +15,8 @@ struct DevTerm {
         uint32_t pad;     // LUCENE with hits.data: the term's row in hdir[] ({nfull, off[nfull], tail_off}); otherwise 0
 };
 constexpr uint32_t TERM_FULL_BLOCKS = 1u;
+constexpr uint32_t TERM_SPARSE = 2u; // GOOGLE: fewer than 1 document in 28 docIDs on average — most blocks hold a multi-byte delta, so the
+                                     // bitmap kernel parses them from registers in place instead of trying the static one-byte path
 
 // documents in block b of term t
 #define TRI_BLOCK_N(t, b, index, off) (((t).flags & TERM_FULL_BLOCKS) ? ((b) + 1 == (t).nblocks ? (t).last_n : 32u) : (uint32_t)(index)[(off)-1])

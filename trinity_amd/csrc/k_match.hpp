@@ -36,6 +36,14 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
 #endif
 constexpr uint32_t SPAN_BITS = 1u << 17; // docIDs per dense window
 constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
+// Window bitmap layout in LDS: logical word w lives at bm[w + (w >> 5)] — every row of 32 words is followed by one pad
+// word, so lanes whose blocks lie a small constant number of words apart do not pile onto one bank.  Bitmap B is bitmap A
+// shifted by BM_B_WORDS logical words, i.e. a lane selects it by adding BM_B_WORDS * 32 to its window-relative docID once
+// per block; the per-posting address is then two shifts and an add.  Logical word SPAN_WORDS (first of the spare row) is
+// the sink for documents outside the window.
+constexpr uint32_t BM_B_WORDS = SPAN_WORDS + 32;
+constexpr uint32_t BM_STRIDE = BM_B_WORDS + BM_B_WORDS / 32; // physical words per bitmap == pad(BM_B_WORDS)
+__device__ __forceinline__ uint32_t bm_pad(const uint32_t w) { return w + (w >> 5); }
 
 // LDS state of the candidate-tile kernel
 struct AndShared {
@@ -49,7 +57,7 @@ struct AndShared {
 
 // LDS state of the bitmap-window kernel
 struct DenseShared {
-        uint32_t bits[2][SPAN_WORDS + 1]; // two docID-window bitmaps (candidates / survivors), +1 sink word each
+        uint32_t bm[2 * BM_STRIDE]; // two docID-window bitmaps A, B (rows padded, one spare row holding the sink word)
         uint32_t tbase[DENSE_WG]; // expansion: per-thread output base; decode passes: the deferred (slow) block list
         uint32_t scan[8];
         uint32_t bcast[4];
@@ -59,7 +67,7 @@ struct DenseShared {
         DevTerm seg_term[MAX_QTERMS];
         uint32_t nslow;
 };
-constexpr uint32_t DENSE_SLOW_CAP = DENSE_WG;
+constexpr uint32_t DENSE_SLOW_CAP = DENSE_WG / 4; // 16-byte entries in tbase[]
 
 // Workgroup-cooperative lower bound over a sorted global array: first i in [0, n) with a[i] >= key, else n.
 // 256-ary search: every lane probes the end of its segment, one ballot per wave finds the first segment whose
@@ -92,30 +100,22 @@ __device__ uint32_t wg_lower_bound(uint32_t *scan, const uint32_t *__restrict__ 
         return lo;
 }
 
-// The first 32 payload bytes of a block from THREE 16-byte-aligned loads, realigned in registers (a dword select
-// stage, then v_alignbyte).  Returns true when bytes 0..30 — the 31 doc deltas of a full block — are all one-byte varints
-// (every block of a head term), in which case delta j is byte j of v[].  One wave-load touches 64 cache lines whatever
-// its width, so 3 wide loads per block instead of ~13 eight-byte stream loads takes the pressure off the L1/TA path;
-// the freqs and hits behind the deltas are never touched in DocumentsOnly mode.
+// The first 32 payload bytes of a block from three wide loads at the enclosing dword boundary, realigned in registers
+// (v_alignbyte).  Returns true when bytes 0..30 — the 31 doc deltas of a full block — are all one-byte varints (every
+// block of a head term), in which case delta j is byte j of v[].  One wave-load touches 64 cache lines whatever its width,
+// so 3 wide loads per block instead of ~13 eight-byte stream loads takes the pressure off the L1/TA path; the freqs and
+// hits behind the deltas are never touched in DocumentsOnly mode.  The pointer is derived by arithmetic (not through an
+// integer) so the loads stay global_load (a flat load would also tie up the LDS counter the bitmap atomics use).
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 __device__ __forceinline__ bool load_block_bytes32(const uint8_t *__restrict__ p, uint32_t (&v)[8]) {
-        const uintptr_t a = (uintptr_t)p;
-        const uint4 *q = (const uint4 *)(a & ~(uintptr_t)15);
-        const uint4 A = q[0], B = q[1], C = q[2];
-        const uint32_t sk = (uint32_t)(a & 15u);
-        uint32_t r[12] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z, C.w};
-        if (sk & 4u) {
-#pragma unroll
-                for (int i = 0; i < 11; ++i)
-                        r[i] = r[i + 1];
-        }
-        if (sk & 8u) {
-#pragma unroll
-                for (int i = 0; i < 10; ++i)
-                        r[i] = r[i + 2];
-        }
+        const uint32_t sk = (uint32_t)((uintptr_t)p & 3u);
+        const uint8_t *q = p - sk;
+        const u32x4_a4 A = *(const u32x4_a4 *)q, B = *(const u32x4_a4 *)(q + 16);
+        const uint32_t C = *(const uint32_t *)(q + 32);
+        const uint32_t r[9] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C};
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-                v[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], sk & 3u);
+                v[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], sk);
         return ((v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | (v[7] & 0x00ffffffu)) & 0x80808080u) == 0;
 }
 
@@ -309,28 +309,35 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
 // One lane decodes one block (unpack_block, google_codec.cpp:596-639) and ORs its documents into / tests them
 // against a window bitmap in LDS.  Consecutive documents of a dense list fall into the same 32-bit word, so the
 // lane keeps the current word in registers and touches LDS once per word, not once per posting.
-// Bitmap word -> LDS slot.  Neighbouring lanes decode neighbouring blocks, i.e. words a small constant stride apart,
-// which lands lanes l and l+16 on one bank; XOR-ing in the next five index bits spreads every 32-word row differently.
-// A bijection inside each 1024-word group; the sink word (index SPAN_WORDS) maps to itself.
-#if TRI_DENSE_V == 1
-__device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w ^ ((w >> 5) & 31u); }
+// One posting into a window bitmap.  `rel` = docID - window start (+ BM_B_WORDS * 32 for bitmap B).  Fire-and-forget:
+// no value comes back from LDS, so nothing in the lane's chain waits on it.  Every term only SETS bits; a conjunct is
+// folded in by AND-ing whole bitmaps afterwards (dense_task), 8 words per thread instead of a dependent LDS read per
+// posting.  dense_visit: the block lies wholly inside the window.  dense_visit_clamped: it may not — documents outside go
+// to the sink word (documents below the window wrap to huge values).
+__device__ __forceinline__ void dense_visit(uint32_t *bm, const uint32_t rel) {
+        // byte address of word pad(rel >> 5) in three instructions (the compiler's own form — two shifts, two masks, an add —
+        // takes five, and this is the innermost statement of the engine)
+        uint32_t w, r, a;
+        asm("v_lshrrev_b32 %0, 5, %1" : "=v"(w) : "v"(rel));
+        asm("v_lshrrev_b32 %0, 10, %1" : "=v"(r) : "v"(rel));
+        asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a) : "v"(w), "v"(r));
+#if defined(TRI_EXP) && TRI_EXP == 1
+        asm volatile("" ::"v"(a), "v"(1u << (rel & 31u))); // experiment: no LDS operation at all
+#elif defined(TRI_EXP) && TRI_EXP == 2
+        *(volatile uint32_t *)((uint8_t *)bm + a) = 1u << (rel & 31u); // experiment: plain store
 #else
-__device__ __forceinline__ uint32_t bswz(const uint32_t w) { return w; }
+        atomicOr((uint32_t *)((uint8_t *)bm + a), 1u << (rel & 31u));
 #endif
-
-// One posting into a window bitmap, by its window-relative docID (documents below the window wrap to huge values).
-// Branch-free, fire-and-forget (no value comes back from LDS, so nothing in the lane's chain waits on it); documents
-// outside the window go to the sink word.  Every term only SETS bits: a conjunct is folded in by AND-ing whole bitmaps
-// afterwards (dense_task), which costs 8 words per thread instead of a dependent LDS read per posting.
-__device__ __forceinline__ void dense_visit(const uint32_t rel, uint32_t *dst) {
-        const uint32_t word = bswz(min(rel >> 5, SPAN_WORDS));
-        atomicOr(&dst[word], 1u << (rel & 31u));
+}
+__device__ __forceinline__ void dense_visit_clamped(uint32_t *bm, const uint32_t rel, const uint32_t wbase) {
+        atomicOr(&bm[bm_pad(min(rel >> 5, SPAN_WORDS) + wbase)], 1u << (rel & 31u));
 }
 
-// Generic block walk over the per-lane byte stream (any varint lengths, any n).
+// Generic block walk over the per-lane byte stream (any varint lengths, any n, any position relative to the window).
 template <int CODEC>
 __device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
-                                                   const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *dst) {
+                                                   const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *bm,
+                                                   const uint32_t wbase) {
         uint32_t rel = prev - w0;
         const uint32_t nd = n - 1;
         if (CODEC != CODEC_GOOGLE) {
@@ -338,9 +345,9 @@ __device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ i
                 ls.init(index, t, b, off);
                 for (uint32_t i = 0; i < nd; ++i) {
                         rel += ls.next();
-                        dense_visit(rel, dst);
+                        dense_visit_clamped(bm, rel, wbase);
                 }
-                dense_visit(last - w0, dst);
+                dense_visit_clamped(bm, last - w0, wbase);
                 return;
         }
         VbStream s;
@@ -356,28 +363,114 @@ __device__ __forceinline__ void dense_block_stream(const uint8_t *__restrict__ i
                                 if (j < k) {
                                         rel += (uint32_t)(w & 0xffu);
                                         w >>= 8;
-                                        dense_visit(rel, dst);
+                                        dense_visit_clamped(bm, rel, wbase);
                                 }
                         }
                         i += k;
                 } else {
                         rel += s.next();
-                        dense_visit(rel, dst);
+                        dense_visit_clamped(bm, rel, wbase);
                         ++i;
                 }
         }
-        dense_visit(last - w0, dst);
+        dense_visit_clamped(bm, last - w0, wbase);
+}
+
+// GOOGLE blocks that miss the static path (a multi-byte delta somewhere, a short last block, a block straddling the
+// window's end): the first 60 payload bytes come from four wide loads issued together — one memory round trip, like the
+// static path — and the varints are parsed out of registers: the outer loop over the loaded dwords is static, the inner
+// loop takes every varint that is complete in the 64-bit window.  (The byte stream's refills are dependent loads; walking
+// a block through it costs several round trips.)  More than 60 bytes of deltas: the stream finishes the block.
+__device__ __forceinline__ void dense_block_regs(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
+                                                 const uint32_t last, const uint32_t w0, uint32_t *bm, const uint32_t wbase) {
+        const uint8_t *p = index + off;
+        const uint32_t sk = (uint32_t)((uintptr_t)p & 3u);
+        const uint8_t *q = p - sk;
+        const u32x4_a4 A = *(const u32x4_a4 *)q, B = *(const u32x4_a4 *)(q + 16), C = *(const u32x4_a4 *)(q + 32), D = *(const u32x4_a4 *)(q + 48);
+        const uint32_t raw[16] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C.x, C.y, C.z, C.w, D.x, D.y, D.z, D.w};
+        uint64_t win = 0;
+        uint32_t have = 0, done = 0, rel = prev - w0;
+        const uint32_t nd = n - 1;
+#pragma unroll
+        for (int d = 0; d < 15; ++d) {
+                win |= (uint64_t)__builtin_amdgcn_alignbyte(raw[d + 1], raw[d], sk) << (have * 8); // have <= 4 here
+                have += 4;
+                while (done < nd) {
+                        uint32_t len;
+                        const uint32_t v = vb_decode(win, len);
+                        if (len > have)
+                                break;
+                        win >>= 8 * len;
+                        have -= len;
+                        rel += v;
+                        dense_visit_clamped(bm, rel, wbase);
+                        ++done;
+                }
+        }
+        if (done < nd) {
+                VbStream st;
+                st.init(p + (60 - have));
+                for (; done < nd; ++done) {
+                        rel += st.next();
+                        dense_visit_clamped(bm, rel, wbase);
+                }
+        }
+        dense_visit_clamped(bm, last - w0, wbase);
+}
+
+// One deferred GOOGLE block decoded by a whole wave (arguments wave-uniform): lane i looks at payload byte i as if a varint
+// started there; the true starts are found by walking the lengths (a scalar loop of readlanes, <= 31 steps), the deltas of
+// the start lanes are prefix-summed across the wave, and every start lane sets its bit.  ~200 instructions of latency
+// instead of the ~800 of a lane parsing the block alone — this is what runs while the rest of the workgroup waits at
+// the barrier, so latency is what counts.
+__device__ __forceinline__ void dense_block_coop(const uint8_t *__restrict__ index, const uint32_t off, const uint32_t n, const uint32_t prev,
+                                                 const uint32_t last, const uint32_t w0, uint32_t *bm, const uint32_t wbase) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint8_t *p = index + off + lane;
+        const uint32_t sk = (uint32_t)((uintptr_t)p & 3u);
+        const uint32_t *q = (const uint32_t *)(p - sk);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2];
+        const uint64_t w = (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, sk) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sk) << 32);
+        uint32_t len;
+        const uint32_t v = vb_decode(w, len);
+        const uint32_t nd = n - 1;
+        uint64_t starts = 0;
+        uint32_t s = 0, found = 0;
+        for (; found < nd && s < 64; ++found) {
+                starts |= 1ull << s;
+                s += (uint32_t)__builtin_amdgcn_readlane((int)len, (int)s);
+        }
+        if (found < nd) { // > 64 bytes of deltas (rare): one lane parses the block alone; setting a bit twice is harmless
+                if (lane == 0)
+                        dense_block_regs(index, off, n, prev, last, w0, bm, wbase);
+                return;
+        }
+        const bool is_start = (starts >> lane) & 1ull;
+        uint32_t x = is_start ? v : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t y = __shfl_up(x, d, 64);
+                if ((int)lane >= d)
+                        x += y;
+        }
+        if (is_start)
+                dense_visit_clamped(bm, prev - w0 + x, wbase);
+        if (lane == 0)
+                dense_visit_clamped(bm, last - w0, wbase);
 }
 
 // One pass over a window: the blocks of terms [kbeg, kend) that reach the window form one virtual work list (term after
 // term), dealt out to the lanes round by round — so a short list does not leave most of the workgroup idle and the terms
-// of a pass share one barrier.  Terms below ksplit set bits in A (bits[0]), the others in B (bits[1]).  A block that
-// cannot take the static register path (a multi-byte delta, a short last block) is not decoded in place — that would make
-// its whole wave run the slow stream path — but appended to an LDS list which the workgroup then works off densely.
+// of a pass share one barrier.  Terms below ksplit set bits in A, the others in B.  GOOGLE blocks take one of:
+//   static   a full block of one-byte deltas (every block of a head term): 31 unrolled byte adds from registers;
+//            the block straddling a window end runs the same code with the clamped visit
+//   regs     terms flagged TERM_SPARSE (most blocks hold a multi-byte delta): varints parsed from registers, in place
+//   deferred the odd block of a dense term (a multi-byte delta, a short last block): decoding it in place would make its
+//            whole wave run the slow path, so it is appended to an LDS list that the waves then work off cooperatively
 template <int WG, int CODEC>
 __device__ __forceinline__ void dense_pass(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                            const uint32_t *__restrict__ blk_off, const uint32_t kbeg, const uint32_t kend, const uint32_t ksplit,
-                                           const uint32_t w0) {
+                                           const uint32_t w0 PROF_ARG) {
         const uint32_t tid = threadIdx.x;
         uint32_t total = 0;
         for (uint32_t k = kbeg; k < kend; ++k)
@@ -397,53 +490,68 @@ __device__ __forceinline__ void dense_pass(DenseShared &sh, const uint8_t *__res
                         const uint32_t last = bl[b];
                         const uint32_t off = blk_off[t.first_block + b];
                         const uint32_t n = TRI_BLOCK_N(t, b, index, off);
-                        uint32_t *dst = sh.bits[k < ksplit ? 0 : 1];
-                        bool decoded = false;
-                        if (CODEC == CODEC_GOOGLE && n == 32) {
+                        const uint32_t wbase = k < ksplit ? 0u : BM_B_WORDS;
+                        if (CODEC != CODEC_GOOGLE)
+                                dense_block_stream<CODEC>(index, t, b, off, n, prev, last, w0, sh.bm, wbase);
+                        else if (t.flags & TERM_SPARSE)
+                                dense_block_regs(index, off, n, prev, last, w0, sh.bm, wbase);
+                        else {
                                 uint32_t dv[8];
-                                if (load_block_bytes32(index + off, dv)) {
+                                const bool fits = n == 32 && load_block_bytes32(index + off, dv);
+                                const bool inside = prev + 1 >= w0 && last - w0 < SPAN_BITS;
+                                if (fits && inside) {
+                                        uint32_t rel = prev - w0 + wbase * 32u;
+#pragma unroll
+                                        for (int j = 0; j < 31; ++j) {
+                                                rel += (dv[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+                                                dense_visit(sh.bm, rel);
+                                        }
+                                        dense_visit(sh.bm, last - w0 + wbase * 32u);
+                                } else if (fits) {
                                         uint32_t rel = prev - w0;
 #pragma unroll
                                         for (int j = 0; j < 31; ++j) {
                                                 rel += (dv[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-                                                dense_visit(rel, dst);
+                                                dense_visit_clamped(sh.bm, rel, wbase);
                                         }
-                                        dense_visit(last - w0, dst);
-                                        decoded = true;
+                                        dense_visit_clamped(sh.bm, last - w0, wbase);
+                                } else {
+                                        const uint32_t slot = atomicAdd(&sh.nslow, 1u);
+                                        if (slot < DENSE_SLOW_CAP) {
+                                                sh.tbase[4 * slot + 0] = off;
+                                                sh.tbase[4 * slot + 1] = prev;
+                                                sh.tbase[4 * slot + 2] = last;
+                                                sh.tbase[4 * slot + 3] = n | (wbase ? 0x100u : 0u);
+                                        } else
+                                                dense_block_regs(index, off, n, prev, last, w0, sh.bm, wbase);
                                 }
                         }
-                        if (!decoded) {
-                                const uint32_t slot = CODEC == CODEC_GOOGLE ? atomicAdd(&sh.nslow, 1u) : DENSE_SLOW_CAP;
-                                if (slot < DENSE_SLOW_CAP)
-                                        sh.tbase[slot] = (k << 16) | r; // r <= SPAN_BITS / 32 + 1 blocks of one term reach a window
-                                else
-                                        dense_block_stream<CODEC>(index, t, b, off, n, prev, last, w0, dst);
-                        }
                 }
         }
+        PROF_LAP(3);
         if (CODEC == CODEC_GOOGLE) {
                 __syncthreads();
+                PROF_LAP(4);
                 const uint32_t ns = min(uni(sh.nslow), DENSE_SLOW_CAP);
-                for (uint32_t i = tid; i < ns; i += WG) {
-                        const uint32_t e = sh.tbase[i];
-                        const uint32_t k = e >> 16;
-                        const DevTerm t = sh.seg_term[k];
-                        const uint32_t b = sh.seg_lo[k] + (e & 0xffffu);
-                        const uint32_t *bl = blk_last + t.first_block;
-                        const uint32_t off = blk_off[t.first_block + b];
-                        dense_block_stream<CODEC>(index, t, b, off, TRI_BLOCK_N(t, b, index, off), b ? bl[b - 1] : 0, bl[b], w0, sh.bits[k < ksplit ? 0 : 1]);
+                for (uint32_t i = uni(tid >> 6); i < ns; i += WG / 64) {
+                        const uint32_t off = uni(sh.tbase[4 * i + 0]), prev = uni(sh.tbase[4 * i + 1]), last = uni(sh.tbase[4 * i + 2]);
+                        const uint32_t nw = uni(sh.tbase[4 * i + 3]);
+                        dense_block_coop(index, off, nw & 0xffu, prev, last, w0, sh.bm, (nw & 0x100u) ? BM_B_WORDS : 0u);
                 }
-                __syncthreads();
-                sh.nslow = 0; // uniform store; the next pass's appends come after at least one more barrier
+                if (ns) { // uniform
+                        __syncthreads();
+                        sh.nslow = 0; // uniform store; the next pass's appends come after at least one more barrier
+                }
         }
         __syncthreads();
+        PROF_LAP(5);
 }
 
 template <int WG, int CODEC>
 __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                            const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                            const uint32_t *__restrict__ qterms, const DevQuery q, const DevTask task, uint32_t *__restrict__ out,
-                           uint32_t *__restrict__ count_out) {
+                           uint32_t *__restrict__ count_out PROF_ARG) {
         const uint32_t tid = threadIdx.x;
         uint32_t *qout = out + task.out_off;
         uint32_t produced = 0;
@@ -536,31 +644,31 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                 // bits[0] = A: the lead group's union, then the running conjunction; bits[1] = B: the union of the group being
                 // read.  Every term only sets bits; a finished group is folded in word-wise (A &= B) before B is reused, and
                 // the last group's fold is fused into the expansion below.
-                for (uint32_t i = tid; i < SPAN_WORDS; i += WG) {
-                        sh.bits[0][i] = 0;
-                        sh.bits[1][i] = 0;
-                }
+                PROF_LAP(1);
+                for (uint32_t i = tid; i < 2 * BM_STRIDE; i += WG)
+                        sh.bm[i] = 0;
                 __syncthreads();
-                dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, 0, g2, g1, w0); // groups 0 and 1 together
+                PROF_LAP(2);
+                dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, 0, g2, g1, w0 PROF_PASS); // groups 0 and 1 together
                 for (uint32_t kb = g2; kb < q.nterms;) {
                         uint32_t ke = kb + 1;
                         while (ke < q.nterms && !(qterms[q.term_base + ke] & QT_GROUP))
                                 ++ke;
-                        for (uint32_t i = tid; i < SPAN_WORDS; i += WG) {
-                                sh.bits[0][i] &= sh.bits[1][i];
-                                sh.bits[1][i] = 0;
+                        for (uint32_t i = tid; i < BM_STRIDE; i += WG) {
+                                sh.bm[i] &= sh.bm[BM_STRIDE + i];
+                                sh.bm[BM_STRIDE + i] = 0;
                         }
                         __syncthreads();
-                        dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, kb, ke, kb, w0);
+                        dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, kb, ke, kb, w0 PROF_PASS);
                         kb = ke;
                 }
                 // ---- expand the survivors bitmap into ascending docIDs
-                uint32_t *fin = sh.bits[0];
-                uint32_t *pre = sh.bits[1]; // B dies word by word as it is folded in: per-word exclusive prefix takes its place
+                uint32_t *fin = sh.bm;
+                uint32_t *pre = sh.bm + BM_STRIDE; // B dies word by word as it is folded in: per-word exclusive prefix takes its place
                 {
                         uint32_t run = 0;
                         for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
-                                const uint32_t wi = bswz(tid * (SPAN_WORDS / WG) + j);
+                                const uint32_t wi = bm_pad(tid * (SPAN_WORDS / WG) + j);
                                 uint32_t m = fin[wi];
                                 if (ngroups > 1) {
                                         m &= pre[wi];
@@ -581,10 +689,11 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                         }
                         sh.tbase[tid] = ex + wbase;
                         __syncthreads();
+                        PROF_LAP(6);
                         // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
                         for (uint32_t wi = tid; wi < SPAN_WORDS; wi += WG) {
-                                uint32_t m = fin[bswz(wi)];
-                                uint32_t o = produced + sh.tbase[wi / (SPAN_WORDS / WG)] + pre[bswz(wi)];
+                                uint32_t m = fin[bm_pad(wi)];
+                                uint32_t o = produced + sh.tbase[wi / (SPAN_WORDS / WG)] + pre[bm_pad(wi)];
                                 const uint32_t base = w0 + wi * 32;
                                 while (m) {
                                         qout[o++] = base + (uint32_t)__builtin_ctz(m);
@@ -593,12 +702,14 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                         }
                         produced += uni(total);
                         __syncthreads();
+                        PROF_LAP(7);
                 }
                 ++w;
         }
         __syncthreads();
         if (uni(tid >> 6) == 0)
                 *count_out = produced;
+        PROF_LAP(8);
 }
 
 // bitmap-window tasks: persistent 512-thread workgroups draw TASK_DENSE tasks, heaviest first
@@ -611,6 +722,8 @@ __global__ __launch_bounds__(DENSE_WG) void k_and_dense(const uint8_t *__restric
                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ counts) {
         __shared__ DenseShared sh;
         const uint32_t wave = uni(threadIdx.x >> 6);
+        PROF_DECL;
+        PROF_START();
         for (;;) {
                 if (wave == 0) { // uniform draw: 64 lanes add 1 each (one +64 atomic), see k_and
                         const uint32_t old = atomicAdd(ticket, 1u);
@@ -623,8 +736,12 @@ __global__ __launch_bounds__(DENSE_WG) void k_and_dense(const uint8_t *__restric
                         break;
                 const uint32_t tix = sched[ticket_no];
                 const DevTask task = tasks[tix];
-                dense_task<DENSE_WG, CODEC>(sh, index, blk_last, blk_off, win, terms, qterms, plan[task.slot], task, out, counts + tix);
+                const DevQuery q = plan[task.slot];
+                PROF_LAP(0);
+                dense_task<DENSE_WG, CODEC>(sh, index, blk_last, blk_off, win, terms, qterms, q, task, out, counts + tix PROF_PASS);
         }
+        PROF_LAP(9);
+        PROF_FLUSH();
 }
 
 // candidate-tile tasks (TASK_CAND)

@@ -66,6 +66,12 @@ struct tri_index {
         uint8_t *d_index = nullptr, *d_hits = nullptr;
         uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr, *d_win = nullptr;
         uint32_t *d_blk_hits = nullptr, *d_hdir = nullptr; // LUCENE + hits.data: positional access (k_phrase.hpp)
+        // GOOGLE: the document deltas of every block re-laid out as one contiguous stream per term ([n][n-1 prefix varints] per
+        // block, bytes exactly as in the chunk) with its own offset column.  In the chunk a block's deltas are followed by its
+        // freqs and hits, so a DocumentsOnly scan of a head term drags ~3x the bytes it decodes through HBM; the matching kernels
+        // (k_and_dense, k_and) read this stream instead.  Scoring and phrases keep reading the chunk itself.
+        uint8_t *d_dstream = nullptr;
+        uint32_t *d_blk_doff = nullptr;
         uint32_t nwin = 0; // windows per win[] row (+1 sentinel column)
         DevTerm *d_terms = nullptr;
         std::vector<DevTerm> terms;
@@ -275,6 +281,12 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         ix->hitbytes.assign(nterms, 0);
         std::vector<uint32_t> blk_last, blk_off;
         std::vector<uint32_t> blk_hits, hdir; // LUCENE + hits.data only
+        std::vector<uint8_t> dstream;         // GOOGLE only
+        std::vector<uint32_t> blk_doff;
+        if (codec == TRI_CODEC_GOOGLE) {
+                dstream.reserve(len / 3 + 64);
+                blk_doff.reserve(len / 96 + nterms);
+        }
         const bool want_hits = codec == TRI_CODEC_LUCENE && hits_len;
         blk_last.reserve(len / 96 + nterms);
         blk_off.reserve(len / 96 + nterms);
@@ -425,7 +437,16 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                                 return fail(TRI_ERR_FORMAT, "term %zu: bad block header (n=%u, delta=%u, len=%u)", ti, n, delta, blockLength);
                         lastDoc += delta;
                         const uint8_t *s = p;
-                        for (uint32_t i = 0; i < 2 * n - 1; ++i)
+                        for (uint32_t i = 0; i + 1 < n; ++i)
+                                s += h_vb_len(*s);
+                        if ((uint64_t)(s - p) > blockLength)
+                                return fail(TRI_ERR_FORMAT, "term %zu: deltas overrun the block", ti);
+                        if (dstream.size() + 64 > 0xffffffffull)
+                                return fail(TRI_ERR_UNSUPPORTED, "delta stream exceeds 4 GiB");
+                        dstream.push_back((uint8_t)n);
+                        blk_doff.push_back((uint32_t)dstream.size());
+                        dstream.insert(dstream.end(), p, s);
+                        for (uint32_t i = 0; i < n; ++i)
                                 s += h_vb_len(*s);
                         if ((uint64_t)(s - p) > blockLength)
                                 return fail(TRI_ERR_FORMAT, "term %zu: deltas+freqs overrun the block", ti);
@@ -443,6 +464,8 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 if (docs != t.documents)
                         return fail(TRI_ERR_FORMAT, "term %zu: %u documents in blocks, %u declared", ti, docs, t.documents);
                 dt.flags = full_blocks ? TERM_FULL_BLOCKS : 0;
+                if ((uint64_t)docs * 28 < lastDoc)
+                        dt.flags |= TERM_SPARSE;
                 ix->docbytes[ti] = db;
                 ix->hitbytes[ti] = hb;
                 postings += docs;
@@ -479,6 +502,11 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         int rc;
         if ((rc = dev_upload(&ix->d_blk_last, blk_last)) || (rc = dev_upload(&ix->d_blk_off, blk_off)) || (rc = dev_upload(&ix->d_terms, ix->terms)))
                 return rc;
+        if (codec == TRI_CODEC_GOOGLE) {
+                dstream.resize(dstream.size() + 64, 0); // over-read slack, like index[]
+                if ((rc = dev_upload(&ix->d_dstream, dstream)) || (rc = dev_upload(&ix->d_blk_doff, blk_doff)))
+                        return rc;
+        }
         if (hits_len) { // LUCENE: hits.data (positions) resident next to the index
                 HIP_TRY(hipMalloc((void **)&ix->d_hits, hits_len + 64));
                 HIP_TRY(hipMemset(ix->d_hits, 0, hits_len + 64));
@@ -507,6 +535,8 @@ extern "C" void tri_index_destroy(tri_index *ix) {
         hipFree(ix->d_hits);
         hipFree(ix->d_blk_hits);
         hipFree(ix->d_hdir);
+        hipFree(ix->d_dstream);
+        hipFree(ix->d_blk_doff);
         hipFree(ix->d_blk_last);
         hipFree(ix->d_blk_off);
         hipFree(ix->d_win);
@@ -845,6 +875,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         uint64_t DENSE_MIN_POSTINGS = 512 * 1024;
         if (const char *e = getenv("TRINITY_DENSE_MIN"))
                 DENSE_MIN_POSTINGS = strtoull(e, nullptr, 10);
+        uint64_t DENSE_TASK_COST = TASK_COST;
+        if (const char *e = getenv("TRINITY_DENSE_TASK_COST"))
+                DENSE_TASK_COST = strtoull(e, nullptr, 10);
         std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
         for (auto &t : tmp) {
                 const uint32_t slot = (uint32_t)b->plan.size();
@@ -891,7 +924,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if (dense) {
                         const uint32_t nwin = last_doc / SPAN_BITS + 1;
                         const uint64_t per_win = std::max<uint64_t>(1, sumdf / (ix->info.docs_cnt / SPAN_BITS + 1));
-                        const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, TASK_COST / per_win);
+                        const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / per_win);
                         uint32_t ord = 0;
                         uint64_t lead_blocks = 0;
                         for (uint32_t k = 0; k < nlead; ++k)
@@ -1023,17 +1056,20 @@ extern "C" int tri_batch_run(tri_batch *b) {
         HIP_TRY(hipEventRecord(dev->ev0, dev->stream));
         if (n) {
                 HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 256, dev->stream));
-                // two persistent kernels back to back on the engine stream: bitmap windows (512 threads), then candidate tiles
+                // two persistent kernels back to back on the engine stream: bitmap windows (512 threads), then candidate tiles.
+                // GOOGLE: matching reads the contiguous delta streams, not the chunks (see tri_index::d_dstream)
+                const uint8_t *match_bytes = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_dstream : b->ix->d_index;
+                const uint32_t *match_off = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_blk_doff : b->ix->d_blk_off;
                 if (b->n_dense) {
-                        TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * 4)), dim3(DENSE_WG), dev->stream, b->ix->d_index,
-                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
+                        TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * 4)), dim3(DENSE_WG), dev->stream, match_bytes,
+                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
                                            b->d_ticket + 16, b->d_out, b->d_counts);
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(dev->ev_a, dev->stream));
                 if (b->n_cand)
-                        TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * 4)), dim3(AND_WG), dev->stream, b->ix->d_index,
-                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
+                        TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * 4)), dim3(AND_WG), dev->stream, match_bytes,
+                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
                                            b->n_cand, b->d_ticket, b->d_out, b->d_counts);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipEventRecord(dev->ev_b, dev->stream));
@@ -1248,3 +1284,17 @@ extern "C" int tri_batch_topk_device(tri_batch *b, void **docids, void **scores,
         *counts = b->d_top_counts;
         return TRI_OK;
 }
+
+#ifdef TRI_PROF
+// perf-probe builds: read back and reset the per-phase cycle totals (dev_stream.hpp)
+extern "C" int tri_debug_prof(uint64_t *out32) {
+        unsigned long long h[32];
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof h));
+        for (int i = 0; i < 32; ++i)
+                out32[i] = h[i];
+        memset(h, 0, sizeof h);
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), h, sizeof h));
+        return TRI_OK;
+}
+#endif
