@@ -548,7 +548,7 @@ __device__ __forceinline__ void dense_pass(DenseShared &sh, const uint8_t *__res
 }
 
 template <int WG, int CODEC>
-__device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+__device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                            const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                            const uint32_t *__restrict__ qterms, const DevQuery q, const DevTask task, uint32_t *__restrict__ out,
                            uint32_t *__restrict__ count_out PROF_ARG) {
@@ -557,6 +557,8 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
         uint32_t produced = 0;
         sh.lcur[tid & 15] = 0; // per term: a block index at or before the first block that can matter
         sh.nslow = 0;
+        for (uint32_t i = tid; i < 2 * BM_STRIDE; i += WG)
+                sh.bm[i] = 0;
         __syncthreads();
         // number of terms in the lead group (it creates the candidates; the other groups test them)
         uint32_t nlead = 1;
@@ -645,9 +647,7 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                 // read.  Every term only sets bits; a finished group is folded in word-wise (A &= B) before B is reused, and
                 // the last group's fold is fused into the expansion below.
                 PROF_LAP(1);
-                for (uint32_t i = tid; i < 2 * BM_STRIDE; i += WG)
-                        sh.bm[i] = 0;
-                __syncthreads();
+                __syncthreads(); // (bitmaps: zeroed at task start, re-zeroed by every expansion sweep)
                 PROF_LAP(2);
                 dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, 0, g2, g1, w0 PROF_PASS); // groups 0 and 1 together
                 for (uint32_t kb = g2; kb < q.nterms;) {
@@ -691,12 +691,17 @@ __device__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, c
                         __syncthreads();
                         PROF_LAP(6);
                         // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
+                        // (both bitmaps are left zeroed for the next window as they are read)
                         for (uint32_t wi = tid; wi < SPAN_WORDS; wi += WG) {
-                                uint32_t m = fin[bm_pad(wi)];
-                                uint32_t o = produced + sh.tbase[wi / (SPAN_WORDS / WG)] + pre[bm_pad(wi)];
+                                const uint32_t pw = bm_pad(wi);
+                                uint32_t m = fin[pw];
+                                uint32_t ob = (produced + sh.tbase[wi / (SPAN_WORDS / WG)] + pre[pw]) * 4u; // byte offset: uniform base + 32-bit lane offset
+                                fin[pw] = 0;
+                                pre[pw] = 0;
                                 const uint32_t base = w0 + wi * 32;
                                 while (m) {
-                                        qout[o++] = base + (uint32_t)__builtin_ctz(m);
+                                        *(uint32_t *)((uint8_t *)qout + ob) = base + (uint32_t)__builtin_ctz(m);
+                                        ob += 4;
                                         m &= m - 1;
                                 }
                         }

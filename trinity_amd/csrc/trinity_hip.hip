@@ -1061,7 +1061,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 const uint8_t *match_bytes = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_dstream : b->ix->d_index;
                 const uint32_t *match_off = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_blk_doff : b->ix->d_blk_off;
                 if (b->n_dense) {
-                        TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * 4)), dim3(DENSE_WG), dev->stream, match_bytes,
+                        TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * (2048 / DENSE_WG))), dim3(DENSE_WG), dev->stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
                                            b->d_ticket + 16, b->d_out, b->d_counts);
                         HIP_TRY(hipGetLastError());
