@@ -64,7 +64,10 @@ struct DenseShared {
         uint32_t lcur[16];
         uint32_t seg_lo[MAX_QTERMS];      // per query term: first block reaching the current window ...
         uint32_t seg_cnt[MAX_QTERMS + 1]; // ... and how many do (+ sentinel)
-        DevTerm seg_term[MAX_QTERMS];
+        DevTerm seg_term[MAX_QTERMS];     // the query's terms (staged once per task)
+        uint32_t seg_tt[MAX_QTERMS];      // ... and their qterms[] words (term id | QT_GROUP)
+        uint32_t seg_wlo[MAX_QTERMS];     // win[w], win[w + 1] of every indexed term for the current window
+        uint32_t seg_whi[MAX_QTERMS];
         uint32_t nslow;
 };
 constexpr uint32_t DENSE_SLOW_CAP = DENSE_WG / 4; // 16-byte entries in tbase[]
@@ -560,37 +563,65 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
         for (uint32_t i = tid; i < 2 * BM_STRIDE; i += WG)
                 sh.bm[i] = 0;
         __syncthreads();
+        // ---- the query's terms, staged in LDS once per task (every lane runs the same code: lanes >= nterms repeat the last term)
+        {
+                const uint32_t kk = min(tid, q.nterms - 1);
+                const uint32_t tt = qterms[q.term_base + kk];
+                sh.seg_tt[kk] = tt;
+                sh.seg_term[kk] = terms[tt & ~QT_GROUP];
+        }
+        __syncthreads();
         // number of terms in the lead group (it creates the candidates; the other groups test them)
         uint32_t nlead = 1;
-        while (nlead < q.nterms && !(qterms[q.term_base + nlead] & QT_GROUP))
+        while (nlead < q.nterms && !(uni(sh.seg_tt[nlead]) & QT_GROUP))
                 ++nlead;
         bool done = false; // uniform
         for (uint32_t w = task.tile_begin; w < task.tile_end && !done;) {
-                // ---- skip windows no lead-group list reaches: position the lead cursors at w, look at the first
-                //      document each may hold at or after it
-                uint32_t wnext = 0xffffffffu;
-                for (uint32_t k = 0; k < nlead; ++k) {
-                        const DevTerm t = terms[qterms[q.term_base + k] & ~QT_GROUP];
-                        const uint32_t *bl = blk_last + t.first_block;
-                        uint32_t cur;
-                        if (t.win_off != 0xffffffffu)
-                                cur = win[t.win_off + w]; // indexed list: first block with last >= w * SPAN_BITS
-                        else {
-                                cur = uni(sh.lcur[k]);
-                                if (cur < t.nblocks && bl[cur] < w * SPAN_BITS)
-                                        cur += wg_lower_bound<WG>(sh.scan, bl + cur, t.nblocks - cur, w * SPAN_BITS);
-                                __syncthreads();
-                                sh.lcur[k] = cur;
+                // ---- window index entries of every (indexed) term for window w, fetched side by side: one memory round trip
+                //      per window instead of one per term.  win[w] = first block with last >= w * SPAN_BITS.
+                for (;;) {
+                        {
+                                const uint32_t kk = min(tid, q.nterms - 1);
+                                const uint32_t wo = sh.seg_term[kk].win_off;
+                                const uint32_t at = wo != 0xffffffffu ? wo + w : 0u; // (win[] is never shorter than two entries)
+                                sh.seg_wlo[kk] = win[at];
+                                sh.seg_whi[kk] = win[at + 1];
                         }
-                        if (cur < t.nblocks) {
-                                const uint32_t first_possible = cur ? bl[cur - 1] + 1 : 1;
-                                wnext = min(wnext, max(w, first_possible / SPAN_BITS));
+                        __syncthreads();
+                        // skip windows no lead-group list reaches: look at the first document each may hold at or after w
+                        uint32_t wnext = 0xffffffffu;
+                        for (uint32_t k = 0; k < nlead; ++k) {
+                                const DevTerm t = sh.seg_term[k];
+                                const uint32_t *bl = blk_last + t.first_block;
+                                uint32_t cur;
+                                bool here = false; // the list surely holds a document of window w
+                                if (uni(t.win_off) != 0xffffffffu) {
+                                        cur = uni(sh.seg_wlo[k]);
+                                        here = cur != uni(sh.seg_whi[k]); // a block ends inside the window
+                                } else {
+                                        cur = uni(sh.lcur[k]);
+                                        if (cur < uni(t.nblocks) && bl[cur] < w * SPAN_BITS)
+                                                cur += wg_lower_bound<WG>(sh.scan, bl + cur, t.nblocks - cur, w * SPAN_BITS);
+                                        __syncthreads();
+                                        sh.lcur[k] = cur;
+                                }
+                                if (here)
+                                        wnext = w;
+                                else if (cur < uni(t.nblocks)) {
+                                        const uint32_t first_possible = cur ? bl[cur - 1] + 1 : 1;
+                                        wnext = min(wnext, max(w, first_possible / SPAN_BITS));
+                                }
                         }
+                        wnext = uni(wnext);
+                        __syncthreads(); // seg_wlo / seg_whi may be rewritten
+                        if (wnext == w || wnext >= task.tile_end) {
+                                w = wnext;
+                                break;
+                        }
+                        w = wnext; // the lead jumped ahead: fetch that window's entries
                 }
-                __syncthreads();
-                if (wnext >= task.tile_end)
+                if (w >= task.tile_end)
                         break; // the lead group holds nothing more in this task's range
-                w = wnext;
                 const uint32_t w0 = w * SPAN_BITS;
                 const uint32_t wlast = w0 + (SPAN_BITS - 1);
                 // ---- block range of every term in this window; a group none of whose lists reaches the window or beyond
@@ -598,8 +629,9 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                 uint32_t ngroups = 0, g1 = q.nterms, g2 = q.nterms; // first term of group 1 / group 2
                 bool galive = false;
                 for (uint32_t k = 0; k < q.nterms; ++k) {
-                        const uint32_t tt = qterms[q.term_base + k];
-                        const DevTerm t = terms[tt & ~QT_GROUP];
+                        const uint32_t tt = uni(sh.seg_tt[k]);
+                        const DevTerm t = sh.seg_term[k];
+                        const uint32_t nblocks = uni(t.nblocks);
                         const uint32_t *bl = blk_last + t.first_block;
                         if (tt & QT_GROUP) {
                                 if (k && !galive)
@@ -613,30 +645,29 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                         }
                         // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
                         uint32_t b_lo, b_hi;
-                        if (t.win_off != 0xffffffffu) {
-                                // indexed list: two scalar loads replace both directory searches (win[w + 1] is the first block
-                                // with last >= the next window's first docID; it may still hold documents of this window)
-                                b_lo = win[t.win_off + w];
-                                b_hi = min(win[t.win_off + w + 1], t.nblocks - 1);
+                        if (uni(t.win_off) != 0xffffffffu) {
+                                // indexed list: the two staged entries replace both directory searches (win[w + 1] is the first
+                                // block with last >= the next window's first docID; it may still hold documents of this window)
+                                b_lo = uni(sh.seg_wlo[k]);
+                                b_hi = min(uni(sh.seg_whi[k]), nblocks - 1);
                         } else {
                                 b_lo = uni(sh.lcur[k]);
-                                if (b_lo < t.nblocks && bl[b_lo] < w0)
-                                        b_lo += wg_lower_bound<WG>(sh.scan, bl + b_lo, t.nblocks - b_lo, w0);
+                                if (b_lo < nblocks && bl[b_lo] < w0)
+                                        b_lo += wg_lower_bound<WG>(sh.scan, bl + b_lo, nblocks - b_lo, w0);
                                 b_hi = b_lo;
-                                if (b_lo < t.nblocks) {
-                                        b_hi = b_lo + wg_lower_bound<WG>(sh.scan, bl + b_lo, t.nblocks - b_lo, wlast);
-                                        if (b_hi >= t.nblocks)
-                                                b_hi = t.nblocks - 1;
+                                if (b_lo < nblocks) {
+                                        b_hi = b_lo + wg_lower_bound<WG>(sh.scan, bl + b_lo, nblocks - b_lo, wlast);
+                                        if (b_hi >= nblocks)
+                                                b_hi = nblocks - 1;
                                 }
                                 __syncthreads(); // cursor reads done
-                                sh.lcur[k] = b_lo < t.nblocks ? b_hi : b_lo;
+                                sh.lcur[k] = b_lo < nblocks ? b_hi : b_lo;
                         }
-                        if (b_lo < t.nblocks)
+                        if (b_lo < nblocks)
                                 galive = true;
                         // uniform stores by every lane (see the control-flow note in k_and)
                         sh.seg_lo[k] = b_lo;
-                        sh.seg_cnt[k] = b_lo < t.nblocks ? b_hi - b_lo + 1 : 0;
-                        sh.seg_term[k] = t;
+                        sh.seg_cnt[k] = b_lo < nblocks ? b_hi - b_lo + 1 : 0;
                 }
                 sh.seg_cnt[q.nterms] = 0xffffffffu; // sentinel: the lane-to-term walk stops here
                 if (!galive)
