@@ -875,7 +875,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         uint64_t DENSE_MIN_POSTINGS = 512 * 1024;
         if (const char *e = getenv("TRINITY_DENSE_MIN"))
                 DENSE_MIN_POSTINGS = strtoull(e, nullptr, 10);
-        uint64_t DENSE_TASK_COST = TASK_COST;
+        uint64_t DENSE_TASK_COST = 2 * TASK_COST; // bitmap-window tasks stage their terms once: two windows of a head pair per task
         if (const char *e = getenv("TRINITY_DENSE_TASK_COST"))
                 DENSE_TASK_COST = strtoull(e, nullptr, 10);
         std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
