@@ -36,6 +36,9 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
 #endif
 constexpr uint32_t SPAN_BITS = 1u << 17; // docIDs per dense window
 constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
+constexpr uint32_t CELL_LOG2 = 10; // docID cells of the per-term block index (DevTerm::win_off)
+constexpr uint32_t CELL_DOCS = 1u << CELL_LOG2;
+constexpr uint32_t CELLS_PER_SPAN = SPAN_BITS / CELL_DOCS;
 // Window bitmap layout in LDS: logical word w lives at bm[w + (w >> 5)] — every row of 32 words is followed by one pad
 // word, so lanes whose blocks lie a small constant number of words apart do not pile onto one bank.  Bitmap B is bitmap A
 // shifted by BM_B_WORDS logical words, i.e. a lane selects it by adding BM_B_WORDS * 32 to its window-relative docID once
@@ -49,7 +52,6 @@ __device__ __forceinline__ uint32_t bm_pad(const uint32_t w) { return w + (w >> 
 struct AndShared {
         uint32_t cand[TILE_CANDS];
         uint32_t hit[TILE_BLOCKS]; // bit k of hit[r] <=> logical candidate r*32+k matched
-        uint32_t blkof[AND_WG + 1];
         uint32_t scan[8];
         uint32_t bcast[4];
         uint32_t lcur[16]; // per term: directory cursor, uniform across the workgroup
@@ -188,8 +190,8 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict_
 // Caller syncs before and after.
 template <int CODEC>
 __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                const uint32_t *__restrict__ blk_off, const DevTerm t, const uint32_t C, const uint32_t lcur_slot,
-                                const bool block_driven) {
+                                const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm t, const uint32_t C,
+                                const uint32_t lcur_slot, const bool block_driven) {
         const uint32_t tid = threadIdx.x;
         const uint32_t *bl = blk_last + t.first_block;
         const uint32_t *bo = blk_off + t.first_block;
@@ -256,9 +258,10 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                 }
         } else {
                 // candidate-driven galloping: each candidate finds its block in the directory; the first
-                // candidate of each run that maps to the same block decodes it and merges forward
-                sh.blkof[0] = 0xffffffffu;
-                __syncthreads();
+                // candidate of each run that maps to the same block decodes it and merges forward.  Waves run
+                // independently here (no workgroup barrier inside the loop): a run is recognised inside the wave by a
+                // shuffle, and a block that two waves both start on is simply merged twice (hit bits are idempotent).
+                uint32_t carry = 0xffffffffu; // block of the last candidate this wave looked at
                 uint32_t wcur = 0; // this wave's directory cursor: its candidates only move forward from round to round
                 for (uint32_t base = 0; base < C; base += AND_WG) {
                         TRACE(20, base, C);
@@ -269,7 +272,14 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                         // cooperative 64-ary searches; each lane then bisects only inside that (cache-resident) range
                         const uint32_t wbase = base + (tid & ~63u);
                         uint32_t rlo = 0, rhi = 0;
-                        if (wbase < C) { // wave-uniform
+                        if (t.win_off != 0xffffffffu) {
+                                // indexed list: the candidate's docID cell brackets its block with one independent load pair
+                                if (j < C) {
+                                        const uint32_t c = sh.cand[phys(j)] >> CELL_LOG2;
+                                        rlo = win[t.win_off + c];
+                                        rhi = win[t.win_off + c + 1];
+                                }
+                        } else if (wbase < C) { // wave-uniform
                                 const uint32_t nval = min(64u, C - wbase);
                                 const uint32_t klo = sh.cand[phys(wbase)], khi = sh.cand[phys(wbase + nval - 1)];
                                 rlo = wave_lower_bound(bl, wcur, t.nblocks, klo);
@@ -288,22 +298,14 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                 }
                                 bj = lo; // == nblocks: beyond the list
                         }
-                        sh.blkof[tid + 1] = bj;
-                        __syncthreads();
-                        const uint32_t prevb = sh.blkof[tid];
-                        __syncthreads();
-                        {
-                                // carry the last lane's block into the next round (slot 0), branch-free:
-                                // lanes of the last wave all store lane 63's value, other waves rewrite their own slot
-                                const uint32_t lastb = __shfl(bj, 63, 64);
-                                const bool lastwave = (tid >> 6) == (AND_WG / 64 - 1);
-                                sh.blkof[lastwave ? 0 : tid + 1] = lastwave ? lastb : bj;
-                        }
+                        uint32_t prevb = __shfl_up(bj, 1, 64);
+                        if ((tid & 63u) == 0)
+                                prevb = carry;
+                        carry = __shfl(bj, 63, 64);
                         if (j < C && bj < t.nblocks && bj != prevb) {
                                 const uint32_t prev = bj ? bl[bj - 1] : 0;
                                 merge_block<CODEC>(sh, index, t, bj, bo[bj], TRI_BLOCK_N(t, bj, index, bo[bj]), prev, bl[bj], j, cv, C);
                         }
-                        __syncthreads();
                 }
         }
 }
@@ -583,9 +585,9 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                         {
                                 const uint32_t kk = min(tid, q.nterms - 1);
                                 const uint32_t wo = sh.seg_term[kk].win_off;
-                                const uint32_t at = wo != 0xffffffffu ? wo + w : 0u; // (win[] is never shorter than two entries)
+                                const uint32_t at = wo != 0xffffffffu ? wo + w * CELLS_PER_SPAN : 0u; // (a win[] row covers one window more than the corpus)
                                 sh.seg_wlo[kk] = win[at];
-                                sh.seg_whi[kk] = win[at + 1];
+                                sh.seg_whi[kk] = win[at + CELLS_PER_SPAN];
                         }
                         __syncthreads();
                         // skip windows no lead-group list reaches: look at the first document each may hold at or after w
@@ -792,6 +794,8 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
         __shared__ AndShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
+        PROF_DECL;
+        PROF_START();
         for (;;) {
                 // next query: wave 0 draws the ticket.  All 64 lanes add 1 (the compiler folds that into ONE
                 // global atomic of +64 with a uniform operand — no lane-divergent branch at the loop head), so the
@@ -815,6 +819,7 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                 uint32_t produced = 0;
                 sh.lcur[tid & 15] = 0xffffffffu; // "not positioned yet"
                 const uint32_t tb_end = min(lead.nblocks, task.tile_end * TILE_BLOCKS);
+                PROF_LAP(10);
 
                 for (uint32_t tb = task.tile_begin * TILE_BLOCKS; tb < tb_end; tb += TILE_BLOCKS) {
                         const uint32_t nb = min((uint32_t)TILE_BLOCKS, lead.nblocks - tb);
@@ -836,6 +841,7 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                 sh.cand[row | ((n - 1 + tid) & 31u)] = last;
                         }
                         __syncthreads();
+                        PROF_LAP(11);
                         TRACE(2, slot, tb);
 
                         // ---- every other group filters the surviving candidates: a candidate survives a group when any
@@ -854,9 +860,10 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                 const bool bd = t.nblocks <= lead.documents;
 #endif
                                 TRACE(3, slot, (k << 16) | (bd ? 1 : 0));
-                                and_filter_tile<CODEC>(sh, index, blk_last, blk_off, t, C, k - 1, bd);
+                                and_filter_tile<CODEC>(sh, index, blk_last, blk_off, win, t, C, k - 1, bd);
                                 TRACE(4, slot, C);
                                 __syncthreads();
+                                PROF_LAP(bd ? 12 : 13);
                                 const bool lastterm = k + 1 == q.nterms;
                                 if (!lastterm && !(qterms[q.term_base + k + 1] & QT_GROUP))
                                         continue; // more terms of this OR group to come
@@ -906,11 +913,14 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                         }
                         produced += C;
                         __syncthreads();
+                        PROF_LAP(14);
                 }
                 if (wave == 0)
                         counts[tix] = produced; // scalar branch; the wave's lanes store one identical dword
                 TRACE(5, slot, produced);
         }
+        PROF_LAP(15);
+        PROF_FLUSH();
         TRACE(6, 0, 0);
 }
 

@@ -55,8 +55,9 @@ extern "C" int tri_abi_version(void) { return TRI_ABI_VERSION; }
 
 struct tri_dev {
         int device;
-        hipStream_t stream;
+        hipStream_t stream, stream2; // stream2: the candidate-tile kernel when the two matching kernels run side by side
         hipEvent_t ev0, ev1, ev_a, ev_b; // ev_a / ev_b: after k_and_dense / after k_and
+        hipEvent_t ev_fork, ev_join;
         int cus;
 };
 
@@ -72,7 +73,7 @@ struct tri_index {
         // (k_and_dense, k_and) read this stream instead.  Scoring and phrases keep reading the chunk itself.
         uint8_t *d_dstream = nullptr;
         uint32_t *d_blk_doff = nullptr;
-        uint32_t nwin = 0; // windows per win[] row (+1 sentinel column)
+        uint32_t nwin = 0; // cells per win[] row
         DevTerm *d_terms = nullptr;
         std::vector<DevTerm> terms;
         std::vector<uint32_t> h_blk_last; // host copy of the directory's last-docID column (planner: task output offsets)
@@ -151,6 +152,9 @@ extern "C" int tri_dev_open(int device, tri_dev **out) {
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&d->ev0));
         HIP_TRY(hipEventCreate(&d->ev1));
+        HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&d->ev_a));
         HIP_TRY(hipEventCreate(&d->ev_b));
         hipDeviceProp_t prop;
@@ -166,6 +170,9 @@ extern "C" void tri_dev_close(tri_dev *d) {
         hipSetDevice(d->device);
         hipEventDestroy(d->ev0);
         hipEventDestroy(d->ev1);
+        hipEventDestroy(d->ev_fork);
+        hipEventDestroy(d->ev_join);
+        hipStreamDestroy(d->stream2);
         hipEventDestroy(d->ev_a);
         hipEventDestroy(d->ev_b);
         hipStreamDestroy(d->stream);
@@ -472,9 +479,12 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 docb += db;
                 hitb += hb;
         }
-        // per-window block index of the longer lists (TASK_DENSE reads two entries instead of searching the directory)
+        // docID-cell index of the longer lists: win[row + c] = first block whose last docID >= c * CELL_DOCS.  With 288 GB of HBM
+        // a 4-byte entry per 1024 docIDs per indexed term is cheap (66 MB at the 10M-document config) and turns directory
+        // searches into one load pair: TASK_DENSE reads the entries of its window's ends (every SPAN_BITS / CELL_DOCS-th), a
+        // galloping candidate brackets its block to the handful of blocks that end inside its cell.
         const uint32_t max_doc = blk_last.empty() ? 0 : *std::max_element(blk_last.begin(), blk_last.end());
-        ix->nwin = max_doc / SPAN_BITS + 2;
+        ix->nwin = (max_doc / SPAN_BITS + 2) * (SPAN_BITS / CELL_DOCS) + 1;
         std::vector<uint32_t> win;
         for (size_t ti = 0; ti < nterms; ++ti) {
                 DevTerm &dt = ix->terms[ti];
@@ -484,8 +494,10 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 dt.win_off = (uint32_t)win.size();
                 const uint32_t *bl = &blk_last[dt.first_block];
                 uint32_t b = 0;
+                if ((uint64_t)win.size() + ix->nwin > 0xfffffff0ull)
+                        return fail(TRI_ERR_UNSUPPORTED, "cell index exceeds 2^32 entries");
                 for (uint32_t w = 0; w < ix->nwin; ++w) {
-                        const uint64_t key = (uint64_t)w * SPAN_BITS;
+                        const uint64_t key = (uint64_t)w * CELL_DOCS;
                         while (b < dt.nblocks && bl[b] < key)
                                 ++b;
                         win.push_back(b);
@@ -1060,18 +1072,38 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 // GOOGLE: matching reads the contiguous delta streams, not the chunks (see tri_index::d_dstream)
                 const uint8_t *match_bytes = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_dstream : b->ix->d_index;
                 const uint32_t *match_off = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_blk_doff : b->ix->d_blk_off;
+                uint32_t dense_wgs = 2048 / DENSE_WG, cand_wgs = 4; // workgroups per CU
+                bool overlap = false;
+                if (const char *e = getenv("TRINITY_OVERLAP")) { // "d,c": run both kernels side by side with d / c workgroups per CU
+                        unsigned d = 0, c = 0;
+                        if (sscanf(e, "%u,%u", &d, &c) == 2 && d && c && b->n_dense && b->n_cand) {
+                                overlap = true;
+                                dense_wgs = d;
+                                cand_wgs = c;
+                        }
+                }
+                hipStream_t cand_stream = dev->stream;
+                if (overlap) {
+                        HIP_TRY(hipEventRecord(dev->ev_fork, dev->stream));
+                        HIP_TRY(hipStreamWaitEvent(dev->stream2, dev->ev_fork, 0));
+                        cand_stream = dev->stream2;
+                }
                 if (b->n_dense) {
-                        TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * (2048 / DENSE_WG))), dim3(DENSE_WG), dev->stream, match_bytes,
+                        TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * dense_wgs)), dim3(DENSE_WG), dev->stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
                                            b->d_ticket + 16, b->d_out, b->d_counts);
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(dev->ev_a, dev->stream));
                 if (b->n_cand)
-                        TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * 4)), dim3(AND_WG), dev->stream, match_bytes,
+                        TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
                                            b->n_cand, b->d_ticket, b->d_out, b->d_counts);
                 HIP_TRY(hipGetLastError());
+                if (overlap) {
+                        HIP_TRY(hipEventRecord(dev->ev_join, dev->stream2));
+                        HIP_TRY(hipStreamWaitEvent(dev->stream, dev->ev_join, 0));
+                }
                 HIP_TRY(hipEventRecord(dev->ev_b, dev->stream));
                 if (!b->ptasks.empty()) {
                         // positional constraints: filter + compact the match segments of the queries that hold phrases
