@@ -1481,3 +1481,81 @@ uint64_t to_fnv1a_docs(const uint32_t *docs, size_t n) {
         }
         return h;
 }
+
+/* ------------------------------------------------------------------ timed multi-threaded batch (bench.py cpu_baseline) */
+/* One query per thread (exec_query is re-entrant per thread in the reference: exec.cpp:12 thread_local curRCTX; exec.h:132-154
+ * exec_query_par runs one std::async per source).  Threads draw programs from a shared cursor until the batch or the time
+ * budget is exhausted.  Results are counted and discarded. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+        const to_index *ix;
+        const uint32_t *progs;
+        uint32_t proglen, nq, flags;
+        double deadline;
+        uint64_t cursor, done, matches;
+        pthread_mutex_t mu;
+} mt_state;
+
+static double mt_now(void) {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *mt_worker(void *arg) {
+        mt_state *st = (mt_state *)arg;
+        uint64_t done = 0, matches = 0;
+        for (;;) {
+                if (mt_now() >= st->deadline)
+                        break;
+                const uint64_t i = __atomic_fetch_add(&st->cursor, 1, __ATOMIC_RELAXED);
+                if (i >= st->nq)
+                        break;
+                to_result r;
+                memset(&r, 0, sizeof r);
+                if (to_exec_query(st->ix, st->progs + i * st->proglen, st->proglen, st->flags, &r) == 0) {
+                        ++done;
+                        matches += r.n;
+                }
+                to_result_free(&r);
+        }
+        pthread_mutex_lock(&st->mu);
+        st->done += done;
+        st->matches += matches;
+        pthread_mutex_unlock(&st->mu);
+        return NULL;
+}
+
+/* nq programs of `proglen` tokens each, back to back in `progs`.  Returns the queries completed; *out_matches and
+ * *out_seconds (wall) are filled. */
+uint64_t to_exec_batch_mt(const to_index *ix, const uint32_t *progs, uint32_t proglen, uint32_t nq, uint32_t flags, uint32_t nthreads,
+                          double budget_seconds, uint64_t *out_matches, double *out_seconds) {
+        mt_state st;
+        memset(&st, 0, sizeof st);
+        st.ix = ix;
+        st.progs = progs;
+        st.proglen = proglen;
+        st.nq = nq;
+        st.flags = flags;
+        pthread_mutex_init(&st.mu, NULL);
+        if (!nthreads)
+                nthreads = 1;
+        pthread_t *th = (pthread_t *)xmalloc(sizeof(pthread_t) * nthreads);
+        const double t0 = mt_now();
+        st.deadline = t0 + budget_seconds;
+        uint32_t started = 0;
+        for (; started < nthreads; ++started)
+                if (pthread_create(&th[started], NULL, mt_worker, &st))
+                        break;
+        for (uint32_t i = 0; i < started; ++i)
+                pthread_join(th[i], NULL);
+        if (out_seconds)
+                *out_seconds = mt_now() - t0;
+        if (out_matches)
+                *out_matches = st.matches;
+        free(th);
+        pthread_mutex_destroy(&st.mu);
+        return st.done;
+}

@@ -150,6 +150,10 @@ void to_result_free(to_result *);
  * tie rule: score descending, docID ascending).  Returns min(n,k). */
 uint32_t to_topk(const to_result *, uint32_t k, uint32_t *docs, float *scores);
 
+/* bench.py cpu_baseline, all-cores leg: one query per thread from a shared cursor until the batch or the budget runs out */
+uint64_t to_exec_batch_mt(const to_index *, const uint32_t *progs, uint32_t proglen, uint32_t nq, uint32_t flags, uint32_t nthreads,
+                          double budget_seconds, uint64_t *out_matches, double *out_seconds);
+
 /* FNV-1a (64) over the little-endian docID stream — the fixture hash of SURVEY §8(c). */
 uint64_t to_fnv1a_docs(const uint32_t *docs, size_t n);
 

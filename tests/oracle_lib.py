@@ -215,6 +215,29 @@ class Index:
         lib().to_result_free(C.byref(r))
         return docs, scores
 
+    def exec_count(self, prog, flags):
+        """Run one postfix program and return only the number of matches (no copy: the multi-threaded CPU-baseline leg of
+        bench.py calls this from many threads; ctypes drops the GIL for the duration of the C call)."""
+        p = np.ascontiguousarray(prog, dtype=np.uint32)
+        r = ToResult()
+        rc = lib().to_exec_query(self.ptr, p.ctypes.data, p.size, flags, C.byref(r))
+        if rc != 0:
+            raise ValueError(f"to_exec_query rc={rc}")
+        n = int(r.n)
+        lib().to_result_free(C.byref(r))
+        return n
+
+    def exec_batch_mt(self, progs, flags, nthreads, budget_s):
+        """progs: [nq, proglen] u32.  One query per thread (C, pthreads) until the batch or the time budget runs out.
+        Returns (queries done, matches, wall seconds)."""
+        p = np.ascontiguousarray(progs, dtype=np.uint32)
+        m, sec = C.c_uint64(), C.c_double()
+        f = lib().to_exec_batch_mt
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+        n = f(self.ptr, p.ctypes.data, p.shape[1], p.shape[0], flags, nthreads, budget_s, C.byref(m), C.byref(sec))
+        return int(n), int(m.value), float(sec.value)
+
     def topk(self, docs, scores, k):
         r = ToResult()
         d = np.ascontiguousarray(docs, dtype=np.uint32)
