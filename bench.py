@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=16384, help="queries per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="SURVEY §8(d) query sets; cfg2 (default) is the configuration BASELINE.json's metric is quoted on, the others are "
+                         "extra measurements (whole-step roofline only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,14 +69,26 @@ def main():
 
     # ---- synthetic segment (identical on every rank) and this rank's query batch
     t0 = time.time()
-    seg = T.Segment(args.docs, args.vocab, 10, 42)
+    from trinity_amd import workloads as W
+
+    progs = None
+    wl_desc = None
+    codec = T.engine.CODEC_GOOGLE
+    if args.workload != "cfg2":
+        allp, wflags, wtopk, codec, wl_desc = W.build(args.workload, args.docs, args.vocab, 10, 42, args.queries * world)
+        progs = allp[rank::world][: args.queries]  # interleaved shard: same mix on every rank
+    seg = T.Segment(args.docs, args.vocab, 10, 42, codec=codec)
     build_s = time.time() - t0
     dev = T.Device(local_rank)
     ix = T.Index.from_segment(dev, seg)
     info = ix.info()
-    qall = T.gen_queries(args.vocab, 1337, args.queries * world, 2)
-    qs = TD.shard_rows(qall, rank, world, args.queries)  # interleaved shard: same cost distribution on every rank
-    batch = T.Batch.conjunctions(ix, qs, T.FLAG_DOCUMENTS_ONLY)
+    if progs is None:
+        qall = T.gen_queries(args.vocab, 1337, args.queries * world, 2)
+        qs = TD.shard_rows(qall, rank, world, args.queries)  # interleaved shard: same cost distribution on every rank
+        batch = T.Batch.conjunctions(ix, qs, T.FLAG_DOCUMENTS_ONLY)
+    else:
+        qs = None
+        batch = T.Batch(ix, progs, wflags, topk=wtopk)
 
     def barrier():
         if dist is not None:
@@ -127,7 +142,13 @@ def main():
         achieved = kalg[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
         k_ms = kernel_ms / steps
         alg = float(binfo["algorithmic_bytes"])
-        traffic = pmc_traffic(args, world)
+        traffic = pmc_traffic(args, world) if progs is None else None
+        if progs is not None:
+            # extra workloads launch more kernels (k_phrase, k_score, k_topk_merge): whole-step figures only
+            dom = "whole step"
+            kms = {dom: k_ms}
+            kalg = {dom: alg}
+            achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         out = {
             "metric": "queries/sec",
             "value": qps,
@@ -142,7 +163,7 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": "cfg2: batched 2-term AND, google_codec, DocumentsOnly, Zipf(1.0) 10M docs / 1M terms" if args.docs == 10_000_000 else f"2-term AND, google_codec, DocumentsOnly, {args.docs} docs / {args.vocab} terms",
+                "workload": (wl_desc + f", Zipf(1.0) {args.docs} docs / {args.vocab} terms") if wl_desc else ("cfg2: batched 2-term AND, google_codec, DocumentsOnly, Zipf(1.0) 10M docs / 1M terms" if args.docs == 10_000_000 else f"2-term AND, google_codec, DocumentsOnly, {args.docs} docs / {args.vocab} terms"),
                 "docs": args.docs,
                 "vocab": args.vocab,
                 "queries_per_gpu_per_step": args.queries,
@@ -162,14 +183,14 @@ def main():
                 "kernel": dom,
                 "kernel_ms": kms[dom],
                 "algorithmic_bytes_per_launch": kalg[dom],
-                "queries_per_launch": int(binfo["dense_queries"] if dom == "k_and_dense" else binfo["cand_queries"]),
+                "queries_per_launch": int(binfo["dense_queries"] if dom == "k_and_dense" else binfo["cand_queries"] if dom == "k_and" else args.queries),
                 "other_kernels": {k: {"kernel_ms": kms[k], "algorithmic_bytes_per_launch": kalg[k], "achieved": (kalg[k] / (kms[k] * 1e-3) / 1e9 if kms[k] > 0 else 0.0), "traffic": (traffic or {}).get(k)} for k in kms if k != dom},
                 "whole_step": {"kernel_ms": k_ms, "algorithmic_bytes": alg, "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else 0.0},
             },
             "segment_build_s": build_s,
         }
         if args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(seg, qs, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(seg, qs, args.cpu_seconds) if progs is None else cpu_baseline_programs(seg, progs, wflags, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
     batch.close()
@@ -192,6 +213,27 @@ def pmc_traffic(args, world):
     except Exception:
         pass
     return None
+
+
+def cpu_baseline_programs(seg, progs, flags, budget_s):
+    """Extra workloads: the CPU oracle, one thread, on the first programs of rank 0's batch until the budget is spent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    if seg.codec == 2:
+        ora = O.Index.generate(seg.D, seg.V, seg.slots, seg.seed, codec="lucene")
+    else:
+        ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
+    n = matches = 0
+    t0 = time.perf_counter()
+    for p in progs:
+        matches += ora.exec_count(p, flags)
+        n += 1
+        if time.perf_counter() - t0 > budget_s and n >= 16:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": f"first {n} programs of rank 0's batch ({matches} matches) in {dt:.1f}s, oracle single thread", "host_cpus": os.cpu_count()}
 
 
 def cpu_baseline(seg, qs, budget_s):

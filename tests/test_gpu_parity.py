@@ -483,3 +483,34 @@ def test_lucene_forced_dense_and_fixtures(T, dev, monkeypatch):
             checked += 1
         w.ix.close()
     assert checked >= 100
+
+
+# ------------------------------------------------------------------------------------------ SURVEY §8(d) workloads (bench.py --workload)
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
+def test_workload_matches_oracle(T, dev, name):
+    """The query sets bench.py times, at a size the oracle finishes in seconds: same programs, bit-exact docID sets
+    (scored sets: top-K equal, BM25 within 1e-5).  cfg4's document-sampled phrases must match somewhere."""
+    from trinity_amd import workloads as W
+
+    D, V = 30000, 3000
+    progs, flags, topk, codec, _ = W.build(name, D, V, 10, 42, 160)
+    w = World(T, dev, D, V, 10, 42, codec=codec)
+    if flags & T.FLAG_ACCUMULATED_SCORE:
+        d, s, c, counts = run_scored(w, progs, topk)
+        for i, p in enumerate(progs):
+            docs, scores = w.ora.exec(p, O.FLAG_ACCUM_SCORE)
+            assert int(counts[i]) == len(docs), i
+            td, ts = w.ora.topk(docs, scores, topk)
+            assert d[i, : len(td)].tolist() == td.tolist(), i
+            np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+    else:
+        sets, hashes, _ = run_docs_only(w, progs)
+        sampled_hits = 0
+        for i, (p, got, h) in enumerate(zip(progs, sets, hashes)):
+            want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+            assert np.array_equal(got, want), (name, i, p.tolist(), len(got), len(want))
+            assert int(h) == O.fnv1a_docs(want)
+            sampled_hits += len(want) > 0
+        if name == "cfg4":
+            assert sampled_hits >= len(progs) // 2  # every document-sampled phrase occurs in its document
+    w.ix.close()

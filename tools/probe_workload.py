@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Perf probe (GPU): run one SURVEY §8(d) workload and print step time (+ per-phase cycle shares on TRI_PROF builds).
+   WORKLOAD=cfg3 NQ=2048 [TRINITY_HIP_LIB=build/libtrinity_hip_prof.so] python tools/probe_workload.py"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("TRINITY_HIP_LIB"):
+    import trinity_amd.engine as E
+    E.LIB_HIP = os.path.abspath(os.environ["TRINITY_HIP_LIB"])
+import trinity_amd as T
+from trinity_amd import workloads as W
+import trinity_amd.engine as E
+
+name = os.environ.get("WORKLOAD", "cfg3")
+D, V, NQ = int(os.environ.get("DOCS", 10_000_000)), int(os.environ.get("VOCAB", 1_000_000)), int(os.environ.get("NQ", 2048))
+progs, flags, topk, codec, desc = W.build(name, D, V, 10, 42, NQ)
+if os.environ.get("CODEC"):
+    codec = int(os.environ["CODEC"])
+    desc += f" [codec forced to {codec}]"
+seg = T.Segment(D, V, 10, 42, codec=codec)
+dev = T.Device(0)
+ix = T.Index.from_segment(dev, seg)
+b = T.Batch(ix, progs, flags, topk=topk)
+best = 1e9
+for _ in range(3):
+    b.run(); b.sync(); best = min(best, b.info()["last_run_ms"])
+inf = b.info()
+L = E.hip_lib()
+if hasattr(L, "tri_debug_prof"):
+    buf = (C.c_uint64 * 32)(); L.tri_debug_prof(buf); v = list(buf)[:16]; tot = sum(v) or 1
+    print("  prof " + " ".join(f"p{i}={x / tot * 100:.1f}%" for i, x in enumerate(v) if x), f"(total {tot:.3e} cycles)")
+print(f"{desc}: {NQ} queries {best:.2f} ms  matches {inf['matches']:.3e}  alg {inf['algorithmic_bytes'] / best / 1e6:.1f} GB/s  {NQ / best * 1e3:.0f} q/s")

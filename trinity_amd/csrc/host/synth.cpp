@@ -163,6 +163,29 @@ void tri_synth_segment_stats(void *h, uint64_t *sumTermsDocs, uint64_t *sumTermH
         *totalTerms = s->totalTerms;
         *docsCnt = s->docsCnt;
 }
+// nq phrases of nterms terms each: even queries take the terms of nterms consecutive token slots of a random
+// document of the corpus (D, slots, corpus_seed) — such a phrase has at least one match —, odd queries take random Zipf terms.
+// Token (doc d, slot p) is draw number (d-1)*slots + (p-1) of the corpus stream, and splitmix64 is a counter-based generator,
+// so no corpus needs to be materialised.
+void tri_synth_phrase_queries(uint32_t D, uint32_t V, uint32_t slots, uint64_t corpus_seed, uint64_t seed, uint32_t nq, uint32_t nterms, uint32_t *out) {
+        Zipf z(V);
+        uint64_t st = seed;
+        if (nterms > slots)
+                nterms = slots;
+        for (uint32_t q = 0; q < nq; ++q) {
+                uint32_t *t = out + size_t(q) * nterms;
+                if ((q & 1u) == 0) {
+                        const uint32_t d = uint32_t(splitmix64(st) % D);                  // document d + 1
+                        const uint32_t p = uint32_t(splitmix64(st) % (slots - nterms + 1)); // first slot
+                        for (uint32_t i = 0; i < nterms; ++i) {
+                                uint64_t s = corpus_seed + (uint64_t(d) * slots + p + i) * 0x9e3779b97f4a7c15ull; // state before the draw
+                                t[i] = z.rank(splitmix64(s));
+                        }
+                } else
+                        for (uint32_t i = 0; i < nterms; ++i)
+                                t[i] = z.rank(splitmix64(st));
+        }
+}
 // nq queries x nterms distinct Zipf-sampled term ranks
 void tri_synth_queries(uint32_t V, uint64_t seed, uint32_t nq, uint32_t nterms, uint32_t *out) {
         Zipf z(V);

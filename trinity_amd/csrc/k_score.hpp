@@ -99,7 +99,7 @@ __device__ void topk_offer(TopK &tk, const uint32_t k, const bool valid, const d
 struct ScoreShared {
         uint32_t cand[SCORE_TILE];
         double score[SCORE_TILE];
-        uint32_t hit[SCORE_TILE / 32]; // per scoring term: which matches this term holds
+        uint16_t mptr[32][AND_WG]; // per lane (column): the tile indices of the matches its block coincides with
         uint32_t blkof[AND_WG + 1];
         uint32_t scan[8];
         uint32_t bcast[4];
@@ -124,6 +124,8 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
         __shared__ ScoreShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
+        PROF_DECL;
+        PROF_START();
         for (;;) {
                 if (wave == 0) {
                         const uint32_t old = atomicAdd(ticket, 1u);
@@ -150,79 +152,132 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                 sh.score[j] = (q.nphrases && pscore) ? pscore[task.out_off + tb + j] : 0.0;
                         }
                         __syncthreads();
+                        PROF_LAP(0);
                         for (uint32_t ti = 0; ti < q.nscore; ++ti) {
                                 const DevTerm t = terms[sterms[q.score_base + ti]];
                                 const double w = sweights[q.score_base + ti];
                                 const uint32_t *bl = blk_last + t.first_block;
                                 const uint32_t *bo = blk_off + t.first_block;
-                                sh.blkof[0] = 0xffffffffu;
-                                if (tid < SCORE_TILE / 32)
-                                        sh.hit[tid] = 0;
-                                __syncthreads();
-                                for (uint32_t base = 0; base < C; base += AND_WG) {
-                                        const uint32_t j = base + tid;
-                                        uint32_t bj = 0xffffffffu, cv = 0;
-                                        if (j < C) {
-                                                cv = sh.cand[j];
-                                                uint32_t lo = 0, hi = t.nblocks;
+                                // one block of the term against the matches from index j on (cv = match j, known to be <= the
+                                // block's last document).  Deltas: every document gallops forward through the tile's matches
+                                // (exponential probe + bisection in LDS — under an OR a sparse term's neighbours are thousands of
+                                // matches apart, a linear walk would visit them all) and remembers the index of the match it
+                                // coincides with; freqs: the i-th marked document scores the i-th remembered match.  A match is a
+                                // document of at most one block, so no two lanes touch the same score.
+                                auto score_block = [&](const uint32_t bj, const uint32_t j, uint32_t cv) {
+                                        const uint32_t prev = bj ? bl[bj - 1] : 0;
+                                        const uint32_t last = bl[bj];
+                                        const uint32_t off = bo[bj];
+                                        const uint32_t n = TRI_BLOCK_N(t, bj, index, off);
+                                        DeltaStream<CODEC> s;
+                                        s.init(index, t, bj, off);
+                                        uint32_t doc = prev, ptr = j, mask = 0, nm = 0;
+                                        for (uint32_t i = 0; i < n; ++i) {
+                                                doc = (i + 1 < n) ? doc + s.next() : last;
+                                                if (cv < doc) {
+                                                        uint32_t step = 1, lo = ptr + 1; // first index in (ptr, C] whose match >= doc
+                                                        while (lo + step <= C && sh.cand[lo + step - 1] < doc) {
+                                                                lo += step;
+                                                                step <<= 1;
+                                                        }
+                                                        uint32_t hi = min(lo + step - 1, C);
+                                                        while (lo < hi) {
+                                                                const uint32_t mid = (lo + hi) >> 1;
+                                                                if (sh.cand[mid] < doc)
+                                                                        lo = mid + 1;
+                                                                else
+                                                                        hi = mid;
+                                                        }
+                                                        ptr = lo;
+                                                        cv = ptr < C ? sh.cand[ptr] : 0xffffffffu;
+                                                }
+                                                if (cv == doc) {
+                                                        mask |= 1u << i;
+                                                        sh.mptr[nm++][tid] = (uint16_t)ptr;
+                                                }
+                                        }
+                                        PROF_LAP(9);
+                                        // freqs follow the n-1 deltas
+                                        FreqStream<CODEC> fs;
+                                        fs.init(index, t, bj, off, s);
+                                        nm = 0;
+                                        for (uint32_t i = 0; i < n; ++i) {
+                                                const uint32_t f = fs.next();
+                                                if ((mask >> i) & 1u)
+                                                        sh.score[sh.mptr[nm++][tid]] += (double)bm25_term(w, f);
+                                        }
+                                        PROF_LAP(10);
+                                };
+                                // the term's blocks that can hold a match of this tile
+                                const uint32_t cmin = sh.cand[0], cmax = sh.cand[C - 1];
+                                const uint32_t b0 = wg_lower_bound<AND_WG>(sh.scan, bl, t.nblocks, cmin);
+                                uint32_t b1 = b0;
+                                if (b0 < t.nblocks) {
+                                        b1 = b0 + wg_lower_bound<AND_WG>(sh.scan, bl + b0, t.nblocks - b0, cmax);
+                                        if (b1 >= t.nblocks)
+                                                b1 = t.nblocks - 1;
+                                }
+                                __syncthreads(); // searches done
+                                PROF_LAP(1);
+                                if (b0 < t.nblocks && b1 - b0 + 1 <= C) {
+                                        // block-driven (dense results — unions of head terms, window-sized conjunctions): one lane per
+                                        // block of the term in range, a binary search of the tile's matches in LDS for the first one
+                                        // the block can hold.  (Match-driven, 256 consecutive matches of a dense result map to a
+                                        // handful of blocks and leave most lanes idle.)
+                                        for (uint32_t b = b0 + tid; b <= b1; b += AND_WG) {
+                                                const uint32_t prev = b ? bl[b - 1] : 0;
+                                                uint32_t lo = 0, hi = C;
                                                 while (lo < hi) {
                                                         const uint32_t mid = (lo + hi) >> 1;
-                                                        if (bl[mid] < cv)
+                                                        if (sh.cand[mid] <= prev)
                                                                 lo = mid + 1;
                                                         else
                                                                 hi = mid;
                                                 }
-                                                bj = lo;
+                                                PROF_LAP(8);
+                                                if (lo < C && sh.cand[lo] <= bl[b])
+                                                        score_block(b, lo, sh.cand[lo]);
                                         }
-                                        sh.blkof[tid + 1] = bj;
+                                        PROF_LAP(2);
                                         __syncthreads();
-                                        const uint32_t prevb = sh.blkof[tid];
+                                        PROF_LAP(3);
+                                } else if (b0 < t.nblocks) {
+                                        // match-driven: every match finds its block inside [b0, b1]; the first match of a block run
+                                        // decodes the block and merges forward
+                                        sh.blkof[0] = 0xffffffffu;
                                         __syncthreads();
-                                        {
-                                                const uint32_t lastb = __shfl(bj, 63, 64);
-                                                const bool lastwave = (tid >> 6) == (AND_WG / 64 - 1);
-                                                sh.blkof[lastwave ? 0 : tid + 1] = lastwave ? lastb : bj;
-                                        }
-                                        if (j < C && bj < t.nblocks && bj != prevb) {
-                                                const uint32_t prev = bj ? bl[bj - 1] : 0;
-                                                const uint32_t last = bl[bj];
-                                                const uint32_t off = bo[bj];
-                                                const uint32_t n = TRI_BLOCK_N(t, bj, index, off);
-                                                DeltaStream<CODEC> s;
-                                                s.init(index, t, bj, off);
-                                                // deltas: merge the block's documents against the matches from j on; remember
-                                                // the block positions (mask) and the matches (hit bits) that coincide.  Under an
-                                                // OR a match need not be a document of this list.
-                                                uint32_t doc = prev, ptr = j, mask = 0;
-                                                for (uint32_t i = 0; i < n; ++i) {
-                                                        doc = (i + 1 < n) ? doc + s.next() : last;
-                                                        while (cv < doc) {
-                                                                ++ptr;
-                                                                cv = ptr < C ? sh.cand[ptr] : 0xffffffffu;
+                                        for (uint32_t base = 0; base < C; base += AND_WG) {
+                                                const uint32_t j = base + tid;
+                                                uint32_t bj = 0xffffffffu, cv = 0;
+                                                if (j < C) {
+                                                        cv = sh.cand[j];
+                                                        uint32_t lo = b0, hi = b1 + 1;
+                                                        while (lo < hi) {
+                                                                const uint32_t mid = (lo + hi) >> 1;
+                                                                if (bl[mid] < cv)
+                                                                        lo = mid + 1;
+                                                                else
+                                                                        hi = mid;
                                                         }
-                                                        if (cv == doc) {
-                                                                mask |= 1u << i;
-                                                                atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
-                                                        }
+                                                        bj = lo;
                                                 }
-                                                // freqs follow the n-1 deltas; the i-th marked position belongs to the i-th
-                                                // marked match (both ascending; only this lane marks matches in its block's range)
-                                                ptr = j;
-                                                FreqStream<CODEC> fs;
-                                                fs.init(index, t, bj, off, s);
-                                                for (uint32_t i = 0; i < n; ++i) {
-                                                        const uint32_t f = fs.next();
-                                                        if ((mask >> i) & 1u) {
-                                                                while (!((sh.hit[ptr >> 5] >> (ptr & 31)) & 1u))
-                                                                        ++ptr;
-                                                                sh.score[ptr] += (double)bm25_term(w, f);
-                                                                ++ptr;
-                                                        }
+                                                sh.blkof[tid + 1] = bj;
+                                                __syncthreads();
+                                                const uint32_t prevb = sh.blkof[tid];
+                                                __syncthreads();
+                                                {
+                                                        const uint32_t lastb = __shfl(bj, 63, 64);
+                                                        const bool lastwave = (tid >> 6) == (AND_WG / 64 - 1);
+                                                        sh.blkof[lastwave ? 0 : tid + 1] = lastwave ? lastb : bj;
                                                 }
+                                                if (j < C && bj < t.nblocks && bj != prevb)
+                                                        score_block(bj, j, cv);
+                                                __syncthreads();
                                         }
-                                        __syncthreads();
+                                        PROF_LAP(4);
                                 }
                         }
+                        PROF_LAP(5);
                         if (all_scores) // full score stream: what consider(id, score) receives for every match
                                 for (uint32_t j = tid; j < C; j += AND_WG)
                                         all_scores[task.out_off + tb + j] = sh.score[j];
@@ -234,6 +289,7 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                 }
                         }
                         __syncthreads();
+                        PROF_LAP(6);
                 }
                 if (k) {
                         topk_prune(sh.tk, k, sh.scan);
@@ -246,7 +302,9 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                 part_counts[tix] = n;
                 }
                 __syncthreads();
+                PROF_LAP(7);
         }
+        PROF_FLUSH();
 }
 
 // one workgroup per query: stream the tasks' partial lists through the same top-K structure

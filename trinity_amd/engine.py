@@ -143,6 +143,16 @@ def gen_queries(V, seed, nq, nterms):
     return out
 
 
+def gen_phrase_queries(D, V, slots, corpus_seed, seed, nq, nterms):
+    """cfg4 phrases: even rows are consecutive tokens of a random document (>= 1 match), odd rows random Zipf terms."""
+    out = np.zeros((nq, nterms), dtype=np.uint32)
+    L = host_lib()
+    L.tri_synth_phrase_queries.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.tri_synth_phrase_queries.restype = None
+    L.tri_synth_phrase_queries(D, V, slots, corpus_seed, seed, nq, nterms, out.ctypes.data)
+    return out
+
+
 class Segment:
     """A synthetic GOOGLE-codec segment built on the host (csrc/host/synth.cpp): raw `index` bytes + term table."""
 

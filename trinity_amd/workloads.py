@@ -1,0 +1,72 @@
+"""Query workloads of SURVEY.md §8(d) as postfix programs (include/trinity_hip.h tri_query), shared by bench.py and the tests.
+
+cfg2  batched `A B`, DocumentsOnly
+cfg3  5-term mixed, equal parts `A B (C|D|E)`, `(A|B) (C|D) E`, `A B C D E`, `A|B|C|D|E`; BM25 top-100
+cfg4  phrases `"A B"`, `"A B C"`: half sampled from consecutive slots of a random document, half random terms
+cfg5  mixed batch = 50 % cfg2 / 30 % cfg3 / 10 % pure OR / 10 % cfg4
+
+Terms are Zipf ranks from the segment's own distribution (query seed 1337, distinct within a query)."""
+import numpy as np
+
+from . import engine as E
+
+T, A, O, P = E.OP_TERM, E.OP_AND, E.OP_OR, E.OP_PHRASE
+
+
+def _t(x):
+    return E.tok(T, int(x))
+
+
+def and2(rows):
+    return [np.array([_t(a), _t(b), E.tok(A, 2)], dtype=np.uint32) for a, b in rows]
+
+
+def mixed5(rows):
+    out = []
+    for i, (a, b, c, d, e) in enumerate(rows):
+        k = i & 3
+        if k == 0:  # A B (C|D|E)
+            p = [_t(a), _t(b), _t(c), _t(d), _t(e), E.tok(O, 3), E.tok(A, 3)]
+        elif k == 1:  # (A|B) (C|D) E
+            p = [_t(a), _t(b), E.tok(O, 2), _t(c), _t(d), E.tok(O, 2), _t(e), E.tok(A, 3)]
+        elif k == 2:  # A B C D E
+            p = [_t(a), _t(b), _t(c), _t(d), _t(e), E.tok(A, 5)]
+        else:  # A|B|C|D|E
+            p = [_t(a), _t(b), _t(c), _t(d), _t(e), E.tok(O, 5)]
+        out.append(np.array(p, dtype=np.uint32))
+    return out
+
+
+def or5(rows):
+    return [np.array([_t(x) for x in r] + [E.tok(O, len(r))], dtype=np.uint32) for r in rows]
+
+
+def phrases(rows):
+    return [np.array([_t(x) for x in r] + [E.tok(P, len(r))], dtype=np.uint32) for r in rows]
+
+
+def _dedup(rows):
+    """A phrase sampled from a document may repeat a term; that is a legal phrase, keep it."""
+    return rows
+
+
+def build(name, D, V, slots, corpus_seed, nq, seed=1337):
+    """Returns (programs, flags, topk, codec, description)."""
+    if name == "cfg2":
+        return and2(E.gen_queries(V, seed, nq, 2)), E.FLAG_DOCUMENTS_ONLY, 0, E.CODEC_GOOGLE, "cfg2: batched 2-term AND, google_codec, DocumentsOnly"
+    if name == "cfg3":
+        return mixed5(E.gen_queries(V, seed, nq, 5)), E.FLAG_ACCUMULATED_SCORE, 100, E.CODEC_LUCENE, "cfg3: 5-term mixed AND/OR, lucene_codec (PFOR128), BM25 top-100"
+    if name == "cfg4":
+        h = nq // 2
+        progs = phrases(E.gen_phrase_queries(D, V, slots, corpus_seed, seed, h, 2)) + phrases(E.gen_phrase_queries(D, V, slots, corpus_seed, seed + 1, nq - h, 3))
+        return progs, E.FLAG_DOCUMENTS_ONLY, 0, E.CODEC_GOOGLE, 'cfg4: phrases "A B" / "A B C", google_codec, DocumentsOnly'
+    if name == "cfg5":
+        n2, n3, no = nq // 2, (nq * 3) // 10, nq // 10
+        n4 = nq - n2 - n3 - no
+        progs = and2(E.gen_queries(V, seed, n2, 2)) + mixed5(E.gen_queries(V, seed + 1, n3, 5)) + or5(E.gen_queries(V, seed + 2, no, 5))
+        h = n4 // 2
+        progs += phrases(E.gen_phrase_queries(D, V, slots, corpus_seed, seed + 3, h, 2)) + phrases(E.gen_phrase_queries(D, V, slots, corpus_seed, seed + 4, n4 - h, 3))
+        # interleave the classes so that any contiguous shard of the batch has the same mix
+        order = np.random.default_rng(seed).permutation(len(progs))
+        return [progs[i] for i in order], E.FLAG_DOCUMENTS_ONLY, 0, E.CODEC_GOOGLE, "cfg5: mixed batch 50% 2-term AND / 30% 5-term mixed / 10% 5-way OR / 10% phrases, google_codec, DocumentsOnly"
+    raise ValueError(f"unknown workload {name}")
