@@ -725,6 +725,24 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                         PROF_LAP(6);
                         // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
                         // (both bitmaps are left zeroed for the next window as they are read)
+                        if (uni(total) >= SPAN_BITS / 8) {
+                                // dense result (a union of head terms): one lane per BIT.  Each wave walks its own 512 words, 64 bits at
+                                // a time: ballot, rank by mbcnt, one coalesced store per step.  (Lane-per-word stores of a dense window
+                                // hit 64 different cache lines per instruction.)
+                                const uint32_t lane = tid & 63u, wv = tid >> 6;
+                                uint32_t o = produced + sh.tbase[wv * 64]; // matches before this wave's first word
+                                for (uint32_t c = 0; c < SPAN_WORDS / (WG / 64) / 2; ++c) {
+                                        const uint32_t wi = wv * (SPAN_WORDS / (WG / 64)) + 2 * c + (lane >> 5);
+                                        const bool bit = (fin[bm_pad(wi)] >> (lane & 31u)) & 1u;
+                                        const uint64_t m = __ballot(bit);
+                                        if (bit)
+                                                qout[o + __popcll(m & ((1ull << lane) - 1ull))] = w0 + wi * 32 + (lane & 31u);
+                                        o += (uint32_t)__popcll(m);
+                                }
+                                __syncthreads();
+                                for (uint32_t i = tid; i < 2 * BM_STRIDE; i += WG)
+                                        sh.bm[i] = 0;
+                        } else
                         for (uint32_t wi = tid; wi < SPAN_WORDS; wi += WG) {
                                 const uint32_t pw = bm_pad(wi);
                                 uint32_t m = fin[pw];
