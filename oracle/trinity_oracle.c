@@ -1135,6 +1135,48 @@ static uint16_t ctx_term_id(to_ctx *c, uint32_t term) {
         return c->nTermIDs;
 }
 
+/* ================================================================== Filter (logicalnot) */
+typedef struct { /* docset_iterators.h:147-172 */
+        to_iter it;
+        to_iter *req, *filter;
+} to_filter;
+
+/* docset_iterators.cpp:652-659 */
+static int filter_matches(to_filter *f, uint32_t id) {
+        uint32_t excl = f->filter->cur;
+        if (excl < id)
+                excl = f->filter->advance(f->filter, id);
+        return excl != id;
+}
+
+/* docset_iterators.cpp:661-668 */
+static uint32_t filter_next(to_iter *self) {
+        to_filter *f = (to_filter *)self;
+        for (uint32_t id = f->req->next(f->req);; id = f->req->next(f->req)) {
+                if (id == TO_DOCIDS_END)
+                        return f->it.cur = TO_DOCIDS_END;
+                else if (filter_matches(f, id))
+                        return f->it.cur = id;
+        }
+}
+
+/* docset_iterators.cpp:670-677 */
+static uint32_t filter_advance(to_iter *self, uint32_t target) {
+        to_filter *f = (to_filter *)self;
+        for (uint32_t id = f->req->advance(f->req, target);; id = f->req->next(f->req)) {
+                if (id == TO_DOCIDS_END)
+                        return f->it.cur = TO_DOCIDS_END;
+                else if (filter_matches(f, id))
+                        return f->it.cur = id;
+        }
+}
+
+/* docset_iterators_scorers.cpp:59-73: the score of a Filter is the score of what it requires */
+static double filter_score(to_iter *self) {
+        to_filter *f = (to_filter *)self;
+        return f->req->score(f->req);
+}
+
 typedef struct pnode {
         uint32_t op, term;
         struct pnode **kids;
@@ -1216,6 +1258,20 @@ static pnode *parse_prog(to_ctx *c, const uint32_t *prog, uint32_t len) {
                         n->empty = n->nkids == 0;
                         for (uint32_t j = 0; j < n->nkids; ++j)
                                 n->cost += n->kids[j]->cost;
+                } else if (op == TO_OP_NOT) {
+                        if (arg != 2)
+                                return NULL;
+                        /* exec.cpp:55-60: cost of a logicalnot is its lhs'; an excluded operand that can never match leaves
+                         * the required one alone (compilation_ctx.cpp: [a NOT <constfalse>] => a) */
+                        if (kids[1]->empty) {
+                                sp -= arg;
+                                stack[sp++] = kids[0];
+                                continue;
+                        }
+                        n->kids[n->nkids++] = kids[0];
+                        n->kids[n->nkids++] = kids[1];
+                        n->empty = kids[0]->empty;
+                        n->cost = kids[0]->cost;
                 } else
                         return NULL;
                 sp -= arg;
@@ -1267,6 +1323,17 @@ static to_iter *build_iter(to_ctx *c, const pnode *n) {
                         for (uint32_t i = 0; i < n->nkids; ++i)
                                 cj->c.its[i] = build_iter(c, n->kids[i]);
                         return &cj->c.it;
+                }
+                case TO_OP_NOT: { /* exec.cpp:424-427 */
+                        to_filter *f = (to_filter *)ctx_own(c, xcalloc(1, sizeof *f));
+                        f->it.type = IT_FILTER;
+                        f->it.next = filter_next;
+                        f->it.advance = filter_advance;
+                        f->it.score = filter_score;
+                        f->it.cost = n->cost;
+                        f->req = build_iter(c, n->kids[0]);
+                        f->filter = build_iter(c, n->kids[1]);
+                        return &f->it;
                 }
                 case TO_OP_OR: {
                         if (n->nkids == 1)

@@ -38,6 +38,7 @@ extern "C" {
 #define TO_OP_AND 1u    /* operand = number of children (>= 2) */
 #define TO_OP_OR 2u     /* operand = number of children (>= 2) */
 #define TO_OP_PHRASE 3u /* operand = number of terms; the n preceding tokens must be TERMs */
+#define TO_OP_NOT 4u    /* operand = 2: the two preceding sub-programs are (required, excluded); exec.cpp:424-427 logicalnot */
 #define TO_TOK(op, arg) (((uint32_t)(op) << 28) | ((uint32_t)(arg)&0x0fffffffu))
 #define TO_TOK_OP(t) ((t) >> 28)
 #define TO_TOK_ARG(t) ((t)&0x0fffffffu)

@@ -33,6 +33,16 @@ TEMPLATES = [
     '"t{a} t{b}"',
     '"t{a} t{b} t{c}"',
     '"t{a} t{b}" t{c}',
+    # logicalnot -> DocsSetIterators::Filter / FilteredDocsSetSpan (exec.cpp:424-427, 488-501)
+    "t{a} NOT t{b}",
+    "t{a} t{b} NOT t{c}",
+    # (a root-level `(x OR y) NOT z` is left out on purpose: when cost(z) <= cost(x OR y) the reference runs it as
+    #  FilteredDocsSetSpan over DocsSetSpanForDisjunctions, whose process() ignores `min` (docset_spans.cpp:98-110), so the
+    #  excluded documents are emitted anyway — 1902 instead of 1054 documents for `(t0 OR t1) NOT t2` on the tiny corpus.
+    #  The same query under an AND takes the iterator path and is exact.)
+    "(t{a} OR t{b}) t{d} NOT t{c}",
+    "t{a} NOT (t{b} OR t{c})",
+    "t{a} NOT (t{b} t{c})",
 ]
 
 

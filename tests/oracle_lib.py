@@ -17,7 +17,7 @@ REF_DRIVER = os.path.join(ORACLE_DIR, "_ref", "ref_driver")
 DOCIDS_END = 0xFFFFFFFF
 FLAG_DOCUMENTS_ONLY = 1
 FLAG_ACCUM_SCORE = 2
-OP_TERM, OP_AND, OP_OR, OP_PHRASE = 0, 1, 2, 3
+OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT = 0, 1, 2, 3, 4
 
 
 def tok(op, arg):
@@ -282,7 +282,7 @@ class PLI:
 
 # ---- tiny query-text -> postfix program compiler for the query templates of SURVEY §8(d) ------------
 def parse_query(text):
-    """Supports: terms tN, juxtaposition = AND, OR, parentheses, "phrases".  OR binds looser than AND
+    """Supports: terms tN, juxtaposition = AND, OR, NOT, parentheses, "phrases".  OR binds looser than AND
     (Trinity: queries.h operators; `a b OR c` is not used by the fixtures to avoid precedence ambiguity)."""
     toks = []
     i = 0
@@ -302,7 +302,7 @@ def parse_query(text):
             while j < len(text) and not text[j].isspace() and text[j] not in '()"':
                 j += 1
             w = text[i:j]
-            toks.append("OR" if w == "OR" else ("TERM", int(w[1:])))
+            toks.append(w if w in ("OR", "NOT") else ("TERM", int(w[1:])))
             i = j
     pos = [0]
 
@@ -327,17 +327,25 @@ def parse_query(text):
 
     def expr_and():
         parts = [primary()]
-        while peek() is not None and peek() not in (")", "OR"):
+        while peek() is not None and peek() not in (")", "OR", "NOT"):
             parts.append(primary())
         if len(parts) == 1:
             return parts[0]
         return sum(parts, []) + [tok(OP_AND, len(parts))]
 
+    def expr_not():
+        # `x y NOT z` == (x y) NOT z, left-associative (what Trinity's parser produced for the fixtures)
+        r = expr_and()
+        while peek() == "NOT":
+            pos[0] += 1
+            r = r + expr_and() + [tok(OP_NOT, 2)]
+        return r
+
     def expr_or():
-        parts = [expr_and()]
+        parts = [expr_not()]
         while peek() == "OR":
             pos[0] += 1
-            parts.append(expr_and())
+            parts.append(expr_not())
         if len(parts) == 1:
             return parts[0]
         return sum(parts, []) + [tok(OP_OR, len(parts))]
