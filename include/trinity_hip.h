@@ -46,6 +46,8 @@ extern "C" {
 #define TRI_OP_AND 1u    /* arg = #children   (DocsSetIterators::Conjuction[AllPLI])              */
 #define TRI_OP_OR 2u     /* arg = #children   (DocsSetIterators::Disjunction[AllPLI] / union span) */
 #define TRI_OP_PHRASE 3u /* arg = #terms, the preceding arg tokens are TERMs (DocsSetIterators::Phrase) */
+#define TRI_OP_NOT 4u    /* operand = 2: the two preceding sub-programs are (required, excluded) — exec.cpp:424-427 logicalnot -> DocsSetIterators::Filter.
+                            Lowered: NOT at the root or under AND, excluded side = a term or an OR of terms */
 #define TRI_TOK(op, arg) (((uint32_t)(op) << 28) | ((uint32_t)(arg)&0x0fffffffu))
 
 typedef struct tri_dev tri_dev;

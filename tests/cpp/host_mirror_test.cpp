@@ -88,6 +88,12 @@ int main(int argc, char **argv) {
                         exec_query(src.conjunction({src.phrase({"t0", "t1"}), src.term("t2")}), &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
                         show("phrase_scored", c);
                 }
+                { // t3 t5 NOT (t1 OR t2): DocsSetIterators::Filter over a conjunction, scored (the excluded side does not score)
+                        Collect c;
+                        auto q = src.filter(src.conjunction({src.term("t3"), src.term("t5")}), src.disjunction({src.term("t1"), src.term("t2")}));
+                        exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("not_scored", c);
+                }
                 { // unknown term => no documents
                         Collect c;
                         exec_query(src.conjunction({src.term("t0"), src.term("nosuchterm")}), &src, &c, nullptr, unsigned(ExecFlags::DocumentsOnly));

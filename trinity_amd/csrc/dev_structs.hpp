@@ -26,6 +26,10 @@ constexpr uint32_t WIN_MIN_BLOCKS = 128;
 // group by group, cheapest group first (exec.cpp:35-110 cost model); bit 31 marks the first term of a group.
 // Root OR of terms == a single group.  (Conjuction / DisjunctionAllPLI semantics, docset_iterators.cpp:226-405.)
 constexpr uint32_t QT_GROUP = 0x80000000u;
+// logicalnot (DocsSetIterators::Filter, docset_iterators.cpp:652-677): the documents of the excluded terms are removed from the
+// conjunction.  The excluded terms form ONE group, always the last of the query; QT_NOT marks its first term.
+constexpr uint32_t QT_NOT = 0x40000000u;
+constexpr uint32_t QT_TERM = 0x3fffffffu; // the term id inside a qterms[] word
 constexpr uint32_t MAX_QTERMS = 16;
 struct DevQuery {
         uint32_t nterms;    // total terms over all groups (<= MAX_QTERMS)

@@ -104,7 +104,7 @@ namespace trinity_amd {
 
         // ------------------------------------------------------------------ iterators (plan nodes + cursors)
         namespace DocsSetIterators {
-                enum class Type : uint8_t { PostingsListIterator = 0, Disjunction = 4, DisjunctionAllPLI, Phrase, Conjuction, ConjuctionAllPLI }; // docset_iterators_base.h:10-23
+                enum class Type : uint8_t { PostingsListIterator = 0, Filter = 2, Disjunction = 4, DisjunctionAllPLI, Phrase, Conjuction, ConjuctionAllPLI }; // docset_iterators_base.h:10-23
 
                 struct Iterator : public relevant_document_provider { // docset_iterators_base.h:45-96
                         struct {
@@ -255,6 +255,18 @@ namespace trinity_amd {
                                 w.push_back(0.0);
                         }
                 };
+                struct Filter final : public Iterator { // docset_iterators.h:147-172: documents of req that filter does not hold
+                        Iterator *const req, *const filter;
+                        Filter(Iterator *const r, Iterator *const f)
+                            : Iterator{Type::Filter, r->isrc}, req{r}, filter{f} {}
+                        uint64_t cost() const override { return req->cost(); } // docset_iterators.cpp:10-64
+                        void lower(std::vector<uint32_t> &prog, std::vector<double> &w, Similarity::IndexSourceTermsScorer *scorer) const override {
+                                req->lower(prog, w, scorer);
+                                filter->lower(prog, w, nullptr); // the excluded side is never scored (docset_iterators_scorers.cpp:59-73)
+                                prog.push_back(TRI_TOK(TRI_OP_NOT, 2));
+                                w.push_back(0.0);
+                        }
+                };
                 struct Phrase final : public Iterator { // docset_iterators.h:364-402
                         std::vector<Codecs::PostingsListIterator *> its;
                         Phrase(Codecs::PostingsListIterator **iterators, uint16_t cnt)
@@ -379,6 +391,7 @@ namespace trinity_amd {
                 }
                 DocsSetIterators::Iterator *conjunction(std::vector<DocsSetIterators::Iterator *> its) { return reg<DocsSetIterators::Conjuction>(its.data(), uint16_t(its.size())); }
                 DocsSetIterators::Iterator *disjunction(std::vector<DocsSetIterators::Iterator *> its) { return reg<DocsSetIterators::Disjunction>(its.data(), uint16_t(its.size())); }
+                DocsSetIterators::Iterator *filter(DocsSetIterators::Iterator *req, DocsSetIterators::Iterator *excl) { return reg<DocsSetIterators::Filter>(req, excl); } // exec.cpp:424-427
                 DocsSetIterators::Iterator *phrase(const std::vector<std::string> &terms) {
                         std::vector<Codecs::PostingsListIterator *> its;
                         for (const auto &t : terms)

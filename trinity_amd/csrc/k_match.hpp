@@ -570,7 +570,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                 const uint32_t kk = min(tid, q.nterms - 1);
                 const uint32_t tt = qterms[q.term_base + kk];
                 sh.seg_tt[kk] = tt;
-                sh.seg_term[kk] = terms[tt & ~QT_GROUP];
+                sh.seg_term[kk] = terms[tt & QT_TERM];
         }
         __syncthreads();
         // number of terms in the lead group (it creates the candidates; the other groups test them)
@@ -629,7 +629,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                 // ---- block range of every term in this window; a group none of whose lists reaches the window or beyond
                 //      ends the task (an exhausted conjunct: no further match anywhere)
                 uint32_t ngroups = 0, g1 = q.nterms, g2 = q.nterms; // first term of group 1 / group 2
-                bool galive = false;
+                bool galive = false, neg = false;
                 for (uint32_t k = 0; k < q.nterms; ++k) {
                         const uint32_t tt = uni(sh.seg_tt[k]);
                         const DevTerm t = sh.seg_term[k];
@@ -644,6 +644,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                                         g2 = k;
                                 ++ngroups;
                                 galive = false;
+                                neg = tt & QT_NOT; // the excluded group (always last): exhausted or not, it ends nothing
                         }
                         // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
                         uint32_t b_lo, b_hi;
@@ -672,7 +673,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                         sh.seg_cnt[k] = b_lo < nblocks ? b_hi - b_lo + 1 : 0;
                 }
                 sh.seg_cnt[q.nterms] = 0xffffffffu; // sentinel: the lane-to-term walk stops here
-                if (!galive)
+                if (!galive && !neg)
                         done = true;
                 if (done)
                         break;
@@ -704,7 +705,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                                 const uint32_t wi = bm_pad(tid * (SPAN_WORDS / WG) + j);
                                 uint32_t m = fin[wi];
                                 if (ngroups > 1) {
-                                        m &= pre[wi];
+                                        m &= neg ? ~pre[wi] : pre[wi]; // the last group is the one still in B; an excluded group removes
                                         fin[wi] = m;
                                 }
                                 pre[wi] = run;
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                 const DevTask task = tasks[tix];
                 const uint32_t slot = task.slot;
                 const DevQuery q = plan[slot];
-                const DevTerm lead = terms[qterms[q.term_base] & ~QT_GROUP];
+                const DevTerm lead = terms[qterms[q.term_base] & QT_TERM];
                 TRACE(1, slot, q.nterms);
                 uint32_t *qout = out + task.out_off;
                 uint32_t produced = 0;
@@ -864,11 +865,14 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
 
                         // ---- every other group filters the surviving candidates: a candidate survives a group when any
                         //      of the group's terms holds it (hit bits are OR-ed across the group's terms)
+                        bool gneg = false; // the group being filtered is the excluded one (logicalnot): its hits remove
                         for (uint32_t k = 1; k < q.nterms && C; ++k) {
                                 const uint32_t tt = qterms[q.term_base + k];
-                                const DevTerm t = terms[tt & ~QT_GROUP];
-                                if (tt & QT_GROUP)
+                                const DevTerm t = terms[tt & QT_TERM];
+                                if (tt & QT_GROUP) {
                                         sh.hit[tid] = 0;
+                                        gneg = tt & QT_NOT;
+                                }
                                 __syncthreads();
 #if defined(TRI_FORCE_CAND)
                                 const bool bd = false;
@@ -886,7 +890,11 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                 if (!lastterm && !(qterms[q.term_base + k + 1] & QT_GROUP))
                                         continue; // more terms of this OR group to come
                                 // compact survivors (stable => still ascending)
-                                const uint32_t bits = sh.hit[tid];
+                                uint32_t bits = sh.hit[tid];
+                                if (gneg) { // row tid holds candidates tid * 32 ..: keep the ones NOT hit
+                                        const uint32_t left = C > tid * 32 ? C - tid * 32 : 0u;
+                                        bits = ~bits & (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
+                                }
                                 const uint32_t cnt = __popc(bits);
                                 uint32_t wtot;
                                 uint32_t ex = wave_excl_scan(cnt, wtot);

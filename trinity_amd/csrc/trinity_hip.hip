@@ -29,6 +29,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <functional>
 #include <vector>
 
 // ------------------------------------------------------------------------------------------ errors
@@ -678,6 +679,16 @@ namespace {
                                         n.empty = n.kids.empty();
                                         for (int k : n.kids)
                                                 n.cost += nodes[k].cost;
+                                } else if (op == TRI_OP_NOT) {
+                                        if (arg != 2)
+                                                return -1;
+                                        if (nodes[kids[1]].empty) { // [a NOT <never matches>] => a
+                                                st.push_back(kids[0]);
+                                                continue;
+                                        }
+                                        n.kids = kids; // {required, excluded}
+                                        n.empty = nodes[kids[0]].empty;
+                                        n.cost = nodes[kids[0]].cost; // exec.cpp:55-60
                                 } else
                                         return -1;
                         }
@@ -788,14 +799,37 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         groups.push_back(std::move(u));
                         return true;
                 };
+                // logicalnot at the root or under an AND: its required side joins the conjunction, its excluded side (a term or an
+                // OR of terms) joins the query's excluded set: A B -C == A ∧ B ∧ ¬C (Filter semantics, docset_iterators.cpp:652-677)
                 bool ok = true;
-                if (r.op == TRI_OP_AND)
-                        for (int k : r.kids)
-                                ok &= add_group(nodes[k]);
-                else
-                        ok = add_group(r);
-                if (!ok)
-                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: only AND of terms / phrases / OR-of-terms groups (and a root OR of terms) are lowered so far", qi);
+                std::vector<uint32_t> negs;
+                std::function<void(int)> lower = [&](int ni) {
+                        const PNode &x = nodes[ni];
+                        if (x.op == TRI_OP_NOT) {
+                                lower(x.kids[0]);
+                                const PNode &e = nodes[x.kids[1]];
+                                if (e.op == TRI_OP_TERM)
+                                        negs.push_back(e.term);
+                                else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1)
+                                        negs.push_back(nodes[e.kids[0]].term);
+                                else if (e.op == TRI_OP_OR) {
+                                        for (int k : e.kids) {
+                                                if (nodes[k].op != TRI_OP_TERM)
+                                                        ok = false;
+                                                else
+                                                        negs.push_back(nodes[k].term);
+                                        }
+                                } else
+                                        ok = false;
+                        } else if (x.op == TRI_OP_AND) {
+                                for (int k : x.kids)
+                                        lower(k);
+                        } else
+                                ok &= add_group(x);
+                };
+                lower(root);
+                if (!ok || groups.empty())
+                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, and NOT (at the root or under AND) of a term or an OR of terms", qi);
                 auto gcost = [&](const std::vector<uint32_t> &g) {
                         uint64_t c = 0;
                         for (uint32_t x : g)
@@ -807,6 +841,15 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 for (const auto &g : groups)
                         for (size_t i = 0; i < g.size(); ++i)
                                 uniq.push_back(g[i] | (i == 0 ? QT_GROUP : 0u));
+                {
+                        // the excluded terms: one more group, the last, marked QT_NOT
+                        std::vector<uint32_t> u;
+                        for (uint32_t x : negs)
+                                if (ix->terms[x].documents && std::find(u.begin(), u.end(), x) == u.end())
+                                        u.push_back(x);
+                        for (size_t i = 0; i < u.size(); ++i)
+                                uniq.push_back(u[i] | (i == 0 ? (QT_GROUP | QT_NOT) : 0u));
+                }
                 if (uniq.size() > MAX_QTERMS)
                         return fail(TRI_ERR_UNSUPPORTED, "query %zu: more than %u terms", qi, MAX_QTERMS);
                 const uint32_t nlead = (uint32_t)groups[0].size();
@@ -863,7 +906,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 {
                         std::vector<uint32_t> seen;
                         for (uint32_t tt : uniq) {
-                                const uint32_t term = tt & ~QT_GROUP;
+                                const uint32_t term = tt & QT_TERM;
                                 b->qterms.push_back(tt);
                                 if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
                                         seen.push_back(term);
@@ -872,7 +915,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         }
                         // cost estimate: the lead group is decoded fully; every other list costs min(its blocks x 32, lead docs x 32)
                         for (size_t i = 0; i < uniq.size(); ++i) {
-                                const DevTerm &tk = ix->terms[uniq[i] & ~QT_GROUP];
+                                const DevTerm &tk = ix->terms[uniq[i] & QT_TERM];
                                 t.cost += i < nlead ? tk.documents : 32ull * std::min<uint64_t>(tk.nblocks, lead_docs);
                         }
                 }
@@ -895,34 +938,38 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint32_t slot = (uint32_t)b->plan.size();
                 b->slot_of_query[t.q.qid] = slot;
                 const uint32_t *qt = &b->qterms[t.q.term_base];
-                const DevTerm &lead = ix->terms[qt[0] & ~QT_GROUP];
+                const DevTerm &lead = ix->terms[qt[0] & QT_TERM];
                 const uint32_t nlead = t.nlead;
                 uint64_t lead_docs = 0;
                 for (uint32_t k = 0; k < nlead; ++k)
-                        lead_docs += ix->terms[qt[k] & ~QT_GROUP].documents;
+                        lead_docs += ix->terms[qt[k] & QT_TERM].documents;
                 // TASK_DENSE (bitmap windows) when the lead group is an OR (it has to be materialised as a set anyway), or
                 // when every other list is within a factor 32 of the lead (no block could be skipped) and there is enough
                 // work per docID window to keep 256 lanes busy
                 uint64_t sumdf = 0;
                 bool dense = t.q.nterms >= 2;
-                uint32_t last_doc = 0xffffffffu, glast = 0; // no match beyond the group whose lists end first
+                uint32_t last_doc = 0xffffffffu, glast = 0; // no match beyond the (required) group whose lists end first
+                bool in_neg = false;
                 for (uint32_t k = 0; k < t.q.nterms; ++k) {
-                        const DevTerm &tk = ix->terms[qt[k] & ~QT_GROUP];
+                        const DevTerm &tk = ix->terms[qt[k] & QT_TERM];
                         sumdf += tk.documents;
                         dense &= tk.nblocks <= lead_docs;
                         if (k && (qt[k] & QT_GROUP)) {
                                 last_doc = std::min(last_doc, glast);
                                 glast = 0;
+                                in_neg = qt[k] & QT_NOT;
                         }
-                        glast = std::max(glast, ix->h_blk_last[tk.first_block + tk.nblocks - 1]);
+                        if (!in_neg)
+                                glast = std::max(glast, ix->h_blk_last[tk.first_block + tk.nblocks - 1]);
                 }
-                last_doc = std::min(last_doc, glast);
+                if (!in_neg)
+                        last_doc = std::min(last_doc, glast);
                 dense &= sumdf >= DENSE_MIN_POSTINGS;
                 dense |= nlead > 1;
                 if (dense) {
                         std::vector<uint32_t> seen;
                         for (uint32_t k = 0; k < t.q.nterms; ++k) {
-                                const uint32_t term = qt[k] & ~QT_GROUP;
+                                const uint32_t term = qt[k] & QT_TERM;
                                 if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
                                         seen.push_back(term);
                                         b->term_bytes_dense += ix->docbytes[term];
@@ -940,14 +987,14 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         uint32_t ord = 0;
                         uint64_t lead_blocks = 0;
                         for (uint32_t k = 0; k < nlead; ++k)
-                                lead_blocks += ix->terms[qt[k] & ~QT_GROUP].nblocks;
+                                lead_blocks += ix->terms[qt[k] & QT_TERM].nblocks;
                         for (uint32_t wb = 0; wb < nwin; wb += win_per_task, ++ord) {
                                 const uint32_t we = std::min(nwin, wb + win_per_task);
                                 // matches of windows [wb, we) are lead-group documents of blocks b1 .. (next task's b1) of every
                                 // lead list: a private region (+32 slots of slack per lead list and task for the straddling block)
                                 uint64_t b1 = 0;
                                 for (uint32_t k = 0; k < nlead; ++k) {
-                                        const DevTerm &tk = ix->terms[qt[k] & ~QT_GROUP];
+                                        const DevTerm &tk = ix->terms[qt[k] & QT_TERM];
                                         const uint32_t *lb = &ix->h_blk_last[tk.first_block];
                                         b1 += (uint64_t)(std::lower_bound(lb, lb + tk.nblocks, wb * SPAN_BITS) - lb);
                                 }

@@ -8,7 +8,7 @@ import numpy as np
 
 from .build import LIB_HIP, LIB_HOST
 
-OP_TERM, OP_AND, OP_OR, OP_PHRASE = 0, 1, 2, 3
+OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT = 0, 1, 2, 3, 4
 FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE = 1, 2
 CODEC_GOOGLE, CODEC_LUCENE = 1, 2
 FNV_EMPTY = 1469598103934665603
