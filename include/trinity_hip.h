@@ -116,6 +116,13 @@ int tri_index_get_info(const tri_index *, tri_index_info *);
 /* algorithmic doc bytes (SURVEY §8d docbytes(t)) of the given terms */
 int tri_index_term_docbytes(const tri_index *, const uint32_t *terms, size_t n, uint64_t *out);
 
+/* Masked documents of this segment: documents updated or deleted by newer segments, which exec_query drops right before
+ * consider() — masked_documents_registry::test (docidupdates.h:90-119; exec.cpp:914-975, 1000-1030).  Replaces the set
+ * (any order, duplicates allowed; n == 0 clears it).  Kept on the device as a bitmap over docIDs and applied inside the
+ * matching kernels, so match counts, docsets, scores and top-K of batches run afterwards never contain a masked document.
+ * Batches created before the call keep working; the set they see is the one in place when they RUN. */
+int tri_index_set_masked(tri_index *, const uint32_t *docids, size_t n);
+
 /* ---- postings decode (codec seam) -----------------------------------------------------------------
  * Replaces Codecs::PostingsListIterator::next() driven to exhaustion (google_codec.cpp:777-819,
  * unpack_block :596-639): decodes whole postings lists on the GPU.  out_offsets[n+1] receives the prefix

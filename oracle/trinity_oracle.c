@@ -419,9 +419,27 @@ to_index *to_index_wrap(const uint8_t *bytes, size_t len, const to_term *terms, 
         return ix;
 }
 
+static int cmp_u32(const void *a, const void *b) {
+        const uint32_t x = *(const uint32_t *)a, y = *(const uint32_t *)b;
+        return x < y ? -1 : x > y;
+}
+
+void to_index_set_masked(to_index *ix, const uint32_t *docids, size_t n) {
+        free(ix->masked);
+        ix->masked = NULL;
+        ix->nmasked = 0;
+        if (!n)
+                return;
+        ix->masked = (uint32_t *)xmalloc(sizeof(uint32_t) * n);
+        memcpy(ix->masked, docids, sizeof(uint32_t) * n);
+        qsort(ix->masked, n, sizeof(uint32_t), cmp_u32);
+        ix->nmasked = n;
+}
+
 void to_index_free(to_index *ix) {
         if (!ix)
                 return;
+        free(ix->masked);
         if (ix->owns) {
                 free(ix->bytes);
                 free(ix->terms);
@@ -1458,6 +1476,23 @@ int to_exec_query(const to_index *ix, const uint32_t *prog, uint32_t proglen, ui
                         span_disjunction(&c, kids, cnt, flags, out);
                 } else
                         span_generic(sit, flags, out);
+        }
+        /* exec.cpp:914-975 / 1000-1030: a match is handed to consider() only if !maskedDocumentsRegistry->test(id).  Both lists
+         * ascend, so one merge pass drops the masked matches (and their scores). */
+        if (ix->nmasked && out->n) {
+                size_t w = 0, mi = 0;
+                for (size_t i = 0; i < out->n; ++i) {
+                        const uint32_t d = out->docs[i];
+                        while (mi < ix->nmasked && ix->masked[mi] < d)
+                                ++mi;
+                        if (mi < ix->nmasked && ix->masked[mi] == d)
+                                continue;
+                        out->docs[w] = d;
+                        if (out->scores)
+                                out->scores[w] = out->scores[i];
+                        ++w;
+                }
+                out->n = w;
         }
         for (size_t i = 0; i < c.nowned; ++i)
                 free(c.owned[i]);

@@ -86,6 +86,12 @@ typedef struct to_index {
         uint64_t sumTermsDocs;
         uint32_t docsCnt;
         int owns;
+        /* masked documents (docidupdates.h:90-119 masked_documents_registry::test): documents updated or deleted by a newer
+         * segment; exec_query drops them right before consider() (exec.cpp:914-975).  Sorted ascending; NULL/0 = none.
+         * The reference's registry (banks + bloom filter) cannot be built here (docidupdates.cpp needs boost spreadsort):
+         * only its observable behaviour — set membership — is restated; "parity unpinned" for the registry itself. */
+        uint32_t *masked;
+        size_t nmasked;
         int codec;     /* TO_CODEC_GOOGLE (default, 0 also means Google) or TO_CODEC_LUCENE */
         uint8_t *hits; /* Lucene: the segment's hits.data (lucene_codec.h:206) */
         size_t hits_len;
@@ -109,6 +115,8 @@ to_index *to_google_encode(const to_corpus *);
 to_index *to_index_wrap(const uint8_t *bytes, size_t len, const to_term *terms, uint32_t nterms, uint32_t docsCnt,
                         uint64_t sumTermsDocs, uint64_t sumTermHits);
 void to_index_free(to_index *);
+/* replace the index's masked-document set (copied; any order, duplicates allowed) */
+void to_index_set_masked(to_index *, const uint32_t *docids, size_t n);
 
 /* Walk one chunk's block headers (format check, algorithmic-byte accounting):
  * returns number of blocks; fills header / delta+freq / hit / skiplist byte counts and #postings. */

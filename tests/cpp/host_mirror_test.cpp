@@ -94,6 +94,16 @@ int main(int argc, char **argv) {
                         exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
                         show("not_scored", c);
                 }
+                { // masked documents: every 3rd document of the segment was superseded by a newer one
+                        std::vector<docid_t> masked;
+                        for (docid_t d = 3; d <= fs.docsCnt; d += 3)
+                                masked.push_back(d);
+                        src.set_masked_documents(masked);
+                        Collect c;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("masked_scored", c);
+                        src.set_masked_documents({});
+                }
                 { // unknown term => no documents
                         Collect c;
                         exec_query(src.conjunction({src.term("t0"), src.term("nosuchterm")}), &src, &c, nullptr, unsigned(ExecFlags::DocumentsOnly));

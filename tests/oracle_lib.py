@@ -39,6 +39,8 @@ class ToIndex(C.Structure):
         ("sumTermsDocs", C.c_uint64),
         ("docsCnt", C.c_uint32),
         ("owns", C.c_int),
+        ("masked", C.POINTER(C.c_uint32)),
+        ("nmasked", C.c_size_t),
         ("codec", C.c_int),
         ("hits", C.POINTER(C.c_uint8)),
         ("hits_len", C.c_size_t),
@@ -214,6 +216,13 @@ class Index:
             scores = np.ctypeslib.as_array(r.scores, shape=(r.n,)).copy() if r.n else np.zeros(0, np.float64)
         lib().to_result_free(C.byref(r))
         return docs, scores
+
+    def set_masked(self, docids):
+        d = np.ascontiguousarray(docids, dtype=np.uint32)
+        f = lib().to_index_set_masked
+        f.restype = None
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        f(self.ptr, d.ctypes.data, d.size)
 
     def exec_count(self, prog, flags):
         """Run one postfix program and return only the number of matches (no copy: the multi-threaded CPU-baseline leg of

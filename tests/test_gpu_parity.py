@@ -581,3 +581,47 @@ def test_not_of_conjunction_is_refused(T, dev):
     with pytest.raises(T.TrinityError):
         T.Batch(w.ix, [O.parse_query("t0 OR (t1 NOT t2)")], T.FLAG_DOCUMENTS_ONLY)
     w.ix.close()
+
+
+# ------------------------------------------------------------------------------------------ masked documents
+@pytest.mark.parametrize("codec", [1, 2])
+def test_masked_documents_are_dropped(T, dev, codec, monkeypatch):
+    """masked_documents_registry::test (docidupdates.h:90-119; exec.cpp:914-975): a document masked by a newer segment never
+    reaches consider().  Every query shape, both matching kernels, scored and not; then the set is cleared again."""
+    w = World(T, dev, 30000, 3000, 10, 42, codec=codec)
+    rng = np.random.default_rng(5)
+    masked = np.unique(np.concatenate([rng.integers(1, 30001, 4000), np.arange(100, 400), [1, 30000, 29999]])).astype(np.uint32)
+    texts = (template_queries(w, 81, 6) + not_queries(w, 82, 4) + phrase_queries(w, 83, 3) + ["t0", "t7", "t0 t1", "t0 OR t1", "t2500", "t0 NOT t1"])
+    progs = [O.parse_query(t) for t in texts]
+    base_sets, _, _ = run_docs_only(w, progs)
+    w.ix.set_masked(masked)
+    w.ora.set_masked(masked)
+    try:
+        for dense_min in ("", "0"):  # planner's choice, then the bitmap-window kernel forced
+            if dense_min:
+                monkeypatch.setenv("TRINITY_DENSE_MIN", dense_min)
+            sets, hashes, _ = run_docs_only(w, progs)
+            dropped = 0
+            for t, p, got, h, full in zip(texts, progs, sets, hashes, base_sets):
+                want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+                assert np.array_equal(got, want), (t, len(got), len(want))
+                assert np.array_equal(got, full[~np.isin(full, masked)]), t  # == the unmasked result minus the masked set
+                assert int(h) == O.fnv1a_docs(want)
+                dropped += len(full) - len(got)
+            assert dropped > 1000
+        monkeypatch.delenv("TRINITY_DENSE_MIN", raising=False)
+        scored = [p for t, p in zip(texts, progs)]
+        d, s, c, counts = run_scored(w, scored, 20)
+        for i, p in enumerate(scored):
+            docs, scores = w.ora.exec(p, O.FLAG_ACCUM_SCORE)
+            assert int(counts[i]) == len(docs), texts[i]
+            td, ts = w.ora.topk(docs, scores, 20)
+            assert d[i, : len(td)].tolist() == td.tolist(), texts[i]
+            np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+    finally:
+        w.ix.set_masked(np.zeros(0, np.uint32))
+        w.ora.set_masked(np.zeros(0, np.uint32))
+    sets, _, _ = run_docs_only(w, progs)
+    for got, full in zip(sets, base_sets):
+        assert np.array_equal(got, full)
+    w.ix.close()

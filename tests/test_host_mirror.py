@@ -62,6 +62,7 @@ def test_mirror_results_match_oracle(T, tmp_path):
     expect("or_even", "t3 OR t7", 1, keep=lambda d: (d & 1) == 0)
     expect("phrase_scored", '"t0 t1" t2', 2)
     expect("not_scored", "t3 t5 NOT (t1 OR t2)", 2)
+    expect("masked_scored", "t0 t1", 2, keep=lambda d: (d % 3) != 0)
     assert int(lines["unknown"]["n"]) == 0
     expect("batch0", "t1 t2", 1)
     expect("batch1", "t8 OR t9", 1)

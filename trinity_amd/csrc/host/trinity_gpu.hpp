@@ -355,6 +355,11 @@ namespace trinity_amd {
                 IndexSource(const IndexSource &) = delete;
 
                 tri_index *handle() const noexcept { return ix; }
+                // The documents of this source that newer sources of the collection have updated or deleted — what
+                // IndexSourcesCollection::commit() derives per source (index_source.cpp:3-30) and exec_query tests through
+                // masked_documents_registry::test before every consider() (exec.cpp:914-975).  Uploaded once per refresh of the
+                // collection; the matching kernels drop these documents themselves.
+                void set_masked_documents(const std::vector<docid_t> &ids) { check(tri_index_set_masked(ix, ids.data(), ids.size())); }
                 field_statistics default_field_stats() const { return fs; }
 
                 // index_source.h:103: unknown term => no documents

@@ -556,7 +556,7 @@ template <int WG, int CODEC>
 __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                            const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                            const uint32_t *__restrict__ qterms, const DevQuery q, const DevTask task, uint32_t *__restrict__ out,
-                           uint32_t *__restrict__ count_out PROF_ARG) {
+                           uint32_t *__restrict__ count_out, const uint32_t *__restrict__ masked PROF_ARG) {
         const uint32_t tid = threadIdx.x;
         uint32_t *qout = out + task.out_off;
         uint32_t produced = 0;
@@ -704,10 +704,11 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                         for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
                                 const uint32_t wi = bm_pad(tid * (SPAN_WORDS / WG) + j);
                                 uint32_t m = fin[wi];
-                                if (ngroups > 1) {
+                                if (ngroups > 1)
                                         m &= neg ? ~pre[wi] : pre[wi]; // the last group is the one still in B; an excluded group removes
-                                        fin[wi] = m;
-                                }
+                                if (masked) // masked_documents_registry::test (docidupdates.h:90-119): updated / deleted elsewhere
+                                        m &= ~masked[w0 / 32 + tid * (SPAN_WORDS / WG) + j];
+                                fin[wi] = m;
                                 pre[wi] = run;
                                 run += __popc(m);
                         }
@@ -776,7 +777,8 @@ __global__ __launch_bounds__(DENSE_WG) void k_and_dense(const uint8_t *__restric
                                                         const DevTerm *__restrict__ terms, const DevQuery *__restrict__ plan,
                                                         const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched,
                                                         const uint32_t *__restrict__ qterms, const uint32_t ntasks, uint32_t *__restrict__ ticket,
-                                                        uint32_t *__restrict__ out, uint32_t *__restrict__ counts) {
+                                                        uint32_t *__restrict__ out, uint32_t *__restrict__ counts,
+                                                        const uint32_t *__restrict__ masked) {
         __shared__ DenseShared sh;
         const uint32_t wave = uni(threadIdx.x >> 6);
         PROF_DECL;
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(DENSE_WG) void k_and_dense(const uint8_t *__restric
                 const DevTask task = tasks[tix];
                 const DevQuery q = plan[task.slot];
                 PROF_LAP(0);
-                dense_task<DENSE_WG, CODEC>(sh, index, blk_last, blk_off, win, terms, qterms, q, task, out, counts + tix PROF_PASS);
+                dense_task<DENSE_WG, CODEC>(sh, index, blk_last, blk_off, win, terms, qterms, q, task, out, counts + tix, masked PROF_PASS);
         }
         PROF_LAP(9);
         PROF_FLUSH();
@@ -809,7 +811,8 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                                 const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
                                                 const uint32_t *__restrict__ sched, const uint32_t *__restrict__ qterms,
                                                 const uint32_t ntasks, uint32_t *__restrict__ ticket,
-                                                uint32_t *__restrict__ out, uint32_t *__restrict__ counts) {
+                                                uint32_t *__restrict__ out, uint32_t *__restrict__ counts,
+                                                const uint32_t *__restrict__ masked) {
         __shared__ AndShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
@@ -895,6 +898,14 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                         const uint32_t left = C > tid * 32 ? C - tid * 32 : 0u;
                                         bits = ~bits & (left >= 32 ? 0xffffffffu : ((1u << left) - 1u));
                                 }
+                                if (masked && lastterm) // drop the survivors a newer segment has masked (docidupdates.h:90-119)
+                                        for (uint32_t m = bits; m;) {
+                                                const uint32_t kbit = __builtin_ctz(m);
+                                                m &= m - 1;
+                                                const uint32_t doc = sh.cand[phys(tid * 32 + kbit)];
+                                                if ((masked[doc >> 5] >> (doc & 31u)) & 1u)
+                                                        bits &= ~(1u << kbit);
+                                        }
                                 const uint32_t cnt = __popc(bits);
                                 uint32_t wtot;
                                 uint32_t ex = wave_excl_scan(cnt, wtot);
@@ -934,8 +945,38 @@ __global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ inde
                                 __syncthreads();
                         }
                         if (q.nterms == 1) {
-                                for (uint32_t j = tid; j < C; j += AND_WG)
-                                        qout[produced + j] = sh.cand[phys(j)];
+                                if (!masked) {
+                                        for (uint32_t j = tid; j < C; j += AND_WG)
+                                                qout[produced + j] = sh.cand[phys(j)];
+                                } else {
+                                        // single-term query over a segment with masked documents: row-wise keep mask, scan, write
+                                        const uint32_t left = C > tid * 32 ? C - tid * 32 : 0u;
+                                        uint32_t bits = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+                                        for (uint32_t m = bits; m;) {
+                                                const uint32_t kbit = __builtin_ctz(m);
+                                                m &= m - 1;
+                                                const uint32_t doc = sh.cand[phys(tid * 32 + kbit)];
+                                                if ((masked[doc >> 5] >> (doc & 31u)) & 1u)
+                                                        bits &= ~(1u << kbit);
+                                        }
+                                        uint32_t wtot;
+                                        uint32_t ex = wave_excl_scan(__popc(bits), wtot);
+                                        sh.scan[tid >> 6] = wtot;
+                                        __syncthreads();
+                                        uint32_t wbase = 0, total = 0;
+                                        for (int w = 0; w < AND_WG / 64; ++w) {
+                                                if (w < (int)(tid >> 6))
+                                                        wbase += sh.scan[w];
+                                                total += sh.scan[w];
+                                        }
+                                        uint32_t o = produced + ex + wbase;
+                                        for (uint32_t m = bits; m;) {
+                                                const uint32_t kbit = __builtin_ctz(m);
+                                                m &= m - 1;
+                                                qout[o++] = sh.cand[phys(tid * 32 + kbit)];
+                                        }
+                                        C = uni(total);
+                                }
                         }
                         produced += C;
                         __syncthreads();

@@ -74,6 +74,8 @@ struct tri_index {
         // (k_and_dense, k_and) read this stream instead.  Scoring and phrases keep reading the chunk itself.
         uint8_t *d_dstream = nullptr;
         uint32_t *d_blk_doff = nullptr;
+        uint32_t *d_masked = nullptr; // bitmap over docIDs of the masked documents (nullptr: none); max_doc / 32 + 2 words
+        uint32_t max_doc = 0;
         uint32_t nwin = 0; // cells per win[] row
         DevTerm *d_terms = nullptr;
         std::vector<DevTerm> terms;
@@ -486,6 +488,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         // galloping candidate brackets its block to the handful of blocks that end inside its cell.
         const uint32_t max_doc = blk_last.empty() ? 0 : *std::max_element(blk_last.begin(), blk_last.end());
         ix->nwin = (max_doc / SPAN_BITS + 2) * (SPAN_BITS / CELL_DOCS) + 1;
+        ix->max_doc = max_doc;
         std::vector<uint32_t> win;
         for (size_t ti = 0; ti < nterms; ++ti) {
                 DevTerm &dt = ix->terms[ti];
@@ -540,6 +543,28 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         return TRI_OK;
 }
 
+extern "C" int tri_index_set_masked(tri_index *ix, const uint32_t *docids, size_t n) {
+        if (!ix || (!docids && n))
+                return fail(TRI_ERR_INVALID, "tri_index_set_masked: null argument");
+        HIP_TRY(hipSetDevice(ix->dev->device));
+        HIP_TRY(hipStreamSynchronize(ix->dev->stream)); // no batch of this device is reading the old bitmap
+        if (!n) {
+                hipFree(ix->d_masked);
+                ix->d_masked = nullptr;
+                return TRI_OK;
+        }
+        // whole docID windows (the bitmap kernel reads a window's worth of words at a time), one spare window
+        const size_t words = ((size_t)ix->max_doc / SPAN_BITS + 2) * (SPAN_BITS / 32);
+        std::vector<uint32_t> bm(words, 0);
+        for (size_t i = 0; i < n; ++i)
+                if (docids[i] <= ix->max_doc) // a document this segment does not hold cannot match anyway
+                        bm[docids[i] >> 5] |= 1u << (docids[i] & 31);
+        if (!ix->d_masked)
+                HIP_TRY(hipMalloc((void **)&ix->d_masked, words * 4));
+        HIP_TRY(hipMemcpy(ix->d_masked, bm.data(), words * 4, hipMemcpyHostToDevice));
+        return TRI_OK;
+}
+
 extern "C" void tri_index_destroy(tri_index *ix) {
         if (!ix)
                 return;
@@ -550,6 +575,7 @@ extern "C" void tri_index_destroy(tri_index *ix) {
         hipFree(ix->d_hdir);
         hipFree(ix->d_dstream);
         hipFree(ix->d_blk_doff);
+        hipFree(ix->d_masked);
         hipFree(ix->d_blk_last);
         hipFree(ix->d_blk_off);
         hipFree(ix->d_win);
@@ -1138,14 +1164,14 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 if (b->n_dense) {
                         TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * dense_wgs)), dim3(DENSE_WG), dev->stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
-                                           b->d_ticket + 16, b->d_out, b->d_counts);
+                                           b->d_ticket + 16, b->d_out, b->d_counts, b->ix->d_masked);
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(dev->ev_a, dev->stream));
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
-                                           b->n_cand, b->d_ticket, b->d_out, b->d_counts);
+                                           b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked);
                 HIP_TRY(hipGetLastError());
                 if (overlap) {
                         HIP_TRY(hipEventRecord(dev->ev_join, dev->stream2));

@@ -63,7 +63,7 @@ class TriBatchInfo(C.Structure):
 # every symbol include/trinity_hip.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream",
-    "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_decode_terms",
+    "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_docset_hashes",
 ]  # fmt: skip
@@ -92,6 +92,7 @@ def hip_lib():
     L.tri_index_destroy.argtypes = [vp]
     L.tri_index_get_info.argtypes = [vp, C.POINTER(TriIndexInfo)]
     L.tri_index_term_docbytes.argtypes = [vp, vp, C.c_size_t, vp]
+    L.tri_index_set_masked.argtypes = [vp, vp, C.c_size_t]
     L.tri_decode_terms.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     L.tri_batch_create.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
     L.tri_batch_destroy.argtypes = [vp]
@@ -215,6 +216,11 @@ class Index:
         i = TriIndexInfo()
         _check(hip_lib().tri_index_get_info(self.h, C.byref(i)))
         return {k: getattr(i, k) for k, _ in TriIndexInfo._fields_}
+
+    def set_masked(self, docids):
+        """Replace the segment's masked-document set (masked_documents_registry::test, docidupdates.h:90-119)."""
+        d = np.ascontiguousarray(docids, dtype=np.uint32)
+        _check(hip_lib().tri_index_set_masked(self.h, d.ctypes.data if d.size else None, d.size))
 
     def term_docbytes(self, terms):
         t = np.ascontiguousarray(terms, dtype=np.uint32)
