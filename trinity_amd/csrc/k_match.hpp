@@ -31,9 +31,6 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
         return x - v;
 }
 
-#ifndef TRI_DENSE_V
-#define TRI_DENSE_V 1
-#endif
 constexpr uint32_t SPAN_BITS = 1u << 17; // docIDs per dense window
 constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
 constexpr uint32_t CELL_LOG2 = 10; // docID cells of the per-term block index (DevTerm::win_off)
@@ -326,13 +323,7 @@ __device__ __forceinline__ void dense_visit(uint32_t *bm, const uint32_t rel) {
         asm("v_lshrrev_b32 %0, 5, %1" : "=v"(w) : "v"(rel));
         asm("v_lshrrev_b32 %0, 10, %1" : "=v"(r) : "v"(rel));
         asm("v_add_lshl_u32 %0, %1, %2, 2" : "=v"(a) : "v"(w), "v"(r));
-#if defined(TRI_EXP) && TRI_EXP == 1
-        asm volatile("" ::"v"(a), "v"(1u << (rel & 31u))); // experiment: no LDS operation at all
-#elif defined(TRI_EXP) && TRI_EXP == 2
-        *(volatile uint32_t *)((uint8_t *)bm + a) = 1u << (rel & 31u); // experiment: plain store
-#else
         atomicOr((uint32_t *)((uint8_t *)bm + a), 1u << (rel & 31u));
-#endif
 }
 __device__ __forceinline__ void dense_visit_clamped(uint32_t *bm, const uint32_t rel, const uint32_t wbase) {
         atomicOr(&bm[bm_pad(min(rel >> 5, SPAN_WORDS) + wbase)], 1u << (rel & 31u));

@@ -94,9 +94,18 @@ struct HitStream<CODEC_LUCENE> {
         }
 };
 
+// Candidates are handled in tiles held in LDS: up to PHRASE_TILE of them, fewer when the phrase has many distinct terms
+// (one row of hit locators per distinct term: PHRASE_SLOTS entries in all).
+constexpr uint32_t PHRASE_TILE = 1024;
+constexpr uint32_t PHRASE_SLOTS = 4096;
 struct PhraseShared {
-        uint32_t hits_off[MAX_PHRASE_TERMS][AND_WG]; // byte offset into index[] of the candidate's hits, per phrase term
-        uint32_t freq[MAX_PHRASE_TERMS][AND_WG];
+        uint32_t cdoc[PHRASE_TILE];     // the tile's candidates (ascending)
+        uint32_t hits_off[PHRASE_SLOTS]; // [row * tile + j]: where candidate j's hits of the row's term start (GOOGLE: byte offset into
+                                         // index[]; LUCENE: hit ordinal within the term)
+        uint32_t freq[PHRASE_SLOTS];
+        double ps[PHRASE_TILE];         // scored mode: sum of the phrase scores of the candidate
+        uint8_t alive[PHRASE_TILE];
+        uint32_t row[MAX_PHRASE_TERMS]; // phrase position -> row (a term repeated in the phrase shares the row of its first occurrence)
         uint32_t scan[8];
         uint32_t bcast[4];
 };
@@ -199,6 +208,91 @@ __device__ __forceinline__ bool phrase_has_pos(const HitCtx &ctx, const uint32_t
         return false;
 }
 
+// Block-driven location: one lane walks one block of term t ONCE for all the tile's candidates it holds (phrase terms are
+// conjuncts of the query, so every candidate in the block's docID range is a document of the block): deltas mark the slots,
+// then freqs and hits are walked in lockstep up to the last marked slot, leaving (hits locator, freq) for each candidate.
+// Candidate-driven location (phrase_locate) redoes that walk per candidate; it is kept for the case of few candidates
+// scattered over a long list.
+template <int CODEC>
+__device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                    const uint32_t *__restrict__ blk_off, const HitCtx &ctx, const DevTerm t, const uint32_t b,
+                                                    const uint32_t C, const uint32_t slot0) {
+        const uint32_t *bl = blk_last + t.first_block;
+        const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
+        uint32_t lo = 0, hi = C; // first candidate > prev
+        while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (sh.cdoc[mid] <= prev)
+                        lo = mid + 1;
+                else
+                        hi = mid;
+        }
+        const uint32_t ci = lo;
+        if (ci >= C || sh.cdoc[ci] > last)
+                return;
+        const uint32_t off = blk_off[t.first_block + b];
+        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
+        uint32_t mask = 0, cj = ci, doc = prev;
+        uint32_t cv = sh.cdoc[cj];
+        if (CODEC == CODEC_GOOGLE) {
+                VbStream s;
+                s.init(index + off);
+                for (uint32_t i = 0; i < n; ++i) {
+                        doc = i + 1 < n ? doc + s.next() : last;
+                        if (cv == doc) {
+                                mask |= 1u << i;
+                                ++cj;
+                                cv = cj < C ? sh.cdoc[cj] : 0xffffffffu;
+                        }
+                }
+                VbStream sf = s; // freqs start here
+                for (uint32_t i = 0; i < n; ++i)
+                        (void)s.next(); // s: hits start
+                cj = ci;
+                for (uint32_t i = 0; i < n && (mask >> i); ++i) {
+                        const uint32_t f = sf.next();
+                        if ((mask >> i) & 1u) {
+                                sh.hits_off[slot0 + cj] = (uint32_t)(s.tell() - index);
+                                sh.freq[slot0 + cj] = f;
+                                ++cj;
+                                if (!((mask >> i) >> 1))
+                                        break;
+                        }
+                        uint32_t plen = 0; // payload length state restarts with every document
+                        for (uint32_t h = 0; h < f; ++h) {
+                                const uint32_t v = s.next();
+                                if (v & 1u)
+                                        plen = s.byte();
+                                s.skip(plen);
+                        }
+                }
+        } else {
+                DeltaStream<CODEC> ds;
+                ds.init(index, t, b, off);
+                for (uint32_t i = 0; i < n; ++i) {
+                        doc = i + 1 < n ? doc + ds.next() : last;
+                        if (cv == doc) {
+                                mask |= 1u << i;
+                                ++cj;
+                                cv = cj < C ? sh.cdoc[cj] : 0xffffffffu;
+                        }
+                }
+                FreqStream<CODEC> fs;
+                fs.init(index, t, b, off, ds);
+                uint32_t h = ctx.blk_hits[t.first_block + b];
+                cj = ci;
+                for (uint32_t i = 0; i < n && (mask >> i); ++i) {
+                        const uint32_t f = fs.next();
+                        if ((mask >> i) & 1u) {
+                                sh.hits_off[slot0 + cj] = h;
+                                sh.freq[slot0 + cj] = f;
+                                ++cj;
+                        }
+                        h += f;
+                }
+        }
+}
+
 template <int CODEC>
 __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ index, const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits,
                                                    const uint32_t *__restrict__ hdir, const uint32_t *__restrict__ blk_last,
@@ -226,41 +320,81 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                 const DevQuery q = plan[task.slot];
                 const uint32_t M = counts[tix];
                 uint32_t *seg = out + task.out_off;
+                // tile size: PHRASE_SLOTS locator entries shared by the rows (distinct terms) of the query's widest phrase
+                uint32_t maxrows = 1;
+                for (uint32_t pi = 0; pi < q.nphrases; ++pi) {
+                        const DevPhrase ph = phrases[q.phrase_base + pi];
+                        uint32_t rows = 0;
+                        for (uint32_t k = 0; k < ph.nterms; ++k) {
+                                bool seen = false;
+                                for (uint32_t m = 0; m < k; ++m)
+                                        seen |= pterms[ph.term_base + m] == pterms[ph.term_base + k];
+                                rows += !seen;
+                        }
+                        maxrows = max(maxrows, rows);
+                }
+                const uint32_t tile = uni(min(PHRASE_TILE, max((uint32_t)AND_WG, (PHRASE_SLOTS / maxrows) & ~(uint32_t)(AND_WG - 1))));
                 uint32_t wpos = 0;
-                for (uint32_t tb = 0; tb < M; tb += AND_WG) {
-                        const uint32_t j = tb + tid;
-                        const bool have = j < M;
-                        const uint32_t doc = have ? seg[j] : 0;
-                        bool ok = have;
-                        double ps = 0;
+                for (uint32_t tb = 0; tb < M; tb += tile) {
+                        const uint32_t C = min(tile, M - tb);
+                        for (uint32_t j = tid; j < C; j += AND_WG) {
+                                sh.cdoc[j] = seg[tb + j];
+                                sh.alive[j] = 1;
+                                sh.ps[j] = 0;
+                        }
+                        __syncthreads();
+                        const uint32_t cmin = sh.cdoc[0], cmax = sh.cdoc[C - 1];
                         for (uint32_t pi = 0; pi < q.nphrases; ++pi) {
                                 const DevPhrase ph = phrases[q.phrase_base + pi];
-                                uint32_t cnt = 0;
-                                if (ok) {
-                                        // materialise: hit address + freq of every distinct phrase term (first occurrence order)
-                                        for (uint32_t k = 0; k < ph.nterms; ++k) {
-                                                const uint32_t tk = pterms[ph.term_base + k];
-                                                uint32_t first = k;
-                                                for (uint32_t m = 0; m < k; ++m)
-                                                        if (pterms[ph.term_base + m] == tk) {
-                                                                first = m;
-                                                                break;
-                                                        }
-                                                if (first == k) {
+                                // ---- locate: (hits locator, freq) of every candidate for every distinct phrase term
+                                uint32_t rows = 0;
+                                for (uint32_t k = 0; k < ph.nterms; ++k) {
+                                        const uint32_t tk = pterms[ph.term_base + k];
+                                        uint32_t first = k;
+                                        for (uint32_t m = 0; m < k; ++m)
+                                                if (pterms[ph.term_base + m] == tk) {
+                                                        first = m;
+                                                        break;
+                                                }
+                                        if (first != k) {
+                                                sh.row[k] = uni(sh.row[first]); // uniform store
+                                                continue;
+                                        }
+                                        const uint32_t slot0 = rows * tile;
+                                        sh.row[k] = rows++;
+                                        const DevTerm t = terms[tk];
+                                        const uint32_t *bl = blk_last + t.first_block;
+                                        const uint32_t b0 = wg_lower_bound<AND_WG>(sh.scan, bl, t.nblocks, cmin);
+                                        uint32_t b1 = b0;
+                                        if (b0 < t.nblocks) {
+                                                b1 = b0 + wg_lower_bound<AND_WG>(sh.scan, bl + b0, t.nblocks - b0, cmax);
+                                                if (b1 >= t.nblocks)
+                                                        b1 = t.nblocks - 1;
+                                        }
+                                        __syncthreads();
+                                        if (b0 < t.nblocks && b1 - b0 + 1 <= 2 * C) {
+                                                for (uint32_t b = b0 + tid; b <= b1; b += AND_WG)
+                                                        phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, t, b, C, slot0);
+                                        } else {
+                                                for (uint32_t j = tid; j < C; j += AND_WG) {
                                                         uint32_t ho, f;
-                                                        phrase_locate<CODEC>(index, blk_last, blk_off, ctx, terms[tk], doc, ho, f);
-                                                        sh.hits_off[k][tid] = ho;
-                                                        sh.freq[k][tid] = f;
-                                                } else {
-                                                        sh.hits_off[k][tid] = sh.hits_off[first][tid];
-                                                        sh.freq[k][tid] = sh.freq[first][tid];
+                                                        phrase_locate<CODEC>(index, blk_last, blk_off, ctx, t, sh.cdoc[j], ho, f);
+                                                        sh.hits_off[slot0 + j] = ho;
+                                                        sh.freq[slot0 + j] = f;
                                                 }
                                         }
+                                        __syncthreads();
+                                }
+                                // ---- check: one lane per candidate
+                                for (uint32_t j = tid; j < C; j += AND_WG) {
+                                        if (!sh.alive[j])
+                                                continue;
+                                        uint32_t cnt = 0;
                                         // walk the start positions of term 0 (docset_iterators.cpp:101-143)
                                         HitStream<CODEC> s0;
-                                        s0.init(ctx, terms[pterms[ph.term_base]].pad, sh.hits_off[0][tid]);
+                                        s0.init(ctx, terms[pterms[ph.term_base]].pad, sh.hits_off[sh.row[0] * tile + j]);
                                         uint32_t p0 = 0;
-                                        const uint32_t f0 = sh.freq[0][tid] & HitStream<CODEC>::FREQ_MASK;
+                                        const uint32_t f0 = sh.freq[sh.row[0] * tile + j] & HitStream<CODEC>::FREQ_MASK;
                                         for (uint32_t h = 0; h < f0 && cnt < max_match_cnt; ++h) {
                                                 p0 = (p0 + s0.next()) & 0xffffu;
                                                 if (!p0)
@@ -269,9 +403,11 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                 for (uint32_t k = 1; k < ph.nterms && all; ++k) {
                                                         const uint32_t qpos = p0 + k;
                                                         const uint32_t tk = pterms[ph.term_base + k];
+                                                        const uint32_t rk = sh.row[k];
                                                         // dws->test(term_k, qpos): term k has a hit there …
-                                                        all = phrase_has_pos<CODEC>(ctx, terms[tk].pad, sh.hits_off[k][tid], sh.freq[k][tid], qpos);
-                                                        // … and no term materialised after it overwrote the slot (last writer wins)
+                                                        all = phrase_has_pos<CODEC>(ctx, terms[tk].pad, sh.hits_off[rk * tile + j], sh.freq[rk * tile + j], qpos);
+                                                        // … and no term materialised after it overwrote the slot (last writer wins; only first
+                                                        // occurrences materialise, in phrase order)
                                                         uint32_t firstk = k;
                                                         for (uint32_t m = 0; m < k; ++m)
                                                                 if (pterms[ph.term_base + m] == tk) {
@@ -282,41 +418,48 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                                 const uint32_t tm = pterms[ph.term_base + m];
                                                                 if (tm == tk)
                                                                         continue;
-                                                                bool seen = false; // only first occurrences materialise
+                                                                bool seen = false;
                                                                 for (uint32_t z = 0; z < m; ++z)
                                                                         seen |= pterms[ph.term_base + z] == tm;
-                                                                if (!seen && phrase_has_pos<CODEC>(ctx, terms[tm].pad, sh.hits_off[m][tid], sh.freq[m][tid], qpos))
+                                                                const uint32_t rm = sh.row[m];
+                                                                if (!seen && phrase_has_pos<CODEC>(ctx, terms[tm].pad, sh.hits_off[rm * tile + j], sh.freq[rm * tile + j], qpos))
                                                                         all = false;
                                                         }
                                                 }
                                                 if (all)
                                                         ++cnt;
                                         }
-                                        ok = cnt != 0;
+                                        if (!cnt)
+                                                sh.alive[j] = 0;
                                         // docset_iterators_scorers.cpp:220-224: scorer->score(id, matchCnt, weight)
                                         const uint16_t mc = (uint16_t)cnt;
-                                        ps += (double)(float)(ph.weight * (double)(float)mc / (double)((float)mc + 1.2f));
+                                        sh.ps[j] += (double)(float)(ph.weight * (double)(float)mc / (double)((float)mc + 1.2f));
                                 }
+                                __syncthreads();
                         }
-                        // stable in-place compaction of the survivors (the write cursor never passes the read cursor)
-                        const uint64_t m = __ballot(ok);
-                        const uint32_t before = __popcll(m & ((1ull << (tid & 63)) - 1ull));
-                        sh.scan[tid >> 6] = __popcll(m);
-                        __syncthreads();
-                        uint32_t base = 0, tot = 0;
-                        for (uint32_t w = 0; w < AND_WG / 64; ++w) {
-                                if (w < (tid >> 6))
-                                        base += sh.scan[w];
-                                tot += sh.scan[w];
+                        // ---- stable in-place compaction of the survivors (the write cursor never passes the read cursor)
+                        for (uint32_t base = 0; base < C; base += AND_WG) {
+                                const uint32_t j = base + tid;
+                                const bool ok = j < C && sh.alive[j];
+                                const uint64_t m = __ballot(ok);
+                                const uint32_t before = __popcll(m & ((1ull << (tid & 63)) - 1ull));
+                                sh.scan[tid >> 6] = __popcll(m);
+                                __syncthreads();
+                                uint32_t wbase = 0, tot = 0;
+                                for (uint32_t w = 0; w < AND_WG / 64; ++w) {
+                                        if (w < (tid >> 6))
+                                                wbase += sh.scan[w];
+                                        tot += sh.scan[w];
+                                }
+                                tot = uni(tot);
+                                if (ok) {
+                                        seg[wpos + wbase + before] = sh.cdoc[j];
+                                        if (pscore)
+                                                pscore[task.out_off + wpos + wbase + before] = sh.ps[j];
+                                }
+                                wpos += tot;
+                                __syncthreads();
                         }
-                        tot = uni(tot);
-                        if (ok) {
-                                seg[wpos + base + before] = doc;
-                                if (pscore)
-                                        pscore[task.out_off + wpos + base + before] = ps;
-                        }
-                        wpos += tot;
-                        __syncthreads();
                 }
                 if (wave == 0)
                         counts[tix] = wpos;
