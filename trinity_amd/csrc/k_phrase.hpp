@@ -305,6 +305,8 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
         const HitCtx ctx{CODEC == CODEC_GOOGLE ? index : hits, blk_hits, hdir};
+        PROF_DECL;
+        PROF_START();
         for (;;) {
                 if (wave == 0) {
                         const uint32_t old = atomicAdd(ticket, 1u);
@@ -344,6 +346,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                         }
                         __syncthreads();
                         const uint32_t cmin = sh.cdoc[0], cmax = sh.cdoc[C - 1];
+                        PROF_LAP(0);
                         for (uint32_t pi = 0; pi < q.nphrases; ++pi) {
                                 const DevPhrase ph = phrases[q.phrase_base + pi];
                                 // ---- locate: (hits locator, freq) of every candidate for every distinct phrase term
@@ -385,6 +388,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                         }
                                         __syncthreads();
                                 }
+                                PROF_LAP(1);
                                 // ---- check: one lane per candidate
                                 for (uint32_t j = tid; j < C; j += AND_WG) {
                                         if (!sh.alive[j])
@@ -435,7 +439,9 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                         const uint16_t mc = (uint16_t)cnt;
                                         sh.ps[j] += (double)(float)(ph.weight * (double)(float)mc / (double)((float)mc + 1.2f));
                                 }
+                                PROF_LAP(2);
                                 __syncthreads();
+                                PROF_LAP(3);
                         }
                         // ---- stable in-place compaction of the survivors (the write cursor never passes the read cursor)
                         for (uint32_t base = 0; base < C; base += AND_WG) {
@@ -464,5 +470,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                 if (wave == 0)
                         counts[tix] = wpos;
                 __syncthreads();
+                PROF_LAP(4);
         }
+        PROF_FLUSH();
 }
