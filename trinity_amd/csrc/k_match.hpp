@@ -763,7 +763,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
 
 // bitmap-window tasks: persistent 512-thread workgroups draw TASK_DENSE tasks, heaviest first
 template <int CODEC>
-__global__ __launch_bounds__(DENSE_WG) void k_and_dense(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+__global__ __launch_bounds__(DENSE_WG, 8) void k_and_dense(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                         const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
                                                         const DevTerm *__restrict__ terms, const DevQuery *__restrict__ plan,
                                                         const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched,
