@@ -796,7 +796,10 @@ __global__ __launch_bounds__(DENSE_WG, 8) void k_and_dense(const uint8_t *__rest
 
 // candidate-tile tasks (TASK_CAND)
 template <int CODEC>
-__global__ __launch_bounds__(AND_WG) void k_and(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+#ifndef TRI_AND_WAVES
+#define TRI_AND_WAVES 4
+#endif
+__global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                 const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
                                                 const DevTerm *__restrict__ terms,
                                                 const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
