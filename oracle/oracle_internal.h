@@ -33,7 +33,8 @@ struct to_iter { /* docset_iterators_base.h:45-96 Iterator + relevant_documents.
 #define TO_PLI_HEAD                                                  \
         to_iter it;                                                  \
         uint16_t freq; /* codecs.h:217 tokenpos_t */                 \
-        double idf;    /* docset_iterators_scorers.cpp:10-36 */      \
+        double idf;    /* the term's ScorerWeight (docset_iterators_scorers.cpp:10-36): BM25 idf, TF-IDF idf, unused for Trivial */ \
+        int sim;       /* TO_SIM_* of the index at creation time */  \
         uint32_t term, documents;                                    \
         uint32_t (*materialize)(struct to_pli *, uint16_t *out_pos); \
         void (*destroy)(struct to_pli *);

@@ -131,6 +131,10 @@ int main(int argc, char **argv) {
         collection.insert(src);
         // NB: collection.commit() only gathers masked documents (index_source.cpp:3-30); there are none.
         Similarity::IndexSourcesCollectionBM25Scorer bm25;
+        Similarity::IndexSourcesCollectionTFIDFScorer tfidf;
+        Similarity::IndexSourcesCollectionTrivialScorer trivial;
+        Similarity::IndexSourcesCollectionTermsScorer *collScorer = &bm25; // `sim bm25|tfidf|trivial` switches it
+        std::string simName = "bm25";
         auto noMasked = masked_documents_registry::make(nullptr, 0);
 
         std::string line;
@@ -240,6 +244,12 @@ int main(int argc, char **argv) {
                                 ++cnt;
                         }
                         printf("{\"cmd\":\"positions\",\"term\":%u,\"nth\":%u,\"docs\":%u,\"fnv\":\"%" PRIu64 "\"}\n", t, nth, cnt, h);
+                } else if (cmd == "sim") {
+                        is >> simName;
+                        collScorer = simName == "tfidf" ? static_cast<Similarity::IndexSourcesCollectionTermsScorer *>(&tfidf)
+                                     : simName == "trivial" ? static_cast<Similarity::IndexSourcesCollectionTermsScorer *>(&trivial)
+                                                            : static_cast<Similarity::IndexSourcesCollectionTermsScorer *>(&bm25);
+                        printf("{\"cmd\":\"sim\",\"name\":\"%s\"}\n", simName.c_str());
                 } else if (cmd == "query" || cmd == "queryfull") {
                         uint32_t flags, k = 0;
                         is >> flags;
@@ -253,15 +263,15 @@ int main(int argc, char **argv) {
                         query q{str32_t(text.data(), uint32_t(text.size()))};
                         std::unique_ptr<Similarity::IndexSourceTermsScorer> scorer;
                         if (flags & unsigned(ExecFlags::AccumulatedScoreScheme)) {
-                                bm25.reset(&collection);
-                                scorer.reset(bm25.new_source_scorer(src));
+                                collScorer->reset(&collection);
+                                scorer.reset(collScorer->new_source_scorer(src));
                         }
                         exec_query(q, src, noMasked.get(), &coll, nullptr, flags, scorer.get());
                         const size_t n = coll.ids.size(), kk = n < 16 ? n : 16;
                         double ssum = 0;
                         for (auto s : coll.scores)
                                 ssum += s;
-                        printf("{\"cmd\":\"%s\",\"flags\":%u,\"q\":\"", cmd.c_str(), flags);
+                        printf("{\"cmd\":\"%s\",\"flags\":%u,\"sim\":\"%s\",\"q\":\"", cmd.c_str(), flags, simName.c_str());
                         for (char c : text) {
                                 if (c == '"')
                                         printf("\\\"");

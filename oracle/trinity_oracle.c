@@ -759,7 +759,8 @@ to_pli *to_pli_new(const to_index *ix, uint32_t term) {
                 it->p = ptr + 2;
         } else
                 pli_finalize(it);
-        it->idf = to_bm25_idf(t->documents, ix->docsCnt);
+        it->sim = ix->similarity;
+        it->idf = to_sim_weight(ix->similarity, t->documents, ix->docsCnt);
         return it;
 }
 
@@ -801,10 +802,28 @@ float to_bm25_score(double idf, uint16_t freq) {
         return (float)(idf * (float)freq / (double)((float)freq + norm));
 }
 
+double to_sim_weight(int sim, uint32_t docFreq, uint64_t docsCnt) {
+        if (sim == TO_SIM_TFIDF)
+                return log((double)(docsCnt + 1) / (double)(docFreq + 1)) + 1.0; /* u64 / double -> double division */
+        if (sim == TO_SIM_TRIVIAL)
+                return 0.0;
+        return to_bm25_idf(docFreq, docsCnt);
+}
+
+float to_sim_score(int sim, double weight, uint16_t freq) {
+        if (sim == TO_SIM_TFIDF) {
+                const float tf = sqrtf((float)freq);
+                return (float)(tf * weight);
+        }
+        if (sim == TO_SIM_TRIVIAL)
+                return (float)freq;
+        return to_bm25_score(weight, freq);
+}
+
 /* docset_iterators_scorers.cpp:28-32 */
 double to_pli_score_bm25(to_iter *self) {
         to_pli *it = (to_pli *)self;
-        return to_bm25_score(it->idf, it->freq);
+        return to_sim_score(it->sim, it->idf, it->freq);
 }
 
 /* ================================================================== Conjuction */
@@ -999,6 +1018,7 @@ typedef struct { /* docset_iterators.h:364-402 */
         uint16_t maxMatchCnt, matchCnt;
         uint16_t execTermID[MAX_PHRASE]; /* distinct per distinct term (queryexec_ctx::resolve_term) */
         double weight;                   /* similarity.h:202-226: sum of the terms' idf */
+        int sim;                         /* TO_SIM_* */
         to_dws *dws;
         uint16_t *hits0;
         uint16_t *scratch;
@@ -1120,7 +1140,7 @@ static uint32_t phrase_advance(to_iter *self, uint32_t target) {
 /* docset_iterators_scorers.cpp:195-228: scorer->score(id, matchCnt, weight) */
 static double phrase_score(to_iter *self) {
         to_phrase *ph = (to_phrase *)self;
-        return to_bm25_score(ph->weight, ph->matchCnt);
+        return to_sim_score(ph->sim, ph->weight, ph->matchCnt);
 }
 
 /* ================================================================== plan -> iterator tree */
@@ -1314,6 +1334,7 @@ static to_iter *build_iter(to_ctx *c, const pnode *n) {
                         ph->it.next = phrase_next;
                         ph->it.advance = phrase_advance;
                         ph->it.score = phrase_score;
+                        ph->sim = c->ix->similarity;
                         ph->it.cost = n->cost;
                         ph->size = ph->nterms = (uint16_t)n->nkids;
                         ph->its = (to_pli **)ctx_own(c, xmalloc(sizeof(to_pli *) * n->nkids));
@@ -1322,7 +1343,7 @@ static to_iter *build_iter(to_ctx *c, const pnode *n) {
                         for (uint32_t i = 0; i < n->nkids; ++i) {
                                 ph->its[i] = (to_pli *)ctx_own(c, to_pli_new(c->ix, n->kids[i]->term));
                                 ph->execTermID[i] = ctx_term_id(c, n->kids[i]->term);
-                                ph->weight += to_bm25_idf(c->ix->terms[n->kids[i]->term].documents, c->ix->docsCnt);
+                                ph->weight += to_sim_weight(c->ix->similarity, c->ix->terms[n->kids[i]->term].documents, c->ix->docsCnt);
                         }
                         ph->dws = (to_dws *)ctx_own(c, xcalloc(1, sizeof(to_dws)));
                         ph->hits0 = (uint16_t *)ctx_own(c, xmalloc(sizeof(uint16_t) * 65536));

@@ -95,7 +95,13 @@ typedef struct to_index {
         int codec;     /* TO_CODEC_GOOGLE (default, 0 also means Google) or TO_CODEC_LUCENE */
         uint8_t *hits; /* Lucene: the segment's hits.data (lucene_codec.h:206) */
         size_t hits_len;
+        int similarity; /* TO_SIM_*: which Similarity::IndexSourcesCollection*Scorer AccumulatedScoreScheme queries use */
 } to_index;
+
+/* similarity.h: BM25 :165-255 (default), TF-IDF :75-163, Trivial :56-72 */
+#define TO_SIM_BM25 0
+#define TO_SIM_TFIDF 1
+#define TO_SIM_TRIVIAL 2
 
 #define TO_CODEC_GOOGLE 1
 #define TO_CODEC_LUCENE 2
@@ -142,6 +148,11 @@ uint32_t to_decode_term(const to_index *, uint32_t term, uint32_t *docs, uint32_
 double to_bm25_idf(uint32_t docFreq, uint64_t docsCnt);
 /* similarity.h:228-235 */
 float to_bm25_score(double idf, uint16_t freq);
+/* the ScorerWeight contribution of one term (new_scorer_weight sums it over a phrase's terms) and score(id, freq, weight)
+ * of the three scorers: BM25 as above; TF-IDF similarity.h:85-87 idf = log((docsCnt+1)/(double)(df+1)) + 1, :92-94
+ * tf = sqrt(float freq), :133-138 score = tf * weight; Trivial :64-66 score = freq, no weight */
+double to_sim_weight(int sim, uint32_t docFreq, uint64_t docsCnt);
+float to_sim_score(int sim, double weight, uint16_t freq);
 
 /* ------------------------------------------------------------------ query execution     */
 typedef struct to_result {

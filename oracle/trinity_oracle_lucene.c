@@ -524,7 +524,8 @@ to_pli *to_lucene_pli_new(const to_index *ix, uint32_t term) {
         it->documents = t->documents;
         it->materialize = l_materialize;
         it->destroy = l_destroy;
-        it->idf = to_bm25_idf(t->documents, ix->docsCnt);
+        it->sim = ix->similarity;
+        it->idf = to_sim_weight(ix->similarity, t->documents, ix->docsCnt);
         it->curSkipListLastDocID = TO_DOCIDS_END;
         if (!t->size) {
                 it->it.cur = TO_DOCIDS_END;

@@ -94,6 +94,19 @@ int main(int argc, char **argv) {
                         exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
                         show("not_scored", c);
                 }
+                { // the other scorers of similarity.h through the same seam
+                        Similarity::IndexSourcesCollectionTFIDFScorer tfidf;
+                        std::unique_ptr<Similarity::IndexSourceTermsScorer> s2(tfidf.new_source_scorer(&src));
+                        Collect c;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1"), src.disjunction({src.term("t2"), src.term("t3")})}), &src, &c, nullptr,
+                                   unsigned(ExecFlags::AccumulatedScoreScheme), s2.get());
+                        show("tfidf_scored", c);
+                        Similarity::IndexSourcesCollectionTrivialScorer trivial;
+                        std::unique_ptr<Similarity::IndexSourceTermsScorer> s3(trivial.new_source_scorer(&src));
+                        Collect c3;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, &c3, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), s3.get());
+                        show("trivial_scored", c3);
+                }
                 { // masked documents: every 3rd document of the segment was superseded by a newer one
                         std::vector<docid_t> masked;
                         for (docid_t d = 3; d <= fs.docsCnt; d += 3)

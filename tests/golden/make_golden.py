@@ -68,6 +68,16 @@ def commands_for(name, D, V, slots, seed):
                     cmds.append(f"queryfull {flags} {text}")
                 else:
                     cmds.append(f"query {flags} {10 if flags == 2 else 0} {text}")
+    # the other two scorers of similarity.h (TF-IDF :75-163, Trivial :56-72) on a subset: scored records carry "sim"
+    SIM_TEMPLATES = ["t{a} t{b}", "t{a} OR t{b} OR t{c}", "t{a} t{b} (t{c} OR t{d} OR t{e})", '"t{a} t{b}" t{c}', "t{a} t{b} NOT t{c}"]
+    for sim in ("tfidf", "trivial"):
+        cmds.append(f"sim {sim}")
+        for ri, row in enumerate(head + qs.tolist()[:5]):
+            a, b, c, d, e = [int(x) for x in row]
+            for tpl in SIM_TEMPLATES:
+                text = tpl.format(a=a, b=b, c=c, d=d, e=e)
+                cmds.append(f"queryfull 2 {text}" if name == "tiny" and ri < 2 else f"query 2 10 {text}")
+    cmds.append("sim bm25")
     # a term with zero documents (if the corpus has one) and an out-of-vocabulary term
     cmds.append(f"query 1 0 t0 t{V + 5}")
     cmds.append(f"query 1 0 t0 OR t{V + 5}")

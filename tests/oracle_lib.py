@@ -18,6 +18,7 @@ DOCIDS_END = 0xFFFFFFFF
 FLAG_DOCUMENTS_ONLY = 1
 FLAG_ACCUM_SCORE = 2
 OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT = 0, 1, 2, 3, 4
+SIM_BM25, SIM_TFIDF, SIM_TRIVIAL = 0, 1, 2
 
 
 def tok(op, arg):
@@ -44,6 +45,7 @@ class ToIndex(C.Structure):
         ("codec", C.c_int),
         ("hits", C.POINTER(C.c_uint8)),
         ("hits_len", C.c_size_t),
+        ("similarity", C.c_int),
     ]
 
 
@@ -216,6 +218,10 @@ class Index:
             scores = np.ctypeslib.as_array(r.scores, shape=(r.n,)).copy() if r.n else np.zeros(0, np.float64)
         lib().to_result_free(C.byref(r))
         return docs, scores
+
+    def set_similarity(self, sim):
+        """SIM_BM25 (default) / SIM_TFIDF / SIM_TRIVIAL: the scorer AccumulatedScoreScheme queries use (similarity.h)."""
+        self.ptr.contents.similarity = int(sim)
 
     def set_masked(self, docids):
         d = np.ascontiguousarray(docids, dtype=np.uint32)

@@ -223,8 +223,11 @@ def test_and_properties_at_scale(medium):
 
 
 # ------------------------------------------------------------------------------------------ BM25 + top-K (K5)
-def run_scored(w, programs, k):
-    b = w.T.Batch(w.ix, programs, w.T.FLAG_ACCUMULATED_SCORE, topk=k)
+SIMS = {"bm25": 0, "tfidf": 1, "trivial": 2}  # TRI_SIM_* == O.SIM_*
+
+
+def run_scored(w, programs, k, similarity=0):
+    b = w.T.Batch(w.ix, programs, w.T.FLAG_ACCUMULATED_SCORE, topk=k, similarity=similarity)
     b.run()
     b.sync()
     d, s, c = b.topk_results()
@@ -258,16 +261,18 @@ def test_scored_against_reference_fixtures(T, dev):
         g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
         c = g["corpus"]
         w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
-        recs = [r for r in g["results"] if r["cmd"] == "query" and r["flags"] == 2 and "top" in r and gpu_lowers(r["q"])]
-        d, s, cnt, counts = run_scored(w, [O.parse_query(r["q"]) for r in recs], 10)
-        for i, r in enumerate(recs):
-            assert int(counts[i]) == r["n"], r["q"]
-            top = r["top"]
-            assert d[i, : len(top)].tolist() == [x[0] for x in top], r["q"]
-            np.testing.assert_allclose(s[i, : len(top)], [x[1] for x in top], rtol=1e-5)
-            checked += 1
+        for sim, simid in SIMS.items():  # BM25 and the TF-IDF / Trivial scorers of similarity.h, all from the genuine reference
+            recs = [r for r in g["results"] if r["cmd"] == "query" and r["flags"] == 2 and "top" in r and gpu_lowers(r["q"]) and r.get("sim", "bm25") == sim]
+            assert len(recs) >= 15, sim
+            d, s, cnt, counts = run_scored(w, [O.parse_query(r["q"]) for r in recs], 10, similarity=simid)
+            for i, r in enumerate(recs):
+                assert int(counts[i]) == r["n"], r["q"]
+                top = r["top"]
+                assert d[i, : len(top)].tolist() == [x[0] for x in top], (sim, r["q"])
+                np.testing.assert_allclose(s[i, : len(top)], [x[1] for x in top], rtol=1e-5)
+                checked += 1
         w.ix.close()
-    assert checked >= 90
+    assert checked >= 150
 
 
 # ------------------------------------------------------------------------------------------ OR and mixed AND/OR (K4)
@@ -625,3 +630,24 @@ def test_masked_documents_are_dropped(T, dev, codec, monkeypatch):
     for got, full in zip(sets, base_sets):
         assert np.array_equal(got, full)
     w.ix.close()
+
+
+@pytest.mark.parametrize("sim", ["tfidf", "trivial"])
+@pytest.mark.parametrize("world", ["small", "small_l"])
+def test_other_similarities_match_oracle(request, world, sim):
+    """IndexSourcesCollectionTFIDFScorer / ...TrivialScorer (similarity.h:75-163 / 56-72) through k_score and k_phrase."""
+    w = request.getfixturevalue(world)
+    texts = template_queries(w, 91, 6) + phrase_queries(w, 92, 2) + [t for t in not_queries(w, 93, 2) if '"' not in t] + ["t0 t1", "t5"]
+    progs = [O.parse_query(t) for t in texts]
+    w.ora.set_similarity(SIMS[sim])
+    try:
+        d, s, c, counts = run_scored(w, progs, 50, similarity=SIMS[sim])
+        for i, t in enumerate(texts):
+            docs, scores = w.ora.exec(progs[i], O.FLAG_ACCUM_SCORE)
+            assert int(counts[i]) == len(docs), t
+            td, ts = w.ora.topk(docs, scores, 50)
+            # Trivial scores are small integers: ties everywhere, so the tie rule (docID ascending) is what is being checked
+            assert d[i, : len(td)].tolist() == td.tolist(), (sim, t)
+            np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+    finally:
+        w.ora.set_similarity(0)

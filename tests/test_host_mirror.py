@@ -44,8 +44,10 @@ def test_mirror_results_match_oracle(T, tmp_path):
         k, _, rest = l.partition(" ")
         lines[k] = dict(kv.split("=") for kv in rest.split() if "=" in kv) or rest
 
-    def expect(name, text, flags, keep=None):
+    def expect(name, text, flags, keep=None, sim=0):
+        ora.set_similarity(sim)
         docs, scores = ora.exec(O.parse_query(text), flags)
+        ora.set_similarity(0)
         if keep is not None:
             m = keep(docs)
             docs = docs[m]
@@ -62,6 +64,8 @@ def test_mirror_results_match_oracle(T, tmp_path):
     expect("or_even", "t3 OR t7", 1, keep=lambda d: (d & 1) == 0)
     expect("phrase_scored", '"t0 t1" t2', 2)
     expect("not_scored", "t3 t5 NOT (t1 OR t2)", 2)
+    expect("tfidf_scored", "t0 t1 (t2 OR t3)", 2, sim=O.SIM_TFIDF)
+    expect("trivial_scored", "t0 t1", 2, sim=O.SIM_TRIVIAL)
     expect("masked_scored", "t0 t1", 2, keep=lambda d: (d % 3) != 0)
     assert int(lines["unknown"]["n"]) == 0
     expect("batch0", "t1 t2", 1)

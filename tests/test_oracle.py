@@ -183,6 +183,7 @@ def test_queries_match_reference(golden):
     for r in g["results"]:
         if r["cmd"] not in ("query", "queryfull"):
             continue
+        ix.set_similarity({"bm25": O.SIM_BM25, "tfidf": O.SIM_TFIDF, "trivial": O.SIM_TRIVIAL}[r.get("sim", "bm25")])
         docs, scores = ix.exec(O.parse_query(r["q"]), r["flags"])
         assert len(docs) == r["n"], r["q"]
         assert str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]  # bit-exact docID set, ascending
@@ -201,6 +202,7 @@ def test_queries_match_reference(golden):
         elif "docs" in r:
             assert docs.tolist() == r["docs"]
         n += 1
+    ix.set_similarity(O.SIM_BM25)
     assert n > 200
 
 
@@ -290,6 +292,7 @@ def test_lucene_codec_results_equal_reference_fixtures(both_codecs):
             d, f = lx.decode_term(r["term"])
             assert str(O.fnv1a_docs(d)) == r["docs_fnv"] and str(O.fnv1a_docs(f)) == r["freqs_fnv"]
         elif r["cmd"] in ("query", "queryfull"):
+            lx.set_similarity({"bm25": O.SIM_BM25, "tfidf": O.SIM_TFIDF, "trivial": O.SIM_TRIVIAL}[r.get("sim", "bm25")])
             docs, scores = lx.exec(O.parse_query(r["q"]), r["flags"])
             assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
             if r["flags"] & 2:

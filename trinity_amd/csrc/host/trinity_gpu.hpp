@@ -433,6 +433,41 @@ namespace trinity_amd {
                         };
                         IndexSourceTermsScorer *new_source_scorer(IndexSource *s) override { return new Scorer(this, s); }
                 };
+
+                // similarity.h:75-163: idf = log((docsCnt + 1) / double(df + 1)) + 1, tf = sqrt(float freq), score = tf * weight
+                struct IndexSourcesCollectionTFIDFScorer : public IndexSourcesCollectionTermsScorer {
+                        struct Scorer final : public IndexSourceTermsScorer {
+                                struct Weight final : public ScorerWeight {
+                                        const double v;
+                                        explicit Weight(double value)
+                                            : v{value} {}
+                                };
+                                using IndexSourceTermsScorer::IndexSourceTermsScorer;
+                                static double idf(const uint32_t docFreq, const uint64_t docsCnt) { return std::log((docsCnt + 1) / double(docFreq + 1)) + 1.0; }
+                                ScorerWeight *new_scorer_weight(const std::string *terms, uint16_t cnt) override {
+                                        double w = 0;
+                                        for (uint16_t i = 0; i != cnt; ++i)
+                                                w += idf(src->resolve_term_ctx(terms[i]).documents, src->default_field_stats().docsCnt);
+                                        return new Weight(w);
+                                }
+                                float score(isrc_docid_t, uint16_t freq, const ScorerWeight *w) override { return std::sqrt(float(freq)) * static_cast<const Weight *>(w)->v; }
+                                int device_similarity() const override { return TRI_SIM_TFIDF; }
+                                double device_weight(const ScorerWeight *w) const override { return static_cast<const Weight *>(w)->v; }
+                        };
+                        IndexSourceTermsScorer *new_source_scorer(IndexSource *s) override { return new Scorer(this, s); }
+                };
+
+                // similarity.h:56-72: score = freq, no weight
+                struct IndexSourcesCollectionTrivialScorer : public IndexSourcesCollectionTermsScorer {
+                        struct Scorer final : public IndexSourceTermsScorer {
+                                using IndexSourceTermsScorer::IndexSourceTermsScorer;
+                                ScorerWeight *new_scorer_weight(const std::string *, uint16_t) override { return nullptr; }
+                                float score(isrc_docid_t, uint16_t freq, const ScorerWeight *) override { return freq; }
+                                int device_similarity() const override { return TRI_SIM_TRIVIAL; }
+                                double device_weight(const ScorerWeight *) const override { return 0.0; }
+                        };
+                        IndexSourceTermsScorer *new_source_scorer(IndexSource *s) override { return new Scorer(this, s); }
+                };
         } // namespace Similarity
 
         // ------------------------------------------------------------------ execution

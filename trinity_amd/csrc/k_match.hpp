@@ -45,6 +45,18 @@ constexpr uint32_t BM_B_WORDS = SPAN_WORDS + 32;
 constexpr uint32_t BM_STRIDE = BM_B_WORDS + BM_B_WORDS / 32; // physical words per bitmap == pad(BM_B_WORDS)
 __device__ __forceinline__ uint32_t bm_pad(const uint32_t w) { return w + (w >> 5); }
 
+// IndexSourceTermsScorer::score(id, freq, weight) of the three scorers of similarity.h — BM25 :228-235
+// float(idf * float(f) / double(f + 1.2f)); TF-IDF :92-94, :133-138 float(sqrt(float f) * weight); Trivial :64-66 f.
+// freq is what PostingsListIterator::freq / Phrase::matchCnt expose: tokenpos_t, 16 bits (codecs.h:217).
+__device__ __forceinline__ float sim_score(const int sim, const double weight, const uint32_t freq32) {
+        const float f = (float)(uint16_t)freq32;
+        if (sim == TRI_SIM_TFIDF)
+                return (float)((double)sqrtf(f) * weight);
+        if (sim == TRI_SIM_TRIVIAL)
+                return f;
+        return (float)(weight * (double)f / (double)(f + 1.2f));
+}
+
 // LDS state of the candidate-tile kernel
 struct AndShared {
         uint32_t cand[TILE_CANDS];

@@ -300,7 +300,8 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                    const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
                                                    const uint32_t *__restrict__ ptasks, const uint32_t nptasks, const DevPhrase *__restrict__ phrases,
                                                    const uint32_t *__restrict__ pterms, uint32_t *__restrict__ ticket, uint32_t *__restrict__ out,
-                                                   uint32_t *__restrict__ counts, double *__restrict__ pscore, const uint32_t max_match_cnt) {
+                                                   uint32_t *__restrict__ counts, double *__restrict__ pscore, const uint32_t max_match_cnt,
+                                                   const int sim) {
         __shared__ PhraseShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
@@ -436,8 +437,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                         if (!cnt)
                                                 sh.alive[j] = 0;
                                         // docset_iterators_scorers.cpp:220-224: scorer->score(id, matchCnt, weight)
-                                        const uint16_t mc = (uint16_t)cnt;
-                                        sh.ps[j] += (double)(float)(ph.weight * (double)(float)mc / (double)((float)mc + 1.2f));
+                                        sh.ps[j] += cnt ? (double)sim_score(sim, ph.weight, cnt) : 0.0;
                                 }
                                 PROF_LAP(2);
                                 __syncthreads();

@@ -106,10 +106,6 @@ struct ScoreShared {
         TopK tk;
 };
 
-__device__ __forceinline__ float bm25_term(const double idf, const uint32_t freq32) {
-        const uint16_t freq = (uint16_t)freq32; // PostingsListIterator::freq is tokenpos_t (codecs.h:217)
-        return (float)(idf * (double)(float)freq / (double)((float)freq + 1.2f));
-}
 
 template <int CODEC>
 __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
@@ -120,7 +116,7 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                                   const uint32_t *__restrict__ out, const uint32_t *__restrict__ counts, const uint32_t k,
                                                   uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
                                                   uint32_t *__restrict__ part_counts, double *__restrict__ all_scores,
-                                                  const double *__restrict__ pscore) {
+                                                  const double *__restrict__ pscore, const int sim) {
         __shared__ ScoreShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
@@ -204,7 +200,7 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                         for (uint32_t i = 0; i < n; ++i) {
                                                 const uint32_t f = fs.next();
                                                 if ((mask >> i) & 1u)
-                                                        sh.score[sh.mptr[nm++][tid]] += (double)bm25_term(w, f);
+                                                        sh.score[sh.mptr[nm++][tid]] += (double)sim_score(sim, w, f);
                                         }
                                         PROF_LAP(10);
                                 };

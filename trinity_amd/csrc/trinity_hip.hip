@@ -88,6 +88,7 @@ struct tri_index {
 struct tri_batch {
         tri_index *ix;
         uint32_t flags, topk;
+        int similarity = TRI_SIM_BM25;
         size_t nq;
         std::vector<DevQuery> plan; // execution order (cost descending)
         std::vector<uint32_t> qterms;
@@ -735,14 +736,26 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         const bool scored = mode == TRI_FLAG_ACCUMULATED_SCORE;
         if (scored && topk > TOPK_MAX)
                 return fail(TRI_ERR_INVALID, "AccumulatedScoreScheme: topk <= %u (0 = keep every match's score instead of a top-K)", TOPK_MAX);
-        if (scored && similarity != TRI_SIM_BM25)
-                return fail(TRI_ERR_UNSUPPORTED, "only TRI_SIM_BM25 is lowered");
+        if (similarity != TRI_SIM_BM25 && similarity != TRI_SIM_TFIDF && similarity != TRI_SIM_TRIVIAL)
+                return fail(TRI_ERR_INVALID, "unknown similarity %d", similarity);
+        // the ScorerWeight contribution of one term (IndexSourceTermsScorer::new_scorer_weight sums it over a phrase's terms):
+        // BM25 similarity.h:179-181 (float math), TF-IDF :85-87 (double), Trivial has none
+        auto term_weight = [&](const uint32_t df) -> double {
+                if (similarity == TRI_SIM_TFIDF)
+                        return std::log((double)((uint64_t)ix->info.docs_cnt + 1) / (double)(df + 1)) + 1.0;
+                if (similarity == TRI_SIM_TRIVIAL)
+                        return 0.0;
+                const float num = (float)((uint64_t)ix->info.docs_cnt - (uint64_t)df) + 0.5f;
+                const float den = (float)df + 0.5f;
+                return (double)std::log(1 + num / den);
+        };
         tri_dev *dev = ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
         auto b = std::make_unique<tri_batch>();
         b->ix = ix;
         b->flags = flags;
         b->topk = topk;
+        b->similarity = similarity;
         b->nq = nq;
         b->slot_of_query.assign(nq, UINT32_MAX);
         struct Tmp {
@@ -782,7 +795,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                         const uint32_t x = nodes[k].term;
                                         ph.terms.push_back(x);
                                         const uint32_t df = ix->terms[x].documents;
-                                        ph.weight += (double)std::log(1 + ((float)((uint64_t)ix->info.docs_cnt - (uint64_t)df) + 0.5f) / ((float)df + 0.5f));
+                                        ph.weight += term_weight(df);
                                         bool dup = false;
                                         for (const auto &og : groups)
                                                 dup |= og.size() == 1 && og[0] == x;
@@ -902,10 +915,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         for (uint32_t x : leaves)
                                 sc.emplace_back(x, 0.0);
                         for (auto &e : sc) {
-                                const uint32_t df = ix->terms[e.first].documents;
-                                const float num = (float)((uint64_t)ix->info.docs_cnt - (uint64_t)df) + 0.5f;
-                                const float den = (float)df + 0.5f;
-                                e.second = (double)std::log(1 + num / den);
+                                e.second = term_weight(ix->terms[e.first].documents);
                         }
                         if (weights) {
                                 // caller-provided weights follow the program's TERM tokens; map by first occurrence
@@ -1184,14 +1194,15 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         TRI_LAUNCH(k_phrase, b->ix->codec, dim3(std::min<uint32_t>(np, (uint32_t)dev->cus * 4)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_ptasks, np, b->d_phrases, b->d_pterms,
                                            b->d_ticket + 48, b->d_out, b->d_counts, b->d_pscore,
-                                           (b->flags & TRI_FLAG_ACCUMULATED_SCORE) ? 65535u : 1u); // exec.cpp:296 trackCnt
+                                           (b->flags & TRI_FLAG_ACCUMULATED_SCORE) ? 65535u : 1u, // exec.cpp:296 trackCnt
+                                           b->similarity);
                         HIP_TRY(hipGetLastError());
                 }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                         TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 2)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, n,
                                            b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,
-                                           b->d_all_scores, b->d_pscore);
+                                           b->d_all_scores, b->d_pscore, b->similarity);
                         HIP_TRY(hipGetLastError());
                         const uint32_t nqs = (uint32_t)b->plan.size();
                         if (b->topk)
