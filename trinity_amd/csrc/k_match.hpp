@@ -141,6 +141,32 @@ __device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__rest
         uint32_t doc = prev;
         uint32_t v[8];
         if (CODEC == CODEC_GOOGLE && n == 32 && load_block_bytes32(index + off, v)) {
+                // the (at most 8) candidates that can fall into this block, fetched from LDS in one go and kept in registers as a
+                // shift queue: the per-document step is then an add and a compare, with no LDS round trip in the lane's chain
+                uint32_t c[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                        c[i] = ptr + i < C ? sh.cand[phys(ptr + i)] : 0xffffffffu;
+                if (c[7] > last) {
+                        uint32_t at = ptr;
+#pragma unroll
+                        for (int j = 0; j < 32; ++j) {
+                                doc = j < 31 ? doc + ((v[j >> 2] >> ((j & 3) * 8)) & 0xffu) : last;
+                                while (c[0] <= doc) {
+                                        if (c[0] == doc)
+                                                atomicOr(&sh.hit[at >> 5], 1u << (at & 31));
+                                        ++at;
+#pragma unroll
+                                        for (int i = 0; i < 7; ++i)
+                                                c[i] = c[i + 1];
+                                        c[7] = 0xffffffffu;
+                                }
+                                if (c[0] > last)
+                                        return;
+                        }
+                        return;
+                }
+                // nine or more candidates in one block's range: walk them through LDS
 #pragma unroll
                 for (int j = 0; j < 32; ++j) {
                         doc = j < 31 ? doc + ((v[j >> 2] >> ((j & 3) * 8)) & 0xffu) : last;
@@ -200,7 +226,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound(const uint32_t *__restrict_
 template <int CODEC>
 __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                 const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm t, const uint32_t C,
-                                const uint32_t lcur_slot, const bool block_driven) {
+                                const uint32_t lcur_slot, const bool block_driven PROF_ARG) {
         const uint32_t tid = threadIdx.x;
         const uint32_t *bl = blk_last + t.first_block;
         const uint32_t *bo = blk_off + t.first_block;
@@ -232,6 +258,7 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                 break;
                 }
                 sh.lcur[lcur_slot] = lcur; // uniform value, branch-free store
+                PROF_LAP(5);
                 TRACE(10, lcur, t.nblocks);
                 for (uint32_t cb = lcur; cb < t.nblocks; cb += AND_WG) {
                         TRACE(11, cb, t.nblocks);
@@ -253,8 +280,10 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                         }
                                         uint32_t ptr = lo;
                                         uint32_t cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
+                                        PROF_LAP(6);
                                         if (cv <= last)
                                                 merge_block<CODEC>(sh, index, t, b, bo[b], TRI_BLOCK_N(t, b, index, bo[b]), prev, last, ptr, cv, C);
+                                        PROF_LAP(7);
                                 }
                         }
                         // workgroup-wide OR of `beyond`, branch-free: one ballot per wave, four LDS words
@@ -262,6 +291,7 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                         __syncthreads();
                         const uint32_t any_beyond = uni(sh.scan[4] | sh.scan[5] | sh.scan[6] | sh.scan[7]);
                         __syncthreads();
+                        PROF_LAP(8);
                         if (any_beyond)
                                 break;
                 }
@@ -891,7 +921,7 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                 const bool bd = t.nblocks <= lead.documents;
 #endif
                                 TRACE(3, slot, (k << 16) | (bd ? 1 : 0));
-                                and_filter_tile<CODEC>(sh, index, blk_last, blk_off, win, t, C, k - 1, bd);
+                                and_filter_tile<CODEC>(sh, index, blk_last, blk_off, win, t, C, k - 1, bd PROF_PASS);
                                 TRACE(4, slot, C);
                                 __syncthreads();
                                 PROF_LAP(bd ? 12 : 13);
