@@ -121,26 +121,35 @@ __device__ uint32_t wg_lower_bound(uint32_t *scan, const uint32_t *__restrict__ 
 // hits behind the deltas are never touched in DocumentsOnly mode.  The pointer is derived by arithmetic (not through an
 // integer) so the loads stay global_load (a flat load would also tie up the LDS counter the bitmap atomics use).
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ bool load_block_bytes32(const uint8_t *__restrict__ p, uint32_t (&v)[8]) {
-        const uint32_t sk = (uint32_t)((uintptr_t)p & 3u);
-        const uint8_t *q = p - sk;
+// (issue / finish are separate so that a caller can put other work — an LDS search — between the loads and their first use)
+__device__ __forceinline__ void block_bytes32_issue(const uint8_t *__restrict__ p, uint32_t (&r)[9]) {
+        const uint8_t *q = p - ((uintptr_t)p & 3u);
         const u32x4_a4 A = *(const u32x4_a4 *)q, B = *(const u32x4_a4 *)(q + 16);
-        const uint32_t C = *(const uint32_t *)(q + 32);
-        const uint32_t r[9] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, C};
+        r[0] = A.x, r[1] = A.y, r[2] = A.z, r[3] = A.w, r[4] = B.x, r[5] = B.y, r[6] = B.z, r[7] = B.w;
+        r[8] = *(const uint32_t *)(q + 32);
+}
+__device__ __forceinline__ bool block_bytes32_finish(const uint8_t *__restrict__ p, const uint32_t (&r)[9], uint32_t (&v)[8]) {
+        const uint32_t sk = (uint32_t)((uintptr_t)p & 3u);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
                 v[i] = __builtin_amdgcn_alignbyte(r[i + 1], r[i], sk);
         return ((v[0] | v[1] | v[2] | v[3] | v[4] | v[5] | v[6] | (v[7] & 0x00ffffffu)) & 0x80808080u) == 0;
+}
+__device__ __forceinline__ bool load_block_bytes32(const uint8_t *__restrict__ p, uint32_t (&v)[8]) {
+        uint32_t r[9];
+        block_bytes32_issue(p, r);
+        return block_bytes32_finish(p, r, v);
 }
 
 // Merge one block of term t against the candidates from `ptr` on (cv = candidate at ptr): set the hit bit of every
 // candidate that is a document of the block.  Full blocks of one-byte deltas take the register path above.
 template <int CODEC>
 __device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
-                                            const uint32_t n, const uint32_t prev, const uint32_t last, uint32_t ptr, uint32_t cv, const uint32_t C) {
+                                            const uint32_t n, const uint32_t prev, const uint32_t last, uint32_t ptr, uint32_t cv, const uint32_t C,
+                                            const uint32_t (*raw)[9] = nullptr) {
         uint32_t doc = prev;
         uint32_t v[8];
-        if (CODEC == CODEC_GOOGLE && n == 32 && load_block_bytes32(index + off, v)) {
+        if (CODEC == CODEC_GOOGLE && n == 32 && (raw ? block_bytes32_finish(index + off, *raw, v) : load_block_bytes32(index + off, v))) {
                 // the (at most 8) candidates that can fall into this block, fetched from LDS in one go and kept in registers as a
                 // shift queue: the per-document step is then an add and a compare, with no LDS round trip in the lane's chain
                 uint32_t c[8];
@@ -260,13 +269,35 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                 sh.lcur[lcur_slot] = lcur; // uniform value, branch-free store
                 PROF_LAP(5);
                 TRACE(10, lcur, t.nblocks);
+                // directory entries are fetched one round ahead and the block's payload loads are issued before the LDS search, so
+                // a round costs about one memory round trip instead of three dependent ones
+                uint32_t nprev = 0, nlast = 0, noff = 0;
+                {
+                        const uint32_t b = lcur + tid;
+                        if (b < t.nblocks) {
+                                nprev = b ? bl[b - 1] : 0;
+                                nlast = bl[b];
+                                noff = bo[b];
+                        }
+                }
                 for (uint32_t cb = lcur; cb < t.nblocks; cb += AND_WG) {
                         TRACE(11, cb, t.nblocks);
                         const uint32_t b = cb + tid;
                         bool beyond = true;
+                        const uint32_t prev = nprev, last = nlast, off = noff; // docs of block b lie in (prev, last]
+                        uint32_t raw[9];
+                        const bool full = CODEC == CODEC_GOOGLE && b < t.nblocks && prev < cmax && TRI_BLOCK_N(t, b, index, off) == 32;
+                        if (full)
+                                block_bytes32_issue(index + off, raw);
+                        {
+                                const uint32_t b2 = b + AND_WG;
+                                if (b2 < t.nblocks) {
+                                        nprev = bl[b2 - 1];
+                                        nlast = bl[b2];
+                                        noff = bo[b2];
+                                }
+                        }
                         if (b < t.nblocks) {
-                                const uint32_t prev = b ? bl[b - 1] : 0; // docs of block b lie in (prev, last]
-                                const uint32_t last = bl[b];
                                 beyond = last >= cmax;
                                 if (prev < cmax) {
                                         // first candidate > prev
@@ -282,7 +313,7 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                         uint32_t cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
                                         PROF_LAP(6);
                                         if (cv <= last)
-                                                merge_block<CODEC>(sh, index, t, b, bo[b], TRI_BLOCK_N(t, b, index, bo[b]), prev, last, ptr, cv, C);
+                                                merge_block<CODEC>(sh, index, t, b, off, TRI_BLOCK_N(t, b, index, off), prev, last, ptr, cv, C, full ? &raw : nullptr);
                                         PROF_LAP(7);
                                 }
                         }
