@@ -28,9 +28,40 @@
 using namespace Trinity;
 
 namespace {
+        uint64_t fnv_bytes(const uint8_t *p, size_t n, uint64_t h = 1469598103934665603ull);
         struct Collector final : public MatchedIndexDocumentsFilter {
                 std::vector<docid_t> ids;
                 std::vector<double> scores;
+                // default ("rich match") mode: what consider(const matched_document &) is handed, in a canonical form — the
+                // matched terms sorted by term rank (collect_doc_matching_terms visits them in tree / heap order,
+                // queryexec_ctx.cpp:382-520), each with its freq and positions
+                uint64_t richFnv{1469598103934665603ull}, termsTotal{0}, hitsTotal{0};
+                std::vector<std::vector<uint32_t>> richDocs; // first few documents in full: doc, nterms, {rank, freq, pos...}...
+                void consider(const matched_document &m) override {
+                        ids.push_back(m.id);
+                        std::vector<std::vector<uint32_t>> ts;
+                        for (uint16_t i = 0; i < m.matchedTermsCnt; ++i) {
+                                const auto &mt = m.matchedTerms[i];
+                                const auto tok = mt.queryCtx->term.token;
+                                uint32_t rank = 0;
+                                for (uint32_t k = 1; k < tok.size(); ++k)
+                                        rank = rank * 10 + uint32_t(tok.data()[k] - '0');
+                                std::vector<uint32_t> one{rank, uint32_t(mt.hits->freq)};
+                                for (uint32_t h = 0; h < mt.hits->freq; ++h)
+                                        one.push_back(mt.hits->all[h].pos);
+                                ts.push_back(std::move(one));
+                        }
+                        std::sort(ts.begin(), ts.end());
+                        std::vector<uint32_t> flat{uint32_t(m.id), uint32_t(ts.size())};
+                        for (const auto &one : ts) {
+                                flat.insert(flat.end(), one.begin(), one.end());
+                                hitsTotal += one[1];
+                        }
+                        termsTotal += ts.size();
+                        richFnv = fnv_bytes(reinterpret_cast<const uint8_t *>(flat.data()), flat.size() * 4, richFnv);
+                        if (richDocs.size() < 24)
+                                richDocs.push_back(std::move(flat));
+                }
                 void consider(const docid_t id) override { ids.push_back(id); }
                 void consider(const docid_t id, const double score) override {
                         ids.push_back(id);
@@ -63,7 +94,7 @@ namespace {
                 bool index_empty() const override { return false; }
         };
 
-        uint64_t fnv_bytes(const uint8_t *p, size_t n, uint64_t h = 1469598103934665603ull) {
+        uint64_t fnv_bytes(const uint8_t *p, size_t n, uint64_t h) {
                 for (size_t i = 0; i < n; ++i)
                         h = (h ^ p[i]) * 1099511628211ull;
                 return h;
@@ -283,6 +314,17 @@ int main(int argc, char **argv) {
                         printf(",");
                         print_u32s("last", coll.ids.data() + (n - kk), kk);
                         printf(",\"score_sum\":%.17g", ssum);
+                        if (!(flags & 3u)) {
+                                printf(",\"rich_fnv\":\"%" PRIu64 "\",\"terms_total\":%" PRIu64 ",\"hits_total\":%" PRIu64 ",\"rich_docs\":[", coll.richFnv, coll.termsTotal,
+                                       coll.hitsTotal);
+                                for (size_t i = 0; i < coll.richDocs.size(); ++i) {
+                                        printf("%s[", i ? "," : "");
+                                        for (size_t j = 0; j < coll.richDocs[i].size(); ++j)
+                                                printf("%s%u", j ? "," : "", coll.richDocs[i][j]);
+                                        printf("]");
+                                }
+                                printf("]");
+                        }
                         if (k && !coll.scores.empty()) {
                                 to_result r;
                                 r.docs = coll.ids.data();

@@ -1521,6 +1521,138 @@ int to_exec_query(const to_index *ix, const uint32_t *prog, uint32_t proglen, ui
         return rc;
 }
 
+/* ================================================================== default ("rich match") mode */
+typedef struct {
+        uint32_t terms[64];
+        uint32_t n;
+} termset;
+
+static void termset_add(termset *ts, uint32_t t) {
+        for (uint32_t i = 0; i < ts->n; ++i)
+                if (ts->terms[i] == t)
+                        return;
+        if (ts->n < 64)
+                ts->terms[ts->n++] = t;
+}
+
+/* queryexec_ctx.cpp:382-520 collect_doc_matching_terms: the postings iterators that sit on docID, through the tree */
+static void collect_terms(to_iter *it, uint32_t doc, termset *out) {
+        switch (it->type) {
+                case IT_PLI:
+                        termset_add(out, ((to_pli *)it)->term);
+                        break;
+                case IT_PHRASE: {
+                        to_phrase *ph = (to_phrase *)it;
+                        for (uint16_t i = 0; i < ph->size; ++i)
+                                termset_add(out, ph->its[i]->term);
+                } break;
+                case IT_CONJ: {
+                        to_conj_s *c = (to_conj_s *)it;
+                        for (uint16_t i = 0; i < c->nscore; ++i)
+                                collect_terms(c->c.its[i], doc, out);
+                } break;
+                case IT_DISJ: {
+                        to_disj *d = (to_disj *)it;
+                        for (uint32_t i = 1; i <= d->n; ++i)
+                                if (d->heap[i]->cur == doc)
+                                        collect_terms(d->heap[i], doc, out);
+                } break;
+                case IT_FILTER:
+                        collect_terms(((to_filter *)it)->req, doc, out);
+                        break;
+        }
+}
+
+static void rich_push(to_rich *r, uint32_t v) {
+        if (r->nflat == r->capflat) {
+                r->capflat = r->capflat ? r->capflat * 2 : 4096;
+                r->flat = (uint32_t *)xrealloc(r->flat, sizeof(uint32_t) * r->capflat);
+        }
+        r->flat[r->nflat++] = v;
+}
+
+int to_exec_query_rich(const to_index *ix, const uint32_t *prog, uint32_t proglen, to_rich *out) {
+        memset(out, 0, sizeof *out);
+        to_ctx c;
+        memset(&c, 0, sizeof c);
+        c.ix = ix;
+        c.flags = 0; /* neither DocumentsOnly nor AccumulatedScoreScheme: phrases stop at the first match (exec.cpp:296) */
+        int rc = 0;
+        pnode *root = parse_prog(&c, prog, proglen);
+        if (!root)
+                rc = -2;
+        else if (!root->empty) {
+                /* exec.cpp:452-505: outside the two fast modes the root iterator itself drives the execution (GenericDocsSetSpan) */
+                to_iter *sit = build_iter(&c, root);
+                /* hits come from separate postings iterators (one per distinct term): the tree's own have been consumed by the
+                 * phrase checks, which is what the reference's term_hits cache per (term, document) is for (prepare_match) */
+                to_pli *hp[64];
+                uint32_t hterm[64], nh = 0;
+                uint16_t *pos = (uint16_t *)xmalloc(sizeof(uint16_t) * 65536);
+                size_t capdocs = 0, mi = 0;
+                for (uint32_t doc = sit->next(sit); doc != TO_DOCIDS_END; doc = sit->next(sit)) {
+                        while (mi < ix->nmasked && ix->masked[mi] < doc)
+                                ++mi;
+                        if (mi < ix->nmasked && ix->masked[mi] == doc)
+                                continue; /* exec.cpp:1350-1380: masked documents never reach prepare_match */
+                        termset ts;
+                        ts.n = 0;
+                        collect_terms(sit, doc, &ts);
+                        /* canonical order: ascending term rank */
+                        for (uint32_t a = 1; a < ts.n; ++a) {
+                                const uint32_t x = ts.terms[a];
+                                uint32_t b = a;
+                                while (b > 0 && ts.terms[b - 1] > x) {
+                                        ts.terms[b] = ts.terms[b - 1];
+                                        --b;
+                                }
+                                ts.terms[b] = x;
+                        }
+                        if (out->n == capdocs) {
+                                capdocs = capdocs ? capdocs * 2 : 1024;
+                                out->docs = (uint32_t *)xrealloc(out->docs, sizeof(uint32_t) * capdocs);
+                        }
+                        out->docs[out->n++] = doc;
+                        rich_push(out, doc);
+                        rich_push(out, ts.n);
+                        for (uint32_t i = 0; i < ts.n; ++i) {
+                                uint32_t k = 0;
+                                while (k < nh && hterm[k] != ts.terms[i])
+                                        ++k;
+                                if (k == nh) {
+                                        if (nh == 64)
+                                                abort();
+                                        hterm[nh] = ts.terms[i];
+                                        hp[nh++] = (to_pli *)ctx_own(&c, to_pli_new(ix, ts.terms[i]));
+                                }
+                                to_pli *p = hp[k];
+                                if (p->it.cur < doc)
+                                        p->it.advance(&p->it, doc);
+                                if (p->it.cur != doc)
+                                        abort(); /* a collected term holds the document by construction */
+                                const uint32_t f = p->materialize(p, pos);
+                                rich_push(out, ts.terms[i]);
+                                rich_push(out, f);
+                                for (uint32_t h = 0; h < f; ++h)
+                                        rich_push(out, pos[h]);
+                                out->hits_total += f;
+                        }
+                        out->terms_total += ts.n;
+                }
+                free(pos);
+        }
+        for (size_t i = 0; i < c.nowned; ++i)
+                free(c.owned[i]);
+        free(c.owned);
+        return rc;
+}
+
+void to_rich_free(to_rich *r) {
+        free(r->docs);
+        free(r->flat);
+        memset(r, 0, sizeof *r);
+}
+
 void to_result_free(to_result *r) {
         free(r->docs);
         free(r->scores);

@@ -166,6 +166,21 @@ typedef struct to_result {
 int to_exec_query(const to_index *, const uint32_t *prog, uint32_t proglen, uint32_t flags, to_result *out);
 void to_result_free(to_result *);
 
+/* ---- the default ("rich match") execution mode: exec_query without DocumentsOnly / AccumulatedScoreScheme (exec.cpp:1350-1501).
+ * Every match is handed to consider(const matched_document &) with the query terms that matched it and their hits
+ * (queryexec_ctx.cpp:382-648 collect_doc_matching_terms + prepare_match; matches.h:109-130).  Restated in a canonical form:
+ * per match, in docID order, the u32 words  doc, nterms, then per matched term — ascending term rank — rank, freq, pos[freq].
+ * (The reference collects the terms in tree / heap order; an application sees a set.) */
+typedef struct to_rich {
+        uint32_t *docs;
+        size_t n;
+        uint32_t *flat; /* the canonical stream */
+        size_t nflat, capflat;
+        uint64_t terms_total, hits_total;
+} to_rich;
+int to_exec_query_rich(const to_index *, const uint32_t *prog, uint32_t proglen, to_rich *out);
+void to_rich_free(to_rich *);
+
 /* Application-side top-K over a result (Trinity ships none: matches.h:139-185; the build defines the
  * tie rule: score descending, docID ascending).  Returns min(n,k). */
 uint32_t to_topk(const to_result *, uint32_t k, uint32_t *docs, float *scores);

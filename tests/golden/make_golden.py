@@ -68,6 +68,11 @@ def commands_for(name, D, V, slots, seed):
                     cmds.append(f"queryfull {flags} {text}")
                 else:
                     cmds.append(f"query {flags} {10 if flags == 2 else 0} {text}")
+    # the default ("rich match") mode, flags 0: matched terms + hits per document, canonicalised by the driver (rich_fnv)
+    for ri, row in enumerate(head + qs.tolist()[:6]):
+        a, b, c, d, e = [int(x) for x in row]
+        for tpl in TEMPLATES:
+            cmds.append("query 0 0 " + tpl.format(a=a, b=b, c=c, d=d, e=e))
     # the other two scorers of similarity.h (TF-IDF :75-163, Trivial :56-72) on a subset: scored records carry "sim"
     SIM_TEMPLATES = ["t{a} t{b}", "t{a} OR t{b} OR t{c}", "t{a} t{b} (t{c} OR t{d} OR t{e})", '"t{a} t{b}" t{c}', "t{a} t{b} NOT t{c}"]
     for sim in ("tfidf", "trivial"):

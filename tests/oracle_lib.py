@@ -219,6 +219,29 @@ class Index:
         lib().to_result_free(C.byref(r))
         return docs, scores
 
+    def exec_rich(self, prog):
+        """Default ("rich match") mode: returns (docs u32[], flat u32[]) — flat = per match: doc, nterms, then per matched term
+        (ascending rank) rank, freq, pos[freq]; plus (terms_total, hits_total)."""
+
+        class ToRich(C.Structure):
+            _fields_ = [("docs", C.POINTER(C.c_uint32)), ("n", C.c_size_t), ("flat", C.POINTER(C.c_uint32)), ("nflat", C.c_size_t), ("capflat", C.c_size_t),
+                        ("terms_total", C.c_uint64), ("hits_total", C.c_uint64)]
+
+        p = np.ascontiguousarray(prog, dtype=np.uint32)
+        r = ToRich()
+        f = lib().to_exec_query_rich
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        rc = f(self.ptr, p.ctypes.data, p.size, C.byref(r))
+        if rc != 0:
+            raise ValueError(f"to_exec_query_rich rc={rc}")
+        docs = np.ctypeslib.as_array(r.docs, shape=(r.n,)).copy() if r.n else np.zeros(0, np.uint32)
+        flat = np.ctypeslib.as_array(r.flat, shape=(r.nflat,)).copy() if r.nflat else np.zeros(0, np.uint32)
+        tt, ht = int(r.terms_total), int(r.hits_total)
+        lib().to_rich_free.argtypes = [C.c_void_p]
+        lib().to_rich_free(C.byref(r))
+        return docs, flat, tt, ht
+
     def set_similarity(self, sim):
         """SIM_BM25 (default) / SIM_TFIDF / SIM_TRIVIAL: the scorer AccumulatedScoreScheme queries use (similarity.h)."""
         self.ptr.contents.similarity = int(sim)

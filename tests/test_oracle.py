@@ -181,7 +181,7 @@ def test_queries_match_reference(golden):
     g, ix = golden
     n = 0
     for r in g["results"]:
-        if r["cmd"] not in ("query", "queryfull"):
+        if r["cmd"] not in ("query", "queryfull") or r["flags"] == 0:
             continue
         ix.set_similarity({"bm25": O.SIM_BM25, "tfidf": O.SIM_TFIDF, "trivial": O.SIM_TRIVIAL}[r.get("sim", "bm25")])
         docs, scores = ix.exec(O.parse_query(r["q"]), r["flags"])
@@ -204,6 +204,26 @@ def test_queries_match_reference(golden):
         n += 1
     ix.set_similarity(O.SIM_BM25)
     assert n > 200
+
+
+def test_rich_mode_matches_reference(golden):
+    """exec_query's default mode (flags 0): per match the query terms that matched and their hits — the canonical stream's
+    FNV, the totals and the first documents in full, against the genuine reference."""
+    g, ix = golden
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] != "query" or r["flags"] != 0:
+            continue
+        docs, flat, tt, ht = ix.exec_rich(O.parse_query(r["q"]))
+        assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
+        assert tt == r["terms_total"] and ht == r["hits_total"], r["q"]
+        assert str(O.fnv1a_u32_stream(flat)) == r["rich_fnv"], r["q"]
+        at = 0
+        for want in r["rich_docs"]:
+            assert flat[at : at + len(want)].tolist() == want, (r["q"], want)
+            at += len(want)
+        n += 1
+    assert n >= 100
 
 
 def test_bm25_formula_known_answers():
@@ -291,6 +311,9 @@ def test_lucene_codec_results_equal_reference_fixtures(both_codecs):
         if r["cmd"] == "decode":
             d, f = lx.decode_term(r["term"])
             assert str(O.fnv1a_docs(d)) == r["docs_fnv"] and str(O.fnv1a_docs(f)) == r["freqs_fnv"]
+        elif r["cmd"] in ("query", "queryfull") and r["flags"] == 0:
+            docs, flat, tt, ht = lx.exec_rich(O.parse_query(r["q"]))
+            assert len(docs) == r["n"] and str(O.fnv1a_u32_stream(flat)) == r["rich_fnv"], r["q"]
         elif r["cmd"] in ("query", "queryfull"):
             lx.set_similarity({"bm25": O.SIM_BM25, "tfidf": O.SIM_TFIDF, "trivial": O.SIM_TRIVIAL}[r.get("sim", "bm25")])
             docs, scores = lx.exec(O.parse_query(r["q"]), r["flags"])
