@@ -34,6 +34,9 @@ extern "C" {
 /* exec.h:11-43 ExecFlags (same values) */
 #define TRI_FLAG_DOCUMENTS_ONLY 1u
 #define TRI_FLAG_ACCUMULATED_SCORE 2u
+#define TRI_FLAG_MATCHED_TERMS 4u /* exec_query's DEFAULT mode (no ExecFlags, exec.cpp:1350-1501): every match comes with the query
+                                     terms that matched it and their hits — what consider(const matched_document &) receives
+                                     (matches.h:109-130; queryexec_ctx.cpp:382-648).  Results: tri_batch_matched_terms */
 
 /* similarity.h scorers: Trivial :56-72, TF-IDF :75-163, BM25 :165-255 */
 #define TRI_SIM_BM25 0
@@ -159,6 +162,15 @@ int tri_batch_docset(tri_batch *, size_t q, uint32_t *out, size_t cap, size_t *n
 /* AccumulatedScore with topk == 0: the score of every match of query q, parallel to tri_batch_docset(q) — the
  * (id, score) stream MatchedIndexDocumentsFilter::consider(id, score) receives (matches.h:169; exec.cpp:1322-1341) */
 int tri_batch_scores(tri_batch *, size_t q, double *out, size_t cap, size_t *n);
+/* TRI_FLAG_MATCHED_TERMS batches.  tri_batch_query_terms: the query's reportable terms (every TERM / PHRASE-member of the
+ * program outside the excluded side of a NOT, distinct, in order of first appearance; at most 16), i.e. the meaning of bit k
+ * and column k below.  tri_batch_matched_terms, for the n matches of query q in ascending docID order (n and the docIDs as
+ * returned by tri_batch_docset): present[i] bit k = term k matched document i; freq[i * nterms + k] = its frequency there
+ * (term_hits::freq, 0 when absent); positions = the hits' positions, match-major then term-minor (the run of (i, k) starts at
+ * the sum of all freq before it), *npos of them in all; pass positions == NULL to learn *npos. */
+int tri_batch_query_terms(tri_batch *, size_t q, uint32_t *terms /* [16] */, uint32_t *nterms);
+int tri_batch_matched_terms(tri_batch *, size_t q, uint32_t *present /* [n] */, uint16_t *freq /* [n * nterms] */, uint16_t *positions,
+                            size_t pos_cap, size_t *npos);
 /* AccumulatedScore with topk >= 1: docids/scores are [nq][topk] row-major, counts[nq] = min(matches, topk) */
 int tri_batch_topk(tri_batch *, uint32_t *docids, float *scores, uint32_t *counts);
 /* device-resident result blocks for the multi-GPU gather (per rank: [nq][topk] u32 + f32, [nq] u32) */

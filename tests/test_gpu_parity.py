@@ -651,3 +651,70 @@ def test_other_similarities_match_oracle(request, world, sim):
             np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
     finally:
         w.ora.set_similarity(0)
+
+
+# ------------------------------------------------------------------------------------------ the default ("rich match") mode, SURVEY §8f-1
+def rich_flat(docs, terms, present, freq, pos):
+    """The canonical stream of oracle.to_exec_query_rich / ref_driver from the engine's arrays: per match  doc, nterms, then per
+    matched term in ascending rank  rank, freq, pos[freq]."""
+    out = []
+    at = 0
+    order = np.argsort(terms, kind="stable")
+    for i, d in enumerate(docs.tolist()):
+        offs = {}
+        for k in range(len(terms)):  # positions are match-major, term-minor in the engine's term order
+            offs[k] = at
+            at += int(freq[i, k])
+        ks = [k for k in order.tolist() if (int(present[i]) >> k) & 1]
+        out += [d, len(ks)]
+        for k in ks:
+            f = int(freq[i, k])
+            out += [int(terms[k]), f] + pos[offs[k] : offs[k] + f].tolist()
+    assert at == len(pos)
+    return np.array(out, dtype=np.uint32)
+
+
+def run_rich(w, programs):
+    b = w.T.Batch(w.ix, programs, w.T.FLAG_MATCHED_TERMS)
+    b.run()
+    b.sync()
+    counts = b.counts()
+    res = []
+    for i in range(len(programs)):
+        n = int(counts[i])
+        docs = b.docset(i, n)
+        res.append((docs,) + b.matched_terms(i, n))
+    b.close()
+    return res
+
+
+@pytest.mark.parametrize("world,n", [("small", 12), ("dense", 12), ("medium", 5), ("small_l", 8)])
+def test_rich_mode_matches_oracle(request, world, n):
+    """exec_query's default mode: the matched terms of every match with their frequencies and positions, both codecs, every
+    lowered query shape (conjunctions, unions, CNF, NOT, phrases)."""
+    w = request.getfixturevalue(world)
+    texts = template_queries(w, 101, n) + not_queries(w, 102, 2) + phrase_queries(w, 103, 2) + ["t0 t1", "t5", "t0 OR t1 OR t2"]
+    progs = [O.parse_query(t) for t in texts]
+    for t, p, (docs, terms, present, freq, pos) in zip(texts, progs, run_rich(w, progs)):
+        wdocs, wflat, tt, ht = w.ora.exec_rich(p)
+        assert np.array_equal(docs, wdocs), t
+        got = rich_flat(docs, terms, present, freq, pos)
+        assert int(freq.sum()) == ht and int(sum(bin(int(x)).count("1") for x in present)) == tt, t
+        assert np.array_equal(got, wflat), t
+
+
+def test_rich_mode_against_reference_fixtures(T, dev):
+    """flags 0 records produced by the genuine reference (consider(const matched_document &) canonicalised by ref_driver)."""
+    checked = 0
+    for name in ("small", "dense"):
+        g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
+        c = g["corpus"]
+        w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
+        recs = [r for r in g["results"] if r["cmd"] == "query" and r["flags"] == 0 and gpu_lowers(r["q"])]
+        for r, (docs, terms, present, freq, pos) in zip(recs, run_rich(w, [O.parse_query(r["q"]) for r in recs])):
+            assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
+            assert int(freq.sum()) == r["hits_total"], r["q"]
+            assert str(O.fnv1a_u32_stream(rich_flat(docs, terms, present, freq, pos))) == r["rich_fnv"], r["q"]
+            checked += 1
+        w.ix.close()
+    assert checked >= 150

@@ -112,6 +112,13 @@ struct tri_batch {
         double *d_part_scores = nullptr;
         float *d_top_scores = nullptr;
         double *d_all_scores = nullptr; // topk == 0: one double per out[] slot
+        // TRI_FLAG_MATCHED_TERMS (k_rich.hpp): sterms[] holds every query's reportable terms; R = the widest query's count
+        uint32_t rich_R = 0;
+        uint32_t *d_rich_present = nullptr, *d_task_hits = nullptr;
+        uint16_t *d_rich_freq = nullptr, *d_rich_pool = nullptr;
+        uint64_t *d_task_pos_base = nullptr;
+        std::vector<uint64_t> h_task_pos_base; // per task; [ntasks] = the pool's size
+        size_t rich_pool_cap = 0;
         // phrases
         std::vector<DevPhrase> phrases;
         std::vector<uint32_t> pterms, ptasks;
@@ -132,6 +139,7 @@ struct tri_batch {
 #include "k_match.hpp"
 #include "k_score.hpp"
 #include "k_phrase.hpp"
+#include "k_rich.hpp"
 
 // launch the instantiation of a codec-templated kernel that matches the uploaded segment
 #define TRI_LAUNCH(K, codec, grid, block, stream, ...)                                              \
@@ -730,10 +738,11 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 uint32_t flags, uint32_t topk, int similarity, tri_batch **out) {
         if (!ix || !out || (!prog && prog_len) || (!queries && nq))
                 return fail(TRI_ERR_INVALID, "tri_batch_create: null argument");
-        const uint32_t mode = flags & (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE);
-        if (mode == 0 || mode == (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE))
-                return fail(TRI_ERR_INVALID, "DocumentsOnly and AccumulatedScoreScheme are mutually exclusive; the default rich mode is not lowered (exec.h:45-48)");
+        const uint32_t mode = flags & (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE | TRI_FLAG_MATCHED_TERMS);
+        if (mode != TRI_FLAG_DOCUMENTS_ONLY && mode != TRI_FLAG_ACCUMULATED_SCORE && mode != TRI_FLAG_MATCHED_TERMS)
+                return fail(TRI_ERR_INVALID, "exactly one of DocumentsOnly, AccumulatedScoreScheme, MatchedTerms (exec_query's default mode): the modes are mutually exclusive (exec.h:45-48)");
         const bool scored = mode == TRI_FLAG_ACCUMULATED_SCORE;
+        const bool rich = mode == TRI_FLAG_MATCHED_TERMS;
         if (scored && topk > TOPK_MAX)
                 return fail(TRI_ERR_INVALID, "AccumulatedScoreScheme: topk <= %u (0 = keep every match's score instead of a top-K)", TOPK_MAX);
         if (similarity != TRI_SIM_BM25 && similarity != TRI_SIM_TFIDF && similarity != TRI_SIM_TRIVIAL)
@@ -907,6 +916,34 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 }
                 t.q.score_base = (uint32_t)b->sterms.size();
                 t.q.nscore = 0;
+                if (rich) {
+                        // the reportable terms: every postings iterator collect_doc_matching_terms can reach (queryexec_ctx.cpp:382-520) —
+                        // group members and phrase terms, not the excluded side of a NOT —, distinct, in order of first appearance
+                        std::vector<uint32_t> rt;
+                        auto add = [&](uint32_t x) {
+                                if (std::find(rt.begin(), rt.end(), x) == rt.end())
+                                        rt.push_back(x);
+                        };
+                        for (uint32_t pi = 0; pi < tq.prog_len; ++pi) {
+                                const uint32_t tok = prog[tq.prog_off + pi];
+                                if ((tok >> 28) != TRI_OP_TERM)
+                                        continue;
+                                const uint32_t x = tok & 0x0fffffffu;
+                                bool positive = std::find(leaves.begin(), leaves.end(), x) != leaves.end();
+                                for (const auto &ph : qphrases)
+                                        positive |= std::find(ph.terms.begin(), ph.terms.end(), x) != ph.terms.end();
+                                if (positive)
+                                        add(x);
+                        }
+                        if (rt.size() > 16)
+                                return fail(TRI_ERR_UNSUPPORTED, "query %zu: more than 16 reportable terms", qi);
+                        for (uint32_t x : rt) {
+                                b->sterms.push_back(x);
+                                b->term_bytes += ix->hitbytes[x]; // the hits of every reported term are read
+                        }
+                        t.q.nscore = (uint32_t)rt.size();
+                        b->rich_R = std::max<uint32_t>(b->rich_R, t.q.nscore);
+                }
                 if (scored) {
                         // one scorer per PostingsListIterator of the conjunction, summed in iterator order
                         // (docset_iterators_scorers.cpp:173-193); weight = BM25 idf (similarity.h:179-181, float math)
@@ -1083,6 +1120,15 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         HIP_TRY(hipMemset(b->d_pscore, 0, (off + 64) * 8));
                 }
         }
+        if (rich) {
+                if ((rc = dev_upload(&b->d_sterms, b->sterms)))
+                        return rc;
+                b->rich_R = std::max<uint32_t>(b->rich_R, 1);
+                HIP_TRY(hipMalloc((void **)&b->d_rich_present, (off + 64) * 4));
+                HIP_TRY(hipMalloc((void **)&b->d_rich_freq, (off + 64) * 2 * b->rich_R));
+                HIP_TRY(hipMalloc((void **)&b->d_task_hits, (b->tasks.size() + 1) * 4));
+                HIP_TRY(hipMalloc((void **)&b->d_task_pos_base, (b->tasks.size() + 1) * 8));
+        }
         if (scored) {
                 if ((rc = dev_upload(&b->d_sterms, b->sterms)) || (rc = dev_upload(&b->d_sweights, b->sweights)))
                         return rc;
@@ -1125,6 +1171,11 @@ extern "C" void tri_batch_destroy(tri_batch *b) {
         hipFree(b->d_top_scores);
         hipFree(b->d_top_counts);
         hipFree(b->d_all_scores);
+        hipFree(b->d_rich_present);
+        hipFree(b->d_rich_freq);
+        hipFree(b->d_task_hits);
+        hipFree(b->d_task_pos_base);
+        hipFree(b->d_rich_pool);
         hipFree(b->d_phrases);
         hipFree(b->d_pterms);
         hipFree(b->d_ptasks);
@@ -1196,6 +1247,23 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                            b->d_ticket + 48, b->d_out, b->d_counts, b->d_pscore,
                                            (b->flags & TRI_FLAG_ACCUMULATED_SCORE) ? 65535u : 1u, // exec.cpp:296 trackCnt
                                            b->similarity);
+                        HIP_TRY(hipGetLastError());
+                }
+                if (b->flags & TRI_FLAG_MATCHED_TERMS) {
+                        // COUNT pass: which reportable terms hold each match, with what frequency; hit totals per task
+                        HIP_TRY(hipMemsetAsync(b->d_rich_present, 0, (b->out_capacity + 64) * 4, dev->stream));
+                        HIP_TRY(hipMemsetAsync(b->d_rich_freq, 0, (b->out_capacity + 64) * 2 * b->rich_R, dev->stream));
+                        HIP_TRY(hipMemsetAsync(b->d_task_hits, 0, (b->tasks.size() + 1) * 4, dev->stream));
+                        if (b->ix->codec == TRI_CODEC_LUCENE)
+                                hipLaunchKernelGGL((k_rich<CODEC_LUCENE, false>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
+                                                   b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched,
+                                                   b->d_sterms, n, b->d_ticket + 32, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
+                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr);
+                        else
+                                hipLaunchKernelGGL((k_rich<CODEC_GOOGLE, false>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
+                                                   b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched,
+                                                   b->d_sterms, n, b->d_ticket + 32, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
+                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr);
                         HIP_TRY(hipGetLastError());
                 }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
@@ -1278,7 +1346,106 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 b->info.algorithmic_bytes = b->term_bytes + outb;
         } else
                 b->info.algorithmic_bytes = b->term_bytes + 4 * m; // docbytes + 4 B per match (docs-only)
+        if ((b->flags & TRI_FLAG_MATCHED_TERMS) && !b->tasks.empty()) {
+                // the COUNT pass left every task's hit total: turn them into pool offsets (the pool is packed: task after task in
+                // query order, inside a task match-major then term-minor), then the WRITE pass fills in the positions
+                const size_t nt = b->tasks.size();
+                std::vector<uint32_t> th(nt);
+                HIP_TRY(hipMemcpy(th.data(), b->d_task_hits, nt * 4, hipMemcpyDeviceToHost));
+                b->h_task_pos_base.assign(nt + 1, 0);
+                for (size_t i = 0; i < nt; ++i)
+                        b->h_task_pos_base[i + 1] = b->h_task_pos_base[i] + th[i];
+                const size_t total = b->h_task_pos_base[nt];
+                if (total + 64 > b->rich_pool_cap) {
+                        hipFree(b->d_rich_pool);
+                        b->d_rich_pool = nullptr;
+                        b->rich_pool_cap = total + total / 8 + 64;
+                        HIP_TRY(hipMalloc((void **)&b->d_rich_pool, b->rich_pool_cap * 2));
+                }
+                HIP_TRY(hipMemcpy(b->d_task_pos_base, b->h_task_pos_base.data(), (nt + 1) * 8, hipMemcpyHostToDevice));
+                HIP_TRY(hipMemsetAsync(b->d_ticket + 40, 0, 4, dev->stream));
+                const uint32_t n = (uint32_t)nt;
+                if (b->ix->codec == TRI_CODEC_LUCENE)
+                        hipLaunchKernelGGL((k_rich<CODEC_LUCENE, true>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_hits,
+                                           b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, n,
+                                           b->d_ticket + 40, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
+                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool);
+                else
+                        hipLaunchKernelGGL((k_rich<CODEC_GOOGLE, true>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_hits,
+                                           b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, n,
+                                           b->d_ticket + 40, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
+                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(dev->stream));
+                b->info.algorithmic_bytes += 2 * total + 4 * m; // + the positions handed over and a present mask per match
+        }
         b->synced = true;
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_query_terms(tri_batch *b, size_t q, uint32_t *terms, uint32_t *nterms) {
+        if (!b || !terms || !nterms || q >= b->nq)
+                return fail(TRI_ERR_INVALID, "bad argument");
+        if (!(b->flags & TRI_FLAG_MATCHED_TERMS))
+                return fail(TRI_ERR_INVALID, "not a TRI_FLAG_MATCHED_TERMS batch");
+        const uint32_t slot = b->slot_of_query[q];
+        *nterms = 0;
+        if (slot == UINT32_MAX)
+                return TRI_OK;
+        const DevQuery &dq = b->plan[slot];
+        for (uint32_t k = 0; k < dq.nscore; ++k)
+                terms[k] = b->sterms[dq.score_base + k];
+        *nterms = dq.nscore;
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_matched_terms(tri_batch *b, size_t q, uint32_t *present, uint16_t *freq, uint16_t *positions, size_t pos_cap, size_t *npos) {
+        if (!b || !npos || q >= b->nq)
+                return fail(TRI_ERR_INVALID, "bad argument");
+        if (!(b->flags & TRI_FLAG_MATCHED_TERMS))
+                return fail(TRI_ERR_INVALID, "not a TRI_FLAG_MATCHED_TERMS batch");
+        if (!b->synced)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync first");
+        *npos = 0;
+        const uint32_t slot = b->slot_of_query[q];
+        if (slot == UINT32_MAX)
+                return TRI_OK;
+        const DevQuery &dq = b->plan[slot];
+        tri_dev *dev = b->ix->dev;
+        HIP_TRY(hipSetDevice(dev->device));
+        // the query's tasks are consecutive, so its hits are one contiguous run of the pool
+        const uint64_t p0 = b->h_task_pos_base[dq.first_task], p1 = b->h_task_pos_base[dq.first_task + dq.ntasks];
+        *npos = (size_t)(p1 - p0);
+        if (positions) {
+                if (pos_cap < *npos)
+                        return fail(TRI_ERR_INVALID, "positions need %zu slots, %zu given", *npos, pos_cap);
+                if (*npos)
+                        HIP_TRY(hipMemcpyAsync(positions, b->d_rich_pool + p0, *npos * 2, hipMemcpyDeviceToHost, dev->stream));
+        }
+        // per-match rows live at the tasks' out[] slots; freq rows are R wide on the device, nscore wide for the caller
+        size_t w = 0;
+        std::vector<uint16_t> rows;
+        for (uint32_t t = 0; t < dq.ntasks; ++t) {
+                const uint32_t c = b->h_counts[dq.first_task + t];
+                if (!c)
+                        continue;
+                const uint64_t off = b->tasks[dq.first_task + t].out_off;
+                if (present)
+                        HIP_TRY(hipMemcpyAsync(present + w, b->d_rich_present + off, (size_t)c * 4, hipMemcpyDeviceToHost, dev->stream));
+                if (freq) {
+                        if (b->rich_R == dq.nscore)
+                                HIP_TRY(hipMemcpyAsync(freq + w * dq.nscore, b->d_rich_freq + off * b->rich_R, (size_t)c * 2 * b->rich_R, hipMemcpyDeviceToHost, dev->stream));
+                        else {
+                                rows.resize((size_t)c * b->rich_R);
+                                HIP_TRY(hipMemcpy(rows.data(), b->d_rich_freq + off * b->rich_R, (size_t)c * 2 * b->rich_R, hipMemcpyDeviceToHost));
+                                for (size_t i = 0; i < c; ++i)
+                                        for (uint32_t k = 0; k < dq.nscore; ++k)
+                                                freq[(w + i) * dq.nscore + k] = rows[i * b->rich_R + k];
+                        }
+                }
+                w += c;
+        }
+        HIP_TRY(hipStreamSynchronize(dev->stream));
         return TRI_OK;
 }
 

@@ -9,7 +9,7 @@ import numpy as np
 from .build import LIB_HIP, LIB_HOST
 
 OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT = 0, 1, 2, 3, 4
-FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE = 1, 2
+FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE, FLAG_MATCHED_TERMS = 1, 2, 4
 CODEC_GOOGLE, CODEC_LUCENE = 1, 2
 FNV_EMPTY = 1469598103934665603
 
@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream",
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
-    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_docset_hashes",
+    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_docset_hashes",
 ]  # fmt: skip
 
 _hip = None
@@ -99,6 +99,8 @@ def hip_lib():
     L.tri_batch_run.argtypes = [vp]
     L.tri_batch_sync.argtypes = [vp]
     L.tri_batch_get_info.argtypes = [vp, C.POINTER(TriBatchInfo)]
+    L.tri_batch_query_terms.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint32)]
+    L.tri_batch_matched_terms.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_match_counts.argtypes = [vp, vp]
     L.tri_batch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_scores.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -281,6 +283,22 @@ class Batch:
         i = TriBatchInfo()
         _check(hip_lib().tri_batch_get_info(self.h, C.byref(i)))
         return {k: getattr(i, k) for k, _ in TriBatchInfo._fields_}
+
+    def matched_terms(self, q, n):
+        """FLAG_MATCHED_TERMS batches: (terms u32[nt], present u32[n], freq u16[n, nt], positions u16[npos]) for the n matches of
+        query q (ascending docID, as docset(q, n) returns them); positions are match-major then term-minor."""
+        L = hip_lib()
+        terms = np.zeros(16, dtype=np.uint32)
+        nt = C.c_uint32()
+        _check(L.tri_batch_query_terms(self.h, q, terms.ctypes.data, C.byref(nt)))
+        nt = nt.value
+        npos = C.c_size_t()
+        _check(L.tri_batch_matched_terms(self.h, q, None, None, None, 0, C.byref(npos)))
+        present = np.zeros(n, dtype=np.uint32)
+        freq = np.zeros((n, max(nt, 1)), dtype=np.uint16)
+        pos = np.zeros(max(1, npos.value), dtype=np.uint16)
+        _check(L.tri_batch_matched_terms(self.h, q, present.ctypes.data, freq.ctypes.data, pos.ctypes.data, pos.size, C.byref(npos)))
+        return terms[:nt], present, freq[:, :nt], pos[: npos.value]
 
     def counts(self):
         out = np.zeros(self.nq, dtype=np.uint64)
