@@ -107,6 +107,31 @@ int main(int argc, char **argv) {
                         exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, &c3, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), s3.get());
                         show("trivial_scored", c3);
                 }
+                { // the default execution mode: consider(const matched_document &) with the matched terms and their hits
+                        struct Rich final : public MatchedIndexDocumentsFilter {
+                                size_t n{0}, terms{0}, hits{0};
+                                uint64_t h{1469598103934665603ull};
+                                void consider(const matched_document &m) override {
+                                        ++n;
+                                        terms += m.matchedTermsCnt;
+                                        // order-independent digest over (doc, term token, freq, positions)
+                                        for (uint16_t i = 0; i < m.matchedTermsCnt; ++i) {
+                                                const auto &mt = m.matchedTerms[i];
+                                                uint64_t x = 1469598103934665603ull;
+                                                auto mix = [&](uint64_t v) { x = (x ^ v) * 1099511628211ull; };
+                                                mix(m.id);
+                                                mix(strtoul(mt.queryCtx->term.token.c_str() + 1, nullptr, 10));
+                                                mix(mt.hits->freq);
+                                                for (uint16_t k = 0; k < mt.hits->freq; ++k)
+                                                        mix(mt.hits->all[k].pos);
+                                                h += x;
+                                                hits += mt.hits->freq;
+                                        }
+                                }
+                        } rich;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1"), src.disjunction({src.term("t2"), src.term("t3"), src.term("t4")})}), &src, &rich);
+                        printf("rich n=%zu terms=%zu hits=%zu digest=%" PRIu64 "\n", rich.n, rich.terms, rich.hits, rich.h);
+                }
                 { // masked documents: every 3rd document of the segment was superseded by a newer one
                         std::vector<docid_t> masked;
                         for (docid_t d = 3; d <= fs.docsCnt; d += 3)

@@ -67,6 +67,22 @@ def test_mirror_results_match_oracle(T, tmp_path):
     expect("tfidf_scored", "t0 t1 (t2 OR t3)", 2, sim=O.SIM_TFIDF)
     expect("trivial_scored", "t0 t1", 2, sim=O.SIM_TRIVIAL)
     expect("masked_scored", "t0 t1", 2, keep=lambda d: (d % 3) != 0)
+    # default mode: the same digest from the oracle's canonical stream
+    docs, flat, tt, ht = ora.exec_rich(O.parse_query("t0 t1 (t2 OR t3 OR t4)"))
+    r = lines["rich"]
+    assert (int(r["n"]), int(r["terms"]), int(r["hits"])) == (len(docs), tt, ht)
+    M, digest, at, fl = (1 << 64) - 1, 1469598103934665603, 0, flat.tolist()
+    while at < len(fl):
+        doc, nt = fl[at], fl[at + 1]
+        at += 2
+        for _ in range(nt):
+            rank, f = fl[at], fl[at + 1]
+            x = 1469598103934665603
+            for v in [doc, rank, f] + fl[at + 2 : at + 2 + f]:
+                x = ((x ^ v) * 1099511628211) & M
+            digest = (digest + x) & M
+            at += 2 + f
+    assert int(r["digest"]) == digest
     assert int(lines["unknown"]["n"]) == 0
     expect("batch0", "t1 t2", 1)
     expect("batch1", "t8 OR t9", 1)

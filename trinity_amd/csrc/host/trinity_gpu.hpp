@@ -28,6 +28,7 @@ namespace trinity_amd {
         using isrc_docid_t = uint32_t; // common.h:36
         using docid_t = uint32_t;      // common.h:39
         using tokenpos_t = uint16_t;   // common.h:46
+        using exec_term_id_t = uint16_t; // common.h: per-query term id
         static constexpr isrc_docid_t DocIDsEND{std::numeric_limits<isrc_docid_t>::max()}; // common.h:43
 
         enum class ExecFlags : uint32_t { DocumentsOnly = 1, AccumulatedScoreScheme = 2 }; // exec.h:11-43
@@ -300,7 +301,32 @@ namespace trinity_amd {
                 virtual ~MatchesProxy() = default;
         };
 
+        // ---- what the default execution mode hands to the application (matches.h:34-130), positions only (no payloads)
+        struct term_hit {
+                tokenpos_t pos;
+        };
+        struct term_hits {
+                tokenpos_t freq{0};
+                term_hit *all{nullptr};
+        };
+        struct query_term_ctx {
+                struct {
+                        exec_term_id_t id;
+                        std::string token;
+                } term;
+        };
+        struct matched_query_term {
+                const query_term_ctx *queryCtx;
+                term_hits *hits;
+        };
+        struct matched_document {
+                docid_t id{0};
+                uint16_t matchedTermsCnt{0};
+                matched_query_term *matchedTerms{nullptr};
+        };
+
         struct MatchedIndexDocumentsFilter { // matches.h:139-185
+                virtual void consider(const matched_document &) {} // default execution mode
                 virtual void consider(const docid_t) {}
                 virtual void consider(const docid_t *ids, const size_t cnt) {
                         for (size_t i = 0; i != cnt; ++i)
@@ -326,6 +352,7 @@ namespace trinity_amd {
         class IndexSource { // index_source.h:19-156, backed by an uploaded segment
                 tri_dev *dev{nullptr};
                 tri_index *ix{nullptr};
+                std::vector<std::string> names;                 // row -> term
                 std::unordered_map<std::string, uint32_t> dict; // term -> row; the reference's SegmentTerms (terms.h) is host-only and out of scope
                 std::vector<term_index_ctx> table;
                 std::unique_ptr<Codecs::Google::AccessProxy> access;
@@ -343,6 +370,7 @@ namespace trinity_amd {
                         check(tri_dev_open(device, &dev));
                         static_assert(sizeof(term_index_ctx) == sizeof(tri_term), "term_index_ctx layout");
                         check(tri_index_upload(dev, index, len, nullptr, 0, TRI_CODEC_GOOGLE, reinterpret_cast<const tri_term *>(tctx.data()), tctx.size(), stats.docsCnt, &ix));
+                        names = terms;
                         for (uint32_t i = 0; i < terms.size(); ++i)
                                 dict.emplace(terms[i], i);
                         access.reset(new Codecs::Google::AccessProxy(index));
@@ -355,6 +383,7 @@ namespace trinity_amd {
                 IndexSource(const IndexSource &) = delete;
 
                 tri_index *handle() const noexcept { return ix; }
+                const std::string &term_name(const uint32_t row) const { return names.at(row); }
                 // The documents of this source that newer sources of the collection have updated or deleted — what
                 // IndexSourcesCollection::commit() derives per source (index_source.cpp:3-30) and exec_query tests through
                 // masked_documents_registry::test before every consider() (exec.cpp:914-975).  Uploaded once per refresh of the
@@ -480,8 +509,6 @@ namespace trinity_amd {
                 const auto mask = f & (unsigned(ExecFlags::DocumentsOnly) | unsigned(ExecFlags::AccumulatedScoreScheme));
                 if (mask && (mask & (mask - 1)))
                         throw invalid_argument("DocumentsOnly and AccumulatedScoreScheme are mutually exclusive modes");
-                if (!mask)
-                        throw invalid_argument("the default (rich match) execution mode is not lowered to the GPU engine");
         }
 
         // Lower iterator trees (the mirror of build_iterator's output), attach one ScorerWeight per TERM token
@@ -490,6 +517,8 @@ namespace trinity_amd {
                                   Similarity::IndexSourceTermsScorer *scorer) {
                 validate_flags(flags);
                 const bool scored = flags & unsigned(ExecFlags::AccumulatedScoreScheme);
+                if (!(flags & (unsigned(ExecFlags::DocumentsOnly) | unsigned(ExecFlags::AccumulatedScoreScheme))))
+                        flags = TRI_FLAG_MATCHED_TERMS; // no ExecFlags: exec_query's default mode (exec.cpp:1350-1501)
                 if (scored && !scorer)
                         throw invalid_argument("IndexSourceTermsScorer not set"); // exec.h:105-108
                 std::vector<uint32_t> prog;
@@ -559,9 +588,59 @@ namespace trinity_amd {
         // exec.cpp:509-1517 for the two lowered modes: build the span over the iterator tree, process(1, DocIDsEND),
         // deliver through the no-mask handlers (exec.cpp:1213-1229 docs-only, 1322-1341 accumulated score), honouring an
         // IndexDocumentsFilter (matches.h:198-201) and cooperative cancellation (exec.cpp:1505-1510).
-        inline void exec_query(DocsSetIterators::Iterator *root, IndexSource *, MatchedIndexDocumentsFilter *matchesFilter, IndexDocumentsFilter *f = nullptr,
+        // The default mode: every match is delivered as a matched_document — the query terms that matched it and their hits
+        // (prepare_match, queryexec_ctx.cpp:522-648) — rebuilt here from the engine's packed arrays.
+        inline void exec_query_default_mode(DocsSetIterators::Iterator *root, IndexSource *src, MatchedIndexDocumentsFilter *mf, IndexDocumentsFilter *df) {
+                auto b = run_batch(src, {root}, 0, 0, nullptr);
+                size_t n = 0, npos = 0;
+                check(tri_batch_docset(b.get(), 0, nullptr, 0, &n));
+                std::vector<docid_t> ids(n);
+                if (n)
+                        check(tri_batch_docset(b.get(), 0, ids.data(), n, &n));
+                uint32_t terms[16], nt = 0;
+                check(tri_batch_query_terms(b.get(), 0, terms, &nt));
+                check(tri_batch_matched_terms(b.get(), 0, nullptr, nullptr, nullptr, 0, &npos));
+                std::vector<uint32_t> present(n);
+                std::vector<uint16_t> freq(n * std::max<uint32_t>(nt, 1)), pos(npos);
+                check(tri_batch_matched_terms(b.get(), 0, present.data(), freq.data(), pos.data(), pos.size(), &npos));
+                std::vector<query_term_ctx> qctx(nt);
+                for (uint32_t k = 0; k < nt; ++k) {
+                        qctx[k].term.id = exec_term_id_t(k + 1);
+                        qctx[k].term.token = src->term_name(terms[k]);
+                }
+                std::vector<term_hits> th(nt);
+                std::vector<matched_query_term> mts(nt);
+                std::vector<std::vector<term_hit>> store(nt);
+                size_t at = 0;
+                try {
+                        for (size_t i = 0; i < n; ++i) {
+                                matched_document md;
+                                md.id = ids[i];
+                                md.matchedTerms = mts.data();
+                                for (uint32_t k = 0; k < nt; ++k) {
+                                        const uint32_t f = freq[i * nt + k];
+                                        if ((present[i] >> k) & 1u) {
+                                                store[k].resize(f);
+                                                for (uint32_t h = 0; h < f; ++h)
+                                                        store[k][h].pos = pos[at + h];
+                                                th[k].freq = tokenpos_t(f);
+                                                th[k].all = store[k].data();
+                                                mts[md.matchedTermsCnt++] = {&qctx[k], &th[k]};
+                                        }
+                                        at += f;
+                                }
+                                if (!(df && df->filter(md.id)))
+                                        mf->consider(md);
+                        }
+                } catch (const aborted_search_exception &) {
+                }
+        }
+
+        inline void exec_query(DocsSetIterators::Iterator *root, IndexSource *src, MatchedIndexDocumentsFilter *matchesFilter, IndexDocumentsFilter *f = nullptr,
                                const uint32_t flags = 0, Similarity::IndexSourceTermsScorer *scorer = nullptr) {
                 validate_flags(flags);
+                if (!(flags & (unsigned(ExecFlags::DocumentsOnly) | unsigned(ExecFlags::AccumulatedScoreScheme))))
+                        return exec_query_default_mode(root, src, matchesFilter, f);
                 struct Handler final : public MatchesProxy {
                         MatchedIndexDocumentsFilter *mf;
                         IndexDocumentsFilter *df;
