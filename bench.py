@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=16384, help="queries per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
                     help="SURVEY §8(d) query sets; cfg2 (default) is the configuration BASELINE.json's metric is quoted on, the others are "
                          "extra measurements (whole-step roofline only)")
     args = ap.parse_args()

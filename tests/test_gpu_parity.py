@@ -498,7 +498,7 @@ def test_lucene_forced_dense_and_fixtures(T, dev, monkeypatch):
 
 
 # ------------------------------------------------------------------------------------------ SURVEY §8(d) workloads (bench.py --workload)
-@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4", "cfg5"])
+@pytest.mark.parametrize("name", ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
 def test_workload_matches_oracle(T, dev, name):
     """The query sets bench.py times, at a size the oracle finishes in seconds: same programs, bit-exact docID sets
     (scored sets: top-K equal, BM25 within 1e-5).  cfg4's document-sampled phrases must match somewhere."""

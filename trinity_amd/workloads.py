@@ -1,5 +1,6 @@
 """Query workloads of SURVEY.md §8(d) as postfix programs (include/trinity_hip.h tri_query), shared by bench.py and the tests.
 
+cfg1  `A B`, BM25 top-10 (the reference's own CPU-runnable configuration: 100K documents, 2000 queries)
 cfg2  batched `A B`, DocumentsOnly
 cfg3  5-term mixed, equal parts `A B (C|D|E)`, `(A|B) (C|D) E`, `A B C D E`, `A|B|C|D|E`; BM25 top-100
 cfg4  phrases `"A B"`, `"A B C"`: half sampled from consecutive slots of a random document, half random terms
@@ -52,6 +53,8 @@ def _dedup(rows):
 
 def build(name, D, V, slots, corpus_seed, nq, seed=1337):
     """Returns (programs, flags, topk, codec, description)."""
+    if name == "cfg1":  # BASELINE.json configs[0]: the reference's CPU-runnable case (S corpus: 100K documents / 10K terms, 2000 queries)
+        return and2(E.gen_queries(V, seed, nq, 2)), E.FLAG_ACCUMULATED_SCORE, 10, E.CODEC_GOOGLE, "cfg1: 2-term AND, google_codec, AccumulatedScore + BM25, top-10"
     if name == "cfg2":
         return and2(E.gen_queries(V, seed, nq, 2)), E.FLAG_DOCUMENTS_ONLY, 0, E.CODEC_GOOGLE, "cfg2: batched 2-term AND, google_codec, DocumentsOnly"
     if name == "cfg3":
