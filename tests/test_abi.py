@@ -94,3 +94,35 @@ def test_lucene_segment_builder_matches_oracle_bytes(T, cfg):
     seg = T.Segment(D, V, S, seed, codec=CODEC_LUCENE)
     ix = O.Index.generate(D, V, S, seed, codec="lucene")
     assert np.array_equal(seg.index, ix.bytes()) and np.array_equal(seg.hits, ix.hits()) and np.array_equal(seg.terms, ix.terms())
+
+
+def test_error_contract_without_a_gpu():
+    """C-ABI error behaviour (include/trinity_hip.h: int status + tri_last_error, nothing thrown across the boundary).  Runs on
+    the CPU-only build box as well: without a device tri_dev_open must FAIL loudly (there is no fallback), and argument
+    errors are reported before any device work."""
+    import ctypes as C
+
+    import trinity_amd.engine as E
+
+    L = E.hip_lib()
+    dev = C.c_void_p()
+    rc = L.tri_dev_open(10_000, C.byref(dev))  # no such device anywhere
+    assert rc < 0 and not dev.value
+    assert L.tri_last_error()  # a message is always left behind
+    out = C.c_void_p()
+    assert L.tri_batch_create(None, None, 0, None, 0, None, 1, 0, 0, C.byref(out)) == -1 and not out.value  # TRI_ERR_INVALID
+    assert L.tri_index_upload(None, None, 0, None, 0, 1, None, 0, 0, C.byref(out)) == -1
+    assert L.tri_batch_run(None) < 0 and L.tri_batch_sync(None) < 0
+    n = C.c_size_t()
+    assert L.tri_batch_docset(None, 0, None, 0, C.byref(n)) < 0
+    assert L.tri_index_set_masked(None, None, 0) < 0
+    L.tri_batch_destroy(None)  # destroying nothing is a no-op
+    L.tri_index_destroy(None)
+    L.tri_dev_close(None)
+    import pytest
+
+    import torch
+
+    if not torch.cuda.is_available():
+        with pytest.raises(E.TrinityError):
+            E.Device(0)  # the Python binding turns the status into an exception; it never falls back to a CPU path

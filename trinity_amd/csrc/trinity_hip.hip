@@ -63,7 +63,7 @@ struct tri_dev {
 };
 
 struct tri_index {
-        tri_dev *dev;
+        tri_dev *dev = nullptr;
         int codec = TRI_CODEC_GOOGLE;
         uint8_t *d_index = nullptr, *d_hits = nullptr;
         uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr, *d_win = nullptr;
@@ -83,10 +83,25 @@ struct tri_index {
         std::vector<tri_term> tctx;
         std::vector<uint64_t> docbytes, hitbytes;
         tri_index_info info{};
+        ~tri_index() { // also runs when tri_index_upload fails half-way
+                if (dev)
+                        hipSetDevice(dev->device);
+                hipFree(d_index);
+                hipFree(d_hits);
+                hipFree(d_blk_hits);
+                hipFree(d_hdir);
+                hipFree(d_dstream);
+                hipFree(d_blk_doff);
+                hipFree(d_masked);
+                hipFree(d_blk_last);
+                hipFree(d_blk_off);
+                hipFree(d_win);
+                hipFree(d_terms);
+        }
 };
 
 struct tri_batch {
-        tri_index *ix;
+        tri_index *ix = nullptr;
         uint32_t flags, topk;
         int similarity = TRI_SIM_BM25;
         size_t nq;
@@ -132,6 +147,36 @@ struct tri_batch {
         std::vector<uint64_t> h_query_counts; // per plan slot
         bool synced = false;
         tri_batch_info info{};
+        ~tri_batch() { // also runs when tri_batch_create fails half-way: nothing allocated so far is leaked
+                if (ix)
+                        hipSetDevice(ix->dev->device);
+                hipFree(d_plan);
+                hipFree(d_tasks);
+                hipFree(d_sched);
+                hipFree(d_qterms);
+                hipFree(d_out);
+                hipFree(d_counts);
+                hipFree(d_ticket);
+                hipFree(d_hashes);
+                hipFree(d_sterms);
+                hipFree(d_sweights);
+                hipFree(d_part_docs);
+                hipFree(d_part_scores);
+                hipFree(d_part_counts);
+                hipFree(d_top_docs);
+                hipFree(d_top_scores);
+                hipFree(d_top_counts);
+                hipFree(d_all_scores);
+                hipFree(d_rich_present);
+                hipFree(d_rich_freq);
+                hipFree(d_task_hits);
+                hipFree(d_task_pos_base);
+                hipFree(d_rich_pool);
+                hipFree(d_phrases);
+                hipFree(d_pterms);
+                hipFree(d_ptasks);
+                hipFree(d_pscore);
+        }
 };
 
 #include "dev_stream.hpp"
@@ -575,21 +620,7 @@ extern "C" int tri_index_set_masked(tri_index *ix, const uint32_t *docids, size_
 }
 
 extern "C" void tri_index_destroy(tri_index *ix) {
-        if (!ix)
-                return;
-        hipSetDevice(ix->dev->device);
-        hipFree(ix->d_index);
-        hipFree(ix->d_hits);
-        hipFree(ix->d_blk_hits);
-        hipFree(ix->d_hdir);
-        hipFree(ix->d_dstream);
-        hipFree(ix->d_blk_doff);
-        hipFree(ix->d_masked);
-        hipFree(ix->d_blk_last);
-        hipFree(ix->d_blk_off);
-        hipFree(ix->d_win);
-        hipFree(ix->d_terms);
-        delete ix;
+        delete ix; // ~tri_index releases the device buffers
 }
 
 extern "C" int tri_index_get_info(const tri_index *ix, tri_index_info *info) {
@@ -1151,36 +1182,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
 }
 
 extern "C" void tri_batch_destroy(tri_batch *b) {
-        if (!b)
-                return;
-        hipSetDevice(b->ix->dev->device);
-        hipFree(b->d_plan);
-        hipFree(b->d_tasks);
-        hipFree(b->d_sched);
-        hipFree(b->d_qterms);
-        hipFree(b->d_out);
-        hipFree(b->d_counts);
-        hipFree(b->d_ticket);
-        hipFree(b->d_hashes);
-        hipFree(b->d_sterms);
-        hipFree(b->d_sweights);
-        hipFree(b->d_part_docs);
-        hipFree(b->d_part_scores);
-        hipFree(b->d_part_counts);
-        hipFree(b->d_top_docs);
-        hipFree(b->d_top_scores);
-        hipFree(b->d_top_counts);
-        hipFree(b->d_all_scores);
-        hipFree(b->d_rich_present);
-        hipFree(b->d_rich_freq);
-        hipFree(b->d_task_hits);
-        hipFree(b->d_task_pos_base);
-        hipFree(b->d_rich_pool);
-        hipFree(b->d_phrases);
-        hipFree(b->d_pterms);
-        hipFree(b->d_ptasks);
-        hipFree(b->d_pscore);
-        delete b;
+        delete b; // ~tri_batch releases the device buffers
 }
 
 extern "C" int tri_batch_run(tri_batch *b) {
