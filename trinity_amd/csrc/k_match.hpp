@@ -143,13 +143,14 @@ __device__ __forceinline__ bool load_block_bytes32(const uint8_t *__restrict__ p
 
 // Merge one block of term t against the candidates from `ptr` on (cv = candidate at ptr): set the hit bit of every
 // candidate that is a document of the block.  Full blocks of one-byte deltas take the register path above.
-template <int CODEC>
+// (PRE: the caller has already issued the payload loads into raw[] — by reference, so the array stays in registers)
+template <int CODEC, bool PRE>
 __device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
                                             const uint32_t n, const uint32_t prev, const uint32_t last, uint32_t ptr, uint32_t cv, const uint32_t C,
-                                            const uint32_t (*raw)[9] = nullptr) {
+                                            const uint32_t (&raw)[9]) {
         uint32_t doc = prev;
         uint32_t v[8];
-        if (CODEC == CODEC_GOOGLE && n == 32 && (raw ? block_bytes32_finish(index + off, *raw, v) : load_block_bytes32(index + off, v))) {
+        if (CODEC == CODEC_GOOGLE && n == 32 && (PRE ? block_bytes32_finish(index + off, raw, v) : load_block_bytes32(index + off, v))) {
                 // the (at most 8) candidates that can fall into this block, fetched from LDS in one go and kept in registers as a
                 // shift queue: the per-document step is then an add and a compare, with no LDS round trip in the lane's chain
                 uint32_t c[8];
@@ -312,8 +313,12 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                                         uint32_t ptr = lo;
                                         uint32_t cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
                                         PROF_LAP(6);
-                                        if (cv <= last)
-                                                merge_block<CODEC>(sh, index, t, b, off, TRI_BLOCK_N(t, b, index, off), prev, last, ptr, cv, C, full ? &raw : nullptr);
+                                        if (cv <= last) {
+                                                if (full)
+                                                        merge_block<CODEC, true>(sh, index, t, b, off, 32, prev, last, ptr, cv, C, raw);
+                                                else
+                                                        merge_block<CODEC, false>(sh, index, t, b, off, TRI_BLOCK_N(t, b, index, off), prev, last, ptr, cv, C, raw);
+                                        }
                                         PROF_LAP(7);
                                 }
                         }
@@ -374,7 +379,8 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
                         carry = __shfl(bj, 63, 64);
                         if (j < C && bj < t.nblocks && bj != prevb) {
                                 const uint32_t prev = bj ? bl[bj - 1] : 0;
-                                merge_block<CODEC>(sh, index, t, bj, bo[bj], TRI_BLOCK_N(t, bj, index, bo[bj]), prev, bl[bj], j, cv, C);
+                                const uint32_t none[9] = {};
+                                merge_block<CODEC, false>(sh, index, t, bj, bo[bj], TRI_BLOCK_N(t, bj, index, bo[bj]), prev, bl[bj], j, cv, C, none);
                         }
                 }
         }
