@@ -191,6 +191,12 @@ def main():
         }
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(seg, qs, args.cpu_seconds) if progs is None else cpu_baseline_programs(seg, progs, wflags, args.cpu_seconds)
+            # the sample the oracle just ran is also a full-size parity check: same queries, same segment, match totals must agree
+            n_s = out["cpu_baseline"].pop("_n", 0)
+            m_s = out["cpu_baseline"].pop("_matches", None)
+            if n_s and m_s is not None:
+                gpu_m = int(batch.counts()[:n_s].astype(np.uint64).sum())
+                out["parity_check"] = {"queries": n_s, "cpu_oracle_matches": int(m_s), "gpu_matches": gpu_m, "equal": bool(gpu_m == int(m_s))}
         print(json.dumps(out), flush=True)
 
     batch.close()
@@ -233,7 +239,8 @@ def cpu_baseline_programs(seg, progs, flags, budget_s):
             break
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} programs of rank 0's batch ({matches} matches) in {dt:.1f}s, oracle single thread", "host_cpus": os.cpu_count()}
+            "sample": f"first {n} programs of rank 0's batch ({matches} matches) in {dt:.1f}s, oracle single thread", "host_cpus": os.cpu_count(),
+            "_n": n, "_matches": matches}
 
 
 def cpu_baseline(seg, qs, budget_s):
@@ -263,6 +270,8 @@ def cpu_baseline(seg, qs, budget_s):
         "sample": f"first {n} queries of rank 0's batch ({matches} matches) in {dt:.1f}s, oracle/trinity_oracle.c single thread",
         "matched_docids_per_sec": matches / dt,
         "host_cpus": os.cpu_count(),
+        "_n": n,
+        "_matches": matches,
     }
     # also one query per thread on all host cores (the reference's exec_query is re-entrant per thread,
     # exec.cpp:12).  Same oracle, same queries, drawn from a shared cursor by C threads.
