@@ -51,6 +51,8 @@ extern "C" {
 #define TRI_OP_PHRASE 3u /* arg = #terms, the preceding arg tokens are TERMs (DocsSetIterators::Phrase) */
 #define TRI_OP_NOT 4u    /* operand = 2: the two preceding sub-programs are (required, excluded) — exec.cpp:424-427 logicalnot -> DocsSetIterators::Filter.
                             Lowered: NOT at the root or under AND, excluded side = a term or an OR of terms */
+#define TRI_OP_OPT 5u    /* operand = 2: (main, optional) — consttrueexpr under an AND (`a <b>`) -> DocsSetIterators::Optional, exec.cpp:366-377: the
+                            documents of main; the optional side (a term or an OR of terms) only adds its score / its matched terms */
 #define TRI_TOK(op, arg) (((uint32_t)(op) << 28) | ((uint32_t)(arg)&0x0fffffffu))
 
 typedef struct tri_dev tri_dev;

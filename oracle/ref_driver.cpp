@@ -291,7 +291,8 @@ int main(int argc, char **argv) {
                         while (!text.empty() && text[0] == ' ')
                                 text.erase(0, 1);
                         Collector coll;
-                        query q{str32_t(text.data(), uint32_t(text.size()))};
+                        // `a <b>`: ConstTrueExpr needs its parser flag (queries.h:238); default tokens parser
+                        query q{str32_t(text.data(), uint32_t(text.size())), default_token_parser_impl, unsigned(ast_parser::Flags::ParseConstTrueExpr)};
                         std::unique_ptr<Similarity::IndexSourceTermsScorer> scorer;
                         if (flags & unsigned(ExecFlags::AccumulatedScoreScheme)) {
                                 collScorer->reset(&collection);

@@ -1215,6 +1215,40 @@ static double filter_score(to_iter *self) {
         return f->req->score(f->req);
 }
 
+/* ================================================================== Optional (consttrueexpr under an AND) */
+typedef struct { /* docset_iterators.h:174-206 */
+        to_iter it;
+        to_iter *main, *opt;
+} to_optional;
+
+static uint32_t optional_next(to_iter *self) {
+        to_optional *o = (to_optional *)self;
+        return o->it.cur = o->main->next(o->main);
+}
+
+static uint32_t optional_advance(to_iter *self, uint32_t target) {
+        to_optional *o = (to_optional *)self;
+        return o->it.cur = o->main->advance(o->main, target);
+}
+
+/* does the optional side hold the document the main side sits on?  (docset_iterators_scorers.cpp:87-101, queryexec_ctx.cpp:418-432) */
+static int optional_opt_matches(to_optional *o) {
+        const uint32_t id = o->main->cur;
+        uint32_t optId = o->opt->cur;
+        if (optId < id)
+                optId = o->opt->advance(o->opt, id);
+        return optId == id;
+}
+
+/* docset_iterators_scorers.cpp:77-104 */
+static double optional_score(to_iter *self) {
+        to_optional *o = (to_optional *)self;
+        double score = o->main->score(o->main);
+        if (optional_opt_matches(o))
+                score += o->opt->score(o->opt);
+        return score;
+}
+
 typedef struct pnode {
         uint32_t op, term;
         struct pnode **kids;
@@ -1296,6 +1330,18 @@ static pnode *parse_prog(to_ctx *c, const uint32_t *prog, uint32_t len) {
                         n->empty = n->nkids == 0;
                         for (uint32_t j = 0; j < n->nkids; ++j)
                                 n->cost += n->kids[j]->cost;
+                } else if (op == TO_OP_OPT) {
+                        if (arg != 2)
+                                return NULL;
+                        if (kids[1]->empty) { /* an optional side that can never match adds nothing */
+                                sp -= arg;
+                                stack[sp++] = kids[0];
+                                continue;
+                        }
+                        n->kids[n->nkids++] = kids[0];
+                        n->kids[n->nkids++] = kids[1];
+                        n->empty = kids[0]->empty;
+                        n->cost = kids[0]->cost; /* exec.cpp:71-76: the cost of the other side of the AND */
                 } else if (op == TO_OP_NOT) {
                         if (arg != 2)
                                 return NULL;
@@ -1362,6 +1408,17 @@ static to_iter *build_iter(to_ctx *c, const pnode *n) {
                         for (uint32_t i = 0; i < n->nkids; ++i)
                                 cj->c.its[i] = build_iter(c, n->kids[i]);
                         return &cj->c.it;
+                }
+                case TO_OP_OPT: { /* exec.cpp:366-377 */
+                        to_optional *o = (to_optional *)ctx_own(c, xcalloc(1, sizeof *o));
+                        o->it.type = IT_OPTIONAL;
+                        o->it.next = optional_next;
+                        o->it.advance = optional_advance;
+                        o->it.score = optional_score;
+                        o->it.cost = n->cost;
+                        o->main = build_iter(c, n->kids[0]);
+                        o->opt = build_iter(c, n->kids[1]);
+                        return &o->it;
                 }
                 case TO_OP_NOT: { /* exec.cpp:424-427 */
                         to_filter *f = (to_filter *)ctx_own(c, xcalloc(1, sizeof *f));
@@ -1560,6 +1617,12 @@ static void collect_terms(to_iter *it, uint32_t doc, termset *out) {
                 case IT_FILTER:
                         collect_terms(((to_filter *)it)->req, doc, out);
                         break;
+                case IT_OPTIONAL: { /* queryexec_ctx.cpp:418-432 */
+                        to_optional *o = (to_optional *)it;
+                        collect_terms(o->main, doc, out);
+                        if (optional_opt_matches(o))
+                                collect_terms(o->opt, doc, out);
+                } break;
         }
 }
 

@@ -39,6 +39,8 @@ extern "C" {
 #define TO_OP_OR 2u     /* operand = number of children (>= 2) */
 #define TO_OP_PHRASE 3u /* operand = number of terms; the n preceding tokens must be TERMs */
 #define TO_OP_NOT 4u    /* operand = 2: the two preceding sub-programs are (required, excluded); exec.cpp:424-427 logicalnot */
+#define TO_OP_OPT 5u    /* operand = 2: (main, optional) — `a <b>`: consttrueexpr under an AND -> DocsSetIterators::Optional (exec.cpp:366-377):
+                           the documents of main; optional only adds its score / its matched terms where it matches */
 #define TO_TOK(op, arg) (((uint32_t)(op) << 28) | ((uint32_t)(arg)&0x0fffffffu))
 #define TO_TOK_OP(t) ((t) >> 28)
 #define TO_TOK_ARG(t) ((t)&0x0fffffffu)

@@ -94,6 +94,12 @@ int main(int argc, char **argv) {
                         exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
                         show("not_scored", c);
                 }
+                { // t3 t1 <t5 OR t2>: DocsSetIterators::Optional — main's documents, the optional side only scores where it matches
+                        Collect c;
+                        auto q = src.optional(src.conjunction({src.term("t3"), src.term("t1")}), src.disjunction({src.term("t5"), src.term("t2")}));
+                        exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("optional_scored", c);
+                }
                 { // the other scorers of similarity.h through the same seam
                         Similarity::IndexSourcesCollectionTFIDFScorer tfidf;
                         std::unique_ptr<Similarity::IndexSourceTermsScorer> s2(tfidf.new_source_scorer(&src));

@@ -43,6 +43,11 @@ TEMPLATES = [
     "(t{a} OR t{b}) t{d} NOT t{c}",
     "t{a} NOT (t{b} OR t{c})",
     "t{a} NOT (t{b} t{c})",
+    # consttrueexpr under an AND -> DocsSetIterators::Optional (exec.cpp:366-377; parser flag ParseConstTrueExpr)
+    "t{a} <t{b}>",
+    "t{a} t{b} <t{c} OR t{d}>",
+    "t{a} <t{c}> t{b}",
+    "(t{a} OR t{b}) <t{c}>",
 ]
 
 

@@ -17,7 +17,7 @@ REF_DRIVER = os.path.join(ORACLE_DIR, "_ref", "ref_driver")
 DOCIDS_END = 0xFFFFFFFF
 FLAG_DOCUMENTS_ONLY = 1
 FLAG_ACCUM_SCORE = 2
-OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT = 0, 1, 2, 3, 4
+OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT, OP_OPT = 0, 1, 2, 3, 4, 5
 SIM_BM25, SIM_TFIDF, SIM_TRIVIAL = 0, 1, 2
 
 
@@ -320,7 +320,7 @@ class PLI:
 
 # ---- tiny query-text -> postfix program compiler for the query templates of SURVEY §8(d) ------------
 def parse_query(text):
-    """Supports: terms tN, juxtaposition = AND, OR, NOT, parentheses, "phrases".  OR binds looser than AND
+    """Supports: terms tN, juxtaposition = AND, OR, NOT, parentheses, "phrases", <optional>.  OR binds looser than AND
     (Trinity: queries.h operators; `a b OR c` is not used by the fixtures to avoid precedence ambiguity)."""
     toks = []
     i = 0
@@ -328,7 +328,7 @@ def parse_query(text):
         ch = text[i]
         if ch.isspace():
             i += 1
-        elif ch in "()":
+        elif ch in "()<>":
             toks.append(ch)
             i += 1
         elif ch == '"':
@@ -337,7 +337,7 @@ def parse_query(text):
             i = j + 1
         else:
             j = i
-            while j < len(text) and not text[j].isspace() and text[j] not in '()"':
+            while j < len(text) and not text[j].isspace() and text[j] not in '()"<>':
                 j += 1
             w = text[i:j]
             toks.append(w if w in ("OR", "NOT") else ("TERM", int(w[1:])))
@@ -355,6 +355,11 @@ def parse_query(text):
             assert peek() == ")"
             pos[0] += 1
             return r
+        if t == "<":  # <expr>: ConstTrueExpr (ast_parser::Flags::ParseConstTrueExpr) — optional under an AND
+            r = expr_or()
+            assert peek() == ">"
+            pos[0] += 1
+            return ("OPT", r)
         if t[0] == "TERM":
             return [tok(OP_TERM, t[1])]
         if t[0] == "PHRASE":
@@ -365,11 +370,18 @@ def parse_query(text):
 
     def expr_and():
         parts = [primary()]
-        while peek() is not None and peek() not in (")", "OR", "NOT"):
+        while peek() is not None and peek() not in (")", ">", "OR", "NOT"):
             parts.append(primary())
-        if len(parts) == 1:
-            return parts[0]
-        return sum(parts, []) + [tok(OP_AND, len(parts))]
+        # juxtaposition is a left-associative binary AND in Trinity; an AND with a <...> operand becomes Optional(other, opt)
+        # (exec.cpp:366-377), and a <...> that is not under an AND is just its expression (:434-441)
+        req = [p_ for p_ in parts if not (isinstance(p_, tuple) and p_[0] == "OPT")]
+        opts = [p_[1] for p_ in parts if isinstance(p_, tuple) and p_[0] == "OPT"]
+        if not req:
+            req, opts = [opts[0]], opts[1:]
+        r = req[0] if len(req) == 1 else sum(req, []) + [tok(OP_AND, len(req))]
+        for o in opts:
+            r = r + o + [tok(OP_OPT, 2)]
+        return r
 
     def expr_not():
         # `x y NOT z` == (x y) NOT z, left-associative (what Trinity's parser produced for the fixtures)

@@ -718,3 +718,36 @@ def test_rich_mode_against_reference_fixtures(T, dev):
             checked += 1
         w.ix.close()
     assert checked >= 150
+
+
+# ------------------------------------------------------------------------------------------ Optional (consttrueexpr under an AND)
+OPT_TEMPLATES = ["t{a} <t{b}>", "t{a} t{b} <t{c} OR t{d}>", "t{a} <t{c}> t{b}", "(t{a} OR t{b}) <t{c}>", "t{a} <t{a}>", "(t{a} t{b} NOT t{e}) <t{c}>", '"t{a} t{b}" <t{c}>']
+
+
+def opt_queries(w, seed, n):
+    rows = w.T.gen_queries(w.V, seed, n, 5).tolist()
+    head = [[0, 1, 2, 3, 4], [3, 0, 1, 4, 7], [5, 2, 0, 3, 9]]
+    return [tpl.format(a=a, b=b, c=c, d=d, e=e) for a, b, c, d, e in head + rows for tpl in OPT_TEMPLATES]
+
+
+@pytest.mark.parametrize("world", ["small", "dense", "small_l"])
+def test_optional_matches_oracle(request, world):
+    """`a <b>`: the documents of a; b adds its score where it matches (docset_iterators_scorers.cpp:77-104) and is reported among
+    the matched terms where it matches (queryexec_ctx.cpp:418-432) — in all three execution modes."""
+    w = request.getfixturevalue(world)
+    texts = opt_queries(w, 111, 8)
+    progs = [O.parse_query(t) for t in texts]
+    sets, hashes, _ = run_docs_only(w, progs)
+    for t, p, got in zip(texts, progs, sets):
+        want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+        assert np.array_equal(got, want), t
+    d, s, c, counts = run_scored(w, progs, 20)
+    for i, t in enumerate(texts):
+        docs, scores = w.ora.exec(progs[i], O.FLAG_ACCUM_SCORE)
+        assert int(counts[i]) == len(docs), t
+        td, ts = w.ora.topk(docs, scores, 20)
+        assert d[i, : len(td)].tolist() == td.tolist(), t
+        np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+    for t, p, (docs, terms, present, freq, pos) in zip(texts, progs, run_rich(w, progs)):
+        wdocs, wflat, tt, ht = w.ora.exec_rich(p)
+        assert np.array_equal(docs, wdocs) and np.array_equal(rich_flat(docs, terms, present, freq, pos), wflat), t

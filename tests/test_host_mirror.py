@@ -64,6 +64,7 @@ def test_mirror_results_match_oracle(T, tmp_path):
     expect("or_even", "t3 OR t7", 1, keep=lambda d: (d & 1) == 0)
     expect("phrase_scored", '"t0 t1" t2', 2)
     expect("not_scored", "t3 t5 NOT (t1 OR t2)", 2)
+    expect("optional_scored", "t3 t1 <t5 OR t2>", 2)
     expect("tfidf_scored", "t0 t1 (t2 OR t3)", 2, sim=O.SIM_TFIDF)
     expect("trivial_scored", "t0 t1", 2, sim=O.SIM_TRIVIAL)
     expect("masked_scored", "t0 t1", 2, keep=lambda d: (d % 3) != 0)

@@ -105,7 +105,7 @@ namespace trinity_amd {
 
         // ------------------------------------------------------------------ iterators (plan nodes + cursors)
         namespace DocsSetIterators {
-                enum class Type : uint8_t { PostingsListIterator = 0, Filter = 2, Disjunction = 4, DisjunctionAllPLI, Phrase, Conjuction, ConjuctionAllPLI }; // docset_iterators_base.h:10-23
+                enum class Type : uint8_t { PostingsListIterator = 0, Filter = 2, Optional = 3, Disjunction = 4, DisjunctionAllPLI, Phrase, Conjuction, ConjuctionAllPLI }; // docset_iterators_base.h:10-23
 
                 struct Iterator : public relevant_document_provider { // docset_iterators_base.h:45-96
                         struct {
@@ -268,6 +268,18 @@ namespace trinity_amd {
                                 w.push_back(0.0);
                         }
                 };
+                struct Optional final : public Iterator { // docset_iterators.h:174-206: main's documents; opt adds score / matched terms where it matches
+                        Iterator *const main, *const opt;
+                        Optional(Iterator *const m, Iterator *const o)
+                            : Iterator{Type::Optional, m->isrc}, main{m}, opt{o} {}
+                        uint64_t cost() const override { return main->cost(); }
+                        void lower(std::vector<uint32_t> &prog, std::vector<double> &w, Similarity::IndexSourceTermsScorer *scorer) const override {
+                                main->lower(prog, w, scorer);
+                                opt->lower(prog, w, scorer);
+                                prog.push_back(TRI_TOK(TRI_OP_OPT, 2));
+                                w.push_back(0.0);
+                        }
+                };
                 struct Phrase final : public Iterator { // docset_iterators.h:364-402
                         std::vector<Codecs::PostingsListIterator *> its;
                         Phrase(Codecs::PostingsListIterator **iterators, uint16_t cnt)
@@ -425,6 +437,7 @@ namespace trinity_amd {
                 }
                 DocsSetIterators::Iterator *conjunction(std::vector<DocsSetIterators::Iterator *> its) { return reg<DocsSetIterators::Conjuction>(its.data(), uint16_t(its.size())); }
                 DocsSetIterators::Iterator *disjunction(std::vector<DocsSetIterators::Iterator *> its) { return reg<DocsSetIterators::Disjunction>(its.data(), uint16_t(its.size())); }
+                DocsSetIterators::Iterator *optional(DocsSetIterators::Iterator *main, DocsSetIterators::Iterator *opt) { return reg<DocsSetIterators::Optional>(main, opt); } // exec.cpp:366-377
                 DocsSetIterators::Iterator *filter(DocsSetIterators::Iterator *req, DocsSetIterators::Iterator *excl) { return reg<DocsSetIterators::Filter>(req, excl); } // exec.cpp:424-427
                 DocsSetIterators::Iterator *phrase(const std::vector<std::string> &terms) {
                         std::vector<Codecs::PostingsListIterator *> its;

@@ -745,6 +745,16 @@ namespace {
                                         n.empty = n.kids.empty();
                                         for (int k : n.kids)
                                                 n.cost += nodes[k].cost;
+                                } else if (op == TRI_OP_OPT) {
+                                        if (arg != 2)
+                                                return -1;
+                                        if (nodes[kids[1]].empty) { // an optional side that can never match adds nothing
+                                                st.push_back(kids[0]);
+                                                continue;
+                                        }
+                                        n.kids = kids; // {main, optional}
+                                        n.empty = nodes[kids[0]].empty;
+                                        n.cost = nodes[kids[0]].cost;
                                 } else if (op == TRI_OP_NOT) {
                                         if (arg != 2)
                                                 return -1;
@@ -881,10 +891,28 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 // logicalnot at the root or under an AND: its required side joins the conjunction, its excluded side (a term or an
                 // OR of terms) joins the query's excluded set: A B -C == A ∧ B ∧ ¬C (Filter semantics, docset_iterators.cpp:652-677)
                 bool ok = true;
-                std::vector<uint32_t> negs;
+                std::vector<uint32_t> negs, opts;
                 std::function<void(int)> lower = [&](int ni) {
                         const PNode &x = nodes[ni];
-                        if (x.op == TRI_OP_NOT) {
+                        if (x.op == TRI_OP_OPT) {
+                                // Optional(main, opt): the documents of main; opt's terms score (and are reported) where they match —
+                                // exactly how k_score / k_rich treat a term a match does not hold
+                                lower(x.kids[0]);
+                                const PNode &e = nodes[x.kids[1]];
+                                if (e.op == TRI_OP_TERM)
+                                        opts.push_back(e.term);
+                                else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1)
+                                        opts.push_back(nodes[e.kids[0]].term);
+                                else if (e.op == TRI_OP_OR) {
+                                        for (int k : e.kids) {
+                                                if (nodes[k].op != TRI_OP_TERM)
+                                                        ok = false;
+                                                else
+                                                        opts.push_back(nodes[k].term);
+                                        }
+                                } else
+                                        ok = false;
+                        } else if (x.op == TRI_OP_NOT) {
                                 lower(x.kids[0]);
                                 const PNode &e = nodes[x.kids[1]];
                                 if (e.op == TRI_OP_TERM)
@@ -907,8 +935,14 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 ok &= add_group(x);
                 };
                 lower(root);
+                for (uint32_t x : opts)
+                        if (ix->terms[x].documents) {
+                                leaves.push_back(x); // one more scorer / reportable term each; never part of the docID set
+                                if (mode != TRI_FLAG_DOCUMENTS_ONLY)
+                                        b->term_bytes += ix->docbytes[x]; // its postings are read by k_score / k_rich
+                        }
                 if (!ok || groups.empty())
-                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, and NOT (at the root or under AND) of a term or an OR of terms", qi);
+                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, and <optional> terms under AND", qi);
                 auto gcost = [&](const std::vector<uint32_t> &g) {
                         uint64_t c = 0;
                         for (uint32_t x : g)
