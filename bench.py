@@ -80,7 +80,9 @@ def main():
     seg = T.Segment(args.docs, args.vocab, 10, 42, codec=codec)
     build_s = time.time() - t0
     dev = T.Device(local_rank)
+    t0 = time.time()
     ix = T.Index.from_segment(dev, seg)
+    upload_s = time.time() - t0  # one-time: format walk + directory / delta-stream / cell-index build on the host, then PCIe
     info = ix.info()
     if progs is None:
         qall = T.gen_queries(args.vocab, 1337, args.queries * world, 2)
@@ -188,6 +190,7 @@ def main():
                 "whole_step": {"kernel_ms": k_ms, "algorithmic_bytes": alg, "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else 0.0},
             },
             "segment_build_s": build_s,
+            "index_upload_s": upload_s,
         }
         if args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(seg, qs, args.cpu_seconds) if progs is None else cpu_baseline_programs(seg, progs, wflags, args.cpu_seconds)

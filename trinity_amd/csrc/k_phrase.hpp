@@ -23,7 +23,7 @@
 // its row and lands on the absolute hit index, which HitStream<CODEC_LUCENE> turns into (block, quarter, slot).
 struct HitCtx {
         const uint8_t *base;      // GOOGLE: index[] (hits are inline), LUCENE: hits.data
-        const uint32_t *blk_hits; // LUCENE: hits of the term before each directory row
+        const uint32_t *blk_hits; // per directory row, where its hits start — LUCENE: hit ordinal within the term; GOOGLE: byte offset into index[]
         const uint32_t *hdir;     // LUCENE: per term { nfull, off[0..nfull-1], tail_off } into hits.data
 };
 
@@ -153,7 +153,7 @@ __device__ __forceinline__ void phrase_locate<CODEC_LUCENE>(const uint8_t *__res
 
 template <>
 __device__ __forceinline__ void phrase_locate<CODEC_GOOGLE>(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                                            const uint32_t *__restrict__ blk_off, const HitCtx &, const DevTerm t, const uint32_t doc,
+                                                            const uint32_t *__restrict__ blk_off, const HitCtx &ctx, const DevTerm t, const uint32_t doc,
                                                             uint32_t &hits_off, uint32_t &freq) {
         const uint32_t *bl = blk_last + t.first_block;
         uint32_t lo = 0, hi = t.nblocks;
@@ -176,8 +176,7 @@ __device__ __forceinline__ void phrase_locate<CODEC_GOOGLE>(const uint8_t *__res
                         idx = i;
         }
         VbStream sf = s; // freqs start here
-        for (uint32_t i = 0; i < n; ++i)
-                (void)s.next(); // s: hits start
+        s.init(index + ctx.blk_hits[t.first_block + b]); // the block's hits (the directory knows where they start: no walk over the n freqs)
         for (uint32_t i = 0; i < idx; ++i) { // skip the hits of the preceding slots
                 const uint32_t f = sf.next();
                 uint32_t plen = 0; // payload length state restarts with every document
@@ -246,8 +245,7 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
                         }
                 }
                 VbStream sf = s; // freqs start here
-                for (uint32_t i = 0; i < n; ++i)
-                        (void)s.next(); // s: hits start
+                s.init(index + ctx.blk_hits[t.first_block + b]); // hits start (from the directory)
                 cj = ci;
                 for (uint32_t i = 0; i < n && (mask >> i); ++i) {
                         const uint32_t f = sf.next();

@@ -67,7 +67,8 @@ struct tri_index {
         int codec = TRI_CODEC_GOOGLE;
         uint8_t *d_index = nullptr, *d_hits = nullptr;
         uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr, *d_win = nullptr;
-        uint32_t *d_blk_hits = nullptr, *d_hdir = nullptr; // LUCENE + hits.data: positional access (k_phrase.hpp)
+        uint32_t *d_blk_hits = nullptr, *d_hdir = nullptr; // where a directory row's hits start — LUCENE + hits.data: hit ordinal within the term
+                                                           // (+ hdir: the 128-hit blocks of hits.data); GOOGLE: byte offset into index[]
         // GOOGLE: the document deltas of every block re-laid out as one contiguous stream per term ([n][n-1 prefix varints] per
         // block, bytes exactly as in the chunk) with its own offset column.  In the chunk a block's deltas are followed by its
         // freqs and hits, so a DocumentsOnly scan of a head term drags ~3x the bytes it decodes through HBM; the matching kernels
@@ -512,6 +513,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                         dstream.insert(dstream.end(), p, s);
                         for (uint32_t i = 0; i < n; ++i)
                                 s += h_vb_len(*s);
+                        blk_hits.push_back((uint32_t)(s - index)); // GOOGLE: byte offset of the block's first hit (k_phrase / k_rich start there)
                         if ((uint64_t)(s - p) > blockLength)
                                 return fail(TRI_ERR_FORMAT, "term %zu: deltas+freqs overrun the block", ti);
                         db += (uint64_t)(s - h);
@@ -584,6 +586,8 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 if (want_hits && ((rc = dev_upload(&ix->d_blk_hits, blk_hits)) || (rc = dev_upload(&ix->d_hdir, hdir))))
                         return rc;
         }
+        if (codec == TRI_CODEC_GOOGLE && (rc = dev_upload(&ix->d_blk_hits, blk_hits)))
+                return rc;
         ix->h_blk_last = std::move(blk_last);
         ix->info.index_bytes = len;
         ix->info.directory_bytes = ix->h_blk_last.size() * 8 + nterms * sizeof(DevTerm) + win.size() * 4;
