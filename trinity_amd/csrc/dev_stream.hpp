@@ -93,22 +93,25 @@ __device__ __forceinline__ uint32_t vb_decode(uint64_t w, uint32_t &len) {
 }
 
 // Per-lane byte stream over global memory: a 16-byte register window (lo = next 8 bytes, hi = the following
-// ones) refilled from aligned 8-byte loads, with three further qwords always in flight so that the load
-// latency sits behind ~24 bytes of decoding (index[] carries >= 64 bytes of slack past the last chunk).
+// ones) refilled from aligned 8-byte loads, with AHEAD further qwords always in flight so that the load
+// latency sits behind 8 * AHEAD bytes of decoding (index[] carries >= 64 bytes of slack past the last chunk).
+#ifndef TRI_VB_AHEAD
+#define TRI_VB_AHEAD 3
+#endif
 struct VbStream {
+        static constexpr int AHEAD = TRI_VB_AHEAD; // qwords in flight beyond the 16-byte window
         const uint64_t *q;
-        uint64_t lo, hi, n1, n2, n3;
+        uint64_t lo, hi, n[AHEAD];
         int valid;
 
         __device__ __forceinline__ void init(const uint8_t *p) {
-                const uintptr_t a = (uintptr_t)p;
-                const uint32_t sk = (uint32_t)(a & 7u);
-                q = (const uint64_t *)(a & ~(uintptr_t)7);
+                const uint32_t sk = (uint32_t)((uintptr_t)p & 7u);
+                q = (const uint64_t *)(p - sk); // by pointer arithmetic, not through an integer: the loads stay global_load
                 const uint64_t w0 = q[0], w1 = q[1];
-                n1 = q[2];
-                n2 = q[3];
-                n3 = q[4];
-                q += 5;
+#pragma unroll
+                for (int i = 0; i < AHEAD; ++i)
+                        n[i] = q[2 + i];
+                q += 2 + AHEAD;
                 const uint32_t sh = sk * 8;
                 lo = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
                 hi = sh ? (w1 >> sh) : w1;
@@ -116,10 +119,11 @@ struct VbStream {
         }
         __device__ __forceinline__ void refill() {
                 if (valid <= 8) {
-                        const uint64_t w = n1;
-                        n1 = n2;
-                        n2 = n3;
-                        n3 = *q++;
+                        const uint64_t w = n[0];
+#pragma unroll
+                        for (int i = 0; i + 1 < AHEAD; ++i)
+                                n[i] = n[i + 1];
+                        n[AHEAD - 1] = *q++;
                         const uint32_t sh = (uint32_t)valid * 8; // 0..64
                         if (valid == 8)
                                 hi = w;
@@ -143,8 +147,8 @@ struct VbStream {
                 valid -= (int)len;
                 return v;
         }
-        // address of the next unread byte (24 bytes sit in n1..n3, `valid` more in the window)
-        __device__ __forceinline__ const uint8_t *tell() const { return (const uint8_t *)q - 24 - valid; }
+        // address of the next unread byte (8 * AHEAD bytes sit in n[], `valid` more in the window)
+        __device__ __forceinline__ const uint8_t *tell() const { return (const uint8_t *)q - 8 * AHEAD - valid; }
         __device__ __forceinline__ uint32_t byte() {
                 refill();
                 const uint32_t b = (uint32_t)lo & 0xffu;

@@ -506,7 +506,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                                 s += h_vb_len(*s);
                         if ((uint64_t)(s - p) > blockLength)
                                 return fail(TRI_ERR_FORMAT, "term %zu: deltas overrun the block", ti);
-                        if (dstream.size() + 64 > 0xffffffffull)
+                        if (dstream.size() + 256 > 0xffffffffull)
                                 return fail(TRI_ERR_UNSUPPORTED, "delta stream exceeds 4 GiB");
                         dstream.push_back((uint8_t)n);
                         blk_doff.push_back((uint32_t)dstream.size());
@@ -567,21 +567,21 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         int rcw;
         if ((rcw = dev_upload(&ix->d_win, win)))
                 return rcw;
-        HIP_TRY(hipMalloc((void **)&ix->d_index, len + 64));
-        HIP_TRY(hipMemset(ix->d_index, 0, len + 64));
+        HIP_TRY(hipMalloc((void **)&ix->d_index, len + 256)); // over-read slack: the byte streams keep several qwords in flight past the cursor
+        HIP_TRY(hipMemset(ix->d_index, 0, len + 256));
         if (len)
                 HIP_TRY(hipMemcpy(ix->d_index, index, len, hipMemcpyHostToDevice));
         int rc;
         if ((rc = dev_upload(&ix->d_blk_last, blk_last)) || (rc = dev_upload(&ix->d_blk_off, blk_off)) || (rc = dev_upload(&ix->d_terms, ix->terms)))
                 return rc;
         if (codec == TRI_CODEC_GOOGLE) {
-                dstream.resize(dstream.size() + 64, 0); // over-read slack, like index[]
+                dstream.resize(dstream.size() + 256, 0); // over-read slack, like index[]
                 if ((rc = dev_upload(&ix->d_dstream, dstream)) || (rc = dev_upload(&ix->d_blk_doff, blk_doff)))
                         return rc;
         }
         if (hits_len) { // LUCENE: hits.data (positions) resident next to the index
-                HIP_TRY(hipMalloc((void **)&ix->d_hits, hits_len + 64));
-                HIP_TRY(hipMemset(ix->d_hits, 0, hits_len + 64));
+                HIP_TRY(hipMalloc((void **)&ix->d_hits, hits_len + 256));
+                HIP_TRY(hipMemset(ix->d_hits, 0, hits_len + 256));
                 HIP_TRY(hipMemcpy(ix->d_hits, hits, hits_len, hipMemcpyHostToDevice));
                 if (want_hits && ((rc = dev_upload(&ix->d_blk_hits, blk_hits)) || (rc = dev_upload(&ix->d_hdir, hdir))))
                         return rc;
