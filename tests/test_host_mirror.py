@@ -97,3 +97,23 @@ def test_mirror_results_match_oracle(T, tmp_path):
     i = int(np.searchsorted(d5, 1000))
     assert int(p["adv1000"]) == d5[i] and int(p["freq"]) == f5[i] and int(p["again"]) == d5[i]
     assert "invalid_argument" in res.stdout.splitlines()[-1]
+
+
+def test_workload_generators_on_cpu(T):
+    """trinity_amd/workloads.py (what bench.py --workload times): every program parses in the oracle, and the phrases that
+    csrc/host/synth.cpp samples from a document's consecutive token slots — by addressing the corpus stream as a counter-based
+    generator, without materialising the corpus — really occur in the oracle's independently generated corpus."""
+    from trinity_amd import workloads as W
+
+    D, V = 5000, 500
+    ora = O.Index.generate(D, V, 10, 42)
+    for name in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
+        progs, flags, topk, codec, desc = W.build(name, D, V, 10, 42, 60)
+        assert len(progs) == 60 and desc.startswith(name)
+        hits = 0
+        for p in progs:
+            docs, _ = ora.exec(p, O.FLAG_DOCUMENTS_ONLY if not (flags & 2) else O.FLAG_ACCUM_SCORE)
+            hits += len(docs) > 0
+        if name == "cfg4":
+            # even rows of each half are document-sampled: at least those must match
+            assert hits >= 30
