@@ -141,9 +141,11 @@ int tri_decode_terms(tri_index *, const uint32_t *terms, size_t n, uint32_t *doc
  * (docset_iterators_scorers.cpp) with Similarity BM25 (similarity.h:165-255), and the application's
  * top-K MatchedIndexDocumentsFilter::consider(id, score) heap (matches.h:155-171).
  *
- * prog/queries: postfix programs.  flags: TRI_FLAG_DOCUMENTS_ONLY (results = ascending docID sets) or
+ * prog/queries: postfix programs.  flags — exactly one of: TRI_FLAG_DOCUMENTS_ONLY (results = ascending docID sets),
  * TRI_FLAG_ACCUMULATED_SCORE (topk >= 1: results = top-K by score desc, docID asc + total match counts;
- * topk == 0: every match's score is kept, see tri_batch_scores).
+ * topk == 0: every match's score is kept, see tri_batch_scores), TRI_FLAG_MATCHED_TERMS (exec_query's default mode:
+ * ascending docID sets + per match the matched query terms with their hits, see tri_batch_matched_terms).
+ * similarity: TRI_SIM_BM25 / TRI_SIM_TFIDF / TRI_SIM_TRIVIAL — which IndexSourceTermsScorer::score() the device evaluates.
  * weights: optional, one double per program token (TERM tokens: the term's ScorerWeight, PHRASE tokens:
  * the phrase's); NULL => BM25 idf computed from the index's own statistics exactly as
  * IndexSourcesCollectionBM25Scorer does for a single source (similarity.h:179-181, 202-226). */
