@@ -5,7 +5,7 @@
 
 // ------------------------------------------------------------------------------------------ k_and
 constexpr int AND_WG = 256;   // candidate-tile kernel (k_and) and the scoring kernels
-constexpr int DENSE_WG = 512; // bitmap-window kernel (k_and_dense): 8 waves share one 36 KB window state
+constexpr int DENSE_WG = 512; // bitmap-window kernel (k_and_dense): 8 waves share one 38 KB window state
 constexpr int TILE_BLOCKS = 256; // one candidate row per lane: must equal AND_WG
 static_assert(TILE_BLOCKS == 256, "the candidate kernel maps one 32-candidate row to each of its 256 lanes");
 constexpr int TILE_CANDS = TILE_BLOCKS * 32;
@@ -387,9 +387,8 @@ __device__ void and_filter_tile(AndShared &sh, const uint8_t *__restrict__ index
 }
 
 // ---- TASK_DENSE: bitmap algebra over docID windows -------------------------------------------------------
-// One lane decodes one block (unpack_block, google_codec.cpp:596-639) and ORs its documents into / tests them
-// against a window bitmap in LDS.  Consecutive documents of a dense list fall into the same 32-bit word, so the
-// lane keeps the current word in registers and touches LDS once per word, not once per posting.
+// One lane decodes one block (unpack_block, google_codec.cpp:596-639) and sets its documents' bits in a window bitmap in
+// LDS; groups are combined by word-wise AND / AND-NOT of whole bitmaps; the survivors are expanded to ascending docIDs.
 // One posting into a window bitmap.  `rel` = docID - window start (+ BM_B_WORDS * 32 for bitmap B).  Fire-and-forget:
 // no value comes back from LDS, so nothing in the lane's chain waits on it.  Every term only SETS bits; a conjunct is
 // folded in by AND-ing whole bitmaps afterwards (dense_task), 8 words per thread instead of a dependent LDS read per
