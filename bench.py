@@ -57,15 +57,20 @@ def main():
     import trinity_amd as T
     from trinity_amd import dist as TD
 
-    T.build_all()
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one rank makes sure the native libraries are built (normally a no-op: the built .so travel with the tree); the
+        # others wait instead of racing hipcc on the same output file
+        if local_rank == 0:
+            T.build_all()
+        dist.barrier()
     else:
         torch.cuda.set_device(local_rank)
+        T.build_all()
 
     # ---- synthetic segment (identical on every rank) and this rank's query batch
     t0 = time.time()
