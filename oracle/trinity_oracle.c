@@ -1529,8 +1529,18 @@ static void span_disjunction(to_ctx *c, to_iter **its, uint32_t cnt, uint32_t fl
         }
 }
 
+/* the result buffers of `out` are reused when it already owns some (n is reset): the multi-threaded baseline keeps one result
+ * per thread — the application-side collector a MatchedIndexDocumentsFilter would be — instead of growing a fresh one per
+ * query (large reallocations are mmap/munmap calls, which serialise the threads in the kernel) */
+static int exec_query_into(const to_index *ix, const uint32_t *prog, uint32_t proglen, uint32_t flags, to_result *out);
+
 int to_exec_query(const to_index *ix, const uint32_t *prog, uint32_t proglen, uint32_t flags, to_result *out) {
         memset(out, 0, sizeof *out);
+        return exec_query_into(ix, prog, proglen, flags, out);
+}
+
+static int exec_query_into(const to_index *ix, const uint32_t *prog, uint32_t proglen, uint32_t flags, to_result *out) {
+        out->n = 0;
         if ((flags & (TO_FLAG_DOCUMENTS_ONLY | TO_FLAG_ACCUM_SCORE)) == 0 ||
             (flags & (TO_FLAG_DOCUMENTS_ONLY | TO_FLAG_ACCUM_SCORE)) == (TO_FLAG_DOCUMENTS_ONLY | TO_FLAG_ACCUM_SCORE))
                 return -1; /* exec.h:45-48: mutually exclusive; the default rich mode is out of scope */
@@ -1810,6 +1820,7 @@ uint64_t to_fnv1a_docs(const uint32_t *docs, size_t n) {
 typedef struct {
         const to_index *ix;
         const uint32_t *progs;
+        const uint32_t *order; /* query indices, heaviest first (longest-processing-time-first keeps the tail short) */
         uint32_t proglen, nq, flags;
         double deadline;
         uint64_t cursor, done, matches;
@@ -1825,20 +1836,21 @@ static double mt_now(void) {
 static void *mt_worker(void *arg) {
         mt_state *st = (mt_state *)arg;
         uint64_t done = 0, matches = 0;
+        to_result r; /* this thread's collector, reused from query to query */
+        memset(&r, 0, sizeof r);
         for (;;) {
                 if (mt_now() >= st->deadline)
                         break;
-                const uint64_t i = __atomic_fetch_add(&st->cursor, 1, __ATOMIC_RELAXED);
-                if (i >= st->nq)
+                const uint64_t at = __atomic_fetch_add(&st->cursor, 1, __ATOMIC_RELAXED);
+                if (at >= st->nq)
                         break;
-                to_result r;
-                memset(&r, 0, sizeof r);
-                if (to_exec_query(st->ix, st->progs + i * st->proglen, st->proglen, st->flags, &r) == 0) {
+                const uint64_t i = st->order[at];
+                if (exec_query_into(st->ix, st->progs + i * st->proglen, st->proglen, st->flags, &r) == 0) {
                         ++done;
                         matches += r.n;
                 }
-                to_result_free(&r);
         }
+        to_result_free(&r);
         pthread_mutex_lock(&st->mu);
         st->done += done;
         st->matches += matches;
@@ -1860,6 +1872,36 @@ uint64_t to_exec_batch_mt(const to_index *ix, const uint32_t *progs, uint32_t pr
         pthread_mutex_init(&st.mu, NULL);
         if (!nthreads)
                 nthreads = 1;
+        /* heaviest queries first: cost = sum of the document frequencies of the program's terms */
+        uint64_t *cost = (uint64_t *)xmalloc(sizeof(uint64_t) * (nq ? nq : 1));
+        uint32_t *order = (uint32_t *)xmalloc(sizeof(uint32_t) * (nq ? nq : 1));
+        for (uint32_t q = 0; q < nq; ++q) {
+                uint64_t c = 0;
+                for (uint32_t k = 0; k < proglen; ++k) {
+                        const uint32_t tok = progs[(size_t)q * proglen + k];
+                        if (TO_TOK_OP(tok) == TO_OP_TERM && TO_TOK_ARG(tok) < ix->nterms)
+                                c += ix->terms[TO_TOK_ARG(tok)].documents;
+                }
+                cost[q] = c;
+                order[q] = q;
+        }
+        /* a stable counting-free sort is enough here: qsort on (cost desc, index asc) */
+        {
+                /* sort indices by cost, descending */
+                uint32_t *tmp = order;
+                /* simple shell sort: no extra context pointer needed */
+                for (uint32_t gap = nq / 2; gap > 0; gap /= 2)
+                        for (uint32_t a = gap; a < nq; ++a) {
+                                const uint32_t x = tmp[a];
+                                uint32_t b = a;
+                                while (b >= gap && (cost[tmp[b - gap]] < cost[x] || (cost[tmp[b - gap]] == cost[x] && tmp[b - gap] > x))) {
+                                        tmp[b] = tmp[b - gap];
+                                        b -= gap;
+                                }
+                                tmp[b] = x;
+                        }
+        }
+        st.order = order;
         pthread_t *th = (pthread_t *)xmalloc(sizeof(pthread_t) * nthreads);
         const double t0 = mt_now();
         st.deadline = t0 + budget_seconds;
@@ -1874,6 +1916,8 @@ uint64_t to_exec_batch_mt(const to_index *ix, const uint32_t *progs, uint32_t pr
         if (out_matches)
                 *out_matches = st.matches;
         free(th);
+        free(cost);
+        free(order);
         pthread_mutex_destroy(&st.mu);
         return st.done;
 }
