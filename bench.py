@@ -286,7 +286,8 @@ def cpu_baseline(seg, qs, budget_s):
     try:
         ncores = len(os.sched_getaffinity(0))
         progs = np.array([[O.tok(O.OP_TERM, a), O.tok(O.OP_TERM, b), O.tok(O.OP_AND, 2)] for a, b in qs.tolist()], dtype=np.uint32)
-        done, m, dt2 = ora.exec_batch_mt(progs, O.FLAG_DOCUMENTS_ONLY, ncores, max(4.0, budget_s * 0.6))
+        # heaviest queries first, so the figure is only meaningful over the WHOLE batch: the budget is a safety net, not a cut
+        done, m, dt2 = ora.exec_batch_mt(progs, O.FLAG_DOCUMENTS_ONLY, ncores, max(30.0, budget_s * 3))
         res["all_cores"] = {
             "value": done / dt2,
             "unit": "queries/s",
