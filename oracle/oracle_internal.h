@@ -17,7 +17,7 @@ void buf_u8(buf_t *b, uint8_t v);
 void buf_u32(buf_t *b, uint32_t v);
 void buf_bytes(buf_t *b, const void *p, size_t n);
 
-enum { IT_PLI = 0, IT_CONJ, IT_DISJ, IT_PHRASE, IT_FILTER, IT_OPTIONAL };
+enum { IT_PLI = 0, IT_CONJ, IT_DISJ, IT_PHRASE, IT_FILTER, IT_OPTIONAL, IT_SOME };
 
 typedef struct to_iter to_iter;
 struct to_iter { /* docset_iterators_base.h:45-96 Iterator + relevant_documents.h:43-67 IteratorScorer */

@@ -101,6 +101,31 @@ namespace {
         }
         uint64_t fnv_u32(uint32_t v, uint64_t h) { return fnv_bytes(reinterpret_cast<const uint8_t *>(&v), 4, h); }
 
+        // `[a, b, c]` parses as MatchSome with min 1 (queries.cpp:424-448); an application sets the threshold on the node
+        void set_matchsome_min(ast_node *n, const uint16_t min) {
+                if (!n)
+                        return;
+                switch (n->type) {
+                        case ast_node::Type::BinOp:
+                                set_matchsome_min(n->binop.lhs, min);
+                                set_matchsome_min(n->binop.rhs, min);
+                                break;
+                        case ast_node::Type::UnaryOp:
+                                set_matchsome_min(n->unaryop.expr, min);
+                                break;
+                        case ast_node::Type::ConstTrueExpr:
+                                set_matchsome_min(n->expr, min);
+                                break;
+                        case ast_node::Type::MatchSome:
+                                n->match_some.min = std::min<uint16_t>(min, n->match_some.size);
+                                for (uint16_t i = 0; i < n->match_some.size; ++i)
+                                        set_matchsome_min(n->match_some.nodes[i], min);
+                                break;
+                        default:
+                                break;
+                }
+        }
+
         void print_u32s(const char *name, const uint32_t *v, size_t n) {
                 printf("\"%s\":[", name);
                 for (size_t i = 0; i < n; ++i)
@@ -281,18 +306,23 @@ int main(int argc, char **argv) {
                                      : simName == "trivial" ? static_cast<Similarity::IndexSourcesCollectionTermsScorer *>(&trivial)
                                                             : static_cast<Similarity::IndexSourcesCollectionTermsScorer *>(&bm25);
                         printf("{\"cmd\":\"sim\",\"name\":\"%s\"}\n", simName.c_str());
-                } else if (cmd == "query" || cmd == "queryfull") {
-                        uint32_t flags, k = 0;
+                } else if (cmd == "query" || cmd == "queryfull" || cmd == "querysome") {
+                        uint32_t flags, k = 0, someMin = 0;
                         is >> flags;
-                        if (cmd == "query")
+                        if (cmd != "queryfull")
                                 is >> k;
+                        if (cmd == "querysome")
+                                is >> someMin; // threshold for every [a, b, ...] of the query
                         std::string text;
                         std::getline(is, text);
                         while (!text.empty() && text[0] == ' ')
                                 text.erase(0, 1);
                         Collector coll;
                         // `a <b>`: ConstTrueExpr needs its parser flag (queries.h:238); default tokens parser
-                        query q{str32_t(text.data(), uint32_t(text.size())), default_token_parser_impl, unsigned(ast_parser::Flags::ParseConstTrueExpr)};
+                        query q{str32_t(text.data(), uint32_t(text.size())), default_token_parser_impl,
+                                unsigned(ast_parser::Flags::ParseConstTrueExpr) | unsigned(ast_parser::Flags::ParseMatchSomeExpr)};
+                        if (someMin)
+                                set_matchsome_min(q.root, uint16_t(someMin));
                         std::unique_ptr<Similarity::IndexSourceTermsScorer> scorer;
                         if (flags & unsigned(ExecFlags::AccumulatedScoreScheme)) {
                                 collScorer->reset(&collection);
@@ -303,7 +333,7 @@ int main(int argc, char **argv) {
                         double ssum = 0;
                         for (auto s : coll.scores)
                                 ssum += s;
-                        printf("{\"cmd\":\"%s\",\"flags\":%u,\"sim\":\"%s\",\"q\":\"", cmd.c_str(), flags, simName.c_str());
+                        printf("{\"cmd\":\"%s\",\"flags\":%u,\"sim\":\"%s\",\"min\":%u,\"q\":\"", cmd.c_str(), flags, simName.c_str(), someMin);
                         for (char c : text) {
                                 if (c == '"')
                                         printf("\\\"");

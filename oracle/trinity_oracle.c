@@ -1249,6 +1249,170 @@ static double optional_score(to_iter *self) {
         return score;
 }
 
+/* ================================================================== DisjunctionSome (matchsome) */
+typedef struct sm_tracker { /* docset_iterators.h:66-72 it_tracker */
+        to_iter *it;
+        uint64_t cost;
+        uint32_t id;
+        struct sm_tracker *next;
+} sm_tracker;
+
+typedef struct { /* docset_iterators.h:61-137; Switch/prioqueue.h binary heaps (1-based), top = least by the comparator */
+        to_iter it;
+        sm_tracker *lead, *store;
+        uint16_t threshold, curCnt;
+        sm_tracker **head; /* least id on top */
+        uint32_t nhead;
+        sm_tracker **tail; /* least cost on top, at most threshold - 1 entries */
+        uint32_t ntail, captail;
+} to_some;
+
+static int sm_less_id(const sm_tracker *a, const sm_tracker *b) { return a->id < b->id; }
+static int sm_less_cost(const sm_tracker *a, const sm_tracker *b) { return a->cost < b->cost; }
+
+static void sm_up(sm_tracker **h, uint32_t i, int (*less)(const sm_tracker *, const sm_tracker *)) {
+        sm_tracker *x = h[i];
+        while (i > 1 && less(x, h[i / 2])) {
+                h[i] = h[i / 2];
+                i /= 2;
+        }
+        h[i] = x;
+}
+
+static void sm_down(sm_tracker **h, uint32_t n, uint32_t i, int (*less)(const sm_tracker *, const sm_tracker *)) {
+        sm_tracker *x = h[i];
+        for (;;) {
+                uint32_t c = i * 2;
+                if (c > n)
+                        break;
+                if (c + 1 <= n && less(h[c + 1], h[c]))
+                        ++c;
+                if (!less(h[c], x))
+                        break;
+                h[i] = h[c];
+                i = c;
+        }
+        h[i] = x;
+}
+
+static void sm_push(sm_tracker **h, uint32_t *n, sm_tracker *t, int (*less)(const sm_tracker *, const sm_tracker *)) {
+        h[++*n] = t;
+        sm_up(h, *n, less);
+}
+
+static sm_tracker *sm_pop(sm_tracker **h, uint32_t *n, int (*less)(const sm_tracker *, const sm_tracker *)) {
+        sm_tracker *top = h[1];
+        h[1] = h[*n];
+        --*n;
+        if (*n)
+                sm_down(h, *n, 1, less);
+        return top;
+}
+
+/* Switch/prioqueue.h:178-204 try_push on the tail (capacity threshold - 1): 1 when pushed, else 0 with *evicted = the entry that
+ * has to go (the former top when it compares less than v, else v itself) */
+static int sm_tail_try_push(to_some *s, sm_tracker *v, sm_tracker **evicted) {
+        if (s->ntail < s->captail) {
+                sm_push(s->tail, &s->ntail, v, sm_less_cost);
+                return 1;
+        }
+        if (s->ntail && sm_less_cost(s->tail[1], v)) {
+                *evicted = s->tail[1];
+                s->tail[1] = v;
+                sm_down(s->tail, s->ntail, 1, sm_less_cost);
+                return 0;
+        }
+        *evicted = v;
+        return 0;
+}
+
+static void sm_add_lead(to_some *s, sm_tracker *t) { /* docset_iterators.h:111-115 */
+        t->next = s->lead;
+        s->lead = t;
+        ++s->curCnt;
+}
+
+static void sm_update_current(to_some *s) { /* docset_iterators.cpp:679-691 */
+        s->lead = sm_pop(s->head, &s->nhead, sm_less_id);
+        s->lead->next = NULL;
+        s->curCnt = 1;
+        s->it.cur = s->lead->id;
+        while (s->nhead && s->head[1]->id == s->it.cur)
+                sm_add_lead(s, sm_pop(s->head, &s->nhead, sm_less_id));
+}
+
+static void sm_advance_tail(to_some *s, sm_tracker *top) { /* :787-794 */
+        top->id = top->it->advance(top->it, s->it.cur);
+        if (top->id == s->it.cur)
+                sm_add_lead(s, top);
+        else
+                sm_push(s->head, &s->nhead, top, sm_less_id);
+}
+
+static uint32_t sm_next_impl(to_some *s) { /* :693-709 */
+        while (s->curCnt < s->threshold) {
+                if (s->curCnt + s->ntail >= s->threshold)
+                        sm_advance_tail(s, sm_pop(s->tail, &s->ntail, sm_less_cost));
+                else {
+                        for (sm_tracker *t = s->lead; t; t = t->next)
+                                sm_push(s->tail, &s->ntail, t, sm_less_cost);
+                        sm_update_current(s);
+                }
+        }
+        return s->it.cur;
+}
+
+static uint32_t some_next(to_iter *self) { /* :745-761 */
+        to_some *s = (to_some *)self;
+        const uint32_t doc = s->it.cur;
+        sm_tracker *evicted = NULL;
+        for (sm_tracker *t = s->lead, *nx; t; t = nx) {
+                nx = t->next; /* (the list is rebuilt by update_current; a pushed tracker's link is dead) */
+                if (!sm_tail_try_push(s, t, &evicted)) {
+                        evicted->id = evicted->id == doc ? evicted->it->next(evicted->it) : evicted->it->advance(evicted->it, doc + 1);
+                        sm_push(s->head, &s->nhead, evicted, sm_less_id);
+                }
+        }
+        sm_update_current(s);
+        return sm_next_impl(s);
+}
+
+static uint32_t some_advance(to_iter *self, uint32_t target) { /* :763-785 */
+        to_some *s = (to_some *)self;
+        sm_tracker *evicted = NULL;
+        for (sm_tracker *t = s->lead, *nx; t; t = nx) {
+                nx = t->next;
+                if (!sm_tail_try_push(s, t, &evicted)) {
+                        evicted->id = evicted->it->advance(evicted->it, target);
+                        sm_push(s->head, &s->nhead, evicted, sm_less_id);
+                }
+        }
+        for (sm_tracker *top = s->head[1]; top->id < target; top = s->head[1]) {
+                /* the tail is full here (it holds threshold - 1 entries and at least threshold were offered) */
+                sm_tail_try_push(s, top, &evicted);
+                evicted->id = evicted->it->advance(evicted->it, target);
+                s->head[1] = evicted;
+                sm_down(s->head, s->nhead, 1, sm_less_id);
+        }
+        sm_update_current(s);
+        return sm_next_impl(s);
+}
+
+static void some_update_matched_cnt(to_some *s) { /* :796-811: the tail may hold more matches of the current document */
+        for (uint32_t i = s->ntail; i;)
+                sm_advance_tail(s, s->tail[i--]);
+        s->ntail = 0;
+}
+
+static double some_score(to_iter *self) { /* docset_iterators_scorers.cpp:38-57 */
+        to_some *s = (to_some *)self;
+        double sum = 0;
+        some_update_matched_cnt(s);
+        for (sm_tracker *t = s->lead; t; t = t->next)
+                sum += t->it->score(t->it);
+        return sum;
+}
+
 typedef struct pnode {
         uint32_t op, term;
         struct pnode **kids;
@@ -1281,10 +1445,11 @@ static pnode *parse_prog(to_ctx *c, const uint32_t *prog, uint32_t len) {
                         stack[sp++] = n;
                         continue;
                 }
-                if (arg < 1 || arg > sp)
+                const uint32_t nk = op == TO_OP_SOME ? (arg & 0xffffu) : arg; /* operands taken off the stack */
+                if (nk < 1 || nk > sp)
                         return NULL;
                 pnode *n = pn_new(c, op);
-                pnode **kids = stack + (sp - arg);
+                pnode **kids = stack + (sp - nk);
                 n->kids = (pnode **)ctx_own(c, xmalloc(sizeof(pnode *) * (len + 1)));
                 if (op == TO_OP_PHRASE) {
                         if (arg > MAX_PHRASE)
@@ -1330,6 +1495,39 @@ static pnode *parse_prog(to_ctx *c, const uint32_t *prog, uint32_t len) {
                         n->empty = n->nkids == 0;
                         for (uint32_t j = 0; j < n->nkids; ++j)
                                 n->cost += n->kids[j]->cost;
+                } else if (op == TO_OP_SOME) {
+                        const uint32_t cnt = arg & 0xffffu, min = arg >> 16;
+                        if (!min || min > cnt)
+                                return NULL;
+                        uint32_t alive = 0;
+                        for (uint32_t k = 0; k < cnt; ++k)
+                                if (!kids[k]->empty) {
+                                        n->kids[n->nkids++] = kids[k];
+                                        ++alive;
+                                }
+                        n->term = min; /* the threshold rides in the otherwise unused field */
+                        n->empty = alive < min;
+                        { /* docset_iterators.cpp:733-742: the sum of the (cnt - min + 1) smallest costs */
+                                uint64_t cs[64];
+                                uint32_t m = 0;
+                                for (uint32_t k = 0; k < n->nkids && m < 64; ++k)
+                                        cs[m++] = n->kids[k]->cost;
+                                for (uint32_t a = 1; a < m; ++a) {
+                                        const uint64_t x = cs[a];
+                                        uint32_t b = a;
+                                        while (b > 0 && cs[b - 1] > x) {
+                                                cs[b] = cs[b - 1];
+                                                --b;
+                                        }
+                                        cs[b] = x;
+                                }
+                                const uint32_t take = m >= min ? m - min + 1 : 0;
+                                for (uint32_t k = 0; k < take; ++k)
+                                        n->cost += cs[k];
+                        }
+                        sp -= cnt;
+                        stack[sp++] = n;
+                        continue;
                 } else if (op == TO_OP_OPT) {
                         if (arg != 2)
                                 return NULL;
@@ -1408,6 +1606,28 @@ static to_iter *build_iter(to_ctx *c, const pnode *n) {
                         for (uint32_t i = 0; i < n->nkids; ++i)
                                 cj->c.its[i] = build_iter(c, n->kids[i]);
                         return &cj->c.it;
+                }
+                case TO_OP_SOME: { /* exec.cpp:276-283 */
+                        const uint32_t cnt = n->nkids, min = n->term;
+                        to_some *s = (to_some *)ctx_own(c, xcalloc(1, sizeof *s));
+                        s->it.type = IT_SOME;
+                        s->it.next = some_next;
+                        s->it.advance = some_advance;
+                        s->it.score = some_score;
+                        s->it.cost = n->cost;
+                        s->threshold = (uint16_t)min;
+                        s->store = (sm_tracker *)ctx_own(c, xcalloc(cnt + 1, sizeof(sm_tracker)));
+                        s->head = (sm_tracker **)ctx_own(c, xcalloc(cnt + 2, sizeof(sm_tracker *)));
+                        s->tail = (sm_tracker **)ctx_own(c, xcalloc(cnt + 2, sizeof(sm_tracker *)));
+                        s->captail = min - 1;
+                        for (uint32_t i = 0; i < cnt; ++i) { /* docset_iterators.cpp:711-731: everything starts on the lead list */
+                                sm_tracker *t = &s->store[i];
+                                t->it = build_iter(c, n->kids[i]);
+                                t->cost = n->kids[i]->cost;
+                                t->id = 0;
+                                sm_add_lead(s, t);
+                        }
+                        return &s->it;
                 }
                 case TO_OP_OPT: { /* exec.cpp:366-377 */
                         to_optional *o = (to_optional *)ctx_own(c, xcalloc(1, sizeof *o));
@@ -1627,6 +1847,12 @@ static void collect_terms(to_iter *it, uint32_t doc, termset *out) {
                 case IT_FILTER:
                         collect_terms(((to_filter *)it)->req, doc, out);
                         break;
+                case IT_SOME: { /* queryexec_ctx.cpp:396-409 */
+                        to_some *s = (to_some *)it;
+                        some_update_matched_cnt(s);
+                        for (sm_tracker *t = s->lead; t; t = t->next)
+                                collect_terms(t->it, doc, out);
+                } break;
                 case IT_OPTIONAL: { /* queryexec_ctx.cpp:418-432 */
                         to_optional *o = (to_optional *)it;
                         collect_terms(o->main, doc, out);

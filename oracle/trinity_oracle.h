@@ -41,6 +41,8 @@ extern "C" {
 #define TO_OP_NOT 4u    /* operand = 2: the two preceding sub-programs are (required, excluded); exec.cpp:424-427 logicalnot */
 #define TO_OP_OPT 5u    /* operand = 2: (main, optional) — `a <b>`: consttrueexpr under an AND -> DocsSetIterators::Optional (exec.cpp:366-377):
                            the documents of main; optional only adds its score / its matched terms where it matches */
+#define TO_OP_SOME 6u   /* operand = (min << 16) | n: at least `min` of the n preceding sub-programs match — matchsome -> DocsSetIterators::DisjunctionSome
+                           (exec.cpp:276-283; docset_iterators.cpp:679-811).  Oracle only so far: the GPU planner does not lower it yet */
 #define TO_TOK(op, arg) (((uint32_t)(op) << 28) | ((uint32_t)(arg)&0x0fffffffu))
 #define TO_TOK_OP(t) ((t) >> 28)
 #define TO_TOK_ARG(t) ((t)&0x0fffffffu)

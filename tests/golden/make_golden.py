@@ -78,6 +78,16 @@ def commands_for(name, D, V, slots, seed):
         a, b, c, d, e = [int(x) for x in row]
         for tpl in TEMPLATES:
             cmds.append("query 0 0 " + tpl.format(a=a, b=b, c=c, d=d, e=e))
+    # matchsome -> DisjunctionSome (exec.cpp:276-283): `[a, b, ...]` with the threshold set on the node; all three modes
+    SOME = [("[t{a}, t{b}, t{c}]", 2), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 2), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 3), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 5),
+            ("t{a} [t{b}, t{c}, t{d}]", 2), ("[t{a}, t{b} t{c}, t{d} OR t{e}]", 2)]
+    for ri, row in enumerate(head + qs.tolist()[:7]):
+        a, b, c, d, e = [int(x) for x in row]
+        for tpl, mn in SOME:
+            text = tpl.format(a=a, b=b, c=c, d=d, e=e)
+            cmds.append(f"querysome 1 0 {mn} {text}")
+            cmds.append(f"querysome 2 10 {mn} {text}")
+            cmds.append(f"querysome 0 0 {mn} {text}")
     # the other two scorers of similarity.h (TF-IDF :75-163, Trivial :56-72) on a subset: scored records carry "sim"
     SIM_TEMPLATES = ["t{a} t{b}", "t{a} OR t{b} OR t{c}", "t{a} t{b} (t{c} OR t{d} OR t{e})", '"t{a} t{b}" t{c}', "t{a} t{b} NOT t{c}"]
     for sim in ("tfidf", "trivial"):

@@ -17,7 +17,7 @@ REF_DRIVER = os.path.join(ORACLE_DIR, "_ref", "ref_driver")
 DOCIDS_END = 0xFFFFFFFF
 FLAG_DOCUMENTS_ONLY = 1
 FLAG_ACCUM_SCORE = 2
-OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT, OP_OPT = 0, 1, 2, 3, 4, 5
+OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT, OP_OPT, OP_SOME = 0, 1, 2, 3, 4, 5, 6
 SIM_BM25, SIM_TFIDF, SIM_TRIVIAL = 0, 1, 2
 
 
@@ -319,7 +319,7 @@ class PLI:
 
 
 # ---- tiny query-text -> postfix program compiler for the query templates of SURVEY §8(d) ------------
-def parse_query(text):
+def parse_query(text, some_min=1):
     """Supports: terms tN, juxtaposition = AND, OR, NOT, parentheses, "phrases", <optional>.  OR binds looser than AND
     (Trinity: queries.h operators; `a b OR c` is not used by the fixtures to avoid precedence ambiguity)."""
     toks = []
@@ -328,7 +328,7 @@ def parse_query(text):
         ch = text[i]
         if ch.isspace():
             i += 1
-        elif ch in "()<>":
+        elif ch in "()<>[],":
             toks.append(ch)
             i += 1
         elif ch == '"':
@@ -337,7 +337,7 @@ def parse_query(text):
             i = j + 1
         else:
             j = i
-            while j < len(text) and not text[j].isspace() and text[j] not in '()"<>':
+            while j < len(text) and not text[j].isspace() and text[j] not in '()"<>[],':
                 j += 1
             w = text[i:j]
             toks.append(w if w in ("OR", "NOT") else ("TERM", int(w[1:])))
@@ -355,6 +355,14 @@ def parse_query(text):
             assert peek() == ")"
             pos[0] += 1
             return r
+        if t == "[":  # [a, b, ...]: MatchSome (ast_parser::Flags::ParseMatchSomeExpr); the threshold is set on the node by the application
+            kids = [expr_or()]
+            while peek() == ",":
+                pos[0] += 1
+                kids.append(expr_or())
+            assert peek() == "]"
+            pos[0] += 1
+            return sum(kids, []) + [tok(OP_SOME, (min(some_min, len(kids)) << 16) | len(kids))]
         if t == "<":  # <expr>: ConstTrueExpr (ast_parser::Flags::ParseConstTrueExpr) — optional under an AND
             r = expr_or()
             assert peek() == ">"
@@ -370,7 +378,7 @@ def parse_query(text):
 
     def expr_and():
         parts = [primary()]
-        while peek() is not None and peek() not in (")", ">", "OR", "NOT"):
+        while peek() is not None and peek() not in (")", ">", "]", ",", "OR", "NOT"):
             parts.append(primary())
         # juxtaposition is a left-associative binary AND in Trinity; an AND with a <...> operand becomes Optional(other, opt)
         # (exec.cpp:366-377), and a <...> that is not under an AND is just its expression (:434-441)

@@ -206,6 +206,33 @@ def test_queries_match_reference(golden):
     assert n > 200
 
 
+def test_matchsome_matches_reference(golden):
+    """matchsome -> DocsSetIterators::DisjunctionSome (docset_iterators.cpp:679-811, the two-heap min-should-match iterator):
+    docID sets, BM25 sums / top-10 and the default mode's matched terms, thresholds 2..n, nested under AND and over
+    sub-expressions.  Oracle only: the GPU planner does not lower it yet."""
+    g, ix = golden
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] != "querysome":
+            continue
+        p = O.parse_query(r["q"], some_min=r["min"])
+        if r["flags"] == 0:
+            docs, flat, tt, ht = ix.exec_rich(p)
+            assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], (r["q"], r["min"])
+            assert (tt, ht) == (r["terms_total"], r["hits_total"]) and str(O.fnv1a_u32_stream(flat)) == r["rich_fnv"], (r["q"], r["min"])
+        else:
+            docs, scores = ix.exec(p, r["flags"])
+            assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], (r["q"], r["min"])
+            if r["flags"] & 2:
+                assert abs(scores.sum() - r["score_sum"]) <= 1e-5 * max(1.0, abs(r["score_sum"]))
+                if "top" in r:
+                    td, ts = ix.topk(docs, scores, len(r["top"]))
+                    assert td.tolist() == [x[0] for x in r["top"]]
+                    np.testing.assert_allclose(ts, [x[1] for x in r["top"]], rtol=1e-5)
+        n += 1
+    assert n >= 150
+
+
 def test_rich_mode_matches_reference(golden):
     """exec_query's default mode (flags 0): per match the query terms that matched and their hits — the canonical stream's
     FNV, the totals and the first documents in full, against the genuine reference."""
