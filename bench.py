@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """bench.py — the hot path's headline benchmark on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): batched 2-term AND queries (Zipf-sampled terms, seed 1337,
-distinct within a query) over the 10M-document / 1M-term synthetic Zipf(1.0) segment (corpus seed 42,
-google_codec), DocumentsOnly mode — every query's full ascending docID set is materialised in HBM.
-One "step" = one pass of the engine over one batch of --queries queries per GPU (index and compiled batch
-already resident in HBM).  Multi-GPU: one process per GPU, the index replicated, every rank runs its own
-batch of the same size (weak scaling; queries are independent, exec.h:57-62), and the per-query match counts
-are all-gathered over RCCL at the end of every step (the only exchange the DocumentsOnly path has).
+Default workload (BASELINE.json configs[1]): batched 2-term AND queries (Zipf-sampled terms, seed 1337,
+distinct within a query) over the 10M-document / 1M-term synthetic Zipf(1.0) segment (corpus seed 42, google_codec),
+DocumentsOnly mode — every query's full ascending docID set is materialised in HBM.  --workload cfg3 / cfg4 / cfg5 / cfg1 are
+the other query sets of SURVEY §8(d) (cfg5 = the mixed batch: a DocumentsOnly batch on the google_codec segment plus a BM25
+top-100 batch on the lucene_codec segment of the same corpus, both per step).
+One "step" = one pass of the engine over one batch of --queries queries per GPU (index and compiled batches already resident
+in HBM).  Multi-GPU: one process per GPU, the index replicated, every rank runs its own shard of the same size (weak scaling;
+queries are independent, exec.h:57-62); at the end of every step the ranks all_gather their result blocks over RCCL straight
+from the engine's device buffers: per-query match counts and, for scored batches, the [Q/G][K] top-K docID/score blocks
+(trinity_amd/dist.py ResultGather — the only exchange the path has).
 
-Rank 0 prints ONE JSON line: metric/value = queries/s over all GPUs; `roofline` = algorithmic bytes (SURVEY §8d:
-sum over queries of docbytes(t) of both terms + 4 B per match) / mean kernel time measured with HIP events on the
-engine's stream; `cpu_baseline` = the CPU oracle (restatement of the reference exec path, one thread) timed on a
-bounded sample of the same batch.
+Rank 0 prints ONE JSON line: metric/value = queries/s over all GPUs (kernels + result gather; the docID sets themselves stay in
+HBM — copying every set back over PCIe would make the rate PCIe-bound); `roofline` = the dominant kernel's
+algorithmic bytes (sum over its queries of docbytes(t) + 4 B per match, or + 8 B x min(matches, K) when scored)
+/ its mean launch duration measured with HIP events on the engine's stream; `cpu_baseline` = the CPU oracle (restatement of the
+reference exec path) timed on a bounded sample of the same batch, which doubles as a per-query full-size parity check.
 """
 import argparse
 import json
@@ -27,6 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+KERNELS = ("k_and_dense", "k_and", "k_fused")  # the kernels with per-launch HIP-event brackets and their own algorithmic bytes
+KMS = {"k_and_dense": "dense_ms", "k_and": "cand_ms", "k_fused": "fused_ms"}
+KALG = {"k_and_dense": "dense_algorithmic_bytes", "k_and": "cand_algorithmic_bytes", "k_fused": "fused_algorithmic_bytes"}
+KQ = {"k_and_dense": "dense_queries", "k_and": "cand_queries", "k_fused": "fused_queries"}
 
 
 def main():
@@ -36,12 +44,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=10_000_000)
     ap.add_argument("--vocab", type=int, default=1_000_000)
-    ap.add_argument("--queries", type=int, default=16384, help="queries per GPU per step")
+    ap.add_argument("--queries", type=int, default=0, help="queries per GPU per step (default: 16384; cfg3: 8192; cfg5: 12500 = a 100K batch over 8 GPUs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
     ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
-                    help="SURVEY §8(d) query sets; cfg2 (default) is the configuration BASELINE.json's metric is quoted on, the others are "
-                         "extra measurements (whole-step roofline only)")
+                    help="SURVEY §8(d) query sets; cfg2 (default) is the configuration BASELINE.json's metric is quoted on")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="planner option (tri_dev_set_option), e.g. fused=0")
     args = ap.parse_args()
+    if not args.queries:
+        args.queries = {"cfg3": 8192, "cfg5": 12500, "cfg1": 2000}.get(args.workload, 16384)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -56,12 +66,13 @@ def main():
 
     import trinity_amd as T
     from trinity_amd import dist as TD
+    from trinity_amd import workloads as W
 
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         # one rank makes sure the native libraries are built (normally a no-op: the built .so travel with the tree); the
         # others wait instead of racing hipcc on the same output file
@@ -69,93 +80,91 @@ def main():
             T.build_all()
         dist.barrier()
     else:
-        torch.cuda.set_device(local_rank)
         T.build_all()
 
-    # ---- synthetic segment (identical on every rank) and this rank's query batch
-    t0 = time.time()
-    from trinity_amd import workloads as W
-
-    progs = None
-    wl_desc = None
-    codec = T.engine.CODEC_GOOGLE
-    if args.workload != "cfg2":
-        allp, wflags, wtopk, codec, wl_desc = W.build(args.workload, args.docs, args.vocab, 10, 42, args.queries * world)
-        progs = allp[rank::world][: args.queries]  # interleaved shard: same mix on every rank
-    seg = T.Segment(args.docs, args.vocab, 10, 42, codec=codec)
-    build_s = time.time() - t0
+    # ---- synthetic segments (identical on every rank) and this rank's query shard
+    docs, vocab = (100_000, 10_000) if args.workload == "cfg1" and args.docs == 10_000_000 else (args.docs, args.vocab)
+    parts, wl_desc = W.build_parts(args.workload, docs, vocab, 10, 42, args.queries * world)
     dev = T.Device(local_rank)
-    t0 = time.time()
-    ix = T.Index.from_segment(dev, seg)
-    upload_s = time.time() - t0  # one-time: format walk + directory / delta-stream / cell-index build on the host, then PCIe
-    info = ix.info()
-    if progs is None:
-        qall = T.gen_queries(args.vocab, 1337, args.queries * world, 2)
-        qs = TD.shard_rows(qall, rank, world, args.queries)  # interleaved shard: same cost distribution on every rank
-        batch = T.Batch.conjunctions(ix, qs, T.FLAG_DOCUMENTS_ONLY)
-    else:
-        qs = None
-        batch = T.Batch(ix, progs, wflags, topk=wtopk)
+    for o in args.option:
+        k, v = o.split("=", 1)
+        dev.set_option(k, int(v))
+    segs, ixs, build_s, upload_s = {}, {}, 0.0, 0.0
+    for pt in parts:
+        if pt.codec not in segs:
+            t0 = time.time()
+            segs[pt.codec] = T.Segment(docs, vocab, 10, 42, codec=pt.codec)
+            build_s += time.time() - t0
+            t0 = time.time()
+            ixs[pt.codec] = T.Index.from_segment(dev, segs[pt.codec])
+            upload_s += time.time() - t0  # one-time: format walk + directory / delta-stream / cell-index build on the host, then PCIe
+    batches, shard_progs = [], []
+    for pt in parts:
+        mine = pt.programs[rank::world]  # interleaved shard: same mix on every rank
+        shard_progs.append(mine)
+        batches.append(T.Batch(ixs[pt.codec], mine, pt.flags, topk=pt.topk))
+    nq_rank = sum(len(p) for p in shard_progs)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    counts_dev = None
+    gathers = []
     if dist is not None:
-        counts_dev = torch.zeros(args.queries, dtype=torch.int64, device="cuda")
+        gathers = [TD.ResultGather(dist, TD.device_blocks(b, torch.device("cuda", local_rank))) for b in batches]
 
     def step():
-        batch.run()
-        batch.sync()
-        if dist is not None:
-            # result exchange: per-query match counts to every rank (docsets stay sharded in HBM)
-            counts_dev.copy_(torch.from_numpy(batch.counts().astype(np.int64)))
-            TD.gather_counts(dist, counts_dev)
-        return batch.info()
+        for b in batches:
+            b.run()
+        for b in batches:
+            b.sync()
+        for g in gathers:  # result exchange straight from the engine's device buffers (docsets stay sharded in HBM)
+            g.step()
+        if gathers:
+            torch.cuda.current_stream().synchronize()  # the receive side is complete before the next step rewrites the send buffers
+        return [b.info() for b in batches]
 
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = dense_ms = cand_ms = 0.0
-    binfo = None
+    acc = {}
+    infos = None
     for _ in range(args.steps):
-        binfo = step()
-        kernel_ms += binfo["last_run_ms"]
-        dense_ms += binfo["dense_ms"]
-        cand_ms += binfo["cand_ms"]
+        infos = step()
+        for i in infos:
+            for k in ("last_run_ms", "dense_ms", "cand_ms", "fused_ms", "rest_ms"):
+                acc[k] = acc.get(k, 0.0) + i[k]
     barrier()
     elapsed = time.perf_counter() - t0
+    tot = {k: float(sum(i[k] for i in infos)) for k in ("matches", "algorithmic_bytes", "dense_algorithmic_bytes", "cand_algorithmic_bytes", "fused_algorithmic_bytes",
+                                                       "dense_queries", "cand_queries", "fused_queries")}  # fmt: skip
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        m = torch.tensor([float(binfo["matches"]), float(binfo["algorithmic_bytes"])], dtype=torch.float64, device="cuda")
+        m = torch.tensor([tot["matches"], tot["algorithmic_bytes"]], dtype=torch.float64, device="cuda")
         dist.all_reduce(m, op=dist.ReduceOp.SUM)
         matches_all, alg_all = float(m[0].item()), float(m[1].item())
     else:
-        matches_all, alg_all = float(binfo["matches"]), float(binfo["algorithmic_bytes"])
+        matches_all, alg_all = tot["matches"], tot["algorithmic_bytes"]
 
     if rank == 0:
         steps = max(1, args.steps)
         ms_per_step = elapsed * 1e3 / steps
-        qps = args.queries * world * steps / elapsed
-        # the step launches two matching kernels back to back on the engine stream; the dominant one carries the roofline
-        kms = {"k_and_dense": dense_ms / steps, "k_and": cand_ms / steps}
-        kalg = {"k_and_dense": float(binfo["dense_algorithmic_bytes"]), "k_and": float(binfo["cand_algorithmic_bytes"])}
+        qps = nq_rank * world * steps / elapsed
+        kms = {k: acc[KMS[k]] / steps for k in KERNELS}
+        kalg = {k: tot[KALG[k]] for k in KERNELS}
+        k_ms = acc["last_run_ms"] / steps
+        rest_ms = acc["rest_ms"] / steps
         dom = max(kms, key=kms.get)
-        achieved = kalg[dom] / (kms[dom] * 1e-3) / 1e9 if kms[dom] > 0 else 0.0
-        k_ms = kernel_ms / steps
-        alg = float(binfo["algorithmic_bytes"])
-        traffic = pmc_traffic(args, world) if progs is None else None
-        if progs is not None:
-            # extra workloads launch more kernels (k_phrase, k_score, k_topk_merge): whole-step figures only
-            dom = "whole step"
-            kms = {dom: k_ms}
-            kalg = {dom: alg}
-            achieved = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+
+        def gbs(b, ms):
+            return b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+        traffic, traffic_src = pmc_traffic(args, world)
+        info0 = ixs[parts[0].codec].info()
         out = {
             "metric": "queries/sec",
             "value": qps,
@@ -167,48 +176,52 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32",
+            "dtype": "u32" if not any(pt.flags & T.FLAG_ACCUMULATED_SCORE for pt in parts) else "u32 docIDs / f64 sums of f32 BM25 terms",
             "data": "synthetic",
             "config": {
-                "workload": (wl_desc + f", Zipf(1.0) {args.docs} docs / {args.vocab} terms") if wl_desc else ("cfg2: batched 2-term AND, google_codec, DocumentsOnly, Zipf(1.0) 10M docs / 1M terms" if args.docs == 10_000_000 else f"2-term AND, google_codec, DocumentsOnly, {args.docs} docs / {args.vocab} terms"),
-                "docs": args.docs,
-                "vocab": args.vocab,
-                "queries_per_gpu_per_step": args.queries,
-                "index_bytes": int(info["index_bytes"]),
-                "postings": int(info["postings"]),
-                "parallelism": f"query-sharded x{world}, index replicated",
+                "workload": f"{wl_desc}, Zipf(1.0) {docs} docs / {vocab} terms",
+                "docs": docs,
+                "vocab": vocab,
+                "queries_per_gpu_per_step": nq_rank,
+                "batches_per_step": [{"part": pt.name, "queries": len(sp), "codec": "google" if pt.codec == T.engine.CODEC_GOOGLE else "lucene",
+                                      "mode": "AccumulatedScore top-%d" % pt.topk if pt.flags & T.FLAG_ACCUMULATED_SCORE else "DocumentsOnly"} for pt, sp in zip(parts, shard_progs)],  # fmt: skip
+                "index_bytes": int(info0["index_bytes"]),
+                "postings": int(info0["postings"]),
+                "parallelism": f"query-sharded x{world}, index replicated" + (", per-step RCCL all_gather of counts + top-K blocks" if world > 1 else ""),
+                "options": args.option,
             },
             "matched_docids_per_sec": matches_all * steps / elapsed,
             "matches_per_step": matches_all,
+            "value_excludes": "result delivery to the host: docID sets / top-K blocks stay in HBM (PCIe-inclusive figure: DESIGN.md §5)",
             "roofline": {
                 "bound": "hbm",
-                "achieved": achieved,
+                "achieved": gbs(kalg[dom], kms[dom]),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
+                "frac": gbs(kalg[dom], kms[dom]) / HBM_PEAK_GBS,
                 "traffic": (traffic or {}).get(dom),
+                "traffic_source": traffic_src,
                 "kernel": dom,
                 "kernel_ms": kms[dom],
                 "algorithmic_bytes_per_launch": kalg[dom],
-                "queries_per_launch": int(binfo["dense_queries"] if dom == "k_and_dense" else binfo["cand_queries"] if dom == "k_and" else args.queries),
-                "other_kernels": {k: {"kernel_ms": kms[k], "algorithmic_bytes_per_launch": kalg[k], "achieved": (kalg[k] / (kms[k] * 1e-3) / 1e9 if kms[k] > 0 else 0.0), "traffic": (traffic or {}).get(k)} for k in kms if k != dom},
-                "whole_step": {"kernel_ms": k_ms, "algorithmic_bytes": alg, "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else 0.0},
+                "queries_per_launch": int(tot[KQ[dom]]),
+                "other_kernels": {k: {"kernel_ms": kms[k], "algorithmic_bytes_per_launch": kalg[k], "achieved": gbs(kalg[k], kms[k]), "queries": int(tot[KQ[k]]),
+                                      "traffic": (traffic or {}).get(k)} for k in KERNELS if k != dom and kms[k] > 0},  # fmt: skip
+                "post_passes_ms": rest_ms,  # k_phrase / k_score (queries matched by k_and) / k_topk_merge / k_rich: no bytes of their own
+                "whole_step": {"kernel_ms": k_ms, "algorithmic_bytes": tot["algorithmic_bytes"], "achieved": gbs(tot["algorithmic_bytes"], k_ms),
+                               "frac": gbs(tot["algorithmic_bytes"], k_ms) / HBM_PEAK_GBS},  # fmt: skip
             },
             "segment_build_s": build_s,
             "index_upload_s": upload_s,
         }
         if args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(seg, qs, args.cpu_seconds) if progs is None else cpu_baseline_programs(seg, progs, wflags, args.cpu_seconds)
-            # the sample the oracle just ran is also a full-size parity check: same queries, same segment, match totals must agree
-            n_s = out["cpu_baseline"].pop("_n", 0)
-            m_s = out["cpu_baseline"].pop("_matches", None)
-            if n_s and m_s is not None:
-                gpu_m = int(batch.counts()[:n_s].astype(np.uint64).sum())
-                out["parity_check"] = {"queries": n_s, "cpu_oracle_matches": int(m_s), "gpu_matches": gpu_m, "equal": bool(gpu_m == int(m_s))}
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(segs, parts, shard_progs, batches, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    batch.close()
-    ix.close()
+    for b in batches:
+        b.close()
+    for ix in ixs.values():
+        ix.close()
     dev.close()
     if dist is not None:
         dist.barrier()
@@ -216,88 +229,84 @@ def main():
 
 
 def pmc_traffic(args, world):
-    """HBM bytes per launch of each matching kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
-    correction + WRITE_SIZE; profiles/pmc_latest.json, collected with this exact workload) — PMC counters cannot be read
-    from inside the timed run, so the figures are reported only when the configuration matches."""
+    """HBM bytes per launch of each kernel from the COMMITTED rocprofv3 PMC passes of this exact workload (FETCH_SIZE x2 per the gfx950
+    correction + WRITE_SIZE; profiles/pmc_latest.json) — PMC counters cannot be read from inside the timed run, so the figures are
+    quoted from that file (named in roofline.traffic_source) and only when docs / vocab / queries match."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
-            p = json.load(f)["bench_cfg2"]
+            p = json.load(f)["bench_" + args.workload]
         if (p["docs"], p["vocab"], p["queries"]) == (args.docs, args.vocab, args.queries):
-            return {k: v["traffic_bytes_per_launch"] for k, v in p["kernels"].items()}
+            return {k: v["traffic_bytes_per_launch"] for k, v in p["kernels"].items()}, "profiles/pmc_latest.json (" + p.get("collected", "committed rocprofv3 --pmc passes") + ")"
     except Exception:
         pass
-    return None
+    return None, None
 
 
-def cpu_baseline_programs(seg, progs, flags, budget_s):
-    """Extra workloads: the CPU oracle, one thread, on the first programs of rank 0's batch until the budget is spent."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-
-    if seg.codec == 2:
-        ora = O.Index.generate(seg.D, seg.V, seg.slots, seg.seed, codec="lucene")
-    else:
-        ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
-    n = matches = 0
-    t0 = time.perf_counter()
-    for p in progs:
-        matches += ora.exec_count(p, flags)
-        n += 1
-        if time.perf_counter() - t0 > budget_s and n >= 16:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "queries/s", "cores": 1, "kind": "port",
-            "sample": f"first {n} programs of rank 0's batch ({matches} matches) in {dt:.1f}s, oracle single thread", "host_cpus": os.cpu_count(),
-            "_n": n, "_matches": matches}
-
-
-def cpu_baseline(seg, qs, budget_s):
-    """The CPU oracle (plain-C restatement of the reference's iterator path: Google::Decoder next/advance ->
-    Conjuction leapfrog -> GenericDocsSetSpan), one thread, on the first queries of the same batch until the time
-    budget is spent.  A reported baseline only."""
+def cpu_baseline(segs, parts, shard_progs, batches, budget_s):
+    """The CPU oracle (plain-C restatement of the reference's iterator path), one thread, on the first programs of every part of rank
+    0's shard until the time budget is spent; a reported baseline only.  Every sampled query is also a full-size parity check:
+    per-query match counts, FNV-1a of the docID set (DocumentsOnly) or the top-K docIDs (scored) must equal the GPU's.  For
+    DocumentsOnly 2-term batches the all-cores figure (one query per thread) is added."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib as O
 
-    ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
-    n = 0
-    matches = 0
-    t0 = time.perf_counter()
-    for a, b in qs.tolist():
-        docs, _ = ora.exec(np.array([O.tok(O.OP_TERM, a), O.tok(O.OP_TERM, b), O.tok(O.OP_AND, 2)], dtype=np.uint32), O.FLAG_DOCUMENTS_ONLY)
-        matches += len(docs)
-        n += 1
-        if time.perf_counter() - t0 > budget_s and n >= 32:
-            break
-    dt = time.perf_counter() - t0
-    res = {
-        "value": n / dt,
-        "unit": "queries/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"first {n} queries of rank 0's batch ({matches} matches) in {dt:.1f}s, oracle/trinity_oracle.c single thread",
-        "matched_docids_per_sec": matches / dt,
-        "host_cpus": os.cpu_count(),
-        "_n": n,
-        "_matches": matches,
-    }
-    # SURVEY §8(d): also one query per thread on all host cores (the reference's exec_query is re-entrant per thread,
-    # exec.cpp:12).  Same oracle, same queries, drawn from a shared cursor by C threads.
-    try:
-        ncores = len(os.sched_getaffinity(0))
-        progs = np.array([[O.tok(O.OP_TERM, a), O.tok(O.OP_TERM, b), O.tok(O.OP_AND, 2)] for a, b in qs.tolist()], dtype=np.uint32)
-        # heaviest queries first, so the figure is only meaningful over the WHOLE batch: the budget is a safety net, not a cut
-        done, m, dt2 = ora.exec_batch_mt(progs, O.FLAG_DOCUMENTS_ONLY, ncores, max(30.0, budget_s * 3))
-        res["all_cores"] = {
-            "value": done / dt2,
-            "unit": "queries/s",
-            "cores": ncores,
-            "sample": f"{done} queries of the same batch ({m} matches) in {dt2:.1f}s, one query per thread (pthreads, oracle to_exec_batch_mt)",
-            "matched_docids_per_sec": m / dt2,
-        }
-    except Exception as e:  # the single-thread figure stands on its own
-        res["all_cores"] = {"error": str(e)}
-    return res
+    n = matches = 0
+    bad = []
+    checked = {"counts": 0, "docset_hashes": 0, "topk_lists": 0}
+    t_total = 0.0
+    all_cores = None
+    for pi, (pt, progs, batch) in enumerate(zip(parts, shard_progs, batches)):
+        seg = segs[pt.codec]
+        if seg.codec == 2:
+            ora = O.Index.generate(seg.D, seg.V, seg.slots, seg.seed, codec="lucene")
+        else:
+            ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
+        scored = bool(pt.flags & 2)
+        gcounts = batch.counts()
+        ghash = batch.docset_hashes() if not scored else None
+        gtop = batch.topk_results() if scored and pt.topk else None
+        share = budget_s * len(progs) / max(1, sum(len(p) for p in shard_progs))
+        t0 = time.perf_counter()
+        for qi, p in enumerate(progs):
+            docs, scores = ora.exec(p, O.FLAG_ACCUM_SCORE if scored else O.FLAG_DOCUMENTS_ONLY)
+            dt_q = time.perf_counter()
+            matches += len(docs)
+            n += 1
+            if int(gcounts[qi]) != len(docs):
+                bad.append((pi, qi, "count", int(gcounts[qi]), len(docs)))
+            checked["counts"] += 1
+            if ghash is not None:
+                if int(ghash[qi]) != O.fnv1a_docs(docs):
+                    bad.append((pi, qi, "docset hash"))
+                checked["docset_hashes"] += 1
+            if gtop is not None:
+                td, ts = ora.topk(docs, scores, pt.topk)
+                if gtop[0][qi, : len(td)].tolist() != td.tolist() or not np.allclose(gtop[1][qi, : len(td)], ts, rtol=1e-5, atol=0):
+                    bad.append((pi, qi, "top-k"))
+                checked["topk_lists"] += 1
+            t_total -= time.perf_counter() - dt_q  # the checking is not part of the baseline
+            if time.perf_counter() - t0 > share and qi + 1 >= 16:
+                break
+        t_total += time.perf_counter() - t0
+        if pi == 0 and not scored and all(len(p) == 3 for p in progs[:8]):
+            # SURVEY §8(d): also one query per thread on all host cores (the reference's exec_query is re-entrant per thread,
+            # exec.cpp:12).  Same oracle, same queries, drawn heaviest first from a shared cursor by C threads.
+            try:
+                ncores = len(os.sched_getaffinity(0))
+                pa = np.array([p for p in progs if len(p) == 3], dtype=np.uint32)
+                done, m, dt2 = ora.exec_batch_mt(pa, O.FLAG_DOCUMENTS_ONLY, ncores, max(30.0, budget_s * 3))
+                all_cores = {"value": done / dt2, "unit": "queries/s", "cores": ncores, "matched_docids_per_sec": m / dt2,
+                             "sample": f"{done} 2-term queries of the same batch ({m} matches) in {dt2:.1f}s, one query per thread (pthreads, oracle to_exec_batch_mt)"}  # fmt: skip
+            except Exception as e:  # the single-thread figure stands on its own
+                all_cores = {"error": str(e)}
+    res = {"value": n / t_total, "unit": "queries/s", "cores": 1, "kind": "port",
+           "sample": f"first {n} programs of rank 0's shard, proportionally from every part ({matches} matches) in {t_total:.1f}s, oracle/trinity_oracle.c single thread",
+           "matched_docids_per_sec": matches / t_total, "host_cpus": os.cpu_count()}  # fmt: skip
+    if all_cores is not None:
+        res["all_cores"] = all_cores
+    parity = {"queries": n, "per_query": checked, "mismatches": len(bad), "first_mismatches": bad[:5], "equal": not bad}
+    return res, parity
 
 
 if __name__ == "__main__":

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define TRI_ABI_VERSION 1
+#define TRI_ABI_VERSION 2 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option */
 
 /* status codes */
 #define TRI_OK 0
@@ -95,6 +95,10 @@ typedef struct tri_batch_info {
         float dense_ms, cand_ms;
         uint64_t dense_algorithmic_bytes, cand_algorithmic_bytes;
         uint64_t dense_queries, cand_queries;
+        /* k_fused: AccumulatedScore top-K of dense queries in one pass (decode -> match -> score -> select per docID window) */
+        float fused_ms, rest_ms; /* rest_ms: everything after the matching kernels (k_phrase, k_rich, k_score, k_topk_merge) */
+        uint64_t fused_algorithmic_bytes;
+        uint64_t fused_queries;
 } tri_batch_info;
 
 const char *tri_last_error(void);
@@ -106,6 +110,19 @@ void tri_dev_close(tri_dev *);
 int tri_dev_sync(tri_dev *);
 /* the engine's HIP stream (hipStream_t as void*), for callers that order their own work against it */
 void *tri_dev_stream(tri_dev *);
+/* Planner / launch options of this device handle; they apply to batches created afterwards.  The reference has no counterpart (its
+ * planner's constants are compiled in, exec.cpp:35-110); these are the thresholds of the GPU planner:
+ *   "dense_min_postings"  a multi-term query runs as bitmap / score windows when its lists hold at least this many postings (default 524288;
+ *                         0 = every query whose lists allow it)
+ *   "dense_task_cost"     postings per bitmap-window task (default 196608)
+ *   "fused"               1 (default): AccumulatedScore top-K batches run their dense queries through the one-pass kernel; 0: match, then score
+ *   "fused_task_cost"     postings per one-pass task (default 1048576)
+ *   "fused_freq_cap"      0 (default): a window field saturates at the largest freq its width holds; else at this freq (documents above it are
+ *                         rescored from the postings — same results, slower)
+ *   "overlap_dense_wgs" / "overlap_cand_wgs"  both non-zero: the two matching kernels run side by side with that many workgroups per CU
+ * Unknown names fail with TRI_ERR_INVALID. */
+int tri_dev_set_option(tri_dev *, const char *name, uint64_t value);
+int tri_dev_get_option(tri_dev *, const char *name, uint64_t *value);
 
 /* ---- index upload ---------------------------------------------------------------------------------
  * Replaces SegmentIndexSource's mmap of `index` (segment_index_source.cpp:84-93) + per-query
@@ -160,8 +177,10 @@ int tri_batch_get_info(const tri_batch *, tri_batch_info *);
 
 /* results (call after tri_batch_sync) */
 int tri_batch_match_counts(tri_batch *, uint64_t *counts /* [nq] */);
-/* DocumentsOnly: copy query q's ascending docID set; what MatchedIndexDocumentsFilter::consider(ids, cnt)
- * (matches.h:161-165) receives */
+/* Copy query q's ascending docID set; what MatchedIndexDocumentsFilter::consider(ids, cnt) (matches.h:161-165) receives.
+ * DocumentsOnly, MatchedTerms and AccumulatedScore batches with topk == 0 materialise every query's set.  An AccumulatedScore batch
+ * with topk >= 1 delivers top-K lists and match counts; queries it ran through the one-pass kernel have no materialised set and
+ * the call fails with TRI_ERR_INVALID for them (tri_batch_docset_hashes likewise when the batch holds such a query). */
 int tri_batch_docset(tri_batch *, size_t q, uint32_t *out, size_t cap, size_t *n);
 /* AccumulatedScore with topk == 0: the score of every match of query q, parallel to tri_batch_docset(q) — the
  * (id, score) stream MatchedIndexDocumentsFilter::consider(id, score) receives (matches.h:169; exec.cpp:1322-1341) */
@@ -177,8 +196,11 @@ int tri_batch_matched_terms(tri_batch *, size_t q, uint32_t *present /* [n] */, 
                             size_t pos_cap, size_t *npos);
 /* AccumulatedScore with topk >= 1: docids/scores are [nq][topk] row-major, counts[nq] = min(matches, topk) */
 int tri_batch_topk(tri_batch *, uint32_t *docids, float *scores, uint32_t *counts);
-/* device-resident result blocks for the multi-GPU gather (per rank: [nq][topk] u32 + f32, [nq] u32) */
+/* device-resident result blocks for the multi-GPU gather (per rank: [nq][topk] u32 + f32, [nq] u32); valid once the run has
+ * completed on the engine stream (tri_dev_stream) */
 int tri_batch_topk_device(tri_batch *, void **docids, void **scores, void **counts);
+/* device-resident per-query match counts of the last run, u64[nq] (every mode; rich mode: after the COUNT pass) */
+int tri_batch_counts_device(tri_batch *, void **counts);
 /* FNV-1a(64) of every query's docID set computed from the device results (tests at full size) */
 int tri_batch_docset_hashes(tri_batch *, uint64_t *hashes /* [nq] */);
 

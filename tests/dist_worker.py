@@ -41,13 +41,12 @@ def main():
         return counts, docs, scores, tc
 
     counts, docs, scores, tc = answer(mine)
-    gc = TD.gather_counts(dist, torch.from_numpy(counts))
-    gd, gs, gtc = TD.gather_topk(dist, torch.from_numpy(docs), torch.from_numpy(scores), torch.from_numpy(tc))
+    # the same ResultGather bench.py drives over the engine's device buffers (there: backend nccl = RCCL, tensors from device_blocks)
+    g = TD.ResultGather(dist, {"counts": torch.from_numpy(counts), "docs": torch.from_numpy(docs), "scores": torch.from_numpy(scores), "topk_counts": torch.from_numpy(tc)})
+    for _ in range(2):  # a step can be repeated: the receive buffers are reused
+        g.step()
     if rank == 0:
-        all_counts = TD.interleave([t.numpy() for t in gc])
-        all_docs = TD.interleave([t.numpy() for t in gd])
-        all_scores = TD.interleave([t.numpy() for t in gs])
-        all_tc = TD.interleave([t.numpy() for t in gtc])
+        all_counts, all_docs, all_scores, all_tc = (g.global_order(n) for n in ("counts", "docs", "scores", "topk_counts"))
         want = answer(qall)
         assert np.array_equal(all_counts, want[0])
         assert np.array_equal(all_docs, want[1])

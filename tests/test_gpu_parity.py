@@ -1,6 +1,7 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI, against the CPU
 oracle on the same seeded inputs, against the fixtures produced by the genuine reference, and — at sizes the
 oracle cannot cover quickly — through size-independent properties."""
+import contextlib
 import json
 import os
 
@@ -28,9 +29,22 @@ def dev(T):
     d.close()
 
 
+@contextlib.contextmanager
+def options(dev, **kw):
+    """Planner options of the device handle (tri_dev_set_option) for the batches created inside the block."""
+    old = {k: dev.get_option(k) for k in kw}
+    for k, v in kw.items():
+        dev.set_option(k, v)
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            dev.set_option(k, v)
+
+
 class World:
     def __init__(self, T, dev, D, V, slots, seed, codec=1):
-        self.T, self.D, self.V = T, D, V
+        self.T, self.D, self.V, self.dev = T, D, V, dev
         self.seg = T.Segment(D, V, slots, seed, codec=codec)
         if codec == 1:
             self.ora = O.Index.wrap(self.seg.index, self.seg.terms, self.seg.docs_cnt, self.seg.sum_terms_docs, self.seg.sum_term_hits)
@@ -141,14 +155,14 @@ def test_and_dense_windows_match_oracle(large):
 
 
 @pytest.mark.parametrize("world,nq", [("small", 300), ("dense", 200)])
-def test_and_forced_dense_path_matches_oracle(request, monkeypatch, world, nq):
-    """TRINITY_DENSE_MIN=0 forces every eligible query through the bitmap-window path: sparse windows, windows
+def test_and_forced_dense_path_matches_oracle(request, world, nq):
+    """dense_min_postings = 0 forces every eligible query through the bitmap-window path: sparse windows, windows
     with no blocks, lists ending mid-window, k-way conjunctions."""
-    monkeypatch.setenv("TRINITY_DENSE_MIN", "0")
     w = request.getfixturevalue(world)
     T = w.T
     qs = T.gen_queries(w.V, 7, nq, 2).tolist() + T.gen_queries(w.V, 8, 60, 3).tolist() + [[0, 1], [0, 1, 2, 3], [w.V - 1, 0]]
-    sets, _, _ = run_docs_only(w, [and_prog(T, q) for q in qs])
+    with options(w.dev, dense_min_postings=0):
+        sets, _, _ = run_docs_only(w, [and_prog(T, q) for q in qs])
     for q, got in zip(qs, sets):
         want, _ = w.ora.exec(and_prog(T, q), O.FLAG_DOCUMENTS_ONLY)
         assert np.array_equal(got, want), (q, len(got), len(want))
@@ -325,6 +339,83 @@ def test_union_of_head_terms_large(large):
         assert np.array_equal(got, want), (t, len(got), len(want))
 
 
+# ------------------------------------------------------------------------------------------ one-pass scored windows (k_fused)
+FUSED_EXTRA = ["t{a}", "t{a} t{b}", "t{a} t{a}", "t{a} t{b} t{c} t{d} t{e}", "t{a} NOT t{b}", "(t{a} OR t{b}) NOT t{c}", "t{a} t{b} NOT (t{c} OR t{d})",
+               "t{a} <t{b}>", "t{a} t{b} <t{c} OR t{d}>", "(t{a} OR t{b}) (t{a} OR t{c})", "t{a} OR t{b} OR t{c} OR t{d} OR t{e} OR t{a}"]
+
+
+def fused_queries(w, seed, n):
+    rows = w.T.gen_queries(w.V, seed, n, 5).tolist() + [[0, 1, 2, 3, 4], [4, 3, 2, 1, 0], [0, w.V - 1, 1, w.V - 2, 2]]
+    return [tpl.format(a=a, b=b, c=c, d=d, e=e) for a, b, c, d, e in rows for tpl in TEMPLATES + FUSED_EXTRA]
+
+
+def check_scored(w, texts, progs, k, similarity=0, tag=None):
+    d, s, c, counts = run_scored(w, progs, k, similarity=similarity)
+    for i, t in enumerate(texts):
+        docs, scores = w.ora.exec(progs[i], O.FLAG_ACCUM_SCORE)
+        assert int(counts[i]) == len(docs), (tag, t)
+        td, ts = w.ora.topk(docs, scores, k)
+        assert int(c[i]) == len(td), (tag, t)
+        assert d[i, : len(td)].tolist() == td.tolist(), (tag, t)
+        np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("world,n,k", [("small", 12, 10), ("dense", 10, 100), ("small_l", 12, 100), ("dense_l", 10, 256), ("medium", 5, 100), ("medium_l", 6, 10)])
+def test_fused_scored_windows_match_oracle(request, world, n, k):
+    """AccumulatedScore top-K with every eligible query forced through the one-pass kernel (dense_min_postings = 0): conjunctions,
+    unions, CNF, NOT, optional terms, repeated terms, single terms; both codecs; then with the window fields saturating at freq 1
+    and 3 (every document above is rescored from the postings) and, as the cross-check, with the one-pass kernel off."""
+    w = request.getfixturevalue(world)
+    texts = fused_queries(w, 41, n)
+    progs = [O.parse_query(t) for t in texts]
+    for opts in ({"dense_min_postings": 0}, {"dense_min_postings": 0, "fused_freq_cap": 1}, {"dense_min_postings": 0, "fused_freq_cap": 3},
+                 {"dense_min_postings": 0, "fused_task_cost": 4096}, {"dense_min_postings": 0, "fused": 0}):
+        with options(w.dev, **opts):
+            check_scored(w, texts, progs, k, tag=opts)
+
+
+@pytest.mark.parametrize("sim", ["tfidf", "trivial"])
+@pytest.mark.parametrize("world", ["dense", "dense_l"])
+def test_fused_other_similarities(request, world, sim):
+    w = request.getfixturevalue(world)
+    texts = fused_queries(w, 43, 6)
+    progs = [O.parse_query(t) for t in texts]
+    w.ora.set_similarity(SIMS[sim])
+    try:
+        for opts in ({"dense_min_postings": 0}, {"dense_min_postings": 0, "fused_freq_cap": 2}):
+            with options(w.dev, **opts):
+                check_scored(w, texts, progs, 50, similarity=SIMS[sim], tag=(sim, opts))
+    finally:
+        w.ora.set_similarity(0)
+
+
+def test_fused_large_unions_and_cnf(large):
+    """2M documents: unions and CNFs of head terms (millions of matches per query, hundreds of windows, several tasks per query)."""
+    w = large
+    texts = ["t0 OR t1", "t0 OR t1 OR t2 OR t3 OR t4", "t0 t1 (t2 OR t3 OR t4)", "(t0 OR t1) (t2 OR t3) t4", "t0 t1", "t0 t1 t2 t3 t4", "t100000 OR t150000 OR t199999",
+             "t0 OR t199999", "t3 t5 NOT t1", "t2 <t7 OR t9>"]
+    progs = [O.parse_query(t) for t in texts]
+    for opts in ({}, {"fused_task_cost": 200000}):
+        with options(w.dev, **opts):
+            check_scored(w, texts, progs, 100, tag=opts)
+
+
+def test_fused_batches_do_not_materialise_docsets(small):
+    """An AccumulatedScore top-K batch run through the one-pass kernel keeps top-K lists and counts; asking it for a docID set
+    fails with TRI_ERR_INVALID instead of returning stale memory."""
+    w, T = small, small.T
+    with options(w.dev, dense_min_postings=0):
+        b = T.Batch(w.ix, [O.parse_query("t0 OR t1")], T.FLAG_ACCUMULATED_SCORE, topk=10)
+    b.run()
+    b.sync()
+    assert int(b.counts()[0]) > 0 and b.info()["fused_queries"] == 1
+    with pytest.raises(T.TrinityError):
+        b.docset(0)
+    with pytest.raises(T.TrinityError):
+        b.docset_hashes()
+    b.close()
+
+
 # ------------------------------------------------------------------------------------------ phrases (K6)
 PHRASE_TEMPLATES = ['"t{a} t{b}"', '"t{a} t{b} t{c}"', '"t{a} t{b}" t{c}', '"t{a} t{b}" "t{c} t{d}"', '"t{a} t{a}"', '"t{a} t{b} t{a}"', 't{e} "t{b} t{a}"']
 
@@ -480,16 +571,16 @@ def test_lucene_phrase_needs_hits(T, dev):
     ix.close()
 
 
-def test_lucene_forced_dense_and_fixtures(T, dev, monkeypatch):
+def test_lucene_forced_dense_and_fixtures(T, dev):
     """Reference fixture records (non-phrase) against a LUCENE-coded segment, bitmap-window path forced."""
-    monkeypatch.setenv("TRINITY_DENSE_MIN", "0")
     checked = 0
     for name in ("small", "dense"):
         g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
         c = g["corpus"]
         w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"], codec=2)
         recs = [r for r in g["results"] if r["cmd"] in ("query", "queryfull") and r["flags"] == 1 and '"' not in r["q"] and gpu_lowers(r["q"])]
-        sets, hashes, _ = run_docs_only(w, [O.parse_query(r["q"]) for r in recs])
+        with options(dev, dense_min_postings=0):
+            sets, hashes, _ = run_docs_only(w, [O.parse_query(r["q"]) for r in recs])
         for r, got, h in zip(recs, sets, hashes):
             assert len(got) == r["n"] and str(int(h)) == r["fnv"], r["q"]
             checked += 1
@@ -505,27 +596,24 @@ def test_workload_matches_oracle(T, dev, name):
     from trinity_amd import workloads as W
 
     D, V = 30000, 3000
-    progs, flags, topk, codec, _ = W.build(name, D, V, 10, 42, 160)
-    w = World(T, dev, D, V, 10, 42, codec=codec)
-    if flags & T.FLAG_ACCUMULATED_SCORE:
-        d, s, c, counts = run_scored(w, progs, topk)
-        for i, p in enumerate(progs):
-            docs, scores = w.ora.exec(p, O.FLAG_ACCUM_SCORE)
-            assert int(counts[i]) == len(docs), i
-            td, ts = w.ora.topk(docs, scores, topk)
-            assert d[i, : len(td)].tolist() == td.tolist(), i
-            np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
-    else:
-        sets, hashes, _ = run_docs_only(w, progs)
-        sampled_hits = 0
-        for i, (p, got, h) in enumerate(zip(progs, sets, hashes)):
-            want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
-            assert np.array_equal(got, want), (name, i, p.tolist(), len(got), len(want))
-            assert int(h) == O.fnv1a_docs(want)
-            sampled_hits += len(want) > 0
-        if name == "cfg4":
-            assert sampled_hits >= len(progs) // 2  # every document-sampled phrase occurs in its document
-    w.ix.close()
+    parts, _ = W.build_parts(name, D, V, 10, 42, 160)
+    for progs, flags, topk, codec in ((pt.programs, pt.flags, pt.topk, pt.codec) for pt in parts):
+        w = World(T, dev, D, V, 10, 42, codec=codec)
+        if flags & T.FLAG_ACCUMULATED_SCORE:
+            for opts in ({}, {"dense_min_postings": 0}):  # the planner's choice at this size, then the one-pass scored windows forced
+                with options(dev, **opts):
+                    check_scored(w, [str(i) for i in range(len(progs))], progs, topk, tag=(name, opts))
+        else:
+            sets, hashes, _ = run_docs_only(w, progs)
+            sampled_hits = 0
+            for i, (p, got, h) in enumerate(zip(progs, sets, hashes)):
+                want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+                assert np.array_equal(got, want), (name, i, p.tolist(), len(got), len(want))
+                assert int(h) == O.fnv1a_docs(want)
+                sampled_hits += len(want) > 0
+            if name == "cfg4":
+                assert sampled_hits >= len(progs) // 2  # every document-sampled phrase occurs in its document
+        w.ix.close()
 
 
 # ------------------------------------------------------------------------------------------ logicalnot (DocsSetIterators::Filter)
@@ -552,12 +640,12 @@ def test_not_docsets_match_oracle(request, world, n):
         assert int(h) == O.fnv1a_docs(want)
 
 
-def test_not_forced_dense(T, dev, monkeypatch):
-    monkeypatch.setenv("TRINITY_DENSE_MIN", "0")
+def test_not_forced_dense(T, dev):
     w = World(T, dev, 20000, 500, 12, 7)
     texts = not_queries(w, 72, 10)
     progs = [O.parse_query(t) for t in texts]
-    sets, _, info = run_docs_only(w, progs)
+    with options(dev, dense_min_postings=0):
+        sets, _, info = run_docs_only(w, progs)
     for t, p, got in zip(texts, progs, sets):
         want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
         assert np.array_equal(got, want), (t, len(got), len(want))
@@ -590,7 +678,7 @@ def test_not_of_conjunction_is_refused(T, dev):
 
 # ------------------------------------------------------------------------------------------ masked documents
 @pytest.mark.parametrize("codec", [1, 2])
-def test_masked_documents_are_dropped(T, dev, codec, monkeypatch):
+def test_masked_documents_are_dropped(T, dev, codec):
     """masked_documents_registry::test (docidupdates.h:90-119; exec.cpp:914-975): a document masked by a newer segment never
     reaches consider().  Every query shape, both matching kernels, scored and not; then the set is cleared again."""
     w = World(T, dev, 30000, 3000, 10, 42, codec=codec)
@@ -602,10 +690,9 @@ def test_masked_documents_are_dropped(T, dev, codec, monkeypatch):
     w.ix.set_masked(masked)
     w.ora.set_masked(masked)
     try:
-        for dense_min in ("", "0"):  # planner's choice, then the bitmap-window kernel forced
-            if dense_min:
-                monkeypatch.setenv("TRINITY_DENSE_MIN", dense_min)
-            sets, hashes, _ = run_docs_only(w, progs)
+        for dense_min in (None, 0):  # planner's choice, then the bitmap-window kernel forced
+            with options(dev, **({} if dense_min is None else {"dense_min_postings": dense_min})):
+                sets, hashes, _ = run_docs_only(w, progs)
             dropped = 0
             for t, p, got, h, full in zip(texts, progs, sets, hashes, base_sets):
                 want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
@@ -614,15 +701,16 @@ def test_masked_documents_are_dropped(T, dev, codec, monkeypatch):
                 assert int(h) == O.fnv1a_docs(want)
                 dropped += len(full) - len(got)
             assert dropped > 1000
-        monkeypatch.delenv("TRINITY_DENSE_MIN", raising=False)
         scored = [p for t, p in zip(texts, progs)]
-        d, s, c, counts = run_scored(w, scored, 20)
-        for i, p in enumerate(scored):
-            docs, scores = w.ora.exec(p, O.FLAG_ACCUM_SCORE)
-            assert int(counts[i]) == len(docs), texts[i]
-            td, ts = w.ora.topk(docs, scores, 20)
-            assert d[i, : len(td)].tolist() == td.tolist(), texts[i]
-            np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+        for opts in ({}, {"dense_min_postings": 0}, {"dense_min_postings": 0, "fused": 0}):  # planner's choice; one-pass scored windows forced; match-then-score forced
+            with options(dev, **opts):
+                d, s, c, counts = run_scored(w, scored, 20)
+            for i, p in enumerate(scored):
+                docs, scores = w.ora.exec(p, O.FLAG_ACCUM_SCORE)
+                assert int(counts[i]) == len(docs), (opts, texts[i])
+                td, ts = w.ora.topk(docs, scores, 20)
+                assert d[i, : len(td)].tolist() == td.tolist(), (opts, texts[i])
+                np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
     finally:
         w.ix.set_masked(np.zeros(0, np.uint32))
         w.ora.set_masked(np.zeros(0, np.uint32))

@@ -108,12 +108,14 @@ def test_workload_generators_on_cpu(T):
     D, V = 5000, 500
     ora = O.Index.generate(D, V, 10, 42)
     for name in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
-        progs, flags, topk, codec, desc = W.build(name, D, V, 10, 42, 60)
-        assert len(progs) == 60 and desc.startswith(name)
+        parts, desc = W.build_parts(name, D, V, 10, 42, 60)
+        assert sum(len(pt.programs) for pt in parts) == 60 and desc.startswith(name)
+        assert (len(parts) == 2 and parts[1].flags & 2 and parts[1].topk == 100) if name == "cfg5" else len(parts) == 1  # cfg5's 30 % share is scored
         hits = 0
-        for p in progs:
-            docs, _ = ora.exec(p, O.FLAG_DOCUMENTS_ONLY if not (flags & 2) else O.FLAG_ACCUM_SCORE)
-            hits += len(docs) > 0
+        for pt in parts:
+            for p in pt.programs:
+                docs, _ = ora.exec(p, O.FLAG_DOCUMENTS_ONLY if not (pt.flags & 2) else O.FLAG_ACCUM_SCORE)
+                hits += len(docs) > 0
         if name == "cfg4":
             # even rows of each half are document-sampled: at least those must match
             assert hits >= 30

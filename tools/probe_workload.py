@@ -12,7 +12,7 @@ import trinity_amd.engine as E
 
 name = os.environ.get("WORKLOAD", "cfg3")
 D, V, NQ = int(os.environ.get("DOCS", 10_000_000)), int(os.environ.get("VOCAB", 1_000_000)), int(os.environ.get("NQ", 2048))
-progs, flags, topk, codec, desc = W.build(name, D, V, 10, 42, NQ)
+progs, flags, topk, codec, desc = W.build(name, D, V, 10, 42, NQ)  # single-part workloads (cfg5 runs as two batches: bench.py)
 if os.environ.get("CODEC"):
     codec = int(os.environ["CODEC"])
     desc += f" [codec forced to {codec}]"

@@ -40,6 +40,7 @@ struct DevQuery {
         uint32_t first_task, ntasks;
         uint32_t score_base, nscore; // AccumulatedScoreScheme: sterms[]/sweights[] slice, reference summation order
         uint32_t phrase_base, nphrases; // positional constraints applied to the match list (DocsSetIterators::Phrase)
+        uint32_t fused_idx, pad0;       // TASK_FUSED queries: row in the batch's DevFused table (k_fused.hpp)
 };
 
 // A phrase constraint: its terms (phrase order) live in pterms[term_base .. +nterms); weight = sum of the terms' idf
@@ -64,3 +65,20 @@ struct DevTask {
 };
 constexpr uint32_t TASK_CAND = 0;  // candidate tiles of the lead list, filtered by galloping / block-driven merge
 constexpr uint32_t TASK_DENSE = 1; // bitmap algebra over fixed docID windows (every list dense enough)
+constexpr uint32_t TASK_FUSED = 2; // AccumulatedScoreScheme + top-K of a dense query: decode, match, score and select in one pass over docID
+                                   // windows (k_fused.hpp); tile_begin / tile_end count windows of FUS_W documents; nothing is written to out[]
+
+constexpr uint32_t FUS_MAX_SLOTS = 8;
+// planner -> kernel: how a fused query's terms map onto the window words
+struct DevFused {
+        uint32_t nslots;                // distinct terms: CNF terms (incl. the excluded group) and scoring-only (optional) terms
+        uint32_t fbits;                 // field width: 8 (<= 4 slots) or 4
+        uint32_t cap;                   // largest freq a field holds exactly; cap + 2 <= 1 << fbits (code cap + 1 = "cap or more")
+        uint32_t nreq;                  // required groups
+        uint32_t term[FUS_MAX_SLOTS];   // slot -> term
+        uint32_t gmask[FUS_MAX_SLOTS];  // per required group: the fields of its slots ((word & gmask) != 0 <=> group satisfied)
+        uint32_t gslots[FUS_MAX_SLOTS]; // per required group: bit s = slot s belongs to it (window skipping)
+        uint32_t nmask;                 // fields of the excluded group (logicalnot), 0 = none
+        uint32_t pad;
+};
+

@@ -1,0 +1,526 @@
+// k_fused.hpp — AccumulatedScoreScheme in ONE pass: decode -> match -> BM25 -> top-K per docID window, nothing spilled to HBM
+// Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
+#pragma once
+#include "k_score.hpp"
+
+// What the reference does per matching document (docset_spans.cpp:681-790 window accumulate; docset_iterators_scorers.cpp:10-36,
+// 107-193 score wrappers; similarity.h:228-235 BM25; matches.h:155-171 the application's top-K heap) happens here per docID
+// WINDOW, for every query whose lists are dense enough that no block could be skipped (the planner's TASK_DENSE class) and
+// that asks for a top-K:
+//
+//   * LDS holds one 32-bit word per document of the window (FUS_W documents).  The query's distinct terms (<= 8) are SLOTS; a
+//     slot owns a field of the word — 8 bits when the query has <= 4 slots, 4 bits otherwise — holding 0 = "the document does
+//     not have the term", else min(freq, cap) + 1.  A posting is ONE fire-and-forget ds_or_b32: the docID picks the word, the
+//     freq the code.  All terms of the query are decoded in one pass (no per-group passes, no bitmap folds), each list exactly
+//     once, freqs in the same block visit as the deltas.
+//   * the epilogue sweeps the window's words: the CNF predicate is a handful of mask tests on the word (a required group =
+//     "any of these fields non-zero", the excluded group = "all zero"), the score is the sum of one table lookup per BYTE of the
+//     word (tables built per task in LDS from the scorers' weights: entry = sum over the byte's fields of
+//     IndexSourceTermsScorer::score(freq), doubles — the sum of a handful of floats is exact in double, so the order of
+//     summation cannot matter), compared against the task's current k-th best (score desc, docID asc); the few survivors are
+//     appended to a candidate buffer that is pruned by rank when it fills.  The sweep re-zeroes the words.
+//   * a field that saturates (freq > cap) makes its table entry NaN; such a (rare) document is rescored exactly: the term's
+//     block is located through the directory and its freq decoded (fused_lookup_freq).
+// Per task the kernel leaves min(matches, k) (docID, score) pairs and the match count; k_topk_merge folds the tasks of a query.
+constexpr int FUS_WG = 512;
+constexpr uint32_t FUS_CELLS = 15; // docID cells (of CELL_DOCS) per window: 60 KB of words, two workgroups per CU
+constexpr uint32_t FUS_W = FUS_CELLS * CELL_DOCS;
+constexpr uint32_t FUS_CAP = 512; // candidate buffer; k <= TOPK_MAX = 256
+static_assert(FUS_W % FUS_WG == 0, "the sweep deals whole rounds of words to the workgroup");
+static_assert(TOPK_MAX * 2 <= FUS_CAP, "a pruned buffer must leave room for a round of newcomers");
+
+struct FusedShared {
+        uint32_t acc[FUS_W + 64]; // [FUS_W] = sink for documents outside the window
+        double tab[4][256];       // per byte of the word: score contribution of the byte's fields (NaN: a saturated field)
+        double tk_s[FUS_CAP];
+        uint32_t tk_d[FUS_CAP];
+        DevTerm term[FUS_MAX_SLOTS];
+        uint32_t seg_lo[FUS_MAX_SLOTS];
+        uint32_t seg_cnt[FUS_MAX_SLOTS + 1];
+        uint32_t seg_np[FUS_MAX_SLOTS]; // first docID >= w0 the slot's list may still hold (0xffffffff: exhausted)
+        double thr_s;
+        uint32_t thr_d;
+        uint32_t tk_n, tk_full, overflow, matches;
+        uint32_t bcast[4];
+        DevFused fq; // the query's slot map, staged once per task (dynamic indexing stays in LDS, not in scratch)
+};
+
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+typedef uint64_t u64_a1 __attribute__((aligned(1)));
+__device__ __forceinline__ uint32_t ldu32(const uint8_t *p) { return *(const u32_a1 *)p; } // gfx950 global loads take any alignment
+__device__ __forceinline__ uint64_t ldu64(const uint8_t *p) { return *(const u64_a1 *)p; }
+
+// ---- LUCENE: one quarter (32 values) of an ints() group, read by one lane without the general stream's state machine
+// (codec_streams.hpp LValStream).  The quarter's packed words are held in registers: NW words fetched up front with wide loads (a
+// quarter of width b occupies exactly b words), so the value loop touches no memory; the low parts come out of a two-word funnel
+// (v_alignbit), a used-up word is a register shift.  The quarter's exceptions — found through the per-row exception index built
+// at upload (blk_exc) instead of a scan of the group's list — sit in a 32-bit position mask and a packed queue of high parts and
+// are patched branch-free.  Takes quarters of width <= NW whose exception high parts fit 32 bits: every block of the terms that
+// carry the postings volume (head terms: widths 1-4, a handful of 1-2 bit exceptions).  The others take the general streams.
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+template <int NW>
+struct PfRegs {
+        uint32_t w[NW];
+        uint32_t sh, b, mask, excmask, eb, emask, hq;
+        __device__ __forceinline__ bool init(const uint8_t *g, const uint32_t q, const uint32_t e0, const uint32_t cnt) {
+                const uint32_t L = g[0];
+                excmask = 0;
+                eb = 0;
+                emask = 0;
+                hq = 0;
+                sh = 0;
+                if (!L) { // lucene_codec.cpp:31-39: every value equal, one prefix varint
+                        uint32_t len;
+                        w[0] = vb_decode(ldu64(g + 1), len);
+#pragma unroll
+                        for (int k = 1; k < NW; ++k)
+                                w[k] = 0;
+                        b = 0;
+                        mask = 0xffffffffu;
+                        return true;
+                }
+                const uint32_t w0 = ldu32(g + 1);
+                b = w0 & 0xffu;
+                const uint32_t nexc = (w0 >> 8) & 0xffu;
+                eb = (w0 >> 16) & 0xffu;
+                if (b > NW || cnt > 16 || cnt * eb > 32)
+                        return false;
+                mask = (1u << b) - 1u; // (b <= NW < 32)
+                const uint8_t *q0 = g + 5 + 4 * (q * b);
+#pragma unroll
+                for (int k = 0; k < NW; k += 4) {
+                        const u32x4_a1 v = *(const u32x4_a1 *)(q0 + 4 * k);
+                        w[k] = v.x, w[k + 1] = v.y, w[k + 2] = v.z, w[k + 3] = v.w;
+                }
+                if (cnt) {
+                        emask = eb >= 32 ? 0xffffffffu : ((1u << eb) - 1u);
+                        const uint8_t *epos = g + 5 + 16 * b;
+                        const uint8_t *ehigh = epos + 4 * ((nexc + 3) / 4);
+                        uint64_t p0 = ldu64(epos + e0);
+                        const uint64_t p1 = ldu64(epos + e0 + 8);
+                        for (uint32_t e = 0; e < cnt; ++e) {
+                                if (e == 8)
+                                        p0 = p1;
+                                excmask |= 1u << ((uint32_t)p0 & 31u);
+                                p0 >>= 8;
+                        }
+                        const uint32_t bit0 = e0 * eb;
+                        hq = (uint32_t)(ldu64(ehigh + (bit0 >> 3)) >> (bit0 & 7u)); // 32 bits from any bit offset
+                }
+                return true;
+        }
+        __device__ __forceinline__ uint32_t next(const uint32_t i) {
+                uint32_t x = __builtin_amdgcn_alignbit(w[1], w[0], sh) & mask;
+                sh += b;
+                // a word is used up: shift the register queue.  The branch is WAVE-uniform (lanes of one list share a width and cross
+                // word boundaries together), the shift inside is per lane by select — a lane-divergent branch here made the compiler
+                // copy the whole queue on every value
+                if (__builtin_amdgcn_ballot_w64(sh >= 32) != 0ull) {
+                        const bool r = sh >= 32;
+#pragma unroll
+                        for (int k = 0; k + 1 < NW; ++k)
+                                w[k] = r ? w[k + 1] : w[k];
+                        sh = r ? sh - 32 : sh;
+                }
+                const uint32_t m = (uint32_t)(-(int32_t)((excmask >> i) & 1u)); // all ones at an exception
+                x |= (hq & emask & m) << b;
+                hq >>= (eb & m);
+                return x;
+        }
+};
+
+// The freq of `doc` in term t (the document is known to be one of the term's): rescoring of a saturated field.
+template <int CODEC>
+__device__ __noinline__ uint32_t fused_lookup_freq(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+                                      const DevTerm &t, const uint32_t doc) {
+        const uint32_t *bl = blk_last + t.first_block;
+        uint32_t lo = 0, hi = t.nblocks;
+        while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (bl[mid] < doc)
+                        lo = mid + 1;
+                else
+                        hi = mid;
+        }
+        const uint32_t b = lo;
+        const uint32_t off = blk_off[t.first_block + b];
+        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
+        uint32_t d = b ? bl[b - 1] : 0, pos = n - 1;
+        DeltaStream<CODEC> ds;
+        ds.init(index, t, b, off);
+        for (uint32_t i = 0; i + 1 < n; ++i) { // (GOOGLE: the freqs start where the deltas end, so all of them are walked)
+                d += ds.next();
+                if (d == doc && pos == n - 1)
+                        pos = i;
+        }
+        FreqStream<CODEC> fs;
+        fs.init(index, t, b, off, ds);
+        uint32_t f = 0;
+        for (uint32_t i = 0; i <= pos; ++i)
+                f = fs.next();
+        return f & 0xffffu;
+}
+
+// One directory row (<= 32 documents) of a slot's term into the window words, through the codec's general value streams: GOOGLE
+// rows, the varbyte tail of a LUCENE list, and the PFOR quarters the register reader (PfRegs) does not take.
+template <int CODEC>
+__device__ __forceinline__ void fused_row_streams(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
+                                                  const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift,
+                                                  const uint32_t cap) {
+        uint32_t rel = prev - w0; // documents below the window wrap to huge values and land in the sink word
+        DeltaStream<CODEC> ds;
+        ds.init(index, t, b, off);
+        FreqStream<CODEC> fs;
+        if (CODEC == CODEC_GOOGLE) { // the freqs follow the n - 1 deltas: find where they start, then walk both in step
+                DeltaStream<CODEC> sk = ds;
+                for (uint32_t i = 0; i + 1 < n; ++i)
+                        (void)sk.next();
+                fs.init(index, t, b, off, sk);
+        } else
+                fs.init(index, t, b, off, ds);
+        for (uint32_t i = 0; i < n; ++i) {
+                rel = (i + 1 < n) ? rel + ds.next() : last - w0;
+                const uint32_t f = fs.next() & 0xffffu;
+                atomicOr(&acc[min(rel, FUS_W)], (min(f, cap) + 1u) << shift);
+        }
+}
+
+// (LUCENE: out of line — the general streams' state must not weigh on the registers of the PFOR fast path, and only the tail rows
+// and the odd wide quarter come here.  GOOGLE rows have no other route: inline.)
+__device__ __noinline__ void fused_row_streams_lucene(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
+                                                      const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc,
+                                                      const uint32_t shift, const uint32_t cap) {
+        fused_row_streams<CODEC_LUCENE>(index, t, b, off, n, prev, last, w0, acc, shift, cap);
+}
+
+template <int CODEC>
+__device__ __forceinline__ void fused_row(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_exc, const DevTerm &t, const uint32_t b,
+                                          const uint32_t off, const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0,
+                                          uint32_t *acc, const uint32_t shift, const uint32_t cap) {
+        if (CODEC == CODEC_LUCENE && b < t.npfor) {
+                const uint8_t *g = index + off;
+                const uint32_t L = g[0];
+                uint32_t vl = 0; // (only decoded when L == 0)
+                if (!L) {
+                        const uint32_t b0 = g[1];
+                        vl = b0 < 0x80 ? 1 : b0 < 0xc0 ? 2 : b0 < 0xe0 ? 3 : b0 < 0xf0 ? 4 : 5;
+                }
+                const uint8_t *gf = g + 1 + (L ? 4 * L : vl);
+                const uint32_t x = blk_exc[t.first_block + b]; // e0_d | cnt_d << 8 | e0_f << 16 | cnt_f << 24
+                {
+                        PfRegs<8> rd;
+                        PfRegs<4> rf;
+                        const bool okd = rd.init(g, b & 3u, x & 0xffu, (x >> 8) & 0xffu);
+                        const bool okf = rf.init(gf, b & 3u, (x >> 16) & 0xffu, x >> 24);
+                        if (okd && okf) {
+                                uint32_t rel = prev - w0; // documents below the window wrap to huge values and land in the sink word
+#pragma unroll 2
+                                for (uint32_t i = 0; i < 32; ++i) {
+                                        rel += rd.next(i);
+                                        const uint32_t f = rf.next(i) & 0xffffu;
+                                        atomicOr(&acc[min(rel, FUS_W)], (min(f, cap) + 1u) << shift);
+                                }
+                                return;
+                        }
+                }
+        }
+        if (CODEC == CODEC_LUCENE)
+                fused_row_streams_lucene(index, t, b, off, n, prev, last, w0, acc, shift, cap);
+        else
+                fused_row_streams<CODEC>(index, t, b, off, n, prev, last, w0, acc, shift, cap);
+}
+
+// Keep the best k of the n (<= FUS_CAP) buffered candidates, best first (rank by counting: the order is strict).
+__device__ void fused_prune(FusedShared &sh, const uint32_t n, const uint32_t k) {
+        const uint32_t tid = threadIdx.x;
+        double es = 0;
+        uint32_t ed = 0, rk = 0xffffffffu;
+        if (tid < n) {
+                es = sh.tk_s[tid];
+                ed = sh.tk_d[tid];
+                uint32_t c = 0;
+                for (uint32_t j = 0; j < n; ++j)
+                        c += better(sh.tk_s[j], sh.tk_d[j], es, ed) ? 1u : 0u;
+                rk = c;
+        }
+        __syncthreads();
+        if (rk < k) {
+                sh.tk_s[rk] = es;
+                sh.tk_d[rk] = ed;
+        }
+        __syncthreads();
+        const uint32_t m = n < k ? n : k;
+        // uniform stores by every lane
+        sh.tk_n = m;
+        sh.overflow = 0;
+        if (m == k) {
+                sh.tk_full = 1;
+                sh.thr_s = sh.tk_s[k - 1];
+                sh.thr_d = sh.tk_d[k - 1];
+        }
+        __syncthreads();
+}
+
+template <int CODEC>
+__global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                     const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_exc,
+                                                     const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
+                                                     const DevQuery *__restrict__ plan, const DevFused *__restrict__ fused,
+                                                     const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched,
+                                                     const uint32_t *__restrict__ sterms, const double *__restrict__ sweights, const uint32_t ntasks,
+                                                     uint32_t *__restrict__ ticket, uint32_t *__restrict__ counts, const uint32_t k,
+                                                     uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
+                                                     uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked, const int sim) {
+        __shared__ FusedShared sh;
+        const uint32_t tid = threadIdx.x;
+        const uint32_t wave = uni(tid >> 6);
+        for (uint32_t i = tid; i < FUS_W + 64; i += FUS_WG)
+                sh.acc[i] = 0;
+        PROF_DECL;
+        PROF_START();
+        for (;;) {
+                if (wave == 0) { // uniform draw (see k_and)
+                        const uint32_t old = atomicAdd(ticket, 1u);
+                        sh.bcast[0] = uni(old) >> 6;
+                }
+                __syncthreads();
+                const uint32_t ticket_no = uni(sh.bcast[0]);
+                __syncthreads();
+                if (ticket_no >= ntasks)
+                        break;
+                const uint32_t tix = sched[ticket_no];
+                const DevTask task = tasks[tix];
+                const DevQuery q = plan[task.slot];
+                // ---- per task: the query's slot map, the slots' terms, the score tables, an empty candidate buffer
+                {
+                        const uint32_t wi = min(tid, (uint32_t)(sizeof(DevFused) / 4 - 1)); // (every lane stores: no divergent branch around the barriers)
+                        ((uint32_t *)&sh.fq)[wi] = ((const uint32_t *)(fused + q.fused_idx))[wi];
+                }
+                __syncthreads();
+                const DevFused &fq = sh.fq;
+                const uint32_t nslots = uni(fq.nslots), fbits = uni(fq.fbits), cap = uni(fq.cap), nreq = uni(fq.nreq), nmask = uni(fq.nmask);
+                const uint32_t kk = min(tid, nslots - 1); // lanes >= nslots mirror the last slot
+                sh.term[kk] = terms[fq.term[kk]];
+                sh.tk_n = 0;
+                sh.tk_full = 0;
+                sh.overflow = 0;
+                sh.matches = 0;
+                {
+                        // tab[c][v]: the fields inside byte c of the word.  code 0 = absent; code - 1 = freq; code cap + 1 = saturated
+                        const uint32_t nch = (nslots * fbits + 7) / 8, per = 8 / fbits, fmask = (1u << fbits) - 1u;
+                        for (uint32_t e = tid; e < nch * 256; e += FUS_WG) {
+                                const uint32_t c = e >> 8, v = e & 255u;
+                                double s = 0.0;
+                                bool sat = false;
+                                for (uint32_t j = 0; j < per; ++j) {
+                                        const uint32_t slot = c * per + j, code = (v >> (j * fbits)) & fmask;
+                                        if (slot >= nslots || !code)
+                                                continue;
+                                        if (code > cap) {
+                                                sat = true;
+                                                continue;
+                                        }
+                                        const uint32_t term = fq.term[slot];
+                                        for (uint32_t si = 0; si < q.nscore; ++si) // every scorer of this term, reference order
+                                                if (sterms[q.score_base + si] == term)
+                                                        s += (double)sim_score(sim, sweights[q.score_base + si], code - 1u);
+                                }
+                                sh.tab[c][v] = sat ? __builtin_nan("") : s;
+                        }
+                }
+                __syncthreads();
+                const DevTerm myt = sh.term[kk];
+                const uint32_t *mybl = blk_last + myt.first_block;
+                const bool indexed = myt.win_off != 0xffffffffu;
+                uint32_t w = task.tile_begin;
+                // directory position of my slot's list: indexed lists keep the two cell-index entries of the window's ends (the
+                // far one is fetched a window ahead), short lists a cursor
+                uint32_t e_lo = 0, e_hi = 0, pf = 0, cur = 0;
+                if (indexed) {
+                        e_lo = win[myt.win_off + w * FUS_CELLS];
+                        e_hi = win[myt.win_off + (w + 1) * FUS_CELLS];
+                        pf = win[myt.win_off + (w + 2) * FUS_CELLS];
+                } else {
+                        uint32_t lo = 0, hi = myt.nblocks; // first block whose last document >= the task's first docID
+                        const uint32_t key = w * FUS_W;
+                        while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (mybl[mid] < key)
+                                        lo = mid + 1;
+                                else
+                                        hi = mid;
+                        }
+                        cur = lo;
+                }
+                uint32_t my_matches = 0;
+                PROF_LAP(0);
+                while (w < task.tile_end) {
+                        const uint32_t w0 = w * FUS_W, wlast = w0 + (FUS_W - 1);
+                        // ---- my slot's blocks that can hold documents of [w0, wlast], and the first docID >= w0 it may still hold
+                        {
+                                uint32_t b_lo, b_hi, np = 0xffffffffu;
+                                bool here = false;
+                                if (indexed) {
+                                        b_lo = e_lo;
+                                        b_hi = min(e_hi, myt.nblocks - 1);
+                                        here = e_lo != e_hi; // a block ends inside the window
+                                } else {
+                                        while (cur < myt.nblocks && mybl[cur] < w0)
+                                                ++cur;
+                                        b_lo = b_hi = cur;
+                                        while (b_hi + 1 < myt.nblocks && mybl[b_hi] < wlast)
+                                                ++b_hi;
+                                }
+                                if (b_lo < myt.nblocks) {
+                                        const uint32_t first_possible = here ? w0 : (b_lo ? mybl[b_lo - 1] + 1 : 1u);
+                                        np = max(w0, first_possible);
+                                }
+                                sh.seg_lo[kk] = b_lo;
+                                sh.seg_cnt[kk] = b_lo < myt.nblocks ? b_hi - b_lo + 1 : 0;
+                                sh.seg_np[kk] = np;
+                        }
+                        sh.seg_cnt[nslots] = 0xffffffffu; // sentinel: the lane-to-slot walk stops here
+                        __syncthreads();
+                        // ---- no match before the latest "first possible document" over the required groups (a group: its earliest slot)
+                        uint32_t need = 0;
+                        for (uint32_t g = 0; g < nreq; ++g) {
+                                uint32_t gnp = 0xffffffffu;
+                                for (uint32_t s = 0; s < nslots; ++s)
+                                        if ((fq.gslots[g] >> s) & 1u)
+                                                gnp = min(gnp, sh.seg_np[s]);
+                                need = max(need, gnp);
+                        }
+                        need = uni(need);
+                        uint32_t total = 0;
+                        for (uint32_t s = 0; s < nslots; ++s)
+                                total += sh.seg_cnt[s];
+                        total = uni(total);
+                        __syncthreads(); // seg_* are rewritten when the window moves
+                        if (need == 0xffffffffu)
+                                break; // a required group is exhausted: no further match anywhere
+                        const uint32_t wnext = need / FUS_W;
+                        if (wnext > w) { // nothing can match before window wnext: jump
+                                w = wnext;
+                                if (indexed) {
+                                        e_lo = win[myt.win_off + w * FUS_CELLS];
+                                        e_hi = win[myt.win_off + (w + 1) * FUS_CELLS];
+                                        pf = win[myt.win_off + (w + 2) * FUS_CELLS];
+                                }
+                                continue;
+                        }
+                        PROF_LAP(1);
+                        // ---- set pass: the rows of all slots form one work list, dealt out round by round
+                        for (uint32_t v0 = 0; v0 < total; v0 += FUS_WG) {
+                                const uint32_t v = v0 + tid;
+                                if (v < total) {
+                                        uint32_t s = 0, r = v;
+                                        for (uint32_t c = sh.seg_cnt[s]; r >= c; c = sh.seg_cnt[s]) {
+                                                r -= c;
+                                                ++s;
+                                        }
+                                        const DevTerm t = sh.term[s];
+                                        const uint32_t b = sh.seg_lo[s] + r;
+                                        const uint32_t *bl = blk_last + t.first_block;
+                                        const uint32_t prev = b ? bl[b - 1] : 0;
+                                        const uint32_t last = bl[b];
+                                        const uint32_t off = blk_off[t.first_block + b];
+                                        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
+                                        fused_row<CODEC>(index, blk_exc, t, b, off, n, prev, last, w0, sh.acc, s * fbits, cap);
+                                }
+                        }
+                        // the next window's far cell-index entry travels while the set pass runs
+                        if (indexed) {
+                                e_lo = e_hi;
+                                e_hi = pf;
+                                pf = win[myt.win_off + (w + 3) * FUS_CELLS];
+                        }
+                        PROF_LAP(2);
+                        __syncthreads();
+                        PROF_LAP(3);
+                        // ---- sweep: predicate, score, threshold; re-zero.  A full candidate buffer is pruned and the sweep resumed
+                        //      (unprocessed words are simply still non-zero).
+                        // the first four required groups' masks live in registers (a missing group tests true on any non-zero word)
+                        const uint32_t gm0 = uni(fq.gmask[0]), gm1 = nreq > 1 ? uni(fq.gmask[1]) : 0xffffffffu, gm2 = nreq > 2 ? uni(fq.gmask[2]) : 0xffffffffu,
+                                       gm3 = nreq > 3 ? uni(fq.gmask[3]) : 0xffffffffu;
+                        for (;;) {
+                                const bool full = uni(sh.tk_full) != 0;
+                                const double thr_s = sh.thr_s;
+                                const uint32_t thr_d = sh.thr_d;
+                                for (uint32_t j = 0; j < FUS_W / FUS_WG; ++j) {
+                                        const uint32_t i = j * FUS_WG + tid;
+                                        const uint32_t x = sh.acc[i];
+                                        if (!x)
+                                                continue;
+                                        bool m = (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
+                                        for (uint32_t g = 4; g < nreq; ++g)
+                                                m &= (x & fq.gmask[g]) != 0;
+                                        const uint32_t doc = w0 + i;
+                                        if (m && masked) // masked_documents_registry::test (docidupdates.h:90-119)
+                                                m = !((masked[doc >> 5] >> (doc & 31u)) & 1u);
+                                        if (m) {
+                                                double sc = sh.tab[0][x & 0xffu];
+                                                if (nslots * fbits > 8)
+                                                        sc += sh.tab[1][(x >> 8) & 0xffu];
+                                                if (nslots * fbits > 16)
+                                                        sc += sh.tab[2][(x >> 16) & 0xffu];
+                                                if (nslots * fbits > 24)
+                                                        sc += sh.tab[3][x >> 24];
+                                                if (sc != sc) { // a saturated field: rescore from the postings, scorer by scorer
+                                                        sc = 0.0;
+                                                        const uint32_t fmask = (1u << fbits) - 1u;
+                                                        for (uint32_t si = 0; si < q.nscore; ++si) {
+                                                                const uint32_t term = sterms[q.score_base + si];
+                                                                uint32_t s = 0;
+                                                                while (s + 1 < nslots && fq.term[s] != term)
+                                                                        ++s;
+                                                                const uint32_t code = (x >> (s * fbits)) & fmask;
+                                                                if (!code)
+                                                                        continue;
+                                                                const uint32_t f = code > cap ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[s], doc) : code - 1u;
+                                                                sc += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                                        }
+                                                }
+                                                if (!full || better(sc, doc, thr_s, thr_d)) {
+                                                        const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
+                                                        if (slot >= FUS_CAP) {
+                                                                sh.overflow = 1; // the word stays: the resumed sweep takes it
+                                                                break;
+                                                        }
+                                                        sh.tk_s[slot] = sc;
+                                                        sh.tk_d[slot] = doc;
+                                                }
+                                                ++my_matches;
+                                        }
+                                        sh.acc[i] = 0;
+                                }
+                                __syncthreads();
+                                const uint32_t ov = uni(sh.overflow);
+                                const uint32_t n = min(uni(sh.tk_n), FUS_CAP);
+                                __syncthreads();
+                                if (ov || n > (FUS_CAP + k) / 2)
+                                        fused_prune(sh, n, k);
+                                if (!ov)
+                                        break;
+                        }
+                        PROF_LAP(4);
+                        ++w;
+                }
+                // ---- the task's result: its best k (ranked) and its match count
+                __syncthreads();
+                fused_prune(sh, min(uni(sh.tk_n), FUS_CAP), k);
+                atomicAdd(&sh.matches, my_matches); // (every lane: no single-lane branch)
+                __syncthreads();
+                const uint32_t n = uni(sh.tk_n);
+                for (uint32_t i = tid; i < n; i += FUS_WG) {
+                        part_docs[(uint64_t)tix * k + i] = sh.tk_d[i];
+                        part_scores[(uint64_t)tix * k + i] = sh.tk_s[i];
+                }
+                if (wave == 0) {
+                        part_counts[tix] = n;
+                        counts[tix] = uni(sh.matches);
+                }
+                __syncthreads();
+                PROF_LAP(5);
+        }
+        PROF_FLUSH();
+}

@@ -337,6 +337,19 @@ __global__ __launch_bounds__(AND_WG) void k_topk_merge(const DevQuery *__restric
         }
 }
 
+// per-query match counts on the device (the multi-GPU result gather reads them without a host bounce): one lane per plan slot
+__global__ void k_query_counts(const DevQuery *__restrict__ plan, const uint32_t *__restrict__ counts_by_task, const uint32_t nq,
+                               uint64_t *__restrict__ qcounts) {
+        const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+        if (s >= nq)
+                return;
+        const DevQuery q = plan[s];
+        uint64_t c = 0;
+        for (uint32_t t = 0; t < q.ntasks; ++t)
+                c += counts_by_task[q.first_task + t];
+        qcounts[q.qid] = c;
+}
+
 // FNV-1a(64) of each query's docID set (little-endian bytes), one lane per query — verification helper
 __global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks_by_query,
                                const uint32_t *__restrict__ counts_by_query, const uint32_t nq, const uint32_t *__restrict__ out,

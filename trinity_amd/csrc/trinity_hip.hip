@@ -45,7 +45,7 @@ static int fail(int code, const char *fmt, ...) {
         do {                                                                                                \
                 hipError_t e_ = (expr);                                                                     \
                 if (e_ != hipSuccess)                                                                       \
-                        return fail(TRI_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+                        return fail(e_ == hipErrorOutOfMemory ? TRI_ERR_NOMEM : TRI_ERR_DEVICE, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
         } while (0)
 
 extern "C" const char *tri_last_error(void) { return g_err; }
@@ -54,12 +54,22 @@ extern "C" int tri_abi_version(void) { return TRI_ABI_VERSION; }
 // device-visible structures and kernels
 #include "dev_structs.hpp"
 
+// planner / launch options of a device handle (tri_dev_set_option); the defaults are what bench.py measures
+struct tri_options {
+        uint64_t dense_min_postings = 512 * 1024; // TASK_DENSE needs at least this many postings over the query's lists (0: every multi-term query)
+        uint64_t dense_task_cost = 192 * 1024;    // postings per bitmap-window task
+        uint64_t fused = 1;                       // AccumulatedScore top-K of dense queries in one pass (k_fused); 0: k_and_dense + k_score
+        uint64_t fused_task_cost = 1024 * 1024;   // postings per fused task
+        uint64_t fused_freq_cap = 0;              // 0: the field width decides; else a smaller saturation point (exercises the rescoring path)
+        uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
+};
+
 struct tri_dev {
         int device;
         hipStream_t stream, stream2; // stream2: the candidate-tile kernel when the two matching kernels run side by side
-        hipEvent_t ev0, ev1, ev_a, ev_b; // ev_a / ev_b: after k_and_dense / after k_and
         hipEvent_t ev_fork, ev_join;
         int cus;
+        tri_options opt;
 };
 
 struct tri_index {
@@ -75,6 +85,10 @@ struct tri_index {
         // (k_and_dense, k_and) read this stream instead.  Scoring and phrases keep reading the chunk itself.
         uint8_t *d_dstream = nullptr;
         uint32_t *d_blk_doff = nullptr;
+        // LUCENE: per directory row (a quarter of a 128-document block) where ITS exceptions sit in the two ints() groups' exception
+        // lists: e0_deltas | cnt_deltas << 8 | e0_freqs << 16 | cnt_freqs << 24 — a lane patches its quarter without scanning the
+        // exceptions of the other three (k_fused.hpp PfQuarter)
+        uint32_t *d_blk_exc = nullptr;
         uint32_t *d_masked = nullptr; // bitmap over docIDs of the masked documents (nullptr: none); max_doc / 32 + 2 words
         uint32_t max_doc = 0;
         uint32_t nwin = 0; // cells per win[] row
@@ -93,6 +107,7 @@ struct tri_index {
                 hipFree(d_hdir);
                 hipFree(d_dstream);
                 hipFree(d_blk_doff);
+                hipFree(d_blk_exc);
                 hipFree(d_masked);
                 hipFree(d_blk_last);
                 hipFree(d_blk_off);
@@ -112,13 +127,21 @@ struct tri_batch {
         DevQuery *d_plan = nullptr;
         std::vector<DevTask> tasks; // scheduling order (cost descending)
         DevTask *d_tasks = nullptr;
-        uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones
-        uint32_t n_dense = 0, n_cand = 0;
+        uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones, then the TASK_FUSED ones
+        uint32_t n_dense = 0, n_cand = 0, n_fused = 0;
+        std::vector<DevFused> fused; // slot maps of the TASK_FUSED queries (DevQuery::fused_idx)
+        DevFused *d_fused = nullptr;
+        uint64_t term_bytes_fused = 0;
+        // HIP events on the engine stream: start, after k_and_dense, after k_and, after k_fused, end (owned by the batch: two batches
+        // in flight on one device keep their own timings)
+        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev1 = nullptr;
+        bool ran = false;
         uint32_t *d_qterms = nullptr;
         uint32_t *d_out = nullptr;
         uint32_t *d_counts = nullptr; // per task, indexed first_task + i in query order
         uint32_t *d_ticket = nullptr;
         uint64_t *d_hashes = nullptr;
+        uint64_t *d_qcounts = nullptr; // per caller query: matches of the last run (device copy for the result gather)
         // AccumulatedScoreScheme
         std::vector<uint32_t> sterms;
         std::vector<double> sweights;
@@ -151,6 +174,10 @@ struct tri_batch {
         ~tri_batch() { // also runs when tri_batch_create fails half-way: nothing allocated so far is leaked
                 if (ix)
                         hipSetDevice(ix->dev->device);
+                for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev1})
+                        if (e)
+                                hipEventDestroy(e);
+                hipFree(d_fused);
                 hipFree(d_plan);
                 hipFree(d_tasks);
                 hipFree(d_sched);
@@ -159,6 +186,7 @@ struct tri_batch {
                 hipFree(d_counts);
                 hipFree(d_ticket);
                 hipFree(d_hashes);
+                hipFree(d_qcounts);
                 hipFree(d_sterms);
                 hipFree(d_sweights);
                 hipFree(d_part_docs);
@@ -184,6 +212,7 @@ struct tri_batch {
 #include "k_decode.hpp"
 #include "k_match.hpp"
 #include "k_score.hpp"
+#include "k_fused.hpp"
 #include "k_phrase.hpp"
 #include "k_rich.hpp"
 
@@ -208,13 +237,9 @@ extern "C" int tri_dev_open(int device, tri_dev **out) {
         auto d = std::make_unique<tri_dev>();
         d->device = device;
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreate(&d->ev0));
-        HIP_TRY(hipEventCreate(&d->ev1));
         HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
-        HIP_TRY(hipEventCreate(&d->ev_a));
-        HIP_TRY(hipEventCreate(&d->ev_b));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
         d->cus = prop.multiProcessorCount;
@@ -226,15 +251,49 @@ extern "C" void tri_dev_close(tri_dev *d) {
         if (!d)
                 return;
         hipSetDevice(d->device);
-        hipEventDestroy(d->ev0);
-        hipEventDestroy(d->ev1);
         hipEventDestroy(d->ev_fork);
         hipEventDestroy(d->ev_join);
         hipStreamDestroy(d->stream2);
-        hipEventDestroy(d->ev_a);
-        hipEventDestroy(d->ev_b);
         hipStreamDestroy(d->stream);
         delete d;
+}
+
+namespace {
+        uint64_t *option_slot(tri_options &o, const char *name) {
+                static const struct {
+                        const char *name;
+                        uint64_t tri_options::*field;
+                } table[] = {{"dense_min_postings", &tri_options::dense_min_postings}, {"dense_task_cost", &tri_options::dense_task_cost},
+                             {"fused", &tri_options::fused},
+                             {"fused_task_cost", &tri_options::fused_task_cost},
+                             {"fused_freq_cap", &tri_options::fused_freq_cap},
+                             {"overlap_dense_wgs", &tri_options::overlap_dense_wgs},
+                             {"overlap_cand_wgs", &tri_options::overlap_cand_wgs}};
+                for (const auto &e : table)
+                        if (!strcmp(e.name, name))
+                                return &(o.*(e.field));
+                return nullptr;
+        }
+} // namespace
+
+extern "C" int tri_dev_set_option(tri_dev *d, const char *name, uint64_t value) {
+        if (!d || !name)
+                return fail(TRI_ERR_INVALID, "tri_dev_set_option: null argument");
+        uint64_t *slot = option_slot(d->opt, name);
+        if (!slot)
+                return fail(TRI_ERR_INVALID, "tri_dev_set_option: unknown option '%s'", name);
+        *slot = value;
+        return TRI_OK;
+}
+
+extern "C" int tri_dev_get_option(tri_dev *d, const char *name, uint64_t *value) {
+        if (!d || !name || !value)
+                return fail(TRI_ERR_INVALID, "tri_dev_get_option: null argument");
+        const uint64_t *slot = option_slot(d->opt, name);
+        if (!slot)
+                return fail(TRI_ERR_INVALID, "tri_dev_get_option: unknown option '%s'", name);
+        *value = *slot;
+        return TRI_OK;
 }
 
 extern "C" int tri_dev_sync(tri_dev *d) {
@@ -276,13 +335,15 @@ namespace {
                         return 0;
                 const uint32_t L = p[0];
                 if (!L) {
+                        if (p + 1 >= end || p + 1 + h_vb_len(p[1]) > end)
+                                return 0;
                         uint32_t x;
                         const size_t n = h_vb_get(p + 1, x);
                         for (int i = 0; i < 128; ++i)
                                 v[i] = x;
                         return 1 + n;
                 }
-                if (p + 1 + 4 * (size_t)L > end + 16)
+                if (p + 1 + 4 * (size_t)L > end)
                         return 0;
                 std::vector<uint32_t> w(L + 2, 0);
                 memcpy(w.data(), p + 1, (size_t)L * 4);
@@ -316,7 +377,34 @@ namespace {
         inline size_t h_ints_skip(const uint8_t *p, const uint8_t *end) {
                 if (p >= end)
                         return 0;
-                return p[0] ? 1 + 4 * (size_t)p[0] : 1 + h_vb_len(p[1]);
+                if (!p[0] && p + 1 >= end)
+                        return 0;
+                const size_t n = p[0] ? 1 + 4 * (size_t)p[0] : 1 + h_vb_len(p[1]);
+                return p + n <= end ? n : 0;
+        }
+        // Per quarter (32 values) of a VALIDATED ints() group: where its exceptions start in the group's list and how many it has,
+        // packed e0 | cnt << 8.  (The positions are ascending, so a quarter's exceptions are one run of the list.)
+        inline bool h_ints_exc(const uint8_t *p, uint32_t out[4]) {
+                out[0] = out[1] = out[2] = out[3] = 0;
+                const uint32_t L = p[0];
+                if (!L)
+                        return true;
+                uint32_t w0;
+                memcpy(&w0, p + 1, 4);
+                const uint32_t b = w0 & 0xff, nexc = (w0 >> 8) & 0xff;
+                const uint8_t *epos = p + 5 + 16 * (size_t)b;
+                uint32_t cnt[4] = {0, 0, 0, 0}, e0[4] = {0, 0, 0, 0};
+                for (uint32_t e = 0; e < nexc; ++e) {
+                        const uint32_t q = epos[e] >> 5;
+                        if (q > 3 || (e && epos[e] <= epos[e - 1]))
+                                return false;
+                        if (!cnt[q])
+                                e0[q] = e;
+                        ++cnt[q];
+                }
+                for (int q = 0; q < 4; ++q)
+                        out[q] = e0[q] | cnt[q] << 8;
+                return true;
         }
 
         template <class T>
@@ -346,6 +434,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         ix->hitbytes.assign(nterms, 0);
         std::vector<uint32_t> blk_last, blk_off;
         std::vector<uint32_t> blk_hits, hdir; // LUCENE + hits.data only
+        std::vector<uint32_t> blk_exc;        // LUCENE only
         std::vector<uint8_t> dstream;         // GOOGLE only
         std::vector<uint32_t> blk_doff;
         if (codec == TRI_CODEC_GOOGLE) {
@@ -398,11 +487,13 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                                 if (!used)
                                         return fail(TRI_ERR_FORMAT, "term %zu: bad ints() group", ti);
                                 p += used;
-                                const size_t usedf = want_hits ? h_ints_decode(p, end, fvals) : h_ints_skip(p, end);
-                                if (!usedf)
-                                        return fail(TRI_ERR_FORMAT, "term %zu: bad freqs group", ti);
+                                uint32_t xd[4], xf[4];
+                                const size_t usedf = h_ints_decode(p, end, fvals);
+                                if (!usedf || !h_ints_exc(index + goff, xd) || !h_ints_exc(p, xf))
+                                        return fail(TRI_ERR_FORMAT, "term %zu: bad freqs group / exception list", ti);
                                 p += usedf;
                                 for (uint32_t q4 = 0; q4 < 4; ++q4) {
+                                        blk_exc.push_back(xd[q4] | xf[q4] << 16);
                                         if (want_hits)
                                                 blk_hits.push_back((uint32_t)hits_seen);
                                         for (uint32_t i = 0; i < 32; ++i) {
@@ -423,11 +514,12 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                         while (left) {
                                 const uint32_t n = std::min(left, 32u);
                                 blk_off.push_back((uint32_t)(p - index));
+                                blk_exc.push_back(0);
                                 if (want_hits)
                                         blk_hits.push_back((uint32_t)hits_seen);
                                 for (uint32_t i = 0; i < n; ++i) {
                                         uint32_t d, f;
-                                        if (p + 10 > end + 16)
+                                        if (p >= end || p + h_vb_len(*p) >= end || p + h_vb_len(*p) + h_vb_len(p[h_vb_len(*p)]) > end)
                                                 return fail(TRI_ERR_FORMAT, "term %zu: truncated tail", ti);
                                         p += h_vb_get(p, d);
                                         p += h_vb_get(p, f);
@@ -495,26 +587,37 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                                 return fail(TRI_ERR_FORMAT, "term %zu: truncated block header", ti);
                         const uint8_t *h = p;
                         uint32_t delta, blockLength;
+                        // (every varint is bounded before it is read: a malformed or truncated chunk must end in TRI_ERR_FORMAT, not in a read past the buffer)
+                        if (p + h_vb_len(*p) >= end)
+                                return fail(TRI_ERR_FORMAT, "term %zu: truncated block header", ti);
                         p += h_vb_get(p, delta);
+                        if (p + h_vb_len(*p) >= end)
+                                return fail(TRI_ERR_FORMAT, "term %zu: truncated block header", ti);
                         p += h_vb_get(p, blockLength);
                         const uint32_t n = *p++;
                         if (n < 1 || n > 32 || !delta || (uint64_t)(end - p) < blockLength)
                                 return fail(TRI_ERR_FORMAT, "term %zu: bad block header (n=%u, delta=%u, len=%u)", ti, n, delta, blockLength);
                         lastDoc += delta;
-                        const uint8_t *s = p;
-                        for (uint32_t i = 0; i + 1 < n; ++i)
+                        const uint8_t *s = p, *const bend = p + blockLength;
+                        for (uint32_t i = 0; i + 1 < n; ++i) {
+                                if (s >= bend)
+                                        return fail(TRI_ERR_FORMAT, "term %zu: deltas overrun the block", ti);
                                 s += h_vb_len(*s);
-                        if ((uint64_t)(s - p) > blockLength)
+                        }
+                        if (s > bend)
                                 return fail(TRI_ERR_FORMAT, "term %zu: deltas overrun the block", ti);
                         if (dstream.size() + 256 > 0xffffffffull)
                                 return fail(TRI_ERR_UNSUPPORTED, "delta stream exceeds 4 GiB");
                         dstream.push_back((uint8_t)n);
                         blk_doff.push_back((uint32_t)dstream.size());
                         dstream.insert(dstream.end(), p, s);
-                        for (uint32_t i = 0; i < n; ++i)
+                        for (uint32_t i = 0; i < n; ++i) {
+                                if (s >= bend)
+                                        return fail(TRI_ERR_FORMAT, "term %zu: deltas+freqs overrun the block", ti);
                                 s += h_vb_len(*s);
+                        }
                         blk_hits.push_back((uint32_t)(s - index)); // GOOGLE: byte offset of the block's first hit (k_phrase / k_rich start there)
-                        if ((uint64_t)(s - p) > blockLength)
+                        if (s > bend)
                                 return fail(TRI_ERR_FORMAT, "term %zu: deltas+freqs overrun the block", ti);
                         db += (uint64_t)(s - h);
                         hb += blockLength - (uint64_t)(s - p);
@@ -529,7 +632,10 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 }
                 if (docs != t.documents)
                         return fail(TRI_ERR_FORMAT, "term %zu: %u documents in blocks, %u declared", ti, docs, t.documents);
-                dt.flags = full_blocks ? TERM_FULL_BLOCKS : 0;
+                if (!full_blocks) // the reference encoder only ever leaves the LAST block short (google_codec.cpp:76-88); the kernels' tile and
+                                  // output layouts (32 slots per non-final block) rely on it, so a foreign chunk that does not is refused here
+                        return fail(TRI_ERR_UNSUPPORTED, "term %zu: a block other than the last holds fewer than 32 documents", ti);
+                dt.flags = TERM_FULL_BLOCKS;
                 if ((uint64_t)docs * 28 < lastDoc)
                         dt.flags |= TERM_SPARSE;
                 ix->docbytes[ti] = db;
@@ -587,6 +693,8 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                         return rc;
         }
         if (codec == TRI_CODEC_GOOGLE && (rc = dev_upload(&ix->d_blk_hits, blk_hits)))
+                return rc;
+        if (codec == TRI_CODEC_LUCENE && (rc = dev_upload(&ix->d_blk_exc, blk_exc)))
                 return rc;
         ix->h_blk_last = std::move(blk_last);
         ix->info.index_bytes = len;
@@ -816,6 +924,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 DevQuery q;
                 uint64_t cost;
                 uint32_t nlead;
+                bool fusable; // AccumulatedScore + top-K, no phrase, <= FUS_MAX_SLOTS distinct terms: may run as TASK_FUSED
+                DevFused fz;
         };
         std::vector<Tmp> tmp;
         std::vector<PNode> nodes;
@@ -1038,6 +1148,59 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         }
                         t.q.nscore = (uint32_t)sc.size();
                 }
+                // ---- slot map for the one-pass scored path (k_fused.hpp): the query's distinct terms, CNF terms first
+                t.fusable = false;
+                t.fz = DevFused{};
+                if (scored && topk && qphrases.empty() && dev->opt.fused) {
+                        std::vector<uint32_t> slots;
+                        auto slot_of = [&](uint32_t term) {
+                                for (size_t i = 0; i < slots.size(); ++i)
+                                        if (slots[i] == term)
+                                                return (uint32_t)i;
+                                slots.push_back(term);
+                                return (uint32_t)slots.size() - 1;
+                        };
+                        for (uint32_t tt : uniq)
+                                slot_of(tt & QT_TERM);
+                        for (uint32_t x : leaves)
+                                slot_of(x);
+                        if (slots.size() <= FUS_MAX_SLOTS) {
+                                DevFused &z = t.fz;
+                                z.nslots = (uint32_t)slots.size();
+                                z.fbits = z.nslots <= 4 ? 8u : 4u;
+                                z.cap = (1u << z.fbits) - 2u;
+                                if (dev->opt.fused_freq_cap && dev->opt.fused_freq_cap < z.cap)
+                                        z.cap = (uint32_t)dev->opt.fused_freq_cap;
+                                const uint32_t fm = (1u << z.fbits) - 1u;
+                                for (size_t i = 0; i < slots.size(); ++i)
+                                        z.term[i] = slots[i];
+                                int g = -1;
+                                bool in_not = false;
+                                uint32_t nreq_groups = 0;
+                                for (uint32_t tt : uniq)
+                                        nreq_groups += (tt & QT_GROUP) && !(tt & QT_NOT);
+                                for (uint32_t tt : uniq) {
+                                        if (nreq_groups > FUS_MAX_SLOTS)
+                                                break; // (a CNF that repeats its terms over more groups than the slot map holds)
+                                        if (tt & QT_GROUP) {
+                                                in_not = tt & QT_NOT;
+                                                if (!in_not)
+                                                        ++g;
+                                        }
+                                        const uint32_t sidx = slot_of(tt & QT_TERM);
+                                        if (in_not)
+                                                z.nmask |= fm << (sidx * z.fbits);
+                                        else {
+                                                z.gmask[g] |= fm << (sidx * z.fbits);
+                                                z.gslots[g] |= 1u << sidx;
+                                        }
+                                }
+                                z.nreq = (uint32_t)(g + 1);
+                                t.fusable = z.nreq >= 1 && nreq_groups <= FUS_MAX_SLOTS;
+                        }
+                }
+                t.q.fused_idx = 0;
+                t.q.pad0 = 0;
                 t.q.nterms = (uint32_t)uniq.size();
                 t.q.term_base = (uint32_t)b->qterms.size();
                 t.q.out_cap = 0;
@@ -1068,13 +1231,10 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->plan.reserve(tmp.size());
         // cut every query into tasks of roughly TASK_COST postings, then schedule heaviest first
         constexpr uint64_t TASK_COST = 96 * 1024;
-        // tunables (environment overrides exist for tests and perf probes)
-        uint64_t DENSE_MIN_POSTINGS = 512 * 1024;
-        if (const char *e = getenv("TRINITY_DENSE_MIN"))
-                DENSE_MIN_POSTINGS = strtoull(e, nullptr, 10);
-        uint64_t DENSE_TASK_COST = 2 * TASK_COST; // bitmap-window tasks stage their terms once: two windows of a head pair per task
-        if (const char *e = getenv("TRINITY_DENSE_TASK_COST"))
-                DENSE_TASK_COST = strtoull(e, nullptr, 10);
+        // planner thresholds: tri_dev_set_option (defaults: tri_options)
+        const uint64_t DENSE_MIN_POSTINGS = dev->opt.dense_min_postings;
+        const uint64_t DENSE_TASK_COST = std::max<uint64_t>(1, dev->opt.dense_task_cost); // bitmap-window tasks stage their terms once: two windows of a head pair per task
+        const uint64_t FUSED_TASK_COST = std::max<uint64_t>(1, dev->opt.fused_task_cost);
         std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
         for (auto &t : tmp) {
                 const uint32_t slot = (uint32_t)b->plan.size();
@@ -1108,6 +1268,32 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         last_doc = std::min(last_doc, glast);
                 dense &= sumdf >= DENSE_MIN_POSTINGS;
                 dense |= nlead > 1;
+                const bool fuse = dense && t.fusable;
+                if (fuse) {
+                        // every list of the slot map is read once (the optional terms too)
+                        uint64_t slotdf = 0;
+                        for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
+                                slotdf += ix->terms[t.fz.term[sidx]].documents;
+                                b->term_bytes_fused += ix->docbytes[t.fz.term[sidx]];
+                        }
+                        ++b->info.fused_queries;
+                        t.q.fused_idx = (uint32_t)b->fused.size();
+                        b->fused.push_back(t.fz);
+                        t.q.out_off = off;
+                        t.q.out_cap = 0; // the docID set is never materialised
+                        t.q.first_task = (uint32_t)b->tasks.size();
+                        const uint32_t nwin = last_doc / FUS_W + 1;
+                        const uint64_t per_win = std::max<uint64_t>(1, slotdf / (ix->info.docs_cnt / FUS_W + 1));
+                        const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
+                        for (uint32_t wb = 0; wb < nwin; wb += win_per_task) {
+                                const uint32_t we = std::min(nwin, wb + win_per_task);
+                                order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
+                                b->tasks.push_back({slot, wb, we, TASK_FUSED, off});
+                        }
+                        t.q.ntasks = (uint32_t)b->tasks.size() - t.q.first_task;
+                        b->plan.push_back(t.q);
+                        continue;
+                }
                 if (dense) {
                         std::vector<uint32_t> seen;
                         for (uint32_t k = 0; k < t.q.nterms; ++k) {
@@ -1173,14 +1359,22 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if (b->tasks[o.second].kind == TASK_CAND)
                         sched.push_back(o.second);
         b->n_cand = (uint32_t)sched.size() - b->n_dense;
+        for (const auto &o : order)
+                if (b->tasks[o.second].kind == TASK_FUSED)
+                        sched.push_back(o.second);
+        b->n_fused = (uint32_t)sched.size() - b->n_dense - b->n_cand;
         b->out_capacity = off;
         int rc;
         if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)) || (rc = dev_upload(&b->d_tasks, b->tasks)) ||
-            (rc = dev_upload(&b->d_sched, sched)))
+            (rc = dev_upload(&b->d_sched, sched)) || (rc = dev_upload(&b->d_fused, b->fused)))
                 return rc;
+        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_b, &b->ev_c, &b->ev1})
+                HIP_TRY(hipEventCreate(e));
         HIP_TRY(hipMalloc((void **)&b->d_out, (off + 64) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_counts, (b->tasks.size() + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_ticket, 256));
+        HIP_TRY(hipMalloc((void **)&b->d_qcounts, (nq + 1) * 8));
+        HIP_TRY(hipMemset(b->d_qcounts, 0, (nq + 1) * 8)); // queries that can never match keep count 0
         if (!b->phrases.empty()) {
                 if ((rc = dev_upload(&b->d_phrases, b->phrases)) || (rc = dev_upload(&b->d_pterms, b->pterms)) || (rc = dev_upload(&b->d_ptasks, b->ptasks)))
                         return rc;
@@ -1214,7 +1408,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         }
         b->info.nqueries = nq;
         b->info.out_capacity = off;
-        b->info.launches = scored ? 3 : 1;
+        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (!b->ptasks.empty()) + (rich ? 2 : 0) +
+                           ((scored && b->n_dense + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
         *out = b.release();
         return TRI_OK;
 }
@@ -1239,7 +1434,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
         }
         memset(g_trace_host, 0, 64 * 16);
 #endif
-        HIP_TRY(hipEventRecord(dev->ev0, dev->stream));
+        b->ran = true;
+        HIP_TRY(hipEventRecord(b->ev0, dev->stream));
         if (n) {
                 HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 256, dev->stream));
                 // two persistent kernels back to back on the engine stream: bitmap windows (512 threads), then candidate tiles.
@@ -1248,13 +1444,10 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 const uint32_t *match_off = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_blk_doff : b->ix->d_blk_off;
                 uint32_t dense_wgs = 2048 / DENSE_WG, cand_wgs = 4; // workgroups per CU
                 bool overlap = false;
-                if (const char *e = getenv("TRINITY_OVERLAP")) { // "d,c": run both kernels side by side with d / c workgroups per CU
-                        unsigned d = 0, c = 0;
-                        if (sscanf(e, "%u,%u", &d, &c) == 2 && d && c && b->n_dense && b->n_cand) {
-                                overlap = true;
-                                dense_wgs = d;
-                                cand_wgs = c;
-                        }
+                if (dev->opt.overlap_dense_wgs && dev->opt.overlap_cand_wgs && b->n_dense && b->n_cand) { // both kernels side by side
+                        overlap = true;
+                        dense_wgs = (uint32_t)dev->opt.overlap_dense_wgs;
+                        cand_wgs = (uint32_t)dev->opt.overlap_cand_wgs;
                 }
                 hipStream_t cand_stream = dev->stream;
                 if (overlap) {
@@ -1268,7 +1461,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                            b->d_ticket + 16, b->d_out, b->d_counts, b->ix->d_masked);
                         HIP_TRY(hipGetLastError());
                 }
-                HIP_TRY(hipEventRecord(dev->ev_a, dev->stream));
+                HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
@@ -1278,7 +1471,16 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipEventRecord(dev->ev_join, dev->stream2));
                         HIP_TRY(hipStreamWaitEvent(dev->stream, dev->ev_join, 0));
                 }
-                HIP_TRY(hipEventRecord(dev->ev_b, dev->stream));
+                HIP_TRY(hipEventRecord(b->ev_b, dev->stream));
+                if (b->n_fused) {
+                        // AccumulatedScore top-K of the dense queries: decode -> match -> score -> select in one pass, two workgroups per CU
+                        TRI_LAUNCH(k_fused, b->ix->codec, dim3(std::min<uint32_t>(b->n_fused, (uint32_t)dev->cus * 2)), dim3(FUS_WG), dev->stream, b->ix->d_index,
+                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_exc, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks,
+                                           b->d_sched + b->n_dense + b->n_cand, b->d_sterms, b->d_sweights, b->n_fused, b->d_ticket + 56, b->d_counts, b->topk,
+                                           b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked, b->similarity);
+                        HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
                 if (!b->ptasks.empty()) {
                         // positional constraints: filter + compact the match segments of the queries that hold phrases
                         const uint32_t np = (uint32_t)b->ptasks.size();
@@ -1307,8 +1509,10 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
-                        TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 2)), dim3(AND_WG), dev->stream, b->ix->d_index,
-                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, n,
+                        const uint32_t nlegacy = b->n_dense + b->n_cand; // the TASK_FUSED tasks have scored themselves
+                        if (nlegacy)
+                        TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(nlegacy, (uint32_t)dev->cus * 2)), dim3(AND_WG), dev->stream, b->ix->d_index,
+                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, nlegacy,
                                            b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,
                                            b->d_all_scores, b->d_pscore, b->similarity);
                         HIP_TRY(hipGetLastError());
@@ -1319,7 +1523,17 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
         }
-        HIP_TRY(hipEventRecord(dev->ev1, dev->stream));
+        else {
+                HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
+                HIP_TRY(hipEventRecord(b->ev_b, dev->stream));
+                HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
+        }
+        if (!b->plan.empty()) {
+                const uint32_t nqs = (uint32_t)b->plan.size();
+                hipLaunchKernelGGL(k_query_counts, dim3((nqs + 255) / 256), dim3(256), 0, dev->stream, b->d_plan, b->d_counts, nqs, b->d_qcounts);
+                HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(b->ev1, dev->stream));
         return TRI_OK;
 }
 
@@ -1328,12 +1542,14 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 return fail(TRI_ERR_INVALID, "null batch");
         tri_dev *dev = b->ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
+        if (!b->ran)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync: the batch has not been run");
 #if (defined(TRI_TRACE) && !defined(TRI_TRACE_NOPOLL)) || defined(TRI_POLL)
         {
                 const char *w = getenv("TRINITY_WATCHDOG_S");
                 const double limit = w ? atof(w) : 10.0;
                 double waited = 0;
-                while (hipEventQuery(dev->ev1) == hipErrorNotReady) {
+                while (hipEventQuery(b->ev1) == hipErrorNotReady) {
                         struct timespec ts = {0, 50 * 1000 * 1000};
                         nanosleep(&ts, nullptr);
                         waited += 0.05;
@@ -1353,21 +1569,25 @@ extern "C" int tri_batch_sync(tri_batch *b) {
 #endif
         HIP_TRY(hipStreamSynchronize(dev->stream));
         float ms = 0;
-        if (hipEventElapsedTime(&ms, dev->ev0, dev->ev1) == hipSuccess)
+        if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
                 b->info.last_run_ms = ms;
-        b->info.dense_ms = b->info.cand_ms = 0;
+        b->info.dense_ms = b->info.cand_ms = b->info.fused_ms = b->info.rest_ms = 0;
         if (!b->tasks.empty()) {
-                if (hipEventElapsedTime(&ms, dev->ev0, dev->ev_a) == hipSuccess)
+                if (hipEventElapsedTime(&ms, b->ev0, b->ev_a) == hipSuccess)
                         b->info.dense_ms = ms; // includes the 256-byte ticket memset that precedes it
-                if (hipEventElapsedTime(&ms, dev->ev_a, dev->ev_b) == hipSuccess)
+                if (hipEventElapsedTime(&ms, b->ev_a, b->ev_b) == hipSuccess)
                         b->info.cand_ms = ms;
+                if (hipEventElapsedTime(&ms, b->ev_b, b->ev_c) == hipSuccess)
+                        b->info.fused_ms = ms;
+                if (hipEventElapsedTime(&ms, b->ev_c, b->ev1) == hipSuccess)
+                        b->info.rest_ms = ms;
         }
         b->h_counts.resize(b->tasks.size());
         if (!b->tasks.empty())
                 HIP_TRY(hipMemcpy(b->h_counts.data(), b->d_counts, b->tasks.size() * 4, hipMemcpyDeviceToHost));
         uint64_t m = 0;
         b->h_query_counts.assign(b->plan.size(), 0);
-        uint64_t m_dense = 0;
+        uint64_t m_dense = 0, m_fused = 0, out_fused = 0;
         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                 const DevQuery &q = b->plan[sidx];
                 for (uint32_t t = 0; t < q.ntasks; ++t)
@@ -1375,9 +1595,14 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 m += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_DENSE)
                         m_dense += b->h_query_counts[sidx];
+                if (q.ntasks && b->tasks[q.first_task].kind == TASK_FUSED) {
+                        m_fused += b->h_query_counts[sidx];
+                        out_fused += 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk);
+                }
         }
         b->info.dense_algorithmic_bytes = b->term_bytes_dense + 4 * m_dense;
-        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense) + 4 * (m - m_dense);
+        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_fused) + 4 * (m - m_dense - m_fused);
+        b->info.fused_algorithmic_bytes = b->term_bytes_fused + out_fused; // docbytes + 8 B x min(matches, K)
         b->info.matches = m;
         if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                 uint64_t outb = 0; // 8 B x min(matches, K) per query
@@ -1515,6 +1740,8 @@ extern "C" int tri_batch_docset(tri_batch *b, size_t q, uint32_t *out, size_t ca
         *n = slot == UINT32_MAX ? 0 : b->h_query_counts[slot];
         if (!*n || !out)
                 return TRI_OK;
+        if (b->plan[slot].ntasks && b->tasks[b->plan[slot].first_task].kind == TASK_FUSED)
+                return fail(TRI_ERR_INVALID, "query %zu ran through the one-pass scored kernel: an AccumulatedScore top-K batch keeps top-K lists and match counts, not docID sets (use topk == 0 or DocumentsOnly)", q);
         if (cap < *n)
                 return fail(TRI_ERR_INVALID, "docset needs %zu slots, %zu given", *n, cap);
         HIP_TRY(hipSetDevice(b->ix->dev->device));
@@ -1541,6 +1768,8 @@ extern "C" int tri_batch_docset_hashes(tri_batch *b, uint64_t *hashes) {
         tri_dev *dev = b->ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
         const uint32_t n = (uint32_t)b->plan.size();
+        if (b->n_fused)
+                return fail(TRI_ERR_INVALID, "the batch holds queries that ran through the one-pass scored kernel: their docID sets are not materialised");
         std::vector<uint64_t> h(n);
         if (n) {
                 if (!b->d_hashes)
@@ -1594,6 +1823,13 @@ extern "C" int tri_batch_scores(tri_batch *b, size_t q, double *out, size_t cap,
                 w += c;
         }
         HIP_TRY(hipStreamSynchronize(b->ix->dev->stream));
+        return TRI_OK;
+}
+
+extern "C" int tri_batch_counts_device(tri_batch *b, void **counts) {
+        if (!b || !counts)
+                return fail(TRI_ERR_INVALID, "null argument");
+        *counts = b->d_qcounts;
         return TRI_OK;
 }
 

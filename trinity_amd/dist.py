@@ -1,9 +1,11 @@
 """Multi-GPU plumbing: one process per GPU, index replicated, the query stream sharded, results gathered.
 
 Queries are independent units (reference: exec.h:57-62, index_source.h:210-211 — per-source results only need a
-merge), so there is NO data-path collective.  The only exchanges are fixed-shape result blocks at the end of a
-batch: per-query match counts (DocumentsOnly) and `[Q/G][K]` top-K docID/score blocks (AccumulatedScoreScheme),
-all-gathered with torch.distributed — backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+merge; exec_query_par, exec.h:132-176, collects one result vector per source), so there is NO data-path collective.
+The only exchange is the result gather at the end of a step: fixed-shape blocks per rank — per-query match counts
+u64[Q/G] and, for AccumulatedScoreScheme top-K batches, [Q/G][K] docIDs + scores and [Q/G] list lengths — sent with
+torch.distributed all_gather: backend "nccl" (= RCCL over xGMI) straight from the engine's device-resident result
+buffers (no host bounce), "gloo" on CPU tensors in the tests.  The same ResultGather drives both.
 """
 import numpy as np
 
@@ -19,25 +21,6 @@ def unshard_index(nq_total, rank, world):
     return np.arange(rank, nq_total, world)
 
 
-def gather_counts(dist, counts_t):
-    """all_gather of per-query match counts; returns a list of per-rank tensors (same device as counts_t)."""
-    out = [counts_t.new_zeros(counts_t.shape) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, counts_t)
-    return out
-
-
-def gather_topk(dist, docs_t, scores_t, counts_t):
-    """all_gather of the fixed-shape top-K result blocks ([Q/G][K] u32-as-int32 docIDs, f32 scores, [Q/G] counts)."""
-    w = dist.get_world_size()
-    d = [docs_t.new_zeros(docs_t.shape) for _ in range(w)]
-    s = [scores_t.new_zeros(scores_t.shape) for _ in range(w)]
-    c = [counts_t.new_zeros(counts_t.shape) for _ in range(w)]
-    dist.all_gather(d, docs_t)
-    dist.all_gather(s, scores_t)
-    dist.all_gather(c, counts_t)
-    return d, s, c
-
-
 def interleave(per_rank_arrays):
     """Undo shard_rows: per-rank arrays (equal leading length) -> global query order."""
     w = len(per_rank_arrays)
@@ -46,3 +29,46 @@ def interleave(per_rank_arrays):
     for r, a in enumerate(per_rank_arrays):
         out[r::w] = a
     return out
+
+
+class _DeviceBlock:
+    """A typed view of raw device memory for torch (zero copy) through the CUDA array interface."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def device_blocks(batch, device):
+    """The result blocks of an engine Batch as torch tensors over the engine's own device buffers (no copy): "counts" i64[nq];
+    AccumulatedScore top-K batches add "docs" i32[nq][k] (docIDs, bit pattern of the u32), "scores" f32[nq][k], "topk_counts" i32[nq]."""
+    import torch
+
+    p = batch.device_results()
+    nq, k = batch.nq, batch.topk
+    out = {"counts": torch.as_tensor(_DeviceBlock(p["counts"], (nq,), "<i8"), device=device)}
+    if "docs" in p:
+        out["docs"] = torch.as_tensor(_DeviceBlock(p["docs"], (nq, k), "<i4"), device=device)
+        out["scores"] = torch.as_tensor(_DeviceBlock(p["scores"], (nq, k), "<f4"), device=device)
+        out["topk_counts"] = torch.as_tensor(_DeviceBlock(p["topk_counts"], (nq,), "<i4"), device=device)
+    return out
+
+
+class ResultGather:
+    """The per-step result exchange: every rank contributes the same named fixed-shape blocks; step() all_gathers each into
+    preallocated per-rank receive buffers and returns {name: [tensor of rank 0, tensor of rank 1, …]}."""
+
+    def __init__(self, dist, blocks):
+        import torch
+
+        self.dist, self.blocks = dist, dict(blocks)
+        self.world = dist.get_world_size()
+        self.recv = {name: [torch.empty_like(t) for _ in range(self.world)] for name, t in self.blocks.items()}
+
+    def step(self):
+        for name, t in self.blocks.items():
+            self.dist.all_gather(self.recv[name], t)
+        return self.recv
+
+    def global_order(self, name):
+        """The gathered block re-interleaved to global query order (numpy; test / verification helper)."""
+        return interleave([t.cpu().numpy() for t in self.recv[name]])

@@ -57,15 +57,19 @@ class TriBatchInfo(C.Structure):
         ("cand_algorithmic_bytes", C.c_uint64),
         ("dense_queries", C.c_uint64),
         ("cand_queries", C.c_uint64),
+        ("fused_ms", C.c_float),
+        ("rest_ms", C.c_float),
+        ("fused_algorithmic_bytes", C.c_uint64),
+        ("fused_queries", C.c_uint64),
     ]
 
 
 # every symbol include/trinity_hip.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
-    "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream",
+    "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream", "tri_dev_set_option", "tri_dev_get_option",
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
-    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_docset_hashes",
+    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
 ]  # fmt: skip
 
 _hip = None
@@ -88,6 +92,8 @@ def hip_lib():
     L.tri_dev_sync.argtypes = [vp]
     L.tri_dev_stream.restype = vp
     L.tri_dev_stream.argtypes = [vp]
+    L.tri_dev_set_option.argtypes = [vp, C.c_char_p, C.c_uint64]
+    L.tri_dev_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
     L.tri_index_upload.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_uint32, C.POINTER(vp)]
     L.tri_index_destroy.argtypes = [vp]
     L.tri_index_get_info.argtypes = [vp, C.POINTER(TriIndexInfo)]
@@ -106,6 +112,7 @@ def hip_lib():
     L.tri_batch_scores.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_topk.argtypes = [vp, vp, vp, vp]
     L.tri_batch_topk_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.tri_batch_counts_device.argtypes = [vp, C.POINTER(vp)]
     L.tri_batch_docset_hashes.argtypes = [vp, vp]
     _hip = L
     return L
@@ -193,6 +200,15 @@ class Device:
 
     def sync(self):
         _check(hip_lib().tri_dev_sync(self.h))
+
+    def set_option(self, name, value):
+        """Planner / launch option (include/trinity_hip.h tri_dev_set_option); applies to batches created afterwards."""
+        _check(hip_lib().tri_dev_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_uint64()
+        _check(hip_lib().tri_dev_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def close(self):
         if self.h:
@@ -324,6 +340,19 @@ class Batch:
     def docset_hashes(self):
         out = np.zeros(self.nq, dtype=np.uint64)
         _check(hip_lib().tri_batch_docset_hashes(self.h, out.ctypes.data))
+        return out
+
+    def device_results(self):
+        """Raw device pointers of the result blocks the multi-GPU gather sends: {"counts": u64[nq]} and, for AccumulatedScore top-K
+        batches, {"docs": u32[nq][k], "scores": f32[nq][k], "topk_counts": u32[nq]}.  Valid after the run completed on the engine stream."""
+        L = hip_lib()
+        p = C.c_void_p()
+        _check(L.tri_batch_counts_device(self.h, C.byref(p)))
+        out = {"counts": p.value}
+        if (self.flags & FLAG_ACCUMULATED_SCORE) and self.topk:
+            d, s, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            _check(L.tri_batch_topk_device(self.h, C.byref(d), C.byref(s), C.byref(c)))
+            out.update(docs=d.value, scores=s.value, topk_counts=c.value)
         return out
 
     def topk_results(self):
