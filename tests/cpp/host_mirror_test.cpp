@@ -88,6 +88,16 @@ int main(int argc, char **argv) {
                         exec_query(src.conjunction({src.phrase({"t0", "t1"}), src.term("t2")}), &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
                         show("phrase_scored", c);
                 }
+                { // "t0 t1" t0 : the standalone t0 scores with its OWN ScorerWeight, not with the (unused) weight of the phrase member
+                        Collect c;
+                        exec_query(src.conjunction({src.phrase({"t0", "t1"}), src.term("t0")}), &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("phrase_and_member_scored", c);
+                }
+                { // "t0 t1" "t0 t2" : two phrases that start with the same term keep their own weights
+                        Collect c;
+                        exec_query(src.conjunction({src.phrase({"t0", "t1"}), src.phrase({"t0", "t2"})}), &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("two_phrases_scored", c);
+                }
                 { // t3 t5 NOT (t1 OR t2): DocsSetIterators::Filter over a conjunction, scored (the excluded side does not score)
                         Collect c;
                         auto q = src.filter(src.conjunction({src.term("t3"), src.term("t5")}), src.disjunction({src.term("t1"), src.term("t2")}));

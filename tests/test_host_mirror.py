@@ -63,6 +63,8 @@ def test_mirror_results_match_oracle(T, tmp_path):
     expect("mixed_scored", "t0 t1 (t2 OR t3 OR t4)", 2)
     expect("or_even", "t3 OR t7", 1, keep=lambda d: (d & 1) == 0)
     expect("phrase_scored", '"t0 t1" t2', 2)
+    expect("phrase_and_member_scored", '"t0 t1" t0', 2)  # ScorerWeights are per program token, not per term
+    expect("two_phrases_scored", '"t0 t1" "t0 t2"', 2)
     expect("not_scored", "t3 t5 NOT (t1 OR t2)", 2)
     expect("optional_scored", "t3 t1 <t5 OR t2>", 2)
     expect("tfidf_scored", "t0 t1 (t2 OR t3)", 2, sim=O.SIM_TFIDF)

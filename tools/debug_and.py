@@ -1,5 +1,5 @@
 """Debug driver (not a test): runs a few AND queries against a chosen engine build with the in-kernel trace
-watchdog.  usage: TRINITY_HIP_LIB=trinity_amd/libtrinity_hip_dbgA.so python tests/debug_and.py"""
+watchdog.  usage: TRINITY_HIP_LIB=trinity_amd/libtrinity_hip_dbgA.so python tools/debug_and.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -21,12 +21,17 @@
 //     appended to a candidate buffer that is pruned by rank when it fills.  The sweep re-zeroes the words.
 //   * a field that saturates (freq > cap) makes its table entry NaN; such a (rare) document is rescored exactly: the term's
 //     block is located through the directory and its freq decoded (fused_lookup_freq).
+//   * a row (<= 32 documents) that reaches beyond the window leaves a HINT — the first of its documents past the window — so
+//     the windows it merely spans neither decode it again nor count as windows its list can match in: sparse lists cost one
+//     decode per row, and a conjunction jumps to the next window every required group can reach.
 // Per task the kernel leaves min(matches, k) (docID, score) pairs and the match count; k_topk_merge folds the tasks of a query.
 constexpr int FUS_WG = 512;
 constexpr uint32_t FUS_CELLS = 15; // docID cells (of CELL_DOCS) per window: 60 KB of words, two workgroups per CU
 constexpr uint32_t FUS_W = FUS_CELLS * CELL_DOCS;
 constexpr uint32_t FUS_CAP = 512; // candidate buffer; k <= TOPK_MAX = 256
-static_assert(FUS_W % FUS_WG == 0, "the sweep deals whole rounds of words to the workgroup");
+constexpr uint32_t FUS_WPT = FUS_W / FUS_WG; // window words per thread
+constexpr uint32_t FUS_SWB = 6;              // ... swept in batches of this many (independent LDS reads in flight)
+static_assert(FUS_W % FUS_WG == 0 && FUS_WPT % FUS_SWB == 0, "the sweep deals whole batches of words to every thread");
 static_assert(TOPK_MAX * 2 <= FUS_CAP, "a pruned buffer must leave room for a round of newcomers");
 
 struct FusedShared {
@@ -37,7 +42,9 @@ struct FusedShared {
         DevTerm term[FUS_MAX_SLOTS];
         uint32_t seg_lo[FUS_MAX_SLOTS];
         uint32_t seg_cnt[FUS_MAX_SLOTS + 1];
-        uint32_t seg_np[FUS_MAX_SLOTS]; // first docID >= w0 the slot's list may still hold (0xffffffff: exhausted)
+        uint32_t seg_np[FUS_MAX_SLOTS];   // first docID >= w0 the slot's list may still hold (0xffffffff: exhausted)
+        uint32_t hint_row[FUS_MAX_SLOTS]; // the slot's row that reached beyond the last window it was decoded in ...
+        uint32_t hint_doc[FUS_MAX_SLOTS]; // ... and the first of its documents past that window
         double thr_s;
         uint32_t thr_d;
         uint32_t tk_n, tk_full, overflow, matches;
@@ -47,31 +54,46 @@ struct FusedShared {
 
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
 typedef uint64_t u64_a1 __attribute__((aligned(1)));
+typedef uint32_t u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 __device__ __forceinline__ uint32_t ldu32(const uint8_t *p) { return *(const u32_a1 *)p; } // gfx950 global loads take any alignment
 __device__ __forceinline__ uint64_t ldu64(const uint8_t *p) { return *(const u64_a1 *)p; }
 
+// bytes of an ints() group from its header word as the row record caches it (bit 31: every value equal to the low 31 bits)
+__device__ __forceinline__ uint32_t pfor_group_bytes(const uint32_t hdr) {
+        if (hdr >> 31) {
+                const uint32_t v = hdr & 0x7fffffffu;
+                return 1u + (v < (1u << 7) ? 1u : v < (1u << 14) ? 2u : v < (1u << 21) ? 3u : v < (1u << 28) ? 4u : 5u);
+        }
+        const uint32_t b = hdr & 0xffu, nexc = (hdr >> 8) & 0xffu, eb = (hdr >> 16) & 0xffu;
+        return 1u + 4u * (1u + 4u * b + (nexc + 3u) / 4u + (nexc * eb + 31u) / 32u);
+}
+
 // ---- LUCENE: one quarter (32 values) of an ints() group, read by one lane without the general stream's state machine
-// (codec_streams.hpp LValStream).  The quarter's packed words are held in registers: NW words fetched up front with wide loads (a
-// quarter of width b occupies exactly b words), so the value loop touches no memory; the low parts come out of a two-word funnel
-// (v_alignbit), a used-up word is a register shift.  The quarter's exceptions — found through the per-row exception index built
-// at upload (blk_exc) instead of a scan of the group's list — sit in a 32-bit position mask and a packed queue of high parts and
-// are patched branch-free.  Takes quarters of width <= NW whose exception high parts fit 32 bits: every block of the terms that
-// carry the postings volume (head terms: widths 1-4, a handful of 1-2 bit exceptions).  The others take the general streams.
-typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+// (codec_streams.hpp LValStream).  The quarter's packed words sit in a register queue of NW words fetched with wide loads (a
+// quarter of width b occupies exactly b words; widths > NW re-load the upper half of the queue every NW / 2 words, far ahead of
+// their use); the low parts come out of a two-word funnel (v_alignbit), a used-up word is a shift of the queue.  The quarter's
+// exceptions — found through the per-row exception index built at upload instead of a scan of the group's list — sit in a
+// 32-bit position mask and a packed queue of high parts and are patched branch-free.  Everything the lane needs to address its
+// loads (offset, header words, exception index) comes in ONE 16-byte row record, so a row costs two memory round trips.
 template <int NW>
 struct PfRegs {
         uint32_t w[NW];
-        uint32_t sh, b, mask, excmask, eb, emask, hq;
-        __device__ __forceinline__ bool init(const uint8_t *g, const uint32_t q, const uint32_t e0, const uint32_t cnt) {
-                const uint32_t L = g[0];
+        const uint8_t *wp; // the next NW / 2 words of a wide quarter
+        uint32_t sh, b, mask, excmask, eb, emask, used;
+        uint64_t hq;
+        // g: the group's first byte; hdr: its header word (row record); e0 / cnt: the quarter's run of the exception list.
+        // false: not representable here (> 16 exceptions or > 64 bits of high parts in the quarter): general streams.
+        __device__ __forceinline__ bool init(const uint8_t *g, const uint32_t hdr, const uint32_t q, const uint32_t e0, const uint32_t cnt) {
                 excmask = 0;
                 eb = 0;
                 emask = 0;
                 hq = 0;
                 sh = 0;
-                if (!L) { // lucene_codec.cpp:31-39: every value equal, one prefix varint
-                        uint32_t len;
-                        w[0] = vb_decode(ldu64(g + 1), len);
+                used = 0;
+                wp = g;
+                if (hdr >> 31) { // lucene_codec.cpp:31-39: every value equal
+                        w[0] = hdr & 0x7fffffffu;
 #pragma unroll
                         for (int k = 1; k < NW; ++k)
                                 w[k] = 0;
@@ -79,51 +101,67 @@ struct PfRegs {
                         mask = 0xffffffffu;
                         return true;
                 }
-                const uint32_t w0 = ldu32(g + 1);
-                b = w0 & 0xffu;
-                const uint32_t nexc = (w0 >> 8) & 0xffu;
-                eb = (w0 >> 16) & 0xffu;
-                if (b > NW || cnt > 16 || cnt * eb > 32)
+                b = hdr & 0xffu;
+                const uint32_t nexc = (hdr >> 8) & 0xffu;
+                eb = (hdr >> 16) & 0xffu;
+                if (cnt > 16 || cnt * eb > 64)
                         return false;
-                mask = (1u << b) - 1u; // (b <= NW < 32)
+                mask = b >= 32 ? 0xffffffffu : ((1u << b) - 1u);
                 const uint8_t *q0 = g + 5 + 4 * (q * b);
 #pragma unroll
                 for (int k = 0; k < NW; k += 4) {
                         const u32x4_a1 v = *(const u32x4_a1 *)(q0 + 4 * k);
                         w[k] = v.x, w[k + 1] = v.y, w[k + 2] = v.z, w[k + 3] = v.w;
                 }
+                wp = q0 + 4 * NW;
                 if (cnt) {
                         emask = eb >= 32 ? 0xffffffffu : ((1u << eb) - 1u);
                         const uint8_t *epos = g + 5 + 16 * b;
                         const uint8_t *ehigh = epos + 4 * ((nexc + 3) / 4);
                         uint64_t p0 = ldu64(epos + e0);
                         const uint64_t p1 = ldu64(epos + e0 + 8);
+                        const uint32_t bit0 = e0 * eb;
+                        const uint8_t *hp = ehigh + (bit0 >> 3);
+                        const uint32_t hs = bit0 & 7u;
+                        const uint64_t h0 = ldu64(hp), h1 = ldu64(hp + 8);
+                        hq = hs ? ((h0 >> hs) | (h1 << (64 - hs))) : h0; // 64 bits from any bit offset
                         for (uint32_t e = 0; e < cnt; ++e) {
                                 if (e == 8)
                                         p0 = p1;
                                 excmask |= 1u << ((uint32_t)p0 & 31u);
                                 p0 >>= 8;
                         }
-                        const uint32_t bit0 = e0 * eb;
-                        hq = (uint32_t)(ldu64(ehigh + (bit0 >> 3)) >> (bit0 & 7u)); // 32 bits from any bit offset
                 }
                 return true;
         }
         __device__ __forceinline__ uint32_t next(const uint32_t i) {
                 uint32_t x = __builtin_amdgcn_alignbit(w[1], w[0], sh) & mask;
                 sh += b;
-                // a word is used up: shift the register queue.  The branch is WAVE-uniform (lanes of one list share a width and cross
-                // word boundaries together), the shift inside is per lane by select — a lane-divergent branch here made the compiler
-                // copy the whole queue on every value
+                // a word is used up: shift the queue.  The branches are WAVE-uniform (lanes of one list share a width and cross word
+                // boundaries together), the work inside is per lane by select — a lane-divergent branch here made the compiler copy
+                // the whole queue on every value
                 if (__builtin_amdgcn_ballot_w64(sh >= 32) != 0ull) {
                         const bool r = sh >= 32;
 #pragma unroll
                         for (int k = 0; k + 1 < NW; ++k)
                                 w[k] = r ? w[k + 1] : w[k];
                         sh = r ? sh - 32 : sh;
+                        used += r ? 1u : 0u;
+                        const bool f = r && used == NW / 2 && b > NW; // a wide quarter has moved half a queue: fetch the next half
+                        if (__builtin_amdgcn_ballot_w64(f) != 0ull) {
+                                if (NW == 8) {
+                                        const u32x4_a1 v = *(const u32x4_a1 *)wp; // (lanes that do not need it read a valid address and drop it)
+                                        w[4] = f ? v.x : w[4], w[5] = f ? v.y : w[5], w[6] = f ? v.z : w[6], w[7] = f ? v.w : w[7];
+                                } else {
+                                        const u32x2_a1 v = *(const u32x2_a1 *)wp;
+                                        w[NW / 2] = f ? v.x : w[NW / 2], w[NW / 2 + 1] = f ? v.y : w[NW / 2 + 1];
+                                }
+                                wp += f ? 2 * NW : 0;
+                                used = f ? 0u : used;
+                        }
                 }
                 const uint32_t m = (uint32_t)(-(int32_t)((excmask >> i) & 1u)); // all ones at an exception
-                x |= (hq & emask & m) << b;
+                x |= ((uint32_t)hq & emask & m) << (b & 31u);
                 hq >>= (eb & m);
                 return x;
         }
@@ -132,7 +170,7 @@ struct PfRegs {
 // The freq of `doc` in term t (the document is known to be one of the term's): rescoring of a saturated field.
 template <int CODEC>
 __device__ __noinline__ uint32_t fused_lookup_freq(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
-                                      const DevTerm &t, const uint32_t doc) {
+                                                   const DevTerm &t, const uint32_t doc) {
         const uint32_t *bl = blk_last + t.first_block;
         uint32_t lo = 0, hi = t.nblocks;
         while (lo < hi) {
@@ -161,13 +199,20 @@ __device__ __noinline__ uint32_t fused_lookup_freq(const uint8_t *__restrict__ i
         return f & 0xffffu;
 }
 
-// One directory row (<= 32 documents) of a slot's term into the window words, through the codec's general value streams: GOOGLE
-// rows, the varbyte tail of a LUCENE list, and the PFOR quarters the register reader (PfRegs) does not take.
+// One posting into the window words.  rel = docID - w0 (documents below the window wrap to huge values: they and the documents
+// past the window land in the sink word); `past` keeps the smallest rel - FUS_W >= 0, i.e. the row's first document past the window.
+__device__ __forceinline__ void fused_post(uint32_t *acc, const uint32_t rel, const uint32_t f, const uint32_t cap, const uint32_t shift, uint32_t &past) {
+        past = min(past, rel - FUS_W); // (in-window and below-window documents give values >= 2^31: never the minimum of a real one)
+        atomicOr(&acc[min(rel, FUS_W)], (min(f & 0xffffu, cap) + 1u) << shift);
+}
+
+// One directory row (<= 32 documents) of a slot's term into the window words through the codec's general value streams: GOOGLE
+// rows, and the PFOR quarters the register reader (PfRegs) does not take.
 template <int CODEC>
-__device__ __forceinline__ void fused_row_streams(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
-                                                  const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift,
-                                                  const uint32_t cap) {
-        uint32_t rel = prev - w0; // documents below the window wrap to huge values and land in the sink word
+__device__ __forceinline__ uint32_t fused_row_streams(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
+                                                      const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift,
+                                                      const uint32_t cap) {
+        uint32_t rel = prev - w0, past = 0xffffffffu;
         DeltaStream<CODEC> ds;
         ds.init(index, t, b, off);
         FreqStream<CODEC> fs;
@@ -180,54 +225,51 @@ __device__ __forceinline__ void fused_row_streams(const uint8_t *__restrict__ in
                 fs.init(index, t, b, off, ds);
         for (uint32_t i = 0; i < n; ++i) {
                 rel = (i + 1 < n) ? rel + ds.next() : last - w0;
-                const uint32_t f = fs.next() & 0xffffu;
-                atomicOr(&acc[min(rel, FUS_W)], (min(f, cap) + 1u) << shift);
+                fused_post(acc, rel, fs.next(), cap, shift, past);
         }
+        return past;
+}
+// (LUCENE: out of line — the general streams' state must not weigh on the registers of the PFOR fast path; only quarters with
+// more than 16 exceptions come here.)
+__device__ __noinline__ uint32_t fused_row_streams_lucene(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
+                                                          const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc,
+                                                          const uint32_t shift, const uint32_t cap) {
+        return fused_row_streams<CODEC_LUCENE>(index, t, b, off, n, prev, last, w0, acc, shift, cap);
 }
 
-// (LUCENE: out of line — the general streams' state must not weigh on the registers of the PFOR fast path, and only the tail rows
-// and the odd wide quarter come here.  GOOGLE rows have no other route: inline.)
-__device__ __noinline__ void fused_row_streams_lucene(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
-                                                      const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc,
-                                                      const uint32_t shift, const uint32_t cap) {
-        fused_row_streams<CODEC_LUCENE>(index, t, b, off, n, prev, last, w0, acc, shift, cap);
-}
-
+// Returns the row's first document past the window as rel - FUS_W (>= 2^31: none).
+// LUCENE: rec = the row record {group offset, exception index, deltas header, freqs header}; GOOGLE: rec_x = payload offset.
 template <int CODEC>
-__device__ __forceinline__ void fused_row(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_exc, const DevTerm &t, const uint32_t b,
-                                          const uint32_t off, const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0,
-                                          uint32_t *acc, const uint32_t shift, const uint32_t cap) {
-        if (CODEC == CODEC_LUCENE && b < t.npfor) {
-                const uint8_t *g = index + off;
-                const uint32_t L = g[0];
-                uint32_t vl = 0; // (only decoded when L == 0)
-                if (!L) {
-                        const uint32_t b0 = g[1];
-                        vl = b0 < 0x80 ? 1 : b0 < 0xc0 ? 2 : b0 < 0xe0 ? 3 : b0 < 0xf0 ? 4 : 5;
-                }
-                const uint8_t *gf = g + 1 + (L ? 4 * L : vl);
-                const uint32_t x = blk_exc[t.first_block + b]; // e0_d | cnt_d << 8 | e0_f << 16 | cnt_f << 24
-                {
-                        PfRegs<8> rd;
-                        PfRegs<4> rf;
-                        const bool okd = rd.init(g, b & 3u, x & 0xffu, (x >> 8) & 0xffu);
-                        const bool okf = rf.init(gf, b & 3u, (x >> 16) & 0xffu, x >> 24);
-                        if (okd && okf) {
-                                uint32_t rel = prev - w0; // documents below the window wrap to huge values and land in the sink word
-#pragma unroll 2
-                                for (uint32_t i = 0; i < 32; ++i) {
-                                        rel += rd.next(i);
-                                        const uint32_t f = rf.next(i) & 0xffffu;
-                                        atomicOr(&acc[min(rel, FUS_W)], (min(f, cap) + 1u) << shift);
-                                }
-                                return;
+__device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t rec_x,
+                                              const uint32_t rec_y, const uint32_t rec_z, const uint32_t rec_w, const uint32_t n, const uint32_t prev,
+                                              const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift, const uint32_t cap) {
+        if (CODEC == CODEC_LUCENE) {
+                uint32_t rel = prev - w0, past = 0xffffffffu;
+                if (b >= t.npfor) { // the list's varbyte tail (lucene_codec.cpp:321-337): (delta, freq) pairs, fewer than 128 documents
+                        VbStream vb;
+                        vb.init(index + rec_x);
+                        for (uint32_t i = 0; i < n; ++i) {
+                                rel += vb.next();
+                                fused_post(acc, rel, vb.next(), cap, shift, past);
                         }
+                        return past;
                 }
+                const uint8_t *g = index + rec_x;
+                PfRegs<8> rd;
+                PfRegs<4> rf;
+                const bool okd = rd.init(g, rec_z, b & 3u, rec_y & 0xffu, (rec_y >> 8) & 0xffu);
+                const bool okf = rf.init(g + pfor_group_bytes(rec_z), rec_w, b & 3u, (rec_y >> 16) & 0xffu, rec_y >> 24);
+                if (okd && okf) {
+#pragma unroll 2
+                        for (uint32_t i = 0; i < 32; ++i) {
+                                rel += rd.next(i);
+                                fused_post(acc, rel, rf.next(i), cap, shift, past);
+                        }
+                        return past;
+                }
+                return fused_row_streams_lucene(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
         }
-        if (CODEC == CODEC_LUCENE)
-                fused_row_streams_lucene(index, t, b, off, n, prev, last, w0, acc, shift, cap);
-        else
-                fused_row_streams<CODEC>(index, t, b, off, n, prev, last, w0, acc, shift, cap);
+        return fused_row_streams<CODEC>(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
 }
 
 // Keep the best k of the n (<= FUS_CAP) buffered candidates, best first (rank by counting: the order is strict).
@@ -263,7 +305,7 @@ __device__ void fused_prune(FusedShared &sh, const uint32_t n, const uint32_t k)
 
 template <int CODEC>
 __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                                     const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_exc,
+                                                     const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
                                                      const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                                                      const DevQuery *__restrict__ plan, const DevFused *__restrict__ fused,
                                                      const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched,
@@ -299,15 +341,17 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                 __syncthreads();
                 const DevFused &fq = sh.fq;
                 const uint32_t nslots = uni(fq.nslots), fbits = uni(fq.fbits), cap = uni(fq.cap), nreq = uni(fq.nreq), nmask = uni(fq.nmask);
-                const uint32_t kk = min(tid, nslots - 1); // lanes >= nslots mirror the last slot
+                const uint32_t nch = (nslots * fbits + 7) / 8; // bytes of the word in use
+                const uint32_t kk = min(tid, nslots - 1);      // lanes >= nslots mirror the last slot
                 sh.term[kk] = terms[fq.term[kk]];
+                sh.hint_row[kk] = 0xffffffffu;
                 sh.tk_n = 0;
                 sh.tk_full = 0;
                 sh.overflow = 0;
                 sh.matches = 0;
                 {
                         // tab[c][v]: the fields inside byte c of the word.  code 0 = absent; code - 1 = freq; code cap + 1 = saturated
-                        const uint32_t nch = (nslots * fbits + 7) / 8, per = 8 / fbits, fmask = (1u << fbits) - 1u;
+                        const uint32_t per = 8 / fbits, fmask = (1u << fbits) - 1u;
                         for (uint32_t e = tid; e < nch * 256; e += FUS_WG) {
                                 const uint32_t c = e >> 8, v = e & 255u;
                                 double s = 0.0;
@@ -352,6 +396,9 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                         }
                         cur = lo;
                 }
+                // the first four required groups' masks live in registers (a missing group tests true on any non-zero word)
+                const uint32_t gm0 = uni(fq.gmask[0]), gm1 = nreq > 1 ? uni(fq.gmask[1]) : 0xffffffffu, gm2 = nreq > 2 ? uni(fq.gmask[2]) : 0xffffffffu,
+                               gm3 = nreq > 3 ? uni(fq.gmask[3]) : 0xffffffffu;
                 uint32_t my_matches = 0;
                 PROF_LAP(0);
                 while (w < task.tile_end) {
@@ -371,12 +418,21 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                                         while (b_hi + 1 < myt.nblocks && mybl[b_hi] < wlast)
                                                 ++b_hi;
                                 }
+                                uint32_t cnt = 0;
                                 if (b_lo < myt.nblocks) {
-                                        const uint32_t first_possible = here ? w0 : (b_lo ? mybl[b_lo - 1] + 1 : 1u);
-                                        np = max(w0, first_possible);
+                                        cnt = b_hi - b_lo + 1;
+                                        const uint32_t hd = sh.hint_doc[kk];
+                                        if (sh.hint_row[kk] == b_lo) { // the row was decoded before: its next document is known
+                                                np = max(w0, hd);
+                                                if (hd > wlast)
+                                                        cnt = 0; // ... and lies past this window: the row (and with it the list) has nothing here
+                                        } else {
+                                                const uint32_t first_possible = here ? w0 : (b_lo ? mybl[b_lo - 1] + 1 : 1u);
+                                                np = max(w0, first_possible);
+                                        }
                                 }
                                 sh.seg_lo[kk] = b_lo;
-                                sh.seg_cnt[kk] = b_lo < myt.nblocks ? b_hi - b_lo + 1 : 0;
+                                sh.seg_cnt[kk] = cnt;
                                 sh.seg_np[kk] = np;
                         }
                         sh.seg_cnt[nslots] = 0xffffffffu; // sentinel: the lane-to-slot walk stops here
@@ -423,9 +479,19 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                                         const uint32_t *bl = blk_last + t.first_block;
                                         const uint32_t prev = b ? bl[b - 1] : 0;
                                         const uint32_t last = bl[b];
-                                        const uint32_t off = blk_off[t.first_block + b];
-                                        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
-                                        fused_row<CODEC>(index, blk_exc, t, b, off, n, prev, last, w0, sh.acc, s * fbits, cap);
+                                        uint32_t past;
+                                        if (CODEC == CODEC_LUCENE) {
+                                                const uint4 rec = blk_rec[t.first_block + b];
+                                                past = fused_row<CODEC>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, sh.acc,
+                                                                        s * fbits, cap);
+                                        } else {
+                                                const uint32_t off = blk_off[t.first_block + b];
+                                                past = fused_row<CODEC>(index, t, b, off, 0, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, sh.acc, s * fbits, cap);
+                                        }
+                                        if (past < 0x80000000u) { // the row reaches past the window (it is the slot's last row here): leave the hint
+                                                sh.hint_row[s] = b;
+                                                sh.hint_doc[s] = w0 + FUS_W + past;
+                                        }
                                 }
                         }
                         // the next window's far cell-index entry travels while the set pass runs
@@ -437,61 +503,100 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                         PROF_LAP(2);
                         __syncthreads();
                         PROF_LAP(3);
-                        // ---- sweep: predicate, score, threshold; re-zero.  A full candidate buffer is pruned and the sweep resumed
-                        //      (unprocessed words are simply still non-zero).
-                        // the first four required groups' masks live in registers (a missing group tests true on any non-zero word)
-                        const uint32_t gm0 = uni(fq.gmask[0]), gm1 = nreq > 1 ? uni(fq.gmask[1]) : 0xffffffffu, gm2 = nreq > 2 ? uni(fq.gmask[2]) : 0xffffffffu,
-                                       gm3 = nreq > 3 ? uni(fq.gmask[3]) : 0xffffffffu;
+                        // ---- sweep: predicate, score, threshold; re-zero.  Words are taken in batches (independent LDS reads, then
+                        //      independent table lookups); the rare candidate is appended to the buffer; a full buffer is pruned and the
+                        //      sweep resumed over the words that were put back.
                         for (;;) {
                                 const bool full = uni(sh.tk_full) != 0;
                                 const double thr_s = sh.thr_s;
                                 const uint32_t thr_d = sh.thr_d;
-                                for (uint32_t j = 0; j < FUS_W / FUS_WG; ++j) {
-                                        const uint32_t i = j * FUS_WG + tid;
-                                        const uint32_t x = sh.acc[i];
-                                        if (!x)
+                                for (uint32_t jb = 0; jb < FUS_WPT; jb += FUS_SWB) {
+                                        uint32_t x[FUS_SWB];
+                                        uint32_t any = 0;
+#pragma unroll
+                                        for (uint32_t u = 0; u < FUS_SWB; ++u) {
+                                                x[u] = sh.acc[(jb + u) * FUS_WG + tid];
+                                                any |= x[u];
+                                        }
+                                        if (__builtin_amdgcn_ballot_w64(any != 0) == 0ull)
+                                                continue; // nothing in this wave's slice of the batch
+                                        double sc[FUS_SWB];
+                                        uint32_t mm = 0;
+#pragma unroll
+                                        for (uint32_t u = 0; u < FUS_SWB; ++u) {
+                                                sh.acc[(jb + u) * FUS_WG + tid] = 0;
+                                                bool m = x[u] != 0 && (x[u] & nmask) == 0 && (x[u] & gm0) && (x[u] & gm1) && (x[u] & gm2) && (x[u] & gm3);
+                                                for (uint32_t g = 4; g < nreq; ++g)
+                                                        m &= (x[u] & fq.gmask[g]) != 0;
+                                                mm |= (m ? 1u : 0u) << u;
+                                                sc[u] = sh.tab[0][x[u] & 0xffu];
+                                        }
+                                        if (nch > 1) {
+#pragma unroll
+                                                for (uint32_t u = 0; u < FUS_SWB; ++u)
+                                                        sc[u] += sh.tab[1][(x[u] >> 8) & 0xffu];
+                                        }
+                                        if (nch > 2) {
+#pragma unroll
+                                                for (uint32_t u = 0; u < FUS_SWB; ++u)
+                                                        sc[u] += sh.tab[2][(x[u] >> 16) & 0xffu];
+                                        }
+                                        if (nch > 3) {
+#pragma unroll
+                                                for (uint32_t u = 0; u < FUS_SWB; ++u)
+                                                        sc[u] += sh.tab[3][x[u] >> 24];
+                                        }
+                                        if (masked && mm) { // masked_documents_registry::test (docidupdates.h:90-119)
+#pragma unroll
+                                                for (uint32_t u = 0; u < FUS_SWB; ++u) {
+                                                        const uint32_t doc = w0 + (jb + u) * FUS_WG + tid;
+                                                        if (((mm >> u) & 1u) && ((masked[doc >> 5] >> (doc & 31u)) & 1u))
+                                                                mm &= ~(1u << u);
+                                                }
+                                        }
+                                        my_matches += __popc(mm);
+                                        uint32_t cand = 0;
+#pragma unroll
+                                        for (uint32_t u = 0; u < FUS_SWB; ++u) {
+                                                const uint32_t doc = w0 + (jb + u) * FUS_WG + tid;
+                                                const bool c = ((mm >> u) & 1u) && (!full || !(sc[u] == sc[u]) || better(sc[u], doc, thr_s, thr_d));
+                                                cand |= (c ? 1u : 0u) << u;
+                                        }
+                                        if (__builtin_amdgcn_ballot_w64(cand != 0) == 0ull)
                                                 continue;
-                                        bool m = (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
-                                        for (uint32_t g = 4; g < nreq; ++g)
-                                                m &= (x & fq.gmask[g]) != 0;
-                                        const uint32_t doc = w0 + i;
-                                        if (m && masked) // masked_documents_registry::test (docidupdates.h:90-119)
-                                                m = !((masked[doc >> 5] >> (doc & 31u)) & 1u);
-                                        if (m) {
-                                                double sc = sh.tab[0][x & 0xffu];
-                                                if (nslots * fbits > 8)
-                                                        sc += sh.tab[1][(x >> 8) & 0xffu];
-                                                if (nslots * fbits > 16)
-                                                        sc += sh.tab[2][(x >> 16) & 0xffu];
-                                                if (nslots * fbits > 24)
-                                                        sc += sh.tab[3][x >> 24];
-                                                if (sc != sc) { // a saturated field: rescore from the postings, scorer by scorer
-                                                        sc = 0.0;
+#pragma unroll
+                                        for (uint32_t u = 0; u < FUS_SWB; ++u) {
+                                                if (!((cand >> u) & 1u))
+                                                        continue;
+                                                const uint32_t doc = w0 + (jb + u) * FUS_WG + tid;
+                                                double s = sc[u];
+                                                if (!(s == s)) { // a saturated field: rescore from the postings, scorer by scorer
+                                                        s = 0.0;
                                                         const uint32_t fmask = (1u << fbits) - 1u;
                                                         for (uint32_t si = 0; si < q.nscore; ++si) {
                                                                 const uint32_t term = sterms[q.score_base + si];
-                                                                uint32_t s = 0;
-                                                                while (s + 1 < nslots && fq.term[s] != term)
-                                                                        ++s;
-                                                                const uint32_t code = (x >> (s * fbits)) & fmask;
+                                                                uint32_t sl = 0;
+                                                                while (sl + 1 < nslots && fq.term[sl] != term)
+                                                                        ++sl;
+                                                                const uint32_t code = (x[u] >> (sl * fbits)) & fmask;
                                                                 if (!code)
                                                                         continue;
-                                                                const uint32_t f = code > cap ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[s], doc) : code - 1u;
-                                                                sc += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                                                const uint32_t f = code > cap ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[sl], doc) : code - 1u;
+                                                                s += (double)sim_score(sim, sweights[q.score_base + si], f);
                                                         }
+                                                        if (full && !better(s, doc, thr_s, thr_d))
+                                                                continue;
                                                 }
-                                                if (!full || better(sc, doc, thr_s, thr_d)) {
-                                                        const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
-                                                        if (slot >= FUS_CAP) {
-                                                                sh.overflow = 1; // the word stays: the resumed sweep takes it
-                                                                break;
-                                                        }
-                                                        sh.tk_s[slot] = sc;
-                                                        sh.tk_d[slot] = doc;
+                                                const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
+                                                if (slot >= FUS_CAP) { // no room: the word goes back, the resumed sweep takes it again
+                                                        sh.overflow = 1;
+                                                        sh.acc[(jb + u) * FUS_WG + tid] = x[u];
+                                                        --my_matches;
+                                                        continue;
                                                 }
-                                                ++my_matches;
+                                                sh.tk_s[slot] = s;
+                                                sh.tk_d[slot] = doc;
                                         }
-                                        sh.acc[i] = 0;
                                 }
                                 __syncthreads();
                                 const uint32_t ov = uni(sh.overflow);

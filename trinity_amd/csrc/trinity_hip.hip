@@ -85,10 +85,13 @@ struct tri_index {
         // (k_and_dense, k_and) read this stream instead.  Scoring and phrases keep reading the chunk itself.
         uint8_t *d_dstream = nullptr;
         uint32_t *d_blk_doff = nullptr;
-        // LUCENE: per directory row (a quarter of a 128-document block) where ITS exceptions sit in the two ints() groups' exception
-        // lists: e0_deltas | cnt_deltas << 8 | e0_freqs << 16 | cnt_freqs << 24 — a lane patches its quarter without scanning the
-        // exceptions of the other three (k_fused.hpp PfQuarter)
-        uint32_t *d_blk_exc = nullptr;
+        // LUCENE: one 16-byte record per directory row (a quarter of a 128-document block, or a run of the varbyte tail) with all a lane
+        // needs to address the row's payload in ONE load: {offset of the deltas group (tail: of the pairs), exception index, header word of
+        // the deltas group, header word of the freqs group}.  Exception index = where THIS quarter's exceptions sit in the two groups'
+        // lists: e0_deltas | cnt_deltas << 8 | e0_freqs << 16 | cnt_freqs << 24 (a lane patches its quarter without scanning the other
+        // three's).  Header word = the group's first payload word (width | nexc << 8 | excwidth << 16), or bit 31 | value for an
+        // all-equal group (k_fused.hpp PfRegs)
+        uint4 *d_blk_rec = nullptr;
         uint32_t *d_masked = nullptr; // bitmap over docIDs of the masked documents (nullptr: none); max_doc / 32 + 2 words
         uint32_t max_doc = 0;
         uint32_t nwin = 0; // cells per win[] row
@@ -107,7 +110,7 @@ struct tri_index {
                 hipFree(d_hdir);
                 hipFree(d_dstream);
                 hipFree(d_blk_doff);
-                hipFree(d_blk_exc);
+                hipFree(d_blk_rec);
                 hipFree(d_masked);
                 hipFree(d_blk_last);
                 hipFree(d_blk_off);
@@ -434,7 +437,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         ix->hitbytes.assign(nterms, 0);
         std::vector<uint32_t> blk_last, blk_off;
         std::vector<uint32_t> blk_hits, hdir; // LUCENE + hits.data only
-        std::vector<uint32_t> blk_exc;        // LUCENE only
+        std::vector<uint4> blk_rec;           // LUCENE only
         std::vector<uint8_t> dstream;         // GOOGLE only
         std::vector<uint32_t> blk_doff;
         if (codec == TRI_CODEC_GOOGLE) {
@@ -492,8 +495,20 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                                 if (!usedf || !h_ints_exc(index + goff, xd) || !h_ints_exc(p, xf))
                                         return fail(TRI_ERR_FORMAT, "term %zu: bad freqs group / exception list", ti);
                                 p += usedf;
+                                uint32_t hdr[2];
+                                for (int gi = 0; gi < 2; ++gi) { // the two groups' header words as the row records cache them
+                                        const uint8_t *gp = gi ? p - usedf : index + goff;
+                                        if (gp[0])
+                                                memcpy(&hdr[gi], gp + 1, 4);
+                                        else {
+                                                const uint32_t v = gi ? fvals[0] : vals[0];
+                                                if (v >> 31)
+                                                        return fail(TRI_ERR_UNSUPPORTED, "term %zu: an all-equal group of value %u", ti, v);
+                                                hdr[gi] = 0x80000000u | v;
+                                        }
+                                }
                                 for (uint32_t q4 = 0; q4 < 4; ++q4) {
-                                        blk_exc.push_back(xd[q4] | xf[q4] << 16);
+                                        blk_rec.push_back(make_uint4(goff, xd[q4] | xf[q4] << 16, hdr[0], hdr[1]));
                                         if (want_hits)
                                                 blk_hits.push_back((uint32_t)hits_seen);
                                         for (uint32_t i = 0; i < 32; ++i) {
@@ -514,7 +529,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                         while (left) {
                                 const uint32_t n = std::min(left, 32u);
                                 blk_off.push_back((uint32_t)(p - index));
-                                blk_exc.push_back(0);
+                                blk_rec.push_back(make_uint4((uint32_t)(p - index), 0, 0, 0));
                                 if (want_hits)
                                         blk_hits.push_back((uint32_t)hits_seen);
                                 for (uint32_t i = 0; i < n; ++i) {
@@ -694,7 +709,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         }
         if (codec == TRI_CODEC_GOOGLE && (rc = dev_upload(&ix->d_blk_hits, blk_hits)))
                 return rc;
-        if (codec == TRI_CODEC_LUCENE && (rc = dev_upload(&ix->d_blk_exc, blk_exc)))
+        if (codec == TRI_CODEC_LUCENE && (rc = dev_upload(&ix->d_blk_rec, blk_rec)))
                 return rc;
         ix->h_blk_last = std::move(blk_last);
         ix->info.index_bytes = len;
@@ -803,6 +818,7 @@ extern "C" int tri_decode_terms(tri_index *ix, const uint32_t *terms, size_t n, 
 namespace {
         struct PNode {
                 uint32_t op, term;
+                uint32_t tok = 0; // index of the program token this node came from (caller-supplied ScorerWeights are per token)
                 std::vector<int> kids;
                 uint64_t cost = 0;
                 bool empty = false;
@@ -816,6 +832,7 @@ namespace {
                         const uint32_t op = prog[i] >> 28, arg = prog[i] & 0x0fffffffu;
                         PNode n;
                         n.op = op;
+                        n.tok = i;
                         if (op == TRI_OP_TERM) {
                                 n.term = arg;
                                 n.cost = arg < ix->terms.size() ? ix->terms[arg].documents : 0;
@@ -942,11 +959,13 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         continue; // matches nothing (compiles to constfalse in the reference)
                 // ---- conjunctive normal form over terms: AND of (term | OR of terms); a root OR is one group
                 std::vector<std::vector<uint32_t>> groups;
-                std::vector<uint32_t> leaves; // every TERM leaf in evaluation order: one scorer each
+                std::vector<uint32_t> leaves;     // every TERM leaf in evaluation order: one scorer each
+                std::vector<uint32_t> leaf_tok;   // ... and the program token it came from
                 struct PhraseTmp {
                         std::vector<uint32_t> terms;
                         double weight;
                 };
+                std::vector<uint32_t> ts_tok; // (scratch of add_group: token indices parallel to ts)
                 std::vector<PhraseTmp> qphrases;
                 auto add_group = [&](const PNode &g) -> bool {
                         std::vector<uint32_t> ts;
@@ -966,30 +985,30 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                         if (!dup)
                                                 groups.push_back({x});
                                 }
-                                if (weights) { // the PHRASE token's ScorerWeight, when the caller supplies weights
-                                        for (uint32_t pi = 0; pi < tq.prog_len; ++pi)
-                                                if ((prog[tq.prog_off + pi] >> 28) == TRI_OP_PHRASE && (prog[tq.prog_off + pi] & 0x0fffffffu) == g.kids.size() &&
-                                                    pi >= g.kids.size() && prog[tq.prog_off + pi - g.kids.size()] == TRI_TOK(TRI_OP_TERM, ph.terms[0])) {
-                                                        ph.weight = weights[tq.prog_off + pi];
-                                                        break;
-                                                }
-                                }
+                                if (weights) // the PHRASE token's own ScorerWeight, when the caller supplies weights (by token position: two phrases
+                                             // that start with the same term keep their own weights)
+                                        ph.weight = weights[tq.prog_off + g.tok];
                                 qphrases.push_back(std::move(ph));
                                 return true;
                         }
-                        if (g.op == TRI_OP_PHRASE)
+                        ts_tok.clear();
+                        if (g.op == TRI_OP_PHRASE) {
                                 ts.push_back(nodes[g.kids[0]].term); // a one-word phrase is a term (exec.cpp: phrase of size 1)
-                        else if (g.op == TRI_OP_TERM)
+                                ts_tok.push_back(nodes[g.kids[0]].tok);
+                        } else if (g.op == TRI_OP_TERM) {
                                 ts.push_back(g.term);
-                        else if (g.op == TRI_OP_OR) {
+                                ts_tok.push_back(g.tok);
+                        } else if (g.op == TRI_OP_OR) {
                                 for (int k : g.kids) {
                                         if (nodes[k].op != TRI_OP_TERM)
                                                 return false;
                                         ts.push_back(nodes[k].term);
+                                        ts_tok.push_back(nodes[k].tok);
                                 }
                         } else
                                 return false;
                         leaves.insert(leaves.end(), ts.begin(), ts.end());
+                        leaf_tok.insert(leaf_tok.end(), ts_tok.begin(), ts_tok.end());
                         // a term repeated inside a group, or a single-term group seen before, adds nothing to the docID set
                         std::vector<uint32_t> u;
                         for (uint32_t x : ts)
@@ -1005,7 +1024,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 // logicalnot at the root or under an AND: its required side joins the conjunction, its excluded side (a term or an
                 // OR of terms) joins the query's excluded set: A B -C == A ∧ B ∧ ¬C (Filter semantics, docset_iterators.cpp:652-677)
                 bool ok = true;
-                std::vector<uint32_t> negs, opts;
+                std::vector<uint32_t> negs, opts, opt_tok;
                 std::function<void(int)> lower = [&](int ni) {
                         const PNode &x = nodes[ni];
                         if (x.op == TRI_OP_OPT) {
@@ -1013,16 +1032,20 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 // exactly how k_score / k_rich treat a term a match does not hold
                                 lower(x.kids[0]);
                                 const PNode &e = nodes[x.kids[1]];
-                                if (e.op == TRI_OP_TERM)
+                                if (e.op == TRI_OP_TERM) {
                                         opts.push_back(e.term);
-                                else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1)
+                                        opt_tok.push_back(e.tok);
+                                } else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1) {
                                         opts.push_back(nodes[e.kids[0]].term);
-                                else if (e.op == TRI_OP_OR) {
+                                        opt_tok.push_back(nodes[e.kids[0]].tok);
+                                } else if (e.op == TRI_OP_OR) {
                                         for (int k : e.kids) {
                                                 if (nodes[k].op != TRI_OP_TERM)
                                                         ok = false;
-                                                else
+                                                else {
                                                         opts.push_back(nodes[k].term);
+                                                        opt_tok.push_back(nodes[k].tok);
+                                                }
                                         }
                                 } else
                                         ok = false;
@@ -1049,9 +1072,10 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 ok &= add_group(x);
                 };
                 lower(root);
-                for (uint32_t x : opts)
-                        if (ix->terms[x].documents) {
+                for (size_t oi = 0; oi < opts.size(); ++oi)
+                        if (const uint32_t x = opts[oi]; ix->terms[x].documents) {
                                 leaves.push_back(x); // one more scorer / reportable term each; never part of the docID set
+                                leaf_tok.push_back(opt_tok[oi]);
                                 if (mode != TRI_FLAG_DOCUMENTS_ONLY)
                                         b->term_bytes += ix->docbytes[x]; // its postings are read by k_score / k_rich
                         }
@@ -1128,20 +1152,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         // (docset_iterators_scorers.cpp:173-193); weight = BM25 idf (similarity.h:179-181, float math)
                         // unless the caller supplied ScorerWeights per TERM token
                         std::vector<std::pair<uint32_t, double>> sc;
-                        for (uint32_t x : leaves)
-                                sc.emplace_back(x, 0.0);
-                        for (auto &e : sc) {
-                                e.second = term_weight(ix->terms[e.first].documents);
-                        }
-                        if (weights) {
-                                // caller-provided weights follow the program's TERM tokens; map by first occurrence
-                                for (auto &e : sc)
-                                        for (uint32_t pi = 0; pi < tq.prog_len; ++pi)
-                                                if (prog[tq.prog_off + pi] == TRI_TOK(TRI_OP_TERM, e.first)) {
-                                                        e.second = weights[tq.prog_off + pi];
-                                                        break;
-                                                }
-                        }
+                        for (size_t li = 0; li < leaves.size(); ++li) // caller-provided weights: the leaf's OWN TERM token (a term that also sits inside a
+                                                                      // phrase or on an excluded side has another token with another weight)
+                                sc.emplace_back(leaves[li], weights ? weights[tq.prog_off + leaf_tok[li]] : term_weight(ix->terms[leaves[li]].documents));
                         for (auto &e : sc) {
                                 b->sterms.push_back(e.first);
                                 b->sweights.push_back(e.second);
@@ -1475,7 +1488,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 if (b->n_fused) {
                         // AccumulatedScore top-K of the dense queries: decode -> match -> score -> select in one pass, two workgroups per CU
                         TRI_LAUNCH(k_fused, b->ix->codec, dim3(std::min<uint32_t>(b->n_fused, (uint32_t)dev->cus * 2)), dim3(FUS_WG), dev->stream, b->ix->d_index,
-                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_exc, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks,
+                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks,
                                            b->d_sched + b->n_dense + b->n_cand, b->d_sterms, b->d_sweights, b->n_fused, b->d_ticket + 56, b->d_counts, b->topk,
                                            b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked, b->similarity);
                         HIP_TRY(hipGetLastError());
