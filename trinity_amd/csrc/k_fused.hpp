@@ -25,13 +25,19 @@
 //     the windows it merely spans neither decode it again nor count as windows its list can match in: sparse lists cost one
 //     decode per row, and a conjunction jumps to the next window every required group can reach.
 // Per task the kernel leaves min(matches, k) (docID, score) pairs and the match count; k_topk_merge folds the tasks of a query.
-constexpr int FUS_WG = 512;
-constexpr uint32_t FUS_CELLS = 15; // docID cells (of CELL_DOCS) per window: 60 KB of words, two workgroups per CU
+#ifndef TRI_FUS_WG
+#define TRI_FUS_WG 512
+#endif
+#ifndef TRI_FUS_CELLS
+#define TRI_FUS_CELLS 14
+#endif
+constexpr int FUS_WG = TRI_FUS_WG;
+constexpr uint32_t FUS_CELLS = TRI_FUS_CELLS; // docID cells (of CELL_DOCS) per window (14: 56 KB of words, two 512-thread workgroups per CU)
 constexpr uint32_t FUS_W = FUS_CELLS * CELL_DOCS;
 constexpr uint32_t FUS_CAP = 512; // candidate buffer; k <= TOPK_MAX = 256
-constexpr uint32_t FUS_WPT = FUS_W / FUS_WG; // window words per thread
-constexpr uint32_t FUS_SWB = 6;              // ... swept in batches of this many (independent LDS reads in flight)
-static_assert(FUS_W % FUS_WG == 0 && FUS_WPT % FUS_SWB == 0, "the sweep deals whole batches of words to every thread");
+constexpr uint32_t FUS_CHUNKS = FUS_W / (4 * FUS_WG); // the sweep takes the window in 16-byte chunks: this many per thread
+constexpr uint32_t FUS_WLIST = 512;                   // per wave: documents waiting to be scored (a chunk adds up to 256: flushed beyond 256)
+static_assert(FUS_W % (4 * FUS_WG) == 0, "the sweep deals whole 16-byte chunks of words to every thread");
 static_assert(TOPK_MAX * 2 <= FUS_CAP, "a pruned buffer must leave room for a round of newcomers");
 
 struct FusedShared {
@@ -40,17 +46,21 @@ struct FusedShared {
         double tk_s[FUS_CAP];
         uint32_t tk_d[FUS_CAP];
         DevTerm term[FUS_MAX_SLOTS];
-        uint32_t seg_lo[FUS_MAX_SLOTS];
-        uint32_t seg_cnt[FUS_MAX_SLOTS + 1];
-        uint32_t seg_np[FUS_MAX_SLOTS];   // first docID >= w0 the slot's list may still hold (0xffffffff: exhausted)
         uint32_t hint_row[FUS_MAX_SLOTS]; // the slot's row that reached beyond the last window it was decoded in ...
         uint32_t hint_doc[FUS_MAX_SLOTS]; // ... and the first of its documents past that window
+        uint16_t wlist[FUS_WG / 64][FUS_WLIST]; // per wave: window-relative docIDs waiting to be scored
+        double ub[FUS_MAX_SLOTS];               // per slot: an upper bound of its score contribution
         double thr_s;
         uint32_t thr_d;
+        uint32_t emask; // fields of the ESSENTIAL slots: a document none of whose essential fields is set cannot beat the threshold
         uint32_t tk_n, tk_full, overflow, matches;
         uint32_t bcast[4];
         DevFused fq; // the query's slot map, staged once per task (dynamic indexing stays in LDS, not in scratch)
 };
+
+// workgroups a CU holds: LDS (160 KB) and the 2048-thread limit; the register budget follows (launch bounds)
+constexpr uint32_t FUS_WGS_PER_CU = (160u * 1024u / sizeof(FusedShared)) < (2048u / FUS_WG) ? (160u * 1024u / sizeof(FusedShared)) : (2048u / FUS_WG);
+static_assert(FUS_WGS_PER_CU >= 1, "the window state must fit the CU's LDS");
 
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
 typedef uint64_t u64_a1 __attribute__((aligned(1)));
@@ -79,7 +89,8 @@ __device__ __forceinline__ uint32_t pfor_group_bytes(const uint32_t hdr) {
 template <int NW>
 struct PfRegs {
         uint32_t w[NW];
-        const uint8_t *wp; // the next NW / 2 words of a wide quarter
+        uint32_t nx[NW / 2]; // wide quarters: the NW / 2 words that follow the queue, fetched a refill ahead
+        const uint8_t *wp;   // ... and where they came from
         uint32_t sh, b, mask, excmask, eb, emask, used;
         uint64_t hq;
         // g: the group's first byte; hdr: its header word (row record); e0 / cnt: the quarter's run of the exception list.
@@ -97,6 +108,9 @@ struct PfRegs {
 #pragma unroll
                         for (int k = 1; k < NW; ++k)
                                 w[k] = 0;
+#pragma unroll
+                        for (int k = 0; k < NW / 2; ++k)
+                                nx[k] = 0;
                         b = 0;
                         mask = 0xffffffffu;
                         return true;
@@ -114,6 +128,18 @@ struct PfRegs {
                         w[k] = v.x, w[k + 1] = v.y, w[k + 2] = v.z, w[k + 3] = v.w;
                 }
                 wp = q0 + 4 * NW;
+#pragma unroll
+                for (int k = 0; k < NW / 2; ++k)
+                        nx[k] = 0;
+                if (__builtin_amdgcn_ballot_w64(b > NW) != 0ull) { // (wave-uniform: only waves that hold a wide quarter pay the extra load)
+                        if (NW == 8) {
+                                const u32x4_a1 v = *(const u32x4_a1 *)wp;
+                                nx[0] = v.x, nx[1] = v.y, nx[NW / 2 - 2] = v.z, nx[NW / 2 - 1] = v.w;
+                        } else {
+                                const u32x2_a1 v = *(const u32x2_a1 *)wp;
+                                nx[0] = v.x, nx[1] = v.y;
+                        }
+                }
                 if (cnt) {
                         emask = eb >= 32 ? 0xffffffffu : ((1u << eb) - 1u);
                         const uint8_t *epos = g + 5 + 16 * b;
@@ -147,17 +173,23 @@ struct PfRegs {
                                 w[k] = r ? w[k + 1] : w[k];
                         sh = r ? sh - 32 : sh;
                         used += r ? 1u : 0u;
-                        const bool f = r && used == NW / 2 && b > NW; // a wide quarter has moved half a queue: fetch the next half
+                        const bool f = r && used == NW / 2 && b > NW; // a wide quarter has moved half a queue: the prefetched words take
+                                                                      // the upper half, the next ones are requested — nothing waits on memory here:
+                                                                      // every lane of the wave re-loads nx (a lane that did not move re-reads the
+                                                                      // same words), so the loaded values are first touched a refill later
                         if (__builtin_amdgcn_ballot_w64(f) != 0ull) {
-                                if (NW == 8) {
-                                        const u32x4_a1 v = *(const u32x4_a1 *)wp; // (lanes that do not need it read a valid address and drop it)
-                                        w[4] = f ? v.x : w[4], w[5] = f ? v.y : w[5], w[6] = f ? v.z : w[6], w[7] = f ? v.w : w[7];
-                                } else {
-                                        const u32x2_a1 v = *(const u32x2_a1 *)wp;
-                                        w[NW / 2] = f ? v.x : w[NW / 2], w[NW / 2 + 1] = f ? v.y : w[NW / 2 + 1];
-                                }
+#pragma unroll
+                                for (int k = 0; k < NW / 2; ++k)
+                                        w[NW / 2 + k] = f ? nx[k] : w[NW / 2 + k];
                                 wp += f ? 2 * NW : 0;
                                 used = f ? 0u : used;
+                                if (NW == 8) {
+                                        const u32x4_a1 v = *(const u32x4_a1 *)wp;
+                                        nx[0] = v.x, nx[1] = v.y, nx[NW / 2 - 2] = v.z, nx[NW / 2 - 1] = v.w;
+                                } else {
+                                        const u32x2_a1 v = *(const u32x2_a1 *)wp;
+                                        nx[0] = v.x, nx[1] = v.y;
+                                }
                         }
                 }
                 const uint32_t m = (uint32_t)(-(int32_t)((excmask >> i) & 1u)); // all ones at an exception
@@ -199,11 +231,18 @@ __device__ __noinline__ uint32_t fused_lookup_freq(const uint8_t *__restrict__ i
         return f & 0xffffu;
 }
 
+// Where a window-relative docID lives in acc[].  The lanes of a wave walk consecutive rows of one list, so at any moment their
+// documents sit a near-constant stride apart (64 for a list that holds every other document) — straight indexing would put the
+// wave's ds_or on a handful of LDS banks.  XOR-ing bits 6..10 into the bank bits spreads them; an involution (the source bits are
+// untouched), identity on the sink index FUS_W (a multiple of 2048).
+__device__ __forceinline__ uint32_t fused_slot(const uint32_t rel) { return rel ^ ((rel >> 6) & 31u); }
+static_assert(FUS_W % 2048 == 0, "fused_slot must map the sink index onto itself");
+
 // One posting into the window words.  rel = docID - w0 (documents below the window wrap to huge values: they and the documents
 // past the window land in the sink word); `past` keeps the smallest rel - FUS_W >= 0, i.e. the row's first document past the window.
 __device__ __forceinline__ void fused_post(uint32_t *acc, const uint32_t rel, const uint32_t f, const uint32_t cap, const uint32_t shift, uint32_t &past) {
         past = min(past, rel - FUS_W); // (in-window and below-window documents give values >= 2^31: never the minimum of a real one)
-        atomicOr(&acc[min(rel, FUS_W)], (min(f & 0xffffu, cap) + 1u) << shift);
+        atomicOr(&acc[fused_slot(min(rel, FUS_W))], (min(f & 0xffffu, cap) + 1u) << shift);
 }
 
 // One directory row (<= 32 documents) of a slot's term into the window words through the codec's general value streams: GOOGLE
@@ -242,7 +281,7 @@ __device__ __noinline__ uint32_t fused_row_streams_lucene(const uint8_t *__restr
 template <int CODEC>
 __device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t rec_x,
                                               const uint32_t rec_y, const uint32_t rec_z, const uint32_t rec_w, const uint32_t n, const uint32_t prev,
-                                              const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift, const uint32_t cap) {
+                                              const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift, const uint32_t cap PROF_ARG) {
         if (CODEC == CODEC_LUCENE) {
                 uint32_t rel = prev - w0, past = 0xffffffffu;
                 if (b >= t.npfor) { // the list's varbyte tail (lucene_codec.cpp:321-337): (delta, freq) pairs, fewer than 128 documents
@@ -259,12 +298,14 @@ __device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index,
                 PfRegs<4> rf;
                 const bool okd = rd.init(g, rec_z, b & 3u, rec_y & 0xffu, (rec_y >> 8) & 0xffu);
                 const bool okf = rf.init(g + pfor_group_bytes(rec_z), rec_w, b & 3u, (rec_y >> 16) & 0xffu, rec_y >> 24);
+                PROF_LAP(9);
                 if (okd && okf) {
 #pragma unroll 2
                         for (uint32_t i = 0; i < 32; ++i) {
                                 rel += rd.next(i);
                                 fused_post(acc, rel, rf.next(i), cap, shift, past);
                         }
+                        PROF_LAP(10);
                         return past;
                 }
                 return fused_row_streams_lucene(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
@@ -303,8 +344,143 @@ __device__ void fused_prune(FusedShared &sh, const uint32_t n, const uint32_t k)
         __syncthreads();
 }
 
+// MaxScore pruning (exact): with the slots ordered by their score bound, the longest prefix whose bounds sum to less than the current
+// k-th best cannot lift a document over the threshold on its own — only documents holding at least one of the OTHER (essential)
+// slots need a score.  Recomputed by every lane (uniform) whenever the threshold moves; no threshold yet: every slot is essential.
+__device__ __forceinline__ uint32_t fused_essential(const FusedShared &sh, const uint32_t nslots, const uint32_t fbits) {
+        if (!uni(sh.tk_full))
+                return 0xffffffffu;
+        const double thr = sh.thr_s;
+        const uint32_t fm = (1u << fbits) - 1u;
+        uint32_t done = 0, emask = 0;
+        double p = 0.0;
+        for (uint32_t r = 0; r < nslots; ++r) { // selection by ascending bound (<= 8 slots)
+                uint32_t best = 0;
+                double bv = 1e300;
+                for (uint32_t sl = 0; sl < nslots; ++sl)
+                        if (!((done >> sl) & 1u) && sh.ub[sl] < bv) {
+                                bv = sh.ub[sl];
+                                best = sl;
+                        }
+                done |= 1u << best;
+                p += bv;
+                if (!(p < thr)) // this slot (and every later one) can carry a document over the threshold
+                        emask |= fm << (best * fbits);
+        }
+        return emask;
+}
+
+// Score the documents a wave has queued (window-relative docIDs in its wlist), one per lane: table lookups, the rare exact
+// rescoring, threshold, append to the workgroup's candidate buffer.  A full buffer puts the word back for the resumed sweep.
 template <int CODEC>
-__global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+__device__ __noinline__ void fused_flush(FusedShared &sh, const uint32_t wn, const uint32_t w0, const uint32_t nch, const bool full, const double thr_s,
+                                            const uint32_t thr_d, uint32_t &my_matches, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                            const uint32_t *__restrict__ blk_off, const DevQuery &q, const uint32_t *__restrict__ sterms,
+                                            const double *__restrict__ sweights, const int sim) {
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        const DevFused &fq = sh.fq;
+        for (uint32_t c = lane; c < wn; c += 64) {
+                const uint32_t idx = sh.wlist[wv][c];
+                const uint32_t x = sh.acc[idx];
+                sh.acc[idx] = 0;
+                double s = sh.tab[0][x & 0xffu];
+                if (nch > 1)
+                        s += sh.tab[1][(x >> 8) & 0xffu];
+                if (nch > 2)
+                        s += sh.tab[2][(x >> 16) & 0xffu];
+                if (nch > 3)
+                        s += sh.tab[3][x >> 24];
+                const uint32_t doc = w0 + fused_slot(idx);
+                if (!(s == s)) { // a saturated field: rescore from the postings, scorer by scorer
+                        s = 0.0;
+                        const uint32_t fbits = fq.fbits, cap = fq.cap, fmask = (1u << fbits) - 1u;
+                        for (uint32_t si = 0; si < q.nscore; ++si) {
+                                const uint32_t term = sterms[q.score_base + si];
+                                uint32_t sl = 0;
+                                while (sl + 1 < fq.nslots && fq.term[sl] != term)
+                                        ++sl;
+                                const uint32_t code = (x >> (sl * fbits)) & fmask;
+                                if (!code)
+                                        continue;
+                                const uint32_t f = code > cap ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[sl], doc) : code - 1u;
+                                s += (double)sim_score(sim, sweights[q.score_base + si], f);
+                        }
+                }
+                if (full && !better(s, doc, thr_s, thr_d))
+                        continue;
+                const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
+                if (slot >= FUS_CAP) { // no room: the word goes back, the resumed sweep takes it again
+                        sh.overflow = 1;
+                        sh.acc[idx] = x;
+                        --my_matches;
+                        continue;
+                }
+                sh.tk_s[slot] = s;
+                sh.tk_d[slot] = doc;
+        }
+}
+
+// Sweep stage 1 over the window's words, 16 bytes per lane at a time: the CNF predicate (PK: 0 = a union — any field of the one
+// required group; 1 = up to four groups from registers, excluded fields; 2 = any number of groups, masked documents) counts the
+// matches; a match that holds an ESSENTIAL slot is queued on the wave's list, everything else is re-zeroed at once; the list is
+// scored by the wave itself when it fills and at the end (fused_flush).
+template <int CODEC, int PK>
+__device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, const uint32_t nch, const bool full, const double thr_s, const uint32_t thr_d,
+                                            const uint32_t emask, const uint32_t nmask, const uint32_t nreq, const uint32_t gm0, const uint32_t gm1,
+                                            const uint32_t gm2, const uint32_t gm3, const uint32_t *__restrict__ masked, uint32_t &my_matches,
+                                            const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+                                            const DevQuery &q, const uint32_t *__restrict__ sterms, const double *__restrict__ sweights, const int sim) {
+        const uint32_t tid = threadIdx.x, wave = uni(tid >> 6);
+        uint32_t wn = 0; // entries on this wave's list (wave-uniform)
+#pragma unroll 1
+        for (uint32_t j = 0; j < FUS_CHUNKS; ++j) { // (kept a loop: unrolled, the chunk bodies' invariants crowd the register file)
+                const uint32_t i0 = j * (4 * FUS_WG) + 4 * tid;
+                const uint4 v = *(const uint4 *)&sh.acc[i0];
+                if (__builtin_amdgcn_ballot_w64((v.x | v.y | v.z | v.w) != 0) == 0ull)
+                        continue; // nothing in this wave's slice
+                uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t c = 0; c < 4; ++c) {
+                        const uint32_t x = xs[c];
+                        bool m;
+                        if (PK == 0)
+                                m = (x & gm0) != 0;
+                        else if (PK == 1)
+                                m = (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
+                        else {
+                                m = x != 0 && (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
+                                for (uint32_t g = 4; g < nreq; ++g)
+                                        m &= (x & sh.fq.gmask[g]) != 0;
+                                if (masked && m) { // masked_documents_registry::test (docidupdates.h:90-119)
+                                        const uint32_t doc = w0 + fused_slot(i0 + c);
+                                        m = !((masked[doc >> 5] >> (doc & 31u)) & 1u);
+                                }
+                        }
+                        my_matches += m ? 1u : 0u;
+                        const bool e = m && (x & emask) != 0;
+                        const uint64_t bal = __builtin_amdgcn_ballot_w64(e);
+                        if (bal != 0ull) { // (wave-uniform)
+                                if (e)
+                                        sh.wlist[wave][wn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)(i0 + c);
+                                wn += (uint32_t)__popcll(bal);
+                        }
+                        xs[c] = e ? x : 0u; // queued words keep their code until they are scored
+                }
+                *(uint4 *)&sh.acc[i0] = make_uint4(xs[0], xs[1], xs[2], xs[3]);
+                if (wn > FUS_WLIST - 4 * 64) { // the next chunk might not fit: score what is queued
+                        __builtin_amdgcn_wave_barrier();
+                        fused_flush<CODEC>(sh, wn, w0, nch, full, thr_s, thr_d, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                        wn = 0;
+                }
+        }
+        if (wn) {
+                __builtin_amdgcn_wave_barrier();
+                fused_flush<CODEC>(sh, wn, w0, nch, full, thr_s, thr_d, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+        }
+}
+
+template <int CODEC>
+__global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void k_fused(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                      const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
                                                      const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                                                      const DevQuery *__restrict__ plan, const DevFused *__restrict__ fused,
@@ -342,13 +518,15 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                 const DevFused &fq = sh.fq;
                 const uint32_t nslots = uni(fq.nslots), fbits = uni(fq.fbits), cap = uni(fq.cap), nreq = uni(fq.nreq), nmask = uni(fq.nmask);
                 const uint32_t nch = (nslots * fbits + 7) / 8; // bytes of the word in use
-                const uint32_t kk = min(tid, nslots - 1);      // lanes >= nslots mirror the last slot
+                const uint32_t kk = min(tid & 63u, nslots - 1); // in EVERY wave lane s (< nslots) tracks slot s, the lanes above mirror the last slot:
+                                                                // a wave reads the slots' block ranges out of its own lanes (readlane), no LDS, no barrier
                 sh.term[kk] = terms[fq.term[kk]];
                 sh.hint_row[kk] = 0xffffffffu;
                 sh.tk_n = 0;
                 sh.tk_full = 0;
                 sh.overflow = 0;
                 sh.matches = 0;
+                sh.emask = 0xffffffffu; // no threshold yet: every slot is essential
                 {
                         // tab[c][v]: the fields inside byte c of the word.  code 0 = absent; code - 1 = freq; code cap + 1 = saturated
                         const uint32_t per = 8 / fbits, fmask = (1u << fbits) - 1u;
@@ -371,6 +549,14 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                                 }
                                 sh.tab[c][v] = sat ? __builtin_nan("") : s;
                         }
+                        // per slot an upper bound of what it can add: BM25 float(w f / (f + 1.2)) < w; TF-IDF sqrt(f) w with f <= 65535; Trivial f
+                        double ubs = 0.0;
+                        for (uint32_t si = 0; si < q.nscore; ++si)
+                                if (sterms[q.score_base + si] == fq.term[kk]) {
+                                        const double wgt = sweights[q.score_base + si];
+                                        ubs += sim == TRI_SIM_TRIVIAL ? 65535.0 : sim == TRI_SIM_TFIDF ? (wgt > 0 ? 256.0 * wgt : 0.0) : (wgt > 0 ? wgt : 0.0);
+                                }
+                        sh.ub[kk] = ubs * (1.0 + 1e-6);
                 }
                 __syncthreads();
                 const DevTerm myt = sh.term[kk];
@@ -396,14 +582,19 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                         }
                         cur = lo;
                 }
+                // (short lists: the cursor's block bounds are kept in registers — the directory is read when the cursor moves, not per window)
+                uint32_t cur_last = (!indexed && cur < myt.nblocks) ? mybl[cur] : 0xffffffffu, cur_prev = (!indexed && cur) ? mybl[cur - 1] : 0u;
                 // the first four required groups' masks live in registers (a missing group tests true on any non-zero word)
                 const uint32_t gm0 = uni(fq.gmask[0]), gm1 = nreq > 1 ? uni(fq.gmask[1]) : 0xffffffffu, gm2 = nreq > 2 ? uni(fq.gmask[2]) : 0xffffffffu,
                                gm3 = nreq > 3 ? uni(fq.gmask[3]) : 0xffffffffu;
+                const uint32_t gsl0 = uni(fq.gslots[0]), gsl1 = nreq > 1 ? uni(fq.gslots[1]) : 0u, gsl2 = nreq > 2 ? uni(fq.gslots[2]) : 0u,
+                               gsl3 = nreq > 3 ? uni(fq.gslots[3]) : 0u; // (an absent group has no slots: its "next possible" would be "never" — skipped below)
                 uint32_t my_matches = 0;
                 PROF_LAP(0);
                 while (w < task.tile_end) {
                         const uint32_t w0 = w * FUS_W, wlast = w0 + (FUS_W - 1);
                         // ---- my slot's blocks that can hold documents of [w0, wlast], and the first docID >= w0 it may still hold
+                        uint32_t my_lo, my_cnt, my_np;
                         {
                                 uint32_t b_lo, b_hi, np = 0xffffffffu;
                                 bool here = false;
@@ -412,11 +603,15 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                                         b_hi = min(e_hi, myt.nblocks - 1);
                                         here = e_lo != e_hi; // a block ends inside the window
                                 } else {
-                                        while (cur < myt.nblocks && mybl[cur] < w0)
+                                        while (cur < myt.nblocks && cur_last < w0) {
                                                 ++cur;
+                                                cur_prev = cur_last;
+                                                cur_last = cur < myt.nblocks ? mybl[cur] : 0xffffffffu;
+                                        }
                                         b_lo = b_hi = cur;
-                                        while (b_hi + 1 < myt.nblocks && mybl[b_hi] < wlast)
-                                                ++b_hi;
+                                        if (cur_last < wlast) // (rare for a short list: further blocks end inside the window)
+                                                while (b_hi + 1 < myt.nblocks && mybl[b_hi] < wlast)
+                                                        ++b_hi;
                                 }
                                 uint32_t cnt = 0;
                                 if (b_lo < myt.nblocks) {
@@ -427,31 +622,34 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                                                 if (hd > wlast)
                                                         cnt = 0; // ... and lies past this window: the row (and with it the list) has nothing here
                                         } else {
-                                                const uint32_t first_possible = here ? w0 : (b_lo ? mybl[b_lo - 1] + 1 : 1u);
+                                                const uint32_t first_possible = here ? w0 : !indexed ? cur_prev + 1 : (b_lo ? mybl[b_lo - 1] + 1 : 1u);
                                                 np = max(w0, first_possible);
                                         }
                                 }
-                                sh.seg_lo[kk] = b_lo;
-                                sh.seg_cnt[kk] = cnt;
-                                sh.seg_np[kk] = np;
+                                my_lo = b_lo;
+                                my_cnt = cnt;
+                                my_np = np;
                         }
-                        sh.seg_cnt[nslots] = 0xffffffffu; // sentinel: the lane-to-slot walk stops here
-                        __syncthreads();
-                        // ---- no match before the latest "first possible document" over the required groups (a group: its earliest slot)
+                        // ---- every wave gathers the slots' ranges from its own lanes: no match before the latest "first possible document"
+                        //      over the required groups (a group: its earliest slot)
+                        uint32_t s_lo[FUS_MAX_SLOTS], s_cnt[FUS_MAX_SLOTS], s_np[FUS_MAX_SLOTS], total = 0;
+#pragma unroll
+                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                                const bool on = s < nslots;
+                                s_lo[s] = (uint32_t)__builtin_amdgcn_readlane((int)my_lo, (int)s);
+                                s_cnt[s] = on ? (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (int)s) : 0u;
+                                s_np[s] = on ? (uint32_t)__builtin_amdgcn_readlane((int)my_np, (int)s) : 0xffffffffu;
+                                total += s_cnt[s];
+                        }
                         uint32_t need = 0;
                         for (uint32_t g = 0; g < nreq; ++g) {
+                                const uint32_t gs = g == 0 ? gsl0 : g == 1 ? gsl1 : g == 2 ? gsl2 : g == 3 ? gsl3 : uni(fq.gslots[g]);
                                 uint32_t gnp = 0xffffffffu;
-                                for (uint32_t s = 0; s < nslots; ++s)
-                                        if ((fq.gslots[g] >> s) & 1u)
-                                                gnp = min(gnp, sh.seg_np[s]);
+#pragma unroll
+                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                        gnp = ((gs >> s) & 1u) ? min(gnp, s_np[s]) : gnp;
                                 need = max(need, gnp);
                         }
-                        need = uni(need);
-                        uint32_t total = 0;
-                        for (uint32_t s = 0; s < nslots; ++s)
-                                total += sh.seg_cnt[s];
-                        total = uni(total);
-                        __syncthreads(); // seg_* are rewritten when the window moves
                         if (need == 0xffffffffu)
                                 break; // a required group is exhausted: no further match anywhere
                         const uint32_t wnext = need / FUS_W;
@@ -469,24 +667,32 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                         for (uint32_t v0 = 0; v0 < total; v0 += FUS_WG) {
                                 const uint32_t v = v0 + tid;
                                 if (v < total) {
-                                        uint32_t s = 0, r = v;
-                                        for (uint32_t c = sh.seg_cnt[s]; r >= c; c = sh.seg_cnt[s]) {
-                                                r -= c;
-                                                ++s;
+                                        uint32_t s = 0, r = v, lo = s_lo[0];
+#pragma unroll
+                                        for (uint32_t k2 = 0; k2 + 1 < FUS_MAX_SLOTS; ++k2) { // which slot's rows v falls into (ranges are wave-uniform)
+                                                const bool nextslot = s == k2 && r >= s_cnt[k2];
+                                                r = nextslot ? r - s_cnt[k2] : r;
+                                                lo = nextslot ? s_lo[k2 + 1] : lo;
+                                                s = nextslot ? k2 + 1 : s;
                                         }
                                         const DevTerm t = sh.term[s];
-                                        const uint32_t b = sh.seg_lo[s] + r;
+                                        const uint32_t b = lo + r;
                                         const uint32_t *bl = blk_last + t.first_block;
                                         const uint32_t prev = b ? bl[b - 1] : 0;
                                         const uint32_t last = bl[b];
                                         uint32_t past;
                                         if (CODEC == CODEC_LUCENE) {
                                                 const uint4 rec = blk_rec[t.first_block + b];
+#ifdef TRI_PROF
+                                                if (rec.x + prev + last == 0xfffffff0u) // (probe builds: the record has arrived when the lap is taken)
+                                                        sh.bcast[3] = 1;
+                                                PROF_LAP(8);
+#endif
                                                 past = fused_row<CODEC>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, sh.acc,
-                                                                        s * fbits, cap);
+                                                                        s * fbits, cap PROF_PASS);
                                         } else {
                                                 const uint32_t off = blk_off[t.first_block + b];
-                                                past = fused_row<CODEC>(index, t, b, off, 0, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, sh.acc, s * fbits, cap);
+                                                past = fused_row<CODEC>(index, t, b, off, 0, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, sh.acc, s * fbits, cap PROF_PASS);
                                         }
                                         if (past < 0x80000000u) { // the row reaches past the window (it is the slot's last row here): leave the hint
                                                 sh.hint_row[s] = b;
@@ -503,107 +709,34 @@ __global__ __launch_bounds__(FUS_WG, 4) void k_fused(const uint8_t *__restrict__
                         PROF_LAP(2);
                         __syncthreads();
                         PROF_LAP(3);
-                        // ---- sweep: predicate, score, threshold; re-zero.  Words are taken in batches (independent LDS reads, then
-                        //      independent table lookups); the rare candidate is appended to the buffer; a full buffer is pruned and the
-                        //      sweep resumed over the words that were put back.
+                        // ---- sweep, stage 1 per 16-byte chunk: the CNF predicate counts the matches; a match that holds an ESSENTIAL slot is
+                        //      queued on the wave's list (everything else is re-zeroed at once); the list is scored by the wave itself when
+                        //      it fills and at the end (fused_flush), so only documents that can beat the threshold ever pay the table
+                        //      lookups.  A full candidate buffer is pruned and the sweep resumed over the words that were put back.
                         for (;;) {
                                 const bool full = uni(sh.tk_full) != 0;
                                 const double thr_s = sh.thr_s;
                                 const uint32_t thr_d = sh.thr_d;
-                                for (uint32_t jb = 0; jb < FUS_WPT; jb += FUS_SWB) {
-                                        uint32_t x[FUS_SWB];
-                                        uint32_t any = 0;
-#pragma unroll
-                                        for (uint32_t u = 0; u < FUS_SWB; ++u) {
-                                                x[u] = sh.acc[(jb + u) * FUS_WG + tid];
-                                                any |= x[u];
-                                        }
-                                        if (__builtin_amdgcn_ballot_w64(any != 0) == 0ull)
-                                                continue; // nothing in this wave's slice of the batch
-                                        double sc[FUS_SWB];
-                                        uint32_t mm = 0;
-#pragma unroll
-                                        for (uint32_t u = 0; u < FUS_SWB; ++u) {
-                                                sh.acc[(jb + u) * FUS_WG + tid] = 0;
-                                                bool m = x[u] != 0 && (x[u] & nmask) == 0 && (x[u] & gm0) && (x[u] & gm1) && (x[u] & gm2) && (x[u] & gm3);
-                                                for (uint32_t g = 4; g < nreq; ++g)
-                                                        m &= (x[u] & fq.gmask[g]) != 0;
-                                                mm |= (m ? 1u : 0u) << u;
-                                                sc[u] = sh.tab[0][x[u] & 0xffu];
-                                        }
-                                        if (nch > 1) {
-#pragma unroll
-                                                for (uint32_t u = 0; u < FUS_SWB; ++u)
-                                                        sc[u] += sh.tab[1][(x[u] >> 8) & 0xffu];
-                                        }
-                                        if (nch > 2) {
-#pragma unroll
-                                                for (uint32_t u = 0; u < FUS_SWB; ++u)
-                                                        sc[u] += sh.tab[2][(x[u] >> 16) & 0xffu];
-                                        }
-                                        if (nch > 3) {
-#pragma unroll
-                                                for (uint32_t u = 0; u < FUS_SWB; ++u)
-                                                        sc[u] += sh.tab[3][x[u] >> 24];
-                                        }
-                                        if (masked && mm) { // masked_documents_registry::test (docidupdates.h:90-119)
-#pragma unroll
-                                                for (uint32_t u = 0; u < FUS_SWB; ++u) {
-                                                        const uint32_t doc = w0 + (jb + u) * FUS_WG + tid;
-                                                        if (((mm >> u) & 1u) && ((masked[doc >> 5] >> (doc & 31u)) & 1u))
-                                                                mm &= ~(1u << u);
-                                                }
-                                        }
-                                        my_matches += __popc(mm);
-                                        uint32_t cand = 0;
-#pragma unroll
-                                        for (uint32_t u = 0; u < FUS_SWB; ++u) {
-                                                const uint32_t doc = w0 + (jb + u) * FUS_WG + tid;
-                                                const bool c = ((mm >> u) & 1u) && (!full || !(sc[u] == sc[u]) || better(sc[u], doc, thr_s, thr_d));
-                                                cand |= (c ? 1u : 0u) << u;
-                                        }
-                                        if (__builtin_amdgcn_ballot_w64(cand != 0) == 0ull)
-                                                continue;
-#pragma unroll
-                                        for (uint32_t u = 0; u < FUS_SWB; ++u) {
-                                                if (!((cand >> u) & 1u))
-                                                        continue;
-                                                const uint32_t doc = w0 + (jb + u) * FUS_WG + tid;
-                                                double s = sc[u];
-                                                if (!(s == s)) { // a saturated field: rescore from the postings, scorer by scorer
-                                                        s = 0.0;
-                                                        const uint32_t fmask = (1u << fbits) - 1u;
-                                                        for (uint32_t si = 0; si < q.nscore; ++si) {
-                                                                const uint32_t term = sterms[q.score_base + si];
-                                                                uint32_t sl = 0;
-                                                                while (sl + 1 < nslots && fq.term[sl] != term)
-                                                                        ++sl;
-                                                                const uint32_t code = (x[u] >> (sl * fbits)) & fmask;
-                                                                if (!code)
-                                                                        continue;
-                                                                const uint32_t f = code > cap ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[sl], doc) : code - 1u;
-                                                                s += (double)sim_score(sim, sweights[q.score_base + si], f);
-                                                        }
-                                                        if (full && !better(s, doc, thr_s, thr_d))
-                                                                continue;
-                                                }
-                                                const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
-                                                if (slot >= FUS_CAP) { // no room: the word goes back, the resumed sweep takes it again
-                                                        sh.overflow = 1;
-                                                        sh.acc[(jb + u) * FUS_WG + tid] = x[u];
-                                                        --my_matches;
-                                                        continue;
-                                                }
-                                                sh.tk_s[slot] = s;
-                                                sh.tk_d[slot] = doc;
-                                        }
-                                }
+                                const uint32_t emask = uni(sh.emask);
+                                // the predicate in its cheapest form for the query at hand (uniform): one required group and nothing excluded (a
+                                // union: any of its fields), up to four groups from registers, or the general walk with masked documents on top
+                                if (!masked && nreq == 1 && nmask == 0)
+                                        fused_sweep<CODEC, 0>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                else if (!masked && nreq <= 4)
+                                        fused_sweep<CODEC, 1>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                else
+                                        fused_sweep<CODEC, 2>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                PROF_LAP(6);
                                 __syncthreads();
+                                PROF_LAP(7);
                                 const uint32_t ov = uni(sh.overflow);
                                 const uint32_t n = min(uni(sh.tk_n), FUS_CAP);
-                                __syncthreads();
-                                if (ov || n > (FUS_CAP + k) / 2)
+                                if (ov || n > (FUS_CAP + k) / 2) {
+                                        __syncthreads(); // (every lane has read overflow / tk_n)
                                         fused_prune(sh, n, k);
+                                        sh.emask = fused_essential(sh, nslots, fbits); // same value from every lane
+                                        __syncthreads();
+                                }
                                 if (!ov)
                                         break;
                         }

@@ -1281,7 +1281,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         last_doc = std::min(last_doc, glast);
                 dense &= sumdf >= DENSE_MIN_POSTINGS;
                 dense |= nlead > 1;
-                const bool fuse = dense && t.fusable;
+                const bool fuse = dense && t.fusable && (dev->opt.fused != 2 || t.fz.nreq == 1); // (fused == 2: only pure unions)
                 if (fuse) {
                         // every list of the slot map is read once (the optional terms too)
                         uint64_t slotdf = 0;
@@ -1486,8 +1486,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 }
                 HIP_TRY(hipEventRecord(b->ev_b, dev->stream));
                 if (b->n_fused) {
-                        // AccumulatedScore top-K of the dense queries: decode -> match -> score -> select in one pass, two workgroups per CU
-                        TRI_LAUNCH(k_fused, b->ix->codec, dim3(std::min<uint32_t>(b->n_fused, (uint32_t)dev->cus * 2)), dim3(FUS_WG), dev->stream, b->ix->d_index,
+                        // AccumulatedScore top-K of the dense queries: decode -> match -> score -> select in one pass; as many workgroups per CU as its LDS holds
+                        TRI_LAUNCH(k_fused, b->ix->codec, dim3(std::min<uint32_t>(b->n_fused, (uint32_t)dev->cus * FUS_WGS_PER_CU)), dim3(FUS_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks,
                                            b->d_sched + b->n_dense + b->n_cand, b->d_sterms, b->d_sweights, b->n_fused, b->d_ticket + 56, b->d_counts, b->topk,
                                            b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked, b->similarity);
