@@ -1,0 +1,119 @@
+"""Full-size GPU parity (run with -m gpu on an MI355X): the 10M-document / 1M-term segment BASELINE.json's metric is quoted on.
+
+Per QUERY, not in aggregate: match counts and FNV-1a of the docID set (DocumentsOnly; tri_batch_docset_hashes hashes the device
+results without copying the sets back), top-K docID lists and scores (AccumulatedScore), against the CPU oracle on the same
+segment bytes.  The samples cover both matching kernels of cfg2 (head x head pairs run as bitmap windows, Zipf pairs mostly as
+candidate tiles), cfg4's phrases, and cfg3's 5-term mixes through the one-pass scored kernel on both codecs."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+D, V = 10_000_000, 1_000_000
+
+
+@pytest.fixture(scope="module")
+def T():
+    import trinity_amd
+
+    trinity_amd.build_all()
+    return trinity_amd
+
+
+@pytest.fixture(scope="module")
+def dev(T):
+    d = T.Device(0)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def google(T, dev):
+    seg = T.Segment(D, V, 10, 42)
+    ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
+    ix = T.Index.from_segment(dev, seg)
+    yield seg, ora, ix
+    ix.close()
+
+
+@pytest.fixture(scope="module")
+def lucene(T, dev):
+    seg = T.Segment(D, V, 10, 42, codec=2)
+    ora = O.Index.generate(D, V, 10, 42, codec="lucene")
+    ix = T.Index.from_segment(dev, seg)
+    yield seg, ora, ix
+    ix.close()
+
+
+def check_docsets(T, ix, ora, progs, want_classes=()):
+    b = T.Batch(ix, progs, T.FLAG_DOCUMENTS_ONLY)
+    b.run()
+    b.sync()
+    counts, hashes, info = b.counts(), b.docset_hashes(), b.info()
+    b.close()
+    for name in want_classes:
+        assert info[name] > 0, (name, info)
+    total = 0
+    for i, p in enumerate(progs):
+        docs, _ = ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+        assert int(counts[i]) == len(docs), (i, p.tolist(), int(counts[i]), len(docs))
+        assert int(hashes[i]) == O.fnv1a_docs(docs), (i, p.tolist())
+        total += len(docs)
+    return total
+
+
+def check_scored(T, ix, ora, progs, k, want_fused=True):
+    b = T.Batch(ix, progs, T.FLAG_ACCUMULATED_SCORE, topk=k)
+    b.run()
+    b.sync()
+    counts, (d, s, c), info = b.counts(), b.topk_results(), b.info()
+    b.close()
+    if want_fused:
+        assert info["fused_queries"] > 0, info
+    for i, p in enumerate(progs):
+        docs, scores = ora.exec(p, O.FLAG_ACCUM_SCORE)
+        assert int(counts[i]) == len(docs), (i, p.tolist(), int(counts[i]), len(docs))
+        td, ts = ora.topk(docs, scores, k)
+        assert int(c[i]) == len(td), (i, p.tolist())
+        assert d[i, : len(td)].tolist() == td.tolist(), (i, p.tolist())
+        np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+
+
+def test_cfg2_per_query_counts_and_hashes(T, google):
+    """256 queries of the bench's own workload shape: 64 head x head pairs (TASK_DENSE: bitmap windows, millions of matches each)
+    and 192 Zipf-drawn pairs of the cfg2 generator (mostly TASK_CAND: galloping / block-driven candidate tiles)."""
+    from trinity_amd import workloads as W
+
+    seg, ora, ix = google
+    rng = np.random.default_rng(11)
+    heads = [tuple(int(x) for x in rng.choice(24, 2, replace=False)) for _ in range(64)]
+    progs = W.and2(heads) + W.and2(T.gen_queries(V, 1337, 16384, 2)[:192])
+    total = check_docsets(T, ix, ora, progs, want_classes=("dense_queries", "cand_queries"))
+    assert total > 50_000_000
+
+
+def test_cfg4_phrases_per_query(T, google):
+    seg, ora, ix = google
+    from trinity_amd import workloads as W
+
+    progs, _, _, _, _ = W.build("cfg4", D, V, 10, 42, 96)
+    assert check_docsets(T, ix, ora, progs) > 0
+
+
+def test_cfg3_scored_lucene_per_query(T, lucene):
+    """cfg3's four 5-term shapes on the lucene_codec segment, BM25 top-100: the one-pass scored kernel (unions, CNFs) and the
+    candidate-tile + scoring path (sparse leads) at full size, plus the heaviest unions there are (the five head terms)."""
+    from trinity_amd import workloads as W
+
+    seg, ora, ix = lucene
+    progs = W.mixed5(T.gen_queries(V, 1337, 8192, 5)[:64]) + [O.parse_query(t) for t in ("t0 OR t1 OR t2 OR t3 OR t4", "t0 t1 (t2 OR t3 OR t4)", "(t0 OR t1) (t2 OR t3) t4", "t0 t1 t2 t3 t4")]
+    check_scored(T, ix, ora, progs, 100)
+
+
+def test_cfg3_scored_google_per_query(T, google):
+    seg, ora, ix = google
+    from trinity_amd import workloads as W
+
+    progs = W.mixed5(T.gen_queries(V, 1338, 8192, 5)[:32]) + [O.parse_query(t) for t in ("t0 OR t1 OR t2 OR t3 OR t4", "t0 t1")]
+    check_scored(T, ix, ora, progs, 10)
