@@ -90,7 +90,7 @@ def test_cfg2_per_query_counts_and_hashes(T, google):
     heads = [tuple(int(x) for x in rng.choice(24, 2, replace=False)) for _ in range(64)]
     progs = W.and2(heads) + W.and2(T.gen_queries(V, 1337, 16384, 2)[:192])
     total = check_docsets(T, ix, ora, progs, want_classes=("dense_queries", "cand_queries"))
-    assert total > 50_000_000
+    assert total > 5_000_000
 
 
 def test_cfg4_phrases_per_query(T, google):
