@@ -89,8 +89,7 @@ __device__ __forceinline__ uint32_t pfor_group_bytes(const uint32_t hdr) {
 template <int NW>
 struct PfRegs {
         uint32_t w[NW];
-        uint32_t nx[NW / 2]; // wide quarters: the NW / 2 words that follow the queue, fetched a refill ahead
-        const uint8_t *wp;   // ... and where they came from
+        const uint8_t *wp; // wide quarters: the NW / 2 words that follow the queue
         uint32_t sh, b, mask, excmask, eb, emask, used;
         uint64_t hq;
         // g: the group's first byte; hdr: its header word (row record); e0 / cnt: the quarter's run of the exception list.
@@ -108,9 +107,6 @@ struct PfRegs {
 #pragma unroll
                         for (int k = 1; k < NW; ++k)
                                 w[k] = 0;
-#pragma unroll
-                        for (int k = 0; k < NW / 2; ++k)
-                                nx[k] = 0;
                         b = 0;
                         mask = 0xffffffffu;
                         return true;
@@ -128,18 +124,6 @@ struct PfRegs {
                         w[k] = v.x, w[k + 1] = v.y, w[k + 2] = v.z, w[k + 3] = v.w;
                 }
                 wp = q0 + 4 * NW;
-#pragma unroll
-                for (int k = 0; k < NW / 2; ++k)
-                        nx[k] = 0;
-                if (__builtin_amdgcn_ballot_w64(b > NW) != 0ull) { // (wave-uniform: only waves that hold a wide quarter pay the extra load)
-                        if (NW == 8) {
-                                const u32x4_a1 v = *(const u32x4_a1 *)wp;
-                                nx[0] = v.x, nx[1] = v.y, nx[NW / 2 - 2] = v.z, nx[NW / 2 - 1] = v.w;
-                        } else {
-                                const u32x2_a1 v = *(const u32x2_a1 *)wp;
-                                nx[0] = v.x, nx[1] = v.y;
-                        }
-                }
                 if (cnt) {
                         emask = eb >= 32 ? 0xffffffffu : ((1u << eb) - 1u);
                         const uint8_t *epos = g + 5 + 16 * b;
@@ -173,23 +157,17 @@ struct PfRegs {
                                 w[k] = r ? w[k + 1] : w[k];
                         sh = r ? sh - 32 : sh;
                         used += r ? 1u : 0u;
-                        const bool f = r && used == NW / 2 && b > NW; // a wide quarter has moved half a queue: the prefetched words take
-                                                                      // the upper half, the next ones are requested — nothing waits on memory here:
-                                                                      // every lane of the wave re-loads nx (a lane that did not move re-reads the
-                                                                      // same words), so the loaded values are first touched a refill later
+                        const bool f = r && used == NW / 2 && b > NW; // a wide quarter has moved half a queue: fetch the next half
                         if (__builtin_amdgcn_ballot_w64(f) != 0ull) {
-#pragma unroll
-                                for (int k = 0; k < NW / 2; ++k)
-                                        w[NW / 2 + k] = f ? nx[k] : w[NW / 2 + k];
-                                wp += f ? 2 * NW : 0;
-                                used = f ? 0u : used;
                                 if (NW == 8) {
-                                        const u32x4_a1 v = *(const u32x4_a1 *)wp;
-                                        nx[0] = v.x, nx[1] = v.y, nx[NW / 2 - 2] = v.z, nx[NW / 2 - 1] = v.w;
+                                        const u32x4_a1 v = *(const u32x4_a1 *)wp; // (lanes that do not need it read a valid address and drop it)
+                                        w[4] = f ? v.x : w[4], w[5] = f ? v.y : w[5], w[6] = f ? v.z : w[6], w[7] = f ? v.w : w[7];
                                 } else {
                                         const u32x2_a1 v = *(const u32x2_a1 *)wp;
-                                        nx[0] = v.x, nx[1] = v.y;
+                                        w[NW / 2] = f ? v.x : w[NW / 2], w[NW / 2 + 1] = f ? v.y : w[NW / 2 + 1];
                                 }
+                                wp += f ? 2 * NW : 0;
+                                used = f ? 0u : used;
                         }
                 }
                 const uint32_t m = (uint32_t)(-(int32_t)((excmask >> i) & 1u)); // all ones at an exception
@@ -374,50 +352,57 @@ __device__ __forceinline__ uint32_t fused_essential(const FusedShared &sh, const
 // rescoring, threshold, append to the workgroup's candidate buffer.  A full buffer puts the word back for the resumed sweep.
 template <int CODEC>
 __device__ __noinline__ void fused_flush(FusedShared &sh, const uint32_t wn, const uint32_t w0, const uint32_t nch, const bool full, const double thr_s,
-                                            const uint32_t thr_d, uint32_t &my_matches, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                            const uint32_t thr_d, uint32_t &wave_matches, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                             const uint32_t *__restrict__ blk_off, const DevQuery &q, const uint32_t *__restrict__ sterms,
                                             const double *__restrict__ sweights, const int sim) {
         const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
         const DevFused &fq = sh.fq;
-        for (uint32_t c = lane; c < wn; c += 64) {
-                const uint32_t idx = sh.wlist[wv][c];
-                const uint32_t x = sh.acc[idx];
-                sh.acc[idx] = 0;
-                double s = sh.tab[0][x & 0xffu];
-                if (nch > 1)
-                        s += sh.tab[1][(x >> 8) & 0xffu];
-                if (nch > 2)
-                        s += sh.tab[2][(x >> 16) & 0xffu];
-                if (nch > 3)
-                        s += sh.tab[3][x >> 24];
-                const uint32_t doc = w0 + fused_slot(idx);
-                if (!(s == s)) { // a saturated field: rescore from the postings, scorer by scorer
-                        s = 0.0;
-                        const uint32_t fbits = fq.fbits, cap = fq.cap, fmask = (1u << fbits) - 1u;
-                        for (uint32_t si = 0; si < q.nscore; ++si) {
-                                const uint32_t term = sterms[q.score_base + si];
-                                uint32_t sl = 0;
-                                while (sl + 1 < fq.nslots && fq.term[sl] != term)
-                                        ++sl;
-                                const uint32_t code = (x >> (sl * fbits)) & fmask;
-                                if (!code)
-                                        continue;
-                                const uint32_t f = code > cap ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[sl], doc) : code - 1u;
-                                s += (double)sim_score(sim, sweights[q.score_base + si], f);
+        uint32_t nback = 0; // documents put back (wave-uniform: counted where the whole wave has reconverged)
+        for (uint32_t c0 = 0; c0 < wn; c0 += 64) {
+                const uint32_t c = c0 + lane;
+                bool back = false;
+                if (c < wn) {
+                        const uint32_t idx = sh.wlist[wv][c];
+                        const uint32_t x = sh.acc[idx];
+                        sh.acc[idx] = 0;
+                        double s = sh.tab[0][x & 0xffu];
+                        if (nch > 1)
+                                s += sh.tab[1][(x >> 8) & 0xffu];
+                        if (nch > 2)
+                                s += sh.tab[2][(x >> 16) & 0xffu];
+                        if (nch > 3)
+                                s += sh.tab[3][x >> 24];
+                        const uint32_t doc = w0 + fused_slot(idx);
+                        if (!(s == s)) { // a saturated field: rescore from the postings, scorer by scorer
+                                s = 0.0;
+                                const uint32_t fbits = fq.fbits, cap = fq.cap, fmask = (1u << fbits) - 1u;
+                                for (uint32_t si = 0; si < q.nscore; ++si) {
+                                        const uint32_t term = sterms[q.score_base + si];
+                                        uint32_t sl = 0;
+                                        while (sl + 1 < fq.nslots && fq.term[sl] != term)
+                                                ++sl;
+                                        const uint32_t code = (x >> (sl * fbits)) & fmask;
+                                        if (!code)
+                                                continue;
+                                        const uint32_t f = code > cap ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[sl], doc) : code - 1u;
+                                        s += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                }
+                        }
+                        if (!full || better(s, doc, thr_s, thr_d)) {
+                                const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
+                                if (slot >= FUS_CAP) { // no room: the word goes back, the resumed sweep takes (and counts) it again
+                                        back = true;
+                                        sh.overflow = 1;
+                                        sh.acc[idx] = x;
+                                } else {
+                                        sh.tk_s[slot] = s;
+                                        sh.tk_d[slot] = doc;
+                                }
                         }
                 }
-                if (full && !better(s, doc, thr_s, thr_d))
-                        continue;
-                const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
-                if (slot >= FUS_CAP) { // no room: the word goes back, the resumed sweep takes it again
-                        sh.overflow = 1;
-                        sh.acc[idx] = x;
-                        --my_matches;
-                        continue;
-                }
-                sh.tk_s[slot] = s;
-                sh.tk_d[slot] = doc;
+                nback += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(back));
         }
+        wave_matches -= nback;
 }
 
 // Sweep stage 1 over the window's words, 16 bytes per lane at a time: the CNF predicate (PK: 0 = a union — any field of the one
@@ -427,7 +412,7 @@ __device__ __noinline__ void fused_flush(FusedShared &sh, const uint32_t wn, con
 template <int CODEC, int PK>
 __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, const uint32_t nch, const bool full, const double thr_s, const uint32_t thr_d,
                                             const uint32_t emask, const uint32_t nmask, const uint32_t nreq, const uint32_t gm0, const uint32_t gm1,
-                                            const uint32_t gm2, const uint32_t gm3, const uint32_t *__restrict__ masked, uint32_t &my_matches,
+                                            const uint32_t gm2, const uint32_t gm3, const uint32_t *__restrict__ masked, uint32_t &wave_matches,
                                             const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
                                             const DevQuery &q, const uint32_t *__restrict__ sterms, const double *__restrict__ sweights, const int sim) {
         const uint32_t tid = threadIdx.x, wave = uni(tid >> 6);
@@ -456,7 +441,7 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                                         m = !((masked[doc >> 5] >> (doc & 31u)) & 1u);
                                 }
                         }
-                        my_matches += m ? 1u : 0u;
+                        wave_matches += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(m)); // (wave-uniform counter: scalar registers)
                         const bool e = m && (x & emask) != 0;
                         const uint64_t bal = __builtin_amdgcn_ballot_w64(e);
                         if (bal != 0ull) { // (wave-uniform)
@@ -469,13 +454,13 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                 *(uint4 *)&sh.acc[i0] = make_uint4(xs[0], xs[1], xs[2], xs[3]);
                 if (wn > FUS_WLIST - 4 * 64) { // the next chunk might not fit: score what is queued
                         __builtin_amdgcn_wave_barrier();
-                        fused_flush<CODEC>(sh, wn, w0, nch, full, thr_s, thr_d, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                        fused_flush<CODEC>(sh, wn, w0, nch, full, thr_s, thr_d, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
                         wn = 0;
                 }
         }
         if (wn) {
                 __builtin_amdgcn_wave_barrier();
-                fused_flush<CODEC>(sh, wn, w0, nch, full, thr_s, thr_d, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                fused_flush<CODEC>(sh, wn, w0, nch, full, thr_s, thr_d, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
         }
 }
 
@@ -589,7 +574,7 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                gm3 = nreq > 3 ? uni(fq.gmask[3]) : 0xffffffffu;
                 const uint32_t gsl0 = uni(fq.gslots[0]), gsl1 = nreq > 1 ? uni(fq.gslots[1]) : 0u, gsl2 = nreq > 2 ? uni(fq.gslots[2]) : 0u,
                                gsl3 = nreq > 3 ? uni(fq.gslots[3]) : 0u; // (an absent group has no slots: its "next possible" would be "never" — skipped below)
-                uint32_t my_matches = 0;
+                uint32_t wave_matches = 0; // matches this wave has counted (wave-uniform)
                 PROF_LAP(0);
                 while (w < task.tile_end) {
                         const uint32_t w0 = w * FUS_W, wlast = w0 + (FUS_W - 1);
@@ -721,11 +706,11 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                 // the predicate in its cheapest form for the query at hand (uniform): one required group and nothing excluded (a
                                 // union: any of its fields), up to four groups from registers, or the general walk with masked documents on top
                                 if (!masked && nreq == 1 && nmask == 0)
-                                        fused_sweep<CODEC, 0>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        fused_sweep<CODEC, 0>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
                                 else if (!masked && nreq <= 4)
-                                        fused_sweep<CODEC, 1>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        fused_sweep<CODEC, 1>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
                                 else
-                                        fused_sweep<CODEC, 2>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, my_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        fused_sweep<CODEC, 2>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
                                 PROF_LAP(6);
                                 __syncthreads();
                                 PROF_LAP(7);
@@ -746,7 +731,7 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 // ---- the task's result: its best k (ranked) and its match count
                 __syncthreads();
                 fused_prune(sh, min(uni(sh.tk_n), FUS_CAP), k);
-                atomicAdd(&sh.matches, my_matches); // (every lane: no single-lane branch)
+                atomicAdd(&sh.matches, (tid & 63u) == 0 ? wave_matches : 0u); // (every lane issues it: no single-lane branch)
                 __syncthreads();
                 const uint32_t n = uni(sh.tk_n);
                 for (uint32_t i = tid; i < n; i += FUS_WG) {
