@@ -70,7 +70,7 @@ def main():
 
     dist = None
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run: the result gather runs even with one rank
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -150,6 +150,20 @@ def main():
     else:
         matches_all, alg_all = tot["matches"], tot["algorithmic_bytes"]
 
+    gather_check = None
+    if dist is not None:
+        # what arrived in this rank's slot of every gathered block is what the engine reports locally (host copies through the C-ABI)
+        ok = True
+        for b, g in zip(batches, gathers):
+            ok &= bool(np.array_equal(g.recv["counts"][rank].cpu().numpy().astype(np.uint64), b.counts()))
+            if "docs" in g.recv:
+                d, s_, c = b.topk_results()
+                ok &= bool(np.array_equal(g.recv["docs"][rank].cpu().numpy().view(np.uint32), d) and np.array_equal(g.recv["scores"][rank].cpu().numpy(), s_)
+                           and np.array_equal(g.recv["topk_counts"][rank].cpu().numpy().view(np.uint32), c))  # fmt: skip
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        gather_check = {"ranks": world, "blocks": sorted({k for g in gathers for k in g.recv}), "equal_on_every_rank": bool(t.item() == 1.0)}
+
     if rank == 0:
         steps = max(1, args.steps)
         ms_per_step = elapsed * 1e3 / steps
@@ -214,6 +228,8 @@ def main():
             "segment_build_s": build_s,
             "index_upload_s": upload_s,
         }
+        if gather_check is not None:
+            out["gather_check"] = gather_check
         if args.cpu_seconds > 0:
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(segs, parts, shard_progs, batches, args.cpu_seconds)
         print(json.dumps(out), flush=True)
