@@ -15,6 +15,12 @@
 //   positions <term> <everyNth>    -> {fnv} materialize_hits positions of every Nth document
 //   query <flags> <k> <text…>      -> {n, fnv, first[], last[], score_sum, top[[doc,score]…]}  exec_query()
 //   queryfull <flags> <text…>      -> as query plus full docs[] (+scores[])
+//   hits <term>                    -> {docs, fnv} every document's (doc, freq, {pos, payloadLen, payload}…) via materialize_hits
+//
+// `ref_driver edge` (instead of D V slots seed) indexes the EDGE corpus below — a few thousand hand-shaped documents over 8 terms
+// that put the codec's corner cases into reference-produced bytes: hits with payloads of changing and of constant length, a
+// position-0 hit that carries a payload (counted) and one that does not (ignored: a document of frequency 0), a document with
+// more than 65535 hits (freq is tokenpos_t: it wraps), positions up to MaxPosition - 1, repeated positions.
 #include "exec.h"
 #include "google_codec.h"
 #include "trinity_oracle.h" // corpus generator + hashing only (this repo's code)
@@ -92,6 +98,8 @@ namespace {
                 Codecs::Decoder *new_postings_decoder(const str8_t, const term_index_ctx ctx) override { return access->new_decoder(ctx); }
                 field_statistics default_field_stats() override { return fs; }
                 bool index_empty() const override { return false; }
+                tokenpos_t maxPos{8192}; // index_source.h:134 default; the edge corpus indexes up to MaxPosition - 1 and says so
+                tokenpos_t max_indexed_position() const override { return maxPos; }
         };
 
         uint64_t fnv_bytes(const uint8_t *p, size_t n, uint64_t h) {
@@ -134,14 +142,107 @@ namespace {
         }
 } // namespace
 
+// ---- the edge corpus: per term, per document, the hits (position, payload bytes) handed to Encoder::new_hit
+struct EdgeHit {
+        uint32_t pos;
+        std::vector<uint8_t> payload;
+};
+static constexpr uint32_t EDGE_D = 3000, EDGE_V = 8;
+static std::vector<EdgeHit> edge_hits(const uint32_t t, const uint32_t d, bool &present) {
+        std::vector<EdgeHit> h;
+        present = false;
+        auto bytes = [&](uint32_t n, uint32_t salt) {
+                std::vector<uint8_t> b(n);
+                for (uint32_t k = 0; k < n; ++k)
+                        b[k] = uint8_t(d * 7 + salt * 13 + k);
+                return b;
+        };
+        switch (t) {
+                case 0: // every document: 1..4 hits, payload lengths that change from hit to hit, or stay put (d % 5 == 0)
+                        present = true;
+                        for (uint32_t j = 0; j < 1 + d % 4; ++j)
+                                h.push_back({1 + 3 * j + (d & 1), bytes(d % 5 == 0 ? 3 : (d + j) % 9, j)});
+                        break;
+                case 1:
+                        if (d % 3 == 0) { // a position-0 hit WITH a payload: counted (google_codec.cpp:38-74)
+                                present = true;
+                                h.push_back({0, {uint8_t(d), uint8_t(d >> 8)}});
+                        } else if (d % 7 == 0) { // a position-0 hit without payload: ignored, the document is committed with frequency 0
+                                present = true;
+                                h.push_back({0, {}});
+                        }
+                        break;
+                case 2:
+                        if (d == 100) { // 70000 hits: freq wraps in tokenpos_t (codecs.h:217)
+                                present = true;
+                                for (uint32_t j = 0; j < 70000; ++j)
+                                        h.push_back({j / 5 + 1, {}});
+                        } else if (d == 200) {
+                                present = true;
+                                for (uint32_t j = 0; j < 300; ++j)
+                                        h.push_back({2 * j + 1, bytes(1, j)});
+                        } else if (d >= 50 && d <= 150 && d % 10 == 0) {
+                                present = true;
+                                h.push_back({3, {}});
+                                h.push_back({9, {}});
+                        }
+                        break;
+                case 3:
+                        if (d % 11 == 0) { // the last legal positions (trinity_limits.h:15)
+                                present = true;
+                                h.push_back({16380, {}});
+                                h.push_back({16381, bytes(8, 1)});
+                                h.push_back({16383, {}});
+                        }
+                        break;
+                case 4:
+                        if (d % 4 == 0) {
+                                present = true;
+                                h.push_back({5, bytes(d % 3, 4)});
+                                h.push_back({16382, {}});
+                        } else if (d % 4 == 2) {
+                                present = true;
+                                h.push_back({5, {}});
+                        }
+                        break;
+                case 5:
+                        if (d % 4 == 0) {
+                                present = true;
+                                h.push_back({6, {}});
+                                h.push_back({16383, bytes(2, 5)});
+                        } else if (d % 4 == 2) {
+                                present = true;
+                                h.push_back({7, bytes(4, 5)});
+                        }
+                        break;
+                case 6:
+                        if (d == 7 || d == 1999 || d == 3000) {
+                                present = true;
+                                h.push_back({d % 100 + 1, {}});
+                        }
+                        break;
+                default:
+                        if (d % 13 == 0) { // repeated positions, payload length 0 -> 8 -> 0
+                                present = true;
+                                h.push_back({4, {}});
+                                h.push_back({4, bytes(8, 7)});
+                                h.push_back({4, {}});
+                        }
+                        break;
+        }
+        return h;
+}
+
 int main(int argc, char **argv) {
-        if (argc < 5) {
-                fprintf(stderr, "usage: %s D V slots seed < commands\n", argv[0]);
+        const bool edge = argc >= 2 && std::string(argv[1]) == "edge";
+        if (argc < 5 && !edge) {
+                fprintf(stderr, "usage: %s D V slots seed < commands   |   %s edge < commands\n", argv[0], argv[0]);
                 return 2;
         }
-        const uint32_t D = strtoul(argv[1], nullptr, 10), V = strtoul(argv[2], nullptr, 10), slots = strtoul(argv[3], nullptr, 10);
-        const uint64_t seed = strtoull(argv[4], nullptr, 10);
-        to_corpus *corpus = to_corpus_generate(D, V, slots, seed);
+        const uint32_t D = edge ? EDGE_D : strtoul(argv[1], nullptr, 10), V = edge ? EDGE_V : strtoul(argv[2], nullptr, 10),
+                       slots = edge ? 0 : strtoul(argv[3], nullptr, 10);
+        const uint64_t seed = edge ? 0 : strtoull(argv[4], nullptr, 10);
+        to_corpus *corpus = edge ? nullptr : to_corpus_generate(D, V, slots, seed);
 
         // ---- index with the reference's own encoder (google_codec.cpp:9-176), terms in rank order
         Codecs::Google::IndexSession sess("/tmp");
@@ -149,9 +250,32 @@ int main(int argc, char **argv) {
         std::unique_ptr<Codecs::Encoder> enc(sess.new_encoder());
         MemIndexSource *src = new MemIndexSource();
         src->terms.resize(V);
+        if (edge)
+                src->maxPos = Limits::MaxPosition;
         uint64_t postings = 0;
         uint32_t totalTerms = 0;
-        for (uint32_t t = 0; t < V; ++t) {
+        uint64_t edgeHits = 0;
+        for (uint32_t t = 0; edge && t < V; ++t) {
+                term_index_ctx tctx;
+                enc->begin_term();
+                for (uint32_t d = 1; d <= D; ++d) {
+                        bool present;
+                        const auto hs = edge_hits(t, d, present);
+                        if (!present)
+                                continue;
+                        enc->begin_document(d);
+                        for (const auto &h : hs) {
+                                enc->new_hit(h.pos, {h.payload.data(), uint8_t(h.payload.size())});
+                                edgeHits += h.pos || !h.payload.empty();
+                        }
+                        enc->end_document();
+                }
+                enc->end_term(&tctx);
+                src->terms[t] = tctx;
+                postings += tctx.documents;
+                ++totalTerms;
+        }
+        for (uint32_t t = 0; !edge && t < V; ++t) {
                 const uint64_t b = corpus->term_off[t], e = corpus->term_off[t + 1];
                 if (b == e) {
                         src->terms[t] = term_index_ctx{0, range32_t{0, 0}};
@@ -178,7 +302,7 @@ int main(int argc, char **argv) {
         const size_t indexLen = sess.indexOut.size();
         Codecs::Google::AccessProxy access("/tmp", index.data());
         src->access = &access;
-        src->fs.sumTermHits = corpus->ntokens;
+        src->fs.sumTermHits = edge ? edgeHits : corpus->ntokens;
         src->fs.totalTerms = totalTerms;
         src->fs.sumTermsDocs = postings;
         src->fs.docsCnt = D;
@@ -206,8 +330,8 @@ int main(int argc, char **argv) {
                                 th = fnv_u32(src->terms[t].indexChunk.offset, th);
                                 th = fnv_u32(src->terms[t].indexChunk.size(), th);
                         }
-                        printf("{\"cmd\":\"index\",\"len\":%zu,\"fnv\":\"%" PRIu64 "\",\"terms_fnv\":\"%" PRIu64 "\",\"postings\":%" PRIu64 ",\"totalTerms\":%u}\n", indexLen,
-                               fnv_bytes(index.data(), indexLen), th, postings, totalTerms);
+                        printf("{\"cmd\":\"index\",\"len\":%zu,\"fnv\":\"%" PRIu64 "\",\"terms_fnv\":\"%" PRIu64 "\",\"postings\":%" PRIu64 ",\"totalTerms\":%u,\"sumTermHits\":%" PRIu64 ",\"docsCnt\":%u}\n", indexLen,
+                               fnv_bytes(index.data(), indexLen), th, postings, totalTerms, uint64_t(src->fs.sumTermHits), D);
                 } else if (cmd == "dumpindex") {
                         std::string path;
                         is >> path;
@@ -300,6 +424,29 @@ int main(int argc, char **argv) {
                                 ++cnt;
                         }
                         printf("{\"cmd\":\"positions\",\"term\":%u,\"nth\":%u,\"docs\":%u,\"fnv\":\"%" PRIu64 "\"}\n", t, nth, cnt, h);
+                } else if (cmd == "hits") {
+                        uint32_t t;
+                        is >> t;
+                        std::unique_ptr<Codecs::Decoder> dec(access.new_decoder(src->terms[t]));
+                        std::unique_ptr<Codecs::PostingsListIterator> it(dec->new_iterator());
+                        DocWordsSpace dws(Limits::MaxPosition);
+                        std::vector<term_hit> hits(1 << 17);
+                        uint64_t h = 1469598103934665603ull, hpos = 1469598103934665603ull;
+                        uint32_t cnt = 0;
+                        for (auto id = it->next(); id != DocIDsEND; id = it->next(), ++cnt) {
+                                const auto f = it->freq; // tokenpos_t: what the iterator exposes
+                                dws.reset();
+                                it->materialize_hits(&dws, hits.data());
+                                h = fnv_u32(id, fnv_u32(f, h));
+                                hpos = fnv_u32(id, fnv_u32(f, hpos));
+                                for (uint32_t k = 0; k < f; ++k) {
+                                        h = fnv_u32(hits[k].pos, h);
+                                        h = fnv_u32(hits[k].payloadLen, h);
+                                        h = fnv_bytes(reinterpret_cast<const uint8_t *>(&hits[k].payload), 8, h);
+                                        hpos = fnv_u32(hits[k].pos, hpos);
+                                }
+                        }
+                        printf("{\"cmd\":\"hits\",\"term\":%u,\"docs\":%u,\"fnv\":\"%" PRIu64 "\",\"pos_fnv\":\"%" PRIu64 "\"}\n", t, cnt, h, hpos);
                 } else if (cmd == "sim") {
                         is >> simName;
                         collScorer = simName == "tfidf" ? static_cast<Similarity::IndexSourcesCollectionTermsScorer *>(&tfidf)
@@ -385,6 +532,7 @@ int main(int argc, char **argv) {
                 }
                 fflush(stdout);
         }
-        to_corpus_free(corpus);
+        if (corpus)
+                to_corpus_free(corpus);
         return 0;
 }

@@ -104,7 +104,44 @@ def commands_for(name, D, V, slots, seed):
     return cmds
 
 
+EDGE_QUERIES = ["t0 t1", "t1", "t2", "t2 t0", "t0 OR t1 OR t6", '"t4 t5"', '"t5 t4"', '"t4 t5" t0', "t3 t4", "t7", "t0 NOT t1", "t1 <t6>", "t3 OR t7", "t2 t3",
+                "t1 t3", "t6", "t4 t5", "t0 t3 t7", '"t4 t5" t3']
+# (term 2 holds the document with 70000 hits: the reference's own hit walks lose their place behind it — materialize_hits reads
+#  freq as tokenpos_t and trips its payload-size assertion —, so the fixtures keep it out of phrases and of the default mode and
+#  pin what IS defined: its docIDs, and the wrapped frequency that scores.)
+EDGE_RICH = ["t0 t1", '"t4 t5" t0', "t3 t7", "t1 t3", "t0 t3 t7", "t3 OR t7", "t1 <t6>", '"t4 t5" t3']
+
+
+def edge_fixture():
+    """tests/golden/ref_edge.json: the edge corpus as REFERENCE-PRODUCED bytes (raw `index` + term table, base64) and the reference's
+    answers on it — so the oracle and the GPU read bytes they did not write: payloads, position 0, freq 0, wrapped freq, MaxPosition."""
+    import base64
+    import tempfile
+
+    import numpy as np
+
+    with tempfile.TemporaryDirectory() as td:
+        prefix = os.path.join(td, "edge")
+        cmds = ["index", f"dumpindex {prefix}"] + [f"decode {t}" for t in range(8)] + [f"hits {t}" for t in (0, 1, 3, 4, 5, 6, 7)]
+        for t in (0, 1, 3, 4):
+            cmds += [f"advance {t} {s} 2000" for s in (1, 2)]
+        for q in EDGE_QUERIES:
+            cmds += [f"queryfull 1 {q}", f"queryfull 2 {q}"]
+        cmds += [f"query 0 0 {q}" for q in EDGE_RICH]
+        res = O.run_ref_driver_edge(cmds)
+        assert len(res) == len(cmds), (len(res), len(cmds))
+        index = open(prefix + ".index", "rb").read()
+        terms = np.fromfile(prefix + ".terms", dtype=np.uint32).reshape(-1, 3)
+    out = {"corpus": "edge (oracle/ref_driver.cpp edge_hits)", "docsCnt": res[0]["docsCnt"], "sumTermHits": res[0]["sumTermHits"], "postings": res[0]["postings"],
+           "index_b64": base64.b64encode(index).decode(), "terms": terms.tolist(), "results": res}  # fmt: skip
+    path = os.path.join(HERE, "ref_edge.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print(path, len(res), "records", os.path.getsize(path), "bytes")
+
+
 def main():
+    edge_fixture()
     for name, (D, V, slots, seed) in CORPORA.items():
         cmds = commands_for(name, D, V, slots, seed)
         res = O.run_ref_driver(D, V, slots, seed, cmds)

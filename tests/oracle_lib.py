@@ -419,3 +419,22 @@ def run_ref_driver(D, V, slots, seed, commands):
 
     out = subprocess.run([REF_DRIVER, str(D), str(V), str(slots), str(seed)], input="\n".join(commands) + "\n", capture_output=True, text=True, check=True)
     return [json.loads(l) for l in out.stdout.splitlines() if l.strip()]
+
+
+def run_ref_driver_edge(commands):
+    """The genuine reference over its EDGE corpus (oracle/ref_driver.cpp: payload-bearing hits, position-0 hits, a document with
+    more than 65535 hits, positions up to MaxPosition - 1, repeated positions)."""
+    import json
+
+    out = subprocess.run([REF_DRIVER, "edge"], input="\n".join(commands) + "\n", capture_output=True, text=True, check=True)
+    return [json.loads(l) for l in out.stdout.splitlines() if l.strip()]
+
+
+def fnv1a_u32s(values, h=1469598103934665603):
+    """FNV-1a(64) over little-endian u32 values (ref_driver's fnv_u32 chain)."""
+    for v in values:
+        v = int(v) & 0xFFFFFFFF
+        for _ in range(4):
+            h = ((h ^ (v & 0xFF)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+            v >>= 8
+    return h

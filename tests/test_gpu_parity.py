@@ -839,3 +839,67 @@ def test_optional_matches_oracle(request, world):
     for t, p, (docs, terms, present, freq, pos) in zip(texts, progs, run_rich(w, progs)):
         wdocs, wflat, tt, ht = w.ora.exec_rich(p)
         assert np.array_equal(docs, wdocs) and np.array_equal(rich_flat(docs, terms, present, freq, pos), wflat), t
+
+
+# ------------------------------------------------------------------------------------------ the reference-produced EDGE segment
+def test_edge_segment_from_reference(T, dev):
+    """tests/golden/ref_edge.json holds a segment the GENUINE reference wrote (raw index bytes + term table) with the codec's corner
+    cases in it — hits with payloads of changing and constant length, a counted position-0 hit, documents of frequency 0, a
+    document of 70000 hits (freq wraps in tokenpos_t), positions up to MaxPosition - 1, repeated positions — and the reference's
+    answers.  The GPU reads bytes it did not write: decode, docID sets, BM25 (id, score) streams, phrases over payload-bearing
+    hits, and the default mode's matched terms + positions."""
+    import base64
+
+    g = json.load(open(os.path.join(GOLDEN, "ref_edge.json")))
+    index = np.frombuffer(base64.b64decode(g["index_b64"]), dtype=np.uint8)
+    terms = np.array(g["terms"], dtype=np.uint32)
+    ix = T.Index(dev, index, terms, g["docsCnt"])
+    ora = O.Index.wrap(index, terms, g["docsCnt"], g["postings"], g["sumTermHits"])
+    try:
+        # codec seam
+        df = terms[:, 0].astype(np.int64)
+        docs, freqs, offs = ix.decode_terms(np.arange(len(terms), dtype=np.uint32), df)
+        for r in g["results"]:
+            if r["cmd"] == "decode":
+                t = r["term"]
+                d, f = docs[int(offs[t]) : int(offs[t + 1])], freqs[int(offs[t]) : int(offs[t + 1])]
+                assert len(d) == r["n"] and str(O.fnv1a_docs(d)) == r["docs_fnv"], t
+                assert str(O.fnv1a_docs(f & 0xFFFF)) == r["freqs_fnv"], t  # PostingsListIterator::freq is tokenpos_t
+        assert int(freqs[int(offs[2]) : int(offs[3])].max()) == 70000
+        # span seam: every fixture query, DocumentsOnly and the full (id, score) stream
+        recs = [r for r in g["results"] if r["cmd"] == "queryfull"]
+        for flags in (1, 2):
+            rs = [r for r in recs if r["flags"] == flags]
+            progs = [O.parse_query(r["q"]) for r in rs]
+            b = T.Batch(ix, progs, T.FLAG_DOCUMENTS_ONLY if flags == 1 else T.FLAG_ACCUMULATED_SCORE, topk=0)
+            b.run()
+            b.sync()
+            counts = b.counts()
+            for i, r in enumerate(rs):
+                got = b.docset(i, int(counts[i]))
+                assert got.tolist() == r["docs"], (flags, r["q"])
+                if flags == 2:
+                    np.testing.assert_allclose(b.scores(i, int(counts[i])), r.get("scores", []), rtol=1e-5, atol=0)
+            b.close()
+            if flags == 2:  # and as top-K lists, planner's choice and the one-pass windows forced (frequency 0 scores 0, the wrapped one as wrapped)
+                for opts in ({}, {"dense_min_postings": 0}):
+                    with options(dev, **opts):
+                        b = T.Batch(ix, progs, T.FLAG_ACCUMULATED_SCORE, topk=10)
+                    b.run()
+                    b.sync()
+                    d, s, c = b.topk_results()
+                    for i, r in enumerate(rs):
+                        td, ts = ora.topk(np.array(r["docs"], dtype=np.uint32), np.array(r.get("scores", []), dtype=np.float64), 10)
+                        assert int(b.counts()[i]) == r["n"] and d[i, : len(td)].tolist() == td.tolist(), (opts, r["q"])
+                        np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+                    b.close()
+        # default mode: matched terms, frequencies, positions (hits with payloads in between)
+        w = type("W", (), {"T": T, "ix": ix})
+        rich = [r for r in g["results"] if r["cmd"] == "query" and r["flags"] == 0]
+        for r, (rdocs, rterms, present, freq, pos) in zip(rich, run_rich(w, [O.parse_query(r["q"]) for r in rich])):
+            assert len(rdocs) == r["n"] and str(O.fnv1a_docs(rdocs)) == r["fnv"], r["q"]
+            assert int(freq.sum()) == r["hits_total"], r["q"]
+            assert str(O.fnv1a_u32_stream(rich_flat(rdocs, rterms, present, freq, pos))) == r["rich_fnv"], r["q"]
+        assert len(rich) >= 8
+    finally:
+        ix.close()

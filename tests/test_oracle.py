@@ -364,3 +364,88 @@ def test_lucene_codec_results_equal_reference_fixtures(both_codecs):
             done, h = _advance_trace(lx, D, r["term"], int(r["seed"]), r["steps"])
             assert done == r["done"] and str(h) == r["trace_fnv"], r  # same (doc, freq) after every next()/advance()
     assert n > 200
+
+
+# ---- the EDGE segment: reference-PRODUCED bytes (payload-bearing hits, position 0, freq 0, a wrapped frequency, MaxPosition) ----
+def load_edge():
+    import base64
+
+    with open(os.path.join(GOLDEN, "ref_edge.json")) as f:
+        g = json.load(f)
+    index = np.frombuffer(base64.b64decode(g["index_b64"]), dtype=np.uint8)
+    terms = np.array(g["terms"], dtype=np.uint32)
+    return g, index, terms
+
+
+@pytest.fixture(scope="module")
+def edge():
+    g, index, terms = load_edge()
+    return g, O.Index.wrap(index, terms, g["docsCnt"], g["postings"], g["sumTermHits"])
+
+
+def test_edge_segment_bytes_are_the_reference_s(edge):
+    g, ix = edge
+    r = g["results"][0]
+    assert r["cmd"] == "index" and r["len"] == len(ix.bytes()) and str(fnv_bytes(ix.bytes())) == r["fnv"]
+
+
+def test_edge_decode_and_hits_match_reference(edge):
+    """next() to exhaustion (freq as the iterator exposes it: tokenpos_t — the 70000-hit document reads 4464, a document whose
+    only hit sits at position 0 without payload reads 0) and materialize_hits positions across payloads of changing length."""
+    g, ix = edge
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] == "decode":
+            d, f = ix.decode_term(r["term"])
+            assert len(d) == r["n"] and str(O.fnv1a_docs(d)) == r["docs_fnv"], r["term"]
+            assert str(O.fnv1a_docs(f & 0xFFFF)) == r["freqs_fnv"], r["term"]
+            n += 1
+        elif r["cmd"] == "hits":
+            it = O.PLI(ix, r["term"])
+            vals, docs = [], 0
+            while True:
+                i = it.next()
+                if i == O.DOCIDS_END:
+                    break
+                f = it.freq()
+                pos = it.positions()
+                assert len(pos) == f, (r["term"], i, f, len(pos))
+                vals += [f, i] + pos
+                docs += 1
+            # ref_driver: hpos = fnv_u32(id, fnv_u32(f, hpos)) then the positions
+            assert docs == r["docs"] and str(O.fnv1a_u32s(vals)) == r["pos_fnv"], r["term"]
+            n += 1
+    assert n >= 14
+    d, f = ix.decode_term(2)
+    assert int(f[d.tolist().index(100)]) & 0xFFFF == 70000 & 0xFFFF  # the wrapped frequency
+    d, f = ix.decode_term(1)
+    assert (f == 0).sum() > 100  # documents of frequency 0
+
+
+def test_edge_advance_traces_match_reference(edge):
+    g, ix = edge
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] == "advance":
+            done, h = _advance_trace(ix, g["docsCnt"], r["term"], int(r["seed"]), r["steps"])
+            assert done == r["done"] and str(h) == r["trace_fnv"], r
+            n += 1
+    assert n == 8
+
+
+def test_edge_queries_match_reference(edge):
+    g, ix = edge
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] == "queryfull":
+            docs, scores = ix.exec(O.parse_query(r["q"]), r["flags"])
+            assert docs.tolist() == r["docs"], (r["q"], r["flags"])
+            if r["flags"] & 2:
+                np.testing.assert_allclose(scores, r.get("scores", []), rtol=1e-5, atol=0)  # (an empty result prints no scores)
+            n += 1
+        elif r["cmd"] == "query" and r["flags"] == 0:
+            docs, flat, tt, ht = ix.exec_rich(O.parse_query(r["q"]))
+            assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
+            assert (tt, ht) == (r["terms_total"], r["hits_total"]) and str(O.fnv1a_u32_stream(flat)) == r["rich_fnv"], r["q"]
+            n += 1
+    assert n >= 40
