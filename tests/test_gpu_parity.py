@@ -417,7 +417,10 @@ def test_fused_batches_do_not_materialise_docsets(small):
 
 
 # ------------------------------------------------------------------------------------------ phrases (K6)
-PHRASE_TEMPLATES = ['"t{a} t{b}"', '"t{a} t{b} t{c}"', '"t{a} t{b}" t{c}', '"t{a} t{b}" "t{c} t{d}"', '"t{a} t{a}"', '"t{a} t{b} t{a}"', 't{e} "t{b} t{a}"']
+PHRASE_TEMPLATES = ['"t{a} t{b}"', '"t{a} t{b} t{c}"', '"t{a} t{b}" t{c}', '"t{a} t{b}" "t{c} t{d}"', '"t{a} t{a}"', '"t{a} t{b} t{a}"', 't{e} "t{b} t{a}"',
+                    # phrases that share terms (one DocWordsSpace / one set of term hits per candidate document, queryexec_ctx.cpp:317-351), a
+                    # phrase next to one of its own terms
+                    '"t{a} t{b}" "t{b} t{c}"', '"t{a} t{b}" "t{c} t{a}"', '"t{a} t{b} t{c}" "t{b} t{c}"', '"t{a} t{b}" t{a}']
 
 
 def phrase_queries(w, seed, n):
