@@ -119,6 +119,7 @@ void *tri_dev_stream(tri_dev *);
  *   "fused_task_cost"     postings per one-pass task (default 1048576)
  *   "fused_freq_cap"      0 (default): a window field saturates at the largest freq its width holds; else at this freq (documents above it are
  *                         rescored from the postings — same results, slower)
+ *   "fused_halfwords"     1 (default): one-pass queries of <= 5 distinct terms keep 16 bits per document (windows twice as long); 0: 32
  *   "overlap_dense_wgs" / "overlap_cand_wgs"  both non-zero: the two matching kernels run side by side with that many workgroups per CU
  * Unknown names fail with TRI_ERR_INVALID. */
 int tri_dev_set_option(tri_dev *, const char *name, uint64_t value);

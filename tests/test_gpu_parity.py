@@ -340,7 +340,7 @@ def test_union_of_head_terms_large(large):
 
 
 # ------------------------------------------------------------------------------------------ one-pass scored windows (k_fused)
-FUSED_EXTRA = ["t{a}", "t{a} t{b}", "t{a} t{a}", "t{a} t{b} t{c} t{d} t{e}", "t{a} NOT t{b}", "(t{a} OR t{b}) NOT t{c}", "t{a} t{b} NOT (t{c} OR t{d})",
+FUSED_EXTRA = ["t{a} OR t{b} OR t{c} OR t{d} OR t{e} OR t0 OR t1 OR t2", "t{a} t{b} (t{c} OR t{d} OR t{e} OR t0 OR t1)", "t{a}", "t{a} t{b}", "t{a} t{a}", "t{a} t{b} t{c} t{d} t{e}", "t{a} NOT t{b}", "(t{a} OR t{b}) NOT t{c}", "t{a} t{b} NOT (t{c} OR t{d})",
                "t{a} <t{b}>", "t{a} t{b} <t{c} OR t{d}>", "(t{a} OR t{b}) (t{a} OR t{c})", "t{a} OR t{b} OR t{c} OR t{d} OR t{e} OR t{a}"]
 
 
@@ -369,7 +369,8 @@ def test_fused_scored_windows_match_oracle(request, world, n, k):
     texts = fused_queries(w, 41, n)
     progs = [O.parse_query(t) for t in texts]
     for opts in ({"dense_min_postings": 0}, {"dense_min_postings": 0, "fused_freq_cap": 1}, {"dense_min_postings": 0, "fused_freq_cap": 3},
-                 {"dense_min_postings": 0, "fused_task_cost": 4096}, {"dense_min_postings": 0, "fused": 0}):
+                 {"dense_min_postings": 0, "fused_task_cost": 4096}, {"dense_min_postings": 0, "fused_halfwords": 0},
+                 {"dense_min_postings": 0, "fused_halfwords": 0, "fused_freq_cap": 2}, {"dense_min_postings": 0, "fused": 0}):
         with options(w.dev, **opts):
             check_scored(w, texts, progs, k, tag=opts)
 

@@ -67,18 +67,19 @@ constexpr uint32_t TASK_CAND = 0;  // candidate tiles of the lead list, filtered
 constexpr uint32_t TASK_DENSE = 1; // bitmap algebra over fixed docID windows (every list dense enough)
 constexpr uint32_t TASK_FUSED = 2; // AccumulatedScoreScheme + top-K of a dense query: decode, match, score and select in one pass over docID
                                    // windows (k_fused.hpp); tile_begin / tile_end count windows of FUS_W documents; nothing is written to out[]
+constexpr uint32_t TASK_FUSED16 = 3; // ... with 16-bit window words (<= 5 distinct terms): windows of 2 * FUS_W documents
 
 constexpr uint32_t FUS_MAX_SLOTS = 8;
 // planner -> kernel: how a fused query's terms map onto the window words
 struct DevFused {
         uint32_t nslots;                // distinct terms: CNF terms (incl. the excluded group) and scoring-only (optional) terms
-        uint32_t fbits;                 // field width: 8 (<= 4 slots) or 4
+        uint32_t fbits;                 // field width — 32-bit words: 8 (<= 4 slots) or 4; 16-bit words (hw): 8 / 5 / 4 / 3 for <= 2 / 3 / 4 / 5 slots
         uint32_t cap;                   // largest freq a field holds exactly; cap + 2 <= 1 << fbits (code cap + 1 = "cap or more")
         uint32_t nreq;                  // required groups
         uint32_t term[FUS_MAX_SLOTS];   // slot -> term
         uint32_t gmask[FUS_MAX_SLOTS];  // per required group: the fields of its slots ((word & gmask) != 0 <=> group satisfied)
         uint32_t gslots[FUS_MAX_SLOTS]; // per required group: bit s = slot s belongs to it (window skipping)
         uint32_t nmask;                 // fields of the excluded group (logicalnot), 0 = none
-        uint32_t pad;
+        uint32_t hw;                    // 1: 16-bit window words (two documents per LDS word, windows twice as long)
 };
 

@@ -8,9 +8,10 @@
 // WINDOW, for every query whose lists are dense enough that no block could be skipped (the planner's TASK_DENSE class) and
 // that asks for a top-K:
 //
-//   * LDS holds one 32-bit word per document of the window (FUS_W documents).  The query's distinct terms (<= 8) are SLOTS; a
-//     slot owns a field of the word — 8 bits when the query has <= 4 slots, 4 bits otherwise — holding 0 = "the document does
-//     not have the term", else min(freq, cap) + 1.  A posting is ONE fire-and-forget ds_or_b32: the docID picks the word, the
+//   * LDS holds one word per document of the window: 32 bits, or — queries of <= 5 distinct terms — 16 bits, which doubles the
+//     window (HW = 1: twice the documents per barrier, per directory lookup, per sweep).  The query's distinct terms (<= 8) are
+//     SLOTS; a slot owns a field of the word (32-bit words: 8 bits with <= 4 slots, else 4; 16-bit words: 8 / 5 / 4 / 3 bits for
+//     <= 2 / 3 / 4 / 5 slots) holding 0 = "the document does not have the term", else min(freq, cap) + 1.  A posting is ONE fire-and-forget ds_or_b32: the docID picks the word, the
 //     freq the code.  All terms of the query are decoded in one pass (no per-group passes, no bitmap folds), each list exactly
 //     once, freqs in the same block visit as the deltas.
 //   * the epilogue sweeps the window's words: the CNF predicate is a handful of mask tests on the word (a required group =
@@ -34,9 +35,15 @@
 constexpr int FUS_WG = TRI_FUS_WG;
 constexpr uint32_t FUS_CELLS = TRI_FUS_CELLS; // docID cells (of CELL_DOCS) per window (14: 56 KB of words, two 512-thread workgroups per CU)
 constexpr uint32_t FUS_W = FUS_CELLS * CELL_DOCS;
+// window geometry by word width (HW = 1: two documents per 32-bit LDS word)
+template <int HW>
+struct FusGeom {
+        static constexpr uint32_t W = FUS_W << HW;         // documents per window
+        static constexpr uint32_t CELLS = FUS_CELLS << HW; // docID cells per window
+};
 constexpr uint32_t FUS_CAP = 512; // candidate buffer; k <= TOPK_MAX = 256
 constexpr uint32_t FUS_CHUNKS = FUS_W / (4 * FUS_WG); // the sweep takes the window in 16-byte chunks: this many per thread
-constexpr uint32_t FUS_WLIST = 512;                   // per wave: documents waiting to be scored (a chunk adds up to 256: flushed beyond 256)
+constexpr uint32_t FUS_WLIST = 512;                   // per wave: documents waiting to be scored (a word position adds up to 64, 128 with 16-bit words: flushed when the next might not fit)
 static_assert(FUS_W % (4 * FUS_WG) == 0, "the sweep deals whole 16-byte chunks of words to every thread");
 static_assert(TOPK_MAX * 2 <= FUS_CAP, "a pruned buffer must leave room for a round of newcomers");
 
@@ -209,23 +216,22 @@ __device__ __noinline__ uint32_t fused_lookup_freq(const uint8_t *__restrict__ i
         return f & 0xffffu;
 }
 
-// Where a window-relative docID lives in acc[].  The lanes of a wave walk consecutive rows of one list, so at any moment their
-// documents sit a near-constant stride apart (64 for a list that holds every other document) — straight indexing would put the
-// wave's ds_or on a handful of LDS banks.  XOR-ing bits 6..10 into the bank bits spreads them; an involution (the source bits are
-// untouched), identity on the sink index FUS_W (a multiple of 2048).
-__device__ __forceinline__ uint32_t fused_slot(const uint32_t rel) { return rel ^ ((rel >> 6) & 31u); }
-static_assert(FUS_W % 2048 == 0, "fused_slot must map the sink index onto itself");
-
 // One posting into the window words.  rel = docID - w0 (documents below the window wrap to huge values: they and the documents
-// past the window land in the sink word); `past` keeps the smallest rel - FUS_W >= 0, i.e. the row's first document past the window.
+// past the window land in the sink word); `past` keeps the smallest rel - W >= 0, i.e. the row's first document past the window.
+template <int HW>
 __device__ __forceinline__ void fused_post(uint32_t *acc, const uint32_t rel, const uint32_t f, const uint32_t cap, const uint32_t shift, uint32_t &past) {
-        past = min(past, rel - FUS_W); // (in-window and below-window documents give values >= 2^31: never the minimum of a real one)
-        atomicOr(&acc[fused_slot(min(rel, FUS_W))], (min(f & 0xffffu, cap) + 1u) << shift);
+        constexpr uint32_t W = FusGeom<HW>::W;
+        past = min(past, rel - W); // (in-window and below-window documents give values >= 2^31: never the minimum of a real one)
+        const uint32_t r = min(rel, W), code = min(f & 0xffffu, cap) + 1u;
+        if (HW)
+                atomicOr(&acc[r >> 1], code << (shift + ((r & 1u) << 4))); // (the sink r == W is the low half of word FUS_W)
+        else
+                atomicOr(&acc[r], code << shift);
 }
 
 // One directory row (<= 32 documents) of a slot's term into the window words through the codec's general value streams: GOOGLE
 // rows, and the PFOR quarters the register reader (PfRegs) does not take.
-template <int CODEC>
+template <int CODEC, int HW>
 __device__ __forceinline__ uint32_t fused_row_streams(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
                                                       const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift,
                                                       const uint32_t cap) {
@@ -242,21 +248,22 @@ __device__ __forceinline__ uint32_t fused_row_streams(const uint8_t *__restrict_
                 fs.init(index, t, b, off, ds);
         for (uint32_t i = 0; i < n; ++i) {
                 rel = (i + 1 < n) ? rel + ds.next() : last - w0;
-                fused_post(acc, rel, fs.next(), cap, shift, past);
+                fused_post<HW>(acc, rel, fs.next(), cap, shift, past);
         }
         return past;
 }
 // (LUCENE: out of line — the general streams' state must not weigh on the registers of the PFOR fast path; only quarters with
 // more than 16 exceptions come here.)
+template <int HW>
 __device__ __noinline__ uint32_t fused_row_streams_lucene(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
                                                           const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc,
                                                           const uint32_t shift, const uint32_t cap) {
-        return fused_row_streams<CODEC_LUCENE>(index, t, b, off, n, prev, last, w0, acc, shift, cap);
+        return fused_row_streams<CODEC_LUCENE, HW>(index, t, b, off, n, prev, last, w0, acc, shift, cap);
 }
 
-// Returns the row's first document past the window as rel - FUS_W (>= 2^31: none).
+// Returns the row's first document past the window as rel - W (>= 2^31: none).
 // LUCENE: rec = the row record {group offset, exception index, deltas header, freqs header}; GOOGLE: rec_x = payload offset.
-template <int CODEC>
+template <int CODEC, int HW>
 __device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t rec_x,
                                               const uint32_t rec_y, const uint32_t rec_z, const uint32_t rec_w, const uint32_t n, const uint32_t prev,
                                               const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift, const uint32_t cap PROF_ARG) {
@@ -267,7 +274,7 @@ __device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index,
                         vb.init(index + rec_x);
                         for (uint32_t i = 0; i < n; ++i) {
                                 rel += vb.next();
-                                fused_post(acc, rel, vb.next(), cap, shift, past);
+                                fused_post<HW>(acc, rel, vb.next(), cap, shift, past);
                         }
                         return past;
                 }
@@ -281,14 +288,14 @@ __device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index,
 #pragma unroll 2
                         for (uint32_t i = 0; i < 32; ++i) {
                                 rel += rd.next(i);
-                                fused_post(acc, rel, rf.next(i), cap, shift, past);
+                                fused_post<HW>(acc, rel, rf.next(i), cap, shift, past);
                         }
                         PROF_LAP(10);
                         return past;
                 }
-                return fused_row_streams_lucene(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
+                return fused_row_streams_lucene<HW>(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
         }
-        return fused_row_streams<CODEC>(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
+        return fused_row_streams<CODEC, HW>(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
 }
 
 // Keep the best k of the n (<= FUS_CAP) buffered candidates, best first (rank by counting: the order is strict).
@@ -348,31 +355,40 @@ __device__ __forceinline__ uint32_t fused_essential(const FusedShared &sh, const
         return emask;
 }
 
-// Score the documents a wave has queued (window-relative docIDs in its wlist), one per lane: table lookups, the rare exact
-// rescoring, threshold, append to the workgroup's candidate buffer.  A full buffer puts the word back for the resumed sweep.
-template <int CODEC>
-__device__ __noinline__ void fused_flush(FusedShared &sh, const uint32_t wn, const uint32_t w0, const uint32_t nch, const bool full, const double thr_s,
-                                            const uint32_t thr_d, uint32_t &wave_matches, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                            const uint32_t *__restrict__ blk_off, const DevQuery &q, const uint32_t *__restrict__ sterms,
-                                            const double *__restrict__ sweights, const int sim) {
+// Score the documents a wave has queued (window-relative docIDs in its wlist), one per lane: table lookups (one per chunk of
+// the word: cb bits, a whole number of fields), the rare exact rescoring, threshold, append to the workgroup's candidate buffer.
+// A full buffer puts the word back for the resumed sweep.
+template <int CODEC, int HW>
+__device__ __noinline__ void fused_flush(FusedShared &sh, const uint32_t wn, const uint32_t w0, const uint32_t nch, const uint32_t cb, const bool full,
+                                         const double thr_s, const uint32_t thr_d, uint32_t &wave_matches, const uint8_t *__restrict__ index,
+                                         const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const DevQuery &q,
+                                         const uint32_t *__restrict__ sterms, const double *__restrict__ sweights, const int sim) {
         const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
         const DevFused &fq = sh.fq;
+        const uint32_t cm = (1u << cb) - 1u;
         uint32_t nback = 0; // documents put back (wave-uniform: counted where the whole wave has reconverged)
         for (uint32_t c0 = 0; c0 < wn; c0 += 64) {
                 const uint32_t c = c0 + lane;
                 bool back = false;
                 if (c < wn) {
                         const uint32_t idx = sh.wlist[wv][c];
-                        const uint32_t x = sh.acc[idx];
-                        sh.acc[idx] = 0;
-                        double s = sh.tab[0][x & 0xffu];
+                        uint32_t x;
+                        if (HW) { // two documents per word: the other half may be on another lane's plate
+                                const uint32_t wsh = (idx & 1u) << 4;
+                                x = (sh.acc[idx >> 1] >> wsh) & 0xffffu;
+                                atomicAnd(&sh.acc[idx >> 1], ~(0xffffu << wsh));
+                        } else {
+                                x = sh.acc[idx];
+                                sh.acc[idx] = 0;
+                        }
+                        double s = sh.tab[0][x & cm];
                         if (nch > 1)
-                                s += sh.tab[1][(x >> 8) & 0xffu];
+                                s += sh.tab[1][(x >> cb) & cm];
                         if (nch > 2)
-                                s += sh.tab[2][(x >> 16) & 0xffu];
+                                s += sh.tab[2][(x >> (2 * cb)) & cm];
                         if (nch > 3)
-                                s += sh.tab[3][x >> 24];
-                        const uint32_t doc = w0 + fused_slot(idx);
+                                s += sh.tab[3][(x >> (3 * cb)) & cm];
+                        const uint32_t doc = w0 + idx;
                         if (!(s == s)) { // a saturated field: rescore from the postings, scorer by scorer
                                 s = 0.0;
                                 const uint32_t fbits = fq.fbits, cap = fq.cap, fmask = (1u << fbits) - 1u;
@@ -393,7 +409,10 @@ __device__ __noinline__ void fused_flush(FusedShared &sh, const uint32_t wn, con
                                 if (slot >= FUS_CAP) { // no room: the word goes back, the resumed sweep takes (and counts) it again
                                         back = true;
                                         sh.overflow = 1;
-                                        sh.acc[idx] = x;
+                                        if (HW)
+                                                atomicOr(&sh.acc[idx >> 1], x << ((idx & 1u) << 4));
+                                        else
+                                                sh.acc[idx] = x;
                                 } else {
                                         sh.tk_s[slot] = s;
                                         sh.tk_d[slot] = doc;
@@ -409,14 +428,16 @@ __device__ __noinline__ void fused_flush(FusedShared &sh, const uint32_t wn, con
 // required group; 1 = up to four groups from registers, excluded fields; 2 = any number of groups, masked documents) counts the
 // matches; a match that holds an ESSENTIAL slot is queued on the wave's list, everything else is re-zeroed at once; the list is
 // scored by the wave itself when it fills and at the end (fused_flush).
-template <int CODEC, int PK>
-__device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, const uint32_t nch, const bool full, const double thr_s, const uint32_t thr_d,
-                                            const uint32_t emask, const uint32_t nmask, const uint32_t nreq, const uint32_t gm0, const uint32_t gm1,
-                                            const uint32_t gm2, const uint32_t gm3, const uint32_t *__restrict__ masked, uint32_t &wave_matches,
-                                            const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
-                                            const DevQuery &q, const uint32_t *__restrict__ sterms, const double *__restrict__ sweights, const int sim) {
+template <int CODEC, int PK, int HW>
+__device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, const uint32_t nch, const uint32_t cb, const bool full, const double thr_s,
+                                            const uint32_t thr_d, const uint32_t emask, const uint32_t nmask, const uint32_t nreq, const uint32_t gm0,
+                                            const uint32_t gm1, const uint32_t gm2, const uint32_t gm3, const uint32_t *__restrict__ masked,
+                                            uint32_t &wave_matches, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                            const uint32_t *__restrict__ blk_off, const DevQuery &q, const uint32_t *__restrict__ sterms,
+                                            const double *__restrict__ sweights, const int sim) {
         const uint32_t tid = threadIdx.x, wave = uni(tid >> 6);
-        uint32_t wn = 0; // entries on this wave's list (wave-uniform)
+        constexpr uint32_t DPW = HW ? 2 : 1; // documents per word
+        uint32_t wn = 0;                     // entries on this wave's list (wave-uniform)
 #pragma unroll 1
         for (uint32_t j = 0; j < FUS_CHUNKS; ++j) { // (kept a loop: unrolled, the chunk bodies' invariants crowd the register file)
                 const uint32_t i0 = j * (4 * FUS_WG) + 4 * tid;
@@ -426,45 +447,50 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                 uint32_t xs[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (uint32_t c = 0; c < 4; ++c) {
-                        const uint32_t x = xs[c];
-                        bool m;
-                        if (PK == 0)
-                                m = (x & gm0) != 0;
-                        else if (PK == 1)
-                                m = (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
-                        else {
-                                m = x != 0 && (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
-                                for (uint32_t g = 4; g < nreq; ++g)
-                                        m &= (x & sh.fq.gmask[g]) != 0;
-                                if (masked && m) { // masked_documents_registry::test (docidupdates.h:90-119)
-                                        const uint32_t doc = w0 + fused_slot(i0 + c);
-                                        m = !((masked[doc >> 5] >> (doc & 31u)) & 1u);
+                        uint32_t keep = 0;
+#pragma unroll
+                        for (uint32_t h = 0; h < DPW; ++h) {
+                                const uint32_t x = HW ? (xs[c] >> (16 * h)) & 0xffffu : xs[c];
+                                const uint32_t idx = (i0 + c) * DPW + h; // window-relative docID
+                                bool m;
+                                if (PK == 0)
+                                        m = (x & gm0) != 0;
+                                else if (PK == 1)
+                                        m = (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
+                                else {
+                                        m = x != 0 && (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
+                                        for (uint32_t g = 4; g < nreq; ++g)
+                                                m &= (x & sh.fq.gmask[g]) != 0;
+                                        if (masked && m) { // masked_documents_registry::test (docidupdates.h:90-119)
+                                                const uint32_t doc = w0 + idx;
+                                                m = !((masked[doc >> 5] >> (doc & 31u)) & 1u);
+                                        }
                                 }
+                                wave_matches += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(m)); // (wave-uniform counter: scalar registers)
+                                const bool e = m && (x & emask) != 0;
+                                const uint64_t bal = __builtin_amdgcn_ballot_w64(e);
+                                if (bal != 0ull) { // (wave-uniform)
+                                        if (e)
+                                                sh.wlist[wave][wn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)idx;
+                                        wn += (uint32_t)__popcll(bal);
+                                }
+                                keep |= (e ? x : 0u) << (16 * h); // queued documents keep their code until they are scored
                         }
-                        wave_matches += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(m)); // (wave-uniform counter: scalar registers)
-                        const bool e = m && (x & emask) != 0;
-                        const uint64_t bal = __builtin_amdgcn_ballot_w64(e);
-                        if (bal != 0ull) { // (wave-uniform)
-                                if (e)
-                                        sh.wlist[wave][wn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)(i0 + c);
-                                wn += (uint32_t)__popcll(bal);
+                        sh.acc[i0 + c] = keep; // (written back word by word: a flush may run before the chunk is through)
+                        if (wn > FUS_WLIST - 64 * DPW) { // the next word position might not fit: score what is queued
+                                __builtin_amdgcn_wave_barrier();
+                                fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                wn = 0;
                         }
-                        xs[c] = e ? x : 0u; // queued words keep their code until they are scored
-                }
-                *(uint4 *)&sh.acc[i0] = make_uint4(xs[0], xs[1], xs[2], xs[3]);
-                if (wn > FUS_WLIST - 4 * 64) { // the next chunk might not fit: score what is queued
-                        __builtin_amdgcn_wave_barrier();
-                        fused_flush<CODEC>(sh, wn, w0, nch, full, thr_s, thr_d, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
-                        wn = 0;
                 }
         }
         if (wn) {
                 __builtin_amdgcn_wave_barrier();
-                fused_flush<CODEC>(sh, wn, w0, nch, full, thr_s, thr_d, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
         }
 }
 
-template <int CODEC>
+template <int CODEC, int HW>
 __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void k_fused(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                      const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
                                                      const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
@@ -475,6 +501,7 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                                      uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
                                                      uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked, const int sim) {
         __shared__ FusedShared sh;
+        constexpr uint32_t W = FusGeom<HW>::W, CELLS = FusGeom<HW>::CELLS;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
         for (uint32_t i = tid; i < FUS_W + 64; i += FUS_WG)
@@ -502,7 +529,7 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 __syncthreads();
                 const DevFused &fq = sh.fq;
                 const uint32_t nslots = uni(fq.nslots), fbits = uni(fq.fbits), cap = uni(fq.cap), nreq = uni(fq.nreq), nmask = uni(fq.nmask);
-                const uint32_t nch = (nslots * fbits + 7) / 8; // bytes of the word in use
+                const uint32_t per = 8 / fbits, cb = per * fbits, nch = (nslots + per - 1) / per; // the word is scored in nch chunks of cb bits (per fields each)
                 const uint32_t kk = min(tid & 63u, nslots - 1); // in EVERY wave lane s (< nslots) tracks slot s, the lanes above mirror the last slot:
                                                                 // a wave reads the slots' block ranges out of its own lanes (readlane), no LDS, no barrier
                 sh.term[kk] = terms[fq.term[kk]];
@@ -513,8 +540,8 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 sh.matches = 0;
                 sh.emask = 0xffffffffu; // no threshold yet: every slot is essential
                 {
-                        // tab[c][v]: the fields inside byte c of the word.  code 0 = absent; code - 1 = freq; code cap + 1 = saturated
-                        const uint32_t per = 8 / fbits, fmask = (1u << fbits) - 1u;
+                        // tab[c][v]: the fields inside chunk c of the word (v < 1 << cb).  code 0 = absent; code - 1 = freq; code cap + 1 = saturated
+                        const uint32_t fmask = (1u << fbits) - 1u;
                         for (uint32_t e = tid; e < nch * 256; e += FUS_WG) {
                                 const uint32_t c = e >> 8, v = e & 255u;
                                 double s = 0.0;
@@ -552,12 +579,12 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 // far one is fetched a window ahead), short lists a cursor
                 uint32_t e_lo = 0, e_hi = 0, pf = 0, cur = 0;
                 if (indexed) {
-                        e_lo = win[myt.win_off + w * FUS_CELLS];
-                        e_hi = win[myt.win_off + (w + 1) * FUS_CELLS];
-                        pf = win[myt.win_off + (w + 2) * FUS_CELLS];
+                        e_lo = win[myt.win_off + w * CELLS];
+                        e_hi = win[myt.win_off + (w + 1) * CELLS];
+                        pf = win[myt.win_off + (w + 2) * CELLS];
                 } else {
                         uint32_t lo = 0, hi = myt.nblocks; // first block whose last document >= the task's first docID
-                        const uint32_t key = w * FUS_W;
+                        const uint32_t key = w * W;
                         while (lo < hi) {
                                 const uint32_t mid = (lo + hi) >> 1;
                                 if (mybl[mid] < key)
@@ -577,7 +604,7 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 uint32_t wave_matches = 0; // matches this wave has counted (wave-uniform)
                 PROF_LAP(0);
                 while (w < task.tile_end) {
-                        const uint32_t w0 = w * FUS_W, wlast = w0 + (FUS_W - 1);
+                        const uint32_t w0 = w * W, wlast = w0 + (W - 1);
                         // ---- my slot's blocks that can hold documents of [w0, wlast], and the first docID >= w0 it may still hold
                         uint32_t my_lo, my_cnt, my_np;
                         {
@@ -637,13 +664,13 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                         }
                         if (need == 0xffffffffu)
                                 break; // a required group is exhausted: no further match anywhere
-                        const uint32_t wnext = need / FUS_W;
+                        const uint32_t wnext = need / W;
                         if (wnext > w) { // nothing can match before window wnext: jump
                                 w = wnext;
                                 if (indexed) {
-                                        e_lo = win[myt.win_off + w * FUS_CELLS];
-                                        e_hi = win[myt.win_off + (w + 1) * FUS_CELLS];
-                                        pf = win[myt.win_off + (w + 2) * FUS_CELLS];
+                                        e_lo = win[myt.win_off + w * CELLS];
+                                        e_hi = win[myt.win_off + (w + 1) * CELLS];
+                                        pf = win[myt.win_off + (w + 2) * CELLS];
                                 }
                                 continue;
                         }
@@ -673,15 +700,15 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                                         sh.bcast[3] = 1;
                                                 PROF_LAP(8);
 #endif
-                                                past = fused_row<CODEC>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, sh.acc,
+                                                past = fused_row<CODEC, HW>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, sh.acc,
                                                                         s * fbits, cap PROF_PASS);
                                         } else {
                                                 const uint32_t off = blk_off[t.first_block + b];
-                                                past = fused_row<CODEC>(index, t, b, off, 0, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, sh.acc, s * fbits, cap PROF_PASS);
+                                                past = fused_row<CODEC, HW>(index, t, b, off, 0, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, sh.acc, s * fbits, cap PROF_PASS);
                                         }
                                         if (past < 0x80000000u) { // the row reaches past the window (it is the slot's last row here): leave the hint
                                                 sh.hint_row[s] = b;
-                                                sh.hint_doc[s] = w0 + FUS_W + past;
+                                                sh.hint_doc[s] = w0 + W + past;
                                         }
                                 }
                         }
@@ -689,7 +716,7 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                         if (indexed) {
                                 e_lo = e_hi;
                                 e_hi = pf;
-                                pf = win[myt.win_off + (w + 3) * FUS_CELLS];
+                                pf = win[myt.win_off + (w + 3) * CELLS];
                         }
                         PROF_LAP(2);
                         __syncthreads();
@@ -706,11 +733,11 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                 // the predicate in its cheapest form for the query at hand (uniform): one required group and nothing excluded (a
                                 // union: any of its fields), up to four groups from registers, or the general walk with masked documents on top
                                 if (!masked && nreq == 1 && nmask == 0)
-                                        fused_sweep<CODEC, 0>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        fused_sweep<CODEC, 0, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
                                 else if (!masked && nreq <= 4)
-                                        fused_sweep<CODEC, 1>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        fused_sweep<CODEC, 1, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
                                 else
-                                        fused_sweep<CODEC, 2>(sh, w0, nch, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        fused_sweep<CODEC, 2, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
                                 PROF_LAP(6);
                                 __syncthreads();
                                 PROF_LAP(7);

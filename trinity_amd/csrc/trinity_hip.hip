@@ -61,6 +61,7 @@ struct tri_options {
         uint64_t fused = 1;                       // AccumulatedScore top-K of dense queries in one pass (k_fused); 0: k_and_dense + k_score
         uint64_t fused_task_cost = 1024 * 1024;   // postings per fused task
         uint64_t fused_freq_cap = 0;              // 0: the field width decides; else a smaller saturation point (exercises the rescoring path)
+        uint64_t fused_halfwords = 1;             // 16-bit window words for queries of <= 5 distinct terms (windows twice as long); 0: always 32-bit
         uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
 };
 
@@ -131,7 +132,7 @@ struct tri_batch {
         std::vector<DevTask> tasks; // scheduling order (cost descending)
         DevTask *d_tasks = nullptr;
         uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones, then the TASK_FUSED ones
-        uint32_t n_dense = 0, n_cand = 0, n_fused = 0;
+        uint32_t n_dense = 0, n_cand = 0, n_fused = 0, n_fused16 = 0; // (n_fused: 32-bit window words; n_fused16: 16-bit)
         std::vector<DevFused> fused; // slot maps of the TASK_FUSED queries (DevQuery::fused_idx)
         DevFused *d_fused = nullptr;
         uint64_t term_bytes_fused = 0;
@@ -270,6 +271,7 @@ namespace {
                              {"fused", &tri_options::fused},
                              {"fused_task_cost", &tri_options::fused_task_cost},
                              {"fused_freq_cap", &tri_options::fused_freq_cap},
+                             {"fused_halfwords", &tri_options::fused_halfwords},
                              {"overlap_dense_wgs", &tri_options::overlap_dense_wgs},
                              {"overlap_cand_wgs", &tri_options::overlap_cand_wgs}};
                 for (const auto &e : table)
@@ -1180,7 +1182,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         if (slots.size() <= FUS_MAX_SLOTS) {
                                 DevFused &z = t.fz;
                                 z.nslots = (uint32_t)slots.size();
-                                z.fbits = z.nslots <= 4 ? 8u : 4u;
+                                z.hw = (dev->opt.fused_halfwords && z.nslots <= 5) ? 1u : 0u;
+                                z.fbits = z.hw ? std::min(8u, 16u / z.nslots) : (z.nslots <= 4 ? 8u : 4u);
                                 z.cap = (1u << z.fbits) - 2u;
                                 if (dev->opt.fused_freq_cap && dev->opt.fused_freq_cap < z.cap)
                                         z.cap = (uint32_t)dev->opt.fused_freq_cap;
@@ -1295,13 +1298,14 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         t.q.out_off = off;
                         t.q.out_cap = 0; // the docID set is never materialised
                         t.q.first_task = (uint32_t)b->tasks.size();
-                        const uint32_t nwin = last_doc / FUS_W + 1;
-                        const uint64_t per_win = std::max<uint64_t>(1, slotdf / (ix->info.docs_cnt / FUS_W + 1));
+                        const uint32_t fw = FUS_W << t.fz.hw; // documents per window of this query's word width
+                        const uint32_t nwin = last_doc / fw + 1;
+                        const uint64_t per_win = std::max<uint64_t>(1, slotdf / (ix->info.docs_cnt / fw + 1));
                         const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
                         for (uint32_t wb = 0; wb < nwin; wb += win_per_task) {
                                 const uint32_t we = std::min(nwin, wb + win_per_task);
                                 order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
-                                b->tasks.push_back({slot, wb, we, TASK_FUSED, off});
+                                b->tasks.push_back({slot, wb, we, t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off});
                         }
                         t.q.ntasks = (uint32_t)b->tasks.size() - t.q.first_task;
                         b->plan.push_back(t.q);
@@ -1376,6 +1380,10 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if (b->tasks[o.second].kind == TASK_FUSED)
                         sched.push_back(o.second);
         b->n_fused = (uint32_t)sched.size() - b->n_dense - b->n_cand;
+        for (const auto &o : order)
+                if (b->tasks[o.second].kind == TASK_FUSED16)
+                        sched.push_back(o.second);
+        b->n_fused16 = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused;
         b->out_capacity = off;
         int rc;
         if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)) || (rc = dev_upload(&b->d_tasks, b->tasks)) ||
@@ -1421,7 +1429,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         }
         b->info.nqueries = nq;
         b->info.out_capacity = off;
-        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (!b->ptasks.empty()) + (rich ? 2 : 0) +
+        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (!b->ptasks.empty()) + (rich ? 2 : 0) +
                            ((scored && b->n_dense + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
         *out = b.release();
         return TRI_OK;
@@ -1485,12 +1493,30 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipStreamWaitEvent(dev->stream, dev->ev_join, 0));
                 }
                 HIP_TRY(hipEventRecord(b->ev_b, dev->stream));
-                if (b->n_fused) {
-                        // AccumulatedScore top-K of the dense queries: decode -> match -> score -> select in one pass; as many workgroups per CU as its LDS holds
-                        TRI_LAUNCH(k_fused, b->ix->codec, dim3(std::min<uint32_t>(b->n_fused, (uint32_t)dev->cus * FUS_WGS_PER_CU)), dim3(FUS_WG), dev->stream, b->ix->d_index,
-                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks,
-                                           b->d_sched + b->n_dense + b->n_cand, b->d_sterms, b->d_sweights, b->n_fused, b->d_ticket + 56, b->d_counts, b->topk,
-                                           b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked, b->similarity);
+                // AccumulatedScore top-K of the dense queries: decode -> match -> score -> select in one pass; as many workgroups per CU as its
+                // LDS holds.  Two instantiations: 32-bit window words, and 16-bit ones (queries of <= 5 distinct terms: windows twice as long)
+                for (int hw = 0; hw < 2; ++hw) {
+                        const uint32_t nf = hw ? b->n_fused16 : b->n_fused;
+                        if (!nf)
+                                continue;
+                        const uint32_t *fsched = b->d_sched + b->n_dense + b->n_cand + (hw ? b->n_fused : 0);
+                        const dim3 grid(std::min<uint32_t>(nf, (uint32_t)dev->cus * FUS_WGS_PER_CU));
+#define TRI_FUSED_ARGS                                                                                                                                 \
+        b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, fsched, \
+                b->d_sterms, b->d_sweights, nf, b->d_ticket + 56 + 4 * hw, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,    \
+                b->ix->d_masked, b->similarity
+                        if (b->ix->codec == TRI_CODEC_LUCENE) {
+                                if (hw)
+                                        hipLaunchKernelGGL((k_fused<CODEC_LUCENE, 1>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                                else
+                                        hipLaunchKernelGGL((k_fused<CODEC_LUCENE, 0>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                        } else {
+                                if (hw)
+                                        hipLaunchKernelGGL((k_fused<CODEC_GOOGLE, 1>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                                else
+                                        hipLaunchKernelGGL((k_fused<CODEC_GOOGLE, 0>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                        }
+#undef TRI_FUSED_ARGS
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
@@ -1608,7 +1634,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 m += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_DENSE)
                         m_dense += b->h_query_counts[sidx];
-                if (q.ntasks && b->tasks[q.first_task].kind == TASK_FUSED) {
+                if (q.ntasks && (b->tasks[q.first_task].kind == TASK_FUSED || b->tasks[q.first_task].kind == TASK_FUSED16)) {
                         m_fused += b->h_query_counts[sidx];
                         out_fused += 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk);
                 }
@@ -1753,7 +1779,7 @@ extern "C" int tri_batch_docset(tri_batch *b, size_t q, uint32_t *out, size_t ca
         *n = slot == UINT32_MAX ? 0 : b->h_query_counts[slot];
         if (!*n || !out)
                 return TRI_OK;
-        if (b->plan[slot].ntasks && b->tasks[b->plan[slot].first_task].kind == TASK_FUSED)
+        if (b->plan[slot].ntasks && (b->tasks[b->plan[slot].first_task].kind == TASK_FUSED || b->tasks[b->plan[slot].first_task].kind == TASK_FUSED16))
                 return fail(TRI_ERR_INVALID, "query %zu ran through the one-pass scored kernel: an AccumulatedScore top-K batch keeps top-K lists and match counts, not docID sets (use topk == 0 or DocumentsOnly)", q);
         if (cap < *n)
                 return fail(TRI_ERR_INVALID, "docset needs %zu slots, %zu given", *n, cap);
@@ -1781,7 +1807,7 @@ extern "C" int tri_batch_docset_hashes(tri_batch *b, uint64_t *hashes) {
         tri_dev *dev = b->ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
         const uint32_t n = (uint32_t)b->plan.size();
-        if (b->n_fused)
+        if (b->n_fused + b->n_fused16)
                 return fail(TRI_ERR_INVALID, "the batch holds queries that ran through the one-pass scored kernel: their docID sets are not materialised");
         std::vector<uint64_t> h(n);
         if (n) {
