@@ -48,7 +48,7 @@ static_assert(FUS_W % (4 * FUS_WG) == 0, "the sweep deals whole 16-byte chunks o
 static_assert(TOPK_MAX * 2 <= FUS_CAP, "a pruned buffer must leave room for a round of newcomers");
 
 struct FusedShared {
-        uint32_t acc[FUS_W + 64]; // [FUS_W] = sink for documents outside the window
+        alignas(16) uint32_t acc[FUS_W + 64]; // [FUS_W] = sink for documents outside the window
         double tab[4][256];       // per byte of the word: score contribution of the byte's fields (NaN: a saturated field)
         double tk_s[FUS_CAP];
         uint32_t tk_d[FUS_CAP];
@@ -359,10 +359,10 @@ __device__ __forceinline__ uint32_t fused_essential(const FusedShared &sh, const
 // the word: cb bits, a whole number of fields), the rare exact rescoring, threshold, append to the workgroup's candidate buffer.
 // A full buffer puts the word back for the resumed sweep.
 template <int CODEC, int HW>
-__device__ __noinline__ void fused_flush(FusedShared &sh, const uint32_t wn, const uint32_t w0, const uint32_t nch, const uint32_t cb, const bool full,
-                                         const double thr_s, const uint32_t thr_d, uint32_t &wave_matches, const uint8_t *__restrict__ index,
-                                         const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const DevQuery &q,
-                                         const uint32_t *__restrict__ sterms, const double *__restrict__ sweights, const int sim) {
+__device__ __noinline__ uint32_t fused_flush(FusedShared &sh, const uint32_t wn, const uint32_t w0, const uint32_t nch, const uint32_t cb, const bool full,
+                                             const double thr_s, const uint32_t thr_d, const uint8_t *__restrict__ index,
+                                             const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const DevQuery &q,
+                                             const uint32_t *__restrict__ sterms, const double *__restrict__ sweights, const int sim) {
         const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
         const DevFused &fq = sh.fq;
         const uint32_t cm = (1u << cb) - 1u;
@@ -421,7 +421,7 @@ __device__ __noinline__ void fused_flush(FusedShared &sh, const uint32_t wn, con
                 }
                 nback += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(back));
         }
-        wave_matches -= nback;
+        return nback; // (returned, not subtracted through a reference: the caller's counter stays in a scalar register)
 }
 
 // Sweep stage 1 over the window's words, 16 bytes per lane at a time: the CNF predicate (PK: 0 = a union — any field of the one
@@ -434,13 +434,96 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                                             const uint32_t gm1, const uint32_t gm2, const uint32_t gm3, const uint32_t *__restrict__ masked,
                                             uint32_t &wave_matches, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                             const uint32_t *__restrict__ blk_off, const DevQuery &q, const uint32_t *__restrict__ sterms,
-                                            const double *__restrict__ sweights, const int sim) {
-        const uint32_t tid = threadIdx.x, wave = uni(tid >> 6);
+                                            const double *__restrict__ sweights, const int sim PROF_ARG) {
+        const uint32_t wave = uni(threadIdx.x >> 6);
         constexpr uint32_t DPW = HW ? 2 : 1; // documents per word
+        // (the lane's word address is recomputed per chunk from the hardware lane count: kept in a register across the flush calls it
+        //  was spilled, and every chunk began with a scratch round trip)
+        auto lane_id = []() {
+                uint32_t l;
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+                return l;
+        };
         uint32_t wn = 0;                     // entries on this wave's list (wave-uniform)
+        if (HW && PK != 2) {
+                // 16-bit words, predicates of up to four groups: BOTH documents of a word at once.  nz16(y) = v_pk_min_u16(y, 1|1<<16)
+                // has bit 0 / 16 set where the low / high half of y is non-zero; a required group is nz16(x & its fields), the
+                // excluded group its complement; the matches are counted with one v_bcnt per word, and only a word that holds a
+                // document with an ESSENTIAL field (rare once the threshold stands) takes the per-document path below.
+                auto nz16 = [](const uint32_t y) {
+                        uint32_t r;
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(y), "s"(0x00010001u));
+                        return r;
+                };
+                auto rep = [](const uint32_t m16) { return m16 | (m16 << 16); };
+                const uint32_t G0 = rep(gm0), G1 = rep(gm1), G2 = rep(gm2), G3 = rep(gm3), N = rep(nmask), E = rep(emask);
+                uint32_t lane_matches = 0;
+#pragma unroll 1
+                for (uint32_t j = 0; j < FUS_CHUNKS; ++j) {
+                        const uint32_t i0 = j * (4 * FUS_WG) + 256 * wave + 4 * lane_id();
+                        const uint4 v = *(const uint4 *)&sh.acc[i0];
+                        if (__builtin_amdgcn_ballot_w64((v.x | v.y | v.z | v.w) != 0) == 0ull)
+                                continue; // nothing in this wave's slice
+                        const uint32_t xs[4] = {v.x, v.y, v.z, v.w};
+                        uint32_t es[4], anye = 0;
+#pragma unroll
+                        for (uint32_t c = 0; c < 4; ++c) {
+                                const uint32_t x = xs[c];
+                                uint32_t m = nz16(x & G0);
+                                if (PK == 1) {
+                                        m &= nz16(x & G1);
+                                        if (nreq > 2) // (uniform)
+                                                m &= nz16(x & G2) & nz16(x & G3);
+                                        if (nmask)
+                                                m &= ~nz16(x & N);
+                                }
+                                lane_matches += __popc(m);
+                                es[c] = m & nz16(x & E);
+                                anye |= es[c];
+                        }
+                        if (__builtin_amdgcn_ballot_w64(anye != 0) == 0ull) { // no document of these 512 words can beat the threshold
+                                *(uint4 *)&sh.acc[i0] = make_uint4(0, 0, 0, 0);
+                                continue;
+                        }
+                        // the queued documents keep their codes until they are scored, everything else is re-zeroed now (a flush below
+                        // reads — and clears — the words of the documents on the list)
+                        *(uint4 *)&sh.acc[i0] = make_uint4(xs[0] & (es[0] * 0xffffu), xs[1] & (es[1] * 0xffffu), xs[2] & (es[2] * 0xffffu), xs[3] & (es[3] * 0xffffu));
+                        // the lane's (<= 8) essential documents as a bit set, queued one per round: bit 2c + h = half h of word c
+                        uint32_t e8 = ((es[0] | (es[0] >> 15)) & 3u) | (((es[1] | (es[1] >> 15)) & 3u) << 2) | (((es[2] | (es[2] >> 15)) & 3u) << 4) |
+                                      (((es[3] | (es[3] >> 15)) & 3u) << 6);
+                        for (;;) {
+                                const uint64_t bal = __builtin_amdgcn_ballot_w64(e8 != 0);
+                                if (bal == 0ull)
+                                        break;
+                                if (wn > FUS_WLIST - 64) { // this round might not fit: score what is queued
+                                        __builtin_amdgcn_wave_barrier();
+                                        PROF_LAP(6);
+                                        wave_matches -= fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        PROF_LAP(11);
+                                        wn = 0;
+                                }
+                                if (e8)
+                                        sh.wlist[wave][wn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)(i0 * 2 + (uint32_t)__builtin_ctz(e8));
+                                wn += (uint32_t)__popcll(bal);
+                                e8 &= e8 - 1u;
+                        }
+                }
+                PROF_LAP(6);
+                // the lanes' counts into the wave's (scalar) counter
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1)
+                        lane_matches += __shfl_xor(lane_matches, d, 64);
+                wave_matches += uni(lane_matches);
+                if (wn) {
+                        __builtin_amdgcn_wave_barrier();
+                        wave_matches -= fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
+                }
+                PROF_LAP(11);
+                return;
+        }
 #pragma unroll 1
         for (uint32_t j = 0; j < FUS_CHUNKS; ++j) { // (kept a loop: unrolled, the chunk bodies' invariants crowd the register file)
-                const uint32_t i0 = j * (4 * FUS_WG) + 4 * tid;
+                const uint32_t i0 = j * (4 * FUS_WG) + 256 * wave + 4 * lane_id();
                 const uint4 v = *(const uint4 *)&sh.acc[i0];
                 if (__builtin_amdgcn_ballot_w64((v.x | v.y | v.z | v.w) != 0) == 0ull)
                         continue; // nothing in this wave's slice
@@ -479,14 +562,14 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                         sh.acc[i0 + c] = keep; // (written back word by word: a flush may run before the chunk is through)
                         if (wn > FUS_WLIST - 64 * DPW) { // the next word position might not fit: score what is queued
                                 __builtin_amdgcn_wave_barrier();
-                                fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                wave_matches -= fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
                                 wn = 0;
                         }
                 }
         }
         if (wn) {
                 __builtin_amdgcn_wave_barrier();
-                fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                wave_matches -= fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
         }
 }
 
@@ -733,11 +816,11 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                 // the predicate in its cheapest form for the query at hand (uniform): one required group and nothing excluded (a
                                 // union: any of its fields), up to four groups from registers, or the general walk with masked documents on top
                                 if (!masked && nreq == 1 && nmask == 0)
-                                        fused_sweep<CODEC, 0, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        fused_sweep<CODEC, 0, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
                                 else if (!masked && nreq <= 4)
-                                        fused_sweep<CODEC, 1, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        fused_sweep<CODEC, 1, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
                                 else
-                                        fused_sweep<CODEC, 2, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        fused_sweep<CODEC, 2, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
                                 PROF_LAP(6);
                                 __syncthreads();
                                 PROF_LAP(7);
