@@ -62,6 +62,9 @@ struct FusedShared {
         uint32_t emask; // fields of the ESSENTIAL slots: a document none of whose essential fields is set cannot beat the threshold
         uint32_t tk_n, tk_full, overflow, matches;
         uint32_t bcast[4];
+        alignas(16) uint32_t rng_lo[FUS_MAX_SLOTS]; // the next window (next_w; 0xffffffff: none) and the slots' row ranges in it, left by wave 0
+        alignas(16) uint32_t rng_cnt[FUS_MAX_SLOTS];
+        uint32_t next_w;
         DevFused fq; // the query's slot map, staged once per task (dynamic indexing stays in LDS, not in scratch)
 };
 
@@ -657,17 +660,17 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 const DevTerm myt = sh.term[kk];
                 const uint32_t *mybl = blk_last + myt.first_block;
                 const bool indexed = myt.win_off != 0xffffffffu;
-                uint32_t w = task.tile_begin;
+                const uint32_t wfirst = task.tile_begin;
                 // directory position of my slot's list: indexed lists keep the two cell-index entries of the window's ends (the
                 // far one is fetched a window ahead), short lists a cursor
                 uint32_t e_lo = 0, e_hi = 0, pf = 0, cur = 0;
                 if (indexed) {
-                        e_lo = win[myt.win_off + w * CELLS];
-                        e_hi = win[myt.win_off + (w + 1) * CELLS];
-                        pf = win[myt.win_off + (w + 2) * CELLS];
+                        e_lo = win[myt.win_off + wfirst * CELLS];
+                        e_hi = win[myt.win_off + (wfirst + 1) * CELLS];
+                        pf = win[myt.win_off + (wfirst + 2) * CELLS];
                 } else {
                         uint32_t lo = 0, hi = myt.nblocks; // first block whose last document >= the task's first docID
-                        const uint32_t key = w * W;
+                        const uint32_t key = wfirst * W;
                         while (lo < hi) {
                                 const uint32_t mid = (lo + hi) >> 1;
                                 if (mybl[mid] < key)
@@ -685,12 +688,16 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 const uint32_t gsl0 = uni(fq.gslots[0]), gsl1 = nreq > 1 ? uni(fq.gslots[1]) : 0u, gsl2 = nreq > 2 ? uni(fq.gslots[2]) : 0u,
                                gsl3 = nreq > 3 ? uni(fq.gslots[3]) : 0u; // (an absent group has no slots: its "next possible" would be "never" — skipped below)
                 uint32_t wave_matches = 0; // matches this wave has counted (wave-uniform)
-                PROF_LAP(0);
-                while (w < task.tile_end) {
-                        const uint32_t w0 = w * W, wlast = w0 + (W - 1);
-                        // ---- my slot's blocks that can hold documents of [w0, wlast], and the first docID >= w0 it may still hold
-                        uint32_t my_lo, my_cnt, my_np;
-                        {
+                // ---- WAVE 0 finds the next window that can hold a match and the slots' row ranges in it (lane s tracks slot s), while
+                //      the other waves sweep the current one; everybody picks the result up behind the sweep's barrier
+                auto find_window = [&](uint32_t w) {
+                        for (;;) {
+                                if (w >= task.tile_end) {
+                                        sh.next_w = 0xffffffffu;
+                                        return;
+                                }
+                                const uint32_t w0 = w * W, wlast = w0 + (W - 1);
+                                // my slot's blocks that can hold documents of [w0, wlast], and the first docID >= w0 it may still hold
                                 uint32_t b_lo, b_hi, np = 0xffffffffu;
                                 bool here = false;
                                 if (indexed) {
@@ -721,41 +728,106 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                                 np = max(w0, first_possible);
                                         }
                                 }
-                                my_lo = b_lo;
-                                my_cnt = cnt;
-                                my_np = np;
-                        }
-                        // ---- every wave gathers the slots' ranges from its own lanes: no match before the latest "first possible document"
-                        //      over the required groups (a group: its earliest slot)
-                        uint32_t s_lo[FUS_MAX_SLOTS], s_cnt[FUS_MAX_SLOTS], s_np[FUS_MAX_SLOTS], total = 0;
+                                // no match before the latest "first possible document" over the required groups (a group: its earliest slot)
+                                uint32_t need = 0;
+                                for (uint32_t g = 0; g < nreq; ++g) {
+                                        const uint32_t gs = g == 0 ? gsl0 : g == 1 ? gsl1 : g == 2 ? gsl2 : g == 3 ? gsl3 : uni(fq.gslots[g]);
+                                        uint32_t gnp = 0xffffffffu;
 #pragma unroll
-                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
-                                const bool on = s < nslots;
-                                s_lo[s] = (uint32_t)__builtin_amdgcn_readlane((int)my_lo, (int)s);
-                                s_cnt[s] = on ? (uint32_t)__builtin_amdgcn_readlane((int)my_cnt, (int)s) : 0u;
-                                s_np[s] = on ? (uint32_t)__builtin_amdgcn_readlane((int)my_np, (int)s) : 0xffffffffu;
-                                total += s_cnt[s];
-                        }
-                        uint32_t need = 0;
-                        for (uint32_t g = 0; g < nreq; ++g) {
-                                const uint32_t gs = g == 0 ? gsl0 : g == 1 ? gsl1 : g == 2 ? gsl2 : g == 3 ? gsl3 : uni(fq.gslots[g]);
-                                uint32_t gnp = 0xffffffffu;
-#pragma unroll
-                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
-                                        gnp = ((gs >> s) & 1u) ? min(gnp, s_np[s]) : gnp;
-                                need = max(need, gnp);
-                        }
-                        if (need == 0xffffffffu)
-                                break; // a required group is exhausted: no further match anywhere
-                        const uint32_t wnext = need / W;
-                        if (wnext > w) { // nothing can match before window wnext: jump
-                                w = wnext;
-                                if (indexed) {
-                                        e_lo = win[myt.win_off + w * CELLS];
-                                        e_hi = win[myt.win_off + (w + 1) * CELLS];
-                                        pf = win[myt.win_off + (w + 2) * CELLS];
+                                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                                                const uint32_t snp = (uint32_t)__builtin_amdgcn_readlane((int)np, (int)s);
+                                                gnp = (s < nslots && ((gs >> s) & 1u)) ? min(gnp, snp) : gnp;
+                                        }
+                                        need = max(need, gnp);
                                 }
-                                continue;
+                                if (need == 0xffffffffu) { // a required group is exhausted: no further match anywhere
+                                        sh.next_w = 0xffffffffu;
+                                        return;
+                                }
+                                const uint32_t wnext = need / W;
+                                if (wnext > w) { // nothing can match before window wnext: jump
+                                        w = wnext;
+                                        if (indexed && w < task.tile_end) {
+                                                e_lo = win[myt.win_off + w * CELLS];
+                                                e_hi = win[myt.win_off + (w + 1) * CELLS];
+                                                pf = win[myt.win_off + (w + 2) * CELLS];
+                                        }
+                                        continue;
+                                }
+                                if ((tid & 63u) < nslots) {
+                                        sh.rng_lo[kk] = b_lo;
+                                        sh.rng_cnt[kk] = cnt;
+                                }
+                                sh.next_w = w;
+                                // the far cell-index entry of the window after this one travels while this one is worked on
+                                if (indexed) {
+                                        e_lo = e_hi;
+                                        e_hi = pf;
+                                        pf = win[myt.win_off + (w + 3) * CELLS];
+                                }
+                                return;
+                        }
+                };
+                PROF_LAP(0);
+                // software pipeline: wave 0 looks for window n + 1 while window n (set in the previous round) is swept
+                uint32_t look_from = wfirst, w0 = 0;
+                bool have = false;
+                for (;;) {
+                        if (wave == 0) // (window n's hints are in — the set pass ended with a barrier)
+                                find_window(look_from);
+                        PROF_LAP(1);
+                        if (have) {
+                                // ---- sweep, stage 1 per 16-byte chunk: the CNF predicate counts the matches; a match that holds an ESSENTIAL slot is
+                                //      queued on the wave's list (everything else is re-zeroed at once); the list is scored by the wave itself when
+                                //      it fills and at the end (fused_flush), so only documents that can beat the threshold ever pay the table
+                                //      lookups.  A full candidate buffer is pruned and the sweep resumed over the words that were put back.
+                                for (;;) {
+                                        const bool full = uni(sh.tk_full) != 0;
+                                        const double thr_s = sh.thr_s;
+                                        const uint32_t thr_d = sh.thr_d;
+                                        const uint32_t emask = uni(sh.emask);
+                                        // the predicate in its cheapest form for the query at hand (uniform): one required group and nothing excluded (a
+                                        // union: any of its fields), up to four groups from registers, or the general walk with masked documents on top
+                                        if (!masked && nreq == 1 && nmask == 0)
+                                                fused_sweep<CODEC, 0, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
+                                        else if (!masked && nreq <= 4)
+                                                fused_sweep<CODEC, 1, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
+                                        else
+                                                fused_sweep<CODEC, 2, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
+                                        PROF_LAP(6);
+                                        __syncthreads();
+                                        PROF_LAP(7);
+                                        const uint32_t ov = uni(sh.overflow);
+                                        const uint32_t n = min(uni(sh.tk_n), FUS_CAP);
+                                        if (ov || n > (FUS_CAP + k) / 2) {
+                                                __syncthreads(); // (every lane has read overflow / tk_n)
+                                                fused_prune(sh, n, k);
+                                                sh.emask = fused_essential(sh, nslots, fbits); // same value from every lane
+                                                __syncthreads();
+                                        }
+                                        if (!ov)
+                                                break;
+                                }
+                                PROF_LAP(4);
+                        } else
+                                __syncthreads();
+                        const uint32_t w = uni(sh.next_w);
+                        if (w == 0xffffffffu)
+                                break;
+                        w0 = w * W;
+                        have = true;
+                        look_from = w + 1;
+                        uint32_t s_lo[FUS_MAX_SLOTS], s_cnt[FUS_MAX_SLOTS], total = 0;
+                        {
+                                const uint4 l0 = *(const uint4 *)&sh.rng_lo[0], l1 = *(const uint4 *)&sh.rng_lo[4], c0 = *(const uint4 *)&sh.rng_cnt[0],
+                                            c1 = *(const uint4 *)&sh.rng_cnt[4];
+                                const uint32_t lo8[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w}, cn8[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                                        s_lo[s] = uni(lo8[s]);
+                                        s_cnt[s] = s < nslots ? uni(cn8[s]) : 0u;
+                                        total += s_cnt[s];
+                                }
                         }
                         PROF_LAP(1);
                         // ---- set pass: the rows of all slots form one work list, dealt out round by round
@@ -795,48 +867,9 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                         }
                                 }
                         }
-                        // the next window's far cell-index entry travels while the set pass runs
-                        if (indexed) {
-                                e_lo = e_hi;
-                                e_hi = pf;
-                                pf = win[myt.win_off + (w + 3) * CELLS];
-                        }
                         PROF_LAP(2);
                         __syncthreads();
                         PROF_LAP(3);
-                        // ---- sweep, stage 1 per 16-byte chunk: the CNF predicate counts the matches; a match that holds an ESSENTIAL slot is
-                        //      queued on the wave's list (everything else is re-zeroed at once); the list is scored by the wave itself when
-                        //      it fills and at the end (fused_flush), so only documents that can beat the threshold ever pay the table
-                        //      lookups.  A full candidate buffer is pruned and the sweep resumed over the words that were put back.
-                        for (;;) {
-                                const bool full = uni(sh.tk_full) != 0;
-                                const double thr_s = sh.thr_s;
-                                const uint32_t thr_d = sh.thr_d;
-                                const uint32_t emask = uni(sh.emask);
-                                // the predicate in its cheapest form for the query at hand (uniform): one required group and nothing excluded (a
-                                // union: any of its fields), up to four groups from registers, or the general walk with masked documents on top
-                                if (!masked && nreq == 1 && nmask == 0)
-                                        fused_sweep<CODEC, 0, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
-                                else if (!masked && nreq <= 4)
-                                        fused_sweep<CODEC, 1, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
-                                else
-                                        fused_sweep<CODEC, 2, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
-                                PROF_LAP(6);
-                                __syncthreads();
-                                PROF_LAP(7);
-                                const uint32_t ov = uni(sh.overflow);
-                                const uint32_t n = min(uni(sh.tk_n), FUS_CAP);
-                                if (ov || n > (FUS_CAP + k) / 2) {
-                                        __syncthreads(); // (every lane has read overflow / tk_n)
-                                        fused_prune(sh, n, k);
-                                        sh.emask = fused_essential(sh, nslots, fbits); // same value from every lane
-                                        __syncthreads();
-                                }
-                                if (!ov)
-                                        break;
-                        }
-                        PROF_LAP(4);
-                        ++w;
                 }
                 // ---- the task's result: its best k (ranked) and its match count
                 __syncthreads();
