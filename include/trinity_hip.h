@@ -53,6 +53,8 @@ extern "C" {
                             Lowered: NOT at the root or under AND, excluded side = a term or an OR of terms */
 #define TRI_OP_OPT 5u    /* operand = 2: (main, optional) — consttrueexpr under an AND (`a <b>`) -> DocsSetIterators::Optional, exec.cpp:366-377: the
                             documents of main; the optional side (a term or an OR of terms) only adds its score / its matched terms */
+#define TRI_OP_SOME 6u   /* operand = (min << 16) | #children — matchsome `[a, b, ...]` with a threshold -> DocsSetIterators::DisjunctionSome,
+                            exec.cpp:276-283, docset_iterators.cpp:679-811: the documents at least `min` of the children match */
 #define TRI_TOK(op, arg) (((uint32_t)(op) << 28) | ((uint32_t)(arg)&0x0fffffffu))
 
 typedef struct tri_dev tri_dev;

@@ -73,9 +73,10 @@ def dense(T, dev):
     return World(T, dev, 20000, 500, 12, 7)
 
 
-def gpu_lowers(q):
-    """The fixtures hold one shape the planner does not lower: NOT of an AND (`a NOT (b c)`) -> TRI_ERR_UNSUPPORTED."""
-    if "NOT (" not in q:
+def gpu_lowers(q, rich=False):
+    """Every fixture shape is lowered in DocumentsOnly and AccumulatedScore top-K mode (NOT of an AND — `a NOT (b c)` — runs off a
+    truth table); the default (matched terms) mode still answers TRI_ERR_UNSUPPORTED to that one."""
+    if not rich or "NOT (" not in q:
         return True
     return " OR " in q.split("NOT (", 1)[1]
 
@@ -671,12 +672,87 @@ def test_not_scored_topk_match_oracle(request, world, k):
         np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
 
 
-def test_not_of_conjunction_is_refused(T, dev):
+# ------------------------------------------------------------------------------------------ general trees: truth tables in k_fused
+TREE_TEMPLATES = [("t{a} NOT (t{b} t{c})", 1), ("t{a} OR (t{b} NOT t{c})", 1), ("t{a} OR (t{b} t{c})", 1), ("(t{a} t{b}) OR (t{c} t{d})", 1), ("t{a} <t{b} t{c}>", 1),
+                  ("t{a} (t{b} OR (t{c} t{d}))", 1), ("t{a} NOT (t{b} OR (t{c} t{d}))", 1), ("(t{a} NOT t{b}) OR (t{c} NOT t{d}) OR t{e}", 1), ("t{a} <t{b} NOT t{c}>", 1),
+                  ("[t{a}, t{b}, t{c}]", 2), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 2), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 3), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 5), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 1),
+                  ("t{a} [t{b}, t{c}, t{d}]", 2), ("[t{a}, t{b} t{c}, t{d} OR t{e}]", 2), ("t{e} OR [t{a} t{b}, t{c}, t{d} NOT t{a}]", 2), ("[t{a}, t{b}, t{c}] NOT t{d}", 2)]
+
+
+def tree_queries(w, seed, n):
+    rows = w.T.gen_queries(w.V, seed, n, 5).tolist() + [[0, 1, 2, 3, 4], [4, 3, 2, 1, 0], [1, 0, 3, 2, 5], [0, w.V - 1, 1, w.V - 2, 2]]
+    texts, progs = [], []
+    for a, b, c, d, e in rows:
+        for tpl, mn in TREE_TEMPLATES:
+            texts.append(f"{tpl.format(a=a, b=b, c=c, d=d, e=e)} /{mn}")
+            progs.append(O.parse_query(tpl.format(a=a, b=b, c=c, d=d, e=e), some_min=mn))
+    return texts, progs
+
+
+@pytest.mark.parametrize("world,n", [("small", 8), ("dense", 8), ("dense_l", 6), ("medium", 4)])
+def test_general_trees_docsets_match_oracle(request, world, n):
+    """matchsome, NOT / Optional of a subtree, AND under OR: DocumentsOnly through the truth-table predicate of the one-pass kernel,
+    docID sets equal to the oracle's iterator trees (pinned to the genuine reference on these shapes: tests/golden querysome + NOT records);
+    32-bit and 16-bit window words, many small tasks."""
+    w = request.getfixturevalue(world)
+    texts, progs = tree_queries(w, 71, n)
+    for opts in ({}, {"fused_halfwords": 0}, {"fused_task_cost": 2048}):
+        with options(w.dev, **opts):
+            sets, hashes, info = run_docs_only(w, progs)
+        assert info["fused_queries"] > 0
+        for t, p, got, h in zip(texts, progs, sets, hashes):
+            want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+            assert np.array_equal(got, want), (opts, t, len(got), len(want))
+            assert int(h) == O.fnv1a_docs(want), (opts, t)
+
+
+@pytest.mark.parametrize("world,n,k", [("small", 8, 10), ("dense", 8, 100), ("dense_l", 6, 100), ("medium", 4, 256)])
+def test_general_trees_scored_topk_match_oracle(request, world, n, k):
+    """... and AccumulatedScore top-K: a document's score is the sum over the scorer leaves that sit on it THROUGH the tree
+    (docset_iterators_scorers.cpp:38-57, 77-104, 107-193), which the planner tabulates per presence pattern."""
+    w = request.getfixturevalue(world)
+    texts, progs = tree_queries(w, 72, n)
+    for opts in ({}, {"fused_halfwords": 0}, {"fused_freq_cap": 1}, {"fused_task_cost": 2048}):
+        with options(w.dev, **opts):
+            check_scored(w, texts, progs, k, tag=opts)
+
+
+def test_matchsome_against_reference_fixtures(T, dev):
+    """The genuine reference's DisjunctionSome answers (`querysome` records: DocumentsOnly sets, AccumulatedScore top-10)."""
+    checked = 0
+    for name in ("tiny", "small", "dense"):
+        g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
+        c = g["corpus"]
+        w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
+        recs = [r for r in g["results"] if r["cmd"] == "querysome" and r["flags"] == 1]
+        sets, hashes, _ = run_docs_only(w, [O.parse_query(r["q"], some_min=r["min"]) for r in recs])
+        for r, got, h in zip(recs, sets, hashes):
+            assert len(got) == r["n"] and str(int(h)) == r["fnv"], (name, r["q"], r["min"])
+            checked += 1
+        recs = [r for r in g["results"] if r["cmd"] == "querysome" and r["flags"] == 2 and "top" in r]
+        d, s, cnt, counts = run_scored(w, [O.parse_query(r["q"], some_min=r["min"]) for r in recs], 10)
+        for i, r in enumerate(recs):
+            assert int(counts[i]) == r["n"], (name, r["q"], r["min"])
+            top = r["top"]
+            assert d[i, : len(top)].tolist() == [x[0] for x in top], (name, r["q"], r["min"])
+            np.testing.assert_allclose(s[i, : len(top)], [x[1] for x in top], rtol=1e-5)
+            checked += 1
+        w.ix.close()
+    assert checked >= 300
+
+
+def test_shapes_still_refused(T, dev):
+    """What the planner answers TRI_ERR_UNSUPPORTED to (the caller keeps its CPU span): a multi-word phrase under an OR, a general
+    tree in the default (matched terms) mode or with topk == 0, more than 8 distinct terms in a general tree."""
     w = World(T, dev, 2000, 200, 10, 42)
     with pytest.raises(T.TrinityError):
-        T.Batch(w.ix, [O.parse_query("t0 NOT (t1 t2)")], T.FLAG_DOCUMENTS_ONLY)
+        T.Batch(w.ix, [O.parse_query('t0 OR "t1 t2"')], T.FLAG_DOCUMENTS_ONLY)
     with pytest.raises(T.TrinityError):
-        T.Batch(w.ix, [O.parse_query("t0 OR (t1 NOT t2)")], T.FLAG_DOCUMENTS_ONLY)
+        T.Batch(w.ix, [O.parse_query("t0 NOT (t1 t2)")], T.FLAG_MATCHED_TERMS)
+    with pytest.raises(T.TrinityError):
+        T.Batch(w.ix, [O.parse_query("t0 NOT (t1 t2)")], T.FLAG_ACCUMULATED_SCORE, topk=0)
+    with pytest.raises(T.TrinityError):
+        T.Batch(w.ix, [O.parse_query("t0 OR (t1 t2) OR (t3 t4) OR (t5 t6) OR (t7 t8)")], T.FLAG_DOCUMENTS_ONLY)
     w.ix.close()
 
 
@@ -802,7 +878,7 @@ def test_rich_mode_against_reference_fixtures(T, dev):
         g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
         c = g["corpus"]
         w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
-        recs = [r for r in g["results"] if r["cmd"] == "query" and r["flags"] == 0 and gpu_lowers(r["q"])]
+        recs = [r for r in g["results"] if r["cmd"] == "query" and r["flags"] == 0 and gpu_lowers(r["q"], rich=True)]
         for r, (docs, terms, present, freq, pos) in zip(recs, run_rich(w, [O.parse_query(r["q"]) for r in recs])):
             assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
             assert int(freq.sum()) == r["hits_total"], r["q"]

@@ -67,9 +67,12 @@ constexpr uint32_t TASK_CAND = 0;  // candidate tiles of the lead list, filtered
 constexpr uint32_t TASK_DENSE = 1; // bitmap algebra over fixed docID windows (every list dense enough)
 constexpr uint32_t TASK_FUSED = 2; // AccumulatedScoreScheme + top-K of a dense query: decode, match, score and select in one pass over docID
                                    // windows (k_fused.hpp); tile_begin / tile_end count windows of FUS_W documents; nothing is written to out[]
+                                   // (general trees in DocumentsOnly mode — FUS_MODE_EMIT — write their matches there)
 constexpr uint32_t TASK_FUSED16 = 3; // ... with 16-bit window words (<= 5 distinct terms): windows of 2 * FUS_W documents
 
+constexpr uint32_t TASK_FUSED_GEN = 4; // ... a general tree (truth-table predicate; DocumentsOnly: matches written to out[]): 32-bit window words
 constexpr uint32_t FUS_MAX_SLOTS = 8;
+constexpr uint32_t FUS_MAX_LEAVES = 16; // scorer leaves of a general tree
 // planner -> kernel: how a fused query's terms map onto the window words
 struct DevFused {
         uint32_t nslots;                // distinct terms: CNF terms (incl. the excluded group) and scoring-only (optional) terms
@@ -81,5 +84,15 @@ struct DevFused {
         uint32_t gslots[FUS_MAX_SLOTS]; // per required group: bit s = slot s belongs to it (window skipping)
         uint32_t nmask;                 // fields of the excluded group (logicalnot), 0 = none
         uint32_t hw;                    // 1: 16-bit window words (two documents per LDS word, windows twice as long)
+        // ---- general trees (matchsome, NOT / Optional of any subtree, nested AND / OR): the match predicate is a truth table over the
+        //      slots' PRESENCE bits, and so is every scorer leaf's "contributes to the score of this document" (the reference sums the
+        //      sub-iterators that sit on the document: docset_iterators_scorers.cpp:38-57, 77-104, 107-193)
+        uint32_t mode;                          // FUS_MODE_* bits
+        uint32_t nleaf;                         // scorer leaves (== DevQuery::nscore)
+        uint32_t tt[8];                         // bit p: a document that holds exactly the slots of pattern p matches
+        uint8_t leaf_slot[FUS_MAX_LEAVES];      // scorer leaf -> slot of its term
+        uint32_t ctt[FUS_MAX_LEAVES][8];        // per scorer leaf: the patterns in which it adds its score
 };
+constexpr uint32_t FUS_MODE_TT = 1;   // predicate = tt, scores through ctt
+constexpr uint32_t FUS_MODE_EMIT = 2; // DocumentsOnly: the window's matches are written to out[] (ascending), nothing is scored
 

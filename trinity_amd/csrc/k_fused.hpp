@@ -361,7 +361,7 @@ __device__ __forceinline__ uint32_t fused_essential(const FusedShared &sh, const
 // Score the documents a wave has queued (window-relative docIDs in its wlist), one per lane: table lookups (one per chunk of
 // the word: cb bits, a whole number of fields), the rare exact rescoring, threshold, append to the workgroup's candidate buffer.
 // A full buffer puts the word back for the resumed sweep.
-template <int CODEC, int HW>
+template <int CODEC, int HW, int GEN>
 __device__ __noinline__ uint32_t fused_flush(FusedShared &sh, const uint32_t wn, const uint32_t w0, const uint32_t nch, const uint32_t cb, const bool full,
                                              const double thr_s, const uint32_t thr_d, const uint8_t *__restrict__ index,
                                              const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const DevQuery &q,
@@ -369,6 +369,7 @@ __device__ __noinline__ uint32_t fused_flush(FusedShared &sh, const uint32_t wn,
         const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
         const DevFused &fq = sh.fq;
         const uint32_t cm = (1u << cb) - 1u;
+        const bool ttm = GEN && (uni(fq.mode) & FUS_MODE_TT);
         uint32_t nback = 0; // documents put back (wave-uniform: counted where the whole wave has reconverged)
         for (uint32_t c0 = 0; c0 < wn; c0 += 64) {
                 const uint32_t c = c0 + lane;
@@ -392,7 +393,20 @@ __device__ __noinline__ uint32_t fused_flush(FusedShared &sh, const uint32_t wn,
                         if (nch > 3)
                                 s += sh.tab[3][(x >> (3 * cb)) & cm];
                         const uint32_t doc = w0 + idx;
-                        if (!(s == s)) { // a saturated field: rescore from the postings, scorer by scorer
+                        if (ttm) { // a general tree: the scorer leaves that sit on a document of this presence pattern (DevFused::ctt)
+                                s = 0.0;
+                                const uint32_t fbits = fq.fbits, cap = fq.cap, fmask = (1u << fbits) - 1u;
+                                uint32_t p = 0;
+                                for (uint32_t sl = 0; sl < fq.nslots; ++sl)
+                                        p |= (((x >> (sl * fbits)) & fmask) ? 1u : 0u) << sl;
+                                for (uint32_t si = 0; si < q.nscore; ++si) {
+                                        if (!((fq.ctt[si][p >> 5] >> (p & 31u)) & 1u))
+                                                continue;
+                                        const uint32_t sl = fq.leaf_slot[si], code = (x >> (sl * fbits)) & fmask;
+                                        const uint32_t f = code > cap ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[sl], doc) : code - 1u;
+                                        s += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                }
+                        } else if (!(s == s)) { // a saturated field: rescore from the postings, scorer by scorer
                                 s = 0.0;
                                 const uint32_t fbits = fq.fbits, cap = fq.cap, fmask = (1u << fbits) - 1u;
                                 for (uint32_t si = 0; si < q.nscore; ++si) {
@@ -431,7 +445,7 @@ __device__ __noinline__ uint32_t fused_flush(FusedShared &sh, const uint32_t wn,
 // required group; 1 = up to four groups from registers, excluded fields; 2 = any number of groups, masked documents) counts the
 // matches; a match that holds an ESSENTIAL slot is queued on the wave's list, everything else is re-zeroed at once; the list is
 // scored by the wave itself when it fills and at the end (fused_flush).
-template <int CODEC, int PK, int HW>
+template <int CODEC, int PK, int HW, int GEN>
 __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, const uint32_t nch, const uint32_t cb, const bool full, const double thr_s,
                                             const uint32_t thr_d, const uint32_t emask, const uint32_t nmask, const uint32_t nreq, const uint32_t gm0,
                                             const uint32_t gm1, const uint32_t gm2, const uint32_t gm3, const uint32_t *__restrict__ masked,
@@ -448,6 +462,8 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                 return l;
         };
         uint32_t wn = 0;                     // entries on this wave's list (wave-uniform)
+        const uint32_t fmode = (GEN && PK == 2) ? uni(sh.fq.mode) : 0u, tt_nslots = (GEN && PK == 2) ? uni(sh.fq.nslots) : 0u,
+                       tt_fbits = (GEN && PK == 2) ? uni(sh.fq.fbits) : 0u, tt_fmask = (1u << tt_fbits) - 1u;
         if (HW && PK != 2) {
                 // 16-bit words, predicates of up to four groups: BOTH documents of a word at once.  nz16(y) = v_pk_min_u16(y, 1|1<<16)
                 // has bit 0 / 16 set where the low / high half of y is non-zero; a required group is nz16(x & its fields), the
@@ -501,7 +517,7 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                                 if (wn > FUS_WLIST - 64) { // this round might not fit: score what is queued
                                         __builtin_amdgcn_wave_barrier();
                                         PROF_LAP(6);
-                                        wave_matches -= fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                        wave_matches -= fused_flush<CODEC, HW, GEN>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
                                         PROF_LAP(11);
                                         wn = 0;
                                 }
@@ -519,7 +535,7 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                 wave_matches += uni(lane_matches);
                 if (wn) {
                         __builtin_amdgcn_wave_barrier();
-                        wave_matches -= fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
+                        wave_matches -= fused_flush<CODEC, HW, GEN>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
                 }
                 PROF_LAP(11);
                 return;
@@ -544,16 +560,25 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                                 else if (PK == 1)
                                         m = (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
                                 else {
-                                        m = x != 0 && (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
-                                        for (uint32_t g = 4; g < nreq; ++g)
-                                                m &= (x & sh.fq.gmask[g]) != 0;
+                                        if (fmode & FUS_MODE_TT) { // a general tree: the truth table over the slots' presence bits
+                                                uint32_t p = 0;
+                                                for (uint32_t sl = 0; sl < tt_nslots; ++sl)
+                                                        p |= (((x >> (sl * tt_fbits)) & tt_fmask) ? 1u : 0u) << sl;
+                                                m = x != 0 && ((sh.fq.tt[p >> 5] >> (p & 31u)) & 1u);
+                                        } else {
+                                                m = x != 0 && (x & nmask) == 0 && (x & gm0) && (x & gm1) && (x & gm2) && (x & gm3);
+                                                for (uint32_t g = 4; g < nreq; ++g)
+                                                        m &= (x & sh.fq.gmask[g]) != 0;
+                                        }
                                         if (masked && m) { // masked_documents_registry::test (docidupdates.h:90-119)
                                                 const uint32_t doc = w0 + idx;
                                                 m = !((masked[doc >> 5] >> (doc & 31u)) & 1u);
                                         }
+                                        if ((fmode & FUS_MODE_EMIT) && m) // DocumentsOnly: the window's matches as a bitmap, expanded by the caller
+                                                atomicOr(&((uint32_t *)sh.tk_s)[idx >> 5], 1u << (idx & 31u));
                                 }
                                 wave_matches += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(m)); // (wave-uniform counter: scalar registers)
-                                const bool e = m && (x & emask) != 0;
+                                const bool e = m && (x & emask) != 0 && !(PK == 2 && (fmode & FUS_MODE_EMIT));
                                 const uint64_t bal = __builtin_amdgcn_ballot_w64(e);
                                 if (bal != 0ull) { // (wave-uniform)
                                         if (e)
@@ -565,18 +590,20 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                         sh.acc[i0 + c] = keep; // (written back word by word: a flush may run before the chunk is through)
                         if (wn > FUS_WLIST - 64 * DPW) { // the next word position might not fit: score what is queued
                                 __builtin_amdgcn_wave_barrier();
-                                wave_matches -= fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
+                                wave_matches -= fused_flush<CODEC, HW, GEN>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
                                 wn = 0;
                         }
                 }
         }
         if (wn) {
                 __builtin_amdgcn_wave_barrier();
-                wave_matches -= fused_flush<CODEC, HW>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
+                wave_matches -= fused_flush<CODEC, HW, GEN>(sh, wn, w0, nch, cb, full, thr_s, thr_d, index, blk_last, blk_off, q, sterms, sweights, sim);
         }
 }
 
-template <int CODEC, int HW>
+// GEN = 1: the instantiation that also knows general trees (truth-table predicate, DocumentsOnly emission) — kept out of the
+// CNF kernels, whose registers it would weigh on.
+template <int CODEC, int HW, int GEN>
 __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void k_fused(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                      const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
                                                      const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
@@ -585,7 +612,8 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                                      const uint32_t *__restrict__ sterms, const double *__restrict__ sweights, const uint32_t ntasks,
                                                      uint32_t *__restrict__ ticket, uint32_t *__restrict__ counts, const uint32_t k,
                                                      uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
-                                                     uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked, const int sim) {
+                                                     uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked, const int sim,
+                                                     uint32_t *__restrict__ out) {
         __shared__ FusedShared sh;
         constexpr uint32_t W = FusGeom<HW>::W, CELLS = FusGeom<HW>::CELLS;
         const uint32_t tid = threadIdx.x;
@@ -615,6 +643,11 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 __syncthreads();
                 const DevFused &fq = sh.fq;
                 const uint32_t nslots = uni(fq.nslots), fbits = uni(fq.fbits), cap = uni(fq.cap), nreq = uni(fq.nreq), nmask = uni(fq.nmask);
+                const uint32_t fmode = GEN ? uni(fq.mode) : 0u; // general tree (truth-table predicate) / DocumentsOnly (matches written to out[])
+                uint32_t produced = 0;               // FUS_MODE_EMIT: docIDs this task has written
+                if (fmode & FUS_MODE_EMIT)           // (the window's match bitmap lives in the candidate buffer nobody else needs)
+                        for (uint32_t i = tid; i < 2 * FUS_CAP; i += FUS_WG)
+                                ((uint32_t *)sh.tk_s)[i] = 0;
                 const uint32_t per = 8 / fbits, cb = per * fbits, nch = (nslots + per - 1) / per; // the word is scored in nch chunks of cb bits (per fields each)
                 const uint32_t kk = min(tid & 63u, nslots - 1); // in EVERY wave lane s (< nslots) tracks slot s, the lanes above mirror the last slot:
                                                                 // a wave reads the slots' block ranges out of its own lanes (readlane), no LDS, no barrier
@@ -788,15 +821,42 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                         const uint32_t emask = uni(sh.emask);
                                         // the predicate in its cheapest form for the query at hand (uniform): one required group and nothing excluded (a
                                         // union: any of its fields), up to four groups from registers, or the general walk with masked documents on top
-                                        if (!masked && nreq == 1 && nmask == 0)
-                                                fused_sweep<CODEC, 0, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
-                                        else if (!masked && nreq <= 4)
-                                                fused_sweep<CODEC, 1, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
+                                        if (!fmode && !masked && nreq == 1 && nmask == 0)
+                                                fused_sweep<CODEC, 0, HW, GEN>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
+                                        else if (!fmode && !masked && nreq <= 4)
+                                                fused_sweep<CODEC, 1, HW, GEN>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
                                         else
-                                                fused_sweep<CODEC, 2, HW>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
+                                                fused_sweep<CODEC, 2, HW, GEN>(sh, w0, nch, cb, full, thr_s, thr_d, emask, nmask, nreq, gm0, gm1, gm2, gm3, masked, wave_matches, index, blk_last, blk_off, q, sterms, sweights, sim PROF_PASS);
                                         PROF_LAP(6);
                                         __syncthreads();
                                         PROF_LAP(7);
+                                        if (fmode & FUS_MODE_EMIT) { // the window's match bitmap -> ascending docIDs (two words per thread)
+                                                uint32_t *bm = (uint32_t *)sh.tk_s;
+                                                constexpr uint32_t BW = W / 32;
+                                                static_assert(BW <= 2 * FUS_WG && BW <= 2 * FUS_CAP, "two bitmap words per thread, inside the candidate buffer");
+                                                uint32_t m0 = 2 * tid < BW ? bm[2 * tid] : 0u, m1 = 2 * tid + 1 < BW ? bm[2 * tid + 1] : 0u;
+                                                uint32_t wtot;
+                                                const uint32_t ex = wave_excl_scan((uint32_t)(__popc(m0) + __popc(m1)), wtot);
+                                                sh.tk_d[tid >> 6] = wtot;
+                                                __syncthreads();
+                                                uint32_t wbase = 0, total = 0;
+                                                for (uint32_t wv = 0; wv < FUS_WG / 64; ++wv) {
+                                                        wbase += wv < (tid >> 6) ? sh.tk_d[wv] : 0u;
+                                                        total += sh.tk_d[wv];
+                                                }
+                                                uint32_t *qout = out + task.out_off + produced + wbase + ex;
+                                                const uint32_t base = w0 + 64 * tid;
+                                                for (; m0; m0 &= m0 - 1u)
+                                                        *qout++ = base + (uint32_t)__builtin_ctz(m0);
+                                                for (; m1; m1 &= m1 - 1u)
+                                                        *qout++ = base + 32u + (uint32_t)__builtin_ctz(m1);
+                                                if (2 * tid < BW)
+                                                        bm[2 * tid] = 0;
+                                                if (2 * tid + 1 < BW)
+                                                        bm[2 * tid + 1] = 0;
+                                                produced += uni(total);
+                                                __syncthreads();
+                                        }
                                         const uint32_t ov = uni(sh.overflow);
                                         const uint32_t n = min(uni(sh.tk_n), FUS_CAP);
                                         if (ov || n > (FUS_CAP + k) / 2) {
@@ -876,13 +936,14 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 fused_prune(sh, min(uni(sh.tk_n), FUS_CAP), k);
                 atomicAdd(&sh.matches, (tid & 63u) == 0 ? wave_matches : 0u); // (every lane issues it: no single-lane branch)
                 __syncthreads();
-                const uint32_t n = uni(sh.tk_n);
+                const uint32_t n = (fmode & FUS_MODE_EMIT) ? 0u : uni(sh.tk_n);
                 for (uint32_t i = tid; i < n; i += FUS_WG) {
                         part_docs[(uint64_t)tix * k + i] = sh.tk_d[i];
                         part_scores[(uint64_t)tix * k + i] = sh.tk_s[i];
                 }
                 if (wave == 0) {
-                        part_counts[tix] = n;
+                        if (!(fmode & FUS_MODE_EMIT))
+                                part_counts[tix] = n;
                         counts[tix] = uni(sh.matches);
                 }
                 __syncthreads();

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -132,7 +133,7 @@ struct tri_batch {
         std::vector<DevTask> tasks; // scheduling order (cost descending)
         DevTask *d_tasks = nullptr;
         uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones, then the TASK_FUSED ones
-        uint32_t n_dense = 0, n_cand = 0, n_fused = 0, n_fused16 = 0; // (n_fused: 32-bit window words; n_fused16: 16-bit)
+        uint32_t n_dense = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0; // (n_fused: 32-bit window words; n_fused16: 16-bit; n_fusedgen: general trees)
         std::vector<DevFused> fused; // slot maps of the TASK_FUSED queries (DevQuery::fused_idx)
         DevFused *d_fused = nullptr;
         uint64_t term_bytes_fused = 0;
@@ -840,11 +841,29 @@ namespace {
                                 n.cost = arg < ix->terms.size() ? ix->terms[arg].documents : 0;
                                 n.empty = n.cost == 0; // unknown term == no documents (index_source.h:60-72)
                         } else {
-                                if (arg < 1 || arg > st.size())
+                                const uint32_t nk = op == TRI_OP_SOME ? (arg & 0xffffu) : arg; // operands taken off the stack
+                                if (nk < 1 || nk > st.size())
                                         return -1;
-                                std::vector<int> kids(st.end() - arg, st.end());
-                                st.resize(st.size() - arg);
-                                if (op == TRI_OP_PHRASE) {
+                                std::vector<int> kids(st.end() - nk, st.end());
+                                st.resize(st.size() - nk);
+                                if (op == TRI_OP_SOME) {
+                                        // matchsome (exec.cpp:276-283): operands that can never match are dropped; fewer live operands than
+                                        // the threshold: never matches.  cost: docset_iterators.cpp:733-742, the (cnt - min + 1) cheapest
+                                        const uint32_t mn = arg >> 16;
+                                        if (!mn || mn > nk)
+                                                return -1;
+                                        for (int k : kids)
+                                                if (!nodes[k].empty)
+                                                        n.kids.push_back(k);
+                                        n.term = mn; // (the threshold rides in the otherwise unused field)
+                                        n.empty = n.kids.size() < mn;
+                                        std::vector<uint64_t> cs;
+                                        for (int k : n.kids)
+                                                cs.push_back(nodes[k].cost);
+                                        std::sort(cs.begin(), cs.end());
+                                        for (size_t i = 0; i + mn <= cs.size(); ++i)
+                                                n.cost += cs[i];
+                                } else if (op == TRI_OP_PHRASE) {
                                         if (arg > 16) // trinity_limits.h:12 MaxPhraseSize
                                                 return -1;
                                         for (int k : kids) {
@@ -904,6 +923,134 @@ namespace {
                 }
                 return st.size() == 1 ? st[0] : -1;
         }
+
+        // ---- general trees: what the CNF lowering does not take (matchsome, NOT / Optional of any subtree, AND under OR ...) runs as
+        // TASK_FUSED with a truth table over the presence of the query's distinct terms (<= FUS_MAX_SLOTS, no multi-word phrase).
+        struct TruthPlan {
+                std::vector<uint32_t> slots;               // distinct terms, order of first appearance
+                std::vector<uint32_t> leaves, leaf_tok;    // scorer leaves (positive TERM nodes) in tree order, and their program tokens
+                std::vector<uint32_t> leaf_slot;
+                uint32_t tt[8] = {};
+                std::vector<std::array<uint32_t, 8>> ctt;
+        };
+        struct TruthBuilder {
+                const std::vector<PNode> &nodes;
+                TruthPlan &tp;
+                std::vector<int> leaf_of_node; // node -> scorer leaf index (-1: none)
+                bool ok = true;
+                uint32_t slot_of(uint32_t term) {
+                        for (size_t i = 0; i < tp.slots.size(); ++i)
+                                if (tp.slots[i] == term)
+                                        return (uint32_t)i;
+                        tp.slots.push_back(term);
+                        return (uint32_t)tp.slots.size() - 1;
+                }
+                // first walk: slots for every term, scorer leaves for the terms an iterator of the tree can report
+                void scan(int ni, bool positive) {
+                        const PNode &x = nodes[ni];
+                        if (x.op == TRI_OP_TERM || (x.op == TRI_OP_PHRASE && x.kids.size() == 1)) {
+                                const PNode &t = x.op == TRI_OP_TERM ? x : nodes[x.kids[0]];
+                                const uint32_t sl = slot_of(t.term);
+                                if (positive) {
+                                        leaf_of_node[ni] = (int)tp.leaves.size();
+                                        tp.leaves.push_back(t.term);
+                                        tp.leaf_tok.push_back(t.tok);
+                                        tp.leaf_slot.push_back(sl);
+                                }
+                                return;
+                        }
+                        if (x.op == TRI_OP_PHRASE) {
+                                ok = false; // a positional constraint is not a function of presence
+                                return;
+                        }
+                        for (size_t k = 0; k < x.kids.size(); ++k)
+                                scan(x.kids[k], positive && !(x.op == TRI_OP_NOT && k == 1));
+                }
+                bool eval(int ni, uint32_t p) const {
+                        const PNode &x = nodes[ni];
+                        switch (x.op) {
+                                case TRI_OP_TERM:
+                                        return (p >> slot_const(x.term)) & 1u;
+                                case TRI_OP_PHRASE:
+                                        return (p >> slot_const(nodes[x.kids[0]].term)) & 1u;
+                                case TRI_OP_AND:
+                                        for (int k : x.kids)
+                                                if (!eval(k, p))
+                                                        return false;
+                                        return true;
+                                case TRI_OP_OR:
+                                        for (int k : x.kids)
+                                                if (eval(k, p))
+                                                        return true;
+                                        return false;
+                                case TRI_OP_SOME: {
+                                        uint32_t c = 0;
+                                        for (int k : x.kids)
+                                                c += eval(k, p) ? 1u : 0u;
+                                        return c >= x.term;
+                                }
+                                case TRI_OP_NOT: // Filter (docset_iterators.cpp:652-677)
+                                        return eval(x.kids[0], p) && !eval(x.kids[1], p);
+                                case TRI_OP_OPT: // Optional (docset_iterators.h:174-206): the documents of main
+                                        return eval(x.kids[0], p);
+                        }
+                        return false;
+                }
+                uint32_t slot_const(uint32_t term) const {
+                        for (size_t i = 0; i < tp.slots.size(); ++i)
+                                if (tp.slots[i] == term)
+                                        return (uint32_t)i;
+                        return 0;
+                }
+                // the scorer leaves that sit on a document of pattern p, through the tree (node ni matches p): what the reference's score() /
+                // collect_doc_matching_terms recursion reaches (docset_iterators_scorers.cpp:38-57, 77-104, 107-193; queryexec_ctx.cpp:382-520)
+                void collect(int ni, uint32_t p, uint32_t &mask) const {
+                        const PNode &x = nodes[ni];
+                        switch (x.op) {
+                                case TRI_OP_TERM:
+                                case TRI_OP_PHRASE:
+                                        if (leaf_of_node[ni] >= 0)
+                                                mask |= 1u << leaf_of_node[ni];
+                                        break;
+                                case TRI_OP_AND:
+                                        for (int k : x.kids)
+                                                collect(k, p, mask);
+                                        break;
+                                case TRI_OP_OR:
+                                case TRI_OP_SOME:
+                                        for (int k : x.kids)
+                                                if (eval(k, p))
+                                                        collect(k, p, mask);
+                                        break;
+                                case TRI_OP_NOT:
+                                        collect(x.kids[0], p, mask);
+                                        break;
+                                case TRI_OP_OPT:
+                                        collect(x.kids[0], p, mask);
+                                        if (eval(x.kids[1], p))
+                                                collect(x.kids[1], p, mask);
+                                        break;
+                        }
+                }
+        };
+        bool build_truth(const std::vector<PNode> &nodes, int root, TruthPlan &tp) {
+                TruthBuilder tb{nodes, tp, std::vector<int>(nodes.size(), -1)};
+                tb.scan(root, true);
+                if (!tb.ok || tp.slots.size() > FUS_MAX_SLOTS || tp.leaves.size() > FUS_MAX_LEAVES || tp.leaves.empty())
+                        return false;
+                tp.ctt.assign(tp.leaves.size(), std::array<uint32_t, 8>{});
+                for (uint32_t p = 0; p < (1u << tp.slots.size()); ++p) {
+                        if (!tb.eval(root, p))
+                                continue;
+                        tp.tt[p >> 5] |= 1u << (p & 31u);
+                        uint32_t mask = 0;
+                        tb.collect(root, p, mask);
+                        for (size_t j = 0; j < tp.leaves.size(); ++j)
+                                if ((mask >> j) & 1u)
+                                        tp.ctt[j][p >> 5] |= 1u << (p & 31u);
+                }
+                return !(tp.tt[0] & 1u); // (a tree that matches documents holding none of its terms cannot be enumerated from postings)
+        }
 } // namespace
 
 extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog_len, const tri_query *queries, size_t nq, const double *weights,
@@ -944,6 +1091,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 uint64_t cost;
                 uint32_t nlead;
                 bool fusable; // AccumulatedScore + top-K, no phrase, <= FUS_MAX_SLOTS distinct terms: may run as TASK_FUSED
+                bool truth;   // a general tree: runs as TASK_FUSED whatever its density (there is no other path for it)
                 DevFused fz;
         };
         std::vector<Tmp> tmp;
@@ -1081,8 +1229,21 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 if (mode != TRI_FLAG_DOCUMENTS_ONLY)
                                         b->term_bytes += ix->docbytes[x]; // its postings are read by k_score / k_rich
                         }
-                if (!ok || groups.empty())
-                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, and <optional> terms under AND", qi);
+                TruthPlan tp;
+                bool truth = false;
+                if (!ok || groups.empty()) {
+                        // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp), in
+                        // DocumentsOnly mode and as AccumulatedScore top-K
+                        const bool mode_ok = mode == TRI_FLAG_DOCUMENTS_ONLY || (scored && topk);
+                        if (!mode_ok || !build_truth(nodes, root, tp))
+                                return fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — DocumentsOnly or AccumulatedScore top-K, no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
+                        truth = true;
+                        groups.assign(1, tp.slots); // (one group of every slot: the bookkeeping below — term list, cost, output bound — sees a union)
+                        negs.clear();
+                        leaves = tp.leaves;
+                        leaf_tok = tp.leaf_tok;
+                        qphrases.clear();
+                }
                 auto gcost = [&](const std::vector<uint32_t> &g) {
                         uint64_t c = 0;
                         for (uint32_t x : g)
@@ -1165,8 +1326,53 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 }
                 // ---- slot map for the one-pass scored path (k_fused.hpp): the query's distinct terms, CNF terms first
                 t.fusable = false;
+                t.truth = truth;
                 t.fz = DevFused{};
-                if (scored && topk && qphrases.empty() && dev->opt.fused) {
+                if (truth) {
+                        DevFused &z = t.fz;
+                        z.nslots = (uint32_t)tp.slots.size();
+                        z.hw = 0; // (general trees run in their own instantiation, 32-bit window words)
+                        z.fbits = z.nslots <= 4 ? 8u : 4u;
+                        z.cap = (1u << z.fbits) - 2u;
+                        if (dev->opt.fused_freq_cap && dev->opt.fused_freq_cap < z.cap)
+                                z.cap = (uint32_t)dev->opt.fused_freq_cap;
+                        const uint32_t fm = (1u << z.fbits) - 1u;
+                        for (size_t i = 0; i < tp.slots.size(); ++i)
+                                z.term[i] = tp.slots[i];
+                        z.mode = FUS_MODE_TT | (scored ? 0u : FUS_MODE_EMIT);
+                        z.nleaf = (uint32_t)tp.leaves.size();
+                        memcpy(z.tt, tp.tt, sizeof z.tt);
+                        for (size_t j = 0; j < tp.leaves.size(); ++j) {
+                                z.leaf_slot[j] = (uint8_t)tp.leaf_slot[j];
+                                memcpy(z.ctt[j], tp.ctt[j].data(), sizeof z.ctt[j]);
+                        }
+                        // window skipping needs groups of slots one of which every match holds: the slots of the scorer leaves if no
+                        // matching pattern lacks them all (else every slot: pattern 0 never matches), then every slot all matches hold
+                        const uint32_t npat = 1u << z.nslots;
+                        auto matches = [&](uint32_t p) { return (tp.tt[p >> 5] >> (p & 31u)) & 1u; };
+                        uint32_t g0 = 0;
+                        for (uint32_t sl : tp.leaf_slot)
+                                g0 |= 1u << sl;
+                        for (uint32_t p = 0; p < npat; ++p)
+                                if (matches(p) && !(p & g0))
+                                        g0 = npat - 1;
+                        auto add_req = [&](uint32_t gs) {
+                                z.gslots[z.nreq] = gs;
+                                for (uint32_t sl = 0; sl < z.nslots; ++sl)
+                                        if ((gs >> sl) & 1u)
+                                                z.gmask[z.nreq] |= fm << (sl * z.fbits);
+                                ++z.nreq;
+                        };
+                        add_req(g0);
+                        for (uint32_t sl = 0; sl < z.nslots && z.nreq < FUS_MAX_SLOTS; ++sl) {
+                                bool all = g0 != (1u << sl);
+                                for (uint32_t p = 0; p < npat && all; ++p)
+                                        all = !matches(p) || ((p >> sl) & 1u);
+                                if (all)
+                                        add_req(1u << sl);
+                        }
+                        t.fusable = true;
+                } else if (scored && topk && qphrases.empty() && dev->opt.fused) {
                         std::vector<uint32_t> slots;
                         auto slot_of = [&](uint32_t term) {
                                 for (size_t i = 0; i < slots.size(); ++i)
@@ -1284,7 +1490,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         last_doc = std::min(last_doc, glast);
                 dense &= sumdf >= DENSE_MIN_POSTINGS;
                 dense |= nlead > 1;
-                const bool fuse = dense && t.fusable && (dev->opt.fused != 2 || t.fz.nreq == 1); // (fused == 2: only pure unions)
+                const bool fuse = t.truth || (dense && t.fusable && (dev->opt.fused != 2 || t.fz.nreq == 1)); // (fused == 2: only pure unions)
                 if (fuse) {
                         // every list of the slot map is read once (the optional terms too)
                         uint64_t slotdf = 0;
@@ -1296,16 +1502,33 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         t.q.fused_idx = (uint32_t)b->fused.size();
                         b->fused.push_back(t.fz);
                         t.q.out_off = off;
-                        t.q.out_cap = 0; // the docID set is never materialised
+                        t.q.out_cap = 0; // the docID set is never materialised ...
                         t.q.first_task = (uint32_t)b->tasks.size();
                         const uint32_t fw = FUS_W << t.fz.hw; // documents per window of this query's word width
                         const uint32_t nwin = last_doc / fw + 1;
                         const uint64_t per_win = std::max<uint64_t>(1, slotdf / (ix->info.docs_cnt / fw + 1));
                         const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
-                        for (uint32_t wb = 0; wb < nwin; wb += win_per_task) {
+                        const bool emit = t.fz.mode & FUS_MODE_EMIT; // ... except by a general tree in DocumentsOnly mode: a private region per task,
+                                                                     // bounded like TASK_DENSE's by the slots' blocks that reach the task's windows
+                        uint32_t ord = 0;
+                        for (uint32_t wb = 0; wb < nwin; wb += win_per_task, ++ord) {
                                 const uint32_t we = std::min(nwin, wb + win_per_task);
+                                uint64_t b1 = 0;
+                                if (emit)
+                                        for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
+                                                const DevTerm &tk = ix->terms[t.fz.term[sidx]];
+                                                const uint32_t *lb = &ix->h_blk_last[tk.first_block];
+                                                b1 += (uint64_t)(std::lower_bound(lb, lb + tk.nblocks, wb * fw) - lb);
+                                        }
                                 order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
-                                b->tasks.push_back({slot, wb, we, t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off});
+                                b->tasks.push_back({slot, wb, we, t.fz.mode ? TASK_FUSED_GEN : t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off + (emit ? b1 * 32 + 32ull * ord * t.fz.nslots : 0)});
+                        }
+                        if (emit) {
+                                uint64_t blocks = 0;
+                                for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx)
+                                        blocks += ix->terms[t.fz.term[sidx]].nblocks;
+                                t.q.out_cap = (uint32_t)std::min<uint64_t>(0xffffffffull, blocks * 32 + 32ull * (ord + 1) * t.fz.nslots);
+                                off += t.q.out_cap;
                         }
                         t.q.ntasks = (uint32_t)b->tasks.size() - t.q.first_task;
                         b->plan.push_back(t.q);
@@ -1384,6 +1607,10 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if (b->tasks[o.second].kind == TASK_FUSED16)
                         sched.push_back(o.second);
         b->n_fused16 = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused;
+        for (const auto &o : order)
+                if (b->tasks[o.second].kind == TASK_FUSED_GEN)
+                        sched.push_back(o.second);
+        b->n_fusedgen = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused - b->n_fused16;
         b->out_capacity = off;
         int rc;
         if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)) || (rc = dev_upload(&b->d_tasks, b->tasks)) ||
@@ -1429,7 +1656,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         }
         b->info.nqueries = nq;
         b->info.out_capacity = off;
-        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (!b->ptasks.empty()) + (rich ? 2 : 0) +
+        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (!b->ptasks.empty()) + (rich ? 2 : 0) +
                            ((scored && b->n_dense + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
         *out = b.release();
         return TRI_OK;
@@ -1495,26 +1722,30 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipEventRecord(b->ev_b, dev->stream));
                 // AccumulatedScore top-K of the dense queries: decode -> match -> score -> select in one pass; as many workgroups per CU as its
                 // LDS holds.  Two instantiations: 32-bit window words, and 16-bit ones (queries of <= 5 distinct terms: windows twice as long)
-                for (int hw = 0; hw < 2; ++hw) {
-                        const uint32_t nf = hw ? b->n_fused16 : b->n_fused;
+                for (int variant = 0; variant < 3; ++variant) { // 0: 32-bit words, 1: 16-bit words, 2: general trees (32-bit words)
+                        const uint32_t nf = variant == 0 ? b->n_fused : variant == 1 ? b->n_fused16 : b->n_fusedgen;
                         if (!nf)
                                 continue;
-                        const uint32_t *fsched = b->d_sched + b->n_dense + b->n_cand + (hw ? b->n_fused : 0);
+                        const uint32_t *fsched = b->d_sched + b->n_dense + b->n_cand + (variant >= 1 ? b->n_fused : 0) + (variant == 2 ? b->n_fused16 : 0);
                         const dim3 grid(std::min<uint32_t>(nf, (uint32_t)dev->cus * FUS_WGS_PER_CU));
 #define TRI_FUSED_ARGS                                                                                                                                 \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, fsched, \
-                b->d_sterms, b->d_sweights, nf, b->d_ticket + 56 + 4 * hw, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,    \
-                b->ix->d_masked, b->similarity
+                b->d_sterms, b->d_sweights, nf, b->d_ticket + 56 + 2 * variant, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores,                \
+                b->d_part_counts, b->ix->d_masked, b->similarity, b->d_out
                         if (b->ix->codec == TRI_CODEC_LUCENE) {
-                                if (hw)
-                                        hipLaunchKernelGGL((k_fused<CODEC_LUCENE, 1>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                                if (variant == 0)
+                                        hipLaunchKernelGGL((k_fused<CODEC_LUCENE, 0, 0>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                                else if (variant == 1)
+                                        hipLaunchKernelGGL((k_fused<CODEC_LUCENE, 1, 0>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
                                 else
-                                        hipLaunchKernelGGL((k_fused<CODEC_LUCENE, 0>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                                        hipLaunchKernelGGL((k_fused<CODEC_LUCENE, 0, 1>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
                         } else {
-                                if (hw)
-                                        hipLaunchKernelGGL((k_fused<CODEC_GOOGLE, 1>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                                if (variant == 0)
+                                        hipLaunchKernelGGL((k_fused<CODEC_GOOGLE, 0, 0>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                                else if (variant == 1)
+                                        hipLaunchKernelGGL((k_fused<CODEC_GOOGLE, 1, 0>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
                                 else
-                                        hipLaunchKernelGGL((k_fused<CODEC_GOOGLE, 0>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
+                                        hipLaunchKernelGGL((k_fused<CODEC_GOOGLE, 0, 1>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
                         }
 #undef TRI_FUSED_ARGS
                         HIP_TRY(hipGetLastError());
@@ -1634,9 +1865,9 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 m += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_DENSE)
                         m_dense += b->h_query_counts[sidx];
-                if (q.ntasks && (b->tasks[q.first_task].kind == TASK_FUSED || b->tasks[q.first_task].kind == TASK_FUSED16)) {
+                if (q.ntasks && b->tasks[q.first_task].kind >= TASK_FUSED) {
                         m_fused += b->h_query_counts[sidx];
-                        out_fused += 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk);
+                        out_fused += q.out_cap ? 4 * b->h_query_counts[sidx] : 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk); // (docIDs of a DocumentsOnly general tree)
                 }
         }
         b->info.dense_algorithmic_bytes = b->term_bytes_dense + 4 * m_dense;
@@ -1779,7 +2010,7 @@ extern "C" int tri_batch_docset(tri_batch *b, size_t q, uint32_t *out, size_t ca
         *n = slot == UINT32_MAX ? 0 : b->h_query_counts[slot];
         if (!*n || !out)
                 return TRI_OK;
-        if (b->plan[slot].ntasks && (b->tasks[b->plan[slot].first_task].kind == TASK_FUSED || b->tasks[b->plan[slot].first_task].kind == TASK_FUSED16))
+        if (b->plan[slot].ntasks && !b->plan[slot].out_cap && b->tasks[b->plan[slot].first_task].kind >= TASK_FUSED)
                 return fail(TRI_ERR_INVALID, "query %zu ran through the one-pass scored kernel: an AccumulatedScore top-K batch keeps top-K lists and match counts, not docID sets (use topk == 0 or DocumentsOnly)", q);
         if (cap < *n)
                 return fail(TRI_ERR_INVALID, "docset needs %zu slots, %zu given", *n, cap);
@@ -1807,7 +2038,7 @@ extern "C" int tri_batch_docset_hashes(tri_batch *b, uint64_t *hashes) {
         tri_dev *dev = b->ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
         const uint32_t n = (uint32_t)b->plan.size();
-        if (b->n_fused + b->n_fused16)
+        if ((b->n_fused + b->n_fused16 + b->n_fusedgen) && (b->flags & TRI_FLAG_ACCUMULATED_SCORE)) // (DocumentsOnly: the one-pass kernel's tasks wrote their matches)
                 return fail(TRI_ERR_INVALID, "the batch holds queries that ran through the one-pass scored kernel: their docID sets are not materialised");
         std::vector<uint64_t> h(n);
         if (n) {

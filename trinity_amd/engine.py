@@ -8,7 +8,7 @@ import numpy as np
 
 from .build import LIB_HIP, LIB_HOST
 
-OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT, OP_OPT = 0, 1, 2, 3, 4, 5
+OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT, OP_OPT, OP_SOME = 0, 1, 2, 3, 4, 5, 6  # OP_SOME: arg = (min << 16) | children (matchsome)
 FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE, FLAG_MATCHED_TERMS = 1, 2, 4
 CODEC_GOOGLE, CODEC_LUCENE = 1, 2
 FNV_EMPTY = 1469598103934665603
