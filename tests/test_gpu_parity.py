@@ -741,16 +741,56 @@ def test_matchsome_against_reference_fixtures(T, dev):
     assert checked >= 300
 
 
+@pytest.mark.parametrize("world,n", [("small", 6), ("dense", 6), ("dense_l", 4)])
+def test_general_trees_full_scores_and_rich_mode(request, world, n):
+    """... the full score stream (topk == 0: what consider(id, score) receives for every match) and exec_query's default mode: the
+    terms reported for a match are those whose iterators sit on it THROUGH the tree (queryexec_ctx.cpp:382-520), not every term it holds."""
+    w = request.getfixturevalue(world)
+    texts, progs = tree_queries(w, 73, n)
+    b = w.T.Batch(w.ix, progs, w.T.FLAG_ACCUMULATED_SCORE, topk=0)
+    b.run()
+    b.sync()
+    counts = b.counts()
+    for i, (t, p) in enumerate(zip(texts, progs)):
+        docs, scores = w.ora.exec(p, O.FLAG_ACCUM_SCORE)
+        assert int(counts[i]) == len(docs), t
+        assert np.array_equal(b.docset(i, len(docs)), docs), t
+        np.testing.assert_allclose(b.scores(i, len(docs)), scores, rtol=1e-5, atol=0, err_msg=t)
+    b.close()
+    for t, p, (docs, terms, present, freq, pos) in zip(texts, progs, run_rich(w, progs)):
+        wdocs, wflat, tt, ht = w.ora.exec_rich(p)
+        assert np.array_equal(docs, wdocs), t
+        got = rich_flat(docs, terms, present, freq, pos)
+        assert int(freq.sum()) == ht and int(sum(bin(int(x)).count("1") for x in present)) == tt, t
+        assert np.array_equal(got, wflat), t
+
+
+def test_matchsome_rich_mode_against_reference_fixtures(T, dev):
+    """`querysome 0` records: the genuine reference's matched terms and hits for DisjunctionSome trees."""
+    checked = 0
+    for name in ("small", "dense"):
+        g = json.load(open(os.path.join(GOLDEN, f"ref_{name}.json")))
+        c = g["corpus"]
+        w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
+        recs = [r for r in g["results"] if r["cmd"] == "querysome" and r["flags"] == 0] + [r for r in g["results"] if r["cmd"] == "query" and r["flags"] == 0 and not gpu_lowers(r["q"], rich=True)]
+        progs = [O.parse_query(r["q"], some_min=r.get("min", 1)) for r in recs]
+        for r, (docs, terms, present, freq, pos) in zip(recs, run_rich(w, progs)):
+            assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
+            assert int(freq.sum()) == r["hits_total"], r["q"]
+            assert str(O.fnv1a_u32_stream(rich_flat(docs, terms, present, freq, pos))) == r["rich_fnv"], r["q"]
+            checked += 1
+        w.ix.close()
+    assert checked >= 80
+
+
 def test_shapes_still_refused(T, dev):
-    """What the planner answers TRI_ERR_UNSUPPORTED to (the caller keeps its CPU span): a multi-word phrase under an OR, a general
-    tree in the default (matched terms) mode or with topk == 0, more than 8 distinct terms in a general tree."""
+    """What the planner answers TRI_ERR_UNSUPPORTED to (the caller keeps its CPU span): a multi-word phrase under an OR or inside a
+    general tree, more than 8 distinct terms in a general tree."""
     w = World(T, dev, 2000, 200, 10, 42)
     with pytest.raises(T.TrinityError):
         T.Batch(w.ix, [O.parse_query('t0 OR "t1 t2"')], T.FLAG_DOCUMENTS_ONLY)
     with pytest.raises(T.TrinityError):
-        T.Batch(w.ix, [O.parse_query("t0 NOT (t1 t2)")], T.FLAG_MATCHED_TERMS)
-    with pytest.raises(T.TrinityError):
-        T.Batch(w.ix, [O.parse_query("t0 NOT (t1 t2)")], T.FLAG_ACCUMULATED_SCORE, topk=0)
+        T.Batch(w.ix, [O.parse_query('t0 NOT ("t1 t2" t3)')], T.FLAG_DOCUMENTS_ONLY)
     with pytest.raises(T.TrinityError):
         T.Batch(w.ix, [O.parse_query("t0 OR (t1 t2) OR (t3 t4) OR (t5 t6) OR (t7 t8)")], T.FLAG_DOCUMENTS_ONLY)
     w.ix.close()

@@ -585,7 +585,7 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                                                 sh.wlist[wave][wn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (uint16_t)idx;
                                         wn += (uint32_t)__popcll(bal);
                                 }
-                                keep |= (e ? x : 0u) << (16 * h); // queued documents keep their code until they are scored
+                                keep |= ((e || (GEN && (fmode & FUS_MODE_EMIT) && m)) ? x : 0u) << (16 * h); // queued (emitted) documents keep their code until they are scored (written)
                         }
                         sh.acc[i0 + c] = keep; // (written back word by word: a flush may run before the chunk is through)
                         if (wn > FUS_WLIST - 64 * DPW) { // the next word position might not fit: score what is queued
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                                      uint32_t *__restrict__ ticket, uint32_t *__restrict__ counts, const uint32_t k,
                                                      uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
                                                      uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked, const int sim,
-                                                     uint32_t *__restrict__ out) {
+                                                     uint32_t *__restrict__ out, double *__restrict__ all_scores, uint32_t *__restrict__ allow) {
         __shared__ FusedShared sh;
         constexpr uint32_t W = FusGeom<HW>::W, CELLS = FusGeom<HW>::CELLS;
         const uint32_t tid = threadIdx.x;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 sh.overflow = 0;
                 sh.matches = 0;
                 sh.emask = 0xffffffffu; // no threshold yet: every slot is essential
-                {
+                if (!(fmode & FUS_MODE_EMIT)) { // (emitting tasks keep no top-K: no tables, no bounds — and in the default mode there are no weights)
                         // tab[c][v]: the fields inside chunk c of the word (v < 1 << cb).  code 0 = absent; code - 1 = freq; code cap + 1 = saturated
                         const uint32_t fmask = (1u << fbits) - 1u;
                         for (uint32_t e = tid; e < nch * 256; e += FUS_WG) {
@@ -844,17 +844,43 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                                         wbase += wv < (tid >> 6) ? sh.tk_d[wv] : 0u;
                                                         total += sh.tk_d[wv];
                                                 }
-                                                uint32_t *qout = out + task.out_off + produced + wbase + ex;
-                                                const uint32_t base = w0 + 64 * tid;
-                                                for (; m0; m0 &= m0 - 1u)
-                                                        *qout++ = base + (uint32_t)__builtin_ctz(m0);
-                                                for (; m1; m1 &= m1 - 1u)
-                                                        *qout++ = base + 32u + (uint32_t)__builtin_ctz(m1);
+                                                uint64_t o = task.out_off + produced + wbase + ex;
+                                                const uint32_t fmask = (1u << fbits) - 1u;
+                                                for (uint32_t half = 0; half < 2; ++half)
+                                                        for (uint32_t mm = half ? m1 : m0; mm; mm &= mm - 1u, ++o) {
+                                                                const uint32_t idx = 64 * tid + 32 * half + (uint32_t)__builtin_ctz(mm), doc = w0 + idx;
+                                                                out[o] = doc;
+                                                                if (!all_scores && !allow)
+                                                                        continue;
+                                                                // the document's word is still there: which leaves sit on it (DevFused::ctt), and what they add
+                                                                const uint32_t x = HW ? (sh.acc[idx >> 1] >> ((idx & 1u) << 4)) & 0xffffu : sh.acc[idx];
+                                                                uint32_t p = 0, on = 0;
+                                                                for (uint32_t sl = 0; sl < nslots; ++sl)
+                                                                        p |= (((x >> (sl * fbits)) & fmask) ? 1u : 0u) << sl;
+                                                                double sc = 0.0;
+                                                                for (uint32_t si = 0; si < uni(fq.nleaf); ++si) {
+                                                                        if (!((fq.ctt[si][p >> 5] >> (p & 31u)) & 1u))
+                                                                                continue;
+                                                                        on |= 1u << si;
+                                                                        if (all_scores) {
+                                                                                const uint32_t sl = fq.leaf_slot[si], code = (x >> (sl * fbits)) & fmask;
+                                                                                const uint32_t f = code > cap ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[sl], doc) : code - 1u;
+                                                                                sc += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                                                        }
+                                                                }
+                                                                if (all_scores)
+                                                                        all_scores[o] = sc;
+                                                                if (allow)
+                                                                        allow[o] = on;
+                                                        }
                                                 if (2 * tid < BW)
                                                         bm[2 * tid] = 0;
                                                 if (2 * tid + 1 < BW)
                                                         bm[2 * tid + 1] = 0;
                                                 produced += uni(total);
+                                                __syncthreads();
+                                                for (uint32_t i = tid; i < FUS_W; i += FUS_WG) // (the sweep left the matches' words in place)
+                                                        sh.acc[i] = 0;
                                                 __syncthreads();
                                         }
                                         const uint32_t ov = uni(sh.overflow);

@@ -37,7 +37,9 @@ __global__ __launch_bounds__(AND_WG) void k_rich(const uint8_t *__restrict__ ind
                                                  const uint32_t *__restrict__ sched, const uint32_t *__restrict__ rterms, const uint32_t ntasks,
                                                  uint32_t *__restrict__ ticket, const uint32_t *__restrict__ out, const uint32_t *__restrict__ counts, const uint32_t R,
                                                  uint32_t *__restrict__ present, uint16_t *__restrict__ freq, uint32_t *__restrict__ task_hits,
-                                                 const uint64_t *__restrict__ task_pos_base, uint16_t *__restrict__ pool) {
+                                                 const uint64_t *__restrict__ task_pos_base, uint16_t *__restrict__ pool, const uint32_t *__restrict__ allow) {
+        // allow (or null): per match, the reportable terms an iterator of the query tree sits on — general trees, where holding a term
+        // is not enough (the matching kernel left the mask; every other query's matches carry all ones)
         __shared__ RichShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(AND_WG) void k_rich(const uint8_t *__restrict__ ind
                                                         ptr = lo;
                                                         cv = ptr < C ? sh.cand[ptr] : 0xffffffffu;
                                                 }
-                                                if (cv == doc) {
+                                                if (cv == doc && (!allow || ((allow[(uint64_t)task.out_off + tb + ptr] >> ti) & 1u))) {
                                                         mask |= 1u << i;
                                                         sh.mptr[nm++][tid] = (uint16_t)ptr;
                                                 }

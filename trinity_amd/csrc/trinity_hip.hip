@@ -145,6 +145,8 @@ struct tri_batch {
         uint32_t *d_out = nullptr;
         uint32_t *d_counts = nullptr; // per task, indexed first_task + i in query order
         uint32_t *d_ticket = nullptr;
+        uint32_t *d_rich_allow = nullptr; // default mode, batches that hold general trees: per match the reportable terms the tree sits on
+        bool rich_allow = false;
         uint64_t *d_hashes = nullptr;
         uint64_t *d_qcounts = nullptr; // per caller query: matches of the last run (device copy for the result gather)
         // AccumulatedScoreScheme
@@ -190,6 +192,7 @@ struct tri_batch {
                 hipFree(d_out);
                 hipFree(d_counts);
                 hipFree(d_ticket);
+                hipFree(d_rich_allow);
                 hipFree(d_hashes);
                 hipFree(d_qcounts);
                 hipFree(d_sterms);
@@ -1232,11 +1235,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 TruthPlan tp;
                 bool truth = false;
                 if (!ok || groups.empty()) {
-                        // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp), in
-                        // DocumentsOnly mode and as AccumulatedScore top-K
-                        const bool mode_ok = mode == TRI_FLAG_DOCUMENTS_ONLY || (scored && topk);
-                        if (!mode_ok || !build_truth(nodes, root, tp))
-                                return fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — DocumentsOnly or AccumulatedScore top-K, no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
+                        // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp)
+                        if (!build_truth(nodes, root, tp))
+                                return fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
                         truth = true;
                         groups.assign(1, tp.slots); // (one group of every slot: the bookkeeping below — term list, cost, output bound — sees a union)
                         negs.clear();
@@ -1339,12 +1340,28 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         const uint32_t fm = (1u << z.fbits) - 1u;
                         for (size_t i = 0; i < tp.slots.size(); ++i)
                                 z.term[i] = tp.slots[i];
-                        z.mode = FUS_MODE_TT | (scored ? 0u : FUS_MODE_EMIT);
-                        z.nleaf = (uint32_t)tp.leaves.size();
+                        // DocumentsOnly, the default mode and the full score stream (topk == 0) need the docID set; top-K batches do not
+                        z.mode = FUS_MODE_TT | ((scored && topk) ? 0u : FUS_MODE_EMIT);
                         memcpy(z.tt, tp.tt, sizeof z.tt);
-                        for (size_t j = 0; j < tp.leaves.size(); ++j) {
-                                z.leaf_slot[j] = (uint8_t)tp.leaf_slot[j];
-                                memcpy(z.ctt[j], tp.ctt[j].data(), sizeof z.ctt[j]);
+                        if (rich) {
+                                // per REPORTABLE term (distinct, b->sterms order): reported where any of its leaves sits on the document
+                                z.nleaf = t.q.nscore;
+                                for (uint32_t j = 0; j < t.q.nscore; ++j) {
+                                        const uint32_t term = b->sterms[t.q.score_base + j];
+                                        for (size_t l = 0; l < tp.leaves.size(); ++l)
+                                                if (tp.leaves[l] == term) {
+                                                        z.leaf_slot[j] = (uint8_t)tp.leaf_slot[l];
+                                                        for (int wd = 0; wd < 8; ++wd)
+                                                                z.ctt[j][wd] |= tp.ctt[l][wd];
+                                                }
+                                }
+                                b->rich_allow = true;
+                        } else {
+                                z.nleaf = (uint32_t)tp.leaves.size();
+                                for (size_t j = 0; j < tp.leaves.size(); ++j) {
+                                        z.leaf_slot[j] = (uint8_t)tp.leaf_slot[j];
+                                        memcpy(z.ctt[j], tp.ctt[j].data(), sizeof z.ctt[j]);
+                                }
                         }
                         // window skipping needs groups of slots one of which every match holds: the slots of the scorer leaves if no
                         // matching pattern lacks them all (else every slot: pattern 0 never matches), then every slot all matches hold
@@ -1639,6 +1656,10 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 HIP_TRY(hipMalloc((void **)&b->d_rich_freq, (off + 64) * 2 * b->rich_R));
                 HIP_TRY(hipMalloc((void **)&b->d_task_hits, (b->tasks.size() + 1) * 4));
                 HIP_TRY(hipMalloc((void **)&b->d_task_pos_base, (b->tasks.size() + 1) * 8));
+                if (b->rich_allow) {
+                        HIP_TRY(hipMalloc((void **)&b->d_rich_allow, (off + 64) * 4));
+                        HIP_TRY(hipMemset(b->d_rich_allow, 0xff, (off + 64) * 4)); // (every other query's matches: all terms allowed)
+                }
         }
         if (scored) {
                 if ((rc = dev_upload(&b->d_sterms, b->sterms)) || (rc = dev_upload(&b->d_sweights, b->sweights)))
@@ -1731,7 +1752,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
 #define TRI_FUSED_ARGS                                                                                                                                 \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, fsched, \
                 b->d_sterms, b->d_sweights, nf, b->d_ticket + 56 + 2 * variant, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores,                \
-                b->d_part_counts, b->ix->d_masked, b->similarity, b->d_out
+                b->d_part_counts, b->ix->d_masked, b->similarity, b->d_out, b->d_all_scores, b->d_rich_allow
                         if (b->ix->codec == TRI_CODEC_LUCENE) {
                                 if (variant == 0)
                                         hipLaunchKernelGGL((k_fused<CODEC_LUCENE, 0, 0>), grid, dim3(FUS_WG), 0, dev->stream, TRI_FUSED_ARGS);
@@ -1770,12 +1791,12 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                 hipLaunchKernelGGL((k_rich<CODEC_LUCENE, false>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
                                                    b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched,
                                                    b->d_sterms, n, b->d_ticket + 32, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
-                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr);
+                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr, (const uint32_t *)b->d_rich_allow);
                         else
                                 hipLaunchKernelGGL((k_rich<CODEC_GOOGLE, false>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
                                                    b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched,
                                                    b->d_sterms, n, b->d_ticket + 32, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
-                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr);
+                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr, (const uint32_t *)b->d_rich_allow);
                         HIP_TRY(hipGetLastError());
                 }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
@@ -1904,12 +1925,12 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                         hipLaunchKernelGGL((k_rich<CODEC_LUCENE, true>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_hits,
                                            b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, n,
                                            b->d_ticket + 40, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
-                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool);
+                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool, (const uint32_t *)b->d_rich_allow);
                 else
                         hipLaunchKernelGGL((k_rich<CODEC_GOOGLE, true>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_hits,
                                            b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, n,
                                            b->d_ticket + 40, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
-                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool);
+                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool, (const uint32_t *)b->d_rich_allow);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(dev->stream));
                 b->info.algorithmic_bytes += 2 * total + 4 * m; // + the positions handed over and a present mask per match
