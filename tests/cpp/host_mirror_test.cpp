@@ -110,6 +110,21 @@ int main(int argc, char **argv) {
                         exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
                         show("optional_scored", c);
                 }
+                { // [t0, t1 t2, t3 OR t4] with threshold 2: DocsSetIterators::DisjunctionSome over a term, a conjunction and a disjunction
+                        Collect c;
+                        auto q = src.some({src.term("t0"), src.conjunction({src.term("t1"), src.term("t2")}), src.disjunction({src.term("t3"), src.term("t4")})}, 2);
+                        exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("some_scored", c);
+                        Collect d;
+                        exec_query(q, &src, &d, nullptr, unsigned(ExecFlags::DocumentsOnly), nullptr);
+                        show("some_docs", d);
+                }
+                { // t5 OR (t1 NOT (t2 t3)): a Filter whose excluded side is a conjunction, under a disjunction
+                        Collect c;
+                        auto q = src.disjunction({src.term("t5"), src.filter(src.term("t1"), src.conjunction({src.term("t2"), src.term("t3")}))});
+                        exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("tree_scored", c);
+                }
                 { // the other scorers of similarity.h through the same seam
                         Similarity::IndexSourcesCollectionTFIDFScorer tfidf;
                         std::unique_ptr<Similarity::IndexSourceTermsScorer> s2(tfidf.new_source_scorer(&src));

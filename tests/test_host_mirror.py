@@ -44,9 +44,9 @@ def test_mirror_results_match_oracle(T, tmp_path):
         k, _, rest = l.partition(" ")
         lines[k] = dict(kv.split("=") for kv in rest.split() if "=" in kv) or rest
 
-    def expect(name, text, flags, keep=None, sim=0):
+    def expect(name, text, flags, keep=None, sim=0, some_min=1):
         ora.set_similarity(sim)
-        docs, scores = ora.exec(O.parse_query(text), flags)
+        docs, scores = ora.exec(O.parse_query(text, some_min=some_min), flags)
         ora.set_similarity(0)
         if keep is not None:
             m = keep(docs)
@@ -67,6 +67,9 @@ def test_mirror_results_match_oracle(T, tmp_path):
     expect("two_phrases_scored", '"t0 t1" "t0 t2"', 2)
     expect("not_scored", "t3 t5 NOT (t1 OR t2)", 2)
     expect("optional_scored", "t3 t1 <t5 OR t2>", 2)
+    expect("some_scored", "[t0, t1 t2, t3 OR t4]", 2, some_min=2)
+    expect("some_docs", "[t0, t1 t2, t3 OR t4]", 1, some_min=2)
+    expect("tree_scored", "t5 OR (t1 NOT (t2 t3))", 2)
     expect("tfidf_scored", "t0 t1 (t2 OR t3)", 2, sim=O.SIM_TFIDF)
     expect("trivial_scored", "t0 t1", 2, sim=O.SIM_TRIVIAL)
     expect("masked_scored", "t0 t1", 2, keep=lambda d: (d % 3) != 0)

@@ -15,6 +15,7 @@
 #pragma once
 #include "../../../include/trinity_hip.h"
 #include "google_encoder.hpp"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -105,7 +106,7 @@ namespace trinity_amd {
 
         // ------------------------------------------------------------------ iterators (plan nodes + cursors)
         namespace DocsSetIterators {
-                enum class Type : uint8_t { PostingsListIterator = 0, Filter = 2, Optional = 3, Disjunction = 4, DisjunctionAllPLI, Phrase, Conjuction, ConjuctionAllPLI }; // docset_iterators_base.h:10-23
+                enum class Type : uint8_t { PostingsListIterator = 0, DisjunctionSome = 1, Filter = 2, Optional = 3, Disjunction = 4, DisjunctionAllPLI, Phrase, Conjuction, ConjuctionAllPLI }; // docset_iterators_base.h:10-23
 
                 struct Iterator : public relevant_document_provider { // docset_iterators_base.h:45-96
                         struct {
@@ -253,6 +254,28 @@ namespace trinity_amd {
                                 for (auto it : its)
                                         it->lower(prog, w, scorer);
                                 prog.push_back(TRI_TOK(TRI_OP_OR, its.size()));
+                                w.push_back(0.0);
+                        }
+                };
+                struct DisjunctionSome final : public Iterator { // docset_iterators.h:61-137 (matchsome, exec.cpp:276-283): documents at least minMatch members hold
+                        std::vector<Iterator *> its;
+                        const uint16_t matchThreshold;
+                        DisjunctionSome(Iterator **iterators, uint16_t cnt, uint16_t minMatch)
+                            : Iterator{Type::DisjunctionSome, iterators[0]->isrc}, its(iterators, iterators + cnt), matchThreshold{minMatch} {}
+                        uint64_t cost() const override { // docset_iterators.cpp:733-742: the (cnt - minMatch + 1) cheapest members
+                                std::vector<uint64_t> cs;
+                                for (auto it : its)
+                                        cs.push_back(it->cost());
+                                std::sort(cs.begin(), cs.end());
+                                uint64_t c = 0;
+                                for (size_t i = 0; i + matchThreshold <= cs.size(); ++i)
+                                        c += cs[i];
+                                return c;
+                        }
+                        void lower(std::vector<uint32_t> &prog, std::vector<double> &w, Similarity::IndexSourceTermsScorer *scorer) const override {
+                                for (auto it : its)
+                                        it->lower(prog, w, scorer);
+                                prog.push_back(TRI_TOK(TRI_OP_SOME, (uint32_t(matchThreshold) << 16) | uint32_t(its.size())));
                                 w.push_back(0.0);
                         }
                 };
@@ -437,6 +460,7 @@ namespace trinity_amd {
                 }
                 DocsSetIterators::Iterator *conjunction(std::vector<DocsSetIterators::Iterator *> its) { return reg<DocsSetIterators::Conjuction>(its.data(), uint16_t(its.size())); }
                 DocsSetIterators::Iterator *disjunction(std::vector<DocsSetIterators::Iterator *> its) { return reg<DocsSetIterators::Disjunction>(its.data(), uint16_t(its.size())); }
+                DocsSetIterators::Iterator *some(std::vector<DocsSetIterators::Iterator *> its, uint16_t minMatch) { return reg<DocsSetIterators::DisjunctionSome>(its.data(), uint16_t(its.size()), minMatch); } // exec.cpp:276-283
                 DocsSetIterators::Iterator *optional(DocsSetIterators::Iterator *main, DocsSetIterators::Iterator *opt) { return reg<DocsSetIterators::Optional>(main, opt); } // exec.cpp:366-377
                 DocsSetIterators::Iterator *filter(DocsSetIterators::Iterator *req, DocsSetIterators::Iterator *excl) { return reg<DocsSetIterators::Filter>(req, excl); } // exec.cpp:424-427
                 DocsSetIterators::Iterator *phrase(const std::vector<std::string> &terms) {
