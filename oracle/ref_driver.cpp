@@ -22,6 +22,7 @@
 // position-0 hit that carries a payload (counted) and one that does not (ignored: a document of frequency 0), a document with
 // more than 65535 hits (freq is tokenpos_t: it wraps), positions up to MaxPosition - 1, repeated positions.
 #include "exec.h"
+#include "compilation_ctx.h"
 #include "google_codec.h"
 #include "trinity_oracle.h" // corpus generator + hashing only (this repo's code)
 #include <cinttypes>
@@ -108,6 +109,97 @@ namespace {
                 return h;
         }
         uint64_t fnv_u32(uint32_t v, uint64_t h) { return fnv_bytes(reinterpret_cast<const uint8_t *>(&v), 4, h); }
+
+        // ---- `tree`: what the reference's own compile_query (compilation_ctx.cpp:1738-1758) turns a query into — the exec_node tree
+        // exec.cpp:253-449 builds its iterators from — printed as nested JSON.  Terms print as their corpus indices ("t17" -> 17).
+        struct DumpCtx final : public compilation_ctx {
+                std::vector<std::string> names; // exec term id - 1 -> token
+                uint16_t resolve_query_term(const str8_t term) override {
+                        const std::string t(term.data(), term.size());
+                        for (size_t i = 0; i < names.size(); ++i)
+                                if (names[i] == t)
+                                        return uint16_t(i + 1);
+                        names.push_back(t);
+                        return uint16_t(names.size());
+                }
+                long term_index(const exec_term_id_t id) const { return id && id <= names.size() && names[id - 1].size() > 1 ? atol(names[id - 1].c_str() + 1) : -1; }
+        };
+        void dump_tree(const DumpCtx &c, const exec_node n, std::string &out) {
+                auto terms = [&](const char *op, const exec_term_id_t *ids, size_t cnt) {
+                        out += std::string("{\"op\":\"") + op + "\",\"t\":[";
+                        for (size_t i = 0; i < cnt; ++i)
+                                out += (i ? "," : "") + std::to_string(c.term_index(ids[i]));
+                        out += "]}";
+                };
+                auto kids = [&](const char *op, std::initializer_list<exec_node> ks, const std::string &extra = "") {
+                        out += std::string("{\"op\":\"") + op + "\"" + extra + ",\"k\":[";
+                        bool first = true;
+                        for (const auto &k : ks) {
+                                if (!first)
+                                        out += ",";
+                                first = false;
+                                dump_tree(c, k, out);
+                        }
+                        out += "]}";
+                };
+                switch (n.fp) {
+                        case ENT::matchterm: {
+                                const exec_term_id_t id = n.u16;
+                                terms("term", &id, 1);
+                        } break;
+                        case ENT::matchallterms:
+                        case ENT::matchanyterms: {
+                                const auto run = static_cast<const compilation_ctx::termsrun *>(n.ptr);
+                                terms(n.fp == ENT::matchallterms ? "allterms" : "anyterms", run->terms, run->size);
+                        } break;
+                        case ENT::matchphrase: {
+                                const auto p = static_cast<const compilation_ctx::phrase *>(n.ptr);
+                                terms("phrase", p->termIDs, p->size);
+                        } break;
+                        case ENT::matchallphrases:
+                        case ENT::matchanyphrases: {
+                                const auto run = static_cast<const compilation_ctx::phrasesrun *>(n.ptr);
+                                out += std::string("{\"op\":\"") + (n.fp == ENT::matchallphrases ? "allphrases" : "anyphrases") + "\",\"k\":[";
+                                for (uint16_t i = 0; i < run->size; ++i) {
+                                        if (i)
+                                                out += ",";
+                                        terms("phrase", run->phrases[i]->termIDs, run->phrases[i]->size);
+                                }
+                                out += "]}";
+                        } break;
+                        case ENT::logicaland:
+                        case ENT::logicalor:
+                        case ENT::logicalnot: {
+                                const auto b = static_cast<const compilation_ctx::binop_ctx *>(n.ptr);
+                                kids(n.fp == ENT::logicaland ? "and" : n.fp == ENT::logicalor ? "or" : "not", {b->lhs, b->rhs});
+                        } break;
+                        case ENT::unaryand:
+                        case ENT::unarynot:
+                        case ENT::consttrueexpr: {
+                                const auto u = static_cast<const compilation_ctx::unaryop_ctx *>(n.ptr);
+                                kids(n.fp == ENT::unaryand ? "unaryand" : n.fp == ENT::unarynot ? "unarynot" : "consttrueexpr", {u->expr});
+                        } break;
+                        case ENT::matchsome: {
+                                const auto g = static_cast<const compilation_ctx::partial_match_ctx *>(n.ptr);
+                                out += "{\"op\":\"some\",\"min\":" + std::to_string(g->min) + ",\"k\":[";
+                                for (uint16_t i = 0; i < g->size; ++i) {
+                                        if (i)
+                                                out += ",";
+                                        dump_tree(c, g->nodes[i], out);
+                                }
+                                out += "]}";
+                        } break;
+                        case ENT::constfalse:
+                                out += "{\"op\":\"false\"}";
+                                break;
+                        case ENT::consttrue:
+                                out += "{\"op\":\"true\"}";
+                                break;
+                        default:
+                                out += "{\"op\":\"other\",\"fp\":" + std::to_string(unsigned(n.fp)) + "}";
+                                break;
+                }
+        }
 
         // `[a, b, c]` parses as MatchSome with min 1 (queries.cpp:424-448); an application sets the threshold on the node
         void set_matchsome_min(ast_node *n, const uint16_t min) {
@@ -447,6 +539,32 @@ int main(int argc, char **argv) {
                                 }
                         }
                         printf("{\"cmd\":\"hits\",\"term\":%u,\"docs\":%u,\"fnv\":\"%" PRIu64 "\",\"pos_fnv\":\"%" PRIu64 "\"}\n", t, cnt, h, hpos);
+                } else if (cmd == "tree") {
+                        uint32_t someMin = 0;
+                        is >> someMin;
+                        std::string text;
+                        std::getline(is, text);
+                        while (!text.empty() && text[0] == ' ')
+                                text.erase(0, 1);
+                        query q{str32_t(text.data(), uint32_t(text.size())), default_token_parser_impl,
+                                unsigned(ast_parser::Flags::ParseConstTrueExpr) | unsigned(ast_parser::Flags::ParseMatchSomeExpr)};
+                        if (someMin)
+                                set_matchsome_min(q.root, uint16_t(someMin));
+                        std::string tree = "null";
+                        if (q.root) {
+                                DumpCtx ctx;
+                                const auto root = compile_query(q.root, ctx);
+                                tree.clear();
+                                dump_tree(ctx, root, tree);
+                        }
+                        printf("{\"cmd\":\"tree\",\"min\":%u,\"q\":\"", someMin);
+                        for (char c : text) {
+                                if (c == '"')
+                                        printf("\\\"");
+                                else
+                                        putchar(c);
+                        }
+                        printf("\",\"tree\":%s}\n", tree.c_str());
                 } else if (cmd == "sim") {
                         is >> simName;
                         collScorer = simName == "tfidf" ? static_cast<Similarity::IndexSourcesCollectionTermsScorer *>(&tfidf)

@@ -150,8 +150,49 @@ def edge_fixture():
     print(path, len(res), "records", os.path.getsize(path), "bytes")
 
 
+TREE_EXTRA = ["t{a} t{a} t{b}", "t{a} OR (t{b} t{c})", "t{a} (t{b} OR (t{c} t{d}))", "(t{a} NOT t{b}) OR (t{c} NOT t{d}) OR t{e}", "t{a} <t{b} t{c}>", "t{a} NOT (t{b} OR (t{c} t{d}))",
+              "(t{a} t{b}) OR (t{c} t{d})", "t{a} OR t{b} OR (t{c} t{d} t{e})", "t{a} t{b} t{c} NOT (t{d} t{e})"]
+SOME_TEMPLATES = [("[t{a}, t{b}, t{c}]", 2), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 2), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 3), ("[t{a}, t{b}, t{c}, t{d}, t{e}]", 5),
+                  ("t{a} [t{b}, t{c}, t{d}]", 2), ("[t{a}, t{b} t{c}, t{d} OR t{e}]", 2)]
+
+
+def tree_fixture():
+    """tests/golden/ref_trees.json: what the reference's own compile_query makes of the fixture queries — the exec_node trees
+    exec.cpp:253-449 builds its iterators from (ref_driver `tree`), next to the reference's answers for the same queries on the tiny
+    corpus.  tests lower the TREES to the C-ABI's postfix programs (oracle_lib.program_from_exec_tree), so the planner is driven by
+    real compiler output — reordered, de-duplicated, runs of terms collapsed — rather than by this repo's own query parser."""
+    name = "tiny"
+    D, V, slots, seed = CORPORA[name]
+    rows = [[0, 1, 2, 3, 4], [1, 0, 2, 5, 9], [3, 7, 11, 0, 2], [19, 4, 0, 50, 1], [7, 5, 3, 1, 0]]
+    cmds = []
+    for a, b, c, d, e in rows:
+        for tpl in TEMPLATES + TREE_EXTRA:
+            if '"' in tpl and tpl.count('"') > 2:
+                continue
+            text = tpl.format(a=a, b=b, c=c, d=d, e=e)
+            cmds += [f"tree 0 {text}", f"query 1 0 {text}", f"query 2 10 {text}"]
+        for tpl, mn in SOME_TEMPLATES:
+            text = tpl.format(a=a, b=b, c=c, d=d, e=e)
+            cmds += [f"tree {mn} {text}", f"querysome 1 0 {mn} {text}", f"querysome 2 10 {mn} {text}"]
+    res = O.run_ref_driver(D, V, slots, seed, cmds)
+    assert len(res) == len(cmds), (len(res), len(cmds))
+    recs = []
+    for i in range(0, len(res), 3):
+        t, r1, r2 = res[i : i + 3]
+        assert t["cmd"] == "tree" and t["q"] == r1["q"] == r2["q"]
+        recs.append({"q": t["q"], "min": t["min"], "tree": t["tree"], "n": r1["n"], "fnv": r1["fnv"], "score_sum": r2["score_sum"], "top": r2.get("top", [])})
+    out = {"corpus": {"D": D, "V": V, "slots": slots, "seed": seed}, "results": recs}
+    path = os.path.join(HERE, "ref_trees.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print(path, len(recs), "records", os.path.getsize(path), "bytes")
+
+
 def main():
+    if "--trees-only" in sys.argv:
+        return tree_fixture()
     edge_fixture()
+    tree_fixture()
     for name, (D, V, slots, seed) in CORPORA.items():
         cmds = commands_for(name, D, V, slots, seed)
         res = O.run_ref_driver(D, V, slots, seed, cmds)

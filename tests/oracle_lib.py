@@ -438,3 +438,41 @@ def fnv1a_u32s(values, h=1469598103934665603):
             h = ((h ^ (v & 0xFF)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
             v >>= 8
     return h
+
+
+def program_from_exec_tree(tree):
+    """Lower an exec_node tree as the reference's compile_query produces it (ref_driver `tree`, tests/golden/ref_trees.json) to the
+    C-ABI's postfix program — node by node what exec.cpp:253-449 build_iterator does with it: matchallterms -> Conjuction of the
+    run's terms, matchanyterms -> Disjunction, matchphrase -> Phrase, matchsome -> DisjunctionSome(min), logicalnot -> Filter,
+    logicaland with a consttrueexpr side -> Optional(other side, expression) (exec.cpp:366-377), logicaland / logicalor otherwise."""
+    op = tree["op"]
+
+    def terms():
+        return [tok(OP_TERM, t) for t in tree["t"]]
+
+    if op == "term":
+        return terms()
+    if op == "allterms":
+        return terms() + [tok(OP_AND, len(tree["t"]))]
+    if op == "anyterms":
+        return terms() + [tok(OP_OR, len(tree["t"]))]
+    if op == "phrase":
+        return terms() + ([tok(OP_PHRASE, len(tree["t"]))] if len(tree["t"]) > 1 else [])
+    kids = tree.get("k", [])
+    if op == "and":
+        lhs, rhs = kids
+        if lhs["op"] == "consttrueexpr" or rhs["op"] == "consttrueexpr":
+            main, opt = (rhs, lhs) if lhs["op"] == "consttrueexpr" else (lhs, rhs)
+            return program_from_exec_tree(main) + program_from_exec_tree(opt["k"][0]) + [tok(OP_OPT, 2)]
+        return program_from_exec_tree(lhs) + program_from_exec_tree(rhs) + [tok(OP_AND, 2)]
+    if op == "or":
+        return sum((program_from_exec_tree(k) for k in kids), []) + [tok(OP_OR, len(kids))]
+    if op == "not":
+        return program_from_exec_tree(kids[0]) + program_from_exec_tree(kids[1]) + [tok(OP_NOT, 2)]
+    if op == "some":
+        return sum((program_from_exec_tree(k) for k in kids), []) + [tok(OP_SOME, (tree["min"] << 16) | len(kids))]
+    if op in ("unaryand", "consttrueexpr"):  # (a lone expression: the documents of its operand)
+        return program_from_exec_tree(kids[0])
+    if op in ("allphrases", "anyphrases"):
+        return sum((program_from_exec_tree(k) for k in kids), []) + [tok(OP_AND if op == "allphrases" else OP_OR, len(kids))]
+    raise ValueError(f"exec_node {op} has no iterator")

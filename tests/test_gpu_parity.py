@@ -783,6 +783,26 @@ def test_matchsome_rich_mode_against_reference_fixtures(T, dev):
     assert checked >= 80
 
 
+def test_compiled_exec_trees_through_the_c_abi(T, dev):
+    """The reference's own compile_query output (tests/golden/ref_trees.json: exec_node trees + the reference's answers), lowered to
+    postfix programs and run on the GPU: DocumentsOnly sets and AccumulatedScore top-10."""
+    g = json.load(open(os.path.join(GOLDEN, "ref_trees.json")))
+    c = g["corpus"]
+    w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
+    recs = g["results"]
+    progs = [np.array(O.program_from_exec_tree(r["tree"]), dtype=np.uint32) for r in recs]
+    sets, hashes, _ = run_docs_only(w, progs)
+    d, s, cnt, counts = run_scored(w, progs, 10)
+    for i, r in enumerate(recs):
+        assert len(sets[i]) == r["n"] and str(int(hashes[i])) == r["fnv"], r["q"]
+        assert int(counts[i]) == r["n"], r["q"]
+        top = r["top"]
+        assert d[i, : len(top)].tolist() == [x[0] for x in top], r["q"]
+        np.testing.assert_allclose(s[i, : len(top)], [x[1] for x in top], rtol=1e-5)
+    w.ix.close()
+    assert len(recs) >= 150
+
+
 def test_shapes_still_refused(T, dev):
     """What the planner answers TRI_ERR_UNSUPPORTED to (the caller keeps its CPU span): a multi-word phrase under an OR or inside a
     general tree, more than 8 distinct terms in a general tree."""

@@ -449,3 +449,25 @@ def test_edge_queries_match_reference(edge):
             assert (tt, ht) == (r["terms_total"], r["hits_total"]) and str(O.fnv1a_u32_stream(flat)) == r["rich_fnv"], r["q"]
             n += 1
     assert n >= 40
+
+
+def test_compiled_exec_trees_lower_to_the_reference_s_answers():
+    """tests/golden/ref_trees.json holds what the reference's compile_query makes of 165 queries (the exec_node trees build_iterator
+    consumes) and the reference's answers.  Lowered node by node to postfix programs (oracle_lib.program_from_exec_tree), the oracle
+    must reproduce those answers: the lowering — the same one the GPU tests feed the C-ABI with — is pinned on the CPU."""
+    g = json.load(open(os.path.join(GOLDEN, "ref_trees.json")))
+    c = g["corpus"]
+    ix = O.Index.generate(c["D"], c["V"], c["slots"], c["seed"])
+    shapes = set()
+    for r in g["results"]:
+        prog = np.array(O.program_from_exec_tree(r["tree"]), dtype=np.uint32)
+        shapes.add(json.dumps(r["tree"]).count('"op"'))
+        docs, _ = ix.exec(prog, O.FLAG_DOCUMENTS_ONLY)
+        assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
+        docs, scores = ix.exec(prog, O.FLAG_ACCUM_SCORE)
+        assert len(docs) == r["n"], r["q"]
+        assert abs(float(np.sum(scores)) - r["score_sum"]) <= 1e-6 * max(1.0, r["score_sum"]), r["q"]
+        td, ts = ix.topk(docs, scores, 10)
+        assert td.tolist() == [x[0] for x in r["top"]], r["q"]
+        np.testing.assert_allclose(ts, [x[1] for x in r["top"]], rtol=1e-6)
+    assert len(g["results"]) >= 150 and len(shapes) >= 4
