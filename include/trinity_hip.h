@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define TRI_ABI_VERSION 2 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option */
+#define TRI_ABI_VERSION 3 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes */
 
 /* status codes */
 #define TRI_OK 0
@@ -101,6 +101,10 @@ typedef struct tri_batch_info {
         float fused_ms, rest_ms; /* rest_ms: everything after the matching kernels (k_phrase, k_rich, k_score, k_topk_merge) */
         uint64_t fused_algorithmic_bytes;
         uint64_t fused_queries;
+        /* k_and skips: its algorithmic bytes are no bound.  With the option account_needed_bytes = 1 at batch creation: the bytes a perfect
+         * gallop must read for the candidate-tile queries — the lead lists, of every other list the blocks that can hold a lead candidate
+         * (per lead block: the blocks its docID range meets, at most one per candidate; docbytes / nblocks each), + 4 B per match.  0: not asked */
+        uint64_t cand_needed_bytes;
 } tri_batch_info;
 
 const char *tri_last_error(void);

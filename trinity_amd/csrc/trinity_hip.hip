@@ -62,6 +62,7 @@ struct tri_options {
         uint64_t fused = 1;                       // AccumulatedScore top-K of dense queries in one pass (k_fused); 0: k_and_dense + k_score
         uint64_t fused_task_cost = 1024 * 1024;   // postings per fused task
         uint64_t fused_freq_cap = 0;              // 0: the field width decides; else a smaller saturation point (exercises the rescoring path)
+        uint64_t account_needed_bytes = 0;        // 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query)
         uint64_t fused_halfwords = 1;             // 16-bit window words for queries of <= 5 distinct terms (windows twice as long); 0: always 32-bit
         uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
 };
@@ -145,6 +146,7 @@ struct tri_batch {
         uint32_t *d_out = nullptr;
         uint32_t *d_counts = nullptr; // per task, indexed first_task + i in query order
         uint32_t *d_ticket = nullptr;
+        uint64_t cand_needed_term_bytes = 0; // option account_needed_bytes: see tri_batch_info.cand_needed_bytes
         uint32_t *d_rich_allow = nullptr; // default mode, batches that hold general trees: per match the reportable terms the tree sits on
         bool rich_allow = false;
         uint64_t *d_hashes = nullptr;
@@ -276,6 +278,7 @@ namespace {
                              {"fused_task_cost", &tri_options::fused_task_cost},
                              {"fused_freq_cap", &tri_options::fused_freq_cap},
                              {"fused_halfwords", &tri_options::fused_halfwords},
+                             {"account_needed_bytes", &tri_options::account_needed_bytes},
                              {"overlap_dense_wgs", &tri_options::overlap_dense_wgs},
                              {"overlap_cand_wgs", &tri_options::overlap_cand_wgs}};
                 for (const auto &e : table)
@@ -1597,6 +1600,31 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 b->tasks.push_back({slot, tb, te, TASK_CAND, off + (uint64_t)tb * TILE_CANDS});
                         }
                         t.q.out_cap = lead.documents; // |A ∩ …| <= df of the lead
+                        if (dev->opt.account_needed_bytes) {
+                                // what a perfect gallop must read: the lead list, and of every other list the blocks that can hold a lead
+                                // candidate — per lead block the other list's blocks its docID range meets, at most one per candidate
+                                // (directories only; a block counts docbytes / nblocks)
+                                uint64_t need = ix->docbytes[qt[0] & QT_TERM];
+                                const uint32_t *ll = &ix->h_blk_last[lead.first_block];
+                                for (uint32_t k = 1; k < t.q.nterms; ++k) {
+                                        const DevTerm &tk = ix->terms[qt[k] & QT_TERM];
+                                        const uint32_t *ol = &ix->h_blk_last[tk.first_block];
+                                        uint64_t blocks = 0;
+                                        uint32_t at = 0; // (both directories ascend: the searches move forward)
+                                        for (uint32_t lb = 0; lb < lead.nblocks && at < tk.nblocks; ++lb) {
+                                                const uint32_t lo_doc = lb ? ll[lb - 1] + 1 : 1u, hi_doc = ll[lb];
+                                                at = (uint32_t)(std::lower_bound(ol + at, ol + tk.nblocks, lo_doc) - ol);
+                                                if (at >= tk.nblocks)
+                                                        break;
+                                                const uint32_t last = (uint32_t)(std::lower_bound(ol + at, ol + tk.nblocks, hi_doc) - ol);
+                                                const uint32_t span = std::min(last, tk.nblocks - 1) - at + 1;
+                                                const uint32_t ndocs = lb + 1 == lead.nblocks ? lead.last_n : 32u;
+                                                blocks += std::min(span, ndocs);
+                                        }
+                                        need += (uint64_t)((double)ix->docbytes[qt[k] & QT_TERM] * std::min(1.0, (double)blocks / std::max(1u, tk.nblocks)));
+                                }
+                                b->cand_needed_term_bytes += need;
+                        }
                 }
                 off += t.q.out_cap;
                 t.q.ntasks = (uint32_t)b->tasks.size() - t.q.first_task;
@@ -1893,6 +1921,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         }
         b->info.dense_algorithmic_bytes = b->term_bytes_dense + 4 * m_dense;
         b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_fused) + 4 * (m - m_dense - m_fused);
+        b->info.cand_needed_bytes = b->cand_needed_term_bytes ? b->cand_needed_term_bytes + 4 * (m - m_dense - m_fused) : 0;
         b->info.fused_algorithmic_bytes = b->term_bytes_fused + out_fused; // docbytes + 8 B x min(matches, K)
         b->info.matches = m;
         if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {

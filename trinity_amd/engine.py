@@ -61,6 +61,7 @@ class TriBatchInfo(C.Structure):
         ("rest_ms", C.c_float),
         ("fused_algorithmic_bytes", C.c_uint64),
         ("fused_queries", C.c_uint64),
+        ("cand_needed_bytes", C.c_uint64),
     ]
 
 
