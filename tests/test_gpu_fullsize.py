@@ -117,3 +117,15 @@ def test_cfg3_scored_google_per_query(T, google):
 
     progs = W.mixed5(T.gen_queries(V, 1338, 8192, 5)[:32]) + [O.parse_query(t) for t in ("t0 OR t1 OR t2 OR t3 OR t4", "t0 t1")]
     check_scored(T, ix, ora, progs, 10)
+
+
+def test_general_trees_full_size(T, google, lucene):
+    """matchsome / NOT of a conjunction / AND under OR over head terms and sparse terms of the 10M-document segment: DocumentsOnly
+    sets (many emitting tasks per query, each with its own output region) and BM25 top-100, per query against the oracle."""
+    texts = [("[t0, t1, t2]", 2), ("[t0, t1, t2, t3, t4]", 3), ("t3 NOT (t0 t1)", 1), ("t2 OR (t0 t1)", 1), ("[t5, t900, t40000]", 2), ("t7 [t100, t2000, t30]", 2),
+             ("(t0 NOT t1) OR (t2 NOT t3) OR t4", 1), ("t50000 OR (t1 t60000)", 1)]
+    progs = [O.parse_query(q, some_min=mn) for q, mn in texts]
+    seg, ora, ix = google
+    check_docsets(T, ix, ora, progs)
+    seg, ora, ix = lucene
+    check_scored(T, ix, ora, progs, 100, want_fused=True)
