@@ -65,6 +65,7 @@ struct FusedShared {
         alignas(16) uint32_t rng_lo[FUS_MAX_SLOTS]; // the next window (next_w; 0xffffffff: none) and the slots' row ranges in it, left by wave 0
         alignas(16) uint32_t rng_cnt[FUS_MAX_SLOTS];
         uint32_t next_w;
+        uint32_t dirpos[4][FUS_MAX_SLOTS]; // wave 0's per-slot directory positions between two look-aheads (k_fused: find_window)
         DevFused fq; // the query's slot map, staged once per task (dynamic indexing stays in LDS, not in scratch)
 };
 
@@ -690,31 +691,37 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                         sh.ub[kk] = ubs * (1.0 + 1e-6);
                 }
                 __syncthreads();
-                const DevTerm myt = sh.term[kk];
-                const uint32_t *mybl = blk_last + myt.first_block;
-                const bool indexed = myt.win_off != 0xffffffffu;
                 const uint32_t wfirst = task.tile_begin;
-                // directory position of my slot's list: indexed lists keep the two cell-index entries of the window's ends (the
-                // far one is fetched a window ahead), short lists a cursor
-                uint32_t e_lo = 0, e_hi = 0, pf = 0, cur = 0;
-                if (indexed) {
-                        e_lo = win[myt.win_off + wfirst * CELLS];
-                        e_hi = win[myt.win_off + (wfirst + 1) * CELLS];
-                        pf = win[myt.win_off + (wfirst + 2) * CELLS];
-                } else {
-                        uint32_t lo = 0, hi = myt.nblocks; // first block whose last document >= the task's first docID
-                        const uint32_t key = wfirst * W;
-                        while (lo < hi) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if (mybl[mid] < key)
-                                        lo = mid + 1;
-                                else
-                                        hi = mid;
+                // wave 0, lane s (< nslots): the directory position of slot s's list — indexed lists keep the two cell-index entries of the
+                // window's ends (the far one is fetched a window ahead), short lists a cursor with its block's bounds.  The state lives in LDS
+                // (sh.dirpos) between the look-aheads: held in registers it weighed on — and was spilled by — every wave of the workgroup.
+                if (wave == 0) {
+                        const DevTerm myt = sh.term[kk];
+                        const uint32_t *mybl = blk_last + myt.first_block;
+                        uint32_t e_lo = 0, e_hi = 0, pf = 0, cur = 0;
+                        if (myt.win_off != 0xffffffffu) {
+                                e_lo = win[myt.win_off + wfirst * CELLS];
+                                e_hi = win[myt.win_off + (wfirst + 1) * CELLS];
+                                pf = win[myt.win_off + (wfirst + 2) * CELLS];
+                        } else {
+                                uint32_t lo = 0, hi = myt.nblocks; // first block whose last document >= the task's first docID
+                                const uint32_t key = wfirst * W;
+                                while (lo < hi) {
+                                        const uint32_t mid = (lo + hi) >> 1;
+                                        if (mybl[mid] < key)
+                                                lo = mid + 1;
+                                        else
+                                                hi = mid;
+                                }
+                                cur = lo;
+                                e_lo = cur < myt.nblocks ? mybl[cur] : 0xffffffffu; // (short lists: e_lo / e_hi hold the cursor block's last / previous docID)
+                                e_hi = cur ? mybl[cur - 1] : 0u;
                         }
-                        cur = lo;
+                        sh.dirpos[0][kk] = e_lo;
+                        sh.dirpos[1][kk] = e_hi;
+                        sh.dirpos[2][kk] = pf;
+                        sh.dirpos[3][kk] = cur;
                 }
-                // (short lists: the cursor's block bounds are kept in registers — the directory is read when the cursor moves, not per window)
-                uint32_t cur_last = (!indexed && cur < myt.nblocks) ? mybl[cur] : 0xffffffffu, cur_prev = (!indexed && cur) ? mybl[cur - 1] : 0u;
                 // the first four required groups' masks live in registers (a missing group tests true on any non-zero word)
                 const uint32_t gm0 = uni(fq.gmask[0]), gm1 = nreq > 1 ? uni(fq.gmask[1]) : 0xffffffffu, gm2 = nreq > 2 ? uni(fq.gmask[2]) : 0xffffffffu,
                                gm3 = nreq > 3 ? uni(fq.gmask[3]) : 0xffffffffu;
@@ -724,6 +731,17 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                 // ---- WAVE 0 finds the next window that can hold a match and the slots' row ranges in it (lane s tracks slot s), while
                 //      the other waves sweep the current one; everybody picks the result up behind the sweep's barrier
                 auto find_window = [&](uint32_t w) {
+                        const DevTerm myt = sh.term[kk];
+                        const uint32_t *mybl = blk_last + myt.first_block;
+                        const bool indexed = myt.win_off != 0xffffffffu;
+                        uint32_t e_lo = sh.dirpos[0][kk], e_hi = sh.dirpos[1][kk], pf = sh.dirpos[2][kk], cur = sh.dirpos[3][kk];
+                        uint32_t cur_last = e_lo, cur_prev = e_hi; // (short lists)
+                        auto save = [&]() {
+                                sh.dirpos[0][kk] = indexed ? e_lo : cur_last;
+                                sh.dirpos[1][kk] = indexed ? e_hi : cur_prev;
+                                sh.dirpos[2][kk] = pf;
+                                sh.dirpos[3][kk] = cur;
+                        };
                         for (;;) {
                                 if (w >= task.tile_end) {
                                         sh.next_w = 0xffffffffu;
@@ -798,6 +816,7 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                         e_hi = pf;
                                         pf = win[myt.win_off + (w + 3) * CELLS];
                                 }
+                                save();
                                 return;
                         }
                 };
