@@ -32,6 +32,9 @@
 #ifndef TRI_FUS_CELLS
 #define TRI_FUS_CELLS 14
 #endif
+#ifndef TRI_FUS_UNROLL
+#define TRI_FUS_UNROLL 2 // postings per trip of the PFOR row loop (1: 78.9 ms, 2: 74.0 ms at the time it was measured)
+#endif
 constexpr int FUS_WG = TRI_FUS_WG;
 constexpr uint32_t FUS_CELLS = TRI_FUS_CELLS; // docID cells (of CELL_DOCS) per window (14: 56 KB of words, two 512-thread workgroups per CU)
 constexpr uint32_t FUS_W = FUS_CELLS * CELL_DOCS;
@@ -289,7 +292,7 @@ __device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index,
                 const bool okf = rf.init(g + pfor_group_bytes(rec_z), rec_w, b & 3u, (rec_y >> 16) & 0xffu, rec_y >> 24);
                 PROF_LAP(9);
                 if (okd && okf) {
-#pragma unroll 2
+#pragma unroll TRI_FUS_UNROLL
                         for (uint32_t i = 0; i < 32; ++i) {
                                 rel += rd.next(i);
                                 fused_post<HW>(acc, rel, rf.next(i), cap, shift, past);
@@ -502,7 +505,9 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
                                 anye |= es[c];
                         }
                         if (__builtin_amdgcn_ballot_w64(anye != 0) == 0ull) { // no document of these 512 words can beat the threshold
-                                *(uint4 *)&sh.acc[i0] = make_uint4(0, 0, 0, 0);
+                                uint32_t z; // (materialised here: hoisted out of the loop the zero vector was spilled and re-loaded from scratch per chunk)
+                                asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+                                *(uint4 *)&sh.acc[i0] = make_uint4(z, z, z, z);
                                 continue;
                         }
                         // the queued documents keep their codes until they are scored, everything else is re-zeroed now (a flush below
