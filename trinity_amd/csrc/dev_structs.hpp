@@ -71,6 +71,7 @@ constexpr uint32_t TASK_FUSED = 2; // AccumulatedScoreScheme + top-K of a dense 
 constexpr uint32_t TASK_FUSED16 = 3; // ... with 16-bit window words (<= 5 distinct terms): windows of 2 * FUS_W documents
 
 constexpr uint32_t TASK_FUSED_GEN = 4; // ... a general tree (truth-table predicate; DocumentsOnly: matches written to out[]): 32-bit window words
+constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64)
 constexpr uint32_t FUS_MAX_SLOTS = 8;
 constexpr uint32_t FUS_MAX_LEAVES = 16; // scorer leaves of a general tree
 // planner -> kernel: how a fused query's terms map onto the window words

@@ -96,8 +96,12 @@ struct HitStream<CODEC_LUCENE> {
 
 // Candidates are handled in tiles held in LDS: up to PHRASE_TILE of them, fewer when the phrase has many distinct terms
 // (one row of hit locators per distinct term: PHRASE_SLOTS entries in all).
-constexpr uint32_t PHRASE_TILE = 1024;
-constexpr uint32_t PHRASE_SLOTS = 4096;
+#ifndef TRI_PHRASE_TILE
+#define TRI_PHRASE_TILE 1024
+#endif
+constexpr uint32_t PHRASE_TILE = TRI_PHRASE_TILE;
+constexpr uint32_t PHRASE_SLOTS = 4 * PHRASE_TILE;
+constexpr uint32_t PHRASE_WGS_PER_CU = TRI_PHRASE_TILE >= 1024 ? 3 : TRI_PHRASE_TILE >= 512 ? 6 : 7; // what the LDS (and at 256 the 65 registers) admit
 struct PhraseShared {
         uint32_t cdoc[PHRASE_TILE];     // the tile's candidates (ascending)
         uint32_t hits_off[PHRASE_SLOTS]; // [row * tile + j]: where candidate j's hits of the row's term start (GOOGLE: byte offset into
@@ -176,7 +180,16 @@ __device__ __forceinline__ void phrase_locate<CODEC_GOOGLE>(const uint8_t *__res
                         idx = i;
         }
         VbStream sf = s; // freqs start here
-        s.init(index + ctx.blk_hits[t.first_block + b]); // the block's hits (the directory knows where they start: no walk over the n freqs)
+        const uint32_t hits_at = ctx.blk_hits[t.first_block + b];
+        if (hits_at & BLK_HITS_PLAIN) { // one byte per hit: the preceding slots' hits are as many bytes as their frequencies add up to
+                uint32_t h = hits_at & ~BLK_HITS_PLAIN;
+                for (uint32_t i = 0; i < idx; ++i)
+                        h += sf.next();
+                freq = sf.next();
+                hits_off = h;
+                return;
+        }
+        s.init(index + hits_at); // the block's hits (the directory knows where they start: no walk over the n freqs)
         for (uint32_t i = 0; i < idx; ++i) { // skip the hits of the preceding slots
                 const uint32_t f = sf.next();
                 uint32_t plen = 0; // payload length state restarts with every document
@@ -245,8 +258,22 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
                         }
                 }
                 VbStream sf = s; // freqs start here
-                s.init(index + ctx.blk_hits[t.first_block + b]); // hits start (from the directory)
+                const uint32_t hits_at = ctx.blk_hits[t.first_block + b];
                 cj = ci;
+                if (hits_at & BLK_HITS_PLAIN) { // one byte per hit: locators follow from the frequencies alone
+                        uint32_t h = hits_at & ~BLK_HITS_PLAIN;
+                        for (uint32_t i = 0; i < n && (mask >> i); ++i) {
+                                const uint32_t f = sf.next();
+                                if ((mask >> i) & 1u) {
+                                        sh.hits_off[slot0 + cj] = h;
+                                        sh.freq[slot0 + cj] = f;
+                                        ++cj;
+                                }
+                                h += f;
+                        }
+                        return;
+                }
+                s.init(index + hits_at); // hits start (from the directory)
                 for (uint32_t i = 0; i < n && (mask >> i); ++i) {
                         const uint32_t f = sf.next();
                         if ((mask >> i) & 1u) {
@@ -334,7 +361,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                         }
                         maxrows = max(maxrows, rows);
                 }
-                const uint32_t tile = uni(min(PHRASE_TILE, max((uint32_t)AND_WG, (PHRASE_SLOTS / maxrows) & ~(uint32_t)(AND_WG - 1))));
+                const uint32_t tile = uni(min(PHRASE_TILE, max(64u, (PHRASE_SLOTS / maxrows) & ~63u)));
                 uint32_t wpos = 0;
                 for (uint32_t tb = 0; tb < M; tb += tile) {
                         const uint32_t C = min(tile, M - tb);

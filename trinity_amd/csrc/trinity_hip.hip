@@ -635,14 +635,26 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                         dstream.push_back((uint8_t)n);
                         blk_doff.push_back((uint32_t)dstream.size());
                         dstream.insert(dstream.end(), p, s);
+                        uint64_t nhits = 0;
                         for (uint32_t i = 0; i < n; ++i) {
-                                if (s >= bend)
+                                if (s >= bend || s + h_vb_len(*s) > bend)
                                         return fail(TRI_ERR_FORMAT, "term %zu: deltas+freqs overrun the block", ti);
-                                s += h_vb_len(*s);
+                                uint32_t f;
+                                s += h_vb_get(s, f);
+                                nhits += f;
                         }
-                        blk_hits.push_back((uint32_t)(s - index)); // GOOGLE: byte offset of the block's first hit (k_phrase / k_rich start there)
-                        if (s > bend)
-                                return fail(TRI_ERR_FORMAT, "term %zu: deltas+freqs overrun the block", ti);
+                        // GOOGLE: byte offset of the block's first hit (k_phrase / k_rich start there).  Bit 31 (BLK_HITS_PLAIN): every hit of the
+                        // block is ONE byte — a position delta < 64 without the new-payload-length flag (google_codec.cpp:38-74) —, so a document's
+                        // hits start at the block's first hit + the frequencies before it and no hit has to be parsed to find them
+                        uint32_t hits_at = (uint32_t)(s - index);
+                        if ((uint64_t)(bend - s) == nhits && !(hits_at >> 31)) {
+                                bool plain = true;
+                                for (const uint8_t *q = s; q < bend && plain; ++q)
+                                        plain = !(*q & 0x81u);
+                                if (plain)
+                                        hits_at |= BLK_HITS_PLAIN;
+                        }
+                        blk_hits.push_back(hits_at);
                         db += (uint64_t)(s - h);
                         hb += blockLength - (uint64_t)(s - p);
                         blk_last.push_back(lastDoc);
@@ -1803,7 +1815,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 if (!b->ptasks.empty()) {
                         // positional constraints: filter + compact the match segments of the queries that hold phrases
                         const uint32_t np = (uint32_t)b->ptasks.size();
-                        TRI_LAUNCH(k_phrase, b->ix->codec, dim3(std::min<uint32_t>(np, (uint32_t)dev->cus * 4)), dim3(AND_WG), dev->stream, b->ix->d_index,
+                        TRI_LAUNCH(k_phrase, b->ix->codec, dim3(std::min<uint32_t>(np, (uint32_t)dev->cus * PHRASE_WGS_PER_CU)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_ptasks, np, b->d_phrases, b->d_pterms,
                                            b->d_ticket + 48, b->d_out, b->d_counts, b->d_pscore,
                                            (b->flags & TRI_FLAG_ACCUMULATED_SCORE) ? 65535u : 1u, // exec.cpp:296 trackCnt
