@@ -247,6 +247,44 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
         uint32_t mask = 0, cj = ci, doc = prev;
         uint32_t cv = sh.cdoc[cj];
         if (CODEC == CODEC_GOOGLE) {
+                const uint32_t hits_plain = ctx.blk_hits[t.first_block + b];
+                if (n == 32 && (hits_plain & BLK_HITS_PLAIN)) {
+                        // a full block: 31 deltas and 32 freqs, 63 bytes if every one of them is a single byte (every block of a head term) —
+                        // four wide loads, then byte adds from registers; with one byte per hit the locators are a running sum of the freqs
+                        typedef uint32_t ph_u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+                        const uint8_t *p = index + off;
+                        const ph_u32x4_a1 A = *(const ph_u32x4_a1 *)p, B = *(const ph_u32x4_a1 *)(p + 16), Cq = *(const ph_u32x4_a1 *)(p + 32),
+                                          Dq = *(const ph_u32x4_a1 *)(p + 48);
+                        const uint32_t w[16] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, Cq.x, Cq.y, Cq.z, Cq.w, Dq.x, Dq.y, Dq.z, Dq.w};
+                        uint32_t any = w[15] & 0x00ffffffu; // (byte 63 is the block's first hit)
+#pragma unroll
+                        for (int k = 0; k < 15; ++k)
+                                any |= w[k];
+                        if (!(any & 0x80808080u)) {
+#pragma unroll
+                                for (int j = 0; j < 32; ++j) {
+                                        doc = j < 31 ? doc + ((w[j >> 2] >> ((j & 3) * 8)) & 0xffu) : last;
+                                        if (cv == doc) {
+                                                mask |= 1u << j;
+                                                ++cj;
+                                                cv = cj < C ? sh.cdoc[cj] : 0xffffffffu;
+                                        }
+                                }
+                                uint32_t h = hits_plain & ~BLK_HITS_PLAIN;
+                                cj = ci;
+#pragma unroll
+                                for (int j = 0; j < 32; ++j) {
+                                        const uint32_t f = (w[(31 + j) >> 2] >> (((31 + j) & 3) * 8)) & 0xffu;
+                                        if ((mask >> j) & 1u) {
+                                                sh.hits_off[slot0 + cj] = h;
+                                                sh.freq[slot0 + cj] = f;
+                                                ++cj;
+                                        }
+                                        h += f;
+                                }
+                                return;
+                        }
+                }
                 VbStream s;
                 s.init(index + off);
                 for (uint32_t i = 0; i < n; ++i) {
@@ -321,7 +359,7 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
 template <int CODEC>
 __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ index, const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits,
                                                    const uint32_t *__restrict__ hdir, const uint32_t *__restrict__ blk_last,
-                                                   const uint32_t *__restrict__ blk_off, const DevTerm *__restrict__ terms,
+                                                   const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                                                    const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
                                                    const uint32_t *__restrict__ ptasks, const uint32_t nptasks, const DevPhrase *__restrict__ phrases,
                                                    const uint32_t *__restrict__ pterms, uint32_t *__restrict__ ticket, uint32_t *__restrict__ out,
@@ -405,11 +443,26 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                 for (uint32_t b = b0 + tid; b <= b1; b += AND_WG)
                                                         phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, t, b, C, slot0);
                                         } else {
+                                                // few candidates scattered over a long list: every candidate brackets its block with the two cell-index
+                                                // entries of its docID cell (short lists: a bisection of the directory), and the first candidate of a
+                                                // block walks it for all the block's candidates
                                                 for (uint32_t j = tid; j < C; j += AND_WG) {
-                                                        uint32_t ho, f;
-                                                        phrase_locate<CODEC>(index, blk_last, blk_off, ctx, t, sh.cdoc[j], ho, f);
-                                                        sh.hits_off[slot0 + j] = ho;
-                                                        sh.freq[slot0 + j] = f;
+                                                        const uint32_t doc = sh.cdoc[j];
+                                                        uint32_t lo = 0, hi = t.nblocks;
+                                                        if (t.win_off != 0xffffffffu) {
+                                                                lo = win[t.win_off + (doc >> CELL_LOG2)];
+                                                                hi = min(win[t.win_off + (doc >> CELL_LOG2) + 1] + 1, t.nblocks);
+                                                        }
+                                                        while (lo < hi) {
+                                                                const uint32_t mid = (lo + hi) >> 1;
+                                                                if (bl[mid] < doc)
+                                                                        lo = mid + 1;
+                                                                else
+                                                                        hi = mid;
+                                                        }
+                                                        const uint32_t prevdoc = lo ? bl[lo - 1] : 0;
+                                                        if (j == 0 || sh.cdoc[j - 1] <= prevdoc)
+                                                                phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, t, lo, C, slot0);
                                                 }
                                         }
                                         __syncthreads();

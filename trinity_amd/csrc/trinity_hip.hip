@@ -1816,7 +1816,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         // positional constraints: filter + compact the match segments of the queries that hold phrases
                         const uint32_t np = (uint32_t)b->ptasks.size();
                         TRI_LAUNCH(k_phrase, b->ix->codec, dim3(std::min<uint32_t>(np, (uint32_t)dev->cus * PHRASE_WGS_PER_CU)), dim3(AND_WG), dev->stream, b->ix->d_index,
-                                           b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_ptasks, np, b->d_phrases, b->d_pterms,
+                                           b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_ptasks, np, b->d_phrases, b->d_pterms,
                                            b->d_ticket + 48, b->d_out, b->d_counts, b->d_pscore,
                                            (b->flags & TRI_FLAG_ACCUMULATED_SCORE) ? 65535u : 1u, // exec.cpp:296 trackCnt
                                            b->similarity);
