@@ -34,12 +34,31 @@ template <>
 struct HitStream<CODEC_GOOGLE> { // google_codec.cpp:533-594: varbyte (delta << 1 | newPayloadLen) [u8 len] payload
         VbStream s;
         uint32_t plen;
+        uint64_t pw; // plain: the document's (<= 8) single-byte hits
+        bool plain;
         static constexpr uint32_t FREQ_MASK = 0xffffu; // th->freq is tokenpos_t
+        static constexpr uint32_t FREQ_PLAIN = 0x80000000u; // k_phrase's freq entries: the document's hits are single bytes (BLK_HITS_PLAIN)
         __device__ __forceinline__ void init(const HitCtx &c, const uint32_t, const uint32_t loc) {
+                plain = false;
                 s.init(c.base + loc);
                 plen = 0; // payload length state restarts with every document
         }
+        // fentry: the candidate's frequency as phrase_locate_block left it.  At most eight single-byte hits: one unaligned load holds
+        // them all, and the walk is shifts of a register instead of a byte stream with loads in flight
+        __device__ __forceinline__ void init_entry(const HitCtx &c, const uint32_t pad, const uint32_t loc, const uint32_t fentry) {
+                if ((fentry & FREQ_PLAIN) && (fentry & FREQ_MASK) <= 8u) {
+                        typedef uint64_t ph_u64_a1 __attribute__((aligned(1)));
+                        plain = true;
+                        pw = *(const ph_u64_a1 *)(c.base + loc);
+                } else
+                        init(c, pad, loc);
+        }
         __device__ __forceinline__ uint32_t next() {
+                if (plain) {
+                        const uint32_t v = (uint32_t)pw & 0xffu;
+                        pw >>= 8;
+                        return v >> 1;
+                }
                 const uint32_t v = s.next();
                 if (v & 1u)
                         plen = s.byte();
@@ -79,6 +98,7 @@ struct HitStream<CODEC_LUCENE> {
                 h = loc;
                 seek();
         }
+        __device__ __forceinline__ void init_entry(const HitCtx &c, const uint32_t hdir_off, const uint32_t loc, const uint32_t) { init(c, hdir_off, loc); }
         __device__ __forceinline__ uint32_t next() {
                 if (tail) {
                         const uint32_t v = vb.next();
@@ -208,7 +228,7 @@ __device__ __forceinline__ void phrase_locate<CODEC_GOOGLE>(const uint8_t *__res
 template <int CODEC>
 __device__ __forceinline__ bool phrase_has_pos(const HitCtx &ctx, const uint32_t hdir_off, const uint32_t hits_off, const uint32_t freq, const uint32_t q) {
         HitStream<CODEC> s;
-        s.init(ctx, hdir_off, hits_off);
+        s.init_entry(ctx, hdir_off, hits_off, freq);
         uint32_t pos = 0;
         for (uint32_t h = 0; h < (freq & HitStream<CODEC>::FREQ_MASK); ++h) {
                 pos = (pos + s.next()) & 0xffffu;
@@ -277,7 +297,7 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
                                         const uint32_t f = (w[(31 + j) >> 2] >> (((31 + j) & 3) * 8)) & 0xffu;
                                         if ((mask >> j) & 1u) {
                                                 sh.hits_off[slot0 + cj] = h;
-                                                sh.freq[slot0 + cj] = f;
+                                                sh.freq[slot0 + cj] = f | HitStream<CODEC_GOOGLE>::FREQ_PLAIN;
                                                 ++cj;
                                         }
                                         h += f;
@@ -304,7 +324,7 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
                                 const uint32_t f = sf.next();
                                 if ((mask >> i) & 1u) {
                                         sh.hits_off[slot0 + cj] = h;
-                                        sh.freq[slot0 + cj] = f;
+                                        sh.freq[slot0 + cj] = (f & HitStream<CODEC_GOOGLE>::FREQ_MASK) == f ? (f | HitStream<CODEC_GOOGLE>::FREQ_PLAIN) : f;
                                         ++cj;
                                 }
                                 h += f;
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                         uint32_t cnt = 0;
                                         // walk the start positions of term 0 (docset_iterators.cpp:101-143)
                                         HitStream<CODEC> s0;
-                                        s0.init(ctx, terms[pterms[ph.term_base]].pad, sh.hits_off[sh.row[0] * tile + j]);
+                                        s0.init_entry(ctx, terms[pterms[ph.term_base]].pad, sh.hits_off[sh.row[0] * tile + j], sh.freq[sh.row[0] * tile + j]);
                                         uint32_t p0 = 0;
                                         const uint32_t f0 = sh.freq[sh.row[0] * tile + j] & HitStream<CODEC>::FREQ_MASK;
                                         for (uint32_t h = 0; h < f0 && cnt < max_match_cnt; ++h) {
