@@ -31,10 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNELS = ("k_and_dense", "k_and", "k_fused")  # the kernels with per-launch HIP-event brackets and their own algorithmic bytes
-KMS = {"k_and_dense": "dense_ms", "k_and": "cand_ms", "k_fused": "fused_ms"}
-KALG = {"k_and_dense": "dense_algorithmic_bytes", "k_and": "cand_algorithmic_bytes", "k_fused": "fused_algorithmic_bytes"}
-KQ = {"k_and_dense": "dense_queries", "k_and": "cand_queries", "k_fused": "fused_queries"}
+KERNELS = ("k_and_dense", "k_and", "k_fused", "k_phrase")  # the kernels with per-launch HIP-event brackets and their own algorithmic bytes
+KMS = {"k_and_dense": "dense_ms", "k_and": "cand_ms", "k_fused": "fused_ms", "k_phrase": "phrase_ms"}
+KALG = {"k_and_dense": "dense_algorithmic_bytes", "k_and": "cand_algorithmic_bytes", "k_fused": "fused_algorithmic_bytes", "k_phrase": "phrase_algorithmic_bytes"}
+KQ = {"k_and_dense": "dense_queries", "k_and": "cand_queries", "k_fused": "fused_queries", "k_phrase": "phrase_queries"}
 
 
 def main():
@@ -135,12 +135,12 @@ def main():
     for _ in range(args.steps):
         infos = step()
         for i in infos:
-            for k in ("last_run_ms", "dense_ms", "cand_ms", "fused_ms", "rest_ms"):
+            for k in ("last_run_ms", "dense_ms", "cand_ms", "fused_ms", "phrase_ms", "rest_ms"):
                 acc[k] = acc.get(k, 0.0) + i[k]
     barrier()
     elapsed = time.perf_counter() - t0
     tot = {k: float(sum(i[k] for i in infos)) for k in ("matches", "algorithmic_bytes", "dense_algorithmic_bytes", "cand_algorithmic_bytes", "fused_algorithmic_bytes",
-                                                       "dense_queries", "cand_queries", "fused_queries", "cand_needed_bytes")}  # fmt: skip
+                                                       "dense_queries", "cand_queries", "fused_queries", "cand_needed_bytes", "phrase_algorithmic_bytes", "phrase_queries")}  # fmt: skip
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -230,8 +230,8 @@ def main():
                 "kernel_ms": kms[dom],
                 "algorithmic_bytes_per_launch": kalg[dom],
                 "queries_per_launch": int(tot[KQ[dom]]),
-                "other_kernels": {k: kentry(k) for k in KERNELS if k != dom and kms[k] > 0},
-                "post_passes_ms": rest_ms,  # k_phrase / k_score (queries matched by k_and) / k_topk_merge / k_rich: no bytes of their own
+                "other_kernels": {k: kentry(k) for k in KERNELS if k != dom and tot[KQ[k]] > 0},
+                "post_passes_ms": rest_ms,  # k_score (queries matched by k_and) / k_topk_merge / k_rich: no bytes of their own
                 "whole_step": {"kernel_ms": k_ms, "algorithmic_bytes": tot["algorithmic_bytes"], "achieved": gbs(tot["algorithmic_bytes"], k_ms),
                                "frac": gbs(tot["algorithmic_bytes"], k_ms) / HBM_PEAK_GBS},  # fmt: skip
             },

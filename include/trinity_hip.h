@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define TRI_ABI_VERSION 3 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes */
+#define TRI_ABI_VERSION 3 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_* */
 
 /* status codes */
 #define TRI_OK 0
@@ -98,13 +98,18 @@ typedef struct tri_batch_info {
         uint64_t dense_algorithmic_bytes, cand_algorithmic_bytes;
         uint64_t dense_queries, cand_queries;
         /* k_fused: AccumulatedScore top-K of dense queries in one pass (decode -> match -> score -> select per docID window) */
-        float fused_ms, rest_ms; /* rest_ms: everything after the matching kernels (k_phrase, k_rich, k_score, k_topk_merge) */
+        float fused_ms, rest_ms; /* rest_ms: everything after the matching kernels and k_phrase (k_rich, k_score, k_topk_merge) */
         uint64_t fused_algorithmic_bytes;
         uint64_t fused_queries;
         /* k_and skips: its algorithmic bytes are no bound.  With the option account_needed_bytes = 1 at batch creation: the bytes a perfect
          * gallop must read for the candidate-tile queries — the lead lists, of every other list the blocks that can hold a lead candidate
          * (per lead block: the blocks its docID range meets, at most one per candidate; docbytes / nblocks each), + 4 B per match.  0: not asked */
         uint64_t cand_needed_bytes;
+        /* k_phrase (positional constraints over the match segments): its time, the hit bytes of the phrases' terms (their SURVEY §8(d) share of
+         * algorithmic_bytes — no longer counted under cand_algorithmic_bytes), the queries that hold a phrase; rest_ms no longer includes it */
+        float phrase_ms, pad_;
+        uint64_t phrase_algorithmic_bytes;
+        uint64_t phrase_queries;
 } tri_batch_info;
 
 const char *tri_last_error(void);

@@ -140,12 +140,13 @@ struct tri_batch {
         uint64_t term_bytes_fused = 0;
         // HIP events on the engine stream: start, after k_and_dense, after k_and, after k_fused, end (owned by the batch: two batches
         // in flight on one device keep their own timings)
-        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev1 = nullptr;
+        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_p = nullptr, ev1 = nullptr;
         bool ran = false;
         uint32_t *d_qterms = nullptr;
         uint32_t *d_out = nullptr;
         uint32_t *d_counts = nullptr; // per task, indexed first_task + i in query order
         uint32_t *d_ticket = nullptr;
+        uint64_t term_bytes_phrase_hits = 0; // hit bytes of the phrase terms (part of term_bytes): k_phrase's share
         uint64_t cand_needed_term_bytes = 0; // option account_needed_bytes: see tri_batch_info.cand_needed_bytes
         uint32_t *d_rich_allow = nullptr; // default mode, batches that hold general trees: per match the reportable terms the tree sits on
         bool rich_allow = false;
@@ -183,7 +184,7 @@ struct tri_batch {
         ~tri_batch() { // also runs when tri_batch_create fails half-way: nothing allocated so far is leaked
                 if (ix)
                         hipSetDevice(ix->dev->device);
-                for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev1})
+                for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev_p, ev1})
                         if (e)
                                 hipEventDestroy(e);
                 hipFree(d_fused);
@@ -1294,6 +1295,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         for (uint32_t x : ph.terms) {
                                 b->pterms.push_back(x);
                                 b->term_bytes += ix->hitbytes[x]; // phrase queries also stream the hit bytes
+                                b->term_bytes_phrase_hits += ix->hitbytes[x];
                         }
                 }
                 t.q.score_base = (uint32_t)b->sterms.size();
@@ -1673,7 +1675,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)) || (rc = dev_upload(&b->d_tasks, b->tasks)) ||
             (rc = dev_upload(&b->d_sched, sched)) || (rc = dev_upload(&b->d_fused, b->fused)))
                 return rc;
-        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_b, &b->ev_c, &b->ev1})
+        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1})
                 HIP_TRY(hipEventCreate(e));
         HIP_TRY(hipMalloc((void **)&b->d_out, (off + 64) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_counts, (b->tasks.size() + 1) * 4));
@@ -1822,6 +1824,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                            b->similarity);
                         HIP_TRY(hipGetLastError());
                 }
+                HIP_TRY(hipEventRecord(b->ev_p, dev->stream));
                 if (b->flags & TRI_FLAG_MATCHED_TERMS) {
                         // COUNT pass: which reportable terms hold each match, with what frequency; hit totals per task
                         HIP_TRY(hipMemsetAsync(b->d_rich_present, 0, (b->out_capacity + 64) * 4, dev->stream));
@@ -1858,6 +1861,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_b, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
+                HIP_TRY(hipEventRecord(b->ev_p, dev->stream));
         }
         if (!b->plan.empty()) {
                 const uint32_t nqs = (uint32_t)b->plan.size();
@@ -1902,7 +1906,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
                 b->info.last_run_ms = ms;
-        b->info.dense_ms = b->info.cand_ms = b->info.fused_ms = b->info.rest_ms = 0;
+        b->info.dense_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.rest_ms = 0;
         if (!b->tasks.empty()) {
                 if (hipEventElapsedTime(&ms, b->ev0, b->ev_a) == hipSuccess)
                         b->info.dense_ms = ms; // includes the 256-byte ticket memset that precedes it
@@ -1910,7 +1914,9 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                         b->info.cand_ms = ms;
                 if (hipEventElapsedTime(&ms, b->ev_b, b->ev_c) == hipSuccess)
                         b->info.fused_ms = ms;
-                if (hipEventElapsedTime(&ms, b->ev_c, b->ev1) == hipSuccess)
+                if (hipEventElapsedTime(&ms, b->ev_c, b->ev_p) == hipSuccess)
+                        b->info.phrase_ms = ms;
+                if (hipEventElapsedTime(&ms, b->ev_p, b->ev1) == hipSuccess)
                         b->info.rest_ms = ms;
         }
         b->h_counts.resize(b->tasks.size());
@@ -1932,7 +1938,11 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 }
         }
         b->info.dense_algorithmic_bytes = b->term_bytes_dense + 4 * m_dense;
-        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_fused) + 4 * (m - m_dense - m_fused);
+        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_fused - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_fused);
+        b->info.phrase_algorithmic_bytes = b->term_bytes_phrase_hits; // what k_phrase streams by the SURVEY §8(d) count: the hit bytes of the phrases' terms
+        b->info.phrase_queries = 0;
+        for (const DevQuery &q : b->plan)
+                b->info.phrase_queries += q.nphrases != 0;
         b->info.cand_needed_bytes = b->cand_needed_term_bytes ? b->cand_needed_term_bytes + 4 * (m - m_dense - m_fused) : 0;
         b->info.fused_algorithmic_bytes = b->term_bytes_fused + out_fused; // docbytes + 8 B x min(matches, K)
         b->info.matches = m;

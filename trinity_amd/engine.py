@@ -62,6 +62,10 @@ class TriBatchInfo(C.Structure):
         ("fused_algorithmic_bytes", C.c_uint64),
         ("fused_queries", C.c_uint64),
         ("cand_needed_bytes", C.c_uint64),
+        ("phrase_ms", C.c_float),
+        ("pad_", C.c_float),
+        ("phrase_algorithmic_bytes", C.c_uint64),
+        ("phrase_queries", C.c_uint64),
     ]
 
 
