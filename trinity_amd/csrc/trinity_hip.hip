@@ -708,8 +708,9 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         }
         // device copies
         int rcw;
-        if ((rcw = dev_upload(&ix->d_win, win)))
+        if ((rcw = dev_upload(&ix->d_win, win, 3 * CELLS_PER_SPAN + 8))) // (lanes of terms without a row read entries 0, CELLS_PER_SPAN, 2 * CELLS_PER_SPAN and drop them)
                 return rcw;
+        HIP_TRY(hipMemset(ix->d_win + win.size(), 0, (3 * CELLS_PER_SPAN + 8) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **)&ix->d_index, len + 256)); // over-read slack: the byte streams keep several qwords in flight past the cursor
         HIP_TRY(hipMemset(ix->d_index, 0, len + 256));
         if (len)
