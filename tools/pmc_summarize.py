@@ -27,8 +27,15 @@ for k, v in res.items():
     rd = v.get("FETCH_SIZE", {}).get("per_dispatch_KiB", 0.0) * 1024 * 2
     wr = v.get("WRITE_SIZE", {}).get("per_dispatch_KiB", 0.0) * 1024
     short = k.split("<")[0].replace("void ", "")
-    table[short] = {"kernel": k, "dispatches": v.get("FETCH_SIZE", v.get("WRITE_SIZE"))["dispatches"], "hbm_read_bytes_per_launch_corrected": rd,
-                    "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr}
+    e = table.setdefault(short, {"kernel": [], "dispatches": 0, "hbm_read_bytes_per_launch_corrected": 0.0, "hbm_write_bytes_per_launch": 0.0, "traffic_bytes_per_launch": 0.0})
+    # (a step launches every instantiation of a kernel once — k_and<1> and k_and<2> at cfg5 —: "per launch" adds them up)
+    e["kernel"].append(k)
+    e["dispatches"] = max(e["dispatches"], v.get("FETCH_SIZE", v.get("WRITE_SIZE"))["dispatches"])
+    e["hbm_read_bytes_per_launch_corrected"] += rd
+    e["hbm_write_bytes_per_launch"] += wr
+    e["traffic_bytes_per_launch"] += rd + wr
+for e in table.values():
+    e["kernel"] = " + ".join(sorted(e["kernel"]))
 json.dump(table, open(os.path.join(out, f"pmc_{name}.json"), "w"), indent=1)
 for k, v in sorted(table.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"])[:10]:
     print(f"{k[:40]:40s} n={v['dispatches']:4d} read={v['hbm_read_bytes_per_launch_corrected'] / 1e9:9.3f} GB write={v['hbm_write_bytes_per_launch'] / 1e9:9.3f} GB")
