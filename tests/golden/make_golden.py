@@ -188,11 +188,98 @@ def tree_fixture():
     print(path, len(recs), "records", os.path.getsize(path), "bytes")
 
 
+def random_query(rng, pool):
+    """A random, fully parenthesised query text over distinct terms of `pool` (<= 8 of them): AND / OR / NOT / <optional> / [matchsome]."""
+
+    it = iter(rng.sample(pool, 8))
+
+    def split(budget, n):
+        parts = [1] * n
+        for _ in range(budget - n):
+            parts[rng.randrange(n)] += 1
+        return parts
+
+    def node(depth, budget):
+        if depth == 0 or budget == 1 or rng.random() < 0.2:
+            return f"t{next(it)}"
+        kind = rng.choice(["and", "and", "or", "or", "not", "some", "opt"])
+        if kind == "some" and budget >= 3:
+            n = min(rng.randint(3, 4), budget)
+            return "[" + ", ".join(node(depth - 1, b) for b in split(budget, n)) + "]"
+        if kind in ("not", "opt"):
+            a, b = split(budget, 2)
+            return "(" + node(depth - 1, a) + (" NOT " + node(depth - 1, b) if kind == "not" else " <" + node(depth - 1, b) + ">") + ")"
+        n = min(rng.randint(2, 3), budget)
+        return "(" + (" OR " if kind == "or" else " ").join(node(depth - 1, b) for b in split(budget, n)) + ")"
+
+    q = node(3, rng.randint(3, 8))
+    return q[1:-1] if q.startswith("(") and q.endswith(")") else q
+
+
+def random_fixture():
+    """tests/golden/ref_random.json: 400 random query trees over the tiny corpus — the reference's compiled exec_node tree of each and its
+    answers in all three modes.  Left out: the queries the reference aborts or hangs on (a matchsome nested in a matchsome with a
+    threshold above 1), and root-level `(x OR ...) NOT z` / `[...] NOT z`, where its DocumentsOnly / AccumulatedScore spans emit the
+    excluded documents while its own default mode does not (FilteredDocsSetSpan over a disjunction span: DESIGN.md §8)."""
+    import random
+    import subprocess
+
+    rng = random.Random(20260926)
+    D, V, slots, seed = CORPORA["tiny"]
+    qs = []
+    while len(qs) < 400:
+        q = random_query(rng, list(range(40)))
+        if " " in q:
+            qs.append((q, rng.choice([1, 2, 2, 3]) if "[" in q else 0))
+
+    def cmds_of(q, mn):
+        return [f"tree {mn} {q}"] + ([f"querysome {f} {k} {mn} {q}" for f, k in ((1, 0), (2, 10), (0, 0))] if mn else [f"query {f} {k} {q}" for f, k in ((1, 0), (2, 10), (0, 0))])
+
+    def run(chunk):
+        cmds = sum((cmds_of(q, mn) for q, mn in chunk), [])
+        out = subprocess.run([O.REF_DRIVER, str(D), str(V), str(slots), str(seed)], input="\n".join(cmds) + "\n", capture_output=True, text=True, check=True, timeout=120)
+        res = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(res) == len(cmds)
+        return [res[i : i + 4] for i in range(0, len(res), 4)]
+
+    recs, dropped = [], []
+    for i in range(0, len(qs), 16):
+        chunk = qs[i : i + 16]
+        try:
+            got = run(chunk)
+        except (subprocess.CalledProcessError, subprocess.TimeoutExpired, AssertionError):
+            got = []
+            for one in chunk:  # a query the reference dies on takes its chunk with it: one by one
+                try:
+                    got += run([one])
+                except (subprocess.CalledProcessError, subprocess.TimeoutExpired, AssertionError):
+                    got.append(None)
+                    dropped.append(one[0])
+        for (q, mn), r in zip(chunk, got):
+            if r is None:
+                continue
+            t, r1, r2, r0 = r
+            root = t["tree"]
+            if root["op"] == "not" and root["k"][0]["op"] in ("or", "anyterms", "some"):
+                dropped.append(q)
+                continue
+            recs.append({"q": q, "min": mn, "tree": root, "n": r1["n"], "fnv": r1["fnv"], "score_sum": r2["score_sum"], "top": r2.get("top", []),
+                         "rich_fnv": r0["rich_fnv"], "terms_total": r0["terms_total"], "hits_total": r0["hits_total"]})  # fmt: skip
+    out = {"corpus": {"D": D, "V": V, "slots": slots, "seed": seed}, "dropped": dropped, "results": recs}
+    path = os.path.join(HERE, "ref_random.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print(path, len(recs), "records", len(dropped), "dropped", os.path.getsize(path), "bytes")
+
+
 def main():
     if "--trees-only" in sys.argv:
         return tree_fixture()
+    if "--random-only" in sys.argv:
+        return random_fixture()
     edge_fixture()
     tree_fixture()
+    random_fixture()
     for name, (D, V, slots, seed) in CORPORA.items():
         cmds = commands_for(name, D, V, slots, seed)
         res = O.run_ref_driver(D, V, slots, seed, cmds)

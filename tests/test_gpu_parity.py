@@ -803,6 +803,32 @@ def test_compiled_exec_trees_through_the_c_abi(T, dev):
     assert len(recs) >= 150
 
 
+def test_random_trees_from_the_reference(T, dev):
+    """tests/golden/ref_random.json (384 random trees compiled and answered by the genuine reference) through the C-ABI, all three modes;
+    with the CNF-shaped ones also forced through the one-pass kernel."""
+    g = json.load(open(os.path.join(GOLDEN, "ref_random.json")))
+    c = g["corpus"]
+    w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
+    recs = g["results"]
+    progs = [np.array(O.program_from_exec_tree(r["tree"]), dtype=np.uint32) for r in recs]
+    for opts in ({}, {"dense_min_postings": 0}):
+        with options(dev, **opts):
+            sets, hashes, info = run_docs_only(w, progs)
+            d, s, cnt, counts = run_scored(w, progs, 10)
+        assert info["fused_queries"] > 50  # (the general trees; CNF-shaped ones take the other kernels in DocumentsOnly mode)
+        for i, r in enumerate(recs):
+            assert len(sets[i]) == r["n"] and str(int(hashes[i])) == r["fnv"], (opts, r["q"])
+            assert int(counts[i]) == r["n"], (opts, r["q"])
+            top = r["top"]
+            assert d[i, : len(top)].tolist() == [x[0] for x in top], (opts, r["q"])
+            np.testing.assert_allclose(s[i, : len(top)], [x[1] for x in top], rtol=1e-5)
+    for r, (docs, terms, present, freq, pos) in zip(recs, run_rich(w, progs)):
+        assert len(docs) == r["n"] and int(freq.sum()) == r["hits_total"], r["q"]
+        assert int(sum(bin(int(x)).count("1") for x in present)) == r["terms_total"], r["q"]
+        assert str(O.fnv1a_u32_stream(rich_flat(docs, terms, present, freq, pos))) == r["rich_fnv"], r["q"]
+    w.ix.close()
+
+
 def test_shapes_still_refused(T, dev):
     """What the planner answers TRI_ERR_UNSUPPORTED to (the caller keeps its CPU span): a multi-word phrase under an OR or inside a
     general tree, more than 8 distinct terms in a general tree."""

@@ -471,3 +471,26 @@ def test_compiled_exec_trees_lower_to_the_reference_s_answers():
         assert td.tolist() == [x[0] for x in r["top"]], r["q"]
         np.testing.assert_allclose(ts, [x[1] for x in r["top"]], rtol=1e-6)
     assert len(g["results"]) >= 150 and len(shapes) >= 4
+
+
+def test_random_trees_equal_the_reference():
+    """tests/golden/ref_random.json: 384 random trees of AND / OR / NOT / <optional> / matchsome (depth <= 3, <= 8 distinct terms) as the
+    reference compiled them, with its answers in all three modes.  The oracle's iterators, fed the lowered trees, reproduce them — docID
+    sets, score sums and top-10, and the default mode's matched terms and hits."""
+    g = json.load(open(os.path.join(GOLDEN, "ref_random.json")))
+    c = g["corpus"]
+    ix = O.Index.generate(c["D"], c["V"], c["slots"], c["seed"])
+    ops = set()
+    for r in g["results"]:
+        prog = np.array(O.program_from_exec_tree(r["tree"]), dtype=np.uint32)
+        ops |= {int(t) >> 28 for t in prog}
+        docs, _ = ix.exec(prog, O.FLAG_DOCUMENTS_ONLY)
+        assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
+        docs, scores = ix.exec(prog, O.FLAG_ACCUM_SCORE)
+        assert len(docs) == r["n"] and abs(float(np.sum(scores)) - r["score_sum"]) <= 1e-6 * max(1.0, r["score_sum"]), r["q"]
+        td, ts = ix.topk(docs, scores, 10)
+        assert td.tolist() == [x[0] for x in r["top"]], r["q"]
+        wdocs, wflat, tt, ht = ix.exec_rich(prog)
+        assert len(wdocs) == r["n"] and tt == r["terms_total"] and ht == r["hits_total"], r["q"]
+        assert str(O.fnv1a_u32_stream(wflat)) == r["rich_fnv"], r["q"]
+    assert len(g["results"]) >= 350 and ops >= {O.OP_TERM, O.OP_AND, O.OP_OR, O.OP_NOT, O.OP_OPT, O.OP_SOME}
