@@ -216,6 +216,22 @@ int tri_batch_counts_device(tri_batch *, void **counts);
 /* FNV-1a(64) of every query's docID set computed from the device results (tests at full size) */
 int tri_batch_docset_hashes(tri_batch *, uint64_t *hashes /* [nq] */);
 
+/* ---- collections of segments ------------------------------------------------------------------------
+ * IndexSourcesCollection (index_source.cpp:3-30; exec.h:57-62: exec_query per source, every source masked by the documents the
+ * newer ones update): one tri_batch per source — the SAME queries in the same order (term indices resolved against each source's
+ * term table; per-token weights when the scores of the sources must share their statistics), same flags and topk, all on one device,
+ * oldest source first, each index carrying its masked set (tri_index_set_masked).  The collection batch borrows them: run = the parts
+ * back to back on the engine stream + a device merge — match counts add up, top-K lists merge K-way from the parts' partial lists
+ * (score descending, docID ascending, as one application heap would hold them); docID sets concatenate source after source. */
+typedef struct tri_cbatch tri_cbatch;
+int tri_cbatch_create(tri_batch *const *parts, size_t n, tri_cbatch **out);
+void tri_cbatch_destroy(tri_cbatch *);
+int tri_cbatch_run(tri_cbatch *);
+int tri_cbatch_sync(tri_cbatch *);
+int tri_cbatch_match_counts(tri_cbatch *, uint64_t *counts /* [nq] */);
+int tri_cbatch_topk(tri_cbatch *, uint32_t *docids, float *scores, uint32_t *counts);
+int tri_cbatch_docset(tri_cbatch *, size_t q, uint32_t *out, size_t cap, size_t *n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -842,6 +842,49 @@ def test_shapes_still_refused(T, dev):
     w.ix.close()
 
 
+# ------------------------------------------------------------------------------------------ collections of segments
+def test_collection_of_two_segments(T, dev):
+    """IndexSourcesCollection semantics (index_source.cpp:3-30): an older segment whose documents 1..6000 were re-indexed into a newer
+    one — the older source is masked by the newer one's documents, the same queries run over both, and the application sees the union:
+    docID sets source after source, match counts added up, ONE top-K over both (merged on the device from the parts' partial lists)."""
+    old = World(T, dev, 20000, 2000, 10, 42)
+    new = World(T, dev, 6000, 2000, 10, 7)
+    try:
+        old.ix.set_masked(np.arange(1, 6001, dtype=np.uint32))
+        texts = template_queries(old, 131, 20) + not_queries(old, 132, 4) + ["t0 t1", "t0 OR t1 OR t2 OR t3", "t5", "[t0, t1, t2]"]
+        progs = [O.parse_query(t, some_min=2) for t in texts]
+        for opts in ({}, {"dense_min_postings": 0}):
+            with options(dev, **opts):
+                parts = [T.Batch(w.ix, progs, T.FLAG_DOCUMENTS_ONLY) for w in (old, new)]
+                cb = T.CollectionBatch(parts)
+                cb.run()
+                cb.sync()
+                counts = cb.counts()
+                sparts = [T.Batch(w.ix, progs, T.FLAG_ACCUMULATED_SCORE, topk=10) for w in (old, new)]
+                sb = T.CollectionBatch(sparts)
+                sb.run()
+                sb.sync()
+                d, s, c = sb.topk_results()
+                scounts = sb.counts()
+            for i, (t, p) in enumerate(zip(texts, progs)):
+                do, so = old.ora.exec(p, O.FLAG_ACCUM_SCORE)
+                keep = do > 6000
+                dn, sn = new.ora.exec(p, O.FLAG_ACCUM_SCORE)
+                want = np.concatenate([do[keep], dn])
+                assert int(counts[i]) == len(want) == int(scounts[i]), (opts, t)
+                assert np.array_equal(cb.docset(i, len(want)), want), (opts, t)
+                td, ts = old.ora.topk(want, np.concatenate([so[keep], sn]), 10)
+                assert int(c[i]) == len(td) and d[i, : len(td)].tolist() == td.tolist(), (opts, t)
+                np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+            cb.close()
+            sb.close()
+            for b in parts + sparts:
+                b.close()
+    finally:
+        old.ix.close()
+        new.ix.close()
+
+
 # ------------------------------------------------------------------------------------------ masked documents (SURVEY §8f-2)
 @pytest.mark.parametrize("codec", [1, 2])
 def test_masked_documents_are_dropped(T, dev, codec):

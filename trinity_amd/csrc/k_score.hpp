@@ -350,6 +350,62 @@ __global__ void k_query_counts(const DevQuery *__restrict__ plan, const uint32_t
         qcounts[q.qid] = c;
 }
 
+// ---- collections of segments (IndexSourcesCollection, index_source.cpp:3-30): the same queries ran over every source; one
+// workgroup per query streams the sources' partial top-K lists (doubles, task by task) through the same top-K structure — what
+// the application's heap sees when exec_query hands it consider(id, score) source after source — and adds up the match counts.
+struct DevSource {
+        const DevQuery *plan;
+        const uint32_t *slot_of_query; // caller query -> plan slot of this source's batch (0xffffffff: matches nothing there)
+        const uint32_t *part_docs;
+        const double *part_scores;
+        const uint32_t *part_counts;
+        const uint64_t *qcounts;
+};
+__global__ __launch_bounds__(AND_WG) void k_topk_merge_sources(const DevSource *__restrict__ src, const uint32_t nsrc, const uint32_t nq, const uint32_t k,
+                                                               uint32_t *__restrict__ top_docs, float *__restrict__ top_scores,
+                                                               uint32_t *__restrict__ top_counts, uint64_t *__restrict__ counts) {
+        __shared__ TopK tk;
+        __shared__ uint32_t scan[8];
+        const uint32_t tid = threadIdx.x;
+        for (uint32_t qi = blockIdx.x; qi < nq; qi += gridDim.x) {
+                tk.n = 0;
+                tk.full = 0;
+                __syncthreads();
+                uint64_t total = 0;
+                for (uint32_t s = 0; s < nsrc; ++s) {
+                        const DevSource S = src[s];
+                        total += S.qcounts[qi];
+                        const uint32_t slot = uni(S.slot_of_query[qi]);
+                        if (slot == 0xffffffffu || !k) // (uniform)
+                                continue;
+                        const DevQuery q = S.plan[slot];
+                        const uint32_t ntasks = uni(q.ntasks);
+                        for (uint32_t t = 0; t < ntasks; ++t) {
+                                const uint32_t tix = uni(q.first_task) + t;
+                                const uint32_t c = uni(S.part_counts[tix]);
+                                for (uint32_t base = 0; base < c; base += AND_WG) {
+                                        const uint32_t i = base + tid;
+                                        const bool v = i < c;
+                                        topk_offer(tk, k, v, v ? S.part_scores[(uint64_t)tix * k + i] : 0.0, v ? S.part_docs[(uint64_t)tix * k + i] : 0u, scan);
+                                }
+                        }
+                }
+                if (k) {
+                        topk_prune(tk, k, scan);
+                        const uint32_t n = uni(tk.n);
+                        for (uint32_t i = tid; i < k; i += AND_WG) {
+                                top_docs[(uint64_t)qi * k + i] = i < n ? tk.d[i] : 0u;
+                                top_scores[(uint64_t)qi * k + i] = i < n ? (float)tk.s[i] : 0.0f;
+                        }
+                        if (uni(tid >> 6) == 0) // (a wave-uniform branch: every lane of wave 0 stores the same word)
+                                top_counts[qi] = n;
+                }
+                if (uni(tid >> 6) == 0)
+                        counts[qi] = total;
+                __syncthreads();
+        }
+}
+
 // FNV-1a(64) of each query's docID set (little-endian bytes), one lane per query — verification helper
 __global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks_by_query,
                                const uint32_t *__restrict__ counts_by_query, const uint32_t nq, const uint32_t *__restrict__ out,

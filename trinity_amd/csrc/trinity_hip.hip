@@ -2187,6 +2187,155 @@ extern "C" int tri_batch_topk_device(tri_batch *b, void **docids, void **scores,
         return TRI_OK;
 }
 
+// ------------------------------------------------------------------------------------------ collections of segments
+// IndexSourcesCollection (index_source.cpp:3-30): a query runs over every source of the collection, each source masked by what the
+// newer ones update (tri_index_set_masked), and the application's filter sees the matches of all of them (exec_query per source,
+// exec.h:57-62).  A tri_cbatch borrows one tri_batch per source — the same queries, term indices resolved per source — runs them back
+// to back on the engine stream and merges on the device: match counts add up, top-K lists merge K-way from the parts' partial lists.
+struct tri_cbatch {
+        std::vector<tri_batch *> parts;
+        std::vector<uint32_t *> d_slots; // per part: caller query -> plan slot
+        DevSource *d_src = nullptr;
+        uint32_t *d_top_docs = nullptr, *d_top_counts = nullptr;
+        float *d_top_scores = nullptr;
+        uint64_t *d_counts = nullptr;
+        bool ran = false, synced = false;
+        ~tri_cbatch() {
+                if (!parts.empty())
+                        hipSetDevice(parts[0]->ix->dev->device);
+                for (auto p : d_slots)
+                        hipFree(p);
+                hipFree(d_src);
+                hipFree(d_top_docs);
+                hipFree(d_top_counts);
+                hipFree(d_top_scores);
+                hipFree(d_counts);
+        }
+};
+
+extern "C" int tri_cbatch_create(tri_batch *const *parts, size_t n, tri_cbatch **out) {
+        if (!parts || !n || !out)
+                return fail(TRI_ERR_INVALID, "tri_cbatch_create: null argument");
+        for (size_t i = 0; i < n; ++i) {
+                if (!parts[i])
+                        return fail(TRI_ERR_INVALID, "tri_cbatch_create: null part %zu", i);
+                if (parts[i]->ix->dev != parts[0]->ix->dev || parts[i]->nq != parts[0]->nq || parts[i]->flags != parts[0]->flags ||
+                    parts[i]->topk != parts[0]->topk)
+                        return fail(TRI_ERR_INVALID, "tri_cbatch_create: part %zu differs from part 0 in device, query count, flags or topk", i);
+        }
+        tri_dev *dev = parts[0]->ix->dev;
+        HIP_TRY(hipSetDevice(dev->device));
+        auto c = std::make_unique<tri_cbatch>();
+        c->parts.assign(parts, parts + n);
+        const size_t nq = parts[0]->nq, k = parts[0]->topk;
+        std::vector<DevSource> src(n);
+        for (size_t i = 0; i < n; ++i) {
+                uint32_t *d = nullptr;
+                int rc;
+                if ((rc = dev_upload(&d, parts[i]->slot_of_query)))
+                        return rc;
+                c->d_slots.push_back(d);
+                src[i] = {parts[i]->d_plan, d, parts[i]->d_part_docs, parts[i]->d_part_scores, parts[i]->d_part_counts, parts[i]->d_qcounts};
+        }
+        int rc;
+        if ((rc = dev_upload(&c->d_src, src)))
+                return rc;
+        HIP_TRY(hipMalloc((void **)&c->d_counts, (nq + 1) * 8));
+        if ((parts[0]->flags & TRI_FLAG_ACCUMULATED_SCORE) && k) {
+                HIP_TRY(hipMalloc((void **)&c->d_top_docs, (nq * k + 1) * 4));
+                HIP_TRY(hipMalloc((void **)&c->d_top_scores, (nq * k + 1) * 4));
+                HIP_TRY(hipMalloc((void **)&c->d_top_counts, (nq + 1) * 4));
+        }
+        *out = c.release();
+        return TRI_OK;
+}
+
+extern "C" void tri_cbatch_destroy(tri_cbatch *c) { delete c; }
+
+extern "C" int tri_cbatch_run(tri_cbatch *c) {
+        if (!c)
+                return fail(TRI_ERR_INVALID, "null collection batch");
+        for (tri_batch *p : c->parts)
+                if (int rc = tri_batch_run(p))
+                        return rc;
+        tri_dev *dev = c->parts[0]->ix->dev;
+        const uint32_t nq = (uint32_t)c->parts[0]->nq;
+        const uint32_t k = c->d_top_docs ? c->parts[0]->topk : 0u;
+        if (nq) {
+                hipLaunchKernelGGL(k_topk_merge_sources, dim3(std::min<uint32_t>(nq, (uint32_t)dev->cus * 8)), dim3(AND_WG), 0, dev->stream, c->d_src,
+                                   (uint32_t)c->parts.size(), nq, k, c->d_top_docs, c->d_top_scores, c->d_top_counts, c->d_counts);
+                HIP_TRY(hipGetLastError());
+        }
+        c->ran = true;
+        c->synced = false;
+        return TRI_OK;
+}
+
+extern "C" int tri_cbatch_sync(tri_cbatch *c) {
+        if (!c || !c->ran)
+                return fail(TRI_ERR_INVALID, "tri_cbatch_sync: the collection batch has not been run");
+        for (tri_batch *p : c->parts)
+                if (int rc = tri_batch_sync(p))
+                        return rc;
+        HIP_TRY(hipStreamSynchronize(c->parts[0]->ix->dev->stream));
+        c->synced = true;
+        return TRI_OK;
+}
+
+extern "C" int tri_cbatch_match_counts(tri_cbatch *c, uint64_t *counts) {
+        if (!c || !counts)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (!c->synced)
+                return fail(TRI_ERR_INVALID, "tri_cbatch_sync first");
+        HIP_TRY(hipSetDevice(c->parts[0]->ix->dev->device));
+        HIP_TRY(hipMemcpy(counts, c->d_counts, c->parts[0]->nq * 8, hipMemcpyDeviceToHost));
+        return TRI_OK;
+}
+
+extern "C" int tri_cbatch_topk(tri_cbatch *c, uint32_t *docids, float *scores, uint32_t *counts) {
+        if (!c || !docids || !scores || !counts)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (!c->d_top_docs)
+                return fail(TRI_ERR_INVALID, "the parts were not created with TRI_FLAG_ACCUMULATED_SCORE and topk >= 1");
+        if (!c->synced)
+                return fail(TRI_ERR_INVALID, "tri_cbatch_sync first");
+        const size_t nq = c->parts[0]->nq, k = c->parts[0]->topk;
+        HIP_TRY(hipSetDevice(c->parts[0]->ix->dev->device));
+        HIP_TRY(hipMemcpy(docids, c->d_top_docs, nq * k * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(scores, c->d_top_scores, nq * k * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(counts, c->d_top_counts, nq * 4, hipMemcpyDeviceToHost));
+        return TRI_OK;
+}
+
+// the docID set of query q over the collection: the sources' sets one after the other (each ascending; the sources are disjoint where
+// the newer ones mask the older) — the order exec_query delivers them in when it is called source after source
+extern "C" int tri_cbatch_docset(tri_cbatch *c, size_t q, uint32_t *out, size_t cap, size_t *n) {
+        if (!c || !n)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (!c->synced)
+                return fail(TRI_ERR_INVALID, "tri_cbatch_sync first");
+        size_t total = 0;
+        for (tri_batch *p : c->parts) {
+                size_t m = 0;
+                if (int rc = tri_batch_docset(p, q, nullptr, 0, &m))
+                        return rc;
+                total += m;
+        }
+        *n = total;
+        if (!out)
+                return TRI_OK;
+        if (cap < total)
+                return fail(TRI_ERR_INVALID, "docset needs %zu slots, %zu given", total, cap);
+        size_t w = 0;
+        for (tri_batch *p : c->parts) {
+                size_t m = 0;
+                if (int rc = tri_batch_docset(p, q, out + w, cap - w, &m))
+                        return rc;
+                w += m;
+        }
+        return TRI_OK;
+}
+
 #ifdef TRI_PROF
 // perf-probe builds: read back and reset the per-phase cycle totals (dev_stream.hpp)
 extern "C" int tri_debug_prof(uint64_t *out32) {

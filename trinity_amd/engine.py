@@ -75,6 +75,7 @@ ABI_SYMBOLS = [
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
+    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset",
 ]  # fmt: skip
 
 _hip = None
@@ -119,6 +120,13 @@ def hip_lib():
     L.tri_batch_topk_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.tri_batch_counts_device.argtypes = [vp, C.POINTER(vp)]
     L.tri_batch_docset_hashes.argtypes = [vp, vp]
+    L.tri_cbatch_create.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.tri_cbatch_destroy.argtypes = [vp]
+    L.tri_cbatch_run.argtypes = [vp]
+    L.tri_cbatch_sync.argtypes = [vp]
+    L.tri_cbatch_match_counts.argtypes = [vp, vp]
+    L.tri_cbatch_topk.argtypes = [vp, vp, vp, vp]
+    L.tri_cbatch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     _hip = L
     return L
 
@@ -370,4 +378,44 @@ class Batch:
     def close(self):
         if self.h:
             hip_lib().tri_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+class CollectionBatch:
+    """The same queries over the sources of a collection (IndexSourcesCollection): one Batch per source, oldest first, each index
+    carrying the documents the newer sources update as its masked set; counts add up, top-K lists merge on the device."""
+
+    def __init__(self, batches):
+        self.parts = list(batches)
+        self.nq, self.topk = self.parts[0].nq, self.parts[0].topk
+        arr = (C.c_void_p * len(self.parts))(*[b.h for b in self.parts])
+        self.h = C.c_void_p()
+        _check(hip_lib().tri_cbatch_create(arr, len(self.parts), C.byref(self.h)))
+
+    def run(self):
+        _check(hip_lib().tri_cbatch_run(self.h))
+
+    def sync(self):
+        _check(hip_lib().tri_cbatch_sync(self.h))
+
+    def counts(self):
+        out = np.zeros(self.nq, dtype=np.uint64)
+        _check(hip_lib().tri_cbatch_match_counts(self.h, out.ctypes.data))
+        return out
+
+    def topk_results(self):
+        d = np.zeros((self.nq, self.topk), dtype=np.uint32)
+        s = np.zeros((self.nq, self.topk), dtype=np.float32)
+        c = np.zeros(self.nq, dtype=np.uint32)
+        _check(hip_lib().tri_cbatch_topk(self.h, d.ctypes.data, s.ctypes.data, c.ctypes.data))
+        return d, s, c
+
+    def docset(self, q, n):
+        out = np.zeros(max(1, n), dtype=np.uint32)
+        got = C.c_size_t()
+        _check(hip_lib().tri_cbatch_docset(self.h, q, out.ctypes.data, n, C.byref(got)))
+        return out[: got.value]
+
+    def close(self):
+        if self.h:
+            hip_lib().tri_cbatch_destroy(self.h)
             self.h = C.c_void_p()
