@@ -232,6 +232,16 @@ int tri_cbatch_match_counts(tri_cbatch *, uint64_t *counts /* [nq] */);
 int tri_cbatch_topk(tri_cbatch *, uint32_t *docids, float *scores, uint32_t *counts);
 int tri_cbatch_docset(tri_cbatch *, size_t q, uint32_t *out, size_t cap, size_t *n);
 
+/* ---- write side ----------------------------------------------------------------------
+ * Codecs::Google::Encoder (google_codec.cpp:9-176: begin_term / begin_document / new_hit / end_document / end_term, commit_block
+ * :118-176) on the device: the postings of `nterms` terms, term after term — docs[] ascending and > 0 within a term, freqs[] the counted
+ * hits of each posting, positions[] those hits' positions in posting order (payload-less hits; a position-0 hit without payload is not
+ * a hit, google_codec.cpp:42-45), term_first[t] = postings before term t ([nterms + 1]) — are encoded into the `index` bytes the
+ * reference's encoder writes for them, byte for byte (skiplist cadence across terms included), and the term table
+ * (term_index_ctx: documents, chunk offset, chunk size).  index_out == NULL: sizing call (*index_len and terms_out are filled). */
+int tri_encode_google(tri_dev *, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint64_t *term_first, size_t nterms,
+                      uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out);
+
 #ifdef __cplusplus
 }
 #endif

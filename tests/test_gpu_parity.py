@@ -842,6 +842,74 @@ def test_shapes_still_refused(T, dev):
     w.ix.close()
 
 
+# ------------------------------------------------------------------------------------------ write side on the device
+def random_postings(rng, nterms):
+    """Postings that reach every corner of the encoder: empty terms, 1 / 31 / 32 / 33 / 64 / 65 documents, runs long enough for skiplist
+    entries, deltas of every varint length, frequencies 0 .. 300, positions up to 65535 with repeats."""
+    docs, freqs, pos, tf = [], [], [], [0]
+    sizes = [0, 1, 31, 32, 33, 64, 65, 300, 1000, 2, 5]
+    for t in range(nterms):
+        n = sizes[t % len(sizes)] if t < 3 * len(sizes) else int(rng.integers(0, 200))
+        scale = [1, 3, 200, 20000, 3_000_000][t % 5]
+        d = np.cumsum(rng.integers(1, scale + 1, size=n, dtype=np.int64))
+        d = d[d < 2**32 - 1]
+        f = np.where(rng.random(d.size) < 0.1, 0, rng.integers(1, 4, size=d.size))
+        if d.size and t % 7 == 0:
+            f[int(rng.integers(0, d.size))] = 300
+        for k in f.tolist():
+            p = np.sort(rng.integers(1, [12, 200, 65536][t % 3], size=k))
+            pos += p.tolist()
+        docs += d.tolist()
+        freqs += f.tolist()
+        tf.append(len(docs))
+    return np.array(docs, dtype=np.uint32), np.array(freqs, dtype=np.uint32), np.array(pos, dtype=np.uint16), np.array(tf, dtype=np.uint64)
+
+
+def test_google_encoder_on_the_device(T, dev):
+    """tri_encode_google against the host encoder (byte-identical to the reference's Codecs::Google::Encoder, tests/test_abi.py and the
+    oracle's index FNV): the same postings give the same `index` bytes and term table — skiplist entries across terms included —,
+    and the encoded segment decodes back to the postings on the device."""
+    from trinity_amd import engine as E
+
+    rng = np.random.default_rng(5)
+    for nterms in (1, 40, 400):
+        docs, freqs, pos, tf = random_postings(rng, nterms)
+        got, gterms = dev.encode_google(docs, freqs, pos, tf)
+        want, wterms = E.host_encode_google(docs, freqs, pos, tf)
+        assert np.array_equal(gterms, wterms), nterms
+        assert got.size == want.size and np.array_equal(got, want), (nterms, int(np.argmax(got[: want.size] != want[: got.size])))
+        if nterms == 400:  # round trip through the read side
+            ix = T.Index(dev, got, gterms, int(docs.max()))
+            df = gterms[:, 0].astype(np.int64)
+            d2, f2, offs = ix.decode_terms(np.arange(nterms, dtype=np.uint32), df)
+            assert np.array_equal(d2, docs) and np.array_equal(f2, freqs)
+            ix.close()
+
+
+def test_device_encoder_reproduces_the_synthetic_segment(T, dev):
+    """The tiny corpus' postings (read back through the oracle: documents, frequencies, positions) re-encoded on the device give the
+    segment's own bytes — the bytes the reference's encoder writes for this corpus (tests/test_oracle.py pins their FNV)."""
+    seg = T.Segment(2000, 200, 10, 42)
+    ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
+    docs, freqs, pos, tf, kept = [], [], [], [0], []
+    for t in range(200):
+        if not int(seg.terms[t, 0]):
+            continue  # (the segment writes nothing for a term without documents)
+        it = O.PLI(ora, t)
+        while True:
+            d = it.next()
+            if d == O.DOCIDS_END:
+                break
+            docs.append(d)
+            freqs.append(it.freq())
+            pos += it.positions()
+        tf.append(len(docs))
+        kept.append(t)
+    got, gterms = dev.encode_google(docs, freqs, pos, tf)
+    assert np.array_equal(got, np.asarray(seg.index))
+    assert np.array_equal(gterms, np.asarray(seg.terms)[kept])
+
+
 # ------------------------------------------------------------------------------------------ collections of segments (SURVEY §8f-2)
 def test_collection_of_two_segments(T, dev):
     """IndexSourcesCollection semantics (index_source.cpp:3-30): an older segment whose documents 1..6000 were re-indexed into a newer

@@ -199,4 +199,35 @@ void tri_synth_queries(uint32_t V, uint64_t seed, uint32_t nq, uint32_t nterms, 
                 }
         }
 }
+// The host encoder (google_encoder.hpp, byte-identical to the reference's) over caller-supplied postings: the checker of the device
+// encoder (tri_encode_google, include/trinity_hip.h) in tests.  Same arguments; terms_out rows are {documents, offset, size}.
+// Returns the index length, or -1 when `cap` is too small / the input is malformed.
+long long tri_host_encode_google(const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint64_t *term_first, uint64_t nterms,
+                                 uint8_t *out, uint64_t cap, uint32_t *terms_out) {
+        try {
+                Codecs::Google::IndexSession sess;
+                Codecs::Google::Encoder enc(&sess);
+                uint64_t h = 0;
+                for (uint64_t t = 0; t < nterms; ++t) {
+                        term_index_ctx tctx;
+                        enc.begin_term();
+                        for (uint64_t p = term_first[t]; p < term_first[t + 1]; ++p) {
+                                enc.begin_document(docs[p]);
+                                for (uint32_t k = 0; k < freqs[p]; ++k)
+                                        enc.new_hit(positions[h++]);
+                                enc.end_document();
+                        }
+                        enc.end_term(&tctx);
+                        terms_out[3 * t] = tctx.documents;
+                        terms_out[3 * t + 1] = tctx.offset;
+                        terms_out[3 * t + 2] = tctx.size;
+                }
+                if (sess.indexOut.size() > cap)
+                        return -1;
+                std::memcpy(out, sess.indexOut.data(), sess.indexOut.size());
+                return (long long)sess.indexOut.size();
+        } catch (...) {
+                return -1;
+        }
+}
 }

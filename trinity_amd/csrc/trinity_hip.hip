@@ -224,6 +224,7 @@ struct tri_batch {
 #include "k_match.hpp"
 #include "k_score.hpp"
 #include "k_fused.hpp"
+#include "k_encode.hpp"
 #include "k_phrase.hpp"
 #include "k_rich.hpp"
 
@@ -2333,6 +2334,119 @@ extern "C" int tri_cbatch_docset(tri_cbatch *c, size_t q, uint32_t *out, size_t 
                         return rc;
                 w += m;
         }
+        return TRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ write side
+// Codecs::Google::Encoder (google_codec.cpp:9-176) on the device: postings in, the segment's `index` bytes and term table out —
+// byte for byte what the reference's encoder writes for the same begin_term / begin_document / new_hit / end_document / end_term
+// calls (payload-less hits).  See k_encode.hpp.
+extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint64_t *term_first, size_t nterms,
+                                 uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out) {
+        if (!dev || !term_first || !index_len || (nterms && !terms_out))
+                return fail(TRI_ERR_INVALID, "tri_encode_google: null argument");
+        HIP_TRY(hipSetDevice(dev->device));
+        const uint64_t np = nterms ? term_first[nterms] : 0;
+        if (np && (!docs || !freqs))
+                return fail(TRI_ERR_INVALID, "tri_encode_google: null postings");
+        // ---- host: the block structure (which block belongs to which term) and input validation
+        std::vector<uint32_t> blk_first(nterms + 1, 0), blk_term;
+        uint64_t nhits = 0;
+        for (size_t t = 0; t < nterms; ++t) {
+                if (term_first[t + 1] < term_first[t])
+                        return fail(TRI_ERR_INVALID, "tri_encode_google: term_first must ascend");
+                const uint64_t n = term_first[t + 1] - term_first[t];
+                if (n > 0xffffffffull)
+                        return fail(TRI_ERR_UNSUPPORTED, "term %zu: more than 2^32 documents", t);
+                uint32_t prev = 0;
+                for (uint64_t p = term_first[t]; p < term_first[t + 1]; ++p) {
+                        if (!docs[p] || docs[p] <= prev)
+                                return fail(TRI_ERR_INVALID, "term %zu: document IDs must be > 0 and strictly ascending (codecs.h:188-190)", t);
+                        prev = docs[p];
+                        nhits += freqs[p];
+                }
+                const uint64_t nb = (n + 31) / 32;
+                if ((uint64_t)blk_first[t] + nb > 0xfffffff0ull)
+                        return fail(TRI_ERR_UNSUPPORTED, "more than 2^32 blocks");
+                blk_first[t + 1] = blk_first[t] + (uint32_t)nb;
+                blk_term.insert(blk_term.end(), (size_t)nb, (uint32_t)t);
+        }
+        if (nhits && !positions)
+                return fail(TRI_ERR_INVALID, "tri_encode_google: null positions");
+        const uint32_t nblocks = blk_first[nterms];
+        struct Bufs {
+                uint32_t *docs = nullptr, *freqs = nullptr, *blk_first = nullptr, *blk_term = nullptr, *sizes = nullptr, *tails = nullptr;
+                uint16_t *pos = nullptr;
+                uint64_t *hit_off = nullptr, *term_first = nullptr, *blk_off = nullptr, *term_off = nullptr;
+                uint8_t *out = nullptr;
+                ~Bufs() {
+                        for (void *p : {(void *)docs, (void *)freqs, (void *)blk_first, (void *)blk_term, (void *)sizes, (void *)tails, (void *)pos, (void *)hit_off,
+                                        (void *)term_first, (void *)blk_off, (void *)term_off, (void *)out})
+                                hipFree(p);
+                }
+        } d;
+        std::vector<uint64_t> term_off(nterms + 1, 0);
+        std::vector<uint64_t> blk_off(nblocks + 1, 0);
+        if (nblocks) {
+                HIP_TRY(hipMalloc((void **)&d.docs, np * 4));
+                HIP_TRY(hipMalloc((void **)&d.freqs, np * 4));
+                HIP_TRY(hipMalloc((void **)&d.pos, (nhits + 1) * 2));
+                HIP_TRY(hipMalloc((void **)&d.hit_off, (np + 1) * 8));
+                HIP_TRY(hipMalloc((void **)&d.term_first, (nterms + 1) * 8));
+                HIP_TRY(hipMalloc((void **)&d.blk_first, (nterms + 1) * 4));
+                HIP_TRY(hipMalloc((void **)&d.blk_term, (size_t)nblocks * 4));
+                HIP_TRY(hipMalloc((void **)&d.sizes, (size_t)nblocks * 4));
+                HIP_TRY(hipMalloc((void **)&d.tails, (size_t)nblocks * 4));
+                HIP_TRY(hipMalloc((void **)&d.blk_off, ((size_t)nblocks + 1) * 8));
+                HIP_TRY(hipMemcpyAsync(d.docs, docs, np * 4, hipMemcpyHostToDevice, dev->stream));
+                HIP_TRY(hipMemcpyAsync(d.freqs, freqs, np * 4, hipMemcpyHostToDevice, dev->stream));
+                if (nhits)
+                        HIP_TRY(hipMemcpyAsync(d.pos, positions, nhits * 2, hipMemcpyHostToDevice, dev->stream));
+                HIP_TRY(hipMemcpyAsync(d.term_first, term_first, (nterms + 1) * 8, hipMemcpyHostToDevice, dev->stream));
+                HIP_TRY(hipMemcpyAsync(d.blk_first, blk_first.data(), (nterms + 1) * 4, hipMemcpyHostToDevice, dev->stream));
+                HIP_TRY(hipMemcpyAsync(d.blk_term, blk_term.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, dev->stream));
+                // hits before every posting, then the blocks' sizes and their running sum
+                hipLaunchKernelGGL(k_enc_scan, dim3(1), dim3(1024), 0, dev->stream, d.freqs, d.hit_off, np);
+                const EncArgs a{d.docs, d.freqs, d.pos, d.hit_off, d.term_first, d.blk_first, d.blk_term, nblocks};
+                hipLaunchKernelGGL(k_enc_size, dim3((nblocks + 255) / 256), dim3(256), 0, dev->stream, a, d.sizes, d.tails);
+                hipLaunchKernelGGL(k_enc_scan, dim3(1), dim3(1024), 0, dev->stream, d.sizes, d.blk_off, (uint64_t)nblocks);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(blk_off.data(), d.blk_off, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, dev->stream));
+                HIP_TRY(hipStreamSynchronize(dev->stream));
+        }
+        // ---- host: where every term's chunk starts (2 bytes + its blocks + its skiplist entries)
+        for (size_t t = 0; t < nterms; ++t) {
+                const uint32_t g0 = blk_first[t], g1 = blk_first[t + 1];
+                uint64_t entries = 0;
+                if (g1 > g0) {
+                        const uint32_t first_marked = (g0 + 8) / 8 * 8 - 1;
+                        if (g1 - 1 >= first_marked)
+                                entries = std::min<uint64_t>(65535, (g1 - 1 - first_marked) / 8 + 1);
+                }
+                const uint64_t size = 2 + (blk_off[g1] - blk_off[g0]) + 8 * entries;
+                if (term_off[t] + size > 0xffffffffull)
+                        return fail(TRI_ERR_UNSUPPORTED, "the index would exceed 4 GiB (term_index_ctx offsets are 32 bits)");
+                terms_out[t] = {(uint32_t)(term_first[t + 1] - term_first[t]), (uint32_t)term_off[t], (uint32_t)size};
+                term_off[t + 1] = term_off[t] + size;
+        }
+        *index_len = (size_t)term_off[nterms];
+        if (!index_out)
+                return TRI_OK; // (sizing call)
+        if (cap < *index_len)
+                return fail(TRI_ERR_INVALID, "tri_encode_google: the index needs %zu bytes, %zu given", *index_len, cap);
+        if (!*index_len)
+                return TRI_OK;
+        HIP_TRY(hipMalloc((void **)&d.out, *index_len));
+        HIP_TRY(hipMemsetAsync(d.out, 0, *index_len, dev->stream)); // (a term without documents is two zero bytes)
+        if (nblocks) {
+                HIP_TRY(hipMalloc((void **)&d.term_off, (nterms + 1) * 8));
+                HIP_TRY(hipMemcpyAsync(d.term_off, term_off.data(), (nterms + 1) * 8, hipMemcpyHostToDevice, dev->stream));
+                const EncArgs a{d.docs, d.freqs, d.pos, d.hit_off, d.term_first, d.blk_first, d.blk_term, nblocks};
+                hipLaunchKernelGGL(k_enc_write, dim3((nblocks + 255) / 256), dim3(256), 0, dev->stream, a, d.blk_off, d.tails, d.term_off, d.out);
+                HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(index_out, d.out, *index_len, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipStreamSynchronize(dev->stream));
         return TRI_OK;
 }
 
