@@ -232,6 +232,21 @@ int tri_cbatch_match_counts(tri_cbatch *, uint64_t *counts /* [nq] */);
 int tri_cbatch_topk(tri_cbatch *, uint32_t *docids, float *scores, uint32_t *counts);
 int tri_cbatch_docset(tri_cbatch *, size_t q, uint32_t *out, size_t cap, size_t *n);
 
+/* ---- multi-GPU result gather (RCCL over xGMI) -------------------------------------------------------
+ * exec_query_par gives every source / shard its own result object and the caller combines them (exec.h:132-176).  One process per GPU,
+ * queries sharded, index replicated: after a step every rank's fixed-shape result blocks are exchanged with one group of
+ * ncclAllGather calls on the engine stream, straight from the device buffers (no host bounce).  RCCL is bound at run time (dlopen;
+ * TRI_ERR_UNSUPPORTED when it cannot be loaded).  tri_comm_unique_id on rank 0, its 128 bytes handed to every rank by the launcher's
+ * own means (an env var, a file, torch.distributed's store), tri_comm_create on every rank (collective).
+ * tri_gather_results: counts_all u64[nranks][nq]; for AccumulatedScore top-K batches also docids_all u32[nranks][nq][k],
+ * scores_all f32[nranks][nq][k], topk_counts_all u32[nranks][nq] — device buffers of the caller; enqueued behind the batch's run,
+ * complete after tri_dev_sync.  (Every rank's batch has the same nq and topk.) */
+typedef struct tri_comm tri_comm;
+int tri_comm_unique_id(uint8_t id[128]);
+int tri_comm_create(tri_dev *, const uint8_t id[128], int rank, int nranks, tri_comm **out);
+void tri_comm_destroy(tri_comm *);
+int tri_gather_results(tri_batch *, tri_comm *, void *counts_all, void *docids_all, void *scores_all, void *topk_counts_all);
+
 /* ---- write side ----------------------------------------------------------------------
  * Codecs::Google::Encoder (google_codec.cpp:9-176: begin_term / begin_document / new_hit / end_document / end_term, commit_block
  * :118-176) on the device: the postings of `nterms` terms, term after term — docs[] ascending and > 0 within a term, freqs[] the counted

@@ -842,6 +842,50 @@ def test_shapes_still_refused(T, dev):
     w.ix.close()
 
 
+# ------------------------------------------------------------------------------------------ result gather behind the C-ABI (RCCL)
+def test_gather_results_over_rccl_one_rank(T, dev, small):
+    """tri_comm_* / tri_gather_results with a communicator of one rank (all this box has): what arrives in the [nranks][...] receive
+    buffers is the batch's own device-resident result blocks.  (The torch.distributed form of the same gather — trinity_amd/dist.py —
+    is what bench.py runs and what tests/test_dist_gloo.py covers at world_size 2.)"""
+    import ctypes as C
+
+    from trinity_amd import engine as E
+
+    L = E.hip_lib()
+    uid = (C.c_uint8 * 128)()
+    E._check(L.tri_comm_unique_id(uid))
+    comm = C.c_void_p()
+    E._check(L.tri_comm_create(dev.h, uid, 0, 1, C.byref(comm)))
+    w = small
+    texts = template_queries(w, 141, 20)
+    progs = [O.parse_query(t) for t in texts]
+    b = T.Batch(w.ix, progs, T.FLAG_ACCUMULATED_SCORE, topk=10)
+    b.run()
+    nq, k = b.nq, 10
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    bufs = []
+    for nbytes in (nq * 8, nq * k * 4, nq * k * 4, nq * 4):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), nbytes) == 0
+        bufs.append((p, nbytes))
+    E._check(L.tri_gather_results(b.h, comm, bufs[0][0], bufs[1][0], bufs[2][0], bufs[3][0]))
+    b.sync()
+    dev.sync()
+    host = []
+    for (p, nbytes), dt in zip(bufs, (np.uint64, np.uint32, np.float32, np.uint32)):
+        a = np.zeros(nbytes // np.dtype(dt).itemsize, dtype=dt)
+        assert hip.hipMemcpy(a.ctypes.data, p, nbytes, 2) == 0  # hipMemcpyDeviceToHost
+        host.append(a)
+        hip.hipFree(p)
+    d, s, c = b.topk_results()
+    assert np.array_equal(host[0], b.counts())
+    assert np.array_equal(host[1].reshape(nq, k), d) and np.array_equal(host[2].reshape(nq, k), s) and np.array_equal(host[3], c)
+    b.close()
+    L.tri_comm_destroy(comm)
+
+
 # ------------------------------------------------------------------------------------------ write side on the device (SURVEY §8f-4)
 def random_postings(rng, nterms):
     """Postings that reach every corner of the encoder: empty terms, 1 / 31 / 32 / 33 / 64 / 65 documents, runs long enough for skiplist

@@ -36,7 +36,7 @@ def hipcc():
 
 def build_hip(force=False):
     if force or _newer(LIB_HIP, _deps(HIP_SRCS)):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_HIP] + HIP_SRCS
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_HIP] + HIP_SRCS + ["-ldl"]
         subprocess.run(cmd, check=True)
     return LIB_HIP
 

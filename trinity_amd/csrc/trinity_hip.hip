@@ -27,6 +27,7 @@
 #include <cstring>
 #include <ctime>
 #include <unistd.h>
+#include <dlfcn.h>
 #include <memory>
 #include <numeric>
 #include <string>
@@ -2334,6 +2335,126 @@ extern "C" int tri_cbatch_docset(tri_cbatch *c, size_t q, uint32_t *out, size_t 
                         return rc;
                 w += m;
         }
+        return TRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ multi-GPU result gather (RCCL)
+// exec_query_par hands every source / shard its own result object and the caller combines them (exec.h:132-176).  With the queries
+// sharded over one process per GPU, the fixed-shape result blocks of a batch — per-query match counts and, for top-K batches, the
+// [nq][k] docID / score blocks and list lengths — are exchanged with ONE group of ncclAllGather calls on the engine stream, straight
+// from the device buffers.  RCCL is bound at run time (dlopen): the library has no link-time dependency on it, and inside a process
+// that already holds an RCCL (PyTorch's) the same one is used.
+namespace {
+        struct RcclApi {
+                struct UniqueId {
+                        char internal[128];
+                };
+                int (*GetUniqueId)(UniqueId *) = nullptr;
+                int (*CommInitRank)(void **, int, UniqueId, int) = nullptr;
+                int (*CommDestroy)(void *) = nullptr;
+                int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+                int (*GroupStart)() = nullptr;
+                int (*GroupEnd)() = nullptr;
+                const char *(*GetErrorString)(int) = nullptr;
+                bool ok = false;
+        };
+        RcclApi &rccl() {
+                static RcclApi api;
+                static bool tried = false;
+                if (tried)
+                        return api;
+                tried = true;
+                void *h = nullptr;
+                for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                        if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)))
+                                break;
+                if (!h)
+                        return api;
+                api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+                api.CommInitRank = (decltype(api.CommInitRank))dlsym(h, "ncclCommInitRank");
+                api.CommDestroy = (decltype(api.CommDestroy))dlsym(h, "ncclCommDestroy");
+                api.AllGather = (decltype(api.AllGather))dlsym(h, "ncclAllGather");
+                api.GroupStart = (decltype(api.GroupStart))dlsym(h, "ncclGroupStart");
+                api.GroupEnd = (decltype(api.GroupEnd))dlsym(h, "ncclGroupEnd");
+                api.GetErrorString = (decltype(api.GetErrorString))dlsym(h, "ncclGetErrorString");
+                api.ok = api.GetUniqueId && api.CommInitRank && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd;
+                return api;
+        }
+        int nccl_fail(const char *what, int rc) { return fail(TRI_ERR_DEVICE, "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error"); }
+} // namespace
+
+struct tri_comm {
+        tri_dev *dev = nullptr;
+        void *comm = nullptr;
+        int rank = 0, nranks = 1;
+};
+
+extern "C" int tri_comm_unique_id(uint8_t id[128]) {
+        if (!id)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (!rccl().ok)
+                return fail(TRI_ERR_UNSUPPORTED, "librccl could not be loaded");
+        RcclApi::UniqueId u;
+        if (int rc = rccl().GetUniqueId(&u))
+                return nccl_fail("ncclGetUniqueId", rc);
+        memcpy(id, u.internal, 128);
+        return TRI_OK;
+}
+
+extern "C" int tri_comm_create(tri_dev *dev, const uint8_t id[128], int rank, int nranks, tri_comm **out) {
+        if (!dev || !id || !out || nranks < 1 || rank < 0 || rank >= nranks)
+                return fail(TRI_ERR_INVALID, "tri_comm_create: bad argument");
+        if (!rccl().ok)
+                return fail(TRI_ERR_UNSUPPORTED, "librccl could not be loaded");
+        HIP_TRY(hipSetDevice(dev->device));
+        auto c = std::make_unique<tri_comm>();
+        c->dev = dev;
+        c->rank = rank;
+        c->nranks = nranks;
+        RcclApi::UniqueId u;
+        memcpy(u.internal, id, 128);
+        if (int rc = rccl().CommInitRank(&c->comm, nranks, u, rank))
+                return nccl_fail("ncclCommInitRank", rc);
+        *out = c.release();
+        return TRI_OK;
+}
+
+extern "C" void tri_comm_destroy(tri_comm *c) {
+        if (!c)
+                return;
+        if (c->comm && rccl().ok)
+                rccl().CommDestroy(c->comm);
+        delete c;
+}
+
+// every rank's blocks of batch b (same nq and topk on every rank) into [nranks][...] device buffers: counts_all u64[nranks][nq]; and for
+// AccumulatedScore top-K batches docids_all u32[nranks][nq][k], scores_all f32[nranks][nq][k], topk_counts_all u32[nranks][nq] (NULL
+// for the other modes).  Enqueued on the engine stream behind the batch's run; complete after tri_dev_sync / a stream wait.
+extern "C" int tri_gather_results(tri_batch *b, tri_comm *c, void *counts_all, void *docids_all, void *scores_all, void *topk_counts_all) {
+        if (!b || !c || !counts_all)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (b->ix->dev != c->dev)
+                return fail(TRI_ERR_INVALID, "tri_gather_results: the batch and the communicator live on different device handles");
+        const bool topk = (b->flags & TRI_FLAG_ACCUMULATED_SCORE) && b->topk;
+        if (topk && (!docids_all || !scores_all || !topk_counts_all))
+                return fail(TRI_ERR_INVALID, "tri_gather_results: a top-K batch needs all four receive buffers");
+        tri_dev *dev = c->dev;
+        HIP_TRY(hipSetDevice(dev->device));
+        const RcclApi &R = rccl();
+        const int U8 = 1; // ncclUint8: the blocks travel as bytes
+        int rc = R.GroupStart();
+        if (!rc)
+                rc = R.AllGather(b->d_qcounts, counts_all, b->nq * 8, U8, c->comm, dev->stream);
+        if (!rc && topk) {
+                rc = R.AllGather(b->d_top_docs, docids_all, b->nq * b->topk * 4, U8, c->comm, dev->stream);
+                if (!rc)
+                        rc = R.AllGather(b->d_top_scores, scores_all, b->nq * b->topk * 4, U8, c->comm, dev->stream);
+                if (!rc)
+                        rc = R.AllGather(b->d_top_counts, topk_counts_all, b->nq * 4, U8, c->comm, dev->stream);
+        }
+        const int rc2 = R.GroupEnd();
+        if (rc || rc2)
+                return nccl_fail("ncclAllGather", rc ? rc : rc2);
         return TRI_OK;
 }
 

@@ -76,6 +76,7 @@ ABI_SYMBOLS = [
     "tri_batch_create", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
     "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google",
+    "tri_comm_unique_id", "tri_comm_create", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
 
 _hip = None
@@ -128,6 +129,10 @@ def hip_lib():
     L.tri_cbatch_topk.argtypes = [vp, vp, vp, vp]
     L.tri_cbatch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_encode_google.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.tri_comm_unique_id.argtypes = [vp]
+    L.tri_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.tri_comm_destroy.argtypes = [vp]
+    L.tri_gather_results.argtypes = [vp, vp, vp, vp, vp, vp]
     _hip = L
     return L
 
