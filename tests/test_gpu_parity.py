@@ -842,6 +842,35 @@ def test_shapes_still_refused(T, dev):
     w.ix.close()
 
 
+# ------------------------------------------------------------------------------------------ foreign / damaged chunks at upload
+def test_upload_rejects_what_the_kernels_cannot_read(T, dev):
+    """tri_index_upload validates the chunk format: a chunk whose non-final block holds fewer than 32 documents (legal to the reference's
+    decoder, never written by its encoder; the kernels' tile and output layouts rely on full blocks) answers TRI_ERR_UNSUPPORTED, a
+    truncated or corrupted chunk TRI_ERR_FORMAT — never a read past the buffer, never a wrong answer."""
+    from trinity_amd import engine as E
+
+    one = lambda docs: E.host_encode_google(docs, [1] * len(docs), list(range(1, len(docs) + 1)), [0, len(docs)])[0]
+    a, b = one([1, 2]), one([3, 4, 5])  # two one-block chunks: [u16 0][block]
+    chunk = np.concatenate([a, b[2:]])  # ... glued into one chunk of a 2-document and a 3-document block: documents 1, 2, 5, 6, 7
+    with pytest.raises(T.TrinityError, match="rc=-3"):
+        T.Index(dev, chunk, np.array([[5, 0, chunk.size]], dtype=np.uint32), 7)
+    # the same bytes declared as what they are not
+    with pytest.raises(T.TrinityError, match="rc=-4"):
+        T.Index(dev, a, np.array([[3, 0, a.size]], dtype=np.uint32), 7)  # 2 documents in blocks, 3 declared
+    good, terms = E.host_encode_google(np.arange(1, 101), [2] * 100, [1, 5] * 100, [0, 100])
+    ix = T.Index(dev, good, terms, 100)
+    ix.close()
+    for cut in (1, 3, 17, good.size // 2):
+        with pytest.raises(T.TrinityError, match="rc=-4"):
+            T.Index(dev, good[: good.size - cut], np.array([[100, 0, good.size - cut]], dtype=np.uint32), 100)
+    bad = good.copy()
+    bad[3] = 0xF0  # the first block's length varint now claims five bytes
+    with pytest.raises(T.TrinityError, match="rc=-4"):
+        T.Index(dev, bad, terms, 100)
+    with pytest.raises(T.TrinityError, match="rc=-4"):
+        T.Index(dev, good, np.array([[100, 8, good.size]], dtype=np.uint32), 100)  # chunk outside the index
+
+
 # ------------------------------------------------------------------------------------------ result gather behind the C-ABI (RCCL)
 def test_gather_results_over_rccl_one_rank(T, dev, small):
     """tri_comm_* / tri_gather_results with a communicator of one rank (all this box has): what arrives in the [nranks][...] receive
