@@ -134,96 +134,6 @@ struct PhraseShared {
         uint32_t bcast[4];
 };
 
-// Locate `doc` (known to be a document of term t) and return its hit count and where its first hit is (GOOGLE: byte offset
-// into index[]; LUCENE: hit ordinal within the term).
-template <int CODEC>
-__device__ __forceinline__ void phrase_locate(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
-                                              const HitCtx &ctx, const DevTerm t, const uint32_t doc, uint32_t &hits_off, uint32_t &freq);
-
-template <>
-__device__ __forceinline__ void phrase_locate<CODEC_LUCENE>(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                                            const uint32_t *__restrict__ blk_off, const HitCtx &ctx, const DevTerm t, const uint32_t doc,
-                                                            uint32_t &hits_off, uint32_t &freq) {
-        const uint32_t *bl = blk_last + t.first_block;
-        uint32_t lo = 0, hi = t.nblocks;
-        while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (bl[mid] < doc)
-                        lo = mid + 1;
-                else
-                        hi = mid;
-        }
-        const uint32_t b = lo;
-        const uint32_t off = blk_off[t.first_block + b];
-        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
-        DeltaStream<CODEC_LUCENE> ds;
-        ds.init(index, t, b, off);
-        uint32_t d = b ? bl[b - 1] : 0, idx = n - 1;
-        for (uint32_t i = 0; i + 1 < n; ++i) {
-                d += ds.next();
-                if (d == doc) {
-                        idx = i;
-                        break;
-                }
-        }
-        FreqStream<CODEC_LUCENE> fs;
-        fs.init(index, t, b, off, ds);
-        uint32_t h = ctx.blk_hits[t.first_block + b];
-        for (uint32_t i = 0; i < idx; ++i)
-                h += fs.next();
-        freq = fs.next();
-        hits_off = h;
-}
-
-template <>
-__device__ __forceinline__ void phrase_locate<CODEC_GOOGLE>(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
-                                                            const uint32_t *__restrict__ blk_off, const HitCtx &ctx, const DevTerm t, const uint32_t doc,
-                                                            uint32_t &hits_off, uint32_t &freq) {
-        const uint32_t *bl = blk_last + t.first_block;
-        uint32_t lo = 0, hi = t.nblocks;
-        while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (bl[mid] < doc)
-                        lo = mid + 1;
-                else
-                        hi = mid;
-        }
-        const uint32_t b = lo;
-        const uint32_t off = blk_off[t.first_block + b];
-        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
-        VbStream s;
-        s.init(index + off);
-        uint32_t d = b ? bl[b - 1] : 0, idx = n - 1; // the last slot's docID is implied by the header
-        for (uint32_t i = 0; i + 1 < n; ++i) {
-                d += s.next();
-                if (d == doc)
-                        idx = i;
-        }
-        VbStream sf = s; // freqs start here
-        const uint32_t hits_at = ctx.blk_hits[t.first_block + b];
-        if (hits_at & BLK_HITS_PLAIN) { // one byte per hit: the preceding slots' hits are as many bytes as their frequencies add up to
-                uint32_t h = hits_at & ~BLK_HITS_PLAIN;
-                for (uint32_t i = 0; i < idx; ++i)
-                        h += sf.next();
-                freq = sf.next();
-                hits_off = h;
-                return;
-        }
-        s.init(index + hits_at); // the block's hits (the directory knows where they start: no walk over the n freqs)
-        for (uint32_t i = 0; i < idx; ++i) { // skip the hits of the preceding slots
-                const uint32_t f = sf.next();
-                uint32_t plen = 0; // payload length state restarts with every document
-                for (uint32_t h = 0; h < f; ++h) {
-                        const uint32_t v = s.next();
-                        if (v & 1u)
-                                plen = s.byte();
-                        s.skip(plen);
-                }
-        }
-        freq = sf.next();
-        hits_off = (uint32_t)(s.tell() - index);
-}
-
 // Is position `q` among the `freq` hits starting at index[hits_off]?  (positions ascend within a document)
 template <int CODEC>
 __device__ __forceinline__ bool phrase_has_pos(const HitCtx &ctx, const uint32_t hdir_off, const uint32_t hits_off, const uint32_t freq, const uint32_t q) {
@@ -243,8 +153,8 @@ __device__ __forceinline__ bool phrase_has_pos(const HitCtx &ctx, const uint32_t
 // Block-driven location: one lane walks one block of term t ONCE for all the tile's candidates it holds (phrase terms are
 // conjuncts of the query, so every candidate in the block's docID range is a document of the block): deltas mark the slots,
 // then freqs and hits are walked in lockstep up to the last marked slot, leaving (hits locator, freq) for each candidate.
-// Candidate-driven location (phrase_locate) redoes that walk per candidate; it is kept for the case of few candidates
-// scattered over a long list.
+// Few candidates scattered over a long list: every candidate finds its block through the cell index and the first
+// candidate of a block calls this for all of them (k_phrase).
 template <int CODEC>
 __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                     const uint32_t *__restrict__ blk_off, const HitCtx &ctx, const DevTerm t, const uint32_t b,
