@@ -240,7 +240,7 @@ def main():
         }
         if gather_check is not None:
             out["gather_check"] = gather_check
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:  # the CPU leg (and the per-query parity check that rides on it) runs at N = 1 only
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(segs, parts, shard_progs, batches, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
