@@ -34,6 +34,8 @@ extern "C" {
 /* exec.h:11-43 ExecFlags (same values) */
 #define TRI_FLAG_DOCUMENTS_ONLY 1u
 #define TRI_FLAG_ACCUMULATED_SCORE 2u
+#define TRI_FLAG_HIT_PAYLOADS 8u  /* with TRI_FLAG_MATCHED_TERMS: every hit also comes with term_hit::payloadLen and ::payload (runtime.h:8-20) as
+                                     Google::Decoder::materialize_hits leaves them (google_codec.cpp:533-594): tri_batch_matched_payloads */
 #define TRI_FLAG_MATCHED_TERMS 4u /* exec_query's DEFAULT mode (no ExecFlags, exec.cpp:1350-1501): every match comes with the query
                                      terms that matched it and their hits — what consider(const matched_document &) receives
                                      (matches.h:109-130; queryexec_ctx.cpp:382-648).  Results: tri_batch_matched_terms */
@@ -206,6 +208,10 @@ int tri_batch_scores(tri_batch *, size_t q, double *out, size_t cap, size_t *n);
 int tri_batch_query_terms(tri_batch *, size_t q, uint32_t *terms /* [16] */, uint32_t *nterms);
 int tri_batch_matched_terms(tri_batch *, size_t q, uint32_t *present /* [n] */, uint16_t *freq /* [n * nterms] */, uint16_t *positions,
                             size_t pos_cap, size_t *npos);
+/* TRI_FLAG_MATCHED_TERMS | TRI_FLAG_HIT_PAYLOADS batches: the payloads of query q's hits, parallel to `positions` above (same order,
+ * *n == *npos): lens[i] = term_hit::payloadLen, payloads[i] = term_hit::payload — the word as materialize_hits leaves it, i.e. only its
+ * first lens[i] bytes belong to this hit (google_codec.cpp:533-594).  Pass lens == payloads == NULL to learn *n. */
+int tri_batch_matched_payloads(tri_batch *, size_t q, uint8_t *lens, uint64_t *payloads, size_t cap, size_t *n);
 /* AccumulatedScore with topk >= 1: docids/scores are [nq][topk] row-major, counts[nq] = min(matches, topk) */
 int tri_batch_topk(tri_batch *, uint32_t *docids, float *scores, uint32_t *counts);
 /* device-resident result blocks for the multi-GPU gather (per rank: [nq][topk] u32 + f32, [nq] u32); valid once the run has

@@ -706,6 +706,43 @@ static uint32_t pli_advance(to_iter *self, uint32_t target) {
 /* google_codec.cpp:533-594 (positions only; payload bytes are skipped exactly as the reference reads them) */
 uint32_t to_pli_materialize_positions(to_pli *it, uint16_t *out) { return it->materialize(it, out); }
 
+static uint32_t google_materialize_positions(to_pli *it, uint16_t *out);
+/* google_codec.cpp:533-594 in full: out[i] = {payload, pos, curPayloadSize}.  The payload word is a local that lives across the
+ * document's hits: a new payload overwrites its first curPayloadSize bytes only (memcpy), size 0 clears it. */
+uint32_t to_pli_materialize_hits(to_pli *it, uint16_t *pos_out, uint8_t *plen_out, uint64_t *payload_out) {
+        if (it->materialize != google_materialize_positions) { /* the Lucene-shaped segments of this repo carry no payloads */
+                const uint32_t n = it->materialize(it, pos_out);
+                for (uint32_t i = 0; i < n; ++i) {
+                        plen_out[i] = 0;
+                        payload_out[i] = 0;
+                }
+                return n;
+        }
+        const uint32_t freq = it->freqs[it->blockDocIdx];
+        uint16_t pos = 0;
+        uint8_t curPayloadSize = 0;
+        uint64_t payload = 0;
+        uint32_t step;
+        const uint8_t *p = it->p;
+        for (uint32_t i = 0; i != (uint16_t)freq; ++i) {
+                p += to_varbyte_get32(p, &step);
+                if (step & 1)
+                        curPayloadSize = *p++;
+                pos = (uint16_t)(pos + (step >> 1));
+                if (curPayloadSize) {
+                        memcpy(&payload, p, curPayloadSize <= 8 ? curPayloadSize : 8);
+                        p += curPayloadSize;
+                } else
+                        payload = 0;
+                pos_out[i] = pos;
+                plen_out[i] = curPayloadSize;
+                payload_out[i] = payload;
+        }
+        it->p = p;
+        it->freqs[it->blockDocIdx] = 0; /* google_codec.cpp:593 */
+        return (uint16_t)freq;
+}
+
 static uint32_t google_materialize_positions(to_pli *it, uint16_t *out) {
         const uint32_t freq = it->freqs[it->blockDocIdx];
         uint16_t pos = 0;

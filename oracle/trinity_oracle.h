@@ -143,6 +143,8 @@ uint32_t to_pli_current(const to_pli *);
 uint32_t to_pli_freq(const to_pli *); /* codecs.h:217: exposed as tokenpos_t (u16) */
 /* google_codec.cpp:533-594; returns number of hits written; out_pos needs room for freq entries */
 uint32_t to_pli_materialize_positions(to_pli *, uint16_t *out_pos);
+/* ... with term_hit::payloadLen / ::payload as the reference leaves them (google_codec.cpp:533-594) */
+uint32_t to_pli_materialize_hits(to_pli *it, uint16_t *pos_out, uint8_t *plen_out, uint64_t *payload_out);
 
 /* decode a whole term: docs/freqs arrays (capacity documents); returns count */
 uint32_t to_decode_term(const to_index *, uint32_t term, uint32_t *docs, uint32_t *freqs);

@@ -112,6 +112,8 @@ def lib():
     L.to_pli_advance.argtypes = [C.c_void_p, C.c_uint32]
     L.to_pli_materialize_positions.restype = C.c_uint32
     L.to_pli_materialize_positions.argtypes = [C.c_void_p, u16p]
+    L.to_pli_materialize_hits.restype = C.c_uint32
+    L.to_pli_materialize_hits.argtypes = [C.c_void_p, u16p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
     L.to_decode_term.restype = C.c_uint32
     L.to_decode_term.argtypes = [C.POINTER(ToIndex), C.c_uint32, C.c_void_p, C.c_void_p]
     L.to_bm25_idf.restype = C.c_double
@@ -316,6 +318,12 @@ class PLI:
         buf = (C.c_uint16 * 65536)()
         n = lib().to_pli_materialize_positions(self.p, buf)
         return list(buf[:n])
+
+    def hits(self):
+        """(positions, payload lengths, payload words) of the current document — term_hit as materialize_hits fills it"""
+        pos, ln, pl = (C.c_uint16 * 65536)(), (C.c_uint8 * 65536)(), (C.c_uint64 * 65536)()
+        n = lib().to_pli_materialize_hits(self.p, pos, ln, pl)
+        return list(pos[:n]), list(ln[:n]), list(pl[:n])
 
 
 # ---- tiny query-text -> postfix program compiler for the query templates of SURVEY §8(d) ------------

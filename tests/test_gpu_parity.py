@@ -842,6 +842,69 @@ def test_shapes_still_refused(T, dev):
     w.ix.close()
 
 
+# ------------------------------------------------------------------------------------------ hit payloads in the default mode
+def test_hit_payloads_from_the_reference_segment(T, dev):
+    """TRI_FLAG_MATCHED_TERMS | TRI_FLAG_HIT_PAYLOADS over the reference-written edge segment: for every term the fixture holds the
+    reference's hash over each document's (freq, id) and each hit's (pos, payloadLen, the eight bytes of term_hit::payload) as
+    Google::Decoder::materialize_hits leaves them (payload lengths changing from hit to hit, stale high bytes after a shorter payload).
+    The single-term query `tK` reports exactly that stream; a two-term query reports both terms' payloads per match."""
+    import base64
+
+    g = json.load(open(os.path.join(GOLDEN, "ref_edge.json")))
+    index = np.frombuffer(base64.b64decode(g["index_b64"]), dtype=np.uint8)
+    terms = np.array(g["terms"], dtype=np.uint32)
+    ix = T.Index(dev, index, terms, g["docsCnt"])
+    ora = O.Index.wrap(index, terms, g["docsCnt"], g["postings"], g["sumTermHits"])
+    try:
+        recs = [r for r in g["results"] if r["cmd"] == "hits"]
+        progs = [np.array([T.tok(T.OP_TERM, r["term"])], dtype=np.uint32) for r in recs] + [O.parse_query("t0 t1"), O.parse_query("t0 OR t4")]
+        b = T.Batch(ix, progs, T.FLAG_MATCHED_TERMS | T.FLAG_HIT_PAYLOADS)
+        b.run()
+        b.sync()
+        counts = b.counts()
+        with_payload = 0
+        for qi, r in enumerate(recs):
+            n = int(counts[qi])
+            docs = b.docset(qi, n)
+            _, present, freq, pos = b.matched_terms(qi, n)
+            lens, pl = b.matched_payloads(qi)
+            assert len(lens) == len(pos) == int(freq.sum())
+            h, at = 1469598103934665603, 0
+            for i, d in enumerate(docs.tolist()):
+                f = int(freq[i, 0])
+                h = O.fnv1a_u32s([f, d], h)
+                for k in range(at, at + f):
+                    h = O.fnv1a_u32s([int(pos[k]), int(lens[k]), int(pl[k]) & 0xFFFFFFFF, int(pl[k]) >> 32], h)
+                at += f
+            assert n == r["docs"] and str(h) == r["fnv"], r["term"]
+            with_payload += int(lens.any())
+        assert with_payload >= 1
+        # several terms per match: against the oracle (whose payload walk the CPU suite pins to the same fixture)
+        for qi in (len(recs), len(recs) + 1):
+            n = int(counts[qi])
+            docs = b.docset(qi, n)
+            qterms, present, freq, pos = b.matched_terms(qi, n)
+            lens, pl = b.matched_payloads(qi)
+            at = 0
+            for i, d in enumerate(docs.tolist()):
+                for k, t in enumerate(qterms.tolist()):
+                    f = int(freq[i, k])
+                    if not (int(present[i]) >> k) & 1:
+                        assert f == 0
+                        continue
+                    it = O.PLI(ora, t)
+                    assert it.advance(d) == d
+                    wp, wl, ww = it.hits()
+                    assert pos[at : at + f].tolist() == wp and lens[at : at + f].tolist() == wl and pl[at : at + f].tolist() == ww, (qi, d, t)
+                    at += f
+            assert at == len(pos)
+        b.close()
+        with pytest.raises(T.TrinityError):
+            T.Batch(ix, progs[:1], T.FLAG_DOCUMENTS_ONLY | T.FLAG_HIT_PAYLOADS)
+    finally:
+        ix.close()
+
+
 # ------------------------------------------------------------------------------------------ foreign / damaged chunks at upload
 def test_upload_rejects_what_the_kernels_cannot_read(T, dev):
     """tri_index_upload validates the chunk format: a chunk whose non-final block holds fewer than 32 documents (legal to the reference's

@@ -494,3 +494,30 @@ def test_random_trees_equal_the_reference():
         assert len(wdocs) == r["n"] and tt == r["terms_total"] and ht == r["hits_total"], r["q"]
         assert str(O.fnv1a_u32_stream(wflat)) == r["rich_fnv"], r["q"]
     assert len(g["results"]) >= 350 and ops >= {O.OP_TERM, O.OP_AND, O.OP_OR, O.OP_NOT, O.OP_OPT, O.OP_SOME}
+
+
+def test_edge_hit_payloads_match_reference(edge):
+    """`hits <term>` records carry the reference's hash over every document's (freq, id) and every hit's (pos, payloadLen, the eight bytes
+    of term_hit::payload) — payload lengths that change from hit to hit, the stale high bytes a shorter payload leaves in the word."""
+    g, ix = edge
+    n = 0
+    for r in g["results"]:
+        if r["cmd"] != "hits":
+            continue
+        it = O.PLI(ix, r["term"])
+        h = 1469598103934665603
+        seen_payload = False
+        while True:
+            i = it.next()
+            if i == O.DOCIDS_END:
+                break
+            f = it.freq()
+            pos, ln, pl = it.hits()
+            assert len(pos) == f
+            h = O.fnv1a_u32s([f, i], h)
+            for p_, l_, w_ in zip(pos, ln, pl):
+                h = O.fnv1a_u32s([p_, l_, w_ & 0xFFFFFFFF, w_ >> 32], h)
+                seen_payload |= l_ != 0
+        assert str(h) == r["fnv"], r["term"]
+        n += seen_payload
+    assert n >= 1

@@ -7,4 +7,4 @@ missing — there is no CPU fallback anywhere in this package.
 """
 from .build import build_all, LIB_HIP, LIB_HOST  # noqa: F401
 from .engine import Device, Index, Batch, CollectionBatch, Segment, TrinityError, tok, gen_queries  # noqa: F401
-from .engine import OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT, OP_OPT, OP_SOME, FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE, FLAG_MATCHED_TERMS  # noqa: F401
+from .engine import OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT, OP_OPT, OP_SOME, FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE, FLAG_MATCHED_TERMS, FLAG_HIT_PAYLOADS  # noqa: F401

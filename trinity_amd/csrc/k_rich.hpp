@@ -37,7 +37,11 @@ __global__ __launch_bounds__(AND_WG) void k_rich(const uint8_t *__restrict__ ind
                                                  const uint32_t *__restrict__ sched, const uint32_t *__restrict__ rterms, const uint32_t ntasks,
                                                  uint32_t *__restrict__ ticket, const uint32_t *__restrict__ out, const uint32_t *__restrict__ counts, const uint32_t R,
                                                  uint32_t *__restrict__ present, uint16_t *__restrict__ freq, uint32_t *__restrict__ task_hits,
-                                                 const uint64_t *__restrict__ task_pos_base, uint16_t *__restrict__ pool, const uint32_t *__restrict__ allow) {
+                                                 const uint64_t *__restrict__ task_pos_base, uint16_t *__restrict__ pool, const uint32_t *__restrict__ allow,
+                                                 uint8_t *__restrict__ pool_plen, uint64_t *__restrict__ pool_payload) {
+        // pool_plen / pool_payload (or null; TRI_FLAG_HIT_PAYLOADS): per hit, parallel to `pool`, term_hit::payloadLen and ::payload as
+        // Google::Decoder::materialize_hits leaves them (google_codec.cpp:533-594) — the payload word is carried from hit to hit within a
+        // document and only its first payloadLen bytes are rewritten, exactly as the reference's local variable is
         // allow (or null): per match, the reportable terms an iterator of the query tree sits on — general trees, where holding a term
         // is not enough (the matching kernel left the mask; every other query's matches carry all ones)
         __shared__ RichShared sh;
@@ -175,14 +179,30 @@ __global__ __launch_bounds__(AND_WG) void k_rich(const uint8_t *__restrict__ ind
                                                         const uint32_t fw = f & 0xffffu; // what the COUNT pass recorded (term_hits::freq is tokenpos_t)
                                                         uint16_t *d = ((mask >> i) & 1u) ? dest(sh.mptr[nm++][tid]) : nullptr;
                                                         uint32_t pos = 0, plen = 0; // position and payload-length state restart with every document
+                                                        uint64_t payload = 0;
                                                         for (uint32_t h = 0; h < f; ++h) {
                                                                 const uint32_t v = hs.next();
                                                                 if (v & 1u)
                                                                         plen = hs.byte();
-                                                                hs.skip(plen);
+                                                                if (pool_payload && d) { // the payload bytes, little end first, over the word's low bytes
+                                                                        if (!plen)
+                                                                                payload = 0;
+                                                                        for (uint32_t k = 0; k < plen; ++k) {
+                                                                                const uint64_t by = hs.byte();
+                                                                                if (k < 8)
+                                                                                        payload = (payload & ~(0xffull << (8 * k))) | (by << (8 * k));
+                                                                        }
+                                                                } else
+                                                                        hs.skip(plen);
                                                                 pos = (pos + (v >> 1)) & 0xffffu;
-                                                                if (d && h < fw)
+                                                                if (d && h < fw) {
                                                                         d[h] = (uint16_t)pos;
+                                                                        if (pool_payload) {
+                                                                                const uint64_t at = (uint64_t)(d + h - pool);
+                                                                                pool_plen[at] = (uint8_t)plen;
+                                                                                pool_payload[at] = payload;
+                                                                        }
+                                                                }
                                                         }
                                                 }
                                         } else {
@@ -197,6 +217,10 @@ __global__ __launch_bounds__(AND_WG) void k_rich(const uint8_t *__restrict__ ind
                                                                 for (uint32_t h = 0; h < (f & 0xffffu); ++h) {
                                                                         pos = (pos + hs.next()) & 0xffffu;
                                                                         d[h] = (uint16_t)pos;
+                                                                        if (pool_payload) { // (the Lucene-shaped segments of this repo carry no payloads)
+                                                                                pool_plen[(uint64_t)(d + h - pool)] = 0;
+                                                                                pool_payload[(uint64_t)(d + h - pool)] = 0;
+                                                                        }
                                                                 }
                                                         }
                                                         h0 += f;

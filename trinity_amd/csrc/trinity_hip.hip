@@ -166,6 +166,8 @@ struct tri_batch {
         uint32_t rich_R = 0;
         uint32_t *d_rich_present = nullptr, *d_task_hits = nullptr;
         uint16_t *d_rich_freq = nullptr, *d_rich_pool = nullptr;
+        uint8_t *d_rich_plen = nullptr;     // TRI_FLAG_HIT_PAYLOADS: per hit of the pool, term_hit::payloadLen ...
+        uint64_t *d_rich_payload = nullptr; // ... and term_hit::payload
         uint64_t *d_task_pos_base = nullptr;
         std::vector<uint64_t> h_task_pos_base; // per task; [ntasks] = the pool's size
         size_t rich_pool_cap = 0;
@@ -213,6 +215,8 @@ struct tri_batch {
                 hipFree(d_task_hits);
                 hipFree(d_task_pos_base);
                 hipFree(d_rich_pool);
+                hipFree(d_rich_plen);
+                hipFree(d_rich_payload);
                 hipFree(d_phrases);
                 hipFree(d_pterms);
                 hipFree(d_ptasks);
@@ -1084,6 +1088,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 return fail(TRI_ERR_INVALID, "exactly one of DocumentsOnly, AccumulatedScoreScheme, MatchedTerms (exec_query's default mode): the modes are mutually exclusive (exec.h:45-48)");
         const bool scored = mode == TRI_FLAG_ACCUMULATED_SCORE;
         const bool rich = mode == TRI_FLAG_MATCHED_TERMS;
+        if ((flags & TRI_FLAG_HIT_PAYLOADS) && !rich)
+                return fail(TRI_ERR_INVALID, "TRI_FLAG_HIT_PAYLOADS goes with TRI_FLAG_MATCHED_TERMS (the mode that delivers hits)");
         if (scored && topk > TOPK_MAX)
                 return fail(TRI_ERR_INVALID, "AccumulatedScoreScheme: topk <= %u (0 = keep every match's score instead of a top-K)", TOPK_MAX);
         if (similarity != TRI_SIM_BM25 && similarity != TRI_SIM_TFIDF && similarity != TRI_SIM_TRIVIAL)
@@ -1837,12 +1843,12 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                 hipLaunchKernelGGL((k_rich<CODEC_LUCENE, false>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
                                                    b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched,
                                                    b->d_sterms, n, b->d_ticket + 32, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
-                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr, (const uint32_t *)b->d_rich_allow);
+                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr, (const uint32_t *)b->d_rich_allow, (uint8_t *)nullptr, (uint64_t *)nullptr);
                         else
                                 hipLaunchKernelGGL((k_rich<CODEC_GOOGLE, false>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index,
                                                    b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched,
                                                    b->d_sterms, n, b->d_ticket + 32, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
-                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr, (const uint32_t *)b->d_rich_allow);
+                                                   (const uint64_t *)nullptr, (uint16_t *)nullptr, (const uint32_t *)b->d_rich_allow, (uint8_t *)nullptr, (uint64_t *)nullptr);
                         HIP_TRY(hipGetLastError());
                 }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
@@ -1971,6 +1977,14 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                         b->d_rich_pool = nullptr;
                         b->rich_pool_cap = total + total / 8 + 64;
                         HIP_TRY(hipMalloc((void **)&b->d_rich_pool, b->rich_pool_cap * 2));
+                        if (b->flags & TRI_FLAG_HIT_PAYLOADS) {
+                                hipFree(b->d_rich_plen);
+                                hipFree(b->d_rich_payload);
+                                b->d_rich_plen = nullptr;
+                                b->d_rich_payload = nullptr;
+                                HIP_TRY(hipMalloc((void **)&b->d_rich_plen, b->rich_pool_cap));
+                                HIP_TRY(hipMalloc((void **)&b->d_rich_payload, b->rich_pool_cap * 8));
+                        }
                 }
                 HIP_TRY(hipMemcpy(b->d_task_pos_base, b->h_task_pos_base.data(), (nt + 1) * 8, hipMemcpyHostToDevice));
                 HIP_TRY(hipMemsetAsync(b->d_ticket + 40, 0, 4, dev->stream));
@@ -1979,12 +1993,12 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                         hipLaunchKernelGGL((k_rich<CODEC_LUCENE, true>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_hits,
                                            b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, n,
                                            b->d_ticket + 40, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
-                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool, (const uint32_t *)b->d_rich_allow);
+                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool, (const uint32_t *)b->d_rich_allow, b->d_rich_plen, b->d_rich_payload);
                 else
                         hipLaunchKernelGGL((k_rich<CODEC_GOOGLE, true>), dim3(std::min<uint32_t>(n, (uint32_t)dev->cus * 3)), dim3(AND_WG), 0, dev->stream, b->ix->d_index, b->ix->d_hits,
                                            b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, n,
                                            b->d_ticket + 40, b->d_out, b->d_counts, b->rich_R, b->d_rich_present, b->d_rich_freq, b->d_task_hits,
-                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool, (const uint32_t *)b->d_rich_allow);
+                                           (const uint64_t *)b->d_task_pos_base, b->d_rich_pool, (const uint32_t *)b->d_rich_allow, b->d_rich_plen, b->d_rich_payload);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(dev->stream));
                 b->info.algorithmic_bytes += 2 * total + 4 * m; // + the positions handed over and a present mask per match
@@ -2056,6 +2070,33 @@ extern "C" int tri_batch_matched_terms(tri_batch *b, size_t q, uint32_t *present
                 w += c;
         }
         HIP_TRY(hipStreamSynchronize(dev->stream));
+        return TRI_OK;
+}
+
+// the payloads of query q's hits, parallel to the positions tri_batch_matched_terms returns (same order, same count)
+extern "C" int tri_batch_matched_payloads(tri_batch *b, size_t q, uint8_t *lens, uint64_t *payloads, size_t cap, size_t *n) {
+        if (!b || !n || q >= b->nq)
+                return fail(TRI_ERR_INVALID, "bad argument");
+        if (!(b->flags & TRI_FLAG_MATCHED_TERMS) || !(b->flags & TRI_FLAG_HIT_PAYLOADS))
+                return fail(TRI_ERR_INVALID, "not a TRI_FLAG_MATCHED_TERMS | TRI_FLAG_HIT_PAYLOADS batch");
+        if (!b->synced)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync first");
+        *n = 0;
+        const uint32_t slot = b->slot_of_query[q];
+        if (slot == UINT32_MAX)
+                return TRI_OK;
+        const DevQuery &dq = b->plan[slot];
+        const uint64_t p0 = b->h_task_pos_base[dq.first_task], p1 = b->h_task_pos_base[dq.first_task + dq.ntasks];
+        *n = (size_t)(p1 - p0);
+        if (!lens && !payloads)
+                return TRI_OK;
+        if (cap < *n)
+                return fail(TRI_ERR_INVALID, "payloads need %zu slots, %zu given", *n, cap);
+        HIP_TRY(hipSetDevice(b->ix->dev->device));
+        if (*n && lens)
+                HIP_TRY(hipMemcpy(lens, b->d_rich_plen + p0, *n, hipMemcpyDeviceToHost));
+        if (*n && payloads)
+                HIP_TRY(hipMemcpy(payloads, b->d_rich_payload + p0, *n * 8, hipMemcpyDeviceToHost));
         return TRI_OK;
 }
 

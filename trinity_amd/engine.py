@@ -9,7 +9,7 @@ import numpy as np
 from .build import LIB_HIP, LIB_HOST
 
 OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT, OP_OPT, OP_SOME = 0, 1, 2, 3, 4, 5, 6  # OP_SOME: arg = (min << 16) | children (matchsome)
-FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE, FLAG_MATCHED_TERMS = 1, 2, 4
+FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE, FLAG_MATCHED_TERMS, FLAG_HIT_PAYLOADS = 1, 2, 4, 8
 CODEC_GOOGLE, CODEC_LUCENE = 1, 2
 FNV_EMPTY = 1469598103934665603
 
@@ -74,7 +74,7 @@ ABI_SYMBOLS = [
     "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream", "tri_dev_set_option", "tri_dev_get_option",
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
-    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
+    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
     "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
@@ -114,6 +114,7 @@ def hip_lib():
     L.tri_batch_get_info.argtypes = [vp, C.POINTER(TriBatchInfo)]
     L.tri_batch_query_terms.argtypes = [vp, C.c_size_t, vp, C.POINTER(C.c_uint32)]
     L.tri_batch_matched_terms.argtypes = [vp, C.c_size_t, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.tri_batch_matched_payloads.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_match_counts.argtypes = [vp, vp]
     L.tri_batch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_scores.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -381,6 +382,16 @@ class Batch:
         got = C.c_size_t()
         _check(hip_lib().tri_batch_docset(self.h, q, out.ctypes.data, n, C.byref(got)))
         return out[: got.value]
+
+    def matched_payloads(self, q):
+        """FLAG_MATCHED_TERMS | FLAG_HIT_PAYLOADS batches: (lens u8[npos], payloads u64[npos]) parallel to matched_terms()'s positions."""
+        L = hip_lib()
+        n = C.c_size_t()
+        _check(L.tri_batch_matched_payloads(self.h, q, None, None, 0, C.byref(n)))
+        lens = np.zeros(max(1, n.value), dtype=np.uint8)
+        pl = np.zeros(max(1, n.value), dtype=np.uint64)
+        _check(L.tri_batch_matched_payloads(self.h, q, lens.ctypes.data, pl.ctypes.data, n.value, C.byref(n)))
+        return lens[: n.value], pl[: n.value]
 
     def scores(self, q, n=None):
         if n is None:
