@@ -241,15 +241,14 @@ __device__ __forceinline__ void fused_post(uint32_t *acc, const uint32_t rel, co
 template <int CODEC, int HW>
 __device__ __forceinline__ uint32_t fused_row_streams(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
                                                       const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift,
-                                                      const uint32_t cap) {
+                                                      const uint32_t cap, const uint32_t google_delta_bytes = 0) {
         uint32_t rel = prev - w0, past = 0xffffffffu;
         DeltaStream<CODEC> ds;
         ds.init(index, t, b, off);
         FreqStream<CODEC> fs;
-        if (CODEC == CODEC_GOOGLE) { // the freqs follow the n - 1 deltas: find where they start, then walk both in step
-                DeltaStream<CODEC> sk = ds;
-                for (uint32_t i = 0; i + 1 < n; ++i)
-                        (void)sk.next();
+        if (CODEC == CODEC_GOOGLE) { // the freqs follow the n - 1 deltas (their byte length is known from the directory): both walked in step
+                DeltaStream<CODEC> sk;
+                sk.init(index, t, b, off + google_delta_bytes);
                 fs.init(index, t, b, off, sk);
         } else
                 fs.init(index, t, b, off, ds);
@@ -302,7 +301,27 @@ __device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index,
                 }
                 return fused_row_streams_lucene<HW>(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
         }
-        return fused_row_streams<CODEC, HW>(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
+        if (CODEC == CODEC_GOOGLE && n == 32) {
+                // a full block whose 31 deltas and 32 freqs are single bytes (every block of a head term): 63 bytes in four wide loads,
+                // then byte adds from registers — no varint stream, and no walk over the deltas to find where the freqs start
+                const uint8_t *p = index + rec_x;
+                const u32x4_a1 A = *(const u32x4_a1 *)p, B = *(const u32x4_a1 *)(p + 16), Cq = *(const u32x4_a1 *)(p + 32), Dq = *(const u32x4_a1 *)(p + 48);
+                const uint32_t w[16] = {A.x, A.y, A.z, A.w, B.x, B.y, B.z, B.w, Cq.x, Cq.y, Cq.z, Cq.w, Dq.x, Dq.y, Dq.z, Dq.w};
+                uint32_t any = w[15] & 0x00ffffffu; // (byte 63 is the block's first hit)
+#pragma unroll
+                for (int k = 0; k < 15; ++k)
+                        any |= w[k];
+                if (!(any & 0x80808080u)) {
+                        uint32_t rel = prev - w0, past = 0xffffffffu;
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) {
+                                rel = i < 31 ? rel + ((w[i >> 2] >> ((i & 3) * 8)) & 0xffu) : last - w0;
+                                fused_post<HW>(acc, rel, (w[(31 + i) >> 2] >> (((31 + i) & 3) * 8)) & 0xffu, cap, shift, past);
+                        }
+                        return past;
+                }
+        }
+        return fused_row_streams<CODEC, HW>(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap, rec_y);
 }
 
 // Keep the best k of the n (<= FUS_CAP) buffered candidates, best first (rank by counting: the order is strict).
@@ -612,7 +631,7 @@ __device__ __forceinline__ void fused_sweep(FusedShared &sh, const uint32_t w0, 
 template <int CODEC, int HW, int GEN>
 __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void k_fused(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                      const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
-                                                     const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
+                                                     const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                                                      const DevQuery *__restrict__ plan, const DevFused *__restrict__ fused,
                                                      const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched,
                                                      const uint32_t *__restrict__ sterms, const double *__restrict__ sweights, const uint32_t ntasks,
@@ -969,7 +988,9 @@ __global__ __launch_bounds__(FUS_WG, (FUS_WGS_PER_CU * FUS_WG + 255) / 256) void
                                                                         s * fbits, cap PROF_PASS);
                                         } else {
                                                 const uint32_t off = blk_off[t.first_block + b];
-                                                past = fused_row<CODEC, HW>(index, t, b, off, 0, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, sh.acc, s * fbits, cap PROF_PASS);
+                                                // (GOOGLE: the freqs start where the deltas end — their length comes from the delta stream's offset column)
+                                                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
+                                                past = fused_row<CODEC, HW>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, sh.acc, s * fbits, cap PROF_PASS);
                                         }
                                         if (past < 0x80000000u) { // the row reaches past the window (it is the slot's last row here): leave the hint
                                                 sh.hint_row[s] = b;

@@ -725,6 +725,7 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         if ((rc = dev_upload(&ix->d_blk_last, blk_last)) || (rc = dev_upload(&ix->d_blk_off, blk_off)) || (rc = dev_upload(&ix->d_terms, ix->terms)))
                 return rc;
         if (codec == TRI_CODEC_GOOGLE) {
+                blk_doff.push_back((uint32_t)dstream.size() + 1); // (sentinel: block b's delta bytes = blk_doff[b + 1] - blk_doff[b] - 1 for the last block too)
                 dstream.resize(dstream.size() + 256, 0); // over-read slack, like index[]
                 if ((rc = dev_upload(&ix->d_dstream, dstream)) || (rc = dev_upload(&ix->d_blk_doff, blk_doff)))
                         return rc;
@@ -1801,7 +1802,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         const uint32_t *fsched = b->d_sched + b->n_dense + b->n_cand + (variant >= 1 ? b->n_fused : 0) + (variant == 2 ? b->n_fused16 : 0);
                         const dim3 grid(std::min<uint32_t>(nf, (uint32_t)dev->cus * FUS_WGS_PER_CU));
 #define TRI_FUSED_ARGS                                                                                                                                 \
-        b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, fsched, \
+        b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, fsched, \
                 b->d_sterms, b->d_sweights, nf, b->d_ticket + 56 + 2 * variant, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores,                \
                 b->d_part_counts, b->ix->d_masked, b->similarity, b->d_out, b->d_all_scores, b->d_rich_allow
                         if (b->ix->codec == TRI_CODEC_LUCENE) {
