@@ -129,7 +129,7 @@ void *tri_dev_stream(tri_dev *);
  *                         0 = every query whose lists allow it)
  *   "dense_task_cost"     postings per bitmap-window task (default 196608)
  *   "fused"               1 (default): AccumulatedScore top-K batches run their dense queries through the one-pass kernel; 0: match, then score
- *   "fused_task_cost"     postings per one-pass task (default 1048576)
+ *   "fused_task_cost"     postings per one-pass task (default 0: sized from the batch — 256 K .. 8 M, about two tasks per resident workgroup)
  *   "fused_freq_cap"      0 (default): a window field saturates at the largest freq its width holds; else at this freq (documents above it are
  *                         rescored from the postings — same results, slower)
  *   "fused_halfwords"     1 (default): one-pass queries of <= 5 distinct terms keep 16 bits per document (windows twice as long); 0: 32

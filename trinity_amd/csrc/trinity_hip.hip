@@ -61,7 +61,7 @@ struct tri_options {
         uint64_t dense_min_postings = 512 * 1024; // TASK_DENSE needs at least this many postings over the query's lists (0: every multi-term query)
         uint64_t dense_task_cost = 192 * 1024;    // postings per bitmap-window task
         uint64_t fused = 1;                       // AccumulatedScore top-K of dense queries in one pass (k_fused); 0: k_and_dense + k_score
-        uint64_t fused_task_cost = 1024 * 1024;   // postings per fused task
+        uint64_t fused_task_cost = 0;             // postings per one-pass task; 0: sized from the batch (256 K .. 8 M, about two tasks per resident workgroup)
         uint64_t fused_freq_cap = 0;              // 0: the field width decides; else a smaller saturation point (exercises the rescoring path)
         uint64_t account_needed_bytes = 0;        // 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query)
         uint64_t fused_halfwords = 1;             // 16-bit window words for queries of <= 5 distinct terms (windows twice as long); 0: always 32-bit
@@ -1500,30 +1500,27 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         // planner thresholds: tri_dev_set_option (defaults: tri_options)
         const uint64_t DENSE_MIN_POSTINGS = dev->opt.dense_min_postings;
         const uint64_t DENSE_TASK_COST = std::max<uint64_t>(1, dev->opt.dense_task_cost); // bitmap-window tasks stage their terms once: two windows of a head pair per task
-        const uint64_t FUSED_TASK_COST = std::max<uint64_t>(1, dev->opt.fused_task_cost);
-        std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
-        for (auto &t : tmp) {
-                const uint32_t slot = (uint32_t)b->plan.size();
-                b->slot_of_query[t.q.qid] = slot;
+        // TASK_DENSE (bitmap windows) when the lead group is an OR (it has to be materialised as a set anyway), or when every other list is
+        // within a factor 32 of the lead (no block could be skipped) and there is enough work per docID window to keep 256 lanes busy;
+        // TASK_FUSED when such a query asks for a top-K (or is a general tree)
+        struct Class {
+                uint64_t sumdf, lead_docs;
+                uint32_t last_doc; // no match beyond the (required) group whose lists end first
+                bool dense, fuse;
+        };
+        auto classify = [&](const Tmp &t) {
                 const uint32_t *qt = &b->qterms[t.q.term_base];
-                const DevTerm &lead = ix->terms[qt[0] & QT_TERM];
-                const uint32_t nlead = t.nlead;
-                uint64_t lead_docs = 0;
-                for (uint32_t k = 0; k < nlead; ++k)
-                        lead_docs += ix->terms[qt[k] & QT_TERM].documents;
-                // TASK_DENSE (bitmap windows) when the lead group is an OR (it has to be materialised as a set anyway), or
-                // when every other list is within a factor 32 of the lead (no block could be skipped) and there is enough
-                // work per docID window to keep 256 lanes busy
-                uint64_t sumdf = 0;
-                bool dense = t.q.nterms >= 2;
-                uint32_t last_doc = 0xffffffffu, glast = 0; // no match beyond the (required) group whose lists end first
+                Class c{0, 0, 0xffffffffu, t.q.nterms >= 2, false};
+                for (uint32_t k = 0; k < t.nlead; ++k)
+                        c.lead_docs += ix->terms[qt[k] & QT_TERM].documents;
+                uint32_t glast = 0;
                 bool in_neg = false;
                 for (uint32_t k = 0; k < t.q.nterms; ++k) {
                         const DevTerm &tk = ix->terms[qt[k] & QT_TERM];
-                        sumdf += tk.documents;
-                        dense &= tk.nblocks <= lead_docs;
+                        c.sumdf += tk.documents;
+                        c.dense &= tk.nblocks <= c.lead_docs;
                         if (k && (qt[k] & QT_GROUP)) {
-                                last_doc = std::min(last_doc, glast);
+                                c.last_doc = std::min(c.last_doc, glast);
                                 glast = 0;
                                 in_neg = qt[k] & QT_NOT;
                         }
@@ -1531,10 +1528,36 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 glast = std::max(glast, ix->h_blk_last[tk.first_block + tk.nblocks - 1]);
                 }
                 if (!in_neg)
-                        last_doc = std::min(last_doc, glast);
-                dense &= sumdf >= DENSE_MIN_POSTINGS;
-                dense |= nlead > 1;
-                const bool fuse = t.truth || (dense && t.fusable && (dev->opt.fused != 2 || t.fz.nreq == 1)); // (fused == 2: only pure unions)
+                        c.last_doc = std::min(c.last_doc, glast);
+                c.dense &= c.sumdf >= DENSE_MIN_POSTINGS;
+                c.dense |= t.nlead > 1;
+                c.fuse = t.truth || (c.dense && t.fusable && (dev->opt.fused != 2 || t.fz.nreq == 1)); // (fused == 2: only pure unions)
+                return c;
+        };
+        // one-pass tasks stage the query (slot map, score tables) once per task: the longer the task the better, as long as the batch still
+        // cuts into a couple of tasks per workgroup the device holds (measured at cfg3: 512 K postings per task 55.4 ms, 1 M 51.1, 2 M 49.2,
+        // 4 M 48.0, 8 M and more 47.1).  fused_task_cost = 0 (the default): sized from the batch; otherwise as given
+        uint64_t FUSED_TASK_COST = dev->opt.fused_task_cost;
+        if (!FUSED_TASK_COST) {
+                uint64_t fused_postings = 0;
+                for (const auto &t : tmp)
+                        if (classify(t).fuse)
+                                for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx)
+                                        fused_postings += ix->terms[t.fz.term[sidx]].documents;
+                const uint64_t want_tasks = 2ull * (uint64_t)dev->cus * FUS_WGS_PER_CU;
+                FUSED_TASK_COST = std::min<uint64_t>(8u << 20, std::max<uint64_t>(256u << 10, fused_postings / want_tasks));
+        }
+        std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
+        for (auto &t : tmp) {
+                const uint32_t slot = (uint32_t)b->plan.size();
+                b->slot_of_query[t.q.qid] = slot;
+                const uint32_t *qt = &b->qterms[t.q.term_base];
+                const DevTerm &lead = ix->terms[qt[0] & QT_TERM];
+                const uint32_t nlead = t.nlead;
+                const Class cls = classify(t);
+                const uint64_t sumdf = cls.sumdf;
+                const uint32_t last_doc = cls.last_doc;
+                const bool dense = cls.dense, fuse = cls.fuse;
                 if (fuse) {
                         // every list of the slot map is read once (the optional terms too)
                         uint64_t slotdf = 0;
