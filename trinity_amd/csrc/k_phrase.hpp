@@ -117,11 +117,10 @@ struct HitStream<CODEC_LUCENE> {
 // Candidates are handled in tiles held in LDS: up to PHRASE_TILE of them, fewer when the phrase has many distinct terms
 // (one row of hit locators per distinct term: PHRASE_SLOTS entries in all).
 #ifndef TRI_PHRASE_TILE
-#define TRI_PHRASE_TILE 1024
+#define TRI_PHRASE_TILE 512 // (cfg4, ms: 1024 -> 25.8, 512 -> 23.0, 256 -> 31.0: more workgroups per CU against more tiles per task)
 #endif
 constexpr uint32_t PHRASE_TILE = TRI_PHRASE_TILE;
 constexpr uint32_t PHRASE_SLOTS = 4 * PHRASE_TILE;
-constexpr uint32_t PHRASE_WGS_PER_CU = TRI_PHRASE_TILE >= 1024 ? 3 : TRI_PHRASE_TILE >= 512 ? 6 : 7; // what the LDS (and at 256 the 65 registers) admit
 struct PhraseShared {
         uint32_t cdoc[PHRASE_TILE];     // the tile's candidates (ascending)
         uint32_t hits_off[PHRASE_SLOTS]; // [row * tile + j]: where candidate j's hits of the row's term start (GOOGLE: byte offset into
@@ -133,6 +132,7 @@ struct PhraseShared {
         uint32_t scan[8];
         uint32_t bcast[4];
 };
+constexpr uint32_t PHRASE_WGS_PER_CU = (160u * 1024u / sizeof(PhraseShared)) < 7u ? (160u * 1024u / sizeof(PhraseShared)) : 7u; // LDS; 65 registers: 7 waves per SIMD
 
 // Is position `q` among the `freq` hits starting at index[hits_off]?  (positions ascend within a document)
 template <int CODEC>
