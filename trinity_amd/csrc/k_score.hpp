@@ -12,7 +12,10 @@
 // wrapper (docset_iterators_scorers.cpp:173-193).  The tile is then offered to the task's top-K (score descending,
 // docID ascending: the application-side MatchedIndexDocumentsFilter heap, matches.h:155-171).  k_topk_merge folds
 // the tasks' partial lists into one list per query.
-constexpr uint32_t SCORE_TILE = 4096;
+#ifndef TRI_SCORE_TILE
+#define TRI_SCORE_TILE 4096 // (cfg1, ms: 4096 -> 0.86, 2048 -> 1.00, 1024 -> 1.45: every tile repeats the per-term searches)
+#endif
+constexpr uint32_t SCORE_TILE = TRI_SCORE_TILE;
 constexpr uint32_t TOPK_MAX = 256;
 constexpr uint32_t TOPK_CAP = TOPK_MAX + AND_WG; // survivors + one wave of newcomers
 
@@ -106,6 +109,8 @@ struct ScoreShared {
         TopK tk;
 };
 
+
+constexpr uint32_t SCORE_WGS_PER_CU = (160u * 1024u / sizeof(ScoreShared)) < 6u ? (160u * 1024u / sizeof(ScoreShared)) : 6u; // LDS; ~80-110 registers
 
 template <int CODEC>
 __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,

@@ -1878,7 +1878,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                         const uint32_t nlegacy = b->n_dense + b->n_cand; // the TASK_FUSED tasks have scored themselves
                         if (nlegacy)
-                        TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(nlegacy, (uint32_t)dev->cus * 2)), dim3(AND_WG), dev->stream, b->ix->d_index,
+                        TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(nlegacy, (uint32_t)dev->cus * SCORE_WGS_PER_CU)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, nlegacy,
                                            b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,
                                            b->d_all_scores, b->d_pscore, b->similarity);
