@@ -17,7 +17,8 @@
 extern "C" {
 #endif
 
-#define TRI_ABI_VERSION 3 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_* */
+#define TRI_ABI_VERSION 4 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
+                             4: tri_batch_info grew (term planes, k_planes) */
 
 /* status codes */
 #define TRI_OK 0
@@ -112,6 +113,15 @@ typedef struct tri_batch_info {
         float phrase_ms, pad_;
         uint64_t phrase_algorithmic_bytes;
         uint64_t phrase_queries;
+        /* term planes: the head terms the batch's queries share are decoded ONCE per launch (k_term_planes, first kernel of the run) into
+         * two bitmaps over the docID space each (A: holds the term; B: frequency != 1), which k_and probes, k_and_dense ORs into its windows
+         * and k_planes — AccumulatedScore top-K of CNF queries, predicates evaluated 32 documents per word — reads instead of decoding the
+         * list again for every query that names it.  plane_terms: how many; plane_bytes: their scratch; term_planes_decoded_bytes: the
+         * docbytes of those lists (read once per launch).  dense_ms no longer includes the launch's first memset: term_planes_ms does */
+        float term_planes_ms, planes_ms;
+        uint64_t planes_algorithmic_bytes; /* SURVEY §8(d) bytes of the queries k_planes runs (per query, as if every list were read) */
+        uint64_t planes_queries;
+        uint64_t plane_terms, plane_bytes, term_planes_decoded_bytes;
 } tri_batch_info;
 
 const char *tri_last_error(void);
@@ -134,7 +144,13 @@ void *tri_dev_stream(tri_dev *);
  *                         rescored from the postings — same results, slower)
  *   "fused_halfwords"     1 (default): one-pass queries of <= 5 distinct terms keep 16 bits per document (windows twice as long); 0: 32
  *   "overlap_dense_wgs" / "overlap_cand_wgs"  both non-zero: the two matching kernels run side by side with that many workgroups per CU
- * Unknown names fail with TRI_ERR_INVALID. */
+ *   "planes"              term planes, a bit set (default 7): 1 the candidate-tile kernel probes them, 2 the bitmap-window kernel ORs them into its
+ *                         windows, 4 AccumulatedScore top-K CNF queries run over bit planes (k_planes); 0: every query decodes every list it names
+ *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 64) and the batch's uses repay one
+ *                         decode of its list
+ *   "account_needed_bytes" 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query; default 0)
+ * ("fused" also takes 2: only pure unions run in one pass.)  The options are read when a batch is CREATED, except the two overlap_* ones,
+ * which tri_batch_run reads (they change how existing batches are launched).  Unknown names fail with TRI_ERR_INVALID. */
 int tri_dev_set_option(tri_dev *, const char *name, uint64_t value);
 int tri_dev_get_option(tri_dev *, const char *name, uint64_t *value);
 
@@ -256,12 +272,14 @@ int tri_gather_results(tri_batch *, tri_comm *, void *counts_all, void *docids_a
 /* ---- write side ----------------------------------------------------------------------
  * Codecs::Google::Encoder (google_codec.cpp:9-176: begin_term / begin_document / new_hit / end_document / end_term, commit_block
  * :118-176) on the device: the postings of `nterms` terms, term after term — docs[] ascending and > 0 within a term, freqs[] the counted
- * hits of each posting, positions[] those hits' positions in posting order (payload-less hits; a position-0 hit without payload is not
- * a hit, google_codec.cpp:42-45), term_first[t] = postings before term t ([nterms + 1]) — are encoded into the `index` bytes the
- * reference's encoder writes for them, byte for byte (skiplist cadence across terms included), and the term table
- * (term_index_ctx: documents, chunk offset, chunk size).  index_out == NULL: sizing call (*index_len and terms_out are filled). */
-int tri_encode_google(tri_dev *, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint64_t *term_first, size_t nterms,
-                      uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out);
+ * hits of each posting, positions[npositions] those hits' positions in posting order (payload-less hits; > 0 — a position-0 hit without
+ * payload is not a hit, google_codec.cpp:42-45 — and non-descending within a document, :49; sum(freqs) <= npositions), term_first[t] =
+ * postings before term t ([nterms + 1]) — are encoded into the `index` bytes the reference's encoder writes for them, byte for byte
+ * (skiplist cadence across terms included), and the term table (term_index_ctx: documents, chunk offset, chunk size).  Input that the
+ * reference's encoder would not take (unsorted or zero positions, freqs[] reaching past positions[]) is refused with TRI_ERR_INVALID.
+ * index_out == NULL: sizing call (*index_len and terms_out are filled). */
+int tri_encode_google(tri_dev *, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first,
+                      size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out);
 
 #ifdef __cplusplus
 }

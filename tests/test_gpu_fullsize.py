@@ -23,7 +23,9 @@ def T():
 
 @pytest.fixture(scope="module")
 def dev(T):
-    d = T.Device(0)
+    from conftest import apply_test_options
+
+    d = apply_test_options(T.Device(0))
     yield d
     d.close()
 
@@ -70,7 +72,7 @@ def check_scored(T, ix, ora, progs, k, want_fused=True):
     counts, (d, s, c), info = b.counts(), b.topk_results(), b.info()
     b.close()
     if want_fused:
-        assert info["fused_queries"] > 0, info
+        assert info["fused_queries"] + info["planes_queries"] > 0, info
     for i, p in enumerate(progs):
         docs, scores = ora.exec(p, O.FLAG_ACCUM_SCORE)
         assert int(counts[i]) == len(docs), (i, p.tolist(), int(counts[i]), len(docs))

@@ -24,7 +24,9 @@ def T():
 
 @pytest.fixture(scope="module")
 def dev(T):
-    d = T.Device(0)
+    from conftest import apply_test_options
+
+    d = apply_test_options(T.Device(0))
     yield d
     d.close()
 
@@ -40,6 +42,12 @@ def options(dev, **kw):
     finally:
         for k, v in old.items():
             dev.set_option(k, v)
+
+
+ALL_PLANES = 1 << 30  # plane_div: every term of a batch gets a plane
+# term planes (k_planes.hpp): the planner's choice (head terms of at least docs / 64 documents), a plane for every term, no term
+# planes at all (k_planes decodes every slot into LDS planes; queries of more than six slots stay with k_fused), everything off
+PLANE_SETS = ({}, {"plane_div": ALL_PLANES}, {"plane_div": 0}, {"planes": 0})
 
 
 class World:
@@ -162,11 +170,34 @@ def test_and_forced_dense_path_matches_oracle(request, world, nq):
     w = request.getfixturevalue(world)
     T = w.T
     qs = T.gen_queries(w.V, 7, nq, 2).tolist() + T.gen_queries(w.V, 8, 60, 3).tolist() + [[0, 1], [0, 1, 2, 3], [w.V - 1, 0]]
-    with options(w.dev, dense_min_postings=0):
-        sets, _, _ = run_docs_only(w, [and_prog(T, q) for q in qs])
-    for q, got in zip(qs, sets):
-        want, _ = w.ora.exec(and_prog(T, q), O.FLAG_DOCUMENTS_ONLY)
-        assert np.array_equal(got, want), (q, len(got), len(want))
+    wants = [w.ora.exec(and_prog(T, q), O.FLAG_DOCUMENTS_ONLY)[0] for q in qs]
+    for ps in PLANE_SETS:  # the bitmap windows with the planner's term planes, with a plane for every term, without any
+        with options(w.dev, dense_min_postings=0, **ps):
+            sets, _, info = run_docs_only(w, [and_prog(T, q) for q in qs])
+        assert (info["plane_terms"] > 0) == (ps.get("planes", 7) != 0 and ps.get("plane_div", 64) != 0), ps
+        for q, got, want in zip(qs, sets, wants):
+            assert np.array_equal(got, want), (ps, q, len(got), len(want))
+
+
+@pytest.mark.parametrize("world", ["small", "dense", "small_l"])
+def test_candidate_tiles_probe_term_planes(request, world):
+    """k_and with the probed lists read from term planes (one bit per candidate) instead of bracket + block decode: 2- and 3-term
+    conjunctions, a NOT, an OR group behind a sparse lead — with a plane for every term and with the planner's choice; equal to the
+    oracle and to the run without planes."""
+    w = request.getfixturevalue(world)
+    T = w.T
+    texts = [f"t{a} t{b}" for a, b in T.gen_queries(w.V, 21, 200, 2).tolist()] + [f"t{a} t{b} t{c}" for a, b, c in T.gen_queries(w.V, 22, 80, 3).tolist()]
+    texts += [f"t{a} t{b} NOT t{c}" for a, b, c in T.gen_queries(w.V, 23, 40, 3).tolist()] + [f"t{a} (t{b} OR t{c} OR t0)" for a, b, c in T.gen_queries(w.V, 24, 40, 3).tolist()]
+    progs = [O.parse_query(t) for t in texts]
+    wants = [w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)[0] for p in progs]
+    for ps in ({"planes": 1, "plane_div": ALL_PLANES}, {"planes": 1}, {"planes": 0}):
+        with options(w.dev, **ps):
+            sets, hashes, info = run_docs_only(w, progs)
+        if ps.get("plane_div"):
+            assert info["plane_terms"] > 0
+        for t, got, want, h in zip(texts, sets, wants, hashes):
+            assert np.array_equal(got, want), (ps, t, len(got), len(want))
+            assert int(h) == O.fnv1a_docs(want)
 
 
 @pytest.mark.parametrize("k", [3, 5])
@@ -369,9 +400,13 @@ def test_fused_scored_windows_match_oracle(request, world, n, k):
     w = request.getfixturevalue(world)
     texts = fused_queries(w, 41, n)
     progs = [O.parse_query(t) for t in texts]
-    for opts in ({"dense_min_postings": 0}, {"dense_min_postings": 0, "fused_freq_cap": 1}, {"dense_min_postings": 0, "fused_freq_cap": 3},
-                 {"dense_min_postings": 0, "fused_task_cost": 4096}, {"dense_min_postings": 0, "fused_halfwords": 0},
-                 {"dense_min_postings": 0, "fused_halfwords": 0, "fused_freq_cap": 2}, {"dense_min_postings": 0, "fused": 0}):
+    # k_planes (bit planes): the planner's term planes, a plane for every term, none (every slot decoded per window), small tasks;
+    # then k_fused (window words, planes off) in its variants; then match-then-score
+    for opts in ({"dense_min_postings": 0}, {"dense_min_postings": 0, "plane_div": ALL_PLANES}, {"dense_min_postings": 0, "plane_div": 0},
+                 {"dense_min_postings": 0, "fused_task_cost": 4096}, {"dense_min_postings": 0, "fused_task_cost": 4096, "plane_div": 0},
+                 {"dense_min_postings": 0, "planes": 0}, {"dense_min_postings": 0, "planes": 0, "fused_freq_cap": 1}, {"dense_min_postings": 0, "planes": 0, "fused_freq_cap": 3},
+                 {"dense_min_postings": 0, "planes": 0, "fused_task_cost": 4096}, {"dense_min_postings": 0, "planes": 0, "fused_halfwords": 0},
+                 {"dense_min_postings": 0, "planes": 0, "fused_halfwords": 0, "fused_freq_cap": 2}, {"dense_min_postings": 0, "fused": 0}):
         with options(w.dev, **opts):
             check_scored(w, texts, progs, k, tag=opts)
 
@@ -384,7 +419,8 @@ def test_fused_other_similarities(request, world, sim):
     progs = [O.parse_query(t) for t in texts]
     w.ora.set_similarity(SIMS[sim])
     try:
-        for opts in ({"dense_min_postings": 0}, {"dense_min_postings": 0, "fused_freq_cap": 2}):
+        for opts in ({"dense_min_postings": 0}, {"dense_min_postings": 0, "plane_div": ALL_PLANES}, {"dense_min_postings": 0, "plane_div": 0},
+                     {"dense_min_postings": 0, "planes": 0}, {"dense_min_postings": 0, "planes": 0, "fused_freq_cap": 2}):
             with options(w.dev, **opts):
                 check_scored(w, texts, progs, 50, similarity=SIMS[sim], tag=(sim, opts))
     finally:
@@ -397,7 +433,7 @@ def test_fused_large_unions_and_cnf(large):
     texts = ["t0 OR t1", "t0 OR t1 OR t2 OR t3 OR t4", "t0 t1 (t2 OR t3 OR t4)", "(t0 OR t1) (t2 OR t3) t4", "t0 t1", "t0 t1 t2 t3 t4", "t100000 OR t150000 OR t199999",
              "t0 OR t199999", "t3 t5 NOT t1", "t2 <t7 OR t9>"]
     progs = [O.parse_query(t) for t in texts]
-    for opts in ({}, {"fused_task_cost": 200000}):
+    for opts in ({}, {"fused_task_cost": 200000}, {"plane_div": 0}, {"plane_div": 0, "fused_task_cost": 200000}, {"planes": 0}, {"planes": 0, "fused_task_cost": 200000}):
         with options(w.dev, **opts):
             check_scored(w, texts, progs, 100, tag=opts)
 
@@ -410,7 +446,7 @@ def test_fused_batches_do_not_materialise_docsets(small):
         b = T.Batch(w.ix, [O.parse_query("t0 OR t1")], T.FLAG_ACCUMULATED_SCORE, topk=10)
     b.run()
     b.sync()
-    assert int(b.counts()[0]) > 0 and b.info()["fused_queries"] == 1
+    assert int(b.counts()[0]) > 0 and b.info()["fused_queries"] + b.info()["planes_queries"] == 1
     with pytest.raises(T.TrinityError):
         b.docset(0)
     with pytest.raises(T.TrinityError):

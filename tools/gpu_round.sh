@@ -20,7 +20,12 @@ for stage in "$@"; do
       tail -15 "$out/test_$(echo "$sel" | tr ' ' '_').log"; log "tests[$sel] rc=$rc"; [ $rc -ne 0 ] && exit 1 ;;
     tests)
       timeout -k 10 2400 python -m pytest tests -m gpu -x -q --timeout 900 --durations=15 > "$out/tests_all.log" 2>&1; rc=$?
-      tail -25 "$out/tests_all.log"; log "tests rc=$rc" ;;
+      tail -25 "$out/tests_all.log"; log "tests rc=$rc"; [ $rc -ne 0 ] && exit 1 ;;
+    testopt:*)
+      # testopt:<name>:<TRINITY_TEST_OPTIONS with ; for ,>:<-k expr> — the GPU suite (or a selection) under planner options that force one path
+      name="$(echo "$stage" | cut -d: -f2)"; topts="$(echo "$stage" | cut -d: -f3 | tr ';' ',')"; sel="$(echo "$stage" | cut -d: -f4-)"
+      TRINITY_TEST_OPTIONS="$topts" timeout -k 10 1500 python -m pytest tests -m gpu -x -q ${sel:+-k "$sel"} --timeout 900 > "$out/testopt_$name.log" 2>&1; rc=$?
+      tail -12 "$out/testopt_$name.log"; log "testopt[$name: $topts] rc=$rc"; [ $rc -ne 0 ] && exit 1 ;;
     bench:*)
       # bench:<name>:<args with , for spaces>
       name="$(echo "$stage" | cut -d: -f2)"; args="$(echo "$stage" | cut -d: -f3- | tr ',' ' ')"

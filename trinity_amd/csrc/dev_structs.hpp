@@ -71,6 +71,15 @@ constexpr uint32_t TASK_FUSED = 2; // AccumulatedScoreScheme + top-K of a dense 
 constexpr uint32_t TASK_FUSED16 = 3; // ... with 16-bit window words (<= 5 distinct terms): windows of 2 * FUS_W documents
 
 constexpr uint32_t TASK_FUSED_GEN = 4; // ... a general tree (truth-table predicate; DocumentsOnly: matches written to out[]): 32-bit window words
+constexpr uint32_t TASK_PLANES = 5;    // AccumulatedScoreScheme + top-K of a CNF query over BIT PLANES (k_planes.hpp): per slot a presence bit and an
+                                       // "frequency is not 1" bit per document; windows of PL_W documents; tile_begin / tile_end count those windows
+
+// ---- term planes: per batch LAUNCH, every head term the batch's queries share is decoded ONCE (k_term_planes) into two bitmaps over the
+//      docID space — A: the document holds the term, B: its frequency there is not 1 — which the matching kernels then read instead of
+//      decoding the term's list again for every query that names it (under Zipf a handful of terms carry most of a batch's postings)
+constexpr uint32_t PL_W = 32768;          // documents per plane window (k_term_planes, k_planes)
+constexpr uint32_t PL_WORDS = PL_W / 32;  // words of one plane per window
+constexpr uint32_t PL_NONE = 0xffffffffu; // "this term has no plane in this batch"
 constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64)
 constexpr uint32_t FUS_MAX_SLOTS = 8;
 constexpr uint32_t FUS_MAX_LEAVES = 16; // scorer leaves of a general tree
@@ -93,6 +102,10 @@ struct DevFused {
         uint32_t tt[8];                         // bit p: a document that holds exactly the slots of pattern p matches
         uint8_t leaf_slot[FUS_MAX_LEAVES];      // scorer leaf -> slot of its term
         uint32_t ctt[FUS_MAX_LEAVES][8];        // per scorer leaf: the patterns in which it adds its score
+        // ---- TASK_PLANES (k_planes.hpp): the slot's row in the batch's term planes (PL_NONE: its list is decoded per window), the slots of
+        //      the excluded group as a bit set
+        uint32_t plane[FUS_MAX_SLOTS];
+        uint32_t negslots;
 };
 constexpr uint32_t FUS_MODE_TT = 1;   // predicate = tt, scores through ctt
 constexpr uint32_t FUS_MODE_EMIT = 2; // DocumentsOnly: the window's matches are written to out[] (ascending), nothing is scored

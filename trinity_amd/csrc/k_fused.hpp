@@ -236,15 +236,34 @@ __device__ __forceinline__ void fused_post(uint32_t *acc, const uint32_t rel, co
                 atomicOr(&acc[r], code << shift);
 }
 
-// One directory row (<= 32 documents) of a slot's term into the window words through the codec's general value streams: GOOGLE
-// rows, and the PFOR quarters the register reader (PfRegs) does not take.
-template <int CODEC, int HW>
-__device__ __forceinline__ uint32_t fused_row_streams(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
-                                                      const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift,
-                                                      const uint32_t cap, const uint32_t google_delta_bytes = 0) {
-        uint32_t rel = prev - w0, past = 0xffffffffu;
+// What a decoded posting is handed to.  The window-word kernels (k_fused) use FusedPost: one ds_or of the slot's freq code into the
+// document's word; the bit-plane kernels (k_planes.hpp) bring their own.  post(rel, f): a document at window-relative position rel
+// (documents below the window wrap to huge values) with frequency f; post.doc(rel): the same without a frequency (rows decoded for
+// presence only — NEEDF = false).
+template <int HW>
+struct FusedPost {
+        uint32_t *acc;
+        uint32_t shift, cap;
+        uint32_t past = 0xffffffffu; // the row's first document past the window, as rel - W (>= 2^31: none)
+        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) { fused_post<HW>(acc, rel, f, cap, shift, past); }
+        __device__ __forceinline__ void doc(const uint32_t rel) { fused_post<HW>(acc, rel, cap + 1u, cap, shift, past); }
+};
+
+// One directory row (<= 32 documents) of a slot's term through the codec's general value streams: GOOGLE rows that miss the
+// 63-byte path, and the PFOR quarters the register reader (PfRegs) does not take.
+template <int CODEC, bool NEEDF, class POST>
+__device__ __forceinline__ void row_streams(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
+                                            const uint32_t prev, const uint32_t last, const uint32_t w0, POST &post, const uint32_t google_delta_bytes = 0) {
+        uint32_t rel = prev - w0;
         DeltaStream<CODEC> ds;
         ds.init(index, t, b, off);
+        if (!NEEDF) {
+                for (uint32_t i = 0; i < n; ++i) {
+                        rel = (i + 1 < n) ? rel + ds.next() : last - w0;
+                        post.doc(rel);
+                }
+                return;
+        }
         FreqStream<CODEC> fs;
         if (CODEC == CODEC_GOOGLE) { // the freqs follow the n - 1 deltas (their byte length is known from the directory): both walked in step
                 DeltaStream<CODEC> sk;
@@ -254,52 +273,58 @@ __device__ __forceinline__ uint32_t fused_row_streams(const uint8_t *__restrict_
                 fs.init(index, t, b, off, ds);
         for (uint32_t i = 0; i < n; ++i) {
                 rel = (i + 1 < n) ? rel + ds.next() : last - w0;
-                fused_post<HW>(acc, rel, fs.next(), cap, shift, past);
+                post(rel, fs.next());
         }
-        return past;
 }
 // (LUCENE: out of line — the general streams' state must not weigh on the registers of the PFOR fast path; only quarters with
 // more than 16 exceptions come here.)
-template <int HW>
-__device__ __noinline__ uint32_t fused_row_streams_lucene(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off,
-                                                          const uint32_t n, const uint32_t prev, const uint32_t last, const uint32_t w0, uint32_t *acc,
-                                                          const uint32_t shift, const uint32_t cap) {
-        return fused_row_streams<CODEC_LUCENE, HW>(index, t, b, off, n, prev, last, w0, acc, shift, cap);
+template <bool NEEDF, class POST>
+__device__ __noinline__ void row_streams_lucene(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t off, const uint32_t n,
+                                                const uint32_t prev, const uint32_t last, const uint32_t w0, POST &post) {
+        row_streams<CODEC_LUCENE, NEEDF, POST>(index, t, b, off, n, prev, last, w0, post);
 }
 
-// Returns the row's first document past the window as rel - W (>= 2^31: none).
-// LUCENE: rec = the row record {group offset, exception index, deltas header, freqs header}; GOOGLE: rec_x = payload offset.
-template <int CODEC, int HW>
-__device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t rec_x,
-                                              const uint32_t rec_y, const uint32_t rec_z, const uint32_t rec_w, const uint32_t n, const uint32_t prev,
-                                              const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift, const uint32_t cap PROF_ARG) {
+// One directory row into `post`.  LUCENE: rec = the row record {group offset, exception index, deltas header, freqs header};
+// GOOGLE: rec_x = payload offset, rec_y = byte length of the block's deltas.
+template <int CODEC, bool NEEDF, class POST>
+__device__ __forceinline__ void row_decode(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t rec_x, const uint32_t rec_y,
+                                           const uint32_t rec_z, const uint32_t rec_w, const uint32_t n, const uint32_t prev, const uint32_t last,
+                                           const uint32_t w0, POST &post PROF_ARG) {
         if (CODEC == CODEC_LUCENE) {
-                uint32_t rel = prev - w0, past = 0xffffffffu;
+                uint32_t rel = prev - w0;
                 if (b >= t.npfor) { // the list's varbyte tail (lucene_codec.cpp:321-337): (delta, freq) pairs, fewer than 128 documents
                         VbStream vb;
                         vb.init(index + rec_x);
                         for (uint32_t i = 0; i < n; ++i) {
                                 rel += vb.next();
-                                fused_post<HW>(acc, rel, vb.next(), cap, shift, past);
+                                const uint32_t f = vb.next();
+                                if (NEEDF)
+                                        post(rel, f);
+                                else
+                                        post.doc(rel);
                         }
-                        return past;
+                        return;
                 }
                 const uint8_t *g = index + rec_x;
                 PfRegs<8> rd;
                 PfRegs<4> rf;
                 const bool okd = rd.init(g, rec_z, b & 3u, rec_y & 0xffu, (rec_y >> 8) & 0xffu);
-                const bool okf = rf.init(g + pfor_group_bytes(rec_z), rec_w, b & 3u, (rec_y >> 16) & 0xffu, rec_y >> 24);
+                const bool okf = !NEEDF || rf.init(g + pfor_group_bytes(rec_z), rec_w, b & 3u, (rec_y >> 16) & 0xffu, rec_y >> 24);
                 PROF_LAP(9);
                 if (okd && okf) {
 #pragma unroll TRI_FUS_UNROLL
                         for (uint32_t i = 0; i < 32; ++i) {
                                 rel += rd.next(i);
-                                fused_post<HW>(acc, rel, rf.next(i), cap, shift, past);
+                                if (NEEDF)
+                                        post(rel, rf.next(i));
+                                else
+                                        post.doc(rel);
                         }
                         PROF_LAP(10);
-                        return past;
+                        return;
                 }
-                return fused_row_streams_lucene<HW>(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap);
+                row_streams_lucene<NEEDF, POST>(index, t, b, rec_x, n, prev, last, w0, post);
+                return;
         }
         if (CODEC == CODEC_GOOGLE && n == 32) {
                 // a full block whose 31 deltas and 32 freqs are single bytes (every block of a head term): 63 bytes in four wide loads,
@@ -312,16 +337,29 @@ __device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index,
                 for (int k = 0; k < 15; ++k)
                         any |= w[k];
                 if (!(any & 0x80808080u)) {
-                        uint32_t rel = prev - w0, past = 0xffffffffu;
+                        uint32_t rel = prev - w0;
 #pragma unroll
                         for (int i = 0; i < 32; ++i) {
                                 rel = i < 31 ? rel + ((w[i >> 2] >> ((i & 3) * 8)) & 0xffu) : last - w0;
-                                fused_post<HW>(acc, rel, (w[(31 + i) >> 2] >> (((31 + i) & 3) * 8)) & 0xffu, cap, shift, past);
+                                if (NEEDF)
+                                        post(rel, (w[(31 + i) >> 2] >> (((31 + i) & 3) * 8)) & 0xffu);
+                                else
+                                        post.doc(rel);
                         }
-                        return past;
+                        return;
                 }
         }
-        return fused_row_streams<CODEC, HW>(index, t, b, rec_x, n, prev, last, w0, acc, shift, cap, rec_y);
+        row_streams<CODEC, NEEDF, POST>(index, t, b, rec_x, n, prev, last, w0, post, rec_y);
+}
+
+// k_fused's form: the row into the window words; returns the row's first document past the window as rel - W (>= 2^31: none).
+template <int CODEC, int HW>
+__device__ __forceinline__ uint32_t fused_row(const uint8_t *__restrict__ index, const DevTerm &t, const uint32_t b, const uint32_t rec_x,
+                                              const uint32_t rec_y, const uint32_t rec_z, const uint32_t rec_w, const uint32_t n, const uint32_t prev,
+                                              const uint32_t last, const uint32_t w0, uint32_t *acc, const uint32_t shift, const uint32_t cap PROF_ARG) {
+        FusedPost<HW> post{acc, shift, cap};
+        row_decode<CODEC, true, FusedPost<HW>>(index, t, b, rec_x, rec_y, rec_z, rec_w, n, prev, last, w0, post PROF_PASS);
+        return post.past;
 }
 
 // Keep the best k of the n (<= FUS_CAP) buffered candidates, best first (rank by counting: the order is strict).

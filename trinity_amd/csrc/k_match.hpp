@@ -79,6 +79,7 @@ struct DenseShared {
         uint32_t seg_tt[MAX_QTERMS];      // ... and their qterms[] words (term id | QT_GROUP)
         uint32_t seg_wlo[MAX_QTERMS];     // win[w], win[w + 1] of every indexed term for the current window
         uint32_t seg_whi[MAX_QTERMS];
+        uint32_t seg_plane[MAX_QTERMS];   // the term's row in the batch's term planes (PL_NONE: its rows are decoded)
         uint32_t nslow;
 };
 constexpr uint32_t DENSE_SLOW_CAP = DENSE_WG / 4; // 16-byte entries in tbase[]
@@ -544,11 +545,26 @@ __device__ __forceinline__ void dense_block_coop(const uint8_t *__restrict__ ind
 template <int WG, int CODEC>
 __device__ __forceinline__ void dense_pass(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                            const uint32_t *__restrict__ blk_off, const uint32_t kbeg, const uint32_t kend, const uint32_t ksplit,
-                                           const uint32_t w0 PROF_ARG) {
+                                           const uint32_t w0, const uint32_t *__restrict__ planes, const uint32_t plw PROF_ARG) {
         const uint32_t tid = threadIdx.x;
         uint32_t total = 0;
-        for (uint32_t k = kbeg; k < kend; ++k)
+        for (uint32_t k = kbeg; k < kend; ++k) {
                 total += uni(sh.seg_cnt[k]);
+                // a term with a plane (decoded once per launch by k_term_planes): its documents of this window are SPAN_WORDS words
+                // of plane A, OR-ed into the group's bitmap — 8 coalesced loads per thread instead of a walk over the term's rows
+                const uint32_t prow = uni(sh.seg_plane[k]);
+                if (prow != PL_NONE) {
+                        const uint32_t *pa = planes + (size_t)prow * 2 * plw + (w0 >> 5);
+                        const uint32_t wbase = k < ksplit ? 0u : BM_B_WORDS;
+#pragma unroll
+                        for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
+                                const uint32_t i = j * WG + tid;
+                                const uint32_t v = pa[i];
+                                if (v)
+                                        atomicOr(&sh.bm[bm_pad(i + wbase)], v);
+                        }
+                }
+        }
         for (uint32_t v0 = 0; v0 < total; v0 += WG) {
                 const uint32_t v = v0 + tid;
                 if (v < total) {
@@ -625,7 +641,8 @@ template <int WG, int CODEC>
 __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                            const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                            const uint32_t *__restrict__ qterms, const DevQuery q, const DevTask task, uint32_t *__restrict__ out,
-                           uint32_t *__restrict__ count_out, const uint32_t *__restrict__ masked PROF_ARG) {
+                           uint32_t *__restrict__ count_out, const uint32_t *__restrict__ masked, const uint32_t *__restrict__ qplane,
+                           const uint32_t *__restrict__ planes, const uint32_t plw PROF_ARG) {
         const uint32_t tid = threadIdx.x;
         uint32_t *qout = out + task.out_off;
         uint32_t produced = 0;
@@ -640,6 +657,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                 const uint32_t tt = qterms[q.term_base + kk];
                 sh.seg_tt[kk] = tt;
                 sh.seg_term[kk] = terms[tt & QT_TERM];
+                sh.seg_plane[kk] = qplane ? qplane[q.term_base + kk] : PL_NONE;
         }
         __syncthreads();
         // number of terms in the lead group (it creates the candidates; the other groups test them)
@@ -666,7 +684,10 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                                 const uint32_t *bl = blk_last + t.first_block;
                                 uint32_t cur;
                                 bool here = false; // the list surely holds a document of window w
-                                if (uni(t.win_off) != 0xffffffffu) {
+                                if (uni(sh.seg_plane[k]) != PL_NONE) { // (a plane term is a head term: treated as present in every window)
+                                        cur = 0;
+                                        here = true;
+                                } else if (uni(t.win_off) != 0xffffffffu) {
                                         cur = uni(sh.seg_wlo[k]);
                                         here = cur != uni(sh.seg_whi[k]); // a block ends inside the window
                                 } else {
@@ -717,6 +738,13 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                         }
                         // blocks that can hold documents of [w0, wlast]: first block with last >= w0 ... first with last >= wlast
                         uint32_t b_lo, b_hi;
+                        if (uni(sh.seg_plane[k]) != PL_NONE) { // no rows to walk: dense_pass reads the plane (seg_cnt 0 below); the planner bounds
+                                                               // the task's windows by the lists' last documents, so "alive" costs nothing
+                                galive = true;
+                                sh.seg_lo[k] = 0;
+                                sh.seg_cnt[k] = 0;
+                                continue;
+                        }
                         if (uni(t.win_off) != 0xffffffffu) {
                                 // indexed list: the two staged entries replace both directory searches (win[w + 1] is the first
                                 // block with last >= the next window's first docID; it may still hold documents of this window)
@@ -752,7 +780,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                 PROF_LAP(1);
                 __syncthreads(); // (bitmaps: zeroed at task start, re-zeroed by every expansion sweep)
                 PROF_LAP(2);
-                dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, 0, g2, g1, w0 PROF_PASS); // groups 0 and 1 together
+                dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, 0, g2, g1, w0, planes, plw PROF_PASS); // groups 0 and 1 together
                 for (uint32_t kb = g2; kb < q.nterms;) {
                         uint32_t ke = kb + 1;
                         while (ke < q.nterms && !(qterms[q.term_base + ke] & QT_GROUP))
@@ -762,7 +790,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                                 sh.bm[BM_STRIDE + i] = 0;
                         }
                         __syncthreads();
-                        dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, kb, ke, kb, w0 PROF_PASS);
+                        dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, kb, ke, kb, w0, planes, plw PROF_PASS);
                         kb = ke;
                 }
                 // ---- expand the survivors bitmap into ascending docIDs
@@ -847,7 +875,8 @@ __global__ __launch_bounds__(DENSE_WG, 8) void k_and_dense(const uint8_t *__rest
                                                         const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched,
                                                         const uint32_t *__restrict__ qterms, const uint32_t ntasks, uint32_t *__restrict__ ticket,
                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ counts,
-                                                        const uint32_t *__restrict__ masked) {
+                                                        const uint32_t *__restrict__ masked, const uint32_t *__restrict__ qplane,
+                                                        const uint32_t *__restrict__ planes, const uint32_t plw) {
         __shared__ DenseShared sh;
         const uint32_t wave = uni(threadIdx.x >> 6);
         PROF_DECL;
@@ -866,7 +895,7 @@ __global__ __launch_bounds__(DENSE_WG, 8) void k_and_dense(const uint8_t *__rest
                 const DevTask task = tasks[tix];
                 const DevQuery q = plan[task.slot];
                 PROF_LAP(0);
-                dense_task<DENSE_WG, CODEC>(sh, index, blk_last, blk_off, win, terms, qterms, q, task, out, counts + tix, masked PROF_PASS);
+                dense_task<DENSE_WG, CODEC>(sh, index, blk_last, blk_off, win, terms, qterms, q, task, out, counts + tix, masked, qplane, planes, plw PROF_PASS);
         }
         PROF_LAP(9);
         PROF_FLUSH();
@@ -884,7 +913,8 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                                 const uint32_t *__restrict__ sched, const uint32_t *__restrict__ qterms,
                                                 const uint32_t ntasks, uint32_t *__restrict__ ticket,
                                                 uint32_t *__restrict__ out, uint32_t *__restrict__ counts,
-                                                const uint32_t *__restrict__ masked) {
+                                                const uint32_t *__restrict__ masked, const uint32_t *__restrict__ qplane,
+                                                const uint32_t *__restrict__ planes, const uint32_t plw) {
         __shared__ AndShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
@@ -957,6 +987,16 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                 const bool bd = t.nblocks <= lead.documents;
 #endif
                                 TRACE(3, slot, (k << 16) | (bd ? 1 : 0));
+                                const uint32_t prow = qplane ? qplane[q.term_base + k] : PL_NONE;
+                                if (prow != PL_NONE) {
+                                        // the term has a plane (k_term_planes decoded it once for the whole batch): advance(candidate) is a bit probe
+                                        const uint32_t *pa = planes + (size_t)prow * 2 * plw;
+                                        for (uint32_t j = tid; j < C; j += AND_WG) {
+                                                const uint32_t doc = sh.cand[phys(j)];
+                                                if ((pa[doc >> 5] >> (doc & 31u)) & 1u)
+                                                        atomicOr(&sh.hit[j >> 5], 1u << (j & 31u));
+                                        }
+                                } else
                                 and_filter_tile<CODEC>(sh, index, blk_last, blk_off, win, t, C, k - 1, bd PROF_PASS);
                                 TRACE(4, slot, C);
                                 __syncthreads();

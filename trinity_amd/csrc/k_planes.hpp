@@ -1,0 +1,651 @@
+// k_planes.hpp — term planes (a head term decoded once per launch for every query of the batch that names it) and the
+// AccumulatedScoreScheme top-K kernel that runs over them
+// Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
+#pragma once
+#include "k_fused.hpp"
+
+// Under Zipf a handful of terms carry most of a batch's postings (at the 10M-document configuration the 40 most frequent terms
+// hold 98 % of the postings the 5-term queries of SURVEY §8(d) cfg3 touch), and the reference decodes such a list again for every
+// query that names it (Decoder::init + next() per query, google_codec.cpp:777-819 / lucene_codec.cpp:568-594).  Here every LAUNCH
+// decodes each of those lists ONCE — k_term_planes, inside the timed region, from the segment's own codec bytes — into two
+// bitmaps over the docID space:
+//     plane A   bit d set  <=>  document d holds the term            (PostingsListIterator::current() would stop on d)
+//     plane B   bit d set  <=>  ... and its frequency there is not 1 (the exact frequency is then read from the postings on demand)
+// and the matching kernels read the planes: k_and tests a candidate with one bit probe instead of bracketing and decoding a block
+// (Conjuction::next_impl's advance(), docset_iterators.cpp:308-348), k_and_dense ORs a plane's words into its window bitmap instead
+// of walking the term's rows (docset_spans.cpp:98-173), k_planes (below) evaluates union / CNF predicates 32 documents per word.
+// The planes live in a scratch region owned by the batch (2 x (max docID / 8) bytes per term); nothing survives the launch.
+
+constexpr uint32_t PL_CELLS = PL_W / CELL_DOCS; // cell-index entries per plane window
+constexpr uint32_t PL_STRIDE = PL_WORDS + 32;   // LDS words between a slot's A and B plane (word PL_WORDS of each: the sink)
+
+// A decoded posting into a pair of LDS planes (A at a[], B at a[PL_STRIDE]).  Documents outside the window land in the sink word.
+struct PlanePost {
+        uint32_t *a;
+        __device__ __forceinline__ void doc(const uint32_t rel) {
+                const uint32_t r = min(rel, PL_W);
+                atomicOr(&a[r >> 5], 1u << (r & 31u));
+        }
+        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) {
+                const uint32_t r = min(rel, PL_W);
+                const uint32_t bit = 1u << (r & 31u);
+                atomicOr(&a[r >> 5], bit);
+                if ((f & 0xffffu) != 1u) // (the frequency a scorer sees is tokenpos_t, 16 bits: codecs.h:217)
+                        atomicOr(&a[(r >> 5) + PL_STRIDE], bit);
+        }
+};
+
+// One workgroup per (plane row, window): the rows (<= 32 documents each) of the term that reach the window are decoded, one lane
+// per row, into LDS planes, which are then written out whole — every word of both planes is written by exactly one workgroup,
+// so the scratch region needs no clearing between launches.
+template <int CODEC>
+__global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+                                                        const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
+                                                        const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
+                                                        const DevTerm *__restrict__ terms, const uint32_t *__restrict__ plane_terms,
+                                                        uint32_t *__restrict__ planes, const uint32_t plw) {
+        __shared__ uint32_t pl[2 * PL_STRIDE];
+        const uint32_t tid = threadIdx.x, w = blockIdx.x, row = blockIdx.y;
+        for (uint32_t i = tid; i < 2 * PL_STRIDE; i += AND_WG)
+                pl[i] = 0;
+        const DevTerm t = terms[plane_terms[row]];
+        const uint32_t *bl = blk_last + t.first_block;
+        const uint32_t w0 = w * PL_W;
+        // rows that can hold documents of [w0, w0 + PL_W): first row whose last docID >= w0 ... first row whose last docID >= the next
+        // window's first docID (it may still begin inside this one)
+        uint32_t b_lo, b_hi;
+        if (t.win_off != 0xffffffffu) {
+                b_lo = win[t.win_off + w * PL_CELLS];
+                b_hi = win[t.win_off + (w + 1) * PL_CELLS];
+        } else { // (planes are made for long lists, which are indexed; kept for completeness)
+                uint32_t lo = 0, hi = t.nblocks;
+                while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (bl[mid] < w0)
+                                lo = mid + 1;
+                        else
+                                hi = mid;
+                }
+                b_lo = lo;
+                hi = t.nblocks;
+                while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (bl[mid] < w0 + PL_W)
+                                lo = mid + 1;
+                        else
+                                hi = mid;
+                }
+                b_hi = lo;
+        }
+        b_lo = uni(b_lo);
+        b_hi = uni(min(b_hi, t.nblocks - 1));
+        __syncthreads();
+        if (b_lo < t.nblocks)
+                for (uint32_t b = b_lo + tid; b <= b_hi; b += AND_WG) {
+                        const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
+                        PlanePost post{pl};
+#ifdef TRI_PROF
+                        ProfClock prof_;
+#endif
+                        if (CODEC == CODEC_LUCENE) {
+                                const uint4 rec = blk_rec[t.first_block + b];
+                                row_decode<CODEC, true, PlanePost>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, post PROF_PASS);
+                        } else {
+                                const uint32_t off = blk_off[t.first_block + b];
+                                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
+                                row_decode<CODEC, true, PlanePost>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, post PROF_PASS);
+                        }
+                }
+        __syncthreads();
+        uint32_t *pa = planes + (size_t)row * 2 * plw + (size_t)w * PL_WORDS, *pb = pa + plw;
+        for (uint32_t i = tid; i < PL_WORDS; i += AND_WG) {
+                pa[i] = pl[i];
+                pb[i] = pl[PL_STRIDE + i];
+        }
+}
+
+// ------------------------------------------------------------------------------------------ k_planes
+// AccumulatedScoreScheme + top-K of a CNF query (a union, a conjunction of terms / OR-groups, an excluded group, optional scoring
+// terms: everything k_fused's CNF instantiations take) in one pass over windows of PL_W documents, on BIT PLANES instead of a word
+// per document:
+//   * every slot (distinct term) of the query presents, per window, plane A (the document holds the term) and plane B (its
+//     frequency is not 1).  A head term's planes come straight from the batch's term planes (global memory, L2 / Infinity-Cache
+//     resident: k_term_planes decoded the list once for every query of the launch); any other term's rows that reach the window
+//     are decoded into LDS planes (one lane per row of <= 32 documents, the same row readers as k_fused).
+//   * the predicate is word-wise: a required group = the OR of its slots' A words, the conjunction their AND, the excluded group an
+//     AND-NOT, masked documents (docidupdates.h:90-119) another — 32 documents per instruction; the match count is a popcount.
+//     (What docset_spans.cpp:98-173 / 681-790 do per document and docset_iterators.cpp:226-405 per posting.)
+//   * MaxScore, exact (as in k_fused): only matches that hold an ESSENTIAL slot can beat the current k-th best; they are scored one
+//     per lane: frequency 1 (B clear) comes from a per-slot table, anything else is looked up in the postings — after an upper
+//     bound (the known part + the slots' score bounds) has failed to rule the document out.  A slot that is not essential is
+//     decoded for presence only: its frequencies are never unpacked (the freqs group of a PFOR block is not even addressed).
+//   * per task: min(matches, k) ranked (docID, score) pairs and the match count; k_topk_merge folds a query's tasks.
+constexpr int PLK_WG = 512;
+constexpr uint32_t PLK_MAX_SPARSE = 6;  // slots whose lists are decoded per window (LDS planes); the planner sends wider queries to k_fused
+constexpr uint32_t PLK_CAP = 1024;      // candidate buffer
+constexpr uint32_t PLK_PRUNE_AT = 512;  // pruned to the best k when it holds more than this (a scoring round adds at most PLK_WG)
+constexpr uint32_t PLK_WGS_PER_CU = 2;
+static_assert(PL_WORDS == 2 * PLK_WG, "the sweep gives every thread two words of the window");
+static_assert(PLK_PRUNE_AT + PLK_WG <= PLK_CAP && TOPK_MAX <= PLK_PRUNE_AT, "a round of newcomers always fits");
+
+struct PlanesShared {
+        uint32_t pl[PLK_MAX_SPARSE][2 * PL_STRIDE]; // per decoded slot: plane A, plane B (word PL_WORDS of each: sink)
+        double tk_s[PLK_CAP];
+        uint32_t tk_d[PLK_CAP];
+        DevTerm term[FUS_MAX_SLOTS];
+        double tab1[FUS_MAX_SLOTS]; // per slot: what its scorers add at frequency 1
+        double ub[FUS_MAX_SLOTS];   // per slot: an upper bound of what they add at any frequency
+        double thr_s;
+        uint32_t thr_d;
+        uint32_t tk_n, tk_full, matches, ess; // ess: the essential slots (bit set)
+        uint32_t bcast[4];
+        uint32_t rng_lo[2][FUS_MAX_SLOTS], rng_cnt[2][FUS_MAX_SLOTS]; // per window parity: the decoded slots' row ranges
+        uint32_t alive[2];                                             // ... and the slots whose lists are not exhausted
+        uint32_t hint_row[FUS_MAX_SLOTS], hint_doc[FUS_MAX_SLOTS];     // a row that reached beyond its window: its first document past it
+        DevFused fq;
+};
+static_assert(sizeof(PlanesShared) * PLK_WGS_PER_CU <= 160u * 1024u, "two workgroups per CU");
+
+// PlanePost that also keeps the row's first document past the window (k_fused's hint: a sparse list's row is decoded once, not once
+// per window it spans)
+struct PlanePostH {
+        uint32_t *a;
+        uint32_t past = 0xffffffffu;
+        __device__ __forceinline__ void doc(const uint32_t rel) {
+                past = min(past, rel - PL_W);
+                const uint32_t r = min(rel, PL_W);
+                atomicOr(&a[r >> 5], 1u << (r & 31u));
+        }
+        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) {
+                past = min(past, rel - PL_W);
+                const uint32_t r = min(rel, PL_W);
+                const uint32_t bit = 1u << (r & 31u);
+                atomicOr(&a[r >> 5], bit);
+                if ((f & 0xffffu) != 1u)
+                        atomicOr(&a[(r >> 5) + PL_STRIDE], bit);
+        }
+};
+
+// Keep the best k of the n (<= PLK_CAP) buffered candidates, best first (rank by counting; two entries per thread).
+__device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t k) {
+        const uint32_t tid = threadIdx.x;
+        double es[2];
+        uint32_t ed[2], rk[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+                const uint32_t i = tid + r * PLK_WG;
+                rk[r] = 0xffffffffu;
+                es[r] = 0;
+                ed[r] = 0;
+                if (i < n) {
+                        es[r] = sh.tk_s[i];
+                        ed[r] = sh.tk_d[i];
+                        uint32_t c = 0;
+                        for (uint32_t j = 0; j < n; ++j)
+                                c += better(sh.tk_s[j], sh.tk_d[j], es[r], ed[r]) ? 1u : 0u;
+                        rk[r] = c;
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+                if (rk[r] < k) {
+                        sh.tk_s[rk[r]] = es[r];
+                        sh.tk_d[rk[r]] = ed[r];
+                }
+        __syncthreads();
+        const uint32_t m = n < k ? n : k;
+        // uniform stores by every lane
+        sh.tk_n = m;
+        if (m == k) {
+                sh.tk_full = 1;
+                sh.thr_s = sh.tk_s[k - 1];
+                sh.thr_d = sh.tk_d[k - 1];
+        }
+        __syncthreads();
+}
+
+// MaxScore: the slots that can carry a document over the current k-th best (see fused_essential); a bit set, same value in every lane.
+__device__ __forceinline__ uint32_t planes_essential(const PlanesShared &sh, const uint32_t nslots) {
+        if (!uni(sh.tk_full))
+                return (1u << nslots) - 1u;
+        const double thr = sh.thr_s;
+        uint32_t done = 0, ess = 0;
+        double p = 0.0;
+        for (uint32_t r = 0; r < nslots; ++r) { // selection by ascending bound (<= 8 slots)
+                uint32_t best = 0;
+                double bv = 1e300;
+                for (uint32_t sl = 0; sl < nslots; ++sl)
+                        if (!((done >> sl) & 1u) && sh.ub[sl] < bv) {
+                                bv = sh.ub[sl];
+                                best = sl;
+                        }
+                done |= 1u << best;
+                p += bv;
+                if (!(p < thr)) // this slot (and every later one) can carry a document over the threshold
+                        ess |= 1u << best;
+        }
+        return ess;
+}
+
+template <int CODEC>
+__global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void k_planes(
+        const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
+        const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms, const DevQuery *__restrict__ plan,
+        const DevFused *__restrict__ fused, const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched, const uint32_t *__restrict__ sterms,
+        const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket, uint32_t *__restrict__ counts, const uint32_t k,
+        uint32_t *__restrict__ part_docs, double *__restrict__ part_scores, uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked,
+        const int sim, const uint32_t *__restrict__ planes, const uint32_t plw) {
+        __shared__ PlanesShared sh;
+        const uint32_t tid = threadIdx.x, lane = tid & 63u;
+        const uint32_t wave = uni(tid >> 6);
+        for (uint32_t i = tid; i < PLK_MAX_SPARSE * 2 * PL_STRIDE; i += PLK_WG)
+                (&sh.pl[0][0])[i] = 0;
+        PROF_DECL;
+        PROF_START();
+        for (;;) {
+                if (wave == 0) { // uniform draw (see k_and)
+                        const uint32_t old = atomicAdd(ticket, 1u);
+                        sh.bcast[0] = uni(old) >> 6;
+                }
+                __syncthreads();
+                const uint32_t ticket_no = uni(sh.bcast[0]);
+                __syncthreads();
+                if (ticket_no >= ntasks)
+                        break;
+                const uint32_t tix = sched[ticket_no];
+                const DevTask task = tasks[tix];
+                const DevQuery q = plan[task.slot];
+                {
+                        const uint32_t wi = min(tid, (uint32_t)(sizeof(DevFused) / 4 - 1)); // (every lane stores: no divergent branch around the barriers)
+                        ((uint32_t *)&sh.fq)[wi] = ((const uint32_t *)(fused + q.fused_idx))[wi];
+                }
+                __syncthreads();
+                const DevFused &fq = sh.fq;
+                const uint32_t nslots = uni(fq.nslots), nreq = uni(fq.nreq), negs = uni(fq.negslots);
+                const uint32_t kk = min(lane, nslots - 1); // lane s (< nslots) of every wave looks after slot s, the lanes above mirror the last slot
+                {
+                        sh.term[kk] = terms[fq.term[kk]];
+                        sh.hint_row[kk] = 0xffffffffu;
+                        // what the slot's scorers add at frequency 1, and a bound of what they add at any frequency: BM25 float(w f / (f + 1.2)) < w;
+                        // TF-IDF sqrt(f) w with f <= 65535; Trivial f
+                        double t1 = 0.0, ubs = 0.0;
+                        for (uint32_t si = 0; si < q.nscore; ++si)
+                                if (sterms[q.score_base + si] == fq.term[kk]) {
+                                        const double wgt = sweights[q.score_base + si];
+                                        t1 += (double)sim_score(sim, wgt, 1u);
+                                        ubs += sim == TRI_SIM_TRIVIAL ? 65535.0 : sim == TRI_SIM_TFIDF ? (wgt > 0 ? 256.0 * wgt : 0.0) : (wgt > 0 ? wgt : 0.0);
+                                }
+                        sh.tab1[kk] = t1;
+                        sh.ub[kk] = ubs * (1.0 + 1e-6);
+                        sh.tk_n = 0;
+                        sh.tk_full = 0;
+                        sh.matches = 0;
+                        sh.ess = (1u << nslots) - 1u; // no threshold yet: every slot is essential
+                }
+                __syncthreads();
+                // ---- per task, uniform: which slots read term planes, where the others' LDS planes are, which slots score
+                uint32_t dense_mask = 0, leaf_mask = 0;
+                uint32_t lidx[FUS_MAX_SLOTS];
+                size_t pbase[FUS_MAX_SLOTS];
+                {
+                        uint32_t nl = 0;
+#pragma unroll
+                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                                const uint32_t prow = s < nslots ? uni(fq.plane[s]) : PL_NONE;
+                                pbase[s] = prow != PL_NONE ? (size_t)prow * 2 * plw : 0;
+                                lidx[s] = 0;
+                                if (s < nslots) {
+                                        if (prow != PL_NONE)
+                                                dense_mask |= 1u << s;
+                                        else
+                                                lidx[s] = nl++;
+                                        bool leaf = false;
+                                        for (uint32_t si = 0; si < q.nscore; ++si)
+                                                leaf |= sterms[q.score_base + si] == uni(fq.term[s]);
+                                        if (leaf)
+                                                leaf_mask |= 1u << s;
+                                }
+                        }
+                }
+                const uint32_t sparse_mask = ((1u << nslots) - 1u) & ~dense_mask;
+                const uint32_t wfirst = task.tile_begin, wend = task.tile_end;
+                // ---- wave 0, lane s: the directory position of decoded slot s (indexed lists: two cell-index entries per window; short lists:
+                //      a cursor with its block's last docID)
+                uint32_t cur = 0, cur_last = 0xffffffffu;
+                const DevTerm myt = sh.term[kk];
+                const uint32_t *mybl = blk_last + myt.first_block;
+                const bool my_sparse = (sparse_mask >> kk) & 1u, my_indexed = myt.win_off != 0xffffffffu;
+                if (wave == 0 && my_sparse && !my_indexed) {
+                        uint32_t lo = 0, hi = myt.nblocks; // first block whose last document >= the task's first docID
+                        const uint32_t key = wfirst * PL_W;
+                        while (lo < hi) {
+                                const uint32_t mid = (lo + hi) >> 1;
+                                if (mybl[mid] < key)
+                                        lo = mid + 1;
+                                else
+                                        hi = mid;
+                        }
+                        cur = lo;
+                        cur_last = cur < myt.nblocks ? mybl[cur] : 0xffffffffu;
+                }
+                // rows of my slot that can hold documents of window w: [lo, hi] (first row whose last docID >= w0 ... first whose last >= the
+                // next window's first docID); nothing when lo is beyond the list
+                auto range_of = [&](const uint32_t w, uint32_t &lo, uint32_t &cnt) {
+                        const uint32_t w0 = w * PL_W;
+                        uint32_t hi;
+                        if (!my_sparse) {
+                                lo = 0;
+                                cnt = 0;
+                                return;
+                        }
+                        if (my_indexed) {
+                                lo = win[myt.win_off + w * PL_CELLS];
+                                hi = win[myt.win_off + (w + 1) * PL_CELLS];
+                        } else {
+                                while (cur < myt.nblocks && cur_last < w0) {
+                                        ++cur;
+                                        cur_last = cur < myt.nblocks ? mybl[cur] : 0xffffffffu;
+                                }
+                                lo = hi = cur;
+                                if (cur_last < w0 + (PL_W - 1)) // (rare for a short list: further blocks end inside the window)
+                                        while (hi + 1 < myt.nblocks && mybl[hi] < w0 + (PL_W - 1))
+                                                ++hi;
+                        }
+                        hi = min(hi, myt.nblocks - 1);
+                        cnt = lo < myt.nblocks ? hi - lo + 1 : 0xffffffffu; // (0xffffffff: the list is exhausted)
+                };
+                // wave 0 only, behind a barrier that follows the last set pass: the ranges of window w for everybody.  A row known (from the
+                // hint it left when it was decoded) to continue past this window without a document in it adds nothing here — decided once,
+                // by one wave, so that every wave works from the same ranges
+                auto publish = [&](const uint32_t w, const uint32_t lo, uint32_t cnt) {
+                        const bool dead = my_sparse && cnt == 0xffffffffu;
+                        const uint64_t dm = __builtin_amdgcn_ballot_w64(dead);
+                        if (dead)
+                                cnt = 0;
+                        if (cnt && sh.hint_row[kk] == lo && sh.hint_doc[kk] > w * PL_W + (PL_W - 1))
+                                cnt = 0; // (then lo is the slot's only row here: a row that reaches past the window is the last one that touches it)
+                        if (lane < nslots) {
+                                sh.rng_lo[w & 1u][kk] = lo;
+                                sh.rng_cnt[w & 1u][kk] = cnt;
+                        }
+                        sh.alive[w & 1u] = ~(uint32_t)dm; // (same value from every lane)
+                };
+                if (wave == 0) {
+                        uint32_t lo, cnt;
+                        range_of(wfirst, lo, cnt);
+                        publish(wfirst, lo, cnt);
+                }
+                __syncthreads();
+                uint32_t my_matches = 0;
+                for (uint32_t w = wfirst; w < wend; ++w) {
+                        const uint32_t par = w & 1u, w0 = w * PL_W;
+                        // ---- this window's row ranges (left by wave 0 a window ago)
+                        uint32_t s_lo[FUS_MAX_SLOTS], s_cnt[FUS_MAX_SLOTS], total = 0, rows_mask = 0;
+                        const uint32_t alive = uni(sh.alive[par]);
+#pragma unroll
+                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                                s_lo[s] = 0;
+                                s_cnt[s] = 0;
+                                if (s < nslots && ((sparse_mask >> s) & 1u)) {
+                                        s_lo[s] = uni(sh.rng_lo[par][s]);
+                                        s_cnt[s] = uni(sh.rng_cnt[par][s]);
+                                        total += s_cnt[s];
+                                        if (s_cnt[s])
+                                                rows_mask |= 1u << s;
+                                }
+                        }
+                        // a required group all of whose lists are exhausted ends the task; one that neither reads a term plane nor has a row in
+                        // this window rules the window out
+                        bool dead = false, possible = true;
+                        for (uint32_t g = 0; g < nreq; ++g) {
+                                const uint32_t gs = uni(fq.gslots[g]);
+                                dead |= !(gs & (dense_mask | alive));
+                                possible &= (gs & (dense_mask | rows_mask)) != 0;
+                        }
+                        if (dead)
+                                break;
+                        // wave 0 fetches the next window's directory entries now; they are published behind the set pass
+                        uint32_t n_lo = 0, n_cnt = 0;
+                        const bool more = w + 1 < wend;
+                        if (wave == 0 && more)
+                                range_of(w + 1, n_lo, n_cnt);
+                        if (!possible) {
+                                if (wave == 0 && more)
+                                        publish(w + 1, n_lo, n_cnt);
+                                __syncthreads();
+                                continue;
+                        }
+                        // ---- the term planes' A words of this thread's two words travel while the other lists are decoded
+                        uint32_t a0[FUS_MAX_SLOTS], a1[FUS_MAX_SLOTS];
+#pragma unroll
+                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                                a0[s] = a1[s] = 0;
+                                if ((dense_mask >> s) & 1u) {
+                                        const uint32_t *pa = planes + pbase[s] + (size_t)w * PL_WORDS;
+                                        a0[s] = pa[tid];
+                                        a1[s] = pa[tid + PLK_WG];
+                                }
+                        }
+                        const uint32_t ess = uni(sh.ess);
+                        PROF_LAP(1);
+                        // ---- set pass: the rows of the decoded slots form one work list, one lane per row; a slot that is not essential is decoded
+                        //      for presence only
+                        for (uint32_t v0 = 0; v0 < total; v0 += PLK_WG) {
+                                const uint32_t v = v0 + tid;
+                                uint32_t s = 0, r = v, lo = s_lo[0];
+#pragma unroll
+                                for (uint32_t k2 = 0; k2 + 1 < FUS_MAX_SLOTS; ++k2) { // which slot's rows v falls into (ranges are wave-uniform)
+                                        const bool nextslot = s == k2 && r >= s_cnt[k2];
+                                        r = nextslot ? r - s_cnt[k2] : r;
+                                        lo = nextslot ? s_lo[k2 + 1] : lo;
+                                        s = nextslot ? k2 + 1 : s;
+                                }
+                                const bool act = v < total;
+                                const bool needf = act && ((ess >> s) & 1u);
+                                const bool anyf = __builtin_amdgcn_ballot_w64(needf) != 0ull; // (wave-uniform: one code path per wave)
+                                if (act) {
+                                        const DevTerm t = sh.term[s];
+                                        const uint32_t b = lo + r;
+                                        const uint32_t *bl = blk_last + t.first_block;
+                                        const uint32_t prev = b ? bl[b - 1] : 0;
+                                        const uint32_t last = bl[b];
+                                        uint32_t ls = 0;
+#pragma unroll
+                                        for (uint32_t k2 = 0; k2 < FUS_MAX_SLOTS; ++k2)
+                                                ls = s == k2 ? lidx[k2] : ls;
+                                        PlanePostH post{&sh.pl[ls][0]};
+                                        if (CODEC == CODEC_LUCENE) {
+                                                const uint4 rec = blk_rec[t.first_block + b];
+                                                if (anyf)
+                                                        row_decode<CODEC, true, PlanePostH>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, post PROF_PASS);
+                                                else
+                                                        row_decode<CODEC, false, PlanePostH>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, post PROF_PASS);
+                                        } else {
+                                                const uint32_t off = blk_off[t.first_block + b];
+                                                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
+                                                if (anyf)
+                                                        row_decode<CODEC, true, PlanePostH>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, post PROF_PASS);
+                                                else
+                                                        row_decode<CODEC, false, PlanePostH>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, post PROF_PASS);
+                                        }
+                                        if (post.past < 0x80000000u) { // the row reaches past the window (it is the slot's last row here): leave the hint
+                                                sh.hint_row[s] = b;
+                                                sh.hint_doc[s] = w0 + PL_W + post.past;
+                                        }
+                                }
+                        }
+                        const uint32_t nof = sparse_mask & ~ess; // decoded slots whose B plane says nothing in this window
+                        PROF_LAP(2);
+                        __syncthreads();
+                        PROF_LAP(3);
+                        if (wave == 0 && more) // (this window's hints are in; the next barrier — the sweep's — makes the ranges visible)
+                                publish(w + 1, n_lo, n_cnt);
+                        // ---- sweep: the decoded slots' A words, the predicate, the essential matches
+#pragma unroll
+                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                if ((rows_mask >> s) & 1u) {
+                                        a0[s] = sh.pl[lidx[s]][tid];
+                                        a1[s] = sh.pl[lidx[s]][tid + PLK_WG];
+                                }
+                        uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;
+                        for (uint32_t g = 0; g < nreq; ++g) {
+                                const uint32_t gs = uni(fq.gslots[g]);
+                                uint32_t x0 = 0, x1 = 0;
+#pragma unroll
+                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                        if ((gs >> s) & 1u) {
+                                                x0 |= a0[s];
+                                                x1 |= a1[s];
+                                        }
+                                m0 &= x0;
+                                m1 &= x1;
+                        }
+                        uint32_t e0 = 0, e1 = 0;
+                        {
+                                uint32_t n0 = 0, n1 = 0;
+#pragma unroll
+                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                                        if ((negs >> s) & 1u) {
+                                                n0 |= a0[s];
+                                                n1 |= a1[s];
+                                        }
+                                        if ((ess >> s) & 1u) {
+                                                e0 |= a0[s];
+                                                e1 |= a1[s];
+                                        }
+                                }
+                                m0 &= ~n0;
+                                m1 &= ~n1;
+                        }
+                        if (masked) { // masked_documents_registry::test (docidupdates.h:90-119)
+                                m0 &= ~masked[(w0 >> 5) + tid];
+                                m1 &= ~masked[(w0 >> 5) + tid + PLK_WG];
+                        }
+                        my_matches += (uint32_t)(__popc(m0) + __popc(m1));
+                        e0 &= m0;
+                        e1 &= m1;
+                        // words nobody will score are cleared now (the decoded slots' planes of this window: A and B)
+                        auto clear_mine = [&]() {
+#pragma unroll
+                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                        if ((rows_mask >> s) & 1u) {
+                                                uint32_t *p = &sh.pl[lidx[s]][0];
+                                                p[tid] = 0;
+                                                p[tid + PLK_WG] = 0;
+                                                p[PL_STRIDE + tid] = 0;
+                                                p[PL_STRIDE + tid + PLK_WG] = 0;
+                                        }
+                        };
+                        const bool mine = (e0 | e1) != 0;
+                        if (!mine)
+                                clear_mine();
+                        PROF_LAP(4);
+                        if (uni((uint32_t)__syncthreads_or(mine ? 1 : 0))) {
+                                // ---- scoring rounds: every lane takes one of its essential matches at a time
+                                uint32_t cur_ess = ess;
+                                for (;;) {
+                                        const bool has = (e0 | e1) != 0;
+                                        if (!uni((uint32_t)__syncthreads_or(has ? 1 : 0)))
+                                                break;
+                                        const bool full = uni(sh.tk_full) != 0;
+                                        const double thr_s = sh.thr_s;
+                                        const uint32_t thr_d = sh.thr_d;
+                                        if (has) {
+                                                const uint32_t which = e0 ? 0u : 1u;
+                                                const uint32_t bit = (uint32_t)__builtin_ctz(which ? e1 : e0);
+                                                if (which)
+                                                        e1 &= e1 - 1u;
+                                                else
+                                                        e0 &= e0 - 1u;
+                                                const uint32_t wi = tid + which * PLK_WG, doc = w0 + 32u * wi + bit;
+                                                double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known yet
+                                                uint32_t unk = 0;
+#pragma unroll
+                                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                                                        if (!((leaf_mask >> s) & 1u))
+                                                                continue;
+                                                        const uint32_t av = which ? a1[s] : a0[s];
+                                                        if (!((av >> bit) & 1u))
+                                                                continue;
+                                                        bool f1;
+                                                        if ((dense_mask >> s) & 1u)
+                                                                f1 = !((planes[pbase[s] + plw + (size_t)w * PL_WORDS + wi] >> bit) & 1u);
+                                                        else if ((nof >> s) & 1u)
+                                                                f1 = false;
+                                                        else
+                                                                f1 = !((sh.pl[lidx[s]][PL_STRIDE + wi] >> bit) & 1u);
+                                                        if (f1)
+                                                                sk += sh.tab1[s];
+                                                        else {
+                                                                unk |= 1u << s;
+                                                                sb += sh.ub[s];
+                                                        }
+                                                }
+                                                bool take = !full || better(sk + sb, doc, thr_s, thr_d);
+                                                if (take && unk) { // the bound does not rule the document out: the exact frequencies, from the postings
+                                                        for (uint32_t s = 0; s < nslots; ++s) {
+                                                                if (!((unk >> s) & 1u))
+                                                                        continue;
+                                                                const uint32_t f = fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[s], doc);
+                                                                const uint32_t term = fq.term[s];
+                                                                for (uint32_t si = 0; si < q.nscore; ++si)
+                                                                        if (sterms[q.score_base + si] == term)
+                                                                                sk += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                                        }
+                                                        take = !full || better(sk, doc, thr_s, thr_d);
+                                                }
+                                                if (take) {
+                                                        const uint32_t slot = atomicAdd(&sh.tk_n, 1u); // (a round adds at most PLK_WG: always room)
+                                                        sh.tk_s[slot] = sk;
+                                                        sh.tk_d[slot] = doc;
+                                                }
+                                        }
+                                        __syncthreads();
+                                        const uint32_t n = uni(sh.tk_n);
+                                        if (n > PLK_PRUNE_AT) {
+                                                planes_prune(sh, n, k);
+                                                const uint32_t ne = planes_essential(sh, nslots); // same value from every lane
+                                                sh.ess = ne;
+                                                if (ne != cur_ess) { // the threshold moved: matches that hold none of the remaining essential slots are out
+                                                        cur_ess = ne;
+                                                        uint32_t x0 = 0, x1 = 0;
+#pragma unroll
+                                                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                                                if ((ne >> s) & 1u) {
+                                                                        x0 |= a0[s];
+                                                                        x1 |= a1[s];
+                                                                }
+                                                        e0 &= x0;
+                                                        e1 &= x1;
+                                                }
+                                        }
+                                }
+                                if (mine)
+                                        clear_mine();
+                                __syncthreads();
+                        }
+                        PROF_LAP(5);
+                }
+                // ---- the task's result: its best k (ranked) and its match count
+                __syncthreads();
+                planes_prune(sh, uni(sh.tk_n), k);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1)
+                        my_matches += __shfl_xor(my_matches, d, 64);
+                atomicAdd(&sh.matches, lane == 0 ? my_matches : 0u); // (every lane issues it: no single-lane branch)
+                __syncthreads();
+                const uint32_t n = uni(sh.tk_n);
+                for (uint32_t i = tid; i < n; i += PLK_WG) {
+                        part_docs[(uint64_t)tix * k + i] = sh.tk_d[i];
+                        part_scores[(uint64_t)tix * k + i] = sh.tk_s[i];
+                }
+                if (wave == 0) {
+                        part_counts[tix] = n;
+                        counts[tix] = uni(sh.matches);
+                }
+                __syncthreads();
+                PROF_LAP(6);
+        }
+        PROF_FLUSH();
+}

@@ -31,6 +31,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <unordered_map>
 #include <functional>
 #include <vector>
 
@@ -66,6 +67,8 @@ struct tri_options {
         uint64_t account_needed_bytes = 0;        // 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query)
         uint64_t fused_halfwords = 1;             // 16-bit window words for queries of <= 5 distinct terms (windows twice as long); 0: always 32-bit
         uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
+        uint64_t planes = 7;     // term planes (k_planes.hpp), a bit set: 1 k_and probes them, 2 k_and_dense ORs them in, 4 top-K CNF queries run in k_planes; 0: off
+        uint64_t plane_div = 64; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list)
 };
 
 struct tri_dev {
@@ -136,6 +139,13 @@ struct tri_batch {
         DevTask *d_tasks = nullptr;
         uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones, then the TASK_FUSED ones
         uint32_t n_dense = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0; // (n_fused: 32-bit window words; n_fused16: 16-bit; n_fusedgen: general trees)
+        uint32_t n_planes = 0; // TASK_PLANES tasks (k_planes), scheduled after the general trees
+        // term planes (k_planes.hpp): the head terms the batch's queries share, decoded once per launch into d_planes
+        std::vector<uint32_t> plane_terms; // row -> term
+        uint32_t *d_plane_terms = nullptr, *d_planes = nullptr, *d_qplane = nullptr; // d_qplane: parallel to d_qterms, the term's row or PL_NONE
+        uint32_t plw = 0;                  // words of one plane
+        uint64_t term_bytes_planes = 0, plane_decoded_bytes = 0;
+        hipEvent_t ev_pl = nullptr, ev_k = nullptr; // after k_term_planes; after k_planes
         std::vector<DevFused> fused; // slot maps of the TASK_FUSED queries (DevQuery::fused_idx)
         DevFused *d_fused = nullptr;
         uint64_t term_bytes_fused = 0;
@@ -187,9 +197,12 @@ struct tri_batch {
         ~tri_batch() { // also runs when tri_batch_create fails half-way: nothing allocated so far is leaked
                 if (ix)
                         hipSetDevice(ix->dev->device);
-                for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev_p, ev1})
+                for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k})
                         if (e)
                                 hipEventDestroy(e);
+                hipFree(d_plane_terms);
+                hipFree(d_planes);
+                hipFree(d_qplane);
                 hipFree(d_fused);
                 hipFree(d_plan);
                 hipFree(d_tasks);
@@ -229,6 +242,7 @@ struct tri_batch {
 #include "k_match.hpp"
 #include "k_score.hpp"
 #include "k_fused.hpp"
+#include "k_planes.hpp"
 #include "k_encode.hpp"
 #include "k_phrase.hpp"
 #include "k_rich.hpp"
@@ -287,7 +301,9 @@ namespace {
                              {"fused_halfwords", &tri_options::fused_halfwords},
                              {"account_needed_bytes", &tri_options::account_needed_bytes},
                              {"overlap_dense_wgs", &tri_options::overlap_dense_wgs},
-                             {"overlap_cand_wgs", &tri_options::overlap_cand_wgs}};
+                             {"overlap_cand_wgs", &tri_options::overlap_cand_wgs},
+                             {"planes", &tri_options::planes},
+                             {"plane_div", &tri_options::plane_div}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -443,6 +459,8 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                 return fail(TRI_ERR_INVALID, "tri_index_upload: unknown codec %d", codec);
         if (len > 0xffffffffull)
                 return fail(TRI_ERR_FORMAT, "index exceeds 32-bit chunk offsets (codecs.h:26)");
+        if (codec == TRI_CODEC_GOOGLE && len >= 0x80000000ull) // bit 31 of a block's hits offset carries BLK_HITS_PLAIN (k_phrase / k_rich mask it off)
+                return fail(TRI_ERR_UNSUPPORTED, "a google_codec index of 2 GiB or more (%zu bytes): split the segment", len);
         HIP_TRY(hipSetDevice(dev->device));
         auto ix = std::make_unique<tri_index>();
         ix->dev = dev;
@@ -1251,13 +1269,14 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 ok &= add_group(x);
                 };
                 lower(root);
-                for (size_t oi = 0; oi < opts.size(); ++oi)
-                        if (const uint32_t x = opts[oi]; ix->terms[x].documents) {
-                                leaves.push_back(x); // one more scorer / reportable term each; never part of the docID set
-                                leaf_tok.push_back(opt_tok[oi]);
-                                if (mode != TRI_FLAG_DOCUMENTS_ONLY)
-                                        b->term_bytes += ix->docbytes[x]; // its postings are read by k_score / k_rich
-                        }
+                if (ok && !groups.empty()) // (a general tree — below — counts every term once through its slot list)
+                        for (size_t oi = 0; oi < opts.size(); ++oi)
+                                if (const uint32_t x = opts[oi]; ix->terms[x].documents) {
+                                        leaves.push_back(x); // one more scorer / reportable term each; never part of the docID set
+                                        leaf_tok.push_back(opt_tok[oi]);
+                                        if (mode != TRI_FLAG_DOCUMENTS_ONLY)
+                                                b->term_bytes += ix->docbytes[x]; // its postings are read by k_score / k_rich
+                                }
                 TruthPlan tp;
                 bool truth = false;
                 if (!ok || groups.empty()) {
@@ -1547,6 +1566,24 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint64_t want_tasks = 2ull * (uint64_t)dev->cus * FUS_WGS_PER_CU;
                 FUSED_TASK_COST = std::min<uint64_t>(8u << 20, std::max<uint64_t>(256u << 10, fused_postings / want_tasks));
         }
+        // ---- term planes (k_planes.hpp): a head term is decoded once per launch for all the queries that name it.  Eligible: an indexed list
+        //      of at least docs_cnt / plane_div documents; built when the batch's uses repay one decode of the list (a use as a bitmap-window
+        //      or one-pass slot saves a whole walk, a use as the probed side of a candidate tile saves at most 32 postings per lead document)
+        const uint64_t planes_opt = dev->opt.planes;
+        const uint64_t plane_min_df = dev->opt.plane_div ? std::max<uint64_t>(1, ix->info.docs_cnt / dev->opt.plane_div) : UINT64_MAX;
+        auto plane_ok = [&](uint32_t term) {
+                const DevTerm &tk = ix->terms[term];
+                return planes_opt && tk.documents && tk.documents >= plane_min_df;
+        };
+        std::unordered_map<uint32_t, uint64_t> plane_benefit;
+        struct QUse {
+                uint32_t qpos, term;
+        };
+        struct FUse {
+                uint32_t fidx, slot, term;
+        };
+        std::vector<QUse> quses;
+        std::vector<FUse> fuses;
         std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
         for (auto &t : tmp) {
                 const uint32_t slot = (uint32_t)b->plan.size();
@@ -1559,19 +1596,38 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint32_t last_doc = cls.last_doc;
                 const bool dense = cls.dense, fuse = cls.fuse;
                 if (fuse) {
+                        // a CNF query whose top-K runs over bit planes (k_planes): its head terms read from the batch's term planes, the
+                        // others (at most PLK_MAX_SPARSE) decoded per window into LDS planes
+                        uint32_t nsparse = 0;
+                        for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
+                                t.fz.plane[sidx] = PL_NONE;
+                                nsparse += plane_ok(t.fz.term[sidx]) ? 0u : 1u;
+                        }
+                        const bool pk = !t.truth && (planes_opt & 4u) && nsparse <= PLK_MAX_SPARSE;
+                        {
+                                const uint32_t fm = (1u << t.fz.fbits) - 1u;
+                                t.fz.negslots = 0;
+                                for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx)
+                                        if ((t.fz.nmask >> (sidx * t.fz.fbits)) & fm)
+                                                t.fz.negslots |= 1u << sidx;
+                        }
                         // every list of the slot map is read once (the optional terms too)
                         uint64_t slotdf = 0;
                         for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
                                 slotdf += ix->terms[t.fz.term[sidx]].documents;
-                                b->term_bytes_fused += ix->docbytes[t.fz.term[sidx]];
+                                (pk ? b->term_bytes_planes : b->term_bytes_fused) += ix->docbytes[t.fz.term[sidx]];
+                                if (pk && plane_ok(t.fz.term[sidx])) {
+                                        plane_benefit[t.fz.term[sidx]] += ix->terms[t.fz.term[sidx]].documents;
+                                        fuses.push_back({(uint32_t)b->fused.size(), sidx, t.fz.term[sidx]});
+                                }
                         }
-                        ++b->info.fused_queries;
+                        ++(pk ? b->info.planes_queries : b->info.fused_queries);
                         t.q.fused_idx = (uint32_t)b->fused.size();
                         b->fused.push_back(t.fz);
                         t.q.out_off = off;
                         t.q.out_cap = 0; // the docID set is never materialised ...
                         t.q.first_task = (uint32_t)b->tasks.size();
-                        const uint32_t fw = FUS_W << t.fz.hw; // documents per window of this query's word width
+                        const uint32_t fw = pk ? PL_W : FUS_W << t.fz.hw; // documents per window: plane windows, or this query's word width
                         const uint32_t nwin = last_doc / fw + 1;
                         const uint64_t per_win = std::max<uint64_t>(1, slotdf / (ix->info.docs_cnt / fw + 1));
                         const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
@@ -1588,7 +1644,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                                 b1 += (uint64_t)(std::lower_bound(lb, lb + tk.nblocks, wb * fw) - lb);
                                         }
                                 order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
-                                b->tasks.push_back({slot, wb, we, t.fz.mode ? TASK_FUSED_GEN : t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off + (emit ? b1 * 32 + 32ull * ord * t.fz.nslots : 0)});
+                                b->tasks.push_back({slot, wb, we, pk ? TASK_PLANES : t.fz.mode ? TASK_FUSED_GEN : t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off + (emit ? b1 * 32 + 32ull * ord * t.fz.nslots : 0)});
                         }
                         if (emit) {
                                 uint64_t blocks = 0;
@@ -1609,10 +1665,22 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                         seen.push_back(term);
                                         b->term_bytes_dense += ix->docbytes[term];
                                 }
+                                if ((planes_opt & 2u) && plane_ok(term)) {
+                                        plane_benefit[term] += ix->terms[term].documents;
+                                        quses.push_back({t.q.term_base + k, term});
+                                }
                         }
                         ++b->info.dense_queries;
-                } else
+                } else {
                         ++b->info.cand_queries;
+                        for (uint32_t k = 1; k < t.q.nterms; ++k) { // (the lead list is decoded into the candidate tiles; the others are probed)
+                                const uint32_t term = qt[k] & QT_TERM;
+                                if ((planes_opt & 1u) && plane_ok(term)) {
+                                        plane_benefit[term] += std::min<uint64_t>(ix->terms[term].documents, 32ull * lead.documents);
+                                        quses.push_back({t.q.term_base + k, term});
+                                }
+                        }
+                }
                 t.q.out_off = off;
                 t.q.first_task = (uint32_t)b->tasks.size();
                 if (dense) {
@@ -1703,12 +1771,46 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if (b->tasks[o.second].kind == TASK_FUSED_GEN)
                         sched.push_back(o.second);
         b->n_fusedgen = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused - b->n_fused16;
+        for (const auto &o : order)
+                if (b->tasks[o.second].kind == TASK_PLANES)
+                        sched.push_back(o.second);
+        b->n_planes = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused - b->n_fused16 - b->n_fusedgen;
+        // the planes that pay: rows in term order (deterministic), the uses pointed at them
+        {
+                std::vector<uint32_t> chosen;
+                for (const auto &e : plane_benefit)
+                        if (e.second >= ix->terms[e.first].documents)
+                                chosen.push_back(e.first);
+                for (const auto &u : fuses) // (a one-pass slot counts a whole decode: always chosen; kept explicit)
+                        if (std::find(chosen.begin(), chosen.end(), u.term) == chosen.end())
+                                chosen.push_back(u.term);
+                std::sort(chosen.begin(), chosen.end());
+                std::unordered_map<uint32_t, uint32_t> row_of;
+                for (uint32_t x : chosen) {
+                        row_of[x] = (uint32_t)b->plane_terms.size();
+                        b->plane_terms.push_back(x);
+                        b->plane_decoded_bytes += ix->docbytes[x];
+                }
+                if (!chosen.empty()) {
+                        std::vector<uint32_t> qplane(b->qterms.size(), PL_NONE);
+                        for (const auto &u : quses)
+                                if (auto it = row_of.find(u.term); it != row_of.end())
+                                        qplane[u.qpos] = it->second;
+                        for (const auto &u : fuses)
+                                b->fused[u.fidx].plane[u.slot] = row_of[u.term];
+                        b->plw = ((ix->max_doc >> 17) + 2u) * (SPAN_BITS / 32u); // whole bitmap windows (k_and_dense reads SPAN_WORDS at a time) + a spare one
+                        int rcp;
+                        if ((rcp = dev_upload(&b->d_qplane, qplane)) || (rcp = dev_upload(&b->d_plane_terms, b->plane_terms)))
+                                return rcp;
+                        HIP_TRY(hipMalloc((void **)&b->d_planes, (size_t)b->plane_terms.size() * 2 * b->plw * 4 + 64));
+                }
+        }
         b->out_capacity = off;
         int rc;
         if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)) || (rc = dev_upload(&b->d_tasks, b->tasks)) ||
             (rc = dev_upload(&b->d_sched, sched)) || (rc = dev_upload(&b->d_fused, b->fused)))
                 return rc;
-        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1})
+        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k})
                 HIP_TRY(hipEventCreate(e));
         HIP_TRY(hipMalloc((void **)&b->d_out, (off + 64) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_counts, (b->tasks.size() + 1) * 4));
@@ -1748,11 +1850,16 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 HIP_TRY(hipMalloc((void **)&b->d_top_docs, (nq * topk + 1) * 4));
                 HIP_TRY(hipMalloc((void **)&b->d_top_scores, (nq * topk + 1) * 4));
                 HIP_TRY(hipMalloc((void **)&b->d_top_counts, (nq + 1) * 4));
-                HIP_TRY(hipMemset(b->d_top_counts, 0, (nq + 1) * 4)); // queries that can never match keep count 0
+                HIP_TRY(hipMemset(b->d_top_counts, 0, (nq + 1) * 4)); // queries that can never match keep count 0 ...
+                HIP_TRY(hipMemset(b->d_top_docs, 0, (nq * topk + 1) * 4)); // ... and zeroed rows (k_topk_merge only writes the rows of queries that have a plan slot;
+                HIP_TRY(hipMemset(b->d_top_scores, 0, (nq * topk + 1) * 4)); // the blocks travel whole to the host and to the other ranks)
         }
         b->info.nqueries = nq;
         b->info.out_capacity = off;
-        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (!b->ptasks.empty()) + (rich ? 2 : 0) +
+        b->info.plane_terms = b->plane_terms.size();
+        b->info.plane_bytes = (uint64_t)b->plane_terms.size() * 2 * b->plw * 4;
+        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (!b->plane_terms.empty()) +
+                           (!b->ptasks.empty()) + (rich ? 2 : 0) +
                            ((scored && b->n_dense + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
         *out = b.release();
         return TRI_OK;
@@ -1793,6 +1900,14 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         dense_wgs = (uint32_t)dev->opt.overlap_dense_wgs;
                         cand_wgs = (uint32_t)dev->opt.overlap_cand_wgs;
                 }
+                if (!b->plane_terms.empty()) {
+                        // the head terms the batch shares, decoded once for this launch (every word of every plane is rewritten)
+                        const dim3 grid(b->plw / PL_WORDS, (uint32_t)b->plane_terms.size());
+                        TRI_LAUNCH(k_term_planes, b->ix->codec, grid, dim3(AND_WG), dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec,
+                                   b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plane_terms, b->d_planes, b->plw);
+                        HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipEventRecord(b->ev_pl, dev->stream));
                 hipStream_t cand_stream = dev->stream;
                 if (overlap) {
                         HIP_TRY(hipEventRecord(dev->ev_fork, dev->stream));
@@ -1802,14 +1917,14 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 if (b->n_dense) {
                         TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * dense_wgs)), dim3(DENSE_WG), dev->stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
-                                           b->d_ticket + 16, b->d_out, b->d_counts, b->ix->d_masked);
+                                           b->d_ticket + 16, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->d_planes, b->plw);
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
-                                           b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked);
+                                           b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->d_planes, b->plw);
                 HIP_TRY(hipGetLastError());
                 if (overlap) {
                         HIP_TRY(hipEventRecord(dev->ev_join, dev->stream2));
@@ -1847,6 +1962,17 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
+                if (b->n_planes) {
+                        // AccumulatedScore top-K of the CNF queries over bit planes: the head terms' planes from k_term_planes, the other lists
+                        // decoded per window into LDS planes; union / conjunction predicates 32 documents per word
+                        const uint32_t *psched = b->d_sched + b->n_dense + b->n_cand + b->n_fused + b->n_fused16 + b->n_fusedgen;
+                        const dim3 grid(std::min<uint32_t>(b->n_planes, (uint32_t)dev->cus * PLK_WGS_PER_CU));
+                        TRI_LAUNCH(k_planes, b->ix->codec, grid, dim3(PLK_WG), dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff,
+                                   b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, b->d_sterms, b->d_sweights, b->n_planes, b->d_ticket + 24, b->d_counts,
+                                   b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked, b->similarity, (const uint32_t *)b->d_planes, b->plw);
+                        HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipEventRecord(b->ev_k, dev->stream));
                 if (!b->ptasks.empty()) {
                         // positional constraints: filter + compact the match segments of the queries that hold phrases
                         const uint32_t np = (uint32_t)b->ptasks.size();
@@ -1891,9 +2017,11 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 }
         }
         else {
+                HIP_TRY(hipEventRecord(b->ev_pl, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_b, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
+                HIP_TRY(hipEventRecord(b->ev_k, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_p, dev->stream));
         }
         if (!b->plan.empty()) {
@@ -1939,15 +2067,19 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
                 b->info.last_run_ms = ms;
-        b->info.dense_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.rest_ms = 0;
+        b->info.dense_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.rest_ms = b->info.term_planes_ms = b->info.planes_ms = 0;
         if (!b->tasks.empty()) {
-                if (hipEventElapsedTime(&ms, b->ev0, b->ev_a) == hipSuccess)
-                        b->info.dense_ms = ms; // includes the 256-byte ticket memset that precedes it
+                if (hipEventElapsedTime(&ms, b->ev0, b->ev_pl) == hipSuccess)
+                        b->info.term_planes_ms = ms; // includes the 256-byte ticket memset that precedes it
+                if (hipEventElapsedTime(&ms, b->ev_pl, b->ev_a) == hipSuccess)
+                        b->info.dense_ms = ms;
                 if (hipEventElapsedTime(&ms, b->ev_a, b->ev_b) == hipSuccess)
                         b->info.cand_ms = ms;
                 if (hipEventElapsedTime(&ms, b->ev_b, b->ev_c) == hipSuccess)
                         b->info.fused_ms = ms;
-                if (hipEventElapsedTime(&ms, b->ev_c, b->ev_p) == hipSuccess)
+                if (hipEventElapsedTime(&ms, b->ev_c, b->ev_k) == hipSuccess)
+                        b->info.planes_ms = ms;
+                if (hipEventElapsedTime(&ms, b->ev_k, b->ev_p) == hipSuccess)
                         b->info.phrase_ms = ms;
                 if (hipEventElapsedTime(&ms, b->ev_p, b->ev1) == hipSuccess)
                         b->info.rest_ms = ms;
@@ -1957,7 +2089,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 HIP_TRY(hipMemcpy(b->h_counts.data(), b->d_counts, b->tasks.size() * 4, hipMemcpyDeviceToHost));
         uint64_t m = 0;
         b->h_query_counts.assign(b->plan.size(), 0);
-        uint64_t m_dense = 0, m_fused = 0, out_fused = 0;
+        uint64_t m_dense = 0, m_fused = 0, out_fused = 0, out_planes = 0;
         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                 const DevQuery &q = b->plan[sidx];
                 for (uint32_t t = 0; t < q.ntasks; ++t)
@@ -1966,12 +2098,16 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_DENSE)
                         m_dense += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind >= TASK_FUSED) {
-                        m_fused += b->h_query_counts[sidx];
-                        out_fused += q.out_cap ? 4 * b->h_query_counts[sidx] : 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk); // (docIDs of a DocumentsOnly general tree)
+                        m_fused += b->h_query_counts[sidx]; // (every one-pass kind, k_planes' included)
+                        (b->tasks[q.first_task].kind == TASK_PLANES ? out_planes : out_fused) +=
+                                q.out_cap ? 4 * b->h_query_counts[sidx] : 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk); // (docIDs of a DocumentsOnly general tree)
                 }
         }
         b->info.dense_algorithmic_bytes = b->term_bytes_dense + 4 * m_dense;
-        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_fused - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_fused);
+        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_fused - b->term_bytes_planes - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_fused);
+        b->info.planes_algorithmic_bytes = b->term_bytes_planes + out_planes; // docbytes + 8 B x min(matches, K), per query — the lists
+                                                                              // the batch's queries share are nevertheless decoded once per launch
+        b->info.term_planes_decoded_bytes = b->plane_decoded_bytes;
         b->info.phrase_algorithmic_bytes = b->term_bytes_phrase_hits; // what k_phrase streams by the SURVEY §8(d) count: the hit bytes of the phrases' terms
         b->info.phrase_queries = 0;
         for (const DevQuery &q : b->plan)
@@ -2178,7 +2314,7 @@ extern "C" int tri_batch_docset_hashes(tri_batch *b, uint64_t *hashes) {
         tri_dev *dev = b->ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
         const uint32_t n = (uint32_t)b->plan.size();
-        if ((b->n_fused + b->n_fused16 + b->n_fusedgen) && (b->flags & TRI_FLAG_ACCUMULATED_SCORE)) // (DocumentsOnly: the one-pass kernel's tasks wrote their matches)
+        if ((b->n_fused + b->n_fused16 + b->n_fusedgen + b->n_planes) && (b->flags & TRI_FLAG_ACCUMULATED_SCORE)) // (DocumentsOnly: the one-pass kernel's tasks wrote their matches)
                 return fail(TRI_ERR_INVALID, "the batch holds queries that ran through the one-pass scored kernel: their docID sets are not materialised");
         std::vector<uint64_t> h(n);
         if (n) {
@@ -2527,14 +2663,16 @@ extern "C" int tri_gather_results(tri_batch *b, tri_comm *c, void *counts_all, v
 // Codecs::Google::Encoder (google_codec.cpp:9-176) on the device: postings in, the segment's `index` bytes and term table out —
 // byte for byte what the reference's encoder writes for the same begin_term / begin_document / new_hit / end_document / end_term
 // calls (payload-less hits).  See k_encode.hpp.
-extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint64_t *term_first, size_t nterms,
-                                 uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out) {
+extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first,
+                                 size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out) {
         if (!dev || !term_first || !index_len || (nterms && !terms_out))
                 return fail(TRI_ERR_INVALID, "tri_encode_google: null argument");
         HIP_TRY(hipSetDevice(dev->device));
         const uint64_t np = nterms ? term_first[nterms] : 0;
         if (np && (!docs || !freqs))
                 return fail(TRI_ERR_INVALID, "tri_encode_google: null postings");
+        if (npositions && !positions)
+                return fail(TRI_ERR_INVALID, "tri_encode_google: null positions");
         // ---- host: the block structure (which block belongs to which term) and input validation
         std::vector<uint32_t> blk_first(nterms + 1, 0), blk_term;
         uint64_t nhits = 0;
@@ -2549,6 +2687,16 @@ extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint3
                         if (!docs[p] || docs[p] <= prev)
                                 return fail(TRI_ERR_INVALID, "term %zu: document IDs must be > 0 and strictly ascending (codecs.h:188-190)", t);
                         prev = docs[p];
+                        // the posting's hits: positions[nhits .. nhits + freqs[p]) — counted hits only (new_hit drops a payload-less hit at
+                        // position 0, google_codec.cpp:42-45), non-descending within the document (:49: the encoder writes pos - lastPos)
+                        if ((uint64_t)freqs[p] > npositions - std::min<uint64_t>(npositions, nhits))
+                                return fail(TRI_ERR_INVALID, "term %zu, document %u: freqs[] asks for more positions than the %zu given", t, docs[p], npositions);
+                        uint32_t last_pos = 0;
+                        for (uint64_t h = nhits; h < nhits + freqs[p]; ++h) {
+                                if (!positions[h] || positions[h] < last_pos)
+                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: positions must be > 0 and non-descending within a document (google_codec.cpp:42-49)", t, docs[p]);
+                                last_pos = positions[h];
+                        }
                         nhits += freqs[p];
                 }
                 const uint64_t nb = (n + 31) / 32;
@@ -2557,8 +2705,6 @@ extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint3
                 blk_first[t + 1] = blk_first[t] + (uint32_t)nb;
                 blk_term.insert(blk_term.end(), (size_t)nb, (uint32_t)t);
         }
-        if (nhits && !positions)
-                return fail(TRI_ERR_INVALID, "tri_encode_google: null positions");
         const uint32_t nblocks = blk_first[nterms];
         struct Bufs {
                 uint32_t *docs = nullptr, *freqs = nullptr, *blk_first = nullptr, *blk_term = nullptr, *sizes = nullptr, *tails = nullptr;

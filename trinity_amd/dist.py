@@ -54,19 +54,23 @@ def device_blocks(batch, device):
 
 
 class ResultGather:
-    """The per-step result exchange: every rank contributes the same named fixed-shape blocks; step() all_gathers each into
-    preallocated per-rank receive buffers and returns {name: [tensor of rank 0, tensor of rank 1, …]}."""
+    """The per-step result exchange: every rank contributes the same named fixed-shape blocks; step() gathers each with ONE
+    all_gather_into_tensor into a preallocated [world, ...] receive tensor (no per-rank list, no copies on either side) and returns
+    {name: tensor[world, ...]} — row r is rank r's block."""
 
     def __init__(self, dist, blocks):
         import torch
 
         self.dist, self.blocks = dist, dict(blocks)
         self.world = dist.get_world_size()
-        self.recv = {name: [torch.empty_like(t) for _ in range(self.world)] for name, t in self.blocks.items()}
+        # (the receive tensor in its concatenated form [world * n, ...] — the one layout every backend's all_gather_into_tensor takes —
+        #  and, over the same memory, the [world, n, ...] view callers index by rank)
+        self._flat = {name: torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for name, t in self.blocks.items()}
+        self.recv = {name: f.view((self.world,) + tuple(self.blocks[name].shape)) for name, f in self._flat.items()}
 
     def step(self):
         for name, t in self.blocks.items():
-            self.dist.all_gather(self.recv[name], t)
+            self.dist.all_gather_into_tensor(self._flat[name], t)
         return self.recv
 
     def global_order(self, name):

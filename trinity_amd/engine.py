@@ -66,6 +66,13 @@ class TriBatchInfo(C.Structure):
         ("pad_", C.c_float),
         ("phrase_algorithmic_bytes", C.c_uint64),
         ("phrase_queries", C.c_uint64),
+        ("term_planes_ms", C.c_float),
+        ("planes_ms", C.c_float),
+        ("planes_algorithmic_bytes", C.c_uint64),
+        ("planes_queries", C.c_uint64),
+        ("plane_terms", C.c_uint64),
+        ("plane_bytes", C.c_uint64),
+        ("term_planes_decoded_bytes", C.c_uint64),
     ]
 
 
@@ -129,7 +136,7 @@ def hip_lib():
     L.tri_cbatch_match_counts.argtypes = [vp, vp]
     L.tri_cbatch_topk.argtypes = [vp, vp, vp, vp]
     L.tri_cbatch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
-    L.tri_encode_google.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.tri_encode_google.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_comm_unique_id.argtypes = [vp]
     L.tri_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.tri_comm_destroy.argtypes = [vp]
@@ -242,9 +249,9 @@ class Device:
         terms = np.zeros((max(n, 1), 3), dtype=np.uint32)
         ln = C.c_size_t()
         L = hip_lib()
-        _check(L.tri_encode_google(self.h, d.ctypes.data, f.ctypes.data, p.ctypes.data, tf.ctypes.data, n, None, 0, C.byref(ln), terms.ctypes.data))
+        _check(L.tri_encode_google(self.h, d.ctypes.data, f.ctypes.data, p.ctypes.data, p.size, tf.ctypes.data, n, None, 0, C.byref(ln), terms.ctypes.data))
         out = np.zeros(max(1, ln.value), dtype=np.uint8)
-        _check(L.tri_encode_google(self.h, d.ctypes.data, f.ctypes.data, p.ctypes.data, tf.ctypes.data, n, out.ctypes.data, out.size, C.byref(ln), terms.ctypes.data))
+        _check(L.tri_encode_google(self.h, d.ctypes.data, f.ctypes.data, p.ctypes.data, p.size, tf.ctypes.data, n, out.ctypes.data, out.size, C.byref(ln), terms.ctypes.data))
         return out[: ln.value], terms[:n]
 
     def close(self):
