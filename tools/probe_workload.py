@@ -13,11 +13,17 @@ import trinity_amd.engine as E
 name = os.environ.get("WORKLOAD", "cfg3")
 D, V, NQ = int(os.environ.get("DOCS", 10_000_000)), int(os.environ.get("VOCAB", 1_000_000)), int(os.environ.get("NQ", 2048))
 progs, flags, topk, codec, desc = W.build(name, D, V, 10, 42, NQ)  # single-part workloads (cfg5 runs as two batches: bench.py)
+if os.environ.get("ONLY"):  # cfg3's query classes alone: ONLY=0 `A B (C|D|E)`, 1 `(A|B) (C|D) E`, 2 `A B C D E`, 3 `A|B|C|D|E`
+    keep = int(os.environ["ONLY"])
+    progs = [p for i, p in enumerate(progs) if (i & 3) == keep]
+    desc += f" [class {keep} only: {len(progs)} queries]"
 if os.environ.get("CODEC"):
     codec = int(os.environ["CODEC"])
     desc += f" [codec forced to {codec}]"
 seg = T.Segment(D, V, 10, 42, codec=codec)
 dev = T.Device(0)
+for kv in filter(None, os.environ.get("OPTIONS", "").split(",")):  # OPTIONS="planes=0,fused_task_cost=1048576"
+    dev.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 ix = T.Index.from_segment(dev, seg)
 if os.environ.get("RICH"):
     flags, topk = T.FLAG_MATCHED_TERMS, 0
@@ -33,4 +39,5 @@ L = E.hip_lib()
 if hasattr(L, "tri_debug_prof"):
     buf = (C.c_uint64 * 32)(); L.tri_debug_prof(buf); v = list(buf)[:16]; tot = sum(v) or 1
     print("  prof " + " ".join(f"p{i}={x / tot * 100:.1f}%" for i, x in enumerate(v) if x), f"(total {tot:.3e} cycles)")
-print(f"{desc}: {NQ} queries {best:.2f} ms  matches {inf['matches']:.3e}  alg {inf['algorithmic_bytes'] / best / 1e6:.1f} GB/s  {NQ / best * 1e3:.0f} q/s")
+print("  " + " ".join(f"{k}={inf[k]:.3f}" for k in ("term_planes_ms", "dense_ms", "cand_ms", "fused_ms", "planes_ms", "phrase_ms", "rest_ms")), f"fused_q={inf['fused_queries']} planes_q={inf['planes_queries']} cand_q={inf['cand_queries']} plane_terms={inf['plane_terms']}")
+print(f"{desc}: {len(progs)} queries {best:.2f} ms  matches {inf['matches']:.3e}  alg {inf['algorithmic_bytes'] / best / 1e6:.1f} GB/s  {NQ / best * 1e3:.0f} q/s")

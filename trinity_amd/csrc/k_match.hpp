@@ -637,6 +637,82 @@ __device__ __forceinline__ void dense_pass(DenseShared &sh, const uint8_t *__res
         PROF_LAP(5);
 }
 
+// The window's survivors bitmap (A, with the last group still in B when `fold`: ANDed in, or removed when `neg`) expanded into
+// ascending docIDs at qout[produced ..]; both bitmaps are left zeroed.  Returns the window's match count (uniform).
+template <int WG>
+__device__ __forceinline__ uint32_t dense_expand(DenseShared &sh, const uint32_t w0, const bool fold, const bool neg, const uint32_t *__restrict__ masked,
+                                                 uint32_t *__restrict__ qout, const uint32_t produced PROF_ARG) {
+        const uint32_t tid = threadIdx.x;
+        uint32_t window_total = 0;
+        // ---- expand the survivors bitmap into ascending docIDs
+        uint32_t *fin = sh.bm;
+        uint32_t *pre = sh.bm + BM_STRIDE; // B dies word by word as it is folded in: per-word exclusive prefix takes its place
+        {
+                uint32_t run = 0;
+                for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
+                        const uint32_t wi = bm_pad(tid * (SPAN_WORDS / WG) + j);
+                        uint32_t m = fin[wi];
+                        if (fold)
+                                m &= neg ? ~pre[wi] : pre[wi]; // the last group is the one still in B; an excluded group removes
+                        if (masked) // masked_documents_registry::test (docidupdates.h:90-119): updated / deleted elsewhere
+                                m &= ~masked[w0 / 32 + tid * (SPAN_WORDS / WG) + j];
+                        fin[wi] = m;
+                        pre[wi] = run;
+                        run += __popc(m);
+                }
+                uint32_t wtot;
+                const uint32_t ex = wave_excl_scan(run, wtot);
+                sh.scan[tid >> 6] = wtot;
+                __syncthreads();
+                uint32_t wbase = 0, total = 0;
+                for (int wv = 0; wv < WG / 64; ++wv) {
+                        if (wv < (int)(tid >> 6))
+                                wbase += sh.scan[wv];
+                        total += sh.scan[wv];
+                }
+                sh.tbase[tid] = ex + wbase;
+                __syncthreads();
+                PROF_LAP(6);
+                // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
+                // (both bitmaps are left zeroed for the next window as they are read)
+                if (uni(total) >= SPAN_BITS / 8) {
+                        // dense result (a union of head terms): one lane per BIT.  Each wave walks its own 512 words, 64 bits at
+                        // a time: ballot, rank by mbcnt, one coalesced store per step.  (Lane-per-word stores of a dense window
+                        // hit 64 different cache lines per instruction.)
+                        const uint32_t lane = tid & 63u, wv = tid >> 6;
+                        uint32_t o = produced + sh.tbase[wv * 64]; // matches before this wave's first word
+                        for (uint32_t c = 0; c < SPAN_WORDS / (WG / 64) / 2; ++c) {
+                                const uint32_t wi = wv * (SPAN_WORDS / (WG / 64)) + 2 * c + (lane >> 5);
+                                const bool bit = (fin[bm_pad(wi)] >> (lane & 31u)) & 1u;
+                                const uint64_t m = __ballot(bit);
+                                if (bit)
+                                        qout[o + __popcll(m & ((1ull << lane) - 1ull))] = w0 + wi * 32 + (lane & 31u);
+                                o += (uint32_t)__popcll(m);
+                        }
+                        __syncthreads();
+                        for (uint32_t i = tid; i < 2 * BM_STRIDE; i += WG)
+                                sh.bm[i] = 0;
+                } else
+                for (uint32_t wi = tid; wi < SPAN_WORDS; wi += WG) {
+                        const uint32_t pw = bm_pad(wi);
+                        uint32_t m = fin[pw];
+                        uint32_t ob = (produced + sh.tbase[wi / (SPAN_WORDS / WG)] + pre[pw]) * 4u; // byte offset: uniform base + 32-bit lane offset
+                        fin[pw] = 0;
+                        pre[pw] = 0;
+                        const uint32_t base = w0 + wi * 32;
+                        while (m) {
+                                *(uint32_t *)((uint8_t *)qout + ob) = base + (uint32_t)__builtin_ctz(m);
+                                ob += 4;
+                                m &= m - 1;
+                        }
+                }
+                window_total = uni(total);
+                __syncthreads();
+                PROF_LAP(7);
+        }
+        return window_total;
+}
+
 template <int WG, int CODEC>
 __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                            const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
@@ -660,6 +736,52 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                 sh.seg_plane[kk] = qplane ? qplane[q.term_base + kk] : PL_NONE;
         }
         __syncthreads();
+        // ---- every term of the query has a plane (k_term_planes decoded the lists once for the whole batch): a window's matches are
+        //      word-wise algebra over plane words held in registers — OR inside a group, AND across groups, AND-NOT for the excluded
+        //      group — eight words per thread, no rows, no directory, no set pass; the expansion is the usual one
+        bool allp = planes != nullptr;
+        for (uint32_t k = 0; k < q.nterms; ++k)
+                allp &= uni(sh.seg_plane[k]) != PL_NONE;
+        if (allp) {
+                constexpr uint32_t PER = SPAN_WORDS / WG;
+                static_assert(PER == 8, "two 16-byte loads per thread and term");
+                for (uint32_t w = task.tile_begin; w < task.tile_end; ++w) {
+                        const uint32_t w0 = w * SPAN_BITS;
+                        uint32_t acc[PER], grp[PER];
+                        bool have_acc = false, cur_neg = false;
+#pragma unroll
+                        for (uint32_t j = 0; j < PER; ++j)
+                                acc[j] = grp[j] = 0;
+                        for (uint32_t k = 0; k <= q.nterms; ++k) {
+                                const uint32_t tt = k < q.nterms ? uni(sh.seg_tt[k]) : QT_GROUP; // (k == nterms: the last group is folded in)
+                                if (k && (tt & QT_GROUP)) {
+#pragma unroll
+                                        for (uint32_t j = 0; j < PER; ++j) {
+                                                acc[j] = !have_acc ? grp[j] : cur_neg ? acc[j] & ~grp[j] : acc[j] & grp[j];
+                                                grp[j] = 0;
+                                        }
+                                        have_acc = true;
+                                }
+                                if (k == q.nterms)
+                                        break;
+                                if (tt & QT_GROUP)
+                                        cur_neg = tt & QT_NOT;
+                                const uint4 *pa = (const uint4 *)(planes + (size_t)uni(sh.seg_plane[k]) * 2 * plw + (w0 >> 5) + tid * PER);
+                                const uint4 v0 = pa[0], v1 = pa[1];
+                                grp[0] |= v0.x, grp[1] |= v0.y, grp[2] |= v0.z, grp[3] |= v0.w;
+                                grp[4] |= v1.x, grp[5] |= v1.y, grp[6] |= v1.z, grp[7] |= v1.w;
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < PER; ++j)
+                                sh.bm[bm_pad(tid * PER + j)] = acc[j]; // (this thread's own words: dense_expand reads them back first)
+                        produced += dense_expand<WG>(sh, w0, false, false, masked, qout, produced PROF_PASS);
+                }
+                __syncthreads();
+                if (uni(tid >> 6) == 0)
+                        *count_out = produced;
+                PROF_LAP(8);
+                return;
+        }
         // number of terms in the lead group (it creates the candidates; the other groups test them)
         uint32_t nlead = 1;
         while (nlead < q.nterms && !(uni(sh.seg_tt[nlead]) & QT_GROUP))
@@ -793,72 +915,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                         dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, kb, ke, kb, w0, planes, plw PROF_PASS);
                         kb = ke;
                 }
-                // ---- expand the survivors bitmap into ascending docIDs
-                uint32_t *fin = sh.bm;
-                uint32_t *pre = sh.bm + BM_STRIDE; // B dies word by word as it is folded in: per-word exclusive prefix takes its place
-                {
-                        uint32_t run = 0;
-                        for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
-                                const uint32_t wi = bm_pad(tid * (SPAN_WORDS / WG) + j);
-                                uint32_t m = fin[wi];
-                                if (ngroups > 1)
-                                        m &= neg ? ~pre[wi] : pre[wi]; // the last group is the one still in B; an excluded group removes
-                                if (masked) // masked_documents_registry::test (docidupdates.h:90-119): updated / deleted elsewhere
-                                        m &= ~masked[w0 / 32 + tid * (SPAN_WORDS / WG) + j];
-                                fin[wi] = m;
-                                pre[wi] = run;
-                                run += __popc(m);
-                        }
-                        uint32_t wtot;
-                        const uint32_t ex = wave_excl_scan(run, wtot);
-                        sh.scan[tid >> 6] = wtot;
-                        __syncthreads();
-                        uint32_t wbase = 0, total = 0;
-                        for (int wv = 0; wv < WG / 64; ++wv) {
-                                if (wv < (int)(tid >> 6))
-                                        wbase += sh.scan[wv];
-                                total += sh.scan[wv];
-                        }
-                        sh.tbase[tid] = ex + wbase;
-                        __syncthreads();
-                        PROF_LAP(6);
-                        // word-strided sweep: neighbouring lanes own neighbouring words, so a wave's stores stay together
-                        // (both bitmaps are left zeroed for the next window as they are read)
-                        if (uni(total) >= SPAN_BITS / 8) {
-                                // dense result (a union of head terms): one lane per BIT.  Each wave walks its own 512 words, 64 bits at
-                                // a time: ballot, rank by mbcnt, one coalesced store per step.  (Lane-per-word stores of a dense window
-                                // hit 64 different cache lines per instruction.)
-                                const uint32_t lane = tid & 63u, wv = tid >> 6;
-                                uint32_t o = produced + sh.tbase[wv * 64]; // matches before this wave's first word
-                                for (uint32_t c = 0; c < SPAN_WORDS / (WG / 64) / 2; ++c) {
-                                        const uint32_t wi = wv * (SPAN_WORDS / (WG / 64)) + 2 * c + (lane >> 5);
-                                        const bool bit = (fin[bm_pad(wi)] >> (lane & 31u)) & 1u;
-                                        const uint64_t m = __ballot(bit);
-                                        if (bit)
-                                                qout[o + __popcll(m & ((1ull << lane) - 1ull))] = w0 + wi * 32 + (lane & 31u);
-                                        o += (uint32_t)__popcll(m);
-                                }
-                                __syncthreads();
-                                for (uint32_t i = tid; i < 2 * BM_STRIDE; i += WG)
-                                        sh.bm[i] = 0;
-                        } else
-                        for (uint32_t wi = tid; wi < SPAN_WORDS; wi += WG) {
-                                const uint32_t pw = bm_pad(wi);
-                                uint32_t m = fin[pw];
-                                uint32_t ob = (produced + sh.tbase[wi / (SPAN_WORDS / WG)] + pre[pw]) * 4u; // byte offset: uniform base + 32-bit lane offset
-                                fin[pw] = 0;
-                                pre[pw] = 0;
-                                const uint32_t base = w0 + wi * 32;
-                                while (m) {
-                                        *(uint32_t *)((uint8_t *)qout + ob) = base + (uint32_t)__builtin_ctz(m);
-                                        ob += 4;
-                                        m &= m - 1;
-                                }
-                        }
-                        produced += uni(total);
-                        __syncthreads();
-                        PROF_LAP(7);
-                }
+                produced += dense_expand<WG>(sh, w0, ngroups > 1, neg, masked, qout, produced PROF_PASS);
                 ++w;
         }
         __syncthreads();
@@ -868,8 +925,11 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
 }
 
 // bitmap-window tasks: persistent 512-thread workgroups draw TASK_DENSE tasks, heaviest first
+#ifndef TRI_DENSE_WAVES
+#define TRI_DENSE_WAVES 8 // waves per SIMD the register budget is cut for (8: 64 VGPRs, four 512-thread workgroups per CU)
+#endif
 template <int CODEC>
-__global__ __launch_bounds__(DENSE_WG, 8) void k_and_dense(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
+__global__ __launch_bounds__(DENSE_WG, TRI_DENSE_WAVES) void k_and_dense(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                         const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
                                                         const DevTerm *__restrict__ terms, const DevQuery *__restrict__ plan,
                                                         const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched,

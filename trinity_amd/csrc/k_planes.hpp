@@ -122,11 +122,12 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
 //   * per task: min(matches, k) ranked (docID, score) pairs and the match count; k_topk_merge folds a query's tasks.
 constexpr int PLK_WG = 512;
 constexpr uint32_t PLK_MAX_SPARSE = 6;  // slots whose lists are decoded per window (LDS planes); the planner sends wider queries to k_fused
-constexpr uint32_t PLK_CAP = 1024;      // candidate buffer
-constexpr uint32_t PLK_PRUNE_AT = 512;  // pruned to the best k when it holds more than this (a scoring round adds at most PLK_WG)
+constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per thread when it is pruned)
+constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
+constexpr uint32_t PLK_MAXPAT = 24;     // minimal slot sets of the candidate filter kept as such (more: the essential-slot filter)
 constexpr uint32_t PLK_WGS_PER_CU = 2;
 static_assert(PL_WORDS == 2 * PLK_WG, "the sweep gives every thread two words of the window");
-static_assert(PLK_PRUNE_AT + PLK_WG <= PLK_CAP && TOPK_MAX <= PLK_PRUNE_AT, "a round of newcomers always fits");
+static_assert(PLK_CAP == PLK_WG && TOPK_MAX < PLK_PRUNE_AT && PLK_PRUNE_AT < PLK_CAP, "pruning leaves room; a pruned buffer is below the stop mark");
 
 struct PlanesShared {
         uint32_t pl[PLK_MAX_SPARSE][2 * PL_STRIDE]; // per decoded slot: plane A, plane B (word PL_WORDS of each: sink)
@@ -137,7 +138,10 @@ struct PlanesShared {
         double ub[FUS_MAX_SLOTS];   // per slot: an upper bound of what they add at any frequency
         double thr_s;
         uint32_t thr_d;
-        uint32_t tk_n, tk_full, matches, ess; // ess: the essential slots (bit set)
+        uint32_t tk_n, tk_full, matches, ess; // ess: the slots whose frequencies are worth decoding (they sit in a set of the candidate filter)
+        uint32_t npat;                        // the candidate filter: 0xffffffff = every match (no threshold yet), else that many slot sets
+        uint32_t pat[PLK_MAXPAT];             // ... a match is a candidate when it holds every slot of one of them
+        uint32_t flag[PLK_WG / 64];
         uint32_t bcast[4];
         uint32_t rng_lo[2][FUS_MAX_SLOTS], rng_cnt[2][FUS_MAX_SLOTS]; // per window parity: the decoded slots' row ranges
         uint32_t alive[2];                                             // ... and the slots whose lists are not exhausted
@@ -166,33 +170,24 @@ struct PlanePostH {
         }
 };
 
-// Keep the best k of the n (<= PLK_CAP) buffered candidates, best first (rank by counting; two entries per thread).
+// Keep the best k of the n (<= PLK_CAP = PLK_WG) buffered candidates, best first (rank by counting: the order is strict).
 __device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t k) {
         const uint32_t tid = threadIdx.x;
-        double es[2];
-        uint32_t ed[2], rk[2];
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-                const uint32_t i = tid + r * PLK_WG;
-                rk[r] = 0xffffffffu;
-                es[r] = 0;
-                ed[r] = 0;
-                if (i < n) {
-                        es[r] = sh.tk_s[i];
-                        ed[r] = sh.tk_d[i];
-                        uint32_t c = 0;
-                        for (uint32_t j = 0; j < n; ++j)
-                                c += better(sh.tk_s[j], sh.tk_d[j], es[r], ed[r]) ? 1u : 0u;
-                        rk[r] = c;
-                }
+        double es = 0;
+        uint32_t ed = 0, rk = 0xffffffffu;
+        if (tid < n) {
+                es = sh.tk_s[tid];
+                ed = sh.tk_d[tid];
+                uint32_t c = 0;
+                for (uint32_t j = 0; j < n; ++j)
+                        c += better(sh.tk_s[j], sh.tk_d[j], es, ed) ? 1u : 0u;
+                rk = c;
         }
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-                if (rk[r] < k) {
-                        sh.tk_s[rk[r]] = es[r];
-                        sh.tk_d[rk[r]] = ed[r];
-                }
+        if (rk < k) {
+                sh.tk_s[rk] = es;
+                sh.tk_d[rk] = ed;
+        }
         __syncthreads();
         const uint32_t m = n < k ? n : k;
         // uniform stores by every lane
@@ -226,6 +221,57 @@ __device__ __forceinline__ uint32_t planes_essential(const PlanesShared &sh, con
                         ess |= 1u << best;
         }
         return ess;
+}
+
+// The candidate filter, recomputed whenever the threshold moves (every thread calls it; it ends with a barrier).  A document's score
+// is at most the sum of the bounds of the slots it holds, so only a match whose slot set's bounds reach the current k-th best score can
+// enter the top-K: the MINIMAL such sets (no slot can be dropped) are listed, and a match is a candidate iff it holds every slot of
+// one of them — an OR of ANDs over the slots' A words, 32 documents per instruction.  (MaxScore's "holds an essential slot" is the
+// weaker test this replaces; it stays as the fallback when the list would be long.)  No threshold yet: every match is a candidate.
+__device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
+        const uint32_t tid = threadIdx.x;
+        const double thr = sh.thr_s;
+        const bool full = uni(sh.tk_full) != 0 && 0.0 < thr; // (a threshold of zero or less rules nothing out)
+        sh.npat = full ? 0u : 0xffffffffu; // (uniform stores)
+        sh.ess = (1u << nslots) - 1u;
+        __syncthreads();
+        if (!full)
+                return;
+        if (tid && tid < (1u << nslots)) {
+                auto reaches = [&](const uint32_t p) {
+                        double sum = 0.0;
+                        for (uint32_t sl = 0; sl < nslots; ++sl)
+                                if ((p >> sl) & 1u)
+                                        sum += sh.ub[sl];
+                        return !(sum < thr);
+                };
+                bool minimal = reaches(tid);
+                for (uint32_t sl = 0; sl < nslots && minimal; ++sl)
+                        if (((tid >> sl) & 1u) && reaches(tid & ~(1u << sl)))
+                                minimal = false;
+                if (minimal) {
+                        const uint32_t at = atomicAdd(&sh.npat, 1u);
+                        if (at < PLK_MAXPAT)
+                                sh.pat[at] = tid;
+                }
+        }
+        __syncthreads();
+        uint32_t np = uni(sh.npat);
+        if (np > PLK_MAXPAT) { // too many sets: the essential slots, one set each (a weaker filter, never a wrong one)
+                const uint32_t e = planes_essential(sh, nslots);
+                __syncthreads(); // (every lane has read npat)
+                np = 0;
+                for (uint32_t sl = 0; sl < nslots; ++sl)
+                        if ((e >> sl) & 1u)
+                                sh.pat[np++] = 1u << sl; // (uniform stores)
+                sh.npat = np;
+                __syncthreads();
+        }
+        uint32_t need = 0;
+        for (uint32_t i = 0; i < np; ++i)
+                need |= sh.pat[i];
+        sh.ess = uni(need);
+        __syncthreads();
 }
 
 template <int CODEC>
@@ -281,7 +327,8 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.tk_n = 0;
                         sh.tk_full = 0;
                         sh.matches = 0;
-                        sh.ess = (1u << nslots) - 1u; // no threshold yet: every slot is essential
+                        sh.ess = (1u << nslots) - 1u; // no threshold yet: every slot's frequencies are wanted ...
+                        sh.npat = 0xffffffffu;        // ... and every match is a candidate
                 }
                 __syncthreads();
                 // ---- per task, uniform: which slots read term planes, where the others' LDS planes are, which slots score
@@ -501,20 +548,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 m0 &= x0;
                                 m1 &= x1;
                         }
-                        uint32_t e0 = 0, e1 = 0;
                         {
                                 uint32_t n0 = 0, n1 = 0;
 #pragma unroll
-                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
                                         if ((negs >> s) & 1u) {
                                                 n0 |= a0[s];
                                                 n1 |= a1[s];
                                         }
-                                        if ((ess >> s) & 1u) {
-                                                e0 |= a0[s];
-                                                e1 |= a1[s];
-                                        }
-                                }
                                 m0 &= ~n0;
                                 m1 &= ~n1;
                         }
@@ -523,9 +564,30 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 m1 &= ~masked[(w0 >> 5) + tid + PLK_WG];
                         }
                         my_matches += (uint32_t)(__popc(m0) + __popc(m1));
-                        e0 &= m0;
-                        e1 &= m1;
-                        // words nobody will score are cleared now (the decoded slots' planes of this window: A and B)
+                        // ---- the matches that can still enter the top-K: the candidate filter, word-wise (planes_filter)
+                        auto candidates = [&](uint32_t &c0, uint32_t &c1) { // (ANDed into c0 / c1)
+                                const uint32_t np = uni(sh.npat);
+                                if (np == 0xffffffffu)
+                                        return;
+                                uint32_t y0 = 0, y1 = 0;
+                                for (uint32_t i = 0; i < np; ++i) {
+                                        const uint32_t ps = uni(sh.pat[i]);
+                                        uint32_t x0 = 0xffffffffu, x1 = 0xffffffffu;
+#pragma unroll
+                                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                                if ((ps >> s) & 1u) {
+                                                        x0 &= a0[s];
+                                                        x1 &= a1[s];
+                                                }
+                                        y0 |= x0;
+                                        y1 |= x1;
+                                }
+                                c0 &= y0;
+                                c1 &= y1;
+                        };
+                        uint32_t c0 = m0, c1 = m1;
+                        candidates(c0, c1);
+                        // the decoded slots' words of this window (A and B) are cleared by their owner as soon as it has no candidate left in them
                         auto clear_mine = [&]() {
 #pragma unroll
                                 for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
@@ -537,27 +599,24 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 p[PL_STRIDE + tid + PLK_WG] = 0;
                                         }
                         };
-                        const bool mine = (e0 | e1) != 0;
-                        if (!mine)
-                                clear_mine();
+                        bool cleared = false;
                         PROF_LAP(4);
-                        if (uni((uint32_t)__syncthreads_or(mine ? 1 : 0))) {
-                                // ---- scoring rounds: every lane takes one of its essential matches at a time
-                                uint32_t cur_ess = ess;
+                        for (;;) {
+                                // ---- every wave works its own candidates off, one per lane and step, no workgroup barrier: the known part of the
+                                //      score (frequency 1: the slot's table), a bound for the rest, the exact frequencies from the postings only when
+                                //      the bound does not rule the document out
+                                const bool full = uni(sh.tk_full) != 0;
+                                const double thr_s = sh.thr_s;
+                                const uint32_t thr_d = sh.thr_d;
                                 for (;;) {
-                                        const bool has = (e0 | e1) != 0;
-                                        if (!uni((uint32_t)__syncthreads_or(has ? 1 : 0)))
+                                        const bool has = (c0 | c1) != 0;
+                                        if (__builtin_amdgcn_ballot_w64(has) == 0ull)
                                                 break;
-                                        const bool full = uni(sh.tk_full) != 0;
-                                        const double thr_s = sh.thr_s;
-                                        const uint32_t thr_d = sh.thr_d;
+                                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
+                                                break; // the buffer wants pruning first (the candidates stay where they are)
                                         if (has) {
-                                                const uint32_t which = e0 ? 0u : 1u;
-                                                const uint32_t bit = (uint32_t)__builtin_ctz(which ? e1 : e0);
-                                                if (which)
-                                                        e1 &= e1 - 1u;
-                                                else
-                                                        e0 &= e0 - 1u;
+                                                const uint32_t which = c0 ? 0u : 1u;
+                                                const uint32_t bit = (uint32_t)__builtin_ctz(which ? c1 : c0);
                                                 const uint32_t wi = tid + which * PLK_WG, doc = w0 + 32u * wi + bit;
                                                 double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known yet
                                                 uint32_t unk = 0;
@@ -595,41 +654,52 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                         }
                                                         take = !full || better(sk, doc, thr_s, thr_d);
                                                 }
+                                                bool done = true;
                                                 if (take) {
-                                                        const uint32_t slot = atomicAdd(&sh.tk_n, 1u); // (a round adds at most PLK_WG: always room)
-                                                        sh.tk_s[slot] = sk;
-                                                        sh.tk_d[slot] = doc;
+                                                        const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
+                                                        if (slot < PLK_CAP) {
+                                                                sh.tk_s[slot] = sk;
+                                                                sh.tk_d[slot] = doc;
+                                                        } else
+                                                                done = false; // no room: the candidate stays for after the prune
                                                 }
-                                        }
-                                        __syncthreads();
-                                        const uint32_t n = uni(sh.tk_n);
-                                        if (n > PLK_PRUNE_AT) {
-                                                planes_prune(sh, n, k);
-                                                const uint32_t ne = planes_essential(sh, nslots); // same value from every lane
-                                                sh.ess = ne;
-                                                if (ne != cur_ess) { // the threshold moved: matches that hold none of the remaining essential slots are out
-                                                        cur_ess = ne;
-                                                        uint32_t x0 = 0, x1 = 0;
-#pragma unroll
-                                                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
-                                                                if ((ne >> s) & 1u) {
-                                                                        x0 |= a0[s];
-                                                                        x1 |= a1[s];
-                                                                }
-                                                        e0 &= x0;
-                                                        e1 &= x1;
+                                                if (done) {
+                                                        if (which)
+                                                                c1 &= c1 - 1u;
+                                                        else
+                                                                c0 &= c0 - 1u;
                                                 }
                                         }
                                 }
-                                if (mine)
+                                const bool pending = (c0 | c1) != 0;
+                                if (!pending && !cleared) {
                                         clear_mine();
+                                        cleared = true;
+                                }
+                                sh.flag[wave] = __builtin_amdgcn_ballot_w64(pending) != 0ull ? 1u : 0u; // (wave-uniform value, every lane stores it)
                                 __syncthreads();
+                                uint32_t anyp = 0;
+#pragma unroll
+                                for (uint32_t wv = 0; wv < PLK_WG / 64; ++wv)
+                                        anyp |= sh.flag[wv];
+                                anyp = uni(anyp);
+                                const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
+                                if (n >= PLK_PRUNE_AT) {
+                                        __syncthreads(); // (every lane has read the flags and tk_n)
+                                        planes_prune(sh, n, k);
+                                        planes_filter(sh, nslots);
+                                        if (anyp)
+                                                candidates(c0, c1); // (the threshold moved: what is left is filtered again)
+                                } else if (anyp)
+                                        __syncthreads(); // (cannot happen — a wave only stops early at a full buffer —; kept so that a flag is never rewritten while read)
+                                if (!anyp)
+                                        break;
                         }
                         PROF_LAP(5);
                 }
                 // ---- the task's result: its best k (ranked) and its match count
                 __syncthreads();
-                planes_prune(sh, uni(sh.tk_n), k);
+                planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k);
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1)
                         my_matches += __shfl_xor(my_matches, d, 64);

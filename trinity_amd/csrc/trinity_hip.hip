@@ -1893,7 +1893,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 // GOOGLE: matching reads the contiguous delta streams, not the chunks (see tri_index::d_dstream)
                 const uint8_t *match_bytes = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_dstream : b->ix->d_index;
                 const uint32_t *match_off = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_blk_doff : b->ix->d_blk_off;
-                uint32_t dense_wgs = 2048 / DENSE_WG, cand_wgs = 4; // workgroups per CU
+                uint32_t dense_wgs = TRI_DENSE_WAVES * 256 / DENSE_WG, cand_wgs = 4; // workgroups per CU
                 bool overlap = false;
                 if (dev->opt.overlap_dense_wgs && dev->opt.overlap_cand_wgs && b->n_dense && b->n_cand) { // both kernels side by side
                         overlap = true;
