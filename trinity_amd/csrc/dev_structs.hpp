@@ -73,6 +73,7 @@ constexpr uint32_t TASK_FUSED16 = 3; // ... with 16-bit window words (<= 5 disti
 constexpr uint32_t TASK_FUSED_GEN = 4; // ... a general tree (truth-table predicate; DocumentsOnly: matches written to out[]): 32-bit window words
 constexpr uint32_t TASK_PLANES = 5;    // AccumulatedScoreScheme + top-K of a CNF query over BIT PLANES (k_planes.hpp): per slot a presence bit and an
                                        // "frequency is not 1" bit per document; windows of PL_W documents; tile_begin / tile_end count those windows
+constexpr uint32_t TASK_PLANES8 = 6;   // ... of a query with more than five slots (its own instantiation: more words held in registers)
 
 // ---- term planes: per batch LAUNCH, every head term the batch's queries share is decoded ONCE (k_term_planes) into two bitmaps over the
 //      docID space — A: the document holds the term, B: its frequency there is not 1 — which the matching kernels then read instead of

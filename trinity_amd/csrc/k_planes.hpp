@@ -115,17 +115,22 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
 //   * the predicate is word-wise: a required group = the OR of its slots' A words, the conjunction their AND, the excluded group an
 //     AND-NOT, masked documents (docidupdates.h:90-119) another — 32 documents per instruction; the match count is a popcount.
 //     (What docset_spans.cpp:98-173 / 681-790 do per document and docset_iterators.cpp:226-405 per posting.)
-//   * MaxScore, exact (as in k_fused): only matches that hold an ESSENTIAL slot can beat the current k-th best; they are scored one
-//     per lane: frequency 1 (B clear) comes from a per-slot table, anything else is looked up in the postings — after an upper
-//     bound (the known part + the slots' score bounds) has failed to rule the document out.  A slot that is not essential is
-//     decoded for presence only: its frequencies are never unpacked (the freqs group of a PFOR block is not even addressed).
+//   * the candidate filter is word-wise too.  A slot is at one of three LEVELS in a document: absent, frequency 1 (its scorers add
+//     exactly tab1), any other frequency (they add at most ub).  Whenever the threshold (the k-th best score so far) moves, the
+//     minimal level assignments whose bounds reach it are listed (planes_filter); a match is a candidate iff it meets one of them
+//     — an OR of ANDs over the slots' A / B words.  Matches whose frequencies are all 1 (most of them) are thereby tested against
+//     their EXACT score without ever being touched individually.  (This replaces MaxScore's "holds an essential slot".)
+//   * candidates are scored one per lane by the wave that owns their words, no workgroup barrier: levels from registers, the
+//     exact frequency of a level-2 slot from the postings (directory cell -> block -> walk) only when the bound does not rule the
+//     document out.  A slot no assignment needs is decoded for presence only: the freqs group of its PFOR blocks is not addressed.
 //   * per task: min(matches, k) ranked (docID, score) pairs and the match count; k_topk_merge folds a query's tasks.
 constexpr int PLK_WG = 512;
 constexpr uint32_t PLK_MAX_SPARSE = 6;  // slots whose lists are decoded per window (LDS planes); the planner sends wider queries to k_fused
 constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per thread when it is pruned)
 constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
-constexpr uint32_t PLK_MAXPAT = 24;     // minimal slot sets of the candidate filter kept as such (more: the essential-slot filter)
+constexpr uint32_t PLK_MAXPAT = 32;     // level assignments of the candidate filter kept as such (more: one per essential slot)
 constexpr uint32_t PLK_WGS_PER_CU = 2;
+constexpr uint32_t PLK_NS_SMALL = 5;    // the instantiation for queries of up to this many slots keeps four words per slot in registers
 static_assert(PL_WORDS == 2 * PLK_WG, "the sweep gives every thread two words of the window");
 static_assert(PLK_CAP == PLK_WG && TOPK_MAX < PLK_PRUNE_AT && PLK_PRUNE_AT < PLK_CAP, "pruning leaves room; a pruned buffer is below the stop mark");
 
@@ -136,11 +141,13 @@ struct PlanesShared {
         DevTerm term[FUS_MAX_SLOTS];
         double tab1[FUS_MAX_SLOTS]; // per slot: what its scorers add at frequency 1
         double ub[FUS_MAX_SLOTS];   // per slot: an upper bound of what they add at any frequency
+        double w1[FUS_MAX_SLOTS];   // per slot: tab1 rounded up a hair (the filter must never lose a tie to rounding)
         double thr_s;
         uint32_t thr_d;
-        uint32_t tk_n, tk_full, matches, ess; // ess: the slots whose frequencies are worth decoding (they sit in a set of the candidate filter)
-        uint32_t npat;                        // the candidate filter: 0xffffffff = every match (no threshold yet), else that many slot sets
-        uint32_t pat[PLK_MAXPAT];             // ... a match is a candidate when it holds every slot of one of them
+        uint32_t tk_n, tk_full, matches, ess; // ess: the slots whose frequencies are worth decoding (some assignment names them)
+        uint32_t leaf;                        // the slots that have a scorer
+        uint32_t npat;                        // the candidate filter: 0xffffffff = every match (no threshold yet), else that many assignments
+        uint32_t pat[PLK_MAXPAT];             // ... bits 0-7: slots at level >= 1, bits 8-15: slots at level 2
         uint32_t flag[PLK_WG / 64];
         uint32_t bcast[4];
         uint32_t rng_lo[2][FUS_MAX_SLOTS], rng_cnt[2][FUS_MAX_SLOTS]; // per window parity: the decoded slots' row ranges
@@ -200,10 +207,9 @@ __device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t 
         __syncthreads();
 }
 
-// MaxScore: the slots that can carry a document over the current k-th best (see fused_essential); a bit set, same value in every lane.
+// MaxScore's essential slots — the fallback filter: with the slots ordered by their score bound, the longest prefix whose bounds sum to
+// less than the k-th best cannot lift a document over it; a bit set of the OTHER slots, same value in every lane.
 __device__ __forceinline__ uint32_t planes_essential(const PlanesShared &sh, const uint32_t nslots) {
-        if (!uni(sh.tk_full))
-                return (1u << nslots) - 1u;
         const double thr = sh.thr_s;
         uint32_t done = 0, ess = 0;
         double p = 0.0;
@@ -223,41 +229,60 @@ __device__ __forceinline__ uint32_t planes_essential(const PlanesShared &sh, con
         return ess;
 }
 
-// The candidate filter, recomputed whenever the threshold moves (every thread calls it; it ends with a barrier).  A document's score
-// is at most the sum of the bounds of the slots it holds, so only a match whose slot set's bounds reach the current k-th best score can
-// enter the top-K: the MINIMAL such sets (no slot can be dropped) are listed, and a match is a candidate iff it holds every slot of
-// one of them — an OR of ANDs over the slots' A words, 32 documents per instruction.  (MaxScore's "holds an essential slot" is the
-// weaker test this replaces; it stays as the fallback when the list would be long.)  No threshold yet: every match is a candidate.
+// The candidate filter, recomputed whenever the threshold moves (every thread calls it; it ends with a barrier).  Every scoring slot is
+// at level 0 (absent), 1 (frequency 1: adds exactly tab1) or 2 (another frequency: adds at most ub >= tab1) in a document, so a
+// document's score is at most the sum of its slots' level weights.  The MINIMAL level assignments whose weights reach the current k-th
+// best score are listed (lowering any slot by one level drops below it); a match is a candidate iff it is at least at those levels for
+// one of them.  3^nslots assignments, a few per thread.  No threshold yet, or one that rules nothing out: every match is a candidate.
 __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         const uint32_t tid = threadIdx.x;
         const double thr = sh.thr_s;
-        const bool full = uni(sh.tk_full) != 0 && 0.0 < thr; // (a threshold of zero or less rules nothing out)
+        const bool full = uni(sh.tk_full) != 0 && 0.0 < thr;
+        const uint32_t leaf = uni(sh.leaf);
         sh.npat = full ? 0u : 0xffffffffu; // (uniform stores)
         sh.ess = (1u << nslots) - 1u;
         __syncthreads();
         if (!full)
                 return;
-        if (tid && tid < (1u << nslots)) {
-                auto reaches = [&](const uint32_t p) {
+        uint32_t total = 1;
+        for (uint32_t sl = 0; sl < nslots; ++sl)
+                total *= 3u;
+        for (uint32_t a = tid; a < total; a += PLK_WG) {
+                uint32_t lv[FUS_MAX_SLOTS], x = a;
+                bool valid = a != 0;
+                for (uint32_t sl = 0; sl < nslots; ++sl) {
+                        lv[sl] = x % 3u;
+                        x /= 3u;
+                        valid &= lv[sl] == 0 || ((leaf >> sl) & 1u); // (a slot without a scorer adds nothing at any level)
+                }
+                if (!valid)
+                        continue;
+                auto reaches = [&](const uint32_t lowered) { // (lowered: the slot taken down one level; nslots: none)
                         double sum = 0.0;
-                        for (uint32_t sl = 0; sl < nslots; ++sl)
-                                if ((p >> sl) & 1u)
-                                        sum += sh.ub[sl];
+                        for (uint32_t sl = 0; sl < nslots; ++sl) {
+                                const uint32_t l = lv[sl] - (sl == lowered ? 1u : 0u);
+                                sum += l == 2 ? sh.ub[sl] : l == 1 ? sh.w1[sl] : 0.0;
+                        }
                         return !(sum < thr);
                 };
-                bool minimal = reaches(tid);
+                bool minimal = reaches(nslots);
                 for (uint32_t sl = 0; sl < nslots && minimal; ++sl)
-                        if (((tid >> sl) & 1u) && reaches(tid & ~(1u << sl)))
+                        if (lv[sl] && reaches(sl))
                                 minimal = false;
                 if (minimal) {
+                        uint32_t m1 = 0, m2 = 0;
+                        for (uint32_t sl = 0; sl < nslots; ++sl) {
+                                m1 |= (lv[sl] ? 1u : 0u) << sl;
+                                m2 |= (lv[sl] == 2 ? 1u : 0u) << sl;
+                        }
                         const uint32_t at = atomicAdd(&sh.npat, 1u);
                         if (at < PLK_MAXPAT)
-                                sh.pat[at] = tid;
+                                sh.pat[at] = m1 | m2 << 8;
                 }
         }
         __syncthreads();
         uint32_t np = uni(sh.npat);
-        if (np > PLK_MAXPAT) { // too many sets: the essential slots, one set each (a weaker filter, never a wrong one)
+        if (np > PLK_MAXPAT) { // too many assignments: the essential slots at level 1, one each (a weaker filter, never a wrong one)
                 const uint32_t e = planes_essential(sh, nslots);
                 __syncthreads(); // (every lane has read npat)
                 np = 0;
@@ -269,12 +294,50 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         }
         uint32_t need = 0;
         for (uint32_t i = 0; i < np; ++i)
-                need |= sh.pat[i];
+                need |= sh.pat[i] & 0xffu;
         sh.ess = uni(need);
         __syncthreads();
 }
 
+// The frequency of `doc` in term t (the document is known to be one of the term's): the directory cell brackets the block, a short
+// bisection finds it, one walk over the block's deltas and frequencies.
 template <int CODEC>
+__device__ __noinline__ uint32_t planes_lookup_freq(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+                                                    const uint32_t *__restrict__ win, const DevTerm &t, const uint32_t doc) {
+        const uint32_t *bl = blk_last + t.first_block;
+        uint32_t lo = 0, hi = t.nblocks;
+        if (t.win_off != 0xffffffffu) { // first block whose last docID >= doc lies between the entries of the document's cell and the next
+                lo = win[t.win_off + (doc >> CELL_LOG2)];
+                hi = min(win[t.win_off + (doc >> CELL_LOG2) + 1], t.nblocks - 1);
+        }
+        while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (bl[mid] < doc)
+                        lo = mid + 1;
+                else
+                        hi = mid;
+        }
+        const uint32_t b = lo;
+        const uint32_t off = blk_off[t.first_block + b];
+        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
+        uint32_t d = b ? bl[b - 1] : 0, pos = n - 1;
+        DeltaStream<CODEC> ds;
+        ds.init(index, t, b, off);
+        for (uint32_t i = 0; i + 1 < n; ++i) { // (GOOGLE: the freqs start where the deltas end, so all of them are walked)
+                d += ds.next();
+                if (d == doc && pos == n - 1)
+                        pos = i;
+        }
+        FreqStream<CODEC> fs;
+        fs.init(index, t, b, off, ds);
+        uint32_t f = 0;
+        for (uint32_t i = 0; i <= pos; ++i)
+                f = fs.next();
+        return f & 0xffffu;
+}
+
+// NS: the slots the instantiation keeps in registers (four words each: A and level-2 words of the thread's two window words)
+template <int CODEC, int NS>
 __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void k_planes(
         const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
         const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms, const DevQuery *__restrict__ plan,
@@ -308,7 +371,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 }
                 __syncthreads();
                 const DevFused &fq = sh.fq;
-                const uint32_t nslots = uni(fq.nslots), nreq = uni(fq.nreq), negs = uni(fq.negslots);
+                const uint32_t nslots = min(uni(fq.nslots), (uint32_t)NS), nreq = uni(fq.nreq), negs = uni(fq.negslots);
                 const uint32_t kk = min(lane, nslots - 1); // lane s (< nslots) of every wave looks after slot s, the lanes above mirror the last slot
                 {
                         sh.term[kk] = terms[fq.term[kk]];
@@ -316,14 +379,19 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         // what the slot's scorers add at frequency 1, and a bound of what they add at any frequency: BM25 float(w f / (f + 1.2)) < w;
                         // TF-IDF sqrt(f) w with f <= 65535; Trivial f
                         double t1 = 0.0, ubs = 0.0;
+                        bool leaf = false;
                         for (uint32_t si = 0; si < q.nscore; ++si)
                                 if (sterms[q.score_base + si] == fq.term[kk]) {
                                         const double wgt = sweights[q.score_base + si];
                                         t1 += (double)sim_score(sim, wgt, 1u);
                                         ubs += sim == TRI_SIM_TRIVIAL ? 65535.0 : sim == TRI_SIM_TFIDF ? (wgt > 0 ? 256.0 * wgt : 0.0) : (wgt > 0 ? wgt : 0.0);
+                                        leaf = true;
                                 }
                         sh.tab1[kk] = t1;
-                        sh.ub[kk] = ubs * (1.0 + 1e-6);
+                        sh.w1[kk] = t1 > 0 ? t1 * (1.0 + 1e-9) : t1 * (1.0 - 1e-9);
+                        sh.ub[kk] = fmax(ubs * (1.0 + 1e-6), t1 > 0 ? t1 * (1.0 + 1e-9) : 0.0);
+                        const uint64_t lm = __builtin_amdgcn_ballot_w64(leaf && lane < nslots);
+                        sh.leaf = (uint32_t)lm; // (same value from every lane)
                         sh.tk_n = 0;
                         sh.tk_full = 0;
                         sh.matches = 0;
@@ -332,13 +400,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 }
                 __syncthreads();
                 // ---- per task, uniform: which slots read term planes, where the others' LDS planes are, which slots score
-                uint32_t dense_mask = 0, leaf_mask = 0;
-                uint32_t lidx[FUS_MAX_SLOTS];
-                size_t pbase[FUS_MAX_SLOTS];
+                uint32_t dense_mask = 0;
+                const uint32_t leaf_mask = uni(sh.leaf);
+                uint32_t lidx[NS];
+                size_t pbase[NS];
                 {
                         uint32_t nl = 0;
 #pragma unroll
-                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                        for (uint32_t s = 0; s < NS; ++s) {
                                 const uint32_t prow = s < nslots ? uni(fq.plane[s]) : PL_NONE;
                                 pbase[s] = prow != PL_NONE ? (size_t)prow * 2 * plw : 0;
                                 lidx[s] = 0;
@@ -347,11 +416,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 dense_mask |= 1u << s;
                                         else
                                                 lidx[s] = nl++;
-                                        bool leaf = false;
-                                        for (uint32_t si = 0; si < q.nscore; ++si)
-                                                leaf |= sterms[q.score_base + si] == uni(fq.term[s]);
-                                        if (leaf)
-                                                leaf_mask |= 1u << s;
                                 }
                         }
                 }
@@ -428,10 +492,10 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 for (uint32_t w = wfirst; w < wend; ++w) {
                         const uint32_t par = w & 1u, w0 = w * PL_W;
                         // ---- this window's row ranges (left by wave 0 a window ago)
-                        uint32_t s_lo[FUS_MAX_SLOTS], s_cnt[FUS_MAX_SLOTS], total = 0, rows_mask = 0;
+                        uint32_t s_lo[NS], s_cnt[NS], total = 0, rows_mask = 0;
                         const uint32_t alive = uni(sh.alive[par]);
 #pragma unroll
-                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
+                        for (uint32_t s = 0; s < NS; ++s) {
                                 s_lo[s] = 0;
                                 s_cnt[s] = 0;
                                 if (s < nslots && ((sparse_mask >> s) & 1u)) {
@@ -463,26 +527,31 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 __syncthreads();
                                 continue;
                         }
-                        // ---- the term planes' A words of this thread's two words travel while the other lists are decoded
-                        uint32_t a0[FUS_MAX_SLOTS], a1[FUS_MAX_SLOTS];
+                        // ---- the term planes' words of this thread's two window words travel while the other lists are decoded: a = plane A,
+                        //      h = the level-2 plane (B: frequency not 1)
+                        uint32_t a0[NS], a1[NS], h0[NS], h1[NS];
 #pragma unroll
-                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
-                                a0[s] = a1[s] = 0;
+                        for (uint32_t s = 0; s < NS; ++s) {
+                                a0[s] = a1[s] = h0[s] = h1[s] = 0;
                                 if ((dense_mask >> s) & 1u) {
                                         const uint32_t *pa = planes + pbase[s] + (size_t)w * PL_WORDS;
                                         a0[s] = pa[tid];
                                         a1[s] = pa[tid + PLK_WG];
+                                        if ((leaf_mask >> s) & 1u) {
+                                                h0[s] = pa[plw + tid];
+                                                h1[s] = pa[plw + tid + PLK_WG];
+                                        }
                                 }
                         }
                         const uint32_t ess = uni(sh.ess);
                         PROF_LAP(1);
-                        // ---- set pass: the rows of the decoded slots form one work list, one lane per row; a slot that is not essential is decoded
-                        //      for presence only
+                        // ---- set pass: the rows of the decoded slots form one work list, one lane per row; a slot no assignment of the filter
+                        //      names is decoded for presence only
                         for (uint32_t v0 = 0; v0 < total; v0 += PLK_WG) {
                                 const uint32_t v = v0 + tid;
                                 uint32_t s = 0, r = v, lo = s_lo[0];
 #pragma unroll
-                                for (uint32_t k2 = 0; k2 + 1 < FUS_MAX_SLOTS; ++k2) { // which slot's rows v falls into (ranges are wave-uniform)
+                                for (uint32_t k2 = 0; k2 + 1 < NS; ++k2) { // which slot's rows v falls into (ranges are wave-uniform)
                                         const bool nextslot = s == k2 && r >= s_cnt[k2];
                                         r = nextslot ? r - s_cnt[k2] : r;
                                         lo = nextslot ? s_lo[k2 + 1] : lo;
@@ -499,7 +568,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         const uint32_t last = bl[b];
                                         uint32_t ls = 0;
 #pragma unroll
-                                        for (uint32_t k2 = 0; k2 < FUS_MAX_SLOTS; ++k2)
+                                        for (uint32_t k2 = 0; k2 < NS; ++k2)
                                                 ls = s == k2 ? lidx[k2] : ls;
                                         PlanePostH post{&sh.pl[ls][0]};
                                         if (CODEC == CODEC_LUCENE) {
@@ -522,25 +591,30 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         }
                                 }
                         }
-                        const uint32_t nof = sparse_mask & ~ess; // decoded slots whose B plane says nothing in this window
+                        const uint32_t nof = sparse_mask & ~ess; // decoded slots whose B plane says nothing in this window: level 2 wherever present
                         PROF_LAP(2);
                         __syncthreads();
                         PROF_LAP(3);
                         if (wave == 0 && more) // (this window's hints are in; the next barrier — the sweep's — makes the ranges visible)
                                 publish(w + 1, n_lo, n_cnt);
-                        // ---- sweep: the decoded slots' A words, the predicate, the essential matches
+                        // ---- sweep: the decoded slots' words, the predicate, the candidates
 #pragma unroll
-                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                        for (uint32_t s = 0; s < NS; ++s)
                                 if ((rows_mask >> s) & 1u) {
-                                        a0[s] = sh.pl[lidx[s]][tid];
-                                        a1[s] = sh.pl[lidx[s]][tid + PLK_WG];
+                                        const uint32_t *p = &sh.pl[lidx[s]][0];
+                                        a0[s] = p[tid];
+                                        a1[s] = p[tid + PLK_WG];
+                                        if ((leaf_mask >> s) & 1u) {
+                                                h0[s] = ((nof >> s) & 1u) ? a0[s] : p[PL_STRIDE + tid];
+                                                h1[s] = ((nof >> s) & 1u) ? a1[s] : p[PL_STRIDE + tid + PLK_WG];
+                                        }
                                 }
                         uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;
                         for (uint32_t g = 0; g < nreq; ++g) {
                                 const uint32_t gs = uni(fq.gslots[g]);
                                 uint32_t x0 = 0, x1 = 0;
 #pragma unroll
-                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                for (uint32_t s = 0; s < NS; ++s)
                                         if ((gs >> s) & 1u) {
                                                 x0 |= a0[s];
                                                 x1 |= a1[s];
@@ -551,7 +625,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         {
                                 uint32_t n0 = 0, n1 = 0;
 #pragma unroll
-                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                for (uint32_t s = 0; s < NS; ++s)
                                         if ((negs >> s) & 1u) {
                                                 n0 |= a0[s];
                                                 n1 |= a1[s];
@@ -574,11 +648,16 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         const uint32_t ps = uni(sh.pat[i]);
                                         uint32_t x0 = 0xffffffffu, x1 = 0xffffffffu;
 #pragma unroll
-                                        for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                        for (uint32_t s = 0; s < NS; ++s) {
                                                 if ((ps >> s) & 1u) {
                                                         x0 &= a0[s];
                                                         x1 &= a1[s];
                                                 }
+                                                if ((ps >> (8 + s)) & 1u) {
+                                                        x0 &= h0[s];
+                                                        x1 &= h1[s];
+                                                }
+                                        }
                                         y0 |= x0;
                                         y1 |= x1;
                                 }
@@ -590,7 +669,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         // the decoded slots' words of this window (A and B) are cleared by their owner as soon as it has no candidate left in them
                         auto clear_mine = [&]() {
 #pragma unroll
-                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s)
+                                for (uint32_t s = 0; s < NS; ++s)
                                         if ((rows_mask >> s) & 1u) {
                                                 uint32_t *p = &sh.pl[lidx[s]][0];
                                                 p[tid] = 0;
@@ -602,9 +681,9 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         bool cleared = false;
                         PROF_LAP(4);
                         for (;;) {
-                                // ---- every wave works its own candidates off, one per lane and step, no workgroup barrier: the known part of the
-                                //      score (frequency 1: the slot's table), a bound for the rest, the exact frequencies from the postings only when
-                                //      the bound does not rule the document out
+                                // ---- every wave works its own candidates off, one per lane and step, no workgroup barrier: the levels from
+                                //      registers give the known part of the score and a bound for the rest; the exact frequencies come from the
+                                //      postings only when the bound does not rule the document out
                                 const bool full = uni(sh.tk_full) != 0;
                                 const double thr_s = sh.thr_s;
                                 const uint32_t thr_d = sh.thr_d;
@@ -617,24 +696,15 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         if (has) {
                                                 const uint32_t which = c0 ? 0u : 1u;
                                                 const uint32_t bit = (uint32_t)__builtin_ctz(which ? c1 : c0);
-                                                const uint32_t wi = tid + which * PLK_WG, doc = w0 + 32u * wi + bit;
+                                                const uint32_t doc = w0 + 32u * (tid + which * PLK_WG) + bit;
                                                 double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known yet
                                                 uint32_t unk = 0;
 #pragma unroll
-                                                for (uint32_t s = 0; s < FUS_MAX_SLOTS; ++s) {
-                                                        if (!((leaf_mask >> s) & 1u))
+                                                for (uint32_t s = 0; s < NS; ++s) {
+                                                        const uint32_t av = which ? a1[s] : a0[s], hv = which ? h1[s] : h0[s];
+                                                        if (!((leaf_mask >> s) & 1u) || !((av >> bit) & 1u))
                                                                 continue;
-                                                        const uint32_t av = which ? a1[s] : a0[s];
-                                                        if (!((av >> bit) & 1u))
-                                                                continue;
-                                                        bool f1;
-                                                        if ((dense_mask >> s) & 1u)
-                                                                f1 = !((planes[pbase[s] + plw + (size_t)w * PL_WORDS + wi] >> bit) & 1u);
-                                                        else if ((nof >> s) & 1u)
-                                                                f1 = false;
-                                                        else
-                                                                f1 = !((sh.pl[lidx[s]][PL_STRIDE + wi] >> bit) & 1u);
-                                                        if (f1)
+                                                        if (!((hv >> bit) & 1u))
                                                                 sk += sh.tab1[s];
                                                         else {
                                                                 unk |= 1u << s;
@@ -646,7 +716,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                         for (uint32_t s = 0; s < nslots; ++s) {
                                                                 if (!((unk >> s) & 1u))
                                                                         continue;
-                                                                const uint32_t f = fused_lookup_freq<CODEC>(index, blk_last, blk_off, sh.term[s], doc);
+                                                                const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, win, sh.term[s], doc);
                                                                 const uint32_t term = fq.term[s];
                                                                 for (uint32_t si = 0; si < q.nscore; ++si)
                                                                         if (sterms[q.score_base + si] == term)

@@ -139,7 +139,7 @@ struct tri_batch {
         DevTask *d_tasks = nullptr;
         uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones, then the TASK_FUSED ones
         uint32_t n_dense = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0; // (n_fused: 32-bit window words; n_fused16: 16-bit; n_fusedgen: general trees)
-        uint32_t n_planes = 0; // TASK_PLANES tasks (k_planes), scheduled after the general trees
+        uint32_t n_planes = 0, n_planes8 = 0; // TASK_PLANES / TASK_PLANES8 tasks (k_planes), scheduled after the general trees
         // term planes (k_planes.hpp): the head terms the batch's queries share, decoded once per launch into d_planes
         std::vector<uint32_t> plane_terms; // row -> term
         uint32_t *d_plane_terms = nullptr, *d_planes = nullptr, *d_qplane = nullptr; // d_qplane: parallel to d_qterms, the term's row or PL_NONE
@@ -1644,7 +1644,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                                 b1 += (uint64_t)(std::lower_bound(lb, lb + tk.nblocks, wb * fw) - lb);
                                         }
                                 order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
-                                b->tasks.push_back({slot, wb, we, pk ? TASK_PLANES : t.fz.mode ? TASK_FUSED_GEN : t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off + (emit ? b1 * 32 + 32ull * ord * t.fz.nslots : 0)});
+                                b->tasks.push_back({slot, wb, we, pk ? (t.fz.nslots <= PLK_NS_SMALL ? TASK_PLANES : TASK_PLANES8) : t.fz.mode ? TASK_FUSED_GEN : t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off + (emit ? b1 * 32 + 32ull * ord * t.fz.nslots : 0)});
                         }
                         if (emit) {
                                 uint64_t blocks = 0;
@@ -1775,6 +1775,10 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if (b->tasks[o.second].kind == TASK_PLANES)
                         sched.push_back(o.second);
         b->n_planes = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused - b->n_fused16 - b->n_fusedgen;
+        for (const auto &o : order)
+                if (b->tasks[o.second].kind == TASK_PLANES8)
+                        sched.push_back(o.second);
+        b->n_planes8 = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused - b->n_fused16 - b->n_fusedgen - b->n_planes;
         // the planes that pay: rows in term order (deterministic), the uses pointed at them
         {
                 std::vector<uint32_t> chosen;
@@ -1858,7 +1862,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->info.out_capacity = off;
         b->info.plane_terms = b->plane_terms.size();
         b->info.plane_bytes = (uint64_t)b->plane_terms.size() * 2 * b->plw * 4;
-        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (!b->plane_terms.empty()) +
+        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (b->n_planes8 != 0) + (!b->plane_terms.empty()) +
                            (!b->ptasks.empty()) + (rich ? 2 : 0) +
                            ((scored && b->n_dense + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
         *out = b.release();
@@ -1962,14 +1966,31 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
-                if (b->n_planes) {
+                for (int wide = 0; wide < 2; ++wide) {
                         // AccumulatedScore top-K of the CNF queries over bit planes: the head terms' planes from k_term_planes, the other lists
-                        // decoded per window into LDS planes; union / conjunction predicates 32 documents per word
-                        const uint32_t *psched = b->d_sched + b->n_dense + b->n_cand + b->n_fused + b->n_fused16 + b->n_fusedgen;
-                        const dim3 grid(std::min<uint32_t>(b->n_planes, (uint32_t)dev->cus * PLK_WGS_PER_CU));
-                        TRI_LAUNCH(k_planes, b->ix->codec, grid, dim3(PLK_WG), dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff,
-                                   b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, b->d_sterms, b->d_sweights, b->n_planes, b->d_ticket + 24, b->d_counts,
-                                   b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked, b->similarity, (const uint32_t *)b->d_planes, b->plw);
+                        // decoded per window into LDS planes; union / conjunction predicates and the candidate filter 32 documents per word
+                        // (two instantiations: queries of up to five slots, wider ones)
+                        const uint32_t np = wide ? b->n_planes8 : b->n_planes;
+                        if (!np)
+                                continue;
+                        const uint32_t *psched = b->d_sched + b->n_dense + b->n_cand + b->n_fused + b->n_fused16 + b->n_fusedgen + (wide ? b->n_planes : 0);
+                        const dim3 grid(std::min<uint32_t>(np, (uint32_t)dev->cus * PLK_WGS_PER_CU));
+#define TRI_PLANES_ARGS                                                                                                                                      \
+        b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, \
+                b->d_sterms, b->d_sweights, np, b->d_ticket + 24 + 2 * wide, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked,     \
+                b->similarity, (const uint32_t *)b->d_planes, b->plw
+                        if (b->ix->codec == TRI_CODEC_LUCENE) {
+                                if (wide)
+                                        hipLaunchKernelGGL((k_planes<CODEC_LUCENE, FUS_MAX_SLOTS>), grid, dim3(PLK_WG), 0, dev->stream, TRI_PLANES_ARGS);
+                                else
+                                        hipLaunchKernelGGL((k_planes<CODEC_LUCENE, PLK_NS_SMALL>), grid, dim3(PLK_WG), 0, dev->stream, TRI_PLANES_ARGS);
+                        } else {
+                                if (wide)
+                                        hipLaunchKernelGGL((k_planes<CODEC_GOOGLE, FUS_MAX_SLOTS>), grid, dim3(PLK_WG), 0, dev->stream, TRI_PLANES_ARGS);
+                                else
+                                        hipLaunchKernelGGL((k_planes<CODEC_GOOGLE, PLK_NS_SMALL>), grid, dim3(PLK_WG), 0, dev->stream, TRI_PLANES_ARGS);
+                        }
+#undef TRI_PLANES_ARGS
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_k, dev->stream));
@@ -2099,7 +2120,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                         m_dense += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind >= TASK_FUSED) {
                         m_fused += b->h_query_counts[sidx]; // (every one-pass kind, k_planes' included)
-                        (b->tasks[q.first_task].kind == TASK_PLANES ? out_planes : out_fused) +=
+                        (b->tasks[q.first_task].kind >= TASK_PLANES ? out_planes : out_fused) +=
                                 q.out_cap ? 4 * b->h_query_counts[sidx] : 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk); // (docIDs of a DocumentsOnly general tree)
                 }
         }
@@ -2314,7 +2335,7 @@ extern "C" int tri_batch_docset_hashes(tri_batch *b, uint64_t *hashes) {
         tri_dev *dev = b->ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
         const uint32_t n = (uint32_t)b->plan.size();
-        if ((b->n_fused + b->n_fused16 + b->n_fusedgen + b->n_planes) && (b->flags & TRI_FLAG_ACCUMULATED_SCORE)) // (DocumentsOnly: the one-pass kernel's tasks wrote their matches)
+        if ((b->n_fused + b->n_fused16 + b->n_fusedgen + b->n_planes + b->n_planes8) && (b->flags & TRI_FLAG_ACCUMULATED_SCORE)) // (DocumentsOnly: the one-pass kernel's tasks wrote their matches)
                 return fail(TRI_ERR_INVALID, "the batch holds queries that ran through the one-pass scored kernel: their docID sets are not materialised");
         std::vector<uint64_t> h(n);
         if (n) {
