@@ -37,6 +37,7 @@ struct ProfClock {
 #define PROF_FLUSH() prof_.flush()
 #define PROF_ARG , ProfClock &prof_
 #define PROF_PASS , prof_
+#define PROF_COUNT(slot, n) atomicAdd(&g_prof[slot], (unsigned long long)(n)) // event counters: g_prof[16 ..]
 #else
 #define PROF_DECL
 #define PROF_START()
@@ -44,6 +45,7 @@ struct ProfClock {
 #define PROF_FLUSH()
 #define PROF_ARG
 #define PROF_PASS
+#define PROF_COUNT(slot, n)
 #endif
 
 #ifdef TRI_TRACE

@@ -130,6 +130,7 @@ constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per threa
 constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
 constexpr uint32_t PLK_MAXPAT = 32;     // level assignments of the candidate filter kept as such (more: one per essential slot)
 constexpr uint32_t PLK_WGS_PER_CU = 2;
+constexpr uint32_t PLK_WQ = 128;        // per-wave queue of candidates waiting for a frequency lookup: worked off 64 at a time, every lane busy
 constexpr uint32_t PLK_NS_SMALL = 5;    // the instantiation for queries of up to this many slots keeps four words per slot in registers
 static_assert(PL_WORDS == 2 * PLK_WG, "the sweep gives every thread two words of the window");
 static_assert(PLK_CAP == PLK_WG && TOPK_MAX < PLK_PRUNE_AT && PLK_PRUNE_AT < PLK_CAP, "pruning leaves room; a pruned buffer is below the stop mark");
@@ -149,6 +150,7 @@ struct PlanesShared {
         uint32_t npat;                        // the candidate filter: 0xffffffff = every match (no threshold yet), else that many assignments
         uint32_t pat[PLK_MAXPAT];             // ... bits 0-7: slots at level >= 1, bits 8-15: slots at level 2
         uint32_t flag[PLK_WG / 64];
+        uint32_t wq[PLK_WG / 64][PLK_WQ]; // per wave: candidates waiting for exact frequencies (rel docID << 16 | level-2 slots << 8 | slots held)
         uint32_t bcast[4];
         uint32_t rng_lo[2][FUS_MAX_SLOTS], rng_cnt[2][FUS_MAX_SLOTS]; // per window parity: the decoded slots' row ranges
         uint32_t alive[2];                                             // ... and the slots whose lists are not exhausted
@@ -282,7 +284,35 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         }
         __syncthreads();
         uint32_t np = uni(sh.npat);
-        if (np > PLK_MAXPAT) { // too many assignments: the essential slots at level 1, one each (a weaker filter, never a wrong one)
+        if (np > PLK_MAXPAT) {
+                // too many assignments: one level only — the minimal SETS of slots whose bounds reach the threshold (a weaker filter,
+                // never a wrong one; at most C(8, 4) = 70 of them, 10 for five slots)
+                __syncthreads(); // (every lane has read npat)
+                sh.npat = 0;
+                __syncthreads();
+                if (tid && tid < (1u << nslots) && !(tid & ~leaf)) {
+                        auto reaches = [&](const uint32_t pset) {
+                                double sum = 0.0;
+                                for (uint32_t sl = 0; sl < nslots; ++sl)
+                                        if ((pset >> sl) & 1u)
+                                                sum += sh.ub[sl];
+                                return !(sum < thr);
+                        };
+                        bool minimal = reaches(tid);
+                        for (uint32_t sl = 0; sl < nslots && minimal; ++sl)
+                                if (((tid >> sl) & 1u) && reaches(tid & ~(1u << sl)))
+                                        minimal = false;
+                        if (minimal) {
+                                const uint32_t at = atomicAdd(&sh.npat, 1u);
+                                if (at < PLK_MAXPAT)
+                                        sh.pat[at] = tid;
+                        }
+                }
+                __syncthreads();
+                np = uni(sh.npat);
+                PROF_COUNT(21, tid == 0 ? 1 : 0);
+        }
+        if (np > PLK_MAXPAT) { // still too many: the essential slots, one set each
                 const uint32_t e = planes_essential(sh, nslots);
                 __syncthreads(); // (every lane has read npat)
                 np = 0;
@@ -291,6 +321,7 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                                 sh.pat[np++] = 1u << sl; // (uniform stores)
                 sh.npat = np;
                 __syncthreads();
+                PROF_COUNT(22, tid == 0 ? 1 : 0);
         }
         uint32_t need = 0;
         for (uint32_t i = 0; i < np; ++i)
@@ -299,41 +330,50 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         __syncthreads();
 }
 
-// The frequency of `doc` in term t (the document is known to be one of the term's): the directory cell brackets the block, a short
-// bisection finds it, one walk over the block's deltas and frequencies.
+// The frequency of `doc` in term t (the document is known to be one of the term's): the directory cell brackets the block, one round
+// of independent loads (after a bisection down to 16 blocks, if need be) finds it, and the row is read by the same register readers as
+// everywhere else (row_decode) with a probe for the one document — four memory round trips in all.
+struct FreqProbe {
+        uint32_t target, f = 0;
+        __device__ __forceinline__ void doc(const uint32_t) {}
+        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t fr) { f = rel == target ? fr : f; }
+};
 template <int CODEC>
 __device__ __noinline__ uint32_t planes_lookup_freq(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
-                                                    const uint32_t *__restrict__ win, const DevTerm &t, const uint32_t doc) {
+                                                    const uint4 *__restrict__ blk_rec, const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
+                                                    const DevTerm &t, const uint32_t doc) {
         const uint32_t *bl = blk_last + t.first_block;
-        uint32_t lo = 0, hi = t.nblocks;
-        if (t.win_off != 0xffffffffu) { // first block whose last docID >= doc lies between the entries of the document's cell and the next
+        uint32_t lo = 0, hi = t.nblocks - 1; // the first block whose last docID >= doc lies in [lo, hi]
+        if (t.win_off != 0xffffffffu) {
                 lo = win[t.win_off + (doc >> CELL_LOG2)];
                 hi = min(win[t.win_off + (doc >> CELL_LOG2) + 1], t.nblocks - 1);
         }
-        while (lo < hi) {
+        while (hi - lo > 16) {
                 const uint32_t mid = (lo + hi) >> 1;
                 if (bl[mid] < doc)
                         lo = mid + 1;
                 else
                         hi = mid;
         }
-        const uint32_t b = lo;
-        const uint32_t off = blk_off[t.first_block + b];
-        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
-        uint32_t d = b ? bl[b - 1] : 0, pos = n - 1;
-        DeltaStream<CODEC> ds;
-        ds.init(index, t, b, off);
-        for (uint32_t i = 0; i + 1 < n; ++i) { // (GOOGLE: the freqs start where the deltas end, so all of them are walked)
-                d += ds.next();
-                if (d == doc && pos == n - 1)
-                        pos = i;
+        uint32_t below = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i) // (independent loads: one round trip)
+                below += (lo + i < hi && bl[lo + i] < doc) ? 1u : 0u;
+        const uint32_t b = lo + below;
+        const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
+        FreqProbe probe{doc};
+#ifdef TRI_PROF
+        ProfClock prof_;
+#endif
+        if (CODEC == CODEC_LUCENE) {
+                const uint4 rec = blk_rec[t.first_block + b];
+                row_decode<CODEC, true, FreqProbe>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, 0u, probe PROF_PASS);
+        } else {
+                const uint32_t off = blk_off[t.first_block + b];
+                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
+                row_decode<CODEC, true, FreqProbe>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, 0u, probe PROF_PASS);
         }
-        FreqStream<CODEC> fs;
-        fs.init(index, t, b, off, ds);
-        uint32_t f = 0;
-        for (uint32_t i = 0; i <= pos; ++i)
-                f = fs.next();
-        return f & 0xffffu;
+        return probe.f & 0xffffu;
 }
 
 // NS: the slots the instantiation keeps in registers (four words each: A and level-2 words of the thread's two window words)
@@ -679,31 +719,79 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         }
                         };
                         bool cleared = false;
+                        uint32_t qn = 0; // entries on this wave's lookup queue (wave-uniform)
                         PROF_LAP(4);
                         for (;;) {
                                 // ---- every wave works its own candidates off, one per lane and step, no workgroup barrier: the levels from
-                                //      registers give the known part of the score and a bound for the rest; the exact frequencies come from the
-                                //      postings only when the bound does not rule the document out
+                                //      registers give the known part of the score and a bound for the rest.  A candidate the bound does not rule
+                                //      out and whose score is not fully known goes onto the wave's queue; the queue is worked off 64 at a time —
+                                //      every lane fetching exact frequencies from the postings at once, not one lane while 63 wait
                                 const bool full = uni(sh.tk_full) != 0;
                                 const double thr_s = sh.thr_s;
                                 const uint32_t thr_d = sh.thr_d;
+                                auto offer = [&](const double sc, const uint32_t doc) { // false: no room (the buffer wants pruning)
+                                        const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
+                                        if (slot >= PLK_CAP)
+                                                return false;
+                                        sh.tk_s[slot] = sc;
+                                        sh.tk_d[slot] = doc;
+                                        return true;
+                                };
+                                auto work_queue = [&]() { // the last (up to) 64 entries of the queue; entries that found no room go back
+                                        const uint32_t take_n = min(qn, 64u), base = qn - take_n;
+                                        qn = base;
+                                        bool back = false;
+                                        uint32_t ent = 0;
+                                        if (lane < take_n) {
+                                                ent = sh.wq[wave][base + lane];
+                                                const uint32_t doc = w0 + (ent >> 16), held = ent & 0xffu, unk = (ent >> 8) & 0xffu;
+                                                double sk = 0.0;
+                                                for (uint32_t s = 0; s < nslots; ++s) {
+                                                        if (!((held >> s) & 1u))
+                                                                continue;
+                                                        if (!((unk >> s) & 1u)) {
+                                                                sk += sh.tab1[s];
+                                                                continue;
+                                                        }
+                                                        const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, sh.term[s], doc);
+                                                        const uint32_t term = fq.term[s];
+                                                        for (uint32_t si = 0; si < q.nscore; ++si)
+                                                                if (sterms[q.score_base + si] == term)
+                                                                        sk += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                                }
+                                                if (!full || better(sk, doc, thr_s, thr_d))
+                                                        back = !offer(sk, doc);
+                                        }
+                                        PROF_COUNT(17, lane == 0 ? take_n : 0);
+                                        const uint64_t bm = __builtin_amdgcn_ballot_w64(back);
+                                        if (back)
+                                                sh.wq[wave][qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = ent;
+                                        qn += (uint32_t)__popcll(bm);
+                                };
                                 for (;;) {
-                                        const bool has = (c0 | c1) != 0;
-                                        if (__builtin_amdgcn_ballot_w64(has) == 0ull)
-                                                break;
                                         if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
-                                                break; // the buffer wants pruning first (the candidates stay where they are)
+                                                break; // the buffer wants pruning first (candidates and queue stay where they are)
+                                        const bool has = (c0 | c1) != 0;
+                                        if (__builtin_amdgcn_ballot_w64(has) == 0ull) {
+                                                if (!qn)
+                                                        break;
+                                                work_queue();
+                                                continue;
+                                        }
+                                        bool enq = false;
+                                        uint32_t ent = 0;
                                         if (has) {
                                                 const uint32_t which = c0 ? 0u : 1u;
                                                 const uint32_t bit = (uint32_t)__builtin_ctz(which ? c1 : c0);
-                                                const uint32_t doc = w0 + 32u * (tid + which * PLK_WG) + bit;
+                                                const uint32_t rel = 32u * (tid + which * PLK_WG) + bit, doc = w0 + rel;
                                                 double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known yet
-                                                uint32_t unk = 0;
+                                                uint32_t unk = 0, held = 0;
 #pragma unroll
                                                 for (uint32_t s = 0; s < NS; ++s) {
                                                         const uint32_t av = which ? a1[s] : a0[s], hv = which ? h1[s] : h0[s];
                                                         if (!((leaf_mask >> s) & 1u) || !((av >> bit) & 1u))
                                                                 continue;
+                                                        held |= 1u << s;
                                                         if (!((hv >> bit) & 1u))
                                                                 sk += sh.tab1[s];
                                                         else {
@@ -711,27 +799,13 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                                 sb += sh.ub[s];
                                                         }
                                                 }
-                                                bool take = !full || better(sk + sb, doc, thr_s, thr_d);
-                                                if (take && unk) { // the bound does not rule the document out: the exact frequencies, from the postings
-                                                        for (uint32_t s = 0; s < nslots; ++s) {
-                                                                if (!((unk >> s) & 1u))
-                                                                        continue;
-                                                                const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, win, sh.term[s], doc);
-                                                                const uint32_t term = fq.term[s];
-                                                                for (uint32_t si = 0; si < q.nscore; ++si)
-                                                                        if (sterms[q.score_base + si] == term)
-                                                                                sk += (double)sim_score(sim, sweights[q.score_base + si], f);
-                                                        }
-                                                        take = !full || better(sk, doc, thr_s, thr_d);
-                                                }
                                                 bool done = true;
-                                                if (take) {
-                                                        const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
-                                                        if (slot < PLK_CAP) {
-                                                                sh.tk_s[slot] = sk;
-                                                                sh.tk_d[slot] = doc;
+                                                if (!full || better(sk + sb, doc, thr_s, thr_d)) {
+                                                        if (unk) {
+                                                                enq = true;
+                                                                ent = rel << 16 | unk << 8 | held;
                                                         } else
-                                                                done = false; // no room: the candidate stays for after the prune
+                                                                done = offer(sk, doc); // (no room: the candidate stays for after the prune)
                                                 }
                                                 if (done) {
                                                         if (which)
@@ -740,13 +814,20 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                                 c0 &= c0 - 1u;
                                                 }
                                         }
+                                        PROF_COUNT(16, lane == 0 ? __popcll(__builtin_amdgcn_ballot_w64(has)) : 0);
+                                        const uint64_t em = __builtin_amdgcn_ballot_w64(enq);
+                                        if (enq)
+                                                sh.wq[wave][qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u))] = ent;
+                                        qn += (uint32_t)__popcll(em);
+                                        if (qn >= 64)
+                                                work_queue();
                                 }
                                 const bool pending = (c0 | c1) != 0;
                                 if (!pending && !cleared) {
                                         clear_mine();
                                         cleared = true;
                                 }
-                                sh.flag[wave] = __builtin_amdgcn_ballot_w64(pending) != 0ull ? 1u : 0u; // (wave-uniform value, every lane stores it)
+                                sh.flag[wave] = (__builtin_amdgcn_ballot_w64(pending) != 0ull || qn) ? 1u : 0u; // (wave-uniform value, every lane stores it)
                                 __syncthreads();
                                 uint32_t anyp = 0;
 #pragma unroll
@@ -758,6 +839,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         __syncthreads(); // (every lane has read the flags and tk_n)
                                         planes_prune(sh, n, k);
                                         planes_filter(sh, nslots);
+                                        PROF_COUNT(18, tid == 0 ? 1 : 0);
                                         if (anyp)
                                                 candidates(c0, c1); // (the threshold moved: what is left is filtered again)
                                 } else if (anyp)
@@ -765,6 +847,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 if (!anyp)
                                         break;
                         }
+                        PROF_COUNT(19, tid == 0 ? 1 : 0);
                         PROF_LAP(5);
                 }
                 // ---- the task's result: its best k (ranked) and its match count
