@@ -771,6 +771,10 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 for (;;) {
                                         if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
                                                 break; // the buffer wants pruning first (candidates and queue stay where they are)
+                                        if (qn >= 64) { // (a step below may add 64 entries: the queue is kept below 64 before it)
+                                                work_queue();
+                                                continue;
+                                        }
                                         const bool has = (c0 | c1) != 0;
                                         if (__builtin_amdgcn_ballot_w64(has) == 0ull) {
                                                 if (!qn)
@@ -819,8 +823,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         if (enq)
                                                 sh.wq[wave][qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u))] = ent;
                                         qn += (uint32_t)__popcll(em);
-                                        if (qn >= 64)
-                                                work_queue();
                                 }
                                 const bool pending = (c0 | c1) != 0;
                                 if (!pending && !cleared) {
