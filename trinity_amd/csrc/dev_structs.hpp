@@ -76,11 +76,12 @@ constexpr uint32_t TASK_PLANES = 5;    // AccumulatedScoreScheme + top-K of a CN
 constexpr uint32_t TASK_PLANES8 = 6;   // ... of a query with more than five slots (its own instantiation: more words held in registers)
 
 // ---- term planes: per batch LAUNCH, every head term the batch's queries share is decoded ONCE (k_term_planes) into two bitmaps over the
-//      docID space — A: the document holds the term, B: its frequency there is not 1 — which the matching kernels then read instead of
+//      docID space — A: the document holds the term, B: its frequency there is not 1, C: nor 2 — which the matching kernels then read instead of
 //      decoding the term's list again for every query that names it (under Zipf a handful of terms carry most of a batch's postings)
 constexpr uint32_t PL_W = 32768;          // documents per plane window (k_term_planes, k_planes)
 constexpr uint32_t PL_WORDS = PL_W / 32;  // words of one plane per window
 constexpr uint32_t PL_NONE = 0xffffffffu; // "this term has no plane in this batch"
+constexpr uint32_t PL_PLANES = 3;         // planes per term — A: the document holds the term; B: its frequency there is not 1; C: nor 2
 constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64)
 constexpr uint32_t FUS_MAX_SLOTS = 8;
 constexpr uint32_t FUS_MAX_LEAVES = 16; // scorer leaves of a general tree

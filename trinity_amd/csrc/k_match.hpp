@@ -554,7 +554,7 @@ __device__ __forceinline__ void dense_pass(DenseShared &sh, const uint8_t *__res
                 // of plane A, OR-ed into the group's bitmap — 8 coalesced loads per thread instead of a walk over the term's rows
                 const uint32_t prow = uni(sh.seg_plane[k]);
                 if (prow != PL_NONE) {
-                        const uint32_t *pa = planes + (size_t)prow * 2 * plw + (w0 >> 5);
+                        const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw + (w0 >> 5);
                         const uint32_t wbase = k < ksplit ? 0u : BM_B_WORDS;
 #pragma unroll
                         for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
@@ -766,7 +766,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                                         break;
                                 if (tt & QT_GROUP)
                                         cur_neg = tt & QT_NOT;
-                                const uint4 *pa = (const uint4 *)(planes + (size_t)uni(sh.seg_plane[k]) * 2 * plw + (w0 >> 5) + tid * PER);
+                                const uint4 *pa = (const uint4 *)(planes + (size_t)uni(sh.seg_plane[k]) * PL_PLANES * plw + (w0 >> 5) + tid * PER);
                                 const uint4 v0 = pa[0], v1 = pa[1];
                                 grp[0] |= v0.x, grp[1] |= v0.y, grp[2] |= v0.z, grp[3] |= v0.w;
                                 grp[4] |= v1.x, grp[5] |= v1.y, grp[6] |= v1.z, grp[7] |= v1.w;
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                 const uint32_t prow = qplane ? qplane[q.term_base + k] : PL_NONE;
                                 if (prow != PL_NONE) {
                                         // the term has a plane (k_term_planes decoded it once for the whole batch): advance(candidate) is a bit probe
-                                        const uint32_t *pa = planes + (size_t)prow * 2 * plw;
+                                        const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
                                         for (uint32_t j = tid; j < C; j += AND_WG) {
                                                 const uint32_t doc = sh.cand[phys(j)];
                                                 if ((pa[doc >> 5] >> (doc & 31u)) & 1u)

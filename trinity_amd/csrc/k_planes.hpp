@@ -7,19 +7,20 @@
 // Under Zipf a handful of terms carry most of a batch's postings (at the 10M-document configuration the 40 most frequent terms
 // hold 98 % of the postings the 5-term queries of SURVEY §8(d) cfg3 touch), and the reference decodes such a list again for every
 // query that names it (Decoder::init + next() per query, google_codec.cpp:777-819 / lucene_codec.cpp:568-594).  Here every LAUNCH
-// decodes each of those lists ONCE — k_term_planes, inside the timed region, from the segment's own codec bytes — into two
+// decodes each of those lists ONCE — k_term_planes, inside the timed region, from the segment's own codec bytes — into three
 // bitmaps over the docID space:
 //     plane A   bit d set  <=>  document d holds the term            (PostingsListIterator::current() would stop on d)
-//     plane B   bit d set  <=>  ... and its frequency there is not 1 (the exact frequency is then read from the postings on demand)
+//     plane B   bit d set  <=>  ... and its frequency there is not 1
+//     plane C   bit d set  <=>  ... and not 2 either (the exact frequency is then read from the postings on demand)
 // and the matching kernels read the planes: k_and tests a candidate with one bit probe instead of bracketing and decoding a block
 // (Conjuction::next_impl's advance(), docset_iterators.cpp:308-348), k_and_dense ORs a plane's words into its window bitmap instead
 // of walking the term's rows (docset_spans.cpp:98-173), k_planes (below) evaluates union / CNF predicates 32 documents per word.
-// The planes live in a scratch region owned by the batch (2 x (max docID / 8) bytes per term); nothing survives the launch.
+// The planes live in a scratch region owned by the batch (3 x (max docID / 8) bytes per term); nothing survives the launch.
 
 constexpr uint32_t PL_CELLS = PL_W / CELL_DOCS; // cell-index entries per plane window
-constexpr uint32_t PL_STRIDE = PL_WORDS + 32;   // LDS words between a slot's A and B plane (word PL_WORDS of each: the sink)
+constexpr uint32_t PL_STRIDE = PL_WORDS + 32;   // LDS words between a slot's planes (word PL_WORDS of each: the sink)
 
-// A decoded posting into a pair of LDS planes (A at a[], B at a[PL_STRIDE]).  Documents outside the window land in the sink word.
+// A decoded posting into LDS planes A, B, C (a[], a[PL_STRIDE], a[2 * PL_STRIDE]).  Documents outside the window land in the sink word.
 struct PlanePost {
         uint32_t *a;
         __device__ __forceinline__ void doc(const uint32_t rel) {
@@ -28,15 +29,18 @@ struct PlanePost {
         }
         __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) {
                 const uint32_t r = min(rel, PL_W);
-                const uint32_t bit = 1u << (r & 31u);
+                const uint32_t bit = 1u << (r & 31u), f16 = f & 0xffffu; // (the frequency a scorer sees is tokenpos_t, 16 bits: codecs.h:217)
                 atomicOr(&a[r >> 5], bit);
-                if ((f & 0xffffu) != 1u) // (the frequency a scorer sees is tokenpos_t, 16 bits: codecs.h:217)
+                if (f16 != 1u) {
                         atomicOr(&a[(r >> 5) + PL_STRIDE], bit);
+                        if (f16 != 2u)
+                                atomicOr(&a[(r >> 5) + 2 * PL_STRIDE], bit);
+                }
         }
 };
 
 // One workgroup per (plane row, window): the rows (<= 32 documents each) of the term that reach the window are decoded, one lane
-// per row, into LDS planes, which are then written out whole — every word of both planes is written by exactly one workgroup,
+// per row, into LDS planes, which are then written out whole — every word of every plane is written by exactly one workgroup,
 // so the scratch region needs no clearing between launches.
 template <int CODEC>
 __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
@@ -44,9 +48,9 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                                                         const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
                                                         const DevTerm *__restrict__ terms, const uint32_t *__restrict__ plane_terms,
                                                         uint32_t *__restrict__ planes, const uint32_t plw) {
-        __shared__ uint32_t pl[2 * PL_STRIDE];
+        __shared__ uint32_t pl[PL_PLANES * PL_STRIDE];
         const uint32_t tid = threadIdx.x, w = blockIdx.x, row = blockIdx.y;
-        for (uint32_t i = tid; i < 2 * PL_STRIDE; i += AND_WG)
+        for (uint32_t i = tid; i < PL_PLANES * PL_STRIDE; i += AND_WG)
                 pl[i] = 0;
         const DevTerm t = terms[plane_terms[row]];
         const uint32_t *bl = blk_last + t.first_block;
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
         if (t.win_off != 0xffffffffu) {
                 b_lo = win[t.win_off + w * PL_CELLS];
                 b_hi = win[t.win_off + (w + 1) * PL_CELLS];
-        } else { // (planes are made for long lists, which are indexed; kept for completeness)
+        } else { // (a short list: planes are made for long ones, but the planner may be told to give every term one)
                 uint32_t lo = 0, hi = t.nblocks;
                 while (lo < hi) {
                         const uint32_t mid = (lo + hi) >> 1;
@@ -97,10 +101,11 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                         }
                 }
         __syncthreads();
-        uint32_t *pa = planes + (size_t)row * 2 * plw + (size_t)w * PL_WORDS, *pb = pa + plw;
+        uint32_t *pa = planes + (size_t)row * PL_PLANES * plw + (size_t)w * PL_WORDS;
         for (uint32_t i = tid; i < PL_WORDS; i += AND_WG) {
                 pa[i] = pl[i];
-                pb[i] = pl[PL_STRIDE + i];
+                pa[plw + i] = pl[PL_STRIDE + i];
+                pa[2 * plw + i] = pl[2 * PL_STRIDE + i];
         }
 }
 
@@ -108,30 +113,34 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
 // AccumulatedScoreScheme + top-K of a CNF query (a union, a conjunction of terms / OR-groups, an excluded group, optional scoring
 // terms: everything k_fused's CNF instantiations take) in one pass over windows of PL_W documents, on BIT PLANES instead of a word
 // per document:
-//   * every slot (distinct term) of the query presents, per window, plane A (the document holds the term) and plane B (its
-//     frequency is not 1).  A head term's planes come straight from the batch's term planes (global memory, L2 / Infinity-Cache
-//     resident: k_term_planes decoded the list once for every query of the launch); any other term's rows that reach the window
-//     are decoded into LDS planes (one lane per row of <= 32 documents, the same row readers as k_fused).
+//   * every slot (distinct term) of the query presents, per window, LEVEL planes: A (the document holds the term), B (its frequency
+//     is not 1) and, for a head term, C (nor 2).  A head term's planes come straight from the batch's term planes (global memory,
+//     L2 / Infinity-Cache resident: k_term_planes decoded the list once for every query of the launch).  Any other term's rows that
+//     fall into the task's docID range are decoded ONCE, at the start of the task — one lane per row of <= 32 documents, every lane
+//     of the workgroup busy, the same row readers as k_fused — into a sorted (docID, frequency-is-not-1) list in a scratch region
+//     of the workgroup; per window the list's next entries are picked up with one coalesced load and OR-ed into LDS planes.
 //   * the predicate is word-wise: a required group = the OR of its slots' A words, the conjunction their AND, the excluded group an
 //     AND-NOT, masked documents (docidupdates.h:90-119) another — 32 documents per instruction; the match count is a popcount.
 //     (What docset_spans.cpp:98-173 / 681-790 do per document and docset_iterators.cpp:226-405 per posting.)
-//   * the candidate filter is word-wise too.  A slot is at one of three LEVELS in a document: absent, frequency 1 (its scorers add
-//     exactly tab1), any other frequency (they add at most ub).  Whenever the threshold (the k-th best score so far) moves, the
-//     minimal level assignments whose bounds reach it are listed (planes_filter); a match is a candidate iff it meets one of them
-//     — an OR of ANDs over the slots' A / B words.  Matches whose frequencies are all 1 (most of them) are thereby tested against
-//     their EXACT score without ever being touched individually.  (This replaces MaxScore's "holds an essential slot".)
-//   * candidates are scored one per lane by the wave that owns their words, no workgroup barrier: levels from registers, the
-//     exact frequency of a level-2 slot from the postings (directory cell -> block -> walk) only when the bound does not rule the
-//     document out.  A slot no assignment needs is decoded for presence only: the freqs group of its PFOR blocks is not addressed.
+//   * the candidate filter is word-wise too.  A slot is at one of up to four LEVELS in a document: absent, frequency 1, frequency 2
+//     (head terms; its scorers then add exactly what they add at that frequency), any other frequency (they add at most a bound).
+//     Whenever the threshold (the k-th best score so far) moves, the minimal level assignments whose weights reach it are listed
+//     (planes_filter); a match is a candidate iff it meets one of them — an OR of ANDs over the slots' level words.  Matches whose
+//     frequencies are all known (almost all of them) are thereby tested against their EXACT score without being touched one by one.
+//     (This replaces MaxScore's "holds an essential slot".)
+//   * candidates are scored one per lane by the wave that owns their words, no workgroup barrier: levels from registers; a
+//     candidate with a slot of unknown frequency that the bound does not rule out waits on the wave's queue, and the queue is
+//     worked off 64 at a time — the exact frequencies come from the postings (directory cell -> block -> register row reader).
 //   * per task: min(matches, k) ranked (docID, score) pairs and the match count; k_topk_merge folds a query's tasks.
 constexpr int PLK_WG = 512;
-constexpr uint32_t PLK_MAX_SPARSE = 6;  // slots whose lists are decoded per window (LDS planes); the planner sends wider queries to k_fused
+constexpr uint32_t PLK_MAX_SPARSE = 6;  // slots whose lists are decoded per task (LDS planes); the planner sends wider queries to k_fused
 constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per thread when it is pruned)
 constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
-constexpr uint32_t PLK_MAXPAT = 32;     // level assignments of the candidate filter kept as such (more: one per essential slot)
+constexpr uint32_t PLK_MAXPAT = 32;     // level assignments of the candidate filter kept as such (more: coarser filters)
 constexpr uint32_t PLK_WGS_PER_CU = 2;
 constexpr uint32_t PLK_WQ = 128;        // per-wave queue of candidates waiting for a frequency lookup: worked off 64 at a time, every lane busy
-constexpr uint32_t PLK_NS_SMALL = 5;    // the instantiation for queries of up to this many slots keeps four words per slot in registers
+constexpr uint32_t PLK_NS_SMALL = 5;    // the instantiation for queries of up to this many slots keeps six words per slot in registers
+constexpr uint32_t PLK_PAD = 0xffffffffu; // list padding (sorts last)
 static_assert(PL_WORDS == 2 * PLK_WG, "the sweep gives every thread two words of the window");
 static_assert(PLK_CAP == PLK_WG && TOPK_MAX < PLK_PRUNE_AT && PLK_PRUNE_AT < PLK_CAP, "pruning leaves room; a pruned buffer is below the stop mark");
 
@@ -140,43 +149,31 @@ struct PlanesShared {
         double tk_s[PLK_CAP];
         uint32_t tk_d[PLK_CAP];
         DevTerm term[FUS_MAX_SLOTS];
-        double tab1[FUS_MAX_SLOTS]; // per slot: what its scorers add at frequency 1
-        double ub[FUS_MAX_SLOTS];   // per slot: an upper bound of what they add at any frequency
-        double w1[FUS_MAX_SLOTS];   // per slot: tab1 rounded up a hair (the filter must never lose a tie to rounding)
+        double wl[FUS_MAX_SLOTS][4]; // per slot and level: what its scorers add (exact below the slot's top level)
+        double wf[FUS_MAX_SLOTS][4]; // ... rounded up a hair for the filter (it must never lose a tie to rounding), non-decreasing in the level; top level: a bound
         double thr_s;
         uint32_t thr_d;
-        uint32_t tk_n, tk_full, matches, ess; // ess: the slots whose frequencies are worth decoding (some assignment names them)
-        uint32_t leaf;                        // the slots that have a scorer
-        uint32_t npat;                        // the candidate filter: 0xffffffff = every match (no threshold yet), else that many assignments
-        uint32_t pat[PLK_MAXPAT];             // ... bits 0-7: slots at level >= 1, bits 8-15: slots at level 2
+        uint32_t tk_n, tk_full, matches;
+        uint32_t leaf;                // the slots that have a scorer
+        uint32_t top[FUS_MAX_SLOTS];  // per slot: its top level (3: a term plane; 2: a decoded list; 0: no scorer)
+        uint32_t npat;                // the candidate filter: 0xffffffff = every match (no threshold yet), else that many assignments
+        uint32_t pat[PLK_MAXPAT];     // ... two bits per slot: the level the slot must at least be at
         uint32_t flag[PLK_WG / 64];
-        uint32_t wq[PLK_WG / 64][PLK_WQ]; // per wave: candidates waiting for exact frequencies (rel docID << 16 | level-2 slots << 8 | slots held)
+        uint32_t wq[PLK_WG / 64][PLK_WQ]; // per wave: candidates waiting for exact frequencies (rel docID << 16 | the slots' levels, two bits each)
         uint32_t bcast[4];
-        uint32_t rng_lo[2][FUS_MAX_SLOTS], rng_cnt[2][FUS_MAX_SLOTS]; // per window parity: the decoded slots' row ranges
-        uint32_t alive[2];                                             // ... and the slots whose lists are not exhausted
-        uint32_t hint_row[FUS_MAX_SLOTS], hint_doc[FUS_MAX_SLOTS];     // a row that reached beyond its window: its first document past it
+        uint32_t sp_row0[FUS_MAX_SLOTS], sp_n[FUS_MAX_SLOTS], sp_base[FUS_MAX_SLOTS]; // decoded slots: first row, rows, first entry of the list in the scratch region
+        uint32_t cur[FUS_MAX_SLOTS];  // ... the list's next entry
+        uint32_t more;                // a window took a whole chunk of some list: its set pass goes round again
         DevFused fq;
 };
 static_assert(sizeof(PlanesShared) * PLK_WGS_PER_CU <= 160u * 1024u, "two workgroups per CU");
 
-// PlanePost that also keeps the row's first document past the window (k_fused's hint: a sparse list's row is decoded once, not once
-// per window it spans)
-struct PlanePostH {
-        uint32_t *a;
-        uint32_t past = 0xffffffffu;
-        __device__ __forceinline__ void doc(const uint32_t rel) {
-                past = min(past, rel - PL_W);
-                const uint32_t r = min(rel, PL_W);
-                atomicOr(&a[r >> 5], 1u << (r & 31u));
-        }
-        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) {
-                past = min(past, rel - PL_W);
-                const uint32_t r = min(rel, PL_W);
-                const uint32_t bit = 1u << (r & 31u);
-                atomicOr(&a[r >> 5], bit);
-                if ((f & 0xffffu) != 1u)
-                        atomicOr(&a[(r >> 5) + PL_STRIDE], bit);
-        }
+// A row of a decoded slot into its list: 32 entries per row (docID << 1 | frequency-is-not-1), the unused ones of a short last row padded.
+struct ListPost {
+        uint32_t *out;
+        uint32_t i = 0;
+        __device__ __forceinline__ void doc(const uint32_t rel) { out[i++] = rel << 1 | 1u; }
+        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) { out[i++] = rel << 1 | ((f & 0xffffu) != 1u ? 1u : 0u); }
 };
 
 // Keep the best k of the n (<= PLK_CAP = PLK_WG) buffered candidates, best first (rank by counting: the order is strict).
@@ -209,124 +206,85 @@ __device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t 
         __syncthreads();
 }
 
-// MaxScore's essential slots — the fallback filter: with the slots ordered by their score bound, the longest prefix whose bounds sum to
-// less than the k-th best cannot lift a document over it; a bit set of the OTHER slots, same value in every lane.
-__device__ __forceinline__ uint32_t planes_essential(const PlanesShared &sh, const uint32_t nslots) {
-        const double thr = sh.thr_s;
-        uint32_t done = 0, ess = 0;
-        double p = 0.0;
-        for (uint32_t r = 0; r < nslots; ++r) { // selection by ascending bound (<= 8 slots)
-                uint32_t best = 0;
-                double bv = 1e300;
-                for (uint32_t sl = 0; sl < nslots; ++sl)
-                        if (!((done >> sl) & 1u) && sh.ub[sl] < bv) {
-                                bv = sh.ub[sl];
-                                best = sl;
-                        }
-                done |= 1u << best;
-                p += bv;
-                if (!(p < thr)) // this slot (and every later one) can carry a document over the threshold
-                        ess |= 1u << best;
-        }
-        return ess;
-}
-
-// The candidate filter, recomputed whenever the threshold moves (every thread calls it; it ends with a barrier).  Every scoring slot is
-// at level 0 (absent), 1 (frequency 1: adds exactly tab1) or 2 (another frequency: adds at most ub >= tab1) in a document, so a
-// document's score is at most the sum of its slots' level weights.  The MINIMAL level assignments whose weights reach the current k-th
-// best score are listed (lowering any slot by one level drops below it); a match is a candidate iff it is at least at those levels for
-// one of them.  3^nslots assignments, a few per thread.  No threshold yet, or one that rules nothing out: every match is a candidate.
+// The candidate filter, recomputed whenever the threshold moves (every thread calls it; it ends with a barrier).  Every scoring slot
+// is at a level 0 .. top[slot] in a document and adds at most wf[slot][level] there (exactly, below the top level), so a document's
+// score is at most the sum of its slots' level weights.  The MINIMAL level assignments whose weights reach the current k-th best
+// score are listed (lowering any slot by one level drops below it); a match is a candidate iff it is at least at those levels for
+// one of them.  At most 4^nslots assignments, spread over the threads.  Too many minimal ones: the same with only "present / absent"
+// per slot (weights: the bounds); still too many: the slots MaxScore calls essential, one each.  No threshold yet, or one that
+// rules nothing out: every match is a candidate.
 __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         const uint32_t tid = threadIdx.x;
         const double thr = sh.thr_s;
         const bool full = uni(sh.tk_full) != 0 && 0.0 < thr;
-        const uint32_t leaf = uni(sh.leaf);
         sh.npat = full ? 0u : 0xffffffffu; // (uniform stores)
-        sh.ess = (1u << nslots) - 1u;
         __syncthreads();
         if (!full)
                 return;
-        uint32_t total = 1;
-        for (uint32_t sl = 0; sl < nslots; ++sl)
-                total *= 3u;
-        for (uint32_t a = tid; a < total; a += PLK_WG) {
-                uint32_t lv[FUS_MAX_SLOTS], x = a;
-                bool valid = a != 0;
-                for (uint32_t sl = 0; sl < nslots; ++sl) {
-                        lv[sl] = x % 3u;
-                        x /= 3u;
-                        valid &= lv[sl] == 0 || ((leaf >> sl) & 1u); // (a slot without a scorer adds nothing at any level)
-                }
-                if (!valid)
-                        continue;
-                auto reaches = [&](const uint32_t lowered) { // (lowered: the slot taken down one level; nslots: none)
-                        double sum = 0.0;
+        for (int coarse = 0; coarse < 2; ++coarse) {
+                uint32_t total = 1;
+                for (uint32_t sl = 0; sl < nslots; ++sl)
+                        total *= (coarse ? (uni(sh.top[sl]) ? 2u : 1u) : uni(sh.top[sl]) + 1u);
+                for (uint32_t a = tid; a < total; a += PLK_WG) {
+                        uint32_t lv[FUS_MAX_SLOTS], x = a;
                         for (uint32_t sl = 0; sl < nslots; ++sl) {
-                                const uint32_t l = lv[sl] - (sl == lowered ? 1u : 0u);
-                                sum += l == 2 ? sh.ub[sl] : l == 1 ? sh.w1[sl] : 0.0;
+                                const uint32_t base = coarse ? (sh.top[sl] ? 2u : 1u) : sh.top[sl] + 1u;
+                                lv[sl] = x % base;
+                                x /= base;
+                                if (coarse && lv[sl])
+                                        lv[sl] = sh.top[sl]; // (present: weighed with the slot's bound, required at level 1 below)
                         }
-                        return !(sum < thr);
-                };
-                bool minimal = reaches(nslots);
-                for (uint32_t sl = 0; sl < nslots && minimal; ++sl)
-                        if (lv[sl] && reaches(sl))
-                                minimal = false;
-                if (minimal) {
-                        uint32_t m1 = 0, m2 = 0;
-                        for (uint32_t sl = 0; sl < nslots; ++sl) {
-                                m1 |= (lv[sl] ? 1u : 0u) << sl;
-                                m2 |= (lv[sl] == 2 ? 1u : 0u) << sl;
+                        if (!a)
+                                continue;
+                        auto reaches = [&](const uint32_t lowered) { // (lowered: the slot taken down one level — coarse: to absent; nslots: none)
+                                double sum = 0.0;
+                                for (uint32_t sl = 0; sl < nslots; ++sl) {
+                                        const uint32_t l = sl == lowered ? (coarse ? 0u : lv[sl] - 1u) : lv[sl];
+                                        sum += l ? sh.wf[sl][l] : 0.0;
+                                }
+                                return !(sum < thr);
+                        };
+                        bool minimal = reaches(nslots);
+                        for (uint32_t sl = 0; sl < nslots && minimal; ++sl)
+                                if (lv[sl] && reaches(sl))
+                                        minimal = false;
+                        if (minimal) {
+                                uint32_t code = 0;
+                                for (uint32_t sl = 0; sl < nslots; ++sl)
+                                        code |= (coarse ? (lv[sl] ? 1u : 0u) : lv[sl]) << (2 * sl);
+                                const uint32_t at = atomicAdd(&sh.npat, 1u);
+                                if (at < PLK_MAXPAT)
+                                        sh.pat[at] = code;
                         }
-                        const uint32_t at = atomicAdd(&sh.npat, 1u);
-                        if (at < PLK_MAXPAT)
-                                sh.pat[at] = m1 | m2 << 8;
                 }
-        }
-        __syncthreads();
-        uint32_t np = uni(sh.npat);
-        if (np > PLK_MAXPAT) {
-                // too many assignments: one level only — the minimal SETS of slots whose bounds reach the threshold (a weaker filter,
-                // never a wrong one; at most C(8, 4) = 70 of them, 10 for five slots)
+                __syncthreads();
+                if (uni(sh.npat) <= PLK_MAXPAT)
+                        return;
+                PROF_COUNT(21 + coarse, tid == 0 ? 1 : 0);
                 __syncthreads(); // (every lane has read npat)
                 sh.npat = 0;
                 __syncthreads();
-                if (tid && tid < (1u << nslots) && !(tid & ~leaf)) {
-                        auto reaches = [&](const uint32_t pset) {
-                                double sum = 0.0;
-                                for (uint32_t sl = 0; sl < nslots; ++sl)
-                                        if ((pset >> sl) & 1u)
-                                                sum += sh.ub[sl];
-                                return !(sum < thr);
-                        };
-                        bool minimal = reaches(tid);
-                        for (uint32_t sl = 0; sl < nslots && minimal; ++sl)
-                                if (((tid >> sl) & 1u) && reaches(tid & ~(1u << sl)))
-                                        minimal = false;
-                        if (minimal) {
-                                const uint32_t at = atomicAdd(&sh.npat, 1u);
-                                if (at < PLK_MAXPAT)
-                                        sh.pat[at] = tid;
+        }
+        // MaxScore's essential slots: with the slots ordered by their bound, the longest prefix whose bounds sum to less than the
+        // threshold cannot lift a document over it; a match must hold one of the others
+        uint32_t done = 0, np = 0;
+        double p = 0.0;
+        for (uint32_t r = 0; r < nslots; ++r) { // selection by ascending bound (<= 8 slots); same values in every lane
+                uint32_t best = 0;
+                double bv = 1e300;
+                for (uint32_t sl = 0; sl < nslots; ++sl) {
+                        const double b = sh.top[sl] ? sh.wf[sl][sh.top[sl]] : 0.0;
+                        if (!((done >> sl) & 1u) && b < bv) {
+                                bv = b;
+                                best = sl;
                         }
                 }
-                __syncthreads();
-                np = uni(sh.npat);
-                PROF_COUNT(21, tid == 0 ? 1 : 0);
+                done |= 1u << best;
+                p += bv;
+                if (!(p < thr) && sh.top[best])
+                        sh.pat[np++] = 1u << (2 * best); // (uniform stores)
         }
-        if (np > PLK_MAXPAT) { // still too many: the essential slots, one set each
-                const uint32_t e = planes_essential(sh, nslots);
-                __syncthreads(); // (every lane has read npat)
-                np = 0;
-                for (uint32_t sl = 0; sl < nslots; ++sl)
-                        if ((e >> sl) & 1u)
-                                sh.pat[np++] = 1u << sl; // (uniform stores)
-                sh.npat = np;
-                __syncthreads();
-                PROF_COUNT(22, tid == 0 ? 1 : 0);
-        }
-        uint32_t need = 0;
-        for (uint32_t i = 0; i < np; ++i)
-                need |= sh.pat[i] & 0xffu;
-        sh.ess = uni(need);
+        sh.npat = np;
         __syncthreads();
 }
 
@@ -376,7 +334,31 @@ __device__ __noinline__ uint32_t planes_lookup_freq(const uint8_t *__restrict__ 
         return probe.f & 0xffffu;
 }
 
-// NS: the slots the instantiation keeps in registers (four words each: A and level-2 words of the thread's two window words)
+// One row of a decoded slot into its list (out of line: the row readers' registers must not weigh on the window loop)
+template <int CODEC>
+__device__ __noinline__ void planes_list_row(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+                                             const uint4 *__restrict__ blk_rec, const uint32_t *__restrict__ blk_doff, const DevTerm &t, const uint32_t b,
+                                             uint32_t *__restrict__ out) {
+        const uint32_t *bl = blk_last + t.first_block;
+        const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
+        ListPost post{out};
+#ifdef TRI_PROF
+        ProfClock prof_;
+#endif
+        if (CODEC == CODEC_LUCENE) {
+                const uint4 rec = blk_rec[t.first_block + b];
+                row_decode<CODEC, true, ListPost>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, 0u, post PROF_PASS);
+        } else {
+                const uint32_t off = blk_off[t.first_block + b];
+                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
+                row_decode<CODEC, true, ListPost>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, 0u, post PROF_PASS);
+        }
+        for (uint32_t i = post.i; i < 32; ++i)
+                out[i] = PLK_PAD;
+}
+
+// NS: the slots the instantiation keeps in registers (six words each: the A, B and C words of the thread's two window words).
+// scratch: sparse_cap u32 per workgroup — the lists of the task's decoded slots.
 template <int CODEC, int NS>
 __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void k_planes(
         const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
@@ -384,10 +366,11 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
         const DevFused *__restrict__ fused, const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched, const uint32_t *__restrict__ sterms,
         const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket, uint32_t *__restrict__ counts, const uint32_t k,
         uint32_t *__restrict__ part_docs, double *__restrict__ part_scores, uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked,
-        const int sim, const uint32_t *__restrict__ planes, const uint32_t plw) {
+        const int sim, const uint32_t *__restrict__ planes, const uint32_t plw, uint32_t *__restrict__ scratch, const uint32_t sparse_cap) {
         __shared__ PlanesShared sh;
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
         const uint32_t wave = uni(tid >> 6);
+        uint32_t *const lists = scratch + (size_t)blockIdx.x * sparse_cap;
         for (uint32_t i = tid; i < PLK_MAX_SPARSE * 2 * PL_STRIDE; i += PLK_WG)
                 (&sh.pl[0][0])[i] = 0;
         PROF_DECL;
@@ -413,230 +396,183 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 const DevFused &fq = sh.fq;
                 const uint32_t nslots = min(uni(fq.nslots), (uint32_t)NS), nreq = uni(fq.nreq), negs = uni(fq.negslots);
                 const uint32_t kk = min(lane, nslots - 1); // lane s (< nslots) of every wave looks after slot s, the lanes above mirror the last slot
+                const uint32_t wfirst = task.tile_begin, wend = task.tile_end;
                 {
-                        sh.term[kk] = terms[fq.term[kk]];
-                        sh.hint_row[kk] = 0xffffffffu;
-                        // what the slot's scorers add at frequency 1, and a bound of what they add at any frequency: BM25 float(w f / (f + 1.2)) < w;
+                        const DevTerm myt = terms[fq.term[kk]];
+                        sh.term[kk] = myt;
+                        const bool dense = fq.plane[kk] != PL_NONE;
+                        // what the slot's scorers add at frequency 1 and 2, and a bound of what they add at any frequency: BM25 float(w f / (f + 1.2)) < w;
                         // TF-IDF sqrt(f) w with f <= 65535; Trivial f
-                        double t1 = 0.0, ubs = 0.0;
+                        double t1 = 0.0, t2 = 0.0, ubs = 0.0;
                         bool leaf = false;
                         for (uint32_t si = 0; si < q.nscore; ++si)
                                 if (sterms[q.score_base + si] == fq.term[kk]) {
                                         const double wgt = sweights[q.score_base + si];
                                         t1 += (double)sim_score(sim, wgt, 1u);
+                                        t2 += (double)sim_score(sim, wgt, 2u);
                                         ubs += sim == TRI_SIM_TRIVIAL ? 65535.0 : sim == TRI_SIM_TFIDF ? (wgt > 0 ? 256.0 * wgt : 0.0) : (wgt > 0 ? wgt : 0.0);
                                         leaf = true;
                                 }
-                        sh.tab1[kk] = t1;
-                        sh.w1[kk] = t1 > 0 ? t1 * (1.0 + 1e-9) : t1 * (1.0 - 1e-9);
-                        sh.ub[kk] = fmax(ubs * (1.0 + 1e-6), t1 > 0 ? t1 * (1.0 + 1e-9) : 0.0);
+                        const uint32_t top = !leaf ? 0u : dense ? 3u : 2u;
+                        auto up = [](const double x) { return x > 0 ? x * (1.0 + 1e-9) : x * (1.0 - 1e-9); };
+                        const double bound = fmax(ubs * (1.0 + 1e-6), fmax(up(t1), up(t2)));
+                        sh.wl[kk][0] = 0.0, sh.wl[kk][1] = t1, sh.wl[kk][2] = t2, sh.wl[kk][3] = 0.0;
+                        // the filter's weights: non-decreasing in the level (a negative contribution is bounded by the level below), the top one a bound
+                        const double f1 = fmax(up(t1), 0.0), f2 = top == 3 ? fmax(up(t2), f1) : bound;
+                        sh.wf[kk][0] = 0.0, sh.wf[kk][1] = f1, sh.wf[kk][2] = f2, sh.wf[kk][3] = bound;
+                        sh.top[kk] = top;
                         const uint64_t lm = __builtin_amdgcn_ballot_w64(leaf && lane < nslots);
                         sh.leaf = (uint32_t)lm; // (same value from every lane)
                         sh.tk_n = 0;
                         sh.tk_full = 0;
                         sh.matches = 0;
-                        sh.ess = (1u << nslots) - 1u; // no threshold yet: every slot's frequencies are wanted ...
-                        sh.npat = 0xffffffffu;        // ... and every match is a candidate
+                        sh.more = 0;
+                        sh.npat = 0xffffffffu; // no threshold yet: every match is a candidate
+                        // a decoded slot's rows that can hold documents of the task's range [first window's first docID, last window's end)
+                        uint32_t row0 = 0, nrows = 0;
+                        if (!dense) {
+                                const uint32_t *bl = blk_last + myt.first_block;
+                                const uint32_t d0 = wfirst * PL_W, d1 = wend * PL_W; // (the planner keeps max docID below 2^31: no wrap)
+                                uint32_t lo = 0, hi = myt.nblocks;
+                                while (lo < hi) {
+                                        const uint32_t mid = (lo + hi) >> 1;
+                                        if (bl[mid] < d0)
+                                                lo = mid + 1;
+                                        else
+                                                hi = mid;
+                                }
+                                row0 = lo;
+                                hi = myt.nblocks;
+                                while (lo < hi) {
+                                        const uint32_t mid = (lo + hi) >> 1;
+                                        if (bl[mid] < d1)
+                                                lo = mid + 1;
+                                        else
+                                                hi = mid;
+                                }
+                                nrows = row0 < myt.nblocks ? min(lo, myt.nblocks - 1) - row0 + 1 : 0;
+                        }
+                        // the lists' places in the scratch region: an exclusive scan over the slots (lanes 0 .. nslots-1 hold distinct slots)
+                        uint32_t base = 0;
+                        for (uint32_t s2 = 0; s2 < nslots; ++s2) {
+                                const uint32_t n2 = (uint32_t)__builtin_amdgcn_readlane((int)nrows, (int)s2);
+                                base += s2 < kk ? n2 * 32u : 0u;
+                        }
+                        sh.sp_row0[kk] = row0;
+                        sh.sp_n[kk] = nrows;
+                        sh.sp_base[kk] = base;
+                        sh.cur[kk] = 0;
                 }
                 __syncthreads();
                 // ---- per task, uniform: which slots read term planes, where the others' LDS planes are, which slots score
                 uint32_t dense_mask = 0;
                 const uint32_t leaf_mask = uni(sh.leaf);
-                uint32_t lidx[NS];
+                uint32_t lidx[NS], top[NS];
                 size_t pbase[NS];
+                uint32_t list_rows = 0;
                 {
                         uint32_t nl = 0;
 #pragma unroll
                         for (uint32_t s = 0; s < NS; ++s) {
                                 const uint32_t prow = s < nslots ? uni(fq.plane[s]) : PL_NONE;
-                                pbase[s] = prow != PL_NONE ? (size_t)prow * 2 * plw : 0;
+                                pbase[s] = prow != PL_NONE ? (size_t)prow * PL_PLANES * plw : 0;
                                 lidx[s] = 0;
+                                top[s] = s < nslots ? uni(sh.top[s]) : 0u;
                                 if (s < nslots) {
                                         if (prow != PL_NONE)
                                                 dense_mask |= 1u << s;
-                                        else
+                                        else {
                                                 lidx[s] = nl++;
+                                                list_rows += uni(sh.sp_n[s]);
+                                        }
                                 }
                         }
                 }
                 const uint32_t sparse_mask = ((1u << nslots) - 1u) & ~dense_mask;
-                const uint32_t wfirst = task.tile_begin, wend = task.tile_end;
-                // ---- wave 0, lane s: the directory position of decoded slot s (indexed lists: two cell-index entries per window; short lists:
-                //      a cursor with its block's last docID)
-                uint32_t cur = 0, cur_last = 0xffffffffu;
-                const DevTerm myt = sh.term[kk];
-                const uint32_t *mybl = blk_last + myt.first_block;
-                const bool my_sparse = (sparse_mask >> kk) & 1u, my_indexed = myt.win_off != 0xffffffffu;
-                if (wave == 0 && my_sparse && !my_indexed) {
-                        uint32_t lo = 0, hi = myt.nblocks; // first block whose last document >= the task's first docID
-                        const uint32_t key = wfirst * PL_W;
-                        while (lo < hi) {
-                                const uint32_t mid = (lo + hi) >> 1;
-                                if (mybl[mid] < key)
-                                        lo = mid + 1;
-                                else
-                                        hi = mid;
-                        }
-                        cur = lo;
-                        cur_last = cur < myt.nblocks ? mybl[cur] : 0xffffffffu;
-                }
-                // rows of my slot that can hold documents of window w: [lo, hi] (first row whose last docID >= w0 ... first whose last >= the
-                // next window's first docID); nothing when lo is beyond the list
-                auto range_of = [&](const uint32_t w, uint32_t &lo, uint32_t &cnt) {
-                        const uint32_t w0 = w * PL_W;
-                        uint32_t hi;
-                        if (!my_sparse) {
-                                lo = 0;
-                                cnt = 0;
-                                return;
-                        }
-                        if (my_indexed) {
-                                lo = win[myt.win_off + w * PL_CELLS];
-                                hi = win[myt.win_off + (w + 1) * PL_CELLS];
-                        } else {
-                                while (cur < myt.nblocks && cur_last < w0) {
-                                        ++cur;
-                                        cur_last = cur < myt.nblocks ? mybl[cur] : 0xffffffffu;
+                PROF_LAP(0);
+                // ---- the decoded slots' lists: every row that can reach the task's range, one lane per row, 32 entries each
+                for (uint32_t v0 = 0; v0 < list_rows; v0 += PLK_WG) {
+                        const uint32_t v = v0 + tid;
+                        if (v < list_rows) {
+                                uint32_t s = 0, r = v;
+                                for (uint32_t s2 = 0; s2 < nslots; ++s2) { // which slot's rows v falls into
+                                        const uint32_t n2 = ((sparse_mask >> s2) & 1u) ? uni(sh.sp_n[s2]) : 0u;
+                                        if (s == s2 && r >= n2) {
+                                                r -= n2;
+                                                s = s2 + 1;
+                                        }
                                 }
-                                lo = hi = cur;
-                                if (cur_last < w0 + (PL_W - 1)) // (rare for a short list: further blocks end inside the window)
-                                        while (hi + 1 < myt.nblocks && mybl[hi] < w0 + (PL_W - 1))
-                                                ++hi;
+                                planes_list_row<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, sh.term[s], sh.sp_row0[s] + r, lists + sh.sp_base[s] + r * 32u);
                         }
-                        hi = min(hi, myt.nblocks - 1);
-                        cnt = lo < myt.nblocks ? hi - lo + 1 : 0xffffffffu; // (0xffffffff: the list is exhausted)
-                };
-                // wave 0 only, behind a barrier that follows the last set pass: the ranges of window w for everybody.  A row known (from the
-                // hint it left when it was decoded) to continue past this window without a document in it adds nothing here — decided once,
-                // by one wave, so that every wave works from the same ranges
-                auto publish = [&](const uint32_t w, const uint32_t lo, uint32_t cnt) {
-                        const bool dead = my_sparse && cnt == 0xffffffffu;
-                        const uint64_t dm = __builtin_amdgcn_ballot_w64(dead);
-                        if (dead)
-                                cnt = 0;
-                        if (cnt && sh.hint_row[kk] == lo && sh.hint_doc[kk] > w * PL_W + (PL_W - 1))
-                                cnt = 0; // (then lo is the slot's only row here: a row that reaches past the window is the last one that touches it)
-                        if (lane < nslots) {
-                                sh.rng_lo[w & 1u][kk] = lo;
-                                sh.rng_cnt[w & 1u][kk] = cnt;
-                        }
-                        sh.alive[w & 1u] = ~(uint32_t)dm; // (same value from every lane)
-                };
-                if (wave == 0) {
-                        uint32_t lo, cnt;
-                        range_of(wfirst, lo, cnt);
-                        publish(wfirst, lo, cnt);
                 }
-                __syncthreads();
+                __syncthreads(); // (the lists are written: a workgroup barrier orders the global stores for the workgroup's own later loads)
+                PROF_LAP(7);
                 uint32_t my_matches = 0;
+                // the lists' cursors as every wave sees them in a set pass: read behind the barrier that follows the previous one (never while
+                // another wave may be adding to them)
+                uint32_t curv[NS];
+#pragma unroll
+                for (uint32_t s = 0; s < NS; ++s)
+                        curv[s] = 0;
                 for (uint32_t w = wfirst; w < wend; ++w) {
-                        const uint32_t par = w & 1u, w0 = w * PL_W;
-                        // ---- this window's row ranges (left by wave 0 a window ago)
-                        uint32_t s_lo[NS], s_cnt[NS], total = 0, rows_mask = 0;
-                        const uint32_t alive = uni(sh.alive[par]);
+                        const uint32_t w0 = w * PL_W, wE = w0 + PL_W;
+                        // ---- the term planes' words of this thread's two window words: a = plane A, b = plane B (frequency not 1), c = plane C (nor 2)
+                        uint32_t a0[NS], a1[NS], b0[NS], b1[NS], c0w[NS], c1w[NS];
 #pragma unroll
                         for (uint32_t s = 0; s < NS; ++s) {
-                                s_lo[s] = 0;
-                                s_cnt[s] = 0;
-                                if (s < nslots && ((sparse_mask >> s) & 1u)) {
-                                        s_lo[s] = uni(sh.rng_lo[par][s]);
-                                        s_cnt[s] = uni(sh.rng_cnt[par][s]);
-                                        total += s_cnt[s];
-                                        if (s_cnt[s])
-                                                rows_mask |= 1u << s;
-                                }
-                        }
-                        // a required group all of whose lists are exhausted ends the task; one that neither reads a term plane nor has a row in
-                        // this window rules the window out
-                        bool dead = false, possible = true;
-                        for (uint32_t g = 0; g < nreq; ++g) {
-                                const uint32_t gs = uni(fq.gslots[g]);
-                                dead |= !(gs & (dense_mask | alive));
-                                possible &= (gs & (dense_mask | rows_mask)) != 0;
-                        }
-                        if (dead)
-                                break;
-                        // wave 0 fetches the next window's directory entries now; they are published behind the set pass
-                        uint32_t n_lo = 0, n_cnt = 0;
-                        const bool more = w + 1 < wend;
-                        if (wave == 0 && more)
-                                range_of(w + 1, n_lo, n_cnt);
-                        if (!possible) {
-                                if (wave == 0 && more)
-                                        publish(w + 1, n_lo, n_cnt);
-                                __syncthreads();
-                                continue;
-                        }
-                        // ---- the term planes' words of this thread's two window words travel while the other lists are decoded: a = plane A,
-                        //      h = the level-2 plane (B: frequency not 1)
-                        uint32_t a0[NS], a1[NS], h0[NS], h1[NS];
-#pragma unroll
-                        for (uint32_t s = 0; s < NS; ++s) {
-                                a0[s] = a1[s] = h0[s] = h1[s] = 0;
+                                a0[s] = a1[s] = b0[s] = b1[s] = c0w[s] = c1w[s] = 0;
                                 if ((dense_mask >> s) & 1u) {
                                         const uint32_t *pa = planes + pbase[s] + (size_t)w * PL_WORDS;
                                         a0[s] = pa[tid];
                                         a1[s] = pa[tid + PLK_WG];
                                         if ((leaf_mask >> s) & 1u) {
-                                                h0[s] = pa[plw + tid];
-                                                h1[s] = pa[plw + tid + PLK_WG];
+                                                b0[s] = pa[plw + tid];
+                                                b1[s] = pa[plw + tid + PLK_WG];
+                                                c0w[s] = pa[2 * plw + tid];
+                                                c1w[s] = pa[2 * plw + tid + PLK_WG];
                                         }
                                 }
                         }
-                        const uint32_t ess = uni(sh.ess);
                         PROF_LAP(1);
-                        // ---- set pass: the rows of the decoded slots form one work list, one lane per row; a slot no assignment of the filter
-                        //      names is decoded for presence only
-                        for (uint32_t v0 = 0; v0 < total; v0 += PLK_WG) {
-                                const uint32_t v = v0 + tid;
-                                uint32_t s = 0, r = v, lo = s_lo[0];
+                        // ---- set pass: the decoded slots' entries of this window, a chunk of PLK_WG per slot and round, into the LDS planes
+                        uint32_t rows_mask = 0; // (decoded slots that may have put something into the planes)
+                        for (;;) {
 #pragma unroll
-                                for (uint32_t k2 = 0; k2 + 1 < NS; ++k2) { // which slot's rows v falls into (ranges are wave-uniform)
-                                        const bool nextslot = s == k2 && r >= s_cnt[k2];
-                                        r = nextslot ? r - s_cnt[k2] : r;
-                                        lo = nextslot ? s_lo[k2 + 1] : lo;
-                                        s = nextslot ? k2 + 1 : s;
+                                for (uint32_t s = 0; s < NS; ++s) {
+                                        if (!((sparse_mask >> s) & 1u))
+                                                continue;
+                                        const uint32_t cur = curv[s], n = uni(sh.sp_n[s]) * 32u;
+                                        if (cur >= n)
+                                                continue;
+                                        rows_mask |= 1u << s;
+                                        const uint32_t e = cur + tid < n ? lists[uni(sh.sp_base[s]) + cur + tid] : PLK_PAD;
+                                        const uint32_t d = e >> 1;
+                                        const bool before = d < wE; // (ascending: the entries below the window's end are a prefix of the chunk)
+                                        if (before && d >= w0) {
+                                                uint32_t *p = &sh.pl[lidx[s]][0];
+                                                const uint32_t r = d - w0, bit = 1u << (r & 31u);
+                                                atomicOr(&p[r >> 5], bit);
+                                                if (e & 1u)
+                                                        atomicOr(&p[PL_STRIDE + (r >> 5)], bit);
+                                        }
+                                        const uint32_t cnt = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(before));
+                                        atomicAdd(&sh.cur[s], lane == 0 ? cnt : 0u); // (every lane issues it: no single-lane branch)
+                                        if (wave == PLK_WG / 64 - 1 && cnt == 64)
+                                                sh.more = 1; // (the whole chunk lies below the window's end: there may be more)
                                 }
-                                const bool act = v < total;
-                                const bool needf = act && ((ess >> s) & 1u);
-                                const bool anyf = __builtin_amdgcn_ballot_w64(needf) != 0ull; // (wave-uniform: one code path per wave)
-                                if (act) {
-                                        const DevTerm t = sh.term[s];
-                                        const uint32_t b = lo + r;
-                                        const uint32_t *bl = blk_last + t.first_block;
-                                        const uint32_t prev = b ? bl[b - 1] : 0;
-                                        const uint32_t last = bl[b];
-                                        uint32_t ls = 0;
+                                PROF_LAP(2);
+                                __syncthreads();
+                                PROF_LAP(3);
 #pragma unroll
-                                        for (uint32_t k2 = 0; k2 < NS; ++k2)
-                                                ls = s == k2 ? lidx[k2] : ls;
-                                        PlanePostH post{&sh.pl[ls][0]};
-                                        if (CODEC == CODEC_LUCENE) {
-                                                const uint4 rec = blk_rec[t.first_block + b];
-                                                if (anyf)
-                                                        row_decode<CODEC, true, PlanePostH>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, post PROF_PASS);
-                                                else
-                                                        row_decode<CODEC, false, PlanePostH>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, post PROF_PASS);
-                                        } else {
-                                                const uint32_t off = blk_off[t.first_block + b];
-                                                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
-                                                if (anyf)
-                                                        row_decode<CODEC, true, PlanePostH>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, post PROF_PASS);
-                                                else
-                                                        row_decode<CODEC, false, PlanePostH>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, post PROF_PASS);
-                                        }
-                                        if (post.past < 0x80000000u) { // the row reaches past the window (it is the slot's last row here): leave the hint
-                                                sh.hint_row[s] = b;
-                                                sh.hint_doc[s] = w0 + PL_W + post.past;
-                                        }
-                                }
+                                for (uint32_t s = 0; s < NS; ++s)
+                                        if ((sparse_mask >> s) & 1u)
+                                                curv[s] = uni(sh.cur[s]); // (stable until the next set pass, which lies behind another barrier)
+                                if (!uni(sh.more))
+                                        break;
+                                __syncthreads(); // (every lane has read the flag)
+                                sh.more = 0;
+                                __syncthreads();
                         }
-                        const uint32_t nof = sparse_mask & ~ess; // decoded slots whose B plane says nothing in this window: level 2 wherever present
-                        PROF_LAP(2);
-                        __syncthreads();
-                        PROF_LAP(3);
-                        if (wave == 0 && more) // (this window's hints are in; the next barrier — the sweep's — makes the ranges visible)
-                                publish(w + 1, n_lo, n_cnt);
                         // ---- sweep: the decoded slots' words, the predicate, the candidates
 #pragma unroll
                         for (uint32_t s = 0; s < NS; ++s)
@@ -644,10 +580,8 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         const uint32_t *p = &sh.pl[lidx[s]][0];
                                         a0[s] = p[tid];
                                         a1[s] = p[tid + PLK_WG];
-                                        if ((leaf_mask >> s) & 1u) {
-                                                h0[s] = ((nof >> s) & 1u) ? a0[s] : p[PL_STRIDE + tid];
-                                                h1[s] = ((nof >> s) & 1u) ? a1[s] : p[PL_STRIDE + tid + PLK_WG];
-                                        }
+                                        b0[s] = p[PL_STRIDE + tid];
+                                        b1[s] = p[PL_STRIDE + tid + PLK_WG];
                                 }
                         uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;
                         for (uint32_t g = 0; g < nreq; ++g) {
@@ -689,13 +623,16 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         uint32_t x0 = 0xffffffffu, x1 = 0xffffffffu;
 #pragma unroll
                                         for (uint32_t s = 0; s < NS; ++s) {
-                                                if ((ps >> s) & 1u) {
+                                                const uint32_t l = (ps >> (2 * s)) & 3u; // (uniform)
+                                                if (l == 1) {
                                                         x0 &= a0[s];
                                                         x1 &= a1[s];
-                                                }
-                                                if ((ps >> (8 + s)) & 1u) {
-                                                        x0 &= h0[s];
-                                                        x1 &= h1[s];
+                                                } else if (l == 2) {
+                                                        x0 &= b0[s];
+                                                        x1 &= b1[s];
+                                                } else if (l == 3) {
+                                                        x0 &= c0w[s];
+                                                        x1 &= c1w[s];
                                                 }
                                         }
                                         y0 |= x0;
@@ -744,13 +681,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         uint32_t ent = 0;
                                         if (lane < take_n) {
                                                 ent = sh.wq[wave][base + lane];
-                                                const uint32_t doc = w0 + (ent >> 16), held = ent & 0xffu, unk = (ent >> 8) & 0xffu;
+                                                const uint32_t doc = w0 + (ent >> 16);
                                                 double sk = 0.0;
                                                 for (uint32_t s = 0; s < nslots; ++s) {
-                                                        if (!((held >> s) & 1u))
+                                                        const uint32_t l = (ent >> (2 * s)) & 3u;
+                                                        if (!l)
                                                                 continue;
-                                                        if (!((unk >> s) & 1u)) {
-                                                                sk += sh.tab1[s];
+                                                        if (l < sh.top[s]) {
+                                                                sk += sh.wl[s][l];
                                                                 continue;
                                                         }
                                                         const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, sh.term[s], doc);
@@ -788,26 +726,28 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 const uint32_t which = c0 ? 0u : 1u;
                                                 const uint32_t bit = (uint32_t)__builtin_ctz(which ? c1 : c0);
                                                 const uint32_t rel = 32u * (tid + which * PLK_WG) + bit, doc = w0 + rel;
-                                                double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known yet
-                                                uint32_t unk = 0, held = 0;
+                                                double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
+                                                uint32_t levels = 0;
+                                                bool unk = false;
 #pragma unroll
                                                 for (uint32_t s = 0; s < NS; ++s) {
-                                                        const uint32_t av = which ? a1[s] : a0[s], hv = which ? h1[s] : h0[s];
-                                                        if (!((leaf_mask >> s) & 1u) || !((av >> bit) & 1u))
+                                                        if (!top[s] || !(((which ? a1[s] : a0[s]) >> bit) & 1u))
                                                                 continue;
-                                                        held |= 1u << s;
-                                                        if (!((hv >> bit) & 1u))
-                                                                sk += sh.tab1[s];
+                                                        const uint32_t bb = ((which ? b1[s] : b0[s]) >> bit) & 1u, cc = ((which ? c1w[s] : c0w[s]) >> bit) & 1u;
+                                                        const uint32_t l = 1u + bb + (bb & cc);
+                                                        levels |= l << (2 * s);
+                                                        if (l < top[s])
+                                                                sk += sh.wl[s][l];
                                                         else {
-                                                                unk |= 1u << s;
-                                                                sb += sh.ub[s];
+                                                                unk = true;
+                                                                sb += sh.wf[s][l];
                                                         }
                                                 }
                                                 bool done = true;
                                                 if (!full || better(sk + sb, doc, thr_s, thr_d)) {
                                                         if (unk) {
                                                                 enq = true;
-                                                                ent = rel << 16 | unk << 8 | held;
+                                                                ent = rel << 16 | levels;
                                                         } else
                                                                 done = offer(sk, doc); // (no room: the candidate stays for after the prune)
                                                 }

@@ -144,6 +144,8 @@ struct tri_batch {
         std::vector<uint32_t> plane_terms; // row -> term
         uint32_t *d_plane_terms = nullptr, *d_planes = nullptr, *d_qplane = nullptr; // d_qplane: parallel to d_qterms, the term's row or PL_NONE
         uint32_t plw = 0;                  // words of one plane
+        uint32_t *d_sparse = nullptr;      // k_planes: per resident workgroup, the lists of a task's decoded (non-plane) slots
+        uint32_t sparse_cap = 0;           // ... entries per workgroup
         uint64_t term_bytes_planes = 0, plane_decoded_bytes = 0;
         hipEvent_t ev_pl = nullptr, ev_k = nullptr; // after k_term_planes; after k_planes
         std::vector<DevFused> fused; // slot maps of the TASK_FUSED queries (DevQuery::fused_idx)
@@ -200,6 +202,7 @@ struct tri_batch {
                 for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k})
                         if (e)
                                 hipEventDestroy(e);
+                hipFree(d_sparse);
                 hipFree(d_plane_terms);
                 hipFree(d_planes);
                 hipFree(d_qplane);
@@ -1603,7 +1606,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 t.fz.plane[sidx] = PL_NONE;
                                 nsparse += plane_ok(t.fz.term[sidx]) ? 0u : 1u;
                         }
-                        const bool pk = !t.truth && (planes_opt & 4u) && nsparse <= PLK_MAX_SPARSE;
+                        const bool pk = !t.truth && (planes_opt & 4u) && nsparse <= PLK_MAX_SPARSE && ix->max_doc < 0x7fff0000u; // (list entries are docID << 1 | flag)
                         {
                                 const uint32_t fm = (1u << t.fz.fbits) - 1u;
                                 t.fz.negslots = 0;
@@ -1643,6 +1646,22 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                                 const uint32_t *lb = &ix->h_blk_last[tk.first_block];
                                                 b1 += (uint64_t)(std::lower_bound(lb, lb + tk.nblocks, wb * fw) - lb);
                                         }
+                                if (pk) { // the rows of the decoded slots that can reach the task's docID range: 32 list entries each (k_planes)
+                                        uint64_t entries = 0;
+                                        for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
+                                                if (plane_ok(t.fz.term[sidx]))
+                                                        continue;
+                                                const DevTerm &tk = ix->terms[t.fz.term[sidx]];
+                                                const uint32_t *lb = &ix->h_blk_last[tk.first_block];
+                                                const uint32_t r0 = (uint32_t)(std::lower_bound(lb, lb + tk.nblocks, wb * fw) - lb);
+                                                const uint32_t r1 = (uint32_t)(std::lower_bound(lb + r0, lb + tk.nblocks, we * fw) - lb);
+                                                if (r0 < tk.nblocks)
+                                                        entries += 32ull * (std::min(r1, tk.nblocks - 1) - r0 + 1);
+                                        }
+                                        if (entries > 0x7fffffffull)
+                                                return fail(TRI_ERR_UNSUPPORTED, "query %u: a task's decoded lists exceed 2^31 entries", t.q.qid);
+                                        b->sparse_cap = std::max(b->sparse_cap, (uint32_t)entries);
+                                }
                                 order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
                                 b->tasks.push_back({slot, wb, we, pk ? (t.fz.nslots <= PLK_NS_SMALL ? TASK_PLANES : TASK_PLANES8) : t.fz.mode ? TASK_FUSED_GEN : t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off + (emit ? b1 * 32 + 32ull * ord * t.fz.nslots : 0)});
                         }
@@ -1806,8 +1825,13 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         int rcp;
                         if ((rcp = dev_upload(&b->d_qplane, qplane)) || (rcp = dev_upload(&b->d_plane_terms, b->plane_terms)))
                                 return rcp;
-                        HIP_TRY(hipMalloc((void **)&b->d_planes, (size_t)b->plane_terms.size() * 2 * b->plw * 4 + 64));
+                        HIP_TRY(hipMalloc((void **)&b->d_planes, (size_t)b->plane_terms.size() * PL_PLANES * b->plw * 4 + 64));
                 }
+        }
+        if (b->n_planes + b->n_planes8) {
+                b->sparse_cap = (b->sparse_cap + 63u) & ~63u;
+                const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
+                HIP_TRY(hipMalloc((void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
         }
         b->out_capacity = off;
         int rc;
@@ -1861,7 +1885,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->info.nqueries = nq;
         b->info.out_capacity = off;
         b->info.plane_terms = b->plane_terms.size();
-        b->info.plane_bytes = (uint64_t)b->plane_terms.size() * 2 * b->plw * 4;
+        b->info.plane_bytes = (uint64_t)b->plane_terms.size() * PL_PLANES * b->plw * 4;
         b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (b->n_planes8 != 0) + (!b->plane_terms.empty()) +
                            (!b->ptasks.empty()) + (rich ? 2 : 0) +
                            ((scored && b->n_dense + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
@@ -1978,7 +2002,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
 #define TRI_PLANES_ARGS                                                                                                                                      \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, \
                 b->d_sterms, b->d_sweights, np, b->d_ticket + 24 + 2 * wide, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked,     \
-                b->similarity, (const uint32_t *)b->d_planes, b->plw
+                b->similarity, (const uint32_t *)b->d_planes, b->plw, b->d_sparse, b->sparse_cap
                         if (b->ix->codec == TRI_CODEC_LUCENE) {
                                 if (wide)
                                         hipLaunchKernelGGL((k_planes<CODEC_LUCENE, FUS_MAX_SLOTS>), grid, dim3(PLK_WG), 0, dev->stream, TRI_PLANES_ARGS);
