@@ -159,7 +159,7 @@ struct PlanesShared {
         uint32_t npat;                // the candidate filter: 0xffffffff = every match (no threshold yet), else that many assignments
         uint32_t pat[PLK_MAXPAT];     // ... two bits per slot: the level the slot must at least be at
         uint32_t flag[PLK_WG / 64];
-        uint32_t wq[PLK_WG / 64][PLK_WQ]; // per wave: candidates waiting for exact frequencies (rel docID << 16 | the slots' levels, two bits each)
+        uint32_t wq[PLK_WG / 64][PLK_WQ][2]; // per wave: candidates waiting for exact frequencies {docID, the slots' levels (two bits each)}
         uint32_t bcast[4];
         uint32_t sp_row0[FUS_MAX_SLOTS], sp_n[FUS_MAX_SLOTS], sp_base[FUS_MAX_SLOTS]; // decoded slots: first row, rows, first entry of the list in the scratch region
         uint32_t cur[FUS_MAX_SLOTS];  // ... the list's next entry
@@ -466,16 +466,15 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 __syncthreads();
                 // ---- per task, uniform: which slots read term planes, where the others' LDS planes are, which slots score
                 uint32_t dense_mask = 0;
-                const uint32_t leaf_mask = uni(sh.leaf);
-                uint32_t lidx[NS], top[NS];
-                size_t pbase[NS];
+                uint32_t lidx[NS], top[NS], prows[NS];
                 uint32_t list_rows = 0;
+                const uint32_t *const gsafe = planes ? planes : (const uint32_t *)lists; // (a batch without term planes: plw is 0, every such load reads the scratch region's first words)
                 {
                         uint32_t nl = 0;
 #pragma unroll
                         for (uint32_t s = 0; s < NS; ++s) {
                                 const uint32_t prow = s < nslots ? uni(fq.plane[s]) : PL_NONE;
-                                pbase[s] = prow != PL_NONE ? (size_t)prow * PL_PLANES * plw : 0;
+                                prows[s] = prow;
                                 lidx[s] = 0;
                                 top[s] = s < nslots ? uni(sh.top[s]) : 0u;
                                 if (s < nslots) {
@@ -514,39 +513,105 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
 #pragma unroll
                 for (uint32_t s = 0; s < NS; ++s)
                         curv[s] = 0;
+                // this wave's queue of candidates that wait for an exact frequency: it lives across the windows and is worked off 64 entries at
+                // a time — every lane fetching from the postings at once, not one lane while 63 wait — and emptied at the end of the task
+                uint32_t qn = 0; // entries on the queue (wave-uniform)
+                auto offer = [&](const double sc, const uint32_t doc) { // false: no room (the buffer wants pruning)
+                        const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
+                        if (slot >= PLK_CAP)
+                                return false;
+                        sh.tk_s[slot] = sc;
+                        sh.tk_d[slot] = doc;
+                        return true;
+                };
+                auto work_queue = [&]() { // the last (up to) 64 entries of the queue; entries that found no room go back
+                        const uint32_t take_n = min(qn, 64u), base = qn - take_n;
+                        qn = base;
+                        bool back = false;
+                        uint32_t doc = 0, levels = 0;
+                        if (lane < take_n) {
+                                doc = sh.wq[wave][base + lane][0];
+                                levels = sh.wq[wave][base + lane][1];
+                                double sk = 0.0;
+                                for (uint32_t s = 0; s < nslots; ++s) {
+                                        const uint32_t l = (levels >> (2 * s)) & 3u;
+                                        if (!l)
+                                                continue;
+                                        if (l < sh.top[s]) {
+                                                sk += sh.wl[s][l];
+                                                continue;
+                                        }
+                                        const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, sh.term[s], doc);
+                                        const uint32_t term = fq.term[s];
+                                        for (uint32_t si = 0; si < q.nscore; ++si)
+                                                if (sterms[q.score_base + si] == term)
+                                                        sk += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                }
+                                if (!uni(sh.tk_full) || better(sk, doc, sh.thr_s, sh.thr_d))
+                                        back = !offer(sk, doc);
+                        }
+                        PROF_COUNT(17, lane == 0 ? take_n : 0);
+                        const uint64_t bm = __builtin_amdgcn_ballot_w64(back);
+                        if (back) {
+                                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                                sh.wq[wave][at][0] = doc;
+                                sh.wq[wave][at][1] = levels;
+                        }
+                        qn += (uint32_t)__popcll(bm);
+                };
                 for (uint32_t w = wfirst; w < wend; ++w) {
                         const uint32_t w0 = w * PL_W, wE = w0 + PL_W;
-                        // ---- the term planes' words of this thread's two window words: a = plane A, b = plane B (frequency not 1), c = plane C (nor 2)
-                        uint32_t a0[NS], a1[NS], b0[NS], b1[NS], c0w[NS], c1w[NS];
-#pragma unroll
-                        for (uint32_t s = 0; s < NS; ++s) {
-                                a0[s] = a1[s] = b0[s] = b1[s] = c0w[s] = c1w[s] = 0;
-                                if ((dense_mask >> s) & 1u) {
-                                        const uint32_t *pa = planes + pbase[s] + (size_t)w * PL_WORDS;
-                                        a0[s] = pa[tid];
-                                        a1[s] = pa[tid + PLK_WG];
-                                        if ((leaf_mask >> s) & 1u) {
-                                                b0[s] = pa[plw + tid];
-                                                b1[s] = pa[plw + tid + PLK_WG];
-                                                c0w[s] = pa[2 * plw + tid];
-                                                c1w[s] = pa[2 * plw + tid + PLK_WG];
-                                        }
-                                }
-                        }
-                        PROF_LAP(1);
-                        // ---- set pass: the decoded slots' entries of this window, a chunk of PLK_WG per slot and round, into the LDS planes
-                        uint32_t rows_mask = 0; // (decoded slots that may have put something into the planes)
-                        for (;;) {
+                        // The level words of one of this thread's two window words (which: 0 / 1): a = plane A, b = plane B (frequency not 1), c = plane C
+                        // (nor 2) — a head term's from the batch's term planes, a decoded slot's from LDS.  They are fetched when needed (the sweep; a
+                        // candidate's scoring) and not kept: thirty live registers cost more in spills than the L2 hits cost in time.  (The plane's row
+                        // is read afresh — a scalar — so that every address is a scalar base plus the thread's offset.)
+                        uint32_t rows_mask = 0; // (decoded slots that may have put something into the LDS planes of this window)
+                        auto level_words = [&](const uint32_t which, uint32_t (&a)[NS], uint32_t (&b)[NS], uint32_t (&c)[NS]) {
+                                // (straight-line on purpose: every load is issued — a slot without a term plane reads row 0's words, one without
+                                //  LDS planes reads slot 0's, and the uniform selects below drop them — so that one wait covers them all; with a
+                                //  branch per slot the compiler waited after each slot's loads)
+                                const uint32_t wi = tid + which * PLK_WG;
+                                uint32_t ga[NS], gb[NS], gc[NS], la[NS], lb[NS];
 #pragma unroll
                                 for (uint32_t s = 0; s < NS; ++s) {
+                                        const uint32_t *pa = gsafe + (prows[s] != PL_NONE ? (size_t)prows[s] * PL_PLANES * plw + (size_t)w * PL_WORDS : (size_t)0);
+                                        const uint32_t *pb = pa + plw, *pc = pb + plw; // (scalar bases: the loads take base + the thread's offset)
+                                        ga[s] = pa[wi];
+                                        gb[s] = pb[wi];
+                                        gc[s] = pc[wi];
+                                        const uint32_t *lp = &sh.pl[lidx[s]][0];
+                                        la[s] = lp[wi];
+                                        lb[s] = lp[PL_STRIDE + wi];
+                                }
+#pragma unroll
+                                for (uint32_t s = 0; s < NS; ++s) {
+                                        const bool dn = prows[s] != PL_NONE, sp = (rows_mask >> s) & 1u, lf = top[s] != 0; // (uniform)
+                                        a[s] = dn ? ga[s] : sp ? la[s] : 0u;
+                                        b[s] = !lf ? 0u : dn ? gb[s] : sp ? lb[s] : 0u;
+                                        c[s] = (lf && dn) ? gc[s] : 0u;
+                                }
+                        };
+                        PROF_LAP(1);
+                        // ---- set pass: the decoded slots' entries of this window, a chunk of PLK_WG per slot and round, into the LDS planes
+                        for (;;) {
+                                uint32_t ent[NS];
+#pragma unroll
+                                for (uint32_t s = 0; s < NS; ++s) { // (all the slots' loads first: one round trip)
+                                        ent[s] = PLK_PAD;
                                         if (!((sparse_mask >> s) & 1u))
                                                 continue;
-                                        const uint32_t cur = curv[s], n = uni(sh.sp_n[s]) * 32u;
-                                        if (cur >= n)
+                                        const uint32_t n = uni(sh.sp_n[s]) * 32u;
+                                        if (curv[s] >= n)
                                                 continue;
                                         rows_mask |= 1u << s;
-                                        const uint32_t e = cur + tid < n ? lists[uni(sh.sp_base[s]) + cur + tid] : PLK_PAD;
-                                        const uint32_t d = e >> 1;
+                                        if (curv[s] + tid < n)
+                                                ent[s] = lists[uni(sh.sp_base[s]) + curv[s] + tid];
+                                }
+#pragma unroll
+                                for (uint32_t s = 0; s < NS; ++s) {
+                                        if (!((rows_mask >> s) & 1u))
+                                                continue;
+                                        const uint32_t e = ent[s], d = e >> 1;
                                         const bool before = d < wE; // (ascending: the entries below the window's end are a prefix of the chunk)
                                         if (before && d >= w0) {
                                                 uint32_t *p = &sh.pl[lidx[s]][0];
@@ -573,76 +638,49 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 sh.more = 0;
                                 __syncthreads();
                         }
-                        // ---- sweep: the decoded slots' words, the predicate, the candidates
-#pragma unroll
-                        for (uint32_t s = 0; s < NS; ++s)
-                                if ((rows_mask >> s) & 1u) {
-                                        const uint32_t *p = &sh.pl[lidx[s]][0];
-                                        a0[s] = p[tid];
-                                        a1[s] = p[tid + PLK_WG];
-                                        b0[s] = p[PL_STRIDE + tid];
-                                        b1[s] = p[PL_STRIDE + tid + PLK_WG];
-                                }
-                        uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;
-                        for (uint32_t g = 0; g < nreq; ++g) {
-                                const uint32_t gs = uni(fq.gslots[g]);
-                                uint32_t x0 = 0, x1 = 0;
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s)
-                                        if ((gs >> s) & 1u) {
-                                                x0 |= a0[s];
-                                                x1 |= a1[s];
-                                        }
-                                m0 &= x0;
-                                m1 &= x1;
-                        }
-                        {
-                                uint32_t n0 = 0, n1 = 0;
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s)
-                                        if ((negs >> s) & 1u) {
-                                                n0 |= a0[s];
-                                                n1 |= a1[s];
-                                        }
-                                m0 &= ~n0;
-                                m1 &= ~n1;
-                        }
-                        if (masked) { // masked_documents_registry::test (docidupdates.h:90-119)
-                                m0 &= ~masked[(w0 >> 5) + tid];
-                                m1 &= ~masked[(w0 >> 5) + tid + PLK_WG];
-                        }
-                        my_matches += (uint32_t)(__popc(m0) + __popc(m1));
-                        // ---- the matches that can still enter the top-K: the candidate filter, word-wise (planes_filter)
-                        auto candidates = [&](uint32_t &c0, uint32_t &c1) { // (ANDed into c0 / c1)
+                        // ---- sweep, one window word at a time: the predicate, then the candidate filter (planes_filter) on the level words
+                        auto filter_word = [&](const uint32_t (&a)[NS], const uint32_t (&b)[NS], const uint32_t (&c)[NS]) {
                                 const uint32_t np = uni(sh.npat);
                                 if (np == 0xffffffffu)
-                                        return;
-                                uint32_t y0 = 0, y1 = 0;
+                                        return 0xffffffffu;
+                                uint32_t y = 0;
                                 for (uint32_t i = 0; i < np; ++i) {
                                         const uint32_t ps = uni(sh.pat[i]);
-                                        uint32_t x0 = 0xffffffffu, x1 = 0xffffffffu;
+                                        uint32_t x = 0xffffffffu;
 #pragma unroll
                                         for (uint32_t s = 0; s < NS; ++s) {
                                                 const uint32_t l = (ps >> (2 * s)) & 3u; // (uniform)
-                                                if (l == 1) {
-                                                        x0 &= a0[s];
-                                                        x1 &= a1[s];
-                                                } else if (l == 2) {
-                                                        x0 &= b0[s];
-                                                        x1 &= b1[s];
-                                                } else if (l == 3) {
-                                                        x0 &= c0w[s];
-                                                        x1 &= c1w[s];
-                                                }
+                                                x &= l == 1 ? a[s] : l == 2 ? b[s] : l == 3 ? c[s] : 0xffffffffu;
                                         }
-                                        y0 |= x0;
-                                        y1 |= x1;
+                                        y |= x;
                                 }
-                                c0 &= y0;
-                                c1 &= y1;
+                                return y;
                         };
-                        uint32_t c0 = m0, c1 = m1;
-                        candidates(c0, c1);
+                        uint32_t cand[2];
+#pragma unroll
+                        for (uint32_t which = 0; which < 2; ++which) {
+                                uint32_t a[NS], b[NS], c[NS];
+                                level_words(which, a, b, c);
+                                uint32_t m = 0xffffffffu;
+                                for (uint32_t g = 0; g < nreq; ++g) {
+                                        const uint32_t gs = uni(fq.gslots[g]);
+                                        uint32_t x = 0;
+#pragma unroll
+                                        for (uint32_t s = 0; s < NS; ++s)
+                                                x |= ((gs >> s) & 1u) ? a[s] : 0u;
+                                        m &= x;
+                                }
+                                uint32_t nx = 0;
+#pragma unroll
+                                for (uint32_t s = 0; s < NS; ++s)
+                                        nx |= ((negs >> s) & 1u) ? a[s] : 0u;
+                                m &= ~nx;
+                                if (masked) // masked_documents_registry::test (docidupdates.h:90-119)
+                                        m &= ~masked[(w0 >> 5) + tid + which * PLK_WG];
+                                my_matches += (uint32_t)__popc(m);
+                                cand[which] = m & filter_word(a, b, c);
+                        }
+                        uint32_t c0 = cand[0], c1 = cand[1];
                         // the decoded slots' words of this window (A and B) are cleared by their owner as soon as it has no candidate left in them
                         auto clear_mine = [&]() {
 #pragma unroll
@@ -656,56 +694,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         }
                         };
                         bool cleared = false;
-                        uint32_t qn = 0; // entries on this wave's lookup queue (wave-uniform)
                         PROF_LAP(4);
                         for (;;) {
-                                // ---- every wave works its own candidates off, one per lane and step, no workgroup barrier: the levels from
-                                //      registers give the known part of the score and a bound for the rest.  A candidate the bound does not rule
-                                //      out and whose score is not fully known goes onto the wave's queue; the queue is worked off 64 at a time —
-                                //      every lane fetching exact frequencies from the postings at once, not one lane while 63 wait
+                                // ---- every wave works its own candidates off, one per lane and step, no workgroup barrier: the document's levels
+                                //      give the known part of its score and a bound for the rest.  A candidate the bound does not rule out and whose
+                                //      score is not fully known goes onto the wave's queue
                                 const bool full = uni(sh.tk_full) != 0;
                                 const double thr_s = sh.thr_s;
                                 const uint32_t thr_d = sh.thr_d;
-                                auto offer = [&](const double sc, const uint32_t doc) { // false: no room (the buffer wants pruning)
-                                        const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
-                                        if (slot >= PLK_CAP)
-                                                return false;
-                                        sh.tk_s[slot] = sc;
-                                        sh.tk_d[slot] = doc;
-                                        return true;
-                                };
-                                auto work_queue = [&]() { // the last (up to) 64 entries of the queue; entries that found no room go back
-                                        const uint32_t take_n = min(qn, 64u), base = qn - take_n;
-                                        qn = base;
-                                        bool back = false;
-                                        uint32_t ent = 0;
-                                        if (lane < take_n) {
-                                                ent = sh.wq[wave][base + lane];
-                                                const uint32_t doc = w0 + (ent >> 16);
-                                                double sk = 0.0;
-                                                for (uint32_t s = 0; s < nslots; ++s) {
-                                                        const uint32_t l = (ent >> (2 * s)) & 3u;
-                                                        if (!l)
-                                                                continue;
-                                                        if (l < sh.top[s]) {
-                                                                sk += sh.wl[s][l];
-                                                                continue;
-                                                        }
-                                                        const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, sh.term[s], doc);
-                                                        const uint32_t term = fq.term[s];
-                                                        for (uint32_t si = 0; si < q.nscore; ++si)
-                                                                if (sterms[q.score_base + si] == term)
-                                                                        sk += (double)sim_score(sim, sweights[q.score_base + si], f);
-                                                }
-                                                if (!full || better(sk, doc, thr_s, thr_d))
-                                                        back = !offer(sk, doc);
-                                        }
-                                        PROF_COUNT(17, lane == 0 ? take_n : 0);
-                                        const uint64_t bm = __builtin_amdgcn_ballot_w64(back);
-                                        if (back)
-                                                sh.wq[wave][qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = ent;
-                                        qn += (uint32_t)__popcll(bm);
-                                };
                                 for (;;) {
                                         if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
                                                 break; // the buffer wants pruning first (candidates and queue stay where they are)
@@ -714,54 +710,58 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 continue;
                                         }
                                         const bool has = (c0 | c1) != 0;
-                                        if (__builtin_amdgcn_ballot_w64(has) == 0ull) {
-                                                if (!qn)
-                                                        break;
-                                                work_queue();
-                                                continue;
-                                        }
+                                        if (__builtin_amdgcn_ballot_w64(has) == 0ull)
+                                                break;
                                         bool enq = false;
-                                        uint32_t ent = 0;
-                                        if (has) {
-                                                const uint32_t which = c0 ? 0u : 1u;
-                                                const uint32_t bit = (uint32_t)__builtin_ctz(which ? c1 : c0);
-                                                const uint32_t rel = 32u * (tid + which * PLK_WG) + bit, doc = w0 + rel;
-                                                double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
-                                                uint32_t levels = 0;
-                                                bool unk = false;
+                                        uint32_t edoc = 0, elev = 0;
+                                        {
+                                                const uint32_t which = c0 ? 0u : 1u; // (lanes without a candidate fetch word 1 and drop it)
+                                                uint32_t a[NS], b[NS], c[NS];
+                                                level_words(which, a, b, c);
+                                                if (has) {
+                                                        const uint32_t bit = (uint32_t)__builtin_ctz(which ? c1 : c0);
+                                                        const uint32_t doc = w0 + 32u * (tid + which * PLK_WG) + bit;
+                                                        double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
+                                                        uint32_t levels = 0;
+                                                        bool unk = false;
 #pragma unroll
-                                                for (uint32_t s = 0; s < NS; ++s) {
-                                                        if (!top[s] || !(((which ? a1[s] : a0[s]) >> bit) & 1u))
-                                                                continue;
-                                                        const uint32_t bb = ((which ? b1[s] : b0[s]) >> bit) & 1u, cc = ((which ? c1w[s] : c0w[s]) >> bit) & 1u;
-                                                        const uint32_t l = 1u + bb + (bb & cc);
-                                                        levels |= l << (2 * s);
-                                                        if (l < top[s])
-                                                                sk += sh.wl[s][l];
-                                                        else {
-                                                                unk = true;
-                                                                sb += sh.wf[s][l];
+                                                        for (uint32_t s = 0; s < NS; ++s) {
+                                                                if (!top[s] || !((a[s] >> bit) & 1u))
+                                                                        continue;
+                                                                const uint32_t bb = (b[s] >> bit) & 1u, cc = (c[s] >> bit) & 1u;
+                                                                const uint32_t l = 1u + bb + (bb & cc);
+                                                                levels |= l << (2 * s);
+                                                                if (l < top[s])
+                                                                        sk += sh.wl[s][l];
+                                                                else {
+                                                                        unk = true;
+                                                                        sb += sh.wf[s][l];
+                                                                }
                                                         }
-                                                }
-                                                bool done = true;
-                                                if (!full || better(sk + sb, doc, thr_s, thr_d)) {
-                                                        if (unk) {
-                                                                enq = true;
-                                                                ent = rel << 16 | levels;
-                                                        } else
-                                                                done = offer(sk, doc); // (no room: the candidate stays for after the prune)
-                                                }
-                                                if (done) {
-                                                        if (which)
-                                                                c1 &= c1 - 1u;
-                                                        else
-                                                                c0 &= c0 - 1u;
+                                                        bool done = true;
+                                                        if (!full || better(sk + sb, doc, thr_s, thr_d)) {
+                                                                if (unk) {
+                                                                        enq = true;
+                                                                        edoc = doc;
+                                                                        elev = levels;
+                                                                } else
+                                                                        done = offer(sk, doc); // (no room: the candidate stays for after the prune)
+                                                        }
+                                                        if (done) {
+                                                                if (which)
+                                                                        c1 &= c1 - 1u;
+                                                                else
+                                                                        c0 &= c0 - 1u;
+                                                        }
                                                 }
                                         }
                                         PROF_COUNT(16, lane == 0 ? __popcll(__builtin_amdgcn_ballot_w64(has)) : 0);
                                         const uint64_t em = __builtin_amdgcn_ballot_w64(enq);
-                                        if (enq)
-                                                sh.wq[wave][qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u))] = ent;
+                                        if (enq) {
+                                                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                                                sh.wq[wave][at][0] = edoc;
+                                                sh.wq[wave][at][1] = elev;
+                                        }
                                         qn += (uint32_t)__popcll(em);
                                 }
                                 const bool pending = (c0 | c1) != 0;
@@ -769,7 +769,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         clear_mine();
                                         cleared = true;
                                 }
-                                sh.flag[wave] = (__builtin_amdgcn_ballot_w64(pending) != 0ull || qn) ? 1u : 0u; // (wave-uniform value, every lane stores it)
+                                sh.flag[wave] = __builtin_amdgcn_ballot_w64(pending) != 0ull ? 1u : 0u; // (wave-uniform value, every lane stores it)
                                 __syncthreads();
                                 uint32_t anyp = 0;
 #pragma unroll
@@ -782,8 +782,18 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         planes_prune(sh, n, k);
                                         planes_filter(sh, nslots);
                                         PROF_COUNT(18, tid == 0 ? 1 : 0);
-                                        if (anyp)
-                                                candidates(c0, c1); // (the threshold moved: what is left is filtered again)
+                                        if (anyp) { // (the threshold moved: what is left is filtered again)
+#pragma unroll
+                                                for (uint32_t which = 0; which < 2; ++which) {
+                                                        uint32_t a[NS], b[NS], c[NS];
+                                                        level_words(which, a, b, c);
+                                                        const uint32_t f = filter_word(a, b, c);
+                                                        if (which)
+                                                                c1 &= f;
+                                                        else
+                                                                c0 &= f;
+                                                }
+                                        }
                                 } else if (anyp)
                                         __syncthreads(); // (cannot happen — a wave only stops early at a full buffer —; kept so that a flag is never rewritten while read)
                                 if (!anyp)
@@ -791,6 +801,24 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         }
                         PROF_COUNT(19, tid == 0 ? 1 : 0);
                         PROF_LAP(5);
+                }
+                // ---- the candidates still waiting for their frequencies
+                for (;;) {
+                        while (qn && uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) < PLK_PRUNE_AT)
+                                work_queue();
+                        sh.flag[wave] = qn ? 1u : 0u; // (wave-uniform value, every lane stores it)
+                        __syncthreads();
+                        uint32_t anyp = 0;
+#pragma unroll
+                        for (uint32_t wv = 0; wv < PLK_WG / 64; ++wv)
+                                anyp |= sh.flag[wv];
+                        anyp = uni(anyp);
+                        const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
+                        __syncthreads(); // (every lane has read the flags and tk_n)
+                        if (n >= PLK_PRUNE_AT)
+                                planes_prune(sh, n, k);
+                        if (!anyp)
+                                break;
                 }
                 // ---- the task's result: its best k (ranked) and its match count
                 __syncthreads();

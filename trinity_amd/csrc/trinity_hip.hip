@@ -1831,7 +1831,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         if (b->n_planes + b->n_planes8) {
                 b->sparse_cap = (b->sparse_cap + 63u) & ~63u;
                 const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
-                HIP_TRY(hipMalloc((void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
+                HIP_TRY(hipMalloc((void **)&b->d_sparse, (wgs * b->sparse_cap + 2 * PL_WORDS) * 4)); // (+ a window's worth of words: the dummy loads of a batch without term planes)
         }
         b->out_capacity = off;
         int rc;
