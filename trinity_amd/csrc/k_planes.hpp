@@ -137,15 +137,21 @@ constexpr uint32_t PLK_MAX_SPARSE = 6;  // slots whose lists are decoded per tas
 constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per thread when it is pruned)
 constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
 constexpr uint32_t PLK_MAXPAT = 32;     // level assignments of the candidate filter kept as such (more: coarser filters)
-constexpr uint32_t PLK_WGS_PER_CU = 2;
+#ifndef TRI_PLK_WGS
+#define TRI_PLK_WGS 2
+#endif
+constexpr uint32_t PLK_WGS_PER_CU = TRI_PLK_WGS; // (LDS: two fit)
 constexpr uint32_t PLK_WQ = 128;        // per-wave queue of candidates waiting for a frequency lookup: worked off 64 at a time, every lane busy
 constexpr uint32_t PLK_NS_SMALL = 5;    // the instantiation for queries of up to this many slots keeps six words per slot in registers
 constexpr uint32_t PLK_PAD = 0xffffffffu; // list padding (sorts last)
-static_assert(PL_WORDS == 2 * PLK_WG, "the sweep gives every thread two words of the window");
+constexpr uint32_t PLK_SW_WORDS = 128;    // a wave's sub-window: two words (64 documents) per lane ...
+constexpr uint32_t PLK_SW = PLK_SW_WORDS * 32; // ... 4096 documents
+constexpr uint32_t PLK_SW_STRIDE = PLK_SW_WORDS + 4; // LDS words between a decoded slot's A and B plane of a sub-window
+static_assert(PL_W % PLK_SW == 0, "a task's windows split into whole sub-windows");
 static_assert(PLK_CAP == PLK_WG && TOPK_MAX < PLK_PRUNE_AT && PLK_PRUNE_AT < PLK_CAP, "pruning leaves room; a pruned buffer is below the stop mark");
 
 struct PlanesShared {
-        uint32_t pl[PLK_MAX_SPARSE][2 * PL_STRIDE]; // per decoded slot: plane A, plane B (word PL_WORDS of each: sink)
+        uint32_t pl[PLK_WG / 64][PLK_MAX_SPARSE][2 * PLK_SW_STRIDE]; // per wave and decoded slot: planes A and B of the wave's current sub-window
         double tk_s[PLK_CAP];
         uint32_t tk_d[PLK_CAP];
         DevTerm term[FUS_MAX_SLOTS];
@@ -162,8 +168,6 @@ struct PlanesShared {
         uint32_t wq[PLK_WG / 64][PLK_WQ][2]; // per wave: candidates waiting for exact frequencies {docID, the slots' levels (two bits each)}
         uint32_t bcast[4];
         uint32_t sp_row0[FUS_MAX_SLOTS], sp_n[FUS_MAX_SLOTS], sp_base[FUS_MAX_SLOTS]; // decoded slots: first row, rows, first entry of the list in the scratch region
-        uint32_t cur[FUS_MAX_SLOTS];  // ... the list's next entry
-        uint32_t more;                // a window took a whole chunk of some list: its set pass goes round again
         DevFused fq;
 };
 static_assert(sizeof(PlanesShared) * PLK_WGS_PER_CU <= 160u * 1024u, "two workgroups per CU");
@@ -371,8 +375,8 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
         const uint32_t wave = uni(tid >> 6);
         uint32_t *const lists = scratch + (size_t)blockIdx.x * sparse_cap;
-        for (uint32_t i = tid; i < PLK_MAX_SPARSE * 2 * PL_STRIDE; i += PLK_WG)
-                (&sh.pl[0][0])[i] = 0;
+        for (uint32_t i = tid; i < (PLK_WG / 64) * PLK_MAX_SPARSE * 2 * PLK_SW_STRIDE; i += PLK_WG)
+                (&sh.pl[0][0][0])[i] = 0;
         PROF_DECL;
         PROF_START();
         for (;;) {
@@ -426,7 +430,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.tk_n = 0;
                         sh.tk_full = 0;
                         sh.matches = 0;
-                        sh.more = 0;
                         sh.npat = 0xffffffffu; // no threshold yet: every match is a candidate
                         // a decoded slot's rows that can hold documents of the task's range [first window's first docID, last window's end)
                         uint32_t row0 = 0, nrows = 0;
@@ -461,7 +464,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.sp_row0[kk] = row0;
                         sh.sp_n[kk] = nrows;
                         sh.sp_base[kk] = base;
-                        sh.cur[kk] = 0;
                 }
                 __syncthreads();
                 // ---- per task, uniform: which slots read term planes, where the others' LDS planes are, which slots score
@@ -507,12 +509,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 __syncthreads(); // (the lists are written: a workgroup barrier orders the global stores for the workgroup's own later loads)
                 PROF_LAP(7);
                 uint32_t my_matches = 0;
-                // the lists' cursors as every wave sees them in a set pass: read behind the barrier that follows the previous one (never while
-                // another wave may be adding to them)
-                uint32_t curv[NS];
-#pragma unroll
-                for (uint32_t s = 0; s < NS; ++s)
-                        curv[s] = 0;
                 // this wave's queue of candidates that wait for an exact frequency: it lives across the windows and is worked off 64 entries at
                 // a time — every lane fetching from the postings at once, not one lane while 63 wait — and emptied at the end of the task
                 uint32_t qn = 0; // entries on the queue (wave-uniform)
@@ -559,152 +555,151 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         }
                         qn += (uint32_t)__popcll(bm);
                 };
-                for (uint32_t w = wfirst; w < wend; ++w) {
-                        const uint32_t w0 = w * PL_W, wE = w0 + PL_W;
-                        // The level words of one of this thread's two window words (which: 0 / 1): a = plane A, b = plane B (frequency not 1), c = plane C
-                        // (nor 2) — a head term's from the batch's term planes, a decoded slot's from LDS.  They are fetched when needed (the sweep; a
-                        // candidate's scoring) and not kept: thirty live registers cost more in spills than the L2 hits cost in time.  (The plane's row
-                        // is read afresh — a scalar — so that every address is a scalar base plus the thread's offset.)
-                        uint32_t rows_mask = 0; // (decoded slots that may have put something into the LDS planes of this window)
-                        auto level_words = [&](const uint32_t which, uint32_t (&a)[NS], uint32_t (&b)[NS], uint32_t (&c)[NS]) {
-                                // (straight-line on purpose: every load is issued — a slot without a term plane reads row 0's words, one without
-                                //  LDS planes reads slot 0's, and the uniform selects below drop them — so that one wait covers them all; with a
-                                //  branch per slot the compiler waited after each slot's loads)
-                                const uint32_t wi = tid + which * PLK_WG;
-                                uint32_t ga[NS], gb[NS], gc[NS], la[NS], lb[NS];
+                // ---- Every WAVE walks its own contiguous share of the task's range, a sub-window of PLK_SW documents (two words per lane) at a
+                //      time, wave-synchronously: no workgroup barrier inside — sixteen independent chains of loads per CU instead of two, which is
+                //      what this kernel is bound by (a window is a few hundred instructions behind a memory round trip).  The waves share the
+                //      candidate buffer, the threshold and the filter; they meet at a barrier only when the buffer wants pruning, and at the end.
+                const uint32_t nsw = (wend - wfirst) * (PL_W / PLK_SW);
+                const uint32_t sw_first = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * wave / (PLK_WG / 64));
+                const uint32_t sw_end = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * (wave + 1) / (PLK_WG / 64));
+                uint32_t sw = sw_first;
+                // the wave's cursors into the decoded slots' lists: the first entry at or beyond its share's first document
+                uint32_t curv[NS];
 #pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s) {
-                                        const uint32_t *pa = gsafe + (prows[s] != PL_NONE ? (size_t)prows[s] * PL_PLANES * plw + (size_t)w * PL_WORDS : (size_t)0);
-                                        const uint32_t *pb = pa + plw, *pc = pb + plw; // (scalar bases: the loads take base + the thread's offset)
-                                        ga[s] = pa[wi];
-                                        gb[s] = pb[wi];
-                                        gc[s] = pc[wi];
-                                        const uint32_t *lp = &sh.pl[lidx[s]][0];
-                                        la[s] = lp[wi];
-                                        lb[s] = lp[PL_STRIDE + wi];
-                                }
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s) {
-                                        const bool dn = prows[s] != PL_NONE, sp = (rows_mask >> s) & 1u, lf = top[s] != 0; // (uniform)
-                                        a[s] = dn ? ga[s] : sp ? la[s] : 0u;
-                                        b[s] = !lf ? 0u : dn ? gb[s] : sp ? lb[s] : 0u;
-                                        c[s] = (lf && dn) ? gc[s] : 0u;
-                                }
-                        };
-                        PROF_LAP(1);
-                        // ---- set pass: the decoded slots' entries of this window, a chunk of PLK_WG per slot and round, into the LDS planes
-                        for (;;) {
-                                uint32_t ent[NS];
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s) { // (all the slots' loads first: one round trip)
-                                        ent[s] = PLK_PAD;
-                                        if (!((sparse_mask >> s) & 1u))
-                                                continue;
-                                        const uint32_t n = uni(sh.sp_n[s]) * 32u;
-                                        if (curv[s] >= n)
-                                                continue;
-                                        rows_mask |= 1u << s;
-                                        if (curv[s] + tid < n)
-                                                ent[s] = lists[uni(sh.sp_base[s]) + curv[s] + tid];
-                                }
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s) {
-                                        if (!((rows_mask >> s) & 1u))
-                                                continue;
-                                        const uint32_t e = ent[s], d = e >> 1;
-                                        const bool before = d < wE; // (ascending: the entries below the window's end are a prefix of the chunk)
-                                        if (before && d >= w0) {
-                                                uint32_t *p = &sh.pl[lidx[s]][0];
-                                                const uint32_t r = d - w0, bit = 1u << (r & 31u);
-                                                atomicOr(&p[r >> 5], bit);
-                                                if (e & 1u)
-                                                        atomicOr(&p[PL_STRIDE + (r >> 5)], bit);
-                                        }
-                                        const uint32_t cnt = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(before));
-                                        atomicAdd(&sh.cur[s], lane == 0 ? cnt : 0u); // (every lane issues it: no single-lane branch)
-                                        if (wave == PLK_WG / 64 - 1 && cnt == 64)
-                                                sh.more = 1; // (the whole chunk lies below the window's end: there may be more)
-                                }
-                                PROF_LAP(2);
-                                __syncthreads();
-                                PROF_LAP(3);
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s)
-                                        if ((sparse_mask >> s) & 1u)
-                                                curv[s] = uni(sh.cur[s]); // (stable until the next set pass, which lies behind another barrier)
-                                if (!uni(sh.more))
-                                        break;
-                                __syncthreads(); // (every lane has read the flag)
-                                sh.more = 0;
-                                __syncthreads();
-                        }
-                        // ---- sweep, one window word at a time: the predicate, then the candidate filter (planes_filter) on the level words
-                        auto filter_word = [&](const uint32_t (&a)[NS], const uint32_t (&b)[NS], const uint32_t (&c)[NS]) {
-                                const uint32_t np = uni(sh.npat);
-                                if (np == 0xffffffffu)
-                                        return 0xffffffffu;
-                                uint32_t y = 0;
-                                for (uint32_t i = 0; i < np; ++i) {
-                                        const uint32_t ps = uni(sh.pat[i]);
-                                        uint32_t x = 0xffffffffu;
+                for (uint32_t s = 0; s < NS; ++s) {
+                        curv[s] = 0;
+                        if ((sparse_mask >> s) & 1u)
+                                curv[s] = wave_lower_bound(lists + uni(sh.sp_base[s]), 0u, uni(sh.sp_n[s]) * 32u, (sw_first * PLK_SW) << 1);
+                }
+                uint32_t c0 = 0, c1 = 0, rows_mask = 0; // the current sub-window's candidates (per lane) and the decoded slots that put something into its LDS planes
+                bool open = false;                      // the current sub-window has been swept (its candidates are being worked off)
+                for (;;) {
+                        while (sw < sw_end) {
+                                if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
+                                        break; // the buffer wants pruning first: to the barrier (the sub-window stays as it is)
+                                const uint32_t w0 = sw * PLK_SW, wE = w0 + PLK_SW;
+                                // The level words of one of this lane's two words of the sub-window (which: 0 / 1): a = plane A, b = plane B (frequency not 1),
+                                // c = plane C (nor 2) — a head term's from the batch's term planes, a decoded slot's from the wave's LDS planes.  Fetched when
+                                // needed (the sweep; a candidate's scoring) and not kept.  Straight-line on purpose: every load is issued — a slot without a
+                                // term plane reads row 0's words, one without LDS planes reads slot 0's, and the uniform selects drop them — so that one wait
+                                // covers them all; every address is a scalar base plus the lane's offset.
+                                auto level_words = [&](const uint32_t which, uint32_t (&a)[NS], uint32_t (&b)[NS], uint32_t (&c)[NS]) {
+                                        const uint32_t wi = lane + which * 64u;
+                                        uint32_t ga[NS], gb[NS], gc[NS], la[NS], lb[NS];
 #pragma unroll
                                         for (uint32_t s = 0; s < NS; ++s) {
-                                                const uint32_t l = (ps >> (2 * s)) & 3u; // (uniform)
-                                                x &= l == 1 ? a[s] : l == 2 ? b[s] : l == 3 ? c[s] : 0xffffffffu;
+                                                const uint32_t *pa = gsafe + (prows[s] != PL_NONE ? (size_t)prows[s] * PL_PLANES * plw + (size_t)(w0 >> 5) : (size_t)0);
+                                                const uint32_t *pb = pa + plw, *pc = pb + plw;
+                                                ga[s] = pa[wi];
+                                                gb[s] = pb[wi];
+                                                gc[s] = pc[wi];
+                                                const uint32_t *lp = &sh.pl[wave][lidx[s]][0];
+                                                la[s] = lp[wi];
+                                                lb[s] = lp[PLK_SW_STRIDE + wi];
                                         }
-                                        y |= x;
-                                }
-                                return y;
-                        };
-                        uint32_t cand[2];
 #pragma unroll
-                        for (uint32_t which = 0; which < 2; ++which) {
-                                uint32_t a[NS], b[NS], c[NS];
-                                level_words(which, a, b, c);
-                                uint32_t m = 0xffffffffu;
-                                for (uint32_t g = 0; g < nreq; ++g) {
-                                        const uint32_t gs = uni(fq.gslots[g]);
-                                        uint32_t x = 0;
-#pragma unroll
-                                        for (uint32_t s = 0; s < NS; ++s)
-                                                x |= ((gs >> s) & 1u) ? a[s] : 0u;
-                                        m &= x;
-                                }
-                                uint32_t nx = 0;
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s)
-                                        nx |= ((negs >> s) & 1u) ? a[s] : 0u;
-                                m &= ~nx;
-                                if (masked) // masked_documents_registry::test (docidupdates.h:90-119)
-                                        m &= ~masked[(w0 >> 5) + tid + which * PLK_WG];
-                                my_matches += (uint32_t)__popc(m);
-                                cand[which] = m & filter_word(a, b, c);
-                        }
-                        uint32_t c0 = cand[0], c1 = cand[1];
-                        // the decoded slots' words of this window (A and B) are cleared by their owner as soon as it has no candidate left in them
-                        auto clear_mine = [&]() {
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s)
-                                        if ((rows_mask >> s) & 1u) {
-                                                uint32_t *p = &sh.pl[lidx[s]][0];
-                                                p[tid] = 0;
-                                                p[tid + PLK_WG] = 0;
-                                                p[PL_STRIDE + tid] = 0;
-                                                p[PL_STRIDE + tid + PLK_WG] = 0;
+                                        for (uint32_t s = 0; s < NS; ++s) {
+                                                const bool dn = prows[s] != PL_NONE, sp = (rows_mask >> s) & 1u, lf = top[s] != 0; // (uniform)
+                                                a[s] = dn ? ga[s] : sp ? la[s] : 0u;
+                                                b[s] = !lf ? 0u : dn ? gb[s] : sp ? lb[s] : 0u;
+                                                c[s] = (lf && dn) ? gc[s] : 0u;
                                         }
-                        };
-                        bool cleared = false;
-                        PROF_LAP(4);
-                        for (;;) {
-                                // ---- every wave works its own candidates off, one per lane and step, no workgroup barrier: the document's levels
-                                //      give the known part of its score and a bound for the rest.  A candidate the bound does not rule out and whose
-                                //      score is not fully known goes onto the wave's queue
+                                };
+                                auto filter_word = [&](const uint32_t (&a)[NS], const uint32_t (&b)[NS], const uint32_t (&c)[NS]) { // the candidate filter on one word
+                                        const uint32_t np = uni(sh.npat);
+                                        if (np == 0xffffffffu)
+                                                return 0xffffffffu;
+                                        uint32_t y = 0;
+                                        for (uint32_t i = 0; i < np; ++i) {
+                                                const uint32_t ps = uni(sh.pat[i]);
+                                                uint32_t x = 0xffffffffu;
+#pragma unroll
+                                                for (uint32_t s = 0; s < NS; ++s) {
+                                                        const uint32_t l = (ps >> (2 * s)) & 3u; // (uniform)
+                                                        x &= l == 1 ? a[s] : l == 2 ? b[s] : l == 3 ? c[s] : 0xffffffffu;
+                                                }
+                                                y |= x;
+                                        }
+                                        return y;
+                                };
+                                if (!open) {
+                                        // ---- set pass: the decoded slots' entries of this sub-window, 64 per slot and round, into the wave's LDS planes
+                                        rows_mask = 0;
+                                        for (;;) {
+                                                uint32_t ent[NS];
+                                                bool more = false;
+#pragma unroll
+                                                for (uint32_t s = 0; s < NS; ++s) { // (all the slots' loads first: one round trip)
+                                                        ent[s] = PLK_PAD;
+                                                        if (!((sparse_mask >> s) & 1u))
+                                                                continue;
+                                                        const uint32_t n = uni(sh.sp_n[s]) * 32u;
+                                                        if (curv[s] >= n)
+                                                                continue;
+                                                        rows_mask |= 1u << s;
+                                                        if (curv[s] + lane < n)
+                                                                ent[s] = lists[uni(sh.sp_base[s]) + curv[s] + lane];
+                                                }
+#pragma unroll
+                                                for (uint32_t s = 0; s < NS; ++s) {
+                                                        if (!((rows_mask >> s) & 1u))
+                                                                continue;
+                                                        const uint32_t e = ent[s], d = e >> 1;
+                                                        const bool before = d < wE; // (ascending: the entries below the sub-window's end are a prefix of the chunk)
+                                                        if (before && d >= w0) {
+                                                                uint32_t *p = &sh.pl[wave][lidx[s]][0];
+                                                                const uint32_t r = d - w0, bit = 1u << (r & 31u);
+                                                                atomicOr(&p[r >> 5], bit);
+                                                                if (e & 1u)
+                                                                        atomicOr(&p[PLK_SW_STRIDE + (r >> 5)], bit);
+                                                        }
+                                                        const uint32_t cnt = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(before));
+                                                        curv[s] += cnt;
+                                                        more |= cnt == 64; // (the whole chunk lies below the sub-window's end: there may be more)
+                                                }
+                                                if (!more)
+                                                        break;
+                                        }
+                                        // ---- sweep, one word at a time: the predicate, then the candidate filter (planes_filter) on the level words
+                                        uint32_t cand[2];
+#pragma unroll
+                                        for (uint32_t which = 0; which < 2; ++which) {
+                                                uint32_t a[NS], b[NS], c[NS];
+                                                level_words(which, a, b, c);
+                                                uint32_t m = 0xffffffffu;
+                                                for (uint32_t g = 0; g < nreq; ++g) {
+                                                        const uint32_t gs = uni(fq.gslots[g]);
+                                                        uint32_t x = 0;
+#pragma unroll
+                                                        for (uint32_t s = 0; s < NS; ++s)
+                                                                x |= ((gs >> s) & 1u) ? a[s] : 0u;
+                                                        m &= x;
+                                                }
+                                                uint32_t nx = 0;
+#pragma unroll
+                                                for (uint32_t s = 0; s < NS; ++s)
+                                                        nx |= ((negs >> s) & 1u) ? a[s] : 0u;
+                                                m &= ~nx;
+                                                if (masked) // masked_documents_registry::test (docidupdates.h:90-119)
+                                                        m &= ~masked[(w0 >> 5) + lane + which * 64u];
+                                                my_matches += (uint32_t)__popc(m);
+                                                cand[which] = m & filter_word(a, b, c);
+                                        }
+                                        c0 = cand[0], c1 = cand[1];
+                                        open = true;
+                                        PROF_COUNT(19, lane == 0 ? 1 : 0);
+                                }
+                                // ---- the sub-window's candidates, one per lane and step: the document's levels give the known part of its score and a
+                                //      bound for the rest.  A candidate the bound does not rule out and whose score is not fully known goes onto the queue
                                 const bool full = uni(sh.tk_full) != 0;
                                 const double thr_s = sh.thr_s;
                                 const uint32_t thr_d = sh.thr_d;
+                                bool stuck = false; // (the buffer filled up under a candidate)
                                 for (;;) {
-                                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
-                                                break; // the buffer wants pruning first (candidates and queue stay where they are)
+                                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
+                                                stuck = true;
+                                                break;
+                                        }
                                         if (qn >= 64) { // (a step below may add 64 entries: the queue is kept below 64 before it)
                                                 work_queue();
                                                 continue;
@@ -720,7 +715,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 level_words(which, a, b, c);
                                                 if (has) {
                                                         const uint32_t bit = (uint32_t)__builtin_ctz(which ? c1 : c0);
-                                                        const uint32_t doc = w0 + 32u * (tid + which * PLK_WG) + bit;
+                                                        const uint32_t doc = w0 + 32u * (lane + which * 64u) + bit;
                                                         double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
                                                         uint32_t levels = 0;
                                                         bool unk = false;
@@ -764,43 +759,40 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         }
                                         qn += (uint32_t)__popcll(em);
                                 }
-                                const bool pending = (c0 | c1) != 0;
-                                if (!pending && !cleared) {
-                                        clear_mine();
-                                        cleared = true;
-                                }
-                                sh.flag[wave] = __builtin_amdgcn_ballot_w64(pending) != 0ull ? 1u : 0u; // (wave-uniform value, every lane stores it)
-                                __syncthreads();
-                                uint32_t anyp = 0;
-#pragma unroll
-                                for (uint32_t wv = 0; wv < PLK_WG / 64; ++wv)
-                                        anyp |= sh.flag[wv];
-                                anyp = uni(anyp);
-                                const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
-                                if (n >= PLK_PRUNE_AT) {
-                                        __syncthreads(); // (every lane has read the flags and tk_n)
-                                        planes_prune(sh, n, k);
-                                        planes_filter(sh, nslots);
-                                        PROF_COUNT(18, tid == 0 ? 1 : 0);
-                                        if (anyp) { // (the threshold moved: what is left is filtered again)
-#pragma unroll
-                                                for (uint32_t which = 0; which < 2; ++which) {
-                                                        uint32_t a[NS], b[NS], c[NS];
-                                                        level_words(which, a, b, c);
-                                                        const uint32_t f = filter_word(a, b, c);
-                                                        if (which)
-                                                                c1 &= f;
-                                                        else
-                                                                c0 &= f;
-                                                }
-                                        }
-                                } else if (anyp)
-                                        __syncthreads(); // (cannot happen — a wave only stops early at a full buffer —; kept so that a flag is never rewritten while read)
-                                if (!anyp)
+                                if (stuck)
                                         break;
+                                // the sub-window is done: its LDS planes are cleared for the next one
+#pragma unroll
+                                for (uint32_t s = 0; s < NS; ++s)
+                                        if ((rows_mask >> s) & 1u) {
+                                                uint32_t *p = &sh.pl[wave][lidx[s]][0];
+                                                p[lane] = 0;
+                                                p[lane + 64] = 0;
+                                                p[PLK_SW_STRIDE + lane] = 0;
+                                                p[PLK_SW_STRIDE + lane + 64] = 0;
+                                        }
+                                open = false;
+                                ++sw;
                         }
-                        PROF_COUNT(19, tid == 0 ? 1 : 0);
+                        PROF_LAP(4);
+                        // ---- the waves meet: prune if the buffer wants it, go on while any of them has sub-windows left
+                        sh.flag[wave] = sw < sw_end ? 1u : 0u; // (wave-uniform value, every lane stores it)
+                        __syncthreads();
+                        uint32_t anyp = 0;
+#pragma unroll
+                        for (uint32_t wv = 0; wv < PLK_WG / 64; ++wv)
+                                anyp |= sh.flag[wv];
+                        anyp = uni(anyp);
+                        const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
+                        __syncthreads(); // (every lane has read the flags and tk_n)
+                        if (n >= PLK_PRUNE_AT) {
+                                planes_prune(sh, n, k);
+                                planes_filter(sh, nslots);
+                                PROF_COUNT(18, tid == 0 ? 1 : 0);
+                        }
                         PROF_LAP(5);
+                        if (!anyp)
+                                break;
                 }
                 // ---- the candidates still waiting for their frequencies
                 for (;;) {
