@@ -163,7 +163,7 @@ struct PlanesShared {
         uint32_t leaf;                // the slots that have a scorer
         uint32_t top[FUS_MAX_SLOTS];  // per slot: its top level (3: a term plane; 2: a decoded list; 0: no scorer)
         uint32_t npat;                // the candidate filter: 0xffffffff = every match (no threshold yet), else that many assignments
-        uint32_t pat[PLK_MAXPAT];     // ... two bits per slot: the level the slot must at least be at
+        alignas(16) uint32_t pat[PLK_MAXPAT + 4]; // ... two bits per slot: the level the slot must at least be at (read four at a time: padded with 0xffffffff)
         uint32_t flag[PLK_WG / 64];
         uint32_t wq[PLK_WG / 64][PLK_WQ][2]; // per wave: candidates waiting for exact frequencies {docID, the slots' levels (two bits each)}
         uint32_t bcast[4];
@@ -262,8 +262,13 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                         }
                 }
                 __syncthreads();
-                if (uni(sh.npat) <= PLK_MAXPAT)
+                if (uni(sh.npat) <= PLK_MAXPAT) {
+                        const uint32_t np = uni(sh.npat);
+                        for (uint32_t j = 0; j < 4; ++j)
+                                sh.pat[np + j] = 0xffffffffu; // (uniform stores: the readers take four at a time)
+                        __syncthreads();
                         return;
+                }
                 PROF_COUNT(21 + coarse, tid == 0 ? 1 : 0);
                 __syncthreads(); // (every lane has read npat)
                 sh.npat = 0;
@@ -288,6 +293,8 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                 if (!(p < thr) && sh.top[best])
                         sh.pat[np++] = 1u << (2 * best); // (uniform stores)
         }
+        for (uint32_t j = 0; j < 4; ++j)
+                sh.pat[np + j] = 0xffffffffu;
         sh.npat = np;
         __syncthreads();
 }
@@ -571,9 +578,26 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         if ((sparse_mask >> s) & 1u)
                                 curv[s] = wave_lower_bound(lists + uni(sh.sp_base[s]), 0u, uni(sh.sp_n[s]) * 32u, (sw_first * PLK_SW) << 1);
                 }
+                // per-task scalars the sub-window loop reads again and again, lifted out of LDS once: the lists' extents, the groups' slot sets, the
+                // term planes' bases (the loads take a scalar base plus the lane's offset)
+                uint32_t sp_n32[NS], sp_off[NS], gsl[FUS_MAX_SLOTS];
+                const uint32_t *pA[NS];
+#pragma unroll
+                for (uint32_t s = 0; s < NS; ++s) {
+                        sp_n32[s] = ((sparse_mask >> s) & 1u) ? uni(sh.sp_n[s]) * 32u : 0u;
+                        sp_off[s] = ((sparse_mask >> s) & 1u) ? uni(sh.sp_base[s]) : 0u;
+                        pA[s] = gsafe + (prows[s] != PL_NONE ? (size_t)prows[s] * PL_PLANES * plw : (size_t)0);
+                }
+#pragma unroll
+                for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g)
+                        gsl[g] = g < nreq ? uni(fq.gslots[g]) : 0u;
                 uint32_t c0 = 0, c1 = 0, rows_mask = 0; // the current sub-window's candidates (per lane) and the decoded slots that put something into its LDS planes
                 bool open = false;                      // the current sub-window has been swept (its candidates are being worked off)
                 for (;;) {
+                        // (threshold and filter move only at a prune, i.e. behind the barrier below: read once per stretch)
+                        const bool full = uni(sh.tk_full) != 0;
+                        const double thr_s = sh.thr_s;
+                        const uint32_t thr_d = sh.thr_d;
                         while (sw < sw_end) {
                                 if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
                                         break; // the buffer wants pruning first: to the barrier (the sub-window stays as it is)
@@ -588,11 +612,11 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         uint32_t ga[NS], gb[NS], gc[NS], la[NS], lb[NS];
 #pragma unroll
                                         for (uint32_t s = 0; s < NS; ++s) {
-                                                const uint32_t *pa = gsafe + (prows[s] != PL_NONE ? (size_t)prows[s] * PL_PLANES * plw + (size_t)(w0 >> 5) : (size_t)0);
-                                                const uint32_t *pb = pa + plw, *pc = pb + plw;
-                                                ga[s] = pa[wi];
-                                                gb[s] = pb[wi];
-                                                gc[s] = pc[wi];
+                                                const uint32_t gi = prows[s] != PL_NONE ? (w0 >> 5) + wi : wi; // (a plane is far below 2^32 bytes: a 32-bit offset)
+                                                const uint32_t *pa = pA[s], *pb = pa + plw, *pc = pb + plw;
+                                                ga[s] = pa[gi];
+                                                gb[s] = pb[gi];
+                                                gc[s] = pc[gi];
                                                 const uint32_t *lp = &sh.pl[wave][lidx[s]][0];
                                                 la[s] = lp[wi];
                                                 lb[s] = lp[PLK_SW_STRIDE + wi];
@@ -610,15 +634,19 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         if (np == 0xffffffffu)
                                                 return 0xffffffffu;
                                         uint32_t y = 0;
-                                        for (uint32_t i = 0; i < np; ++i) {
-                                                const uint32_t ps = uni(sh.pat[i]);
-                                                uint32_t x = 0xffffffffu;
+                                        for (uint32_t i = 0; i < np; i += 4) { // (four assignments per LDS round trip; the list is padded with never-met ones)
+                                                const uint4 p4 = *(const uint4 *)&sh.pat[i];
+                                                const uint32_t pss[4] = {uni(p4.x), uni(p4.y), uni(p4.z), uni(p4.w)};
 #pragma unroll
-                                                for (uint32_t s = 0; s < NS; ++s) {
-                                                        const uint32_t l = (ps >> (2 * s)) & 3u; // (uniform)
-                                                        x &= l == 1 ? a[s] : l == 2 ? b[s] : l == 3 ? c[s] : 0xffffffffu;
+                                                for (uint32_t j = 0; j < 4; ++j) {
+                                                        uint32_t x = 0xffffffffu;
+#pragma unroll
+                                                        for (uint32_t s = 0; s < NS; ++s) {
+                                                                const uint32_t l = (pss[j] >> (2 * s)) & 3u; // (uniform)
+                                                                x &= l == 1 ? a[s] : l == 2 ? b[s] : l == 3 ? c[s] : 0xffffffffu;
+                                                        }
+                                                        y |= pss[j] == 0xffffffffu ? 0u : x;
                                                 }
-                                                y |= x;
                                         }
                                         return y;
                                 };
@@ -633,12 +661,11 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                         ent[s] = PLK_PAD;
                                                         if (!((sparse_mask >> s) & 1u))
                                                                 continue;
-                                                        const uint32_t n = uni(sh.sp_n[s]) * 32u;
-                                                        if (curv[s] >= n)
+                                                        if (curv[s] >= sp_n32[s])
                                                                 continue;
                                                         rows_mask |= 1u << s;
-                                                        if (curv[s] + lane < n)
-                                                                ent[s] = lists[uni(sh.sp_base[s]) + curv[s] + lane];
+                                                        if (curv[s] + lane < sp_n32[s])
+                                                                ent[s] = lists[sp_off[s] + curv[s] + lane];
                                                 }
 #pragma unroll
                                                 for (uint32_t s = 0; s < NS; ++s) {
@@ -667,12 +694,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 uint32_t a[NS], b[NS], c[NS];
                                                 level_words(which, a, b, c);
                                                 uint32_t m = 0xffffffffu;
-                                                for (uint32_t g = 0; g < nreq; ++g) {
-                                                        const uint32_t gs = uni(fq.gslots[g]);
+#pragma unroll
+                                                for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g) {
+                                                        if (g >= nreq)
+                                                                break;
                                                         uint32_t x = 0;
 #pragma unroll
                                                         for (uint32_t s = 0; s < NS; ++s)
-                                                                x |= ((gs >> s) & 1u) ? a[s] : 0u;
+                                                                x |= ((gsl[g] >> s) & 1u) ? a[s] : 0u;
                                                         m &= x;
                                                 }
                                                 uint32_t nx = 0;
@@ -691,11 +720,11 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 }
                                 // ---- the sub-window's candidates, one per lane and step: the document's levels give the known part of its score and a
                                 //      bound for the rest.  A candidate the bound does not rule out and whose score is not fully known goes onto the queue
-                                const bool full = uni(sh.tk_full) != 0;
-                                const double thr_s = sh.thr_s;
-                                const uint32_t thr_d = sh.thr_d;
                                 bool stuck = false; // (the buffer filled up under a candidate)
                                 for (;;) {
+                                        const bool has = (c0 | c1) != 0;
+                                        if (__builtin_amdgcn_ballot_w64(has) == 0ull)
+                                                break;
                                         if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
                                                 stuck = true;
                                                 break;
@@ -704,9 +733,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 work_queue();
                                                 continue;
                                         }
-                                        const bool has = (c0 | c1) != 0;
-                                        if (__builtin_amdgcn_ballot_w64(has) == 0ull)
-                                                break;
                                         bool enq = false;
                                         uint32_t edoc = 0, elev = 0;
                                         {
