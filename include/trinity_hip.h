@@ -122,6 +122,7 @@ typedef struct tri_batch_info {
         uint64_t planes_algorithmic_bytes; /* SURVEY §8(d) bytes of the queries k_planes runs (per query, as if every list were read) */
         uint64_t planes_queries;
         uint64_t plane_terms, plane_bytes, term_planes_decoded_bytes;
+        uint64_t unsupported_queries; /* queries the planner left out of the batch (tri_batch_query_status) */
 } tri_batch_info;
 
 const char *tri_last_error(void);
@@ -198,6 +199,13 @@ int tri_decode_terms(tri_index *, const uint32_t *terms, size_t n, uint32_t *doc
  * IndexSourcesCollectionBM25Scorer does for a single source (similarity.h:179-181, 202-226). */
 int tri_batch_create(tri_index *, const uint32_t *prog, size_t prog_len, const tri_query *queries, size_t nq,
                      const double *weights, uint32_t flags, uint32_t topk, int similarity, tri_batch **out);
+/* A query whose shape the planner does not lower (today: a multi-word phrase under an OR or inside a general tree, a general tree over
+ * more than 8 distinct terms or 16 scored leaves, more than 16 term slots in a CNF, more than 16 reportable terms in the default mode)
+ * does NOT fail tri_batch_create: the query is left out of the batch — it reports no matches — and its status says so, so that one such
+ * query among thousands costs the caller one CPU span (exec.cpp:509-1517 for that query alone), not the batch.  status[q]: TRI_OK or
+ * TRI_ERR_UNSUPPORTED; tri_batch_info.unsupported_queries counts them; tri_last_error() after tri_batch_create describes the last one.
+ * (A malformed program is the caller's bug and still fails the call with TRI_ERR_INVALID.) */
+int tri_batch_query_status(const tri_batch *, int32_t *status /* [nq] */);
 void tri_batch_destroy(tri_batch *);
 /* enqueue the batch on the engine stream (asynchronous) */
 int tri_batch_run(tri_batch *);
@@ -266,6 +274,11 @@ int tri_cbatch_docset(tri_cbatch *, size_t q, uint32_t *out, size_t cap, size_t 
 typedef struct tri_comm tri_comm;
 int tri_comm_unique_id(uint8_t id[128]);
 int tri_comm_create(tri_dev *, const uint8_t id[128], int rank, int nranks, tri_comm **out);
+/* The same gather over the caller's own transport (MPI, UCX, a test's gloo group): allgather(user, send, recv, bytes_per_rank, stream)
+ * must leave, on every rank, rank r's bytes_per_rank bytes of `send` at recv + r * bytes_per_rank (both device memory), either ordered on
+ * `stream` (the engine's hipStream_t) or complete when it returns; non-zero = failure.  tri_gather_results calls it once per block. */
+typedef int (*tri_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank, void *stream);
+int tri_comm_create_custom(tri_dev *, int rank, int nranks, tri_allgather_fn allgather, void *user, tri_comm **out);
 void tri_comm_destroy(tri_comm *);
 int tri_gather_results(tri_batch *, tri_comm *, void *counts_all, void *docids_all, void *scores_all, void *topk_counts_all);
 

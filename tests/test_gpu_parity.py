@@ -866,15 +866,24 @@ def test_random_trees_from_the_reference(T, dev):
 
 
 def test_shapes_still_refused(T, dev):
-    """What the planner answers TRI_ERR_UNSUPPORTED to (the caller keeps its CPU span): a multi-word phrase under an OR or inside a
-    general tree, more than 8 distinct terms in a general tree."""
+    """What the planner does not lower (the caller keeps its CPU span): a multi-word phrase under an OR or inside a general tree, more
+    than 8 distinct terms in a general tree.  Such a query no longer fails the batch: it is left out with status TRI_ERR_UNSUPPORTED and
+    reports no matches, and the other queries of the same batch run."""
     w = World(T, dev, 2000, 200, 10, 42)
-    with pytest.raises(T.TrinityError):
-        T.Batch(w.ix, [O.parse_query('t0 OR "t1 t2"')], T.FLAG_DOCUMENTS_ONLY)
-    with pytest.raises(T.TrinityError):
-        T.Batch(w.ix, [O.parse_query('t0 NOT ("t1 t2" t3)')], T.FLAG_DOCUMENTS_ONLY)
-    with pytest.raises(T.TrinityError):
-        T.Batch(w.ix, [O.parse_query("t0 OR (t1 t2) OR (t3 t4) OR (t5 t6) OR (t7 t8)")], T.FLAG_DOCUMENTS_ONLY)
+    texts = ["t0 t1", 't0 OR "t1 t2"', "t3 OR t4", 't0 NOT ("t1 t2" t3)', "t0 OR (t1 t2) OR (t3 t4) OR (t5 t6) OR (t7 t8)", '"t0 t1"']
+    progs = [O.parse_query(t) for t in texts]
+    for flags, topk in ((T.FLAG_DOCUMENTS_ONLY, 0), (T.FLAG_ACCUMULATED_SCORE, 10), (T.FLAG_MATCHED_TERMS, 0)):
+        b = T.Batch(w.ix, progs, flags, topk=topk)
+        assert b.query_status().tolist() == [0, -3, 0, -3, -3, 0] and b.info()["unsupported_queries"] == 3
+        b.run()
+        b.sync()
+        counts = b.counts()
+        for i, t in enumerate(texts):
+            want = 0 if b.query_status()[i] else len(w.ora.exec(progs[i], O.FLAG_DOCUMENTS_ONLY)[0])
+            assert int(counts[i]) == want, t
+        b.close()
+    with pytest.raises(T.TrinityError):  # (a malformed program is still the caller's bug)
+        T.Batch(w.ix, [np.array([T.tok(T.OP_AND, 2)], dtype=np.uint32)], T.FLAG_DOCUMENTS_ONLY)
     w.ix.close()
 
 
@@ -970,6 +979,20 @@ def test_upload_rejects_what_the_kernels_cannot_read(T, dev):
         T.Index(dev, good, np.array([[100, 8, good.size]], dtype=np.uint32), 100)  # chunk outside the index
 
 
+def test_lucene_upload_names_the_payload_it_reads(T, dev):
+    """A LUCENE-coded segment whose ints() groups are not PFOR128 — e.g. one written by the reference's own FastPFor<4> build — is
+    refused at upload with TRI_ERR_FORMAT and a message that says so (never decoded into wrong postings)."""
+    seg = T.Segment(3000, 100, 10, 42, codec=2)
+    off, size = int(seg.terms[0, 1]), int(seg.terms[0, 2])
+    assert int(seg.terms[0, 0]) >= 128
+    bad = np.array(seg.index, copy=True)
+    g = off + 14  # the first ints() group of term 0: [u8 L][L words]; word 0 = width | nexc << 8 | excwidth << 16
+    assert bad[g] != 0
+    bad[g + 1] = 33  # a packed width no PFOR128 group has (and the group's length no longer follows from its header word)
+    with pytest.raises(T.TrinityError, match="rc=-4.*PFOR128.*FastPFor"):
+        T.Index(dev, bad, seg.terms, seg.docs_cnt, codec=2, hits=seg.hits)
+
+
 # ------------------------------------------------------------------------------------------ result gather behind the C-ABI (RCCL)
 def test_gather_results_over_rccl_one_rank(T, dev, small):
     """tri_comm_* / tri_gather_results with a communicator of one rank (all this box has): what arrives in the [nranks][...] receive
@@ -1012,6 +1035,77 @@ def test_gather_results_over_rccl_one_rank(T, dev, small):
     assert np.array_equal(host[1].reshape(nq, k), d) and np.array_equal(host[2].reshape(nq, k), s) and np.array_equal(host[3], c)
     b.close()
     L.tri_comm_destroy(comm)
+
+
+def test_gather_results_two_ranks_one_gpu(tmp_path):
+    """tri_gather_results at world_size 2 on a one-GPU box: two processes, both on cuda:0, the communicator built over the test's own
+    gloo transport (tri_comm_create_custom) — the blocks, their sizes and the [nranks][...] receive layout checked against the unsharded
+    batch (tests/gather_worker.py)."""
+    import subprocess
+    import sys
+
+    out = tmp_path / "gather.ok"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29633",
+                        os.path.join(os.path.dirname(os.path.abspath(__file__)), "gather_worker.py"), str(out)], capture_output=True, text=True, timeout=600, env=env)  # fmt: skip
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert out.read_text().startswith("ok world=2")
+
+
+def test_two_host_threads_two_device_handles(T):
+    """SURVEY §8(b) threading: the ABI is called concurrently from two host threads, each with its own tri_dev (own stream) on the same
+    GPU, own index upload and own batches — exec_query's re-entrancy per thread (exec.cpp:12).  Every thread's results equal the ones
+    computed alone beforehand, run after run."""
+    import threading
+
+    D, V = 20000, 2000
+    seg = T.Segment(D, V, 10, 42)
+    ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
+    texts = [["t0 t1", "t2 OR t3 OR t4", "t0 t1 (t2 OR t3)", '"t0 t1"', "t5 NOT t1"], ["t1 t2", "t0 OR t9", "t3 t4 t5", '"t1 t2" t0', "[t0, t1, t2]"]]
+    progs = [[O.parse_query(t, some_min=2) for t in tt] for tt in texts]
+    want = [[ora.exec(p, O.FLAG_ACCUM_SCORE) for p in pp] for pp in progs]
+    errors = []
+
+    def worker(i):
+        try:
+            dev = T.Device(0)
+            ix = T.Index.from_segment(dev, seg)
+            for rep in range(6):
+                bd = T.Batch(ix, progs[i], T.FLAG_DOCUMENTS_ONLY)
+                bs = T.Batch(ix, progs[i], T.FLAG_ACCUMULATED_SCORE, topk=10)
+                bd.run()
+                bs.run()
+                bd.sync()
+                bs.sync()
+                d, s, c = bs.topk_results()
+                for q, (docs, scores) in enumerate(want[i]):
+                    assert np.array_equal(bd.docset(q), docs), (i, rep, texts[i][q])
+                    td, ts = ora.topk(docs, scores, 10)
+                    assert d[q, : len(td)].tolist() == td.tolist(), (i, rep, texts[i][q])
+                    np.testing.assert_allclose(s[q, : len(td)], ts, rtol=1e-5, atol=0)
+                bd.close()
+                bs.close()
+            ix.close()
+            dev.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+
+
+def test_device_encoder_refuses_what_the_reference_encoder_would_not_take(T, dev):
+    """tri_encode_google validates on the host: positions non-descending and non-zero within a posting (google_codec.cpp:42-49), freqs[]
+    within positions[] — TRI_ERR_INVALID instead of bytes the reference's encoder would never write."""
+    docs, freqs, tf = np.array([1, 5], np.uint32), np.array([2, 1], np.uint32), np.array([0, 2], np.uint64)
+    dev.encode_google(docs, freqs, np.array([3, 7, 2], np.uint16), tf)  # fine
+    for bad in (np.array([7, 3, 2], np.uint16), np.array([0, 3, 2], np.uint16), np.array([3, 7], np.uint16)):
+        with pytest.raises(T.TrinityError):
+            dev.encode_google(docs, freqs, bad, tf)
 
 
 # ------------------------------------------------------------------------------------------ write side on the device (SURVEY §8f-4)

@@ -570,6 +570,13 @@ namespace trinity_amd {
                 check(tri_batch_create(src->handle(), prog.data(), prog.size(), qs.data(), qs.size(), scored ? weights.data() : nullptr, flags, topk,
                                        scored ? scorer->device_similarity() : TRI_SIM_BM25, &b));
                 BatchPtr bp(b);
+                // (a shape the planner does not lower is left out of the batch with a status, not refused as a whole: these entry points
+                //  run one caller query at a time — exec_queries: one caller batch —, so such a query surfaces as the exception it always did)
+                std::vector<int32_t> st(qs.size(), TRI_OK);
+                check(tri_batch_query_status(b, st.data()));
+                for (const int32_t x : st)
+                        if (x != TRI_OK)
+                                check(x);
                 check(tri_batch_run(b));
                 check(tri_batch_sync(b));
                 return bp;

@@ -607,9 +607,8 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 // needed (the sweep; a candidate's scoring) and not kept.  Straight-line on purpose: every load is issued — a slot without a
                                 // term plane reads row 0's words, one without LDS planes reads slot 0's, and the uniform selects drop them — so that one wait
                                 // covers them all; every address is a scalar base plus the lane's offset.
-                                auto level_words = [&](const uint32_t which, uint32_t (&a)[NS], uint32_t (&b)[NS], uint32_t (&c)[NS]) {
+                                auto plane_words = [&](const uint32_t which, uint32_t (&ga)[NS], uint32_t (&gb)[NS], uint32_t (&gc)[NS]) { // the term planes' part: global loads
                                         const uint32_t wi = lane + which * 64u;
-                                        uint32_t ga[NS], gb[NS], gc[NS], la[NS], lb[NS];
 #pragma unroll
                                         for (uint32_t s = 0; s < NS; ++s) {
                                                 const uint32_t gi = prows[s] != PL_NONE ? (w0 >> 5) + wi : wi; // (a plane is far below 2^32 bytes: a 32-bit offset)
@@ -617,6 +616,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 ga[s] = pa[gi];
                                                 gb[s] = pb[gi];
                                                 gc[s] = pc[gi];
+                                        }
+                                };
+                                auto finish_words = [&](const uint32_t which, const uint32_t (&ga)[NS], const uint32_t (&gb)[NS], const uint32_t (&gc)[NS], uint32_t (&a)[NS],
+                                                        uint32_t (&b)[NS], uint32_t (&c)[NS]) { // ... the decoded slots' part (LDS), and the uniform selects
+                                        const uint32_t wi = lane + which * 64u;
+                                        uint32_t la[NS], lb[NS];
+#pragma unroll
+                                        for (uint32_t s = 0; s < NS; ++s) {
                                                 const uint32_t *lp = &sh.pl[wave][lidx[s]][0];
                                                 la[s] = lp[wi];
                                                 lb[s] = lp[PLK_SW_STRIDE + wi];
@@ -628,6 +635,11 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 b[s] = !lf ? 0u : dn ? gb[s] : sp ? lb[s] : 0u;
                                                 c[s] = (lf && dn) ? gc[s] : 0u;
                                         }
+                                };
+                                auto level_words = [&](const uint32_t which, uint32_t (&a)[NS], uint32_t (&b)[NS], uint32_t (&c)[NS]) {
+                                        uint32_t ga[NS], gb[NS], gc[NS];
+                                        plane_words(which, ga, gb, gc);
+                                        finish_words(which, ga, gb, gc, a, b, c);
                                 };
                                 auto filter_word = [&](const uint32_t (&a)[NS], const uint32_t (&b)[NS], const uint32_t (&c)[NS]) { // the candidate filter on one word
                                         const uint32_t np = uni(sh.npat);
@@ -651,6 +663,10 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         return y;
                                 };
                                 if (!open) {
+                                        // (the term planes' words of both of this lane's words travel together with the lists' entries: one round trip)
+                                        uint32_t g0a[NS], g0b[NS], g0c[NS], g1a[NS], g1b[NS], g1c[NS];
+                                        plane_words(0, g0a, g0b, g0c);
+                                        plane_words(1, g1a, g1b, g1c);
                                         // ---- set pass: the decoded slots' entries of this sub-window, 64 per slot and round, into the wave's LDS planes
                                         rows_mask = 0;
                                         for (;;) {
@@ -692,7 +708,10 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
 #pragma unroll
                                         for (uint32_t which = 0; which < 2; ++which) {
                                                 uint32_t a[NS], b[NS], c[NS];
-                                                level_words(which, a, b, c);
+                                                if (which)
+                                                        finish_words(1, g1a, g1b, g1c, a, b, c);
+                                                else
+                                                        finish_words(0, g0a, g0b, g0c, a, b, c);
                                                 uint32_t m = 0xffffffffu;
 #pragma unroll
                                                 for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g) {

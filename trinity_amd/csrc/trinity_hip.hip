@@ -134,6 +134,7 @@ struct tri_batch {
         std::vector<DevQuery> plan; // execution order (cost descending)
         std::vector<uint32_t> qterms;
         std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: trivially empty)
+        std::vector<int32_t> qstatus;        // per caller query: TRI_OK, or why the planner left it out of the batch (it then reports no matches)
         DevQuery *d_plan = nullptr;
         std::vector<DevTask> tasks; // scheduling order (cost descending)
         DevTask *d_tasks = nullptr;
@@ -524,13 +525,16 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                                         return fail(TRI_ERR_FORMAT, "term %zu: truncated block", ti);
                                 const uint32_t goff = (uint32_t)(p - index);
                                 const size_t used = h_ints_decode(p, end, vals);
-                                if (!used)
-                                        return fail(TRI_ERR_FORMAT, "term %zu: bad ints() group", ti);
+                                if (!used) // (the group's header word does not describe a PFOR128 payload of the declared length)
+                                        return fail(TRI_ERR_FORMAT, "term %zu: an ints() group that is not PFOR128 (include/pfor128.md) — a lucene_codec segment written by the reference's "
+                                                                    "own build carries lemire/FastPFor<4> payloads (lucene_codec.cpp:57-64), which this engine does not read: re-encode "
+                                                                    "the segment with csrc/host/lucene_encoder.hpp, or use google_codec", ti);
                                 p += used;
                                 uint32_t xd[4], xf[4];
                                 const size_t usedf = h_ints_decode(p, end, fvals);
                                 if (!usedf || !h_ints_exc(index + goff, xd) || !h_ints_exc(p, xf))
-                                        return fail(TRI_ERR_FORMAT, "term %zu: bad freqs group / exception list", ti);
+                                        return fail(TRI_ERR_FORMAT, "term %zu: a freqs group / exception list that is not PFOR128 (include/pfor128.md; FastPFor<4> payloads of the reference's own "
+                                                                    "build are not readable)", ti);
                                 p += usedf;
                                 uint32_t hdr[2];
                                 for (int gi = 0; gi < 2; ++gi) { // the two groups' header words as the row records cache them
@@ -1136,6 +1140,13 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->similarity = similarity;
         b->nq = nq;
         b->slot_of_query.assign(nq, UINT32_MAX);
+        b->qstatus.assign(nq, TRI_OK);
+        // a query shape the planner does not lower does not fail the batch: the query is left out (status TRI_ERR_UNSUPPORTED, no matches,
+        // tri_batch_query_status) and the caller keeps its CPU span for it; tri_last_error() describes the last such query
+        auto leave_out = [&](const size_t qi) {
+                b->qstatus[qi] = TRI_ERR_UNSUPPORTED;
+                ++b->info.unsupported_queries;
+        };
         struct Tmp {
                 DevQuery q;
                 uint64_t cost;
@@ -1284,8 +1295,11 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 bool truth = false;
                 if (!ok || groups.empty()) {
                         // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp)
-                        if (!build_truth(nodes, root, tp))
-                                return fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
+                        if (!build_truth(nodes, root, tp)) {
+                                leave_out(qi);
+                                fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
+                                continue;
+                        }
                         truth = true;
                         groups.assign(1, tp.slots); // (one group of every slot: the bookkeeping below — term list, cost, output bound — sees a union)
                         negs.clear();
@@ -1313,8 +1327,37 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         for (size_t i = 0; i < u.size(); ++i)
                                 uniq.push_back(u[i] | (i == 0 ? (QT_GROUP | QT_NOT) : 0u));
                 }
-                if (uniq.size() > MAX_QTERMS)
-                        return fail(TRI_ERR_UNSUPPORTED, "query %zu: more than %u terms", qi, MAX_QTERMS);
+                if (uniq.size() > MAX_QTERMS) {
+                        leave_out(qi);
+                        fail(TRI_ERR_UNSUPPORTED, "query %zu: more than %u terms", qi, MAX_QTERMS);
+                        continue;
+                }
+                // (default mode: the reportable terms — every postings iterator collect_doc_matching_terms can reach (queryexec_ctx.cpp:382-520):
+                //  group members and phrase terms, not the excluded side of a NOT —, distinct, in order of first appearance; counted before
+                //  anything of the query is recorded, so that a query with too many of them can still be left out cleanly)
+                std::vector<uint32_t> rt;
+                if (rich) {
+                        auto add = [&](uint32_t x) {
+                                if (std::find(rt.begin(), rt.end(), x) == rt.end())
+                                        rt.push_back(x);
+                        };
+                        for (uint32_t pi = 0; pi < tq.prog_len; ++pi) {
+                                const uint32_t tok = prog[tq.prog_off + pi];
+                                if ((tok >> 28) != TRI_OP_TERM)
+                                        continue;
+                                const uint32_t x = tok & 0x0fffffffu;
+                                bool positive = std::find(leaves.begin(), leaves.end(), x) != leaves.end();
+                                for (const auto &ph : qphrases)
+                                        positive |= std::find(ph.terms.begin(), ph.terms.end(), x) != ph.terms.end();
+                                if (positive)
+                                        add(x);
+                        }
+                        if (rt.size() > 16) {
+                                leave_out(qi);
+                                fail(TRI_ERR_UNSUPPORTED, "query %zu: more than 16 reportable terms", qi);
+                                continue;
+                        }
+                }
                 const uint32_t nlead = (uint32_t)groups[0].size();
                 const uint64_t lead_docs = gcost(groups[0]);
                 Tmp t;
@@ -1333,26 +1376,6 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 t.q.score_base = (uint32_t)b->sterms.size();
                 t.q.nscore = 0;
                 if (rich) {
-                        // the reportable terms: every postings iterator collect_doc_matching_terms can reach (queryexec_ctx.cpp:382-520) —
-                        // group members and phrase terms, not the excluded side of a NOT —, distinct, in order of first appearance
-                        std::vector<uint32_t> rt;
-                        auto add = [&](uint32_t x) {
-                                if (std::find(rt.begin(), rt.end(), x) == rt.end())
-                                        rt.push_back(x);
-                        };
-                        for (uint32_t pi = 0; pi < tq.prog_len; ++pi) {
-                                const uint32_t tok = prog[tq.prog_off + pi];
-                                if ((tok >> 28) != TRI_OP_TERM)
-                                        continue;
-                                const uint32_t x = tok & 0x0fffffffu;
-                                bool positive = std::find(leaves.begin(), leaves.end(), x) != leaves.end();
-                                for (const auto &ph : qphrases)
-                                        positive |= std::find(ph.terms.begin(), ph.terms.end(), x) != ph.terms.end();
-                                if (positive)
-                                        add(x);
-                        }
-                        if (rt.size() > 16)
-                                return fail(TRI_ERR_UNSUPPORTED, "query %zu: more than 16 reportable terms", qi);
                         for (uint32_t x : rt) {
                                 b->sterms.push_back(x);
                                 b->term_bytes += ix->hitbytes[x]; // the hits of every reported term are read
@@ -2312,6 +2335,14 @@ extern "C" int tri_batch_get_info(const tri_batch *b, tri_batch_info *info) {
         return TRI_OK;
 }
 
+extern "C" int tri_batch_query_status(const tri_batch *b, int32_t *status) {
+        if (!b || !status)
+                return fail(TRI_ERR_INVALID, "null argument");
+        for (size_t q = 0; q < b->nq; ++q)
+                status[q] = b->qstatus[q];
+        return TRI_OK;
+}
+
 extern "C" int tri_batch_match_counts(tri_batch *b, uint64_t *counts) {
         if (!b || !counts)
                 return fail(TRI_ERR_INVALID, "null argument");
@@ -2633,6 +2664,8 @@ struct tri_comm {
         tri_dev *dev = nullptr;
         void *comm = nullptr;
         int rank = 0, nranks = 1;
+        tri_allgather_fn custom = nullptr; // the caller's own transport instead of RCCL (tri_comm_create_custom)
+        void *custom_user = nullptr;
 };
 
 extern "C" int tri_comm_unique_id(uint8_t id[128]) {
@@ -2665,6 +2698,19 @@ extern "C" int tri_comm_create(tri_dev *dev, const uint8_t id[128], int rank, in
         return TRI_OK;
 }
 
+extern "C" int tri_comm_create_custom(tri_dev *dev, int rank, int nranks, tri_allgather_fn allgather, void *user, tri_comm **out) {
+        if (!dev || !out || !allgather || nranks < 1 || rank < 0 || rank >= nranks)
+                return fail(TRI_ERR_INVALID, "tri_comm_create_custom: bad argument");
+        auto c = std::make_unique<tri_comm>();
+        c->dev = dev;
+        c->rank = rank;
+        c->nranks = nranks;
+        c->custom = allgather;
+        c->custom_user = user;
+        *out = c.release();
+        return TRI_OK;
+}
+
 extern "C" void tri_comm_destroy(tri_comm *c) {
         if (!c)
                 return;
@@ -2686,6 +2732,21 @@ extern "C" int tri_gather_results(tri_batch *b, tri_comm *c, void *counts_all, v
                 return fail(TRI_ERR_INVALID, "tri_gather_results: a top-K batch needs all four receive buffers");
         tri_dev *dev = c->dev;
         HIP_TRY(hipSetDevice(dev->device));
+        if (c->custom) { // the same blocks, the same [nranks][...] layout, over the caller's transport
+                struct {
+                        const void *send;
+                        void *recv;
+                        size_t bytes;
+                } blocks[4] = {{b->d_qcounts, counts_all, b->nq * 8},
+                               {topk ? b->d_top_docs : nullptr, docids_all, b->nq * b->topk * 4},
+                               {topk ? b->d_top_scores : nullptr, scores_all, b->nq * b->topk * 4},
+                               {topk ? b->d_top_counts : nullptr, topk_counts_all, b->nq * 4}};
+                for (const auto &x : blocks)
+                        if (x.send)
+                                if (int rc = c->custom(c->custom_user, x.send, x.recv, x.bytes, (void *)dev->stream))
+                                        return fail(TRI_ERR_DEVICE, "tri_gather_results: the caller's allgather returned %d", rc);
+                return TRI_OK;
+        }
         const RcclApi &R = rccl();
         const int U8 = 1; // ncclUint8: the blocks travel as bytes
         int rc = R.GroupStart();

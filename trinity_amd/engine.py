@@ -77,6 +77,7 @@ class TriBatchInfo(C.Structure):
         ("plane_terms", C.c_uint64),
         ("plane_bytes", C.c_uint64),
         ("term_planes_decoded_bytes", C.c_uint64),
+        ("unsupported_queries", C.c_uint64),
     ]
 
 
@@ -84,10 +85,10 @@ class TriBatchInfo(C.Structure):
 ABI_SYMBOLS = [
     "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream", "tri_dev_set_option", "tri_dev_get_option",
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
-    "tri_batch_create", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
+    "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
     "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google",
-    "tri_comm_unique_id", "tri_comm_create", "tri_comm_destroy", "tri_gather_results",
+    "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
 
 _hip = None
@@ -119,6 +120,7 @@ def hip_lib():
     L.tri_index_set_masked.argtypes = [vp, vp, C.c_size_t]
     L.tri_decode_terms.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     L.tri_batch_create.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(vp)]
+    L.tri_batch_query_status.argtypes = [vp, vp]
     L.tri_batch_destroy.argtypes = [vp]
     L.tri_batch_run.argtypes = [vp]
     L.tri_batch_sync.argtypes = [vp]
@@ -143,6 +145,7 @@ def hip_lib():
     L.tri_encode_google.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_comm_unique_id.argtypes = [vp]
     L.tri_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.tri_comm_create_custom.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
     L.tri_comm_destroy.argtypes = [vp]
     L.tri_gather_results.argtypes = [vp, vp, vp, vp, vp, vp]
     _hip = L
@@ -353,6 +356,12 @@ class Batch:
         progs[:, :k] = rows  # TERM tokens: op 0 => the raw term id
         progs[:, k] = tok(OP_AND, k)
         return cls(index, list(progs), flags, topk)
+
+    def query_status(self):
+        """Per query: 0, or the status (TRI_ERR_UNSUPPORTED = -3) with which the planner left it out of the batch."""
+        out = np.zeros(self.nq, dtype=np.int32)
+        _check(hip_lib().tri_batch_query_status(self.h, out.ctypes.data))
+        return out
 
     def run(self):
         _check(hip_lib().tri_batch_run(self.h))
