@@ -162,6 +162,7 @@ struct PlanesShared {
         uint32_t tk_n, tk_full, matches;
         uint32_t leaf;                // the slots that have a scorer
         uint32_t top[FUS_MAX_SLOTS];  // per slot: its top level (3: a term plane; 2: a decoded list; 0: no scorer)
+        uint32_t emask;               // slots one of which every candidate holds (each assignment's rarest slot): a word without any of them skips the filter
         uint32_t npat;                // the candidate filter: 0xffffffff = every match (no threshold yet), else that many assignments
         alignas(16) uint32_t pat[PLK_MAXPAT + 4]; // ... two bits per slot: the level the slot must at least be at (read four at a time: padded with 0xffffffff)
         uint32_t flag[PLK_WG / 64];
@@ -222,9 +223,26 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         const double thr = sh.thr_s;
         const bool full = uni(sh.tk_full) != 0 && 0.0 < thr;
         sh.npat = full ? 0u : 0xffffffffu; // (uniform stores)
+        sh.emask = (1u << nslots) - 1u;
         __syncthreads();
         if (!full)
                 return;
+        // every candidate meets some assignment, hence holds that assignment's rarest slot: the OR of those slots' A words is a cheap
+        // necessary condition (uniform values: every lane computes the same set and stores it)
+        auto rarest_slots = [&](const uint32_t np) {
+                uint32_t e = 0;
+                for (uint32_t i = 0; i < np; ++i) {
+                        const uint32_t code = sh.pat[i];
+                        uint32_t best = 0, bd = 0xffffffffu;
+                        for (uint32_t sl = 0; sl < nslots; ++sl)
+                                if (((code >> (2 * sl)) & 3u) && sh.term[sl].documents < bd) {
+                                        bd = sh.term[sl].documents;
+                                        best = sl;
+                                }
+                        e |= 1u << best;
+                }
+                sh.emask = uni(e);
+        };
         for (int coarse = 0; coarse < 2; ++coarse) {
                 uint32_t total = 1;
                 for (uint32_t sl = 0; sl < nslots; ++sl)
@@ -264,6 +282,7 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                 __syncthreads();
                 if (uni(sh.npat) <= PLK_MAXPAT) {
                         const uint32_t np = uni(sh.npat);
+                        rarest_slots(np);
                         for (uint32_t j = 0; j < 4; ++j)
                                 sh.pat[np + j] = 0xffffffffu; // (uniform stores: the readers take four at a time)
                         __syncthreads();
@@ -293,6 +312,7 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                 if (!(p < thr) && sh.top[best])
                         sh.pat[np++] = 1u << (2 * best); // (uniform stores)
         }
+        rarest_slots(np);
         for (uint32_t j = 0; j < 4; ++j)
                 sh.pat[np + j] = 0xffffffffu;
         sh.npat = np;
@@ -438,6 +458,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.tk_full = 0;
                         sh.matches = 0;
                         sh.npat = 0xffffffffu; // no threshold yet: every match is a candidate
+                        sh.emask = (1u << nslots) - 1u;
                         // a decoded slot's rows that can hold documents of the task's range [first window's first docID, last window's end)
                         uint32_t row0 = 0, nrows = 0;
                         if (!dense) {
@@ -598,6 +619,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const bool full = uni(sh.tk_full) != 0;
                         const double thr_s = sh.thr_s;
                         const uint32_t thr_d = sh.thr_d;
+                        const uint32_t emask = uni(sh.emask);
                         while (sw < sw_end) {
                                 if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
                                         break; // the buffer wants pruning first: to the barrier (the sub-window stays as it is)
@@ -623,10 +645,15 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         const uint32_t wi = lane + which * 64u;
                                         uint32_t la[NS], lb[NS];
 #pragma unroll
-                                        for (uint32_t s = 0; s < NS; ++s) {
-                                                const uint32_t *lp = &sh.pl[wave][lidx[s]][0];
-                                                la[s] = lp[wi];
-                                                lb[s] = lp[PLK_SW_STRIDE + wi];
+                                        for (uint32_t s = 0; s < NS; ++s)
+                                                la[s] = lb[s] = 0;
+                                        if (rows_mask) { // (uniform: a sub-window no decoded list reaches reads no LDS)
+#pragma unroll
+                                                for (uint32_t s = 0; s < NS; ++s) {
+                                                        const uint32_t *lp = &sh.pl[wave][lidx[s]][0];
+                                                        la[s] = lp[wi];
+                                                        lb[s] = lp[PLK_SW_STRIDE + wi];
+                                                }
                                         }
 #pragma unroll
                                         for (uint32_t s = 0; s < NS; ++s) {
@@ -731,7 +758,12 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 if (masked) // masked_documents_registry::test (docidupdates.h:90-119)
                                                         m &= ~masked[(w0 >> 5) + lane + which * 64u];
                                                 my_matches += (uint32_t)__popc(m);
-                                                cand[which] = m & filter_word(a, b, c);
+                                                uint32_t ew = 0; // (documents that hold one of the slots every candidate must hold one of)
+#pragma unroll
+                                                for (uint32_t s = 0; s < NS; ++s)
+                                                        ew |= ((emask >> s) & 1u) ? a[s] : 0u;
+                                                ew &= m;
+                                                cand[which] = __builtin_amdgcn_ballot_w64(ew != 0) != 0ull ? ew & filter_word(a, b, c) : 0u;
                                         }
                                         c0 = cand[0], c1 = cand[1];
                                         open = true;
