@@ -137,6 +137,10 @@ constexpr uint32_t PLK_MAX_SPARSE = 6;  // slots whose lists are decoded per tas
 constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per thread when it is pruned)
 constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
 constexpr uint32_t PLK_MAXPAT = 32;     // level assignments of the candidate filter kept as such (more: coarser filters)
+#ifndef TRI_PLK_SPLIT_AT
+#define TRI_PLK_SPLIT_AT 6
+#endif
+constexpr uint32_t PLK_SPLIT_AT = TRI_PLK_SPLIT_AT; // more assignments than this: those that name a decoded slot are traded for "holds that slot" (checked per document)
 #ifndef TRI_PLK_WGS
 #define TRI_PLK_WGS 2
 #endif
@@ -162,6 +166,7 @@ struct PlanesShared {
         uint32_t tk_n, tk_full, matches;
         uint32_t leaf;                // the slots that have a scorer
         uint32_t top[FUS_MAX_SLOTS];  // per slot: its top level (3: a term plane; 2: a decoded list; 0: no scorer)
+        uint32_t pat2[PLK_MAXPAT + 4]; // (scratch of planes_filter)
         uint32_t emask;               // slots one of which every candidate holds (each assignment's rarest slot): a word without any of them skips the filter
         uint32_t npat;                // the candidate filter: 0xffffffff = every match (no threshold yet), else that many assignments
         alignas(16) uint32_t pat[PLK_MAXPAT + 4]; // ... two bits per slot: the level the slot must at least be at (read four at a time: padded with 0xffffffff)
@@ -281,7 +286,38 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                 }
                 __syncthreads();
                 if (uni(sh.npat) <= PLK_MAXPAT) {
-                        const uint32_t np = uni(sh.npat);
+                        uint32_t np = uni(sh.npat);
+                        if (np > PLK_SPLIT_AT) {
+                                // A long list costs every word of every sub-window (an AND per named slot and assignment).  The assignments
+                                // that name a decoded slot — a list of fewer than 1 document in 64 — are traded for the weaker "holds that
+                                // slot": those few documents are then checked one by one against the same bound (the candidates' scoring
+                                // does exactly that), and only the assignments over term planes alone stay word-wise.  (Uniform: every lane
+                                // walks the list.)
+                                __syncthreads();
+                                uint32_t any = 0, k = 0;
+                                for (uint32_t i = 0; i < np; ++i) {
+                                        const uint32_t code = sh.pat[i];
+                                        uint32_t best = 0xffffffffu, bd = 0xffffffffu;
+                                        for (uint32_t sl = 0; sl < nslots; ++sl)
+                                                if (((code >> (2 * sl)) & 3u) && sh.top[sl] == 2 && sh.term[sl].documents < bd) {
+                                                        bd = sh.term[sl].documents;
+                                                        best = sl;
+                                                }
+                                        if (best != 0xffffffffu)
+                                                any |= 1u << best;
+                                        else
+                                                sh.pat2[k++] = code; // (every wave reads the untouched list and writes the same values)
+                                }
+                                for (uint32_t sl = 0; sl < nslots; ++sl) // (one single-slot assignment per such slot, behind the kept ones)
+                                        if ((any >> sl) & 1u)
+                                                sh.pat2[k++] = 1u << (2 * sl);
+                                __syncthreads();
+                                np = uni(k);
+                                for (uint32_t i = 0; i < np; ++i)
+                                        sh.pat[i] = sh.pat2[i];
+                                sh.npat = np;
+                                __syncthreads();
+                        }
                         rarest_slots(np);
                         for (uint32_t j = 0; j < 4; ++j)
                                 sh.pat[np + j] = 0xffffffffu; // (uniform stores: the readers take four at a time)
