@@ -725,6 +725,54 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         }
                                         return y;
                                 };
+                                // One step over the candidates `cw` of one word: every lane that has one takes its lowest, scores it from the level words
+                                // a / b / c — the known part of the score and a bound for the rest — and offers it, queues it (a slot of unknown
+                                // frequency that the bound does not rule out) or drops it.  false: the buffer had no room (the candidate stays).
+                                auto candidate_step = [&](const uint32_t which, const uint32_t (&a)[NS], const uint32_t (&b)[NS], const uint32_t (&c)[NS], uint32_t &cw) {
+                                        bool enq = false;
+                                        uint32_t edoc = 0, elev = 0;
+                                        if (cw) {
+                                                const uint32_t bit = (uint32_t)__builtin_ctz(cw);
+                                                const uint32_t doc = w0 + 32u * (lane + which * 64u) + bit;
+                                                double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
+                                                uint32_t levels = 0;
+                                                bool unk = false;
+#pragma unroll
+                                                for (uint32_t s = 0; s < NS; ++s) {
+                                                        if (!top[s] || !((a[s] >> bit) & 1u))
+                                                                continue;
+                                                        const uint32_t bb = (b[s] >> bit) & 1u, cc = (c[s] >> bit) & 1u;
+                                                        const uint32_t l = 1u + bb + (bb & cc);
+                                                        levels |= l << (2 * s);
+                                                        if (l < top[s])
+                                                                sk += sh.wl[s][l];
+                                                        else {
+                                                                unk = true;
+                                                                sb += sh.wf[s][l];
+                                                        }
+                                                }
+                                                bool done = true;
+                                                if (!full || better(sk + sb, doc, thr_s, thr_d)) {
+                                                        if (unk) {
+                                                                enq = true;
+                                                                edoc = doc;
+                                                                elev = levels;
+                                                        } else
+                                                                done = offer(sk, doc); // (no room: the candidate stays for after the prune)
+                                                }
+                                                if (done)
+                                                        cw &= cw - 1u;
+                                        }
+                                        PROF_COUNT(16, lane == 0 ? 1 : 0);
+                                        const uint64_t em = __builtin_amdgcn_ballot_w64(enq);
+                                        if (enq) {
+                                                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                                                sh.wq[wave][at][0] = edoc;
+                                                sh.wq[wave][at][1] = elev;
+                                        }
+                                        qn += (uint32_t)__popcll(em);
+                                };
+                                bool stuck = false; // (the buffer filled up under a candidate)
                                 if (!open) {
                                         // (the term planes' words of both of this lane's words travel together with the lists' entries: one round trip)
                                         uint32_t g0a[NS], g0b[NS], g0c[NS], g1a[NS], g1b[NS], g1c[NS];
@@ -799,78 +847,42 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 for (uint32_t s = 0; s < NS; ++s)
                                                         ew |= ((emask >> s) & 1u) ? a[s] : 0u;
                                                 ew &= m;
-                                                cand[which] = __builtin_amdgcn_ballot_w64(ew != 0) != 0ull ? ew & filter_word(a, b, c) : 0u;
+                                                uint32_t cw = __builtin_amdgcn_ballot_w64(ew != 0) != 0ull ? ew & filter_word(a, b, c) : 0u;
+                                                // the word's candidates are worked off right here, while its level words are in registers (a sub-window
+                                                // of a union has one or two: a step of their own, with the words fetched again, cost more than the sweep)
+                                                while (!stuck && __builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
+                                                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
+                                                                stuck = true; // (the rest waits for the prune: the resume path below)
+                                                        else if (qn >= 64)
+                                                                work_queue();
+                                                        else
+                                                                candidate_step(which, a, b, c, cw);
+                                                }
+                                                cand[which] = cw;
                                         }
                                         c0 = cand[0], c1 = cand[1];
                                         open = true;
                                         PROF_COUNT(19, lane == 0 ? 1 : 0);
                                 }
-                                // ---- the sub-window's candidates, one per lane and step: the document's levels give the known part of its score and a
-                                //      bound for the rest.  A candidate the bound does not rule out and whose score is not fully known goes onto the queue
-                                bool stuck = false; // (the buffer filled up under a candidate)
-                                for (;;) {
-                                        const bool has = (c0 | c1) != 0;
-                                        if (__builtin_amdgcn_ballot_w64(has) == 0ull)
-                                                break;
+                                // ---- candidates left over from before a prune: the same steps, with the level words fetched again
+                                while (!stuck && __builtin_amdgcn_ballot_w64((c0 | c1) != 0) != 0ull) {
                                         if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
                                                 stuck = true;
                                                 break;
                                         }
-                                        if (qn >= 64) { // (a step below may add 64 entries: the queue is kept below 64 before it)
+                                        if (qn >= 64) { // (a step may add 64 entries: the queue is kept below 64 before it)
                                                 work_queue();
                                                 continue;
                                         }
-                                        bool enq = false;
-                                        uint32_t edoc = 0, elev = 0;
-                                        {
-                                                const uint32_t which = c0 ? 0u : 1u; // (lanes without a candidate fetch word 1 and drop it)
-                                                uint32_t a[NS], b[NS], c[NS];
-                                                level_words(which, a, b, c);
-                                                if (has) {
-                                                        const uint32_t bit = (uint32_t)__builtin_ctz(which ? c1 : c0);
-                                                        const uint32_t doc = w0 + 32u * (lane + which * 64u) + bit;
-                                                        double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
-                                                        uint32_t levels = 0;
-                                                        bool unk = false;
-#pragma unroll
-                                                        for (uint32_t s = 0; s < NS; ++s) {
-                                                                if (!top[s] || !((a[s] >> bit) & 1u))
-                                                                        continue;
-                                                                const uint32_t bb = (b[s] >> bit) & 1u, cc = (c[s] >> bit) & 1u;
-                                                                const uint32_t l = 1u + bb + (bb & cc);
-                                                                levels |= l << (2 * s);
-                                                                if (l < top[s])
-                                                                        sk += sh.wl[s][l];
-                                                                else {
-                                                                        unk = true;
-                                                                        sb += sh.wf[s][l];
-                                                                }
-                                                        }
-                                                        bool done = true;
-                                                        if (!full || better(sk + sb, doc, thr_s, thr_d)) {
-                                                                if (unk) {
-                                                                        enq = true;
-                                                                        edoc = doc;
-                                                                        elev = levels;
-                                                                } else
-                                                                        done = offer(sk, doc); // (no room: the candidate stays for after the prune)
-                                                        }
-                                                        if (done) {
-                                                                if (which)
-                                                                        c1 &= c1 - 1u;
-                                                                else
-                                                                        c0 &= c0 - 1u;
-                                                        }
-                                                }
-                                        }
-                                        PROF_COUNT(16, lane == 0 ? __popcll(__builtin_amdgcn_ballot_w64(has)) : 0);
-                                        const uint64_t em = __builtin_amdgcn_ballot_w64(enq);
-                                        if (enq) {
-                                                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-                                                sh.wq[wave][at][0] = edoc;
-                                                sh.wq[wave][at][1] = elev;
-                                        }
-                                        qn += (uint32_t)__popcll(em);
+                                        const uint32_t which = c0 ? 0u : 1u; // (lanes without a candidate fetch word 1 and drop it)
+                                        uint32_t a[NS], b[NS], c[NS];
+                                        level_words(which, a, b, c);
+                                        uint32_t cw = which ? c1 : c0;
+                                        candidate_step(which, a, b, c, cw);
+                                        if (which)
+                                                c1 = cw;
+                                        else
+                                                c0 = cw;
                                 }
                                 if (stuck)
                                         break;
