@@ -816,6 +816,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         }
                                         // ---- sweep, one word at a time: the predicate, then the candidate filter (planes_filter) on the level words
                                         uint32_t cand[2];
+                                        bool later = false; // (the queue or the buffer is full: what is left of the candidates goes through the resume path)
 #pragma unroll
                                         for (uint32_t which = 0; which < 2; ++which) {
                                                 uint32_t a[NS], b[NS], c[NS];
@@ -850,11 +851,11 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 uint32_t cw = __builtin_amdgcn_ballot_w64(ew != 0) != 0ull ? ew & filter_word(a, b, c) : 0u;
                                                 // the word's candidates are worked off right here, while its level words are in registers (a sub-window
                                                 // of a union has one or two: a step of their own, with the words fetched again, cost more than the sweep)
-                                                while (!stuck && __builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
-                                                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
-                                                                stuck = true; // (the rest waits for the prune: the resume path below)
-                                                        else if (qn >= 64)
-                                                                work_queue();
+                                                // (no call in here — the queue is worked off, and a full buffer waited out, in the resume path below: a call
+                                                //  among the sweep's live registers made the compiler spill them on the hot path)
+                                                while (!later && __builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
+                                                        if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
+                                                                later = true;
                                                         else
                                                                 candidate_step(which, a, b, c, cw);
                                                 }
