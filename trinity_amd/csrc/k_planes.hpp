@@ -136,11 +136,7 @@ constexpr int PLK_WG = 512;
 constexpr uint32_t PLK_MAX_SPARSE = 6;  // slots whose lists are decoded per task (LDS planes); the planner sends wider queries to k_fused
 constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per thread when it is pruned)
 constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
-constexpr uint32_t PLK_MAXPAT = 32;     // level assignments of the candidate filter kept as such (more: coarser filters)
-#ifndef TRI_PLK_SPLIT_AT
-#define TRI_PLK_SPLIT_AT 6
-#endif
-constexpr uint32_t PLK_SPLIT_AT = TRI_PLK_SPLIT_AT; // more assignments than this: those that name a decoded slot are traded for "holds that slot" (checked per document)
+constexpr uint32_t PLK_FTAB_WORDS = (1u << (2 * FUS_MAX_SLOTS)) / 32; // the filter table: one bit per level vector (two bits per slot)
 #ifndef TRI_PLK_WGS
 #define TRI_PLK_WGS 2
 #endif
@@ -166,10 +162,9 @@ struct PlanesShared {
         uint32_t tk_n, tk_full, matches;
         uint32_t leaf;                // the slots that have a scorer
         uint32_t top[FUS_MAX_SLOTS];  // per slot: its top level (3: a term plane; 2: a decoded list; 0: no scorer)
-        uint32_t pat2[PLK_MAXPAT + 4]; // (scratch of planes_filter)
-        uint32_t emask;               // slots one of which every candidate holds (each assignment's rarest slot): a word without any of them skips the filter
-        uint32_t npat;                // the candidate filter: 0xffffffff = every match (no threshold yet), else that many assignments
-        alignas(16) uint32_t pat[PLK_MAXPAT + 4]; // ... two bits per slot: the level the slot must at least be at (read four at a time: padded with 0xffffffff)
+        uint32_t emask;               // the essential slots (MaxScore): every candidate holds one of them — a word without any of them is skipped
+        uint32_t fall;                // 1: no threshold yet (or one that rules nothing out): every match is a candidate
+        uint32_t ftab[PLK_FTAB_WORDS]; // the candidate filter: bit `code` (two bits per slot: its level) set <=> the levels' weights reach the threshold
         uint32_t flag[PLK_WG / 64];
         uint32_t wq[PLK_WG / 64][PLK_WQ][2]; // per wave: candidates waiting for exact frequencies {docID, the slots' levels (two bits each)}
         uint32_t bcast[4];
@@ -218,122 +213,42 @@ __device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t 
 
 // The candidate filter, recomputed whenever the threshold moves (every thread calls it; it ends with a barrier).  Every scoring slot
 // is at a level 0 .. top[slot] in a document and adds at most wf[slot][level] there (exactly, below the top level), so a document's
-// score is at most the sum of its slots' level weights.  The MINIMAL level assignments whose weights reach the current k-th best
-// score are listed (lowering any slot by one level drops below it); a match is a candidate iff it is at least at those levels for
-// one of them.  At most 4^nslots assignments, spread over the threads.  Too many minimal ones: the same with only "present / absent"
-// per slot (weights: the bounds); still too many: the slots MaxScore calls essential, one each.  No threshold yet, or one that
-// rules nothing out: every match is a candidate.
+// score is at most the sum of its slots' level weights: the TABLE holds, for every level vector (two bits per slot), whether that sum
+// reaches the current k-th best score.  A match is looked up with its own level vector — a few shifts on the words the sweep already
+// holds — so documents whose frequencies are all known (almost all) are tested against their exact score.  To keep that off most
+// documents, MaxScore's essential slots come first, word-wise: with the slots ordered by their bound, the longest prefix whose bounds
+// sum to less than the threshold cannot lift a document over it, so a candidate holds one of the OTHER slots — the OR of their A words
+// picks the few documents that are looked up at all.  No threshold yet, or one that rules nothing out: every match is a candidate.
 __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         const uint32_t tid = threadIdx.x;
         const double thr = sh.thr_s;
         const bool full = uni(sh.tk_full) != 0 && 0.0 < thr;
-        sh.npat = full ? 0u : 0xffffffffu; // (uniform stores)
+        sh.fall = full ? 0u : 1u; // (uniform stores)
         sh.emask = (1u << nslots) - 1u;
-        __syncthreads();
-        if (!full)
+        if (!full) {
+                __syncthreads();
                 return;
-        // every candidate meets some assignment, hence holds that assignment's rarest slot: the OR of those slots' A words is a cheap
-        // necessary condition (uniform values: every lane computes the same set and stores it)
-        auto rarest_slots = [&](const uint32_t np) {
-                uint32_t e = 0;
-                for (uint32_t i = 0; i < np; ++i) {
-                        const uint32_t code = sh.pat[i];
-                        uint32_t best = 0, bd = 0xffffffffu;
-                        for (uint32_t sl = 0; sl < nslots; ++sl)
-                                if (((code >> (2 * sl)) & 3u) && sh.term[sl].documents < bd) {
-                                        bd = sh.term[sl].documents;
-                                        best = sl;
-                                }
-                        e |= 1u << best;
-                }
-                sh.emask = uni(e);
-        };
-        for (int coarse = 0; coarse < 2; ++coarse) {
-                uint32_t total = 1;
-                for (uint32_t sl = 0; sl < nslots; ++sl)
-                        total *= (coarse ? (uni(sh.top[sl]) ? 2u : 1u) : uni(sh.top[sl]) + 1u);
-                for (uint32_t a = tid; a < total; a += PLK_WG) {
-                        uint32_t lv[FUS_MAX_SLOTS], x = a;
-                        for (uint32_t sl = 0; sl < nslots; ++sl) {
-                                const uint32_t base = coarse ? (sh.top[sl] ? 2u : 1u) : sh.top[sl] + 1u;
-                                lv[sl] = x % base;
-                                x /= base;
-                                if (coarse && lv[sl])
-                                        lv[sl] = sh.top[sl]; // (present: weighed with the slot's bound, required at level 1 below)
-                        }
-                        if (!a)
-                                continue;
-                        auto reaches = [&](const uint32_t lowered) { // (lowered: the slot taken down one level — coarse: to absent; nslots: none)
-                                double sum = 0.0;
-                                for (uint32_t sl = 0; sl < nslots; ++sl) {
-                                        const uint32_t l = sl == lowered ? (coarse ? 0u : lv[sl] - 1u) : lv[sl];
-                                        sum += l ? sh.wf[sl][l] : 0.0;
-                                }
-                                return !(sum < thr);
-                        };
-                        bool minimal = reaches(nslots);
-                        for (uint32_t sl = 0; sl < nslots && minimal; ++sl)
-                                if (lv[sl] && reaches(sl))
-                                        minimal = false;
-                        if (minimal) {
-                                uint32_t code = 0;
-                                for (uint32_t sl = 0; sl < nslots; ++sl)
-                                        code |= (coarse ? (lv[sl] ? 1u : 0u) : lv[sl]) << (2 * sl);
-                                const uint32_t at = atomicAdd(&sh.npat, 1u);
-                                if (at < PLK_MAXPAT)
-                                        sh.pat[at] = code;
-                        }
-                }
-                __syncthreads();
-                if (uni(sh.npat) <= PLK_MAXPAT) {
-                        uint32_t np = uni(sh.npat);
-                        if (np > PLK_SPLIT_AT) {
-                                // A long list costs every word of every sub-window (an AND per named slot and assignment).  The assignments
-                                // that name a decoded slot — a list of fewer than 1 document in 64 — are traded for the weaker "holds that
-                                // slot": those few documents are then checked one by one against the same bound (the candidates' scoring
-                                // does exactly that), and only the assignments over term planes alone stay word-wise.  (Uniform: every lane
-                                // walks the list.)
-                                __syncthreads();
-                                uint32_t any = 0, k = 0;
-                                for (uint32_t i = 0; i < np; ++i) {
-                                        const uint32_t code = sh.pat[i];
-                                        uint32_t best = 0xffffffffu, bd = 0xffffffffu;
-                                        for (uint32_t sl = 0; sl < nslots; ++sl)
-                                                if (((code >> (2 * sl)) & 3u) && sh.top[sl] == 2 && sh.term[sl].documents < bd) {
-                                                        bd = sh.term[sl].documents;
-                                                        best = sl;
-                                                }
-                                        if (best != 0xffffffffu)
-                                                any |= 1u << best;
-                                        else
-                                                sh.pat2[k++] = code; // (every wave reads the untouched list and writes the same values)
-                                }
-                                for (uint32_t sl = 0; sl < nslots; ++sl) // (one single-slot assignment per such slot, behind the kept ones)
-                                        if ((any >> sl) & 1u)
-                                                sh.pat2[k++] = 1u << (2 * sl);
-                                __syncthreads();
-                                np = uni(k);
-                                for (uint32_t i = 0; i < np; ++i)
-                                        sh.pat[i] = sh.pat2[i];
-                                sh.npat = np;
-                                __syncthreads();
-                        }
-                        rarest_slots(np);
-                        for (uint32_t j = 0; j < 4; ++j)
-                                sh.pat[np + j] = 0xffffffffu; // (uniform stores: the readers take four at a time)
-                        __syncthreads();
-                        return;
-                }
-                PROF_COUNT(21 + coarse, tid == 0 ? 1 : 0);
-                __syncthreads(); // (every lane has read npat)
-                sh.npat = 0;
-                __syncthreads();
         }
-        // MaxScore's essential slots: with the slots ordered by their bound, the longest prefix whose bounds sum to less than the
-        // threshold cannot lift a document over it; a match must hold one of the others
-        uint32_t done = 0, np = 0;
+        const uint32_t words = (1u << (2 * nslots)) / 32u > 0 ? (1u << (2 * nslots)) / 32u : 1u;
+        for (uint32_t wd = tid; wd < words; wd += PLK_WG) {
+                uint32_t bits = 0;
+                for (uint32_t j = 0; j < 32; ++j) {
+                        const uint32_t code = wd * 32u + j;
+                        double sum = 0.0;
+                        bool valid = code < (1u << (2 * nslots));
+                        for (uint32_t sl = 0; sl < nslots; ++sl) {
+                                const uint32_t l = (code >> (2 * sl)) & 3u;
+                                valid &= l <= sh.top[sl];
+                                sum += l ? sh.wf[sl][l] : 0.0;
+                        }
+                        bits |= (valid && !(sum < thr) ? 1u : 0u) << j;
+                }
+                sh.ftab[wd] = bits;
+        }
+        // the essential slots (same values in every lane)
+        uint32_t done = 0, ess = 0;
         double p = 0.0;
-        for (uint32_t r = 0; r < nslots; ++r) { // selection by ascending bound (<= 8 slots); same values in every lane
+        for (uint32_t r = 0; r < nslots; ++r) { // selection by ascending bound (<= 8 slots)
                 uint32_t best = 0;
                 double bv = 1e300;
                 for (uint32_t sl = 0; sl < nslots; ++sl) {
@@ -345,13 +260,10 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                 }
                 done |= 1u << best;
                 p += bv;
-                if (!(p < thr) && sh.top[best])
-                        sh.pat[np++] = 1u << (2 * best); // (uniform stores)
+                if (!(p < thr))
+                        ess |= 1u << best;
         }
-        rarest_slots(np);
-        for (uint32_t j = 0; j < 4; ++j)
-                sh.pat[np + j] = 0xffffffffu;
-        sh.npat = np;
+        sh.emask = uni(ess);
         __syncthreads();
 }
 
@@ -493,7 +405,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.tk_n = 0;
                         sh.tk_full = 0;
                         sh.matches = 0;
-                        sh.npat = 0xffffffffu; // no threshold yet: every match is a candidate
+                        sh.fall = 1; // no threshold yet: every match is a candidate
                         sh.emask = (1u << nslots) - 1u;
                         // a decoded slot's rows that can hold documents of the task's range [first window's first docID, last window's end)
                         uint32_t row0 = 0, nrows = 0;
@@ -656,6 +568,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const double thr_s = sh.thr_s;
                         const uint32_t thr_d = sh.thr_d;
                         const uint32_t emask = uni(sh.emask);
+                        const bool fall = uni(sh.fall) != 0;
                         while (sw < sw_end) {
                                 if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
                                         break; // the buffer wants pruning first: to the barrier (the sub-window stays as it is)
@@ -703,27 +616,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         uint32_t ga[NS], gb[NS], gc[NS];
                                         plane_words(which, ga, gb, gc);
                                         finish_words(which, ga, gb, gc, a, b, c);
-                                };
-                                auto filter_word = [&](const uint32_t (&a)[NS], const uint32_t (&b)[NS], const uint32_t (&c)[NS]) { // the candidate filter on one word
-                                        const uint32_t np = uni(sh.npat);
-                                        if (np == 0xffffffffu)
-                                                return 0xffffffffu;
-                                        uint32_t y = 0;
-                                        for (uint32_t i = 0; i < np; i += 4) { // (four assignments per LDS round trip; the list is padded with never-met ones)
-                                                const uint4 p4 = *(const uint4 *)&sh.pat[i];
-                                                const uint32_t pss[4] = {uni(p4.x), uni(p4.y), uni(p4.z), uni(p4.w)};
-#pragma unroll
-                                                for (uint32_t j = 0; j < 4; ++j) {
-                                                        uint32_t x = 0xffffffffu;
-#pragma unroll
-                                                        for (uint32_t s = 0; s < NS; ++s) {
-                                                                const uint32_t l = (pss[j] >> (2 * s)) & 3u; // (uniform)
-                                                                x &= l == 1 ? a[s] : l == 2 ? b[s] : l == 3 ? c[s] : 0xffffffffu;
-                                                        }
-                                                        y |= pss[j] == 0xffffffffu ? 0u : x;
-                                                }
-                                        }
-                                        return y;
                                 };
                                 // One step over the candidates `cw` of one word: every lane that has one takes its lowest, scores it from the level words
                                 // a / b / c — the known part of the score and a bound for the rest — and offers it, queues it (a slot of unknown
@@ -843,12 +735,27 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 if (masked) // masked_documents_registry::test (docidupdates.h:90-119)
                                                         m &= ~masked[(w0 >> 5) + lane + which * 64u];
                                                 my_matches += (uint32_t)__popc(m);
-                                                uint32_t ew = 0; // (documents that hold one of the slots every candidate must hold one of)
+                                                // the candidate filter: the documents that hold an essential slot, word-wise; each of them then with its level
+                                                // vector in the table (one per lane and step)
+                                                uint32_t cw = m;
+                                                if (!fall) {
+                                                        uint32_t ew = 0;
 #pragma unroll
-                                                for (uint32_t s = 0; s < NS; ++s)
-                                                        ew |= ((emask >> s) & 1u) ? a[s] : 0u;
-                                                ew &= m;
-                                                uint32_t cw = __builtin_amdgcn_ballot_w64(ew != 0) != 0ull ? ew & filter_word(a, b, c) : 0u;
+                                                        for (uint32_t s = 0; s < NS; ++s)
+                                                                ew |= ((emask >> s) & 1u) ? a[s] : 0u;
+                                                        ew &= m;
+                                                        cw = 0;
+                                                        while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
+                                                                const uint32_t bit = ew ? (uint32_t)__builtin_ctz(ew) : 0u;
+                                                                uint32_t code = 0;
+#pragma unroll
+                                                                for (uint32_t s = 0; s < NS; ++s) // (the planes are nested: the level is the number of them the document is in)
+                                                                        code |= (top[s] ? ((a[s] >> bit) & 1u) + ((b[s] >> bit) & 1u) + ((c[s] >> bit) & 1u) : 0u) << (2 * s); // (a slot without a scorer: level 0)
+                                                                const uint32_t hit = (sh.ftab[code >> 5] >> (code & 31u)) & 1u;
+                                                                cw |= ew ? hit << bit : 0u;
+                                                                ew &= ew - 1u;
+                                                        }
+                                                }
                                                 // the word's candidates are worked off right here, while its level words are in registers (a sub-window
                                                 // of a union has one or two: a step of their own, with the words fetched again, cost more than the sweep)
                                                 // (no call in here — the queue is worked off, and a full buffer waited out, in the resume path below: a call
