@@ -144,6 +144,8 @@ constexpr uint32_t PLK_WGS_PER_CU = TRI_PLK_WGS; // (LDS: two fit)
 constexpr uint32_t PLK_WQ = 128;        // per-wave queue of candidates waiting for a frequency lookup: worked off 64 at a time, every lane busy
 constexpr uint32_t PLK_NS_SMALL = 5;    // the instantiation for queries of up to this many slots keeps six words per slot in registers
 constexpr uint32_t PLK_PAD = 0xffffffffu; // list padding (sorts last)
+constexpr uint32_t PLK_SEED_FIRST = 4096;  // the seed pass takes the shortest decoded list if it has at most this many entries in the task's range ...
+constexpr uint32_t PLK_SEED_MORE = 2048;   // ... and further ones while the total stays below this
 constexpr uint32_t PLK_SW_WORDS = 128;    // a wave's sub-window: two words (64 documents) per lane ...
 constexpr uint32_t PLK_SW = PLK_SW_WORDS * 32; // ... 4096 documents
 constexpr uint32_t PLK_SW_STRIDE = PLK_SW_WORDS + 4; // LDS words between a decoded slot's A and B plane of a sub-window
@@ -560,6 +562,131 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
 #pragma unroll
                 for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g)
                         gsl[g] = g < nreq ? uni(fq.gslots[g]) : 0u;
+                // ---- SEED: the documents of the query's rarest decoded list(s) — a few thousand at most — are scored first, each on its own:
+                //      its levels in the other slots come from plane probes (head terms) and bisections of the other lists.  The top-K is mostly
+                //      made of documents that hold the rare terms, so the threshold — and with it the candidate filter — is close to final before
+                //      the sweep starts, instead of converging over the whole range.  The sweep then leaves those documents out of its candidates
+                //      (they are counted as matches there like every other document).
+                uint32_t seedmask = 0;
+                {
+                        uint32_t seed_items = 0;
+                        for (uint32_t r = 0; r < nslots; ++r) { // ascending list length (uniform)
+                                uint32_t best = 0xffffffffu, bn = 0xffffffffu;
+#pragma unroll
+                                for (uint32_t s = 0; s < NS; ++s)
+                                        if (((sparse_mask >> s) & 1u) && !((seedmask >> s) & 1u) && !((negs >> s) & 1u) && top[s] && sp_n32[s] && sp_n32[s] < bn) {
+                                                bn = sp_n32[s];
+                                                best = s;
+                                        }
+                                if (best == 0xffffffffu || (seedmask ? seed_items + bn > PLK_SEED_MORE : bn > PLK_SEED_FIRST))
+                                        break;
+                                seedmask |= 1u << best;
+                                seed_items += bn;
+                        }
+                        const uint32_t d_lo = wfirst * PL_W, d_hi = wend * PL_W;
+                        const bool full0 = false;
+                        (void)full0;
+                        for (uint32_t v0 = 0; v0 < seed_items; v0 += PLK_WG) { // (uniform trip count)
+                                // this thread's item: an entry of a seed slot's list
+                                const uint32_t v = v0 + tid;
+                                uint32_t ss = 0, ei = v;
+                                bool pend = v < seed_items;
+#pragma unroll
+                                for (uint32_t s = 0; s < NS; ++s)
+                                        if ((seedmask >> s) & 1u) {
+                                                if (ss == s && ei >= sp_n32[s]) {
+                                                        ei -= sp_n32[s];
+                                                        ss = s + 1;
+                                                }
+                                        } else if (ss == s)
+                                                ss = s + 1;
+                                // (ss: the first seed slot whose entries are not all before item v)
+                                uint32_t e = PLK_PAD;
+                                if (pend && ss < NS) {
+                                        uint32_t off = 0;
+#pragma unroll
+                                        for (uint32_t s = 0; s < NS; ++s)
+                                                off = ss == s ? sp_off[s] : off;
+                                        e = lists[off + ei];
+                                }
+                                const uint32_t doc = e >> 1;
+                                pend = pend && e != PLK_PAD && doc >= d_lo && doc < d_hi && doc != 0;
+                                double score = 0.0;
+                                if (pend) {
+                                        // the document's level in every slot
+                                        uint32_t present = 0, levels = 0;
+#pragma unroll
+                                        for (uint32_t s = 0; s < NS; ++s) {
+                                                if (s >= nslots)
+                                                        continue;
+                                                uint32_t l = 0;
+                                                if (prows[s] != PL_NONE) {
+                                                        const uint32_t *pa = pA[s], *pb = pa + plw, *pc = pb + plw;
+                                                        const uint32_t wi = doc >> 5, bit = doc & 31u;
+                                                        l = ((pa[wi] >> bit) & 1u) + ((pb[wi] >> bit) & 1u) + ((pc[wi] >> bit) & 1u);
+                                                } else if (s == ss)
+                                                        l = 1u + (e & 1u);
+                                                else if (sp_n32[s]) { // another decoded list: bisect it
+                                                        const uint32_t *ls = lists + sp_off[s];
+                                                        uint32_t lo = 0, hi = sp_n32[s];
+                                                        const uint32_t key = doc << 1;
+                                                        while (lo < hi) {
+                                                                const uint32_t mid = (lo + hi) >> 1;
+                                                                if (ls[mid] < key)
+                                                                        lo = mid + 1;
+                                                                else
+                                                                        hi = mid;
+                                                        }
+                                                        const uint32_t f = lo < sp_n32[s] ? ls[lo] : PLK_PAD;
+                                                        l = (f >> 1) == doc ? 1u + (f & 1u) : 0u;
+                                                }
+                                                present |= (l ? 1u : 0u) << s;
+                                                levels |= (top[s] ? l : 0u) << (2 * s);
+                                        }
+                                        // a document that an earlier seed slot holds is that slot's item; the predicate: every required group, no excluded slot, not masked
+                                        bool ok = !(present & seedmask & ((1u << ss) - 1u)) && !(present & negs);
+#pragma unroll
+                                        for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g)
+                                                ok = ok && (g >= nreq || (present & gsl[g]) != 0);
+                                        if (ok && masked)
+                                                ok = !((masked[doc >> 5] >> (doc & 31u)) & 1u);
+                                        pend = ok;
+                                        if (ok)
+                                                for (uint32_t s = 0; s < nslots; ++s) {
+                                                        const uint32_t l = (levels >> (2 * s)) & 3u;
+                                                        if (!l)
+                                                                continue;
+                                                        if (l < sh.top[s]) {
+                                                                score += sh.wl[s][l];
+                                                                continue;
+                                                        }
+                                                        const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, sh.term[s], doc);
+                                                        const uint32_t term = fq.term[s];
+                                                        for (uint32_t si = 0; si < q.nscore; ++si)
+                                                                if (sterms[q.score_base + si] == term)
+                                                                        score += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                                }
+                                }
+                                // offered in rounds: a full buffer is pruned in between
+                                for (;;) {
+                                        if (pend && (!uni(sh.tk_full) || better(score, doc, sh.thr_s, sh.thr_d)))
+                                                pend = !offer(score, doc);
+                                        else
+                                                pend = false;
+                                        const uint32_t anyp = (uint32_t)__syncthreads_or(pend ? 1 : 0);
+                                        const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
+                                        __syncthreads(); // (every lane has read tk_n)
+                                        if (n >= PLK_PRUNE_AT)
+                                                planes_prune(sh, n, k);
+                                        if (!uni(anyp))
+                                                break;
+                                }
+                        }
+                        if (seedmask) {
+                                planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k);
+                                planes_filter(sh, nslots);
+                        }
+                }
                 uint32_t c0 = 0, c1 = 0, rows_mask = 0; // the current sub-window's candidates (per lane) and the decoded slots that put something into its LDS planes
                 bool open = false;                      // the current sub-window has been swept (its candidates are being worked off)
                 for (;;) {
@@ -737,13 +864,17 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 my_matches += (uint32_t)__popc(m);
                                                 // the candidate filter: the documents that hold an essential slot, word-wise; each of them then with its level
                                                 // vector in the table (one per lane and step)
-                                                uint32_t cw = m;
+                                                uint32_t seeded = 0; // (documents the seed pass has scored: never candidates here)
+#pragma unroll
+                                                for (uint32_t s = 0; s < NS; ++s)
+                                                        seeded |= ((seedmask >> s) & 1u) ? a[s] : 0u;
+                                                uint32_t cw = m & ~seeded;
                                                 if (!fall) {
                                                         uint32_t ew = 0;
 #pragma unroll
                                                         for (uint32_t s = 0; s < NS; ++s)
                                                                 ew |= ((emask >> s) & 1u) ? a[s] : 0u;
-                                                        ew &= m;
+                                                        ew &= m & ~seeded;
                                                         cw = 0;
                                                         while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
                                                                 const uint32_t bit = ew ? (uint32_t)__builtin_ctz(ew) : 0u;
@@ -754,6 +885,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                                 const uint32_t hit = (sh.ftab[code >> 5] >> (code & 31u)) & 1u;
                                                                 cw |= ew ? hit << bit : 0u;
                                                                 ew &= ew - 1u;
+                                                                PROF_COUNT(20, lane == 0 ? 1 : 0);
                                                         }
                                                 }
                                                 // the word's candidates are worked off right here, while its level words are in registers (a sub-window
@@ -761,8 +893,10 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 // (no call in here — the queue is worked off, and a full buffer waited out, in the resume path below: a call
                                                 //  among the sweep's live registers made the compiler spill them on the hot path)
                                                 while (!later && __builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
-                                                        if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
+                                                        if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
                                                                 later = true;
+                                                                PROF_COUNT(23, lane == 0 ? 1 : 0);
+                                                        }
                                                         else
                                                                 candidate_step(which, a, b, c, cw);
                                                 }
