@@ -28,6 +28,20 @@ ix = T.Index.from_segment(dev, seg)
 if os.environ.get("RICH"):
     flags, topk = T.FLAG_MATCHED_TERMS, 0
     desc += " [default (rich match) mode]"
+if os.environ.get("EACH"):  # EACH=n: the first n queries one batch each — the per-query time distribution (a kernel's tail is its longest task)
+    rows = []
+    for p in progs[: int(os.environ["EACH"])]:
+        b1 = T.Batch(ix, [p], flags, topk=topk)
+        for _ in range(2):
+            b1.run(); b1.sync()
+        i1 = b1.info()
+        rows.append((i1["last_run_ms"], [int(x) for x in p], int(i1["matches"])))
+        b1.close()
+    rows.sort(key=lambda r: -r[0])
+    ms = [r[0] for r in rows]
+    print(f"  per query: mean {sum(ms) / len(ms):.3f} ms  max {ms[0]:.3f}  median {ms[len(ms) // 2]:.3f}  p90 {ms[len(ms) // 10]:.3f}")
+    for r in rows[:12] + rows[-3:]:
+        print(f"    {r[0]:.3f} ms  matches {r[2]:>9}  terms {[x & 0x0FFFFFFF for x in r[1] if x >> 28 == E.OP_TERM]}")
 b = T.Batch(ix, progs, flags, topk=topk)
 best = 1e9
 for _ in range(3):

@@ -37,7 +37,11 @@ struct ProfClock {
 #define PROF_FLUSH() prof_.flush()
 #define PROF_ARG , ProfClock &prof_
 #define PROF_PASS , prof_
-#define PROF_COUNT(slot, n) atomicAdd(&g_prof[slot], (unsigned long long)(n)) // event counters: g_prof[16 ..]
+#ifdef TRI_PROF_COUNTS // (event counters, g_prof[16 ..]: global atomics on a handful of addresses — they distort the phase times, so a build of their own)
+#define PROF_COUNT(slot, n) atomicAdd(&g_prof[slot], (unsigned long long)(n))
+#else
+#define PROF_COUNT(slot, n)
+#endif
 #else
 #define PROF_DECL
 #define PROF_START()

@@ -164,7 +164,7 @@ struct PlanesShared {
         uint32_t tk_n, tk_full, matches;
         uint32_t leaf;                // the slots that have a scorer
         uint32_t top[FUS_MAX_SLOTS];  // per slot: its top level (3: a term plane; 2: a decoded list; 0: no scorer)
-        uint32_t emask;               // the essential slots (MaxScore): every candidate holds one of them — a word without any of them is skipped
+        uint32_t esel;                // the essential planes (two bits per slot — 0: A, 1: B, 2: C, 3: none): every candidate is in one of them
         uint32_t fall;                // 1: no threshold yet (or one that rules nothing out): every match is a candidate
         uint32_t ftab[PLK_FTAB_WORDS]; // the candidate filter: bit `code` (two bits per slot: its level) set <=> the levels' weights reach the threshold
         uint32_t flag[PLK_WG / 64];
@@ -226,7 +226,7 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         const double thr = sh.thr_s;
         const bool full = uni(sh.tk_full) != 0 && 0.0 < thr;
         sh.fall = full ? 0u : 1u; // (uniform stores)
-        sh.emask = (1u << nslots) - 1u;
+        sh.esel = 0; // (plane A of every slot)
         if (!full) {
                 __syncthreads();
                 return;
@@ -247,9 +247,10 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                 }
                 sh.ftab[wd] = bits;
         }
-        // the essential slots (same values in every lane)
+        // the essential planes (same values in every lane): whole slots first, by ascending bound ...
+        const double thr_lo = thr * (1.0 - 1e-9); // (the table adds the weights in its own order: a hair of room for the rounding)
         uint32_t done = 0, ess = 0;
-        double p = 0.0;
+        double p = 0.0, spent = 0.0;
         for (uint32_t r = 0; r < nslots; ++r) { // selection by ascending bound (<= 8 slots)
                 uint32_t best = 0;
                 double bv = 1e300;
@@ -262,10 +263,43 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                 }
                 done |= 1u << best;
                 p += bv;
-                if (!(p < thr))
+                if (!(p < thr_lo))
                         ess |= 1u << best;
+                else
+                        spent = p;
         }
-        sh.emask = uni(ess);
+        // ... then what is left of the threshold buys the essential slots' LOW levels: a slot capped at level c is essential only through
+        // its plane c + 1 (B: frequency not 1 — a fraction of A; C: nor 2).  Each round takes the raise that drops the most documents
+        // (estimated from the terms' document counts) among those that still fit.
+        uint32_t cap[FUS_MAX_SLOTS];
+        for (uint32_t sl = 0; sl < FUS_MAX_SLOTS; ++sl)
+                cap[sl] = sl < nslots && ((ess >> sl) & 1u) ? 0u : 3u;
+        for (uint32_t r = 0; r < 2 * FUS_MAX_SLOTS; ++r) {
+                uint32_t best = 0xffffffffu;
+                double gain = 0.0, cost = 0.0;
+                for (uint32_t sl = 0; sl < nslots; ++sl) {
+                        const uint32_t c = cap[sl], tp = sh.top[sl];
+                        if (c >= tp) // (its top plane already, or not essential at all)
+                                continue;
+                        const double dw = sh.wf[sl][c + 1] - (c ? sh.wf[sl][c] : 0.0);
+                        const double docs = (double)sh.term[sl].documents * (c == 0 ? 0.65 : c == 1 ? 0.2 : 0.15); // (the documents at exactly level c + 1, roughly)
+                        if (spent + dw < thr_lo && gain < docs) {
+                                gain = docs;
+                                cost = dw;
+                                best = sl;
+                        }
+                }
+                if (best == 0xffffffffu)
+                        break;
+                cap[best] += 1;
+                spent += cost;
+        }
+        uint32_t esel = 0;
+        for (uint32_t sl = 0; sl < FUS_MAX_SLOTS; ++sl) {
+                const uint32_t c = cap[sl], tp = sl < nslots ? sh.top[sl] : 0u;
+                esel |= (c + 1 > tp ? 3u : c) << (2 * sl);
+        }
+        sh.esel = uni(esel);
         __syncthreads();
 }
 
@@ -408,7 +442,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.tk_full = 0;
                         sh.matches = 0;
                         sh.fall = 1; // no threshold yet: every match is a candidate
-                        sh.emask = (1u << nslots) - 1u;
+                        sh.esel = 0;
                         // a decoded slot's rows that can hold documents of the task's range [first window's first docID, last window's end)
                         uint32_t row0 = 0, nrows = 0;
                         if (!dense) {
@@ -499,6 +533,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         return true;
                 };
                 auto work_queue = [&]() { // the last (up to) 64 entries of the queue; entries that found no room go back
+                        PROF_LAP(11);
                         const uint32_t take_n = min(qn, 64u), base = qn - take_n;
                         qn = base;
                         bool back = false;
@@ -532,6 +567,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 sh.wq[wave][at][1] = levels;
                         }
                         qn += (uint32_t)__popcll(bm);
+                        PROF_LAP(13);
                 };
                 // ---- Every WAVE walks its own contiguous share of the task's range, a sub-window of PLK_SW documents (two words per lane) at a
                 //      time, wave-synchronously: no workgroup barrier inside — sixteen independent chains of loads per CU instead of two, which is
@@ -694,7 +730,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const bool full = uni(sh.tk_full) != 0;
                         const double thr_s = sh.thr_s;
                         const uint32_t thr_d = sh.thr_d;
-                        const uint32_t emask = uni(sh.emask);
+                        const uint32_t esel = uni(sh.esel);
                         const bool fall = uni(sh.fall) != 0;
                         while (sw < sw_end) {
                                 if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
@@ -833,6 +869,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 if (!more)
                                                         break;
                                         }
+                                        PROF_LAP(8);
                                         // ---- sweep, one word at a time: the predicate, then the candidate filter (planes_filter) on the level words
                                         uint32_t cand[2];
                                         bool later = false; // (the queue or the buffer is full: what is left of the candidates goes through the resume path)
@@ -870,18 +907,23 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                         seeded |= ((seedmask >> s) & 1u) ? a[s] : 0u;
                                                 uint32_t cw = m & ~seeded;
                                                 if (!fall) {
-                                                        uint32_t ew = 0;
+                                                        uint32_t ew = 0, lo[NS], hi[NS];
 #pragma unroll
-                                                        for (uint32_t s = 0; s < NS; ++s)
-                                                                ew |= ((emask >> s) & 1u) ? a[s] : 0u;
+                                                        for (uint32_t s = 0; s < NS; ++s) {
+                                                                const uint32_t e = (esel >> (2 * s)) & 3u; // (uniform)
+                                                                ew |= e == 0 ? a[s] : e == 1 ? b[s] : e == 2 ? c[s] : 0u;
+                                                                // the planes are nested, the level is the number of them a document is in: its two bits, word-wise
+                                                                lo[s] = top[s] ? a[s] ^ b[s] ^ c[s] : 0u; // (a slot without a scorer: level 0)
+                                                                hi[s] = top[s] ? b[s] : 0u;
+                                                        }
                                                         ew &= m & ~seeded;
                                                         cw = 0;
                                                         while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
                                                                 const uint32_t bit = ew ? (uint32_t)__builtin_ctz(ew) : 0u;
                                                                 uint32_t code = 0;
 #pragma unroll
-                                                                for (uint32_t s = 0; s < NS; ++s) // (the planes are nested: the level is the number of them the document is in)
-                                                                        code |= (top[s] ? ((a[s] >> bit) & 1u) + ((b[s] >> bit) & 1u) + ((c[s] >> bit) & 1u) : 0u) << (2 * s); // (a slot without a scorer: level 0)
+                                                                for (uint32_t s = 0; s < NS; ++s)
+                                                                        code |= (((lo[s] >> bit) & 1u) << (2 * s)) | (((hi[s] >> bit) & 1u) << (2 * s + 1));
                                                                 const uint32_t hit = (sh.ftab[code >> 5] >> (code & 31u)) & 1u;
                                                                 cw |= ew ? hit << bit : 0u;
                                                                 ew &= ew - 1u;
@@ -892,6 +934,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 // of a union has one or two: a step of their own, with the words fetched again, cost more than the sweep)
                                                 // (no call in here — the queue is worked off, and a full buffer waited out, in the resume path below: a call
                                                 //  among the sweep's live registers made the compiler spill them on the hot path)
+                                                PROF_LAP(9);
                                                 while (!later && __builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
                                                         if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
                                                                 later = true;
@@ -901,6 +944,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                                 candidate_step(which, a, b, c, cw);
                                                 }
                                                 cand[which] = cw;
+                                                PROF_LAP(10);
                                         }
                                         c0 = cand[0], c1 = cand[1];
                                         open = true;
@@ -926,6 +970,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         else
                                                 c0 = cw;
                                 }
+                                PROF_LAP(11);
                                 if (stuck)
                                         break;
                                 // the sub-window is done: its LDS planes are cleared for the next one
@@ -940,6 +985,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         }
                                 open = false;
                                 ++sw;
+                                PROF_LAP(12);
                         }
                         PROF_LAP(4);
                         // ---- the waves meet: prune if the buffer wants it, go on while any of them has sub-windows left
