@@ -2,6 +2,7 @@
 // AccumulatedScoreScheme top-K kernel that runs over them
 // Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
 #pragma once
+#include <type_traits>
 #include "k_fused.hpp"
 
 // Under Zipf a handful of terms carry most of a batch's postings (at the 10M-document configuration the 40 most frequent terms
@@ -170,6 +171,7 @@ struct PlanesShared {
         uint32_t flag[PLK_WG / 64];
         uint32_t wq[PLK_WG / 64][PLK_WQ][2]; // per wave: candidates waiting for exact frequencies {docID, the slots' levels (two bits each)}
         uint32_t bcast[4];
+        uint32_t zero[2 * PLK_SW_STRIDE]; // what a slot WITHOUT decoded list reads as its LDS planes (so that the sweep needs no per-slot selects)
         uint32_t sp_row0[FUS_MAX_SLOTS], sp_n[FUS_MAX_SLOTS], sp_base[FUS_MAX_SLOTS]; // decoded slots: first row, rows, first entry of the list in the scratch region
         DevFused fq;
 };
@@ -372,6 +374,27 @@ __device__ __noinline__ void planes_list_row(const uint8_t *__restrict__ index, 
                 out[i] = PLK_PAD;
 }
 
+// A uniform bit as an all-ones / all-zeros scalar mask, and (a & mask) | x in one vector instruction (the compiler turns the plain
+// expression into a scalar select plus two vector instructions).
+template <uint32_t POS> __device__ __forceinline__ uint32_t umask_at(const uint32_t bits) {
+        // (volatile: made where it is used — hoisted out of the window loop, the dozens of masks of a query spill to vector lanes and come back
+        //  through v_readlane, a vector instruction each)
+        uint32_t r;
+        asm volatile("s_bfe_i32 %0, %1, %2" : "=s"(r) : "s"(bits), "n"(POS | 0x10000u) : "scc");
+        return r;
+}
+template <uint32_t N, typename F> __device__ __forceinline__ void static_for(F &&f) { // f(integral_constant 0) ... f(integral_constant N - 1)
+        if constexpr (N > 0) {
+                static_for<N - 1>(f);
+                f(std::integral_constant<uint32_t, N - 1>{});
+        }
+}
+__device__ __forceinline__ uint32_t and_or(const uint32_t a, const uint32_t smask, const uint32_t x) {
+        uint32_t r;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(smask), "v"(x));
+        return r;
+}
+
 // NS: the slots the instantiation keeps in registers (six words each: the A, B and C words of the thread's two window words).
 // scratch: sparse_cap u32 per workgroup — the lists of the task's decoded slots.
 template <int CODEC, int NS>
@@ -381,13 +404,15 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
         const DevFused *__restrict__ fused, const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched, const uint32_t *__restrict__ sterms,
         const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket, uint32_t *__restrict__ counts, const uint32_t k,
         uint32_t *__restrict__ part_docs, double *__restrict__ part_scores, uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked,
-        const int sim, const uint32_t *__restrict__ planes, const uint32_t plw, uint32_t *__restrict__ scratch, const uint32_t sparse_cap) {
+        const int sim, const uint32_t *__restrict__ planes, const uint32_t plw, const uint32_t zrow, uint32_t *__restrict__ scratch, const uint32_t sparse_cap) {
         __shared__ PlanesShared sh;
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
         const uint32_t wave = uni(tid >> 6);
         uint32_t *const lists = scratch + (size_t)blockIdx.x * sparse_cap;
         for (uint32_t i = tid; i < (PLK_WG / 64) * PLK_MAX_SPARSE * 2 * PLK_SW_STRIDE; i += PLK_WG)
                 (&sh.pl[0][0][0])[i] = 0;
+        for (uint32_t i = tid; i < 2 * PLK_SW_STRIDE; i += PLK_WG)
+                sh.zero[i] = 0;
         PROF_DECL;
         PROF_START();
         for (;;) {
@@ -482,7 +507,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 uint32_t dense_mask = 0;
                 uint32_t lidx[NS], top[NS], prows[NS];
                 uint32_t list_rows = 0;
-                const uint32_t *const gsafe = planes ? planes : (const uint32_t *)lists; // (a batch without term planes: plw is 0, every such load reads the scratch region's first words)
                 {
                         uint32_t nl = 0;
 #pragma unroll
@@ -502,6 +526,10 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         }
                 }
                 const uint32_t sparse_mask = ((1u << nslots) - 1u) & ~dense_mask;
+                uint32_t leafm = 0; // the slots that have a scorer
+#pragma unroll
+                for (uint32_t s = 0; s < NS; ++s)
+                        leafm |= (top[s] ? 1u : 0u) << s;
                 PROF_LAP(0);
                 // ---- the decoded slots' lists: every row that can reach the task's range, one lane per row, 32 entries each
                 for (uint32_t v0 = 0; v0 < list_rows; v0 += PLK_WG) {
@@ -593,7 +621,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 for (uint32_t s = 0; s < NS; ++s) {
                         sp_n32[s] = ((sparse_mask >> s) & 1u) ? uni(sh.sp_n[s]) * 32u : 0u;
                         sp_off[s] = ((sparse_mask >> s) & 1u) ? uni(sh.sp_base[s]) : 0u;
-                        pA[s] = gsafe + (prows[s] != PL_NONE ? (size_t)prows[s] * PL_PLANES * plw : (size_t)0);
+                        pA[s] = planes + (size_t)(prows[s] != PL_NONE ? prows[s] : zrow) * PL_PLANES * plw; // (zrow: the batch's all-zero row — what a slot without term planes reads)
                 }
 #pragma unroll
                 for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g)
@@ -731,6 +759,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const double thr_s = sh.thr_s;
                         const uint32_t thr_d = sh.thr_d;
                         const uint32_t esel = uni(sh.esel);
+                        uint32_t es_a = 0, es_b = 0, es_c = 0; // the essential planes as bit sets over the slots
+#pragma unroll
+                        for (uint32_t s = 0; s < NS; ++s) {
+                                const uint32_t e = (esel >> (2 * s)) & 3u;
+                                es_a |= (e == 0 ? 1u : 0u) << s;
+                                es_b |= (e == 1 ? 1u : 0u) << s;
+                                es_c |= (e == 2 ? 1u : 0u) << s;
+                        }
                         const bool fall = uni(sh.fall) != 0;
                         while (sw < sw_end) {
                                 if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
@@ -753,26 +789,22 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         }
                                 };
                                 auto finish_words = [&](const uint32_t which, const uint32_t (&ga)[NS], const uint32_t (&gb)[NS], const uint32_t (&gc)[NS], uint32_t (&a)[NS],
-                                                        uint32_t (&b)[NS], uint32_t (&c)[NS]) { // ... the decoded slots' part (LDS), and the uniform selects
+                                                        uint32_t (&b)[NS], uint32_t (&c)[NS]) { // ... the decoded slots' part (LDS)
                                         const uint32_t wi = lane + which * 64u;
-                                        uint32_t la[NS], lb[NS];
+                                        // (no selects: a slot with term planes reads the zero LDS plane here, a decoded slot read the batch's zero row there)
 #pragma unroll
-                                        for (uint32_t s = 0; s < NS; ++s)
-                                                la[s] = lb[s] = 0;
+                                        for (uint32_t s = 0; s < NS; ++s) {
+                                                a[s] = ga[s];
+                                                b[s] = gb[s];
+                                                c[s] = gc[s];
+                                        }
                                         if (rows_mask) { // (uniform: a sub-window no decoded list reaches reads no LDS)
 #pragma unroll
                                                 for (uint32_t s = 0; s < NS; ++s) {
-                                                        const uint32_t *lp = &sh.pl[wave][lidx[s]][0];
-                                                        la[s] = lp[wi];
-                                                        lb[s] = lp[PLK_SW_STRIDE + wi];
+                                                        const uint32_t *lp = ((sparse_mask >> s) & 1u) ? &sh.pl[wave][lidx[s]][0] : &sh.zero[0];
+                                                        a[s] |= lp[wi];
+                                                        b[s] |= lp[PLK_SW_STRIDE + wi];
                                                 }
-                                        }
-#pragma unroll
-                                        for (uint32_t s = 0; s < NS; ++s) {
-                                                const bool dn = prows[s] != PL_NONE, sp = (rows_mask >> s) & 1u, lf = top[s] != 0; // (uniform)
-                                                a[s] = dn ? ga[s] : sp ? la[s] : 0u;
-                                                b[s] = !lf ? 0u : dn ? gb[s] : sp ? lb[s] : 0u;
-                                                c[s] = (lf && dn) ? gc[s] : 0u;
                                         }
                                 };
                                 auto level_words = [&](const uint32_t which, uint32_t (&a)[NS], uint32_t (&b)[NS], uint32_t (&c)[NS]) {
@@ -880,45 +912,52 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                         finish_words(1, g1a, g1b, g1c, a, b, c);
                                                 else
                                                         finish_words(0, g0a, g0b, g0c, a, b, c);
+                                                // (the slots' roles are uniform bit sets: a role's word is and_or'ed together under scalar masks — one vector
+                                                //  instruction per slot and role, where a select costs two and a scalar one)
                                                 uint32_t m = 0xffffffffu;
 #pragma unroll
                                                 for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g) {
                                                         if (g >= nreq)
                                                                 break;
                                                         uint32_t x = 0;
-#pragma unroll
-                                                        for (uint32_t s = 0; s < NS; ++s)
-                                                                x |= ((gsl[g] >> s) & 1u) ? a[s] : 0u;
+                                                        static_for<NS>([&](auto S) { x = and_or(a[S], umask_at<S>(gsl[g]), x); });
                                                         m &= x;
                                                 }
-                                                uint32_t nx = 0;
-#pragma unroll
-                                                for (uint32_t s = 0; s < NS; ++s)
-                                                        nx |= ((negs >> s) & 1u) ? a[s] : 0u;
-                                                m &= ~nx;
+                                                if (negs) {
+                                                        uint32_t nx = 0;
+                                                        static_for<NS>([&](auto S) { nx = and_or(a[S], umask_at<S>(negs), nx); });
+                                                        m &= ~nx;
+                                                }
                                                 if (masked) // masked_documents_registry::test (docidupdates.h:90-119)
                                                         m &= ~masked[(w0 >> 5) + lane + which * 64u];
                                                 my_matches += (uint32_t)__popc(m);
-                                                // the candidate filter: the documents that hold an essential slot, word-wise; each of them then with its level
+                                                // the candidate filter: the documents in an essential plane, word-wise; each of them then with its level
                                                 // vector in the table (one per lane and step)
                                                 uint32_t seeded = 0; // (documents the seed pass has scored: never candidates here)
-#pragma unroll
-                                                for (uint32_t s = 0; s < NS; ++s)
-                                                        seeded |= ((seedmask >> s) & 1u) ? a[s] : 0u;
+                                                if (seedmask) {
+                                                        static_for<NS>([&](auto S) { seeded = and_or(a[S], umask_at<S>(seedmask), seeded); });
+                                                }
                                                 uint32_t cw = m & ~seeded;
                                                 if (!fall) {
-                                                        uint32_t ew = 0, lo[NS], hi[NS];
-#pragma unroll
-                                                        for (uint32_t s = 0; s < NS; ++s) {
-                                                                const uint32_t e = (esel >> (2 * s)) & 3u; // (uniform)
-                                                                ew |= e == 0 ? a[s] : e == 1 ? b[s] : e == 2 ? c[s] : 0u;
-                                                                // the planes are nested, the level is the number of them a document is in: its two bits, word-wise
-                                                                lo[s] = top[s] ? a[s] ^ b[s] ^ c[s] : 0u; // (a slot without a scorer: level 0)
-                                                                hi[s] = top[s] ? b[s] : 0u;
+                                                        uint32_t ew = 0;
+                                                        static_for<NS>([&](auto S) { ew = and_or(a[S], umask_at<S>(es_a), ew); });
+                                                        if (es_b) {
+                                                                static_for<NS>([&](auto S) { ew = and_or(b[S], umask_at<S>(es_b), ew); });
+                                                        }
+                                                        if (es_c) {
+                                                                static_for<NS>([&](auto S) { ew = and_or(c[S], umask_at<S>(es_c), ew); });
                                                         }
                                                         ew &= m & ~seeded;
                                                         cw = 0;
-                                                        while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
+                                                        if (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
+                                                        // the planes are nested, the level is the number of them a document is in: its two bits, word-wise
+                                                        uint32_t lo[NS], hi[NS];
+#pragma unroll
+                                                        for (uint32_t s = 0; s < NS; ++s) {
+                                                                lo[s] = ((leafm >> s) & 1u) ? a[s] ^ b[s] ^ c[s] : 0u; // (a slot without a scorer: level 0)
+                                                                hi[s] = ((leafm >> s) & 1u) ? b[s] : 0u;
+                                                        }
+                                                        do {
                                                                 const uint32_t bit = ew ? (uint32_t)__builtin_ctz(ew) : 0u;
                                                                 uint32_t code = 0;
 #pragma unroll
@@ -928,6 +967,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                                 cw |= ew ? hit << bit : 0u;
                                                                 ew &= ew - 1u;
                                                                 PROF_COUNT(20, lane == 0 ? 1 : 0);
+                                                        } while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull);
                                                         }
                                                 }
                                                 // the word's candidates are worked off right here, while its level words are in registers (a sub-window

@@ -1844,17 +1844,22 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                         qplane[u.qpos] = it->second;
                         for (const auto &u : fuses)
                                 b->fused[u.fidx].plane[u.slot] = row_of[u.term];
-                        b->plw = ((ix->max_doc >> 17) + 2u) * (SPAN_BITS / 32u); // whole bitmap windows (k_and_dense reads SPAN_WORDS at a time) + a spare one
                         int rcp;
                         if ((rcp = dev_upload(&b->d_qplane, qplane)) || (rcp = dev_upload(&b->d_plane_terms, b->plane_terms)))
                                 return rcp;
-                        HIP_TRY(hipMalloc((void **)&b->d_planes, (size_t)b->plane_terms.size() * PL_PLANES * b->plw * 4 + 64));
+                }
+                if (!chosen.empty() || b->n_planes + b->n_planes8) {
+                        // the rows k_term_planes fills, plus an all-zero row: what a k_planes slot WITHOUT term planes reads (so its sweep needs no select)
+                        b->plw = ((ix->max_doc >> 17) + 2u) * (SPAN_BITS / 32u); // whole bitmap windows (k_and_dense reads SPAN_WORDS at a time) + a spare one
+                        const size_t row = (size_t)PL_PLANES * b->plw * 4;
+                        HIP_TRY(hipMalloc((void **)&b->d_planes, (b->plane_terms.size() + 1) * row + 64));
+                        HIP_TRY(hipMemset((uint8_t *)b->d_planes + b->plane_terms.size() * row, 0, row + 64));
                 }
         }
         if (b->n_planes + b->n_planes8) {
                 b->sparse_cap = (b->sparse_cap + 63u) & ~63u;
                 const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
-                HIP_TRY(hipMalloc((void **)&b->d_sparse, (wgs * b->sparse_cap + 2 * PL_WORDS) * 4)); // (+ a window's worth of words: the dummy loads of a batch without term planes)
+                HIP_TRY(hipMalloc((void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
         }
         b->out_capacity = off;
         int rc;
@@ -2025,7 +2030,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
 #define TRI_PLANES_ARGS                                                                                                                                      \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, \
                 b->d_sterms, b->d_sweights, np, b->d_ticket + 24 + 2 * wide, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked,     \
-                b->similarity, (const uint32_t *)b->d_planes, b->plw, b->d_sparse, b->sparse_cap
+                b->similarity, (const uint32_t *)b->d_planes, b->plw, (uint32_t)b->plane_terms.size(), b->d_sparse, b->sparse_cap
                         if (b->ix->codec == TRI_CODEC_LUCENE) {
                                 if (wide)
                                         hipLaunchKernelGGL((k_planes<CODEC_LUCENE, FUS_MAX_SLOTS>), grid, dim3(PLK_WG), 0, dev->stream, TRI_PLANES_ARGS);
