@@ -147,6 +147,8 @@ void *tri_dev_stream(tri_dev *);
  *   "overlap_dense_wgs" / "overlap_cand_wgs"  both non-zero: the two matching kernels run side by side with that many workgroups per CU
  *   "planes"              term planes, a bit set (default 7): 1 the candidate-tile kernel probes them, 2 the bitmap-window kernel ORs them into its
  *                         windows, 4 AccumulatedScore top-K CNF queries run over bit planes (k_planes); 0: every query decodes every list it names
+ *   "planes_split"        a query that runs as bit planes (k_planes) is cut into this many docID ranges, one task each (default 2; 0: cut by postings); the
+ *                         ranges share the query's threshold, results do not depend on the cut
  *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 64) and the batch's uses repay one
  *                         decode of its list
  *   "account_needed_bytes" 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query; default 0)

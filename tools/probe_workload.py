@@ -37,6 +37,9 @@ if os.environ.get("EACH"):  # EACH=n: the first n queries one batch each — the
         i1 = b1.info()
         rows.append((i1["last_run_ms"], [int(x) for x in p], int(i1["matches"])))
         b1.close()
+    if os.environ.get("EACH_OUT"):  # every row, for fitting the planner's cost model offline
+        import json
+        json.dump([{"ms": r[0], "terms": [x & 0x0FFFFFFF for x in r[1] if x >> 28 == E.OP_TERM], "matches": r[2], "df": [int(seg.terms[x & 0x0FFFFFFF][0]) if hasattr(seg, "terms") else 0 for x in r[1] if x >> 28 == E.OP_TERM]} for r in rows], open(os.environ["EACH_OUT"], "w"))
     rows.sort(key=lambda r: -r[0])
     ms = [r[0] for r in rows]
     print(f"  per query: mean {sum(ms) / len(ms):.3f} ms  max {ms[0]:.3f}  median {ms[len(ms) // 2]:.3f}  p90 {ms[len(ms) // 10]:.3f}")
@@ -44,7 +47,7 @@ if os.environ.get("EACH"):  # EACH=n: the first n queries one batch each — the
         print(f"    {r[0]:.3f} ms  matches {r[2]:>9}  terms {[x & 0x0FFFFFFF for x in r[1] if x >> 28 == E.OP_TERM]}")
 b = T.Batch(ix, progs, flags, topk=topk)
 best = 1e9
-for _ in range(3):
+for _ in range(int(os.environ.get('RUNS', 3))):
     import time as _t
     _t0 = _t.perf_counter(); b.run(); b.sync(); wall = (_t.perf_counter() - _t0) * 1e3
     best = min(best, wall if os.environ.get("RICH") else b.info()["last_run_ms"])  # rich mode: sync runs the WRITE pass too
@@ -53,7 +56,11 @@ L = E.hip_lib()
 if hasattr(L, "tri_debug_prof"):
     buf = (C.c_uint64 * 32)(); L.tri_debug_prof(buf); v = list(buf)[:16]; tot = sum(v) or 1
     print("  prof " + " ".join(f"p{i}={x / tot * 100:.1f}%" for i, x in enumerate(v) if x), f"(total {tot:.3e} cycles)")
-    c = list(buf)[16:32]
+    c = list(buf)[16:28]
+    w = list(buf)[28:32]
+    if w[0]:  # k_planes workgroups: when they ended relative to the first one's start (100 MHz clock), last run(s)
+        t0 = (~w[1]) & (2**64 - 1)
+        print(f"  workgroups {w[0]}: mean end {(w[2] / w[0] - t0) / 100:.1f} us, last end {(w[3] - t0) / 100:.1f} us after the first start")
     if any(c):  # event counters (k_planes: 16 candidate steps, 17 frequency lookups, 18 prunes, 19 sub-windows, 20 table-lookup steps, 23 sweeps cut short by a full queue / buffer), over the 3 runs
         print("  counters " + " ".join(f"c{16 + i}={x}" for i, x in enumerate(c) if x))
 print("  " + " ".join(f"{k}={inf[k]:.3f}" for k in ("term_planes_ms", "dense_ms", "cand_ms", "fused_ms", "planes_ms", "phrase_ms", "rest_ms")), f"fused_q={inf['fused_queries']} planes_q={inf['planes_queries']} cand_q={inf['cand_queries']} plane_terms={inf['plane_terms']}")

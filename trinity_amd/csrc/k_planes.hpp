@@ -185,8 +185,21 @@ struct ListPost {
         __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) { out[i++] = rel << 1 | ((f & 0xffffu) != 1u ? 1u : 0u); }
 };
 
-// Keep the best k of the n (<= PLK_CAP = PLK_WG) buffered candidates, best first (rank by counting: the order is strict).
-__device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t k) {
+// A score as an unsigned key of the same order (0: none), for the per-query threshold the tasks of a query share
+__device__ __forceinline__ unsigned long long score_key(const double sc) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(sc);
+        return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_score(const unsigned long long key) {
+        return __longlong_as_double((long long)((key >> 63) ? (key & 0x7fffffffffffffffull) : ~key));
+}
+
+// Keep the best k of the n (<= PLK_CAP = PLK_WG) buffered candidates, best first (rank by counting: the order is strict), and move the
+// threshold.  A query cut into several docID ranges (tasks) shares one threshold through *gthr: a task's k-th best score says that k
+// documents reach it, so no task needs documents below it — the later and the slower ranges filter with the best k-th score any range
+// has seen, not with their own, and cutting a query into ranges costs next to no extra candidates.  (The threshold only ever prunes:
+// results do not depend on when a task sees another's.)
+__device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t k, unsigned long long *__restrict__ gthr) {
         const uint32_t tid = threadIdx.x;
         double es = 0;
         uint32_t ed = 0, rk = 0xffffffffu;
@@ -205,12 +218,22 @@ __device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t 
         }
         __syncthreads();
         const uint32_t m = n < k ? n : k;
+        double ts = 0.0;
+        uint32_t td = 0;
+        if (m == k) {
+                ts = sh.tk_s[k - 1];
+                td = sh.tk_d[k - 1];
+                if (tid == 0)
+                        atomicMax(gthr, score_key(ts));
+        }
+        const unsigned long long g = __atomic_load_n(gthr, __ATOMIC_RELAXED); // (every lane, the same address)
+        const bool other = g != 0ull && (m < k || ts < key_score(g));     // another range's k-th best is the higher one: ties pass (no docID to break them with)
         // uniform stores by every lane
         sh.tk_n = m;
-        if (m == k) {
+        if (m == k || other) {
                 sh.tk_full = 1;
-                sh.thr_s = sh.tk_s[k - 1];
-                sh.thr_d = sh.tk_d[k - 1];
+                sh.thr_s = other ? key_score(g) : ts;
+                sh.thr_d = other ? 0xffffffffu : td;
         }
         __syncthreads();
 }
@@ -404,7 +427,8 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
         const DevFused *__restrict__ fused, const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched, const uint32_t *__restrict__ sterms,
         const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket, uint32_t *__restrict__ counts, const uint32_t k,
         uint32_t *__restrict__ part_docs, double *__restrict__ part_scores, uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked,
-        const int sim, const uint32_t *__restrict__ planes, const uint32_t plw, const uint32_t zrow, uint32_t *__restrict__ scratch, const uint32_t sparse_cap) {
+        const int sim, const uint32_t *__restrict__ planes, const uint32_t plw, const uint32_t zrow, uint32_t *__restrict__ scratch, const uint32_t sparse_cap,
+        unsigned long long *__restrict__ qthr) {
         __shared__ PlanesShared sh;
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
         const uint32_t wave = uni(tid >> 6);
@@ -415,6 +439,9 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 sh.zero[i] = 0;
         PROF_DECL;
         PROF_START();
+#ifdef TRI_PROF
+        const unsigned long long wg_t0 = wall_clock64(); // (100 MHz)
+#endif
         for (;;) {
                 if (wave == 0) { // uniform draw (see k_and)
                         const uint32_t old = atomicAdd(ticket, 1u);
@@ -428,6 +455,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 const uint32_t tix = sched[ticket_no];
                 const DevTask task = tasks[tix];
                 const DevQuery q = plan[task.slot];
+                unsigned long long *const gthr = qthr + task.slot; // the threshold the query's tasks share
                 {
                         const uint32_t wi = min(tid, (uint32_t)(sizeof(DevFused) / 4 - 1)); // (every lane stores: no divergent branch around the barriers)
                         ((uint32_t *)&sh.fq)[wi] = ((const uint32_t *)(fused + q.fused_idx))[wi];
@@ -464,7 +492,13 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const uint64_t lm = __builtin_amdgcn_ballot_w64(leaf && lane < nslots);
                         sh.leaf = (uint32_t)lm; // (same value from every lane)
                         sh.tk_n = 0;
-                        sh.tk_full = 0;
+                        {
+                                // (another range of the query may have a threshold already: this one filters with it from its first window on)
+                                const unsigned long long g = __atomic_load_n(gthr, __ATOMIC_RELAXED);
+                                sh.tk_full = g != 0ull ? 1u : 0u;
+                                sh.thr_s = g != 0ull ? key_score(g) : 0.0;
+                                sh.thr_d = 0xffffffffu;
+                        }
                         sh.matches = 0;
                         sh.fall = 1; // no threshold yet: every match is a candidate
                         sh.esel = 0;
@@ -741,15 +775,13 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
                                         __syncthreads(); // (every lane has read tk_n)
                                         if (n >= PLK_PRUNE_AT)
-                                                planes_prune(sh, n, k);
+                                                planes_prune(sh, n, k, gthr);
                                         if (!uni(anyp))
                                                 break;
                                 }
                         }
-                        if (seedmask) {
-                                planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k);
-                                planes_filter(sh, nslots);
-                        }
+                        planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k, gthr); // (no seeds: still the query's shared threshold, if there is one)
+                        planes_filter(sh, nslots);
                 }
                 uint32_t c0 = 0, c1 = 0, rows_mask = 0; // the current sub-window's candidates (per lane) and the decoded slots that put something into its LDS planes
                 bool open = false;                      // the current sub-window has been swept (its candidates are being worked off)
@@ -1039,7 +1071,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
                         __syncthreads(); // (every lane has read the flags and tk_n)
                         if (n >= PLK_PRUNE_AT) {
-                                planes_prune(sh, n, k);
+                                planes_prune(sh, n, k, gthr);
                                 planes_filter(sh, nslots);
                                 PROF_COUNT(18, tid == 0 ? 1 : 0);
                         }
@@ -1061,13 +1093,13 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
                         __syncthreads(); // (every lane has read the flags and tk_n)
                         if (n >= PLK_PRUNE_AT)
-                                planes_prune(sh, n, k);
+                                planes_prune(sh, n, k, gthr);
                         if (!anyp)
                                 break;
                 }
                 // ---- the task's result: its best k (ranked) and its match count
                 __syncthreads();
-                planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k);
+                planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k, gthr);
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1)
                         my_matches += __shfl_xor(my_matches, d, 64);
@@ -1086,4 +1118,13 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 PROF_LAP(6);
         }
         PROF_FLUSH();
+#ifdef TRI_PROF // when the workgroups ended: g_prof[28] how many, [29] ~(earliest start), [30] sum of the end times, [31] the latest end
+        if (tid == 0) {
+                const unsigned long long t1 = wall_clock64();
+                atomicAdd(&g_prof[28], 1ull);
+                atomicMax(&g_prof[29], ~wg_t0);
+                atomicAdd(&g_prof[30], t1);
+                atomicMax(&g_prof[31], t1);
+        }
+#endif
 }

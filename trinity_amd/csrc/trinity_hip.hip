@@ -68,6 +68,7 @@ struct tri_options {
         uint64_t fused_halfwords = 1;             // 16-bit window words for queries of <= 5 distinct terms (windows twice as long); 0: always 32-bit
         uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
         uint64_t planes = 7;     // term planes (k_planes.hpp), a bit set: 1 k_and probes them, 2 k_and_dense ORs them in, 4 top-K CNF queries run in k_planes; 0: off
+        uint64_t planes_split = 2; // a k_planes query is cut into this many docID ranges (tasks) that share its threshold; 0: by postings like the other one-pass tasks.  cfg3's unions: 0 10.9 ms, 2 8.0, 3 8.5, 4 9.2 (a task has fixed costs)
         uint64_t plane_div = 64; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list)
 };
 
@@ -145,6 +146,7 @@ struct tri_batch {
         std::vector<uint32_t> plane_terms; // row -> term
         uint32_t *d_plane_terms = nullptr, *d_planes = nullptr, *d_qplane = nullptr; // d_qplane: parallel to d_qterms, the term's row or PL_NONE
         uint32_t plw = 0;                  // words of one plane
+        unsigned long long *d_qthr = nullptr; // k_planes: per query, the best k-th score any of its tasks has seen (cleared at every run)
         uint32_t *d_sparse = nullptr;      // k_planes: per resident workgroup, the lists of a task's decoded (non-plane) slots
         uint32_t sparse_cap = 0;           // ... entries per workgroup
         uint64_t term_bytes_planes = 0, plane_decoded_bytes = 0;
@@ -204,6 +206,7 @@ struct tri_batch {
                         if (e)
                                 hipEventDestroy(e);
                 hipFree(d_sparse);
+                hipFree(d_qthr);
                 hipFree(d_plane_terms);
                 hipFree(d_planes);
                 hipFree(d_qplane);
@@ -307,7 +310,8 @@ namespace {
                              {"overlap_dense_wgs", &tri_options::overlap_dense_wgs},
                              {"overlap_cand_wgs", &tri_options::overlap_cand_wgs},
                              {"planes", &tri_options::planes},
-                             {"plane_div", &tri_options::plane_div}};
+                             {"plane_div", &tri_options::plane_div},
+                             {"planes_split", &tri_options::planes_split}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -1656,7 +1660,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         const uint32_t fw = pk ? PL_W : FUS_W << t.fz.hw; // documents per window: plane windows, or this query's word width
                         const uint32_t nwin = last_doc / fw + 1;
                         const uint64_t per_win = std::max<uint64_t>(1, slotdf / (ix->info.docs_cnt / fw + 1));
-                        const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
+                        // (k_planes' cost is the sweep of the range plus its candidates, not the postings: equal ranges, a few per query)
+                        const uint32_t win_per_task = pk && dev->opt.planes_split ? (uint32_t)((nwin + dev->opt.planes_split - 1) / dev->opt.planes_split)
+                                                                                  : (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
                         const bool emit = t.fz.mode & FUS_MODE_EMIT; // ... except by a general tree in DocumentsOnly mode: a private region per task,
                                                                      // bounded like TASK_DENSE's by the slots' blocks that reach the task's windows
                         uint32_t ord = 0;
@@ -1669,8 +1675,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                                 const uint32_t *lb = &ix->h_blk_last[tk.first_block];
                                                 b1 += (uint64_t)(std::lower_bound(lb, lb + tk.nblocks, wb * fw) - lb);
                                         }
+                                uint64_t entries = 0;
                                 if (pk) { // the rows of the decoded slots that can reach the task's docID range: 32 list entries each (k_planes)
-                                        uint64_t entries = 0;
                                         for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
                                                 if (plane_ok(t.fz.term[sidx]))
                                                         continue;
@@ -1685,6 +1691,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                                 return fail(TRI_ERR_UNSUPPORTED, "query %u: a task's decoded lists exceed 2^31 entries", t.q.qid);
                                         b->sparse_cap = std::max(b->sparse_cap, (uint32_t)entries);
                                 }
+                                // (largest first, by postings: for k_planes a poor estimate — its cost is the sweep plus the candidates — but ordering by the
+                                //  decoded entries instead measured worse: cfg3's unions 10.6 ms against 9.2)
                                 order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
                                 b->tasks.push_back({slot, wb, we, pk ? (t.fz.nslots <= PLK_NS_SMALL ? TASK_PLANES : TASK_PLANES8) : t.fz.mode ? TASK_FUSED_GEN : t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off + (emit ? b1 * 32 + 32ull * ord * t.fz.nslots : 0)});
                         }
@@ -1857,6 +1865,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 }
         }
         if (b->n_planes + b->n_planes8) {
+                HIP_TRY(hipMalloc((void **)&b->d_qthr, (b->plan.size() + 1) * 8));
                 b->sparse_cap = (b->sparse_cap + 63u) & ~63u;
                 const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
                 HIP_TRY(hipMalloc((void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
@@ -2018,6 +2027,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
+                if (b->d_qthr)
+                        HIP_TRY(hipMemsetAsync(b->d_qthr, 0, (b->plan.size() + 1) * 8, dev->stream));
                 for (int wide = 0; wide < 2; ++wide) {
                         // AccumulatedScore top-K of the CNF queries over bit planes: the head terms' planes from k_term_planes, the other lists
                         // decoded per window into LDS planes; union / conjunction predicates and the candidate filter 32 documents per word
@@ -2030,7 +2041,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
 #define TRI_PLANES_ARGS                                                                                                                                      \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, \
                 b->d_sterms, b->d_sweights, np, b->d_ticket + 24 + 2 * wide, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked,     \
-                b->similarity, (const uint32_t *)b->d_planes, b->plw, (uint32_t)b->plane_terms.size(), b->d_sparse, b->sparse_cap
+                b->similarity, (const uint32_t *)b->d_planes, b->plw, (uint32_t)b->plane_terms.size(), b->d_sparse, b->sparse_cap, b->d_qthr
                         if (b->ix->codec == TRI_CODEC_LUCENE) {
                                 if (wide)
                                         hipLaunchKernelGGL((k_planes<CODEC_LUCENE, FUS_MAX_SLOTS>), grid, dim3(PLK_WG), 0, dev->stream, TRI_PLANES_ARGS);
