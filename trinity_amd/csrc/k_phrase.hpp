@@ -286,6 +286,24 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
         }
 }
 
+// The first block of term t whose last docID is >= key (t.nblocks: none), found by the whole wave: the cell index brackets it to at
+// most a cell's worth of blocks, then 64 probes a round.
+__device__ __forceinline__ uint32_t phrase_first_block(const uint32_t *__restrict__ bl, const uint32_t *__restrict__ win, const DevTerm &t, const uint32_t key) {
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t lo = 0, hi = t.nblocks;
+        if (t.win_off != 0xffffffffu) {
+                lo = uni(win[t.win_off + (key >> CELL_LOG2)]);
+                hi = min(uni(win[t.win_off + (key >> CELL_LOG2) + 1]) + 1u, t.nblocks);
+        }
+        for (;;) { // (uniform)
+                const bool below = lo + lane < hi && bl[lo + lane] < key;
+                const uint32_t cnt = (uint32_t)__popcll(__ballot(below));
+                lo += cnt;
+                if (cnt != 64u)
+                        return lo;
+        }
+}
+
 template <int CODEC>
 __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ index, const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits,
                                                    const uint32_t *__restrict__ hdir, const uint32_t *__restrict__ blk_last,
@@ -361,17 +379,15 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                         sh.row[k] = rows++;
                                         const DevTerm t = terms[tk];
                                         const uint32_t *bl = blk_last + t.first_block;
-                                        const uint32_t b0 = wg_lower_bound<AND_WG>(sh.scan, bl, t.nblocks, cmin);
-                                        uint32_t b1 = b0;
-                                        if (b0 < t.nblocks) {
-                                                b1 = b0 + wg_lower_bound<AND_WG>(sh.scan, bl + b0, t.nblocks - b0, cmax);
-                                                if (b1 >= t.nblocks)
-                                                        b1 = t.nblocks - 1;
-                                        }
-                                        __syncthreads();
+                                        // the blocks of the tile's docID range: every wave brackets both ends through the cell index on its own
+                                        // (one round of 64 probes each; a list too short for a cell index: two rounds) — no workgroup barrier
+                                        const uint32_t b0 = phrase_first_block(bl, win, t, cmin);
+                                        const uint32_t b1 = b0 < t.nblocks ? min(phrase_first_block(bl, win, t, cmax), t.nblocks - 1) : b0;
+                                        PROF_LAP(8);
                                         if (b0 < t.nblocks && b1 - b0 + 1 <= 2 * C) {
                                                 for (uint32_t b = b0 + tid; b <= b1; b += AND_WG)
                                                         phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, t, b, C, slot0);
+                                                PROF_LAP(9);
                                         } else {
                                                 // few candidates scattered over a long list: every candidate brackets its block with the two cell-index
                                                 // entries of its docID cell (short lists: a bisection of the directory), and the first candidate of a
@@ -394,6 +410,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                         if (j == 0 || sh.cdoc[j - 1] <= prevdoc)
                                                                 phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, t, lo, C, slot0);
                                                 }
+                                                PROF_LAP(10);
                                         }
                                         __syncthreads();
                                 }
