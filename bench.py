@@ -295,6 +295,8 @@ def main():
                 "traffic_source": traffic_src,
                 "physical_frac": physical(dom),  # PMC bytes / kernel time / peak: what actually crossed the fabric (algorithmic > physical where lists are
                                                  # skipped, shared between the batch's queries through the term planes, or served by the Infinity Cache)
+                # ... and with the term planes' build charged to this kernel alone (it reads them instead of decoding the shared head terms per query)
+                "frac_incl_term_planes": gbs(kalg[dom], kms[dom] + acc.get("term_planes_ms", 0.0) / steps) / HBM_PEAK_GBS,
                 "kernel": dom,
                 "kernel_ms": kms[dom],
                 "algorithmic_bytes_per_launch": kalg[dom],

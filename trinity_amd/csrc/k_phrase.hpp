@@ -129,6 +129,7 @@ struct PhraseShared {
         double ps[PHRASE_TILE];         // scored mode: sum of the phrase scores of the candidate
         uint8_t alive[PHRASE_TILE];
         uint32_t row[MAX_PHRASE_TERMS]; // phrase position -> row (a term repeated in the phrase shares the row of its first occurrence)
+        uint32_t rpad[MAX_PHRASE_TERMS]; // row -> its term's DevTerm::pad (LUCENE: the term's row in hdir[])
         uint32_t scan[8];
         uint32_t bcast[4];
 };
@@ -376,8 +377,9 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                 continue;
                                         }
                                         const uint32_t slot0 = rows * tile;
-                                        sh.row[k] = rows++;
                                         const DevTerm t = terms[tk];
+                                        sh.rpad[rows] = t.pad; // (uniform stores)
+                                        sh.row[k] = rows++;
                                         const uint32_t *bl = blk_last + t.first_block;
                                         // the blocks of the tile's docID range: every wave brackets both ends through the cell index on its own
                                         // (one round of 64 probes each; a list too short for a cell index: two rounds) — no workgroup barrier
@@ -429,32 +431,17 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                 p0 = (p0 + s0.next()) & 0xffffu;
                                                 if (!p0)
                                                         continue;
+                                                // dws->test(term_k, p0 + k): term k has a hit there and no term materialised AFTER it overwrote the slot
+                                                // (last writer wins; only first occurrences materialise, in phrase order — and rows are numbered in that
+                                                // order, so the later writers are exactly the rows above term k's)
                                                 bool all = true;
                                                 for (uint32_t k = 1; k < ph.nterms && all; ++k) {
                                                         const uint32_t qpos = p0 + k;
-                                                        const uint32_t tk = pterms[ph.term_base + k];
                                                         const uint32_t rk = sh.row[k];
-                                                        // dws->test(term_k, qpos): term k has a hit there …
-                                                        all = phrase_has_pos<CODEC>(ctx, terms[tk].pad, sh.hits_off[rk * tile + j], sh.freq[rk * tile + j], qpos);
-                                                        // … and no term materialised after it overwrote the slot (last writer wins; only first
-                                                        // occurrences materialise, in phrase order)
-                                                        uint32_t firstk = k;
-                                                        for (uint32_t m = 0; m < k; ++m)
-                                                                if (pterms[ph.term_base + m] == tk) {
-                                                                        firstk = m;
-                                                                        break;
-                                                                }
-                                                        for (uint32_t m = firstk + 1; m < ph.nterms && all; ++m) {
-                                                                const uint32_t tm = pterms[ph.term_base + m];
-                                                                if (tm == tk)
-                                                                        continue;
-                                                                bool seen = false;
-                                                                for (uint32_t z = 0; z < m; ++z)
-                                                                        seen |= pterms[ph.term_base + z] == tm;
-                                                                const uint32_t rm = sh.row[m];
-                                                                if (!seen && phrase_has_pos<CODEC>(ctx, terms[tm].pad, sh.hits_off[rm * tile + j], sh.freq[rm * tile + j], qpos))
+                                                        all = phrase_has_pos<CODEC>(ctx, sh.rpad[rk], sh.hits_off[rk * tile + j], sh.freq[rk * tile + j], qpos);
+                                                        for (uint32_t rm = rk + 1; rm < rows && all; ++rm)
+                                                                if (phrase_has_pos<CODEC>(ctx, sh.rpad[rm], sh.hits_off[rm * tile + j], sh.freq[rm * tile + j], qpos))
                                                                         all = false;
-                                                        }
                                                 }
                                                 if (all)
                                                         ++cnt;
