@@ -173,6 +173,19 @@ int main(int argc, char **argv) {
                         show("masked_scored", c);
                         src.set_masked_documents({});
                 }
+                { // the same through exec_query's own signature (exec.h:50): a registry over the lists of two newer sources
+                        updated_documents newer[2];
+                        for (docid_t d = 3; d <= fs.docsCnt; d += 3)
+                                newer[d & 1].ids.push_back(d);
+                        auto reg = masked_documents_registry::make(newer, 2);
+                        Collect c;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, reg.get(), &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        show("masked_registry", c);
+                        Collect c2;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, static_cast<masked_documents_registry *>(nullptr), &c2, nullptr,
+                                   unsigned(ExecFlags::DocumentsOnly));
+                        show("no_registry", c2);
+                }
                 { // unknown term => no documents
                         Collect c;
                         exec_query(src.conjunction({src.term("t0"), src.term("nosuchterm")}), &src, &c, nullptr, unsigned(ExecFlags::DocumentsOnly));

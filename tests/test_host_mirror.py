@@ -73,6 +73,8 @@ def test_mirror_results_match_oracle(T, tmp_path):
     expect("tfidf_scored", "t0 t1 (t2 OR t3)", 2, sim=O.SIM_TFIDF)
     expect("trivial_scored", "t0 t1", 2, sim=O.SIM_TRIVIAL)
     expect("masked_scored", "t0 t1", 2, keep=lambda d: (d % 3) != 0)
+    expect("masked_registry", "t0 t1", 2, keep=lambda d: (d % 3) != 0)  # exec_query(query, source, masked_documents_registry *, ...): exec.h:50
+    expect("no_registry", "t0 t1", 1)
     # default mode: the same digest from the oracle's canonical stream
     docs, flat, tt, ht = ora.exec_rich(O.parse_query("t0 t1 (t2 OR t3 OR t4)"))
     r = lines["rich"]

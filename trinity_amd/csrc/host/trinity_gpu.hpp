@@ -680,8 +680,45 @@ namespace trinity_amd {
                 }
         }
 
+        // docidupdates.h:15-119.  The documents of a source that newer sources of the collection have updated or deleted.  The reference packs
+        // each source's list into banks with a skiplist (updated_documents, pack_updates / unpack_updates) and hands exec_query a
+        // masked_documents_registry over the lists of all the newer sources — a bloom filter in front of one scanner per list, tested
+        // document by document right before consider() (exec.cpp:914-975).  Its observable behaviour is set membership, and that is what
+        // is mirrored: the registry is the union of its lists, it goes to the device as a docID bitmap (tri_index_set_masked) and the
+        // matching kernels test it where exec_query does.
+        struct updated_documents final {
+                std::vector<docid_t> ids; // ascending (what pack_updates sorts them into)
+        };
+        struct masked_documents_registry final {
+                std::vector<docid_t> ids; // ascending, distinct
+                // docidupdates.h:121-142 masked_documents_registry::make(const updated_documents *, n)
+                static std::unique_ptr<masked_documents_registry> make(const updated_documents *ud, const std::size_t n) {
+                        auto r = std::make_unique<masked_documents_registry>();
+                        for (std::size_t i = 0; i < n; ++i)
+                                r->ids.insert(r->ids.end(), ud[i].ids.begin(), ud[i].ids.end());
+                        std::sort(r->ids.begin(), r->ids.end());
+                        r->ids.erase(std::unique(r->ids.begin(), r->ids.end()), r->ids.end());
+                        return r;
+                }
+                bool test(const docid_t id) const { return std::binary_search(ids.begin(), ids.end(), id); }
+                bool empty() const noexcept { return ids.empty(); }
+        };
+
         inline void exec_query(DocsSetIterators::Iterator *root, IndexSource *src, MatchedIndexDocumentsFilter *matchesFilter, IndexDocumentsFilter *f = nullptr,
-                               const uint32_t flags = 0, Similarity::IndexSourceTermsScorer *scorer = nullptr) {
+                               const uint32_t flags = 0, Similarity::IndexSourceTermsScorer *scorer = nullptr);
+
+        // exec.h:50: exec_query(query, IndexSource *, masked_documents_registry *, MatchedIndexDocumentsFilter *, IndexDocumentsFilter *, flags,
+        // scorer) — the reference's own argument order (the query is the lowered iterator tree here).  The registry becomes the source's
+        // masked set for this call (nullptr / empty: none), then the query runs as above.
+        inline void exec_query(DocsSetIterators::Iterator *root, IndexSource *src, masked_documents_registry *const maskedDocumentsRegistry,
+                               MatchedIndexDocumentsFilter *matchesFilter, IndexDocumentsFilter *const f = nullptr, const uint32_t flags = 0,
+                               Similarity::IndexSourceTermsScorer *scorer = nullptr) {
+                src->set_masked_documents(maskedDocumentsRegistry ? maskedDocumentsRegistry->ids : std::vector<docid_t>{});
+                exec_query(root, src, matchesFilter, f, flags, scorer);
+        }
+
+        inline void exec_query(DocsSetIterators::Iterator *root, IndexSource *src, MatchedIndexDocumentsFilter *matchesFilter, IndexDocumentsFilter *f,
+                               const uint32_t flags, Similarity::IndexSourceTermsScorer *scorer) {
                 validate_flags(flags);
                 if (!(flags & (unsigned(ExecFlags::DocumentsOnly) | unsigned(ExecFlags::AccumulatedScoreScheme))))
                         return exec_query_default_mode(root, src, matchesFilter, f);

@@ -17,6 +17,7 @@
 //                    one lane per needed block, merging the decoded docs against the candidates in LDS
 //                    (Conjuction::next_impl leapfrog, docset_iterators.cpp:308-348, as a set operation)
 #include "../../include/trinity_hip.h"
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -1161,6 +1162,17 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         };
         std::vector<Tmp> tmp;
         std::vector<PNode> nodes;
+#ifdef TRI_CREATE_TIMES // (debug builds: where tri_batch_create's time goes, to stderr)
+        auto ct_last = std::chrono::steady_clock::now();
+        auto ct_mark = [&](const char *what) {
+                const auto now = std::chrono::steady_clock::now();
+                fprintf(stderr, "  create: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - ct_last).count());
+                ct_last = now;
+        };
+#define CT_MARK(x) ct_mark(x)
+#else
+#define CT_MARK(x)
+#endif
         for (size_t qi = 0; qi < nq; ++qi) {
                 const tri_query &tq = queries[qi];
                 if ((uint64_t)tq.prog_off + tq.prog_len > prog_len || !tq.prog_len)
@@ -1615,6 +1627,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         std::vector<QUse> quses;
         std::vector<FUse> fuses;
         std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
+        CT_MARK("lowering + classes");
         for (auto &t : tmp) {
                 const uint32_t slot = (uint32_t)b->plan.size();
                 b->slot_of_query[t.q.qid] = slot;
@@ -1798,6 +1811,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 b->ptasks.push_back(ti);
                 b->plan.push_back(t.q);
         }
+        CT_MARK("tasks");
         std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &c) { return a.first > c.first; });
         std::vector<uint32_t> sched;
         sched.reserve(order.size());
@@ -1870,6 +1884,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
                 HIP_TRY(hipMalloc((void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
         }
+        CT_MARK("order + planes + scratch");
         b->out_capacity = off;
         int rc;
         if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)) || (rc = dev_upload(&b->d_tasks, b->tasks)) ||
@@ -1919,6 +1934,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 HIP_TRY(hipMemset(b->d_top_docs, 0, (nq * topk + 1) * 4)); // ... and zeroed rows (k_topk_merge only writes the rows of queries that have a plan slot;
                 HIP_TRY(hipMemset(b->d_top_scores, 0, (nq * topk + 1) * 4)); // the blocks travel whole to the host and to the other ranks)
         }
+        CT_MARK("uploads + allocations");
         b->info.nqueries = nq;
         b->info.out_capacity = off;
         b->info.plane_terms = b->plane_terms.size();
