@@ -147,7 +147,7 @@ void *tri_dev_stream(tri_dev *);
  *   "overlap_dense_wgs" / "overlap_cand_wgs"  both non-zero: the two matching kernels run side by side with that many workgroups per CU
  *   "planes"              term planes, a bit set (default 7): 1 the candidate-tile kernel probes them, 2 the bitmap-window kernel ORs them into its
  *                         windows, 4 AccumulatedScore top-K CNF queries run over bit planes (k_planes); 0: every query decodes every list it names
- *   "planes_split"        a query that runs as bit planes (k_planes) is cut into this many docID ranges, one task each (default 2; 0: cut by postings); the
+ *   "planes_split"        a query that runs as bit planes (k_planes) is cut into this many docID ranges, one task each (default 0: two, or three in a batch that brings few tasks per workgroup; 65536 and up: cut by postings like k_fused's); the
  *                         ranges share the query's threshold, results do not depend on the cut
  *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 64) and the batch's uses repay one
  *                         decode of its list

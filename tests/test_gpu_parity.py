@@ -403,7 +403,7 @@ def test_fused_scored_windows_match_oracle(request, world, n, k):
     # k_planes (bit planes): the planner's term planes, a plane for every term, none (every slot decoded per window), small tasks;
     # then k_fused (window words, planes off) in its variants; then match-then-score
     for opts in ({"dense_min_postings": 0}, {"dense_min_postings": 0, "plane_div": ALL_PLANES}, {"dense_min_postings": 0, "plane_div": 0},
-                 {"dense_min_postings": 0, "planes_split": 0, "fused_task_cost": 4096}, {"dense_min_postings": 0, "planes_split": 0, "fused_task_cost": 4096, "plane_div": 0},
+                 {"dense_min_postings": 0, "planes_split": 1 << 20, "fused_task_cost": 4096}, {"dense_min_postings": 0, "planes_split": 1 << 20, "fused_task_cost": 4096, "plane_div": 0},
                  {"dense_min_postings": 0, "planes_split": 1}, {"dense_min_postings": 0, "planes_split": 7}, {"dense_min_postings": 0, "planes_split": 64, "plane_div": 0},
                  {"dense_min_postings": 0, "planes": 0}, {"dense_min_postings": 0, "planes": 0, "fused_freq_cap": 1}, {"dense_min_postings": 0, "planes": 0, "fused_freq_cap": 3},
                  {"dense_min_postings": 0, "planes": 0, "fused_task_cost": 4096}, {"dense_min_postings": 0, "planes": 0, "fused_halfwords": 0},
@@ -435,7 +435,7 @@ def test_fused_large_unions_and_cnf(large):
              "t0 OR t199999", "t3 t5 NOT t1", "t2 <t7 OR t9>"]
     progs = [O.parse_query(t) for t in texts]
     # (k_planes: a query's docID ranges — one task each — share its threshold; 1 range, the default 2, many, and the cut by postings)
-    for opts in ({}, {"planes_split": 1}, {"planes_split": 16}, {"planes_split": 0, "fused_task_cost": 200000}, {"plane_div": 0}, {"plane_div": 0, "planes_split": 0, "fused_task_cost": 200000},
+    for opts in ({}, {"planes_split": 1}, {"planes_split": 16}, {"planes_split": 1 << 20, "fused_task_cost": 200000}, {"plane_div": 0}, {"plane_div": 0, "planes_split": 1 << 20, "fused_task_cost": 200000},
                  {"planes": 0}, {"planes": 0, "fused_task_cost": 200000}):
         with options(w.dev, **opts):
             check_scored(w, texts, progs, 100, tag=opts)

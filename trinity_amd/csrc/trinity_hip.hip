@@ -69,7 +69,7 @@ struct tri_options {
         uint64_t fused_halfwords = 1;             // 16-bit window words for queries of <= 5 distinct terms (windows twice as long); 0: always 32-bit
         uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
         uint64_t planes = 7;     // term planes (k_planes.hpp), a bit set: 1 k_and probes them, 2 k_and_dense ORs them in, 4 top-K CNF queries run in k_planes; 0: off
-        uint64_t planes_split = 2; // a k_planes query is cut into this many docID ranges (tasks) that share its threshold; 0: by postings like the other one-pass tasks.  cfg3's unions: 0 10.9 ms, 2 8.0, 3 8.5, 4 9.2 (a task has fixed costs)
+        uint64_t planes_split = 0; // a k_planes query is cut into this many docID ranges (tasks) that share its threshold; 0: 2 or 3 by the batch's size; >= 65536: by postings like the other one-pass tasks.  cfg3's unions: 0 10.9 ms, 2 8.0, 3 8.5, 4 9.2 (a task has fixed costs)
         uint64_t plane_div = 64; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list)
 };
 
@@ -1599,6 +1599,13 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         // cuts into a couple of tasks per workgroup the device holds (measured at cfg3: 512 K postings per task 55.4 ms, 1 M 51.1, 2 M 49.2,
         // 4 M 48.0, 8 M and more 47.1).  fused_task_cost = 0 (the default): sized from the batch; otherwise as given
         uint64_t FUSED_TASK_COST = dev->opt.fused_task_cost;
+        uint64_t onepass_queries = 0;
+        for (const auto &t : tmp)
+                onepass_queries += classify(t).fuse ? 1 : 0;
+        // k_planes: docID ranges per query.  A task has fixed costs (seed pass, end-of-task imbalance: about 140 us), the kernel's tail is its
+        // longest tasks: two ranges when the batch brings ten or more tasks per resident workgroup anyway, three when it does not (measured,
+        // cfg3's mix: 8192 queries 2 > 3 > 4; 3750 queries 6.5 / 5.9 / 6.2 ms for 2 / 3 / 4; 1024 queries 2.11 / 1.97 / 1.96)
+        const uint64_t PLANES_SPLIT = dev->opt.planes_split ? dev->opt.planes_split : (2 * onepass_queries >= 10ull * (uint64_t)dev->cus * PLK_WGS_PER_CU ? 2 : 3);
         if (!FUSED_TASK_COST) {
                 uint64_t fused_postings = 0;
                 for (const auto &t : tmp)
@@ -1674,8 +1681,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         const uint32_t nwin = last_doc / fw + 1;
                         const uint64_t per_win = std::max<uint64_t>(1, slotdf / (ix->info.docs_cnt / fw + 1));
                         // (k_planes' cost is the sweep of the range plus its candidates, not the postings: equal ranges, a few per query)
-                        const uint32_t win_per_task = pk && dev->opt.planes_split ? (uint32_t)((nwin + dev->opt.planes_split - 1) / dev->opt.planes_split)
-                                                                                  : (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
+                        const uint32_t win_per_task = pk && PLANES_SPLIT < 65536 ? (uint32_t)((nwin + PLANES_SPLIT - 1) / PLANES_SPLIT)
+                                                                                 : (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
                         const bool emit = t.fz.mode & FUS_MODE_EMIT; // ... except by a general tree in DocumentsOnly mode: a private region per task,
                                                                      // bounded like TASK_DENSE's by the slots' blocks that reach the task's windows
                         uint32_t ord = 0;
