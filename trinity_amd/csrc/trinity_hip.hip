@@ -32,6 +32,7 @@
 #include <memory>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <functional>
 #include <vector>
@@ -1160,8 +1161,6 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 bool truth;   // a general tree: runs as TASK_FUSED whatever its density (there is no other path for it)
                 DevFused fz;
         };
-        std::vector<Tmp> tmp;
-        std::vector<PNode> nodes;
 #ifdef TRI_CREATE_TIMES // (debug builds: where tri_batch_create's time goes, to stderr)
         auto ct_last = std::chrono::steady_clock::now();
         auto ct_mark = [&](const char *what) {
@@ -1173,387 +1172,453 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
 #else
 #define CT_MARK(x)
 #endif
-        for (size_t qi = 0; qi < nq; ++qi) {
-                const tri_query &tq = queries[qi];
-                if ((uint64_t)tq.prog_off + tq.prog_len > prog_len || !tq.prog_len)
-                        return fail(TRI_ERR_INVALID, "query %zu: program slice out of range", qi);
-                nodes.clear();
-                const int root = parse_program(ix, prog + tq.prog_off, tq.prog_len, nodes);
-                if (root < 0)
-                        return fail(TRI_ERR_INVALID, "query %zu: malformed postfix program", qi);
-                const PNode &r = nodes[root];
-                if (r.empty)
-                        continue; // matches nothing (compiles to constfalse in the reference)
-                // ---- conjunctive normal form over terms: AND of (term | OR of terms); a root OR is one group
-                std::vector<std::vector<uint32_t>> groups;
-                std::vector<uint32_t> leaves;     // every TERM leaf in evaluation order: one scorer each
-                std::vector<uint32_t> leaf_tok;   // ... and the program token it came from
-                struct PhraseTmp {
-                        std::vector<uint32_t> terms;
-                        double weight;
-                };
-                std::vector<uint32_t> ts_tok; // (scratch of add_group: token indices parallel to ts)
-                std::vector<PhraseTmp> qphrases;
-                auto add_group = [&](const PNode &g) -> bool {
-                        std::vector<uint32_t> ts;
-                        if (g.op == TRI_OP_PHRASE && g.kids.size() > 1) {
-                                // Phrase = conjunction of its terms + a positional constraint on the matches (k_phrase);
-                                // it scores as ONE iterator with the summed idf (docset_iterators_scorers.cpp:195-228)
-                                PhraseTmp ph;
-                                ph.weight = 0;
-                                for (int k : g.kids) {
-                                        const uint32_t x = nodes[k].term;
-                                        ph.terms.push_back(x);
-                                        const uint32_t df = ix->terms[x].documents;
-                                        ph.weight += term_weight(df);
-                                        bool dup = false;
+        // ---- lowering, query by query.  Queries are independent, and a query costs about 0.6 us of host time (tree, groups, slot map: small
+        //      allocations) — 9 ms for 16 384 queries, three times the GPU step they compile to: contiguous ranges of the batch are lowered by
+        //      a few host threads, each into a fragment of its own (offsets relative to the fragment), and the fragments are joined in order.
+        struct Frag {
+                std::vector<Tmp> tmp;
+                std::vector<uint32_t> qterms, pterms, sterms;
+                std::vector<double> sweights;
+                std::vector<DevPhrase> phrases;
+                uint64_t term_bytes = 0, term_bytes_phrase_hits = 0;
+                uint32_t rich_R = 0;
+                bool rich_allow = false;
+                std::vector<size_t> left_out; // queries the planner does not lower (status TRI_ERR_UNSUPPORTED)
+                int rc = TRI_OK;
+                std::string err; // the fragment's last error text (fail() keeps it per thread)
+        };
+        auto lower_range = [&](const size_t q_lo, const size_t q_hi, Frag &f) -> int {
+                std::vector<PNode> nodes;
+                for (size_t qi = q_lo; qi < q_hi; ++qi) {
+                        const tri_query &tq = queries[qi];
+                        if ((uint64_t)tq.prog_off + tq.prog_len > prog_len || !tq.prog_len)
+                                return fail(TRI_ERR_INVALID, "query %zu: program slice out of range", qi);
+                        nodes.clear();
+                        const int root = parse_program(ix, prog + tq.prog_off, tq.prog_len, nodes);
+                        if (root < 0)
+                                return fail(TRI_ERR_INVALID, "query %zu: malformed postfix program", qi);
+                        const PNode &r = nodes[root];
+                        if (r.empty)
+                                continue; // matches nothing (compiles to constfalse in the reference)
+                        // ---- conjunctive normal form over terms: AND of (term | OR of terms); a root OR is one group
+                        std::vector<std::vector<uint32_t>> groups;
+                        std::vector<uint32_t> leaves;     // every TERM leaf in evaluation order: one scorer each
+                        std::vector<uint32_t> leaf_tok;   // ... and the program token it came from
+                        struct PhraseTmp {
+                                std::vector<uint32_t> terms;
+                                double weight;
+                        };
+                        std::vector<uint32_t> ts_tok; // (scratch of add_group: token indices parallel to ts)
+                        std::vector<PhraseTmp> qphrases;
+                        auto add_group = [&](const PNode &g) -> bool {
+                                std::vector<uint32_t> ts;
+                                if (g.op == TRI_OP_PHRASE && g.kids.size() > 1) {
+                                        // Phrase = conjunction of its terms + a positional constraint on the matches (k_phrase);
+                                        // it scores as ONE iterator with the summed idf (docset_iterators_scorers.cpp:195-228)
+                                        PhraseTmp ph;
+                                        ph.weight = 0;
+                                        for (int k : g.kids) {
+                                                const uint32_t x = nodes[k].term;
+                                                ph.terms.push_back(x);
+                                                const uint32_t df = ix->terms[x].documents;
+                                                ph.weight += term_weight(df);
+                                                bool dup = false;
+                                                for (const auto &og : groups)
+                                                        dup |= og.size() == 1 && og[0] == x;
+                                                if (!dup)
+                                                        groups.push_back({x});
+                                        }
+                                        if (weights) // the PHRASE token's own ScorerWeight, when the caller supplies weights (by token position: two phrases
+                                                     // that start with the same term keep their own weights)
+                                                ph.weight = weights[tq.prog_off + g.tok];
+                                        qphrases.push_back(std::move(ph));
+                                        return true;
+                                }
+                                ts_tok.clear();
+                                if (g.op == TRI_OP_PHRASE) {
+                                        ts.push_back(nodes[g.kids[0]].term); // a one-word phrase is a term (exec.cpp: phrase of size 1)
+                                        ts_tok.push_back(nodes[g.kids[0]].tok);
+                                } else if (g.op == TRI_OP_TERM) {
+                                        ts.push_back(g.term);
+                                        ts_tok.push_back(g.tok);
+                                } else if (g.op == TRI_OP_OR) {
+                                        for (int k : g.kids) {
+                                                if (nodes[k].op != TRI_OP_TERM)
+                                                        return false;
+                                                ts.push_back(nodes[k].term);
+                                                ts_tok.push_back(nodes[k].tok);
+                                        }
+                                } else
+                                        return false;
+                                leaves.insert(leaves.end(), ts.begin(), ts.end());
+                                leaf_tok.insert(leaf_tok.end(), ts_tok.begin(), ts_tok.end());
+                                // a term repeated inside a group, or a single-term group seen before, adds nothing to the docID set
+                                std::vector<uint32_t> u;
+                                for (uint32_t x : ts)
+                                        if (std::find(u.begin(), u.end(), x) == u.end())
+                                                u.push_back(x);
+                                if (u.size() == 1)
                                         for (const auto &og : groups)
-                                                dup |= og.size() == 1 && og[0] == x;
-                                        if (!dup)
-                                                groups.push_back({x});
-                                }
-                                if (weights) // the PHRASE token's own ScorerWeight, when the caller supplies weights (by token position: two phrases
-                                             // that start with the same term keep their own weights)
-                                        ph.weight = weights[tq.prog_off + g.tok];
-                                qphrases.push_back(std::move(ph));
+                                                if (og.size() == 1 && og[0] == u[0])
+                                                        return true;
+                                groups.push_back(std::move(u));
                                 return true;
-                        }
-                        ts_tok.clear();
-                        if (g.op == TRI_OP_PHRASE) {
-                                ts.push_back(nodes[g.kids[0]].term); // a one-word phrase is a term (exec.cpp: phrase of size 1)
-                                ts_tok.push_back(nodes[g.kids[0]].tok);
-                        } else if (g.op == TRI_OP_TERM) {
-                                ts.push_back(g.term);
-                                ts_tok.push_back(g.tok);
-                        } else if (g.op == TRI_OP_OR) {
-                                for (int k : g.kids) {
-                                        if (nodes[k].op != TRI_OP_TERM)
-                                                return false;
-                                        ts.push_back(nodes[k].term);
-                                        ts_tok.push_back(nodes[k].tok);
-                                }
-                        } else
-                                return false;
-                        leaves.insert(leaves.end(), ts.begin(), ts.end());
-                        leaf_tok.insert(leaf_tok.end(), ts_tok.begin(), ts_tok.end());
-                        // a term repeated inside a group, or a single-term group seen before, adds nothing to the docID set
-                        std::vector<uint32_t> u;
-                        for (uint32_t x : ts)
-                                if (std::find(u.begin(), u.end(), x) == u.end())
-                                        u.push_back(x);
-                        if (u.size() == 1)
-                                for (const auto &og : groups)
-                                        if (og.size() == 1 && og[0] == u[0])
-                                                return true;
-                        groups.push_back(std::move(u));
-                        return true;
-                };
-                // logicalnot at the root or under an AND: its required side joins the conjunction, its excluded side (a term or an
-                // OR of terms) joins the query's excluded set: A B -C == A ∧ B ∧ ¬C (Filter semantics, docset_iterators.cpp:652-677)
-                bool ok = true;
-                std::vector<uint32_t> negs, opts, opt_tok;
-                std::function<void(int)> lower = [&](int ni) {
-                        const PNode &x = nodes[ni];
-                        if (x.op == TRI_OP_OPT) {
-                                // Optional(main, opt): the documents of main; opt's terms score (and are reported) where they match —
-                                // exactly how k_score / k_rich treat a term a match does not hold
-                                lower(x.kids[0]);
-                                const PNode &e = nodes[x.kids[1]];
-                                if (e.op == TRI_OP_TERM) {
-                                        opts.push_back(e.term);
-                                        opt_tok.push_back(e.tok);
-                                } else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1) {
-                                        opts.push_back(nodes[e.kids[0]].term);
-                                        opt_tok.push_back(nodes[e.kids[0]].tok);
-                                } else if (e.op == TRI_OP_OR) {
-                                        for (int k : e.kids) {
-                                                if (nodes[k].op != TRI_OP_TERM)
-                                                        ok = false;
-                                                else {
-                                                        opts.push_back(nodes[k].term);
-                                                        opt_tok.push_back(nodes[k].tok);
-                                                }
-                                        }
-                                } else
-                                        ok = false;
-                        } else if (x.op == TRI_OP_NOT) {
-                                lower(x.kids[0]);
-                                const PNode &e = nodes[x.kids[1]];
-                                if (e.op == TRI_OP_TERM)
-                                        negs.push_back(e.term);
-                                else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1)
-                                        negs.push_back(nodes[e.kids[0]].term);
-                                else if (e.op == TRI_OP_OR) {
-                                        for (int k : e.kids) {
-                                                if (nodes[k].op != TRI_OP_TERM)
-                                                        ok = false;
-                                                else
-                                                        negs.push_back(nodes[k].term);
-                                        }
-                                } else
-                                        ok = false;
-                        } else if (x.op == TRI_OP_AND) {
-                                for (int k : x.kids)
-                                        lower(k);
-                        } else
-                                ok &= add_group(x);
-                };
-                lower(root);
-                if (ok && !groups.empty()) // (a general tree — below — counts every term once through its slot list)
-                        for (size_t oi = 0; oi < opts.size(); ++oi)
-                                if (const uint32_t x = opts[oi]; ix->terms[x].documents) {
-                                        leaves.push_back(x); // one more scorer / reportable term each; never part of the docID set
-                                        leaf_tok.push_back(opt_tok[oi]);
-                                        if (mode != TRI_FLAG_DOCUMENTS_ONLY)
-                                                b->term_bytes += ix->docbytes[x]; // its postings are read by k_score / k_rich
-                                }
-                TruthPlan tp;
-                bool truth = false;
-                if (!ok || groups.empty()) {
-                        // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp)
-                        if (!build_truth(nodes, root, tp)) {
-                                leave_out(qi);
-                                fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
-                                continue;
-                        }
-                        truth = true;
-                        groups.assign(1, tp.slots); // (one group of every slot: the bookkeeping below — term list, cost, output bound — sees a union)
-                        negs.clear();
-                        leaves = tp.leaves;
-                        leaf_tok = tp.leaf_tok;
-                        qphrases.clear();
-                }
-                auto gcost = [&](const std::vector<uint32_t> &g) {
-                        uint64_t c = 0;
-                        for (uint32_t x : g)
-                                c += ix->terms[x].documents;
-                        return c;
-                };
-                std::stable_sort(groups.begin(), groups.end(), [&](const auto &x, const auto &y) { return gcost(x) < gcost(y); });
-                std::vector<uint32_t> uniq; // terms group by group, QT_GROUP on the first of each group
-                for (const auto &g : groups)
-                        for (size_t i = 0; i < g.size(); ++i)
-                                uniq.push_back(g[i] | (i == 0 ? QT_GROUP : 0u));
-                {
-                        // the excluded terms: one more group, the last, marked QT_NOT
-                        std::vector<uint32_t> u;
-                        for (uint32_t x : negs)
-                                if (ix->terms[x].documents && std::find(u.begin(), u.end(), x) == u.end())
-                                        u.push_back(x);
-                        for (size_t i = 0; i < u.size(); ++i)
-                                uniq.push_back(u[i] | (i == 0 ? (QT_GROUP | QT_NOT) : 0u));
-                }
-                if (uniq.size() > MAX_QTERMS) {
-                        leave_out(qi);
-                        fail(TRI_ERR_UNSUPPORTED, "query %zu: more than %u terms", qi, MAX_QTERMS);
-                        continue;
-                }
-                // (default mode: the reportable terms — every postings iterator collect_doc_matching_terms can reach (queryexec_ctx.cpp:382-520):
-                //  group members and phrase terms, not the excluded side of a NOT —, distinct, in order of first appearance; counted before
-                //  anything of the query is recorded, so that a query with too many of them can still be left out cleanly)
-                std::vector<uint32_t> rt;
-                if (rich) {
-                        auto add = [&](uint32_t x) {
-                                if (std::find(rt.begin(), rt.end(), x) == rt.end())
-                                        rt.push_back(x);
                         };
-                        for (uint32_t pi = 0; pi < tq.prog_len; ++pi) {
-                                const uint32_t tok = prog[tq.prog_off + pi];
-                                if ((tok >> 28) != TRI_OP_TERM)
+                        // logicalnot at the root or under an AND: its required side joins the conjunction, its excluded side (a term or an
+                        // OR of terms) joins the query's excluded set: A B -C == A ∧ B ∧ ¬C (Filter semantics, docset_iterators.cpp:652-677)
+                        bool ok = true;
+                        std::vector<uint32_t> negs, opts, opt_tok;
+                        std::function<void(int)> lower = [&](int ni) {
+                                const PNode &x = nodes[ni];
+                                if (x.op == TRI_OP_OPT) {
+                                        // Optional(main, opt): the documents of main; opt's terms score (and are reported) where they match —
+                                        // exactly how k_score / k_rich treat a term a match does not hold
+                                        lower(x.kids[0]);
+                                        const PNode &e = nodes[x.kids[1]];
+                                        if (e.op == TRI_OP_TERM) {
+                                                opts.push_back(e.term);
+                                                opt_tok.push_back(e.tok);
+                                        } else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1) {
+                                                opts.push_back(nodes[e.kids[0]].term);
+                                                opt_tok.push_back(nodes[e.kids[0]].tok);
+                                        } else if (e.op == TRI_OP_OR) {
+                                                for (int k : e.kids) {
+                                                        if (nodes[k].op != TRI_OP_TERM)
+                                                                ok = false;
+                                                        else {
+                                                                opts.push_back(nodes[k].term);
+                                                                opt_tok.push_back(nodes[k].tok);
+                                                        }
+                                                }
+                                        } else
+                                                ok = false;
+                                } else if (x.op == TRI_OP_NOT) {
+                                        lower(x.kids[0]);
+                                        const PNode &e = nodes[x.kids[1]];
+                                        if (e.op == TRI_OP_TERM)
+                                                negs.push_back(e.term);
+                                        else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1)
+                                                negs.push_back(nodes[e.kids[0]].term);
+                                        else if (e.op == TRI_OP_OR) {
+                                                for (int k : e.kids) {
+                                                        if (nodes[k].op != TRI_OP_TERM)
+                                                                ok = false;
+                                                        else
+                                                                negs.push_back(nodes[k].term);
+                                                }
+                                        } else
+                                                ok = false;
+                                } else if (x.op == TRI_OP_AND) {
+                                        for (int k : x.kids)
+                                                lower(k);
+                                } else
+                                        ok &= add_group(x);
+                        };
+                        lower(root);
+                        if (ok && !groups.empty()) // (a general tree — below — counts every term once through its slot list)
+                                for (size_t oi = 0; oi < opts.size(); ++oi)
+                                        if (const uint32_t x = opts[oi]; ix->terms[x].documents) {
+                                                leaves.push_back(x); // one more scorer / reportable term each; never part of the docID set
+                                                leaf_tok.push_back(opt_tok[oi]);
+                                                if (mode != TRI_FLAG_DOCUMENTS_ONLY)
+                                                        f.term_bytes += ix->docbytes[x]; // its postings are read by k_score / k_rich
+                                        }
+                        TruthPlan tp;
+                        bool truth = false;
+                        if (!ok || groups.empty()) {
+                                // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp)
+                                if (!build_truth(nodes, root, tp)) {
+                                        f.left_out.push_back(qi);
+                                        fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
                                         continue;
-                                const uint32_t x = tok & 0x0fffffffu;
-                                bool positive = std::find(leaves.begin(), leaves.end(), x) != leaves.end();
-                                for (const auto &ph : qphrases)
-                                        positive |= std::find(ph.terms.begin(), ph.terms.end(), x) != ph.terms.end();
-                                if (positive)
-                                        add(x);
+                                }
+                                truth = true;
+                                groups.assign(1, tp.slots); // (one group of every slot: the bookkeeping below — term list, cost, output bound — sees a union)
+                                negs.clear();
+                                leaves = tp.leaves;
+                                leaf_tok = tp.leaf_tok;
+                                qphrases.clear();
                         }
-                        if (rt.size() > 16) {
-                                leave_out(qi);
-                                fail(TRI_ERR_UNSUPPORTED, "query %zu: more than 16 reportable terms", qi);
+                        auto gcost = [&](const std::vector<uint32_t> &g) {
+                                uint64_t c = 0;
+                                for (uint32_t x : g)
+                                        c += ix->terms[x].documents;
+                                return c;
+                        };
+                        std::stable_sort(groups.begin(), groups.end(), [&](const auto &x, const auto &y) { return gcost(x) < gcost(y); });
+                        std::vector<uint32_t> uniq; // terms group by group, QT_GROUP on the first of each group
+                        for (const auto &g : groups)
+                                for (size_t i = 0; i < g.size(); ++i)
+                                        uniq.push_back(g[i] | (i == 0 ? QT_GROUP : 0u));
+                        {
+                                // the excluded terms: one more group, the last, marked QT_NOT
+                                std::vector<uint32_t> u;
+                                for (uint32_t x : negs)
+                                        if (ix->terms[x].documents && std::find(u.begin(), u.end(), x) == u.end())
+                                                u.push_back(x);
+                                for (size_t i = 0; i < u.size(); ++i)
+                                        uniq.push_back(u[i] | (i == 0 ? (QT_GROUP | QT_NOT) : 0u));
+                        }
+                        if (uniq.size() > MAX_QTERMS) {
+                                f.left_out.push_back(qi);
+                                fail(TRI_ERR_UNSUPPORTED, "query %zu: more than %u terms", qi, MAX_QTERMS);
                                 continue;
                         }
-                }
-                const uint32_t nlead = (uint32_t)groups[0].size();
-                const uint64_t lead_docs = gcost(groups[0]);
-                Tmp t;
-                if (!qphrases.empty() && ix->codec == TRI_CODEC_LUCENE && !ix->d_hdir)
-                        return fail(TRI_ERR_INVALID, "query %zu: phrase over a LUCENE segment that was uploaded without hits.data", qi);
-                t.q.phrase_base = (uint32_t)b->phrases.size();
-                t.q.nphrases = (uint32_t)qphrases.size();
-                for (const auto &ph : qphrases) {
-                        b->phrases.push_back({(uint32_t)b->pterms.size(), (uint32_t)ph.terms.size(), ph.weight});
-                        for (uint32_t x : ph.terms) {
-                                b->pterms.push_back(x);
-                                b->term_bytes += ix->hitbytes[x]; // phrase queries also stream the hit bytes
-                                b->term_bytes_phrase_hits += ix->hitbytes[x];
-                        }
-                }
-                t.q.score_base = (uint32_t)b->sterms.size();
-                t.q.nscore = 0;
-                if (rich) {
-                        for (uint32_t x : rt) {
-                                b->sterms.push_back(x);
-                                b->term_bytes += ix->hitbytes[x]; // the hits of every reported term are read
-                        }
-                        t.q.nscore = (uint32_t)rt.size();
-                        b->rich_R = std::max<uint32_t>(b->rich_R, t.q.nscore);
-                }
-                if (scored) {
-                        // one scorer per PostingsListIterator of the conjunction, summed in iterator order
-                        // (docset_iterators_scorers.cpp:173-193); weight = BM25 idf (similarity.h:179-181, float math)
-                        // unless the caller supplied ScorerWeights per TERM token
-                        std::vector<std::pair<uint32_t, double>> sc;
-                        for (size_t li = 0; li < leaves.size(); ++li) // caller-provided weights: the leaf's OWN TERM token (a term that also sits inside a
-                                                                      // phrase or on an excluded side has another token with another weight)
-                                sc.emplace_back(leaves[li], weights ? weights[tq.prog_off + leaf_tok[li]] : term_weight(ix->terms[leaves[li]].documents));
-                        for (auto &e : sc) {
-                                b->sterms.push_back(e.first);
-                                b->sweights.push_back(e.second);
-                        }
-                        t.q.nscore = (uint32_t)sc.size();
-                }
-                // ---- slot map for the one-pass scored path (k_fused.hpp): the query's distinct terms, CNF terms first
-                t.fusable = false;
-                t.truth = truth;
-                t.fz = DevFused{};
-                if (truth) {
-                        DevFused &z = t.fz;
-                        z.nslots = (uint32_t)tp.slots.size();
-                        z.hw = 0; // (general trees run in their own instantiation, 32-bit window words)
-                        z.fbits = z.nslots <= 4 ? 8u : 4u;
-                        z.cap = (1u << z.fbits) - 2u;
-                        if (dev->opt.fused_freq_cap && dev->opt.fused_freq_cap < z.cap)
-                                z.cap = (uint32_t)dev->opt.fused_freq_cap;
-                        const uint32_t fm = (1u << z.fbits) - 1u;
-                        for (size_t i = 0; i < tp.slots.size(); ++i)
-                                z.term[i] = tp.slots[i];
-                        // DocumentsOnly, the default mode and the full score stream (topk == 0) need the docID set; top-K batches do not
-                        z.mode = FUS_MODE_TT | ((scored && topk) ? 0u : FUS_MODE_EMIT);
-                        memcpy(z.tt, tp.tt, sizeof z.tt);
+                        // (default mode: the reportable terms — every postings iterator collect_doc_matching_terms can reach (queryexec_ctx.cpp:382-520):
+                        //  group members and phrase terms, not the excluded side of a NOT —, distinct, in order of first appearance; counted before
+                        //  anything of the query is recorded, so that a query with too many of them can still be left out cleanly)
+                        std::vector<uint32_t> rt;
                         if (rich) {
-                                // per REPORTABLE term (distinct, b->sterms order): reported where any of its leaves sits on the document
-                                z.nleaf = t.q.nscore;
-                                for (uint32_t j = 0; j < t.q.nscore; ++j) {
-                                        const uint32_t term = b->sterms[t.q.score_base + j];
-                                        for (size_t l = 0; l < tp.leaves.size(); ++l)
-                                                if (tp.leaves[l] == term) {
-                                                        z.leaf_slot[j] = (uint8_t)tp.leaf_slot[l];
-                                                        for (int wd = 0; wd < 8; ++wd)
-                                                                z.ctt[j][wd] |= tp.ctt[l][wd];
-                                                }
+                                auto add = [&](uint32_t x) {
+                                        if (std::find(rt.begin(), rt.end(), x) == rt.end())
+                                                rt.push_back(x);
+                                };
+                                for (uint32_t pi = 0; pi < tq.prog_len; ++pi) {
+                                        const uint32_t tok = prog[tq.prog_off + pi];
+                                        if ((tok >> 28) != TRI_OP_TERM)
+                                                continue;
+                                        const uint32_t x = tok & 0x0fffffffu;
+                                        bool positive = std::find(leaves.begin(), leaves.end(), x) != leaves.end();
+                                        for (const auto &ph : qphrases)
+                                                positive |= std::find(ph.terms.begin(), ph.terms.end(), x) != ph.terms.end();
+                                        if (positive)
+                                                add(x);
                                 }
-                                b->rich_allow = true;
-                        } else {
-                                z.nleaf = (uint32_t)tp.leaves.size();
-                                for (size_t j = 0; j < tp.leaves.size(); ++j) {
-                                        z.leaf_slot[j] = (uint8_t)tp.leaf_slot[j];
-                                        memcpy(z.ctt[j], tp.ctt[j].data(), sizeof z.ctt[j]);
+                                if (rt.size() > 16) {
+                                        f.left_out.push_back(qi);
+                                        fail(TRI_ERR_UNSUPPORTED, "query %zu: more than 16 reportable terms", qi);
+                                        continue;
                                 }
                         }
-                        // window skipping needs groups of slots one of which every match holds: the slots of the scorer leaves if no
-                        // matching pattern lacks them all (else every slot: pattern 0 never matches), then every slot all matches hold
-                        const uint32_t npat = 1u << z.nslots;
-                        auto matches = [&](uint32_t p) { return (tp.tt[p >> 5] >> (p & 31u)) & 1u; };
-                        uint32_t g0 = 0;
-                        for (uint32_t sl : tp.leaf_slot)
-                                g0 |= 1u << sl;
-                        for (uint32_t p = 0; p < npat; ++p)
-                                if (matches(p) && !(p & g0))
-                                        g0 = npat - 1;
-                        auto add_req = [&](uint32_t gs) {
-                                z.gslots[z.nreq] = gs;
-                                for (uint32_t sl = 0; sl < z.nslots; ++sl)
-                                        if ((gs >> sl) & 1u)
-                                                z.gmask[z.nreq] |= fm << (sl * z.fbits);
-                                ++z.nreq;
-                        };
-                        add_req(g0);
-                        for (uint32_t sl = 0; sl < z.nslots && z.nreq < FUS_MAX_SLOTS; ++sl) {
-                                bool all = g0 != (1u << sl);
-                                for (uint32_t p = 0; p < npat && all; ++p)
-                                        all = !matches(p) || ((p >> sl) & 1u);
-                                if (all)
-                                        add_req(1u << sl);
+                        const uint32_t nlead = (uint32_t)groups[0].size();
+                        const uint64_t lead_docs = gcost(groups[0]);
+                        Tmp t;
+                        if (!qphrases.empty() && ix->codec == TRI_CODEC_LUCENE && !ix->d_hdir)
+                                return fail(TRI_ERR_INVALID, "query %zu: phrase over a LUCENE segment that was uploaded without hits.data", qi);
+                        t.q.phrase_base = (uint32_t)f.phrases.size();
+                        t.q.nphrases = (uint32_t)qphrases.size();
+                        for (const auto &ph : qphrases) {
+                                f.phrases.push_back({(uint32_t)f.pterms.size(), (uint32_t)ph.terms.size(), ph.weight});
+                                for (uint32_t x : ph.terms) {
+                                        f.pterms.push_back(x);
+                                        f.term_bytes += ix->hitbytes[x]; // phrase queries also stream the hit bytes
+                                        f.term_bytes_phrase_hits += ix->hitbytes[x];
+                                }
                         }
-                        t.fusable = true;
-                } else if (scored && topk && qphrases.empty() && dev->opt.fused) {
-                        std::vector<uint32_t> slots;
-                        auto slot_of = [&](uint32_t term) {
-                                for (size_t i = 0; i < slots.size(); ++i)
-                                        if (slots[i] == term)
-                                                return (uint32_t)i;
-                                slots.push_back(term);
-                                return (uint32_t)slots.size() - 1;
-                        };
-                        for (uint32_t tt : uniq)
-                                slot_of(tt & QT_TERM);
-                        for (uint32_t x : leaves)
-                                slot_of(x);
-                        if (slots.size() <= FUS_MAX_SLOTS) {
+                        t.q.score_base = (uint32_t)f.sterms.size();
+                        t.q.nscore = 0;
+                        if (rich) {
+                                for (uint32_t x : rt) {
+                                        f.sterms.push_back(x);
+                                        f.term_bytes += ix->hitbytes[x]; // the hits of every reported term are read
+                                }
+                                t.q.nscore = (uint32_t)rt.size();
+                                f.rich_R = std::max<uint32_t>(f.rich_R, t.q.nscore);
+                        }
+                        if (scored) {
+                                // one scorer per PostingsListIterator of the conjunction, summed in iterator order
+                                // (docset_iterators_scorers.cpp:173-193); weight = BM25 idf (similarity.h:179-181, float math)
+                                // unless the caller supplied ScorerWeights per TERM token
+                                std::vector<std::pair<uint32_t, double>> sc;
+                                for (size_t li = 0; li < leaves.size(); ++li) // caller-provided weights: the leaf's OWN TERM token (a term that also sits inside a
+                                                                              // phrase or on an excluded side has another token with another weight)
+                                        sc.emplace_back(leaves[li], weights ? weights[tq.prog_off + leaf_tok[li]] : term_weight(ix->terms[leaves[li]].documents));
+                                for (auto &e : sc) {
+                                        f.sterms.push_back(e.first);
+                                        f.sweights.push_back(e.second);
+                                }
+                                t.q.nscore = (uint32_t)sc.size();
+                        }
+                        // ---- slot map for the one-pass scored path (k_fused.hpp): the query's distinct terms, CNF terms first
+                        t.fusable = false;
+                        t.truth = truth;
+                        t.fz = DevFused{};
+                        if (truth) {
                                 DevFused &z = t.fz;
-                                z.nslots = (uint32_t)slots.size();
-                                z.hw = (dev->opt.fused_halfwords && z.nslots <= 5) ? 1u : 0u;
-                                z.fbits = z.hw ? std::min(8u, 16u / z.nslots) : (z.nslots <= 4 ? 8u : 4u);
+                                z.nslots = (uint32_t)tp.slots.size();
+                                z.hw = 0; // (general trees run in their own instantiation, 32-bit window words)
+                                z.fbits = z.nslots <= 4 ? 8u : 4u;
                                 z.cap = (1u << z.fbits) - 2u;
                                 if (dev->opt.fused_freq_cap && dev->opt.fused_freq_cap < z.cap)
                                         z.cap = (uint32_t)dev->opt.fused_freq_cap;
                                 const uint32_t fm = (1u << z.fbits) - 1u;
-                                for (size_t i = 0; i < slots.size(); ++i)
-                                        z.term[i] = slots[i];
-                                int g = -1;
-                                bool in_not = false;
-                                uint32_t nreq_groups = 0;
+                                for (size_t i = 0; i < tp.slots.size(); ++i)
+                                        z.term[i] = tp.slots[i];
+                                // DocumentsOnly, the default mode and the full score stream (topk == 0) need the docID set; top-K batches do not
+                                z.mode = FUS_MODE_TT | ((scored && topk) ? 0u : FUS_MODE_EMIT);
+                                memcpy(z.tt, tp.tt, sizeof z.tt);
+                                if (rich) {
+                                        // per REPORTABLE term (distinct, f.sterms order): reported where any of its leaves sits on the document
+                                        z.nleaf = t.q.nscore;
+                                        for (uint32_t j = 0; j < t.q.nscore; ++j) {
+                                                const uint32_t term = f.sterms[t.q.score_base + j];
+                                                for (size_t l = 0; l < tp.leaves.size(); ++l)
+                                                        if (tp.leaves[l] == term) {
+                                                                z.leaf_slot[j] = (uint8_t)tp.leaf_slot[l];
+                                                                for (int wd = 0; wd < 8; ++wd)
+                                                                        z.ctt[j][wd] |= tp.ctt[l][wd];
+                                                        }
+                                        }
+                                        f.rich_allow = true;
+                                } else {
+                                        z.nleaf = (uint32_t)tp.leaves.size();
+                                        for (size_t j = 0; j < tp.leaves.size(); ++j) {
+                                                z.leaf_slot[j] = (uint8_t)tp.leaf_slot[j];
+                                                memcpy(z.ctt[j], tp.ctt[j].data(), sizeof z.ctt[j]);
+                                        }
+                                }
+                                // window skipping needs groups of slots one of which every match holds: the slots of the scorer leaves if no
+                                // matching pattern lacks them all (else every slot: pattern 0 never matches), then every slot all matches hold
+                                const uint32_t npat = 1u << z.nslots;
+                                auto matches = [&](uint32_t p) { return (tp.tt[p >> 5] >> (p & 31u)) & 1u; };
+                                uint32_t g0 = 0;
+                                for (uint32_t sl : tp.leaf_slot)
+                                        g0 |= 1u << sl;
+                                for (uint32_t p = 0; p < npat; ++p)
+                                        if (matches(p) && !(p & g0))
+                                                g0 = npat - 1;
+                                auto add_req = [&](uint32_t gs) {
+                                        z.gslots[z.nreq] = gs;
+                                        for (uint32_t sl = 0; sl < z.nslots; ++sl)
+                                                if ((gs >> sl) & 1u)
+                                                        z.gmask[z.nreq] |= fm << (sl * z.fbits);
+                                        ++z.nreq;
+                                };
+                                add_req(g0);
+                                for (uint32_t sl = 0; sl < z.nslots && z.nreq < FUS_MAX_SLOTS; ++sl) {
+                                        bool all = g0 != (1u << sl);
+                                        for (uint32_t p = 0; p < npat && all; ++p)
+                                                all = !matches(p) || ((p >> sl) & 1u);
+                                        if (all)
+                                                add_req(1u << sl);
+                                }
+                                t.fusable = true;
+                        } else if (scored && topk && qphrases.empty() && dev->opt.fused) {
+                                std::vector<uint32_t> slots;
+                                auto slot_of = [&](uint32_t term) {
+                                        for (size_t i = 0; i < slots.size(); ++i)
+                                                if (slots[i] == term)
+                                                        return (uint32_t)i;
+                                        slots.push_back(term);
+                                        return (uint32_t)slots.size() - 1;
+                                };
                                 for (uint32_t tt : uniq)
-                                        nreq_groups += (tt & QT_GROUP) && !(tt & QT_NOT);
+                                        slot_of(tt & QT_TERM);
+                                for (uint32_t x : leaves)
+                                        slot_of(x);
+                                if (slots.size() <= FUS_MAX_SLOTS) {
+                                        DevFused &z = t.fz;
+                                        z.nslots = (uint32_t)slots.size();
+                                        z.hw = (dev->opt.fused_halfwords && z.nslots <= 5) ? 1u : 0u;
+                                        z.fbits = z.hw ? std::min(8u, 16u / z.nslots) : (z.nslots <= 4 ? 8u : 4u);
+                                        z.cap = (1u << z.fbits) - 2u;
+                                        if (dev->opt.fused_freq_cap && dev->opt.fused_freq_cap < z.cap)
+                                                z.cap = (uint32_t)dev->opt.fused_freq_cap;
+                                        const uint32_t fm = (1u << z.fbits) - 1u;
+                                        for (size_t i = 0; i < slots.size(); ++i)
+                                                z.term[i] = slots[i];
+                                        int g = -1;
+                                        bool in_not = false;
+                                        uint32_t nreq_groups = 0;
+                                        for (uint32_t tt : uniq)
+                                                nreq_groups += (tt & QT_GROUP) && !(tt & QT_NOT);
+                                        for (uint32_t tt : uniq) {
+                                                if (nreq_groups > FUS_MAX_SLOTS)
+                                                        break; // (a CNF that repeats its terms over more groups than the slot map holds)
+                                                if (tt & QT_GROUP) {
+                                                        in_not = tt & QT_NOT;
+                                                        if (!in_not)
+                                                                ++g;
+                                                }
+                                                const uint32_t sidx = slot_of(tt & QT_TERM);
+                                                if (in_not)
+                                                        z.nmask |= fm << (sidx * z.fbits);
+                                                else {
+                                                        z.gmask[g] |= fm << (sidx * z.fbits);
+                                                        z.gslots[g] |= 1u << sidx;
+                                                }
+                                        }
+                                        z.nreq = (uint32_t)(g + 1);
+                                        t.fusable = z.nreq >= 1 && nreq_groups <= FUS_MAX_SLOTS;
+                                }
+                        }
+                        t.q.fused_idx = 0;
+                        t.q.pad0 = 0;
+                        t.q.nterms = (uint32_t)uniq.size();
+                        t.q.term_base = (uint32_t)f.qterms.size();
+                        t.q.out_cap = 0;
+                        t.q.out_off = 0;
+                        t.q.qid = (uint32_t)qi;
+                        t.cost = 0;
+                        t.nlead = nlead;
+                        {
+                                std::vector<uint32_t> seen;
                                 for (uint32_t tt : uniq) {
-                                        if (nreq_groups > FUS_MAX_SLOTS)
-                                                break; // (a CNF that repeats its terms over more groups than the slot map holds)
-                                        if (tt & QT_GROUP) {
-                                                in_not = tt & QT_NOT;
-                                                if (!in_not)
-                                                        ++g;
-                                        }
-                                        const uint32_t sidx = slot_of(tt & QT_TERM);
-                                        if (in_not)
-                                                z.nmask |= fm << (sidx * z.fbits);
-                                        else {
-                                                z.gmask[g] |= fm << (sidx * z.fbits);
-                                                z.gslots[g] |= 1u << sidx;
+                                        const uint32_t term = tt & QT_TERM;
+                                        f.qterms.push_back(tt);
+                                        if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
+                                                seen.push_back(term);
+                                                f.term_bytes += ix->docbytes[term];
                                         }
                                 }
-                                z.nreq = (uint32_t)(g + 1);
-                                t.fusable = z.nreq >= 1 && nreq_groups <= FUS_MAX_SLOTS;
-                        }
-                }
-                t.q.fused_idx = 0;
-                t.q.pad0 = 0;
-                t.q.nterms = (uint32_t)uniq.size();
-                t.q.term_base = (uint32_t)b->qterms.size();
-                t.q.out_cap = 0;
-                t.q.out_off = 0;
-                t.q.qid = (uint32_t)qi;
-                t.cost = 0;
-                t.nlead = nlead;
-                {
-                        std::vector<uint32_t> seen;
-                        for (uint32_t tt : uniq) {
-                                const uint32_t term = tt & QT_TERM;
-                                b->qterms.push_back(tt);
-                                if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
-                                        seen.push_back(term);
-                                        b->term_bytes += ix->docbytes[term];
+                                // cost estimate: the lead group is decoded fully; every other list costs min(its blocks x 32, lead docs x 32)
+                                for (size_t i = 0; i < uniq.size(); ++i) {
+                                        const DevTerm &tk = ix->terms[uniq[i] & QT_TERM];
+                                        t.cost += i < nlead ? tk.documents : 32ull * std::min<uint64_t>(tk.nblocks, lead_docs);
                                 }
                         }
-                        // cost estimate: the lead group is decoded fully; every other list costs min(its blocks x 32, lead docs x 32)
-                        for (size_t i = 0; i < uniq.size(); ++i) {
-                                const DevTerm &tk = ix->terms[uniq[i] & QT_TERM];
-                                t.cost += i < nlead ? tk.documents : 32ull * std::min<uint64_t>(tk.nblocks, lead_docs);
-                        }
+                        f.tmp.push_back(t);
                 }
-                tmp.push_back(t);
+                return TRI_OK;
+        };
+        const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)8, nq / 1024, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
+        std::vector<Frag> frags(nthreads);
+        {
+                auto work = [&](const size_t k) {
+                        Frag &f = frags[k];
+                        f.rc = lower_range(nq * k / nthreads, nq * (k + 1) / nthreads, f);
+                        f.err = tri_last_error();
+                };
+                std::vector<std::thread> pool;
+                for (size_t k = 1; k < nthreads; ++k)
+                        pool.emplace_back(work, k);
+                work(0);
+                for (auto &th : pool)
+                        th.join();
         }
-        std::stable_sort(tmp.begin(), tmp.end(), [](const Tmp &a, const Tmp &c) { return a.cost > c.cost; });
+        std::vector<Tmp *> tmp; // every lowered query, in query order (the records stay in their fragments)
+        for (Frag &f : frags) {
+                if (f.rc != TRI_OK)
+                        return fail(f.rc, "%s", f.err.c_str());
+                const uint32_t qb = (uint32_t)b->qterms.size(), sb = (uint32_t)b->sterms.size(), pb = (uint32_t)b->phrases.size(), ptb = (uint32_t)b->pterms.size();
+                for (Tmp &t : f.tmp) {
+                        t.q.term_base += qb;
+                        t.q.score_base += sb;
+                        t.q.phrase_base += pb;
+                        tmp.push_back(&t);
+                }
+                for (DevPhrase ph : f.phrases) {
+                        ph.term_base += ptb;
+                        b->phrases.push_back(ph);
+                }
+                b->qterms.insert(b->qterms.end(), f.qterms.begin(), f.qterms.end());
+                b->pterms.insert(b->pterms.end(), f.pterms.begin(), f.pterms.end());
+                b->sterms.insert(b->sterms.end(), f.sterms.begin(), f.sterms.end());
+                b->sweights.insert(b->sweights.end(), f.sweights.begin(), f.sweights.end());
+                b->term_bytes += f.term_bytes;
+                b->term_bytes_phrase_hits += f.term_bytes_phrase_hits;
+                b->rich_R = std::max(b->rich_R, f.rich_R);
+                b->rich_allow |= f.rich_allow;
+                for (const size_t qi : f.left_out)
+                        leave_out(qi);
+                if (!f.left_out.empty())
+                        fail(TRI_ERR_UNSUPPORTED, "%s", f.err.c_str()); // (tri_last_error() describes the last query that was left out)
+        }
+        CT_MARK("lowering");
+        // (heaviest first — by index: a Tmp is 800 bytes, sorting the records themselves was a third of tri_batch_create)
+        std::vector<uint32_t> qorder(tmp.size());
+        std::iota(qorder.begin(), qorder.end(), 0u);
+        std::stable_sort(qorder.begin(), qorder.end(), [&](const uint32_t a, const uint32_t c) { return tmp[a]->cost > tmp[c]->cost; });
         uint64_t off = 0;
         b->plan.reserve(tmp.size());
         // cut every query into tasks of roughly TASK_COST postings, then schedule heaviest first
@@ -1600,18 +1665,18 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         // 4 M 48.0, 8 M and more 47.1).  fused_task_cost = 0 (the default): sized from the batch; otherwise as given
         uint64_t FUSED_TASK_COST = dev->opt.fused_task_cost;
         uint64_t onepass_queries = 0;
-        for (const auto &t : tmp)
-                onepass_queries += classify(t).fuse ? 1 : 0;
+        for (const Tmp *tp : tmp)
+                onepass_queries += classify(*tp).fuse ? 1 : 0;
         // k_planes: docID ranges per query.  A task has fixed costs (seed pass, end-of-task imbalance: about 140 us), the kernel's tail is its
         // longest tasks: two ranges when the batch brings ten or more tasks per resident workgroup anyway, three when it does not (measured,
         // cfg3's mix: 8192 queries 2 > 3 > 4; 3750 queries 6.5 / 5.9 / 6.2 ms for 2 / 3 / 4; 1024 queries 2.11 / 1.97 / 1.96)
         const uint64_t PLANES_SPLIT = dev->opt.planes_split ? dev->opt.planes_split : (2 * onepass_queries >= 10ull * (uint64_t)dev->cus * PLK_WGS_PER_CU ? 2 : 3);
         if (!FUSED_TASK_COST) {
                 uint64_t fused_postings = 0;
-                for (const auto &t : tmp)
-                        if (classify(t).fuse)
-                                for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx)
-                                        fused_postings += ix->terms[t.fz.term[sidx]].documents;
+                for (const Tmp *tp : tmp)
+                        if (classify(*tp).fuse)
+                                for (uint32_t sidx = 0; sidx < tp->fz.nslots; ++sidx)
+                                        fused_postings += ix->terms[tp->fz.term[sidx]].documents;
                 const uint64_t want_tasks = 2ull * (uint64_t)dev->cus * FUS_WGS_PER_CU;
                 FUSED_TASK_COST = std::min<uint64_t>(8u << 20, std::max<uint64_t>(256u << 10, fused_postings / want_tasks));
         }
@@ -1634,8 +1699,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         std::vector<QUse> quses;
         std::vector<FUse> fuses;
         std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
-        CT_MARK("lowering + classes");
-        for (auto &t : tmp) {
+        CT_MARK("query order + classes");
+        for (const uint32_t qo : qorder) {
+                Tmp &t = *tmp[qo];
                 const uint32_t slot = (uint32_t)b->plan.size();
                 b->slot_of_query[t.q.qid] = slot;
                 const uint32_t *qt = &b->qterms[t.q.term_base];
