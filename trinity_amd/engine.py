@@ -339,14 +339,14 @@ class Batch:
         progs = [np.ascontiguousarray(p, dtype=np.uint32) for p in programs]
         self.nq = len(progs)
         flat = np.concatenate(progs) if progs else np.zeros(0, np.uint32)
-        q = (TriQuery * max(1, self.nq))()
-        off = 0
-        for i, p in enumerate(progs):
-            q[i].prog_off, q[i].prog_len = off, p.size
-            off += p.size
+        # tri_query[] = (prog_off, prog_len) pairs: laid out with numpy (a ctypes struct array costs a microsecond per field store)
+        q = np.zeros((max(1, self.nq), 2), dtype=np.uint32)
+        if progs:
+            q[:, 1] = np.fromiter((p.size for p in progs), dtype=np.uint32, count=self.nq)
+            q[1:, 0] = np.cumsum(q[:-1, 1], dtype=np.uint64).astype(np.uint32)
         self.flags, self.topk = flags, topk
         self.h = C.c_void_p()
-        _check(hip_lib().tri_batch_create(index.h, flat.ctypes.data, flat.size, q, self.nq, None, flags, topk, similarity, C.byref(self.h)))
+        _check(hip_lib().tri_batch_create(index.h, flat.ctypes.data, flat.size, q.ctypes.data, self.nq, None, flags, topk, similarity, C.byref(self.h)))
 
     @classmethod
     def conjunctions(cls, index, term_rows, flags=FLAG_DOCUMENTS_ONLY, topk=0):
