@@ -123,12 +123,15 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
 //   * the predicate is word-wise: a required group = the OR of its slots' A words, the conjunction their AND, the excluded group an
 //     AND-NOT, masked documents (docidupdates.h:90-119) another — 32 documents per instruction; the match count is a popcount.
 //     (What docset_spans.cpp:98-173 / 681-790 do per document and docset_iterators.cpp:226-405 per posting.)
-//   * the candidate filter is word-wise too.  A slot is at one of up to four LEVELS in a document: absent, frequency 1, frequency 2
-//     (head terms; its scorers then add exactly what they add at that frequency), any other frequency (they add at most a bound).
-//     Whenever the threshold (the k-th best score so far) moves, the minimal level assignments whose weights reach it are listed
-//     (planes_filter); a match is a candidate iff it meets one of them — an OR of ANDs over the slots' level words.  Matches whose
-//     frequencies are all known (almost all of them) are thereby tested against their EXACT score without being touched one by one.
-//     (This replaces MaxScore's "holds an essential slot".)
+//   * the candidate filter.  A slot is at one of up to four LEVELS in a document: absent, frequency 1, frequency 2 (head terms; its
+//     scorers then add exactly what they add at that frequency), any other frequency (they add at most a bound).  Whenever the
+//     threshold (the k-th best score so far) moves, planes_filter rebuilds a TABLE with one bit per level vector (do the levels'
+//     weights reach the threshold?) and the ESSENTIAL PLANES — MaxScore's essential slots refined by level: a slot capped at level c
+//     is essential only through its plane c + 1.  The sweep ORs the essential planes word-wise; only the documents in that word are
+//     looked up in the table (level code from word-wise level bits), and only table hits become candidates — a match whose
+//     frequencies are all known (almost all of them) is thereby tested against its EXACT score without being touched.
+//   * a SEED pass scores the documents of the query's rarest decoded lists before the sweep (plane probes + bisections), so the
+//     threshold is near final from the first window on; the docID ranges (tasks) of a query share one threshold (planes_prune).
 //   * candidates are scored one per lane by the wave that owns their words, no workgroup barrier: levels from registers; a
 //     candidate with a slot of unknown frequency that the bound does not rule out waits on the wave's queue, and the queue is
 //     worked off 64 at a time — the exact frequencies come from the postings (directory cell -> block -> register row reader).

@@ -1664,19 +1664,22 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         // cuts into a couple of tasks per workgroup the device holds (measured at cfg3: 512 K postings per task 55.4 ms, 1 M 51.1, 2 M 49.2,
         // 4 M 48.0, 8 M and more 47.1).  fused_task_cost = 0 (the default): sized from the batch; otherwise as given
         uint64_t FUSED_TASK_COST = dev->opt.fused_task_cost;
+        std::vector<Class> classes(tmp.size()); // (once per query: the passes below and the task loop all ask)
+        for (size_t i = 0; i < tmp.size(); ++i)
+                classes[i] = classify(*tmp[i]);
         uint64_t onepass_queries = 0;
-        for (const Tmp *tp : tmp)
-                onepass_queries += classify(*tp).fuse ? 1 : 0;
+        for (const Class &c : classes)
+                onepass_queries += c.fuse ? 1 : 0;
         // k_planes: docID ranges per query.  A task has fixed costs (seed pass, end-of-task imbalance: about 140 us), the kernel's tail is its
         // longest tasks: two ranges when the batch brings ten or more tasks per resident workgroup anyway, three when it does not (measured,
         // cfg3's mix: 8192 queries 2 > 3 > 4; 3750 queries 6.5 / 5.9 / 6.2 ms for 2 / 3 / 4; 1024 queries 2.11 / 1.97 / 1.96)
         const uint64_t PLANES_SPLIT = dev->opt.planes_split ? dev->opt.planes_split : (2 * onepass_queries >= 10ull * (uint64_t)dev->cus * PLK_WGS_PER_CU ? 2 : 3);
         if (!FUSED_TASK_COST) {
                 uint64_t fused_postings = 0;
-                for (const Tmp *tp : tmp)
-                        if (classify(*tp).fuse)
-                                for (uint32_t sidx = 0; sidx < tp->fz.nslots; ++sidx)
-                                        fused_postings += ix->terms[tp->fz.term[sidx]].documents;
+                for (size_t i = 0; i < tmp.size(); ++i)
+                        if (classes[i].fuse)
+                                for (uint32_t sidx = 0; sidx < tmp[i]->fz.nslots; ++sidx)
+                                        fused_postings += ix->terms[tmp[i]->fz.term[sidx]].documents;
                 const uint64_t want_tasks = 2ull * (uint64_t)dev->cus * FUS_WGS_PER_CU;
                 FUSED_TASK_COST = std::min<uint64_t>(8u << 20, std::max<uint64_t>(256u << 10, fused_postings / want_tasks));
         }
@@ -1707,7 +1710,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint32_t *qt = &b->qterms[t.q.term_base];
                 const DevTerm &lead = ix->terms[qt[0] & QT_TERM];
                 const uint32_t nlead = t.nlead;
-                const Class cls = classify(t);
+                const Class cls = classes[qo];
                 const uint64_t sumdf = cls.sumdf;
                 const uint32_t last_doc = cls.last_doc;
                 const bool dense = cls.dense, fuse = cls.fuse;
