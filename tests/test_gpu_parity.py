@@ -890,6 +890,45 @@ def test_shapes_still_refused(T, dev):
     w.ix.close()
 
 
+def test_large_batch_is_lowered_in_fragments(T, dev):
+    """tri_batch_create lowers batches of 2048 queries and more on several host threads, each range of queries into a fragment of its own
+    (term / phrase / scorer offsets relative to the fragment), joined in order: 6000 queries of every lowered kind — conjunctions, unions,
+    CNFs, phrases (their DevPhrase rows and pterms cross fragment boundaries), NOT, general trees, and shapes the planner leaves out —
+    give, query by query, what the same queries give in batches of 500 (one thread); a malformed program anywhere fails the batch."""
+    w = World(T, dev, 3000, 300, 10, 43)
+    rng = np.random.default_rng(5)
+    shapes = ["t{0} t{1}", "t{0} OR t{1} OR t{2}", "t{0} (t{1} OR t{2})", '"t{0} t{1}"', '"t{0} t{1}" t{2}', "t{0} NOT t{1}", "t{0} OR (t{1} t{2})", 't{0} OR "t{1} t{2}"',
+              "[t{0}, t{1}, t{2}]", "t{0} <t{1}>"]
+    texts = [shapes[i % len(shapes)].format(*rng.choice(40, 3, replace=False)) for i in range(6000)]
+    progs = [O.parse_query(t, some_min=2) for t in texts]
+    for flags, topk in ((T.FLAG_DOCUMENTS_ONLY, 0), (T.FLAG_ACCUMULATED_SCORE, 10)):
+        big = T.Batch(w.ix, progs, flags, topk=topk)
+        big.run()
+        big.sync()
+        st, counts = big.query_status(), big.counts()
+        tk = big.topk_results() if topk else None
+        assert int((st != 0).sum()) == 600 == big.info()["unsupported_queries"]  # (the phrase under an OR: every 10th query)
+        for lo in range(0, len(progs), 500):
+            small = T.Batch(w.ix, progs[lo : lo + 500], flags, topk=topk)
+            small.run()
+            small.sync()
+            assert small.query_status().tolist() == st[lo : lo + 500].tolist()
+            assert small.counts().tolist() == counts[lo : lo + 500].tolist()
+            if topk:
+                d, s_, c = small.topk_results()
+                assert np.array_equal(d, tk[0][lo : lo + 500]) and np.array_equal(s_, tk[1][lo : lo + 500]) and np.array_equal(c, tk[2][lo : lo + 500])
+            small.close()
+        for i in (0, 2999, 5999):  # and against the oracle, at the ends and in the middle
+            if st[i] == 0:
+                assert int(counts[i]) == len(w.ora.exec(progs[i], O.FLAG_DOCUMENTS_ONLY)[0]), texts[i]
+        big.close()
+    bad = list(progs)
+    bad[4321] = np.array([T.tok(T.OP_AND, 2)], dtype=np.uint32)
+    with pytest.raises(T.TrinityError):
+        T.Batch(w.ix, bad, T.FLAG_DOCUMENTS_ONLY)
+    w.ix.close()
+
+
 # ------------------------------------------------------------------------------------------ hit payloads in the default mode
 def test_hit_payloads_from_the_reference_segment(T, dev):
     """TRI_FLAG_MATCHED_TERMS | TRI_FLAG_HIT_PAYLOADS over the reference-written edge segment: for every term the fixture holds the
