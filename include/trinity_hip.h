@@ -17,8 +17,8 @@
 extern "C" {
 #endif
 
-#define TRI_ABI_VERSION 4 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
-                             4: tri_batch_info grew (term planes, k_planes) */
+#define TRI_ABI_VERSION 5 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
+                             4: tri_batch_info grew (term planes, k_planes), tri_batch_query_status, tri_comm_create_custom; 5: tri_encode_google_payloads */
 
 /* status codes */
 #define TRI_OK 0
@@ -295,6 +295,15 @@ int tri_gather_results(tri_batch *, tri_comm *, void *counts_all, void *docids_a
  * index_out == NULL: sizing call (*index_len and terms_out are filled). */
 int tri_encode_google(tri_dev *, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first,
                       size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out);
+
+/* The same with hit payloads (Encoder::new_hit(pos, payload), google_codec.cpp:38-74): payload_lens[h] (0 .. 8) and payloads[h] (the
+ * payload's first byte in the low 8 bits) per hit, parallel to positions[].  A hit is written as varint(position delta << 1 | the
+ * length differs from the previous hit's of the document) [u8 new length] payload bytes, the length state restarting with every
+ * document (:34).  A position-0 hit WITH a payload is a counted hit (:42-45); one without is refused, as by tri_encode_google.
+ * payload_lens == NULL: no hit has a payload (tri_encode_google). */
+int tri_encode_google_payloads(tri_dev *, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
+                               const uint64_t *payloads, size_t npositions, const uint64_t *term_first, size_t nterms, uint8_t *index_out, size_t cap,
+                               size_t *index_len, tri_term *terms_out);
 
 #ifdef __cplusplus
 }

@@ -1194,6 +1194,52 @@ def test_google_encoder_on_the_device(T, dev):
             ix.close()
 
 
+def test_google_encoder_on_the_device_with_payloads(T, dev):
+    """tri_encode_google_payloads against the host encoder (whose payload bytes the reference-written edge segment pins, tests/test_abi.py):
+    hits with payloads of 0 .. 8 bytes whose length changes from hit to hit or stays (both arms of the flag bit, google_codec.cpp:59-66),
+    the length state restarting with every document, a counted position-0 hit with a payload — byte-identical; and the encoded segment,
+    uploaded, hands the same payloads back in the default mode (tri_batch_matched_payloads)."""
+    from trinity_amd import engine as E
+
+    rng = np.random.default_rng(9)
+    for nterms in (1, 37, 200):
+        docs, freqs, pos, tf = random_postings(rng, nterms)
+        style = rng.integers(0, 3, size=pos.size)  # per hit: no payload / the previous one's length again / a fresh length
+        plen = np.where(style == 0, 0, rng.integers(1, 9, size=pos.size)).astype(np.uint8)
+        same = np.flatnonzero(style == 1)
+        plen[same[same > 0]] = plen[same[same > 0] - 1]
+        pv = rng.integers(0, 2**63, size=pos.size, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=pos.size, dtype=np.uint64)
+        # a counted position-0 hit: the first hit of some documents, with a payload
+        first = np.cumsum(np.concatenate([[0], freqs[:-1]])).astype(np.int64)
+        for h in first[(freqs > 0) & (rng.random(freqs.size) < 0.05)].tolist():
+            pos[h], plen[h] = 0, max(1, int(plen[h]))
+        want, wterms = E.host_encode_google(docs, freqs, pos, tf, plen, pv)
+        got, gterms = dev.encode_google(docs, freqs, pos, tf, plen, pv)
+        assert np.array_equal(gterms, wterms), nterms
+        assert got.size == want.size and np.array_equal(got, want), nterms
+    for bad_plen, bad_pos in ((9, 5), (0, 0)):  # a payload of nine bytes; a payload-less hit at position 0
+        with pytest.raises(T.TrinityError):
+            dev.encode_google(np.array([1], np.uint32), np.array([1], np.uint32), np.array([bad_pos], np.uint16), np.array([0, 1], np.uint64),
+                              np.array([bad_plen], np.uint8), np.array([7], np.uint64))
+    # round trip through the engine: the payloads of a term's hits as the default mode reports them
+    docs, freqs, tf = np.array([3, 9, 10], np.uint32), np.array([2, 1, 3], np.uint32), np.array([0, 3], np.uint64)
+    pos = np.array([1, 4, 2, 5, 6, 9], np.uint16)
+    plen = np.array([2, 2, 0, 8, 0, 3], np.uint8)
+    pv = np.array([0x1122, 0x3344, 0, 0x8877665544332211, 0, 0xABCDEF], np.uint64)
+    index, terms = dev.encode_google(docs, freqs, pos, tf, plen, pv)
+    ix = T.Index(dev, index, terms, 10)
+    b = T.Batch(ix, [O.parse_query("t0")], T.FLAG_MATCHED_TERMS | T.FLAG_HIT_PAYLOADS)
+    b.run()
+    b.sync()
+    _, _, _, positions = b.matched_terms(0, 3)
+    lens, words = b.matched_payloads(0)
+    assert positions.tolist() == pos.tolist() and lens.tolist() == plen.tolist()
+    # (term_hit::payload keeps the bytes a shorter payload does not overwrite — google_codec.cpp:533-594; a document starts from zero)
+    assert [int(x) & ((1 << (8 * int(l))) - 1) for x, l in zip(words.tolist(), plen.tolist())] == [int(x) & ((1 << (8 * int(l))) - 1) for x, l in zip(pv.tolist(), plen.tolist())]
+    b.close()
+    ix.close()
+
+
 def test_device_encoder_reproduces_the_synthetic_segment(T, dev):
     """The tiny corpus' postings (read back through the oracle: documents, frequencies, positions) re-encoded on the device give the
     segment's own bytes — the bytes the reference's encoder writes for this corpus (tests/test_oracle.py pins their FNV)."""

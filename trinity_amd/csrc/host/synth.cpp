@@ -202,8 +202,15 @@ void tri_synth_queries(uint32_t V, uint64_t seed, uint32_t nq, uint32_t nterms, 
 // The host encoder (google_encoder.hpp, byte-identical to the reference's) over caller-supplied postings: the checker of the device
 // encoder (tri_encode_google, include/trinity_hip.h) in tests.  Same arguments; terms_out rows are {documents, offset, size}.
 // Returns the index length, or -1 when `cap` is too small / the input is malformed.
+long long tri_host_encode_google_payloads(const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
+                                          const uint64_t *payloads, const uint64_t *term_first, uint64_t nterms, uint8_t *out, uint64_t cap, uint32_t *terms_out);
 long long tri_host_encode_google(const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint64_t *term_first, uint64_t nterms,
                                  uint8_t *out, uint64_t cap, uint32_t *terms_out) {
+        return tri_host_encode_google_payloads(docs, freqs, positions, nullptr, nullptr, term_first, nterms, out, cap, terms_out);
+}
+// ... with hit payloads: payload_lens[h] bytes of payloads[h] (first byte in the low 8 bits) per hit; payload_lens == nullptr: none
+long long tri_host_encode_google_payloads(const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
+                                          const uint64_t *payloads, const uint64_t *term_first, uint64_t nterms, uint8_t *out, uint64_t cap, uint32_t *terms_out) {
         try {
                 Codecs::Google::IndexSession sess;
                 Codecs::Google::Encoder enc(&sess);
@@ -213,8 +220,13 @@ long long tri_host_encode_google(const uint32_t *docs, const uint32_t *freqs, co
                         enc.begin_term();
                         for (uint64_t p = term_first[t]; p < term_first[t + 1]; ++p) {
                                 enc.begin_document(docs[p]);
-                                for (uint32_t k = 0; k < freqs[p]; ++k)
-                                        enc.new_hit(positions[h++]);
+                                for (uint32_t k = 0; k < freqs[p]; ++k, ++h) {
+                                        uint8_t bytes[8];
+                                        const uint8_t plen = payload_lens ? payload_lens[h] : 0;
+                                        for (uint8_t z = 0; z < plen && z < 8; ++z)
+                                                bytes[z] = uint8_t(payloads[h] >> (8 * z));
+                                        enc.new_hit(positions[h], bytes, plen);
+                                }
                                 enc.end_document();
                         }
                         enc.end_term(&tctx);

@@ -6,8 +6,8 @@
 // Codecs::Google::Encoder (google_codec.cpp:9-176) turns a term's postings — ascending docIDs, per document the counted hits'
 // positions — into a chunk:  [u16 skiplist entries] blocks... [skiplist entries {u32 previous block's last docID, u32 offset of
 // the block in the chunk}].  A block of n <= 32 documents is  varint(last docID - previous block's last) varint(length of what
-// follows the n byte) u8(n)  n-1 delta varints  n freq varints  the hits (per document: varint((position delta) << 1) each;
-// payload-less hits).  Every 8th block COUNTED ACROSS TERMS leaves a skiplist entry in its term (at most 65535 per term).
+// follows the n byte) u8(n)  n-1 delta varints  n freq varints  the hits (per document: varint((position delta) << 1 | length
+// changes) [u8 payload length] payload bytes each).  Every 8th block COUNTED ACROSS TERMS leaves a skiplist entry in its term (at most 65535 per term).
 //
 // Here one lane owns one block: a sizing pass, a scan, a writing pass.  The blocks of all terms form one array; term t's blocks
 // are [blk_first[t], blk_first[t + 1]).  Nothing is sequential but the scans.
@@ -79,6 +79,8 @@ __global__ __launch_bounds__(1024) void k_enc_scan(const uint32_t *__restrict__ 
 struct EncArgs {
         const uint32_t *docs, *freqs;
         const uint16_t *positions;
+        const uint8_t *plens;       // per hit: its payload's length (0 .. 8); nullptr: no hit has a payload
+        const uint64_t *payloads;   // per hit: the payload, its first byte in the low 8 bits
         const uint64_t *hit_off;    // [postings + 1]: hits before posting p
         const uint64_t *term_first; // [nterms + 1]: postings before term t
         const uint32_t *blk_first;  // [nterms + 1]: blocks before term t
@@ -115,10 +117,13 @@ __global__ void k_enc_size(const EncArgs a, uint32_t *__restrict__ sizes, uint32
                         body += enc_vlen(d - prev);
                 prev = d;
                 body += enc_vlen(a.freqs[b.p0 + i]);
-                uint32_t last_pos = 0;
+                // a hit: varint(position delta << 1 | the payload length changes) [u8 new length] payload bytes; the length state restarts
+                // with every document (Encoder::new_hit, google_codec.cpp:38-74; begin_document :34)
+                uint32_t last_pos = 0, cur_plen = 0;
                 for (uint64_t h = a.hit_off[b.p0 + i]; h < a.hit_off[b.p0 + i + 1]; ++h) {
-                        const uint32_t pos = a.positions[h];
-                        body += enc_vlen((pos - last_pos) << 1);
+                        const uint32_t pos = a.positions[h], plen = a.plens ? a.plens[h] : 0u, chg = plen != cur_plen ? 1u : 0u;
+                        body += enc_vlen((pos - last_pos) << 1 | chg) + chg + plen;
+                        cur_plen = plen;
                         last_pos = pos;
                 }
         }
@@ -149,10 +154,18 @@ __global__ void k_enc_write(const EncArgs a, const uint64_t *__restrict__ blk_of
         for (uint32_t i = 0; i < b.n; ++i)
                 o = enc_put(o, a.freqs[b.p0 + i]);
         for (uint32_t i = 0; i < b.n; ++i) {
-                uint32_t last_pos = 0;
+                uint32_t last_pos = 0, cur_plen = 0;
                 for (uint64_t h = a.hit_off[b.p0 + i]; h < a.hit_off[b.p0 + i + 1]; ++h) {
-                        const uint32_t pos = a.positions[h];
-                        o = enc_put(o, (pos - last_pos) << 1);
+                        const uint32_t pos = a.positions[h], plen = a.plens ? a.plens[h] : 0u, chg = plen != cur_plen ? 1u : 0u;
+                        o = enc_put(o, (pos - last_pos) << 1 | chg);
+                        if (chg)
+                                *o++ = (uint8_t)plen;
+                        if (plen) {
+                                const uint64_t pl = a.payloads[h];
+                                for (uint32_t k = 0; k < plen; ++k)
+                                        *o++ = (uint8_t)(pl >> (8 * k));
+                        }
+                        cur_plen = plen;
                         last_pos = pos;
                 }
         }

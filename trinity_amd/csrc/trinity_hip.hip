@@ -2879,7 +2879,13 @@ extern "C" int tri_gather_results(tri_batch *b, tri_comm *c, void *counts_all, v
 // calls (payload-less hits).  See k_encode.hpp.
 extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first,
                                  size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out) {
-        if (!dev || !term_first || !index_len || (nterms && !terms_out))
+        return tri_encode_google_payloads(dev, docs, freqs, positions, nullptr, nullptr, npositions, term_first, nterms, index_out, cap, index_len, terms_out);
+}
+
+extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
+                                          const uint64_t *payloads, size_t npositions, const uint64_t *term_first, size_t nterms, uint8_t *index_out, size_t cap,
+                                          size_t *index_len, tri_term *terms_out) {
+        if (!dev || !term_first || !index_len || (nterms && !terms_out) || (payload_lens && !payloads))
                 return fail(TRI_ERR_INVALID, "tri_encode_google: null argument");
         HIP_TRY(hipSetDevice(dev->device));
         const uint64_t np = nterms ? term_first[nterms] : 0;
@@ -2907,8 +2913,11 @@ extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint3
                                 return fail(TRI_ERR_INVALID, "term %zu, document %u: freqs[] asks for more positions than the %zu given", t, docs[p], npositions);
                         uint32_t last_pos = 0;
                         for (uint64_t h = nhits; h < nhits + freqs[p]; ++h) {
-                                if (!positions[h] || positions[h] < last_pos)
-                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: positions must be > 0 and non-descending within a document (google_codec.cpp:42-49)", t, docs[p]);
+                                const uint32_t plen = payload_lens ? payload_lens[h] : 0u;
+                                if (plen > 8)
+                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: a payload of %u bytes (at most 8: google_codec.cpp:46)", t, docs[p], plen);
+                                if ((!positions[h] && !plen) || positions[h] < last_pos) // (a position-0 hit WITH a payload is a counted hit: :42-45)
+                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: positions must be non-descending within a document, and > 0 for a hit without payload (google_codec.cpp:42-49)", t, docs[p]);
                                 last_pos = positions[h];
                         }
                         nhits += freqs[p];
@@ -2923,11 +2932,11 @@ extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint3
         struct Bufs {
                 uint32_t *docs = nullptr, *freqs = nullptr, *blk_first = nullptr, *blk_term = nullptr, *sizes = nullptr, *tails = nullptr;
                 uint16_t *pos = nullptr;
-                uint64_t *hit_off = nullptr, *term_first = nullptr, *blk_off = nullptr, *term_off = nullptr;
-                uint8_t *out = nullptr;
+                uint64_t *hit_off = nullptr, *term_first = nullptr, *blk_off = nullptr, *term_off = nullptr, *payloads = nullptr;
+                uint8_t *out = nullptr, *plens = nullptr;
                 ~Bufs() {
                         for (void *p : {(void *)docs, (void *)freqs, (void *)blk_first, (void *)blk_term, (void *)sizes, (void *)tails, (void *)pos, (void *)hit_off,
-                                        (void *)term_first, (void *)blk_off, (void *)term_off, (void *)out})
+                                        (void *)term_first, (void *)blk_off, (void *)term_off, (void *)out, (void *)payloads, (void *)plens})
                                 hipFree(p);
                 }
         } d;
@@ -2948,12 +2957,18 @@ extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint3
                 HIP_TRY(hipMemcpyAsync(d.freqs, freqs, np * 4, hipMemcpyHostToDevice, dev->stream));
                 if (nhits)
                         HIP_TRY(hipMemcpyAsync(d.pos, positions, nhits * 2, hipMemcpyHostToDevice, dev->stream));
+                if (nhits && payload_lens) {
+                        HIP_TRY(hipMalloc((void **)&d.plens, nhits));
+                        HIP_TRY(hipMalloc((void **)&d.payloads, nhits * 8));
+                        HIP_TRY(hipMemcpyAsync(d.plens, payload_lens, nhits, hipMemcpyHostToDevice, dev->stream));
+                        HIP_TRY(hipMemcpyAsync(d.payloads, payloads, nhits * 8, hipMemcpyHostToDevice, dev->stream));
+                }
                 HIP_TRY(hipMemcpyAsync(d.term_first, term_first, (nterms + 1) * 8, hipMemcpyHostToDevice, dev->stream));
                 HIP_TRY(hipMemcpyAsync(d.blk_first, blk_first.data(), (nterms + 1) * 4, hipMemcpyHostToDevice, dev->stream));
                 HIP_TRY(hipMemcpyAsync(d.blk_term, blk_term.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, dev->stream));
                 // hits before every posting, then the blocks' sizes and their running sum
                 hipLaunchKernelGGL(k_enc_scan, dim3(1), dim3(1024), 0, dev->stream, d.freqs, d.hit_off, np);
-                const EncArgs a{d.docs, d.freqs, d.pos, d.hit_off, d.term_first, d.blk_first, d.blk_term, nblocks};
+                const EncArgs a{d.docs, d.freqs, d.pos, d.plens, d.payloads, d.hit_off, d.term_first, d.blk_first, d.blk_term, nblocks};
                 hipLaunchKernelGGL(k_enc_size, dim3((nblocks + 255) / 256), dim3(256), 0, dev->stream, a, d.sizes, d.tails);
                 hipLaunchKernelGGL(k_enc_scan, dim3(1), dim3(1024), 0, dev->stream, d.sizes, d.blk_off, (uint64_t)nblocks);
                 HIP_TRY(hipGetLastError());
@@ -2987,7 +3002,7 @@ extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint3
         if (nblocks) {
                 HIP_TRY(hipMalloc((void **)&d.term_off, (nterms + 1) * 8));
                 HIP_TRY(hipMemcpyAsync(d.term_off, term_off.data(), (nterms + 1) * 8, hipMemcpyHostToDevice, dev->stream));
-                const EncArgs a{d.docs, d.freqs, d.pos, d.hit_off, d.term_first, d.blk_first, d.blk_term, nblocks};
+                const EncArgs a{d.docs, d.freqs, d.pos, d.plens, d.payloads, d.hit_off, d.term_first, d.blk_first, d.blk_term, nblocks};
                 hipLaunchKernelGGL(k_enc_write, dim3((nblocks + 255) / 256), dim3(256), 0, dev->stream, a, d.blk_off, d.tails, d.term_off, d.out);
                 HIP_TRY(hipGetLastError());
         }

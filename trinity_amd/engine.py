@@ -87,7 +87,7 @@ ABI_SYMBOLS = [
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
-    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google",
+    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
 
@@ -143,6 +143,7 @@ def hip_lib():
     L.tri_cbatch_topk.argtypes = [vp, vp, vp, vp]
     L.tri_cbatch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_encode_google.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.tri_encode_google_payloads.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_comm_unique_id.argtypes = [vp]
     L.tri_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.tri_comm_create_custom.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
@@ -168,6 +169,8 @@ def host_lib():
     L.tri_synth_segment_free.argtypes = [C.c_void_p]
     L.tri_host_encode_google.restype = C.c_longlong
     L.tri_host_encode_google.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.tri_host_encode_google_payloads.restype = C.c_longlong
+    L.tri_host_encode_google_payloads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p]
     L.tri_synth_segment_index.restype = C.POINTER(C.c_uint8)
     L.tri_synth_segment_index.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.tri_synth_segment_terms.restype = C.POINTER(C.c_uint32)
@@ -246,8 +249,9 @@ class Device:
         _check(hip_lib().tri_dev_get_option(self.h, name.encode(), C.byref(v)))
         return v.value
 
-    def encode_google(self, docs, freqs, positions, term_first):
-        """The write side on the device (tri_encode_google): postings of len(term_first) - 1 terms -> (index bytes u8[], term table u32[n, 3])."""
+    def encode_google(self, docs, freqs, positions, term_first, payload_lens=None, payloads=None):
+        """The write side on the device (tri_encode_google / tri_encode_google_payloads): postings of len(term_first) - 1 terms ->
+        (index bytes u8[], term table u32[n, 3]).  payload_lens / payloads: per hit, its payload's length (0 .. 8) and bytes (u64, first byte low)."""
         d = np.ascontiguousarray(docs, dtype=np.uint32)
         f = np.ascontiguousarray(freqs, dtype=np.uint32)
         p = np.ascontiguousarray(positions, dtype=np.uint16)
@@ -256,9 +260,17 @@ class Device:
         terms = np.zeros((max(n, 1), 3), dtype=np.uint32)
         ln = C.c_size_t()
         L = hip_lib()
-        _check(L.tri_encode_google(self.h, d.ctypes.data, f.ctypes.data, p.ctypes.data, p.size, tf.ctypes.data, n, None, 0, C.byref(ln), terms.ctypes.data))
+        if payload_lens is None:
+            call = lambda out, cap: L.tri_encode_google(self.h, d.ctypes.data, f.ctypes.data, p.ctypes.data, p.size, tf.ctypes.data, n, out, cap, C.byref(ln), terms.ctypes.data)
+        else:
+            pl = np.ascontiguousarray(payload_lens, dtype=np.uint8)
+            pv = np.ascontiguousarray(payloads, dtype=np.uint64)
+            assert pl.size == p.size == pv.size
+            call = lambda out, cap: L.tri_encode_google_payloads(self.h, d.ctypes.data, f.ctypes.data, p.ctypes.data, pl.ctypes.data, pv.ctypes.data, p.size, tf.ctypes.data, n, out,
+                                                                  cap, C.byref(ln), terms.ctypes.data)  # fmt: skip
+        _check(call(None, 0))
         out = np.zeros(max(1, ln.value), dtype=np.uint8)
-        _check(L.tri_encode_google(self.h, d.ctypes.data, f.ctypes.data, p.ctypes.data, p.size, tf.ctypes.data, n, out.ctypes.data, out.size, C.byref(ln), terms.ctypes.data))
+        _check(call(out.ctypes.data, out.size))
         return out[: ln.value], terms[:n]
 
     def close(self):
@@ -267,18 +279,21 @@ class Device:
             self.h = C.c_void_p()
 
 
-def host_encode_google(docs, freqs, positions, term_first):
+def host_encode_google(docs, freqs, positions, term_first, payload_lens=None, payloads=None):
     """The HOST encoder (csrc/host/google_encoder.hpp: byte-identical to the reference's) over the same arguments: tests' checker of
     Device.encode_google."""
     d = np.ascontiguousarray(docs, dtype=np.uint32)
     f = np.ascontiguousarray(freqs, dtype=np.uint32)
     p = np.ascontiguousarray(positions, dtype=np.uint16)
     tf = np.ascontiguousarray(term_first, dtype=np.uint64)
+    pl = None if payload_lens is None else np.ascontiguousarray(payload_lens, dtype=np.uint8)
+    pv = None if payload_lens is None else np.ascontiguousarray(payloads, dtype=np.uint64)
     n = tf.size - 1
     terms = np.zeros((max(n, 1), 3), dtype=np.uint32)
-    out = np.zeros(int(d.size * 10 + p.size * 3 + 16 * (n + 1) + 64), dtype=np.uint8)
+    out = np.zeros(int(d.size * 10 + p.size * 13 + 16 * (n + 1) + 64), dtype=np.uint8)
     L = host_lib()
-    ln = L.tri_host_encode_google(d.ctypes.data, f.ctypes.data, p.ctypes.data, tf.ctypes.data, n, out.ctypes.data, out.size, terms.ctypes.data)
+    ln = L.tri_host_encode_google_payloads(d.ctypes.data, f.ctypes.data, p.ctypes.data, None if pl is None else pl.ctypes.data, None if pv is None else pv.ctypes.data,
+                                           tf.ctypes.data, n, out.ctypes.data, out.size, terms.ctypes.data)  # fmt: skip
     if ln < 0:
         raise TrinityError("host encoder failed")
     return out[:ln], terms[:n]
