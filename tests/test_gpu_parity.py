@@ -1180,8 +1180,10 @@ def test_google_encoder_on_the_device(T, dev):
     from trinity_amd import engine as E
 
     rng = np.random.default_rng(5)
-    for nterms in (1, 40, 400):
+    for nterms in (1, 40, 400, 3000):  # (3000 terms: a few hundred thousand postings — the scans run over several chunks, k_encode.hpp)
         docs, freqs, pos, tf = random_postings(rng, nterms)
+        if nterms == 3000:
+            assert docs.size > 4 * 32768
         got, gterms = dev.encode_google(docs, freqs, pos, tf)
         want, wterms = E.host_encode_google(docs, freqs, pos, tf)
         assert np.array_equal(gterms, wterms), nterms

@@ -40,40 +40,78 @@ __device__ __forceinline__ uint8_t *enc_put(uint8_t *o, const uint32_t v) {
         return o;
 }
 
-// exclusive prefix sums of n u32 values (out[n] = total) by ONE workgroup of 1024 threads walking the array: bookkeeping of an
-// encoder, not a hot path
-__global__ __launch_bounds__(1024) void k_enc_scan(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, const uint64_t n) {
-        __shared__ uint64_t wsum[16];
-        __shared__ uint64_t base_s;
+// Exclusive prefix sums of n u32 values, out[n] = the total — over the whole device in three launches: every workgroup adds up its chunk
+// of ENC_SCAN_CHUNK values (k_enc_scan_sums), ONE workgroup turns the chunk sums into chunk bases (k_enc_scan: the single-workgroup scan,
+// also what short arrays use on their own), every workgroup scans its chunk again on top of its base (k_enc_scan_chunks).
+constexpr uint32_t ENC_SCAN_CHUNK = 1024 * 32;
+__device__ __forceinline__ uint64_t enc_wave_incl(uint64_t x, const uint32_t lane) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+                const uint64_t y = __shfl_up(x, d, 64);
+                if ((int)lane >= d)
+                        x += y;
+        }
+        return x;
+}
+// the values [at0, at1) scanned by the calling workgroup (1024 threads) on top of `base`; returns (in every thread) base + their sum
+// (in and out may be the same array: a round reads its 1024 values before the barrier and writes them after)
+template <typename IN>
+__device__ __forceinline__ uint64_t enc_scan_range(const IN *in, uint64_t *out, const uint64_t at0, const uint64_t at1, uint64_t base,
+                                                   uint64_t (&wsum)[16], uint64_t &base_s) {
         const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
         if (tid == 0)
-                base_s = 0;
+                base_s = base;
         __syncthreads();
-        for (uint64_t at = 0; at < n; at += 1024) {
+        for (uint64_t at = at0; at < at1; at += 1024) {
                 const uint64_t i = at + tid;
-                const uint64_t v = i < n ? in[i] : 0;
-                uint64_t x = v;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                        const uint64_t y = __shfl_up(x, d, 64);
-                        if ((int)lane >= d)
-                                x += y;
-                }
+                const uint64_t v = i < at1 ? (uint64_t)in[i] : 0;
+                const uint64_t x = enc_wave_incl(v, lane);
                 if (lane == 63)
                         wsum[wave] = x;
                 __syncthreads();
                 uint64_t before = base_s;
                 for (uint32_t w = 0; w < wave; ++w)
                         before += wsum[w];
-                if (i < n)
+                if (i < at1 && out)
                         out[i] = before + x - v;
                 __syncthreads();
                 if (tid == 1023)
                         base_s = before + x;
                 __syncthreads();
         }
-        if (tid == 0)
-                out[n] = base_s;
+        return base_s;
+}
+__global__ __launch_bounds__(1024) void k_enc_scan(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, const uint64_t n) {
+        __shared__ uint64_t wsum[16];
+        __shared__ uint64_t base_s;
+        const uint64_t total = enc_scan_range(in, out, 0, n, 0, wsum, base_s);
+        if (threadIdx.x == 0)
+                out[n] = total;
+}
+// sums[c] = the sum of chunk c
+__global__ __launch_bounds__(1024) void k_enc_scan_sums(const uint32_t *__restrict__ in, uint64_t *__restrict__ sums, const uint64_t n) {
+        __shared__ uint64_t wsum[16];
+        __shared__ uint64_t base_s;
+        const uint64_t at0 = (uint64_t)blockIdx.x * ENC_SCAN_CHUNK, at1 = at0 + ENC_SCAN_CHUNK < n ? at0 + ENC_SCAN_CHUNK : n;
+        const uint64_t total = enc_scan_range(in, (uint64_t *)nullptr, at0, at1, 0, wsum, base_s);
+        if (threadIdx.x == 0)
+                sums[blockIdx.x] = total;
+}
+// sums[] in place: chunk sums -> chunk bases (exclusive), sums[nchunks] = the total
+__global__ __launch_bounds__(1024) void k_enc_scan_bases(uint64_t *__restrict__ sums, const uint64_t nchunks) {
+        __shared__ uint64_t wsum[16];
+        __shared__ uint64_t base_s;
+        const uint64_t total = enc_scan_range(sums, sums, 0, nchunks, 0, wsum, base_s);
+        if (threadIdx.x == 0)
+                sums[nchunks] = total;
+}
+__global__ __launch_bounds__(1024) void k_enc_scan_chunks(const uint32_t *__restrict__ in, const uint64_t *__restrict__ bases, uint64_t *__restrict__ out, const uint64_t n) {
+        __shared__ uint64_t wsum[16];
+        __shared__ uint64_t base_s;
+        const uint64_t at0 = (uint64_t)blockIdx.x * ENC_SCAN_CHUNK, at1 = at0 + ENC_SCAN_CHUNK < n ? at0 + ENC_SCAN_CHUNK : n;
+        const uint64_t total = enc_scan_range(in, out, at0, at1, bases[blockIdx.x], wsum, base_s);
+        if (threadIdx.x == 0 && at1 == n)
+                out[n] = total;
 }
 
 struct EncArgs {

@@ -2932,11 +2932,12 @@ extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, co
         struct Bufs {
                 uint32_t *docs = nullptr, *freqs = nullptr, *blk_first = nullptr, *blk_term = nullptr, *sizes = nullptr, *tails = nullptr;
                 uint16_t *pos = nullptr;
-                uint64_t *hit_off = nullptr, *term_first = nullptr, *blk_off = nullptr, *term_off = nullptr, *payloads = nullptr;
+                uint64_t *hit_off = nullptr, *term_first = nullptr, *blk_off = nullptr, *term_off = nullptr, *payloads = nullptr, *scan_sums = nullptr;
+                uint64_t scan_cap = 0;
                 uint8_t *out = nullptr, *plens = nullptr;
                 ~Bufs() {
                         for (void *p : {(void *)docs, (void *)freqs, (void *)blk_first, (void *)blk_term, (void *)sizes, (void *)tails, (void *)pos, (void *)hit_off,
-                                        (void *)term_first, (void *)blk_off, (void *)term_off, (void *)out, (void *)payloads, (void *)plens})
+                                        (void *)term_first, (void *)blk_off, (void *)term_off, (void *)out, (void *)payloads, (void *)plens, (void *)scan_sums})
                                 hipFree(p);
                 }
         } d;
@@ -2967,10 +2968,31 @@ extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, co
                 HIP_TRY(hipMemcpyAsync(d.blk_first, blk_first.data(), (nterms + 1) * 4, hipMemcpyHostToDevice, dev->stream));
                 HIP_TRY(hipMemcpyAsync(d.blk_term, blk_term.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, dev->stream));
                 // hits before every posting, then the blocks' sizes and their running sum
-                hipLaunchKernelGGL(k_enc_scan, dim3(1), dim3(1024), 0, dev->stream, d.freqs, d.hit_off, np);
+                // (exclusive scans over the whole device: chunk sums, chunk bases, chunks — k_encode.hpp)
+                auto scan = [&](const uint32_t *in, uint64_t *outp, const uint64_t n) -> int {
+                        const uint64_t nchunks = (n + ENC_SCAN_CHUNK - 1) / ENC_SCAN_CHUNK;
+                        if (nchunks <= 1) {
+                                hipLaunchKernelGGL(k_enc_scan, dim3(1), dim3(1024), 0, dev->stream, in, outp, n);
+                                return TRI_OK;
+                        }
+                        if (nchunks + 1 > d.scan_cap) {
+                                hipFree(d.scan_sums);
+                                d.scan_sums = nullptr;
+                                d.scan_cap = nchunks + 1;
+                                HIP_TRY(hipMalloc((void **)&d.scan_sums, d.scan_cap * 8));
+                        }
+                        hipLaunchKernelGGL(k_enc_scan_sums, dim3((uint32_t)nchunks), dim3(1024), 0, dev->stream, in, d.scan_sums, n);
+                        hipLaunchKernelGGL(k_enc_scan_bases, dim3(1), dim3(1024), 0, dev->stream, d.scan_sums, nchunks);
+                        hipLaunchKernelGGL(k_enc_scan_chunks, dim3((uint32_t)nchunks), dim3(1024), 0, dev->stream, in, (const uint64_t *)d.scan_sums, outp, n);
+                        return TRI_OK;
+                };
+                int rcs;
+                if ((rcs = scan(d.freqs, d.hit_off, np)))
+                        return rcs;
                 const EncArgs a{d.docs, d.freqs, d.pos, d.plens, d.payloads, d.hit_off, d.term_first, d.blk_first, d.blk_term, nblocks};
                 hipLaunchKernelGGL(k_enc_size, dim3((nblocks + 255) / 256), dim3(256), 0, dev->stream, a, d.sizes, d.tails);
-                hipLaunchKernelGGL(k_enc_scan, dim3(1), dim3(1024), 0, dev->stream, d.sizes, d.blk_off, (uint64_t)nblocks);
+                if ((rcs = scan(d.sizes, d.blk_off, (uint64_t)nblocks)))
+                        return rcs;
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(blk_off.data(), d.blk_off, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, dev->stream));
                 HIP_TRY(hipStreamSynchronize(dev->stream));
