@@ -120,7 +120,12 @@ def main():
 
     def create_set():  # a step's batches compiled afresh (no needed-bytes accounting: that walk is a bench-only diagnostic)
         dev.set_option("account_needed_bytes", 0)
-        out = [T.Batch(ixs[pt.codec], sp, pt.flags, topk=pt.topk) for pt, sp in zip(parts, shard_progs)]
+        out = []
+        for pt, sp in zip(parts, shard_progs):
+            t_ = time.perf_counter()
+            out.append(T.Batch(ixs[pt.codec], sp, pt.flags, topk=pt.topk))
+            if os.environ.get("BENCH_TRACE_CREATE"):
+                print(f"[create] {pt.name}: {len(sp)} queries {(time.perf_counter() - t_) * 1e3:.2f} ms", file=sys.stderr, flush=True)
         dev.set_option("account_needed_bytes", 1)
         return out
 
@@ -171,6 +176,14 @@ def main():
     #      read-back loop in which the next step's batches are compiled on the host while the current ones run on the device
     e2e = None
     if args.e2e_steps > 0:
+        # (the device handle recycles the batches' large buffers — tri_dev's pool: two sets are in flight in the loop below, so two are
+        #  created and released first, like the kernels' warm-up steps; a cold 15 GB hipMalloc costs 10 ms alone and 0.5 s next to an RCCL communicator)
+        t1 = time.perf_counter()
+        warm = [create_set(), create_set()]
+        create_cold_ms = (time.perf_counter() - t1) * 1e3 / 2
+        for ws in warm:
+            for b_ in ws:
+                b_.close()
         t1 = time.perf_counter()
         nxt = create_set()
         create_ms = (time.perf_counter() - t1) * 1e3
@@ -198,10 +211,10 @@ def main():
         loop_s = time.perf_counter() - t1
         for b_ in cur:
             b_.close()
-        e2e = {"batch_create_ms": create_ms, "readback_ms": readback_ms, "readback": "match counts" + (" + top-K blocks" if any(pt.topk for pt in parts) else "") + " to the host (docID sets stay in HBM)",
+        e2e = {"batch_create_ms": create_ms, "batch_create_cold_ms": create_cold_ms, "readback_ms": readback_ms, "readback": "match counts" + (" + top-K blocks" if any(pt.topk for pt in parts) else "") + " to the host (docID sets stay in HBM)",
                "steps": args.e2e_steps, "loop_ms_per_step": loop_s * 1e3 / args.e2e_steps,
                "queries_per_sec": nq_rank * world * args.e2e_steps / loop_s,
-               "note": "create (host planning + H2D) -> run -> read-back per step, the next step's batches compiled while the current ones run; the first create is outside the loop"}  # fmt: skip
+               "note": "create (host planning + H2D) -> run -> read-back per step, the next step's batches compiled while the current ones run; the first create is outside the loop; batch_create_cold_ms: before the device handle's buffer pool has anything to recycle"}  # fmt: skip
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

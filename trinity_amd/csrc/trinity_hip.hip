@@ -80,7 +80,76 @@ struct tri_dev {
         hipEvent_t ev_fork, ev_join;
         int cus;
         tri_options opt;
+        // The large buffers of a batch (output regions, score streams, term planes, decoded lists) are recycled from batch to batch: a
+        // caller that compiles a batch per step would otherwise hipMalloc and hipFree gigabytes per step — hipFree synchronises the device
+        // (the next batch cannot be compiled while the current one runs), and in a process that holds an RCCL communicator a 15 GB
+        // hipMalloc was measured at 0.5 - 1 s (bench.py under torch.distributed.run; 10 ms without).  One tri_dev per host thread: no lock.
+        struct Pool {
+                std::vector<std::pair<size_t, void *>> idle;    // (bytes, buffer) not in use
+                std::unordered_map<void *, size_t> size_of;     // every pooled buffer, in use or idle
+                size_t idle_bytes = 0;
+        } pool;
 };
+constexpr size_t POOL_MIN_BYTES = 1u << 20;   // smaller buffers are not worth pooling
+constexpr size_t POOL_IDLE_CAP = 64ull << 30; // idle buffers beyond this are given back to the device (largest first)
+
+// a buffer of at least `bytes`: an idle one of the pool that is not more than twice as large, else a fresh allocation
+static hipError_t pool_alloc(tri_dev *dev, void **out, const size_t bytes) {
+        if (bytes < POOL_MIN_BYTES)
+                return hipMalloc(out, bytes);
+        auto &P = dev->pool;
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < P.idle.size(); ++i)
+                if (P.idle[i].first >= bytes && P.idle[i].first <= 2 * bytes && (best == SIZE_MAX || P.idle[i].first < P.idle[best].first))
+                        best = i;
+        if (best != SIZE_MAX) {
+                *out = P.idle[best].second;
+                P.idle_bytes -= P.idle[best].first;
+                P.idle.erase(P.idle.begin() + (ptrdiff_t)best);
+                return hipSuccess;
+        }
+        const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        hipError_t e = hipMalloc(out, rounded);
+        if (e != hipSuccess && !P.idle.empty()) { // out of memory with idle buffers around: give them back and try again
+                (void)hipGetLastError();
+                for (auto &b : P.idle) {
+                        P.size_of.erase(b.second);
+                        hipFree(b.second);
+                }
+                P.idle.clear();
+                P.idle_bytes = 0;
+                e = hipMalloc(out, rounded);
+        }
+        if (e == hipSuccess)
+                P.size_of[*out] = rounded;
+        return e;
+}
+static void pool_free(tri_dev *dev, void *p) {
+        if (!p)
+                return;
+        if (!dev) {
+                hipFree(p);
+                return;
+        }
+        auto &P = dev->pool;
+        const auto it = P.size_of.find(p);
+        if (it == P.size_of.end()) { // (below POOL_MIN_BYTES: never pooled)
+                hipFree(p);
+                return;
+        }
+        P.idle.emplace_back(it->second, p);
+        P.idle_bytes += it->second;
+        while (P.idle_bytes > POOL_IDLE_CAP) {
+                size_t big = 0;
+                for (size_t i = 1; i < P.idle.size(); ++i)
+                        if (P.idle[i].first > P.idle[big].first)
+                                big = i;
+                P.idle_bytes -= P.idle[big].first;
+                P.size_of.erase(P.idle[big].second);
+                hipFree(P.idle[big].second);
+                P.idle.erase(P.idle.begin() + (ptrdiff_t)big);
+        }
+}
 
 struct tri_index {
         tri_dev *dev = nullptr;
@@ -202,38 +271,41 @@ struct tri_batch {
         bool synced = false;
         tri_batch_info info{};
         ~tri_batch() { // also runs when tri_batch_create fails half-way: nothing allocated so far is leaked
-                if (ix)
+                if (ix) {
                         hipSetDevice(ix->dev->device);
+                        if (ran && !synced) // (its large buffers go back to the device's pool: nothing of this batch may still be running on them)
+                                hipStreamSynchronize(ix->dev->stream);
+                }
                 for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k})
                         if (e)
                                 hipEventDestroy(e);
-                hipFree(d_sparse);
+                pool_free(ix ? ix->dev : nullptr, d_sparse);
                 hipFree(d_qthr);
                 hipFree(d_plane_terms);
-                hipFree(d_planes);
+                pool_free(ix ? ix->dev : nullptr, d_planes);
                 hipFree(d_qplane);
                 hipFree(d_fused);
                 hipFree(d_plan);
                 hipFree(d_tasks);
                 hipFree(d_sched);
                 hipFree(d_qterms);
-                hipFree(d_out);
+                pool_free(ix ? ix->dev : nullptr, d_out);
                 hipFree(d_counts);
                 hipFree(d_ticket);
-                hipFree(d_rich_allow);
+                pool_free(ix ? ix->dev : nullptr, d_rich_allow);
                 hipFree(d_hashes);
                 hipFree(d_qcounts);
                 hipFree(d_sterms);
                 hipFree(d_sweights);
-                hipFree(d_part_docs);
-                hipFree(d_part_scores);
+                pool_free(ix ? ix->dev : nullptr, d_part_docs);
+                pool_free(ix ? ix->dev : nullptr, d_part_scores);
                 hipFree(d_part_counts);
                 hipFree(d_top_docs);
                 hipFree(d_top_scores);
                 hipFree(d_top_counts);
-                hipFree(d_all_scores);
-                hipFree(d_rich_present);
-                hipFree(d_rich_freq);
+                pool_free(ix ? ix->dev : nullptr, d_all_scores);
+                pool_free(ix ? ix->dev : nullptr, d_rich_present);
+                pool_free(ix ? ix->dev : nullptr, d_rich_freq);
                 hipFree(d_task_hits);
                 hipFree(d_task_pos_base);
                 hipFree(d_rich_pool);
@@ -242,7 +314,7 @@ struct tri_batch {
                 hipFree(d_phrases);
                 hipFree(d_pterms);
                 hipFree(d_ptasks);
-                hipFree(d_pscore);
+                pool_free(ix ? ix->dev : nullptr, d_pscore);
         }
 };
 
@@ -295,6 +367,8 @@ extern "C" void tri_dev_close(tri_dev *d) {
         hipEventDestroy(d->ev_join);
         hipStreamDestroy(d->stream2);
         hipStreamDestroy(d->stream);
+        for (auto &b : d->pool.idle) // (buffers still in use belong to batches the caller has not destroyed: theirs to release)
+                hipFree(b.second);
         delete d;
 }
 
@@ -1950,7 +2024,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         // the rows k_term_planes fills, plus an all-zero row: what a k_planes slot WITHOUT term planes reads (so its sweep needs no select)
                         b->plw = ((ix->max_doc >> 17) + 2u) * (SPAN_BITS / 32u); // whole bitmap windows (k_and_dense reads SPAN_WORDS at a time) + a spare one
                         const size_t row = (size_t)PL_PLANES * b->plw * 4;
-                        HIP_TRY(hipMalloc((void **)&b->d_planes, (b->plane_terms.size() + 1) * row + 64));
+                        HIP_TRY(pool_alloc(dev, (void **)&b->d_planes, (b->plane_terms.size() + 1) * row + 64));
                         HIP_TRY(hipMemset((uint8_t *)b->d_planes + b->plane_terms.size() * row, 0, row + 64));
                 }
         }
@@ -1958,7 +2032,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 HIP_TRY(hipMalloc((void **)&b->d_qthr, (b->plan.size() + 1) * 8));
                 b->sparse_cap = (b->sparse_cap + 63u) & ~63u;
                 const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
-                HIP_TRY(hipMalloc((void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
         }
         CT_MARK("order + planes + scratch");
         b->out_capacity = off;
@@ -1968,7 +2042,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 return rc;
         for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k})
                 HIP_TRY(hipEventCreate(e));
-        HIP_TRY(hipMalloc((void **)&b->d_out, (off + 64) * 4));
+        HIP_TRY(pool_alloc(dev, (void **)&b->d_out, (off + 64) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_counts, (b->tasks.size() + 1) * 4));
         HIP_TRY(hipMalloc((void **)&b->d_ticket, 256));
         HIP_TRY(hipMalloc((void **)&b->d_qcounts, (nq + 1) * 8));
@@ -1977,7 +2051,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if ((rc = dev_upload(&b->d_phrases, b->phrases)) || (rc = dev_upload(&b->d_pterms, b->pterms)) || (rc = dev_upload(&b->d_ptasks, b->ptasks)))
                         return rc;
                 if (scored) {
-                        HIP_TRY(hipMalloc((void **)&b->d_pscore, (off + 64) * 8));
+                        HIP_TRY(pool_alloc(dev, (void **)&b->d_pscore, (off + 64) * 8));
                         HIP_TRY(hipMemset(b->d_pscore, 0, (off + 64) * 8));
                 }
         }
@@ -1985,12 +2059,12 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 if ((rc = dev_upload(&b->d_sterms, b->sterms)))
                         return rc;
                 b->rich_R = std::max<uint32_t>(b->rich_R, 1);
-                HIP_TRY(hipMalloc((void **)&b->d_rich_present, (off + 64) * 4));
-                HIP_TRY(hipMalloc((void **)&b->d_rich_freq, (off + 64) * 2 * b->rich_R));
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_rich_present, (off + 64) * 4));
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_rich_freq, (off + 64) * 2 * b->rich_R));
                 HIP_TRY(hipMalloc((void **)&b->d_task_hits, (b->tasks.size() + 1) * 4));
                 HIP_TRY(hipMalloc((void **)&b->d_task_pos_base, (b->tasks.size() + 1) * 8));
                 if (b->rich_allow) {
-                        HIP_TRY(hipMalloc((void **)&b->d_rich_allow, (off + 64) * 4));
+                        HIP_TRY(pool_alloc(dev, (void **)&b->d_rich_allow, (off + 64) * 4));
                         HIP_TRY(hipMemset(b->d_rich_allow, 0xff, (off + 64) * 4)); // (every other query's matches: all terms allowed)
                 }
         }
@@ -1999,9 +2073,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         return rc;
                 const size_t nt = b->tasks.size();
                 if (!topk)
-                        HIP_TRY(hipMalloc((void **)&b->d_all_scores, (off + 64) * 8));
-                HIP_TRY(hipMalloc((void **)&b->d_part_docs, (nt * topk + 1) * 4));
-                HIP_TRY(hipMalloc((void **)&b->d_part_scores, (nt * topk + 1) * 8));
+                        HIP_TRY(pool_alloc(dev, (void **)&b->d_all_scores, (off + 64) * 8));
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_part_docs, (nt * topk + 1) * 4));
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_part_scores, (nt * topk + 1) * 8));
                 HIP_TRY(hipMalloc((void **)&b->d_part_counts, (nt + 1) * 4));
                 HIP_TRY(hipMalloc((void **)&b->d_top_docs, (nq * topk + 1) * 4));
                 HIP_TRY(hipMalloc((void **)&b->d_top_scores, (nq * topk + 1) * 4));
