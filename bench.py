@@ -177,7 +177,7 @@ def main():
     e2e = None
     if args.e2e_steps > 0:
         # (the device handle recycles the batches' large buffers — tri_dev's pool: two sets are in flight in the loop below, so two are
-        #  created and released first, like the kernels' warm-up steps; a cold 15 GB hipMalloc costs 10 ms alone and 0.5 s next to an RCCL communicator)
+        #  created and released first, like the kernels' warm-up steps; a cold 15 GB hipMalloc was measured between 10 ms and 1 s)
         t1 = time.perf_counter()
         warm = [create_set(), create_set()]
         create_cold_ms = (time.perf_counter() - t1) * 1e3 / 2

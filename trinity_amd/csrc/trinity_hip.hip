@@ -82,8 +82,8 @@ struct tri_dev {
         tri_options opt;
         // The large buffers of a batch (output regions, score streams, term planes, decoded lists) are recycled from batch to batch: a
         // caller that compiles a batch per step would otherwise hipMalloc and hipFree gigabytes per step — hipFree synchronises the device
-        // (the next batch cannot be compiled while the current one runs), and in a process that holds an RCCL communicator a 15 GB
-        // hipMalloc was measured at 0.5 - 1 s (bench.py under torch.distributed.run; 10 ms without).  One tri_dev per host thread: no lock.
+        // (the next batch cannot be compiled while the current one runs), and a cold 15 GB hipMalloc was measured anywhere between 10 ms
+        // and 1 s (bench.py's end_to_end.batch_create_cold_ms).  One tri_dev per host thread: no lock.
         struct Pool {
                 std::vector<std::pair<size_t, void *>> idle;    // (bytes, buffer) not in use
                 std::unordered_map<void *, size_t> size_of;     // every pooled buffer, in use or idle
