@@ -149,7 +149,7 @@ void *tri_dev_stream(tri_dev *);
  *                         windows, 4 AccumulatedScore top-K CNF queries run over bit planes (k_planes); 0: every query decodes every list it names
  *   "planes_split"        a query that runs as bit planes (k_planes) is cut into this many docID ranges, one task each (default 0: two, or three in a batch that brings few tasks per workgroup; 65536 and up: cut by postings like k_fused's); the
  *                         ranges share the query's threshold, results do not depend on the cut
- *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 64) and the batch's uses repay one
+ *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 128) and the batch's uses repay one
  *                         decode of its list
  *   "account_needed_bytes" 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query; default 0)
  * ("fused" also takes 2: only pure unions run in one pass.)  The options are read when a batch is CREATED, except the two overlap_* ones,

@@ -71,7 +71,8 @@ struct tri_options {
         uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
         uint64_t planes = 7;     // term planes (k_planes.hpp), a bit set: 1 k_and probes them, 2 k_and_dense ORs them in, 4 top-K CNF queries run in k_planes; 0: off
         uint64_t planes_split = 0; // a k_planes query is cut into this many docID ranges (tasks) that share its threshold; 0: 2 or 3 by the batch's size; >= 65536: by postings like the other one-pass tasks.  cfg3's unions: 0 10.9 ms, 2 8.0, 3 8.5, 4 9.2 (a task has fixed costs)
-        uint64_t plane_div = 64; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list)
+        uint64_t plane_div = 128; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list);
+                                 // measured, step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the planes' build grows with it)
 };
 
 struct tri_dev {
