@@ -27,6 +27,7 @@
 #include "trinity_oracle.h" // corpus generator + hashing only (this repo's code)
 #include <cinttypes>
 #include <cstdio>
+#include <cstdlib>
 #include <iostream>
 #include <sstream>
 #include <string>
@@ -66,7 +67,8 @@ namespace {
                         }
                         termsTotal += ts.size();
                         richFnv = fnv_bytes(reinterpret_cast<const uint8_t *>(flat.data()), flat.size() * 4, richFnv);
-                        if (richDocs.size() < 24)
+                        static const size_t richLimit = getenv("REF_RICH_DOCS") ? size_t(atol(getenv("REF_RICH_DOCS"))) : 24; // (debugging aid: dump more documents in full)
+                        if (richDocs.size() < richLimit)
                                 richDocs.push_back(std::move(flat));
                 }
                 void consider(const docid_t id) override { ids.push_back(id); }

@@ -272,7 +272,57 @@ def random_fixture():
     print(path, len(recs), "records", len(dropped), "dropped", os.path.getsize(path), "bytes")
 
 
+# A multi-word phrase under an OR, inside a matchsome, on the excluded side of a NOT, as the optional side: DocsSetIterators::Phrase is an
+# iterator like any other (exec.cpp:253-449, docset_iterators.cpp:66-224).  AccumulatedScore and the default mode only: in DocumentsOnly
+# mode the reference crashes on a Phrase inside a root OR.
+PHRASE_TREES = [('"t{a} t{b}" OR t{c}', 0), ('t{c} OR "t{a} t{b}" OR "t{d} t{e}"', 0), ('t{e} ("t{a} t{b}" OR t{c})', 0), ('t{d} NOT ("t{a} t{b}" t{c})', 0),
+                ('t{d} NOT "t{a} t{b}"', 0), ('t{e} OR ("t{a} t{b}" t{c})', 0), ('t{d} <"t{a} t{b}">', 0), ('("t{a} t{b}" OR "t{b} t{c}") t{d}', 0),
+                ('"t{a} t{b} t{c}" OR (t{d} t{e})', 0), ('["t{a} t{b}", t{c}, t{d}]', 2), ('["t{a} t{b}", "t{c} t{d}", t{e}]', 1), ('t{e} ["t{a} t{b}", t{c}, t{d}]', 2)]
+
+
+def phrase_tree_fixture():
+    """tests/golden/ref_phrase_trees.json: the reference's compiled tree and its answers (top-10 + score sum, and the default mode's matched
+    terms and hits) for phrases inside trees, on the tiny and the dense corpus.  The GPU planner does not lower these shapes yet (it leaves
+    such a query out with TRI_ERR_UNSUPPORTED): the fixture pins the oracle for the day it does."""
+    import subprocess
+
+    out = {"corpora": {}, "results": []}
+    for name in ("tiny", "dense"):
+        D, V, slots, seed = CORPORA[name]
+        out["corpora"][name] = {"D": D, "V": V, "slots": slots, "seed": seed}
+        rows = [[0, 1, 2, 3, 4], [1, 0, 2, 5, 9], [3, 7, 11, 0, 2], [2, 3, 0, 1, 6]] + O.gen_queries(V, 1337, 6, 5).tolist()
+        for row in rows:
+            a, b, c, d, e = [int(x) for x in row]
+            for tpl, mn in PHRASE_TREES:
+                q = tpl.format(a=a, b=b, c=c, d=d, e=e)
+                cmds = [f"tree {mn} {q}"] + ([f"querysome 2 10 {mn} {q}", f"querysome 0 0 {mn} {q}"] if mn else [f"query 2 10 {q}", f"query 0 0 {q}"])
+                try:
+                    got = subprocess.run([O.REF_DRIVER, str(D), str(V), str(slots), str(seed)], input="\n".join(cmds) + "\n", capture_output=True, text=True, check=True, timeout=60)
+                    res = [json.loads(l) for l in got.stdout.splitlines() if l.startswith("{")]
+                    assert len(res) == 3
+                except (subprocess.CalledProcessError, subprocess.TimeoutExpired, AssertionError):
+                    out.setdefault("dropped", []).append([name, q])
+                    continue
+                t, r2, r0 = res
+                rec = {"corpus": name, "q": q, "min": mn, "tree": t["tree"], "n": r2["n"], "score_sum": r2["score_sum"], "top": r2.get("top", []),
+                       "rich_n": r0["n"], "terms_total": r0["terms_total"], "hits_total": r0["hits_total"], "rich_fnv": r0["rich_fnv"]}  # fmt: skip
+                # By rule, not by result: where a phrase can FAIL on a document that the query still matches while its terms hold the document —
+                # the optional side, a matchsome with a threshold above 1 — the reference's default mode reports those terms with the right
+                # frequency but the hit array of whatever document they were last materialised for (positions that do not ascend, position 0 of
+                # a payload-less hit: `t3 <"t0 t1">` on the tiny corpus, 20 of 689 documents).  The hash of that stream is left out; the
+                # match count, the term and hit totals and the scored answers stay.
+                if '<"' in q or (mn >= 2 and '"' in q):
+                    rec["rich_fnv"] = None
+                out["results"].append(rec)
+    path = os.path.join(HERE, "ref_phrase_trees.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print(path, len(out["results"]), "records", len(out.get("dropped", [])), "dropped", os.path.getsize(path), "bytes")
+
+
 def main():
+    if "--phrase-trees-only" in sys.argv:
+        return phrase_tree_fixture()
     if "--trees-only" in sys.argv:
         return tree_fixture()
     if "--random-only" in sys.argv:
@@ -280,6 +330,7 @@ def main():
     edge_fixture()
     tree_fixture()
     random_fixture()
+    phrase_tree_fixture()
     for name, (D, V, slots, seed) in CORPORA.items():
         cmds = commands_for(name, D, V, slots, seed)
         res = O.run_ref_driver(D, V, slots, seed, cmds)

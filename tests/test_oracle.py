@@ -496,6 +496,34 @@ def test_random_trees_equal_the_reference():
     assert len(g["results"]) >= 350 and ops >= {O.OP_TERM, O.OP_AND, O.OP_OR, O.OP_NOT, O.OP_OPT, O.OP_SOME}
 
 
+def test_phrases_inside_trees_equal_the_reference():
+    """tests/golden/ref_phrase_trees.json: a multi-word phrase under an OR, inside a matchsome, under a NOT / an <optional> — 240 trees as the
+    reference compiled them (tiny and dense corpus), with its answers in AccumulatedScore and default mode (DocumentsOnly crashes the reference
+    on these).  The oracle's iterators reproduce them: Phrase is an iterator like any other (docset_iterators.cpp:66-224).
+    (The GPU planner still leaves these shapes out, per query — tests/test_gpu_parity.py::test_shapes_still_refused; this pins what it will
+    have to return.)"""
+    g = json.load(open(os.path.join(GOLDEN, "ref_phrase_trees.json")))
+    ixs = {name: O.Index.generate(c["D"], c["V"], c["slots"], c["seed"]) for name, c in g["corpora"].items()}
+    ops, nonempty, hashed = set(), 0, 0
+    for r in g["results"]:
+        ix = ixs[r["corpus"]]
+        prog = np.array(O.program_from_exec_tree(r["tree"]), dtype=np.uint32)
+        ops |= {int(t) >> 28 for t in prog}
+        docs, scores = ix.exec(prog, O.FLAG_ACCUM_SCORE)
+        assert len(docs) == r["n"] and abs(float(np.sum(scores)) - r["score_sum"]) <= 1e-6 * max(1.0, r["score_sum"]), r["q"]
+        td, ts = ix.topk(docs, scores, 10)
+        assert td.tolist() == [x[0] for x in r["top"]], r["q"]
+        np.testing.assert_allclose(ts, [x[1] for x in r["top"]], rtol=1e-5, atol=0)
+        wdocs, wflat, tt, ht = ix.exec_rich(prog)
+        assert len(wdocs) == r["rich_n"] and tt == r["terms_total"] and ht == r["hits_total"], r["q"]
+        if r["rich_fnv"] is not None:  # (None: a shape whose default-mode positions the reference itself gets wrong — make_golden.py says which, by rule)
+            assert str(O.fnv1a_u32_stream(wflat)) == r["rich_fnv"], r["q"]
+            hashed += 1
+        nonempty += r["n"] > 0
+    assert hashed >= 180
+    assert len(g["results"]) == 240 and nonempty >= 200 and ops >= {O.OP_TERM, O.OP_AND, O.OP_OR, O.OP_NOT, O.OP_OPT, O.OP_SOME, O.OP_PHRASE}
+
+
 def test_edge_hit_payloads_match_reference(edge):
     """`hits <term>` records carry the reference's hash over every document's (freq, id) and every hit's (pos, payloadLen, the eight bytes
     of term_hit::payload) — payload lengths that change from hit to hit, the stale high bytes a shorter payload leaves in the word."""
