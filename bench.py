@@ -111,19 +111,20 @@ def main():
             t0 = time.time()
             ixs[pt.codec] = T.Index.from_segment(dev, segs[pt.codec])
             upload_s += time.time() - t0  # one-time: format walk + directory / delta-stream / cell-index build on the host, then PCIe
-    batches, shard_progs = [], []
+    batches, shard_progs, shard_flat = [], [], []
     for pt in parts:
         mine = pt.programs[rank::world]  # interleaved shard: same mix on every rank
         shard_progs.append(mine)
-        batches.append(T.Batch(ixs[pt.codec], mine, pt.flags, topk=pt.topk))
+        shard_flat.append(T.engine.flatten(mine))  # the (program words, tri_query table) pair the C-ABI takes: what a C++ caller hands over
+        batches.append(T.Batch(ixs[pt.codec], None, pt.flags, topk=pt.topk, flat=shard_flat[-1]))
     nq_rank = sum(len(p) for p in shard_progs)
 
     def create_set():  # a step's batches compiled afresh (no needed-bytes accounting: that walk is a bench-only diagnostic)
         dev.set_option("account_needed_bytes", 0)
         out = []
-        for pt, sp in zip(parts, shard_progs):
+        for pt, sp, fl in zip(parts, shard_progs, shard_flat):
             t_ = time.perf_counter()
-            out.append(T.Batch(ixs[pt.codec], sp, pt.flags, topk=pt.topk))
+            out.append(T.Batch(ixs[pt.codec], None, pt.flags, topk=pt.topk, flat=fl))
             if os.environ.get("BENCH_TRACE_CREATE"):
                 print(f"[create] {pt.name}: {len(sp)} queries {(time.perf_counter() - t_) * 1e3:.2f} ms", file=sys.stderr, flush=True)
         dev.set_option("account_needed_bytes", 1)

@@ -17,8 +17,9 @@
 extern "C" {
 #endif
 
-#define TRI_ABI_VERSION 5 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
-                             4: tri_batch_info grew (term planes, k_planes), tri_batch_query_status, tri_comm_create_custom; 5: tri_encode_google_payloads */
+#define TRI_ABI_VERSION 6 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
+                             4: tri_batch_info grew (term planes, k_planes), tri_batch_query_status, tri_comm_create_custom; 5: tri_encode_google_payloads;
+                             6: tri_batch_info.create_ms / create_plan_ms, options plane_max_bytes / plan_threads */
 
 /* status codes */
 #define TRI_OK 0
@@ -123,6 +124,9 @@ typedef struct tri_batch_info {
         uint64_t planes_queries;
         uint64_t plane_terms, plane_bytes, term_planes_decoded_bytes;
         uint64_t unsupported_queries; /* queries the planner left out of the batch (tri_batch_query_status) */
+        /* what tri_batch_create itself took: all of it (host planning on the handle's host threads + arena / pool bookkeeping + enqueueing the plan's
+         * one copy on the upload stream), and the host planner's share */
+        float create_ms, create_plan_ms;
 } tri_batch_info;
 
 const char *tri_last_error(void);
@@ -152,6 +156,10 @@ void *tri_dev_stream(tri_dev *);
  *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 128) and the batch's uses repay one
  *                         decode of its list
  *   "account_needed_bytes" 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query; default 0)
+ *   "plane_max_bytes"     scratch budget of a batch's term planes (default 8 GiB): the terms eligible for a plane are the longest lists that fit
+ *   "plan_threads"        host threads tri_batch_create plans large batches with (default 0: up to 16, by the host's cores; 1: the calling thread
+ *                         only).  The threads belong to the handle, are pinned to distinct CPUs next to the creating thread's, and keep polling for
+ *                         about 3 ms after a batch before they sleep (csrc/host_pool.hpp says why); read when the first large batch is created
  * ("fused" also takes 2: only pure unions run in one pass.)  The options are read when a batch is CREATED, except the two overlap_* ones,
  * which tri_batch_run reads (they change how existing batches are launched).  Unknown names fail with TRI_ERR_INVALID. */
 int tri_dev_set_option(tri_dev *, const char *name, uint64_t value);
@@ -258,6 +266,9 @@ int tri_batch_docset_hashes(tri_batch *, uint64_t *hashes /* [nq] */);
 typedef struct tri_cbatch tri_cbatch;
 int tri_cbatch_create(tri_batch *const *parts, size_t n, tri_cbatch **out);
 void tri_cbatch_destroy(tri_cbatch *);
+/* status[q]: TRI_OK, or TRI_ERR_UNSUPPORTED when the planner left query q out of any part (tri_batch_query_status): its answer over the
+ * collection would be incomplete, the caller keeps its CPU path for it */
+int tri_cbatch_query_status(const tri_cbatch *, int32_t *status /* [nq] */);
 int tri_cbatch_run(tri_cbatch *);
 int tri_cbatch_sync(tri_cbatch *);
 int tri_cbatch_match_counts(tri_cbatch *, uint64_t *counts /* [nq] */);

@@ -877,7 +877,7 @@ def test_shapes_still_refused(T, dev):
     texts = ["t0 t1", 't0 OR "t1 t2"', "t3 OR t4", 't0 NOT ("t1 t2" t3)', "t0 OR (t1 t2) OR (t3 t4) OR (t5 t6) OR (t7 t8)", '"t0 t1"']
     progs = [O.parse_query(t) for t in texts]
     for flags, topk in ((T.FLAG_DOCUMENTS_ONLY, 0), (T.FLAG_ACCUMULATED_SCORE, 10), (T.FLAG_MATCHED_TERMS, 0)):
-        b = T.Batch(w.ix, progs, flags, topk=topk)
+        b = T.Batch(w.ix, progs, flags, topk=topk, allow_unsupported=True)
         assert b.query_status().tolist() == [0, -3, 0, -3, -3, 0] and b.info()["unsupported_queries"] == 3
         b.run()
         b.sync()
@@ -903,14 +903,14 @@ def test_large_batch_is_lowered_in_fragments(T, dev):
     texts = [shapes[i % len(shapes)].format(*rng.choice(40, 3, replace=False)) for i in range(6000)]
     progs = [O.parse_query(t, some_min=2) for t in texts]
     for flags, topk in ((T.FLAG_DOCUMENTS_ONLY, 0), (T.FLAG_ACCUMULATED_SCORE, 10)):
-        big = T.Batch(w.ix, progs, flags, topk=topk)
+        big = T.Batch(w.ix, progs, flags, topk=topk, allow_unsupported=True)
         big.run()
         big.sync()
         st, counts = big.query_status(), big.counts()
         tk = big.topk_results() if topk else None
         assert int((st != 0).sum()) == 600 == big.info()["unsupported_queries"]  # (the phrase under an OR: every 10th query)
         for lo in range(0, len(progs), 500):
-            small = T.Batch(w.ix, progs[lo : lo + 500], flags, topk=topk)
+            small = T.Batch(w.ix, progs[lo : lo + 500], flags, topk=topk, allow_unsupported=True)
             small.run()
             small.sync()
             assert small.query_status().tolist() == st[lo : lo + 500].tolist()

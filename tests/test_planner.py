@@ -1,0 +1,130 @@
+"""The host planner behind tri_batch_create (csrc/planner.hpp) on a CPU-only machine, through libtrinity_host.so (csrc/host/plan_host.cpp):
+what every kernel relies on without checking — a query's tasks are consecutive and cover its windows / tiles exactly once, output regions
+never overlap and stay inside the batch's capacity, the schedule is a permutation grouped by kernel with the heavier tasks first, every
+term position that names a plane row names the right term — and that the plan does not depend on how many host threads made it."""
+import numpy as np
+import pytest
+
+import trinity_amd as T
+from trinity_amd import hostplan as HP
+from trinity_amd import workloads as W
+
+
+@pytest.fixture(scope="module")
+def world():
+    T.build.build_host()
+    D, V = 200_000, 20_000
+    segs = {c: T.Segment(D, V, 10, 42, codec=c) for c in (T.engine.CODEC_GOOGLE, T.engine.CODEC_LUCENE)}
+    return D, V, segs, {c: HP.HostIndex.from_segment(s) for c, s in segs.items()}
+
+
+OPTION_SETS = ({}, {"dense_min_postings": 0}, {"planes": 0}, {"plane_div": 1 << 30, "dense_min_postings": 0}, {"dense_min_postings": 0, "planes_split": 5},
+               {"dense_min_postings": 0, "planes_split": 1 << 20, "fused_task_cost": 4096}, {"dense_task_cost": 1000, "dense_min_postings": 0},
+               {"plane_div": 1 << 30, "plane_max_bytes": 300_000})  # fmt: skip
+
+
+def check_plan(p, nq):
+    s = p.s
+    plan, tasks, sched = p.plan, p.tasks, p.sched
+    # queries: plan order = query order; every lowered query knows its slot
+    assert np.all(np.diff(plan["qid"].astype(np.int64)) > 0)
+    lowered = p.slot_of_query[:nq] != 0xFFFFFFFF
+    assert int(lowered.sum()) == s["n_plan"]
+    assert np.array_equal(plan["qid"], np.nonzero(lowered)[0]) and np.array_equal(p.slot_of_query[:nq][lowered], np.arange(s["n_plan"]))
+    # tasks: consecutive per query, in plan order, covering [0, n) of the query's windows / tiles without gaps
+    assert np.array_equal(plan["first_task"].astype(np.int64), np.concatenate([[0], np.cumsum(plan["ntasks"].astype(np.int64))[:-1]]))
+    assert int(plan["ntasks"].sum()) == s["n_tasks"] and np.all(plan["ntasks"] >= 1)
+    assert np.array_equal(tasks["slot"], np.repeat(np.arange(s["n_plan"], dtype=np.uint32), plan["ntasks"]))
+    first = np.zeros(s["n_tasks"], dtype=bool)
+    first[plan["first_task"]] = True
+    assert np.all(tasks["begin"][first] == 0) and np.all(tasks["begin"] < tasks["end"])
+    assert np.all(tasks["begin"][~first] == tasks["end"][:-1][~first[1:]])
+    # one kind per query
+    kind_q = tasks["kind"][plan["first_task"]]
+    assert np.array_equal(tasks["kind"], np.repeat(kind_q, plan["ntasks"]))
+    # output regions: the queries' regions tile [0, out_capacity); a task's region starts inside its query's and tasks ascend
+    assert np.array_equal(plan["out_off"], np.concatenate([[0], np.cumsum(plan["out_cap"].astype(np.uint64))[:-1]]).astype(np.uint64))
+    assert int(plan["out_off"][-1] + plan["out_cap"][-1]) == s["out_capacity"] if s["n_plan"] else s["out_capacity"] == 0
+    q_off, q_cap = np.repeat(plan["out_off"], plan["ntasks"]), np.repeat(plan["out_cap"].astype(np.uint64), plan["ntasks"])
+    assert np.all(tasks["out_off"] >= q_off) and np.all((tasks["out_off"] <= q_off + q_cap))
+    same_q = tasks["slot"][1:] == tasks["slot"][:-1]
+    assert np.all(tasks["out_off"][1:][same_q] >= tasks["out_off"][:-1][same_q])
+    # candidate tiles: a task's region is exactly its tiles' candidates
+    cand = tasks["kind"] == HP.TASK_CAND
+    assert np.array_equal(tasks["out_off"][cand], q_off[cand] + tasks["begin"][cand].astype(np.uint64) * 8192)
+    # schedule: a permutation, grouped by kernel in launch order, the per-kernel counts as reported
+    assert np.array_equal(np.sort(sched), np.arange(s["n_tasks"], dtype=np.uint32))
+    counts = [s["n_dense"], s["n_cand"], s["n_fused"], s["n_fused16"], s["n_fusedgen"], s["n_planes"], s["n_planes8"]]
+    assert sum(counts) == s["n_tasks"]
+    at = 0
+    for kind, c in zip(HP.SCHED_ORDER, counts):
+        assert np.all(tasks["kind"][sched[at : at + c]] == kind)
+        at += c
+    assert s["dense_queries"] + s["cand_queries"] + s["fused_queries"] + s["planes_queries"] == s["n_plan"]
+    # planes: a term position that names a row names its own term's row
+    if s["n_qplane"]:
+        qt, qp, rows = p.qterms & 0x3FFFFFFF, p.qplane, p.plane_terms
+        named = qp != 0xFFFFFFFF
+        assert np.all(qp[named] < len(rows)) and np.array_equal(rows[qp[named]], qt[named])
+        assert np.all(np.diff(rows.astype(np.int64)) > 0)
+
+
+@pytest.mark.parametrize("wl", ["cfg2", "cfg3", "cfg4", "cfg5"])
+def test_plan_invariants_and_thread_independence(world, wl):
+    D, V, segs, hix = world
+    nq = 3000
+    parts, _ = W.build_parts(wl, D, V, 10, 42, nq)
+    for pt in parts:
+        for opts in OPTION_SETS:
+            p1 = HP.HostPlan(hix[pt.codec], pt.programs, pt.flags, pt.topk, threads=1, options=opts)
+            check_plan(p1, len(pt.programs))
+            for th in (3, 8):
+                pn = HP.HostPlan(hix[pt.codec], pt.programs, pt.flags, pt.topk, threads=th, options=opts)
+                assert pn.s == p1.s, opts
+                assert np.array_equal(pn.block, p1.block), (wl, opts, th)  # the same bytes go to the device whatever the thread count
+                assert np.array_equal(pn.slot_of_query, p1.slot_of_query) and np.array_equal(pn.qstatus, p1.qstatus)
+                pn.close()
+            p1.close()
+
+
+def test_heavier_tasks_are_scheduled_first(world):
+    D, V, segs, hix = world
+    parts, _ = W.build_parts("cfg2", D, V, 10, 42, 4000)
+    p = HP.HostPlan(hix[parts[0].codec], parts[0].programs, parts[0].flags, 0, threads=4, options={"dense_min_postings": 100_000})
+    tasks, sched = p.tasks, p.sched
+    # candidate-tile tasks of a 2-term AND: cost = tiles x (lead postings + 32 x min(other blocks, lead documents)) / tiles; the schedule's
+    # order is by cost octave + 3 bits, so within a kernel the spans never grow by more than one bucket (12.5 %) from one task to the next
+    span = (tasks["end"] - tasks["begin"]).astype(np.int64)
+    assert p.s["n_dense"] > 0 and p.s["n_cand"] > 0
+    dense = sched[: p.s["n_dense"]]
+    assert span[dense[0]] >= span[dense[-1]]
+    p.close()
+
+
+def test_unsupported_shapes_and_malformed_programs(world):
+    D, V, segs, hix = world
+    import oracle_lib as O
+
+    texts = ["t0 t1", 't0 OR "t1 t2"', "t3 OR t4", "t0 OR (t1 t2) OR (t3 t4) OR (t5 t6) OR (t7 t8)"]
+    progs = [O.parse_query(t) for t in texts] * 700  # (enough queries for several fragments)
+    p = HP.HostPlan(hix[1], progs, T.FLAG_DOCUMENTS_ONLY, threads=4)
+    assert p.qstatus.tolist() == [0, -3, 0, -3] * 700 and p.s["unsupported_queries"] == 1400 and p.s["n_plan"] == 1400
+    check_plan(p, len(progs))
+    p.close()
+    bad = progs[:2000] + [np.array([T.tok(T.OP_AND, 2)], dtype=np.uint32)] + progs[:100]
+    with pytest.raises(T.TrinityError, match="malformed"):
+        HP.HostPlan(hix[1], bad, T.FLAG_DOCUMENTS_ONLY, threads=4)
+
+
+def test_plane_budget_caps_the_eligible_terms(world):
+    D, V, segs, hix = world
+    parts, _ = W.build_parts("cfg3", D, V, 10, 42, 2000)
+    pt = parts[0]
+    rows = []
+    for budget in (1 << 40, 2_000_000, 300_000):
+        p = HP.HostPlan(hix[pt.codec], pt.programs, pt.flags, pt.topk, threads=2, options={"plane_div": 1 << 30, "dense_min_postings": 0, "plane_max_bytes": budget})
+        check_plan(p, len(pt.programs))
+        assert p.s["n_plane_terms"] * 3 * p.s["plw"] * 4 <= max(budget, 3 * p.s["plw"] * 4)
+        rows.append(p.s["n_plane_terms"])
+        p.close()
+    assert rows[0] > rows[1] > rows[2] >= 1

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(PKG)
 LIB_HIP = os.path.join(PKG, "libtrinity_hip.so")
 LIB_HOST = os.path.join(PKG, "libtrinity_host.so")
 HIP_SRCS = [os.path.join(PKG, "csrc", "trinity_hip.hip")]
-HOST_SRCS = [os.path.join(PKG, "csrc", "host", "synth.cpp")]
+HOST_SRCS = [os.path.join(PKG, "csrc", "host", "synth.cpp"), os.path.join(PKG, "csrc", "host", "plan_host.cpp")]
 
 
 def _newer(target, deps):
@@ -21,8 +21,7 @@ def _newer(target, deps):
 
 def _deps(srcs):
     out = list(srcs) + [os.path.join(ROOT, "include", "trinity_hip.h")]
-    for s in srcs:
-        d = os.path.dirname(s)
+    for d in {os.path.dirname(s) for s in srcs} | {os.path.join(PKG, "csrc")}:  # (the host tools include the planner's headers of csrc/)
         out += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hpp", ".h", ".cuh"))]
     return out
 
@@ -43,7 +42,7 @@ def build_hip(force=False):
 
 def build_host(force=False):
     if force or _newer(LIB_HOST, _deps(HOST_SRCS)):
-        cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_HOST] + HOST_SRCS
+        cmd = ["g++", "-O3", "-std=c++17", "-shared", "-fPIC", "-pthread", "-o", LIB_HOST] + HOST_SRCS
         subprocess.run(cmd, check=True)
     return LIB_HOST
 

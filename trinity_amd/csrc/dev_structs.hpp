@@ -83,6 +83,22 @@ constexpr uint32_t PL_WORDS = PL_W / 32;  // words of one plane per window
 constexpr uint32_t PL_NONE = 0xffffffffu; // "this term has no plane in this batch"
 constexpr uint32_t PL_PLANES = 3;         // planes per term — A: the document holds the term; B: its frequency there is not 1; C: nor 2
 constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64)
+// ---- geometry the host planner (planner.hpp) and the kernels share
+constexpr int TILE_BLOCKS = 256;               // k_and: lead blocks per candidate tile (one 32-candidate row per lane)
+constexpr int TILE_CANDS = TILE_BLOCKS * 32;
+constexpr uint32_t SPAN_BITS = 1u << 17;       // docIDs per bitmap window (k_and_dense)
+constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
+constexpr uint32_t CELL_LOG2 = 10;             // docID cells of the per-term block index (DevTerm::win_off)
+constexpr uint32_t CELL_DOCS = 1u << CELL_LOG2;
+constexpr uint32_t CELLS_PER_SPAN = SPAN_BITS / CELL_DOCS;
+#ifndef TRI_FUS_CELLS
+#define TRI_FUS_CELLS 14
+#endif
+constexpr uint32_t FUS_CELLS = TRI_FUS_CELLS;  // k_fused: docID cells (of CELL_DOCS) per window (14: 56 KB of words, two 512-thread workgroups per CU)
+constexpr uint32_t FUS_W = FUS_CELLS * CELL_DOCS;
+constexpr uint32_t PLK_MAX_SPARSE = 6;         // k_planes: slots whose lists are decoded per task (LDS planes); the planner sends wider queries to k_fused
+constexpr uint32_t PLK_NS_SMALL = 5;           // k_planes: the instantiation for queries of up to this many slots keeps six words per slot in registers
+constexpr uint32_t TOPK_MAX = 256;             // AccumulatedScore: largest K of a top-K batch
 constexpr uint32_t FUS_MAX_SLOTS = 8;
 constexpr uint32_t FUS_MAX_LEAVES = 16; // scorer leaves of a general tree
 // planner -> kernel: how a fused query's terms map onto the window words

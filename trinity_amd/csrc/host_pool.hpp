@@ -1,0 +1,165 @@
+// host_pool.hpp — a small persistent pool of host threads for the planner (planner.hpp): tri_batch_create lowers, classifies and cuts a
+// batch's queries in parallel, and a batch is compiled per step by callers that do not keep batches around, so the threads outlive
+// the call.  Host-only C++17, no HIP; new code, no reference source.
+//
+// What the measurements on the micro-VMs this engine runs in said (tools/plan_probe.py): starting a std::thread costs
+// 4 - 5 ms; a futex wake-up puts the woken thread on the WAKER's CPU (the guest exposes no cache topology, so the scheduler does not look
+// for an idle core), i.e. seven woken workers ran one after the other on one core; sched_yield() sleeps for milliseconds.  Hence: workers
+// are pinned to distinct CPUs of the process's affinity mask (next to the creating thread's CPU, so that the ranks of a node do not pile
+// onto the same cores), they keep POLLING for `hot_us` microseconds after their last job before they sleep on a condition variable
+// (a caller that compiles a batch per step finds them awake: a job is picked up in about a microsecond; from sleep it takes 100 - 300 us),
+// and nobody yields.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <pthread.h>
+#include <sched.h>
+#include <thread>
+#include <vector>
+
+class HostPool {
+      public:
+        // `threads` includes the calling thread: threads - 1 workers are started (fewer when thread creation fails — the pool then
+        // simply has fewer hands; run() still completes on the caller alone)
+        explicit HostPool(unsigned threads, bool pin = true, unsigned hot_us = 3000) : hot_us_(hot_us) {
+                std::vector<int> cpus;
+                int base = 0;
+                if (pin) {
+                        cpu_set_t allowed;
+                        CPU_ZERO(&allowed);
+                        if (!sched_getaffinity(0, sizeof allowed, &allowed))
+                                for (int c = 0; c < CPU_SETSIZE; ++c)
+                                        if (CPU_ISSET(c, &allowed))
+                                                cpus.push_back(c);
+                        const int here = sched_getcpu();
+                        for (size_t i = 0; i < cpus.size(); ++i)
+                                if (cpus[i] == here)
+                                        base = (int)i;
+                }
+                for (unsigned i = 1; i < threads; ++i) {
+                        try {
+                                workers_.emplace_back([this] { loop(); });
+                        } catch (...) {
+                                break;
+                        }
+                        if (cpus.size() > 1) {
+                                cpu_set_t s;
+                                CPU_ZERO(&s);
+                                CPU_SET(cpus[(size_t)(base + (int)i) % cpus.size()], &s);
+                                pthread_setaffinity_np(workers_.back().native_handle(), sizeof s, &s); // (best effort)
+                        }
+                }
+        }
+        ~HostPool() {
+                {
+                        std::lock_guard<std::mutex> g(m_);
+                        stop_ = true;
+                        ++gen_;
+                        gen_hint_.store(gen_, std::memory_order_release);
+                }
+                cv_.notify_all();
+                for (auto &t : workers_)
+                        t.join();
+        }
+        HostPool(const HostPool &) = delete;
+        HostPool &operator=(const HostPool &) = delete;
+        unsigned size() const { return (unsigned)workers_.size() + 1; }
+
+        // fn(k) for every k in [0, n), dealt out dynamically over the workers and the caller; returns when all are done.  fn must not
+        // throw (the planner's bodies catch and record).  Not re-entrant: one run() at a time per pool (one tri_dev per host thread).
+        void run(unsigned n, const std::function<void(unsigned)> &fn) {
+                if (!n)
+                        return;
+                if (n == 1 || workers_.empty()) {
+                        for (unsigned k = 0; k < n; ++k)
+                                fn(k);
+                        return;
+                }
+                uint64_t gen;
+                bool wake;
+                {
+                        std::lock_guard<std::mutex> g(m_);
+                        gen = ++gen_;
+                        fn_ = &fn;
+                        n_.store(n, std::memory_order_relaxed);
+                        left_.store(n, std::memory_order_relaxed);
+                        // a job is taken by a compare-and-swap on (generation, next index): a worker that wakes up late for an earlier
+                        // generation can neither take nor skip a job of this one
+                        state_.store(gen << 32, std::memory_order_release);
+                        gen_hint_.store(gen, std::memory_order_release); // (the polling workers see this)
+                        wake = sleepers_ != 0;
+                }
+                if (wake)
+                        cv_.notify_all();
+                work(gen);
+                // (the caller waits for the stragglers by polling, and on the clock should a worker have been descheduled)
+                for (uint32_t spin = 0; left_.load(std::memory_order_acquire); ++spin)
+                        if (spin > (1u << 22)) {
+                                std::unique_lock<std::mutex> g(m_);
+                                done_cv_.wait_for(g, std::chrono::microseconds(200), [&] { return !left_.load(std::memory_order_acquire); });
+                        }
+        }
+
+      private:
+        void work(const uint64_t gen) {
+                uint64_t cur = state_.load(std::memory_order_acquire);
+                for (;;) {
+                        if ((cur >> 32) != (gen & 0xffffffffull) || (uint32_t)cur >= n_.load(std::memory_order_relaxed))
+                                return;
+                        if (!state_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire))
+                                continue;
+                        (*fn_)((unsigned)(uint32_t)cur);
+                        if (left_.fetch_sub(1, std::memory_order_acq_rel) == 1)
+                                done_cv_.notify_all();
+                        cur = state_.load(std::memory_order_acquire);
+                }
+        }
+        void loop() {
+                using clk = std::chrono::steady_clock;
+                uint64_t seen = 0;
+                for (;;) {
+                        // poll for the next generation while the pool is hot, then sleep
+                        const auto t0 = clk::now();
+                        uint64_t g = gen_hint_.load(std::memory_order_acquire);
+                        for (uint32_t spin = 0; g == seen; ++spin) {
+                                if (!(spin & 1023u) && std::chrono::duration_cast<std::chrono::microseconds>(clk::now() - t0).count() >= (long)hot_us_)
+                                        break;
+#if defined(__x86_64__) || defined(__i386__)
+                                __builtin_ia32_pause();
+#endif
+                                g = gen_hint_.load(std::memory_order_acquire);
+                        }
+                        if (g == seen) {
+                                std::unique_lock<std::mutex> lk(m_);
+                                ++sleepers_;
+                                cv_.wait(lk, [&] { return gen_ != seen; });
+                                --sleepers_;
+                                g = gen_;
+                        }
+                        seen = g;
+                        if (stop_flag())
+                                return;
+                        work(seen);
+                }
+        }
+        bool stop_flag() {
+                std::lock_guard<std::mutex> g(m_);
+                return stop_;
+        }
+        std::vector<std::thread> workers_;
+        std::mutex m_;
+        std::condition_variable cv_, done_cv_;
+        const std::function<void(unsigned)> *fn_ = nullptr; // (written under m_ before state_ is published; read only after a successful CAS)
+        std::atomic<uint32_t> n_{0};
+        std::atomic<uint64_t> state_{0}; // generation << 32 | next job
+        std::atomic<unsigned> left_{0};
+        std::atomic<uint64_t> gen_hint_{0};
+        uint64_t gen_ = 0;
+        unsigned sleepers_ = 0; // (under m_)
+        unsigned hot_us_;
+        bool stop_ = false;
+};

@@ -29,15 +29,11 @@
 #ifndef TRI_FUS_WG
 #define TRI_FUS_WG 512
 #endif
-#ifndef TRI_FUS_CELLS
-#define TRI_FUS_CELLS 14
-#endif
 #ifndef TRI_FUS_UNROLL
 #define TRI_FUS_UNROLL 2 // postings per trip of the PFOR row loop (1: 78.9 ms, 2: 74.0 ms at the time it was measured)
 #endif
 constexpr int FUS_WG = TRI_FUS_WG;
-constexpr uint32_t FUS_CELLS = TRI_FUS_CELLS; // docID cells (of CELL_DOCS) per window (14: 56 KB of words, two 512-thread workgroups per CU)
-constexpr uint32_t FUS_W = FUS_CELLS * CELL_DOCS;
+// (FUS_CELLS, FUS_W: dev_structs.hpp)
 // window geometry by word width (HW = 1: two documents per 32-bit LDS word)
 template <int HW>
 struct FusGeom {

@@ -6,9 +6,7 @@
 // ------------------------------------------------------------------------------------------ k_and
 constexpr int AND_WG = 256;   // candidate-tile kernel (k_and) and the scoring kernels
 constexpr int DENSE_WG = 512; // bitmap-window kernel (k_and_dense): 8 waves share one 38 KB window state
-constexpr int TILE_BLOCKS = 256; // one candidate row per lane: must equal AND_WG
-static_assert(TILE_BLOCKS == 256, "the candidate kernel maps one 32-candidate row to each of its 256 lanes");
-constexpr int TILE_CANDS = TILE_BLOCKS * 32;
+static_assert(TILE_BLOCKS == AND_WG, "the candidate kernel maps one 32-candidate row to each of its 256 lanes"); // (TILE_BLOCKS, TILE_CANDS: dev_structs.hpp)
 
 // Values that are workgroup-uniform by construction but read back from LDS look divergent to the compiler; a
 // loop whose exit depends on one gets exec-masked structurisation, which is fatal around s_barrier (lanes
@@ -31,11 +29,7 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) 
         return x - v;
 }
 
-constexpr uint32_t SPAN_BITS = 1u << 17; // docIDs per dense window
-constexpr uint32_t SPAN_WORDS = SPAN_BITS / 32;
-constexpr uint32_t CELL_LOG2 = 10; // docID cells of the per-term block index (DevTerm::win_off)
-constexpr uint32_t CELL_DOCS = 1u << CELL_LOG2;
-constexpr uint32_t CELLS_PER_SPAN = SPAN_BITS / CELL_DOCS;
+// (SPAN_BITS, SPAN_WORDS, CELL_LOG2, CELL_DOCS, CELLS_PER_SPAN: dev_structs.hpp — the host planner cuts tasks by them)
 // Window bitmap layout in LDS: logical word w lives at bm[w + (w >> 5)] — every row of 32 words is followed by one pad
 // word, so lanes whose blocks lie a small constant number of words apart do not pile onto one bank.  Bitmap B is bitmap A
 // shifted by BM_B_WORDS logical words, i.e. a lane selects it by adding BM_B_WORDS * 32 to its window-relative docID once

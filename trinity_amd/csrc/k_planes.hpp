@@ -137,7 +137,7 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
 //     worked off 64 at a time — the exact frequencies come from the postings (directory cell -> block -> register row reader).
 //   * per task: min(matches, k) ranked (docID, score) pairs and the match count; k_topk_merge folds a query's tasks.
 constexpr int PLK_WG = 512;
-constexpr uint32_t PLK_MAX_SPARSE = 6;  // slots whose lists are decoded per task (LDS planes); the planner sends wider queries to k_fused
+// (PLK_MAX_SPARSE, PLK_NS_SMALL: dev_structs.hpp)
 constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per thread when it is pruned)
 constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
 constexpr uint32_t PLK_FTAB_WORDS = (1u << (2 * FUS_MAX_SLOTS)) / 32; // the filter table: one bit per level vector (two bits per slot)
@@ -146,7 +146,6 @@ constexpr uint32_t PLK_FTAB_WORDS = (1u << (2 * FUS_MAX_SLOTS)) / 32; // the fil
 #endif
 constexpr uint32_t PLK_WGS_PER_CU = TRI_PLK_WGS; // (LDS: two fit)
 constexpr uint32_t PLK_WQ = 128;        // per-wave queue of candidates waiting for a frequency lookup: worked off 64 at a time, every lane busy
-constexpr uint32_t PLK_NS_SMALL = 5;    // the instantiation for queries of up to this many slots keeps six words per slot in registers
 constexpr uint32_t PLK_PAD = 0xffffffffu; // list padding (sorts last)
 constexpr uint32_t PLK_SEED_FIRST = 4096;  // the seed pass takes the shortest decoded list if it has at most this many entries in the task's range ...
 constexpr uint32_t PLK_SEED_MORE = 2048;   // ... and further ones while the total stays below this
@@ -226,17 +225,27 @@ __device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t 
         if (m == k) {
                 ts = sh.tk_s[k - 1];
                 td = sh.tk_d[k - 1];
-                if (tid == 0)
-                        atomicMax(gthr, score_key(ts));
         }
-        const unsigned long long g = __atomic_load_n(gthr, __ATOMIC_RELAXED); // (every lane, the same address)
-        const bool other = g != 0ull && (m < k || ts < key_score(g));     // another range's k-th best is the higher one: ties pass (no docID to break them with)
-        // uniform stores by every lane
-        sh.tk_n = m;
-        if (m == k || other) {
-                sh.tk_full = 1;
-                sh.thr_s = other ? key_score(g) : ts;
-                sh.thr_d = other ? 0xffffffffu : td;
+        // ONE reading of the shared cell decides the (score, docID) pair every lane filters with: lane 0 publishes this range's k-th best and
+        // takes what the cell then holds, wave 0 derives the pair from that single value and stores it, the barrier hands it to the other
+        // waves.  (Each lane reading the cell for itself — other ranges keep raising it — let two waves disagree on whose threshold holds and
+        // leave another range's score next to this range's docID: documents tied with that score and above the docID were then dropped.)
+        if (tid < 64) { // (wave-uniform)
+                unsigned long long g = 0ull;
+                if (tid == 0) {
+                        const unsigned long long mine = m == k ? score_key(ts) : 0ull;
+                        const unsigned long long old = mine ? atomicMax(gthr, mine) : __atomic_load_n(gthr, __ATOMIC_RELAXED);
+                        g = old > mine ? old : mine;
+                }
+                g = ((unsigned long long)uni((uint32_t)(g >> 32)) << 32) | uni((uint32_t)g);
+                const bool other = g != 0ull && (m < k || ts < key_score(g)); // another range's k-th best is the higher one: ties pass (no docID to break them with)
+                // uniform stores by the lanes of wave 0
+                sh.tk_n = m;
+                if (m == k || other) {
+                        sh.tk_full = 1;
+                        sh.thr_s = other ? key_score(g) : ts;
+                        sh.thr_d = other ? 0xffffffffu : td;
+                }
         }
         __syncthreads();
 }

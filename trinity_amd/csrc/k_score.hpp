@@ -16,7 +16,7 @@
 #define TRI_SCORE_TILE 4096 // (cfg1, ms: 4096 -> 0.86, 2048 -> 1.00, 1024 -> 1.45: every tile repeats the per-term searches)
 #endif
 constexpr uint32_t SCORE_TILE = TRI_SCORE_TILE;
-constexpr uint32_t TOPK_MAX = 256;
+// (TOPK_MAX: dev_structs.hpp)
 constexpr uint32_t TOPK_CAP = TOPK_MAX + AND_WG; // survivors + one wave of newcomers
 
 struct TopK {

@@ -1,0 +1,1372 @@
+// planner.hpp — the host planner behind tri_batch_create: postfix query programs -> the plan the kernels execute.
+//
+// Takes over, for a whole batch of queries at once, what the reference does per query before the first posting is touched:
+// queryexec_ctx::build_iterator (exec.cpp:253-449: flattening of nested AND / OR :339-358, 382-393, operand ordering by cost
+// :35-110, 133-240), build_span's choice of execution strategy (:452-505) and the scorer-weight set-up (similarity.h:179-226) —
+// restated as data: CNF groups or a truth table per query, an execution class (candidate tiles / bitmap windows / one-pass scored
+// windows / bit planes), tasks cut to even cost with private output regions, the head terms the batch shares (term planes), and one
+// contiguous host block that is copied to the device in a single transfer.
+//
+// Host-only C++17, no HIP: trinity_hip.hip materialises the plan on the device; tools/plan_probe.cpp and tests/test_planner.py drive it
+// without one.  The queries of a batch are independent, so every pass over them runs on a few host threads (HostPool) over contiguous
+// fragments of the batch; what is global (the one-pass task size, the chosen planes, offsets into the shared arrays) is settled between
+// the passes from per-fragment sums.  New code, no reference source.
+#pragma once
+#include "host_pool.hpp"
+#include "index_host.hpp"
+
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <memory>
+
+// planner / launch options of a device handle (tri_dev_set_option); the defaults are what bench.py measures
+struct tri_options {
+        uint64_t dense_min_postings = 512 * 1024; // TASK_DENSE needs at least this many postings over the query's lists (0: every multi-term query)
+        uint64_t dense_task_cost = 192 * 1024;    // postings per bitmap-window task
+        uint64_t fused = 1;                       // AccumulatedScore top-K of dense queries in one pass (k_fused); 0: k_and_dense + k_score
+        uint64_t fused_task_cost = 0;             // postings per one-pass task; 0: sized from the batch (256 K .. 8 M, about two tasks per resident workgroup)
+        uint64_t fused_freq_cap = 0;              // 0: the field width decides; else a smaller saturation point (exercises the rescoring path)
+        uint64_t account_needed_bytes = 0;        // 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query)
+        uint64_t fused_halfwords = 1;             // 16-bit window words for queries of <= 5 distinct terms (windows twice as long); 0: always 32-bit
+        uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
+        uint64_t planes = 7;     // term planes (k_planes.hpp), a bit set: 1 k_and probes them, 2 k_and_dense ORs them in, 4 top-K CNF queries run in k_planes; 0: off
+        uint64_t planes_split = 0; // a k_planes query is cut into this many docID ranges (tasks) that share its threshold; 0: 2 or 3 by the batch's size; >= 65536: by postings like the other one-pass tasks.  cfg3's unions: 0 10.9 ms, 2 8.0, 3 8.5, 4 9.2 (a task has fixed costs)
+        uint64_t plane_div = 128; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list);
+                                 // measured, step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the planes' build grows with it)
+        uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs 3 bitmaps over the docID space and one decode per run)
+        uint64_t plan_threads = 0;             // host threads tri_batch_create plans with; 0: up to 16, one per 512 queries
+};
+
+struct PlanEnv {
+        tri_options opt;
+        uint32_t cus = 256;          // compute units of the device (task sizes aim at a couple of tasks per resident workgroup)
+        uint32_t fus_wgs_per_cu = 2; // k_fused workgroups a CU holds (LDS)
+        uint32_t plk_wgs_per_cu = 2; // k_planes workgroups a CU holds
+};
+
+template <class T>
+struct Span { // a typed window into the plan's host block
+        T *p = nullptr;
+        size_t n = 0;
+        size_t size() const { return n; }
+        bool empty() const { return !n; }
+        T *data() { return p; }
+        const T *data() const { return p; }
+        T &operator[](size_t i) { return p[i]; }
+        const T &operator[](size_t i) const { return p[i]; }
+        T *begin() { return p; }
+        T *end() { return p + n; }
+        const T *begin() const { return p; }
+        const T *end() const { return p + n; }
+};
+
+struct PlanInput {
+        const uint32_t *prog = nullptr;
+        size_t prog_len = 0;
+        const tri_query *queries = nullptr;
+        size_t nq = 0;
+        const double *weights = nullptr; // optional: one ScorerWeight per program token
+        uint32_t flags = 0, topk = 0;
+        int similarity = TRI_SIM_BM25;
+};
+
+// What tri_batch_create hands to the device and keeps on the host to read results back.  Every array lives in ONE block (64-byte aligned
+// sections, `off_*` = a section's byte offset): the device copy is one transfer of block[0, block_bytes) and a section's device address is
+// arena + off_*.
+struct BatchPlan {
+        uint8_t *block = nullptr;
+        size_t block_bytes = 0;
+        Span<DevQuery> plan;        // one per lowered query, in query order
+        Span<uint32_t> qterms;      // CNF term lists (QT_GROUP / QT_NOT marks)
+        Span<DevTask> tasks;        // a query's tasks are consecutive
+        Span<uint32_t> sched;       // task indices by kernel, heaviest first: [0, n_dense) TASK_DENSE, then TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8
+        Span<DevFused> fused;       // slot maps of the one-pass queries (DevQuery::fused_idx)
+        Span<uint32_t> qplane;      // parallel to qterms: the term's row in the batch's term planes, or PL_NONE (empty: no planes)
+        Span<uint32_t> plane_terms; // row -> term
+        Span<uint32_t> sterms;      // scored: scorer terms in the reference's summation order; default mode: reportable terms
+        Span<double> sweights;      // scored: their ScorerWeights
+        Span<DevPhrase> phrases;
+        Span<uint32_t> pterms, ptasks;
+        size_t off_plan = 0, off_qterms = 0, off_tasks = 0, off_sched = 0, off_fused = 0, off_qplane = 0, off_plane_terms = 0, off_sterms = 0, off_sweights = 0,
+               off_phrases = 0, off_pterms = 0, off_ptasks = 0;
+        std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: can never match)
+        std::vector<int32_t> qstatus;        // per caller query: TRI_OK, or why the planner left it out of the batch (it then reports no matches)
+        uint32_t n_dense = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0, n_planes = 0, n_planes8 = 0;
+        uint32_t plw = 0;        // words of one term plane
+        uint32_t sparse_cap = 0; // k_planes: list entries a task's decoded slots can need
+        uint32_t rich_R = 0;     // default mode: reportable terms of the widest query
+        bool rich_allow = false; // default mode: the batch holds general trees (per match: which reportable terms the tree sits on)
+        uint64_t out_capacity = 0;
+        uint64_t term_bytes = 0, term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, term_bytes_phrase_hits = 0, plane_decoded_bytes = 0,
+                 cand_needed_term_bytes = 0;
+        uint64_t dense_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, unsupported_queries = 0;
+        std::string last_unsupported; // describes the last query that was left out
+        double plan_ms[4] = {0, 0, 0, 0}; // lowering + classes, tasks, layout + fill, schedule + planes
+};
+
+namespace trip {
+        constexpr uint64_t TASK_COST = 96 * 1024; // postings per candidate-tile task
+        constexpr size_t SECTION_ALIGN = 64;
+
+        struct PNode {
+                uint32_t op = 0, term = 0;
+                uint32_t tok = 0; // index of the program token this node came from (caller-supplied ScorerWeights are per token)
+                uint32_t kid_off = 0, kid_n = 0; // children: kidpool[kid_off, +kid_n)
+                uint64_t cost = 0;
+                bool empty = false;
+        };
+
+        // one fragment's scratch for parsing and lowering a query: reused from query to query (clear() keeps the capacity — a query costs
+        // no allocation once the vectors have grown to the batch's widest query)
+        struct Scratch {
+                std::vector<PNode> nodes;
+                std::vector<int> kidpool, st, tmpk;
+                std::vector<uint64_t> cs;
+                std::vector<uint32_t> gt, gs; // CNF groups, flat: group g = gt[gs[g], gs[g + 1])
+                std::vector<uint32_t> gorder, leaves, leaf_tok, negs, opts, opt_tok, ts, ts_tok, u, uniq, rt, seen, phterms, slots;
+                struct PhraseTmp {
+                        uint32_t t0, n;
+                        double weight;
+                };
+                std::vector<PhraseTmp> qphrases;
+                std::vector<std::pair<uint32_t, double>> sc;
+                const int *kids(const PNode &x) const { return kidpool.data() + x.kid_off; }
+        };
+
+        // Parse one postfix program into a tree with the reference's flattening (exec.cpp:339-358, 382-393), emptiness propagation and cost
+        // model (exec.cpp:35-110).  Returns root index or -1.
+        inline int parse_program(const HostIndex &ix, const uint32_t *prog, uint32_t len, Scratch &S) {
+                auto &nodes = S.nodes;
+                auto &st = S.st;
+                auto &pool = S.kidpool;
+                nodes.clear();
+                st.clear();
+                pool.clear();
+                for (uint32_t i = 0; i < len; ++i) {
+                        const uint32_t op = prog[i] >> 28, arg = prog[i] & 0x0fffffffu;
+                        PNode n;
+                        n.op = op;
+                        n.tok = i;
+                        if (op == TRI_OP_TERM) {
+                                n.term = arg;
+                                n.cost = arg < ix.terms.size() ? ix.terms[arg].documents : 0;
+                                n.empty = n.cost == 0; // unknown term == no documents (index_source.h:60-72)
+                        } else {
+                                const uint32_t nk = op == TRI_OP_SOME ? (arg & 0xffffu) : arg; // operands taken off the stack
+                                if (nk < 1 || nk > st.size())
+                                        return -1;
+                                S.tmpk.assign(st.end() - nk, st.end());
+                                st.resize(st.size() - nk);
+                                const std::vector<int> &kids = S.tmpk;
+                                n.kid_off = (uint32_t)pool.size();
+                                if (op == TRI_OP_SOME) {
+                                        // matchsome (exec.cpp:276-283): operands that can never match are dropped; fewer live operands than
+                                        // the threshold: never matches.  cost: docset_iterators.cpp:733-742, the (cnt - min + 1) cheapest
+                                        const uint32_t mn = arg >> 16;
+                                        if (!mn || mn > nk)
+                                                return -1;
+                                        for (int k : kids)
+                                                if (!nodes[k].empty)
+                                                        pool.push_back(k);
+                                        n.kid_n = (uint32_t)pool.size() - n.kid_off;
+                                        n.term = mn; // (the threshold rides in the otherwise unused field)
+                                        n.empty = n.kid_n < mn;
+                                        S.cs.clear();
+                                        for (uint32_t k = 0; k < n.kid_n; ++k)
+                                                S.cs.push_back(nodes[pool[n.kid_off + k]].cost);
+                                        std::sort(S.cs.begin(), S.cs.end());
+                                        for (size_t k = 0; k + mn <= S.cs.size(); ++k)
+                                                n.cost += S.cs[k];
+                                } else if (op == TRI_OP_PHRASE) {
+                                        if (arg > MAX_PHRASE_TERMS) // trinity_limits.h:12 MaxPhraseSize
+                                                return -1;
+                                        for (int k : kids) {
+                                                if (nodes[k].op != TRI_OP_TERM)
+                                                        return -1;
+                                                n.empty |= nodes[k].empty;
+                                                pool.push_back(k);
+                                        }
+                                        n.kid_n = nk;
+                                        n.cost = nodes[kids[0]].cost + UINT32_MAX + (uint64_t)UINT16_MAX * arg;
+                                } else if (op == TRI_OP_AND) {
+                                        for (int k : kids) {
+                                                n.empty |= nodes[k].empty;
+                                                if (nodes[k].op == TRI_OP_AND)
+                                                        for (uint32_t j = 0; j < nodes[k].kid_n; ++j)
+                                                                pool.push_back(pool[nodes[k].kid_off + j]);
+                                                else
+                                                        pool.push_back(k);
+                                        }
+                                        n.kid_n = (uint32_t)pool.size() - n.kid_off;
+                                        std::stable_sort(pool.begin() + n.kid_off, pool.end(), [&](int a, int b) { return nodes[a].cost < nodes[b].cost; });
+                                        n.cost = nodes[pool[n.kid_off]].cost;
+                                } else if (op == TRI_OP_OR) {
+                                        for (int k : kids) {
+                                                if (nodes[k].empty)
+                                                        continue;
+                                                if (nodes[k].op == TRI_OP_OR)
+                                                        for (uint32_t j = 0; j < nodes[k].kid_n; ++j)
+                                                                pool.push_back(pool[nodes[k].kid_off + j]);
+                                                else
+                                                        pool.push_back(k);
+                                        }
+                                        n.kid_n = (uint32_t)pool.size() - n.kid_off;
+                                        n.empty = n.kid_n == 0;
+                                        for (uint32_t k = 0; k < n.kid_n; ++k)
+                                                n.cost += nodes[pool[n.kid_off + k]].cost;
+                                } else if (op == TRI_OP_OPT) {
+                                        if (arg != 2)
+                                                return -1;
+                                        if (nodes[kids[1]].empty) { // an optional side that can never match adds nothing
+                                                st.push_back(kids[0]);
+                                                continue;
+                                        }
+                                        pool.push_back(kids[0]); // {main, optional}
+                                        pool.push_back(kids[1]);
+                                        n.kid_n = 2;
+                                        n.empty = nodes[kids[0]].empty;
+                                        n.cost = nodes[kids[0]].cost;
+                                } else if (op == TRI_OP_NOT) {
+                                        if (arg != 2)
+                                                return -1;
+                                        if (nodes[kids[1]].empty) { // [a NOT <never matches>] => a
+                                                st.push_back(kids[0]);
+                                                continue;
+                                        }
+                                        pool.push_back(kids[0]); // {required, excluded}
+                                        pool.push_back(kids[1]);
+                                        n.kid_n = 2;
+                                        n.empty = nodes[kids[0]].empty;
+                                        n.cost = nodes[kids[0]].cost; // exec.cpp:55-60
+                                } else
+                                        return -1;
+                        }
+                        nodes.push_back(n);
+                        st.push_back((int)nodes.size() - 1);
+                }
+                return st.size() == 1 ? st[0] : -1;
+        }
+
+        // ---- general trees: what the CNF lowering does not take (matchsome, NOT / Optional of any subtree, AND under OR ...) runs as
+        // TASK_FUSED with a truth table over the presence of the query's distinct terms (<= FUS_MAX_SLOTS, no multi-word phrase).
+        struct TruthPlan {
+                std::vector<uint32_t> slots;            // distinct terms, order of first appearance
+                std::vector<uint32_t> leaves, leaf_tok; // scorer leaves (positive TERM nodes) in tree order, and their program tokens
+                std::vector<uint32_t> leaf_slot;
+                uint32_t tt[8] = {};
+                std::vector<std::array<uint32_t, 8>> ctt;
+        };
+        struct TruthBuilder {
+                const Scratch &S;
+                TruthPlan &tp;
+                std::vector<int> leaf_of_node; // node -> scorer leaf index (-1: none)
+                bool ok = true;
+                uint32_t slot_of(uint32_t term) {
+                        for (size_t i = 0; i < tp.slots.size(); ++i)
+                                if (tp.slots[i] == term)
+                                        return (uint32_t)i;
+                        tp.slots.push_back(term);
+                        return (uint32_t)tp.slots.size() - 1;
+                }
+                // first walk: slots for every term, scorer leaves for the terms an iterator of the tree can report
+                void scan(int ni, bool positive) {
+                        const PNode &x = S.nodes[ni];
+                        if (x.op == TRI_OP_TERM || (x.op == TRI_OP_PHRASE && x.kid_n == 1)) {
+                                const PNode &t = x.op == TRI_OP_TERM ? x : S.nodes[S.kids(x)[0]];
+                                const uint32_t sl = slot_of(t.term);
+                                if (positive) {
+                                        leaf_of_node[ni] = (int)tp.leaves.size();
+                                        tp.leaves.push_back(t.term);
+                                        tp.leaf_tok.push_back(t.tok);
+                                        tp.leaf_slot.push_back(sl);
+                                }
+                                return;
+                        }
+                        if (x.op == TRI_OP_PHRASE) {
+                                ok = false; // a positional constraint is not a function of presence
+                                return;
+                        }
+                        for (uint32_t k = 0; k < x.kid_n; ++k)
+                                scan(S.kids(x)[k], positive && !(x.op == TRI_OP_NOT && k == 1));
+                }
+                uint32_t slot_const(uint32_t term) const {
+                        for (size_t i = 0; i < tp.slots.size(); ++i)
+                                if (tp.slots[i] == term)
+                                        return (uint32_t)i;
+                        return 0;
+                }
+                bool eval(int ni, uint32_t p) const {
+                        const PNode &x = S.nodes[ni];
+                        const int *kd = S.kids(x);
+                        switch (x.op) {
+                                case TRI_OP_TERM:
+                                        return (p >> slot_const(x.term)) & 1u;
+                                case TRI_OP_PHRASE:
+                                        return (p >> slot_const(S.nodes[kd[0]].term)) & 1u;
+                                case TRI_OP_AND:
+                                        for (uint32_t k = 0; k < x.kid_n; ++k)
+                                                if (!eval(kd[k], p))
+                                                        return false;
+                                        return true;
+                                case TRI_OP_OR:
+                                        for (uint32_t k = 0; k < x.kid_n; ++k)
+                                                if (eval(kd[k], p))
+                                                        return true;
+                                        return false;
+                                case TRI_OP_SOME: {
+                                        uint32_t c = 0;
+                                        for (uint32_t k = 0; k < x.kid_n; ++k)
+                                                c += eval(kd[k], p) ? 1u : 0u;
+                                        return c >= x.term;
+                                }
+                                case TRI_OP_NOT: // Filter (docset_iterators.cpp:652-677)
+                                        return eval(kd[0], p) && !eval(kd[1], p);
+                                case TRI_OP_OPT: // Optional (docset_iterators.h:174-206): the documents of main
+                                        return eval(kd[0], p);
+                        }
+                        return false;
+                }
+                // the scorer leaves that sit on a document of pattern p, through the tree (node ni matches p): what the reference's score() /
+                // collect_doc_matching_terms recursion reaches (docset_iterators_scorers.cpp:38-57, 77-104, 107-193; queryexec_ctx.cpp:382-520)
+                void collect(int ni, uint32_t p, uint32_t &mask) const {
+                        const PNode &x = S.nodes[ni];
+                        const int *kd = S.kids(x);
+                        switch (x.op) {
+                                case TRI_OP_TERM:
+                                case TRI_OP_PHRASE:
+                                        if (leaf_of_node[ni] >= 0)
+                                                mask |= 1u << leaf_of_node[ni];
+                                        break;
+                                case TRI_OP_AND:
+                                        for (uint32_t k = 0; k < x.kid_n; ++k)
+                                                collect(kd[k], p, mask);
+                                        break;
+                                case TRI_OP_OR:
+                                case TRI_OP_SOME:
+                                        for (uint32_t k = 0; k < x.kid_n; ++k)
+                                                if (eval(kd[k], p))
+                                                        collect(kd[k], p, mask);
+                                        break;
+                                case TRI_OP_NOT:
+                                        collect(kd[0], p, mask);
+                                        break;
+                                case TRI_OP_OPT:
+                                        collect(kd[0], p, mask);
+                                        if (eval(kd[1], p))
+                                                collect(kd[1], p, mask);
+                                        break;
+                        }
+                }
+        };
+        inline bool build_truth(const Scratch &S, int root, TruthPlan &tp) {
+                TruthBuilder tb{S, tp, std::vector<int>(S.nodes.size(), -1)};
+                tb.scan(root, true);
+                if (!tb.ok || tp.slots.size() > FUS_MAX_SLOTS || tp.leaves.size() > FUS_MAX_LEAVES || tp.leaves.empty())
+                        return false;
+                tp.ctt.assign(tp.leaves.size(), std::array<uint32_t, 8>{});
+                for (uint32_t p = 0; p < (1u << tp.slots.size()); ++p) {
+                        if (!tb.eval(root, p))
+                                continue;
+                        tp.tt[p >> 5] |= 1u << (p & 31u);
+                        uint32_t mask = 0;
+                        tb.collect(root, p, mask);
+                        for (size_t j = 0; j < tp.leaves.size(); ++j)
+                                if ((mask >> j) & 1u)
+                                        tp.ctt[j][p >> 5] |= 1u << (p & 31u);
+                }
+                return !(tp.tt[0] & 1u); // (a tree that matches documents holding none of its terms cannot be enumerated from postings)
+        }
+
+        // a lowered query before it has its place in the batch
+        struct Tmp {
+                DevQuery q;
+                uint64_t cost;
+                uint32_t nlead;
+                int32_t fz;   // index into the fragment's slot maps (-1: none): may run in one pass (k_fused / k_planes)
+                bool truth;   // a general tree: runs as TASK_FUSED whatever its density (there is no other path for it)
+                // execution class (second half of the first pass)
+                uint64_t sumdf, lead_docs;
+                uint32_t last_doc; // no match beyond the (required) group whose lists end first
+                bool dense, fuse;
+        };
+
+        struct QUse { // a CNF term position that could read a plane
+                uint32_t qpos, term;
+        };
+        struct FUse { // a one-pass slot that reads a plane
+                uint32_t fidx, slot, term;
+        };
+
+        // everything a fragment (a contiguous range of the batch's queries) produces; offsets are relative to the fragment
+        struct Frag {
+                size_t q_lo = 0, q_hi = 0;
+                Scratch S;
+                std::vector<Tmp> tmp;
+                std::vector<uint32_t> qterms, pterms, sterms;
+                std::vector<double> sweights;
+                std::vector<DevPhrase> phrases;
+                std::vector<DevFused> fz; // slot maps of the queries that may run in one pass (Tmp::fz)
+                uint64_t term_bytes = 0, term_bytes_phrase_hits = 0;
+                uint32_t rich_R = 0;
+                bool rich_allow = false;
+                std::vector<size_t> left_out; // queries the planner does not lower (status TRI_ERR_UNSUPPORTED)
+                uint64_t onepass_queries = 0, fused_postings = 0;
+                // second pass
+                std::vector<DevTask> tasks; // slot: index into tmp; out_off: relative to the fragment's first output slot
+                std::vector<uint64_t> tcost;
+                std::vector<DevFused> fused;
+                std::vector<uint32_t> ptasks;
+                std::vector<QUse> quses;
+                std::vector<FUse> fuses;
+                std::vector<uint64_t> benefit; // per eligible term (by df rank): postings of decoding the batch's uses save
+                uint64_t off = 0;
+                uint32_t sparse_cap = 0;
+                uint64_t term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, cand_needed = 0;
+                uint64_t dense_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0;
+                // bases in the batch's arrays (settled between the passes)
+                size_t b_plan = 0, b_qterms = 0, b_sterms = 0, b_phrases = 0, b_pterms = 0, b_tasks = 0, b_fused = 0, b_ptasks = 0;
+                uint64_t b_off = 0;
+                int rc = TRI_OK;
+                std::string err;
+        };
+
+        struct Ctx {
+                const HostIndex &ix;
+                const PlanEnv &env;
+                const PlanInput &in;
+                bool scored, rich;
+                uint32_t mode;
+                // term planes: a term is eligible when its df rank is below n_ok
+                uint32_t n_ok = 0;
+                bool plane_ok(uint32_t term) const { return ix.df_rank[term] < n_ok; }
+                // settled after the first pass
+                uint64_t planes_split = 2, fused_task_cost = 0;
+                // the ScorerWeight contribution of one term (IndexSourceTermsScorer::new_scorer_weight sums it over a phrase's terms):
+                // BM25 similarity.h:179-181 (float math), TF-IDF :85-87 (double), Trivial has none
+                double term_weight(const uint32_t df) const {
+                        if (in.similarity == TRI_SIM_TFIDF)
+                                return std::log((double)((uint64_t)ix.info.docs_cnt + 1) / (double)(df + 1)) + 1.0;
+                        if (in.similarity == TRI_SIM_TRIVIAL)
+                                return 0.0;
+                        const float num = (float)((uint64_t)ix.info.docs_cnt - (uint64_t)df) + 0.5f;
+                        const float den = (float)df + 0.5f;
+                        return (double)std::log(1 + num / den);
+                }
+                // first block of `t` whose last docID >= key: the docID-cell index when the list has one and key is a cell boundary (every
+                // window boundary is), else a search of the directory column
+                uint32_t first_block_ge(const DevTerm &t, const uint64_t key) const {
+                        if (t.win_off != 0xffffffffu && !ix.win.empty() && !(key & (CELL_DOCS - 1)) && (key >> CELL_LOG2) < ix.nwin)
+                                return ix.win[t.win_off + (key >> CELL_LOG2)];
+                        const uint32_t *lb = &ix.blk_last[t.first_block];
+                        return (uint32_t)(std::lower_bound(lb, lb + t.nblocks, (uint32_t)std::min<uint64_t>(key, 0xffffffffull)) - lb);
+                }
+        };
+
+        // ---- first pass: lower the queries [q_lo, q_hi) of the batch into `f` and class them
+        inline int lower_range(const Ctx &C, Frag &f) {
+                const HostIndex &ix = C.ix;
+                const PlanInput &in = C.in;
+                const tri_options &opt = C.env.opt;
+                const bool scored = C.scored, rich = C.rich;
+                const uint32_t mode = C.mode, topk = in.topk;
+                const double *weights = in.weights;
+                Scratch &S = f.S;
+                for (size_t qi = f.q_lo; qi < f.q_hi; ++qi) {
+                        const tri_query &tq = in.queries[qi];
+                        if ((uint64_t)tq.prog_off + tq.prog_len > in.prog_len || !tq.prog_len)
+                                return herr(f.err, TRI_ERR_INVALID, "query %zu: program slice out of range", qi);
+                        const uint32_t *prog = in.prog + tq.prog_off;
+                        const int root = parse_program(ix, prog, tq.prog_len, S);
+                        if (root < 0)
+                                return herr(f.err, TRI_ERR_INVALID, "query %zu: malformed postfix program", qi);
+                        const std::vector<PNode> &nodes = S.nodes;
+                        if (nodes[root].empty)
+                                continue; // matches nothing (compiles to constfalse in the reference)
+                        // ---- conjunctive normal form over terms: AND of (term | OR of terms); a root OR is one group
+                        auto &gt = S.gt;
+                        auto &gs = S.gs;
+                        gt.clear();
+                        gs.assign(1, 0u);
+                        S.leaves.clear();   // every TERM leaf in evaluation order: one scorer each
+                        S.leaf_tok.clear(); // ... and the program token it came from
+                        S.qphrases.clear();
+                        S.phterms.clear();
+                        S.negs.clear();
+                        S.opts.clear();
+                        S.opt_tok.clear();
+                        auto ngroups = [&]() { return (uint32_t)gs.size() - 1; };
+                        auto single_seen = [&](uint32_t x) {
+                                for (uint32_t g = 0; g < ngroups(); ++g)
+                                        if (gs[g + 1] - gs[g] == 1 && gt[gs[g]] == x)
+                                                return true;
+                                return false;
+                        };
+                        auto add_group = [&](const PNode &g) -> bool {
+                                const int *kd = S.kids(g);
+                                if (g.op == TRI_OP_PHRASE && g.kid_n > 1) {
+                                        // Phrase = conjunction of its terms + a positional constraint on the matches (k_phrase);
+                                        // it scores as ONE iterator with the summed idf (docset_iterators_scorers.cpp:195-228)
+                                        Scratch::PhraseTmp ph{(uint32_t)S.phterms.size(), g.kid_n, 0.0};
+                                        for (uint32_t k = 0; k < g.kid_n; ++k) {
+                                                const uint32_t x = nodes[kd[k]].term;
+                                                S.phterms.push_back(x);
+                                                ph.weight += C.term_weight(ix.terms[x].documents);
+                                                if (!single_seen(x)) {
+                                                        gt.push_back(x);
+                                                        gs.push_back((uint32_t)gt.size());
+                                                }
+                                        }
+                                        if (weights) // the PHRASE token's own ScorerWeight, when the caller supplies weights (by token position: two phrases
+                                                     // that start with the same term keep their own weights)
+                                                ph.weight = weights[tq.prog_off + g.tok];
+                                        S.qphrases.push_back(ph);
+                                        return true;
+                                }
+                                auto &ts = S.ts;
+                                auto &ts_tok = S.ts_tok;
+                                ts.clear();
+                                ts_tok.clear();
+                                if (g.op == TRI_OP_PHRASE) {
+                                        ts.push_back(nodes[kd[0]].term); // a one-word phrase is a term (exec.cpp: phrase of size 1)
+                                        ts_tok.push_back(nodes[kd[0]].tok);
+                                } else if (g.op == TRI_OP_TERM) {
+                                        ts.push_back(g.term);
+                                        ts_tok.push_back(g.tok);
+                                } else if (g.op == TRI_OP_OR) {
+                                        for (uint32_t k = 0; k < g.kid_n; ++k) {
+                                                if (nodes[kd[k]].op != TRI_OP_TERM)
+                                                        return false;
+                                                ts.push_back(nodes[kd[k]].term);
+                                                ts_tok.push_back(nodes[kd[k]].tok);
+                                        }
+                                } else
+                                        return false;
+                                S.leaves.insert(S.leaves.end(), ts.begin(), ts.end());
+                                S.leaf_tok.insert(S.leaf_tok.end(), ts_tok.begin(), ts_tok.end());
+                                // a term repeated inside a group, or a single-term group seen before, adds nothing to the docID set
+                                auto &u = S.u;
+                                u.clear();
+                                for (uint32_t x : ts)
+                                        if (std::find(u.begin(), u.end(), x) == u.end())
+                                                u.push_back(x);
+                                if (u.size() == 1 && single_seen(u[0]))
+                                        return true;
+                                gt.insert(gt.end(), u.begin(), u.end());
+                                gs.push_back((uint32_t)gt.size());
+                                return true;
+                        };
+                        // logicalnot at the root or under an AND: its required side joins the conjunction, its excluded side (a term or an
+                        // OR of terms) joins the query's excluded set: A B -C == A ∧ B ∧ ¬C (Filter semantics, docset_iterators.cpp:652-677)
+                        bool ok = true;
+                        struct Rec {
+                                const std::vector<PNode> &nodes;
+                                Scratch &S;
+                                bool &ok;
+                                decltype(add_group) &add;
+                                void side(const PNode &e, std::vector<uint32_t> &terms, std::vector<uint32_t> *toks) {
+                                        const int *kd = S.kids(e);
+                                        if (e.op == TRI_OP_TERM) {
+                                                terms.push_back(e.term);
+                                                if (toks)
+                                                        toks->push_back(e.tok);
+                                        } else if (e.op == TRI_OP_PHRASE && e.kid_n == 1) {
+                                                terms.push_back(nodes[kd[0]].term);
+                                                if (toks)
+                                                        toks->push_back(nodes[kd[0]].tok);
+                                        } else if (e.op == TRI_OP_OR) {
+                                                for (uint32_t k = 0; k < e.kid_n; ++k) {
+                                                        if (nodes[kd[k]].op != TRI_OP_TERM)
+                                                                ok = false;
+                                                        else {
+                                                                terms.push_back(nodes[kd[k]].term);
+                                                                if (toks)
+                                                                        toks->push_back(nodes[kd[k]].tok);
+                                                        }
+                                                }
+                                        } else
+                                                ok = false;
+                                }
+                                void lower(int ni) {
+                                        const PNode &x = nodes[ni];
+                                        const int *kd = S.kids(x);
+                                        if (x.op == TRI_OP_OPT) {
+                                                // Optional(main, opt): the documents of main; opt's terms score (and are reported) where they match —
+                                                // exactly how k_score / k_rich treat a term a match does not hold
+                                                lower(kd[0]);
+                                                side(nodes[kd[1]], S.opts, &S.opt_tok);
+                                        } else if (x.op == TRI_OP_NOT) {
+                                                lower(kd[0]);
+                                                side(nodes[kd[1]], S.negs, nullptr);
+                                        } else if (x.op == TRI_OP_AND) {
+                                                for (uint32_t k = 0; k < x.kid_n; ++k)
+                                                        lower(kd[k]);
+                                        } else
+                                                ok &= add(x);
+                                }
+                        } rec{nodes, S, ok, add_group};
+                        rec.lower(root);
+                        if (ok && ngroups()) // (a general tree — below — counts every term once through its slot list)
+                                for (size_t oi = 0; oi < S.opts.size(); ++oi)
+                                        if (const uint32_t x = S.opts[oi]; ix.terms[x].documents) {
+                                                S.leaves.push_back(x); // one more scorer / reportable term each; never part of the docID set
+                                                S.leaf_tok.push_back(S.opt_tok[oi]);
+                                                if (mode != TRI_FLAG_DOCUMENTS_ONLY)
+                                                        f.term_bytes += ix.docbytes[x]; // its postings are read by k_score / k_rich
+                                        }
+                        TruthPlan tp;
+                        bool truth = false;
+                        if (!ok || !ngroups()) {
+                                // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp)
+                                if (!build_truth(S, root, tp)) {
+                                        f.left_out.push_back(qi);
+                                        herr(f.err, TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
+                                        continue;
+                                }
+                                truth = true;
+                                gt = tp.slots; // (one group of every slot: the bookkeeping below — term list, cost, output bound — sees a union)
+                                gs.assign({0u, (uint32_t)gt.size()});
+                                S.negs.clear();
+                                S.leaves = tp.leaves;
+                                S.leaf_tok = tp.leaf_tok;
+                                S.qphrases.clear();
+                                S.phterms.clear();
+                        }
+                        auto gcost = [&](uint32_t g) {
+                                uint64_t c = 0;
+                                for (uint32_t i = gs[g]; i < gs[g + 1]; ++i)
+                                        c += ix.terms[gt[i]].documents;
+                                return c;
+                        };
+                        auto &gorder = S.gorder;
+                        gorder.resize(ngroups());
+                        std::iota(gorder.begin(), gorder.end(), 0u);
+                        if (ngroups() == 2) { // (the common case: a stable two-element sort)
+                                if (gcost(1) < gcost(0))
+                                        std::swap(gorder[0], gorder[1]);
+                        } else if (ngroups() > 2)
+                                std::stable_sort(gorder.begin(), gorder.end(), [&](uint32_t x, uint32_t y) { return gcost(x) < gcost(y); });
+                        auto &uniq = S.uniq; // terms group by group, QT_GROUP on the first of each group
+                        uniq.clear();
+                        for (uint32_t g : gorder)
+                                for (uint32_t i = gs[g]; i < gs[g + 1]; ++i)
+                                        uniq.push_back(gt[i] | (i == gs[g] ? QT_GROUP : 0u));
+                        {
+                                // the excluded terms: one more group, the last, marked QT_NOT
+                                auto &u = S.u;
+                                u.clear();
+                                for (uint32_t x : S.negs)
+                                        if (ix.terms[x].documents && std::find(u.begin(), u.end(), x) == u.end())
+                                                u.push_back(x);
+                                for (size_t i = 0; i < u.size(); ++i)
+                                        uniq.push_back(u[i] | (i == 0 ? (QT_GROUP | QT_NOT) : 0u));
+                        }
+                        if (uniq.size() > MAX_QTERMS) {
+                                f.left_out.push_back(qi);
+                                herr(f.err, TRI_ERR_UNSUPPORTED, "query %zu: more than %u terms", qi, MAX_QTERMS);
+                                continue;
+                        }
+                        // (default mode: the reportable terms — every postings iterator collect_doc_matching_terms can reach (queryexec_ctx.cpp:382-520):
+                        //  group members and phrase terms, not the excluded side of a NOT —, distinct, in order of first appearance; counted before
+                        //  anything of the query is recorded, so that a query with too many of them can still be left out cleanly)
+                        auto &rt = S.rt;
+                        rt.clear();
+                        if (rich) {
+                                for (uint32_t pi = 0; pi < tq.prog_len; ++pi) {
+                                        const uint32_t tok = prog[pi];
+                                        if ((tok >> 28) != TRI_OP_TERM)
+                                                continue;
+                                        const uint32_t x = tok & 0x0fffffffu;
+                                        const bool positive = std::find(S.leaves.begin(), S.leaves.end(), x) != S.leaves.end() ||
+                                                              std::find(S.phterms.begin(), S.phterms.end(), x) != S.phterms.end();
+                                        if (positive && std::find(rt.begin(), rt.end(), x) == rt.end())
+                                                rt.push_back(x);
+                                }
+                                if (rt.size() > 16) {
+                                        f.left_out.push_back(qi);
+                                        herr(f.err, TRI_ERR_UNSUPPORTED, "query %zu: more than 16 reportable terms", qi);
+                                        continue;
+                                }
+                        }
+                        const uint32_t g0 = gorder[0];
+                        const uint32_t nlead = gs[g0 + 1] - gs[g0];
+                        const uint64_t lead_docs = gcost(g0);
+                        Tmp t{};
+                        if (!S.qphrases.empty() && ix.codec == TRI_CODEC_LUCENE && !ix.has_hdir)
+                                return herr(f.err, TRI_ERR_INVALID, "query %zu: phrase over a LUCENE segment that was uploaded without hits.data", qi);
+                        t.q.phrase_base = (uint32_t)f.phrases.size();
+                        t.q.nphrases = (uint32_t)S.qphrases.size();
+                        for (const auto &ph : S.qphrases) {
+                                f.phrases.push_back({(uint32_t)f.pterms.size(), ph.n, ph.weight});
+                                for (uint32_t k = 0; k < ph.n; ++k) {
+                                        const uint32_t x = S.phterms[ph.t0 + k];
+                                        f.pterms.push_back(x);
+                                        f.term_bytes += ix.hitbytes[x]; // phrase queries also stream the hit bytes
+                                        f.term_bytes_phrase_hits += ix.hitbytes[x];
+                                }
+                        }
+                        t.q.score_base = (uint32_t)f.sterms.size();
+                        t.q.nscore = 0;
+                        if (rich) {
+                                for (uint32_t x : rt) {
+                                        f.sterms.push_back(x);
+                                        f.term_bytes += ix.hitbytes[x]; // the hits of every reported term are read
+                                }
+                                t.q.nscore = (uint32_t)rt.size();
+                                f.rich_R = std::max<uint32_t>(f.rich_R, t.q.nscore);
+                        }
+                        if (scored) {
+                                // one scorer per PostingsListIterator of the conjunction, summed in iterator order
+                                // (docset_iterators_scorers.cpp:173-193); weight = BM25 idf (similarity.h:179-181, float math)
+                                // unless the caller supplied ScorerWeights per TERM token — the leaf's OWN token (a term that also sits
+                                // inside a phrase or on an excluded side has another token with another weight)
+                                for (size_t li = 0; li < S.leaves.size(); ++li) {
+                                        f.sterms.push_back(S.leaves[li]);
+                                        f.sweights.push_back(weights ? weights[tq.prog_off + S.leaf_tok[li]] : C.term_weight(ix.terms[S.leaves[li]].documents));
+                                }
+                                t.q.nscore = (uint32_t)S.leaves.size();
+                        }
+                        // ---- slot map for the one-pass scored path (k_fused.hpp): the query's distinct terms, CNF terms first
+                        t.fz = -1;
+                        t.truth = truth;
+                        if (truth) {
+                                DevFused z{};
+                                z.nslots = (uint32_t)tp.slots.size();
+                                z.hw = 0; // (general trees run in their own instantiation, 32-bit window words)
+                                z.fbits = z.nslots <= 4 ? 8u : 4u;
+                                z.cap = (1u << z.fbits) - 2u;
+                                if (opt.fused_freq_cap && opt.fused_freq_cap < z.cap)
+                                        z.cap = (uint32_t)opt.fused_freq_cap;
+                                const uint32_t fm = (1u << z.fbits) - 1u;
+                                for (size_t i = 0; i < tp.slots.size(); ++i)
+                                        z.term[i] = tp.slots[i];
+                                // DocumentsOnly, the default mode and the full score stream (topk == 0) need the docID set; top-K batches do not
+                                z.mode = FUS_MODE_TT | ((scored && topk) ? 0u : FUS_MODE_EMIT);
+                                memcpy(z.tt, tp.tt, sizeof z.tt);
+                                if (rich) {
+                                        // per REPORTABLE term (distinct, f.sterms order): reported where any of its leaves sits on the document
+                                        z.nleaf = t.q.nscore;
+                                        for (uint32_t j = 0; j < t.q.nscore; ++j) {
+                                                const uint32_t term = f.sterms[t.q.score_base + j];
+                                                for (size_t l = 0; l < tp.leaves.size(); ++l)
+                                                        if (tp.leaves[l] == term) {
+                                                                z.leaf_slot[j] = (uint8_t)tp.leaf_slot[l];
+                                                                for (int wd = 0; wd < 8; ++wd)
+                                                                        z.ctt[j][wd] |= tp.ctt[l][wd];
+                                                        }
+                                        }
+                                        f.rich_allow = true;
+                                } else {
+                                        z.nleaf = (uint32_t)tp.leaves.size();
+                                        for (size_t j = 0; j < tp.leaves.size(); ++j) {
+                                                z.leaf_slot[j] = (uint8_t)tp.leaf_slot[j];
+                                                memcpy(z.ctt[j], tp.ctt[j].data(), sizeof z.ctt[j]);
+                                        }
+                                }
+                                // window skipping needs groups of slots one of which every match holds: the slots of the scorer leaves if no
+                                // matching pattern lacks them all (else every slot: pattern 0 never matches), then every slot all matches hold
+                                const uint32_t npat = 1u << z.nslots;
+                                auto matches = [&](uint32_t p) { return (tp.tt[p >> 5] >> (p & 31u)) & 1u; };
+                                uint32_t gl = 0;
+                                for (uint32_t sl : tp.leaf_slot)
+                                        gl |= 1u << sl;
+                                for (uint32_t p = 0; p < npat; ++p)
+                                        if (matches(p) && !(p & gl))
+                                                gl = npat - 1;
+                                auto add_req = [&](uint32_t gsl) {
+                                        z.gslots[z.nreq] = gsl;
+                                        for (uint32_t sl = 0; sl < z.nslots; ++sl)
+                                                if ((gsl >> sl) & 1u)
+                                                        z.gmask[z.nreq] |= fm << (sl * z.fbits);
+                                        ++z.nreq;
+                                };
+                                add_req(gl);
+                                for (uint32_t sl = 0; sl < z.nslots && z.nreq < FUS_MAX_SLOTS; ++sl) {
+                                        bool all = gl != (1u << sl);
+                                        for (uint32_t p = 0; p < npat && all; ++p)
+                                                all = !matches(p) || ((p >> sl) & 1u);
+                                        if (all)
+                                                add_req(1u << sl);
+                                }
+                                t.fz = (int32_t)f.fz.size();
+                                f.fz.push_back(z);
+                        } else if (scored && topk && S.qphrases.empty() && opt.fused) {
+                                auto &slots = S.slots;
+                                slots.clear();
+                                auto slot_of = [&](uint32_t term) {
+                                        for (size_t i = 0; i < slots.size(); ++i)
+                                                if (slots[i] == term)
+                                                        return (uint32_t)i;
+                                        slots.push_back(term);
+                                        return (uint32_t)slots.size() - 1;
+                                };
+                                for (uint32_t tt : uniq)
+                                        slot_of(tt & QT_TERM);
+                                for (uint32_t x : S.leaves)
+                                        slot_of(x);
+                                if (slots.size() <= FUS_MAX_SLOTS) {
+                                        DevFused z{};
+                                        z.nslots = (uint32_t)slots.size();
+                                        z.hw = (opt.fused_halfwords && z.nslots <= 5) ? 1u : 0u;
+                                        z.fbits = z.hw ? std::min(8u, 16u / z.nslots) : (z.nslots <= 4 ? 8u : 4u);
+                                        z.cap = (1u << z.fbits) - 2u;
+                                        if (opt.fused_freq_cap && opt.fused_freq_cap < z.cap)
+                                                z.cap = (uint32_t)opt.fused_freq_cap;
+                                        const uint32_t fm = (1u << z.fbits) - 1u;
+                                        for (size_t i = 0; i < slots.size(); ++i)
+                                                z.term[i] = slots[i];
+                                        int g = -1;
+                                        bool in_not = false;
+                                        uint32_t nreq_groups = 0;
+                                        for (uint32_t tt : uniq)
+                                                nreq_groups += (tt & QT_GROUP) && !(tt & QT_NOT);
+                                        for (uint32_t tt : uniq) {
+                                                if (nreq_groups > FUS_MAX_SLOTS)
+                                                        break; // (a CNF that repeats its terms over more groups than the slot map holds)
+                                                if (tt & QT_GROUP) {
+                                                        in_not = tt & QT_NOT;
+                                                        if (!in_not)
+                                                                ++g;
+                                                }
+                                                const uint32_t sidx = slot_of(tt & QT_TERM);
+                                                if (in_not)
+                                                        z.nmask |= fm << (sidx * z.fbits);
+                                                else {
+                                                        z.gmask[g] |= fm << (sidx * z.fbits);
+                                                        z.gslots[g] |= 1u << sidx;
+                                                }
+                                        }
+                                        z.nreq = (uint32_t)(g + 1);
+                                        if (z.nreq >= 1 && nreq_groups <= FUS_MAX_SLOTS) {
+                                                t.fz = (int32_t)f.fz.size();
+                                                f.fz.push_back(z);
+                                        }
+                                }
+                        }
+                        t.q.fused_idx = 0;
+                        t.q.pad0 = 0;
+                        t.q.nterms = (uint32_t)uniq.size();
+                        t.q.term_base = (uint32_t)f.qterms.size();
+                        t.q.out_cap = 0;
+                        t.q.out_off = 0;
+                        t.q.qid = (uint32_t)qi;
+                        t.cost = 0;
+                        t.nlead = nlead;
+                        {
+                                auto &seen = S.seen;
+                                seen.clear();
+                                for (uint32_t tt : uniq) {
+                                        const uint32_t term = tt & QT_TERM;
+                                        f.qterms.push_back(tt);
+                                        if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
+                                                seen.push_back(term);
+                                                f.term_bytes += ix.docbytes[term];
+                                        }
+                                }
+                                // cost estimate: the lead group is decoded fully; every other list costs min(its blocks x 32, lead docs x 32)
+                                for (size_t i = 0; i < uniq.size(); ++i) {
+                                        const DevTerm &tk = ix.terms[uniq[i] & QT_TERM];
+                                        t.cost += i < nlead ? tk.documents : 32ull * std::min<uint64_t>(tk.nblocks, lead_docs);
+                                }
+                        }
+                        // ---- execution class.  TASK_DENSE (bitmap windows) when the lead group is an OR (it has to be materialised as a set
+                        //      anyway), or when every other list is within a factor 32 of the lead (no block could be skipped) and there is
+                        //      enough work per docID window to keep 256 lanes busy; one pass (TASK_FUSED / TASK_PLANES) when such a query
+                        //      asks for a top-K, or is a general tree
+                        {
+                                t.sumdf = 0;
+                                t.lead_docs = lead_docs;
+                                t.last_doc = 0xffffffffu;
+                                t.dense = uniq.size() >= 2;
+                                uint32_t glast = 0;
+                                bool in_neg = false;
+                                for (size_t k = 0; k < uniq.size(); ++k) {
+                                        const DevTerm &tk = ix.terms[uniq[k] & QT_TERM];
+                                        t.sumdf += tk.documents;
+                                        t.dense &= tk.nblocks <= lead_docs;
+                                        if (k && (uniq[k] & QT_GROUP)) {
+                                                t.last_doc = std::min(t.last_doc, glast);
+                                                glast = 0;
+                                                in_neg = uniq[k] & QT_NOT;
+                                        }
+                                        if (!in_neg)
+                                                glast = std::max(glast, ix.blk_last[tk.first_block + tk.nblocks - 1]);
+                                }
+                                if (!in_neg)
+                                        t.last_doc = std::min(t.last_doc, glast);
+                                t.dense &= t.sumdf >= opt.dense_min_postings;
+                                t.dense |= nlead > 1;
+                                const bool fusable = t.fz >= 0;
+                                t.fuse = truth || (t.dense && fusable && (opt.fused != 2 || f.fz[t.fz].nreq == 1)); // (fused == 2: only pure unions)
+                                if (t.fuse) {
+                                        ++f.onepass_queries;
+                                        const DevFused &z = f.fz[t.fz];
+                                        for (uint32_t sidx = 0; sidx < z.nslots; ++sidx)
+                                                f.fused_postings += ix.terms[z.term[sidx]].documents;
+                                }
+                        }
+                        f.tmp.push_back(t);
+                }
+                return TRI_OK;
+        }
+
+        // ---- second pass: cut the fragment's queries into tasks (offsets relative to the fragment)
+        inline int task_range(const Ctx &C, Frag &f) {
+                const HostIndex &ix = C.ix;
+                const tri_options &opt = C.env.opt;
+                const uint64_t planes_opt = opt.planes;
+                const uint64_t DENSE_TASK_COST = std::max<uint64_t>(1, opt.dense_task_cost); // bitmap-window tasks stage their terms once: two windows of a head pair per task
+                const uint64_t PLANES_SPLIT = C.planes_split, FUSED_TASK_COST = C.fused_task_cost;
+                f.benefit.assign(C.n_ok, 0);
+                uint64_t off = 0;
+                for (size_t ti = 0; ti < f.tmp.size(); ++ti) {
+                        Tmp &t = f.tmp[ti];
+                        const uint32_t slot = (uint32_t)ti;
+                        const uint32_t *qt = &f.qterms[t.q.term_base];
+                        const DevTerm &lead = ix.terms[qt[0] & QT_TERM];
+                        const uint32_t nlead = t.nlead;
+                        const uint32_t last_doc = t.last_doc;
+                        if (t.fuse) {
+                                // a CNF query whose top-K runs over bit planes (k_planes): its head terms read from the batch's term planes, the
+                                // others (at most PLK_MAX_SPARSE) decoded per window into LDS planes
+                                DevFused z = f.fz[t.fz];
+                                uint32_t nsparse = 0;
+                                for (uint32_t sidx = 0; sidx < z.nslots; ++sidx) {
+                                        z.plane[sidx] = PL_NONE;
+                                        nsparse += C.plane_ok(z.term[sidx]) ? 0u : 1u;
+                                }
+                                const bool pk = !t.truth && (planes_opt & 4u) && nsparse <= PLK_MAX_SPARSE && ix.max_doc < 0x7fff0000u; // (list entries are docID << 1 | flag)
+                                {
+                                        const uint32_t fm = (1u << z.fbits) - 1u;
+                                        z.negslots = 0;
+                                        for (uint32_t sidx = 0; sidx < z.nslots; ++sidx)
+                                                if ((z.nmask >> (sidx * z.fbits)) & fm)
+                                                        z.negslots |= 1u << sidx;
+                                }
+                                // every list of the slot map is read once (the optional terms too)
+                                uint64_t slotdf = 0;
+                                for (uint32_t sidx = 0; sidx < z.nslots; ++sidx) {
+                                        slotdf += ix.terms[z.term[sidx]].documents;
+                                        (pk ? f.term_bytes_planes : f.term_bytes_fused) += ix.docbytes[z.term[sidx]];
+                                        if (pk && C.plane_ok(z.term[sidx])) {
+                                                f.benefit[ix.df_rank[z.term[sidx]]] += ix.terms[z.term[sidx]].documents;
+                                                f.fuses.push_back({(uint32_t)f.fused.size(), sidx, z.term[sidx]});
+                                        }
+                                }
+                                ++(pk ? f.planes_queries : f.fused_queries);
+                                t.q.fused_idx = (uint32_t)f.fused.size();
+                                t.q.out_off = off;
+                                t.q.out_cap = 0; // the docID set is never materialised ...
+                                t.q.first_task = (uint32_t)f.tasks.size();
+                                const uint32_t fw = pk ? PL_W : FUS_W << z.hw; // documents per window: plane windows, or this query's word width
+                                const uint32_t nwin = last_doc / fw + 1;
+                                const uint64_t per_win = std::max<uint64_t>(1, slotdf / (ix.info.docs_cnt / fw + 1));
+                                // (k_planes' cost is the sweep of the range plus its candidates, not the postings: equal ranges, a few per query)
+                                const uint32_t win_per_task = pk && PLANES_SPLIT < 65536 ? (uint32_t)((nwin + PLANES_SPLIT - 1) / PLANES_SPLIT)
+                                                                                         : (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
+                                const bool emit = z.mode & FUS_MODE_EMIT; // ... except by a general tree in DocumentsOnly mode: a private region per task,
+                                                                          // bounded like TASK_DENSE's by the slots' blocks that reach the task's windows
+                                uint32_t ord = 0;
+                                for (uint32_t wb = 0; wb < nwin; wb += win_per_task, ++ord) {
+                                        const uint32_t we = std::min(nwin, wb + win_per_task);
+                                        uint64_t b1 = 0;
+                                        if (emit)
+                                                for (uint32_t sidx = 0; sidx < z.nslots; ++sidx)
+                                                        b1 += C.first_block_ge(ix.terms[z.term[sidx]], (uint64_t)wb * fw);
+                                        uint64_t entries = 0;
+                                        if (pk) { // the rows of the decoded slots that can reach the task's docID range: 32 list entries each (k_planes)
+                                                for (uint32_t sidx = 0; sidx < z.nslots; ++sidx) {
+                                                        if (C.plane_ok(z.term[sidx]))
+                                                                continue;
+                                                        const DevTerm &tk = ix.terms[z.term[sidx]];
+                                                        const uint32_t r0 = C.first_block_ge(tk, (uint64_t)wb * fw);
+                                                        const uint32_t r1 = C.first_block_ge(tk, (uint64_t)we * fw);
+                                                        if (r0 < tk.nblocks)
+                                                                entries += 32ull * (std::min(r1, tk.nblocks - 1) - r0 + 1);
+                                                }
+                                                if (entries > 0x7fffffffull)
+                                                        return herr(f.err, TRI_ERR_UNSUPPORTED, "query %u: a task's decoded lists exceed 2^31 entries", t.q.qid);
+                                                f.sparse_cap = std::max(f.sparse_cap, (uint32_t)entries);
+                                        }
+                                        // (largest first, by postings: for k_planes a poor estimate — its cost is the sweep plus the candidates — but ordering by the
+                                        //  decoded entries instead measured worse: cfg3's unions 10.6 ms against 9.2)
+                                        f.tcost.push_back(per_win * (we - wb));
+                                        f.tasks.push_back({slot, wb, we, pk ? (z.nslots <= PLK_NS_SMALL ? TASK_PLANES : TASK_PLANES8) : z.mode ? TASK_FUSED_GEN : z.hw ? TASK_FUSED16 : TASK_FUSED,
+                                                           off + (emit ? b1 * 32 + 32ull * ord * z.nslots : 0)});
+                                }
+                                if (emit) {
+                                        uint64_t blocks = 0;
+                                        for (uint32_t sidx = 0; sidx < z.nslots; ++sidx)
+                                                blocks += ix.terms[z.term[sidx]].nblocks;
+                                        t.q.out_cap = (uint32_t)std::min<uint64_t>(0xffffffffull, blocks * 32 + 32ull * (ord + 1) * z.nslots);
+                                        off += t.q.out_cap;
+                                }
+                                t.q.ntasks = (uint32_t)f.tasks.size() - t.q.first_task;
+                                f.fused.push_back(z);
+                                continue;
+                        }
+                        if (t.dense) {
+                                auto &seen = f.S.seen;
+                                seen.clear();
+                                for (uint32_t k = 0; k < t.q.nterms; ++k) {
+                                        const uint32_t term = qt[k] & QT_TERM;
+                                        if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
+                                                seen.push_back(term);
+                                                f.term_bytes_dense += ix.docbytes[term];
+                                        }
+                                        if ((planes_opt & 2u) && C.plane_ok(term)) {
+                                                f.benefit[ix.df_rank[term]] += ix.terms[term].documents;
+                                                f.quses.push_back({t.q.term_base + k, term});
+                                        }
+                                }
+                                ++f.dense_queries;
+                        } else {
+                                ++f.cand_queries;
+                                for (uint32_t k = 1; k < t.q.nterms; ++k) { // (the lead list is decoded into the candidate tiles; the others are probed)
+                                        const uint32_t term = qt[k] & QT_TERM;
+                                        if ((planes_opt & 1u) && C.plane_ok(term)) {
+                                                f.benefit[ix.df_rank[term]] += std::min<uint64_t>(ix.terms[term].documents, 32ull * lead.documents);
+                                                f.quses.push_back({t.q.term_base + k, term});
+                                        }
+                                }
+                        }
+                        t.q.out_off = off;
+                        t.q.first_task = (uint32_t)f.tasks.size();
+                        if (t.dense) {
+                                const uint32_t nwin = last_doc / SPAN_BITS + 1;
+                                const uint64_t per_win = std::max<uint64_t>(1, t.sumdf / (ix.info.docs_cnt / SPAN_BITS + 1));
+                                const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / per_win);
+                                uint32_t ord = 0;
+                                uint64_t lead_blocks = 0;
+                                for (uint32_t k = 0; k < nlead; ++k)
+                                        lead_blocks += ix.terms[qt[k] & QT_TERM].nblocks;
+                                for (uint32_t wb = 0; wb < nwin; wb += win_per_task, ++ord) {
+                                        const uint32_t we = std::min(nwin, wb + win_per_task);
+                                        // matches of windows [wb, we) are lead-group documents of blocks b1 .. (next task's b1) of every
+                                        // lead list: a private region (+32 slots of slack per lead list and task for the straddling block)
+                                        uint64_t b1 = 0;
+                                        for (uint32_t k = 0; k < nlead; ++k)
+                                                b1 += C.first_block_ge(ix.terms[qt[k] & QT_TERM], (uint64_t)wb * SPAN_BITS);
+                                        f.tcost.push_back(per_win * (we - wb));
+                                        f.tasks.push_back({slot, wb, we, TASK_DENSE, off + b1 * 32 + 32ull * ord * nlead});
+                                }
+                                t.q.out_cap = (uint32_t)std::min<uint64_t>(0xffffffffull, lead_blocks * 32 + 32ull * (ord + 1) * nlead);
+                        } else {
+                                const uint32_t ntiles = (lead.nblocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
+                                const uint64_t per_tile = std::max<uint64_t>(1, t.cost / ntiles);
+                                const uint32_t tiles_per_task = (uint32_t)std::max<uint64_t>(1, TASK_COST / per_tile);
+                                for (uint32_t tb = 0; tb < ntiles; tb += tiles_per_task) {
+                                        const uint32_t te = std::min(ntiles, tb + tiles_per_task);
+                                        f.tcost.push_back(per_tile * (te - tb));
+                                        f.tasks.push_back({slot, tb, te, TASK_CAND, off + (uint64_t)tb * TILE_CANDS});
+                                }
+                                t.q.out_cap = lead.documents; // |A ∩ …| <= df of the lead
+                                if (opt.account_needed_bytes) {
+                                        // what a perfect gallop must read: the lead list, and of every other list the blocks that can hold a lead
+                                        // candidate — per lead block the other list's blocks its docID range meets, at most one per candidate
+                                        // (directories only; a block counts docbytes / nblocks)
+                                        uint64_t need = ix.docbytes[qt[0] & QT_TERM];
+                                        const uint32_t *ll = &ix.blk_last[lead.first_block];
+                                        for (uint32_t k = 1; k < t.q.nterms; ++k) {
+                                                const DevTerm &tk = ix.terms[qt[k] & QT_TERM];
+                                                const uint32_t *ol = &ix.blk_last[tk.first_block];
+                                                uint64_t blocks = 0;
+                                                uint32_t at = 0; // (both directories ascend: the searches move forward)
+                                                for (uint32_t lb = 0; lb < lead.nblocks && at < tk.nblocks; ++lb) {
+                                                        const uint32_t lo_doc = lb ? ll[lb - 1] + 1 : 1u, hi_doc = ll[lb];
+                                                        at = (uint32_t)(std::lower_bound(ol + at, ol + tk.nblocks, lo_doc) - ol);
+                                                        if (at >= tk.nblocks)
+                                                                break;
+                                                        const uint32_t last = (uint32_t)(std::lower_bound(ol + at, ol + tk.nblocks, hi_doc) - ol);
+                                                        const uint32_t span = std::min(last, tk.nblocks - 1) - at + 1;
+                                                        const uint32_t ndocs = lb + 1 == lead.nblocks ? lead.last_n : 32u;
+                                                        blocks += std::min(span, ndocs);
+                                                }
+                                                need += (uint64_t)((double)ix.docbytes[qt[k] & QT_TERM] * std::min(1.0, (double)blocks / std::max(1u, tk.nblocks)));
+                                        }
+                                        f.cand_needed += need;
+                                }
+                        }
+                        off += t.q.out_cap;
+                        t.q.ntasks = (uint32_t)f.tasks.size() - t.q.first_task;
+                        if (t.q.nphrases)
+                                for (uint32_t k = t.q.first_task; k < t.q.first_task + t.q.ntasks; ++k)
+                                        f.ptasks.push_back(k);
+                }
+                f.off = off;
+                return TRI_OK;
+        }
+
+        inline double ms_since(std::chrono::steady_clock::time_point &t0) {
+                const auto now = std::chrono::steady_clock::now();
+                const double ms = std::chrono::duration<double, std::milli>(now - t0).count();
+                t0 = now;
+                return ms;
+        }
+} // namespace trip
+
+// Plan a batch.  `alloc_block(bytes)` provides the host block the plan's arrays are laid out in (pinned memory when a device will copy
+// it; it must stay valid as long as the plan is used, and is 64-byte aligned); `pool` may be null (everything on the calling thread).
+// Returns TRI_OK, or an error code with its text in `err` (a query shape the planner does not lower is NOT an error: BatchPlan::qstatus).
+inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &in, HostPool *pool, const std::function<uint8_t *(size_t)> &alloc_block,
+                      BatchPlan &P, std::string &err) {
+        using namespace trip;
+        auto t0 = std::chrono::steady_clock::now();
+        const uint32_t mode = in.flags & (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE | TRI_FLAG_MATCHED_TERMS);
+        Ctx C{ix, env, in, mode == TRI_FLAG_ACCUMULATED_SCORE, mode == TRI_FLAG_MATCHED_TERMS, mode};
+        const tri_options &opt = env.opt;
+        const size_t nq = in.nq;
+        P.slot_of_query.assign(nq, UINT32_MAX);
+        P.qstatus.assign(nq, TRI_OK);
+        // ---- which terms may get a plane: an indexed list of at least docs_cnt / plane_div documents, the longest lists first up to the
+        //      scratch budget (a plane row is three bitmaps over the docID space)
+        P.plw = ((ix.max_doc >> 17) + 2u) * (SPAN_BITS / 32u); // whole bitmap windows (k_and_dense reads SPAN_WORDS at a time) + a spare one
+        if (opt.planes && opt.plane_div && !ix.df_sorted.empty()) {
+                const uint64_t min_df = std::max<uint64_t>(1, ix.info.docs_cnt / opt.plane_div);
+                // df_sorted descends: the first rank whose list is too short
+                const size_t n = (size_t)(std::partition_point(ix.df_sorted.begin(), ix.df_sorted.end(), [&](uint32_t d) { return d && d >= min_df; }) - ix.df_sorted.begin());
+                const uint64_t row_bytes = (uint64_t)PL_PLANES * P.plw * 4;
+                C.n_ok = (uint32_t)std::min<uint64_t>(n, std::max<uint64_t>(1, opt.plane_max_bytes / std::max<uint64_t>(1, row_bytes)));
+        }
+        // ---- fragments: contiguous ranges of the batch, a couple per thread (dealt out dynamically)
+        const unsigned nthreads = pool ? std::min<unsigned>(pool->size(), (unsigned)std::max<size_t>(1, nq / 512)) : 1u;
+        const size_t nfrag = nthreads <= 1 ? 1 : std::min<size_t>(2 * nthreads, std::max<size_t>(1, nq / 256));
+        std::vector<Frag> frags(nfrag);
+        for (size_t k = 0; k < nfrag; ++k) {
+                frags[k].q_lo = nq * k / nfrag;
+                frags[k].q_hi = nq * (k + 1) / nfrag;
+        }
+        auto run = [&](const std::function<void(unsigned)> &fn) {
+                if (pool && nfrag > 1)
+                        pool->run((unsigned)nfrag, fn);
+                else
+                        for (unsigned k = 0; k < nfrag; ++k)
+                                fn(k);
+        };
+        auto first_error = [&]() -> int {
+                for (Frag &f : frags)
+                        if (f.rc != TRI_OK) {
+                                err = f.err;
+                                return f.rc;
+                        }
+                return TRI_OK;
+        };
+        run([&](unsigned k) {
+                Frag &f = frags[k];
+                try {
+                        f.rc = lower_range(C, f);
+                } catch (const std::bad_alloc &) {
+                        f.rc = herr(f.err, TRI_ERR_NOMEM, "tri_batch_create: out of host memory while lowering the batch");
+                } catch (...) {
+                        f.rc = herr(f.err, TRI_ERR_INVALID, "tri_batch_create: unexpected exception while lowering the batch");
+                }
+        });
+        if (int rc = first_error())
+                return rc;
+        // ---- between the passes: what depends on the whole batch
+        uint64_t onepass_queries = 0, fused_postings = 0;
+        for (const Frag &f : frags) {
+                onepass_queries += f.onepass_queries;
+                fused_postings += f.fused_postings;
+        }
+        // k_planes: docID ranges per query.  A task has fixed costs (seed pass, end-of-task imbalance: about 140 us), the kernel's tail is its
+        // longest tasks: two ranges when the batch brings ten or more tasks per resident workgroup anyway, three when it does not (measured,
+        // cfg3's mix: 8192 queries 2 > 3 > 4; 3750 queries 6.5 / 5.9 / 6.2 ms for 2 / 3 / 4; 1024 queries 2.11 / 1.97 / 1.96)
+        C.planes_split = opt.planes_split ? opt.planes_split : (2 * onepass_queries >= 10ull * (uint64_t)env.cus * env.plk_wgs_per_cu ? 2 : 3);
+        // one-pass tasks stage the query (slot map, score tables) once per task: the longer the task the better, as long as the batch still
+        // cuts into a couple of tasks per workgroup the device holds (measured at cfg3: 512 K postings per task 55.4 ms, 1 M 51.1, 2 M 49.2,
+        // 4 M 48.0, 8 M and more 47.1).  fused_task_cost = 0 (the default): sized from the batch; otherwise as given
+        C.fused_task_cost = opt.fused_task_cost;
+        if (!C.fused_task_cost) {
+                const uint64_t want_tasks = 2ull * (uint64_t)env.cus * env.fus_wgs_per_cu;
+                C.fused_task_cost = std::min<uint64_t>(8u << 20, std::max<uint64_t>(256u << 10, fused_postings / std::max<uint64_t>(1, want_tasks)));
+        }
+        P.plan_ms[0] = ms_since(t0);
+        run([&](unsigned k) {
+                Frag &f = frags[k];
+                try {
+                        f.rc = task_range(C, f);
+                } catch (const std::bad_alloc &) {
+                        f.rc = herr(f.err, TRI_ERR_NOMEM, "tri_batch_create: out of host memory while cutting the batch into tasks");
+                } catch (...) {
+                        f.rc = herr(f.err, TRI_ERR_INVALID, "tri_batch_create: unexpected exception while cutting the batch into tasks");
+                }
+        });
+        if (int rc = first_error())
+                return rc;
+        P.plan_ms[1] = ms_since(t0);
+        // ---- the fragments' places in the batch's arrays; sums
+        size_t n_plan = 0, n_qterms = 0, n_sterms = 0, n_phrases = 0, n_pterms = 0, n_tasks = 0, n_fused = 0, n_ptasks = 0;
+        uint64_t off = 0;
+        std::vector<uint64_t> benefit(C.n_ok, 0);
+        for (Frag &f : frags) {
+                f.b_plan = n_plan, f.b_qterms = n_qterms, f.b_sterms = n_sterms, f.b_phrases = n_phrases, f.b_pterms = n_pterms, f.b_tasks = n_tasks, f.b_fused = n_fused,
+                f.b_ptasks = n_ptasks, f.b_off = off;
+                n_plan += f.tmp.size(), n_qterms += f.qterms.size(), n_sterms += f.sterms.size(), n_phrases += f.phrases.size(), n_pterms += f.pterms.size(),
+                        n_tasks += f.tasks.size(), n_fused += f.fused.size(), n_ptasks += f.ptasks.size(), off += f.off;
+                P.term_bytes += f.term_bytes, P.term_bytes_phrase_hits += f.term_bytes_phrase_hits, P.term_bytes_dense += f.term_bytes_dense,
+                        P.term_bytes_fused += f.term_bytes_fused, P.term_bytes_planes += f.term_bytes_planes, P.cand_needed_term_bytes += f.cand_needed;
+                P.dense_queries += f.dense_queries, P.cand_queries += f.cand_queries, P.fused_queries += f.fused_queries, P.planes_queries += f.planes_queries;
+                P.rich_R = std::max(P.rich_R, f.rich_R);
+                P.rich_allow |= f.rich_allow;
+                P.sparse_cap = std::max(P.sparse_cap, f.sparse_cap);
+                for (uint32_t r = 0; r < C.n_ok; ++r)
+                        benefit[r] += f.benefit[r];
+                for (const size_t qi : f.left_out) { // a query shape the planner does not lower does not fail the batch: the query is left out (status
+                                                     // TRI_ERR_UNSUPPORTED, no matches) and the caller keeps its CPU span for it
+                        P.qstatus[qi] = TRI_ERR_UNSUPPORTED;
+                        ++P.unsupported_queries;
+                }
+                if (!f.left_out.empty())
+                        P.last_unsupported = f.err;
+        }
+        if (n_qterms > 0xfffffff0ull || n_sterms > 0xfffffff0ull || n_tasks > 0xfffffff0ull || n_pterms > 0xfffffff0ull)
+                return herr(err, TRI_ERR_UNSUPPORTED, "tri_batch_create: the batch exceeds 2^32 terms or tasks: split it");
+        P.out_capacity = off;
+        // ---- the planes that pay: rows in term order (deterministic), the uses pointed at them.  A term is chosen when the batch's uses repay
+        //      one decode of its list (a one-pass slot counts a whole decode: always chosen)
+        std::vector<uint32_t> chosen; // terms
+        {
+                std::vector<uint32_t> rank_term; // df rank -> term, for the eligible ranks only (built lazily from the uses)
+                rank_term.assign(C.n_ok, UINT32_MAX);
+                for (const Frag &f : frags) {
+                        for (const QUse &u : f.quses)
+                                rank_term[ix.df_rank[u.term]] = u.term;
+                        for (const FUse &u : f.fuses)
+                                rank_term[ix.df_rank[u.term]] = u.term;
+                }
+                std::vector<uint8_t> forced(C.n_ok, 0);
+                for (const Frag &f : frags)
+                        for (const FUse &u : f.fuses)
+                                forced[ix.df_rank[u.term]] = 1;
+                for (uint32_t r = 0; r < C.n_ok; ++r)
+                        if (rank_term[r] != UINT32_MAX && (forced[r] || benefit[r] >= ix.terms[rank_term[r]].documents))
+                                chosen.push_back(rank_term[r]);
+                std::sort(chosen.begin(), chosen.end());
+        }
+        std::vector<uint32_t> row_of_rank(C.n_ok, PL_NONE);
+        for (size_t i = 0; i < chosen.size(); ++i) {
+                row_of_rank[ix.df_rank[chosen[i]]] = (uint32_t)i;
+                P.plane_decoded_bytes += ix.docbytes[chosen[i]];
+        }
+        // ---- layout of the host block
+        size_t bytes = 0;
+        auto section = [&](size_t &off_out, size_t n, size_t elem) {
+                off_out = bytes;
+                bytes += (n * elem + SECTION_ALIGN + SECTION_ALIGN - 1) & ~(SECTION_ALIGN - 1); // (a spare 64 bytes behind every array: wide loads at an array's end stay inside the block)
+        };
+        const size_t n_qplane = chosen.empty() ? 0 : n_qterms;
+        section(P.off_plan, n_plan, sizeof(DevQuery));
+        section(P.off_qterms, n_qterms, 4);
+        section(P.off_tasks, n_tasks, sizeof(DevTask));
+        section(P.off_sched, n_tasks, 4);
+        section(P.off_fused, n_fused, sizeof(DevFused));
+        section(P.off_qplane, n_qplane, 4);
+        section(P.off_plane_terms, chosen.size(), 4);
+        section(P.off_sterms, n_sterms, 4);
+        section(P.off_sweights, C.scored ? n_sterms : 0, 8);
+        section(P.off_phrases, n_phrases, sizeof(DevPhrase));
+        section(P.off_pterms, n_pterms, 4);
+        section(P.off_ptasks, n_ptasks, 4);
+        P.block_bytes = bytes;
+        P.block = alloc_block(bytes);
+        if (!P.block)
+                return herr(err, TRI_ERR_NOMEM, "tri_batch_create: no host memory for the plan (%zu bytes)", bytes);
+        auto span = [&](auto &s, size_t off_, size_t n) {
+                using T = std::remove_reference_t<decltype(*s.p)>;
+                s.p = reinterpret_cast<T *>(P.block + off_);
+                s.n = n;
+        };
+        span(P.plan, P.off_plan, n_plan);
+        span(P.qterms, P.off_qterms, n_qterms);
+        span(P.tasks, P.off_tasks, n_tasks);
+        span(P.sched, P.off_sched, n_tasks);
+        span(P.fused, P.off_fused, n_fused);
+        span(P.qplane, P.off_qplane, n_qplane);
+        span(P.plane_terms, P.off_plane_terms, chosen.size());
+        span(P.sterms, P.off_sterms, n_sterms);
+        span(P.sweights, P.off_sweights, C.scored ? n_sterms : 0);
+        span(P.phrases, P.off_phrases, n_phrases);
+        span(P.pterms, P.off_pterms, n_pterms);
+        span(P.ptasks, P.off_ptasks, n_ptasks);
+        std::copy(chosen.begin(), chosen.end(), P.plane_terms.p);
+        std::vector<uint64_t> tcost(n_tasks);
+        // ---- every fragment writes its part of the arrays, rebased
+        run([&](unsigned k) {
+                Frag &f = frags[k];
+                for (size_t i = 0; i < f.tmp.size(); ++i) {
+                        DevQuery q = f.tmp[i].q;
+                        q.term_base += (uint32_t)f.b_qterms;
+                        q.score_base += (uint32_t)f.b_sterms;
+                        q.phrase_base += (uint32_t)f.b_phrases;
+                        q.first_task += (uint32_t)f.b_tasks;
+                        q.out_off += f.b_off;
+                        if (f.tmp[i].fuse)
+                                q.fused_idx += (uint32_t)f.b_fused;
+                        P.plan[f.b_plan + i] = q;
+                        P.slot_of_query[q.qid] = (uint32_t)(f.b_plan + i);
+                }
+                for (size_t i = 0; i < f.tasks.size(); ++i) {
+                        DevTask t = f.tasks[i];
+                        t.slot += (uint32_t)f.b_plan;
+                        t.out_off += f.b_off;
+                        P.tasks[f.b_tasks + i] = t;
+                        tcost[f.b_tasks + i] = f.tcost[i];
+                }
+                if (!f.qterms.empty())
+                        memcpy(&P.qterms[f.b_qterms], f.qterms.data(), f.qterms.size() * 4);
+                if (!f.sterms.empty())
+                        memcpy(&P.sterms[f.b_sterms], f.sterms.data(), f.sterms.size() * 4);
+                if (C.scored && !f.sweights.empty())
+                        memcpy(&P.sweights[f.b_sterms], f.sweights.data(), f.sweights.size() * 8);
+                for (size_t i = 0; i < f.phrases.size(); ++i) {
+                        DevPhrase ph = f.phrases[i];
+                        ph.term_base += (uint32_t)f.b_pterms;
+                        P.phrases[f.b_phrases + i] = ph;
+                }
+                if (!f.pterms.empty())
+                        memcpy(&P.pterms[f.b_pterms], f.pterms.data(), f.pterms.size() * 4);
+                for (size_t i = 0; i < f.ptasks.size(); ++i)
+                        P.ptasks[f.b_ptasks + i] = f.ptasks[i] + (uint32_t)f.b_tasks;
+                for (size_t i = 0; i < f.fused.size(); ++i)
+                        P.fused[f.b_fused + i] = f.fused[i];
+                for (const FUse &u : f.fuses)
+                        P.fused[f.b_fused + u.fidx].plane[u.slot] = row_of_rank[ix.df_rank[u.term]];
+                if (n_qplane) {
+                        std::fill(&P.qplane.p[f.b_qterms], &P.qplane.p[f.b_qterms] + f.qterms.size(), PL_NONE);
+                        for (const QUse &u : f.quses)
+                                P.qplane[f.b_qterms + u.qpos] = row_of_rank[ix.df_rank[u.term]];
+                }
+        });
+        P.plan_ms[2] = ms_since(t0);
+        // ---- the schedule: per kernel, heaviest tasks first.  A counting sort by (kernel, cost octave + 3 bits): tasks within 12 % of each
+        //      other keep their order in the batch — all a longest-first dispatch needs
+        {
+                constexpr uint32_t NB = 64 * 8;
+                static const uint32_t kind_rank[7] = {1, 0, 2, 3, 4, 5, 6}; // TASK_CAND after TASK_DENSE, then the one-pass kinds as numbered
+                auto key = [&](size_t i) {
+                        const uint64_t c = std::max<uint64_t>(1, tcost[i]);
+                        const uint32_t lg = 63u - (uint32_t)__builtin_clzll(c);
+                        const uint32_t frac = lg >= 3 ? (uint32_t)((c >> (lg - 3)) & 7u) : (uint32_t)((c << (3 - lg)) & 7u);
+                        return kind_rank[P.tasks[i].kind] * NB + (NB - 1 - (lg * 8 + frac));
+                };
+                std::vector<uint32_t> cnt(7 * NB + 1, 0);
+                std::vector<uint32_t> keys(n_tasks);
+                for (size_t i = 0; i < n_tasks; ++i)
+                        ++cnt[(keys[i] = key(i)) + 1];
+                P.n_dense = std::accumulate(cnt.begin() + 1, cnt.begin() + 1 + NB, 0u);
+                P.n_cand = std::accumulate(cnt.begin() + 1 + NB, cnt.begin() + 1 + 2 * NB, 0u);
+                P.n_fused = std::accumulate(cnt.begin() + 1 + 2 * NB, cnt.begin() + 1 + 3 * NB, 0u);
+                P.n_fused16 = std::accumulate(cnt.begin() + 1 + 3 * NB, cnt.begin() + 1 + 4 * NB, 0u);
+                P.n_fusedgen = std::accumulate(cnt.begin() + 1 + 4 * NB, cnt.begin() + 1 + 5 * NB, 0u);
+                P.n_planes = std::accumulate(cnt.begin() + 1 + 5 * NB, cnt.begin() + 1 + 6 * NB, 0u);
+                P.n_planes8 = std::accumulate(cnt.begin() + 1 + 6 * NB, cnt.begin() + 1 + 7 * NB, 0u);
+                for (size_t i = 1; i < cnt.size(); ++i)
+                        cnt[i] += cnt[i - 1];
+                for (size_t i = 0; i < n_tasks; ++i)
+                        P.sched[cnt[keys[i]]++] = (uint32_t)i;
+        }
+        P.sparse_cap = (P.sparse_cap + 63u) & ~63u;
+        P.plan_ms[3] = ms_since(t0);
+        return TRI_OK;
+}

@@ -56,43 +56,59 @@ static int fail(int code, const char *fmt, ...) {
 extern "C" const char *tri_last_error(void) { return g_err; }
 extern "C" int tri_abi_version(void) { return TRI_ABI_VERSION; }
 
-// device-visible structures and kernels
-#include "dev_structs.hpp"
-
-// planner / launch options of a device handle (tri_dev_set_option); the defaults are what bench.py measures
-struct tri_options {
-        uint64_t dense_min_postings = 512 * 1024; // TASK_DENSE needs at least this many postings over the query's lists (0: every multi-term query)
-        uint64_t dense_task_cost = 192 * 1024;    // postings per bitmap-window task
-        uint64_t fused = 1;                       // AccumulatedScore top-K of dense queries in one pass (k_fused); 0: k_and_dense + k_score
-        uint64_t fused_task_cost = 0;             // postings per one-pass task; 0: sized from the batch (256 K .. 8 M, about two tasks per resident workgroup)
-        uint64_t fused_freq_cap = 0;              // 0: the field width decides; else a smaller saturation point (exercises the rescoring path)
-        uint64_t account_needed_bytes = 0;        // 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query)
-        uint64_t fused_halfwords = 1;             // 16-bit window words for queries of <= 5 distinct terms (windows twice as long); 0: always 32-bit
-        uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
-        uint64_t planes = 7;     // term planes (k_planes.hpp), a bit set: 1 k_and probes them, 2 k_and_dense ORs them in, 4 top-K CNF queries run in k_planes; 0: off
-        uint64_t planes_split = 0; // a k_planes query is cut into this many docID ranges (tasks) that share its threshold; 0: 2 or 3 by the batch's size; >= 65536: by postings like the other one-pass tasks.  cfg3's unions: 0 10.9 ms, 2 8.0, 3 8.5, 4 9.2 (a task has fixed costs)
-        uint64_t plane_div = 128; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list);
-                                 // measured, step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the planes' build grows with it)
-};
+// the host planner (planner.hpp: options, PlanEnv, BatchPlan, plan_batch), the upload-time walk (index_host.hpp) and the structures
+// the planner shares with the kernels (dev_structs.hpp)
+#include "planner.hpp"
 
 struct tri_dev {
         int device;
         hipStream_t stream, stream2; // stream2: the candidate-tile kernel when the two matching kernels run side by side
+        hipStream_t stream_up;       // plans travel to the device on their own stream: a batch is compiled and uploaded while the previous one runs
         hipEvent_t ev_fork, ev_join;
         int cus;
         tri_options opt;
-        // The large buffers of a batch (output regions, score streams, term planes, decoded lists) are recycled from batch to batch: a
-        // caller that compiles a batch per step would otherwise hipMalloc and hipFree gigabytes per step — hipFree synchronises the device
-        // (the next batch cannot be compiled while the current one runs), and a cold 15 GB hipMalloc was measured anywhere between 10 ms
-        // and 1 s (bench.py's end_to_end.batch_create_cold_ms).  One tri_dev per host thread: no lock.
+        int refs = 0;         // indexes and batches alive on this handle ...
+        bool closing = false; // ... tri_dev_close with some left: the handle goes with the last of them
+        // The large buffers of a batch (output regions, score streams, term planes, decoded lists) and its plan arena are recycled from
+        // batch to batch: a caller that compiles a batch per step would otherwise hipMalloc and hipFree gigabytes per step — hipFree
+        // synchronises the device (the next batch cannot be compiled while the current one runs), and a cold 15 GB hipMalloc was measured
+        // anywhere between 10 ms and 1 s (bench.py's end_to_end.batch_create_cold_ms).  One tri_dev per host thread: no lock.
         struct Pool {
                 std::vector<std::pair<size_t, void *>> idle;    // (bytes, buffer) not in use
                 std::unordered_map<void *, size_t> size_of;     // every pooled buffer, in use or idle
                 size_t idle_bytes = 0;
         } pool;
+        // ... likewise the pinned host blocks the plans are laid out in (hipHostMalloc costs about a millisecond per megabyte) ...
+        std::vector<std::pair<size_t, void *>> pinned_idle;
+        // ... and the HIP events of a batch (nine per batch)
+        std::vector<hipEvent_t> events_idle;
+        std::unique_ptr<HostPool> hpool; // the planner's host threads: started by the first batch large enough to be planned in fragments
 };
-constexpr size_t POOL_MIN_BYTES = 1u << 20;   // smaller buffers are not worth pooling
+constexpr size_t POOL_MIN_BYTES = 64u << 10;  // smaller buffers are not worth pooling
 constexpr size_t POOL_IDLE_CAP = 64ull << 30; // idle buffers beyond this are given back to the device (largest first)
+constexpr size_t PINNED_IDLE_MAX = 8;         // idle pinned blocks kept
+
+static void dev_destroy(tri_dev *d) {
+        hipSetDevice(d->device);
+        d->hpool.reset();
+        hipEventDestroy(d->ev_fork);
+        hipEventDestroy(d->ev_join);
+        for (hipEvent_t e : d->events_idle)
+                hipEventDestroy(e);
+        hipStreamDestroy(d->stream_up);
+        hipStreamDestroy(d->stream2);
+        hipStreamDestroy(d->stream);
+        for (auto &b : d->pool.idle)
+                hipFree(b.second);
+        for (auto &b : d->pinned_idle)
+                hipHostFree(b.second);
+        delete d;
+}
+static void dev_retain(tri_dev *d) { ++d->refs; }
+static void dev_release(tri_dev *d) {
+        if (d && --d->refs == 0 && d->closing)
+                dev_destroy(d);
+}
 
 // a buffer of at least `bytes`: an idle one of the pool that is not more than twice as large, else a fresh allocation
 static hipError_t pool_alloc(tri_dev *dev, void **out, const size_t bytes) {
@@ -109,7 +125,8 @@ static hipError_t pool_alloc(tri_dev *dev, void **out, const size_t bytes) {
                 P.idle.erase(P.idle.begin() + (ptrdiff_t)best);
                 return hipSuccess;
         }
-        const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        const size_t gran = bytes >= (8u << 20) ? (2u << 20) : (64u << 10);
+        const size_t rounded = (bytes + gran - 1) & ~(gran - 1);
         hipError_t e = hipMalloc(out, rounded);
         if (e != hipSuccess && !P.idle.empty()) { // out of memory with idle buffers around: give them back and try again
                 (void)hipGetLastError();
@@ -151,10 +168,50 @@ static void pool_free(tri_dev *dev, void *p) {
                 P.idle.erase(P.idle.begin() + (ptrdiff_t)big);
         }
 }
+// pinned host block of at least `bytes` (64-byte aligned: hipHostMalloc is page-aligned); *cap = its size
+static uint8_t *pinned_alloc(tri_dev *dev, const size_t bytes, size_t *cap) {
+        auto &I = dev->pinned_idle;
+        size_t best = SIZE_MAX;
+        for (size_t i = 0; i < I.size(); ++i)
+                if (I[i].first >= bytes && I[i].first <= 4 * bytes + (1u << 20) && (best == SIZE_MAX || I[i].first < I[best].first))
+                        best = i;
+        if (best != SIZE_MAX) {
+                void *p = I[best].second;
+                *cap = I[best].first;
+                I.erase(I.begin() + (ptrdiff_t)best);
+                return static_cast<uint8_t *>(p);
+        }
+        const size_t rounded = (bytes + bytes / 4 + (256u << 10)) & ~(size_t)((64u << 10) - 1); // (a quarter of slack: the next batch of the same caller is about as large)
+        void *p = nullptr;
+        if (hipHostMalloc(&p, rounded, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                return nullptr;
+        }
+        *cap = rounded;
+        return static_cast<uint8_t *>(p);
+}
+static void pinned_free(tri_dev *dev, void *p, const size_t cap) {
+        if (!p)
+                return;
+        if (!dev || dev->pinned_idle.size() >= PINNED_IDLE_MAX) {
+                hipHostFree(p);
+                return;
+        }
+        dev->pinned_idle.emplace_back(cap, p);
+}
+static hipError_t event_get(tri_dev *dev, hipEvent_t *e) {
+        if (!dev->events_idle.empty()) {
+                *e = dev->events_idle.back();
+                dev->events_idle.pop_back();
+                return hipSuccess;
+        }
+        return hipEventCreate(e);
+}
 
-struct tri_index {
+// the uploaded segment: what the walk derived (HostIndex; the planner reads terms / blk_last / docbytes / hitbytes / win / the df order)
+// plus its device copies
+struct tri_index : HostIndex {
         tri_dev *dev = nullptr;
-        int codec = TRI_CODEC_GOOGLE;
         uint8_t *d_index = nullptr, *d_hits = nullptr;
         uint32_t *d_blk_last = nullptr, *d_blk_off = nullptr, *d_win = nullptr;
         uint32_t *d_blk_hits = nullptr, *d_hdir = nullptr; // where a directory row's hits start — LUCENE + hits.data: hit ordinal within the term
@@ -173,14 +230,7 @@ struct tri_index {
         // all-equal group (k_fused.hpp PfRegs)
         uint4 *d_blk_rec = nullptr;
         uint32_t *d_masked = nullptr; // bitmap over docIDs of the masked documents (nullptr: none); max_doc / 32 + 2 words
-        uint32_t max_doc = 0;
-        uint32_t nwin = 0; // cells per win[] row
         DevTerm *d_terms = nullptr;
-        std::vector<DevTerm> terms;
-        std::vector<uint32_t> h_blk_last; // host copy of the directory's last-docID column (planner: task output offsets)
-        std::vector<tri_term> tctx;
-        std::vector<uint64_t> docbytes, hitbytes;
-        tri_index_info info{};
         ~tri_index() { // also runs when tri_index_upload fails half-way
                 if (dev)
                         hipSetDevice(dev->device);
@@ -196,53 +246,39 @@ struct tri_index {
                 hipFree(d_blk_off);
                 hipFree(d_win);
                 hipFree(d_terms);
+                dev_release(dev);
         }
 };
 
-struct tri_batch {
+// a compiled batch: the plan (BatchPlan: the host block with every array the kernels read, laid out by the planner) and its device side —
+// ONE arena that holds the block's copy followed by the batch's small device-only arrays, plus the large pooled buffers
+struct tri_batch : BatchPlan {
         tri_index *ix = nullptr;
+        tri_dev *dev = nullptr;
         uint32_t flags, topk;
         int similarity = TRI_SIM_BM25;
         size_t nq;
-        std::vector<DevQuery> plan; // execution order (cost descending)
-        std::vector<uint32_t> qterms;
-        std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: trivially empty)
-        std::vector<int32_t> qstatus;        // per caller query: TRI_OK, or why the planner left it out of the batch (it then reports no matches)
+        size_t block_cap = 0;       // size of the pinned host block (BatchPlan::block) as the pool knows it
+        uint8_t *d_arena = nullptr; // [copy of block][counts][ticket][qthr][part_counts][task_hits][task_pos_base] [zeroed at creation: qcounts, top_counts, top_docs, top_scores]
         DevQuery *d_plan = nullptr;
-        std::vector<DevTask> tasks; // scheduling order (cost descending)
         DevTask *d_tasks = nullptr;
-        uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones, then the TASK_FUSED ones
-        uint32_t n_dense = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0; // (n_fused: 32-bit window words; n_fused16: 16-bit; n_fusedgen: general trees)
-        uint32_t n_planes = 0, n_planes8 = 0; // TASK_PLANES / TASK_PLANES8 tasks (k_planes), scheduled after the general trees
-        // term planes (k_planes.hpp): the head terms the batch's queries share, decoded once per launch into d_planes
-        std::vector<uint32_t> plane_terms; // row -> term
-        uint32_t *d_plane_terms = nullptr, *d_planes = nullptr, *d_qplane = nullptr; // d_qplane: parallel to d_qterms, the term's row or PL_NONE
-        uint32_t plw = 0;                  // words of one plane
+        uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones, then the one-pass kinds
+        uint32_t *d_plane_terms = nullptr, *d_planes = nullptr, *d_qplane = nullptr; // d_qplane: parallel to d_qterms, the term's row or PL_NONE (nullptr: the batch has no planes)
         unsigned long long *d_qthr = nullptr; // k_planes: per query, the best k-th score any of its tasks has seen (cleared at every run)
         uint32_t *d_sparse = nullptr;      // k_planes: per resident workgroup, the lists of a task's decoded (non-plane) slots
-        uint32_t sparse_cap = 0;           // ... entries per workgroup
-        uint64_t term_bytes_planes = 0, plane_decoded_bytes = 0;
-        hipEvent_t ev_pl = nullptr, ev_k = nullptr; // after k_term_planes; after k_planes
-        std::vector<DevFused> fused; // slot maps of the TASK_FUSED queries (DevQuery::fused_idx)
         DevFused *d_fused = nullptr;
-        uint64_t term_bytes_fused = 0;
-        // HIP events on the engine stream: start, after k_and_dense, after k_and, after k_fused, end (owned by the batch: two batches
-        // in flight on one device keep their own timings)
-        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_p = nullptr, ev1 = nullptr;
+        // HIP events on the engine stream: start, after k_term_planes, k_and_dense, k_and, k_fused, k_planes, k_phrase, end (owned by the
+        // batch: two batches in flight on one device keep their own timings); ev_up: the plan has arrived (upload stream)
+        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_p = nullptr, ev1 = nullptr, ev_pl = nullptr, ev_k = nullptr, ev_up = nullptr;
         bool ran = false;
         uint32_t *d_qterms = nullptr;
         uint32_t *d_out = nullptr;
         uint32_t *d_counts = nullptr; // per task, indexed first_task + i in query order
         uint32_t *d_ticket = nullptr;
-        uint64_t term_bytes_phrase_hits = 0; // hit bytes of the phrase terms (part of term_bytes): k_phrase's share
-        uint64_t cand_needed_term_bytes = 0; // option account_needed_bytes: see tri_batch_info.cand_needed_bytes
         uint32_t *d_rich_allow = nullptr; // default mode, batches that hold general trees: per match the reportable terms the tree sits on
-        bool rich_allow = false;
         uint64_t *d_hashes = nullptr;
         uint64_t *d_qcounts = nullptr; // per caller query: matches of the last run (device copy for the result gather)
         // AccumulatedScoreScheme
-        std::vector<uint32_t> sterms;
-        std::vector<double> sweights;
         uint32_t *d_sterms = nullptr;
         double *d_sweights = nullptr;
         uint32_t *d_part_docs = nullptr, *d_part_counts = nullptr, *d_top_docs = nullptr, *d_top_counts = nullptr;
@@ -250,7 +286,6 @@ struct tri_batch {
         float *d_top_scores = nullptr;
         double *d_all_scores = nullptr; // topk == 0: one double per out[] slot
         // TRI_FLAG_MATCHED_TERMS (k_rich.hpp): sterms[] holds every query's reportable terms; R = the widest query's count
-        uint32_t rich_R = 0;
         uint32_t *d_rich_present = nullptr, *d_task_hits = nullptr;
         uint16_t *d_rich_freq = nullptr, *d_rich_pool = nullptr;
         uint8_t *d_rich_plen = nullptr;     // TRI_FLAG_HIT_PAYLOADS: per hit of the pool, term_hit::payloadLen ...
@@ -259,65 +294,48 @@ struct tri_batch {
         std::vector<uint64_t> h_task_pos_base; // per task; [ntasks] = the pool's size
         size_t rich_pool_cap = 0;
         // phrases
-        std::vector<DevPhrase> phrases;
-        std::vector<uint32_t> pterms, ptasks;
         DevPhrase *d_phrases = nullptr;
         uint32_t *d_pterms = nullptr, *d_ptasks = nullptr;
         double *d_pscore = nullptr; // per out[] slot: sum of the phrase scores of the match (scored mode)
-        uint64_t out_capacity = 0;
-        uint64_t term_bytes = 0; // sum of docbytes over all query terms
-        uint64_t term_bytes_dense = 0; // … of the queries that run as TASK_DENSE
         std::vector<uint32_t> h_counts;       // per task
         std::vector<uint64_t> h_query_counts; // per plan slot
         bool synced = false;
         tri_batch_info info{};
         ~tri_batch() { // also runs when tri_batch_create fails half-way: nothing allocated so far is leaked
-                if (ix) {
-                        hipSetDevice(ix->dev->device);
+                if (dev) {
+                        hipSetDevice(dev->device);
                         if (ran && !synced) // (its large buffers go back to the device's pool: nothing of this batch may still be running on them)
-                                hipStreamSynchronize(ix->dev->stream);
+                                hipStreamSynchronize(dev->stream);
+                        if (ev_up)
+                                hipEventSynchronize(ev_up); // (the pinned block goes back to the pool: its copy must have left)
                 }
-                for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k})
-                        if (e)
-                                hipEventDestroy(e);
-                pool_free(ix ? ix->dev : nullptr, d_sparse);
-                hipFree(d_qthr);
-                hipFree(d_plane_terms);
-                pool_free(ix ? ix->dev : nullptr, d_planes);
-                hipFree(d_qplane);
-                hipFree(d_fused);
-                hipFree(d_plan);
-                hipFree(d_tasks);
-                hipFree(d_sched);
-                hipFree(d_qterms);
-                pool_free(ix ? ix->dev : nullptr, d_out);
-                hipFree(d_counts);
-                hipFree(d_ticket);
-                pool_free(ix ? ix->dev : nullptr, d_rich_allow);
+                for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k, ev_up})
+                        if (e) {
+                                if (dev)
+                                        dev->events_idle.push_back(e);
+                                else
+                                        hipEventDestroy(e);
+                        }
+                pinned_free(dev, block, block_cap);
+                pool_free(dev, d_arena);
+                pool_free(dev, d_sparse);
+                pool_free(dev, d_planes);
+                pool_free(dev, d_out);
+                pool_free(dev, d_rich_allow);
                 hipFree(d_hashes);
-                hipFree(d_qcounts);
-                hipFree(d_sterms);
-                hipFree(d_sweights);
-                pool_free(ix ? ix->dev : nullptr, d_part_docs);
-                pool_free(ix ? ix->dev : nullptr, d_part_scores);
-                hipFree(d_part_counts);
-                hipFree(d_top_docs);
-                hipFree(d_top_scores);
-                hipFree(d_top_counts);
-                pool_free(ix ? ix->dev : nullptr, d_all_scores);
-                pool_free(ix ? ix->dev : nullptr, d_rich_present);
-                pool_free(ix ? ix->dev : nullptr, d_rich_freq);
-                hipFree(d_task_hits);
-                hipFree(d_task_pos_base);
+                pool_free(dev, d_part_docs);
+                pool_free(dev, d_part_scores);
+                pool_free(dev, d_all_scores);
+                pool_free(dev, d_rich_present);
+                pool_free(dev, d_rich_freq);
                 hipFree(d_rich_pool);
                 hipFree(d_rich_plen);
                 hipFree(d_rich_payload);
-                hipFree(d_phrases);
-                hipFree(d_pterms);
-                hipFree(d_ptasks);
-                pool_free(ix ? ix->dev : nullptr, d_pscore);
+                pool_free(dev, d_pscore);
+                dev_release(dev);
         }
 };
+
 
 #include "dev_stream.hpp"
 #include "k_decode.hpp"
@@ -351,6 +369,7 @@ extern "C" int tri_dev_open(int device, tri_dev **out) {
         d->device = device;
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&d->stream_up, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
         hipDeviceProp_t prop;
@@ -363,14 +382,13 @@ extern "C" int tri_dev_open(int device, tri_dev **out) {
 extern "C" void tri_dev_close(tri_dev *d) {
         if (!d)
                 return;
-        hipSetDevice(d->device);
-        hipEventDestroy(d->ev_fork);
-        hipEventDestroy(d->ev_join);
-        hipStreamDestroy(d->stream2);
-        hipStreamDestroy(d->stream);
-        for (auto &b : d->pool.idle) // (buffers still in use belong to batches the caller has not destroyed: theirs to release)
-                hipFree(b.second);
-        delete d;
+        // indexes or batches of this handle still alive (a caller that closes first and destroys later): they keep using the handle's
+        // streams and pools, and the last of them to go takes the handle along
+        if (d->refs > 0) {
+                d->closing = true;
+                return;
+        }
+        dev_destroy(d);
 }
 
 namespace {
@@ -388,7 +406,9 @@ namespace {
                              {"overlap_cand_wgs", &tri_options::overlap_cand_wgs},
                              {"planes", &tri_options::planes},
                              {"plane_div", &tri_options::plane_div},
-                             {"planes_split", &tri_options::planes_split}};
+                             {"planes_split", &tri_options::planes_split},
+                             {"plane_max_bytes", &tri_options::plane_max_bytes},
+                             {"plan_threads", &tri_options::plan_threads}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -427,106 +447,6 @@ extern "C" void *tri_dev_stream(tri_dev *d) { return d ? (void *)d->stream : nul
 
 // ------------------------------------------------------------------------------------------ host: upload
 namespace {
-        // host-side prefix varint (Switch/switch_compiler_aux.h:53-80) — used only by the upload-time walk
-        inline size_t h_vb_get(const uint8_t *ip, uint32_t &v) {
-                const uint32_t x = ip[0];
-                if (!(x & 0x80u)) {
-                        v = x;
-                        return 1;
-                } else if (!(x & 0x40u)) {
-                        v = ((x & 0x3fu) << 8) | ip[1];
-                        return 2;
-                } else if (!(x & 0x20u)) {
-                        v = ((x & 0x1fu) << 16) | ip[1] | ((uint32_t)ip[2] << 8);
-                        return 3;
-                } else if (!(x & 0x10u)) {
-                        v = ((x & 0x0fu) << 24) | ((uint32_t)ip[1] << 16) | ((uint32_t)ip[2] << 8) | ip[3];
-                        return 4;
-                }
-                v = ip[1] | ((uint32_t)ip[2] << 8) | ((uint32_t)ip[3] << 16) | ((uint32_t)ip[4] << 24);
-                return 5;
-        }
-        inline size_t h_vb_len(uint8_t b0) { return b0 < 0x80 ? 1 : b0 < 0xc0 ? 2 : b0 < 0xe0 ? 3 : b0 < 0xf0 ? 4 : 5; }
-
-        // ints() group of 128 values (lucene_codec.cpp:69-100 framing; PFOR128 payload, include/pfor128.md).  Returns the
-        // bytes consumed, 0 when malformed.  Upload-time only: it yields the per-32-document directory rows.
-        inline size_t h_ints_decode(const uint8_t *p, const uint8_t *end, uint32_t *v) {
-                if (p >= end)
-                        return 0;
-                const uint32_t L = p[0];
-                if (!L) {
-                        if (p + 1 >= end || p + 1 + h_vb_len(p[1]) > end)
-                                return 0;
-                        uint32_t x;
-                        const size_t n = h_vb_get(p + 1, x);
-                        for (int i = 0; i < 128; ++i)
-                                v[i] = x;
-                        return 1 + n;
-                }
-                if (p + 1 + 4 * (size_t)L > end)
-                        return 0;
-                std::vector<uint32_t> w(L + 2, 0);
-                memcpy(w.data(), p + 1, (size_t)L * 4);
-                const uint32_t b = w[0] & 0xff, nexc = (w[0] >> 8) & 0xff, eb = (w[0] >> 16) & 0xff;
-                if (b > 32 || eb > 32 || 1 + 4 * b + (nexc + 3) / 4 + (nexc * eb + 31) / 32 != L)
-                        return 0;
-                const uint32_t *packed = w.data() + 1, *epos = packed + 4 * b, *ehigh = epos + (nexc + 3) / 4;
-                for (uint32_t i = 0; i < 128; ++i) {
-                        uint32_t x = 0;
-                        if (b) {
-                                const uint32_t bit = i * b;
-                                uint64_t win = packed[bit >> 5];
-                                if ((bit & 31) + b > 32)
-                                        win |= (uint64_t)packed[(bit >> 5) + 1] << 32;
-                                x = (uint32_t)((win >> (bit & 31)) & (b == 32 ? 0xffffffffull : ((1ull << b) - 1)));
-                        }
-                        v[i] = x;
-                }
-                for (uint32_t e = 0; e < nexc; ++e) {
-                        const uint32_t pos = (epos[e >> 2] >> ((e & 3) * 8)) & 0xff;
-                        const uint32_t bit = e * eb;
-                        uint64_t win = ehigh[bit >> 5];
-                        if ((bit & 31) + eb > 32)
-                                win |= (uint64_t)ehigh[(bit >> 5) + 1] << 32;
-                        if (pos >= 128 || b >= 32)
-                                return 0;
-                        v[pos] |= (uint32_t)((win >> (bit & 31)) & (eb == 32 ? 0xffffffffull : ((1ull << eb) - 1))) << b;
-                }
-                return 1 + (size_t)L * 4;
-        }
-        inline size_t h_ints_skip(const uint8_t *p, const uint8_t *end) {
-                if (p >= end)
-                        return 0;
-                if (!p[0] && p + 1 >= end)
-                        return 0;
-                const size_t n = p[0] ? 1 + 4 * (size_t)p[0] : 1 + h_vb_len(p[1]);
-                return p + n <= end ? n : 0;
-        }
-        // Per quarter (32 values) of a VALIDATED ints() group: where its exceptions start in the group's list and how many it has,
-        // packed e0 | cnt << 8.  (The positions are ascending, so a quarter's exceptions are one run of the list.)
-        inline bool h_ints_exc(const uint8_t *p, uint32_t out[4]) {
-                out[0] = out[1] = out[2] = out[3] = 0;
-                const uint32_t L = p[0];
-                if (!L)
-                        return true;
-                uint32_t w0;
-                memcpy(&w0, p + 1, 4);
-                const uint32_t b = w0 & 0xff, nexc = (w0 >> 8) & 0xff;
-                const uint8_t *epos = p + 5 + 16 * (size_t)b;
-                uint32_t cnt[4] = {0, 0, 0, 0}, e0[4] = {0, 0, 0, 0};
-                for (uint32_t e = 0; e < nexc; ++e) {
-                        const uint32_t q = epos[e] >> 5;
-                        if (q > 3 || (e && epos[e] <= epos[e - 1]))
-                                return false;
-                        if (!cnt[q])
-                                e0[q] = e;
-                        ++cnt[q];
-                }
-                for (int q = 0; q < 4; ++q)
-                        out[q] = e0[q] | cnt[q] << 8;
-                return true;
-        }
-
         template <class T>
         int dev_upload(T **dst, const std::vector<T> &src, size_t extra = 0) {
                 HIP_TRY(hipMalloc((void **)dst, (src.size() + extra) * sizeof(T) + 16));
@@ -540,325 +460,54 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
                                 const tri_term *terms, size_t nterms, uint32_t docs_cnt, tri_index **out) {
         if (!dev || !out || (!index && len) || (!terms && nterms) || (!hits && hits_len))
                 return fail(TRI_ERR_INVALID, "tri_index_upload: null argument");
-        if (codec != TRI_CODEC_GOOGLE && codec != TRI_CODEC_LUCENE)
-                return fail(TRI_ERR_INVALID, "tri_index_upload: unknown codec %d", codec);
-        if (len > 0xffffffffull)
-                return fail(TRI_ERR_FORMAT, "index exceeds 32-bit chunk offsets (codecs.h:26)");
-        if (codec == TRI_CODEC_GOOGLE && len >= 0x80000000ull) // bit 31 of a block's hits offset carries BLK_HITS_PLAIN (k_phrase / k_rich mask it off)
-                return fail(TRI_ERR_UNSUPPORTED, "a google_codec index of 2 GiB or more (%zu bytes): split the segment", len);
         HIP_TRY(hipSetDevice(dev->device));
         auto ix = std::make_unique<tri_index>();
+        // One pass over every chunk on the host (index_host.hpp): hop block headers (google_codec.cpp:641-697), validate, record the
+        // directory, the delta streams / row records, the docID-cell index and the algorithmic byte split of SURVEY §8(d)
+        {
+                std::string err;
+                if (const int rc = build_host_index(index, len, hits, hits_len, codec, terms, nterms, docs_cnt, *ix, err))
+                        return fail(rc, "%s", err.c_str());
+        }
         ix->dev = dev;
-        ix->codec = codec;
-        ix->terms.resize(nterms);
-        ix->tctx.assign(terms, terms + nterms);
-        ix->docbytes.assign(nterms, 0);
-        ix->hitbytes.assign(nterms, 0);
-        std::vector<uint32_t> blk_last, blk_off;
-        std::vector<uint32_t> blk_hits, hdir; // LUCENE + hits.data only
-        std::vector<uint4> blk_rec;           // LUCENE only
-        std::vector<uint8_t> dstream;         // GOOGLE only
-        std::vector<uint32_t> blk_doff;
-        if (codec == TRI_CODEC_GOOGLE) {
-                dstream.reserve(len / 3 + 64);
-                blk_doff.reserve(len / 96 + nterms);
-        }
-        const bool want_hits = codec == TRI_CODEC_LUCENE && hits_len;
-        blk_last.reserve(len / 96 + nterms);
-        blk_off.reserve(len / 96 + nterms);
-        uint64_t postings = 0, docb = 0, hitb = 0;
-        // One pass over every chunk: hop block headers (google_codec.cpp:641-697), validate, record the directory
-        // and the algorithmic byte split of SURVEY §8(d).
-        for (size_t ti = 0; ti < nterms; ++ti) {
-                const tri_term &t = terms[ti];
-                DevTerm &dt = ix->terms[ti];
-                dt.documents = t.documents;
-                dt.first_block = (uint32_t)blk_last.size();
-                dt.nblocks = 0;
-                dt.last_n = 0;
-                dt.flags = 0;
-                dt.npfor = 0;
-                dt.pad = 0;
-                if (!t.size || !t.documents) {
-                        dt.documents = 0;
-                        continue;
-                }
-                if (codec == TRI_CODEC_LUCENE) {
-                        // Lucene-shaped chunk (lucene_codec.cpp:163-388): 14-byte header, full 128-document blocks as two ints()
-                        // groups, varbyte (delta, freq) tail, 22-byte skiplist entries.  One directory row per 32 documents.
-                        if ((uint64_t)t.offset + t.size > len || t.size < 14)
-                                return fail(TRI_ERR_FORMAT, "term %zu: chunk [%u,+%u) outside index (%zu)", ti, t.offset, t.size, len);
-                        const uint8_t *base = index + t.offset, *p = base + 14;
-                        uint32_t posChunk, hitsOff, sumHits;
-                        uint16_t sk;
-                        memcpy(&hitsOff, base, 4);
-                        memcpy(&sumHits, base + 4, 4);
-                        memcpy(&posChunk, base + 8, 4);
-                        memcpy(&sk, base + 12, 2);
-                        if (14 + (size_t)sk * 22 > t.size)
-                                return fail(TRI_ERR_FORMAT, "term %zu: skiplist larger than chunk", ti);
-                        const uint8_t *end = base + t.size - (size_t)sk * 22;
-                        uint32_t left = t.documents, doc = 0;
-                        uint32_t vals[128], fvals[128];
-                        uint64_t hits_seen = 0;
-                        while (left >= 128) {
-                                if (p >= end)
-                                        return fail(TRI_ERR_FORMAT, "term %zu: truncated block", ti);
-                                const uint32_t goff = (uint32_t)(p - index);
-                                const size_t used = h_ints_decode(p, end, vals);
-                                if (!used) // (the group's header word does not describe a PFOR128 payload of the declared length)
-                                        return fail(TRI_ERR_FORMAT, "term %zu: an ints() group that is not PFOR128 (include/pfor128.md) — a lucene_codec segment written by the reference's "
-                                                                    "own build carries lemire/FastPFor<4> payloads (lucene_codec.cpp:57-64), which this engine does not read: re-encode "
-                                                                    "the segment with csrc/host/lucene_encoder.hpp, or use google_codec", ti);
-                                p += used;
-                                uint32_t xd[4], xf[4];
-                                const size_t usedf = h_ints_decode(p, end, fvals);
-                                if (!usedf || !h_ints_exc(index + goff, xd) || !h_ints_exc(p, xf))
-                                        return fail(TRI_ERR_FORMAT, "term %zu: a freqs group / exception list that is not PFOR128 (include/pfor128.md; FastPFor<4> payloads of the reference's own "
-                                                                    "build are not readable)", ti);
-                                p += usedf;
-                                uint32_t hdr[2];
-                                for (int gi = 0; gi < 2; ++gi) { // the two groups' header words as the row records cache them
-                                        const uint8_t *gp = gi ? p - usedf : index + goff;
-                                        if (gp[0])
-                                                memcpy(&hdr[gi], gp + 1, 4);
-                                        else {
-                                                const uint32_t v = gi ? fvals[0] : vals[0];
-                                                if (v >> 31)
-                                                        return fail(TRI_ERR_UNSUPPORTED, "term %zu: an all-equal group of value %u", ti, v);
-                                                hdr[gi] = 0x80000000u | v;
-                                        }
-                                }
-                                for (uint32_t q4 = 0; q4 < 4; ++q4) {
-                                        blk_rec.push_back(make_uint4(goff, xd[q4] | xf[q4] << 16, hdr[0], hdr[1]));
-                                        if (want_hits)
-                                                blk_hits.push_back((uint32_t)hits_seen);
-                                        for (uint32_t i = 0; i < 32; ++i) {
-                                                if (!vals[q4 * 32 + i])
-                                                        return fail(TRI_ERR_FORMAT, "term %zu: zero document delta", ti);
-                                                doc += vals[q4 * 32 + i];
-                                                if (want_hits)
-                                                        hits_seen += fvals[q4 * 32 + i];
-                                        }
-                                        blk_last.push_back(doc);
-                                        blk_off.push_back(goff);
-                                        dt.nblocks++;
-                                }
-                                left -= 128;
-                        }
-                        dt.npfor = dt.nblocks;
-                        dt.last_n = 32;
-                        while (left) {
-                                const uint32_t n = std::min(left, 32u);
-                                blk_off.push_back((uint32_t)(p - index));
-                                blk_rec.push_back(make_uint4((uint32_t)(p - index), 0, 0, 0));
-                                if (want_hits)
-                                        blk_hits.push_back((uint32_t)hits_seen);
-                                for (uint32_t i = 0; i < n; ++i) {
-                                        uint32_t d, f;
-                                        if (p >= end || p + h_vb_len(*p) >= end || p + h_vb_len(*p) + h_vb_len(p[h_vb_len(*p)]) > end)
-                                                return fail(TRI_ERR_FORMAT, "term %zu: truncated tail", ti);
-                                        p += h_vb_get(p, d);
-                                        p += h_vb_get(p, f);
-                                        if (!d)
-                                                return fail(TRI_ERR_FORMAT, "term %zu: zero document delta", ti);
-                                        doc += d;
-                                        hits_seen += f;
-                                }
-                                blk_last.push_back(doc);
-                                dt.nblocks++;
-                                dt.last_n = n;
-                                left -= n;
-                        }
-                        if (p != end)
-                                return fail(TRI_ERR_FORMAT, "term %zu: %zd stray bytes before the skiplist", ti, (ssize_t)(end - p));
-                        dt.flags = TERM_FULL_BLOCKS;
-                        if (want_hits) {
-                                // hits.data of this term (lucene_codec.cpp:245-307, 339-352): sumHits / 128 full blocks
-                                // { ints(posDeltas) ints(payloadLens) varbyte(payloadBytes) payload }, then the varbyte tail
-                                if (hits_seen != sumHits)
-                                        return fail(TRI_ERR_FORMAT, "term %zu: %llu hits by frequency, %u declared", ti, (unsigned long long)hits_seen, sumHits);
-                                if ((uint64_t)hitsOff + posChunk > hits_len)
-                                        return fail(TRI_ERR_FORMAT, "term %zu: positions chunk [%u,+%u) outside hits.data (%zu)", ti, hitsOff, posChunk, hits_len);
-                                const uint8_t *hp = hits + hitsOff, *hend = hp + posChunk;
-                                const uint32_t nfull = sumHits / 128;
-                                dt.pad = (uint32_t)hdir.size();
-                                hdir.push_back(nfull);
-                                for (uint32_t hb = 0; hb < nfull; ++hb) {
-                                        hdir.push_back((uint32_t)(hp - hits));
-                                        for (int g = 0; g < 2; ++g) {
-                                                const size_t used = h_ints_skip(hp, hend);
-                                                if (!used || hp + used > hend)
-                                                        return fail(TRI_ERR_FORMAT, "term %zu: bad hits block %u", ti, hb);
-                                                hp += used;
-                                        }
-                                        uint32_t payloadBytes;
-                                        hp += h_vb_get(hp, payloadBytes);
-                                        if (hp + payloadBytes > hend)
-                                                return fail(TRI_ERR_FORMAT, "term %zu: hits block %u payload overruns the chunk", ti, hb);
-                                        hp += payloadBytes;
-                                }
-                                hdir.push_back((uint32_t)(hp - hits));
-                        }
-                        const uint64_t db = (uint64_t)(end - base); // 14-byte header + block bytes, no skiplist, no hits.data
-                        ix->docbytes[ti] = db;
-                        ix->hitbytes[ti] = posChunk;
-                        postings += t.documents;
-                        docb += db;
-                        hitb += posChunk;
-                        continue;
-                }
-                if ((uint64_t)t.offset + t.size > len || t.size < 2)
-                        return fail(TRI_ERR_FORMAT, "term %zu: chunk [%u,+%u) outside index (%zu)", ti, t.offset, t.size, len);
-                const uint8_t *base = index + t.offset, *p = base + 2, *end = base + t.size;
-                uint16_t sk;
-                memcpy(&sk, base, 2);
-                if ((size_t)sk * 8 + 2 > t.size)
-                        return fail(TRI_ERR_FORMAT, "term %zu: skiplist larger than chunk", ti);
-                end -= (size_t)sk * 8;
-                uint64_t db = 2, hb = 0;
-                uint32_t lastDoc = 0, docs = 0;
-                bool full_blocks = true;
-                while (p != end) {
-                        if (p + 3 > end)
-                                return fail(TRI_ERR_FORMAT, "term %zu: truncated block header", ti);
-                        const uint8_t *h = p;
-                        uint32_t delta, blockLength;
-                        // (every varint is bounded before it is read: a malformed or truncated chunk must end in TRI_ERR_FORMAT, not in a read past the buffer)
-                        if (p + h_vb_len(*p) >= end)
-                                return fail(TRI_ERR_FORMAT, "term %zu: truncated block header", ti);
-                        p += h_vb_get(p, delta);
-                        if (p + h_vb_len(*p) >= end)
-                                return fail(TRI_ERR_FORMAT, "term %zu: truncated block header", ti);
-                        p += h_vb_get(p, blockLength);
-                        const uint32_t n = *p++;
-                        if (n < 1 || n > 32 || !delta || (uint64_t)(end - p) < blockLength)
-                                return fail(TRI_ERR_FORMAT, "term %zu: bad block header (n=%u, delta=%u, len=%u)", ti, n, delta, blockLength);
-                        lastDoc += delta;
-                        const uint8_t *s = p, *const bend = p + blockLength;
-                        for (uint32_t i = 0; i + 1 < n; ++i) {
-                                if (s >= bend)
-                                        return fail(TRI_ERR_FORMAT, "term %zu: deltas overrun the block", ti);
-                                s += h_vb_len(*s);
-                        }
-                        if (s > bend)
-                                return fail(TRI_ERR_FORMAT, "term %zu: deltas overrun the block", ti);
-                        if (dstream.size() + 256 > 0xffffffffull)
-                                return fail(TRI_ERR_UNSUPPORTED, "delta stream exceeds 4 GiB");
-                        dstream.push_back((uint8_t)n);
-                        blk_doff.push_back((uint32_t)dstream.size());
-                        dstream.insert(dstream.end(), p, s);
-                        uint64_t nhits = 0;
-                        for (uint32_t i = 0; i < n; ++i) {
-                                if (s >= bend || s + h_vb_len(*s) > bend)
-                                        return fail(TRI_ERR_FORMAT, "term %zu: deltas+freqs overrun the block", ti);
-                                uint32_t f;
-                                s += h_vb_get(s, f);
-                                nhits += f;
-                        }
-                        // GOOGLE: byte offset of the block's first hit (k_phrase / k_rich start there).  Bit 31 (BLK_HITS_PLAIN): every hit of the
-                        // block is ONE byte — a position delta < 64 without the new-payload-length flag (google_codec.cpp:38-74) —, so a document's
-                        // hits start at the block's first hit + the frequencies before it and no hit has to be parsed to find them
-                        uint32_t hits_at = (uint32_t)(s - index);
-                        if ((uint64_t)(bend - s) == nhits && !(hits_at >> 31)) {
-                                bool plain = true;
-                                for (const uint8_t *q = s; q < bend && plain; ++q)
-                                        plain = !(*q & 0x81u);
-                                if (plain)
-                                        hits_at |= BLK_HITS_PLAIN;
-                        }
-                        blk_hits.push_back(hits_at);
-                        db += (uint64_t)(s - h);
-                        hb += blockLength - (uint64_t)(s - p);
-                        blk_last.push_back(lastDoc);
-                        blk_off.push_back((uint32_t)(p - index));
-                        if (dt.nblocks && dt.last_n != 32)
-                                full_blocks = false; // a short block that is not the last one
-                        dt.nblocks++;
-                        dt.last_n = n;
-                        docs += n;
-                        p += blockLength;
-                }
-                if (docs != t.documents)
-                        return fail(TRI_ERR_FORMAT, "term %zu: %u documents in blocks, %u declared", ti, docs, t.documents);
-                if (!full_blocks) // the reference encoder only ever leaves the LAST block short (google_codec.cpp:76-88); the kernels' tile and
-                                  // output layouts (32 slots per non-final block) rely on it, so a foreign chunk that does not is refused here
-                        return fail(TRI_ERR_UNSUPPORTED, "term %zu: a block other than the last holds fewer than 32 documents", ti);
-                dt.flags = TERM_FULL_BLOCKS;
-                if ((uint64_t)docs * 28 < lastDoc)
-                        dt.flags |= TERM_SPARSE;
-                ix->docbytes[ti] = db;
-                ix->hitbytes[ti] = hb;
-                postings += docs;
-                docb += db;
-                hitb += hb;
-        }
-        // docID-cell index of the longer lists: win[row + c] = first block whose last docID >= c * CELL_DOCS.  With 288 GB of HBM
-        // a 4-byte entry per 1024 docIDs per indexed term is cheap (66 MB at the 10M-document config) and turns directory
-        // searches into one load pair: TASK_DENSE reads the entries of its window's ends (every SPAN_BITS / CELL_DOCS-th), a
-        // galloping candidate brackets its block to the handful of blocks that end inside its cell.
-        const uint32_t max_doc = blk_last.empty() ? 0 : *std::max_element(blk_last.begin(), blk_last.end());
-        ix->nwin = (max_doc / SPAN_BITS + 2) * (SPAN_BITS / CELL_DOCS) + 1;
-        ix->max_doc = max_doc;
-        std::vector<uint32_t> win;
-        for (size_t ti = 0; ti < nterms; ++ti) {
-                DevTerm &dt = ix->terms[ti];
-                dt.win_off = 0xffffffffu;
-                if (dt.nblocks < WIN_MIN_BLOCKS)
-                        continue;
-                dt.win_off = (uint32_t)win.size();
-                const uint32_t *bl = &blk_last[dt.first_block];
-                uint32_t b = 0;
-                if ((uint64_t)win.size() + ix->nwin > 0xfffffff0ull)
-                        return fail(TRI_ERR_UNSUPPORTED, "cell index exceeds 2^32 entries");
-                for (uint32_t w = 0; w < ix->nwin; ++w) {
-                        const uint64_t key = (uint64_t)w * CELL_DOCS;
-                        while (b < dt.nblocks && bl[b] < key)
-                                ++b;
-                        win.push_back(b);
-                }
-        }
+        dev_retain(dev);
         // device copies
-        int rcw;
-        if ((rcw = dev_upload(&ix->d_win, win, 3 * CELLS_PER_SPAN + 8))) // (lanes of terms without a row read entries 0, CELLS_PER_SPAN, 2 * CELLS_PER_SPAN and drop them)
-                return rcw;
-        HIP_TRY(hipMemset(ix->d_win + win.size(), 0, (3 * CELLS_PER_SPAN + 8) * sizeof(uint32_t)));
+        int rc;
+        if ((rc = dev_upload(&ix->d_win, ix->win, 3 * CELLS_PER_SPAN + 8))) // (lanes of terms without a row read entries 0, CELLS_PER_SPAN, 2 * CELLS_PER_SPAN and drop them)
+                return rc;
+        HIP_TRY(hipMemset(ix->d_win + ix->win.size(), 0, (3 * CELLS_PER_SPAN + 8) * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void **)&ix->d_index, len + 256)); // over-read slack: the byte streams keep several qwords in flight past the cursor
         HIP_TRY(hipMemset(ix->d_index, 0, len + 256));
         if (len)
                 HIP_TRY(hipMemcpy(ix->d_index, index, len, hipMemcpyHostToDevice));
-        int rc;
-        if ((rc = dev_upload(&ix->d_blk_last, blk_last)) || (rc = dev_upload(&ix->d_blk_off, blk_off)) || (rc = dev_upload(&ix->d_terms, ix->terms)))
+        if ((rc = dev_upload(&ix->d_blk_last, ix->blk_last)) || (rc = dev_upload(&ix->d_blk_off, ix->blk_off)) || (rc = dev_upload(&ix->d_terms, ix->terms)))
                 return rc;
         if (codec == TRI_CODEC_GOOGLE) {
-                blk_doff.push_back((uint32_t)dstream.size() + 1); // (sentinel: block b's delta bytes = blk_doff[b + 1] - blk_doff[b] - 1 for the last block too)
-                dstream.resize(dstream.size() + 256, 0); // over-read slack, like index[]
-                if ((rc = dev_upload(&ix->d_dstream, dstream)) || (rc = dev_upload(&ix->d_blk_doff, blk_doff)))
+                ix->blk_doff.push_back((uint32_t)ix->dstream.size() + 1); // (sentinel: block b's delta bytes = blk_doff[b + 1] - blk_doff[b] - 1 for the last block too)
+                ix->dstream.resize(ix->dstream.size() + 256, 0); // over-read slack, like index[]
+                if ((rc = dev_upload(&ix->d_dstream, ix->dstream)) || (rc = dev_upload(&ix->d_blk_doff, ix->blk_doff)))
                         return rc;
         }
         if (hits_len) { // LUCENE: hits.data (positions) resident next to the index
                 HIP_TRY(hipMalloc((void **)&ix->d_hits, hits_len + 256));
                 HIP_TRY(hipMemset(ix->d_hits, 0, hits_len + 256));
                 HIP_TRY(hipMemcpy(ix->d_hits, hits, hits_len, hipMemcpyHostToDevice));
-                if (want_hits && ((rc = dev_upload(&ix->d_blk_hits, blk_hits)) || (rc = dev_upload(&ix->d_hdir, hdir))))
+                if (ix->has_hdir && ((rc = dev_upload(&ix->d_blk_hits, ix->blk_hits)) || (rc = dev_upload(&ix->d_hdir, ix->hdir))))
                         return rc;
         }
-        if (codec == TRI_CODEC_GOOGLE && (rc = dev_upload(&ix->d_blk_hits, blk_hits)))
+        if (codec == TRI_CODEC_GOOGLE && (rc = dev_upload(&ix->d_blk_hits, ix->blk_hits)))
                 return rc;
-        if (codec == TRI_CODEC_LUCENE && (rc = dev_upload(&ix->d_blk_rec, blk_rec)))
-                return rc;
-        ix->h_blk_last = std::move(blk_last);
-        ix->info.index_bytes = len;
-        ix->info.directory_bytes = ix->h_blk_last.size() * 8 + nterms * sizeof(DevTerm) + win.size() * 4;
-        ix->info.blocks = ix->h_blk_last.size();
-        ix->info.postings = postings;
-        ix->info.doc_bytes = docb;
-        ix->info.hit_bytes = hitb;
-        ix->info.nterms = (uint32_t)nterms;
-        ix->info.docs_cnt = docs_cnt;
+        if (codec == TRI_CODEC_LUCENE) {
+                static_assert(sizeof(RowRec) == sizeof(uint4), "row records are read as uint4");
+                HIP_TRY(hipMalloc((void **)&ix->d_blk_rec, ix->blk_rec.size() * sizeof(uint4) + 16));
+                if (!ix->blk_rec.empty())
+                        HIP_TRY(hipMemcpy(ix->d_blk_rec, ix->blk_rec.data(), ix->blk_rec.size() * sizeof(uint4), hipMemcpyHostToDevice));
+        }
+        ix->release_device_columns(); // (the host keeps what the planner reads: terms, blk_last, docbytes / hitbytes, win, the df order)
         *out = ix.release();
         return TRI_OK;
 }
+
 
 extern "C" int tri_index_set_masked(tri_index *ix, const uint32_t *docids, size_t n) {
         if (!ix || (!docids && n))
@@ -950,242 +599,11 @@ extern "C" int tri_decode_terms(tri_index *ix, const uint32_t *terms, size_t n, 
         return TRI_OK;
 }
 
-// ------------------------------------------------------------------------------------------ host: planner
-namespace {
-        struct PNode {
-                uint32_t op, term;
-                uint32_t tok = 0; // index of the program token this node came from (caller-supplied ScorerWeights are per token)
-                std::vector<int> kids;
-                uint64_t cost = 0;
-                bool empty = false;
-        };
-
-        // Parse one postfix program into a tree with the reference's flattening (exec.cpp:339-358, 382-393),
-        // emptiness propagation and cost model (exec.cpp:35-110).  Returns root index or -1.
-        int parse_program(const tri_index *ix, const uint32_t *prog, uint32_t len, std::vector<PNode> &nodes) {
-                std::vector<int> st;
-                for (uint32_t i = 0; i < len; ++i) {
-                        const uint32_t op = prog[i] >> 28, arg = prog[i] & 0x0fffffffu;
-                        PNode n;
-                        n.op = op;
-                        n.tok = i;
-                        if (op == TRI_OP_TERM) {
-                                n.term = arg;
-                                n.cost = arg < ix->terms.size() ? ix->terms[arg].documents : 0;
-                                n.empty = n.cost == 0; // unknown term == no documents (index_source.h:60-72)
-                        } else {
-                                const uint32_t nk = op == TRI_OP_SOME ? (arg & 0xffffu) : arg; // operands taken off the stack
-                                if (nk < 1 || nk > st.size())
-                                        return -1;
-                                std::vector<int> kids(st.end() - nk, st.end());
-                                st.resize(st.size() - nk);
-                                if (op == TRI_OP_SOME) {
-                                        // matchsome (exec.cpp:276-283): operands that can never match are dropped; fewer live operands than
-                                        // the threshold: never matches.  cost: docset_iterators.cpp:733-742, the (cnt - min + 1) cheapest
-                                        const uint32_t mn = arg >> 16;
-                                        if (!mn || mn > nk)
-                                                return -1;
-                                        for (int k : kids)
-                                                if (!nodes[k].empty)
-                                                        n.kids.push_back(k);
-                                        n.term = mn; // (the threshold rides in the otherwise unused field)
-                                        n.empty = n.kids.size() < mn;
-                                        std::vector<uint64_t> cs;
-                                        for (int k : n.kids)
-                                                cs.push_back(nodes[k].cost);
-                                        std::sort(cs.begin(), cs.end());
-                                        for (size_t i = 0; i + mn <= cs.size(); ++i)
-                                                n.cost += cs[i];
-                                } else if (op == TRI_OP_PHRASE) {
-                                        if (arg > 16) // trinity_limits.h:12 MaxPhraseSize
-                                                return -1;
-                                        for (int k : kids) {
-                                                if (nodes[k].op != TRI_OP_TERM)
-                                                        return -1;
-                                                n.empty |= nodes[k].empty;
-                                        }
-                                        n.kids = kids;
-                                        n.cost = nodes[kids[0]].cost + UINT32_MAX + (uint64_t)UINT16_MAX * arg;
-                                } else if (op == TRI_OP_AND) {
-                                        for (int k : kids) {
-                                                n.empty |= nodes[k].empty;
-                                                if (nodes[k].op == TRI_OP_AND)
-                                                        n.kids.insert(n.kids.end(), nodes[k].kids.begin(), nodes[k].kids.end());
-                                                else
-                                                        n.kids.push_back(k);
-                                        }
-                                        std::stable_sort(n.kids.begin(), n.kids.end(), [&](int a, int b) { return nodes[a].cost < nodes[b].cost; });
-                                        n.cost = nodes[n.kids[0]].cost;
-                                } else if (op == TRI_OP_OR) {
-                                        for (int k : kids) {
-                                                if (nodes[k].empty)
-                                                        continue;
-                                                if (nodes[k].op == TRI_OP_OR)
-                                                        n.kids.insert(n.kids.end(), nodes[k].kids.begin(), nodes[k].kids.end());
-                                                else
-                                                        n.kids.push_back(k);
-                                        }
-                                        n.empty = n.kids.empty();
-                                        for (int k : n.kids)
-                                                n.cost += nodes[k].cost;
-                                } else if (op == TRI_OP_OPT) {
-                                        if (arg != 2)
-                                                return -1;
-                                        if (nodes[kids[1]].empty) { // an optional side that can never match adds nothing
-                                                st.push_back(kids[0]);
-                                                continue;
-                                        }
-                                        n.kids = kids; // {main, optional}
-                                        n.empty = nodes[kids[0]].empty;
-                                        n.cost = nodes[kids[0]].cost;
-                                } else if (op == TRI_OP_NOT) {
-                                        if (arg != 2)
-                                                return -1;
-                                        if (nodes[kids[1]].empty) { // [a NOT <never matches>] => a
-                                                st.push_back(kids[0]);
-                                                continue;
-                                        }
-                                        n.kids = kids; // {required, excluded}
-                                        n.empty = nodes[kids[0]].empty;
-                                        n.cost = nodes[kids[0]].cost; // exec.cpp:55-60
-                                } else
-                                        return -1;
-                        }
-                        nodes.push_back(std::move(n));
-                        st.push_back((int)nodes.size() - 1);
-                }
-                return st.size() == 1 ? st[0] : -1;
-        }
-
-        // ---- general trees: what the CNF lowering does not take (matchsome, NOT / Optional of any subtree, AND under OR ...) runs as
-        // TASK_FUSED with a truth table over the presence of the query's distinct terms (<= FUS_MAX_SLOTS, no multi-word phrase).
-        struct TruthPlan {
-                std::vector<uint32_t> slots;               // distinct terms, order of first appearance
-                std::vector<uint32_t> leaves, leaf_tok;    // scorer leaves (positive TERM nodes) in tree order, and their program tokens
-                std::vector<uint32_t> leaf_slot;
-                uint32_t tt[8] = {};
-                std::vector<std::array<uint32_t, 8>> ctt;
-        };
-        struct TruthBuilder {
-                const std::vector<PNode> &nodes;
-                TruthPlan &tp;
-                std::vector<int> leaf_of_node; // node -> scorer leaf index (-1: none)
-                bool ok = true;
-                uint32_t slot_of(uint32_t term) {
-                        for (size_t i = 0; i < tp.slots.size(); ++i)
-                                if (tp.slots[i] == term)
-                                        return (uint32_t)i;
-                        tp.slots.push_back(term);
-                        return (uint32_t)tp.slots.size() - 1;
-                }
-                // first walk: slots for every term, scorer leaves for the terms an iterator of the tree can report
-                void scan(int ni, bool positive) {
-                        const PNode &x = nodes[ni];
-                        if (x.op == TRI_OP_TERM || (x.op == TRI_OP_PHRASE && x.kids.size() == 1)) {
-                                const PNode &t = x.op == TRI_OP_TERM ? x : nodes[x.kids[0]];
-                                const uint32_t sl = slot_of(t.term);
-                                if (positive) {
-                                        leaf_of_node[ni] = (int)tp.leaves.size();
-                                        tp.leaves.push_back(t.term);
-                                        tp.leaf_tok.push_back(t.tok);
-                                        tp.leaf_slot.push_back(sl);
-                                }
-                                return;
-                        }
-                        if (x.op == TRI_OP_PHRASE) {
-                                ok = false; // a positional constraint is not a function of presence
-                                return;
-                        }
-                        for (size_t k = 0; k < x.kids.size(); ++k)
-                                scan(x.kids[k], positive && !(x.op == TRI_OP_NOT && k == 1));
-                }
-                bool eval(int ni, uint32_t p) const {
-                        const PNode &x = nodes[ni];
-                        switch (x.op) {
-                                case TRI_OP_TERM:
-                                        return (p >> slot_const(x.term)) & 1u;
-                                case TRI_OP_PHRASE:
-                                        return (p >> slot_const(nodes[x.kids[0]].term)) & 1u;
-                                case TRI_OP_AND:
-                                        for (int k : x.kids)
-                                                if (!eval(k, p))
-                                                        return false;
-                                        return true;
-                                case TRI_OP_OR:
-                                        for (int k : x.kids)
-                                                if (eval(k, p))
-                                                        return true;
-                                        return false;
-                                case TRI_OP_SOME: {
-                                        uint32_t c = 0;
-                                        for (int k : x.kids)
-                                                c += eval(k, p) ? 1u : 0u;
-                                        return c >= x.term;
-                                }
-                                case TRI_OP_NOT: // Filter (docset_iterators.cpp:652-677)
-                                        return eval(x.kids[0], p) && !eval(x.kids[1], p);
-                                case TRI_OP_OPT: // Optional (docset_iterators.h:174-206): the documents of main
-                                        return eval(x.kids[0], p);
-                        }
-                        return false;
-                }
-                uint32_t slot_const(uint32_t term) const {
-                        for (size_t i = 0; i < tp.slots.size(); ++i)
-                                if (tp.slots[i] == term)
-                                        return (uint32_t)i;
-                        return 0;
-                }
-                // the scorer leaves that sit on a document of pattern p, through the tree (node ni matches p): what the reference's score() /
-                // collect_doc_matching_terms recursion reaches (docset_iterators_scorers.cpp:38-57, 77-104, 107-193; queryexec_ctx.cpp:382-520)
-                void collect(int ni, uint32_t p, uint32_t &mask) const {
-                        const PNode &x = nodes[ni];
-                        switch (x.op) {
-                                case TRI_OP_TERM:
-                                case TRI_OP_PHRASE:
-                                        if (leaf_of_node[ni] >= 0)
-                                                mask |= 1u << leaf_of_node[ni];
-                                        break;
-                                case TRI_OP_AND:
-                                        for (int k : x.kids)
-                                                collect(k, p, mask);
-                                        break;
-                                case TRI_OP_OR:
-                                case TRI_OP_SOME:
-                                        for (int k : x.kids)
-                                                if (eval(k, p))
-                                                        collect(k, p, mask);
-                                        break;
-                                case TRI_OP_NOT:
-                                        collect(x.kids[0], p, mask);
-                                        break;
-                                case TRI_OP_OPT:
-                                        collect(x.kids[0], p, mask);
-                                        if (eval(x.kids[1], p))
-                                                collect(x.kids[1], p, mask);
-                                        break;
-                        }
-                }
-        };
-        bool build_truth(const std::vector<PNode> &nodes, int root, TruthPlan &tp) {
-                TruthBuilder tb{nodes, tp, std::vector<int>(nodes.size(), -1)};
-                tb.scan(root, true);
-                if (!tb.ok || tp.slots.size() > FUS_MAX_SLOTS || tp.leaves.size() > FUS_MAX_LEAVES || tp.leaves.empty())
-                        return false;
-                tp.ctt.assign(tp.leaves.size(), std::array<uint32_t, 8>{});
-                for (uint32_t p = 0; p < (1u << tp.slots.size()); ++p) {
-                        if (!tb.eval(root, p))
-                                continue;
-                        tp.tt[p >> 5] |= 1u << (p & 31u);
-                        uint32_t mask = 0;
-                        tb.collect(root, p, mask);
-                        for (size_t j = 0; j < tp.leaves.size(); ++j)
-                                if ((mask >> j) & 1u)
-                                        tp.ctt[j][p >> 5] |= 1u << (p & 31u);
-                }
-                return !(tp.tt[0] & 1u); // (a tree that matches documents holding none of its terms cannot be enumerated from postings)
-        }
-} // namespace
-
+// ------------------------------------------------------------------------------------------ host: batches
+// tri_batch_create = the host planner (planner.hpp: lowering, execution classes, tasks, term planes, schedule — on the device handle's
+// host threads) + the plan's way to the device: ONE pinned block, ONE arena, ONE copy on the upload stream.  Everything a steady caller
+// needs per batch comes from the handle's pools (arena, pinned block, output regions, events): no hipMalloc, no hipFree, no device
+// synchronisation — the next batch is compiled and uploaded while the current one runs.
 extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog_len, const tri_query *queries, size_t nq, const double *weights,
                                 uint32_t flags, uint32_t topk, int similarity, tri_batch **out) {
         if (!ix || !out || (!prog && prog_len) || (!queries && nq))
@@ -1201,901 +619,153 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 return fail(TRI_ERR_INVALID, "AccumulatedScoreScheme: topk <= %u (0 = keep every match's score instead of a top-K)", TOPK_MAX);
         if (similarity != TRI_SIM_BM25 && similarity != TRI_SIM_TFIDF && similarity != TRI_SIM_TRIVIAL)
                 return fail(TRI_ERR_INVALID, "unknown similarity %d", similarity);
-        // the ScorerWeight contribution of one term (IndexSourceTermsScorer::new_scorer_weight sums it over a phrase's terms):
-        // BM25 similarity.h:179-181 (float math), TF-IDF :85-87 (double), Trivial has none
-        auto term_weight = [&](const uint32_t df) -> double {
-                if (similarity == TRI_SIM_TFIDF)
-                        return std::log((double)((uint64_t)ix->info.docs_cnt + 1) / (double)(df + 1)) + 1.0;
-                if (similarity == TRI_SIM_TRIVIAL)
-                        return 0.0;
-                const float num = (float)((uint64_t)ix->info.docs_cnt - (uint64_t)df) + 0.5f;
-                const float den = (float)df + 0.5f;
-                return (double)std::log(1 + num / den);
-        };
         tri_dev *dev = ix->dev;
         HIP_TRY(hipSetDevice(dev->device));
+        const auto t_create = std::chrono::steady_clock::now();
         auto b = std::make_unique<tri_batch>();
         b->ix = ix;
+        b->dev = dev;
+        dev_retain(dev);
         b->flags = flags;
         b->topk = topk;
         b->similarity = similarity;
         b->nq = nq;
-        b->slot_of_query.assign(nq, UINT32_MAX);
-        b->qstatus.assign(nq, TRI_OK);
-        // a query shape the planner does not lower does not fail the batch: the query is left out (status TRI_ERR_UNSUPPORTED, no matches,
-        // tri_batch_query_status) and the caller keeps its CPU span for it; tri_last_error() describes the last such query
-        auto leave_out = [&](const size_t qi) {
-                b->qstatus[qi] = TRI_ERR_UNSUPPORTED;
-                ++b->info.unsupported_queries;
-        };
-        struct Tmp {
-                DevQuery q;
-                uint64_t cost;
-                uint32_t nlead;
-                bool fusable; // AccumulatedScore + top-K, no phrase, <= FUS_MAX_SLOTS distinct terms: may run as TASK_FUSED
-                bool truth;   // a general tree: runs as TASK_FUSED whatever its density (there is no other path for it)
-                DevFused fz;
-        };
-#ifdef TRI_CREATE_TIMES // (debug builds: where tri_batch_create's time goes, to stderr)
-        auto ct_last = std::chrono::steady_clock::now();
-        auto ct_mark = [&](const char *what) {
-                const auto now = std::chrono::steady_clock::now();
-                fprintf(stderr, "  create: %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - ct_last).count());
-                ct_last = now;
-        };
-#define CT_MARK(x) ct_mark(x)
-#else
-#define CT_MARK(x)
-#endif
-        // ---- lowering, query by query.  Queries are independent, and a query costs about 0.6 us of host time (tree, groups, slot map: small
-        //      allocations) — 9 ms for 16 384 queries, three times the GPU step they compile to: contiguous ranges of the batch are lowered by
-        //      a few host threads, each into a fragment of its own (offsets relative to the fragment), and the fragments are joined in order.
-        struct Frag {
-                std::vector<Tmp> tmp;
-                std::vector<uint32_t> qterms, pterms, sterms;
-                std::vector<double> sweights;
-                std::vector<DevPhrase> phrases;
-                uint64_t term_bytes = 0, term_bytes_phrase_hits = 0;
-                uint32_t rich_R = 0;
-                bool rich_allow = false;
-                std::vector<size_t> left_out; // queries the planner does not lower (status TRI_ERR_UNSUPPORTED)
-                int rc = TRI_OK;
-                std::string err; // the fragment's last error text (fail() keeps it per thread)
-        };
-        auto lower_range = [&](const size_t q_lo, const size_t q_hi, Frag &f) -> int {
-                std::vector<PNode> nodes;
-                for (size_t qi = q_lo; qi < q_hi; ++qi) {
-                        const tri_query &tq = queries[qi];
-                        if ((uint64_t)tq.prog_off + tq.prog_len > prog_len || !tq.prog_len)
-                                return fail(TRI_ERR_INVALID, "query %zu: program slice out of range", qi);
-                        nodes.clear();
-                        const int root = parse_program(ix, prog + tq.prog_off, tq.prog_len, nodes);
-                        if (root < 0)
-                                return fail(TRI_ERR_INVALID, "query %zu: malformed postfix program", qi);
-                        const PNode &r = nodes[root];
-                        if (r.empty)
-                                continue; // matches nothing (compiles to constfalse in the reference)
-                        // ---- conjunctive normal form over terms: AND of (term | OR of terms); a root OR is one group
-                        std::vector<std::vector<uint32_t>> groups;
-                        std::vector<uint32_t> leaves;     // every TERM leaf in evaluation order: one scorer each
-                        std::vector<uint32_t> leaf_tok;   // ... and the program token it came from
-                        struct PhraseTmp {
-                                std::vector<uint32_t> terms;
-                                double weight;
-                        };
-                        std::vector<uint32_t> ts_tok; // (scratch of add_group: token indices parallel to ts)
-                        std::vector<PhraseTmp> qphrases;
-                        auto add_group = [&](const PNode &g) -> bool {
-                                std::vector<uint32_t> ts;
-                                if (g.op == TRI_OP_PHRASE && g.kids.size() > 1) {
-                                        // Phrase = conjunction of its terms + a positional constraint on the matches (k_phrase);
-                                        // it scores as ONE iterator with the summed idf (docset_iterators_scorers.cpp:195-228)
-                                        PhraseTmp ph;
-                                        ph.weight = 0;
-                                        for (int k : g.kids) {
-                                                const uint32_t x = nodes[k].term;
-                                                ph.terms.push_back(x);
-                                                const uint32_t df = ix->terms[x].documents;
-                                                ph.weight += term_weight(df);
-                                                bool dup = false;
-                                                for (const auto &og : groups)
-                                                        dup |= og.size() == 1 && og[0] == x;
-                                                if (!dup)
-                                                        groups.push_back({x});
-                                        }
-                                        if (weights) // the PHRASE token's own ScorerWeight, when the caller supplies weights (by token position: two phrases
-                                                     // that start with the same term keep their own weights)
-                                                ph.weight = weights[tq.prog_off + g.tok];
-                                        qphrases.push_back(std::move(ph));
-                                        return true;
-                                }
-                                ts_tok.clear();
-                                if (g.op == TRI_OP_PHRASE) {
-                                        ts.push_back(nodes[g.kids[0]].term); // a one-word phrase is a term (exec.cpp: phrase of size 1)
-                                        ts_tok.push_back(nodes[g.kids[0]].tok);
-                                } else if (g.op == TRI_OP_TERM) {
-                                        ts.push_back(g.term);
-                                        ts_tok.push_back(g.tok);
-                                } else if (g.op == TRI_OP_OR) {
-                                        for (int k : g.kids) {
-                                                if (nodes[k].op != TRI_OP_TERM)
-                                                        return false;
-                                                ts.push_back(nodes[k].term);
-                                                ts_tok.push_back(nodes[k].tok);
-                                        }
-                                } else
-                                        return false;
-                                leaves.insert(leaves.end(), ts.begin(), ts.end());
-                                leaf_tok.insert(leaf_tok.end(), ts_tok.begin(), ts_tok.end());
-                                // a term repeated inside a group, or a single-term group seen before, adds nothing to the docID set
-                                std::vector<uint32_t> u;
-                                for (uint32_t x : ts)
-                                        if (std::find(u.begin(), u.end(), x) == u.end())
-                                                u.push_back(x);
-                                if (u.size() == 1)
-                                        for (const auto &og : groups)
-                                                if (og.size() == 1 && og[0] == u[0])
-                                                        return true;
-                                groups.push_back(std::move(u));
-                                return true;
-                        };
-                        // logicalnot at the root or under an AND: its required side joins the conjunction, its excluded side (a term or an
-                        // OR of terms) joins the query's excluded set: A B -C == A ∧ B ∧ ¬C (Filter semantics, docset_iterators.cpp:652-677)
-                        bool ok = true;
-                        std::vector<uint32_t> negs, opts, opt_tok;
-                        std::function<void(int)> lower = [&](int ni) {
-                                const PNode &x = nodes[ni];
-                                if (x.op == TRI_OP_OPT) {
-                                        // Optional(main, opt): the documents of main; opt's terms score (and are reported) where they match —
-                                        // exactly how k_score / k_rich treat a term a match does not hold
-                                        lower(x.kids[0]);
-                                        const PNode &e = nodes[x.kids[1]];
-                                        if (e.op == TRI_OP_TERM) {
-                                                opts.push_back(e.term);
-                                                opt_tok.push_back(e.tok);
-                                        } else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1) {
-                                                opts.push_back(nodes[e.kids[0]].term);
-                                                opt_tok.push_back(nodes[e.kids[0]].tok);
-                                        } else if (e.op == TRI_OP_OR) {
-                                                for (int k : e.kids) {
-                                                        if (nodes[k].op != TRI_OP_TERM)
-                                                                ok = false;
-                                                        else {
-                                                                opts.push_back(nodes[k].term);
-                                                                opt_tok.push_back(nodes[k].tok);
-                                                        }
-                                                }
-                                        } else
-                                                ok = false;
-                                } else if (x.op == TRI_OP_NOT) {
-                                        lower(x.kids[0]);
-                                        const PNode &e = nodes[x.kids[1]];
-                                        if (e.op == TRI_OP_TERM)
-                                                negs.push_back(e.term);
-                                        else if (e.op == TRI_OP_PHRASE && e.kids.size() == 1)
-                                                negs.push_back(nodes[e.kids[0]].term);
-                                        else if (e.op == TRI_OP_OR) {
-                                                for (int k : e.kids) {
-                                                        if (nodes[k].op != TRI_OP_TERM)
-                                                                ok = false;
-                                                        else
-                                                                negs.push_back(nodes[k].term);
-                                                }
-                                        } else
-                                                ok = false;
-                                } else if (x.op == TRI_OP_AND) {
-                                        for (int k : x.kids)
-                                                lower(k);
-                                } else
-                                        ok &= add_group(x);
-                        };
-                        lower(root);
-                        if (ok && !groups.empty()) // (a general tree — below — counts every term once through its slot list)
-                                for (size_t oi = 0; oi < opts.size(); ++oi)
-                                        if (const uint32_t x = opts[oi]; ix->terms[x].documents) {
-                                                leaves.push_back(x); // one more scorer / reportable term each; never part of the docID set
-                                                leaf_tok.push_back(opt_tok[oi]);
-                                                if (mode != TRI_FLAG_DOCUMENTS_ONLY)
-                                                        f.term_bytes += ix->docbytes[x]; // its postings are read by k_score / k_rich
-                                        }
-                        TruthPlan tp;
-                        bool truth = false;
-                        if (!ok || groups.empty()) {
-                                // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp)
-                                if (!build_truth(nodes, root, tp)) {
-                                        f.left_out.push_back(qi);
-                                        fail(TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
-                                        continue;
-                                }
-                                truth = true;
-                                groups.assign(1, tp.slots); // (one group of every slot: the bookkeeping below — term list, cost, output bound — sees a union)
-                                negs.clear();
-                                leaves = tp.leaves;
-                                leaf_tok = tp.leaf_tok;
-                                qphrases.clear();
+        // ---- plan (host)
+        PlanEnv env;
+        env.opt = dev->opt;
+        env.cus = (uint32_t)dev->cus;
+        env.fus_wgs_per_cu = FUS_WGS_PER_CU;
+        env.plk_wgs_per_cu = PLK_WGS_PER_CU;
+        PlanInput in;
+        in.prog = prog;
+        in.prog_len = prog_len;
+        in.queries = queries;
+        in.nq = nq;
+        in.weights = weights;
+        in.flags = flags;
+        in.topk = topk;
+        in.similarity = similarity;
+        if (nq >= 1024 && !dev->hpool) { // (batches below a thousand queries are planned on the calling thread)
+                const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+                const unsigned want = dev->opt.plan_threads ? (unsigned)std::min<uint64_t>(dev->opt.plan_threads, 64) : std::min(16u, hw);
+                if (want > 1) {
+                        try {
+                                dev->hpool = std::make_unique<HostPool>(want);
+                        } catch (...) { // (no threads to be had: the calling thread plans alone)
                         }
-                        auto gcost = [&](const std::vector<uint32_t> &g) {
-                                uint64_t c = 0;
-                                for (uint32_t x : g)
-                                        c += ix->terms[x].documents;
-                                return c;
-                        };
-                        std::stable_sort(groups.begin(), groups.end(), [&](const auto &x, const auto &y) { return gcost(x) < gcost(y); });
-                        std::vector<uint32_t> uniq; // terms group by group, QT_GROUP on the first of each group
-                        for (const auto &g : groups)
-                                for (size_t i = 0; i < g.size(); ++i)
-                                        uniq.push_back(g[i] | (i == 0 ? QT_GROUP : 0u));
-                        {
-                                // the excluded terms: one more group, the last, marked QT_NOT
-                                std::vector<uint32_t> u;
-                                for (uint32_t x : negs)
-                                        if (ix->terms[x].documents && std::find(u.begin(), u.end(), x) == u.end())
-                                                u.push_back(x);
-                                for (size_t i = 0; i < u.size(); ++i)
-                                        uniq.push_back(u[i] | (i == 0 ? (QT_GROUP | QT_NOT) : 0u));
-                        }
-                        if (uniq.size() > MAX_QTERMS) {
-                                f.left_out.push_back(qi);
-                                fail(TRI_ERR_UNSUPPORTED, "query %zu: more than %u terms", qi, MAX_QTERMS);
-                                continue;
-                        }
-                        // (default mode: the reportable terms — every postings iterator collect_doc_matching_terms can reach (queryexec_ctx.cpp:382-520):
-                        //  group members and phrase terms, not the excluded side of a NOT —, distinct, in order of first appearance; counted before
-                        //  anything of the query is recorded, so that a query with too many of them can still be left out cleanly)
-                        std::vector<uint32_t> rt;
-                        if (rich) {
-                                auto add = [&](uint32_t x) {
-                                        if (std::find(rt.begin(), rt.end(), x) == rt.end())
-                                                rt.push_back(x);
-                                };
-                                for (uint32_t pi = 0; pi < tq.prog_len; ++pi) {
-                                        const uint32_t tok = prog[tq.prog_off + pi];
-                                        if ((tok >> 28) != TRI_OP_TERM)
-                                                continue;
-                                        const uint32_t x = tok & 0x0fffffffu;
-                                        bool positive = std::find(leaves.begin(), leaves.end(), x) != leaves.end();
-                                        for (const auto &ph : qphrases)
-                                                positive |= std::find(ph.terms.begin(), ph.terms.end(), x) != ph.terms.end();
-                                        if (positive)
-                                                add(x);
-                                }
-                                if (rt.size() > 16) {
-                                        f.left_out.push_back(qi);
-                                        fail(TRI_ERR_UNSUPPORTED, "query %zu: more than 16 reportable terms", qi);
-                                        continue;
-                                }
-                        }
-                        const uint32_t nlead = (uint32_t)groups[0].size();
-                        const uint64_t lead_docs = gcost(groups[0]);
-                        Tmp t;
-                        if (!qphrases.empty() && ix->codec == TRI_CODEC_LUCENE && !ix->d_hdir)
-                                return fail(TRI_ERR_INVALID, "query %zu: phrase over a LUCENE segment that was uploaded without hits.data", qi);
-                        t.q.phrase_base = (uint32_t)f.phrases.size();
-                        t.q.nphrases = (uint32_t)qphrases.size();
-                        for (const auto &ph : qphrases) {
-                                f.phrases.push_back({(uint32_t)f.pterms.size(), (uint32_t)ph.terms.size(), ph.weight});
-                                for (uint32_t x : ph.terms) {
-                                        f.pterms.push_back(x);
-                                        f.term_bytes += ix->hitbytes[x]; // phrase queries also stream the hit bytes
-                                        f.term_bytes_phrase_hits += ix->hitbytes[x];
-                                }
-                        }
-                        t.q.score_base = (uint32_t)f.sterms.size();
-                        t.q.nscore = 0;
-                        if (rich) {
-                                for (uint32_t x : rt) {
-                                        f.sterms.push_back(x);
-                                        f.term_bytes += ix->hitbytes[x]; // the hits of every reported term are read
-                                }
-                                t.q.nscore = (uint32_t)rt.size();
-                                f.rich_R = std::max<uint32_t>(f.rich_R, t.q.nscore);
-                        }
-                        if (scored) {
-                                // one scorer per PostingsListIterator of the conjunction, summed in iterator order
-                                // (docset_iterators_scorers.cpp:173-193); weight = BM25 idf (similarity.h:179-181, float math)
-                                // unless the caller supplied ScorerWeights per TERM token
-                                std::vector<std::pair<uint32_t, double>> sc;
-                                for (size_t li = 0; li < leaves.size(); ++li) // caller-provided weights: the leaf's OWN TERM token (a term that also sits inside a
-                                                                              // phrase or on an excluded side has another token with another weight)
-                                        sc.emplace_back(leaves[li], weights ? weights[tq.prog_off + leaf_tok[li]] : term_weight(ix->terms[leaves[li]].documents));
-                                for (auto &e : sc) {
-                                        f.sterms.push_back(e.first);
-                                        f.sweights.push_back(e.second);
-                                }
-                                t.q.nscore = (uint32_t)sc.size();
-                        }
-                        // ---- slot map for the one-pass scored path (k_fused.hpp): the query's distinct terms, CNF terms first
-                        t.fusable = false;
-                        t.truth = truth;
-                        t.fz = DevFused{};
-                        if (truth) {
-                                DevFused &z = t.fz;
-                                z.nslots = (uint32_t)tp.slots.size();
-                                z.hw = 0; // (general trees run in their own instantiation, 32-bit window words)
-                                z.fbits = z.nslots <= 4 ? 8u : 4u;
-                                z.cap = (1u << z.fbits) - 2u;
-                                if (dev->opt.fused_freq_cap && dev->opt.fused_freq_cap < z.cap)
-                                        z.cap = (uint32_t)dev->opt.fused_freq_cap;
-                                const uint32_t fm = (1u << z.fbits) - 1u;
-                                for (size_t i = 0; i < tp.slots.size(); ++i)
-                                        z.term[i] = tp.slots[i];
-                                // DocumentsOnly, the default mode and the full score stream (topk == 0) need the docID set; top-K batches do not
-                                z.mode = FUS_MODE_TT | ((scored && topk) ? 0u : FUS_MODE_EMIT);
-                                memcpy(z.tt, tp.tt, sizeof z.tt);
-                                if (rich) {
-                                        // per REPORTABLE term (distinct, f.sterms order): reported where any of its leaves sits on the document
-                                        z.nleaf = t.q.nscore;
-                                        for (uint32_t j = 0; j < t.q.nscore; ++j) {
-                                                const uint32_t term = f.sterms[t.q.score_base + j];
-                                                for (size_t l = 0; l < tp.leaves.size(); ++l)
-                                                        if (tp.leaves[l] == term) {
-                                                                z.leaf_slot[j] = (uint8_t)tp.leaf_slot[l];
-                                                                for (int wd = 0; wd < 8; ++wd)
-                                                                        z.ctt[j][wd] |= tp.ctt[l][wd];
-                                                        }
-                                        }
-                                        f.rich_allow = true;
-                                } else {
-                                        z.nleaf = (uint32_t)tp.leaves.size();
-                                        for (size_t j = 0; j < tp.leaves.size(); ++j) {
-                                                z.leaf_slot[j] = (uint8_t)tp.leaf_slot[j];
-                                                memcpy(z.ctt[j], tp.ctt[j].data(), sizeof z.ctt[j]);
-                                        }
-                                }
-                                // window skipping needs groups of slots one of which every match holds: the slots of the scorer leaves if no
-                                // matching pattern lacks them all (else every slot: pattern 0 never matches), then every slot all matches hold
-                                const uint32_t npat = 1u << z.nslots;
-                                auto matches = [&](uint32_t p) { return (tp.tt[p >> 5] >> (p & 31u)) & 1u; };
-                                uint32_t g0 = 0;
-                                for (uint32_t sl : tp.leaf_slot)
-                                        g0 |= 1u << sl;
-                                for (uint32_t p = 0; p < npat; ++p)
-                                        if (matches(p) && !(p & g0))
-                                                g0 = npat - 1;
-                                auto add_req = [&](uint32_t gs) {
-                                        z.gslots[z.nreq] = gs;
-                                        for (uint32_t sl = 0; sl < z.nslots; ++sl)
-                                                if ((gs >> sl) & 1u)
-                                                        z.gmask[z.nreq] |= fm << (sl * z.fbits);
-                                        ++z.nreq;
-                                };
-                                add_req(g0);
-                                for (uint32_t sl = 0; sl < z.nslots && z.nreq < FUS_MAX_SLOTS; ++sl) {
-                                        bool all = g0 != (1u << sl);
-                                        for (uint32_t p = 0; p < npat && all; ++p)
-                                                all = !matches(p) || ((p >> sl) & 1u);
-                                        if (all)
-                                                add_req(1u << sl);
-                                }
-                                t.fusable = true;
-                        } else if (scored && topk && qphrases.empty() && dev->opt.fused) {
-                                std::vector<uint32_t> slots;
-                                auto slot_of = [&](uint32_t term) {
-                                        for (size_t i = 0; i < slots.size(); ++i)
-                                                if (slots[i] == term)
-                                                        return (uint32_t)i;
-                                        slots.push_back(term);
-                                        return (uint32_t)slots.size() - 1;
-                                };
-                                for (uint32_t tt : uniq)
-                                        slot_of(tt & QT_TERM);
-                                for (uint32_t x : leaves)
-                                        slot_of(x);
-                                if (slots.size() <= FUS_MAX_SLOTS) {
-                                        DevFused &z = t.fz;
-                                        z.nslots = (uint32_t)slots.size();
-                                        z.hw = (dev->opt.fused_halfwords && z.nslots <= 5) ? 1u : 0u;
-                                        z.fbits = z.hw ? std::min(8u, 16u / z.nslots) : (z.nslots <= 4 ? 8u : 4u);
-                                        z.cap = (1u << z.fbits) - 2u;
-                                        if (dev->opt.fused_freq_cap && dev->opt.fused_freq_cap < z.cap)
-                                                z.cap = (uint32_t)dev->opt.fused_freq_cap;
-                                        const uint32_t fm = (1u << z.fbits) - 1u;
-                                        for (size_t i = 0; i < slots.size(); ++i)
-                                                z.term[i] = slots[i];
-                                        int g = -1;
-                                        bool in_not = false;
-                                        uint32_t nreq_groups = 0;
-                                        for (uint32_t tt : uniq)
-                                                nreq_groups += (tt & QT_GROUP) && !(tt & QT_NOT);
-                                        for (uint32_t tt : uniq) {
-                                                if (nreq_groups > FUS_MAX_SLOTS)
-                                                        break; // (a CNF that repeats its terms over more groups than the slot map holds)
-                                                if (tt & QT_GROUP) {
-                                                        in_not = tt & QT_NOT;
-                                                        if (!in_not)
-                                                                ++g;
-                                                }
-                                                const uint32_t sidx = slot_of(tt & QT_TERM);
-                                                if (in_not)
-                                                        z.nmask |= fm << (sidx * z.fbits);
-                                                else {
-                                                        z.gmask[g] |= fm << (sidx * z.fbits);
-                                                        z.gslots[g] |= 1u << sidx;
-                                                }
-                                        }
-                                        z.nreq = (uint32_t)(g + 1);
-                                        t.fusable = z.nreq >= 1 && nreq_groups <= FUS_MAX_SLOTS;
-                                }
-                        }
-                        t.q.fused_idx = 0;
-                        t.q.pad0 = 0;
-                        t.q.nterms = (uint32_t)uniq.size();
-                        t.q.term_base = (uint32_t)f.qterms.size();
-                        t.q.out_cap = 0;
-                        t.q.out_off = 0;
-                        t.q.qid = (uint32_t)qi;
-                        t.cost = 0;
-                        t.nlead = nlead;
-                        {
-                                std::vector<uint32_t> seen;
-                                for (uint32_t tt : uniq) {
-                                        const uint32_t term = tt & QT_TERM;
-                                        f.qterms.push_back(tt);
-                                        if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
-                                                seen.push_back(term);
-                                                f.term_bytes += ix->docbytes[term];
-                                        }
-                                }
-                                // cost estimate: the lead group is decoded fully; every other list costs min(its blocks x 32, lead docs x 32)
-                                for (size_t i = 0; i < uniq.size(); ++i) {
-                                        const DevTerm &tk = ix->terms[uniq[i] & QT_TERM];
-                                        t.cost += i < nlead ? tk.documents : 32ull * std::min<uint64_t>(tk.nblocks, lead_docs);
-                                }
-                        }
-                        f.tmp.push_back(t);
                 }
-                return TRI_OK;
-        };
-        const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)8, nq / 1024, (size_t)std::max(1u, std::thread::hardware_concurrency())}));
-        std::vector<Frag> frags(nthreads);
+        }
         {
-                auto work = [&](const size_t k) {
-                        Frag &f = frags[k];
-                        f.rc = lower_range(nq * k / nthreads, nq * (k + 1) / nthreads, f);
-                        f.err = tri_last_error();
-                };
-                std::vector<std::thread> pool;
-                for (size_t k = 1; k < nthreads; ++k)
-                        pool.emplace_back(work, k);
-                work(0);
-                for (auto &th : pool)
-                        th.join();
+                std::string err;
+                int rc;
+                try {
+                        rc = plan_batch(*ix, env, in, dev->hpool.get(), [&](size_t bytes) { return pinned_alloc(dev, bytes, &b->block_cap); }, *b, err);
+                } catch (const std::bad_alloc &) {
+                        return fail(TRI_ERR_NOMEM, "tri_batch_create: out of host memory");
+                }
+                if (rc != TRI_OK)
+                        return fail(rc, "%s", err.c_str());
+                if (!b->last_unsupported.empty())
+                        fail(TRI_ERR_UNSUPPORTED, "%s", b->last_unsupported.c_str()); // (tri_last_error() describes the last query that was left out; the call succeeds)
         }
-        std::vector<Tmp *> tmp; // every lowered query, in query order (the records stay in their fragments)
-        for (Frag &f : frags) {
-                if (f.rc != TRI_OK)
-                        return fail(f.rc, "%s", f.err.c_str());
-                const uint32_t qb = (uint32_t)b->qterms.size(), sb = (uint32_t)b->sterms.size(), pb = (uint32_t)b->phrases.size(), ptb = (uint32_t)b->pterms.size();
-                for (Tmp &t : f.tmp) {
-                        t.q.term_base += qb;
-                        t.q.score_base += sb;
-                        t.q.phrase_base += pb;
-                        tmp.push_back(&t);
-                }
-                for (DevPhrase ph : f.phrases) {
-                        ph.term_base += ptb;
-                        b->phrases.push_back(ph);
-                }
-                b->qterms.insert(b->qterms.end(), f.qterms.begin(), f.qterms.end());
-                b->pterms.insert(b->pterms.end(), f.pterms.begin(), f.pterms.end());
-                b->sterms.insert(b->sterms.end(), f.sterms.begin(), f.sterms.end());
-                b->sweights.insert(b->sweights.end(), f.sweights.begin(), f.sweights.end());
-                b->term_bytes += f.term_bytes;
-                b->term_bytes_phrase_hits += f.term_bytes_phrase_hits;
-                b->rich_R = std::max(b->rich_R, f.rich_R);
-                b->rich_allow |= f.rich_allow;
-                for (const size_t qi : f.left_out)
-                        leave_out(qi);
-                if (!f.left_out.empty())
-                        fail(TRI_ERR_UNSUPPORTED, "%s", f.err.c_str()); // (tri_last_error() describes the last query that was left out)
+        const size_t nt = b->tasks.size(), np = b->plan.size();
+        const uint64_t off = b->out_capacity;
+        // ---- the arena: the block's copy, then the batch's small device-only arrays; the part that must start out zero comes last
+        size_t a = b->block_bytes;
+        auto carve = [&](size_t bytes) {
+                const size_t at = a;
+                a += (bytes + 255) & ~(size_t)255;
+                return at;
+        };
+        const size_t a_counts = carve((nt + 1) * 4), a_ticket = carve(256);
+        const bool planes_tasks = b->n_planes + b->n_planes8;
+        const size_t a_qthr = planes_tasks ? carve((np + 1) * 8) : 0;
+        const size_t a_part_counts = scored ? carve((nt + 1) * 4) : 0;
+        const size_t a_task_hits = rich ? carve((nt + 1) * 4) : 0, a_task_pos = rich ? carve((nt + 1) * 8) : 0;
+        const size_t a_zero = a;
+        const size_t a_qcounts = carve((nq + 1) * 8); // queries that can never match keep count 0 ...
+        const size_t a_top_counts = scored ? carve((nq + 1) * 4) : 0;
+        const size_t a_top_docs = scored ? carve((nq * topk + 1) * 4) : 0; // ... and zeroed rows (k_topk_merge only writes the rows of queries that have a plan slot;
+        const size_t a_top_scores = scored ? carve((nq * topk + 1) * 4) : 0; // the blocks travel whole to the host and to the other ranks)
+        HIP_TRY(pool_alloc(dev, (void **)&b->d_arena, a + 256));
+        uint8_t *const A = b->d_arena;
+        b->d_plan = (DevQuery *)(A + b->off_plan);
+        b->d_qterms = (uint32_t *)(A + b->off_qterms);
+        b->d_tasks = (DevTask *)(A + b->off_tasks);
+        b->d_sched = (uint32_t *)(A + b->off_sched);
+        b->d_fused = (DevFused *)(A + b->off_fused);
+        b->d_qplane = b->qplane.empty() ? nullptr : (uint32_t *)(A + b->off_qplane);
+        b->d_plane_terms = (uint32_t *)(A + b->off_plane_terms);
+        b->d_sterms = (uint32_t *)(A + b->off_sterms);
+        b->d_sweights = (double *)(A + b->off_sweights);
+        b->d_phrases = (DevPhrase *)(A + b->off_phrases);
+        b->d_pterms = (uint32_t *)(A + b->off_pterms);
+        b->d_ptasks = (uint32_t *)(A + b->off_ptasks);
+        b->d_counts = (uint32_t *)(A + a_counts);
+        b->d_ticket = (uint32_t *)(A + a_ticket);
+        b->d_qthr = planes_tasks ? (unsigned long long *)(A + a_qthr) : nullptr;
+        b->d_part_counts = scored ? (uint32_t *)(A + a_part_counts) : nullptr;
+        b->d_task_hits = rich ? (uint32_t *)(A + a_task_hits) : nullptr;
+        b->d_task_pos_base = rich ? (uint64_t *)(A + a_task_pos) : nullptr;
+        b->d_qcounts = (uint64_t *)(A + a_qcounts);
+        b->d_top_counts = scored ? (uint32_t *)(A + a_top_counts) : nullptr;
+        b->d_top_docs = scored ? (uint32_t *)(A + a_top_docs) : nullptr;
+        b->d_top_scores = scored ? (float *)(A + a_top_scores) : nullptr;
+        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k, &b->ev_up})
+                HIP_TRY(event_get(dev, e));
+        if (b->block_bytes)
+                HIP_TRY(hipMemcpyAsync(A, b->block, b->block_bytes, hipMemcpyHostToDevice, dev->stream_up));
+        HIP_TRY(hipMemsetAsync(A + a_zero, 0, a - a_zero, dev->stream_up));
+        // ---- the large buffers (the device handle's pool)
+        if (!b->plane_terms.empty() || planes_tasks) {
+                // the rows k_term_planes fills, plus an all-zero row: what a k_planes slot WITHOUT term planes reads (so its sweep needs no select)
+                const size_t row = (size_t)PL_PLANES * b->plw * 4;
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_planes, (b->plane_terms.size() + 1) * row + 64));
+                HIP_TRY(hipMemsetAsync((uint8_t *)b->d_planes + b->plane_terms.size() * row, 0, row + 64, dev->stream_up));
         }
-        CT_MARK("lowering");
-        // (heaviest first — by index: a Tmp is 800 bytes, sorting the records themselves was a third of tri_batch_create)
-        std::vector<uint32_t> qorder(tmp.size());
-        std::iota(qorder.begin(), qorder.end(), 0u);
-        std::stable_sort(qorder.begin(), qorder.end(), [&](const uint32_t a, const uint32_t c) { return tmp[a]->cost > tmp[c]->cost; });
-        uint64_t off = 0;
-        b->plan.reserve(tmp.size());
-        // cut every query into tasks of roughly TASK_COST postings, then schedule heaviest first
-        constexpr uint64_t TASK_COST = 96 * 1024;
-        // planner thresholds: tri_dev_set_option (defaults: tri_options)
-        const uint64_t DENSE_MIN_POSTINGS = dev->opt.dense_min_postings;
-        const uint64_t DENSE_TASK_COST = std::max<uint64_t>(1, dev->opt.dense_task_cost); // bitmap-window tasks stage their terms once: two windows of a head pair per task
-        // TASK_DENSE (bitmap windows) when the lead group is an OR (it has to be materialised as a set anyway), or when every other list is
-        // within a factor 32 of the lead (no block could be skipped) and there is enough work per docID window to keep 256 lanes busy;
-        // TASK_FUSED when such a query asks for a top-K (or is a general tree)
-        struct Class {
-                uint64_t sumdf, lead_docs;
-                uint32_t last_doc; // no match beyond the (required) group whose lists end first
-                bool dense, fuse;
-        };
-        auto classify = [&](const Tmp &t) {
-                const uint32_t *qt = &b->qterms[t.q.term_base];
-                Class c{0, 0, 0xffffffffu, t.q.nterms >= 2, false};
-                for (uint32_t k = 0; k < t.nlead; ++k)
-                        c.lead_docs += ix->terms[qt[k] & QT_TERM].documents;
-                uint32_t glast = 0;
-                bool in_neg = false;
-                for (uint32_t k = 0; k < t.q.nterms; ++k) {
-                        const DevTerm &tk = ix->terms[qt[k] & QT_TERM];
-                        c.sumdf += tk.documents;
-                        c.dense &= tk.nblocks <= c.lead_docs;
-                        if (k && (qt[k] & QT_GROUP)) {
-                                c.last_doc = std::min(c.last_doc, glast);
-                                glast = 0;
-                                in_neg = qt[k] & QT_NOT;
-                        }
-                        if (!in_neg)
-                                glast = std::max(glast, ix->h_blk_last[tk.first_block + tk.nblocks - 1]);
-                }
-                if (!in_neg)
-                        c.last_doc = std::min(c.last_doc, glast);
-                c.dense &= c.sumdf >= DENSE_MIN_POSTINGS;
-                c.dense |= t.nlead > 1;
-                c.fuse = t.truth || (c.dense && t.fusable && (dev->opt.fused != 2 || t.fz.nreq == 1)); // (fused == 2: only pure unions)
-                return c;
-        };
-        // one-pass tasks stage the query (slot map, score tables) once per task: the longer the task the better, as long as the batch still
-        // cuts into a couple of tasks per workgroup the device holds (measured at cfg3: 512 K postings per task 55.4 ms, 1 M 51.1, 2 M 49.2,
-        // 4 M 48.0, 8 M and more 47.1).  fused_task_cost = 0 (the default): sized from the batch; otherwise as given
-        uint64_t FUSED_TASK_COST = dev->opt.fused_task_cost;
-        std::vector<Class> classes(tmp.size()); // (once per query: the passes below and the task loop all ask)
-        for (size_t i = 0; i < tmp.size(); ++i)
-                classes[i] = classify(*tmp[i]);
-        uint64_t onepass_queries = 0;
-        for (const Class &c : classes)
-                onepass_queries += c.fuse ? 1 : 0;
-        // k_planes: docID ranges per query.  A task has fixed costs (seed pass, end-of-task imbalance: about 140 us), the kernel's tail is its
-        // longest tasks: two ranges when the batch brings ten or more tasks per resident workgroup anyway, three when it does not (measured,
-        // cfg3's mix: 8192 queries 2 > 3 > 4; 3750 queries 6.5 / 5.9 / 6.2 ms for 2 / 3 / 4; 1024 queries 2.11 / 1.97 / 1.96)
-        const uint64_t PLANES_SPLIT = dev->opt.planes_split ? dev->opt.planes_split : (2 * onepass_queries >= 10ull * (uint64_t)dev->cus * PLK_WGS_PER_CU ? 2 : 3);
-        if (!FUSED_TASK_COST) {
-                uint64_t fused_postings = 0;
-                for (size_t i = 0; i < tmp.size(); ++i)
-                        if (classes[i].fuse)
-                                for (uint32_t sidx = 0; sidx < tmp[i]->fz.nslots; ++sidx)
-                                        fused_postings += ix->terms[tmp[i]->fz.term[sidx]].documents;
-                const uint64_t want_tasks = 2ull * (uint64_t)dev->cus * FUS_WGS_PER_CU;
-                FUSED_TASK_COST = std::min<uint64_t>(8u << 20, std::max<uint64_t>(256u << 10, fused_postings / want_tasks));
-        }
-        // ---- term planes (k_planes.hpp): a head term is decoded once per launch for all the queries that name it.  Eligible: an indexed list
-        //      of at least docs_cnt / plane_div documents; built when the batch's uses repay one decode of the list (a use as a bitmap-window
-        //      or one-pass slot saves a whole walk, a use as the probed side of a candidate tile saves at most 32 postings per lead document)
-        const uint64_t planes_opt = dev->opt.planes;
-        const uint64_t plane_min_df = dev->opt.plane_div ? std::max<uint64_t>(1, ix->info.docs_cnt / dev->opt.plane_div) : UINT64_MAX;
-        auto plane_ok = [&](uint32_t term) {
-                const DevTerm &tk = ix->terms[term];
-                return planes_opt && tk.documents && tk.documents >= plane_min_df;
-        };
-        std::unordered_map<uint32_t, uint64_t> plane_benefit;
-        struct QUse {
-                uint32_t qpos, term;
-        };
-        struct FUse {
-                uint32_t fidx, slot, term;
-        };
-        std::vector<QUse> quses;
-        std::vector<FUse> fuses;
-        std::vector<std::pair<uint64_t, uint32_t>> order; // (task cost, task index)
-        CT_MARK("query order + classes");
-        for (const uint32_t qo : qorder) {
-                Tmp &t = *tmp[qo];
-                const uint32_t slot = (uint32_t)b->plan.size();
-                b->slot_of_query[t.q.qid] = slot;
-                const uint32_t *qt = &b->qterms[t.q.term_base];
-                const DevTerm &lead = ix->terms[qt[0] & QT_TERM];
-                const uint32_t nlead = t.nlead;
-                const Class cls = classes[qo];
-                const uint64_t sumdf = cls.sumdf;
-                const uint32_t last_doc = cls.last_doc;
-                const bool dense = cls.dense, fuse = cls.fuse;
-                if (fuse) {
-                        // a CNF query whose top-K runs over bit planes (k_planes): its head terms read from the batch's term planes, the
-                        // others (at most PLK_MAX_SPARSE) decoded per window into LDS planes
-                        uint32_t nsparse = 0;
-                        for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
-                                t.fz.plane[sidx] = PL_NONE;
-                                nsparse += plane_ok(t.fz.term[sidx]) ? 0u : 1u;
-                        }
-                        const bool pk = !t.truth && (planes_opt & 4u) && nsparse <= PLK_MAX_SPARSE && ix->max_doc < 0x7fff0000u; // (list entries are docID << 1 | flag)
-                        {
-                                const uint32_t fm = (1u << t.fz.fbits) - 1u;
-                                t.fz.negslots = 0;
-                                for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx)
-                                        if ((t.fz.nmask >> (sidx * t.fz.fbits)) & fm)
-                                                t.fz.negslots |= 1u << sidx;
-                        }
-                        // every list of the slot map is read once (the optional terms too)
-                        uint64_t slotdf = 0;
-                        for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
-                                slotdf += ix->terms[t.fz.term[sidx]].documents;
-                                (pk ? b->term_bytes_planes : b->term_bytes_fused) += ix->docbytes[t.fz.term[sidx]];
-                                if (pk && plane_ok(t.fz.term[sidx])) {
-                                        plane_benefit[t.fz.term[sidx]] += ix->terms[t.fz.term[sidx]].documents;
-                                        fuses.push_back({(uint32_t)b->fused.size(), sidx, t.fz.term[sidx]});
-                                }
-                        }
-                        ++(pk ? b->info.planes_queries : b->info.fused_queries);
-                        t.q.fused_idx = (uint32_t)b->fused.size();
-                        b->fused.push_back(t.fz);
-                        t.q.out_off = off;
-                        t.q.out_cap = 0; // the docID set is never materialised ...
-                        t.q.first_task = (uint32_t)b->tasks.size();
-                        const uint32_t fw = pk ? PL_W : FUS_W << t.fz.hw; // documents per window: plane windows, or this query's word width
-                        const uint32_t nwin = last_doc / fw + 1;
-                        const uint64_t per_win = std::max<uint64_t>(1, slotdf / (ix->info.docs_cnt / fw + 1));
-                        // (k_planes' cost is the sweep of the range plus its candidates, not the postings: equal ranges, a few per query)
-                        const uint32_t win_per_task = pk && PLANES_SPLIT < 65536 ? (uint32_t)((nwin + PLANES_SPLIT - 1) / PLANES_SPLIT)
-                                                                                 : (uint32_t)std::max<uint64_t>(1, FUSED_TASK_COST / per_win);
-                        const bool emit = t.fz.mode & FUS_MODE_EMIT; // ... except by a general tree in DocumentsOnly mode: a private region per task,
-                                                                     // bounded like TASK_DENSE's by the slots' blocks that reach the task's windows
-                        uint32_t ord = 0;
-                        for (uint32_t wb = 0; wb < nwin; wb += win_per_task, ++ord) {
-                                const uint32_t we = std::min(nwin, wb + win_per_task);
-                                uint64_t b1 = 0;
-                                if (emit)
-                                        for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
-                                                const DevTerm &tk = ix->terms[t.fz.term[sidx]];
-                                                const uint32_t *lb = &ix->h_blk_last[tk.first_block];
-                                                b1 += (uint64_t)(std::lower_bound(lb, lb + tk.nblocks, wb * fw) - lb);
-                                        }
-                                uint64_t entries = 0;
-                                if (pk) { // the rows of the decoded slots that can reach the task's docID range: 32 list entries each (k_planes)
-                                        for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx) {
-                                                if (plane_ok(t.fz.term[sidx]))
-                                                        continue;
-                                                const DevTerm &tk = ix->terms[t.fz.term[sidx]];
-                                                const uint32_t *lb = &ix->h_blk_last[tk.first_block];
-                                                const uint32_t r0 = (uint32_t)(std::lower_bound(lb, lb + tk.nblocks, wb * fw) - lb);
-                                                const uint32_t r1 = (uint32_t)(std::lower_bound(lb + r0, lb + tk.nblocks, we * fw) - lb);
-                                                if (r0 < tk.nblocks)
-                                                        entries += 32ull * (std::min(r1, tk.nblocks - 1) - r0 + 1);
-                                        }
-                                        if (entries > 0x7fffffffull)
-                                                return fail(TRI_ERR_UNSUPPORTED, "query %u: a task's decoded lists exceed 2^31 entries", t.q.qid);
-                                        b->sparse_cap = std::max(b->sparse_cap, (uint32_t)entries);
-                                }
-                                // (largest first, by postings: for k_planes a poor estimate — its cost is the sweep plus the candidates — but ordering by the
-                                //  decoded entries instead measured worse: cfg3's unions 10.6 ms against 9.2)
-                                order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
-                                b->tasks.push_back({slot, wb, we, pk ? (t.fz.nslots <= PLK_NS_SMALL ? TASK_PLANES : TASK_PLANES8) : t.fz.mode ? TASK_FUSED_GEN : t.fz.hw ? TASK_FUSED16 : TASK_FUSED, off + (emit ? b1 * 32 + 32ull * ord * t.fz.nslots : 0)});
-                        }
-                        if (emit) {
-                                uint64_t blocks = 0;
-                                for (uint32_t sidx = 0; sidx < t.fz.nslots; ++sidx)
-                                        blocks += ix->terms[t.fz.term[sidx]].nblocks;
-                                t.q.out_cap = (uint32_t)std::min<uint64_t>(0xffffffffull, blocks * 32 + 32ull * (ord + 1) * t.fz.nslots);
-                                off += t.q.out_cap;
-                        }
-                        t.q.ntasks = (uint32_t)b->tasks.size() - t.q.first_task;
-                        b->plan.push_back(t.q);
-                        continue;
-                }
-                if (dense) {
-                        std::vector<uint32_t> seen;
-                        for (uint32_t k = 0; k < t.q.nterms; ++k) {
-                                const uint32_t term = qt[k] & QT_TERM;
-                                if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
-                                        seen.push_back(term);
-                                        b->term_bytes_dense += ix->docbytes[term];
-                                }
-                                if ((planes_opt & 2u) && plane_ok(term)) {
-                                        plane_benefit[term] += ix->terms[term].documents;
-                                        quses.push_back({t.q.term_base + k, term});
-                                }
-                        }
-                        ++b->info.dense_queries;
-                } else {
-                        ++b->info.cand_queries;
-                        for (uint32_t k = 1; k < t.q.nterms; ++k) { // (the lead list is decoded into the candidate tiles; the others are probed)
-                                const uint32_t term = qt[k] & QT_TERM;
-                                if ((planes_opt & 1u) && plane_ok(term)) {
-                                        plane_benefit[term] += std::min<uint64_t>(ix->terms[term].documents, 32ull * lead.documents);
-                                        quses.push_back({t.q.term_base + k, term});
-                                }
-                        }
-                }
-                t.q.out_off = off;
-                t.q.first_task = (uint32_t)b->tasks.size();
-                if (dense) {
-                        const uint32_t nwin = last_doc / SPAN_BITS + 1;
-                        const uint64_t per_win = std::max<uint64_t>(1, sumdf / (ix->info.docs_cnt / SPAN_BITS + 1));
-                        const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / per_win);
-                        uint32_t ord = 0;
-                        uint64_t lead_blocks = 0;
-                        for (uint32_t k = 0; k < nlead; ++k)
-                                lead_blocks += ix->terms[qt[k] & QT_TERM].nblocks;
-                        for (uint32_t wb = 0; wb < nwin; wb += win_per_task, ++ord) {
-                                const uint32_t we = std::min(nwin, wb + win_per_task);
-                                // matches of windows [wb, we) are lead-group documents of blocks b1 .. (next task's b1) of every
-                                // lead list: a private region (+32 slots of slack per lead list and task for the straddling block)
-                                uint64_t b1 = 0;
-                                for (uint32_t k = 0; k < nlead; ++k) {
-                                        const DevTerm &tk = ix->terms[qt[k] & QT_TERM];
-                                        const uint32_t *lb = &ix->h_blk_last[tk.first_block];
-                                        b1 += (uint64_t)(std::lower_bound(lb, lb + tk.nblocks, wb * SPAN_BITS) - lb);
-                                }
-                                order.emplace_back(per_win * (we - wb), (uint32_t)b->tasks.size());
-                                b->tasks.push_back({slot, wb, we, TASK_DENSE, off + b1 * 32 + 32ull * ord * nlead});
-                        }
-                        t.q.out_cap = (uint32_t)std::min<uint64_t>(0xffffffffull, lead_blocks * 32 + 32ull * (ord + 1) * nlead);
-                } else {
-                        const uint32_t ntiles = (lead.nblocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
-                        const uint64_t per_tile = std::max<uint64_t>(1, t.cost / ntiles);
-                        const uint32_t tiles_per_task = (uint32_t)std::max<uint64_t>(1, TASK_COST / per_tile);
-                        for (uint32_t tb = 0; tb < ntiles; tb += tiles_per_task) {
-                                const uint32_t te = std::min(ntiles, tb + tiles_per_task);
-                                order.emplace_back(per_tile * (te - tb), (uint32_t)b->tasks.size());
-                                b->tasks.push_back({slot, tb, te, TASK_CAND, off + (uint64_t)tb * TILE_CANDS});
-                        }
-                        t.q.out_cap = lead.documents; // |A ∩ …| <= df of the lead
-                        if (dev->opt.account_needed_bytes) {
-                                // what a perfect gallop must read: the lead list, and of every other list the blocks that can hold a lead
-                                // candidate — per lead block the other list's blocks its docID range meets, at most one per candidate
-                                // (directories only; a block counts docbytes / nblocks)
-                                uint64_t need = ix->docbytes[qt[0] & QT_TERM];
-                                const uint32_t *ll = &ix->h_blk_last[lead.first_block];
-                                for (uint32_t k = 1; k < t.q.nterms; ++k) {
-                                        const DevTerm &tk = ix->terms[qt[k] & QT_TERM];
-                                        const uint32_t *ol = &ix->h_blk_last[tk.first_block];
-                                        uint64_t blocks = 0;
-                                        uint32_t at = 0; // (both directories ascend: the searches move forward)
-                                        for (uint32_t lb = 0; lb < lead.nblocks && at < tk.nblocks; ++lb) {
-                                                const uint32_t lo_doc = lb ? ll[lb - 1] + 1 : 1u, hi_doc = ll[lb];
-                                                at = (uint32_t)(std::lower_bound(ol + at, ol + tk.nblocks, lo_doc) - ol);
-                                                if (at >= tk.nblocks)
-                                                        break;
-                                                const uint32_t last = (uint32_t)(std::lower_bound(ol + at, ol + tk.nblocks, hi_doc) - ol);
-                                                const uint32_t span = std::min(last, tk.nblocks - 1) - at + 1;
-                                                const uint32_t ndocs = lb + 1 == lead.nblocks ? lead.last_n : 32u;
-                                                blocks += std::min(span, ndocs);
-                                        }
-                                        need += (uint64_t)((double)ix->docbytes[qt[k] & QT_TERM] * std::min(1.0, (double)blocks / std::max(1u, tk.nblocks)));
-                                }
-                                b->cand_needed_term_bytes += need;
-                        }
-                }
-                off += t.q.out_cap;
-                t.q.ntasks = (uint32_t)b->tasks.size() - t.q.first_task;
-                if (t.q.nphrases)
-                        for (uint32_t ti = t.q.first_task; ti < t.q.first_task + t.q.ntasks; ++ti)
-                                b->ptasks.push_back(ti);
-                b->plan.push_back(t.q);
-        }
-        CT_MARK("tasks");
-        std::stable_sort(order.begin(), order.end(), [](const auto &a, const auto &c) { return a.first > c.first; });
-        std::vector<uint32_t> sched;
-        sched.reserve(order.size());
-        for (const auto &o : order)
-                if (b->tasks[o.second].kind == TASK_DENSE)
-                        sched.push_back(o.second);
-        b->n_dense = (uint32_t)sched.size();
-        for (const auto &o : order)
-                if (b->tasks[o.second].kind == TASK_CAND)
-                        sched.push_back(o.second);
-        b->n_cand = (uint32_t)sched.size() - b->n_dense;
-        for (const auto &o : order)
-                if (b->tasks[o.second].kind == TASK_FUSED)
-                        sched.push_back(o.second);
-        b->n_fused = (uint32_t)sched.size() - b->n_dense - b->n_cand;
-        for (const auto &o : order)
-                if (b->tasks[o.second].kind == TASK_FUSED16)
-                        sched.push_back(o.second);
-        b->n_fused16 = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused;
-        for (const auto &o : order)
-                if (b->tasks[o.second].kind == TASK_FUSED_GEN)
-                        sched.push_back(o.second);
-        b->n_fusedgen = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused - b->n_fused16;
-        for (const auto &o : order)
-                if (b->tasks[o.second].kind == TASK_PLANES)
-                        sched.push_back(o.second);
-        b->n_planes = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused - b->n_fused16 - b->n_fusedgen;
-        for (const auto &o : order)
-                if (b->tasks[o.second].kind == TASK_PLANES8)
-                        sched.push_back(o.second);
-        b->n_planes8 = (uint32_t)sched.size() - b->n_dense - b->n_cand - b->n_fused - b->n_fused16 - b->n_fusedgen - b->n_planes;
-        // the planes that pay: rows in term order (deterministic), the uses pointed at them
-        {
-                std::vector<uint32_t> chosen;
-                for (const auto &e : plane_benefit)
-                        if (e.second >= ix->terms[e.first].documents)
-                                chosen.push_back(e.first);
-                for (const auto &u : fuses) // (a one-pass slot counts a whole decode: always chosen; kept explicit)
-                        if (std::find(chosen.begin(), chosen.end(), u.term) == chosen.end())
-                                chosen.push_back(u.term);
-                std::sort(chosen.begin(), chosen.end());
-                std::unordered_map<uint32_t, uint32_t> row_of;
-                for (uint32_t x : chosen) {
-                        row_of[x] = (uint32_t)b->plane_terms.size();
-                        b->plane_terms.push_back(x);
-                        b->plane_decoded_bytes += ix->docbytes[x];
-                }
-                if (!chosen.empty()) {
-                        std::vector<uint32_t> qplane(b->qterms.size(), PL_NONE);
-                        for (const auto &u : quses)
-                                if (auto it = row_of.find(u.term); it != row_of.end())
-                                        qplane[u.qpos] = it->second;
-                        for (const auto &u : fuses)
-                                b->fused[u.fidx].plane[u.slot] = row_of[u.term];
-                        int rcp;
-                        if ((rcp = dev_upload(&b->d_qplane, qplane)) || (rcp = dev_upload(&b->d_plane_terms, b->plane_terms)))
-                                return rcp;
-                }
-                if (!chosen.empty() || b->n_planes + b->n_planes8) {
-                        // the rows k_term_planes fills, plus an all-zero row: what a k_planes slot WITHOUT term planes reads (so its sweep needs no select)
-                        b->plw = ((ix->max_doc >> 17) + 2u) * (SPAN_BITS / 32u); // whole bitmap windows (k_and_dense reads SPAN_WORDS at a time) + a spare one
-                        const size_t row = (size_t)PL_PLANES * b->plw * 4;
-                        HIP_TRY(pool_alloc(dev, (void **)&b->d_planes, (b->plane_terms.size() + 1) * row + 64));
-                        HIP_TRY(hipMemset((uint8_t *)b->d_planes + b->plane_terms.size() * row, 0, row + 64));
-                }
-        }
-        if (b->n_planes + b->n_planes8) {
-                HIP_TRY(hipMalloc((void **)&b->d_qthr, (b->plan.size() + 1) * 8));
-                b->sparse_cap = (b->sparse_cap + 63u) & ~63u;
+        if (planes_tasks) {
                 const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
                 HIP_TRY(pool_alloc(dev, (void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
         }
-        CT_MARK("order + planes + scratch");
-        b->out_capacity = off;
-        int rc;
-        if ((rc = dev_upload(&b->d_plan, b->plan)) || (rc = dev_upload(&b->d_qterms, b->qterms)) || (rc = dev_upload(&b->d_tasks, b->tasks)) ||
-            (rc = dev_upload(&b->d_sched, sched)) || (rc = dev_upload(&b->d_fused, b->fused)))
-                return rc;
-        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k})
-                HIP_TRY(hipEventCreate(e));
         HIP_TRY(pool_alloc(dev, (void **)&b->d_out, (off + 64) * 4));
-        HIP_TRY(hipMalloc((void **)&b->d_counts, (b->tasks.size() + 1) * 4));
-        HIP_TRY(hipMalloc((void **)&b->d_ticket, 256));
-        HIP_TRY(hipMalloc((void **)&b->d_qcounts, (nq + 1) * 8));
-        HIP_TRY(hipMemset(b->d_qcounts, 0, (nq + 1) * 8)); // queries that can never match keep count 0
-        if (!b->phrases.empty()) {
-                if ((rc = dev_upload(&b->d_phrases, b->phrases)) || (rc = dev_upload(&b->d_pterms, b->pterms)) || (rc = dev_upload(&b->d_ptasks, b->ptasks)))
-                        return rc;
-                if (scored) {
-                        HIP_TRY(pool_alloc(dev, (void **)&b->d_pscore, (off + 64) * 8));
-                        HIP_TRY(hipMemset(b->d_pscore, 0, (off + 64) * 8));
-                }
+        if (!b->phrases.empty() && scored) {
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_pscore, (off + 64) * 8));
+                HIP_TRY(hipMemsetAsync(b->d_pscore, 0, (off + 64) * 8, dev->stream_up));
         }
         if (rich) {
-                if ((rc = dev_upload(&b->d_sterms, b->sterms)))
-                        return rc;
                 b->rich_R = std::max<uint32_t>(b->rich_R, 1);
                 HIP_TRY(pool_alloc(dev, (void **)&b->d_rich_present, (off + 64) * 4));
                 HIP_TRY(pool_alloc(dev, (void **)&b->d_rich_freq, (off + 64) * 2 * b->rich_R));
-                HIP_TRY(hipMalloc((void **)&b->d_task_hits, (b->tasks.size() + 1) * 4));
-                HIP_TRY(hipMalloc((void **)&b->d_task_pos_base, (b->tasks.size() + 1) * 8));
                 if (b->rich_allow) {
                         HIP_TRY(pool_alloc(dev, (void **)&b->d_rich_allow, (off + 64) * 4));
-                        HIP_TRY(hipMemset(b->d_rich_allow, 0xff, (off + 64) * 4)); // (every other query's matches: all terms allowed)
+                        HIP_TRY(hipMemsetAsync(b->d_rich_allow, 0xff, (off + 64) * 4, dev->stream_up)); // (every other query's matches: all terms allowed)
                 }
         }
         if (scored) {
-                if ((rc = dev_upload(&b->d_sterms, b->sterms)) || (rc = dev_upload(&b->d_sweights, b->sweights)))
-                        return rc;
-                const size_t nt = b->tasks.size();
                 if (!topk)
                         HIP_TRY(pool_alloc(dev, (void **)&b->d_all_scores, (off + 64) * 8));
                 HIP_TRY(pool_alloc(dev, (void **)&b->d_part_docs, (nt * topk + 1) * 4));
                 HIP_TRY(pool_alloc(dev, (void **)&b->d_part_scores, (nt * topk + 1) * 8));
-                HIP_TRY(hipMalloc((void **)&b->d_part_counts, (nt + 1) * 4));
-                HIP_TRY(hipMalloc((void **)&b->d_top_docs, (nq * topk + 1) * 4));
-                HIP_TRY(hipMalloc((void **)&b->d_top_scores, (nq * topk + 1) * 4));
-                HIP_TRY(hipMalloc((void **)&b->d_top_counts, (nq + 1) * 4));
-                HIP_TRY(hipMemset(b->d_top_counts, 0, (nq + 1) * 4)); // queries that can never match keep count 0 ...
-                HIP_TRY(hipMemset(b->d_top_docs, 0, (nq * topk + 1) * 4)); // ... and zeroed rows (k_topk_merge only writes the rows of queries that have a plan slot;
-                HIP_TRY(hipMemset(b->d_top_scores, 0, (nq * topk + 1) * 4)); // the blocks travel whole to the host and to the other ranks)
         }
-        CT_MARK("uploads + allocations");
+        HIP_TRY(hipEventRecord(b->ev_up, dev->stream_up));
         b->info.nqueries = nq;
         b->info.out_capacity = off;
+        b->info.dense_queries = b->dense_queries;
+        b->info.cand_queries = b->cand_queries;
+        b->info.fused_queries = b->fused_queries;
+        b->info.planes_queries = b->planes_queries;
+        b->info.unsupported_queries = b->unsupported_queries;
         b->info.plane_terms = b->plane_terms.size();
         b->info.plane_bytes = (uint64_t)b->plane_terms.size() * PL_PLANES * b->plw * 4;
         b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (b->n_planes8 != 0) + (!b->plane_terms.empty()) +
                            (!b->ptasks.empty()) + (rich ? 2 : 0) +
                            ((scored && b->n_dense + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
+        b->info.create_plan_ms = (float)(b->plan_ms[0] + b->plan_ms[1] + b->plan_ms[2] + b->plan_ms[3]);
+        b->info.create_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
         *out = b.release();
         return TRI_OK;
 }
+
 
 extern "C" void tri_batch_destroy(tri_batch *b) {
         delete b; // ~tri_batch releases the device buffers
@@ -2104,7 +774,7 @@ extern "C" void tri_batch_destroy(tri_batch *b) {
 extern "C" int tri_batch_run(tri_batch *b) {
         if (!b)
                 return fail(TRI_ERR_INVALID, "null batch");
-        tri_dev *dev = b->ix->dev;
+        tri_dev *dev = b->dev;
         HIP_TRY(hipSetDevice(dev->device));
         b->synced = false;
         const uint32_t n = (uint32_t)b->tasks.size();
@@ -2118,6 +788,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
         memset(g_trace_host, 0, 64 * 16);
 #endif
         b->ran = true;
+        HIP_TRY(hipStreamWaitEvent(dev->stream, b->ev_up, 0)); // the plan's copy (upload stream) has arrived
         HIP_TRY(hipEventRecord(b->ev0, dev->stream));
         if (n) {
                 HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 256, dev->stream));
@@ -2713,6 +1384,21 @@ extern "C" int tri_cbatch_create(tri_batch *const *parts, size_t n, tri_cbatch *
 }
 
 extern "C" void tri_cbatch_destroy(tri_cbatch *c) { delete c; }
+
+// per query: TRI_OK, or TRI_ERR_UNSUPPORTED when the planner left the query out of ANY part (its answer over the collection is then
+// incomplete: the caller keeps its CPU path for that query, as with tri_batch_query_status)
+extern "C" int tri_cbatch_query_status(const tri_cbatch *c, int32_t *status) {
+        if (!c || !status)
+                return fail(TRI_ERR_INVALID, "null argument");
+        const size_t nq = c->parts[0]->nq;
+        for (size_t q = 0; q < nq; ++q) {
+                status[q] = TRI_OK;
+                for (const tri_batch *p : c->parts)
+                        if (p->qstatus[q] != TRI_OK)
+                                status[q] = p->qstatus[q];
+        }
+        return TRI_OK;
+}
 
 extern "C" int tri_cbatch_run(tri_cbatch *c) {
         if (!c)

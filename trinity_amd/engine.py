@@ -78,6 +78,8 @@ class TriBatchInfo(C.Structure):
         ("plane_bytes", C.c_uint64),
         ("term_planes_decoded_bytes", C.c_uint64),
         ("unsupported_queries", C.c_uint64),
+        ("create_ms", C.c_float),
+        ("create_plan_ms", C.c_float),
     ]
 
 
@@ -87,7 +89,7 @@ ABI_SYMBOLS = [
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
-    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads",
+    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
 
@@ -137,6 +139,7 @@ def hip_lib():
     L.tri_batch_docset_hashes.argtypes = [vp, vp]
     L.tri_cbatch_create.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     L.tri_cbatch_destroy.argtypes = [vp]
+    L.tri_cbatch_query_status.argtypes = [vp, vp]
     L.tri_cbatch_run.argtypes = [vp]
     L.tri_cbatch_sync.argtypes = [vp]
     L.tri_cbatch_match_counts.argtypes = [vp, vp]
@@ -200,6 +203,18 @@ def gen_phrase_queries(D, V, slots, corpus_seed, seed, nq, nterms):
     L.tri_synth_phrase_queries.restype = None
     L.tri_synth_phrase_queries(D, V, slots, corpus_seed, seed, nq, nterms, out.ctypes.data)
     return out
+
+
+def flatten(programs):
+    """(flat u32 program, (nq, 2) u32 tri_query table of (offset, length)) of a list of postfix programs — laid out with numpy (a ctypes
+    struct array costs a microsecond per field store)."""
+    progs = [np.ascontiguousarray(p, dtype=np.uint32) for p in programs]
+    flat = np.concatenate(progs) if progs else np.zeros(0, np.uint32)
+    q = np.zeros((max(1, len(progs)), 2), dtype=np.uint32)
+    if progs:
+        q[:, 1] = np.fromiter((p.size for p in progs), dtype=np.uint32, count=len(progs))
+        q[1:, 0] = np.cumsum(q[:-1, 1], dtype=np.uint64).astype(np.uint32)
+    return flat, q
 
 
 class Segment:
@@ -349,19 +364,23 @@ class Index:
 class Batch:
     """A compiled batch of postfix query programs."""
 
-    def __init__(self, index, programs, flags, topk=0, similarity=0):
+    def __init__(self, index, programs, flags, topk=0, similarity=0, allow_unsupported=False, flat=None):
+        """programs: a list of postfix programs (u32 arrays) — or flat = flatten(programs), the (program, tri_query table) pair the C-ABI
+        takes, prepared once by a caller that compiles the same queries again and again (bench.py's end-to-end loop).
+        A query whose shape the planner does not lower is left out of the batch with a per-query status (it reports no matches): unless
+        the caller says it handles that (allow_unsupported=True, then query_status()), such a batch raises instead of answering silently."""
         self.index = index
-        progs = [np.ascontiguousarray(p, dtype=np.uint32) for p in programs]
-        self.nq = len(progs)
-        flat = np.concatenate(progs) if progs else np.zeros(0, np.uint32)
-        # tri_query[] = (prog_off, prog_len) pairs: laid out with numpy (a ctypes struct array costs a microsecond per field store)
-        q = np.zeros((max(1, self.nq), 2), dtype=np.uint32)
-        if progs:
-            q[:, 1] = np.fromiter((p.size for p in progs), dtype=np.uint32, count=self.nq)
-            q[1:, 0] = np.cumsum(q[:-1, 1], dtype=np.uint64).astype(np.uint32)
+        self.nq = len(programs) if flat is None else flat[1].shape[0]
+        flat, q = flatten(programs) if flat is None else flat
         self.flags, self.topk = flags, topk
         self.h = C.c_void_p()
         _check(hip_lib().tri_batch_create(index.h, flat.ctypes.data, flat.size, q.ctypes.data, self.nq, None, flags, topk, similarity, C.byref(self.h)))
+        if not allow_unsupported:
+            n = self.info()["unsupported_queries"]
+            if n:
+                msg = hip_lib().tri_last_error().decode()
+                self.close()
+                raise TrinityError(f"{n} queries of the batch have a shape the planner does not lower (allow_unsupported=True + query_status() to run the rest): {msg}")
 
     @classmethod
     def conjunctions(cls, index, term_rows, flags=FLAG_DOCUMENTS_ONLY, topk=0):
@@ -470,12 +489,20 @@ class CollectionBatch:
     """The same queries over the sources of a collection (IndexSourcesCollection): one Batch per source, oldest first, each index
     carrying the documents the newer sources update as its masked set; counts add up, top-K lists merge on the device."""
 
-    def __init__(self, batches):
+    def __init__(self, batches, allow_unsupported=False):
         self.parts = list(batches)
         self.nq, self.topk = self.parts[0].nq, self.parts[0].topk
         arr = (C.c_void_p * len(self.parts))(*[b.h for b in self.parts])
         self.h = C.c_void_p()
         _check(hip_lib().tri_cbatch_create(arr, len(self.parts), C.byref(self.h)))
+        if not allow_unsupported and self.query_status().any():
+            self.close()
+            raise TrinityError("queries of the collection batch have a shape the planner does not lower (allow_unsupported=True + query_status())")
+
+    def query_status(self):
+        out = np.zeros(self.nq, dtype=np.int32)
+        _check(hip_lib().tri_cbatch_query_status(self.h, out.ctypes.data))
+        return out
 
     def run(self):
         _check(hip_lib().tri_cbatch_run(self.h))

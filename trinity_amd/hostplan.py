@@ -1,0 +1,126 @@
+"""The host planner without a device (csrc/host/plan_host.cpp in libtrinity_host.so): plans a batch exactly as tri_batch_create does
+and hands back the plan's host block — for the CPU tests of the planner (tests/test_planner.py) and tools/plan_probe.py.  Test and
+probe infrastructure: the product path is tri_batch_create in libtrinity_hip.so, which includes the same planner.hpp."""
+import ctypes as C
+
+import numpy as np
+
+from .engine import TrinityError, flatten, host_lib  # noqa: F401
+
+_SUMMARY = ["block_bytes", "n_plan", "n_qterms", "n_tasks", "n_fused_maps", "n_qplane", "n_plane_terms", "n_sterms", "n_sweights", "n_phrases", "n_pterms", "n_ptasks",
+            "off_plan", "off_qterms", "off_tasks", "off_sched", "off_fused", "off_qplane", "off_plane_terms", "off_sterms", "off_sweights", "off_phrases", "off_pterms", "off_ptasks",
+            "n_dense", "n_cand", "n_fused", "n_fused16", "n_fusedgen", "n_planes", "n_planes8", "plw", "sparse_cap", "out_capacity", "term_bytes", "term_bytes_dense",
+            "dense_queries", "cand_queries", "fused_queries", "planes_queries", "unsupported_queries", "rich_R", "sizeof_query", "sizeof_task", "sizeof_fused", "sizeof_phrase",
+            "cand_needed_term_bytes", "plane_decoded_bytes"]  # fmt: skip
+
+DEV_QUERY = np.dtype([("nterms", "<u4"), ("term_base", "<u4"), ("out_off", "<u8"), ("out_cap", "<u4"), ("qid", "<u4"), ("first_task", "<u4"), ("ntasks", "<u4"),
+                      ("score_base", "<u4"), ("nscore", "<u4"), ("phrase_base", "<u4"), ("nphrases", "<u4"), ("fused_idx", "<u4"), ("pad0", "<u4")])  # fmt: skip
+DEV_TASK = np.dtype([("slot", "<u4"), ("begin", "<u4"), ("end", "<u4"), ("kind", "<u4"), ("out_off", "<u8")])
+TASK_CAND, TASK_DENSE, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8 = range(7)
+SCHED_ORDER = [TASK_DENSE, TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8]
+
+
+def _lib():
+    L = host_lib()
+    if not hasattr(L, "_plan_ready"):
+        vp = C.c_void_p
+        L.tri_host_index_build.restype = vp
+        L.tri_host_index_build.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_int, vp, C.c_uint64, C.c_uint32, C.c_char_p, C.c_uint64]
+        L.tri_host_index_free.argtypes = [vp]
+        L.tri_host_plan.restype = vp
+        L.tri_host_plan.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint, vp, vp, C.c_uint, C.c_uint32, C.c_char_p, C.c_uint64]
+        L.tri_host_plan_free.argtypes = [vp]
+        L.tri_host_plan_summary.argtypes = [vp, vp, vp]
+        L.tri_host_plan_block.restype = C.POINTER(C.c_uint8)
+        L.tri_host_plan_block.argtypes = [vp]
+        L.tri_host_plan_query_maps.argtypes = [vp, vp, vp]
+        L._plan_ready = True
+    return L
+
+
+class HostIndex:
+    def __init__(self, index_bytes, terms, docs_cnt, codec=1, hits=None):
+        b = np.ascontiguousarray(index_bytes, dtype=np.uint8)
+        t = np.ascontiguousarray(terms, dtype=np.uint32).reshape(-1, 3)
+        h = np.ascontiguousarray(hits, dtype=np.uint8) if hits is not None and len(hits) else None
+        err = C.create_string_buffer(600)
+        self.h = _lib().tri_host_index_build(b.ctypes.data, b.size, h.ctypes.data if h is not None else None, h.size if h is not None else 0, codec, t.ctypes.data, t.shape[0],
+                                             docs_cnt, err, 600)  # fmt: skip
+        if not self.h:
+            raise TrinityError(err.value.decode())
+
+    @classmethod
+    def from_segment(cls, seg):
+        return cls(seg.index, seg.terms, seg.docs_cnt, codec=seg.codec, hits=seg.hits)
+
+    def close(self):
+        if self.h:
+            _lib().tri_host_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class HostPlan:
+    """One planned batch: .s (summary dict), .ms (the four phase times), and the plan's arrays as numpy views of its block."""
+
+    def __init__(self, hindex, programs, flags, topk=0, similarity=0, threads=1, options=None, cus=256, flat=None):
+        self.nq = len(programs) if flat is None else flat[1].shape[0]
+        prog, q = flatten(programs) if flat is None else flat
+        options = options or {}
+        names = (C.c_char_p * max(1, len(options)))(*[k.encode() for k in options])
+        values = np.array(list(options.values()) or [0], dtype=np.uint64)
+        err = C.create_string_buffer(600)
+        self.h = _lib().tri_host_plan(hindex.h, prog.ctypes.data, prog.size, q.ctypes.data, self.nq, flags, topk, similarity, threads, names, values.ctypes.data, len(options), cus,
+                                      err, 600)  # fmt: skip
+        if not self.h:
+            raise TrinityError(err.value.decode())
+        out = np.zeros(len(_SUMMARY), dtype=np.uint64)
+        ms = np.zeros(4, dtype=np.float64)
+        _lib().tri_host_plan_summary(self.h, out.ctypes.data, ms.ctypes.data)
+        self.s = {k: int(v) for k, v in zip(_SUMMARY, out)}
+        self.ms = ms
+        assert self.s["sizeof_query"] == DEV_QUERY.itemsize and self.s["sizeof_task"] == DEV_TASK.itemsize
+        p = _lib().tri_host_plan_block(self.h)
+        self.block = np.ctypeslib.as_array(p, shape=(max(1, self.s["block_bytes"]),))
+        self.slot_of_query = np.zeros(max(1, self.nq), dtype=np.uint32)
+        self.qstatus = np.zeros(max(1, self.nq), dtype=np.int32)
+        _lib().tri_host_plan_query_maps(self.h, self.slot_of_query.ctypes.data, self.qstatus.ctypes.data)
+
+    def _view(self, off, n, dtype):
+        dt = np.dtype(dtype)
+        return self.block[self.s[off] : self.s[off] + n * dt.itemsize].view(dt)
+
+    @property
+    def plan(self):
+        return self._view("off_plan", self.s["n_plan"], DEV_QUERY)
+
+    @property
+    def tasks(self):
+        return self._view("off_tasks", self.s["n_tasks"], DEV_TASK)
+
+    @property
+    def sched(self):
+        return self._view("off_sched", self.s["n_tasks"], "<u4")
+
+    @property
+    def qterms(self):
+        return self._view("off_qterms", self.s["n_qterms"], "<u4")
+
+    @property
+    def qplane(self):
+        return self._view("off_qplane", self.s["n_qplane"], "<u4")
+
+    @property
+    def plane_terms(self):
+        return self._view("off_plane_terms", self.s["n_plane_terms"], "<u4")
+
+    def close(self):
+        if self.h:
+            self.block = None
+            _lib().tri_host_plan_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
