@@ -9,22 +9,31 @@ distinct within a query) over the 10M-document / 1M-term synthetic Zipf(1.0) seg
 DocumentsOnly mode — every query's full ascending docID set is materialised in HBM.  --workload cfg3 / cfg4 / cfg5 / cfg1 are
 the other query sets of SURVEY §8(d) (cfg5 = the mixed batch: a DocumentsOnly batch on the google_codec segment plus a BM25
 top-100 batch on the lucene_codec segment of the same corpus, both per step).
-One "step" = one pass of the engine over one batch of --queries queries per GPU (index and compiled batches already resident
-in HBM).  Multi-GPU: one process per GPU, the index replicated, the query stream sharded (queries are independent, exec.h:57-62):
+
+One "step" = what the reference's exec_query does for every query of a batch of --queries queries per GPU, end to end
+(exec.cpp:530-876, 1511-1516: plan the query, run it, deliver the results): tri_batch_create (host planning on the device handle's
+host threads + one H2D copy of the plan) -> tri_batch_run -> tri_batch_sync -> read-back of the match counts (and, scored, the
+top-K blocks) to the host [-> the result all_gather over RCCL at N > 1], PIPELINED: the next step's batch is compiled and uploaded
+while the current one runs — the timed K steps hold exactly K creates, K runs, K read-backs.  The index is resident in HBM; the
+docID sets themselves stay in HBM (DESIGN.md §5 has the PCIe-inclusive figure).  `kernels_only` is the same batch re-run without
+planning or read-back (HIP-event time of the runs inside the same timed steps).
+
+Multi-GPU: one process per GPU, the index replicated, the query stream sharded (queries are independent, exec.h:57-62):
 --scaling weak (default) gives every rank a shard of --queries queries, --scaling strong splits --queries over the ranks; with
 --gpus N > 1 the default workload is cfg5, the mixed 100K-query batch BASELINE.json's scaling criterion is quoted on (12500 queries
 per GPU).  At the end of every step the ranks all_gather their result blocks over RCCL straight from the engine's device buffers:
 per-query match counts and, for scored batches, the [Q/G][K] top-K docID/score blocks (trinity_amd/dist.py ResultGather — the
-only exchange the path has).
+only exchange the path has).  A line is self-contained for scaling: at N = 1 `scaling_ref` is this GPU's rate on one rank's cfg5 shard
+(the workload the N > 1 lines run), at N > 1 `scaling_ref` is rank 0's rate on its shard with the other ranks parked at a barrier,
+and `speedup_vs_scaling_ref` = value / that.
 
-Rank 0 prints ONE JSON line: metric/value = queries/s over all GPUs (kernels + result gather; the docID sets themselves stay in
-HBM — copying every set back over PCIe would make the rate PCIe-bound); `roofline` = the dominant kernel's
-algorithmic bytes (sum over its queries of docbytes(t) + 4 B per match, or + 8 B x min(matches, K) when scored)
-/ its mean launch duration measured with HIP events on the engine's stream; `cpu_baseline` = the CPU oracle (restatement of the
-reference exec path) timed on a bounded sample of the same batch, which doubles as a per-query full-size parity check.
-`end_to_end` = what the kernel-only `value` leaves out: tri_batch_create (host planning + H2D) and the result read-back (match
-counts, top-K blocks) per batch, and the rate of a create / run / read-back loop with the next batch compiled while the current
-one runs.
+Rank 0 prints ONE JSON line: metric/value = queries/s over all GPUs.  `roofline`: bound "hbm"; `frac` is the BATCH-LEVEL bound — every
+distinct list the step's queries name read once + every output written once (tri_batch_info.bound_bytes) / the step's kernel time /
+peak — for the whole step and, under `kernels`, per kernel (HIP events on the engine's stream around each launch, inside the timed
+steps), next to `physical_frac` (committed rocprofv3 PMC traffic of the same workload / kernel time / peak) and SURVEY §8(d)'s per-query
+algorithmic bytes (`per_query_algorithmic`: a figure no kernel that shares decodes or skips reads, so it carries no fraction).
+`cpu_baseline` = the CPU oracle (restatement of the reference exec path, planning included) timed on a bounded sample of the same
+batch, which doubles as a per-query full-size parity check.
 """
 import argparse
 import json
@@ -36,11 +45,188 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNELS = ("k_and_dense", "k_and", "k_fused", "k_planes", "k_phrase")  # the kernels with per-launch HIP-event brackets and their own algorithmic bytes
+KERNELS = ("k_and_dense", "k_and", "k_fused", "k_planes", "k_phrase")  # the kernels with per-launch HIP-event brackets and their own byte counts
 KMS = {"k_and_dense": "dense_ms", "k_and": "cand_ms", "k_fused": "fused_ms", "k_planes": "planes_ms", "k_phrase": "phrase_ms"}
 KALG = {"k_and_dense": "dense_algorithmic_bytes", "k_and": "cand_algorithmic_bytes", "k_fused": "fused_algorithmic_bytes", "k_planes": "planes_algorithmic_bytes",
         "k_phrase": "phrase_algorithmic_bytes"}  # fmt: skip
+KBOUND = {"k_and_dense": "dense_bound_bytes", "k_and": "cand_bound_bytes", "k_fused": "fused_bound_bytes", "k_planes": "planes_bound_bytes", "k_phrase": "phrase_bound_bytes"}
 KQ = {"k_and_dense": "dense_queries", "k_and": "cand_queries", "k_fused": "fused_queries", "k_planes": "planes_queries", "k_phrase": "phrase_queries"}
+MS_KEYS = ("last_run_ms", "dense_ms", "cand_ms", "fused_ms", "phrase_ms", "rest_ms", "planes_ms", "term_planes_ms", "create_ms", "create_plan_ms")
+TOT_KEYS = ("matches", "algorithmic_bytes", "dense_algorithmic_bytes", "cand_algorithmic_bytes", "fused_algorithmic_bytes", "dense_queries", "cand_queries", "fused_queries",
+            "cand_needed_bytes", "phrase_algorithmic_bytes", "phrase_queries", "planes_algorithmic_bytes", "planes_queries", "plane_terms", "plane_bytes", "term_planes_decoded_bytes",
+            "bound_bytes", "dense_bound_bytes", "cand_bound_bytes", "fused_bound_bytes", "planes_bound_bytes", "phrase_bound_bytes")  # fmt: skip
+
+
+class DryDevice:
+    """--dry-run: option store in place of a device handle."""
+
+    def __init__(self):
+        self.opts = {}
+
+    def set_option(self, k, v):
+        self.opts[k] = int(v)
+
+    def close(self):
+        pass
+
+
+class DryBatch:
+    """--dry-run: a batch planned by the REAL host planner (csrc/planner.hpp through libtrinity_host.so) that never runs: its result blocks
+    are zeros with the shapes of tri_batch_counts_device / tri_batch_topk_device, on CPU tensors."""
+
+    def __init__(self, hix, flags, topk, flat, opts):
+        import torch
+
+        from trinity_amd import hostplan as HP
+
+        self.flags, self.topk, self.nq = flags, topk, flat[1].shape[0]
+        self.plan = HP.HostPlan(hix.h, None, flags, topk, threads=4, options={k: v for k, v in opts.items() if k != "account_needed_bytes"}, flat=flat)
+        self._blocks = {"counts": torch.zeros(self.nq, dtype=torch.int64)}
+        if (flags & 2) and topk:
+            self._blocks.update(docs=torch.zeros((self.nq, topk), dtype=torch.int32), scores=torch.zeros((self.nq, topk), dtype=torch.float32),
+                                topk_counts=torch.zeros(self.nq, dtype=torch.int32))  # fmt: skip
+
+    def run(self):
+        pass
+
+    def sync(self):
+        pass
+
+    def blocks(self):
+        return self._blocks
+
+    def info(self):
+        d = dict.fromkeys(MS_KEYS + TOT_KEYS, 0.0)
+        d.update(create_plan_ms=float(self.plan.ms.sum()), create_ms=float(self.plan.ms.sum()), last_run_ms=1e-6)
+        d.update({k: float(self.plan.s[k]) for k in ("dense_queries", "cand_queries", "fused_queries", "planes_queries")})
+        return d
+
+    def counts(self):
+        return self._blocks["counts"].numpy().astype("uint64")
+
+    def topk_results(self):
+        b = self._blocks
+        return b["docs"].numpy().view("uint32"), b["scores"].numpy(), b["topk_counts"].numpy().view("uint32")
+
+    def close(self):
+        if self.plan:
+            self.plan.close()
+            self.plan = None
+
+
+class DryIndex:
+    def __init__(self, dev, seg):
+        from trinity_amd import hostplan as HP
+
+        self.dev, self.h, self.seg = dev, HP.HostIndex.from_segment(seg), seg
+
+    @classmethod
+    def from_segment(cls, dev, seg):
+        return cls(dev, seg)
+
+    def info(self):
+        return {"index_bytes": int(self.seg.index.size), "postings": int(self.seg.sum_terms_docs)}
+
+    def close(self):
+        self.h.close()
+
+
+class DryEngine:
+    """--dry-run: the names Workload uses of the trinity_amd package, backed by the host planner alone."""
+
+    def __init__(self, T):
+        self.Segment, self.engine, self.Index = T.Segment, T.engine, DryIndex
+
+    def Batch(self, ix, programs, flags, topk=0, flat=None):
+        return DryBatch(ix, flags, topk, flat, ix.dev.opts)
+
+
+class Workload:
+    """One rank's shard of a SURVEY §8(d) workload on a device: the segments' indexes and, per engine batch of a step, the query programs
+    in the flat form the C-ABI takes (prepared once: what a C++ caller hands to tri_batch_create)."""
+
+    def __init__(self, T, W, dev, name, docs, vocab, total_queries, rank, world, segs, ixs):
+        self.T, self.dev, self.name = T, dev, name
+        self.parts, self.desc = W.build_parts(name, docs, vocab, 10, 42, total_queries)
+        self.build_s = self.upload_s = 0.0
+        for pt in self.parts:
+            if pt.codec not in segs:
+                t0 = time.time()
+                segs[pt.codec] = T.Segment(docs, vocab, 10, 42, codec=pt.codec)
+                self.build_s += time.time() - t0
+                t0 = time.time()
+                ixs[pt.codec] = T.Index.from_segment(dev, segs[pt.codec])
+                self.upload_s += time.time() - t0  # one-time: format walk + directory / delta-stream / cell-index build on the host, then PCIe
+        self.segs, self.ixs = segs, ixs
+        self.progs = [pt.programs[rank::world] for pt in self.parts]  # interleaved shard: same mix on every rank
+        self.flat = [T.engine.flatten(p) for p in self.progs]
+        self.nq = sum(len(p) for p in self.progs)
+
+    def create_set(self):
+        return [self.T.Batch(self.ixs[pt.codec], None, pt.flags, topk=pt.topk, flat=fl) for pt, fl in zip(self.parts, self.flat)]
+
+
+def read_back(T, bs):  # what every caller needs on the host: match counts and, scored, the top-K blocks
+    for b_ in bs:
+        b_.counts()
+        if (b_.flags & T.FLAG_ACCUMULATED_SCORE) and b_.topk:
+            b_.topk_results()
+
+
+class Pipeline:
+    """create -> run -> sync -> read back [-> gather], the next set compiled while the current one runs."""
+
+    def __init__(self, T, wl, gathers=None, blocks_of=None, sync_stream=True):
+        self.T, self.wl, self.gathers, self.blocks_of, self.sync_stream = T, wl, gathers, blocks_of, sync_stream
+        self.cur = wl.create_set()
+        self.done = None  # the last completed set: its results stay readable
+        self.readback_s = 0.0
+
+    def step(self):
+        T = self.T
+        for b in self.cur:
+            b.run()
+        nxt = self.wl.create_set()  # host planning + the plan's H2D copy while `cur` runs on the engine stream
+        for b in self.cur:
+            b.sync()
+        t0 = time.perf_counter()
+        read_back(T, self.cur)
+        self.readback_s += time.perf_counter() - t0
+        if self.gathers:  # result exchange straight from the engine's device buffers (docsets stay sharded in HBM)
+            for g, b in zip(self.gathers, self.cur):
+                g.rebind(self.blocks_of(b))
+                g.step()
+            if self.sync_stream:
+                import torch
+
+                torch.cuda.current_stream().synchronize()  # the receive side is complete before the send buffers go back to the pool
+        infos = [b.info() for b in self.cur]
+        if self.done:
+            for b in self.done:
+                b.close()
+        self.done, self.cur = self.cur, nxt
+        return infos
+
+    def close(self):
+        for bs in (self.cur, self.done):
+            for b in bs or []:
+                b.close()
+        self.cur = self.done = None
+
+
+def timed(pipe, steps, warmup, barrier):
+    for _ in range(warmup):
+        pipe.step()
+    barrier()
+    pipe.readback_s = 0.0
+    acc = {}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for i in pipe.step():
+            for k in MS_KEYS:
+                acc[k] = acc.get(k, 0.0) + i[k]
+    barrier()
+    return time.perf_counter() - t0, acc
 
 
 def main():
@@ -55,8 +241,10 @@ def main():
     ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
                     help="SURVEY §8(d) query sets; default: cfg2 at one GPU (the configuration BASELINE.json's metric is quoted on), cfg5 (the mixed 100K batch) at N > 1")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --queries per GPU; strong: --queries in all, split over the GPUs")
-    ap.add_argument("--e2e-steps", type=int, default=3, help="create / run / read-back steps of the end-to-end leg (0 = skip)")
+    ap.add_argument("--scaling-ref-steps", type=int, default=3, help="steps of the scaling reference leg (0 = skip): N = 1: one rank's cfg5 shard on this GPU; N > 1: rank 0 alone on its shard")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="planner option (tri_dev_set_option), e.g. fused=0")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / sharding / gather plumbing WITHOUT a GPU (tests/test_bench_launch.py): the batches are planned by the real host "
+                                                          "planner, nothing runs, the result blocks are zeros on CPU tensors gathered over gloo; the line says dry_run and measures nothing")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -81,146 +269,94 @@ def main():
     from trinity_amd import workloads as W
 
     dist = None
-    torch.cuda.set_device(local_rank)
+    dry = args.dry_run
+    if not dry:
+        torch.cuda.set_device(local_rank)
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # launched by torch.distributed.run: the result gather runs even with one rank
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         # one rank makes sure the native libraries are built (normally a no-op: the built .so travel with the tree); the
         # others wait instead of racing hipcc on the same output file
         if local_rank == 0:
-            T.build_all()
+            T.build.build_host() if dry else T.build_all()
         dist.barrier()
     else:
-        T.build_all()
+        T.build.build_host() if dry else T.build_all()
 
-    # ---- synthetic segments (identical on every rank) and this rank's query shard
-    docs, vocab = (100_000, 10_000) if args.workload == "cfg1" and args.docs == 10_000_000 else (args.docs, args.vocab)
-    parts, wl_desc = W.build_parts(args.workload, docs, vocab, 10, 42, total_queries)
-    dev = T.Device(local_rank)
-    dev.set_option("account_needed_bytes", 1)  # batch creation also works out what a perfect gallop must read for k_and's queries (untimed)
-    for o in args.option:
-        k, v = o.split("=", 1)
-        dev.set_option(k, int(v))
-    segs, ixs, build_s, upload_s = {}, {}, 0.0, 0.0
-    for pt in parts:
-        if pt.codec not in segs:
-            t0 = time.time()
-            segs[pt.codec] = T.Segment(docs, vocab, 10, 42, codec=pt.codec)
-            build_s += time.time() - t0
-            t0 = time.time()
-            ixs[pt.codec] = T.Index.from_segment(dev, segs[pt.codec])
-            upload_s += time.time() - t0  # one-time: format walk + directory / delta-stream / cell-index build on the host, then PCIe
-    batches, shard_progs, shard_flat = [], [], []
-    for pt in parts:
-        mine = pt.programs[rank::world]  # interleaved shard: same mix on every rank
-        shard_progs.append(mine)
-        shard_flat.append(T.engine.flatten(mine))  # the (program words, tri_query table) pair the C-ABI takes: what a C++ caller hands over
-        batches.append(T.Batch(ixs[pt.codec], None, pt.flags, topk=pt.topk, flat=shard_flat[-1]))
-    nq_rank = sum(len(p) for p in shard_progs)
-
-    def create_set():  # a step's batches compiled afresh (no needed-bytes accounting: that walk is a bench-only diagnostic)
-        dev.set_option("account_needed_bytes", 0)
-        out = []
-        for pt, sp, fl in zip(parts, shard_progs, shard_flat):
-            t_ = time.perf_counter()
-            out.append(T.Batch(ixs[pt.codec], None, pt.flags, topk=pt.topk, flat=fl))
-            if os.environ.get("BENCH_TRACE_CREATE"):
-                print(f"[create] {pt.name}: {len(sp)} queries {(time.perf_counter() - t_) * 1e3:.2f} ms", file=sys.stderr, flush=True)
-        dev.set_option("account_needed_bytes", 1)
-        return out
-
-    def read_back(bs):  # what every caller needs on the host: match counts and, scored, the top-K blocks
-        for b_ in bs:
-            b_.counts()
-            if (b_.flags & T.FLAG_ACCUMULATED_SCORE) and b_.topk:
-                b_.topk_results()
+    def device_sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
-    gathers = []
+    # ---- synthetic segments (identical on every rank) and this rank's query shard
+    docs, vocab = (100_000, 10_000) if args.workload == "cfg1" and args.docs == 10_000_000 else (args.docs, args.vocab)
+    dev = DryDevice() if dry else T.Device(local_rank)
+    for o in args.option:
+        k, v = o.split("=", 1)
+        dev.set_option(k, int(v))
+    segs, ixs = {}, {}
+    wl = Workload(DryEngine(T) if dry else T, W, dev, args.workload, docs, vocab, total_queries, rank, world, segs, ixs)
+    parts, nq_rank = wl.parts, wl.nq
+
+    # ---- the diagnostic set: the same batches created once with account_needed_bytes (a directory walk per candidate-tile query and a
+    #      pass over the plan: untimed) — its run gives the byte counts of the roofline block, its results are what the parity check,
+    #      the CPU leg and the gather check read
+    dev.set_option("account_needed_bytes", 1)
+    batches = wl.create_set()
+    dev.set_option("account_needed_bytes", 0)
+    for b in batches:
+        b.run()
+    for b in batches:
+        b.sync()
+    infos = [b.info() for b in batches]
+    tot = {k: float(sum(i[k] for i in infos)) for k in TOT_KEYS}
+
+    dev_t = torch.device("cpu") if dry else torch.device("cuda", local_rank)
+    blocks_of = (lambda b: b.blocks()) if dry else (lambda b: TD.device_blocks(b, dev_t))
+    gathers = [TD.ResultGather(dist, blocks_of(b)) for b in batches] if dist is not None else None
+    pipe = Pipeline(T, wl, gathers, blocks_of, sync_stream=not dry)
+
+    # ---- scaling reference (before the timed region; every rank takes part so that the ranks stay in step)
+    scaling_ref = None
+    if args.scaling_ref_steps > 0:
+        if world > 1:
+            # rank 0 alone on its shard (no gather, the other ranks parked at the barrier): the one-GPU rate of THIS workload in THIS run
+            barrier()
+            if rank == 0:
+                solo = Pipeline(T, wl)
+                el, _ = timed(solo, args.scaling_ref_steps, 1, device_sync)
+                solo.close()
+                scaling_ref = {"workload": wl.desc, "queries_per_step": nq_rank, "steps": args.scaling_ref_steps, "value": nq_rank * args.scaling_ref_steps / el, "unit": "queries/s",
+                               "what": "rank 0 alone on its shard of this run's workload (the other ranks parked at a barrier), the same create -> run -> read-back loop without the gather"}  # fmt: skip
+            barrier()
+        elif args.workload != "cfg5" and docs == 10_000_000:
+            # one rank's shard of the mixed 100K batch (what the N > 1 lines run per GPU) on this GPU
+            t0 = time.time()
+            ref_wl = Workload(T, W, dev, "cfg5", docs, vocab, 12500, 0, 1, segs, ixs)
+            ref = Pipeline(T, ref_wl)
+            el, _ = timed(ref, args.scaling_ref_steps, 1, device_sync)
+            ref.close()
+            scaling_ref = {"workload": ref_wl.desc, "queries_per_step": ref_wl.nq, "steps": args.scaling_ref_steps, "value": ref_wl.nq * args.scaling_ref_steps / el, "unit": "queries/s",
+                           "what": "one GPU's shard of the mixed 100K-query batch (12500 queries: what bench.py --gpus N > 1 runs per GPU), the same create -> run -> read-back loop; "
+                                   "compare the N > 1 lines' per_gpu_value with this, not with `value` (cfg2)", "setup_s": time.time() - t0}  # fmt: skip
+
+    # ---- the timed region
+    elapsed, acc = timed(pipe, args.steps, args.warmup, barrier)
+    readback_ms = pipe.readback_s * 1e3 / max(1, args.steps)
+
     if dist is not None:
-        gathers = [TD.ResultGather(dist, TD.device_blocks(b, torch.device("cuda", local_rank))) for b in batches]
-
-    def step():
-        for b in batches:
-            b.run()
-        for b in batches:
-            b.sync()
-        for g in gathers:  # result exchange straight from the engine's device buffers (docsets stay sharded in HBM)
-            g.step()
-        if gathers:
-            torch.cuda.current_stream().synchronize()  # the receive side is complete before the next step rewrites the send buffers
-        return [b.info() for b in batches]
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    acc = {}
-    infos = None
-    for _ in range(args.steps):
-        infos = step()
-        for i in infos:
-            for k in ("last_run_ms", "dense_ms", "cand_ms", "fused_ms", "phrase_ms", "rest_ms", "planes_ms", "term_planes_ms"):
-                acc[k] = acc.get(k, 0.0) + i[k]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    tot = {k: float(sum(i[k] for i in infos)) for k in ("matches", "algorithmic_bytes", "dense_algorithmic_bytes", "cand_algorithmic_bytes", "fused_algorithmic_bytes",
-                                                       "dense_queries", "cand_queries", "fused_queries", "cand_needed_bytes", "phrase_algorithmic_bytes", "phrase_queries",
-                                                       "planes_algorithmic_bytes", "planes_queries", "plane_terms", "plane_bytes", "term_planes_decoded_bytes")}  # fmt: skip
-
-    # ---- end to end (rank 0's view; every rank runs it so the ranks stay in step): batch creation, read-back, and a create / run /
-    #      read-back loop in which the next step's batches are compiled on the host while the current ones run on the device
-    e2e = None
-    if args.e2e_steps > 0:
-        # (the device handle recycles the batches' large buffers — tri_dev's pool: two sets are in flight in the loop below, so two are
-        #  created and released first, like the kernels' warm-up steps; a cold 15 GB hipMalloc was measured between 10 ms and 1 s)
-        t1 = time.perf_counter()
-        warm = [create_set(), create_set()]
-        create_cold_ms = (time.perf_counter() - t1) * 1e3 / 2
-        for ws in warm:
-            for b_ in ws:
-                b_.close()
-        t1 = time.perf_counter()
-        nxt = create_set()
-        create_ms = (time.perf_counter() - t1) * 1e3
-        t1 = time.perf_counter()
-        read_back(batches)
-        readback_ms = (time.perf_counter() - t1) * 1e3
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        cur = nxt
-        for b_ in cur:
-            b_.run()
-        for _ in range(args.e2e_steps - 1):
-            nxt = create_set()  # (host planning + H2D while `cur` runs on the engine stream)
-            for b_ in cur:
-                b_.sync()
-            read_back(cur)
-            for b_ in nxt:
-                b_.run()
-            for b_ in cur:
-                b_.close()
-            cur = nxt
-        for b_ in cur:
-            b_.sync()
-        read_back(cur)
-        loop_s = time.perf_counter() - t1
-        for b_ in cur:
-            b_.close()
-        e2e = {"batch_create_ms": create_ms, "batch_create_cold_ms": create_cold_ms, "readback_ms": readback_ms, "readback": "match counts" + (" + top-K blocks" if any(pt.topk for pt in parts) else "") + " to the host (docID sets stay in HBM)",
-               "steps": args.e2e_steps, "loop_ms_per_step": loop_s * 1e3 / args.e2e_steps,
-               "queries_per_sec": nq_rank * world * args.e2e_steps / loop_s,
-               "note": "create (host planning + H2D) -> run -> read-back per step, the next step's batches compiled while the current ones run; the first create is outside the loop; batch_create_cold_ms: before the device handle's buffer pool has anything to recycle"}  # fmt: skip
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        m = torch.tensor([tot["matches"], tot["algorithmic_bytes"]], dtype=torch.float64, device="cuda")
+        m = torch.tensor([tot["matches"], tot["algorithmic_bytes"]], dtype=torch.float64, device=dev_t)
         dist.all_reduce(m, op=dist.ReduceOp.SUM)
         matches_all, alg_all = float(m[0].item()), float(m[1].item())
     else:
@@ -230,46 +366,56 @@ def main():
     if dist is not None:
         # what arrived in this rank's slot of every gathered block is what the engine reports locally (host copies through the C-ABI)
         ok = True
-        for b, g in zip(batches, gathers):
+        for b, g in zip(pipe.done, gathers):
             ok &= bool(np.array_equal(g.recv["counts"][rank].cpu().numpy().astype(np.uint64), b.counts()))
             if "docs" in g.recv:
                 d, s_, c = b.topk_results()
                 ok &= bool(np.array_equal(g.recv["docs"][rank].cpu().numpy().view(np.uint32), d) and np.array_equal(g.recv["scores"][rank].cpu().numpy(), s_)
                            and np.array_equal(g.recv["topk_counts"][rank].cpu().numpy().view(np.uint32), c))  # fmt: skip
-        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cuda")
+        # ... and the pipelined batches answer what the diagnostic set answered
+        for b, b0 in zip(pipe.done, batches):
+            ok &= bool(np.array_equal(b.counts(), b0.counts()))
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         gather_check = {"ranks": world, "blocks": sorted({k for g in gathers for k in g.recv}), "equal_on_every_rank": bool(t.item() == 1.0)}
+    same_as_resident = all(bool(np.array_equal(b.counts(), b0.counts())) for b, b0 in zip(pipe.done, batches))
 
     if rank == 0:
         steps = max(1, args.steps)
         ms_per_step = elapsed * 1e3 / steps
         qps = nq_rank * world * steps / elapsed
         kms = {k: acc.get(KMS[k], 0.0) / steps for k in KERNELS}
-        kalg = {k: tot[KALG[k]] for k in KERNELS}
-        k_ms = acc["last_run_ms"] / steps
+        k_ms = acc["last_run_ms"] / steps  # HIP events around the whole run, per step (all batches of the step)
         rest_ms = acc["rest_ms"] / steps
+        tp_ms = acc.get("term_planes_ms", 0.0) / steps
         dom = max(kms, key=kms.get)
+        traffic, traffic_src = pmc_traffic(args, world)
 
         def gbs(b, ms):
             return b / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
-        def physical(k):  # PMC traffic of the kernel / its time / peak (None without a committed PMC pass of this exact workload)
-            tr = (traffic or {}).get(k)
-            return gbs(tr, kms[k]) / HBM_PEAK_GBS if tr and kms[k] > 0 else None
+        def frac(b, ms):
+            return gbs(b, ms) / HBM_PEAK_GBS
 
         def kentry(k):
-            e = {"kernel_ms": kms[k], "algorithmic_bytes_per_launch": kalg[k], "achieved": gbs(kalg[k], kms[k]), "frac": gbs(kalg[k], kms[k]) / HBM_PEAK_GBS,
-                 "queries": int(tot[KQ[k]]), "traffic": (traffic or {}).get(k), "physical_frac": physical(k)}  # fmt: skip
+            tr = (traffic or {}).get(k)
+            e = {"kernel_ms": kms[k], "queries": int(tot[KQ[k]]),
+                 # the batch-level bound of the kernel's own queries: their distinct lists once + their output once
+                 "bound_bytes_per_launch": tot[KBOUND[k]], "achieved": gbs(tot[KBOUND[k]], kms[k]), "frac": frac(tot[KBOUND[k]], kms[k]),
+                 "traffic": tr, "physical_frac": frac(tr, kms[k]) if tr else None,
+                 # sum over the kernel's queries of docbytes(t) + output — charges a shared list once per query that names it and
+                 # counts lists a gallop skips: an effective rate, not a fraction of anything
+                 "per_query_algorithmic": {"bytes_per_launch": tot[KALG[k]], "effective_GBps": gbs(tot[KALG[k]], kms[k])}}  # fmt: skip
             if k == "k_and" and tot["cand_needed_bytes"]:
-                # galloping skips, so algorithmic bytes are no bound for this kernel (its "achieved" can exceed the peak): the bound is what a
-                # perfect gallop must read (tri_batch_info.cand_needed_bytes: lead lists + the blocks that can hold a lead candidate + output)
+                # what a perfect gallop must read for these queries, query by query (lead lists + the blocks that can hold a lead candidate + output)
                 e["needed_bytes_per_launch"] = tot["cand_needed_bytes"]
-                e["needed_achieved"] = gbs(tot["cand_needed_bytes"], kms[k])
-                e["needed_frac"] = e["needed_achieved"] / HBM_PEAK_GBS
+                e["needed_frac"] = frac(tot["cand_needed_bytes"], kms[k])
             return e
 
-        traffic, traffic_src = pmc_traffic(args, world)
+        step_traffic = sum(v for v in (traffic or {}).values() if v) if traffic else None
         info0 = ixs[parts[0].codec].info()
+        if dry:
+            k_ms = max(k_ms, 1e-9)
         out = {
             "metric": "queries/sec",
             "value": qps,
@@ -283,58 +429,68 @@ def main():
             "vs_baseline": None,
             "dtype": "u32" if not any(pt.flags & T.FLAG_ACCUMULATED_SCORE for pt in parts) else "u32 docIDs / f64 sums of f32 BM25 terms",
             "data": "synthetic",
+            **({"dry_run": "NO DEVICE: launcher / sharding / planner / gather plumbing only — value measures nothing"} if dry else {}),
             "config": {
-                "workload": f"{wl_desc}, Zipf(1.0) {docs} docs / {vocab} terms",
+                "workload": f"{wl.desc}, Zipf(1.0) {docs} docs / {vocab} terms",
                 "docs": docs,
                 "vocab": vocab,
                 "queries_per_gpu_per_step": nq_rank,
                 "queries_per_step": nq_rank * world,
                 "batches_per_step": [{"part": pt.name, "queries": len(sp), "codec": "google" if pt.codec == T.engine.CODEC_GOOGLE else "lucene",
-                                      "mode": "AccumulatedScore top-%d" % pt.topk if pt.flags & T.FLAG_ACCUMULATED_SCORE else "DocumentsOnly"} for pt, sp in zip(parts, shard_progs)],  # fmt: skip
+                                      "mode": "AccumulatedScore top-%d" % pt.topk if pt.flags & T.FLAG_ACCUMULATED_SCORE else "DocumentsOnly"} for pt, sp in zip(parts, wl.progs)],  # fmt: skip
                 "index_bytes": int(info0["index_bytes"]),
                 "postings": int(info0["postings"]),
                 "parallelism": f"query-sharded x{world}, index replicated" + (", per-step RCCL all_gather of counts + top-K blocks" if world > 1 else ""),
                 "options": args.option,
             },
+            "step": "tri_batch_create (host planning + the plan's H2D copy) -> tri_batch_run -> tri_batch_sync -> match counts" + (" + top-K blocks" if any(pt.topk for pt in parts) else "") +
+                    " read back to the host" + (" -> RCCL all_gather of the result blocks" if world > 1 else "") + "; the next step's batches are compiled while the current ones run",
+            "value_excludes": "the docID sets' way to the host: they stay in HBM, the host reads match counts / top-K blocks (PCIe-inclusive figure: DESIGN.md §5)",
+            "per_gpu_value": qps / world,
             "matched_docids_per_sec": matches_all * steps / elapsed,
             "matches_per_step": matches_all,
-            "value_excludes": "result delivery to the host: docID sets / top-K blocks stay in HBM (PCIe-inclusive figure: DESIGN.md §5)",
+            "pipelined_results_equal_resident_batch": same_as_resident,
+            "kernels_only": {"value": nq_rank * world / (k_ms * 1e-3) if k_ms > 0 else None, "ms_per_step": k_ms, "unit": "queries/s",
+                             "what": "the step's kernels alone (HIP events around tri_batch_run inside the timed steps): no planning, no read-back"},
+            "end_to_end": {"batch_create_ms": acc["create_ms"] / steps, "batch_create_plan_ms": acc["create_plan_ms"] / steps, "readback_ms": readback_ms,
+                           "what": "per step, inside the timed region: tri_batch_create (all batches of the step; its host-planner share) and the read-back of the match counts" +
+                                   (" + top-K blocks" if any(pt.topk for pt in parts) else "")},
             "roofline": {
                 "bound": "hbm",
-                "achieved": gbs(kalg[dom], kms[dom]),
+                "scope": "step",
+                # the batch-level bound: every DISTINCT list the step's queries name read once + every output written once
+                "bound_bytes": tot["bound_bytes"],
+                "achieved": gbs(tot["bound_bytes"], k_ms),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
-                "frac": gbs(kalg[dom], kms[dom]) / HBM_PEAK_GBS,
-                "traffic": (traffic or {}).get(dom),
+                "frac": frac(tot["bound_bytes"], k_ms),
+                "kernel_ms": k_ms,
+                "traffic": step_traffic,
                 "traffic_source": traffic_src,
-                "physical_frac": physical(dom),  # PMC bytes / kernel time / peak: what actually crossed the fabric (algorithmic > physical where lists are
-                                                 # skipped, shared between the batch's queries through the term planes, or served by the Infinity Cache)
-                # ... and with the term planes' build charged to this kernel alone (it reads them instead of decoding the shared head terms per query)
-                "frac_incl_term_planes": gbs(kalg[dom], kms[dom] + acc.get("term_planes_ms", 0.0) / steps) / HBM_PEAK_GBS,
-                "kernel": dom,
-                "kernel_ms": kms[dom],
-                "algorithmic_bytes_per_launch": kalg[dom],
-                "queries_per_launch": int(tot[KQ[dom]]),
-                "other_kernels": {k: kentry(k) for k in KERNELS if k != dom and tot[KQ[k]] > 0},
-                "post_passes_ms": rest_ms,  # k_score (queries matched by k_and) / k_topk_merge / k_rich: no bytes of their own
-                # the head terms the batch's queries share are decoded ONCE per launch (k_term_planes) instead of once per query that names them:
-                # its time is part of the step, its bytes are what it reads of the codec's lists
-                "term_planes": {"kernel_ms": acc.get("term_planes_ms", 0.0) / steps, "terms": int(tot["plane_terms"]), "decoded_list_bytes_per_launch": tot["term_planes_decoded_bytes"],
-                                "scratch_bytes": tot["plane_bytes"]},  # fmt: skip
-                "whole_step": dict({"kernel_ms": k_ms, "algorithmic_bytes": tot["algorithmic_bytes"], "achieved": gbs(tot["algorithmic_bytes"], k_ms)},
-                                   **({} if tot["cand_queries"] else {"frac": gbs(tot["algorithmic_bytes"], k_ms) / HBM_PEAK_GBS})),  # (no fraction when a skipping kernel is in the step)
+                "physical_frac": frac(step_traffic, k_ms) if step_traffic else None,  # PMC bytes / kernel time / peak (Infinity-Cache hits included)
+                "dominant_kernel": dom,
+                "kernels": {k: kentry(k) for k in KERNELS if tot[KQ[k]] > 0},
+                "post_passes_ms": rest_ms,  # k_score (queries matched by k_and) / k_topk_merge / k_rich
+                # the head terms the batch's queries share are decoded ONCE per launch (k_term_planes): its time is part of the step
+                "term_planes": {"kernel_ms": tp_ms, "terms": int(tot["plane_terms"]), "decoded_list_bytes_per_launch": tot["term_planes_decoded_bytes"],
+                                "scratch_bytes": tot["plane_bytes"], "traffic": (traffic or {}).get("k_term_planes")},  # fmt: skip
+                "per_query_algorithmic": {"bytes_per_step": tot["algorithmic_bytes"], "effective_GBps": gbs(tot["algorithmic_bytes"], k_ms),
+                                          "what": "SURVEY §8(d): sum over queries of docbytes(t) + output; a list shared by n queries counts n times, skipped blocks count: no fraction"},
             },
-            "segment_build_s": build_s,
-            "index_upload_s": upload_s,
+            "segment_build_s": wl.build_s,
+            "index_upload_s": wl.upload_s,
         }
-        if e2e is not None:
-            out["end_to_end"] = e2e
+        if scaling_ref is not None:
+            out["scaling_ref"] = scaling_ref
+            if world > 1:
+                out["speedup_vs_scaling_ref"] = qps / scaling_ref["value"]
         if gather_check is not None:
             out["gather_check"] = gather_check
-        if args.cpu_seconds > 0 and world == 1:  # the CPU leg (and the per-query parity check that rides on it) runs at N = 1 only
-            out["cpu_baseline"], out["parity_check"] = cpu_baseline(segs, parts, shard_progs, batches, args.cpu_seconds)
+        if args.cpu_seconds > 0 and world == 1 and not dry:  # the CPU leg (and the per-query parity check that rides on it) runs at N = 1 only
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(segs, parts, wl.progs, batches, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
+    pipe.close()
     for b in batches:
         b.close()
     for ix in ixs.values():

@@ -19,7 +19,7 @@ extern "C" {
 
 #define TRI_ABI_VERSION 6 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
                              4: tri_batch_info grew (term planes, k_planes), tri_batch_query_status, tri_comm_create_custom; 5: tri_encode_google_payloads;
-                             6: tri_batch_info.create_ms / create_plan_ms, options plane_max_bytes / plan_threads */
+                             6: tri_batch_info.create_ms / create_plan_ms / *_bound_bytes, options plane_max_bytes / plan_threads, tri_cbatch_query_status */
 
 /* status codes */
 #define TRI_OK 0
@@ -127,6 +127,12 @@ typedef struct tri_batch_info {
         /* what tri_batch_create itself took: all of it (host planning on the handle's host threads + arena / pool bookkeeping + enqueueing the plan's
          * one copy on the upload stream), and the host planner's share */
         float create_ms, create_plan_ms;
+        /* With the option account_needed_bytes = 1 at creation (else 0): the BATCH-LEVEL bound — a batch that shares decodes must read every
+         * DISTINCT list its queries name once (doc bytes; hit bytes of the distinct phrase / reported terms) and write every output once
+         * (4 B per match, or 8 B x min(matches, K) when scored): bound_bytes for the whole batch, *_bound_bytes for the queries each kernel
+         * runs (distinct lists of THOSE queries + their output; k_phrase: the distinct phrase terms' hit bytes).  SURVEY §8(d)'s per-query
+         * count (algorithmic_bytes) charges a list once per query that names it, which no kernel that shares decodes reads */
+        uint64_t bound_bytes, dense_bound_bytes, cand_bound_bytes, fused_bound_bytes, planes_bound_bytes, phrase_bound_bytes;
 } tri_batch_info;
 
 const char *tri_last_error(void);

@@ -101,6 +101,10 @@ struct BatchPlan {
         uint64_t term_bytes = 0, term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, term_bytes_phrase_hits = 0, plane_decoded_bytes = 0,
                  cand_needed_term_bytes = 0;
         uint64_t dense_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, unsupported_queries = 0;
+        // option account_needed_bytes (a diagnostic of bench.py, untimed): the bytes of the DISTINCT lists the batch's queries name — each
+        // list once, however many queries share it: what a batch that shares decodes has to read at least — over the whole batch (doc bytes,
+        // plus the hit bytes of the distinct phrase / reported terms) and per execution class (by task kind; [7]: the phrases' hit bytes)
+        uint64_t distinct_bytes = 0, distinct_bytes_kind[8] = {};
         std::string last_unsupported; // describes the last query that was left out
         double plan_ms[4] = {0, 0, 0, 0}; // lowering + classes, tasks, layout + fill, schedule + planes
 };
@@ -1368,5 +1372,45 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         }
         P.sparse_cap = (P.sparse_cap + 63u) & ~63u;
         P.plan_ms[3] = ms_since(t0);
+        if (opt.account_needed_bytes && !ix.terms.empty()) {
+                // (diagnostic: one pass over the plan with a mark per term and class)
+                std::vector<uint8_t> seen(ix.terms.size(), 0); // bit k: counted for kind k; bit 7: counted for the batch
+                std::vector<uint8_t> seen_hits(ix.terms.size(), 0);
+                for (size_t sidx = 0; sidx < n_plan; ++sidx) {
+                        const DevQuery &q = P.plan[sidx];
+                        const uint32_t kind = P.tasks[q.first_task].kind;
+                        auto touch = [&](uint32_t term) {
+                                if (!(seen[term] & 0x80u))
+                                        P.distinct_bytes += ix.docbytes[term];
+                                if (!(seen[term] & (1u << kind)))
+                                        P.distinct_bytes_kind[kind] += ix.docbytes[term];
+                                seen[term] |= (uint8_t)(0x80u | (1u << kind));
+                        };
+                        if (kind >= TASK_FUSED) {
+                                const DevFused &z = P.fused[q.fused_idx];
+                                for (uint32_t k = 0; k < z.nslots; ++k)
+                                        touch(z.term[k]);
+                        } else {
+                                for (uint32_t k = 0; k < q.nterms; ++k)
+                                        touch(P.qterms[q.term_base + k] & QT_TERM);
+                                if (mode != TRI_FLAG_DOCUMENTS_ONLY) // (k_score / k_rich read the scorer / reported terms' lists)
+                                        for (uint32_t k = 0; k < q.nscore; ++k)
+                                                touch(P.sterms[q.score_base + k]);
+                        }
+                        auto touch_hits = [&](uint32_t term, bool phrase) {
+                                if (!(seen_hits[term] & 1u))
+                                        P.distinct_bytes += ix.hitbytes[term];
+                                if (phrase && !(seen_hits[term] & 2u))
+                                        P.distinct_bytes_kind[7] += ix.hitbytes[term];
+                                seen_hits[term] |= (uint8_t)(1u | (phrase ? 2u : 0u));
+                        };
+                        for (uint32_t ph = 0; ph < q.nphrases; ++ph)
+                                for (uint32_t k = 0; k < P.phrases[q.phrase_base + ph].nterms; ++k)
+                                        touch_hits(P.pterms[P.phrases[q.phrase_base + ph].term_base + k], true);
+                        if (C.rich)
+                                for (uint32_t k = 0; k < q.nscore; ++k)
+                                        touch_hits(P.sterms[q.score_base + k], false);
+                }
+        }
         return TRI_OK;
 }

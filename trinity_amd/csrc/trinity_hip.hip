@@ -1037,6 +1037,26 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         b->info.cand_needed_bytes = b->cand_needed_term_bytes ? b->cand_needed_term_bytes + 4 * (m - m_dense - m_fused) : 0;
         b->info.fused_algorithmic_bytes = b->term_bytes_fused + out_fused; // docbytes + 8 B x min(matches, K)
         b->info.matches = m;
+        if (b->distinct_bytes) { // (option account_needed_bytes: the batch-level bound — every distinct list once + every output once)
+                const uint64_t m_cand = m - m_dense - m_fused;
+                const bool sc = b->flags & TRI_FLAG_ACCUMULATED_SCORE;
+                uint64_t out_legacy_dense = 4 * m_dense, out_legacy_cand = 4 * m_cand;
+                if (sc && b->topk) { // (queries matched by k_and_dense / k_and of a top-K batch deliver 8 B x min(matches, K))
+                        out_legacy_dense = out_legacy_cand = 0;
+                        for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
+                                const DevQuery &q = b->plan[sidx];
+                                if (!q.ntasks || b->tasks[q.first_task].kind >= TASK_FUSED)
+                                        continue;
+                                (b->tasks[q.first_task].kind == TASK_DENSE ? out_legacy_dense : out_legacy_cand) += 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk);
+                        }
+                }
+                b->info.dense_bound_bytes = b->distinct_bytes_kind[TASK_DENSE] + out_legacy_dense;
+                b->info.cand_bound_bytes = b->distinct_bytes_kind[TASK_CAND] + out_legacy_cand;
+                b->info.fused_bound_bytes = b->distinct_bytes_kind[TASK_FUSED] + b->distinct_bytes_kind[TASK_FUSED16] + b->distinct_bytes_kind[TASK_FUSED_GEN] + out_fused;
+                b->info.planes_bound_bytes = b->distinct_bytes_kind[TASK_PLANES] + b->distinct_bytes_kind[TASK_PLANES8] + out_planes;
+                b->info.phrase_bound_bytes = b->distinct_bytes_kind[7];
+                b->info.bound_bytes = b->distinct_bytes + out_legacy_dense + out_legacy_cand + out_fused + out_planes;
+        }
         if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                 uint64_t outb = 0; // 8 B x min(matches, K) per query
                 for (uint64_t c : b->h_query_counts)

@@ -68,6 +68,12 @@ class ResultGather:
         self._flat = {name: torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for name, t in self.blocks.items()}
         self.recv = {name: f.view((self.world,) + tuple(self.blocks[name].shape)) for name, f in self._flat.items()}
 
+    def rebind(self, blocks):
+        """Point the gather at another batch's result blocks of the same shapes (a caller that compiles a batch per step gathers from a
+        different batch every step; the receive buffers stay)."""
+        assert {n: (tuple(t.shape), t.dtype) for n, t in blocks.items()} == {n: (tuple(t.shape), t.dtype) for n, t in self.blocks.items()}
+        self.blocks = dict(blocks)
+
     def step(self):
         for name, t in self.blocks.items():
             self.dist.all_gather_into_tensor(self._flat[name], t)

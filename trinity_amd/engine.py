@@ -80,6 +80,12 @@ class TriBatchInfo(C.Structure):
         ("unsupported_queries", C.c_uint64),
         ("create_ms", C.c_float),
         ("create_plan_ms", C.c_float),
+        ("bound_bytes", C.c_uint64),
+        ("dense_bound_bytes", C.c_uint64),
+        ("cand_bound_bytes", C.c_uint64),
+        ("fused_bound_bytes", C.c_uint64),
+        ("planes_bound_bytes", C.c_uint64),
+        ("phrase_bound_bytes", C.c_uint64),
     ]
 
 
