@@ -133,6 +133,10 @@ typedef struct tri_batch_info {
          * runs (distinct lists of THOSE queries + their output; k_phrase: the distinct phrase terms' hit bytes).  SURVEY §8(d)'s per-query
          * count (algorithmic_bytes) charges a list once per query that names it, which no kernel that shares decodes reads */
         uint64_t bound_bytes, dense_bound_bytes, cand_bound_bytes, fused_bound_bytes, planes_bound_bytes, phrase_bound_bytes;
+        /* k_psets: the bitmap-window queries ALL of whose terms have a term plane (word-wise algebra over the planes, then the expansion into
+         * docIDs) — until ABI 6 part of k_and_dense's figures: its time, queries, SURVEY §8(d) bytes and batch-level bound */
+        float pset_ms, pad2_;
+        uint64_t pset_queries, pset_algorithmic_bytes, pset_bound_bytes;
 } tri_batch_info;
 
 const char *tri_last_error(void);

@@ -83,15 +83,19 @@ def check_scored(T, ix, ora, progs, k, want_fused=True):
 
 
 def test_cfg2_per_query_counts_and_hashes(T, google):
-    """256 queries of the bench's own workload shape: 64 head x head pairs (TASK_DENSE: bitmap windows, millions of matches each)
-    and 192 Zipf-drawn pairs of the cfg2 generator (mostly TASK_CAND: galloping / block-driven candidate tiles)."""
+    """272 queries of the bench's own workload shape: 64 head x head pairs (TASK_PSET: plane algebra, millions of matches each),
+    192 Zipf-drawn pairs of the cfg2 generator (mostly TASK_CAND: galloping / block-driven candidate tiles, plane probes) and 16
+    TASK_DENSE ones (bitmap windows with decoded rows)."""
     from trinity_amd import workloads as W
 
     seg, ora, ix = google
     rng = np.random.default_rng(11)
     heads = [tuple(int(x) for x in rng.choice(24, 2, replace=False)) for _ in range(64)]
     progs = W.and2(heads) + W.and2(T.gen_queries(V, 1337, 16384, 2)[:192])
-    total = check_docsets(T, ix, ora, progs, want_classes=("dense_queries", "cand_queries"))
+    # ... and 16 conjunctions of a head term with a union that holds a list too short for a plane: still bitmap windows with decoded rows (k_and_dense)
+    for a, b, c in zip(rng.choice(24, 16), rng.integers(2000, 20000, 16), rng.choice(24, 16)):
+        progs.append(np.array([T.tok(T.OP_TERM, int(a)), T.tok(T.OP_TERM, int(b)), T.tok(T.OP_OR, 2), T.tok(T.OP_TERM, int(c)), T.tok(T.OP_AND, 2)], dtype=np.uint32))
+    total = check_docsets(T, ix, ora, progs, want_classes=("pset_queries", "dense_queries", "cand_queries"))
     assert total > 5_000_000
 
 

@@ -54,13 +54,13 @@ def check_plan(p, nq):
     assert np.array_equal(tasks["out_off"][cand], q_off[cand] + tasks["begin"][cand].astype(np.uint64) * 8192)
     # schedule: a permutation, grouped by kernel in launch order, the per-kernel counts as reported
     assert np.array_equal(np.sort(sched), np.arange(s["n_tasks"], dtype=np.uint32))
-    counts = [s["n_dense"], s["n_cand"], s["n_fused"], s["n_fused16"], s["n_fusedgen"], s["n_planes"], s["n_planes8"]]
+    counts = [s["n_dense"], s["n_pset"], s["n_cand"], s["n_fused"], s["n_fused16"], s["n_fusedgen"], s["n_planes"], s["n_planes8"]]
     assert sum(counts) == s["n_tasks"]
     at = 0
     for kind, c in zip(HP.SCHED_ORDER, counts):
         assert np.all(tasks["kind"][sched[at : at + c]] == kind)
         at += c
-    assert s["dense_queries"] + s["cand_queries"] + s["fused_queries"] + s["planes_queries"] == s["n_plan"]
+    assert s["dense_queries"] + s["pset_queries"] + s["cand_queries"] + s["fused_queries"] + s["planes_queries"] == s["n_plan"]
     # planes: a term position that names a row names its own term's row
     if s["n_qplane"]:
         qt, qp, rows = p.qterms & 0x3FFFFFFF, p.qplane, p.plane_terms
@@ -95,8 +95,8 @@ def test_heavier_tasks_are_scheduled_first(world):
     # candidate-tile tasks of a 2-term AND: cost = tiles x (lead postings + 32 x min(other blocks, lead documents)) / tiles; the schedule's
     # order is by cost octave + 3 bits, so within a kernel the spans never grow by more than one bucket (12.5 %) from one task to the next
     span = (tasks["end"] - tasks["begin"]).astype(np.int64)
-    assert p.s["n_dense"] > 0 and p.s["n_cand"] > 0
-    dense = sched[: p.s["n_dense"]]
+    assert p.s["n_dense"] + p.s["n_pset"] > 0 and p.s["n_cand"] > 0
+    dense = sched[: p.s["n_dense"] + p.s["n_pset"]][: max(p.s["n_dense"], 1) if p.s["n_dense"] else p.s["n_pset"]]
     assert span[dense[0]] >= span[dense[-1]]
     p.close()
 
@@ -128,3 +128,20 @@ def test_plane_budget_caps_the_eligible_terms(world):
         rows.append(p.s["n_plane_terms"])
         p.close()
     assert rows[0] > rows[1] > rows[2] >= 1
+
+
+def test_plane_set_tasks_name_a_row_for_every_term(world):
+    D, V, segs, hix = world
+    parts, _ = W.build_parts("cfg2", D, V, 10, 42, 4000)
+    p = HP.HostPlan(hix[parts[0].codec], parts[0].programs, parts[0].flags, 0, threads=4, options={"dense_min_postings": 0, "plane_div": 64})
+    check_plan(p, 4000)
+    plan, tasks = p.plan, p.tasks
+    assert p.s["n_pset"] > 0 and p.s["n_dense"] > 0  # (both kinds of bitmap-window queries in one batch: some partner lists are too short for a plane)
+    kind_q = tasks["kind"][plan["first_task"]]
+    for sidx in np.nonzero(kind_q == HP.TASK_PSET)[0][:200]:
+        q = plan[sidx]
+        assert np.all(p.qplane[q["term_base"] : q["term_base"] + q["nterms"]] != 0xFFFFFFFF)
+    for sidx in np.nonzero(kind_q == HP.TASK_DENSE)[0][:200]:
+        q = plan[sidx]
+        assert np.any(p.qplane[q["term_base"] : q["term_base"] + q["nterms"]] == 0xFFFFFFFF)
+    p.close()

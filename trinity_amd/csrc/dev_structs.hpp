@@ -2,6 +2,11 @@
 // Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
 #pragma once
 #include <cstdint>
+#ifdef __HIPCC__
+#define TRI_HD __host__ __device__
+#else
+#define TRI_HD // (the host planner and its CPU tests compile these headers with g++)
+#endif
 
 struct DevTerm {
         uint32_t documents;
@@ -74,6 +79,30 @@ constexpr uint32_t TASK_FUSED_GEN = 4; // ... a general tree (truth-table predic
 constexpr uint32_t TASK_PLANES = 5;    // AccumulatedScoreScheme + top-K of a CNF query over BIT PLANES (k_planes.hpp): per slot a presence bit and an
                                        // "frequency is not 1" bit per document; windows of PL_W documents; tile_begin / tile_end count those windows
 constexpr uint32_t TASK_PLANES8 = 6;   // ... of a query with more than five slots (its own instantiation: more words held in registers)
+constexpr uint32_t TASK_PSET = 7;      // docID windows of a query ALL of whose terms have a term plane (k_psets.hpp): word-wise algebra over the planes, then
+                                       // the expansion; same windows, same private output regions as TASK_DENSE (a docset-materialising kind, not a one-pass one)
+constexpr uint32_t TASK_KINDS = 8;
+// A TASK_PSET task as k_psets reads it: ONE 64-byte record instead of the sched -> task -> query -> qterms / qplane chain of dependent loads
+// (four memory round trips before a two-window task's first plane word: measured, they were most of the kernel's fixed cost).  Written by
+// the planner next to the DevTask (which the host keeps reading for the result read-back); units[] is indexed like the schedule's TASK_PSET
+// section: sched[n_dense + i] names a task, pset_of_task gives its unit.
+constexpr uint32_t PSET_INLINE_TERMS = 4;
+constexpr uint32_t PSET_TASK_WINDOWS = 2; // docID windows per TASK_PSET task: the same for every query, so that the tasks of a window range line up —
+                                          // the schedule runs them window range by window range, and a range's plane words (88 head terms x 32 KB at cfg2)
+                                          // stay in the XCDs' L2 while every query that reads them is in flight
+struct DevPsetUnit {
+        uint64_t out_off;   // the task's private output region
+        uint32_t w_begin, w_end;
+        uint32_t tix;       // index into counts[]
+        uint32_t nterms;
+        uint32_t term_base; // qterms[] / qplane[] slice (read by the kernel only when nterms > PSET_INLINE_TERMS)
+        uint32_t pad;
+        uint32_t tt[PSET_INLINE_TERMS];  // qterms[] words (term | QT_GROUP | QT_NOT) ...
+        uint32_t row[PSET_INLINE_TERMS]; // ... and the terms' plane rows
+};
+static_assert(sizeof(DevPsetUnit) == 64, "one cache-line half per unit");
+// the one-pass kinds (decode -> match -> score -> top-K inside one kernel: k_fused / k_planes); the others materialise docID sets
+TRI_HD constexpr bool task_onepass(const uint32_t kind) { return kind >= TASK_FUSED && kind <= TASK_PLANES8; }
 
 // ---- term planes: per batch LAUNCH, every head term the batch's queries share is decoded ONCE (k_term_planes) into two bitmaps over the
 //      docID space — A: the document holds the term, B: its frequency there is not 1, C: nor 2 — which the matching kernels then read instead of

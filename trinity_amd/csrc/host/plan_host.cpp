@@ -88,15 +88,16 @@ void *tri_host_plan(void *hindex, const uint32_t *prog, uint64_t prog_len, const
 void tri_host_plan_free(void *p) { delete static_cast<HostPlan *>(p); }
 
 // sizes and offsets of the plan's sections, counters: out[0..] in the order below
-void tri_host_plan_summary(void *p, uint64_t *out /* [48] */, double *ms /* [4] */) {
+void tri_host_plan_summary(void *p, uint64_t *out /* [50] */, double *ms /* [4] */) {
         const BatchPlan &P = static_cast<HostPlan *>(p)->P;
         const uint64_t v[] = {P.block_bytes,       P.plan.size(),    P.qterms.size(),      P.tasks.size(),  P.fused.size(),       P.qplane.size(),    P.plane_terms.size(), P.sterms.size(),
                               P.sweights.size(),   P.phrases.size(), P.pterms.size(),      P.ptasks.size(), P.off_plan,           P.off_qterms,       P.off_tasks,          P.off_sched,
                               P.off_fused,         P.off_qplane,     P.off_plane_terms,    P.off_sterms,    P.off_sweights,       P.off_phrases,      P.off_pterms,         P.off_ptasks,
                               P.n_dense,           P.n_cand,         P.n_fused,            P.n_fused16,     P.n_fusedgen,         P.n_planes,         P.n_planes8,          P.plw,
                               P.sparse_cap,        P.out_capacity,   P.term_bytes,         P.term_bytes_dense, P.dense_queries,   P.cand_queries,     P.fused_queries,      P.planes_queries,
-                              P.unsupported_queries, P.rich_R,       sizeof(DevQuery),     sizeof(DevTask), sizeof(DevFused),     sizeof(DevPhrase),  P.cand_needed_term_bytes, P.plane_decoded_bytes};
-        static_assert(sizeof v / sizeof v[0] == 48, "summary layout");
+                              P.unsupported_queries, P.rich_R,       sizeof(DevQuery),     sizeof(DevTask), sizeof(DevFused),     sizeof(DevPhrase),  P.cand_needed_term_bytes, P.plane_decoded_bytes,
+                              P.n_pset,            P.pset_queries};
+        static_assert(sizeof v / sizeof v[0] == 50, "summary layout");
         memcpy(out, v, sizeof v);
         if (ms)
                 memcpy(ms, P.plan_ms, sizeof P.plan_ms);

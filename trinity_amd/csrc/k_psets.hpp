@@ -1,0 +1,198 @@
+// k_psets.hpp — docset algebra of the queries ALL of whose terms have a term plane (TASK_PSET): intersections / unions / exclusions of head
+// terms, the queries that materialise the batch's largest docID sets (cfg2: 1804 of 16384 queries write 395 M of the step's 395 M matches).
+// Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
+//
+// What it replaces in the reference: Conjuction::next_impl / DisjunctionAllPLI::next over Google::Decoder::next (docset_iterators.cpp:
+// 226-405; google_codec.cpp:777-819) driven by GenericDocsSetSpan::process / DocsSetSpanForDisjunctions::process (docset_spans.cpp:98-173,
+// 269-290) — per matching document two virtual calls and a decode step; here a docID window of 131072 documents is 4096 words of
+// AND / OR / AND-NOT over the planes k_term_planes decoded once for the whole batch, and the work is the EXPANSION of the survivors
+// into ascending docIDs.
+//
+// Until round 3 these queries ran in k_and_dense's plane-only branch: plane words -> LDS bitmap -> a workgroup-wide scan (five barriers
+// per window) -> every lane storing its own words' docIDs straight to HBM, 4 bytes at a time, a wave's store instruction spread over a
+// dozen cache lines.  The measurements (r03: 11.8 us per window and workgroup, 3.85 GB read + 1.59 GB written per launch) said the
+// window's fixed costs and the scattered stores were the time, not the algebra.  Here:
+//   * a wave owns 512 consecutive words (16384 documents) of the window — two 16-byte loads per lane and term —, keeps the survivors in
+//     registers, and only its COUNT crosses to the other waves: ONE barrier per window (double-buffered counts) instead of six;
+//   * the wave expands its survivors into a private LDS staging buffer (scattered 4-byte LDS writes are cheap) and copies the buffer out
+//     with coalesced stores: a store instruction covers 256 contiguous bytes;
+//   * a wave whose sub-window holds more survivors than the staging buffer (a union of head terms: one document in 16 or denser) walks
+//     its words one lane per BIT — ballot, rank by mbcnt, one coalesced store per 64 bits.
+// A task is a run of windows of one query with a private, bound-allocated output region (planner.hpp: the same layout as TASK_DENSE,
+// so k_score / k_rich / k_phrase / the result read-back see no difference).
+#pragma once
+
+constexpr int PSET_WG = 512;
+constexpr uint32_t PSET_WAVES = PSET_WG / 64;
+constexpr uint32_t PSET_WORDS = SPAN_WORDS / PSET_WAVES; // words of the window a wave owns
+constexpr uint32_t PSET_PER = PSET_WORDS / 64;           // ... and a lane: 8 (two 16-byte loads per term)
+constexpr uint32_t PSET_STAGE = 1024;                    // docIDs a wave stages per sub-window before it copies them out
+static_assert(PSET_PER == 8, "two 16-byte loads per lane and term");
+static_assert(PSET_STAGE >= PSET_WORDS, "the dense walk parks the wave's words in its staging buffer");
+
+struct PsetShared {
+        uint32_t stage[PSET_WAVES][PSET_STAGE];
+        uint32_t cnt[2][PSET_WAVES]; // per window parity: the waves' survivor counts
+        DevPsetUnit unit[2];         // the task being run and the next one (fetched while the current one runs)
+        uint32_t tick[2];            // ... and their tickets (>= ntasks: none)
+};
+
+#ifndef TRI_PSET_WAVES
+#define TRI_PSET_WAVES 8 // waves per SIMD the register budget is cut for (four 512-thread workgroups per CU: 4 x 33 KB of LDS)
+#endif
+// units[]: the TASK_PSET tasks (DevPsetUnit, dev_structs.hpp); order[]: the units in the order they are run (window range by window range);
+// ticket: the persistent workgroups' shared cursor into order[].
+__global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPsetUnit *__restrict__ units, const uint32_t *__restrict__ order, const uint32_t ntasks,
+                                                                   uint32_t *__restrict__ ticket, const uint32_t *__restrict__ qterms, const uint32_t *__restrict__ qplane,
+                                                                   uint32_t *__restrict__ out, uint32_t *__restrict__ counts, const uint32_t *__restrict__ masked,
+                                                                   const uint32_t *__restrict__ planes, const uint32_t plw) {
+        __shared__ PsetShared sh;
+        const uint32_t tid = threadIdx.x, lane = tid & 63u;
+        const uint32_t wave = uni(tid >> 6);
+        // ---- task pipeline: a task's ticket is drawn two tasks ahead and its unit record is fetched one task ahead, by wave 0, while the
+        //      workgroup runs the current task — the ticket's atomic and the record's two dependent loads (order[] -> units[]) are off the
+        //      critical path.  Lane l of wave 0 carries word l of the 16-word record.
+        uint32_t nt = 0xffffffffu; // (wave 0) the ticket after the one in sh.tick[]
+        if (wave == 0) {
+                const uint32_t t0 = uni(atomicAdd(ticket, 1u)) >> 6; // uniform draw: 64 lanes add 1 each (one +64 atomic), see k_and
+                uint32_t wd = 0;
+                if (t0 < ntasks)
+                        wd = ((const uint32_t *)(units + order[t0]))[lane & 15u];
+                ((uint32_t *)&sh.unit[0])[lane & 15u] = wd;
+                sh.tick[0] = t0;
+                nt = uni(atomicAdd(ticket, 1u)) >> 6;
+        }
+        for (uint32_t p = 0;; p ^= 1u) {
+                __syncthreads();
+                if (uni(sh.tick[p]) >= ntasks)
+                        break;
+                const DevPsetUnit &U = sh.unit[p];
+                const uint32_t nterms = uni(U.nterms), w_begin = uni(U.w_begin), w_end = uni(U.w_end), tix = uni(U.tix), term_base = uni(U.term_base);
+                uint32_t *const qout = out + (((uint64_t)uni((uint32_t)(U.out_off >> 32)) << 32) | uni((uint32_t)U.out_off));
+                // (wave 0) the next task's record and the ticket after it: issued now, used when this task is done
+                uint32_t nwd = 0, nnt = 0xffffffffu;
+                if (wave == 0) {
+                        if (nt < ntasks)
+                                nwd = ((const uint32_t *)(units + order[nt]))[lane & 15u];
+                        nnt = atomicAdd(ticket, 1u);
+                }
+                uint32_t produced = 0, par = 0;
+                for (uint32_t w = w_begin; w < w_end; ++w, par ^= 1u) {
+                        const uint32_t w0 = w * SPAN_BITS;
+                        const uint32_t word0 = (w0 >> 5) + tid * PSET_PER; // this lane's first word of the window
+                        // ---- the window's survivors, this lane's eight words: OR inside a group, AND across groups, AND-NOT for the excluded group
+                        uint32_t acc[PSET_PER], grp[PSET_PER];
+                        bool have_acc = false, cur_neg = false;
+#pragma unroll
+                        for (uint32_t j = 0; j < PSET_PER; ++j)
+                                acc[j] = grp[j] = 0;
+                        for (uint32_t k = 0; k <= nterms; ++k) {
+                                uint32_t tt = QT_GROUP, row = 0; // (k == nterms: the last group is folded in)
+                                if (k < nterms) {
+                                        if (nterms <= PSET_INLINE_TERMS) {
+                                                tt = uni(U.tt[k]);
+                                                row = uni(U.row[k]);
+                                        } else {
+                                                tt = uni(qterms[term_base + k]);
+                                                row = uni(qplane[term_base + k]);
+                                        }
+                                }
+                                if (k && (tt & QT_GROUP)) {
+#pragma unroll
+                                        for (uint32_t j = 0; j < PSET_PER; ++j) {
+                                                acc[j] = !have_acc ? grp[j] : cur_neg ? acc[j] & ~grp[j] : acc[j] & grp[j];
+                                                grp[j] = 0;
+                                        }
+                                        have_acc = true;
+                                }
+                                if (k == nterms)
+                                        break;
+                                if (tt & QT_GROUP)
+                                        cur_neg = tt & QT_NOT;
+                                const uint4 *pa = (const uint4 *)(planes + (size_t)row * PL_PLANES * plw + word0);
+#if defined(TRI_PSET_VARIANT) && TRI_PSET_VARIANT == 3 // (perf probe 3: no plane loads — words made up from the lane's address)
+                                const uint32_t hsh = (word0 * 2654435761u) ^ (k * 40503u);
+                                const uint4 v0 = make_uint4(hsh & (hsh >> 3) & (hsh >> 7), 0, (hsh >> 5) & (hsh << 2) & (hsh >> 11), 0), v1 = make_uint4(0, hsh & 0x10001u, 0, hsh & 0x200u);
+#else
+                                const uint4 v0 = pa[0], v1 = pa[1];
+#endif
+                                grp[0] |= v0.x, grp[1] |= v0.y, grp[2] |= v0.z, grp[3] |= v0.w;
+                                grp[4] |= v1.x, grp[5] |= v1.y, grp[6] |= v1.z, grp[7] |= v1.w;
+                        }
+                        if (masked) { // masked_documents_registry::test (docidupdates.h:90-119): updated / deleted elsewhere
+                                const uint4 *pm = (const uint4 *)(masked + word0);
+                                const uint4 m0 = pm[0], m1 = pm[1];
+                                acc[0] &= ~m0.x, acc[1] &= ~m0.y, acc[2] &= ~m0.z, acc[3] &= ~m0.w;
+                                acc[4] &= ~m1.x, acc[5] &= ~m1.y, acc[6] &= ~m1.z, acc[7] &= ~m1.w;
+                        }
+                        // ---- counts: lane -> wave (shuffles) -> workgroup (one LDS word per wave, one barrier)
+                        uint32_t c = 0;
+#pragma unroll
+                        for (uint32_t j = 0; j < PSET_PER; ++j)
+                                c += (uint32_t)__popc(acc[j]);
+                        uint32_t T;
+                        const uint32_t ex = wave_excl_scan(c, T);
+                        T = uni(T);
+                        sh.cnt[par][wave] = T; // (the same value from every lane of the wave)
+                        __syncthreads();
+                        uint32_t base = produced, tot = 0;
+#pragma unroll
+                        for (uint32_t wv = 0; wv < PSET_WAVES; ++wv) {
+                                const uint32_t x = uni(sh.cnt[par][wv]);
+                                base += wv < wave ? x : 0u;
+                                tot += x;
+                        }
+                        produced += tot;
+                        if (!T)
+                                continue; // (wave-uniform; the barrier above is the window's only one)
+#if defined(TRI_PSET_VARIANT) && TRI_PSET_VARIANT == 1 // (perf probe: counts only)
+                        continue;
+#endif
+                        uint32_t *const st = sh.stage[wave];
+                        if (T <= PSET_STAGE) {
+                                // ---- sparse: every lane writes its words' docIDs into the wave's staging buffer at its rank, then the wave copies the
+                                //      buffer out — 64 consecutive docIDs per store instruction
+                                uint32_t o = ex;
+#pragma unroll
+                                for (uint32_t j = 0; j < PSET_PER; ++j) {
+                                        uint32_t m = acc[j];
+                                        const uint32_t b0 = (word0 + j) << 5;
+                                        while (m) {
+                                                st[o++] = b0 + (uint32_t)__builtin_ctz(m);
+                                                m &= m - 1u;
+                                        }
+                                }
+                                __builtin_amdgcn_wave_barrier();
+#if !defined(TRI_PSET_VARIANT) || TRI_PSET_VARIANT != 2 // (perf probe 2: no copy-out)
+                                for (uint32_t i = lane; i < T; i += 64u)
+                                        qout[base + i] = st[i];
+#endif
+                                __builtin_amdgcn_wave_barrier(); // (the next window's staging writes stay behind these reads)
+                        } else {
+                                // ---- dense (a union of head terms): the wave's 512 words parked in LDS, then one lane per BIT, 64 bits a step:
+                                //      ballot, rank by mbcnt, one coalesced store
+#pragma unroll
+                                for (uint32_t j = 0; j < PSET_PER; ++j)
+                                        st[lane * PSET_PER + j] = acc[j];
+                                __builtin_amdgcn_wave_barrier();
+                                uint32_t o = base;
+                                const uint32_t wbase = (w0 >> 5) + wave * PSET_WORDS;
+                                for (uint32_t cidx = 0; cidx < PSET_WORDS / 2; ++cidx) {
+                                        const uint32_t wi = 2u * cidx + (lane >> 5);
+                                        const bool bit = (st[wi] >> (lane & 31u)) & 1u;
+                                        const uint64_t bm = __builtin_amdgcn_ballot_w64(bit);
+                                        if (bit)
+                                                qout[o + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = ((wbase + wi) << 5) + (lane & 31u);
+                                        o += (uint32_t)__popcll(bm);
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                        }
+                }
+                if (wave == 0) { // (uniform stores by the lanes of wave 0: no lane-divergent branch next to the loop's barriers)
+                        counts[tix] = produced;
+                        ((uint32_t *)&sh.unit[p ^ 1u])[lane & 15u] = nwd; // the next task, read by everybody behind the barrier at the loop's head
+                        sh.tick[p ^ 1u] = nt;
+                        nt = uni(nnt) >> 6;
+                }
+        }
+}

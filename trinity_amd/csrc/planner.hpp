@@ -80,7 +80,7 @@ struct BatchPlan {
         Span<DevQuery> plan;        // one per lowered query, in query order
         Span<uint32_t> qterms;      // CNF term lists (QT_GROUP / QT_NOT marks)
         Span<DevTask> tasks;        // a query's tasks are consecutive
-        Span<uint32_t> sched;       // task indices by kernel, heaviest first: [0, n_dense) TASK_DENSE, then TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8
+        Span<uint32_t> sched;       // task indices by kernel, heaviest first: [0, n_dense) TASK_DENSE, then TASK_PSET, TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8
         Span<DevFused> fused;       // slot maps of the one-pass queries (DevQuery::fused_idx)
         Span<uint32_t> qplane;      // parallel to qterms: the term's row in the batch's term planes, or PL_NONE (empty: no planes)
         Span<uint32_t> plane_terms; // row -> term
@@ -88,11 +88,14 @@ struct BatchPlan {
         Span<double> sweights;      // scored: their ScorerWeights
         Span<DevPhrase> phrases;
         Span<uint32_t> pterms, ptasks;
+        Span<DevPsetUnit> units;    // the TASK_PSET tasks as k_psets reads them (task order) ...
+        Span<uint32_t> pset_sched;  // ... and the order it runs them in: unit indices, docID window range by window range
+        size_t off_units = 0, off_pset_sched = 0;
         size_t off_plan = 0, off_qterms = 0, off_tasks = 0, off_sched = 0, off_fused = 0, off_qplane = 0, off_plane_terms = 0, off_sterms = 0, off_sweights = 0,
                off_phrases = 0, off_pterms = 0, off_ptasks = 0;
         std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: can never match)
         std::vector<int32_t> qstatus;        // per caller query: TRI_OK, or why the planner left it out of the batch (it then reports no matches)
-        uint32_t n_dense = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0, n_planes = 0, n_planes8 = 0;
+        uint32_t n_dense = 0, n_pset = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0, n_planes = 0, n_planes8 = 0;
         uint32_t plw = 0;        // words of one term plane
         uint32_t sparse_cap = 0; // k_planes: list entries a task's decoded slots can need
         uint32_t rich_R = 0;     // default mode: reportable terms of the widest query
@@ -100,11 +103,12 @@ struct BatchPlan {
         uint64_t out_capacity = 0;
         uint64_t term_bytes = 0, term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, term_bytes_phrase_hits = 0, plane_decoded_bytes = 0,
                  cand_needed_term_bytes = 0;
-        uint64_t dense_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, unsupported_queries = 0;
+        uint64_t dense_queries = 0, pset_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, unsupported_queries = 0;
+        uint64_t term_bytes_pset = 0;
         // option account_needed_bytes (a diagnostic of bench.py, untimed): the bytes of the DISTINCT lists the batch's queries name — each
         // list once, however many queries share it: what a batch that shares decodes has to read at least — over the whole batch (doc bytes,
-        // plus the hit bytes of the distinct phrase / reported terms) and per execution class (by task kind; [7]: the phrases' hit bytes)
-        uint64_t distinct_bytes = 0, distinct_bytes_kind[8] = {};
+        // plus the hit bytes of the distinct phrase / reported terms) and per execution class (by task kind; [TASK_KINDS]: the phrases' hit bytes)
+        uint64_t distinct_bytes = 0, distinct_bytes_kind[TASK_KINDS + 1] = {};
         std::string last_unsupported; // describes the last query that was left out
         double plan_ms[4] = {0, 0, 0, 0}; // lowering + classes, tasks, layout + fill, schedule + planes
 };
@@ -421,15 +425,16 @@ namespace trip {
                 std::vector<uint64_t> tcost;
                 std::vector<DevFused> fused;
                 std::vector<uint32_t> ptasks;
+                std::vector<DevPsetUnit> units; // tix: index into the fragment's tasks; row[]: filled once the planes are chosen
                 std::vector<QUse> quses;
                 std::vector<FUse> fuses;
                 std::vector<uint64_t> benefit; // per eligible term (by df rank): postings of decoding the batch's uses save
                 uint64_t off = 0;
                 uint32_t sparse_cap = 0;
                 uint64_t term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, cand_needed = 0;
-                uint64_t dense_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0;
+                uint64_t dense_queries = 0, pset_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, term_bytes_pset = 0;
                 // bases in the batch's arrays (settled between the passes)
-                size_t b_plan = 0, b_qterms = 0, b_sterms = 0, b_phrases = 0, b_pterms = 0, b_tasks = 0, b_fused = 0, b_ptasks = 0;
+                size_t b_plan = 0, b_qterms = 0, b_sterms = 0, b_phrases = 0, b_pterms = 0, b_tasks = 0, b_fused = 0, b_ptasks = 0, b_units = 0;
                 uint64_t b_off = 0;
                 int rc = TRI_OK;
                 std::string err;
@@ -1009,6 +1014,21 @@ namespace trip {
                                 f.fused.push_back(z);
                                 continue;
                         }
+                        // every term of a bitmap-window query has a plane (a use as a window operand repays the decode by itself: such a term is
+                        // always chosen): the query's windows are word-wise algebra over the planes — its own kernel (k_psets.hpp)
+                        bool pset = t.dense && (planes_opt & 2u);
+                        for (uint32_t k = 0; pset && k < t.q.nterms; ++k)
+                                pset = C.plane_ok(qt[k] & QT_TERM);
+                        // a single lead list too short for a plane against lists that all have one: candidate tiles, every candidate tested with one
+                        // bit probe per list (k_and) — the bitmap kernel would decode the lead into an LDS window bitmap and expand the window
+                        // workgroup-wide for a handful of matches per window (cfg2: 253 such queries took 0.57 ms there, a third of the dense class's time)
+                        if (t.dense && !pset && nlead == 1 && (planes_opt & 1u) && !C.plane_ok(qt[0] & QT_TERM) && t.q.nterms >= 2) {
+                                bool probes = true;
+                                for (uint32_t k = 1; probes && k < t.q.nterms; ++k)
+                                        probes = C.plane_ok(qt[k] & QT_TERM);
+                                if (probes)
+                                        t.dense = false;
+                        }
                         if (t.dense) {
                                 auto &seen = f.S.seen;
                                 seen.clear();
@@ -1016,14 +1036,14 @@ namespace trip {
                                         const uint32_t term = qt[k] & QT_TERM;
                                         if (std::find(seen.begin(), seen.end(), term) == seen.end()) {
                                                 seen.push_back(term);
-                                                f.term_bytes_dense += ix.docbytes[term];
+                                                (pset ? f.term_bytes_pset : f.term_bytes_dense) += ix.docbytes[term];
                                         }
                                         if ((planes_opt & 2u) && C.plane_ok(term)) {
                                                 f.benefit[ix.df_rank[term]] += ix.terms[term].documents;
                                                 f.quses.push_back({t.q.term_base + k, term});
                                         }
                                 }
-                                ++f.dense_queries;
+                                ++(pset ? f.pset_queries : f.dense_queries);
                         } else {
                                 ++f.cand_queries;
                                 for (uint32_t k = 1; k < t.q.nterms; ++k) { // (the lead list is decoded into the candidate tiles; the others are probed)
@@ -1039,7 +1059,7 @@ namespace trip {
                         if (t.dense) {
                                 const uint32_t nwin = last_doc / SPAN_BITS + 1;
                                 const uint64_t per_win = std::max<uint64_t>(1, t.sumdf / (ix.info.docs_cnt / SPAN_BITS + 1));
-                                const uint32_t win_per_task = (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / per_win);
+                                const uint32_t win_per_task = pset ? PSET_TASK_WINDOWS : (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / per_win);
                                 uint32_t ord = 0;
                                 uint64_t lead_blocks = 0;
                                 for (uint32_t k = 0; k < nlead; ++k)
@@ -1051,8 +1071,19 @@ namespace trip {
                                         uint64_t b1 = 0;
                                         for (uint32_t k = 0; k < nlead; ++k)
                                                 b1 += C.first_block_ge(ix.terms[qt[k] & QT_TERM], (uint64_t)wb * SPAN_BITS);
-                                        f.tcost.push_back(per_win * (we - wb));
-                                        f.tasks.push_back({slot, wb, we, TASK_DENSE, off + b1 * 32 + 32ull * ord * nlead});
+                                        f.tcost.push_back(pset ? wb : per_win * (we - wb)); // (TASK_PSET: the schedule goes by window range, not by cost)
+                                        if (pset) {
+                                                DevPsetUnit u{};
+                                                u.out_off = off + b1 * 32 + 32ull * ord * nlead;
+                                                u.w_begin = wb, u.w_end = we;
+                                                u.tix = (uint32_t)f.tasks.size();
+                                                u.nterms = t.q.nterms;
+                                                u.term_base = t.q.term_base;
+                                                for (uint32_t k = 0; k < t.q.nterms && k < PSET_INLINE_TERMS; ++k)
+                                                        u.tt[k] = qt[k];
+                                                f.units.push_back(u);
+                                        }
+                                        f.tasks.push_back({slot, wb, we, pset ? TASK_PSET : TASK_DENSE, off + b1 * 32 + 32ull * ord * nlead});
                                 }
                                 t.q.out_cap = (uint32_t)std::min<uint64_t>(0xffffffffull, lead_blocks * 32 + 32ull * (ord + 1) * nlead);
                         } else {
@@ -1200,17 +1231,19 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 return rc;
         P.plan_ms[1] = ms_since(t0);
         // ---- the fragments' places in the batch's arrays; sums
-        size_t n_plan = 0, n_qterms = 0, n_sterms = 0, n_phrases = 0, n_pterms = 0, n_tasks = 0, n_fused = 0, n_ptasks = 0;
+        size_t n_plan = 0, n_qterms = 0, n_sterms = 0, n_phrases = 0, n_pterms = 0, n_tasks = 0, n_fused = 0, n_ptasks = 0, n_units = 0;
         uint64_t off = 0;
         std::vector<uint64_t> benefit(C.n_ok, 0);
         for (Frag &f : frags) {
                 f.b_plan = n_plan, f.b_qterms = n_qterms, f.b_sterms = n_sterms, f.b_phrases = n_phrases, f.b_pterms = n_pterms, f.b_tasks = n_tasks, f.b_fused = n_fused,
-                f.b_ptasks = n_ptasks, f.b_off = off;
+                f.b_ptasks = n_ptasks, f.b_off = off, f.b_units = n_units;
+                n_units += f.units.size();
                 n_plan += f.tmp.size(), n_qterms += f.qterms.size(), n_sterms += f.sterms.size(), n_phrases += f.phrases.size(), n_pterms += f.pterms.size(),
                         n_tasks += f.tasks.size(), n_fused += f.fused.size(), n_ptasks += f.ptasks.size(), off += f.off;
                 P.term_bytes += f.term_bytes, P.term_bytes_phrase_hits += f.term_bytes_phrase_hits, P.term_bytes_dense += f.term_bytes_dense,
                         P.term_bytes_fused += f.term_bytes_fused, P.term_bytes_planes += f.term_bytes_planes, P.cand_needed_term_bytes += f.cand_needed;
                 P.dense_queries += f.dense_queries, P.cand_queries += f.cand_queries, P.fused_queries += f.fused_queries, P.planes_queries += f.planes_queries;
+                P.pset_queries += f.pset_queries, P.term_bytes_pset += f.term_bytes_pset;
                 P.rich_R = std::max(P.rich_R, f.rich_R);
                 P.rich_allow |= f.rich_allow;
                 P.sparse_cap = std::max(P.sparse_cap, f.sparse_cap);
@@ -1272,6 +1305,8 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         section(P.off_phrases, n_phrases, sizeof(DevPhrase));
         section(P.off_pterms, n_pterms, 4);
         section(P.off_ptasks, n_ptasks, 4);
+        section(P.off_units, n_units, sizeof(DevPsetUnit));
+        section(P.off_pset_sched, n_units, 4);
         P.block_bytes = bytes;
         P.block = alloc_block(bytes);
         if (!P.block)
@@ -1293,6 +1328,9 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         span(P.phrases, P.off_phrases, n_phrases);
         span(P.pterms, P.off_pterms, n_pterms);
         span(P.ptasks, P.off_ptasks, n_ptasks);
+        span(P.units, P.off_units, n_units);
+        span(P.pset_sched, P.off_pset_sched, n_units);
+        std::vector<uint32_t> unit_of_task(n_units ? n_tasks : 0);
         std::copy(chosen.begin(), chosen.end(), P.plane_terms.p);
         std::vector<uint64_t> tcost(n_tasks);
         // ---- every fragment writes its part of the arrays, rebased
@@ -1336,6 +1374,16 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         P.fused[f.b_fused + i] = f.fused[i];
                 for (const FUse &u : f.fuses)
                         P.fused[f.b_fused + u.fidx].plane[u.slot] = row_of_rank[ix.df_rank[u.term]];
+                for (size_t i = 0; i < f.units.size(); ++i) {
+                        DevPsetUnit u = f.units[i];
+                        u.out_off += f.b_off;
+                        u.tix += (uint32_t)f.b_tasks;
+                        u.term_base += (uint32_t)f.b_qterms;
+                        for (uint32_t k = 0; k < u.nterms && k < PSET_INLINE_TERMS; ++k)
+                                u.row[k] = row_of_rank[ix.df_rank[u.tt[k] & QT_TERM]];
+                        P.units[f.b_units + i] = u;
+                        unit_of_task[u.tix] = (uint32_t)(f.b_units + i);
+                }
                 if (n_qplane) {
                         std::fill(&P.qplane.p[f.b_qterms], &P.qplane.p[f.b_qterms] + f.qterms.size(), PL_NONE);
                         for (const QUse &u : f.quses)
@@ -1347,28 +1395,28 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         //      other keep their order in the batch — all a longest-first dispatch needs
         {
                 constexpr uint32_t NB = 64 * 8;
-                static const uint32_t kind_rank[7] = {1, 0, 2, 3, 4, 5, 6}; // TASK_CAND after TASK_DENSE, then the one-pass kinds as numbered
+                static const uint32_t kind_rank[TASK_KINDS] = {2, 0, 3, 4, 5, 6, 7, 1}; // launch order: TASK_DENSE, TASK_PSET, TASK_CAND, then the one-pass kinds as numbered
                 auto key = [&](size_t i) {
                         const uint64_t c = std::max<uint64_t>(1, tcost[i]);
                         const uint32_t lg = 63u - (uint32_t)__builtin_clzll(c);
                         const uint32_t frac = lg >= 3 ? (uint32_t)((c >> (lg - 3)) & 7u) : (uint32_t)((c << (3 - lg)) & 7u);
+                        if (P.tasks[i].kind == TASK_PSET) // by docID window range, ascending (tcost holds the first window)
+                                return kind_rank[TASK_PSET] * NB + (uint32_t)std::min<uint64_t>(tcost[i] / PSET_TASK_WINDOWS, NB - 1);
                         return kind_rank[P.tasks[i].kind] * NB + (NB - 1 - (lg * 8 + frac));
                 };
-                std::vector<uint32_t> cnt(7 * NB + 1, 0);
+                std::vector<uint32_t> cnt(TASK_KINDS * NB + 1, 0);
                 std::vector<uint32_t> keys(n_tasks);
                 for (size_t i = 0; i < n_tasks; ++i)
                         ++cnt[(keys[i] = key(i)) + 1];
-                P.n_dense = std::accumulate(cnt.begin() + 1, cnt.begin() + 1 + NB, 0u);
-                P.n_cand = std::accumulate(cnt.begin() + 1 + NB, cnt.begin() + 1 + 2 * NB, 0u);
-                P.n_fused = std::accumulate(cnt.begin() + 1 + 2 * NB, cnt.begin() + 1 + 3 * NB, 0u);
-                P.n_fused16 = std::accumulate(cnt.begin() + 1 + 3 * NB, cnt.begin() + 1 + 4 * NB, 0u);
-                P.n_fusedgen = std::accumulate(cnt.begin() + 1 + 4 * NB, cnt.begin() + 1 + 5 * NB, 0u);
-                P.n_planes = std::accumulate(cnt.begin() + 1 + 5 * NB, cnt.begin() + 1 + 6 * NB, 0u);
-                P.n_planes8 = std::accumulate(cnt.begin() + 1 + 6 * NB, cnt.begin() + 1 + 7 * NB, 0u);
+                uint32_t *const per_kernel[TASK_KINDS] = {&P.n_dense, &P.n_pset, &P.n_cand, &P.n_fused, &P.n_fused16, &P.n_fusedgen, &P.n_planes, &P.n_planes8};
+                for (uint32_t r = 0; r < TASK_KINDS; ++r)
+                        *per_kernel[r] = std::accumulate(cnt.begin() + 1 + r * NB, cnt.begin() + 1 + (r + 1) * NB, 0u);
                 for (size_t i = 1; i < cnt.size(); ++i)
                         cnt[i] += cnt[i - 1];
                 for (size_t i = 0; i < n_tasks; ++i)
                         P.sched[cnt[keys[i]]++] = (uint32_t)i;
+                for (size_t i = 0; i < n_units; ++i)
+                        P.pset_sched[i] = unit_of_task[P.sched[P.n_dense + i]];
         }
         P.sparse_cap = (P.sparse_cap + 63u) & ~63u;
         P.plan_ms[3] = ms_since(t0);
@@ -1386,7 +1434,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                         P.distinct_bytes_kind[kind] += ix.docbytes[term];
                                 seen[term] |= (uint8_t)(0x80u | (1u << kind));
                         };
-                        if (kind >= TASK_FUSED) {
+                        if (task_onepass(kind)) {
                                 const DevFused &z = P.fused[q.fused_idx];
                                 for (uint32_t k = 0; k < z.nslots; ++k)
                                         touch(z.term[k]);
@@ -1401,7 +1449,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                 if (!(seen_hits[term] & 1u))
                                         P.distinct_bytes += ix.hitbytes[term];
                                 if (phrase && !(seen_hits[term] & 2u))
-                                        P.distinct_bytes_kind[7] += ix.hitbytes[term];
+                                        P.distinct_bytes_kind[TASK_KINDS] += ix.hitbytes[term];
                                 seen_hits[term] |= (uint8_t)(1u | (phrase ? 2u : 0u));
                         };
                         for (uint32_t ph = 0; ph < q.nphrases; ++ph)

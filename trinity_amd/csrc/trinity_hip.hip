@@ -269,7 +269,7 @@ struct tri_batch : BatchPlan {
         DevFused *d_fused = nullptr;
         // HIP events on the engine stream: start, after k_term_planes, k_and_dense, k_and, k_fused, k_planes, k_phrase, end (owned by the
         // batch: two batches in flight on one device keep their own timings); ev_up: the plan has arrived (upload stream)
-        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_p = nullptr, ev1 = nullptr, ev_pl = nullptr, ev_k = nullptr, ev_up = nullptr;
+        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_s = nullptr, ev_b = nullptr, ev_c = nullptr, ev_p = nullptr, ev1 = nullptr, ev_pl = nullptr, ev_k = nullptr, ev_up = nullptr; // (ev_s: after k_psets)
         bool ran = false;
         uint32_t *d_qterms = nullptr;
         uint32_t *d_out = nullptr;
@@ -309,7 +309,7 @@ struct tri_batch : BatchPlan {
                         if (ev_up)
                                 hipEventSynchronize(ev_up); // (the pinned block goes back to the pool: its copy must have left)
                 }
-                for (hipEvent_t e : {ev0, ev_a, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k, ev_up})
+                for (hipEvent_t e : {ev0, ev_a, ev_s, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k, ev_up})
                         if (e) {
                                 if (dev)
                                         dev->events_idle.push_back(e);
@@ -343,6 +343,7 @@ struct tri_batch : BatchPlan {
 #include "k_score.hpp"
 #include "k_fused.hpp"
 #include "k_planes.hpp"
+#include "k_psets.hpp"
 #include "k_encode.hpp"
 #include "k_phrase.hpp"
 #include "k_rich.hpp"
@@ -711,7 +712,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->d_top_counts = scored ? (uint32_t *)(A + a_top_counts) : nullptr;
         b->d_top_docs = scored ? (uint32_t *)(A + a_top_docs) : nullptr;
         b->d_top_scores = scored ? (float *)(A + a_top_scores) : nullptr;
-        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k, &b->ev_up})
+        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_s, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k, &b->ev_up})
                 HIP_TRY(event_get(dev, e));
         if (b->block_bytes)
                 HIP_TRY(hipMemcpyAsync(A, b->block, b->block_bytes, hipMemcpyHostToDevice, dev->stream_up));
@@ -757,9 +758,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->info.unsupported_queries = b->unsupported_queries;
         b->info.plane_terms = b->plane_terms.size();
         b->info.plane_bytes = (uint64_t)b->plane_terms.size() * PL_PLANES * b->plw * 4;
-        b->info.launches = (b->n_dense != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (b->n_planes8 != 0) + (!b->plane_terms.empty()) +
+        b->info.launches = (b->n_dense != 0) + (b->n_pset != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (b->n_planes8 != 0) + (!b->plane_terms.empty()) +
                            (!b->ptasks.empty()) + (rich ? 2 : 0) +
-                           ((scored && b->n_dense + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
+                           ((scored && b->n_dense + b->n_pset + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
         b->info.create_plan_ms = (float)(b->plan_ms[0] + b->plan_ms[1] + b->plan_ms[2] + b->plan_ms[3]);
         b->info.create_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
         *out = b.release();
@@ -824,9 +825,17 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
+                if (b->n_pset) {
+                        // the queries all of whose terms have planes: word-wise algebra over the planes + expansion (k_psets.hpp)
+                        hipLaunchKernelGGL(k_psets, dim3(std::min<uint32_t>(b->n_pset, (uint32_t)dev->cus * (TRI_PSET_WAVES * 256 / PSET_WG))), dim3(PSET_WG), 0, dev->stream,
+                                           (const DevPsetUnit *)(b->d_arena + b->off_units), (const uint32_t *)(b->d_arena + b->off_pset_sched), b->n_pset, b->d_ticket + 20,
+                                           (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_planes, b->plw);
+                        HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipEventRecord(b->ev_s, dev->stream));
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
-                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense, b->d_qterms,
+                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense + b->n_pset, b->d_qterms,
                                            b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->d_planes, b->plw);
                 HIP_TRY(hipGetLastError());
                 if (overlap) {
@@ -840,7 +849,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         const uint32_t nf = variant == 0 ? b->n_fused : variant == 1 ? b->n_fused16 : b->n_fusedgen;
                         if (!nf)
                                 continue;
-                        const uint32_t *fsched = b->d_sched + b->n_dense + b->n_cand + (variant >= 1 ? b->n_fused : 0) + (variant == 2 ? b->n_fused16 : 0);
+                        const uint32_t *fsched = b->d_sched + b->n_dense + b->n_pset + b->n_cand + (variant >= 1 ? b->n_fused : 0) + (variant == 2 ? b->n_fused16 : 0);
                         const dim3 grid(std::min<uint32_t>(nf, (uint32_t)dev->cus * FUS_WGS_PER_CU));
 #define TRI_FUSED_ARGS                                                                                                                                 \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, fsched, \
@@ -874,7 +883,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         const uint32_t np = wide ? b->n_planes8 : b->n_planes;
                         if (!np)
                                 continue;
-                        const uint32_t *psched = b->d_sched + b->n_dense + b->n_cand + b->n_fused + b->n_fused16 + b->n_fusedgen + (wide ? b->n_planes : 0);
+                        const uint32_t *psched = b->d_sched + b->n_dense + b->n_pset + b->n_cand + b->n_fused + b->n_fused16 + b->n_fusedgen + (wide ? b->n_planes : 0);
                         const dim3 grid(std::min<uint32_t>(np, (uint32_t)dev->cus * PLK_WGS_PER_CU));
 #define TRI_PLANES_ARGS                                                                                                                                      \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, \
@@ -924,7 +933,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
-                        const uint32_t nlegacy = b->n_dense + b->n_cand; // the TASK_FUSED tasks have scored themselves
+                        const uint32_t nlegacy = b->n_dense + b->n_pset + b->n_cand; // (the sets k_and_dense / k_psets / k_and materialised; the one-pass tasks have scored themselves)
                         if (nlegacy)
                         TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(nlegacy, (uint32_t)dev->cus * SCORE_WGS_PER_CU)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, nlegacy,
@@ -941,6 +950,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
         else {
                 HIP_TRY(hipEventRecord(b->ev_pl, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
+                HIP_TRY(hipEventRecord(b->ev_s, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_b, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_k, dev->stream));
@@ -989,13 +999,15 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
                 b->info.last_run_ms = ms;
-        b->info.dense_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.rest_ms = b->info.term_planes_ms = b->info.planes_ms = 0;
+        b->info.dense_ms = b->info.pset_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.rest_ms = b->info.term_planes_ms = b->info.planes_ms = 0;
         if (!b->tasks.empty()) {
                 if (hipEventElapsedTime(&ms, b->ev0, b->ev_pl) == hipSuccess)
                         b->info.term_planes_ms = ms; // includes the 256-byte ticket memset that precedes it
                 if (hipEventElapsedTime(&ms, b->ev_pl, b->ev_a) == hipSuccess)
                         b->info.dense_ms = ms;
-                if (hipEventElapsedTime(&ms, b->ev_a, b->ev_b) == hipSuccess)
+                if (hipEventElapsedTime(&ms, b->ev_a, b->ev_s) == hipSuccess)
+                        b->info.pset_ms = ms;
+                if (hipEventElapsedTime(&ms, b->ev_s, b->ev_b) == hipSuccess)
                         b->info.cand_ms = ms;
                 if (hipEventElapsedTime(&ms, b->ev_b, b->ev_c) == hipSuccess)
                         b->info.fused_ms = ms;
@@ -1011,7 +1023,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 HIP_TRY(hipMemcpy(b->h_counts.data(), b->d_counts, b->tasks.size() * 4, hipMemcpyDeviceToHost));
         uint64_t m = 0;
         b->h_query_counts.assign(b->plan.size(), 0);
-        uint64_t m_dense = 0, m_fused = 0, out_fused = 0, out_planes = 0;
+        uint64_t m_dense = 0, m_pset = 0, m_fused = 0, out_fused = 0, out_planes = 0;
         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                 const DevQuery &q = b->plan[sidx];
                 for (uint32_t t = 0; t < q.ntasks; ++t)
@@ -1019,14 +1031,18 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 m += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_DENSE)
                         m_dense += b->h_query_counts[sidx];
-                if (q.ntasks && b->tasks[q.first_task].kind >= TASK_FUSED) {
+                if (q.ntasks && b->tasks[q.first_task].kind == TASK_PSET)
+                        m_pset += b->h_query_counts[sidx];
+                if (q.ntasks && task_onepass(b->tasks[q.first_task].kind)) {
                         m_fused += b->h_query_counts[sidx]; // (every one-pass kind, k_planes' included)
-                        (b->tasks[q.first_task].kind >= TASK_PLANES ? out_planes : out_fused) +=
+                        (b->tasks[q.first_task].kind >= TASK_PLANES ? out_planes : out_fused) += // (one-pass kinds only: TASK_PLANES / TASK_PLANES8 are the last two of them)
                                 q.out_cap ? 4 * b->h_query_counts[sidx] : 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk); // (docIDs of a DocumentsOnly general tree)
                 }
         }
         b->info.dense_algorithmic_bytes = b->term_bytes_dense + 4 * m_dense;
-        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_fused - b->term_bytes_planes - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_fused);
+        b->info.pset_algorithmic_bytes = b->term_bytes_pset + 4 * m_pset;
+        b->info.pset_queries = b->pset_queries;
+        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_pset - b->term_bytes_fused - b->term_bytes_planes - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_pset - m_fused);
         b->info.planes_algorithmic_bytes = b->term_bytes_planes + out_planes; // docbytes + 8 B x min(matches, K), per query — the lists
                                                                               // the batch's queries share are nevertheless decoded once per launch
         b->info.term_planes_decoded_bytes = b->plane_decoded_bytes;
@@ -1034,28 +1050,30 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         b->info.phrase_queries = 0;
         for (const DevQuery &q : b->plan)
                 b->info.phrase_queries += q.nphrases != 0;
-        b->info.cand_needed_bytes = b->cand_needed_term_bytes ? b->cand_needed_term_bytes + 4 * (m - m_dense - m_fused) : 0;
+        b->info.cand_needed_bytes = b->cand_needed_term_bytes ? b->cand_needed_term_bytes + 4 * (m - m_dense - m_pset - m_fused) : 0;
         b->info.fused_algorithmic_bytes = b->term_bytes_fused + out_fused; // docbytes + 8 B x min(matches, K)
         b->info.matches = m;
         if (b->distinct_bytes) { // (option account_needed_bytes: the batch-level bound — every distinct list once + every output once)
-                const uint64_t m_cand = m - m_dense - m_fused;
+                const uint64_t m_cand = m - m_dense - m_pset - m_fused;
                 const bool sc = b->flags & TRI_FLAG_ACCUMULATED_SCORE;
-                uint64_t out_legacy_dense = 4 * m_dense, out_legacy_cand = 4 * m_cand;
-                if (sc && b->topk) { // (queries matched by k_and_dense / k_and of a top-K batch deliver 8 B x min(matches, K))
-                        out_legacy_dense = out_legacy_cand = 0;
+                uint64_t out_legacy_dense = 4 * m_dense, out_legacy_pset = 4 * m_pset, out_legacy_cand = 4 * m_cand;
+                if (sc && b->topk) { // (queries matched by k_and_dense / k_psets / k_and of a top-K batch deliver 8 B x min(matches, K))
+                        out_legacy_dense = out_legacy_pset = out_legacy_cand = 0;
                         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                                 const DevQuery &q = b->plan[sidx];
-                                if (!q.ntasks || b->tasks[q.first_task].kind >= TASK_FUSED)
+                                if (!q.ntasks || task_onepass(b->tasks[q.first_task].kind))
                                         continue;
-                                (b->tasks[q.first_task].kind == TASK_DENSE ? out_legacy_dense : out_legacy_cand) += 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk);
+                                const uint32_t kd = b->tasks[q.first_task].kind;
+                                (kd == TASK_DENSE ? out_legacy_dense : kd == TASK_PSET ? out_legacy_pset : out_legacy_cand) += 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk);
                         }
                 }
+                b->info.pset_bound_bytes = b->distinct_bytes_kind[TASK_PSET] + out_legacy_pset;
                 b->info.dense_bound_bytes = b->distinct_bytes_kind[TASK_DENSE] + out_legacy_dense;
                 b->info.cand_bound_bytes = b->distinct_bytes_kind[TASK_CAND] + out_legacy_cand;
                 b->info.fused_bound_bytes = b->distinct_bytes_kind[TASK_FUSED] + b->distinct_bytes_kind[TASK_FUSED16] + b->distinct_bytes_kind[TASK_FUSED_GEN] + out_fused;
                 b->info.planes_bound_bytes = b->distinct_bytes_kind[TASK_PLANES] + b->distinct_bytes_kind[TASK_PLANES8] + out_planes;
-                b->info.phrase_bound_bytes = b->distinct_bytes_kind[7];
-                b->info.bound_bytes = b->distinct_bytes + out_legacy_dense + out_legacy_cand + out_fused + out_planes;
+                b->info.phrase_bound_bytes = b->distinct_bytes_kind[TASK_KINDS];
+                b->info.bound_bytes = b->distinct_bytes + out_legacy_dense + out_legacy_pset + out_legacy_cand + out_fused + out_planes;
         }
         if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                 uint64_t outb = 0; // 8 B x min(matches, K) per query
@@ -1236,7 +1254,7 @@ extern "C" int tri_batch_docset(tri_batch *b, size_t q, uint32_t *out, size_t ca
         *n = slot == UINT32_MAX ? 0 : b->h_query_counts[slot];
         if (!*n || !out)
                 return TRI_OK;
-        if (b->plan[slot].ntasks && !b->plan[slot].out_cap && b->tasks[b->plan[slot].first_task].kind >= TASK_FUSED)
+        if (b->plan[slot].ntasks && !b->plan[slot].out_cap && task_onepass(b->tasks[b->plan[slot].first_task].kind))
                 return fail(TRI_ERR_INVALID, "query %zu ran through the one-pass scored kernel: an AccumulatedScore top-K batch keeps top-K lists and match counts, not docID sets (use topk == 0 or DocumentsOnly)", q);
         if (cap < *n)
                 return fail(TRI_ERR_INVALID, "docset needs %zu slots, %zu given", *n, cap);

@@ -86,6 +86,11 @@ class TriBatchInfo(C.Structure):
         ("fused_bound_bytes", C.c_uint64),
         ("planes_bound_bytes", C.c_uint64),
         ("phrase_bound_bytes", C.c_uint64),
+        ("pset_ms", C.c_float),
+        ("pad2_", C.c_float),
+        ("pset_queries", C.c_uint64),
+        ("pset_algorithmic_bytes", C.c_uint64),
+        ("pset_bound_bytes", C.c_uint64),
     ]
 
 
