@@ -1,5 +1,5 @@
 // k_psets.hpp — docset algebra of the queries ALL of whose terms have a term plane (TASK_PSET): intersections / unions / exclusions of head
-// terms, the queries that materialise the batch's largest docID sets (cfg2: 1804 of 16384 queries write 395 M of the step's 395 M matches).
+// terms, the queries that materialise the batch's largest docID sets (cfg2: 1551 of 16384 queries write 380 M of the step's 395 M matches).
 // Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
 //
 // What it replaces in the reference: Conjuction::next_impl / DisjunctionAllPLI::next over Google::Decoder::next (docset_iterators.cpp:
@@ -10,22 +10,37 @@
 //
 // Until round 3 these queries ran in k_and_dense's plane-only branch: plane words -> LDS bitmap -> a workgroup-wide scan (five barriers
 // per window) -> every lane storing its own words' docIDs straight to HBM, 4 bytes at a time, a wave's store instruction spread over a
-// dozen cache lines.  The measurements (r03: 11.8 us per window and workgroup, 3.85 GB read + 1.59 GB written per launch) said the
-// window's fixed costs and the scattered stores were the time, not the algebra.  Here:
-//   * a wave owns 512 consecutive words (16384 documents) of the window — two 16-byte loads per lane and term —, keeps the survivors in
-//     registers, and only its COUNT crosses to the other waves: ONE barrier per window (double-buffered counts) instead of six;
+// dozen cache lines (r03: 11.8 us per window and workgroup).  Here:
+//   * a wave owns 512 consecutive words (16384 documents) of a step — two 16-byte loads per lane and term —, keeps the survivors in
+//     registers, and only its COUNT crosses to the other waves: ONE barrier per step (double-buffered counts) instead of six;
 //   * the wave expands its survivors into a private LDS staging buffer (scattered 4-byte LDS writes are cheap) and copies the buffer out
 //     with coalesced stores: a store instruction covers 256 contiguous bytes;
 //   * a wave whose sub-window holds more survivors than the staging buffer (a union of head terms: one document in 16 or denser) walks
-//     its words one lane per BIT — ballot, rank by mbcnt, one coalesced store per 64 bits.
-// A task is a run of windows of one query with a private, bound-allocated output region (planner.hpp: the same layout as TASK_DENSE,
-// so k_score / k_rich / k_phrase / the result read-back see no difference).
+//     its words one lane per BIT — ballot, rank by mbcnt, one coalesced store per 64 bits;
+//   * a task is ONE 64-byte record (DevPsetUnit) fetched a task ahead by wave 0 together with the ticket after it, instead of the
+//     sched -> task -> query -> qterms / qplane chain of dependent loads; tasks are two windows of one query, and the schedule runs them
+//     window range by window range, so that a range's plane words are in the XCDs' L2 while every query that reads them is in flight.
+// A task has a private, bound-allocated output region (planner.hpp: the same layout as TASK_DENSE, so k_score / k_rich / k_phrase / the
+// result read-back see no difference).
+// Measured (cfg2, 1551 queries, 119 K windows, 380 M docIDs): 1.05 ms.  Probe builds said where it goes: without the
+// expansion 0.59 ms, without the plane loads 0.58 ms (half the matches), without the copy-out 0.92 ms; the phase clocks: 39 % at the first
+// use of the plane words, 19 % at the barrier, 16 % expanding, 13 % counting.  About 400 wave instructions per sub-window, 250 of them the
+// expansion's count-trailing-zeros loops (eight words per lane, a loop's trips = the wave's densest word: 20 % of the lane-iterations
+// extract a bit) — 0.6 ms of issue slots by themselves.  Tried on the way and not kept (each correct, each measured): the next window's
+// words requested before the expansion (1.03 - 1.13 ms: 16 more registers, spills at 8 waves per SIMD, nothing gained at 6); 256- and
+// 128-thread workgroups (1.09 / 1.30 ms); no workgroup synchronisation at all — every wave an item on its own, the counts published in
+// global cells and read back by the later sub-windows of the task (1.37 ms: two more memory round trips on every wave's critical path).
 #pragma once
 
-constexpr int PSET_WG = 512;
+#ifndef TRI_PSET_WG
+#define TRI_PSET_WG 512
+#endif
+constexpr int PSET_WG = TRI_PSET_WG;
 constexpr uint32_t PSET_WAVES = PSET_WG / 64;
-constexpr uint32_t PSET_WORDS = SPAN_WORDS / PSET_WAVES; // words of the window a wave owns
+constexpr uint32_t PSET_WORDS = 512;                     // words of a step a wave owns (16384 documents) ...
 constexpr uint32_t PSET_PER = PSET_WORDS / 64;           // ... and a lane: 8 (two 16-byte loads per term)
+constexpr uint32_t PSET_STEP_WORDS = PSET_WAVES * PSET_WORDS; // words the workgroup takes per step (between two barriers)
+static_assert(SPAN_WORDS % PSET_STEP_WORDS == 0, "a docID window is a whole number of steps");
 constexpr uint32_t PSET_STAGE = 1024;                    // docIDs a wave stages per sub-window before it copies them out
 static_assert(PSET_PER == 8, "two 16-byte loads per lane and term");
 static_assert(PSET_STAGE >= PSET_WORDS, "the dense walk parks the wave's words in its staging buffer");
@@ -38,7 +53,7 @@ struct PsetShared {
 };
 
 #ifndef TRI_PSET_WAVES
-#define TRI_PSET_WAVES 8 // waves per SIMD the register budget is cut for (four 512-thread workgroups per CU: 4 x 33 KB of LDS)
+#define TRI_PSET_WAVES 8 // waves per SIMD the register budget is cut for (512-thread workgroups: four per CU, 33 KB of LDS each)
 #endif
 // units[]: the TASK_PSET tasks (DevPsetUnit, dev_structs.hpp); order[]: the units in the order they are run (window range by window range);
 // ticket: the persistent workgroups' shared cursor into order[].
@@ -77,9 +92,8 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                         nnt = atomicAdd(ticket, 1u);
                 }
                 uint32_t produced = 0, par = 0;
-                for (uint32_t w = w_begin; w < w_end; ++w, par ^= 1u) {
-                        const uint32_t w0 = w * SPAN_BITS;
-                        const uint32_t word0 = (w0 >> 5) + tid * PSET_PER; // this lane's first word of the window
+                for (uint32_t sw = w_begin * SPAN_WORDS; sw < w_end * SPAN_WORDS; sw += PSET_STEP_WORDS, par ^= 1u) {
+                        const uint32_t word0 = sw + tid * PSET_PER; // this lane's first word of the step
                         // ---- the window's survivors, this lane's eight words: OR inside a group, AND across groups, AND-NOT for the excluded group
                         uint32_t acc[PSET_PER], grp[PSET_PER];
                         bool have_acc = false, cur_neg = false;
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                                         st[lane * PSET_PER + j] = acc[j];
                                 __builtin_amdgcn_wave_barrier();
                                 uint32_t o = base;
-                                const uint32_t wbase = (w0 >> 5) + wave * PSET_WORDS;
+                                const uint32_t wbase = sw + wave * PSET_WORDS;
                                 for (uint32_t cidx = 0; cidx < PSET_WORDS / 2; ++cidx) {
                                         const uint32_t wi = 2u * cidx + (lane >> 5);
                                         const bool bit = (st[wi] >> (lane & 31u)) & 1u;
