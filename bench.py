@@ -45,14 +45,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-KERNELS = ("k_and_dense", "k_psets", "k_and", "k_fused", "k_planes", "k_phrase")  # the kernels with per-launch HIP-event brackets and their own byte counts
-KMS = {"k_and_dense": "dense_ms", "k_psets": "pset_ms", "k_and": "cand_ms", "k_fused": "fused_ms", "k_planes": "planes_ms", "k_phrase": "phrase_ms"}
-KALG = {"k_and_dense": "dense_algorithmic_bytes", "k_psets": "pset_algorithmic_bytes", "k_and": "cand_algorithmic_bytes", "k_fused": "fused_algorithmic_bytes", "k_planes": "planes_algorithmic_bytes",
+KERNELS = ("k_and_dense", "k_psets", "k_probe", "k_and", "k_fused", "k_planes", "k_phrase")  # the kernels with per-launch HIP-event brackets and their own byte counts
+KMS = {"k_and_dense": "dense_ms", "k_psets": "pset_ms", "k_probe": "probe_ms", "k_and": "cand_ms", "k_fused": "fused_ms", "k_planes": "planes_ms", "k_phrase": "phrase_ms"}
+KALG = {"k_and_dense": "dense_algorithmic_bytes", "k_psets": "pset_algorithmic_bytes", "k_probe": "probe_algorithmic_bytes", "k_and": "cand_algorithmic_bytes", "k_fused": "fused_algorithmic_bytes", "k_planes": "planes_algorithmic_bytes",
         "k_phrase": "phrase_algorithmic_bytes"}  # fmt: skip
-KBOUND = {"k_and_dense": "dense_bound_bytes", "k_psets": "pset_bound_bytes", "k_and": "cand_bound_bytes", "k_fused": "fused_bound_bytes", "k_planes": "planes_bound_bytes", "k_phrase": "phrase_bound_bytes"}
-KQ = {"k_and_dense": "dense_queries", "k_psets": "pset_queries", "k_and": "cand_queries", "k_fused": "fused_queries", "k_planes": "planes_queries", "k_phrase": "phrase_queries"}
-MS_KEYS = ("last_run_ms", "dense_ms", "pset_ms", "cand_ms", "fused_ms", "phrase_ms", "rest_ms", "planes_ms", "term_planes_ms", "create_ms", "create_plan_ms")
-TOT_KEYS = ("matches", "algorithmic_bytes", "dense_algorithmic_bytes", "cand_algorithmic_bytes", "fused_algorithmic_bytes", "dense_queries", "pset_queries", "pset_algorithmic_bytes", "pset_bound_bytes", "cand_queries", "fused_queries",
+KBOUND = {"k_and_dense": "dense_bound_bytes", "k_psets": "pset_bound_bytes", "k_probe": "probe_bound_bytes", "k_and": "cand_bound_bytes", "k_fused": "fused_bound_bytes", "k_planes": "planes_bound_bytes", "k_phrase": "phrase_bound_bytes"}
+KQ = {"k_and_dense": "dense_queries", "k_psets": "pset_queries", "k_probe": "probe_queries", "k_and": "cand_queries", "k_fused": "fused_queries", "k_planes": "planes_queries", "k_phrase": "phrase_queries"}
+MS_KEYS = ("last_run_ms", "dense_ms", "pset_ms", "probe_ms", "cand_ms", "fused_ms", "phrase_ms", "rest_ms", "planes_ms", "term_planes_ms", "create_ms", "create_plan_ms")
+TOT_KEYS = ("matches", "algorithmic_bytes", "dense_algorithmic_bytes", "cand_algorithmic_bytes", "fused_algorithmic_bytes", "dense_queries", "pset_queries", "pset_algorithmic_bytes", "pset_bound_bytes", "probe_queries", "probe_algorithmic_bytes", "probe_bound_bytes", "cand_queries", "fused_queries",
             "cand_needed_bytes", "phrase_algorithmic_bytes", "phrase_queries", "planes_algorithmic_bytes", "planes_queries", "plane_terms", "plane_bytes", "term_planes_decoded_bytes",
             "bound_bytes", "dense_bound_bytes", "cand_bound_bytes", "fused_bound_bytes", "planes_bound_bytes", "phrase_bound_bytes")  # fmt: skip
 

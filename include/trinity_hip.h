@@ -135,8 +135,12 @@ typedef struct tri_batch_info {
         uint64_t bound_bytes, dense_bound_bytes, cand_bound_bytes, fused_bound_bytes, planes_bound_bytes, phrase_bound_bytes;
         /* k_psets: the bitmap-window queries ALL of whose terms have a term plane (word-wise algebra over the planes, then the expansion into
          * docIDs) — until ABI 6 part of k_and_dense's figures: its time, queries, SURVEY §8(d) bytes and batch-level bound */
-        float pset_ms, pad2_;
+        float pset_ms;
+        /* k_probe: one short lead list against lists that all have a term plane (a wave decodes the lead's blocks into registers and tests every
+         * document with one bit probe per list) — until ABI 6 part of k_and's figures */
+        float probe_ms;
         uint64_t pset_queries, pset_algorithmic_bytes, pset_bound_bytes;
+        uint64_t probe_queries, probe_algorithmic_bytes, probe_bound_bytes;
 } tri_batch_info;
 
 const char *tri_last_error(void);
@@ -167,6 +171,10 @@ void *tri_dev_stream(tri_dev *);
  *                         decode of its list
  *   "account_needed_bytes" 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query; default 0)
  *   "plane_max_bytes"     scratch budget of a batch's term planes (default 8 GiB): the terms eligible for a plane are the longest lists that fit
+ *   "probe_max_blocks"    > 0: a conjunction of ONE lead list of at most this many blocks with lists that all have planes runs in k_probe (a wave per
+ *                         task, csrc/k_probe.hpp) instead of candidate tiles (default 0: off — measured slower at cfg2, planner.hpp)
+ *   "overlap"             1: the candidate-tile kernel runs on a second stream beside the window kernels (default 0; measured: no gain, the persistent
+ *                         grids do not interleave)
  *   "plan_threads"        host threads tri_batch_create plans large batches with (default 0: up to 16, by the host's cores; 1: the calling thread
  *                         only).  The threads belong to the handle, are pinned to distinct CPUs next to the creating thread's, and keep polling for
  *                         about 3 ms after a batch before they sleep (csrc/host_pool.hpp says why); read when the first large batch is created

@@ -47,7 +47,7 @@ def options(dev, **kw):
 ALL_PLANES = 1 << 30  # plane_div: every term of a batch gets a plane
 # term planes (k_planes.hpp): the planner's choice (head terms of at least docs / 64 documents), a plane for every term, no term
 # planes at all (k_planes decodes every slot into LDS planes; queries of more than six slots stay with k_fused), everything off
-PLANE_SETS = ({}, {"plane_div": ALL_PLANES}, {"plane_div": 0}, {"planes": 0})
+PLANE_SETS = ({}, {"plane_div": ALL_PLANES}, {"plane_div": 0}, {"planes": 0}, {"plane_div": ALL_PLANES, "probe_max_blocks": 1 << 20})  # (the last: every single-lead conjunction through k_probe)
 
 
 class World:
@@ -191,11 +191,13 @@ def test_candidate_tiles_probe_term_planes(request, world):
     texts += [f"t{a} t{b} NOT t{c}" for a, b, c in T.gen_queries(w.V, 23, 40, 3).tolist()] + [f"t{a} (t{b} OR t{c} OR t0)" for a, b, c in T.gen_queries(w.V, 24, 40, 3).tolist()]
     progs = [O.parse_query(t) for t in texts]
     wants = [w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)[0] for p in progs]
-    for ps in ({"planes": 1, "plane_div": ALL_PLANES}, {"planes": 1}, {"planes": 0}):
+    for ps in ({"planes": 1, "plane_div": ALL_PLANES}, {"planes": 1}, {"planes": 0}, {"planes": 1, "plane_div": ALL_PLANES, "probe_max_blocks": 1 << 20},
+               {"planes": 1, "plane_div": ALL_PLANES, "probe_max_blocks": 3}):  # (the last two: k_probe — a wave per task — for every lead, for leads of up to 3 blocks)
         with options(w.dev, **ps):
             sets, hashes, info = run_docs_only(w, progs)
         if ps.get("plane_div"):
             assert info["plane_terms"] > 0
+        assert (info["probe_queries"] > 0) == bool(ps.get("probe_max_blocks")) or w.dev.get_option("planes") == 0 or w.dev.get_option("plane_div") == 0, (ps, info["probe_queries"])
         for t, got, want, h in zip(texts, sets, wants, hashes):
             assert np.array_equal(got, want), (ps, t, len(got), len(want))
             assert int(h) == O.fnv1a_docs(want)

@@ -54,13 +54,27 @@ def check_plan(p, nq):
     assert np.array_equal(tasks["out_off"][cand], q_off[cand] + tasks["begin"][cand].astype(np.uint64) * 8192)
     # schedule: a permutation, grouped by kernel in launch order, the per-kernel counts as reported
     assert np.array_equal(np.sort(sched), np.arange(s["n_tasks"], dtype=np.uint32))
-    counts = [s["n_dense"], s["n_pset"], s["n_cand"], s["n_fused"], s["n_fused16"], s["n_fusedgen"], s["n_planes"], s["n_planes8"]]
+    counts = [s["n_dense"], s["n_pset"], s["n_probe"], s["n_cand"], s["n_fused"], s["n_fused16"], s["n_fusedgen"], s["n_planes"], s["n_planes8"]]
     assert sum(counts) == s["n_tasks"]
     at = 0
     for kind, c in zip(HP.SCHED_ORDER, counts):
         assert np.all(tasks["kind"][sched[at : at + c]] == kind)
         at += c
-    assert s["dense_queries"] + s["pset_queries"] + s["cand_queries"] + s["fused_queries"] + s["planes_queries"] == s["n_plan"]
+    assert s["dense_queries"] + s["pset_queries"] + s["probe_queries"] + s["cand_queries"] + s["fused_queries"] + s["planes_queries"] == s["n_plan"]
+    # unit records (k_psets / k_probe): one per task of those kinds in run order, the task's own geometry, every probed term's row inline
+    if s["n_pset"] + s["n_probe"]:
+        units, us = p.units, p.unit_sched
+        assert s["sizeof_unit"] == HP.DEV_UNIT.itemsize and len(set(us.tolist())) == len(us)
+        ran = units[us]
+        assert np.array_equal(ran["tix"], sched[s["n_dense"] : s["n_dense"] + len(us)])
+        tk = tasks[ran["tix"]]
+        assert np.array_equal(tk["begin"], ran["begin"]) and np.array_equal(tk["end"], ran["end"]) and np.array_equal(tk["out_off"], ran["out_off"])
+        assert np.all(tk["kind"][: s["n_pset"]] == HP.TASK_PSET) and np.all(tk["kind"][s["n_pset"] :] == HP.TASK_PROBE)
+        assert np.all(np.diff(ran["begin"][: s["n_pset"]].astype(np.int64)) >= 0)  # plane-set tasks run window range by window range
+        for u in ran[:: max(1, len(ran) // 300)]:
+            k0 = 1 if tasks[u["tix"]]["kind"] == HP.TASK_PROBE else 0
+            for k in range(k0, min(int(u["nterms"]), 4)):
+                assert p.plane_terms[u["row"][k]] == (u["tt"][k] & 0x3FFFFFFF) == (p.qterms[u["term_base"] + k] & 0x3FFFFFFF)
     # planes: a term position that names a row names its own term's row
     if s["n_qplane"]:
         qt, qp, rows = p.qterms & 0x3FFFFFFF, p.qplane, p.plane_terms

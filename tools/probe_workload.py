@@ -63,5 +63,5 @@ if hasattr(L, "tri_debug_prof"):
         print(f"  workgroups {w[0]}: mean end {(w[2] / w[0] - t0) / 100:.1f} us, last end {(w[3] - t0) / 100:.1f} us after the first start")
     if any(c):  # event counters (k_planes: 16 candidate steps, 17 frequency lookups, 18 prunes, 19 sub-windows, 20 table-lookup steps, 23 sweeps cut short by a full queue / buffer), over the 3 runs
         print("  counters " + " ".join(f"c{16 + i}={x}" for i, x in enumerate(c) if x))
-print("  " + " ".join(f"{k}={inf[k]:.3f}" for k in ("term_planes_ms", "dense_ms", "pset_ms", "cand_ms", "fused_ms", "planes_ms", "phrase_ms", "rest_ms")), f"fused_q={inf['fused_queries']} planes_q={inf['planes_queries']} cand_q={inf['cand_queries']} plane_terms={inf['plane_terms']}")
+print("  " + " ".join(f"{k}={inf[k]:.3f}" for k in ("term_planes_ms", "dense_ms", "pset_ms", "probe_ms", "cand_ms", "fused_ms", "planes_ms", "phrase_ms", "rest_ms")), f"fused_q={inf['fused_queries']} planes_q={inf['planes_queries']} cand_q={inf['cand_queries']} plane_terms={inf['plane_terms']}")
 print(f"{desc}: {len(progs)} queries {best:.2f} ms  matches {inf['matches']:.3e}  alg {inf['algorithmic_bytes'] / best / 1e6:.1f} GB/s  {NQ / best * 1e3:.0f} q/s")

@@ -81,7 +81,9 @@ constexpr uint32_t TASK_PLANES = 5;    // AccumulatedScoreScheme + top-K of a CN
 constexpr uint32_t TASK_PLANES8 = 6;   // ... of a query with more than five slots (its own instantiation: more words held in registers)
 constexpr uint32_t TASK_PSET = 7;      // docID windows of a query ALL of whose terms have a term plane (k_psets.hpp): word-wise algebra over the planes, then
                                        // the expansion; same windows, same private output regions as TASK_DENSE (a docset-materialising kind, not a one-pass one)
-constexpr uint32_t TASK_KINDS = 8;
+constexpr uint32_t TASK_PROBE = 8;     // candidate tiles of ONE lead list tested against lists that all have a term plane (k_probe.hpp): a wave decodes 64 lead
+                                       // blocks into registers and probes the planes — same tiles, same private output regions as TASK_CAND
+constexpr uint32_t TASK_KINDS = 9;
 // A TASK_PSET task as k_psets reads it: ONE 64-byte record instead of the sched -> task -> query -> qterms / qplane chain of dependent loads
 // (four memory round trips before a two-window task's first plane word: measured, they were most of the kernel's fixed cost).  Written by
 // the planner next to the DevTask (which the host keeps reading for the result read-back); units[] is indexed like the schedule's TASK_PSET
@@ -90,13 +92,13 @@ constexpr uint32_t PSET_INLINE_TERMS = 4;
 constexpr uint32_t PSET_TASK_WINDOWS = 2; // docID windows per TASK_PSET task: the same for every query, so that the tasks of a window range line up —
                                           // the schedule runs them window range by window range, and a range's plane words (88 head terms x 32 KB at cfg2)
                                           // stay in the XCDs' L2 while every query that reads them is in flight
-struct DevPsetUnit {
+struct DevPsetUnit { // (also the record of a TASK_PROBE task: w_begin / w_end are its lead tiles, tt[0] its lead term)
         uint64_t out_off;   // the task's private output region
         uint32_t w_begin, w_end;
         uint32_t tix;       // index into counts[]
         uint32_t nterms;
         uint32_t term_base; // qterms[] / qplane[] slice (read by the kernel only when nterms > PSET_INLINE_TERMS)
-        uint32_t pad;
+        uint32_t first;     // 1: the first task of its query (planner bookkeeping)
         uint32_t tt[PSET_INLINE_TERMS];  // qterms[] words (term | QT_GROUP | QT_NOT) ...
         uint32_t row[PSET_INLINE_TERMS]; // ... and the terms' plane rows
 };

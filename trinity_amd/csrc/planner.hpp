@@ -30,12 +30,16 @@ struct tri_options {
         uint64_t account_needed_bytes = 0;        // 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query)
         uint64_t fused_halfwords = 1;             // 16-bit window words for queries of <= 5 distinct terms (windows twice as long); 0: always 32-bit
         uint64_t overlap_dense_wgs = 0, overlap_cand_wgs = 0; // both non-zero: the two matching kernels side by side on two streams
+        uint64_t overlap = 0;                                 // 1: the candidate-tile kernel (k_and) on a second stream beside the window kernels (k_and_dense, k_psets, k_probe), full grids
         uint64_t planes = 7;     // term planes (k_planes.hpp), a bit set: 1 k_and probes them, 2 k_and_dense ORs them in, 4 top-K CNF queries run in k_planes; 0: off
         uint64_t planes_split = 0; // a k_planes query is cut into this many docID ranges (tasks) that share its threshold; 0: 2 or 3 by the batch's size; >= 65536: by postings like the other one-pass tasks.  cfg3's unions: 0 10.9 ms, 2 8.0, 3 8.5, 4 9.2 (a task has fixed costs)
         uint64_t plane_div = 128; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list);
                                  // measured, step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the planes' build grows with it)
         uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs 3 bitmaps over the docID space and one decode per run)
         uint64_t plan_threads = 0;             // host threads tri_batch_create plans with; 0: up to 16, one per 512 queries
+        uint64_t probe_max_blocks = 0;         // > 0: a lead list of at most this many blocks against lists that all have planes runs in k_probe (a wave per task) instead of
+                                               // k_and's candidate tiles.  Off by default — measured at cfg2 (step ms / k_probe / k_and): 0: 2.14 / - / 0.78; 64: 2.25 / 0.15 / 0.75;
+                                               // 256: 2.26 / 0.22 / 0.70; 1024: 2.35 / 0.41 / 0.59; all: 2.55 / 0.82 / 0.41 — k_and's time is its tail, not its task count
 };
 
 struct PlanEnv {
@@ -80,7 +84,7 @@ struct BatchPlan {
         Span<DevQuery> plan;        // one per lowered query, in query order
         Span<uint32_t> qterms;      // CNF term lists (QT_GROUP / QT_NOT marks)
         Span<DevTask> tasks;        // a query's tasks are consecutive
-        Span<uint32_t> sched;       // task indices by kernel, heaviest first: [0, n_dense) TASK_DENSE, then TASK_PSET, TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8
+        Span<uint32_t> sched;       // task indices by kernel, heaviest first: [0, n_dense) TASK_DENSE, then TASK_PSET, TASK_PROBE, TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8
         Span<DevFused> fused;       // slot maps of the one-pass queries (DevQuery::fused_idx)
         Span<uint32_t> qplane;      // parallel to qterms: the term's row in the batch's term planes, or PL_NONE (empty: no planes)
         Span<uint32_t> plane_terms; // row -> term
@@ -88,14 +92,15 @@ struct BatchPlan {
         Span<double> sweights;      // scored: their ScorerWeights
         Span<DevPhrase> phrases;
         Span<uint32_t> pterms, ptasks;
-        Span<DevPsetUnit> units;    // the TASK_PSET tasks as k_psets reads them (task order) ...
-        Span<uint32_t> pset_sched;  // ... and the order it runs them in: unit indices, docID window range by window range
+        Span<DevPsetUnit> units;    // the TASK_PSET and TASK_PROBE tasks as k_psets / k_probe read them (task order) ...
+        Span<uint32_t> pset_sched;  // ... and the order they are run in, as unit indices: [0, n_pset) TASK_PSET, docID window range by window range; then
+                                    // the n_probe TASK_PROBE ones, heaviest first
         size_t off_units = 0, off_pset_sched = 0;
         size_t off_plan = 0, off_qterms = 0, off_tasks = 0, off_sched = 0, off_fused = 0, off_qplane = 0, off_plane_terms = 0, off_sterms = 0, off_sweights = 0,
                off_phrases = 0, off_pterms = 0, off_ptasks = 0;
         std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: can never match)
         std::vector<int32_t> qstatus;        // per caller query: TRI_OK, or why the planner left it out of the batch (it then reports no matches)
-        uint32_t n_dense = 0, n_pset = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0, n_planes = 0, n_planes8 = 0;
+        uint32_t n_dense = 0, n_pset = 0, n_probe = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0, n_planes = 0, n_planes8 = 0;
         uint32_t plw = 0;        // words of one term plane
         uint32_t sparse_cap = 0; // k_planes: list entries a task's decoded slots can need
         uint32_t rich_R = 0;     // default mode: reportable terms of the widest query
@@ -103,8 +108,8 @@ struct BatchPlan {
         uint64_t out_capacity = 0;
         uint64_t term_bytes = 0, term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, term_bytes_phrase_hits = 0, plane_decoded_bytes = 0,
                  cand_needed_term_bytes = 0;
-        uint64_t dense_queries = 0, pset_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, unsupported_queries = 0;
-        uint64_t term_bytes_pset = 0;
+        uint64_t dense_queries = 0, pset_queries = 0, probe_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, unsupported_queries = 0;
+        uint64_t term_bytes_pset = 0, term_bytes_probe = 0;
         // option account_needed_bytes (a diagnostic of bench.py, untimed): the bytes of the DISTINCT lists the batch's queries name — each
         // list once, however many queries share it: what a batch that shares decodes has to read at least — over the whole batch (doc bytes,
         // plus the hit bytes of the distinct phrase / reported terms) and per execution class (by task kind; [TASK_KINDS]: the phrases' hit bytes)
@@ -432,7 +437,8 @@ namespace trip {
                 uint64_t off = 0;
                 uint32_t sparse_cap = 0;
                 uint64_t term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, cand_needed = 0;
-                uint64_t dense_queries = 0, pset_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, term_bytes_pset = 0;
+                uint64_t dense_queries = 0, pset_queries = 0, probe_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, term_bytes_pset = 0, term_bytes_probe = 0;
+                uint64_t probe_demoted = 0, probe_demoted_bytes = 0; // (fill pass) queries whose probes found no plane: candidate tiles after all
                 // bases in the batch's arrays (settled between the passes)
                 size_t b_plan = 0, b_qterms = 0, b_sterms = 0, b_phrases = 0, b_pterms = 0, b_tasks = 0, b_fused = 0, b_ptasks = 0, b_units = 0;
                 uint64_t b_off = 0;
@@ -1016,6 +1022,7 @@ namespace trip {
                         }
                         // every term of a bitmap-window query has a plane (a use as a window operand repays the decode by itself: such a term is
                         // always chosen): the query's windows are word-wise algebra over the planes — its own kernel (k_psets.hpp)
+                        bool probe = false;
                         bool pset = t.dense && (planes_opt & 2u);
                         for (uint32_t k = 0; pset && k < t.q.nterms; ++k)
                                 pset = C.plane_ok(qt[k] & QT_TERM);
@@ -1045,7 +1052,21 @@ namespace trip {
                                 }
                                 ++(pset ? f.pset_queries : f.dense_queries);
                         } else {
-                                ++f.cand_queries;
+                                // one lead list against lists that are all long enough for a plane: should the batch's uses repay every one of those
+                                // planes (settled once the whole batch is known: the fill pass), the task runs in k_probe, else as candidate tiles
+                                probe = nlead == 1 && t.q.nterms >= 2 && t.q.nphrases == 0 && (planes_opt & 1u) && lead.nblocks <= opt.probe_max_blocks;
+                                for (uint32_t k = 1; probe && k < t.q.nterms; ++k)
+                                        probe = C.plane_ok(qt[k] & QT_TERM);
+                                ++(probe ? f.probe_queries : f.cand_queries);
+                                if (probe) {
+                                        auto &seen = f.S.seen;
+                                        seen.clear();
+                                        for (uint32_t k = 0; k < t.q.nterms; ++k)
+                                                if (std::find(seen.begin(), seen.end(), qt[k] & QT_TERM) == seen.end()) {
+                                                        seen.push_back(qt[k] & QT_TERM);
+                                                        f.term_bytes_probe += ix.docbytes[qt[k] & QT_TERM];
+                                                }
+                                }
                                 for (uint32_t k = 1; k < t.q.nterms; ++k) { // (the lead list is decoded into the candidate tiles; the others are probed)
                                         const uint32_t term = qt[k] & QT_TERM;
                                         if ((planes_opt & 1u) && C.plane_ok(term)) {
@@ -1093,7 +1114,19 @@ namespace trip {
                                 for (uint32_t tb = 0; tb < ntiles; tb += tiles_per_task) {
                                         const uint32_t te = std::min(ntiles, tb + tiles_per_task);
                                         f.tcost.push_back(per_tile * (te - tb));
-                                        f.tasks.push_back({slot, tb, te, TASK_CAND, off + (uint64_t)tb * TILE_CANDS});
+                                        if (probe) {
+                                                DevPsetUnit u{};
+                                                u.out_off = off + (uint64_t)tb * TILE_CANDS;
+                                                u.w_begin = tb, u.w_end = te;
+                                                u.tix = (uint32_t)f.tasks.size();
+                                                u.nterms = t.q.nterms;
+                                                u.term_base = t.q.term_base;
+                                                u.first = tb == 0;
+                                                for (uint32_t k = 0; k < t.q.nterms && k < PSET_INLINE_TERMS; ++k)
+                                                        u.tt[k] = qt[k];
+                                                f.units.push_back(u);
+                                        }
+                                        f.tasks.push_back({slot, tb, te, probe ? TASK_PROBE : TASK_CAND, off + (uint64_t)tb * TILE_CANDS});
                                 }
                                 t.q.out_cap = lead.documents; // |A ∩ …| <= df of the lead
                                 if (opt.account_needed_bytes) {
@@ -1244,6 +1277,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         P.term_bytes_fused += f.term_bytes_fused, P.term_bytes_planes += f.term_bytes_planes, P.cand_needed_term_bytes += f.cand_needed;
                 P.dense_queries += f.dense_queries, P.cand_queries += f.cand_queries, P.fused_queries += f.fused_queries, P.planes_queries += f.planes_queries;
                 P.pset_queries += f.pset_queries, P.term_bytes_pset += f.term_bytes_pset;
+                P.probe_queries += f.probe_queries, P.term_bytes_probe += f.term_bytes_probe;
                 P.rich_R = std::max(P.rich_R, f.rich_R);
                 P.rich_allow |= f.rich_allow;
                 P.sparse_cap = std::max(P.sparse_cap, f.sparse_cap);
@@ -1379,8 +1413,29 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         u.out_off += f.b_off;
                         u.tix += (uint32_t)f.b_tasks;
                         u.term_base += (uint32_t)f.b_qterms;
-                        for (uint32_t k = 0; k < u.nterms && k < PSET_INLINE_TERMS; ++k)
-                                u.row[k] = row_of_rank[ix.df_rank[u.tt[k] & QT_TERM]];
+                        const bool is_probe = f.tasks[f.units[i].tix].kind == TASK_PROBE;
+                        bool rows = true;
+                        for (uint32_t k = is_probe ? 1u : 0u; k < u.nterms; ++k) { // (a TASK_PROBE unit's term 0 is the lead: decoded, never probed)
+                                const uint32_t term = (k < PSET_INLINE_TERMS ? u.tt[k] : f.qterms[f.units[i].term_base + k]) & QT_TERM;
+                                const uint32_t row = row_of_rank[ix.df_rank[term]];
+                                rows &= row != PL_NONE;
+                                if (k < PSET_INLINE_TERMS)
+                                        u.row[k] = row;
+                        }
+                        if (is_probe && !rows) { // a probed list did not get its plane (the batch's uses do not repay its decode): candidate tiles after all
+                                P.tasks[u.tix].kind = TASK_CAND;
+                                if (u.first) {
+                                        ++f.probe_demoted;
+                                        const uint32_t *qt = &f.qterms[f.units[i].term_base];
+                                        auto &seen = f.S.seen;
+                                        seen.clear();
+                                        for (uint32_t k = 0; k < u.nterms; ++k)
+                                                if (std::find(seen.begin(), seen.end(), qt[k] & QT_TERM) == seen.end()) {
+                                                        seen.push_back(qt[k] & QT_TERM);
+                                                        f.probe_demoted_bytes += ix.docbytes[qt[k] & QT_TERM];
+                                                }
+                                }
+                        }
                         P.units[f.b_units + i] = u;
                         unit_of_task[u.tix] = (uint32_t)(f.b_units + i);
                 }
@@ -1390,12 +1445,16 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                 P.qplane[f.b_qterms + u.qpos] = row_of_rank[ix.df_rank[u.term]];
                 }
         });
+        for (const Frag &f : frags) { // (what the fill pass sent back to the candidate tiles)
+                P.probe_queries -= f.probe_demoted, P.cand_queries += f.probe_demoted;
+                P.term_bytes_probe -= f.probe_demoted_bytes;
+        }
         P.plan_ms[2] = ms_since(t0);
         // ---- the schedule: per kernel, heaviest tasks first.  A counting sort by (kernel, cost octave + 3 bits): tasks within 12 % of each
         //      other keep their order in the batch — all a longest-first dispatch needs
         {
                 constexpr uint32_t NB = 64 * 8;
-                static const uint32_t kind_rank[TASK_KINDS] = {2, 0, 3, 4, 5, 6, 7, 1}; // launch order: TASK_DENSE, TASK_PSET, TASK_CAND, then the one-pass kinds as numbered
+                static const uint32_t kind_rank[TASK_KINDS] = {3, 0, 4, 5, 6, 7, 8, 1, 2}; // launch order: TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, then the one-pass kinds as numbered
                 auto key = [&](size_t i) {
                         const uint64_t c = std::max<uint64_t>(1, tcost[i]);
                         const uint32_t lg = 63u - (uint32_t)__builtin_clzll(c);
@@ -1408,14 +1467,14 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 std::vector<uint32_t> keys(n_tasks);
                 for (size_t i = 0; i < n_tasks; ++i)
                         ++cnt[(keys[i] = key(i)) + 1];
-                uint32_t *const per_kernel[TASK_KINDS] = {&P.n_dense, &P.n_pset, &P.n_cand, &P.n_fused, &P.n_fused16, &P.n_fusedgen, &P.n_planes, &P.n_planes8};
+                uint32_t *const per_kernel[TASK_KINDS] = {&P.n_dense, &P.n_pset, &P.n_probe, &P.n_cand, &P.n_fused, &P.n_fused16, &P.n_fusedgen, &P.n_planes, &P.n_planes8};
                 for (uint32_t r = 0; r < TASK_KINDS; ++r)
                         *per_kernel[r] = std::accumulate(cnt.begin() + 1 + r * NB, cnt.begin() + 1 + (r + 1) * NB, 0u);
                 for (size_t i = 1; i < cnt.size(); ++i)
                         cnt[i] += cnt[i - 1];
                 for (size_t i = 0; i < n_tasks; ++i)
                         P.sched[cnt[keys[i]]++] = (uint32_t)i;
-                for (size_t i = 0; i < n_units; ++i)
+                for (size_t i = 0; i < (size_t)P.n_pset + P.n_probe; ++i) // (units of demoted tasks are simply never run)
                         P.pset_sched[i] = unit_of_task[P.sched[P.n_dense + i]];
         }
         P.sparse_cap = (P.sparse_cap + 63u) & ~63u;

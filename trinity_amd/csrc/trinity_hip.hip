@@ -269,7 +269,7 @@ struct tri_batch : BatchPlan {
         DevFused *d_fused = nullptr;
         // HIP events on the engine stream: start, after k_term_planes, k_and_dense, k_and, k_fused, k_planes, k_phrase, end (owned by the
         // batch: two batches in flight on one device keep their own timings); ev_up: the plan has arrived (upload stream)
-        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_s = nullptr, ev_b = nullptr, ev_c = nullptr, ev_p = nullptr, ev1 = nullptr, ev_pl = nullptr, ev_k = nullptr, ev_up = nullptr; // (ev_s: after k_psets)
+        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_s = nullptr, ev_r = nullptr, ev_b = nullptr, ev_c = nullptr, ev_p = nullptr, ev1 = nullptr, ev_pl = nullptr, ev_k = nullptr, ev_up = nullptr; // (ev_s: after k_psets; ev_r: after k_probe)
         bool ran = false;
         uint32_t *d_qterms = nullptr;
         uint32_t *d_out = nullptr;
@@ -309,7 +309,7 @@ struct tri_batch : BatchPlan {
                         if (ev_up)
                                 hipEventSynchronize(ev_up); // (the pinned block goes back to the pool: its copy must have left)
                 }
-                for (hipEvent_t e : {ev0, ev_a, ev_s, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k, ev_up})
+                for (hipEvent_t e : {ev0, ev_a, ev_s, ev_r, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k, ev_up})
                         if (e) {
                                 if (dev)
                                         dev->events_idle.push_back(e);
@@ -344,6 +344,7 @@ struct tri_batch : BatchPlan {
 #include "k_fused.hpp"
 #include "k_planes.hpp"
 #include "k_psets.hpp"
+#include "k_probe.hpp"
 #include "k_encode.hpp"
 #include "k_phrase.hpp"
 #include "k_rich.hpp"
@@ -405,11 +406,13 @@ namespace {
                              {"account_needed_bytes", &tri_options::account_needed_bytes},
                              {"overlap_dense_wgs", &tri_options::overlap_dense_wgs},
                              {"overlap_cand_wgs", &tri_options::overlap_cand_wgs},
+                             {"overlap", &tri_options::overlap},
                              {"planes", &tri_options::planes},
                              {"plane_div", &tri_options::plane_div},
                              {"planes_split", &tri_options::planes_split},
                              {"plane_max_bytes", &tri_options::plane_max_bytes},
-                             {"plan_threads", &tri_options::plan_threads}};
+                             {"plan_threads", &tri_options::plan_threads},
+                             {"probe_max_blocks", &tri_options::probe_max_blocks}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -712,7 +715,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->d_top_counts = scored ? (uint32_t *)(A + a_top_counts) : nullptr;
         b->d_top_docs = scored ? (uint32_t *)(A + a_top_docs) : nullptr;
         b->d_top_scores = scored ? (float *)(A + a_top_scores) : nullptr;
-        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_s, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k, &b->ev_up})
+        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_s, &b->ev_r, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k, &b->ev_up})
                 HIP_TRY(event_get(dev, e));
         if (b->block_bytes)
                 HIP_TRY(hipMemcpyAsync(A, b->block, b->block_bytes, hipMemcpyHostToDevice, dev->stream_up));
@@ -758,9 +761,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->info.unsupported_queries = b->unsupported_queries;
         b->info.plane_terms = b->plane_terms.size();
         b->info.plane_bytes = (uint64_t)b->plane_terms.size() * PL_PLANES * b->plw * 4;
-        b->info.launches = (b->n_dense != 0) + (b->n_pset != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (b->n_planes8 != 0) + (!b->plane_terms.empty()) +
+        b->info.launches = (b->n_dense != 0) + (b->n_pset != 0) + (b->n_probe != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (b->n_planes8 != 0) + (!b->plane_terms.empty()) +
                            (!b->ptasks.empty()) + (rich ? 2 : 0) +
-                           ((scored && b->n_dense + b->n_pset + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
+                           ((scored && b->n_dense + b->n_pset + b->n_probe + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
         b->info.create_plan_ms = (float)(b->plan_ms[0] + b->plan_ms[1] + b->plan_ms[2] + b->plan_ms[3]);
         b->info.create_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
         *out = b.release();
@@ -803,7 +806,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         overlap = true;
                         dense_wgs = (uint32_t)dev->opt.overlap_dense_wgs;
                         cand_wgs = (uint32_t)dev->opt.overlap_cand_wgs;
-                }
+                } else if (dev->opt.overlap && b->n_cand && b->n_dense + b->n_pset + b->n_probe)
+                        overlap = true; // (full grids: the second kernel's workgroups take the slots the first one's tail leaves)
                 if (!b->plane_terms.empty()) {
                         // the head terms the batch shares, decoded once for this launch (every word of every plane is rewritten)
                         const dim3 grid(b->plw / PL_WORDS, (uint32_t)b->plane_terms.size());
@@ -833,9 +837,18 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_s, dev->stream));
+                if (b->n_probe) {
+                        // one short lead list against lists that all have planes: a wave per task, the lead's documents probed from registers (k_probe.hpp)
+                        TRI_LAUNCH(k_probe, b->ix->codec, dim3(std::min<uint32_t>((b->n_probe + PROBE_WG / 64 - 1) / (PROBE_WG / 64), (uint32_t)dev->cus * (TRI_PROBE_WAVES * 256 / PROBE_WG))),
+                                   dim3(PROBE_WG), dev->stream, match_bytes, b->ix->d_blk_last, match_off, b->ix->d_terms, (const DevPsetUnit *)(b->d_arena + b->off_units),
+                                   (const uint32_t *)(b->d_arena + b->off_pset_sched) + b->n_pset, b->n_probe, b->d_ticket + 22, (const uint32_t *)b->d_qterms,
+                                   (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_planes, b->plw);
+                        HIP_TRY(hipGetLastError());
+                }
+                HIP_TRY(hipEventRecord(b->ev_r, dev->stream));
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
-                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense + b->n_pset, b->d_qterms,
+                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense + b->n_pset + b->n_probe, b->d_qterms,
                                            b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->d_planes, b->plw);
                 HIP_TRY(hipGetLastError());
                 if (overlap) {
@@ -849,7 +862,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         const uint32_t nf = variant == 0 ? b->n_fused : variant == 1 ? b->n_fused16 : b->n_fusedgen;
                         if (!nf)
                                 continue;
-                        const uint32_t *fsched = b->d_sched + b->n_dense + b->n_pset + b->n_cand + (variant >= 1 ? b->n_fused : 0) + (variant == 2 ? b->n_fused16 : 0);
+                        const uint32_t *fsched = b->d_sched + b->n_dense + b->n_pset + b->n_probe + b->n_cand + (variant >= 1 ? b->n_fused : 0) + (variant == 2 ? b->n_fused16 : 0);
                         const dim3 grid(std::min<uint32_t>(nf, (uint32_t)dev->cus * FUS_WGS_PER_CU));
 #define TRI_FUSED_ARGS                                                                                                                                 \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, fsched, \
@@ -883,7 +896,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         const uint32_t np = wide ? b->n_planes8 : b->n_planes;
                         if (!np)
                                 continue;
-                        const uint32_t *psched = b->d_sched + b->n_dense + b->n_pset + b->n_cand + b->n_fused + b->n_fused16 + b->n_fusedgen + (wide ? b->n_planes : 0);
+                        const uint32_t *psched = b->d_sched + b->n_dense + b->n_pset + b->n_probe + b->n_cand + b->n_fused + b->n_fused16 + b->n_fusedgen + (wide ? b->n_planes : 0);
                         const dim3 grid(std::min<uint32_t>(np, (uint32_t)dev->cus * PLK_WGS_PER_CU));
 #define TRI_PLANES_ARGS                                                                                                                                      \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, \
@@ -933,7 +946,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
-                        const uint32_t nlegacy = b->n_dense + b->n_pset + b->n_cand; // (the sets k_and_dense / k_psets / k_and materialised; the one-pass tasks have scored themselves)
+                        const uint32_t nlegacy = b->n_dense + b->n_pset + b->n_probe + b->n_cand; // (the sets k_and_dense / k_psets / k_probe / k_and materialised; the one-pass tasks have scored themselves)
                         if (nlegacy)
                         TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(nlegacy, (uint32_t)dev->cus * SCORE_WGS_PER_CU)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, nlegacy,
@@ -951,6 +964,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipEventRecord(b->ev_pl, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_s, dev->stream));
+                HIP_TRY(hipEventRecord(b->ev_r, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_b, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_k, dev->stream));
@@ -999,7 +1013,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
                 b->info.last_run_ms = ms;
-        b->info.dense_ms = b->info.pset_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.rest_ms = b->info.term_planes_ms = b->info.planes_ms = 0;
+        b->info.dense_ms = b->info.pset_ms = b->info.probe_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.rest_ms = b->info.term_planes_ms = b->info.planes_ms = 0;
         if (!b->tasks.empty()) {
                 if (hipEventElapsedTime(&ms, b->ev0, b->ev_pl) == hipSuccess)
                         b->info.term_planes_ms = ms; // includes the 256-byte ticket memset that precedes it
@@ -1007,7 +1021,9 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                         b->info.dense_ms = ms;
                 if (hipEventElapsedTime(&ms, b->ev_a, b->ev_s) == hipSuccess)
                         b->info.pset_ms = ms;
-                if (hipEventElapsedTime(&ms, b->ev_s, b->ev_b) == hipSuccess)
+                if (hipEventElapsedTime(&ms, b->ev_s, b->ev_r) == hipSuccess)
+                        b->info.probe_ms = ms;
+                if (hipEventElapsedTime(&ms, b->ev_r, b->ev_b) == hipSuccess)
                         b->info.cand_ms = ms;
                 if (hipEventElapsedTime(&ms, b->ev_b, b->ev_c) == hipSuccess)
                         b->info.fused_ms = ms;
@@ -1023,7 +1039,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 HIP_TRY(hipMemcpy(b->h_counts.data(), b->d_counts, b->tasks.size() * 4, hipMemcpyDeviceToHost));
         uint64_t m = 0;
         b->h_query_counts.assign(b->plan.size(), 0);
-        uint64_t m_dense = 0, m_pset = 0, m_fused = 0, out_fused = 0, out_planes = 0;
+        uint64_t m_dense = 0, m_pset = 0, m_probe = 0, m_fused = 0, out_fused = 0, out_planes = 0;
         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                 const DevQuery &q = b->plan[sidx];
                 for (uint32_t t = 0; t < q.ntasks; ++t)
@@ -1033,6 +1049,8 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                         m_dense += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_PSET)
                         m_pset += b->h_query_counts[sidx];
+                if (q.ntasks && b->tasks[q.first_task].kind == TASK_PROBE)
+                        m_probe += b->h_query_counts[sidx];
                 if (q.ntasks && task_onepass(b->tasks[q.first_task].kind)) {
                         m_fused += b->h_query_counts[sidx]; // (every one-pass kind, k_planes' included)
                         (b->tasks[q.first_task].kind >= TASK_PLANES ? out_planes : out_fused) += // (one-pass kinds only: TASK_PLANES / TASK_PLANES8 are the last two of them)
@@ -1042,7 +1060,10 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         b->info.dense_algorithmic_bytes = b->term_bytes_dense + 4 * m_dense;
         b->info.pset_algorithmic_bytes = b->term_bytes_pset + 4 * m_pset;
         b->info.pset_queries = b->pset_queries;
-        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_pset - b->term_bytes_fused - b->term_bytes_planes - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_pset - m_fused);
+        b->info.probe_algorithmic_bytes = b->term_bytes_probe + 4 * m_probe;
+        b->info.probe_queries = b->probe_queries;
+        b->info.cand_queries = b->cand_queries;
+        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_pset - b->term_bytes_probe - b->term_bytes_fused - b->term_bytes_planes - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_pset - m_probe - m_fused);
         b->info.planes_algorithmic_bytes = b->term_bytes_planes + out_planes; // docbytes + 8 B x min(matches, K), per query — the lists
                                                                               // the batch's queries share are nevertheless decoded once per launch
         b->info.term_planes_decoded_bytes = b->plane_decoded_bytes;
@@ -1050,30 +1071,31 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         b->info.phrase_queries = 0;
         for (const DevQuery &q : b->plan)
                 b->info.phrase_queries += q.nphrases != 0;
-        b->info.cand_needed_bytes = b->cand_needed_term_bytes ? b->cand_needed_term_bytes + 4 * (m - m_dense - m_pset - m_fused) : 0;
+        b->info.cand_needed_bytes = b->cand_needed_term_bytes ? b->cand_needed_term_bytes + 4 * (m - m_dense - m_pset - m_fused) : 0; // (the candidate-tile AND the probe queries: what a perfect gallop reads)
         b->info.fused_algorithmic_bytes = b->term_bytes_fused + out_fused; // docbytes + 8 B x min(matches, K)
         b->info.matches = m;
         if (b->distinct_bytes) { // (option account_needed_bytes: the batch-level bound — every distinct list once + every output once)
-                const uint64_t m_cand = m - m_dense - m_pset - m_fused;
+                const uint64_t m_cand = m - m_dense - m_pset - m_probe - m_fused;
                 const bool sc = b->flags & TRI_FLAG_ACCUMULATED_SCORE;
-                uint64_t out_legacy_dense = 4 * m_dense, out_legacy_pset = 4 * m_pset, out_legacy_cand = 4 * m_cand;
+                uint64_t out_legacy_dense = 4 * m_dense, out_legacy_pset = 4 * m_pset, out_legacy_probe = 4 * m_probe, out_legacy_cand = 4 * m_cand;
                 if (sc && b->topk) { // (queries matched by k_and_dense / k_psets / k_and of a top-K batch deliver 8 B x min(matches, K))
-                        out_legacy_dense = out_legacy_pset = out_legacy_cand = 0;
+                        out_legacy_dense = out_legacy_pset = out_legacy_probe = out_legacy_cand = 0;
                         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                                 const DevQuery &q = b->plan[sidx];
                                 if (!q.ntasks || task_onepass(b->tasks[q.first_task].kind))
                                         continue;
                                 const uint32_t kd = b->tasks[q.first_task].kind;
-                                (kd == TASK_DENSE ? out_legacy_dense : kd == TASK_PSET ? out_legacy_pset : out_legacy_cand) += 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk);
+                                (kd == TASK_DENSE ? out_legacy_dense : kd == TASK_PSET ? out_legacy_pset : kd == TASK_PROBE ? out_legacy_probe : out_legacy_cand) += 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk);
                         }
                 }
                 b->info.pset_bound_bytes = b->distinct_bytes_kind[TASK_PSET] + out_legacy_pset;
+                b->info.probe_bound_bytes = b->distinct_bytes_kind[TASK_PROBE] + out_legacy_probe;
                 b->info.dense_bound_bytes = b->distinct_bytes_kind[TASK_DENSE] + out_legacy_dense;
                 b->info.cand_bound_bytes = b->distinct_bytes_kind[TASK_CAND] + out_legacy_cand;
                 b->info.fused_bound_bytes = b->distinct_bytes_kind[TASK_FUSED] + b->distinct_bytes_kind[TASK_FUSED16] + b->distinct_bytes_kind[TASK_FUSED_GEN] + out_fused;
                 b->info.planes_bound_bytes = b->distinct_bytes_kind[TASK_PLANES] + b->distinct_bytes_kind[TASK_PLANES8] + out_planes;
                 b->info.phrase_bound_bytes = b->distinct_bytes_kind[TASK_KINDS];
-                b->info.bound_bytes = b->distinct_bytes + out_legacy_dense + out_legacy_pset + out_legacy_cand + out_fused + out_planes;
+                b->info.bound_bytes = b->distinct_bytes + out_legacy_dense + out_legacy_pset + out_legacy_probe + out_legacy_cand + out_fused + out_planes;
         }
         if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                 uint64_t outb = 0; // 8 B x min(matches, K) per query

@@ -87,10 +87,13 @@ class TriBatchInfo(C.Structure):
         ("planes_bound_bytes", C.c_uint64),
         ("phrase_bound_bytes", C.c_uint64),
         ("pset_ms", C.c_float),
-        ("pad2_", C.c_float),
+        ("probe_ms", C.c_float),
         ("pset_queries", C.c_uint64),
         ("pset_algorithmic_bytes", C.c_uint64),
         ("pset_bound_bytes", C.c_uint64),
+        ("probe_queries", C.c_uint64),
+        ("probe_algorithmic_bytes", C.c_uint64),
+        ("probe_bound_bytes", C.c_uint64),
     ]
 
 

@@ -11,13 +11,14 @@ _SUMMARY = ["block_bytes", "n_plan", "n_qterms", "n_tasks", "n_fused_maps", "n_q
             "off_plan", "off_qterms", "off_tasks", "off_sched", "off_fused", "off_qplane", "off_plane_terms", "off_sterms", "off_sweights", "off_phrases", "off_pterms", "off_ptasks",
             "n_dense", "n_cand", "n_fused", "n_fused16", "n_fusedgen", "n_planes", "n_planes8", "plw", "sparse_cap", "out_capacity", "term_bytes", "term_bytes_dense",
             "dense_queries", "cand_queries", "fused_queries", "planes_queries", "unsupported_queries", "rich_R", "sizeof_query", "sizeof_task", "sizeof_fused", "sizeof_phrase",
-            "cand_needed_term_bytes", "plane_decoded_bytes", "n_pset", "pset_queries"]  # fmt: skip
+            "cand_needed_term_bytes", "plane_decoded_bytes", "n_pset", "pset_queries", "n_probe", "probe_queries", "n_units", "off_units", "off_unit_sched", "sizeof_unit"]  # fmt: skip
 
 DEV_QUERY = np.dtype([("nterms", "<u4"), ("term_base", "<u4"), ("out_off", "<u8"), ("out_cap", "<u4"), ("qid", "<u4"), ("first_task", "<u4"), ("ntasks", "<u4"),
                       ("score_base", "<u4"), ("nscore", "<u4"), ("phrase_base", "<u4"), ("nphrases", "<u4"), ("fused_idx", "<u4"), ("pad0", "<u4")])  # fmt: skip
 DEV_TASK = np.dtype([("slot", "<u4"), ("begin", "<u4"), ("end", "<u4"), ("kind", "<u4"), ("out_off", "<u8")])
-TASK_CAND, TASK_DENSE, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8, TASK_PSET = range(8)
-SCHED_ORDER = [TASK_DENSE, TASK_PSET, TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8]
+TASK_CAND, TASK_DENSE, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8, TASK_PSET, TASK_PROBE = range(9)
+DEV_UNIT = np.dtype([("out_off", "<u8"), ("begin", "<u4"), ("end", "<u4"), ("tix", "<u4"), ("nterms", "<u4"), ("term_base", "<u4"), ("first", "<u4"), ("tt", "<u4", 4), ("row", "<u4", 4)])
+SCHED_ORDER = [TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8]
 
 
 def _lib():
@@ -103,6 +104,14 @@ class HostPlan:
     @property
     def sched(self):
         return self._view("off_sched", self.s["n_tasks"], "<u4")
+
+    @property
+    def units(self):
+        return self._view("off_units", self.s["n_units"], DEV_UNIT)
+
+    @property
+    def unit_sched(self):
+        return self._view("off_unit_sched", self.s["n_pset"] + self.s["n_probe"], "<u4")
 
     @property
     def qterms(self):
