@@ -78,6 +78,23 @@ namespace {
                 }
         };
 
+        // `filter <seed> <permille>`: the documents an application-side IndexDocumentsFilter (matches.h:198-201) rules out — document d when
+        // splitmix64(seed + d) % 1000 < permille (a rule instead of a list: the fixture stays small, the tests rebuild the set).  exec_query
+        // tests it for every match right before consider(), where it tests masked_documents_registry::test (exec.cpp:1095-1150 and the
+        // sibling handlers of the other two modes): with the registry's own bank / bloom structures unbuildable here (docidupdates.cpp needs
+        // boost), this pins WHERE and HOW a dropped document disappears — before consider, in all three modes — with reference code
+        struct HashFilter final : public IndexDocumentsFilter {
+                uint64_t seed{0};
+                uint32_t permille{0};
+                static uint64_t mix(uint64_t x) {
+                        x += 0x9e3779b97f4a7c15ull;
+                        x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+                        x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+                        return x ^ (x >> 31);
+                }
+                bool filter(const docid_t id) override { return mix(seed + id) % 1000u < permille; }
+        };
+
         // A custom IndexSource over an in-memory Google-codec index (index_source.h:19-24 invites exactly this)
         struct MemIndexSource final : public IndexSource {
                 std::vector<term_index_ctx> terms;
@@ -410,6 +427,7 @@ int main(int argc, char **argv) {
         Similarity::IndexSourcesCollectionTermsScorer *collScorer = &bm25; // `sim bm25|tfidf|trivial` switches it
         std::string simName = "bm25";
         auto noMasked = masked_documents_registry::make(nullptr, 0);
+        HashFilter docFilter; // (permille 0: off — exec_query is handed no filter at all)
 
         std::string line;
         while (std::getline(std::cin, line)) {
@@ -567,6 +585,9 @@ int main(int argc, char **argv) {
                                         putchar(c);
                         }
                         printf("\",\"tree\":%s}\n", tree.c_str());
+                } else if (cmd == "filter") {
+                        is >> docFilter.seed >> docFilter.permille;
+                        printf("{\"cmd\":\"filter\",\"seed\":%" PRIu64 ",\"permille\":%u}\n", docFilter.seed, docFilter.permille);
                 } else if (cmd == "sim") {
                         is >> simName;
                         collScorer = simName == "tfidf" ? static_cast<Similarity::IndexSourcesCollectionTermsScorer *>(&tfidf)
@@ -595,12 +616,15 @@ int main(int argc, char **argv) {
                                 collScorer->reset(&collection);
                                 scorer.reset(collScorer->new_source_scorer(src));
                         }
-                        exec_query(q, src, noMasked.get(), &coll, nullptr, flags, scorer.get());
+                        exec_query(q, src, noMasked.get(), &coll, docFilter.permille ? &docFilter : nullptr, flags, scorer.get());
                         const size_t n = coll.ids.size(), kk = n < 16 ? n : 16;
                         double ssum = 0;
                         for (auto s : coll.scores)
                                 ssum += s;
-                        printf("{\"cmd\":\"%s\",\"flags\":%u,\"sim\":\"%s\",\"min\":%u,\"q\":\"", cmd.c_str(), flags, simName.c_str(), someMin);
+                        printf("{\"cmd\":\"%s\",\"flags\":%u,\"sim\":\"%s\",\"min\":%u,", cmd.c_str(), flags, simName.c_str(), someMin);
+                        if (docFilter.permille)
+                                printf("\"filter\":[%" PRIu64 ",%u],", docFilter.seed, docFilter.permille);
+                        printf("\"q\":\"");
                         for (char c : text) {
                                 if (c == '"')
                                         printf("\\\"");

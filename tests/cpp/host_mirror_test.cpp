@@ -2,7 +2,9 @@
 // against Trinity would: build an index source, build iterator trees, exec_query with a
 // MatchedIndexDocumentsFilter in DocumentsOnly and AccumulatedScoreScheme+BM25 modes, drive a
 // PostingsListIterator by hand.  Prints one line per check for the Python test to compare with the oracle.
-//   usage: host_mirror_test <index file> <terms file (u32 triples)> <docsCnt>
+//   usage: host_mirror_test <index file> <terms file (u32 triples)> <docsCnt> [LUCENE <hits.data file>]
+// (with the two extra arguments the segment is opened through Codecs::Lucene::AccessProxy, the way SegmentIndexSource picks the codec by the
+//  name in the segment's `id` file, segment_index_source.cpp:172-179; the checks are the same)
 #include "../../trinity_amd/csrc/host/trinity_gpu.hpp"
 #include <cinttypes>
 #include <cstdio>
@@ -50,8 +52,15 @@ int main(int argc, char **argv) {
                 fs.totalTerms += tctx[i].documents != 0;
         }
         fs.docsCnt = uint32_t(strtoul(argv[3], nullptr, 10));
+        const std::string codec = argc >= 6 ? argv[4] : "GOOGLE";
+        std::vector<uint8_t> hits;
+        if (argc >= 6) {
+                std::ifstream fh(argv[5], std::ios::binary);
+                hits.assign((std::istreambuf_iterator<char>(fh)), std::istreambuf_iterator<char>());
+        }
         try {
-                IndexSource src(0, index.data(), index.size(), names, tctx, fs);
+                IndexSource src(0, index.data(), index.size(), names, tctx, fs, codec, hits.data(), hits.size());
+                printf("codec %s\n", src.new_postings_decoder("t0", src.resolve_term_ctx("t0")) ? (codec == "LUCENE" ? "LUCENE" : "GOOGLE") : "?");
                 Similarity::IndexSourcesCollectionBM25Scorer bm25;
                 std::unique_ptr<Similarity::IndexSourceTermsScorer> scorer(bm25.new_source_scorer(&src));
 
@@ -185,6 +194,23 @@ int main(int argc, char **argv) {
                         exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, static_cast<masked_documents_registry *>(nullptr), &c2, nullptr,
                                    unsigned(ExecFlags::DocumentsOnly));
                         show("no_registry", c2);
+                        // the registry is per call (exec.h:50): the registry-less exec_query that follows sees the source's own set again — none here,
+                        // then a set of the application's own that a call WITH a registry must leave in place
+                        Collect c3;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, reg.get(), &c3, nullptr, unsigned(ExecFlags::DocumentsOnly));
+                        Collect c4;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, &c4, nullptr, unsigned(ExecFlags::DocumentsOnly));
+                        show("after_registry", c4);
+                        std::vector<docid_t> own;
+                        for (docid_t d = 5; d <= fs.docsCnt; d += 5)
+                                own.push_back(d);
+                        src.set_masked_documents(own);
+                        Collect c5;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, reg.get(), &c5, nullptr, unsigned(ExecFlags::DocumentsOnly));
+                        Collect c6;
+                        exec_query(src.conjunction({src.term("t0"), src.term("t1")}), &src, &c6, nullptr, unsigned(ExecFlags::DocumentsOnly));
+                        show("own_set_restored", c6);
+                        src.set_masked_documents({});
                 }
                 { // unknown term => no documents
                         Collect c;

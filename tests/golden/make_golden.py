@@ -320,6 +320,45 @@ def phrase_tree_fixture():
     print(path, len(out["results"]), "records", len(out.get("dropped", [])), "dropped", os.path.getsize(path), "bytes")
 
 
+MASKED_TEMPLATES = ["t{a} t{b}", "t{a} t{b} t{c} t{d} t{e}", "t{a} OR t{b}", "t{a} OR t{b} OR t{c} OR t{d} OR t{e}", "t{a} t{b} (t{c} OR t{d} OR t{e})",
+                    "(t{a} OR t{b}) (t{c} OR t{d}) t{e}", '"t{a} t{b}"', '"t{a} t{b}" t{c}', "t{a} NOT t{b}", "t{a} <t{b}>", "t{a} NOT (t{b} t{c})", "t{a} OR (t{b} t{c})"]
+
+
+def masked_fixture():
+    """tests/golden/ref_masked.json: documents ruled out right before consider().  The reference drops a match when
+    masked_documents_registry::test(id) or IndexDocumentsFilter::filter(id) says so, in the same `if` of the same handler, in every execution
+    mode (exec.cpp:1095-1150 and the handlers after it; matches.h:198-201).  The registry's own structures cannot be built here
+    (docidupdates.cpp needs boost), the filter hook can: `filter <seed> <permille>` hands exec_query a rule-backed IndexDocumentsFilter
+    (document d is dropped when splitmix64(seed + d) % 1000 < permille — masked_docs() below rebuilds the set) and the records pin what
+    comes out: docID sets (flags 1), scores / top-10 (flags 2: the dropped documents leave the top-K and the score sum), matched terms
+    and hits (flags 0).  The oracle and the GPU reproduce them with that set installed as the segment's masked documents."""
+    out = {"corpora": {}, "filters": [[7, 300], [11, 50], [3, 900]], "results": []}
+    for name in ("tiny", "dense"):
+        D, V, slots, seed = CORPORA[name]
+        out["corpora"][name] = {"D": D, "V": V, "slots": slots, "seed": seed}
+        rows = [[0, 1, 2, 3, 4], [1, 0, 2, 5, 9], [3, 7, 11, 0, 2]] + O.gen_queries(V, 1337, 4, 5).tolist()
+        cmds = []
+        for fs, pm in out["filters"]:
+            cmds.append(f"filter {fs} {pm}")
+            for row in rows:
+                a, b, c, d, e = [int(x) for x in row]
+                for tpl in MASKED_TEMPLATES:
+                    q = tpl.format(a=a, b=b, c=c, d=d, e=e)
+                    cmds += [f"query 1 0 {q}", f"query 2 10 {q}", f"query 0 0 {q}"]
+            cmds.append("querysome 2 10 2 [t0, t1, t2, t3]")
+            cmds.append("querysome 1 0 2 [t0, t1, t2, t3]")
+        res = [r for r in O.run_ref_driver(D, V, slots, seed, cmds) if r["cmd"] != "filter"]
+        for r in res:
+            assert r["filter"][1] > 0
+            r.pop("rich_docs", None)  # (the full per-document dumps are a debugging aid; the hash covers them)
+            r["corpus"] = name
+        out["results"] += res
+    path = os.path.join(HERE, "ref_masked.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print(path, len(out["results"]), "records", os.path.getsize(path), "bytes")
+
+
 def main():
     if "--phrase-trees-only" in sys.argv:
         return phrase_tree_fixture()
@@ -327,10 +366,13 @@ def main():
         return tree_fixture()
     if "--random-only" in sys.argv:
         return random_fixture()
+    if "--masked-only" in sys.argv:
+        return masked_fixture()
     edge_fixture()
     tree_fixture()
     random_fixture()
     phrase_tree_fixture()
+    masked_fixture()
     for name, (D, V, slots, seed) in CORPORA.items():
         cmds = commands_for(name, D, V, slots, seed)
         res = O.run_ref_driver(D, V, slots, seed, cmds)

@@ -421,6 +421,16 @@ def parse_query(text, some_min=1):
     return np.array(r, dtype=np.uint32)
 
 
+def masked_docs(D, seed, permille):
+    """The documents ref_driver's `filter <seed> <permille>` rules out (oracle/ref_driver.cpp HashFilter): d in 1..D with
+    splitmix64(seed + d) % 1000 < permille."""
+    x = (np.arange(1, D + 1, dtype=np.uint64) + np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    x = x ^ (x >> np.uint64(31))
+    return (np.nonzero(x % np.uint64(1000) < np.uint64(permille))[0] + 1).astype(np.uint32)
+
+
 def run_ref_driver(D, V, slots, seed, commands):
     """Run the genuine reference (oracle/_ref/ref_driver) over the same corpus; returns parsed JSON lines."""
     import json

@@ -1539,3 +1539,43 @@ def test_edge_segment_from_reference(T, dev):
         assert len(rich) >= 8
     finally:
         ix.close()
+
+
+def test_masked_documents_against_the_reference_s_filter_records(T, dev):
+    """tests/golden/ref_masked.json: the reference with a rule-backed IndexDocumentsFilter — tested in the same condition as
+    masked_documents_registry::test, right before consider() (exec.cpp:1095-1150 and the handlers of the other modes; matches.h:198-201).
+    With the same documents installed through tri_index_set_masked the engine returns the reference's docID sets (DocumentsOnly), match
+    counts + top-10 (AccumulatedScore: k_planes / k_fused / k_and + k_score all drop them before the ranking) and matched terms + hits
+    (the default mode), for every record: 5 %, 30 % and 90 % of the documents dropped, two corpora."""
+    g = json.load(open(os.path.join(GOLDEN, "ref_masked.json")))
+    seen = {0: 0, 1: 0, 2: 0}
+    for name, c in g["corpora"].items():
+        w = World(T, dev, c["D"], c["V"], c["slots"], c["seed"])
+        for fs, pm in g["filters"]:
+            recs = [r for r in g["results"] if r["corpus"] == name and r["filter"] == [fs, pm]]
+            with np.errstate(over="ignore"):
+                w.ix.set_masked(O.masked_docs(c["D"], fs, pm))
+            for flags in (1, 2, 0):
+                rs = [r for r in recs if r["flags"] == flags]
+                progs = [O.parse_query(r["q"], some_min=r["min"] or 1) for r in rs]
+                if flags == 1:
+                    sets, hashes, _ = run_docs_only(w, progs)
+                    for r, got, h in zip(rs, sets, hashes):
+                        assert len(got) == r["n"] and str(O.fnv1a_docs(got)) == r["fnv"] == str(int(h)), (name, fs, pm, r["q"])
+                elif flags == 2:
+                    for opts in ({}, {"dense_min_postings": 0}):  # the planner's choice; every eligible query in one pass
+                        with options(dev, **opts):
+                            d, s, cnt, counts = run_scored(w, progs, 10)
+                        for i, r in enumerate(rs):
+                            top = r.get("top", [])
+                            assert int(counts[i]) == r["n"] and int(cnt[i]) == len(top), (name, fs, pm, r["q"])
+                            assert d[i, : len(top)].tolist() == [x[0] for x in top], (name, fs, pm, r["q"], opts)
+                            np.testing.assert_allclose(s[i, : len(top)], [x[1] for x in top], rtol=1e-5, atol=0)
+                else:
+                    for r, (docs, terms, present, freq, pos) in zip(rs, run_rich(w, progs)):
+                        assert len(docs) == r["n"] and int(freq.sum()) == r["hits_total"], r["q"]
+                        assert int(sum(bin(int(x)).count("1") for x in present)) == r["terms_total"], r["q"]
+                        assert str(O.fnv1a_u32_stream(rich_flat(docs, terms, present, freq, pos))) == r["rich_fnv"], r["q"]
+                seen[flags] += len(rs)
+        w.ix.close()
+    assert min(seen.values()) >= 400

@@ -28,17 +28,20 @@ def test_mirror_compiles_and_links(T):
 
 
 @pytest.mark.gpu
-def test_mirror_results_match_oracle(T, tmp_path):
+@pytest.mark.parametrize("codec", ["GOOGLE", "LUCENE"])
+def test_mirror_results_match_oracle(T, tmp_path, codec):
     from trinity_amd.build import MIRROR_TEST_BIN
 
     D, V = 20000, 500
-    seg = T.Segment(D, V, 12, 7)
-    ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
-    ipath, tpath = str(tmp_path / "index"), str(tmp_path / "terms")
+    seg = T.Segment(D, V, 12, 7, codec=2 if codec == "LUCENE" else 1)
+    ora = O.Index.generate(D, V, 12, 7)  # (the Google-coded oracle: the results do not depend on the codec the segment is stored in)
+    ipath, tpath, hpath = str(tmp_path / "index"), str(tmp_path / "terms"), str(tmp_path / "hits.data")
     np.asarray(seg.index).tofile(ipath)
     np.ascontiguousarray(seg.terms, dtype=np.uint32).tofile(tpath)
-    res = subprocess.run([MIRROR_TEST_BIN, ipath, tpath, str(D)], capture_output=True, text=True, timeout=120)
+    np.asarray(seg.hits).tofile(hpath)
+    res = subprocess.run([MIRROR_TEST_BIN, ipath, tpath, str(D)] + (["LUCENE", hpath] if codec == "LUCENE" else []), capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.splitlines()[0] == "codec " + codec  # (Codecs::Lucene::AccessProxy / Codecs::Google::AccessProxy made the decoder)
     lines = {}
     for l in res.stdout.splitlines():
         k, _, rest = l.partition(" ")
@@ -75,6 +78,8 @@ def test_mirror_results_match_oracle(T, tmp_path):
     expect("masked_scored", "t0 t1", 2, keep=lambda d: (d % 3) != 0)
     expect("masked_registry", "t0 t1", 2, keep=lambda d: (d % 3) != 0)  # exec_query(query, source, masked_documents_registry *, ...): exec.h:50
     expect("no_registry", "t0 t1", 1)
+    expect("after_registry", "t0 t1", 1)  # the registry was per call
+    expect("own_set_restored", "t0 t1", 1, keep=lambda d: (d % 5) != 0)  # ... and a call with a registry leaves the source's own set in place
     # default mode: the same digest from the oracle's canonical stream
     docs, flat, tt, ht = ora.exec_rich(O.parse_query("t0 t1 (t2 OR t3 OR t4)"))
     r = lines["rich"]

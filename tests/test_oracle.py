@@ -549,3 +549,41 @@ def test_edge_hit_payloads_match_reference(edge):
         assert str(h) == r["fnv"], r["term"]
         n += seen_payload
     assert n >= 1
+
+
+def test_documents_ruled_out_before_consider_equal_the_reference():
+    """tests/golden/ref_masked.json: the reference run with a rule-backed IndexDocumentsFilter (`filter <seed> <permille>`, matches.h:198-201)
+    — the hook exec_query tests in the same condition as masked_documents_registry::test, right before consider(), in every execution mode
+    (exec.cpp:1095-1150 ...).  The oracle with the same documents installed as the segment's MASKED set gives the reference's docID sets
+    (DocumentsOnly), score sums and top-10 (AccumulatedScore: a dropped document leaves the ranking), matched terms and hits (default
+    mode) — 1524 records over two corpora and three drop rates (5 %, 30 %, 90 %): the masking semantics of SURVEY §8(f2) pinned to
+    reference code."""
+    g = json.load(open(os.path.join(GOLDEN, "ref_masked.json")))
+    ixs = {name: O.Index.generate(c["D"], c["V"], c["slots"], c["seed"]) for name, c in g["corpora"].items()}
+    n, by_mode, dropped_any = 0, {0: 0, 1: 0, 2: 0}, 0
+    cur = None
+    for r in g["results"]:
+        ix, c = ixs[r["corpus"]], g["corpora"][r["corpus"]]
+        key = (r["corpus"], tuple(r["filter"]))
+        if key != cur:
+            with np.errstate(over="ignore"):
+                ix.set_masked(O.masked_docs(c["D"], *r["filter"]))
+            cur = key
+        prog = O.parse_query(r["q"], some_min=r["min"] or 1)
+        if r["flags"] == 0:
+            docs, flat, tt, ht = ix.exec_rich(prog)
+            assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], r["q"]
+            assert tt == r["terms_total"] and ht == r["hits_total"] and str(O.fnv1a_u32_stream(flat)) == r["rich_fnv"], r["q"]
+        else:
+            docs, scores = ix.exec(prog, r["flags"])
+            assert len(docs) == r["n"] and str(O.fnv1a_docs(docs)) == r["fnv"], (r["q"], r["filter"])
+            if r["flags"] & 2:
+                assert abs(scores.sum() - r["score_sum"]) <= 1e-5 * max(1.0, abs(r["score_sum"]))
+                td, ts = ix.topk(docs, scores, len(r.get("top", [])))
+                assert td.tolist() == [x[0] for x in r.get("top", [])], r["q"]
+                np.testing.assert_allclose(ts, [x[1] for x in r.get("top", [])], rtol=1e-5)
+        by_mode[r["flags"]] += 1
+        n += 1
+    for ix in ixs.values():
+        ix.set_masked(np.zeros(0, np.uint32))
+    assert n == len(g["results"]) >= 1500 and min(by_mode.values()) >= 400

@@ -216,6 +216,26 @@ namespace trinity_amd {
                                 }
                         };
                 } // namespace Google
+
+                // lucene_codec.h:246-283 — the codec SegmentIndexSource picks for a segment whose `id` file names "LUCENE"
+                // (segment_index_source.cpp:172-179).  Besides the index it maps the segment's hits.data (lucene_codec.h:206: positions and payloads
+                // live in their own file).  The engine reads this repo's PFOR128 ints() payload (include/pfor128.md), see INTEGRATION.md §1
+                namespace Lucene {
+                        struct Decoder final : public Codecs::Decoder {
+                                void init(const term_index_ctx &t, Codecs::AccessProxy *) override { indexTermCtx = t; }
+                        };
+                        struct AccessProxy final : public Codecs::AccessProxy {
+                                const uint8_t *const hitsDataPtr;
+                                AccessProxy(const uint8_t *index, const uint8_t *hits)
+                                    : Codecs::AccessProxy(index), hitsDataPtr{hits} {}
+                                const char *codec_identifier() override { return "LUCENE"; }
+                                Codecs::Decoder *new_decoder(const term_index_ctx &t) override {
+                                        auto d = new Decoder();
+                                        d->init(t, this);
+                                        return d;
+                                }
+                        };
+                } // namespace Lucene
         }         // namespace Codecs
 
         inline Codecs::PostingsListIterator::PostingsListIterator(Decoder *d)
@@ -390,25 +410,41 @@ namespace trinity_amd {
                 std::vector<std::string> names;                 // row -> term
                 std::unordered_map<std::string, uint32_t> dict; // term -> row; the reference's SegmentTerms (terms.h) is host-only and out of scope
                 std::vector<term_index_ctx> table;
-                std::unique_ptr<Codecs::Google::AccessProxy> access;
+                std::unique_ptr<Codecs::AccessProxy> access; // Google or Lucene, by the codec name of the segment (segment_index_source.cpp:172-179)
                 std::vector<std::unique_ptr<Codecs::Decoder>> decoders;
                 std::vector<std::unique_ptr<DocsSetIterators::Iterator>> registry; // queryexec_ctx::reg_pli / reg_docset_it
                 field_statistics fs;
 
+                std::vector<docid_t> masked; // the set installed with set_masked_documents (kept: exec_query's per-call registry restores it)
+
               public:
-                // `index`/`len`: the segment's raw GOOGLE-codec `index` bytes; terms[i] names table[i]
+                // `index`/`len`: the segment's raw `index` bytes; terms[i] names table[i].  `codec`: the name in the segment's `id` file — "GOOGLE", or
+                // "LUCENE" with the segment's hits.data in `hits` (segment_index_source.cpp:147-179 reads the name and picks the AccessProxy)
                 IndexSource(int device, const uint8_t *index, size_t len, const std::vector<std::string> &terms, const std::vector<term_index_ctx> &tctx,
-                            const field_statistics &stats)
+                            const field_statistics &stats, const std::string &codec = "GOOGLE", const uint8_t *hits = nullptr, size_t hits_len = 0)
                     : table(tctx), fs(stats) {
                         if (terms.size() != tctx.size())
                                 throw invalid_argument("terms/tctx size mismatch");
+                        if (codec != "GOOGLE" && codec != "LUCENE")
+                                throw invalid_argument("unknown codec"); // segment_index_source.cpp:178: "Unknown codec"
                         check(tri_dev_open(device, &dev));
                         static_assert(sizeof(term_index_ctx) == sizeof(tri_term), "term_index_ctx layout");
-                        check(tri_index_upload(dev, index, len, nullptr, 0, TRI_CODEC_GOOGLE, reinterpret_cast<const tri_term *>(tctx.data()), tctx.size(), stats.docsCnt, &ix));
+                        const bool lucene = codec == "LUCENE";
+                        const int rc = tri_index_upload(dev, index, len, lucene ? hits : nullptr, lucene ? hits_len : 0, lucene ? TRI_CODEC_LUCENE : TRI_CODEC_GOOGLE,
+                                                        reinterpret_cast<const tri_term *>(tctx.data()), tctx.size(), stats.docsCnt, &ix);
+                        if (rc != TRI_OK) {
+                                const std::string why = tri_last_error();
+                                tri_dev_close(dev);
+                                dev = nullptr;
+                                throw data_error(why);
+                        }
                         names = terms;
                         for (uint32_t i = 0; i < terms.size(); ++i)
                                 dict.emplace(terms[i], i);
-                        access.reset(new Codecs::Google::AccessProxy(index));
+                        if (lucene)
+                                access.reset(new Codecs::Lucene::AccessProxy(index, hits));
+                        else
+                                access.reset(new Codecs::Google::AccessProxy(index));
                 }
                 ~IndexSource() {
                         registry.clear();
@@ -423,7 +459,11 @@ namespace trinity_amd {
                 // IndexSourcesCollection::commit() derives per source (index_source.cpp:3-30) and exec_query tests through
                 // masked_documents_registry::test before every consider() (exec.cpp:914-975).  Uploaded once per refresh of the
                 // collection; the matching kernels drop these documents themselves.
-                void set_masked_documents(const std::vector<docid_t> &ids) { check(tri_index_set_masked(ix, ids.data(), ids.size())); }
+                void set_masked_documents(const std::vector<docid_t> &ids) {
+                        check(tri_index_set_masked(ix, ids.data(), ids.size()));
+                        masked = ids;
+                }
+                const std::vector<docid_t> &masked_documents() const noexcept { return masked; }
                 field_statistics default_field_stats() const { return fs; }
 
                 // index_source.h:103: unknown term => no documents
@@ -713,6 +753,18 @@ namespace trinity_amd {
         inline void exec_query(DocsSetIterators::Iterator *root, IndexSource *src, masked_documents_registry *const maskedDocumentsRegistry,
                                MatchedIndexDocumentsFilter *matchesFilter, IndexDocumentsFilter *const f = nullptr, const uint32_t flags = 0,
                                Similarity::IndexSourceTermsScorer *scorer = nullptr) {
+                // (the reference's registry is strictly per call, exec.h:50: whatever set the source carried before is back when the call returns,
+                //  also when the application's filter throws)
+                struct Restore {
+                        IndexSource *src;
+                        std::vector<docid_t> before;
+                        ~Restore() {
+                                try {
+                                        src->set_masked_documents(before);
+                                } catch (...) {
+                                }
+                        }
+                } restore{src, src->masked_documents()};
                 src->set_masked_documents(maskedDocumentsRegistry ? maskedDocumentsRegistry->ids : std::vector<docid_t>{});
                 exec_query(root, src, matchesFilter, f, flags, scorer);
         }
