@@ -1025,8 +1025,8 @@ def test_upload_rejects_what_the_kernels_cannot_read(T, dev):
 
 
 def test_lucene_upload_names_the_payload_it_reads(T, dev):
-    """A LUCENE-coded segment whose ints() groups are not PFOR128 — e.g. one written by the reference's own FastPFor<4> build — is
-    refused at upload with TRI_ERR_FORMAT and a message that says so (never decoded into wrong postings)."""
+    """A LUCENE-coded segment whose ints() groups are neither PFOR128 nor FastPFor<4> words is refused at upload with TRI_ERR_FORMAT and
+    a message that names both (never decoded into wrong postings); likewise a FastPFor-flavoured segment with a damaged group."""
     seg = T.Segment(3000, 100, 10, 42, codec=2)
     off, size = int(seg.terms[0, 1]), int(seg.terms[0, 2])
     assert int(seg.terms[0, 0]) >= 128
@@ -1036,6 +1036,54 @@ def test_lucene_upload_names_the_payload_it_reads(T, dev):
     bad[g + 1] = 33  # a packed width no PFOR128 group has (and the group's length no longer follows from its header word)
     with pytest.raises(T.TrinityError, match="rc=-4.*PFOR128.*FastPFor"):
         T.Index(dev, bad, seg.terms, seg.docs_cnt, codec=2, hits=seg.hits)
+    segf = T.Segment(3000, 100, 10, 42, codec=3)
+    off = int(segf.terms[0, 1])
+    badf = np.array(segf.index, copy=True)
+    g = off + 14
+    assert badf[g] != 0 and badf[g + 1] == 128  # [u8 L][128 = the value count encodeArray stores first]...
+    badf[g + 5] ^= 0x04  # ... [the offset of the metadata]: no longer 1 + 4 b
+    with pytest.raises(T.TrinityError, match="rc=-4.*FastPFor"):
+        T.Index(dev, badf, segf.terms, segf.docs_cnt, codec=2, hits=segf.hits)
+
+
+def test_lucene_segment_with_the_reference_builds_payload_words(T, dev):
+    """A LUCENE segment whose ints() groups carry FastPFor<4> words — the payload the reference's own lucene_codec build writes
+    (lucene_codec.cpp:57-64; restated from the library's published algorithm, parity unpinned: csrc/fastpfor128.hpp) — loads (the upload
+    transcribes every group to PFOR128, index and hits.data) and answers like the same corpus in the other encodings: decode of every
+    term, docID sets incl. phrases (positions come from the transcribed hits.data), BM25 top-K, the default mode."""
+    D, V = 30000, 1500
+    w = World(T, dev, D, V, 10, 42, codec=2)
+    segf = T.Segment(D, V, 10, 42, codec=3)
+    assert segf.payload == "fastpfor" and segf.index.size != w.seg.index.size
+    ixf = T.Index.from_segment(dev, segf)
+    terms = np.arange(0, V, 7, dtype=np.uint32)
+    df = segf.terms[terms, 0]
+    docs, freqs, offs = ixf.decode_terms(terms, df)
+    for i, t in enumerate(terms.tolist()[:80]):
+        wd, wf = w.ora.decode_term(t)
+        assert np.array_equal(docs[offs[i] : offs[i + 1]], wd) and np.array_equal(freqs[offs[i] : offs[i + 1]], wf), t
+    texts = template_queries(w, 311, 10) + phrase_queries(w, 312, 6) + not_queries(w, 313, 3)
+    progs = [O.parse_query(t) for t in texts]
+    b = T.Batch(ixf, progs, T.FLAG_DOCUMENTS_ONLY)
+    b.run()
+    b.sync()
+    counts = b.counts()
+    for i, (t, p) in enumerate(zip(texts, progs)):
+        want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+        assert np.array_equal(b.docset(i, int(counts[i])), want), t
+    b.close()
+    sb = T.Batch(ixf, progs, T.FLAG_ACCUMULATED_SCORE, topk=10)
+    sb.run()
+    sb.sync()
+    d, s, c = sb.topk_results()
+    for i, p in enumerate(progs):
+        dd, ss = w.ora.exec(p, O.FLAG_ACCUM_SCORE)
+        td, ts = w.ora.topk(dd, ss, 10)
+        assert d[i, : len(td)].tolist() == td.tolist(), texts[i]
+        np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+    sb.close()
+    ixf.close()
+    w.ix.close()
 
 
 # ------------------------------------------------------------------------------------------ result gather behind the C-ABI (RCCL)

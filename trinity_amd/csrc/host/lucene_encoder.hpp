@@ -7,6 +7,7 @@
 // payload is this repo's PFOR128 (include/pfor128.md) because the reference's (lemire/FastPFor) is absent: PARITY
 // UNPINNED for those bytes.  New code; independent of oracle/.
 #pragma once
+#include "../fastpfor128.hpp"
 #include "google_encoder.hpp"
 #include <algorithm>
 
@@ -35,11 +36,23 @@ namespace trinity_amd {
                                 }
                         };
 
-                        // ints() group of 128 values (lucene_codec.cpp:26-66 framing, PFOR128 payload)
-                        inline void ints_encode(const uint32_t *v, std::vector<uint8_t> &out) {
+                        // which words an ints() group carries: this repo's PFOR128 (what the kernels read), or FastPFor<4>'s as the reference's own
+                        // build writes them (csrc/fastpfor128.hpp: a segment a genuine Trinity opens)
+                        enum class Payload { PFOR128, FastPFor };
+
+                        // ints() group of 128 values (lucene_codec.cpp:26-66 framing)
+                        inline void ints_encode(const uint32_t *v, std::vector<uint8_t> &out, const Payload payload = Payload::PFOR128) {
                                 if (std::all_of(v + 1, v + BLOCK_SIZE, [&](uint32_t x) { return x == v[0]; })) {
                                         out.push_back(0);
                                         put_varbyte32(out, v[0]);
+                                        return;
+                                }
+                                if (payload == Payload::FastPFor) {
+                                        std::vector<uint32_t> w;
+                                        trif::fastpfor_encode(v, w);
+                                        out.push_back(uint8_t(w.size())); // lucene_codec.cpp:63: the word count (<= 135 for 128 values)
+                                        const auto *p = reinterpret_cast<const uint8_t *>(w.data());
+                                        out.insert(out.end(), p, p + w.size() * 4);
                                         return;
                                 }
                                 struct Choice {
@@ -91,6 +104,7 @@ namespace trinity_amd {
                                         uint16_t curHitsBlockHits;
                                 };
                                 IndexSession *const sess;
+                                const Payload payload;
                                 std::vector<SkipEntry> skiplist;
                                 SkipEntry cur{};
                                 uint32_t deltas[BLOCK_SIZE], freqs[BLOCK_SIZE], hitPos[BLOCK_SIZE], hitLen[BLOCK_SIZE];
@@ -105,14 +119,14 @@ namespace trinity_amd {
                                 void flush_docs_block() {
                                         if (skiplist.size() < UINT16_MAX) // SKIPLIST_STEP == 1: every block (lucene_codec.h:57)
                                                 skiplist.push_back(cur);
-                                        ints_encode(deltas, sess->indexOut);
-                                        ints_encode(freqs, sess->indexOut);
+                                        ints_encode(deltas, sess->indexOut, payload);
+                                        ints_encode(freqs, sess->indexOut, payload);
                                         buffered = 0;
                                 }
 
                               public:
-                                explicit Encoder(IndexSession *s)
-                                    : sess{s} {}
+                                explicit Encoder(IndexSession *s, const Payload p = Payload::PFOR128)
+                                    : sess{s}, payload{p} {}
                                 void begin_term() {
                                         lastDoc = hitsInBlock = sumHits = buffered = termDocs = 0;
                                         termStart = uint32_t(sess->indexOut.size());
@@ -146,8 +160,8 @@ namespace trinity_amd {
                                         lastPos = pos;
                                         if (++hitsInBlock == BLOCK_SIZE) {
                                                 sumHits += hitsInBlock;
-                                                ints_encode(hitPos, sess->positionsOut);
-                                                ints_encode(hitLen, sess->positionsOut);
+                                                ints_encode(hitPos, sess->positionsOut, payload);
+                                                ints_encode(hitLen, sess->positionsOut, payload);
                                                 put_varbyte32(sess->positionsOut, 0); // payload bytes of this block
                                                 lastHitsBlockTotalHits = sumHits;
                                                 lastHitsBlockOffset = uint32_t(sess->positionsOut.size()) - posStart;

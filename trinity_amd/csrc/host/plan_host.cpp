@@ -109,3 +109,25 @@ void tri_host_plan_query_maps(void *p, uint32_t *slot_of_query, int32_t *qstatus
         memcpy(qstatus, P.qstatus.data(), P.qstatus.size() * 4);
 }
 }
+
+// ---- the two ints() payloads (csrc/fastpfor128.hpp) for the CPU tests: encode / decode one 128-value group
+extern "C" {
+// FastPFor<4>::encodeArray of 128 values: words into out (cap >= 160), returns the word count
+uint32_t tri_host_fastpfor_encode(const uint32_t *v, uint32_t *out) {
+        std::vector<uint32_t> w;
+        trif::fastpfor_encode(v, w);
+        memcpy(out, w.data(), w.size() * 4);
+        return (uint32_t)w.size();
+}
+int tri_host_fastpfor_decode(const uint32_t *w, uint32_t L, uint32_t *v) { return trif::fastpfor_decode(w, L, v) ? 1 : 0; }
+// facts of a host index the tests compare between the two payload flavours of one corpus: per term {documents, nblocks, last document}
+void tri_host_index_facts(void *h, uint64_t *info6, uint32_t *per_term3) {
+        const HostIndex &H = *static_cast<HostIndex *>(h);
+        info6[0] = H.info.postings, info6[1] = H.info.blocks, info6[2] = H.info.doc_bytes, info6[3] = H.info.hit_bytes, info6[4] = H.transcoded_groups, info6[5] = H.dev_index.size();
+        for (size_t t = 0; t < H.terms.size(); ++t) {
+                per_term3[3 * t] = H.terms[t].documents;
+                per_term3[3 * t + 1] = H.terms[t].nblocks;
+                per_term3[3 * t + 2] = H.terms[t].nblocks ? H.blk_last[H.terms[t].first_block + H.terms[t].nblocks - 1] : 0;
+        }
+}
+}

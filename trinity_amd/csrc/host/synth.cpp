@@ -63,7 +63,7 @@ extern "C" {
 static void *segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed, int codec);
 // Build the synthetic GOOGLE-codec segment.  Returns an opaque handle (NULL on failure).
 void *tri_synth_segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed) { return segment_build(D, V, slots, seed, 1); }
-// codec: 1 = GOOGLE, 2 = LUCENE-shaped (PFOR128 payload)
+// codec: 1 = GOOGLE, 2 = LUCENE-shaped (PFOR128 payload), 3 = LUCENE-shaped with FastPFor<4> payload words (csrc/fastpfor128.hpp)
 void *tri_synth_segment_build_codec(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed, int codec) { return segment_build(D, V, slots, seed, codec); }
 const uint8_t *tri_synth_segment_hits(void *h, uint64_t *len);
 
@@ -115,9 +115,9 @@ static void *segment_build(uint32_t D, uint32_t V, uint32_t slots, uint64_t seed
                                 ++seg->totalTerms;
                         }
                 };
-                if (codec == 2) {
+                if (codec == 2 || codec == 3) { // (3: the ints() groups carry FastPFor<4> words, as the reference's own build writes them)
                         Codecs::Lucene::IndexSession sess;
-                        Codecs::Lucene::Encoder enc(&sess);
+                        Codecs::Lucene::Encoder enc(&sess, codec == 3 ? Codecs::Lucene::Payload::FastPFor : Codecs::Lucene::Payload::PFOR128);
                         feed(enc);
                         seg->index.swap(sess.indexOut);
                         seg->hits.swap(sess.positionsOut);

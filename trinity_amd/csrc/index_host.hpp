@@ -6,6 +6,7 @@
 #pragma once
 #include "../../include/trinity_hip.h"
 #include "dev_structs.hpp"
+#include "fastpfor128.hpp"
 
 #include <algorithm>
 #include <cstdarg>
@@ -49,11 +50,18 @@ struct HostIndex {
         // "A term gets a plane when it holds at least N documents" is then rank < (number of terms with >= N documents) — one binary
         // search per batch instead of a hash map per query term (planner.hpp)
         std::vector<uint32_t> df_rank, df_sorted;
+        // LUCENE segments whose ints() groups carry FastPFor<4> words (the reference's own build, fastpfor128.hpp): the image the DEVICE gets is
+        // this transcoded copy — every group re-encoded as PFOR128, chunk offsets rewritten — instead of the caller's bytes (empty: the caller's
+        // bytes are what the kernels read).  tctx keeps the CALLER's term table; dev_tctx is the transcoded image's
+        std::vector<uint8_t> dev_index, dev_hits;
+        uint64_t transcoded_groups = 0;
         void release_device_columns() {
                 for (auto *v : {&blk_off, &blk_hits, &hdir, &blk_doff, &win})
                         std::vector<uint32_t>().swap(*v);
                 std::vector<RowRec>().swap(blk_rec);
                 std::vector<uint8_t>().swap(dstream);
+                std::vector<uint8_t>().swap(dev_index);
+                std::vector<uint8_t>().swap(dev_hits);
         }
 };
 
@@ -159,6 +167,146 @@ namespace trih {
         }
 } // namespace trih
 
+// A LUCENE segment with FastPFor<4> payload words -> the same segment with PFOR128 ones (fastpfor128.hpp), chunk by chunk: 14-byte term
+// header, 128-document blocks as two ints() groups, the varbyte tail (lucene_codec.cpp:163-388); the chunk's trailing skiplist is dropped
+// (the engine builds its own directory; skiplistSize 0), the term's positions chunk in hits.data — blocks of 128 hits as two ints() groups +
+// payload bytes, then the tail (lucene_codec.cpp:245-307, 339-366) — likewise.  Returns TRI_OK with out_index empty when no group of the
+// segment is FastPFor-flavoured (nothing to do).
+inline int lucene_transcode(const uint8_t *index, size_t len, const uint8_t *hits, size_t hits_len, const tri_term *terms, size_t nterms,
+                            std::vector<uint8_t> &out_index, std::vector<uint8_t> &out_hits, std::vector<tri_term> &out_terms, uint64_t &ngroups, std::string &err) {
+        using namespace trih;
+        // ---- is there anything to do?  (the first ints() group of the first term that has a full block tells: a segment is written by one build)
+        bool any = false;
+        for (size_t ti = 0; ti < nterms && !any; ++ti) {
+                const tri_term &t = terms[ti];
+                if (t.documents < 128 || t.size < 14 + 6 || (uint64_t)t.offset + t.size > len)
+                        continue;
+                const uint8_t *g = index + t.offset + 14;
+                if (g[0] == 0)
+                        continue; // (an all-equal group: look further)
+                any = trif::group_is_fastpfor(g);
+                break;
+        }
+        out_index.clear();
+        out_hits.clear();
+        if (!any)
+                return TRI_OK;
+        out_terms.assign(terms, terms + nterms);
+        out_index.reserve(len + len / 8);
+        out_hits.reserve(hits_len + hits_len / 8);
+        ngroups = 0;
+        // one ints() group at p -> re-encoded at the end of `out`; returns the bytes consumed (0: malformed)
+        auto group = [&](const uint8_t *p, const uint8_t *end, std::vector<uint8_t> &out) -> size_t {
+                if (p >= end)
+                        return 0;
+                const uint32_t L = p[0];
+                if (!L) {
+                        if (p + 1 >= end)
+                                return 0;
+                        const size_t n = 1 + h_vb_len(p[1]);
+                        if (p + n > end)
+                                return 0;
+                        out.insert(out.end(), p, p + n);
+                        return n;
+                }
+                if (p + 1 + 4 * (size_t)L > end)
+                        return 0;
+                if (!trif::group_is_fastpfor(p)) { // (already PFOR128: kept as it is — h_ints_decode validates it in the walk)
+                        out.insert(out.end(), p, p + 1 + 4 * (size_t)L);
+                        return 1 + 4 * (size_t)L;
+                }
+                std::vector<uint32_t> w(L);
+                memcpy(w.data(), p + 1, 4 * (size_t)L);
+                uint32_t v[128];
+                if (!trif::fastpfor_decode(w.data(), L, v))
+                        return 0;
+                bool eq = true;
+                for (uint32_t i = 1; i < 128; ++i)
+                        eq &= v[i] == v[0];
+                if (eq) { // (FastPFor never sees such a group — lucene_codec.cpp:31-39 short-cuts it — but a foreign writer might)
+                        out.push_back(0);
+                        uint8_t tmp[5];
+                        size_t n = 0;
+                        const uint32_t x = v[0];
+                        if (x < (1u << 7))
+                                tmp[n++] = (uint8_t)x;
+                        else if (x < (1u << 14))
+                                tmp[n++] = (uint8_t)(0x80u | (x >> 8)), tmp[n++] = (uint8_t)x;
+                        else if (x < (1u << 21))
+                                tmp[n++] = (uint8_t)(0xc0u | (x >> 16)), tmp[n++] = (uint8_t)x, tmp[n++] = (uint8_t)(x >> 8);
+                        else if (x < (1u << 28))
+                                tmp[n++] = (uint8_t)(0xe0u | (x >> 24)), tmp[n++] = (uint8_t)(x >> 16), tmp[n++] = (uint8_t)(x >> 8), tmp[n++] = (uint8_t)x;
+                        else
+                                tmp[n++] = 0xf0u, tmp[n++] = (uint8_t)x, tmp[n++] = (uint8_t)(x >> 8), tmp[n++] = (uint8_t)(x >> 16), tmp[n++] = (uint8_t)(x >> 24);
+                        out.insert(out.end(), tmp, tmp + n);
+                } else
+                        trif::pfor128_encode(v, out);
+                ++ngroups;
+                return 1 + 4 * (size_t)L;
+        };
+        for (size_t ti = 0; ti < nterms; ++ti) {
+                const tri_term &t = terms[ti];
+                tri_term &o = out_terms[ti];
+                if (!t.size || !t.documents)
+                        continue;
+                if ((uint64_t)t.offset + t.size > len || t.size < 14)
+                        return herr(err, TRI_ERR_FORMAT, "term %zu: chunk [%u,+%u) outside index (%zu)", ti, t.offset, t.size, len);
+                const uint8_t *base = index + t.offset, *p = base + 14;
+                uint32_t hitsOff, sumHits, posChunk;
+                uint16_t sk;
+                memcpy(&hitsOff, base, 4);
+                memcpy(&sumHits, base + 4, 4);
+                memcpy(&posChunk, base + 8, 4);
+                memcpy(&sk, base + 12, 2);
+                if (14 + (size_t)sk * 22 > t.size)
+                        return herr(err, TRI_ERR_FORMAT, "term %zu: skiplist larger than chunk", ti);
+                const uint8_t *end = base + t.size - (size_t)sk * 22;
+                if (out_index.size() > 0xfffffff0ull - t.size)
+                        return herr(err, TRI_ERR_UNSUPPORTED, "the transcoded index would exceed 4 GiB");
+                o.offset = (uint32_t)out_index.size();
+                out_index.insert(out_index.end(), base, base + 14); // (header: patched below)
+                for (uint32_t left = t.documents; left >= 128; left -= 128)
+                        for (int gi = 0; gi < 2; ++gi) {
+                                const size_t used = group(p, end, out_index);
+                                if (!used)
+                                        return herr(err, TRI_ERR_FORMAT, "term %zu: an ints() group that is neither FastPFor<4> (csrc/fastpfor128.hpp) nor PFOR128 (include/pfor128.md)", ti);
+                                p += used;
+                        }
+                out_index.insert(out_index.end(), p, end); // the varbyte (delta, freq) tail; the skiplist stays behind
+                // ---- the term's positions chunk
+                uint32_t new_hits_off = (uint32_t)out_hits.size(), new_pos_chunk = 0;
+                if (hits_len) {
+                        if ((uint64_t)hitsOff + posChunk > hits_len)
+                                return herr(err, TRI_ERR_FORMAT, "term %zu: positions chunk [%u,+%u) outside hits.data (%zu)", ti, hitsOff, posChunk, hits_len);
+                        const uint8_t *hp = hits + hitsOff, *hend = hp + posChunk;
+                        for (uint32_t hb = 0; hb < sumHits / 128; ++hb) {
+                                for (int gi = 0; gi < 2; ++gi) {
+                                        const size_t used = group(hp, hend, out_hits);
+                                        if (!used)
+                                                return herr(err, TRI_ERR_FORMAT, "term %zu: bad hits block %u", ti, hb);
+                                        hp += used;
+                                }
+                                if (hp >= hend || hp + h_vb_len(*hp) > hend)
+                                        return herr(err, TRI_ERR_FORMAT, "term %zu: hits block %u is truncated", ti, hb);
+                                uint32_t payloadBytes;
+                                const size_t n = h_vb_get(hp, payloadBytes);
+                                if (hp + n + payloadBytes > hend)
+                                        return herr(err, TRI_ERR_FORMAT, "term %zu: hits block %u payload overruns the chunk", ti, hb);
+                                out_hits.insert(out_hits.end(), hp, hp + n + payloadBytes);
+                                hp += n + payloadBytes;
+                        }
+                        out_hits.insert(out_hits.end(), hp, hend); // the tail hits
+                        new_pos_chunk = (uint32_t)(out_hits.size() - new_hits_off);
+                }
+                const uint16_t nosk = 0;
+                memcpy(out_index.data() + o.offset, &new_hits_off, 4);
+                memcpy(out_index.data() + o.offset + 8, &new_pos_chunk, 4);
+                memcpy(out_index.data() + o.offset + 12, &nosk, 2);
+                o.size = (uint32_t)(out_index.size() - o.offset);
+        }
+        return TRI_OK;
+}
+
 // The walk.  `index` / `hits`: the segment's raw codec bytes; `terms[i]` what IndexSource::resolve_term_ctx returns for term i.
 inline int build_host_index(const uint8_t *index, size_t len, const uint8_t *hits, size_t hits_len, int codec, const tri_term *terms, size_t nterms,
                             uint32_t docs_cnt, HostIndex &H, std::string &err) {
@@ -175,6 +323,33 @@ inline int build_host_index(const uint8_t *index, size_t len, const uint8_t *hit
         H.tctx.assign(terms, terms + nterms);
         H.docbytes.assign(nterms, 0);
         H.hitbytes.assign(nterms, 0);
+        // a LUCENE segment as the reference's own build writes it (FastPFor<4> payload words): the walk below — and the device — see its
+        // PFOR128 transcription; the SURVEY §8(d) byte counts are taken from the bytes the caller handed over (what the reference would stream)
+        std::vector<tri_term> dev_terms;
+        std::vector<uint64_t> orig_docbytes, orig_hitbytes;
+        if (codec == TRI_CODEC_LUCENE) {
+                if (const int rc = lucene_transcode(index, len, hits, hits_len, terms, nterms, H.dev_index, H.dev_hits, dev_terms, H.transcoded_groups, err))
+                        return rc;
+                if (!H.dev_index.empty()) {
+                        orig_docbytes.assign(nterms, 0);
+                        orig_hitbytes.assign(nterms, 0);
+                        for (size_t ti = 0; ti < nterms; ++ti)
+                                if (terms[ti].size >= 14 && terms[ti].documents) {
+                                        uint16_t sk;
+                                        uint32_t pc;
+                                        memcpy(&sk, index + terms[ti].offset + 12, 2);
+                                        memcpy(&pc, index + terms[ti].offset + 8, 4);
+                                        orig_docbytes[ti] = terms[ti].size - (uint64_t)sk * 22;
+                                        orig_hitbytes[ti] = pc;
+                                }
+                        H.dev_index.resize(H.dev_index.size() + 16, 0); // (slack for the walk's bounded reads; dropped again below)
+                        index = H.dev_index.data();
+                        len = H.dev_index.size() - 16;
+                        hits = H.dev_hits.empty() ? nullptr : H.dev_hits.data();
+                        hits_len = H.dev_hits.size();
+                        terms = dev_terms.data();
+                }
+        }
         std::vector<uint32_t> &blk_last = H.blk_last, &blk_off = H.blk_off;
         std::vector<uint32_t> &blk_hits = H.blk_hits, &hdir = H.hdir; // (hdir: LUCENE + hits.data only)
         std::vector<RowRec> &blk_rec = H.blk_rec;                     // LUCENE only
@@ -228,15 +403,14 @@ inline int build_host_index(const uint8_t *index, size_t len, const uint8_t *hit
                                 const uint32_t goff = (uint32_t)(p - index);
                                 const size_t used = h_ints_decode(p, end, vals);
                                 if (!used) // (the group's header word does not describe a PFOR128 payload of the declared length)
-                                        return herr(err, TRI_ERR_FORMAT, "term %zu: an ints() group that is not PFOR128 (include/pfor128.md) — a lucene_codec segment written by the reference's "
-                                                                    "own build carries lemire/FastPFor<4> payloads (lucene_codec.cpp:57-64), which this engine does not read: re-encode "
-                                                                    "the segment with csrc/host/lucene_encoder.hpp, or use google_codec", ti);
+                                        return herr(err, TRI_ERR_FORMAT, "term %zu: an ints() group that is neither PFOR128 (include/pfor128.md) nor FastPFor<4> words as the reference's "
+                                                                    "lucene_codec writes them (lucene_codec.cpp:57-64; csrc/fastpfor128.hpp transcribes those at upload)", ti);
                                 p += used;
                                 uint32_t xd[4], xf[4];
                                 const size_t usedf = h_ints_decode(p, end, fvals);
                                 if (!usedf || !h_ints_exc(index + goff, xd) || !h_ints_exc(p, xf))
-                                        return herr(err, TRI_ERR_FORMAT, "term %zu: a freqs group / exception list that is not PFOR128 (include/pfor128.md; FastPFor<4> payloads of the reference's own "
-                                                                    "build are not readable)", ti);
+                                        return herr(err, TRI_ERR_FORMAT, "term %zu: a freqs group / exception list that is neither PFOR128 (include/pfor128.md) nor FastPFor<4> words "
+                                                                    "(csrc/fastpfor128.hpp)", ti);
                                 p += usedf;
                                 uint32_t hdr[2];
                                 for (int gi = 0; gi < 2; ++gi) { // the two groups' header words as the row records cache them
@@ -440,6 +614,16 @@ inline int build_host_index(const uint8_t *index, size_t len, const uint8_t *hit
                 }
         }
         H.has_hdir = want_hits;
+        if (!orig_docbytes.empty()) { // (a transcoded segment: the roofline's byte counts are those of the caller's encoding)
+                H.dev_index.resize(len);
+                docb = hitb = 0;
+                for (size_t ti = 0; ti < nterms; ++ti) {
+                        H.docbytes[ti] = orig_docbytes[ti];
+                        H.hitbytes[ti] = orig_hitbytes[ti];
+                        docb += orig_docbytes[ti];
+                        hitb += orig_hitbytes[ti];
+                }
+        }
         H.info.index_bytes = len;
         H.info.directory_bytes = blk_last.size() * 8 + nterms * sizeof(DevTerm) + win.size() * 4;
         H.info.blocks = blk_last.size();

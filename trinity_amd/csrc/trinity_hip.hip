@@ -475,6 +475,12 @@ extern "C" int tri_index_upload(tri_dev *dev, const uint8_t *index, size_t len, 
         }
         ix->dev = dev;
         dev_retain(dev);
+        if (!ix->dev_index.empty()) { // a LUCENE segment with FastPFor<4> payload words: the device gets its PFOR128 transcription (index_host.hpp)
+                index = ix->dev_index.data();
+                len = ix->dev_index.size();
+                hits = ix->dev_hits.empty() ? nullptr : ix->dev_hits.data();
+                hits_len = ix->dev_hits.size();
+        }
         // device copies
         int rc;
         if ((rc = dev_upload(&ix->d_win, ix->win, 3 * CELLS_PER_SPAN + 8))) // (lanes of terms without a row read entries 0, CELLS_PER_SPAN, 2 * CELLS_PER_SPAN and drop them)

@@ -236,7 +236,9 @@ class Segment:
 
     def __init__(self, D, V, slots=10, seed=42, codec=CODEC_GOOGLE):
         L = host_lib()
-        self.D, self.V, self.slots, self.seed, self.codec = D, V, slots, seed, codec
+        # codec 3: the LUCENE-shaped container with FastPFor<4> payload words (what the reference's own build writes; csrc/fastpfor128.hpp) —
+        # to everything downstream it is a LUCENE segment (codec 2)
+        self.D, self.V, self.slots, self.seed, self.codec, self.payload = D, V, slots, seed, min(codec, CODEC_LUCENE), "fastpfor" if codec == 3 else "native"
         self.h = L.tri_synth_segment_build_codec(D, V, slots, seed, codec)
         if not self.h:
             raise TrinityError("segment build failed (index larger than 4 GiB?)")
