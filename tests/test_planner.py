@@ -74,13 +74,17 @@ def check_plan(p, nq):
         for u in ran[:: max(1, len(ran) // 300)]:
             k0 = 1 if tasks[u["tix"]]["kind"] == HP.TASK_PROBE else 0
             for k in range(k0, min(int(u["nterms"]), 4)):
-                assert p.plane_terms[u["row"][k]] == (u["tt"][k] & 0x3FFFFFFF) == (p.qterms[u["term_base"] + k] & 0x3FFFFFFF)
+                assert (u["tt"][k] & 0x3FFFFFFF) == (p.qterms[u["term_base"] + k] & 0x3FFFFFFF) and u["row"][k] == p.qplane[u["term_base"] + k] != 0xFFFFFFFF
     # planes: a term position that names a row names its own term's row
     if s["n_qplane"]:
+        # (a row is the term's rank by document count — the planes live with the index, every batch names the same row for the same term)
         qt, qp, rows = p.qterms & 0x3FFFFFFF, p.qplane, p.plane_terms
         named = qp != 0xFFFFFFFF
-        assert np.all(qp[named] < len(rows)) and np.array_equal(rows[qp[named]], qt[named])
-        assert np.all(np.diff(rows.astype(np.int64)) > 0)
+        assert np.all(np.isin(qt[named], rows)) and np.all(np.diff(rows.astype(np.int64)) > 0)
+        row_of = {}
+        for t_, r_ in zip(qt[named].tolist(), qp[named].tolist()):
+            assert row_of.setdefault(t_, r_) == r_  # one row per term ...
+        assert len(set(row_of.values())) == len(row_of)  # ... and one term per row
 
 
 @pytest.mark.parametrize("wl", ["cfg2", "cfg3", "cfg4", "cfg5"])
@@ -139,6 +143,7 @@ def test_plane_budget_caps_the_eligible_terms(world):
         p = HP.HostPlan(hix[pt.codec], pt.programs, pt.flags, pt.topk, threads=2, options={"plane_div": 1 << 30, "dense_min_postings": 0, "plane_max_bytes": budget})
         check_plan(p, len(pt.programs))
         assert p.s["n_plane_terms"] * 3 * p.s["plw"] * 4 <= max(budget, 3 * p.s["plw"] * 4)
+        assert p.s["n_qplane"] == 0 or int(p.qplane[p.qplane != 0xFFFFFFFF].max()) < max(1, budget // (3 * p.s["plw"] * 4))  # rows stay inside the budget's rows
         rows.append(p.s["n_plane_terms"])
         p.close()
     assert rows[0] > rows[1] > rows[2] >= 1

@@ -47,13 +47,13 @@ template <int CODEC>
 __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                         const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
                                                         const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
-                                                        const DevTerm *__restrict__ terms, const uint32_t *__restrict__ plane_terms,
+                                                        const DevTerm *__restrict__ terms, const uint32_t *__restrict__ build /* (term, row) pairs */,
                                                         uint32_t *__restrict__ planes, const uint32_t plw) {
         __shared__ uint32_t pl[PL_PLANES * PL_STRIDE];
-        const uint32_t tid = threadIdx.x, w = blockIdx.x, row = blockIdx.y;
+        const uint32_t tid = threadIdx.x, w = blockIdx.x, row = build[2 * blockIdx.y + 1];
         for (uint32_t i = tid; i < PL_PLANES * PL_STRIDE; i += AND_WG)
                 pl[i] = 0;
-        const DevTerm t = terms[plane_terms[row]];
+        const DevTerm t = terms[build[2 * blockIdx.y]];
         const uint32_t *bl = blk_last + t.first_block;
         const uint32_t w0 = w * PL_W;
         // rows that can hold documents of [w0, w0 + PL_W): first row whose last docID >= w0 ... first row whose last docID >= the next

@@ -102,6 +102,7 @@ struct BatchPlan {
         std::vector<int32_t> qstatus;        // per caller query: TRI_OK, or why the planner left it out of the batch (it then reports no matches)
         uint32_t n_dense = 0, n_pset = 0, n_probe = 0, n_cand = 0, n_fused = 0, n_fused16 = 0, n_fusedgen = 0, n_planes = 0, n_planes8 = 0;
         uint32_t plw = 0;        // words of one term plane
+        uint32_t plane_rows = 0; // rows the batch may address: the terms eligible for a plane under the options it was planned with (row = df rank)
         uint32_t sparse_cap = 0; // k_planes: list entries a task's decoded slots can need
         uint32_t rich_R = 0;     // default mode: reportable terms of the widest query
         bool rich_allow = false; // default mode: the batch holds general trees (per match: which reportable terms the tree sits on)
@@ -1315,11 +1316,14 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                 chosen.push_back(rank_term[r]);
                 std::sort(chosen.begin(), chosen.end());
         }
+        // a term's plane row is its DF RANK: the rows live with the INDEX (tri_index's plane cache: a head term is decoded into its planes the
+        // first time any batch wants them and stays — the index does not change), so every batch addresses the same row for the same term
         std::vector<uint32_t> row_of_rank(C.n_ok, PL_NONE);
         for (size_t i = 0; i < chosen.size(); ++i) {
-                row_of_rank[ix.df_rank[chosen[i]]] = (uint32_t)i;
+                row_of_rank[ix.df_rank[chosen[i]]] = ix.df_rank[chosen[i]];
                 P.plane_decoded_bytes += ix.docbytes[chosen[i]];
         }
+        P.plane_rows = C.n_ok;
         // ---- layout of the host block
         size_t bytes = 0;
         auto section = [&](size_t &off_out, size_t n, size_t elem) {

@@ -231,6 +231,14 @@ struct tri_index : HostIndex {
         uint4 *d_blk_rec = nullptr;
         uint32_t *d_masked = nullptr; // bitmap over docIDs of the masked documents (nullptr: none); max_doc / 32 + 2 words
         DevTerm *d_terms = nullptr;
+        // ---- the term planes live with the index (they are a function of its lists alone): row r = the planes A / B / C of the term of df
+        //      rank r, built by k_term_planes the first time a batch's run wants them and kept — a caller that compiles a batch per step does
+        //      not decode the same head terms step after step.  pc_cap rows + one all-zero row (index pc_cap); pc_built[r]: row r's build has
+        //      been enqueued on the engine stream (every later kernel of the stream sees it).  Grown (engine stream drained, rows copied) when
+        //      a batch is planned with more eligible terms than it holds.
+        uint32_t *d_pcache = nullptr;
+        uint32_t pc_cap = 0, pc_plw = 0;
+        std::vector<uint8_t> pc_built;
         ~tri_index() { // also runs when tri_index_upload fails half-way
                 if (dev)
                         hipSetDevice(dev->device);
@@ -246,6 +254,7 @@ struct tri_index : HostIndex {
                 hipFree(d_blk_off);
                 hipFree(d_win);
                 hipFree(d_terms);
+                hipFree(d_pcache);
                 dev_release(dev);
         }
 };
@@ -263,7 +272,7 @@ struct tri_batch : BatchPlan {
         DevQuery *d_plan = nullptr;
         DevTask *d_tasks = nullptr;
         uint32_t *d_sched = nullptr; // task indices, heaviest first: [0, n_dense) TASK_DENSE, then the TASK_CAND ones, then the one-pass kinds
-        uint32_t *d_plane_terms = nullptr, *d_planes = nullptr, *d_qplane = nullptr; // d_qplane: parallel to d_qterms, the term's row or PL_NONE (nullptr: the batch has no planes)
+        uint32_t *d_plane_terms = nullptr, *d_qplane = nullptr, *d_build = nullptr; // d_build: (term, row) pairs of the plane rows a run has to build first // d_qplane: parallel to d_qterms, the term's row or PL_NONE (nullptr: the batch has no planes)
         unsigned long long *d_qthr = nullptr; // k_planes: per query, the best k-th score any of its tasks has seen (cleared at every run)
         uint32_t *d_sparse = nullptr;      // k_planes: per resident workgroup, the lists of a task's decoded (non-plane) slots
         DevFused *d_fused = nullptr;
@@ -319,7 +328,6 @@ struct tri_batch : BatchPlan {
                 pinned_free(dev, block, block_cap);
                 pool_free(dev, d_arena);
                 pool_free(dev, d_sparse);
-                pool_free(dev, d_planes);
                 pool_free(dev, d_out);
                 pool_free(dev, d_rich_allow);
                 hipFree(d_hashes);
@@ -687,7 +695,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 a += (bytes + 255) & ~(size_t)255;
                 return at;
         };
-        const size_t a_counts = carve((nt + 1) * 4), a_ticket = carve(256);
+        const size_t a_counts = carve((nt + 1) * 4), a_ticket = carve(256), a_build = carve((b->plane_terms.size() + 1) * 8);
         const bool planes_tasks = b->n_planes + b->n_planes8;
         const size_t a_qthr = planes_tasks ? carve((np + 1) * 8) : 0;
         const size_t a_part_counts = scored ? carve((nt + 1) * 4) : 0;
@@ -713,6 +721,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->d_ptasks = (uint32_t *)(A + b->off_ptasks);
         b->d_counts = (uint32_t *)(A + a_counts);
         b->d_ticket = (uint32_t *)(A + a_ticket);
+        b->d_build = (uint32_t *)(A + a_build);
         b->d_qthr = planes_tasks ? (unsigned long long *)(A + a_qthr) : nullptr;
         b->d_part_counts = scored ? (uint32_t *)(A + a_part_counts) : nullptr;
         b->d_task_hits = rich ? (uint32_t *)(A + a_task_hits) : nullptr;
@@ -728,10 +737,25 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         HIP_TRY(hipMemsetAsync(A + a_zero, 0, a - a_zero, dev->stream_up));
         // ---- the large buffers (the device handle's pool)
         if (!b->plane_terms.empty() || planes_tasks) {
-                // the rows k_term_planes fills, plus an all-zero row: what a k_planes slot WITHOUT term planes reads (so its sweep needs no select)
-                const size_t row = (size_t)PL_PLANES * b->plw * 4;
-                HIP_TRY(pool_alloc(dev, (void **)&b->d_planes, (b->plane_terms.size() + 1) * row + 64));
-                HIP_TRY(hipMemsetAsync((uint8_t *)b->d_planes + b->plane_terms.size() * row, 0, row + 64, dev->stream_up));
+                // the index's plane cache holds a row for every term this batch could name (row = df rank < plane_rows), plus an all-zero row:
+                // what a k_planes slot WITHOUT term planes reads (so its sweep needs no select)
+                const uint32_t want = std::max<uint32_t>(1, b->plane_rows);
+                if (want > ix->pc_cap || b->plw != ix->pc_plw) {
+                        const size_t row = (size_t)PL_PLANES * b->plw * 4;
+                        uint32_t *fresh = nullptr;
+                        HIP_TRY(hipMalloc((void **)&fresh, ((size_t)want + 1) * row + 64));
+                        HIP_TRY(hipStreamSynchronize(dev->stream)); // (no run in flight reads the old rows while they move)
+                        if (ix->d_pcache && b->plw == ix->pc_plw)
+                                HIP_TRY(hipMemcpy(fresh, ix->d_pcache, (size_t)ix->pc_cap * row, hipMemcpyDeviceToDevice));
+                        else
+                                ix->pc_built.clear();
+                        HIP_TRY(hipMemset((uint8_t *)fresh + (size_t)want * row, 0, row + 64));
+                        hipFree(ix->d_pcache);
+                        ix->d_pcache = fresh;
+                        ix->pc_cap = want;
+                        ix->pc_plw = b->plw;
+                        ix->pc_built.resize(want, 0);
+                }
         }
         if (planes_tasks) {
                 const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
@@ -766,7 +790,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->info.planes_queries = b->planes_queries;
         b->info.unsupported_queries = b->unsupported_queries;
         b->info.plane_terms = b->plane_terms.size();
-        b->info.plane_bytes = (uint64_t)b->plane_terms.size() * PL_PLANES * b->plw * 4;
+        b->info.plane_bytes = (uint64_t)b->plane_terms.size() * PL_PLANES * b->plw * 4; // (rows of the index's plane cache this batch reads)
         b->info.launches = (b->n_dense != 0) + (b->n_pset != 0) + (b->n_probe != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (b->n_planes8 != 0) + (!b->plane_terms.empty()) +
                            (!b->ptasks.empty()) + (rich ? 2 : 0) +
                            ((scored && b->n_dense + b->n_pset + b->n_probe + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
@@ -814,12 +838,29 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         cand_wgs = (uint32_t)dev->opt.overlap_cand_wgs;
                 } else if (dev->opt.overlap && b->n_cand && b->n_dense + b->n_pset + b->n_probe)
                         overlap = true; // (full grids: the second kernel's workgroups take the slots the first one's tail leaves)
+                b->info.term_planes_decoded_bytes = 0;
                 if (!b->plane_terms.empty()) {
-                        // the head terms the batch shares, decoded once for this launch (every word of every plane is rewritten)
-                        const dim3 grid(b->plw / PL_WORDS, (uint32_t)b->plane_terms.size());
-                        TRI_LAUNCH(k_term_planes, b->ix->codec, grid, dim3(AND_WG), dev->stream, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec,
-                                   b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plane_terms, b->d_planes, b->plw);
-                        HIP_TRY(hipGetLastError());
+                        // the head terms the batch's queries share: the rows of the index's plane cache that no earlier run has built are decoded now
+                        // — once for the index, not once per batch (every word of a row is written: no memset)
+                        tri_index *ix = b->ix;
+                        std::vector<uint32_t> build;
+                        for (const uint32_t term : b->plane_terms) {
+                                const uint32_t row = ix->df_rank[term];
+                                if (row < ix->pc_cap && !ix->pc_built[row]) {
+                                        build.push_back(term);
+                                        build.push_back(row);
+                                        b->info.term_planes_decoded_bytes += ix->docbytes[term];
+                                }
+                        }
+                        if (!build.empty()) {
+                                HIP_TRY(hipMemcpyAsync(b->d_build, build.data(), build.size() * 4, hipMemcpyHostToDevice, dev->stream)); // (pageable source: staged before the call returns)
+                                const dim3 grid(b->plw / PL_WORDS, (uint32_t)(build.size() / 2));
+                                TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff, ix->d_win,
+                                           ix->d_terms, (const uint32_t *)b->d_build, ix->d_pcache, b->plw);
+                                HIP_TRY(hipGetLastError());
+                                for (size_t i = 1; i < build.size(); i += 2)
+                                        ix->pc_built[build[i]] = 1;
+                        }
                 }
                 HIP_TRY(hipEventRecord(b->ev_pl, dev->stream));
                 hipStream_t cand_stream = dev->stream;
@@ -831,7 +872,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 if (b->n_dense) {
                         TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * dense_wgs)), dim3(DENSE_WG), dev->stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
-                                           b->d_ticket + 16, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->d_planes, b->plw);
+                                           b->d_ticket + 16, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->ix->d_pcache, b->plw);
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
@@ -839,7 +880,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         // the queries all of whose terms have planes: word-wise algebra over the planes + expansion (k_psets.hpp)
                         hipLaunchKernelGGL(k_psets, dim3(std::min<uint32_t>(b->n_pset, (uint32_t)dev->cus * (TRI_PSET_WAVES * 256 / PSET_WG))), dim3(PSET_WG), 0, dev->stream,
                                            (const DevPsetUnit *)(b->d_arena + b->off_units), (const uint32_t *)(b->d_arena + b->off_pset_sched), b->n_pset, b->d_ticket + 20,
-                                           (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_planes, b->plw);
+                                           (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->ix->d_pcache, b->plw);
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_s, dev->stream));
@@ -848,14 +889,14 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         TRI_LAUNCH(k_probe, b->ix->codec, dim3(std::min<uint32_t>((b->n_probe + PROBE_WG / 64 - 1) / (PROBE_WG / 64), (uint32_t)dev->cus * (TRI_PROBE_WAVES * 256 / PROBE_WG))),
                                    dim3(PROBE_WG), dev->stream, match_bytes, b->ix->d_blk_last, match_off, b->ix->d_terms, (const DevPsetUnit *)(b->d_arena + b->off_units),
                                    (const uint32_t *)(b->d_arena + b->off_pset_sched) + b->n_pset, b->n_probe, b->d_ticket + 22, (const uint32_t *)b->d_qterms,
-                                   (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_planes, b->plw);
+                                   (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->ix->d_pcache, b->plw);
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_r, dev->stream));
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense + b->n_pset + b->n_probe, b->d_qterms,
-                                           b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->d_planes, b->plw);
+                                           b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->ix->d_pcache, b->plw);
                 HIP_TRY(hipGetLastError());
                 if (overlap) {
                         HIP_TRY(hipEventRecord(dev->ev_join, dev->stream2));
@@ -907,7 +948,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
 #define TRI_PLANES_ARGS                                                                                                                                      \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, \
                 b->d_sterms, b->d_sweights, np, b->d_ticket + 24 + 2 * wide, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked,     \
-                b->similarity, (const uint32_t *)b->d_planes, b->plw, (uint32_t)b->plane_terms.size(), b->d_sparse, b->sparse_cap, b->d_qthr
+                b->similarity, (const uint32_t *)b->ix->d_pcache, b->plw, b->ix->pc_cap, b->d_sparse, b->sparse_cap, b->d_qthr
                         if (b->ix->codec == TRI_CODEC_LUCENE) {
                                 if (wide)
                                         hipLaunchKernelGGL((k_planes<CODEC_LUCENE, FUS_MAX_SLOTS>), grid, dim3(PLK_WG), 0, dev->stream, TRI_PLANES_ARGS);
@@ -1072,7 +1113,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_pset - b->term_bytes_probe - b->term_bytes_fused - b->term_bytes_planes - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_pset - m_probe - m_fused);
         b->info.planes_algorithmic_bytes = b->term_bytes_planes + out_planes; // docbytes + 8 B x min(matches, K), per query — the lists
                                                                               // the batch's queries share are nevertheless decoded once per launch
-        b->info.term_planes_decoded_bytes = b->plane_decoded_bytes;
+        // (term_planes_decoded_bytes: set by tri_batch_run — the list bytes of the plane rows THAT run had to build; 0 once the index's cache holds them)
         b->info.phrase_algorithmic_bytes = b->term_bytes_phrase_hits; // what k_phrase streams by the SURVEY §8(d) count: the hit bytes of the phrases' terms
         b->info.phrase_queries = 0;
         for (const DevQuery &q : b->plan)
