@@ -122,6 +122,17 @@ struct BatchPlan {
 namespace trip {
         constexpr uint64_t TASK_COST = 96 * 1024; // postings per candidate-tile task
         constexpr size_t SECTION_ALIGN = 64;
+        constexpr uint32_t SCHED_NB = 64 * 4; // schedule buckets per kernel: cost octave + 2 bits
+        // launch order of the task kinds: TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, then the one-pass kinds as numbered
+        constexpr uint32_t SCHED_RANK[TASK_KINDS] = {3, 0, 4, 5, 6, 7, 8, 1, 2};
+        inline uint32_t sched_key(const uint32_t kind, const uint64_t cost) {
+                if (kind == TASK_PSET) // by docID window range, ascending (`cost` holds the first window)
+                        return SCHED_RANK[TASK_PSET] * SCHED_NB + (uint32_t)std::min<uint64_t>(cost / PSET_TASK_WINDOWS, SCHED_NB - 1);
+                const uint64_t c = std::max<uint64_t>(1, cost);
+                const uint32_t lg = 63u - (uint32_t)__builtin_clzll(c);
+                const uint32_t frac = lg >= 2 ? (uint32_t)((c >> (lg - 2)) & 3u) : (uint32_t)((c << (2 - lg)) & 3u);
+                return SCHED_RANK[kind] * SCHED_NB + (SCHED_NB - 1 - (lg * 4 + frac));
+        }
 
         struct PNode {
                 uint32_t op = 0, term = 0;
@@ -435,6 +446,7 @@ namespace trip {
                 std::vector<QUse> quses;
                 std::vector<FUse> fuses;
                 std::vector<uint64_t> benefit; // per eligible term (by df rank): postings of decoding the batch's uses save
+                std::vector<uint32_t> keys, hist; // (fill pass) per task its schedule bucket; tasks per bucket
                 uint64_t off = 0;
                 uint32_t sparse_cap = 0;
                 uint64_t term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, cand_needed = 0;
@@ -1370,7 +1382,6 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         span(P.pset_sched, P.off_pset_sched, n_units);
         std::vector<uint32_t> unit_of_task(n_units ? n_tasks : 0);
         std::copy(chosen.begin(), chosen.end(), P.plane_terms.p);
-        std::vector<uint64_t> tcost(n_tasks);
         // ---- every fragment writes its part of the arrays, rebased
         run([&](unsigned k) {
                 Frag &f = frags[k];
@@ -1391,7 +1402,6 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         t.slot += (uint32_t)f.b_plan;
                         t.out_off += f.b_off;
                         P.tasks[f.b_tasks + i] = t;
-                        tcost[f.b_tasks + i] = f.tcost[i];
                 }
                 if (!f.qterms.empty())
                         memcpy(&P.qterms[f.b_qterms], f.qterms.data(), f.qterms.size() * 4);
@@ -1443,6 +1453,10 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         P.units[f.b_units + i] = u;
                         unit_of_task[u.tix] = (uint32_t)(f.b_units + i);
                 }
+                f.keys.resize(f.tasks.size());
+                f.hist.assign(TASK_KINDS * SCHED_NB, 0u);
+                for (size_t i = 0; i < f.tasks.size(); ++i) // (the kinds are final: a probe task whose planes were not chosen is a candidate-tile task by now)
+                        ++f.hist[f.keys[i] = sched_key(P.tasks[f.b_tasks + i].kind, f.tcost[i])];
                 if (n_qplane) {
                         std::fill(&P.qplane.p[f.b_qterms], &P.qplane.p[f.b_qterms] + f.qterms.size(), PL_NONE);
                         for (const QUse &u : f.quses)
@@ -1454,32 +1468,32 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 P.term_bytes_probe -= f.probe_demoted_bytes;
         }
         P.plan_ms[2] = ms_since(t0);
-        // ---- the schedule: per kernel, heaviest tasks first.  A counting sort by (kernel, cost octave + 3 bits): tasks within 12 % of each
-        //      other keep their order in the batch — all a longest-first dispatch needs
+        // ---- the schedule: per kernel, heaviest tasks first.  A counting sort by (kernel, cost octave + 2 bits) — tasks within a fifth of each
+        //      other keep their order in the batch: all a longest-first dispatch needs; TASK_PSET goes by docID window range instead.  The
+        //      fragments counted their tasks per bucket in the fill pass; their places are settled here, the scatter runs on the pool again
         {
-                constexpr uint32_t NB = 64 * 8;
-                static const uint32_t kind_rank[TASK_KINDS] = {3, 0, 4, 5, 6, 7, 8, 1, 2}; // launch order: TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, then the one-pass kinds as numbered
-                auto key = [&](size_t i) {
-                        const uint64_t c = std::max<uint64_t>(1, tcost[i]);
-                        const uint32_t lg = 63u - (uint32_t)__builtin_clzll(c);
-                        const uint32_t frac = lg >= 3 ? (uint32_t)((c >> (lg - 3)) & 7u) : (uint32_t)((c << (3 - lg)) & 7u);
-                        if (P.tasks[i].kind == TASK_PSET) // by docID window range, ascending (tcost holds the first window)
-                                return kind_rank[TASK_PSET] * NB + (uint32_t)std::min<uint64_t>(tcost[i] / PSET_TASK_WINDOWS, NB - 1);
-                        return kind_rank[P.tasks[i].kind] * NB + (NB - 1 - (lg * 8 + frac));
-                };
-                std::vector<uint32_t> cnt(TASK_KINDS * NB + 1, 0);
-                std::vector<uint32_t> keys(n_tasks);
-                for (size_t i = 0; i < n_tasks; ++i)
-                        ++cnt[(keys[i] = key(i)) + 1];
                 uint32_t *const per_kernel[TASK_KINDS] = {&P.n_dense, &P.n_pset, &P.n_probe, &P.n_cand, &P.n_fused, &P.n_fused16, &P.n_fusedgen, &P.n_planes, &P.n_planes8};
-                for (uint32_t r = 0; r < TASK_KINDS; ++r)
-                        *per_kernel[r] = std::accumulate(cnt.begin() + 1 + r * NB, cnt.begin() + 1 + (r + 1) * NB, 0u);
-                for (size_t i = 1; i < cnt.size(); ++i)
-                        cnt[i] += cnt[i - 1];
-                for (size_t i = 0; i < n_tasks; ++i)
-                        P.sched[cnt[keys[i]]++] = (uint32_t)i;
-                for (size_t i = 0; i < (size_t)P.n_pset + P.n_probe; ++i) // (units of demoted tasks are simply never run)
-                        P.pset_sched[i] = unit_of_task[P.sched[P.n_dense + i]];
+                uint32_t at = 0;
+                for (uint32_t r = 0; r < TASK_KINDS; ++r) {
+                        const uint32_t before = at;
+                        for (uint32_t bk = r * SCHED_NB; bk < (r + 1) * SCHED_NB; ++bk)
+                                for (Frag &f : frags) {
+                                        const uint32_t c = f.hist[bk];
+                                        f.hist[bk] = at; // (count -> the fragment's first place in the bucket)
+                                        at += c;
+                                }
+                        *per_kernel[r] = at - before;
+                }
+                const uint32_t n_dense = P.n_dense, n_units_run = P.n_pset + P.n_probe;
+                run([&](unsigned k) {
+                        Frag &f = frags[k];
+                        for (size_t i = 0; i < f.tasks.size(); ++i) {
+                                const uint32_t pos = f.hist[f.keys[i]]++, ti = (uint32_t)(f.b_tasks + i);
+                                P.sched[pos] = ti;
+                                if (pos >= n_dense && pos - n_dense < n_units_run) // (a TASK_PSET / TASK_PROBE task: its unit record runs at the same place)
+                                        P.pset_sched[pos - n_dense] = unit_of_task[ti];
+                        }
+                });
         }
         P.sparse_cap = (P.sparse_cap + 63u) & ~63u;
         P.plan_ms[3] = ms_since(t0);
