@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define TRI_ABI_VERSION 6 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
+#define TRI_ABI_VERSION 7 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
                              4: tri_batch_info grew (term planes, k_planes), tri_batch_query_status, tri_comm_create_custom; 5: tri_encode_google_payloads;
                              6: tri_batch_info.create_ms / create_plan_ms / *_bound_bytes, options plane_max_bytes / plan_threads, tri_cbatch_query_status */
 
@@ -111,7 +111,7 @@ typedef struct tri_batch_info {
         uint64_t cand_needed_bytes;
         /* k_phrase (positional constraints over the match segments): its time, the hit bytes of the phrases' terms (their SURVEY §8(d) share of
          * algorithmic_bytes — no longer counted under cand_algorithmic_bytes), the queries that hold a phrase; rest_ms no longer includes it */
-        float phrase_ms, pad_;
+        float phrase_ms, tree_ms; /* tree_ms (ABI 7): the TASK_TREE kernels (k_tree.hpp) — until then part of rest_ms */
         uint64_t phrase_algorithmic_bytes;
         uint64_t phrase_queries;
         /* term planes: the head terms the batch's queries share are decoded ONCE per launch (k_term_planes, first kernel of the run) into
@@ -141,6 +141,10 @@ typedef struct tri_batch_info {
         float probe_ms;
         uint64_t pset_queries, pset_algorithmic_bytes, pset_bound_bytes;
         uint64_t probe_queries, probe_algorithmic_bytes, probe_bound_bytes;
+        /* TASK_TREE (ABI 7): the queries evaluated as set algebra over one bitmap per leaf (k_tree.hpp) — a multi-word phrase under OR / NOT /
+         * matchsome / <optional>, trees over more distinct terms than the truth-table kernel holds, CNFs of more than 16 terms; the bitmap
+         * scratch their leaves and match sets take (option tree_max_bytes bounds it: TRI_ERR_NOMEM, split the batch) */
+        uint64_t tree_queries, tree_scratch_bytes;
 } tri_batch_info;
 
 const char *tri_last_error(void);

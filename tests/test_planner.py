@@ -27,10 +27,13 @@ def check_plan(p, nq):
     s = p.s
     plan, tasks, sched = p.plan, p.tasks, p.sched
     # queries: plan order = query order; every lowered query knows its slot
-    assert np.all(np.diff(plan["qid"].astype(np.int64)) > 0)
+    # (a hidden phrase query — a phrase leaf of a TASK_TREE query — has a slot and tasks, and no caller query: qid = 0xffffffff)
+    vis = plan["qid"] != 0xFFFFFFFF
+    assert np.all(np.diff(plan["qid"][vis].astype(np.int64)) > 0)
     lowered = p.slot_of_query[:nq] != 0xFFFFFFFF
-    assert int(lowered.sum()) == s["n_plan"]
-    assert np.array_equal(plan["qid"], np.nonzero(lowered)[0]) and np.array_equal(p.slot_of_query[:nq][lowered], np.arange(s["n_plan"]))
+    assert int(lowered.sum()) == int(vis.sum()) and int((~vis).sum()) == s["n_tree_hidden"]
+    assert np.array_equal(plan["qid"][vis], np.nonzero(lowered)[0]) and np.array_equal(p.slot_of_query[:nq][lowered], np.nonzero(vis)[0])
+    assert np.array_equal(np.sort(p.tree_hidden), np.nonzero(~vis)[0])
     # tasks: consecutive per query, in plan order, covering [0, n) of the query's windows / tiles without gaps
     assert np.array_equal(plan["first_task"].astype(np.int64), np.concatenate([[0], np.cumsum(plan["ntasks"].astype(np.int64))[:-1]]))
     assert int(plan["ntasks"].sum()) == s["n_tasks"] and np.all(plan["ntasks"] >= 1)
@@ -54,13 +57,28 @@ def check_plan(p, nq):
     assert np.array_equal(tasks["out_off"][cand], q_off[cand] + tasks["begin"][cand].astype(np.uint64) * 8192)
     # schedule: a permutation, grouped by kernel in launch order, the per-kernel counts as reported
     assert np.array_equal(np.sort(sched), np.arange(s["n_tasks"], dtype=np.uint32))
-    counts = [s["n_dense"], s["n_pset"], s["n_probe"], s["n_cand"], s["n_fused"], s["n_fused16"], s["n_fusedgen"], s["n_planes"], s["n_planes8"]]
+    counts = [s["n_dense"], s["n_pset"], s["n_probe"], s["n_cand"], s["n_fused"], s["n_fused16"], s["n_fusedgen"], s["n_planes"], s["n_planes8"], s["n_tree"]]
     assert sum(counts) == s["n_tasks"]
     at = 0
     for kind, c in zip(HP.SCHED_ORDER, counts):
         assert np.all(tasks["kind"][sched[at : at + c]] == kind)
         at += c
-    assert s["dense_queries"] + s["pset_queries"] + s["probe_queries"] + s["cand_queries"] + s["fused_queries"] + s["planes_queries"] == s["n_plan"]
+    assert s["dense_queries"] + s["pset_queries"] + s["probe_queries"] + s["cand_queries"] + s["fused_queries"] + s["planes_queries"] + s["tree_queries"] == s["n_plan"]
+    # TASK_TREE: one task per query; a record of postfix nodes — children before parents, one root, every leaf with a row of its own kind;
+    # a phrase leaf names a hidden query that precedes the tree query in the plan
+    assert s["n_tree"] == s["tree_queries"] and np.all(np.diff(p.tree_terms.astype(np.int64)) > 0)
+    for sl in np.nonzero(kind_q == HP.TASK_TREE)[0][:300]:
+        assert plan["ntasks"][sl] == 1
+        nd = p.tree_nodes(sl)
+        assert 1 <= len(nd) <= 64 and nd["parent"][-1] == 0xFF and np.all(nd["parent"][:-1] > np.arange(len(nd) - 1))
+        for k, x in enumerate(nd):
+            if x["op"] == 0:  # TERM
+                assert p.tree_terms[x["row"]] == x["arg"]
+            elif x["op"] == 3:  # PHRASE
+                assert x["row"] >> 31 and p.tree_hidden[x["row"] & 0x7FFFFFFF] == x["arg"] < sl and not vis[x["arg"]] and plan["nphrases"][x["arg"]] == 1
+            else:
+                kids = [j for j in range(k) if (int(x["kids"]) >> j) & 1]
+                assert kids and all(nd["parent"][j] == k for j in kids) and sorted(nd["ord"][kids].tolist()) == list(range(len(kids)))
     # unit records (k_psets / k_probe): one per task of those kinds in run order, the task's own geometry, every probed term's row inline
     if s["n_pset"] + s["n_probe"]:
         units, us = p.units, p.unit_sched
@@ -123,12 +141,18 @@ def test_unsupported_shapes_and_malformed_programs(world):
     D, V, segs, hix = world
     import oracle_lib as O
 
-    texts = ["t0 t1", 't0 OR "t1 t2"', "t3 OR t4", "t0 OR (t1 t2) OR (t3 t4) OR (t5 t6) OR (t7 t8)"]
-    progs = [O.parse_query(t) for t in texts] * 700  # (enough queries for several fragments)
-    p = HP.HostPlan(hix[1], progs, T.FLAG_DOCUMENTS_ONLY, threads=4)
-    assert p.qstatus.tolist() == [0, -3, 0, -3] * 700 and p.s["unsupported_queries"] == 1400 and p.s["n_plan"] == 1400
-    check_plan(p, len(progs))
-    p.close()
+    big = " OR ".join(f"(t{2 * i} t{2 * i + 1})" for i in range(40))  # more than 64 nodes: still left out
+    texts = ["t0 t1", 't0 OR "t1 t2"', big, "t0 OR (t1 t2) OR (t3 t4) OR (t5 t6) OR (t7 t8)", '[t0, "t1 t2", "t2 t3 t4"]']
+    progs = [O.parse_query(t, some_min=2) for t in texts] * 700  # (enough queries for several fragments)
+    for flags, topk in ((T.FLAG_DOCUMENTS_ONLY, 0), (T.FLAG_ACCUMULATED_SCORE, 10), (T.FLAG_MATCHED_TERMS, 0)):
+        p = HP.HostPlan(hix[1], progs, flags, topk, threads=4)
+        assert p.qstatus.tolist() == [0, 0, -3, 0, 0] * 700 and p.s["unsupported_queries"] == 700
+        assert p.s["tree_queries"] == 2100 and p.s["n_tree_hidden"] == 2100 and p.s["n_plan"] == 2800 + 2100  # (three phrase leaves per five queries)
+        check_plan(p, len(progs))
+        p1 = HP.HostPlan(hix[1], progs, flags, topk, threads=1)
+        assert np.array_equal(p1.block, p.block)
+        p1.close()
+        p.close()
     bad = progs[:2000] + [np.array([T.tok(T.OP_AND, 2)], dtype=np.uint32)] + progs[:100]
     with pytest.raises(T.TrinityError, match="malformed"):
         HP.HostPlan(hix[1], bad, T.FLAG_DOCUMENTS_ONLY, threads=4)

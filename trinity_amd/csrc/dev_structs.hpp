@@ -83,7 +83,9 @@ constexpr uint32_t TASK_PSET = 7;      // docID windows of a query ALL of whose 
                                        // the expansion; same windows, same private output regions as TASK_DENSE (a docset-materialising kind, not a one-pass one)
 constexpr uint32_t TASK_PROBE = 8;     // candidate tiles of ONE lead list tested against lists that all have a term plane (k_probe.hpp): a wave decodes 64 lead
                                        // blocks into registers and probes the planes — same tiles, same private output regions as TASK_CAND
-constexpr uint32_t TASK_KINDS = 9;
+constexpr uint32_t TASK_TREE = 9;      // ANY tree — multi-word phrases under OR / NOT / matchsome, more distinct terms than a truth table holds, CNFs wider than
+                                       // MAX_QTERMS — evaluated over whole-corpus bitmaps, one per leaf (k_tree.hpp); one task per query; tile_end = its chunks
+constexpr uint32_t TASK_KINDS = 10;
 // A TASK_PSET task as k_psets reads it: ONE 64-byte record instead of the sched -> task -> query -> qterms / qplane chain of dependent loads
 // (four memory round trips before a two-window task's first plane word: measured, they were most of the kernel's fixed cost).  Written by
 // the planner next to the DevTask (which the host keeps reading for the result read-back); units[] is indexed like the schedule's TASK_PSET
@@ -103,6 +105,25 @@ struct DevPsetUnit { // (also the record of a TASK_PROBE task: w_begin / w_end a
         uint32_t row[PSET_INLINE_TERMS]; // ... and the terms' plane rows
 };
 static_assert(sizeof(DevPsetUnit) == 64, "one cache-line half per unit");
+// ---- TASK_TREE: the query tree as the kernels read it (k_tree.hpp).  A record in the plan's tree[] words (DevQuery::fused_idx = its first word):
+//      TREE_HDR_WORDS header words { nnodes, 0... }, then nnodes DevTreeNode in POSTFIX order (children before parents, the root last)
+constexpr uint32_t TREE_MAX_NODES = 64;     // node values and "an iterator sits on the document" flags are bit sets in a 64-bit word
+constexpr uint32_t TREE_HDR_WORDS = 8;
+constexpr uint32_t TREE_CHUNK_WORDS = 2048; // bitmap words (x 32 documents) a workgroup of the tree kernels takes
+constexpr uint32_t TREE_ROW_PHRASE = 0x80000000u; // DevTreeNode::row: a one-plane row of the batch's phrase rows (else: a PL_PLANES-plane row of its tree rows)
+struct DevTreeNode {
+        uint8_t op;     // TRI_OP_TERM (a term leaf), TRI_OP_PHRASE (a multi-word phrase leaf), TRI_OP_AND / OR / NOT / OPT / SOME
+        uint8_t parent; // node index; the root: 0xff
+        uint8_t ord;    // position among the parent's children (NOT / OPT: 0 = the required / main side)
+        uint8_t thr;    // SOME: the threshold
+        uint32_t arg;   // term leaf: the term; phrase leaf: the plan slot of the hidden query that evaluates the phrase
+        uint32_t row;   // leaf: its bitmap row
+        uint32_t score; // leaf: its scorer (index into the query's sterms / sweights slice), 0xffffffff: none (an excluded side scores nothing)
+        uint32_t rmask; // leaf, default mode: the reportable terms (bits into the query's sterms slice) reported where the leaf sits on the document
+        uint8_t kid0, kid1, pad0, pad1; // NOT / OPT: the two sides
+        uint64_t kids;  // inner node: bit k = node k is a child
+};
+static_assert(sizeof(DevTreeNode) == 32, "eight words per node");
 // the one-pass kinds (decode -> match -> score -> top-K inside one kernel: k_fused / k_planes); the others materialise docID sets
 TRI_HD constexpr bool task_onepass(const uint32_t kind) { return kind >= TASK_FUSED && kind <= TASK_PLANES8; }
 

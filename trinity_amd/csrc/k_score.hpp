@@ -318,6 +318,8 @@ __global__ __launch_bounds__(AND_WG) void k_topk_merge(const DevQuery *__restric
         const uint32_t tid = threadIdx.x;
         for (uint32_t slot = blockIdx.x; slot < nq; slot += gridDim.x) {
                 const DevQuery q = plan[slot];
+                if (q.qid == 0xffffffffu) // (a hidden phrase query of a TASK_TREE query: no caller query, no row)
+                        continue;
                 tk.n = 0;
                 tk.full = 0;
                 __syncthreads();
@@ -349,6 +351,8 @@ __global__ void k_query_counts(const DevQuery *__restrict__ plan, const uint32_t
         if (s >= nq)
                 return;
         const DevQuery q = plan[s];
+        if (q.qid == 0xffffffffu) // (a hidden phrase query of a TASK_TREE query)
+                return;
         uint64_t c = 0;
         for (uint32_t t = 0; t < q.ntasks; ++t)
                 c += counts_by_task[q.first_task + t];

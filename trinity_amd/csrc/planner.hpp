@@ -37,6 +37,7 @@ struct tri_options {
                                  // measured, step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the planes' build grows with it)
         uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs 3 bitmaps over the docID space and one decode per run)
         uint64_t plan_threads = 0;             // host threads tri_batch_create plans with; 0: up to 16, one per 512 queries
+        uint64_t tree_max_bytes = 16ull << 30; // scratch budget of a batch's TASK_TREE queries (a PL_PLANES-plane row per distinct term leaf, a plane per phrase leaf and per query)
         uint64_t probe_max_blocks = 0;         // > 0: a lead list of at most this many blocks against lists that all have planes runs in k_probe (a wave per task) instead of
                                                // k_and's candidate tiles.  Off by default — measured at cfg2 (step ms / k_probe / k_and): 0: 2.14 / - / 0.78; 64: 2.25 / 0.15 / 0.75;
                                                // 256: 2.26 / 0.22 / 0.70; 1024: 2.35 / 0.41 / 0.59; all: 2.55 / 0.82 / 0.41 — k_and's time is its tail, not its task count
@@ -96,6 +97,12 @@ struct BatchPlan {
         Span<uint32_t> pset_sched;  // ... and the order they are run in, as unit indices: [0, n_pset) TASK_PSET, docID window range by window range; then
                                     // the n_probe TASK_PROBE ones, heaviest first
         size_t off_units = 0, off_pset_sched = 0;
+        Span<uint32_t> tree;        // TASK_TREE records: TREE_HDR_WORDS header words + DevTreeNode per node (DevQuery::fused_idx: the record's first word)
+        Span<uint32_t> tree_terms;  // the distinct term leaves of the batch's TASK_TREE queries, ascending: term -> row of the batch's tree rows
+        Span<uint32_t> tree_hidden; // hidden phrase queries: their plan slots (position: the row of the batch's phrase rows)
+        size_t off_tree = 0, off_tree_terms = 0, off_tree_hidden = 0;
+        uint32_t n_tree = 0;        // TASK_TREE tasks (the last section of sched)
+        uint64_t tree_queries = 0, tree_scratch_bytes = 0;
         size_t off_plan = 0, off_qterms = 0, off_tasks = 0, off_sched = 0, off_fused = 0, off_qplane = 0, off_plane_terms = 0, off_sterms = 0, off_sweights = 0,
                off_phrases = 0, off_pterms = 0, off_ptasks = 0;
         std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: can never match)
@@ -124,7 +131,7 @@ namespace trip {
         constexpr size_t SECTION_ALIGN = 64;
         constexpr uint32_t SCHED_NB = 64 * 4; // schedule buckets per kernel: cost octave + 2 bits
         // launch order of the task kinds: TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, then the one-pass kinds as numbered
-        constexpr uint32_t SCHED_RANK[TASK_KINDS] = {3, 0, 4, 5, 6, 7, 8, 1, 2};
+        constexpr uint32_t SCHED_RANK[TASK_KINDS] = {3, 0, 4, 5, 6, 7, 8, 1, 2, 9};
         inline uint32_t sched_key(const uint32_t kind, const uint64_t cost) {
                 if (kind == TASK_PSET) // by docID window range, ascending (`cost` holds the first window)
                         return SCHED_RANK[TASK_PSET] * SCHED_NB + (uint32_t)std::min<uint64_t>(cost / PSET_TASK_WINDOWS, SCHED_NB - 1);
@@ -410,6 +417,10 @@ namespace trip {
                 uint32_t nlead;
                 int32_t fz;   // index into the fragment's slot maps (-1: none): may run in one pass (k_fused / k_planes)
                 bool truth;   // a general tree: runs as TASK_FUSED whatever its density (there is no other path for it)
+                bool tree;    // ... one the truth table does not hold: TASK_TREE (q.fused_idx: its record in the fragment's treepool; tree_ub: its matches at most)
+                bool hidden;  // a phrase evaluated for a TASK_TREE query of the batch (no caller query of its own); hidden_ord: which of the fragment's
+                uint64_t tree_ub;
+                uint32_t hidden_ord;
                 // execution class (second half of the first pass)
                 uint64_t sumdf, lead_docs;
                 uint32_t last_doc; // no match beyond the (required) group whose lists end first
@@ -447,13 +458,17 @@ namespace trip {
                 std::vector<FUse> fuses;
                 std::vector<uint64_t> benefit; // per eligible term (by df rank): postings of decoding the batch's uses save
                 std::vector<uint32_t> keys, hist; // (fill pass) per task its schedule bucket; tasks per bucket
+                std::vector<uint32_t> treepool;   // TASK_TREE records (DevQuery::fused_idx: a record's first word)
+                std::vector<uint32_t> tree_terms; // the term leaves of the fragment's TASK_TREE queries
+                uint32_t n_hidden = 0;            // hidden phrase queries (Tmp::hidden_ord)
+                uint64_t tree_queries = 0;
                 uint64_t off = 0;
                 uint32_t sparse_cap = 0;
                 uint64_t term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, cand_needed = 0;
                 uint64_t dense_queries = 0, pset_queries = 0, probe_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, term_bytes_pset = 0, term_bytes_probe = 0;
                 uint64_t probe_demoted = 0, probe_demoted_bytes = 0; // (fill pass) queries whose probes found no plane: candidate tiles after all
                 // bases in the batch's arrays (settled between the passes)
-                size_t b_plan = 0, b_qterms = 0, b_sterms = 0, b_phrases = 0, b_pterms = 0, b_tasks = 0, b_fused = 0, b_ptasks = 0, b_units = 0;
+                size_t b_plan = 0, b_qterms = 0, b_sterms = 0, b_phrases = 0, b_pterms = 0, b_tasks = 0, b_fused = 0, b_ptasks = 0, b_units = 0, b_tree = 0, b_hidden = 0;
                 uint64_t b_off = 0;
                 int rc = TRI_OK;
                 std::string err;
@@ -470,6 +485,7 @@ namespace trip {
                 bool plane_ok(uint32_t term) const { return ix.df_rank[term] < n_ok; }
                 // settled after the first pass
                 uint64_t planes_split = 2, fused_task_cost = 0;
+                uint32_t plw = 0; // words of a bitmap over the docID space (BatchPlan::plw)
                 // the ScorerWeight contribution of one term (IndexSourceTermsScorer::new_scorer_weight sums it over a phrase's terms):
                 // BM25 similarity.h:179-181 (float math), TF-IDF :85-87 (double), Trivial has none
                 double term_weight(const uint32_t df) const {
@@ -491,26 +507,25 @@ namespace trip {
                 }
         };
 
-        // ---- first pass: lower the queries [q_lo, q_hi) of the batch into `f` and class them
-        inline int lower_range(const Ctx &C, Frag &f) {
+        inline int lower_tree(const Ctx &C, Frag &f, size_t qi, const uint32_t *prog, uint32_t plen, const double *wq, int root);
+
+        // ---- first pass, one query: the program prog[0, plen) of caller query qi lowered into `f` and classed.  wq: the ScorerWeights of the
+        //      program's tokens (or null); hidden: a phrase that a TASK_TREE query of the batch reads as a leaf (lower_tree) — it has a plan
+        //      slot and tasks like any phrase query, and no caller query of its own
+        inline int lower_query(const Ctx &C, Frag &f, const size_t qi, const uint32_t *prog, const uint32_t plen, const double *wq, const bool hidden) {
                 const HostIndex &ix = C.ix;
                 const PlanInput &in = C.in;
                 const tri_options &opt = C.env.opt;
-                const bool scored = C.scored, rich = C.rich;
+                const bool scored = C.scored, rich = C.rich && !hidden;
                 const uint32_t mode = C.mode, topk = in.topk;
-                const double *weights = in.weights;
                 Scratch &S = f.S;
-                for (size_t qi = f.q_lo; qi < f.q_hi; ++qi) {
-                        const tri_query &tq = in.queries[qi];
-                        if ((uint64_t)tq.prog_off + tq.prog_len > in.prog_len || !tq.prog_len)
-                                return herr(f.err, TRI_ERR_INVALID, "query %zu: program slice out of range", qi);
-                        const uint32_t *prog = in.prog + tq.prog_off;
-                        const int root = parse_program(ix, prog, tq.prog_len, S);
+                {
+                        const int root = parse_program(ix, prog, plen, S);
                         if (root < 0)
                                 return herr(f.err, TRI_ERR_INVALID, "query %zu: malformed postfix program", qi);
                         const std::vector<PNode> &nodes = S.nodes;
                         if (nodes[root].empty)
-                                continue; // matches nothing (compiles to constfalse in the reference)
+                                return TRI_OK; // matches nothing (compiles to constfalse in the reference)
                         // ---- conjunctive normal form over terms: AND of (term | OR of terms); a root OR is one group
                         auto &gt = S.gt;
                         auto &gs = S.gs;
@@ -545,9 +560,9 @@ namespace trip {
                                                         gs.push_back((uint32_t)gt.size());
                                                 }
                                         }
-                                        if (weights) // the PHRASE token's own ScorerWeight, when the caller supplies weights (by token position: two phrases
-                                                     // that start with the same term keep their own weights)
-                                                ph.weight = weights[tq.prog_off + g.tok];
+                                        if (wq) // the PHRASE token's own ScorerWeight, when the caller supplies weights (by token position: two phrases
+                                                // that start with the same term keep their own weights)
+                                                ph.weight = wq[g.tok];
                                         S.qphrases.push_back(ph);
                                         return true;
                                 }
@@ -645,12 +660,10 @@ namespace trip {
                         TruthPlan tp;
                         bool truth = false;
                         if (!ok || !ngroups()) {
-                                // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp)
-                                if (!build_truth(S, root, tp)) {
-                                        f.left_out.push_back(qi);
-                                        herr(f.err, TRI_ERR_UNSUPPORTED, "query %zu: lowered so far: AND of terms / phrases / OR-of-terms groups, a root OR of terms, NOT (at the root or under AND) of a term or an OR of terms, <optional> terms under AND; and — no multi-word phrase, <= %u distinct terms, <= %u scored leaves — any tree of AND / OR / NOT / <optional> / matchsome", qi, FUS_MAX_SLOTS, FUS_MAX_LEAVES);
-                                        continue;
-                                }
+                                // not a CNF of terms: a general tree over <= FUS_MAX_SLOTS distinct terms runs off a truth table (k_fused.hpp);
+                                // anything else — a multi-word phrase below the root conjunction, more terms or leaves — over leaf bitmaps (k_tree.hpp)
+                                if (!build_truth(S, root, tp))
+                                        return hidden ? herr(f.err, TRI_ERR_INVALID, "query %zu: a phrase leaf that is not a phrase", qi) : lower_tree(C, f, qi, prog, plen, wq, root);
                                 truth = true;
                                 gt = tp.slots; // (one group of every slot: the bookkeeping below — term list, cost, output bound — sees a union)
                                 gs.assign({0u, (uint32_t)gt.size()});
@@ -689,18 +702,15 @@ namespace trip {
                                 for (size_t i = 0; i < u.size(); ++i)
                                         uniq.push_back(u[i] | (i == 0 ? (QT_GROUP | QT_NOT) : 0u));
                         }
-                        if (uniq.size() > MAX_QTERMS) {
-                                f.left_out.push_back(qi);
-                                herr(f.err, TRI_ERR_UNSUPPORTED, "query %zu: more than %u terms", qi, MAX_QTERMS);
-                                continue;
-                        }
+                        if (uniq.size() > MAX_QTERMS) // a conjunctive normal form wider than the CNF kernels' term lists: the tree path
+                                return hidden ? herr(f.err, TRI_ERR_INVALID, "query %zu: a phrase of more than %u terms", qi, MAX_QTERMS) : lower_tree(C, f, qi, prog, plen, wq, root);
                         // (default mode: the reportable terms — every postings iterator collect_doc_matching_terms can reach (queryexec_ctx.cpp:382-520):
                         //  group members and phrase terms, not the excluded side of a NOT —, distinct, in order of first appearance; counted before
                         //  anything of the query is recorded, so that a query with too many of them can still be left out cleanly)
                         auto &rt = S.rt;
                         rt.clear();
                         if (rich) {
-                                for (uint32_t pi = 0; pi < tq.prog_len; ++pi) {
+                                for (uint32_t pi = 0; pi < plen; ++pi) {
                                         const uint32_t tok = prog[pi];
                                         if ((tok >> 28) != TRI_OP_TERM)
                                                 continue;
@@ -713,7 +723,7 @@ namespace trip {
                                 if (rt.size() > 16) {
                                         f.left_out.push_back(qi);
                                         herr(f.err, TRI_ERR_UNSUPPORTED, "query %zu: more than 16 reportable terms", qi);
-                                        continue;
+                                        return TRI_OK;
                                 }
                         }
                         const uint32_t g0 = gorder[0];
@@ -750,7 +760,7 @@ namespace trip {
                                 // inside a phrase or on an excluded side has another token with another weight)
                                 for (size_t li = 0; li < S.leaves.size(); ++li) {
                                         f.sterms.push_back(S.leaves[li]);
-                                        f.sweights.push_back(weights ? weights[tq.prog_off + S.leaf_tok[li]] : C.term_weight(ix.terms[S.leaves[li]].documents));
+                                        f.sweights.push_back(wq ? wq[S.leaf_tok[li]] : C.term_weight(ix.terms[S.leaves[li]].documents));
                                 }
                                 t.q.nscore = (uint32_t)S.leaves.size();
                         }
@@ -933,8 +943,265 @@ namespace trip {
                                                 f.fused_postings += ix.terms[z.term[sidx]].documents;
                                 }
                         }
+                        t.hidden = hidden;
                         f.tmp.push_back(t);
                 }
+                return TRI_OK;
+        }
+
+        // ---- first pass: lower the queries [q_lo, q_hi) of the batch into `f` and class them
+        inline int lower_range(const Ctx &C, Frag &f) {
+                const PlanInput &in = C.in;
+                for (size_t qi = f.q_lo; qi < f.q_hi; ++qi) {
+                        const tri_query &tq = in.queries[qi];
+                        if ((uint64_t)tq.prog_off + tq.prog_len > in.prog_len || !tq.prog_len)
+                                return herr(f.err, TRI_ERR_INVALID, "query %zu: program slice out of range", qi);
+                        if (const int rc = lower_query(C, f, qi, in.prog + tq.prog_off, tq.prog_len, in.weights ? in.weights + tq.prog_off : nullptr, false))
+                                return rc;
+                }
+                return TRI_OK;
+        }
+
+
+        // ---- a query the CNF lowering and the truth table leave: the tree itself goes to the device (TASK_TREE, k_tree.hpp).  Every leaf
+        //      becomes a bitmap over the docID space — a term's plane row (k_term_planes, once per run for every tree query of the batch that
+        //      names it), a multi-word phrase's matches (a HIDDEN query of the same batch: the conjunction of its terms + the positional check,
+        //      through the kernels every phrase query takes; its match list is scattered into the row) —, the inner nodes are word-wise algebra
+        //      (DocsSetIterators::Conjuction / Disjunction / DisjunctionSome / Filter / Optional, docset_iterators.cpp:226-677, as set operations),
+        //      and scores / reported terms follow the reference's recursion over the iterators that sit on a match
+        //      (docset_iterators_scorers.cpp:38-228, queryexec_ctx.cpp:382-520) document by document.
+        inline int lower_tree(const Ctx &C, Frag &f, const size_t qi, const uint32_t *prog, const uint32_t plen, const double *wq, const int root) {
+                const HostIndex &ix = C.ix;
+                Scratch &S = f.S;
+                auto leave_out = [&](const char *why) {
+                        f.left_out.push_back(qi);
+                        herr(f.err, TRI_ERR_UNSUPPORTED, "query %zu: %s", qi, why);
+                        return TRI_OK;
+                };
+                struct PhraseLeaf {
+                        uint32_t node, t0, n, tok;
+                };
+                std::vector<DevTreeNode> tn;
+                std::vector<PhraseLeaf> phl;
+                std::vector<uint32_t> phterms, leaf_tok; // phrase leaves' terms; per node, the program token of a leaf
+                std::vector<uint8_t> positive;           // per node: a leaf an iterator of the tree can report (not under an excluded side)
+                bool ok = true;
+                // postfix emission (children first); returns the node's index
+                std::function<int(int, bool)> emit = [&](const int ni, const bool pos) -> int {
+                        const PNode x = S.nodes[ni];
+                        const int *kd = S.kids(x);
+                        DevTreeNode d{};
+                        d.parent = 0xff;
+                        d.score = 0xffffffffu;
+                        uint32_t tok = x.tok;
+                        if (x.op == TRI_OP_TERM || (x.op == TRI_OP_PHRASE && x.kid_n == 1)) {
+                                const PNode &t = x.op == TRI_OP_TERM ? x : S.nodes[kd[0]];
+                                d.op = TRI_OP_TERM;
+                                d.arg = t.term;
+                                tok = t.tok;
+                                if (t.term >= ix.terms.size() || !ix.terms[t.term].documents)
+                                        ok = false; // (parse_program drops what can never match: not reached)
+                        } else if (x.op == TRI_OP_PHRASE) {
+                                d.op = TRI_OP_PHRASE;
+                                phl.push_back({(uint32_t)tn.size(), (uint32_t)phterms.size(), x.kid_n, x.tok});
+                                for (uint32_t k = 0; k < x.kid_n; ++k)
+                                        phterms.push_back(S.nodes[kd[k]].term);
+                        } else {
+                                d.op = (uint8_t)x.op;
+                                d.thr = x.op == TRI_OP_SOME ? (uint8_t)std::min<uint32_t>(x.term, 255) : 0;
+                                std::vector<int> kids;
+                                for (uint32_t k = 0; k < x.kid_n && ok; ++k)
+                                        kids.push_back(emit(kd[k], pos && !(x.op == TRI_OP_NOT && k == 1)));
+                                if (!ok || tn.size() + 1 > TREE_MAX_NODES)
+                                        return ok = false, -1;
+                                for (size_t k = 0; k < kids.size(); ++k) {
+                                        d.kids |= 1ull << kids[k];
+                                        tn[kids[k]].parent = (uint8_t)tn.size();
+                                        tn[kids[k]].ord = (uint8_t)k;
+                                }
+                                if (x.op == TRI_OP_NOT || x.op == TRI_OP_OPT)
+                                        d.kid0 = (uint8_t)kids[0], d.kid1 = (uint8_t)kids[1];
+                        }
+                        if (tn.size() + 1 > TREE_MAX_NODES)
+                                return ok = false, -1;
+                        tn.push_back(d);
+                        leaf_tok.push_back(tok);
+                        positive.push_back(pos && (d.op == TRI_OP_TERM || d.op == TRI_OP_PHRASE));
+                        return (int)tn.size() - 1;
+                };
+                emit(root, true);
+                if (!ok)
+                        return leave_out("a tree of more than 64 nodes");
+                const uint32_t nn = (uint32_t)tn.size();
+                if (C.scored && std::find(positive.begin(), positive.end(), 1) == positive.end())
+                        return leave_out("a tree without a scoring leaf");
+                // the value of every node for a document that holds none of the leaves, and an upper bound of a node's matches
+                uint64_t ub_root = 0;
+                {
+                        uint64_t val = 0;
+                        std::vector<uint64_t> ub(nn, 0);
+                        for (uint32_t i = 0; i < nn; ++i) {
+                                const DevTreeNode &d = tn[i];
+                                bool v = false;
+                                uint64_t u = 0, sum = 0, mn = UINT64_MAX;
+                                for (uint32_t k = 0; k < i; ++k)
+                                        if ((d.kids >> k) & 1ull)
+                                                sum += ub[k], mn = std::min(mn, ub[k]);
+                                switch (d.op) {
+                                        case TRI_OP_TERM:
+                                                u = ix.terms[d.arg].documents;
+                                                break;
+                                        case TRI_OP_PHRASE:
+                                                u = UINT64_MAX;
+                                                for (const PhraseLeaf &p : phl)
+                                                        if (p.node == i)
+                                                                for (uint32_t k = 0; k < p.n; ++k)
+                                                                        u = std::min<uint64_t>(u, ix.terms[phterms[p.t0 + k]].documents);
+                                                break;
+                                        case TRI_OP_AND:
+                                                v = (val & d.kids) == d.kids;
+                                                u = mn;
+                                                break;
+                                        case TRI_OP_OR:
+                                                v = (val & d.kids) != 0;
+                                                u = sum;
+                                                break;
+                                        case TRI_OP_SOME:
+                                                v = (uint32_t)__builtin_popcountll(val & d.kids) >= d.thr;
+                                                u = sum;
+                                                break;
+                                        case TRI_OP_NOT:
+                                                v = ((val >> d.kid0) & 1ull) && !((val >> d.kid1) & 1ull);
+                                                u = ub[d.kid0];
+                                                break;
+                                        case TRI_OP_OPT:
+                                                v = (val >> d.kid0) & 1ull;
+                                                u = ub[d.kid0];
+                                                break;
+                                }
+                                val |= (uint64_t)v << i;
+                                ub[i] = std::min<uint64_t>(u, ix.max_doc);
+                        }
+                        if ((val >> (nn - 1)) & 1ull)
+                                return leave_out("a tree that matches documents holding none of its terms cannot be enumerated from postings");
+                        if (ub[nn - 1] > 0xffffffffull)
+                                return leave_out("a tree of more than 2^32 possible matches");
+                        ub_root = ub[nn - 1];
+                }
+                // the reportable terms (default mode): what the positive leaves' iterators are, distinct, in order of first appearance in the program
+                std::vector<uint32_t> rt;
+                if (C.rich) {
+                        auto is_pos = [&](uint32_t term) {
+                                for (uint32_t i = 0; i < nn; ++i)
+                                        if (positive[i] && tn[i].op == TRI_OP_TERM && tn[i].arg == term)
+                                                return true;
+                                for (const PhraseLeaf &p : phl)
+                                        if (positive[p.node])
+                                                for (uint32_t k = 0; k < p.n; ++k)
+                                                        if (phterms[p.t0 + k] == term)
+                                                                return true;
+                                return false;
+                        };
+                        for (uint32_t pi = 0; pi < plen; ++pi) {
+                                if ((prog[pi] >> 28) != TRI_OP_TERM)
+                                        continue;
+                                const uint32_t x = prog[pi] & 0x0fffffffu;
+                                if (std::find(rt.begin(), rt.end(), x) == rt.end() && is_pos(x))
+                                        rt.push_back(x);
+                        }
+                        if (rt.size() > 16)
+                                return leave_out("more than 16 reportable terms");
+                        auto bit_of = [&](uint32_t term) { return 1u << (uint32_t)(std::find(rt.begin(), rt.end(), term) - rt.begin()); };
+                        for (uint32_t i = 0; i < nn; ++i)
+                                if (positive[i] && tn[i].op == TRI_OP_TERM)
+                                        tn[i].rmask = bit_of(tn[i].arg);
+                        for (const PhraseLeaf &p : phl)
+                                if (positive[p.node])
+                                        for (uint32_t k = 0; k < p.n; ++k)
+                                                tn[p.node].rmask |= bit_of(phterms[p.t0 + k]);
+                }
+                if (!phl.empty() && ix.codec == TRI_CODEC_LUCENE && !ix.has_hdir)
+                        return herr(f.err, TRI_ERR_INVALID, "query %zu: phrase over a LUCENE segment that was uploaded without hits.data", qi);
+                // ---- the phrase leaves: one hidden query each (S is reused by their lowering: nothing of this query's parse is read below)
+                std::vector<double> pweight(phl.size(), 0.0);
+                for (size_t pi = 0; pi < phl.size(); ++pi) {
+                        const PhraseLeaf &p = phl[pi];
+                        std::vector<uint32_t> hp;
+                        std::vector<double> hw;
+                        for (uint32_t k = 0; k < p.n; ++k)
+                                hp.push_back((TRI_OP_TERM << 28) | phterms[p.t0 + k]);
+                        hp.push_back((TRI_OP_PHRASE << 28) | p.n);
+                        if (wq) {
+                                hw.assign(p.n + 1, 0.0);
+                                hw[p.n] = wq[p.tok];
+                        }
+                        const size_t before = f.tmp.size(), lo_before = f.left_out.size();
+                        if (const int rc = lower_query(C, f, qi, hp.data(), (uint32_t)hp.size(), wq ? hw.data() : nullptr, true))
+                                return rc;
+                        if (f.tmp.size() != before + 1 || f.left_out.size() != lo_before) {
+                                f.left_out.resize(lo_before);
+                                return leave_out("a phrase leaf the planner does not lower");
+                        }
+                        Tmp &h = f.tmp.back();
+                        h.hidden_ord = f.n_hidden++;
+                        tn[p.node].arg = (uint32_t)before;                 // (fragment-relative plan slot: rebased in the fill pass)
+                        tn[p.node].row = TREE_ROW_PHRASE | h.hidden_ord;   // (likewise)
+                        pweight[pi] = f.phrases[h.q.phrase_base].weight;
+                }
+                // ---- the query itself
+                Tmp t{};
+                t.tree = true;
+                t.tree_ub = ub_root;
+                t.fz = -1;
+                t.q.qid = (uint32_t)qi;
+                t.q.term_base = (uint32_t)f.qterms.size();
+                t.q.phrase_base = (uint32_t)f.phrases.size();
+                t.q.score_base = (uint32_t)f.sterms.size();
+                t.cost = ub_root;
+                std::vector<uint32_t> seen;
+                auto once = [&](uint32_t term) {
+                        if (std::find(seen.begin(), seen.end(), term) != seen.end())
+                                return false;
+                        seen.push_back(term);
+                        return true;
+                };
+                for (uint32_t i = 0; i < nn; ++i)
+                        if (tn[i].op == TRI_OP_TERM) {
+                                f.tree_terms.push_back(tn[i].arg);
+                                if (once(tn[i].arg))
+                                        f.term_bytes += ix.docbytes[tn[i].arg];
+                        }
+                if (C.rich) {
+                        for (uint32_t x : rt) {
+                                f.sterms.push_back(x);
+                                f.term_bytes += ix.hitbytes[x];
+                        }
+                        t.q.nscore = (uint32_t)rt.size();
+                        f.rich_R = std::max<uint32_t>(f.rich_R, t.q.nscore);
+                        f.rich_allow = true;
+                } else if (C.scored) {
+                        // one scorer per positive leaf, summed in tree order (docset_iterators_scorers.cpp:38-228)
+                        for (uint32_t i = 0; i < nn; ++i) {
+                                if (!positive[i])
+                                        continue;
+                                tn[i].score = t.q.nscore++;
+                                if (tn[i].op == TRI_OP_TERM) {
+                                        f.sterms.push_back(tn[i].arg);
+                                        f.sweights.push_back(wq ? wq[leaf_tok[i]] : C.term_weight(ix.terms[tn[i].arg].documents));
+                                } else { // (a phrase leaf's score comes with its hidden query's matches — k_phrase; the slot keeps the arrays parallel)
+                                        size_t pi = 0;
+                                        while (phl[pi].node != i)
+                                                ++pi;
+                                        f.sterms.push_back(phterms[phl[pi].t0]);
+                                        f.sweights.push_back(pweight[pi]);
+                                }
+                        }
+                }
+                t.q.fused_idx = (uint32_t)f.treepool.size();
+                f.treepool.resize(f.treepool.size() + TREE_HDR_WORDS + nn * (sizeof(DevTreeNode) / 4), 0u);
+                f.treepool[t.q.fused_idx] = nn;
+                memcpy(&f.treepool[t.q.fused_idx + TREE_HDR_WORDS], tn.data(), nn * sizeof(DevTreeNode));
+                f.tmp.push_back(t);
                 return TRI_OK;
         }
 
@@ -950,6 +1217,17 @@ namespace trip {
                 for (size_t ti = 0; ti < f.tmp.size(); ++ti) {
                         Tmp &t = f.tmp[ti];
                         const uint32_t slot = (uint32_t)ti;
+                        if (t.tree) { // one task: its chunks of the docID space are the kernels' grid, its region the bound of the tree's matches
+                                t.q.out_off = off;
+                                t.q.out_cap = (uint32_t)t.tree_ub;
+                                t.q.first_task = (uint32_t)f.tasks.size();
+                                t.q.ntasks = 1;
+                                f.tcost.push_back(std::max<uint64_t>(1, t.tree_ub));
+                                f.tasks.push_back({slot, 0, (C.plw + TREE_CHUNK_WORDS - 1) / TREE_CHUNK_WORDS, TASK_TREE, off});
+                                off += t.q.out_cap;
+                                ++f.tree_queries;
+                                continue;
+                        }
                         const uint32_t *qt = &f.qterms[t.q.term_base];
                         const DevTerm &lead = ix.terms[qt[0] & QT_TERM];
                         const uint32_t nlead = t.nlead;
@@ -1202,6 +1480,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         // ---- which terms may get a plane: an indexed list of at least docs_cnt / plane_div documents, the longest lists first up to the
         //      scratch budget (a plane row is three bitmaps over the docID space)
         P.plw = ((ix.max_doc >> 17) + 2u) * (SPAN_BITS / 32u); // whole bitmap windows (k_and_dense reads SPAN_WORDS at a time) + a spare one
+        C.plw = P.plw;
         if (opt.planes && opt.plane_div && !ix.df_sorted.empty()) {
                 const uint64_t min_df = std::max<uint64_t>(1, ix.info.docs_cnt / opt.plane_div);
                 // df_sorted descends: the first rank whose list is too short
@@ -1277,13 +1556,18 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 return rc;
         P.plan_ms[1] = ms_since(t0);
         // ---- the fragments' places in the batch's arrays; sums
-        size_t n_plan = 0, n_qterms = 0, n_sterms = 0, n_phrases = 0, n_pterms = 0, n_tasks = 0, n_fused = 0, n_ptasks = 0, n_units = 0;
+        size_t n_plan = 0, n_qterms = 0, n_sterms = 0, n_phrases = 0, n_pterms = 0, n_tasks = 0, n_fused = 0, n_ptasks = 0, n_units = 0, n_treewords = 0, n_hidden = 0;
+        std::vector<uint32_t> tree_terms;
         uint64_t off = 0;
         std::vector<uint64_t> benefit(C.n_ok, 0);
         for (Frag &f : frags) {
                 f.b_plan = n_plan, f.b_qterms = n_qterms, f.b_sterms = n_sterms, f.b_phrases = n_phrases, f.b_pterms = n_pterms, f.b_tasks = n_tasks, f.b_fused = n_fused,
                 f.b_ptasks = n_ptasks, f.b_off = off, f.b_units = n_units;
                 n_units += f.units.size();
+                f.b_tree = n_treewords, f.b_hidden = n_hidden;
+                n_treewords += f.treepool.size(), n_hidden += f.n_hidden;
+                tree_terms.insert(tree_terms.end(), f.tree_terms.begin(), f.tree_terms.end());
+                P.tree_queries += f.tree_queries;
                 n_plan += f.tmp.size(), n_qterms += f.qterms.size(), n_sterms += f.sterms.size(), n_phrases += f.phrases.size(), n_pterms += f.pterms.size(),
                         n_tasks += f.tasks.size(), n_fused += f.fused.size(), n_ptasks += f.ptasks.size(), off += f.off;
                 P.term_bytes += f.term_bytes, P.term_bytes_phrase_hits += f.term_bytes_phrase_hits, P.term_bytes_dense += f.term_bytes_dense,
@@ -1307,6 +1591,12 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         if (n_qterms > 0xfffffff0ull || n_sterms > 0xfffffff0ull || n_tasks > 0xfffffff0ull || n_pterms > 0xfffffff0ull)
                 return herr(err, TRI_ERR_UNSUPPORTED, "tri_batch_create: the batch exceeds 2^32 terms or tasks: split it");
         P.out_capacity = off;
+        std::sort(tree_terms.begin(), tree_terms.end());
+        tree_terms.erase(std::unique(tree_terms.begin(), tree_terms.end()), tree_terms.end());
+        P.tree_scratch_bytes = ((uint64_t)tree_terms.size() * PL_PLANES + n_hidden + P.tree_queries) * P.plw * 4;
+        if (P.tree_scratch_bytes > opt.tree_max_bytes)
+                return herr(err, TRI_ERR_NOMEM, "tri_batch_create: the batch's %llu tree queries need %llu bytes of bitmap scratch (%zu distinct term leaves, %zu phrase leaves; option tree_max_bytes = %llu): split the batch",
+                            (unsigned long long)P.tree_queries, (unsigned long long)P.tree_scratch_bytes, tree_terms.size(), n_hidden, (unsigned long long)opt.tree_max_bytes);
         // ---- the planes that pay: rows in term order (deterministic), the uses pointed at them.  A term is chosen when the batch's uses repay
         //      one decode of its list (a one-pass slot counts a whole decode: always chosen)
         std::vector<uint32_t> chosen; // terms
@@ -1357,6 +1647,9 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         section(P.off_ptasks, n_ptasks, 4);
         section(P.off_units, n_units, sizeof(DevPsetUnit));
         section(P.off_pset_sched, n_units, 4);
+        section(P.off_tree, n_treewords, 4);
+        section(P.off_tree_terms, tree_terms.size(), 4);
+        section(P.off_tree_hidden, n_hidden, 4);
         P.block_bytes = bytes;
         P.block = alloc_block(bytes);
         if (!P.block)
@@ -1380,6 +1673,10 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         span(P.ptasks, P.off_ptasks, n_ptasks);
         span(P.units, P.off_units, n_units);
         span(P.pset_sched, P.off_pset_sched, n_units);
+        span(P.tree, P.off_tree, n_treewords);
+        span(P.tree_terms, P.off_tree_terms, tree_terms.size());
+        span(P.tree_hidden, P.off_tree_hidden, n_hidden);
+        std::copy(tree_terms.begin(), tree_terms.end(), P.tree_terms.p);
         std::vector<uint32_t> unit_of_task(n_units ? n_tasks : 0);
         std::copy(chosen.begin(), chosen.end(), P.plane_terms.p);
         // ---- every fragment writes its part of the arrays, rebased
@@ -1394,8 +1691,30 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         q.out_off += f.b_off;
                         if (f.tmp[i].fuse)
                                 q.fused_idx += (uint32_t)f.b_fused;
+                        if (f.tmp[i].tree)
+                                q.fused_idx += (uint32_t)f.b_tree;
+                        if (f.tmp[i].hidden) { // (no caller query of its own: its matches are a leaf of a TASK_TREE query)
+                                q.qid = 0xffffffffu;
+                                P.tree_hidden[f.b_hidden + f.tmp[i].hidden_ord] = (uint32_t)(f.b_plan + i);
+                        } else
+                                P.slot_of_query[q.qid] = (uint32_t)(f.b_plan + i);
                         P.plan[f.b_plan + i] = q;
-                        P.slot_of_query[q.qid] = (uint32_t)(f.b_plan + i);
+                }
+                if (!f.treepool.empty()) {
+                        memcpy(&P.tree[f.b_tree], f.treepool.data(), f.treepool.size() * 4);
+                        for (size_t i = 0; i < f.tmp.size(); ++i) {
+                                if (!f.tmp[i].tree)
+                                        continue;
+                                uint32_t *rec = &P.tree[f.b_tree + f.tmp[i].q.fused_idx];
+                                DevTreeNode *tn = reinterpret_cast<DevTreeNode *>(rec + TREE_HDR_WORDS);
+                                for (uint32_t k = 0; k < rec[0]; ++k)
+                                        if (tn[k].op == TRI_OP_TERM)
+                                                tn[k].row = (uint32_t)(std::lower_bound(P.tree_terms.begin(), P.tree_terms.end(), tn[k].arg) - P.tree_terms.begin());
+                                        else if (tn[k].op == TRI_OP_PHRASE) {
+                                                tn[k].arg += (uint32_t)f.b_plan;
+                                                tn[k].row += (uint32_t)f.b_hidden;
+                                        }
+                        }
                 }
                 for (size_t i = 0; i < f.tasks.size(); ++i) {
                         DevTask t = f.tasks[i];
@@ -1472,7 +1791,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         //      other keep their order in the batch: all a longest-first dispatch needs; TASK_PSET goes by docID window range instead.  The
         //      fragments counted their tasks per bucket in the fill pass; their places are settled here, the scatter runs on the pool again
         {
-                uint32_t *const per_kernel[TASK_KINDS] = {&P.n_dense, &P.n_pset, &P.n_probe, &P.n_cand, &P.n_fused, &P.n_fused16, &P.n_fusedgen, &P.n_planes, &P.n_planes8};
+                uint32_t *const per_kernel[TASK_KINDS] = {&P.n_dense, &P.n_pset, &P.n_probe, &P.n_cand, &P.n_fused, &P.n_fused16, &P.n_fusedgen, &P.n_planes, &P.n_planes8, &P.n_tree};
                 uint32_t at = 0;
                 for (uint32_t r = 0; r < TASK_KINDS; ++r) {
                         const uint32_t before = at;
@@ -1511,7 +1830,13 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                         P.distinct_bytes_kind[kind] += ix.docbytes[term];
                                 seen[term] |= (uint8_t)(0x80u | (1u << kind));
                         };
-                        if (task_onepass(kind)) {
+                        if (kind == TASK_TREE) {
+                                const uint32_t *rec = &P.tree[q.fused_idx];
+                                const DevTreeNode *tn = reinterpret_cast<const DevTreeNode *>(rec + TREE_HDR_WORDS);
+                                for (uint32_t k = 0; k < rec[0]; ++k)
+                                        if (tn[k].op == TRI_OP_TERM)
+                                                touch(tn[k].arg);
+                        } else if (task_onepass(kind)) {
                                 const DevFused &z = P.fused[q.fused_idx];
                                 for (uint32_t k = 0; k < z.nslots; ++k)
                                         touch(z.term[k]);

@@ -278,7 +278,11 @@ struct tri_batch : BatchPlan {
         DevFused *d_fused = nullptr;
         // HIP events on the engine stream: start, after k_term_planes, k_and_dense, k_and, k_fused, k_planes, k_phrase, end (owned by the
         // batch: two batches in flight on one device keep their own timings); ev_up: the plan has arrived (upload stream)
-        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_s = nullptr, ev_r = nullptr, ev_b = nullptr, ev_c = nullptr, ev_p = nullptr, ev1 = nullptr, ev_pl = nullptr, ev_k = nullptr, ev_up = nullptr; // (ev_s: after k_psets; ev_r: after k_probe)
+        hipEvent_t ev0 = nullptr, ev_a = nullptr, ev_s = nullptr, ev_r = nullptr, ev_b = nullptr, ev_c = nullptr, ev_p = nullptr, ev1 = nullptr, ev_pl = nullptr, ev_k = nullptr, ev_up = nullptr, ev_t = nullptr; // (ev_s: after k_psets; ev_r: after k_probe; ev_t: after the tree kernels)
+        // TASK_TREE (k_tree.hpp): one scratch block — [tree rows: a PL_PLANES-plane row per distinct term leaf][phrase rows: a plane per hidden phrase query]
+        // [a match bitmap per tree query][per query and chunk: matches][(term, row) pairs for k_term_planes]
+        uint32_t *d_tree_scratch = nullptr, *d_tree_rows = nullptr, *d_tree_prows = nullptr, *d_tree_qbits = nullptr, *d_tree_cc = nullptr, *d_tree_build = nullptr;
+        double *d_tree_scores = nullptr; // scored top-K batches: the tree queries' score stream (topk == 0: d_all_scores holds it)
         bool ran = false;
         uint32_t *d_qterms = nullptr;
         uint32_t *d_out = nullptr;
@@ -318,7 +322,7 @@ struct tri_batch : BatchPlan {
                         if (ev_up)
                                 hipEventSynchronize(ev_up); // (the pinned block goes back to the pool: its copy must have left)
                 }
-                for (hipEvent_t e : {ev0, ev_a, ev_s, ev_r, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k, ev_up})
+                for (hipEvent_t e : {ev0, ev_a, ev_s, ev_r, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k, ev_up, ev_t})
                         if (e) {
                                 if (dev)
                                         dev->events_idle.push_back(e);
@@ -340,6 +344,8 @@ struct tri_batch : BatchPlan {
                 hipFree(d_rich_plen);
                 hipFree(d_rich_payload);
                 pool_free(dev, d_pscore);
+                pool_free(dev, d_tree_scratch);
+                pool_free(dev, d_tree_scores);
                 dev_release(dev);
         }
 };
@@ -356,6 +362,7 @@ struct tri_batch : BatchPlan {
 #include "k_encode.hpp"
 #include "k_phrase.hpp"
 #include "k_rich.hpp"
+#include "k_tree.hpp"
 
 // launch the instantiation of a codec-templated kernel that matches the uploaded segment
 #define TRI_LAUNCH(K, codec, grid, block, stream, ...)                                              \
@@ -420,7 +427,7 @@ namespace {
                              {"planes_split", &tri_options::planes_split},
                              {"plane_max_bytes", &tri_options::plane_max_bytes},
                              {"plan_threads", &tri_options::plan_threads},
-                             {"probe_max_blocks", &tri_options::probe_max_blocks}};
+                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"tree_max_bytes", &tri_options::tree_max_bytes}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -688,6 +695,13 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         }
         const size_t nt = b->tasks.size(), np = b->plan.size();
         const uint64_t off = b->out_capacity;
+        static const bool dbg_create = getenv("TRINITY_DEBUG_CREATE") != nullptr; // (stderr: where a create's time goes past the planner)
+        double dbg_t[6] = {0, 0, 0, 0, 0, 0};
+        auto dbg_lap = [&](int i) {
+                if (dbg_create)
+                        dbg_t[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
+        };
+        dbg_lap(0);
         // ---- the arena: the block's copy, then the batch's small device-only arrays; the part that must start out zero comes last
         size_t a = b->block_bytes;
         auto carve = [&](size_t bytes) {
@@ -730,11 +744,12 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->d_top_counts = scored ? (uint32_t *)(A + a_top_counts) : nullptr;
         b->d_top_docs = scored ? (uint32_t *)(A + a_top_docs) : nullptr;
         b->d_top_scores = scored ? (float *)(A + a_top_scores) : nullptr;
-        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_s, &b->ev_r, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k, &b->ev_up})
+        for (hipEvent_t *e : {&b->ev0, &b->ev_a, &b->ev_s, &b->ev_r, &b->ev_b, &b->ev_c, &b->ev_p, &b->ev1, &b->ev_pl, &b->ev_k, &b->ev_up, &b->ev_t})
                 HIP_TRY(event_get(dev, e));
         if (b->block_bytes)
                 HIP_TRY(hipMemcpyAsync(A, b->block, b->block_bytes, hipMemcpyHostToDevice, dev->stream_up));
         HIP_TRY(hipMemsetAsync(A + a_zero, 0, a - a_zero, dev->stream_up));
+        dbg_lap(1);
         // ---- the large buffers (the device handle's pool)
         if (!b->plane_terms.empty() || planes_tasks) {
                 // the index's plane cache holds a row for every term this batch could name (row = df rank < plane_rows), plus an all-zero row:
@@ -761,7 +776,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
                 HIP_TRY(pool_alloc(dev, (void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
         }
+        dbg_lap(2);
         HIP_TRY(pool_alloc(dev, (void **)&b->d_out, (off + 64) * 4));
+        dbg_lap(3);
         if (!b->phrases.empty() && scored) {
                 HIP_TRY(pool_alloc(dev, (void **)&b->d_pscore, (off + 64) * 8));
                 HIP_TRY(hipMemsetAsync(b->d_pscore, 0, (off + 64) * 8, dev->stream_up));
@@ -781,8 +798,27 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 HIP_TRY(pool_alloc(dev, (void **)&b->d_part_docs, (nt * topk + 1) * 4));
                 HIP_TRY(pool_alloc(dev, (void **)&b->d_part_scores, (nt * topk + 1) * 8));
         }
+        if (b->n_tree) {
+                const size_t plw = b->plw, nterms = b->tree_terms.size(), nhid = b->tree_hidden.size(), nchunks = (plw + TREE_CHUNK_WORDS - 1) / TREE_CHUNK_WORDS;
+                const size_t w_rows = nterms * PL_PLANES * plw, w_prows = nhid * plw, w_qbits = (size_t)b->n_tree * plw, w_cc = (size_t)b->n_tree * nchunks + 64;
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_tree_scratch, (w_rows + w_prows + w_qbits + w_cc + 2 * nterms + 64) * 4));
+                b->d_tree_rows = b->d_tree_scratch;
+                b->d_tree_prows = b->d_tree_rows + w_rows;
+                b->d_tree_qbits = b->d_tree_prows + w_prows;
+                b->d_tree_cc = b->d_tree_qbits + w_qbits;
+                b->d_tree_build = b->d_tree_cc + w_cc;
+                std::vector<uint32_t> build(2 * nterms);
+                for (size_t i = 0; i < nterms; ++i)
+                        build[2 * i] = b->tree_terms[i], build[2 * i + 1] = (uint32_t)i;
+                if (nterms)
+                        HIP_TRY(hipMemcpyAsync(b->d_tree_build, build.data(), build.size() * 4, hipMemcpyHostToDevice, dev->stream_up)); // (pageable source: staged before the call returns)
+                if (scored && topk)
+                        HIP_TRY(pool_alloc(dev, (void **)&b->d_tree_scores, (off + 64) * 8));
+        }
         HIP_TRY(hipEventRecord(b->ev_up, dev->stream_up));
         b->info.nqueries = nq;
+        b->info.tree_queries = b->tree_queries;
+        b->info.tree_scratch_bytes = b->tree_scratch_bytes;
         b->info.out_capacity = off;
         b->info.dense_queries = b->dense_queries;
         b->info.cand_queries = b->cand_queries;
@@ -796,6 +832,9 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                            ((scored && b->n_dense + b->n_pset + b->n_probe + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
         b->info.create_plan_ms = (float)(b->plan_ms[0] + b->plan_ms[1] + b->plan_ms[2] + b->plan_ms[3]);
         b->info.create_ms = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
+        if (dbg_create)
+                fprintf(stderr, "[tri create] nq %zu: plan %.3f  arena+copy %.3f  planes/sparse %.3f  out(%.1f MB) %.3f  rest %.3f  total %.3f ms\n", nq, dbg_t[0], dbg_t[1] - dbg_t[0],
+                        dbg_t[2] - dbg_t[1], (double)off * 4 / 1e6, dbg_t[3] - dbg_t[2], b->info.create_ms - dbg_t[3], b->info.create_ms);
         *out = b.release();
         return TRI_OK;
 }
@@ -975,6 +1014,49 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_p, dev->stream));
+                if (b->n_tree) {
+                        // the queries no other kernel takes (k_tree.hpp): leaf bitmaps — the distinct term leaves decoded once, the phrase leaves from their
+                        // hidden queries' match lists (k_phrase has just filtered them) —, the trees word by word, the match bitmaps expanded
+                        const uint32_t plw = b->plw, nterms = (uint32_t)b->tree_terms.size(), nhid = (uint32_t)b->tree_hidden.size();
+                        const uint32_t nchunks = (plw + TREE_CHUNK_WORDS - 1) / TREE_CHUNK_WORDS;
+                        const uint32_t *tsched = b->d_sched + (n - b->n_tree);
+                        const uint32_t *d_tree = (const uint32_t *)(b->d_arena + b->off_tree);
+                        tri_index *ix = b->ix;
+                        for (uint32_t y0 = 0; y0 < nterms; y0 += 65535u) { // (gridDim.y <= 65535)
+                                const dim3 grid(plw / PL_WORDS, std::min(65535u, nterms - y0));
+                                TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff, ix->d_win,
+                                           ix->d_terms, (const uint32_t *)b->d_tree_build + 2 * (size_t)y0, b->d_tree_rows, plw);
+                                HIP_TRY(hipGetLastError());
+                        }
+                        if (nhid) {
+                                HIP_TRY(hipMemsetAsync(b->d_tree_prows, 0, (size_t)nhid * plw * 4, dev->stream));
+                                hipLaunchKernelGGL(k_tree_gather, dim3(nhid), dim3(TREE_WG), 0, dev->stream, b->d_plan, b->d_tasks, (const uint32_t *)(b->d_arena + b->off_tree_hidden), b->d_out,
+                                                   b->d_counts, b->d_pscore, b->d_tree_prows, plw);
+                                HIP_TRY(hipGetLastError());
+                        }
+                        const bool scored_run = b->flags & TRI_FLAG_ACCUMULATED_SCORE, rich_run = b->flags & TRI_FLAG_MATCHED_TERMS;
+                        double *tscores = scored_run ? (b->topk ? b->d_tree_scores : b->d_all_scores) : nullptr;
+                        for (uint32_t y0 = 0; y0 < b->n_tree; y0 += 65535u) {
+                                const dim3 grid(nchunks, std::min(65535u, b->n_tree - y0));
+                                uint32_t *qbits = b->d_tree_qbits + (size_t)y0 * plw, *cc = b->d_tree_cc + (size_t)y0 * nchunks;
+                                hipLaunchKernelGGL(k_tree_eval, grid, dim3(TREE_WG), 0, dev->stream, b->d_plan, b->d_tasks, tsched + y0, d_tree, (const uint32_t *)b->d_tree_rows,
+                                                   (const uint32_t *)b->d_tree_prows, (const uint32_t *)ix->d_masked, qbits, cc, plw);
+                                hipLaunchKernelGGL(k_tree_expand, grid, dim3(TREE_WG), 0, dev->stream, b->d_plan, b->d_tasks, tsched + y0, (const uint32_t *)qbits, (const uint32_t *)cc,
+                                                   b->d_out, b->d_counts, plw);
+                                if (scored_run || rich_run)
+                                        TRI_LAUNCH(k_tree_leaves, ix->codec, grid, dim3(TREE_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_terms, b->d_plan, b->d_tasks,
+                                                   tsched + y0, d_tree, (const uint32_t *)b->d_tree_rows, (const uint32_t *)b->d_tree_prows, (const uint32_t *)cc, (const uint32_t *)b->d_out,
+                                                   (const uint32_t *)b->d_counts, (const double *)b->d_sweights, (const double *)b->d_pscore, tscores, rich_run ? b->d_rich_allow : nullptr,
+                                                   plw, b->similarity);
+                                HIP_TRY(hipGetLastError());
+                        }
+                        if (scored_run && b->topk) {
+                                hipLaunchKernelGGL(k_tree_topk, dim3(b->n_tree), dim3(AND_WG), 0, dev->stream, tsched, b->d_tasks, (const uint32_t *)b->d_out, (const uint32_t *)b->d_counts,
+                                                   (const double *)tscores, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts);
+                                HIP_TRY(hipGetLastError());
+                        }
+                }
+                HIP_TRY(hipEventRecord(b->ev_t, dev->stream));
                 if (b->flags & TRI_FLAG_MATCHED_TERMS) {
                         // COUNT pass: which reportable terms hold each match, with what frequency; hit totals per task
                         HIP_TRY(hipMemsetAsync(b->d_rich_present, 0, (b->out_capacity + 64) * 4, dev->stream));
@@ -1016,6 +1098,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipEventRecord(b->ev_c, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_k, dev->stream));
                 HIP_TRY(hipEventRecord(b->ev_p, dev->stream));
+                HIP_TRY(hipEventRecord(b->ev_t, dev->stream));
         }
         if (!b->plan.empty()) {
                 const uint32_t nqs = (uint32_t)b->plan.size();
@@ -1060,7 +1143,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
                 b->info.last_run_ms = ms;
-        b->info.dense_ms = b->info.pset_ms = b->info.probe_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.rest_ms = b->info.term_planes_ms = b->info.planes_ms = 0;
+        b->info.dense_ms = b->info.pset_ms = b->info.probe_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.tree_ms = b->info.rest_ms = b->info.term_planes_ms = b->info.planes_ms = 0;
         if (!b->tasks.empty()) {
                 if (hipEventElapsedTime(&ms, b->ev0, b->ev_pl) == hipSuccess)
                         b->info.term_planes_ms = ms; // includes the 256-byte ticket memset that precedes it
@@ -1078,7 +1161,9 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                         b->info.planes_ms = ms;
                 if (hipEventElapsedTime(&ms, b->ev_k, b->ev_p) == hipSuccess)
                         b->info.phrase_ms = ms;
-                if (hipEventElapsedTime(&ms, b->ev_p, b->ev1) == hipSuccess)
+                if (hipEventElapsedTime(&ms, b->ev_p, b->ev_t) == hipSuccess)
+                        b->info.tree_ms = ms;
+                if (hipEventElapsedTime(&ms, b->ev_t, b->ev1) == hipSuccess)
                         b->info.rest_ms = ms;
         }
         b->h_counts.resize(b->tasks.size());
@@ -1086,12 +1171,16 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 HIP_TRY(hipMemcpy(b->h_counts.data(), b->d_counts, b->tasks.size() * 4, hipMemcpyDeviceToHost));
         uint64_t m = 0;
         b->h_query_counts.assign(b->plan.size(), 0);
-        uint64_t m_dense = 0, m_pset = 0, m_probe = 0, m_fused = 0, out_fused = 0, out_planes = 0;
+        uint64_t m_dense = 0, m_pset = 0, m_probe = 0, m_fused = 0, out_fused = 0, out_planes = 0, m_tree = 0;
         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                 const DevQuery &q = b->plan[sidx];
                 for (uint32_t t = 0; t < q.ntasks; ++t)
                         b->h_query_counts[sidx] += b->h_counts[q.first_task + t];
+                if (q.qid == 0xffffffffu) // (a hidden phrase query: its matches are a leaf of a TASK_TREE query, not a result)
+                        continue;
                 m += b->h_query_counts[sidx];
+                if (q.ntasks && b->tasks[q.first_task].kind == TASK_TREE)
+                        m_tree += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_DENSE)
                         m_dense += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_PSET)
@@ -1110,7 +1199,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         b->info.probe_algorithmic_bytes = b->term_bytes_probe + 4 * m_probe;
         b->info.probe_queries = b->probe_queries;
         b->info.cand_queries = b->cand_queries;
-        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_pset - b->term_bytes_probe - b->term_bytes_fused - b->term_bytes_planes - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_pset - m_probe - m_fused);
+        b->info.cand_algorithmic_bytes = (b->term_bytes - b->term_bytes_dense - b->term_bytes_pset - b->term_bytes_probe - b->term_bytes_fused - b->term_bytes_planes - b->term_bytes_phrase_hits) + 4 * (m - m_dense - m_pset - m_probe - m_fused - m_tree);
         b->info.planes_algorithmic_bytes = b->term_bytes_planes + out_planes; // docbytes + 8 B x min(matches, K), per query — the lists
                                                                               // the batch's queries share are nevertheless decoded once per launch
         // (term_planes_decoded_bytes: set by tri_batch_run — the list bytes of the plane rows THAT run had to build; 0 once the index's cache holds them)
@@ -1118,18 +1207,18 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         b->info.phrase_queries = 0;
         for (const DevQuery &q : b->plan)
                 b->info.phrase_queries += q.nphrases != 0;
-        b->info.cand_needed_bytes = b->cand_needed_term_bytes ? b->cand_needed_term_bytes + 4 * (m - m_dense - m_pset - m_fused) : 0; // (the candidate-tile AND the probe queries: what a perfect gallop reads)
+        b->info.cand_needed_bytes = b->cand_needed_term_bytes ? b->cand_needed_term_bytes + 4 * (m - m_dense - m_pset - m_fused - m_tree) : 0; // (the candidate-tile AND the probe queries: what a perfect gallop reads)
         b->info.fused_algorithmic_bytes = b->term_bytes_fused + out_fused; // docbytes + 8 B x min(matches, K)
         b->info.matches = m;
         if (b->distinct_bytes) { // (option account_needed_bytes: the batch-level bound — every distinct list once + every output once)
-                const uint64_t m_cand = m - m_dense - m_pset - m_probe - m_fused;
+                const uint64_t m_cand = m - m_dense - m_pset - m_probe - m_fused - m_tree;
                 const bool sc = b->flags & TRI_FLAG_ACCUMULATED_SCORE;
                 uint64_t out_legacy_dense = 4 * m_dense, out_legacy_pset = 4 * m_pset, out_legacy_probe = 4 * m_probe, out_legacy_cand = 4 * m_cand;
                 if (sc && b->topk) { // (queries matched by k_and_dense / k_psets / k_and of a top-K batch deliver 8 B x min(matches, K))
                         out_legacy_dense = out_legacy_pset = out_legacy_probe = out_legacy_cand = 0;
                         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                                 const DevQuery &q = b->plan[sidx];
-                                if (!q.ntasks || task_onepass(b->tasks[q.first_task].kind))
+                                if (!q.ntasks || task_onepass(b->tasks[q.first_task].kind) || b->tasks[q.first_task].kind == TASK_TREE || q.qid == 0xffffffffu)
                                         continue;
                                 const uint32_t kd = b->tasks[q.first_task].kind;
                                 (kd == TASK_DENSE ? out_legacy_dense : kd == TASK_PSET ? out_legacy_pset : kd == TASK_PROBE ? out_legacy_probe : out_legacy_cand) += 8 * std::min<uint64_t>(b->h_query_counts[sidx], b->topk);

@@ -67,7 +67,7 @@ class TriBatchInfo(C.Structure):
         ("fused_queries", C.c_uint64),
         ("cand_needed_bytes", C.c_uint64),
         ("phrase_ms", C.c_float),
-        ("pad_", C.c_float),
+        ("tree_ms", C.c_float),
         ("phrase_algorithmic_bytes", C.c_uint64),
         ("phrase_queries", C.c_uint64),
         ("term_planes_ms", C.c_float),
@@ -94,6 +94,8 @@ class TriBatchInfo(C.Structure):
         ("probe_queries", C.c_uint64),
         ("probe_algorithmic_bytes", C.c_uint64),
         ("probe_bound_bytes", C.c_uint64),
+        ("tree_queries", C.c_uint64),
+        ("tree_scratch_bytes", C.c_uint64),
     ]
 
 

@@ -11,14 +11,18 @@ _SUMMARY = ["block_bytes", "n_plan", "n_qterms", "n_tasks", "n_fused_maps", "n_q
             "off_plan", "off_qterms", "off_tasks", "off_sched", "off_fused", "off_qplane", "off_plane_terms", "off_sterms", "off_sweights", "off_phrases", "off_pterms", "off_ptasks",
             "n_dense", "n_cand", "n_fused", "n_fused16", "n_fusedgen", "n_planes", "n_planes8", "plw", "sparse_cap", "out_capacity", "term_bytes", "term_bytes_dense",
             "dense_queries", "cand_queries", "fused_queries", "planes_queries", "unsupported_queries", "rich_R", "sizeof_query", "sizeof_task", "sizeof_fused", "sizeof_phrase",
-            "cand_needed_term_bytes", "plane_decoded_bytes", "n_pset", "pset_queries", "n_probe", "probe_queries", "n_units", "off_units", "off_unit_sched", "sizeof_unit"]  # fmt: skip
+            "cand_needed_term_bytes", "plane_decoded_bytes", "n_pset", "pset_queries", "n_probe", "probe_queries", "n_units", "off_units", "off_unit_sched", "sizeof_unit",
+            "n_tree", "tree_queries", "n_tree_words", "off_tree", "n_tree_terms", "off_tree_terms", "n_tree_hidden", "off_tree_hidden"]  # fmt: skip
 
 DEV_QUERY = np.dtype([("nterms", "<u4"), ("term_base", "<u4"), ("out_off", "<u8"), ("out_cap", "<u4"), ("qid", "<u4"), ("first_task", "<u4"), ("ntasks", "<u4"),
                       ("score_base", "<u4"), ("nscore", "<u4"), ("phrase_base", "<u4"), ("nphrases", "<u4"), ("fused_idx", "<u4"), ("pad0", "<u4")])  # fmt: skip
 DEV_TASK = np.dtype([("slot", "<u4"), ("begin", "<u4"), ("end", "<u4"), ("kind", "<u4"), ("out_off", "<u8")])
-TASK_CAND, TASK_DENSE, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8, TASK_PSET, TASK_PROBE = range(9)
+TASK_CAND, TASK_DENSE, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8, TASK_PSET, TASK_PROBE, TASK_TREE = range(10)
+DEV_TREE_NODE = np.dtype([("op", "u1"), ("parent", "u1"), ("ord", "u1"), ("thr", "u1"), ("arg", "<u4"), ("row", "<u4"), ("score", "<u4"), ("rmask", "<u4"),
+                          ("kid0", "u1"), ("kid1", "u1"), ("pad", "u1", 2), ("kids", "<u8")])  # fmt: skip
+TREE_HDR_WORDS = 8
 DEV_UNIT = np.dtype([("out_off", "<u8"), ("begin", "<u4"), ("end", "<u4"), ("tix", "<u4"), ("nterms", "<u4"), ("term_base", "<u4"), ("first", "<u4"), ("tt", "<u4", 4), ("row", "<u4", 4)])
-SCHED_ORDER = [TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8]
+SCHED_ORDER = [TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8, TASK_TREE]
 
 
 def _lib():
@@ -124,6 +128,21 @@ class HostPlan:
     @property
     def plane_terms(self):
         return self._view("off_plane_terms", self.s["n_plane_terms"], "<u4")
+
+    @property
+    def tree_terms(self):
+        return self._view("off_tree_terms", self.s["n_tree_terms"], "<u4")
+
+    @property
+    def tree_hidden(self):
+        return self._view("off_tree_hidden", self.s["n_tree_hidden"], "<u4")
+
+    def tree_nodes(self, slot):
+        """The DevTreeNode records of the TASK_TREE query in plan slot `slot`."""
+        words = self._view("off_tree", self.s["n_tree_words"], "<u4")
+        at = int(self.plan[slot]["fused_idx"])
+        n = int(words[at])
+        return words[at + TREE_HDR_WORDS : at + TREE_HDR_WORDS + 8 * n].view(DEV_TREE_NODE)
 
     def close(self):
         if self.h:
