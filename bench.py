@@ -201,6 +201,9 @@ class Pipeline:
 
                 torch.cuda.current_stream().synchronize()  # the receive side is complete before the send buffers go back to the pool
         infos = [b.info() for b in self.cur]
+        for i, c in zip(infos, nxt):  # the tri_batch_create calls made INSIDE this step are the next set's (the current set's were made a step earlier)
+            ci = c.info()
+            i["create_ms"], i["create_plan_ms"] = ci["create_ms"], ci["create_plan_ms"]
         if self.done:
             for b in self.done:
                 b.close()
@@ -332,7 +335,7 @@ def main():
             barrier()
             if rank == 0:
                 solo = Pipeline(T, wl)
-                el, _ = timed(solo, args.scaling_ref_steps, 1, device_sync)
+                el, _ = timed(solo, args.scaling_ref_steps, 3, device_sync)  # (three warm-up steps: see below)
                 solo.close()
                 scaling_ref = {"workload": wl.desc, "queries_per_step": nq_rank, "steps": args.scaling_ref_steps, "value": nq_rank * args.scaling_ref_steps / el, "unit": "queries/s",
                                "what": "rank 0 alone on its shard of this run's workload (the other ranks parked at a barrier), the same create -> run -> read-back loop without the gather"}  # fmt: skip
@@ -340,9 +343,12 @@ def main():
         elif args.workload != "cfg5" and docs == 10_000_000:
             # one rank's shard of the mixed 100K batch (what the N > 1 lines run per GPU) on this GPU
             t0 = time.time()
-            ref_wl = Workload(T, W, dev, "cfg5", docs, vocab, 12500, 0, 1, segs, ixs)
+            ref_wl = Workload(DryEngine(T) if dry else T, W, dev, "cfg5", docs, vocab, 12500, 0, 1, segs, ixs)
             ref = Pipeline(T, ref_wl)
-            el, _ = timed(ref, args.scaling_ref_steps, 1, device_sync)
+            # (three warm-up steps: three sets of batches are alive in the loop — done, current, next —, and the first allocation of each one's
+            #  17 GB output region costs up to half a second (measured: 0.2 ms .. 484 ms); from the fourth create on the device pool recycles them.
+            #  With one warm-up step two of those allocations fell into the three timed steps: 70 K queries/s reported for a 540 K loop)
+            el, _ = timed(ref, args.scaling_ref_steps, 3, device_sync)
             ref.close()
             scaling_ref = {"workload": ref_wl.desc, "queries_per_step": ref_wl.nq, "steps": args.scaling_ref_steps, "value": ref_wl.nq * args.scaling_ref_steps / el, "unit": "queries/s",
                            "what": "one GPU's shard of the mixed 100K-query batch (12500 queries: what bench.py --gpus N > 1 runs per GPU), the same create -> run -> read-back loop; "
