@@ -28,6 +28,7 @@ extern "C" {
 #define TRI_ERR_UNSUPPORTED (-3) /* query shape not lowered yet        */
 #define TRI_ERR_FORMAT (-4)      /* index bytes fail validation        (reference: Switch::data_error)      */
 #define TRI_ERR_NOMEM (-5)
+#define TRI_ERR_INTERNAL (-6)    /* the engine contradicts itself (a result block that does not add up): a bug, never a caller's error */
 
 /* codecs (segment `id` file codec name: indexer.cpp:266-270, segment_index_source.cpp:172-179) */
 #define TRI_CODEC_GOOGLE 1
@@ -145,6 +146,10 @@ typedef struct tri_batch_info {
          * matchsome / <optional>, trees over more distinct terms than the truth-table kernel holds, CNFs of more than 16 terms; the bitmap
          * scratch their leaves and match sets take (option tree_max_bytes bounds it: TRI_ERR_NOMEM, split the batch) */
         uint64_t tree_queries, tree_scratch_bytes;
+        /* queries whose docID set the engine holds as a bitmap (ABI 7; DocumentsOnly unions / conjunctions of head terms expected to match one
+         * document in 32 or more — option result_bitmaps, default 1): tri_batch_docset expands them on read-back, tri_batch_docset_bitmap hands
+         * the words over; match counts, hashes and everything else read the same */
+        uint64_t bitmap_queries;
 } tri_batch_info;
 
 const char *tri_last_error(void);
@@ -252,6 +257,12 @@ int tri_batch_match_counts(tri_batch *, uint64_t *counts /* [nq] */);
  * with topk >= 1 delivers top-K lists and match counts; queries it ran through the one-pass kernel have no materialised set and
  * the call fails with TRI_ERR_INVALID for them (tri_batch_docset_hashes likewise when the batch holds such a query). */
 int tri_batch_docset(tri_batch *, size_t q, uint32_t *out, size_t cap, size_t *n);
+/* The docID set of query q in the form the engine holds it.  *form = 0: ascending docIDs (tri_batch_docset copies them), nothing else is set.
+ * *form = 1: a BITMAP — a DocumentsOnly union / conjunction of head terms expected to match one document in 32 or more keeps one bit per
+ * document instead of four bytes per match (option result_bitmaps, default 1; tri_batch_info.bitmap_queries): bit j of words[i] set <=> document
+ * *first_doc + 32 i + j matches; *nwords words (words == NULL: sizes only).  tri_batch_docset expands such a set on read-back; a caller that
+ * replays consider(ids, cnt) (matches.h:161-165) or intersects further can take the words as they are. */
+int tri_batch_docset_bitmap(tri_batch *, size_t q, int *form, uint32_t *words, size_t cap, uint32_t *first_doc, size_t *nwords);
 /* AccumulatedScore with topk == 0: the score of every match of query q, parallel to tri_batch_docset(q) — the
  * (id, score) stream MatchedIndexDocumentsFilter::consider(id, score) receives (matches.h:169; exec.cpp:1322-1341) */
 int tri_batch_scores(tri_batch *, size_t q, double *out, size_t cap, size_t *n);

@@ -374,6 +374,53 @@ def test_union_of_head_terms_large(large):
         assert np.array_equal(got, want), (t, len(got), len(want))
 
 
+@pytest.mark.parametrize("world", ["large", "dense", "medium_l"])
+def test_docsets_delivered_as_bitmaps(request, world):
+    """RESULT_BITMAP (dev_structs.hpp): a DocumentsOnly union / conjunction of head terms expected to match one document in 32 or more is held
+    as one bit per document — through both bitmap-window kernels (k_psets: every term has a plane; k_and_dense: rows decoded, windows the lead
+    group skips written as zeros), with and without masked documents.  tri_batch_docset expands it, tri_batch_docset_bitmap hands the words
+    over, counts and hashes read the same; result_bitmaps = 0 gives the same sets as ascending docIDs."""
+    w = request.getfixturevalue(world)
+    T, V = w.T, w.V
+    texts = ["t0 OR t1", "t0 OR t1 OR t2 OR t3 OR t4", "t0 t1", "t0 t1 (t2 OR t3 OR t4)", "(t0 OR t1) (t2 OR t3) t4", "(t0 OR t1 OR t2) NOT t3", f"t0 OR t{V // 2} OR t{V - 1}",
+             f"t{V // 2} OR t{V // 2 + 1}", "t5 t6", f"(t0 OR t{V - 2}) (t1 OR t{V - 3})"]  # fmt: skip
+    progs = [O.parse_query(t) for t in texts]
+    masked = np.array(sorted(set(np.random.default_rng(5).integers(1, w.D, w.D // 9).tolist())), dtype=np.uint32)
+    try:
+        for mk in (None, masked):
+            if mk is not None:
+                w.ix.set_masked(mk)
+                w.ora.set_masked(mk)
+            want = [w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)[0] for p in progs]
+            seen_forms = set()
+            for opts in ({}, {"dense_min_postings": 0}, {"dense_min_postings": 0, "planes": 0}, {"dense_min_postings": 0, "plane_div": ALL_PLANES}, {"result_bitmaps": 0}):
+                with options(w.dev, **opts):
+                    b = T.Batch(w.ix, progs, T.FLAG_DOCUMENTS_ONLY)
+                for rep in range(2):
+                    b.run()
+                    b.sync()
+                    info = b.info()
+                    assert (info["bitmap_queries"] == 0) == (opts.get("result_bitmaps", 1) == 0 or info["dense_queries"] + info["pset_queries"] == 0), opts
+                    counts, hashes = b.counts(), b.docset_hashes()
+                    nbm = 0
+                    for i, t in enumerate(texts):
+                        assert int(counts[i]) == len(want[i]) and int(hashes[i]) == O.fnv1a_docs(want[i]), (opts, t)
+                        assert np.array_equal(b.docset(i, len(want[i])), want[i]), (opts, t)
+                        bm = b.docset_bitmap(i)
+                        if bm is not None:
+                            first, words = bm
+                            bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+                            assert first % 32 == 0 and np.array_equal(np.nonzero(bits)[0].astype(np.uint32) + first, want[i]), (opts, t)
+                            nbm += 1
+                    assert nbm == info["bitmap_queries"]
+                    seen_forms.add(nbm > 0)
+                b.close()
+            assert seen_forms == {True, False}
+    finally:
+        w.ix.set_masked(np.zeros(0, np.uint32))
+        w.ora.set_masked(np.zeros(0, np.uint32))
+
+
 # ------------------------------------------------------------------------------------------ one-pass scored windows (k_fused)
 FUSED_EXTRA = ["t{a} OR t{b} OR t{c} OR t{d} OR t{e} OR t0 OR t1 OR t2", "t{a} t{b} (t{c} OR t{d} OR t{e} OR t0 OR t1)", "t{a}", "t{a} t{b}", "t{a} t{a}", "t{a} t{b} t{c} t{d} t{e}", "t{a} NOT t{b}", "(t{a} OR t{b}) NOT t{c}", "t{a} t{b} NOT (t{c} OR t{d})",
                "t{a} <t{b}>", "t{a} t{b} <t{c} OR t{d}>", "(t{a} OR t{b}) (t{a} OR t{c})", "t{a} OR t{b} OR t{c} OR t{d} OR t{e} OR t{a}"]

@@ -45,9 +45,17 @@ struct DevQuery {
         uint32_t first_task, ntasks;
         uint32_t score_base, nscore; // AccumulatedScoreScheme: sterms[]/sweights[] slice, reference summation order
         uint32_t phrase_base, nphrases; // positional constraints applied to the match list (DocsSetIterators::Phrase)
-        uint32_t fused_idx, pad0;       // TASK_FUSED queries: row in the batch's DevFused table (k_fused.hpp)
+        uint32_t fused_idx, form;       // fused_idx: TASK_FUSED queries: row in the batch's DevFused table (k_fused.hpp); TASK_TREE: the query's record in tree[].
+                                        // form: RESULT_DOCIDS / RESULT_BITMAP — how the query's docID set lies in out[]
 };
 
+// How a materialised docID set lies in its region of out[]: ascending docIDs, task segment after task segment (the in-order concatenation is the
+// set), or — DocumentsOnly bitmap-window queries whose expected matches outnumber the bitmap's words (a union of head terms, a conjunction of two
+// of them: one document in 32 or denser) — ONE BIT PER DOCUMENT: word i of the region covers docIDs [32 i, 32 i + 32), a task writes the words of
+// its docID windows (every one of them, matches or not), counts[] still holds the task's matches.  1.25 MB per query at 10 M documents whatever it
+// matches, instead of 4 bytes per match and the expansion's instructions: what a consumer that replays consider(ids, cnt) expands on its side
+// (tri_batch_docset does it on read-back; tri_batch_docset_bitmap hands the words over as they are)
+constexpr uint32_t RESULT_DOCIDS = 0, RESULT_BITMAP = 1;
 // A phrase constraint: its terms (phrase order) live in pterms[term_base .. +nterms); weight = sum of the terms' idf
 // (similarity.h:209-217).
 constexpr uint32_t MAX_PHRASE_TERMS = 16; // trinity_limits.h:12 MaxPhraseSize
@@ -100,11 +108,12 @@ struct DevPsetUnit { // (also the record of a TASK_PROBE task: w_begin / w_end a
         uint32_t tix;       // index into counts[]
         uint32_t nterms;
         uint32_t term_base; // qterms[] / qplane[] slice (read by the kernel only when nterms > PSET_INLINE_TERMS)
-        uint32_t first;     // 1: the first task of its query (planner bookkeeping)
+        uint32_t first;     // bit 0: the first task of its query (planner bookkeeping); bit 1 (PSET_UNIT_BITMAP): the query's result is a bitmap (RESULT_BITMAP)
         uint32_t tt[PSET_INLINE_TERMS];  // qterms[] words (term | QT_GROUP | QT_NOT) ...
         uint32_t row[PSET_INLINE_TERMS]; // ... and the terms' plane rows
 };
 static_assert(sizeof(DevPsetUnit) == 64, "one cache-line half per unit");
+constexpr uint32_t PSET_UNIT_FIRST = 1u, PSET_UNIT_BITMAP = 2u;
 // ---- TASK_TREE: the query tree as the kernels read it (k_tree.hpp).  A record in the plan's tree[] words (DevQuery::fused_idx = its first word):
 //      TREE_HDR_WORDS header words { nnodes, 0... }, then nnodes DevTreeNode in POSTFIX order (children before parents, the root last)
 constexpr uint32_t TREE_MAX_NODES = 64;     // node values and "an iterator sits on the document" flags are bit sets in a 64-bit word

@@ -707,6 +707,51 @@ __device__ __forceinline__ uint32_t dense_expand(DenseShared &sh, const uint32_t
         return window_total;
 }
 
+// RESULT_BITMAP (dev_structs.hpp): the window's survivors bitmap written out AS IT IS — SPAN_WORDS words at wout, eight per thread in two 16-byte
+// stores — instead of expanded; both LDS bitmaps are left zeroed.  Returns the window's match count (uniform).
+template <int WG>
+__device__ __forceinline__ uint32_t dense_store(DenseShared &sh, const uint32_t w0, const bool fold, const bool neg, const uint32_t *__restrict__ masked,
+                                                uint32_t *__restrict__ wout) {
+        constexpr uint32_t PER = SPAN_WORDS / WG;
+        static_assert(PER == 8, "two 16-byte stores per thread");
+        const uint32_t tid = threadIdx.x;
+        uint32_t *fin = sh.bm, *pre = sh.bm + BM_STRIDE;
+        uint32_t m[PER], run = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; ++j) {
+                const uint32_t wi = bm_pad(tid * PER + j);
+                m[j] = fin[wi];
+                if (fold)
+                        m[j] &= neg ? ~pre[wi] : pre[wi];
+                if (masked) // masked_documents_registry::test (docidupdates.h:90-119)
+                        m[j] &= ~masked[w0 / 32 + tid * PER + j];
+                fin[wi] = 0;
+                pre[wi] = 0;
+                run += __popc(m[j]);
+        }
+        uint4 *o = (uint4 *)(wout + tid * PER);
+        o[0] = make_uint4(m[0], m[1], m[2], m[3]);
+        o[1] = make_uint4(m[4], m[5], m[6], m[7]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+                run += __shfl_xor(run, d, 64);
+        sh.scan[tid >> 6] = run;
+        __syncthreads();
+        uint32_t total = 0;
+        for (int wv = 0; wv < WG / 64; ++wv)
+                total += sh.scan[wv];
+        total = uni(total);
+        __syncthreads();
+        return total;
+}
+// ... a window that cannot hold a match (the lead group skipped it, a conjunct is exhausted): all zero
+template <int WG>
+__device__ __forceinline__ void dense_store_zero(uint32_t *__restrict__ wout) {
+        uint4 *o = (uint4 *)(wout + threadIdx.x * (SPAN_WORDS / WG));
+        o[0] = make_uint4(0, 0, 0, 0);
+        o[1] = make_uint4(0, 0, 0, 0);
+}
+
 template <int WG, int CODEC>
 __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                            const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
@@ -716,6 +761,8 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
         const uint32_t tid = threadIdx.x;
         uint32_t *qout = out + task.out_off;
         uint32_t produced = 0;
+        const bool as_bitmap = uni(q.form) == RESULT_BITMAP; // the windows' words go out as they are: window w at qout + (w - tile_begin) * SPAN_WORDS
+        uint32_t wdone = task.tile_begin;                    // ... the first window of the task not written yet
         sh.lcur[tid & 15] = 0; // per term: a block index at or before the first block that can matter
         sh.nslow = 0;
         for (uint32_t i = tid; i < 2 * BM_STRIDE; i += WG)
@@ -768,7 +815,10 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
 #pragma unroll
                         for (uint32_t j = 0; j < PER; ++j)
                                 sh.bm[bm_pad(tid * PER + j)] = acc[j]; // (this thread's own words: dense_expand reads them back first)
-                        produced += dense_expand<WG>(sh, w0, false, false, masked, qout, produced PROF_PASS);
+                        if (as_bitmap)
+                                produced += dense_store<WG>(sh, w0, false, false, masked, qout + (size_t)(w - task.tile_begin) * SPAN_WORDS);
+                        else
+                                produced += dense_expand<WG>(sh, w0, false, false, masked, qout, produced PROF_PASS);
                 }
                 __syncthreads();
                 if (uni(tid >> 6) == 0)
@@ -909,9 +959,18 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                         dense_pass<WG, CODEC>(sh, index, blk_last, blk_off, kb, ke, kb, w0, planes, plw PROF_PASS);
                         kb = ke;
                 }
-                produced += dense_expand<WG>(sh, w0, ngroups > 1, neg, masked, qout, produced PROF_PASS);
+                if (as_bitmap) {
+                        for (; wdone < w; ++wdone) // (windows the lead group skipped)
+                                dense_store_zero<WG>(qout + (size_t)(wdone - task.tile_begin) * SPAN_WORDS);
+                        produced += dense_store<WG>(sh, w0, ngroups > 1, neg, masked, qout + (size_t)(w - task.tile_begin) * SPAN_WORDS);
+                        wdone = w + 1;
+                } else
+                        produced += dense_expand<WG>(sh, w0, ngroups > 1, neg, masked, qout, produced PROF_PASS);
                 ++w;
         }
+        if (as_bitmap)
+                for (; wdone < task.tile_end; ++wdone) // (... and the ones behind the last window that could hold a match)
+                        dense_store_zero<WG>(qout + (size_t)(wdone - task.tile_begin) * SPAN_WORDS);
         __syncthreads();
         if (uni(tid >> 6) == 0)
                 *count_out = produced;

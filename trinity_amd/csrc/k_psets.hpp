@@ -83,6 +83,7 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                         break;
                 const DevPsetUnit &U = sh.unit[p];
                 const uint32_t nterms = uni(U.nterms), w_begin = uni(U.w_begin), w_end = uni(U.w_end), tix = uni(U.tix), term_base = uni(U.term_base);
+                const bool as_bitmap = uni(U.first) & PSET_UNIT_BITMAP; // RESULT_BITMAP (dev_structs.hpp): the survivors' words go out as they are
                 uint32_t *const qout = out + (((uint64_t)uni((uint32_t)(U.out_off >> 32)) << 32) | uni((uint32_t)U.out_off));
                 // (wave 0) the next task's record and the ticket after it: issued now, used when this task is done
                 uint32_t nwd = 0, nnt = 0xffffffffu;
@@ -138,6 +139,15 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                                 const uint4 m0 = pm[0], m1 = pm[1];
                                 acc[0] &= ~m0.x, acc[1] &= ~m0.y, acc[2] &= ~m0.z, acc[3] &= ~m0.w;
                                 acc[4] &= ~m1.x, acc[5] &= ~m1.y, acc[6] &= ~m1.z, acc[7] &= ~m1.w;
+                        }
+                        if (as_bitmap) { // nothing to expand, nothing to rank: two 16-byte stores per lane, the counts summed at the task's end
+                                uint4 *o = (uint4 *)(qout + (word0 - w_begin * SPAN_WORDS));
+                                o[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                                o[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+#pragma unroll
+                                for (uint32_t j = 0; j < PSET_PER; ++j)
+                                        produced += (uint32_t)__popc(acc[j]); // (per lane here; reduced below)
+                                continue;
                         }
                         // ---- counts: lane -> wave (shuffles) -> workgroup (one LDS word per wave, one barrier)
                         uint32_t c = 0;
@@ -201,6 +211,18 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                                 }
                                 __builtin_amdgcn_wave_barrier();
                         }
+                }
+                if (as_bitmap) { // the lanes' counts -> the task's (uniform branch: the record is the workgroup's)
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1)
+                                produced += __shfl_xor(produced, d, 64);
+                        __syncthreads(); // (cnt[] of the previous task's last step has been read by everybody)
+                        sh.cnt[0][wave] = produced;
+                        __syncthreads();
+                        produced = 0;
+#pragma unroll
+                        for (uint32_t wv = 0; wv < PSET_WAVES; ++wv)
+                                produced += uni(sh.cnt[0][wv]);
                 }
                 if (wave == 0) { // (uniform stores by the lanes of wave 0: no lane-divergent branch next to the loop's barriers)
                         counts[tix] = produced;

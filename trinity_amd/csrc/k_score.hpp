@@ -424,6 +424,23 @@ __global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const DevTask 
                 return;
         const DevQuery q = plan[s];
         uint64_t h = 1469598103934665603ull;
+        if (q.form == RESULT_BITMAP) { // one bit per document: the tasks' windows in order, a word's bits ascending
+                for (uint32_t t = 0; t < q.ntasks; ++t) {
+                        const DevTask tk = tasks_by_query[q.first_task + t];
+                        const uint32_t *p = out + tk.out_off;
+                        const uint32_t nw = (tk.tile_end - tk.tile_begin) * SPAN_WORDS;
+                        for (uint32_t i = 0; i < nw; ++i)
+                                for (uint32_t m = p[i]; m; m &= m - 1u) {
+                                        uint32_t d = (tk.tile_begin * SPAN_WORDS + i) * 32u + (uint32_t)__builtin_ctz(m);
+                                        for (int b = 0; b < 4; ++b) {
+                                                h = (h ^ (d & 0xffu)) * 1099511628211ull;
+                                                d >>= 8;
+                                        }
+                                }
+                }
+                hashes[s] = h;
+                return;
+        }
         for (uint32_t t = 0; t < q.ntasks; ++t) {
                 const uint32_t *p = out + tasks_by_query[q.first_task + t].out_off;
                 const uint32_t n = counts_by_query[q.first_task + t];

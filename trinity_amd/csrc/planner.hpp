@@ -37,6 +37,8 @@ struct tri_options {
                                  // measured, step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the planes' build grows with it)
         uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs 3 bitmaps over the docID space and one decode per run)
         uint64_t plan_threads = 0;             // host threads tri_batch_create plans with; 0: up to 16, one per 512 queries
+        uint64_t result_bitmaps = 1;           // DocumentsOnly: a bitmap-window query whose expected matches outnumber the words of a bitmap over its docID range
+                                               // delivers its docID set AS that bitmap (RESULT_BITMAP, dev_structs.hpp); 0: always ascending docIDs
         uint64_t tree_max_bytes = 16ull << 30; // scratch budget of a batch's TASK_TREE queries (a PL_PLANES-plane row per distinct term leaf, a plane per phrase leaf and per query)
         uint64_t probe_max_blocks = 0;         // > 0: a lead list of at most this many blocks against lists that all have planes runs in k_probe (a wave per task) instead of
                                                // k_and's candidate tiles.  Off by default — measured at cfg2 (step ms / k_probe / k_and): 0: 2.14 / - / 0.78; 64: 2.25 / 0.15 / 0.75;
@@ -103,6 +105,7 @@ struct BatchPlan {
         size_t off_tree = 0, off_tree_terms = 0, off_tree_hidden = 0;
         uint32_t n_tree = 0;        // TASK_TREE tasks (the last section of sched)
         uint64_t tree_queries = 0, tree_scratch_bytes = 0;
+        uint64_t bitmap_queries = 0; // queries whose docID set is delivered as a bitmap (RESULT_BITMAP)
         size_t off_plan = 0, off_qterms = 0, off_tasks = 0, off_sched = 0, off_fused = 0, off_qplane = 0, off_plane_terms = 0, off_sterms = 0, off_sweights = 0,
                off_phrases = 0, off_pterms = 0, off_ptasks = 0;
         std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: can never match)
@@ -461,7 +464,7 @@ namespace trip {
                 std::vector<uint32_t> treepool;   // TASK_TREE records (DevQuery::fused_idx: a record's first word)
                 std::vector<uint32_t> tree_terms; // the term leaves of the fragment's TASK_TREE queries
                 uint32_t n_hidden = 0;            // hidden phrase queries (Tmp::hidden_ord)
-                uint64_t tree_queries = 0;
+                uint64_t tree_queries = 0, bitmap_queries = 0;
                 uint64_t off = 0;
                 uint32_t sparse_cap = 0;
                 uint64_t term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, cand_needed = 0;
@@ -882,7 +885,7 @@ namespace trip {
                                 }
                         }
                         t.q.fused_idx = 0;
-                        t.q.pad0 = 0;
+                        t.q.form = RESULT_DOCIDS;
                         t.q.nterms = (uint32_t)uniq.size();
                         t.q.term_base = (uint32_t)f.qterms.size();
                         t.q.out_cap = 0;
@@ -1370,6 +1373,28 @@ namespace trip {
                         t.q.first_task = (uint32_t)f.tasks.size();
                         if (t.dense) {
                                 const uint32_t nwin = last_doc / SPAN_BITS + 1;
+                                // the result's form: a bitmap over the query's docID range when the matches to expect — the lead group's documents, thinned
+                                // by every further required group as if the lists were independent — outnumber the bitmap's words
+                                bool bitmap = false;
+                                if (C.mode == TRI_FLAG_DOCUMENTS_ONLY && opt.result_bitmaps && !t.q.nphrases) {
+                                        const double N = std::max<double>(1.0, (double)ix.info.docs_cnt);
+                                        double est = 1.0, g = 0.0;
+                                        bool negg = false;
+                                        for (uint32_t k = 0; k <= t.q.nterms; ++k) {
+                                                if (k == t.q.nterms || (k && (qt[k] & QT_GROUP))) {
+                                                        if (!negg)
+                                                                est *= std::min(1.0, g / N);
+                                                        g = 0.0;
+                                                }
+                                                if (k == t.q.nterms)
+                                                        break;
+                                                if (qt[k] & QT_GROUP)
+                                                        negg = qt[k] & QT_NOT;
+                                                g += ix.terms[qt[k] & QT_TERM].documents;
+                                        }
+                                        bitmap = est * N >= (double)nwin * SPAN_WORDS;
+                                }
+                                t.q.form = bitmap ? RESULT_BITMAP : RESULT_DOCIDS;
                                 const uint64_t per_win = std::max<uint64_t>(1, t.sumdf / (ix.info.docs_cnt / SPAN_BITS + 1));
                                 const uint32_t win_per_task = pset ? PSET_TASK_WINDOWS : (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / per_win);
                                 uint32_t ord = 0;
@@ -1384,9 +1409,11 @@ namespace trip {
                                         for (uint32_t k = 0; k < nlead; ++k)
                                                 b1 += C.first_block_ge(ix.terms[qt[k] & QT_TERM], (uint64_t)wb * SPAN_BITS);
                                         f.tcost.push_back(pset ? wb : per_win * (we - wb)); // (TASK_PSET: the schedule goes by window range, not by cost)
+                                        const uint64_t task_off = bitmap ? off + (uint64_t)wb * SPAN_WORDS : off + b1 * 32 + 32ull * ord * nlead;
                                         if (pset) {
                                                 DevPsetUnit u{};
-                                                u.out_off = off + b1 * 32 + 32ull * ord * nlead;
+                                                u.out_off = task_off;
+                                                u.first = bitmap ? PSET_UNIT_BITMAP : 0u;
                                                 u.w_begin = wb, u.w_end = we;
                                                 u.tix = (uint32_t)f.tasks.size();
                                                 u.nterms = t.q.nterms;
@@ -1395,9 +1422,10 @@ namespace trip {
                                                         u.tt[k] = qt[k];
                                                 f.units.push_back(u);
                                         }
-                                        f.tasks.push_back({slot, wb, we, pset ? TASK_PSET : TASK_DENSE, off + b1 * 32 + 32ull * ord * nlead});
+                                        f.tasks.push_back({slot, wb, we, pset ? TASK_PSET : TASK_DENSE, task_off});
                                 }
-                                t.q.out_cap = (uint32_t)std::min<uint64_t>(0xffffffffull, lead_blocks * 32 + 32ull * (ord + 1) * nlead);
+                                t.q.out_cap = bitmap ? nwin * SPAN_WORDS : (uint32_t)std::min<uint64_t>(0xffffffffull, lead_blocks * 32 + 32ull * (ord + 1) * nlead);
+                                f.bitmap_queries += bitmap;
                         } else {
                                 const uint32_t ntiles = (lead.nblocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
                                 const uint64_t per_tile = std::max<uint64_t>(1, t.cost / ntiles);
@@ -1412,7 +1440,7 @@ namespace trip {
                                                 u.tix = (uint32_t)f.tasks.size();
                                                 u.nterms = t.q.nterms;
                                                 u.term_base = t.q.term_base;
-                                                u.first = tb == 0;
+                                                u.first = tb == 0 ? PSET_UNIT_FIRST : 0u;
                                                 for (uint32_t k = 0; k < t.q.nterms && k < PSET_INLINE_TERMS; ++k)
                                                         u.tt[k] = qt[k];
                                                 f.units.push_back(u);
@@ -1568,6 +1596,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 n_treewords += f.treepool.size(), n_hidden += f.n_hidden;
                 tree_terms.insert(tree_terms.end(), f.tree_terms.begin(), f.tree_terms.end());
                 P.tree_queries += f.tree_queries;
+                P.bitmap_queries += f.bitmap_queries;
                 n_plan += f.tmp.size(), n_qterms += f.qterms.size(), n_sterms += f.sterms.size(), n_phrases += f.phrases.size(), n_pterms += f.pterms.size(),
                         n_tasks += f.tasks.size(), n_fused += f.fused.size(), n_ptasks += f.ptasks.size(), off += f.off;
                 P.term_bytes += f.term_bytes, P.term_bytes_phrase_hits += f.term_bytes_phrase_hits, P.term_bytes_dense += f.term_bytes_dense,
@@ -1757,7 +1786,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         }
                         if (is_probe && !rows) { // a probed list did not get its plane (the batch's uses do not repay its decode): candidate tiles after all
                                 P.tasks[u.tix].kind = TASK_CAND;
-                                if (u.first) {
+                                if (u.first & PSET_UNIT_FIRST) {
                                         ++f.probe_demoted;
                                         const uint32_t *qt = &f.qterms[f.units[i].term_base];
                                         auto &seen = f.S.seen;

@@ -427,7 +427,7 @@ namespace {
                              {"planes_split", &tri_options::planes_split},
                              {"plane_max_bytes", &tri_options::plane_max_bytes},
                              {"plan_threads", &tri_options::plan_threads},
-                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"tree_max_bytes", &tri_options::tree_max_bytes}};
+                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -818,6 +818,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         HIP_TRY(hipEventRecord(b->ev_up, dev->stream_up));
         b->info.nqueries = nq;
         b->info.tree_queries = b->tree_queries;
+        b->info.bitmap_queries = b->bitmap_queries;
         b->info.tree_scratch_bytes = b->tree_scratch_bytes;
         b->info.out_capacity = off;
         b->info.dense_queries = b->dense_queries;
@@ -1172,6 +1173,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         uint64_t m = 0;
         b->h_query_counts.assign(b->plan.size(), 0);
         uint64_t m_dense = 0, m_pset = 0, m_probe = 0, m_fused = 0, out_fused = 0, out_planes = 0, m_tree = 0;
+        uint64_t outb_dense = 0, outb_pset = 0; // bytes the bitmap-window queries' results take in the form they are delivered in (a bitmap: its words)
         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
                 const DevQuery &q = b->plan[sidx];
                 for (uint32_t t = 0; t < q.ntasks; ++t)
@@ -1181,10 +1183,14 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 m += b->h_query_counts[sidx];
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_TREE)
                         m_tree += b->h_query_counts[sidx];
-                if (q.ntasks && b->tasks[q.first_task].kind == TASK_DENSE)
+                if (q.ntasks && b->tasks[q.first_task].kind == TASK_DENSE) {
                         m_dense += b->h_query_counts[sidx];
-                if (q.ntasks && b->tasks[q.first_task].kind == TASK_PSET)
+                        outb_dense += q.form == RESULT_BITMAP ? 4ull * q.out_cap : 4 * b->h_query_counts[sidx];
+                }
+                if (q.ntasks && b->tasks[q.first_task].kind == TASK_PSET) {
                         m_pset += b->h_query_counts[sidx];
+                        outb_pset += q.form == RESULT_BITMAP ? 4ull * q.out_cap : 4 * b->h_query_counts[sidx];
+                }
                 if (q.ntasks && b->tasks[q.first_task].kind == TASK_PROBE)
                         m_probe += b->h_query_counts[sidx];
                 if (q.ntasks && task_onepass(b->tasks[q.first_task].kind)) {
@@ -1213,7 +1219,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         if (b->distinct_bytes) { // (option account_needed_bytes: the batch-level bound — every distinct list once + every output once)
                 const uint64_t m_cand = m - m_dense - m_pset - m_probe - m_fused - m_tree;
                 const bool sc = b->flags & TRI_FLAG_ACCUMULATED_SCORE;
-                uint64_t out_legacy_dense = 4 * m_dense, out_legacy_pset = 4 * m_pset, out_legacy_probe = 4 * m_probe, out_legacy_cand = 4 * m_cand;
+                uint64_t out_legacy_dense = outb_dense, out_legacy_pset = outb_pset, out_legacy_probe = 4 * m_probe, out_legacy_cand = 4 * m_cand; // (the bound counts a result in the form it is delivered in)
                 if (sc && b->topk) { // (queries matched by k_and_dense / k_psets / k_and of a top-K batch deliver 8 B x min(matches, K))
                         out_legacy_dense = out_legacy_pset = out_legacy_probe = out_legacy_cand = 0;
                         for (size_t sidx = 0; sidx < b->plan.size(); ++sidx) {
@@ -1419,6 +1425,21 @@ extern "C" int tri_batch_docset(tri_batch *b, size_t q, uint32_t *out, size_t ca
         HIP_TRY(hipSetDevice(b->ix->dev->device));
         // the docID set is the in-order concatenation of the query's task segments
         const DevQuery &dq = b->plan[slot];
+        if (dq.form == RESULT_BITMAP) { // one bit per document (dev_structs.hpp): the region's words come over as they are, the docIDs are written out here
+                const uint32_t w_lo = b->tasks[dq.first_task].tile_begin, w_hi = b->tasks[dq.first_task + dq.ntasks - 1].tile_end;
+                std::vector<uint32_t> words((size_t)(w_hi - w_lo) * SPAN_WORDS);
+                HIP_TRY(hipMemcpy(words.data(), b->d_out + dq.out_off, words.size() * 4, hipMemcpyDeviceToHost));
+                size_t w = 0;
+                for (size_t i = 0; i < words.size(); ++i)
+                        for (uint32_t m = words[i]; m; m &= m - 1u) {
+                                if (w == *n)
+                                        return fail(TRI_ERR_INTERNAL, "query %zu: its bitmap holds more documents than its tasks counted", q);
+                                out[w++] = (uint32_t)(((size_t)w_lo * SPAN_WORDS + i) * 32u + (uint32_t)__builtin_ctz(m));
+                        }
+                if (w != *n)
+                        return fail(TRI_ERR_INTERNAL, "query %zu: its bitmap holds %zu documents, its tasks counted %zu", q, w, *n);
+                return TRI_OK;
+        }
         size_t w = 0;
         for (uint32_t t = 0; t < dq.ntasks; ++t) {
                 const uint32_t c = b->h_counts[dq.first_task + t];
@@ -1429,6 +1450,32 @@ extern "C" int tri_batch_docset(tri_batch *b, size_t q, uint32_t *out, size_t ca
                 w += c;
         }
         HIP_TRY(hipStreamSynchronize(b->ix->dev->stream));
+        return TRI_OK;
+}
+
+// The docID set of query q as the engine holds it when the planner chose the bitmap form for it (dev_structs.hpp RESULT_BITMAP: DocumentsOnly
+// unions / conjunctions of head terms): *first_doc = the docID of bit 0 of words[0] (a multiple of 32), *nwords = the words that follow — bit j of
+// word i: document *first_doc + 32 i + j matches.  words == NULL: only *form (0 docIDs: use tri_batch_docset; 1 bitmap), *first_doc, *nwords.
+extern "C" int tri_batch_docset_bitmap(tri_batch *b, size_t q, int *form, uint32_t *words, size_t cap, uint32_t *first_doc, size_t *nwords) {
+        if (!b || !form || !first_doc || !nwords || q >= b->nq)
+                return fail(TRI_ERR_INVALID, "bad argument");
+        if (!b->synced)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync first");
+        const uint32_t slot = b->slot_of_query[q];
+        *form = 0, *first_doc = 0, *nwords = 0;
+        if (slot == UINT32_MAX || b->plan[slot].form != RESULT_BITMAP)
+                return TRI_OK;
+        const DevQuery &dq = b->plan[slot];
+        const uint32_t w_lo = b->tasks[dq.first_task].tile_begin, w_hi = b->tasks[dq.first_task + dq.ntasks - 1].tile_end;
+        *form = 1;
+        *first_doc = w_lo * SPAN_BITS;
+        *nwords = (size_t)(w_hi - w_lo) * SPAN_WORDS;
+        if (!words)
+                return TRI_OK;
+        if (cap < *nwords)
+                return fail(TRI_ERR_INVALID, "bitmap needs %zu words, %zu given", *nwords, cap);
+        HIP_TRY(hipSetDevice(b->ix->dev->device));
+        HIP_TRY(hipMemcpy(words, b->d_out + dq.out_off, *nwords * 4, hipMemcpyDeviceToHost));
         return TRI_OK;
 }
 

@@ -96,6 +96,7 @@ class TriBatchInfo(C.Structure):
         ("probe_bound_bytes", C.c_uint64),
         ("tree_queries", C.c_uint64),
         ("tree_scratch_bytes", C.c_uint64),
+        ("bitmap_queries", C.c_uint64),
     ]
 
 
@@ -104,7 +105,7 @@ ABI_SYMBOLS = [
     "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream", "tri_dev_set_option", "tri_dev_get_option",
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
-    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
+    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_docset_bitmap", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
     "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
@@ -148,6 +149,7 @@ def hip_lib():
     L.tri_batch_matched_payloads.argtypes = [vp, C.c_size_t, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_match_counts.argtypes = [vp, vp]
     L.tri_batch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.tri_batch_docset_bitmap.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int), vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
     L.tri_batch_scores.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_topk.argtypes = [vp, vp, vp, vp]
     L.tri_batch_topk_device.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
@@ -454,6 +456,18 @@ class Batch:
         got = C.c_size_t()
         _check(hip_lib().tri_batch_docset(self.h, q, out.ctypes.data, n, C.byref(got)))
         return out[: got.value]
+
+    def docset_bitmap(self, q):
+        """None when the engine holds query q's docID set as ascending docIDs; else (first_doc, words u32[]): bit j of words[i] = document
+        first_doc + 32 i + j matches (DocumentsOnly queries expected to match one document in 32 or more; option result_bitmaps)."""
+        L = hip_lib()
+        form, first, nw = C.c_int(), C.c_uint32(), C.c_size_t()
+        _check(L.tri_batch_docset_bitmap(self.h, q, C.byref(form), None, 0, C.byref(first), C.byref(nw)))
+        if not form.value:
+            return None
+        words = np.zeros(nw.value, dtype=np.uint32)
+        _check(L.tri_batch_docset_bitmap(self.h, q, C.byref(form), words.ctypes.data, nw.value, C.byref(first), C.byref(nw)))
+        return first.value, words
 
     def matched_payloads(self, q):
         """FLAG_MATCHED_TERMS | FLAG_HIT_PAYLOADS batches: (lens u8[npos], payloads u64[npos]) parallel to matched_terms()'s positions."""

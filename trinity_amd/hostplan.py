@@ -15,7 +15,7 @@ _SUMMARY = ["block_bytes", "n_plan", "n_qterms", "n_tasks", "n_fused_maps", "n_q
             "n_tree", "tree_queries", "n_tree_words", "off_tree", "n_tree_terms", "off_tree_terms", "n_tree_hidden", "off_tree_hidden"]  # fmt: skip
 
 DEV_QUERY = np.dtype([("nterms", "<u4"), ("term_base", "<u4"), ("out_off", "<u8"), ("out_cap", "<u4"), ("qid", "<u4"), ("first_task", "<u4"), ("ntasks", "<u4"),
-                      ("score_base", "<u4"), ("nscore", "<u4"), ("phrase_base", "<u4"), ("nphrases", "<u4"), ("fused_idx", "<u4"), ("pad0", "<u4")])  # fmt: skip
+                      ("score_base", "<u4"), ("nscore", "<u4"), ("phrase_base", "<u4"), ("nphrases", "<u4"), ("fused_idx", "<u4"), ("form", "<u4")])  # fmt: skip
 DEV_TASK = np.dtype([("slot", "<u4"), ("begin", "<u4"), ("end", "<u4"), ("kind", "<u4"), ("out_off", "<u8")])
 TASK_CAND, TASK_DENSE, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8, TASK_PSET, TASK_PROBE, TASK_TREE = range(10)
 DEV_TREE_NODE = np.dtype([("op", "u1"), ("parent", "u1"), ("ord", "u1"), ("thr", "u1"), ("arg", "<u4"), ("row", "<u4"), ("score", "<u4"), ("rmask", "<u4"),
