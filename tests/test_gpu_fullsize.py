@@ -135,3 +135,54 @@ def test_general_trees_full_size(T, google, lucene):
     check_docsets(T, ix, ora, progs)
     seg, ora, ix = lucene
     check_scored(T, ix, ora, progs, 100, want_fused=True)
+
+
+def test_google_index_beyond_2_gib(T, dev):
+    """codecs.h:26 allows chunks up to 4 GiB; until round 4 a google_codec index of 2 GiB or more was refused (bit 31 of a block's hits offset
+    carried a flag).  A 34 M-document / 680 M-posting segment (2.4 GB): terms whose chunks lie beyond the 2 GiB mark — conjunctions, unions,
+    phrases (k_phrase reads their hits), scores, and the default mode's positions (k_rich) — against the oracle on the same bytes."""
+    seg = T.Segment(34_000_000, 1_000_000, 20, 42)
+    assert seg.index.size >= (1 << 31) + (1 << 26), seg.index.size
+    ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
+    ix = T.Index.from_segment(dev, seg)
+    far = np.nonzero(seg.terms[:, 1].astype(np.uint64) >= (1 << 31))[0]
+    assert len(far) > 1000
+    far = far[np.argsort(-seg.terms[far, 0].astype(np.int64), kind="stable")][:24].tolist()  # the longest lists out there
+    texts = [f"t{a} t{b}" for a, b in zip(far[0::2], far[1::2])] + [f"t{a} OR t{b} OR t{c}" for a, b, c in zip(far[0::3], far[1::3], far[2::3])]
+    texts += [f'"t{a} t{b}"' for a, b in zip(far[0::2], far[1::2])] + [f't1 OR "t{far[1]} t{far[2]}"', f"t{far[3]} NOT t{far[4]}"]
+    texts += [f"t{k % 3} t{a}" for k, a in enumerate(far[:12])] + [f'"t{k % 3} t{a}"' for k, a in enumerate(far[:12])] + [f'"t{a} t{k % 3}"' for k, a in enumerate(far[:12])]  # (a head term's documents hold them)
+    progs = [O.parse_query(t) for t in texts]
+    b = T.Batch(ix, progs, T.FLAG_DOCUMENTS_ONLY)
+    b.run()
+    b.sync()
+    counts, hashes = b.counts(), b.docset_hashes()
+    nonempty = 0
+    for i, (t, p) in enumerate(zip(texts, progs)):
+        want, _ = ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+        assert int(counts[i]) == len(want) and int(hashes[i]) == O.fnv1a_docs(want), t
+        nonempty += len(want) > 0
+    b.close()
+    assert nonempty >= 24, nonempty
+    b = T.Batch(ix, progs, T.FLAG_ACCUMULATED_SCORE, topk=10)
+    b.run()
+    b.sync()
+    d, s, c = b.topk_results()
+    for i, (t, p) in enumerate(zip(texts, progs)):
+        docs, scores = ora.exec(p, O.FLAG_ACCUM_SCORE)
+        td, ts = ora.topk(docs, scores, 10)
+        assert d[i, : len(td)].tolist() == td.tolist(), t
+        np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0, err_msg=t)
+    b.close()
+    rich = progs[:4] + progs[-36::5]
+    b = T.Batch(ix, rich, T.FLAG_MATCHED_TERMS)
+    b.run()
+    b.sync()
+    counts = b.counts()
+    for i, p in enumerate(rich):
+        wdocs, wflat, tt, ht = ora.exec_rich(p)
+        n = int(counts[i])
+        docs = b.docset(i, n)
+        terms, present, freq, pos = b.matched_terms(i, n)
+        assert np.array_equal(docs, wdocs) and int(freq.sum()) == ht and int(sum(bin(int(x)).count("1") for x in present)) == tt
+    b.close()
+    ix.close()

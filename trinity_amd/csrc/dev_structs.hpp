@@ -143,7 +143,9 @@ constexpr uint32_t PL_W = 32768;          // documents per plane window (k_term_
 constexpr uint32_t PL_WORDS = PL_W / 32;  // words of one plane per window
 constexpr uint32_t PL_NONE = 0xffffffffu; // "this term has no plane in this batch"
 constexpr uint32_t PL_PLANES = 3;         // planes per term — A: the document holds the term; B: its frequency there is not 1; C: nor 2
-constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64)
+constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64).  The entry's
+                                                 // low 31 bits: where the block's hits start, in bytes PAST blk_off[] (the block's deltas and frequencies lie
+                                                 // between: a few hundred bytes) — index offsets themselves keep all their 32 bits (codecs.h:26: chunks up to 4 GiB)
 // ---- geometry the host planner (planner.hpp) and the kernels share
 constexpr int TILE_BLOCKS = 256;               // k_and: lead blocks per candidate tile (one 32-candidate row per lane)
 constexpr int TILE_CANDS = TILE_BLOCKS * 32;

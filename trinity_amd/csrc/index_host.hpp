@@ -315,8 +315,6 @@ inline int build_host_index(const uint8_t *index, size_t len, const uint8_t *hit
                 return herr(err, TRI_ERR_INVALID, "tri_index_upload: unknown codec %d", codec);
         if (len > 0xffffffffull)
                 return herr(err, TRI_ERR_FORMAT, "index exceeds 32-bit chunk offsets (codecs.h:26)");
-        if (codec == TRI_CODEC_GOOGLE && len >= 0x80000000ull) // bit 31 of a block's hits offset carries BLK_HITS_PLAIN (k_phrase / k_rich mask it off)
-                return herr(err, TRI_ERR_UNSUPPORTED, "a google_codec index of 2 GiB or more (%zu bytes): split the segment", len);
         H = HostIndex{};
         H.codec = codec;
         H.terms.resize(nterms);
@@ -554,7 +552,7 @@ inline int build_host_index(const uint8_t *index, size_t len, const uint8_t *hit
                         // GOOGLE: byte offset of the block's first hit (k_phrase / k_rich start there).  Bit 31 (BLK_HITS_PLAIN): every hit of the
                         // block is ONE byte — a position delta < 64 without the new-payload-length flag (google_codec.cpp:38-74) —, so a document's
                         // hits start at the block's first hit + the frequencies before it and no hit has to be parsed to find them
-                        uint32_t hits_at = (uint32_t)(s - index);
+                        uint32_t hits_at = (uint32_t)(s - p); // (relative to the block's payload: blk_off[] below)
                         if ((uint64_t)(bend - s) == nhits && !(hits_at >> 31)) {
                                 bool plain = true;
                                 for (const uint8_t *q = s; q < bend && plain; ++q)

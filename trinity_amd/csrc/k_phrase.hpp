@@ -201,7 +201,7 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
                                                 cv = cj < C ? sh.cdoc[cj] : 0xffffffffu;
                                         }
                                 }
-                                uint32_t h = hits_plain & ~BLK_HITS_PLAIN;
+                                uint32_t h = off + (hits_plain & ~BLK_HITS_PLAIN);
                                 cj = ci;
 #pragma unroll
                                 for (int j = 0; j < 32; ++j) {
@@ -230,7 +230,7 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
                 const uint32_t hits_at = ctx.blk_hits[t.first_block + b];
                 cj = ci;
                 if (hits_at & BLK_HITS_PLAIN) { // one byte per hit: locators follow from the frequencies alone
-                        uint32_t h = hits_at & ~BLK_HITS_PLAIN;
+                        uint32_t h = off + (hits_at & ~BLK_HITS_PLAIN);
                         for (uint32_t i = 0; i < n && (mask >> i); ++i) {
                                 const uint32_t f = sf.next();
                                 if ((mask >> i) & 1u) {
@@ -242,7 +242,7 @@ __device__ __forceinline__ void phrase_locate_block(PhraseShared &sh, const uint
                         }
                         return;
                 }
-                s.init(index + hits_at); // hits start (from the directory)
+                s.init(index + off + hits_at); // hits start (from the directory)
                 for (uint32_t i = 0; i < n && (mask >> i); ++i) {
                         const uint32_t f = sf.next();
                         if ((mask >> i) & 1u) {

@@ -173,7 +173,7 @@ __global__ __launch_bounds__(AND_WG) void k_rich(const uint8_t *__restrict__ ind
                                         if constexpr (CODEC == CODEC_GOOGLE) {
                                                 // the hits follow the n freqs in the same byte stream (google_codec.cpp:533-594)
                                                 VbStream hs;
-                                                hs.init(index + (ctx.blk_hits[t.first_block + bj] & ~BLK_HITS_PLAIN)); // where the block's hits start (directory)
+                                                hs.init(index + off + (ctx.blk_hits[t.first_block + bj] & ~BLK_HITS_PLAIN)); // where the block's hits start (directory: bytes past the block's payload offset)
                                                 for (uint32_t i = 0; i < n && (mask >> i); ++i) {
                                                         const uint32_t f = fs.next();
                                                         const uint32_t fw = f & 0xffffu; // what the COUNT pass recorded (term_hits::freq is tokenpos_t)

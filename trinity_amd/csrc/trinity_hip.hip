@@ -780,8 +780,8 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         HIP_TRY(pool_alloc(dev, (void **)&b->d_out, (off + 64) * 4));
         dbg_lap(3);
         if (!b->phrases.empty() && scored) {
-                HIP_TRY(pool_alloc(dev, (void **)&b->d_pscore, (off + 64) * 8));
-                HIP_TRY(hipMemsetAsync(b->d_pscore, 0, (off + 64) * 8, dev->stream_up));
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_pscore, (off + 64) * 8)); // (no clearing: k_phrase writes the entry of every match it keeps, and only
+                                                                                  //  the matches of queries that hold a phrase are ever read — k_score, k_tree_leaves)
         }
         if (rich) {
                 b->rich_R = std::max<uint32_t>(b->rich_R, 1);
