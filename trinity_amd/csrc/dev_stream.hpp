@@ -52,6 +52,25 @@ struct ProfClock {
 #define PROF_COUNT(slot, n)
 #endif
 
+// -DTRI_TASKTIMES builds (perf probes): k_and leaves, per ticket, when the task started and ended (wall_clock64: 100 MHz) in a host-mapped buffer;
+// with TRINITY_TASKTIMES set tri_batch_sync prints the kernel's span, how busy its workgroups were and its longest tasks
+#ifdef TRI_TASKTIMES
+static unsigned long long *g_tt_host = nullptr;
+static size_t g_tt_cap = 0;
+__device__ unsigned long long *g_tt = nullptr;
+#define TASKTIME_(i) do { if (threadIdx.x == 0) g_tt[(i)] = wall_clock64(); } while (0)
+#if TRI_TASKTIMES == 2 // (2: k_score's tasks instead of k_and's)
+#define TASKTIME(i)
+#define TASKTIME_SCORE(i) TASKTIME_(i)
+#else
+#define TASKTIME(i) TASKTIME_(i)
+#define TASKTIME_SCORE(i)
+#endif
+#else
+#define TASKTIME(i)
+#define TASKTIME_SCORE(i)
+#endif
+
 #ifdef TRI_TRACE
 static uint32_t *g_trace_host = nullptr;
 __device__ volatile uint32_t *g_trace = nullptr;

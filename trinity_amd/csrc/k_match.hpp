@@ -136,6 +136,26 @@ __device__ __forceinline__ bool load_block_bytes32(const uint8_t *__restrict__ p
         return block_bytes32_finish(p, r, v);
 }
 
+// The first candidate at or behind `ptr` that is >= doc (C: none), found by GALLOPING from ptr: a block of a rare term spans the docID range of
+// thousands of candidates, and the lane that merges it must not walk them one by one (measured: a 21-document list against a tile of 8192
+// candidates took 680 us of single-lane LDS reads — cfg3's k_and spent half its span in a handful of such tiles)
+__device__ __forceinline__ uint32_t cand_gallop(const AndShared &sh, uint32_t ptr, const uint32_t C, const uint32_t doc) {
+        uint32_t step = 1, lo = ptr;
+        while (lo + step <= C && sh.cand[phys(lo + step - 1)] < doc) {
+                lo += step;
+                step <<= 1;
+        }
+        uint32_t hi = min(lo + step - 1, C);
+        while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (sh.cand[phys(mid)] < doc)
+                        lo = mid + 1;
+                else
+                        hi = mid;
+        }
+        return lo;
+}
+
 // Merge one block of term t against the candidates from `ptr` on (cv = candidate at ptr): set the hit bit of every
 // candidate that is a document of the block.  Full blocks of one-byte deltas take the register path above.
 // (PRE: the caller has already issued the payload loads into raw[] — by reference, so the array stays in registers)
@@ -178,10 +198,8 @@ __device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__rest
                         if (cv <= doc) {
                                 if (cv == doc)
                                         atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
-                                do { // at most a handful of candidates fall into one block
-                                        ++ptr;
-                                        cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
-                                } while (cv < doc);
+                                ptr = cand_gallop(sh, ptr + 1, C, doc); // (usually the next candidate or the one after)
+                                cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
                                 if (cv == doc) // (only after skipping candidates that were below doc)
                                         atomicOr(&sh.hit[ptr >> 5], 1u << (ptr & 31));
                                 if (cv > last)
@@ -194,8 +212,8 @@ __device__ __forceinline__ void merge_block(AndShared &sh, const uint8_t *__rest
         s.init(index, t, b, off);
         for (uint32_t i = 0; i < n; ++i) {
                 doc = (i + 1 < n) ? doc + s.next() : last;
-                while (cv < doc) {
-                        ++ptr;
+                if (cv < doc) {
+                        ptr = cand_gallop(sh, ptr + 1, C, doc);
                         cv = ptr < C ? sh.cand[phys(ptr)] : 0xffffffffu;
                 }
                 if (cv == doc)
@@ -1047,6 +1065,7 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                 if (ticket_no >= ntasks)
                         break;
                 const uint32_t tix = sched[ticket_no];
+                TASKTIME(8 * ticket_no);
                 const DevTask task = tasks[tix];
                 const uint32_t slot = task.slot;
                 const DevQuery q = plan[slot];
@@ -1079,6 +1098,7 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                         }
                         __syncthreads();
                         PROF_LAP(11);
+                        TASKTIME(8 * ticket_no + 2); // (probe builds: the last tile's stamps stay)
                         TRACE(2, slot, tb);
 
                         // ---- every other group filters the surviving candidates: a candidate survives a group when any
@@ -1113,6 +1133,7 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                 and_filter_tile<CODEC>(sh, index, blk_last, blk_off, win, t, C, k - 1, bd PROF_PASS);
                                 TRACE(4, slot, C);
                                 __syncthreads();
+                                TASKTIME(8 * ticket_no + 2 + min(k, 5u));
                                 PROF_LAP(bd ? 12 : 13);
                                 const bool lastterm = k + 1 == q.nterms;
                                 if (!lastterm && !(qterms[q.term_base + k + 1] & QT_GROUP))
@@ -1209,6 +1230,7 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                 }
                 if (wave == 0)
                         counts[tix] = produced; // scalar branch; the wave's lanes store one identical dword
+                TASKTIME(8 * ticket_no + 1);
                 TRACE(5, slot, produced);
         }
         PROF_LAP(15);

@@ -99,6 +99,44 @@ __device__ void topk_offer(TopK &tk, const uint32_t k, const bool valid, const d
                 topk_prune(tk, k, scan);
 }
 
+// The frequency of `doc` in term t (a document of the term): the block through the docID-cell index (or a bisection of the directory), the
+// deltas to the document's slot, the freqs up to it.  What a scorer whose term has a PLANE needs only for the documents planes B and C mark
+// "neither 1 nor 2" (k_planes.hpp).
+template <int CODEC>
+__device__ __noinline__ uint32_t score_lookup_freq(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+                                                   const uint32_t *__restrict__ win, const DevTerm &t, const uint32_t doc) {
+        const uint32_t *bl = blk_last + t.first_block;
+        uint32_t lo = 0, hi = t.nblocks;
+        if (t.win_off != 0xffffffffu) {
+                lo = win[t.win_off + (doc >> CELL_LOG2)];
+                hi = min(win[t.win_off + (doc >> CELL_LOG2) + 1] + 1u, t.nblocks);
+        }
+        while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (bl[mid] < doc)
+                        lo = mid + 1;
+                else
+                        hi = mid;
+        }
+        const uint32_t b = lo;
+        const uint32_t off = blk_off[t.first_block + b];
+        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
+        uint32_t d = b ? bl[b - 1] : 0, pos = n - 1;
+        DeltaStream<CODEC> ds;
+        ds.init(index, t, b, off);
+        for (uint32_t i = 0; i + 1 < n; ++i) { // (GOOGLE: the freqs start where the deltas end, so all of them are walked)
+                d += ds.next();
+                if (d == doc && pos == n - 1)
+                        pos = i;
+        }
+        FreqStream<CODEC> fs;
+        fs.init(index, t, b, off, ds);
+        uint32_t f = 0;
+        for (uint32_t i = 0; i <= pos; ++i)
+                f = fs.next();
+        return f;
+}
+
 struct ScoreShared {
         uint32_t cand[SCORE_TILE];
         double score[SCORE_TILE];
@@ -121,7 +159,8 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                                   const uint32_t *__restrict__ out, const uint32_t *__restrict__ counts, const uint32_t k,
                                                   uint32_t *__restrict__ part_docs, double *__restrict__ part_scores,
                                                   uint32_t *__restrict__ part_counts, double *__restrict__ all_scores,
-                                                  const double *__restrict__ pscore, const int sim) {
+                                                  const double *__restrict__ pscore, const int sim, const uint32_t *__restrict__ win,
+                                                  const uint32_t *__restrict__ splane, const uint32_t *__restrict__ planes, const uint32_t plw) {
         __shared__ ScoreShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
@@ -138,6 +177,7 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                 if (ticket_no >= ntasks)
                         break;
                 const uint32_t tix = sched[ticket_no];
+                TASKTIME_SCORE(8 * ticket_no);
                 const DevTask task = tasks[tix];
                 const DevQuery q = plan[task.slot];
                 const uint32_t M = counts[tix];
@@ -159,6 +199,25 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                 const double w = sweights[q.score_base + ti];
                                 const uint32_t *bl = blk_last + t.first_block;
                                 const uint32_t *bo = blk_off + t.first_block;
+                                const uint32_t prow = splane ? uni(splane[q.score_base + ti]) : PL_NONE;
+                                if (prow != PL_NONE) {
+                                        // the term has a plane (k_term_planes decoded its list once, for every batch of the index): whether a match holds
+                                        // the term is bit A, its frequency there 1 unless bit B says otherwise, 2 unless bit C does — only a match both
+                                        // mark goes to the postings.  (A head term's blocks in a tile's docID range outnumber the tile's matches: without
+                                        // the planes every match decoded a block of every scorer — cfg3: 900 us for a tile of 8192 matches and four head terms)
+                                        const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
+                                        for (uint32_t j = tid; j < C; j += AND_WG) {
+                                                const uint32_t doc = sh.cand[j], wi = doc >> 5, bit = doc & 31u;
+                                                if (!((pa[wi] >> bit) & 1u))
+                                                        continue;
+                                                uint32_t f = 1;
+                                                if ((pa[plw + wi] >> bit) & 1u)
+                                                        f = ((pa[2 * (size_t)plw + wi] >> bit) & 1u) ? score_lookup_freq<CODEC>(index, blk_last, blk_off, win, t, doc) : 2u;
+                                                sh.score[j] += (double)sim_score(sim, w, f);
+                                        }
+                                        __syncthreads();
+                                        continue;
+                                }
                                 // one block of the term against the matches from index j on (cv = match j, known to be <= the
                                 // block's last document).  Deltas: every document gallops forward through the tile's matches
                                 // (exponential probe + bisection in LDS — under an OR a sparse term's neighbours are thousands of
@@ -302,6 +361,7 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                         if (wave == 0)
                                 part_counts[tix] = n;
                 }
+                TASKTIME_SCORE(8 * ticket_no + 1);
                 __syncthreads();
                 PROF_LAP(7);
         }

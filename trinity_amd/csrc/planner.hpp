@@ -24,6 +24,8 @@
 struct tri_options {
         uint64_t dense_min_postings = 512 * 1024; // TASK_DENSE needs at least this many postings over the query's lists (0: every multi-term query)
         uint64_t dense_task_cost = 192 * 1024;    // postings per bitmap-window task
+        uint64_t cand_task_cost = 32 * 1024;      // cost units (postings decoded + 32 per partner block that can hold a candidate) per candidate-tile task
+                                                  // (cfg3's k_and, ms at 96 K / 32 K / 8 K: 0.61 / 0.60 / 0.60 — before the galloping merge 2.93 / 1.75 / 1.77)
         uint64_t fused = 1;                       // AccumulatedScore top-K of dense queries in one pass (k_fused); 0: k_and_dense + k_score
         uint64_t fused_task_cost = 0;             // postings per one-pass task; 0: sized from the batch (256 K .. 8 M, about two tasks per resident workgroup)
         uint64_t fused_freq_cap = 0;              // 0: the field width decides; else a smaller saturation point (exercises the rescoring path)
@@ -33,8 +35,10 @@ struct tri_options {
         uint64_t overlap = 0;                                 // 1: the candidate-tile kernel (k_and) on a second stream beside the window kernels (k_and_dense, k_psets, k_probe), full grids
         uint64_t planes = 7;     // term planes (k_planes.hpp), a bit set: 1 k_and probes them, 2 k_and_dense ORs them in, 4 top-K CNF queries run in k_planes; 0: off
         uint64_t planes_split = 0; // a k_planes query is cut into this many docID ranges (tasks) that share its threshold; 0: 2 or 3 by the batch's size; >= 65536: by postings like the other one-pass tasks.  cfg3's unions: 0 10.9 ms, 2 8.0, 3 8.5, 4 9.2 (a task has fixed costs)
-        uint64_t plane_div = 128; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list);
-                                 // measured, step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the planes' build grows with it)
+        uint64_t plane_div = 512; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list).
+                                 // While a batch built its own planes: step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the
+                                 // build grew with it).  The planes live with the index now (built once): 128 / 512 / 4096: cfg2 1.48 / 1.44 / 1.40, cfg3 12.64 / 12.40 / 12.4,
+                                 // cfg4 17.4 / 16.9 / 16.9 — 355 rows (1.3 GB at 10 M documents) at 512
         uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs 3 bitmaps over the docID space and one decode per run)
         uint64_t plan_threads = 0;             // host threads tri_batch_create plans with; 0: up to 16, one per 512 queries
         uint64_t result_bitmaps = 1;           // DocumentsOnly: a bitmap-window query whose expected matches outnumber the words of a bitmap over its docID range
@@ -91,6 +95,9 @@ struct BatchPlan {
         Span<DevFused> fused;       // slot maps of the one-pass queries (DevQuery::fused_idx)
         Span<uint32_t> qplane;      // parallel to qterms: the term's row in the batch's term planes, or PL_NONE (empty: no planes)
         Span<uint32_t> plane_terms; // row -> term
+        Span<uint32_t> splane;      // parallel to sterms (scored batches with planes; else empty): the scorer's term's plane row, or PL_NONE — k_score reads a
+                                    // match's frequency off planes B / C instead of decoding a block of the term
+        size_t off_splane = 0;
         Span<uint32_t> sterms;      // scored: scorer terms in the reference's summation order; default mode: reportable terms
         Span<double> sweights;      // scored: their ScorerWeights
         Span<DevPhrase> phrases;
@@ -130,7 +137,6 @@ struct BatchPlan {
 };
 
 namespace trip {
-        constexpr uint64_t TASK_COST = 96 * 1024; // postings per candidate-tile task
         constexpr size_t SECTION_ALIGN = 64;
         constexpr uint32_t SCHED_NB = 64 * 4; // schedule buckets per kernel: cost octave + 2 bits
         // launch order of the task kinds: TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, then the one-pass kinds as numbered
@@ -457,7 +463,7 @@ namespace trip {
                 std::vector<DevFused> fused;
                 std::vector<uint32_t> ptasks;
                 std::vector<DevPsetUnit> units; // tix: index into the fragment's tasks; row[]: filled once the planes are chosen
-                std::vector<QUse> quses;
+                std::vector<QUse> quses, suses; // (suses: scorer positions — qpos indexes the fragment's sterms)
                 std::vector<FUse> fuses;
                 std::vector<uint64_t> benefit; // per eligible term (by df rank): postings of decoding the batch's uses save
                 std::vector<uint32_t> keys, hist; // (fill pass) per task its schedule bucket; tasks per bucket
@@ -1369,6 +1375,14 @@ namespace trip {
                                         }
                                 }
                         }
+                        if (C.scored && (planes_opt & 1u)) // k_score: a scorer whose term has a plane reads the match's frequency off the planes
+                                for (uint32_t k = 0; k < t.q.nscore; ++k) {
+                                        const uint32_t term = f.sterms[t.q.score_base + k];
+                                        if (C.plane_ok(term)) {
+                                                f.benefit[ix.df_rank[term]] += std::min<uint64_t>(ix.terms[term].documents, 32ull * t.lead_docs);
+                                                f.suses.push_back({t.q.score_base + k, term});
+                                        }
+                                }
                         t.q.out_off = off;
                         t.q.first_task = (uint32_t)f.tasks.size();
                         if (t.dense) {
@@ -1429,7 +1443,7 @@ namespace trip {
                         } else {
                                 const uint32_t ntiles = (lead.nblocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
                                 const uint64_t per_tile = std::max<uint64_t>(1, t.cost / ntiles);
-                                const uint32_t tiles_per_task = (uint32_t)std::max<uint64_t>(1, TASK_COST / per_tile);
+                                const uint32_t tiles_per_task = (uint32_t)std::max<uint64_t>(1, std::max<uint64_t>(1, opt.cand_task_cost) / per_tile);
                                 for (uint32_t tb = 0; tb < ntiles; tb += tiles_per_task) {
                                         const uint32_t te = std::min(ntiles, tb + tiles_per_task);
                                         f.tcost.push_back(per_tile * (te - tb));
@@ -1635,6 +1649,8 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 for (const Frag &f : frags) {
                         for (const QUse &u : f.quses)
                                 rank_term[ix.df_rank[u.term]] = u.term;
+                        for (const QUse &u : f.suses)
+                                rank_term[ix.df_rank[u.term]] = u.term;
                         for (const FUse &u : f.fuses)
                                 rank_term[ix.df_rank[u.term]] = u.term;
                 }
@@ -1669,6 +1685,8 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         section(P.off_fused, n_fused, sizeof(DevFused));
         section(P.off_qplane, n_qplane, 4);
         section(P.off_plane_terms, chosen.size(), 4);
+        const size_t n_splane = (chosen.empty() || !C.scored) ? 0 : n_sterms;
+        section(P.off_splane, n_splane, 4);
         section(P.off_sterms, n_sterms, 4);
         section(P.off_sweights, C.scored ? n_sterms : 0, 8);
         section(P.off_phrases, n_phrases, sizeof(DevPhrase));
@@ -1695,6 +1713,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         span(P.fused, P.off_fused, n_fused);
         span(P.qplane, P.off_qplane, n_qplane);
         span(P.plane_terms, P.off_plane_terms, chosen.size());
+        span(P.splane, P.off_splane, n_splane);
         span(P.sterms, P.off_sterms, n_sterms);
         span(P.sweights, P.off_sweights, C.scored ? n_sterms : 0);
         span(P.phrases, P.off_phrases, n_phrases);
@@ -1805,6 +1824,11 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 f.hist.assign(TASK_KINDS * SCHED_NB, 0u);
                 for (size_t i = 0; i < f.tasks.size(); ++i) // (the kinds are final: a probe task whose planes were not chosen is a candidate-tile task by now)
                         ++f.hist[f.keys[i] = sched_key(P.tasks[f.b_tasks + i].kind, f.tcost[i])];
+                if (n_splane) {
+                        std::fill(&P.splane.p[f.b_sterms], &P.splane.p[f.b_sterms] + f.sterms.size(), PL_NONE);
+                        for (const QUse &u : f.suses)
+                                P.splane[f.b_sterms + u.qpos] = row_of_rank[ix.df_rank[u.term]];
+                }
                 if (n_qplane) {
                         std::fill(&P.qplane.p[f.b_qterms], &P.qplane.p[f.b_qterms] + f.qterms.size(), PL_NONE);
                         for (const QUse &u : f.quses)

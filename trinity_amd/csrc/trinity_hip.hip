@@ -427,7 +427,7 @@ namespace {
                              {"planes_split", &tri_options::planes_split},
                              {"plane_max_bytes", &tri_options::plane_max_bytes},
                              {"plan_threads", &tri_options::plan_threads},
-                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}};
+                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -862,6 +862,20 @@ extern "C" int tri_batch_run(tri_batch *b) {
         memset(g_trace_host, 0, 64 * 16);
 #endif
         b->ran = true;
+#ifdef TRI_TASKTIMES
+        if (b->n_cand) {
+                if (g_tt_cap < 8 * (size_t)b->tasks.size()) {
+                        if (g_tt_host)
+                                hipHostFree(g_tt_host);
+                        g_tt_cap = 8 * (size_t)b->tasks.size() + 1024;
+                        HIP_TRY(hipHostMalloc((void **)&g_tt_host, g_tt_cap * 8, hipHostMallocMapped | hipHostMallocCoherent));
+                        unsigned long long *dptr = nullptr;
+                        HIP_TRY(hipHostGetDevicePointer((void **)&dptr, g_tt_host, 0));
+                        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_tt), &dptr, sizeof dptr));
+                }
+                memset(g_tt_host, 0, g_tt_cap * 8);
+        }
+#endif
         HIP_TRY(hipStreamWaitEvent(dev->stream, b->ev_up, 0)); // the plan's copy (upload stream) has arrived
         HIP_TRY(hipEventRecord(b->ev0, dev->stream));
         if (n) {
@@ -1081,7 +1095,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(nlegacy, (uint32_t)dev->cus * SCORE_WGS_PER_CU)), dim3(AND_WG), dev->stream, b->ix->d_index,
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, nlegacy,
                                            b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,
-                                           b->d_all_scores, b->d_pscore, b->similarity);
+                                           b->d_all_scores, b->d_pscore, b->similarity, b->ix->d_win, b->splane.empty() ? (const uint32_t *)nullptr : (const uint32_t *)(b->d_arena + b->off_splane),
+                                           (const uint32_t *)b->ix->d_pcache, b->plw);
                         HIP_TRY(hipGetLastError());
                         const uint32_t nqs = (uint32_t)b->plan.size();
                         if (b->topk)
@@ -1141,6 +1156,58 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         }
 #endif
         HIP_TRY(hipStreamSynchronize(dev->stream));
+#ifdef TRI_TASKTIMES
+        if (b->n_cand && getenv("TRINITY_TASKTIMES")) {
+#if TRI_TASKTIMES == 2 // (k_score: tickets run over the docset-materialising tasks, sched[0 ..))
+                const uint32_t nc = b->n_dense + b->n_pset + b->n_probe + b->n_cand, first = 0;
+#else
+                const uint32_t nc = b->n_cand, first = b->n_dense + b->n_pset + b->n_probe;
+#endif
+                unsigned long long t0 = ~0ull, t1 = 0, busy = 0;
+                std::vector<std::pair<unsigned long long, uint32_t>> by;
+                for (uint32_t i = 0; i < nc; ++i) {
+                        const unsigned long long s = g_tt_host[8 * i], e = g_tt_host[8 * i + 1];
+                        if (!s || !e)
+                                continue;
+                        t0 = std::min(t0, s), t1 = std::max(t1, e);
+                        busy += e - s;
+                        by.emplace_back(e - s, i);
+                }
+                std::sort(by.rbegin(), by.rend());
+                const double span_us = (double)(t1 - t0) / 100.0;
+                const unsigned wgs = std::min<uint32_t>(nc, (uint32_t)dev->cus * 4);
+                fprintf(stderr, "[tri tasktimes] k_and: %u tasks, span %.1f us, busy %.1f %% of %u workgroups; mean task %.2f us\n", nc, span_us,
+                        100.0 * (double)busy / ((double)(t1 - t0) * wgs), wgs, (double)busy / 100.0 / std::max<size_t>(1, by.size()));
+                // when the k-th longest-running... the finish-time profile: tasks still running at 25 / 50 / 75 / 90 % of the span
+                for (const double f : {0.25, 0.5, 0.75, 0.9}) {
+                        const unsigned long long at = t0 + (unsigned long long)((double)(t1 - t0) * f);
+                        unsigned running = 0;
+                        for (uint32_t i = 0; i < nc; ++i)
+                                running += g_tt_host[8 * i] <= at && g_tt_host[8 * i + 1] > at;
+                        fprintf(stderr, "   at %2.0f %% of the span: %u tasks running\n", f * 100, running);
+                }
+                for (size_t k = 0; k < std::min<size_t>(12, by.size()); ++k) {
+                        const uint32_t ti = b->sched[first + by[k].second];
+                        const DevTask &tk = b->tasks[ti];
+                        const DevQuery &q = b->plan[tk.slot];
+                        std::string tt;
+                        for (uint32_t j = 0; j < q.nterms; ++j) {
+                                const uint32_t term = b->qterms[q.term_base + j] & QT_TERM;
+                                char buf[96];
+                                snprintf(buf, sizeof buf, " %s%u(df %u%s)", (b->qterms[q.term_base + j] & QT_GROUP) ? "|" : "", term, b->ix->terms[term].documents,
+                                         (!b->qplane.empty() && b->qplane[q.term_base + j] != PL_NONE) ? " plane" : "");
+                                tt += buf;
+                        }
+                        fprintf(stderr, "   %.1f us (started %.1f us in)  ticket %u  tiles [%u, %u)  query %u:%s\n", (double)by[k].first / 100.0,
+                                (double)(g_tt_host[8 * by[k].second] - t0) / 100.0, by[k].second, tk.tile_begin, tk.tile_end, q.qid, tt.c_str());
+                        fprintf(stderr, "        last tile: lead decoded +%.1f us", ((double)g_tt_host[8 * by[k].second + 2] - (double)g_tt_host[8 * by[k].second]) / 100.0);
+                        for (int j = 3; j < 8; ++j)
+                                if (g_tt_host[8 * by[k].second + j])
+                                        fprintf(stderr, "  term %d +%.1f", j - 2, ((double)g_tt_host[8 * by[k].second + j] - (double)g_tt_host[8 * by[k].second]) / 100.0);
+                        fprintf(stderr, "\n");
+                }
+        }
+#endif
         float ms = 0;
         if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess)
                 b->info.last_run_ms = ms;
