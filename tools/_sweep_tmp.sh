@@ -1,3 +1,7 @@
-for wl in cfg1:2000 cfg3:8192 cfg2:16384; do
-WORKLOAD=${wl%%:*} NQ=${wl##*:} $( [ ${wl%%:*} = cfg1 ] && echo "DOCS=100000 VOCAB=10000" ) RUNS=4 env $( [ ${wl%%:*} = cfg1 ] && echo "DOCS=100000 VOCAB=10000" ) python tools/probe_workload.py 2>&1 | grep -v amdgpu | tail -2 | cut -c1-330
+for dw in 0 4096 16384 49152; do
+echo "== dense_window_cost $dw"
+python bench.py --workload cfg5 --steps 4 --warmup 2 --cpu-seconds 0 --scaling-ref-steps 0 --option dense_window_cost=$dw 2>/dev/null | python3 -c "
+import json,sys
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=j['roofline']
+print(round(j['value']), 'ms', round(j['ms_per_step'],3), 'kern', round(j['kernels_only']['ms_per_step'],3), {k:round(v['kernel_ms'],3) for k,v in r['kernels'].items()})"
 done

@@ -59,16 +59,32 @@ static unsigned long long *g_tt_host = nullptr;
 static size_t g_tt_cap = 0;
 __device__ unsigned long long *g_tt = nullptr;
 #define TASKTIME_(i) do { if (threadIdx.x == 0) g_tt[(i)] = wall_clock64(); } while (0)
-#if TRI_TASKTIMES == 2 // (2: k_score's tasks instead of k_and's)
+#if TRI_TASKTIMES == 2 // (2: k_score's tasks instead of k_and's; 3: k_planes')
 #define TASKTIME(i)
 #define TASKTIME_SCORE(i) TASKTIME_(i)
+#define TASKTIME_PLANES(i)
+#define TASKTIME_DENSE(i)
+#elif TRI_TASKTIMES == 3
+#define TASKTIME(i)
+#define TASKTIME_SCORE(i)
+#define TASKTIME_PLANES(i) TASKTIME_(i)
+#define TASKTIME_DENSE(i)
+#elif TRI_TASKTIMES == 4 // (k_and_dense)
+#define TASKTIME(i)
+#define TASKTIME_SCORE(i)
+#define TASKTIME_PLANES(i)
+#define TASKTIME_DENSE(i) TASKTIME_(i)
 #else
 #define TASKTIME(i) TASKTIME_(i)
 #define TASKTIME_SCORE(i)
+#define TASKTIME_PLANES(i)
+#define TASKTIME_DENSE(i)
 #endif
 #else
 #define TASKTIME(i)
 #define TASKTIME_SCORE(i)
+#define TASKTIME_PLANES(i)
+#define TASKTIME_DENSE(i)
 #endif
 
 #ifdef TRI_TRACE

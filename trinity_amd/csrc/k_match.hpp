@@ -1026,7 +1026,9 @@ __global__ __launch_bounds__(DENSE_WG, TRI_DENSE_WAVES) void k_and_dense(const u
                 const DevTask task = tasks[tix];
                 const DevQuery q = plan[task.slot];
                 PROF_LAP(0);
+                TASKTIME_DENSE(8 * ticket_no);
                 dense_task<DENSE_WG, CODEC>(sh, index, blk_last, blk_off, win, terms, qterms, q, task, out, counts + tix, masked, qplane, planes, plw PROF_PASS);
+                TASKTIME_DENSE(8 * ticket_no + 1);
         }
         PROF_LAP(9);
         PROF_FLUSH();

@@ -465,6 +465,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 if (ticket_no >= ntasks)
                         break;
                 const uint32_t tix = sched[ticket_no];
+                TASKTIME_PLANES(8 * ticket_no);
                 const DevTask task = tasks[tix];
                 const DevQuery q = plan[task.slot];
                 unsigned long long *const gthr = qthr + task.slot; // the threshold the query's tasks share
@@ -1126,6 +1127,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         part_counts[tix] = n;
                         counts[tix] = uni(sh.matches);
                 }
+                TASKTIME_PLANES(8 * ticket_no + 1);
                 __syncthreads();
                 PROF_LAP(6);
         }

@@ -24,6 +24,8 @@
 struct tri_options {
         uint64_t dense_min_postings = 512 * 1024; // TASK_DENSE needs at least this many postings over the query's lists (0: every multi-term query)
         uint64_t dense_task_cost = 192 * 1024;    // postings per bitmap-window task
+        uint64_t dense_window_cost = 16 * 1024;   // ... a docID window counts this many postings whatever it holds (k_and_dense: directory look-ups, barriers, the sweep:
+                                                  // measured 28 us a window on unions of rare terms — a task of 77 near-empty windows ran 2.2 ms, cfg5's k_and_dense 58 % busy)
         uint64_t cand_task_cost = 32 * 1024;      // cost units (postings decoded + 32 per partner block that can hold a candidate) per candidate-tile task
                                                   // (cfg3's k_and, ms at 96 K / 32 K / 8 K: 0.61 / 0.60 / 0.60 — before the galloping merge 2.93 / 1.75 / 1.77)
         uint64_t fused = 1;                       // AccumulatedScore top-K of dense queries in one pass (k_fused); 0: k_and_dense + k_score
@@ -1409,7 +1411,7 @@ namespace trip {
                                         bitmap = est * N >= (double)nwin * SPAN_WORDS;
                                 }
                                 t.q.form = bitmap ? RESULT_BITMAP : RESULT_DOCIDS;
-                                const uint64_t per_win = std::max<uint64_t>(1, t.sumdf / (ix.info.docs_cnt / SPAN_BITS + 1));
+                                const uint64_t per_win = std::max<uint64_t>(1, t.sumdf / (ix.info.docs_cnt / SPAN_BITS + 1)) + (pset ? 0 : opt.dense_window_cost);
                                 const uint32_t win_per_task = pset ? PSET_TASK_WINDOWS : (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / per_win);
                                 uint32_t ord = 0;
                                 uint64_t lead_blocks = 0;

@@ -427,7 +427,7 @@ namespace {
                              {"planes_split", &tri_options::planes_split},
                              {"plane_max_bytes", &tri_options::plane_max_bytes},
                              {"plan_threads", &tri_options::plan_threads},
-                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}};
+                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}, {"dense_window_cost", &tri_options::dense_window_cost}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -863,7 +863,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
 #endif
         b->ran = true;
 #ifdef TRI_TASKTIMES
-        if (b->n_cand) {
+        if (b->tasks.size()) {
                 if (g_tt_cap < 8 * (size_t)b->tasks.size()) {
                         if (g_tt_host)
                                 hipHostFree(g_tt_host);
@@ -1157,9 +1157,13 @@ extern "C" int tri_batch_sync(tri_batch *b) {
 #endif
         HIP_TRY(hipStreamSynchronize(dev->stream));
 #ifdef TRI_TASKTIMES
-        if (b->n_cand && getenv("TRINITY_TASKTIMES")) {
+        if (b->tasks.size() && getenv("TRINITY_TASKTIMES")) {
 #if TRI_TASKTIMES == 2 // (k_score: tickets run over the docset-materialising tasks, sched[0 ..))
                 const uint32_t nc = b->n_dense + b->n_pset + b->n_probe + b->n_cand, first = 0;
+#elif TRI_TASKTIMES == 4 // (k_and_dense)
+                const uint32_t nc = b->n_dense, first = 0;
+#elif TRI_TASKTIMES == 3 // (k_planes, the narrow instantiation)
+                const uint32_t nc = b->n_planes, first = b->n_dense + b->n_pset + b->n_probe + b->n_cand + b->n_fused + b->n_fused16 + b->n_fusedgen;
 #else
                 const uint32_t nc = b->n_cand, first = b->n_dense + b->n_pset + b->n_probe;
 #endif
@@ -1175,7 +1179,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 }
                 std::sort(by.rbegin(), by.rend());
                 const double span_us = (double)(t1 - t0) / 100.0;
-                const unsigned wgs = std::min<uint32_t>(nc, (uint32_t)dev->cus * 4);
+                const unsigned wgs = std::min<uint32_t>(nc, (uint32_t)dev->cus * (TRI_TASKTIMES == 3 ? PLK_WGS_PER_CU : TRI_TASKTIMES == 2 ? SCORE_WGS_PER_CU : 4));
                 fprintf(stderr, "[tri tasktimes] k_and: %u tasks, span %.1f us, busy %.1f %% of %u workgroups; mean task %.2f us\n", nc, span_us,
                         100.0 * (double)busy / ((double)(t1 - t0) * wgs), wgs, (double)busy / 100.0 / std::max<size_t>(1, by.size()));
                 // when the k-th longest-running... the finish-time profile: tasks still running at 25 / 50 / 75 / 90 % of the span
@@ -1191,6 +1195,16 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                         const DevTask &tk = b->tasks[ti];
                         const DevQuery &q = b->plan[tk.slot];
                         std::string tt;
+                        if (task_onepass(tk.kind)) {
+                                const DevFused &z = b->fused[q.fused_idx];
+                                char buf[96];
+                                for (uint32_t j = 0; j < z.nslots; ++j) {
+                                        snprintf(buf, sizeof buf, " %u(df %u%s)", z.term[j], b->ix->terms[z.term[j]].documents, z.plane[j] != PL_NONE ? " plane" : "");
+                                        tt += buf;
+                                }
+                                snprintf(buf, sizeof buf, " nreq %u", z.nreq);
+                                tt += buf;
+                        } else
                         for (uint32_t j = 0; j < q.nterms; ++j) {
                                 const uint32_t term = b->qterms[q.term_base + j] & QT_TERM;
                                 char buf[96];
