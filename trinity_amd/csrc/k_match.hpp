@@ -875,10 +875,13 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                                         cur = uni(sh.seg_wlo[k]);
                                         here = cur != uni(sh.seg_whi[k]); // a block ends inside the window
                                 } else {
+                                        // a list too short for a cell index (fewer than WIN_MIN_BLOCKS blocks): every wave finds the block by itself — two
+                                        // rounds of 64 probes, no LDS, no barrier (a workgroup-wide search cost two barriers per list and window: most of the
+                                        // 28 us a near-empty window of a union of rare terms took).  The cursor only moves forward and every wave stores the
+                                        // same value: a wave that reads it late starts from the answer
                                         cur = uni(sh.lcur[k]);
                                         if (cur < uni(t.nblocks) && bl[cur] < w * SPAN_BITS)
-                                                cur += wg_lower_bound<WG>(sh.scan, bl + cur, t.nblocks - cur, w * SPAN_BITS);
-                                        __syncthreads();
+                                                cur = uni(wave_lower_bound(bl, cur, t.nblocks, w * SPAN_BITS));
                                         sh.lcur[k] = cur;
                                 }
                                 if (here)
@@ -935,17 +938,16 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                                 b_lo = uni(sh.seg_wlo[k]);
                                 b_hi = min(uni(sh.seg_whi[k]), nblocks - 1);
                         } else {
-                                b_lo = uni(sh.lcur[k]);
+                                b_lo = uni(sh.lcur[k]); // (the lead pass above left a lead list's cursor on its first block of this window; the cursor stays there:
+                                                        //  the next window's search starts from it)
                                 if (b_lo < nblocks && bl[b_lo] < w0)
-                                        b_lo += wg_lower_bound<WG>(sh.scan, bl + b_lo, nblocks - b_lo, w0);
+                                        b_lo = uni(wave_lower_bound(bl, b_lo, nblocks, w0));
                                 b_hi = b_lo;
                                 if (b_lo < nblocks) {
-                                        b_hi = b_lo + wg_lower_bound<WG>(sh.scan, bl + b_lo, nblocks - b_lo, wlast);
+                                        b_hi = uni(wave_lower_bound(bl, b_lo, nblocks, wlast));
                                         if (b_hi >= nblocks)
                                                 b_hi = nblocks - 1;
                                 }
-                                __syncthreads(); // cursor reads done
-                                sh.lcur[k] = b_lo < nblocks ? b_hi : b_lo;
                         }
                         if (b_lo < nblocks)
                                 galive = true;
