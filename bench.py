@@ -418,7 +418,8 @@ def main():
                 e["needed_frac"] = frac(tot["cand_needed_bytes"], kms[k])
             return e
 
-        step_traffic = sum(v for v in (traffic or {}).values() if v) if traffic else None
+        # (the term planes live with the index: k_term_planes ran once, in the warm-up — the profile saw that one dispatch, a timed step has none)
+        step_traffic = sum(v for k, v in (traffic or {}).items() if v and (k != "k_term_planes" or tp_ms > 0.02)) if traffic else None
         info0 = ixs[parts[0].codec].info()
         if dry:
             k_ms = max(k_ms, 1e-9)
