@@ -64,27 +64,38 @@ __device__ unsigned long long *g_tt = nullptr;
 #define TASKTIME_SCORE(i) TASKTIME_(i)
 #define TASKTIME_PLANES(i)
 #define TASKTIME_DENSE(i)
+#define TASKTIME_PHRASE(i)
 #elif TRI_TASKTIMES == 3
 #define TASKTIME(i)
 #define TASKTIME_SCORE(i)
 #define TASKTIME_PLANES(i) TASKTIME_(i)
 #define TASKTIME_DENSE(i)
+#define TASKTIME_PHRASE(i)
 #elif TRI_TASKTIMES == 4 // (k_and_dense)
 #define TASKTIME(i)
 #define TASKTIME_SCORE(i)
 #define TASKTIME_PLANES(i)
 #define TASKTIME_DENSE(i) TASKTIME_(i)
+#define TASKTIME_PHRASE(i)
+#elif TRI_TASKTIMES == 5 // (k_phrase)
+#define TASKTIME(i)
+#define TASKTIME_SCORE(i)
+#define TASKTIME_PLANES(i)
+#define TASKTIME_DENSE(i)
+#define TASKTIME_PHRASE(i) TASKTIME_(i)
 #else
 #define TASKTIME(i) TASKTIME_(i)
 #define TASKTIME_SCORE(i)
 #define TASKTIME_PLANES(i)
 #define TASKTIME_DENSE(i)
+#define TASKTIME_PHRASE(i)
 #endif
 #else
 #define TASKTIME(i)
 #define TASKTIME_SCORE(i)
 #define TASKTIME_PLANES(i)
 #define TASKTIME_DENSE(i)
+#define TASKTIME_PHRASE(i)
 #endif
 
 #ifdef TRI_TRACE

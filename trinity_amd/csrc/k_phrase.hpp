@@ -331,6 +331,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                 if (ticket_no >= nptasks)
                         break;
                 const uint32_t tix = ptasks[ticket_no];
+                TASKTIME_PHRASE(8 * ticket_no);
                 const DevTask task = tasks[tix];
                 const DevQuery q = plan[task.slot];
                 const uint32_t M = counts[tix];
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                 }
                 if (wave == 0)
                         counts[tix] = wpos;
+                TASKTIME_PHRASE(8 * ticket_no + 1);
                 __syncthreads();
                 PROF_LAP(4);
         }

@@ -1869,6 +1869,30 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         }
                 });
         }
+        // ---- k_phrase's tasks, heaviest first: a task's candidates are bounded by its output region (the lead's documents in its range); in query
+        //      order the 4 ms tasks of a head x head phrase started anywhere in the kernel's span and its last fifth ran on a tenth of the
+        //      workgroups (cfg4: 70 % busy).  A counting sort by the region's size (octave + 2 bits), descending, stable
+        if (P.ptasks.size() > 1) {
+                const size_t np = P.ptasks.size();
+                std::vector<uint32_t> key(np), sorted(np);
+                uint32_t hist[SCHED_NB + 1] = {};
+                for (size_t i = 0; i < np; ++i) {
+                        const uint32_t ti = P.ptasks[i];
+                        const DevTask &tk = P.tasks[ti];
+                        const DevQuery &q = P.plan[tk.slot];
+                        const uint64_t end = ti + 1 < q.first_task + q.ntasks ? P.tasks[ti + 1].out_off : q.out_off + q.out_cap;
+                        const uint64_t c = std::max<uint64_t>(1, end - tk.out_off);
+                        const uint32_t lg = 63u - (uint32_t)__builtin_clzll(c);
+                        const uint32_t frac = lg >= 2 ? (uint32_t)((c >> (lg - 2)) & 3u) : (uint32_t)((c << (2 - lg)) & 3u);
+                        key[i] = SCHED_NB - 1 - (lg * 4 + frac);
+                        ++hist[key[i] + 1];
+                }
+                for (uint32_t bk = 0; bk < SCHED_NB; ++bk)
+                        hist[bk + 1] += hist[bk];
+                for (size_t i = 0; i < np; ++i)
+                        sorted[hist[key[i]]++] = P.ptasks[i];
+                std::copy(sorted.begin(), sorted.end(), P.ptasks.p);
+        }
         P.sparse_cap = (P.sparse_cap + 63u) & ~63u;
         P.plan_ms[3] = ms_since(t0);
         if (opt.account_needed_bytes && !ix.terms.empty()) {

@@ -1160,6 +1160,8 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         if (b->tasks.size() && getenv("TRINITY_TASKTIMES")) {
 #if TRI_TASKTIMES == 2 // (k_score: tickets run over the docset-materialising tasks, sched[0 ..))
                 const uint32_t nc = b->n_dense + b->n_pset + b->n_probe + b->n_cand, first = 0;
+#elif TRI_TASKTIMES == 5 // (k_phrase: tickets run over ptasks[])
+                const uint32_t nc = (uint32_t)b->ptasks.size(), first = 0;
 #elif TRI_TASKTIMES == 4 // (k_and_dense)
                 const uint32_t nc = b->n_dense, first = 0;
 #elif TRI_TASKTIMES == 3 // (k_planes, the narrow instantiation)
@@ -1179,7 +1181,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 }
                 std::sort(by.rbegin(), by.rend());
                 const double span_us = (double)(t1 - t0) / 100.0;
-                const unsigned wgs = std::min<uint32_t>(nc, (uint32_t)dev->cus * (TRI_TASKTIMES == 3 ? PLK_WGS_PER_CU : TRI_TASKTIMES == 2 ? SCORE_WGS_PER_CU : 4));
+                const unsigned wgs = std::min<uint32_t>(nc, (uint32_t)dev->cus * (TRI_TASKTIMES == 3 ? PLK_WGS_PER_CU : TRI_TASKTIMES == 2 ? SCORE_WGS_PER_CU : TRI_TASKTIMES == 5 ? PHRASE_WGS_PER_CU : 4));
                 fprintf(stderr, "[tri tasktimes] k_and: %u tasks, span %.1f us, busy %.1f %% of %u workgroups; mean task %.2f us\n", nc, span_us,
                         100.0 * (double)busy / ((double)(t1 - t0) * wgs), wgs, (double)busy / 100.0 / std::max<size_t>(1, by.size()));
                 // when the k-th longest-running... the finish-time profile: tasks still running at 25 / 50 / 75 / 90 % of the span
@@ -1190,8 +1192,26 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                                 running += g_tt_host[8 * i] <= at && g_tt_host[8 * i + 1] > at;
                         fprintf(stderr, "   at %2.0f %% of the span: %u tasks running\n", f * 100, running);
                 }
+#if TRI_TASKTIMES == 1 // (k_and: the mean of every stamp over all tasks, relative to the task's start)
+                {
+                        double sum[8] = {0}, cnt[8] = {0};
+                        for (uint32_t i = 0; i < nc; ++i)
+                                for (int j = 1; j < 8; ++j)
+                                        if (g_tt_host[8 * i + j] && g_tt_host[8 * i])
+                                                sum[j] += (double)(g_tt_host[8 * i + j] - g_tt_host[8 * i]) / 100.0, cnt[j] += 1;
+                        fprintf(stderr, "   means over the tasks (us after the task's start): end %.1f  last tile's lead decoded %.1f", sum[1] / std::max(1.0, cnt[1]), sum[2] / std::max(1.0, cnt[2]));
+                        for (int j = 3; j < 8; ++j)
+                                if (cnt[j])
+                                        fprintf(stderr, "  term %d %.1f (%.0f tasks)", j - 2, sum[j] / cnt[j], cnt[j]);
+                        fprintf(stderr, "\n");
+                }
+#endif
                 for (size_t k = 0; k < std::min<size_t>(12, by.size()); ++k) {
+#if TRI_TASKTIMES == 5
+                        const uint32_t ti = b->ptasks[by[k].second];
+#else
                         const uint32_t ti = b->sched[first + by[k].second];
+#endif
                         const DevTask &tk = b->tasks[ti];
                         const DevQuery &q = b->plan[tk.slot];
                         std::string tt;
@@ -1210,6 +1230,11 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                                 char buf[96];
                                 snprintf(buf, sizeof buf, " %s%u(df %u%s)", (b->qterms[q.term_base + j] & QT_GROUP) ? "|" : "", term, b->ix->terms[term].documents,
                                          (!b->qplane.empty() && b->qplane[q.term_base + j] != PL_NONE) ? " plane" : "");
+                                tt += buf;
+                        }
+                        {
+                                char buf[64];
+                                snprintf(buf, sizeof buf, "  matches %u phrases %u", b->h_counts.empty() ? 0u : b->h_counts[ti], q.nphrases);
                                 tt += buf;
                         }
                         fprintf(stderr, "   %.1f us (started %.1f us in)  ticket %u  tiles [%u, %u)  query %u:%s\n", (double)by[k].first / 100.0,
