@@ -340,6 +340,22 @@ int tri_gather_results(tri_batch *, tri_comm *, void *counts_all, void *docids_a
 int tri_encode_google(tri_dev *, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first,
                       size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out);
 
+/* SegmentIndexSession::commit (indexer.cpp:311-478) on the device (ABI 7).  The session's postings in INSERTION order — one entry per (document, term), as
+ * document_proxy::insert serialised them (indexer.cpp:33-111): term_ids[i], doc_ids[i], freqs[i] = its counted hits, whose positions (and payloads) follow
+ * each other in positions[] (payload_lens[] / payloads[]; NULL: none) in the same order — are sorted by (termID & 31, termID, documentID): the order the
+ * reference's commit feeds its encoder in (it buckets by termID & 31 and sorts every bucket by (termID, documentID), :399-416; the Google encoder's skiplist
+ * cadence runs across terms, so the order is part of the bytes), gathered, and encoded by the device encoder: index_out / *index_len = the `index` bytes,
+ * term_ids_out[t] / terms_out[t] = the t-th term committed and its term_index_ctx, *nterms how many, *stats what commit adds to the field statistics
+ * (:360 docsCnt, :457 sumTermHits, :470 sumTermsDocs, :476 totalTerms).  The bytes equal tri_encode_google_payloads over the same postings handed over
+ * term after term in that order.  index_out == NULL: sizing call (*index_len, *nterms, *stats).  What commit or the encoder would refuse — document 0, the
+ * same (term, document) twice, positions out of order — is TRI_ERR_INVALID naming the posting. */
+typedef struct tri_commit_stats {
+        uint64_t docs_cnt, sum_terms_docs, sum_term_hits, total_terms;
+} tri_commit_stats;
+int tri_commit_google(tri_dev *, const uint32_t *term_ids, const uint32_t *doc_ids, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
+                      const uint64_t *payloads, size_t npostings, size_t npositions, uint8_t *index_out, size_t cap, size_t *index_len, uint32_t *term_ids_out,
+                      tri_term *terms_out, size_t terms_cap, size_t *nterms, tri_commit_stats *stats);
+
 /* The same with hit payloads (Encoder::new_hit(pos, payload), google_codec.cpp:38-74): payload_lens[h] (0 .. 8) and payloads[h] (the
  * payload's first byte in the low 8 bits) per hit, parallel to positions[].  A hit is written as varint(position delta << 1 | the
  * length differs from the previous hit's of the document) [u8 new length] payload bytes, the length state restarting with every

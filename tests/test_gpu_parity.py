@@ -1374,6 +1374,57 @@ def test_google_encoder_on_the_device(T, dev):
             ix.close()
 
 
+@pytest.mark.parametrize("payloads", [False, True])
+def test_commit_on_the_device(T, dev, payloads):
+    """tri_commit_google — SegmentIndexSession::commit (indexer.cpp:311-478): a session's postings in INSERTION order (document after document, a
+    document's terms in any order) are sorted on the device by (termID & 31, termID, documentID) — the order the reference's commit walks its 32 buckets
+    in —, gathered and encoded there.  The bytes, the committed terms' order and their term table equal the host encoder's over the same postings handed
+    over term after term in that order; the field statistics are the session's; what commit would refuse is refused."""
+    from trinity_amd import engine as E
+
+    def slices(hit0, idx):  # the hits of the postings idx, one posting after the other
+        n = (hit0[idx + 1] - hit0[idx]).astype(np.int64)
+        return np.repeat(hit0[idx] - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum())) if idx.size else np.zeros(0, np.int64)
+
+    rng = np.random.default_rng(17)
+    for nterms in (1, 60, 1500):
+        docs, freqs, pos, tf = random_postings(rng, nterms)
+        hit0 = np.concatenate([[0], np.cumsum(freqs.astype(np.int64))])
+        plen = rng.integers(0, 9, size=pos.size).astype(np.uint8) if payloads else None
+        pval = rng.integers(0, 2**63, size=pos.size, dtype=np.uint64) if payloads else None
+        if payloads:
+            pval &= (np.uint64(1) << (plen.astype(np.uint64) * np.uint64(8))) - np.uint64(1)  # (only the payload's own bytes count)
+            pval[plen == 8] = rng.integers(0, 2**63, size=int((plen == 8).sum()), dtype=np.uint64)
+        tids = rng.choice(np.arange(1, 50 * nterms + 64, dtype=np.uint32), size=nterms, replace=False)  # (many share their low five bits)
+        term_of = np.repeat(np.arange(nterms), np.diff(tf).astype(np.int64))
+        # the session: documents in a random order, every document's postings together, its terms in a random order
+        order = np.lexsort((rng.random(docs.size), rng.permutation(int(docs.max()) + 1)[docs] if docs.size else docs))
+        s_terms, s_docs, s_freqs = tids[term_of[order]], docs[order], freqs[order]
+        take = slices(hit0, order)
+        s_pos = pos[take]
+        got, gtids, gterms, stats = dev.commit_google(s_terms, s_docs, s_freqs, s_pos, None if plen is None else plen[take], None if pval is None else pval[take])
+        # what commit feeds the encoder: the terms that have postings, by (termID & 31, termID); each one's documents ascending
+        live = [t for t in range(nterms) if tf[t + 1] > tf[t]]
+        live.sort(key=lambda t: (int(tids[t]) & 31, int(tids[t])))
+        sel = np.concatenate([np.arange(tf[t], tf[t + 1], dtype=np.int64) for t in live]) if live else np.zeros(0, np.int64)
+        wtf = np.concatenate([[0], np.cumsum([int(tf[t + 1] - tf[t]) for t in live])]).astype(np.uint64)
+        wtake = slices(hit0, sel)
+        want, wterms = E.host_encode_google(docs[sel], freqs[sel], pos[wtake], wtf, None if plen is None else plen[wtake], None if pval is None else pval[wtake])
+        assert gtids.tolist() == [int(tids[t]) for t in live], nterms
+        assert np.array_equal(gterms, wterms), nterms
+        assert got.size == want.size and np.array_equal(got, want), (nterms, int(np.argmax(got[: want.size] != want[: got.size])))
+        assert stats == {"docs_cnt": len(set(docs.tolist())), "sum_terms_docs": int(docs.size), "sum_term_hits": int(freqs.sum()), "total_terms": len(live)}
+    # refused: the same (term, document) twice; document 0; positions out of order
+    with pytest.raises(T.TrinityError, match="twice"):
+        dev.commit_google([7, 7], [5, 5], [1, 1], [3, 4])
+    with pytest.raises(T.TrinityError, match="document 0"):
+        dev.commit_google([7], [0], [1], [3])
+    with pytest.raises(T.TrinityError, match="positions"):
+        dev.commit_google([7], [5], [2], [9, 3])
+    got, gtids, gterms, stats = dev.commit_google(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint16))
+    assert got.size == 0 and gtids.size == 0 and stats["total_terms"] == 0
+
+
 def test_google_encoder_on_the_device_with_payloads(T, dev):
     """tri_encode_google_payloads against the host encoder (whose payload bytes the reference-written edge segment pins, tests/test_abi.py):
     hits with payloads of 0 .. 8 bytes whose length changes from hit to hit or stays (both arms of the flag bit, google_codec.cpp:59-66),

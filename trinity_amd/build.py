@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 LIB_HIP = os.path.join(PKG, "libtrinity_hip.so")
 LIB_HOST = os.path.join(PKG, "libtrinity_host.so")
-HIP_SRCS = [os.path.join(PKG, "csrc", "trinity_hip.hip")]
+HIP_SRCS = [os.path.join(PKG, "csrc", "trinity_hip.hip"), os.path.join(PKG, "csrc", "commit_sort.hip")]
 HOST_SRCS = [os.path.join(PKG, "csrc", "host", "synth.cpp"), os.path.join(PKG, "csrc", "host", "plan_host.cpp")]
 
 

@@ -363,6 +363,7 @@ struct tri_batch : BatchPlan {
 #include "k_phrase.hpp"
 #include "k_rich.hpp"
 #include "k_tree.hpp"
+#include "k_commit.hpp"
 
 // launch the instantiation of a codec-templated kernel that matches the uploaded segment
 #define TRI_LAUNCH(K, codec, grid, block, stream, ...)                                              \
@@ -1184,7 +1185,21 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 const unsigned wgs = std::min<uint32_t>(nc, (uint32_t)dev->cus * (TRI_TASKTIMES == 3 ? PLK_WGS_PER_CU : TRI_TASKTIMES == 2 ? SCORE_WGS_PER_CU : TRI_TASKTIMES == 5 ? PHRASE_WGS_PER_CU : 4));
                 fprintf(stderr, "[tri tasktimes] k_and: %u tasks, span %.1f us, busy %.1f %% of %u workgroups; mean task %.2f us\n", nc, span_us,
                         100.0 * (double)busy / ((double)(t1 - t0) * wgs), wgs, (double)busy / 100.0 / std::max<size_t>(1, by.size()));
-                // when the k-th longest-running... the finish-time profile: tasks still running at 25 / 50 / 75 / 90 % of the span
+                if (!by.empty()) { // (by: descending) the distribution, and what share of the workgroups' time the longest tasks take
+                        auto at = [&](double f) { return (double)by[std::min(by.size() - 1, (size_t)(f * by.size()))].first / 100.0; };
+                        unsigned long long top1 = 0, top5 = 0, top20 = 0;
+                        for (size_t i = 0; i < by.size(); ++i) {
+                                if (i < by.size() / 100)
+                                        top1 += by[i].first;
+                                if (i < by.size() / 20)
+                                        top5 += by[i].first;
+                                if (i < by.size() / 5)
+                                        top20 += by[i].first;
+                        }
+                        fprintf(stderr, "   task us: max %.1f  p99 %.1f  p90 %.1f  p50 %.1f  p10 %.1f; the longest 1 %% / 5 %% / 20 %% of the tasks take %.1f / %.1f / %.1f %% of the time\n", at(0), at(0.01), at(0.1),
+                                at(0.5), at(0.9), 100.0 * top1 / busy, 100.0 * top5 / busy, 100.0 * top20 / busy);
+                }
+                // the finish-time profile: tasks still running at 25 / 50 / 75 / 90 % of the span
                 for (const double f : {0.25, 0.5, 0.75, 0.9}) {
                         const unsigned long long at = t0 + (unsigned long long)((double)(t1 - t0) * f);
                         unsigned running = 0;
@@ -1992,71 +2007,57 @@ extern "C" int tri_encode_google(tri_dev *dev, const uint32_t *docs, const uint3
         return tri_encode_google_payloads(dev, docs, freqs, positions, nullptr, nullptr, npositions, term_first, nterms, index_out, cap, index_len, terms_out);
 }
 
-extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
-                                          const uint64_t *payloads, size_t npositions, const uint64_t *term_first, size_t nterms, uint8_t *index_out, size_t cap,
-                                          size_t *index_len, tri_term *terms_out) {
-        if (!dev || !term_first || !index_len || (nterms && !terms_out) || (payload_lens && !payloads))
-                return fail(TRI_ERR_INVALID, "tri_encode_google: null argument");
-        HIP_TRY(hipSetDevice(dev->device));
-        const uint64_t np = nterms ? term_first[nterms] : 0;
-        if (np && (!docs || !freqs))
-                return fail(TRI_ERR_INVALID, "tri_encode_google: null postings");
-        if (npositions && !positions)
-                return fail(TRI_ERR_INVALID, "tri_encode_google: null positions");
-        // ---- host: the block structure (which block belongs to which term) and input validation
+// ---- the device side of the Google encoder, shared by tri_encode_google[_payloads] (postings uploaded from the host) and tri_commit_google
+//      (postings sorted and gathered on the device): d.docs / d.freqs / d.pos (/ d.plens, d.payloads) hold np postings and nhits hits grouped by term as
+//      term_first (host) says, validated by the caller
+namespace {
+struct EncBufs {
+        uint32_t *docs = nullptr, *freqs = nullptr, *blk_first = nullptr, *blk_term = nullptr, *sizes = nullptr, *tails = nullptr;
+        uint16_t *pos = nullptr;
+        uint64_t *hit_off = nullptr, *term_first = nullptr, *blk_off = nullptr, *term_off = nullptr, *payloads = nullptr, *scan_sums = nullptr;
+        uint64_t scan_cap = 0;
+        uint8_t *out = nullptr, *plens = nullptr;
+        ~EncBufs() {
+                for (void *p : {(void *)docs, (void *)freqs, (void *)blk_first, (void *)blk_term, (void *)sizes, (void *)tails, (void *)pos, (void *)hit_off,
+                                (void *)term_first, (void *)blk_off, (void *)term_off, (void *)out, (void *)payloads, (void *)plens, (void *)scan_sums})
+                        hipFree(p);
+        }
+};
+// exclusive scan of n u32 into u64 over the whole device: chunk sums, chunk bases, chunks (k_encode.hpp)
+int enc_scan(tri_dev *dev, EncBufs &d, const uint32_t *in, uint64_t *outp, const uint64_t n) {
+        const uint64_t nchunks = (n + ENC_SCAN_CHUNK - 1) / ENC_SCAN_CHUNK;
+        if (nchunks <= 1) {
+                hipLaunchKernelGGL(k_enc_scan, dim3(1), dim3(1024), 0, dev->stream, in, outp, n);
+                return TRI_OK;
+        }
+        if (nchunks + 1 > d.scan_cap) {
+                hipFree(d.scan_sums);
+                d.scan_sums = nullptr;
+                d.scan_cap = nchunks + 1;
+                HIP_TRY(hipMalloc((void **)&d.scan_sums, d.scan_cap * 8));
+        }
+        hipLaunchKernelGGL(k_enc_scan_sums, dim3((uint32_t)nchunks), dim3(1024), 0, dev->stream, in, d.scan_sums, n);
+        hipLaunchKernelGGL(k_enc_scan_bases, dim3(1), dim3(1024), 0, dev->stream, d.scan_sums, nchunks);
+        hipLaunchKernelGGL(k_enc_scan_chunks, dim3((uint32_t)nchunks), dim3(1024), 0, dev->stream, in, (const uint64_t *)d.scan_sums, outp, n);
+        return TRI_OK;
+}
+int encode_google_device(tri_dev *dev, EncBufs &d, const uint64_t *term_first, const size_t nterms, const uint64_t np, const uint64_t nhits, uint8_t *index_out,
+                         const size_t cap, size_t *index_len, tri_term *terms_out) {
+        (void)np;
+        (void)nhits;
+        // ---- host: the block structure (which block belongs to which term)
         std::vector<uint32_t> blk_first(nterms + 1, 0), blk_term;
-        uint64_t nhits = 0;
         for (size_t t = 0; t < nterms; ++t) {
-                if (term_first[t + 1] < term_first[t])
-                        return fail(TRI_ERR_INVALID, "tri_encode_google: term_first must ascend");
-                const uint64_t n = term_first[t + 1] - term_first[t];
-                if (n > 0xffffffffull)
-                        return fail(TRI_ERR_UNSUPPORTED, "term %zu: more than 2^32 documents", t);
-                uint32_t prev = 0;
-                for (uint64_t p = term_first[t]; p < term_first[t + 1]; ++p) {
-                        if (!docs[p] || docs[p] <= prev)
-                                return fail(TRI_ERR_INVALID, "term %zu: document IDs must be > 0 and strictly ascending (codecs.h:188-190)", t);
-                        prev = docs[p];
-                        // the posting's hits: positions[nhits .. nhits + freqs[p]) — counted hits only (new_hit drops a payload-less hit at
-                        // position 0, google_codec.cpp:42-45), non-descending within the document (:49: the encoder writes pos - lastPos)
-                        if ((uint64_t)freqs[p] > npositions - std::min<uint64_t>(npositions, nhits))
-                                return fail(TRI_ERR_INVALID, "term %zu, document %u: freqs[] asks for more positions than the %zu given", t, docs[p], npositions);
-                        uint32_t last_pos = 0;
-                        for (uint64_t h = nhits; h < nhits + freqs[p]; ++h) {
-                                const uint32_t plen = payload_lens ? payload_lens[h] : 0u;
-                                if (plen > 8)
-                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: a payload of %u bytes (at most 8: google_codec.cpp:46)", t, docs[p], plen);
-                                if ((!positions[h] && !plen) || positions[h] < last_pos) // (a position-0 hit WITH a payload is a counted hit: :42-45)
-                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: positions must be non-descending within a document, and > 0 for a hit without payload (google_codec.cpp:42-49)", t, docs[p]);
-                                last_pos = positions[h];
-                        }
-                        nhits += freqs[p];
-                }
-                const uint64_t nb = (n + 31) / 32;
+                const uint64_t nb = (term_first[t + 1] - term_first[t] + 31) / 32;
                 if ((uint64_t)blk_first[t] + nb > 0xfffffff0ull)
                         return fail(TRI_ERR_UNSUPPORTED, "more than 2^32 blocks");
                 blk_first[t + 1] = blk_first[t] + (uint32_t)nb;
                 blk_term.insert(blk_term.end(), (size_t)nb, (uint32_t)t);
         }
         const uint32_t nblocks = blk_first[nterms];
-        struct Bufs {
-                uint32_t *docs = nullptr, *freqs = nullptr, *blk_first = nullptr, *blk_term = nullptr, *sizes = nullptr, *tails = nullptr;
-                uint16_t *pos = nullptr;
-                uint64_t *hit_off = nullptr, *term_first = nullptr, *blk_off = nullptr, *term_off = nullptr, *payloads = nullptr, *scan_sums = nullptr;
-                uint64_t scan_cap = 0;
-                uint8_t *out = nullptr, *plens = nullptr;
-                ~Bufs() {
-                        for (void *p : {(void *)docs, (void *)freqs, (void *)blk_first, (void *)blk_term, (void *)sizes, (void *)tails, (void *)pos, (void *)hit_off,
-                                        (void *)term_first, (void *)blk_off, (void *)term_off, (void *)out, (void *)payloads, (void *)plens, (void *)scan_sums})
-                                hipFree(p);
-                }
-        } d;
         std::vector<uint64_t> term_off(nterms + 1, 0);
         std::vector<uint64_t> blk_off(nblocks + 1, 0);
         if (nblocks) {
-                HIP_TRY(hipMalloc((void **)&d.docs, np * 4));
-                HIP_TRY(hipMalloc((void **)&d.freqs, np * 4));
-                HIP_TRY(hipMalloc((void **)&d.pos, (nhits + 1) * 2));
                 HIP_TRY(hipMalloc((void **)&d.hit_off, (np + 1) * 8));
                 HIP_TRY(hipMalloc((void **)&d.term_first, (nterms + 1) * 8));
                 HIP_TRY(hipMalloc((void **)&d.blk_first, (nterms + 1) * 4));
@@ -2064,44 +2065,17 @@ extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, co
                 HIP_TRY(hipMalloc((void **)&d.sizes, (size_t)nblocks * 4));
                 HIP_TRY(hipMalloc((void **)&d.tails, (size_t)nblocks * 4));
                 HIP_TRY(hipMalloc((void **)&d.blk_off, ((size_t)nblocks + 1) * 8));
-                HIP_TRY(hipMemcpyAsync(d.docs, docs, np * 4, hipMemcpyHostToDevice, dev->stream));
-                HIP_TRY(hipMemcpyAsync(d.freqs, freqs, np * 4, hipMemcpyHostToDevice, dev->stream));
-                if (nhits)
-                        HIP_TRY(hipMemcpyAsync(d.pos, positions, nhits * 2, hipMemcpyHostToDevice, dev->stream));
-                if (nhits && payload_lens) {
-                        HIP_TRY(hipMalloc((void **)&d.plens, nhits));
-                        HIP_TRY(hipMalloc((void **)&d.payloads, nhits * 8));
-                        HIP_TRY(hipMemcpyAsync(d.plens, payload_lens, nhits, hipMemcpyHostToDevice, dev->stream));
-                        HIP_TRY(hipMemcpyAsync(d.payloads, payloads, nhits * 8, hipMemcpyHostToDevice, dev->stream));
-                }
                 HIP_TRY(hipMemcpyAsync(d.term_first, term_first, (nterms + 1) * 8, hipMemcpyHostToDevice, dev->stream));
                 HIP_TRY(hipMemcpyAsync(d.blk_first, blk_first.data(), (nterms + 1) * 4, hipMemcpyHostToDevice, dev->stream));
                 HIP_TRY(hipMemcpyAsync(d.blk_term, blk_term.data(), (size_t)nblocks * 4, hipMemcpyHostToDevice, dev->stream));
                 // hits before every posting, then the blocks' sizes and their running sum
                 // (exclusive scans over the whole device: chunk sums, chunk bases, chunks — k_encode.hpp)
-                auto scan = [&](const uint32_t *in, uint64_t *outp, const uint64_t n) -> int {
-                        const uint64_t nchunks = (n + ENC_SCAN_CHUNK - 1) / ENC_SCAN_CHUNK;
-                        if (nchunks <= 1) {
-                                hipLaunchKernelGGL(k_enc_scan, dim3(1), dim3(1024), 0, dev->stream, in, outp, n);
-                                return TRI_OK;
-                        }
-                        if (nchunks + 1 > d.scan_cap) {
-                                hipFree(d.scan_sums);
-                                d.scan_sums = nullptr;
-                                d.scan_cap = nchunks + 1;
-                                HIP_TRY(hipMalloc((void **)&d.scan_sums, d.scan_cap * 8));
-                        }
-                        hipLaunchKernelGGL(k_enc_scan_sums, dim3((uint32_t)nchunks), dim3(1024), 0, dev->stream, in, d.scan_sums, n);
-                        hipLaunchKernelGGL(k_enc_scan_bases, dim3(1), dim3(1024), 0, dev->stream, d.scan_sums, nchunks);
-                        hipLaunchKernelGGL(k_enc_scan_chunks, dim3((uint32_t)nchunks), dim3(1024), 0, dev->stream, in, (const uint64_t *)d.scan_sums, outp, n);
-                        return TRI_OK;
-                };
                 int rcs;
-                if ((rcs = scan(d.freqs, d.hit_off, np)))
+                if ((rcs = enc_scan(dev, d, d.freqs, d.hit_off, np)))
                         return rcs;
                 const EncArgs a{d.docs, d.freqs, d.pos, d.plens, d.payloads, d.hit_off, d.term_first, d.blk_first, d.blk_term, nblocks};
                 hipLaunchKernelGGL(k_enc_size, dim3((nblocks + 255) / 256), dim3(256), 0, dev->stream, a, d.sizes, d.tails);
-                if ((rcs = scan(d.sizes, d.blk_off, (uint64_t)nblocks)))
+                if ((rcs = enc_scan(dev, d, d.sizes, d.blk_off, (uint64_t)nblocks)))
                         return rcs;
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(blk_off.data(), d.blk_off, ((size_t)nblocks + 1) * 8, hipMemcpyDeviceToHost, dev->stream));
@@ -2140,6 +2114,204 @@ extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, co
         }
         HIP_TRY(hipMemcpyAsync(index_out, d.out, *index_len, hipMemcpyDeviceToHost, dev->stream));
         HIP_TRY(hipStreamSynchronize(dev->stream));
+        return TRI_OK;
+}
+
+} // namespace
+
+extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
+                                          const uint64_t *payloads, size_t npositions, const uint64_t *term_first, size_t nterms, uint8_t *index_out, size_t cap,
+                                          size_t *index_len, tri_term *terms_out) {
+        if (!dev || !term_first || !index_len || (nterms && !terms_out) || (payload_lens && !payloads))
+                return fail(TRI_ERR_INVALID, "tri_encode_google: null argument");
+        HIP_TRY(hipSetDevice(dev->device));
+        const uint64_t np = nterms ? term_first[nterms] : 0;
+        if (np && (!docs || !freqs))
+                return fail(TRI_ERR_INVALID, "tri_encode_google: null postings");
+        if (npositions && !positions)
+                return fail(TRI_ERR_INVALID, "tri_encode_google: null positions");
+        // ---- host: input validation (what the reference's encoder would refuse)
+        uint64_t nhits = 0;
+        for (size_t t = 0; t < nterms; ++t) {
+                if (term_first[t + 1] < term_first[t])
+                        return fail(TRI_ERR_INVALID, "tri_encode_google: term_first must ascend");
+                const uint64_t n = term_first[t + 1] - term_first[t];
+                if (n > 0xffffffffull)
+                        return fail(TRI_ERR_UNSUPPORTED, "term %zu: more than 2^32 documents", t);
+                uint32_t prev = 0;
+                for (uint64_t p = term_first[t]; p < term_first[t + 1]; ++p) {
+                        if (!docs[p] || docs[p] <= prev)
+                                return fail(TRI_ERR_INVALID, "term %zu: document IDs must be > 0 and strictly ascending (codecs.h:188-190)", t);
+                        prev = docs[p];
+                        // the posting's hits: positions[nhits .. nhits + freqs[p]) — counted hits only (new_hit drops a payload-less hit at
+                        // position 0, google_codec.cpp:42-45), non-descending within the document (:49: the encoder writes pos - lastPos)
+                        if ((uint64_t)freqs[p] > npositions - std::min<uint64_t>(npositions, nhits))
+                                return fail(TRI_ERR_INVALID, "term %zu, document %u: freqs[] asks for more positions than the %zu given", t, docs[p], npositions);
+                        uint32_t last_pos = 0;
+                        for (uint64_t h = nhits; h < nhits + freqs[p]; ++h) {
+                                const uint32_t plen = payload_lens ? payload_lens[h] : 0u;
+                                if (plen > 8)
+                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: a payload of %u bytes (at most 8: google_codec.cpp:46)", t, docs[p], plen);
+                                if ((!positions[h] && !plen) || positions[h] < last_pos) // (a position-0 hit WITH a payload is a counted hit: :42-45)
+                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: positions must be non-descending within a document, and > 0 for a hit without payload (google_codec.cpp:42-49)", t, docs[p]);
+                                last_pos = positions[h];
+                        }
+                        nhits += freqs[p];
+                }
+        }
+        EncBufs d;
+        if (np) {
+                HIP_TRY(hipMalloc((void **)&d.docs, np * 4));
+                HIP_TRY(hipMalloc((void **)&d.freqs, np * 4));
+                HIP_TRY(hipMalloc((void **)&d.pos, (nhits + 1) * 2));
+                HIP_TRY(hipMemcpyAsync(d.docs, docs, np * 4, hipMemcpyHostToDevice, dev->stream));
+                HIP_TRY(hipMemcpyAsync(d.freqs, freqs, np * 4, hipMemcpyHostToDevice, dev->stream));
+                if (nhits)
+                        HIP_TRY(hipMemcpyAsync(d.pos, positions, nhits * 2, hipMemcpyHostToDevice, dev->stream));
+                if (nhits && payload_lens) {
+                        HIP_TRY(hipMalloc((void **)&d.plens, nhits));
+                        HIP_TRY(hipMalloc((void **)&d.payloads, nhits * 8));
+                        HIP_TRY(hipMemcpyAsync(d.plens, payload_lens, nhits, hipMemcpyHostToDevice, dev->stream));
+                        HIP_TRY(hipMemcpyAsync(d.payloads, payloads, nhits * 8, hipMemcpyHostToDevice, dev->stream));
+                }
+        }
+        return encode_google_device(dev, d, term_first, nterms, np, nhits, index_out, cap, index_len, terms_out);
+}
+
+// ---- SegmentIndexSession::commit (indexer.cpp:311-478) on the device: sort, gather, encode (k_commit.hpp, commit_sort.hip, k_encode.hpp)
+extern "C" int tri_sort_pairs_u64_u32(const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned *vals_in, unsigned *vals_out, size_t n, void *tmp,
+                                      size_t *tmp_bytes, hipStream_t stream); // (commit_sort.hip)
+
+extern "C" int tri_commit_google(tri_dev *dev, const uint32_t *term_ids, const uint32_t *doc_ids, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
+                                 const uint64_t *payloads, size_t npostings, size_t npositions, uint8_t *index_out, size_t cap, size_t *index_len, uint32_t *term_ids_out,
+                                 tri_term *terms_out, size_t terms_cap, size_t *nterms, tri_commit_stats *stats) {
+        if (!dev || !index_len || !nterms || (npostings && (!term_ids || !doc_ids || !freqs)) || (payload_lens && !payloads) || (npositions && !positions))
+                return fail(TRI_ERR_INVALID, "tri_commit_google: null argument");
+        if (npostings > 0xfffffff0ull)
+                return fail(TRI_ERR_UNSUPPORTED, "tri_commit_google: more than 2^32 postings in one session: commit in parts");
+        HIP_TRY(hipSetDevice(dev->device));
+        const uint64_t np = npostings;
+        uint64_t nhits = 0, docs_cnt = 0;
+        for (uint64_t i = 0; i < np; ++i) { // (the session's own bookkeeping: hits in all, documents = runs of one documentID in insertion order)
+                nhits += freqs[i];
+                docs_cnt += i == 0 || doc_ids[i] != doc_ids[i - 1];
+        }
+        if (nhits > npositions)
+                return fail(TRI_ERR_INVALID, "tri_commit_google: freqs[] asks for %llu positions, %zu given", (unsigned long long)nhits, npositions);
+        *nterms = 0;
+        *index_len = 0;
+        if (stats)
+                *stats = tri_commit_stats{docs_cnt, np, nhits, 0};
+        if (!np)
+                return TRI_OK;
+        struct Tmp {
+                std::vector<void *> p;
+                ~Tmp() {
+                        for (void *q : p)
+                                hipFree(q);
+                }
+                hipError_t get(void **out, size_t bytes) {
+                        const hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+                        if (e == hipSuccess)
+                                p.push_back(*out);
+                        return e;
+                }
+        } tmp;
+        uint32_t *d_terms, *d_docs_in, *d_freqs_in, *d_vals, *d_perm, *d_marks, *d_term_ids;
+        unsigned long long *d_keys, *d_keys_sorted, *d_err;
+        uint16_t *d_pos_in = nullptr;
+        uint8_t *d_plens_in = nullptr;
+        uint64_t *d_payloads_in = nullptr, *d_hit_off_in, *d_hit_off_out, *d_mark_rank, *d_term_first;
+        HIP_TRY(tmp.get((void **)&d_terms, np * 4));
+        HIP_TRY(tmp.get((void **)&d_docs_in, np * 4));
+        HIP_TRY(tmp.get((void **)&d_freqs_in, np * 4));
+        HIP_TRY(tmp.get((void **)&d_keys, np * 8));
+        HIP_TRY(tmp.get((void **)&d_keys_sorted, np * 8));
+        HIP_TRY(tmp.get((void **)&d_vals, np * 4));
+        HIP_TRY(tmp.get((void **)&d_perm, np * 4));
+        HIP_TRY(tmp.get((void **)&d_marks, np * 4));
+        HIP_TRY(tmp.get((void **)&d_hit_off_in, (np + 1) * 8));
+        HIP_TRY(tmp.get((void **)&d_hit_off_out, (np + 1) * 8));
+        HIP_TRY(tmp.get((void **)&d_mark_rank, (np + 1) * 8));
+        HIP_TRY(tmp.get((void **)&d_err, 8));
+        HIP_TRY(hipMemcpyAsync(d_terms, term_ids, np * 4, hipMemcpyHostToDevice, dev->stream));
+        HIP_TRY(hipMemcpyAsync(d_docs_in, doc_ids, np * 4, hipMemcpyHostToDevice, dev->stream));
+        HIP_TRY(hipMemcpyAsync(d_freqs_in, freqs, np * 4, hipMemcpyHostToDevice, dev->stream));
+        if (nhits) {
+                HIP_TRY(tmp.get((void **)&d_pos_in, nhits * 2));
+                HIP_TRY(hipMemcpyAsync(d_pos_in, positions, nhits * 2, hipMemcpyHostToDevice, dev->stream));
+                if (payload_lens) {
+                        HIP_TRY(tmp.get((void **)&d_plens_in, nhits));
+                        HIP_TRY(tmp.get((void **)&d_payloads_in, nhits * 8));
+                        HIP_TRY(hipMemcpyAsync(d_plens_in, payload_lens, nhits, hipMemcpyHostToDevice, dev->stream));
+                        HIP_TRY(hipMemcpyAsync(d_payloads_in, payloads, nhits * 8, hipMemcpyHostToDevice, dev->stream));
+                }
+        }
+        EncBufs d; // (the sorted postings: what the encoder reads)
+        HIP_TRY(hipMalloc((void **)&d.docs, np * 4));
+        HIP_TRY(hipMalloc((void **)&d.freqs, np * 4));
+        HIP_TRY(hipMalloc((void **)&d.pos, (nhits + 1) * 2));
+        if (nhits && payload_lens) {
+                HIP_TRY(hipMalloc((void **)&d.plens, nhits));
+                HIP_TRY(hipMalloc((void **)&d.payloads, nhits * 8));
+        }
+        const dim3 grid((uint32_t)((np + 255) / 256)), block(256);
+        // ---- keys in the order the reference's commit walks (bucket = termID & 31, then termID, then documentID), sorted with the postings' indices
+        hipLaunchKernelGGL(k_commit_keys, grid, block, 0, dev->stream, (const uint32_t *)d_terms, (const uint32_t *)d_docs_in, d_keys, d_vals, np);
+        size_t sort_bytes = 0;
+        HIP_TRY((hipError_t)tri_sort_pairs_u64_u32(d_keys, d_keys_sorted, d_vals, d_perm, np, nullptr, &sort_bytes, dev->stream));
+        void *d_sort_tmp = nullptr;
+        HIP_TRY(tmp.get(&d_sort_tmp, sort_bytes));
+        HIP_TRY((hipError_t)tri_sort_pairs_u64_u32(d_keys, d_keys_sorted, d_vals, d_perm, np, d_sort_tmp, &sort_bytes, dev->stream));
+        // ---- documents and frequencies in sorted order; the hits follow their postings
+        hipLaunchKernelGGL(k_commit_gather, grid, block, 0, dev->stream, (const unsigned long long *)d_keys_sorted, (const uint32_t *)d_perm, (const uint32_t *)d_freqs_in, d.docs,
+                           d.freqs, d_marks, np);
+        int rcs;
+        EncBufs scan_scratch; // (enc_scan's chunk sums)
+        if ((rcs = enc_scan(dev, scan_scratch, d_freqs_in, d_hit_off_in, np)) || (rcs = enc_scan(dev, scan_scratch, d.freqs, d_hit_off_out, np)) ||
+            (rcs = enc_scan(dev, scan_scratch, d_marks, d_mark_rank, np)))
+                return rcs;
+        hipLaunchKernelGGL(k_commit_hits, grid, block, 0, dev->stream, (const uint32_t *)d_perm, (const uint64_t *)d_hit_off_in, (const uint64_t *)d_hit_off_out,
+                           (const uint32_t *)d.freqs, (const uint16_t *)d_pos_in, d.pos, (const uint8_t *)d_plens_in, d.plens, (const uint64_t *)d_payloads_in, d.payloads, np);
+        HIP_TRY(hipMemsetAsync(d_err, 0xff, 8, dev->stream));
+        hipLaunchKernelGGL(k_commit_validate, grid, block, 0, dev->stream, (const unsigned long long *)d_keys_sorted, (const uint32_t *)d.freqs, (const uint64_t *)d_hit_off_out,
+                           (const uint16_t *)d.pos, (const uint8_t *)d.plens, np, d_err);
+        HIP_TRY(hipGetLastError());
+        unsigned long long err = 0;
+        uint64_t nt = 0;
+        HIP_TRY(hipMemcpyAsync(&err, d_err, 8, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipMemcpyAsync(&nt, d_mark_rank + np, 8, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipStreamSynchronize(dev->stream));
+        if (err != ~0ull) {
+                static const char *const why[] = {"", "document 0", "the same (term, document) twice (indexer.cpp:446: documentID > prevDID)",
+                                                  "positions must be non-descending within a document, and > 0 for a hit without payload (google_codec.cpp:42-49)",
+                                                  "a payload of more than 8 bytes (google_codec.cpp:46)"};
+                return fail(TRI_ERR_INVALID, "tri_commit_google: sorted posting %llu: %s", (unsigned long long)(err >> 8) - 1, why[std::min<unsigned long long>(err & 0xff, 4)]);
+        }
+        *nterms = (size_t)nt;
+        if (stats)
+                stats->total_terms = nt;
+        // ---- the distinct terms: first postings and termIDs, commit order
+        HIP_TRY(tmp.get((void **)&d_term_first, (nt + 1) * 8));
+        HIP_TRY(tmp.get((void **)&d_term_ids, nt * 4));
+        hipLaunchKernelGGL(k_commit_terms, grid, block, 0, dev->stream, (const unsigned long long *)d_keys_sorted, (const uint32_t *)d_marks, (const uint64_t *)d_mark_rank, d_term_first,
+                           d_term_ids, np);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint64_t> term_first(nt + 1);
+        std::vector<uint32_t> tids(nt);
+        HIP_TRY(hipMemcpyAsync(term_first.data(), d_term_first, nt * 8, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipMemcpyAsync(tids.data(), d_term_ids, nt * 4, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipStreamSynchronize(dev->stream));
+        term_first[nt] = np;
+        std::vector<tri_term> tt(nt);
+        if (int rc = encode_google_device(dev, d, term_first.data(), nt, np, nhits, index_out && terms_cap >= nt ? index_out : nullptr, cap, index_len, tt.data()))
+                return rc;
+        if (!index_out)
+                return TRI_OK; // (sizing call: *index_len and *nterms)
+        if (terms_cap < nt || !terms_out || !term_ids_out)
+                return fail(TRI_ERR_INVALID, "tri_commit_google: the session holds %llu distinct terms, room for %zu given", (unsigned long long)nt, terms_cap);
+        memcpy(terms_out, tt.data(), nt * sizeof(tri_term));
+        memcpy(term_ids_out, tids.data(), nt * 4);
         return TRI_OK;
 }
 

@@ -106,7 +106,7 @@ ABI_SYMBOLS = [
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_docset_bitmap", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
-    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads",
+    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
 
@@ -165,6 +165,7 @@ def hip_lib():
     L.tri_cbatch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_encode_google.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_encode_google_payloads.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.tri_commit_google.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_comm_unique_id.argtypes = [vp]
     L.tri_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.tri_comm_create_custom.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.POINTER(vp)]
@@ -307,6 +308,31 @@ class Device:
         out = np.zeros(max(1, ln.value), dtype=np.uint8)
         _check(call(out.ctypes.data, out.size))
         return out[: ln.value], terms[:n]
+
+    def commit_google(self, term_ids, doc_ids, freqs, positions, payload_lens=None, payloads=None):
+        """SegmentIndexSession::commit on the device (tri_commit_google): a session's postings in insertion order -> (index bytes u8[], the committed
+        termIDs u32[n] in commit order, their term table u32[n, 3], stats {docs_cnt, sum_terms_docs, sum_term_hits, total_terms})."""
+        t = np.ascontiguousarray(term_ids, dtype=np.uint32)
+        d = np.ascontiguousarray(doc_ids, dtype=np.uint32)
+        f = np.ascontiguousarray(freqs, dtype=np.uint32)
+        p = np.ascontiguousarray(positions, dtype=np.uint16)
+        pl = None if payload_lens is None else np.ascontiguousarray(payload_lens, dtype=np.uint8)
+        pv = None if payload_lens is None else np.ascontiguousarray(payloads, dtype=np.uint64)
+        assert t.size == d.size == f.size and (pl is None or pl.size == p.size == pv.size)
+        ln, nt = C.c_size_t(), C.c_size_t()
+        stats = np.zeros(4, dtype=np.uint64)
+        L = hip_lib()
+
+        def call(out, cap, tids, terms, tcap):
+            return L.tri_commit_google(self.h, t.ctypes.data, d.ctypes.data, f.ctypes.data, p.ctypes.data, None if pl is None else pl.ctypes.data,
+                                       None if pv is None else pv.ctypes.data, t.size, p.size, out, cap, C.byref(ln), tids, terms, tcap, C.byref(nt), stats.ctypes.data)  # fmt: skip
+
+        _check(call(None, 0, None, None, 0))
+        out = np.zeros(max(1, ln.value), dtype=np.uint8)
+        tids = np.zeros(max(1, nt.value), dtype=np.uint32)
+        terms = np.zeros((max(1, nt.value), 3), dtype=np.uint32)
+        _check(call(out.ctypes.data, out.size, tids.ctypes.data, terms.ctypes.data, nt.value))
+        return out[: ln.value], tids[: nt.value], terms[: nt.value], dict(zip(("docs_cnt", "sum_terms_docs", "sum_term_hits", "total_terms"), (int(x) for x in stats)))
 
     def close(self):
         if self.h:
