@@ -356,6 +356,19 @@ int tri_commit_google(tri_dev *, const uint32_t *term_ids, const uint32_t *doc_i
                       const uint64_t *payloads, size_t npostings, size_t npositions, uint8_t *index_out, size_t cap, size_t *index_len, uint32_t *term_ids_out,
                       tri_term *terms_out, size_t terms_cap, size_t *nterms, tri_commit_stats *stats);
 
+/* Codecs::Google::IndexSession::merge (google_codec.cpp:186-438), for a whole dictionary at once (ABI 7): parts[0 .. nparts) are the participants' uploaded
+ * google_codec indexes, MOST RECENT FIRST (merge.cpp:100-157 orders them so), each with the documents its newer segments mask installed by
+ * tri_index_set_masked (its masked_documents_registry); part_terms[t * nparts + p] = output term t's index in participant p's term table (0xffffffff: the
+ * participant does not hold it) — the caller walks its dictionaries as MergeCandidatesCollection::merge does (merge.cpp:100-157) and hands the output terms
+ * over in the order it wants them encoded.  Per output term: the union of the participants' documents; a document several participants hold comes from the
+ * most recent one; it is dropped when THAT participant's masked set holds it (google_codec.cpp:377-401) — hits and payloads copied, re-encoded by the device
+ * encoder.  index_out / terms_out[t] as tri_encode_google_payloads (a term that keeps no document: documents == 0, its two chunk bytes are still in the
+ * index — begin_term / end_term ran, merge.cpp:275-282 — and the caller leaves it out of the dictionary); *stats: what the merge adds to the field
+ * statistics (docs_cnt is the caller's).  The bytes equal the device / host encoder's over the merged postings; the reference's raw-chunk fast path for a
+ * term only one unmasked participant holds (append_index_chunk, merge.cpp:167-178) copies bytes this call re-encodes.  index_out == NULL: sizing call. */
+int tri_merge_google(tri_dev *, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
+                     tri_term *terms_out, tri_commit_stats *stats);
+
 /* The same with hit payloads (Encoder::new_hit(pos, payload), google_codec.cpp:38-74): payload_lens[h] (0 .. 8) and payloads[h] (the
  * payload's first byte in the low 8 bits) per hit, parallel to positions[].  A hit is written as varint(position delta << 1 | the
  * length differs from the previous hit's of the document) [u8 new length] payload bytes, the length state restarting with every

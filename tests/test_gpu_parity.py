@@ -1387,7 +1387,7 @@ def test_commit_on_the_device(T, dev, payloads):
         return np.repeat(hit0[idx] - np.concatenate([[0], np.cumsum(n)[:-1]]), n) + np.arange(int(n.sum())) if idx.size else np.zeros(0, np.int64)
 
     rng = np.random.default_rng(17)
-    for nterms in (1, 60, 1500):
+    for nterms in (1, 60, 2500):
         docs, freqs, pos, tf = random_postings(rng, nterms)
         hit0 = np.concatenate([[0], np.cumsum(freqs.astype(np.int64))])
         plen = rng.integers(0, 9, size=pos.size).astype(np.uint8) if payloads else None
@@ -1398,7 +1398,8 @@ def test_commit_on_the_device(T, dev, payloads):
         tids = rng.choice(np.arange(1, 50 * nterms + 64, dtype=np.uint32), size=nterms, replace=False)  # (many share their low five bits)
         term_of = np.repeat(np.arange(nterms), np.diff(tf).astype(np.int64))
         # the session: documents in a random order, every document's postings together, its terms in a random order
-        order = np.lexsort((rng.random(docs.size), rng.permutation(int(docs.max()) + 1)[docs] if docs.size else docs))
+        uniq, inv = np.unique(docs, return_inverse=True)
+        order = np.lexsort((rng.random(docs.size), rng.permutation(uniq.size)[inv]))  # (grouped by document, the documents in a random order)
         s_terms, s_docs, s_freqs = tids[term_of[order]], docs[order], freqs[order]
         take = slices(hit0, order)
         s_pos = pos[take]
@@ -1423,6 +1424,90 @@ def test_commit_on_the_device(T, dev, payloads):
         dev.commit_google([7], [5], [2], [9, 3])
     got, gtids, gterms, stats = dev.commit_google(np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.uint16))
     assert got.size == 0 and gtids.size == 0 and stats["total_terms"] == 0
+
+
+def test_merge_on_the_device(T, dev):
+    """tri_merge_google — Codecs::Google::IndexSession::merge (google_codec.cpp:186-438) over a whole dictionary: three segments with overlapping
+    dictionaries and documentIDs, each masked by its own set; per output term the union of the documents, a document from the MOST RECENT participant that
+    holds it, dropped when that participant's masked set holds it, hits and payloads carried over.  The merged `index` bytes and term table equal the host
+    encoder's over the postings a plain restatement of the reference's k-way walk keeps; a term that keeps nothing stays as an empty chunk."""
+    from trinity_amd import engine as E
+
+    rng = np.random.default_rng(23)
+    G, D, nparts = 260, 6000, 3
+    segs = []
+    for p in range(nparts):
+        held = np.sort(rng.choice(G, size=int(G * 0.7), replace=False))
+        docs, freqs, pos, plen, pval, tf = [], [], [], [], [], [0]
+        for g in held.tolist():
+            n = [1, 31, 32, 33, 70, 400][g % 6] if g % 11 else 0  # (some terms hold no document in this segment)
+            d = np.sort(rng.choice(np.arange(1, D), size=n, replace=False))
+            f = rng.integers(0, 4, size=n)
+            for k in f.tolist():
+                pp = np.sort(rng.integers(1, 2000, size=k))
+                pl = rng.integers(0, 9, size=k) if g % 3 == 0 else np.zeros(k, np.int64)
+                pos += pp.tolist()
+                plen += pl.tolist()
+                pval += [int(rng.integers(0, 2**62)) & ((1 << (8 * int(x))) - 1) for x in pl.tolist()]
+            docs += d.tolist()
+            freqs += f.tolist()
+            tf.append(len(docs))
+        a = dict(held=held, docs=np.array(docs, np.uint32), freqs=np.array(freqs, np.uint32), pos=np.array(pos, np.uint16), plen=np.array(plen, np.uint8),
+                 pval=np.array(pval, np.uint64), tf=np.array(tf, np.uint64), masked=np.sort(rng.choice(np.arange(1, D), size=D // 6, replace=False)).astype(np.uint32))  # fmt: skip
+        a["hit0"] = np.concatenate([[0], np.cumsum(a["freqs"].astype(np.int64))])
+        index, terms = E.host_encode_google(a["docs"], a["freqs"], a["pos"], a["tf"], a["plen"], a["pval"])
+        a["ix"] = T.Index(dev, index, terms, D)
+        a["ix"].set_masked(a["masked"])
+        segs.append(a)
+    out_terms = [g for g in range(G) if any(g in s["held"] for s in segs)]
+    part_terms = np.full((len(out_terms), nparts), 0xFFFFFFFF, dtype=np.uint32)
+    for t, g in enumerate(out_terms):
+        for p, s in enumerate(segs):
+            k = np.searchsorted(s["held"], g)
+            if k < len(s["held"]) and s["held"][k] == g:
+                part_terms[t, p] = k
+    got, gterms, stats = dev.merge_google([s["ix"] for s in segs], part_terms)
+    # the reference's walk, restated: lowest documentID first; among the participants that hold it the most recent (lowest index) supplies it; its own masked set decides
+    docs, freqs, pos, plen, pval, tf = [], [], [], [], [], [0]
+    for t, g in enumerate(out_terms):
+        best = {}
+        for p, s in enumerate(segs):
+            k = int(part_terms[t, p])
+            if k == 0xFFFFFFFF:
+                continue
+            for i in range(int(s["tf"][k]), int(s["tf"][k + 1])):
+                best.setdefault(int(s["docs"][i]), (p, i))
+        for dd in sorted(best):
+            p, i = best[dd]
+            s = segs[p]
+            km = int(np.searchsorted(s["masked"], dd))
+            if km < len(s["masked"]) and s["masked"][km] == dd:
+                continue
+            h0, h1 = int(s["hit0"][i]), int(s["hit0"][i + 1])
+            docs.append(dd)
+            freqs.append(int(s["freqs"][i]))
+            pos += s["pos"][h0:h1].tolist()
+            plen += s["plen"][h0:h1].tolist()
+            pval += s["pval"][h0:h1].tolist()
+        tf.append(len(docs))
+    want, wterms = E.host_encode_google(np.array(docs, np.uint32), np.array(freqs, np.uint32), np.array(pos, np.uint16), np.array(tf, np.uint64), np.array(plen, np.uint8),
+                                        np.array(pval, np.uint64))  # fmt: skip
+    assert np.array_equal(gterms, wterms)
+    assert got.size == want.size and np.array_equal(got, want), int(np.argmax(got[: want.size] != want[: got.size]))
+    assert int((gterms[:, 0] == 0).sum()) > 0  # (terms that keep nothing are there, empty)
+    assert stats["sum_terms_docs"] == len(docs) and stats["sum_term_hits"] == int(np.sum(freqs)) and stats["total_terms"] == int((wterms[:, 0] > 0).sum())
+    # the merged segment reads back: every term's postings through the decoder
+    ix = T.Index(dev, got, gterms, D)
+    d2, f2, offs = ix.decode_terms(np.arange(len(out_terms), dtype=np.uint32), gterms[:, 0].astype(np.int64))
+    assert np.array_equal(d2, np.array(docs, np.uint32)) and np.array_equal(f2, np.array(freqs, np.uint32))
+    ix.close()
+    # one participant, nothing masked: the postings come through unchanged
+    segs[0]["ix"].set_masked(np.zeros(0, np.uint32))
+    one, oterms, _ = dev.merge_google([segs[0]["ix"]], np.arange(len(segs[0]["held"]), dtype=np.uint32).reshape(-1, 1))
+    w1, t1 = E.host_encode_google(segs[0]["docs"], segs[0]["freqs"], segs[0]["pos"], segs[0]["tf"], segs[0]["plen"], segs[0]["pval"])
+    assert np.array_equal(one, w1) and np.array_equal(oterms, t1)
+    for s in segs:
+        s["ix"].close()
 
 
 def test_google_encoder_on_the_device_with_payloads(T, dev):

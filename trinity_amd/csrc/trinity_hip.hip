@@ -2315,6 +2315,161 @@ extern "C" int tri_commit_google(tri_dev *dev, const uint32_t *term_ids, const u
         return TRI_OK;
 }
 
+// ---- Codecs::Google::IndexSession::merge (google_codec.cpp:186-438) for a whole dictionary, on the device (k_commit.hpp)
+extern "C" int tri_merge_google(tri_dev *dev, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
+                                tri_term *terms_out, tri_commit_stats *stats) {
+        if (!dev || !parts || !nparts || (nterms && (!part_terms || !terms_out)) || !index_len)
+                return fail(TRI_ERR_INVALID, "tri_merge_google: null argument");
+        if (nparts > 65535)
+                return fail(TRI_ERR_INVALID, "tri_merge_google: at most 65535 participants (google_codec.cpp:186: uint16_t participantsCnt)");
+        HIP_TRY(hipSetDevice(dev->device));
+        for (size_t p = 0; p < nparts; ++p)
+                if (!parts[p] || parts[p]->dev != dev || parts[p]->codec != TRI_CODEC_GOOGLE)
+                        return fail(TRI_ERR_INVALID, "tri_merge_google: participant %zu is not a google_codec index of this device", p);
+        // ---- the jobs: every (participant, output term) that holds postings, participant-major — the most recent participant's postings first, so that
+        //      a stable sort leaves them first among equal (term, document) keys
+        std::vector<std::vector<MergeJob>> jobs(nparts);
+        std::vector<uint64_t> part_first(nparts + 1, 0);
+        uint64_t np = 0;
+        for (size_t p = 0; p < nparts; ++p) {
+                part_first[p] = np;
+                for (size_t t = 0; t < nterms; ++t) {
+                        const uint32_t idx = part_terms[t * nparts + p];
+                        if (idx == 0xffffffffu)
+                                continue;
+                        if (idx >= parts[p]->terms.size())
+                                return fail(TRI_ERR_INVALID, "tri_merge_google: output term %zu: term %u out of range in participant %zu", t, idx, p);
+                        const DevTerm &dt = parts[p]->terms[idx];
+                        if (!dt.documents)
+                                continue; // (merge.cpp:263-270: a participant without documents for the term takes no part)
+                        if (!(dt.flags & TERM_FULL_BLOCKS))
+                                return fail(TRI_ERR_UNSUPPORTED, "tri_merge_google: term %u of participant %zu has short blocks inside its list (not written by the reference's encoder)", idx, p);
+                        jobs[p].push_back({idx, (uint32_t)t, np});
+                        np += dt.documents;
+                }
+        }
+        part_first[nparts] = np;
+        if (np > 0xfffffff0ull)
+                return fail(TRI_ERR_UNSUPPORTED, "tri_merge_google: more than 2^32 postings: merge in parts");
+        *index_len = 0;
+        if (stats)
+                *stats = tri_commit_stats{0, 0, 0, 0};
+        struct Tmp {
+                std::vector<void *> p;
+                ~Tmp() {
+                        for (void *q : p)
+                                hipFree(q);
+                }
+                hipError_t get(void **out, size_t bytes) {
+                        const hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+                        if (e == hipSuccess)
+                                p.push_back(*out);
+                        return e;
+                }
+        } tmp;
+        EncBufs d;       // the merged postings: what the encoder reads
+        EncBufs scratch; // (enc_scan's chunk sums)
+        std::vector<uint64_t> term_first(nterms + 1, 0);
+        uint64_t kept = 0, nh_out = 0;
+        if (np) {
+                unsigned long long *d_keys, *d_keys_sorted;
+                uint32_t *d_vals, *d_perm, *d_freqs_all, *d_keep, *d_src_of, *d_term_cnt;
+                uint64_t *d_hit_off_all, *d_rank, *d_part_first, *d_hit_off_out, *d_term_first;
+                const uint32_t **d_masked;
+                HIP_TRY(tmp.get((void **)&d_keys, np * 8));
+                HIP_TRY(tmp.get((void **)&d_keys_sorted, np * 8));
+                HIP_TRY(tmp.get((void **)&d_vals, np * 4));
+                HIP_TRY(tmp.get((void **)&d_perm, np * 4));
+                HIP_TRY(tmp.get((void **)&d_freqs_all, np * 4));
+                HIP_TRY(tmp.get((void **)&d_keep, np * 4));
+                HIP_TRY(tmp.get((void **)&d_hit_off_all, (np + 1) * 8));
+                HIP_TRY(tmp.get((void **)&d_rank, (np + 1) * 8));
+                HIP_TRY(tmp.get((void **)&d_part_first, (nparts + 1) * 8));
+                HIP_TRY(tmp.get((void **)&d_masked, nparts * sizeof(void *)));
+                HIP_TRY(tmp.get((void **)&d_term_cnt, (nterms + 1) * 4));
+                HIP_TRY(tmp.get((void **)&d_term_first, (nterms + 2) * 8));
+                std::vector<const uint32_t *> masked(nparts);
+                for (size_t p = 0; p < nparts; ++p)
+                        masked[p] = parts[p]->d_masked;
+                HIP_TRY(hipMemcpyAsync(d_part_first, part_first.data(), (nparts + 1) * 8, hipMemcpyHostToDevice, dev->stream));
+                HIP_TRY(hipMemcpyAsync(d_masked, masked.data(), nparts * sizeof(void *), hipMemcpyHostToDevice, dev->stream));
+                std::vector<MergeJob *> d_jobs(nparts, nullptr);
+                for (size_t p = 0; p < nparts; ++p) {
+                        if (jobs[p].empty())
+                                continue;
+                        HIP_TRY(tmp.get((void **)&d_jobs[p], jobs[p].size() * sizeof(MergeJob)));
+                        HIP_TRY(hipMemcpyAsync(d_jobs[p], jobs[p].data(), jobs[p].size() * sizeof(MergeJob), hipMemcpyHostToDevice, dev->stream));
+                        const tri_index *ix = parts[p];
+                        hipLaunchKernelGGL((k_merge_decode<CODEC_GOOGLE>), dim3((uint32_t)std::min<size_t>(jobs[p].size(), (size_t)dev->cus * 16)), dim3(256), 0, dev->stream, ix->d_index,
+                                           ix->d_blk_last, ix->d_blk_off, ix->d_terms, (const MergeJob *)d_jobs[p], (uint32_t)jobs[p].size(), d_freqs_all, d_keys, d_vals);
+                }
+                HIP_TRY(hipGetLastError());
+                int rcs;
+                if ((rcs = enc_scan(dev, scratch, d_freqs_all, d_hit_off_all, np)))
+                        return rcs;
+                uint64_t nh_all = 0;
+                HIP_TRY(hipMemcpyAsync(&nh_all, d_hit_off_all + np, 8, hipMemcpyDeviceToHost, dev->stream));
+                HIP_TRY(hipStreamSynchronize(dev->stream));
+                uint16_t *d_pos_all;
+                uint8_t *d_plens_all;
+                uint64_t *d_payloads_all;
+                HIP_TRY(tmp.get((void **)&d_pos_all, (nh_all + 1) * 2));
+                HIP_TRY(tmp.get((void **)&d_plens_all, nh_all + 1));
+                HIP_TRY(tmp.get((void **)&d_payloads_all, (nh_all + 1) * 8));
+                for (size_t p = 0; p < nparts; ++p) {
+                        if (jobs[p].empty())
+                                continue;
+                        const tri_index *ix = parts[p];
+                        hipLaunchKernelGGL(k_merge_hits, dim3((uint32_t)std::min<size_t>(jobs[p].size(), (size_t)dev->cus * 16)), dim3(256), 0, dev->stream, ix->d_index, ix->d_blk_off,
+                                           ix->d_blk_hits, ix->d_terms, (const MergeJob *)d_jobs[p], (uint32_t)jobs[p].size(), (const uint32_t *)d_freqs_all, (const uint64_t *)d_hit_off_all,
+                                           d_pos_all, d_plens_all, d_payloads_all);
+                }
+                HIP_TRY(hipGetLastError());
+                // ---- sort by (output term, document); the first of equal keys is the most recent participant's
+                size_t sort_bytes = 0;
+                HIP_TRY((hipError_t)tri_sort_pairs_u64_u32(d_keys, d_keys_sorted, d_vals, d_perm, np, nullptr, &sort_bytes, dev->stream));
+                void *d_sort_tmp = nullptr;
+                HIP_TRY(tmp.get(&d_sort_tmp, sort_bytes));
+                HIP_TRY((hipError_t)tri_sort_pairs_u64_u32(d_keys, d_keys_sorted, d_vals, d_perm, np, d_sort_tmp, &sort_bytes, dev->stream));
+                const dim3 grid((uint32_t)((np + 255) / 256)), block(256);
+                hipLaunchKernelGGL(k_merge_select, grid, block, 0, dev->stream, (const unsigned long long *)d_keys_sorted, (const uint32_t *)d_perm, (const uint64_t *)d_part_first,
+                                   (uint32_t)nparts, (const uint32_t *const *)d_masked, d_keep, np);
+                if ((rcs = enc_scan(dev, scratch, d_keep, d_rank, np)))
+                        return rcs;
+                HIP_TRY(hipMemcpyAsync(&kept, d_rank + np, 8, hipMemcpyDeviceToHost, dev->stream));
+                HIP_TRY(hipStreamSynchronize(dev->stream));
+                HIP_TRY(hipMalloc((void **)&d.docs, (kept + 1) * 4));
+                HIP_TRY(hipMalloc((void **)&d.freqs, (kept + 1) * 4));
+                HIP_TRY(tmp.get((void **)&d_src_of, (kept + 1) * 4));
+                HIP_TRY(tmp.get((void **)&d_hit_off_out, (kept + 2) * 8));
+                HIP_TRY(hipMemsetAsync(d_term_cnt, 0, (nterms + 1) * 4, dev->stream));
+                hipLaunchKernelGGL(k_merge_compact, grid, block, 0, dev->stream, (const unsigned long long *)d_keys_sorted, (const uint32_t *)d_perm, (const uint32_t *)d_keep,
+                                   (const uint64_t *)d_rank, (const uint32_t *)d_freqs_all, d.docs, d.freqs, d_src_of, d_term_cnt, np);
+                if ((rcs = enc_scan(dev, scratch, d.freqs, d_hit_off_out, kept)) || (rcs = enc_scan(dev, scratch, d_term_cnt, d_term_first, nterms)))
+                        return rcs;
+                HIP_TRY(hipMemcpyAsync(&nh_out, d_hit_off_out + kept, 8, hipMemcpyDeviceToHost, dev->stream));
+                HIP_TRY(hipMemcpyAsync(term_first.data(), d_term_first, (nterms + 1) * 8, hipMemcpyDeviceToHost, dev->stream));
+                HIP_TRY(hipStreamSynchronize(dev->stream));
+                HIP_TRY(hipMalloc((void **)&d.pos, (nh_out + 1) * 2));
+                HIP_TRY(hipMalloc((void **)&d.plens, nh_out + 1));
+                HIP_TRY(hipMalloc((void **)&d.payloads, (nh_out + 1) * 8));
+                if (kept)
+                        hipLaunchKernelGGL(k_commit_hits, dim3((uint32_t)((kept + 255) / 256)), block, 0, dev->stream, (const uint32_t *)d_src_of, (const uint64_t *)d_hit_off_all,
+                                           (const uint64_t *)d_hit_off_out, (const uint32_t *)d.freqs, (const uint16_t *)d_pos_all, d.pos, (const uint8_t *)d_plens_all, d.plens,
+                                           (const uint64_t *)d_payloads_all, d.payloads, kept);
+                HIP_TRY(hipGetLastError());
+        }
+        if (int rc = encode_google_device(dev, d, term_first.data(), nterms, kept, nh_out, index_out, cap, index_len, terms_out))
+                return rc;
+        if (stats) {
+                stats->sum_terms_docs = kept;
+                stats->sum_term_hits = nh_out;
+                for (size_t t = 0; t < nterms; ++t)
+                        stats->total_terms += term_first[t + 1] > term_first[t]; // (merge.cpp:241: a term that keeps no document is dropped from the dictionary)
+        }
+        return TRI_OK;
+}
+
 #ifdef TRI_PROF
 // perf-probe builds: read back and reset the per-phase cycle totals (dev_stream.hpp)
 extern "C" int tri_debug_prof(uint64_t *out32) {

@@ -106,7 +106,7 @@ ABI_SYMBOLS = [
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_docset_bitmap", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
-    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google",
+    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google", "tri_merge_google",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
 
@@ -165,6 +165,7 @@ def hip_lib():
     L.tri_cbatch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_encode_google.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_encode_google_payloads.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.tri_merge_google.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp]
     L.tri_commit_google.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_comm_unique_id.argtypes = [vp]
     L.tri_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
@@ -333,6 +334,22 @@ class Device:
         terms = np.zeros((max(1, nt.value), 3), dtype=np.uint32)
         _check(call(out.ctypes.data, out.size, tids.ctypes.data, terms.ctypes.data, nt.value))
         return out[: ln.value], tids[: nt.value], terms[: nt.value], dict(zip(("docs_cnt", "sum_terms_docs", "sum_term_hits", "total_terms"), (int(x) for x in stats)))
+
+    def merge_google(self, parts, part_terms):
+        """Codecs::Google::IndexSession::merge for a whole dictionary (tri_merge_google): parts = uploaded google_codec Index objects, most recent first
+        (each with its masked documents set); part_terms u32[nterms, nparts] = the output term's index in each part (0xffffffff: absent) ->
+        (index bytes, term table u32[nterms, 3], stats)."""
+        pt = np.ascontiguousarray(part_terms, dtype=np.uint32).reshape(-1, len(parts))
+        hs = (C.c_void_p * len(parts))(*[p.h for p in parts])
+        terms = np.zeros((max(1, pt.shape[0]), 3), dtype=np.uint32)
+        ln = C.c_size_t()
+        stats = np.zeros(4, dtype=np.uint64)
+        L = hip_lib()
+        call = lambda out, cap: L.tri_merge_google(self.h, hs, len(parts), pt.ctypes.data, pt.shape[0], out, cap, C.byref(ln), terms.ctypes.data, stats.ctypes.data)
+        _check(call(None, 0))
+        out = np.zeros(max(1, ln.value), dtype=np.uint8)
+        _check(call(out.ctypes.data, out.size))
+        return out[: ln.value], terms[: pt.shape[0]], dict(zip(("docs_cnt", "sum_terms_docs", "sum_term_hits", "total_terms"), (int(x) for x in stats)))
 
     def close(self):
         if self.h:
