@@ -340,6 +340,14 @@ int tri_gather_results(tri_batch *, tri_comm *, void *counts_all, void *docids_a
 int tri_encode_google(tri_dev *, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first,
                       size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len, tri_term *terms_out);
 
+/* Codecs::Lucene::Encoder (lucene_codec.cpp:163-388) on the device (ABI 7): the same postings as tri_encode_google (payload-less hits) into the Lucene-shaped
+ * segment — `index` (per term: the 14-byte header, 128-document blocks as two ints() groups, the prefix-varint tail, one 22-byte skiplist entry per block) and
+ * `hits.data` (128-hit blocks of position deltas, varint tail) — with this repo's PFOR128 ints() payload (include/pfor128.md; the reference's FastPFor words
+ * are absent from its tree): byte-identical to trinity_amd/csrc/host/lucene_encoder.hpp, the writer of every Lucene-shaped segment this engine reads.
+ * index_out == NULL: sizing call (*index_len, *hits_len, terms_out). */
+int tri_encode_lucene(tri_dev *, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first, size_t nterms,
+                      uint8_t *index_out, size_t index_cap, size_t *index_len, uint8_t *hits_out, size_t hits_cap, size_t *hits_len, tri_term *terms_out);
+
 /* SegmentIndexSession::commit (indexer.cpp:311-478) on the device (ABI 7).  The session's postings in INSERTION order — one entry per (document, term), as
  * document_proxy::insert serialised them (indexer.cpp:33-111): term_ids[i], doc_ids[i], freqs[i] = its counted hits, whose positions (and payloads) follow
  * each other in positions[] (payload_lens[] / payloads[]; NULL: none) in the same order — are sorted by (termID & 31, termID, documentID): the order the

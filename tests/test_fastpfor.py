@@ -135,3 +135,70 @@ def HP_parts(D, V):
     from trinity_amd import workloads as W
 
     return W.build_parts("cfg3", D, V, 10, 42, 400)
+
+
+# ------------------------------------------------------------------------------------------ the device encoder's units, on the CPU
+def lucene_postings(rng, nterms):
+    """Postings that reach every corner of the Lucene-shaped encoder: terms of 0 / 1 / 127 / 128 / 129 / 255 / 256 / 257 documents (blocks exactly full,
+    one short, one over), hit counts that end exactly on a 128-hit block, deltas of every varint length, a document of 700 hits."""
+    docs, freqs, pos, tf = [], [], [], [0]
+    sizes = [0, 1, 127, 128, 129, 255, 256, 257, 1000, 5, 384, 640]
+    for t in range(nterms):
+        n = sizes[t % len(sizes)] if t < 3 * len(sizes) else int(rng.integers(0, 700))
+        d = np.cumsum(rng.integers(1, [1, 3, 200, 20000, 3_000_000][t % 5] + 1, size=n, dtype=np.int64))
+        d = d[d < 2**32 - 1]
+        f = rng.integers(0, [2, 4, 9, 40][t % 4], size=d.size)
+        if d.size and t % 7 == 0:
+            f[int(rng.integers(0, d.size))] = 700
+        if d.size and t % 9 == 0:  # (the term's hits end exactly on a block of 128)
+            short = (-int(f.sum())) % 128
+            f[-1] += short
+        for k in f.tolist():
+            pos += np.sort(rng.integers(1, [12, 200, 65536][t % 3], size=k)).tolist()
+        docs += d.tolist()
+        freqs += f.tolist()
+        tf.append(len(docs))
+    return np.array(docs, np.uint32), np.array(freqs, np.uint32), np.array(pos, np.uint16), np.array(tf, np.uint64)
+
+
+def test_the_device_encoders_group_writer_equals_the_host_encoders():
+    """csrc/pfor128_group.hpp (plan + emit through a getter: what a lane of k_lencode.hpp runs) against lucene_encoder.hpp::ints_encode, byte for byte:
+    all-equal groups, every width, exceptions of every count and size, the five-byte varint."""
+    T.build.build_host()
+    rng = np.random.default_rng(1)
+    for trial in range(6000):
+        kind = trial % 7
+        if kind == 0:
+            v = np.full(128, rng.integers(0, 2**32), np.uint32)
+        elif kind == 1:
+            v = rng.integers(0, 2 ** int(rng.integers(1, 33)), 128, dtype=np.uint64).astype(np.uint32)
+        elif kind == 2:
+            v = rng.integers(0, 2 ** int(rng.integers(1, 12)), 128, dtype=np.uint64).astype(np.uint32)
+            k = int(rng.integers(1, 40))
+            v[rng.choice(128, k, replace=False)] = rng.integers(0, 2**32, k, dtype=np.uint64).astype(np.uint32)
+        elif kind == 3:
+            v = np.zeros(128, np.uint32)
+            v[int(rng.integers(0, 128))] = int(rng.integers(1, 2**32))
+        elif kind == 4:
+            v = rng.integers(0, 2, 128).astype(np.uint32)
+        elif kind == 5:
+            v = rng.integers(1, 300, 128).astype(np.uint32)
+        else:
+            v = (rng.integers(0, 2**32, 128, dtype=np.uint64) >> rng.integers(0, 32, 128).astype(np.uint64)).astype(np.uint32)
+        a, b = HP.pfor128_group_pair(v)
+        assert a is not None and np.array_equal(a, b), (trial, kind)
+
+
+def test_the_device_encoders_units_equal_the_sequential_encoder():
+    """csrc/lucene_enc_units.hpp — per-block sizes, prefix sums, per-block and per-term writes, the skiplist entries from the postings' indices — run in plain
+    loops, against the sequential state machine of lucene_encoder.hpp: `index`, `hits.data` and the term table, byte for byte.  (The kernels of k_lencode.hpp
+    are these units, one per lane: tests/test_gpu_parity.py::test_lucene_encoder_on_the_device.)"""
+    T.build.build_host()
+    rng = np.random.default_rng(3)
+    for nterms in (1, 12, 36, 300):
+        d, f, p, tf = lucene_postings(rng, nterms)
+        want = HP.lucene_encode(d, f, p, tf)
+        got = HP.lucene_encode(d, f, p, tf, units=True)
+        for x, y, name in zip(got, want, ("index", "hits.data", "terms")):
+            assert x.shape == y.shape and np.array_equal(x, y), (nterms, name)
+    assert want[0].size > 100_000 and want[1].size > 300_000

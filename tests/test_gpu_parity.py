@@ -1510,6 +1510,32 @@ def test_merge_on_the_device(T, dev):
         s["ix"].close()
 
 
+def test_lucene_encoder_on_the_device(T, dev):
+    """tri_encode_lucene — Codecs::Lucene::Encoder (lucene_codec.cpp:163-388) with the PFOR128 payload, one unit of csrc/lucene_enc_units.hpp per lane:
+    `index`, `hits.data` and the term table equal the sequential host encoder's (lucene_encoder.hpp: the writer of every Lucene-shaped segment the engine
+    reads) byte for byte, and the encoded segment reads back through the upload and the decoder."""
+    from test_fastpfor import lucene_postings
+
+    from trinity_amd import hostplan as HP
+
+    rng = np.random.default_rng(3)
+    for nterms in (1, 36, 300, 1500):
+        docs, freqs, pos, tf = lucene_postings(rng, nterms)
+        gi, gh, gt = dev.encode_lucene(docs, freqs, pos, tf)
+        wi, wh, wt = HP.lucene_encode(docs, freqs, pos, tf)
+        assert np.array_equal(gt, wt), nterms
+        assert gi.size == wi.size and np.array_equal(gi, wi), (nterms, "index", int(np.argmax(gi[: wi.size] != wi[: gi.size])))
+        assert gh.size == wh.size and np.array_equal(gh, wh), (nterms, "hits.data", int(np.argmax(gh[: wh.size] != wh[: gh.size])))
+        if nterms == 300:  # round trip through the read side
+            ix = T.Index(dev, gi, gt, int(docs.max()), codec=2, hits=gh)
+            df = gt[:, 0].astype(np.int64)
+            d2, f2, offs = ix.decode_terms(np.arange(nterms, dtype=np.uint32), df)
+            assert np.array_equal(d2, docs) and np.array_equal(f2, freqs)
+            ix.close()
+    with pytest.raises(T.TrinityError):
+        dev.encode_lucene([5, 3], [0, 0], [], [0, 2])  # (documents must ascend within a term)
+
+
 def test_google_encoder_on_the_device_with_payloads(T, dev):
     """tri_encode_google_payloads against the host encoder (whose payload bytes the reference-written edge segment pins, tests/test_abi.py):
     hits with payloads of 0 .. 8 bytes whose length changes from hit to hit or stays (both arms of the flag bit, google_codec.cpp:59-66),

@@ -3,6 +3,8 @@
 // whatever the thread count) and tools/plan_probe.py times.  The product library (libtrinity_hip.so) includes the same two headers;
 // nothing here is part of the C-ABI of include/trinity_hip.h.  New code, no reference source.
 #include "../planner.hpp"
+#include "../lucene_enc_units.hpp"
+#include "lucene_encoder.hpp"
 
 #include <cstdlib>
 #include <memory>
@@ -111,8 +113,93 @@ void tri_host_plan_query_maps(void *p, uint32_t *slot_of_query, int32_t *qstatus
 }
 }
 
+// ---- the Lucene-shaped encoder two ways, for the CPU tests: the sequential host encoder (lucene_encoder.hpp: the state machine the reference's encoder is),
+//      and the device encoder's UNITS (lucene_enc_units.hpp) run in plain loops with serial prefix sums in between — exactly what k_lencode.hpp's kernels and
+//      the device scans do.  Both write index / hits.data / the term table {documents, offset, size}; return 0, or -1 when a buffer is too small.
+extern "C" {
+int tri_host_lucene_encode(const uint32_t *docs, const uint32_t *freqs, const uint16_t *pos, const uint64_t *term_first, uint64_t nterms, uint8_t *index_out, uint64_t icap,
+                           uint64_t *ilen, uint8_t *hits_out, uint64_t hcap, uint64_t *hlen, uint32_t *terms3) {
+        using namespace trinity_amd::Codecs;
+        Lucene::IndexSession sess;
+        Lucene::Encoder enc(&sess);
+        uint64_t h = 0;
+        for (uint64_t t = 0; t < nterms; ++t) {
+                enc.begin_term();
+                for (uint64_t p = term_first[t]; p < term_first[t + 1]; ++p) {
+                        enc.begin_document(docs[p]);
+                        for (uint32_t i = 0; i < freqs[p]; ++i)
+                                enc.new_hit(pos[h++]);
+                        enc.end_document();
+                }
+                trinity_amd::term_index_ctx tctx;
+                enc.end_term(&tctx);
+                terms3[3 * t] = tctx.documents, terms3[3 * t + 1] = tctx.offset, terms3[3 * t + 2] = tctx.size;
+        }
+        *ilen = sess.indexOut.size(), *hlen = sess.positionsOut.size();
+        if (*ilen > icap || *hlen > hcap)
+                return -1;
+        memcpy(index_out, sess.indexOut.data(), *ilen);
+        memcpy(hits_out, sess.positionsOut.data(), *hlen);
+        return 0;
+}
+int tri_host_lucene_encode_units(const uint32_t *docs, const uint32_t *freqs, const uint16_t *pos, const uint64_t *term_first, uint64_t nterms, uint8_t *index_out, uint64_t icap,
+                                 uint64_t *ilen, uint8_t *hits_out, uint64_t hcap, uint64_t *hlen, uint32_t *terms3) {
+        const uint64_t np = term_first[nterms];
+        std::vector<uint64_t> hit_off(np + 1, 0), dblk_first(nterms + 1, 0), hblk_first(nterms + 1, 0);
+        for (uint64_t p = 0; p < np; ++p)
+                hit_off[p + 1] = hit_off[p] + freqs[p];
+        for (uint64_t t = 0; t < nterms; ++t) {
+                dblk_first[t + 1] = dblk_first[t] + (term_first[t + 1] - term_first[t]) / LENC_BLOCK;
+                hblk_first[t + 1] = hblk_first[t] + (hit_off[term_first[t + 1]] - hit_off[term_first[t]]) / LENC_BLOCK;
+        }
+        std::vector<uint32_t> hdelta(hit_off[np] + 1);
+        LencArgs a{docs, freqs, pos, hit_off.data(), term_first, hdelta.data(), dblk_first.data(), hblk_first.data(), nterms};
+        for (uint64_t p = 0; p < np; ++p)
+                lenc_unit_hdelta(a, p, hdelta.data());
+        const uint64_t nd = dblk_first[nterms], nh = hblk_first[nterms];
+        std::vector<uint64_t> doff(nd + 1, 0), hoff(nh + 1, 0), term_off(nterms + 1, 0), hterm_off(nterms + 1, 0);
+        std::vector<uint32_t> tail_d(nterms + 1), tail_h(nterms + 1);
+        for (uint64_t g = 0; g < nd; ++g)
+                doff[g + 1] = doff[g] + lenc_unit_dblk_size(a, g);
+        for (uint64_t h = 0; h < nh; ++h)
+                hoff[h + 1] = hoff[h] + lenc_unit_hblk_size(a, h);
+        for (uint64_t t = 0; t < nterms; ++t)
+                lenc_unit_tail_size(a, t, &tail_d[t], &tail_h[t]);
+        LencPlace pl{doff.data(), hoff.data(), term_off.data(), hterm_off.data(), tail_d.data(), tail_h.data()};
+        for (uint64_t t = 0; t < nterms; ++t) {
+                term_off[t + 1] = term_off[t] + lenc_term_index_size(a, pl, t);
+                hterm_off[t + 1] = hterm_off[t] + lenc_term_hits_size(a, pl, t);
+        }
+        *ilen = term_off[nterms], *hlen = hterm_off[nterms];
+        if (*ilen > icap || *hlen > hcap)
+                return -1;
+        for (uint64_t g = 0; g < nd; ++g)
+                lenc_unit_dblk_write(a, pl, g, index_out);
+        for (uint64_t h = 0; h < nh; ++h)
+                lenc_unit_hblk_write(a, pl, h, hits_out);
+        for (uint64_t t = 0; t < nterms; ++t) {
+                lenc_unit_term_write(a, pl, t, index_out, hits_out);
+                terms3[3 * t] = (uint32_t)(term_first[t + 1] - term_first[t]), terms3[3 * t + 1] = (uint32_t)term_off[t], terms3[3 * t + 2] = lenc_term_index_size(a, pl, t);
+        }
+        return 0;
+}
+}
+
 // ---- the two ints() payloads (csrc/fastpfor128.hpp) for the CPU tests: encode / decode one 128-value group
 extern "C" {
+// one ints() group two ways: the device encoder's plan / emit pair (pfor128_group.hpp) into a, the host encoder (lucene_encoder.hpp) into b; returns both lengths
+void tri_host_pfor128_group(const uint32_t *v, uint8_t *a, uint32_t *alen, uint8_t *b, uint32_t *blen) {
+        auto get = [&](uint32_t i) { return v[i]; };
+        const Pfor128Plan p = pfor128_plan(get);
+        uint8_t *e = pfor128_emit(get, p, a);
+        *alen = (uint32_t)(e - a);
+        if ((uint32_t)(e - a) != p.bytes)
+                *alen = 0xffffffffu; // (the plan and the emitter disagree)
+        std::vector<uint8_t> o;
+        trinity_amd::Codecs::Lucene::ints_encode(v, o);
+        memcpy(b, o.data(), o.size());
+        *blen = (uint32_t)o.size();
+}
 // FastPFor<4>::encodeArray of 128 values: words into out (cap >= 160), returns the word count
 uint32_t tri_host_fastpfor_encode(const uint32_t *v, uint32_t *out) {
         std::vector<uint32_t> w;

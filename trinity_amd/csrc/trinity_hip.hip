@@ -364,6 +364,7 @@ struct tri_batch : BatchPlan {
 #include "k_rich.hpp"
 #include "k_tree.hpp"
 #include "k_commit.hpp"
+#include "k_lencode.hpp"
 
 // launch the instantiation of a codec-templated kernel that matches the uploaded segment
 #define TRI_LAUNCH(K, codec, grid, block, stream, ...)                                              \
@@ -2176,6 +2177,136 @@ extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, co
                 }
         }
         return encode_google_device(dev, d, term_first, nterms, np, nhits, index_out, cap, index_len, terms_out);
+}
+
+// ---- Codecs::Lucene::Encoder (lucene_codec.cpp:163-388) on the device, PFOR128 payload (k_lencode.hpp, lucene_enc_units.hpp)
+extern "C" int tri_encode_lucene(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first, size_t nterms,
+                                 uint8_t *index_out, size_t index_cap, size_t *index_len, uint8_t *hits_out, size_t hits_cap, size_t *hits_len, tri_term *terms_out) {
+        if (!dev || !term_first || !index_len || !hits_len || (nterms && !terms_out))
+                return fail(TRI_ERR_INVALID, "tri_encode_lucene: null argument");
+        HIP_TRY(hipSetDevice(dev->device));
+        const uint64_t np = nterms ? term_first[nterms] : 0;
+        if (np && (!docs || !freqs))
+                return fail(TRI_ERR_INVALID, "tri_encode_lucene: null postings");
+        if (npositions && !positions)
+                return fail(TRI_ERR_INVALID, "tri_encode_lucene: null positions");
+        // ---- host: what the encoder would refuse (lucene_encoder.hpp: documents > 0 and ascending within a term; a hit at position 0 is not a hit — refused
+        //      here, as by tri_encode_google, rather than dropped silently; positions non-descending within a document)
+        uint64_t nhits = 0;
+        for (size_t t = 0; t < nterms; ++t) {
+                if (term_first[t + 1] < term_first[t])
+                        return fail(TRI_ERR_INVALID, "tri_encode_lucene: term_first must ascend");
+                uint32_t prev = 0;
+                for (uint64_t p = term_first[t]; p < term_first[t + 1]; ++p) {
+                        if (!docs[p] || docs[p] <= prev)
+                                return fail(TRI_ERR_INVALID, "term %zu: document IDs must be > 0 and strictly ascending (codecs.h:188-190)", t);
+                        prev = docs[p];
+                        if ((uint64_t)freqs[p] > npositions - std::min<uint64_t>(npositions, nhits))
+                                return fail(TRI_ERR_INVALID, "term %zu, document %u: freqs[] asks for more positions than the %zu given", t, docs[p], npositions);
+                        uint32_t last_pos = 0;
+                        for (uint64_t h = nhits; h < nhits + freqs[p]; ++h) {
+                                if (!positions[h] || positions[h] < last_pos)
+                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: positions must be > 0 and non-descending within a document", t, docs[p]);
+                                last_pos = positions[h];
+                        }
+                        nhits += freqs[p];
+                }
+        }
+        struct Tmp {
+                std::vector<void *> p;
+                ~Tmp() {
+                        for (void *q : p)
+                                hipFree(q);
+                }
+                hipError_t get(void **out, size_t bytes) {
+                        const hipError_t e = hipMalloc(out, bytes ? bytes : 8);
+                        if (e == hipSuccess)
+                                p.push_back(*out);
+                        return e;
+                }
+        } tmp;
+        EncBufs scratch; // (enc_scan's chunk sums)
+        uint32_t *d_docs, *d_freqs, *d_hdelta, *d_dcnt, *d_hcnt, *d_dsize, *d_hsize, *d_tail_d, *d_tail_h, *d_isize, *d_hsz;
+        uint16_t *d_pos;
+        uint64_t *d_hit_off, *d_term_first, *d_dblk_first, *d_hblk_first, *d_doff, *d_hoff, *d_term_off, *d_hterm_off;
+        HIP_TRY(tmp.get((void **)&d_docs, (np + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_freqs, (np + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_pos, (nhits + 1) * 2));
+        HIP_TRY(tmp.get((void **)&d_hdelta, (nhits + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_hit_off, (np + 2) * 8));
+        HIP_TRY(tmp.get((void **)&d_term_first, (nterms + 1) * 8));
+        HIP_TRY(tmp.get((void **)&d_dcnt, (nterms + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_hcnt, (nterms + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_dblk_first, (nterms + 2) * 8));
+        HIP_TRY(tmp.get((void **)&d_hblk_first, (nterms + 2) * 8));
+        HIP_TRY(tmp.get((void **)&d_tail_d, (nterms + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_tail_h, (nterms + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_isize, (nterms + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_hsz, (nterms + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_term_off, (nterms + 2) * 8));
+        HIP_TRY(tmp.get((void **)&d_hterm_off, (nterms + 2) * 8));
+        if (np) {
+                HIP_TRY(hipMemcpyAsync(d_docs, docs, np * 4, hipMemcpyHostToDevice, dev->stream));
+                HIP_TRY(hipMemcpyAsync(d_freqs, freqs, np * 4, hipMemcpyHostToDevice, dev->stream));
+        }
+        if (nhits)
+                HIP_TRY(hipMemcpyAsync(d_pos, positions, nhits * 2, hipMemcpyHostToDevice, dev->stream));
+        HIP_TRY(hipMemcpyAsync(d_term_first, term_first, (nterms + 1) * 8, hipMemcpyHostToDevice, dev->stream));
+        int rcs;
+        if ((rcs = enc_scan(dev, scratch, d_freqs, d_hit_off, np)))
+                return rcs;
+        const dim3 block(256);
+        auto grid = [](uint64_t n) { return dim3((uint32_t)std::max<uint64_t>(1, (n + 255) / 256)); };
+        LencArgs a{d_docs, d_freqs, d_pos, d_hit_off, d_term_first, d_hdelta, d_dblk_first, d_hblk_first, (uint64_t)nterms};
+        hipLaunchKernelGGL(k_lenc_hdelta, grid(np), block, 0, dev->stream, a, d_hdelta, np);
+        hipLaunchKernelGGL(k_lenc_term_counts, grid(nterms), block, 0, dev->stream, (const uint64_t *)d_term_first, (const uint64_t *)d_hit_off, (uint64_t)nterms, d_dcnt, d_hcnt);
+        if ((rcs = enc_scan(dev, scratch, d_dcnt, d_dblk_first, nterms)) || (rcs = enc_scan(dev, scratch, d_hcnt, d_hblk_first, nterms)))
+                return rcs;
+        uint64_t nd = 0, nh = 0;
+        HIP_TRY(hipMemcpyAsync(&nd, d_dblk_first + nterms, 8, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipMemcpyAsync(&nh, d_hblk_first + nterms, 8, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipStreamSynchronize(dev->stream));
+        HIP_TRY(tmp.get((void **)&d_dsize, (nd + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_hsize, (nh + 1) * 4));
+        HIP_TRY(tmp.get((void **)&d_doff, (nd + 2) * 8));
+        HIP_TRY(tmp.get((void **)&d_hoff, (nh + 2) * 8));
+        hipLaunchKernelGGL(k_lenc_dblk_size, grid(nd), block, 0, dev->stream, a, nd, d_dsize);
+        hipLaunchKernelGGL(k_lenc_hblk_size, grid(nh), block, 0, dev->stream, a, nh, d_hsize);
+        hipLaunchKernelGGL(k_lenc_tail_size, grid(nterms), block, 0, dev->stream, a, d_tail_d, d_tail_h);
+        if ((rcs = enc_scan(dev, scratch, d_dsize, d_doff, nd)) || (rcs = enc_scan(dev, scratch, d_hsize, d_hoff, nh)))
+                return rcs;
+        LencPlace pl{d_doff, d_hoff, d_term_off, d_hterm_off, d_tail_d, d_tail_h};
+        hipLaunchKernelGGL(k_lenc_term_sizes, grid(nterms), block, 0, dev->stream, a, pl, d_isize, d_hsz);
+        if ((rcs = enc_scan(dev, scratch, d_isize, d_term_off, nterms)) || (rcs = enc_scan(dev, scratch, d_hsz, d_hterm_off, nterms)))
+                return rcs;
+        HIP_TRY(hipGetLastError());
+        std::vector<uint64_t> term_off(nterms + 1), hterm_off(nterms + 1);
+        HIP_TRY(hipMemcpyAsync(term_off.data(), d_term_off, (nterms + 1) * 8, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipMemcpyAsync(hterm_off.data(), d_hterm_off, (nterms + 1) * 8, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipStreamSynchronize(dev->stream));
+        if (term_off[nterms] > 0xffffffffull || hterm_off[nterms] > 0xffffffffull)
+                return fail(TRI_ERR_UNSUPPORTED, "the index or hits.data would exceed 4 GiB (term_index_ctx offsets and the term header's hits offset are 32 bits)");
+        for (size_t t = 0; t < nterms; ++t)
+                terms_out[t] = {(uint32_t)(term_first[t + 1] - term_first[t]), (uint32_t)term_off[t], (uint32_t)(term_off[t + 1] - term_off[t])};
+        *index_len = (size_t)term_off[nterms];
+        *hits_len = (size_t)hterm_off[nterms];
+        if (!index_out)
+                return TRI_OK; // (sizing call)
+        if (index_cap < *index_len || hits_cap < *hits_len || (*hits_len && !hits_out))
+                return fail(TRI_ERR_INVALID, "tri_encode_lucene: the index needs %zu bytes (%zu given), hits.data %zu (%zu given)", *index_len, index_cap, *hits_len, hits_cap);
+        uint8_t *d_index, *d_hits;
+        HIP_TRY(tmp.get((void **)&d_index, *index_len + 8));
+        HIP_TRY(tmp.get((void **)&d_hits, *hits_len + 8));
+        hipLaunchKernelGGL(k_lenc_dblk_write, grid(nd), block, 0, dev->stream, a, pl, nd, d_index);
+        hipLaunchKernelGGL(k_lenc_hblk_write, grid(nh), block, 0, dev->stream, a, pl, nh, d_hits);
+        hipLaunchKernelGGL(k_lenc_term_write, grid(nterms), block, 0, dev->stream, a, pl, d_index, d_hits);
+        HIP_TRY(hipGetLastError());
+        if (*index_len)
+                HIP_TRY(hipMemcpyAsync(index_out, d_index, *index_len, hipMemcpyDeviceToHost, dev->stream));
+        if (*hits_len)
+                HIP_TRY(hipMemcpyAsync(hits_out, d_hits, *hits_len, hipMemcpyDeviceToHost, dev->stream));
+        HIP_TRY(hipStreamSynchronize(dev->stream));
+        return TRI_OK;
 }
 
 // ---- SegmentIndexSession::commit (indexer.cpp:311-478) on the device: sort, gather, encode (k_commit.hpp, commit_sort.hip, k_encode.hpp)

@@ -106,7 +106,7 @@ ABI_SYMBOLS = [
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_docset_bitmap", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
-    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google", "tri_merge_google",
+    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google", "tri_merge_google", "tri_encode_lucene",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
 
@@ -165,6 +165,7 @@ def hip_lib():
     L.tri_cbatch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_encode_google.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_encode_google_payloads.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.tri_encode_lucene.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_merge_google.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp]
     L.tri_commit_google.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_comm_unique_id.argtypes = [vp]
@@ -334,6 +335,22 @@ class Device:
         terms = np.zeros((max(1, nt.value), 3), dtype=np.uint32)
         _check(call(out.ctypes.data, out.size, tids.ctypes.data, terms.ctypes.data, nt.value))
         return out[: ln.value], tids[: nt.value], terms[: nt.value], dict(zip(("docs_cnt", "sum_terms_docs", "sum_term_hits", "total_terms"), (int(x) for x in stats)))
+
+    def encode_lucene(self, docs, freqs, positions, term_first):
+        """The Lucene-shaped codec's encoder on the device (tri_encode_lucene, PFOR128 payload): -> (index bytes, hits.data bytes, term table u32[n, 3])."""
+        d = np.ascontiguousarray(docs, dtype=np.uint32)
+        f = np.ascontiguousarray(freqs, dtype=np.uint32)
+        p = np.ascontiguousarray(positions, dtype=np.uint16)
+        tf = np.ascontiguousarray(term_first, dtype=np.uint64)
+        n = tf.size - 1
+        terms = np.zeros((max(n, 1), 3), dtype=np.uint32)
+        il, hl = C.c_size_t(), C.c_size_t()
+        L = hip_lib()
+        call = lambda io, ic, ho, hc: L.tri_encode_lucene(self.h, d.ctypes.data, f.ctypes.data, p.ctypes.data, p.size, tf.ctypes.data, n, io, ic, C.byref(il), ho, hc, C.byref(hl), terms.ctypes.data)
+        _check(call(None, 0, None, 0))
+        io, ho = np.zeros(max(1, il.value), dtype=np.uint8), np.zeros(max(1, hl.value), dtype=np.uint8)
+        _check(call(io.ctypes.data, io.size, ho.ctypes.data, ho.size))
+        return io[: il.value], ho[: hl.value], terms[:n]
 
     def merge_google(self, parts, part_terms):
         """Codecs::Google::IndexSession::merge for a whole dictionary (tri_merge_google): parts = uploaded google_codec Index objects, most recent first

@@ -39,6 +39,10 @@ def _lib():
         L.tri_host_plan_block.restype = C.POINTER(C.c_uint8)
         L.tri_host_plan_block.argtypes = [vp]
         L.tri_host_plan_query_maps.argtypes = [vp, vp, vp]
+        L.tri_host_pfor128_group.argtypes = [vp, vp, C.POINTER(C.c_uint32), vp, C.POINTER(C.c_uint32)]
+        L.tri_host_pfor128_group.restype = None
+        for f in (L.tri_host_lucene_encode, L.tri_host_lucene_encode_units):
+            f.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64, C.POINTER(C.c_uint64), vp, C.c_uint64, C.POINTER(C.c_uint64), vp]
         L._plan_ready = True
     return L
 
@@ -152,3 +156,30 @@ class HostPlan:
 
     def __del__(self):
         self.close()
+
+
+def pfor128_group_pair(v):
+    """One ints() group of 128 values two ways: (the device encoder's plan / emit pair, the host encoder) -> (bytes, bytes)."""
+    v = np.ascontiguousarray(v, dtype=np.uint32)
+    assert v.size == 128
+    a, b = np.zeros(700, dtype=np.uint8), np.zeros(700, dtype=np.uint8)
+    al, bl = C.c_uint32(), C.c_uint32()
+    _lib().tri_host_pfor128_group(v.ctypes.data, a.ctypes.data, C.byref(al), b.ctypes.data, C.byref(bl))
+    return a[: al.value] if al.value != 0xFFFFFFFF else None, b[: bl.value]
+
+
+def lucene_encode(docs, freqs, positions, term_first, units=False):
+    """The Lucene-shaped encoder on the host: the sequential encoder (csrc/host/lucene_encoder.hpp), or — units=True — the device encoder's units
+    (csrc/lucene_enc_units.hpp) run in plain loops.  -> (index bytes, hits.data bytes, term table u32[n, 3])."""
+    d = np.ascontiguousarray(docs, dtype=np.uint32)
+    f = np.ascontiguousarray(freqs, dtype=np.uint32)
+    p = np.ascontiguousarray(positions, dtype=np.uint16)
+    tf = np.ascontiguousarray(term_first, dtype=np.uint64)
+    n = tf.size - 1
+    icap, hcap = 128 + 16 * n + 12 * d.size, 128 + 6 * p.size + 8 * n
+    io, ho, t3 = np.zeros(icap, dtype=np.uint8), np.zeros(hcap, dtype=np.uint8), np.zeros((max(n, 1), 3), dtype=np.uint32)
+    il, hl = C.c_uint64(), C.c_uint64()
+    fn = _lib().tri_host_lucene_encode_units if units else _lib().tri_host_lucene_encode
+    if fn(d.ctypes.data, f.ctypes.data, p.ctypes.data, tf.ctypes.data, n, io.ctypes.data, icap, C.byref(il), ho.ctypes.data, hcap, C.byref(hl), t3.ctypes.data):
+        raise TrinityError("lucene_encode: buffer too small")
+    return io[: il.value], ho[: hl.value], t3[:n]
