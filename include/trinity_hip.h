@@ -377,6 +377,12 @@ int tri_commit_google(tri_dev *, const uint32_t *term_ids, const uint32_t *doc_i
 int tri_merge_google(tri_dev *, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
                      tri_term *terms_out, tri_commit_stats *stats);
 
+/* tri_commit_google with the session's encoder being the Lucene-shaped codec's (commit is codec-agnostic: sess->new_encoder(), indexer.cpp:323): the same sort
+ * and gather, then tri_encode_lucene's device encoder — `index` + `hits.data`; payload-less hits. */
+int tri_commit_lucene(tri_dev *, const uint32_t *term_ids, const uint32_t *doc_ids, const uint32_t *freqs, const uint16_t *positions, size_t npostings, size_t npositions,
+                      uint8_t *index_out, size_t cap, size_t *index_len, uint8_t *hits_out, size_t hits_cap, size_t *hits_len, uint32_t *term_ids_out, tri_term *terms_out,
+                      size_t terms_cap, size_t *nterms, tri_commit_stats *stats);
+
 /* The same with hit payloads (Encoder::new_hit(pos, payload), google_codec.cpp:38-74): payload_lens[h] (0 .. 8) and payloads[h] (the
  * payload's first byte in the low 8 bits) per hit, parallel to positions[].  A hit is written as varint(position delta << 1 | the
  * length differs from the previous hit's of the document) [u8 new length] payload bytes, the length state restarting with every

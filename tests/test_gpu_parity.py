@@ -1415,6 +1415,13 @@ def test_commit_on_the_device(T, dev, payloads):
         assert np.array_equal(gterms, wterms), nterms
         assert got.size == want.size and np.array_equal(got, want), (nterms, int(np.argmax(got[: want.size] != want[: got.size])))
         assert stats == {"docs_cnt": len(set(docs.tolist())), "sum_terms_docs": int(docs.size), "sum_term_hits": int(freqs.sum()), "total_terms": len(live)}
+        if not payloads:  # the same session committed through the Lucene-shaped codec's encoder (commit is codec-agnostic: indexer.cpp:323)
+            from trinity_amd import hostplan as HP
+
+            li, lh, ltids, lterms, lstats = dev.commit_lucene(s_terms, s_docs, s_freqs, s_pos)
+            wi, wh, wt = HP.lucene_encode(docs[sel], freqs[sel], pos[wtake], wtf)
+            assert ltids.tolist() == gtids.tolist() and np.array_equal(lterms, wt) and lstats == stats, nterms
+            assert np.array_equal(li, wi) and np.array_equal(lh, wh), nterms
     # refused: the same (term, document) twice; document 0; positions out of order
     with pytest.raises(T.TrinityError, match="twice"):
         dev.commit_google([7, 7], [5, 5], [1, 1], [3, 4])

@@ -2180,38 +2180,10 @@ extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, co
 }
 
 // ---- Codecs::Lucene::Encoder (lucene_codec.cpp:163-388) on the device, PFOR128 payload (k_lencode.hpp, lucene_enc_units.hpp)
-extern "C" int tri_encode_lucene(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first, size_t nterms,
-                                 uint8_t *index_out, size_t index_cap, size_t *index_len, uint8_t *hits_out, size_t hits_cap, size_t *hits_len, tri_term *terms_out) {
-        if (!dev || !term_first || !index_len || !hits_len || (nterms && !terms_out))
-                return fail(TRI_ERR_INVALID, "tri_encode_lucene: null argument");
-        HIP_TRY(hipSetDevice(dev->device));
-        const uint64_t np = nterms ? term_first[nterms] : 0;
-        if (np && (!docs || !freqs))
-                return fail(TRI_ERR_INVALID, "tri_encode_lucene: null postings");
-        if (npositions && !positions)
-                return fail(TRI_ERR_INVALID, "tri_encode_lucene: null positions");
-        // ---- host: what the encoder would refuse (lucene_encoder.hpp: documents > 0 and ascending within a term; a hit at position 0 is not a hit — refused
-        //      here, as by tri_encode_google, rather than dropped silently; positions non-descending within a document)
-        uint64_t nhits = 0;
-        for (size_t t = 0; t < nterms; ++t) {
-                if (term_first[t + 1] < term_first[t])
-                        return fail(TRI_ERR_INVALID, "tri_encode_lucene: term_first must ascend");
-                uint32_t prev = 0;
-                for (uint64_t p = term_first[t]; p < term_first[t + 1]; ++p) {
-                        if (!docs[p] || docs[p] <= prev)
-                                return fail(TRI_ERR_INVALID, "term %zu: document IDs must be > 0 and strictly ascending (codecs.h:188-190)", t);
-                        prev = docs[p];
-                        if ((uint64_t)freqs[p] > npositions - std::min<uint64_t>(npositions, nhits))
-                                return fail(TRI_ERR_INVALID, "term %zu, document %u: freqs[] asks for more positions than the %zu given", t, docs[p], npositions);
-                        uint32_t last_pos = 0;
-                        for (uint64_t h = nhits; h < nhits + freqs[p]; ++h) {
-                                if (!positions[h] || positions[h] < last_pos)
-                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: positions must be > 0 and non-descending within a document", t, docs[p]);
-                                last_pos = positions[h];
-                        }
-                        nhits += freqs[p];
-                }
-        }
+// the device side of the Lucene-shaped encoder: d_docs / d_freqs / d_pos hold np postings and nhits hits, term after term as term_first (host) says
+static int encode_lucene_device(tri_dev *dev, const uint32_t *d_docs, const uint32_t *d_freqs, const uint16_t *d_pos, const uint64_t np, const uint64_t nhits, const uint64_t *term_first,
+                                const size_t nterms, uint8_t *index_out, const size_t index_cap, size_t *index_len, uint8_t *hits_out, const size_t hits_cap, size_t *hits_len,
+                                tri_term *terms_out) {
         struct Tmp {
                 std::vector<void *> p;
                 ~Tmp() {
@@ -2226,12 +2198,8 @@ extern "C" int tri_encode_lucene(tri_dev *dev, const uint32_t *docs, const uint3
                 }
         } tmp;
         EncBufs scratch; // (enc_scan's chunk sums)
-        uint32_t *d_docs, *d_freqs, *d_hdelta, *d_dcnt, *d_hcnt, *d_dsize, *d_hsize, *d_tail_d, *d_tail_h, *d_isize, *d_hsz;
-        uint16_t *d_pos;
+        uint32_t *d_hdelta, *d_dcnt, *d_hcnt, *d_dsize, *d_hsize, *d_tail_d, *d_tail_h, *d_isize, *d_hsz;
         uint64_t *d_hit_off, *d_term_first, *d_dblk_first, *d_hblk_first, *d_doff, *d_hoff, *d_term_off, *d_hterm_off;
-        HIP_TRY(tmp.get((void **)&d_docs, (np + 1) * 4));
-        HIP_TRY(tmp.get((void **)&d_freqs, (np + 1) * 4));
-        HIP_TRY(tmp.get((void **)&d_pos, (nhits + 1) * 2));
         HIP_TRY(tmp.get((void **)&d_hdelta, (nhits + 1) * 4));
         HIP_TRY(tmp.get((void **)&d_hit_off, (np + 2) * 8));
         HIP_TRY(tmp.get((void **)&d_term_first, (nterms + 1) * 8));
@@ -2245,12 +2213,6 @@ extern "C" int tri_encode_lucene(tri_dev *dev, const uint32_t *docs, const uint3
         HIP_TRY(tmp.get((void **)&d_hsz, (nterms + 1) * 4));
         HIP_TRY(tmp.get((void **)&d_term_off, (nterms + 2) * 8));
         HIP_TRY(tmp.get((void **)&d_hterm_off, (nterms + 2) * 8));
-        if (np) {
-                HIP_TRY(hipMemcpyAsync(d_docs, docs, np * 4, hipMemcpyHostToDevice, dev->stream));
-                HIP_TRY(hipMemcpyAsync(d_freqs, freqs, np * 4, hipMemcpyHostToDevice, dev->stream));
-        }
-        if (nhits)
-                HIP_TRY(hipMemcpyAsync(d_pos, positions, nhits * 2, hipMemcpyHostToDevice, dev->stream));
         HIP_TRY(hipMemcpyAsync(d_term_first, term_first, (nterms + 1) * 8, hipMemcpyHostToDevice, dev->stream));
         int rcs;
         if ((rcs = enc_scan(dev, scratch, d_freqs, d_hit_off, np)))
@@ -2309,13 +2271,65 @@ extern "C" int tri_encode_lucene(tri_dev *dev, const uint32_t *docs, const uint3
         return TRI_OK;
 }
 
+extern "C" int tri_encode_lucene(tri_dev *dev, const uint32_t *docs, const uint32_t *freqs, const uint16_t *positions, size_t npositions, const uint64_t *term_first, size_t nterms,
+                                 uint8_t *index_out, size_t index_cap, size_t *index_len, uint8_t *hits_out, size_t hits_cap, size_t *hits_len, tri_term *terms_out) {
+        if (!dev || !term_first || !index_len || !hits_len || (nterms && !terms_out))
+                return fail(TRI_ERR_INVALID, "tri_encode_lucene: null argument");
+        HIP_TRY(hipSetDevice(dev->device));
+        const uint64_t np = nterms ? term_first[nterms] : 0;
+        if (np && (!docs || !freqs))
+                return fail(TRI_ERR_INVALID, "tri_encode_lucene: null postings");
+        if (npositions && !positions)
+                return fail(TRI_ERR_INVALID, "tri_encode_lucene: null positions");
+        // ---- host: what the encoder would refuse (lucene_encoder.hpp: documents > 0 and ascending within a term; a hit at position 0 is not a hit — refused
+        //      here, as by tri_encode_google, rather than dropped silently; positions non-descending within a document)
+        uint64_t nhits = 0;
+        for (size_t t = 0; t < nterms; ++t) {
+                if (term_first[t + 1] < term_first[t])
+                        return fail(TRI_ERR_INVALID, "tri_encode_lucene: term_first must ascend");
+                uint32_t prev = 0;
+                for (uint64_t p = term_first[t]; p < term_first[t + 1]; ++p) {
+                        if (!docs[p] || docs[p] <= prev)
+                                return fail(TRI_ERR_INVALID, "term %zu: document IDs must be > 0 and strictly ascending (codecs.h:188-190)", t);
+                        prev = docs[p];
+                        if ((uint64_t)freqs[p] > npositions - std::min<uint64_t>(npositions, nhits))
+                                return fail(TRI_ERR_INVALID, "term %zu, document %u: freqs[] asks for more positions than the %zu given", t, docs[p], npositions);
+                        uint32_t last_pos = 0;
+                        for (uint64_t h = nhits; h < nhits + freqs[p]; ++h) {
+                                if (!positions[h] || positions[h] < last_pos)
+                                        return fail(TRI_ERR_INVALID, "term %zu, document %u: positions must be > 0 and non-descending within a document", t, docs[p]);
+                                last_pos = positions[h];
+                        }
+                        nhits += freqs[p];
+                }
+        }
+        struct Up {
+                uint32_t *docs = nullptr, *freqs = nullptr;
+                uint16_t *pos = nullptr;
+                ~Up() {
+                        hipFree(docs), hipFree(freqs), hipFree(pos);
+                }
+        } u;
+        HIP_TRY(hipMalloc((void **)&u.docs, (np + 1) * 4));
+        HIP_TRY(hipMalloc((void **)&u.freqs, (np + 1) * 4));
+        HIP_TRY(hipMalloc((void **)&u.pos, (nhits + 1) * 2));
+        if (np) {
+                HIP_TRY(hipMemcpyAsync(u.docs, docs, np * 4, hipMemcpyHostToDevice, dev->stream));
+                HIP_TRY(hipMemcpyAsync(u.freqs, freqs, np * 4, hipMemcpyHostToDevice, dev->stream));
+        }
+        if (nhits)
+                HIP_TRY(hipMemcpyAsync(u.pos, positions, nhits * 2, hipMemcpyHostToDevice, dev->stream));
+        return encode_lucene_device(dev, u.docs, u.freqs, u.pos, np, nhits, term_first, nterms, index_out, index_cap, index_len, hits_out, hits_cap, hits_len, terms_out);
+}
+
 // ---- SegmentIndexSession::commit (indexer.cpp:311-478) on the device: sort, gather, encode (k_commit.hpp, commit_sort.hip, k_encode.hpp)
 extern "C" int tri_sort_pairs_u64_u32(const unsigned long long *keys_in, unsigned long long *keys_out, const unsigned *vals_in, unsigned *vals_out, size_t n, void *tmp,
                                       size_t *tmp_bytes, hipStream_t stream); // (commit_sort.hip)
 
-extern "C" int tri_commit_google(tri_dev *dev, const uint32_t *term_ids, const uint32_t *doc_ids, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
-                                 const uint64_t *payloads, size_t npostings, size_t npositions, uint8_t *index_out, size_t cap, size_t *index_len, uint32_t *term_ids_out,
-                                 tri_term *terms_out, size_t terms_cap, size_t *nterms, tri_commit_stats *stats) {
+// (codec: TRI_CODEC_GOOGLE — index_out only —, or TRI_CODEC_LUCENE — index_out + hits_out, payload-less hits)
+static int commit_device(tri_dev *dev, const int codec, const uint32_t *term_ids, const uint32_t *doc_ids, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
+                         const uint64_t *payloads, size_t npostings, size_t npositions, uint8_t *index_out, size_t cap, size_t *index_len, uint8_t *hits_out, size_t hits_cap,
+                         size_t *hits_len, uint32_t *term_ids_out, tri_term *terms_out, size_t terms_cap, size_t *nterms, tri_commit_stats *stats) {
         if (!dev || !index_len || !nterms || (npostings && (!term_ids || !doc_ids || !freqs)) || (payload_lens && !payloads) || (npositions && !positions))
                 return fail(TRI_ERR_INVALID, "tri_commit_google: null argument");
         if (npostings > 0xfffffff0ull)
@@ -2435,7 +2449,11 @@ extern "C" int tri_commit_google(tri_dev *dev, const uint32_t *term_ids, const u
         HIP_TRY(hipStreamSynchronize(dev->stream));
         term_first[nt] = np;
         std::vector<tri_term> tt(nt);
-        if (int rc = encode_google_device(dev, d, term_first.data(), nt, np, nhits, index_out && terms_cap >= nt ? index_out : nullptr, cap, index_len, tt.data()))
+        uint8_t *const io = index_out && terms_cap >= nt ? index_out : nullptr;
+        if (codec == TRI_CODEC_LUCENE) {
+                if (int rc = encode_lucene_device(dev, d.docs, d.freqs, d.pos, np, nhits, term_first.data(), nt, io, cap, index_len, hits_out, hits_cap, hits_len, tt.data()))
+                        return rc;
+        } else if (int rc = encode_google_device(dev, d, term_first.data(), nt, np, nhits, io, cap, index_len, tt.data()))
                 return rc;
         if (!index_out)
                 return TRI_OK; // (sizing call: *index_len and *nterms)
@@ -2444,6 +2462,22 @@ extern "C" int tri_commit_google(tri_dev *dev, const uint32_t *term_ids, const u
         memcpy(terms_out, tt.data(), nt * sizeof(tri_term));
         memcpy(term_ids_out, tids.data(), nt * 4);
         return TRI_OK;
+}
+
+extern "C" int tri_commit_google(tri_dev *dev, const uint32_t *term_ids, const uint32_t *doc_ids, const uint32_t *freqs, const uint16_t *positions, const uint8_t *payload_lens,
+                                 const uint64_t *payloads, size_t npostings, size_t npositions, uint8_t *index_out, size_t cap, size_t *index_len, uint32_t *term_ids_out,
+                                 tri_term *terms_out, size_t terms_cap, size_t *nterms, tri_commit_stats *stats) {
+        return commit_device(dev, TRI_CODEC_GOOGLE, term_ids, doc_ids, freqs, positions, payload_lens, payloads, npostings, npositions, index_out, cap, index_len, nullptr, 0, nullptr,
+                             term_ids_out, terms_out, terms_cap, nterms, stats);
+}
+extern "C" int tri_commit_lucene(tri_dev *dev, const uint32_t *term_ids, const uint32_t *doc_ids, const uint32_t *freqs, const uint16_t *positions, size_t npostings, size_t npositions,
+                                 uint8_t *index_out, size_t cap, size_t *index_len, uint8_t *hits_out, size_t hits_cap, size_t *hits_len, uint32_t *term_ids_out, tri_term *terms_out,
+                                 size_t terms_cap, size_t *nterms, tri_commit_stats *stats) {
+        if (!hits_len)
+                return fail(TRI_ERR_INVALID, "tri_commit_lucene: null argument");
+        *hits_len = 0;
+        return commit_device(dev, TRI_CODEC_LUCENE, term_ids, doc_ids, freqs, positions, nullptr, nullptr, npostings, npositions, index_out, cap, index_len, hits_out, hits_cap, hits_len,
+                             term_ids_out, terms_out, terms_cap, nterms, stats);
 }
 
 // ---- Codecs::Google::IndexSession::merge (google_codec.cpp:186-438) for a whole dictionary, on the device (k_commit.hpp)

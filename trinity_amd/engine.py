@@ -106,7 +106,7 @@ ABI_SYMBOLS = [
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_docset_bitmap", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
-    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google", "tri_merge_google", "tri_encode_lucene",
+    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google", "tri_commit_lucene", "tri_merge_google", "tri_encode_lucene",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
 
@@ -166,6 +166,8 @@ def hip_lib():
     L.tri_encode_google.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_encode_google_payloads.argtypes = [vp, vp, vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_encode_lucene.argtypes = [vp, vp, vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
+    L.tri_commit_lucene.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, C.c_size_t,
+                                    C.POINTER(C.c_size_t), vp]
     L.tri_merge_google.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp]
     L.tri_commit_google.argtypes = [vp, vp, vp, vp, vp, vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp]
     L.tri_comm_unique_id.argtypes = [vp]
@@ -335,6 +337,26 @@ class Device:
         terms = np.zeros((max(1, nt.value), 3), dtype=np.uint32)
         _check(call(out.ctypes.data, out.size, tids.ctypes.data, terms.ctypes.data, nt.value))
         return out[: ln.value], tids[: nt.value], terms[: nt.value], dict(zip(("docs_cnt", "sum_terms_docs", "sum_term_hits", "total_terms"), (int(x) for x in stats)))
+
+    def commit_lucene(self, term_ids, doc_ids, freqs, positions):
+        """tri_commit_lucene: a session's postings in insertion order -> (index bytes, hits.data bytes, committed termIDs, term table, stats)."""
+        t = np.ascontiguousarray(term_ids, dtype=np.uint32)
+        d = np.ascontiguousarray(doc_ids, dtype=np.uint32)
+        f = np.ascontiguousarray(freqs, dtype=np.uint32)
+        p = np.ascontiguousarray(positions, dtype=np.uint16)
+        il, hl, nt = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        stats = np.zeros(4, dtype=np.uint64)
+        L = hip_lib()
+
+        def call(io, ic, ho, hc, tids, terms, tcap):
+            return L.tri_commit_lucene(self.h, t.ctypes.data, d.ctypes.data, f.ctypes.data, p.ctypes.data, t.size, p.size, io, ic, C.byref(il), ho, hc, C.byref(hl), tids, terms, tcap,
+                                       C.byref(nt), stats.ctypes.data)  # fmt: skip
+
+        _check(call(None, 0, None, 0, None, None, 0))
+        io, ho = np.zeros(max(1, il.value), dtype=np.uint8), np.zeros(max(1, hl.value), dtype=np.uint8)
+        tids, terms = np.zeros(max(1, nt.value), dtype=np.uint32), np.zeros((max(1, nt.value), 3), dtype=np.uint32)
+        _check(call(io.ctypes.data, io.size, ho.ctypes.data, ho.size, tids.ctypes.data, terms.ctypes.data, nt.value))
+        return io[: il.value], ho[: hl.value], tids[: nt.value], terms[: nt.value], dict(zip(("docs_cnt", "sum_terms_docs", "sum_term_hits", "total_terms"), (int(x) for x in stats)))
 
     def encode_lucene(self, docs, freqs, positions, term_first):
         """The Lucene-shaped codec's encoder on the device (tri_encode_lucene, PFOR128 payload): -> (index bytes, hits.data bytes, term table u32[n, 3])."""
