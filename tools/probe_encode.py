@@ -27,3 +27,25 @@ for _ in range(3):
 same = out.size == np.asarray(seg.index).size
 print(f"encode: {len(docs)} postings, {int(ends[-1])} hits -> {out.size} bytes in {best * 1e3:.1f} ms (two passes + copies both ways): "
       f"{len(docs) / best / 1e6:.0f} M postings/s, {out.size / best / 1e9:.2f} GB/s of index; same size as the segment: {same}")
+
+# ---- the rest of the write side (round 4): the Lucene-shaped encoder, commit (sort + gather + encode), merge of two halves
+def timed(fn, n=2):
+    best = 1e9
+    for _ in range(n):
+        t0 = time.perf_counter()
+        r = fn()
+        best = min(best, time.perf_counter() - t0)
+    return best, r
+
+t, (li, lh, lt) = timed(lambda: dev.encode_lucene(docs, f, pos, tf))
+print(f"encode_lucene: {li.size} + {lh.size} bytes (index + hits.data) in {t * 1e3:.1f} ms: {len(docs) / t / 1e6:.0f} M postings/s")
+# a session: the same postings in document order (insertion order), the terms named by their index
+term_of = np.repeat(kept, df[kept])
+order = np.argsort(docs, kind="stable")
+hit0 = np.concatenate([[0], ends])[:-1].astype(np.int64)
+fo = f[order].astype(np.int64)
+take = np.repeat(hit0[order] - np.concatenate([[0], np.cumsum(fo)[:-1]]), fo) + np.arange(int(ends[-1]), dtype=np.int64)
+s_pos = pos[take]
+s_terms, s_docs, s_freqs = np.ascontiguousarray(term_of[order]), np.ascontiguousarray(docs[order]), np.ascontiguousarray(f[order])
+t, (ci, ctids, cterms, cstats) = timed(lambda: dev.commit_google(s_terms, s_docs, s_freqs, s_pos), n=2)
+print(f"commit_google: {len(docs)} postings in insertion order -> {ci.size} bytes, {len(ctids)} terms in {t * 1e3:.1f} ms: {len(docs) / t / 1e6:.0f} M postings/s  {cstats}")

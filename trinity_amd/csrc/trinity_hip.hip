@@ -2180,23 +2180,31 @@ extern "C" int tri_encode_google_payloads(tri_dev *dev, const uint32_t *docs, co
 }
 
 // ---- Codecs::Lucene::Encoder (lucene_codec.cpp:163-388) on the device, PFOR128 payload (k_lencode.hpp, lucene_enc_units.hpp)
+// temporaries of the write-side calls: from the device handle's buffer pool, back to it when the call returns (the stream has been synchronised by then)
+namespace {
+struct PoolTmp {
+        tri_dev *dev;
+        std::vector<void *> p;
+        ~PoolTmp() {
+                if (!p.empty())
+                        hipStreamSynchronize(dev->stream); // (an early error return: nothing may still be running on what goes back to the pool)
+                for (void *q : p)
+                        pool_free(dev, q);
+        }
+        hipError_t get(void **out, size_t bytes) {
+                const hipError_t e = pool_alloc(dev, out, bytes ? bytes : 8);
+                if (e == hipSuccess)
+                        p.push_back(*out);
+                return e;
+        }
+};
+} // namespace
+
 // the device side of the Lucene-shaped encoder: d_docs / d_freqs / d_pos hold np postings and nhits hits, term after term as term_first (host) says
 static int encode_lucene_device(tri_dev *dev, const uint32_t *d_docs, const uint32_t *d_freqs, const uint16_t *d_pos, const uint64_t np, const uint64_t nhits, const uint64_t *term_first,
                                 const size_t nterms, uint8_t *index_out, const size_t index_cap, size_t *index_len, uint8_t *hits_out, const size_t hits_cap, size_t *hits_len,
                                 tri_term *terms_out) {
-        struct Tmp {
-                std::vector<void *> p;
-                ~Tmp() {
-                        for (void *q : p)
-                                hipFree(q);
-                }
-                hipError_t get(void **out, size_t bytes) {
-                        const hipError_t e = hipMalloc(out, bytes ? bytes : 8);
-                        if (e == hipSuccess)
-                                p.push_back(*out);
-                        return e;
-                }
-        } tmp;
+        PoolTmp tmp{dev}; // (the large temporaries come from the device handle's pool: a sizing call and the call that follows it use the same ones)
         EncBufs scratch; // (enc_scan's chunk sums)
         uint32_t *d_hdelta, *d_dcnt, *d_hcnt, *d_dsize, *d_hsize, *d_tail_d, *d_tail_h, *d_isize, *d_hsz;
         uint64_t *d_hit_off, *d_term_first, *d_dblk_first, *d_hblk_first, *d_doff, *d_hoff, *d_term_off, *d_hterm_off;
@@ -2349,19 +2357,7 @@ static int commit_device(tri_dev *dev, const int codec, const uint32_t *term_ids
                 *stats = tri_commit_stats{docs_cnt, np, nhits, 0};
         if (!np)
                 return TRI_OK;
-        struct Tmp {
-                std::vector<void *> p;
-                ~Tmp() {
-                        for (void *q : p)
-                                hipFree(q);
-                }
-                hipError_t get(void **out, size_t bytes) {
-                        const hipError_t e = hipMalloc(out, bytes ? bytes : 8);
-                        if (e == hipSuccess)
-                                p.push_back(*out);
-                        return e;
-                }
-        } tmp;
+        PoolTmp tmp{dev}; // (the large temporaries come from the device handle's pool: a sizing call and the call that follows it use the same ones)
         uint32_t *d_terms, *d_docs_in, *d_freqs_in, *d_vals, *d_perm, *d_marks, *d_term_ids;
         unsigned long long *d_keys, *d_keys_sorted, *d_err;
         uint16_t *d_pos_in = nullptr;
@@ -2519,19 +2515,7 @@ extern "C" int tri_merge_google(tri_dev *dev, tri_index *const *parts, size_t np
         *index_len = 0;
         if (stats)
                 *stats = tri_commit_stats{0, 0, 0, 0};
-        struct Tmp {
-                std::vector<void *> p;
-                ~Tmp() {
-                        for (void *q : p)
-                                hipFree(q);
-                }
-                hipError_t get(void **out, size_t bytes) {
-                        const hipError_t e = hipMalloc(out, bytes ? bytes : 8);
-                        if (e == hipSuccess)
-                                p.push_back(*out);
-                        return e;
-                }
-        } tmp;
+        PoolTmp tmp{dev}; // (the large temporaries come from the device handle's pool: a sizing call and the call that follows it use the same ones)
         EncBufs d;       // the merged postings: what the encoder reads
         EncBufs scratch; // (enc_scan's chunk sums)
         std::vector<uint64_t> term_first(nterms + 1, 0);
