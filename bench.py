@@ -174,19 +174,36 @@ def read_back(T, bs):  # what every caller needs on the host: match counts and, 
 
 
 class Pipeline:
-    """create -> run -> sync -> read back [-> gather], the next set compiled while the current one runs."""
+    """create -> run -> sync -> read back [-> gather] with two sets of batches in flight and the compiler on a thread of its own: a step QUEUES the
+    set compiled during the previous step behind the running one (the engine stream never drains: with one set in flight the GPU idled about a
+    quarter of a millisecond per step between one set's sync / read-back and the next one's first launch — cfg2: 1.66 ms per step around 1.44 ms
+    of kernels), hands the next set to the compiling thread (tri_batch_create: host planning + the plan's H2D copy; include/trinity_hip.h: one
+    thread may compile while another runs / awaits / releases other batches of the same device), then awaits and reads back the older set.
+    Between the barriers of a timed region of K steps exactly K sets are launched and run to completion: the set running at the region's start
+    was awaited by the barrier before it, the last one launched is awaited by the barrier after it."""
 
     def __init__(self, T, wl, gathers=None, blocks_of=None, sync_stream=True):
+        from concurrent.futures import ThreadPoolExecutor
+
         self.T, self.wl, self.gathers, self.blocks_of, self.sync_stream = T, wl, gathers, blocks_of, sync_stream
-        self.cur = wl.create_set()
+        self.compiler = ThreadPoolExecutor(max_workers=1)
+        self.cur = wl.create_set()  # on the engine stream (running or complete)
+        for b in self.cur:
+            b.run()
+        self.ready = self.compiler.submit(wl.create_set)  # being compiled / compiled, its plan on its way to the device, not launched yet
         self.done = None  # the last completed set: its results stay readable
         self.readback_s = 0.0
 
     def step(self):
         T = self.T
-        for b in self.cur:
-            b.run()
-        nxt = self.wl.create_set()  # host planning + the plan's H2D copy while `cur` runs on the engine stream
+        if self.done:  # (its buffers go back to the device pool before the next set asks for its own)
+            for b in self.done:
+                b.close()
+            self.done = None
+        launched = self.ready.result()
+        self.ready = self.compiler.submit(self.wl.create_set)  # compiled while `cur` and `launched` run and `cur` is read back
+        for b in launched:
+            b.run()  # behind `cur` on the engine stream
         for b in self.cur:
             b.sync()
         t0 = time.perf_counter()
@@ -201,20 +218,19 @@ class Pipeline:
 
                 torch.cuda.current_stream().synchronize()  # the receive side is complete before the send buffers go back to the pool
         infos = [b.info() for b in self.cur]
-        for i, c in zip(infos, nxt):  # the tri_batch_create calls made INSIDE this step are the next set's (the current set's were made a step earlier)
+        for i, c in zip(infos, launched):  # the latest COMPLETED tri_batch_create calls: the set launched in this step, compiled during the previous one
             ci = c.info()
             i["create_ms"], i["create_plan_ms"] = ci["create_ms"], ci["create_plan_ms"]
-        if self.done:
-            for b in self.done:
-                b.close()
-        self.done, self.cur = self.cur, nxt
+        self.done, self.cur = self.cur, launched
         return infos
 
     def close(self):
-        for bs in (self.cur, self.done):
+        ready = self.ready.result() if self.ready is not None else None
+        self.compiler.shutdown()
+        for bs in (self.cur, ready, self.done):
             for b in bs or []:
                 b.close()
-        self.cur = self.done = None
+        self.cur = self.ready = self.done = None
 
 
 def timed(pipe, steps, warmup, barrier):
@@ -451,7 +467,7 @@ def main():
                 "options": args.option,
             },
             "step": "tri_batch_create (host planning + the plan's H2D copy) -> tri_batch_run -> tri_batch_sync -> match counts" + (" + top-K blocks" if any(pt.topk for pt in parts) else "") +
-                    " read back to the host" + (" -> RCCL all_gather of the result blocks" if world > 1 else "") + "; the next step's batches are compiled while the current ones run",
+                    " read back to the host" + (" -> RCCL all_gather of the result blocks" if world > 1 else "") + "; two sets of batches in flight and the compiler on its own host thread: a step launches the set compiled during the previous step behind the running one, then awaits the older one",
             "value_excludes": "the docID sets' way to the host: they stay in HBM, the host reads match counts / top-K blocks (PCIe-inclusive figure: DESIGN.md §5)",
             "per_gpu_value": qps / world,
             "matched_docids_per_sec": matches_all * steps / elapsed,

@@ -246,7 +246,8 @@ int tri_batch_query_status(const tri_batch *, int32_t *status /* [nq] */);
 void tri_batch_destroy(tri_batch *);
 /* enqueue the batch on the engine stream (asynchronous) */
 int tri_batch_run(tri_batch *);
-/* wait for completion; also refreshes tri_batch_info */
+/* wait for THIS batch's completion (its own last event: batches launched behind it on the engine stream are not waited for, so a caller
+ * may keep the next batch queued while it collects this one's results); also refreshes tri_batch_info */
 int tri_batch_sync(tri_batch *);
 int tri_batch_get_info(const tri_batch *, tri_batch_info *);
 

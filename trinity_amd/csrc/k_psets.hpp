@@ -77,8 +77,8 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                 sh.tick[0] = t0;
                 nt = uni(atomicAdd(ticket, 1u)) >> 6;
         }
+        __syncthreads();
         for (uint32_t p = 0;; p ^= 1u) {
-                __syncthreads();
                 if (uni(sh.tick[p]) >= ntasks)
                         break;
                 const DevPsetUnit &U = sh.unit[p];
@@ -228,7 +228,11 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                         counts[tix] = produced;
                         ((uint32_t *)&sh.unit[p ^ 1u])[lane & 15u] = nwd; // the next task, read by everybody behind the barrier at the loop's head
                         sh.tick[p ^ 1u] = nt;
+                        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the record's words are in LDS before this wave reaches the barrier
                         nt = uni(nnt) >> 6;
                 }
+                // (the record's barrier stands here, in the block of the LDS stores above, not at the loop's head: reached over the loop's back
+                //  edge the compiler put no s_waitcnt lgkmcnt(0) between the stores and the s_barrier — see k_and)
+                __syncthreads();
         }
 }

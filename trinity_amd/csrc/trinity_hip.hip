@@ -30,6 +30,7 @@
 #include <unistd.h>
 #include <dlfcn.h>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -83,7 +84,13 @@ struct tri_dev {
         // ... and the HIP events of a batch (nine per batch)
         std::vector<hipEvent_t> events_idle;
         std::unique_ptr<HostPool> hpool; // the planner's host threads: started by the first batch large enough to be planned in fragments
+        // The batch calls of one handle may come from TWO host threads: one compiling the next batch (tri_batch_create) while the other runs,
+        // awaits and releases earlier ones (tri_batch_run / _sync / _destroy) — bench.py's loop; the planner's share of a create (most of it)
+        // runs outside the lock, the pools above, the index's plane cache and everything that enqueues on the streams inside it.  Every other
+        // entry point (uploads, options, encoders, two creates at once): one thread at a time, as before.
+        std::recursive_mutex mu;
 };
+using DevLock = std::lock_guard<std::recursive_mutex>;
 constexpr size_t POOL_MIN_BYTES = 64u << 10;  // smaller buffers are not worth pooling
 constexpr size_t POOL_IDLE_CAP = 64ull << 30; // idle buffers beyond this are given back to the device (largest first)
 constexpr size_t PINNED_IDLE_MAX = 8;         // idle pinned blocks kept
@@ -104,9 +111,19 @@ static void dev_destroy(tri_dev *d) {
                 hipHostFree(b.second);
         delete d;
 }
-static void dev_retain(tri_dev *d) { ++d->refs; }
+static void dev_retain(tri_dev *d) {
+        DevLock g(d->mu);
+        ++d->refs;
+}
 static void dev_release(tri_dev *d) {
-        if (d && --d->refs == 0 && d->closing)
+        if (!d)
+                return;
+        bool last;
+        {
+                DevLock g(d->mu);
+                last = --d->refs == 0 && d->closing;
+        }
+        if (last)
                 dev_destroy(d);
 }
 
@@ -114,6 +131,7 @@ static void dev_release(tri_dev *d) {
 static hipError_t pool_alloc(tri_dev *dev, void **out, const size_t bytes) {
         if (bytes < POOL_MIN_BYTES)
                 return hipMalloc(out, bytes);
+        DevLock g(dev->mu);
         auto &P = dev->pool;
         size_t best = SIZE_MAX;
         for (size_t i = 0; i < P.idle.size(); ++i)
@@ -149,6 +167,7 @@ static void pool_free(tri_dev *dev, void *p) {
                 hipFree(p);
                 return;
         }
+        DevLock g(dev->mu);
         auto &P = dev->pool;
         const auto it = P.size_of.find(p);
         if (it == P.size_of.end()) { // (below POOL_MIN_BYTES: never pooled)
@@ -170,6 +189,7 @@ static void pool_free(tri_dev *dev, void *p) {
 }
 // pinned host block of at least `bytes` (64-byte aligned: hipHostMalloc is page-aligned); *cap = its size
 static uint8_t *pinned_alloc(tri_dev *dev, const size_t bytes, size_t *cap) {
+        DevLock g(dev->mu);
         auto &I = dev->pinned_idle;
         size_t best = SIZE_MAX;
         for (size_t i = 0; i < I.size(); ++i)
@@ -193,13 +213,19 @@ static uint8_t *pinned_alloc(tri_dev *dev, const size_t bytes, size_t *cap) {
 static void pinned_free(tri_dev *dev, void *p, const size_t cap) {
         if (!p)
                 return;
-        if (!dev || dev->pinned_idle.size() >= PINNED_IDLE_MAX) {
+        if (!dev) {
+                hipHostFree(p);
+                return;
+        }
+        DevLock g(dev->mu);
+        if (dev->pinned_idle.size() >= PINNED_IDLE_MAX) {
                 hipHostFree(p);
                 return;
         }
         dev->pinned_idle.emplace_back(cap, p);
 }
 static hipError_t event_get(tri_dev *dev, hipEvent_t *e) {
+        DevLock g(dev->mu);
         if (!dev->events_idle.empty()) {
                 *e = dev->events_idle.back();
                 dev->events_idle.pop_back();
@@ -324,9 +350,10 @@ struct tri_batch : BatchPlan {
                 }
                 for (hipEvent_t e : {ev0, ev_a, ev_s, ev_r, ev_b, ev_c, ev_p, ev1, ev_pl, ev_k, ev_up, ev_t})
                         if (e) {
-                                if (dev)
+                                if (dev) {
+                                        DevLock g(dev->mu);
                                         dev->events_idle.push_back(e);
-                                else
+                                } else
                                         hipEventDestroy(e);
                         }
                 pinned_free(dev, block, block_cap);
@@ -672,7 +699,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         in.flags = flags;
         in.topk = topk;
         in.similarity = similarity;
-        if (nq >= 1024 && !dev->hpool) { // (batches below a thousand queries are planned on the calling thread)
+        if (DevLock g(dev->mu); nq >= 1024 && !dev->hpool) { // (batches below a thousand queries are planned on the calling thread)
                 const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
                 const unsigned want = dev->opt.plan_threads ? (unsigned)std::min<uint64_t>(dev->opt.plan_threads, 64) : std::min(16u, hw);
                 if (want > 1) {
@@ -704,6 +731,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         dbg_t[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count();
         };
         dbg_lap(0);
+        DevLock dev_lock(dev->mu); // (from here on: the device's pools, the index's plane cache, the streams — see tri_dev::mu)
         // ---- the arena: the block's copy, then the batch's small device-only arrays; the part that must start out zero comes last
         size_t a = b->block_bytes;
         auto carve = [&](size_t bytes) {
@@ -851,6 +879,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
         if (!b)
                 return fail(TRI_ERR_INVALID, "null batch");
         tri_dev *dev = b->dev;
+        DevLock dev_lock(dev->mu);
         HIP_TRY(hipSetDevice(dev->device));
         b->synced = false;
         const uint32_t n = (uint32_t)b->tasks.size();
@@ -951,7 +980,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipEventRecord(b->ev_r, dev->stream));
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
-                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense + b->n_pset + b->n_probe, b->d_qterms,
+                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, (const DevCandUnit *)(b->d_arena + b->off_cunits), b->d_qterms,
                                            b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->ix->d_pcache, b->plw);
                 HIP_TRY(hipGetLastError());
                 if (overlap) {
@@ -1157,7 +1186,10 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                 }
         }
 #endif
-        HIP_TRY(hipStreamSynchronize(dev->stream));
+        // THIS batch's last event, not the engine stream: a caller that keeps the stream fed (the next batch launched before this one is
+        // awaited — bench.py's loop) gets this batch's results when THEY are ready, not when everything queued behind them is
+        HIP_TRY(hipEventSynchronize(b->ev1));
+        DevLock dev_lock(dev->mu); // (the wait above stands outside the lock; what follows may enqueue on the engine stream)
 #ifdef TRI_TASKTIMES
         if (b->tasks.size() && getenv("TRINITY_TASKTIMES")) {
 #if TRI_TASKTIMES == 2 // (k_score: tickets run over the docset-materialising tasks, sched[0 ..))
