@@ -175,33 +175,64 @@ def read_back(T, bs):  # what every caller needs on the host: match counts and, 
 
 class Pipeline:
     """create -> run -> sync -> read back [-> gather] with two sets of batches in flight and the compiler on a thread of its own: a step QUEUES the
-    set compiled during the previous step behind the running one (the engine stream never drains: with one set in flight the GPU idled about a
+    set the compiler has ready behind the running one (the engine stream never drains: with one set in flight the GPU idled about a
     quarter of a millisecond per step between one set's sync / read-back and the next one's first launch — cfg2: 1.66 ms per step around 1.44 ms
-    of kernels), hands the next set to the compiling thread (tri_batch_create: host planning + the plan's H2D copy; include/trinity_hip.h: one
+    of kernels) while the compiling thread works on the set after it (tri_batch_create: host planning + the plan's H2D copy; include/trinity_hip.h: one
     thread may compile while another runs / awaits / releases other batches of the same device), then awaits and reads back the older set.
     Between the barriers of a timed region of K steps exactly K sets are launched and run to completion: the set running at the region's start
     was awaited by the barrier before it, the last one launched is awaited by the barrier after it."""
 
     def __init__(self, T, wl, gathers=None, blocks_of=None, sync_stream=True):
-        from concurrent.futures import ThreadPoolExecutor
+        import queue
+        import threading
 
         self.T, self.wl, self.gathers, self.blocks_of, self.sync_stream = T, wl, gathers, blocks_of, sync_stream
-        self.compiler = ThreadPoolExecutor(max_workers=1)
         self.cur = wl.create_set()  # on the engine stream (running or complete)
         for b in self.cur:
             b.run()
-        self.ready = self.compiler.submit(wl.create_set)  # being compiled / compiled, its plan on its way to the device, not launched yet
+        # five sets are alive in the loop (read back, running, launched, compiled and waiting, being compiled): two more sets' worth of buffers
+        # go into the device pool now, so that no timed step pays a cold allocation (cfg5: a 17 GB output region, measured 0.2 .. 484 ms)
+        for spare in [wl.create_set(), wl.create_set()]:
+            for b in spare:
+                b.close()
+        # the compiler: tri_batch_create back to back on its own thread, one compiled set waiting at most (with a create per step handed over
+        # by the main loop its 0.2 ms between a sync's return and the next hand-over added to every create: cfg2 1.69 ms per step around
+        # 1.45 ms creates and 1.45 ms of kernels)
+        self.ready = queue.Queue(maxsize=1)
+        self.stop = False
+
+        def compile_loop():
+            while not self.stop:
+                try:
+                    bs = wl.create_set()
+                except BaseException as e:  # (handed to the main loop: a failed create fails the run)
+                    self.ready.put(e)
+                    return
+                while not self.stop:
+                    try:
+                        self.ready.put(bs, timeout=0.05)
+                        bs = None
+                        break
+                    except queue.Full:
+                        pass
+                if bs is not None:  # (stopped with a compiled set in hand)
+                    for b in bs:
+                        b.close()
+
+        self.compiler = threading.Thread(target=compile_loop, daemon=True)
+        self.compiler.start()
         self.done = None  # the last completed set: its results stay readable
         self.readback_s = 0.0
 
     def step(self):
         T = self.T
-        if self.done:  # (its buffers go back to the device pool before the next set asks for its own)
+        if self.done:  # (its buffers go back to the device pool)
             for b in self.done:
                 b.close()
             self.done = None
-        launched = self.ready.result()
-        self.ready = self.compiler.submit(self.wl.create_set)  # compiled while `cur` and `launched` run and `cur` is read back
+        launched = self.ready.get()
+        if isinstance(launched, BaseException):
+            raise launched
         for b in launched:
             b.run()  # behind `cur` on the engine stream
         for b in self.cur:
@@ -218,19 +249,25 @@ class Pipeline:
 
                 torch.cuda.current_stream().synchronize()  # the receive side is complete before the send buffers go back to the pool
         infos = [b.info() for b in self.cur]
-        for i, c in zip(infos, launched):  # the latest COMPLETED tri_batch_create calls: the set launched in this step, compiled during the previous one
+        for i, c in zip(infos, launched):  # the tri_batch_create calls of the set launched in this step (one set is compiled per step in the steady state)
             ci = c.info()
             i["create_ms"], i["create_plan_ms"] = ci["create_ms"], ci["create_plan_ms"]
         self.done, self.cur = self.cur, launched
         return infos
 
     def close(self):
-        ready = self.ready.result() if self.ready is not None else None
-        self.compiler.shutdown()
-        for bs in (self.cur, ready, self.done):
+        import queue
+
+        self.stop = True
+        self.compiler.join()
+        try:
+            left = self.ready.get_nowait()
+        except queue.Empty:
+            left = None
+        for bs in (self.cur, None if isinstance(left, BaseException) else left, self.done):
             for b in bs or []:
                 b.close()
-        self.cur = self.ready = self.done = None
+        self.cur = self.done = None
 
 
 def timed(pipe, steps, warmup, barrier):
@@ -467,7 +504,7 @@ def main():
                 "options": args.option,
             },
             "step": "tri_batch_create (host planning + the plan's H2D copy) -> tri_batch_run -> tri_batch_sync -> match counts" + (" + top-K blocks" if any(pt.topk for pt in parts) else "") +
-                    " read back to the host" + (" -> RCCL all_gather of the result blocks" if world > 1 else "") + "; two sets of batches in flight and the compiler on its own host thread: a step launches the set compiled during the previous step behind the running one, then awaits the older one",
+                    " read back to the host" + (" -> RCCL all_gather of the result blocks" if world > 1 else "") + "; two sets of batches in flight and the compiler on its own host thread: a step launches the set the compiler has ready behind the running one, then awaits the older one",
             "value_excludes": "the docID sets' way to the host: they stay in HBM, the host reads match counts / top-K blocks (PCIe-inclusive figure: DESIGN.md §5)",
             "per_gpu_value": qps / world,
             "matched_docids_per_sec": matches_all * steps / elapsed,

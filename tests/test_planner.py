@@ -93,28 +93,6 @@ def check_plan(p, nq):
             k0 = 1 if tasks[u["tix"]]["kind"] == HP.TASK_PROBE else 0
             for k in range(k0, min(int(u["nterms"]), 4)):
                 assert (u["tt"][k] & 0x3FFFFFFF) == (p.qterms[u["term_base"] + k] & 0x3FFFFFFF) and u["row"][k] == p.qplane[u["term_base"] + k] != 0xFFFFFFFF
-    # candidate-tile records (k_and): one per TASK_CAND task, STORED in run order; the task's geometry, the first four terms and their rows inline,
-    # the lead's and the second term's directory records (one DevTerm per term, whoever quotes it)
-    if s["n_cand"]:
-        cu = p.cunits
-        assert s["sizeof_cunit"] == HP.DEV_CUNIT.itemsize == 128 and s["n_cunits"] >= s["n_cand"]
-        c0 = s["n_dense"] + s["n_pset"] + s["n_probe"]
-        assert np.array_equal(cu["tix"], sched[c0 : c0 + s["n_cand"]])
-        tk = tasks[cu["tix"]]
-        assert np.all(tk["kind"] == HP.TASK_CAND)
-        assert np.array_equal(tk["begin"], cu["tile_begin"]) and np.array_equal(tk["end"], cu["tile_end"]) and np.array_equal(tk["out_off"], cu["out_off"])
-        q = plan[tk["slot"]]
-        assert np.array_equal(q["nterms"], cu["nterms"]) and np.array_equal(q["term_base"], cu["term_base"])
-        assert np.all(cu["tile_end"].astype(np.int64) * 256 < cu["lead"]["nblocks"].astype(np.int64) + 256)
-        term_rec = {}
-        for u in cu[:: max(1, len(cu) // 400)]:
-            n = int(u["nterms"])
-            for k in range(min(n, 4)):
-                assert u["tt"][k] == p.qterms[u["term_base"] + k]
-                assert u["row"][k] == (p.qplane[u["term_base"] + k] if s["n_qplane"] else 0xFFFFFFFF)
-            assert term_rec.setdefault(int(u["tt"][0]) & 0x3FFFFFFF, u["lead"].tobytes()) == u["lead"].tobytes() and u["lead"]["documents"] > 0
-            if n > 1:
-                assert term_rec.setdefault(int(u["tt"][1]) & 0x3FFFFFFF, u["t1"].tobytes()) == u["t1"].tobytes() and u["t1"]["documents"] > 0
     # planes: a term position that names a row names its own term's row
     if s["n_qplane"]:
         # (a row is the term's rank by document count — the planes live with the index, every batch names the same row for the same term)

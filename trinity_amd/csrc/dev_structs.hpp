@@ -114,22 +114,6 @@ struct DevPsetUnit { // (also the record of a TASK_PROBE task: w_begin / w_end a
 };
 static_assert(sizeof(DevPsetUnit) == 64, "one cache-line half per unit");
 constexpr uint32_t PSET_UNIT_FIRST = 1u, PSET_UNIT_BITMAP = 2u;
-// ---- TASK_CAND: the record of a candidate-tile task as k_and reads it — ONE 128-byte line holding what the kernel used to collect through
-//      sched[] -> tasks[] -> plan[] -> qterms[] -> terms[] (five dependent loads at the head of a 29 us task) and qterms[] / qplane[] / terms[]
-//      again per filtered term.  cunits[] is stored in RUN order: cunits[i] is the task the i-th ticket of k_and hands out
-struct DevCandUnit {
-        uint64_t out_off;              // the task's private output region
-        uint32_t tile_begin, tile_end; // lead tiles [tile_begin, tile_end)
-        uint32_t tix;                  // index into counts[]
-        uint32_t nterms;
-        uint32_t term_base;            // qterms[] / qplane[] slice (read by the kernel only for terms >= PSET_INLINE_TERMS)
-        uint32_t pad;
-        uint32_t tt[PSET_INLINE_TERMS];  // qterms[] words (term | QT_GROUP | QT_NOT) ...
-        uint32_t row[PSET_INLINE_TERMS]; // ... and the terms' plane rows (PL_NONE: none)
-        DevTerm lead;                  // terms[tt[0]]
-        DevTerm t1;                    // terms[tt[1]] (nterms >= 2)
-};
-static_assert(sizeof(DevCandUnit) == 128, "one cache line per unit");
 // ---- TASK_TREE: the query tree as the kernels read it (k_tree.hpp).  A record in the plan's tree[] words (DevQuery::fused_idx = its first word):
 //      TREE_HDR_WORDS header words { nnodes, 0... }, then nnodes DevTreeNode in POSTFIX order (children before parents, the root last)
 constexpr uint32_t TREE_MAX_NODES = 64;     // node values and "an iterator sits on the document" flags are bit sets in a 64-bit word

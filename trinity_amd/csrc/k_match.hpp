@@ -58,8 +58,6 @@ struct AndShared {
         uint32_t scan[8];
         uint32_t bcast[4];
         uint32_t lcur[16]; // per term: directory cursor, uniform across the workgroup
-        DevCandUnit unit[2]; // k_and: the task being run and the next one (fetched while the current one runs) ...
-        uint32_t tick[2];    // ... and their tickets (>= ntasks: none)
 };
 
 // LDS state of the bitmap-window kernel
@@ -1039,22 +1037,15 @@ __global__ __launch_bounds__(DENSE_WG, TRI_DENSE_WAVES) void k_and_dense(const u
 }
 
 // candidate-tile tasks (TASK_CAND)
-// a DevTerm held in LDS (a task record), every word made wave-uniform (scalar registers)
-__device__ __forceinline__ DevTerm lds_term(const DevTerm &t) {
-        DevTerm r;
-        r.documents = uni(t.documents), r.first_block = uni(t.first_block), r.nblocks = uni(t.nblocks), r.last_n = uni(t.last_n);
-        r.win_off = uni(t.win_off), r.flags = uni(t.flags), r.npfor = uni(t.npfor), r.pad = uni(t.pad);
-        return r;
-}
-
 template <int CODEC>
 #ifndef TRI_AND_WAVES
 #define TRI_AND_WAVES 4
 #endif
 __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last,
                                                 const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win,
-                                                const DevTerm *__restrict__ terms, const DevCandUnit *__restrict__ cunits,
-                                                const uint32_t *__restrict__ qterms,
+                                                const DevTerm *__restrict__ terms,
+                                                const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
+                                                const uint32_t *__restrict__ sched, const uint32_t *__restrict__ qterms,
                                                 const uint32_t ntasks, uint32_t *__restrict__ ticket,
                                                 uint32_t *__restrict__ out, uint32_t *__restrict__ counts,
                                                 const uint32_t *__restrict__ masked, const uint32_t *__restrict__ qplane,
@@ -1064,69 +1055,38 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
         const uint32_t wave = uni(tid >> 6);
         PROF_DECL;
         PROF_START();
-        // ---- task pipeline: the NEXT task's ticket is drawn and its 128-byte record (DevCandUnit, stored in run order: cunits[ticket]) fetched
-        //      while the workgroup runs the current task, by the LAST wave — the one with the least to do in the lead's decode (a short lead's
-        //      blocks all belong to wave 0's lanes), so that waiting for the atomic's answer before the record's load costs nothing.  The
-        //      ticket's atomic and the record's load are off the critical path, and the task's head needs no sched -> task -> query -> qterms
-        //      -> terms chain.  One task ahead, not two as k_psets: these tasks' times vary (a schedule by ESTIMATED cost), and every task
-        //      a workgroup holds in reserve is a task no idle workgroup can take at the kernel's end (two ahead: k_and 0.71 -> 0.77 ms).
-        //      All 64 lanes add 1 (the compiler folds that into ONE global atomic of +64 with a uniform operand — no lane-divergent branch
-        //      at the loop head), so the counter advances in units of 64 per draw.  Lane l of the wave carries word l & 31 of the record.
-#ifndef TRI_AND_FETCH_WAVE
-#define TRI_AND_FETCH_WAVE (AND_WG / 64 - 1)
-#endif
-#ifndef TRI_AND_AHEAD
-#define TRI_AND_AHEAD 1
-#endif
-        const bool fetcher = wave == TRI_AND_FETCH_WAVE;
-        uint32_t nt2 = 0xffffffffu;
-        if (fetcher) {
-                const uint32_t t0 = uni(atomicAdd(ticket, 1u)) >> 6;
-                uint32_t wd = 0;
-                if (t0 < ntasks)
-                        wd = ((const uint32_t *)(cunits + t0))[tid & 31u];
-                ((uint32_t *)&sh.unit[0])[tid & 31u] = wd;
-                sh.tick[0] = t0;
-#if TRI_AND_AHEAD == 2
-                nt2 = uni(atomicAdd(ticket, 1u)) >> 6;
-#endif
-        }
-        __syncthreads();
-        for (uint32_t p = 0;; p ^= 1u) {
-                const uint32_t ticket_no = uni(sh.tick[p]);
+        for (;;) {
+                // (Tried in round 4 and dropped: ONE 128-byte record per task — geometry, the first four terms with their plane rows, the lead's and the
+                //  second term's DevTerm — stored in run order and fetched a task ahead by one wave, instead of the sched -> task -> query ->
+                //  qterms -> terms chain below.  k_and 0.71 -> 0.72 ms at cfg2 (the chain's loads are scalar and L2-resident: the task's time is the
+                //  lead's decode and the probes), 0.77 ms with the ticket drawn two tasks ahead (every task held in reserve is one no idle
+                //  workgroup can take at the kernel's end), and 0.3 ms more host planning per batch for the 3 MB of records.)
+                // next query: wave 0 draws the ticket.  All 64 lanes add 1 (the compiler folds that into ONE
+                // global atomic of +64 with a uniform operand — no lane-divergent branch at the loop head), so the
+                // counter advances in units of 64 per draw.
+                if (wave == 0) {
+                        const uint32_t old = atomicAdd(ticket, 1u);
+                        sh.bcast[0] = uni(old) >> 6;
+                }
+                __syncthreads();
+                const uint32_t ticket_no = uni(sh.bcast[0]);
+                __syncthreads();
                 if (ticket_no >= ntasks)
                         break;
-                const DevCandUnit &U = sh.unit[p];
+                const uint32_t tix = sched[ticket_no];
                 TASKTIME(8 * ticket_no);
-                const uint32_t nterms = uni(U.nterms), term_base = uni(U.term_base), tix = uni(U.tix), tile_begin = uni(U.tile_begin), tile_end = uni(U.tile_end);
-                const DevTerm lead = lds_term(U.lead);
-                // (the fetching wave) the next task's ticket and record: issued now, used when this task is done
-                uint32_t nwd = 0, nt = 0xffffffffu;
-#if TRI_AND_AHEAD == 2
-                uint32_t nnt = 0xffffffffu;
-                if (fetcher) {
-                        nt = nt2;
-                        if (nt < ntasks)
-                                nwd = ((const uint32_t *)(cunits + nt))[tid & 31u];
-                        nnt = atomicAdd(ticket, 1u);
-                }
-#else
-                if (fetcher) {
-                        nt = uni(atomicAdd(ticket, 1u)) >> 6;
-                        if (nt < ntasks)
-                                nwd = ((const uint32_t *)(cunits + nt))[tid & 31u];
-                }
-#endif
-                TRACE(1, tix, nterms);
-                uint32_t *qout = out + (((uint64_t)uni((uint32_t)(U.out_off >> 32)) << 32) | uni((uint32_t)U.out_off));
+                const DevTask task = tasks[tix];
+                const uint32_t slot = task.slot;
+                const DevQuery q = plan[slot];
+                const DevTerm lead = terms[qterms[q.term_base] & QT_TERM];
+                TRACE(1, slot, q.nterms);
+                uint32_t *qout = out + task.out_off;
                 uint32_t produced = 0;
                 sh.lcur[tid & 15] = 0xffffffffu; // "not positioned yet"
-                const uint32_t tb_end = min(lead.nblocks, tile_end * TILE_BLOCKS);
-                // a term of the query: its qterms[] word and plane row (the first PSET_INLINE_TERMS ride in the record)
-                auto term_word = [&](const uint32_t k) { return k < PSET_INLINE_TERMS ? uni(U.tt[k]) : uni(qterms[term_base + k]); };
+                const uint32_t tb_end = min(lead.nblocks, task.tile_end * TILE_BLOCKS);
                 PROF_LAP(10);
 
-                for (uint32_t tb = tile_begin * TILE_BLOCKS; tb < tb_end; tb += TILE_BLOCKS) {
+                for (uint32_t tb = task.tile_begin * TILE_BLOCKS; tb < tb_end; tb += TILE_BLOCKS) {
                         const uint32_t nb = min((uint32_t)TILE_BLOCKS, lead.nblocks - tb);
                         uint32_t C = (tb + nb == lead.nblocks) ? (nb - 1) * 32 + lead.last_n : nb * 32;
                         // ---- decode the lead tile: one lane per block (unpack_block, google_codec.cpp:596-639)
@@ -1148,20 +1108,28 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                         __syncthreads();
                         PROF_LAP(11);
                         TASKTIME(8 * ticket_no + 2); // (probe builds: the last tile's stamps stay)
-                        TRACE(2, tix, tb);
+                        TRACE(2, slot, tb);
 
                         // ---- every other group filters the surviving candidates: a candidate survives a group when any
                         //      of the group's terms holds it (hit bits are OR-ed across the group's terms)
                         bool gneg = false; // the group being filtered is the excluded one (logicalnot): its hits remove
-                        for (uint32_t k = 1; k < nterms && C; ++k) {
-                                const uint32_t tt = term_word(k);
+                        for (uint32_t k = 1; k < q.nterms && C; ++k) {
+                                const uint32_t tt = qterms[q.term_base + k];
+                                const DevTerm t = terms[tt & QT_TERM];
                                 if (tt & QT_GROUP) {
                                         sh.hit[tid] = 0;
                                         gneg = tt & QT_NOT;
                                 }
                                 __syncthreads();
-                                const uint32_t prow = !qplane ? PL_NONE : k < PSET_INLINE_TERMS ? uni(U.row[k]) : uni(qplane[term_base + k]);
-                                bool bd = false;
+#if defined(TRI_FORCE_CAND)
+                                const bool bd = false;
+#elif defined(TRI_FORCE_BLOCK)
+                                const bool bd = true;
+#else
+                                const bool bd = t.nblocks <= lead.documents;
+#endif
+                                TRACE(3, slot, (k << 16) | (bd ? 1 : 0));
+                                const uint32_t prow = qplane ? qplane[q.term_base + k] : PL_NONE;
                                 if (prow != PL_NONE) {
                                         // the term has a plane (k_term_planes decoded it once for the whole batch): advance(candidate) is a bit probe
                                         const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
@@ -1170,24 +1138,14 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                                 if ((pa[doc >> 5] >> (doc & 31u)) & 1u)
                                                         atomicOr(&sh.hit[j >> 5], 1u << (j & 31u));
                                         }
-                                } else {
-                                        const DevTerm t = k == 1 ? lds_term(U.t1) : terms[tt & QT_TERM];
-#if defined(TRI_FORCE_CAND)
-                                        bd = false;
-#elif defined(TRI_FORCE_BLOCK)
-                                        bd = true;
-#else
-                                        bd = t.nblocks <= lead.documents;
-#endif
-                                        TRACE(3, tix, (k << 16) | (bd ? 1 : 0));
-                                        and_filter_tile<CODEC>(sh, index, blk_last, blk_off, win, t, C, k - 1, bd PROF_PASS);
-                                }
-                                TRACE(4, tix, C);
+                                } else
+                                and_filter_tile<CODEC>(sh, index, blk_last, blk_off, win, t, C, k - 1, bd PROF_PASS);
+                                TRACE(4, slot, C);
                                 __syncthreads();
                                 TASKTIME(8 * ticket_no + 2 + min(k, 5u));
                                 PROF_LAP(bd ? 12 : 13);
-                                const bool lastterm = k + 1 == nterms;
-                                if (!lastterm && !(term_word(k + 1) & QT_GROUP))
+                                const bool lastterm = k + 1 == q.nterms;
+                                if (!lastterm && !(qterms[q.term_base + k + 1] & QT_GROUP))
                                         continue; // more terms of this OR group to come
                                 // compact survivors (stable => still ascending)
                                 uint32_t bits = sh.hit[tid];
@@ -1241,7 +1199,7 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                 C = uni(total);
                                 __syncthreads();
                         }
-                        if (nterms == 1) {
+                        if (q.nterms == 1) {
                                 if (!masked) {
                                         for (uint32_t j = tid; j < C; j += AND_WG)
                                                 qout[produced + j] = sh.cand[phys(j)];
@@ -1279,21 +1237,10 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                         __syncthreads();
                         PROF_LAP(14);
                 }
-                if (fetcher) { // scalar branch; the wave's lanes store identical dwords
-                        counts[tix] = produced;
-                        ((uint32_t *)&sh.unit[p ^ 1u])[tid & 31u] = nwd; // the next task, read by everybody behind the barrier at the loop's head
-                        sh.tick[p ^ 1u] = nt;
-                        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the record's words are in LDS before this wave reaches the barrier (see below)
-#if TRI_AND_AHEAD == 2
-                        nt2 = uni(nnt) >> 6;
-#endif
-                }
+                if (wave == 0)
+                        counts[tix] = produced; // scalar branch; the wave's lanes store one identical dword
                 TASKTIME(8 * ticket_no + 1);
-                TRACE(5, tix, produced);
-                // the record's barrier stands HERE, in the block of the LDS stores above, not at the loop's head: there the compiler put no
-                // s_waitcnt lgkmcnt(0) between the stores (reached over the loop's back edge) and the s_barrier, and the other waves read the
-                // previous record's words (measured: 0.25 % more matches than there are, different every run; a fault at cfg5)
-                __syncthreads();
+                TRACE(5, slot, produced);
         }
         PROF_LAP(15);
         PROF_FLUSH();

@@ -108,9 +108,6 @@ struct BatchPlan {
         Span<uint32_t> pset_sched;  // ... and the order they are run in, as unit indices: [0, n_pset) TASK_PSET, docID window range by window range; then
                                     // the n_probe TASK_PROBE ones, heaviest first
         size_t off_units = 0, off_pset_sched = 0;
-        Span<DevCandUnit> cunits;   // the TASK_CAND tasks as k_and reads them, in RUN order (cunits[i]: the task at sched[n_dense + n_pset + n_probe + i]); sized for
-                                    // the TASK_PROBE tasks too (the fill pass may send them back to the candidate tiles)
-        size_t off_cunits = 0;
         Span<uint32_t> tree;        // TASK_TREE records: TREE_HDR_WORDS header words + DevTreeNode per node (DevQuery::fused_idx: the record's first word)
         Span<uint32_t> tree_terms;  // the distinct term leaves of the batch's TASK_TREE queries, ascending: term -> row of the batch's tree rows
         Span<uint32_t> tree_hidden; // hidden phrase queries: their plan slots (position: the row of the batch's phrase rows)
@@ -1603,7 +1600,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 return rc;
         P.plan_ms[1] = ms_since(t0);
         // ---- the fragments' places in the batch's arrays; sums
-        size_t n_plan = 0, n_qterms = 0, n_sterms = 0, n_phrases = 0, n_pterms = 0, n_tasks = 0, n_fused = 0, n_ptasks = 0, n_units = 0, n_treewords = 0, n_hidden = 0, n_cunits = 0;
+        size_t n_plan = 0, n_qterms = 0, n_sterms = 0, n_phrases = 0, n_pterms = 0, n_tasks = 0, n_fused = 0, n_ptasks = 0, n_units = 0, n_treewords = 0, n_hidden = 0;
         std::vector<uint32_t> tree_terms;
         uint64_t off = 0;
         std::vector<uint64_t> benefit(C.n_ok, 0);
@@ -1611,8 +1608,6 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 f.b_plan = n_plan, f.b_qterms = n_qterms, f.b_sterms = n_sterms, f.b_phrases = n_phrases, f.b_pterms = n_pterms, f.b_tasks = n_tasks, f.b_fused = n_fused,
                 f.b_ptasks = n_ptasks, f.b_off = off, f.b_units = n_units;
                 n_units += f.units.size();
-                for (const DevTask &tk : f.tasks)
-                        n_cunits += tk.kind == TASK_CAND || tk.kind == TASK_PROBE;
                 f.b_tree = n_treewords, f.b_hidden = n_hidden;
                 n_treewords += f.treepool.size(), n_hidden += f.n_hidden;
                 tree_terms.insert(tree_terms.end(), f.tree_terms.begin(), f.tree_terms.end());
@@ -1701,7 +1696,6 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         section(P.off_ptasks, n_ptasks, 4);
         section(P.off_units, n_units, sizeof(DevPsetUnit));
         section(P.off_pset_sched, n_units, 4);
-        section(P.off_cunits, n_cunits, sizeof(DevCandUnit));
         section(P.off_tree, n_treewords, 4);
         section(P.off_tree_terms, tree_terms.size(), 4);
         section(P.off_tree_hidden, n_hidden, 4);
@@ -1729,7 +1723,6 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         span(P.ptasks, P.off_ptasks, n_ptasks);
         span(P.units, P.off_units, n_units);
         span(P.pset_sched, P.off_pset_sched, n_units);
-        span(P.cunits, P.off_cunits, n_cunits);
         span(P.tree, P.off_tree, n_treewords);
         span(P.tree_terms, P.off_tree_terms, tree_terms.size());
         span(P.tree_hidden, P.off_tree_hidden, n_hidden);
@@ -1865,7 +1858,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                 }
                         *per_kernel[r] = at - before;
                 }
-                const uint32_t n_dense = P.n_dense, n_units_run = P.n_pset + P.n_probe, cand0 = n_dense + n_units_run, n_cand = P.n_cand;
+                const uint32_t n_dense = P.n_dense, n_units_run = P.n_pset + P.n_probe;
                 run([&](unsigned k) {
                         Frag &f = frags[k];
                         for (size_t i = 0; i < f.tasks.size(); ++i) {
@@ -1873,24 +1866,6 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                 P.sched[pos] = ti;
                                 if (pos >= n_dense && pos - n_dense < n_units_run) // (a TASK_PSET / TASK_PROBE task: its unit record runs at the same place)
                                         P.pset_sched[pos - n_dense] = unit_of_task[ti];
-                                else if (pos >= cand0 && pos - cand0 < n_cand) { // a TASK_CAND task: its record, at its place in the run order
-                                        const DevTask &tk = P.tasks[ti];
-                                        const DevQuery &q = P.plan[tk.slot];
-                                        DevCandUnit u{};
-                                        u.out_off = tk.out_off;
-                                        u.tile_begin = tk.tile_begin, u.tile_end = tk.tile_end;
-                                        u.tix = ti;
-                                        u.nterms = q.nterms;
-                                        u.term_base = q.term_base;
-                                        for (uint32_t j = 0; j < q.nterms && j < PSET_INLINE_TERMS; ++j) {
-                                                u.tt[j] = P.qterms[q.term_base + j];
-                                                u.row[j] = n_qplane ? P.qplane[q.term_base + j] : PL_NONE;
-                                        }
-                                        u.lead = ix.terms[u.tt[0] & QT_TERM];
-                                        if (q.nterms > 1)
-                                                u.t1 = ix.terms[u.tt[1] & QT_TERM];
-                                        P.cunits[pos - cand0] = u;
-                                }
                         }
                 });
         }

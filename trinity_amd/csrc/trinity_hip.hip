@@ -93,7 +93,7 @@ struct tri_dev {
 using DevLock = std::lock_guard<std::recursive_mutex>;
 constexpr size_t POOL_MIN_BYTES = 64u << 10;  // smaller buffers are not worth pooling
 constexpr size_t POOL_IDLE_CAP = 64ull << 30; // idle buffers beyond this are given back to the device (largest first)
-constexpr size_t PINNED_IDLE_MAX = 8;         // idle pinned blocks kept
+constexpr size_t PINNED_IDLE_MAX = 16;        // idle pinned blocks kept (the longest idle one is dropped for a newly released one)
 
 static void dev_destroy(tri_dev *d) {
         hipSetDevice(d->device);
@@ -218,9 +218,9 @@ static void pinned_free(tri_dev *dev, void *p, const size_t cap) {
                 return;
         }
         DevLock g(dev->mu);
-        if (dev->pinned_idle.size() >= PINNED_IDLE_MAX) {
-                hipHostFree(p);
-                return;
+        if (dev->pinned_idle.size() >= PINNED_IDLE_MAX) { // full: the block idle for longest goes, the one just released stays — the list follows the
+                hipHostFree(dev->pinned_idle.front().second); // caller's CURRENT batches (a list full of another workload's block sizes made every create
+                dev->pinned_idle.erase(dev->pinned_idle.begin()); // of the next one a hipHostMalloc: bench.py's cfg2 loop after its cfg5 leg, 1.2 -> 4 ms a create)
         }
         dev->pinned_idle.emplace_back(cap, p);
 }
@@ -980,7 +980,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipEventRecord(b->ev_r, dev->stream));
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
-                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, (const DevCandUnit *)(b->d_arena + b->off_cunits), b->d_qterms,
+                                           b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense + b->n_pset + b->n_probe, b->d_qterms,
                                            b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->ix->d_pcache, b->plw);
                 HIP_TRY(hipGetLastError());
                 if (overlap) {

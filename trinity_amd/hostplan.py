@@ -12,8 +12,7 @@ _SUMMARY = ["block_bytes", "n_plan", "n_qterms", "n_tasks", "n_fused_maps", "n_q
             "n_dense", "n_cand", "n_fused", "n_fused16", "n_fusedgen", "n_planes", "n_planes8", "plw", "sparse_cap", "out_capacity", "term_bytes", "term_bytes_dense",
             "dense_queries", "cand_queries", "fused_queries", "planes_queries", "unsupported_queries", "rich_R", "sizeof_query", "sizeof_task", "sizeof_fused", "sizeof_phrase",
             "cand_needed_term_bytes", "plane_decoded_bytes", "n_pset", "pset_queries", "n_probe", "probe_queries", "n_units", "off_units", "off_unit_sched", "sizeof_unit",
-            "n_tree", "tree_queries", "n_tree_words", "off_tree", "n_tree_terms", "off_tree_terms", "n_tree_hidden", "off_tree_hidden",
-            "n_cunits", "off_cunits", "sizeof_cunit", "_r0", "_r1", "_r2", "_r3", "_r4"]  # fmt: skip
+            "n_tree", "tree_queries", "n_tree_words", "off_tree", "n_tree_terms", "off_tree_terms", "n_tree_hidden", "off_tree_hidden"]  # fmt: skip
 
 DEV_QUERY = np.dtype([("nterms", "<u4"), ("term_base", "<u4"), ("out_off", "<u8"), ("out_cap", "<u4"), ("qid", "<u4"), ("first_task", "<u4"), ("ntasks", "<u4"),
                       ("score_base", "<u4"), ("nscore", "<u4"), ("phrase_base", "<u4"), ("nphrases", "<u4"), ("fused_idx", "<u4"), ("form", "<u4")])  # fmt: skip
@@ -23,10 +22,6 @@ DEV_TREE_NODE = np.dtype([("op", "u1"), ("parent", "u1"), ("ord", "u1"), ("thr",
                           ("kid0", "u1"), ("kid1", "u1"), ("pad", "u1", 2), ("kids", "<u8")])  # fmt: skip
 TREE_HDR_WORDS = 8
 DEV_UNIT = np.dtype([("out_off", "<u8"), ("begin", "<u4"), ("end", "<u4"), ("tix", "<u4"), ("nterms", "<u4"), ("term_base", "<u4"), ("first", "<u4"), ("tt", "<u4", 4), ("row", "<u4", 4)])
-DEV_TERM = np.dtype([(n, "<u4") for n in ("documents", "first_block", "nblocks", "last_n", "win_off", "flags", "npfor", "pad")])
-# the record of a TASK_CAND task as k_and reads it (dev_structs.hpp: DevCandUnit), stored in run order
-DEV_CUNIT = np.dtype([("out_off", "<u8"), ("tile_begin", "<u4"), ("tile_end", "<u4"), ("tix", "<u4"), ("nterms", "<u4"), ("term_base", "<u4"), ("pad", "<u4"), ("tt", "<u4", 4), ("row", "<u4", 4),
-                      ("lead", DEV_TERM), ("t1", DEV_TERM)])  # fmt: skip
 SCHED_ORDER = [TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, TASK_FUSED, TASK_FUSED16, TASK_FUSED_GEN, TASK_PLANES, TASK_PLANES8, TASK_TREE]
 
 
@@ -125,11 +120,6 @@ class HostPlan:
     @property
     def unit_sched(self):
         return self._view("off_unit_sched", self.s["n_pset"] + self.s["n_probe"], "<u4")
-
-    @property
-    def cunits(self):
-        """The TASK_CAND tasks' records in run order (the first n_cand of the section are filled)."""
-        return self._view("off_cunits", self.s["n_cand"], DEV_CUNIT)
 
     @property
     def qterms(self):
