@@ -821,7 +821,8 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 // c = plane C (nor 2) — a head term's from the batch's term planes, a decoded slot's from the wave's LDS planes.  Fetched when
                                 // needed (the sweep; a candidate's scoring) and not kept.  Straight-line on purpose: every load is issued — a slot without a
                                 // term plane reads row 0's words, one without LDS planes reads slot 0's, and the uniform selects drop them — so that one wait
-                                // covers them all; every address is a scalar base plus the lane's offset.
+                                // covers them all; every address is a scalar base plus the lane's offset.  (Round 4 measured the other way — words b / c loaded
+                                // only where word a has a bit: cfg3 10.5 -> 14.4 ms; the branch and the second wait cost more than the loads they save.)
                                 auto plane_words = [&](const uint32_t which, uint32_t (&ga)[NS], uint32_t (&gb)[NS], uint32_t (&gc)[NS]) { // the term planes' part: global loads
                                         const uint32_t wi = lane + which * 64u;
 #pragma unroll
