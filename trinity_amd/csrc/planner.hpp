@@ -242,7 +242,17 @@ namespace trip {
                                                         pool.push_back(k);
                                         }
                                         n.kid_n = (uint32_t)pool.size() - n.kid_off;
-                                        std::stable_sort(pool.begin() + n.kid_off, pool.end(), [&](int a, int b) { return nodes[a].cost < nodes[b].cost; });
+                                        if (n.kid_n <= 16) { // stable insertion sort (std::stable_sort takes a heap buffer per call: a malloc per AND of two terms)
+                                                int *kb = pool.data() + n.kid_off;
+                                                for (uint32_t a = 1; a < n.kid_n; ++a) {
+                                                        const int v = kb[a];
+                                                        uint32_t b = a;
+                                                        for (; b && nodes[kb[b - 1]].cost > nodes[v].cost; --b)
+                                                                kb[b] = kb[b - 1];
+                                                        kb[b] = v;
+                                                }
+                                        } else
+                                                std::stable_sort(pool.begin() + n.kid_off, pool.end(), [&](int a, int b) { return nodes[a].cost < nodes[b].cost; });
                                         n.cost = nodes[pool[n.kid_off]].cost;
                                 } else if (op == TRI_OP_OR) {
                                         for (int k : kids) {
@@ -963,7 +973,30 @@ namespace trip {
         // ---- first pass: lower the queries [q_lo, q_hi) of the batch into `f` and class them
         inline int lower_range(const Ctx &C, Frag &f) {
                 const PlanInput &in = C.in;
+                // a query's lowering reads a handful of per-term records (directory entry, list bytes, rank by document count) at term ids drawn from
+                // a vocabulary of millions: the pass is a chain of cache misses (cfg2: 280 ns per 2-term query on one thread).  The term ids stand in
+                // the program's TERM tokens, so the records of the query AHEAD queries on are requested while this one is lowered
+                constexpr size_t AHEAD = 6;
+                const size_t nterms = C.ix.terms.size();
+                auto prefetch_query = [&](const size_t q) {
+                        const tri_query &t = in.queries[q];
+                        if ((uint64_t)t.prog_off + t.prog_len > in.prog_len)
+                                return;
+                        for (uint32_t i = 0; i < t.prog_len && i < 16; ++i) {
+                                const uint32_t tok = in.prog[t.prog_off + i];
+                                const uint32_t x = tok & 0x0fffffffu;
+                                if ((tok >> 28) == TRI_OP_TERM && x < nterms) {
+                                        __builtin_prefetch(&C.ix.terms[x]);
+                                        __builtin_prefetch(&C.ix.docbytes[x]);
+                                        __builtin_prefetch(&C.ix.df_rank[x]);
+                                }
+                        }
+                };
+                for (size_t q = f.q_lo; q < std::min(f.q_hi, f.q_lo + AHEAD); ++q)
+                        prefetch_query(q);
                 for (size_t qi = f.q_lo; qi < f.q_hi; ++qi) {
+                        if (qi + AHEAD < f.q_hi)
+                                prefetch_query(qi + AHEAD);
                         const tri_query &tq = in.queries[qi];
                         if ((uint64_t)tq.prog_off + tq.prog_len > in.prog_len || !tq.prog_len)
                                 return herr(f.err, TRI_ERR_INVALID, "query %zu: program slice out of range", qi);
@@ -1547,6 +1580,18 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         for (unsigned k = 0; k < nfrag; ++k)
                                 fn(k);
         };
+        static const bool dbg_plan = getenv("TRINITY_DEBUG_PLAN") != nullptr; // (stderr: the passes and the serial stretches between them)
+        auto dbg_t0 = std::chrono::steady_clock::now();
+        std::string dbg_line;
+        auto dbg = [&](const char *what) {
+                if (!dbg_plan)
+                        return;
+                const auto now = std::chrono::steady_clock::now();
+                char buf[64];
+                snprintf(buf, sizeof buf, " %s %.3f", what, std::chrono::duration<double, std::milli>(now - dbg_t0).count());
+                dbg_line += buf;
+                dbg_t0 = now;
+        };
         auto first_error = [&]() -> int {
                 for (Frag &f : frags)
                         if (f.rc != TRI_OK) {
@@ -1555,6 +1600,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         }
                 return TRI_OK;
         };
+        dbg("setup");
         run([&](unsigned k) {
                 Frag &f = frags[k];
                 try {
@@ -1565,6 +1611,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         f.rc = herr(f.err, TRI_ERR_INVALID, "tri_batch_create: unexpected exception while lowering the batch");
                 }
         });
+        dbg("LOWER");
         if (int rc = first_error())
                 return rc;
         // ---- between the passes: what depends on the whole batch
@@ -1585,6 +1632,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 const uint64_t want_tasks = 2ull * (uint64_t)env.cus * env.fus_wgs_per_cu;
                 C.fused_task_cost = std::min<uint64_t>(8u << 20, std::max<uint64_t>(256u << 10, fused_postings / std::max<uint64_t>(1, want_tasks)));
         }
+        dbg("glue0");
         P.plan_ms[0] = ms_since(t0);
         run([&](unsigned k) {
                 Frag &f = frags[k];
@@ -1596,6 +1644,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         f.rc = herr(f.err, TRI_ERR_INVALID, "tri_batch_create: unexpected exception while cutting the batch into tasks");
                 }
         });
+        dbg("TASKS");
         if (int rc = first_error())
                 return rc;
         P.plan_ms[1] = ms_since(t0);
@@ -1700,7 +1749,9 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         section(P.off_tree_terms, tree_terms.size(), 4);
         section(P.off_tree_hidden, n_hidden, 4);
         P.block_bytes = bytes;
+        dbg("sums+planes+layout");
         P.block = alloc_block(bytes);
+        dbg("alloc_block");
         if (!P.block)
                 return herr(err, TRI_ERR_NOMEM, "tri_batch_create: no host memory for the plan (%zu bytes)", bytes);
         auto span = [&](auto &s, size_t off_, size_t n) {
@@ -1729,6 +1780,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         std::copy(tree_terms.begin(), tree_terms.end(), P.tree_terms.p);
         std::vector<uint32_t> unit_of_task(n_units ? n_tasks : 0);
         std::copy(chosen.begin(), chosen.end(), P.plane_terms.p);
+        dbg("spans");
         // ---- every fragment writes its part of the arrays, rebased
         run([&](unsigned k) {
                 Frag &f = frags[k];
@@ -1841,6 +1893,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 P.probe_queries -= f.probe_demoted, P.cand_queries += f.probe_demoted;
                 P.term_bytes_probe -= f.probe_demoted_bytes;
         }
+        dbg("FILL");
         P.plan_ms[2] = ms_since(t0);
         // ---- the schedule: per kernel, heaviest tasks first.  A counting sort by (kernel, cost octave + 2 bits) — tasks within a fifth of each
         //      other keep their order in the batch: all a longest-first dispatch needs; TASK_PSET goes by docID window range instead.  The
@@ -1894,6 +1947,9 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 std::copy(sorted.begin(), sorted.end(), P.ptasks.p);
         }
         P.sparse_cap = (P.sparse_cap + 63u) & ~63u;
+        dbg("sched+rest");
+        if (dbg_plan)
+                fprintf(stderr, "[tri plan] nq %zu frags %zu:%s\n", nq, nfrag, dbg_line.c_str());
         P.plan_ms[3] = ms_since(t0);
         if (opt.account_needed_bytes && !ix.terms.empty()) {
                 // (diagnostic: one pass over the plan with a mark per term and class)
