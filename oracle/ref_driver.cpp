@@ -16,6 +16,7 @@
 //   query <flags> <k> <text…>      -> {n, fnv, first[], last[], score_sum, top[[doc,score]…]}  exec_query()
 //   queryfull <flags> <text…>      -> as query plus full docs[] (+scores[])
 //   hits <term>                    -> {docs, fnv} every document's (doc, freq, {pos, payloadLen, payload}…) via materialize_hits
+//   merge <seed> <parts> <terms> <maxdoc> -> the input postings of <parts> small segments and the chunks IndexSession::merge writes for them
 //
 // `ref_driver edge` (instead of D V slots seed) indexes the EDGE corpus below — a few thousand hand-shaped documents over 8 terms
 // that put the codec's corner cases into reference-produced bytes: hits with payloads of changing and of constant length, a
@@ -28,7 +29,9 @@
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -585,6 +588,114 @@ int main(int argc, char **argv) {
                                         putchar(c);
                         }
                         printf("\",\"tree\":%s}\n", tree.c_str());
+                } else if (cmd == "merge") {
+                        // `merge <seed> <participants> <terms> <maxdoc>`: Codecs::Google::IndexSession::merge (google_codec.cpp:186-438) as
+                        // MergeCandidatesCollection::merge drives it (merge.cpp:254-288): small segments written by the reference's encoder, the most
+                        // recent first, then per output term begin_term / merge(participants holding documents) / end_term into a fresh session.
+                        // The line carries the INPUT postings too, so a test needs no generator of its own.  The masked registries are empty
+                        // (their scanner lives in docidupdates.cpp, which needs boost: unbuildable here) — what a non-empty one does is the
+                        // single `maskedDocsReg->test(lowestDID)` of google_codec.cpp:398, on the registry of the participant that supplies the
+                        // document
+                        uint64_t mseed;
+                        uint32_t nparts, G, maxdoc;
+                        is >> mseed >> nparts >> G >> maxdoc;
+                        uint64_t st = mseed;
+                        auto rnd = [&]() { return st = HashFilter::mix(st + 0x632be59bd9b4e019ull); };
+                        struct Part {
+                                std::unique_ptr<Codecs::Google::IndexSession> sess;
+                                std::vector<uint8_t> bytes;
+                                std::unique_ptr<Codecs::Google::AccessProxy> ap;
+                                std::vector<term_index_ctx> tctx; // per global term (documents 0: not held)
+                        };
+                        std::vector<Part> parts(nparts);
+                        std::string out = "{\"cmd\":\"merge\",\"seed\":" + std::to_string(mseed) + ",\"maxdoc\":" + std::to_string(maxdoc) + ",\"parts\":[";
+                        for (uint32_t pi = 0; pi < nparts; ++pi) {
+                                Part &P = parts[pi];
+                                P.sess.reset(new Codecs::Google::IndexSession("/tmp"));
+                                P.sess->begin();
+                                std::unique_ptr<Codecs::Encoder> penc(P.sess->new_encoder());
+                                P.tctx.assign(G, term_index_ctx{0, range32_t{0, 0}});
+                                out += pi ? ",[" : "[";
+                                bool firstTerm = true;
+                                for (uint32_t g = 0; g < G; ++g) {
+                                        if (rnd() % 10 >= 7)
+                                                continue; // the segment does not hold the term
+                                        static const uint32_t sizes[] = {1, 2, 31, 32, 33, 64, 70, 129, 300};
+                                        const uint32_t want = sizes[rnd() % 9];
+                                        std::vector<uint32_t> docs;
+                                        for (uint32_t k = 0; k < want; ++k)
+                                                docs.push_back(1 + uint32_t(rnd() % (maxdoc - 1)));
+                                        std::sort(docs.begin(), docs.end());
+                                        docs.erase(std::unique(docs.begin(), docs.end()), docs.end());
+                                        const bool payloads = g % 3 == 0;
+                                        term_index_ctx tctx;
+                                        penc->begin_term();
+                                        out += std::string(firstTerm ? "" : ",") + "{\"g\":" + std::to_string(g) + ",\"docs\":[";
+                                        firstTerm = false;
+                                        std::string hs;
+                                        for (size_t di = 0; di < docs.size(); ++di) {
+                                                out += (di ? "," : "") + std::to_string(docs[di]);
+                                                penc->begin_document(docs[di]);
+                                                const uint32_t freq = uint32_t(rnd() % 4);
+                                                std::vector<uint32_t> pos;
+                                                for (uint32_t k = 0; k < freq; ++k)
+                                                        pos.push_back(1 + uint32_t(rnd() % 2000));
+                                                std::sort(pos.begin(), pos.end());
+                                                hs += std::string(di ? "," : "") + "[";
+                                                for (uint32_t k = 0; k < freq; ++k) {
+                                                        const uint8_t plen = payloads ? uint8_t(rnd() % 9) : 0;
+                                                        uint64_t pv = plen ? rnd() : 0;
+                                                        if (plen && plen < 8)
+                                                                pv &= (1ull << (8 * plen)) - 1;
+                                                        penc->new_hit(tokenpos_t(pos[k]), {reinterpret_cast<const uint8_t *>(&pv), plen});
+                                                        hs += std::string(k ? "," : "") + "[" + std::to_string(pos[k]) + "," + std::to_string(plen) + ",\"" + std::to_string(pv) + "\"]";
+                                                }
+                                                hs += "]";
+                                                penc->end_document();
+                                        }
+                                        penc->end_term(&tctx);
+                                        P.tctx[g] = tctx;
+                                        out += "],\"hits\":[" + hs + "]}";
+                                }
+                                out += "]";
+                                P.sess->end();
+                                P.bytes.assign(P.sess->indexOut.size() + 16, 0);
+                                memcpy(P.bytes.data(), P.sess->indexOut.data(), P.sess->indexOut.size());
+                                P.ap.reset(new Codecs::Google::AccessProxy("/tmp", P.bytes.data()));
+                        }
+                        Codecs::Google::IndexSession osess("/tmp");
+                        osess.begin();
+                        std::unique_ptr<Codecs::Encoder> oenc(osess.new_encoder());
+                        out += "],\"out\":[";
+                        bool firstOut = true;
+                        for (uint32_t g = 0; g < G; ++g) {
+                                std::vector<Codecs::IndexSession::merge_participant> mp;
+                                for (uint32_t pi = 0; pi < nparts; ++pi) // participant 0 is the most recent (merge.cpp: candidates ordered by generation, latest first)
+                                        if (parts[pi].tctx[g].documents)
+                                                mp.push_back({parts[pi].ap.get(), parts[pi].tctx[g], masked_documents_registry::make(nullptr, 0).release()});
+                                if (mp.empty())
+                                        continue;
+                                term_index_ctx tctx;
+                                const size_t before = osess.indexOut.size();
+                                oenc->begin_term();
+                                osess.merge(mp.data(), uint16_t(mp.size()), oenc.get());
+                                oenc->end_term(&tctx);
+                                for (auto &m : mp)
+                                        delete m.maskedDocsReg;
+                                out += std::string(firstOut ? "" : ",") + "{\"g\":" + std::to_string(g) + ",\"participants\":" + std::to_string(mp.size()) + ",\"documents\":" + std::to_string(tctx.documents) +
+                                       ",\"offset\":" + std::to_string(tctx.indexChunk.offset) + ",\"size\":" + std::to_string(tctx.indexChunk.size()) + ",\"written_from\":" + std::to_string(before) + ",\"chunk\":\"";
+                                firstOut = false;
+                                static const char hexd[] = "0123456789abcdef";
+                                for (uint32_t k = 0; k < tctx.indexChunk.size(); ++k) {
+                                        const uint8_t b = reinterpret_cast<const uint8_t *>(osess.indexOut.data())[tctx.indexChunk.offset + k];
+                                        out += hexd[b >> 4];
+                                        out += hexd[b & 15];
+                                }
+                                out += "\"}";
+                        }
+                        osess.end();
+                        out += "],\"out_len\":" + std::to_string(osess.indexOut.size()) + "}";
+                        puts(out.c_str());
                 } else if (cmd == "filter") {
                         is >> docFilter.seed >> docFilter.permille;
                         printf("{\"cmd\":\"filter\",\"seed\":%" PRIu64 ",\"permille\":%u}\n", docFilter.seed, docFilter.permille);

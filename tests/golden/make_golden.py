@@ -359,7 +359,24 @@ def masked_fixture():
     print(path, len(out["results"]), "records", os.path.getsize(path), "bytes")
 
 
+def merge_fixture():
+    """tests/golden/ref_merge.json: Codecs::Google::IndexSession::merge (google_codec.cpp:186-438), driven per term as MergeCandidatesCollection::merge
+    does (merge.cpp:254-288: begin_term / merge(the participants that hold documents, most recent first) / end_term) over small segments written by
+    the reference's own encoder.  Each record carries the participants' INPUT postings (documents, positions, payloads) and the chunk bytes the
+    reference wrote per output term: what pins "the union of the documents, a document from the most recent participant that holds it, its hits and
+    payloads carried over, re-blocked by the encoder".  The masked registries are empty (see the `merge` command in oracle/ref_driver.cpp)."""
+    cases = [(11, 3, 36, 3000), (5, 4, 24, 700), (3, 1, 12, 500), (17, 2, 16, 120)]  # (seed, participants, terms, documentIDs below): fewer IDs -> more shared documents
+    res = O.run_ref_driver(1000, 100, 10, 42, [f"merge {a} {b} {c} {d}" for a, b, c, d in cases])
+    assert len(res) == len(cases) and all(r["out"] for r in res)
+    path = os.path.join(HERE, "ref_merge.json")
+    with open(path, "w") as f:
+        json.dump({"cases": [list(c) for c in cases], "results": res}, f, separators=(",", ":"))
+    print(path, len(res), "records", os.path.getsize(path), "bytes")
+
+
 def main():
+    if "--merge-only" in sys.argv:
+        return merge_fixture()
     if "--phrase-trees-only" in sys.argv:
         return phrase_tree_fixture()
     if "--trees-only" in sys.argv:
@@ -373,6 +390,7 @@ def main():
     random_fixture()
     phrase_tree_fixture()
     masked_fixture()
+    merge_fixture()
     for name, (D, V, slots, seed) in CORPORA.items():
         cmds = commands_for(name, D, V, slots, seed)
         res = O.run_ref_driver(D, V, slots, seed, cmds)
