@@ -32,12 +32,14 @@ distinct list the step's queries name read once + every output written once (tri
 peak — for the whole step and, under `kernels`, per kernel (HIP events on the engine's stream around each launch, inside the timed
 steps), next to `physical_frac` (committed rocprofv3 PMC traffic of the same workload / kernel time / peak) and SURVEY §8(d)'s per-query
 algorithmic bytes (`per_query_algorithmic`: a figure no kernel that shares decodes or skips reads, so it carries no fraction).
-`cpu_baseline` = the CPU oracle (restatement of the reference exec path, planning included) timed on a bounded sample of the same
-batch, which doubles as a per-query full-size parity check.
+`cpu_baseline` = a bounded sample of the same batch on the host's cores: the CPU oracle (a restatement of the reference's exec path, planning
+included; kind "port"), which doubles as a per-query full-size parity check, and — for the Google-codec workloads, where oracle/_ref/ref_driver
+is there — the GENUINE reference's exec_query over the same queries (kind "reference": that figure leads, the port's stands under `port`).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -575,7 +577,63 @@ def pmc_traffic(args, world):
     return None, None
 
 
-def cpu_baseline(segs, parts, shard_progs, batches, budget_s):
+def program_text(prog):
+    """A postfix program (include/trinity_hip.h: TRI_TOK) as the query text the reference's parser reads; None when it has no such text (matchsome's
+    threshold is not part of the text)."""
+    st = []
+    for tok in [int(x) for x in prog]:
+        op, arg = tok >> 28, tok & 0x0FFFFFFF
+        if op == 0:
+            st.append(f"t{arg}")
+            continue
+        n = 2 if op in (4, 5) else arg
+        if op == 6 or n < 1 or n > len(st):
+            return None
+        kids, st = st[len(st) - n :], st[: len(st) - n]
+        if op == 1:
+            st.append("(" + " ".join(kids) + ")")
+        elif op == 2:
+            st.append("(" + " OR ".join(kids) + ")")
+        elif op == 3:
+            st.append('"' + " ".join(kids) + '"')
+        elif op == 4:
+            st.append("(" + kids[0] + " NOT " + kids[1] + ")")
+        else:
+            st.append("(" + kids[0] + " <" + kids[1] + ">)")
+    if len(st) != 1:
+        return None
+    t = st[0]
+    return t[1:-1] if t.startswith("(") and t.endswith(")") and t.count("(") == 1 else t
+
+
+def cpu_reference(seg, pt, progs, gcounts, budget_s):
+    """The GENUINE reference on the same sample: oracle/_ref/ref_driver (the reference's own sources compiled where they lie, oracle/Makefile) indexes
+    the same synthetic corpus with the reference's encoder and runs exec_query over the queries' text, one thread, the clock around exec_query only.
+    Google codec only (the Lucene side of the reference needs a library this image lacks).  Never fails the run: an error is reported in its place."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    try:
+        if not os.path.exists(exe):
+            return {"error": "oracle/_ref/ref_driver is not built (it is built where /root/reference exists: __graft_entry__.build())"}
+        texts = [program_text(p) for p in progs]
+        if any(t is None for t in texts):
+            return {"error": "a sampled program has no query text"}
+        scored = bool(pt.flags & 2)
+        inp = f"timed {2 if scored else 1} {budget_s:.3f} {len(texts)}\n" + "\n".join(texts) + "\n"
+        t0 = time.perf_counter()
+        r = subprocess.run([exe, str(seg.D), str(seg.V), str(seg.slots), str(seg.seed)], input=inp, capture_output=True, text=True, timeout=budget_s * 4 + 240)
+        wall = time.perf_counter() - t0
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        n, secs = int(j["queries"]), float(j["seconds"])
+        same = [int(c) for c in j["counts"]] == [int(c) for c in gcounts[:n]]
+        return {"value": n / secs, "unit": "queries/s", "cores": 1, "kind": "reference",
+                "sample": f"first {n} queries of rank 0's shard ({j['matches']} matches) in {secs:.1f}s: exec_query of the reference compiled from its own sources (oracle/_ref/ref_driver, "
+                          f"`timed`), one thread, {'AccumulatedScoreScheme + BM25' if scored else 'DocumentsOnly'}; corpus + index built by the reference's encoder in {wall - secs:.1f}s (untimed)",
+                "matched_docids_per_sec": int(j["matches"]) / secs, "host_cpus": os.cpu_count(), "match_counts_equal_gpu": same}  # fmt: skip
+    except Exception as e:  # a reported baseline: the line stands without it
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def cpu_baseline(segs, parts, shard_progs, batches, budget_s, reference=True):
     """The CPU oracle (plain-C restatement of the reference's iterator path), one thread, on the first programs of every part of rank
     0's shard until the time budget is spent; a reported baseline only.  Every sampled query is also a full-size parity check:
     per-query match counts, FNV-1a of the docID set (DocumentsOnly) or the top-K docIDs (scored) must equal the GPU's.  For
@@ -586,6 +644,7 @@ def cpu_baseline(segs, parts, shard_progs, batches, budget_s):
 
     n = matches = 0
     bad = []
+    used = []  # per part: how many of its programs the port leg ran
     checked = {"counts": 0, "docset_hashes": 0, "topk_lists": 0}
     t_total = 0.0
     all_cores = None
@@ -622,6 +681,7 @@ def cpu_baseline(segs, parts, shard_progs, batches, budget_s):
             if time.perf_counter() - t0 > share and qi + 1 >= 16:
                 break
         t_total += time.perf_counter() - t0
+        used.append(qi + 1)
         if pi == 0 and not scored and all(len(p) == 3 for p in progs[:8]):
             # also one query per thread on all host cores (the reference's exec_query is re-entrant per thread,
             # exec.cpp:12).  Same oracle, same queries, drawn heaviest first from a shared cursor by C threads.
@@ -640,6 +700,15 @@ def cpu_baseline(segs, parts, shard_progs, batches, budget_s):
     if all_cores is not None:
         res["all_cores"] = all_cores
     parity = {"queries": n, "per_query": checked, "mismatches": len(bad), "first_mismatches": bad[:5], "equal": not bad}
+    if reference and len(parts) == 1 and parts[0].codec == 1:
+        # the same sample through the genuine reference (when its driver is there): that figure leads, the port's stands beside it
+        ref = cpu_reference(segs[1], parts[0], shard_progs[0][: used[0]], batches[0].counts(), budget_s)
+        if "value" in ref:
+            parity["reference_match_counts_equal"] = ref.pop("match_counts_equal_gpu")
+            ref["port"] = res
+            res = ref
+        else:
+            res["reference"] = ref
     return res, parity
 
 

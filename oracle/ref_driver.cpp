@@ -16,6 +16,7 @@
 //   query <flags> <k> <text…>      -> {n, fnv, first[], last[], score_sum, top[[doc,score]…]}  exec_query()
 //   queryfull <flags> <text…>      -> as query plus full docs[] (+scores[])
 //   hits <term>                    -> {docs, fnv} every document's (doc, freq, {pos, payloadLen, payload}…) via materialize_hits
+//   timed <flags> <budget s> <count> + <count> query lines -> {queries, matches, seconds, counts[]}: exec_query timed (bench.py's cpu_baseline of kind "reference")
 //   merge <seed> <parts> <terms> <maxdoc> -> the input postings of <parts> small segments and the chunks IndexSession::merge writes for them
 //
 // `ref_driver edge` (instead of D V slots seed) indexes the EDGE corpus below — a few thousand hand-shaped documents over 8 terms
@@ -29,6 +30,7 @@
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <algorithm>
 #include <iostream>
 #include <memory>
@@ -696,6 +698,53 @@ int main(int argc, char **argv) {
                         osess.end();
                         out += "],\"out_len\":" + std::to_string(osess.indexOut.size()) + "}";
                         puts(out.c_str());
+                } else if (cmd == "timed") {
+                        // `timed <flags> <budget seconds> <count>` + <count> lines of query text: bench.py's CPU baseline of kind "reference" — exec_query
+                        // (compile_query + the iterator / span loops, exec.cpp) over the queries in order until the budget is spent; the clock runs
+                        // around exec_query only (parsing the text stands outside, as the engine's side is handed compiled programs).  Matches go
+                        // into a vector (DocumentsOnly) or a (docID, score) pair of vectors, as an application's filter would keep them
+                        uint32_t flags, count;
+                        double budget;
+                        is >> flags >> budget >> count;
+                        std::vector<std::string> texts(count);
+                        for (auto &t : texts)
+                                std::getline(std::cin, t);
+                        struct Keep final : public MatchedIndexDocumentsFilter {
+                                std::vector<docid_t> ids;
+                                std::vector<double> scores;
+                                void consider(const docid_t id) override { ids.push_back(id); }
+                                void consider(const docid_t id, const double score) override {
+                                        ids.push_back(id);
+                                        scores.push_back(score);
+                                }
+                                void consider(const matched_document &m) override { ids.push_back(m.id); }
+                        } keep;
+                        std::vector<uint64_t> counts;
+                        uint64_t matches = 0, ns = 0;
+                        for (uint32_t i = 0; i < count; ++i) {
+                                query q{str32_t(texts[i].data(), uint32_t(texts[i].size())), default_token_parser_impl,
+                                        unsigned(ast_parser::Flags::ParseConstTrueExpr) | unsigned(ast_parser::Flags::ParseMatchSomeExpr)};
+                                std::unique_ptr<Similarity::IndexSourceTermsScorer> scorer;
+                                if (flags & unsigned(ExecFlags::AccumulatedScoreScheme)) {
+                                        collScorer->reset(&collection);
+                                        scorer.reset(collScorer->new_source_scorer(src));
+                                }
+                                keep.ids.clear();
+                                keep.scores.clear();
+                                struct timespec a, b;
+                                clock_gettime(CLOCK_MONOTONIC, &a);
+                                exec_query(q, src, noMasked.get(), &keep, nullptr, flags, scorer.get());
+                                clock_gettime(CLOCK_MONOTONIC, &b);
+                                ns += uint64_t(b.tv_sec - a.tv_sec) * 1000000000ull + uint64_t(b.tv_nsec) - uint64_t(a.tv_nsec);
+                                counts.push_back(keep.ids.size());
+                                matches += keep.ids.size();
+                                if (double(ns) * 1e-9 > budget && i + 1 >= 16)
+                                        break;
+                        }
+                        printf("{\"cmd\":\"timed\",\"flags\":%u,\"queries\":%zu,\"matches\":%" PRIu64 ",\"seconds\":%.6f,\"counts\":[", flags, counts.size(), matches, double(ns) * 1e-9);
+                        for (size_t i = 0; i < counts.size(); ++i)
+                                printf("%s%" PRIu64, i ? "," : "", counts[i]);
+                        printf("]}\n");
                 } else if (cmd == "filter") {
                         is >> docFilter.seed >> docFilter.permille;
                         printf("{\"cmd\":\"filter\",\"seed\":%" PRIu64 ",\"permille\":%u}\n", docFilter.seed, docFilter.permille);

@@ -8,6 +8,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -43,3 +45,33 @@ def test_two_ranks_default_workload_is_the_mixed_batch():
 def test_strong_scaling_splits_the_batch():
     out = run_bench(2, ["--queries", "1000", "--scaling", "strong", "--workload", "cfg2", "--scaling-ref-steps", "0"])
     assert out["scaling"] == "strong" and out["config"]["queries_per_gpu_per_step"] == 500 and out["config"]["queries_per_step"] == 1000 and "scaling_ref" not in out
+
+
+def test_reference_cpu_leg_runs_the_genuine_reference_on_the_sample():
+    """bench.py's cpu_baseline of kind "reference": the sampled programs as query text through oracle/_ref/ref_driver's `timed` command (exec_query of the
+    reference compiled from its own sources) — the match counts it reports equal the oracle's for conjunctions, unions, phrases, exclusions and
+    optional parts, unscored and scored; a program without a text (matchsome) is refused, a missing driver is an error entry, not an exception."""
+    import importlib.util
+    from types import SimpleNamespace
+
+    import numpy as np
+    import oracle_lib as O
+    import trinity_amd as T
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.program_text(O.parse_query("t1 t2")) == "t1 t2" and bench.program_text(O.parse_query("[t0, t1, t2]", some_min=2)) is None
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "ref_driver")):
+        pytest.skip("oracle/_ref/ref_driver is built only where /root/reference exists")
+    D, V = 20000, 2000
+    seg = T.Segment(D, V, 10, 42)
+    ora = O.Index.wrap(seg.index, seg.terms, seg.docs_cnt, seg.sum_terms_docs, seg.sum_term_hits)
+    texts = ["t0 t1", "t3 OR t5 OR t9", "t0 t1 (t2 OR t3 OR t4)", "t3 t5 NOT t1", '"t0 t1" t2', '"t4 t5 t6"', "t0 <t7>", "t1 NOT (t2 OR t3)", "t11 t400", "t1999 t3"]
+    progs = [O.parse_query(t) for t in texts]
+    for flags, oflag in ((1, O.FLAG_DOCUMENTS_ONLY), (2, O.FLAG_ACCUM_SCORE)):
+        want = [len(ora.exec(p, oflag)[0]) for p in progs]
+        r = bench.cpu_reference(seg, SimpleNamespace(flags=flags), progs, np.array(want), 5.0)
+        assert "error" not in r, r
+        assert r["kind"] == "reference" and r["match_counts_equal_gpu"] and r["value"] > 0 and f"first {len(progs)} queries" in r["sample"]
+    assert "error" in bench.cpu_reference(seg, SimpleNamespace(flags=1), [O.parse_query("[t0, t1, t2]", some_min=2)], np.array([0]), 1.0)
