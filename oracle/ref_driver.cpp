@@ -17,6 +17,7 @@
 //   queryfull <flags> <text…>      -> as query plus full docs[] (+scores[])
 //   hits <term>                    -> {docs, fnv} every document's (doc, freq, {pos, payloadLen, payload}…) via materialize_hits
 //   timed <flags> <budget s> <count> + <count> query lines -> {queries, matches, seconds, counts[]}: exec_query timed (bench.py's cpu_baseline of kind "reference")
+//   commit <seed> <documents> <vocab> <maxdoc> -> a SegmentIndexSession's input in insertion order and the index / term chunks its commit() wrote
 //   merge <seed> <parts> <terms> <maxdoc> -> the input postings of <parts> small segments and the chunks IndexSession::merge writes for them
 //
 // `ref_driver edge` (instead of D V slots seed) indexes the EDGE corpus below — a few thousand hand-shaped documents over 8 terms
@@ -26,6 +27,8 @@
 #include "exec.h"
 #include "compilation_ctx.h"
 #include "google_codec.h"
+#include "indexer.h"
+#include "terms.h"
 #include "trinity_oracle.h" // corpus generator + hashing only (this repo's code)
 #include <cinttypes>
 #include <cstdio>
@@ -36,6 +39,9 @@
 #include <memory>
 #include <sstream>
 #include <string>
+#include <sys/wait.h>
+#include <unistd.h>
+#include <unordered_map>
 #include <vector>
 
 using namespace Trinity;
@@ -698,6 +704,168 @@ int main(int argc, char **argv) {
                         osess.end();
                         out += "],\"out_len\":" + std::to_string(osess.indexOut.size()) + "}";
                         puts(out.c_str());
+                } else if (cmd == "commit") {
+                        // `commit <seed> <documents> <vocab> <maxdoc>`: SegmentIndexSession (indexer.cpp:14-230) fed documents in a shuffled order — every
+                        // document a few terms with their hits, some with payloads — and SegmentIndexSession::commit (indexer.cpp:311-560) into a Google
+                        // IndexSession.  The line carries the input in INSERTION order with the session's transient term ids, and what commit wrote:
+                        // the `index` bytes and, per term, its chunk.  commit ends in persist_segment -> pack_updates (docidupdates.cpp: needs boost,
+                        // unbuildable here, left unresolved at link time); by then the encoded index and the dictionary are on disk (indexer.cpp:243,
+                        // codecs.cpp:17-27), so the commit runs in a CHILD process that is allowed to die at that call and the files are read here
+                        uint64_t cseed;
+                        uint32_t ndocs, vocab, maxdoc;
+                        is >> cseed >> ndocs >> vocab >> maxdoc;
+                        uint64_t st = cseed;
+                        auto rnd = [&]() { return st = HashFilter::mix(st + 0x2545f4914f6cdd1dull); };
+                        struct Hit {
+                                uint32_t pos;
+                                uint8_t plen;
+                                uint64_t pval;
+                        };
+                        struct DocIn {
+                                uint32_t doc;
+                                std::vector<std::pair<uint32_t, std::vector<Hit>>> terms; // (vocabulary index, hits in position order)
+                        };
+                        std::vector<DocIn> docsIn;
+                        {
+                                std::vector<uint32_t> ids;
+                                while (ids.size() < ndocs) {
+                                        const uint32_t d = 1 + uint32_t(rnd() % (maxdoc - 1));
+                                        if (std::find(ids.begin(), ids.end(), d) == ids.end())
+                                                ids.push_back(d);
+                                }
+                                // insertion order: 4096-document blocks descending, ascending inside a block — not the (term, document) order commit has to
+                                // produce, and a pattern the session's document tracker takes (SparseFixedBitSet::try_set reported a fresh document as
+                                // "already committed" for a fully shuffled order)
+                                std::sort(ids.begin(), ids.end(), [](uint32_t a, uint32_t b) { return (a >> 12) != (b >> 12) ? (a >> 12) > (b >> 12) : a < b; });
+                                for (const uint32_t d : ids) {
+                                        DocIn di{d, {}};
+                                        const uint32_t nt = 1 + uint32_t(rnd() % 6);
+                                        while (di.terms.size() < nt) {
+                                                const uint64_t r = rnd();
+                                                const uint32_t w = uint32_t((r % vocab) * ((r >> 32) % vocab) / vocab); // (skewed towards the low indices)
+                                                bool dup = false;
+                                                for (const auto &t : di.terms)
+                                                        dup |= t.first == w;
+                                                if (dup)
+                                                        continue;
+                                                std::vector<Hit> hs(1 + rnd() % 3);
+                                                std::vector<uint32_t> ps;
+                                                for (size_t k = 0; k < hs.size(); ++k)
+                                                        ps.push_back(1 + uint32_t(rnd() % 3000));
+                                                std::sort(ps.begin(), ps.end());
+                                                for (size_t k = 0; k < hs.size(); ++k) {
+                                                        hs[k].pos = ps[k];
+                                                        hs[k].plen = w % 3 == 0 ? uint8_t(rnd() % 9) : 0;
+                                                        hs[k].pval = hs[k].plen ? rnd() : 0;
+                                                        if (hs[k].plen && hs[k].plen < 8)
+                                                                hs[k].pval &= (1ull << (8 * hs[k].plen)) - 1;
+                                                }
+                                                di.terms.push_back({w, std::move(hs)});
+                                        }
+                                        docsIn.push_back(std::move(di));
+                                }
+                        }
+                        char dir[] = "/tmp/trinity_ref_commit_XXXXXX";
+                        if (!mkdtemp(dir)) {
+                                printf("{\"cmd\":\"commit\",\"error\":\"mkdtemp\"}\n");
+                                continue;
+                        }
+                        fflush(stdout);
+                        int pfd[2];
+                        if (pipe(pfd)) {
+                                printf("{\"cmd\":\"commit\",\"error\":\"pipe\"}\n");
+                                continue;
+                        }
+                        const pid_t pid = fork();
+                        if (pid == 0) {
+                                close(pfd[0]);
+                                Codecs::Google::IndexSession cis(dir);
+                                SegmentIndexSession sis;
+                                std::string ids; // the session's transient id of every vocabulary index it saw, sent to the parent before commit
+                                for (const auto &di : docsIn) {
+                                        auto proxy = sis.begin(di.doc);
+                                        for (const auto &t : di.terms) {
+                                                const std::string name = "w" + std::to_string(t.first);
+                                                const uint32_t tid = sis.term_id(str8_t(name.data(), uint8_t(name.size())));
+                                                ids += std::to_string(t.first) + ":" + std::to_string(tid) + ",";
+                                                for (const auto &h : t.second)
+                                                        proxy.insert(tid, tokenpos_t(h.pos), {reinterpret_cast<const uint8_t *>(&h.pval), h.plen});
+                                        }
+                                        sis.insert(proxy);
+                                }
+                                if (write(pfd[1], ids.data(), ids.size()) != ssize_t(ids.size()))
+                                        _exit(3);
+                                close(pfd[1]);
+                                sis.commit(&cis); // (does not return: see above)
+                                _exit(0);
+                        }
+                        close(pfd[1]);
+                        std::string ids;
+                        {
+                                char buf[4096];
+                                ssize_t got;
+                                while ((got = read(pfd[0], buf, sizeof buf)) > 0)
+                                        ids.append(buf, size_t(got));
+                                close(pfd[0]);
+                        }
+                        int status = 0;
+                        waitpid(pid, &status, 0);
+                        auto slurp = [&](const char *name) {
+                                std::vector<uint8_t> v;
+                                if (FILE *f = fopen((std::string(dir) + "/" + name).c_str(), "rb")) {
+                                        uint8_t buf[65536];
+                                        size_t got;
+                                        while ((got = fread(buf, 1, sizeof buf, f)) > 0)
+                                                v.insert(v.end(), buf, buf + got);
+                                        fclose(f);
+                                }
+                                return v;
+                        };
+                        std::vector<uint8_t> cidx = slurp("index.t");
+                        if (cidx.empty())
+                                cidx = slurp("index");
+                        const std::vector<uint8_t> tdata = slurp("terms.data");
+                        std::unordered_map<uint32_t, uint32_t> idOf;
+                        for (size_t a = 0; a < ids.size();) {
+                                const size_t c = ids.find(':', a), e = ids.find(',', c);
+                                idOf[uint32_t(strtoul(ids.c_str() + a, nullptr, 10))] = uint32_t(strtoul(ids.c_str() + c + 1, nullptr, 10));
+                                a = e + 1;
+                        }
+                        static const char hexd[] = "0123456789abcdef";
+                        std::string out = "{\"cmd\":\"commit\",\"seed\":" + std::to_string(cseed) + ",\"child\":\"" +
+                                          (WIFSIGNALED(status) ? "signal " + std::to_string(WTERMSIG(status)) : "exit " + std::to_string(WEXITSTATUS(status))) + "\",\"docs\":[";
+                        for (size_t i = 0; i < docsIn.size(); ++i) {
+                                out += std::string(i ? "," : "") + "{\"d\":" + std::to_string(docsIn[i].doc) + ",\"terms\":[";
+                                for (size_t k = 0; k < docsIn[i].terms.size(); ++k) {
+                                        const auto &t = docsIn[i].terms[k];
+                                        out += std::string(k ? "," : "") + "{\"w\":" + std::to_string(t.first) + ",\"id\":" + std::to_string(idOf[t.first]) + ",\"hits\":[";
+                                        for (size_t h = 0; h < t.second.size(); ++h)
+                                                out += std::string(h ? "," : "") + "[" + std::to_string(t.second[h].pos) + "," + std::to_string(t.second[h].plen) + ",\"" + std::to_string(t.second[h].pval) + "\"]";
+                                        out += "]}";
+                                }
+                                out += "]}";
+                        }
+                        out += "],\"terms\":[";
+                        {
+                                terms_data_view view({tdata.data(), uint32_t(tdata.size())});
+                                bool first = true;
+                                for (auto it = view.begin(); it != view.end(); ++it) {
+                                        const auto cur = *it;
+                                        out += std::string(first ? "" : ",") + "{\"w\":" + std::string(cur.first.data() + 1, cur.first.size() - 1) + ",\"documents\":" + std::to_string(cur.second.documents) +
+                                               ",\"offset\":" + std::to_string(cur.second.indexChunk.offset) + ",\"size\":" + std::to_string(cur.second.indexChunk.size()) + "}";
+                                        first = false;
+                                }
+                        }
+                        out += "],\"index\":\"";
+                        for (const uint8_t b : cidx) {
+                                out += hexd[b >> 4];
+                                out += hexd[b & 15];
+                        }
+                        out += "\"}";
+                        puts(out.c_str());
+                        for (const char *f : {"index.t", "index", "terms.data", "terms.idx", "updated_documents.ids", "codec"})
+                                unlink((std::string(dir) + "/" + f).c_str());
+                        rmdir(dir);
                 } else if (cmd == "timed") {
                         // `timed <flags> <budget seconds> <count>` + <count> lines of query text: bench.py's CPU baseline of kind "reference" — exec_query
                         // (compile_query + the iterator / span loops, exec.cpp) over the queries in order until the budget is spent; the clock runs

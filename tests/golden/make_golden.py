@@ -374,7 +374,23 @@ def merge_fixture():
     print(path, len(res), "records", os.path.getsize(path), "bytes")
 
 
+def commit_fixture():
+    """tests/golden/ref_commit.json: SegmentIndexSession::commit (indexer.cpp:311-560) of the genuine reference over sessions fed out of (term, document)
+    order — the input in insertion order with the session's transient term ids, and the `index` bytes + per-term chunks commit wrote (`ref_driver commit`;
+    the commit runs in a child process that dies at the one call this image cannot link, after the files are written: see the command's comment).
+    Pins the walk tri_commit_google reproduces: buckets by termID & 31 in bucket order, (termID, documentID) inside a bucket, hits replayed."""
+    cases = [(3, 400, 60, 20000), (9, 1500, 300, 70000)]  # (seed, documents, vocabulary, documentIDs below)
+    res = O.run_ref_driver(1000, 100, 10, 42, [f"commit {a} {b} {c} {d}" for a, b, c, d in cases])
+    assert len(res) == len(cases) and all(r["terms"] and r["index"] for r in res)
+    path = os.path.join(HERE, "ref_commit.json")
+    with open(path, "w") as f:
+        json.dump({"cases": [list(c) for c in cases], "results": res}, f, separators=(",", ":"))
+    print(path, len(res), "records", os.path.getsize(path), "bytes")
+
+
 def main():
+    if "--commit-only" in sys.argv:
+        return commit_fixture()
     if "--merge-only" in sys.argv:
         return merge_fixture()
     if "--phrase-trees-only" in sys.argv:
@@ -391,6 +407,7 @@ def main():
     phrase_tree_fixture()
     masked_fixture()
     merge_fixture()
+    commit_fixture()
     for name, (D, V, slots, seed) in CORPORA.items():
         cmds = commands_for(name, D, V, slots, seed)
         res = O.run_ref_driver(D, V, slots, seed, cmds)
