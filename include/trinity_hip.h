@@ -9,8 +9,8 @@
  * Threading: one tri_dev per (host thread, device) — with ONE exception, made for a caller that keeps the engine stream fed: while one
  * thread runs, awaits, reads and destroys batches of a device (tri_batch_run / _sync / the result calls / _destroy), ONE other thread may
  * compile the next ones (tri_batch_create) on the same device; the handle's pools, the index's plane cache and everything that enqueues on
- * its streams are locked for that (the host planner — most of a create — runs outside the lock).  Everything else (uploads, options, the
- * write side, two creates at once) stays one thread at a time.  tri_last_error() is per thread.
+ * its streams are locked for that (the host planner — most of a create — runs outside that lock; creates from several threads plan one after
+ * the other).  Everything else (uploads, options, the write side) stays one thread at a time.  tri_last_error() is per thread.
  */
 #ifndef TRINITY_HIP_H
 #define TRINITY_HIP_H

@@ -87,8 +87,9 @@ struct tri_dev {
         // The batch calls of one handle may come from TWO host threads: one compiling the next batch (tri_batch_create) while the other runs,
         // awaits and releases earlier ones (tri_batch_run / _sync / _destroy) — bench.py's loop; the planner's share of a create (most of it)
         // runs outside the lock, the pools above, the index's plane cache and everything that enqueues on the streams inside it.  Every other
-        // entry point (uploads, options, encoders, two creates at once): one thread at a time, as before.
+        // entry point (uploads, options, encoders): one thread at a time, as before.
         std::recursive_mutex mu;
+        std::mutex plan_mu; // the planner's host threads take one batch at a time: creates from two threads plan one after the other
 };
 using DevLock = std::lock_guard<std::recursive_mutex>;
 constexpr size_t POOL_MIN_BYTES = 64u << 10;  // smaller buffers are not worth pooling
@@ -713,6 +714,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 std::string err;
                 int rc;
                 try {
+                        std::lock_guard<std::mutex> plan_lock(dev->plan_mu);
                         rc = plan_batch(*ix, env, in, dev->hpool.get(), [&](size_t bytes) { return pinned_alloc(dev, bytes, &b->block_cap); }, *b, err);
                 } catch (const std::bad_alloc &) {
                         return fail(TRI_ERR_NOMEM, "tri_batch_create: out of host memory");
