@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "_ref", "liboracle.so")
+LIB_PATH = os.environ.get("TRINITY_ORACLE_LIB") or os.path.join(ORACLE_DIR, "_ref", "liboracle.so")  # (the env override: the sanitizer build, tests/test_oracle_sanitized.py)
 REF_DRIVER = os.path.join(ORACLE_DIR, "_ref", "ref_driver")
 
 DOCIDS_END = 0xFFFFFFFF
@@ -431,11 +431,16 @@ def masked_docs(D, seed, permille):
     return (np.nonzero(x % np.uint64(1000) < np.uint64(permille))[0] + 1).astype(np.uint32)
 
 
+def _plain_env():
+    """The reference driver is not a sanitizer build: it runs without the preloaded runtime tests/test_oracle_sanitized.py puts in the environment."""
+    return {k: v for k, v in os.environ.items() if k != "LD_PRELOAD"}
+
+
 def run_ref_driver(D, V, slots, seed, commands):
     """Run the genuine reference (oracle/_ref/ref_driver) over the same corpus; returns parsed JSON lines."""
     import json
 
-    out = subprocess.run([REF_DRIVER, str(D), str(V), str(slots), str(seed)], input="\n".join(commands) + "\n", capture_output=True, text=True, check=True)
+    out = subprocess.run([REF_DRIVER, str(D), str(V), str(slots), str(seed)], input="\n".join(commands) + "\n", capture_output=True, text=True, check=True, env=_plain_env())
     return [json.loads(l) for l in out.stdout.splitlines() if l.strip()]
 
 
@@ -444,7 +449,7 @@ def run_ref_driver_edge(commands):
     more than 65535 hits, positions up to MaxPosition - 1, repeated positions)."""
     import json
 
-    out = subprocess.run([REF_DRIVER, "edge"], input="\n".join(commands) + "\n", capture_output=True, text=True, check=True)
+    out = subprocess.run([REF_DRIVER, "edge"], input="\n".join(commands) + "\n", capture_output=True, text=True, check=True, env=_plain_env())
     return [json.loads(l) for l in out.stdout.splitlines() if l.strip()]
 
 
