@@ -11,6 +11,7 @@ from .build import LIB_HIP, LIB_HOST
 # perf probes: an alternative build of the engine (build/libtrinity_hip_*.so: -DTRI_PROF, other launch bounds ...) for this process.
 # The harness only — the library itself reads nothing from the environment.
 LIB_HIP = os.environ.get("TRINITY_HIP_LIB") or LIB_HIP
+LIB_HOST = os.environ.get("TRINITY_HOST_LIB") or LIB_HOST  # (the host tools under ThreadSanitizer: tests/test_planner_tsan.py)
 
 OP_TERM, OP_AND, OP_OR, OP_PHRASE, OP_NOT, OP_OPT, OP_SOME = 0, 1, 2, 3, 4, 5, 6  # OP_SOME: arg = (min << 16) | children (matchsome)
 FLAG_DOCUMENTS_ONLY, FLAG_ACCUMULATED_SCORE, FLAG_MATCHED_TERMS, FLAG_HIT_PAYLOADS = 1, 2, 4, 8
