@@ -16,7 +16,7 @@
 //   query <flags> <k> <text…>      -> {n, fnv, first[], last[], score_sum, top[[doc,score]…]}  exec_query()
 //   queryfull <flags> <text…>      -> as query plus full docs[] (+scores[])
 //   hits <term>                    -> {docs, fnv} every document's (doc, freq, {pos, payloadLen, payload}…) via materialize_hits
-//   timed <flags> <budget s> <count> + <count> query lines -> {queries, matches, seconds, counts[]}: exec_query timed (bench.py's cpu_baseline of kind "reference")
+//   timed <flags> <budget s> <count> [threads] + <count> query lines -> {queries, matches, seconds, counts[]}: exec_query timed (bench.py's cpu_baseline of kind "reference")
 //   commit <seed> <documents> <vocab> <maxdoc> -> a SegmentIndexSession's input in insertion order and the index / term chunks its commit() wrote
 //   merge <seed> <parts> <terms> <maxdoc> -> the input postings of <parts> small segments and the chunks IndexSession::merge writes for them
 //
@@ -35,6 +35,8 @@
 #include <cstdlib>
 #include <ctime>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <iostream>
 #include <memory>
 #include <sstream>
@@ -912,7 +914,36 @@ int main(int argc, char **argv) {
                         printf("{\"cmd\":\"timed\",\"flags\":%u,\"queries\":%zu,\"matches\":%" PRIu64 ",\"seconds\":%.6f,\"counts\":[", flags, counts.size(), matches, double(ns) * 1e-9);
                         for (size_t i = 0; i < counts.size(); ++i)
                                 printf("%s%" PRIu64, i ? "," : "", counts[i]);
-                        printf("]}\n");
+                        printf("]");
+                        // ... and the same queries, one per thread at a time on <threads> threads (exec_query is re-entrant: one queryexec_ctx per call,
+                        // exec.cpp:12; the index source is shared and read-only), drawn from a shared cursor; wall clock around the whole pool
+                        unsigned threads = 0;
+                        is >> threads;
+                        if (threads > 1 && !(flags & unsigned(ExecFlags::AccumulatedScoreScheme))) {
+                                const size_t nrun = counts.size();
+                                std::vector<uint64_t> mtCounts(nrun, 0);
+                                std::atomic<size_t> cursor{0};
+                                struct timespec a, b;
+                                clock_gettime(CLOCK_MONOTONIC, &a);
+                                std::vector<std::thread> pool;
+                                for (unsigned t = 0; t < threads; ++t)
+                                        pool.emplace_back([&]() {
+                                                Keep mine;
+                                                for (size_t i; (i = cursor.fetch_add(1)) < nrun;) {
+                                                        query q{str32_t(texts[i].data(), uint32_t(texts[i].size())), default_token_parser_impl,
+                                                                unsigned(ast_parser::Flags::ParseConstTrueExpr) | unsigned(ast_parser::Flags::ParseMatchSomeExpr)};
+                                                        mine.ids.clear();
+                                                        exec_query(q, src, noMasked.get(), &mine, nullptr, flags, nullptr);
+                                                        mtCounts[i] = mine.ids.size();
+                                                }
+                                        });
+                                for (auto &t : pool)
+                                        t.join();
+                                clock_gettime(CLOCK_MONOTONIC, &b);
+                                const double wall = double(b.tv_sec - a.tv_sec) + double(b.tv_nsec - a.tv_nsec) * 1e-9;
+                                printf(",\"threads\":%u,\"mt_seconds\":%.6f,\"mt_counts_equal\":%s", threads, wall, mtCounts == counts ? "true" : "false");
+                        }
+                        printf("}\n");
                 } else if (cmd == "filter") {
                         is >> docFilter.seed >> docFilter.permille;
                         printf("{\"cmd\":\"filter\",\"seed\":%" PRIu64 ",\"permille\":%u}\n", docFilter.seed, docFilter.permille);
