@@ -623,7 +623,9 @@ def cpu_reference(seg, pt, progs, gcounts, budget_s):
         t0 = time.perf_counter()
         r = subprocess.run([exe, str(seg.D), str(seg.V), str(seg.slots), str(seg.seed)], input=inp, capture_output=True, text=True, timeout=budget_s * 4 + 240)
         wall = time.perf_counter() - t0
-        j = json.loads(r.stdout.strip().splitlines()[-1])
+        lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+        j = next(x for x in lines if x.get("cmd") == "timed")
+        j.update(next((x for x in lines if x.get("cmd") == "timedmt"), {}))  # (a second line: the all-cores pass, when it ran to its end)
         n, secs = int(j["queries"]), float(j["seconds"])
         same = [int(c) for c in j["counts"]] == [int(c) for c in gcounts[:n]]
         all_cores = None

@@ -914,7 +914,8 @@ int main(int argc, char **argv) {
                         printf("{\"cmd\":\"timed\",\"flags\":%u,\"queries\":%zu,\"matches\":%" PRIu64 ",\"seconds\":%.6f,\"counts\":[", flags, counts.size(), matches, double(ns) * 1e-9);
                         for (size_t i = 0; i < counts.size(); ++i)
                                 printf("%s%" PRIu64, i ? "," : "", counts[i]);
-                        printf("]");
+                        printf("]}\n");
+                        fflush(stdout); // (the single-thread figure stands whatever happens below)
                         // ... and the same queries, one per thread at a time on <threads> threads (exec_query is re-entrant: one queryexec_ctx per call,
                         // exec.cpp:12; the index source is shared and read-only), drawn from a shared cursor; wall clock around the whole pool
                         unsigned threads = 0;
@@ -941,9 +942,8 @@ int main(int argc, char **argv) {
                                         t.join();
                                 clock_gettime(CLOCK_MONOTONIC, &b);
                                 const double wall = double(b.tv_sec - a.tv_sec) + double(b.tv_nsec - a.tv_nsec) * 1e-9;
-                                printf(",\"threads\":%u,\"mt_seconds\":%.6f,\"mt_counts_equal\":%s", threads, wall, mtCounts == counts ? "true" : "false");
+                                printf("{\"cmd\":\"timedmt\",\"queries\":%zu,\"threads\":%u,\"mt_seconds\":%.6f,\"mt_counts_equal\":%s}\n", nrun, threads, wall, mtCounts == counts ? "true" : "false");
                         }
-                        printf("}\n");
                 } else if (cmd == "filter") {
                         is >> docFilter.seed >> docFilter.permille;
                         printf("{\"cmd\":\"filter\",\"seed\":%" PRIu64 ",\"permille\":%u}\n", docFilter.seed, docFilter.permille);
