@@ -188,3 +188,23 @@ def test_plane_set_tasks_name_a_row_for_every_term(world):
         q = plan[sidx]
         assert np.any(p.qplane[q["term_base"] : q["term_base"] + q["nterms"]] == 0xFFFFFFFF)
     p.close()
+
+
+def test_recycled_fragments_plan_the_same(world):
+    """tri_dev keeps the planner's per-fragment arrays from plan to plan (planner.hpp: Frag::recycle, FragCache).  A plan made on buffers that earlier plans
+    of OTHER shapes left behind — another workload, the other codec, another thread count — is byte for byte the plan made on fresh ones, with the same
+    counters."""
+    D, V, segs, hix = world
+    order = [("cfg3", 2), ("cfg2", 1), ("cfg5", 1), ("cfg5", 2), ("cfg4", 1), ("cfg2", 1), ("cfg3", 2)]
+    for wl, codec in order:
+        parts, _ = W.build_parts(wl, D, V, 10, 42, 3000 if wl != "cfg4" else 700)
+        for pt in parts:
+            if pt.codec != codec:
+                continue
+            for threads in (8, 1):
+                fresh = HP.HostPlan(hix[codec], pt.programs, pt.flags, pt.topk, threads=threads)
+                reused = HP.HostPlan(hix[codec], pt.programs, pt.flags, pt.topk, threads=threads, options={"frag_cache": 1})
+                assert bytes(fresh.block) == bytes(reused.block), (wl, codec, threads)
+                assert dict(fresh.s) == dict(reused.s), (wl, codec, threads)
+                fresh.close()
+                reused.close()

@@ -24,7 +24,7 @@ for codec in (1, 2):
             if pt.codec != codec:
                 continue
             for rep in range(3):
-                p = HP.HostPlan(hi, pt.programs, pt.flags, pt.topk, threads=8)
+                p = HP.HostPlan(hi, pt.programs, pt.flags, pt.topk, threads=8, options={"frag_cache": rep & 1})  # (every other plan on recycled fragments)
                 assert p.s["n_tasks"] > 0
                 p.close()
 print("planned ok")

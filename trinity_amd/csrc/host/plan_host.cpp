@@ -8,6 +8,7 @@
 
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 
 namespace {
         struct HostPlan {
@@ -45,8 +46,13 @@ void *tri_host_plan(void *hindex, const uint32_t *prog, uint64_t prog_len, const
         const HostIndex &H = *static_cast<HostIndex *>(hindex);
         PlanEnv env;
         env.cus = cus ? cus : 256;
+        bool use_frag_cache = false; // option "frag_cache" = 1 (this harness only): the fragments' buffers of earlier calls are reused, as tri_dev does
         for (unsigned i = 0; i < nopt; ++i) {
                 const std::string n = opt_names[i];
+                if (n == "frag_cache") {
+                        use_frag_cache = opt_values[i] != 0;
+                        continue;
+                }
                 tri_options &o = env.opt;
                 uint64_t *slot = n == "dense_min_postings" ? &o.dense_min_postings : n == "dense_task_cost" ? &o.dense_task_cost : n == "fused" ? &o.fused
                                  : n == "fused_task_cost" ? &o.fused_task_cost : n == "fused_freq_cap" ? &o.fused_freq_cap : n == "fused_halfwords" ? &o.fused_halfwords
@@ -72,6 +78,11 @@ void *tri_host_plan(void *hindex, const uint32_t *prog, uint64_t prog_len, const
         if (threads > 1)
                 pool = std::make_unique<HostPool>(threads);
         std::string e;
+        static trip::FragCache g_frag_cache;
+        static std::mutex g_frag_mu;
+        std::unique_lock<std::mutex> frag_lock(g_frag_mu, std::defer_lock);
+        if (use_frag_cache)
+                frag_lock.lock();
         const int rc = plan_batch(
                 H, env, in, pool.get(),
                 [&](size_t bytes) {
@@ -80,7 +91,7 @@ void *tri_host_plan(void *hindex, const uint32_t *prog, uint64_t prog_len, const
                                 memset(hp->block, 0, bytes);
                         return hp->block;
                 },
-                hp->P, e);
+                hp->P, e, use_frag_cache ? &g_frag_cache : nullptr);
         if (rc != TRI_OK) {
                 put_err(err, errcap, e);
                 return nullptr;

@@ -493,6 +493,32 @@ namespace trip {
                 uint64_t b_off = 0;
                 int rc = TRI_OK;
                 std::string err;
+                // A fragment of an earlier plan as a fresh one that keeps its buffers: every field takes its default, the vectors named below come back
+                // EMPTY with their capacity (a vector not named here is simply allocated anew — never stale).  A caller that compiles a batch per step
+                // otherwise mallocs, grows by doubling and page-faults about 10 MB of fragment arrays per plan (cfg2, one thread: 8.0 -> 6.4 ms of
+                // planning with the memory recycled)
+                void recycle() {
+                        Frag fresh;
+                        auto keep = [](auto &dst, auto &src) {
+                                src.clear();
+                                dst = std::move(src);
+                        };
+                        keep(fresh.S.nodes, S.nodes), keep(fresh.S.kidpool, S.kidpool), keep(fresh.S.st, S.st), keep(fresh.S.tmpk, S.tmpk), keep(fresh.S.cs, S.cs);
+                        keep(fresh.S.gt, S.gt), keep(fresh.S.gs, S.gs), keep(fresh.S.gorder, S.gorder), keep(fresh.S.leaves, S.leaves), keep(fresh.S.leaf_tok, S.leaf_tok);
+                        keep(fresh.S.negs, S.negs), keep(fresh.S.opts, S.opts), keep(fresh.S.opt_tok, S.opt_tok), keep(fresh.S.ts, S.ts), keep(fresh.S.ts_tok, S.ts_tok);
+                        keep(fresh.S.u, S.u), keep(fresh.S.uniq, S.uniq), keep(fresh.S.rt, S.rt), keep(fresh.S.seen, S.seen), keep(fresh.S.phterms, S.phterms);
+                        keep(fresh.S.slots, S.slots), keep(fresh.S.qphrases, S.qphrases), keep(fresh.S.sc, S.sc);
+                        keep(fresh.tmp, tmp), keep(fresh.qterms, qterms), keep(fresh.pterms, pterms), keep(fresh.sterms, sterms), keep(fresh.sweights, sweights);
+                        keep(fresh.phrases, phrases), keep(fresh.fz, fz), keep(fresh.left_out, left_out), keep(fresh.tasks, tasks), keep(fresh.tcost, tcost);
+                        keep(fresh.fused, fused), keep(fresh.ptasks, ptasks), keep(fresh.units, units), keep(fresh.quses, quses), keep(fresh.suses, suses);
+                        keep(fresh.fuses, fuses), keep(fresh.benefit, benefit), keep(fresh.keys, keys), keep(fresh.hist, hist), keep(fresh.treepool, treepool);
+                        keep(fresh.tree_terms, tree_terms);
+                        *this = std::move(fresh);
+                }
+        };
+        // the fragments of a caller's earlier plans (tri_dev keeps one; plan_batch takes what it needs out of it and puts it back)
+        struct FragCache {
+                std::vector<Frag> frags;
         };
 
         struct Ctx {
@@ -992,11 +1018,28 @@ namespace trip {
                                 }
                         }
                 };
+                // ... and, half as far ahead, what hangs off those records: the directory entry of the list's last block (the query's docID range)
+                auto prefetch_tails = [&](const size_t q) {
+                        const tri_query &t = in.queries[q];
+                        if ((uint64_t)t.prog_off + t.prog_len > in.prog_len)
+                                return;
+                        for (uint32_t i = 0; i < t.prog_len && i < 16; ++i) {
+                                const uint32_t tok = in.prog[t.prog_off + i];
+                                const uint32_t x = tok & 0x0fffffffu;
+                                if ((tok >> 28) == TRI_OP_TERM && x < nterms) {
+                                        const DevTerm &tk = C.ix.terms[x];
+                                        if (tk.nblocks)
+                                                __builtin_prefetch(&C.ix.blk_last[tk.first_block + tk.nblocks - 1]);
+                                }
+                        }
+                };
                 for (size_t q = f.q_lo; q < std::min(f.q_hi, f.q_lo + AHEAD); ++q)
                         prefetch_query(q);
                 for (size_t qi = f.q_lo; qi < f.q_hi; ++qi) {
                         if (qi + AHEAD < f.q_hi)
                                 prefetch_query(qi + AHEAD);
+                        if (qi + AHEAD / 2 < f.q_hi)
+                                prefetch_tails(qi + AHEAD / 2);
                         const tri_query &tq = in.queries[qi];
                         if ((uint64_t)tq.prog_off + tq.prog_len > in.prog_len || !tq.prog_len)
                                 return herr(f.err, TRI_ERR_INVALID, "query %zu: program slice out of range", qi);
@@ -1259,6 +1302,15 @@ namespace trip {
                 f.benefit.assign(C.n_ok, 0);
                 uint64_t off = 0;
                 for (size_t ti = 0; ti < f.tmp.size(); ++ti) {
+                        if (ti + 6 < f.tmp.size()) { // (the per-term records of the query six queries on: see lower_range)
+                                const Tmp &a = f.tmp[ti + 6];
+                                for (uint32_t k = 0; k < a.q.nterms && k < 8 && !a.tree; ++k) {
+                                        const uint32_t x = f.qterms[a.q.term_base + k] & QT_TERM;
+                                        __builtin_prefetch(&ix.terms[x]);
+                                        __builtin_prefetch(&ix.docbytes[x]);
+                                        __builtin_prefetch(&ix.df_rank[x]);
+                                }
+                        }
                         Tmp &t = f.tmp[ti];
                         const uint32_t slot = (uint32_t)ti;
                         if (t.tree) { // one task: its chunks of the docID space are the kernels' grid, its region the bound of the tree's matches
@@ -1545,7 +1597,7 @@ namespace trip {
 // it; it must stay valid as long as the plan is used, and is 64-byte aligned); `pool` may be null (everything on the calling thread).
 // Returns TRI_OK, or an error code with its text in `err` (a query shape the planner does not lower is NOT an error: BatchPlan::qstatus).
 inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &in, HostPool *pool, const std::function<uint8_t *(size_t)> &alloc_block,
-                      BatchPlan &P, std::string &err) {
+                      BatchPlan &P, std::string &err, trip::FragCache *frag_cache = nullptr) {
         using namespace trip;
         auto t0 = std::chrono::steady_clock::now();
         const uint32_t mode = in.flags & (TRI_FLAG_DOCUMENTS_ONLY | TRI_FLAG_ACCUMULATED_SCORE | TRI_FLAG_MATCHED_TERMS);
@@ -1569,7 +1621,23 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         const unsigned nthreads = pool ? std::min<unsigned>(pool->size(), (unsigned)std::max<size_t>(1, nq / 512)) : 1u;
         const size_t nfrag = nthreads <= 1 ? 1 : std::min<size_t>(2 * nthreads, std::max<size_t>(1, nq / 256));
         std::vector<Frag> frags(nfrag);
+        struct GiveBack { // (every way out of this function hands the fragments' buffers back to the caller's cache)
+                std::vector<Frag> &frags;
+                trip::FragCache *cache;
+                ~GiveBack() {
+                        if (!cache)
+                                return;
+                        if (cache->frags.size() < frags.size())
+                                cache->frags.resize(frags.size());
+                        for (size_t k = 0; k < frags.size(); ++k)
+                                cache->frags[k] = std::move(frags[k]);
+                }
+        } give_back{frags, frag_cache};
         for (size_t k = 0; k < nfrag; ++k) {
+                if (frag_cache && k < frag_cache->frags.size()) {
+                        frags[k] = std::move(frag_cache->frags[k]);
+                        frags[k].recycle();
+                }
                 frags[k].q_lo = nq * k / nfrag;
                 frags[k].q_hi = nq * (k + 1) / nfrag;
         }

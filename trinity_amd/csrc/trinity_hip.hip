@@ -90,6 +90,7 @@ struct tri_dev {
         // entry point (uploads, options, encoders): one thread at a time, as before.
         std::recursive_mutex mu;
         std::mutex plan_mu; // the planner's host threads take one batch at a time: creates from two threads plan one after the other
+        trip::FragCache frag_cache; // the planner's per-fragment arrays, recycled from plan to plan (under plan_mu)
 };
 using DevLock = std::lock_guard<std::recursive_mutex>;
 constexpr size_t POOL_MIN_BYTES = 64u << 10;  // smaller buffers are not worth pooling
@@ -715,7 +716,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 int rc;
                 try {
                         std::lock_guard<std::mutex> plan_lock(dev->plan_mu);
-                        rc = plan_batch(*ix, env, in, dev->hpool.get(), [&](size_t bytes) { return pinned_alloc(dev, bytes, &b->block_cap); }, *b, err);
+                        rc = plan_batch(*ix, env, in, dev->hpool.get(), [&](size_t bytes) { return pinned_alloc(dev, bytes, &b->block_cap); }, *b, err, &dev->frag_cache);
                 } catch (const std::bad_alloc &) {
                         return fail(TRI_ERR_NOMEM, "tri_batch_create: out of host memory");
                 }
