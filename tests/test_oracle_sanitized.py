@@ -27,3 +27,22 @@ def test_oracle_suites_pass_under_asan_and_ubsan():
     assert r.returncode == 0, tail
     assert "AddressSanitizer" not in tail and "runtime error:" not in r.stdout + r.stderr, tail
     assert " passed" in r.stdout and "liboracle_asan.so" in env["TRINITY_ORACLE_LIB"]
+
+
+@pytest.mark.skipif(_runtime("libasan.so") is None or _runtime("libubsan.so") is None, reason="gcc's sanitizer runtimes not found")
+def test_host_tools_pass_under_asan_and_ubsan(tmp_path):
+    """libtrinity_host.so's sources — the host planner (the code tri_batch_create runs, csrc/planner.hpp, fragments recycled or fresh), the byte-exact
+    encoders of both codecs, the Lucene encoder's units (the device kernels' bodies, lucene_enc_units.hpp / pfor128_group.hpp), the FastPFor restatement
+    and the transcoder, the corpus generator — built with ASan + UBSan and run through their CPU suites."""
+    from trinity_amd.build import HOST_SRCS
+
+    lib = str(tmp_path / "libtrinity_host_asan.so")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                    "-o", lib] + HOST_SRCS, check=True)  # fmt: skip
+    env = dict(os.environ)
+    env.update(LD_PRELOAD=f"{_runtime('libasan.so')} {_runtime('libubsan.so')}", ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1", TRINITY_HOST_LIB=lib)
+    suites = [os.path.join(ROOT, "tests", f) for f in ("test_planner.py", "test_fastpfor.py", "test_golden_merge.py")]
+    r = subprocess.run([sys.executable, "-m", "pytest"] + suites + ["-x", "-q", "-s", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
+    tail = r.stdout[-2500:] + r.stderr[-2500:]
+    assert r.returncode == 0 and " passed" in r.stdout, tail
+    assert "AddressSanitizer" not in r.stdout + r.stderr and "runtime error:" not in r.stdout + r.stderr, tail

@@ -149,8 +149,10 @@ int tri_host_lucene_encode(const uint32_t *docs, const uint32_t *freqs, const ui
         *ilen = sess.indexOut.size(), *hlen = sess.positionsOut.size();
         if (*ilen > icap || *hlen > hcap)
                 return -1;
-        memcpy(index_out, sess.indexOut.data(), *ilen);
-        memcpy(hits_out, sess.positionsOut.data(), *hlen);
+        if (*ilen)
+                memcpy(index_out, sess.indexOut.data(), *ilen);
+        if (*hlen) // (a session without hits has no buffer to copy from)
+                memcpy(hits_out, sess.positionsOut.data(), *hlen);
         return 0;
 }
 int tri_host_lucene_encode_units(const uint32_t *docs, const uint32_t *freqs, const uint16_t *pos, const uint64_t *term_first, uint64_t nterms, uint8_t *index_out, uint64_t icap,
