@@ -208,3 +208,48 @@ def test_recycled_fragments_plan_the_same(world):
                 assert dict(fresh.s) == dict(reused.s), (wl, codec, threads)
                 fresh.close()
                 reused.close()
+
+
+def test_random_token_streams_are_planned_or_refused(world):
+    """The planner is the C-ABI's front door: any sequence of tokens — operands missing, counts of zero, term ids past the dictionary, thresholds above the
+    operand count, phrases of operators — is either lowered into a plan that satisfies every invariant or refused with TRI_ERR_INVALID; it never crashes
+    (this test also runs under ASan + UBSan: tests/test_oracle_sanitized.py).  Well-formed random trees among them must come out as plans."""
+    D, V, segs, hix = world
+    rng = np.random.default_rng(99)
+
+    def random_program(wellformed):
+        if wellformed:  # a random postfix tree over a few terms
+            st, out = 0, []
+            for _ in range(int(rng.integers(1, 14))):
+                if st >= 2 and rng.random() < 0.45:
+                    op = int(rng.choice([T.OP_AND, T.OP_OR, T.OP_NOT, T.OP_OPT, T.OP_SOME]))
+                    n = 2 if op in (T.OP_NOT, T.OP_OPT) else int(rng.integers(2, st + 1))
+                    out.append(T.tok(op, n | ((int(rng.integers(1, n + 1)) << 16) if op == T.OP_SOME else 0)))
+                    st -= n - 1
+                else:
+                    out.append(T.tok(T.OP_TERM, int(rng.integers(0, 40))))
+                    st += 1
+            if st > 1:
+                out.append(T.tok(T.OP_AND, st))
+            return np.array(out, dtype=np.uint32)
+        n = int(rng.integers(1, 12))
+        ops = rng.integers(0, 8, size=n)  # (7: not an operator at all)
+        args = np.where(rng.random(n) < 0.7, rng.integers(0, 6, size=n), rng.integers(0, 1 << 28, size=n))
+        return ((ops.astype(np.uint32) << 28) | args.astype(np.uint32)).astype(np.uint32)
+
+    planned = refused = 0
+    for flags, topk in ((T.FLAG_DOCUMENTS_ONLY, 0), (T.FLAG_ACCUMULATED_SCORE, 10), (T.FLAG_MATCHED_TERMS, 0)):
+        for round_ in range(60):
+            wellformed = round_ % 3 == 0
+            progs = [random_program(wellformed) for _ in range(int(rng.integers(1, 40)))]
+            try:
+                p = HP.HostPlan(hix[1 + (round_ & 1)], progs, flags, topk, threads=1 + 3 * (round_ & 1))
+            except T.TrinityError as e:
+                assert not wellformed, (progs, str(e))
+                refused += 1
+                continue
+            if p.s["n_plan"]:
+                check_plan(p, len(progs))
+            p.close()
+            planned += 1
+    assert planned >= 60 and refused >= 30
