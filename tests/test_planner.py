@@ -253,3 +253,43 @@ def test_random_token_streams_are_planned_or_refused(world):
             p.close()
             planned += 1
     assert planned >= 60 and refused >= 30
+
+
+@pytest.mark.parametrize("codec", [T.engine.CODEC_GOOGLE, T.engine.CODEC_LUCENE])
+def test_corrupted_segments_are_walked_or_refused(codec):
+    """The upload walk (csrc/index_host.hpp: build_host_index — what tri_index_upload runs over the caller's bytes before anything reaches the device): a
+    segment with flipped bytes, a truncated tail, or term-table entries that point elsewhere is either walked to a directory or refused with a message; it
+    never reads outside the buffers it was given (the same test runs under ASan + UBSan)."""
+    seg = T.Segment(6000, 300, 8, 5, codec=codec)
+    index0, terms0 = np.array(seg.index, dtype=np.uint8), np.array(seg.terms, dtype=np.uint32).reshape(-1, 3)
+    hits0 = np.array(seg.hits, dtype=np.uint8) if codec == T.engine.CODEC_LUCENE else None
+    HP.HostIndex(index0, terms0, seg.docs_cnt, codec=codec, hits=hits0).close()  # (the untouched segment is accepted)
+    rng = np.random.default_rng(17 + codec)
+    walked = refused = 0
+    for trial in range(250):
+        index, terms = index0.copy(), terms0.copy()
+        hits = None if hits0 is None else hits0.copy()
+        kind = trial % 5
+        if kind == 0:  # random bytes overwritten
+            at = rng.integers(0, index.size, size=int(rng.integers(1, 9)))
+            index[at] = rng.integers(0, 256, size=at.size)
+        elif kind == 1:  # the tail cut off
+            index = index[: int(rng.integers(0, index.size))].copy()
+        elif kind == 2:  # a term's chunk moved / resized / its document count changed
+            t = int(rng.integers(0, terms.shape[0]))
+            terms[t, int(rng.integers(0, 3))] = int(rng.integers(0, 1 << 32, dtype=np.uint64))
+        elif kind == 3:  # runs of 0xff / 0x00 (long varints, zero lengths)
+            a = int(rng.integers(0, index.size - 64))
+            index[a : a + int(rng.integers(1, 64))] = 0xFF if trial & 8 else 0
+        elif hits is not None and hits.size:  # the hits file damaged
+            at = rng.integers(0, hits.size, size=int(rng.integers(1, 9)))
+            hits[at] = rng.integers(0, 256, size=at.size)
+        else:
+            terms[:, 1] = np.roll(terms[:, 1], 1)
+        try:
+            HP.HostIndex(index, terms, seg.docs_cnt, codec=codec, hits=hits).close()
+            walked += 1
+        except T.TrinityError as e:
+            assert str(e)
+            refused += 1
+    assert refused >= 60 and walked + refused == 250
