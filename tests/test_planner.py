@@ -293,3 +293,34 @@ def test_corrupted_segments_are_walked_or_refused(codec):
             assert str(e)
             refused += 1
     assert refused >= 60 and walked + refused == 250
+
+
+def test_upload_walk_takes_the_reference_written_segment_and_refuses_wandering_deltas():
+    """The walk reads every interior delta: the reference-written edge segment (payloads, frequency 0, a 70000-hit document, positions up to MaxPosition - 1)
+    is accepted as before; the same bytes with ONE interior delta of a full block enlarged — the block's documents now run past the block's last
+    document, which the kernels' bitmaps rely on — are refused."""
+    from test_oracle import load_edge
+
+    g, index, terms = load_edge()
+    index = np.frombuffer(bytes(index), dtype=np.uint8).copy()
+    terms = np.array(terms, dtype=np.uint32).reshape(-1, 3)
+    HP.HostIndex(index, terms, g["docsCnt"]).close()
+    # a plain synthetic segment: the first block of the longest list is [skiplist count u16][delta varint][length varint][n = 32][31 one-byte deltas ...]
+    seg = T.Segment(20000, 500, 8, 3)
+    idx, tt = np.array(seg.index, dtype=np.uint8), np.array(seg.terms, dtype=np.uint32).reshape(-1, 3)
+    t = int(np.argmax(tt[:, 0]))
+    base = int(tt[t, 1]) + 2
+    p = base
+    for _ in range(2):  # the block header's two prefix varints
+        b0 = int(idx[p])
+        p += 1 if b0 < 0x80 else 2 if b0 < 0xC0 else 3 if b0 < 0xE0 else 4 if b0 < 0xF0 else 5
+    assert idx[p] == 32 and np.all(idx[p + 1 : p + 32] < 0x80)  # (a head term: a full block of one-byte deltas)
+    bad = idx.copy()
+    bad[p + 5] = 0x7F  # one document pushed far beyond the block's last
+    with pytest.raises(T.TrinityError, match="run past its last document"):
+        HP.HostIndex(bad, tt, seg.docs_cnt)
+    bad = idx.copy()
+    bad[p + 5] = 0  # ... or repeated
+    with pytest.raises(T.TrinityError, match="repeats inside a block"):
+        HP.HostIndex(bad, tt, seg.docs_cnt)
+    HP.HostIndex(idx, tt, seg.docs_cnt).close()

@@ -529,13 +529,21 @@ inline int build_host_index(const uint8_t *index, size_t len, const uint8_t *hit
                                 return herr(err, TRI_ERR_FORMAT, "term %zu: bad block header (n=%u, delta=%u, len=%u)", ti, n, delta, blockLength);
                         lastDoc += delta;
                         const uint8_t *s = p, *const bend = p + blockLength;
+                        // the interior deltas are READ, not only stepped over: every kernel places a block's documents inside (previous block's last, this
+                        // block's last] — window bitmaps, plane rows sized by the segment's last documentID — and a chunk whose deltas say otherwise (a
+                        // damaged file) must end here, not in a store outside a bitmap
+                        uint64_t span = 0;
                         for (uint32_t i = 0; i + 1 < n; ++i) {
-                                if (s >= bend)
+                                if (s >= bend || s + h_vb_len(*s) > bend)
                                         return herr(err, TRI_ERR_FORMAT, "term %zu: deltas overrun the block", ti);
-                                s += h_vb_len(*s);
+                                uint32_t dv;
+                                s += h_vb_get(s, dv);
+                                if (!dv)
+                                        return herr(err, TRI_ERR_FORMAT, "term %zu: a document repeats inside a block (delta 0)", ti);
+                                span += dv;
                         }
-                        if (s > bend)
-                                return herr(err, TRI_ERR_FORMAT, "term %zu: deltas overrun the block", ti);
+                        if (span >= delta)
+                                return herr(err, TRI_ERR_FORMAT, "term %zu: a block's documents run past its last document (%llu >= %u)", ti, (unsigned long long)span, delta);
                         if (dstream.size() + 256 > 0xffffffffull)
                                 return herr(err, TRI_ERR_UNSUPPORTED, "delta stream exceeds 4 GiB");
                         dstream.push_back((uint8_t)n);
