@@ -131,3 +131,15 @@ def test_workload_generators_on_cpu(T):
         if name == "cfg4":
             # even rows of each half are document-sampled: at least those must match
             assert hits >= 30
+
+
+def test_write_side_mirror_compiles_and_links(T, tmp_path):
+    """trinity_gpu_write.hpp — SegmentIndexSession (begin / insert / commit) and the dictionary-wide merge over tri_commit_* / tri_merge_google — and the
+    application-shaped driver tests/cpp/host_mirror_write_test.cpp build warning-free and link against the engine (the driver needs a device to run)."""
+    from trinity_amd.build import PKG, ROOT
+
+    exe = str(tmp_path / "host_mirror_write_test")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "host_mirror_write_test.cpp"), "-L" + PKG, "-ltrinity_hip",
+                        "-Wl,-rpath," + PKG], capture_output=True, text=True)  # fmt: skip
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "libtrinity_hip.so" in subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
