@@ -105,7 +105,7 @@ uint32_t to_fastpfor_encode128(const uint32_t *v, uint32_t *out) {
 
 /* 1: decoded; 0: not a FastPFor<4> stream of one 128-value block */
 int to_fastpfor_decode128(const uint32_t *w, uint32_t L, uint32_t *v) {
-        if (L < 5 || w[0] != 128 || w[1] < 1 || (w[1] - 1) % 4 || w[1] + 3 > L)
+        if (L < 5 || w[0] != 128 || w[1] < 1 || w[1] > L || (w[1] - 1) % 4 || (uint64_t)w[1] + 3 > L) /* (64-bit: no wrap) */
                 return 0;
         const unsigned b = (w[1] - 1) / 4;
         if (b > 32)
@@ -115,7 +115,7 @@ int to_fastpfor_decode128(const uint32_t *w, uint32_t L, uint32_t *v) {
                 v[i] = get_bits(w + 2, &bit, b);
         const uint32_t *p = w + 1 + w[1];
         const uint32_t nb = *p++;
-        if (nb < 2 || (uint32_t)(p - w) + (nb + 3) / 4 + 1 > L)
+        if (nb < 2 || nb > 4u * L || (uint64_t)(p - w) + (nb + 3) / 4 + 1 > L)
                 return 0;
         const uint8_t *bytes = (const uint8_t *)p;
         p += (nb + 3) / 4;

@@ -103,6 +103,18 @@ def test_product_and_oracle_restatements_agree():
     assert n == 600
 
 
+
+def test_a_value_count_near_2_32_is_refused_not_followed():
+    """w[1] = 0xfffffffd passed `(n - 1) % 4 == 0` and `1 + n + 2 > L` wrapped to 0 in 32 bits: the decoder then
+    read 16 GB past the group.  Both restatements must refuse such a group (TRI_ERR_FORMAT at upload), not crash."""
+    for n in (0xFFFFFFFD, 0xFFFFFFF9, 0x7FFFFFFD, 125):
+        w = np.array([128, n, 0, 0, 0, 0, 0, 0], dtype=np.uint32)
+        assert dec_product(w) is None
+        assert dec_oracle(w) is None
+    # a byte count of the exception header that does not fit the group
+    w = np.array([128, 1, 0xFFFFFFFE, 0, 0, 0, 0, 0], dtype=np.uint32)
+    assert dec_product(w) is None and dec_oracle(w) is None
+
 def _facts(h, nterms):
     L = host_lib()
     L.tri_host_index_facts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]

@@ -128,13 +128,13 @@ namespace trif {
                 if (L < 5 || w[0] != N)
                         return false;
                 const uint32_t n = w[1];
-                if (n < 1 || (n - 1) % 4 || 1 + n + 2 > L)
+                if (n < 1 || n > L || (n - 1) % 4 || (uint64_t)n + 3 > L) // (64-bit: n near 2^32 must not wrap past the check)
                         return false;
                 const uint32_t bpacked = (n - 1) / 4;
                 const uint32_t *meta = w + 1 + n;
                 const uint32_t bcsize = meta[0];
                 const uint32_t bcwords = (bcsize + 3) / 4;
-                if (bcsize < 2 || 1 + n + 1 + bcwords + 1 > L)
+                if (bcsize < 2 || bcsize > 4u * L || (uint64_t)n + 3 + bcwords > L)
                         return false;
                 const uint8_t *bc = reinterpret_cast<const uint8_t *>(meta + 1);
                 const uint32_t b = bc[0], nexc = bc[1];
@@ -156,7 +156,7 @@ namespace trif {
                                 return false;
                         const uint32_t cnt = *p++;
                         const uint32_t groups = (cnt + 31) / 32;
-                        if (cnt != nexc || (uint32_t)(p - w) + groups * k != L)
+                        if (cnt != nexc || (uint64_t)(p - w) + (uint64_t)groups * k != L)
                                 return false;
                         high.resize((size_t)groups * 32);
                         for (uint32_t g = 0; g < groups; ++g)

@@ -84,11 +84,15 @@ class HostPool {
                 {
                         std::lock_guard<std::mutex> g(m_);
                         gen = ++gen_;
+                        // a job is taken by a compare-and-swap on (generation, next index): a worker that wakes up late for an earlier
+                        // generation can neither take nor skip a job of this one.  The ticket is CLOSED (index 2^32 - 1: beyond any n) in the
+                        // new generation BEFORE fn_ / n_ / left_ change: a straggler still inside work(gen - 1) that holds the old
+                        // (generation, n_old) and then reads the NEW, larger n_ can no longer win its CAS on the old word — it would have
+                        // run fn(n_old) of the new job, a second time, and taken left_ to zero one job early.
+                        state_.store(gen << 32 | 0xffffffffull, std::memory_order_seq_cst);
                         fn_ = &fn;
                         n_.store(n, std::memory_order_relaxed);
                         left_.store(n, std::memory_order_relaxed);
-                        // a job is taken by a compare-and-swap on (generation, next index): a worker that wakes up late for an earlier
-                        // generation can neither take nor skip a job of this one
                         state_.store(gen << 32, std::memory_order_release);
                         gen_hint_.store(gen, std::memory_order_release); // (the polling workers see this)
                         wake = sleepers_ != 0;
