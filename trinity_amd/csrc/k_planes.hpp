@@ -112,72 +112,83 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
 
 // ------------------------------------------------------------------------------------------ k_planes
 // AccumulatedScoreScheme + top-K of a CNF query (a union, a conjunction of terms / OR-groups, an excluded group, optional scoring
-// terms: everything k_fused's CNF instantiations take) in one pass over windows of PL_W documents, on BIT PLANES instead of a word
-// per document:
-//   * every slot (distinct term) of the query presents, per window, LEVEL planes: A (the document holds the term), B (its frequency
-//     is not 1) and, for a head term, C (nor 2).  A head term's planes come straight from the batch's term planes (global memory,
-//     L2 / Infinity-Cache resident: k_term_planes decoded the list once for every query of the launch).  Any other term's rows that
-//     fall into the task's docID range are decoded ONCE, at the start of the task — one lane per row of <= 32 documents, every lane
-//     of the workgroup busy, the same row readers as k_fused — into a sorted (docID, frequency-is-not-1) list in a scratch region
-//     of the workgroup; per window the list's next entries are picked up with one coalesced load and OR-ed into LDS planes.
-//   * the predicate is word-wise: a required group = the OR of its slots' A words, the conjunction their AND, the excluded group an
-//     AND-NOT, masked documents (docidupdates.h:90-119) another — 32 documents per instruction; the match count is a popcount.
-//     (What docset_spans.cpp:98-173 / 681-790 do per document and docset_iterators.cpp:226-405 per posting.)
-//   * the candidate filter.  A slot is at one of up to four LEVELS in a document: absent, frequency 1, frequency 2 (head terms; its
-//     scorers then add exactly what they add at that frequency), any other frequency (they add at most a bound).  Whenever the
-//     threshold (the k-th best score so far) moves, planes_filter rebuilds a TABLE with one bit per level vector (do the levels'
-//     weights reach the threshold?) and the ESSENTIAL PLANES — MaxScore's essential slots refined by level: a slot capped at level c
-//     is essential only through its plane c + 1.  The sweep ORs the essential planes word-wise; only the documents in that word are
-//     looked up in the table (level code from word-wise level bits), and only table hits become candidates — a match whose
-//     frequencies are all known (almost all of them) is thereby tested against its EXACT score without being touched.
-//   * a SEED pass scores the documents of the query's rarest decoded lists before the sweep (plane probes + bisections), so the
-//     threshold is near final from the first window on; the docID ranges (tasks) of a query share one threshold (planes_prune).
-//   * candidates are scored one per lane by the wave that owns their words, no workgroup barrier: levels from registers; a
-//     candidate with a slot of unknown frequency that the bound does not rule out waits on the wave's queue, and the queue is
-//     worked off 64 at a time — the exact frequencies come from the postings (directory cell -> block -> register row reader).
+// terms: everything k_fused's CNF instantiations take) in one pass, on BIT PLANES instead of a word per document.  Round 5's shape:
+// the query's slots (distinct terms) fall into two kinds, and each kind is worked the way its size asks for.
+//   * DENSE slots — head terms with rows in the index's term planes (A: the document holds the term, B: its frequency is not 1, C: nor 2;
+//     k_term_planes decoded the list once for every query of every launch).  They are SWEPT: every wave streams its share of the task's
+//     docID range through plane A of the dense slots only — the predicate word-wise (a required group = the OR of its slots' A words, the
+//     conjunction their AND, the excluded group an AND-NOT, masked documents another: 32 documents per instruction; what
+//     docset_spans.cpp:98-173 / 681-790 do per document and docset_iterators.cpp:226-405 per posting), the match count a popcount, and a
+//     PRESENCE FILTER (below) that says, word-wise, which documents could reach the current k-th best score at all.  The A words are
+//     fetched several sub-windows AHEAD into a register ring; planes B and C are read only by the lanes whose words hold a candidate, and
+//     those loads travel while the wave sweeps the next sub-window (a three-stage software pipeline: no round trip is waited for).
+//     Round 4 loaded all three planes of all five slots for every word and waited for them: 31 GB per cfg3 launch against 8.9 GB of
+//     algorithmic bytes, latency-bound at 4 waves per SIMD.
+//   * SPARSE slots — every other term (at most PLK_MAX_SPARSE).  Their rows that can reach the task's range are decoded ONCE per task, one
+//     lane per row of <= 32 documents (the same register row readers as k_fused), into sorted lists of docID << 1 | (frequency is not 1)
+//     in a scratch region of the workgroup; then EVERY document of those lists is evaluated on its own (phase A): its level in the dense
+//     slots from three plane probes each, in the other sparse slots from a bisection of their lists (a hashed byte filter in LDS says
+//     which lists can hold it at all), the predicate, the exact score (frequencies beyond the planes' levels from the postings), an
+//     offer to the top-K.  The top-K is mostly made of documents that hold the rare terms, so the threshold is near final before the
+//     sweep starts — and the sweep never sees a sparse slot: no LDS planes to set and clear per sub-window, no list cursor in its way.
+//   * the two phases meet in the match COUNT and in the candidates.  The sweep counts the documents that match through their dense slots
+//     alone; a sparse document adds (matches with all its slots) - (matches with its dense slots alone) — +1 where a rare term completes
+//     a conjunction, -1 where an excluded rare term removes a match, 0 where it only adds to the score.  A sweep candidate that the
+//     hashed filter and a bisection find in a sparse list is dropped there: phase A has scored it, with all its terms.  A query none of
+//     whose required groups can be satisfied by dense slots alone (a conjunction with a rare term: cfg3's `A B (C|D|E)`) has no sweep.
+//   * the candidate filter.  A dense slot is at one of four LEVELS in a document (absent, frequency 1, frequency 2 — its scorers then add
+//     exactly what they add at that frequency —, any other frequency: at most a bound).  Whenever the threshold (the k-th best score so
+//     far) moves, planes_filter rebuilds (a) the PRESENCE table — one bit per set of dense slots: do their bounds reach the threshold? —
+//     which the sweep evaluates word-wise as a monotone Boolean function of the A words (planes_presence: a tree of v_and_or under
+//     scalar masks), (b) the LEVEL table with one bit per level vector and (c) the essential planes (MaxScore's essential slots refined
+//     by level), which stage 3 applies to the few documents that passed (a).
+//   * candidates are scored one per lane from the level words in registers; a candidate with a slot of unknown frequency that the bound
+//     does not rule out waits on the wave's queue, worked off 64 at a time (directory cell -> block -> register row reader).  The waves
+//     share the candidate buffer, the threshold and the tables; they meet at a barrier only when the buffer wants pruning, and at the
+//     end.  The docID ranges (tasks) of a query share one threshold (planes_prune).
 //   * per task: min(matches, k) ranked (docID, score) pairs and the match count; k_topk_merge folds a query's tasks.
 constexpr int PLK_WG = 512;
 // (PLK_MAX_SPARSE, PLK_NS_SMALL: dev_structs.hpp)
 constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per thread when it is pruned)
 constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
-constexpr uint32_t PLK_FTAB_WORDS = (1u << (2 * FUS_MAX_SLOTS)) / 32; // the filter table: one bit per level vector (two bits per slot)
+constexpr uint32_t PLK_FTAB_WORDS = (1u << (2 * FUS_MAX_SLOTS)) / 32; // the level table: one bit per level vector (two bits per dense slot)
 #ifndef TRI_PLK_WGS
 #define TRI_PLK_WGS 2
 #endif
-constexpr uint32_t PLK_WGS_PER_CU = TRI_PLK_WGS; // (LDS: two fit)
+constexpr uint32_t PLK_WGS_PER_CU = TRI_PLK_WGS;
 constexpr uint32_t PLK_WQ = 128;        // per-wave queue of candidates waiting for a frequency lookup: worked off 64 at a time, every lane busy
 constexpr uint32_t PLK_PAD = 0xffffffffu; // list padding (sorts last)
-constexpr uint32_t PLK_SEED_FIRST = 4096;  // the seed pass takes the shortest decoded list if it has at most this many entries in the task's range ...
-constexpr uint32_t PLK_SEED_MORE = 2048;   // ... and further ones while the total stays below this
-constexpr uint32_t PLK_SW_WORDS = 128;    // a wave's sub-window: two words (64 documents) per lane ...
+constexpr uint32_t PLK_SW_WORDS = 128;    // a wave's sub-window: two consecutive words (64 documents) per lane ...
 constexpr uint32_t PLK_SW = PLK_SW_WORDS * 32; // ... 4096 documents
-constexpr uint32_t PLK_SW_STRIDE = PLK_SW_WORDS + 4; // LDS words between a decoded slot's A and B plane of a sub-window
+constexpr uint32_t PLK_HF = 32768;        // hashed filter of the task's sparse documents: one byte per docID & (PLK_HF - 1), bit j = sparse list j may hold it
 static_assert(PL_W % PLK_SW == 0, "a task's windows split into whole sub-windows");
 static_assert(PLK_CAP == PLK_WG && TOPK_MAX < PLK_PRUNE_AT && PLK_PRUNE_AT < PLK_CAP, "pruning leaves room; a pruned buffer is below the stop mark");
+static_assert(PLK_MAX_SPARSE <= 8, "one filter bit per sparse list");
 
 struct PlanesShared {
-        uint32_t pl[PLK_WG / 64][PLK_MAX_SPARSE][2 * PLK_SW_STRIDE]; // per wave and decoded slot: planes A and B of the wave's current sub-window
         double tk_s[PLK_CAP];
         uint32_t tk_d[PLK_CAP];
         DevTerm term[FUS_MAX_SLOTS];
         double wl[FUS_MAX_SLOTS][4]; // per slot and level: what its scorers add (exact below the slot's top level)
         double wf[FUS_MAX_SLOTS][4]; // ... rounded up a hair for the filter (it must never lose a tie to rounding), non-decreasing in the level; top level: a bound
+        double dwf[FUS_MAX_SLOTS][4]; // wf[] of the DENSE slots, by dense position (the sweep's tables are over dense positions)
         double thr_s;
         uint32_t thr_d;
         uint32_t tk_n, tk_full, matches;
-        uint32_t leaf;                // the slots that have a scorer
         uint32_t top[FUS_MAX_SLOTS];  // per slot: its top level (3: a term plane; 2: a decoded list; 0: no scorer)
-        uint32_t esel;                // the essential planes (two bits per slot — 0: A, 1: B, 2: C, 3: none): every candidate is in one of them
+        uint32_t dtop[FUS_MAX_SLOTS], ddocs[FUS_MAX_SLOTS]; // by dense position: top level, the term's documents
+        uint32_t esel;                // the essential planes (two bits per dense position — 0: A, 1: B, 2: C, 3: none): every candidate is in one of them
         uint32_t fall;                // 1: no threshold yet (or one that rules nothing out): every match is a candidate
-        uint32_t ftab[PLK_FTAB_WORDS]; // the candidate filter: bit `code` (two bits per slot: its level) set <=> the levels' weights reach the threshold
+        uint32_t atab;                // the presence table (up to five dense slots): bit `set` <=> the bounds of the slots of `set` reach the threshold
+        uint32_t ftab[PLK_FTAB_WORDS]; // the level table: bit `code` (two bits per dense position: its level) set <=> the levels' weights reach the threshold
         uint32_t flag[PLK_WG / 64];
-        uint32_t wq[PLK_WG / 64][PLK_WQ][2]; // per wave: candidates waiting for exact frequencies {docID, the slots' levels (two bits each)}
+        uint32_t wq[PLK_WG / 64][PLK_WQ][2]; // per wave: candidates waiting for exact frequencies {docID, the slots' levels (two bits per SLOT)}
         uint32_t bcast[4];
-        uint32_t zero[2 * PLK_SW_STRIDE]; // what a slot WITHOUT decoded list reads as its LDS planes (so that the sweep needs no per-slot selects)
-        uint32_t sp_row0[FUS_MAX_SLOTS], sp_n[FUS_MAX_SLOTS], sp_base[FUS_MAX_SLOTS]; // decoded slots: first row, rows, first entry of the list in the scratch region
+        uint32_t sp_row0[FUS_MAX_SLOTS], sp_n[FUS_MAX_SLOTS], sp_base[FUS_MAX_SLOTS]; // sparse slots: first row, rows, first entry of the list in the scratch region
+        uint32_t hf[PLK_HF / 4];      // the hashed filter (bytes)
         DevFused fq;
 };
-static_assert(sizeof(PlanesShared) * PLK_WGS_PER_CU <= 160u * 1024u, "two workgroups per CU");
+static_assert(sizeof(PlanesShared) * PLK_WGS_PER_CU <= 160u * 1024u, "the workgroups of a CU share its LDS");
 
 // A row of a decoded slot into its list: 32 entries per row (docID << 1 | frequency-is-not-1), the unused ones of a short last row padded.
 struct ListPost {
@@ -250,35 +261,48 @@ __device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t 
         __syncthreads();
 }
 
-// The candidate filter, recomputed whenever the threshold moves (every thread calls it; it ends with a barrier).  Every scoring slot
-// is at a level 0 .. top[slot] in a document and adds at most wf[slot][level] there (exactly, below the top level), so a document's
-// score is at most the sum of its slots' level weights: the TABLE holds, for every level vector (two bits per slot), whether that sum
-// reaches the current k-th best score.  A match is looked up with its own level vector — a few shifts on the words the sweep already
-// holds — so documents whose frequencies are all known (almost all) are tested against their exact score.  To keep that off most
-// documents, MaxScore's essential slots come first, word-wise: with the slots ordered by their bound, the longest prefix whose bounds
-// sum to less than the threshold cannot lift a document over it, so a candidate holds one of the OTHER slots — the OR of their A words
-// picks the few documents that are looked up at all.  No threshold yet, or one that rules nothing out: every match is a candidate.
-__device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
+// The candidate filter of the SWEEP, recomputed whenever the threshold moves (every thread calls it; it ends with a barrier).  It speaks of
+// the nd DENSE slots by their dense position (a document the sweep may offer holds no sparse term: phase A owns those).  A slot is at a level
+// 0 .. dtop[i] in a document and adds at most dwf[i][level] there (exactly, below the top level), so a document's score is at most the sum of
+// its slots' level weights:
+//   * the LEVEL table holds, for every level vector (two bits per position), whether that sum reaches the current k-th best score — a
+//     document whose frequencies are all known (almost all) is thereby tested against its EXACT score without being touched;
+//   * the PRESENCE table (nd <= 5) holds the same for the sets of slots a document may hold, every slot at its top level's bound: what the
+//     sweep evaluates word-wise on plane A alone, before anyone looks at planes B and C;
+//   * the essential planes: with the slots ordered by their bound, the longest prefix whose bounds sum to less than the threshold cannot lift a
+//     document over it, so a candidate holds one of the OTHER slots; what is left of the threshold then buys those slots' LOW levels (a slot
+//     capped at level c is essential only through its plane c + 1).  Stage 3 ORs the essential planes before it walks a word's documents.
+// No threshold yet, or one that rules nothing out: every match is a candidate.
+__device__ void planes_filter(PlanesShared &sh, const uint32_t nd) {
         const uint32_t tid = threadIdx.x;
         const double thr = sh.thr_s;
         const bool full = uni(sh.tk_full) != 0 && 0.0 < thr;
         sh.fall = full ? 0u : 1u; // (uniform stores)
         sh.esel = 0; // (plane A of every slot)
         if (!full) {
+                sh.atab = 0xffffffffu;
                 __syncthreads();
                 return;
         }
-        const uint32_t words = (1u << (2 * nslots)) / 32u > 0 ? (1u << (2 * nslots)) / 32u : 1u;
+        if (tid < 64) { // (wave 0; lanes 32 .. 63 mirror): the presence table — same summation order as the level table, every addend at least the level's
+                const uint32_t set = tid & 31u;
+                double sum = 0.0;
+                for (uint32_t i = 0; i < nd && i < 5u; ++i)
+                        sum += ((set >> i) & 1u) && sh.dtop[i] ? sh.dwf[i][sh.dtop[i]] : 0.0;
+                const uint64_t bm = __builtin_amdgcn_ballot_w64(!(sum < thr));
+                sh.atab = (uint32_t)bm; // (same value from every lane)
+        }
+        const uint32_t words = (1u << (2 * nd)) / 32u > 0 ? (1u << (2 * nd)) / 32u : 1u;
         for (uint32_t wd = tid; wd < words; wd += PLK_WG) {
                 uint32_t bits = 0;
                 for (uint32_t j = 0; j < 32; ++j) {
                         const uint32_t code = wd * 32u + j;
                         double sum = 0.0;
-                        bool valid = code < (1u << (2 * nslots));
-                        for (uint32_t sl = 0; sl < nslots; ++sl) {
-                                const uint32_t l = (code >> (2 * sl)) & 3u;
-                                valid &= l <= sh.top[sl];
-                                sum += l ? sh.wf[sl][l] : 0.0;
+                        bool valid = code < (1u << (2 * nd));
+                        for (uint32_t i = 0; i < nd; ++i) {
+                                const uint32_t l = (code >> (2 * i)) & 3u;
+                                valid &= l <= sh.dtop[i];
+                                sum += l ? sh.dwf[i][l] : 0.0;
                         }
                         bits |= (valid && !(sum < thr) ? 1u : 0u) << j;
                 }
@@ -288,14 +312,14 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         const double thr_lo = thr * (1.0 - 1e-9); // (the table adds the weights in its own order: a hair of room for the rounding)
         uint32_t done = 0, ess = 0;
         double p = 0.0, spent = 0.0;
-        for (uint32_t r = 0; r < nslots; ++r) { // selection by ascending bound (<= 8 slots)
+        for (uint32_t r = 0; r < nd; ++r) { // selection by ascending bound (<= 8 slots)
                 uint32_t best = 0;
                 double bv = 1e300;
-                for (uint32_t sl = 0; sl < nslots; ++sl) {
-                        const double b = sh.top[sl] ? sh.wf[sl][sh.top[sl]] : 0.0;
-                        if (!((done >> sl) & 1u) && b < bv) {
+                for (uint32_t i = 0; i < nd; ++i) {
+                        const double b = sh.dtop[i] ? sh.dwf[i][sh.dtop[i]] : 0.0;
+                        if (!((done >> i) & 1u) && b < bv) {
                                 bv = b;
-                                best = sl;
+                                best = i;
                         }
                 }
                 done |= 1u << best;
@@ -309,21 +333,21 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
         // its plane c + 1 (B: frequency not 1 — a fraction of A; C: nor 2).  Each round takes the raise that drops the most documents
         // (estimated from the terms' document counts) among those that still fit.
         uint32_t cap[FUS_MAX_SLOTS];
-        for (uint32_t sl = 0; sl < FUS_MAX_SLOTS; ++sl)
-                cap[sl] = sl < nslots && ((ess >> sl) & 1u) ? 0u : 3u;
+        for (uint32_t i = 0; i < FUS_MAX_SLOTS; ++i)
+                cap[i] = i < nd && ((ess >> i) & 1u) ? 0u : 3u;
         for (uint32_t r = 0; r < 2 * FUS_MAX_SLOTS; ++r) {
                 uint32_t best = 0xffffffffu;
                 double gain = 0.0, cost = 0.0;
-                for (uint32_t sl = 0; sl < nslots; ++sl) {
-                        const uint32_t c = cap[sl], tp = sh.top[sl];
+                for (uint32_t i = 0; i < nd; ++i) {
+                        const uint32_t c = cap[i], tp = sh.dtop[i];
                         if (c >= tp) // (its top plane already, or not essential at all)
                                 continue;
-                        const double dw = sh.wf[sl][c + 1] - (c ? sh.wf[sl][c] : 0.0);
-                        const double docs = (double)sh.term[sl].documents * (c == 0 ? 0.65 : c == 1 ? 0.2 : 0.15); // (the documents at exactly level c + 1, roughly)
+                        const double dw = sh.dwf[i][c + 1] - (c ? sh.dwf[i][c] : 0.0);
+                        const double docs = (double)sh.ddocs[i] * (c == 0 ? 0.65 : c == 1 ? 0.2 : 0.15); // (the documents at exactly level c + 1, roughly)
                         if (spent + dw < thr_lo && gain < docs) {
                                 gain = docs;
                                 cost = dw;
-                                best = sl;
+                                best = i;
                         }
                 }
                 if (best == 0xffffffffu)
@@ -332,9 +356,9 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nslots) {
                 spent += cost;
         }
         uint32_t esel = 0;
-        for (uint32_t sl = 0; sl < FUS_MAX_SLOTS; ++sl) {
-                const uint32_t c = cap[sl], tp = sl < nslots ? sh.top[sl] : 0u;
-                esel |= (c + 1 > tp ? 3u : c) << (2 * sl);
+        for (uint32_t i = 0; i < FUS_MAX_SLOTS; ++i) {
+                const uint32_t c = cap[i], tp = i < nd ? sh.dtop[i] : 0u;
+                esel |= (c + 1 > tp ? 3u : c) << (2 * i);
         }
         sh.esel = uni(esel);
         __syncthreads();
@@ -430,8 +454,47 @@ __device__ __forceinline__ uint32_t and_or(const uint32_t a, const uint32_t smas
         return r;
 }
 
-// NS: the slots the instantiation keeps in registers (six words each: the A, B and C words of the thread's two window words).
-// scratch: sparse_cap u32 per workgroup — the lists of the task's decoded slots.
+// The presence filter on TWO words at once (p, q: the dense slots' plane-A words): bit d of the result <=> the bounds of the slots document d
+// holds reach the threshold, i.e. the table T (PlanesShared::atab) looked up with the document's NV presence bits — for 32 documents per
+// word.  T is monotone (a superset of slots never scores less), so f = OR over the sets T passes of the AND of their slots' words; factored
+// as a tree over the slots with T's bits as uniform scalar masks (s_bfe_i32, made where they are used).  planes_presence_tree<NV, BASE>
+// leaves out the constant part T[BASE] (the set without any of the NV slots): the caller ORs it in one level up, where it costs one and_or
+// under the parent's slot word — 4 vector instructions per word for two slots, 10 for three, 46 for five, whatever the table holds.
+template <uint32_t NV, uint32_t BASE, uint32_t NP>
+__device__ __forceinline__ void planes_presence_tree(const uint32_t T, const uint32_t (&p)[NP], const uint32_t (&q)[NP], uint32_t &fp, uint32_t &fq) {
+        if constexpr (NV == 0) {
+                fp = 0;
+                fq = 0;
+        } else {
+                uint32_t lp, lq, hp, hq;
+                planes_presence_tree<NV - 1, BASE, NP>(T, p, q, lp, lq);
+                planes_presence_tree<NV - 1, BASE + (1u << (NV - 1)), NP>(T, p, q, hp, hq);
+                const uint32_t c = umask_at<BASE + (1u << (NV - 1))>(T); // (the slot alone completes the set)
+                fp = and_or(p[NV - 1], c, (p[NV - 1] & hp) | lp);
+                fq = and_or(q[NV - 1], c, (q[NV - 1] & hq) | lq);
+        }
+}
+
+// the entry of `doc` in a sorted list of n entries (docID << 1 | flag; padding sorts last), PLK_PAD when it holds none
+__device__ __forceinline__ uint32_t planes_list_find(const uint32_t *__restrict__ ls, const uint32_t n, const uint32_t doc) {
+        uint32_t lo = 0, hi = n;
+        const uint32_t key = doc << 1;
+        while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (ls[mid] < key)
+                        lo = mid + 1;
+                else
+                        hi = mid;
+        }
+        const uint32_t f = lo < n ? ls[lo] : PLK_PAD;
+        return (f >> 1) == doc ? f : PLK_PAD;
+}
+
+// how far ahead the sweep fetches plane A: ND slots x two words per lane and sub-window in flight per step of the ring (about a kilobyte
+// per wave and sub-window and slot; the CU needs some tens of kilobytes in flight to cover HBM's latency at its share of the bandwidth)
+template <int ND> struct PlkRing { static constexpr uint32_t PF = ND <= 1 ? 4 : ND == 2 ? 3 : ND == 3 ? 2 : 1; };
+
+// NS: the slots the instantiation can hold.  scratch: sparse_cap u32 per workgroup — the lists of the task's sparse slots.
 template <int CODEC, int NS>
 __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void k_planes(
         const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
@@ -445,10 +508,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
         const uint32_t wave = uni(tid >> 6);
         uint32_t *const lists = scratch + (size_t)blockIdx.x * sparse_cap;
-        for (uint32_t i = tid; i < (PLK_WG / 64) * PLK_MAX_SPARSE * 2 * PLK_SW_STRIDE; i += PLK_WG)
-                (&sh.pl[0][0][0])[i] = 0;
-        for (uint32_t i = tid; i < 2 * PLK_SW_STRIDE; i += PLK_WG)
-                sh.zero[i] = 0;
         PROF_DECL;
         PROF_START();
 #ifdef TRI_PROF
@@ -473,11 +532,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const uint32_t wi = min(tid, (uint32_t)(sizeof(DevFused) / 4 - 1)); // (every lane stores: no divergent branch around the barriers)
                         ((uint32_t *)&sh.fq)[wi] = ((const uint32_t *)(fused + q.fused_idx))[wi];
                 }
+                for (uint32_t i = tid; i < PLK_HF / 4; i += PLK_WG)
+                        sh.hf[i] = 0;
                 __syncthreads();
                 const DevFused &fq = sh.fq;
                 const uint32_t nslots = min(uni(fq.nslots), (uint32_t)NS), nreq = uni(fq.nreq), negs = uni(fq.negslots);
                 const uint32_t kk = min(lane, nslots - 1); // lane s (< nslots) of every wave looks after slot s, the lanes above mirror the last slot
                 const uint32_t wfirst = task.tile_begin, wend = task.tile_end;
+                const uint32_t d_lo = wfirst * PL_W, d_hi = wend * PL_W; // (the planner keeps max docID below 2^31: no wrap)
                 {
                         const DevTerm myt = terms[fq.term[kk]];
                         sh.term[kk] = myt;
@@ -502,11 +564,9 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const double f1 = fmax(up(t1), 0.0), f2 = top == 3 ? fmax(up(t2), f1) : bound;
                         sh.wf[kk][0] = 0.0, sh.wf[kk][1] = f1, sh.wf[kk][2] = f2, sh.wf[kk][3] = bound;
                         sh.top[kk] = top;
-                        const uint64_t lm = __builtin_amdgcn_ballot_w64(leaf && lane < nslots);
-                        sh.leaf = (uint32_t)lm; // (same value from every lane)
                         sh.tk_n = 0;
                         {
-                                // (another range of the query may have a threshold already: this one filters with it from its first window on)
+                                // (another range of the query may have a threshold already: this one filters with it from its first document on)
                                 const unsigned long long g = __atomic_load_n(gthr, __ATOMIC_RELAXED);
                                 sh.tk_full = g != 0ull ? 1u : 0u;
                                 sh.thr_s = g != 0ull ? key_score(g) : 0.0;
@@ -515,15 +575,15 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.matches = 0;
                         sh.fall = 1; // no threshold yet: every match is a candidate
                         sh.esel = 0;
-                        // a decoded slot's rows that can hold documents of the task's range [first window's first docID, last window's end)
+                        sh.atab = 0xffffffffu;
+                        // a sparse slot's rows that can hold documents of the task's range [first window's first docID, last window's end)
                         uint32_t row0 = 0, nrows = 0;
                         if (!dense) {
                                 const uint32_t *bl = blk_last + myt.first_block;
-                                const uint32_t d0 = wfirst * PL_W, d1 = wend * PL_W; // (the planner keeps max docID below 2^31: no wrap)
                                 uint32_t lo = 0, hi = myt.nblocks;
                                 while (lo < hi) {
                                         const uint32_t mid = (lo + hi) >> 1;
-                                        if (bl[mid] < d0)
+                                        if (bl[mid] < d_lo)
                                                 lo = mid + 1;
                                         else
                                                 hi = mid;
@@ -532,7 +592,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 hi = myt.nblocks;
                                 while (lo < hi) {
                                         const uint32_t mid = (lo + hi) >> 1;
-                                        if (bl[mid] < d1)
+                                        if (bl[mid] < d_hi)
                                                 lo = mid + 1;
                                         else
                                                 hi = mid;
@@ -550,35 +610,57 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.sp_base[kk] = base;
                 }
                 __syncthreads();
-                // ---- per task, uniform: which slots read term planes, where the others' LDS planes are, which slots score
-                uint32_t dense_mask = 0;
-                uint32_t lidx[NS], top[NS], prows[NS];
-                uint32_t list_rows = 0;
-                {
-                        uint32_t nl = 0;
-#pragma unroll
-                        for (uint32_t s = 0; s < NS; ++s) {
-                                const uint32_t prow = s < nslots ? uni(fq.plane[s]) : PL_NONE;
-                                prows[s] = prow;
-                                lidx[s] = 0;
-                                top[s] = s < nslots ? uni(sh.top[s]) : 0u;
-                                if (s < nslots) {
-                                        if (prow != PL_NONE)
-                                                dense_mask |= 1u << s;
-                                        else {
-                                                lidx[s] = nl++;
-                                                list_rows += uni(sh.sp_n[s]);
-                                        }
-                                }
-                        }
-                }
-                const uint32_t sparse_mask = ((1u << nslots) - 1u) & ~dense_mask;
-                uint32_t leafm = 0; // the slots that have a scorer
+                // ---- per task, uniform: the dense slots by position, the sparse slots by ordinal, the slots' roles over both index spaces
+                uint32_t dense_mask = 0, leafm = 0, list_rows = 0;
 #pragma unroll
                 for (uint32_t s = 0; s < NS; ++s)
-                        leafm |= (top[s] ? 1u : 0u) << s;
+                        if (s < nslots) {
+                                if (uni(fq.plane[s]) != PL_NONE)
+                                        dense_mask |= 1u << s;
+                                else
+                                        list_rows += uni(sh.sp_n[s]);
+                                leafm |= (uni(sh.top[s]) ? 1u : 0u) << s;
+                        }
+                const uint32_t sparse_mask = ((1u << nslots) - 1u) & ~dense_mask;
+                dense_mask = uni(dense_mask), leafm = uni(leafm), list_rows = uni(list_rows);
+                const uint32_t nd = (uint32_t)__builtin_popcount(dense_mask), nsp = (uint32_t)__builtin_popcount(sparse_mask);
+                uint32_t dsl[NS]; // dense position -> slot
+                const uint32_t *pA[NS];
+                {
+                        uint32_t dm = dense_mask;
+#pragma unroll
+                        for (uint32_t i = 0; i < NS; ++i) {
+                                const uint32_t s = dm ? (uint32_t)__builtin_ctz(dm) : 0u;
+                                dsl[i] = uni(s);
+                                pA[i] = planes + (size_t)(dm ? uni(fq.plane[s]) : zrow) * PL_PLANES * plw; // (zrow: the all-zero row — what a position beyond nd reads)
+                                dm &= dm - 1u;
+                        }
+                }
+                auto to_dense = [&](const uint32_t slots) { // a set of slots as a set of dense positions
+                        uint32_t out = 0;
+#pragma unroll
+                        for (uint32_t i = 0; i < NS; ++i)
+                                out |= (i < nd ? (slots >> dsl[i]) & 1u : 0u) << i;
+                        return out;
+                };
+                uint32_t gsl[FUS_MAX_SLOTS], gd[FUS_MAX_SLOTS];
+                bool sweepable = true; // every required group holds a dense slot: documents can match through their dense slots alone
+#pragma unroll
+                for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g) {
+                        gsl[g] = g < nreq ? uni(fq.gslots[g]) : 0u;
+                        gd[g] = uni(to_dense(gsl[g]));
+                        sweepable = sweepable && (g >= nreq || gd[g] != 0);
+                }
+                const uint32_t negd = uni(to_dense(negs)), leafd = uni(to_dense(leafm));
+#pragma unroll
+                for (uint32_t i = 0; i < NS; ++i)
+                        if (tid == i && i < nd) {
+                                sh.dwf[i][0] = sh.wf[dsl[i]][0], sh.dwf[i][1] = sh.wf[dsl[i]][1], sh.dwf[i][2] = sh.wf[dsl[i]][2], sh.dwf[i][3] = sh.wf[dsl[i]][3];
+                                sh.dtop[i] = sh.top[dsl[i]];
+                                sh.ddocs[i] = sh.term[dsl[i]].documents;
+                        }
                 PROF_LAP(0);
-                // ---- the decoded slots' lists: every row that can reach the task's range, one lane per row, 32 entries each
+                // ---- the sparse slots' lists: every row that can reach the task's range, one lane per row, 32 entries each
                 for (uint32_t v0 = 0; v0 < list_rows; v0 += PLK_WG) {
                         const uint32_t v = v0 + tid;
                         if (v < list_rows) {
@@ -595,10 +677,45 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 }
                 __syncthreads(); // (the lists are written: a workgroup barrier orders the global stores for the workgroup's own later loads)
                 PROF_LAP(7);
-                uint32_t my_matches = 0;
-                // this wave's queue of candidates that wait for an exact frequency: it lives across the windows and is worked off 64 entries at
-                // a time — every lane fetching from the postings at once, not one lane while 63 wait — and emptied at the end of the task
-                uint32_t qn = 0; // entries on the queue (wave-uniform)
+                // the sparse slots by ordinal: slot, list extent, list base (uniform registers)
+                uint32_t ssl[PLK_MAX_SPARSE], sp_n32[PLK_MAX_SPARSE], sp_off[PLK_MAX_SPARSE];
+                {
+                        uint32_t sm = sparse_mask;
+#pragma unroll
+                        for (uint32_t j = 0; j < PLK_MAX_SPARSE; ++j) {
+                                const uint32_t s = sm ? (uint32_t)__builtin_ctz(sm) : 0u;
+                                ssl[j] = uni(s);
+                                sp_n32[j] = sm ? uni(sh.sp_n[s]) * 32u : 0u;
+                                sp_off[j] = sm ? uni(sh.sp_base[s]) : 0u;
+                                sm &= sm - 1u;
+                        }
+                }
+                const uint32_t total_items = list_rows * 32u;
+                // an item (index into the concatenation of the lists) -> its list's ordinal and the entry
+                auto item_entry = [&](const uint32_t v, uint32_t &j_out) {
+                        uint32_t j = 0, ei = v, off = 0;
+#pragma unroll
+                        for (uint32_t j2 = 0; j2 < PLK_MAX_SPARSE; ++j2) {
+                                if (j == j2 && j2 < nsp && ei >= sp_n32[j2]) {
+                                        ei -= sp_n32[j2];
+                                        j = j2 + 1;
+                                }
+                                off = j == j2 ? sp_off[j2] : off;
+                        }
+                        j_out = j;
+                        return v < total_items && j < nsp ? lists[off + ei] : PLK_PAD;
+                };
+                // ---- the hashed filter: every sparse document of the range marks its byte with its list's bit
+                for (uint32_t v = tid; v < total_items; v += PLK_WG) {
+                        uint32_t j;
+                        const uint32_t e = item_entry(v, j), doc = e >> 1;
+                        if (e != PLK_PAD && doc >= d_lo && doc < d_hi)
+                                atomicOr(&sh.hf[(doc & (PLK_HF - 1u)) >> 2], (1u << j) << (8u * (doc & 3u)));
+                }
+                __syncthreads();
+                PROF_LAP(1);
+                uint32_t my_matches = 0; // (wraps: phase A adds signed corrections)
+                uint32_t qn = 0;         // entries on this wave's queue of candidates that wait for an exact frequency (wave-uniform)
                 auto offer = [&](const double sc, const uint32_t doc) { // false: no room (the buffer wants pruning)
                         const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
                         if (slot >= PLK_CAP)
@@ -607,8 +724,27 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.tk_d[slot] = doc;
                         return true;
                 };
+                // the exact score of a document from its slots' levels (two bits per slot): frequencies 1 / 2 from the level weights, anything
+                // else from the postings
+                auto exact_score = [&](const uint32_t doc, const uint32_t levels) {
+                        double sk = 0.0;
+                        for (uint32_t s = 0; s < nslots; ++s) {
+                                const uint32_t l = (levels >> (2 * s)) & 3u;
+                                if (!l)
+                                        continue;
+                                if (l < sh.top[s]) {
+                                        sk += sh.wl[s][l];
+                                        continue;
+                                }
+                                const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, sh.term[s], doc);
+                                const uint32_t term = fq.term[s];
+                                for (uint32_t si = 0; si < q.nscore; ++si)
+                                        if (sterms[q.score_base + si] == term)
+                                                sk += (double)sim_score(sim, sweights[q.score_base + si], f);
+                        }
+                        return sk;
+                };
                 auto work_queue = [&]() { // the last (up to) 64 entries of the queue; entries that found no room go back
-                        PROF_LAP(11);
                         const uint32_t take_n = min(qn, 64u), base = qn - take_n;
                         qn = base;
                         bool back = false;
@@ -616,21 +752,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         if (lane < take_n) {
                                 doc = sh.wq[wave][base + lane][0];
                                 levels = sh.wq[wave][base + lane][1];
-                                double sk = 0.0;
-                                for (uint32_t s = 0; s < nslots; ++s) {
-                                        const uint32_t l = (levels >> (2 * s)) & 3u;
-                                        if (!l)
-                                                continue;
-                                        if (l < sh.top[s]) {
-                                                sk += sh.wl[s][l];
-                                                continue;
-                                        }
-                                        const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, sh.term[s], doc);
-                                        const uint32_t term = fq.term[s];
-                                        for (uint32_t si = 0; si < q.nscore; ++si)
-                                                if (sterms[q.score_base + si] == term)
-                                                        sk += (double)sim_score(sim, sweights[q.score_base + si], f);
-                                }
+                                const double sk = exact_score(doc, levels);
                                 if (!uni(sh.tk_full) || better(sk, doc, sh.thr_s, sh.thr_d))
                                         back = !offer(sk, doc);
                         }
@@ -642,256 +764,225 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 sh.wq[wave][at][1] = levels;
                         }
                         qn += (uint32_t)__popcll(bm);
-                        PROF_LAP(13);
+                        PROF_LAP(11);
                 };
-                // ---- Every WAVE walks its own contiguous share of the task's range, a sub-window of PLK_SW documents (two words per lane) at a
-                //      time, wave-synchronously: no workgroup barrier inside — sixteen independent chains of loads per CU instead of two, which is
-                //      what this kernel is bound by (a window is a few hundred instructions behind a memory round trip).  The waves share the
-                //      candidate buffer, the threshold and the filter; they meet at a barrier only when the buffer wants pruning, and at the end.
-                const uint32_t nsw = (wend - wfirst) * (PL_W / PLK_SW);
-                const uint32_t sw_first = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * wave / (PLK_WG / 64));
-                const uint32_t sw_end = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * (wave + 1) / (PLK_WG / 64));
-                uint32_t sw = sw_first;
-                // the wave's cursors into the decoded slots' lists: the first entry at or beyond its share's first document
-                uint32_t curv[NS];
+                // the waves meet: prune if the buffer wants it; false: no wave has work left
+                auto meet = [&](const bool more) {
+                        sh.flag[wave] = more ? 1u : 0u; // (wave-uniform value, every lane stores it)
+                        __syncthreads();
+                        uint32_t anyp = 0;
 #pragma unroll
-                for (uint32_t s = 0; s < NS; ++s) {
-                        curv[s] = 0;
-                        if ((sparse_mask >> s) & 1u)
-                                curv[s] = wave_lower_bound(lists + uni(sh.sp_base[s]), 0u, uni(sh.sp_n[s]) * 32u, (sw_first * PLK_SW) << 1);
-                }
-                // per-task scalars the sub-window loop reads again and again, lifted out of LDS once: the lists' extents, the groups' slot sets, the
-                // term planes' bases (the loads take a scalar base plus the lane's offset)
-                uint32_t sp_n32[NS], sp_off[NS], gsl[FUS_MAX_SLOTS];
-                const uint32_t *pA[NS];
-#pragma unroll
-                for (uint32_t s = 0; s < NS; ++s) {
-                        sp_n32[s] = ((sparse_mask >> s) & 1u) ? uni(sh.sp_n[s]) * 32u : 0u;
-                        sp_off[s] = ((sparse_mask >> s) & 1u) ? uni(sh.sp_base[s]) : 0u;
-                        pA[s] = planes + (size_t)(prows[s] != PL_NONE ? prows[s] : zrow) * PL_PLANES * plw; // (zrow: the batch's all-zero row — what a slot without term planes reads)
-                }
-#pragma unroll
-                for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g)
-                        gsl[g] = g < nreq ? uni(fq.gslots[g]) : 0u;
-                // ---- SEED: the documents of the query's rarest decoded list(s) — a few thousand at most — are scored first, each on its own:
-                //      its levels in the other slots come from plane probes (head terms) and bisections of the other lists.  The top-K is mostly
-                //      made of documents that hold the rare terms, so the threshold — and with it the candidate filter — is close to final before
-                //      the sweep starts, instead of converging over the whole range.  The sweep then leaves those documents out of its candidates
-                //      (they are counted as matches there like every other document).
-                uint32_t seedmask = 0;
-                {
-                        uint32_t seed_items = 0;
-                        for (uint32_t r = 0; r < nslots; ++r) { // ascending list length (uniform)
-                                uint32_t best = 0xffffffffu, bn = 0xffffffffu;
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s)
-                                        if (((sparse_mask >> s) & 1u) && !((seedmask >> s) & 1u) && !((negs >> s) & 1u) && top[s] && sp_n32[s] && sp_n32[s] < bn) {
-                                                bn = sp_n32[s];
-                                                best = s;
-                                        }
-                                if (best == 0xffffffffu || (seedmask ? seed_items + bn > PLK_SEED_MORE : bn > PLK_SEED_FIRST))
-                                        break;
-                                seedmask |= 1u << best;
-                                seed_items += bn;
+                        for (uint32_t wv = 0; wv < PLK_WG / 64; ++wv)
+                                anyp |= sh.flag[wv];
+                        anyp = uni(anyp);
+                        const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
+                        __syncthreads(); // (every lane has read the flags and tk_n)
+                        bool pruned = false;
+                        if (n >= PLK_PRUNE_AT) {
+                                planes_prune(sh, n, k, gthr);
+                                pruned = true;
+                                PROF_COUNT(18, tid == 0 ? 1 : 0);
                         }
-                        const uint32_t d_lo = wfirst * PL_W, d_hi = wend * PL_W;
-                        const bool full0 = false;
-                        (void)full0;
-                        for (uint32_t v0 = 0; v0 < seed_items; v0 += PLK_WG) { // (uniform trip count)
-                                // this thread's item: an entry of a seed slot's list
-                                const uint32_t v = v0 + tid;
-                                uint32_t ss = 0, ei = v;
-                                bool pend = v < seed_items;
+                        PROF_LAP(5);
+                        return ((uint32_t)(anyp != 0)) | (pruned ? 2u : 0u);
+                };
+                // ---- PHASE A: every document of the sparse lists, each on its own — 64 per wave and step, the waves interleaved
+                {
+                        const uint32_t nchunks = (total_items + 63u) / 64u;
+                        uint32_t chunk = wave;
+                        bool have = false, pend = false;
+                        double pscore = 0.0;
+                        uint32_t pdoc = 0;
+                        for (;;) {
+                                while (chunk < nchunks) {
+                                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
+                                                break; // the buffer wants pruning first: to the barrier (the chunk stays as it is)
+                                        const bool full = uni(sh.tk_full) != 0;
+                                        if (!have) {
+                                                uint32_t j;
+                                                const uint32_t e = item_entry(chunk * 64u + lane, j), doc = e >> 1;
+                                                bool valid = e != PLK_PAD && doc >= d_lo && doc < d_hi && doc != 0;
+                                                uint32_t present = 0, levels = 0;
+                                                if (valid) {
+                                                        // the other sparse lists that may hold the document (the filter's byte), each bisected: a document an
+                                                        // EARLIER list holds is that list's item
+                                                        const uint32_t hb = (sh.hf[(doc & (PLK_HF - 1u)) >> 2] >> (8u * (doc & 3u))) & 0xffu;
 #pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s)
-                                        if ((seedmask >> s) & 1u) {
-                                                if (ss == s && ei >= sp_n32[s]) {
-                                                        ei -= sp_n32[s];
-                                                        ss = s + 1;
+                                                        for (uint32_t j2 = 0; j2 < PLK_MAX_SPARSE; ++j2) {
+                                                                if (j2 >= nsp)
+                                                                        break;
+                                                                uint32_t f = PLK_PAD;
+                                                                if (j2 == j)
+                                                                        f = e;
+                                                                else if ((hb >> j2) & 1u)
+                                                                        f = planes_list_find(lists + sp_off[j2], sp_n32[j2], doc);
+                                                                if (f != PLK_PAD) {
+                                                                        valid = valid && j2 >= j;
+                                                                        present |= 1u << ssl[j2];
+                                                                        levels |= (((leafm >> ssl[j2]) & 1u) ? 1u + (f & 1u) : 0u) << (2u * ssl[j2]);
+                                                                }
+                                                        }
                                                 }
-                                        } else if (ss == s)
-                                                ss = s + 1;
-                                // (ss: the first seed slot whose entries are not all before item v)
-                                uint32_t e = PLK_PAD;
-                                if (pend && ss < NS) {
-                                        uint32_t off = 0;
-#pragma unroll
-                                        for (uint32_t s = 0; s < NS; ++s)
-                                                off = ss == s ? sp_off[s] : off;
-                                        e = lists[off + ei];
-                                }
-                                const uint32_t doc = e >> 1;
-                                pend = pend && e != PLK_PAD && doc >= d_lo && doc < d_hi && doc != 0;
-                                double score = 0.0;
-                                if (pend) {
-                                        // the document's level in every slot
-                                        uint32_t present = 0, levels = 0;
-#pragma unroll
-                                        for (uint32_t s = 0; s < NS; ++s) {
-                                                if (s >= nslots)
-                                                        continue;
-                                                uint32_t l = 0;
-                                                if (prows[s] != PL_NONE) {
-                                                        const uint32_t *pa = pA[s], *pb = pa + plw, *pc = pb + plw;
+                                                pend = false;
+                                                if (valid) {
+                                                        // its level in the dense slots: three plane probes each
                                                         const uint32_t wi = doc >> 5, bit = doc & 31u;
-                                                        l = ((pa[wi] >> bit) & 1u) + ((pb[wi] >> bit) & 1u) + ((pc[wi] >> bit) & 1u);
-                                                } else if (s == ss)
-                                                        l = 1u + (e & 1u);
-                                                else if (sp_n32[s]) { // another decoded list: bisect it
-                                                        const uint32_t *ls = lists + sp_off[s];
-                                                        uint32_t lo = 0, hi = sp_n32[s];
-                                                        const uint32_t key = doc << 1;
-                                                        while (lo < hi) {
-                                                                const uint32_t mid = (lo + hi) >> 1;
-                                                                if (ls[mid] < key)
-                                                                        lo = mid + 1;
-                                                                else
-                                                                        hi = mid;
-                                                        }
-                                                        const uint32_t f = lo < sp_n32[s] ? ls[lo] : PLK_PAD;
-                                                        l = (f >> 1) == doc ? 1u + (f & 1u) : 0u;
-                                                }
-                                                present |= (l ? 1u : 0u) << s;
-                                                levels |= (top[s] ? l : 0u) << (2 * s);
-                                        }
-                                        // a document that an earlier seed slot holds is that slot's item; the predicate: every required group, no excluded slot, not masked
-                                        bool ok = !(present & seedmask & ((1u << ss) - 1u)) && !(present & negs);
 #pragma unroll
-                                        for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g)
-                                                ok = ok && (g >= nreq || (present & gsl[g]) != 0);
-                                        if (ok && masked)
-                                                ok = !((masked[doc >> 5] >> (doc & 31u)) & 1u);
-                                        pend = ok;
-                                        if (ok)
-                                                for (uint32_t s = 0; s < nslots; ++s) {
-                                                        const uint32_t l = (levels >> (2 * s)) & 3u;
-                                                        if (!l)
-                                                                continue;
-                                                        if (l < sh.top[s]) {
-                                                                score += sh.wl[s][l];
-                                                                continue;
+                                                        for (uint32_t i = 0; i < NS; ++i) {
+                                                                if (i >= nd)
+                                                                        break;
+                                                                const uint32_t *pa = pA[i], *pb = pa + plw, *pc = pb + plw;
+                                                                const uint32_t la = (pa[wi] >> bit) & 1u, l = la + ((pb[wi] >> bit) & 1u) + ((pc[wi] >> bit) & 1u);
+                                                                present |= la << dsl[i];
+                                                                levels |= (((leafd >> i) & 1u) ? l : 0u) << (2u * dsl[i]);
                                                         }
-                                                        const uint32_t f = planes_lookup_freq<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, sh.term[s], doc);
-                                                        const uint32_t term = fq.term[s];
-                                                        for (uint32_t si = 0; si < q.nscore; ++si)
-                                                                if (sterms[q.score_base + si] == term)
-                                                                        score += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                                        // the predicate with all the slots, and with the dense slots alone (what the sweep counts)
+                                                        const uint32_t pd = present & dense_mask;
+                                                        bool okf = !(present & negs), okd = sweepable && !(pd & negs);
+#pragma unroll
+                                                        for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g) {
+                                                                okf = okf && (g >= nreq || (present & gsl[g]) != 0);
+                                                                okd = okd && (g >= nreq || (pd & gsl[g]) != 0);
+                                                        }
+                                                        if (masked && ((masked[wi] >> bit) & 1u)) // masked_documents_registry::test (docidupdates.h:90-119)
+                                                                okf = okd = false;
+                                                        my_matches += (okf ? 1u : 0u) - (okd ? 1u : 0u);
+                                                        if (okf) {
+                                                                // a bound first: the frequencies beyond the levels cost a walk into the postings
+                                                                double sb = 0.0;
+                                                                for (uint32_t s = 0; s < nslots; ++s) {
+                                                                        const uint32_t l = (levels >> (2 * s)) & 3u;
+                                                                        sb += l ? sh.wf[s][l] : 0.0;
+                                                                }
+                                                                if (!full || better(sb, doc, sh.thr_s, sh.thr_d)) {
+                                                                        pscore = exact_score(doc, levels);
+                                                                        pdoc = doc;
+                                                                        pend = true;
+                                                                }
+                                                        }
                                                 }
-                                }
-                                // offered in rounds: a full buffer is pruned in between
-                                for (;;) {
-                                        if (pend && (!uni(sh.tk_full) || better(score, doc, sh.thr_s, sh.thr_d)))
-                                                pend = !offer(score, doc);
+                                                have = true;
+                                                PROF_COUNT(22, lane == 0 ? 1 : 0);
+                                        }
+                                        if (pend && (!full || better(pscore, pdoc, sh.thr_s, sh.thr_d)))
+                                                pend = !offer(pscore, pdoc);
                                         else
                                                 pend = false;
-                                        const uint32_t anyp = (uint32_t)__syncthreads_or(pend ? 1 : 0);
-                                        const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
-                                        __syncthreads(); // (every lane has read tk_n)
-                                        if (n >= PLK_PRUNE_AT)
-                                                planes_prune(sh, n, k, gthr);
-                                        if (!uni(anyp))
-                                                break;
+                                        if (__builtin_amdgcn_ballot_w64(pend) != 0ull)
+                                                break; // no room: to the barrier, the offers are made again behind it
+                                        have = false;
+                                        chunk += PLK_WG / 64;
                                 }
+                                PROF_LAP(2);
+                                if (!(meet(chunk < nchunks) & 1u))
+                                        break;
                         }
-                        planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k, gthr); // (no seeds: still the query's shared threshold, if there is one)
-                        planes_filter(sh, nslots);
                 }
-                uint32_t c0 = 0, c1 = 0, rows_mask = 0; // the current sub-window's candidates (per lane) and the decoded slots that put something into its LDS planes
-                bool open = false;                      // the current sub-window has been swept (its candidates are being worked off)
-                for (;;) {
-                        // (threshold and filter move only at a prune, i.e. behind the barrier below: read once per stretch)
-                        const bool full = uni(sh.tk_full) != 0;
-                        const double thr_s = sh.thr_s;
-                        const uint32_t thr_d = sh.thr_d;
-                        const uint32_t esel = uni(sh.esel);
-                        uint32_t es_a = 0, es_b = 0, es_c = 0; // the essential planes as bit sets over the slots
+                // ---- the threshold after phase A (or another range's), the sweep's tables
+                planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k, gthr);
+                const bool sweep_on = sweepable && nd != 0;
+                if (sweep_on)
+                        planes_filter(sh, nd);
+                PROF_LAP(3);
+                // ---- PHASE B: the sweep over the dense slots.  Every WAVE walks its own contiguous share of the task's range, a sub-window of PLK_SW
+                //      documents (two consecutive words per lane) at a time, wave-synchronously: no workgroup barrier inside.  Three stages in
+                //      flight per wave: (1) plane A of the next PF sub-windows is on its way into the register ring; (2) the sub-window whose A
+                //      words have arrived is swept — predicate, count, presence filter — and the lanes whose words hold a candidate send for their
+                //      B / C words; (3) the sub-window swept one step earlier, whose B / C words have arrived by now, has its candidates put through
+                //      the level table and scored.
+                auto sweep = [&](auto NDc) {
+                        constexpr uint32_t ND = decltype(NDc)::value;
+                        constexpr uint32_t PF = PlkRing<(int)ND>::PF;
+                        const uint32_t nsw = (wend - wfirst) * (PL_W / PLK_SW);
+                        const uint32_t sw_first = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * wave / (PLK_WG / 64));
+                        const uint32_t sw_end = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * (wave + 1) / (PLK_WG / 64));
+                        uint32_t sw = sw_first;
+                        const uint2 *pa2[ND];
 #pragma unroll
-                        for (uint32_t s = 0; s < NS; ++s) {
-                                const uint32_t e = (esel >> (2 * s)) & 3u;
-                                es_a |= (e == 0 ? 1u : 0u) << s;
-                                es_b |= (e == 1 ? 1u : 0u) << s;
-                                es_c |= (e == 2 ? 1u : 0u) << s;
-                        }
-                        const bool fall = uni(sh.fall) != 0;
-                        while (sw < sw_end) {
-                                if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
-                                        break; // the buffer wants pruning first: to the barrier (the sub-window stays as it is)
-                                const uint32_t w0 = sw * PLK_SW, wE = w0 + PLK_SW;
-                                // The level words of one of this lane's two words of the sub-window (which: 0 / 1): a = plane A, b = plane B (frequency not 1),
-                                // c = plane C (nor 2) — a head term's from the batch's term planes, a decoded slot's from the wave's LDS planes.  Fetched when
-                                // needed (the sweep; a candidate's scoring) and not kept.  Straight-line on purpose: every load is issued — a slot without a
-                                // term plane reads row 0's words, one without LDS planes reads slot 0's, and the uniform selects drop them — so that one wait
-                                // covers them all; every address is a scalar base plus the lane's offset.  (Round 4 measured the other way — words b / c loaded
-                                // only where word a has a bit: cfg3 10.5 -> 14.4 ms; the branch and the second wait cost more than the loads they save.)
-                                auto plane_words = [&](const uint32_t which, uint32_t (&ga)[NS], uint32_t (&gb)[NS], uint32_t (&gc)[NS]) { // the term planes' part: global loads
-                                        const uint32_t wi = lane + which * 64u;
+                        for (uint32_t i = 0; i < ND; ++i)
+                                pa2[i] = reinterpret_cast<const uint2 *>(pA[i]); // (rows and sub-windows are multiples of 128 words: 8-byte aligned)
+                        const uint2 *const mk2 = reinterpret_cast<const uint2 *>(masked);
+                        const uint32_t plw2 = plw >> 1; // (plw is a multiple of the window's words)
+                        uint2 ring[PF][ND], ringm[PF];
+                        auto fetch_a = [&](const uint32_t sw_, uint2 (&g)[ND], uint2 &gm) {
+                                const uint32_t wb = sw_ * (PLK_SW_WORDS / 2) + lane;
 #pragma unroll
-                                        for (uint32_t s = 0; s < NS; ++s) {
-                                                const uint32_t gi = prows[s] != PL_NONE ? (w0 >> 5) + wi : wi; // (a plane is far below 2^32 bytes: a 32-bit offset)
-                                                const uint32_t *pa = pA[s], *pb = pa + plw, *pc = pb + plw;
-                                                ga[s] = pa[gi];
-                                                gb[s] = pb[gi];
-                                                gc[s] = pc[gi];
-                                        }
-                                };
-                                auto finish_words = [&](const uint32_t which, const uint32_t (&ga)[NS], const uint32_t (&gb)[NS], const uint32_t (&gc)[NS], uint32_t (&a)[NS],
-                                                        uint32_t (&b)[NS], uint32_t (&c)[NS]) { // ... the decoded slots' part (LDS)
-                                        const uint32_t wi = lane + which * 64u;
-                                        // (no selects: a slot with term planes reads the zero LDS plane here, a decoded slot read the batch's zero row there)
+                                for (uint32_t i = 0; i < ND; ++i)
+                                        g[i] = pa2[i][i < nd ? wb : lane]; // (a position beyond nd reads the all-zero row)
+                                if (masked)
+                                        gm = mk2[wb];
+                        };
+                        // stage 3's registers: the kept sub-window (ksw), its A words, its candidates, its B / C words (in flight after stage 2)
+                        uint2 ka[ND], kb[ND], kc[ND], kcand = make_uint2(0u, 0u);
+                        uint32_t ksw = 0;
+                        bool kpend = false; // (uniform)
 #pragma unroll
-                                        for (uint32_t s = 0; s < NS; ++s) {
-                                                a[s] = ga[s];
-                                                b[s] = gb[s];
-                                                c[s] = gc[s];
-                                        }
-                                        if (rows_mask) { // (uniform: a sub-window no decoded list reaches reads no LDS)
+                        for (uint32_t i = 0; i < ND; ++i)
+                                ka[i] = kb[i] = kc[i] = make_uint2(0u, 0u);
+                        for (;;) {
+                                // (threshold and tables move only at a prune, i.e. behind the barrier below: read once per stretch)
+                                const bool full = uni(sh.tk_full) != 0;
+                                const double thr_s = sh.thr_s;
+                                const uint32_t thr_d = sh.thr_d;
+                                const uint32_t esel = uni(sh.esel), atab = uni(sh.atab);
+                                uint32_t es_a = 0, es_b = 0, es_c = 0; // the essential planes as bit sets over the dense positions
 #pragma unroll
-                                                for (uint32_t s = 0; s < NS; ++s) {
-                                                        const uint32_t *lp = ((sparse_mask >> s) & 1u) ? &sh.pl[wave][lidx[s]][0] : &sh.zero[0];
-                                                        a[s] |= lp[wi];
-                                                        b[s] |= lp[PLK_SW_STRIDE + wi];
-                                                }
-                                        }
-                                };
-                                auto level_words = [&](const uint32_t which, uint32_t (&a)[NS], uint32_t (&b)[NS], uint32_t (&c)[NS]) {
-                                        uint32_t ga[NS], gb[NS], gc[NS];
-                                        plane_words(which, ga, gb, gc);
-                                        finish_words(which, ga, gb, gc, a, b, c);
-                                };
-                                // One step over the candidates `cw` of one word: every lane that has one takes its lowest, scores it from the level words
-                                // a / b / c — the known part of the score and a bound for the rest — and offers it, queues it (a slot of unknown
-                                // frequency that the bound does not rule out) or drops it.  false: the buffer had no room (the candidate stays).
-                                auto candidate_step = [&](const uint32_t which, const uint32_t (&a)[NS], const uint32_t (&b)[NS], const uint32_t (&c)[NS], uint32_t &cw) {
+                                for (uint32_t i = 0; i < ND; ++i) {
+                                        const uint32_t e = (esel >> (2 * i)) & 3u;
+                                        es_a |= (e == 0 ? 1u : 0u) << i;
+                                        es_b |= (e == 1 ? 1u : 0u) << i;
+                                        es_c |= (e == 2 ? 1u : 0u) << i;
+                                }
+                                es_a = uni(es_a), es_b = uni(es_b), es_c = uni(es_c);
+                                const uint32_t es_any = es_a | es_b | es_c;
+                                (void)es_any, (void)atab;
+                                const bool fall = uni(sh.fall) != 0;
+                                // One step over the candidates `cw` of one word of the kept sub-window: every lane that has one takes its lowest, scores it
+                                // from the level words — the known part of the score and a bound for the rest — and offers it, queues it (a slot of
+                                // unknown frequency that the bound does not rule out) or drops it.  A document of a sparse list is dropped: phase A has
+                                // scored it.  false from offer: the buffer had no room (the candidate stays).
+                                auto candidate_step = [&](const uint32_t which, uint32_t &cw) {
                                         bool enq = false;
                                         uint32_t edoc = 0, elev = 0;
                                         if (cw) {
                                                 const uint32_t bit = (uint32_t)__builtin_ctz(cw);
-                                                const uint32_t doc = w0 + 32u * (lane + which * 64u) + bit;
-                                                double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
-                                                uint32_t levels = 0;
-                                                bool unk = false;
+                                                const uint32_t doc = ksw * PLK_SW + 32u * (2u * lane + which) + bit;
+                                                const uint32_t hb = (sh.hf[(doc & (PLK_HF - 1u)) >> 2] >> (8u * (doc & 3u))) & 0xffu;
+                                                bool sparse_doc = false;
+                                                if (hb) {
 #pragma unroll
-                                                for (uint32_t s = 0; s < NS; ++s) {
-                                                        if (!top[s] || !((a[s] >> bit) & 1u))
-                                                                continue;
-                                                        const uint32_t bb = (b[s] >> bit) & 1u, cc = (c[s] >> bit) & 1u;
-                                                        const uint32_t l = 1u + bb + (bb & cc);
-                                                        levels |= l << (2 * s);
-                                                        if (l < top[s])
-                                                                sk += sh.wl[s][l];
-                                                        else {
-                                                                unk = true;
-                                                                sb += sh.wf[s][l];
-                                                        }
+                                                        for (uint32_t j = 0; j < PLK_MAX_SPARSE; ++j)
+                                                                if (j < nsp && ((hb >> j) & 1u))
+                                                                        sparse_doc = sparse_doc || planes_list_find(lists + sp_off[j], sp_n32[j], doc) != PLK_PAD;
                                                 }
                                                 bool done = true;
-                                                if (!full || better(sk + sb, doc, thr_s, thr_d)) {
-                                                        if (unk) {
-                                                                enq = true;
-                                                                edoc = doc;
-                                                                elev = levels;
-                                                        } else
-                                                                done = offer(sk, doc); // (no room: the candidate stays for after the prune)
+                                                if (!sparse_doc) {
+                                                        double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
+                                                        uint32_t levels = 0;
+                                                        bool unk = false;
+#pragma unroll
+                                                        for (uint32_t i = 0; i < ND; ++i) {
+                                                                const uint32_t aw = which ? ka[i].y : ka[i].x, bw = which ? kb[i].y : kb[i].x, cwd = which ? kc[i].y : kc[i].x;
+                                                                if (!((leafd >> i) & 1u) || !((aw >> bit) & 1u))
+                                                                        continue;
+                                                                const uint32_t bb = (bw >> bit) & 1u, cc = (cwd >> bit) & 1u;
+                                                                const uint32_t l = 1u + bb + (bb & cc);
+                                                                levels |= l << (2u * dsl[i]);
+                                                                if (l < 3u)
+                                                                        sk += sh.wl[dsl[i]][l];
+                                                                else {
+                                                                        unk = true;
+                                                                        sb += sh.dwf[i][3];
+                                                                }
+                                                        }
+                                                        if (!full || better(sk + sb, doc, thr_s, thr_d)) {
+                                                                if (unk) {
+                                                                        enq = true;
+                                                                        edoc = doc;
+                                                                        elev = levels;
+                                                                } else
+                                                                        done = offer(sk, doc); // (no room: the candidate stays for after the prune)
+                                                        }
                                                 }
                                                 if (done)
                                                         cw &= cw - 1u;
@@ -905,210 +996,206 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         }
                                         qn += (uint32_t)__popcll(em);
                                 };
-                                bool stuck = false; // (the buffer filled up under a candidate)
-                                if (!open) {
-                                        // (the term planes' words of both of this lane's words travel together with the lists' entries: one round trip)
-                                        uint32_t g0a[NS], g0b[NS], g0c[NS], g1a[NS], g1b[NS], g1c[NS];
-                                        plane_words(0, g0a, g0b, g0c);
-                                        plane_words(1, g1a, g1b, g1c);
-                                        // ---- set pass: the decoded slots' entries of this sub-window, 64 per slot and round, into the wave's LDS planes
-                                        rows_mask = 0;
-                                        for (;;) {
-                                                uint32_t ent[NS];
-                                                bool more = false;
-#pragma unroll
-                                                for (uint32_t s = 0; s < NS; ++s) { // (all the slots' loads first: one round trip)
-                                                        ent[s] = PLK_PAD;
-                                                        if (!((sparse_mask >> s) & 1u))
-                                                                continue;
-                                                        if (curv[s] >= sp_n32[s])
-                                                                continue;
-                                                        rows_mask |= 1u << s;
-                                                        if (curv[s] + lane < sp_n32[s])
-                                                                ent[s] = lists[sp_off[s] + curv[s] + lane];
-                                                }
-#pragma unroll
-                                                for (uint32_t s = 0; s < NS; ++s) {
-                                                        if (!((rows_mask >> s) & 1u))
-                                                                continue;
-                                                        const uint32_t e = ent[s], d = e >> 1;
-                                                        const bool before = d < wE; // (ascending: the entries below the sub-window's end are a prefix of the chunk)
-                                                        if (before && d >= w0) {
-                                                                uint32_t *p = &sh.pl[wave][lidx[s]][0];
-                                                                const uint32_t r = d - w0, bit = 1u << (r & 31u);
-                                                                atomicOr(&p[r >> 5], bit);
-                                                                if (e & 1u)
-                                                                        atomicOr(&p[PLK_SW_STRIDE + (r >> 5)], bit);
-                                                        }
-                                                        const uint32_t cnt = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(before));
-                                                        curv[s] += cnt;
-                                                        more |= cnt == 64; // (the whole chunk lies below the sub-window's end: there may be more)
-                                                }
-                                                if (!more)
-                                                        break;
-                                        }
-                                        PROF_LAP(8);
-                                        // ---- sweep, one word at a time: the predicate, then the candidate filter (planes_filter) on the level words
-                                        uint32_t cand[2];
-                                        bool later = false; // (the queue or the buffer is full: what is left of the candidates goes through the resume path)
+                                // stage 3 on the kept sub-window; false: it stopped short (the queue or the buffer is full) — the rest after the meet
+                                auto stage3 = [&]() {
+                                        bool short_ = false;
 #pragma unroll
                                         for (uint32_t which = 0; which < 2; ++which) {
-                                                uint32_t a[NS], b[NS], c[NS];
+                                                uint32_t cw = which ? kcand.y : kcand.x;
+                                                if (__builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
+                                                        if (!fall) {
+                                                                // the documents in an essential plane, word-wise; each of them then with its level vector in the table
+                                                                uint32_t ew = 0;
+                                                                static_for<ND>([&](auto I) { ew = and_or(which ? ka[I].y : ka[I].x, umask_at<I>(es_a), ew); });
+                                                                if (es_b) {
+                                                                        static_for<ND>([&](auto I) { ew = and_or(which ? kb[I].y : kb[I].x, umask_at<I>(es_b), ew); });
+                                                                }
+                                                                if (es_c) {
+                                                                        static_for<ND>([&](auto I) { ew = and_or(which ? kc[I].y : kc[I].x, umask_at<I>(es_c), ew); });
+                                                                }
+                                                                ew &= cw;
+                                                                cw = 0;
+                                                                if (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
+                                                                        // the planes are nested, the level is the number of them a document is in: its two bits, word-wise
+                                                                        uint32_t lo[ND], hi[ND];
+#pragma unroll
+                                                                        for (uint32_t i = 0; i < ND; ++i) {
+                                                                                const uint32_t aw = which ? ka[i].y : ka[i].x, bw = which ? kb[i].y : kb[i].x, cwd = which ? kc[i].y : kc[i].x;
+                                                                                lo[i] = ((leafd >> i) & 1u) ? aw ^ bw ^ cwd : 0u; // (a slot without a scorer: level 0)
+                                                                                hi[i] = ((leafd >> i) & 1u) ? bw : 0u;
+                                                                        }
+                                                                        do {
+                                                                                const uint32_t bit = ew ? (uint32_t)__builtin_ctz(ew) : 0u;
+                                                                                uint32_t code = 0;
+#pragma unroll
+                                                                                for (uint32_t i = 0; i < ND; ++i)
+                                                                                        code |= (((lo[i] >> bit) & 1u) << (2 * i)) | (((hi[i] >> bit) & 1u) << (2 * i + 1));
+                                                                                const uint32_t hit = (sh.ftab[code >> 5] >> (code & 31u)) & 1u;
+                                                                                cw |= ew ? hit << bit : 0u;
+                                                                                ew &= ew - 1u;
+                                                                                PROF_COUNT(20, lane == 0 ? 1 : 0);
+                                                                        } while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull);
+                                                                }
+                                                        }
+                                                        while (!short_ && __builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
+                                                                if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
+                                                                        short_ = true;
+                                                                        PROF_COUNT(23, lane == 0 ? 1 : 0);
+                                                                } else
+                                                                        candidate_step(which, cw);
+                                                        }
+                                                        PROF_COUNT(21, lane == 0 ? 1 : 0);
+                                                }
                                                 if (which)
-                                                        finish_words(1, g1a, g1b, g1c, a, b, c);
+                                                        kcand.y = cw;
                                                 else
-                                                        finish_words(0, g0a, g0b, g0c, a, b, c);
-                                                // (the slots' roles are uniform bit sets: a role's word is and_or'ed together under scalar masks — one vector
-                                                //  instruction per slot and role, where a select costs two and a scalar one)
-                                                uint32_t m = 0xffffffffu;
-#pragma unroll
-                                                for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g) {
-                                                        if (g >= nreq)
-                                                                break;
-                                                        uint32_t x = 0;
-                                                        static_for<NS>([&](auto S) { x = and_or(a[S], umask_at<S>(gsl[g]), x); });
-                                                        m &= x;
-                                                }
-                                                if (negs) {
-                                                        uint32_t nx = 0;
-                                                        static_for<NS>([&](auto S) { nx = and_or(a[S], umask_at<S>(negs), nx); });
-                                                        m &= ~nx;
-                                                }
-                                                if (masked) // masked_documents_registry::test (docidupdates.h:90-119)
-                                                        m &= ~masked[(w0 >> 5) + lane + which * 64u];
-                                                my_matches += (uint32_t)__popc(m);
-                                                // the candidate filter: the documents in an essential plane, word-wise; each of them then with its level
-                                                // vector in the table (one per lane and step)
-                                                uint32_t seeded = 0; // (documents the seed pass has scored: never candidates here)
-                                                if (seedmask) {
-                                                        static_for<NS>([&](auto S) { seeded = and_or(a[S], umask_at<S>(seedmask), seeded); });
-                                                }
-                                                uint32_t cw = m & ~seeded;
-                                                if (!fall) {
-                                                        uint32_t ew = 0;
-                                                        static_for<NS>([&](auto S) { ew = and_or(a[S], umask_at<S>(es_a), ew); });
-                                                        if (es_b) {
-                                                                static_for<NS>([&](auto S) { ew = and_or(b[S], umask_at<S>(es_b), ew); });
-                                                        }
-                                                        if (es_c) {
-                                                                static_for<NS>([&](auto S) { ew = and_or(c[S], umask_at<S>(es_c), ew); });
-                                                        }
-                                                        ew &= m & ~seeded;
-                                                        cw = 0;
-                                                        if (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
-                                                        // the planes are nested, the level is the number of them a document is in: its two bits, word-wise
-                                                        uint32_t lo[NS], hi[NS];
-#pragma unroll
-                                                        for (uint32_t s = 0; s < NS; ++s) {
-                                                                lo[s] = ((leafm >> s) & 1u) ? a[s] ^ b[s] ^ c[s] : 0u; // (a slot without a scorer: level 0)
-                                                                hi[s] = ((leafm >> s) & 1u) ? b[s] : 0u;
-                                                        }
-                                                        do {
-                                                                const uint32_t bit = ew ? (uint32_t)__builtin_ctz(ew) : 0u;
-                                                                uint32_t code = 0;
-#pragma unroll
-                                                                for (uint32_t s = 0; s < NS; ++s)
-                                                                        code |= (((lo[s] >> bit) & 1u) << (2 * s)) | (((hi[s] >> bit) & 1u) << (2 * s + 1));
-                                                                const uint32_t hit = (sh.ftab[code >> 5] >> (code & 31u)) & 1u;
-                                                                cw |= ew ? hit << bit : 0u;
-                                                                ew &= ew - 1u;
-                                                                PROF_COUNT(20, lane == 0 ? 1 : 0);
-                                                        } while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull);
-                                                        }
-                                                }
-                                                // the word's candidates are worked off right here, while its level words are in registers (a sub-window
-                                                // of a union has one or two: a step of their own, with the words fetched again, cost more than the sweep)
-                                                // (no call in here — the queue is worked off, and a full buffer waited out, in the resume path below: a call
-                                                //  among the sweep's live registers made the compiler spill them on the hot path)
-                                                PROF_LAP(9);
-                                                while (!later && __builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
-                                                        if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
-                                                                later = true;
-                                                                PROF_COUNT(23, lane == 0 ? 1 : 0);
-                                                        }
-                                                        else
-                                                                candidate_step(which, a, b, c, cw);
-                                                }
-                                                cand[which] = cw;
-                                                PROF_LAP(10);
+                                                        kcand.x = cw;
                                         }
-                                        c0 = cand[0], c1 = cand[1];
-                                        open = true;
-                                        PROF_COUNT(19, lane == 0 ? 1 : 0);
-                                }
-                                // ---- candidates left over from before a prune: the same steps, with the level words fetched again
-                                while (!stuck && __builtin_amdgcn_ballot_w64((c0 | c1) != 0) != 0ull) {
-                                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
-                                                stuck = true;
-                                                break;
+                                        kpend = __builtin_amdgcn_ballot_w64((kcand.x | kcand.y) != 0) != 0ull;
+                                        return !short_;
+                                };
+                                bool done = false;
+                                for (;;) { // the hot segments of this stretch (a segment ends where the queue wants working off, or at the stretch's end)
+#pragma unroll
+                                        for (uint32_t r = 0; r < PF; ++r) { // (re)fill the ring: the next PF sub-windows' A words
+                                                if (sw + r < sw_end)
+                                                        fetch_a(sw + r, ring[r], ringm[r]);
                                         }
-                                        if (qn >= 64) { // (a step may add 64 entries: the queue is kept below 64 before it)
+                                        bool stop = false;
+                                        while (!stop && (sw < sw_end || kpend)) {
+                                                static_for<PF>([&](auto R) {
+                                                        constexpr uint32_t r = decltype(R)::value;
+                                                        if (stop || !(sw < sw_end || kpend)) // (uniform)
+                                                                return;
+                                                        if (kpend) {
+                                                                if (!stage3()) {
+                                                                        stop = true;
+                                                                        return;
+                                                                }
+                                                                PROF_LAP(9);
+                                                        }
+                                                        if (!(sw < sw_end))
+                                                                return;
+                                                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
+                                                                stop = true; // the buffer wants pruning first: to the barrier (the sub-window stays as it is)
+                                                                return;
+                                                        }
+                                                        // ---- stage 2: the sub-window whose A words the ring holds
+                                                        uint32_t p[ND], qq[ND];
+#pragma unroll
+                                                        for (uint32_t i = 0; i < ND; ++i) {
+                                                                p[i] = ring[r][i].x;
+                                                                qq[i] = ring[r][i].y;
+                                                        }
+                                                        // the predicate word-wise (the slots' roles are uniform bit sets: a role's word is and_or'ed together under scalar
+                                                        // masks — one vector instruction per slot, word and role), the match count
+                                                        uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;
+#pragma unroll
+                                                        for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g) {
+                                                                if (g >= nreq)
+                                                                        break;
+                                                                uint32_t x0 = 0, x1 = 0;
+                                                                static_for<ND>([&](auto I) {
+                                                                        const uint32_t mk = umask_at<I>(gd[g]);
+                                                                        x0 = and_or(p[I], mk, x0);
+                                                                        x1 = and_or(qq[I], mk, x1);
+                                                                });
+                                                                m0 &= x0;
+                                                                m1 &= x1;
+                                                        }
+                                                        if (negd) {
+                                                                uint32_t n0 = 0, n1 = 0;
+                                                                static_for<ND>([&](auto I) {
+                                                                        const uint32_t mk = umask_at<I>(negd);
+                                                                        n0 = and_or(p[I], mk, n0);
+                                                                        n1 = and_or(qq[I], mk, n1);
+                                                                });
+                                                                m0 &= ~n0;
+                                                                m1 &= ~n1;
+                                                        }
+                                                        if (masked) { // masked_documents_registry::test (docidupdates.h:90-119)
+                                                                m0 &= ~ringm[r].x;
+                                                                m1 &= ~ringm[r].y;
+                                                        }
+                                                        my_matches += (uint32_t)__popc(m0) + (uint32_t)__popc(m1);
+                                                        uint32_t c0 = m0, c1 = m1;
+                                                        if (!fall) {
+                                                                // the presence filter: can the slots a document HOLDS reach the threshold at all?  Up to five dense slots:
+                                                                // exactly (the table looked up word-wise); more: MaxScore's essential slots — a candidate holds one of them
+                                                                uint32_t f0 = 0, f1 = 0;
+                                                                if constexpr (ND <= 5) {
+                                                                        planes_presence_tree<ND, 0, ND>(atab, p, qq, f0, f1);
+                                                                        const uint32_t cz = umask_at<0>(atab); // (a threshold nothing is needed for)
+                                                                        f0 |= cz;
+                                                                        f1 |= cz;
+                                                                } else {
+                                                                        static_for<ND>([&](auto I) {
+                                                                                const uint32_t mk = umask_at<I>(es_any);
+                                                                                f0 = and_or(p[I], mk, f0);
+                                                                                f1 = and_or(qq[I], mk, f1);
+                                                                        });
+                                                                }
+                                                                c0 &= f0;
+                                                                c1 &= f1;
+                                                        }
+                                                        // hand over to stage 3: the A words and the candidates stay, the B / C words are sent for — by the lanes that hold a
+                                                        // candidate; the others read the all-zero row's first words (one cache line for the whole wave)
+                                                        kcand = make_uint2(c0, c1);
+                                                        ksw = sw;
+                                                        kpend = __builtin_amdgcn_ballot_w64((c0 | c1) != 0) != 0ull;
+                                                        {
+                                                                const bool mine = (c0 | c1) != 0;
+                                                                const uint32_t wb = sw * (PLK_SW_WORDS / 2) + lane;
+#pragma unroll
+                                                                for (uint32_t i = 0; i < ND; ++i) {
+                                                                        ka[i] = ring[r][i];
+                                                                        const uint2 *src = mine && i < nd ? pa2[i] + wb : reinterpret_cast<const uint2 *>(planes + (size_t)zrow * PL_PLANES * plw) + lane;
+                                                                        kb[i] = src[plw2];
+                                                                        kc[i] = src[2 * plw2];
+                                                                }
+                                                        }
+                                                        // ... and the ring's place goes to the sub-window PF ahead
+                                                        if (sw + PF < sw_end)
+                                                                fetch_a(sw + PF, ring[r], ringm[r]);
+                                                        ++sw;
+                                                        PROF_COUNT(19, lane == 0 ? 1 : 0);
+                                                        PROF_LAP(8);
+                                                });
+                                        }
+                                        // the queue is worked off out here: a call among the sweep's live registers would have the compiler spill them on the hot path
+                                        while (qn >= 64 && uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) < PLK_PRUNE_AT)
                                                 work_queue();
-                                                continue;
-                                        }
-                                        const uint32_t which = c0 ? 0u : 1u; // (lanes without a candidate fetch word 1 and drop it)
-                                        uint32_t a[NS], b[NS], c[NS];
-                                        level_words(which, a, b, c);
-                                        uint32_t cw = which ? c1 : c0;
-                                        candidate_step(which, a, b, c, cw);
-                                        if (which)
-                                                c1 = cw;
-                                        else
-                                                c0 = cw;
+                                        done = !(sw < sw_end || kpend);
+                                        if (done || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
+                                                break;
                                 }
-                                PROF_LAP(11);
-                                if (stuck)
+                                PROF_LAP(4);
+                                // ---- the waves meet: prune if the buffer wants it, go on while any of them has work left
+                                const uint32_t mres = meet(!done);
+                                if (mres & 2u)
+                                        planes_filter(sh, nd);
+                                if (!(mres & 1u))
                                         break;
-                                // the sub-window is done: its LDS planes are cleared for the next one
-#pragma unroll
-                                for (uint32_t s = 0; s < NS; ++s)
-                                        if ((rows_mask >> s) & 1u) {
-                                                uint32_t *p = &sh.pl[wave][lidx[s]][0];
-                                                p[lane] = 0;
-                                                p[lane + 64] = 0;
-                                                p[PLK_SW_STRIDE + lane] = 0;
-                                                p[PLK_SW_STRIDE + lane + 64] = 0;
-                                        }
-                                open = false;
-                                ++sw;
-                                PROF_LAP(12);
                         }
-                        PROF_LAP(4);
-                        // ---- the waves meet: prune if the buffer wants it, go on while any of them has sub-windows left
-                        sh.flag[wave] = sw < sw_end ? 1u : 0u; // (wave-uniform value, every lane stores it)
-                        __syncthreads();
-                        uint32_t anyp = 0;
-#pragma unroll
-                        for (uint32_t wv = 0; wv < PLK_WG / 64; ++wv)
-                                anyp |= sh.flag[wv];
-                        anyp = uni(anyp);
-                        const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
-                        __syncthreads(); // (every lane has read the flags and tk_n)
-                        if (n >= PLK_PRUNE_AT) {
-                                planes_prune(sh, n, k, gthr);
-                                planes_filter(sh, nslots);
-                                PROF_COUNT(18, tid == 0 ? 1 : 0);
-                        }
-                        PROF_LAP(5);
-                        if (!anyp)
-                                break;
+                };
+                if (sweep_on) {
+                        if constexpr (NS == PLK_NS_SMALL) {
+                                if (nd <= 1)
+                                        sweep(std::integral_constant<uint32_t, 1>{});
+                                else if (nd == 2)
+                                        sweep(std::integral_constant<uint32_t, 2>{});
+                                else if (nd == 3)
+                                        sweep(std::integral_constant<uint32_t, 3>{});
+                                else
+                                        sweep(std::integral_constant<uint32_t, 5>{});
+                        } else
+                                sweep(std::integral_constant<uint32_t, (uint32_t)NS>{});
                 }
                 // ---- the candidates still waiting for their frequencies
                 for (;;) {
                         while (qn && uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) < PLK_PRUNE_AT)
                                 work_queue();
-                        sh.flag[wave] = qn ? 1u : 0u; // (wave-uniform value, every lane stores it)
-                        __syncthreads();
-                        uint32_t anyp = 0;
-#pragma unroll
-                        for (uint32_t wv = 0; wv < PLK_WG / 64; ++wv)
-                                anyp |= sh.flag[wv];
-                        anyp = uni(anyp);
-                        const uint32_t n = min(uni(sh.tk_n), PLK_CAP);
-                        __syncthreads(); // (every lane has read the flags and tk_n)
-                        if (n >= PLK_PRUNE_AT)
-                                planes_prune(sh, n, k, gthr);
-                        if (!anyp)
+                        if (!(meet(qn != 0) & 1u))
                                 break;
                 }
                 // ---- the task's result: its best k (ranked) and its match count
@@ -1117,7 +1204,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1)
                         my_matches += __shfl_xor(my_matches, d, 64);
-                atomicAdd(&sh.matches, lane == 0 ? my_matches : 0u); // (every lane issues it: no single-lane branch)
+                atomicAdd(&sh.matches, lane == 0 ? my_matches : 0u); // (every lane issues it: no single-lane branch; the corrections wrap, the sum does not)
                 __syncthreads();
                 const uint32_t n = uni(sh.tk_n);
                 for (uint32_t i = tid; i < n; i += PLK_WG) {
