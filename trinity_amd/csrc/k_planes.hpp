@@ -160,6 +160,7 @@ constexpr uint32_t PLK_WQ = 128;        // per-wave queue of candidates waiting 
 constexpr uint32_t PLK_PAD = 0xffffffffu; // list padding (sorts last)
 constexpr uint32_t PLK_SW_WORDS = 128;    // a wave's sub-window: two consecutive words (64 documents) per lane ...
 constexpr uint32_t PLK_SW = PLK_SW_WORDS * 32; // ... 4096 documents
+constexpr uint32_t PLK_CQ = 64 + 2 * 64;   // per-wave queue of candidate words: a batch of 64 plus what one sub-window can add
 constexpr uint32_t PLK_HF = 32768;        // hashed filter of the task's sparse documents: one byte per docID & (PLK_HF - 1), bit j = sparse list j may hold it
 static_assert(PL_W % PLK_SW == 0, "a task's windows split into whole sub-windows");
 static_assert(PLK_CAP == PLK_WG && TOPK_MAX < PLK_PRUNE_AT && PLK_PRUNE_AT < PLK_CAP, "pruning leaves room; a pruned buffer is below the stop mark");
@@ -186,8 +187,23 @@ struct PlanesShared {
         uint32_t bcast[4];
         uint32_t sp_row0[FUS_MAX_SLOTS], sp_n[FUS_MAX_SLOTS], sp_base[FUS_MAX_SLOTS]; // sparse slots: first row, rows, first entry of the list in the scratch region
         uint32_t hf[PLK_HF / 4];      // the hashed filter (bytes)
+        // the sweep's arguments (planes_sweep_segment: a function of its own, so that its registers are allocated apart from the rest of the kernel's)
+        struct SweepArgs {
+                uint32_t nd, nreq, negd, leafd, nsp, zrow;
+                uint32_t dsl[FUS_MAX_SLOTS], prow[FUS_MAX_SLOTS], gd[FUS_MAX_SLOTS]; // dense position -> slot, -> plane row; required groups as sets of dense positions
+                uint32_t sp_off[PLK_MAX_SPARSE], sp_n32[PLK_MAX_SPARSE];            // the sparse lists (a sweep candidate found in one of them is phase A's)
+        } sa;
+        // ... and each wave's state between two segments: its next sub-window, its share's end, its two queues' fill
+        uint32_t w_sw[PLK_WG / 64], w_end[PLK_WG / 64], w_qn[PLK_WG / 64], w_cqn[PLK_WG / 64];
+        uint32_t cq[PLK_WG / 64][PLK_CQ][2]; // per wave: words that hold candidates {word of the plane row, candidate bits}, worked off 64 at a time
         DevFused fq;
 };
+// ONE object for the kernel and the functions it calls: a static __shared__ behind an accessor keeps every access a plain LDS instruction
+// (a reference handed to a non-inlined function would arrive as a flat pointer)
+__device__ __forceinline__ PlanesShared &plk_shared() {
+        __shared__ PlanesShared sh;
+        return sh;
+}
 static_assert(sizeof(PlanesShared) * PLK_WGS_PER_CU <= 160u * 1024u, "the workgroups of a CU share its LDS");
 
 // A row of a decoded slot into its list: 32 entries per row (docID << 1 | frequency-is-not-1), the unused ones of a short last row padded.
@@ -439,7 +455,8 @@ template <uint32_t POS> __device__ __forceinline__ uint32_t umask_at(const uint3
         // (volatile: made where it is used — hoisted out of the window loop, the dozens of masks of a query spill to vector lanes and come back
         //  through v_readlane, a vector instruction each)
         uint32_t r;
-        asm volatile("s_bfe_i32 %0, %1, %2" : "=s"(r) : "s"(bits), "n"(POS | 0x10000u) : "scc");
+        const uint32_t sbits = (uint32_t)__builtin_amdgcn_readfirstlane((int)bits); // (folded away where the compiler knows the value to be uniform)
+        asm volatile("s_bfe_i32 %0, %1, %2" : "=s"(r) : "s"(sbits), "n"(POS | 0x10000u) : "scc");
         return r;
 }
 template <uint32_t N, typename F> __device__ __forceinline__ void static_for(F &&f) { // f(integral_constant 0) ... f(integral_constant N - 1)
@@ -475,8 +492,13 @@ __device__ __forceinline__ void planes_presence_tree(const uint32_t T, const uin
         }
 }
 
+// pointers into global memory, said so: a function that is not a kernel sees its pointer arguments as generic, and every access through them
+// becomes a flat instruction (both memory counters, a vector address)
+typedef const __attribute__((address_space(1))) uint32_t *PlkG1;
+typedef uint32_t PlkU2 __attribute__((ext_vector_type(2))); // (a built-in vector: loads through an address-space pointer need no operator=)
+typedef const __attribute__((address_space(1))) PlkU2 *PlkG2;
 // the entry of `doc` in a sorted list of n entries (docID << 1 | flag; padding sorts last), PLK_PAD when it holds none
-__device__ __forceinline__ uint32_t planes_list_find(const uint32_t *__restrict__ ls, const uint32_t n, const uint32_t doc) {
+template <typename P> __device__ __forceinline__ uint32_t planes_list_find(const P ls, const uint32_t n, const uint32_t doc) {
         uint32_t lo = 0, hi = n;
         const uint32_t key = doc << 1;
         while (lo < hi) {
@@ -494,6 +516,368 @@ __device__ __forceinline__ uint32_t planes_list_find(const uint32_t *__restrict_
 // per wave and sub-window and slot; the CU needs some tens of kilobytes in flight to cover HBM's latency at its share of the bandwidth)
 template <int ND> struct PlkRing { static constexpr uint32_t PF = ND <= 1 ? 4 : ND == 2 ? 3 : ND == 3 ? 2 : 1; };
 
+// ---- PHASE B of k_planes, one SEGMENT of one wave: the sweep over the dense slots.  The wave walks its share of the task's range a sub-window of
+//      PLK_SW documents (two consecutive words per lane) at a time, wave-synchronously — no workgroup barrier inside:
+//      * plane A of the next PF sub-windows is on its way into a register ring while the sub-window whose words have arrived is swept:
+//        predicate, count, presence filter.  These are the ONLY loads of the loop, consumed in the order they were issued: the wave never
+//        waits for the load it has just sent.
+//      * the words that hold a candidate (a few lanes of a sub-window, most sub-windows) go on the wave's queue of candidate WORDS in LDS —
+//        {word of the plane row, candidate bits} —; when 64 wait, every lane takes one: the A / B / C words of all the dense slots for that
+//        word in one round trip, the essential planes, the level table per document, the survivors scored — 64 lanes busy on what one or two
+//        lanes per sub-window would otherwise do behind a round trip of their own.
+//      A function of its own (not inlined): its registers — the ring, a dozen scalar masks — are allocated apart from the rest of the
+//      kernel's (inlined, the compiler spilled the ring to scratch behind every load: a wait per load).  Its arguments and the wave's state
+//      between two segments travel through LDS (PlanesShared::sa, w_*).  Returns 0 when the wave's share is done, 1 when it stopped for the
+//      frequency queue (64 entries wait) or for the candidate buffer (it wants pruning: the waves meet).
+template <typename T> __device__ __forceinline__ T *uni_ptr(T *p) { // a pointer every lane holds alike, as a scalar (a function's arguments arrive in vector registers)
+        const uint64_t v = (uint64_t)p;
+        return (T *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+}
+// ---- a batch of candidate WORDS of one wave (see planes_sweep_segment): the last (up to) 64 of its queue, one per lane — the A / B / C words
+//      of all the dense slots for that word in one round trip, the essential planes, the level table per document, the survivors scored.
+//      `state` in and out: the frequency queue's fill (bits 0..15), the word queue's (16..30); bit 31 out: it stopped short (the frequency
+//      queue or the candidate buffer is full) — what is left of the words' candidates is back on the word queue.  Not inlined: it runs once
+//      per some forty sub-windows, and its registers must not weigh on the sweep's loop.
+template <int ND_>
+__device__ __noinline__ uint32_t planes_work_words(const uint32_t *__restrict__ planes_, const uint32_t plw_, const uint32_t *__restrict__ lists_, const uint32_t state) {
+        constexpr uint32_t ND = (uint32_t)ND_;
+        PlanesShared &sh = plk_shared();
+        const uint32_t lane = threadIdx.x & 63u, wave = uni(threadIdx.x >> 6);
+        const uint32_t *const planes = uni_ptr(planes_), *const lists = uni_ptr(lists_);
+        const uint32_t plw = uni(plw_);
+        uint32_t qn = uni(state) & 0xffffu, cqn = (uni(state) >> 16) & 0x7fffu;
+        const uint32_t nd = uni(sh.sa.nd), leafd = uni(sh.sa.leafd), nsp = uni(sh.sa.nsp);
+        uint32_t dsl[ND];
+        PlkG1 pa1[ND];
+#pragma unroll
+        for (uint32_t i = 0; i < ND; ++i) {
+                dsl[i] = uni(sh.sa.dsl[i]);
+                pa1[i] = (PlkG1)(planes + (size_t)uni(sh.sa.prow[i]) * PL_PLANES * plw);
+        }
+        const PlkG1 lists1 = (PlkG1)lists;
+        const bool full = uni(sh.tk_full) != 0;
+        const double thr_s = sh.thr_s;
+        const uint32_t thr_d = sh.thr_d;
+        const uint32_t esel = uni(sh.esel);
+        uint32_t es_a = 0, es_b = 0, es_c = 0; // the essential planes as bit sets over the dense positions
+#pragma unroll
+        for (uint32_t i = 0; i < ND; ++i) {
+                const uint32_t e = (esel >> (2 * i)) & 3u;
+                es_a |= (e == 0 ? 1u : 0u) << i;
+                es_b |= (e == 1 ? 1u : 0u) << i;
+                es_c |= (e == 2 ? 1u : 0u) << i;
+        }
+        es_a = uni(es_a), es_b = uni(es_b), es_c = uni(es_c);
+        const bool fall = uni(sh.fall) != 0;
+        auto offer = [&](const double sc, const uint32_t doc) __attribute__((always_inline)) { // false: no room (the buffer wants pruning)
+                const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
+                if (slot >= PLK_CAP)
+                        return false;
+                sh.tk_s[slot] = sc;
+                sh.tk_d[slot] = doc;
+                return true;
+        };
+        // ---- a batch of candidate words: the last (up to) 64 of the queue, one per lane.  false: it stopped short (the frequency queue or the
+        //      candidate buffer is full) — what is left of the words' candidates is back on the queue
+        {
+                const uint32_t take_n = min(cqn, 64u), base = cqn - take_n;
+                cqn = base;
+                const bool mine = lane < take_n;
+                const uint32_t wi = mine ? sh.cq[wave][base + lane][0] : lane; // (a lane without a word reads the row's first words and has no candidates)
+                uint32_t cw = mine ? sh.cq[wave][base + lane][1] : 0u;
+                uint32_t a[ND], b[ND], c[ND];
+#pragma unroll
+                for (uint32_t i = 0; i < ND; ++i) { // (all the loads first: one round trip)
+                        const uint32_t at = i < nd ? wi : lane;
+                        a[i] = pa1[i][at];
+                        b[i] = pa1[i][plw + at];
+                        c[i] = pa1[i][2 * plw + at];
+                }
+                if (!fall) {
+                        // the documents in an essential plane, word-wise; each of them then with its level vector in the table
+                        uint32_t ew = 0;
+                        static_for<ND>([&](auto I) __attribute__((always_inline)) { ew = and_or(a[I], umask_at<I>(es_a), ew); });
+                        if (es_b) {
+                                static_for<ND>([&](auto I) __attribute__((always_inline)) { ew = and_or(b[I], umask_at<I>(es_b), ew); });
+                        }
+                        if (es_c) {
+                                static_for<ND>([&](auto I) __attribute__((always_inline)) { ew = and_or(c[I], umask_at<I>(es_c), ew); });
+                        }
+                        ew &= cw;
+                        cw = 0;
+                        // the planes are nested, the level is the number of them a document is in: its two bits, word-wise
+                        uint32_t lo[ND], hi[ND];
+#pragma unroll
+                        for (uint32_t i = 0; i < ND; ++i) {
+                                lo[i] = ((leafd >> i) & 1u) ? a[i] ^ b[i] ^ c[i] : 0u; // (a slot without a scorer: level 0)
+                                hi[i] = ((leafd >> i) & 1u) ? b[i] : 0u;
+                        }
+                        while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
+                                const uint32_t bit = ew ? (uint32_t)__builtin_ctz(ew) : 0u;
+                                uint32_t code = 0;
+#pragma unroll
+                                for (uint32_t i = 0; i < ND; ++i)
+                                        code |= (((lo[i] >> bit) & 1u) << (2 * i)) | (((hi[i] >> bit) & 1u) << (2 * i + 1));
+                                const uint32_t hit = (sh.ftab[code >> 5] >> (code & 31u)) & 1u;
+                                cw |= ew ? hit << bit : 0u;
+                                ew &= ew - 1u;
+                                PROF_COUNT(20, lane == 0 ? 1 : 0);
+                        }
+                }
+                // One step over the words' candidates: every lane that has one takes its lowest, scores it from the level words — the known part
+                // of the score and a bound for the rest — and offers it, queues it (a slot of unknown frequency that the bound does not rule out)
+                // or drops it.  A document of a sparse list is dropped: phase A has scored it.  offer false: no room (the candidate stays).
+                bool short_ = false;
+                while (__builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
+                        if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
+                                short_ = true;
+                                PROF_COUNT(23, lane == 0 ? 1 : 0);
+                                break;
+                        }
+                        bool enq = false;
+                        uint32_t edoc = 0, elev = 0;
+                        if (cw) {
+                                const uint32_t bit = (uint32_t)__builtin_ctz(cw);
+                                const uint32_t doc = 32u * wi + bit;
+                                const uint32_t hb = (sh.hf[(doc & (PLK_HF - 1u)) >> 2] >> (8u * (doc & 3u))) & 0xffu;
+                                bool sparse_doc = false;
+                                if (hb) {
+                                        for (uint32_t j = 0; j < nsp; ++j)
+                                                if ((hb >> j) & 1u)
+                                                        sparse_doc = sparse_doc || planes_list_find(lists1 + sh.sa.sp_off[j], sh.sa.sp_n32[j], doc) != PLK_PAD;
+                                }
+                                bool done = true;
+                                if (!sparse_doc) {
+                                        double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
+                                        uint32_t levels = 0;
+                                        bool unk = false;
+#pragma unroll
+                                        for (uint32_t i = 0; i < ND; ++i) {
+                                                if (!((leafd >> i) & 1u) || !((a[i] >> bit) & 1u))
+                                                        continue;
+                                                const uint32_t bb = (b[i] >> bit) & 1u, cc = (c[i] >> bit) & 1u;
+                                                const uint32_t l = 1u + bb + (bb & cc);
+                                                levels |= l << (2u * dsl[i]);
+                                                if (l < 3u)
+                                                        sk += sh.wl[dsl[i]][l];
+                                                else {
+                                                        unk = true;
+                                                        sb += sh.dwf[i][3];
+                                                }
+                                        }
+                                        if (!full || better(sk + sb, doc, thr_s, thr_d)) {
+                                                if (unk) {
+                                                        enq = true;
+                                                        edoc = doc;
+                                                        elev = levels;
+                                                } else
+                                                        done = offer(sk, doc); // (no room: the candidate stays for after the prune)
+                                        }
+                                }
+                                if (done)
+                                        cw &= cw - 1u;
+                        }
+                        PROF_COUNT(16, lane == 0 ? 1 : 0);
+                        const uint64_t em = __builtin_amdgcn_ballot_w64(enq);
+                        if (enq) {
+                                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                                sh.wq[wave][at][0] = edoc;
+                                sh.wq[wave][at][1] = elev;
+                        }
+                        qn += (uint32_t)__popcll(em);
+                }
+                if (short_) { // the words that still hold candidates go back (the level table has been through them: only survivors are left)
+                        const uint64_t bm = __builtin_amdgcn_ballot_w64(cw != 0);
+                        if (cw) {
+                                const uint32_t at = cqn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                                sh.cq[wave][at][0] = wi;
+                                sh.cq[wave][at][1] = cw;
+                        }
+                        cqn += (uint32_t)__popcll(bm);
+                }
+                PROF_COUNT(21, lane == 0 ? 1 : 0);
+                return qn | cqn << 16 | (short_ ? 0x80000000u : 0u);
+        }
+}
+
+template <int ND_>
+__device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict__ planes_, const uint32_t plw_, const uint32_t *__restrict__ masked_,
+                                                      const uint32_t *__restrict__ lists_) {
+        constexpr uint32_t ND = (uint32_t)ND_;
+        constexpr uint32_t PF = PlkRing<ND_>::PF;
+        PlanesShared &sh = plk_shared();
+        const uint32_t lane = threadIdx.x & 63u, wave = uni(threadIdx.x >> 6);
+        const uint32_t *const planes = uni_ptr(planes_), *const masked = uni_ptr(masked_), *const lists = uni_ptr(lists_);
+        const uint32_t plw = uni(plw_);
+        const uint32_t nd = uni(sh.sa.nd), nreq = uni(sh.sa.nreq), negd = uni(sh.sa.negd);
+        uint32_t sw = uni(sh.w_sw[wave]), qn = uni(sh.w_qn[wave]), cqn = uni(sh.w_cqn[wave]);
+        const uint32_t sw_end = uni(sh.w_end[wave]);
+        PlkG1 pa1[ND]; // plane A of the dense positions (a position beyond nd: the all-zero row)
+#pragma unroll
+        for (uint32_t i = 0; i < ND; ++i)
+                pa1[i] = (PlkG1)(planes + (size_t)uni(sh.sa.prow[i]) * PL_PLANES * plw);
+        // the first three required groups in scalar registers (a group beyond the query's: every position — it changes nothing), further ones from LDS
+        constexpr uint32_t GREG = 3;
+        uint32_t gd[GREG];
+#pragma unroll
+        for (uint32_t g = 0; g < GREG; ++g)
+                gd[g] = g < nreq ? uni(sh.sa.gd[g]) : 0xffffffffu;
+        const PlkG2 mk2 = (PlkG2)(masked ? masked : planes + (size_t)uni(sh.sa.zrow) * PL_PLANES * plw); // (rows and sub-windows are multiples of 128 words: 8-byte aligned)
+        uint32_t my_matches = 0;
+        // (threshold and tables move only at a prune, i.e. between two segments)
+        const uint32_t esel = uni(sh.esel), atab = uni(sh.atab);
+        uint32_t es_a = 0, es_b = 0, es_c = 0; // the essential planes as bit sets over the dense positions
+#pragma unroll
+        for (uint32_t i = 0; i < ND; ++i) {
+                const uint32_t e = (esel >> (2 * i)) & 3u;
+                es_a |= (e == 0 ? 1u : 0u) << i;
+                es_b |= (e == 1 ? 1u : 0u) << i;
+                es_c |= (e == 2 ? 1u : 0u) << i;
+        }
+        es_a = uni(es_a), es_b = uni(es_b), es_c = uni(es_c);
+        const uint32_t es_any = es_a | es_b | es_c;
+        (void)es_any, (void)atab;
+        const bool fall = uni(sh.fall) != 0;
+        PlkU2 ring[PF][ND], ringm[PF];
+        // (every fetch issues the same ND + 1 loads — a share's last sub-windows fetch its last one again, a segment without masked documents reads
+        //  the all-zero row for them — so that the compiler can COUNT the loads in flight: it then waits for the ring's oldest place only, not for
+        //  the places it has just sent for)
+        auto fetch_a = [&](const uint32_t sw_, PlkU2 (&g)[ND], PlkU2 &gm) __attribute__((always_inline)) {
+                const uint32_t wb = min(sw_, sw_end - 1u) * (PLK_SW_WORDS / 2) + lane;
+#pragma unroll
+                for (uint32_t i = 0; i < ND; ++i)
+                        g[i] = ((PlkG2)pa1[i])[i < nd ? wb : lane];
+                gm = mk2[masked ? wb : lane];
+        };
+        bool stop = false; // (uniform, like sw / qn / cqn: the segment's control flow is the wave's)
+        // words left over from the previous segment first (they were cut short by a full queue or buffer)
+        auto work_words = [&]() __attribute__((always_inline)) { // true: the batch went through
+                const uint32_t st = uni(planes_work_words<ND_>(planes, plw, lists, qn | cqn << 16));
+                qn = st & 0xffffu, cqn = (st >> 16) & 0x7fffu;
+                return (st >> 31) == 0u;
+        };
+        while (!stop && cqn >= 64)
+                stop = !work_words();
+        if (!stop) {
+#pragma unroll
+                for (uint32_t r = 0; r < PF; ++r) // fill the ring: the next PF sub-windows' A words
+                        fetch_a(sw + r, ring[r], ringm[r]);
+        }
+        while (!stop && sw < sw_end) {
+                static_for<PF>([&](auto R) __attribute__((always_inline)) {
+                        constexpr uint32_t r = decltype(R)::value;
+                        sw = uni(sw), cqn = uni(cqn);
+                        if (stop || !(sw < sw_end)) // (uniform)
+                                return;
+                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
+                                stop = true; // the buffer wants pruning first (the sub-window stays as it is)
+                                return;
+                        }
+                        uint32_t p[ND], qq[ND];
+#pragma unroll
+                        for (uint32_t i = 0; i < ND; ++i) {
+                                p[i] = ring[r][i].x;
+                                qq[i] = ring[r][i].y;
+                        }
+                        const PlkU2 mk = ringm[r];
+                        // ... and the ring's place goes to the sub-window PF ahead
+                        fetch_a(sw + PF, ring[r], ringm[r]);
+                        // the predicate word-wise (the slots' roles are uniform bit sets: a role's word is and_or'ed together under scalar masks — one vector
+                        // instruction per slot, word and role), the match count
+                        uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;
+                        static_for<GREG>([&](auto G) __attribute__((always_inline)) {
+                                constexpr uint32_t g = decltype(G)::value;
+                                if (g >= nreq) // (uniform)
+                                        return;
+                                const uint32_t gmask = gd[g];
+                                uint32_t x0 = 0, x1 = 0;
+                                static_for<ND>([&](auto I) __attribute__((always_inline)) {
+                                        const uint32_t mk_ = umask_at<I>(gmask);
+                                        x0 = and_or(p[I], mk_, x0);
+                                        x1 = and_or(qq[I], mk_, x1);
+                                });
+                                m0 &= x0;
+                                m1 &= x1;
+                        });
+                        for (uint32_t g = GREG; g < nreq; ++g) { // (rare: a conjunction of more than three groups that dense slots can satisfy)
+                                const uint32_t gmask = uni(sh.sa.gd[g]);
+                                uint32_t x0 = 0, x1 = 0;
+                                static_for<ND>([&](auto I) __attribute__((always_inline)) {
+                                        const uint32_t mk_ = umask_at<I>(gmask);
+                                        x0 = and_or(p[I], mk_, x0);
+                                        x1 = and_or(qq[I], mk_, x1);
+                                });
+                                m0 &= x0;
+                                m1 &= x1;
+                        }
+                        if (negd) {
+                                uint32_t n0 = 0, n1 = 0;
+                                static_for<ND>([&](auto I) __attribute__((always_inline)) {
+                                        const uint32_t mk_ = umask_at<I>(negd);
+                                        n0 = and_or(p[I], mk_, n0);
+                                        n1 = and_or(qq[I], mk_, n1);
+                                });
+                                m0 &= ~n0;
+                                m1 &= ~n1;
+                        }
+                        m0 &= ~mk.x; // masked_documents_registry::test (docidupdates.h:90-119)
+                        m1 &= ~mk.y;
+                        my_matches += (uint32_t)__popc(m0) + (uint32_t)__popc(m1);
+                        uint32_t c0 = m0, c1 = m1;
+                        if (!fall) {
+                                // the presence filter: can the slots a document HOLDS reach the threshold at all?  Up to five dense slots: exactly (the
+                                // table looked up word-wise); more: MaxScore's essential slots — a candidate holds one of them
+                                uint32_t f0 = 0, f1 = 0;
+                                if constexpr (ND <= 5) {
+                                        planes_presence_tree<ND, 0, ND>(atab, p, qq, f0, f1);
+                                        const uint32_t cz = umask_at<0>(atab); // (a threshold nothing is needed for)
+                                        f0 |= cz;
+                                        f1 |= cz;
+                                } else {
+                                        static_for<ND>([&](auto I) __attribute__((always_inline)) {
+                                                const uint32_t mk_ = umask_at<I>(es_any);
+                                                f0 = and_or(p[I], mk_, f0);
+                                                f1 = and_or(qq[I], mk_, f1);
+                                        });
+                                }
+                                c0 &= f0;
+                                c1 &= f1;
+                        }
+                        // the words that hold a candidate go on the wave's queue
+                        if (__builtin_amdgcn_ballot_w64((c0 | c1) != 0) != 0ull) {
+                                const uint32_t w2 = 2u * (sw * (PLK_SW_WORDS / 2) + lane);
+                                const uint64_t b0 = __builtin_amdgcn_ballot_w64(c0 != 0), b1 = __builtin_amdgcn_ballot_w64(c1 != 0);
+                                if (c0) {
+                                        const uint32_t at = cqn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u));
+                                        sh.cq[wave][at][0] = w2;
+                                        sh.cq[wave][at][1] = c0;
+                                }
+                                cqn += (uint32_t)__popcll(b0);
+                                if (c1) {
+                                        const uint32_t at = cqn + __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+                                        sh.cq[wave][at][0] = w2 + 1u;
+                                        sh.cq[wave][at][1] = c1;
+                                }
+                                cqn += (uint32_t)__popcll(b1);
+                        }
+                        ++sw;
+                        PROF_COUNT(19, lane == 0 ? 1 : 0);
+                        while (!stop && cqn >= 64)
+                                stop = !work_words();
+                });
+        }
+        // the share is swept: the words still on the queue
+        while (!stop && sw >= sw_end && cqn)
+                stop = !work_words();
+        // the wave's state for its next segment, its matches so far
+        sh.w_sw[wave] = sw, sh.w_qn[wave] = qn, sh.w_cqn[wave] = cqn; // (wave-uniform values, every lane stores them)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+                my_matches += __shfl_xor(my_matches, d, 64);
+        atomicAdd(&sh.matches, lane == 0 ? my_matches : 0u);
+        return sw < sw_end || cqn ? 1u : 0u;
+}
+
 // NS: the slots the instantiation can hold.  scratch: sparse_cap u32 per workgroup — the lists of the task's sparse slots.
 template <int CODEC, int NS>
 __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void k_planes(
@@ -504,7 +888,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
         uint32_t *__restrict__ part_docs, double *__restrict__ part_scores, uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked,
         const int sim, const uint32_t *__restrict__ planes, const uint32_t plw, const uint32_t zrow, uint32_t *__restrict__ scratch, const uint32_t sparse_cap,
         unsigned long long *__restrict__ qthr) {
-        __shared__ PlanesShared sh;
+        PlanesShared &sh = plk_shared();
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
         const uint32_t wave = uni(tid >> 6);
         uint32_t *const lists = scratch + (size_t)blockIdx.x * sparse_cap;
@@ -884,288 +1268,53 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 if (sweep_on)
                         planes_filter(sh, nd);
                 PROF_LAP(3);
-                // ---- PHASE B: the sweep over the dense slots.  Every WAVE walks its own contiguous share of the task's range, a sub-window of PLK_SW
-                //      documents (two consecutive words per lane) at a time, wave-synchronously: no workgroup barrier inside.  Three stages in
-                //      flight per wave: (1) plane A of the next PF sub-windows is on its way into the register ring; (2) the sub-window whose A
-                //      words have arrived is swept — predicate, count, presence filter — and the lanes whose words hold a candidate send for their
-                //      B / C words; (3) the sub-window swept one step earlier, whose B / C words have arrived by now, has its candidates put through
-                //      the level table and scored.
-                auto sweep = [&](auto NDc) {
-                        constexpr uint32_t ND = decltype(NDc)::value;
-                        constexpr uint32_t PF = PlkRing<(int)ND>::PF;
-                        const uint32_t nsw = (wend - wfirst) * (PL_W / PLK_SW);
-                        const uint32_t sw_first = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * wave / (PLK_WG / 64));
-                        const uint32_t sw_end = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * (wave + 1) / (PLK_WG / 64));
-                        uint32_t sw = sw_first;
-                        const uint2 *pa2[ND];
+                // ---- PHASE B: the sweep over the dense slots (planes_sweep_segment, above), segment by segment: a segment ends where the wave's queue
+                //      wants working off, where the candidate buffer wants pruning, or with the wave's share of the range
+                if (sweep_on) {
+                        if (tid == 0) {
+                                sh.sa.nd = nd, sh.sa.nreq = nreq, sh.sa.negd = negd, sh.sa.leafd = leafd, sh.sa.nsp = nsp, sh.sa.zrow = zrow;
 #pragma unroll
-                        for (uint32_t i = 0; i < ND; ++i)
-                                pa2[i] = reinterpret_cast<const uint2 *>(pA[i]); // (rows and sub-windows are multiples of 128 words: 8-byte aligned)
-                        const uint2 *const mk2 = reinterpret_cast<const uint2 *>(masked);
-                        const uint32_t plw2 = plw >> 1; // (plw is a multiple of the window's words)
-                        uint2 ring[PF][ND], ringm[PF];
-                        auto fetch_a = [&](const uint32_t sw_, uint2 (&g)[ND], uint2 &gm) {
-                                const uint32_t wb = sw_ * (PLK_SW_WORDS / 2) + lane;
-#pragma unroll
-                                for (uint32_t i = 0; i < ND; ++i)
-                                        g[i] = pa2[i][i < nd ? wb : lane]; // (a position beyond nd reads the all-zero row)
-                                if (masked)
-                                        gm = mk2[wb];
-                        };
-                        // stage 3's registers: the kept sub-window (ksw), its A words, its candidates, its B / C words (in flight after stage 2)
-                        uint2 ka[ND], kb[ND], kc[ND], kcand = make_uint2(0u, 0u);
-                        uint32_t ksw = 0;
-                        bool kpend = false; // (uniform)
-#pragma unroll
-                        for (uint32_t i = 0; i < ND; ++i)
-                                ka[i] = kb[i] = kc[i] = make_uint2(0u, 0u);
-                        for (;;) {
-                                // (threshold and tables move only at a prune, i.e. behind the barrier below: read once per stretch)
-                                const bool full = uni(sh.tk_full) != 0;
-                                const double thr_s = sh.thr_s;
-                                const uint32_t thr_d = sh.thr_d;
-                                const uint32_t esel = uni(sh.esel), atab = uni(sh.atab);
-                                uint32_t es_a = 0, es_b = 0, es_c = 0; // the essential planes as bit sets over the dense positions
-#pragma unroll
-                                for (uint32_t i = 0; i < ND; ++i) {
-                                        const uint32_t e = (esel >> (2 * i)) & 3u;
-                                        es_a |= (e == 0 ? 1u : 0u) << i;
-                                        es_b |= (e == 1 ? 1u : 0u) << i;
-                                        es_c |= (e == 2 ? 1u : 0u) << i;
+                                for (uint32_t i = 0; i < NS; ++i) {
+                                        sh.sa.dsl[i] = dsl[i];
+                                        sh.sa.prow[i] = i < nd ? fq.plane[dsl[i]] : zrow;
                                 }
-                                es_a = uni(es_a), es_b = uni(es_b), es_c = uni(es_c);
-                                const uint32_t es_any = es_a | es_b | es_c;
-                                (void)es_any, (void)atab;
-                                const bool fall = uni(sh.fall) != 0;
-                                // One step over the candidates `cw` of one word of the kept sub-window: every lane that has one takes its lowest, scores it
-                                // from the level words — the known part of the score and a bound for the rest — and offers it, queues it (a slot of
-                                // unknown frequency that the bound does not rule out) or drops it.  A document of a sparse list is dropped: phase A has
-                                // scored it.  false from offer: the buffer had no room (the candidate stays).
-                                auto candidate_step = [&](const uint32_t which, uint32_t &cw) {
-                                        bool enq = false;
-                                        uint32_t edoc = 0, elev = 0;
-                                        if (cw) {
-                                                const uint32_t bit = (uint32_t)__builtin_ctz(cw);
-                                                const uint32_t doc = ksw * PLK_SW + 32u * (2u * lane + which) + bit;
-                                                const uint32_t hb = (sh.hf[(doc & (PLK_HF - 1u)) >> 2] >> (8u * (doc & 3u))) & 0xffu;
-                                                bool sparse_doc = false;
-                                                if (hb) {
 #pragma unroll
-                                                        for (uint32_t j = 0; j < PLK_MAX_SPARSE; ++j)
-                                                                if (j < nsp && ((hb >> j) & 1u))
-                                                                        sparse_doc = sparse_doc || planes_list_find(lists + sp_off[j], sp_n32[j], doc) != PLK_PAD;
-                                                }
-                                                bool done = true;
-                                                if (!sparse_doc) {
-                                                        double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
-                                                        uint32_t levels = 0;
-                                                        bool unk = false;
+                                for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g)
+                                        sh.sa.gd[g] = gd[g];
 #pragma unroll
-                                                        for (uint32_t i = 0; i < ND; ++i) {
-                                                                const uint32_t aw = which ? ka[i].y : ka[i].x, bw = which ? kb[i].y : kb[i].x, cwd = which ? kc[i].y : kc[i].x;
-                                                                if (!((leafd >> i) & 1u) || !((aw >> bit) & 1u))
-                                                                        continue;
-                                                                const uint32_t bb = (bw >> bit) & 1u, cc = (cwd >> bit) & 1u;
-                                                                const uint32_t l = 1u + bb + (bb & cc);
-                                                                levels |= l << (2u * dsl[i]);
-                                                                if (l < 3u)
-                                                                        sk += sh.wl[dsl[i]][l];
-                                                                else {
-                                                                        unk = true;
-                                                                        sb += sh.dwf[i][3];
-                                                                }
-                                                        }
-                                                        if (!full || better(sk + sb, doc, thr_s, thr_d)) {
-                                                                if (unk) {
-                                                                        enq = true;
-                                                                        edoc = doc;
-                                                                        elev = levels;
-                                                                } else
-                                                                        done = offer(sk, doc); // (no room: the candidate stays for after the prune)
-                                                        }
-                                                }
-                                                if (done)
-                                                        cw &= cw - 1u;
-                                        }
-                                        PROF_COUNT(16, lane == 0 ? 1 : 0);
-                                        const uint64_t em = __builtin_amdgcn_ballot_w64(enq);
-                                        if (enq) {
-                                                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-                                                sh.wq[wave][at][0] = edoc;
-                                                sh.wq[wave][at][1] = elev;
-                                        }
-                                        qn += (uint32_t)__popcll(em);
-                                };
-                                // stage 3 on the kept sub-window; false: it stopped short (the queue or the buffer is full) — the rest after the meet
-                                auto stage3 = [&]() {
-                                        bool short_ = false;
-#pragma unroll
-                                        for (uint32_t which = 0; which < 2; ++which) {
-                                                uint32_t cw = which ? kcand.y : kcand.x;
-                                                if (__builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
-                                                        if (!fall) {
-                                                                // the documents in an essential plane, word-wise; each of them then with its level vector in the table
-                                                                uint32_t ew = 0;
-                                                                static_for<ND>([&](auto I) { ew = and_or(which ? ka[I].y : ka[I].x, umask_at<I>(es_a), ew); });
-                                                                if (es_b) {
-                                                                        static_for<ND>([&](auto I) { ew = and_or(which ? kb[I].y : kb[I].x, umask_at<I>(es_b), ew); });
-                                                                }
-                                                                if (es_c) {
-                                                                        static_for<ND>([&](auto I) { ew = and_or(which ? kc[I].y : kc[I].x, umask_at<I>(es_c), ew); });
-                                                                }
-                                                                ew &= cw;
-                                                                cw = 0;
-                                                                if (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
-                                                                        // the planes are nested, the level is the number of them a document is in: its two bits, word-wise
-                                                                        uint32_t lo[ND], hi[ND];
-#pragma unroll
-                                                                        for (uint32_t i = 0; i < ND; ++i) {
-                                                                                const uint32_t aw = which ? ka[i].y : ka[i].x, bw = which ? kb[i].y : kb[i].x, cwd = which ? kc[i].y : kc[i].x;
-                                                                                lo[i] = ((leafd >> i) & 1u) ? aw ^ bw ^ cwd : 0u; // (a slot without a scorer: level 0)
-                                                                                hi[i] = ((leafd >> i) & 1u) ? bw : 0u;
-                                                                        }
-                                                                        do {
-                                                                                const uint32_t bit = ew ? (uint32_t)__builtin_ctz(ew) : 0u;
-                                                                                uint32_t code = 0;
-#pragma unroll
-                                                                                for (uint32_t i = 0; i < ND; ++i)
-                                                                                        code |= (((lo[i] >> bit) & 1u) << (2 * i)) | (((hi[i] >> bit) & 1u) << (2 * i + 1));
-                                                                                const uint32_t hit = (sh.ftab[code >> 5] >> (code & 31u)) & 1u;
-                                                                                cw |= ew ? hit << bit : 0u;
-                                                                                ew &= ew - 1u;
-                                                                                PROF_COUNT(20, lane == 0 ? 1 : 0);
-                                                                        } while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull);
-                                                                }
-                                                        }
-                                                        while (!short_ && __builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
-                                                                if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
-                                                                        short_ = true;
-                                                                        PROF_COUNT(23, lane == 0 ? 1 : 0);
-                                                                } else
-                                                                        candidate_step(which, cw);
-                                                        }
-                                                        PROF_COUNT(21, lane == 0 ? 1 : 0);
-                                                }
-                                                if (which)
-                                                        kcand.y = cw;
-                                                else
-                                                        kcand.x = cw;
-                                        }
-                                        kpend = __builtin_amdgcn_ballot_w64((kcand.x | kcand.y) != 0) != 0ull;
-                                        return !short_;
-                                };
+                                for (uint32_t j = 0; j < PLK_MAX_SPARSE; ++j) {
+                                        sh.sa.sp_off[j] = sp_off[j];
+                                        sh.sa.sp_n32[j] = sp_n32[j];
+                                }
+                        }
+                        {
+                                const uint32_t nsw = (wend - wfirst) * (PL_W / PLK_SW); // every WAVE walks its own contiguous share of the task's range
+                                sh.w_sw[wave] = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * wave / (PLK_WG / 64)); // (wave-uniform values, every lane stores them)
+                                sh.w_end[wave] = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * (wave + 1) / (PLK_WG / 64));
+                                sh.w_qn[wave] = 0, sh.w_cqn[wave] = 0;
+                        }
+                        __syncthreads();
+                        for (;;) {
                                 bool done = false;
-                                for (;;) { // the hot segments of this stretch (a segment ends where the queue wants working off, or at the stretch's end)
-#pragma unroll
-                                        for (uint32_t r = 0; r < PF; ++r) { // (re)fill the ring: the next PF sub-windows' A words
-                                                if (sw + r < sw_end)
-                                                        fetch_a(sw + r, ring[r], ringm[r]);
-                                        }
-                                        bool stop = false;
-                                        while (!stop && (sw < sw_end || kpend)) {
-                                                static_for<PF>([&](auto R) {
-                                                        constexpr uint32_t r = decltype(R)::value;
-                                                        if (stop || !(sw < sw_end || kpend)) // (uniform)
-                                                                return;
-                                                        if (kpend) {
-                                                                if (!stage3()) {
-                                                                        stop = true;
-                                                                        return;
-                                                                }
-                                                                PROF_LAP(9);
-                                                        }
-                                                        if (!(sw < sw_end))
-                                                                return;
-                                                        if (uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
-                                                                stop = true; // the buffer wants pruning first: to the barrier (the sub-window stays as it is)
-                                                                return;
-                                                        }
-                                                        // ---- stage 2: the sub-window whose A words the ring holds
-                                                        uint32_t p[ND], qq[ND];
-#pragma unroll
-                                                        for (uint32_t i = 0; i < ND; ++i) {
-                                                                p[i] = ring[r][i].x;
-                                                                qq[i] = ring[r][i].y;
-                                                        }
-                                                        // the predicate word-wise (the slots' roles are uniform bit sets: a role's word is and_or'ed together under scalar
-                                                        // masks — one vector instruction per slot, word and role), the match count
-                                                        uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;
-#pragma unroll
-                                                        for (uint32_t g = 0; g < FUS_MAX_SLOTS; ++g) {
-                                                                if (g >= nreq)
-                                                                        break;
-                                                                uint32_t x0 = 0, x1 = 0;
-                                                                static_for<ND>([&](auto I) {
-                                                                        const uint32_t mk = umask_at<I>(gd[g]);
-                                                                        x0 = and_or(p[I], mk, x0);
-                                                                        x1 = and_or(qq[I], mk, x1);
-                                                                });
-                                                                m0 &= x0;
-                                                                m1 &= x1;
-                                                        }
-                                                        if (negd) {
-                                                                uint32_t n0 = 0, n1 = 0;
-                                                                static_for<ND>([&](auto I) {
-                                                                        const uint32_t mk = umask_at<I>(negd);
-                                                                        n0 = and_or(p[I], mk, n0);
-                                                                        n1 = and_or(qq[I], mk, n1);
-                                                                });
-                                                                m0 &= ~n0;
-                                                                m1 &= ~n1;
-                                                        }
-                                                        if (masked) { // masked_documents_registry::test (docidupdates.h:90-119)
-                                                                m0 &= ~ringm[r].x;
-                                                                m1 &= ~ringm[r].y;
-                                                        }
-                                                        my_matches += (uint32_t)__popc(m0) + (uint32_t)__popc(m1);
-                                                        uint32_t c0 = m0, c1 = m1;
-                                                        if (!fall) {
-                                                                // the presence filter: can the slots a document HOLDS reach the threshold at all?  Up to five dense slots:
-                                                                // exactly (the table looked up word-wise); more: MaxScore's essential slots — a candidate holds one of them
-                                                                uint32_t f0 = 0, f1 = 0;
-                                                                if constexpr (ND <= 5) {
-                                                                        planes_presence_tree<ND, 0, ND>(atab, p, qq, f0, f1);
-                                                                        const uint32_t cz = umask_at<0>(atab); // (a threshold nothing is needed for)
-                                                                        f0 |= cz;
-                                                                        f1 |= cz;
-                                                                } else {
-                                                                        static_for<ND>([&](auto I) {
-                                                                                const uint32_t mk = umask_at<I>(es_any);
-                                                                                f0 = and_or(p[I], mk, f0);
-                                                                                f1 = and_or(qq[I], mk, f1);
-                                                                        });
-                                                                }
-                                                                c0 &= f0;
-                                                                c1 &= f1;
-                                                        }
-                                                        // hand over to stage 3: the A words and the candidates stay, the B / C words are sent for — by the lanes that hold a
-                                                        // candidate; the others read the all-zero row's first words (one cache line for the whole wave)
-                                                        kcand = make_uint2(c0, c1);
-                                                        ksw = sw;
-                                                        kpend = __builtin_amdgcn_ballot_w64((c0 | c1) != 0) != 0ull;
-                                                        {
-                                                                const bool mine = (c0 | c1) != 0;
-                                                                const uint32_t wb = sw * (PLK_SW_WORDS / 2) + lane;
-#pragma unroll
-                                                                for (uint32_t i = 0; i < ND; ++i) {
-                                                                        ka[i] = ring[r][i];
-                                                                        const uint2 *src = mine && i < nd ? pa2[i] + wb : reinterpret_cast<const uint2 *>(planes + (size_t)zrow * PL_PLANES * plw) + lane;
-                                                                        kb[i] = src[plw2];
-                                                                        kc[i] = src[2 * plw2];
-                                                                }
-                                                        }
-                                                        // ... and the ring's place goes to the sub-window PF ahead
-                                                        if (sw + PF < sw_end)
-                                                                fetch_a(sw + PF, ring[r], ringm[r]);
-                                                        ++sw;
-                                                        PROF_COUNT(19, lane == 0 ? 1 : 0);
-                                                        PROF_LAP(8);
-                                                });
-                                        }
+                                for (;;) {
+                                        sh.w_qn[wave] = qn;
+                                        uint32_t r;
+                                        if constexpr (NS == PLK_NS_SMALL) {
+                                                if (nd <= 1)
+                                                        r = planes_sweep_segment<1>(planes, plw, masked, lists);
+                                                else if (nd == 2)
+                                                        r = planes_sweep_segment<2>(planes, plw, masked, lists);
+                                                else if (nd == 3)
+                                                        r = planes_sweep_segment<3>(planes, plw, masked, lists);
+                                                else
+                                                        r = planes_sweep_segment<5>(planes, plw, masked, lists);
+                                        } else
+                                                r = planes_sweep_segment<NS>(planes, plw, masked, lists);
+                                        qn = uni(sh.w_qn[wave]);
                                         // the queue is worked off out here: a call among the sweep's live registers would have the compiler spill them on the hot path
                                         while (qn >= 64 && uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) < PLK_PRUNE_AT)
                                                 work_queue();
-                                        done = !(sw < sw_end || kpend);
+                                        done = uni(r) == 0;
                                         if (done || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT)
                                                 break;
                                 }
@@ -1177,19 +1326,6 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 if (!(mres & 1u))
                                         break;
                         }
-                };
-                if (sweep_on) {
-                        if constexpr (NS == PLK_NS_SMALL) {
-                                if (nd <= 1)
-                                        sweep(std::integral_constant<uint32_t, 1>{});
-                                else if (nd == 2)
-                                        sweep(std::integral_constant<uint32_t, 2>{});
-                                else if (nd == 3)
-                                        sweep(std::integral_constant<uint32_t, 3>{});
-                                else
-                                        sweep(std::integral_constant<uint32_t, 5>{});
-                        } else
-                                sweep(std::integral_constant<uint32_t, (uint32_t)NS>{});
                 }
                 // ---- the candidates still waiting for their frequencies
                 for (;;) {
