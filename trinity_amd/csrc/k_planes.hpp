@@ -712,10 +712,25 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
         const uint32_t nd = uni(sh.sa.nd), nreq = uni(sh.sa.nreq), negd = uni(sh.sa.negd);
         uint32_t sw = uni(sh.w_sw[wave]), qn = uni(sh.w_qn[wave]), cqn = uni(sh.w_cqn[wave]);
         const uint32_t sw_end = uni(sh.w_end[wave]);
+        constexpr uint32_t SWS = PLK_WG / 64; // the waves' sub-windows interleave: wave w sweeps first + w, first + w + 8, ... — whatever the candidates' density
+                                              // does along the range, every wave gets its share of it, and the eight of them read each plane row front to back together
+        const uint32_t sw_last = sw_end - 1u - (sw_end - 1u - sw) % SWS; // this wave's last sub-window (sw < sw_end here, or nothing is fetched)
         PlkG1 pa1[ND]; // plane A of the dense positions (a position beyond nd: the all-zero row)
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i)
                 pa1[i] = (PlkG1)(planes + (size_t)uni(sh.sa.prow[i]) * PL_PLANES * plw);
+        // the slots' ESSENTIAL planes (planes_filter: every candidate is in one of them).  Plane A is in the ring anyway; a slot that is essential through
+        // its plane B or C has that plane's words fetched beside it (any other position fetches the all-zero row's first words: one cache line)
+        PlkG1 pe1[ND];
+        uint32_t es_fetch = 0; // the positions whose essential plane is B or C
+#pragma unroll
+        for (uint32_t i = 0; i < ND; ++i) {
+                const uint32_t e = (uni(sh.esel) >> (2 * i)) & 3u;
+                const bool bc = i < nd && (e == 1u || e == 2u);
+                es_fetch |= (bc ? 1u : 0u) << i;
+                pe1[i] = bc ? pa1[i] + (size_t)e * plw : (PlkG1)(planes + (size_t)uni(sh.sa.zrow) * PL_PLANES * plw);
+        }
+        es_fetch = uni(es_fetch);
         // the first three required groups in scalar registers (a group beyond the query's: every position — it changes nothing), further ones from LDS
         constexpr uint32_t GREG = 3;
         uint32_t gd[GREG];
@@ -738,15 +753,17 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
         const uint32_t es_any = es_a | es_b | es_c;
         (void)es_any, (void)atab;
         const bool fall = uni(sh.fall) != 0;
-        PlkU2 ring[PF][ND], ringm[PF];
+        PlkU2 ring[PF][ND], ringe[PF][ND], ringm[PF];
         // (every fetch issues the same ND + 1 loads — a share's last sub-windows fetch its last one again, a segment without masked documents reads
         //  the all-zero row for them — so that the compiler can COUNT the loads in flight: it then waits for the ring's oldest place only, not for
         //  the places it has just sent for)
-        auto fetch_a = [&](const uint32_t sw_, PlkU2 (&g)[ND], PlkU2 &gm) __attribute__((always_inline)) {
-                const uint32_t wb = min(sw_, sw_end - 1u) * (PLK_SW_WORDS / 2) + lane;
+        auto fetch_a = [&](const uint32_t sw_, PlkU2 (&g)[ND], PlkU2 (&ge)[ND], PlkU2 &gm) __attribute__((always_inline)) {
+                const uint32_t wb = min(sw_, sw_last) * (PLK_SW_WORDS / 2) + lane;
 #pragma unroll
-                for (uint32_t i = 0; i < ND; ++i)
+                for (uint32_t i = 0; i < ND; ++i) {
                         g[i] = ((PlkG2)pa1[i])[i < nd ? wb : lane];
+                        ge[i] = ((PlkG2)pe1[i])[((es_fetch >> i) & 1u) ? wb : lane];
+                }
                 gm = mk2[masked ? wb : lane];
         };
         bool stop = false; // (uniform, like sw / qn / cqn: the segment's control flow is the wave's)
@@ -758,10 +775,10 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
         };
         while (!stop && cqn >= 64)
                 stop = !work_words();
-        if (!stop) {
+        if (!stop && sw < sw_end) {
 #pragma unroll
                 for (uint32_t r = 0; r < PF; ++r) // fill the ring: the next PF sub-windows' A words
-                        fetch_a(sw + r, ring[r], ringm[r]);
+                        fetch_a(sw + r * SWS, ring[r], ringe[r], ringm[r]);
         }
         while (!stop && sw < sw_end) {
                 static_for<PF>([&](auto R) __attribute__((always_inline)) {
@@ -779,9 +796,15 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
                                 p[i] = ring[r][i].x;
                                 qq[i] = ring[r][i].y;
                         }
+                        uint32_t e0 = 0, e1 = 0; // the essential planes' words: B / C as fetched ...
+#pragma unroll
+                        for (uint32_t i = 0; i < ND; ++i) {
+                                e0 |= ringe[r][i].x;
+                                e1 |= ringe[r][i].y;
+                        }
                         const PlkU2 mk = ringm[r];
                         // ... and the ring's place goes to the sub-window PF ahead
-                        fetch_a(sw + PF, ring[r], ringm[r]);
+                        fetch_a(sw + PF * SWS, ring[r], ringe[r], ringm[r]);
                         // the predicate word-wise (the slots' roles are uniform bit sets: a role's word is and_or'ed together under scalar masks — one vector
                         // instruction per slot, word and role), the match count
                         uint32_t m0 = 0xffffffffu, m1 = 0xffffffffu;
@@ -840,8 +863,13 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
                                                 f1 = and_or(qq[I], mk_, f1);
                                         });
                                 }
-                                c0 &= f0;
-                                c1 &= f1;
+                                static_for<ND>([&](auto I) __attribute__((always_inline)) { // ... A from the ring
+                                        const uint32_t mk_ = umask_at<I>(es_a);
+                                        e0 = and_or(p[I], mk_, e0);
+                                        e1 = and_or(qq[I], mk_, e1);
+                                });
+                                c0 &= f0 & e0;
+                                c1 &= f1 & e1;
                         }
                         // the words that hold a candidate go on the wave's queue
                         if (__builtin_amdgcn_ballot_w64((c0 | c1) != 0) != 0ull) {
@@ -860,7 +888,7 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
                                 }
                                 cqn += (uint32_t)__popcll(b1);
                         }
-                        ++sw;
+                        sw += SWS;
                         PROF_COUNT(19, lane == 0 ? 1 : 0);
                         while (!stop && cqn >= 64)
                                 stop = !work_words();
@@ -1098,6 +1126,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 }
                 __syncthreads();
                 PROF_LAP(1);
+                TASKTIME_PLANES(8 * ticket_no + 2);
                 uint32_t my_matches = 0; // (wraps: phase A adds signed corrections)
                 uint32_t qn = 0;         // entries on this wave's queue of candidates that wait for an exact frequency (wave-uniform)
                 auto offer = [&](const double sc, const uint32_t doc) { // false: no room (the buffer wants pruning)
@@ -1262,12 +1291,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         break;
                         }
                 }
+                TASKTIME_PLANES(8 * ticket_no + 3);
                 // ---- the threshold after phase A (or another range's), the sweep's tables
                 planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k, gthr);
                 const bool sweep_on = sweepable && nd != 0;
                 if (sweep_on)
                         planes_filter(sh, nd);
                 PROF_LAP(3);
+                TASKTIME_PLANES(8 * ticket_no + 4);
                 // ---- PHASE B: the sweep over the dense slots (planes_sweep_segment, above), segment by segment: a segment ends where the wave's queue
                 //      wants working off, where the candidate buffer wants pruning, or with the wave's share of the range
                 if (sweep_on) {
@@ -1288,9 +1319,8 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 }
                         }
                         {
-                                const uint32_t nsw = (wend - wfirst) * (PL_W / PLK_SW); // every WAVE walks its own contiguous share of the task's range
-                                sh.w_sw[wave] = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * wave / (PLK_WG / 64)); // (wave-uniform values, every lane stores them)
-                                sh.w_end[wave] = wfirst * (PL_W / PLK_SW) + (uint32_t)((uint64_t)nsw * (wave + 1) / (PLK_WG / 64));
+                                sh.w_sw[wave] = wfirst * (PL_W / PLK_SW) + wave; // the waves' sub-windows interleave (wave-uniform values, every lane stores them)
+                                sh.w_end[wave] = wend * (PL_W / PLK_SW);
                                 sh.w_qn[wave] = 0, sh.w_cqn[wave] = 0;
                         }
                         __syncthreads();
@@ -1327,6 +1357,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         break;
                         }
                 }
+                TASKTIME_PLANES(8 * ticket_no + 5);
                 // ---- the candidates still waiting for their frequencies
                 for (;;) {
                         while (qn && uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) < PLK_PRUNE_AT)
@@ -1334,6 +1365,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         if (!(meet(qn != 0) & 1u))
                                 break;
                 }
+                TASKTIME_PLANES(8 * ticket_no + 6);
                 // ---- the task's result: its best k (ranked) and its match count
                 __syncthreads();
                 planes_prune(sh, min(uni(sh.tk_n), PLK_CAP), k, gthr);

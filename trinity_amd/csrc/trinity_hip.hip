@@ -1243,6 +1243,32 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                                 running += g_tt_host[8 * i] <= at && g_tt_host[8 * i + 1] > at;
                         fprintf(stderr, "   at %2.0f %% of the span: %u tasks running\n", f * 100, running);
                 }
+#if TRI_TASKTIMES == 3 // (k_planes: stamps 2 .. 6 = lists decoded + filter filled, phase A done, tables ready, sweep done, queue drained; 1 = end)
+                {
+                        const char *nm[8] = {"", "", "setup+lists", "phase A", "prune+tables", "sweep", "drain", "end"};
+                        double sum[8] = {0};
+                        std::vector<double> span[8];
+                        for (uint32_t i = 0; i < nc; ++i) {
+                                unsigned long long prev = g_tt_host[8 * i];
+                                for (int j = 2; j <= 7; ++j) {
+                                        const unsigned long long at = j == 7 ? g_tt_host[8 * i + 1] : g_tt_host[8 * i + j];
+                                        if (!at || !prev)
+                                                continue;
+                                        const double d = (double)(at - prev) / 100.0;
+                                        sum[j] += d;
+                                        span[j].push_back(d);
+                                        prev = at;
+                                }
+                        }
+                        fprintf(stderr, "   phases (us per task: mean / median / p90):");
+                        for (int j = 2; j <= 7; ++j)
+                                if (!span[j].empty()) {
+                                        std::sort(span[j].begin(), span[j].end());
+                                        fprintf(stderr, "  %s %.1f / %.1f / %.1f", nm[j], sum[j] / span[j].size(), span[j][span[j].size() / 2], span[j][span[j].size() * 9 / 10]);
+                                }
+                        fprintf(stderr, "\n");
+                }
+#endif
 #if TRI_TASKTIMES == 1 // (k_and: the mean of every stamp over all tasks, relative to the task's start)
                 {
                         double sum[8] = {0}, cnt[8] = {0};
