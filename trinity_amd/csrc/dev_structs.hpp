@@ -142,7 +142,13 @@ TRI_HD constexpr bool task_onepass(const uint32_t kind) { return kind >= TASK_FU
 constexpr uint32_t PL_W = 32768;          // documents per plane window (k_term_planes, k_planes)
 constexpr uint32_t PL_WORDS = PL_W / 32;  // words of one plane per window
 constexpr uint32_t PL_NONE = 0xffffffffu; // "this term has no plane in this batch"
-constexpr uint32_t PL_PLANES = 3;         // planes per term — A: the document holds the term; B: its frequency there is not 1; C: nor 2
+constexpr uint32_t PL_NESTED = 6;         // nested planes per term — plane k (0-based): the document holds the term and its frequency f there is >= k + 1, or is one the
+                                          // planes do not tell (f = 0, f >= PL_NESTED: every plane set — the exact value is then read from the postings).  Plane 0 ("A")
+                                          // is presence; planes 1 / 2 ("B" / "C") read as before: f is not 1, nor 2.  A document's LEVEL is the number of nested planes
+                                          // it is in: levels 1 .. PL_NESTED - 1 ARE the frequency.  The nested planes are what a SWEEP streams (one plane, front to back)
+constexpr uint32_t PL_LEVEL_WORDS = 3;    // ... and after them the same levels bit-sliced and INTERLEAVED — words 3 w, 3 w + 1, 3 w + 2: bit 0, 1, 2 of the level of the
+                                          // 32 documents of word w — what a PROBE reads: one 12-byte access tells a document's frequency where the nested planes take six
+constexpr uint32_t PL_PLANES = PL_NESTED + PL_LEVEL_WORDS; // words of a term's row per word of the docID space (the row's stride is PL_PLANES * plw)
 constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64).  The entry's
                                                  // low 31 bits: where the block's hits start, in bytes PAST blk_off[] (the block's deltas and frequencies lie
                                                  // between: a few hundred bytes) — index offsets themselves keep all their 32 bits (codecs.h:26: chunks up to 4 GiB)

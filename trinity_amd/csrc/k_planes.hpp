@@ -8,11 +8,12 @@
 // Under Zipf a handful of terms carry most of a batch's postings (at the 10M-document configuration the 40 most frequent terms
 // hold 98 % of the postings the 5-term queries of SURVEY §8(d) cfg3 touch), and the reference decodes such a list again for every
 // query that names it (Decoder::init + next() per query, google_codec.cpp:777-819 / lucene_codec.cpp:568-594).  Here every LAUNCH
-// decodes each of those lists ONCE — k_term_planes, inside the timed region, from the segment's own codec bytes — into three
-// bitmaps over the docID space:
-//     plane A   bit d set  <=>  document d holds the term            (PostingsListIterator::current() would stop on d)
-//     plane B   bit d set  <=>  ... and its frequency there is not 1
-//     plane C   bit d set  <=>  ... and not 2 either (the exact frequency is then read from the postings on demand)
+// decodes each of those lists ONCE — k_term_planes, from the segment's own codec bytes — into PL_NESTED nested bitmaps over the docID space (+ the same levels bit-sliced, for probes):
+//     plane 0 ("A")  bit d set  <=>  document d holds the term            (PostingsListIterator::current() would stop on d)
+//     plane k        bit d set  <=>  ... and its frequency there is >= k + 1 — or one the planes do not tell (0, >= PL_NESTED: every plane set)
+// (planes 1 / 2, "B" / "C": the frequency is not 1, nor 2 — what k_score and k_tree_leaves read).  The number of planes a document is in is its
+// LEVEL: levels 1 .. PL_NESTED - 1 are the frequency itself, the top level says "read it from the postings" (round 5: three planes told 1 / 2 /
+// anything else, and a union with the most frequent term walked into the postings for every document that holds it three times or more)
 // and the matching kernels read the planes: k_and tests a candidate with one bit probe instead of bracketing and decoding a block
 // (Conjuction::next_impl's advance(), docset_iterators.cpp:308-348), k_and_dense ORs a plane's words into its window bitmap instead
 // of walking the term's rows (docset_spans.cpp:98-173), k_planes (below) evaluates union / CNF predicates 32 documents per word.
@@ -21,7 +22,7 @@
 constexpr uint32_t PL_CELLS = PL_W / CELL_DOCS; // cell-index entries per plane window
 constexpr uint32_t PL_STRIDE = PL_WORDS + 32;   // LDS words between a slot's planes (word PL_WORDS of each: the sink)
 
-// A decoded posting into LDS planes A, B, C (a[], a[PL_STRIDE], a[2 * PL_STRIDE]).  Documents outside the window land in the sink word.
+// A decoded posting into the LDS planes (a[k * PL_STRIDE ...]: plane k).  Documents outside the window land in the sink word.
 struct PlanePost {
         uint32_t *a;
         __device__ __forceinline__ void doc(const uint32_t rel) {
@@ -31,12 +32,12 @@ struct PlanePost {
         __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) {
                 const uint32_t r = min(rel, PL_W);
                 const uint32_t bit = 1u << (r & 31u), f16 = f & 0xffffu; // (the frequency a scorer sees is tokenpos_t, 16 bits: codecs.h:217)
+                const uint32_t level = f16 == 0u || f16 > PL_NESTED ? PL_NESTED : f16; // (a frequency the planes do not tell: every plane)
                 atomicOr(&a[r >> 5], bit);
-                if (f16 != 1u) {
-                        atomicOr(&a[(r >> 5) + PL_STRIDE], bit);
-                        if (f16 != 2u)
-                                atomicOr(&a[(r >> 5) + 2 * PL_STRIDE], bit);
-                }
+#pragma unroll
+                for (uint32_t k = 1; k < PL_NESTED; ++k)
+                        if (k < level)
+                                atomicOr(&a[(r >> 5) + k * PL_STRIDE], bit);
         }
 };
 
@@ -49,9 +50,9 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                                                         const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
                                                         const DevTerm *__restrict__ terms, const uint32_t *__restrict__ build /* (term, row) pairs */,
                                                         uint32_t *__restrict__ planes, const uint32_t plw) {
-        __shared__ uint32_t pl[PL_PLANES * PL_STRIDE];
+        __shared__ uint32_t pl[PL_NESTED * PL_STRIDE];
         const uint32_t tid = threadIdx.x, w = blockIdx.x, row = build[2 * blockIdx.y + 1];
-        for (uint32_t i = tid; i < PL_PLANES * PL_STRIDE; i += AND_WG)
+        for (uint32_t i = tid; i < PL_NESTED * PL_STRIDE; i += AND_WG)
                 pl[i] = 0;
         const DevTerm t = terms[build[2 * blockIdx.y]];
         const uint32_t *bl = blk_last + t.first_block;
@@ -103,10 +104,19 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                 }
         __syncthreads();
         uint32_t *pa = planes + (size_t)row * PL_PLANES * plw + (size_t)w * PL_WORDS;
+        static_assert(PL_NESTED == 6 && PL_LEVEL_WORDS == 3, "the level's bits below are written for six nested planes");
+        uint32_t *lv = planes + (size_t)row * PL_PLANES * plw + (size_t)PL_NESTED * plw + 3u * (size_t)w * PL_WORDS; // the window's interleaved level words
         for (uint32_t i = tid; i < PL_WORDS; i += AND_WG) {
-                pa[i] = pl[i];
-                pa[plw + i] = pl[PL_STRIDE + i];
-                pa[2 * plw + i] = pl[2 * PL_STRIDE + i];
+                uint32_t x[PL_NESTED];
+#pragma unroll
+                for (uint32_t k = 0; k < PL_NESTED; ++k) {
+                        x[k] = pl[k * PL_STRIDE + i];
+                        pa[(size_t)k * plw + i] = x[k];
+                }
+                // the level (the number of nested planes a document is in) bit-sliced: odd; 2, 3 or 6; 4 or more
+                lv[3u * i] = x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[4] ^ x[5];
+                lv[3u * i + 1u] = (x[1] & ~x[3]) | x[5];
+                lv[3u * i + 2u] = x[3];
         }
 }
 
@@ -151,7 +161,9 @@ constexpr int PLK_WG = 512;
 // (PLK_MAX_SPARSE, PLK_NS_SMALL: dev_structs.hpp)
 constexpr uint32_t PLK_CAP = 512;       // candidate buffer (one entry per thread when it is pruned)
 constexpr uint32_t PLK_PRUNE_AT = 384;  // the waves stop taking candidates once it holds this many: it is pruned to the best k, then they resume
-constexpr uint32_t PLK_FTAB_WORDS = (1u << (2 * FUS_MAX_SLOTS)) / 32; // the level table: one bit per level vector (two bits per dense slot)
+constexpr uint32_t PLK_LV = PL_NESTED;   // a dense slot's top level (the planes' "read it from the postings"); levels 1 .. PLK_LV - 1 are the frequency
+constexpr uint32_t PLK_TAB_ND = 5;       // the level table (three bits per dense position) and the presence table cover queries of up to this many dense slots
+constexpr uint32_t PLK_FTAB_WORDS = (1u << (3 * PLK_TAB_ND)) / 32; // the level table: one bit per level vector
 #ifndef TRI_PLK_WGS
 #define TRI_PLK_WGS 2
 #endif
@@ -170,20 +182,20 @@ struct PlanesShared {
         double tk_s[PLK_CAP];
         uint32_t tk_d[PLK_CAP];
         DevTerm term[FUS_MAX_SLOTS];
-        double wl[FUS_MAX_SLOTS][4]; // per slot and level: what its scorers add (exact below the slot's top level)
-        double wf[FUS_MAX_SLOTS][4]; // ... rounded up a hair for the filter (it must never lose a tie to rounding), non-decreasing in the level; top level: a bound
-        double dwf[FUS_MAX_SLOTS][4]; // wf[] of the DENSE slots, by dense position (the sweep's tables are over dense positions)
+        double wl[FUS_MAX_SLOTS][8]; // per slot and level (= frequency, below PLK_LV): what its scorers add
+        double wf[FUS_MAX_SLOTS][8]; // ... rounded up a hair for the filter (it must never lose a tie to rounding), non-decreasing in the level; level PLK_LV: a bound
+        double dwf[FUS_MAX_SLOTS][8]; // wf[] of the DENSE slots, by dense position (the sweep's tables are over dense positions)
         double thr_s;
         uint32_t thr_d;
         uint32_t tk_n, tk_full, matches;
-        uint32_t top[FUS_MAX_SLOTS];  // per slot: its top level (3: a term plane; 2: a decoded list; 0: no scorer)
+        uint32_t top[FUS_MAX_SLOTS];  // per slot: PLK_LV where it has a scorer, else 0
         uint32_t dtop[FUS_MAX_SLOTS], ddocs[FUS_MAX_SLOTS]; // by dense position: top level, the term's documents
-        uint32_t esel;                // the essential planes (two bits per dense position — 0: A, 1: B, 2: C, 3: none): every candidate is in one of them
+        uint32_t esel;                // the essential planes (three bits per dense position — its nested plane 0 .. PL_NESTED - 1, 7: none): every candidate is in one of them
         uint32_t fall;                // 1: no threshold yet (or one that rules nothing out): every match is a candidate
         uint32_t atab;                // the presence table (up to five dense slots): bit `set` <=> the bounds of the slots of `set` reach the threshold
-        uint32_t ftab[PLK_FTAB_WORDS]; // the level table: bit `code` (two bits per dense position: its level) set <=> the levels' weights reach the threshold
+        uint32_t ftab[PLK_FTAB_WORDS]; // the level table: bit `code` (three bits per dense position: its level) set <=> the levels' weights reach the threshold
         uint32_t flag[PLK_WG / 64];
-        uint32_t wq[PLK_WG / 64][PLK_WQ][2]; // per wave: candidates waiting for exact frequencies {docID, the slots' levels (two bits per SLOT)}
+        uint32_t wq[PLK_WG / 64][PLK_WQ][2]; // per wave: candidates waiting for exact frequencies {docID, the slots' levels (three bits per SLOT)}
         uint32_t bcast[4];
         uint32_t sp_row0[FUS_MAX_SLOTS], sp_n[FUS_MAX_SLOTS], sp_base[FUS_MAX_SLOTS]; // sparse slots: first row, rows, first entry of the list in the scratch region
         uint32_t hf[PLK_HF / 4];      // the hashed filter (bytes)
@@ -206,12 +218,19 @@ __device__ __forceinline__ PlanesShared &plk_shared() {
 }
 static_assert(sizeof(PlanesShared) * PLK_WGS_PER_CU <= 160u * 1024u, "the workgroups of a CU share its LDS");
 
-// A row of a decoded slot into its list: 32 entries per row (docID << 1 | frequency-is-not-1), the unused ones of a short last row padded.
+// A row of a sparse slot into its list: 32 entries per row (docID << 1 | frequency-is-not-1), the unused ones of a short last row padded; the
+// frequencies themselves go into a parallel array (fout[i] belongs to out[i])
 struct ListPost {
-        uint32_t *out;
+        uint32_t *out, *fout;
         uint32_t i = 0;
-        __device__ __forceinline__ void doc(const uint32_t rel) { out[i++] = rel << 1 | 1u; }
-        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) { out[i++] = rel << 1 | ((f & 0xffffu) != 1u ? 1u : 0u); }
+        __device__ __forceinline__ void doc(const uint32_t rel) {
+                fout[i] = 0u;
+                out[i++] = rel << 1 | 1u;
+        }
+        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) {
+                fout[i] = f & 0xffffu;
+                out[i++] = rel << 1 | ((f & 0xffffu) != 1u ? 1u : 0u);
+        }
 };
 
 // A score as an unsigned key of the same order (0: none), for the per-query threshold the tasks of a query share
@@ -281,13 +300,13 @@ __device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t 
 // the nd DENSE slots by their dense position (a document the sweep may offer holds no sparse term: phase A owns those).  A slot is at a level
 // 0 .. dtop[i] in a document and adds at most dwf[i][level] there (exactly, below the top level), so a document's score is at most the sum of
 // its slots' level weights:
-//   * the LEVEL table holds, for every level vector (two bits per position), whether that sum reaches the current k-th best score — a
-//     document whose frequencies are all known (almost all) is thereby tested against its EXACT score without being touched;
-//   * the PRESENCE table (nd <= 5) holds the same for the sets of slots a document may hold, every slot at its top level's bound: what the
-//     sweep evaluates word-wise on plane A alone, before anyone looks at planes B and C;
+//   * the LEVEL table (nd <= PLK_TAB_ND) holds, for every level vector (three bits per position), whether that sum reaches the current k-th
+//     best score — a document whose frequencies the planes tell (almost all) is thereby tested against its EXACT score without being touched;
+//   * the PRESENCE table (nd <= PLK_TAB_ND) holds the same for the sets of slots a document may hold, every slot at its top level's bound: what
+//     the sweep evaluates word-wise on plane A alone;
 //   * the essential planes: with the slots ordered by their bound, the longest prefix whose bounds sum to less than the threshold cannot lift a
 //     document over it, so a candidate holds one of the OTHER slots; what is left of the threshold then buys those slots' LOW levels (a slot
-//     capped at level c is essential only through its plane c + 1).  Stage 3 ORs the essential planes before it walks a word's documents.
+//     capped at level c is essential only through its plane c: frequency > c).  The sweep fetches that plane beside plane A.
 // No threshold yet, or one that rules nothing out: every match is a candidate.
 __device__ void planes_filter(PlanesShared &sh, const uint32_t nd) {
         const uint32_t tid = threadIdx.x;
@@ -303,26 +322,28 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nd) {
         if (tid < 64) { // (wave 0; lanes 32 .. 63 mirror): the presence table — same summation order as the level table, every addend at least the level's
                 const uint32_t set = tid & 31u;
                 double sum = 0.0;
-                for (uint32_t i = 0; i < nd && i < 5u; ++i)
+                for (uint32_t i = 0; i < nd && i < PLK_TAB_ND; ++i)
                         sum += ((set >> i) & 1u) && sh.dtop[i] ? sh.dwf[i][sh.dtop[i]] : 0.0;
                 const uint64_t bm = __builtin_amdgcn_ballot_w64(!(sum < thr));
                 sh.atab = (uint32_t)bm; // (same value from every lane)
         }
-        const uint32_t words = (1u << (2 * nd)) / 32u > 0 ? (1u << (2 * nd)) / 32u : 1u;
-        for (uint32_t wd = tid; wd < words; wd += PLK_WG) {
-                uint32_t bits = 0;
-                for (uint32_t j = 0; j < 32; ++j) {
-                        const uint32_t code = wd * 32u + j;
-                        double sum = 0.0;
-                        bool valid = code < (1u << (2 * nd));
-                        for (uint32_t i = 0; i < nd; ++i) {
-                                const uint32_t l = (code >> (2 * i)) & 3u;
-                                valid &= l <= sh.dtop[i];
-                                sum += l ? sh.dwf[i][l] : 0.0;
+        if (nd <= PLK_TAB_ND) {
+                const uint32_t codes = 1u << (3 * nd), words = codes / 32u > 0 ? codes / 32u : 1u;
+                for (uint32_t wd = tid; wd < words; wd += PLK_WG) {
+                        uint32_t bits = 0;
+                        for (uint32_t j = 0; j < 32; ++j) {
+                                const uint32_t code = wd * 32u + j;
+                                double sum = 0.0;
+                                bool valid = code < codes;
+                                for (uint32_t i = 0; i < nd; ++i) {
+                                        const uint32_t l = (code >> (3 * i)) & 7u;
+                                        valid &= l <= sh.dtop[i];
+                                        sum += l ? sh.dwf[i][l & 7u] : 0.0;
+                                }
+                                bits |= (valid && !(sum < thr) ? 1u : 0u) << j;
                         }
-                        bits |= (valid && !(sum < thr) ? 1u : 0u) << j;
+                        sh.ftab[wd] = bits;
                 }
-                sh.ftab[wd] = bits;
         }
         // the essential planes (same values in every lane): whole slots first, by ascending bound ...
         const double thr_lo = thr * (1.0 - 1e-9); // (the table adds the weights in its own order: a hair of room for the rounding)
@@ -345,21 +366,22 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nd) {
                 else
                         spent = p;
         }
-        // ... then what is left of the threshold buys the essential slots' LOW levels: a slot capped at level c is essential only through
-        // its plane c + 1 (B: frequency not 1 — a fraction of A; C: nor 2).  Each round takes the raise that drops the most documents
-        // (estimated from the terms' document counts) among those that still fit.
+        // ... then what is left of the threshold buys the essential slots' LOW levels: a slot capped at level c is essential only through its plane
+        // c (frequency > c: a fraction of the plane below).  Each round takes the raise that drops the most documents (estimated from the terms'
+        // document counts and a frequency's usual share) among those that still fit.
         uint32_t cap[FUS_MAX_SLOTS];
         for (uint32_t i = 0; i < FUS_MAX_SLOTS; ++i)
-                cap[i] = i < nd && ((ess >> i) & 1u) ? 0u : 3u;
-        for (uint32_t r = 0; r < 2 * FUS_MAX_SLOTS; ++r) {
+                cap[i] = i < nd && ((ess >> i) & 1u) ? 0u : 7u;
+        for (uint32_t r = 0; r < PLK_LV * FUS_MAX_SLOTS; ++r) {
                 uint32_t best = 0xffffffffu;
                 double gain = 0.0, cost = 0.0;
                 for (uint32_t i = 0; i < nd; ++i) {
                         const uint32_t c = cap[i], tp = sh.dtop[i];
                         if (c >= tp) // (its top plane already, or not essential at all)
                                 continue;
-                        const double dw = sh.dwf[i][c + 1] - (c ? sh.dwf[i][c] : 0.0);
-                        const double docs = (double)sh.ddocs[i] * (c == 0 ? 0.65 : c == 1 ? 0.2 : 0.15); // (the documents at exactly level c + 1, roughly)
+                        const double dw = sh.dwf[i][(c + 1) & 7u] - (c ? sh.dwf[i][c & 7u] : 0.0);
+                        const double share = c == 0 ? 0.65 : c == 1 ? 0.2 : c == 2 ? 0.1 : c == 3 ? 0.03 : c == 4 ? 0.015 : 0.005; // (the documents at exactly level c + 1, roughly)
+                        const double docs = (double)sh.ddocs[i] * share;
                         if (spent + dw < thr_lo && gain < docs) {
                                 gain = docs;
                                 cost = dw;
@@ -374,7 +396,7 @@ __device__ void planes_filter(PlanesShared &sh, const uint32_t nd) {
         uint32_t esel = 0;
         for (uint32_t i = 0; i < FUS_MAX_SLOTS; ++i) {
                 const uint32_t c = cap[i], tp = i < nd ? sh.dtop[i] : 0u;
-                esel |= (c + 1 > tp ? 3u : c) << (2 * i);
+                esel |= (c + 1 > tp ? 7u : c) << (3 * i);
         }
         sh.esel = uni(esel);
         __syncthreads();
@@ -430,10 +452,10 @@ __device__ __noinline__ uint32_t planes_lookup_freq(const uint8_t *__restrict__ 
 template <int CODEC>
 __device__ __noinline__ void planes_list_row(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
                                              const uint4 *__restrict__ blk_rec, const uint32_t *__restrict__ blk_doff, const DevTerm &t, const uint32_t b,
-                                             uint32_t *__restrict__ out) {
+                                             uint32_t *__restrict__ out, uint32_t *__restrict__ fout) {
         const uint32_t *bl = blk_last + t.first_block;
         const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
-        ListPost post{out};
+        ListPost post{out, fout};
 #ifdef TRI_PROF
         ProfClock prof_;
 #endif
@@ -497,7 +519,8 @@ __device__ __forceinline__ void planes_presence_tree(const uint32_t T, const uin
 typedef const __attribute__((address_space(1))) uint32_t *PlkG1;
 typedef uint32_t PlkU2 __attribute__((ext_vector_type(2))); // (a built-in vector: loads through an address-space pointer need no operator=)
 typedef const __attribute__((address_space(1))) PlkU2 *PlkG2;
-// the entry of `doc` in a sorted list of n entries (docID << 1 | flag; padding sorts last), PLK_PAD when it holds none
+// where `doc` stands in a sorted list of n entries (docID << 1 | flag; padding sorts last), PLK_NOT_FOUND when the list does not hold it
+constexpr uint32_t PLK_NOT_FOUND = 0xffffffffu;
 template <typename P> __device__ __forceinline__ uint32_t planes_list_find(const P ls, const uint32_t n, const uint32_t doc) {
         uint32_t lo = 0, hi = n;
         const uint32_t key = doc << 1;
@@ -509,7 +532,7 @@ template <typename P> __device__ __forceinline__ uint32_t planes_list_find(const
                         hi = mid;
         }
         const uint32_t f = lo < n ? ls[lo] : PLK_PAD;
-        return (f >> 1) == doc ? f : PLK_PAD;
+        return (f >> 1) == doc ? lo : PLK_NOT_FOUND;
 }
 
 // how far ahead the sweep fetches plane A: ND slots x two words per lane and sub-window in flight per step of the ring (about a kilobyte
@@ -559,15 +582,6 @@ __device__ __noinline__ uint32_t planes_work_words(const uint32_t *__restrict__ 
         const double thr_s = sh.thr_s;
         const uint32_t thr_d = sh.thr_d;
         const uint32_t esel = uni(sh.esel);
-        uint32_t es_a = 0, es_b = 0, es_c = 0; // the essential planes as bit sets over the dense positions
-#pragma unroll
-        for (uint32_t i = 0; i < ND; ++i) {
-                const uint32_t e = (esel >> (2 * i)) & 3u;
-                es_a |= (e == 0 ? 1u : 0u) << i;
-                es_b |= (e == 1 ? 1u : 0u) << i;
-                es_c |= (e == 2 ? 1u : 0u) << i;
-        }
-        es_a = uni(es_a), es_b = uni(es_b), es_c = uni(es_c);
         const bool fall = uni(sh.fall) != 0;
         auto offer = [&](const double sc, const uint32_t doc) __attribute__((always_inline)) { // false: no room (the buffer wants pruning)
                 const uint32_t slot = atomicAdd(&sh.tk_n, 1u);
@@ -577,127 +591,122 @@ __device__ __noinline__ uint32_t planes_work_words(const uint32_t *__restrict__ 
                 sh.tk_d[slot] = doc;
                 return true;
         };
-        // ---- a batch of candidate words: the last (up to) 64 of the queue, one per lane.  false: it stopped short (the frequency queue or the
-        //      candidate buffer is full) — what is left of the words' candidates is back on the queue
-        {
-                const uint32_t take_n = min(cqn, 64u), base = cqn - take_n;
-                cqn = base;
-                const bool mine = lane < take_n;
-                const uint32_t wi = mine ? sh.cq[wave][base + lane][0] : lane; // (a lane without a word reads the row's first words and has no candidates)
-                uint32_t cw = mine ? sh.cq[wave][base + lane][1] : 0u;
-                uint32_t a[ND], b[ND], c[ND];
+        const uint32_t take_n = min(cqn, 64u), base = cqn - take_n;
+        cqn = base;
+        const bool mine = lane < take_n;
+        const uint32_t wi = mine ? sh.cq[wave][base + lane][0] : lane; // (a lane without a word reads the row's first words and has no candidates)
+        uint32_t cw = mine ? sh.cq[wave][base + lane][1] : 0u;
+        // the word's level in every dense slot, bit-sliced: the planes are nested, the level is the number of them a document is in — its three
+        // bits word-wise (l0: the level is odd; l1: it is 2, 3 or 6; l2: it is 4 or more), and the slot's essential plane on the way
+        uint32_t l0[ND], l1[ND], l2[ND], ew = 0;
+        static_assert(PL_NESTED == 6 && PL_LEVEL_WORDS == 3, "the planes' words below are derived from three level bits of six levels");
 #pragma unroll
-                for (uint32_t i = 0; i < ND; ++i) { // (all the loads first: one round trip)
-                        const uint32_t at = i < nd ? wi : lane;
-                        a[i] = pa1[i][at];
-                        b[i] = pa1[i][plw + at];
-                        c[i] = pa1[i][2 * plw + at];
-                }
-                if (!fall) {
-                        // the documents in an essential plane, word-wise; each of them then with its level vector in the table
-                        uint32_t ew = 0;
-                        static_for<ND>([&](auto I) __attribute__((always_inline)) { ew = and_or(a[I], umask_at<I>(es_a), ew); });
-                        if (es_b) {
-                                static_for<ND>([&](auto I) __attribute__((always_inline)) { ew = and_or(b[I], umask_at<I>(es_b), ew); });
-                        }
-                        if (es_c) {
-                                static_for<ND>([&](auto I) __attribute__((always_inline)) { ew = and_or(c[I], umask_at<I>(es_c), ew); });
-                        }
-                        ew &= cw;
+        for (uint32_t i = 0; i < ND; ++i) { // (all the loads first: one round trip — three adjacent words per slot)
+                const PlkG1 lv = pa1[i] + (size_t)PL_NESTED * plw + 3u * (i < nd ? wi : lane);
+                l0[i] = lv[0];
+                l1[i] = lv[1];
+                l2[i] = lv[2];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < ND; ++i) {
+                // the slot's essential plane (nested plane e: the level is above e) from the level's bits
+                const uint32_t e = uni((esel >> (3 * i)) & 7u);
+                const uint32_t x0 = l0[i], x1 = l1[i], x2 = l2[i];
+                ew |= e == 0u ? x0 | x1 | x2 : e == 1u ? x1 | x2 : e == 2u ? x2 | (x1 & x0) : e == 3u ? x2 : e == 4u ? x2 & (x0 | x1) : e == 5u ? x2 & x1 : 0u; // (uniform selects)
+                if (!((leafd >> i) & 1u)) // (a slot without a scorer: level 0)
+                        l0[i] = l1[i] = l2[i] = 0u;
+        }
+        if (!fall) {
+                // the documents in an essential plane; each of them then with its level vector in the table (queries of up to PLK_TAB_ND dense slots)
+                ew &= cw;
+                if constexpr (ND <= PLK_TAB_ND) {
                         cw = 0;
-                        // the planes are nested, the level is the number of them a document is in: its two bits, word-wise
-                        uint32_t lo[ND], hi[ND];
-#pragma unroll
-                        for (uint32_t i = 0; i < ND; ++i) {
-                                lo[i] = ((leafd >> i) & 1u) ? a[i] ^ b[i] ^ c[i] : 0u; // (a slot without a scorer: level 0)
-                                hi[i] = ((leafd >> i) & 1u) ? b[i] : 0u;
-                        }
                         while (__builtin_amdgcn_ballot_w64(ew != 0) != 0ull) {
                                 const uint32_t bit = ew ? (uint32_t)__builtin_ctz(ew) : 0u;
                                 uint32_t code = 0;
 #pragma unroll
                                 for (uint32_t i = 0; i < ND; ++i)
-                                        code |= (((lo[i] >> bit) & 1u) << (2 * i)) | (((hi[i] >> bit) & 1u) << (2 * i + 1));
+                                        code |= (((l0[i] >> bit) & 1u) << (3 * i)) | (((l1[i] >> bit) & 1u) << (3 * i + 1)) | (((l2[i] >> bit) & 1u) << (3 * i + 2));
                                 const uint32_t hit = (sh.ftab[code >> 5] >> (code & 31u)) & 1u;
                                 cw |= ew ? hit << bit : 0u;
                                 ew &= ew - 1u;
                                 PROF_COUNT(20, lane == 0 ? 1 : 0);
                         }
-                }
-                // One step over the words' candidates: every lane that has one takes its lowest, scores it from the level words — the known part
-                // of the score and a bound for the rest — and offers it, queues it (a slot of unknown frequency that the bound does not rule out)
-                // or drops it.  A document of a sparse list is dropped: phase A has scored it.  offer false: no room (the candidate stays).
-                bool short_ = false;
-                while (__builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
-                        if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
-                                short_ = true;
-                                PROF_COUNT(23, lane == 0 ? 1 : 0);
-                                break;
-                        }
-                        bool enq = false;
-                        uint32_t edoc = 0, elev = 0;
-                        if (cw) {
-                                const uint32_t bit = (uint32_t)__builtin_ctz(cw);
-                                const uint32_t doc = 32u * wi + bit;
-                                const uint32_t hb = (sh.hf[(doc & (PLK_HF - 1u)) >> 2] >> (8u * (doc & 3u))) & 0xffu;
-                                bool sparse_doc = false;
-                                if (hb) {
-                                        for (uint32_t j = 0; j < nsp; ++j)
-                                                if ((hb >> j) & 1u)
-                                                        sparse_doc = sparse_doc || planes_list_find(lists1 + sh.sa.sp_off[j], sh.sa.sp_n32[j], doc) != PLK_PAD;
-                                }
-                                bool done = true;
-                                if (!sparse_doc) {
-                                        double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency is not known
-                                        uint32_t levels = 0;
-                                        bool unk = false;
-#pragma unroll
-                                        for (uint32_t i = 0; i < ND; ++i) {
-                                                if (!((leafd >> i) & 1u) || !((a[i] >> bit) & 1u))
-                                                        continue;
-                                                const uint32_t bb = (b[i] >> bit) & 1u, cc = (c[i] >> bit) & 1u;
-                                                const uint32_t l = 1u + bb + (bb & cc);
-                                                levels |= l << (2u * dsl[i]);
-                                                if (l < 3u)
-                                                        sk += sh.wl[dsl[i]][l];
-                                                else {
-                                                        unk = true;
-                                                        sb += sh.dwf[i][3];
-                                                }
-                                        }
-                                        if (!full || better(sk + sb, doc, thr_s, thr_d)) {
-                                                if (unk) {
-                                                        enq = true;
-                                                        edoc = doc;
-                                                        elev = levels;
-                                                } else
-                                                        done = offer(sk, doc); // (no room: the candidate stays for after the prune)
-                                        }
-                                }
-                                if (done)
-                                        cw &= cw - 1u;
-                        }
-                        PROF_COUNT(16, lane == 0 ? 1 : 0);
-                        const uint64_t em = __builtin_amdgcn_ballot_w64(enq);
-                        if (enq) {
-                                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-                                sh.wq[wave][at][0] = edoc;
-                                sh.wq[wave][at][1] = elev;
-                        }
-                        qn += (uint32_t)__popcll(em);
-                }
-                if (short_) { // the words that still hold candidates go back (the level table has been through them: only survivors are left)
-                        const uint64_t bm = __builtin_amdgcn_ballot_w64(cw != 0);
-                        if (cw) {
-                                const uint32_t at = cqn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                                sh.cq[wave][at][0] = wi;
-                                sh.cq[wave][at][1] = cw;
-                        }
-                        cqn += (uint32_t)__popcll(bm);
-                }
-                PROF_COUNT(21, lane == 0 ? 1 : 0);
-                return qn | cqn << 16 | (short_ ? 0x80000000u : 0u);
+                } else
+                        cw = ew;
         }
+        // One step over the words' candidates: every lane that has one takes its lowest, scores it from its levels — exactly where the planes tell
+        // the frequencies, with a bound where they do not — and offers it, queues it (a frequency to be read from the postings that the bound
+        // does not rule out) or drops it.  A document of a sparse list is dropped: phase A has scored it.  offer false: no room (the candidate stays).
+        bool short_ = false;
+        while (__builtin_amdgcn_ballot_w64(cw != 0) != 0ull) {
+                if (qn >= 64 || uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) >= PLK_PRUNE_AT) {
+                        short_ = true;
+                        PROF_COUNT(23, lane == 0 ? 1 : 0);
+                        break;
+                }
+                bool enq = false;
+                uint32_t edoc = 0, elev = 0;
+                if (cw) {
+                        const uint32_t bit = (uint32_t)__builtin_ctz(cw);
+                        const uint32_t doc = 32u * wi + bit;
+                        const uint32_t hb = (sh.hf[(doc & (PLK_HF - 1u)) >> 2] >> (8u * (doc & 3u))) & 0xffu;
+                        bool sparse_doc = false;
+                        if (hb) {
+                                for (uint32_t j = 0; j < nsp; ++j)
+                                        if ((hb >> j) & 1u)
+                                                sparse_doc = sparse_doc || planes_list_find(lists1 + sh.sa.sp_off[j], sh.sa.sp_n32[j], doc) != PLK_NOT_FOUND;
+                        }
+                        bool done = true;
+                        if (!sparse_doc) {
+                                double sk = 0.0, sb = 0.0; // the known part of the score; bounds of the slots whose frequency the planes do not tell
+                                uint32_t levels = 0;
+                                bool unk = false;
+#pragma unroll
+                                for (uint32_t i = 0; i < ND; ++i) {
+                                        const uint32_t l = ((l0[i] >> bit) & 1u) | (((l1[i] >> bit) & 1u) << 1) | (((l2[i] >> bit) & 1u) << 2);
+                                        if (!l)
+                                                continue;
+                                        levels |= l << (3u * dsl[i]);
+                                        if (l < PLK_LV)
+                                                sk += sh.wl[dsl[i]][l];
+                                        else {
+                                                unk = true;
+                                                sb += sh.dwf[i][PLK_LV];
+                                        }
+                                }
+                                if (!full || better(sk + sb, doc, thr_s, thr_d)) {
+                                        if (unk) {
+                                                enq = true;
+                                                edoc = doc;
+                                                elev = levels;
+                                        } else
+                                                done = offer(sk, doc); // (no room: the candidate stays for after the prune)
+                                }
+                        }
+                        if (done)
+                                cw &= cw - 1u;
+                }
+                PROF_COUNT(16, lane == 0 ? 1 : 0);
+                const uint64_t em = __builtin_amdgcn_ballot_w64(enq);
+                if (enq) {
+                        const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                        sh.wq[wave][at][0] = edoc;
+                        sh.wq[wave][at][1] = elev;
+                }
+                qn += (uint32_t)__popcll(em);
+        }
+        if (short_) { // the words that still hold candidates go back (the level table has been through them: only survivors are left)
+                const uint64_t bm = __builtin_amdgcn_ballot_w64(cw != 0);
+                if (cw) {
+                        const uint32_t at = cqn + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        sh.cq[wave][at][0] = wi;
+                        sh.cq[wave][at][1] = cw;
+                }
+                cqn += (uint32_t)__popcll(bm);
+        }
+        PROF_COUNT(21, lane == 0 ? 1 : 0);
+        return qn | cqn << 16 | (short_ ? 0x80000000u : 0u);
 }
 
 template <int ND_>
@@ -720,13 +729,13 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
         for (uint32_t i = 0; i < ND; ++i)
                 pa1[i] = (PlkG1)(planes + (size_t)uni(sh.sa.prow[i]) * PL_PLANES * plw);
         // the slots' ESSENTIAL planes (planes_filter: every candidate is in one of them).  Plane A is in the ring anyway; a slot that is essential through
-        // its plane B or C has that plane's words fetched beside it (any other position fetches the all-zero row's first words: one cache line)
+        // a higher plane (a frequency above some level) has that plane's words fetched beside it (any other position fetches the all-zero row's first words: one cache line)
         PlkG1 pe1[ND];
-        uint32_t es_fetch = 0; // the positions whose essential plane is B or C
+        uint32_t es_fetch = 0; // the positions whose essential plane is one above plane A
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i) {
-                const uint32_t e = (uni(sh.esel) >> (2 * i)) & 3u;
-                const bool bc = i < nd && (e == 1u || e == 2u);
+                const uint32_t e = (uni(sh.esel) >> (3 * i)) & 7u;
+                const bool bc = i < nd && e >= 1u && e < PL_NESTED;
                 es_fetch |= (bc ? 1u : 0u) << i;
                 pe1[i] = bc ? pa1[i] + (size_t)e * plw : (PlkG1)(planes + (size_t)uni(sh.sa.zrow) * PL_PLANES * plw);
         }
@@ -741,16 +750,14 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
         uint32_t my_matches = 0;
         // (threshold and tables move only at a prune, i.e. between two segments)
         const uint32_t esel = uni(sh.esel), atab = uni(sh.atab);
-        uint32_t es_a = 0, es_b = 0, es_c = 0; // the essential planes as bit sets over the dense positions
+        uint32_t es_a = 0, es_any = 0; // the positions that are essential through plane A; through any plane
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i) {
-                const uint32_t e = (esel >> (2 * i)) & 3u;
+                const uint32_t e = (esel >> (3 * i)) & 7u;
                 es_a |= (e == 0 ? 1u : 0u) << i;
-                es_b |= (e == 1 ? 1u : 0u) << i;
-                es_c |= (e == 2 ? 1u : 0u) << i;
+                es_any |= (e != 7u ? 1u : 0u) << i;
         }
-        es_a = uni(es_a), es_b = uni(es_b), es_c = uni(es_c);
-        const uint32_t es_any = es_a | es_b | es_c;
+        es_a = uni(es_a), es_any = uni(es_any);
         (void)es_any, (void)atab;
         const bool fall = uni(sh.fall) != 0;
         PlkU2 ring[PF][ND], ringe[PF][ND], ringm[PF];
@@ -796,7 +803,7 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
                                 p[i] = ring[r][i].x;
                                 qq[i] = ring[r][i].y;
                         }
-                        uint32_t e0 = 0, e1 = 0; // the essential planes' words: B / C as fetched ...
+                        uint32_t e0 = 0, e1 = 0; // the essential planes' words: the higher planes as fetched ...
 #pragma unroll
                         for (uint32_t i = 0; i < ND; ++i) {
                                 e0 |= ringe[r][i].x;
@@ -851,7 +858,7 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
                                 // the presence filter: can the slots a document HOLDS reach the threshold at all?  Up to five dense slots: exactly (the
                                 // table looked up word-wise); more: MaxScore's essential slots — a candidate holds one of them
                                 uint32_t f0 = 0, f1 = 0;
-                                if constexpr (ND <= 5) {
+                                if constexpr (ND <= PLK_TAB_ND) {
                                         planes_presence_tree<ND, 0, ND>(atab, p, qq, f0, f1);
                                         const uint32_t cz = umask_at<0>(atab); // (a threshold nothing is needed for)
                                         f0 |= cz;
@@ -919,7 +926,8 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
         PlanesShared &sh = plk_shared();
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
         const uint32_t wave = uni(tid >> 6);
-        uint32_t *const lists = scratch + (size_t)blockIdx.x * sparse_cap;
+        uint32_t *const lists = scratch + (size_t)blockIdx.x * 2u * sparse_cap; // the sparse slots' lists: entries ...
+        uint32_t *const lfreq = lists + sparse_cap;                            // ... and their frequencies
         PROF_DECL;
         PROF_START();
 #ifdef TRI_PROF
@@ -956,26 +964,35 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         const DevTerm myt = terms[fq.term[kk]];
                         sh.term[kk] = myt;
                         const bool dense = fq.plane[kk] != PL_NONE;
-                        // what the slot's scorers add at frequency 1 and 2, and a bound of what they add at any frequency: BM25 float(w f / (f + 1.2)) < w;
-                        // TF-IDF sqrt(f) w with f <= 65535; Trivial f
-                        double t1 = 0.0, t2 = 0.0, ubs = 0.0;
+                        // what the slot's scorers add at the frequencies the planes tell (1 .. PLK_LV - 1), and a bound of what they add at any frequency:
+                        // BM25 float(w f / (f + 1.2)) < w; TF-IDF sqrt(f) w with f <= 65535; Trivial f
+                        double tl[PLK_LV], ubs = 0.0;
+#pragma unroll
+                        for (uint32_t l = 0; l < PLK_LV; ++l)
+                                tl[l] = 0.0;
                         bool leaf = false;
                         for (uint32_t si = 0; si < q.nscore; ++si)
                                 if (sterms[q.score_base + si] == fq.term[kk]) {
                                         const double wgt = sweights[q.score_base + si];
-                                        t1 += (double)sim_score(sim, wgt, 1u);
-                                        t2 += (double)sim_score(sim, wgt, 2u);
+#pragma unroll
+                                        for (uint32_t l = 1; l < PLK_LV; ++l)
+                                                tl[l] += (double)sim_score(sim, wgt, l);
                                         ubs += sim == TRI_SIM_TRIVIAL ? 65535.0 : sim == TRI_SIM_TFIDF ? (wgt > 0 ? 256.0 * wgt : 0.0) : (wgt > 0 ? wgt : 0.0);
                                         leaf = true;
                                 }
-                        const uint32_t top = !leaf ? 0u : dense ? 3u : 2u;
                         auto up = [](const double x) { return x > 0 ? x * (1.0 + 1e-9) : x * (1.0 - 1e-9); };
-                        const double bound = fmax(ubs * (1.0 + 1e-6), fmax(up(t1), up(t2)));
-                        sh.wl[kk][0] = 0.0, sh.wl[kk][1] = t1, sh.wl[kk][2] = t2, sh.wl[kk][3] = 0.0;
                         // the filter's weights: non-decreasing in the level (a negative contribution is bounded by the level below), the top one a bound
-                        const double f1 = fmax(up(t1), 0.0), f2 = top == 3 ? fmax(up(t2), f1) : bound;
-                        sh.wf[kk][0] = 0.0, sh.wf[kk][1] = f1, sh.wf[kk][2] = f2, sh.wf[kk][3] = bound;
-                        sh.top[kk] = top;
+                        double fl = 0.0;
+                        sh.wl[kk][0] = 0.0, sh.wf[kk][0] = 0.0;
+#pragma unroll
+                        for (uint32_t l = 1; l < PLK_LV; ++l) {
+                                fl = fmax(up(tl[l]), fl);
+                                sh.wl[kk][l] = tl[l];
+                                sh.wf[kk][l] = fl;
+                        }
+                        sh.wl[kk][PLK_LV] = 0.0;
+                        sh.wf[kk][PLK_LV] = fmax(ubs * (1.0 + 1e-6), fl);
+                        sh.top[kk] = leaf ? PLK_LV : 0u;
                         sh.tk_n = 0;
                         {
                                 // (another range of the query may have a threshold already: this one filters with it from its first document on)
@@ -1067,7 +1084,9 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
 #pragma unroll
                 for (uint32_t i = 0; i < NS; ++i)
                         if (tid == i && i < nd) {
-                                sh.dwf[i][0] = sh.wf[dsl[i]][0], sh.dwf[i][1] = sh.wf[dsl[i]][1], sh.dwf[i][2] = sh.wf[dsl[i]][2], sh.dwf[i][3] = sh.wf[dsl[i]][3];
+#pragma unroll
+                                for (uint32_t l = 0; l <= PLK_LV; ++l)
+                                        sh.dwf[i][l] = sh.wf[dsl[i]][l];
                                 sh.dtop[i] = sh.top[dsl[i]];
                                 sh.ddocs[i] = sh.term[dsl[i]].documents;
                         }
@@ -1084,7 +1103,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 s = s2 + 1;
                                         }
                                 }
-                                planes_list_row<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, sh.term[s], sh.sp_row0[s] + r, lists + sh.sp_base[s] + r * 32u);
+                                planes_list_row<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, sh.term[s], sh.sp_row0[s] + r, lists + sh.sp_base[s] + r * 32u, lfreq + sh.sp_base[s] + r * 32u);
                         }
                 }
                 __syncthreads(); // (the lists are written: a workgroup barrier orders the global stores for the workgroup's own later loads)
@@ -1104,7 +1123,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 }
                 const uint32_t total_items = list_rows * 32u;
                 // an item (index into the concatenation of the lists) -> its list's ordinal and the entry
-                auto item_entry = [&](const uint32_t v, uint32_t &j_out) {
+                auto item_entry = [&](const uint32_t v, uint32_t &j_out, uint32_t &at_out) {
                         uint32_t j = 0, ei = v, off = 0;
 #pragma unroll
                         for (uint32_t j2 = 0; j2 < PLK_MAX_SPARSE; ++j2) {
@@ -1115,12 +1134,13 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                 off = j == j2 ? sp_off[j2] : off;
                         }
                         j_out = j;
+                        at_out = off + ei;
                         return v < total_items && j < nsp ? lists[off + ei] : PLK_PAD;
                 };
                 // ---- the hashed filter: every sparse document of the range marks its byte with its list's bit
                 for (uint32_t v = tid; v < total_items; v += PLK_WG) {
-                        uint32_t j;
-                        const uint32_t e = item_entry(v, j), doc = e >> 1;
+                        uint32_t j, at;
+                        const uint32_t e = item_entry(v, j, at), doc = e >> 1;
                         if (e != PLK_PAD && doc >= d_lo && doc < d_hi)
                                 atomicOr(&sh.hf[(doc & (PLK_HF - 1u)) >> 2], (1u << j) << (8u * (doc & 3u)));
                 }
@@ -1137,15 +1157,15 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.tk_d[slot] = doc;
                         return true;
                 };
-                // the exact score of a document from its slots' levels (two bits per slot): frequencies 1 / 2 from the level weights, anything
-                // else from the postings
+                // the exact score of a document from its DENSE slots' levels (three bits per slot): the frequencies the planes tell from the level weights,
+                // the others from the postings
                 auto exact_score = [&](const uint32_t doc, const uint32_t levels) {
                         double sk = 0.0;
                         for (uint32_t s = 0; s < nslots; ++s) {
-                                const uint32_t l = (levels >> (2 * s)) & 3u;
+                                const uint32_t l = (levels >> (3 * s)) & 7u;
                                 if (!l)
                                         continue;
-                                if (l < sh.top[s]) {
+                                if (l < PLK_LV) {
                                         sk += sh.wl[s][l];
                                         continue;
                                 }
@@ -1212,10 +1232,11 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                 break; // the buffer wants pruning first: to the barrier (the chunk stays as it is)
                                         const bool full = uni(sh.tk_full) != 0;
                                         if (!have) {
-                                                uint32_t j;
-                                                const uint32_t e = item_entry(chunk * 64u + lane, j), doc = e >> 1;
+                                                uint32_t j, at;
+                                                const uint32_t e = item_entry(chunk * 64u + lane, j, at), doc = e >> 1;
                                                 bool valid = e != PLK_PAD && doc >= d_lo && doc < d_hi && doc != 0;
                                                 uint32_t present = 0, levels = 0;
+                                                double sk = 0.0; // the sparse slots' part of the score: their frequencies stand in the lists
                                                 if (valid) {
                                                         // the other sparse lists that may hold the document (the filter's byte), each bisected: a document an
                                                         // EARLIER list holds is that list's item
@@ -1224,30 +1245,37 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                         for (uint32_t j2 = 0; j2 < PLK_MAX_SPARSE; ++j2) {
                                                                 if (j2 >= nsp)
                                                                         break;
-                                                                uint32_t f = PLK_PAD;
+                                                                uint32_t fat = PLK_NOT_FOUND;
                                                                 if (j2 == j)
-                                                                        f = e;
-                                                                else if ((hb >> j2) & 1u)
-                                                                        f = planes_list_find(lists + sp_off[j2], sp_n32[j2], doc);
-                                                                if (f != PLK_PAD) {
+                                                                        fat = at;
+                                                                else if ((hb >> j2) & 1u) {
+                                                                        fat = planes_list_find(lists + sp_off[j2], sp_n32[j2], doc);
+                                                                        fat = fat != PLK_NOT_FOUND ? fat + sp_off[j2] : fat;
+                                                                }
+                                                                if (fat != PLK_NOT_FOUND) {
                                                                         valid = valid && j2 >= j;
                                                                         present |= 1u << ssl[j2];
-                                                                        levels |= (((leafm >> ssl[j2]) & 1u) ? 1u + (f & 1u) : 0u) << (2u * ssl[j2]);
+                                                                        if ((leafm >> ssl[j2]) & 1u) {
+                                                                                const uint32_t f = lfreq[fat], term = fq.term[ssl[j2]];
+                                                                                for (uint32_t si = 0; si < q.nscore; ++si)
+                                                                                        if (sterms[q.score_base + si] == term)
+                                                                                                sk += (double)sim_score(sim, sweights[q.score_base + si], f);
+                                                                        }
                                                                 }
                                                         }
                                                 }
                                                 pend = false;
                                                 if (valid) {
-                                                        // its level in the dense slots: three plane probes each
+                                                        // its level in the dense slots: one probe each
                                                         const uint32_t wi = doc >> 5, bit = doc & 31u;
 #pragma unroll
                                                         for (uint32_t i = 0; i < NS; ++i) {
                                                                 if (i >= nd)
                                                                         break;
-                                                                const uint32_t *pa = pA[i], *pb = pa + plw, *pc = pb + plw;
-                                                                const uint32_t la = (pa[wi] >> bit) & 1u, l = la + ((pb[wi] >> bit) & 1u) + ((pc[wi] >> bit) & 1u);
-                                                                present |= la << dsl[i];
-                                                                levels |= (((leafd >> i) & 1u) ? l : 0u) << (2u * dsl[i]);
+                                                                const uint32_t *lv = pA[i] + (size_t)PL_NESTED * plw + 3u * wi; // (the level's three bits: adjacent words)
+                                                                const uint32_t l = ((lv[0] >> bit) & 1u) | (((lv[1] >> bit) & 1u) << 1) | (((lv[2] >> bit) & 1u) << 2);
+                                                                present |= (l ? 1u : 0u) << dsl[i];
+                                                                levels |= (((leafd >> i) & 1u) ? l : 0u) << (3u * dsl[i]);
                                                         }
                                                         // the predicate with all the slots, and with the dense slots alone (what the sweep counts)
                                                         const uint32_t pd = present & dense_mask;
@@ -1261,14 +1289,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                                 okf = okd = false;
                                                         my_matches += (okf ? 1u : 0u) - (okd ? 1u : 0u);
                                                         if (okf) {
-                                                                // a bound first: the frequencies beyond the levels cost a walk into the postings
-                                                                double sb = 0.0;
+                                                                // a bound first: a frequency the planes do not tell costs a walk into the postings
+                                                                double sb = sk;
                                                                 for (uint32_t s = 0; s < nslots; ++s) {
-                                                                        const uint32_t l = (levels >> (2 * s)) & 3u;
+                                                                        const uint32_t l = (levels >> (3 * s)) & 7u;
                                                                         sb += l ? sh.wf[s][l] : 0.0;
                                                                 }
-                                                                if (!full || better(sb, doc, sh.thr_s, sh.thr_d)) {
-                                                                        pscore = exact_score(doc, levels);
+                                                                if (!full || better(sb * (1.0 + 1e-9), doc, sh.thr_s, sh.thr_d)) {
+                                                                        pscore = sk + exact_score(doc, levels);
                                                                         pdoc = doc;
                                                                         pend = true;
                                                                 }

@@ -41,7 +41,7 @@ struct tri_options {
                                  // While a batch built its own planes: step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the
                                  // build grew with it).  The planes live with the index now (built once): 128 / 512 / 4096: cfg2 1.48 / 1.44 / 1.40, cfg3 12.64 / 12.40 / 12.4,
                                  // cfg4 17.4 / 16.9 / 16.9 — 355 rows (1.3 GB at 10 M documents) at 512
-        uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs 3 bitmaps over the docID space and one decode per run)
+        uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs PL_PLANES bitmaps over the docID space and one decode per index)
         uint64_t plan_threads = 0;             // host threads tri_batch_create plans with; 0: up to 16, one per 512 queries
         uint64_t result_bitmaps = 1;           // DocumentsOnly: a bitmap-window query whose expected matches outnumber the words of a bitmap over its docID range
                                                // delivers its docID set AS that bitmap (RESULT_BITMAP, dev_structs.hpp); 0: always ascending docIDs
@@ -1607,7 +1607,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         P.slot_of_query.assign(nq, UINT32_MAX);
         P.qstatus.assign(nq, TRI_OK);
         // ---- which terms may get a plane: an indexed list of at least docs_cnt / plane_div documents, the longest lists first up to the
-        //      scratch budget (a plane row is three bitmaps over the docID space)
+        //      scratch budget (a plane row is PL_PLANES bitmaps over the docID space)
         P.plw = ((ix.max_doc >> 17) + 2u) * (SPAN_BITS / 32u); // whole bitmap windows (k_and_dense reads SPAN_WORDS at a time) + a spare one
         C.plw = P.plw;
         if (opt.planes && opt.plane_div && !ix.df_sorted.empty()) {

@@ -807,7 +807,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         }
         if (planes_tasks) {
                 const uint64_t wgs = std::min<uint64_t>(std::max(b->n_planes, b->n_planes8), (uint64_t)dev->cus * PLK_WGS_PER_CU);
-                HIP_TRY(pool_alloc(dev, (void **)&b->d_sparse, (wgs * b->sparse_cap + 64) * 4));
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_sparse, (2 * wgs * b->sparse_cap + 64) * 4)); // (per workgroup: the lists' entries, then their frequencies)
         }
         dbg_lap(2);
         HIP_TRY(pool_alloc(dev, (void **)&b->d_out, (off + 64) * 4));
