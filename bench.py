@@ -147,9 +147,9 @@ class Workload:
     """One rank's shard of a SURVEY §8(d) workload on a device: the segments' indexes and, per engine batch of a step, the query programs
     in the flat form the C-ABI takes (prepared once: what a C++ caller hands to tri_batch_create)."""
 
-    def __init__(self, T, W, dev, name, docs, vocab, total_queries, rank, world, segs, ixs):
+    def __init__(self, T, W, dev, name, docs, vocab, total_queries, rank, world, segs, ixs, seed=1337):
         self.T, self.dev, self.name = T, dev, name
-        self.parts, self.desc = W.build_parts(name, docs, vocab, 10, 42, total_queries)
+        self.parts, self.desc = W.build_parts(name, docs, vocab, 10, 42, total_queries, seed=seed)
         self.build_s = self.upload_s = 0.0
         for pt in self.parts:
             if pt.codec not in segs:
@@ -166,6 +166,21 @@ class Workload:
 
     def create_set(self):
         return [self.T.Batch(self.ixs[pt.codec], None, pt.flags, topk=pt.topk, flat=fl) for pt, fl in zip(self.parts, self.flat)]
+
+
+class RotatingWorkload:
+    """A query STREAM: create_set() hands out the sets of several workloads (same shape, different query seeds) in turn, so that no two
+    consecutive steps run the same programs (the headline loop replays one set: its head terms' planes, L2 and the Infinity Cache are warm
+    by construction)."""
+
+    def __init__(self, wls):
+        self.wls, self.i = wls, 0
+        self.parts, self.nq, self.desc = wls[0].parts, wls[0].nq, wls[0].desc
+
+    def create_set(self):
+        wl = self.wls[self.i % len(self.wls)]
+        self.i += 1
+        return wl.create_set()
 
 
 def read_back(T, bs):  # what every caller needs on the host: match counts and, scored, the top-K blocks
@@ -202,11 +217,14 @@ class Pipeline:
         # 1.45 ms creates and 1.45 ms of kernels)
         self.ready = queue.Queue(maxsize=1)
         self.stop = False
+        self.creates = []  # (start, end) of every create_set() of the compiler thread, time.perf_counter()
 
         def compile_loop():
             while not self.stop:
                 try:
+                    t_c = time.perf_counter()
                     bs = wl.create_set()
+                    self.creates.append((t_c, time.perf_counter()))
                 except BaseException as e:  # (handed to the main loop: a failed create fails the run)
                     self.ready.put(e)
                     return
@@ -284,7 +302,25 @@ def timed(pipe, steps, warmup, barrier):
             for k in MS_KEYS:
                 acc[k] = acc.get(k, 0.0) + i[k]
     barrier()
-    return time.perf_counter() - t0, acc
+    t1 = time.perf_counter()
+    acc["_region"] = (t0, t1)
+    return t1 - t0, acc
+
+
+def create_stats(pipe, region, steps, ms_per_step):
+    """The tri_batch_create calls that RAN inside the timed region (the compiler thread's own clock around create_set(): all batches of a step),
+    and whether the claim "planning is inside the loop" holds: the main loop takes one compiled set per step and the compiler holds at most two
+    ahead (one queued, one in hand), so a region of K steps must see at least K - 2 creates END inside it; and a compiler that needs longer per
+    set than a step lasts would have to have been the loop's bound — the step time cannot be below the median create."""
+    t0, t1 = region
+    inside = sorted((e - s) * 1e3 for s, e in pipe.creates if t0 <= e <= t1)
+    n = len(inside)
+    med = inside[n // 2] if n else None
+    ok = n >= steps - 2 and (med is None or med <= ms_per_step * 1.10)
+    return {"creates_in_timed_region": n, "create_wall_ms": {"min": inside[0], "median": med, "max": inside[-1]} if n else None,
+            "planning_included": bool(ok),
+            "what": "tri_batch_create calls (all batches of a step) that ran to their end inside the timed region, by the compiler thread's clock; planning_included: at least "
+                    "steps - 2 of them did (the compiler runs at most two sets ahead) and their median does not exceed the step time"}  # fmt: skip
 
 
 def main():
@@ -300,6 +336,9 @@ def main():
                     help="SURVEY §8(d) query sets; default: cfg2 at one GPU (the configuration BASELINE.json's metric is quoted on), cfg5 (the mixed 100K batch) at N > 1")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --queries per GPU; strong: --queries in all, split over the GPUs")
     ap.add_argument("--scaling-ref-steps", type=int, default=3, help="steps of the scaling reference leg (0 = skip): N = 1: one rank's cfg5 shard on this GPU; N > 1: rank 0 alone on its shard")
+    ap.add_argument("--rotating-sets", type=int, default=8, help="N = 1: distinct query sets (seeds 1337 ...) cycled through the loop in the rotating legs (0 / 1 = skip them)")
+    ap.add_argument("--rotating-steps", type=int, default=16, help="timed steps of each rotating leg")
+    ap.add_argument("--delivered-steps", type=int, default=3, help="N = 1: steps of the leg that also brings every docID set to pinned host memory (0 = skip)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="planner option (tri_dev_set_option), e.g. fused=0")
     ap.add_argument("--dry-run", action="store_true", help="launcher / sharding / gather plumbing WITHOUT a GPU (tests/test_bench_launch.py): the batches are planned by the real host "
                                                           "planner, nothing runs, the result blocks are zeros on CPU tensors gathered over gloo; the line says dry_run and measures nothing")
@@ -412,6 +451,62 @@ def main():
     # ---- the timed region
     elapsed, acc = timed(pipe, args.steps, args.warmup, barrier)
     readback_ms = pipe.readback_s * 1e3 / max(1, args.steps)
+    region = acc.pop("_region")
+    cstats = create_stats(pipe, region, args.steps, elapsed * 1e3 / max(1, args.steps))
+
+    # ---- legs that make the headline harder to flatter (N = 1, after the timed region; none of them feeds `value`)
+    rotating = delivered = None
+    if world == 1 and not dry and args.rotating_sets > 1 and args.rotating_steps > 0:
+        # (b) a query STREAM: args.rotating_sets distinct sets (query seeds 1337, 1338, ...) cycled through the same loop.  `warm`: every head term's
+        #     plane row is in the index's cache (a cycle of warm-up built them).  `cold_planes`: option planes_rebuild — every run decodes the plane
+        #     rows its batch names again, i.e. what the stream pays when each step's head terms have just been evicted (k_term_planes inside the step)
+        wls = [wl] + [Workload(T, W, dev, args.workload, docs, vocab, total_queries, rank, world, segs, ixs, seed=1337 + i) for i in range(1, args.rotating_sets)]
+        legs = {}
+        for leg, rebuild in (("warm", 0), ("cold_planes", 1)):
+            dev.set_option("planes_rebuild", rebuild)
+            rp = Pipeline(T, RotatingWorkload(wls))
+            el, racc = timed(rp, args.rotating_steps, args.rotating_sets + 2, device_sync)
+            rreg = racc.pop("_region")
+            legs[leg] = {"value": nq_rank * args.rotating_steps / el, "ms_per_step": el * 1e3 / args.rotating_steps, "kernel_ms_per_step": racc["last_run_ms"] / args.rotating_steps,
+                         "term_planes_ms_per_step": racc.get("term_planes_ms", 0.0) / args.rotating_steps, **{k: v for k, v in create_stats(rp, rreg, args.rotating_steps, el * 1e3 / args.rotating_steps).items() if k != "what"}}  # fmt: skip
+            rp.close()
+        dev.set_option("planes_rebuild", 0)
+        rotating = {"sets": args.rotating_sets, "steps": args.rotating_steps, "unit": "queries/s", **legs,
+                    "what": "the same create -> run -> sync -> read-back loop over a STREAM of distinct query sets (seeds 1337 ...; the headline loop replays ONE set): `warm` with every "
+                            "head term's plane row cached with the index, `cold_planes` with the rows a step names decoded again in that step (planes_rebuild: every row evicted)"}  # fmt: skip
+    if world == 1 and not dry and args.delivered_steps > 0:
+        # (c) delivery: the docID sets themselves brought to the host — what MatchedIndexDocumentsFilter::consider(ids, cnt) (matches.h:161-165) is fed — into PINNED
+        #     memory by tri_batch_docsets (one device-side gather + one copy per batch); serial loop (create -> run -> sync -> deliver), no overlap
+        docs_parts = [i for i, pt in enumerate(parts) if not (pt.flags & T.FLAG_ACCUMULATED_SCORE)]
+        need = [int(batches[i].counts().sum()) for i in docs_parts]
+        if docs_parts and max(need) * 4 <= (6 << 30):
+            pinned = torch.empty(max(need) + 64, dtype=torch.int32).pin_memory()
+            bytes_step = 0
+            for it in range(args.delivered_steps + 1):  # (the first one untimed)
+                if it == 1:
+                    device_sync()
+                    t0 = time.perf_counter()
+                bs = wl.create_set()
+                for b in bs:
+                    b.run()
+                bytes_step = 0
+                for i, b in enumerate(bs):
+                    b.sync()
+                    if i in docs_parts:
+                        _, offs = b.docsets(out=pinned)
+                        bytes_step += int(offs[-1]) * 4
+                    else:
+                        read_back(T, [b])
+                for b in bs:
+                    b.close()
+            el = time.perf_counter() - t0
+            delivered = {"value": nq_rank * args.delivered_steps / el, "unit": "queries/s", "ms_per_step": el * 1e3 / args.delivered_steps, "steps": args.delivered_steps,
+                         "docid_bytes_per_step": bytes_step, "host_GBps": bytes_step * args.delivered_steps / el / 1e9,
+                         "what": "create -> run -> sync -> tri_batch_docsets: EVERY query's ascending docID set gathered on the device and copied into pinned host memory (the feed of "
+                                 "consider(ids, cnt)); serial, PCIe-bound — `value` above leaves the sets in HBM"}  # fmt: skip
+            del pinned
+        else:
+            delivered = {"skipped": "no DocumentsOnly part" if not docs_parts else f"{max(need) * 4 / 2**30:.1f} GiB of docIDs per step: not brought to the host in this leg"}
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev_t)
@@ -439,6 +534,18 @@ def main():
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev_t)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         gather_check = {"ranks": world, "blocks": sorted({k for g in gathers for k in g.recv}), "equal_on_every_rank": bool(t.item() == 1.0)}
+    # (c) how many of the step's matches exist as docIDs in HBM (4 bytes each) and how many as bits of a result bitmap (RESULT_BITMAP: dense results)
+    mat_ids = mat_bits = 0
+    for pt, b0 in zip(parts, batches):
+        cnts = b0.counts()
+        if (pt.flags & T.FLAG_ACCUMULATED_SCORE) and pt.topk:
+            mat_ids += int(np.minimum(cnts, pt.topk).sum())  # (a scored top-K batch materialises its top-K lists)
+            continue
+        if dry:
+            continue
+        forms = np.array([b0.docset_form(q) for q in range(len(cnts))], dtype=bool)
+        mat_bits += int(cnts[forms].sum())
+        mat_ids += int(cnts[~forms].sum())
     same_as_resident = all(bool(np.array_equal(b.counts(), b0.counts())) for b, b0 in zip(pipe.done, batches))
 
     if rank == 0:
@@ -511,10 +618,14 @@ def main():
             "per_gpu_value": qps / world,
             "matched_docids_per_sec": matches_all * steps / elapsed,
             "matches_per_step": matches_all,
+            **({"docids_materialised_per_sec": mat_ids * steps / elapsed, "docids_materialised_per_step": mat_ids, "matches_kept_as_bitmap_bits_per_step": mat_bits,
+                "materialised_what": "of this rank's matches per step: written to HBM as 4-byte docIDs (scored batches: their top-K lists) / kept as bits of a result bitmap "
+                                     "(tri_batch_docset_bitmap; tri_batch_docsets expands them on delivery)"} if world == 1 else {}),
             "pipelined_results_equal_resident_batch": same_as_resident,
             "kernels_only": {"value": nq_rank * world / (k_ms * 1e-3) if k_ms > 0 else None, "ms_per_step": k_ms, "unit": "queries/s",
                              "what": "the step's kernels alone (HIP events around tri_batch_run inside the timed steps): no planning, no read-back"},
-            "end_to_end": {"batch_create_ms": acc["create_ms"] / steps, "batch_create_plan_ms": acc["create_plan_ms"] / steps, "readback_ms": readback_ms,
+            "end_to_end": {"batch_create_ms": acc["create_ms"] / steps, "batch_create_plan_ms": acc["create_plan_ms"] / steps, "readback_ms": readback_ms, **cstats,
+                           "batch_create_ms_what": "engine-reported tri_batch_create time of the sets LAUNCHED in the timed steps (they may have been compiled before the region began, and the time includes waiting for the device lock the running thread holds): see create_wall_ms for the creates that ran inside the region",
                            "what": "per step, inside the timed region: tri_batch_create (all batches of the step; its host-planner share) and the read-back of the match counts" +
                                    (" + top-K blocks" if any(pt.topk for pt in parts) else "")},
             "roofline": {
@@ -542,6 +653,11 @@ def main():
             "segment_build_s": wl.build_s,
             "index_upload_s": wl.upload_s,
         }
+        if rotating is not None:
+            out["rotating"] = rotating
+            out["value_rotating"] = rotating["cold_planes"]["value"]
+        if delivered is not None:
+            out["delivered"] = delivered
         if scaling_ref is not None:
             out["scaling_ref"] = scaling_ref
             if world > 1:
@@ -571,7 +687,11 @@ def pmc_traffic(args, world):
         with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as f:
             p = json.load(f)["bench_" + args.workload]
         if (p["docs"], p["vocab"], p["queries"]) == (args.docs, args.vocab, args.queries):
-            return {k: v["traffic_bytes_per_launch"] for k, v in p["kernels"].items()}, "profiles/pmc_latest.json (" + p.get("collected", "committed rocprofv3 --pmc passes") + ")"
+            from trinity_amd.build import kernels_stamp
+
+            if p.get("kernels_stamp") != kernels_stamp():  # the counters were collected on other kernels than the ones this run times: not quoted
+                return None, f"profiles/pmc_latest.json is STALE for this build (collected at kernels_stamp {p.get('kernels_stamp')}, git {p.get('git_head')}; this tree: {kernels_stamp()}): traffic not quoted"
+            return {k: v["traffic_bytes_per_launch"] for k, v in p["kernels"].items()}, "profiles/pmc_latest.json (" + p.get("collected", "committed rocprofv3 --pmc passes") + f"; kernels_stamp {p['kernels_stamp']}, git {p.get('git_head')})"
     except Exception:
         pass
     return None, None

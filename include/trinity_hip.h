@@ -21,9 +21,10 @@
 extern "C" {
 #endif
 
-#define TRI_ABI_VERSION 7 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
+#define TRI_ABI_VERSION 8 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
                              4: tri_batch_info grew (term planes, k_planes), tri_batch_query_status, tri_comm_create_custom; 5: tri_encode_google_payloads;
-                             6: tri_batch_info.create_ms / create_plan_ms / *_bound_bytes, options plane_max_bytes / plan_threads, tri_cbatch_query_status */
+                             6: tri_batch_info.create_ms / create_plan_ms / *_bound_bytes, options plane_max_bytes / plan_threads, tri_cbatch_query_status;
+                             8: tri_batch_docsets (every query's docID set in one call), option planes_rebuild */
 
 /* status codes */
 #define TRI_OK 0
@@ -180,10 +181,12 @@ void *tri_dev_stream(tri_dev *);
  *                         windows, 4 AccumulatedScore top-K CNF queries run over bit planes (k_planes); 0: every query decodes every list it names
  *   "planes_split"        a query that runs as bit planes (k_planes) is cut into this many docID ranges, one task each (default 0: two, or three in a batch that brings few tasks per workgroup; 65536 and up: cut by postings like k_fused's); the
  *                         ranges share the query's threshold, results do not depend on the cut
- *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 128) and the batch's uses repay one
+ *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 512) and the batch's uses repay one
  *                         decode of its list
  *   "account_needed_bytes" 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query; default 0)
  *   "plane_max_bytes"     scratch budget of a batch's term planes (default 8 GiB): the terms eligible for a plane are the longest lists that fit
+ *   "planes_rebuild"      1: every tri_batch_run decodes the plane rows its batch names again — a COLD plane cache, what a query stream whose head
+ *                         terms were all just evicted pays per batch (default 0: a row is built once per index); a measurement switch, read by tri_batch_run
  *   "probe_max_blocks"    > 0: a conjunction of ONE lead list of at most this many blocks with lists that all have planes runs in k_probe (a wave per
  *                         task, csrc/k_probe.hpp) instead of candidate tiles (default 0: off — measured slower at cfg2, planner.hpp)
  *   "overlap"             1: the candidate-tile kernel runs on a second stream beside the window kernels (default 0; measured: no gain, the persistent
@@ -191,7 +194,7 @@ void *tri_dev_stream(tri_dev *);
  *   "plan_threads"        host threads tri_batch_create plans large batches with (default 0: up to 16, by the host's cores; 1: the calling thread
  *                         only).  The threads belong to the handle, are pinned to distinct CPUs next to the creating thread's, and keep polling for
  *                         about 3 ms after a batch before they sleep (csrc/host_pool.hpp says why); read when the first large batch is created
- * ("fused" also takes 2: only pure unions run in one pass.)  The options are read when a batch is CREATED, except the two overlap_* ones,
+ * ("fused" also takes 2: only pure unions run in one pass.)  The options are read when a batch is CREATED, except the two overlap_* ones and planes_rebuild,
  * which tri_batch_run reads (they change how existing batches are launched).  Unknown names fail with TRI_ERR_INVALID. */
 int tri_dev_set_option(tri_dev *, const char *name, uint64_t value);
 int tri_dev_get_option(tri_dev *, const char *name, uint64_t *value);
@@ -268,6 +271,13 @@ int tri_batch_docset(tri_batch *, size_t q, uint32_t *out, size_t cap, size_t *n
  * *first_doc + 32 i + j matches; *nwords words (words == NULL: sizes only).  tri_batch_docset expands such a set on read-back; a caller that
  * replays consider(ids, cnt) (matches.h:161-165) or intersects further can take the words as they are. */
 int tri_batch_docset_bitmap(tri_batch *, size_t q, int *form, uint32_t *words, size_t cap, uint32_t *first_doc, size_t *nwords);
+/* EVERY query's docID set in one call — the batch form of the delivery above: out[offsets[q] .. offsets[q + 1]) = query q's ascending docIDs
+ * (queries in the caller's order, offsets[nq] = the total; out == NULL: offsets only).  The sets are gathered on the device into one contiguous
+ * buffer (task segments in order, bitmap-form results expanded) and cross to the host in ONE copy: with `out` in pinned memory that is PCIe's rate,
+ * where tri_batch_docset pays a copy and a synchronisation per task segment.  What a caller that replays
+ * MatchedIndexDocumentsFilter::consider(const docid_t *, size_t) (matches.h:161-165; exec.cpp:1213-1229 hands every match to consider()) loops
+ * over.  Fails like tri_batch_docset for a query of an AccumulatedScore top-K batch whose set was never materialised. */
+int tri_batch_docsets(tri_batch *, uint32_t *out, size_t cap, uint64_t *offsets /* [nq + 1] */);
 /* AccumulatedScore with topk == 0: the score of every match of query q, parallel to tri_batch_docset(q) — the
  * (id, score) stream MatchedIndexDocumentsFilter::consider(id, score) receives (matches.h:169; exec.cpp:1322-1341) */
 int tri_batch_scores(tri_batch *, size_t q, double *out, size_t cap, size_t *n);

@@ -374,6 +374,41 @@ def test_union_of_head_terms_large(large):
         assert np.array_equal(got, want), (t, len(got), len(want))
 
 
+@pytest.mark.parametrize("world", ["large", "medium_l"])
+def test_docsets_in_one_call(request, world):
+    """tri_batch_docsets: every query's ascending docID set, queries in the caller's order, one device-side gather + one copy — conjunctions cut
+    into many candidate-tile tasks, unions, phrases, NOT, a general tree and an empty result in one batch, also into a caller's buffer
+    and in the default (MatchedTerms) mode; an AccumulatedScore top-K batch refuses."""
+    w = request.getfixturevalue(world)
+    T, V = w.T, w.V
+    texts = [f"t{a} t{b}" for a, b in T.gen_queries(V, 77, 40, 2).tolist()] + ["t0 t1 t2", "t3 OR t5 OR t9", '"t0 t1"', '"t1 t2 t3" t0', "t3 t5 NOT t1", "t2 OR (t0 t1)",
+                                                                              f"t{V - 1} t{V - 2} t{V - 3} t{V - 4}", "t0 OR t1 OR t2 OR t3 OR t4"]  # fmt: skip
+    progs = [O.parse_query(t) for t in texts]
+    want = [w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)[0] for p in progs]
+    for flags in (T.FLAG_DOCUMENTS_ONLY, T.FLAG_MATCHED_TERMS):
+        with options(w.dev, cand_task_cost=4096):  # (many tasks per query: the gather adds up the earlier tasks' matches)
+            b = T.Batch(w.ix, progs, flags)
+        b.run()
+        b.sync()
+        flat, offs = b.docsets()
+        assert offs.tolist() == np.concatenate([[0], np.cumsum([len(x) for x in want])]).tolist()
+        for i, t in enumerate(texts):
+            assert np.array_equal(flat[int(offs[i]) : int(offs[i + 1])], want[i]), t
+        mine = np.full(int(offs[-1]) + 7, 0xFFFFFFFF, dtype=np.uint32)  # (a caller's buffer, larger than needed: the tail stays untouched)
+        flat2, offs2 = b.docsets(out=mine)
+        assert flat2 is mine and np.array_equal(mine[: int(offs[-1])], flat[: int(offs[-1])]) and np.array_equal(offs, offs2) and (mine[int(offs[-1]) :] == 0xFFFFFFFF).all()
+        with pytest.raises(T.TrinityError):
+            b.docsets(out=np.zeros(max(1, int(offs[-1]) - 1), dtype=np.uint32))  # (too small: refused, nothing written past it)
+        b.close()
+    sb = T.Batch(w.ix, progs[:4], T.FLAG_ACCUMULATED_SCORE, topk=10)
+    sb.run()
+    sb.sync()
+    if sb.info()["planes_queries"] + sb.info()["fused_queries"]:
+        with pytest.raises(T.TrinityError):
+            sb.docsets()
+    sb.close()
+
+
 @pytest.mark.parametrize("world", ["large", "dense", "medium_l"])
 def test_docsets_delivered_as_bitmaps(request, world):
     """RESULT_BITMAP (dev_structs.hpp): a DocumentsOnly union / conjunction of head terms expected to match one document in 32 or more is held
@@ -414,6 +449,10 @@ def test_docsets_delivered_as_bitmaps(request, world):
                             nbm += 1
                     assert nbm == info["bitmap_queries"]
                     seen_forms.add(nbm > 0)
+                    flat, offs = b.docsets()  # every set in one call: both forms through k_deliver_docsets
+                    assert int(offs[-1]) == sum(len(x) for x in want)
+                    for i, t in enumerate(texts):
+                        assert np.array_equal(flat[int(offs[i]) : int(offs[i + 1])], want[i]), (opts, t)
                 b.close()
             assert seen_forms == {True, False}
     finally:

@@ -6,6 +6,7 @@ profiles/pmc_latest.json (what bench.py quotes as roofline.traffic, with its sou
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +14,11 @@ tag, rnd = sys.argv[1], sys.argv[2]
 src, dst = os.path.join(root, "gpurun_out", tag), os.path.join(root, "profiles")
 latest_path = os.path.join(dst, "pmc_latest.json")
 latest = json.load(open(latest_path)) if os.path.exists(latest_path) else {}
+sys.path.insert(0, root)
+from trinity_amd.build import kernels_stamp  # noqa: E402
+
+stamp = kernels_stamp()  # (the tree the profiles were collected from: run this before touching the kernels again)
+head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 for f in sorted(os.listdir(src)):
     p = os.path.join(src, f)
     if f.startswith("bench_") and f.endswith(".json") and os.path.getsize(p):
@@ -31,6 +37,7 @@ for f in sorted(os.listdir(src)):
             pass
         latest[f"bench_{name}"] = {
             "collected": f"{rnd}: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --workload {name}; profiles/{rnd}_{f}",
+            "kernels_stamp": stamp, "git_head": head,
             "docs": cfg.get("docs"), "vocab": cfg.get("vocab"), "queries": cfg.get("queries_per_gpu_per_step"),
             "kernels": {k: {"traffic_bytes_per_launch": v["traffic_bytes_per_launch"], "hbm_read_bytes_per_launch_corrected": v["hbm_read_bytes_per_launch_corrected"],
                             "hbm_write_bytes_per_launch": v["hbm_write_bytes_per_launch"], "dispatches": v["dispatches"]} for k, v in table.items() if k.startswith("k_")},

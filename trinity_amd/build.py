@@ -63,3 +63,17 @@ def build_mirror_test(force=False):
 
 def build_all(force=False):
     return build_hip(force), build_host(force), build_mirror_test(force)
+
+
+def kernels_stamp():
+    """SHA-256 (16 hex digits) over the device sources (csrc/*.hip, csrc/*.hpp): what a committed profile is stamped with — bench.py quotes
+    profiles/pmc_latest.json's traffic only while the stamp it carries is that of the kernels it runs."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]

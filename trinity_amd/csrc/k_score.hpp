@@ -515,3 +515,59 @@ __global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const DevTask 
         hashes[s] = h;
 }
 
+// Every query's docID set into ONE contiguous buffer (tri_batch_docsets): a workgroup per task copies the task's segment — or, for a query
+// whose result is a bitmap (RESULT_BITMAP), writes out the documents of its windows' words — to flat[slot_off[query] + the matches of the
+// query's earlier tasks ...).  The in-order concatenation of a query's task segments IS its ascending docID set.
+__global__ __launch_bounds__(256) void k_deliver_docsets(const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks, const uint32_t *__restrict__ counts,
+                                                         const uint32_t *__restrict__ out, const uint64_t *__restrict__ slot_off, uint32_t *__restrict__ flat) {
+        __shared__ uint32_t scan[256];
+        __shared__ uint64_t base_sh;
+        const uint32_t tix = blockIdx.x, tid = threadIdx.x;
+        const DevTask tk = tasks[tix];
+        if (task_onepass(tk.kind) && tk.kind != TASK_FUSED_GEN)
+                return; // (a one-pass scored task keeps no docID set; uniform)
+        const DevQuery q = plan[tk.slot];
+        const uint32_t c = counts[tix];
+        // the matches of the query's earlier tasks
+        uint64_t before = 0;
+        for (uint32_t t = q.first_task + tid; t < tix; t += 256)
+                before += counts[t];
+        scan[tid] = (uint32_t)before; // (a query's matches fit 32 bits)
+        __syncthreads();
+        for (uint32_t d = 128; d; d >>= 1) {
+                if (tid < d)
+                        scan[tid] += scan[tid + d];
+                __syncthreads();
+        }
+        if (tid == 0)
+                base_sh = slot_off[tk.slot] + scan[0];
+        __syncthreads();
+        uint32_t *dst = flat + base_sh;
+        if (q.form != RESULT_BITMAP) {
+                const uint32_t *src = out + tk.out_off;
+                for (uint32_t i = tid; i < c; i += 256)
+                        dst[i] = src[i];
+                return;
+        }
+        const uint32_t *p = out + tk.out_off;
+        const uint32_t nw = (tk.tile_end - tk.tile_begin) * SPAN_WORDS;
+        uint32_t done = 0; // documents written so far (uniform)
+        for (uint32_t w0 = 0; w0 < nw; w0 += 256) {
+                __syncthreads();
+                uint32_t m = w0 + tid < nw ? p[w0 + tid] : 0u;
+                const uint32_t pc = (uint32_t)__popc(m);
+                scan[tid] = pc;
+                __syncthreads();
+                for (uint32_t d = 1; d < 256; d <<= 1) { // inclusive scan
+                        const uint32_t v = tid >= d ? scan[tid - d] : 0u;
+                        __syncthreads();
+                        scan[tid] += v;
+                        __syncthreads();
+                }
+                uint32_t at = done + scan[tid] - pc;
+                const uint32_t doc0 = (tk.tile_begin * SPAN_WORDS + w0 + tid) * 32u;
+                for (; m; m &= m - 1u)
+                        dst[at++] = doc0 + (uint32_t)__builtin_ctz(m);
+                done += scan[255];
+        }
+}

@@ -65,6 +65,7 @@ struct tri_dev {
         int device;
         hipStream_t stream, stream2; // stream2: the candidate-tile kernel when the two matching kernels run side by side
         hipStream_t stream_up;       // plans travel to the device on their own stream: a batch is compiled and uploaded while the previous one runs
+        hipStream_t stream_rb;       // read-backs of a SYNCED batch's results (docID sets, scores, hashes): they wait for nothing queued behind that batch on the engine stream
         hipEvent_t ev_fork, ev_join;
         int cus;
         tri_options opt;
@@ -105,6 +106,7 @@ static void dev_destroy(tri_dev *d) {
         for (hipEvent_t e : d->events_idle)
                 hipEventDestroy(e);
         hipStreamDestroy(d->stream_up);
+        hipStreamDestroy(d->stream_rb);
         hipStreamDestroy(d->stream2);
         hipStreamDestroy(d->stream);
         for (auto &b : d->pool.idle)
@@ -418,6 +420,7 @@ extern "C" int tri_dev_open(int device, tri_dev **out) {
         HIP_TRY(hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&d->stream2, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&d->stream_up, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&d->stream_rb, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
         hipDeviceProp_t prop;
@@ -457,6 +460,7 @@ namespace {
                              {"plane_div", &tri_options::plane_div},
                              {"planes_split", &tri_options::planes_split},
                              {"plane_max_bytes", &tri_options::plane_max_bytes},
+                             {"planes_rebuild", &tri_options::planes_rebuild},
                              {"plan_threads", &tri_options::plan_threads},
                              {"probe_max_blocks", &tri_options::probe_max_blocks}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}, {"dense_window_cost", &tri_options::dense_window_cost}};
                 for (const auto &e : table)
@@ -934,7 +938,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         std::vector<uint32_t> build;
                         for (const uint32_t term : b->plane_terms) {
                                 const uint32_t row = ix->df_rank[term];
-                                if (row < ix->pc_cap && !ix->pc_built[row]) {
+                                if (row < ix->pc_cap && (!ix->pc_built[row] || dev->opt.planes_rebuild)) {
                                         build.push_back(term);
                                         build.push_back(row);
                                         b->info.term_planes_decoded_bytes += ix->docbytes[term];
@@ -1623,16 +1627,18 @@ extern "C" int tri_batch_docset(tri_batch *b, size_t q, uint32_t *out, size_t ca
                         return fail(TRI_ERR_INTERNAL, "query %zu: its bitmap holds %zu documents, its tasks counted %zu", q, w, *n);
                 return TRI_OK;
         }
+        // (the batch is synced: its results are complete — the copies go on the read-back stream and wait for nothing queued behind the batch)
+        DevLock g(b->ix->dev->mu);
         size_t w = 0;
         for (uint32_t t = 0; t < dq.ntasks; ++t) {
                 const uint32_t c = b->h_counts[dq.first_task + t];
                 if (!c)
                         continue;
                 const uint32_t *src = b->d_out + b->tasks[dq.first_task + t].out_off;
-                HIP_TRY(hipMemcpyAsync(out + w, src, (size_t)c * 4, hipMemcpyDeviceToHost, b->ix->dev->stream));
+                HIP_TRY(hipMemcpyAsync(out + w, src, (size_t)c * 4, hipMemcpyDeviceToHost, b->ix->dev->stream_rb));
                 w += c;
         }
-        HIP_TRY(hipStreamSynchronize(b->ix->dev->stream));
+        HIP_TRY(hipStreamSynchronize(b->ix->dev->stream_rb));
         return TRI_OK;
 }
 
@@ -1676,10 +1682,11 @@ extern "C" int tri_batch_docset_hashes(tri_batch *b, uint64_t *hashes) {
         if (n) {
                 if (!b->d_hashes)
                         HIP_TRY(hipMalloc((void **)&b->d_hashes, (size_t)n * 8));
-                hipLaunchKernelGGL(k_hash_docsets, dim3((n + 63) / 64), dim3(64), 0, dev->stream, b->d_plan, b->d_tasks, b->d_counts, n, b->d_out,
+                DevLock g(dev->mu);
+                hipLaunchKernelGGL(k_hash_docsets, dim3((n + 63) / 64), dim3(64), 0, dev->stream_rb, b->d_plan, b->d_tasks, b->d_counts, n, b->d_out,
                                    b->d_hashes);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipStreamSynchronize(dev->stream));
+                HIP_TRY(hipStreamSynchronize(dev->stream_rb));
                 HIP_TRY(hipMemcpy(h.data(), b->d_hashes, (size_t)n * 8, hipMemcpyDeviceToHost));
         }
         for (size_t q = 0; q < b->nq; ++q)
@@ -1716,15 +1723,68 @@ extern "C" int tri_batch_scores(tri_batch *b, size_t q, double *out, size_t cap,
                 return fail(TRI_ERR_INVALID, "scores need %zu slots, %zu given", *n, cap);
         HIP_TRY(hipSetDevice(b->ix->dev->device));
         const DevQuery &dq = b->plan[slot];
+        DevLock g(b->ix->dev->mu);
         size_t w = 0;
         for (uint32_t t = 0; t < dq.ntasks; ++t) {
                 const uint32_t c = b->h_counts[dq.first_task + t];
                 if (!c)
                         continue;
-                HIP_TRY(hipMemcpyAsync(out + w, b->d_all_scores + b->tasks[dq.first_task + t].out_off, (size_t)c * 8, hipMemcpyDeviceToHost, b->ix->dev->stream));
+                HIP_TRY(hipMemcpyAsync(out + w, b->d_all_scores + b->tasks[dq.first_task + t].out_off, (size_t)c * 8, hipMemcpyDeviceToHost, b->ix->dev->stream_rb));
                 w += c;
         }
-        HIP_TRY(hipStreamSynchronize(b->ix->dev->stream));
+        HIP_TRY(hipStreamSynchronize(b->ix->dev->stream_rb));
+        return TRI_OK;
+}
+
+// ---- every query's docID set in ONE call: what a caller that replays MatchedIndexDocumentsFilter::consider(const docid_t *, size_t) (matches.h:161-165)
+//      per query needs on the host.  out[offsets[q] .. offsets[q + 1]) = query q's ascending docIDs, queries in the caller's order; the sets are
+//      gathered on the device into one contiguous buffer (k_deliver_docsets: the tasks' segments in order, bitmap-form results expanded) and come
+//      over in a single copy — at a pinned `out` that is PCIe's rate, not a copy and a synchronisation per task segment
+extern "C" int tri_batch_docsets(tri_batch *b, uint32_t *out, size_t cap, uint64_t *offsets) {
+        if (!b || !offsets)
+                return fail(TRI_ERR_INVALID, "null argument");
+        if (!b->synced)
+                return fail(TRI_ERR_INVALID, "tri_batch_sync first");
+        tri_dev *dev = b->ix->dev;
+        const size_t nslots = b->plan.size();
+        std::vector<uint64_t> slot_off(nslots + 1, 0);
+        uint64_t total = 0;
+        for (size_t q = 0; q < b->nq; ++q) {
+                const uint32_t slot = b->slot_of_query[q];
+                offsets[q] = total;
+                if (slot == UINT32_MAX)
+                        continue;
+                const DevQuery &dq = b->plan[slot];
+                if (dq.ntasks && !dq.out_cap && task_onepass(b->tasks[dq.first_task].kind) && b->h_query_counts[slot])
+                        return fail(TRI_ERR_INVALID, "query %zu ran through the one-pass scored kernel: an AccumulatedScore top-K batch keeps top-K lists and match counts, not docID sets", q);
+                slot_off[slot] = total;
+                total += b->h_query_counts[slot];
+        }
+        offsets[b->nq] = total;
+        if (!out || !total)
+                return TRI_OK;
+        if (cap < total)
+                return fail(TRI_ERR_INVALID, "the docID sets need %llu slots, %zu given", (unsigned long long)total, cap);
+        HIP_TRY(hipSetDevice(dev->device));
+        DevLock g(dev->mu);
+        uint32_t *d_flat = nullptr;
+        uint64_t *d_slot_off = nullptr;
+        HIP_TRY(pool_alloc(dev, (void **)&d_flat, (total + 64) * 4));
+        hipError_t e = pool_alloc(dev, (void **)&d_slot_off, (nslots + 1) * 8 + POOL_MIN_BYTES);
+        if (e == hipSuccess)
+                e = hipMemcpyAsync(d_slot_off, slot_off.data(), (nslots + 1) * 8, hipMemcpyHostToDevice, dev->stream_rb);
+        if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_deliver_docsets, dim3((uint32_t)b->tasks.size()), dim3(256), 0, dev->stream_rb, (const DevQuery *)b->d_plan, (const DevTask *)b->d_tasks,
+                                   (const uint32_t *)b->d_counts, (const uint32_t *)b->d_out, (const uint64_t *)d_slot_off, d_flat);
+                e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+                e = hipMemcpyAsync(out, d_flat, total * 4, hipMemcpyDeviceToHost, dev->stream_rb);
+        if (e == hipSuccess)
+                e = hipStreamSynchronize(dev->stream_rb);
+        pool_free(dev, d_flat);
+        pool_free(dev, d_slot_off);
+        HIP_TRY(e);
         return TRI_OK;
 }
 
