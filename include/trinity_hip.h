@@ -371,7 +371,10 @@ int tri_encode_lucene(tri_dev *, const uint32_t *docs, const uint32_t *freqs, co
  * term_ids_out[t] / terms_out[t] = the t-th term committed and its term_index_ctx, *nterms how many, *stats what commit adds to the field statistics
  * (:360 docsCnt, :457 sumTermHits, :470 sumTermsDocs, :476 totalTerms).  The bytes equal tri_encode_google_payloads over the same postings handed over
  * term after term in that order.  index_out == NULL: sizing call (*index_len, *nterms, *stats).  What commit or the encoder would refuse — document 0, the
- * same (term, document) twice, positions out of order — is TRI_ERR_INVALID naming the posting. */
+ * same (term, document) twice, positions out of order — is TRI_ERR_INVALID naming the posting.  A hit at position 0 WITHOUT a payload is not a storable hit:
+ * the reference's Encoder::new_hit skips it (google_codec.cpp:42-45) while commit still counts it in sumTermHits (indexer.cpp:447).  The caller drops such hits
+ * before the call (freqs[i] = the hits it hands over) and adds their number to stats->sum_term_hits on its side — csrc/host/trinity_gpu_write.hpp's
+ * SegmentIndexSession::insert / commit do exactly that; handed over as they are they are refused (TRI_ERR_INVALID) rather than silently re-counted. */
 typedef struct tri_commit_stats {
         uint64_t docs_cnt, sum_terms_docs, sum_term_hits, total_terms;
 } tri_commit_stats;

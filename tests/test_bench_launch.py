@@ -75,3 +75,30 @@ def test_reference_cpu_leg_runs_the_genuine_reference_on_the_sample():
         assert "error" not in r, r
         assert r["kind"] == "reference" and r["match_counts_equal_gpu"] and r["value"] > 0 and f"first {len(progs)} queries" in r["sample"]
     assert "error" in bench.cpu_reference(seg, SimpleNamespace(flags=1), [O.parse_query("[t0, t1, t2]", some_min=2)], np.array([0]), 1.0)
+
+
+def test_ranks_of_a_node_pin_their_planner_threads_to_disjoint_cpus():
+    """Eight ranks started side by side (LOCAL_RANK / LOCAL_WORLD_SIZE as torch.distributed.run exports them): each one's planner pool pins its
+    workers inside its own slice of the affinity mask — disjoint from every other rank's, whatever CPU the creating thread runs on (round 4's
+    pool took the CPUs next to the creator's: ranks landing within 16 CPUs of each other stacked their spinning workers)."""
+    ncpu = len(os.sched_getaffinity(0))
+    world = 8 if ncpu >= 8 else 2
+    seen = {}
+    for r in range(world):
+        env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(world))
+        res = subprocess.run([sys.executable, "-c", "import json, sys; sys.path.insert(0, %r); from trinity_amd import hostplan as HP; print(json.dumps(HP.pool_cpus(16)))" % ROOT],
+                             capture_output=True, text=True, timeout=120, env=env)  # fmt: skip
+        assert res.returncode == 0, res.stderr[-2000:]
+        seen[r] = json.loads(res.stdout.strip().splitlines()[-1])
+    allowed = sorted(os.sched_getaffinity(0))
+    for r, cpus in seen.items():
+        lo, hi = len(allowed) * r // world, len(allowed) * (r + 1) // world
+        assert cpus and set(cpus) <= set(allowed[lo:hi]) and len(set(cpus)) == len(cpus) == min(15, hi - lo), (r, cpus)
+    flat = [c for cpus in seen.values() for c in cpus]
+    assert len(flat) == len(set(flat))  # no CPU carries two ranks' pollers
+    # without the launcher's variables: next to the creating thread, still distinct CPUs
+    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    res = subprocess.run([sys.executable, "-c", "import json, sys; sys.path.insert(0, %r); from trinity_amd import hostplan as HP; print(json.dumps(HP.pool_cpus(4)))" % ROOT],
+                         capture_output=True, text=True, timeout=120, env=env)  # fmt: skip
+    solo = json.loads(res.stdout.strip().splitlines()[-1])
+    assert len(solo) == min(3, ncpu) and len(set(solo)) == len(solo)

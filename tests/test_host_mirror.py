@@ -143,3 +143,23 @@ def test_write_side_mirror_compiles_and_links(T, tmp_path):
                         "-Wl,-rpath," + PKG], capture_output=True, text=True)  # fmt: skip
     assert r.returncode == 0, r.stderr[-3000:]
     assert "libtrinity_hip.so" in subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+
+
+@pytest.mark.gpu
+def test_write_side_driver_commits_and_merges_on_the_device(T):
+    """tests/cpp/host_mirror_write_test: application code against the mirror's SegmentIndexSession (begin / insert / commit) and merge_google, RUN on the
+    device — three documents fed out of order, a payload, a hit at position 0 (counted, never stored).  The committed bytes and term table equal the
+    host encoder's over commit's walk (the driver checks it and says so), the statistics count the dropped hit, and the committed segment uploaded
+    and merged with itself comes back unchanged."""
+    from trinity_amd.build import MIRROR_WRITE_BIN
+
+    res = subprocess.run([MIRROR_WRITE_BIN], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = res.stdout.splitlines()
+    head = out[0].replace(",", "").split()  # index N bytes T terms documents D postings P hits H
+    assert head[0] == "index" and int(head[3]) == 9 and int(head[6]) == 3 and int(head[8]) == 11 and int(head[10]) == 13, out[0]  # (12 stored hits + the one at position 0)
+    table = {l.split()[0]: l for l in out[1:10]}
+    assert set(table) == {"world", "of", "warcraft", "mists", "hello", "again", "mice", "and", "men"}
+    assert "documents=2" in table["world"] and "documents=2" in table["of"] and "documents=1" in table["mice"]
+    assert any(l.startswith("host_encoder") and "same=1" in l and "term_table_same=1" in l for l in out), res.stdout
+    assert out[-1].startswith("merged") and out[-1].endswith("same=1"), out[-1]

@@ -61,8 +61,23 @@ def build_mirror_test(force=False):
     return MIRROR_TEST_BIN
 
 
+MIRROR_WRITE_SRC = os.path.join(ROOT, "tests", "cpp", "host_mirror_write_test.cpp")
+MIRROR_WRITE_BIN = os.path.join(ROOT, "tests", "cpp", "host_mirror_write_test")
+
+
+def build_mirror_write_test(force=False):
+    """The write side of the operator surface (csrc/host/trinity_gpu_write.hpp: SegmentIndexSession begin / insert / commit, merge) compiled into its
+    driver; in-tree, so that it travels to the GPU box, where tests/test_host_mirror.py runs it."""
+    deps = [MIRROR_WRITE_SRC, os.path.join(PKG, "csrc", "host", "trinity_gpu_write.hpp"), os.path.join(PKG, "csrc", "host", "google_encoder.hpp"), os.path.join(ROOT, "include", "trinity_hip.h")]
+    if force or _newer(MIRROR_WRITE_BIN, deps):
+        build_hip()
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-o", MIRROR_WRITE_BIN, MIRROR_WRITE_SRC, "-L" + PKG, "-ltrinity_hip", "-Wl,-rpath,$ORIGIN/../../trinity_amd"]
+        subprocess.run(cmd, check=True)
+    return MIRROR_WRITE_BIN
+
+
 def build_all(force=False):
-    return build_hip(force), build_host(force), build_mirror_test(force)
+    return build_hip(force), build_host(force), build_mirror_test(force), build_mirror_write_test(force)
 
 
 def kernels_stamp():

@@ -222,6 +222,16 @@ uint32_t tri_host_fastpfor_encode(const uint32_t *v, uint32_t *out) {
 }
 int tri_host_fastpfor_decode(const uint32_t *w, uint32_t L, uint32_t *v) { return trif::fastpfor_decode(w, L, v) ? 1 : 0; }
 // facts of a host index the tests compare between the two payload flavours of one corpus: per term {documents, nblocks, last document}
+// the CPUs a device handle's planner pool of `threads` threads pins its workers to in THIS process (LOCAL_RANK / LOCAL_WORLD_SIZE in the environment:
+// the rank's slice of the affinity mask, csrc/host_pool.hpp); returns how many (<= cap written)
+uint32_t tri_host_pool_cpus(uint32_t threads, int32_t *out, uint32_t cap) {
+        HostPool pool(threads);
+        const std::vector<int> &c = pool.pinned_cpus();
+        for (size_t i = 0; i < c.size() && i < cap; ++i)
+                out[i] = c[i];
+        return (uint32_t)c.size();
+}
+
 void tri_host_index_facts(void *h, uint64_t *info6, uint32_t *per_term3) {
         const HostIndex &H = *static_cast<HostIndex *>(h);
         info6[0] = H.info.postings, info6[1] = H.info.blocks, info6[2] = H.info.doc_bytes, info6[3] = H.info.hit_bytes, info6[4] = H.transcoded_groups, info6[5] = H.dev_index.size();

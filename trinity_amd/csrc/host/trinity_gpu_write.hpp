@@ -32,6 +32,7 @@ namespace trinity_amd {
                 std::vector<uint8_t> payloadLens;
                 std::vector<uint64_t> payloads;
                 bool anyPayload{false};
+                uint64_t droppedHits{0}; // hits at position 0 without a payload: counted, never stored (google_codec.cpp:42-45)
                 std::unordered_map<std::string, uint32_t> dictionary; // transient ids, first seen first: 1, 2, ... (indexer.cpp:161-185)
                 std::vector<std::string> invDict;
                 std::unordered_set<isrc_docid_t> tracked; // SegmentIndexSession::track (indexer.cpp:187-217)
@@ -99,8 +100,10 @@ namespace trinity_amd {
                                 uint32_t counted = 0;
                                 for (; e < h.size() && h[e].termID == h[i].termID; ++e) {
                                         // a hit at position 0 without a payload is not stored (google_codec.cpp:42-45): the posting's frequency counts the others
-                                        if (!h[e].position && !h[e].payloadLen)
+                                        if (!h[e].position && !h[e].payloadLen) {
+                                                ++droppedHits; // (commit still counts it: defaultFieldStats.sumTermHits += hitsCnt, indexer.cpp:447)
                                                 continue;
+                                        }
                                         positions.push_back(h[e].position);
                                         payloadLens.push_back(h[e].payloadLen);
                                         payloads.push_back(h[e].payload);
@@ -137,6 +140,7 @@ namespace trinity_amd {
                         std::vector<uint32_t> ids(nterms);
                         std::vector<tri_term> tctx(nterms);
                         call(out.index.data(), out.index.size(), out.hits.data(), out.hits.size(), ids.data(), tctx.data(), nterms);
+                        out.stats.sum_term_hits += droppedHits; // (the hits insert() did not hand over: the reference's statistic counts them, indexer.cpp:447)
                         out.terms.reserve(nterms);
                         for (size_t i = 0; i < nterms; ++i)
                                 out.terms.emplace_back(std::string(term(ids[i])), term_index_ctx{tctx[i].documents, tctx[i].offset, tctx[i].size}); // indexer.cpp:525-533

@@ -5,8 +5,8 @@
 // What the measurements on the micro-VMs this engine runs in said (tools/plan_probe.py): starting a std::thread costs
 // 4 - 5 ms; a futex wake-up puts the woken thread on the WAKER's CPU (the guest exposes no cache topology, so the scheduler does not look
 // for an idle core), i.e. seven woken workers ran one after the other on one core; sched_yield() sleeps for milliseconds.  Hence: workers
-// are pinned to distinct CPUs of the process's affinity mask (next to the creating thread's CPU, so that the ranks of a node do not pile
-// onto the same cores), they keep POLLING for `hot_us` microseconds after their last job before they sleep on a condition variable
+// are pinned to distinct CPUs of the process's affinity mask (a rank's own slice of it under a one-process-per-GPU launcher, else the CPUs
+// next to the creating thread's: pin_candidates), they keep POLLING for `hot_us` microseconds after their last job before they sleep on a condition variable
 // (a caller that compiles a batch per step finds them awake: a job is picked up in about a microsecond; from sleep it takes 100 - 300 us),
 // and nobody yields.
 #pragma once
@@ -14,6 +14,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdlib>
 #include <functional>
 #include <mutex>
 #include <pthread.h>
@@ -29,16 +30,9 @@ class HostPool {
                 std::vector<int> cpus;
                 int base = 0;
                 if (pin) {
-                        cpu_set_t allowed;
-                        CPU_ZERO(&allowed);
-                        if (!sched_getaffinity(0, sizeof allowed, &allowed))
-                                for (int c = 0; c < CPU_SETSIZE; ++c)
-                                        if (CPU_ISSET(c, &allowed))
-                                                cpus.push_back(c);
-                        const int here = sched_getcpu();
-                        for (size_t i = 0; i < cpus.size(); ++i)
-                                if (cpus[i] == here)
-                                        base = (int)i;
+                        cpus = pin_candidates(&base);
+                        if (threads > cpus.size() + 1 && !cpus.empty()) // (a rank's slice may be narrower than the threads asked for: no two pollers on one CPU)
+                                threads = (unsigned)cpus.size() + 1;
                 }
                 for (unsigned i = 1; i < threads; ++i) {
                         try {
@@ -46,14 +40,45 @@ class HostPool {
                         } catch (...) {
                                 break;
                         }
-                        if (cpus.size() > 1) {
+                        if (cpus.size() > 1 || (base < 0 && !cpus.empty())) { // (a rank's slice is honoured even when it is a single CPU)
+                                const int cpu = cpus[(size_t)(base + (int)i) % cpus.size()];
                                 cpu_set_t s;
                                 CPU_ZERO(&s);
-                                CPU_SET(cpus[(size_t)(base + (int)i) % cpus.size()], &s);
+                                CPU_SET(cpu, &s);
                                 pthread_setaffinity_np(workers_.back().native_handle(), sizeof s, &s); // (best effort)
+                                pinned_.push_back(cpu);
                         }
                 }
         }
+        // The CPUs a pool of this process pins its workers to, and where among them it starts (*base: the worker i goes to
+        // cpus[(base + i) % cpus.size()]).  One process per GPU is the deployment (torch.distributed.run / any launcher that exports LOCAL_RANK and
+        // LOCAL_WORLD_SIZE): the ranks of a node then take DISJOINT contiguous slices of the affinity mask — slice r of LOCAL_WORLD_SIZE — whatever
+        // CPU each rank's creating thread happens to run on (eight ranks started side by side land within a few CPUs of each other: their fifteen
+        // spinning workers each would otherwise pile onto the same cores).  Without those variables: the CPUs next to the creating thread's.
+        static std::vector<int> pin_candidates(int *base) {
+                std::vector<int> cpus;
+                cpu_set_t allowed;
+                CPU_ZERO(&allowed);
+                if (!sched_getaffinity(0, sizeof allowed, &allowed))
+                        for (int c = 0; c < CPU_SETSIZE; ++c)
+                                if (CPU_ISSET(c, &allowed))
+                                        cpus.push_back(c);
+                *base = 0;
+                const char *lr = getenv("LOCAL_RANK"), *lw = getenv("LOCAL_WORLD_SIZE");
+                const long r = lr ? strtol(lr, nullptr, 10) : -1, w = lw ? strtol(lw, nullptr, 10) : 0;
+                if (w > 1 && r >= 0 && r < w && cpus.size() >= (size_t)w) {
+                        const size_t lo = cpus.size() * (size_t)r / (size_t)w, hi = cpus.size() * (size_t)(r + 1) / (size_t)w;
+                        cpus = std::vector<int>(cpus.begin() + (long)lo, cpus.begin() + (long)hi);
+                        *base = -1; // (worker 1 takes the slice's first CPU)
+                        return cpus;
+                }
+                const int here = sched_getcpu();
+                for (size_t i = 0; i < cpus.size(); ++i)
+                        if (cpus[i] == here)
+                                *base = (int)i;
+                return cpus;
+        }
+        const std::vector<int> &pinned_cpus() const { return pinned_; } // (worker i + 1's CPU)
         ~HostPool() {
                 {
                         std::lock_guard<std::mutex> g(m_);
@@ -155,6 +180,7 @@ class HostPool {
                 return stop_;
         }
         std::vector<std::thread> workers_;
+        std::vector<int> pinned_;
         std::mutex m_;
         std::condition_variable cv_, done_cv_;
         const std::function<void(unsigned)> *fn_ = nullptr; // (written under m_ before state_ is published; read only after a successful CAS)

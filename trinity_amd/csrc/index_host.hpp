@@ -527,6 +527,8 @@ inline int build_host_index(const uint8_t *index, size_t len, const uint8_t *hit
                         const uint32_t n = *p++;
                         if (n < 1 || n > 32 || !delta || (uint64_t)(end - p) < blockLength)
                                 return herr(err, TRI_ERR_FORMAT, "term %zu: bad block header (n=%u, delta=%u, len=%u)", ti, n, delta, blockLength);
+                        if ((uint64_t)lastDoc + delta > 0xffffffffull) // (a running sum past 2^32 would wrap: the directory's last documents must ascend)
+                                return herr(err, TRI_ERR_FORMAT, "term %zu: the blocks' document deltas run past 2^32", ti);
                         lastDoc += delta;
                         const uint8_t *s = p, *const bend = p + blockLength;
                         // the interior deltas are READ, not only stepped over: every kernel places a block's documents inside (previous block's last, this

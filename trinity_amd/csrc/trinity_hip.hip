@@ -228,6 +228,12 @@ static void pinned_free(tri_dev *dev, void *p, const size_t cap) {
         }
         dev->pinned_idle.emplace_back(cap, p);
 }
+static void event_put(tri_dev *dev, hipEvent_t e) {
+        if (!e)
+                return;
+        DevLock g(dev->mu);
+        dev->events_idle.push_back(e);
+}
 static hipError_t event_get(tri_dev *dev, hipEvent_t *e) {
         DevLock g(dev->mu);
         if (!dev->events_idle.empty()) {
@@ -269,6 +275,8 @@ struct tri_index : HostIndex {
         uint32_t *d_pcache = nullptr;
         uint32_t pc_cap = 0, pc_plw = 0;
         std::vector<uint8_t> pc_built;
+        hipEvent_t ev_pc_ready = nullptr;                       // the last growth's move of the rows (upload stream): every run waits for it
+        std::vector<std::pair<void *, hipEvent_t>> pc_retired; // outgrown row buffers and the engine-stream point their last readers precede
         ~tri_index() { // also runs when tri_index_upload fails half-way
                 if (dev)
                         hipSetDevice(dev->device);
@@ -284,7 +292,13 @@ struct tri_index : HostIndex {
                 hipFree(d_blk_off);
                 hipFree(d_win);
                 hipFree(d_terms);
-                hipFree(d_pcache);
+                pool_free(dev, d_pcache); // (pooled: tri_batch_create grows it without a device-wide synchronisation)
+                for (auto &r : pc_retired) {
+                        pool_free(dev, r.first);
+                        hipEventDestroy(r.second);
+                }
+                if (ev_pc_ready)
+                        hipEventDestroy(ev_pc_ready);
                 dev_release(dev);
         }
 };
@@ -792,17 +806,37 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 // the index's plane cache holds a row for every term this batch could name (row = df rank < plane_rows), plus an all-zero row:
                 // what a k_planes slot WITHOUT term planes reads (so its sweep needs no select)
                 const uint32_t want = std::max<uint32_t>(1, b->plane_rows);
+                // (rows whose readers are through go back to the pool: no call here waits for the device)
+                for (size_t i = 0; i < ix->pc_retired.size();)
+                        if (hipEventQuery(ix->pc_retired[i].second) == hipSuccess) {
+                                pool_free(dev, ix->pc_retired[i].first);
+                                event_put(dev, ix->pc_retired[i].second);
+                                ix->pc_retired.erase(ix->pc_retired.begin() + (long)i);
+                        } else
+                                ++i;
                 if (want > ix->pc_cap || b->plw != ix->pc_plw) {
+                        // Grown WITHOUT draining the engine stream (round 4 synchronised it here: a stall in the serving loop whenever a batch was planned with more
+                        // eligible terms): the rows move on the upload stream behind everything the engine stream holds so far (runs that read or build the old
+                        // rows), later runs wait for the move's event (tri_batch_run), and the old buffer is retired — pooled again once that point has passed
                         const size_t row = (size_t)PL_PLANES * b->plw * 4;
                         uint32_t *fresh = nullptr;
-                        HIP_TRY(hipMalloc((void **)&fresh, ((size_t)want + 1) * row + 64));
-                        HIP_TRY(hipStreamSynchronize(dev->stream)); // (no run in flight reads the old rows while they move)
+                        HIP_TRY(pool_alloc(dev, (void **)&fresh, ((size_t)want + 1) * row + 64));
+                        hipEvent_t drained = nullptr;
+                        HIP_TRY(event_get(dev, &drained));
+                        if (!ix->ev_pc_ready)
+                                HIP_TRY(event_get(dev, &ix->ev_pc_ready));
+                        HIP_TRY(hipEventRecord(drained, dev->stream));
+                        HIP_TRY(hipStreamWaitEvent(dev->stream_up, drained, 0));
                         if (ix->d_pcache && b->plw == ix->pc_plw)
-                                HIP_TRY(hipMemcpy(fresh, ix->d_pcache, (size_t)ix->pc_cap * row, hipMemcpyDeviceToDevice));
+                                HIP_TRY(hipMemcpyAsync(fresh, ix->d_pcache, (size_t)ix->pc_cap * row, hipMemcpyDeviceToDevice, dev->stream_up));
                         else
                                 ix->pc_built.clear();
-                        HIP_TRY(hipMemset((uint8_t *)fresh + (size_t)want * row, 0, row + 64));
-                        hipFree(ix->d_pcache);
+                        HIP_TRY(hipMemsetAsync((uint8_t *)fresh + (size_t)want * row, 0, row + 64, dev->stream_up));
+                        HIP_TRY(hipEventRecord(ix->ev_pc_ready, dev->stream_up));
+                        if (ix->d_pcache)
+                                ix->pc_retired.emplace_back(ix->d_pcache, drained);
+                        else
+                                event_put(dev, drained);
                         ix->d_pcache = fresh;
                         ix->pc_cap = want;
                         ix->pc_plw = b->plw;
@@ -915,6 +949,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
         }
 #endif
         HIP_TRY(hipStreamWaitEvent(dev->stream, b->ev_up, 0)); // the plan's copy (upload stream) has arrived
+        if (b->ix->ev_pc_ready)
+                HIP_TRY(hipStreamWaitEvent(dev->stream, b->ix->ev_pc_ready, 0)); // ... and so have the plane cache's rows, should it have been grown since
         HIP_TRY(hipEventRecord(b->ev0, dev->stream));
         if (n) {
                 HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 256, dev->stream));

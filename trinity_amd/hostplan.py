@@ -183,3 +183,14 @@ def lucene_encode(docs, freqs, positions, term_first, units=False):
     if fn(d.ctypes.data, f.ctypes.data, p.ctypes.data, tf.ctypes.data, n, io.ctypes.data, icap, C.byref(il), ho.ctypes.data, hcap, C.byref(hl), t3.ctypes.data):
         raise TrinityError("lucene_encode: buffer too small")
     return io[: il.value], ho[: hl.value], t3[:n]
+
+
+def pool_cpus(threads=16):
+    """The CPUs the planner's host pool of `threads` threads pins its workers to in this process (csrc/host_pool.hpp: a rank's own slice of the
+    affinity mask when LOCAL_RANK / LOCAL_WORLD_SIZE are set, else the CPUs next to the calling thread's)."""
+    L = host_lib()
+    L.tri_host_pool_cpus.restype = C.c_uint32
+    L.tri_host_pool_cpus.argtypes = [C.c_uint32, C.c_void_p, C.c_uint32]
+    out = np.zeros(256, dtype=np.int32)
+    n = L.tri_host_pool_cpus(threads, out.ctypes.data, out.size)
+    return out[:n].tolist()
