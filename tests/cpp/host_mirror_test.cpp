@@ -86,6 +86,33 @@ int main(int argc, char **argv) {
                         exec_query(q, &src, &c, nullptr, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
                         show("mixed_scored", c);
                 }
+                { // the span seam window by window, as a composite span drives a child (docset_spans.h:292-296): 8192-document windows over the whole docID
+                  // space, some of them "just advance" calls (no proxy, min == max) — ONE device batch for the whole walk
+                        struct Feed final : public MatchesProxy {
+                                Collect c;
+                                void process(relevant_document_provider *p) override { c.consider(p->document(), p->score()); }
+                        } feed;
+                        auto q = src.conjunction({src.term("t0"), src.term("t1"), src.disjunction({src.term("t2"), src.term("t3"), src.term("t4")})});
+                        GpuDocsSetSpan span(q, unsigned(ExecFlags::AccumulatedScoreScheme), scorer.get());
+                        isrc_docid_t next = 1;
+                        unsigned windows = 0;
+                        bool ordered = true;
+                        for (isrc_docid_t lo = 1; lo < fs.docsCnt + 8192u; lo += 8192, ++windows) {
+                                if (windows % 5 == 4) { // an "advance only" call first: nothing delivered, the estimate of the next match comes back
+                                        const isrc_docid_t est = span.process(nullptr, lo, lo);
+                                        ordered = ordered && (est == DocIDsEND || est >= lo);
+                                }
+                                next = span.process(&feed, lo, lo + 8192);
+                                ordered = ordered && (next == DocIDsEND || next >= lo + 8192);
+                        }
+                        for (size_t i = 1; i < feed.c.ids.size(); ++i)
+                                ordered = ordered && feed.c.ids[i - 1] < feed.c.ids[i];
+                        double sum = 0;
+                        for (auto s : feed.c.scores)
+                                sum += s;
+                        printf("span_windows n=%zu fnv=%" PRIu64 " score_sum=%.17g batches=%u windows=%u ordered=%d end=%d\n", feed.c.ids.size(), fnv(feed.c.ids), sum, span.batches_run(), windows,
+                               int(ordered), int(next == DocIDsEND));
+                }
                 { // t3 OR t7 with an IndexDocumentsFilter
                         Collect c;
                         EvenOnly even;

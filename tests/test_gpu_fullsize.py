@@ -186,3 +186,21 @@ def test_google_index_beyond_2_gib(T, dev):
         assert np.array_equal(docs, wdocs) and int(freq.sum()) == ht and int(sum(bin(int(x)).count("1") for x in present)) == tt
     b.close()
     ix.close()
+
+
+def test_the_100k_mixed_batch_runs_whole_on_one_gpu():
+    """`north_star`'s scaling batch — 100 K mixed queries (cfg5), strong scaling — at its N = 1 point: ONE GPU takes the whole batch (output regions of
+    70 K DocumentsOnly queries, the plane rows, 30 K scored queries), through bench.py's own loop; per-query parity on a sample against the CPU oracle
+    rides along, and the pipelined sets answer what a resident batch answers."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--scaling", "strong", "--workload", "cfg5", "--queries", "100000", "--steps", "2", "--warmup", "1", "--cpu-seconds", "4",
+                          "--rotating-sets", "0", "--delivered-steps", "0", "--scaling-ref-steps", "0"], capture_output=True, text=True, timeout=1200)  # fmt: skip
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["config"]["queries_per_step"] == 100000 and out["config"]["workload"].startswith("cfg5")
+    assert out["value"] > 0 and out["pipelined_results_equal_resident_batch"] and out["end_to_end"]["planning_included"]
+    assert out["parity_check"]["equal"] and out["parity_check"]["queries"] >= 100 and out["parity_check"]["mismatches"] == 0

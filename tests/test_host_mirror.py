@@ -64,6 +64,10 @@ def test_mirror_results_match_oracle(T, tmp_path, codec):
     expect("and_docs", "t0 t1", 1)
     expect("and_scored", "t0 t1", 2)
     expect("mixed_scored", "t0 t1 (t2 OR t3 OR t4)", 2)
+    # DocsSetSpan::process(mp, min, max) as a windowed call (docset_spans.h:84, 292-296): the same matches and scores out of 8192-document windows,
+    # in ascending order, with ONE tri_batch_create for the whole walk
+    expect("span_windows", "t0 t1 (t2 OR t3 OR t4)", 2)
+    assert lines["span_windows"]["batches"] == "1" and int(lines["span_windows"]["windows"]) >= 3 and lines["span_windows"]["ordered"] == "1" and lines["span_windows"]["end"] == "1"
     expect("or_even", "t3 OR t7", 1, keep=lambda d: (d & 1) == 0)
     expect("phrase_scored", '"t0 t1" t2', 2)
     expect("phrase_and_member_scored", '"t0 t1" t0', 2)  # ScorerWeights are per program token, not per term

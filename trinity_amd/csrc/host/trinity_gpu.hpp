@@ -629,43 +629,56 @@ namespace trinity_amd {
                 virtual ~DocsSetSpan() = default;
         };
 
-        // The batch-granular seam: process() runs the whole iterator tree on the GPU and replays the matches in
-        // ascending docID order through the caller's MatchesProxy, as GenericDocsSetSpan::process
-        // (docset_spans.cpp:269-290) and the window-union spans (98-173, 681-790) do; returns the first match >= max.
+        // The batch-granular seam: the FIRST process() runs the whole iterator tree on the GPU — one tri_batch_create / run / read-back —, and the span
+        // keeps the ascending match list (+ scores); every process(mp, min, max) then replays the matches of [min, max) from it, found by a
+        // binary search, through the caller's MatchesProxy in ascending docID order, as GenericDocsSetSpan::process (docset_spans.cpp:269-290)
+        // and the window-union spans (98-173, 681-790) do, and returns the first match >= max.  A composite caller that walks the docID space
+        // window by window (docset_spans.h:292-296: min == max with no proxy means "just advance") therefore costs ONE device batch for the
+        // whole walk, not one per window (round 4 compiled and ran the query again on every call); batches_run() says how many there were.
         class GpuDocsSetSpan final : public DocsSetSpan {
                 DocsSetIterators::Iterator *const root;
                 const uint32_t flags;
                 Similarity::IndexSourceTermsScorer *const scorer;
+                std::vector<uint32_t> ids; // the query's matches, ascending (filled by the first process())
+                std::vector<double> sc;    // ... and their scores (AccumulatedScoreScheme)
+                bool ran{false};
+                unsigned batches{0};
 
-              public:
-                GpuDocsSetSpan(DocsSetIterators::Iterator *r, uint32_t f, Similarity::IndexSourceTermsScorer *s)
-                    : root{r}, flags{f}, scorer{s} {}
-                uint64_t cost() override { return root->cost(); }
-                isrc_docid_t process(MatchesProxy *mp, const isrc_docid_t min, const isrc_docid_t max) override {
+                void run_once() {
+                        if (ran)
+                                return;
                         const bool scored = flags & unsigned(ExecFlags::AccumulatedScoreScheme);
                         auto b = run_batch(root->isrc, {root}, flags, 0, scorer);
+                        ++batches;
                         size_t n = 0;
                         check(tri_batch_docset(b.get(), 0, nullptr, 0, &n));
-                        std::vector<uint32_t> ids(n);
-                        std::vector<double> sc(scored ? n : 0);
+                        ids.resize(n);
+                        sc.resize(scored ? n : 0);
                         if (n) {
                                 check(tri_batch_docset(b.get(), 0, ids.data(), n, &n));
                                 if (scored)
                                         check(tri_batch_scores(b.get(), 0, sc.data(), n, &n));
                         }
+                        ran = true;
+                }
+
+              public:
+                GpuDocsSetSpan(DocsSetIterators::Iterator *r, uint32_t f, Similarity::IndexSourceTermsScorer *s)
+                    : root{r}, flags{f}, scorer{s} {}
+                uint64_t cost() override { return root->cost(); }
+                unsigned batches_run() const { return batches; } // device batches this span has compiled and run (1 after any number of windows)
+                isrc_docid_t process(MatchesProxy *mp, const isrc_docid_t min, const isrc_docid_t max) override {
+                        run_once();
+                        const bool scored = !sc.empty();
+                        size_t i = size_t(std::lower_bound(ids.begin(), ids.end(), uint32_t(min)) - ids.begin());
                         relevant_document rel;
-                        for (size_t i = 0; i < n; ++i) {
-                                if (ids[i] < min)
-                                        continue;
-                                if (ids[i] >= max)
-                                        return ids[i];
+                        for (; i < ids.size() && ids[i] < max; ++i)
                                 if (mp) {
                                         rel.set_document(ids[i]);
                                         rel.score_ = scored ? sc[i] : 0.0;
                                         mp->process(&rel);
                                 }
-                        }
-                        return DocIDsEND;
+                        return i < ids.size() ? isrc_docid_t(ids[i]) : DocIDsEND;
                 }
         };
 
