@@ -193,6 +193,7 @@ def test_the_100k_mixed_batch_runs_whole_on_one_gpu():
     70 K DocumentsOnly queries, the plane rows, 30 K scored queries), through bench.py's own loop; per-query parity on a sample against the CPU oracle
     rides along, and the pipelined sets answer what a resident batch answers."""
     import json
+    import os
     import subprocess
     import sys
 

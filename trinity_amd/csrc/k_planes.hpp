@@ -242,27 +242,50 @@ __device__ __forceinline__ double key_score(const unsigned long long key) {
         return __longlong_as_double((long long)((key >> 63) ? (key & 0x7fffffffffffffffull) : ~key));
 }
 
-// Keep the best k of the n (<= PLK_CAP = PLK_WG) buffered candidates, best first (rank by counting: the order is strict), and move the
-// threshold.  A query cut into several docID ranges (tasks) shares one threshold through *gthr: a task's k-th best score says that k
+// Keep the best k of the n (<= PLK_CAP = PLK_WG) buffered candidates, best first, and move the threshold.  The buffer is SORTED — a bitonic
+// network over one element per thread (the order is strict: documents are distinct; empty places rank last): the exchanges at distances below 64
+// are lane shuffles inside the waves, only the six at distances 64 / 128 / 256 go through LDS behind a barrier.  (Round 4 ranked by counting:
+// every thread compared its element with all n — 5 K instructions per thread and prune, 18 us; a task prunes four to six times.)
+// A query cut into several docID ranges (tasks) shares one threshold through *gthr: a task's k-th best score says that k
 // documents reach it, so no task needs documents below it — the later and the slower ranges filter with the best k-th score any range
 // has seen, not with their own, and cutting a query into ranges costs next to no extra candidates.  (The threshold only ever prunes:
 // results do not depend on when a task sees another's.)
 __device__ void planes_prune(PlanesShared &sh, const uint32_t n, const uint32_t k, unsigned long long *__restrict__ gthr) {
         const uint32_t tid = threadIdx.x;
-        double es = 0;
-        uint32_t ed = 0, rk = 0xffffffffu;
+        static_assert(PLK_CAP == PLK_WG && PLK_WG == 512, "one element per thread, a network of 512");
+        double es = -__builtin_huge_val(); // (an empty place: every candidate is better — scores are finite)
+        uint32_t ed = 0xffffffffu;
         if (tid < n) {
                 es = sh.tk_s[tid];
                 ed = sh.tk_d[tid];
-                uint32_t c = 0;
-                for (uint32_t j = 0; j < n; ++j)
-                        c += better(sh.tk_s[j], sh.tk_d[j], es, ed) ? 1u : 0u;
-                rk = c;
         }
-        __syncthreads();
-        if (rk < k) {
-                sh.tk_s[rk] = es;
-                sh.tk_d[rk] = ed;
+#pragma unroll
+        for (uint32_t k2 = 2; k2 <= PLK_WG; k2 <<= 1) {
+#pragma unroll
+                for (uint32_t j = k2 >> 1; j > 0; j >>= 1) {
+                        double ps;
+                        uint32_t pd;
+                        if (j >= 64) { // the partner sits in another wave
+                                sh.tk_s[tid] = es;
+                                sh.tk_d[tid] = ed;
+                                __syncthreads();
+                                ps = sh.tk_s[tid ^ j];
+                                pd = sh.tk_d[tid ^ j];
+                                __syncthreads();
+                        } else {
+                                ps = __shfl_xor(es, (int)j, 64);
+                                pd = __shfl_xor(ed, (int)j, 64);
+                        }
+                        // an ascending run (best first) keeps the better element at the lower place, a descending one at the higher
+                        const bool take_better = ((tid & j) == 0) == ((tid & k2) == 0);
+                        const bool swap = take_better ? better(ps, pd, es, ed) : better(es, ed, ps, pd);
+                        es = swap ? ps : es;
+                        ed = swap ? pd : ed;
+                }
+        }
+        if (tid < k) { // (place tid holds the element of rank tid)
+                sh.tk_s[tid] = es;
+                sh.tk_d[tid] = ed;
         }
         __syncthreads();
         const uint32_t m = n < k ? n : k;
