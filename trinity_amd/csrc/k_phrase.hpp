@@ -130,6 +130,9 @@ struct PhraseShared {
         uint8_t alive[PHRASE_TILE];
         uint32_t row[MAX_PHRASE_TERMS]; // phrase position -> row (a term repeated in the phrase shares the row of its first occurrence)
         uint32_t rpad[MAX_PHRASE_TERMS]; // row -> its term's DevTerm::pad (LUCENE: the term's row in hdir[])
+        DevTerm rterm[MAX_PHRASE_TERMS]; // row -> its term
+        uint32_t rtk[MAX_PHRASE_TERMS], rbx[2 * MAX_PHRASE_TERMS]; // row -> its term id; the two ends of the tile's block range as the waves found them
+        uint32_t rb0[MAX_PHRASE_TERMS], rnb[MAX_PHRASE_TERMS], rstart[MAX_PHRASE_TERMS]; // row -> first block of the tile's docID range, blocks walked (0: the scattered path), where its blocks start in the pass
         uint32_t scan[8];
         uint32_t bcast[4];
 };
@@ -306,7 +309,7 @@ __device__ __forceinline__ uint32_t phrase_first_block(const uint32_t *__restric
 }
 
 template <int CODEC>
-__global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ index, const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits,
+__global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phrase(const uint8_t *__restrict__ index, const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits,
                                                    const uint32_t *__restrict__ hdir, const uint32_t *__restrict__ blk_last,
                                                    const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                                                    const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
@@ -351,21 +354,35 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                 }
                 const uint32_t tile = uni(min(PHRASE_TILE, max(64u, (PHRASE_SLOTS / maxrows) & ~63u)));
                 uint32_t wpos = 0;
+                // the NEXT tile's candidates travel while this one is worked on (the compaction below writes behind the read cursor: it never reaches them)
+                constexpr uint32_t PER = PHRASE_TILE / AND_WG;
+                uint32_t nx[PER];
+#pragma unroll
+                for (uint32_t i = 0; i < PER; ++i)
+                        nx[i] = tid + i * AND_WG < min(tile, M) ? seg[tid + i * AND_WG] : 0u;
                 for (uint32_t tb = 0; tb < M; tb += tile) {
                         const uint32_t C = min(tile, M - tb);
-                        for (uint32_t j = tid; j < C; j += AND_WG) {
-                                sh.cdoc[j] = seg[tb + j];
-                                sh.alive[j] = 1;
-                                sh.ps[j] = 0;
+#pragma unroll
+                        for (uint32_t i = 0; i < PER; ++i) {
+                                const uint32_t j = tid + i * AND_WG;
+                                if (j < C) {
+                                        sh.cdoc[j] = nx[i];
+                                        sh.alive[j] = 1;
+                                        sh.ps[j] = 0;
+                                }
+                                nx[i] = tb + tile + j < M && j < tile ? seg[tb + tile + j] : 0u;
                         }
                         __syncthreads();
                         const uint32_t cmin = sh.cdoc[0], cmax = sh.cdoc[C - 1];
                         PROF_LAP(0);
                         for (uint32_t pi = 0; pi < q.nphrases; ++pi) {
                                 const DevPhrase ph = phrases[q.phrase_base + pi];
-                                // ---- locate: (hits locator, freq) of every candidate for every distinct phrase term
-                                uint32_t rows = 0;
-                                for (uint32_t k = 0; k < ph.nterms; ++k) {
+                                // ---- locate: (hits locator, freq) of every candidate for every distinct phrase term.  The rows (distinct terms) are set up
+                                //      first — term, the blocks of the tile's docID range —, then ONE pass walks the blocks of ALL the rows, a lane per block
+                                //      (round 4 walked row after row with a barrier in between: a two-word phrase of head terms kept 50 and then 30 of the 256
+                                //      lanes busy for one block's walk each, twice)
+                                uint32_t rows = 0, total_blocks = 0;
+                                for (uint32_t k = 0; k < ph.nterms; ++k) { // the rows: a term repeated in the phrase shares the row of its first occurrence (uniform stores)
                                         const uint32_t tk = pterms[ph.term_base + k];
                                         uint32_t first = k;
                                         for (uint32_t m = 0; m < k; ++m)
@@ -374,55 +391,138 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                         break;
                                                 }
                                         if (first != k) {
-                                                sh.row[k] = uni(sh.row[first]); // uniform store
+                                                sh.row[k] = uni(sh.row[first]);
                                                 continue;
                                         }
-                                        const uint32_t slot0 = rows * tile;
-                                        const DevTerm t = terms[tk];
-                                        sh.rpad[rows] = t.pad; // (uniform stores)
+                                        sh.rtk[rows] = tk;
                                         sh.row[k] = rows++;
-                                        const uint32_t *bl = blk_last + t.first_block;
-                                        // the blocks of the tile's docID range: every wave brackets both ends through the cell index on its own
-                                        // (one round of 64 probes each; a list too short for a cell index: two rounds) — no workgroup barrier
-                                        const uint32_t b0 = phrase_first_block(bl, win, t, cmin);
-                                        const uint32_t b1 = b0 < t.nblocks ? min(phrase_first_block(bl, win, t, cmax), t.nblocks - 1) : b0;
-                                        PROF_LAP(8);
-                                        if (b0 < t.nblocks && b1 - b0 + 1 <= 2 * C) {
-                                                for (uint32_t b = b0 + tid; b <= b1; b += AND_WG)
-                                                        phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, t, b, C, slot0);
-                                                PROF_LAP(9);
-                                        } else {
-                                                // few candidates scattered over a long list: every candidate brackets its block with the two cell-index
-                                                // entries of its docID cell (short lists: a bisection of the directory), and the first candidate of a
-                                                // block walks it for all the block's candidates
-                                                for (uint32_t j = tid; j < C; j += AND_WG) {
-                                                        const uint32_t doc = sh.cdoc[j];
-                                                        uint32_t lo = 0, hi = t.nblocks;
-                                                        if (t.win_off != 0xffffffffu) {
-                                                                lo = win[t.win_off + (doc >> CELL_LOG2)];
-                                                                hi = min(win[t.win_off + (doc >> CELL_LOG2) + 1] + 1, t.nblocks);
-                                                        }
-                                                        while (lo < hi) {
-                                                                const uint32_t mid = (lo + hi) >> 1;
-                                                                if (bl[mid] < doc)
-                                                                        lo = mid + 1;
-                                                                else
-                                                                        hi = mid;
-                                                        }
-                                                        const uint32_t prevdoc = lo ? bl[lo - 1] : 0;
-                                                        if (j == 0 || sh.cdoc[j - 1] <= prevdoc)
-                                                                phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, t, lo, C, slot0);
-                                                }
-                                                PROF_LAP(10);
-                                        }
-                                        __syncthreads();
                                 }
+                                if (tid < rows) { // the rows' terms: one load each, together
+                                        const DevTerm t = terms[sh.rtk[tid]];
+                                        sh.rterm[tid] = t;
+                                        sh.rpad[tid] = t.pad;
+                                }
+                                __syncthreads();
+                                // the blocks of the tile's docID range: a WAVE per (row, end of the range) brackets it through the cell index (one round of 64
+                                // probes; a list too short for a cell index: two rounds) — the four waves search side by side (round 4: every wave searched
+                                // every row's two ends itself, one after the other)
+                                for (uint32_t it = wave; it < 2 * rows; it += AND_WG / 64) {
+                                        const DevTerm t = sh.rterm[it >> 1];
+                                        const uint32_t res = phrase_first_block(blk_last + t.first_block, win, t, (it & 1u) ? cmax : cmin);
+                                        sh.rbx[it] = res; // (wave-uniform value, every lane stores it)
+                                }
+                                __syncthreads();
+                                for (uint32_t r = 0; r < rows; ++r) { // (uniform stores)
+                                        const uint32_t nb = uni(sh.rterm[r].nblocks), b0 = uni(sh.rbx[2 * r]);
+                                        const uint32_t b1 = b0 < nb ? min(uni(sh.rbx[2 * r + 1]), nb - 1) : b0;
+                                        const bool walk = b0 < nb && b1 - b0 + 1 <= 2 * C; // (else: few candidates scattered over a long list, below)
+                                        sh.rb0[r] = b0;
+                                        sh.rnb[r] = walk ? b1 - b0 + 1 : 0u;
+                                        sh.rstart[r] = total_blocks;
+                                        total_blocks += walk ? b1 - b0 + 1 : 0u;
+                                }
+                                PROF_LAP(8);
+                                for (uint32_t v = tid; v < total_blocks; v += AND_WG) {
+                                        uint32_t r = 0;
+                                        for (uint32_t r2 = 1; r2 < rows; ++r2)
+                                                r = v >= sh.rstart[r2] ? r2 : r; // (rstart ascends; a row without a walk has an empty range: the next row takes its start)
+                                        while (!sh.rnb[r])
+                                                ++r;
+                                        phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, sh.rterm[r], sh.rb0[r] + (v - sh.rstart[r]), C, r * tile);
+                                }
+                                PROF_LAP(9);
+                                for (uint32_t r = 0; r < rows; ++r) {
+                                        if (sh.rnb[r] || sh.rb0[r] >= sh.rterm[r].nblocks) // (uniform)
+                                                continue;
+                                        // few candidates scattered over a long list: every candidate brackets its block with the two cell-index
+                                        // entries of its docID cell (short lists: a bisection of the directory), and the first candidate of a
+                                        // block walks it for all the block's candidates
+                                        const DevTerm t = sh.rterm[r];
+                                        const uint32_t *bl = blk_last + t.first_block;
+                                        for (uint32_t j = tid; j < C; j += AND_WG) {
+                                                const uint32_t doc = sh.cdoc[j];
+                                                uint32_t lo = 0, hi = t.nblocks;
+                                                if (t.win_off != 0xffffffffu) {
+                                                        lo = win[t.win_off + (doc >> CELL_LOG2)];
+                                                        hi = min(win[t.win_off + (doc >> CELL_LOG2) + 1] + 1, t.nblocks);
+                                                }
+                                                while (lo < hi) {
+                                                        const uint32_t mid = (lo + hi) >> 1;
+                                                        if (bl[mid] < doc)
+                                                                lo = mid + 1;
+                                                        else
+                                                                hi = mid;
+                                                }
+                                                const uint32_t prevdoc = lo ? bl[lo - 1] : 0;
+                                                if (j == 0 || sh.cdoc[j - 1] <= prevdoc)
+                                                        phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, t, lo, C, r * tile);
+                                        }
+                                        PROF_LAP(10);
+                                }
+                                __syncthreads();
                                 PROF_LAP(1);
                                 // ---- check: one lane per candidate
                                 for (uint32_t j = tid; j < C; j += AND_WG) {
                                         if (!sh.alive[j])
                                                 continue;
                                         uint32_t cnt = 0;
+                                        // GOOGLE, the usual case — up to four distinct terms, every one of the candidate's hit runs at most eight single-byte hits —:
+                                        // the rows' hit bytes are fetched TOGETHER, one unaligned 8-byte load each (one round trip for the whole check, where the
+                                        // streams below send for a row's bytes when the walk reaches it), and the walks are shifts of registers
+                                        bool fast = CODEC == CODEC_GOOGLE && rows <= 4;
+                                        uint64_t pw[4] = {0, 0, 0, 0};
+                                        uint32_t pf[4] = {0, 0, 0, 0};
+                                        if (CODEC == CODEC_GOOGLE && rows <= 4) {
+                                                typedef uint64_t ph_u64_a1 __attribute__((aligned(1)));
+#pragma unroll
+                                                for (uint32_t r = 0; r < 4; ++r) {
+                                                        if (r >= rows)
+                                                                break;
+                                                        const uint32_t fe = sh.freq[r * tile + j];
+                                                        pf[r] = fe & HitStream<CODEC_GOOGLE>::FREQ_MASK;
+                                                        fast = fast && (fe & HitStream<CODEC_GOOGLE>::FREQ_PLAIN) && pf[r] <= 8u;
+                                                }
+                                                if (fast) {
+#pragma unroll
+                                                        for (uint32_t r = 0; r < 4; ++r)
+                                                                if (r < rows)
+                                                                        pw[r] = *(const ph_u64_a1 *)(index + sh.hits_off[r * tile + j]);
+                                                }
+                                        }
+                                        if (fast) {
+                                                auto has_pos = [&](const uint32_t r, const uint32_t q) { // is position q among row r's hits? (positions ascend)
+                                                        uint64_t w = r == 0 ? pw[0] : r == 1 ? pw[1] : r == 2 ? pw[2] : pw[3];
+                                                        const uint32_t f = r == 0 ? pf[0] : r == 1 ? pf[1] : r == 2 ? pf[2] : pf[3];
+                                                        uint32_t pos = 0;
+                                                        for (uint32_t h = 0; h < f; ++h) {
+                                                                pos += ((uint32_t)w & 0xffu) >> 1;
+                                                                w >>= 8;
+                                                                if (pos >= q)
+                                                                        return pos == q;
+                                                        }
+                                                        return false;
+                                                };
+                                                const uint32_t r0 = sh.row[0];
+                                                uint64_t w0 = r0 == 0 ? pw[0] : r0 == 1 ? pw[1] : r0 == 2 ? pw[2] : pw[3];
+                                                const uint32_t f0 = r0 == 0 ? pf[0] : r0 == 1 ? pf[1] : r0 == 2 ? pf[2] : pf[3];
+                                                uint32_t p0 = 0;
+                                                for (uint32_t h = 0; h < f0 && cnt < max_match_cnt; ++h) {
+                                                        p0 += ((uint32_t)w0 & 0xffu) >> 1;
+                                                        w0 >>= 8;
+                                                        if (!p0)
+                                                                continue;
+                                                        bool all = true;
+                                                        for (uint32_t k = 1; k < ph.nterms && all; ++k) {
+                                                                const uint32_t qpos = p0 + k, rk = sh.row[k];
+                                                                all = has_pos(rk, qpos);
+                                                                for (uint32_t rm = rk + 1; rm < rows && all; ++rm) // (last writer wins: a row materialised later owns the slot)
+                                                                        if (has_pos(rm, qpos))
+                                                                                all = false;
+                                                        }
+                                                        if (all)
+                                                                ++cnt;
+                                                }
+                                        } else {
                                         // walk the start positions of term 0 (docset_iterators.cpp:101-143)
                                         HitStream<CODEC> s0;
                                         s0.init_entry(ctx, terms[pterms[ph.term_base]].pad, sh.hits_off[sh.row[0] * tile + j], sh.freq[sh.row[0] * tile + j]);
@@ -446,6 +546,7 @@ __global__ __launch_bounds__(AND_WG) void k_phrase(const uint8_t *__restrict__ i
                                                 }
                                                 if (all)
                                                         ++cnt;
+                                        }
                                         }
                                         if (!cnt)
                                                 sh.alive[j] = 0;

@@ -960,7 +960,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 const uint32_t *match_off = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_blk_doff : b->ix->d_blk_off;
                 uint32_t dense_wgs = TRI_DENSE_WAVES * 256 / DENSE_WG, cand_wgs = 4; // workgroups per CU
                 bool overlap = false;
-                if (dev->opt.overlap_dense_wgs && dev->opt.overlap_cand_wgs && b->n_dense && b->n_cand) { // both kernels side by side
+                if (dev->opt.overlap_dense_wgs && dev->opt.overlap_cand_wgs && (b->n_dense || b->n_pset) && b->n_cand) { // the window kernels and the candidate-tile kernel side by side
                         overlap = true;
                         dense_wgs = (uint32_t)dev->opt.overlap_dense_wgs;
                         cand_wgs = (uint32_t)dev->opt.overlap_cand_wgs;
@@ -1006,7 +1006,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
                 if (b->n_pset) {
                         // the queries all of whose terms have planes: word-wise algebra over the planes + expansion (k_psets.hpp)
-                        hipLaunchKernelGGL(k_psets, dim3(std::min<uint32_t>(b->n_pset, (uint32_t)dev->cus * (TRI_PSET_WAVES * 256 / PSET_WG))), dim3(PSET_WG), 0, dev->stream,
+                        hipLaunchKernelGGL(k_psets, dim3(std::min<uint32_t>(b->n_pset, (uint32_t)dev->cus * (overlap && dev->opt.overlap_dense_wgs ? std::min<uint32_t>(dense_wgs, TRI_PSET_WAVES * 256 / PSET_WG) : TRI_PSET_WAVES * 256 / PSET_WG))), dim3(PSET_WG), 0, dev->stream,
                                            (const DevPsetUnit *)(b->d_arena + b->off_units), (const uint32_t *)(b->d_arena + b->off_pset_sched), b->n_pset, b->d_ticket + 20,
                                            (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->ix->d_pcache, b->plw);
                         HIP_TRY(hipGetLastError());
