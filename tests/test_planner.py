@@ -92,7 +92,13 @@ def check_plan(p, nq):
         for u in ran[:: max(1, len(ran) // 300)]:
             k0 = 1 if tasks[u["tix"]]["kind"] == HP.TASK_PROBE else 0
             for k in range(k0, min(int(u["nterms"]), 4)):
-                assert (u["tt"][k] & 0x3FFFFFFF) == (p.qterms[u["term_base"] + k] & 0x3FFFFFFF) and u["row"][k] == p.qplane[u["term_base"] + k] != 0xFFFFFFFF
+                scatter = bool(u["first"] & 4)  # PSET_UNIT_SCATTER: a union may name terms without a plane (their documents are set in the stored words)
+                assert (u["tt"][k] & 0x3FFFFFFF) == (p.qterms[u["term_base"] + k] & 0x3FFFFFFF) and u["row"][k] == p.qplane[u["term_base"] + k]
+                assert scatter or u["row"][k] != 0xFFFFFFFF
+            if u["first"] & 4:  # ... but at least one of its terms has one, it is ONE group with nothing excluded, and its result is a bitmap
+                tw = p.qterms[u["term_base"] : u["term_base"] + int(u["nterms"])]
+                assert (u["first"] & 2) and (tw[0] >> 31) and not np.any(tw[1:] >> 31) and not np.any((tw >> 30) & 1)
+                assert np.any(p.qplane[u["term_base"] : u["term_base"] + int(u["nterms"])] != 0xFFFFFFFF)
     # planes: a term position that names a row names its own term's row
     if s["n_qplane"]:
         # (a row is the term's rank by document count — the planes live with the index, every batch names the same row for the same term)

@@ -108,12 +108,14 @@ struct DevPsetUnit { // (also the record of a TASK_PROBE task: w_begin / w_end a
         uint32_t tix;       // index into counts[]
         uint32_t nterms;
         uint32_t term_base; // qterms[] / qplane[] slice (read by the kernel only when nterms > PSET_INLINE_TERMS)
-        uint32_t first;     // bit 0: the first task of its query (planner bookkeeping); bit 1 (PSET_UNIT_BITMAP): the query's result is a bitmap (RESULT_BITMAP)
+        uint32_t first;     // bit 0: the first task of its query (planner bookkeeping); bit 1 (PSET_UNIT_BITMAP): the query's result is a bitmap (RESULT_BITMAP); bit 2: PSET_UNIT_SCATTER
         uint32_t tt[PSET_INLINE_TERMS];  // qterms[] words (term | QT_GROUP | QT_NOT) ...
         uint32_t row[PSET_INLINE_TERMS]; // ... and the terms' plane rows
 };
 static_assert(sizeof(DevPsetUnit) == 64, "one cache-line half per unit");
 constexpr uint32_t PSET_UNIT_FIRST = 1u, PSET_UNIT_BITMAP = 2u;
+constexpr uint32_t PSET_UNIT_SCATTER = 4u; // a UNION some of whose terms have no plane (qplane[] = PL_NONE for them), result a bitmap: the plane terms' words are OR-ed and stored,
+                                           // then the other terms' documents of the task's range are set in the stored words one by one (k_psets.hpp: psets_scatter)
 // ---- TASK_TREE: the query tree as the kernels read it (k_tree.hpp).  A record in the plan's tree[] words (DevQuery::fused_idx = its first word):
 //      TREE_HDR_WORDS header words { nnodes, 0... }, then nnodes DevTreeNode in POSTFIX order (children before parents, the root last)
 constexpr uint32_t TREE_MAX_NODES = 64;     // node values and "an iterator sits on the document" flags are bit sets in a 64-bit word

@@ -1,5 +1,5 @@
 // k_psets.hpp — docset algebra of the queries ALL of whose terms have a term plane (TASK_PSET): intersections / unions / exclusions of head
-// terms, the queries that materialise the batch's largest docID sets (cfg2: 1551 of 16384 queries write 380 M of the step's 395 M matches).
+// terms (and, round 5, unions of head terms with others whose few documents are scattered into the stored result: PSET_UNIT_SCATTER), the queries that materialise the batch's largest docID sets (cfg2: 1551 of 16384 queries write 380 M of the step's 395 M matches).
 // Part of libtrinity_hip.so (MI355X / gfx950); included by trinity_hip.hip.  New code, no reference source.
 //
 // What it replaces in the reference: Conjuction::next_impl / DisjunctionAllPLI::next over Google::Decoder::next (docset_iterators.cpp:
@@ -52,15 +52,93 @@ struct PsetShared {
         uint32_t tick[2];            // ... and their tickets (>= ntasks: none)
 };
 
+// ---- PSET_UNIT_SCATTER: a union's terms WITHOUT a plane, after the plane terms' words of the task's windows have been stored: every row of such a
+//      term that can reach the task's docID range is decoded, one lane per row of <= 32 documents (the register row readers of k_fused), and its
+//      documents are set in the stored words one by one — an atomic OR whose old value says whether the document is new to the union (the count).
+//      A rare term brings a handful of documents per task; k_and_dense decoded every list of such a query into an LDS window bitmap, window by
+//      window, behind half a dozen barriers each.  Not inlined: the row readers' registers must not weigh on the windows' loop.
+struct PsetScatterPost {
+        uint32_t *bm;               // the task's words (bit 0 of word 0: the task's first document)
+        const uint32_t *masked;     // masked documents (absolute docIDs), or nullptr
+        uint32_t doc0, nbits, added = 0;
+        __device__ __forceinline__ void doc(const uint32_t rel) {
+                if (rel >= nbits) // (a row reaches across the range's ends: the neighbouring tasks take those documents)
+                        return;
+                const uint32_t d = doc0 + rel, bit = 1u << (rel & 31u);
+                if (masked && ((masked[d >> 5] >> (d & 31u)) & 1u))
+                        return;
+                added += (atomicOr(&bm[rel >> 5], bit) & bit) ? 0u : 1u;
+        }
+        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t) { doc(rel); }
+};
+template <int CODEC>
+__device__ __noinline__ uint32_t psets_scatter(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+                                               const uint4 *__restrict__ blk_rec, const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
+                                               const DevTerm *__restrict__ terms, const uint32_t term, const uint32_t w_begin, const uint32_t w_end, uint32_t *__restrict__ bm,
+                                               const uint32_t *__restrict__ masked) {
+        const DevTerm t = terms[term];
+        if (!t.nblocks)
+                return 0;
+        const uint32_t *bl = blk_last + t.first_block;
+        const uint32_t d0 = w_begin * SPAN_BITS, d1 = w_end * SPAN_BITS; // (the planner keeps max docID below 2^31: no wrap)
+        // rows that can hold documents of [d0, d1): first row whose last docID >= d0 ... first row whose last docID >= d1 (it may still begin inside)
+        uint32_t b_lo, b_hi;
+        if (t.win_off != 0xffffffffu) {
+                b_lo = win[t.win_off + w_begin * CELLS_PER_SPAN];
+                b_hi = win[t.win_off + w_end * CELLS_PER_SPAN];
+        } else {
+                uint32_t lo = 0, hi = t.nblocks;
+                while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (bl[mid] < d0)
+                                lo = mid + 1;
+                        else
+                                hi = mid;
+                }
+                b_lo = lo;
+                hi = t.nblocks;
+                while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (bl[mid] < d1)
+                                lo = mid + 1;
+                        else
+                                hi = mid;
+                }
+                b_hi = lo;
+        }
+        b_lo = uni(b_lo);
+        b_hi = uni(min(b_hi, t.nblocks - 1));
+        PsetScatterPost post{bm, masked, d0, d1 - d0};
+        if (b_lo < t.nblocks)
+                for (uint32_t b = b_lo + threadIdx.x; b <= b_hi; b += PSET_WG) {
+                        const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
+#ifdef TRI_PROF
+                        ProfClock prof_;
+#endif
+                        if (CODEC == CODEC_LUCENE) {
+                                const uint4 rec = blk_rec[t.first_block + b];
+                                row_decode<CODEC, false, PsetScatterPost>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, d0, post PROF_PASS);
+                        } else {
+                                const uint32_t off = blk_off[t.first_block + b];
+                                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
+                                row_decode<CODEC, false, PsetScatterPost>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, d0, post PROF_PASS);
+                        }
+                }
+        return post.added;
+}
+
 #ifndef TRI_PSET_WAVES
 #define TRI_PSET_WAVES 8 // waves per SIMD the register budget is cut for (512-thread workgroups: four per CU, 33 KB of LDS each)
 #endif
 // units[]: the TASK_PSET tasks (DevPsetUnit, dev_structs.hpp); order[]: the units in the order they are run (window range by window range);
 // ticket: the persistent workgroups' shared cursor into order[].
+template <int CODEC>
 __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPsetUnit *__restrict__ units, const uint32_t *__restrict__ order, const uint32_t ntasks,
                                                                    uint32_t *__restrict__ ticket, const uint32_t *__restrict__ qterms, const uint32_t *__restrict__ qplane,
                                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ counts, const uint32_t *__restrict__ masked,
-                                                                   const uint32_t *__restrict__ planes, const uint32_t plw) {
+                                                                   const uint32_t *__restrict__ planes, const uint32_t plw, const uint8_t *__restrict__ index,
+                                                                   const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
+                                                                   const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms) {
         __shared__ PsetShared sh;
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
         const uint32_t wave = uni(tid >> 6);
@@ -124,6 +202,8 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                                         break;
                                 if (tt & QT_GROUP)
                                         cur_neg = tt & QT_NOT;
+                                if (row == PL_NONE) // (a PSET_UNIT_SCATTER union's term without a plane: its documents are set after the windows, below)
+                                        continue;
                                 const uint4 *pa = (const uint4 *)(planes + (size_t)row * PL_PLANES * plw + word0);
 #if defined(TRI_PSET_VARIANT) && TRI_PSET_VARIANT == 3 // (perf probe 3: no plane loads — words made up from the lane's address)
                                 const uint32_t hsh = (word0 * 2654435761u) ^ (k * 40503u);
@@ -210,6 +290,14 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                                         o += (uint32_t)__popcll(bm);
                                 }
                                 __builtin_amdgcn_wave_barrier();
+                        }
+                }
+                if (uni(U.first) & PSET_UNIT_SCATTER) { // (uniform)
+                        __syncthreads(); // the task's words are stored: the documents of the terms without a plane go in on top of them
+                        for (uint32_t k = 0; k < nterms; ++k) {
+                                if (uni(qplane[term_base + k]) != PL_NONE)
+                                        continue;
+                                produced += psets_scatter<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, terms, uni(qterms[term_base + k]) & QT_TERM, w_begin, w_end, qout, masked);
                         }
                 }
                 if (as_bitmap) { // the lanes' counts -> the task's (uniform branch: the record is the workgroup's)

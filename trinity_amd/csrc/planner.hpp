@@ -1415,6 +1415,23 @@ namespace trip {
                         bool pset = t.dense && (planes_opt & 2u);
                         for (uint32_t k = 0; pset && k < t.q.nterms; ++k)
                                 pset = C.plane_ok(qt[k] & QT_TERM);
+                        // ... and a DocumentsOnly UNION (one group, nothing excluded) of head terms AND others whose result is a bitmap anyway (the head terms alone match
+                        // one document in 32 or more): the head terms' plane words are OR-ed and stored like any other k_psets window, the other terms' few
+                        // documents are then set in the stored words one by one (PSET_UNIT_SCATTER) — where k_and_dense decodes every list into an LDS window
+                        // bitmap behind half a dozen barriers per window (cfg5's 5-way unions: 2.5 of the shard's 8.9 ms)
+                        bool pscatter = false;
+                        if (t.dense && !pset && (planes_opt & 2u) && C.mode == TRI_FLAG_DOCUMENTS_ONLY && opt.result_bitmaps && !t.q.nphrases && t.q.nterms >= 2) {
+                                uint64_t plane_df = 0;
+                                bool one_group = true;
+                                for (uint32_t k = 0; k < t.q.nterms; ++k) {
+                                        one_group = one_group && !(qt[k] & QT_NOT) && (k == 0) == ((qt[k] & QT_GROUP) != 0);
+                                        if (C.plane_ok(qt[k] & QT_TERM))
+                                                plane_df += ix.terms[qt[k] & QT_TERM].documents;
+                                }
+                                const uint32_t nwin = last_doc / SPAN_BITS + 1;
+                                pscatter = one_group && plane_df && (double)plane_df >= (double)nwin * SPAN_WORDS; // (the form below is decided the same way, on all the terms)
+                                pset = pscatter;
+                        }
                         // a single lead list too short for a plane against lists that all have one: candidate tiles, every candidate tested with one
                         // bit probe per list (k_and) — the bitmap kernel would decode the lead into an LDS window bitmap and expand the window
                         // workgroup-wide for a handful of matches per window (cfg2: 253 such queries took 0.57 ms there, a third of the dense class's time)
@@ -1516,7 +1533,7 @@ namespace trip {
                                         if (pset) {
                                                 DevPsetUnit u{};
                                                 u.out_off = task_off;
-                                                u.first = bitmap ? PSET_UNIT_BITMAP : 0u;
+                                                u.first = (bitmap ? PSET_UNIT_BITMAP : 0u) | (pscatter ? PSET_UNIT_SCATTER : 0u);
                                                 u.w_begin = wb, u.w_end = we;
                                                 u.tix = (uint32_t)f.tasks.size();
                                                 u.nterms = t.q.nterms;
@@ -1693,7 +1710,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         // k_planes: docID ranges per query.  A task has fixed costs (seed pass, end-of-task imbalance: about 140 us), the kernel's tail is its
         // longest tasks: two ranges when the batch brings ten or more tasks per resident workgroup anyway, three when it does not (measured,
         // cfg3's mix: 8192 queries 2 > 3 > 4; 3750 queries 6.5 / 5.9 / 6.2 ms for 2 / 3 / 4; 1024 queries 2.11 / 1.97 / 1.96)
-        C.planes_split = opt.planes_split ? opt.planes_split : (2 * onepass_queries >= 10ull * (uint64_t)env.cus * env.plk_wgs_per_cu ? 2 : 3);
+        C.planes_split = opt.planes_split ? opt.planes_split : (2 * onepass_queries >= 4ull * (uint64_t)env.cus * env.plk_wgs_per_cu ? 2 : 3) /* (round 5: a task's tail is short now — two ranges from four tasks per resident workgroup on; cfg5's shard, ms: 2 -> 2.25, 3 -> 2.35, 4 -> 2.50) */;
         // one-pass tasks stage the query (slot map, score tables) once per task: the longer the task the better, as long as the batch still
         // cuts into a couple of tasks per workgroup the device holds (measured at cfg3: 512 K postings per task 55.4 ms, 1 M 51.1, 2 M 49.2,
         // 4 M 48.0, 8 M and more 47.1).  fused_task_cost = 0 (the default): sized from the batch; otherwise as given
@@ -1922,7 +1939,8 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         bool rows = true;
                         for (uint32_t k = is_probe ? 1u : 0u; k < u.nterms; ++k) { // (a TASK_PROBE unit's term 0 is the lead: decoded, never probed)
                                 const uint32_t term = (k < PSET_INLINE_TERMS ? u.tt[k] : f.qterms[f.units[i].term_base + k]) & QT_TERM;
-                                const uint32_t row = row_of_rank[ix.df_rank[term]];
+                                const uint32_t rank = ix.df_rank[term];
+                                const uint32_t row = rank < row_of_rank.size() ? row_of_rank[rank] : PL_NONE; // (a PSET_UNIT_SCATTER union names terms without a plane)
                                 rows &= row != PL_NONE;
                                 if (k < PSET_INLINE_TERMS)
                                         u.row[k] = row;

@@ -1006,9 +1006,10 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
                 if (b->n_pset) {
                         // the queries all of whose terms have planes: word-wise algebra over the planes + expansion (k_psets.hpp)
-                        hipLaunchKernelGGL(k_psets, dim3(std::min<uint32_t>(b->n_pset, (uint32_t)dev->cus * (overlap && dev->opt.overlap_dense_wgs ? std::min<uint32_t>(dense_wgs, TRI_PSET_WAVES * 256 / PSET_WG) : TRI_PSET_WAVES * 256 / PSET_WG))), dim3(PSET_WG), 0, dev->stream,
-                                           (const DevPsetUnit *)(b->d_arena + b->off_units), (const uint32_t *)(b->d_arena + b->off_pset_sched), b->n_pset, b->d_ticket + 20,
-                                           (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->ix->d_pcache, b->plw);
+                        TRI_LAUNCH(k_psets, b->ix->codec, dim3(std::min<uint32_t>(b->n_pset, (uint32_t)dev->cus * (overlap && dev->opt.overlap_dense_wgs ? std::min<uint32_t>(dense_wgs, TRI_PSET_WAVES * 256 / PSET_WG) : TRI_PSET_WAVES * 256 / PSET_WG))), dim3(PSET_WG), dev->stream,
+                                   (const DevPsetUnit *)(b->d_arena + b->off_units), (const uint32_t *)(b->d_arena + b->off_pset_sched), b->n_pset, b->d_ticket + 20,
+                                   (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->ix->d_pcache, b->plw,
+                                   b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms);
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_s, dev->stream));
