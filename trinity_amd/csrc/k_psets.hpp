@@ -45,9 +45,14 @@ constexpr uint32_t PSET_STAGE = 1024;                    // docIDs a wave stages
 static_assert(PSET_PER == 8, "two 16-byte loads per lane and term");
 static_assert(PSET_STAGE >= PSET_WORDS, "the dense walk parks the wave's words in its staging buffer");
 
+struct PsetScatterShared { // (part of PsetShared)
+        DevTerm term[MAX_QTERMS]; // the union's terms without a plane ...
+        uint32_t b_lo[MAX_QTERMS], nrows[MAX_QTERMS]; // ... their rows that can reach the task's range
+};
 struct PsetShared {
         uint32_t stage[PSET_WAVES][PSET_STAGE];
         uint32_t cnt[2][PSET_WAVES]; // per window parity: the waves' survivor counts
+        PsetScatterShared scatter;   // PSET_UNIT_SCATTER tasks: the terms without a plane
         DevPsetUnit unit[2];         // the task being run and the next one (fetched while the current one runs)
         uint32_t tick[2];            // ... and their tickets (>= ntasks: none)
 };
@@ -72,58 +77,79 @@ struct PsetScatterPost {
         __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t) { doc(rel); }
 };
 template <int CODEC>
-__device__ __noinline__ uint32_t psets_scatter(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+__device__ __noinline__ uint32_t psets_scatter(PsetScatterShared &ss, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
                                                const uint4 *__restrict__ blk_rec, const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
-                                               const DevTerm *__restrict__ terms, const uint32_t term, const uint32_t w_begin, const uint32_t w_end, uint32_t *__restrict__ bm,
-                                               const uint32_t *__restrict__ masked) {
-        const DevTerm t = terms[term];
-        if (!t.nblocks)
-                return 0;
-        const uint32_t *bl = blk_last + t.first_block;
+                                               const DevTerm *__restrict__ terms, const uint32_t *__restrict__ qterms, const uint32_t *__restrict__ qplane, const uint32_t nterms,
+                                               const uint32_t w_begin, const uint32_t w_end, uint32_t *__restrict__ bm, const uint32_t *__restrict__ masked) {
+        const uint32_t tid = threadIdx.x;
         const uint32_t d0 = w_begin * SPAN_BITS, d1 = w_end * SPAN_BITS; // (the planner keeps max docID below 2^31: no wrap)
-        // rows that can hold documents of [d0, d1): first row whose last docID >= d0 ... first row whose last docID >= d1 (it may still begin inside)
-        uint32_t b_lo, b_hi;
-        if (t.win_off != 0xffffffffu) {
-                b_lo = win[t.win_off + w_begin * CELLS_PER_SPAN];
-                b_hi = win[t.win_off + w_end * CELLS_PER_SPAN];
-        } else {
-                uint32_t lo = 0, hi = t.nblocks;
-                while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (bl[mid] < d0)
-                                lo = mid + 1;
-                        else
-                                hi = mid;
-                }
-                b_lo = lo;
-                hi = t.nblocks;
-                while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (bl[mid] < d1)
-                                lo = mid + 1;
-                        else
-                                hi = mid;
-                }
-                b_hi = lo;
-        }
-        b_lo = uni(b_lo);
-        b_hi = uni(min(b_hi, t.nblocks - 1));
-        PsetScatterPost post{bm, masked, d0, d1 - d0};
-        if (b_lo < t.nblocks)
-                for (uint32_t b = b_lo + threadIdx.x; b <= b_hi; b += PSET_WG) {
-                        const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
-#ifdef TRI_PROF
-                        ProfClock prof_;
-#endif
-                        if (CODEC == CODEC_LUCENE) {
-                                const uint4 rec = blk_rec[t.first_block + b];
-                                row_decode<CODEC, false, PsetScatterPost>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, d0, post PROF_PASS);
-                        } else {
-                                const uint32_t off = blk_off[t.first_block + b];
-                                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
-                                row_decode<CODEC, false, PsetScatterPost>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, d0, post PROF_PASS);
+        // lane k looks after term k: its record and its rows that can hold documents of [d0, d1) — first row whose last docID >= d0 ... first row
+        // whose last docID >= d1 (it may still begin inside) — all the terms side by side: one chain of dependent loads for the task, not one per term
+        if (tid < MAX_QTERMS) {
+                uint32_t lo_b = 0, n = 0;
+                if (tid < nterms && qplane[tid] == PL_NONE) {
+                        const DevTerm t = terms[qterms[tid] & QT_TERM];
+                        ss.term[tid] = t;
+                        if (t.nblocks) {
+                                const uint32_t *bl = blk_last + t.first_block;
+                                uint32_t b_lo, b_hi;
+                                if (t.win_off != 0xffffffffu) {
+                                        b_lo = win[t.win_off + w_begin * CELLS_PER_SPAN];
+                                        b_hi = win[t.win_off + w_end * CELLS_PER_SPAN];
+                                } else {
+                                        uint32_t lo = 0, hi = t.nblocks;
+                                        while (lo < hi) {
+                                                const uint32_t mid = (lo + hi) >> 1;
+                                                if (bl[mid] < d0)
+                                                        lo = mid + 1;
+                                                else
+                                                        hi = mid;
+                                        }
+                                        b_lo = lo;
+                                        hi = t.nblocks;
+                                        while (lo < hi) {
+                                                const uint32_t mid = (lo + hi) >> 1;
+                                                if (bl[mid] < d1)
+                                                        lo = mid + 1;
+                                                else
+                                                        hi = mid;
+                                        }
+                                        b_hi = lo;
+                                }
+                                b_hi = min(b_hi, t.nblocks - 1);
+                                lo_b = b_lo;
+                                n = b_lo < t.nblocks ? b_hi - b_lo + 1 : 0u;
                         }
                 }
+                ss.b_lo[tid] = lo_b;
+                ss.nrows[tid] = n;
+        }
+        __syncthreads();
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < nterms; ++k)
+                total += uni(ss.nrows[k]);
+        PsetScatterPost post{bm, masked, d0, d1 - d0};
+        for (uint32_t v = tid; v < total; v += PSET_WG) { // one lane per row, the terms' rows one after the other
+                uint32_t k = 0, r = v;
+                for (; r >= ss.nrows[k]; ++k)
+                        r -= ss.nrows[k];
+                const DevTerm t = ss.term[k];
+                const uint32_t b = ss.b_lo[k] + r;
+                const uint32_t *bl = blk_last + t.first_block;
+                const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
+#ifdef TRI_PROF
+                ProfClock prof_;
+#endif
+                if (CODEC == CODEC_LUCENE) {
+                        const uint4 rec = blk_rec[t.first_block + b];
+                        row_decode<CODEC, false, PsetScatterPost>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, d0, post PROF_PASS);
+                } else {
+                        const uint32_t off = blk_off[t.first_block + b];
+                        const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
+                        row_decode<CODEC, false, PsetScatterPost>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, d0, post PROF_PASS);
+                }
+        }
+        __syncthreads(); // (ss is the next task's, too)
         return post.added;
 }
 
@@ -294,11 +320,7 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                 }
                 if (uni(U.first) & PSET_UNIT_SCATTER) { // (uniform)
                         __syncthreads(); // the task's words are stored: the documents of the terms without a plane go in on top of them
-                        for (uint32_t k = 0; k < nterms; ++k) {
-                                if (uni(qplane[term_base + k]) != PL_NONE)
-                                        continue;
-                                produced += psets_scatter<CODEC>(index, blk_last, blk_off, blk_rec, blk_doff, win, terms, uni(qterms[term_base + k]) & QT_TERM, w_begin, w_end, qout, masked);
-                        }
+                        produced += psets_scatter<CODEC>(sh.scatter, index, blk_last, blk_off, blk_rec, blk_doff, win, terms, qterms + term_base, qplane + term_base, nterms, w_begin, w_end, qout, masked);
                 }
                 if (as_bitmap) { // the lanes' counts -> the task's (uniform branch: the record is the workgroup's)
 #pragma unroll
