@@ -34,7 +34,7 @@ for stage in "$@"; do
     prof:*)
       name="$(echo "$stage" | cut -d: -f2)"; args="$(echo "$stage" | cut -d: -f3- | tr ',' ' ')"
       rm -rf "$out/trace_$name"
-      (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$name" -- python "$root/bench.py" $args --cpu-seconds 0 --scaling-ref-steps 0 > "$out/prof_$name.json" 2> "$out/prof_$name.err")
+      (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_$name" -- python "$root/bench.py" $args --cpu-seconds 0 --scaling-ref-steps 0 --rotating-sets 0 --delivered-steps 0 > "$out/prof_$name.json" 2> "$out/prof_$name.err")
       find "$out/trace_$name" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats_$name.csv" \;
       rm -rf "$out/trace_$name"
       head -12 "$out/kernel_stats_$name.csv"; log "prof $name done" ;;
@@ -42,14 +42,14 @@ for stage in "$@"; do
       name="$(echo "$stage" | cut -d: -f2)"; args="$(echo "$stage" | cut -d: -f3- | tr ',' ' ')"
       for ctr in FETCH_SIZE WRITE_SIZE; do
         rm -rf "$out/pmc_${name}_$ctr"
-        (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$out/pmc_${name}_$ctr" -- python "$root/bench.py" $args --cpu-seconds 0 --scaling-ref-steps 0 > "$out/pmc_${name}_$ctr.json" 2> "$out/pmc_${name}_$ctr.err")
+        (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$out/pmc_${name}_$ctr" -- python "$root/bench.py" $args --cpu-seconds 0 --scaling-ref-steps 0 --rotating-sets 0 --delivered-steps 0 > "$out/pmc_${name}_$ctr.json" 2> "$out/pmc_${name}_$ctr.err")
       done
       python3 "$root/tools/pmc_summarize.py" "$out" "$name" | tee "$out/pmc_$name.txt"; log "pmc $name done" ;;
     sq:*)
       # SQ issue / stall counters of every kernel (one pass, 8 SQ slots): where the waves' cycles go
       name="$(echo "$stage" | cut -d: -f2)"; args="$(echo "$stage" | cut -d: -f3- | tr ',' ' ')"
       rm -rf "$out/sq_$name"
-      (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --pmc ${SQ_CTRS:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS} --output-format csv -d "$out/sq_$name" -- python "$root/bench.py" $args --cpu-seconds 0 --scaling-ref-steps 0 > "$out/sq_$name.json" 2> "$out/sq_$name.err")
+      (cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --pmc ${SQ_CTRS:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS} --output-format csv -d "$out/sq_$name" -- python "$root/bench.py" $args --cpu-seconds 0 --scaling-ref-steps 0 --rotating-sets 0 --delivered-steps 0 > "$out/sq_$name.json" 2> "$out/sq_$name.err")
       python3 "$root/tools/sq_summarize.py" "$out/sq_$name" | tee "$out/sq_$name.txt"; rm -rf "$out/sq_$name"; log "sq $name done" ;;
     cmd:*)
       c="${stage#cmd:}"; timeout -k 10 900 bash -c "$c" > "$out/cmd_$(echo "$c" | md5sum | cut -c1-8).log" 2>&1; log "cmd rc=$?" ;;
