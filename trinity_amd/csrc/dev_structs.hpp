@@ -150,7 +150,10 @@ constexpr uint32_t PL_NESTED = 6;         // nested planes per term — plane k 
                                           // it is in: levels 1 .. PL_NESTED - 1 ARE the frequency.  The nested planes are what a SWEEP streams (one plane, front to back)
 constexpr uint32_t PL_LEVEL_WORDS = 3;    // ... and after them the same levels bit-sliced and INTERLEAVED — words 3 w, 3 w + 1, 3 w + 2: bit 0, 1, 2 of the level of the
                                           // 32 documents of word w — what a PROBE reads: one 12-byte access tells a document's frequency where the nested planes take six
-constexpr uint32_t PL_PLANES = PL_NESTED + PL_LEVEL_WORDS; // words of a term's row per word of the docID space (the row's stride is PL_PLANES * plw)
+constexpr uint32_t PL_STORED = 4;         // the nested planes a row actually holds: 0 .. PL_STORED - 1 (f >= 1 .. f >= 4).  A sweep that wants "f > c" for a higher c streams
+                                          // plane PL_STORED - 1 instead (a superset: the level words sort it out) — the planes above it are one bit in a thousand and cost a
+                                          // full plane each to build, to keep and to stream
+constexpr uint32_t PL_PLANES = PL_STORED + PL_LEVEL_WORDS; // words of a term's row per word of the docID space (the row's stride is PL_PLANES * plw)
 constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64).  The entry's
                                                  // low 31 bits: where the block's hits start, in bytes PAST blk_off[] (the block's deltas and frequencies lie
                                                  // between: a few hundred bytes) — index offsets themselves keep all their 32 bits (codecs.h:26: chunks up to 4 GiB)

@@ -105,13 +105,14 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
         __syncthreads();
         uint32_t *pa = planes + (size_t)row * PL_PLANES * plw + (size_t)w * PL_WORDS;
         static_assert(PL_NESTED == 6 && PL_LEVEL_WORDS == 3, "the level's bits below are written for six nested planes");
-        uint32_t *lv = planes + (size_t)row * PL_PLANES * plw + (size_t)PL_NESTED * plw + 3u * (size_t)w * PL_WORDS; // the window's interleaved level words
+        uint32_t *lv = planes + (size_t)row * PL_PLANES * plw + (size_t)PL_STORED * plw + 3u * (size_t)w * PL_WORDS; // the window's interleaved level words
         for (uint32_t i = tid; i < PL_WORDS; i += AND_WG) {
                 uint32_t x[PL_NESTED];
 #pragma unroll
                 for (uint32_t k = 0; k < PL_NESTED; ++k) {
                         x[k] = pl[k * PL_STRIDE + i];
-                        pa[(size_t)k * plw + i] = x[k];
+                        if (k < PL_STORED)
+                                pa[(size_t)k * plw + i] = x[k];
                 }
                 // the level (the number of nested planes a document is in) bit-sliced: odd; 2, 3 or 6; 4 or more
                 lv[3u * i] = x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[4] ^ x[5];
@@ -625,7 +626,7 @@ __device__ __noinline__ uint32_t planes_work_words(const uint32_t *__restrict__ 
         static_assert(PL_NESTED == 6 && PL_LEVEL_WORDS == 3, "the planes' words below are derived from three level bits of six levels");
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i) { // (all the loads first: one round trip — three adjacent words per slot)
-                const PlkG1 lv = pa1[i] + (size_t)PL_NESTED * plw + 3u * (i < nd ? wi : lane);
+                const PlkG1 lv = pa1[i] + (size_t)PL_STORED * plw + 3u * (i < nd ? wi : lane);
                 l0[i] = lv[0];
                 l1[i] = lv[1];
                 l2[i] = lv[2];
@@ -758,9 +759,14 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i) {
                 const uint32_t e = (uni(sh.esel) >> (3 * i)) & 7u;
+#ifdef TRI_PLK_NO_EFETCH
+                const bool bc = false;
+#else
                 const bool bc = i < nd && e >= 1u && e < PL_NESTED;
+                const uint32_t es = e < PL_STORED ? e : PL_STORED - 1u; // (a plane the rows do not hold: the highest one they do — a superset)
+#endif
                 es_fetch |= (bc ? 1u : 0u) << i;
-                pe1[i] = bc ? pa1[i] + (size_t)e * plw : (PlkG1)(planes + (size_t)uni(sh.sa.zrow) * PL_PLANES * plw);
+                pe1[i] = bc ? pa1[i] + (size_t)es * plw : (PlkG1)(planes + (size_t)uni(sh.sa.zrow) * PL_PLANES * plw);
         }
         es_fetch = uni(es_fetch);
         // the first three required groups in scalar registers (a group beyond the query's: every position — it changes nothing), further ones from LDS
@@ -777,7 +783,11 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i) {
                 const uint32_t e = (esel >> (3 * i)) & 7u;
+#ifdef TRI_PLK_NO_EFETCH
+                es_a |= (e != 7u ? 1u : 0u) << i;
+#else
                 es_a |= (e == 0 ? 1u : 0u) << i;
+#endif
                 es_any |= (e != 7u ? 1u : 0u) << i;
         }
         es_a = uni(es_a), es_any = uni(es_any);
@@ -1030,7 +1040,11 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                         sh.atab = 0xffffffffu;
                         // a sparse slot's rows that can hold documents of the task's range [first window's first docID, last window's end)
                         uint32_t row0 = 0, nrows = 0;
-                        if (!dense) {
+                        if (!dense && myt.win_off != 0xffffffffu) { // (the cell index: the first block whose last docID reaches a cell's start — two loads)
+                                row0 = win[myt.win_off + (d_lo >> CELL_LOG2)];
+                                const uint32_t r1 = win[myt.win_off + (d_hi >> CELL_LOG2)];
+                                nrows = row0 < myt.nblocks ? min(r1, myt.nblocks - 1) - row0 + 1 : 0;
+                        } else if (!dense) {
                                 const uint32_t *bl = blk_last + myt.first_block;
                                 uint32_t lo = 0, hi = myt.nblocks;
                                 while (lo < hi) {
@@ -1295,7 +1309,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                         for (uint32_t i = 0; i < NS; ++i) {
                                                                 if (i >= nd)
                                                                         break;
-                                                                const uint32_t *lv = pA[i] + (size_t)PL_NESTED * plw + 3u * wi; // (the level's three bits: adjacent words)
+                                                                const uint32_t *lv = pA[i] + (size_t)PL_STORED * plw + 3u * wi; // (the level's three bits: adjacent words)
                                                                 const uint32_t l = ((lv[0] >> bit) & 1u) | (((lv[1] >> bit) & 1u) << 1) | (((lv[2] >> bit) & 1u) << 2);
                                                                 present |= (l ? 1u : 0u) << dsl[i];
                                                                 levels |= (((leafd >> i) & 1u) ? l : 0u) << (3u * dsl[i]);
