@@ -24,7 +24,7 @@ extern "C" {
 #define TRI_ABI_VERSION 8 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
                              4: tri_batch_info grew (term planes, k_planes), tri_batch_query_status, tri_comm_create_custom; 5: tri_encode_google_payloads;
                              6: tri_batch_info.create_ms / create_plan_ms / *_bound_bytes, options plane_max_bytes / plan_threads, tri_cbatch_query_status;
-                             8: tri_batch_docsets (every query's docID set in one call), option planes_rebuild */
+                             8: tri_batch_docsets (every query's docID set in one call), tri_merge_lucene, option planes_rebuild */
 
 /* status codes */
 #define TRI_OK 0
@@ -394,6 +394,14 @@ int tri_commit_google(tri_dev *, const uint32_t *term_ids, const uint32_t *doc_i
  * term only one unmasked participant holds (append_index_chunk, merge.cpp:167-178) copies bytes this call re-encodes.  index_out == NULL: sizing call. */
 int tri_merge_google(tri_dev *, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
                      tri_term *terms_out, tri_commit_stats *stats);
+/* Codecs::Lucene::IndexSession::merge (lucene_codec.cpp:963-1396), likewise for a whole dictionary (ABI 8): the same walk — participants most recent first, the most recent
+ * holder's posting wins, dropped when that participant masks the document — over lucene_codec indexes uploaded WITH their hits.data; what is kept is re-encoded by the device's
+ * Lucene-shaped encoder (tri_encode_lucene: PFOR128 ints() payload, positions only — a participant's payloads are not carried, as in tri_encode_lucene): index_out / hits_out =
+ * the merged `index` and `hits.data`, terms_out[t] as tri_encode_lucene.  The bytes equal the host encoder's over the merged postings; the walk is the one
+ * tests/golden/ref_merge.json pins for the Google codec (the reference's Lucene side needs FastPFor: unbuildable here, so this pair stays unpinned by reference bytes).
+ * index_out == NULL: sizing call (*index_len, *hits_len). */
+int tri_merge_lucene(tri_dev *, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
+                     uint8_t *hits_out, size_t hits_cap, size_t *hits_len, tri_term *terms_out, tri_commit_stats *stats);
 
 /* tri_commit_google with the session's encoder being the Lucene-shaped codec's (commit is codec-agnostic: sess->new_encoder(), indexer.cpp:323): the same sort
  * and gather, then tri_encode_lucene's device encoder — `index` + `hits.data`; payload-less hits. */

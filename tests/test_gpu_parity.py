@@ -1556,6 +1556,89 @@ def test_merge_on_the_device(T, dev):
         s["ix"].close()
 
 
+def test_lucene_merge_on_the_device(T, dev):
+    """tri_merge_lucene — Codecs::Lucene::IndexSession::merge (lucene_codec.cpp:963-1396) over a whole dictionary: three Lucene-shaped segments (uploaded with
+    their hits.data) with overlapping dictionaries and documentIDs, each masked by its own set; per output term the union of the documents, a document from the
+    MOST RECENT participant that holds it, dropped when that participant's masked set holds it, positions carried over.  `index`, `hits.data` and the term table
+    equal the host encoder's over the postings the restated walk keeps (the walk tests/golden/ref_merge.json pins for the Google codec), lists across the
+    128-document block cadence and the 128-hit block cadence included; the merged segment reads back through upload and decode."""
+    from trinity_amd import hostplan as HP
+
+    rng = np.random.default_rng(29)
+    G, D, nparts = 200, 9000, 3
+    segs = []
+    for p in range(nparts):
+        held = np.sort(rng.choice(G, size=int(G * 0.7), replace=False))
+        docs, freqs, pos, tf = [], [], [], [0]
+        for g in held.tolist():
+            n = [1, 31, 127, 128, 129, 300, 700][g % 7] if g % 11 else 0  # (some terms hold no document in this segment)
+            d = np.sort(rng.choice(np.arange(1, D), size=n, replace=False))
+            f = rng.integers(0, 5, size=n)
+            for k in f.tolist():
+                pos += np.sort(rng.choice(np.arange(1, 3000), size=k, replace=False)).tolist()
+            docs += d.tolist()
+            freqs += f.tolist()
+            tf.append(len(docs))
+        a = dict(held=held, docs=np.array(docs, np.uint32), freqs=np.array(freqs, np.uint32), pos=np.array(pos, np.uint16), tf=np.array(tf, np.uint64),
+                 masked=np.sort(rng.choice(np.arange(1, D), size=D // 6, replace=False)).astype(np.uint32))  # fmt: skip
+        a["hit0"] = np.concatenate([[0], np.cumsum(a["freqs"].astype(np.int64))])
+        index, hits, terms = HP.lucene_encode(a["docs"], a["freqs"], a["pos"], a["tf"])
+        a["ix"] = T.Index(dev, index, terms, D, codec=2, hits=hits)
+        a["ix"].set_masked(a["masked"])
+        segs.append(a)
+    out_terms = [g for g in range(G) if any(g in s["held"] for s in segs)]
+    part_terms = np.full((len(out_terms), nparts), 0xFFFFFFFF, dtype=np.uint32)
+    for t, g in enumerate(out_terms):
+        for p, s in enumerate(segs):
+            k = np.searchsorted(s["held"], g)
+            if k < len(s["held"]) and s["held"][k] == g:
+                part_terms[t, p] = k
+    gi, gh, gterms, stats = dev.merge_lucene([s["ix"] for s in segs], part_terms)
+    docs, freqs, pos, tf = [], [], [], [0]
+    for t, g in enumerate(out_terms):
+        best = {}
+        for p, s in enumerate(segs):
+            k = int(part_terms[t, p])
+            if k == 0xFFFFFFFF:
+                continue
+            for i in range(int(s["tf"][k]), int(s["tf"][k + 1])):
+                best.setdefault(int(s["docs"][i]), (p, i))
+        for dd in sorted(best):
+            p, i = best[dd]
+            s = segs[p]
+            km = int(np.searchsorted(s["masked"], dd))
+            if km < len(s["masked"]) and s["masked"][km] == dd:
+                continue
+            h0, h1 = int(s["hit0"][i]), int(s["hit0"][i + 1])
+            docs.append(dd)
+            freqs.append(int(s["freqs"][i]))
+            pos += s["pos"][h0:h1].tolist()
+        tf.append(len(docs))
+    wi, wh, wterms = HP.lucene_encode(np.array(docs, np.uint32), np.array(freqs, np.uint32), np.array(pos, np.uint16), np.array(tf, np.uint64))
+    assert np.array_equal(gterms, wterms)
+    assert gi.size == wi.size and np.array_equal(gi, wi), ("index", int(np.argmax(gi[: wi.size] != wi[: gi.size])))
+    assert gh.size == wh.size and np.array_equal(gh, wh), ("hits.data", int(np.argmax(gh[: wh.size] != wh[: gh.size])))
+    assert int((gterms[:, 0] == 0).sum()) > 0  # (terms that keep nothing are there, empty)
+    assert stats["sum_terms_docs"] == len(docs) and stats["sum_term_hits"] == int(np.sum(freqs)) and stats["total_terms"] == int((wterms[:, 0] > 0).sum())
+    ix = T.Index(dev, gi, gterms, D, codec=2, hits=gh)
+    d2, f2, offs = ix.decode_terms(np.arange(len(out_terms), dtype=np.uint32), gterms[:, 0].astype(np.int64))
+    assert np.array_equal(d2, np.array(docs, np.uint32)) and np.array_equal(f2, np.array(freqs, np.uint32))
+    # ... and a phrase over the merged segment's positions equals the same phrase evaluated per winning posting (the hits came through in order)
+    ix.close()
+    # one participant, nothing masked: the postings come through unchanged
+    s0 = segs[0]
+    s0["ix"].set_masked(np.zeros(0, np.uint32))
+    only = np.arange(len(s0["held"]), dtype=np.uint32).reshape(-1, 1)
+    i1, h1_, t1, _ = dev.merge_lucene([s0["ix"]], only)
+    wi1, wh1, wt1 = HP.lucene_encode(s0["docs"], s0["freqs"], s0["pos"], s0["tf"])
+    assert np.array_equal(i1, wi1) and np.array_equal(h1_, wh1) and np.array_equal(t1, wt1)
+    # a Google-coded participant, or one uploaded without its hits.data, is refused
+    with pytest.raises(T.TrinityError):
+        dev.merge_lucene([T.Index(dev, wi1, wt1, D, codec=2)], only)
+    for s in segs:
+        s["ix"].close()
+
+
 def test_lucene_encoder_on_the_device(T, dev):
     """tri_encode_lucene — Codecs::Lucene::Encoder (lucene_codec.cpp:163-388) with the PFOR128 payload, one unit of csrc/lucene_enc_units.hpp per lane:
     `index`, `hits.data` and the term table equal the sequential host encoder's (lucene_encoder.hpp: the writer of every Lucene-shaped segment the engine

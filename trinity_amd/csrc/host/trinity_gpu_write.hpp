@@ -171,4 +171,25 @@ namespace trinity_amd {
                         out.terms.emplace_back(std::string(), term_index_ctx{tctx[t].documents, tctx[t].offset, tctx[t].size}); // (the caller names them: it walked the dictionaries)
                 return out;
         }
+        // ... and the Lucene-shaped codec's (lucene_codec.cpp:963-1396): the participants were uploaded with their hits.data; `index` and `hits` (hits.data) come back
+        inline committed_segment merge_lucene(tri_dev *dev, const std::vector<tri_index *> &participants, const std::vector<std::vector<uint32_t>> &termOf) {
+                committed_segment out;
+                const size_t np = participants.size(), nt = termOf.size();
+                std::vector<uint32_t> flat(nt * np, no_term);
+                for (size_t t = 0; t < nt; ++t) {
+                        if (termOf[t].size() != np)
+                                throw invalid_argument("merge_lucene: one entry per participant and output term");
+                        std::copy(termOf[t].begin(), termOf[t].end(), flat.begin() + t * np);
+                }
+                size_t indexLen = 0, hitsLen = 0;
+                std::vector<tri_term> tctx(nt);
+                check(tri_merge_lucene(dev, participants.data(), np, flat.data(), nt, nullptr, 0, &indexLen, nullptr, 0, &hitsLen, tctx.data(), &out.stats));
+                out.index.resize(indexLen);
+                out.hits.resize(hitsLen);
+                check(tri_merge_lucene(dev, participants.data(), np, flat.data(), nt, out.index.data(), out.index.size(), &indexLen, out.hits.data(), out.hits.size(), &hitsLen, tctx.data(),
+                                       &out.stats));
+                for (size_t t = 0; t < nt; ++t)
+                        out.terms.emplace_back(std::string(), term_index_ctx{tctx[t].documents, tctx[t].offset, tctx[t].size});
+                return out;
+        }
 } // namespace trinity_amd

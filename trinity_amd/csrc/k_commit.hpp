@@ -167,6 +167,41 @@ __global__ __launch_bounds__(256) void k_merge_hits(const uint8_t *__restrict__ 
                 }
         }
 }
+// ... LUCENE: a term's positions are ONE stream in hits.data, found by count (blk_hits[]: the hits before the row; hdir[]: the 128-hit blocks' offsets — k_phrase.hpp);
+// this engine's Lucene-shaped segments carry no payloads (lucene_encoder.hpp), so length and word are zero
+__global__ __launch_bounds__(256) void k_merge_hits_lucene(const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits, const uint32_t *__restrict__ hdir,
+                                                           const DevTerm *__restrict__ terms, const MergeJob *__restrict__ jobs, const uint32_t njobs, const uint32_t *__restrict__ freqs,
+                                                           const uint64_t *__restrict__ hit_off, uint16_t *__restrict__ pos_out, uint8_t *__restrict__ plens_out,
+                                                           uint64_t *__restrict__ payloads_out) {
+        const HitCtx ctx{hits, blk_hits, hdir};
+        for (uint32_t ji = blockIdx.x; ji < njobs; ji += gridDim.x) {
+                const MergeJob job = jobs[ji];
+                const DevTerm t = terms[job.term];
+                for (uint32_t b = threadIdx.x; b < t.nblocks; b += blockDim.x) {
+                        const uint32_t gb = t.first_block + b;
+                        const uint32_t n = (t.flags & TERM_FULL_BLOCKS) ? (b + 1 == t.nblocks ? t.last_n : 32u) : 0u; // (merge_device takes full-block lists only)
+                        const uint64_t at = job.out_off + (uint64_t)b * 32;
+                        uint32_t total = 0;
+                        for (uint32_t i = 0; i < n; ++i)
+                                total += freqs[at + i];
+                        if (!total)
+                                continue;
+                        HitStream<CODEC_LUCENE> s;
+                        s.init(ctx, t.pad, blk_hits[gb]);
+                        for (uint32_t i = 0; i < n; ++i) {
+                                const uint32_t f = freqs[at + i];
+                                uint64_t dst = hit_off[at + i];
+                                uint32_t pos = 0; // (the position restarts with every document)
+                                for (uint32_t h = 0; h < f; ++h, ++dst) {
+                                        pos += s.next();
+                                        pos_out[dst] = (uint16_t)pos;
+                                        plens_out[dst] = 0;
+                                        payloads_out[dst] = 0;
+                                }
+                        }
+                }
+        }
+}
 // sorted posting j: the first of a run of equal (term, document) keys — the most recent participant's — wins; kept unless its participant masks the document
 __global__ void k_merge_select(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ perm, const uint64_t *__restrict__ part_first /* [nparts + 1] */,
                                const uint32_t nparts, const uint32_t *const *__restrict__ masked /* [nparts]: bitmap or null */, uint32_t *__restrict__ keep, const uint64_t n) {

@@ -2635,16 +2635,22 @@ extern "C" int tri_commit_lucene(tri_dev *dev, const uint32_t *term_ids, const u
 }
 
 // ---- Codecs::Google::IndexSession::merge (google_codec.cpp:186-438) for a whole dictionary, on the device (k_commit.hpp)
-extern "C" int tri_merge_google(tri_dev *dev, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
-                                tri_term *terms_out, tri_commit_stats *stats) {
+// The codecs' merge for a whole dictionary (Codecs::Google::IndexSession::merge, google_codec.cpp:186-438; Codecs::Lucene::IndexSession::merge, lucene_codec.cpp:963-1396 — the
+// same k-way walk over the participants' postings, most recent first, the winner kept unless its participant masks it; the codecs differ in how postings and hits are stored,
+// i.e. in the decode and the encode at the two ends of the sort below)
+static int merge_device(tri_dev *dev, const int codec, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
+                        uint8_t *hits_out, size_t hits_cap, size_t *hits_len, tri_term *terms_out, tri_commit_stats *stats) {
         if (!dev || !parts || !nparts || (nterms && (!part_terms || !terms_out)) || !index_len)
                 return fail(TRI_ERR_INVALID, "tri_merge_google: null argument");
         if (nparts > 65535)
                 return fail(TRI_ERR_INVALID, "tri_merge_google: at most 65535 participants (google_codec.cpp:186: uint16_t participantsCnt)");
         HIP_TRY(hipSetDevice(dev->device));
-        for (size_t p = 0; p < nparts; ++p)
-                if (!parts[p] || parts[p]->dev != dev || parts[p]->codec != TRI_CODEC_GOOGLE)
-                        return fail(TRI_ERR_INVALID, "tri_merge_google: participant %zu is not a google_codec index of this device", p);
+        for (size_t p = 0; p < nparts; ++p) {
+                if (!parts[p] || parts[p]->dev != dev || parts[p]->codec != codec)
+                        return fail(TRI_ERR_INVALID, "tri_merge_%s: participant %zu is not a %s index of this device", codec == TRI_CODEC_GOOGLE ? "google" : "lucene", p, codec == TRI_CODEC_GOOGLE ? "google_codec" : "lucene_codec");
+                if (codec == TRI_CODEC_LUCENE && !parts[p]->d_hits && parts[p]->info.postings)
+                        return fail(TRI_ERR_INVALID, "tri_merge_lucene: participant %zu was uploaded without its hits.data (the merged segment needs every hit)", p);
+        }
         // ---- the jobs: every (participant, output term) that holds postings, participant-major — the most recent participant's postings first, so that
         //      a stable sort leaves them first among equal (term, document) keys
         std::vector<std::vector<MergeJob>> jobs(nparts);
@@ -2707,8 +2713,8 @@ extern "C" int tri_merge_google(tri_dev *dev, tri_index *const *parts, size_t np
                         HIP_TRY(tmp.get((void **)&d_jobs[p], jobs[p].size() * sizeof(MergeJob)));
                         HIP_TRY(hipMemcpyAsync(d_jobs[p], jobs[p].data(), jobs[p].size() * sizeof(MergeJob), hipMemcpyHostToDevice, dev->stream));
                         const tri_index *ix = parts[p];
-                        hipLaunchKernelGGL((k_merge_decode<CODEC_GOOGLE>), dim3((uint32_t)std::min<size_t>(jobs[p].size(), (size_t)dev->cus * 16)), dim3(256), 0, dev->stream, ix->d_index,
-                                           ix->d_blk_last, ix->d_blk_off, ix->d_terms, (const MergeJob *)d_jobs[p], (uint32_t)jobs[p].size(), d_freqs_all, d_keys, d_vals);
+                        TRI_LAUNCH(k_merge_decode, codec, dim3((uint32_t)std::min<size_t>(jobs[p].size(), (size_t)dev->cus * 16)), dim3(256), dev->stream, ix->d_index,
+                                   ix->d_blk_last, ix->d_blk_off, ix->d_terms, (const MergeJob *)d_jobs[p], (uint32_t)jobs[p].size(), d_freqs_all, d_keys, d_vals);
                 }
                 HIP_TRY(hipGetLastError());
                 int rcs;
@@ -2727,9 +2733,14 @@ extern "C" int tri_merge_google(tri_dev *dev, tri_index *const *parts, size_t np
                         if (jobs[p].empty())
                                 continue;
                         const tri_index *ix = parts[p];
-                        hipLaunchKernelGGL(k_merge_hits, dim3((uint32_t)std::min<size_t>(jobs[p].size(), (size_t)dev->cus * 16)), dim3(256), 0, dev->stream, ix->d_index, ix->d_blk_off,
-                                           ix->d_blk_hits, ix->d_terms, (const MergeJob *)d_jobs[p], (uint32_t)jobs[p].size(), (const uint32_t *)d_freqs_all, (const uint64_t *)d_hit_off_all,
-                                           d_pos_all, d_plens_all, d_payloads_all);
+                        if (codec == TRI_CODEC_LUCENE)
+                                hipLaunchKernelGGL(k_merge_hits_lucene, dim3((uint32_t)std::min<size_t>(jobs[p].size(), (size_t)dev->cus * 16)), dim3(256), 0, dev->stream, ix->d_hits,
+                                                   ix->d_blk_hits, ix->d_hdir, ix->d_terms, (const MergeJob *)d_jobs[p], (uint32_t)jobs[p].size(), (const uint32_t *)d_freqs_all,
+                                                   (const uint64_t *)d_hit_off_all, d_pos_all, d_plens_all, d_payloads_all);
+                        else
+                                hipLaunchKernelGGL(k_merge_hits, dim3((uint32_t)std::min<size_t>(jobs[p].size(), (size_t)dev->cus * 16)), dim3(256), 0, dev->stream, ix->d_index, ix->d_blk_off,
+                                                   ix->d_blk_hits, ix->d_terms, (const MergeJob *)d_jobs[p], (uint32_t)jobs[p].size(), (const uint32_t *)d_freqs_all, (const uint64_t *)d_hit_off_all,
+                                                   d_pos_all, d_plens_all, d_payloads_all);
                 }
                 HIP_TRY(hipGetLastError());
                 // ---- sort by (output term, document); the first of equal keys is the most recent participant's
@@ -2766,7 +2777,10 @@ extern "C" int tri_merge_google(tri_dev *dev, tri_index *const *parts, size_t np
                                            (const uint64_t *)d_payloads_all, d.payloads, kept);
                 HIP_TRY(hipGetLastError());
         }
-        if (int rc = encode_google_device(dev, d, term_first.data(), nterms, kept, nh_out, index_out, cap, index_len, terms_out))
+        if (codec == TRI_CODEC_LUCENE) {
+                if (int rc = encode_lucene_device(dev, d.docs, d.freqs, d.pos, kept, nh_out, term_first.data(), nterms, index_out, cap, index_len, hits_out, hits_cap, hits_len, terms_out))
+                        return rc;
+        } else if (int rc = encode_google_device(dev, d, term_first.data(), nterms, kept, nh_out, index_out, cap, index_len, terms_out))
                 return rc;
         if (stats) {
                 stats->sum_terms_docs = kept;
@@ -2775,6 +2789,17 @@ extern "C" int tri_merge_google(tri_dev *dev, tri_index *const *parts, size_t np
                         stats->total_terms += term_first[t + 1] > term_first[t]; // (merge.cpp:241: a term that keeps no document is dropped from the dictionary)
         }
         return TRI_OK;
+}
+extern "C" int tri_merge_google(tri_dev *dev, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
+                                tri_term *terms_out, tri_commit_stats *stats) {
+        return merge_device(dev, TRI_CODEC_GOOGLE, parts, nparts, part_terms, nterms, index_out, cap, index_len, nullptr, 0, nullptr, terms_out, stats);
+}
+extern "C" int tri_merge_lucene(tri_dev *dev, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
+                                uint8_t *hits_out, size_t hits_cap, size_t *hits_len, tri_term *terms_out, tri_commit_stats *stats) {
+        if (!hits_len)
+                return fail(TRI_ERR_INVALID, "tri_merge_lucene: null argument");
+        *hits_len = 0;
+        return merge_device(dev, TRI_CODEC_LUCENE, parts, nparts, part_terms, nterms, index_out, cap, index_len, hits_out, hits_cap, hits_len, terms_out, stats);
 }
 
 #ifdef TRI_PROF

@@ -107,7 +107,7 @@ ABI_SYMBOLS = [
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_docset_bitmap", "tri_batch_docsets", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
-    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google", "tri_commit_lucene", "tri_merge_google", "tri_encode_lucene",
+    "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google", "tri_commit_lucene", "tri_merge_google", "tri_merge_lucene", "tri_encode_lucene",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
 
@@ -391,6 +391,23 @@ class Device:
         out = np.zeros(max(1, ln.value), dtype=np.uint8)
         _check(call(out.ctypes.data, out.size))
         return out[: ln.value], terms[: pt.shape[0]], dict(zip(("docs_cnt", "sum_terms_docs", "sum_term_hits", "total_terms"), (int(x) for x in stats)))
+
+    def merge_lucene(self, parts, part_terms):
+        """Codecs::Lucene::IndexSession::merge for a whole dictionary (tri_merge_lucene): parts = lucene_codec Index objects uploaded with their hits.data, most recent
+        first -> (index bytes, hits.data bytes, term table u32[nterms, 3], stats)."""
+        pt = np.ascontiguousarray(part_terms, dtype=np.uint32).reshape(-1, len(parts))
+        hs = (C.c_void_p * len(parts))(*[p.h for p in parts])
+        terms = np.zeros((max(1, pt.shape[0]), 3), dtype=np.uint32)
+        ln, hl = C.c_size_t(), C.c_size_t()
+        stats = np.zeros(4, dtype=np.uint64)
+        L = hip_lib()
+        L.tri_merge_lucene.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t),
+                                       C.c_void_p, C.c_void_p]  # fmt: skip
+        call = lambda out, cap, hout, hcap: L.tri_merge_lucene(self.h, hs, len(parts), pt.ctypes.data, pt.shape[0], out, cap, C.byref(ln), hout, hcap, C.byref(hl), terms.ctypes.data, stats.ctypes.data)
+        _check(call(None, 0, None, 0))
+        out, hout = np.zeros(max(1, ln.value), dtype=np.uint8), np.zeros(max(1, hl.value), dtype=np.uint8)
+        _check(call(out.ctypes.data, out.size, hout.ctypes.data, hout.size))
+        return out[: ln.value], hout[: hl.value], terms[: pt.shape[0]], dict(zip(("docs_cnt", "sum_terms_docs", "sum_term_hits", "total_terms"), (int(x) for x in stats)))
 
     def close(self):
         if self.h:
