@@ -131,6 +131,7 @@ struct PhraseShared {
         uint32_t row[MAX_PHRASE_TERMS]; // phrase position -> row (a term repeated in the phrase shares the row of its first occurrence)
         uint32_t rpad[MAX_PHRASE_TERMS]; // row -> its term's DevTerm::pad (LUCENE: the term's row in hdir[])
         DevTerm rterm[MAX_PHRASE_TERMS]; // row -> its term
+        uint32_t rrow[MAX_PHRASE_TERMS]; // row -> its term's plane row when the term is located by rank (PL_NONE: by walking its blocks)
         uint32_t rtk[MAX_PHRASE_TERMS], rbx[2 * MAX_PHRASE_TERMS]; // row -> its term id; the two ends of the tile's block range as the waves found them
         uint32_t rb0[MAX_PHRASE_TERMS], rnb[MAX_PHRASE_TERMS], rstart[MAX_PHRASE_TERMS]; // row -> first block of the tile's docID range, blocks walked (0: the scattered path), where its blocks start in the pass
         uint32_t scan[8];
@@ -308,6 +309,54 @@ __device__ __forceinline__ uint32_t phrase_first_block(const uint32_t *__restric
         }
 }
 
+// ---- the hits entries of a head term's postings (GOOGLE; lists of full blocks), once per index: phs[hs_off[row] + 32 b + slot] = what phrase_locate_block leaves
+//      for that document — the hits locator (byte offset into index[]) in the low word, the frequency entry (with FREQ_PLAIN where the document's hits are single bytes)
+//      in the high word.  With the row's rank directory (k_term_planes) a candidate's entry is TWO dependent loads away — its rank in plane 0, then the entry — where
+//      the block walk decodes a 63-byte block per 32 documents of the tile's range, a lane per block, most lanes idle.  One lane per block here, all blocks of the term.
+__global__ __launch_bounds__(256) void k_term_hits(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ blk_hits,
+                                                   const DevTerm *__restrict__ terms, const uint32_t *__restrict__ build /* (term, row) pairs */, const uint64_t *__restrict__ hs_off,
+                                                   unsigned long long *__restrict__ phs, uint32_t *__restrict__ term_row) {
+        const uint32_t term = build[2 * blockIdx.y], row = build[2 * blockIdx.y + 1];
+        const DevTerm t = terms[term];
+        const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+        if (b == 0)
+                term_row[term] = row; // (every later kernel of the stream sees the row: k_phrase takes the rank path for this term from now on)
+        if (b >= t.nblocks)
+                return;
+        unsigned long long *out = phs + hs_off[row] + 32ull * b;
+        const uint32_t gb = t.first_block + b;
+        const uint32_t off = blk_off[gb];
+        const uint32_t n = TRI_BLOCK_N(t, b, index, off);
+        VbStream s;
+        s.init(index + off);
+        for (uint32_t i = 0; i + 1 < n; ++i)
+                (void)s.next(); // (the deltas: the frequencies follow them)
+        const uint32_t hits_at = blk_hits[gb];
+        if (hits_at & BLK_HITS_PLAIN) { // one byte per hit: locators follow from the frequencies alone
+                uint32_t h = off + (hits_at & ~BLK_HITS_PLAIN);
+                for (uint32_t i = 0; i < n; ++i) {
+                        const uint32_t f = s.next();
+                        const uint32_t fe = (f & HitStream<CODEC_GOOGLE>::FREQ_MASK) == f ? (f | HitStream<CODEC_GOOGLE>::FREQ_PLAIN) : f;
+                        out[i] = (unsigned long long)h | ((unsigned long long)fe << 32);
+                        h += f;
+                }
+                return;
+        }
+        VbStream sh_;
+        sh_.init(index + off + hits_at); // hits start (from the directory)
+        for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t f = s.next();
+                out[i] = (unsigned long long)(uint32_t)(sh_.tell() - index) | ((unsigned long long)f << 32);
+                uint32_t plen = 0; // payload length state restarts with every document
+                for (uint32_t h = 0; h < f; ++h) {
+                        const uint32_t v = sh_.next();
+                        if (v & 1u)
+                                plen = sh_.byte();
+                        sh_.skip(plen);
+                }
+        }
+}
+
 template <int CODEC>
 __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phrase(const uint8_t *__restrict__ index, const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits,
                                                    const uint32_t *__restrict__ hdir, const uint32_t *__restrict__ blk_last,
@@ -316,11 +365,17 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                                    const uint32_t *__restrict__ ptasks, const uint32_t nptasks, const DevPhrase *__restrict__ phrases,
                                                    const uint32_t *__restrict__ pterms, uint32_t *__restrict__ ticket, uint32_t *__restrict__ out,
                                                    uint32_t *__restrict__ counts, double *__restrict__ pscore, const uint32_t max_match_cnt,
-                                                   const int sim) {
+                                                   const int sim, const uint32_t *__restrict__ planes, const uint32_t plw, const uint32_t *__restrict__ prank,
+                                                   const unsigned long long *__restrict__ phs, const uint64_t *__restrict__ hs_off, const uint32_t *__restrict__ term_row) {
         __shared__ PhraseShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
         const HitCtx ctx{CODEC == CODEC_GOOGLE ? index : hits, blk_hits, hdir};
+#ifdef TRI_PHRASE_NOLOCATE
+        for (uint32_t i = tid; i < PHRASE_SLOTS; i += AND_WG)
+                sh.hits_off[i] = 0, sh.freq[i] = 1u | 0x80000000u;
+        __syncthreads();
+#endif
         PROF_DECL;
         PROF_START();
         for (;;) {
@@ -401,18 +456,25 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                         const DevTerm t = terms[sh.rtk[tid]];
                                         sh.rterm[tid] = t;
                                         sh.rpad[tid] = t.pad;
+                                        sh.rrow[tid] = CODEC == CODEC_GOOGLE && term_row ? term_row[sh.rtk[tid]] : PL_NONE; // the term's plane row, once its rank directory and hits entries are there
                                 }
                                 __syncthreads();
                                 // the blocks of the tile's docID range: a WAVE per (row, end of the range) brackets it through the cell index (one round of 64
                                 // probes; a list too short for a cell index: two rounds) — the four waves search side by side (round 4: every wave searched
                                 // every row's two ends itself, one after the other)
                                 for (uint32_t it = wave; it < 2 * rows; it += AND_WG / 64) {
+                                        if (uni(sh.rrow[it >> 1]) != PL_NONE)
+                                                continue; // (located by rank below: no block range)
                                         const DevTerm t = sh.rterm[it >> 1];
                                         const uint32_t res = phrase_first_block(blk_last + t.first_block, win, t, (it & 1u) ? cmax : cmin);
                                         sh.rbx[it] = res; // (wave-uniform value, every lane stores it)
                                 }
                                 __syncthreads();
                                 for (uint32_t r = 0; r < rows; ++r) { // (uniform stores)
+                                        if (uni(sh.rrow[r]) != PL_NONE) {
+                                                sh.rb0[r] = 0xffffffffu, sh.rnb[r] = 0, sh.rstart[r] = total_blocks;
+                                                continue;
+                                        }
                                         const uint32_t nb = uni(sh.rterm[r].nblocks), b0 = uni(sh.rbx[2 * r]);
                                         const uint32_t b1 = b0 < nb ? min(uni(sh.rbx[2 * r + 1]), nb - 1) : b0;
                                         const bool walk = b0 < nb && b1 - b0 + 1 <= 2 * C; // (else: few candidates scattered over a long list, below)
@@ -422,6 +484,9 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                         total_blocks += walk ? b1 - b0 + 1 : 0u;
                                 }
                                 PROF_LAP(8);
+#ifdef TRI_PHRASE_NOLOCATE // (perf probe: what the kernel costs WITHOUT the block walks — wrong results)
+                                if (total_blocks > 0x7fffffffu)
+#endif
                                 for (uint32_t v = tid; v < total_blocks; v += AND_WG) {
                                         uint32_t r = 0;
                                         for (uint32_t r2 = 1; r2 < rows; ++r2)
@@ -432,6 +497,29 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                 }
                                 PROF_LAP(9);
                                 for (uint32_t r = 0; r < rows; ++r) {
+                                        const uint32_t prow = uni(sh.rrow[r]);
+                                        if (prow != PL_NONE) {
+                                                // a head term: every candidate's entry by RANK — its posting index is its group's directory entry plus the plane-0 bits of the
+                                                // group before it (one 32-byte piece of plane 0), and the posting's entry (k_term_hits) is what a block walk would have left
+                                                static_assert(PL_RANK_DOCS == 256, "a group is eight plane words: two 16-byte loads");
+                                                const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
+                                                const uint32_t *rd = prank + (size_t)prow * (plw / (PL_RANK_DOCS / 32u));
+                                                const unsigned long long *hs = phs + hs_off[prow];
+                                                for (uint32_t j = tid; j < C; j += AND_WG) {
+                                                        const uint32_t doc = sh.cdoc[j], g = doc / PL_RANK_DOCS, k = (doc >> 5) & 7u;
+                                                        const uint4 x0 = *(const uint4 *)(pa + 8u * g), x1 = *(const uint4 *)(pa + 8u * g + 4u);
+                                                        uint32_t rank = rd[g];
+                                                        const uint32_t w8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                                                        for (uint32_t i = 0; i < 8; ++i)
+                                                                rank += i < k ? (uint32_t)__popc(w8[i]) : i == k ? (uint32_t)__popc(w8[i] & ((1u << (doc & 31u)) - 1u)) : 0u;
+                                                        const unsigned long long e = hs[rank];
+                                                        sh.hits_off[r * tile + j] = (uint32_t)e;
+                                                        sh.freq[r * tile + j] = (uint32_t)(e >> 32);
+                                                }
+                                                PROF_LAP(10);
+                                                continue;
+                                        }
                                         if (sh.rnb[r] || sh.rb0[r] >= sh.rterm[r].nblocks) // (uniform)
                                                 continue;
                                         // few candidates scattered over a long list: every candidate brackets its block with the two cell-index

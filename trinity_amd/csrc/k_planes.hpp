@@ -25,12 +25,21 @@ constexpr uint32_t PL_STRIDE = PL_WORDS + 32;   // LDS words between a slot's pl
 // A decoded posting into the LDS planes (a[k * PL_STRIDE ...]: plane k).  Documents outside the window land in the sink word.
 struct PlanePost {
         uint32_t *a;
+        uint32_t *rd;  // the window's rank directory (LDS): per group of PL_RANK_DOCS documents the lowest posting index seen
+        uint32_t pidx; // the posting index of the row's next document (rows of a list of full blocks: 32 b + slot)
+        __device__ __forceinline__ void rank(const uint32_t rel) {
+                if (rel < PL_W)
+                        atomicMin(&rd[rel / PL_RANK_DOCS], pidx);
+                ++pidx;
+        }
         __device__ __forceinline__ void doc(const uint32_t rel) {
                 const uint32_t r = min(rel, PL_W);
+                rank(rel);
                 atomicOr(&a[r >> 5], 1u << (r & 31u));
         }
         __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t f) {
                 const uint32_t r = min(rel, PL_W);
+                rank(rel);
                 const uint32_t bit = 1u << (r & 31u), f16 = f & 0xffffu; // (the frequency a scorer sees is tokenpos_t, 16 bits: codecs.h:217)
                 const uint32_t level = f16 == 0u || f16 > PL_NESTED ? PL_NESTED : f16; // (a frequency the planes do not tell: every plane)
                 atomicOr(&a[r >> 5], bit);
@@ -49,11 +58,14 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                                                         const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
                                                         const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
                                                         const DevTerm *__restrict__ terms, const uint32_t *__restrict__ build /* (term, row) pairs */,
-                                                        uint32_t *__restrict__ planes, const uint32_t plw) {
+                                                        uint32_t *__restrict__ planes, const uint32_t plw, uint32_t *__restrict__ prank /* rank directories, or null */) {
         __shared__ uint32_t pl[PL_NESTED * PL_STRIDE];
+        __shared__ uint32_t rdir[PL_W / PL_RANK_DOCS];
         const uint32_t tid = threadIdx.x, w = blockIdx.x, row = build[2 * blockIdx.y + 1];
         for (uint32_t i = tid; i < PL_NESTED * PL_STRIDE; i += AND_WG)
                 pl[i] = 0;
+        for (uint32_t i = tid; i < PL_W / PL_RANK_DOCS; i += AND_WG)
+                rdir[i] = 0xffffffffu;
         const DevTerm t = terms[build[2 * blockIdx.y]];
         const uint32_t *bl = blk_last + t.first_block;
         const uint32_t w0 = w * PL_W;
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
         if (b_lo < t.nblocks)
                 for (uint32_t b = b_lo + tid; b <= b_hi; b += AND_WG) {
                         const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
-                        PlanePost post{pl};
+                        PlanePost post{pl, rdir, 32u * b};
 #ifdef TRI_PROF
                         ProfClock prof_;
 #endif
@@ -104,6 +116,9 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                 }
         __syncthreads();
         uint32_t *pa = planes + (size_t)row * PL_PLANES * plw + (size_t)w * PL_WORDS;
+        if (prank) // (rank of a document = its group's entry + the plane-0 bits of the group before it: k_phrase.hpp)
+                for (uint32_t i = tid; i < PL_W / PL_RANK_DOCS; i += AND_WG)
+                        prank[(size_t)row * (plw / (PL_RANK_DOCS / 32u)) + (size_t)w * (PL_W / PL_RANK_DOCS) + i] = rdir[i];
         static_assert(PL_NESTED == 6 && PL_LEVEL_WORDS == 3, "the level's bits below are written for six nested planes");
         uint32_t *lv = planes + (size_t)row * PL_PLANES * plw + (size_t)PL_STORED * plw + 3u * (size_t)w * PL_WORDS; // the window's interleaved level words
         for (uint32_t i = tid; i < PL_WORDS; i += AND_WG) {

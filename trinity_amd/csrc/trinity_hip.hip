@@ -275,6 +275,17 @@ struct tri_index : HostIndex {
         uint32_t *d_pcache = nullptr;
         uint32_t pc_cap = 0, pc_plw = 0;
         std::vector<uint8_t> pc_built;
+        // ... and what k_phrase needs to find a head term's hits WITHOUT walking its blocks (round 5): per row a RANK DIRECTORY over plane 0 — d_prank[row * (plw / 8) + g]
+        // = the posting index of the first document of docID group g (256 documents), filled by k_term_planes —, and per posting the hits locator and frequency entry
+        // phrase_locate_block would compute (d_phs[hs_off[row] + posting]; k_term_hits; GOOGLE, lists of full blocks).  d_term_row[term] = its row once both are there
+        uint32_t *d_prank = nullptr, *d_term_row = nullptr;
+        unsigned long long *d_phs = nullptr;
+        uint64_t *d_hs_off = nullptr;
+        uint32_t *d_ph_pairs = nullptr;   // (term, row) pairs of the rows whose hits entries were built, appended run after run (a row is built once: 2 * pc_cap words)
+        size_t ph_pairs_n = 0;
+        std::vector<uint64_t> hs_off;     // [pc_cap + 1]: prefix sums of the rows' document counts (row = df rank)
+        std::vector<uint8_t> ph_built;    // [pc_cap]: the row's hits entries have been enqueued
+        std::vector<uint32_t> rank_term;  // [pc_cap]: the term of df rank r
         hipEvent_t ev_pc_ready = nullptr;                       // the last growth's move of the rows (upload stream): every run waits for it
         std::vector<std::pair<void *, hipEvent_t>> pc_retired; // outgrown row buffers and the engine-stream point their last readers precede
         ~tri_index() { // also runs when tri_index_upload fails half-way
@@ -293,6 +304,11 @@ struct tri_index : HostIndex {
                 hipFree(d_win);
                 hipFree(d_terms);
                 pool_free(dev, d_pcache); // (pooled: tri_batch_create grows it without a device-wide synchronisation)
+                pool_free(dev, d_prank);
+                pool_free(dev, d_phs);
+                pool_free(dev, d_hs_off);
+                pool_free(dev, d_ph_pairs);
+                hipFree(d_term_row);
                 for (auto &r : pc_retired) {
                         pool_free(dev, r.first);
                         hipEventDestroy(r.second);
@@ -832,6 +848,52 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         else
                                 ix->pc_built.clear();
                         HIP_TRY(hipMemsetAsync((uint8_t *)fresh + (size_t)want * row, 0, row + 64, dev->stream_up));
+                        {
+                                // the rank directories and hits entries of the rows (k_phrase's rank path): sized for every row the cache can hold, moved like the rows
+                                const bool same = ix->d_pcache && b->plw == ix->pc_plw;
+                                std::vector<uint64_t> hs(want + 1, 0);
+                                std::vector<uint32_t> rt(want, 0xffffffffu);
+                                for (size_t t = 0; t < ix->terms.size(); ++t)
+                                        if (ix->df_rank[t] < want)
+                                                rt[ix->df_rank[t]] = (uint32_t)t;
+                                for (uint32_t r = 0; r < want; ++r)
+                                        hs[r + 1] = hs[r] + (rt[r] != 0xffffffffu ? ix->terms[rt[r]].documents : 0u);
+                                uint32_t *prank = nullptr;
+                                unsigned long long *phs = nullptr;
+                                uint64_t *hso = nullptr;
+                                uint32_t *pairs = nullptr;
+                                const size_t groups = b->plw / 8;
+                                HIP_TRY(pool_alloc(dev, (void **)&pairs, (size_t)want * 8 + POOL_MIN_BYTES));
+                                HIP_TRY(pool_alloc(dev, (void **)&prank, (size_t)want * groups * 4 + 64));
+                                HIP_TRY(pool_alloc(dev, (void **)&phs, (hs[want] + 8) * 8));
+                                HIP_TRY(pool_alloc(dev, (void **)&hso, ((size_t)want + 1) * 8 + POOL_MIN_BYTES));
+                                if (same && ix->d_prank) {
+                                        HIP_TRY(hipMemcpyAsync(pairs, ix->d_ph_pairs, ix->ph_pairs_n * 8, hipMemcpyDeviceToDevice, dev->stream_up));
+                                        HIP_TRY(hipMemcpyAsync(prank, ix->d_prank, (size_t)ix->pc_cap * groups * 4, hipMemcpyDeviceToDevice, dev->stream_up));
+                                        HIP_TRY(hipMemcpyAsync(phs, ix->d_phs, ix->hs_off[ix->pc_cap] * 8, hipMemcpyDeviceToDevice, dev->stream_up));
+                                } else {
+                                        ix->ph_built.clear();
+                                        ix->ph_pairs_n = 0;
+                                }
+                                ix->hs_off = hs; // (a row's offset depends on the rows before it alone: what was built stays where it was)
+                                HIP_TRY(hipMemcpyAsync(hso, ix->hs_off.data(), ((size_t)want + 1) * 8, hipMemcpyHostToDevice, dev->stream_up)); // (hs_off outlives the copy: a member)
+                                if (!ix->d_term_row) {
+                                        HIP_TRY(hipMalloc((void **)&ix->d_term_row, (ix->terms.size() + 1) * 4));
+                                        HIP_TRY(hipMemsetAsync(ix->d_term_row, 0xff, (ix->terms.size() + 1) * 4, dev->stream_up));
+                                } else if (!same)
+                                        HIP_TRY(hipMemsetAsync(ix->d_term_row, 0xff, (ix->terms.size() + 1) * 4, dev->stream_up));
+                                if (ix->d_prank) { // (retired with the rows: same readers)
+                                        for (void *old : {(void *)ix->d_prank, (void *)ix->d_phs, (void *)ix->d_hs_off, (void *)ix->d_ph_pairs}) {
+                                                hipEvent_t e2 = nullptr;
+                                                HIP_TRY(event_get(dev, &e2));
+                                                HIP_TRY(hipEventRecord(e2, dev->stream));
+                                                ix->pc_retired.emplace_back(old, e2);
+                                        }
+                                }
+                                ix->d_prank = prank, ix->d_phs = phs, ix->d_hs_off = hso, ix->d_ph_pairs = pairs;
+                                ix->rank_term = rt;
+                                ix->ph_built.resize(want, 0);
+                        }
                         HIP_TRY(hipEventRecord(ix->ev_pc_ready, dev->stream_up));
                         if (ix->d_pcache)
                                 ix->pc_retired.emplace_back(ix->d_pcache, drained);
@@ -984,7 +1046,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                 HIP_TRY(hipMemcpyAsync(b->d_build, build.data(), build.size() * 4, hipMemcpyHostToDevice, dev->stream)); // (pageable source: staged before the call returns)
                                 const dim3 grid(b->plw / PL_WORDS, (uint32_t)(build.size() / 2));
                                 TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff, ix->d_win,
-                                           ix->d_terms, (const uint32_t *)b->d_build, ix->d_pcache, b->plw);
+                                           ix->d_terms, (const uint32_t *)b->d_build, ix->d_pcache, b->plw, ix->d_prank);
                                 HIP_TRY(hipGetLastError());
                                 for (size_t i = 1; i < build.size(); i += 2)
                                         ix->pc_built[build[i]] = 1;
@@ -1093,6 +1155,49 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_k, dev->stream));
+                if (!b->ptasks.empty() && b->ix->codec == TRI_CODEC_GOOGLE && b->ix->d_prank && b->ix->pc_cap) {
+                        // the phrases' head terms are located by RANK in plane 0 (k_phrase.hpp): rows (plane 0 + rank directory) and per-posting hits entries of the
+                        // phrase terms that have none yet are built now — once for the index
+                        tri_index *ix = b->ix;
+                        std::vector<uint32_t> rows_build, hits_build;
+                        uint32_t max_blocks = 0;
+                        for (size_t i = 0; i < b->pterms.size(); ++i) {
+                                const uint32_t term = b->pterms[i], r = ix->df_rank[term];
+                                if (r >= ix->pc_cap || ix->ph_built[r])
+                                        continue;
+                                const DevTerm &t = ix->terms[term];
+                                if (!(t.flags & TERM_FULL_BLOCKS) || !t.documents)
+                                        continue;
+                                ix->ph_built[r] = 1;
+                                hits_build.push_back(term);
+                                hits_build.push_back(r);
+                                max_blocks = std::max(max_blocks, t.nblocks);
+                                if (!ix->pc_built[r]) {
+                                        ix->pc_built[r] = 1;
+                                        rows_build.push_back(term);
+                                        rows_build.push_back(r);
+                                }
+                        }
+                        if (!hits_build.empty()) {
+                                uint32_t *d_pairs = ix->d_ph_pairs + 2 * ix->ph_pairs_n; // (every row is built once: the pairs of all runs fit 2 * pc_cap words; rows first, their subset second)
+                                HIP_TRY(hipMemcpyAsync(d_pairs, hits_build.data(), hits_build.size() * 4, hipMemcpyHostToDevice, dev->stream)); // (pageable source: staged before the call returns)
+                                ix->ph_pairs_n += hits_build.size() / 2;
+                                if (!rows_build.empty()) {
+                                        // (the rows that no plane user has built yet: the same pairs buffer cannot hold a second list — a scratch of the batch's arena does: d_build is
+                                        //  sized for the batch's plane terms, so these go one k_term_planes launch per row, from the pairs just written)
+                                        for (size_t i = 0; i < hits_build.size(); i += 2)
+                                                if (std::find(rows_build.begin(), rows_build.end(), hits_build[i]) != rows_build.end()) {
+                                                        const dim3 grid(b->plw / PL_WORDS, 1);
+                                                        TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff,
+                                                                   ix->d_win, ix->d_terms, (const uint32_t *)d_pairs + i, ix->d_pcache, b->plw, ix->d_prank);
+                                                }
+                                }
+                                const uint32_t npairs = (uint32_t)(hits_build.size() / 2);
+                                hipLaunchKernelGGL(k_term_hits, dim3((max_blocks + 255) / 256, npairs), dim3(256), 0, dev->stream, ix->d_index, ix->d_blk_off, ix->d_blk_hits, ix->d_terms,
+                                                   (const uint32_t *)d_pairs, (const uint64_t *)ix->d_hs_off, ix->d_phs, ix->d_term_row);
+                                HIP_TRY(hipGetLastError());
+                        }
+                }
                 if (!b->ptasks.empty()) {
                         // positional constraints: filter + compact the match segments of the queries that hold phrases
                         const uint32_t np = (uint32_t)b->ptasks.size();
@@ -1100,7 +1205,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                            b->ix->d_hits, b->ix->d_blk_hits, b->ix->d_hdir, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_ptasks, np, b->d_phrases, b->d_pterms,
                                            b->d_ticket + 48, b->d_out, b->d_counts, b->d_pscore,
                                            (b->flags & TRI_FLAG_ACCUMULATED_SCORE) ? 65535u : 1u, // exec.cpp:296 trackCnt
-                                           b->similarity);
+                                           b->similarity, (const uint32_t *)b->ix->d_pcache, b->ix->pc_plw, (const uint32_t *)b->ix->d_prank, (const unsigned long long *)b->ix->d_phs,
+                                           (const uint64_t *)b->ix->d_hs_off, (const uint32_t *)(b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_term_row : nullptr));
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_p, dev->stream));
@@ -1115,7 +1221,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         for (uint32_t y0 = 0; y0 < nterms; y0 += 65535u) { // (gridDim.y <= 65535)
                                 const dim3 grid(plw / PL_WORDS, std::min(65535u, nterms - y0));
                                 TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff, ix->d_win,
-                                           ix->d_terms, (const uint32_t *)b->d_tree_build + 2 * (size_t)y0, b->d_tree_rows, plw);
+                                           ix->d_terms, (const uint32_t *)b->d_tree_build + 2 * (size_t)y0, b->d_tree_rows, plw, (uint32_t *)nullptr);
                                 HIP_TRY(hipGetLastError());
                         }
                         if (nhid) {
