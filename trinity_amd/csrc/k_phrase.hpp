@@ -408,7 +408,7 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                         maxrows = max(maxrows, rows);
                 }
                 const uint32_t tile = uni(min(PHRASE_TILE, max(64u, (PHRASE_SLOTS / maxrows) & ~63u)));
-                uint32_t wpos = 0;
+                uint32_t wpos = 0, task_rows = 0; // task_rows: the rows of the query's one phrase, once they are set up (0: set them up)
                 // the NEXT tile's candidates travel while this one is worked on (the compaction below writes behind the read cursor: it never reaches them)
                 constexpr uint32_t PER = PHRASE_TILE / AND_WG;
                 uint32_t nx[PER];
@@ -436,7 +436,8 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                 //      first — term, the blocks of the tile's docID range —, then ONE pass walks the blocks of ALL the rows, a lane per block
                                 //      (round 4 walked row after row with a barrier in between: a two-word phrase of head terms kept 50 and then 30 of the 256
                                 //      lanes busy for one block's walk each, twice)
-                                uint32_t rows = 0, total_blocks = 0;
+                                uint32_t rows = task_rows, total_blocks = 0;
+                                if (!rows) { // (a query with ONE phrase sets its rows up once per task, not once per tile: a round trip and a barrier less per tile)
                                 for (uint32_t k = 0; k < ph.nterms; ++k) { // the rows: a term repeated in the phrase shares the row of its first occurrence (uniform stores)
                                         const uint32_t tk = pterms[ph.term_base + k];
                                         uint32_t first = k;
@@ -459,6 +460,9 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                         sh.rrow[tid] = CODEC == CODEC_GOOGLE && term_row ? term_row[sh.rtk[tid]] : PL_NONE; // the term's plane row, once its rank directory and hits entries are there
                                 }
                                 __syncthreads();
+                                if (q.nphrases == 1)
+                                        task_rows = rows;
+                                }
                                 // the blocks of the tile's docID range: a WAVE per (row, end of the range) brackets it through the cell index (one round of 64
                                 // probes; a list too short for a cell index: two rounds) — the four waves search side by side (round 4: every wave searched
                                 // every row's two ends itself, one after the other)
@@ -496,8 +500,15 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                         phrase_locate_block<CODEC>(sh, index, blk_last, blk_off, ctx, sh.rterm[r], sh.rb0[r] + (v - sh.rstart[r]), C, r * tile);
                                 }
                                 PROF_LAP(9);
+                                // every row a head term located by rank (the usual shape of an expensive phrase): the lookups move into the check below — a candidate's
+                                // lane fetches the rows' directory entries and plane words TOGETHER, then the rows' entries together, with no barrier in between
+                                bool all_rank = CODEC == CODEC_GOOGLE && rows <= 4;
+                                for (uint32_t r = 0; r < rows; ++r)
+                                        all_rank = all_rank && uni(sh.rrow[r]) != PL_NONE;
                                 for (uint32_t r = 0; r < rows; ++r) {
                                         const uint32_t prow = uni(sh.rrow[r]);
+                                        if (prow != PL_NONE && all_rank)
+                                                continue;
                                         if (prow != PL_NONE) {
                                                 // a head term: every candidate's entry by RANK — its posting index is its group's directory entry plus the plane-0 bits of the
                                                 // group before it (one 32-byte piece of plane 0), and the posting's entry (k_term_hits) is what a block walk would have left
@@ -554,6 +565,32 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                         if (!sh.alive[j])
                                                 continue;
                                         uint32_t cnt = 0;
+                                        if (all_rank) { // (uniform) the rows' entries by rank, all rows' loads side by side
+                                                const uint32_t doc = sh.cdoc[j], g = doc / PL_RANK_DOCS, k = (doc >> 5) & 7u, below = (1u << (doc & 31u)) - 1u;
+                                                uint32_t rk[4] = {0, 0, 0, 0};
+#pragma unroll
+                                                for (uint32_t r = 0; r < 4; ++r) {
+                                                        if (r >= rows)
+                                                                break;
+                                                        const uint32_t prow = uni(sh.rrow[r]);
+                                                        const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
+                                                        const uint4 x0 = *(const uint4 *)(pa + 8u * g), x1 = *(const uint4 *)(pa + 8u * g + 4u);
+                                                        uint32_t rank = prank[(size_t)prow * (plw / (PL_RANK_DOCS / 32u)) + g];
+                                                        const uint32_t w8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                                                        for (uint32_t i = 0; i < 8; ++i)
+                                                                rank += i < k ? (uint32_t)__popc(w8[i]) : i == k ? (uint32_t)__popc(w8[i] & below) : 0u;
+                                                        rk[r] = rank;
+                                                }
+#pragma unroll
+                                                for (uint32_t r = 0; r < 4; ++r) {
+                                                        if (r >= rows)
+                                                                break;
+                                                        const unsigned long long e = phs[hs_off[uni(sh.rrow[r])] + rk[r]];
+                                                        sh.hits_off[r * tile + j] = (uint32_t)e; // (this lane's own places: read back below without a barrier)
+                                                        sh.freq[r * tile + j] = (uint32_t)(e >> 32);
+                                                }
+                                        }
                                         // GOOGLE, the usual case — up to four distinct terms, every one of the candidate's hit runs at most eight single-byte hits —:
                                         // the rows' hit bytes are fetched TOGETHER, one unaligned 8-byte load each (one round trip for the whole check, where the
                                         // streams below send for a row's bytes when the walk reaches it), and the walks are shifts of registers
