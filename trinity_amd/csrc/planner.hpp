@@ -1429,7 +1429,10 @@ namespace trip {
                                                 plane_df += ix.terms[qt[k] & QT_TERM].documents;
                                 }
                                 const uint32_t nwin = last_doc / SPAN_BITS + 1;
-                                pscatter = one_group && plane_df && (double)plane_df >= (double)nwin * SPAN_WORDS; // (the form below is decided the same way, on all the terms)
+                                // (the result's form is decided below the same way on ALL the terms — min(N, sum of their documents) against the bitmap's words —: what
+                                //  holds for the head terms alone holds for all of them, so a scatter union's result IS a bitmap)
+                                const double N = std::max<double>(1.0, (double)ix.info.docs_cnt);
+                                pscatter = one_group && plane_df && std::min<double>(N, (double)plane_df) >= (double)nwin * SPAN_WORDS;
                                 pset = pscatter;
                         }
                         // a single lead list too short for a plane against lists that all have one: candidate tiles, every candidate tested with one
@@ -1514,6 +1517,8 @@ namespace trip {
                                         }
                                         bitmap = est * N >= (double)nwin * SPAN_WORDS;
                                 }
+                                if (pscatter && !bitmap)
+                                        return herr(f.err, TRI_ERR_INTERNAL, "query %u: a scatter union whose result is not a bitmap", t.q.qid);
                                 t.q.form = bitmap ? RESULT_BITMAP : RESULT_DOCIDS;
                                 const uint64_t per_win = std::max<uint64_t>(1, t.sumdf / (ix.info.docs_cnt / SPAN_BITS + 1)) + (pset ? 0 : opt.dense_window_cost);
                                 const uint32_t win_per_task = pset ? PSET_TASK_WINDOWS : (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / per_win);
