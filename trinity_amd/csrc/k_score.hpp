@@ -205,14 +205,17 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                         // the term is bit A, its frequency there 1 unless bit B says otherwise, 2 unless bit C does — only a match both
                                         // mark goes to the postings.  (A head term's blocks in a tile's docID range outnumber the tile's matches: without
                                         // the planes every match decoded a block of every scorer — cfg3: 900 us for a tile of 8192 matches and four head terms)
-                                        const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
+                                        // (round 5: the row's interleaved LEVEL words tell the frequency itself up to PL_NESTED - 1 — one 12-byte probe —; the postings are
+                                        //  walked only for the top level: a frequency of 0 or of PL_NESTED and more)
+                                        const uint32_t *lvw = planes + (size_t)prow * PL_PLANES * plw + (size_t)PL_STORED * plw;
                                         for (uint32_t j = tid; j < C; j += AND_WG) {
                                                 const uint32_t doc = sh.cand[j], wi = doc >> 5, bit = doc & 31u;
-                                                if (!((pa[wi] >> bit) & 1u))
+                                                const uint32_t *lv = lvw + 3u * wi;
+                                                uint32_t f = ((lv[0] >> bit) & 1u) | (((lv[1] >> bit) & 1u) << 1) | (((lv[2] >> bit) & 1u) << 2);
+                                                if (!f)
                                                         continue;
-                                                uint32_t f = 1;
-                                                if ((pa[plw + wi] >> bit) & 1u)
-                                                        f = ((pa[2 * (size_t)plw + wi] >> bit) & 1u) ? score_lookup_freq<CODEC>(index, blk_last, blk_off, win, t, doc) : 2u;
+                                                if (f == PL_NESTED)
+                                                        f = score_lookup_freq<CODEC>(index, blk_last, blk_off, win, t, doc);
                                                 sh.score[j] += (double)sim_score(sim, w, f);
                                         }
                                         __syncthreads();

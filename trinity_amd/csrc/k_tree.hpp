@@ -294,9 +294,11 @@ __global__ __launch_bounds__(TREE_WG) void k_tree_leaves(const uint8_t *__restri
                                 continue;
                         if (nd.op == TRI_OP_TERM) {
                                 const uint32_t *pa = tree_row(nd, trows, prows, plw);
-                                uint32_t f = 1;
-                                if ((pa[plw + wi] >> bit) & 1u) // plane B: the frequency is not 1 ...
-                                        f = ((pa[2 * (size_t)plw + wi] >> bit) & 1u) ? fused_lookup_freq<CODEC>(index, blk_last, blk_off, terms[nd.arg], doc) : 2u; // ... C: nor 2
+                                // (the row's interleaved level words: the frequency itself up to PL_NESTED - 1; the top level: read it from the postings)
+                                const uint32_t *lv = pa + (size_t)PL_STORED * plw + 3u * wi;
+                                uint32_t f = ((lv[0] >> bit) & 1u) | (((lv[1] >> bit) & 1u) << 1) | (((lv[2] >> bit) & 1u) << 2);
+                                if (f == PL_NESTED || !f)
+                                        f = fused_lookup_freq<CODEC>(index, blk_last, blk_off, terms[nd.arg], doc);
                                 s += (double)sim_score(sim, sweights[q.score_base + nd.score], f);
                         } else { // the phrase's score for this document: its hidden query's list holds it (k_phrase: scorer->score(id, matchCnt, weight))
                                 const DevQuery hq = plan[nd.arg];
