@@ -465,7 +465,9 @@ def main():
         for leg, rebuild in (("warm", 0), ("cold_planes", 1)):
             dev.set_option("planes_rebuild", rebuild)
             rp = Pipeline(T, RotatingWorkload(wls))
-            el, racc = timed(rp, args.rotating_steps, args.rotating_sets + 2, device_sync)
+            # (two cycles of warm-up: the sets' output regions differ in size, and the device pool must have seen every size that can be alive at once —
+            #  with one cycle a timed create still met a cold 1.6 GB hipMalloc now and then: 76 ms in a 1.4 ms step)
+            el, racc = timed(rp, args.rotating_steps, 2 * args.rotating_sets + 2, device_sync)
             rreg = racc.pop("_region")
             legs[leg] = {"value": nq_rank * args.rotating_steps / el, "ms_per_step": el * 1e3 / args.rotating_steps, "kernel_ms_per_step": racc["last_run_ms"] / args.rotating_steps,
                          "term_planes_ms_per_step": racc.get("term_planes_ms", 0.0) / args.rotating_steps, **{k: v for k, v in create_stats(rp, rreg, args.rotating_steps, el * 1e3 / args.rotating_steps).items() if k != "what"}}  # fmt: skip

@@ -154,6 +154,7 @@ constexpr uint32_t PL_STORED = 4;         // the nested planes a row actually ho
                                           // plane PL_STORED - 1 instead (a superset: the level words sort it out) — the planes above it are one bit in a thousand and cost a
                                           // full plane each to build, to keep and to stream
 constexpr uint32_t PL_PLANES = PL_STORED + PL_LEVEL_WORDS; // words of a term's row per word of the docID space (the row's stride is PL_PLANES * plw)
+constexpr uint32_t PL_RANK_WORDS = 16;     // ... a 64-byte record: [0] the posting index of the group's first document, [1 .. 8] the group's eight plane-0 words (one line tells a document's rank)
 constexpr uint32_t PL_RANK_DOCS = 256;     // a row's rank directory (tri_index::d_prank) has an entry per this many documents: the posting index of the group's first document
 constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64).  The entry's
                                                  // low 31 bits: where the block's hits start, in bytes PAST blk_off[] (the block's deltas and frequencies lie

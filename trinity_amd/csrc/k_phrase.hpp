@@ -512,15 +512,14 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                         if (prow != PL_NONE) {
                                                 // a head term: every candidate's entry by RANK — its posting index is its group's directory entry plus the plane-0 bits of the
                                                 // group before it (one 32-byte piece of plane 0), and the posting's entry (k_term_hits) is what a block walk would have left
-                                                static_assert(PL_RANK_DOCS == 256, "a group is eight plane words: two 16-byte loads");
-                                                const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
-                                                const uint32_t *rd = prank + (size_t)prow * (plw / (PL_RANK_DOCS / 32u));
+                                                const uint32_t *rd = prank + (size_t)prow * (plw / (PL_RANK_DOCS / 32u)) * PL_RANK_WORDS;
                                                 const unsigned long long *hs = phs + hs_off[prow];
                                                 for (uint32_t j = tid; j < C; j += AND_WG) {
                                                         const uint32_t doc = sh.cdoc[j], g = doc / PL_RANK_DOCS, k = (doc >> 5) & 7u;
-                                                        const uint4 x0 = *(const uint4 *)(pa + 8u * g), x1 = *(const uint4 *)(pa + 8u * g + 4u);
-                                                        uint32_t rank = rd[g];
-                                                        const uint32_t w8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                                                        const uint4 *rec = (const uint4 *)(rd + (size_t)g * PL_RANK_WORDS); // (one 64-byte line: the group's rank and its plane-0 words)
+                                                        const uint4 x0 = rec[0], x1 = rec[1], x2 = rec[2];
+                                                        uint32_t rank = x0.x;
+                                                        const uint32_t w8[8] = {x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x};
 #pragma unroll
                                                         for (uint32_t i = 0; i < 8; ++i)
                                                                 rank += i < k ? (uint32_t)__popc(w8[i]) : i == k ? (uint32_t)__popc(w8[i] & ((1u << (doc & 31u)) - 1u)) : 0u;
@@ -573,10 +572,10 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                                         if (r >= rows)
                                                                 break;
                                                         const uint32_t prow = uni(sh.rrow[r]);
-                                                        const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
-                                                        const uint4 x0 = *(const uint4 *)(pa + 8u * g), x1 = *(const uint4 *)(pa + 8u * g + 4u);
-                                                        uint32_t rank = prank[(size_t)prow * (plw / (PL_RANK_DOCS / 32u)) + g];
-                                                        const uint32_t w8[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                                                        const uint4 *rec = (const uint4 *)(prank + ((size_t)prow * (plw / (PL_RANK_DOCS / 32u)) + g) * PL_RANK_WORDS);
+                                                        const uint4 x0 = rec[0], x1 = rec[1], x2 = rec[2];
+                                                        uint32_t rank = x0.x;
+                                                        const uint32_t w8[8] = {x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x};
 #pragma unroll
                                                         for (uint32_t i = 0; i < 8; ++i)
                                                                 rank += i < k ? (uint32_t)__popc(w8[i]) : i == k ? (uint32_t)__popc(w8[i] & below) : 0u;

@@ -116,9 +116,14 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                 }
         __syncthreads();
         uint32_t *pa = planes + (size_t)row * PL_PLANES * plw + (size_t)w * PL_WORDS;
-        if (prank) // (rank of a document = its group's entry + the plane-0 bits of the group before it: k_phrase.hpp)
-                for (uint32_t i = tid; i < PL_W / PL_RANK_DOCS; i += AND_WG)
-                        prank[(size_t)row * (plw / (PL_RANK_DOCS / 32u)) + (size_t)w * (PL_W / PL_RANK_DOCS) + i] = rdir[i];
+        if (prank) { // (rank of a document = its group's entry + the plane-0 bits of the group before it, both in ONE 64-byte record: k_phrase.hpp)
+                static_assert(PL_RANK_DOCS == 256 && PL_RANK_WORDS == 16, "a record: the rank, the group's eight plane-0 words, padding to a cache line");
+                uint32_t *rec = prank + ((size_t)row * (plw / (PL_RANK_DOCS / 32u)) + (size_t)w * (PL_W / PL_RANK_DOCS)) * PL_RANK_WORDS;
+                for (uint32_t i = tid; i < (PL_W / PL_RANK_DOCS) * PL_RANK_WORDS; i += AND_WG) {
+                        const uint32_t g = i / PL_RANK_WORDS, k = i % PL_RANK_WORDS;
+                        rec[i] = k == 0 ? rdir[g] : k <= 8 ? pl[8u * g + k - 1u] : 0u;
+                }
+        }
         static_assert(PL_NESTED == 6 && PL_LEVEL_WORDS == 3, "the level's bits below are written for six nested planes");
         uint32_t *lv = planes + (size_t)row * PL_PLANES * plw + (size_t)PL_STORED * plw + 3u * (size_t)w * PL_WORDS; // the window's interleaved level words
         for (uint32_t i = tid; i < PL_WORDS; i += AND_WG) {

@@ -275,8 +275,8 @@ struct tri_index : HostIndex {
         uint32_t *d_pcache = nullptr;
         uint32_t pc_cap = 0, pc_plw = 0;
         std::vector<uint8_t> pc_built;
-        // ... and what k_phrase needs to find a head term's hits WITHOUT walking its blocks (round 5): per row a RANK DIRECTORY over plane 0 — d_prank[row * (plw / 8) + g]
-        // = the posting index of the first document of docID group g (256 documents), filled by k_term_planes —, and per posting the hits locator and frequency entry
+        // ... and what k_phrase needs to find a head term's hits WITHOUT walking its blocks (round 5): per row a RANK DIRECTORY over plane 0 — a 64-byte record per docID group g of 256 documents at d_prank[(row * (plw / 8) + g) * 16]:
+        // the posting index of the group's first document and the group's eight plane-0 words, filled by k_term_planes —, and per posting the hits locator and frequency entry
         // phrase_locate_block would compute (d_phs[hs_off[row] + posting]; k_term_hits; GOOGLE, lists of full blocks).  d_term_row[term] = its row once both are there
         uint32_t *d_prank = nullptr, *d_term_row = nullptr;
         unsigned long long *d_phs = nullptr;
@@ -864,12 +864,12 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 uint32_t *pairs = nullptr;
                                 const size_t groups = b->plw / 8;
                                 HIP_TRY(pool_alloc(dev, (void **)&pairs, (size_t)want * 8 + POOL_MIN_BYTES));
-                                HIP_TRY(pool_alloc(dev, (void **)&prank, (size_t)want * groups * 4 + 64));
+                                HIP_TRY(pool_alloc(dev, (void **)&prank, (size_t)want * groups * PL_RANK_WORDS * 4 + 64));
                                 HIP_TRY(pool_alloc(dev, (void **)&phs, (hs[want] + 8) * 8));
                                 HIP_TRY(pool_alloc(dev, (void **)&hso, ((size_t)want + 1) * 8 + POOL_MIN_BYTES));
                                 if (same && ix->d_prank) {
                                         HIP_TRY(hipMemcpyAsync(pairs, ix->d_ph_pairs, ix->ph_pairs_n * 8, hipMemcpyDeviceToDevice, dev->stream_up));
-                                        HIP_TRY(hipMemcpyAsync(prank, ix->d_prank, (size_t)ix->pc_cap * groups * 4, hipMemcpyDeviceToDevice, dev->stream_up));
+                                        HIP_TRY(hipMemcpyAsync(prank, ix->d_prank, (size_t)ix->pc_cap * groups * PL_RANK_WORDS * 4, hipMemcpyDeviceToDevice, dev->stream_up));
                                         HIP_TRY(hipMemcpyAsync(phs, ix->d_phs, ix->hs_off[ix->pc_cap] * 8, hipMemcpyDeviceToDevice, dev->stream_up));
                                 } else {
                                         ix->ph_built.clear();
