@@ -207,9 +207,11 @@ class Pipeline:
         self.cur = wl.create_set()  # on the engine stream (running or complete)
         for b in self.cur:
             b.run()
-        # five sets are alive in the loop (read back, running, launched, compiled and waiting, being compiled): two more sets' worth of buffers
-        # go into the device pool now, so that no timed step pays a cold allocation (cfg5: a 17 GB output region, measured 0.2 .. 484 ms)
-        for spare in [wl.create_set(), wl.create_set()]:
+        # up to five sets are alive in the loop (read back and not yet released, running, launched, compiled and waiting, being compiled — the fifth
+        # only when the compiler starts a set before the main loop has released the one it read back: rare while a create is shorter than a
+        # step, the rule once they take about as long).  Their buffers go into the device pool NOW, so that no timed step pays a cold
+        # allocation (cfg2: a 6 GB output region, 77 ms in the middle of a timed region; cfg5: 17 GB, 0.2 .. 484 ms)
+        for spare in [wl.create_set() for _ in range(4)]:
             for b in spare:
                 b.close()
         # the compiler: tri_batch_create back to back on its own thread, one compiled set waiting at most (with a create per step handed over

@@ -181,12 +181,14 @@ void *tri_dev_stream(tri_dev *);
  *                         windows, 4 AccumulatedScore top-K CNF queries run over bit planes (k_planes); 0: every query decodes every list it names
  *   "planes_split"        a query that runs as bit planes (k_planes) is cut into this many docID ranges, one task each (default 0: two, or three in a batch that brings few tasks per workgroup; 65536 and up: cut by postings like k_fused's); the
  *                         ranges share the query's threshold, results do not depend on the cut
- *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 512) and the batch's uses repay one
+ *   "plane_div"           a term gets a plane when it holds at least docs_cnt / plane_div documents (default 1024) and the batch's uses repay one
  *                         decode of its list
  *   "account_needed_bytes" 1: tri_batch_create also works out tri_batch_info.cand_needed_bytes (a directory walk per candidate-tile query; default 0)
  *   "plane_max_bytes"     scratch budget of a batch's term planes (default 8 GiB): the terms eligible for a plane are the longest lists that fit
  *   "planes_rebuild"      1: every tri_batch_run decodes the plane rows its batch names again — a COLD plane cache, what a query stream whose head
  *                         terms were all just evicted pays per batch (default 0: a row is built once per index); a measurement switch, read by tri_batch_run
+ *   "cand_xcd"            1 (default): the candidate-tile kernel's tasks are queued per XCD by the plane row they probe — a row's probes land in ONE 4 MB L2
+ *                         (csrc/planner.hpp, "k_and's queues"); 0: the heaviest-first order dealt round the queues.  Results do not depend on it
  *   "probe_max_blocks"    > 0: a conjunction of ONE lead list of at most this many blocks with lists that all have planes runs in k_probe (a wave per
  *                         task, csrc/k_probe.hpp) instead of candidate tiles (default 0: off — measured slower at cfg2, planner.hpp)
  *   "overlap"             1: the candidate-tile kernel runs on a second stream beside the window kernels (default 0; measured: no gain, the persistent

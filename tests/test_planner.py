@@ -143,6 +143,56 @@ def test_heavier_tasks_are_scheduled_first(world):
     p.close()
 
 
+def test_candidate_tile_tasks_are_queued_per_xcd_by_the_row_they_probe(world):
+    """k_and's section of the schedule is cut into one queue per XCD: every task in exactly one queue.  In a batch of two-term conjunctions with long leads
+    (`cand_xcd`, the default) a queue is ordered by the plane row its tasks probe first: a row sits in ONE queue — a row that outweighs a 16th of the
+    section in a few — its tasks next to each other, and the queues carry about the same number of tiles; without it the cost order is dealt round the
+    queues.  The set of tasks is the same either way, and so is the plan whatever the number of planning threads."""
+    D, V, segs, hix = world
+    parts, _ = W.build_parts("cfg2", D, V, 10, 42, 4000)
+    seen = {}
+    for xcd, threads in ((1, 4), (1, 1), (0, 4)):
+        p = HP.HostPlan(hix[parts[0].codec], parts[0].programs, parts[0].flags, 0, threads=threads, options={"cand_xcd": xcd, "plane_div": 64})
+        s, tasks, plan, qpl = p.s, p.tasks, p.plan, p.qplane
+        c0, nc = s["n_dense"] + s["n_pset"] + s["n_probe"], s["n_cand"]
+        cq = p.cand_q.astype(np.int64)
+        assert nc >= 64 and cq[0] == 0 and cq[8] == nc and np.all(np.diff(cq) >= 0)
+        sec = p.sched[c0 : c0 + nc].copy()
+        assert np.all(tasks["kind"][sec] == HP.TASK_CAND)
+        if (xcd, threads) == (1, 1):
+            assert np.array_equal(sec, seen[1, 4])  # (the queues do not depend on how the batch was cut for planning)
+        seen[xcd, threads] = sec
+        tiles = (tasks["end"] - tasks["begin"]).astype(np.int64)[sec] + 1
+        loads = np.array([tiles[cq[x] : cq[x + 1]].sum() for x in range(8)])
+        assert loads.max() <= 1.25 * loads.mean() + 8, loads
+        if not xcd:
+            assert np.all(np.diff(cq) >= nc // 8) and np.all(np.diff(cq) <= nc // 8 + 1)
+            p.close()
+            continue
+        rows = np.full(nc, -1, dtype=np.int64)
+        for i, ti in enumerate(sec):
+            q = plan[tasks["slot"][ti]]
+            for k in range(1, int(q["nterms"])):
+                r = int(qpl[int(q["term_base"]) + k]) if len(qpl) else 0xFFFFFFFF
+                if r != 0xFFFFFFFF:
+                    rows[i] = r
+                    break
+        assert (rows >= 0).sum() > nc // 4  # (the world's head terms have planes at this plane_div)
+        queue_of = np.searchsorted(cq, np.arange(nc), side="right") - 1
+        total = tiles[rows >= 0].sum()
+        contiguous = 0
+        for r in np.unique(rows[rows >= 0]):
+            at = np.flatnonzero((rows == r) & (tiles <= 4))  # (the long tasks go first, whatever they probe)
+            if not len(at):
+                continue
+            qs = np.unique(queue_of[at])
+            assert len(qs) <= max(1, -(-16 * tiles[rows == r].sum() // total)), (r, qs)
+            contiguous += all(a[-1] - a[0] + 1 == len(a) for a in (at[queue_of[at] == x] for x in qs))
+        assert contiguous >= min(8 * 30, len(np.unique(rows[rows >= 0]))) // 2  # (30 places per queue: the lightest rows of a crowded queue share one)
+        p.close()
+    assert np.array_equal(np.sort(seen[0, 4]), np.sort(seen[1, 4]))
+
+
 def test_unsupported_shapes_and_malformed_programs(world):
     D, V, segs, hix = world
     import oracle_lib as O

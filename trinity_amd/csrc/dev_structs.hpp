@@ -76,6 +76,9 @@ struct DevTask {
         uint32_t kind;
         uint64_t out_off; // absolute docID slot in out[] where this task's segment starts
 };
+constexpr uint32_t CAND_QUEUES = 8;      // k_and's task queues: one per XCD (BatchPlan::cand_q), a ticket word each, 64 bytes apart (CAND_TICKET_STRIDE words)
+constexpr uint32_t CAND_TICKET_STRIDE = 16;
+constexpr uint32_t CAND_HEAVY_TILES = 3; // a TASK_CAND task of more lead tiles runs at its queue's start, in cost order
 constexpr uint32_t TASK_CAND = 0;  // candidate tiles of the lead list, filtered by galloping / block-driven merge
 constexpr uint32_t TASK_DENSE = 1; // bitmap algebra over fixed docID windows (every list dense enough)
 constexpr uint32_t TASK_FUSED = 2; // AccumulatedScoreScheme + top-K of a dense query: decode, match, score and select in one pass over docID

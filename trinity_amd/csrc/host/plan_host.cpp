@@ -57,7 +57,8 @@ void *tri_host_plan(void *hindex, const uint32_t *prog, uint64_t prog_len, const
                 uint64_t *slot = n == "dense_min_postings" ? &o.dense_min_postings : n == "dense_task_cost" ? &o.dense_task_cost : n == "fused" ? &o.fused
                                  : n == "fused_task_cost" ? &o.fused_task_cost : n == "fused_freq_cap" ? &o.fused_freq_cap : n == "fused_halfwords" ? &o.fused_halfwords
                                  : n == "account_needed_bytes" ? &o.account_needed_bytes : n == "planes" ? &o.planes : n == "planes_split" ? &o.planes_split
-                                 : n == "plane_div" ? &o.plane_div : n == "plane_max_bytes" ? &o.plane_max_bytes : n == "probe_max_blocks" ? &o.probe_max_blocks : n == "tree_max_bytes" ? &o.tree_max_bytes : n == "result_bitmaps" ? &o.result_bitmaps : n == "cand_task_cost" ? &o.cand_task_cost : n == "dense_window_cost" ? &o.dense_window_cost : nullptr;
+                                 : n == "plane_div" ? &o.plane_div : n == "plane_max_bytes" ? &o.plane_max_bytes : n == "probe_max_blocks" ? &o.probe_max_blocks : n == "tree_max_bytes" ? &o.tree_max_bytes : n == "result_bitmaps" ? &o.result_bitmaps : n == "cand_task_cost" ? &o.cand_task_cost : n == "dense_window_cost" ? &o.dense_window_cost
+                                 : n == "cand_xcd" ? &o.cand_xcd : nullptr;
                 if (!slot) {
                         put_err(err, errcap, "unknown option " + n);
                         return nullptr;
@@ -101,7 +102,7 @@ void *tri_host_plan(void *hindex, const uint32_t *prog, uint64_t prog_len, const
 void tri_host_plan_free(void *p) { delete static_cast<HostPlan *>(p); }
 
 // sizes and offsets of the plan's sections, counters: out[0..] in the order below
-void tri_host_plan_summary(void *p, uint64_t *out /* [64] */, double *ms /* [4] */) {
+void tri_host_plan_summary(void *p, uint64_t *out /* [65] */, double *ms /* [4] */) {
         const BatchPlan &P = static_cast<HostPlan *>(p)->P;
         const uint64_t v[] = {P.block_bytes,       P.plan.size(),    P.qterms.size(),      P.tasks.size(),  P.fused.size(),       P.qplane.size(),    P.plane_terms.size(), P.sterms.size(),
                               P.sweights.size(),   P.phrases.size(), P.pterms.size(),      P.ptasks.size(), P.off_plan,           P.off_qterms,       P.off_tasks,          P.off_sched,
@@ -110,8 +111,9 @@ void tri_host_plan_summary(void *p, uint64_t *out /* [64] */, double *ms /* [4] 
                               P.sparse_cap,        P.out_capacity,   P.term_bytes,         P.term_bytes_dense, P.dense_queries,   P.cand_queries,     P.fused_queries,      P.planes_queries,
                               P.unsupported_queries, P.rich_R,       sizeof(DevQuery),     sizeof(DevTask), sizeof(DevFused),     sizeof(DevPhrase),  P.cand_needed_term_bytes, P.plane_decoded_bytes,
                               P.n_pset,            P.pset_queries,   P.n_probe,            P.probe_queries, P.units.size(),       P.off_units,        P.off_pset_sched,     sizeof(DevPsetUnit),
-                              P.n_tree,            P.tree_queries,   P.tree.size(),        P.off_tree,      P.tree_terms.size(),  P.off_tree_terms,   P.tree_hidden.size(), P.off_tree_hidden};
-        static_assert(sizeof v / sizeof v[0] == 64, "summary layout");
+                              P.n_tree,            P.tree_queries,   P.tree.size(),        P.off_tree,      P.tree_terms.size(),  P.off_tree_terms,   P.tree_hidden.size(), P.off_tree_hidden,
+                              P.off_cand_q};
+        static_assert(sizeof v / sizeof v[0] == 65, "summary layout");
         memcpy(out, v, sizeof v);
         if (ms)
                 memcpy(ms, P.plan_ms, sizeof P.plan_ms);

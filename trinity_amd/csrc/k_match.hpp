@@ -1046,13 +1046,17 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                                 const DevTerm *__restrict__ terms,
                                                 const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
                                                 const uint32_t *__restrict__ sched, const uint32_t *__restrict__ qterms,
-                                                const uint32_t ntasks, uint32_t *__restrict__ ticket,
+                                                const uint32_t *__restrict__ cand_q, uint32_t *__restrict__ ticket,
                                                 uint32_t *__restrict__ out, uint32_t *__restrict__ counts,
                                                 const uint32_t *__restrict__ masked, const uint32_t *__restrict__ qplane,
                                                 const uint32_t *__restrict__ planes, const uint32_t plw) {
         __shared__ AndShared sh;
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
+        // the queue of the XCD this workgroup runs on (HW_REG_XCC_ID: register 20, bits 0 .. 3) — placement changes speed only: every queue is
+        // drained by whoever gets there, the own one first
+        const uint32_t home = uni(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))) % CAND_QUEUES;
+        uint32_t qdone = 0; // (wave 0's: the queues found empty)
         PROF_DECL;
         PROF_START();
         for (;;) {
@@ -1064,14 +1068,29 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                 // next query: wave 0 draws the ticket.  All 64 lanes add 1 (the compiler folds that into ONE
                 // global atomic of +64 with a uniform operand — no lane-divergent branch at the loop head), so the
                 // counter advances in units of 64 per draw.
+                //
+                // One ticket word per XCD (a single word drawn by 1024 workgroups costs ~3 us a draw under load; a word per XCD a tenth), and the
+                // queue behind it holds the tasks that probe the SAME plane rows (planner.hpp, "k_and's queues"): the XCD's L2 keeps a row's
+                // sectors from one task's probes to the next's.
                 if (wave == 0) {
-                        const uint32_t old = atomicAdd(ticket, 1u);
-                        sh.bcast[0] = uni(old) >> 6;
+                        uint32_t got = 0xffffffffu;
+                        for (uint32_t t = 0; t < CAND_QUEUES && got == 0xffffffffu; ++t) {
+                                const uint32_t x = (home + t) % CAND_QUEUES;
+                                if ((qdone >> x) & 1u)
+                                        continue;
+                                const uint32_t q0 = cand_q[x], qn = cand_q[x + 1] - q0;
+                                const uint32_t old = uni(atomicAdd(ticket + x * CAND_TICKET_STRIDE, 1u)) >> 6;
+                                if (old < qn)
+                                        got = q0 + old;
+                                else
+                                        qdone |= 1u << x;
+                        }
+                        sh.bcast[0] = got;
                 }
                 __syncthreads();
                 const uint32_t ticket_no = uni(sh.bcast[0]);
                 __syncthreads();
-                if (ticket_no >= ntasks)
+                if (ticket_no == 0xffffffffu)
                         break;
                 const uint32_t tix = sched[ticket_no];
                 TASKTIME(8 * ticket_no);
@@ -1132,11 +1151,25 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                 const uint32_t prow = qplane ? qplane[q.term_base + k] : PL_NONE;
                                 if (prow != PL_NONE) {
                                         // the term has a plane (k_term_planes decoded it once for the whole batch): advance(candidate) is a bit probe
+                                        // (eight probes of a lane in flight together: one at a time, a tile of 8192 candidates was 32 dependent round trips —
+                                        //  12 us of a 24 us task at cfg2)
                                         const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
-                                        for (uint32_t j = tid; j < C; j += AND_WG) {
-                                                const uint32_t doc = sh.cand[phys(j)];
-                                                if ((pa[doc >> 5] >> (doc & 31u)) & 1u)
-                                                        atomicOr(&sh.hit[j >> 5], 1u << (j & 31u));
+                                        for (uint32_t j0 = tid; j0 < C; j0 += AND_WG * 8) {
+                                                uint32_t doc[8], w[8];
+#pragma unroll
+                                                for (int u = 0; u < 8; ++u) {
+                                                        const uint32_t j = j0 + u * AND_WG;
+                                                        doc[u] = j < C ? sh.cand[phys(j)] : 0u;
+                                                }
+#pragma unroll
+                                                for (int u = 0; u < 8; ++u)
+                                                        w[u] = pa[doc[u] >> 5];
+#pragma unroll
+                                                for (int u = 0; u < 8; ++u) {
+                                                        const uint32_t j = j0 + u * AND_WG;
+                                                        if (j < C && ((w[u] >> (doc[u] & 31u)) & 1u))
+                                                                atomicOr(&sh.hit[j >> 5], 1u << (j & 31u));
+                                                }
                                         }
                                 } else
                                 and_filter_tile<CODEC>(sh, index, blk_last, blk_off, win, t, C, k - 1, bd PROF_PASS);

@@ -19,6 +19,7 @@
 #include <chrono>
 #include <cmath>
 #include <memory>
+#include <numeric>
 
 // planner / launch options of a device handle (tri_dev_set_option); the defaults are what bench.py measures
 struct tri_options {
@@ -37,13 +38,16 @@ struct tri_options {
         uint64_t overlap = 0;                                 // 1: the candidate-tile kernel (k_and) on a second stream beside the window kernels (k_and_dense, k_psets, k_probe), full grids
         uint64_t planes = 7;     // term planes (k_planes.hpp), a bit set: 1 k_and probes them, 2 k_and_dense ORs them in, 4 top-K CNF queries run in k_planes; 0: off
         uint64_t planes_split = 0; // a k_planes query is cut into this many docID ranges (tasks) that share its threshold; 0: 2 or 3 by the batch's size; >= 65536: by postings like the other one-pass tasks.  cfg3's unions: 0 10.9 ms, 2 8.0, 3 8.5, 4 9.2 (a task has fixed costs)
-        uint64_t plane_div = 512; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list).
+        uint64_t plane_div = 1024; // a term gets a plane when it holds at least docs_cnt / plane_div documents (and the batch's uses repay one decode of its list).
+                                 // Round 5 (k_planes' level words, k_and's row queues), step ms at 512 / 1024 / 2048: cfg3 5.95 / 5.63 / 5.57, cfg5 7.42 / 7.27 / 7.28, cfg2 1.30 / 1.31 / 1.31
+                                 // — 698 rows at cfg3 (8.75 MB each at 10 M documents).  Earlier rounds:
                                  // While a batch built its own planes: step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the
                                  // build grew with it).  The planes live with the index now (built once): 128 / 512 / 4096: cfg2 1.48 / 1.44 / 1.40, cfg3 12.64 / 12.40 / 12.4,
                                  // cfg4 17.4 / 16.9 / 16.9 — 355 rows (1.3 GB at 10 M documents) at 512
         uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs PL_PLANES bitmaps over the docID space and one decode per index)
         uint64_t planes_rebuild = 0;           // 1: every tri_batch_run decodes the plane rows its batch names AGAIN (a cold plane cache: what a query stream pays whose head
                                                // terms have all just been evicted) — a measurement switch (bench.py's rotating leg), never a speed-up
+        uint64_t cand_xcd = 1;                 // k_and's tasks queued per XCD by the plane row they probe (planner.hpp "k_and's queues"); 0: the cost order dealt round the queues
         uint64_t plan_threads = 0;             // host threads tri_batch_create plans with; 0: up to 16, one per 512 queries
         uint64_t result_bitmaps = 1;           // DocumentsOnly: a bitmap-window query whose expected matches outnumber the words of a bitmap over its docID range
                                                // delivers its docID set AS that bitmap (RESULT_BITMAP, dev_structs.hpp); 0: always ascending docIDs
@@ -110,6 +114,8 @@ struct BatchPlan {
         Span<uint32_t> pset_sched;  // ... and the order they are run in, as unit indices: [0, n_pset) TASK_PSET, docID window range by window range; then
                                     // the n_probe TASK_PROBE ones, heaviest first
         size_t off_units = 0, off_pset_sched = 0;
+        Span<uint32_t> cand_q;      // k_and's task queues, one per XCD: queue x = the TASK_CAND section of sched at [cand_q[x], cand_q[x + 1]) (CAND_QUEUES + 1 bounds)
+        size_t off_cand_q = 0;
         Span<uint32_t> tree;        // TASK_TREE records: TREE_HDR_WORDS header words + DevTreeNode per node (DevQuery::fused_idx: the record's first word)
         Span<uint32_t> tree_terms;  // the distinct term leaves of the batch's TASK_TREE queries, ascending: term -> row of the batch's tree rows
         Span<uint32_t> tree_hidden; // hidden phrase queries: their plan slots (position: the row of the batch's phrase rows)
@@ -143,6 +149,10 @@ struct BatchPlan {
 namespace trip {
         constexpr size_t SECTION_ALIGN = 64;
         constexpr uint32_t SCHED_NB = 64 * 4; // schedule buckets per kernel: cost octave + 2 bits
+        constexpr uint32_t CAND_SUBS = 128, CAND_COST_SUBS = 16; // ... k_and's in row order have buckets of their own (behind the kernels': CAND_KEY0): per queue, 16 for the long and the
+                                                               // row-less tasks by cost, 111 places for rows, one for the stragglers
+        constexpr uint32_t CAND_KEY0 = TASK_KINDS * SCHED_NB, SCHED_KEYS = CAND_KEY0 + CAND_QUEUES * CAND_SUBS;
+        constexpr uint64_t CAND_ROWS_MIN_LEAD = 1024;
         // launch order of the task kinds: TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, then the one-pass kinds as numbered
         constexpr uint32_t SCHED_RANK[TASK_KINDS] = {3, 0, 4, 5, 6, 7, 8, 1, 2, 9};
         inline uint32_t sched_key(const uint32_t kind, const uint64_t cost) {
@@ -480,6 +490,7 @@ namespace trip {
                 std::vector<QUse> quses, suses; // (suses: scorer positions — qpos indexes the fragment's sterms)
                 std::vector<FUse> fuses;
                 std::vector<uint64_t> benefit; // per eligible term (by df rank): postings of decoding the batch's uses save
+                std::vector<uint64_t> cand_row; // per eligible term: tiles (+ 1 a task) of the candidate-tile tasks whose first probed term it is
                 std::vector<uint32_t> keys, hist; // (fill pass) per task its schedule bucket; tasks per bucket
                 std::vector<uint32_t> treepool;   // TASK_TREE records (DevQuery::fused_idx: a record's first word)
                 std::vector<uint32_t> tree_terms; // the term leaves of the fragment's TASK_TREE queries
@@ -489,6 +500,7 @@ namespace trip {
                 uint32_t sparse_cap = 0;
                 uint64_t term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, cand_needed = 0;
                 uint64_t dense_queries = 0, pset_queries = 0, probe_queries = 0, cand_queries = 0, fused_queries = 0, planes_queries = 0, term_bytes_pset = 0, term_bytes_probe = 0;
+                uint64_t cand_lead_docs = 0, cand_terms = 0; // (candidate-tile queries: their leads' documents, their terms)
                 uint64_t probe_demoted = 0, probe_demoted_bytes = 0; // (fill pass) queries whose probes found no plane: candidate tiles after all
                 // bases in the batch's arrays (settled between the passes)
                 size_t b_plan = 0, b_qterms = 0, b_sterms = 0, b_phrases = 0, b_pterms = 0, b_tasks = 0, b_fused = 0, b_ptasks = 0, b_units = 0, b_tree = 0, b_hidden = 0;
@@ -513,7 +525,7 @@ namespace trip {
                         keep(fresh.tmp, tmp), keep(fresh.qterms, qterms), keep(fresh.pterms, pterms), keep(fresh.sterms, sterms), keep(fresh.sweights, sweights);
                         keep(fresh.phrases, phrases), keep(fresh.fz, fz), keep(fresh.left_out, left_out), keep(fresh.tasks, tasks), keep(fresh.tcost, tcost);
                         keep(fresh.fused, fused), keep(fresh.ptasks, ptasks), keep(fresh.units, units), keep(fresh.quses, quses), keep(fresh.suses, suses);
-                        keep(fresh.fuses, fuses), keep(fresh.benefit, benefit), keep(fresh.keys, keys), keep(fresh.hist, hist), keep(fresh.treepool, treepool);
+                        keep(fresh.fuses, fuses), keep(fresh.benefit, benefit), keep(fresh.cand_row, cand_row), keep(fresh.keys, keys), keep(fresh.hist, hist), keep(fresh.treepool, treepool);
                         keep(fresh.tree_terms, tree_terms);
                         *this = std::move(fresh);
                 }
@@ -1302,6 +1314,7 @@ namespace trip {
                 const uint64_t DENSE_TASK_COST = std::max<uint64_t>(1, opt.dense_task_cost); // bitmap-window tasks stage their terms once: two windows of a head pair per task
                 const uint64_t PLANES_SPLIT = C.planes_split, FUSED_TASK_COST = C.fused_task_cost;
                 f.benefit.assign(C.n_ok, 0);
+                f.cand_row.assign(C.n_ok, 0);
                 uint64_t off = 0;
                 for (size_t ti = 0; ti < f.tmp.size(); ++ti) {
                         if (ti + 6 < f.tmp.size()) { // (the per-term records of the query six queries on: see lower_range)
@@ -1467,6 +1480,7 @@ namespace trip {
                                 for (uint32_t k = 1; probe && k < t.q.nterms; ++k)
                                         probe = C.plane_ok(qt[k] & QT_TERM);
                                 ++(probe ? f.probe_queries : f.cand_queries);
+                                f.cand_lead_docs += lead.documents, f.cand_terms += t.q.nterms;
                                 if (probe) {
                                         auto &seen = f.S.seen;
                                         seen.clear();
@@ -1476,11 +1490,17 @@ namespace trip {
                                                         f.term_bytes_probe += ix.docbytes[qt[k] & QT_TERM];
                                                 }
                                 }
+                                bool first_row = !probe;
                                 for (uint32_t k = 1; k < t.q.nterms; ++k) { // (the lead list is decoded into the candidate tiles; the others are probed)
                                         const uint32_t term = qt[k] & QT_TERM;
                                         if ((planes_opt & 1u) && C.plane_ok(term)) {
                                                 f.benefit[ix.df_rank[term]] += std::min<uint64_t>(ix.terms[term].documents, 32ull * lead.documents);
                                                 f.quses.push_back({t.q.term_base + k, term});
+                                                if (first_row) { // (k_and's queues: what the row's tasks will weigh)
+                                                        const uint32_t ntiles = (lead.nblocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
+                                                        f.cand_row[ix.df_rank[term]] += ntiles + (ntiles + CAND_HEAVY_TILES - 1) / CAND_HEAVY_TILES;
+                                                        first_row = false;
+                                                }
                                         }
                                 }
                         }
@@ -1743,8 +1763,8 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         // ---- the fragments' places in the batch's arrays; sums
         size_t n_plan = 0, n_qterms = 0, n_sterms = 0, n_phrases = 0, n_pterms = 0, n_tasks = 0, n_fused = 0, n_ptasks = 0, n_units = 0, n_treewords = 0, n_hidden = 0;
         std::vector<uint32_t> tree_terms;
-        uint64_t off = 0;
-        std::vector<uint64_t> benefit(C.n_ok, 0);
+        uint64_t off = 0, cand_lead_docs = 0, cand_terms = 0, cand_queries_all = 0;
+        std::vector<uint64_t> benefit(C.n_ok, 0), cand_row(C.n_ok, 0);
         for (Frag &f : frags) {
                 f.b_plan = n_plan, f.b_qterms = n_qterms, f.b_sterms = n_sterms, f.b_phrases = n_phrases, f.b_pterms = n_pterms, f.b_tasks = n_tasks, f.b_fused = n_fused,
                 f.b_ptasks = n_ptasks, f.b_off = off, f.b_units = n_units;
@@ -1758,6 +1778,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         n_tasks += f.tasks.size(), n_fused += f.fused.size(), n_ptasks += f.ptasks.size(), off += f.off;
                 P.term_bytes += f.term_bytes, P.term_bytes_phrase_hits += f.term_bytes_phrase_hits, P.term_bytes_dense += f.term_bytes_dense,
                         P.term_bytes_fused += f.term_bytes_fused, P.term_bytes_planes += f.term_bytes_planes, P.cand_needed_term_bytes += f.cand_needed;
+                cand_lead_docs += f.cand_lead_docs, cand_terms += f.cand_terms, cand_queries_all += f.cand_queries + f.probe_queries;
                 P.dense_queries += f.dense_queries, P.cand_queries += f.cand_queries, P.fused_queries += f.fused_queries, P.planes_queries += f.planes_queries;
                 P.pset_queries += f.pset_queries, P.term_bytes_pset += f.term_bytes_pset;
                 P.probe_queries += f.probe_queries, P.term_bytes_probe += f.term_bytes_probe;
@@ -1765,7 +1786,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 P.rich_allow |= f.rich_allow;
                 P.sparse_cap = std::max(P.sparse_cap, f.sparse_cap);
                 for (uint32_t r = 0; r < C.n_ok; ++r)
-                        benefit[r] += f.benefit[r];
+                        benefit[r] += f.benefit[r], cand_row[r] += f.cand_row[r];
                 for (const size_t qi : f.left_out) { // a query shape the planner does not lower does not fail the batch: the query is left out (status
                                                      // TRI_ERR_UNSUPPORTED, no matches) and the caller keeps its CPU span for it
                         P.qstatus[qi] = TRI_ERR_UNSUPPORTED;
@@ -1814,6 +1835,42 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 P.plane_decoded_bytes += ix.docbytes[chosen[i]];
         }
         P.plane_rows = C.n_ok;
+        // k_and's tasks ordered by the plane row they probe ("k_and's queues" below): where the probes are the kernel's traffic — conjunctions of two or
+        // three terms whose leads average a thousand documents or more (cfg2: 3.4 K).  Rare leads against four lists (cfg3 / cfg5: a few hundred
+        // candidates a task, several rows each) gain nothing from the order and lose the heaviest-first start: measured 0.49 -> 0.54 ms, 0.68 -> 0.72 ms
+        const bool cand_rows = opt.cand_xcd && !chosen.empty() && cand_queries_all && cand_lead_docs >= CAND_ROWS_MIN_LEAD * cand_queries_all && cand_terms <= 3 * cand_queries_all;
+        uint32_t cand_first = 0, cand_qat[CAND_QUEUES] = {};
+        // row -> queue(s) and the row's place in the queue: heaviest row first to the least loaded queue (the rows are a few hundred); a row that outweighs
+        // a 16th of the section is cut into pieces of that size, each placed on its own (a Zipf batch's first term is probed by a sixth of the tasks)
+        struct RowQ {
+                uint8_t n = 0, q[CAND_QUEUES] = {}, sub[CAND_QUEUES] = {};
+        };
+        std::vector<RowQ> rowq(cand_rows ? C.n_ok : 0);
+        if (cand_rows) {
+                uint64_t total = 0, load[CAND_QUEUES] = {};
+                uint32_t placed[CAND_QUEUES] = {};
+                std::vector<uint32_t> rows;
+                for (uint32_t r = 0; r < C.n_ok; ++r)
+                        if (cand_row[r] && row_of_rank[r] != PL_NONE)
+                                rows.push_back(r), total += cand_row[r];
+                std::sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return cand_row[a] != cand_row[b] ? cand_row[a] > cand_row[b] : a < b; });
+                const uint64_t cap = std::max<uint64_t>(1, total / (2 * CAND_QUEUES));
+                for (const uint32_t r : rows) {
+                        RowQ &z = rowq[r];
+                        z.n = (uint8_t)std::min<uint64_t>(CAND_QUEUES, (cand_row[r] + cap - 1) / cap);
+                        for (uint32_t k = 0; k < z.n; ++k) {
+                                const uint32_t x = (uint32_t)(std::min_element(load, load + CAND_QUEUES) - load);
+                                load[x] += cand_row[r] / z.n;
+                                z.q[k] = (uint8_t)x;
+                                z.sub[k] = (uint8_t)(CAND_COST_SUBS + placed[x]++ % (CAND_SUBS - CAND_COST_SUBS - 1));
+                        }
+                }
+        }
+        if (dbg_plan) {
+                char buf[96];
+                snprintf(buf, sizeof buf, " [cand queries %llu lead docs %llu terms %llu rows %d]", (unsigned long long)cand_queries_all, (unsigned long long)cand_lead_docs, (unsigned long long)cand_terms, (int)cand_rows);
+                dbg_line += buf;
+        }
         // ---- layout of the host block
         size_t bytes = 0;
         auto section = [&](size_t &off_out, size_t n, size_t elem) {
@@ -1837,6 +1894,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         section(P.off_ptasks, n_ptasks, 4);
         section(P.off_units, n_units, sizeof(DevPsetUnit));
         section(P.off_pset_sched, n_units, 4);
+        section(P.off_cand_q, CAND_QUEUES + 1, 4);
         section(P.off_tree, n_treewords, 4);
         section(P.off_tree_terms, tree_terms.size(), 4);
         section(P.off_tree_hidden, n_hidden, 4);
@@ -1866,6 +1924,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         span(P.ptasks, P.off_ptasks, n_ptasks);
         span(P.units, P.off_units, n_units);
         span(P.pset_sched, P.off_pset_sched, n_units);
+        span(P.cand_q, P.off_cand_q, CAND_QUEUES + 1);
         span(P.tree, P.off_tree, n_treewords);
         span(P.tree_terms, P.off_tree_terms, tree_terms.size());
         span(P.tree_hidden, P.off_tree_hidden, n_hidden);
@@ -1967,10 +2026,6 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         P.units[f.b_units + i] = u;
                         unit_of_task[u.tix] = (uint32_t)(f.b_units + i);
                 }
-                f.keys.resize(f.tasks.size());
-                f.hist.assign(TASK_KINDS * SCHED_NB, 0u);
-                for (size_t i = 0; i < f.tasks.size(); ++i) // (the kinds are final: a probe task whose planes were not chosen is a candidate-tile task by now)
-                        ++f.hist[f.keys[i] = sched_key(P.tasks[f.b_tasks + i].kind, f.tcost[i])];
                 if (n_splane) {
                         std::fill(&P.splane.p[f.b_sterms], &P.splane.p[f.b_sterms] + f.sterms.size(), PL_NONE);
                         for (const QUse &u : f.suses)
@@ -1980,6 +2035,32 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         std::fill(&P.qplane.p[f.b_qterms], &P.qplane.p[f.b_qterms] + f.qterms.size(), PL_NONE);
                         for (const QUse &u : f.quses)
                                 P.qplane[f.b_qterms + u.qpos] = row_of_rank[ix.df_rank[u.term]];
+                }
+                f.keys.resize(f.tasks.size());
+                f.hist.assign(SCHED_KEYS, 0u);
+                for (size_t i = 0; i < f.tasks.size(); ++i) { // (the kinds are final: a probe task whose planes were not chosen is a candidate-tile task by now)
+                        const DevTask &tk = P.tasks[f.b_tasks + i];
+                        if (tk.kind != TASK_CAND || !cand_rows) {
+                                ++f.hist[f.keys[i] = sched_key(tk.kind, f.tcost[i])];
+                                continue;
+                        }
+                        // k_and's queues (below): the XCD's queue and the place in it by the plane row the task probes first
+                        const DevQuery &q = P.plan[tk.slot];
+                        uint32_t row = PL_NONE;
+                        for (uint32_t k = 1; k < q.nterms && row == PL_NONE; ++k)
+                                row = P.qplane[q.term_base + k];
+                        uint32_t queue, sub;
+                        if (tk.tile_end - tk.tile_begin > CAND_HEAVY_TILES || row == PL_NONE)
+                                // the long tasks, and the ones that gallop through every list (100 us and more where a probing task takes 20): first, dealt
+                                // round the queues, heaviest first — left to the end they were the kernel's tail (a tenth of its span on a tenth of the workgroups)
+                                queue = (uint32_t)(f.b_tasks + i) % CAND_QUEUES, sub = (sched_key(TASK_CAND, f.tcost[i]) % SCHED_NB) / (SCHED_NB / CAND_COST_SUBS);
+                        else if (row < rowq.size() && rowq[row].n) {
+                                const RowQ &z = rowq[row];
+                                const uint32_t piece = (uint32_t)(f.b_tasks + i) % z.n;
+                                queue = z.q[piece], sub = z.sub[piece];
+                        } else // (a row the tally above did not see: a demoted probe task's)
+                                queue = row % CAND_QUEUES, sub = CAND_SUBS - 1;
+                        ++f.hist[f.keys[i] = CAND_KEY0 + queue * CAND_SUBS + sub];
                 }
         });
         for (const Frag &f : frags) { // (what the fill pass sent back to the candidate tiles)
@@ -1996,11 +2077,22 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 uint32_t at = 0;
                 for (uint32_t r = 0; r < TASK_KINDS; ++r) {
                         const uint32_t before = at;
-                        for (uint32_t bk = r * SCHED_NB; bk < (r + 1) * SCHED_NB; ++bk)
+                        if (r == SCHED_RANK[TASK_CAND])
+                                cand_first = at;
+                        auto place = [&](const uint32_t bk) {
                                 for (Frag &f : frags) {
                                         const uint32_t c = f.hist[bk];
                                         f.hist[bk] = at; // (count -> the fragment's first place in the bucket)
                                         at += c;
+                                }
+                        };
+                        for (uint32_t bk = r * SCHED_NB; bk < (r + 1) * SCHED_NB; ++bk)
+                                place(bk);
+                        if (r == SCHED_RANK[TASK_CAND]) // (a `cand_rows` batch: k_and's tasks are all in the row buckets)
+                                for (uint32_t bk = CAND_KEY0; bk < SCHED_KEYS; ++bk) {
+                                        if ((bk - CAND_KEY0) % CAND_SUBS == 0)
+                                                cand_qat[(bk - CAND_KEY0) / CAND_SUBS] = at;
+                                        place(bk);
                                 }
                         *per_kernel[r] = at - before;
                 }
@@ -2014,6 +2106,29 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                         P.pset_sched[pos - n_dense] = unit_of_task[ti];
                         }
                 });
+        }
+        // ---- k_and's queues.  A candidate tile probes the planes of the query's other terms: ONE bit per candidate, a 64-byte sector of a 1.25 MB row
+        //      each — in cost order the tasks in flight probe a hundred rows at once and every sector comes from HBM (cfg2: 2.9 GB per step of them).
+        //      The section is cut into one queue per XCD (workgroups draw from the queue of the XCD they run on, and from the next ones when theirs is
+        //      empty).  A batch of few-term conjunctions with long leads (`cand_rows`) orders a queue BY THE ROW ITS TASKS PROBE, every row in ONE
+        //      queue (the keys above; the counting sort placed them): an XCD works through a couple of rows at a time, its 4 MB L2 keeps their sectors
+        //      for the row's next tasks — k_and reads 0.76 GB (PMC, profiles/README.md).  Any other batch: the cost order, dealt round the queues
+        {
+                const uint32_t nc = P.n_cand;
+                uint32_t *const sc = P.sched.p + cand_first;
+                if (cand_rows) {
+                        for (uint32_t x = 0; x <= CAND_QUEUES; ++x)
+                                P.cand_q[x] = x < CAND_QUEUES ? cand_qat[x] - cand_first : nc;
+                } else {
+                        const std::vector<uint32_t> was(sc, sc + nc);
+                        uint32_t pos = 0;
+                        for (uint32_t x = 0; x < CAND_QUEUES; ++x) {
+                                P.cand_q[x] = pos;
+                                for (uint32_t i = x; i < nc; i += CAND_QUEUES)
+                                        sc[pos++] = was[i];
+                        }
+                        P.cand_q[CAND_QUEUES] = pos;
+                }
         }
         // ---- k_phrase's tasks, heaviest first: a task's candidates are bounded by its output region (the lead's documents in its range); in query
         //      order the 4 ms tasks of a head x head phrase started anywhere in the kernel's span and its last fifth ran on a tenth of the

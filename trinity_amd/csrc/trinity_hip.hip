@@ -94,6 +94,8 @@ struct tri_dev {
         trip::FragCache frag_cache; // the planner's per-fragment arrays, recycled from plan to plan (under plan_mu)
 };
 using DevLock = std::lock_guard<std::recursive_mutex>;
+constexpr size_t TICKET_CAND_WORD = 64;        // a batch's ticket words: [0, 64) one per kernel; then k_and's CAND_QUEUES, 64 bytes apart
+constexpr size_t TICKET_BYTES = (TICKET_CAND_WORD + CAND_QUEUES * CAND_TICKET_STRIDE) * 4;
 constexpr size_t POOL_MIN_BYTES = 64u << 10;  // smaller buffers are not worth pooling
 constexpr size_t POOL_IDLE_CAP = 64ull << 30; // idle buffers beyond this are given back to the device (largest first)
 constexpr size_t PINNED_IDLE_MAX = 16;        // idle pinned blocks kept (the longest idle one is dropped for a newly released one)
@@ -491,6 +493,7 @@ namespace {
                              {"planes_split", &tri_options::planes_split},
                              {"plane_max_bytes", &tri_options::plane_max_bytes},
                              {"planes_rebuild", &tri_options::planes_rebuild},
+                             {"cand_xcd", &tri_options::cand_xcd},
                              {"plan_threads", &tri_options::plan_threads},
                              {"probe_max_blocks", &tri_options::probe_max_blocks}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}, {"dense_window_cost", &tri_options::dense_window_cost}};
                 for (const auto &e : table)
@@ -776,7 +779,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                 a += (bytes + 255) & ~(size_t)255;
                 return at;
         };
-        const size_t a_counts = carve((nt + 1) * 4), a_ticket = carve(256), a_build = carve((b->plane_terms.size() + 1) * 8);
+        const size_t a_counts = carve((nt + 1) * 4), a_ticket = carve(TICKET_BYTES), a_build = carve((b->plane_terms.size() + 1) * 8);
         const bool planes_tasks = b->n_planes + b->n_planes8;
         const size_t a_qthr = planes_tasks ? carve((np + 1) * 8) : 0;
         const size_t a_part_counts = scored ? carve((nt + 1) * 4) : 0;
@@ -1015,7 +1018,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 HIP_TRY(hipStreamWaitEvent(dev->stream, b->ix->ev_pc_ready, 0)); // ... and so have the plane cache's rows, should it have been grown since
         HIP_TRY(hipEventRecord(b->ev0, dev->stream));
         if (n) {
-                HIP_TRY(hipMemsetAsync(b->d_ticket, 0, 256, dev->stream));
+                HIP_TRY(hipMemsetAsync(b->d_ticket, 0, TICKET_BYTES, dev->stream));
                 // two persistent kernels back to back on the engine stream: bitmap windows (512 threads), then candidate tiles.
                 // GOOGLE: matching reads the contiguous delta streams, not the chunks (see tri_index::d_dstream)
                 const uint8_t *match_bytes = b->ix->codec == TRI_CODEC_GOOGLE ? b->ix->d_dstream : b->ix->d_index;
@@ -1087,7 +1090,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 if (b->n_cand)
                         TRI_LAUNCH(k_and, b->ix->codec, dim3(std::min<uint32_t>(b->n_cand, (uint32_t)dev->cus * cand_wgs)), dim3(AND_WG), cand_stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched + b->n_dense + b->n_pset + b->n_probe, b->d_qterms,
-                                           b->n_cand, b->d_ticket, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->ix->d_pcache, b->plw);
+                                           (const uint32_t *)(b->d_arena + b->off_cand_q), b->d_ticket + TICKET_CAND_WORD, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->d_qplane, (const uint32_t *)b->ix->d_pcache, b->plw);
                 HIP_TRY(hipGetLastError());
                 if (overlap) {
                         HIP_TRY(hipEventRecord(dev->ev_join, dev->stream2));
@@ -1477,7 +1480,7 @@ extern "C" int tri_batch_sync(tri_batch *b) {
         b->info.dense_ms = b->info.pset_ms = b->info.probe_ms = b->info.cand_ms = b->info.fused_ms = b->info.phrase_ms = b->info.tree_ms = b->info.rest_ms = b->info.term_planes_ms = b->info.planes_ms = 0;
         if (!b->tasks.empty()) {
                 if (hipEventElapsedTime(&ms, b->ev0, b->ev_pl) == hipSuccess)
-                        b->info.term_planes_ms = ms; // includes the 256-byte ticket memset that precedes it
+                        b->info.term_planes_ms = ms; // includes the ticket memset that precedes it
                 if (hipEventElapsedTime(&ms, b->ev_pl, b->ev_a) == hipSuccess)
                         b->info.dense_ms = ms;
                 if (hipEventElapsedTime(&ms, b->ev_a, b->ev_s) == hipSuccess)

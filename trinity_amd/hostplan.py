@@ -12,7 +12,7 @@ _SUMMARY = ["block_bytes", "n_plan", "n_qterms", "n_tasks", "n_fused_maps", "n_q
             "n_dense", "n_cand", "n_fused", "n_fused16", "n_fusedgen", "n_planes", "n_planes8", "plw", "sparse_cap", "out_capacity", "term_bytes", "term_bytes_dense",
             "dense_queries", "cand_queries", "fused_queries", "planes_queries", "unsupported_queries", "rich_R", "sizeof_query", "sizeof_task", "sizeof_fused", "sizeof_phrase",
             "cand_needed_term_bytes", "plane_decoded_bytes", "n_pset", "pset_queries", "n_probe", "probe_queries", "n_units", "off_units", "off_unit_sched", "sizeof_unit",
-            "n_tree", "tree_queries", "n_tree_words", "off_tree", "n_tree_terms", "off_tree_terms", "n_tree_hidden", "off_tree_hidden"]  # fmt: skip
+            "n_tree", "tree_queries", "n_tree_words", "off_tree", "n_tree_terms", "off_tree_terms", "n_tree_hidden", "off_tree_hidden", "off_cand_q"]  # fmt: skip
 
 DEV_QUERY = np.dtype([("nterms", "<u4"), ("term_base", "<u4"), ("out_off", "<u8"), ("out_cap", "<u4"), ("qid", "<u4"), ("first_task", "<u4"), ("ntasks", "<u4"),
                       ("score_base", "<u4"), ("nscore", "<u4"), ("phrase_base", "<u4"), ("nphrases", "<u4"), ("fused_idx", "<u4"), ("form", "<u4")])  # fmt: skip
@@ -120,6 +120,11 @@ class HostPlan:
     @property
     def unit_sched(self):
         return self._view("off_unit_sched", self.s["n_pset"] + self.s["n_probe"], "<u4")
+
+    @property
+    def cand_q(self):
+        """k_and's queues, one per XCD: queue x is the TASK_CAND section of sched at [cand_q[x], cand_q[x + 1])."""
+        return self._view("off_cand_q", 9, "<u4")
 
     @property
     def qterms(self):
