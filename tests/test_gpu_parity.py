@@ -203,6 +203,23 @@ def test_candidate_tiles_probe_term_planes(request, world):
             assert int(h) == O.fnv1a_docs(want)
 
 
+def test_candidate_tile_queues_per_xcd(large):
+    """k_and draws its tasks from one queue per XCD.  On the 2M-document segment a batch of two- and three-term conjunctions has leads long enough
+    for the planner to order the queues by the plane row the tasks probe (`cand_xcd`, the default: planner.hpp "k_and's queues"); without it the
+    cost order is dealt round the queues.  Either way every task runs exactly once, whoever draws it: the docID sets equal the oracle's."""
+    w, T = large, large.T
+    texts = [f"t{a} t{b}" for a, b in T.gen_queries(w.V, 31, 600, 2).tolist()] + [f"t{a} t{b} t{c}" for a, b, c in T.gen_queries(w.V, 32, 100, 3).tolist()]
+    progs = [O.parse_query(t) for t in texts]
+    wants = [w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)[0] for p in progs]
+    for xcd in (1, 0):
+        with options(w.dev, cand_xcd=xcd):
+            sets, hashes, info = run_docs_only(w, progs)
+        assert info["cand_queries"] > 400, info["cand_queries"]
+        for t, got, want, h in zip(texts, sets, wants, hashes):
+            assert np.array_equal(got, want), (xcd, t, len(got), len(want))
+            assert int(h) == O.fnv1a_docs(want)
+
+
 @pytest.mark.parametrize("k", [3, 5])
 def test_and_k_terms_matches_oracle(small, dense, k):
     for w in (small, dense):
