@@ -197,6 +197,9 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                         nnt = atomicAdd(ticket, 1u);
                 }
                 uint32_t produced = 0, par = 0;
+                const uint32_t pair_row0 = uni(U.row[0]), pair_row1 = uni(U.row[1]), pair_tt1 = uni(U.tt[1]);
+                const bool pair = nterms == 2 && pair_row0 != PL_NONE && pair_row1 != PL_NONE;
+                const bool pair_and = pair_tt1 & QT_GROUP, pair_not = pair_tt1 & QT_NOT; // (the second term opens a group of its own: AND, or AND-NOT)
                 for (uint32_t sw = w_begin * SPAN_WORDS; sw < w_end * SPAN_WORDS; sw += PSET_STEP_WORDS, par ^= 1u) {
                         const uint32_t word0 = sw + tid * PSET_PER; // this lane's first word of the step
                         // ---- the window's survivors, this lane's eight words: OR inside a group, AND across groups, AND-NOT for the excluded group
@@ -205,6 +208,17 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
 #pragma unroll
                         for (uint32_t j = 0; j < PSET_PER; ++j)
                                 acc[j] = grp[j] = 0;
+                        if (pair) {
+                                // two terms with planes — the batch's usual query: both terms' words travel together (the general loop below waits for a
+                                // term's two loads before it issues the next term's: a round trip per term and step)
+                                const uint4 *pa = (const uint4 *)(planes + (size_t)pair_row0 * PL_PLANES * plw + word0);
+                                const uint4 *pb = (const uint4 *)(planes + (size_t)pair_row1 * PL_PLANES * plw + word0);
+                                const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+                                const uint32_t av[PSET_PER] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bv[PSET_PER] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                                for (uint32_t j = 0; j < PSET_PER; ++j)
+                                        acc[j] = !pair_and ? av[j] | bv[j] : pair_not ? av[j] & ~bv[j] : av[j] & bv[j];
+                        } else
                         for (uint32_t k = 0; k <= nterms; ++k) {
                                 uint32_t tt = QT_GROUP, row = 0; // (k == nterms: the last group is folded in)
                                 if (k < nterms) {
