@@ -211,7 +211,13 @@ class Pipeline:
         # only when the compiler starts a set before the main loop has released the one it read back: rare while a create is shorter than a
         # step, the rule once they take about as long).  Their buffers go into the device pool NOW, so that no timed step pays a cold
         # allocation (cfg2: a 6 GB output region, 77 ms in the middle of a timed region; cfg5: 17 GB, 0.2 .. 484 ms)
-        for spare in [wl.create_set() for _ in range(4)]:
+        spares = []
+        try:
+            for _ in range(4):
+                spares.append(wl.create_set())
+        except Exception:  # (a batch so large that five sets do not fit the device: the loop then allocates what it needs as it goes — the pool gives idle buffers back)
+            pass
+        for spare in spares:
             for b in spare:
                 b.close()
         # the compiler: tri_batch_create back to back on its own thread, one compiled set waiting at most (with a create per step handed over
