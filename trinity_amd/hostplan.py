@@ -72,7 +72,7 @@ class HostIndex:
 
 
 class HostPlan:
-    """One planned batch: .s (summary dict), .ms (the four phase times), and the plan's arrays as numpy views of its block."""
+    """One planned batch: .s (summary dict), .ms (the four phase times), and the plan's arrays as numpy views of (a copy of) its block."""
 
     def __init__(self, hindex, programs, flags, topk=0, similarity=0, threads=1, options=None, cus=256, flat=None):
         self.nq = len(programs) if flat is None else flat[1].shape[0]
@@ -92,7 +92,8 @@ class HostPlan:
         self.ms = ms
         assert self.s["sizeof_query"] == DEV_QUERY.itemsize and self.s["sizeof_task"] == DEV_TASK.itemsize
         p = _lib().tri_host_plan_block(self.h)
-        self.block = np.ctypeslib.as_array(p, shape=(max(1, self.s["block_bytes"]),))
+        # (a copy of its own: the arrays handed out below are views of it and stay readable after close() — a failing test's report formats them then)
+        self.block = np.ctypeslib.as_array(p, shape=(max(1, self.s["block_bytes"]),)).copy()
         self.slot_of_query = np.zeros(max(1, self.nq), dtype=np.uint32)
         self.qstatus = np.zeros(max(1, self.nq), dtype=np.int32)
         _lib().tri_host_plan_query_maps(self.h, self.slot_of_query.ctypes.data, self.qstatus.ctypes.data)
