@@ -7,10 +7,11 @@
  * whose work it takes over; INTEGRATION.md shows the binding a Trinity maintainer would add.
  *
  * Threading: one tri_dev per (host thread, device) — with ONE exception, made for a caller that keeps the engine stream fed: while one
- * thread runs, awaits, reads and destroys batches of a device (tri_batch_run / _sync / the result calls / _destroy), ONE other thread may
+ * thread runs, awaits, reads and destroys batches of a device (tri_batch_run / _sync / the result calls / _destroy), other threads may
  * compile the next ones (tri_batch_create) on the same device; the handle's pools, the index's plane cache and everything that enqueues on
- * its streams are locked for that (the host planner — most of a create — runs outside that lock; creates from several threads plan one after
- * the other).  Everything else (uploads, options, the write side) stays one thread at a time.  tri_last_error() is per thread.
+ * its streams are locked for that.  The host planner — most of a create — runs outside that lock, in one of the handle's TWO planner
+ * contexts (a pool of host threads each): two creates plan side by side, a third waits for a context.  Everything else (uploads, options,
+ * the write side) stays one thread at a time.  tri_last_error() is per thread.
  */
 #ifndef TRINITY_HIP_H
 #define TRINITY_HIP_H
@@ -24,6 +25,7 @@ extern "C" {
 #define TRI_ABI_VERSION 8 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
                              4: tri_batch_info grew (term planes, k_planes), tri_batch_query_status, tri_comm_create_custom; 5: tri_encode_google_payloads;
                              6: tri_batch_info.create_ms / create_plan_ms / *_bound_bytes, options plane_max_bytes / plan_threads, tri_cbatch_query_status;
+                             7: TASK_TREE (any query tree), tri_batch_info.tree_ms / tree_queries / tree_scratch_bytes, tri_commit_* / tri_merge_google;
                              8: tri_batch_docsets (every query's docID set in one call), tri_merge_lucene, option planes_rebuild */
 
 /* status codes */

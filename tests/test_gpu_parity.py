@@ -426,6 +426,29 @@ def test_docsets_in_one_call(request, world):
     sb.close()
 
 
+@pytest.mark.parametrize("world", ["large", "medium_l"])
+def test_docsets_with_phrase_leaves_of_trees(request, world):
+    """tri_batch_docsets over a batch whose TASK_TREE queries have multi-word phrase LEAVES: the planner evaluates such a leaf as a hidden query
+    (qid 0xffffffff, no place in the caller's order) whose tasks must not be delivered — round 5 copied their segments to flat[0 ...] over the
+    first query's set, and past the buffer's end when the hidden phrase matched more documents than the batch delivers (`t5 NOT "t0 t1"`)."""
+    w = request.getfixturevalue(world)
+    T, V = w.T, w.V
+    texts = ["t7 t9", 't2 OR "t0 t1"', 't5 NOT "t0 t1"', f't{V - 1} NOT "t0 t1"', '"t0 t1" OR "t1 t2"', "t3 t4", '(t2 OR "t1 t0") NOT t3']
+    progs = [O.parse_query(t) for t in texts]
+    want = [w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)[0] for p in progs]
+    for flags in (T.FLAG_DOCUMENTS_ONLY, T.FLAG_MATCHED_TERMS):
+        b = T.Batch(w.ix, progs, flags)
+        b.run()
+        b.sync()
+        assert b.info()["tree_queries"] >= 4
+        for rep in range(2):
+            flat, offs = b.docsets()
+            assert offs.tolist() == np.concatenate([[0], np.cumsum([len(x) for x in want])]).tolist()
+            for i, t in enumerate(texts):
+                assert np.array_equal(flat[int(offs[i]) : int(offs[i + 1])], want[i]), t
+        b.close()
+
+
 @pytest.mark.parametrize("world", ["large", "dense", "medium_l"])
 def test_docsets_delivered_as_bitmaps(request, world):
     """RESULT_BITMAP (dev_structs.hpp): a DocumentsOnly union / conjunction of head terms expected to match one document in 32 or more is held

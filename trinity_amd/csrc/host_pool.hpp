@@ -26,13 +26,25 @@ class HostPool {
       public:
         // `threads` includes the calling thread: threads - 1 workers are started (fewer when thread creation fails — the pool then
         // simply has fewer hands; run() still completes on the caller alone)
-        explicit HostPool(unsigned threads, bool pin = true, unsigned hot_us = 3000) : hot_us_(hot_us) {
+        // `part` of `nparts`: a process that keeps several pools (tri_dev's planner contexts: two batches compiled side by side) gives each its own
+        // stretch of the candidate CPUs — a rank's slice is cut into nparts contiguous pieces; without a slice pool `part` starts `part * threads`
+        // CPUs past the creating thread's — so that no two pools' pollers share a CPU.
+        explicit HostPool(unsigned threads, bool pin = true, unsigned hot_us = 3000, unsigned part = 0, unsigned nparts = 1) : hot_us_(hot_us) {
                 std::vector<int> cpus;
                 int base = 0;
                 if (pin) {
                         cpus = pin_candidates(&base);
+                        if (nparts > 1 && part < nparts) {
+                                if (base < 0 && cpus.size() >= nparts) { // (a rank's slice: this pool's piece of it)
+                                        const size_t lo = cpus.size() * part / nparts, hi = cpus.size() * (part + 1) / nparts;
+                                        cpus = std::vector<int>(cpus.begin() + (long)lo, cpus.begin() + (long)hi);
+                                } else if (base >= 0)
+                                        base += (int)(part * threads);
+                        }
                         if (threads > cpus.size() + 1 && !cpus.empty()) // (a rank's slice may be narrower than the threads asked for: no two pollers on one CPU)
                                 threads = (unsigned)cpus.size() + 1;
+                        if (base < 0 && cpus.size() < 2) // a one-CPU slice: the unpinned caller would share that CPU with a polling worker — the caller plans alone
+                                threads = 1;
                 }
                 for (unsigned i = 1; i < threads; ++i) {
                         try {
@@ -54,7 +66,9 @@ class HostPool {
         // cpus[(base + i) % cpus.size()]).  One process per GPU is the deployment (torch.distributed.run / any launcher that exports LOCAL_RANK and
         // LOCAL_WORLD_SIZE): the ranks of a node then take DISJOINT contiguous slices of the affinity mask — slice r of LOCAL_WORLD_SIZE — whatever
         // CPU each rank's creating thread happens to run on (eight ranks started side by side land within a few CPUs of each other: their fifteen
-        // spinning workers each would otherwise pile onto the same cores).  Without those variables: the CPUs next to the creating thread's.
+        // spinning workers each would otherwise pile onto the same cores).  Without those variables — or with values that do not parse as
+        // 0 <= LOCAL_RANK < LOCAL_WORLD_SIZE <= the mask's CPUs (strtol: a non-numeric value reads as 0 / fails the range check) — the CPUs
+        // next to the creating thread's, as for a single process.
         static std::vector<int> pin_candidates(int *base) {
                 std::vector<int> cpus;
                 cpu_set_t allowed;

@@ -1037,6 +1037,10 @@ __global__ __launch_bounds__(DENSE_WG, TRI_DENSE_WAVES) void k_and_dense(const u
 }
 
 // candidate-tile tasks (TASK_CAND)
+#ifndef TRI_AND_PROBES
+#define TRI_AND_PROBES 8
+#endif
+constexpr int AND_PROBES = TRI_AND_PROBES; // plane probes of a lane in flight together
 template <int CODEC>
 #ifndef TRI_AND_WAVES
 #define TRI_AND_WAVES 4
@@ -1154,18 +1158,18 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                         // (eight probes of a lane in flight together: one at a time, a tile of 8192 candidates was 32 dependent round trips —
                                         //  12 us of a 24 us task at cfg2)
                                         const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
-                                        for (uint32_t j0 = tid; j0 < C; j0 += AND_WG * 8) {
-                                                uint32_t doc[8], w[8];
+                                        for (uint32_t j0 = tid; j0 < C; j0 += AND_WG * AND_PROBES) {
+                                                uint32_t doc[AND_PROBES], w[AND_PROBES];
 #pragma unroll
-                                                for (int u = 0; u < 8; ++u) {
+                                                for (int u = 0; u < AND_PROBES; ++u) {
                                                         const uint32_t j = j0 + u * AND_WG;
                                                         doc[u] = j < C ? sh.cand[phys(j)] : 0u;
                                                 }
 #pragma unroll
-                                                for (int u = 0; u < 8; ++u)
+                                                for (int u = 0; u < AND_PROBES; ++u)
                                                         w[u] = pa[doc[u] >> 5];
 #pragma unroll
-                                                for (int u = 0; u < 8; ++u) {
+                                                for (int u = 0; u < AND_PROBES; ++u) {
                                                         const uint32_t j = j0 + u * AND_WG;
                                                         if (j < C && ((w[u] >> (doc[u] & 31u)) & 1u))
                                                                 atomicOr(&sh.hit[j >> 5], 1u << (j & 31u));

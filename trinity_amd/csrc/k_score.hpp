@@ -530,6 +530,8 @@ __global__ __launch_bounds__(256) void k_deliver_docsets(const DevQuery *__restr
         if (task_onepass(tk.kind) && tk.kind != TASK_FUSED_GEN)
                 return; // (a one-pass scored task keeps no docID set; uniform)
         const DevQuery q = plan[tk.slot];
+        if (q.qid == 0xffffffffu)
+                return; // (a hidden phrase query — a leaf of a TASK_TREE query: no caller query, no place in flat[]; uniform)
         const uint32_t c = counts[tix];
         // the matches of the query's earlier tasks
         uint64_t before = 0;

@@ -84,14 +84,21 @@ struct tri_dev {
         std::vector<std::pair<size_t, void *>> pinned_idle;
         // ... and the HIP events of a batch (nine per batch)
         std::vector<hipEvent_t> events_idle;
-        std::unique_ptr<HostPool> hpool; // the planner's host threads: started by the first batch large enough to be planned in fragments
+        // The planner's host threads: PLAN_CTXS independent planner contexts — a pool of host threads and the per-fragment arrays it recycles, under a
+        // lock of their own — so that TWO threads may compile batches of this device at the same time (a create is 0.6 - 1.1 ms of host planning for
+        // 16 K queries on 8 - 16 threads and scales no further: a caller whose steps are shorter than that compiles two batches side by side).  A
+        // context's pool is started by the first large batch that finds the context free; pool k pins its workers to its own stretch of the CPUs.
+        static constexpr unsigned PLAN_CTXS = 2;
+        struct PlanCtx {
+                std::mutex mu;                  // one batch at a time per context
+                std::unique_ptr<HostPool> pool; // (created under mu)
+                trip::FragCache frag_cache;     // (under mu)
+        } planners[PLAN_CTXS];
         // The batch calls of one handle may come from TWO host threads: one compiling the next batch (tri_batch_create) while the other runs,
         // awaits and releases earlier ones (tri_batch_run / _sync / _destroy) — bench.py's loop; the planner's share of a create (most of it)
         // runs outside the lock, the pools above, the index's plane cache and everything that enqueues on the streams inside it.  Every other
         // entry point (uploads, options, encoders): one thread at a time, as before.
         std::recursive_mutex mu;
-        std::mutex plan_mu; // the planner's host threads take one batch at a time: creates from two threads plan one after the other
-        trip::FragCache frag_cache; // the planner's per-fragment arrays, recycled from plan to plan (under plan_mu)
 };
 using DevLock = std::lock_guard<std::recursive_mutex>;
 constexpr size_t TICKET_CAND_WORD = 64;        // a batch's ticket words: [0, 64) one per kernel; then k_and's CAND_QUEUES, 64 bytes apart
@@ -102,7 +109,8 @@ constexpr size_t PINNED_IDLE_MAX = 16;        // idle pinned blocks kept (the lo
 
 static void dev_destroy(tri_dev *d) {
         hipSetDevice(d->device);
-        d->hpool.reset();
+        for (auto &pc : d->planners)
+                pc.pool.reset();
         hipEventDestroy(d->ev_fork);
         hipEventDestroy(d->ev_join);
         for (hipEvent_t e : d->events_idle)
@@ -738,22 +746,33 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         in.flags = flags;
         in.topk = topk;
         in.similarity = similarity;
-        if (DevLock g(dev->mu); nq >= 1024 && !dev->hpool) { // (batches below a thousand queries are planned on the calling thread)
-                const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-                const unsigned want = dev->opt.plan_threads ? (unsigned)std::min<uint64_t>(dev->opt.plan_threads, 64) : std::min(16u, hw);
-                if (want > 1) {
-                        try {
-                                dev->hpool = std::make_unique<HostPool>(want);
-                        } catch (...) { // (no threads to be had: the calling thread plans alone)
-                        }
-                }
-        }
         {
                 std::string err;
                 int rc;
                 try {
-                        std::lock_guard<std::mutex> plan_lock(dev->plan_mu);
-                        rc = plan_batch(*ix, env, in, dev->hpool.get(), [&](size_t bytes) { return pinned_alloc(dev, bytes, &b->block_cap); }, *b, err, &dev->frag_cache);
+                        // a free planner context (the first one when both are busy: creates from more threads than contexts plan one after the other)
+                        unsigned which = 0;
+                        std::unique_lock<std::mutex> plan_lock(dev->planners[0].mu, std::try_to_lock);
+                        for (unsigned k = 1; k < tri_dev::PLAN_CTXS && !plan_lock.owns_lock(); ++k) {
+                                plan_lock = std::unique_lock<std::mutex>(dev->planners[k].mu, std::try_to_lock);
+                                which = k;
+                        }
+                        if (!plan_lock.owns_lock()) {
+                                which = 0;
+                                plan_lock = std::unique_lock<std::mutex>(dev->planners[0].mu);
+                        }
+                        tri_dev::PlanCtx &pc = dev->planners[which];
+                        if (nq >= 1024 && !pc.pool) { // (batches below a thousand queries are planned on the calling thread)
+                                const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+                                const unsigned want = dev->opt.plan_threads ? (unsigned)std::min<uint64_t>(dev->opt.plan_threads, 64) : std::min(16u, hw);
+                                if (want > 1) {
+                                        try {
+                                                pc.pool = std::make_unique<HostPool>(want, true, 3000, which, tri_dev::PLAN_CTXS);
+                                        } catch (...) { // (no threads to be had: the calling thread plans alone)
+                                        }
+                                }
+                        }
+                        rc = plan_batch(*ix, env, in, pc.pool.get(), [&](size_t bytes) { return pinned_alloc(dev, bytes, &b->block_cap); }, *b, err, &pc.frag_cache);
                 } catch (const std::bad_alloc &) {
                         return fail(TRI_ERR_NOMEM, "tri_batch_create: out of host memory");
                 }
@@ -841,6 +860,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         uint32_t *fresh = nullptr;
                         HIP_TRY(pool_alloc(dev, (void **)&fresh, ((size_t)want + 1) * row + 64));
                         hipEvent_t drained = nullptr;
+                        std::vector<void *> outgrown; // the buffers this growth replaces
                         HIP_TRY(event_get(dev, &drained));
                         if (!ix->ev_pc_ready)
                                 HIP_TRY(event_get(dev, &ix->ev_pc_ready));
@@ -885,23 +905,26 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                         HIP_TRY(hipMemsetAsync(ix->d_term_row, 0xff, (ix->terms.size() + 1) * 4, dev->stream_up));
                                 } else if (!same)
                                         HIP_TRY(hipMemsetAsync(ix->d_term_row, 0xff, (ix->terms.size() + 1) * 4, dev->stream_up));
-                                if (ix->d_prank) { // (retired with the rows: same readers)
-                                        for (void *old : {(void *)ix->d_prank, (void *)ix->d_phs, (void *)ix->d_hs_off, (void *)ix->d_ph_pairs}) {
-                                                hipEvent_t e2 = nullptr;
-                                                HIP_TRY(event_get(dev, &e2));
-                                                HIP_TRY(hipEventRecord(e2, dev->stream));
-                                                ix->pc_retired.emplace_back(old, e2);
-                                        }
-                                }
+                                if (ix->d_prank) // (retired with the rows: same readers, and the copies above read them)
+                                        for (void *old : {(void *)ix->d_prank, (void *)ix->d_phs, (void *)ix->d_hs_off, (void *)ix->d_ph_pairs})
+                                                outgrown.push_back(old);
                                 ix->d_prank = prank, ix->d_phs = phs, ix->d_hs_off = hso, ix->d_ph_pairs = pairs;
                                 ix->rank_term = rt;
                                 ix->ph_built.resize(want, 0);
                         }
                         HIP_TRY(hipEventRecord(ix->ev_pc_ready, dev->stream_up));
+                        // The outgrown buffers are retired on events recorded on the UPLOAD stream, behind the copies that read them: that point is past
+                        // the engine stream's earlier readers too (stream_up waited for `drained`).  (Round 5 retired them on events of the engine
+                        // stream recorded BEFORE the copies were enqueued: the next tri_batch_create could pool a buffer the copy had not read yet.)
                         if (ix->d_pcache)
-                                ix->pc_retired.emplace_back(ix->d_pcache, drained);
-                        else
-                                event_put(dev, drained);
+                                outgrown.push_back(ix->d_pcache);
+                        for (void *old : outgrown) {
+                                hipEvent_t e2 = nullptr;
+                                HIP_TRY(event_get(dev, &e2));
+                                HIP_TRY(hipEventRecord(e2, dev->stream_up));
+                                ix->pc_retired.emplace_back(old, e2);
+                        }
+                        event_put(dev, drained);
                         ix->d_pcache = fresh;
                         ix->pc_cap = want;
                         ix->pc_plw = b->plw;
@@ -1047,10 +1070,13 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         }
                         if (!build.empty()) {
                                 HIP_TRY(hipMemcpyAsync(b->d_build, build.data(), build.size() * 4, hipMemcpyHostToDevice, dev->stream)); // (pageable source: staged before the call returns)
-                                const dim3 grid(b->plw / PL_WORDS, (uint32_t)(build.size() / 2));
-                                TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff, ix->d_win,
-                                           ix->d_terms, (const uint32_t *)b->d_build, ix->d_pcache, b->plw, ix->d_prank);
-                                HIP_TRY(hipGetLastError());
+                                const uint32_t nrows = (uint32_t)(build.size() / 2);
+                                for (uint32_t y0 = 0; y0 < nrows; y0 += 65535u) { // (gridDim.y <= 65535)
+                                        const dim3 grid(b->plw / PL_WORDS, std::min(65535u, nrows - y0));
+                                        TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff,
+                                                   ix->d_win, ix->d_terms, (const uint32_t *)b->d_build + 2 * (size_t)y0, ix->d_pcache, b->plw, ix->d_prank);
+                                        HIP_TRY(hipGetLastError());
+                                }
                                 for (size_t i = 1; i < build.size(); i += 2)
                                         ix->pc_built[build[i]] = 1;
                         }
@@ -1193,12 +1219,15 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                                         const dim3 grid(b->plw / PL_WORDS, 1);
                                                         TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff,
                                                                    ix->d_win, ix->d_terms, (const uint32_t *)d_pairs + i, ix->d_pcache, b->plw, ix->d_prank);
+                                                        HIP_TRY(hipGetLastError());
                                                 }
                                 }
                                 const uint32_t npairs = (uint32_t)(hits_build.size() / 2);
-                                hipLaunchKernelGGL(k_term_hits, dim3((max_blocks + 255) / 256, npairs), dim3(256), 0, dev->stream, ix->d_index, ix->d_blk_off, ix->d_blk_hits, ix->d_terms,
-                                                   (const uint32_t *)d_pairs, (const uint64_t *)ix->d_hs_off, ix->d_phs, ix->d_term_row);
-                                HIP_TRY(hipGetLastError());
+                                for (uint32_t y0 = 0; y0 < npairs; y0 += 65535u) { // (gridDim.y <= 65535: a small index at a high plane_div makes almost every term eligible)
+                                        hipLaunchKernelGGL(k_term_hits, dim3((max_blocks + 255) / 256, std::min(65535u, npairs - y0)), dim3(256), 0, dev->stream, ix->d_index, ix->d_blk_off,
+                                                           ix->d_blk_hits, ix->d_terms, (const uint32_t *)d_pairs + 2 * (size_t)y0, (const uint64_t *)ix->d_hs_off, ix->d_phs, ix->d_term_row);
+                                        HIP_TRY(hipGetLastError());
+                                }
                         }
                 }
                 if (!b->ptasks.empty()) {
@@ -2750,9 +2779,9 @@ extern "C" int tri_commit_lucene(tri_dev *dev, const uint32_t *term_ids, const u
 static int merge_device(tri_dev *dev, const int codec, tri_index *const *parts, size_t nparts, const uint32_t *part_terms, size_t nterms, uint8_t *index_out, size_t cap, size_t *index_len,
                         uint8_t *hits_out, size_t hits_cap, size_t *hits_len, tri_term *terms_out, tri_commit_stats *stats) {
         if (!dev || !parts || !nparts || (nterms && (!part_terms || !terms_out)) || !index_len)
-                return fail(TRI_ERR_INVALID, "tri_merge_google: null argument");
+                return fail(TRI_ERR_INVALID, "tri_merge_%s: null argument", codec == TRI_CODEC_GOOGLE ? "google" : "lucene");
         if (nparts > 65535)
-                return fail(TRI_ERR_INVALID, "tri_merge_google: at most 65535 participants (google_codec.cpp:186: uint16_t participantsCnt)");
+                return fail(TRI_ERR_INVALID, "tri_merge_%s: at most 65535 participants (google_codec.cpp:186 / lucene_codec.cpp:963: uint16_t participantsCnt)", codec == TRI_CODEC_GOOGLE ? "google" : "lucene");
         HIP_TRY(hipSetDevice(dev->device));
         for (size_t p = 0; p < nparts; ++p) {
                 if (!parts[p] || parts[p]->dev != dev || parts[p]->codec != codec)
