@@ -381,6 +381,57 @@ def test_or_and_mixed_scored_topk_match_oracle(request, world, n, k):
         np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("codec", [1, 2])
+def test_plane_rows_are_built_by_need(T, dev, codec):
+    """The index's plane cache holds a row in two parts (dev_structs.hpp: PL_HI): plane 0 — all a DocumentsOnly batch reads — is built when any batch's run
+    names the term, the high part (nested planes 1 .. 3 + the level words: six times as large) only once a SCORED batch does.  One fresh index,
+    DocumentsOnly -> scored (the one-pass kernel and match-then-score) -> DocumentsOnly again, every result checked against the oracle; what each run decoded
+    says which parts were built when."""
+    w = World(T, dev, 60000, 3000, 10, 11, codec=codec)
+    texts = ["t0 t1", "t0 OR t3", "t2 t5 t9", "t1 (t4 OR t7)", "t0 t1 t2 t3 t4", "t6 OR t8 OR t11 OR t40 OR t90", "t3 t5 NOT t1", f"t0 t{w.V - 1}", f"t{w.V // 2} t1"]
+    progs = [O.parse_query(t) for t in texts]
+
+    def docs_only():
+        sets, _, info = run_docs_only(w, progs)
+        for t, p, got in zip(texts, progs, sets):
+            want, _ = w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)
+            assert np.array_equal(got, want), (t, len(got), len(want))
+        return info
+
+    def scored(**opts):
+        with options(w.dev, **opts):
+            b = T.Batch(w.ix, progs, T.FLAG_ACCUMULATED_SCORE, topk=10)
+        b.run()
+        b.sync()
+        d, s, c = b.topk_results()
+        counts = b.counts()
+        info = b.info()
+        b.close()
+        for i, t in enumerate(texts):
+            docs, scores = w.ora.exec(progs[i], O.FLAG_ACCUM_SCORE)
+            assert int(counts[i]) == len(docs), t
+            td, ts = w.ora.topk(docs, scores, 10)
+            assert d[i, : len(td)].tolist() == td.tolist(), t
+            np.testing.assert_allclose(s[i, : len(td)], ts, rtol=1e-5, atol=0)
+        return info
+
+    try:
+        i1 = docs_only()
+        assert i1["plane_terms"] >= 5 and i1["term_planes_decoded_bytes"] > 0
+        per_row0 = i1["plane_bytes"] // i1["plane_terms"]  # plane 0 alone: a bitmap over the docID space
+        assert i1["plane_bytes"] == i1["plane_terms"] * per_row0 and per_row0 >= w.D // 8
+        assert docs_only()["term_planes_decoded_bytes"] == 0  # (its rows are there)
+        i2 = scored(dense_min_postings=0)  # (every eligible query through the one-pass kernel: k_planes reads the high parts)
+        assert i2["planes_queries"] >= 3 and i2["term_planes_decoded_bytes"] > 0 and i2["plane_bytes"] == i2["plane_terms"] * 7 * per_row0
+        i3 = scored(fused=0, planes=3)  # (match, then score: k_score reads the level words of the same rows)
+        assert i3["planes_queries"] == 0 and i3["plane_bytes"] == i3["plane_terms"] * 7 * per_row0
+        assert scored(dense_min_postings=0)["term_planes_decoded_bytes"] == 0
+        i4 = docs_only()
+        assert i4["term_planes_decoded_bytes"] == 0 and i4["plane_bytes"] == i1["plane_bytes"]
+    finally:
+        w.ix.close()
+
+
 def test_union_of_head_terms_large(large):
     w, T = large, large.T
     texts = ["t0 OR t1", "t0 OR t1 OR t2 OR t3 OR t4", "t0 t1 (t2 OR t3 OR t4)", "(t0 OR t1) (t2 OR t3) t4", "t100000 OR t150000 OR t199999"]

@@ -141,9 +141,11 @@ static_assert(sizeof(DevTreeNode) == 32, "eight words per node");
 // the one-pass kinds (decode -> match -> score -> top-K inside one kernel: k_fused / k_planes); the others materialise docID sets
 TRI_HD constexpr bool task_onepass(const uint32_t kind) { return kind >= TASK_FUSED && kind <= TASK_PLANES8; }
 
-// ---- term planes: per batch LAUNCH, every head term the batch's queries share is decoded ONCE (k_term_planes) into two bitmaps over the
-//      docID space — A: the document holds the term, B: its frequency there is not 1, C: nor 2 — which the matching kernels then read instead of
-//      decoding the term's list again for every query that names it (under Zipf a handful of terms carry most of a batch's postings)
+// ---- term planes: every head term the queries of an index's batches share is decoded ONCE per index (k_term_planes, the first time a batch's run names
+//      it; the rows live in tri_index's plane cache) into bitmaps over the docID space, which the matching kernels then read instead of decoding the
+//      term's list again for every query that names it (under Zipf a handful of terms carry most of a batch's postings).  A row has TWO parts, kept in
+//      two regions and built BY NEED: plane 0 (the document holds the term: all a DocumentsOnly batch reads — k_and's probes, k_psets' / k_and_dense's
+//      words, k_phrase's rank records) and, only once a scored batch names the row, the HIGH part: nested planes 1 .. PL_STORED - 1 and the level words
 constexpr uint32_t PL_W = 32768;          // documents per plane window (k_term_planes, k_planes)
 constexpr uint32_t PL_WORDS = PL_W / 32;  // words of one plane per window
 constexpr uint32_t PL_NONE = 0xffffffffu; // "this term has no plane in this batch"
@@ -156,7 +158,10 @@ constexpr uint32_t PL_LEVEL_WORDS = 3;    // ... and after them the same levels 
 constexpr uint32_t PL_STORED = 4;         // the nested planes a row actually holds: 0 .. PL_STORED - 1 (f >= 1 .. f >= 4).  A sweep that wants "f > c" for a higher c streams
                                           // plane PL_STORED - 1 instead (a superset: the level words sort it out) — the planes above it are one bit in a thousand and cost a
                                           // full plane each to build, to keep and to stream
-constexpr uint32_t PL_PLANES = PL_STORED + PL_LEVEL_WORDS; // words of a term's row per word of the docID space (the row's stride is PL_PLANES * plw)
+constexpr uint32_t PL_PLANES = PL_STORED + PL_LEVEL_WORDS; // words of a term's row per word of the docID space, both parts together (a TASK_TREE batch's own rows keep them side by side: stride PL_PLANES * plw)
+constexpr uint32_t PL_HI = PL_PLANES - 1;                 // ... of its HIGH part: nested planes 1 .. PL_STORED - 1 (plane k at (k - 1) * plw), then the interleaved level words (at
+                                                          // PL_HI_LEVELS * plw + 3 w).  Plane cache: plane 0 of row r = planes0 + r * plw; its high part = planes_hi + r * PL_HI * plw
+constexpr uint32_t PL_HI_LEVELS = PL_STORED - 1;
 constexpr uint32_t PL_RANK_WORDS = 16;     // ... a 64-byte record: [0] the posting index of the group's first document, [1 .. 8] the group's eight plane-0 words (one line tells a document's rank)
 constexpr uint32_t PL_RANK_DOCS = 256;     // a row's rank directory (tri_index::d_prank) has an entry per this many documents: the posting index of the group's first document
 constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64).  The entry's

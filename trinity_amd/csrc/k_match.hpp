@@ -566,7 +566,7 @@ __device__ __forceinline__ void dense_pass(DenseShared &sh, const uint8_t *__res
                 // of plane A, OR-ed into the group's bitmap — 8 coalesced loads per thread instead of a walk over the term's rows
                 const uint32_t prow = uni(sh.seg_plane[k]);
                 if (prow != PL_NONE) {
-                        const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw + (w0 >> 5);
+                        const uint32_t *pa = planes + (size_t)prow * plw + (w0 >> 5);
                         const uint32_t wbase = k < ksplit ? 0u : BM_B_WORDS;
 #pragma unroll
                         for (uint32_t j = 0; j < SPAN_WORDS / WG; ++j) {
@@ -825,7 +825,7 @@ __device__ __forceinline__ void dense_task(DenseShared &sh, const uint8_t *__res
                                         break;
                                 if (tt & QT_GROUP)
                                         cur_neg = tt & QT_NOT;
-                                const uint4 *pa = (const uint4 *)(planes + (size_t)uni(sh.seg_plane[k]) * PL_PLANES * plw + (w0 >> 5) + tid * PER);
+                                const uint4 *pa = (const uint4 *)(planes + (size_t)uni(sh.seg_plane[k]) * plw + (w0 >> 5) + tid * PER);
                                 const uint4 v0 = pa[0], v1 = pa[1];
                                 grp[0] |= v0.x, grp[1] |= v0.y, grp[2] |= v0.z, grp[3] |= v0.w;
                                 grp[4] |= v1.x, grp[5] |= v1.y, grp[6] |= v1.z, grp[7] |= v1.w;
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                         // the term has a plane (k_term_planes decoded it once for the whole batch): advance(candidate) is a bit probe
                                         // (eight probes of a lane in flight together: one at a time, a tile of 8192 candidates was 32 dependent round trips —
                                         //  12 us of a 24 us task at cfg2)
-                                        const uint32_t *pa = planes + (size_t)prow * PL_PLANES * plw;
+                                        const uint32_t *pa = planes + (size_t)prow * plw; // (plane 0 of the row: the plane cache's first region)
                                         for (uint32_t j0 = tid; j0 < C; j0 += AND_WG * AND_PROBES) {
                                                 uint32_t doc[AND_PROBES], w[AND_PROBES];
 #pragma unroll

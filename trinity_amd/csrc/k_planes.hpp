@@ -7,8 +7,9 @@
 
 // Under Zipf a handful of terms carry most of a batch's postings (at the 10M-document configuration the 40 most frequent terms
 // hold 98 % of the postings the 5-term queries of SURVEY §8(d) cfg3 touch), and the reference decodes such a list again for every
-// query that names it (Decoder::init + next() per query, google_codec.cpp:777-819 / lucene_codec.cpp:568-594).  Here every LAUNCH
-// decodes each of those lists ONCE — k_term_planes, from the segment's own codec bytes — into PL_NESTED nested bitmaps over the docID space (+ the same levels bit-sliced, for probes):
+// query that names it (Decoder::init + next() per query, google_codec.cpp:777-819 / lucene_codec.cpp:568-594).  Here each of those lists is
+// decoded ONCE PER INDEX — k_term_planes, from the segment's own codec bytes, the first time a batch's run names the term; the rows stay in the
+// index's plane cache (tri_index, trinity_hip.hip) — into PL_NESTED nested bitmaps over the docID space (+ the same levels bit-sliced, for probes):
 //     plane 0 ("A")  bit d set  <=>  document d holds the term            (PostingsListIterator::current() would stop on d)
 //     plane k        bit d set  <=>  ... and its frequency there is >= k + 1 — or one the planes do not tell (0, >= PL_NESTED: every plane set)
 // (planes 1 / 2, "B" / "C": the frequency is not 1, nor 2 — what k_score and k_tree_leaves read).  The number of planes a document is in is its
@@ -17,7 +18,8 @@
 // and the matching kernels read the planes: k_and tests a candidate with one bit probe instead of bracketing and decoding a block
 // (Conjuction::next_impl's advance(), docset_iterators.cpp:308-348), k_and_dense ORs a plane's words into its window bitmap instead
 // of walking the term's rows (docset_spans.cpp:98-173), k_planes (below) evaluates union / CNF predicates 32 documents per word.
-// The planes live in a scratch region owned by the batch (3 x (max docID / 8) bytes per term); nothing survives the launch.
+// A row is built BY NEED (round 6): plane 0 — 1.25 MB per term at 10 M documents, all a DocumentsOnly batch reads — when any batch names the term, the
+// HIGH part (planes 1 .. PL_STORED - 1 + the three level words: 7.5 MB more) the first time a SCORED batch does (dev_structs.hpp: PL_HI).
 
 constexpr uint32_t PL_CELLS = PL_W / CELL_DOCS; // cell-index entries per plane window
 constexpr uint32_t PL_STRIDE = PL_WORDS + 32;   // LDS words between a slot's planes (word PL_WORDS of each: the sink)
@@ -27,6 +29,7 @@ struct PlanePost {
         uint32_t *a;
         uint32_t *rd;  // the window's rank directory (LDS): per group of PL_RANK_DOCS documents the lowest posting index seen
         uint32_t pidx; // the posting index of the row's next document (rows of a list of full blocks: 32 b + slot)
+        bool levels;   // false: plane 0 only (the row's high part is not being built)
         __device__ __forceinline__ void rank(const uint32_t rel) {
                 if (rel < PL_W)
                         atomicMin(&rd[rel / PL_RANK_DOCS], pidx);
@@ -43,10 +46,12 @@ struct PlanePost {
                 const uint32_t bit = 1u << (r & 31u), f16 = f & 0xffffu; // (the frequency a scorer sees is tokenpos_t, 16 bits: codecs.h:217)
                 const uint32_t level = f16 == 0u || f16 > PL_NESTED ? PL_NESTED : f16; // (a frequency the planes do not tell: every plane)
                 atomicOr(&a[r >> 5], bit);
+                if (levels) {
 #pragma unroll
-                for (uint32_t k = 1; k < PL_NESTED; ++k)
-                        if (k < level)
-                                atomicOr(&a[(r >> 5) + k * PL_STRIDE], bit);
+                        for (uint32_t k = 1; k < PL_NESTED; ++k)
+                                if (k < level)
+                                        atomicOr(&a[(r >> 5) + k * PL_STRIDE], bit);
+                }
         }
 };
 
@@ -58,11 +63,14 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                                                         const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
                                                         const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
                                                         const DevTerm *__restrict__ terms, const uint32_t *__restrict__ build /* (term, row) pairs */,
-                                                        uint32_t *__restrict__ planes, const uint32_t plw, uint32_t *__restrict__ prank /* rank directories, or null */) {
+                                                        uint32_t *__restrict__ planes0, const size_t stride0 /* words between two rows' plane 0 */,
+                                                        uint32_t *__restrict__ planes_hi /* the rows' high parts, or null: plane 0 only */, const size_t stride_hi,
+                                                        const uint32_t plw, uint32_t *__restrict__ prank /* rank directories, or null */) {
         __shared__ uint32_t pl[PL_NESTED * PL_STRIDE];
         __shared__ uint32_t rdir[PL_W / PL_RANK_DOCS];
         const uint32_t tid = threadIdx.x, w = blockIdx.x, row = build[2 * blockIdx.y + 1];
-        for (uint32_t i = tid; i < PL_NESTED * PL_STRIDE; i += AND_WG)
+        const bool hi = planes_hi != nullptr; // (uniform)
+        for (uint32_t i = tid; i < (hi ? PL_NESTED : 1u) * PL_STRIDE; i += AND_WG)
                 pl[i] = 0;
         for (uint32_t i = tid; i < PL_W / PL_RANK_DOCS; i += AND_WG)
                 rdir[i] = 0xffffffffu;
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
         if (b_lo < t.nblocks)
                 for (uint32_t b = b_lo + tid; b <= b_hi; b += AND_WG) {
                         const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
-                        PlanePost post{pl, rdir, 32u * b};
+                        PlanePost post{pl, rdir, 32u * b, hi};
 #ifdef TRI_PROF
                         ProfClock prof_;
 #endif
@@ -115,7 +123,7 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                         }
                 }
         __syncthreads();
-        uint32_t *pa = planes + (size_t)row * PL_PLANES * plw + (size_t)w * PL_WORDS;
+        uint32_t *pa = planes0 + (size_t)row * stride0 + (size_t)w * PL_WORDS;
         if (prank) { // (rank of a document = its group's entry + the plane-0 bits of the group before it, both in ONE 64-byte record: k_phrase.hpp)
                 static_assert(PL_RANK_DOCS == 256 && PL_RANK_WORDS == 16, "a record: the rank, the group's eight plane-0 words, padding to a cache line");
                 uint32_t *rec = prank + ((size_t)row * (plw / (PL_RANK_DOCS / 32u)) + (size_t)w * (PL_W / PL_RANK_DOCS)) * PL_RANK_WORDS;
@@ -124,16 +132,23 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
                         rec[i] = k == 0 ? rdir[g] : k <= 8 ? pl[8u * g + k - 1u] : 0u;
                 }
         }
+        if (!hi) { // plane 0 alone: all a DocumentsOnly batch reads
+                for (uint32_t i = tid; i < PL_WORDS; i += AND_WG)
+                        pa[i] = pl[i];
+                return;
+        }
         static_assert(PL_NESTED == 6 && PL_LEVEL_WORDS == 3, "the level's bits below are written for six nested planes");
-        uint32_t *lv = planes + (size_t)row * PL_PLANES * plw + (size_t)PL_STORED * plw + 3u * (size_t)w * PL_WORDS; // the window's interleaved level words
+        uint32_t *ph = planes_hi + (size_t)row * stride_hi + (size_t)w * PL_WORDS;                           // the window's words of nested plane 1; plane k: + (k - 1) * plw
+        uint32_t *lv = planes_hi + (size_t)row * stride_hi + (size_t)PL_HI_LEVELS * plw + 3u * (size_t)w * PL_WORDS; // the window's interleaved level words
         for (uint32_t i = tid; i < PL_WORDS; i += AND_WG) {
                 uint32_t x[PL_NESTED];
 #pragma unroll
                 for (uint32_t k = 0; k < PL_NESTED; ++k) {
                         x[k] = pl[k * PL_STRIDE + i];
-                        if (k < PL_STORED)
-                                pa[(size_t)k * plw + i] = x[k];
+                        if (k >= 1 && k < PL_STORED)
+                                ph[(size_t)(k - 1) * plw + i] = x[k];
                 }
+                pa[i] = x[0];
                 // the level (the number of nested planes a document is in) bit-sliced: odd; 2, 3 or 6; 4 or more
                 lv[3u * i] = x[0] ^ x[1] ^ x[2] ^ x[3] ^ x[4] ^ x[5];
                 lv[3u * i + 1u] = (x[1] & ~x[3]) | x[5];
@@ -606,20 +621,20 @@ template <typename T> __device__ __forceinline__ T *uni_ptr(T *p) { // a pointer
 //      queue or the candidate buffer is full) — what is left of the words' candidates is back on the word queue.  Not inlined: it runs once
 //      per some forty sub-windows, and its registers must not weigh on the sweep's loop.
 template <int ND_>
-__device__ __noinline__ uint32_t planes_work_words(const uint32_t *__restrict__ planes_, const uint32_t plw_, const uint32_t *__restrict__ lists_, const uint32_t state) {
+__device__ __noinline__ uint32_t planes_work_words(const uint32_t *__restrict__ planes_hi_, const uint32_t plw_, const uint32_t *__restrict__ lists_, const uint32_t state) {
         constexpr uint32_t ND = (uint32_t)ND_;
         PlanesShared &sh = plk_shared();
         const uint32_t lane = threadIdx.x & 63u, wave = uni(threadIdx.x >> 6);
-        const uint32_t *const planes = uni_ptr(planes_), *const lists = uni_ptr(lists_);
+        const uint32_t *const planes_hi = uni_ptr(planes_hi_), *const lists = uni_ptr(lists_);
         const uint32_t plw = uni(plw_);
         uint32_t qn = uni(state) & 0xffffu, cqn = (uni(state) >> 16) & 0x7fffu;
         const uint32_t nd = uni(sh.sa.nd), leafd = uni(sh.sa.leafd), nsp = uni(sh.sa.nsp);
         uint32_t dsl[ND];
-        PlkG1 pa1[ND];
+        PlkG1 ph1[ND]; // the dense positions' level words
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i) {
                 dsl[i] = uni(sh.sa.dsl[i]);
-                pa1[i] = (PlkG1)(planes + (size_t)uni(sh.sa.prow[i]) * PL_PLANES * plw);
+                ph1[i] = (PlkG1)(planes_hi + (size_t)uni(sh.sa.prow[i]) * PL_HI * plw + (size_t)PL_HI_LEVELS * plw);
         }
         const PlkG1 lists1 = (PlkG1)lists;
         const bool full = uni(sh.tk_full) != 0;
@@ -646,7 +661,7 @@ __device__ __noinline__ uint32_t planes_work_words(const uint32_t *__restrict__ 
         static_assert(PL_NESTED == 6 && PL_LEVEL_WORDS == 3, "the planes' words below are derived from three level bits of six levels");
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i) { // (all the loads first: one round trip — three adjacent words per slot)
-                const PlkG1 lv = pa1[i] + (size_t)PL_STORED * plw + 3u * (i < nd ? wi : lane);
+                const PlkG1 lv = ph1[i] + 3u * (i < nd ? wi : lane);
                 l0[i] = lv[0];
                 l1[i] = lv[1];
                 l2[i] = lv[2];
@@ -754,13 +769,13 @@ __device__ __noinline__ uint32_t planes_work_words(const uint32_t *__restrict__ 
 }
 
 template <int ND_>
-__device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict__ planes_, const uint32_t plw_, const uint32_t *__restrict__ masked_,
-                                                      const uint32_t *__restrict__ lists_) {
+__device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict__ planes0_, const uint32_t *__restrict__ planes_hi_, const uint32_t plw_,
+                                                      const uint32_t *__restrict__ masked_, const uint32_t *__restrict__ lists_) {
         constexpr uint32_t ND = (uint32_t)ND_;
         constexpr uint32_t PF = PlkRing<ND_>::PF;
         PlanesShared &sh = plk_shared();
         const uint32_t lane = threadIdx.x & 63u, wave = uni(threadIdx.x >> 6);
-        const uint32_t *const planes = uni_ptr(planes_), *const masked = uni_ptr(masked_), *const lists = uni_ptr(lists_);
+        const uint32_t *const planes0 = uni_ptr(planes0_), *const planes_hi = uni_ptr(planes_hi_), *const masked = uni_ptr(masked_), *const lists = uni_ptr(lists_);
         const uint32_t plw = uni(plw_);
         const uint32_t nd = uni(sh.sa.nd), nreq = uni(sh.sa.nreq), negd = uni(sh.sa.negd);
         uint32_t sw = uni(sh.w_sw[wave]), qn = uni(sh.w_qn[wave]), cqn = uni(sh.w_cqn[wave]);
@@ -771,7 +786,7 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
         PlkG1 pa1[ND]; // plane A of the dense positions (a position beyond nd: the all-zero row)
 #pragma unroll
         for (uint32_t i = 0; i < ND; ++i)
-                pa1[i] = (PlkG1)(planes + (size_t)uni(sh.sa.prow[i]) * PL_PLANES * plw);
+                pa1[i] = (PlkG1)(planes0 + (size_t)uni(sh.sa.prow[i]) * plw);
         // the slots' ESSENTIAL planes (planes_filter: every candidate is in one of them).  Plane A is in the ring anyway; a slot that is essential through
         // a higher plane (a frequency above some level) has that plane's words fetched beside it (any other position fetches the all-zero row's first words: one cache line)
         PlkG1 pe1[ND];
@@ -786,7 +801,7 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
                 const uint32_t es = e < PL_STORED ? e : PL_STORED - 1u; // (a plane the rows do not hold: the highest one they do — a superset)
 #endif
                 es_fetch |= (bc ? 1u : 0u) << i;
-                pe1[i] = bc ? pa1[i] + (size_t)es * plw : (PlkG1)(planes + (size_t)uni(sh.sa.zrow) * PL_PLANES * plw);
+                pe1[i] = bc ? (PlkG1)(planes_hi + (size_t)uni(sh.sa.prow[i]) * PL_HI * plw + (size_t)(es - 1u) * plw) : (PlkG1)(planes0 + (size_t)uni(sh.sa.zrow) * plw); // (bc: es >= 1)
         }
         es_fetch = uni(es_fetch);
         // the first three required groups in scalar registers (a group beyond the query's: every position — it changes nothing), further ones from LDS
@@ -795,7 +810,7 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
 #pragma unroll
         for (uint32_t g = 0; g < GREG; ++g)
                 gd[g] = g < nreq ? uni(sh.sa.gd[g]) : 0xffffffffu;
-        const PlkG2 mk2 = (PlkG2)(masked ? masked : planes + (size_t)uni(sh.sa.zrow) * PL_PLANES * plw); // (rows and sub-windows are multiples of 128 words: 8-byte aligned)
+        const PlkG2 mk2 = (PlkG2)(masked ? masked : planes0 + (size_t)uni(sh.sa.zrow) * plw); // (rows and sub-windows are multiples of 128 words: 8-byte aligned)
         uint32_t my_matches = 0;
         // (threshold and tables move only at a prune, i.e. between two segments)
         const uint32_t esel = uni(sh.esel), atab = uni(sh.atab);
@@ -829,7 +844,7 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
         bool stop = false; // (uniform, like sw / qn / cqn: the segment's control flow is the wave's)
         // words left over from the previous segment first (they were cut short by a full queue or buffer)
         auto work_words = [&]() __attribute__((always_inline)) { // true: the batch went through
-                const uint32_t st = uni(planes_work_words<ND_>(planes, plw, lists, qn | cqn << 16));
+                const uint32_t st = uni(planes_work_words<ND_>(planes_hi, plw, lists, qn | cqn << 16));
                 qn = st & 0xffffu, cqn = (st >> 16) & 0x7fffu;
                 return (st >> 31) == 0u;
         };
@@ -974,7 +989,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
         const DevFused *__restrict__ fused, const DevTask *__restrict__ tasks, const uint32_t *__restrict__ sched, const uint32_t *__restrict__ sterms,
         const double *__restrict__ sweights, const uint32_t ntasks, uint32_t *__restrict__ ticket, uint32_t *__restrict__ counts, const uint32_t k,
         uint32_t *__restrict__ part_docs, double *__restrict__ part_scores, uint32_t *__restrict__ part_counts, const uint32_t *__restrict__ masked,
-        const int sim, const uint32_t *__restrict__ planes, const uint32_t plw, const uint32_t zrow, uint32_t *__restrict__ scratch, const uint32_t sparse_cap,
+        const int sim, const uint32_t *__restrict__ planes0, const uint32_t *__restrict__ planes_hi, const uint32_t plw, const uint32_t zrow, uint32_t *__restrict__ scratch, const uint32_t sparse_cap,
         unsigned long long *__restrict__ qthr) {
         PlanesShared &sh = plk_shared();
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -1111,14 +1126,14 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                 dense_mask = uni(dense_mask), leafm = uni(leafm), list_rows = uni(list_rows);
                 const uint32_t nd = (uint32_t)__builtin_popcount(dense_mask), nsp = (uint32_t)__builtin_popcount(sparse_mask);
                 uint32_t dsl[NS]; // dense position -> slot
-                const uint32_t *pA[NS];
+                const uint32_t *pLV[NS]; // ... -> its row's level words
                 {
                         uint32_t dm = dense_mask;
 #pragma unroll
                         for (uint32_t i = 0; i < NS; ++i) {
                                 const uint32_t s = dm ? (uint32_t)__builtin_ctz(dm) : 0u;
                                 dsl[i] = uni(s);
-                                pA[i] = planes + (size_t)(dm ? uni(fq.plane[s]) : zrow) * PL_PLANES * plw; // (zrow: the all-zero row — what a position beyond nd reads)
+                                pLV[i] = planes_hi + (size_t)(dm ? uni(fq.plane[s]) : zrow) * PL_HI * plw + (size_t)PL_HI_LEVELS * plw; // (zrow: the all-zero row — what a position beyond nd reads)
                                 dm &= dm - 1u;
                         }
                 }
@@ -1329,7 +1344,7 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                                         for (uint32_t i = 0; i < NS; ++i) {
                                                                 if (i >= nd)
                                                                         break;
-                                                                const uint32_t *lv = pA[i] + (size_t)PL_STORED * plw + 3u * wi; // (the level's three bits: adjacent words)
+                                                                const uint32_t *lv = pLV[i] + 3u * wi; // (the level's three bits: adjacent words)
                                                                 const uint32_t l = ((lv[0] >> bit) & 1u) | (((lv[1] >> bit) & 1u) << 1) | (((lv[2] >> bit) & 1u) << 2);
                                                                 present |= (l ? 1u : 0u) << dsl[i];
                                                                 levels |= (((leafd >> i) & 1u) ? l : 0u) << (3u * dsl[i]);
@@ -1416,15 +1431,15 @@ __global__ __launch_bounds__(PLK_WG, (PLK_WGS_PER_CU * PLK_WG + 255) / 256) void
                                         uint32_t r;
                                         if constexpr (NS == PLK_NS_SMALL) {
                                                 if (nd <= 1)
-                                                        r = planes_sweep_segment<1>(planes, plw, masked, lists);
+                                                        r = planes_sweep_segment<1>(planes0, planes_hi, plw, masked, lists);
                                                 else if (nd == 2)
-                                                        r = planes_sweep_segment<2>(planes, plw, masked, lists);
+                                                        r = planes_sweep_segment<2>(planes0, planes_hi, plw, masked, lists);
                                                 else if (nd == 3)
-                                                        r = planes_sweep_segment<3>(planes, plw, masked, lists);
+                                                        r = planes_sweep_segment<3>(planes0, planes_hi, plw, masked, lists);
                                                 else
-                                                        r = planes_sweep_segment<5>(planes, plw, masked, lists);
+                                                        r = planes_sweep_segment<5>(planes0, planes_hi, plw, masked, lists);
                                         } else
-                                                r = planes_sweep_segment<NS>(planes, plw, masked, lists);
+                                                r = planes_sweep_segment<NS>(planes0, planes_hi, plw, masked, lists);
                                         qn = uni(sh.w_qn[wave]);
                                         // the queue is worked off out here: a call among the sweep's live registers would have the compiler spill them on the hot path
                                         while (qn >= 64 && uni(__atomic_load_n(&sh.tk_n, __ATOMIC_RELAXED)) < PLK_PRUNE_AT)

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(PROBE_WG, TRI_PROBE_WAVES) void k_probe(const uint8
                                                 grp = 0;
                                                 neg = tt & QT_NOT;
                                         }
-                                        const uint32_t *pa = planes + (size_t)row * PL_PLANES * plw;
+                                        const uint32_t *pa = planes + (size_t)row * plw;
 #pragma unroll
                                         for (uint32_t u = 0; u < PROBE_UNROLL; ++u)
                                                 grp |= ((pa[doc[u] >> 5] >> (doc[u] & 31u)) & 1u) << u;

@@ -211,8 +211,8 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                         if (pair) {
                                 // two terms with planes — the batch's usual query: both terms' words travel together (the general loop below waits for a
                                 // term's two loads before it issues the next term's: a round trip per term and step)
-                                const uint4 *pa = (const uint4 *)(planes + (size_t)pair_row0 * PL_PLANES * plw + word0);
-                                const uint4 *pb = (const uint4 *)(planes + (size_t)pair_row1 * PL_PLANES * plw + word0);
+                                const uint4 *pa = (const uint4 *)(planes + (size_t)pair_row0 * plw + word0);
+                                const uint4 *pb = (const uint4 *)(planes + (size_t)pair_row1 * plw + word0);
                                 const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
                                 const uint32_t av[PSET_PER] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bv[PSET_PER] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                                         cur_neg = tt & QT_NOT;
                                 if (row == PL_NONE) // (a PSET_UNIT_SCATTER union's term without a plane: its documents are set after the windows, below)
                                         continue;
-                                const uint4 *pa = (const uint4 *)(planes + (size_t)row * PL_PLANES * plw + word0);
+                                const uint4 *pa = (const uint4 *)(planes + (size_t)row * plw + word0);
 #if defined(TRI_PSET_VARIANT) && TRI_PSET_VARIANT == 3 // (perf probe 3: no plane loads — words made up from the lane's address)
                                 const uint32_t hsh = (word0 * 2654435761u) ^ (k * 40503u);
                                 const uint4 v0 = make_uint4(hsh & (hsh >> 3) & (hsh >> 7), 0, (hsh >> 5) & (hsh << 2) & (hsh >> 11), 0), v1 = make_uint4(0, hsh & 0x10001u, 0, hsh & 0x200u);

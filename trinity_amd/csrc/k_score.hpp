@@ -207,7 +207,7 @@ __global__ __launch_bounds__(AND_WG) void k_score(const uint8_t *__restrict__ in
                                         // the planes every match decoded a block of every scorer — cfg3: 900 us for a tile of 8192 matches and four head terms)
                                         // (round 5: the row's interleaved LEVEL words tell the frequency itself up to PL_NESTED - 1 — one 12-byte probe —; the postings are
                                         //  walked only for the top level: a frequency of 0 or of PL_NESTED and more)
-                                        const uint32_t *lvw = planes + (size_t)prow * PL_PLANES * plw + (size_t)PL_STORED * plw;
+                                        const uint32_t *lvw = planes + (size_t)prow * PL_HI * plw + (size_t)PL_HI_LEVELS * plw; // (`planes`: the rows' HIGH parts)
                                         for (uint32_t j = tid; j < C; j += AND_WG) {
                                                 const uint32_t doc = sh.cand[j], wi = doc >> 5, bit = doc & 31u;
                                                 const uint32_t *lv = lvw + 3u * wi;

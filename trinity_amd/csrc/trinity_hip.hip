@@ -277,12 +277,15 @@ struct tri_index : HostIndex {
         uint4 *d_blk_rec = nullptr;
         uint32_t *d_masked = nullptr; // bitmap over docIDs of the masked documents (nullptr: none); max_doc / 32 + 2 words
         DevTerm *d_terms = nullptr;
-        // ---- the term planes live with the index (they are a function of its lists alone): row r = the planes A / B / C of the term of df
-        //      rank r, built by k_term_planes the first time a batch's run wants them and kept — a caller that compiles a batch per step does
-        //      not decode the same head terms step after step.  pc_cap rows + one all-zero row (index pc_cap); pc_built[r]: row r's build has
-        //      been enqueued on the engine stream (every later kernel of the stream sees it).  Grown (engine stream drained, rows copied) when
-        //      a batch is planned with more eligible terms than it holds.
-        uint32_t *d_pcache = nullptr;
+        // ---- the term planes live with the index (they are a function of its lists alone): row r = the planes of the term of df rank r, built
+        //      by k_term_planes the first time a batch's run wants them and kept — a caller that compiles a batch per step does not decode the
+        //      same head terms step after step.  Two regions, built BY NEED (dev_structs.hpp: PL_HI): d_pcache holds every row's PLANE 0 (plw
+        //      words a row: all a DocumentsOnly batch reads), d_pcache_hi the rows' HIGH parts (nested planes 1 .. 3 + level words, PL_HI * plw
+        //      words a row) — allocated by the first scored batch that reads planes, a row's part built when such a batch names the row.  pc_cap
+        //      rows + one all-zero row (index pc_cap) in each region; pc_built[r]: bit 0 plane 0, bit 1 the high part — the build has been
+        //      enqueued on the engine stream (every later kernel of the stream sees it).  Grown (rows moved on the upload stream) when a batch is
+        //      planned with more eligible terms than it holds.
+        uint32_t *d_pcache = nullptr, *d_pcache_hi = nullptr;
         uint32_t pc_cap = 0, pc_plw = 0;
         std::vector<uint8_t> pc_built;
         // ... and what k_phrase needs to find a head term's hits WITHOUT walking its blocks (round 5): per row a RANK DIRECTORY over plane 0 — a 64-byte record per docID group g of 256 documents at d_prank[(row * (plw / 8) + g) * 16]:
@@ -314,6 +317,7 @@ struct tri_index : HostIndex {
                 hipFree(d_win);
                 hipFree(d_terms);
                 pool_free(dev, d_pcache); // (pooled: tri_batch_create grows it without a device-wide synchronisation)
+                pool_free(dev, d_pcache_hi);
                 pool_free(dev, d_prank);
                 pool_free(dev, d_phs);
                 pool_free(dev, d_hs_off);
@@ -354,6 +358,7 @@ struct tri_batch : BatchPlan {
         uint32_t *d_tree_scratch = nullptr, *d_tree_rows = nullptr, *d_tree_prows = nullptr, *d_tree_qbits = nullptr, *d_tree_cc = nullptr, *d_tree_build = nullptr;
         double *d_tree_scores = nullptr; // scored top-K batches: the tree queries' score stream (topk == 0: d_all_scores holds it)
         bool ran = false;
+        bool planes_hi = false; // the batch reads the HIGH parts of its plane rows (k_planes, k_score's level words): its run builds them where they are missing
         uint32_t *d_qterms = nullptr;
         uint32_t *d_out = nullptr;
         uint32_t *d_counts = nullptr; // per task, indexed first_task + i in query order
@@ -852,13 +857,21 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 ix->pc_retired.erase(ix->pc_retired.begin() + (long)i);
                         } else
                                 ++i;
-                if (want > ix->pc_cap || b->plw != ix->pc_plw) {
+                // (does this batch read the rows' HIGH parts — a scored batch whose one-pass kernel or scorers read planes?)
+                b->planes_hi = planes_tasks || !b->splane.empty();
+                if (want > ix->pc_cap || b->plw != ix->pc_plw || (b->planes_hi && !ix->d_pcache_hi)) {
                         // Grown WITHOUT draining the engine stream (round 4 synchronised it here: a stall in the serving loop whenever a batch was planned with more
                         // eligible terms): the rows move on the upload stream behind everything the engine stream holds so far (runs that read or build the old
                         // rows), later runs wait for the move's event (tri_batch_run), and the old buffer is retired — pooled again once that point has passed
-                        const size_t row = (size_t)PL_PLANES * b->plw * 4;
-                        uint32_t *fresh = nullptr;
-                        HIP_TRY(pool_alloc(dev, (void **)&fresh, ((size_t)want + 1) * row + 64));
+                        const size_t row = (size_t)b->plw * 4, row_hi = (size_t)PL_HI * b->plw * 4;
+                        const bool resize = want > ix->pc_cap || b->plw != ix->pc_plw; // (else: only the high region is new)
+                        const uint32_t cap = std::max(want, b->plw == ix->pc_plw ? ix->pc_cap : 0u);
+                        const bool with_hi = b->planes_hi || ix->d_pcache_hi;
+                        uint32_t *fresh = nullptr, *fresh_hi = nullptr;
+                        if (resize)
+                                HIP_TRY(pool_alloc(dev, (void **)&fresh, ((size_t)cap + 1) * row + 64));
+                        if (with_hi && (resize || !ix->d_pcache_hi))
+                                HIP_TRY(pool_alloc(dev, (void **)&fresh_hi, ((size_t)cap + 1) * row_hi + 64));
                         hipEvent_t drained = nullptr;
                         std::vector<void *> outgrown; // the buffers this growth replaces
                         HIP_TRY(event_get(dev, &drained));
@@ -866,30 +879,41 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 HIP_TRY(event_get(dev, &ix->ev_pc_ready));
                         HIP_TRY(hipEventRecord(drained, dev->stream));
                         HIP_TRY(hipStreamWaitEvent(dev->stream_up, drained, 0));
-                        if (ix->d_pcache && b->plw == ix->pc_plw)
-                                HIP_TRY(hipMemcpyAsync(fresh, ix->d_pcache, (size_t)ix->pc_cap * row, hipMemcpyDeviceToDevice, dev->stream_up));
-                        else
-                                ix->pc_built.clear();
-                        HIP_TRY(hipMemsetAsync((uint8_t *)fresh + (size_t)want * row, 0, row + 64, dev->stream_up));
-                        {
+                        const bool same_plw = ix->d_pcache && b->plw == ix->pc_plw;
+                        if (fresh) {
+                                if (same_plw)
+                                        HIP_TRY(hipMemcpyAsync(fresh, ix->d_pcache, (size_t)ix->pc_cap * row, hipMemcpyDeviceToDevice, dev->stream_up));
+                                else
+                                        ix->pc_built.clear();
+                                HIP_TRY(hipMemsetAsync((uint8_t *)fresh + (size_t)cap * row, 0, row + 64, dev->stream_up));
+                        }
+                        if (fresh_hi) {
+                                if (same_plw && ix->d_pcache_hi)
+                                        HIP_TRY(hipMemcpyAsync(fresh_hi, ix->d_pcache_hi, (size_t)ix->pc_cap * row_hi, hipMemcpyDeviceToDevice, dev->stream_up));
+                                else
+                                        for (auto &bb : ix->pc_built)
+                                                bb &= (uint8_t)~2u; // (no row has its high part yet)
+                                HIP_TRY(hipMemsetAsync((uint8_t *)fresh_hi + (size_t)cap * row_hi, 0, row_hi + 64, dev->stream_up));
+                        }
+                        if (resize) {
                                 // the rank directories and hits entries of the rows (k_phrase's rank path): sized for every row the cache can hold, moved like the rows
-                                const bool same = ix->d_pcache && b->plw == ix->pc_plw;
-                                std::vector<uint64_t> hs(want + 1, 0);
-                                std::vector<uint32_t> rt(want, 0xffffffffu);
+                                const bool same = same_plw;
+                                std::vector<uint64_t> hs(cap + 1, 0);
+                                std::vector<uint32_t> rt(cap, 0xffffffffu);
                                 for (size_t t = 0; t < ix->terms.size(); ++t)
-                                        if (ix->df_rank[t] < want)
+                                        if (ix->df_rank[t] < cap)
                                                 rt[ix->df_rank[t]] = (uint32_t)t;
-                                for (uint32_t r = 0; r < want; ++r)
+                                for (uint32_t r = 0; r < cap; ++r)
                                         hs[r + 1] = hs[r] + (rt[r] != 0xffffffffu ? ix->terms[rt[r]].documents : 0u);
                                 uint32_t *prank = nullptr;
                                 unsigned long long *phs = nullptr;
                                 uint64_t *hso = nullptr;
                                 uint32_t *pairs = nullptr;
                                 const size_t groups = b->plw / 8;
-                                HIP_TRY(pool_alloc(dev, (void **)&pairs, (size_t)want * 8 + POOL_MIN_BYTES));
-                                HIP_TRY(pool_alloc(dev, (void **)&prank, (size_t)want * groups * PL_RANK_WORDS * 4 + 64));
-                                HIP_TRY(pool_alloc(dev, (void **)&phs, (hs[want] + 8) * 8));
-                                HIP_TRY(pool_alloc(dev, (void **)&hso, ((size_t)want + 1) * 8 + POOL_MIN_BYTES));
+                                HIP_TRY(pool_alloc(dev, (void **)&pairs, (size_t)cap * 8 + POOL_MIN_BYTES));
+                                HIP_TRY(pool_alloc(dev, (void **)&prank, (size_t)cap * groups * PL_RANK_WORDS * 4 + 64));
+                                HIP_TRY(pool_alloc(dev, (void **)&phs, (hs[cap] + 8) * 8));
+                                HIP_TRY(pool_alloc(dev, (void **)&hso, ((size_t)cap + 1) * 8 + POOL_MIN_BYTES));
                                 if (same && ix->d_prank) {
                                         HIP_TRY(hipMemcpyAsync(pairs, ix->d_ph_pairs, ix->ph_pairs_n * 8, hipMemcpyDeviceToDevice, dev->stream_up));
                                         HIP_TRY(hipMemcpyAsync(prank, ix->d_prank, (size_t)ix->pc_cap * groups * PL_RANK_WORDS * 4, hipMemcpyDeviceToDevice, dev->stream_up));
@@ -899,7 +923,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                         ix->ph_pairs_n = 0;
                                 }
                                 ix->hs_off = hs; // (a row's offset depends on the rows before it alone: what was built stays where it was)
-                                HIP_TRY(hipMemcpyAsync(hso, ix->hs_off.data(), ((size_t)want + 1) * 8, hipMemcpyHostToDevice, dev->stream_up)); // (hs_off outlives the copy: a member)
+                                HIP_TRY(hipMemcpyAsync(hso, ix->hs_off.data(), ((size_t)cap + 1) * 8, hipMemcpyHostToDevice, dev->stream_up)); // (hs_off outlives the copy: a member)
                                 if (!ix->d_term_row) {
                                         HIP_TRY(hipMalloc((void **)&ix->d_term_row, (ix->terms.size() + 1) * 4));
                                         HIP_TRY(hipMemsetAsync(ix->d_term_row, 0xff, (ix->terms.size() + 1) * 4, dev->stream_up));
@@ -910,14 +934,16 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                                 outgrown.push_back(old);
                                 ix->d_prank = prank, ix->d_phs = phs, ix->d_hs_off = hso, ix->d_ph_pairs = pairs;
                                 ix->rank_term = rt;
-                                ix->ph_built.resize(want, 0);
+                                ix->ph_built.resize(cap, 0);
                         }
                         HIP_TRY(hipEventRecord(ix->ev_pc_ready, dev->stream_up));
                         // The outgrown buffers are retired on events recorded on the UPLOAD stream, behind the copies that read them: that point is past
                         // the engine stream's earlier readers too (stream_up waited for `drained`).  (Round 5 retired them on events of the engine
                         // stream recorded BEFORE the copies were enqueued: the next tri_batch_create could pool a buffer the copy had not read yet.)
-                        if (ix->d_pcache)
+                        if (fresh && ix->d_pcache)
                                 outgrown.push_back(ix->d_pcache);
+                        if (fresh_hi && ix->d_pcache_hi)
+                                outgrown.push_back(ix->d_pcache_hi);
                         for (void *old : outgrown) {
                                 hipEvent_t e2 = nullptr;
                                 HIP_TRY(event_get(dev, &e2));
@@ -925,10 +951,13 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                                 ix->pc_retired.emplace_back(old, e2);
                         }
                         event_put(dev, drained);
-                        ix->d_pcache = fresh;
-                        ix->pc_cap = want;
+                        if (fresh)
+                                ix->d_pcache = fresh;
+                        if (fresh_hi)
+                                ix->d_pcache_hi = fresh_hi;
+                        ix->pc_cap = cap;
                         ix->pc_plw = b->plw;
-                        ix->pc_built.resize(want, 0);
+                        ix->pc_built.resize(cap, 0);
                 }
         }
         if (planes_tasks) {
@@ -986,7 +1015,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->info.planes_queries = b->planes_queries;
         b->info.unsupported_queries = b->unsupported_queries;
         b->info.plane_terms = b->plane_terms.size();
-        b->info.plane_bytes = (uint64_t)b->plane_terms.size() * PL_PLANES * b->plw * 4; // (rows of the index's plane cache this batch reads)
+        b->info.plane_bytes = (uint64_t)b->plane_terms.size() * (b->planes_hi ? PL_PLANES : 1u) * b->plw * 4; // (what this batch reads of its rows of the index's plane cache: plane 0, a scored batch the high parts too)
         b->info.launches = (b->n_dense != 0) + (b->n_pset != 0) + (b->n_probe != 0) + (b->n_cand != 0) + (b->n_fused != 0) + (b->n_fused16 != 0) + (b->n_fusedgen != 0) + (b->n_planes != 0) + (b->n_planes8 != 0) + (!b->plane_terms.empty()) +
                            (!b->ptasks.empty()) + (rich ? 2 : 0) +
                            ((scored && b->n_dense + b->n_pset + b->n_probe + b->n_cand) ? 1 : 0) + ((scored && topk) ? 1 : 0);
@@ -1060,9 +1089,10 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         // — once for the index, not once per batch (every word of a row is written: no memset)
                         tri_index *ix = b->ix;
                         std::vector<uint32_t> build;
+                        const uint8_t needs = b->planes_hi ? 3u : 1u; // (bit 0: plane 0; bit 1: the row's high part — scored batches only)
                         for (const uint32_t term : b->plane_terms) {
                                 const uint32_t row = ix->df_rank[term];
-                                if (row < ix->pc_cap && (!ix->pc_built[row] || dev->opt.planes_rebuild)) {
+                                if (row < ix->pc_cap && ((ix->pc_built[row] & needs) != needs || dev->opt.planes_rebuild)) {
                                         build.push_back(term);
                                         build.push_back(row);
                                         b->info.term_planes_decoded_bytes += ix->docbytes[term];
@@ -1073,12 +1103,14 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                 const uint32_t nrows = (uint32_t)(build.size() / 2);
                                 for (uint32_t y0 = 0; y0 < nrows; y0 += 65535u) { // (gridDim.y <= 65535)
                                         const dim3 grid(b->plw / PL_WORDS, std::min(65535u, nrows - y0));
+                                        // (a row that gains its high part is decoded whole again: plane 0 is rewritten with the words it holds)
                                         TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff,
-                                                   ix->d_win, ix->d_terms, (const uint32_t *)b->d_build + 2 * (size_t)y0, ix->d_pcache, b->plw, ix->d_prank);
+                                                   ix->d_win, ix->d_terms, (const uint32_t *)b->d_build + 2 * (size_t)y0, ix->d_pcache, (size_t)b->plw,
+                                                   b->planes_hi ? ix->d_pcache_hi : (uint32_t *)nullptr, (size_t)PL_HI * b->plw, b->plw, ix->d_prank);
                                         HIP_TRY(hipGetLastError());
                                 }
                                 for (size_t i = 1; i < build.size(); i += 2)
-                                        ix->pc_built[build[i]] = 1;
+                                        ix->pc_built[build[i]] |= needs;
                         }
                 }
                 HIP_TRY(hipEventRecord(b->ev_pl, dev->stream));
@@ -1168,7 +1200,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
 #define TRI_PLANES_ARGS                                                                                                                                      \
         b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_fused, b->d_tasks, psched, \
                 b->d_sterms, b->d_sweights, np, b->d_ticket + 24 + 2 * wide, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts, b->ix->d_masked,     \
-                b->similarity, (const uint32_t *)b->ix->d_pcache, b->plw, b->ix->pc_cap, b->d_sparse, b->sparse_cap, b->d_qthr
+                b->similarity, (const uint32_t *)b->ix->d_pcache, (const uint32_t *)b->ix->d_pcache_hi, b->plw, b->ix->pc_cap, b->d_sparse, b->sparse_cap, b->d_qthr
                         if (b->ix->codec == TRI_CODEC_LUCENE) {
                                 if (wide)
                                         hipLaunchKernelGGL((k_planes<CODEC_LUCENE, FUS_MAX_SLOTS>), grid, dim3(PLK_WG), 0, dev->stream, TRI_PLANES_ARGS);
@@ -1201,8 +1233,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                 hits_build.push_back(term);
                                 hits_build.push_back(r);
                                 max_blocks = std::max(max_blocks, t.nblocks);
-                                if (!ix->pc_built[r]) {
-                                        ix->pc_built[r] = 1;
+                                if (!(ix->pc_built[r] & 1u)) {
+                                        ix->pc_built[r] |= 1u;
                                         rows_build.push_back(term);
                                         rows_build.push_back(r);
                                 }
@@ -1218,7 +1250,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                                 if (std::find(rows_build.begin(), rows_build.end(), hits_build[i]) != rows_build.end()) {
                                                         const dim3 grid(b->plw / PL_WORDS, 1);
                                                         TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff,
-                                                                   ix->d_win, ix->d_terms, (const uint32_t *)d_pairs + i, ix->d_pcache, b->plw, ix->d_prank);
+                                                                   ix->d_win, ix->d_terms, (const uint32_t *)d_pairs + i, ix->d_pcache, (size_t)b->plw, (uint32_t *)nullptr, (size_t)0, b->plw, ix->d_prank);
                                                         HIP_TRY(hipGetLastError());
                                                 }
                                 }
@@ -1253,7 +1285,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         for (uint32_t y0 = 0; y0 < nterms; y0 += 65535u) { // (gridDim.y <= 65535)
                                 const dim3 grid(plw / PL_WORDS, std::min(65535u, nterms - y0));
                                 TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff, ix->d_win,
-                                           ix->d_terms, (const uint32_t *)b->d_tree_build + 2 * (size_t)y0, b->d_tree_rows, plw, (uint32_t *)nullptr);
+                                           ix->d_terms, (const uint32_t *)b->d_tree_build + 2 * (size_t)y0, b->d_tree_rows, (size_t)PL_PLANES * plw, b->d_tree_rows + plw,
+                                           (size_t)PL_PLANES * plw, plw, (uint32_t *)nullptr); // (a tree row keeps its two parts side by side: plane k at k * plw)
                                 HIP_TRY(hipGetLastError());
                         }
                         if (nhid) {
@@ -1309,7 +1342,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                            b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, nlegacy,
                                            b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,
                                            b->d_all_scores, b->d_pscore, b->similarity, b->ix->d_win, b->splane.empty() ? (const uint32_t *)nullptr : (const uint32_t *)(b->d_arena + b->off_splane),
-                                           (const uint32_t *)b->ix->d_pcache, b->plw);
+                                           (const uint32_t *)b->ix->d_pcache_hi, b->plw); // (the scorers read the level words: the rows' high parts)
                         HIP_TRY(hipGetLastError());
                         const uint32_t nqs = (uint32_t)b->plan.size();
                         if (b->topk)
