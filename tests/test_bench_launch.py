@@ -82,7 +82,7 @@ def test_ranks_of_a_node_pin_their_planner_threads_to_disjoint_cpus():
     workers inside its own slice of the affinity mask — disjoint from every other rank's, whatever CPU the creating thread runs on (round 4's
     pool took the CPUs next to the creator's: ranks landing within 16 CPUs of each other stacked their spinning workers)."""
     ncpu = len(os.sched_getaffinity(0))
-    world = 8 if ncpu >= 8 else 2
+    world = 8 if ncpu >= 16 else max(1, min(4, ncpu // 2))  # (slices of two CPUs or more: a one-CPU slice gets no worker at all — below)
     seen = {}
     for r in range(world):
         env = dict(os.environ, LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(world))
@@ -96,6 +96,11 @@ def test_ranks_of_a_node_pin_their_planner_threads_to_disjoint_cpus():
         assert cpus and set(cpus) <= set(allowed[lo:hi]) and len(set(cpus)) == len(cpus) == min(15, hi - lo), (r, cpus)
     flat = [c for cpus in seen.values() for c in cpus]
     assert len(flat) == len(set(flat))  # no CPU carries two ranks' pollers
+    # a slice of ONE CPU: no worker (it would poll on the CPU the unpinned caller runs on) — the caller plans alone
+    env = dict(os.environ, LOCAL_RANK="0", LOCAL_WORLD_SIZE=str(ncpu))
+    res = subprocess.run([sys.executable, "-c", "import json, sys; sys.path.insert(0, %r); from trinity_amd import hostplan as HP; print(json.dumps(HP.pool_cpus(16)))" % ROOT],
+                         capture_output=True, text=True, timeout=120, env=env)  # fmt: skip
+    assert res.returncode == 0 and (ncpu < 2 or json.loads(res.stdout.strip().splitlines()[-1]) == []), res.stdout[-500:] + res.stderr[-1000:]
     # without the launcher's variables: next to the creating thread, still distinct CPUs
     env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK", "LOCAL_WORLD_SIZE")}
     res = subprocess.run([sys.executable, "-c", "import json, sys; sys.path.insert(0, %r); from trinity_amd import hostplan as HP; print(json.dumps(HP.pool_cpus(4)))" % ROOT],

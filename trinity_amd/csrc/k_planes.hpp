@@ -156,6 +156,103 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
         }
 }
 
+// PLANE 0 ALONE (+ the rank records, when a phrase batch asks for them): what a DocumentsOnly batch builds of a row — and what a stream whose head terms
+// change from batch to batch pays per batch (bench.py's rotating.cold_planes leg).  One workgroup per (row, P0_GROUP windows): k_term_planes' workgroup per
+// window spends its time on fixed costs for all but the longest lists — a term of the plane threshold's length brings ONE block per window, and the
+// workgroup still walks build[] -> terms[] -> win[] -> blk_last[] -> blk_off[] -> the block's bytes (six dependent round trips), clears and writes an LDS
+// plane; at cfg2 178 K such workgroups (583 rows x 306 windows) took 1.64 ms to decode 103 MB of lists.  Here the chain is paid once per P0_GROUP windows,
+// and the lanes of a round hold that many times more blocks.
+constexpr uint32_t P0_GROUP = 4;                     // windows a workgroup takes (16 KB of LDS plane: eight workgroups per CU)
+constexpr uint32_t P0_WORDS = P0_GROUP * PL_WORDS;   // ... their words of plane 0 (word P0_WORDS: the sink)
+struct Plane0Post {
+        uint32_t *a, *rd; // the group's plane words; its rank directory (null: none wanted)
+        uint32_t pidx;
+        __device__ __forceinline__ void doc(const uint32_t rel) {
+                const uint32_t r = min(rel, P0_GROUP * PL_W);
+                if (rd) {
+                        if (rel < P0_GROUP * PL_W)
+                                atomicMin(&rd[rel / PL_RANK_DOCS], pidx);
+                        ++pidx;
+                }
+                atomicOr(&a[r >> 5], 1u << (r & 31u));
+        }
+        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t) { doc(rel); }
+};
+template <int CODEC>
+__global__ __launch_bounds__(AND_WG) void k_term_plane0(const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+                                                        const uint4 *__restrict__ blk_rec, const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
+                                                        const DevTerm *__restrict__ terms, const uint32_t *__restrict__ build /* (term, row) pairs */,
+                                                        uint32_t *__restrict__ planes0, const uint32_t plw, uint32_t *__restrict__ prank /* rank directories, or null */) {
+        __shared__ uint32_t pl[P0_WORDS + 32];
+        __shared__ uint32_t rdir[P0_GROUP * PL_W / PL_RANK_DOCS];
+        const uint32_t tid = threadIdx.x, g = blockIdx.x, row = build[2 * blockIdx.y + 1];
+        const uint32_t nwin = plw / PL_WORDS, wfirst = g * P0_GROUP, wn = min(P0_GROUP, nwin - wfirst); // (the last group may be short)
+        for (uint32_t i = tid; i < P0_WORDS + 32; i += AND_WG)
+                pl[i] = 0;
+        if (prank)
+                for (uint32_t i = tid; i < P0_GROUP * PL_W / PL_RANK_DOCS; i += AND_WG)
+                        rdir[i] = 0xffffffffu;
+        const DevTerm t = terms[build[2 * blockIdx.y]];
+        const uint32_t *bl = blk_last + t.first_block;
+        const uint32_t w0 = wfirst * PL_W, w1 = w0 + wn * PL_W; // (the planner keeps max docID below 2^31: no wrap)
+        // rows that can hold documents of [w0, w1): first row whose last docID >= w0 ... first row whose last docID >= w1 (it may still begin inside)
+        uint32_t b_lo, b_hi;
+        if (t.win_off != 0xffffffffu) {
+                b_lo = win[t.win_off + wfirst * PL_CELLS];
+                b_hi = win[t.win_off + (wfirst + wn) * PL_CELLS];
+        } else {
+                uint32_t lo = 0, hi = t.nblocks;
+                while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (bl[mid] < w0)
+                                lo = mid + 1;
+                        else
+                                hi = mid;
+                }
+                b_lo = lo;
+                hi = t.nblocks;
+                while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (bl[mid] < w1)
+                                lo = mid + 1;
+                        else
+                                hi = mid;
+                }
+                b_hi = lo;
+        }
+        b_lo = uni(b_lo);
+        b_hi = uni(min(b_hi, t.nblocks - 1));
+        __syncthreads();
+        if (b_lo < t.nblocks)
+                for (uint32_t b = b_lo + tid; b <= b_hi; b += AND_WG) {
+                        const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
+                        Plane0Post post{pl, prank ? rdir : nullptr, 32u * b};
+#ifdef TRI_PROF
+                        ProfClock prof_;
+#endif
+                        // (documents beyond the group's last window land in the sink: a short last group's w1 is the docID space's end anyway)
+                        if (CODEC == CODEC_LUCENE) {
+                                const uint4 rec = blk_rec[t.first_block + b];
+                                row_decode<CODEC, false, Plane0Post>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, w0, post PROF_PASS);
+                        } else {
+                                const uint32_t off = blk_off[t.first_block + b];
+                                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
+                                row_decode<CODEC, false, Plane0Post>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, w0, post PROF_PASS);
+                        }
+                }
+        __syncthreads();
+        uint32_t *pa = planes0 + (size_t)row * plw + (size_t)wfirst * PL_WORDS;
+        for (uint32_t i = tid; i < wn * PL_WORDS; i += AND_WG)
+                pa[i] = pl[i];
+        if (prank) { // (a 64-byte record per PL_RANK_DOCS documents: the group's first posting, its eight plane-0 words — k_term_planes)
+                uint32_t *rec = prank + ((size_t)row * (plw / (PL_RANK_DOCS / 32u)) + (size_t)wfirst * (PL_W / PL_RANK_DOCS)) * PL_RANK_WORDS;
+                for (uint32_t i = tid; i < wn * (PL_W / PL_RANK_DOCS) * PL_RANK_WORDS; i += AND_WG) {
+                        const uint32_t gg = i / PL_RANK_WORDS, k = i % PL_RANK_WORDS;
+                        rec[i] = k == 0 ? rdir[gg] : k <= 8 ? pl[8u * gg + k - 1u] : 0u;
+                }
+        }
+}
+
 // ------------------------------------------------------------------------------------------ k_planes
 // AccumulatedScoreScheme + top-K of a CNF query (a union, a conjunction of terms / OR-groups, an excluded group, optional scoring
 // terms: everything k_fused's CNF instantiations take) in one pass, on BIT PLANES instead of a word per document.  Round 5's shape:

@@ -282,7 +282,7 @@ struct tri_index : HostIndex {
         //      same head terms step after step.  Two regions, built BY NEED (dev_structs.hpp: PL_HI): d_pcache holds every row's PLANE 0 (plw
         //      words a row: all a DocumentsOnly batch reads), d_pcache_hi the rows' HIGH parts (nested planes 1 .. 3 + level words, PL_HI * plw
         //      words a row) — allocated by the first scored batch that reads planes, a row's part built when such a batch names the row.  pc_cap
-        //      rows + one all-zero row (index pc_cap) in each region; pc_built[r]: bit 0 plane 0, bit 1 the high part — the build has been
+        //      rows + one all-zero row (index pc_cap) in each region; pc_built[r]: bit 0 plane 0, bit 1 the high part, bit 2 the rank records — the build has been
         //      enqueued on the engine stream (every later kernel of the stream sees it).  Grown (rows moved on the upload stream) when a batch is
         //      planned with more eligible terms than it holds.
         uint32_t *d_pcache = nullptr, *d_pcache_hi = nullptr;
@@ -1100,13 +1100,16 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         }
                         if (!build.empty()) {
                                 HIP_TRY(hipMemcpyAsync(b->d_build, build.data(), build.size() * 4, hipMemcpyHostToDevice, dev->stream)); // (pageable source: staged before the call returns)
-                                const uint32_t nrows = (uint32_t)(build.size() / 2);
+                                const uint32_t nrows = (uint32_t)(build.size() / 2), nwin = b->plw / PL_WORDS;
                                 for (uint32_t y0 = 0; y0 < nrows; y0 += 65535u) { // (gridDim.y <= 65535)
-                                        const dim3 grid(b->plw / PL_WORDS, std::min(65535u, nrows - y0));
-                                        // (a row that gains its high part is decoded whole again: plane 0 is rewritten with the words it holds)
-                                        TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff,
-                                                   ix->d_win, ix->d_terms, (const uint32_t *)b->d_build + 2 * (size_t)y0, ix->d_pcache, (size_t)b->plw,
-                                                   b->planes_hi ? ix->d_pcache_hi : (uint32_t *)nullptr, (size_t)PL_HI * b->plw, b->plw, ix->d_prank);
+                                        const uint32_t ny = std::min(65535u, nrows - y0);
+                                        if (b->planes_hi) // (a row that gains its high part is decoded whole again: plane 0 is rewritten with the words it holds)
+                                                TRI_LAUNCH(k_term_planes, ix->codec, dim3(nwin, ny), dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec,
+                                                           ix->d_blk_doff, ix->d_win, ix->d_terms, (const uint32_t *)b->d_build + 2 * (size_t)y0, ix->d_pcache, (size_t)b->plw, ix->d_pcache_hi,
+                                                           (size_t)PL_HI * b->plw, b->plw, (uint32_t *)nullptr);
+                                        else // plane 0 alone, P0_GROUP windows to a workgroup (the rank records: built when a phrase batch asks for them, below)
+                                                TRI_LAUNCH(k_term_plane0, ix->codec, dim3((nwin + P0_GROUP - 1) / P0_GROUP, ny), dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off,
+                                                           ix->d_blk_rec, ix->d_blk_doff, ix->d_win, ix->d_terms, (const uint32_t *)b->d_build + 2 * (size_t)y0, ix->d_pcache, b->plw, (uint32_t *)nullptr);
                                         HIP_TRY(hipGetLastError());
                                 }
                                 for (size_t i = 1; i < build.size(); i += 2)
@@ -1233,8 +1236,8 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                 hits_build.push_back(term);
                                 hits_build.push_back(r);
                                 max_blocks = std::max(max_blocks, t.nblocks);
-                                if (!(ix->pc_built[r] & 1u)) {
-                                        ix->pc_built[r] |= 1u;
+                                if (!(ix->pc_built[r] & 4u)) { // (bit 2: the row's rank records — with them plane 0, if it is not there yet)
+                                        ix->pc_built[r] |= 5u;
                                         rows_build.push_back(term);
                                         rows_build.push_back(r);
                                 }
@@ -1248,9 +1251,9 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                         //  sized for the batch's plane terms, so these go one k_term_planes launch per row, from the pairs just written)
                                         for (size_t i = 0; i < hits_build.size(); i += 2)
                                                 if (std::find(rows_build.begin(), rows_build.end(), hits_build[i]) != rows_build.end()) {
-                                                        const dim3 grid(b->plw / PL_WORDS, 1);
-                                                        TRI_LAUNCH(k_term_planes, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff,
-                                                                   ix->d_win, ix->d_terms, (const uint32_t *)d_pairs + i, ix->d_pcache, (size_t)b->plw, (uint32_t *)nullptr, (size_t)0, b->plw, ix->d_prank);
+                                                        const dim3 grid((b->plw / PL_WORDS + P0_GROUP - 1) / P0_GROUP, 1);
+                                                        TRI_LAUNCH(k_term_plane0, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff,
+                                                                   ix->d_win, ix->d_terms, (const uint32_t *)d_pairs + i, ix->d_pcache, b->plw, ix->d_prank);
                                                         HIP_TRY(hipGetLastError());
                                                 }
                                 }
