@@ -47,6 +47,9 @@ struct tri_options {
         uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs PL_PLANES bitmaps over the docID space and one decode per index)
         uint64_t planes_rebuild = 0;           // 1: every tri_batch_run decodes the plane rows its batch names AGAIN (a cold plane cache: what a query stream pays whose head
                                                // terms have all just been evicted) — a measurement switch (bench.py's rotating leg), never a speed-up
+        uint64_t planes_order = 1;             // k_planes' tasks: 1 docID range by range, within a range by the heaviest plane row they sweep (the workgroups in flight stream the same
+                                               // head rows from about the same place: those words come from L2); 2: row by row, a query's ranges side by side; 0: heaviest task first.
+                                               // Round 6, k_planes ms at 0 / 1 / 2: cfg3 4.40 / 4.12 / 4.33, cfg5's shard 2.17 / 2.10 / 2.20 (with four ranges a query: 5.44 / 4.73 / -)
         uint64_t cand_xcd = 1;                 // k_and's tasks queued per XCD by the plane row they probe (planner.hpp "k_and's queues"); 0: the cost order dealt round the queues
         uint64_t plan_threads = 0;             // host threads tri_batch_create plans with; 0: up to 16, one per 512 queries
         uint64_t result_bitmaps = 1;           // DocumentsOnly: a bitmap-window query whose expected matches outnumber the words of a bitmap over its docID range
@@ -2040,6 +2043,18 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 f.hist.assign(SCHED_KEYS, 0u);
                 for (size_t i = 0; i < f.tasks.size(); ++i) { // (the kinds are final: a probe task whose planes were not chosen is a candidate-tile task by now)
                         const DevTask &tk = P.tasks[f.b_tasks + i];
+                        if ((tk.kind == TASK_PLANES || tk.kind == TASK_PLANES8) && opt.planes_order) {
+                                // (option planes_order: k_planes' tasks range by range, within a range by the heaviest plane row they sweep — the workgroups
+                                //  in flight then stream the same head rows from the same place: L2 instead of the fabric)
+                                const DevQuery &q = P.plan[tk.slot];
+                                const DevFused &z = P.fused[q.fused_idx];
+                                uint32_t minrow = PL_NONE;
+                                for (uint32_t sidx = 0; sidx < z.nslots; ++sidx)
+                                        minrow = std::min(minrow, z.plane[sidx]);
+                                const uint32_t ord = (uint32_t)(f.b_tasks + i) - q.first_task, per = SCHED_NB / 4;
+                                ++f.hist[f.keys[i] = SCHED_RANK[tk.kind] * SCHED_NB + (opt.planes_order == 2 ? std::min(minrow, per - 1) * 4 + std::min(ord, 3u) : std::min(ord, 3u) * per + std::min(minrow, per - 1))];
+                                continue;
+                        }
                         if (tk.kind != TASK_CAND || !cand_rows) {
                                 ++f.hist[f.keys[i] = sched_key(tk.kind, f.tcost[i])];
                                 continue;
