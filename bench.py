@@ -19,13 +19,13 @@ docID sets themselves stay in HBM (DESIGN.md §5 has the PCIe-inclusive figure).
 planning or read-back (HIP-event time of the runs inside the same timed steps).
 
 Multi-GPU: one process per GPU, the index replicated, the query stream sharded (queries are independent, exec.h:57-62):
---scaling weak (default) gives every rank a shard of --queries queries, --scaling strong splits --queries over the ranks; with
---gpus N > 1 the default workload is cfg5, the mixed 100K-query batch BASELINE.json's scaling criterion is quoted on (12500 queries
-per GPU).  At the end of every step the ranks all_gather their result blocks over RCCL straight from the engine's device buffers:
+--scaling weak gives every rank a shard of --queries queries, --scaling strong splits --queries over the ranks; with --gpus N > 1 the
+default workload is cfg5, the mixed 100K-query batch BASELINE.json's scaling criterion is quoted on, STRONG scaling: the 100 000 queries
+split over the N ranks (N = 1: weak, the cfg2 headline).  At the end of every step the ranks all_gather their result blocks over RCCL straight from the engine's device buffers:
 per-query match counts and, for scored batches, the [Q/G][K] top-K docID/score blocks (trinity_amd/dist.py ResultGather — the
-only exchange the path has).  A line is self-contained for scaling: at N = 1 `scaling_ref` is this GPU's rate on one rank's cfg5 shard
-(the workload the N > 1 lines run), at N > 1 `scaling_ref` is rank 0's rate on its shard with the other ranks parked at a barrier,
-and `speedup_vs_scaling_ref` = value / that.
+only exchange the path has).  Every line carries `scaling_point` — the mixed 100 K-query batch, strong scaling: value, per_gpu_value,
+gather_ms, hbm_bytes_in_use and `n1`, the SAME workload on one GPU measured in the same run (N = 1: this GPU runs the whole 100 K batch after
+the cfg2 headline; N > 1: rank 0 alone on the whole batch, the other ranks parked at a barrier) — so a curve can be read from the lines alone.
 
 Rank 0 prints ONE JSON line: metric/value = queries/s over all GPUs.  `roofline`: bound "hbm"; `frac` is the BATCH-LEVEL bound — every
 distinct list the step's queries name read once + every output written once (tri_batch_info.bound_bytes) / the step's kernel time /
@@ -47,6 +47,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SCALING_TOTAL_QUERIES = 100_000  # the mixed batch north_star's scaling target is worded on (BASELINE.json configs[4])
+
+
+def hbm_in_use(mem):
+    """tri_dev_memory -> what the bench line states: the engine's pooled buffers in use (batches' arenas, output regions, plane caches), the idle ones it keeps,
+    and everything resident on the device (indexes, RCCL, the runtime: total - free)."""
+    return {"engine_pool_in_use": mem["pool_in_use_bytes"], "engine_pool_idle": mem["pool_idle_bytes"], "device_in_use": mem["device_total_bytes"] - mem["device_free_bytes"],
+            "device_total": mem["device_total_bytes"]}
 KERNELS = ("k_and_dense", "k_psets", "k_probe", "k_and", "k_fused", "k_planes", "k_phrase")  # the kernels with per-launch HIP-event brackets and their own byte counts
 KMS = {"k_and_dense": "dense_ms", "k_psets": "pset_ms", "k_probe": "probe_ms", "k_and": "cand_ms", "k_fused": "fused_ms", "k_planes": "planes_ms", "k_phrase": "phrase_ms"}
 KALG = {"k_and_dense": "dense_algorithmic_bytes", "k_psets": "pset_algorithmic_bytes", "k_probe": "probe_algorithmic_bytes", "k_and": "cand_algorithmic_bytes", "k_fused": "fused_algorithmic_bytes", "k_planes": "planes_algorithmic_bytes",
@@ -67,6 +75,9 @@ class DryDevice:
 
     def set_option(self, k, v):
         self.opts[k] = int(v)
+
+    def memory(self):
+        return {"pool_in_use_bytes": 0, "pool_idle_bytes": 0, "pinned_idle_bytes": 0, "device_free_bytes": 0, "device_total_bytes": 0}
 
     def close(self):
         pass
@@ -261,6 +272,7 @@ class Pipeline:
             th.start()
         self.done = None  # the last completed set: its results stay readable
         self.readback_s = 0.0
+        self.gather_s = 0.0
 
     def step(self):
         T = self.T
@@ -279,6 +291,7 @@ class Pipeline:
         read_back(T, self.cur)
         self.readback_s += time.perf_counter() - t0
         if self.gathers:  # result exchange straight from the engine's device buffers (docsets stay sharded in HBM)
+            t0 = time.perf_counter()
             for g, b in zip(self.gathers, self.cur):
                 g.rebind(self.blocks_of(b))
                 g.step()
@@ -286,6 +299,7 @@ class Pipeline:
                 import torch
 
                 torch.cuda.current_stream().synchronize()  # the receive side is complete before the send buffers go back to the pool
+            self.gather_s += time.perf_counter() - t0
         infos = [b.info() for b in self.cur]
         for i, c in zip(infos, launched):  # the tri_batch_create calls of the set launched in this step (one set is compiled per step in the steady state)
             ci = c.info()
@@ -316,6 +330,7 @@ def timed(pipe, steps, warmup, barrier):
         pipe.step()
     barrier()
     pipe.readback_s = 0.0
+    pipe.gather_s = 0.0
     acc = {}
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -359,7 +374,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline sample budget (0 = skip)")
     ap.add_argument("--workload", default=None, choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"],
                     help="SURVEY §8(d) query sets; default: cfg2 at one GPU (the configuration BASELINE.json's metric is quoted on), cfg5 (the mixed 100K batch) at N > 1")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: --queries per GPU; strong: --queries in all, split over the GPUs")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="weak: --queries per GPU; strong: --queries in all, split over the GPUs.  Default: weak at N = 1 (the cfg2 "
+                    "headline), STRONG at N > 1 — north_star's target is ONE 100 K-query mixed batch sharded over the node's GPUs")
+    ap.add_argument("--scaling-total", type=int, default=SCALING_TOTAL_QUERIES, help="N = 1: queries of the mixed batch the scaling point's leg runs (north_star: 100000)")
     ap.add_argument("--scaling-ref-steps", type=int, default=3, help="steps of the scaling reference leg (0 = skip): N = 1: one rank's cfg5 shard on this GPU; N > 1: rank 0 alone on its shard")
     ap.add_argument("--rotating-sets", type=int, default=8, help="N = 1: distinct query sets (seeds 1337 ...) cycled through the loop in the rotating legs (0 / 1 = skip them)")
     ap.add_argument("--rotating-steps", type=int, default=16, help="timed steps of each rotating leg")
@@ -379,6 +396,8 @@ def main():
         args.gpus = world
     if args.workload is None:
         args.workload = "cfg2" if world == 1 else "cfg5"
+    if args.scaling is None:
+        args.scaling = "weak" if world == 1 else "strong"
     per_gpu_default = {"cfg3": 8192, "cfg5": 12500, "cfg1": 2000}.get(args.workload, 16384)
     if not args.queries:
         args.queries = per_gpu_default * (8 if args.scaling == "strong" else 1)  # strong: the 8-GPU batch (cfg5: 100K queries) at every N
@@ -448,36 +467,36 @@ def main():
     Pipeline.COMPILERS = max(1, args.compilers)
     pipe = Pipeline(T, wl, gathers, blocks_of, sync_stream=not dry)
 
-    # ---- scaling reference (before the timed region; every rank takes part so that the ranks stay in step)
-    scaling_ref = None
+    # ---- the scaling curve's N = 1 point, measured in THIS run (before the timed region; every rank takes part so that the ranks stay in step).  The curve
+    #      north_star asks for is ONE mixed 100 K-query batch (cfg5) sharded over the node's GPUs: strong scaling.  N > 1: rank 0 alone runs the WHOLE
+    #      batch of this run (the other ranks parked at a barrier) — the same workload on one GPU; N = 1 (the cfg2 headline): this GPU runs the whole
+    #      100 K mixed batch.  Either way the line carries `scaling_point` with the same-workload one-GPU rate beside its own.
+    n1 = None
     if args.scaling_ref_steps > 0:
-        if world > 1:
-            # rank 0 alone on its shard (no gather, the other ranks parked at the barrier): the one-GPU rate of THIS workload in THIS run
+        n1_total = total_queries if world > 1 else args.scaling_total
+        n1_workload = args.workload if world > 1 else "cfg5"
+        if world > 1 or (args.workload != "cfg5" and docs == 10_000_000) or dry:
             barrier()
             if rank == 0:
-                solo = Pipeline(T, wl)
-                el, _ = timed(solo, args.scaling_ref_steps, 3, device_sync)  # (three warm-up steps: see below)
+                t0 = time.time()
+                n1_wl = wl if (world == 1 and n1_workload == args.workload and n1_total == total_queries) else \
+                    Workload(DryEngine(T) if dry else T, W, dev, n1_workload, docs, vocab, n1_total, 0, 1, segs, ixs)
+                solo = Pipeline(T, n1_wl, compilers=1)  # (a 100 K batch plans in a few ms against a step of tens: one compiler, one set fewer alive)
+                # (three warm-up steps: the sets alive in the loop each allocate their output regions once — up to half a second for a 17 GB region;
+                #  from the fourth create on the device pool recycles them)
+                el, _ = timed(solo, args.scaling_ref_steps, 3, device_sync)
+                mem = dev.memory()
                 solo.close()
-                scaling_ref = {"workload": wl.desc, "queries_per_step": nq_rank, "steps": args.scaling_ref_steps, "value": nq_rank * args.scaling_ref_steps / el, "unit": "queries/s",
-                               "what": "rank 0 alone on its shard of this run's workload (the other ranks parked at a barrier), the same create -> run -> read-back loop without the gather"}  # fmt: skip
+                n1 = {"workload": n1_wl.desc, "scaling": "strong", "total_queries": n1_wl.nq, "n_gpus": 1, "steps": args.scaling_ref_steps, "value": n1_wl.nq * args.scaling_ref_steps / el,
+                      "unit": "queries/s", "ms_per_step": el * 1e3 / args.scaling_ref_steps, "hbm_bytes_in_use": hbm_in_use(mem), "setup_s": time.time() - t0,
+                      "what": "ONE GPU (rank 0, the other ranks parked at a barrier) on the whole batch: the same create -> run -> sync -> read-back loop, no gather"}  # fmt: skip
             barrier()
-        elif args.workload != "cfg5" and docs == 10_000_000:
-            # one rank's shard of the mixed 100K batch (what the N > 1 lines run per GPU) on this GPU
-            t0 = time.time()
-            ref_wl = Workload(DryEngine(T) if dry else T, W, dev, "cfg5", docs, vocab, 12500, 0, 1, segs, ixs)
-            ref = Pipeline(T, ref_wl)
-            # (three warm-up steps: three sets of batches are alive in the loop — done, current, next —, and the first allocation of each one's
-            #  17 GB output region costs up to half a second (measured: 0.2 ms .. 484 ms); from the fourth create on the device pool recycles them.
-            #  With one warm-up step two of those allocations fell into the three timed steps: 70 K queries/s reported for a 540 K loop)
-            el, _ = timed(ref, args.scaling_ref_steps, 3, device_sync)
-            ref.close()
-            scaling_ref = {"workload": ref_wl.desc, "queries_per_step": ref_wl.nq, "steps": args.scaling_ref_steps, "value": ref_wl.nq * args.scaling_ref_steps / el, "unit": "queries/s",
-                           "what": "one GPU's shard of the mixed 100K-query batch (12500 queries: what bench.py --gpus N > 1 runs per GPU), the same create -> run -> read-back loop; "
-                                   "compare the N > 1 lines' per_gpu_value with this, not with `value` (cfg2)", "setup_s": time.time() - t0}  # fmt: skip
 
     # ---- the timed region
     elapsed, acc = timed(pipe, args.steps, args.warmup, barrier)
     readback_ms = pipe.readback_s * 1e3 / max(1, args.steps)
+    gather_ms = pipe.gather_s * 1e3 / max(1, args.steps)
+    mem_after = dev.memory()
     region = acc.pop("_region")
     cstats = create_stats(pipe, region, args.steps, elapsed * 1e3 / max(1, args.steps))
 
@@ -605,8 +624,7 @@ def main():
                  "per_query_algorithmic": {"bytes_per_launch": tot[KALG[k]], "effective_GBps": gbs(tot[KALG[k]], kms[k])}}  # fmt: skip
             if k == "k_and" and tot["cand_needed_bytes"]:
                 # what a perfect gallop must read for these queries, query by query (lead lists + the blocks that can hold a lead candidate + output)
-                e["needed_bytes_per_launch"] = tot["cand_needed_bytes"]
-                e["needed_frac"] = frac(tot["cand_needed_bytes"], kms[k])
+                e["gallop_model_bytes_per_launch"] = tot["cand_needed_bytes"]  # (a MODEL of what a perfect gallop would read — k_and probes plane rows instead: these bytes are not moved, no fraction)
             return e
 
         # (the term planes live with the index: k_term_planes ran once, in the warm-up — the profile saw that one dispatch, a timed step has none)
@@ -687,10 +705,19 @@ def main():
             out["value_rotating"] = rotating["cold_planes"]["value"]
         if delivered is not None:
             out["delivered"] = delivered
-        if scaling_ref is not None:
-            out["scaling_ref"] = scaling_ref
-            if world > 1:
-                out["speedup_vs_scaling_ref"] = qps / scaling_ref["value"]
+        out["hbm_bytes_in_use"] = hbm_in_use(mem_after)
+        if world > 1:
+            out["gather_ms"] = gather_ms
+        # the scaling curve's point this line stands for, self-contained: the mixed batch, strong scaling, with the same workload's one-GPU rate beside it
+        if world > 1:
+            out["scaling_point"] = {"workload": wl.desc, "scaling": args.scaling, "total_queries": nq_rank * world, "n_gpus": world, "value": qps, "unit": "queries/s",
+                                    "per_gpu_value": qps / world, "ms_per_step": ms_per_step, "gather_ms": gather_ms, "hbm_bytes_in_use": hbm_in_use(mem_after), "n1": n1,
+                                    "speedup_vs_n1": qps / n1["value"] if n1 else None,
+                                    "what": "this run: N ranks, the batch split over them, per-step RCCL all_gather of counts + top-K blocks; n1: rank 0 alone on the whole batch, same run"}  # fmt: skip
+        elif n1 is not None:
+            out["scaling_point"] = {**{k: v for k, v in n1.items() if k not in ("what", "setup_s")}, "per_gpu_value": n1["value"], "gather_ms": None, "n1": n1, "speedup_vs_n1": 1.0,
+                                    "what": "the N = 1 point of the scaling curve (`value` above is the cfg2 headline, a different workload): this GPU on the whole mixed 100 K-query "
+                                            "batch bench.py --gpus N > 1 splits over N GPUs"}  # fmt: skip
         if gather_check is not None:
             out["gather_check"] = gather_check
         if args.cpu_seconds > 0 and world == 1 and not dry:  # the CPU leg (and the per-query parity check that rides on it) runs at N = 1 only

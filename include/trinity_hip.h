@@ -22,11 +22,12 @@
 extern "C" {
 #endif
 
-#define TRI_ABI_VERSION 8 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
+#define TRI_ABI_VERSION 9 /* 2: tri_batch_info grew (fused_*), tri_dev_set_option / tri_dev_get_option; 3: TRI_OP_SOME, tri_batch_info.cand_needed_bytes / phrase_*;
                              4: tri_batch_info grew (term planes, k_planes), tri_batch_query_status, tri_comm_create_custom; 5: tri_encode_google_payloads;
                              6: tri_batch_info.create_ms / create_plan_ms / *_bound_bytes, options plane_max_bytes / plan_threads, tri_cbatch_query_status;
                              7: TASK_TREE (any query tree), tri_batch_info.tree_ms / tree_queries / tree_scratch_bytes, tri_commit_* / tri_merge_google;
-                             8: tri_batch_docsets (every query's docID set in one call), tri_merge_lucene, option planes_rebuild */
+                             8: tri_batch_docsets (every query's docID set in one call), tri_merge_lucene, option planes_rebuild;
+                             9: tri_dev_memory (HBM in use), two planner contexts per handle (two threads may compile at once), plane rows built by need */
 
 /* status codes */
 #define TRI_OK 0
@@ -202,6 +203,15 @@ void *tri_dev_stream(tri_dev *);
  * which tri_batch_run reads (they change how existing batches are launched).  Unknown names fail with TRI_ERR_INVALID. */
 int tri_dev_set_option(tri_dev *, const char *name, uint64_t value);
 int tri_dev_get_option(tri_dev *, const char *name, uint64_t *value);
+
+/* What the handle holds of the device's memory (no reference counterpart: Trinity mmaps its segments and mallocs per query — queryexec_ctx.cpp:187-249).
+ * pool_*: the handle's buffer pool — batches' arenas, output regions, score streams, the indexes' plane caches; in use / idle (idle buffers go back to
+ * the device beyond 64 GiB, or when an allocation fails).  device_*: hipMemGetInfo — everything on the device, other processes' memory included. */
+typedef struct {
+        uint64_t pool_in_use_bytes, pool_idle_bytes, pinned_idle_bytes;
+        uint64_t device_free_bytes, device_total_bytes;
+} tri_dev_memory_info;
+int tri_dev_memory(tri_dev *, tri_dev_memory_info *out);
 
 /* ---- index upload ---------------------------------------------------------------------------------
  * Replaces SegmentIndexSource's mmap of `index` (segment_index_source.cpp:84-93) + per-query

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol(T):
     L = hip_lib()
     for s in decl:
         assert getattr(L, s) is not None
-    assert L.tri_abi_version() == 8
+    assert L.tri_abi_version() == 9
 
 
 def test_missing_library_fails_loudly(T, monkeypatch):

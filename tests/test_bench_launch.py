@@ -31,20 +31,56 @@ def run_bench(nproc, extra):
     return json.loads(lines[0])
 
 
-def test_two_ranks_default_workload_is_the_mixed_batch():
+POINT_KEYS = {"workload", "scaling", "total_queries", "n_gpus", "value", "unit", "per_gpu_value", "ms_per_step", "gather_ms", "hbm_bytes_in_use", "n1", "speedup_vs_n1", "what"}
+
+
+def check_scaling_point(out, n, total):
+    """Every line carries the scaling curve's point it stands for, self-contained: the mixed batch, strong scaling, the same workload's one-GPU rate (n1) beside it."""
+    sp = out["scaling_point"]
+    assert POINT_KEYS <= set(sp), sorted(POINT_KEYS - set(sp))
+    assert sp["scaling"] == "strong" and sp["n_gpus"] == n and sp["total_queries"] == total and sp["workload"].startswith("cfg5")
+    assert sp["per_gpu_value"] * n == pytest.approx(sp["value"]) and set(sp["hbm_bytes_in_use"]) == {"engine_pool_in_use", "engine_pool_idle", "device_in_use", "device_total"}
+    n1 = sp["n1"]
+    assert n1["n_gpus"] == 1 and n1["total_queries"] == total and n1["workload"] == sp["workload"] and n1["value"] > 0
+    assert sp["speedup_vs_n1"] == pytest.approx(sp["value"] / n1["value"])
+    assert (sp["gather_ms"] is None) == (n == 1)
+    assert "hbm_bytes_in_use" in out
+
+
+def test_two_ranks_default_workload_is_the_mixed_batch_split_over_the_ranks():
     out = run_bench(2, ["--queries", "1000"])
-    assert out["n_gpus"] == 2 and out["dry_run"] and out["scaling"] == "weak"
-    assert out["config"]["workload"].startswith("cfg5") and out["config"]["queries_per_gpu_per_step"] == 1000 and out["config"]["queries_per_step"] == 2000
-    assert [b["queries"] for b in out["config"]["batches_per_step"]] == [700, 300]
+    assert out["n_gpus"] == 2 and out["dry_run"] and out["scaling"] == "strong"  # (north_star: ONE batch sharded over the GPUs)
+    assert out["config"]["workload"].startswith("cfg5") and out["config"]["queries_per_gpu_per_step"] == 500 and out["config"]["queries_per_step"] == 1000
+    assert [b["queries"] for b in out["config"]["batches_per_step"]] == [350, 150]
     assert out["gather_check"] == {"ranks": 2, "blocks": ["counts", "docs", "scores", "topk_counts"], "equal_on_every_rank": True}
-    assert out["scaling_ref"]["queries_per_step"] == 1000 and "speedup_vs_scaling_ref" in out and out["per_gpu_value"] * 2 == out["value"]
+    assert out["per_gpu_value"] * 2 == out["value"] and out["gather_ms"] >= 0
+    check_scaling_point(out, 2, 1000)
     for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "vs_baseline", "dtype", "data", "roofline", "kernels_only", "end_to_end"):
         assert k in out
 
 
-def test_strong_scaling_splits_the_batch():
+def test_eight_ranks_carry_the_same_block():
+    out = run_bench(8, ["--queries", "1600"])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["queries_per_gpu_per_step"] == 200
+    check_scaling_point(out, 8, 1600)
+
+
+def test_one_gpu_line_carries_the_mixed_batch_point_beside_the_cfg2_headline():
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--dry-run", "--docs", "100000", "--vocab", "10000", "--queries", "512", "--scaling-total", "800",
+           "--scaling-ref-steps", "2"]  # fmt: skip
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and out["scaling"] == "weak" and out["config"]["workload"].startswith("cfg2")  # the headline stays BASELINE.json's configs[1]
+    check_scaling_point(out, 1, 800)
+    assert out["scaling_point"]["speedup_vs_n1"] == 1.0
+
+
+def test_weak_and_strong_scaling_on_request():
     out = run_bench(2, ["--queries", "1000", "--scaling", "strong", "--workload", "cfg2", "--scaling-ref-steps", "0"])
-    assert out["scaling"] == "strong" and out["config"]["queries_per_gpu_per_step"] == 500 and out["config"]["queries_per_step"] == 1000 and "scaling_ref" not in out
+    assert out["scaling"] == "strong" and out["config"]["queries_per_gpu_per_step"] == 500 and out["config"]["queries_per_step"] == 1000 and out["scaling_point"]["n1"] is None
+    out = run_bench(2, ["--queries", "600", "--scaling", "weak", "--scaling-ref-steps", "0"])
+    assert out["scaling"] == "weak" and out["config"]["queries_per_gpu_per_step"] == 600 and out["config"]["queries_per_step"] == 1200
 
 
 def test_reference_cpu_leg_runs_the_genuine_reference_on_the_sample():

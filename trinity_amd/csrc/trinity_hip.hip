@@ -536,6 +536,26 @@ extern "C" int tri_dev_get_option(tri_dev *d, const char *name, uint64_t *value)
         return TRI_OK;
 }
 
+extern "C" int tri_dev_memory(tri_dev *d, tri_dev_memory_info *out) {
+        if (!d || !out)
+                return fail(TRI_ERR_INVALID, "tri_dev_memory: null argument");
+        HIP_TRY(hipSetDevice(d->device));
+        size_t fr = 0, total = 0;
+        HIP_TRY(hipMemGetInfo(&fr, &total));
+        DevLock g(d->mu);
+        uint64_t all = 0, pinned = 0;
+        for (const auto &kv : d->pool.size_of)
+                all += kv.second;
+        for (const auto &pb : d->pinned_idle)
+                pinned += pb.first;
+        out->pool_idle_bytes = d->pool.idle_bytes;
+        out->pool_in_use_bytes = all - d->pool.idle_bytes;
+        out->pinned_idle_bytes = pinned;
+        out->device_free_bytes = fr;
+        out->device_total_bytes = total;
+        return TRI_OK;
+}
+
 extern "C" int tri_dev_sync(tri_dev *d) {
         if (!d)
                 return fail(TRI_ERR_INVALID, "null dev");

@@ -103,7 +103,7 @@ class TriBatchInfo(C.Structure):
 
 # every symbol include/trinity_hip.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
-    "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream", "tri_dev_set_option", "tri_dev_get_option",
+    "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream", "tri_dev_set_option", "tri_dev_get_option", "tri_dev_memory",
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
     "tri_batch_match_counts", "tri_batch_docset", "tri_batch_docset_bitmap", "tri_batch_docsets", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
@@ -133,6 +133,7 @@ def hip_lib():
     L.tri_dev_stream.argtypes = [vp]
     L.tri_dev_set_option.argtypes = [vp, C.c_char_p, C.c_uint64]
     L.tri_dev_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_uint64)]
+    L.tri_dev_memory.argtypes = [vp, C.POINTER(C.c_uint64 * 5)]
     L.tri_index_upload.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_uint32, C.POINTER(vp)]
     L.tri_index_destroy.argtypes = [vp]
     L.tri_index_get_info.argtypes = [vp, C.POINTER(TriIndexInfo)]
@@ -290,6 +291,12 @@ class Device:
         v = C.c_uint64()
         _check(hip_lib().tri_dev_get_option(self.h, name.encode(), C.byref(v)))
         return v.value
+
+    def memory(self):
+        """tri_dev_memory: the handle's buffer pool (in use / idle), its idle pinned blocks, and the device's free / total bytes."""
+        v = (C.c_uint64 * 5)()
+        _check(hip_lib().tri_dev_memory(self.h, C.byref(v)))
+        return dict(zip(("pool_in_use_bytes", "pool_idle_bytes", "pinned_idle_bytes", "device_free_bytes", "device_total_bytes"), (int(x) for x in v)))
 
     def encode_google(self, docs, freqs, positions, term_first, payload_lens=None, payloads=None):
         """The write side on the device (tri_encode_google / tri_encode_google_payloads): postings of len(term_first) - 1 terms ->
