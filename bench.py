@@ -524,11 +524,26 @@ def main():
                             "head term's plane row cached with the index, `cold_planes` with the rows a step names decoded again in that step (planes_rebuild: every row evicted)"}  # fmt: skip
     if world == 1 and not dry and args.delivered_steps > 0:
         # (c) delivery: the docID sets themselves brought to the host — what MatchedIndexDocumentsFilter::consider(ids, cnt) (matches.h:161-165) is fed — into PINNED
-        #     memory by tri_batch_docsets (one device-side gather + one copy per batch); serial loop (create -> run -> sync -> deliver), no overlap
+        #     memory, one device-side gather + one copy per batch.  Two legs: `as_docids` — tri_batch_docsets, every set as ascending 4-byte docIDs (dense results
+        #     expanded on the device first), serial: create -> run -> sync -> deliver; and the leg `value` is taken from — tri_batch_docsets_mixed, every set in the
+        #     form the engine holds it (a dense set crosses PCIe as the words of its bitmap), OVERLAPPED: set n is delivered on the read-back stream while set n + 1's
+        #     kernels run (the delivery waits outside the handle's lock)
         docs_parts = [i for i, pt in enumerate(parts) if not (pt.flags & T.FLAG_ACCUMULATED_SCORE)]
         need = [int(batches[i].counts().sum()) for i in docs_parts]
         if docs_parts and max(need) * 4 <= (6 << 30):
             pinned = torch.empty(max(need) + 64, dtype=torch.int32).pin_memory()
+
+            def deliver(bs, mixed):
+                nbytes = 0
+                for i, b in enumerate(bs):
+                    b.sync()
+                    if i in docs_parts:
+                        offs = (b.docsets_mixed(out=pinned) if mixed else b.docsets(out=pinned))[1]
+                        nbytes += int(offs[-1]) * 4
+                    else:
+                        read_back(T, [b])
+                return nbytes
+
             bytes_step = 0
             for it in range(args.delivered_steps + 1):  # (the first one untimed)
                 if it == 1:
@@ -537,21 +552,38 @@ def main():
                 bs = wl.create_set()
                 for b in bs:
                     b.run()
-                bytes_step = 0
-                for i, b in enumerate(bs):
-                    b.sync()
-                    if i in docs_parts:
-                        _, offs = b.docsets(out=pinned)
-                        bytes_step += int(offs[-1]) * 4
-                    else:
-                        read_back(T, [b])
+                bytes_step = deliver(bs, False)
                 for b in bs:
                     b.close()
             el = time.perf_counter() - t0
-            delivered = {"value": nq_rank * args.delivered_steps / el, "unit": "queries/s", "ms_per_step": el * 1e3 / args.delivered_steps, "steps": args.delivered_steps,
-                         "docid_bytes_per_step": bytes_step, "host_GBps": bytes_step * args.delivered_steps / el / 1e9,
-                         "what": "create -> run -> sync -> tri_batch_docsets: EVERY query's ascending docID set gathered on the device and copied into pinned host memory (the feed of "
-                                 "consider(ids, cnt)); serial, PCIe-bound — `value` above leaves the sets in HBM"}  # fmt: skip
+            as_docids = {"value": nq_rank * args.delivered_steps / el, "unit": "queries/s", "ms_per_step": el * 1e3 / args.delivered_steps, "docid_bytes_per_step": bytes_step,
+                         "host_GBps": bytes_step * args.delivered_steps / el / 1e9}  # fmt: skip
+            prev = wl.create_set()
+            for b in prev:
+                b.run()
+            msteps = 2 * args.delivered_steps
+            for it in range(msteps + 1):  # (the first one untimed)
+                if it == 1:
+                    device_sync()
+                    t0 = time.perf_counter()
+                nxt = wl.create_set()
+                for b in nxt:
+                    b.run()  # behind `prev` on the engine stream
+                bytes_step = deliver(prev, True)  # ... whose delivery (read-back stream) runs beside these kernels
+                for b in prev:
+                    b.close()
+                prev = nxt
+            for b in prev:
+                b.sync()
+            el = time.perf_counter() - t0
+            for b in prev:
+                b.close()
+            delivered = {"value": nq_rank * msteps / el, "unit": "queries/s", "ms_per_step": el * 1e3 / msteps, "steps": msteps,
+                         "docid_bytes_per_step": bytes_step, "host_GBps": bytes_step * msteps / el / 1e9, "as_docids": as_docids,
+                         "what": "create -> run -> sync -> tri_batch_docsets_mixed: EVERY query's docID set in the form the engine holds it — ascending docIDs, or the words of a "
+                                 "bitmap over the docID range for the dense ones — gathered on the device and copied into pinned host memory (the feed of consider(ids, cnt), which "
+                                 "expands a bitmap on its side), set n delivered while set n + 1 runs; PCIe-bound — `value` above leaves the sets in HBM.  as_docids: every set as "
+                                 "4-byte docIDs (tri_batch_docsets), serial"}  # fmt: skip
             del pinned
         else:
             delivered = {"skipped": "no DocumentsOnly part" if not docs_parts else f"{max(need) * 4 / 2**30:.1f} GiB of docIDs per step: not brought to the host in this leg"}
@@ -583,7 +615,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         gather_check = {"ranks": world, "blocks": sorted({k for g in gathers for k in g.recv}), "equal_on_every_rank": bool(t.item() == 1.0)}
     # (c) how many of the step's matches exist as docIDs in HBM (4 bytes each) and how many as bits of a result bitmap (RESULT_BITMAP: dense results)
-    mat_ids = mat_bits = 0
+    mat_ids = mat_bits = bitmap_queries = bitmap_bytes = 0
     for pt, b0 in zip(parts, batches):
         cnts = b0.counts()
         if (pt.flags & T.FLAG_ACCUMULATED_SCORE) and pt.topk:
@@ -591,9 +623,12 @@ def main():
             continue
         if dry:
             continue
-        forms = np.array([b0.docset_form(q) for q in range(len(cnts))], dtype=bool)
+        words = np.array([b0.docset_bitmap_words(q) for q in range(len(cnts))], dtype=np.int64)
+        forms = words > 0
         mat_bits += int(cnts[forms].sum())
         mat_ids += int(cnts[~forms].sum())
+        bitmap_queries += int(forms.sum())
+        bitmap_bytes += int(words.sum()) * 4  # (a RESULT_BITMAP region is one bit per document of the query's docID range, whatever it matches)
     same_as_resident = all(bool(np.array_equal(b.counts(), b0.counts())) for b, b0 in zip(pipe.done, batches))
 
     if rank == 0:
@@ -665,7 +700,7 @@ def main():
             "per_gpu_value": qps / world,
             "matched_docids_per_sec": matches_all * steps / elapsed,
             "matches_per_step": matches_all,
-            **({"docids_materialised_per_sec": mat_ids * steps / elapsed, "docids_materialised_per_step": mat_ids, "matches_kept_as_bitmap_bits_per_step": mat_bits,
+            **({"docids_materialised_per_sec": mat_ids * steps / elapsed, "docids_materialised_per_step": mat_ids, "matches_kept_as_bitmap_bits_per_step": mat_bits, "bitmap_queries_per_step": bitmap_queries, "bitmap_bytes_per_step": bitmap_bytes,
                 "materialised_what": "of this rank's matches per step: written to HBM as 4-byte docIDs (scored batches: their top-K lists) / kept as bits of a result bitmap "
                                      "(tri_batch_docset_bitmap; tri_batch_docsets expands them on delivery)"} if world == 1 else {}),
             "pipelined_results_equal_resident_batch": same_as_resident,

@@ -27,7 +27,7 @@ extern "C" {
                              6: tri_batch_info.create_ms / create_plan_ms / *_bound_bytes, options plane_max_bytes / plan_threads, tri_cbatch_query_status;
                              7: TASK_TREE (any query tree), tri_batch_info.tree_ms / tree_queries / tree_scratch_bytes, tri_commit_* / tri_merge_google;
                              8: tri_batch_docsets (every query's docID set in one call), tri_merge_lucene, option planes_rebuild;
-                             9: tri_dev_memory (HBM in use), two planner contexts per handle (two threads may compile at once), plane rows built by need */
+                             9: tri_dev_memory (HBM in use), tri_batch_docsets_mixed (dense sets delivered as bitmap words), two planner contexts per handle (two threads may compile at once), plane rows built by need */
 
 /* status codes */
 #define TRI_OK 0
@@ -292,6 +292,12 @@ int tri_batch_docset_bitmap(tri_batch *, size_t q, int *form, uint32_t *words, s
  * MatchedIndexDocumentsFilter::consider(const docid_t *, size_t) (matches.h:161-165; exec.cpp:1213-1229 hands every match to consider()) loops
  * over.  Fails like tri_batch_docset for a query of an AccumulatedScore top-K batch whose set was never materialised. */
 int tri_batch_docsets(tri_batch *, uint32_t *out, size_t cap, uint64_t *offsets /* [nq + 1] */);
+/* ... each set in the form the engine holds it (the batch form of tri_batch_docset / tri_batch_docset_bitmap): forms[q] = 0: out[offsets[q] .. offsets[q + 1]) = query q's
+ * ascending docIDs; 1 (a DocumentsOnly union / conjunction of head terms expected to match one document in 32 or more — option result_bitmaps): the words of a bitmap
+ * over the query's docID range, bit j of word i = document 32 i + j matches (tri_batch_match_counts gives its matches).  A dense set crosses PCIe as one bit per document
+ * instead of four bytes per match; the caller expands it into the ids of consider(const docid_t *, size_t) (matches.h:161-165), or keeps the bitmap.  Same calling
+ * convention as tri_batch_docsets (out == NULL: offsets and forms only).  Both calls wait outside the handle's lock: another thread may compile or run meanwhile. */
+int tri_batch_docsets_mixed(tri_batch *, uint32_t *out, size_t cap /* words */, uint64_t *offsets /* [nq + 1] */, uint32_t *forms /* [nq] */);
 /* AccumulatedScore with topk == 0: the score of every match of query q, parallel to tri_batch_docset(q) — the
  * (id, score) stream MatchedIndexDocumentsFilter::consider(id, score) receives (matches.h:169; exec.cpp:1322-1341) */
 int tri_batch_scores(tri_batch *, size_t q, double *out, size_t cap, size_t *n);

@@ -544,6 +544,18 @@ def test_docsets_delivered_as_bitmaps(request, world):
                     assert int(offs[-1]) == sum(len(x) for x in want)
                     for i, t in enumerate(texts):
                         assert np.array_equal(flat[int(offs[i]) : int(offs[i + 1])], want[i]), (opts, t)
+                    # ... and each set in the form the engine holds it (tri_batch_docsets_mixed): the dense ones as the words of their bitmaps
+                    mflat, moffs, forms = b.docsets_mixed()
+                    assert int(forms.sum()) == nbm
+                    for i, t in enumerate(texts):
+                        part = mflat[int(moffs[i]) : int(moffs[i + 1])]
+                        if forms[i]:
+                            bits = np.unpackbits(part.view(np.uint8), bitorder="little")
+                            assert np.array_equal(np.nonzero(bits)[0].astype(np.uint32), want[i]), (opts, t)
+                        else:
+                            assert np.array_equal(part, want[i]), (opts, t)
+                    if nbm:
+                        assert int(moffs[-1]) < int(offs[-1])  # (a dense set weighs less as bits than as docIDs: that is when the planner chooses the form)
                 b.close()
             assert seen_forms == {True, False}
     finally:

@@ -521,8 +521,9 @@ __global__ void k_hash_docsets(const DevQuery *__restrict__ plan, const DevTask 
 // Every query's docID set into ONE contiguous buffer (tri_batch_docsets): a workgroup per task copies the task's segment — or, for a query
 // whose result is a bitmap (RESULT_BITMAP), writes out the documents of its windows' words — to flat[slot_off[query] + the matches of the
 // query's earlier tasks ...).  The in-order concatenation of a query's task segments IS its ascending docID set.
+// `mixed` (tri_batch_docsets_mixed): a RESULT_BITMAP query's words go out AS THEY ARE — flat[slot_off[query] + word of the query's region] — instead of as docIDs.
 __global__ __launch_bounds__(256) void k_deliver_docsets(const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks, const uint32_t *__restrict__ counts,
-                                                         const uint32_t *__restrict__ out, const uint64_t *__restrict__ slot_off, uint32_t *__restrict__ flat) {
+                                                         const uint32_t *__restrict__ out, const uint64_t *__restrict__ slot_off, uint32_t *__restrict__ flat, const uint32_t mixed) {
         __shared__ uint32_t scan[256];
         __shared__ uint64_t base_sh;
         const uint32_t tix = blockIdx.x, tid = threadIdx.x;
@@ -533,6 +534,14 @@ __global__ __launch_bounds__(256) void k_deliver_docsets(const DevQuery *__restr
         if (q.qid == 0xffffffffu)
                 return; // (a hidden phrase query — a leaf of a TASK_TREE query: no caller query, no place in flat[]; uniform)
         const uint32_t c = counts[tix];
+        if (mixed && q.form == RESULT_BITMAP) { // the task's windows, word for word (16 bytes a lane and step: regions and windows are multiples of SPAN_WORDS)
+                const uint4 *src = (const uint4 *)(out + tk.out_off);
+                uint4 *dst4 = (uint4 *)(flat + slot_off[tk.slot] + (tk.out_off - q.out_off));
+                const uint32_t n4 = (tk.tile_end - tk.tile_begin) * (SPAN_WORDS / 4);
+                for (uint32_t i = threadIdx.x; i < n4; i += 256)
+                        dst4[i] = src[i];
+                return;
+        }
         // the matches of the query's earlier tasks
         uint64_t before = 0;
         for (uint32_t t = q.first_task + tid; t < tix; t += 256)

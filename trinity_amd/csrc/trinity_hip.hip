@@ -1502,6 +1502,35 @@ extern "C" int tri_batch_sync(tri_batch *b) {
                                         fprintf(stderr, "  %s %.1f / %.1f / %.1f", nm[j], sum[j] / span[j].size(), span[j][span[j].size() / 2], span[j][span[j].size() * 9 / 10]);
                                 }
                         fprintf(stderr, "\n");
+                        // ... and by the query's DENSE slots (the sweep's instantiation) and whether it holds sparse ones: where the kernel's time goes
+                        double tsum[9][2], ssum[9][2], asum[9][2];
+                        unsigned tcnt[9][2];
+                        for (int x = 0; x < 9; ++x)
+                                for (int y = 0; y < 2; ++y)
+                                        tsum[x][y] = ssum[x][y] = asum[x][y] = 0.0, tcnt[x][y] = 0;
+                        for (uint32_t i = 0; i < nc; ++i) {
+                                const unsigned long long s0 = g_tt_host[8 * i], e0 = g_tt_host[8 * i + 1];
+                                if (!s0 || !e0)
+                                        continue;
+                                const DevTask &tk = b->tasks[b->sched[first + i]];
+                                const DevFused &z = b->fused[b->plan[tk.slot].fused_idx];
+                                uint32_t nd = 0;
+                                for (uint32_t k = 0; k < z.nslots; ++k)
+                                        nd += z.plane[k] != PL_NONE;
+                                const int sp = nd < z.nslots;
+                                nd = std::min(nd, 8u);
+                                tsum[nd][sp] += (double)(e0 - s0) / 100.0;
+                                if (g_tt_host[8 * i + 5] > g_tt_host[8 * i + 4] && g_tt_host[8 * i + 4])
+                                        ssum[nd][sp] += (double)(g_tt_host[8 * i + 5] - g_tt_host[8 * i + 4]) / 100.0;
+                                if (g_tt_host[8 * i + 3] > g_tt_host[8 * i + 2] && g_tt_host[8 * i + 2])
+                                        asum[nd][sp] += (double)(g_tt_host[8 * i + 3] - g_tt_host[8 * i + 2]) / 100.0;
+                                ++tcnt[nd][sp];
+                        }
+                        for (uint32_t nd = 0; nd <= 8; ++nd)
+                                for (int sp = 0; sp < 2; ++sp)
+                                        if (tcnt[nd][sp])
+                                                fprintf(stderr, "   %u dense slots%s: %u tasks, %.1f %% of the time; per task %.1f us (sweep %.1f, phase A %.1f)\n", nd, sp ? " + sparse" : "          ",
+                                                        tcnt[nd][sp], 100.0 * tsum[nd][sp] * 100.0 / (double)busy, tsum[nd][sp] / tcnt[nd][sp], ssum[nd][sp] / tcnt[nd][sp], asum[nd][sp] / tcnt[nd][sp]);
                 }
 #endif
 #if TRI_TASKTIMES == 1 // (k_and: the mean of every stamp over all tasks, relative to the task's start)
@@ -1967,13 +1996,10 @@ extern "C" int tri_batch_scores(tri_batch *b, size_t q, double *out, size_t cap,
         return TRI_OK;
 }
 
-// ---- every query's docID set in ONE call: what a caller that replays MatchedIndexDocumentsFilter::consider(const docid_t *, size_t) (matches.h:161-165)
-//      per query needs on the host.  out[offsets[q] .. offsets[q + 1]) = query q's ascending docIDs, queries in the caller's order; the sets are
-//      gathered on the device into one contiguous buffer (k_deliver_docsets: the tasks' segments in order, bitmap-form results expanded) and come
-//      over in a single copy — at a pinned `out` that is PCIe's rate, not a copy and a synchronisation per task segment
-extern "C" int tri_batch_docsets(tri_batch *b, uint32_t *out, size_t cap, uint64_t *offsets) {
+// (forms == nullptr: every set as ascending docIDs — tri_batch_docsets; else tri_batch_docsets_mixed: a RESULT_BITMAP query's region goes out as its words)
+static int docsets_deliver(tri_batch *b, uint32_t *out, size_t cap, uint64_t *offsets, uint32_t *forms, const char *fn) {
         if (!b || !offsets)
-                return fail(TRI_ERR_INVALID, "null argument");
+                return fail(TRI_ERR_INVALID, "%s: null argument", fn);
         if (!b->synced)
                 return fail(TRI_ERR_INVALID, "tri_batch_sync first");
         tri_dev *dev = b->ix->dev;
@@ -1983,13 +2009,19 @@ extern "C" int tri_batch_docsets(tri_batch *b, uint32_t *out, size_t cap, uint64
         for (size_t q = 0; q < b->nq; ++q) {
                 const uint32_t slot = b->slot_of_query[q];
                 offsets[q] = total;
+                if (forms)
+                        forms[q] = RESULT_DOCIDS;
                 if (slot == UINT32_MAX)
                         continue;
                 const DevQuery &dq = b->plan[slot];
                 if (dq.ntasks && !dq.out_cap && task_onepass(b->tasks[dq.first_task].kind) && b->h_query_counts[slot])
                         return fail(TRI_ERR_INVALID, "query %zu ran through the one-pass scored kernel: an AccumulatedScore top-K batch keeps top-K lists and match counts, not docID sets", q);
                 slot_off[slot] = total;
-                total += b->h_query_counts[slot];
+                if (forms && dq.form == RESULT_BITMAP) {
+                        forms[q] = RESULT_BITMAP;
+                        total += dq.out_cap; // (the region's words: one bit per document of the query's docID range, from document 0)
+                } else
+                        total += b->h_query_counts[slot];
         }
         offsets[b->nq] = total;
         if (!out || !total)
@@ -1997,26 +2029,46 @@ extern "C" int tri_batch_docsets(tri_batch *b, uint32_t *out, size_t cap, uint64
         if (cap < total)
                 return fail(TRI_ERR_INVALID, "the docID sets need %llu slots, %zu given", (unsigned long long)total, cap);
         HIP_TRY(hipSetDevice(dev->device));
-        DevLock g(dev->mu);
         uint32_t *d_flat = nullptr;
         uint64_t *d_slot_off = nullptr;
-        HIP_TRY(pool_alloc(dev, (void **)&d_flat, (total + 64) * 4));
-        hipError_t e = pool_alloc(dev, (void **)&d_slot_off, (nslots + 1) * 8 + POOL_MIN_BYTES);
-        if (e == hipSuccess)
-                e = hipMemcpyAsync(d_slot_off, slot_off.data(), (nslots + 1) * 8, hipMemcpyHostToDevice, dev->stream_rb);
-        if (e == hipSuccess) {
-                hipLaunchKernelGGL(k_deliver_docsets, dim3((uint32_t)b->tasks.size()), dim3(256), 0, dev->stream_rb, (const DevQuery *)b->d_plan, (const DevTask *)b->d_tasks,
-                                   (const uint32_t *)b->d_counts, (const uint32_t *)b->d_out, (const uint64_t *)d_slot_off, d_flat);
-                e = hipGetLastError();
+        hipError_t e;
+        {
+                // (the device lock covers the pool and the enqueues; the WAIT for the copy stands outside it: a thread that compiles the next batch, or runs
+                //  one, is not held up by the seconds a large delivery spends on PCIe — the read-back stream's work overlaps the engine stream's)
+                DevLock g(dev->mu);
+                HIP_TRY(pool_alloc(dev, (void **)&d_flat, (total + 64) * 4));
+                e = pool_alloc(dev, (void **)&d_slot_off, (nslots + 1) * 8 + POOL_MIN_BYTES);
+                if (e == hipSuccess)
+                        e = hipMemcpyAsync(d_slot_off, slot_off.data(), (nslots + 1) * 8, hipMemcpyHostToDevice, dev->stream_rb); // (pageable source: staged before the call returns)
+                if (e == hipSuccess) {
+                        hipLaunchKernelGGL(k_deliver_docsets, dim3((uint32_t)b->tasks.size()), dim3(256), 0, dev->stream_rb, (const DevQuery *)b->d_plan, (const DevTask *)b->d_tasks,
+                                           (const uint32_t *)b->d_counts, (const uint32_t *)b->d_out, (const uint64_t *)d_slot_off, d_flat, forms ? 1u : 0u);
+                        e = hipGetLastError();
+                }
+                if (e == hipSuccess)
+                        e = hipMemcpyAsync(out, d_flat, total * 4, hipMemcpyDeviceToHost, dev->stream_rb);
         }
-        if (e == hipSuccess)
-                e = hipMemcpyAsync(out, d_flat, total * 4, hipMemcpyDeviceToHost, dev->stream_rb);
         if (e == hipSuccess)
                 e = hipStreamSynchronize(dev->stream_rb);
         pool_free(dev, d_flat);
         pool_free(dev, d_slot_off);
         HIP_TRY(e);
         return TRI_OK;
+}
+
+// ---- every query's docID set in ONE call: what a caller that replays MatchedIndexDocumentsFilter::consider(const docid_t *, size_t) (matches.h:161-165)
+//      per query needs on the host.  out[offsets[q] .. offsets[q + 1]) = query q's ascending docIDs, queries in the caller's order; the sets are
+//      gathered on the device into one contiguous buffer (k_deliver_docsets: the tasks' segments in order, bitmap-form results expanded) and come
+//      over in a single copy — at a pinned `out` that is PCIe's rate, not a copy and a synchronisation per task segment
+extern "C" int tri_batch_docsets(tri_batch *b, uint32_t *out, size_t cap, uint64_t *offsets) { return docsets_deliver(b, out, cap, offsets, nullptr, "tri_batch_docsets"); }
+
+// ... and each set in the FORM THE ENGINE HOLDS IT: forms[q] = RESULT_DOCIDS: ascending docIDs as above; RESULT_BITMAP (a union / conjunction of head terms that matches one
+// document in 32 or more): out[offsets[q] .. offsets[q + 1]) = the words of a bitmap over the query's docID range — bit j of word i = document 32 i + j matches.  A dense set
+// crosses PCIe as a bit per document instead of four bytes per match (and is not expanded on the device first); the consumer expands it, or hands the bitmap on
+extern "C" int tri_batch_docsets_mixed(tri_batch *b, uint32_t *out, size_t cap, uint64_t *offsets, uint32_t *forms) {
+        if (!forms)
+                return fail(TRI_ERR_INVALID, "tri_batch_docsets_mixed: null forms");
+        return docsets_deliver(b, out, cap, offsets, forms, "tri_batch_docsets_mixed");
 }
 
 extern "C" int tri_batch_counts_device(tri_batch *b, void **counts) {

@@ -106,7 +106,7 @@ ABI_SYMBOLS = [
     "tri_last_error", "tri_abi_version", "tri_dev_open", "tri_dev_close", "tri_dev_sync", "tri_dev_stream", "tri_dev_set_option", "tri_dev_get_option", "tri_dev_memory",
     "tri_index_upload", "tri_index_destroy", "tri_index_get_info", "tri_index_term_docbytes", "tri_index_set_masked", "tri_decode_terms",
     "tri_batch_create", "tri_batch_query_status", "tri_batch_destroy", "tri_batch_run", "tri_batch_sync", "tri_batch_get_info",
-    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_docset_bitmap", "tri_batch_docsets", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
+    "tri_batch_match_counts", "tri_batch_docset", "tri_batch_docset_bitmap", "tri_batch_docsets", "tri_batch_docsets_mixed", "tri_batch_scores", "tri_batch_query_terms", "tri_batch_matched_terms", "tri_batch_matched_payloads", "tri_batch_topk", "tri_batch_topk_device", "tri_batch_counts_device", "tri_batch_docset_hashes",
     "tri_cbatch_create", "tri_cbatch_destroy", "tri_cbatch_query_status", "tri_cbatch_run", "tri_cbatch_sync", "tri_cbatch_match_counts", "tri_cbatch_topk", "tri_cbatch_docset", "tri_encode_google", "tri_encode_google_payloads", "tri_commit_google", "tri_commit_lucene", "tri_merge_google", "tri_merge_lucene", "tri_encode_lucene",
     "tri_comm_unique_id", "tri_comm_create", "tri_comm_create_custom", "tri_comm_destroy", "tri_gather_results",
 ]  # fmt: skip
@@ -152,6 +152,7 @@ def hip_lib():
     L.tri_batch_match_counts.argtypes = [vp, vp]
     L.tri_batch_docset.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_docsets.argtypes = [vp, vp, C.c_size_t, vp]
+    L.tri_batch_docsets_mixed.argtypes = [vp, vp, C.c_size_t, vp, vp]
     L.tri_batch_docset_bitmap.argtypes = [vp, C.c_size_t, C.POINTER(C.c_int), vp, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
     L.tri_batch_scores.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.tri_batch_topk.argtypes = [vp, vp, vp, vp]
@@ -579,11 +580,31 @@ class Batch:
         _check(L.tri_batch_docsets(self.h, ptr, cap, offs.ctypes.data))
         return out, offs
 
+    def docsets_mixed(self, out=None):
+        """Every query's docID set in the form the engine holds it (tri_batch_docsets_mixed): (flat u32[], offsets u64[nq + 1], forms u32[nq]) — forms[q] = 0:
+        flat[offsets[q]:offsets[q + 1]] = query q's ascending docIDs; 1: the words of a bitmap over its docID range (bit j of word i = document 32 i + j)."""
+        L = hip_lib()
+        offs = np.zeros(self.nq + 1, dtype=np.uint64)
+        forms = np.zeros(max(1, self.nq), dtype=np.uint32)
+        _check(L.tri_batch_docsets_mixed(self.h, None, 0, offs.ctypes.data, forms.ctypes.data))
+        total = int(offs[-1])
+        if out is None:
+            out = np.zeros(max(1, total), dtype=np.uint32)
+        ptr, cap = (out.data_ptr(), out.numel()) if hasattr(out, "data_ptr") else (out.ctypes.data, out.size)
+        _check(L.tri_batch_docsets_mixed(self.h, ptr, cap, offs.ctypes.data, forms.ctypes.data))
+        return out, offs, forms[: self.nq]
+
     def docset_form(self, q):
         """1 when the engine holds query q's docID set as a bitmap (RESULT_BITMAP), 0: ascending docIDs."""
         form, first, nw = C.c_int(), C.c_uint32(), C.c_size_t()
         _check(hip_lib().tri_batch_docset_bitmap(self.h, q, C.byref(form), None, 0, C.byref(first), C.byref(nw)))
         return form.value
+
+    def docset_bitmap_words(self, q):
+        """Words of query q's result bitmap (0: its docID set is held as ascending docIDs)."""
+        form, first, nw = C.c_int(), C.c_uint32(), C.c_size_t()
+        _check(hip_lib().tri_batch_docset_bitmap(self.h, q, C.byref(form), None, 0, C.byref(first), C.byref(nw)))
+        return int(nw.value) if form.value else 0
 
     def docset_bitmap(self, q):
         """None when the engine holds query q's docID set as ascending docIDs; else (first_doc, words u32[]): bit j of words[i] = document
