@@ -37,6 +37,7 @@ included; kind "port"), which doubles as a per-query full-size parity check, and
 is there — the GENUINE reference's exec_query over the same queries (kind "reference": that figure leads, the port's stands under `port`).
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -332,14 +333,27 @@ def timed(pipe, steps, warmup, barrier):
     pipe.readback_s = 0.0
     pipe.gather_s = 0.0
     acc = {}
+    walls = []
+    # (the cyclic collector stays out of the timed region: a generation-2 pass over the workloads' million-object program lists took milliseconds of a
+    #  1.2 ms step now and then; nothing in the loop makes reference cycles)
+    gc_was = gc.isenabled()
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
+    tp = t0
     for _ in range(steps):
         for i in pipe.step():
             for k in MS_KEYS:
                 acc[k] = acc.get(k, 0.0) + i[k]
+        tn = time.perf_counter()
+        walls.append((tn - tp) * 1e3)
+        tp = tn
     barrier()
     t1 = time.perf_counter()
+    if gc_was:
+        gc.enable()
     acc["_region"] = (t0, t1)
+    acc["_walls"] = walls
     return t1 - t0, acc
 
 
@@ -498,6 +512,7 @@ def main():
     gather_ms = pipe.gather_s * 1e3 / max(1, args.steps)
     mem_after = dev.memory()
     region = acc.pop("_region")
+    walls = sorted(acc.pop("_walls"))
     cstats = create_stats(pipe, region, args.steps, elapsed * 1e3 / max(1, args.steps))
 
     # ---- legs that make the headline harder to flatter (N = 1, after the timed region; none of them feeds `value`)
@@ -515,6 +530,7 @@ def main():
             #  with one cycle a timed create still met a cold 1.6 GB hipMalloc now and then: 76 ms in a 1.4 ms step)
             el, racc = timed(rp, args.rotating_steps, 2 * args.rotating_sets + 2, device_sync)
             rreg = racc.pop("_region")
+            racc.pop("_walls")
             legs[leg] = {"value": nq_rank * args.rotating_steps / el, "ms_per_step": el * 1e3 / args.rotating_steps, "kernel_ms_per_step": racc["last_run_ms"] / args.rotating_steps,
                          "term_planes_ms_per_step": racc.get("term_planes_ms", 0.0) / args.rotating_steps, **{k: v for k, v in create_stats(rp, rreg, args.rotating_steps, el * 1e3 / args.rotating_steps).items() if k != "what"}}  # fmt: skip
             rp.close()
@@ -675,6 +691,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "step_wall_ms": {"min": walls[0], "median": walls[len(walls) // 2], "p90": walls[min(len(walls) - 1, len(walls) * 9 // 10)], "max": walls[-1]} if walls else None,
             "higher_is_better": True,
             "scaling": args.scaling,
             "vs_baseline": None,

@@ -822,6 +822,32 @@ namespace trinity_amd {
                 auto b = run_batch(src, roots, flags, 0, scorer);
                 std::vector<uint32_t> ids;
                 std::vector<double> sc;
+                if (!scored) {
+                        // every set in ONE delivery, each in the form the engine holds it (tri_batch_docsets_mixed): a dense set arrives as the words of a bitmap over
+                        // its docID range — a bit per document across PCIe instead of four bytes per match — and is expanded here into consider()'s ids
+                        std::vector<uint64_t> offs(roots.size() + 1);
+                        std::vector<uint32_t> forms(roots.size() + 1), flat;
+                        check(tri_batch_docsets_mixed(b.get(), nullptr, 0, offs.data(), forms.data()));
+                        flat.resize(offs.back() + 1);
+                        check(tri_batch_docsets_mixed(b.get(), flat.data(), flat.size(), offs.data(), forms.data()));
+                        for (size_t q = 0; q < roots.size(); ++q) {
+                                const uint32_t *part = flat.data() + offs[q];
+                                size_t n = offs[q + 1] - offs[q];
+                                if (forms[q]) { // bit j of word i: document 32 i + j
+                                        ids.clear();
+                                        for (size_t i = 0; i < n; ++i)
+                                                for (uint32_t m = part[i]; m; m &= m - 1)
+                                                        ids.push_back((uint32_t)(32 * i) + (uint32_t)__builtin_ctz(m));
+                                        part = ids.data();
+                                        n = ids.size();
+                                }
+                                try {
+                                        filters[q]->consider(part, n);
+                                } catch (const aborted_search_exception &) {
+                                }
+                        }
+                        return;
+                }
                 for (size_t q = 0; q < roots.size(); ++q) {
                         size_t n = 0;
                         check(tri_batch_docset(b.get(), q, nullptr, 0, &n));

@@ -10,10 +10,12 @@
 // (a caller that compiles a batch per step finds them awake: a job is picked up in about a microsecond; from sleep it takes 100 - 300 us),
 // and nobody yields.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <functional>
 #include <mutex>
@@ -22,6 +24,43 @@
 #include <thread>
 #include <vector>
 
+// The CPUs this process may USE at once: the affinity mask's size, capped by the cgroup's CPU bandwidth quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us) —
+// a container that shows 256 CPUs may be allowed 16 of them per period, and a process whose polling threads use more is THROTTLED: every thread stopped until the
+// period's end (measured on the GPU box, quota 16: two pools of 15 pollers -> 86 of 250 periods throttled, one tri_batch_create in fifty took 50 - 60 ms).
+inline unsigned host_cpu_budget() {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t allowed;
+        CPU_ZERO(&allowed);
+        if (!sched_getaffinity(0, sizeof allowed, &allowed))
+                n = std::max(1, CPU_COUNT(&allowed));
+        auto quota = [](const char *path, const char *period_path) -> double {
+                FILE *f = fopen(path, "r");
+                if (!f)
+                        return 0.0;
+                char a[64] = {0}, b[64] = {0};
+                const int got = fscanf(f, "%63s %63s", a, b);
+                fclose(f);
+                if (got < 1 || a[0] == 'm' || a[0] == '-') // ("max" / -1: no quota)
+                        return 0.0;
+                double q = atof(a), p = got >= 2 ? atof(b) : 0.0;
+                if (period_path) {
+                        FILE *g = fopen(period_path, "r");
+                        if (g) {
+                                if (fscanf(g, "%63s", b) == 1)
+                                        p = atof(b);
+                                fclose(g);
+                        }
+                }
+                return q > 0 && p > 0 ? q / p : 0.0;
+        };
+        double q = quota("/sys/fs/cgroup/cpu.max", nullptr);
+        if (q <= 0)
+                q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+        if (q > 0)
+                n = std::min<unsigned>(n, std::max(1u, (unsigned)q));
+        return n;
+}
+
 class HostPool {
       public:
         // `threads` includes the calling thread: threads - 1 workers are started (fewer when thread creation fails — the pool then
@@ -29,17 +68,27 @@ class HostPool {
         // `part` of `nparts`: a process that keeps several pools (tri_dev's planner contexts: two batches compiled side by side) gives each its own
         // stretch of the candidate CPUs — a rank's slice is cut into nparts contiguous pieces; without a slice pool `part` starts `part * threads`
         // CPUs past the creating thread's — so that no two pools' pollers share a CPU.
-        explicit HostPool(unsigned threads, bool pin = true, unsigned hot_us = 3000, unsigned part = 0, unsigned nparts = 1) : hot_us_(hot_us) {
+        // `anchor` (>= 0): the candidate index the FIRST pool of the process started from (anchor()): the pools are created by different threads, on
+        // whatever CPUs those happen to run — each starting from its own creator's CPU, two pools' stretches overlapped now and then, and two pollers on
+        // one CPU cost a planning pass its time slice (measured: one create in a hundred took 10 - 20 ms, a single pass of it 17 ms).
+        // `spread`: a worker's affinity is the pool's whole STRETCH of CPUs (its own CPU first in line, twice as many CPUs as workers where the mask has
+        // them) instead of the one CPU — on a large shared host a worker pinned to ONE CPU cannot be moved when something else is given that CPU, and a
+        // worker parked with a fragment in hand costs the planning pass a time slice (measured on a 256-CPU box, load 20: one create in a hundred took
+        // 10 - 58 ms, all of it one pass waiting for its last fragment); within a stretch the scheduler finds it another CPU.
+        explicit HostPool(unsigned threads, bool pin = true, unsigned hot_us = 3000, unsigned part = 0, unsigned nparts = 1, int anchor = -1, bool spread = false) : hot_us_(hot_us) {
                 std::vector<int> cpus;
                 int base = 0;
                 if (pin) {
                         cpus = pin_candidates(&base);
+                        if (base >= 0 && anchor >= 0)
+                                base = anchor;
+                        anchor_ = base;
                         if (nparts > 1 && part < nparts) {
                                 if (base < 0 && cpus.size() >= nparts) { // (a rank's slice: this pool's piece of it)
                                         const size_t lo = cpus.size() * part / nparts, hi = cpus.size() * (part + 1) / nparts;
                                         cpus = std::vector<int>(cpus.begin() + (long)lo, cpus.begin() + (long)hi);
                                 } else if (base >= 0)
-                                        base += (int)(part * threads);
+                                        base += (int)(part * threads * (spread ? 2u : 1u));
                         }
                         if (threads > cpus.size() + 1 && !cpus.empty()) // (a rank's slice may be narrower than the threads asked for: no two pollers on one CPU)
                                 threads = (unsigned)cpus.size() + 1;
@@ -57,6 +106,11 @@ class HostPool {
                                 cpu_set_t s;
                                 CPU_ZERO(&s);
                                 CPU_SET(cpu, &s);
+                                if (spread) { // (the stretch: this pool's CPUs — a rank's whole piece of its slice, else 2 x threads CPUs from the pool's start)
+                                        const size_t span = base < 0 ? cpus.size() : std::min<size_t>(cpus.size(), 2u * threads);
+                                        for (size_t k = 0; k < span; ++k)
+                                                CPU_SET(cpus[(size_t)(std::max(base, 0) + (int)k) % cpus.size()], &s);
+                                }
                                 pthread_setaffinity_np(workers_.back().native_handle(), sizeof s, &s); // (best effort)
                                 pinned_.push_back(cpu);
                         }
@@ -93,6 +147,7 @@ class HostPool {
                 return cpus;
         }
         const std::vector<int> &pinned_cpus() const { return pinned_; } // (worker i + 1's CPU)
+        int anchor() const { return anchor_; }                          // where this pool's stretch of the candidates starts (-1: a rank's slice): hand it to the process's next pool
         ~HostPool() {
                 {
                         std::lock_guard<std::mutex> g(m_);
@@ -138,6 +193,13 @@ class HostPool {
                 }
                 if (wake)
                         cv_.notify_all();
+                static const bool dbg = getenv("TRINITY_DEBUG_POOL") != nullptr; // (stderr: a run() of more than 3 ms, job by job — who took it, when, on which CPU)
+                const auto t_run = std::chrono::steady_clock::now();
+                if (dbg) {
+                        dbg_jobs_.assign(n, DbgJob{});
+                        dbg_t0_ = t_run;
+                        dbg_on_.store(true, std::memory_order_release);
+                }
                 work(gen);
                 // (the caller waits for the stragglers by polling, and on the clock should a worker have been descheduled)
                 for (uint32_t spin = 0; left_.load(std::memory_order_acquire); ++spin)
@@ -145,6 +207,16 @@ class HostPool {
                                 std::unique_lock<std::mutex> g(m_);
                                 done_cv_.wait_for(g, std::chrono::microseconds(200), [&] { return !left_.load(std::memory_order_acquire); });
                         }
+                if (dbg) {
+                        dbg_on_.store(false, std::memory_order_release);
+                        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count();
+                        if (ms > 3.0) {
+                                fprintf(stderr, "[tri pool] run of %u jobs took %.3f ms (woke sleepers: %d):", n, ms, (int)wake);
+                                for (unsigned k = 0; k < n; ++k)
+                                        fprintf(stderr, " [%u: %.3f-%.3f ms tid %d cpu %d->%d]", k, dbg_jobs_[k].t0, dbg_jobs_[k].t1, dbg_jobs_[k].tid, dbg_jobs_[k].c0, dbg_jobs_[k].c1);
+                                fprintf(stderr, "\n");
+                        }
+                }
         }
 
       private:
@@ -155,7 +227,18 @@ class HostPool {
                                 return;
                         if (!state_.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel, std::memory_order_acquire))
                                 continue;
-                        (*fn_)((unsigned)(uint32_t)cur);
+                        const unsigned job = (unsigned)(uint32_t)cur;
+                        const bool dbg = dbg_on_.load(std::memory_order_acquire) && job < dbg_jobs_.size();
+                        if (dbg) {
+                                dbg_jobs_[job].t0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0_).count();
+                                dbg_jobs_[job].c0 = sched_getcpu();
+                                dbg_jobs_[job].tid = (int)(uintptr_t)pthread_self() & 0xffff;
+                        }
+                        (*fn_)(job);
+                        if (dbg) {
+                                dbg_jobs_[job].t1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0_).count();
+                                dbg_jobs_[job].c1 = sched_getcpu();
+                        }
                         if (left_.fetch_sub(1, std::memory_order_acq_rel) == 1)
                                 done_cv_.notify_all();
                         cur = state_.load(std::memory_order_acquire);
@@ -193,8 +276,16 @@ class HostPool {
                 std::lock_guard<std::mutex> g(m_);
                 return stop_;
         }
+        struct DbgJob {
+                double t0 = 0, t1 = 0;
+                int tid = 0, c0 = -1, c1 = -1;
+        };
+        std::vector<DbgJob> dbg_jobs_; // (TRINITY_DEBUG_POOL)
+        std::chrono::steady_clock::time_point dbg_t0_;
+        std::atomic<bool> dbg_on_{false};
         std::vector<std::thread> workers_;
         std::vector<int> pinned_;
+        int anchor_ = -1;
         std::mutex m_;
         std::condition_variable cv_, done_cv_;
         const std::function<void(unsigned)> *fn_ = nullptr; // (written under m_ before state_ is published; read only after a successful CAS)

@@ -51,7 +51,10 @@ struct tri_options {
                                                // head rows from about the same place: those words come from L2); 2: row by row, a query's ranges side by side; 0: heaviest task first.
                                                // Round 6, k_planes ms at 0 / 1 / 2: cfg3 4.40 / 4.12 / 4.33, cfg5's shard 2.17 / 2.10 / 2.20 (with four ranges a query: 5.44 / 4.73 / -)
         uint64_t cand_xcd = 1;                 // k_and's tasks queued per XCD by the plane row they probe (planner.hpp "k_and's queues"); 0: the cost order dealt round the queues
-        uint64_t plan_threads = 0;             // host threads tri_batch_create plans with; 0: up to 16, one per 512 queries
+        uint64_t plan_threads = 0;             // host threads a planner context plans with; 0: up to 16, one per 512 queries, within the process's CPU budget (affinity mask, cgroup quota) shared by the handle's contexts
+        uint64_t plan_hot_us = 300;            // ... keep polling for a job this long after their last one before they sleep (a polling thread uses a CPU of the process's quota;
+                                               // the gaps between the passes of one create are below 0.1 ms).  Read when a pool starts
+        uint64_t plan_pin = 2;                 // the planner's workers: 1 each pinned to ONE CPU; 2 to its pool's STRETCH of CPUs (host_pool.hpp: spread); 0 not pinned at all.  Read when a pool starts
         uint64_t result_bitmaps = 1;           // DocumentsOnly: a bitmap-window query whose expected matches outnumber the words of a bitmap over its docID range
                                                // delivers its docID set AS that bitmap (RESULT_BITMAP, dev_structs.hpp); 0: always ascending docIDs
         uint64_t tree_max_bytes = 16ull << 30; // scratch budget of a batch's TASK_TREE queries (a PL_PLANES-plane row per distinct term leaf, a plane per phrase leaf and per query)

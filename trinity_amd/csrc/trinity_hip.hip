@@ -94,6 +94,7 @@ struct tri_dev {
                 std::unique_ptr<HostPool> pool; // (created under mu)
                 trip::FragCache frag_cache;     // (under mu)
         } planners[PLAN_CTXS];
+        int plan_anchor = -1; // where the handle's pools count their CPUs from among the pin candidates (HostPool::anchor of the first pool started): context k's stretch starts k pools further on
         // The batch calls of one handle may come from TWO host threads: one compiling the next batch (tri_batch_create) while the other runs,
         // awaits and releases earlier ones (tri_batch_run / _sync / _destroy) — bench.py's loop; the planner's share of a create (most of it)
         // runs outside the lock, the pools above, the index's plane cache and everything that enqueues on the streams inside it.  Every other
@@ -159,6 +160,13 @@ static hipError_t pool_alloc(tri_dev *dev, void **out, const size_t bytes) {
         }
         const size_t gran = bytes >= (8u << 20) ? (2u << 20) : (64u << 10);
         const size_t rounded = (bytes + gran - 1) & ~(gran - 1);
+        static const bool dbg_pool = getenv("TRINITY_DEBUG_CREATE") != nullptr;
+        if (dbg_pool) {
+                std::string have;
+                for (const auto &b : P.idle)
+                        have += " " + std::to_string(b.first >> 20);
+                fprintf(stderr, "[tri pool_alloc] COLD hipMalloc of %zu MB (idle buffers, MB:%s)\n", rounded >> 20, have.c_str());
+        }
         hipError_t e = hipMalloc(out, rounded);
         if (e != hipSuccess && !P.idle.empty()) { // out of memory with idle buffers around: give them back and try again
                 (void)hipGetLastError();
@@ -508,7 +516,7 @@ namespace {
                              {"planes_rebuild", &tri_options::planes_rebuild},
                              {"cand_xcd", &tri_options::cand_xcd},
                              {"plan_threads", &tri_options::plan_threads},
-                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"planes_order", &tri_options::planes_order}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}, {"dense_window_cost", &tri_options::dense_window_cost}};
+                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"plan_hot_us", &tri_options::plan_hot_us}, {"plan_pin", &tri_options::plan_pin}, {"planes_order", &tri_options::planes_order}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}, {"dense_window_cost", &tri_options::dense_window_cost}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -788,11 +796,19 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         }
                         tri_dev::PlanCtx &pc = dev->planners[which];
                         if (nq >= 1024 && !pc.pool) { // (batches below a thousand queries are planned on the calling thread)
-                                const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-                                const unsigned want = dev->opt.plan_threads ? (unsigned)std::min<uint64_t>(dev->opt.plan_threads, 64) : std::min(16u, hw);
+                                // (default: the handle's contexts share what the process may use — the affinity mask, capped by the cgroup's CPU quota — less two CPUs for the
+                                //  threads that run and await batches; polling workers beyond a quota get the whole process throttled: host_pool.hpp)
+                                const unsigned budget = host_cpu_budget();
+                                const unsigned want = dev->opt.plan_threads ? (unsigned)std::min<uint64_t>(dev->opt.plan_threads, 64)
+                                                                            : std::min(16u, std::max(1u, (budget > 2 ? budget - 2 : 1u) / tri_dev::PLAN_CTXS));
                                 if (want > 1) {
                                         try {
-                                                pc.pool = std::make_unique<HostPool>(want, true, 3000, which, tri_dev::PLAN_CTXS);
+                                                // (every pool of the handle counts its stretch of CPUs from the FIRST pool's anchor, not from its own creator's CPU;
+                                                //  under the handle's lock: two contexts starting their pools at once agree on it)
+                                                DevLock g(dev->mu);
+                                                pc.pool = std::make_unique<HostPool>(want, dev->opt.plan_pin != 0, (unsigned)dev->opt.plan_hot_us, which, tri_dev::PLAN_CTXS, dev->plan_anchor, dev->opt.plan_pin == 2);
+                                                if (dev->plan_anchor < 0)
+                                                        dev->plan_anchor = pc.pool->anchor();
                                         } catch (...) { // (no threads to be had: the calling thread plans alone)
                                         }
                                 }
