@@ -137,6 +137,23 @@ def test_ranks_of_a_node_pin_their_planner_threads_to_disjoint_cpus():
     res = subprocess.run([sys.executable, "-c", "import json, sys; sys.path.insert(0, %r); from trinity_amd import hostplan as HP; print(json.dumps(HP.pool_cpus(16)))" % ROOT],
                          capture_output=True, text=True, timeout=120, env=env)  # fmt: skip
     assert res.returncode == 0 and (ncpu < 2 or json.loads(res.stdout.strip().splitlines()[-1]) == []), res.stdout[-500:] + res.stderr[-1000:]
+    # the CPU budget the pools are sized to: the mask capped by the container's quota, a rank's share of it under a launcher
+    def budget(env):
+        res = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from trinity_amd import hostplan as HP; print(HP.cpu_budget())" % ROOT],
+                             capture_output=True, text=True, timeout=120, env=env)  # fmt: skip
+        assert res.returncode == 0, res.stderr[-2000:]
+        return int(res.stdout.strip().splitlines()[-1])
+
+    solo_env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    whole = budget(solo_env)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else max(1, int(int(q) / int(p)))
+    except (OSError, ValueError):
+        pass
+    assert 1 <= whole <= ncpu and (quota is None or whole == min(ncpu, quota))
+    assert budget(dict(solo_env, LOCAL_RANK="1", LOCAL_WORLD_SIZE="4")) == max(1, whole // 4)
     # without the launcher's variables: next to the creating thread, still distinct CPUs
     env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_RANK", "LOCAL_WORLD_SIZE")}
     res = subprocess.run([sys.executable, "-c", "import json, sys; sys.path.insert(0, %r); from trinity_amd import hostplan as HP; print(json.dumps(HP.pool_cpus(4)))" % ROOT],

@@ -234,6 +234,8 @@ uint32_t tri_host_pool_cpus(uint32_t threads, int32_t *out, uint32_t cap) {
         return (uint32_t)c.size();
 }
 
+uint32_t tri_host_cpu_budget() { return host_cpu_budget(); } // (host_pool.hpp: what the planner's pools are sized to)
+
 void tri_host_index_facts(void *h, uint64_t *info6, uint32_t *per_term3) {
         const HostIndex &H = *static_cast<HostIndex *>(h);
         info6[0] = H.info.postings, info6[1] = H.info.blocks, info6[2] = H.info.doc_bytes, info6[3] = H.info.hit_bytes, info6[4] = H.transcoded_groups, info6[5] = H.dev_index.size();

@@ -58,6 +58,11 @@ inline unsigned host_cpu_budget() {
                 q = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
         if (q > 0)
                 n = std::min<unsigned>(n, std::max(1u, (unsigned)q));
+        // one process per GPU (LOCAL_WORLD_SIZE ranks on this node share the mask and the quota): a rank's share
+        const char *lw = getenv("LOCAL_WORLD_SIZE");
+        const long w = lw ? strtol(lw, nullptr, 10) : 0;
+        if (w > 1)
+                n = std::max(1u, n / (unsigned)w);
         return n;
 }
 

@@ -191,6 +191,14 @@ def lucene_encode(docs, freqs, positions, term_first, units=False):
     return io[: il.value], ho[: hl.value], t3[:n]
 
 
+def cpu_budget():
+    """The CPUs this process may use at once as the planner sees them (csrc/host_pool.hpp host_cpu_budget): the affinity mask, capped by the cgroup's CPU quota,
+    divided by LOCAL_WORLD_SIZE under a one-process-per-GPU launcher."""
+    L = host_lib()
+    L.tri_host_cpu_budget.restype = C.c_uint32
+    return int(L.tri_host_cpu_budget())
+
+
 def pool_cpus(threads=16):
     """The CPUs the planner's host pool of `threads` threads pins its workers to in this process (csrc/host_pool.hpp: a rank's own slice of the
     affinity mask when LOCAL_RANK / LOCAL_WORLD_SIZE are set, else the CPUs next to the calling thread's)."""
