@@ -221,8 +221,12 @@ class Pipeline:
         import threading
 
         self.T, self.wl, self.gathers, self.blocks_of, self.sync_stream = T, wl, gathers, blocks_of, sync_stream
-        self.ncompilers = compilers or Pipeline.COMPILERS
         self.cur = wl.create_set()  # on the engine stream (running or complete)
+        # two compilers where a set is small and its step short (16 K queries: a create takes about as long as the step); ONE where a set's output regions
+        # weigh gigabytes (the 100 K mixed batch: 20 GB a set, bound-allocated — every compiler in the loop is one more set alive, and its creates are a
+        # tenth of the step anyway)
+        set_bytes = sum(4 * int(b.info().get("out_capacity", 0)) for b in self.cur)
+        self.ncompilers = compilers or (Pipeline.COMPILERS if set_bytes < (8 << 30) else 1)
         for b in self.cur:
             b.run()
         # up to five sets are alive in the loop (read back and not yet released, running, launched, compiled and waiting, being compiled — the fifth

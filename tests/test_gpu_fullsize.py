@@ -205,7 +205,8 @@ def test_the_100k_mixed_batch_runs_whole_on_one_gpu():
     assert out["scaling"] == "strong" and out["n_gpus"] == 1 and out["config"]["queries_per_step"] == 100000 and out["config"]["workload"].startswith("cfg5")
     assert out["value"] > 0 and out["pipelined_results_equal_resident_batch"] and out["end_to_end"]["planning_included"]
     assert out["parity_check"]["equal"] and out["parity_check"]["queries"] >= 100 and out["parity_check"]["mismatches"] == 0
-    # what the whole batch holds of the device while its loop runs (several sets of buffers alive: running, launched, read back, compiled): stated, and
-    # within half of the 288 GB (output regions are bound-allocated by the lead's documents, not by a count pass — DESIGN.md §15)
+    # what the whole batch holds of the device while its loop runs (six sets of buffers alive — the resident diagnostic set, running, launched, read back, compiled,
+    # being compiled — at 20 GB of bound-allocated output regions each, two indexes, their plane caches): stated, and within 60 % of the device (output
+    # regions are bound-allocated by the lead's documents, not by a count pass — DESIGN.md §15.6)
     hbm = out["hbm_bytes_in_use"]
-    assert 0 < hbm["engine_pool_in_use"] <= hbm["device_in_use"] < 144 << 30 and hbm["device_total"] > 200 << 30, hbm
+    assert 0 < hbm["engine_pool_in_use"] <= hbm["device_in_use"] < 0.6 * hbm["device_total"] and hbm["device_total"] > 200 << 30, hbm

@@ -47,6 +47,8 @@ struct tri_options {
         uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs PL_PLANES bitmaps over the docID space and one decode per index)
         uint64_t planes_rebuild = 0;           // 1: every tri_batch_run decodes the plane rows its batch names AGAIN (a cold plane cache: what a query stream pays whose head
                                                // terms have all just been evicted) — a measurement switch (bench.py's rotating leg), never a speed-up
+        uint64_t phrase_task_div = 0;          // the tasks of a query with phrases are cut this many times finer (they are k_phrase's tasks too, and a phrase candidate costs far more than the
+                                               // planner's unit: k_phrase's span is its longest task); 0: by the batch's phrase queries per compute unit (4 / 2 / 1: plan_batch)
         uint64_t planes_order = 1;             // k_planes' tasks: 1 docID range by range, within a range by the heaviest plane row they sweep (the workgroups in flight stream the same
                                                // head rows from about the same place: those words come from L2); 2: row by row, a query's ranges side by side; 0: heaviest task first.
                                                // Round 6, k_planes ms at 0 / 1 / 2: cfg3 4.40 / 4.12 / 4.33, cfg5's shard 2.17 / 2.10 / 2.20 (with four ranges a query: 5.44 / 4.73 / -)
@@ -486,7 +488,7 @@ namespace trip {
                 uint32_t rich_R = 0;
                 bool rich_allow = false;
                 std::vector<size_t> left_out; // queries the planner does not lower (status TRI_ERR_UNSUPPORTED)
-                uint64_t onepass_queries = 0, fused_postings = 0;
+                uint64_t onepass_queries = 0, fused_postings = 0, phrase_queries = 0;
                 // second pass
                 std::vector<DevTask> tasks; // slot: index into tmp; out_off: relative to the fragment's first output slot
                 std::vector<uint64_t> tcost;
@@ -551,7 +553,7 @@ namespace trip {
                 uint32_t n_ok = 0;
                 bool plane_ok(uint32_t term) const { return ix.df_rank[term] < n_ok; }
                 // settled after the first pass
-                uint64_t planes_split = 2, fused_task_cost = 0;
+                uint64_t planes_split = 2, fused_task_cost = 0, phrase_task_div = 1;
                 uint32_t plw = 0; // words of a bitmap over the docID space (BatchPlan::plw)
                 // the ScorerWeight contribution of one term (IndexSourceTermsScorer::new_scorer_weight sums it over a phrase's terms):
                 // BM25 similarity.h:179-181 (float math), TF-IDF :85-87 (double), Trivial has none
@@ -801,6 +803,7 @@ namespace trip {
                                 return herr(f.err, TRI_ERR_INVALID, "query %zu: phrase over a LUCENE segment that was uploaded without hits.data", qi);
                         t.q.phrase_base = (uint32_t)f.phrases.size();
                         t.q.nphrases = (uint32_t)S.qphrases.size();
+                        f.phrase_queries += t.q.nphrases ? 1 : 0;
                         for (const auto &ph : S.qphrases) {
                                 f.phrases.push_back({(uint32_t)f.pterms.size(), ph.n, ph.weight});
                                 for (uint32_t k = 0; k < ph.n; ++k) {
@@ -1547,7 +1550,10 @@ namespace trip {
                                         return herr(f.err, TRI_ERR_INTERNAL, "query %u: a scatter union whose result is not a bitmap", t.q.qid);
                                 t.q.form = bitmap ? RESULT_BITMAP : RESULT_DOCIDS;
                                 const uint64_t per_win = std::max<uint64_t>(1, t.sumdf / (ix.info.docs_cnt / SPAN_BITS + 1)) + (pset ? 0 : opt.dense_window_cost);
-                                const uint32_t win_per_task = pset ? PSET_TASK_WINDOWS : (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / per_win);
+                                // (a query with phrases: its tasks are k_phrase's too, where a candidate costs a walk into two or three lists' hits — tens of times a bitmap
+                                //  word; a task of four windows of two head terms was 76 K candidates, 1 - 2 ms, and k_phrase's span is its longest task: option phrase_task_div)
+                                const uint32_t pdiv = t.q.nphrases ? (uint32_t)std::max<uint64_t>(1, C.phrase_task_div) : 1u;
+                                const uint32_t win_per_task = pset ? std::max(1u, PSET_TASK_WINDOWS / pdiv) : (uint32_t)std::max<uint64_t>(1, DENSE_TASK_COST / pdiv / per_win);
                                 uint32_t ord = 0;
                                 uint64_t lead_blocks = 0;
                                 for (uint32_t k = 0; k < nlead; ++k)
@@ -1580,7 +1586,7 @@ namespace trip {
                         } else {
                                 const uint32_t ntiles = (lead.nblocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
                                 const uint64_t per_tile = std::max<uint64_t>(1, t.cost / ntiles);
-                                const uint32_t tiles_per_task = (uint32_t)std::max<uint64_t>(1, std::max<uint64_t>(1, opt.cand_task_cost) / per_tile);
+                                const uint32_t tiles_per_task = (uint32_t)std::max<uint64_t>(1, std::max<uint64_t>(1, opt.cand_task_cost / (t.q.nphrases ? std::max<uint64_t>(1, C.phrase_task_div) : 1)) / per_tile);
                                 for (uint32_t tb = 0; tb < ntiles; tb += tiles_per_task) {
                                         const uint32_t te = std::min(ntiles, tb + tiles_per_task);
                                         f.tcost.push_back(per_tile * (te - tb));
@@ -1733,11 +1739,16 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         if (int rc = first_error())
                 return rc;
         // ---- between the passes: what depends on the whole batch
-        uint64_t onepass_queries = 0, fused_postings = 0;
+        uint64_t onepass_queries = 0, fused_postings = 0, phrase_queries = 0;
         for (const Frag &f : frags) {
                 onepass_queries += f.onepass_queries;
                 fused_postings += f.fused_postings;
+                phrase_queries += f.phrase_queries;
         }
+        // k_phrase's span is its longest task (a phrase candidate costs a walk into two or three lists' hits: a task of four windows of two head terms is 76 K
+        // candidates, 1 - 2 ms) — a batch with few phrase queries per resident workgroup cuts their tasks finer; one with many has tasks enough to fill the tail and
+        // keeps the cheaper large ones.  Measured (k_phrase ms at 1 / 2 / 4 / 8): cfg5's shard, 1 250 phrase queries: 2.05 / 1.13 / 0.64 / 0.64; cfg4, 16 384: 8.05 / 8.26 / 8.42 / 8.41
+        C.phrase_task_div = opt.phrase_task_div ? opt.phrase_task_div : !phrase_queries ? 1 : phrase_queries <= 8ull * env.cus ? 4 : phrase_queries <= 16ull * env.cus ? 2 : 1;
         // k_planes: docID ranges per query.  A task has fixed costs (seed pass, end-of-task imbalance: about 140 us), the kernel's tail is its
         // longest tasks: two ranges when the batch brings ten or more tasks per resident workgroup anyway, three when it does not (measured,
         // cfg3's mix: 8192 queries 2 > 3 > 4; 3750 queries 6.5 / 5.9 / 6.2 ms for 2 / 3 / 4; 1024 queries 2.11 / 1.97 / 1.96)

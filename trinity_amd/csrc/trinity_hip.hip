@@ -516,7 +516,7 @@ namespace {
                              {"planes_rebuild", &tri_options::planes_rebuild},
                              {"cand_xcd", &tri_options::cand_xcd},
                              {"plan_threads", &tri_options::plan_threads},
-                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"plan_hot_us", &tri_options::plan_hot_us}, {"plan_pin", &tri_options::plan_pin}, {"planes_order", &tri_options::planes_order}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}, {"dense_window_cost", &tri_options::dense_window_cost}};
+                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"phrase_task_div", &tri_options::phrase_task_div}, {"plan_hot_us", &tri_options::plan_hot_us}, {"plan_pin", &tri_options::plan_pin}, {"planes_order", &tri_options::planes_order}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}, {"dense_window_cost", &tri_options::dense_window_cost}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
@@ -796,11 +796,13 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         }
                         tri_dev::PlanCtx &pc = dev->planners[which];
                         if (nq >= 1024 && !pc.pool) { // (batches below a thousand queries are planned on the calling thread)
-                                // (default: the handle's contexts share what the process may use — the affinity mask, capped by the cgroup's CPU quota — less two CPUs for the
-                                //  threads that run and await batches; polling workers beyond a quota get the whole process throttled: host_pool.hpp)
+                                // (default: the handle's contexts share what the process may use — the affinity mask, capped by the cgroup's CPU quota — less six CPUs: the two
+                                //  compiling callers, the thread that runs and awaits batches, the runtime's own threads, and slack — a process that uses its whole quota is
+                                //  throttled at the first neighbour's burst: host_pool.hpp.  Under the GPU box's 16-CPU quota: 5 threads a context; measured there, 600 steps of cfg2,
+                                //  5 / 7 threads x 2 compilers: 1.185 ms per step either way, 8 x 1: 1.39 - 1.49 (the planner is the bound), 12 x 1: 1.18)
                                 const unsigned budget = host_cpu_budget();
-                                const unsigned want = dev->opt.plan_threads ? (unsigned)std::min<uint64_t>(dev->opt.plan_threads, 64)
-                                                                            : std::min(16u, std::max(1u, (budget > 2 ? budget - 2 : 1u) / tri_dev::PLAN_CTXS));
+                                const unsigned fair = budget >= 10 ? std::min(16u, (budget - 6) / tri_dev::PLAN_CTXS) : budget >= 4 ? 2u : 1u;
+                                const unsigned want = dev->opt.plan_threads ? (unsigned)std::min<uint64_t>(dev->opt.plan_threads, 64) : fair;
                                 if (want > 1) {
                                         try {
                                                 // (every pool of the handle counts its stretch of CPUs from the FIRST pool's anchor, not from its own creator's CPU;
