@@ -102,7 +102,10 @@ constexpr uint32_t TASK_KINDS = 10;
 // the planner next to the DevTask (which the host keeps reading for the result read-back); units[] is indexed like the schedule's TASK_PSET
 // section: sched[n_dense + i] names a task, pset_of_task gives its unit.
 constexpr uint32_t PSET_INLINE_TERMS = 4;
-constexpr uint32_t PSET_TASK_WINDOWS = 4; // docID windows per TASK_PSET task: the same for every query, so that the tasks of a window range line up —
+#ifndef TRI_PSET_TASK_WINDOWS
+#define TRI_PSET_TASK_WINDOWS 4
+#endif
+constexpr uint32_t PSET_TASK_WINDOWS = TRI_PSET_TASK_WINDOWS; // docID windows per TASK_PSET task: the same for every query, so that the tasks of a window range line up —
                                           // the schedule runs them window range by window range, and a range's plane words (88 head terms x 32 KB at cfg2)
                                           // stay in the XCDs' L2 while every query that reads them is in flight
 struct DevPsetUnit { // (also the record of a TASK_PROBE task: w_begin / w_end are its lead tiles, tt[0] its lead term)
