@@ -1414,6 +1414,62 @@ def test_gather_results_two_ranks_one_gpu(tmp_path):
     assert out.read_text().startswith("ok world=2")
 
 
+def test_two_threads_compile_on_one_handle_while_a_third_runs(large):
+    """include/trinity_hip.h, Threading (ABI 9): ONE device handle, two threads calling tri_batch_create side by side (the handle's two planner contexts — batches of 1500
+    queries: large enough for the pools) while the main thread runs, awaits and reads back what they hand over — bench.py's loop.  Every batch answers what the same
+    programs answer when compiled and run alone."""
+    import queue
+    import threading
+
+    w, T = large, large.T
+    sets = []
+    for seed in (5, 6, 7):
+        qs = T.gen_queries(w.V, seed, 1500, 2)
+        progs = [and_prog(T, q) for q in qs.tolist()]
+        b = T.Batch(w.ix, progs, T.FLAG_DOCUMENTS_ONLY)
+        b.run()
+        b.sync()
+        sets.append((progs, b.counts().copy(), b.docset_hashes().copy()))
+        b.close()
+    ready, errors = queue.Queue(maxsize=2), []
+
+    def compiler(i):
+        try:
+            for rep in range(12):
+                k = (i + rep) % len(sets)
+                ready.put((k, T.Batch(w.ix, sets[k][0], T.FLAG_DOCUMENTS_ONLY)))
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+        finally:
+            ready.put(None)
+
+    ths = [threading.Thread(target=compiler, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    done, seen, prev = 0, 0, None
+    while done < 2:
+        item = ready.get()
+        if item is None:
+            done += 1
+            continue
+        k, b = item
+        b.run()  # behind the previous batch on the engine stream
+        if prev is not None:
+            pk, pb = prev
+            pb.sync()
+            assert np.array_equal(pb.counts(), sets[pk][1]) and np.array_equal(pb.docset_hashes(), sets[pk][2]), pk
+            pb.close()
+            seen += 1
+        prev = (k, b)
+    pk, pb = prev
+    pb.sync()
+    assert np.array_equal(pb.counts(), sets[pk][1]) and np.array_equal(pb.docset_hashes(), sets[pk][2])
+    pb.close()
+    for t in ths:
+        t.join()
+    assert not errors and seen + 1 == 24, (errors, seen)
+
+
 def test_two_host_threads_two_device_handles(T):
     """SURVEY §8(b) threading: the ABI is called concurrently from two host threads, each with its own tri_dev (own stream) on the same
     GPU, own index upload and own batches — exec_query's re-entrancy per thread (exec.cpp:12).  Every thread's results equal the ones
