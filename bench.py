@@ -683,7 +683,8 @@ def main():
             return e
 
         # (the term planes live with the index: k_term_planes ran once, in the warm-up — the profile saw that one dispatch, a timed step has none)
-        step_traffic = sum(v for k, v in (traffic or {}).items() if v and (k != "k_term_planes" or tp_ms > 0.02)) if traffic else None
+        ONCE = ("k_term_planes", "k_term_plane0", "k_term_hits")  # once per index (the plane cache), not per step — unless the step rebuilt them (planes_rebuild)
+        step_traffic = sum(v for k, v in (traffic or {}).items() if v and (k not in ONCE or tp_ms > 0.02)) if traffic else None
         info0 = ixs[parts[0].codec].info()
         if dry:
             k_ms = max(k_ms, 1e-9)
@@ -749,7 +750,7 @@ def main():
                 "post_passes_ms": rest_ms,  # k_score (queries matched by k_and) / k_topk_merge / k_rich
                 # the head terms the batch's queries share are decoded ONCE per launch (k_term_planes): its time is part of the step
                 "term_planes": {"kernel_ms": tp_ms, "terms": int(tot["plane_terms"]), "decoded_list_bytes_per_launch": tot["term_planes_decoded_bytes"],
-                                "scratch_bytes": tot["plane_bytes"], "traffic": (traffic or {}).get("k_term_planes")},  # fmt: skip
+                                "scratch_bytes": tot["plane_bytes"], "traffic": sum((traffic or {}).get(k) or 0 for k in ("k_term_planes", "k_term_plane0")) or None},  # fmt: skip
                 "per_query_algorithmic": {"bytes_per_step": tot["algorithmic_bytes"], "effective_GBps": gbs(tot["algorithmic_bytes"], k_ms),
                                           "what": "SURVEY §8(d): sum over queries of docbytes(t) + output; a list shared by n queries counts n times, skipped blocks count: no fraction"},
             },

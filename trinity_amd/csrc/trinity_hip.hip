@@ -1261,7 +1261,7 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         // the phrases' head terms are located by RANK in plane 0 (k_phrase.hpp): rows (plane 0 + rank directory) and per-posting hits entries of the
                         // phrase terms that have none yet are built now — once for the index
                         tri_index *ix = b->ix;
-                        std::vector<uint32_t> rows_build, hits_build;
+                        std::vector<uint32_t> hits_build, hits_only; // (term, row) pairs: the rows that also need their rank records FIRST, then the ones that have them
                         uint32_t max_blocks = 0;
                         for (size_t i = 0; i < b->pterms.size(); ++i) {
                                 const uint32_t term = b->pterms[i], r = ix->df_rank[term];
@@ -1271,29 +1271,25 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                 if (!(t.flags & TERM_FULL_BLOCKS) || !t.documents)
                                         continue;
                                 ix->ph_built[r] = 1;
-                                hits_build.push_back(term);
-                                hits_build.push_back(r);
                                 max_blocks = std::max(max_blocks, t.nblocks);
-                                if (!(ix->pc_built[r] & 4u)) { // (bit 2: the row's rank records — with them plane 0, if it is not there yet)
-                                        ix->pc_built[r] |= 5u;
-                                        rows_build.push_back(term);
-                                        rows_build.push_back(r);
-                                }
+                                std::vector<uint32_t> &dst = (ix->pc_built[r] & 4u) ? hits_only : hits_build; // (bit 2: the row's rank records — with them plane 0, if it is not there yet)
+                                ix->pc_built[r] |= 5u;
+                                dst.push_back(term);
+                                dst.push_back(r);
                         }
+                        const uint32_t nrows_build = (uint32_t)(hits_build.size() / 2);
+                        hits_build.insert(hits_build.end(), hits_only.begin(), hits_only.end());
                         if (!hits_build.empty()) {
-                                uint32_t *d_pairs = ix->d_ph_pairs + 2 * ix->ph_pairs_n; // (every row is built once: the pairs of all runs fit 2 * pc_cap words; rows first, their subset second)
+                                uint32_t *d_pairs = ix->d_ph_pairs + 2 * ix->ph_pairs_n; // (every row is built once: the pairs of all runs fit 2 * pc_cap words)
                                 HIP_TRY(hipMemcpyAsync(d_pairs, hits_build.data(), hits_build.size() * 4, hipMemcpyHostToDevice, dev->stream)); // (pageable source: staged before the call returns)
                                 ix->ph_pairs_n += hits_build.size() / 2;
-                                if (!rows_build.empty()) {
-                                        // (the rows that no plane user has built yet: the same pairs buffer cannot hold a second list — a scratch of the batch's arena does: d_build is
-                                        //  sized for the batch's plane terms, so these go one k_term_planes launch per row, from the pairs just written)
-                                        for (size_t i = 0; i < hits_build.size(); i += 2)
-                                                if (std::find(rows_build.begin(), rows_build.end(), hits_build[i]) != rows_build.end()) {
-                                                        const dim3 grid((b->plw / PL_WORDS + P0_GROUP - 1) / P0_GROUP, 1);
-                                                        TRI_LAUNCH(k_term_plane0, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff,
-                                                                   ix->d_win, ix->d_terms, (const uint32_t *)d_pairs + i, ix->d_pcache, b->plw, ix->d_prank);
-                                                        HIP_TRY(hipGetLastError());
-                                                }
+                                // the rows without rank records: plane 0 + records in ONE launch over the list's head (round 5 launched a grid per row: 711 launches, 11 ms, the
+                                // first time cfg4's phrases met an index)
+                                for (uint32_t y0 = 0; y0 < nrows_build; y0 += 65535u) {
+                                        const dim3 grid((b->plw / PL_WORDS + P0_GROUP - 1) / P0_GROUP, std::min(65535u, nrows_build - y0));
+                                        TRI_LAUNCH(k_term_plane0, ix->codec, grid, dim3(AND_WG), dev->stream, ix->d_index, ix->d_blk_last, ix->d_blk_off, ix->d_blk_rec, ix->d_blk_doff, ix->d_win,
+                                                   ix->d_terms, (const uint32_t *)d_pairs + 2 * (size_t)y0, ix->d_pcache, b->plw, ix->d_prank);
+                                        HIP_TRY(hipGetLastError());
                                 }
                                 const uint32_t npairs = (uint32_t)(hits_build.size() / 2);
                                 for (uint32_t y0 = 0; y0 < npairs; y0 += 65535u) { // (gridDim.y <= 65535: a small index at a high plane_div makes almost every term eligible)
