@@ -1119,6 +1119,15 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                 const uint32_t n = TRI_BLOCK_N(lead, b, index, off);
                                 const uint32_t last = blk_last[gb];
                                 uint32_t doc = b ? blk_last[gb - 1] : 0;
+#if defined(TRI_AND_EXP) && TRI_AND_EXP == 2 // (perf probe: no delta stream — made-up ascending documents; what the lead's decode costs)
+                                const uint32_t row = tid * 32, step = (last - doc) / 32u + 1u;
+                                for (uint32_t i = 0; i + 1 < n; ++i) {
+                                        doc += step;
+                                        sh.cand[row | ((i + tid) & 31u)] = min(doc, last);
+                                }
+                                sh.cand[row | ((n - 1 + tid) & 31u)] = last;
+                                (void)off;
+#else
                                 DeltaStream<CODEC> s;
                                 s.init(index, lead, b, off);
                                 const uint32_t row = tid * 32;
@@ -1127,6 +1136,7 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                         sh.cand[row | ((i + tid) & 31u)] = doc;
                                 }
                                 sh.cand[row | ((n - 1 + tid) & 31u)] = last;
+#endif
                         }
                         __syncthreads();
                         PROF_LAP(11);
@@ -1167,7 +1177,11 @@ __global__ __launch_bounds__(AND_WG, TRI_AND_WAVES) void k_and(const uint8_t *__
                                                 }
 #pragma unroll
                                                 for (int u = 0; u < AND_PROBES; ++u)
+#if defined(TRI_AND_EXP) && TRI_AND_EXP == 1 // (perf probe: every gather inside one 4 KB stretch of the row — what the probes cost when they do not diverge)
+                                                        w[u] = pa[(doc[u] >> 5) & 0x3ffu];
+#else
                                                         w[u] = pa[doc[u] >> 5];
+#endif
 #pragma unroll
                                                 for (int u = 0; u < AND_PROBES; ++u) {
                                                         const uint32_t j = j0 + u * AND_WG;
