@@ -81,6 +81,13 @@ def dense(T, dev):
     return World(T, dev, 20000, 500, 12, 7)
 
 
+@pytest.fixture(scope="module")
+def longdocs(T, dev):
+    """Documents of 90 token slots: a head term's hits run past position 64 and past seven a document — k_phrase's three ways to a candidate's
+    hits (the entry holds them / a locator / the byte stream) and both of its checks (the 64-bit position words, the walk) in one corpus."""
+    return World(T, dev, 6000, 400, 90, 11)
+
+
 def gpu_lowers(q, rich=False):
     """Every fixture shape is lowered in DocumentsOnly and AccumulatedScore top-K mode (NOT of an AND — `a NOT (b c)` — runs off a
     truth table); the default (matched terms) mode still answers TRI_ERR_UNSUPPORTED to that one."""
@@ -667,7 +674,7 @@ def phrase_queries(w, seed, n):
     return out
 
 
-@pytest.mark.parametrize("world,n", [("small", 25), ("dense", 25), ("medium", 10)])
+@pytest.mark.parametrize("world,n", [("small", 25), ("dense", 25), ("medium", 10), ("longdocs", 12)])
 def test_phrase_docsets_match_oracle(request, world, n):
     w = request.getfixturevalue(world)
     texts = phrase_queries(w, 41, n)
@@ -682,7 +689,7 @@ def test_phrase_docsets_match_oracle(request, world, n):
     assert nonempty >= 20
 
 
-@pytest.mark.parametrize("world,n,k", [("small", 15, 10), ("dense", 15, 100)])
+@pytest.mark.parametrize("world,n,k", [("small", 15, 10), ("dense", 15, 100), ("longdocs", 10, 100)])
 def test_phrase_scored_topk_match_oracle(request, world, n, k):
     """Phrase scoring: scorer->score(id, matchCnt, sum of the terms' idf) — matchCnt counts every start position in
     AccumulatedScoreScheme (docset_iterators_scorers.cpp:195-228, exec.cpp:296)."""

@@ -37,7 +37,14 @@ struct HitStream<CODEC_GOOGLE> { // google_codec.cpp:533-594: varbyte (delta << 
         uint64_t pw; // plain: the document's (<= 8) single-byte hits
         bool plain;
         static constexpr uint32_t FREQ_MASK = 0xffffu; // th->freq is tokenpos_t
-        static constexpr uint32_t FREQ_PLAIN = 0x80000000u; // k_phrase's freq entries: the document's hits are single bytes (BLK_HITS_PLAIN)
+        static constexpr uint32_t FREQ_PLAIN = 0x40000000u; // k_phrase's freq entries: the document's hits are single bytes (BLK_HITS_PLAIN)
+        // ... and the entry HOLDS them (round 6, k_term_hits: a document of a head term with at most seven single-byte hits — almost all): the 64-bit entry is
+        // { hit bytes 0 .. 6 in bits 0 .. 55, the frequency in bits 56 .. 62, bit 63 } — a candidate's hits are in the lane's registers with the entry's load, where
+        // a locator costs one more dependent gather (a 64-byte sector of index[] for eight bytes) per candidate and phrase term
+        static constexpr uint32_t FREQ_INLINE = 0x80000000u;
+        static constexpr uint32_t INLINE_MAX = 7;
+        static __device__ __forceinline__ uint32_t count(const uint32_t fentry) { return (fentry & FREQ_INLINE) ? (fentry >> 24) & 0x7fu : fentry & FREQ_MASK; }
+        static __device__ __forceinline__ uint64_t inline_bytes(const uint32_t loc, const uint32_t fentry) { return (uint64_t)loc | ((uint64_t)(fentry & 0x00ffffffu) << 32); }
         __device__ __forceinline__ void init(const HitCtx &c, const uint32_t, const uint32_t loc) {
                 plain = false;
                 s.init(c.base + loc);
@@ -46,7 +53,10 @@ struct HitStream<CODEC_GOOGLE> { // google_codec.cpp:533-594: varbyte (delta << 
         // fentry: the candidate's frequency as phrase_locate_block left it.  At most eight single-byte hits: one unaligned load holds
         // them all, and the walk is shifts of a register instead of a byte stream with loads in flight
         __device__ __forceinline__ void init_entry(const HitCtx &c, const uint32_t pad, const uint32_t loc, const uint32_t fentry) {
-                if ((fentry & FREQ_PLAIN) && (fentry & FREQ_MASK) <= 8u) {
+                if (fentry & FREQ_INLINE) {
+                        plain = true;
+                        pw = inline_bytes(loc, fentry);
+                } else if ((fentry & FREQ_PLAIN) && (fentry & FREQ_MASK) <= 8u) {
                         typedef uint64_t ph_u64_a1 __attribute__((aligned(1)));
                         plain = true;
                         pw = *(const ph_u64_a1 *)(c.base + loc);
@@ -76,6 +86,7 @@ struct HitStream<CODEC_LUCENE> {
         VbStream vb;
         bool tail;
         static constexpr uint32_t FREQ_MASK = 0xffffffffu;
+        static __device__ __forceinline__ uint32_t count(const uint32_t fentry) { return fentry; }
         __device__ __forceinline__ void seek() {
                 const uint32_t hb = h >> 7;
                 if (hb < nfull) {
@@ -145,7 +156,7 @@ __device__ __forceinline__ bool phrase_has_pos(const HitCtx &ctx, const uint32_t
         HitStream<CODEC> s;
         s.init_entry(ctx, hdir_off, hits_off, freq);
         uint32_t pos = 0;
-        for (uint32_t h = 0; h < (freq & HitStream<CODEC>::FREQ_MASK); ++h) {
+        for (uint32_t h = 0, n = HitStream<CODEC>::count(freq); h < n; ++h) {
                 pos = (pos + s.next()) & 0xffffu;
                 if (pos == q)
                         return true;
@@ -334,10 +345,14 @@ __global__ __launch_bounds__(256) void k_term_hits(const uint8_t *__restrict__ i
         const uint32_t hits_at = blk_hits[gb];
         if (hits_at & BLK_HITS_PLAIN) { // one byte per hit: locators follow from the frequencies alone
                 uint32_t h = off + (hits_at & ~BLK_HITS_PLAIN);
+                typedef uint64_t ph_u64_a1 __attribute__((aligned(1)));
                 for (uint32_t i = 0; i < n; ++i) {
                         const uint32_t f = s.next();
                         const uint32_t fe = (f & HitStream<CODEC_GOOGLE>::FREQ_MASK) == f ? (f | HitStream<CODEC_GOOGLE>::FREQ_PLAIN) : f;
-                        out[i] = (unsigned long long)h | ((unsigned long long)fe << 32);
+                        if (f <= HitStream<CODEC_GOOGLE>::INLINE_MAX) // the hits themselves (see HitStream<CODEC_GOOGLE>::FREQ_INLINE)
+                                out[i] = (*(const ph_u64_a1 *)(index + h) & 0x00ffffffffffffffull) | ((unsigned long long)f << 56) | 0x8000000000000000ull;
+                        else
+                                out[i] = (unsigned long long)h | ((unsigned long long)fe << 32);
                         h += f;
                 }
                 return;
@@ -598,22 +613,68 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                         uint32_t pf[4] = {0, 0, 0, 0};
                                         if (CODEC == CODEC_GOOGLE && rows <= 4) {
                                                 typedef uint64_t ph_u64_a1 __attribute__((aligned(1)));
+                                                uint32_t inl = 0; // the rows whose entry holds the hits themselves (FREQ_INLINE): nothing more to fetch
 #pragma unroll
                                                 for (uint32_t r = 0; r < 4; ++r) {
                                                         if (r >= rows)
                                                                 break;
                                                         const uint32_t fe = sh.freq[r * tile + j];
-                                                        pf[r] = fe & HitStream<CODEC_GOOGLE>::FREQ_MASK;
-                                                        fast = fast && (fe & HitStream<CODEC_GOOGLE>::FREQ_PLAIN) && pf[r] <= 8u;
+                                                        pf[r] = HitStream<CODEC_GOOGLE>::count(fe);
+                                                        if (fe & HitStream<CODEC_GOOGLE>::FREQ_INLINE) {
+                                                                pw[r] = HitStream<CODEC_GOOGLE>::inline_bytes(sh.hits_off[r * tile + j], fe);
+                                                                inl |= 1u << r;
+                                                        } else
+                                                                fast = fast && (fe & HitStream<CODEC_GOOGLE>::FREQ_PLAIN) && pf[r] <= 8u;
                                                 }
                                                 if (fast) {
 #pragma unroll
                                                         for (uint32_t r = 0; r < 4; ++r)
-                                                                if (r < rows)
+                                                                if (r < rows && !((inl >> r) & 1u))
                                                                         pw[r] = *(const ph_u64_a1 *)(index + sh.hits_off[r * tile + j]);
                                                 }
                                         }
+                                        // ... and where every one of those hits sits below position 64 (short documents and fields; bench.py's ten-slot documents), the
+                                        // DocWordsSpace IS a 64-bit word per row: bit p <=> the row's term has a hit at position p.  Ownership (last writer wins: a row
+                                        // materialised later takes the slot) is an AND-NOT with the later rows' words, the phrase a shifted AND, matchCnt a popcount —
+                                        // a few dozen instructions without a divergent loop, where the walk below runs (hits of term 0) x (terms) x (hits of the term)
+                                        // steps and every lane of the wave waits for its slowest (round 6: the kernel's VALU instructions were 4.4 of its 8 ms)
+                                        bool masks = false;
                                         if (fast) {
+                                                uint64_t hm[4] = {0, 0, 0, 0};
+                                                bool ovf = false;
+#pragma unroll
+                                                for (uint32_t r = 0; r < 4; ++r) {
+                                                        if (r >= rows)
+                                                                break;
+                                                        uint32_t pos = 0;
+                                                        uint64_t m = 0;
+#pragma unroll
+                                                        for (uint32_t h = 0; h < 8; ++h) {
+                                                                if (__builtin_amdgcn_ballot_w64(h < pf[r]) == 0ull) // (uniform)
+                                                                        break;
+                                                                pos += ((uint32_t)(pw[r] >> (8u * h)) & 0xffu) >> 1;
+                                                                m |= h < pf[r] ? 1ull << (pos & 63u) : 0ull;
+                                                                ovf = ovf || (h < pf[r] && pos >= 64u);
+                                                        }
+                                                        hm[r] = m;
+                                                }
+                                                if (!ovf) {
+                                                        masks = true;
+                                                        uint64_t own[4], later = 0;
+#pragma unroll
+                                                        for (int r = 3; r >= 0; --r) {
+                                                                own[r] = hm[r] & ~later;
+                                                                later |= hm[r];
+                                                        }
+                                                        auto sel = [&](const uint64_t (&a)[4], const uint32_t r) { return r == 0 ? a[0] : r == 1 ? a[1] : r == 2 ? a[2] : a[3]; }; // (r: uniform)
+                                                        uint64_t acc = sel(hm, uni(sh.row[0])) & ~1ull; // (a start position 0 is no start: docset_iterators.cpp:101-143)
+                                                        for (uint32_t k = 1; k < ph.nterms; ++k)
+                                                                acc &= k < 64u ? sel(own, uni(sh.row[k])) >> k : 0ull;
+                                                        cnt = min((uint32_t)__popcll(acc), max_match_cnt);
+                                                }
+                                        }
+                                        if (masks) {
+                                        } else if (fast) {
                                                 auto has_pos = [&](const uint32_t r, const uint32_t q) { // is position q among row r's hits? (positions ascend)
                                                         uint64_t w = r == 0 ? pw[0] : r == 1 ? pw[1] : r == 2 ? pw[2] : pw[3];
                                                         const uint32_t f = r == 0 ? pf[0] : r == 1 ? pf[1] : r == 2 ? pf[2] : pf[3];
@@ -651,7 +712,7 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                         HitStream<CODEC> s0;
                                         s0.init_entry(ctx, terms[pterms[ph.term_base]].pad, sh.hits_off[sh.row[0] * tile + j], sh.freq[sh.row[0] * tile + j]);
                                         uint32_t p0 = 0;
-                                        const uint32_t f0 = sh.freq[sh.row[0] * tile + j] & HitStream<CODEC>::FREQ_MASK;
+                                        const uint32_t f0 = HitStream<CODEC>::count(sh.freq[sh.row[0] * tile + j]);
                                         for (uint32_t h = 0; h < f0 && cnt < max_match_cnt; ++h) {
                                                 p0 = (p0 + s0.next()) & 0xffffu;
                                                 if (!p0)

@@ -1043,6 +1043,9 @@ __device__ __noinline__ uint32_t planes_sweep_segment(const uint32_t *__restrict
                                 c0 &= f0 & e0;
                                 c1 &= f1 & e1;
                         }
+#if defined(TRI_PLK_EXP) && TRI_PLK_EXP == 1 // (perf probe: the sweep counts and never finds a candidate — what the candidates cost; results wrong)
+                        c0 = c1 = 0;
+#endif
                         // the words that hold a candidate go on the wave's queue
                         if (__builtin_amdgcn_ballot_w64((c0 | c1) != 0) != 0ull) {
                                 const uint32_t w2 = 2u * (sw * (PLK_SW_WORDS / 2) + lane);

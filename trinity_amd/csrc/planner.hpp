@@ -44,6 +44,8 @@ struct tri_options {
                                  // While a batch built its own planes: step ms at 32 / 64 / 128 / 256: cfg3 16.9 / 15.9 / 15.3 / 15.4, cfg2 - / 2.90 / 2.71 / 2.76 (the
                                  // build grew with it).  The planes live with the index now (built once): 128 / 512 / 4096: cfg2 1.48 / 1.44 / 1.40, cfg3 12.64 / 12.40 / 12.4,
                                  // cfg4 17.4 / 16.9 / 16.9 — 355 rows (1.3 GB at 10 M documents) at 512
+        uint64_t plane_amortize = 1;           // a term is given a plane when plane_amortize x (the postings the batch's uses of it save) repay one decode of its list: the rows live with the
+                                               // index, so a stream of batches repays a row over several of them (1: every batch repays its own rows)
         uint64_t plane_max_bytes = 8ull << 30; // scratch budget of a batch's term planes: the eligible terms are the longest lists that fit (each costs PL_PLANES bitmaps over the docID space and one decode per index)
         uint64_t planes_rebuild = 0;           // 1: every tri_batch_run decodes the plane rows its batch names AGAIN (a cold plane cache: what a query stream pays whose head
                                                // terms have all just been evicted) — a measurement switch (bench.py's rotating leg), never a speed-up
@@ -1840,7 +1842,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         for (const FUse &u : f.fuses)
                                 forced[ix.df_rank[u.term]] = 1;
                 for (uint32_t r = 0; r < C.n_ok; ++r)
-                        if (rank_term[r] != UINT32_MAX && (forced[r] || benefit[r] >= ix.terms[rank_term[r]].documents))
+                        if (rank_term[r] != UINT32_MAX && (forced[r] || benefit[r] * std::max<uint64_t>(1, opt.plane_amortize) >= ix.terms[rank_term[r]].documents))
                                 chosen.push_back(rank_term[r]);
                 std::sort(chosen.begin(), chosen.end());
         }

@@ -513,6 +513,7 @@ namespace {
                              {"plane_div", &tri_options::plane_div},
                              {"planes_split", &tri_options::planes_split},
                              {"plane_max_bytes", &tri_options::plane_max_bytes},
+                             {"plane_amortize", &tri_options::plane_amortize},
                              {"planes_rebuild", &tri_options::planes_rebuild},
                              {"cand_xcd", &tri_options::cand_xcd},
                              {"plan_threads", &tri_options::plan_threads},
