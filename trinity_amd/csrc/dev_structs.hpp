@@ -165,7 +165,8 @@ constexpr uint32_t PL_PLANES = PL_STORED + PL_LEVEL_WORDS; // words of a term's 
 constexpr uint32_t PL_HI = PL_PLANES - 1;                 // ... of its HIGH part: nested planes 1 .. PL_STORED - 1 (plane k at (k - 1) * plw), then the interleaved level words (at
                                                           // PL_HI_LEVELS * plw + 3 w).  Plane cache: plane 0 of row r = planes0 + r * plw; its high part = planes_hi + r * PL_HI * plw
 constexpr uint32_t PL_HI_LEVELS = PL_STORED - 1;
-constexpr uint32_t PL_RANK_WORDS = 16;     // ... a 64-byte record: [0] the posting index of the group's first document, [1 .. 8] the group's eight plane-0 words (one line tells a document's rank)
+constexpr uint32_t PL_RANK_WORDS = 16;     // ... a 64-byte record: eight pairs, one per plane-0 word of the group: { the posting index of the word's first document, the word } — a
+                                           // document's rank is one eight-byte load and a popcount (round 5: the group's first posting + the eight words, three 16-byte loads and eight popcounts)
 constexpr uint32_t PL_RANK_DOCS = 256;     // a row's rank directory (tri_index::d_prank) has an entry per this many documents: the posting index of the group's first document
 constexpr uint32_t BLK_HITS_PLAIN = 0x80000000u; // GOOGLE blk_hits[]: every hit of the block is a single byte (no payload, position delta < 64).  The entry's
                                                  // low 31 bits: where the block's hits start, in bytes PAST blk_off[] (the block's deltas and frequencies lie

@@ -143,12 +143,21 @@ struct PhraseShared {
         uint32_t rpad[MAX_PHRASE_TERMS]; // row -> its term's DevTerm::pad (LUCENE: the term's row in hdir[])
         DevTerm rterm[MAX_PHRASE_TERMS]; // row -> its term
         uint32_t rrow[MAX_PHRASE_TERMS]; // row -> its term's plane row when the term is located by rank (PL_NONE: by walking its blocks)
+        uint64_t rhs[MAX_PHRASE_TERMS];  // ... and where that row's hits entries start (hs_off[row])
         uint32_t rtk[MAX_PHRASE_TERMS], rbx[2 * MAX_PHRASE_TERMS]; // row -> its term id; the two ends of the tile's block range as the waves found them
         uint32_t rb0[MAX_PHRASE_TERMS], rnb[MAX_PHRASE_TERMS], rstart[MAX_PHRASE_TERMS]; // row -> first block of the tile's docID range, blocks walked (0: the scattered path), where its blocks start in the pass
         uint32_t scan[8];
         uint32_t bcast[4];
 };
-constexpr uint32_t PHRASE_WGS_PER_CU = (160u * 1024u / sizeof(PhraseShared)) < 7u ? (160u * 1024u / sizeof(PhraseShared)) : 7u; // LDS; 65 registers: 7 waves per SIMD
+// ONE object for the kernel and the functions it calls: a static __shared__ behind an accessor keeps every access a plain LDS instruction (k_planes.hpp)
+__device__ __forceinline__ PhraseShared &phrase_shared() {
+        __shared__ PhraseShared sh;
+        return sh;
+}
+#ifndef TRI_PHRASE_WAVES
+#define TRI_PHRASE_WAVES 6
+#endif
+constexpr uint32_t PHRASE_WGS_PER_CU = (160u * 1024u / sizeof(PhraseShared)) < (uint32_t)TRI_PHRASE_WAVES ? (160u * 1024u / sizeof(PhraseShared)) : (uint32_t)TRI_PHRASE_WAVES; // LDS; the register budget (k_phrase's launch bounds)
 
 // Is position `q` among the `freq` hits starting at index[hits_off]?  (positions ascend within a document)
 template <int CODEC>
@@ -372,8 +381,65 @@ __global__ __launch_bounds__(256) void k_term_hits(const uint8_t *__restrict__ i
         }
 }
 
+// ---- every row of the phrase a head term: the rows' hits entries by RANK, for ALL of a lane's candidates at once (see k_phrase's check).  A function of its
+//      own (not inlined): its registers — eight record pairs, eight entries in flight per lane — are allocated apart from the kernel's (inlined, the compiler
+//      spilled four dozen registers around the check).  The entries go to the lane's own places of hits_off[] / freq[].
+__device__ __noinline__ void phrase_rank_entries(const uint32_t *__restrict__ prank_, const unsigned long long *__restrict__ phs_, const uint32_t plw_, const uint32_t rows_,
+                                                 const uint32_t tile_, const uint32_t C_, const uint32_t cmin_) {
+        PhraseShared &sh = phrase_shared();
+        constexpr uint32_t PER = PHRASE_TILE / AND_WG;
+        const uint32_t tid = threadIdx.x;
+        const uint32_t *const prank = uni_ptr(prank_);
+        const unsigned long long *const phs = uni_ptr(phs_);
+        const uint32_t plw = uni(plw_), rows = uni(rows_), tile = uni(tile_), C = uni(C_), cmin = uni(cmin_);
+        {
+                uint2 rp[PER][4]; // (rank before the document's word, the word)
+                uint32_t below[PER];
+                bool act[PER];
+#pragma unroll
+                for (uint32_t i = 0; i < PER; ++i) {
+                        const uint32_t j = tid + i * AND_WG;
+                        act[i] = j < C && sh.alive[j];
+                        const uint32_t doc = act[i] ? sh.cdoc[j] : cmin;
+                        below[i] = (1u << (doc & 31u)) - 1u;
+#pragma unroll
+                        for (uint32_t r = 0; r < 4; ++r) {
+                                if (r >= rows)
+                                        break;
+                                rp[i][r] = ((const uint2 *)(prank + (size_t)uni(sh.rrow[r]) * (plw / (PL_RANK_DOCS / 32u)) * PL_RANK_WORDS))[doc >> 5];
+                        }
+                }
+                unsigned long long ent[PER][4];
+#pragma unroll
+                for (uint32_t i = 0; i < PER; ++i)
+#pragma unroll
+                        for (uint32_t r = 0; r < 4; ++r) {
+                                if (r >= rows)
+                                        break;
+                                const uint32_t rank = rp[i][r].x + (uint32_t)__popc(rp[i][r].y & below[i]);
+                                ent[i][r] = phs[sh.rhs[r] + rank];
+                        }
+#pragma unroll
+                for (uint32_t i = 0; i < PER; ++i) {
+                        const uint32_t j = tid + i * AND_WG;
+                        if (!act[i])
+                                continue;
+#pragma unroll
+                        for (uint32_t r = 0; r < 4; ++r) {
+                                if (r >= rows)
+                                        break;
+                                sh.hits_off[r * tile + j] = (uint32_t)ent[i][r]; // (this lane's own places: read back below without a barrier)
+                                sh.freq[r * tile + j] = (uint32_t)(ent[i][r] >> 32);
+                        }
+                }
+        }
+}
+
+#ifndef TRI_PHRASE_WAVES
+#define TRI_PHRASE_WAVES 6
+#endif
 template <int CODEC>
-__global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phrase(const uint8_t *__restrict__ index, const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits,
+__global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? TRI_PHRASE_WAVES : 3) void k_phrase(const uint8_t *__restrict__ index, const uint8_t *__restrict__ hits, const uint32_t *__restrict__ blk_hits,
                                                    const uint32_t *__restrict__ hdir, const uint32_t *__restrict__ blk_last,
                                                    const uint32_t *__restrict__ blk_off, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms,
                                                    const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
@@ -382,7 +448,7 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                                    uint32_t *__restrict__ counts, double *__restrict__ pscore, const uint32_t max_match_cnt,
                                                    const int sim, const uint32_t *__restrict__ planes, const uint32_t plw, const uint32_t *__restrict__ prank,
                                                    const unsigned long long *__restrict__ phs, const uint64_t *__restrict__ hs_off, const uint32_t *__restrict__ term_row) {
-        __shared__ PhraseShared sh;
+        PhraseShared &sh = phrase_shared();
         const uint32_t tid = threadIdx.x;
         const uint32_t wave = uni(tid >> 6);
         const HitCtx ctx{CODEC == CODEC_GOOGLE ? index : hits, blk_hits, hdir};
@@ -472,7 +538,9 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                         const DevTerm t = terms[sh.rtk[tid]];
                                         sh.rterm[tid] = t;
                                         sh.rpad[tid] = t.pad;
-                                        sh.rrow[tid] = CODEC == CODEC_GOOGLE && term_row ? term_row[sh.rtk[tid]] : PL_NONE; // the term's plane row, once its rank directory and hits entries are there
+                                        const uint32_t pr = CODEC == CODEC_GOOGLE && term_row ? term_row[sh.rtk[tid]] : PL_NONE; // the term's plane row, once its rank directory and hits entries are there
+                                        sh.rrow[tid] = pr;
+                                        sh.rhs[tid] = pr != PL_NONE ? hs_off[pr] : 0ull;
                                 }
                                 __syncthreads();
                                 if (q.nphrases == 1)
@@ -530,14 +598,9 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                                 const uint32_t *rd = prank + (size_t)prow * (plw / (PL_RANK_DOCS / 32u)) * PL_RANK_WORDS;
                                                 const unsigned long long *hs = phs + hs_off[prow];
                                                 for (uint32_t j = tid; j < C; j += AND_WG) {
-                                                        const uint32_t doc = sh.cdoc[j], g = doc / PL_RANK_DOCS, k = (doc >> 5) & 7u;
-                                                        const uint4 *rec = (const uint4 *)(rd + (size_t)g * PL_RANK_WORDS); // (one 64-byte line: the group's rank and its plane-0 words)
-                                                        const uint4 x0 = rec[0], x1 = rec[1], x2 = rec[2];
-                                                        uint32_t rank = x0.x;
-                                                        const uint32_t w8[8] = {x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x};
-#pragma unroll
-                                                        for (uint32_t i = 0; i < 8; ++i)
-                                                                rank += i < k ? (uint32_t)__popc(w8[i]) : i == k ? (uint32_t)__popc(w8[i] & ((1u << (doc & 31u)) - 1u)) : 0u;
+                                                        const uint32_t doc = sh.cdoc[j];
+                                                        const uint2 rp = ((const uint2 *)rd)[doc >> 5]; // (one pair of the group's record: the rank before the document's word, the word)
+                                                        const uint32_t rank = rp.x + (uint32_t)__popc(rp.y & ((1u << (doc & 31u)) - 1u));
                                                         const unsigned long long e = hs[rank];
                                                         sh.hits_off[r * tile + j] = (uint32_t)e;
                                                         sh.freq[r * tile + j] = (uint32_t)(e >> 32);
@@ -574,37 +637,17 @@ __global__ __launch_bounds__(AND_WG, CODEC == CODEC_GOOGLE ? 6 : 3) void k_phras
                                 }
                                 __syncthreads();
                                 PROF_LAP(1);
+                                // ---- every row a head term: the rows' entries by RANK, for ALL of a lane's candidates at once — first every candidate's and row's rank
+                                //      record pair (ONE eight-byte load: the posting index of the first document of its plane-0 word, and the word), then every entry:
+                                //      two round trips per tile where a lane that took its candidates one after the other paid
+                                //      two per candidate (the kernel waits for these gathers: round 6, 57 % of its cycles in this check at 7 waves per SIMD)
+                                if (all_rank) // (uniform)
+                                        phrase_rank_entries(prank, phs, plw, rows, tile, C, cmin);
                                 // ---- check: one lane per candidate
                                 for (uint32_t j = tid; j < C; j += AND_WG) {
                                         if (!sh.alive[j])
                                                 continue;
                                         uint32_t cnt = 0;
-                                        if (all_rank) { // (uniform) the rows' entries by rank, all rows' loads side by side
-                                                const uint32_t doc = sh.cdoc[j], g = doc / PL_RANK_DOCS, k = (doc >> 5) & 7u, below = (1u << (doc & 31u)) - 1u;
-                                                uint32_t rk[4] = {0, 0, 0, 0};
-#pragma unroll
-                                                for (uint32_t r = 0; r < 4; ++r) {
-                                                        if (r >= rows)
-                                                                break;
-                                                        const uint32_t prow = uni(sh.rrow[r]);
-                                                        const uint4 *rec = (const uint4 *)(prank + ((size_t)prow * (plw / (PL_RANK_DOCS / 32u)) + g) * PL_RANK_WORDS);
-                                                        const uint4 x0 = rec[0], x1 = rec[1], x2 = rec[2];
-                                                        uint32_t rank = x0.x;
-                                                        const uint32_t w8[8] = {x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x};
-#pragma unroll
-                                                        for (uint32_t i = 0; i < 8; ++i)
-                                                                rank += i < k ? (uint32_t)__popc(w8[i]) : i == k ? (uint32_t)__popc(w8[i] & below) : 0u;
-                                                        rk[r] = rank;
-                                                }
-#pragma unroll
-                                                for (uint32_t r = 0; r < 4; ++r) {
-                                                        if (r >= rows)
-                                                                break;
-                                                        const unsigned long long e = phs[hs_off[uni(sh.rrow[r])] + rk[r]];
-                                                        sh.hits_off[r * tile + j] = (uint32_t)e; // (this lane's own places: read back below without a barrier)
-                                                        sh.freq[r * tile + j] = (uint32_t)(e >> 32);
-                                                }
-                                        }
                                         // GOOGLE, the usual case — up to four distinct terms, every one of the candidate's hit runs at most eight single-byte hits —:
                                         // the rows' hit bytes are fetched TOGETHER, one unaligned 8-byte load each (one round trip for the whole check, where the
                                         // streams below send for a row's bytes when the walk reaches it), and the walks are shifts of registers

@@ -55,6 +55,18 @@ struct PlanePost {
         }
 };
 
+// Word k of a group's rank record (dev_structs.hpp: PL_RANK_WORDS): eight pairs { the posting index of the first document of the group's word i, that word of
+// plane 0 } — a document's rank is ONE eight-byte load and a popcount
+__device__ __forceinline__ uint32_t rank_rec_word(const uint32_t first /* the group's first posting */, const uint32_t *w8 /* its eight plane-0 words (LDS) */, const uint32_t k) {
+        if (k & 1u)
+                return w8[k >> 1];
+        uint32_t before = first;
+#pragma unroll
+        for (uint32_t i = 0; i < 7; ++i)
+                before += i < (k >> 1) ? (uint32_t)__popc(w8[i]) : 0u;
+        return before;
+}
+
 // One workgroup per (plane row, window): the rows (<= 32 documents each) of the term that reach the window are decoded, one lane
 // per row, into LDS planes, which are then written out whole — every word of every plane is written by exactly one workgroup,
 // so the scratch region needs no clearing between launches.
@@ -125,11 +137,11 @@ __global__ __launch_bounds__(AND_WG) void k_term_planes(const uint8_t *__restric
         __syncthreads();
         uint32_t *pa = planes0 + (size_t)row * stride0 + (size_t)w * PL_WORDS;
         if (prank) { // (rank of a document = its group's entry + the plane-0 bits of the group before it, both in ONE 64-byte record: k_phrase.hpp)
-                static_assert(PL_RANK_DOCS == 256 && PL_RANK_WORDS == 16, "a record: the rank, the group's eight plane-0 words, padding to a cache line");
+                static_assert(PL_RANK_DOCS == 256 && PL_RANK_WORDS == 16, "a record: eight (rank, plane-0 word) pairs, one cache line");
                 uint32_t *rec = prank + ((size_t)row * (plw / (PL_RANK_DOCS / 32u)) + (size_t)w * (PL_W / PL_RANK_DOCS)) * PL_RANK_WORDS;
                 for (uint32_t i = tid; i < (PL_W / PL_RANK_DOCS) * PL_RANK_WORDS; i += AND_WG) {
                         const uint32_t g = i / PL_RANK_WORDS, k = i % PL_RANK_WORDS;
-                        rec[i] = k == 0 ? rdir[g] : k <= 8 ? pl[8u * g + k - 1u] : 0u;
+                        rec[i] = rank_rec_word(rdir[g], pl + 8u * g, k);
                 }
         }
         if (!hi) { // plane 0 alone: all a DocumentsOnly batch reads
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(AND_WG) void k_term_plane0(const uint8_t *__restric
                 uint32_t *rec = prank + ((size_t)row * (plw / (PL_RANK_DOCS / 32u)) + (size_t)wfirst * (PL_W / PL_RANK_DOCS)) * PL_RANK_WORDS;
                 for (uint32_t i = tid; i < wn * (PL_W / PL_RANK_DOCS) * PL_RANK_WORDS; i += AND_WG) {
                         const uint32_t gg = i / PL_RANK_WORDS, k = i % PL_RANK_WORDS;
-                        rec[i] = k == 0 ? rdir[gg] : k <= 8 ? pl[8u * gg + k - 1u] : 0u;
+                        rec[i] = rank_rec_word(rdir[gg], pl + 8u * gg, k);
                 }
         }
 }
