@@ -12,7 +12,10 @@ import trinity_amd.engine as E
 
 name = os.environ.get("WORKLOAD", "cfg3")
 D, V, NQ = int(os.environ.get("DOCS", 10_000_000)), int(os.environ.get("VOCAB", 1_000_000)), int(os.environ.get("NQ", 2048))
-progs, flags, topk, codec, desc = W.build(name, D, V, 10, 42, NQ)  # single-part workloads (cfg5 runs as two batches: bench.py)
+if name == "or5":  # cfg5's pure 5-way unions alone (DocumentsOnly, google_codec)
+    progs, flags, topk, codec, desc = W.or5(E.gen_queries(V, 1337 + 2, NQ, 5)), E.FLAG_DOCUMENTS_ONLY, 0, E.CODEC_GOOGLE, "or5: 5-way OR, google_codec, DocumentsOnly"
+else:
+    progs, flags, topk, codec, desc = W.build(name, D, V, 10, 42, NQ)  # single-part workloads (cfg5 runs as two batches: bench.py)
 if os.environ.get("ONLY"):  # cfg3's query classes alone: ONLY=0 `A B (C|D|E)`, 1 `(A|B) (C|D) E`, 2 `A B C D E`, 3 `A|B|C|D|E`
     keep = int(os.environ["ONLY"])
     progs = [p for i, p in enumerate(progs) if (i & 3) == keep]

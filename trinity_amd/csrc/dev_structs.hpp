@@ -120,6 +120,9 @@ struct DevPsetUnit { // (also the record of a TASK_PROBE task: w_begin / w_end a
 };
 static_assert(sizeof(DevPsetUnit) == 64, "one cache-line half per unit");
 constexpr uint32_t PSET_UNIT_FIRST = 1u, PSET_UNIT_BITMAP = 2u;
+constexpr uint32_t PSET_UNIT_ROUND_SHIFT = 4, PSET_UNIT_ROUND_MASK = 15u; // DevPsetUnit::first bits 4 .. 7: docID windows per ROUND of the task (k_psets.hpp: the waves' counts cross once a round;
+                                                                          // planner.hpp sizes it so that a wave's survivors of a round fit its staging buffer); 0 reads as 1
+constexpr uint32_t PSET_ROUND_DOCS = 16384, PSET_STAGE_DOCS = 1024; // documents of a window a wave of k_psets owns (eight waves), docIDs its staging buffer holds
 constexpr uint32_t PSET_UNIT_SCATTER = 4u; // a UNION some of whose terms have no plane (qplane[] = PL_NONE for them), result a bitmap: the plane terms' words are OR-ed and stored,
                                            // then the other terms' documents of the task's range are set in the stored words one by one (k_psets.hpp: psets_scatter)
 // ---- TASK_TREE: the query tree as the kernels read it (k_tree.hpp).  A record in the plan's tree[] words (DevQuery::fused_idx = its first word):

@@ -17,15 +17,28 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 // the one-lane-per-row writes of the lead decode (lane t writes row t, column i) off a single bank.
 __device__ __forceinline__ uint32_t phys(uint32_t j) { return (j & ~31u) | ((j + (j >> 5)) & 31u); }
 
+// Exclusive prefix sum across the wave's 64 lanes (every lane active) and the wave's total.  Six DPP adds — within each row of 16 lanes by row_shr:1 / 2 / 4 / 8, then
+// row_bcast:15 carries rows 0 / 2's sums into rows 1 / 3 and row_bcast:31 the lower half's into the upper — and a v_readlane: no LDS crossbar trips (until round 6 this was
+// six __shfl_up steps: a ds_bpermute_b32 and an s_waitcnt lgkmcnt(0) each, a chain of seven LDS round trips per scan in k_psets' / k_and's inner loops).
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total) {
         uint32_t x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if ((int)(threadIdx.x & 63) >= d)
-                        x += y;
-        }
-        total = __shfl(x, 63, 64);
+        // (written out: left to the compiler, an update_dpp + add pair became v_mov 0 / v_mov_dpp / v_add — eighteen instructions — where registers were tight.  A VALU
+        //  result read by a DPP instruction wants two wait states: the s_nop 1 between them; the ones at the ends stand for what the compiler cannot see into)
+        asm volatile("s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                     "s_nop 1"
+                     : "+v"(x));
+        total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
         return x - v;
 }
 

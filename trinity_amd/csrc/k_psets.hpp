@@ -10,26 +10,24 @@
 //
 // Until round 3 these queries ran in k_and_dense's plane-only branch: plane words -> LDS bitmap -> a workgroup-wide scan (five barriers
 // per window) -> every lane storing its own words' docIDs straight to HBM, 4 bytes at a time, a wave's store instruction spread over a
-// dozen cache lines (r03: 11.8 us per window and workgroup).  Here:
-//   * a wave owns 512 consecutive words (16384 documents) of a step — two 16-byte loads per lane and term —, keeps the survivors in
-//     registers, and only its COUNT crosses to the other waves: ONE barrier per step (double-buffered counts) instead of six;
-//   * the wave expands its survivors into a private LDS staging buffer (scattered 4-byte LDS writes are cheap) and copies the buffer out
-//     with coalesced stores: a store instruction covers 256 contiguous bytes;
-//   * a wave whose sub-window holds more survivors than the staging buffer (a union of head terms: one document in 16 or denser) walks
-//     its words one lane per BIT — ballot, rank by mbcnt, one coalesced store per 64 bits;
+// dozen cache lines (r03: 11.8 us per window and workgroup).  Here (rounds 3 - 6; psets_round below says what round 6 changed and why):
+//   * a task (four docID windows of one query) runs in ROUNDS of 1 / 2 / 4 windows (the planner picks: DevPsetUnit::first); in a round a
+//     wave owns a contiguous eighth of the words — a sub-window of 512 words (16384 documents) per window: two 16-byte loads per lane
+//     and term —, keeps a sub-window's survivors in registers, expands them into a private LDS staging buffer (scattered 4-byte LDS
+//     writes are cheap), and only its COUNT crosses to the other waves, ONCE per round; then it copies the buffer out with coalesced
+//     stores: a store instruction covers 256 contiguous bytes;
+//   * a wave whose share holds more survivors than the staging buffer walks its words again behind the barrier, sub-window by
+//     sub-window; a sub-window denser than the buffer (a union of head terms: one document in 16 or denser) one lane per BIT — ballot,
+//     rank by mbcnt, one coalesced store per 64 bits;
 //   * a task is ONE 64-byte record (DevPsetUnit) fetched a task ahead by wave 0 together with the ticket after it, instead of the
-//     sched -> task -> query -> qterms / qplane chain of dependent loads; tasks are two windows of one query, and the schedule runs them
-//     window range by window range, so that a range's plane words are in the XCDs' L2 while every query that reads them is in flight.
+//     sched -> task -> query -> qterms / qplane chain of dependent loads; the schedule runs the tasks window range by window range (and,
+//     option pset_order, by the query's heaviest term within a range), so that a range's plane words are in the XCDs' L2 / the
+//     Infinity Cache while every query that reads them is in flight.
 // A task has a private, bound-allocated output region (planner.hpp: the same layout as TASK_DENSE, so k_score / k_rich / k_phrase / the
 // result read-back see no difference).
-// Measured (cfg2, 1551 queries, 119 K windows, 380 M docIDs): 1.05 ms.  Probe builds said where it goes: without the
-// expansion 0.59 ms, without the plane loads 0.58 ms (half the matches), without the copy-out 0.92 ms; the phase clocks: 39 % at the first
-// use of the plane words, 19 % at the barrier, 16 % expanding, 13 % counting.  About 400 wave instructions per sub-window, 250 of them the
-// expansion's count-trailing-zeros loops (eight words per lane, a loop's trips = the wave's densest word: 20 % of the lane-iterations
-// extract a bit) — 0.6 ms of issue slots by themselves.  Tried on the way and not kept (each correct, each measured): the next window's
-// words requested before the expansion (1.03 - 1.13 ms: 16 more registers, spills at 8 waves per SIMD, nothing gained at 6); 256- and
-// 128-thread workgroups (1.09 / 1.30 ms); no workgroup synchronisation at all — every wave an item on its own, the counts published in
-// global cells and read back by the later sub-windows of the task (1.37 ms: two more memory round trips on every wave's critical path).
+// Measured at cfg2 (1804 queries, 36 K tasks, 380 M matches of which 279 M stay bitmap bits): round 3 1.05 ms, round 5 0.56 (the pair path, dense
+// results as bitmaps), round 6 0.49 - 0.50.  Probe builds (-DTRI_PSET_VARIANT=1 counts only, =2 no copy-out, =3 the general loop without its
+// plane loads) and what was tried and not kept (each correct, each measured): DESIGN.md §15.9.
 #pragma once
 
 #ifndef TRI_PSET_WG
@@ -43,6 +41,9 @@ constexpr uint32_t PSET_STEP_WORDS = PSET_WAVES * PSET_WORDS; // words the workg
 static_assert(SPAN_WORDS % PSET_STEP_WORDS == 0, "a docID window is a whole number of steps");
 constexpr uint32_t PSET_STAGE = 1024;                    // docIDs a wave stages per sub-window before it copies them out
 static_assert(PSET_PER == 8, "two 16-byte loads per lane and term");
+static_assert(PSET_WAVES == 8, "the waves' counts are prefix-summed over lanes 0 .. 7 (psets_task)");
+static_assert(PSET_WORDS * 32 == PSET_ROUND_DOCS && PSET_STAGE == PSET_STAGE_DOCS, "the planner sizes a task's rounds by them (dev_structs.hpp)");
+static_assert(SPAN_WORDS == PSET_WAVES * PSET_WORDS, "a wave's share of a task: one sub-window of PSET_WORDS words per docID window");
 static_assert(PSET_STAGE >= PSET_WORDS, "the dense walk parks the wave's words in its staging buffer");
 
 struct PsetScatterShared { // (part of PsetShared)
@@ -51,7 +52,7 @@ struct PsetScatterShared { // (part of PsetShared)
 };
 struct PsetShared {
         uint32_t stage[PSET_WAVES][PSET_STAGE];
-        uint32_t cnt[2][PSET_WAVES]; // per window parity: the waves' survivor counts
+        alignas(16) uint32_t cnt[2][PSET_WAVES]; // per window parity: the waves' survivor counts (psets_pair reads a parity's eight as two 16-byte words)
         PsetScatterShared scatter;   // PSET_UNIT_SCATTER tasks: the terms without a plane
         DevPsetUnit unit[2];         // the task being run and the next one (fetched while the current one runs)
         uint32_t tick[2];            // ... and their tickets (>= ntasks: none)
@@ -153,6 +154,177 @@ __device__ __noinline__ uint32_t psets_scatter(PsetScatterShared &ss, const uint
         return post.added;
 }
 
+// ---- a task's windows -> its output region.  `words(word0, acc)` gives the lane's eight survivor words at word0 (the pair loop and the general loop of the kernel below).
+//      Round 6, in two steps:
+//      (1) the kernel's VALUs were four fifths busy (SQ counters) and 150 of a wave's 250 vector instructions per step were NOT the expansion: a wave scan of six __shfl_up
+//          (a ds_bpermute_b32, an s_waitcnt and four VALUs each), the eight counts read one by one and added under eight `wv < wave` conditions the compiler hoisted out of
+//          the loop into SGPR pairs, spilled, and read back lane by lane with v_readlane.  Now the scan is six DPP adds (wave_excl_scan), the counts are read ONE per lane
+//          and prefix-summed by three more, the wave's base and the task's total are two v_readlane (0.56 -> 0.50 ms at cfg2).
+//      (2) a wave owned 512 words of every 4096-word STEP, the waves' counts crossed at a barrier per step, and every step ended with its copy-out stores — and gfx9 has ONE
+//          counter for loads and stores: the next step's `s_waitcnt vmcnt(0)` for its plane words waited for those stores' acknowledgements too (a probe build without the
+//          copy-out ran as fast as one without the whole expansion; requesting the next step's words early gained nothing).  Now a wave owns a CONTIGUOUS eighth of the
+//          task's words (its windows x 512 words), stages every survivor of its share in LDS — no barrier, no store until the share is through —, the waves' totals cross
+//          ONCE per task, and each wave copies its docIDs out in one piece.  A wave whose share holds more survivors than its staging buffer (a union of head terms: one
+//          document in 16 or denser) counts them all the same and then walks its words AGAIN behind the barrier, one lane per BIT — ballot, rank by mbcnt, one coalesced
+//          store per 64 bits.
+//      Returns the task's survivor count (as_bitmap: this LANE's share of it — the caller reduces).
+//      `request(word0, buf)` issues the loads of the lane's words at word0, `words(buf, word0, acc)` folds them into the eight survivor words: with
+//      TRI_PSET_PREFETCH a sub-window's words are requested BEFORE the one ahead of it is counted and expanded.
+#ifndef TRI_PSET_PREFETCH
+#define TRI_PSET_PREFETCH 0 // 1: a sub-window's words are requested before the one ahead of it is counted and expanded.  Measured (cfg2): 0.525 ms against 0.489 at eight waves per
+                            // SIMD (sixteen more registers: 8 spilled), 0.503 at six without spills — the kernel does not wait for the latency of ITS loads
+#endif
+struct PsetNoBuf {};
+struct PsetPairBuf {
+        uint4 a0, a1, b0, b1;
+};
+template <class BUF, class R, class F>
+__device__ __forceinline__ uint32_t psets_round(PsetShared &sh, R &&request, F &&words, const uint32_t w_origin, const uint32_t w_begin, const uint32_t w_end, uint32_t *__restrict__ qout,
+                                                const bool as_bitmap, const uint32_t lane, const uint32_t wave, const uint32_t par) {
+        const uint32_t nsub = w_end - w_begin; // sub-windows of PSET_WORDS words of this wave's share (the task's words / PSET_WAVES)
+        const uint32_t wave0 = w_begin * SPAN_WORDS + wave * nsub * PSET_WORDS + lane * PSET_PER; // this lane's first word of its wave's share
+        uint32_t *const st = sh.stage[wave];
+        if (as_bitmap) { // nothing to expand, nothing to rank: two 16-byte stores per lane and sub-window, the counts summed at the task's end
+                uint32_t lane_cnt = 0;
+                BUF nxt;
+                if (TRI_PSET_PREFETCH)
+                        request(wave0, nxt);
+                for (uint32_t sb = 0; sb < nsub; ++sb) {
+                        const uint32_t word0 = wave0 + sb * PSET_WORDS;
+                        BUF cur;
+                        if (TRI_PSET_PREFETCH) {
+                                cur = nxt;
+                                if (sb + 1 < nsub)
+                                        request(word0 + PSET_WORDS, nxt);
+                        } else
+                                request(word0, cur);
+                        uint32_t acc[PSET_PER];
+                        words(cur, word0, acc);
+                        uint4 *o = (uint4 *)(qout + (word0 - w_origin * SPAN_WORDS));
+                        o[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+                        o[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
+#pragma unroll
+                        for (uint32_t j = 0; j < PSET_PER; ++j)
+                                lane_cnt += (uint32_t)__popc(acc[j]);
+                }
+                return lane_cnt;
+        }
+        uint32_t fill = 0; // (wave-uniform) survivors of the share so far; staged while they fit
+        BUF nxt;
+        if (TRI_PSET_PREFETCH)
+                request(wave0, nxt);
+        for (uint32_t sb = 0; sb < nsub; ++sb) {
+                const uint32_t word0 = wave0 + sb * PSET_WORDS;
+                BUF cur;
+                if (TRI_PSET_PREFETCH) {
+                        cur = nxt;
+                        if (sb + 1 < nsub)
+                                request(word0 + PSET_WORDS, nxt);
+                } else
+                        request(word0, cur);
+                uint32_t acc[PSET_PER];
+                words(cur, word0, acc);
+                uint32_t c = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < PSET_PER; ++j)
+                        c += (uint32_t)__popc(acc[j]);
+                uint32_t T;
+                const uint32_t ex = wave_excl_scan(c, T);
+#if !defined(TRI_PSET_VARIANT) || TRI_PSET_VARIANT != 1 // (perf probe 1: counts only)
+                if (T && fill + T <= PSET_STAGE) { // (uniform) every lane writes its words' docIDs into the wave's staging buffer at its rank
+                        uint32_t o = fill + ex;
+#pragma unroll
+                        for (uint32_t j = 0; j < PSET_PER; ++j) {
+                                uint32_t m = acc[j];
+                                const uint32_t d0 = (word0 + j) << 5;
+                                while (m) {
+                                        st[o++] = d0 + (uint32_t)__builtin_ctz(m);
+                                        m &= m - 1u;
+                                }
+                        }
+                }
+#endif
+                fill += T;
+        }
+        // ---- the waves' totals cross: lane k (k < 8; the others repeat them) reads wave k's, an inclusive prefix over lanes 0 .. 7 is three DPP adds
+        if (lane == 0)
+                sh.cnt[par][wave] = fill;
+        __syncthreads();
+        uint32_t own = sh.cnt[par][lane & (PSET_WAVES - 1u)], pre = own;
+        asm volatile("s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_u32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                     "s_nop 1"
+                     : "+v"(pre));
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(pre - own), (int)wave);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)pre, (int)PSET_WAVES - 1);
+#if defined(TRI_PSET_VARIANT) && (TRI_PSET_VARIANT == 1 || TRI_PSET_VARIANT == 2) // (perf probes: no copy-out)
+        return total;
+#endif
+        if (fill <= PSET_STAGE) { // (uniform) the wave's docIDs go out in one piece — 64 consecutive docIDs per store instruction
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t i = lane; i < fill; i += 64u)
+                        qout[base + i] = st[i];
+                __builtin_amdgcn_wave_barrier(); // (the next task's staging writes stay behind these reads)
+        } else {
+                // ---- the share held more than the buffer (the planner's estimate fell short, or a single sub-window is that dense): its words once more (from L2),
+                //      sub-window by sub-window, now that the wave knows where its docIDs go — staged and copied out where a sub-window's survivors fit, else the
+                //      sub-window's 512 words parked in LDS and one lane per BIT, 64 bits a step: ballot, rank by mbcnt, one coalesced store
+                uint32_t o = base;
+                for (uint32_t sb = 0; sb < nsub; ++sb) {
+                        const uint32_t word0 = wave0 + sb * PSET_WORDS;
+                        uint32_t acc[PSET_PER];
+                        BUF cur;
+                        request(word0, cur);
+                        words(cur, word0, acc);
+                        uint32_t c = 0;
+#pragma unroll
+                        for (uint32_t j = 0; j < PSET_PER; ++j)
+                                c += (uint32_t)__popc(acc[j]);
+                        uint32_t T;
+                        const uint32_t ex = wave_excl_scan(c, T);
+                        if (!T)
+                                continue;
+                        if (T <= PSET_STAGE) {
+                                uint32_t at = ex;
+#pragma unroll
+                                for (uint32_t j = 0; j < PSET_PER; ++j) {
+                                        uint32_t m = acc[j];
+                                        const uint32_t d0 = (word0 + j) << 5;
+                                        while (m) {
+                                                st[at++] = d0 + (uint32_t)__builtin_ctz(m);
+                                                m &= m - 1u;
+                                        }
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                                for (uint32_t i = lane; i < T; i += 64u)
+                                        qout[o + i] = st[i];
+                                __builtin_amdgcn_wave_barrier();
+                                o += T;
+                                continue;
+                        }
+#pragma unroll
+                        for (uint32_t j = 0; j < PSET_PER; ++j)
+                                st[lane * PSET_PER + j] = acc[j];
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t wbase = word0 - lane * PSET_PER;
+                        for (uint32_t cidx = 0; cidx < PSET_WORDS / 2; ++cidx) {
+                                const uint32_t wi = 2u * cidx + (lane >> 5);
+                                const bool bit = (st[wi] >> (lane & 31u)) & 1u;
+                                const uint64_t bm = __builtin_amdgcn_ballot_w64(bit);
+                                if (bit)
+                                        qout[o + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = ((wbase + wi) << 5) + (lane & 31u);
+                                o += (uint32_t)__popcll(bm);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                }
+        }
+        return total;
+}
+
 #ifndef TRI_PSET_WAVES
 #define TRI_PSET_WAVES 8 // waves per SIMD the register budget is cut for (512-thread workgroups: four per CU, 33 KB of LDS each)
 #endif
@@ -182,6 +354,7 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                 nt = uni(atomicAdd(ticket, 1u)) >> 6;
         }
         __syncthreads();
+        uint32_t par = 0; // which of cnt[]'s two halves the next exchange of the waves' counts uses
         for (uint32_t p = 0;; p ^= 1u) {
                 if (uni(sh.tick[p]) >= ntasks)
                         break;
@@ -196,142 +369,95 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                                 nwd = ((const uint32_t *)(units + order[nt]))[lane & 15u];
                         nnt = atomicAdd(ticket, 1u);
                 }
-                uint32_t produced = 0, par = 0;
+                uint32_t produced = 0;
+                const uint32_t round_win = std::max(1u, (uni(U.first) >> PSET_UNIT_ROUND_SHIFT) & PSET_UNIT_ROUND_MASK); // windows per round: the waves' counts cross once a round
                 const uint32_t pair_row0 = uni(U.row[0]), pair_row1 = uni(U.row[1]), pair_tt1 = uni(U.tt[1]);
-                const bool pair = nterms == 2 && pair_row0 != PL_NONE && pair_row1 != PL_NONE;
-                const bool pair_and = pair_tt1 & QT_GROUP, pair_not = pair_tt1 & QT_NOT; // (the second term opens a group of its own: AND, or AND-NOT)
-                for (uint32_t sw = w_begin * SPAN_WORDS; sw < w_end * SPAN_WORDS; sw += PSET_STEP_WORDS, par ^= 1u) {
-                        const uint32_t word0 = sw + tid * PSET_PER; // this lane's first word of the step
-                        // ---- the window's survivors, this lane's eight words: OR inside a group, AND across groups, AND-NOT for the excluded group
-                        uint32_t acc[PSET_PER], grp[PSET_PER];
-                        bool have_acc = false, cur_neg = false;
+                if (nterms == 2 && pair_row0 != PL_NONE && pair_row1 != PL_NONE) {
+                        // ---- two terms with planes — the batch's usual query (cfg2: every k_psets query): the operator is chosen once per task (the second term opens a
+                        //      group of its own: AND, or AND-NOT; else OR), both rows' words are requested together (the general loop below waits for a term's two loads
+                        //      before it issues the next term's: a round trip per term)
+                        const uint32_t *const row_a = planes + (size_t)pair_row0 * plw, *const row_b = planes + (size_t)pair_row1 * plw;
+                        const bool pair_or = !(pair_tt1 & QT_GROUP);
+                        const uint32_t flip = (pair_tt1 & QT_NOT) ? ~0u : 0u;
+                        for (uint32_t wb = w_begin; wb < w_end; wb += round_win, par ^= 1u)
+                        produced += psets_round<PsetPairBuf>(
+                            sh,
+                            [&](const uint32_t word0, PsetPairBuf &buf) {
+                                    const uint4 *pa = (const uint4 *)(row_a + word0);
+                                    const uint4 *pb = (const uint4 *)(row_b + word0);
+                                    buf.a0 = pa[0], buf.a1 = pa[1], buf.b0 = pb[0], buf.b1 = pb[1];
+                            },
+                            [&](const PsetPairBuf &buf, const uint32_t word0, uint32_t(&acc)[PSET_PER]) {
+                                    const uint4 a0 = buf.a0, a1 = buf.a1, b0 = buf.b0, b1 = buf.b1;
+                                    if (pair_or) { // (uniform)
+                                            acc[0] = a0.x | b0.x, acc[1] = a0.y | b0.y, acc[2] = a0.z | b0.z, acc[3] = a0.w | b0.w;
+                                            acc[4] = a1.x | b1.x, acc[5] = a1.y | b1.y, acc[6] = a1.z | b1.z, acc[7] = a1.w | b1.w;
+                                    } else {
+                                            acc[0] = a0.x & (b0.x ^ flip), acc[1] = a0.y & (b0.y ^ flip), acc[2] = a0.z & (b0.z ^ flip), acc[3] = a0.w & (b0.w ^ flip);
+                                            acc[4] = a1.x & (b1.x ^ flip), acc[5] = a1.y & (b1.y ^ flip), acc[6] = a1.z & (b1.z ^ flip), acc[7] = a1.w & (b1.w ^ flip);
+                                    }
+                                    if (masked) { // masked_documents_registry::test (docidupdates.h:90-119): updated / deleted elsewhere
+                                            const uint4 *pm = (const uint4 *)(masked + word0);
+                                            const uint4 m0 = pm[0], m1 = pm[1];
+                                            acc[0] &= ~m0.x, acc[1] &= ~m0.y, acc[2] &= ~m0.z, acc[3] &= ~m0.w;
+                                            acc[4] &= ~m1.x, acc[5] &= ~m1.y, acc[6] &= ~m1.z, acc[7] &= ~m1.w;
+                                    }
+                            },
+                            w_begin, wb, min(w_end, wb + round_win), as_bitmap ? qout : qout + produced, as_bitmap, lane, wave, par);
+                } else
+                        for (uint32_t wb = w_begin; wb < w_end; wb += round_win, par ^= 1u)
+                        produced += psets_round<PsetNoBuf>(
+                            sh, [](const uint32_t, PsetNoBuf &) {},
+                            [&](const PsetNoBuf &, const uint32_t word0, uint32_t(&acc)[PSET_PER]) {
+                                    // ---- the lane's eight words: OR inside a group, AND across groups, AND-NOT for the excluded group
+                                    uint32_t grp[PSET_PER];
+                                    bool have_acc = false, cur_neg = false;
 #pragma unroll
-                        for (uint32_t j = 0; j < PSET_PER; ++j)
-                                acc[j] = grp[j] = 0;
-                        if (pair) {
-                                // two terms with planes — the batch's usual query: both terms' words travel together (the general loop below waits for a
-                                // term's two loads before it issues the next term's: a round trip per term and step)
-                                const uint4 *pa = (const uint4 *)(planes + (size_t)pair_row0 * plw + word0);
-                                const uint4 *pb = (const uint4 *)(planes + (size_t)pair_row1 * plw + word0);
-                                const uint4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
-                                const uint32_t av[PSET_PER] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, bv[PSET_PER] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                                    for (uint32_t j = 0; j < PSET_PER; ++j)
+                                            acc[j] = grp[j] = 0;
+                                    for (uint32_t k = 0; k <= nterms; ++k) {
+                                            uint32_t tt = QT_GROUP, row = 0; // (k == nterms: the last group is folded in)
+                                            if (k < nterms) {
+                                                    if (nterms <= PSET_INLINE_TERMS) {
+                                                            tt = uni(U.tt[k]);
+                                                            row = uni(U.row[k]);
+                                                    } else {
+                                                            tt = uni(qterms[term_base + k]);
+                                                            row = uni(qplane[term_base + k]);
+                                                    }
+                                            }
+                                            if (k && (tt & QT_GROUP)) {
 #pragma unroll
-                                for (uint32_t j = 0; j < PSET_PER; ++j)
-                                        acc[j] = !pair_and ? av[j] | bv[j] : pair_not ? av[j] & ~bv[j] : av[j] & bv[j];
-                        } else
-                        for (uint32_t k = 0; k <= nterms; ++k) {
-                                uint32_t tt = QT_GROUP, row = 0; // (k == nterms: the last group is folded in)
-                                if (k < nterms) {
-                                        if (nterms <= PSET_INLINE_TERMS) {
-                                                tt = uni(U.tt[k]);
-                                                row = uni(U.row[k]);
-                                        } else {
-                                                tt = uni(qterms[term_base + k]);
-                                                row = uni(qplane[term_base + k]);
-                                        }
-                                }
-                                if (k && (tt & QT_GROUP)) {
-#pragma unroll
-                                        for (uint32_t j = 0; j < PSET_PER; ++j) {
-                                                acc[j] = !have_acc ? grp[j] : cur_neg ? acc[j] & ~grp[j] : acc[j] & grp[j];
-                                                grp[j] = 0;
-                                        }
-                                        have_acc = true;
-                                }
-                                if (k == nterms)
-                                        break;
-                                if (tt & QT_GROUP)
-                                        cur_neg = tt & QT_NOT;
-                                if (row == PL_NONE) // (a PSET_UNIT_SCATTER union's term without a plane: its documents are set after the windows, below)
-                                        continue;
-                                const uint4 *pa = (const uint4 *)(planes + (size_t)row * plw + word0);
+                                                    for (uint32_t j = 0; j < PSET_PER; ++j) {
+                                                            acc[j] = !have_acc ? grp[j] : cur_neg ? acc[j] & ~grp[j] : acc[j] & grp[j];
+                                                            grp[j] = 0;
+                                                    }
+                                                    have_acc = true;
+                                            }
+                                            if (k == nterms)
+                                                    break;
+                                            if (tt & QT_GROUP)
+                                                    cur_neg = tt & QT_NOT;
+                                            if (row == PL_NONE) // (a PSET_UNIT_SCATTER union's term without a plane: its documents are set after the windows, below)
+                                                    continue;
+                                            const uint4 *pa = (const uint4 *)(planes + (size_t)row * plw + word0);
 #if defined(TRI_PSET_VARIANT) && TRI_PSET_VARIANT == 3 // (perf probe 3: no plane loads — words made up from the lane's address)
-                                const uint32_t hsh = (word0 * 2654435761u) ^ (k * 40503u);
-                                const uint4 v0 = make_uint4(hsh & (hsh >> 3) & (hsh >> 7), 0, (hsh >> 5) & (hsh << 2) & (hsh >> 11), 0), v1 = make_uint4(0, hsh & 0x10001u, 0, hsh & 0x200u);
+                                            const uint32_t hsh = (word0 * 2654435761u) ^ (k * 40503u);
+                                            const uint4 v0 = make_uint4(hsh & (hsh >> 3) & (hsh >> 7), 0, (hsh >> 5) & (hsh << 2) & (hsh >> 11), 0), v1 = make_uint4(0, hsh & 0x10001u, 0, hsh & 0x200u);
 #else
-                                const uint4 v0 = pa[0], v1 = pa[1];
+                                            const uint4 v0 = pa[0], v1 = pa[1];
 #endif
-                                grp[0] |= v0.x, grp[1] |= v0.y, grp[2] |= v0.z, grp[3] |= v0.w;
-                                grp[4] |= v1.x, grp[5] |= v1.y, grp[6] |= v1.z, grp[7] |= v1.w;
-                        }
-                        if (masked) { // masked_documents_registry::test (docidupdates.h:90-119): updated / deleted elsewhere
-                                const uint4 *pm = (const uint4 *)(masked + word0);
-                                const uint4 m0 = pm[0], m1 = pm[1];
-                                acc[0] &= ~m0.x, acc[1] &= ~m0.y, acc[2] &= ~m0.z, acc[3] &= ~m0.w;
-                                acc[4] &= ~m1.x, acc[5] &= ~m1.y, acc[6] &= ~m1.z, acc[7] &= ~m1.w;
-                        }
-                        if (as_bitmap) { // nothing to expand, nothing to rank: two 16-byte stores per lane, the counts summed at the task's end
-                                uint4 *o = (uint4 *)(qout + (word0 - w_begin * SPAN_WORDS));
-                                o[0] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
-                                o[1] = make_uint4(acc[4], acc[5], acc[6], acc[7]);
-#pragma unroll
-                                for (uint32_t j = 0; j < PSET_PER; ++j)
-                                        produced += (uint32_t)__popc(acc[j]); // (per lane here; reduced below)
-                                continue;
-                        }
-                        // ---- counts: lane -> wave (shuffles) -> workgroup (one LDS word per wave, one barrier)
-                        uint32_t c = 0;
-#pragma unroll
-                        for (uint32_t j = 0; j < PSET_PER; ++j)
-                                c += (uint32_t)__popc(acc[j]);
-                        uint32_t T;
-                        const uint32_t ex = wave_excl_scan(c, T);
-                        T = uni(T);
-                        sh.cnt[par][wave] = T; // (the same value from every lane of the wave)
-                        __syncthreads();
-                        uint32_t base = produced, tot = 0;
-#pragma unroll
-                        for (uint32_t wv = 0; wv < PSET_WAVES; ++wv) {
-                                const uint32_t x = uni(sh.cnt[par][wv]);
-                                base += wv < wave ? x : 0u;
-                                tot += x;
-                        }
-                        produced += tot;
-                        if (!T)
-                                continue; // (wave-uniform; the barrier above is the window's only one)
-#if defined(TRI_PSET_VARIANT) && TRI_PSET_VARIANT == 1 // (perf probe: counts only)
-                        continue;
-#endif
-                        uint32_t *const st = sh.stage[wave];
-                        if (T <= PSET_STAGE) {
-                                // ---- sparse: every lane writes its words' docIDs into the wave's staging buffer at its rank, then the wave copies the
-                                //      buffer out — 64 consecutive docIDs per store instruction
-                                uint32_t o = ex;
-#pragma unroll
-                                for (uint32_t j = 0; j < PSET_PER; ++j) {
-                                        uint32_t m = acc[j];
-                                        const uint32_t b0 = (word0 + j) << 5;
-                                        while (m) {
-                                                st[o++] = b0 + (uint32_t)__builtin_ctz(m);
-                                                m &= m - 1u;
-                                        }
-                                }
-                                __builtin_amdgcn_wave_barrier();
-#if !defined(TRI_PSET_VARIANT) || TRI_PSET_VARIANT != 2 // (perf probe 2: no copy-out)
-                                for (uint32_t i = lane; i < T; i += 64u)
-                                        qout[base + i] = st[i];
-#endif
-                                __builtin_amdgcn_wave_barrier(); // (the next window's staging writes stay behind these reads)
-                        } else {
-                                // ---- dense (a union of head terms): the wave's 512 words parked in LDS, then one lane per BIT, 64 bits a step:
-                                //      ballot, rank by mbcnt, one coalesced store
-#pragma unroll
-                                for (uint32_t j = 0; j < PSET_PER; ++j)
-                                        st[lane * PSET_PER + j] = acc[j];
-                                __builtin_amdgcn_wave_barrier();
-                                uint32_t o = base;
-                                const uint32_t wbase = sw + wave * PSET_WORDS;
-                                for (uint32_t cidx = 0; cidx < PSET_WORDS / 2; ++cidx) {
-                                        const uint32_t wi = 2u * cidx + (lane >> 5);
-                                        const bool bit = (st[wi] >> (lane & 31u)) & 1u;
-                                        const uint64_t bm = __builtin_amdgcn_ballot_w64(bit);
-                                        if (bit)
-                                                qout[o + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))] = ((wbase + wi) << 5) + (lane & 31u);
-                                        o += (uint32_t)__popcll(bm);
-                                }
-                                __builtin_amdgcn_wave_barrier();
-                        }
-                }
+                                            grp[0] |= v0.x, grp[1] |= v0.y, grp[2] |= v0.z, grp[3] |= v0.w;
+                                            grp[4] |= v1.x, grp[5] |= v1.y, grp[6] |= v1.z, grp[7] |= v1.w;
+                                    }
+                                    if (masked) { // masked_documents_registry::test (docidupdates.h:90-119): updated / deleted elsewhere
+                                            const uint4 *pm = (const uint4 *)(masked + word0);
+                                            const uint4 m0 = pm[0], m1 = pm[1];
+                                            acc[0] &= ~m0.x, acc[1] &= ~m0.y, acc[2] &= ~m0.z, acc[3] &= ~m0.w;
+                                            acc[4] &= ~m1.x, acc[5] &= ~m1.y, acc[6] &= ~m1.z, acc[7] &= ~m1.w;
+                                    }
+                            },
+                            w_begin, wb, min(w_end, wb + round_win), as_bitmap ? qout : qout + produced, as_bitmap, lane, wave, par);
                 if (uni(U.first) & PSET_UNIT_SCATTER) { // (uniform)
                         __syncthreads(); // the task's words are stored: the documents of the terms without a plane go in on top of them
                         produced += psets_scatter<CODEC>(sh.scatter, index, blk_last, blk_off, blk_rec, blk_doff, win, terms, qterms + term_base, qplane + term_base, nterms, w_begin, w_end, qout, masked);
@@ -340,13 +466,13 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
 #pragma unroll
                         for (int d = 32; d >= 1; d >>= 1)
                                 produced += __shfl_xor(produced, d, 64);
-                        __syncthreads(); // (cnt[] of the previous task's last step has been read by everybody)
-                        sh.cnt[0][wave] = produced;
+                        sh.cnt[par][wave] = produced; // (cnt[par] was last read two barriers ago)
                         __syncthreads();
                         produced = 0;
 #pragma unroll
                         for (uint32_t wv = 0; wv < PSET_WAVES; ++wv)
-                                produced += uni(sh.cnt[0][wv]);
+                                produced += uni(sh.cnt[par][wv]);
+                        par ^= 1u;
                 }
                 if (wave == 0) { // (uniform stores by the lanes of wave 0: no lane-divergent branch next to the loop's barriers)
                         counts[tix] = produced;

@@ -54,6 +54,9 @@ struct tri_options {
         uint64_t planes_order = 1;             // k_planes' tasks: 1 docID range by range, within a range by the heaviest plane row they sweep (the workgroups in flight stream the same
                                                // head rows from about the same place: those words come from L2); 2: row by row, a query's ranges side by side; 0: heaviest task first.
                                                // Round 6, k_planes ms at 0 / 1 / 2: cfg3 4.40 / 4.12 / 4.33, cfg5's shard 2.17 / 2.10 / 2.20 (with four ranges a query: 5.44 / 4.73 / -)
+        uint64_t pset_order = 1;               // k_psets' tasks: 1 docID range by range and, within a range, by the query's HEAVIEST term (PSET_SUBS places by its df rank): the workgroups in
+                                               // flight read that term's words of the range one after the other — the second and later readers from L2, not over the fabric; 0: batch order
+                                               // within a range
         uint64_t cand_xcd = 1;                 // k_and's tasks queued per XCD by the plane row they probe (planner.hpp "k_and's queues"); 0: the cost order dealt round the queues
         uint64_t plan_threads = 0;             // host threads a planner context plans with; 0: up to 16, one per 512 queries, within the process's CPU budget (affinity mask, cgroup quota) shared by the handle's contexts
         uint64_t plan_hot_us = 300;            // ... keep polling for a job this long after their last one before they sleep (a polling thread uses a CPU of the process's quota;
@@ -161,13 +164,16 @@ namespace trip {
         constexpr uint32_t SCHED_NB = 64 * 4; // schedule buckets per kernel: cost octave + 2 bits
         constexpr uint32_t CAND_SUBS = 128, CAND_COST_SUBS = 16; // ... k_and's in row order have buckets of their own (behind the kernels': CAND_KEY0): per queue, 16 for the long and the
                                                                // row-less tasks by cost, 111 places for rows, one for the stragglers
-        constexpr uint32_t CAND_KEY0 = TASK_KINDS * SCHED_NB, SCHED_KEYS = CAND_KEY0 + CAND_QUEUES * CAND_SUBS;
+        constexpr uint32_t PSET_RANGE_BKS = 64, PSET_SUBS = 64; // ... k_psets' by (docID window range, heaviest term of the query): the ranges of a long docID space share the 64 range buckets
+        constexpr uint32_t CAND_KEY0 = TASK_KINDS * SCHED_NB, PSET_KEY0 = CAND_KEY0 + CAND_QUEUES * CAND_SUBS, SCHED_KEYS = PSET_KEY0 + PSET_RANGE_BKS * PSET_SUBS;
+        // a TASK_PSET task's tcost word: its first window in the low half, the df rank of its query's heaviest term in the high half
+        inline uint32_t pset_sub(const uint32_t rank) { return rank < PSET_SUBS / 2 ? rank : std::min(PSET_SUBS / 2 + (rank - PSET_SUBS / 2) / 8, PSET_SUBS - 1); }
         constexpr uint64_t CAND_ROWS_MIN_LEAD = 1024;
         // launch order of the task kinds: TASK_DENSE, TASK_PSET, TASK_PROBE, TASK_CAND, then the one-pass kinds as numbered
         constexpr uint32_t SCHED_RANK[TASK_KINDS] = {3, 0, 4, 5, 6, 7, 8, 1, 2, 9};
         inline uint32_t sched_key(const uint32_t kind, const uint64_t cost) {
                 if (kind == TASK_PSET) // by docID window range, ascending (`cost` holds the first window)
-                        return SCHED_RANK[TASK_PSET] * SCHED_NB + (uint32_t)std::min<uint64_t>(cost / PSET_TASK_WINDOWS, SCHED_NB - 1);
+                        return SCHED_RANK[TASK_PSET] * SCHED_NB + (uint32_t)std::min<uint64_t>((cost & 0xffffffffull) / PSET_TASK_WINDOWS, SCHED_NB - 1);
                 const uint64_t c = std::max<uint64_t>(1, cost);
                 const uint32_t lg = 63u - (uint32_t)__builtin_clzll(c);
                 const uint32_t frac = lg >= 2 ? (uint32_t)((c >> (lg - 2)) & 3u) : (uint32_t)((c << (2 - lg)) & 3u);
@@ -1530,9 +1536,10 @@ namespace trip {
                                 // the result's form: a bitmap over the query's docID range when the matches to expect — the lead group's documents, thinned
                                 // by every further required group as if the lists were independent — outnumber the bitmap's words
                                 bool bitmap = false;
-                                if (C.mode == TRI_FLAG_DOCUMENTS_ONLY && opt.result_bitmaps && !t.q.nphrases) {
+                                double est = 1.0; // the share of the documents expected to match
+                                if (pset || (C.mode == TRI_FLAG_DOCUMENTS_ONLY && opt.result_bitmaps && !t.q.nphrases)) {
                                         const double N = std::max<double>(1.0, (double)ix.info.docs_cnt);
-                                        double est = 1.0, g = 0.0;
+                                        double g = 0.0;
                                         bool negg = false;
                                         for (uint32_t k = 0; k <= t.q.nterms; ++k) {
                                                 if (k == t.q.nterms || (k && (qt[k] & QT_GROUP))) {
@@ -1546,8 +1553,13 @@ namespace trip {
                                                         negg = qt[k] & QT_NOT;
                                                 g += ix.terms[qt[k] & QT_TERM].documents;
                                         }
-                                        bitmap = est * N >= (double)nwin * SPAN_WORDS;
+                                        bitmap = C.mode == TRI_FLAG_DOCUMENTS_ONLY && opt.result_bitmaps && !t.q.nphrases && est * N >= (double)nwin * SPAN_WORDS;
                                 }
+                                // (TASK_PSET) windows per ROUND of k_psets: a wave stages the survivors of its share of a round — a sub-window of PSET_ROUND_DOCS documents per
+                                // window — in PSET_STAGE_DOCS LDS slots before the round's counts cross; as many windows as are expected to fill three quarters of them
+                                uint32_t round_win = 1;
+                                while (round_win < PSET_TASK_WINDOWS && est * (double)PSET_ROUND_DOCS * (double)(round_win * 2u) <= 0.75 * (double)PSET_STAGE_DOCS)
+                                        round_win *= 2u;
                                 if (pscatter && !bitmap)
                                         return herr(f.err, TRI_ERR_INTERNAL, "query %u: a scatter union whose result is not a bitmap", t.q.qid);
                                 t.q.form = bitmap ? RESULT_BITMAP : RESULT_DOCIDS;
@@ -1560,6 +1572,9 @@ namespace trip {
                                 uint64_t lead_blocks = 0;
                                 for (uint32_t k = 0; k < nlead; ++k)
                                         lead_blocks += ix.terms[qt[k] & QT_TERM].nblocks;
+                                uint64_t heaviest = 0xffffffffull; // (TASK_PSET) the df rank of the query's heaviest term: the schedule's place within a window range
+                                for (uint32_t k = 0; pset && k < t.q.nterms; ++k)
+                                        heaviest = std::min<uint64_t>(heaviest, ix.df_rank[qt[k] & QT_TERM]);
                                 for (uint32_t wb = 0; wb < nwin; wb += win_per_task, ++ord) {
                                         const uint32_t we = std::min(nwin, wb + win_per_task);
                                         // matches of windows [wb, we) are lead-group documents of blocks b1 .. (next task's b1) of every
@@ -1567,12 +1582,12 @@ namespace trip {
                                         uint64_t b1 = 0;
                                         for (uint32_t k = 0; k < nlead; ++k)
                                                 b1 += C.first_block_ge(ix.terms[qt[k] & QT_TERM], (uint64_t)wb * SPAN_BITS);
-                                        f.tcost.push_back(pset ? wb : per_win * (we - wb)); // (TASK_PSET: the schedule goes by window range, not by cost)
+                                        f.tcost.push_back(pset ? wb | heaviest << 32 : per_win * (we - wb)); // (TASK_PSET: the schedule goes by window range, not by cost)
                                         const uint64_t task_off = bitmap ? off + (uint64_t)wb * SPAN_WORDS : off + b1 * 32 + 32ull * ord * nlead;
                                         if (pset) {
                                                 DevPsetUnit u{};
                                                 u.out_off = task_off;
-                                                u.first = (bitmap ? PSET_UNIT_BITMAP : 0u) | (pscatter ? PSET_UNIT_SCATTER : 0u);
+                                                u.first = (bitmap ? PSET_UNIT_BITMAP : 0u) | (pscatter ? PSET_UNIT_SCATTER : 0u) | round_win << PSET_UNIT_ROUND_SHIFT;
                                                 u.w_begin = wb, u.w_end = we;
                                                 u.tix = (uint32_t)f.tasks.size();
                                                 u.nterms = t.q.nterms;
@@ -1857,6 +1872,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
         // k_and's tasks ordered by the plane row they probe ("k_and's queues" below): where the probes are the kernel's traffic — conjunctions of two or
         // three terms whose leads average a thousand documents or more (cfg2: 3.4 K).  Rare leads against four lists (cfg3 / cfg5: a few hundred
         // candidates a task, several rows each) gain nothing from the order and lose the heaviest-first start: measured 0.49 -> 0.54 ms, 0.68 -> 0.72 ms
+        const uint32_t pset_ranges = ((ix.max_doc >> 17) + 1u + PSET_TASK_WINDOWS - 1) / PSET_TASK_WINDOWS; // window ranges of the docID space (a TASK_PSET task's range: its first window / PSET_TASK_WINDOWS)
         const bool cand_rows = opt.cand_xcd && !chosen.empty() && cand_queries_all && cand_lead_docs >= CAND_ROWS_MIN_LEAD * cand_queries_all && cand_terms <= 3 * cand_queries_all;
         uint32_t cand_first = 0, cand_qat[CAND_QUEUES] = {};
         // row -> queue(s) and the row's place in the queue: heaviest row first to the least loaded queue (the rows are a few hundred); a row that outweighs
@@ -2071,6 +2087,14 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                 ++f.hist[f.keys[i] = SCHED_RANK[tk.kind] * SCHED_NB + (opt.planes_order == 2 ? std::min(minrow, per - 1) * 4 + std::min(ord, 3u) : std::min(ord, 3u) * per + std::min(minrow, per - 1))];
                                 continue;
                         }
+                        if (tk.kind == TASK_PSET && opt.pset_order) {
+                                // (option pset_order: k_psets' tasks range by range, within a range by the query's heaviest term — the tasks in flight read ITS words of
+                                //  the range one after the other, the second reader on from L2)
+                                const uint32_t range = (uint32_t)(f.tcost[i] & 0xffffffffull) / PSET_TASK_WINDOWS;
+                                const uint32_t rb = pset_ranges <= PSET_RANGE_BKS ? std::min(range, PSET_RANGE_BKS - 1) : (uint32_t)std::min<uint64_t>((uint64_t)range * PSET_RANGE_BKS / pset_ranges, PSET_RANGE_BKS - 1);
+                                ++f.hist[f.keys[i] = PSET_KEY0 + rb * PSET_SUBS + pset_sub((uint32_t)(f.tcost[i] >> 32))];
+                                continue;
+                        }
                         if (tk.kind != TASK_CAND || !cand_rows) {
                                 ++f.hist[f.keys[i] = sched_key(tk.kind, f.tcost[i])];
                                 continue;
@@ -2119,8 +2143,11 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                         };
                         for (uint32_t bk = r * SCHED_NB; bk < (r + 1) * SCHED_NB; ++bk)
                                 place(bk);
+                        if (r == SCHED_RANK[TASK_PSET] && opt.pset_order) // (k_psets' tasks by range and heaviest term)
+                                for (uint32_t bk = PSET_KEY0; bk < PSET_KEY0 + std::min(pset_ranges, PSET_RANGE_BKS) * PSET_SUBS; ++bk)
+                                        place(bk);
                         if (r == SCHED_RANK[TASK_CAND]) // (a `cand_rows` batch: k_and's tasks are all in the row buckets)
-                                for (uint32_t bk = CAND_KEY0; bk < SCHED_KEYS; ++bk) {
+                                for (uint32_t bk = CAND_KEY0; bk < PSET_KEY0; ++bk) {
                                         if ((bk - CAND_KEY0) % CAND_SUBS == 0)
                                                 cand_qat[(bk - CAND_KEY0) / CAND_SUBS] = at;
                                         place(bk);
