@@ -546,13 +546,8 @@ __device__ __forceinline__ void dense_block_coop(const uint8_t *__restrict__ ind
                 return;
         }
         const bool is_start = (starts >> lane) & 1ull;
-        uint32_t x = is_start ? v : 0u;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(x, d, 64);
-                if ((int)lane >= d)
-                        x += y;
-        }
+        uint32_t x = is_start ? v : 0u, wtot;
+        x += wave_excl_scan(x, wtot); // (inclusive: six DPP adds)
         if (is_start)
                 dense_visit_clamped(bm, prev - w0 + x, wbase);
         if (lane == 0)
