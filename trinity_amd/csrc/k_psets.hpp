@@ -46,113 +46,12 @@ static_assert(PSET_WORDS * 32 == PSET_ROUND_DOCS && PSET_STAGE == PSET_STAGE_DOC
 static_assert(SPAN_WORDS == PSET_WAVES * PSET_WORDS, "a wave's share of a task: one sub-window of PSET_WORDS words per docID window");
 static_assert(PSET_STAGE >= PSET_WORDS, "the dense walk parks the wave's words in its staging buffer");
 
-struct PsetScatterShared { // (part of PsetShared)
-        DevTerm term[MAX_QTERMS]; // the union's terms without a plane ...
-        uint32_t b_lo[MAX_QTERMS], nrows[MAX_QTERMS]; // ... their rows that can reach the task's range
-};
 struct PsetShared {
         uint32_t stage[PSET_WAVES][PSET_STAGE];
         alignas(16) uint32_t cnt[2][PSET_WAVES]; // per window parity: the waves' survivor counts (psets_pair reads a parity's eight as two 16-byte words)
-        PsetScatterShared scatter;   // PSET_UNIT_SCATTER tasks: the terms without a plane
         DevPsetUnit unit[2];         // the task being run and the next one (fetched while the current one runs)
         uint32_t tick[2];            // ... and their tickets (>= ntasks: none)
 };
-
-// ---- PSET_UNIT_SCATTER: a union's terms WITHOUT a plane, after the plane terms' words of the task's windows have been stored: every row of such a
-//      term that can reach the task's docID range is decoded, one lane per row of <= 32 documents (the register row readers of k_fused), and its
-//      documents are set in the stored words one by one — an atomic OR whose old value says whether the document is new to the union (the count).
-//      A rare term brings a handful of documents per task; k_and_dense decoded every list of such a query into an LDS window bitmap, window by
-//      window, behind half a dozen barriers each.  Not inlined: the row readers' registers must not weigh on the windows' loop.
-struct PsetScatterPost {
-        uint32_t *bm;               // the task's words (bit 0 of word 0: the task's first document)
-        const uint32_t *masked;     // masked documents (absolute docIDs), or nullptr
-        uint32_t doc0, nbits, added = 0;
-        __device__ __forceinline__ void doc(const uint32_t rel) {
-                if (rel >= nbits) // (a row reaches across the range's ends: the neighbouring tasks take those documents)
-                        return;
-                const uint32_t d = doc0 + rel, bit = 1u << (rel & 31u);
-                if (masked && ((masked[d >> 5] >> (d & 31u)) & 1u))
-                        return;
-                added += (atomicOr(&bm[rel >> 5], bit) & bit) ? 0u : 1u;
-        }
-        __device__ __forceinline__ void operator()(const uint32_t rel, const uint32_t) { doc(rel); }
-};
-template <int CODEC>
-__device__ __noinline__ uint32_t psets_scatter(PsetScatterShared &ss, const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
-                                               const uint4 *__restrict__ blk_rec, const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win,
-                                               const DevTerm *__restrict__ terms, const uint32_t *__restrict__ qterms, const uint32_t *__restrict__ qplane, const uint32_t nterms,
-                                               const uint32_t w_begin, const uint32_t w_end, uint32_t *__restrict__ bm, const uint32_t *__restrict__ masked) {
-        const uint32_t tid = threadIdx.x;
-        const uint32_t d0 = w_begin * SPAN_BITS, d1 = w_end * SPAN_BITS; // (the planner keeps max docID below 2^31: no wrap)
-        // lane k looks after term k: its record and its rows that can hold documents of [d0, d1) — first row whose last docID >= d0 ... first row
-        // whose last docID >= d1 (it may still begin inside) — all the terms side by side: one chain of dependent loads for the task, not one per term
-        if (tid < MAX_QTERMS) {
-                uint32_t lo_b = 0, n = 0;
-                if (tid < nterms && qplane[tid] == PL_NONE) {
-                        const DevTerm t = terms[qterms[tid] & QT_TERM];
-                        ss.term[tid] = t;
-                        if (t.nblocks) {
-                                const uint32_t *bl = blk_last + t.first_block;
-                                uint32_t b_lo, b_hi;
-                                if (t.win_off != 0xffffffffu) {
-                                        b_lo = win[t.win_off + w_begin * CELLS_PER_SPAN];
-                                        b_hi = win[t.win_off + w_end * CELLS_PER_SPAN];
-                                } else {
-                                        uint32_t lo = 0, hi = t.nblocks;
-                                        while (lo < hi) {
-                                                const uint32_t mid = (lo + hi) >> 1;
-                                                if (bl[mid] < d0)
-                                                        lo = mid + 1;
-                                                else
-                                                        hi = mid;
-                                        }
-                                        b_lo = lo;
-                                        hi = t.nblocks;
-                                        while (lo < hi) {
-                                                const uint32_t mid = (lo + hi) >> 1;
-                                                if (bl[mid] < d1)
-                                                        lo = mid + 1;
-                                                else
-                                                        hi = mid;
-                                        }
-                                        b_hi = lo;
-                                }
-                                b_hi = min(b_hi, t.nblocks - 1);
-                                lo_b = b_lo;
-                                n = b_lo < t.nblocks ? b_hi - b_lo + 1 : 0u;
-                        }
-                }
-                ss.b_lo[tid] = lo_b;
-                ss.nrows[tid] = n;
-        }
-        __syncthreads();
-        uint32_t total = 0;
-        for (uint32_t k = 0; k < nterms; ++k)
-                total += uni(ss.nrows[k]);
-        PsetScatterPost post{bm, masked, d0, d1 - d0};
-        for (uint32_t v = tid; v < total; v += PSET_WG) { // one lane per row, the terms' rows one after the other
-                uint32_t k = 0, r = v;
-                for (; r >= ss.nrows[k]; ++k)
-                        r -= ss.nrows[k];
-                const DevTerm t = ss.term[k];
-                const uint32_t b = ss.b_lo[k] + r;
-                const uint32_t *bl = blk_last + t.first_block;
-                const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
-#ifdef TRI_PROF
-                ProfClock prof_;
-#endif
-                if (CODEC == CODEC_LUCENE) {
-                        const uint4 rec = blk_rec[t.first_block + b];
-                        row_decode<CODEC, false, PsetScatterPost>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, d0, post PROF_PASS);
-                } else {
-                        const uint32_t off = blk_off[t.first_block + b];
-                        const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
-                        row_decode<CODEC, false, PsetScatterPost>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, d0, post PROF_PASS);
-                }
-        }
-        __syncthreads(); // (ss is the next task's, too)
-        return post.added;
-}
 
 // ---- a task's windows -> its output region.  `words(word0, acc)` gives the lane's eight survivor words at word0 (the pair loop and the general loop of the kernel below).
 //      Round 6, in two steps:
@@ -334,9 +233,8 @@ template <int CODEC>
 __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPsetUnit *__restrict__ units, const uint32_t *__restrict__ order, const uint32_t ntasks,
                                                                    uint32_t *__restrict__ ticket, const uint32_t *__restrict__ qterms, const uint32_t *__restrict__ qplane,
                                                                    uint32_t *__restrict__ out, uint32_t *__restrict__ counts, const uint32_t *__restrict__ masked,
-                                                                   const uint32_t *__restrict__ planes, const uint32_t plw, const uint8_t *__restrict__ index,
-                                                                   const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off, const uint4 *__restrict__ blk_rec,
-                                                                   const uint32_t *__restrict__ blk_doff, const uint32_t *__restrict__ win, const DevTerm *__restrict__ terms) {
+                                                                   const uint32_t *__restrict__ planes, const uint32_t plw, const uint32_t *__restrict__ scat_off,
+                                                                   const uint32_t *__restrict__ scat_cnt, const uint32_t *__restrict__ scat_docs) {
         __shared__ PsetShared sh;
         const uint32_t tid = threadIdx.x, lane = tid & 63u;
         const uint32_t wave = uni(tid >> 6);
@@ -370,6 +268,9 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                         nnt = atomicAdd(ticket, 1u);
                 }
                 uint32_t produced = 0;
+                uint32_t scat_at = 0, scat_n = 0; // (a PSET_UNIT_SCATTER task's slice of the scatter list: asked for now, needed when the windows are through)
+                if (uni(U.first) & PSET_UNIT_SCATTER)
+                        scat_at = uni(scat_off[tix]), scat_n = uni(scat_cnt[tix]);
                 const uint32_t round_win = std::max(1u, (uni(U.first) >> PSET_UNIT_ROUND_SHIFT) & PSET_UNIT_ROUND_MASK); // windows per round: the waves' counts cross once a round
                 const uint32_t pair_row0 = uni(U.row[0]), pair_row1 = uni(U.row[1]), pair_tt1 = uni(U.tt[1]);
                 if (nterms == 2 && pair_row0 != PL_NONE && pair_row1 != PL_NONE) {
@@ -459,8 +360,14 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                             },
                             w_begin, wb, min(w_end, wb + round_win), as_bitmap ? qout : qout + produced, as_bitmap, lane, wave, par);
                 if (uni(U.first) & PSET_UNIT_SCATTER) { // (uniform)
-                        __syncthreads(); // the task's words are stored: the documents of the terms without a plane go in on top of them
-                        produced += psets_scatter<CODEC>(sh.scatter, index, blk_last, blk_off, blk_rec, blk_doff, win, terms, qterms + term_base, qplane + term_base, nterms, w_begin, w_end, qout, masked);
+                        // a union some of whose terms have NO plane: their documents of this task's windows — k_psets_prep listed them, task by task — go into the words
+                        // just stored (still in L2), one atomic OR each; its old value says whether the document is new to the union (the count)
+                        __syncthreads(); // (the task's words are stored)
+                        const uint32_t off = scat_at, n = scat_n, doc0 = w_begin * SPAN_BITS;
+                        for (uint32_t i = tid; i < n; i += PSET_WG) {
+                                const uint32_t rel = scat_docs[off + i] - doc0, bit = 1u << (rel & 31u);
+                                produced += (atomicOr(&qout[rel >> 5], bit) & bit) ? 0u : 1u; // (per lane: as_bitmap's reduction below adds the lanes up)
+                        }
                 }
                 if (as_bitmap) { // the lanes' counts -> the task's (uniform branch: the record is the workgroup's)
 #pragma unroll
@@ -483,6 +390,122 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
                 }
                 // (the record's barrier stands here, in the block of the LDS stores above, not at the loop's head: reached over the loop's back
                 //  edge the compiler put no s_waitcnt lgkmcnt(0) between the stores and the s_barrier — see k_and)
+                __syncthreads();
+        }
+}
+
+// ---- PSET_UNIT_SCATTER, before k_psets runs: the documents of a union's terms WITHOUT a plane, listed task by task (k_psets_prep).  One workgroup per query (grid: one per
+//      unit of units[]; the one of a scatter query's FIRST task takes the query, the others leave at once): lane k looks after term k (all the terms' records side by side),
+//      then a lane per directory row of <= 32 documents (the register row readers of k_fused) — counted per task in LDS, the tasks' places settled by one scan and one
+//      draw from the batch's cursor, then decoded once more into their places.  scat_off[tix] / scat_cnt[tix]: a task's slice of scat_docs[].
+//      Until round 6 every TASK of such a query did the lookups for its own docID range inside k_psets, between two barriers: a rare term's two or three rows each span
+//      millions of docIDs, so each of the query's twenty tasks went term record -> block directory -> block bytes (five dependent round trips, one lane in 512 working),
+//      decoded the straddling row and kept next to nothing of it — 0.39 of k_psets' 0.96 ms for cfg5's five-way unions, for 0.06 % of their matches.
+constexpr int PSCAT_WG = 256;
+constexpr uint32_t PSCAT_MAX_TASKS = 4096; // tasks of a query: 2^31 documents / (PSET_TASK_WINDOWS windows of 2^17)
+static_assert((1ull << 31) / ((uint64_t)PSET_TASK_WINDOWS * SPAN_BITS) <= PSCAT_MAX_TASKS, "a query's tasks fit the workgroup's LDS counters");
+struct PscatShared {
+        DevTerm term[MAX_QTERMS];   // the union's terms without a plane ...
+        uint32_t nrows[MAX_QTERMS]; // ... and their rows (0: the term has a plane)
+        uint32_t cnt[PSCAT_MAX_TASKS]; // documents per task, then (second pass) the task's cursor into scat_docs[]
+        uint32_t red[PSCAT_WG / 64 + 1];
+};
+struct PscatPost { // pass 1 (place == nullptr): count per task; pass 2: into the task's place
+        uint32_t *cnt;
+        const uint32_t *masked;
+        uint32_t *place;
+        uint32_t nbits, task_docs, cap;
+        __device__ __forceinline__ void doc(const uint32_t d) {
+                if (d >= nbits || (masked && ((masked[d >> 5] >> (d & 31u)) & 1u))) // masked_documents_registry::test (docidupdates.h:90-119)
+                        return;
+                const uint32_t at = atomicAdd(&cnt[d / task_docs], 1u);
+                if (place && at < cap) // (a task that did not fit the list — the planner's bound holds: belt and braces — has its cursor at cap)
+                        place[at] = d;
+        }
+        __device__ __forceinline__ void operator()(const uint32_t d, const uint32_t) { doc(d); }
+};
+template <int CODEC>
+__global__ __launch_bounds__(PSCAT_WG) void k_psets_prep(const DevPsetUnit *__restrict__ units, const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
+                                                         const uint32_t *__restrict__ qterms, const uint32_t *__restrict__ qplane, const uint32_t *__restrict__ masked,
+                                                         const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
+                                                         const uint4 *__restrict__ blk_rec, const uint32_t *__restrict__ blk_doff, const DevTerm *__restrict__ terms,
+                                                         uint32_t *__restrict__ cursor, uint32_t *__restrict__ scat_off, uint32_t *__restrict__ scat_cnt,
+                                                         uint32_t *__restrict__ scat_docs, const uint32_t scat_cap) {
+        __shared__ PscatShared sh;
+        const uint32_t tid = threadIdx.x;
+        const DevPsetUnit &U = units[blockIdx.x];
+        if (!(uni(U.first) & PSET_UNIT_SCATTER) || uni(U.w_begin) != 0)
+                return;
+        const uint32_t nterms = uni(U.nterms), term_base = uni(U.term_base), tix = uni(U.tix);
+        if (tid < MAX_QTERMS) {
+                uint32_t n = 0;
+                if (tid < nterms && qplane[term_base + tid] == PL_NONE) {
+                        const DevTerm t = terms[qterms[term_base + tid] & QT_TERM];
+                        sh.term[tid] = t;
+                        n = t.nblocks;
+                }
+                sh.nrows[tid] = n;
+        }
+        const DevQuery &q = plan[uni(tasks[tix].slot)];
+        const uint32_t ntasks = min(uni(q.ntasks), PSCAT_MAX_TASKS), nbits = uni(q.out_cap) * 32u, task_docs = (uni(U.w_end) - uni(U.w_begin)) * SPAN_BITS;
+        for (uint32_t t = tid; t < ntasks; t += PSCAT_WG)
+                sh.cnt[t] = 0;
+        __syncthreads();
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < nterms; ++k)
+                total += uni(sh.nrows[k]);
+        for (uint32_t pass = 0; pass < 2; ++pass) {
+                PscatPost post{sh.cnt, masked, pass ? scat_docs : nullptr, nbits, task_docs, scat_cap};
+                for (uint32_t v = tid; v < total; v += PSCAT_WG) { // one lane per row, the terms' rows one after the other
+                        uint32_t k = 0, b = v;
+                        for (; b >= sh.nrows[k]; ++k)
+                                b -= sh.nrows[k];
+                        const DevTerm t = sh.term[k];
+                        const uint32_t *bl = blk_last + t.first_block;
+                        const uint32_t prev = b ? bl[b - 1] : 0, last = bl[b];
+#ifdef TRI_PROF
+                        ProfClock prof_;
+#endif
+                        if (CODEC == CODEC_LUCENE) {
+                                const uint4 rec = blk_rec[t.first_block + b];
+                                row_decode<CODEC, false, PscatPost>(index, t, b, rec.x, rec.y, rec.z, rec.w, TRI_BLOCK_N(t, b, index, 0), prev, last, 0u, post PROF_PASS);
+                        } else {
+                                const uint32_t off = blk_off[t.first_block + b];
+                                const uint32_t dlen = blk_doff[t.first_block + b + 1] - blk_doff[t.first_block + b] - 1u;
+                                row_decode<CODEC, false, PscatPost>(index, t, b, off, dlen, 0, 0, TRI_BLOCK_N(t, b, index, off), prev, last, 0u, post PROF_PASS);
+                        }
+                }
+                __syncthreads();
+                if (pass)
+                        break;
+                // ---- the tasks' places: an exclusive prefix over cnt[0 .. ntasks) — every thread a stretch of it —, based at one draw from the batch's cursor
+                const uint32_t per = (ntasks + PSCAT_WG - 1) / PSCAT_WG, t0 = tid * per, t1 = min(ntasks, t0 + per);
+                uint32_t mine = 0;
+                for (uint32_t t = t0; t < t1; ++t)
+                        mine += sh.cnt[t];
+                uint32_t wtot;
+                uint32_t ex = wave_excl_scan(mine, wtot);
+                if ((tid & 63u) == 0)
+                        sh.red[tid >> 6] = wtot;
+                __syncthreads();
+                uint32_t before = 0, all = 0;
+                for (uint32_t w = 0; w < PSCAT_WG / 64; ++w) {
+                        before += w < (tid >> 6) ? sh.red[w] : 0u;
+                        all += sh.red[w];
+                }
+                if (tid == 0)
+                        sh.red[PSCAT_WG / 64] = atomicAdd(cursor, all);
+                __syncthreads();
+                const uint32_t base = uni(sh.red[PSCAT_WG / 64]);
+                uint32_t at = base + before + ex;
+                for (uint32_t t = t0; t < t1; ++t) {
+                        const uint32_t c = sh.cnt[t];
+                        const bool fits = at + c <= scat_cap; // (the planner's bound holds: belt and braces against a store outside the list)
+                        scat_off[tix + t] = fits ? at : 0u;
+                        scat_cnt[tix + t] = fits ? c : 0u;
+                        sh.cnt[t] = fits ? at : scat_cap; // the task's cursor (a task that does not fit: the second pass stores nothing for it)
+                        at += c;
+                }
                 __syncthreads();
         }
 }

@@ -136,6 +136,8 @@ struct BatchPlan {
         uint32_t n_tree = 0;        // TASK_TREE tasks (the last section of sched)
         uint64_t tree_queries = 0, tree_scratch_bytes = 0;
         uint64_t bitmap_queries = 0; // queries whose docID set is delivered as a bitmap (RESULT_BITMAP)
+        uint64_t pscatter_queries = 0, pscatter_docs = 0; // ... of them the unions k_psets runs although some of their terms have no plane (PSET_UNIT_SCATTER), and those terms'
+                                                          // documents over all such queries: the slots k_psets_prep lists them in, task by task
         size_t off_plan = 0, off_qterms = 0, off_tasks = 0, off_sched = 0, off_fused = 0, off_qplane = 0, off_plane_terms = 0, off_sterms = 0, off_sweights = 0,
                off_phrases = 0, off_pterms = 0, off_ptasks = 0;
         std::vector<uint32_t> slot_of_query; // caller query -> plan slot (UINT32_MAX: can never match)
@@ -511,7 +513,7 @@ namespace trip {
                 std::vector<uint32_t> treepool;   // TASK_TREE records (DevQuery::fused_idx: a record's first word)
                 std::vector<uint32_t> tree_terms; // the term leaves of the fragment's TASK_TREE queries
                 uint32_t n_hidden = 0;            // hidden phrase queries (Tmp::hidden_ord)
-                uint64_t tree_queries = 0, bitmap_queries = 0;
+                uint64_t tree_queries = 0, bitmap_queries = 0, pscatter_queries = 0, pscatter_docs = 0;
                 uint64_t off = 0;
                 uint32_t sparse_cap = 0;
                 uint64_t term_bytes_dense = 0, term_bytes_fused = 0, term_bytes_planes = 0, cand_needed = 0;
@@ -1600,6 +1602,7 @@ namespace trip {
                                 }
                                 t.q.out_cap = bitmap ? nwin * SPAN_WORDS : (uint32_t)std::min<uint64_t>(0xffffffffull, lead_blocks * 32 + 32ull * (ord + 1) * nlead);
                                 f.bitmap_queries += bitmap;
+                                f.pscatter_queries += pscatter;
                         } else {
                                 const uint32_t ntiles = (lead.nblocks + TILE_BLOCKS - 1) / TILE_BLOCKS;
                                 const uint64_t per_tile = std::max<uint64_t>(1, t.cost / ntiles);
@@ -1808,6 +1811,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 tree_terms.insert(tree_terms.end(), f.tree_terms.begin(), f.tree_terms.end());
                 P.tree_queries += f.tree_queries;
                 P.bitmap_queries += f.bitmap_queries;
+                P.pscatter_queries += f.pscatter_queries;
                 n_plan += f.tmp.size(), n_qterms += f.qterms.size(), n_sterms += f.sterms.size(), n_phrases += f.phrases.size(), n_pterms += f.pterms.size(),
                         n_tasks += f.tasks.size(), n_fused += f.fused.size(), n_ptasks += f.ptasks.size(), off += f.off;
                 P.term_bytes += f.term_bytes, P.term_bytes_phrase_hits += f.term_bytes_phrase_hits, P.term_bytes_dense += f.term_bytes_dense,
@@ -2043,6 +2047,8 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                                 rows &= row != PL_NONE;
                                 if (k < PSET_INLINE_TERMS)
                                         u.row[k] = row;
+                                if (row == PL_NONE && (u.first & PSET_UNIT_SCATTER) && u.w_begin == 0) // (a scatter union's first task: the documents k_psets_prep lists for the query)
+                                        f.pscatter_docs += ix.terms[term].documents;
                         }
                         if (is_probe && !rows) { // a probed list did not get its plane (the batch's uses do not repay its decode): candidate tiles after all
                                 P.tasks[u.tix].kind = TASK_CAND;
@@ -2119,6 +2125,7 @@ inline int plan_batch(const HostIndex &ix, const PlanEnv &env, const PlanInput &
                 }
         });
         for (const Frag &f : frags) { // (what the fill pass sent back to the candidate tiles)
+                P.pscatter_docs += f.pscatter_docs;
                 P.probe_queries -= f.probe_demoted, P.cand_queries += f.probe_demoted;
                 P.term_bytes_probe -= f.probe_demoted_bytes;
         }

@@ -102,6 +102,7 @@ struct tri_dev {
         std::recursive_mutex mu;
 };
 using DevLock = std::lock_guard<std::recursive_mutex>;
+constexpr size_t TICKET_SCAT_WORD = 44;        // ... k_psets_prep's cursor into the batch's scatter list
 constexpr size_t TICKET_CAND_WORD = 64;        // a batch's ticket words: [0, 64) one per kernel; then k_and's CAND_QUEUES, 64 bytes apart
 constexpr size_t TICKET_BYTES = (TICKET_CAND_WORD + CAND_QUEUES * CAND_TICKET_STRIDE) * 4;
 constexpr size_t POOL_MIN_BYTES = 64u << 10;  // smaller buffers are not worth pooling
@@ -365,6 +366,8 @@ struct tri_batch : BatchPlan {
         // [a match bitmap per tree query][per query and chunk: matches][(term, row) pairs for k_term_planes]
         uint32_t *d_tree_scratch = nullptr, *d_tree_rows = nullptr, *d_tree_prows = nullptr, *d_tree_qbits = nullptr, *d_tree_cc = nullptr, *d_tree_build = nullptr;
         double *d_tree_scores = nullptr; // scored top-K batches: the tree queries' score stream (topk == 0: d_all_scores holds it)
+        uint32_t *d_scat_off = nullptr, *d_scat_cnt = nullptr, *d_scat_docs = nullptr; // PSET_UNIT_SCATTER unions: per task its slice of the list k_psets_prep makes (k_psets.hpp)
+        uint32_t scat_cap = 0;
         bool ran = false;
         bool planes_hi = false; // the batch reads the HIGH parts of its plane rows (k_planes, k_score's level words): its run builds them where they are missing
         uint32_t *d_qterms = nullptr;
@@ -430,6 +433,7 @@ struct tri_batch : BatchPlan {
                 pool_free(dev, d_pscore);
                 pool_free(dev, d_tree_scratch);
                 pool_free(dev, d_tree_scores);
+                pool_free(dev, d_scat_docs);
                 dev_release(dev);
         }
 };
@@ -847,6 +851,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         const size_t a_qthr = planes_tasks ? carve((np + 1) * 8) : 0;
         const size_t a_part_counts = scored ? carve((nt + 1) * 4) : 0;
         const size_t a_task_hits = rich ? carve((nt + 1) * 4) : 0, a_task_pos = rich ? carve((nt + 1) * 8) : 0;
+        const size_t a_scat_off = b->pscatter_queries ? carve((nt + 1) * 4) : 0, a_scat_cnt = b->pscatter_queries ? carve((nt + 1) * 4) : 0;
         const size_t a_zero = a;
         const size_t a_qcounts = carve((nq + 1) * 8); // queries that can never match keep count 0 ...
         const size_t a_top_counts = scored ? carve((nq + 1) * 4) : 0;
@@ -871,6 +876,14 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->d_build = (uint32_t *)(A + a_build);
         b->d_qthr = planes_tasks ? (unsigned long long *)(A + a_qthr) : nullptr;
         b->d_part_counts = scored ? (uint32_t *)(A + a_part_counts) : nullptr;
+        b->d_scat_off = b->pscatter_queries ? (uint32_t *)(A + a_scat_off) : nullptr;
+        b->d_scat_cnt = b->pscatter_queries ? (uint32_t *)(A + a_scat_cnt) : nullptr;
+        if (b->pscatter_queries) {
+                if (b->pscatter_docs + 64 > 0xffffffffull)
+                        return fail(TRI_ERR_UNSUPPORTED, "tri_batch_create: the unions' terms without a plane hold more than 2^32 documents");
+                b->scat_cap = (uint32_t)b->pscatter_docs;
+                HIP_TRY(pool_alloc(dev, (void **)&b->d_scat_docs, ((size_t)b->scat_cap + 64) * 4));
+        }
         b->d_task_hits = rich ? (uint32_t *)(A + a_task_hits) : nullptr;
         b->d_task_pos_base = rich ? (uint64_t *)(A + a_task_pos) : nullptr;
         b->d_qcounts = (uint64_t *)(A + a_qcounts);
@@ -1162,6 +1175,21 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipStreamWaitEvent(dev->stream2, dev->ev_fork, 0));
                         cand_stream = dev->stream2;
                 }
+                // unions with terms that have no plane (PSET_UNIT_SCATTER): those terms' documents listed task by task, a workgroup per query (units[] holds the TASK_PROBE units
+                // too) — on the second stream, beside k_and_dense, where that stream is not k_and's (option overlap)
+                const bool prep = b->n_pset && b->pscatter_queries, prep_forked = prep && !overlap && b->n_dense;
+                if (prep) {
+                        if (prep_forked) {
+                                HIP_TRY(hipEventRecord(dev->ev_fork, dev->stream));
+                                HIP_TRY(hipStreamWaitEvent(dev->stream2, dev->ev_fork, 0));
+                        }
+                        TRI_LAUNCH(k_psets_prep, b->ix->codec, dim3(b->n_pset + b->n_probe), dim3(PSCAT_WG), prep_forked ? dev->stream2 : dev->stream, (const DevPsetUnit *)(b->d_arena + b->off_units),
+                                   b->d_plan, b->d_tasks, (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->ix->d_masked, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off,
+                                   b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_terms, b->d_ticket + TICKET_SCAT_WORD, b->d_scat_off, b->d_scat_cnt, b->d_scat_docs, b->scat_cap);
+                        HIP_TRY(hipGetLastError());
+                        if (prep_forked)
+                                HIP_TRY(hipEventRecord(dev->ev_join, dev->stream2));
+                }
                 if (b->n_dense) {
                         TRI_LAUNCH(k_and_dense, b->ix->codec, dim3(std::min<uint32_t>(b->n_dense, (uint32_t)dev->cus * dense_wgs)), dim3(DENSE_WG), dev->stream, match_bytes,
                                            b->ix->d_blk_last, match_off, b->ix->d_win, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_qterms, b->n_dense,
@@ -1169,12 +1197,14 @@ extern "C" int tri_batch_run(tri_batch *b) {
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_a, dev->stream));
+                if (prep_forked) // (k_psets reads the lists k_psets_prep made beside k_and_dense)
+                        HIP_TRY(hipStreamWaitEvent(dev->stream, dev->ev_join, 0));
                 if (b->n_pset) {
                         // the queries all of whose terms have planes: word-wise algebra over the planes + expansion (k_psets.hpp)
                         TRI_LAUNCH(k_psets, b->ix->codec, dim3(std::min<uint32_t>(b->n_pset, (uint32_t)dev->cus * (overlap && dev->opt.overlap_dense_wgs ? std::min<uint32_t>(dense_wgs, TRI_PSET_WAVES * 256 / PSET_WG) : TRI_PSET_WAVES * 256 / PSET_WG))), dim3(PSET_WG), dev->stream,
                                    (const DevPsetUnit *)(b->d_arena + b->off_units), (const uint32_t *)(b->d_arena + b->off_pset_sched), b->n_pset, b->d_ticket + 20,
                                    (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->d_out, b->d_counts, b->ix->d_masked, (const uint32_t *)b->ix->d_pcache, b->plw,
-                                   b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_win, b->ix->d_terms);
+                                   (const uint32_t *)b->d_scat_off, (const uint32_t *)b->d_scat_cnt, (const uint32_t *)b->d_scat_docs);
                         HIP_TRY(hipGetLastError());
                 }
                 HIP_TRY(hipEventRecord(b->ev_s, dev->stream));
