@@ -450,6 +450,43 @@ def test_union_of_head_terms_large(large):
 
 
 @pytest.mark.parametrize("world", ["large", "medium_l"])
+def test_scatter_unions_list_their_rare_terms_once(request, world):
+    """PSET_UNIT_SCATTER (k_psets.hpp): a DocumentsOnly union of head terms with terms that have NO plane — k_psets_prep lists those terms' documents once per
+    query, task by task (count, scan, place), and every task of k_psets ORs its slice into the words it has just stored.  Terms of a few rows and of hundreds,
+    the same rare term in several queries, a batch run twice (the list's cursor restarts), masked documents, a plane threshold that leaves most terms without a
+    plane — every set against the oracle, counts and hashes included."""
+    w = request.getfixturevalue(world)
+    T, V = w.T, w.V
+    mid = [t for t in (V // 400, V // 100, V // 40, V // 10, V // 3, V - 1) if w.df(t)]
+    texts = [f"t0 OR t{mid[0]} OR t{mid[1]}", "t1 OR t2 OR " + " OR ".join(f"t{t}" for t in mid[2:5]), f"t3 OR t{mid[-1]}", f"t0 OR t1 OR t{mid[0]} OR t{mid[-1]} OR t{mid[2]}",
+             "t2 OR " + " OR ".join(f"t{t}" for t in mid), f"t4 OR t5 OR t{mid[1]}"]  # fmt: skip
+    progs = [O.parse_query(t) for t in texts]
+    masked = np.array(sorted(set(np.random.default_rng(11).integers(1, w.D, w.D // 13).tolist())), dtype=np.uint32)
+    try:
+        for mk in (None, masked):
+            if mk is not None:
+                w.ix.set_masked(mk)
+                w.ora.set_masked(mk)
+            want = [w.ora.exec(p, O.FLAG_DOCUMENTS_ONLY)[0] for p in progs]
+            for opts in ({}, {"dense_min_postings": 0}, {"plane_div": 64}, {"plane_div": 64, "plane_amortize": 1000}):
+                with options(w.dev, **opts):
+                    b = T.Batch(w.ix, progs, T.FLAG_DOCUMENTS_ONLY)
+                for rep in range(2):
+                    b.run()
+                    b.sync()
+                    counts, hashes = b.counts(), b.docset_hashes()
+                    for i, t in enumerate(texts):
+                        assert int(counts[i]) == len(want[i]) and int(hashes[i]) == O.fnv1a_docs(want[i]), (opts, rep, t, int(counts[i]), len(want[i]))
+                        assert np.array_equal(b.docset(i, len(want[i])), want[i]), (opts, rep, t)
+                if not opts and mk is None:
+                    assert b.info()["pset_queries"] >= 1, b.info()  # (the default options send head-term unions with rare terms through k_psets)
+                b.close()
+    finally:
+        w.ix.set_masked(np.zeros(0, np.uint32))
+        w.ora.set_masked(np.zeros(0, np.uint32))
+
+
+@pytest.mark.parametrize("world", ["large", "medium_l"])
 def test_docsets_in_one_call(request, world):
     """tri_batch_docsets: every query's ascending docID set, queries in the caller's order, one device-side gather + one copy — conjunctions cut
     into many candidate-tile tasks, unions, phrases, NOT, a general tree and an empty result in one batch, also into a caller's buffer
