@@ -148,6 +148,36 @@ struct ScoreShared {
 };
 
 
+// ---- the order k_score runs its tasks in: heaviest first, by their MATCH counts — which only the device knows, once the matching kernels are through.  In the schedule's
+//      order (k_and's: by the plane row a task probes) cfg3's 6 209 tasks — half of them without a match, a fifth of them 77 % of the work — kept 68 % of the
+//      workgroups busy: 200 us tasks started 250 us into a 463 us span, the last tenth of it ran on 14 workgroups of 512 (per-task stamps, -DTRI_TASKTIMES=2).  One
+//      workgroup, a counting sort by the count's octave, descending (any order within an octave).
+constexpr int SORD_WG = 1024;
+__global__ __launch_bounds__(SORD_WG) void k_score_order(const uint32_t *__restrict__ sched, const uint32_t *__restrict__ counts, const uint32_t n, uint32_t *__restrict__ order) {
+        __shared__ uint32_t hist[33], cur[33];
+        const uint32_t tid = threadIdx.x;
+        if (tid < 33)
+                hist[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += SORD_WG) {
+                const uint32_t m = counts[sched[i]];
+                atomicAdd(&hist[m ? 32u - (uint32_t)__clz(m) : 0u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+                uint32_t at = 0;
+                for (uint32_t b = 33; b-- > 0;) {
+                        cur[b] = at;
+                        at += hist[b];
+                }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += SORD_WG) {
+                const uint32_t tix = sched[i], m = counts[tix];
+                order[atomicAdd(&cur[m ? 32u - (uint32_t)__clz(m) : 0u], 1u)] = tix;
+        }
+}
+
 constexpr uint32_t SCORE_WGS_PER_CU = (160u * 1024u / sizeof(ScoreShared)) < 6u ? (160u * 1024u / sizeof(ScoreShared)) : 6u; // LDS; ~80-110 registers
 
 template <int CODEC>

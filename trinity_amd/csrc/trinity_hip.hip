@@ -366,6 +366,7 @@ struct tri_batch : BatchPlan {
         // [a match bitmap per tree query][per query and chunk: matches][(term, row) pairs for k_term_planes]
         uint32_t *d_tree_scratch = nullptr, *d_tree_rows = nullptr, *d_tree_prows = nullptr, *d_tree_qbits = nullptr, *d_tree_cc = nullptr, *d_tree_build = nullptr;
         double *d_tree_scores = nullptr; // scored top-K batches: the tree queries' score stream (topk == 0: d_all_scores holds it)
+        uint32_t *d_score_order = nullptr; // AccumulatedScore: the tasks k_score runs, heaviest first by their match counts (k_score_order)
         uint32_t *d_scat_off = nullptr, *d_scat_cnt = nullptr, *d_scat_docs = nullptr; // PSET_UNIT_SCATTER unions: per task its slice of the list k_psets_prep makes (k_psets.hpp)
         uint32_t scat_cap = 0;
         bool ran = false;
@@ -849,7 +850,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         const size_t a_counts = carve((nt + 1) * 4), a_ticket = carve(TICKET_BYTES), a_build = carve((b->plane_terms.size() + 1) * 8);
         const bool planes_tasks = b->n_planes + b->n_planes8;
         const size_t a_qthr = planes_tasks ? carve((np + 1) * 8) : 0;
-        const size_t a_part_counts = scored ? carve((nt + 1) * 4) : 0;
+        const size_t a_part_counts = scored ? carve((nt + 1) * 4) : 0, a_score_order = scored ? carve((nt + 1) * 4) : 0;
         const size_t a_task_hits = rich ? carve((nt + 1) * 4) : 0, a_task_pos = rich ? carve((nt + 1) * 8) : 0;
         const size_t a_scat_off = b->pscatter_queries ? carve((nt + 1) * 4) : 0, a_scat_cnt = b->pscatter_queries ? carve((nt + 1) * 4) : 0;
         const size_t a_zero = a;
@@ -876,6 +877,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->d_build = (uint32_t *)(A + a_build);
         b->d_qthr = planes_tasks ? (unsigned long long *)(A + a_qthr) : nullptr;
         b->d_part_counts = scored ? (uint32_t *)(A + a_part_counts) : nullptr;
+        b->d_score_order = scored ? (uint32_t *)(A + a_score_order) : nullptr;
         b->d_scat_off = b->pscatter_queries ? (uint32_t *)(A + a_scat_off) : nullptr;
         b->d_scat_cnt = b->pscatter_queries ? (uint32_t *)(A + a_scat_cnt) : nullptr;
         if (b->pscatter_queries) {
@@ -1405,12 +1407,15 @@ extern "C" int tri_batch_run(tri_batch *b) {
                 }
                 if (b->flags & TRI_FLAG_ACCUMULATED_SCORE) {
                         const uint32_t nlegacy = b->n_dense + b->n_pset + b->n_probe + b->n_cand; // (the sets k_and_dense / k_psets / k_probe / k_and materialised; the one-pass tasks have scored themselves)
-                        if (nlegacy)
+                        if (nlegacy) {
+                        hipLaunchKernelGGL(k_score_order, dim3(1), dim3(SORD_WG), 0, dev->stream, (const uint32_t *)b->d_sched, (const uint32_t *)b->d_counts, nlegacy, b->d_score_order);
+                        HIP_TRY(hipGetLastError());
                         TRI_LAUNCH(k_score, b->ix->codec, dim3(std::min<uint32_t>(nlegacy, (uint32_t)dev->cus * SCORE_WGS_PER_CU)), dim3(AND_WG), dev->stream, b->ix->d_index,
-                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, b->d_sched, b->d_sterms, b->d_sweights, nlegacy,
+                                           b->ix->d_blk_last, b->ix->d_blk_off, b->ix->d_terms, b->d_plan, b->d_tasks, (const uint32_t *)b->d_score_order, b->d_sterms, b->d_sweights, nlegacy,
                                            b->d_ticket + 32, b->d_out, b->d_counts, b->topk, b->d_part_docs, b->d_part_scores, b->d_part_counts,
                                            b->d_all_scores, b->d_pscore, b->similarity, b->ix->d_win, b->splane.empty() ? (const uint32_t *)nullptr : (const uint32_t *)(b->d_arena + b->off_splane),
                                            (const uint32_t *)b->ix->d_pcache_hi, b->plw); // (the scorers read the level words: the rows' high parts)
+                        }
                         HIP_TRY(hipGetLastError());
                         const uint32_t nqs = (uint32_t)b->plan.size();
                         if (b->topk)
