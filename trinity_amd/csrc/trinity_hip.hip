@@ -804,10 +804,12 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
                         if (nq >= 1024 && !pc.pool) { // (batches below a thousand queries are planned on the calling thread)
                                 // (default: the handle's contexts share what the process may use — the affinity mask, capped by the cgroup's CPU quota — less six CPUs: the two
                                 //  compiling callers, the thread that runs and awaits batches, the runtime's own threads, and slack — a process that uses its whole quota is
-                                //  throttled at the first neighbour's burst: host_pool.hpp.  Under the GPU box's 16-CPU quota: 5 threads a context; measured there, 600 steps of cfg2,
-                                //  5 / 7 threads x 2 compilers: 1.185 ms per step either way, 8 x 1: 1.39 - 1.49 (the planner is the bound), 12 x 1: 1.18)
+                                //  throttled at the first neighbour's burst: host_pool.hpp.  Under the GPU box's 16-CPU quota: 6 threads a context; measured there, 600 steps of cfg2
+                                //  with the kernels at 1.18 ms, 5 / 7 threads x 2 compilers: 1.185 ms per step either way, 8 x 1: 1.39 - 1.49 (the planner is the bound), 12 x 1: 1.18;
+                                //  at the round's end, kernels 1.11 ms, 100 steps, threads a context -> ms per step, a create's median / longest: 4 -> 1.29, 2.65 / 41;
+                                //  5 -> 1.121, 2.0 - 2.2 / 2.6 - 39; 6 -> 1.114, 1.58 / 1.97; 7 -> 1.117, 1.59 / 1.88; 8 -> 1.127, 1.56 / 44 — six: four CPUs of the quota stay free)
                                 const unsigned budget = host_cpu_budget();
-                                const unsigned fair = budget >= 10 ? std::min(16u, (budget - 6) / tri_dev::PLAN_CTXS) : budget >= 4 ? 2u : 1u;
+                                const unsigned fair = budget >= 10 ? std::min(16u, (budget - 4) / tri_dev::PLAN_CTXS) : budget >= 4 ? 2u : 1u;
                                 const unsigned want = dev->opt.plan_threads ? (unsigned)std::min<uint64_t>(dev->opt.plan_threads, 64) : fair;
                                 if (want > 1) {
                                         try {
