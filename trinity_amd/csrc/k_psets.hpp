@@ -394,8 +394,8 @@ __global__ __launch_bounds__(PSET_WG, TRI_PSET_WAVES) void k_psets(const DevPset
         }
 }
 
-// ---- PSET_UNIT_SCATTER, before k_psets runs: the documents of a union's terms WITHOUT a plane, listed task by task (k_psets_prep).  One workgroup per query (grid: one per
-//      unit of units[]; the one of a scatter query's FIRST task takes the query, the others leave at once): lane k looks after term k (all the terms' records side by side),
+// ---- PSET_UNIT_SCATTER, before k_psets runs: the documents of a union's terms WITHOUT a plane, listed task by task (k_psets_prep).  One workgroup per query (k_psets_prep_list
+//      names the queries' first units): lane k looks after term k (all the terms' records side by side),
 //      then a lane per directory row of <= 32 documents (the register row readers of k_fused) — counted per task in LDS, the tasks' places settled by one scan and one
 //      draw from the batch's cursor, then decoded once more into their places.  scat_off[tix] / scat_cnt[tix]: a task's slice of scat_docs[].
 //      Until round 6 every TASK of such a query did the lookups for its own docID range inside k_psets, between two barriers: a rare term's two or three rows each span
@@ -424,8 +424,19 @@ struct PscatPost { // pass 1 (place == nullptr): count per task; pass 2: into th
         }
         __device__ __forceinline__ void operator()(const uint32_t d, const uint32_t) { doc(d); }
 };
+// the scatter queries' first units, in any order: k_psets_prep's work list (a grid over ALL the units — twenty a query, a million for the 100 K batch — whose workgroups
+// left at once unless theirs was such a unit took 5.1 ms there, longer than the k_and_dense it runs beside)
+__global__ __launch_bounds__(256) void k_psets_prep_list(const DevPsetUnit *__restrict__ units, const uint32_t nunits, uint32_t *__restrict__ cursor, uint32_t *__restrict__ list,
+                                                         const uint32_t cap) {
+        const uint32_t u = blockIdx.x * 256u + threadIdx.x;
+        if (u >= nunits || !(units[u].first & PSET_UNIT_SCATTER) || units[u].w_begin != 0)
+                return;
+        const uint32_t at = atomicAdd(cursor, 1u);
+        if (at < cap)
+                list[at] = u;
+}
 template <int CODEC>
-__global__ __launch_bounds__(PSCAT_WG) void k_psets_prep(const DevPsetUnit *__restrict__ units, const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
+__global__ __launch_bounds__(PSCAT_WG) void k_psets_prep(const DevPsetUnit *__restrict__ units, const uint32_t *__restrict__ list, const uint32_t *__restrict__ listed, const DevQuery *__restrict__ plan, const DevTask *__restrict__ tasks,
                                                          const uint32_t *__restrict__ qterms, const uint32_t *__restrict__ qplane, const uint32_t *__restrict__ masked,
                                                          const uint8_t *__restrict__ index, const uint32_t *__restrict__ blk_last, const uint32_t *__restrict__ blk_off,
                                                          const uint4 *__restrict__ blk_rec, const uint32_t *__restrict__ blk_doff, const DevTerm *__restrict__ terms,
@@ -433,9 +444,9 @@ __global__ __launch_bounds__(PSCAT_WG) void k_psets_prep(const DevPsetUnit *__re
                                                          uint32_t *__restrict__ scat_docs, const uint32_t scat_cap) {
         __shared__ PscatShared sh;
         const uint32_t tid = threadIdx.x;
-        const DevPsetUnit &U = units[blockIdx.x];
-        if (!(uni(U.first) & PSET_UNIT_SCATTER) || uni(U.w_begin) != 0)
+        if (blockIdx.x >= uni(*listed)) // (grid: the planner's count of scatter queries == the units k_psets_prep_list found; belt and braces)
                 return;
+        const DevPsetUnit &U = units[uni(list[blockIdx.x])];
         const uint32_t nterms = uni(U.nterms), term_base = uni(U.term_base), tix = uni(U.tix);
         if (tid < MAX_QTERMS) {
                 uint32_t n = 0;

@@ -367,6 +367,7 @@ struct tri_batch : BatchPlan {
         uint32_t *d_tree_scratch = nullptr, *d_tree_rows = nullptr, *d_tree_prows = nullptr, *d_tree_qbits = nullptr, *d_tree_cc = nullptr, *d_tree_build = nullptr;
         double *d_tree_scores = nullptr; // scored top-K batches: the tree queries' score stream (topk == 0: d_all_scores holds it)
         uint32_t *d_score_order = nullptr; // AccumulatedScore: the tasks k_score runs, heaviest first by their match counts (k_score_order)
+        uint32_t *d_scat_list = nullptr; // ... the scatter queries' first units (k_psets_prep_list)
         uint32_t *d_scat_off = nullptr, *d_scat_cnt = nullptr, *d_scat_docs = nullptr; // PSET_UNIT_SCATTER unions: per task its slice of the list k_psets_prep makes (k_psets.hpp)
         uint32_t scat_cap = 0;
         bool ran = false;
@@ -855,6 +856,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         const size_t a_part_counts = scored ? carve((nt + 1) * 4) : 0, a_score_order = scored ? carve((nt + 1) * 4) : 0;
         const size_t a_task_hits = rich ? carve((nt + 1) * 4) : 0, a_task_pos = rich ? carve((nt + 1) * 8) : 0;
         const size_t a_scat_off = b->pscatter_queries ? carve((nt + 1) * 4) : 0, a_scat_cnt = b->pscatter_queries ? carve((nt + 1) * 4) : 0;
+        const size_t a_scat_list = b->pscatter_queries ? carve((b->pscatter_queries + 1) * 4) : 0;
         const size_t a_zero = a;
         const size_t a_qcounts = carve((nq + 1) * 8); // queries that can never match keep count 0 ...
         const size_t a_top_counts = scored ? carve((nq + 1) * 4) : 0;
@@ -882,6 +884,7 @@ extern "C" int tri_batch_create(tri_index *ix, const uint32_t *prog, size_t prog
         b->d_score_order = scored ? (uint32_t *)(A + a_score_order) : nullptr;
         b->d_scat_off = b->pscatter_queries ? (uint32_t *)(A + a_scat_off) : nullptr;
         b->d_scat_cnt = b->pscatter_queries ? (uint32_t *)(A + a_scat_cnt) : nullptr;
+        b->d_scat_list = b->pscatter_queries ? (uint32_t *)(A + a_scat_list) : nullptr;
         if (b->pscatter_queries) {
                 if (b->pscatter_docs + 64 > 0xffffffffull)
                         return fail(TRI_ERR_UNSUPPORTED, "tri_batch_create: the unions' terms without a plane hold more than 2^32 documents");
@@ -1187,8 +1190,13 @@ extern "C" int tri_batch_run(tri_batch *b) {
                                 HIP_TRY(hipEventRecord(dev->ev_fork, dev->stream));
                                 HIP_TRY(hipStreamWaitEvent(dev->stream2, dev->ev_fork, 0));
                         }
-                        TRI_LAUNCH(k_psets_prep, b->ix->codec, dim3(b->n_pset + b->n_probe), dim3(PSCAT_WG), prep_forked ? dev->stream2 : dev->stream, (const DevPsetUnit *)(b->d_arena + b->off_units),
-                                   b->d_plan, b->d_tasks, (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->ix->d_masked, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off,
+                        hipStream_t prep_stream = prep_forked ? dev->stream2 : dev->stream;
+                        const uint32_t nunits = b->n_pset + b->n_probe, nscat = (uint32_t)b->pscatter_queries;
+                        hipLaunchKernelGGL(k_psets_prep_list, dim3((nunits + 255) / 256), dim3(256), 0, prep_stream, (const DevPsetUnit *)(b->d_arena + b->off_units), nunits,
+                                           b->d_ticket + TICKET_SCAT_WORD + 1, b->d_scat_list, nscat);
+                        HIP_TRY(hipGetLastError());
+                        TRI_LAUNCH(k_psets_prep, b->ix->codec, dim3(nscat), dim3(PSCAT_WG), prep_stream, (const DevPsetUnit *)(b->d_arena + b->off_units), (const uint32_t *)b->d_scat_list,
+                                   (const uint32_t *)(b->d_ticket + TICKET_SCAT_WORD + 1), b->d_plan, b->d_tasks, (const uint32_t *)b->d_qterms, (const uint32_t *)b->d_qplane, b->ix->d_masked, b->ix->d_index, b->ix->d_blk_last, b->ix->d_blk_off,
                                    b->ix->d_blk_rec, b->ix->d_blk_doff, b->ix->d_terms, b->d_ticket + TICKET_SCAT_WORD, b->d_scat_off, b->d_scat_cnt, b->d_scat_docs, b->scat_cap);
                         HIP_TRY(hipGetLastError());
                         if (prep_forked)
