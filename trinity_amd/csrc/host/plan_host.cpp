@@ -58,7 +58,7 @@ void *tri_host_plan(void *hindex, const uint32_t *prog, uint64_t prog_len, const
                                  : n == "fused_task_cost" ? &o.fused_task_cost : n == "fused_freq_cap" ? &o.fused_freq_cap : n == "fused_halfwords" ? &o.fused_halfwords
                                  : n == "account_needed_bytes" ? &o.account_needed_bytes : n == "planes" ? &o.planes : n == "planes_split" ? &o.planes_split
                                  : n == "plane_div" ? &o.plane_div : n == "plane_max_bytes" ? &o.plane_max_bytes : n == "probe_max_blocks" ? &o.probe_max_blocks : n == "tree_max_bytes" ? &o.tree_max_bytes : n == "result_bitmaps" ? &o.result_bitmaps : n == "cand_task_cost" ? &o.cand_task_cost : n == "dense_window_cost" ? &o.dense_window_cost
-                                 : n == "cand_xcd" ? &o.cand_xcd : n == "planes_order" ? &o.planes_order : n == "pset_order" ? &o.pset_order : n == "phrase_task_div" ? &o.phrase_task_div : n == "plane_amortize" ? &o.plane_amortize : nullptr;
+                                 : n == "cand_xcd" ? &o.cand_xcd : n == "planes_order" ? &o.planes_order : n == "pset_order" ? &o.pset_order : n == "scatter_bitmap_slack" ? &o.scatter_bitmap_slack : n == "phrase_task_div" ? &o.phrase_task_div : n == "plane_amortize" ? &o.plane_amortize : nullptr;
                 if (!slot) {
                         put_err(err, errcap, "unknown option " + n);
                         return nullptr;

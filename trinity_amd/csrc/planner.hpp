@@ -54,6 +54,10 @@ struct tri_options {
         uint64_t planes_order = 1;             // k_planes' tasks: 1 docID range by range, within a range by the heaviest plane row they sweep (the workgroups in flight stream the same
                                                // head rows from about the same place: those words come from L2); 2: row by row, a query's ranges side by side; 0: heaviest task first.
                                                // Round 6, k_planes ms at 0 / 1 / 2: cfg3 4.40 / 4.12 / 4.33, cfg5's shard 2.17 / 2.10 / 2.20 (with four ranges a query: 5.44 / 4.73 / -)
+        uint64_t scatter_bitmap_slack = 4;     // a DocumentsOnly union of head terms with terms that have no plane runs in k_psets (PSET_UNIT_SCATTER: plane words OR-ed, the other terms'
+                                               // documents listed by k_psets_prep) — its result a bitmap — when its head terms hold one document in 32 x slack or more; 1: only where a
+                                               // bitmap is no larger than the docID list (the rule of every other query).  The rest of those unions decode every list into LDS window
+                                               // bitmaps (k_and_dense): 1.9 us a query against 0.5 (cfg5's 100 K batch).  A result at one document in 128 costs 4 x the bytes as a bitmap
         uint64_t pset_order = 1;               // k_psets' tasks: 1 docID range by range and, within a range, by the query's HEAVIEST term (PSET_SUBS places by its df rank): the workgroups in
                                                // flight read that term's words of the range one after the other — the second and later readers from L2, not over the fabric; 0: batch order
                                                // within a range
@@ -1464,7 +1468,8 @@ namespace trip {
                                 // (the result's form is decided below the same way on ALL the terms — min(N, sum of their documents) against the bitmap's words —: what
                                 //  holds for the head terms alone holds for all of them, so a scatter union's result IS a bitmap)
                                 const double N = std::max<double>(1.0, (double)ix.info.docs_cnt);
-                                pscatter = one_group && plane_df && std::min<double>(N, (double)plane_df) >= (double)nwin * SPAN_WORDS;
+                                // (option scatter_bitmap_slack: such a union is run this way — and its result kept as a bitmap — from 1 / (32 x slack) of the documents on)
+                                pscatter = one_group && plane_df && std::min<double>(N, (double)plane_df) * (double)std::max<uint64_t>(1, opt.scatter_bitmap_slack) >= (double)nwin * SPAN_WORDS;
                                 pset = pscatter;
                         }
                         // a single lead list too short for a plane against lists that all have one: candidate tiles, every candidate tested with one
@@ -1555,7 +1560,7 @@ namespace trip {
                                                         negg = qt[k] & QT_NOT;
                                                 g += ix.terms[qt[k] & QT_TERM].documents;
                                         }
-                                        bitmap = C.mode == TRI_FLAG_DOCUMENTS_ONLY && opt.result_bitmaps && !t.q.nphrases && est * N >= (double)nwin * SPAN_WORDS;
+                                        bitmap = C.mode == TRI_FLAG_DOCUMENTS_ONLY && opt.result_bitmaps && !t.q.nphrases && (pscatter || est * N >= (double)nwin * SPAN_WORDS);
                                 }
                                 // (TASK_PSET) windows per ROUND of k_psets: a wave stages the survivors of its share of a round — a sub-window of PSET_ROUND_DOCS documents per
                                 // window — in PSET_STAGE_DOCS LDS slots before the round's counts cross; as many windows as are expected to fill three quarters of them

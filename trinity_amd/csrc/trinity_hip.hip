@@ -523,7 +523,7 @@ namespace {
                              {"planes_rebuild", &tri_options::planes_rebuild},
                              {"cand_xcd", &tri_options::cand_xcd},
                              {"plan_threads", &tri_options::plan_threads},
-                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"phrase_task_div", &tri_options::phrase_task_div}, {"plan_hot_us", &tri_options::plan_hot_us}, {"plan_pin", &tri_options::plan_pin}, {"planes_order", &tri_options::planes_order}, {"pset_order", &tri_options::pset_order}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}, {"dense_window_cost", &tri_options::dense_window_cost}};
+                             {"probe_max_blocks", &tri_options::probe_max_blocks}, {"phrase_task_div", &tri_options::phrase_task_div}, {"plan_hot_us", &tri_options::plan_hot_us}, {"plan_pin", &tri_options::plan_pin}, {"planes_order", &tri_options::planes_order}, {"pset_order", &tri_options::pset_order}, {"scatter_bitmap_slack", &tri_options::scatter_bitmap_slack}, {"tree_max_bytes", &tri_options::tree_max_bytes}, {"result_bitmaps", &tri_options::result_bitmaps}, {"cand_task_cost", &tri_options::cand_task_cost}, {"dense_window_cost", &tri_options::dense_window_cost}};
                 for (const auto &e : table)
                         if (!strcmp(e.name, name))
                                 return &(o.*(e.field));
